@@ -1,0 +1,116 @@
+/*
+ * opendpd_hip.h — C ABI of the MI355X-native OpenDPD hot path (libopendpd_hip.so).
+ *
+ * The reference (lab-emi/OpenDPD) has no FFI: its operator boundary is the Python duck type
+ * `backbone.forward(x:(B,T,2) fp32, h_0) -> (B,T,2)` behind `models.CoreModel` (models.py:10-160),
+ * chained by `CascadedModel.forward` (models.py:173-176) and driven by `net_train` / `net_eval`
+ * (modules/train_funcs.py:16-90).  This header is the C boundary a binding for that path would
+ * call: plain device pointers + sizes, a HIP stream handle, int return codes.  No torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (fp32 unless stated) valid on the stream's device;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous;
+ *   - `params` is the backbone's parameters flattened in the reference's `named_parameters()` order
+ *     (e.g. DGRU: rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, fc_out.weight,
+ *     fc_out.bias, fc_hid.weight, fc_hid.bias — backbones/dgru.py:22-32); `odpd_param_count` gives P;
+ *   - x, y, dy, dx are (B,T,2) row-major, last dim = (I,Q)  (models.py:150-160);
+ *   - return 0 on success, a negative ODPD_E* code on bad arguments, a positive hipError_t otherwise.
+ */
+#ifndef OPENDPD_HIP_H
+#define OPENDPD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* backbone ids — the strings of the reference registry `models.CoreModel` (models.py:26-141) */
+enum odpd_backbone {
+    ODPD_GRU = 0,        /* backbones/gru.py:4-48 */
+    ODPD_DGRU = 1,       /* backbones/dgru.py:9-74 */
+    ODPD_QGRU = 2,       /* backbones/qgru.py:9-71        (float path; features I,Q,a^2,a^4) */
+    ODPD_QGRU_AMP1 = 3,  /* backbones/qgru_amp1.py:9-76   (float path; features I,Q,a,a^3) */
+    ODPD_LSTM = 4,       /* backbones/lstm.py:4-48 */
+    ODPD_VDLSTM = 5,     /* backbones/vdlstm.py:5-111 */
+    ODPD_DELTAGRU = 6,   /* backbones/deltagru.py:10-276 */
+    ODPD_TRES_DELTAGRU = 7, /* backbones/deltagru_tcnskip.py:11-304 ('deltagru_tcnskip') */
+    ODPD_TCNN = 8,       /* backbones/tcnn.py:5-97 */
+    ODPD_PGJANET = 9,    /* backbones/pgjanet.py:5-84 */
+    ODPD_BACKBONE_COUNT = 10
+};
+
+enum odpd_error {
+    ODPD_OK = 0,
+    ODPD_EINVAL = -1,      /* bad argument (null pointer, B<=0, ...) */
+    ODPD_EUNSUPPORTED = -2 /* backbone / hidden size not supported by the kernels */
+};
+
+/* Model descriptor: what `CoreModel.__init__` receives (models.py:11). */
+typedef struct odpd_model {
+    int32_t backbone; /* enum odpd_backbone */
+    int32_t hidden;   /* hidden_size (channels for tcnn) */
+    float thx;        /* delta threshold on inputs  (deltagru*, models.py:11) */
+    float thh;        /* delta threshold on hidden state */
+    int32_t bits_w;   /* QAT weight bits (0 = float model) — quant/quant_envs.py:145 */
+    int32_t bits_a;   /* QAT activation bits */
+} odpd_model_t;
+
+/* loss kinds — project.py:262-272 */
+enum odpd_loss { ODPD_LOSS_L2 = 0, ODPD_LOSS_L1 = 1 };
+
+/* ---- sizes ------------------------------------------------------------------------------- */
+/* number of parameters P of the backbone (== utils/util.py:8-15 count_net_params), <0 on error */
+int64_t odpd_param_count(const odpd_model_t* m);
+/* floats of recurrent-state checkpoints `odpd_*_fwd` writes for BPTT (0 for non-recurrent) */
+int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T);
+/* rows of per-workgroup gradient partials `odpd_*_bwd` writes: partials is (rows, P+4) */
+int64_t odpd_partial_rows(const odpd_model_t* m, int B);
+/* library/ABI version, and the gfx arch string the code objects were built for */
+int odpd_abi_version(void);
+const char* odpd_built_arch(void);
+
+/* ---- backbone forward / backward (replaces backbone.forward + autograd BPTT) ------------- */
+/* y = backbone(x).  ckpt may be NULL (inference, net_eval train_funcs.py:57-90).
+ * stats (nullable, 4 doubles: dx_zeros, dx_numel, dh_zeros, dh_numel) is ACCUMULATED for the
+ * delta backbones (deltagru.py:241-247). */
+int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int T, const float* params,
+                      const float* x, float* y, float* ckpt, double* stats);
+/* Given dy = dL/dy: writes per-workgroup partial parameter gradients to `partials`
+ * ((odpd_partial_rows, P+4), OVERWRITTEN; nullable when only dx is wanted = frozen PA, models.py:169-171)
+ * and, if dx != NULL, dL/dx (B,T,2) OVERWRITTEN (needed when the backbone is the PA of a cascade). */
+int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int T, const float* params,
+                      const float* x, const float* dy, const float* ckpt, float* partials, float* dx);
+/* Deterministic second-stage reduction: grad[p] = sum_rows partials[row][p]  (grad OVERWRITTEN or
+ * ACCUMULATED if accumulate != 0).  Columns P..P+3 of `partials` carry loss partial sums; their
+ * reduction lands in grad[P..P+3] (so `grad` holds P+4 floats). */
+int odpd_reduce_partials(void* stream, int64_t rows, int64_t P, const float* partials, float* grad,
+                         int accumulate);
+
+/* ---- loss (replaces nn.MSELoss / nn.L1Loss + its backward, project.py:262-272) ------------ */
+/* loss_out[0] = mean over n elements; dy = dLoss/dy (same shape as y). n = B*T*2.
+ * `count` is the GLOBAL element count used for the mean (== n on one GPU; sum over ranks when the
+ * batch is sharded, so that summing rank gradients gives the global-batch gradient). */
+int odpd_loss_fwd_bwd(void* stream, int kind, int64_t n, int64_t count, const float* y,
+                      const float* target, float* dy, float* loss_out);
+
+/* ---- fused train step pieces (replaces train_funcs.py:33-44) ------------------------------ */
+/* One fused launch: forward + loss + backward for a single backbone on (B,T,2) frames.
+ * Writes `partials` ((rows,P+4); column P holds the un-normalised loss partial sum). No y is
+ * written, BPTT state stays on-chip (LDS).  `count` as in odpd_loss_fwd_bwd. */
+int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_kind, int B, int T,
+                       int64_t count, const float* params, const float* x, const float* target,
+                       float* partials);
+/* clip_grad_norm_(max_norm) (0 = no clipping) + AdamW step over P parameters
+ * (torch.optim.AdamW defaults project.py:283: betas .9/.999, eps 1e-8, weight_decay 0.01).
+ * grad is scaled in place like clip_grad_norm_ does.  `step` is the 1-based step index.
+ * norm_out (nullable) receives the pre-clip total norm. */
+int odpd_clip_adamw_step(void* stream, int64_t P, float* params, float* grad, float* exp_avg,
+                         float* exp_avg_sq, int64_t step, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, float max_norm, float* norm_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENDPD_HIP_H */

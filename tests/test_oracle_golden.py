@@ -1,0 +1,90 @@
+"""Pins the CPU oracle (oracle/odpd_oracle.c) to the reference: every function of the oracle is
+checked against golden vectors that oracle/gen_golden.py produced by RUNNING the reference
+(/root/reference, CPU path) — forward outputs, loss, parameter/input gradients and three
+clip+AdamW steps (modules/train_funcs.py:33-44)."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, make_model
+from tests.golden_util import Fixture, rel_err
+
+# fp32 accumulate-order noise between ATen/oneDNN and straight C loops
+FWD_TOL = 2e-5     # relative to max|y|
+GRAD_TOL = 2e-4    # relative to max|g| per tensor group
+STEP_TOL = 2e-5    # parameters after AdamW steps, relative
+
+SINGLE = [
+    ("gru_h11", "gru"), ("gru_h23", "gru"), ("dgru_h13", "dgru"), ("dgru_h8", "dgru"), ("dgru_h23", "dgru"),
+    ("qgru_h10", "qgru"), ("qgru_h16", "qgru"), ("qgru_amp1_h10", "qgru_amp1"),
+]
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return Oracle("f32")
+
+
+@pytest.fixture(scope="module")
+def orc64():
+    return Oracle("f64")
+
+
+@pytest.mark.parametrize("name,bb", SINGLE)
+def test_forward_loss_grads(orc, orc64, name, bb):
+    fx = Fixture(name)
+    m = make_model(bb, fx.meta["hidden"], fx.meta.get("thx", 0), fx.meta.get("thh", 0))
+    names = fx.keys("sd")
+    p = fx.flat("sd", names)
+    assert orc.param_count(m) == p.size == fx.meta["n_param"]
+    y, _ = orc.forward(m, p, fx["x"])
+    assert rel_err(y, fx["y"]) < FWD_TOL
+    # config-shaped frames (T=200, real APA_200MHz slices)
+    ya, _ = orc.forward(m, p, fx["xa"])
+    assert rel_err(ya, fx["ya"]) < FWD_TOL
+    la, _ = orc.loss("l2", ya, fx["ta"])
+    assert abs(la - float(fx["loss_a"])) < 1e-5 * max(1.0, abs(float(fx["loss_a"])))
+    loss, dy = orc.loss("l2", y, fx["tgt"])
+    assert abs(loss - fx["losses"][0]) < 1e-5 * max(1.0, fx["losses"][0])
+    dp, dx = orc.backward(m, p, fx["x"], dy)
+    g_ref = fx.flat("g", names)
+    assert rel_err(dp, g_ref) < GRAD_TOL
+    assert rel_err(dx, fx["gx"]) < GRAD_TOL
+    # fp64 build agrees with both (sanity on the restatement itself)
+    y64, _ = orc64.forward(m, p, fx["x"])
+    assert rel_err(y64, fx["y"]) < FWD_TOL
+
+
+@pytest.mark.parametrize("name,bb", SINGLE)
+def test_three_adamw_steps(orc, name, bb):
+    fx = Fixture(name)
+    m = make_model(bb, fx.meta["hidden"])
+    names = fx.keys("sd")
+    sizes = fx.sizes(names)
+    p = fx.flat("sd", names).copy()
+    mom = np.zeros_like(p)
+    var = np.zeros_like(p)
+    x, tgt = fx["x"], fx["tgt"]
+    for s in range(1, 4):
+        y, _ = orc.forward(m, p, x)
+        loss, dy = orc.loss("l2", y, tgt)
+        assert abs(loss - fx["losses"][s - 1]) < 2e-5 * max(1.0, fx["losses"][s - 1])
+        g, _ = orc.backward(m, p, x, dy, need_dx=False)
+        orc.clip_adamw(p, g, mom, var, s, fx.meta["lr"], fx.meta["clip"], tensor_sizes=sizes)
+        assert rel_err(p, fx.flat(f"p{s}", names)) < STEP_TOL
+    assert rel_err(mom, fx.flat("m3", names)) < 1e-3
+    assert rel_err(var, fx.flat("v3", names)) < 1e-3
+
+
+def test_l1_loss(orc):
+    rng = np.random.RandomState(0)
+    y = rng.randn(3, 5, 2).astype(np.float32)
+    t = rng.randn(3, 5, 2).astype(np.float32)
+    l, dy = orc.loss("l1", y, t)
+    assert abs(l - np.mean(np.abs(y - t))) < 1e-6
+    assert np.allclose(dy, np.sign(y - t) / y.size)
+
+
+def test_bad_args(orc):
+    m = make_model("gru", 200)  # hidden too large for the oracle
+    with pytest.raises(RuntimeError):
+        orc.forward(m, np.zeros(10, np.float32), np.zeros((1, 4, 2), np.float32))
