@@ -1,0 +1,93 @@
+"""ctypes binding of libopendpd_hip.so (include/opendpd_hip.h).  There is NO CPU fallback: if the
+library is missing or the tensors are not on a HIP device, calls raise."""
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+BACKBONE_IDS = {"gru": 0, "dgru": 1, "qgru": 2, "qgru_amp1": 3, "lstm": 4, "vdlstm": 5, "deltagru": 6,
+                "deltagru_tcnskip": 7, "tcnn": 8, "pgjanet": 9}
+LOSS_IDS = {"l2": 0, "l1": 1}
+LOSS_COLS = 4        # extra columns of a partials row (column P = loss partial sum)
+LOSS_WS = 1 + 256    # floats behind `loss_out` (result + per-block scratch)
+
+
+class ModelDesc(C.Structure):
+    """odpd_model_t"""
+    _fields_ = [("backbone", C.c_int32), ("hidden", C.c_int32), ("thx", C.c_float), ("thh", C.c_float),
+                ("bits_w", C.c_int32), ("bits_a", C.c_int32)]
+
+
+_EXPORTS = {
+    # name: (restype, argtypes)
+    "odpd_abi_version": (C.c_int, []),
+    "odpd_built_arch": (C.c_char_p, []),
+    "odpd_param_count": (C.c_int64, [C.POINTER(ModelDesc)]),
+    "odpd_ckpt_floats": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "odpd_partial_rows": (C.c_int64, [C.POINTER(ModelDesc), C.c_int]),
+    "odpd_backbone_fwd": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "odpd_backbone_bwd": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "odpd_reduce_partials": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]),
+    "odpd_loss_fwd_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "odpd_train_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "odpd_clip_adamw_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def exported_symbols():
+    """Names include/opendpd_hip.h declares (used by the CPU test that checks the .so exports them)."""
+    return sorted(_EXPORTS)
+
+
+def load():
+    """Load the HIP library; raises RuntimeError (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). opendpd_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _EXPORTS.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported backbone/hidden size"}.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"{what} failed: {kind}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("opendpd_amd kernels need tensors on a HIP device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError("opendpd_amd kernels need contiguous tensors")
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,2 @@
+"""HIP-backed backbones behind the reference's registry names (models.py:26-141)."""
+from .gru import GRU, DGRU, QGRU, QGRUAmp1  # noqa: F401

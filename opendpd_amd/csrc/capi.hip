@@ -1,0 +1,107 @@
+// capi.hip — the extern "C" surface declared in include/opendpd_hip.h: argument validation and
+// dispatch to the backbone families.
+#include "odpd_host.h"
+
+using namespace odpd;
+
+namespace {
+enum Family { FAM_NONE = 0, FAM_GRU };
+inline Family family_of(int bb) {
+    switch (bb) {
+    case ODPD_GRU: case ODPD_DGRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return FAM_GRU;
+    default: return FAM_NONE;
+    }
+}
+inline int feat_dim(int bb) {
+    switch (bb) {
+    case ODPD_GRU: case ODPD_LSTM: return 2;
+    case ODPD_DGRU: case ODPD_DELTAGRU: case ODPD_TRES_DELTAGRU: case ODPD_TCNN: return 6;
+    case ODPD_QGRU: case ODPD_QGRU_AMP1: case ODPD_VDLSTM: return 4;
+    default: return 0;
+    }
+}
+inline bool model_ok(const odpd_model_t* m) {
+    return m && m->backbone >= 0 && m->backbone < ODPD_BACKBONE_COUNT && m->hidden > 0;
+}
+inline SeqArgs make_args(const odpd_model_t* m, int B, int T) {
+    SeqArgs a{};
+    a.B = B; a.T = T; a.H = m->hidden;
+    a.ngroups = num_groups(B, rows_per_seq(m->hidden) ? rows_per_seq(m->hidden) : 1);
+    a.nck = num_ckpt(T);
+    a.thx = m->thx; a.thh = m->thh;
+    return a;
+}
+}  // namespace
+
+extern "C" int odpd_abi_version(void) { return 1; }
+extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
+
+extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
+    if (!model_ok(m)) return ODPD_EINVAL;
+    const int64_t H = m->hidden, F = feat_dim(m->backbone);
+    switch (m->backbone) {
+    case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
+    case ODPD_DGRU: return 3 * H * F + 3 * H * H + 6 * H + 2 * (H + 6) + 2 + H * H + H;
+    case ODPD_LSTM: return 4 * H * F + 4 * H * H + 8 * H + 2 * H + 2;
+    case ODPD_VDLSTM: return 4 * H * 4 + 4 * H * H + 8 * H + 2 * (4 * H + 4) + 2 * 8 + 2;
+    case ODPD_DELTAGRU: return 3 * H * 6 + 3 * H * H + 6 * H + 2 * H + 2;
+    case ODPD_TRES_DELTAGRU: return 3 * H * 6 + 3 * H * H + 2 * H + 18 + 6;
+    case ODPD_TCNN: return 6 * H + H + 4 * 5 * H + 2 * H;
+    case ODPD_PGJANET: return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
+    default: return ODPD_EUNSUPPORTED;
+    }
+}
+
+extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
+    if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
+    const int R = rows_per_seq(m->hidden);
+    if (!R) return ODPD_EUNSUPPORTED;
+    switch (family_of(m->backbone)) {
+    case FAM_GRU: return (int64_t)num_groups(B, R) * num_ckpt(T) * 64;
+    default: return ODPD_EUNSUPPORTED;
+    }
+}
+
+extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B) {
+    if (!model_ok(m) || B <= 0) return ODPD_EINVAL;
+    switch (family_of(m->backbone)) {
+    case FAM_GRU: return gru_family_rows(m, B, 0);
+    default: return ODPD_EUNSUPPORTED;
+    }
+}
+
+extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int T, const float* params,
+                                 const float* x, float* y, float* ckpt, double* stats) {
+    if (!model_ok(m) || !params || !x || !y || B <= 0 || T <= 0) return ODPD_EINVAL;
+    SeqArgs a = make_args(m, B, T);
+    a.params = params; a.x = x; a.y = y; a.ckpt = ckpt; a.stats = stats;
+    switch (family_of(m->backbone)) {
+    case FAM_GRU: return gru_family_fwd((hipStream_t)stream, m, a);
+    default: return ODPD_EUNSUPPORTED;
+    }
+}
+
+extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int T, const float* params,
+                                 const float* x, const float* dy, const float* ckpt, float* partials, float* dx) {
+    if (!model_ok(m) || !params || !x || !dy || B <= 0 || T <= 0 || (!partials && !dx)) return ODPD_EINVAL;
+    SeqArgs a = make_args(m, B, T);
+    a.params = params; a.x = x; a.dy = dy; a.ckpt = const_cast<float*>(ckpt); a.partials = partials; a.dx = dx;
+    switch (family_of(m->backbone)) {
+    case FAM_GRU:
+        if (!ckpt && a.nck > 1) return ODPD_EINVAL;
+        return gru_family_bwd((hipStream_t)stream, m, a);
+    default: return ODPD_EUNSUPPORTED;
+    }
+}
+
+extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_kind, int B, int T, int64_t count,
+                                  const float* params, const float* x, const float* target, float* partials) {
+    if (!model_ok(m) || !params || !x || !target || !partials || B <= 0 || T <= 0 || count <= 0) return ODPD_EINVAL;
+    SeqArgs a = make_args(m, B, T);
+    a.params = params; a.x = x; a.target = target; a.partials = partials;
+    a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
+    switch (family_of(m->backbone)) {
+    case FAM_GRU: return gru_family_train((hipStream_t)stream, m, a);
+    default: return ODPD_EUNSUPPORTED;
+    }
+}

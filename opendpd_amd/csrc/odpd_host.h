@@ -1,0 +1,89 @@
+// odpd_host.h — host-side helpers shared by the launchers (argument checks, grid sizing, layouts).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/opendpd_hip.h"
+#include "odpd_device.h"
+
+namespace odpd {
+
+#define ODPD_CHECK_HIP(expr)                         \
+    do {                                             \
+        hipError_t _e = (expr);                      \
+        if (_e != hipSuccess) return (int)_e;        \
+    } while (0)
+
+constexpr int kLossCols = 4;  // extra columns of a partials row: [P]=loss partial sum, [P+1..3] reserved
+
+inline int rows_per_seq(int H) { return H <= 16 ? 1 : (H <= 32 ? 2 : 0); }  // R (0 = unsupported)
+inline int seqs_per_wave(int R) { return 4 / R; }
+inline int num_groups(int B, int R) { int spw = seqs_per_wave(R); return (B + spw - 1) / spw; }
+inline int num_ckpt(int T) { return (T + kCkptStride - 1) / kCkptStride; }
+
+// number of CUs of the current device (cached)
+inline int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+// Persistent grid: enough workgroups for `ngroups` wave-tasks, capped at `blocks_per_cu` resident
+// workgroups per CU (each wave then loops over its share of the tasks).
+inline int persistent_grid(int ngroups, int blocks_per_cu) {
+    int need = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
+    int cap = device_cus() * (blocks_per_cu > 0 ? blocks_per_cu : 1);
+    int g = need < cap ? need : cap;
+    return g > 0 ? g : 1;
+}
+
+// ---- parameter layouts (flattened named_parameters() order of the reference modules) -------------
+struct GruLayout {
+    int F, H, dgru;
+    int o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_w_hid, o_b_hid, P;
+};
+__host__ __device__ inline GruLayout gru_layout(int H, int F, int dgru) {
+    GruLayout L;
+    L.F = F; L.H = H; L.dgru = dgru;
+    int o = 0;
+    L.o_w_ih = o; o += 3 * H * F;
+    L.o_w_hh = o; o += 3 * H * H;
+    L.o_b_ih = o; o += 3 * H;
+    L.o_b_hh = o; o += 3 * H;
+    L.o_w_out = o; o += 2 * (dgru ? H + 6 : H);
+    L.o_b_out = o; o += 2;
+    L.o_w_hid = o; o += dgru ? H * H : 0;
+    L.o_b_hid = o; o += dgru ? H : 0;
+    L.P = o;
+    return L;
+}
+
+// kernel arguments shared by the sequence kernels
+struct SeqArgs {
+    const float* params;
+    const float* x;       // (B,T,2)
+    float* y;             // (B,T,2) forward output
+    float* ckpt;          // BPTT checkpoints (nullable in forward = inference)
+    const float* dy;      // (B,T,2)
+    float* partials;      // (rows, P + kLossCols), nullable
+    float* dx;            // (B,T,2), nullable
+    const float* target;  // fused train step
+    double* stats;        // delta sparsity counters (nullable)
+    float inv_count;      // 1 / global element count (fused loss)
+    float thx, thh;
+    int loss_kind;
+    int B, T, H, ngroups, nck;
+};
+
+// family entry points (defined in the family .hip files)
+int gru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_family_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/);
+
+}  // namespace odpd

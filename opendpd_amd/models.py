@@ -1,0 +1,72 @@
+"""Registry + cascade: drop-in for the reference's models.py.
+
+`CoreModel(input_size, hidden_size, num_layers, backbone_type, window_size=None, num_dvr_units=None,
+thx=0, thh=0)` — same constructor, attributes, `forward(x, h_0=None)` contract and state-dict keys
+as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` as models.py:163-176.
+Backbones on the hot path run as HIP kernels; names that are out of this build's scope raise
+NotImplementedError (the reference raises ValueError only for unknown names, models.py:139-141).
+"""
+import torch.nn as nn
+
+from . import backbones as B
+
+# names the reference registry accepts (models.py:26-141)
+REFERENCE_BACKBONES = ("gmp", "gru", "dgru", "qgru", "qgru_amp1", "lstm", "vdlstm", "rvtdcnn", "apnrru", "bojanet",
+                       "deltagru", "deltajanet", "pgjanet", "dvrjanet", "deltagru_tcnskip", "tcnn", "neuraltx", "mcldnn")
+
+
+class CoreModel(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers, backbone_type, window_size=None, num_dvr_units=None,
+                 thx=0, thh=0):
+        super().__init__()
+        self.output_size = 2
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.backbone_type = backbone_type
+        self.thx, self.thh = thx, thh
+        self.window_size, self.num_dvr_units = window_size, num_dvr_units
+        self.batch_first, self.bidirectional, self.bias = True, False, True
+
+        kw = dict(hidden_size=hidden_size, output_size=2, num_layers=num_layers, bidirectional=False,
+                  batch_first=True, bias=True)
+        if backbone_type == "gru":
+            self.backbone = B.GRU(input_size=input_size, **kw)
+        elif backbone_type == "dgru":
+            self.backbone = B.DGRU(**kw)
+        elif backbone_type == "qgru":
+            self.backbone = B.QGRU(**kw)
+        elif backbone_type == "qgru_amp1":
+            self.backbone = B.QGRUAmp1(**kw)
+        elif backbone_type in REFERENCE_BACKBONES:
+            raise NotImplementedError(f"backbone '{backbone_type}' is a reference registry name that this build "
+                                      f"does not provide as a HIP kernel yet")
+        else:
+            raise ValueError(f"The backbone type '{backbone_type}' is not supported. Please add your own "
+                             f"backbone under ./backbones and update models.py accordingly.")
+        try:  # models.py:144-148
+            self.backbone.reset_parameters()
+        except AttributeError:
+            pass
+
+    def forward(self, x, h_0=None):
+        # the reference creates a zero h_0 (models.py:154-155); the kernels start from the zero state
+        if h_0 is not None and bool((h_0 != 0).any()):
+            raise NotImplementedError("non-zero initial hidden state is not supported by the HIP kernels")
+        return self.backbone(x, None)
+
+
+class CascadedModel(nn.Module):
+    """y = PA(DPD(x)) with the PA frozen during DPD learning (models.py:163-176)."""
+
+    def __init__(self, dpd_model, pa_model):
+        super().__init__()
+        self.dpd_model = dpd_model
+        self.pa_model = pa_model
+
+    def freeze_pa_model(self):
+        for p in self.pa_model.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        return self.pa_model(self.dpd_model(x))

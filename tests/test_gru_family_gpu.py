@@ -1,0 +1,158 @@
+"""GPU parity tests of the GRU-family HIP kernels (gru, dgru, qgru, qgru_amp1) through the registry
+and through the raw C ABI: against the reference golden vectors (tests/golden) and against the CPU
+oracle on seeded inputs, including ragged batch / time sizes.
+
+Tolerances (fp32, stated relative to the max magnitude of the compared tensor):
+  forward outputs 2e-5, gradients 2e-4 (BPTT over <= 333 steps; sums in a different order than ATen).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import Fixture, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL, GRAD_TOL = 2e-5, 2e-4
+SINGLE = [("gru_h11", "gru"), ("gru_h23", "gru"), ("dgru_h13", "dgru"), ("dgru_h8", "dgru"), ("dgru_h23", "dgru"),
+          ("qgru_h10", "qgru"), ("qgru_h16", "qgru"), ("qgru_amp1_h10", "qgru_amp1")]
+
+
+def _model(fx, bb):
+    from opendpd_amd import CoreModel
+    net = CoreModel(2, fx.meta["hidden"], 1, bb)
+    net.load_state_dict({k: torch.from_numpy(fx["sd/" + k]) for k in fx.keys("sd")})
+    return net.cuda()
+
+
+@pytest.mark.parametrize("name,bb", SINGLE)
+def test_golden_forward_backward(name, bb):
+    fx = Fixture(name)
+    net = _model(fx, bb)
+    x = torch.from_numpy(fx["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    assert rel_err(y.detach().cpu().numpy(), fx["y"]) < FWD_TOL
+    loss = torch.nn.functional.mse_loss(y, torch.from_numpy(fx["tgt"]).cuda())
+    assert abs(loss.item() - fx["losses"][0]) < 1e-5 * max(1.0, fx["losses"][0])
+    loss.backward()
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), fx["g/" + k]) < GRAD_TOL, k
+    assert rel_err(x.grad.cpu().numpy(), fx["gx"]) < GRAD_TOL
+    # config-shaped frames (T = 200)
+    with torch.no_grad():
+        ya = net(torch.from_numpy(fx["xa"]).cuda())
+    assert rel_err(ya.cpu().numpy(), fx["ya"]) < FWD_TOL
+
+
+@pytest.mark.parametrize("bb,H", [("gru", 11), ("dgru", 13), ("dgru", 23), ("gru", 16), ("dgru", 32), ("qgru", 10),
+                                  ("qgru_amp1", 17)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 64), (7, 65), (5, 200), (130, 63), (2, 333)])
+def test_against_oracle_ragged(bb, H, B, T):
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 1000 + B * 10 + T)
+    net = CoreModel(2, H, 1, bb).cuda()
+    with torch.no_grad():  # biases are zero after init: make them count
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    rng = np.random.RandomState(B * 7 + T)
+    amp = 0.05 + 0.85 * rng.rand(B, T, 1)
+    ph = 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    dy = rng.randn(B, T, 2).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = net(xt)
+    y.backward(torch.from_numpy(dy).cuda())
+    o = Oracle("f32")
+    m = make_model(bb, H)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    yo, _ = o.forward(m, p, x)
+    go, dxo = o.backward(m, p, x, dy)
+    g = np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()])
+    assert rel_err(y.detach().cpu().numpy(), yo) < FWD_TOL
+    assert rel_err(g, go) < GRAD_TOL
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
+
+
+def test_frozen_model_gives_dx_only():
+    """PA of a cascade: requires_grad=False on every parameter, gradient w.r.t. the input only."""
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(3)
+    net = CoreModel(2, 23, 1, "dgru").cuda()
+    for p in net.parameters():
+        p.requires_grad = False
+    rng = np.random.RandomState(1)
+    x = (0.1 + 0.5 * rng.rand(6, 50, 2)).astype(np.float32)
+    dy = rng.randn(6, 50, 2).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    net(xt).backward(torch.from_numpy(dy).cuda())
+    assert all(p.grad is None for p in net.parameters())
+    o = Oracle("f32")
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    _, dxo = o.backward(make_model("dgru", 23), p, x, dy)
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
+
+
+def test_c_abi_direct_and_errors():
+    """Calls the C ABI without the nn.Module layer; bad arguments return error codes."""
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    assert lib.odpd_abi_version() == 1 and lib.odpd_built_arch() == b"gfx950"
+    d = _lib.ModelDesc(_lib.BACKBONE_IDS["gru"], 11, 0.0, 0.0, 0, 0)
+    P = lib.odpd_param_count(C.byref(d))
+    assert P == 519
+    B, T = 4, 16
+    params = torch.randn(P, device="cuda") * 0.3
+    x = torch.rand(B, T, 2, device="cuda") + 0.1
+    y = torch.empty_like(x)
+    assert lib.odpd_backbone_fwd(_lib.stream_ptr(), C.byref(d), B, T, _lib.ptr(params), _lib.ptr(x), _lib.ptr(y), None,
+                                 None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert lib.odpd_backbone_fwd(_lib.stream_ptr(), C.byref(d), 0, T, _lib.ptr(params), _lib.ptr(x), _lib.ptr(y), None,
+                                 None) == -1
+    bad = _lib.ModelDesc(_lib.BACKBONE_IDS["gru"], 100, 0.0, 0.0, 0, 0)
+    assert lib.odpd_backbone_fwd(_lib.stream_ptr(), C.byref(bad), B, T, _lib.ptr(params), _lib.ptr(x), _lib.ptr(y),
+                                 None, None) == -2
+
+
+def test_loss_and_adamw_kernels_match_oracle():
+    from opendpd_amd import _lib
+    from oracle.oracle import Oracle
+    lib = _lib.load()
+    o = Oracle("f32")
+    rng = np.random.RandomState(0)
+    for kind in ("l2", "l1"):
+        y = rng.randn(37, 50, 2).astype(np.float32)
+        t = rng.randn(37, 50, 2).astype(np.float32)
+        lo, dyo = o.loss(kind, y, t)
+        yt, tt = torch.from_numpy(y).cuda(), torch.from_numpy(t).cuda()
+        dy = torch.empty_like(yt)
+        out = torch.zeros(_lib.LOSS_WS, device="cuda")
+        rc = lib.odpd_loss_fwd_bwd(_lib.stream_ptr(), _lib.LOSS_IDS[kind], y.size, y.size, _lib.ptr(yt), _lib.ptr(tt),
+                                   _lib.ptr(dy), _lib.ptr(out))
+        assert rc == 0
+        assert abs(out[0].item() - lo) < 1e-5 * max(1, abs(lo))
+        assert rel_err(dy.cpu().numpy(), dyo) < 1e-6
+    P = 1041
+    p = rng.randn(P).astype(np.float32)
+    m = np.zeros(P, np.float32)
+    v = np.zeros(P, np.float32)
+    pt, mt, vt = (torch.from_numpy(a.copy()).cuda() for a in (p, m, v))
+    for step in (1, 2, 3):
+        g = (rng.randn(P) * (30.0 if step == 2 else 0.1)).astype(np.float32)   # step 2 exceeds the clip norm
+        gt = torch.from_numpy(g.copy()).cuda()
+        nrm = torch.zeros(1, device="cuda")
+        no = o.clip_adamw(p, g, m, v, step, 5e-4, 200.0)
+        rc = lib.odpd_clip_adamw_step(_lib.stream_ptr(), P, _lib.ptr(pt), _lib.ptr(gt), _lib.ptr(mt), _lib.ptr(vt),
+                                      step, 5e-4, 0.9, 0.999, 1e-8, 0.01, 200.0, _lib.ptr(nrm))
+        assert rc == 0
+        assert abs(nrm.item() - no) < 1e-4 * no
+        assert rel_err(pt.cpu().numpy(), p) < 1e-6
+        assert rel_err(mt.cpu().numpy(), m) < 1e-5
+        assert rel_err(vt.cpu().numpy(), v) < 1e-5
+        assert rel_err(gt.cpu().numpy(), g) < 1e-5
