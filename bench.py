@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the OpenDPD train step on MI355X.
+
+Metric (BASELINE.json): IQ samples/s in the train step (forward + MSE + BPTT + clip_grad_norm_(200)
++ AdamW, modules/train_funcs.py:33-44) for the ~1k-parameter DGRU (hidden 13, 1041 params) on
+APA_200MHz-shaped frames (T = 200, fp32 I/Q), data-parallel over N GPUs (one process per GPU, one
+RCCL all-reduce of P+4 floats per step).  Synthetic band-limited frames, random-init weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+
+Prints ONE JSON line on rank 0.  `value` = whole-job IQ samples/s with inputs resident in HBM.
+`roofline` prices the dominant kernel (the fused fwd+loss+bwd launch) against HBM: algorithmic
+bytes = 16 B per IQ sample (fp32 I,Q input + fp32 I,Q target).  The path is vector-ALU
+bound (~360 flop/B), so the fp32-VALU fraction is reported next to the HBM fraction.
+`cpu_baseline` times the CPU oracle (a port of the reference step, oracle/odpd_oracle.c) on the host
+cores of the same box, on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 peak
+ALGO_BYTES_PER_SAMPLE = 16.0
+FLOP_PER_SAMPLE = {13: 2 * 3 * (39 * 19 + 169 + 38)}  # fwd+dgrad+wgrad MACs*2 for DGRU H13 (5.7 kflop)
+
+
+def synth_frames(n_frames, T, seed, device):
+    """APA_200MHz-shaped synthetic frames: band-limited complex Gaussian stream (occupied bandwidth
+    200/983.04 of fs), peak-normalised to 0.914, no sample with |x| < 1e-3, framed at stride 1 exactly as
+    IQFrameDataset does (data_collector.py:239-247); target = memory-polynomial PA-like map of x."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    n = n_frames + T - 1
+    nfft = 1 << (n - 1).bit_length()
+    spec = torch.complex(torch.randn(nfft, generator=g, device=device), torch.randn(nfft, generator=g, device=device))
+    f = torch.fft.fftfreq(nfft, device=device).abs()
+    spec = spec * (f <= 0.5 * 200.0 / 983.04)
+    x = torch.fft.ifft(spec)[:n]
+    x = x / x.abs().max() * 0.914
+    small = x.abs() < 1e-3
+    x = torch.where(small, torch.full_like(x, 1e-3), x)
+    a2 = (x.real ** 2 + x.imag ** 2)
+    xm1 = torch.roll(x, 1)
+    y = x * (1.0 - 0.25 * a2 + 0.05 * a2 * a2) + 0.08 * xm1 * (1.0 - 0.3 * a2)
+    xs = torch.view_as_real(x).float()
+    ys = torch.view_as_real(y).float()
+    fx = xs.unfold(0, T, 1).permute(0, 2, 1).contiguous()   # (n_frames, T, 2)
+    fy = ys.unfold(0, T, 1).permute(0, 2, 1).contiguous()
+    return fx, fy
+
+
+def run_steps(opt, x, t, steps, warmup, count, dist, events=False):
+    from opendpd_amd.train_funcs import fused_train_step
+    for _ in range(warmup):
+        fused_train_step(opt, x, t, "l2", 200.0, count)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if events else None
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(steps):
+        loss = fused_train_step(opt, x, t, "l2", 200.0, count, timing=evs[i] if events else None)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) if events else None
+    return el, kern_ms, float(loss.item())
+
+
+def cpu_baseline(H, T, budget_s=15.0):
+    """Reference-step port (oracle) on the host cores; bounded sample of the same workload."""
+    from oracle.oracle import Oracle, make_model
+    o = Oracle("f32")
+    m = make_model("dgru", H)
+    B = 256
+    rng = np.random.RandomState(0)
+    x = (0.05 + 0.8 * rng.rand(B, T, 2)).astype(np.float32)
+    t = rng.rand(B, T, 2).astype(np.float32)
+    P = o.param_count(m)
+    p = (rng.randn(P) * 0.2).astype(np.float32)
+    mom = np.zeros(P, np.float32)
+    var = np.zeros(P, np.float32)
+    scratch = (np.empty_like(x), np.empty_like(x), np.empty(P, np.float32))
+    o.train_step(m, p, x, t, mom, var, 1, 5e-4, 200.0, scratch=scratch)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.train_step(m, p, x, t, mom, var, n + 2, 5e-4, 200.0, scratch=scratch)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 2000:
+            break
+    return {"value": B * T * n / el, "unit": "IQ samples/s", "cores": o.max_threads(), "kind": "port",
+            "sample": f"{n} train steps of DGRU H{H} on a {B}x{T} synthetic batch ({el:.1f} s, OpenMP over sequences)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step (saturating batch)")
+    ap.add_argument("--ref-batch", type=int, default=256, help="reference batch (arguments.py:32) timed as a side figure")
+    ap.add_argument("--hidden", type=int, default=13)
+    ap.add_argument("--frame-length", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)
+        dist = dist_mod
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW
+    H, T, B = args.hidden, args.frame_length, args.batch
+    torch.manual_seed(0)                      # identical replicas on every rank
+    net = CoreModel(2, H, 1, "dgru").to(dev)
+    opt = FusedAdamW(net, lr=5e-4)
+    x, t = synth_frames(B, T, seed=1000 + rank, device=dev)   # each rank owns its shard of the global batch
+    count = world * B * T * 2
+    el, kern_ms, loss = run_steps(opt, x, t, args.steps, args.warmup, count, dist, events=True)
+    el_t = torch.tensor([el], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+    el = float(el_t.item())
+    value = world * B * T * args.steps / el
+
+    # side figure: the reference batch size (launch/latency-bound regime)
+    ref = None
+    if args.ref_batch and args.ref_batch != B:
+        net2 = CoreModel(2, H, 1, "dgru").to(dev)
+        opt2 = FusedAdamW(net2, lr=5e-4)
+        xr, tr = x[:args.ref_batch].contiguous(), t[:args.ref_batch].contiguous()
+        elr, _, _ = run_steps(opt2, xr, tr, max(args.steps, 50), args.warmup, world * args.ref_batch * T * 2, dist)
+        elr_t = torch.tensor([elr], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(elr_t, op=dist.ReduceOp.MAX)
+        ref = {"batch_per_gpu": args.ref_batch, "value": world * args.ref_batch * T * max(args.steps, 50) / float(elr_t.item()),
+               "ms_per_step": 1e3 * float(elr_t.item()) / max(args.steps, 50)}
+
+    if rank == 0:
+        achieved = ALGO_BYTES_PER_SAMPLE * B * T / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"dgru_h{H}_b{B}_t{T}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "iq_samples_per_sec_train", "value": value, "unit": "IQ samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train_pa DGRU H{H} ({net.backbone.n_flat} params) on APA_200MHz-shaped frames, "
+                                   f"T={T}, fused fwd+MSE+BPTT+clip200+AdamW step",
+                       "batch_per_gpu": B, "global_batch": world * B, "frame_length": T,
+                       "parallelism": f"dp{world}", "loss": float(loss)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "gru_train_kernel<1,DGRU6,true>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * B * T,
+                         "valu_fp32": {"achieved_tflops": FLOP_PER_SAMPLE.get(H, 0) * B * T / (kern_ms * 1e-3) / 1e12,
+                                       "peak_tflops": VALU_FP32_PEAK_TFLOPS,
+                                       "frac": FLOP_PER_SAMPLE.get(H, 0) * B * T / (kern_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS}},
+            "reference_batch": ref,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, T)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

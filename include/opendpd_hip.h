@@ -65,8 +65,9 @@ enum odpd_loss { ODPD_LOSS_L2 = 0, ODPD_LOSS_L1 = 1 };
 int64_t odpd_param_count(const odpd_model_t* m);
 /* floats of recurrent-state checkpoints `odpd_*_fwd` writes for BPTT (0 for non-recurrent) */
 int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T);
-/* rows of per-workgroup gradient partials `odpd_*_bwd` writes: partials is (rows, P+4) */
-int64_t odpd_partial_rows(const odpd_model_t* m, int B);
+/* rows of per-wavefront gradient partials that odpd_backbone_bwd (fused = 0) or odpd_train_fwd_bwd
+ * (fused = 1) write: partials is (rows, P+4) */
+int64_t odpd_partial_rows(const odpd_model_t* m, int B, int fused);
 /* library/ABI version, and the gfx arch string the code objects were built for */
 int odpd_abi_version(void);
 const char* odpd_built_arch(void);
@@ -89,7 +90,8 @@ int odpd_reduce_partials(void* stream, int64_t rows, int64_t P, const float* par
                          int accumulate);
 
 /* ---- loss (replaces nn.MSELoss / nn.L1Loss + its backward, project.py:262-272) ------------ */
-/* loss_out[0] = mean over n elements; dy = dLoss/dy (same shape as y). n = B*T*2.
+/* loss_out[0] = mean over n elements; dy = dLoss/dy (same shape as y, nullable). n = B*T*2.
+ * loss_out must point to 1+256 floats: [0] result, [1..256] scratch for per-workgroup sums.
  * `count` is the GLOBAL element count used for the mean (== n on one GPU; sum over ranks when the
  * batch is sharded, so that summing rank gradients gives the global-batch gradient). */
 int odpd_loss_fwd_bwd(void* stream, int kind, int64_t n, int64_t count, const float* y,
@@ -105,10 +107,12 @@ int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_kind, int B
 /* clip_grad_norm_(max_norm) (0 = no clipping) + AdamW step over P parameters
  * (torch.optim.AdamW defaults project.py:283: betas .9/.999, eps 1e-8, weight_decay 0.01).
  * grad is scaled in place like clip_grad_norm_ does.  `step` is the 1-based step index.
+ * Hyper-parameters are doubles (Python floats in the reference): 1-beta2 etc. are formed in double
+ * and rounded to fp32 once, exactly like torch/optim/adam.py does.
  * norm_out (nullable) receives the pre-clip total norm. */
 int odpd_clip_adamw_step(void* stream, int64_t P, float* params, float* grad, float* exp_avg,
-                         float* exp_avg_sq, int64_t step, float lr, float beta1, float beta2,
-                         float eps, float weight_decay, float max_norm, float* norm_out);
+                         float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2,
+                         double eps, double weight_decay, double max_norm, float* norm_out);
 
 #ifdef __cplusplus
 }

@@ -407,11 +407,87 @@ __global__ __launch_bounds__(kThreads) void gru_fwd_kernel(SeqArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// backward kernel (BPTT with block recompute)
+// backward over one wave-task (BPTT with block recompute).  Shared by the stand-alone backward
+// kernel (dy staged per chunk from HBM, checkpoints in HBM) and the fused train kernel (FUSED: dy
+// frame and checkpoints already in LDS).
+//   xs   : LDS chunk buffer for x              dys : LDS dy chunk buffer (or whole dy frame if FUSED)
+//   ck   : checkpoints of this task, slot c at ck[c*64 + lane]  (HBM, or LDS if FUSED)
 // -------------------------------------------------------------------------------------------------
+template <int R, int FM, bool DG, bool NW, bool DX, bool FUSED>
+__device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, FeatDim<FM>::F, DG>& w,
+                                             const GruWT<R, FeatDim<FM>::F, DG>& wt, GruGrad<R, DG>& G, int b0, int lane,
+                                             int row, int col, int s, float2* xs, float2* dys, int dy_stride,
+                                             float2* dxs, const float* ck) {
+    constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R, S = kCkptStride;
+    float dh = 0.0f;
+    int cur_chunk = -1;
+    for (int blk = a.nck - 1; blk >= 0; --blk) {
+        const int tb = blk * S, nstep = min(S, a.T - tb);
+        const int chunk = tb / kChunk, t0 = chunk * kChunk;
+        if (chunk != cur_chunk) {
+            if constexpr (DX) {
+                if (cur_chunk >= 0) {
+                    const int pt0 = cur_chunk * kChunk;
+                    wave_lds_fence();
+                    stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                }
+            }
+            wave_lds_fence();
+            const int len = min(kChunk, a.T - t0);
+            stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+            if constexpr (!FUSED) stage_in<SPW>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+            wave_lds_fence();
+            cur_chunk = chunk;
+        }
+        // state at the start of the block, then recompute the block into registers
+        float h = blk ? ck[blk * 64 + lane] : 0.0f;
+        float hp_s[S], r_s[S], z_s[S], n_s[S], g_s[S], hid_s[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            if (i < nstep) {
+                const float2 xv = xs[s * kChunkPad + (tb - t0) + i];
+                float f[F];
+                feat_fwd<FM>(xv.x, xv.y, f);
+                hp_s[i] = h;
+                gru_cell_fwd<R, FM, DG>(w, f, h, r_s[i], z_s[i], n_s[i], g_s[i]);
+                hid_s[i] = 0.0f;
+                if constexpr (DG) {
+                    hid_s[i] = rotdot(w.bhid, w.whid[0], h);
+                    if constexpr (R == 2) hid_s[i] = rotdot(hid_s[i], w.whid[1], swap16(h));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = S - 1; i >= 0; --i) {
+            if (i < nstep) {
+                const int tt = (tb - t0) + i;
+                const float2 xv = xs[s * kChunkPad + tt];
+                const float2 dyv = FUSED ? dys[s * dy_stride + tb + i] : dys[s * kChunkPad + tt];
+                float f[F], df[F];
+                feat_fwd<FM>(xv.x, xv.y, f);
+                gru_step_bwd<R, FM, DG, NW, DX>(w, wt, G, f, hp_s[i], r_s[i], z_s[i], n_s[i], g_s[i], hid_s[i], dyv.x,
+                                                dyv.y, row, col, dh, df);
+                if constexpr (DX) {
+                    float dI, dQ;
+                    feat_bwd<FM>(xv.x, xv.y, df, dI, dQ);
+                    if ((lane & (LPS - 1)) == 0) dxs[s * kChunkPad + tt] = make_float2(dI, dQ);
+                }
+            }
+        }
+    }
+    if constexpr (DX) {
+        if (cur_chunk >= 0) {
+            const int pt0 = cur_chunk * kChunk;
+            wave_lds_fence();
+            stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+            wave_lds_fence();
+        }
+    }
+}
+
 template <int R, int FM, bool DG, bool NW, bool DX>
 __global__ __launch_bounds__(kThreads) void gru_bwd_kernel(SeqArgs a) {
-    constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R, S = kCkptStride;
+    constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, row = (lane >> 4) & (R - 1), s = lane / LPS;
@@ -429,75 +505,10 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_kernel(SeqArgs a) {
     load_gru_wT<R, F, DG>(wt, pl, L, row, col, src);
     GruGrad<R, DG> G;
     G.zero();
-
     const int nwaves = gridDim.x * kWavesPerBlock, wave_global = blockIdx.x * kWavesPerBlock + wave;
-    for (int grp = wave_global; grp < a.ngroups; grp += nwaves) {
-        const int b0 = grp * SPW;
-        float dh = 0.0f;
-        int cur_chunk = -1;
-        for (int blk = a.nck - 1; blk >= 0; --blk) {
-            const int tb = blk * S, nstep = min(S, a.T - tb);
-            const int chunk = tb / kChunk, t0 = chunk * kChunk;
-            if (chunk != cur_chunk) {
-                if constexpr (DX) {
-                    if (cur_chunk >= 0) {
-                        const int pt0 = cur_chunk * kChunk;
-                        wave_lds_fence();
-                        stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
-                    }
-                }
-                wave_lds_fence();
-                const int len = min(kChunk, a.T - t0);
-                stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
-                stage_in<SPW>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
-                wave_lds_fence();
-                cur_chunk = chunk;
-            }
-            // state at the start of the block
-            float h = blk ? a.ckpt[((size_t)grp * a.nck + blk) * 64 + lane] : 0.0f;
-            float hp_s[S], r_s[S], z_s[S], n_s[S], g_s[S], hid_s[S];
-#pragma unroll
-            for (int i = 0; i < S; ++i) {
-                if (i < nstep) {
-                    const float2 xv = xs[s * kChunkPad + (tb - t0) + i];
-                    float f[F];
-                    feat_fwd<FM>(xv.x, xv.y, f);
-                    hp_s[i] = h;
-                    gru_cell_fwd<R, FM, DG>(w, f, h, r_s[i], z_s[i], n_s[i], g_s[i]);
-                    hid_s[i] = 0.0f;
-                    if constexpr (DG) {
-                        hid_s[i] = rotdot(w.bhid, w.whid[0], h);
-                        if constexpr (R == 2) hid_s[i] = rotdot(hid_s[i], w.whid[1], swap16(h));
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = S - 1; i >= 0; --i) {
-                if (i < nstep) {
-                    const int tt = (tb - t0) + i;
-                    const float2 xv = xs[s * kChunkPad + tt];
-                    const float2 dyv = dys[s * kChunkPad + tt];
-                    float f[F], df[F];
-                    feat_fwd<FM>(xv.x, xv.y, f);
-                    gru_step_bwd<R, FM, DG, NW, DX>(w, wt, G, f, hp_s[i], r_s[i], z_s[i], n_s[i], g_s[i], hid_s[i],
-                                                    dyv.x, dyv.y, row, col, dh, df);
-                    if constexpr (DX) {
-                        float dI, dQ;
-                        feat_bwd<FM>(xv.x, xv.y, df, dI, dQ);
-                        if ((lane & (LPS - 1)) == 0) dxs[s * kChunkPad + tt] = make_float2(dI, dQ);
-                    }
-                }
-            }
-        }
-        if constexpr (DX) {
-            if (cur_chunk >= 0) {
-                const int pt0 = cur_chunk * kChunk;
-                wave_lds_fence();
-                stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
-                wave_lds_fence();
-            }
-        }
-    }
+    for (int grp = wave_global; grp < a.ngroups; grp += nwaves)
+        gru_bwd_task<R, FM, DG, NW, DX, false>(a, w, wt, G, grp * SPW, lane, row, col, s, xs, dys, 0, dxs,
+                                               a.ckpt + (size_t)grp * a.nck * 64);
     if constexpr (NW) {
         float* prow = a.partials + (size_t)wave_global * (L.P + kLossCols);
         gru_write_partials<R, F, DG>(prow, L, G, lane, row, col, 0.0f);
@@ -505,10 +516,89 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_kernel(SeqArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// fused train kernel: forward + loss + backward per wave-task, BPTT state resident in LDS
+// LDS per wave: x chunk, target chunk, dy frame (SPW x T), checkpoints (nck x 64 floats)
+// -------------------------------------------------------------------------------------------------
+__host__ __device__ inline int dy_frame_stride(int T) { return (T % 32 == 0) ? T + 1 : T; }
+__host__ __device__ inline int train_wave_floats(int T, int R) {
+    const int SPW = 4 / R;
+    return 2 * (2 * SPW * kChunkPad) + 2 * SPW * dy_frame_stride(T) + num_ckpt_hd(T) * 64;
+}
+
+template <int R, int FM, bool DG>
+__global__ __launch_bounds__(kThreads) void gru_train_kernel(SeqArgs a) {
+    constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R, S = kCkptStride;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, row = (lane >> 4) & (R - 1), s = lane / LPS;
+    const GruLayout L = gru_layout(a.H, F, DG);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    const int Tp = dy_frame_stride(a.T);
+    float* wbase = smem + ((L.P + 3) & ~3) + (size_t)wave * train_wave_floats(a.T, R);
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* ts = xs + SPW * kChunkPad;
+    float2* dyf = ts + SPW * kChunkPad;
+    float* ck = reinterpret_cast<float*>(dyf + SPW * Tp);
+    int src[16];
+    rot_sources(src, col);
+    GruW<R, F, DG> w;
+    GruWT<R, F, DG> wt;
+    load_gru_w<R, F, DG>(w, pl, L, row, col, src);
+    load_gru_wT<R, F, DG>(wt, pl, L, row, col, src);
+    GruGrad<R, DG> G;
+    G.zero();
+    float loss_acc = 0.0f;
+    const bool lead = (lane & (LPS - 1)) == 0;
+    const int nwaves = gridDim.x * kWavesPerBlock, wave_global = blockIdx.x * kWavesPerBlock + wave;
+    for (int grp = wave_global; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * SPW;
+        const bool valid = b0 + s < a.B;
+        float h = 0.0f;
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            wave_lds_fence();
+            stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+            stage_in<SPW>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+            wave_lds_fence();
+            for (int tt = 0; tt < len; ++tt) {
+                const float2 xv = xs[s * kChunkPad + tt];
+                const float2 tv = ts[s * kChunkPad + tt];
+                float f[F], r, z, n, ghn, y0, y1, hid;
+                feat_fwd<FM>(xv.x, xv.y, f);
+                gru_cell_fwd<R, FM, DG>(w, f, h, r, z, n, ghn);
+                gru_head_fwd<R, FM, DG>(w, h, f, col, y0, y1, hid);
+                const float d0 = y0 - tv.x, d1 = y1 - tv.y;
+                float g0, g1, l;
+                if (a.loss_kind == ODPD_LOSS_L2) {
+                    const float sc = 2.0f * a.inv_count;
+                    g0 = d0 * sc; g1 = d1 * sc; l = __builtin_fmaf(d0, d0, d1 * d1);
+                } else {
+                    g0 = d0 > 0.f ? a.inv_count : (d0 < 0.f ? -a.inv_count : 0.f);
+                    g1 = d1 > 0.f ? a.inv_count : (d1 < 0.f ? -a.inv_count : 0.f);
+                    l = __builtin_fabsf(d0) + __builtin_fabsf(d1);
+                }
+                if (lead) {
+                    dyf[s * Tp + t0 + tt] = valid ? make_float2(g0, g1) : make_float2(0.f, 0.f);
+                    loss_acc += valid ? l : 0.0f;
+                }
+                const int t1 = t0 + tt + 1;
+                if ((t1 % S) == 0 && t1 < a.T) ck[(t1 / S) * 64 + lane] = h;
+            }
+        }
+        wave_lds_fence();
+        gru_bwd_task<R, FM, DG, true, false, true>(a, w, wt, G, b0, lane, row, col, s, xs, dyf, Tp, nullptr, ck);
+    }
+    float* prow = a.partials + (size_t)wave_global * (L.P + kLossCols);
+    gru_write_partials<R, F, DG>(prow, L, G, lane, row, col, loss_acc);
+}
+
+// -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
 constexpr int kFwdBlocksPerCU = 4;  // grid caps (blocks are independent: a non-resident block simply queues)
 constexpr int kBwdBlocksPerCU = 2;
+constexpr int kTrainBlocksPerCU = 1;
 
 static bool gru_cfg(const odpd_model_t* m, int& FM, bool& DG) {
     switch (m->backbone) {
@@ -535,6 +625,22 @@ static int launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
     const size_t lds = gru_lds_bytes(P, R, 3);
     hipLaunchKernelGGL((gru_bwd_kernel<R, FM, DG, NW, DX>), dim3(persistent_grid(a.ngroups, kBwdBlocksPerCU)),
                        dim3(kThreads), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+template <int R, int FM, bool DG>
+static int launch_train(hipStream_t st, const SeqArgs& a, int P) {
+    const size_t lds = ((size_t)((P + 3) & ~3) + (size_t)kWavesPerBlock * train_wave_floats(a.T, R)) * sizeof(float);
+    if (lds > 160 * 1024) return ODPD_EUNSUPPORTED;  // frame too long for LDS-resident BPTT state
+    auto k = gru_train_kernel<R, FM, DG>;
+    static size_t max_set = 0;
+    if (lds > max_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(160 * 1024));
+        if (e != hipSuccess) return (int)e;
+        max_set = 160 * 1024;
+    }
+    hipLaunchKernelGGL(k, dim3(persistent_grid(a.ngroups, kTrainBlocksPerCU)), dim3(kThreads), lds, st, a);
     return (int)hipGetLastError();
 }
 
@@ -584,14 +690,28 @@ int gru_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 }
 
 int gru_family_rows(const odpd_model_t* m, int B, int which) {
-    (void)which;
     int FM; bool DG;
     if (!gru_cfg(m, FM, DG)) return ODPD_EUNSUPPORTED;
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
-    return persistent_grid(num_groups(B, R), kBwdBlocksPerCU) * kWavesPerBlock;
+    return persistent_grid(num_groups(B, R), which ? kTrainBlocksPerCU : kBwdBlocksPerCU) * kWavesPerBlock;
 }
 
-int gru_family_train(hipStream_t, const odpd_model_t*, const SeqArgs&) { return ODPD_EUNSUPPORTED; }
+int gru_family_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    int FM; bool DG;
+    if (!gru_cfg(m, FM, DG)) return ODPD_EUNSUPPORTED;
+    const int R = rows_per_seq(m->hidden);
+    if (!R) return ODPD_EUNSUPPORTED;
+    const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
+    ODPD_GRU_DISPATCH(1, FEAT_RAW2, false, (launch_train<1, FEAT_RAW2, false>(st, a, P)))
+    ODPD_GRU_DISPATCH(2, FEAT_RAW2, false, (launch_train<2, FEAT_RAW2, false>(st, a, P)))
+    ODPD_GRU_DISPATCH(1, FEAT_DGRU6, true, (launch_train<1, FEAT_DGRU6, true>(st, a, P)))
+    ODPD_GRU_DISPATCH(2, FEAT_DGRU6, true, (launch_train<2, FEAT_DGRU6, true>(st, a, P)))
+    ODPD_GRU_DISPATCH(1, FEAT_Q4, false, (launch_train<1, FEAT_Q4, false>(st, a, P)))
+    ODPD_GRU_DISPATCH(2, FEAT_Q4, false, (launch_train<2, FEAT_Q4, false>(st, a, P)))
+    ODPD_GRU_DISPATCH(1, FEAT_A4, false, (launch_train<1, FEAT_A4, false>(st, a, P)))
+    ODPD_GRU_DISPATCH(2, FEAT_A4, false, (launch_train<2, FEAT_A4, false>(st, a, P)))
+    return ODPD_EUNSUPPORTED;
+}
 
 }  // namespace odpd

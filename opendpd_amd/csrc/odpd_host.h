@@ -19,7 +19,8 @@ constexpr int kLossCols = 4;  // extra columns of a partials row: [P]=loss parti
 inline int rows_per_seq(int H) { return H <= 16 ? 1 : (H <= 32 ? 2 : 0); }  // R (0 = unsupported)
 inline int seqs_per_wave(int R) { return 4 / R; }
 inline int num_groups(int B, int R) { int spw = seqs_per_wave(R); return (B + spw - 1) / spw; }
-inline int num_ckpt(int T) { return (T + kCkptStride - 1) / kCkptStride; }
+__host__ __device__ inline int num_ckpt_hd(int T) { return (T + kCkptStride - 1) / kCkptStride; }
+inline int num_ckpt(int T) { return num_ckpt_hd(T); }
 
 // number of CUs of the current device (cached)
 inline int device_cus() {

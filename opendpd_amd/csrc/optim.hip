@@ -140,15 +140,15 @@ extern "C" int odpd_reduce_partials(void* stream, int64_t rows, int64_t P, const
 }
 
 extern "C" int odpd_clip_adamw_step(void* stream, int64_t P, float* params, float* grad, float* exp_avg,
-                                    float* exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
-                                    float weight_decay, float max_norm, float* norm_out) {
+                                    float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps,
+                                    double weight_decay, double max_norm, float* norm_out) {
     if (!params || !grad || !exp_avg || !exp_avg_sq || P <= 0 || step <= 0) return ODPD_EINVAL;
     // scalar prefactors in double like torch's python-float arithmetic, then rounded to fp32
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1), bc2s = (float)sqrt(bc2);
-    const float decay = (float)(1.0 - (double)lr * (double)weight_decay);
-    const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1), bc2s = (float)sqrt(bc2);
+    const float decay = (float)(1.0 - lr * weight_decay);
+    const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
     hipLaunchKernelGGL(clip_adamw_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, P, params, grad, exp_avg,
-                       exp_avg_sq, step_size, bc2s, decay, w1, beta2, w2, eps, max_norm, norm_out);
+                       exp_avg_sq, step_size, bc2s, decay, w1, (float)beta2, w2, (float)eps, (float)max_norm, norm_out);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,181 @@
+"""Train / eval loops: drop-in for the reference's modules/train_funcs.py.
+
+`net_train` / `net_eval` keep the reference signatures and semantics (train_funcs.py:16-90):
+per batch zero_grad -> forward -> loss -> backward -> clip_grad_norm_ -> optimizer.step, and the
+returned log['loss'] is the unweighted mean of the per-batch losses (train_funcs.py:50).
+
+Fast path: when `optimizer` is a `FusedAdamW` built over a HIP-backed `CoreModel`, the whole step runs
+as three launches on the current stream and never synchronises with the host:
+    odpd_train_fwd_bwd  (forward + loss + BPTT, BPTT state in LDS)
+ -> odpd_reduce_partials (deterministic reduction of per-wavefront gradient rows)
+ -> [one RCCL all-reduce of P+4 floats when the batch is sharded over ranks]
+ -> odpd_clip_adamw_step (global-norm clip + AdamW).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .backbones.native import NativeBackbone
+from .models import CoreModel
+
+
+def _loss_kind(criterion):
+    if isinstance(criterion, nn.MSELoss) and criterion.reduction == "mean":
+        return "l2"
+    if isinstance(criterion, nn.L1Loss) and criterion.reduction == "mean":
+        return "l1"
+    if criterion in ("l2", "l1"):
+        return criterion
+    return None
+
+
+class FusedAdamW:
+    """torch.optim.AdamW (defaults of project.py:283) over the flat parameter buffer of ONE HIP-backed
+    CoreModel, fused with clip_grad_norm_.  Exposes `param_groups[0]['lr']` like a torch optimizer so
+    ReduceLROnPlateau-style schedulers (project.py:289-296) can drive it."""
+
+    def __init__(self, net, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, process_group=None):
+        if not (isinstance(net, CoreModel) and isinstance(net.backbone, NativeBackbone)):
+            raise TypeError("FusedAdamW needs a HIP-backed CoreModel")
+        self.net = net
+        self.backbone = net.backbone
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.process_group = process_group
+        self.step_count = 0
+        self._state_dev = None
+
+    # -- state -------------------------------------------------------------------------------
+    def _ensure(self, device):
+        if self._state_dev == device:
+            return
+        P = self.backbone.n_flat
+        self.grad = torch.zeros(P + _lib.LOSS_COLS, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(P, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(P, dtype=torch.float32, device=device)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=device)
+        self._partials = {}
+        self._state_dev = device
+
+    def partials(self, B, device):
+        self._ensure(device)
+        if B not in self._partials:
+            lib = _lib.load()
+            rows = int(lib.odpd_partial_rows(C.byref(self.backbone.desc), B, 1))
+            _lib.check(0 if rows > 0 else rows, "odpd_partial_rows")
+            self._partials[B] = torch.empty(rows, self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32,
+                                            device=device)
+        return self._partials[B]
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.net.parameters():
+            p.grad = None
+
+    def world_size(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.process_group)
+        return 1
+
+    def allreduce_grad(self):
+        """The ONE collective of the data-parallel step: sum of P+4 floats (gradient + loss partial)."""
+        if self.world_size() > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+
+    def apply(self, max_norm):
+        """clip (max_norm, 0 = off) + AdamW on the flat buffers; self.grad must hold the global gradient."""
+        lib = _lib.load()
+        g = self.param_groups[0]
+        self.step_count += 1
+        flat = self.backbone.flat_params()
+        rc = lib.odpd_clip_adamw_step(_lib.stream_ptr(), self.backbone.n_flat, _lib.ptr(flat), _lib.ptr(self.grad),
+                                      _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.step_count,
+                                      float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                      float(g["weight_decay"]), float(max_norm or 0.0), _lib.ptr(self.norm))
+        _lib.check(rc, "odpd_clip_adamw_step")
+
+    def step(self, max_norm=0.0):
+        """Generic-path step: gathers p.grad (set by autograd) into the flat gradient, then apply()."""
+        ps = list(self.net.parameters())
+        self._ensure(ps[0].device)
+        with torch.no_grad():
+            torch.cat([p.grad.reshape(-1) for p in ps], out=self.grad[:self.backbone.n_flat])
+        self.allreduce_grad()
+        self.apply(max_norm)
+
+
+def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_count=None, timing=None):
+    """One optimiser step (train_funcs.py:33-44) on device tensors x, target of shape (B,T,2).
+    Returns the loss as a 0-dim device tensor (no host sync).  `global_count` = number of target
+    elements of the GLOBAL batch when x is this rank's shard (default: this batch)."""
+    lib = _lib.load()
+    bb = opt.backbone
+    B, T = x.shape[0], x.shape[1]
+    n = B * T * 2
+    count = int(global_count or n)
+    part = opt.partials(B, x.device)
+    flat = bb.flat_params()
+    if timing is not None:
+        timing[0].record()
+    rc = lib.odpd_train_fwd_bwd(_lib.stream_ptr(), C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], B, T, count,
+                                _lib.ptr(flat), _lib.ptr(x), _lib.ptr(target), _lib.ptr(part))
+    if timing is not None:
+        timing[1].record()
+    _lib.check(rc, f"odpd_train_fwd_bwd[{bb.backbone_name}]")
+    rc = lib.odpd_reduce_partials(_lib.stream_ptr(), part.shape[0], bb.n_flat, _lib.ptr(part), _lib.ptr(opt.grad), 0)
+    _lib.check(rc, "odpd_reduce_partials")
+    opt.allreduce_grad()
+    loss = opt.grad[bb.n_flat] / count      # column P = sum of squared / absolute errors
+    opt.apply(grad_clip_val)
+    return loss
+
+
+def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device):
+    """Reference signature (train_funcs.py:16-22)."""
+    net = net.train()
+    losses = []
+    kind = _loss_kind(criterion)
+    fast = isinstance(optimizer, FusedAdamW) and optimizer.net is net and kind is not None
+    for features, targets in dataloader:
+        features = features.to(device, non_blocking=True)
+        targets = targets.to(device, non_blocking=True)
+        if fast:
+            loss = fused_train_step(optimizer, features.contiguous().float(), targets.contiguous().float(), kind,
+                                    grad_clip_val)
+            losses.append(loss)
+            continue
+        optimizer.zero_grad()
+        out = net(features)
+        loss = criterion(out, targets)
+        loss.backward()
+        if isinstance(optimizer, FusedAdamW):
+            optimizer.step(grad_clip_val)
+        else:
+            if grad_clip_val != 0:
+                nn.utils.clip_grad_norm_(net.parameters(), grad_clip_val)
+            optimizer.step()
+        losses.append(loss.detach())
+    # one host sync per epoch instead of one .item() per step (train_funcs.py:48)
+    log["loss"] = float(np.mean(torch.stack([l.float() for l in losses]).cpu().numpy())) if losses else float("nan")
+    return net
+
+
+def net_eval(log, net, dataloader, criterion, device):
+    """Reference signature (train_funcs.py:57-61); returns (net, prediction, ground_truth) as numpy."""
+    net = net.eval()
+    losses, prediction, ground_truth = [], [], []
+    with torch.no_grad():
+        for features, targets in dataloader:
+            features = features.to(device)
+            targets = targets.to(device)
+            outputs = net(features)
+            losses.append(criterion(outputs, targets))
+            prediction.append(outputs)
+            ground_truth.append(targets)
+    log["loss"] = float(np.mean(torch.stack([l.float() for l in losses]).cpu().numpy())) if losses else float("nan")
+    prediction = torch.cat(prediction, dim=0).cpu().numpy()
+    ground_truth = torch.cat(ground_truth, dim=0).cpu().numpy()
+    return net, prediction, ground_truth

@@ -156,3 +156,69 @@ def test_loss_and_adamw_kernels_match_oracle():
         assert rel_err(mt.cpu().numpy(), m) < 1e-5
         assert rel_err(vt.cpu().numpy(), v) < 1e-5
         assert rel_err(gt.cpu().numpy(), g) < 1e-5
+
+
+@pytest.mark.parametrize("name,bb", [("gru_h11", "gru"), ("dgru_h13", "dgru"), ("dgru_h23", "dgru"), ("qgru_h16", "qgru")])
+def test_fused_train_step_follows_reference_trajectory(name, bb):
+    """Three fused steps (fwd+loss+bwd in one launch, reduce, clip 200 + AdamW) reproduce the reference's
+    losses and parameters after each step (tests/golden p1..p3, m3, v3)."""
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    fx = Fixture(name)
+    net = _model(fx, bb)
+    opt = FusedAdamW(net, lr=fx.meta["lr"])
+    x = torch.from_numpy(fx["x"]).cuda()
+    t = torch.from_numpy(fx["tgt"]).cuda()
+    names = fx.keys("sd")
+    for s in range(1, 4):
+        loss = fused_train_step(opt, x, t, "l2", fx.meta["clip"])
+        assert abs(loss.item() - fx["losses"][s - 1]) < 2e-5 * max(1.0, fx["losses"][s - 1])
+        got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in net.parameters()])
+        assert rel_err(got, fx.flat(f"p{s}", names)) < 2e-5, s
+    assert rel_err(opt.exp_avg.cpu().numpy(), fx.flat("m3", names)) < 1e-3
+    assert rel_err(opt.exp_avg_sq.cpu().numpy(), fx.flat("v3", names)) < 1e-3
+
+
+@pytest.mark.parametrize("bb,H,B,T", [("dgru", 13, 256, 200), ("gru", 23, 37, 50), ("dgru", 13, 1027, 64), ("dgru", 9, 3, 333)])
+def test_fused_equals_unfused_gradients(bb, H, B, T):
+    """The fused launch and the fwd/loss/bwd chain of separate kernels give the same gradient and loss."""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    torch.manual_seed(1)
+    net = CoreModel(2, H, 1, bb).cuda()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    t = torch.randn(B, T, 2, device="cuda", generator=g) * 0.3
+    loss = torch.nn.functional.mse_loss(net(x), t)
+    loss.backward()
+    gref = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    lf = fused_train_step(opt, x, t, "l2", 0.0)
+    assert abs(lf.item() - loss.item()) < 1e-5 * max(1.0, loss.item())
+    assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 2e-5
+    # L1 variant against autograd through the unfused kernels
+    for p in net.parameters():
+        p.grad = None
+    l1 = torch.nn.functional.l1_loss(net(x), t)
+    l1.backward()
+    gref = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+    lf = fused_train_step(opt, x, t, "l1", 0.0)
+    assert abs(lf.item() - l1.item()) < 1e-5 * max(1.0, l1.item())
+    assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 2e-5
+
+
+def test_fused_step_is_bit_repeatable():
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(2)
+        net = CoreModel(2, 13, 1, "dgru").cuda()
+        opt = FusedAdamW(net, lr=1e-3)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        x = torch.rand(512, 200, 2, device="cuda", generator=g) * 0.8 + 0.05
+        t = torch.rand(512, 200, 2, device="cuda", generator=g)
+        for _s in range(3):
+            fused_train_step(opt, x, t, "l2", 200.0)
+        outs.append(net.backbone.flat_params().clone())
+    assert torch.equal(outs[0], outs[1])
