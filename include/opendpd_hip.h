@@ -65,7 +65,7 @@ enum odpd_loss { ODPD_LOSS_L2 = 0, ODPD_LOSS_L1 = 1 };
 int64_t odpd_param_count(const odpd_model_t* m);
 /* floats of recurrent-state checkpoints `odpd_*_fwd` writes for BPTT (0 for non-recurrent) */
 int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T);
-/* rows of per-wavefront gradient partials that odpd_backbone_bwd (fused = 0) or odpd_train_fwd_bwd
+/* rows of per-workgroup gradient partials that odpd_backbone_bwd (fused = 0) or odpd_train_fwd_bwd
  * (fused = 1) write: partials is (rows, P+4) */
 int64_t odpd_partial_rows(const odpd_model_t* m, int B, int fused);
 /* library/ABI version, and the gfx arch string the code objects were built for */

@@ -13,7 +13,7 @@
 //                     5 activations per step).
 //   gru_bwd_kernel    BPTT: walks the checkpoints backwards, recomputes each block of S steps into
 //                     registers, back-propagates it; weight gradients are rank-4 (R=1) exact-fp32
-//                     MFMA updates; one row of partial gradients per wavefront (deterministic).
+//                     MFMA updates; one row of partial gradients per workgroup (deterministic).
 //   gru_train_kernel  forward + loss + backward fused in one launch; dy and the checkpoints stay
 //                     in LDS, HBM traffic = x + target only.
 #include "odpd_host.h"
@@ -36,8 +36,13 @@ struct GruW {
 template <int R, int F, bool DG>
 struct GruWT {             // transposed copies for the data-gradient mat-vecs
     float whhT[3][R][16];  // W_hg[16*rowblk + src_k][o]
-    float whidT[DG ? R : 1][16];
+    const float4* whidT_q; // DG: fc_hid^T streamed from the LDS master copy: quad q of row block rb at
+                           //     whidT_q[(rb*4 + q)*64]  (pointer already offset by the lane)
+    const float4* whid_q;  // DG: fc_hid (forward orientation) in the same quad layout, used by the
+                           //     block recompute so that the backward kernels do not pin it in VGPRs
 };
+// floats of the per-block LDS region holding the rotated fc_hid^T and fc_hid quads
+__host__ __device__ inline int whidT_lds_floats(int R, bool DG) { return DG ? 2 * R * 4 * 64 * 4 : 0; }
 
 template <int R, int F, bool DG>
 __device__ __forceinline__ void load_gru_w(GruW<R, F, DG>& w, const float* pl, const GruLayout& L, int row, int col,
@@ -64,7 +69,8 @@ __device__ __forceinline__ void load_gru_w(GruW<R, F, DG>& w, const float* pl, c
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         w.wout[c] = vo ? pl[L.o_w_out + c * OW + o] : 0.0f;
-        w.bout[c] = pl[L.o_b_out + c];
+        // uniform across lanes: keep it in an SGPR
+        w.bout[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pl[L.o_b_out + c])));
         w.woutf[c] = (DG && row == 0 && col < 6) ? pl[L.o_w_out + c * OW + H + col] : 0.0f;
     }
     w.bhid = 0.0f;
@@ -79,11 +85,15 @@ __device__ __forceinline__ void load_gru_w(GruW<R, F, DG>& w, const float* pl, c
             }
     }
 }
+// wl: per-block LDS region of whidT_lds_floats() floats, filled by wave 0 (every wave holds the same
+// per-lane values); contains a __syncthreads() — call from all threads of the block.
 template <int R, int F, bool DG>
 __device__ __forceinline__ void load_gru_wT(GruWT<R, F, DG>& w, const float* pl, const GruLayout& L, int row, int col,
-                                            const int (&src)[16]) {
+                                            const int (&src)[16], float* wl) {
     const int H = L.H, o = 16 * row + col;
     const bool vo = o < H;
+    const int lane = threadIdx.x & 63;
+    float4* wq = reinterpret_cast<float4*>(wl);
 #pragma unroll
     for (int rb = 0; rb < R; ++rb)
 #pragma unroll
@@ -92,8 +102,34 @@ __device__ __forceinline__ void load_gru_wT(GruWT<R, F, DG>& w, const float* pl,
             const bool v = vo && m < H;
 #pragma unroll
             for (int g = 0; g < 3; ++g) w.whhT[g][rb][k] = v ? pl[L.o_w_hh + (g * H + m) * H + o] : 0.0f;
-            if constexpr (DG) w.whidT[rb][k] = v ? pl[L.o_w_hid + m * H + o] : 0.0f;
         }
+    w.whidT_q = nullptr;
+    w.whid_q = nullptr;
+    if constexpr (DG) {
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int rb = 0; rb < R; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int m = 16 * ((row + rb) % R) + src[4 * q + e];
+                        t[e] = (vo && m < H) ? pl[L.o_w_hid + m * H + o] : 0.0f;
+                    }
+                    wq[(rb * 4 + q) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int m = 16 * ((row + rb) % R) + src[4 * q + e];
+                        t[e] = (vo && m < H) ? pl[L.o_w_hid + o * H + m] : 0.0f;
+                    }
+                    wq[((R + rb) * 4 + q) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+        }
+        __syncthreads();
+        w.whidT_q = wq + lane;
+        w.whid_q = wq + R * 4 * 64 + lane;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -202,8 +238,11 @@ __device__ __forceinline__ void gru_step_bwd(const GruW<R, FeatDim<FM>::F, DG>& 
                 }
             }
         }
-        dht = rotdot(dht, wt.whidT[0], dhid);
-        if constexpr (R == 2) dht = rotdot(dht, wt.whidT[1], swap16(dhid));
+        {
+            const float4* wq = wt.whidT_q;
+            dht = rotdot_quads(dht, [wq](int q) { return wq[q * 64]; }, dhid);
+            if constexpr (R == 2) dht = rotdot_quads(dht, [wq](int q) { return wq[(4 + q) * 64]; }, swap16(dhid));
+        }
     } else {
         if constexpr (NW) {
             G.dwout[0] = __builtin_fmaf(dy0, ht, G.dwout[0]);
@@ -333,6 +372,25 @@ __device__ __forceinline__ void gru_write_partials(float* prow, const GruLayout&
     }
 }
 
+// Block-level, fixed-order reduction of the waves' gradient rows: every wave scatters its row into
+// LDS (re-using the block's whole dynamic LDS, all waves are past their task loops), then the block
+// writes ONE row to HBM.  Deterministic: ((w0 + w1) + w2) + w3.
+template <int R, int F, bool DG>
+__device__ __forceinline__ void gru_block_partials(float* smem, float* partials, const GruLayout& L, GruGrad<R, DG>& G,
+                                                   int lane, int wave, int row, int col, float loss_part) {
+    const int P4 = L.P + kLossCols;
+    __syncthreads();
+    gru_write_partials<R, F, DG>(smem + wave * P4, L, G, lane, row, col, loss_part);
+    __syncthreads();
+    float* prow = partials + (size_t)blockIdx.x * P4;
+    for (int i = threadIdx.x; i < P4; i += kThreads) {
+        float v = smem[i];
+#pragma unroll
+        for (int wv = 1; wv < kWavesPerBlock; ++wv) v += smem[wv * P4 + i];
+        prow[i] = v;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // LDS staging of (B,T,2) streams: one chunk = kChunk steps of the wave's SPW sequences
 // -------------------------------------------------------------------------------------------------
@@ -408,19 +466,21 @@ __global__ __launch_bounds__(kThreads) void gru_fwd_kernel(SeqArgs a) {
 
 // -------------------------------------------------------------------------------------------------
 // backward over one wave-task (BPTT with block recompute).  Shared by the stand-alone backward
-// kernel (dy staged per chunk from HBM, checkpoints in HBM) and the fused train kernel (FUSED: dy
-// frame and checkpoints already in LDS).
-//   xs   : LDS chunk buffer for x              dys : LDS dy chunk buffer (or whole dy frame if FUSED)
-//   ck   : checkpoints of this task, slot c at ck[c*64 + lane]  (HBM, or LDS if FUSED)
+// kernel (dy staged per chunk from HBM, checkpoints in HBM) and the fused train kernel (FUSED: the
+// target is staged instead of dy; y, the loss and dy are recomputed here from the block recompute;
+// checkpoints live in LDS).
+//   xs  : LDS chunk buffer for x        dys : LDS chunk buffer for dy (target if FUSED)
+//   ck  : checkpoints of this task, slot c at ck[c*64 + lane]  (HBM, or LDS if FUSED)
 // -------------------------------------------------------------------------------------------------
 template <int R, int FM, bool DG, bool NW, bool DX, bool FUSED>
 __device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, FeatDim<FM>::F, DG>& w,
                                              const GruWT<R, FeatDim<FM>::F, DG>& wt, GruGrad<R, DG>& G, int b0, int lane,
-                                             int row, int col, int s, float2* xs, float2* dys, int dy_stride,
-                                             float2* dxs, const float* ck) {
+                                             int row, int col, int s, float2* xs, float2* dys, float2* dxs,
+                                             const float* ck, float& loss_acc) {
     constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R, S = kCkptStride;
     float dh = 0.0f;
     int cur_chunk = -1;
+    const bool valid = b0 + s < a.B;
     for (int blk = a.nck - 1; blk >= 0; --blk) {
         const int tb = blk * S, nstep = min(S, a.T - tb);
         const int chunk = tb / kChunk, t0 = chunk * kChunk;
@@ -435,7 +495,7 @@ __device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, Fea
             wave_lds_fence();
             const int len = min(kChunk, a.T - t0);
             stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
-            if constexpr (!FUSED) stage_in<SPW>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+            stage_in<SPW>(dys, FUSED ? a.target : a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
             wave_lds_fence();
             cur_chunk = chunk;
         }
@@ -452,8 +512,10 @@ __device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, Fea
                 gru_cell_fwd<R, FM, DG>(w, f, h, r_s[i], z_s[i], n_s[i], g_s[i]);
                 hid_s[i] = 0.0f;
                 if constexpr (DG) {
-                    hid_s[i] = rotdot(w.bhid, w.whid[0], h);
-                    if constexpr (R == 2) hid_s[i] = rotdot(hid_s[i], w.whid[1], swap16(h));
+                    const float4* wq = wt.whid_q;
+                    hid_s[i] = rotdot_quads(w.bhid, [wq](int q) { return wq[q * 64]; }, h);
+                    if constexpr (R == 2)
+                        hid_s[i] = rotdot_quads(hid_s[i], [wq](int q) { return wq[(4 + q) * 64]; }, swap16(h));
                 }
             }
         }
@@ -462,9 +524,35 @@ __device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, Fea
             if (i < nstep) {
                 const int tt = (tb - t0) + i;
                 const float2 xv = xs[s * kChunkPad + tt];
-                const float2 dyv = FUSED ? dys[s * dy_stride + tb + i] : dys[s * kChunkPad + tt];
+                float2 dyv = dys[s * kChunkPad + tt];
                 float f[F], df[F];
                 feat_fwd<FM>(xv.x, xv.y, f);
+                if constexpr (FUSED) {
+                    // output head from the recomputed state, then loss and dL/dy (train_funcs.py:35-39)
+                    float p0, p1;
+                    if constexpr (DG) {
+                        const float act = __builtin_fmaxf(hid_s[i], 0.0f), fs = feat_select<6>(f, col, 0.0f);
+                        p0 = __builtin_fmaf(w.wout[0], act, w.woutf[0] * fs);
+                        p1 = __builtin_fmaf(w.wout[1], act, w.woutf[1] * fs);
+                    } else {
+                        const float ht = __builtin_fmaf(z_s[i], hp_s[i] - n_s[i], n_s[i]);
+                        p0 = w.wout[0] * ht;
+                        p1 = w.wout[1] * ht;
+                    }
+                    const float d0 = seq_sum<R>(p0) + w.bout[0] - dyv.x, d1 = seq_sum<R>(p1) + w.bout[1] - dyv.y;
+                    float l;
+                    if (a.loss_kind == ODPD_LOSS_L2) {
+                        const float sc = 2.0f * a.inv_count;
+                        dyv = make_float2(d0 * sc, d1 * sc);
+                        l = __builtin_fmaf(d0, d0, d1 * d1);
+                    } else {
+                        dyv = make_float2(d0 > 0.f ? a.inv_count : (d0 < 0.f ? -a.inv_count : 0.f),
+                                          d1 > 0.f ? a.inv_count : (d1 < 0.f ? -a.inv_count : 0.f));
+                        l = __builtin_fabsf(d0) + __builtin_fabsf(d1);
+                    }
+                    if (!valid) dyv = make_float2(0.f, 0.f);
+                    loss_acc += (valid && (lane & (LPS - 1)) == 0) ? l : 0.0f;
+                }
                 gru_step_bwd<R, FM, DG, NW, DX>(w, wt, G, f, hp_s[i], r_s[i], z_s[i], n_s[i], g_s[i], hid_s[i], dyv.x,
                                                 dyv.y, row, col, dh, df);
                 if constexpr (DX) {
@@ -485,8 +573,9 @@ __device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, Fea
     }
 }
 
+// registers allow two waves per SIMD for one-row models unless both gradient kinds are requested
 template <int R, int FM, bool DG, bool NW, bool DX>
-__global__ __launch_bounds__(kThreads) void gru_bwd_kernel(SeqArgs a) {
+__global__ __launch_bounds__(kThreads, (R == 1 && !(NW && DX)) ? 2 : 1) void gru_bwd_kernel(SeqArgs a) {
     constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -494,7 +583,8 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_kernel(SeqArgs a) {
     const GruLayout L = gru_layout(a.H, F, DG);
     float* pl = smem;
     stage_params(pl, a.params, L.P);
-    float2* xs = reinterpret_cast<float2*>(smem + ((L.P + 3) & ~3)) + wave * (3 * SPW * kChunkPad);
+    float* wl = smem + ((L.P + 3) & ~3);
+    float2* xs = reinterpret_cast<float2*>(wl + whidT_lds_floats(R, DG)) + wave * (3 * SPW * kChunkPad);
     float2* dys = xs + SPW * kChunkPad;
     float2* dxs = dys + SPW * kChunkPad;
     int src[16];
@@ -502,31 +592,30 @@ __global__ __launch_bounds__(kThreads) void gru_bwd_kernel(SeqArgs a) {
     GruW<R, F, DG> w;
     GruWT<R, F, DG> wt;
     load_gru_w<R, F, DG>(w, pl, L, row, col, src);
-    load_gru_wT<R, F, DG>(wt, pl, L, row, col, src);
+    load_gru_wT<R, F, DG>(wt, pl, L, row, col, src, wl);
     GruGrad<R, DG> G;
     G.zero();
+    float unused = 0.0f;
     const int nwaves = gridDim.x * kWavesPerBlock, wave_global = blockIdx.x * kWavesPerBlock + wave;
     for (int grp = wave_global; grp < a.ngroups; grp += nwaves)
-        gru_bwd_task<R, FM, DG, NW, DX, false>(a, w, wt, G, grp * SPW, lane, row, col, s, xs, dys, 0, dxs,
-                                               a.ckpt + (size_t)grp * a.nck * 64);
-    if constexpr (NW) {
-        float* prow = a.partials + (size_t)wave_global * (L.P + kLossCols);
-        gru_write_partials<R, F, DG>(prow, L, G, lane, row, col, 0.0f);
-    }
+        gru_bwd_task<R, FM, DG, NW, DX, false>(a, w, wt, G, grp * SPW, lane, row, col, s, xs, dys, dxs,
+                                               a.ckpt + (size_t)grp * a.nck * 64, unused);
+    if constexpr (NW) gru_block_partials<R, F, DG>(smem, a.partials, L, G, lane, wave, row, col, 0.0f);
 }
 
 // -------------------------------------------------------------------------------------------------
-// fused train kernel: forward + loss + backward per wave-task, BPTT state resident in LDS
-// LDS per wave: x chunk, target chunk, dy frame (SPW x T), checkpoints (nck x 64 floats)
+// fused train kernel: per wave-task  (1) forward pass of the cell only, leaving a checkpoint of h
+// every S steps in LDS;  (2) backward pass that recomputes each block, forms y, the loss and dL/dy
+// on the fly and back-propagates.  HBM traffic = x (twice, the second read is L2-resident) + target.
+// LDS per wave: x chunk, target chunk, checkpoints (nck x 64 floats).
 // -------------------------------------------------------------------------------------------------
-__host__ __device__ inline int dy_frame_stride(int T) { return (T % 32 == 0) ? T + 1 : T; }
 __host__ __device__ inline int train_wave_floats(int T, int R) {
     const int SPW = 4 / R;
-    return 2 * (2 * SPW * kChunkPad) + 2 * SPW * dy_frame_stride(T) + num_ckpt_hd(T) * 64;
+    return 2 * (2 * SPW * kChunkPad) + num_ckpt_hd(T) * 64;
 }
 
 template <int R, int FM, bool DG>
-__global__ __launch_bounds__(kThreads) void gru_train_kernel(SeqArgs a) {
+__global__ __launch_bounds__(kThreads, R == 1 ? 2 : 1) void gru_train_kernel(SeqArgs a) {
     constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R, S = kCkptStride;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -534,63 +623,42 @@ __global__ __launch_bounds__(kThreads) void gru_train_kernel(SeqArgs a) {
     const GruLayout L = gru_layout(a.H, F, DG);
     float* pl = smem;
     stage_params(pl, a.params, L.P);
-    const int Tp = dy_frame_stride(a.T);
-    float* wbase = smem + ((L.P + 3) & ~3) + (size_t)wave * train_wave_floats(a.T, R);
+    float* wl = smem + ((L.P + 3) & ~3);
+    float* wbase = wl + whidT_lds_floats(R, DG) + (size_t)wave * train_wave_floats(a.T, R);
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ts = xs + SPW * kChunkPad;
-    float2* dyf = ts + SPW * kChunkPad;
-    float* ck = reinterpret_cast<float*>(dyf + SPW * Tp);
+    float* ck = reinterpret_cast<float*>(ts + SPW * kChunkPad);
     int src[16];
     rot_sources(src, col);
     GruW<R, F, DG> w;
     GruWT<R, F, DG> wt;
     load_gru_w<R, F, DG>(w, pl, L, row, col, src);
-    load_gru_wT<R, F, DG>(wt, pl, L, row, col, src);
+    load_gru_wT<R, F, DG>(wt, pl, L, row, col, src, wl);
     GruGrad<R, DG> G;
     G.zero();
     float loss_acc = 0.0f;
-    const bool lead = (lane & (LPS - 1)) == 0;
     const int nwaves = gridDim.x * kWavesPerBlock, wave_global = blockIdx.x * kWavesPerBlock + wave;
     for (int grp = wave_global; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * SPW;
-        const bool valid = b0 + s < a.B;
         float h = 0.0f;
         for (int t0 = 0; t0 < a.T; t0 += kChunk) {
             const int len = min(kChunk, a.T - t0);
             wave_lds_fence();
             stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
-            stage_in<SPW>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
             wave_lds_fence();
             for (int tt = 0; tt < len; ++tt) {
                 const float2 xv = xs[s * kChunkPad + tt];
-                const float2 tv = ts[s * kChunkPad + tt];
-                float f[F], r, z, n, ghn, y0, y1, hid;
+                float f[F], r, z, n, ghn;
                 feat_fwd<FM>(xv.x, xv.y, f);
                 gru_cell_fwd<R, FM, DG>(w, f, h, r, z, n, ghn);
-                gru_head_fwd<R, FM, DG>(w, h, f, col, y0, y1, hid);
-                const float d0 = y0 - tv.x, d1 = y1 - tv.y;
-                float g0, g1, l;
-                if (a.loss_kind == ODPD_LOSS_L2) {
-                    const float sc = 2.0f * a.inv_count;
-                    g0 = d0 * sc; g1 = d1 * sc; l = __builtin_fmaf(d0, d0, d1 * d1);
-                } else {
-                    g0 = d0 > 0.f ? a.inv_count : (d0 < 0.f ? -a.inv_count : 0.f);
-                    g1 = d1 > 0.f ? a.inv_count : (d1 < 0.f ? -a.inv_count : 0.f);
-                    l = __builtin_fabsf(d0) + __builtin_fabsf(d1);
-                }
-                if (lead) {
-                    dyf[s * Tp + t0 + tt] = valid ? make_float2(g0, g1) : make_float2(0.f, 0.f);
-                    loss_acc += valid ? l : 0.0f;
-                }
                 const int t1 = t0 + tt + 1;
                 if ((t1 % S) == 0 && t1 < a.T) ck[(t1 / S) * 64 + lane] = h;
             }
         }
         wave_lds_fence();
-        gru_bwd_task<R, FM, DG, true, false, true>(a, w, wt, G, b0, lane, row, col, s, xs, dyf, Tp, nullptr, ck);
+        gru_bwd_task<R, FM, DG, true, false, true>(a, w, wt, G, b0, lane, row, col, s, xs, ts, nullptr, ck, loss_acc);
     }
-    float* prow = a.partials + (size_t)wave_global * (L.P + kLossCols);
-    gru_write_partials<R, F, DG>(prow, L, G, lane, row, col, loss_acc);
+    gru_block_partials<R, F, DG>(smem, a.partials, L, G, lane, wave, row, col, loss_acc);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -598,7 +666,7 @@ __global__ __launch_bounds__(kThreads) void gru_train_kernel(SeqArgs a) {
 // -------------------------------------------------------------------------------------------------
 constexpr int kFwdBlocksPerCU = 4;  // grid caps (blocks are independent: a non-resident block simply queues)
 constexpr int kBwdBlocksPerCU = 2;
-constexpr int kTrainBlocksPerCU = 1;
+constexpr int kTrainBlocksPerCU = 2;
 
 static bool gru_cfg(const odpd_model_t* m, int& FM, bool& DG) {
     switch (m->backbone) {
@@ -609,8 +677,11 @@ static bool gru_cfg(const odpd_model_t* m, int& FM, bool& DG) {
     default: return false;
     }
 }
-static size_t gru_lds_bytes(int P, int R, int nbuf) {
-    return ((size_t)((P + 3) & ~3)) * 4 + (size_t)kWavesPerBlock * nbuf * (4 / R) * kChunkPad * sizeof(float2);
+static size_t reduce_scratch_bytes(int P) { return (size_t)kWavesPerBlock * (P + kLossCols) * sizeof(float); }
+static size_t gru_lds_bytes(int P, int R, int nbuf, bool dg_bwd = false) {
+    size_t n = ((size_t)((P + 3) & ~3) + whidT_lds_floats(R, dg_bwd)) * 4 +
+               (size_t)kWavesPerBlock * nbuf * (4 / R) * kChunkPad * sizeof(float2);
+    return (dg_bwd || nbuf == 3) && n < reduce_scratch_bytes(P) ? reduce_scratch_bytes(P) : n;
 }
 
 template <int R, int FM, bool DG>
@@ -622,7 +693,7 @@ static int launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
 }
 template <int R, int FM, bool DG, bool NW, bool DX>
 static int launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
-    const size_t lds = gru_lds_bytes(P, R, 3);
+    const size_t lds = gru_lds_bytes(P, R, 3, DG);
     hipLaunchKernelGGL((gru_bwd_kernel<R, FM, DG, NW, DX>), dim3(persistent_grid(a.ngroups, kBwdBlocksPerCU)),
                        dim3(kThreads), lds, st, a);
     return (int)hipGetLastError();
@@ -630,7 +701,9 @@ static int launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
 
 template <int R, int FM, bool DG>
 static int launch_train(hipStream_t st, const SeqArgs& a, int P) {
-    const size_t lds = ((size_t)((P + 3) & ~3) + (size_t)kWavesPerBlock * train_wave_floats(a.T, R)) * sizeof(float);
+    size_t lds = ((size_t)((P + 3) & ~3) + whidT_lds_floats(R, DG) +
+                  (size_t)kWavesPerBlock * train_wave_floats(a.T, R)) * sizeof(float);
+    if (lds < reduce_scratch_bytes(P)) lds = reduce_scratch_bytes(P);
     if (lds > 160 * 1024) return ODPD_EUNSUPPORTED;  // frame too long for LDS-resident BPTT state
     auto k = gru_train_kernel<R, FM, DG>;
     static size_t max_set = 0;
@@ -694,7 +767,7 @@ int gru_family_rows(const odpd_model_t* m, int B, int which) {
     if (!gru_cfg(m, FM, DG)) return ODPD_EUNSUPPORTED;
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
-    return persistent_grid(num_groups(B, R), which ? kTrainBlocksPerCU : kBwdBlocksPerCU) * kWavesPerBlock;
+    return persistent_grid(num_groups(B, R), which ? kTrainBlocksPerCU : kBwdBlocksPerCU);  // one row per block
 }
 
 int gru_family_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {

@@ -130,6 +130,42 @@ __device__ __forceinline__ float rotdot(float acc, const float (&w)[16], float h
     return a0 + a1;
 }
 
+// Rotated dot product with the 16 weights delivered as four quads (e.g. ds_read_b128 from an LDS
+// master copy: only 4-8 weight registers are live at a time).  Two accumulator chains.
+#define ODPD_ROTQ_GROUP(K0, K1, K2, K3, Q)                                                          \
+    asm("s_nop 1\n\t" ODPD_DPPF(0, 2, 3, K0) ODPD_DPPF(1, 2, 4, K1) ODPD_DPPF(0, 2, 5, K2)          \
+            ODPD_DPPF(1, 2, 6, K3)                                                                  \
+        : "+v"(a0), "+v"(a1) : "v"(h), "v"(Q.x), "v"(Q.y), "v"(Q.z), "v"(Q.w))
+template <typename QuadSrc>
+__device__ __forceinline__ float rotdot_quads(float acc, QuadSrc quad, float h) {
+    float a0, a1;
+    {
+        const float4 q = quad(0);
+        a0 = __builtin_fmaf(q.x, h, acc);
+        a1 = 0.0f;
+#if ODPD_DPP_ASM
+        asm("s_nop 1\n\t" ODPD_DPPF(1, 2, 3, 1) ODPD_DPPF(0, 2, 4, 2) ODPD_DPPF(1, 2, 5, 3)
+            : "+v"(a0), "+v"(a1) : "v"(h), "v"(q.y), "v"(q.z), "v"(q.w));
+#else
+        a1 = __builtin_fmaf(q.y, dpp_ror<1>(h), a1);
+        a0 = __builtin_fmaf(q.z, dpp_ror<2>(h), a0);
+        a1 = __builtin_fmaf(q.w, dpp_ror<3>(h), a1);
+#endif
+    }
+#if ODPD_DPP_ASM
+    { const float4 q = quad(1); ODPD_ROTQ_GROUP(4, 5, 6, 7, q); }
+    { const float4 q = quad(2); ODPD_ROTQ_GROUP(8, 9, 10, 11, q); }
+    { const float4 q = quad(3); ODPD_ROTQ_GROUP(12, 13, 14, 15, q); }
+#else
+#define ODPD_RQ(Q, K) { const float4 q = quad(Q); a0 = __builtin_fmaf(q.x, dpp_ror<K>(h), a0); \
+        a1 = __builtin_fmaf(q.y, dpp_ror<K + 1>(h), a1); a0 = __builtin_fmaf(q.z, dpp_ror<K + 2>(h), a0); \
+        a1 = __builtin_fmaf(q.w, dpp_ror<K + 3>(h), a1); }
+    ODPD_RQ(1, 4) ODPD_RQ(2, 8) ODPD_RQ(3, 12)
+#undef ODPD_RQ
+#endif
+    return a0 + a1;
+}
+
 // Three rotated dot products with three different inputs (transposed mat-vec of a gate triple):
 //   a_g += sum_k w_g[k] * row_ror_k(h_g)
 #define ODPD_F3X(K, W0, W1, W2) ODPD_DPPF(0, 3, W0, K) ODPD_DPPF(1, 4, W1, K) ODPD_DPPF(2, 5, W2, K)

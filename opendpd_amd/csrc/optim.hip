@@ -63,20 +63,32 @@ __global__ __launch_bounds__(256) void loss_final_kernel(int nblk, float inv_cou
     if (threadIdx.x == 0) out[0] = tot * inv_count;
 }
 
-// grad[c] = sum_r partials[r][c]; rows summed in a fixed order -> bit-repeatable
-__global__ __launch_bounds__(256) void reduce_partials_kernel(int64_t rows, int64_t cols, const float* __restrict__ part,
-                                                              float* __restrict__ grad, int accumulate) {
-    __shared__ float sh[4][64];
-    // 64 columns per block, 4 row-slices (one per wave), coalesced 256-B row reads
+// grad[c] = sum_r partials[r][c]; fixed summation order -> bit-repeatable.
+// 64 columns per block; 16 waves split the rows (8 independent loads in flight per lane), then a
+// fixed-order combine through LDS.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(int64_t rows, int64_t cols, const float* __restrict__ part,
+                                                               float* __restrict__ grad, int accumulate) {
+    __shared__ float sh[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c = (int64_t)blockIdx.x * 64 + lane;
     float acc = 0.f;
-    if (c < cols)
-        for (int64_t r = wave; r < rows; r += 4) acc += part[r * cols + c];
+    if (c < cols) {
+        int64_t r = wave;
+        for (; r + 7 * 16 < rows; r += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(r + u * 16) * cols + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; r < rows; r += 16) acc += part[r * cols + c];
+    }
     sh[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && c < cols) {
-        float v = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+        float v = sh[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) v += sh[w][lane];
         grad[c] = accumulate ? grad[c] + v : v;
     }
 }
@@ -134,7 +146,7 @@ extern "C" int odpd_reduce_partials(void* stream, int64_t rows, int64_t P, const
                                     int accumulate) {
     if (!partials || !grad || rows <= 0 || P <= 0) return ODPD_EINVAL;
     const int64_t cols = P + kLossCols;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, (hipStream_t)stream, rows,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, rows,
                        cols, partials, grad, accumulate);
     return (int)hipGetLastError();
 }
