@@ -66,8 +66,9 @@ int64_t odpd_param_count(const odpd_model_t* m);
 /* floats of recurrent-state checkpoints `odpd_*_fwd` writes for BPTT (0 for non-recurrent) */
 int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T);
 /* rows of per-workgroup gradient partials that odpd_backbone_bwd (fused = 0) or odpd_train_fwd_bwd
- * (fused = 1) write: partials is (rows, P+4) */
-int64_t odpd_partial_rows(const odpd_model_t* m, int B, int fused);
+ * (fused = 1) write for a (B,T,2) batch: partials is (rows, P+4).  ODPD_EUNSUPPORTED for fused = 1
+ * when T is too long for LDS-resident BPTT state (use the split forward/backward calls then). */
+int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fused);
 /* library/ABI version, and the gfx arch string the code objects were built for */
 int odpd_abi_version(void);
 const char* odpd_built_arch(void);

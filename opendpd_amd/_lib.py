@@ -26,7 +26,7 @@ _EXPORTS = {
     "odpd_built_arch": (C.c_char_p, []),
     "odpd_param_count": (C.c_int64, [C.POINTER(ModelDesc)]),
     "odpd_ckpt_floats": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
-    "odpd_partial_rows": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "odpd_partial_rows": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int]),
     "odpd_backbone_fwd": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "odpd_backbone_bwd": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p,

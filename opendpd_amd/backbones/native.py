@@ -100,7 +100,7 @@ class _BackboneFn(torch.autograd.Function):
         P = mod.n_flat
         partials = grad = dx = None
         if need_w:
-            rows = int(lib.odpd_partial_rows(C.byref(mod.desc), B, 0))
+            rows = int(lib.odpd_partial_rows(C.byref(mod.desc), B, T, 0))
             _lib.check(0 if rows > 0 else rows, "odpd_partial_rows")
             partials = torch.empty(rows, P + _lib.LOSS_COLS, dtype=torch.float32, device=x.device)
         if need_dx:

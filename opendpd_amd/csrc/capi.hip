@@ -62,10 +62,10 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     }
 }
 
-extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int fused) {
-    if (!model_ok(m) || B <= 0) return ODPD_EINVAL;
+extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fused) {
+    if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     switch (family_of(m->backbone)) {
-    case FAM_GRU: return gru_family_rows(m, B, fused ? 1 : 0);
+    case FAM_GRU: return gru_family_rows(m, B, fused ? 1 : 0, T);
     default: return ODPD_EUNSUPPORTED;
     }
 }

@@ -7,60 +7,111 @@
 //   r = s(W_ir x + b_ir + W_hr h + b_hr), z likewise, n = tanh(W_in x + b_in + r*(W_hn h + b_hn)),
 //   h' = (1-z)*n + z*h.
 //
-// Kernels (one wavefront = 4/R sequences, see odpd_device.h for the lane mapping):
-//   gru_fwd_kernel    forward over T steps; writes y and, for training, a checkpoint of h every
-//                     kCkptStride steps (BPTT state = 64 B per sequence per 4 steps instead of
-//                     5 activations per step).
-//   gru_bwd_kernel    BPTT: walks the checkpoints backwards, recomputes each block of S steps into
-//                     registers, back-propagates it; weight gradients are rank-4 (R=1) exact-fp32
-//                     MFMA updates; one row of partial gradients per workgroup (deterministic).
-//   gru_train_kernel  forward + loss + backward fused in one launch; dy and the checkpoints stay
-//                     in LDS, HBM traffic = x + target only.
+// Data layout on chip (one wavefront = 4/R sequences, lane mapping in odpd_device.h):
+//   * the ~1-3 k parameters are staged once per workgroup into LDS, together with "rotated quad
+//     tables" of the recurrent matrices (W_hh, W_hh^T, fc_hid, fc_hid^T): entry [row][quad][lane]
+//     holds the 4 weights lane needs for rotations 4q..4q+3.  Kernels pull the rows they need for
+//     the current PHASE into registers with ds_read_b128 (W_hh for forward/recompute, W_hh^T for the
+//     backward steps) — the two orientations time-share the same registers;
+//   * x / target / dy are staged per chunk of kChunk steps; BPTT state is one checkpoint of h every
+//     kCkptStride steps (HBM for the split kernels, LDS for the fused one).
+// Kernels:
+//   gru_fwd_kernel    forward (inference or training forward with checkpoints)
+//   gru_bwd_kernel    BPTT: per block of S steps recompute forward into registers, back-propagate;
+//                     weight gradients are rank-4 exact-fp32 MFMA updates (v_mfma_f32_16x16x4_f32);
+//                     one row of partial gradients per workgroup, fixed summation order.
+//   gru_train_kernel  forward (cell only) + backward with y / loss / dL/dy formed on the fly:
+//                     HBM traffic = x + target.
 #include "odpd_host.h"
 
 namespace odpd {
 
 // -------------------------------------------------------------------------------------------------
-// register-resident weights
+// LDS rotated-quad weight tables
+// -------------------------------------------------------------------------------------------------
+template <int R, bool DG>
+struct GruTabs {
+    static constexpr int kHH = 0;            // rows g*R + rb           : W_hg[o][16*blk + src]
+    static constexpr int kHHT = 3 * R;       // rows 3R + g*R + rb      : W_hg[16*blk + src][o]
+    static constexpr int kHID = 6 * R;       // rows 6R + rb            : fc_hid[o][16*blk + src]
+    static constexpr int kHIDT = 7 * R;      // rows 7R + rb            : fc_hid[16*blk + src][o]
+    static constexpr int kRows = DG ? 8 * R : 6 * R;
+    static constexpr int kFloats = kRows * 4 * 64 * 4;
+};
+
+// direction of row_ror measured with the instruction itself: lane col receives lane (col + dir*k) & 15
+__device__ __forceinline__ int rot_dir(int col) { return dpp_ror_i<1>(col) == ((col + 15) & 15) ? -1 : 1; }
+
+// Cooperative fill (all waves of the block; ends with __syncthreads()).
+template <int R, bool DG, bool WITH_T>
+__device__ __forceinline__ void fill_gru_tabs(float* tab, const float* pl, const GruLayout& L, int lane, int wave, int nwb) {
+    using T = GruTabs<R, DG>;
+    const int H = L.H, col = lane & 15, row = (lane >> 4) & (R - 1), o = 16 * row + col, dir = rot_dir(col);
+    float4* t4 = reinterpret_cast<float4*>(tab);
+    for (int idx = wave; idx < T::kRows * 4; idx += nwb) {
+        const int tr = idx >> 2, q = idx & 3;
+        const bool transposed = (tr >= T::kHHT && tr < T::kHID) || tr >= T::kHIDT;
+        if (!WITH_T && transposed) continue;
+        const bool hid = tr >= T::kHID;
+        const int local = hid ? (tr - (transposed ? T::kHIDT : T::kHID)) : (tr - (transposed ? T::kHHT : T::kHH));
+        const int g = hid ? 0 : local / R, rb = hid ? local : local % R;
+        const int base = hid ? L.o_w_hid : L.o_w_hh + g * H * H;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 16 * ((row + rb) % R) + ((col + dir * (4 * q + e)) & 15);
+            const bool ok = o < H && m < H;
+            v[e] = ok ? pl[base + (transposed ? m * H + o : o * H + m)] : 0.0f;
+        }
+        t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+}
+
+// Returns the same pointer through an empty asm: the compiler can no longer prove that the table
+// loads of successive blocks read the same addresses, so it cannot hoist them out of the block loop
+// (which would pin W_hh and W_hh^T in registers at the same time again).
+__device__ __forceinline__ const float4* opaque(const float4* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+// pull one table row (16 rotated weights) / a gate triple into registers
+__device__ __forceinline__ void load_rot(float (&w)[16], const float4* trow) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = trow[q * 64];
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+}
+template <int R>
+__device__ __forceinline__ void load_rot3(float (&w)[3][R][16], const float4* tlane, int first_row) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int rb = 0; rb < R; ++rb) load_rot(w[g][rb], tlane + (first_row + g * R + rb) * 4 * 64);
+}
+
+// -------------------------------------------------------------------------------------------------
+// register-resident small weights
 // -------------------------------------------------------------------------------------------------
 template <int R, int F, bool DG>
 struct GruW {
-    float whh[3][R][16];   // [gate][0 = own row, 1 = other row][k]  W_hg[o][16*rowblk + src_k]
     float wih[3][F];
     float b_r, b_z, b_in, b_hn;
     float wout[2], bout[2];
-    float whid[DG ? R : 1][16];
     float bhid;
     float woutf[2];        // DG: fc_out weight of feature `col` (row-0 lanes, col < 6), else 0
 };
-template <int R, int F, bool DG>
-struct GruWT {             // transposed copies for the data-gradient mat-vecs
-    float whhT[3][R][16];  // W_hg[16*rowblk + src_k][o]
-    const float4* whidT_q; // DG: fc_hid^T streamed from the LDS master copy: quad q of row block rb at
-                           //     whidT_q[(rb*4 + q)*64]  (pointer already offset by the lane)
-    const float4* whid_q;  // DG: fc_hid (forward orientation) in the same quad layout, used by the
-                           //     block recompute so that the backward kernels do not pin it in VGPRs
-};
-// floats of the per-block LDS region holding the rotated fc_hid^T and fc_hid quads
-__host__ __device__ inline int whidT_lds_floats(int R, bool DG) { return DG ? 2 * R * 4 * 64 * 4 : 0; }
 
 template <int R, int F, bool DG>
-__device__ __forceinline__ void load_gru_w(GruW<R, F, DG>& w, const float* pl, const GruLayout& L, int row, int col,
-                                           const int (&src)[16]) {
+__device__ __forceinline__ void load_gru_w(GruW<R, F, DG>& w, const float* pl, const GruLayout& L, int row, int col) {
     const int H = L.H, o = 16 * row + col;
     const bool vo = o < H;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-#pragma unroll
-        for (int rb = 0; rb < R; ++rb)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                int m = 16 * ((row + rb) % R) + src[k];
-                w.whh[g][rb][k] = (vo && m < H) ? pl[L.o_w_hh + (g * H + o) * H + m] : 0.0f;
-            }
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int i = 0; i < F; ++i) w.wih[g][i] = vo ? pl[L.o_w_ih + (g * H + o) * F + i] : 0.0f;
-    }
     w.b_r = vo ? pl[L.o_b_ih + o] + pl[L.o_b_hh + o] : 0.0f;
     w.b_z = vo ? pl[L.o_b_ih + H + o] + pl[L.o_b_hh + H + o] : 0.0f;
     w.b_in = vo ? pl[L.o_b_ih + 2 * H + o] : 0.0f;
@@ -73,71 +124,16 @@ __device__ __forceinline__ void load_gru_w(GruW<R, F, DG>& w, const float* pl, c
         w.bout[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pl[L.o_b_out + c])));
         w.woutf[c] = (DG && row == 0 && col < 6) ? pl[L.o_w_out + c * OW + H + col] : 0.0f;
     }
-    w.bhid = 0.0f;
-    if constexpr (DG) {
-        w.bhid = vo ? pl[L.o_b_hid + o] : 0.0f;
-#pragma unroll
-        for (int rb = 0; rb < R; ++rb)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                int m = 16 * ((row + rb) % R) + src[k];
-                w.whid[rb][k] = (vo && m < H) ? pl[L.o_w_hid + o * H + m] : 0.0f;
-            }
-    }
-}
-// wl: per-block LDS region of whidT_lds_floats() floats, filled by wave 0 (every wave holds the same
-// per-lane values); contains a __syncthreads() — call from all threads of the block.
-template <int R, int F, bool DG>
-__device__ __forceinline__ void load_gru_wT(GruWT<R, F, DG>& w, const float* pl, const GruLayout& L, int row, int col,
-                                            const int (&src)[16], float* wl) {
-    const int H = L.H, o = 16 * row + col;
-    const bool vo = o < H;
-    const int lane = threadIdx.x & 63;
-    float4* wq = reinterpret_cast<float4*>(wl);
-#pragma unroll
-    for (int rb = 0; rb < R; ++rb)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            int m = 16 * ((row + rb) % R) + src[k];
-            const bool v = vo && m < H;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) w.whhT[g][rb][k] = v ? pl[L.o_w_hh + (g * H + m) * H + o] : 0.0f;
-        }
-    w.whidT_q = nullptr;
-    w.whid_q = nullptr;
-    if constexpr (DG) {
-        if (threadIdx.x < 64) {
-#pragma unroll
-            for (int rb = 0; rb < R; ++rb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float t[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int m = 16 * ((row + rb) % R) + src[4 * q + e];
-                        t[e] = (vo && m < H) ? pl[L.o_w_hid + m * H + o] : 0.0f;
-                    }
-                    wq[(rb * 4 + q) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int m = 16 * ((row + rb) % R) + src[4 * q + e];
-                        t[e] = (vo && m < H) ? pl[L.o_w_hid + o * H + m] : 0.0f;
-                    }
-                    wq[((R + rb) * 4 + q) * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
-                }
-        }
-        __syncthreads();
-        w.whidT_q = wq + lane;
-        w.whid_q = wq + R * 4 * 64 + lane;
-    }
+    w.bhid = (DG && vo) ? pl[L.o_b_hid + o] : 0.0f;
 }
 
 // -------------------------------------------------------------------------------------------------
 // per-step device functions
 // -------------------------------------------------------------------------------------------------
 template <int R, int FM, bool DG>
-__device__ __forceinline__ void gru_cell_fwd(const GruW<R, FeatDim<FM>::F, DG>& w, const float (&f)[FeatDim<FM>::F],
-                                             float& h, float& r, float& z, float& n, float& ghn) {
+__device__ __forceinline__ void gru_cell_fwd(const GruW<R, FeatDim<FM>::F, DG>& w, const float (&whh)[3][R][16],
+                                             const float (&f)[FeatDim<FM>::F], float& h, float& r, float& z, float& n,
+                                             float& ghn) {
     constexpr int F = FeatDim<FM>::F;
     float ar = w.b_r, az = w.b_z, an = w.b_in, ah = w.b_hn;
 #pragma unroll
@@ -146,10 +142,10 @@ __device__ __forceinline__ void gru_cell_fwd(const GruW<R, FeatDim<FM>::F, DG>& 
         az = __builtin_fmaf(w.wih[1][i], f[i], az);
         an = __builtin_fmaf(w.wih[2][i], f[i], an);
     }
-    rotdot3(ar, az, ah, w.whh[0][0], w.whh[1][0], w.whh[2][0], h);
+    rotdot3(ar, az, ah, whh[0][0], whh[1][0], whh[2][0], h);
     if constexpr (R == 2) {
         float hx = swap16(h);
-        rotdot3(ar, az, ah, w.whh[0][1], w.whh[1][1], w.whh[2][1], hx);
+        rotdot3(ar, az, ah, whh[0][1], whh[1][1], whh[2][1], hx);
     }
     r = sigmoidf_(ar);
     z = sigmoidf_(az);
@@ -158,22 +154,30 @@ __device__ __forceinline__ void gru_cell_fwd(const GruW<R, FeatDim<FM>::F, DG>& 
     h = __builtin_fmaf(z, h - n, n);  // (1-z)*n + z*h
 }
 
-// output head.  hid = fc_hid pre-activation (DG only)
+// acc + (table rows first_row.. of this lane) . h  — fc_hid pre-activation or its transpose product
+template <int R>
+__device__ __forceinline__ float tab_rotdot(float acc, const float4* tlane, int first_row, float h) {
+    const float4* t0 = tlane + first_row * 4 * 64;
+    float v = rotdot_quads(acc, [t0](int q) { return t0[q * 64]; }, h);
+    if constexpr (R == 2) {
+        const float4* t1 = t0 + 4 * 64;
+        v = rotdot_quads(v, [t1](int q) { return t1[q * 64]; }, swap16(h));
+    }
+    return v;
+}
+
+// y from the head inputs: DG: act = relu(fc_hid pre-activation), else act = h
 template <int R, int FM, bool DG>
-__device__ __forceinline__ void gru_head_fwd(const GruW<R, FeatDim<FM>::F, DG>& w, float h,
-                                             const float (&f)[FeatDim<FM>::F], int col, float& y0, float& y1, float& hid) {
+__device__ __forceinline__ void gru_head_out(const GruW<R, FeatDim<FM>::F, DG>& w, float act,
+                                             const float (&f)[FeatDim<FM>::F], int col, float& y0, float& y1) {
     float p0, p1;
-    hid = 0.0f;
     if constexpr (DG) {
-        hid = rotdot(w.bhid, w.whid[0], h);
-        if constexpr (R == 2) hid = rotdot(hid, w.whid[1], swap16(h));
-        float a = __builtin_fmaxf(hid, 0.0f);
-        float fs = feat_select<6>(f, col, 0.0f);
-        p0 = __builtin_fmaf(w.wout[0], a, w.woutf[0] * fs);
-        p1 = __builtin_fmaf(w.wout[1], a, w.woutf[1] * fs);
+        const float fs = feat_select<6>(f, col, 0.0f);
+        p0 = __builtin_fmaf(w.wout[0], act, w.woutf[0] * fs);
+        p1 = __builtin_fmaf(w.wout[1], act, w.woutf[1] * fs);
     } else {
-        p0 = w.wout[0] * h;
-        p1 = w.wout[1] * h;
+        p0 = w.wout[0] * act;
+        p1 = w.wout[1] * act;
     }
     y0 = seq_sum<R>(p0) + w.bout[0];
     y1 = seq_sum<R>(p1) + w.bout[1];
@@ -208,11 +212,12 @@ struct GruGrad {
 // one BPTT step.  In: saved hp,r,z,n,ghn,hid of the step, features f, dy, carry dh (dL/dh_t from
 // later steps).  Out: dh <- dL/dh_{t-1}; df (if DX) = dL/dfeat.
 template <int R, int FM, bool DG, bool NW, bool DX>
-__device__ __forceinline__ void gru_step_bwd(const GruW<R, FeatDim<FM>::F, DG>& w, const GruWT<R, FeatDim<FM>::F, DG>& wt,
-                                             GruGrad<R, DG>& G, const float (&f)[FeatDim<FM>::F], float hp, float r,
-                                             float z, float n, float ghn, float hid, float dy0, float dy1, int row,
-                                             int col, float& dh, float (&df)[FeatDim<FM>::F]) {
+__device__ __forceinline__ void gru_step_bwd(const GruW<R, FeatDim<FM>::F, DG>& w, const float (&whhT)[3][R][16],
+                                             const float4* tlane, GruGrad<R, DG>& G, const float (&f)[FeatDim<FM>::F],
+                                             float hp, float r, float z, float n, float ghn, float hid, float dy0,
+                                             float dy1, int row, int col, float& dh, float (&df)[FeatDim<FM>::F]) {
     constexpr int F = FeatDim<FM>::F;
+    using T = GruTabs<R, DG>;
     const float ht = __builtin_fmaf(z, hp - n, n);
     float dht = dh;
     const float g01 = __builtin_fmaf(dy0, w.wout[0], dy1 * w.wout[1]);
@@ -238,11 +243,7 @@ __device__ __forceinline__ void gru_step_bwd(const GruW<R, FeatDim<FM>::F, DG>& 
                 }
             }
         }
-        {
-            const float4* wq = wt.whidT_q;
-            dht = rotdot_quads(dht, [wq](int q) { return wq[q * 64]; }, dhid);
-            if constexpr (R == 2) dht = rotdot_quads(dht, [wq](int q) { return wq[(4 + q) * 64]; }, swap16(dhid));
-        }
+        dht = tab_rotdot<R>(dht, tlane, T::kHIDT, dhid);  // dht += fc_hid^T dhid
     } else {
         if constexpr (NW) {
             G.dwout[0] = __builtin_fmaf(dy0, ht, G.dwout[0]);
@@ -289,9 +290,8 @@ __device__ __forceinline__ void gru_step_bwd(const GruW<R, FeatDim<FM>::F, DG>& 
     }
     // data gradient to h_{t-1}
     float d0 = dht * z, d1 = 0.0f, d2 = 0.0f;
-    rotdot3x(d0, d1, d2, wt.whhT[0][0], wt.whhT[1][0], wt.whhT[2][0], drp, dzp, dgh);
-    if constexpr (R == 2)
-        rotdot3x(d0, d1, d2, wt.whhT[0][1], wt.whhT[1][1], wt.whhT[2][1], swap16(drp), swap16(dzp), swap16(dgh));
+    rotdot3x(d0, d1, d2, whhT[0][0], whhT[1][0], whhT[2][0], drp, dzp, dgh);
+    if constexpr (R == 2) rotdot3x(d0, d1, d2, whhT[0][1], whhT[1][1], whhT[2][1], swap16(drp), swap16(dzp), swap16(dgh));
     dh = d0 + d1 + d2;
     if constexpr (DX) {
 #pragma unroll
@@ -374,72 +374,92 @@ __device__ __forceinline__ void gru_write_partials(float* prow, const GruLayout&
 
 // Block-level, fixed-order reduction of the waves' gradient rows: every wave scatters its row into
 // LDS (re-using the block's whole dynamic LDS, all waves are past their task loops), then the block
-// writes ONE row to HBM.  Deterministic: ((w0 + w1) + w2) + w3.
+// writes ONE row to HBM.  Deterministic: (((w0 + w1) + w2) + ...).
 template <int R, int F, bool DG>
 __device__ __forceinline__ void gru_block_partials(float* smem, float* partials, const GruLayout& L, GruGrad<R, DG>& G,
-                                                   int lane, int wave, int row, int col, float loss_part) {
+                                                   int lane, int wave, int nwb, int row, int col, float loss_part) {
     const int P4 = L.P + kLossCols;
     __syncthreads();
     gru_write_partials<R, F, DG>(smem + wave * P4, L, G, lane, row, col, loss_part);
     __syncthreads();
     float* prow = partials + (size_t)blockIdx.x * P4;
-    for (int i = threadIdx.x; i < P4; i += kThreads) {
+    for (int i = threadIdx.x; i < P4; i += blockDim.x) {
         float v = smem[i];
-#pragma unroll
-        for (int wv = 1; wv < kWavesPerBlock; ++wv) v += smem[wv * P4 + i];
+        for (int wv = 1; wv < nwb; ++wv) v += smem[wv * P4 + i];
         prow[i] = v;
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-// LDS staging of (B,T,2) streams: one chunk = kChunk steps of the wave's SPW sequences
+// LDS staging of (B,T,2) streams: one chunk = kChunk steps of the wave's SPW sequences,
+// LDS layout [seq][kChunkPad] float2
 // -------------------------------------------------------------------------------------------------
-static_assert(kChunk == 64, "staging maps lane -> time step inside a chunk");
 template <int SPW>
 __device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane,
                                          float2 fill) {
     const float2* g2 = reinterpret_cast<const float2*>(g);
+    constexpr int N = SPW * kChunk / 64;   // float2 per lane
+    static_assert(N >= 1 && (SPW * kChunk) % 64 == 0, "chunk must tile the wave");
 #pragma unroll
-    for (int m = 0; m < SPW; ++m) {
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
         float2 v = fill;
-        if (lane < len && b0 + m < B) v = g2[(size_t)(b0 + m) * T + t0 + lane];
-        lds[m * kChunkPad + lane] = v;
+        if (tt < len && b0 + m < B) v = g2[(size_t)(b0 + m) * T + t0 + tt];
+        lds[m * kChunkPad + tt] = v;
     }
 }
 template <int SPW>
 __device__ __forceinline__ void stage_out(const float2* lds, float* g, int b0, int B, int T, int t0, int len, int lane) {
     float2* g2 = reinterpret_cast<float2*>(g);
+    constexpr int N = SPW * kChunk / 64;
 #pragma unroll
-    for (int m = 0; m < SPW; ++m)
-        if (lane < len && b0 + m < B) g2[(size_t)(b0 + m) * T + t0 + lane] = lds[m * kChunkPad + lane];
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
+        if (tt < len && b0 + m < B) g2[(size_t)(b0 + m) * T + t0 + tt] = lds[m * kChunkPad + tt];
+    }
 }
 
 __device__ __forceinline__ void stage_params(float* pl, const float* params, int P) {
-    for (int i = threadIdx.x; i < P; i += kThreads) pl[i] = params[i];
+    for (int i = threadIdx.x; i < P; i += blockDim.x) pl[i] = params[i];
     __syncthreads();
 }
+
+// common kernel prologue: identifies the lane
+struct LaneId { int lane, wave, nwb, col, row, s; };
+template <int R>
+__device__ __forceinline__ LaneId lane_id() {
+    LaneId id;
+    id.lane = threadIdx.x & 63; id.wave = threadIdx.x >> 6; id.nwb = blockDim.x >> 6;
+    id.col = id.lane & 15; id.row = (id.lane >> 4) & (R - 1); id.s = id.lane / (16 * R);
+    return id;
+}
+__host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 
 // -------------------------------------------------------------------------------------------------
 // forward kernel
 // -------------------------------------------------------------------------------------------------
 template <int R, int FM, bool DG>
-__global__ __launch_bounds__(kThreads) void gru_fwd_kernel(SeqArgs a) {
+__global__ __launch_bounds__(kMaxThreads) void gru_fwd_kernel(SeqArgs a) {
     constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R, S = kCkptStride;
+    using T = GruTabs<R, DG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 15, row = (lane >> 4) & (R - 1), s = lane / LPS;
+    const LaneId id = lane_id<R>();
+    const int lane = id.lane, col = id.col, s = id.s;
     const GruLayout L = gru_layout(a.H, F, DG);
     float* pl = smem;
     stage_params(pl, a.params, L.P);
-    float2* xs = reinterpret_cast<float2*>(smem + ((L.P + 3) & ~3)) + wave * (2 * SPW * kChunkPad);
+    float* tab = smem + pad4(L.P);
+    fill_gru_tabs<R, DG, false>(tab, pl, L, lane, id.wave, id.nwb);
+    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    float2* xs = reinterpret_cast<float2*>(tab + T::kFloats) + id.wave * (2 * SPW * kChunkPad);
     float2* ys = xs + SPW * kChunkPad;
-    int src[16];
-    rot_sources(src, col);
     GruW<R, F, DG> w;
-    load_gru_w<R, F, DG>(w, pl, L, row, col, src);
+    load_gru_w<R, F, DG>(w, pl, L, id.row, col);
+    float whh[3][R][16];
+    load_rot3<R>(whh, tlane, T::kHH);
 
-    const int nwaves = gridDim.x * kWavesPerBlock;
-    for (int grp = blockIdx.x * kWavesPerBlock + wave; grp < a.ngroups; grp += nwaves) {
+    const int nwaves = gridDim.x * id.nwb;
+    for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * SPW;
         float h = 0.0f;
         for (int t0 = 0; t0 < a.T; t0 += kChunk) {
@@ -448,10 +468,12 @@ __global__ __launch_bounds__(kThreads) void gru_fwd_kernel(SeqArgs a) {
             wave_lds_fence();
             for (int tt = 0; tt < len; ++tt) {
                 const float2 xv = xs[s * kChunkPad + tt];
-                float f[F], r, z, n, ghn, y0, y1, hid;
+                float f[F], r, z, n, ghn, y0, y1;
                 feat_fwd<FM>(xv.x, xv.y, f);
-                gru_cell_fwd<R, FM, DG>(w, f, h, r, z, n, ghn);
-                gru_head_fwd<R, FM, DG>(w, h, f, col, y0, y1, hid);
+                gru_cell_fwd<R, FM, DG>(w, whh, f, h, r, z, n, ghn);
+                float act = h;
+                if constexpr (DG) act = __builtin_fmaxf(tab_rotdot<R>(w.bhid, tlane, T::kHID, h), 0.0f);
+                gru_head_out<R, FM, DG>(w, act, f, col, y0, y1);
                 if ((lane & (LPS - 1)) == 0) ys[s * kChunkPad + tt] = make_float2(y0, y1);
                 const int t1 = t0 + tt + 1;
                 if (a.ckpt != nullptr && (t1 % S) == 0 && t1 < a.T)
@@ -465,22 +487,87 @@ __global__ __launch_bounds__(kThreads) void gru_fwd_kernel(SeqArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// backward over one wave-task (BPTT with block recompute).  Shared by the stand-alone backward
-// kernel (dy staged per chunk from HBM, checkpoints in HBM) and the fused train kernel (FUSED: the
-// target is staged instead of dy; y, the loss and dy are recomputed here from the block recompute;
+// One block of S steps: pull W_hh, recompute the forward pass of the block into registers, pull
+// W_hh^T into the same registers, back-propagate.  FULL: nstep == S, no per-step guards.
+// tloc = first step of the block relative to the staged chunk.
+// -------------------------------------------------------------------------------------------------
+template <int R, int FM, bool DG, bool NW, bool DX, bool FUSED, bool FULL>
+__device__ __forceinline__ void gru_bwd_block(const SeqArgs& a, const GruW<R, FeatDim<FM>::F, DG>& w, const float4* tlane,
+                                              GruGrad<R, DG>& G, const LaneId& id, const float2* xs, const float2* dys,
+                                              float2* dxs, int tloc, int nstep, bool valid, float h, float& dh,
+                                              float& loss_acc) {
+    constexpr int F = FeatDim<FM>::F, LPS = 16 * R, S = kCkptStride;
+    using T = GruTabs<R, DG>;
+    const int lane = id.lane, col = id.col, row = id.row, s = id.s;
+    float hp_s[S], r_s[S], z_s[S], n_s[S], g_s[S], hid_s[S];
+    tlane = opaque(tlane);
+    {
+        float whh[3][R][16];
+        load_rot3<R>(whh, tlane, T::kHH);
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            if (FULL || i < nstep) {
+                const float2 xv = xs[s * kChunkPad + tloc + i];
+                float f[F];
+                feat_fwd<FM>(xv.x, xv.y, f);
+                hp_s[i] = h;
+                gru_cell_fwd<R, FM, DG>(w, whh, f, h, r_s[i], z_s[i], n_s[i], g_s[i]);
+                hid_s[i] = 0.0f;
+                if constexpr (DG) hid_s[i] = tab_rotdot<R>(w.bhid, tlane, T::kHID, h);
+            }
+        }
+    }
+    tlane = opaque(tlane);
+    float whhT[3][R][16];
+    load_rot3<R>(whhT, tlane, T::kHHT);
+    const bool l2 = a.loss_kind == ODPD_LOSS_L2;
+#pragma unroll
+    for (int i = S - 1; i >= 0; --i) {
+        if (FULL || i < nstep) {
+            const int tt = tloc + i;
+            const float2 xv = xs[s * kChunkPad + tt];
+            float2 dyv = dys[s * kChunkPad + tt];
+            float f[F], df[F];
+            feat_fwd<FM>(xv.x, xv.y, f);
+            if constexpr (FUSED) {
+                // output head from the recomputed state, then loss and dL/dy (train_funcs.py:35-39)
+                float y0, y1;
+                const float act = DG ? __builtin_fmaxf(hid_s[i], 0.0f) : __builtin_fmaf(z_s[i], hp_s[i] - n_s[i], n_s[i]);
+                gru_head_out<R, FM, DG>(w, act, f, col, y0, y1);
+                const float d0 = y0 - dyv.x, d1 = y1 - dyv.y;
+                const float sc = valid ? a.inv_count : 0.0f;
+                const float s0 = d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f), s1 = d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
+                dyv = make_float2(l2 ? 2.0f * sc * d0 : s0, l2 ? 2.0f * sc * d1 : s1);
+                const float lv = l2 ? __builtin_fmaf(d0, d0, d1 * d1) : __builtin_fabsf(d0) + __builtin_fabsf(d1);
+                loss_acc += (valid && (lane & (LPS - 1)) == 0) ? lv : 0.0f;
+            }
+            gru_step_bwd<R, FM, DG, NW, DX>(w, whhT, tlane, G, f, hp_s[i], r_s[i], z_s[i], n_s[i], g_s[i], hid_s[i],
+                                            dyv.x, dyv.y, row, col, dh, df);
+            if constexpr (DX) {
+                float dI, dQ;
+                feat_bwd<FM>(xv.x, xv.y, df, dI, dQ);
+                if ((lane & (LPS - 1)) == 0) dxs[s * kChunkPad + tt] = make_float2(dI, dQ);
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// backward over one wave-task.  Shared by the stand-alone backward kernel (dy staged per chunk from
+// HBM, checkpoints in HBM) and the fused train kernel (FUSED: the target is staged instead of dy;
 // checkpoints live in LDS).
-//   xs  : LDS chunk buffer for x        dys : LDS chunk buffer for dy (target if FUSED)
-//   ck  : checkpoints of this task, slot c at ck[c*64 + lane]  (HBM, or LDS if FUSED)
+//   xs : LDS chunk buffer for x     dys : LDS chunk buffer for dy (target if FUSED)
+//   ck : checkpoints of this task, slot c at ck[c*64 + lane]  (HBM, or LDS if FUSED)
 // -------------------------------------------------------------------------------------------------
 template <int R, int FM, bool DG, bool NW, bool DX, bool FUSED>
-__device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, FeatDim<FM>::F, DG>& w,
-                                             const GruWT<R, FeatDim<FM>::F, DG>& wt, GruGrad<R, DG>& G, int b0, int lane,
-                                             int row, int col, int s, float2* xs, float2* dys, float2* dxs,
-                                             const float* ck, float& loss_acc) {
-    constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R, S = kCkptStride;
+__device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, FeatDim<FM>::F, DG>& w, const float4* tlane,
+                                             GruGrad<R, DG>& G, int b0, const LaneId& id, float2* xs, float2* dys,
+                                             float2* dxs, const float* ck, float& loss_acc) {
+    constexpr int SPW = 4 / R, S = kCkptStride;
+    const int lane = id.lane;
     float dh = 0.0f;
     int cur_chunk = -1;
-    const bool valid = b0 + s < a.B;
+    const bool valid = b0 + id.s < a.B;
     for (int blk = a.nck - 1; blk >= 0; --blk) {
         const int tb = blk * S, nstep = min(S, a.T - tb);
         const int chunk = tb / kChunk, t0 = chunk * kChunk;
@@ -499,69 +586,13 @@ __device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, Fea
             wave_lds_fence();
             cur_chunk = chunk;
         }
-        // state at the start of the block, then recompute the block into registers
-        float h = blk ? ck[blk * 64 + lane] : 0.0f;
-        float hp_s[S], r_s[S], z_s[S], n_s[S], g_s[S], hid_s[S];
-#pragma unroll
-        for (int i = 0; i < S; ++i) {
-            if (i < nstep) {
-                const float2 xv = xs[s * kChunkPad + (tb - t0) + i];
-                float f[F];
-                feat_fwd<FM>(xv.x, xv.y, f);
-                hp_s[i] = h;
-                gru_cell_fwd<R, FM, DG>(w, f, h, r_s[i], z_s[i], n_s[i], g_s[i]);
-                hid_s[i] = 0.0f;
-                if constexpr (DG) {
-                    const float4* wq = wt.whid_q;
-                    hid_s[i] = rotdot_quads(w.bhid, [wq](int q) { return wq[q * 64]; }, h);
-                    if constexpr (R == 2)
-                        hid_s[i] = rotdot_quads(hid_s[i], [wq](int q) { return wq[(4 + q) * 64]; }, swap16(h));
-                }
-            }
-        }
-#pragma unroll
-        for (int i = S - 1; i >= 0; --i) {
-            if (i < nstep) {
-                const int tt = (tb - t0) + i;
-                const float2 xv = xs[s * kChunkPad + tt];
-                float2 dyv = dys[s * kChunkPad + tt];
-                float f[F], df[F];
-                feat_fwd<FM>(xv.x, xv.y, f);
-                if constexpr (FUSED) {
-                    // output head from the recomputed state, then loss and dL/dy (train_funcs.py:35-39)
-                    float p0, p1;
-                    if constexpr (DG) {
-                        const float act = __builtin_fmaxf(hid_s[i], 0.0f), fs = feat_select<6>(f, col, 0.0f);
-                        p0 = __builtin_fmaf(w.wout[0], act, w.woutf[0] * fs);
-                        p1 = __builtin_fmaf(w.wout[1], act, w.woutf[1] * fs);
-                    } else {
-                        const float ht = __builtin_fmaf(z_s[i], hp_s[i] - n_s[i], n_s[i]);
-                        p0 = w.wout[0] * ht;
-                        p1 = w.wout[1] * ht;
-                    }
-                    const float d0 = seq_sum<R>(p0) + w.bout[0] - dyv.x, d1 = seq_sum<R>(p1) + w.bout[1] - dyv.y;
-                    float l;
-                    if (a.loss_kind == ODPD_LOSS_L2) {
-                        const float sc = 2.0f * a.inv_count;
-                        dyv = make_float2(d0 * sc, d1 * sc);
-                        l = __builtin_fmaf(d0, d0, d1 * d1);
-                    } else {
-                        dyv = make_float2(d0 > 0.f ? a.inv_count : (d0 < 0.f ? -a.inv_count : 0.f),
-                                          d1 > 0.f ? a.inv_count : (d1 < 0.f ? -a.inv_count : 0.f));
-                        l = __builtin_fabsf(d0) + __builtin_fabsf(d1);
-                    }
-                    if (!valid) dyv = make_float2(0.f, 0.f);
-                    loss_acc += (valid && (lane & (LPS - 1)) == 0) ? l : 0.0f;
-                }
-                gru_step_bwd<R, FM, DG, NW, DX>(w, wt, G, f, hp_s[i], r_s[i], z_s[i], n_s[i], g_s[i], hid_s[i], dyv.x,
-                                                dyv.y, row, col, dh, df);
-                if constexpr (DX) {
-                    float dI, dQ;
-                    feat_bwd<FM>(xv.x, xv.y, df, dI, dQ);
-                    if ((lane & (LPS - 1)) == 0) dxs[s * kChunkPad + tt] = make_float2(dI, dQ);
-                }
-            }
-        }
+        const float h0 = blk ? ck[blk * 64 + lane] : 0.0f;
+        if (nstep == S)  // branch-free body: one basic block, the scheduler overlaps consecutive steps
+            gru_bwd_block<R, FM, DG, NW, DX, FUSED, true>(a, w, tlane, G, id, xs, dys, dxs, tb - t0, nstep, valid, h0, dh,
+                                                          loss_acc);
+        else
+            gru_bwd_block<R, FM, DG, NW, DX, FUSED, false>(a, w, tlane, G, id, xs, dys, dxs, tb - t0, nstep, valid, h0, dh,
+                                                           loss_acc);
     }
     if constexpr (DX) {
         if (cur_chunk >= 0) {
@@ -573,34 +604,32 @@ __device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, Fea
     }
 }
 
-// registers allow two waves per SIMD for one-row models unless both gradient kinds are requested
+// one-row models fit two waves per SIMD (8 per CU, one 512-thread workgroup)
 template <int R, int FM, bool DG, bool NW, bool DX>
-__global__ __launch_bounds__(kThreads, (R == 1 && !(NW && DX)) ? 2 : 1) void gru_bwd_kernel(SeqArgs a) {
-    constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R;
+__global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 : 1) void gru_bwd_kernel(SeqArgs a) {
+    constexpr int F = FeatDim<FM>::F, SPW = 4 / R;
+    using T = GruTabs<R, DG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 15, row = (lane >> 4) & (R - 1), s = lane / LPS;
+    const LaneId id = lane_id<R>();
     const GruLayout L = gru_layout(a.H, F, DG);
     float* pl = smem;
     stage_params(pl, a.params, L.P);
-    float* wl = smem + ((L.P + 3) & ~3);
-    float2* xs = reinterpret_cast<float2*>(wl + whidT_lds_floats(R, DG)) + wave * (3 * SPW * kChunkPad);
+    float* tab = smem + pad4(L.P);
+    fill_gru_tabs<R, DG, true>(tab, pl, L, id.lane, id.wave, id.nwb);
+    const float4* tlane = reinterpret_cast<const float4*>(tab) + id.lane;
+    float2* xs = reinterpret_cast<float2*>(tab + T::kFloats) + id.wave * (3 * SPW * kChunkPad);
     float2* dys = xs + SPW * kChunkPad;
     float2* dxs = dys + SPW * kChunkPad;
-    int src[16];
-    rot_sources(src, col);
     GruW<R, F, DG> w;
-    GruWT<R, F, DG> wt;
-    load_gru_w<R, F, DG>(w, pl, L, row, col, src);
-    load_gru_wT<R, F, DG>(wt, pl, L, row, col, src, wl);
+    load_gru_w<R, F, DG>(w, pl, L, id.row, id.col);
     GruGrad<R, DG> G;
     G.zero();
     float unused = 0.0f;
-    const int nwaves = gridDim.x * kWavesPerBlock, wave_global = blockIdx.x * kWavesPerBlock + wave;
-    for (int grp = wave_global; grp < a.ngroups; grp += nwaves)
-        gru_bwd_task<R, FM, DG, NW, DX, false>(a, w, wt, G, grp * SPW, lane, row, col, s, xs, dys, dxs,
+    const int nwaves = gridDim.x * id.nwb;
+    for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves)
+        gru_bwd_task<R, FM, DG, NW, DX, false>(a, w, tlane, G, grp * SPW, id, xs, dys, dxs,
                                                a.ckpt + (size_t)grp * a.nck * 64, unused);
-    if constexpr (NW) gru_block_partials<R, F, DG>(smem, a.partials, L, G, lane, wave, row, col, 0.0f);
+    if constexpr (NW) gru_block_partials<R, F, DG>(smem, a.partials, L, G, id.lane, id.wave, id.nwb, id.row, id.col, 0.0f);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -610,63 +639,76 @@ __global__ __launch_bounds__(kThreads, (R == 1 && !(NW && DX)) ? 2 : 1) void gru
 // LDS per wave: x chunk, target chunk, checkpoints (nck x 64 floats).
 // -------------------------------------------------------------------------------------------------
 __host__ __device__ inline int train_wave_floats(int T, int R) {
-    const int SPW = 4 / R;
-    return 2 * (2 * SPW * kChunkPad) + num_ckpt_hd(T) * 64;
+    return 2 * (2 * (4 / R) * kChunkPad) + num_ckpt_hd(T) * 64;
 }
 
 template <int R, int FM, bool DG>
-__global__ __launch_bounds__(kThreads, R == 1 ? 2 : 1) void gru_train_kernel(SeqArgs a) {
-    constexpr int F = FeatDim<FM>::F, SPW = 4 / R, LPS = 16 * R, S = kCkptStride;
+__global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 : 1) void gru_train_kernel(SeqArgs a) {
+    constexpr int F = FeatDim<FM>::F, SPW = 4 / R, S = kCkptStride;
+    using T = GruTabs<R, DG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 15, row = (lane >> 4) & (R - 1), s = lane / LPS;
+    const LaneId id = lane_id<R>();
+    const int lane = id.lane, s = id.s;
     const GruLayout L = gru_layout(a.H, F, DG);
     float* pl = smem;
     stage_params(pl, a.params, L.P);
-    float* wl = smem + ((L.P + 3) & ~3);
-    float* wbase = wl + whidT_lds_floats(R, DG) + (size_t)wave * train_wave_floats(a.T, R);
+    float* tab = smem + pad4(L.P);
+    fill_gru_tabs<R, DG, true>(tab, pl, L, lane, id.wave, id.nwb);
+    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    float* wbase = tab + T::kFloats + (size_t)id.wave * train_wave_floats(a.T, R);
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ts = xs + SPW * kChunkPad;
     float* ck = reinterpret_cast<float*>(ts + SPW * kChunkPad);
-    int src[16];
-    rot_sources(src, col);
     GruW<R, F, DG> w;
-    GruWT<R, F, DG> wt;
-    load_gru_w<R, F, DG>(w, pl, L, row, col, src);
-    load_gru_wT<R, F, DG>(wt, pl, L, row, col, src, wl);
+    load_gru_w<R, F, DG>(w, pl, L, id.row, id.col);
     GruGrad<R, DG> G;
     G.zero();
     float loss_acc = 0.0f;
-    const int nwaves = gridDim.x * kWavesPerBlock, wave_global = blockIdx.x * kWavesPerBlock + wave;
-    for (int grp = wave_global; grp < a.ngroups; grp += nwaves) {
+    const int nwaves = gridDim.x * id.nwb;
+    for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * SPW;
-        float h = 0.0f;
-        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
-            const int len = min(kChunk, a.T - t0);
-            wave_lds_fence();
-            stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
-            wave_lds_fence();
-            for (int tt = 0; tt < len; ++tt) {
-                const float2 xv = xs[s * kChunkPad + tt];
-                float f[F], r, z, n, ghn;
-                feat_fwd<FM>(xv.x, xv.y, f);
-                gru_cell_fwd<R, FM, DG>(w, f, h, r, z, n, ghn);
-                const int t1 = t0 + tt + 1;
-                if ((t1 % S) == 0 && t1 < a.T) ck[(t1 / S) * 64 + lane] = h;
+        {
+            float whh[3][R][16];
+            load_rot3<R>(whh, opaque(tlane), T::kHH);
+            float h = 0.0f;
+            for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+                const int len = min(kChunk, a.T - t0);
+                wave_lds_fence();
+                stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+                wave_lds_fence();
+                int tt = 0;
+                static_assert(kChunk % S == 0, "chunks start on a checkpoint boundary");
+                for (; tt + S <= len; tt += S) {   // S steps per iteration, one checkpoint at the end
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const float2 xv = xs[s * kChunkPad + tt + i];
+                        float f[F], r, z, n, ghn;
+                        feat_fwd<FM>(xv.x, xv.y, f);
+                        gru_cell_fwd<R, FM, DG>(w, whh, f, h, r, z, n, ghn);
+                    }
+                    const int t1 = t0 + tt + S;
+                    if (t1 < a.T) ck[(t1 / S) * 64 + lane] = h;
+                }
+                for (; tt < len; ++tt) {            // tail of the last chunk (never ends on a checkpoint < T)
+                    const float2 xv = xs[s * kChunkPad + tt];
+                    float f[F], r, z, n, ghn;
+                    feat_fwd<FM>(xv.x, xv.y, f);
+                    gru_cell_fwd<R, FM, DG>(w, whh, f, h, r, z, n, ghn);
+                }
             }
         }
         wave_lds_fence();
-        gru_bwd_task<R, FM, DG, true, false, true>(a, w, wt, G, b0, lane, row, col, s, xs, ts, nullptr, ck, loss_acc);
+        gru_bwd_task<R, FM, DG, true, false, true>(a, w, tlane, G, b0, id, xs, ts, nullptr, ck, loss_acc);
     }
-    gru_block_partials<R, F, DG>(smem, a.partials, L, G, lane, wave, row, col, loss_acc);
+    gru_block_partials<R, F, DG>(smem, a.partials, L, G, lane, id.wave, id.nwb, id.row, id.col, loss_acc);
 }
 
 // -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
-constexpr int kFwdBlocksPerCU = 4;  // grid caps (blocks are independent: a non-resident block simply queues)
-constexpr int kBwdBlocksPerCU = 2;
-constexpr int kTrainBlocksPerCU = 2;
+constexpr int kFwdWavesPerCU = 16;  // 4 waves per SIMD (forward kernels use <= 128 VGPRs for R = 1)
+static int bwd_waves_per_cu(int R) { return R == 1 ? 8 : 4; }
+constexpr size_t kMaxLds = 160 * 1024;
 
 static bool gru_cfg(const odpd_model_t* m, int& FM, bool& DG) {
     switch (m->backbone) {
@@ -677,65 +719,81 @@ static bool gru_cfg(const odpd_model_t* m, int& FM, bool& DG) {
     default: return false;
     }
 }
-static size_t reduce_scratch_bytes(int P) { return (size_t)kWavesPerBlock * (P + kLossCols) * sizeof(float); }
-static size_t gru_lds_bytes(int P, int R, int nbuf, bool dg_bwd = false) {
-    size_t n = ((size_t)((P + 3) & ~3) + whidT_lds_floats(R, dg_bwd)) * 4 +
-               (size_t)kWavesPerBlock * nbuf * (4 / R) * kChunkPad * sizeof(float2);
-    return (dg_bwd || nbuf == 3) && n < reduce_scratch_bytes(P) ? reduce_scratch_bytes(P) : n;
+static int gru_tab_floats(int R, bool DG) { return (DG ? 8 * R : 6 * R) * 4 * 64 * 4; }
+static size_t reduce_scratch_bytes(int P, int waves) { return (size_t)waves * (P + kLossCols) * sizeof(float); }
+// dynamic LDS of a block: params + tables + per-wave region; never smaller than the reduce scratch
+static size_t gru_lds_bytes(int P, int R, bool DG, int waves, size_t wave_floats, bool reduce) {
+    size_t n = ((size_t)pad4(P) + gru_tab_floats(R, DG) + (size_t)waves * wave_floats) * sizeof(float);
+    if (reduce && n < reduce_scratch_bytes(P, waves)) n = reduce_scratch_bytes(P, waves);
+    return n;
+}
+template <typename K>
+static int allow_big_lds(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kMaxLds);
+}
+
+// launch shape of the backward / fused kernels (also fixes the number of partial rows = grid)
+static LaunchShape bwd_shape(int R, int ngroups) { return persistent_shape(ngroups, bwd_waves_per_cu(R), R == 1 ? 8 : 4); }
+// the fused kernel additionally has to fit its LDS-resident checkpoints: shrink the block if needed
+static LaunchShape train_shape(int P, int R, bool DG, int ngroups, int T, size_t* lds_out) {
+    LaunchShape ls = bwd_shape(R, ngroups);
+    for (;;) {
+        size_t lds = gru_lds_bytes(P, R, DG, ls.waves, train_wave_floats(T, R), true);
+        if (lds <= kMaxLds || ls.waves == 1) {
+            if (lds_out) *lds_out = lds;
+            if (lds > kMaxLds) ls.grid = 0;   // does not fit at all
+            else {
+                int need = (ngroups + ls.waves - 1) / ls.waves, cap = device_cus() * (int)(kMaxLds / lds);
+                ls.grid = need < cap ? need : cap;
+            }
+            return ls;
+        }
+        ls.waves /= 2;
+    }
 }
 
 template <int R, int FM, bool DG>
 static int launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
-    const size_t lds = gru_lds_bytes(P, R, 2);
-    hipLaunchKernelGGL((gru_fwd_kernel<R, FM, DG>), dim3(persistent_grid(a.ngroups, kFwdBlocksPerCU)), dim3(kThreads),
-                       lds, st, a);
+    const LaunchShape ls = persistent_shape(a.ngroups, kFwdWavesPerCU);
+    const size_t lds = gru_lds_bytes(P, R, DG, ls.waves, 2 * 2 * (4 / R) * kChunkPad, false);
+    auto k = gru_fwd_kernel<R, FM, DG>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
 }
 template <int R, int FM, bool DG, bool NW, bool DX>
 static int launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
-    const size_t lds = gru_lds_bytes(P, R, 3, DG);
-    hipLaunchKernelGGL((gru_bwd_kernel<R, FM, DG, NW, DX>), dim3(persistent_grid(a.ngroups, kBwdBlocksPerCU)),
-                       dim3(kThreads), lds, st, a);
+    const LaunchShape ls = bwd_shape(R, a.ngroups);
+    const size_t lds = gru_lds_bytes(P, R, DG, ls.waves, 3 * 2 * (4 / R) * kChunkPad, NW);
+    auto k = gru_bwd_kernel<R, FM, DG, NW, DX>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
 }
-
 template <int R, int FM, bool DG>
 static int launch_train(hipStream_t st, const SeqArgs& a, int P) {
-    size_t lds = ((size_t)((P + 3) & ~3) + whidT_lds_floats(R, DG) +
-                  (size_t)kWavesPerBlock * train_wave_floats(a.T, R)) * sizeof(float);
-    if (lds < reduce_scratch_bytes(P)) lds = reduce_scratch_bytes(P);
-    if (lds > 160 * 1024) return ODPD_EUNSUPPORTED;  // frame too long for LDS-resident BPTT state
+    size_t lds = 0;
+    const LaunchShape ls = train_shape(P, R, DG, a.ngroups, a.T, &lds);
+    if (ls.grid <= 0) return ODPD_EUNSUPPORTED;  // frame too long for LDS-resident BPTT state
     auto k = gru_train_kernel<R, FM, DG>;
-    static size_t max_set = 0;
-    if (lds > max_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(160 * 1024));
-        if (e != hipSuccess) return (int)e;
-        max_set = 160 * 1024;
-    }
-    hipLaunchKernelGGL(k, dim3(persistent_grid(a.ngroups, kTrainBlocksPerCU)), dim3(kThreads), lds, st, a);
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
 }
 
-#define ODPD_GRU_DISPATCH(R_, FM_, DG_, CALL)                                                    \
+#define ODPD_GRU_DISPATCH(R_, FM_, DG_, CALL) \
     if (R == R_ && FM == FM_ && DG == DG_) return CALL;
-
-int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
-    int FM; bool DG;
-    if (!gru_cfg(m, FM, DG)) return ODPD_EUNSUPPORTED;
-    const int R = rows_per_seq(m->hidden);
-    if (!R) return ODPD_EUNSUPPORTED;
-    const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
-    ODPD_GRU_DISPATCH(1, FEAT_RAW2, false, (launch_fwd<1, FEAT_RAW2, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_RAW2, false, (launch_fwd<2, FEAT_RAW2, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(1, FEAT_DGRU6, true, (launch_fwd<1, FEAT_DGRU6, true>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_DGRU6, true, (launch_fwd<2, FEAT_DGRU6, true>(st, a, P)))
-    ODPD_GRU_DISPATCH(1, FEAT_Q4, false, (launch_fwd<1, FEAT_Q4, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_Q4, false, (launch_fwd<2, FEAT_Q4, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(1, FEAT_A4, false, (launch_fwd<1, FEAT_A4, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_A4, false, (launch_fwd<2, FEAT_A4, false>(st, a, P)))
-    return ODPD_EUNSUPPORTED;
-}
+#define ODPD_GRU_DISPATCH_ALL(FN, ...)                                              \
+    ODPD_GRU_DISPATCH(1, FEAT_RAW2, false, (FN<1, FEAT_RAW2, false>(__VA_ARGS__)))  \
+    ODPD_GRU_DISPATCH(2, FEAT_RAW2, false, (FN<2, FEAT_RAW2, false>(__VA_ARGS__)))  \
+    ODPD_GRU_DISPATCH(1, FEAT_DGRU6, true, (FN<1, FEAT_DGRU6, true>(__VA_ARGS__)))  \
+    ODPD_GRU_DISPATCH(2, FEAT_DGRU6, true, (FN<2, FEAT_DGRU6, true>(__VA_ARGS__)))  \
+    ODPD_GRU_DISPATCH(1, FEAT_Q4, false, (FN<1, FEAT_Q4, false>(__VA_ARGS__)))      \
+    ODPD_GRU_DISPATCH(2, FEAT_Q4, false, (FN<2, FEAT_Q4, false>(__VA_ARGS__)))      \
+    ODPD_GRU_DISPATCH(1, FEAT_A4, false, (FN<1, FEAT_A4, false>(__VA_ARGS__)))      \
+    ODPD_GRU_DISPATCH(2, FEAT_A4, false, (FN<2, FEAT_A4, false>(__VA_ARGS__)))
 
 template <int R, int FM, bool DG>
 static int launch_bwd_mode(hipStream_t st, const SeqArgs& a, int P) {
@@ -745,46 +803,41 @@ static int launch_bwd_mode(hipStream_t st, const SeqArgs& a, int P) {
     if (nw && dx) return launch_bwd<R, FM, DG, true, true>(st, a, P);
     return ODPD_EINVAL;
 }
+
+static bool gru_setup(const odpd_model_t* m, int& FM, bool& DG, int& R, int& P) {
+    if (!gru_cfg(m, FM, DG)) return false;
+    R = rows_per_seq(m->hidden);
+    if (!R) return false;
+    P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
+    return true;
+}
+
+int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    ODPD_GRU_DISPATCH_ALL(launch_fwd, st, a, P)
+    return ODPD_EUNSUPPORTED;
+}
 int gru_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
-    int FM; bool DG;
-    if (!gru_cfg(m, FM, DG)) return ODPD_EUNSUPPORTED;
-    const int R = rows_per_seq(m->hidden);
-    if (!R) return ODPD_EUNSUPPORTED;
-    const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
-    ODPD_GRU_DISPATCH(1, FEAT_RAW2, false, (launch_bwd_mode<1, FEAT_RAW2, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_RAW2, false, (launch_bwd_mode<2, FEAT_RAW2, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(1, FEAT_DGRU6, true, (launch_bwd_mode<1, FEAT_DGRU6, true>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_DGRU6, true, (launch_bwd_mode<2, FEAT_DGRU6, true>(st, a, P)))
-    ODPD_GRU_DISPATCH(1, FEAT_Q4, false, (launch_bwd_mode<1, FEAT_Q4, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_Q4, false, (launch_bwd_mode<2, FEAT_Q4, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(1, FEAT_A4, false, (launch_bwd_mode<1, FEAT_A4, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_A4, false, (launch_bwd_mode<2, FEAT_A4, false>(st, a, P)))
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    ODPD_GRU_DISPATCH_ALL(launch_bwd_mode, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
-
-int gru_family_rows(const odpd_model_t* m, int B, int which) {
-    int FM; bool DG;
-    if (!gru_cfg(m, FM, DG)) return ODPD_EUNSUPPORTED;
-    const int R = rows_per_seq(m->hidden);
-    if (!R) return ODPD_EUNSUPPORTED;
-    return persistent_grid(num_groups(B, R), which ? kTrainBlocksPerCU : kBwdBlocksPerCU);  // one row per block
-}
-
 int gru_family_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
-    int FM; bool DG;
-    if (!gru_cfg(m, FM, DG)) return ODPD_EUNSUPPORTED;
-    const int R = rows_per_seq(m->hidden);
-    if (!R) return ODPD_EUNSUPPORTED;
-    const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
-    ODPD_GRU_DISPATCH(1, FEAT_RAW2, false, (launch_train<1, FEAT_RAW2, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_RAW2, false, (launch_train<2, FEAT_RAW2, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(1, FEAT_DGRU6, true, (launch_train<1, FEAT_DGRU6, true>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_DGRU6, true, (launch_train<2, FEAT_DGRU6, true>(st, a, P)))
-    ODPD_GRU_DISPATCH(1, FEAT_Q4, false, (launch_train<1, FEAT_Q4, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_Q4, false, (launch_train<2, FEAT_Q4, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(1, FEAT_A4, false, (launch_train<1, FEAT_A4, false>(st, a, P)))
-    ODPD_GRU_DISPATCH(2, FEAT_A4, false, (launch_train<2, FEAT_A4, false>(st, a, P)))
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    ODPD_GRU_DISPATCH_ALL(launch_train, st, a, P)
     return ODPD_EUNSUPPORTED;
+}
+// rows of partials written by the backward (which = 0) or fused (which = 1, needs T) kernels
+int gru_family_rows(const odpd_model_t* m, int B, int which, int T) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    const int ng = num_groups(B, R);
+    if (!which) return bwd_shape(R, ng).grid;
+    const LaunchShape ls = train_shape(P, R, DG, ng, T, nullptr);
+    return ls.grid > 0 ? ls.grid : ODPD_EUNSUPPORTED;
 }
 
 }  // namespace odpd

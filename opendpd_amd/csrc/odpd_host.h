@@ -34,13 +34,22 @@ inline int device_cus() {
     return cus;
 }
 
-// Persistent grid: enough workgroups for `ngroups` wave-tasks, capped at `blocks_per_cu` resident
-// workgroups per CU (each wave then loops over its share of the tasks).
-inline int persistent_grid(int ngroups, int blocks_per_cu) {
-    int need = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;
-    int cap = device_cus() * (blocks_per_cu > 0 ? blocks_per_cu : 1);
-    int g = need < cap ? need : cap;
-    return g > 0 ? g : 1;
+// Launch shape of a persistent sequence kernel: `ngroups` wave-tasks are spread over workgroups of
+// `waves` wavefronts (1,2,4 or 8: as few as keeps every CU busy, so small batches use many CUs with
+// one wave each, large batches share the per-block LDS weight tables between 8 waves); the grid is
+// capped at `waves_per_cu` resident waves per CU and each wave loops over its share of the tasks.
+struct LaunchShape { int grid, waves; };
+inline LaunchShape persistent_shape(int ngroups, int waves_per_cu, int max_waves_per_block = kMaxWavesPerBlock) {
+    const int cus = device_cus();
+    int waves = 1;
+    while (waves < max_waves_per_block && waves < waves_per_cu && ngroups > waves * cus) waves *= 2;
+    int need = (ngroups + waves - 1) / waves;
+    int cap = cus * (waves_per_cu / waves > 0 ? waves_per_cu / waves : 1);
+    LaunchShape ls;
+    ls.waves = waves;
+    ls.grid = need < cap ? need : cap;
+    if (ls.grid < 1) ls.grid = 1;
+    return ls;
 }
 
 // ---- parameter layouts (flattened named_parameters() order of the reference modules) -------------
@@ -85,6 +94,6 @@ struct SeqArgs {
 int gru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
-int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/);
+int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, int T);
 
 }  // namespace odpd

@@ -59,15 +59,15 @@ class FusedAdamW:
         self._partials = {}
         self._state_dev = device
 
-    def partials(self, B, device):
+    def partials(self, B, T, device):
         self._ensure(device)
-        if B not in self._partials:
+        if (B, T) not in self._partials:
             lib = _lib.load()
-            rows = int(lib.odpd_partial_rows(C.byref(self.backbone.desc), B, 1))
+            rows = int(lib.odpd_partial_rows(C.byref(self.backbone.desc), B, T, 1))
             _lib.check(0 if rows > 0 else rows, "odpd_partial_rows")
-            self._partials[B] = torch.empty(rows, self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32,
-                                            device=device)
-        return self._partials[B]
+            self._partials[(B, T)] = torch.empty(rows, self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32,
+                                                 device=device)
+        return self._partials[(B, T)]
 
     def zero_grad(self, set_to_none=True):
         for p in self.net.parameters():
@@ -116,7 +116,7 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     B, T = x.shape[0], x.shape[1]
     n = B * T * 2
     count = int(global_count or n)
-    part = opt.partials(B, x.device)
+    part = opt.partials(B, T, x.device)
     flat = bb.flat_params()
     if timing is not None:
         timing[0].record()
