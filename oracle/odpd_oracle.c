@@ -264,49 +264,620 @@ static void gru_seq_bwd(const odpd_model_t* m, const gru_params_t* g, int T, con
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* LSTM family: lstm.py:45-48 (h0 = c0 = 0), vdlstm.py:56-81.  nn.LSTM gate order i,f,g,o.     */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int H, F, vd;
+    int64_t o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_w_l1, o_b_l1, o_w_l2, o_b_l2;
+} lstm_layout_t;
+static void lstm_layout(const odpd_model_t* m, lstm_layout_t* g) {
+    int64_t H = m->hidden, o = 0;
+    g->H = (int)H; g->vd = (m->backbone == ODPD_VDLSTM); g->F = g->vd ? 4 : 2;
+    g->o_w_ih = o; o += 4 * H * g->F;
+    g->o_w_hh = o; o += 4 * H * H;
+    g->o_b_ih = o; o += 4 * H;
+    g->o_b_hh = o; o += 4 * H;
+    if (g->vd) {   /* fc_lambda_1, fc_lambda_2, fc_out (vdlstm.py:35-43) */
+        g->o_w_l1 = o; o += 4 * H; g->o_b_l1 = o; o += 4;
+        g->o_w_l2 = o; o += 4 * H; g->o_b_l2 = o; o += 4;
+        g->o_w_out = o; o += 2 * 8; g->o_b_out = o; o += 2;
+    } else {
+        g->o_w_l1 = g->o_b_l1 = g->o_w_l2 = g->o_b_l2 = 0;
+        g->o_w_out = o; o += 2 * H; g->o_b_out = o; o += 2;
+    }
+}
+typedef struct { real xin[4], cw[4], sw[4], hp[MAXH], cp[MAXH], i[MAXH], f[MAXH], g[MAXH], o[MAXH], tc[MAXH], h[MAXH], l1[4], l2[4]; } lstm_step_t;
+
+/* vdlstm.py:60-76: windows over the frame with CIRCULAR left padding: element k of window t is
+ * sample (t - 3 + k) mod T */
+static inline int vd_idx(int t, int k, int T) { int j = t - 3 + k; return ((j % T) + T) % T; }
+
+static void lstm_seq_fwd(const lstm_layout_t* L, const real* p, int T, const real* x, real* y, lstm_step_t* S) {
+    int H = L->H, F = L->F;
+    real h[MAXH] = {0}, c[MAXH] = {0};
+    lstm_step_t tmp;
+    for (int t = 0; t < T; ++t) {
+        lstm_step_t* s = S ? &S[t] : &tmp;
+        if (L->vd) {
+            for (int k = 0; k < 4; ++k) {
+                int j = vd_idx(t, k, T);
+                real I = x[2 * j], Q = x[2 * j + 1], a = (real)sqrt((double)(I * I + Q * Q));
+                s->xin[k] = a; s->cw[k] = I / a; s->sw[k] = Q / a;
+            }
+        } else { s->xin[0] = x[2 * t]; s->xin[1] = x[2 * t + 1]; }
+        for (int j = 0; j < H; ++j) { s->hp[j] = h[j]; s->cp[j] = c[j]; }
+        for (int j = 0; j < H; ++j) {
+            real pre[4];
+            for (int k = 0; k < 4; ++k) {
+                real a = p[L->o_b_ih + k * H + j], b = p[L->o_b_hh + k * H + j];
+                for (int i = 0; i < F; ++i) a += p[L->o_w_ih + (k * H + j) * F + i] * s->xin[i];
+                for (int i = 0; i < H; ++i) b += p[L->o_w_hh + (k * H + j) * H + i] * s->hp[i];
+                pre[k] = a + b;
+            }
+            s->i[j] = sigm(pre[0]); s->f[j] = sigm(pre[1]); s->g[j] = tanhr(pre[2]); s->o[j] = sigm(pre[3]);
+            c[j] = s->f[j] * s->cp[j] + s->i[j] * s->g[j];
+            s->tc[j] = tanhr(c[j]);
+            h[j] = s->o[j] * s->tc[j];
+            s->h[j] = h[j];
+        }
+        if (L->vd) {   /* vdlstm.py:78-80 */
+            real z[8];
+            for (int k = 0; k < 4; ++k) {
+                real a = p[L->o_b_l1 + k], b = p[L->o_b_l2 + k];
+                for (int j = 0; j < H; ++j) { a += p[L->o_w_l1 + k * H + j] * h[j]; b += p[L->o_w_l2 + k * H + j] * h[j]; }
+                s->l1[k] = a; s->l2[k] = b;
+                z[k] = a * s->cw[k]; z[4 + k] = b * s->sw[k];
+            }
+            for (int cc = 0; cc < 2; ++cc) {
+                real a = p[L->o_b_out + cc];
+                for (int k = 0; k < 8; ++k) a += p[L->o_w_out + cc * 8 + k] * z[k];
+                y[2 * t + cc] = a;
+            }
+        } else {
+            for (int cc = 0; cc < 2; ++cc) {
+                real a = p[L->o_b_out + cc];
+                for (int j = 0; j < H; ++j) a += p[L->o_w_out + cc * H + j] * h[j];
+                y[2 * t + cc] = a;
+            }
+        }
+    }
+}
+static void lstm_seq_bwd(const lstm_layout_t* L, const real* p, int T, const real* x, const real* dy, const lstm_step_t* S,
+                         real* dp, real* dx) {
+    int H = L->H, F = L->F;
+    real dh[MAXH] = {0}, dc[MAXH] = {0};
+    if (dx) memset(dx, 0, sizeof(real) * 2 * T);
+    for (int t = T - 1; t >= 0; --t) {
+        const lstm_step_t* s = &S[t];
+        real dht[MAXH], dxin[4] = {0}, dcw[4] = {0}, dsw[4] = {0};
+        for (int j = 0; j < H; ++j) dht[j] = dh[j];
+        if (L->vd) {
+            real dz[8] = {0};
+            for (int cc = 0; cc < 2; ++cc) {
+                real d = dy[2 * t + cc];
+                dp[L->o_b_out + cc] += d;
+                for (int k = 0; k < 8; ++k) {
+                    real zk = k < 4 ? s->l1[k] * s->cw[k] : s->l2[k - 4] * s->sw[k - 4];
+                    dp[L->o_w_out + cc * 8 + k] += d * zk;
+                    dz[k] += d * p[L->o_w_out + cc * 8 + k];
+                }
+            }
+            for (int k = 0; k < 4; ++k) {
+                real d1 = dz[k] * s->cw[k], d2 = dz[4 + k] * s->sw[k];
+                dcw[k] = dz[k] * s->l1[k]; dsw[k] = dz[4 + k] * s->l2[k];
+                dp[L->o_b_l1 + k] += d1; dp[L->o_b_l2 + k] += d2;
+                for (int j = 0; j < H; ++j) {
+                    dp[L->o_w_l1 + k * H + j] += d1 * s->h[j]; dp[L->o_w_l2 + k * H + j] += d2 * s->h[j];
+                    dht[j] += d1 * p[L->o_w_l1 + k * H + j] + d2 * p[L->o_w_l2 + k * H + j];
+                }
+            }
+        } else {
+            for (int cc = 0; cc < 2; ++cc) {
+                real d = dy[2 * t + cc];
+                dp[L->o_b_out + cc] += d;
+                for (int j = 0; j < H; ++j) { dp[L->o_w_out + cc * H + j] += d * s->h[j]; dht[j] += d * p[L->o_w_out + cc * H + j]; }
+            }
+        }
+        real dhp[MAXH] = {0}, dcp[MAXH];
+        for (int j = 0; j < H; ++j) {
+            real dO = dht[j] * s->tc[j];
+            real dct = dc[j] + dht[j] * s->o[j] * ((real)1 - s->tc[j] * s->tc[j]);
+            real dI = dct * s->g[j], dF = dct * s->cp[j], dG = dct * s->i[j];
+            dcp[j] = dct * s->f[j];
+            real dpre[4] = {dI * s->i[j] * ((real)1 - s->i[j]), dF * s->f[j] * ((real)1 - s->f[j]),
+                            dG * ((real)1 - s->g[j] * s->g[j]), dO * s->o[j] * ((real)1 - s->o[j])};
+            for (int k = 0; k < 4; ++k) {
+                dp[L->o_b_ih + k * H + j] += dpre[k]; dp[L->o_b_hh + k * H + j] += dpre[k];
+                for (int i = 0; i < F; ++i) { dp[L->o_w_ih + (k * H + j) * F + i] += dpre[k] * s->xin[i]; dxin[i] += dpre[k] * p[L->o_w_ih + (k * H + j) * F + i]; }
+                for (int i = 0; i < H; ++i) { dp[L->o_w_hh + (k * H + j) * H + i] += dpre[k] * s->hp[i]; dhp[i] += dpre[k] * p[L->o_w_hh + (k * H + j) * H + i]; }
+            }
+        }
+        for (int j = 0; j < H; ++j) { dh[j] = dhp[j]; dc[j] = dcp[j]; }
+        if (dx) {
+            if (L->vd) {
+                for (int k = 0; k < 4; ++k) {
+                    int j = vd_idx(t, k, T);
+                    real I = x[2 * j], Q = x[2 * j + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+                    real da = dxin[k] - dcw[k] * I / a2 - dsw[k] * Q / a2;
+                    dx[2 * j] += dcw[k] / a + da * I / a;
+                    dx[2 * j + 1] += dsw[k] / a + da * Q / a;
+                }
+            } else { dx[2 * t] += dxin[0]; dx[2 * t + 1] += dxin[1]; }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Delta-GRU family: deltagru.py:59-77,211-264 and deltagru_tcnskip.py:87-103,248-293           */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int H, tres;
+    int64_t o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_tcn0, o_tcn2;
+} delta_layout_t;
+static void delta_layout(const odpd_model_t* m, delta_layout_t* g) {
+    int64_t H = m->hidden, o = 0;
+    g->H = (int)H; g->tres = (m->backbone == ODPD_TRES_DELTAGRU);
+    g->o_w_ih = o; o += 3 * H * 6;
+    g->o_w_hh = o; o += 3 * H * H;
+    g->o_b_ih = g->o_b_hh = g->o_b_out = g->o_tcn0 = g->o_tcn2 = -1;
+    if (!g->tres) { g->o_b_ih = o; o += 3 * H; g->o_b_hh = o; o += 3 * H; }
+    g->o_w_out = o; o += 2 * H;
+    if (!g->tres) { g->o_b_out = o; o += 2; }
+    else { g->o_tcn0 = o; o += 18; g->o_tcn2 = o; o += 6; }
+}
+static inline real hswish(real v) { real r = v + (real)3; r = r < 0 ? 0 : (r > (real)6 ? (real)6 : r); return v * r / (real)6; }
+static inline real hswish_grad(real v) { return v < (real)-3 ? (real)0 : (v <= (real)3 ? v / (real)3 + (real)0.5 : (real)1); }
+
+typedef struct {
+    real f[6], dxm[6], mx[6], hprev[MAXH], dhm[MAXH], mh[MAXH], r[MAXH], z[MAXH], n[MAXH], dmnh[MAXH], h[MAXH];
+    real s1[3], s2[2];  /* TCN pre-activations (tres) */
+} delta_step_t;
+
+static void delta_feat(const delta_layout_t* L, const real* x, int t, int T, real* f) {
+    real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+    f[0] = I; f[1] = Q; f[2] = a; f[3] = a * a * a;
+    if (L->tres) { int tn = (t + 1) % T; f[4] = x[2 * tn]; f[5] = x[2 * tn + 1]; }   /* torch.roll(x, -1) */
+    else { f[4] = Q / a; f[5] = I / a; }
+}
+
+static void delta_seq_fwd(const odpd_model_t* m, const delta_layout_t* L, const real* p, int T, const real* x, real* y,
+                          delta_step_t* S, double* stats) {
+    int H = L->H;
+    const real thx = (real)(float)m->thx, thh = (real)(float)m->thh;
+    real xp[6] = {0}, h[MAXH] = {0}, hp[MAXH] = {0}, dm[3 * MAXH], dmnh[MAXH];
+    for (int j = 0; j < H; ++j) {
+        if (L->tres) { dm[j] = dm[H + j] = dm[2 * H + j] = 0; dmnh[j] = 0; }
+        else {   /* deltagru.py:165-170 */
+            dm[j] = p[L->o_b_ih + j] + p[L->o_b_hh + j];
+            dm[H + j] = p[L->o_b_ih + H + j] + p[L->o_b_hh + H + j];
+            dm[2 * H + j] = p[L->o_b_ih + 2 * H + j];
+            dmnh[j] = p[L->o_b_hh + 2 * H + j];
+        }
+    }
+    delta_step_t tmp;
+    double zx = 0, zh = 0;
+    for (int t = 0; t < T; ++t) {
+        delta_step_t* s = S ? &S[t] : &tmp;
+        delta_feat(L, x, t, T, s->f);
+        for (int i = 0; i < 6; ++i) {
+            real d = s->f[i] - xp[i], ad = (real)fabs((double)d);
+            s->mx[i] = (ad < thx) ? (real)0 : (real)1;
+            s->dxm[i] = s->mx[i] != 0 ? d : (real)0;
+            if (s->dxm[i] == 0) zx += 1;
+            if (ad >= thx) xp[i] = s->f[i];
+        }
+        for (int j = 0; j < H; ++j) {
+            real d = h[j] - hp[j], ad = (real)fabs((double)d);
+            s->hprev[j] = h[j];
+            s->mh[j] = (ad < thh) ? (real)0 : (real)1;
+            s->dhm[j] = s->mh[j] != 0 ? d : (real)0;
+            if (s->dhm[j] == 0) zh += 1;
+            if (ad >= thh) hp[j] = h[j];
+        }
+        for (int j = 0; j < H; ++j) {
+            real mx[3], mh[3];
+            for (int k = 0; k < 3; ++k) {
+                real a = 0, b = 0;
+                for (int i = 0; i < 6; ++i) a += p[L->o_w_ih + (k * H + j) * 6 + i] * s->dxm[i];
+                for (int i = 0; i < H; ++i) b += p[L->o_w_hh + (k * H + j) * H + i] * s->dhm[i];
+                mx[k] = a + dm[k * H + j]; mh[k] = b;
+            }
+            dm[j] = mx[0] + mh[0]; dm[H + j] = mx[1] + mh[1]; dm[2 * H + j] = mx[2];
+            dmnh[j] = mh[2] + dmnh[j];
+            s->r[j] = sigm(dm[j]); s->z[j] = sigm(dm[H + j]); s->dmnh[j] = dmnh[j];
+            s->n[j] = tanhr(dm[2 * H + j] + s->r[j] * dmnh[j]);
+        }
+        for (int j = 0; j < H; ++j) { h[j] = ((real)1 - s->z[j]) * s->n[j] + s->z[j] * h[j]; s->h[j] = h[j]; }
+        for (int c = 0; c < 2; ++c) {
+            real a = L->tres ? (real)0 : p[L->o_b_out + c];
+            for (int j = 0; j < H; ++j) a += p[L->o_w_out + c * H + j] * h[j];
+            y[2 * t + c] = a;
+        }
+        if (L->tres) {   /* deltagru_tcnskip.py:32-49,88,102: conv(2->3,k3,dil16,pad16) HS conv(3->2,k1) HS */
+            for (int c = 0; c < 3; ++c) {
+                real a = 0;
+                for (int i = 0; i < 2; ++i)
+                    for (int k = 0; k < 3; ++k) {
+                        int tt = t + 16 * (k - 1);
+                        if (tt >= 0 && tt < T) a += p[L->o_tcn0 + (c * 2 + i) * 3 + k] * x[2 * tt + i];
+                    }
+                s->s1[c] = a;
+            }
+            for (int o = 0; o < 2; ++o) {
+                real a = 0;
+                for (int c = 0; c < 3; ++c) a += p[L->o_tcn2 + o * 3 + c] * hswish(s->s1[c]);
+                s->s2[o] = a;
+                y[2 * t + o] += hswish(a);
+            }
+        }
+    }
+    if (stats) { stats[0] += zx; stats[1] += 6.0 * T; stats[2] += zh; stats[3] += (double)H * T; }
+}
+
+static void delta_seq_bwd(const odpd_model_t* m, const delta_layout_t* L, const real* p, int T, const real* x, const real* dy,
+                          const delta_step_t* S, real* dp, real* dx) {
+    int H = L->H;
+    real Gh[MAXH] = {0}, Ghp[MAXH] = {0}, Gxp[6] = {0}, Gdm[3 * MAXH] = {0}, Gnh[MAXH] = {0};
+    real* dfeat = (real*)calloc((size_t)T * 6, sizeof(real));
+    if (dx) memset(dx, 0, sizeof(real) * 2 * T);
+    for (int t = T - 1; t >= 0; --t) {
+        const delta_step_t* s = &S[t];
+        for (int c = 0; c < 2; ++c) {
+            real d = dy[2 * t + c];
+            if (!L->tres) dp[L->o_b_out + c] += d;
+            for (int j = 0; j < H; ++j) { dp[L->o_w_out + c * H + j] += d * s->h[j]; Gh[j] += d * p[L->o_w_out + c * H + j]; }
+        }
+        if (L->tres) {
+            real dh1[3] = {0};
+            for (int o = 0; o < 2; ++o) {
+                real d2 = dy[2 * t + o] * hswish_grad(s->s2[o]);
+                for (int c = 0; c < 3; ++c) { dp[L->o_tcn2 + o * 3 + c] += d2 * hswish(s->s1[c]); dh1[c] += d2 * p[L->o_tcn2 + o * 3 + c]; }
+            }
+            for (int c = 0; c < 3; ++c) {
+                real d1 = dh1[c] * hswish_grad(s->s1[c]);
+                for (int i = 0; i < 2; ++i)
+                    for (int k = 0; k < 3; ++k) {
+                        int tt = t + 16 * (k - 1);
+                        if (tt >= 0 && tt < T) {
+                            dp[L->o_tcn0 + (c * 2 + i) * 3 + k] += d1 * x[2 * tt + i];
+                            if (dx) dx[2 * tt + i] += d1 * p[L->o_tcn0 + (c * 2 + i) * 3 + k];
+                        }
+                    }
+            }
+        }
+        real Ghprev[MAXH];
+        for (int j = 0; j < H; ++j) {
+            real dn = Gh[j] * ((real)1 - s->z[j]), dz = Gh[j] * (s->hprev[j] - s->n[j]);
+            Ghprev[j] = Gh[j] * s->z[j];
+            real dpre = dn * ((real)1 - s->n[j] * s->n[j]);
+            Gdm[2 * H + j] += dpre;
+            real dr = dpre * s->dmnh[j];
+            Gnh[j] += dpre * s->r[j];
+            Gdm[j] += dr * s->r[j] * ((real)1 - s->r[j]);
+            Gdm[H + j] += dz * s->z[j] * ((real)1 - s->z[j]);
+        }
+        real ddx[6] = {0}, ddh[MAXH] = {0};
+        for (int j = 0; j < H; ++j)
+            for (int k = 0; k < 3; ++k) {
+                real gx = Gdm[k * H + j], gh = (k < 2) ? Gdm[k * H + j] : Gnh[j];
+                for (int i = 0; i < 6; ++i) { dp[L->o_w_ih + (k * H + j) * 6 + i] += gx * s->dxm[i]; ddx[i] += gx * p[L->o_w_ih + (k * H + j) * 6 + i]; }
+                for (int i = 0; i < H; ++i) { dp[L->o_w_hh + (k * H + j) * H + i] += gh * s->dhm[i]; ddh[i] += gh * p[L->o_w_hh + (k * H + j) * H + i]; }
+            }
+        for (int i = 0; i < 6; ++i) {
+            real mk = s->mx[i];
+            dfeat[t * 6 + i] += mk * ddx[i] + mk * Gxp[i];
+            Gxp[i] = ((real)1 - mk) * Gxp[i] - mk * ddx[i];
+        }
+        for (int j = 0; j < H; ++j) {
+            real mk = s->mh[j];
+            Ghprev[j] += mk * ddh[j] + mk * Ghp[j];
+            Ghp[j] = ((real)1 - mk) * Ghp[j] - mk * ddh[j];
+            Gh[j] = Ghprev[j];
+        }
+    }
+    if (!L->tres)
+        for (int j = 0; j < H; ++j) {
+            dp[L->o_b_ih + j] += Gdm[j]; dp[L->o_b_hh + j] += Gdm[j];
+            dp[L->o_b_ih + H + j] += Gdm[H + j]; dp[L->o_b_hh + H + j] += Gdm[H + j];
+            dp[L->o_b_ih + 2 * H + j] += Gdm[2 * H + j]; dp[L->o_b_hh + 2 * H + j] += Gnh[j];
+        }
+    if (dx)
+        for (int t = 0; t < T; ++t) {
+            const real* df = dfeat + t * 6;
+            real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+            if (L->tres) {
+                real da = df[2] + (real)3 * a * a * df[3];
+                dx[2 * t] += df[0] + da * I / a; dx[2 * t + 1] += df[1] + da * Q / a;
+                int tn = (t + 1) % T;
+                dx[2 * tn] += df[4]; dx[2 * tn + 1] += df[5];
+            } else {
+                real da = df[2] + (real)3 * a * a * df[3] - (Q / a2) * df[4] - (I / a2) * df[5];
+                dx[2 * t] += df[0] + df[5] / a + da * I / a; dx[2 * t + 1] += df[1] + df[4] / a + da * Q / a;
+            }
+        }
+    free(dfeat);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* TCNN: tcnn.py:82-97.  6 -> C (1x1, bias) HS, 4 x depthwise k5 dil 1,2,4,8 (pad 2d) HS,       */
+/* C -> 2 (1x1, no bias), + [I,Q] residual                                                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int C; int64_t o_w0, o_b0, o_dw[4], o_w5; } tcnn_layout_t;
+static void tcnn_layout(const odpd_model_t* m, tcnn_layout_t* g) {
+    int64_t C = m->hidden, o = 0;
+    g->C = (int)C;
+    g->o_w0 = o; o += 6 * C; g->o_b0 = o; o += C;
+    for (int l = 0; l < 4; ++l) { g->o_dw[l] = o; o += 5 * C; }
+    g->o_w5 = o;
+}
+/* act[l] (T,C) are PRE-activations of stage l = 0..4; returns y. work arrays supplied by caller */
+static void tcnn_seq_fwd(const tcnn_layout_t* L, const real* p, int T, const real* x, real* y, real* feat, real* pre) {
+    int C = L->C;
+    for (int t = 0; t < T; ++t) {
+        real* f = feat + t * 6;
+        real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+        f[0] = I; f[1] = Q; f[2] = a; f[3] = a * a * a; f[4] = Q / a; f[5] = I / a;
+        for (int c = 0; c < C; ++c) {
+            real v = p[L->o_b0 + c];
+            for (int i = 0; i < 6; ++i) v += p[L->o_w0 + c * 6 + i] * f[i];
+            pre[(0 * T + t) * C + c] = v;
+        }
+    }
+    for (int l = 0; l < 4; ++l) {
+        int d = 1 << l;
+        for (int t = 0; t < T; ++t)
+            for (int c = 0; c < C; ++c) {
+                real v = 0;
+                for (int k = 0; k < 5; ++k) {
+                    int tt = t + d * (k - 2);
+                    if (tt >= 0 && tt < T) v += p[L->o_dw[l] + c * 5 + k] * hswish(pre[(l * T + tt) * C + c]);
+                }
+                pre[((l + 1) * T + t) * C + c] = v;
+            }
+    }
+    for (int t = 0; t < T; ++t)
+        for (int o = 0; o < 2; ++o) {
+            real v = 0;
+            for (int c = 0; c < C; ++c) v += p[L->o_w5 + o * C + c] * hswish(pre[(4 * T + t) * C + c]);
+            y[2 * t + o] = v + x[2 * t + o];
+        }
+}
+static void tcnn_seq_bwd(const tcnn_layout_t* L, const real* p, int T, const real* x, const real* dy, const real* feat,
+                         const real* pre, real* dp, real* dx, real* gcur, real* gnext) {
+    int C = L->C;
+    /* gcur = dL/d(hswish(pre[4])) */
+    for (int t = 0; t < T; ++t)
+        for (int c = 0; c < C; ++c) {
+            real g = 0;
+            for (int o = 0; o < 2; ++o) { g += dy[2 * t + o] * p[L->o_w5 + o * C + c]; dp[L->o_w5 + o * C + c] += dy[2 * t + o] * hswish(pre[(4 * T + t) * C + c]); }
+            gcur[t * C + c] = g;
+        }
+    for (int l = 3; l >= 0; --l) {
+        int d = 1 << l;
+        memset(gnext, 0, sizeof(real) * T * C);
+        for (int t = 0; t < T; ++t)
+            for (int c = 0; c < C; ++c) {
+                real gp = gcur[t * C + c] * hswish_grad(pre[((l + 1) * T + t) * C + c]);
+                for (int k = 0; k < 5; ++k) {
+                    int tt = t + d * (k - 2);
+                    if (tt >= 0 && tt < T) {
+                        dp[L->o_dw[l] + c * 5 + k] += gp * hswish(pre[(l * T + tt) * C + c]);
+                        gnext[tt * C + c] += gp * p[L->o_dw[l] + c * 5 + k];
+                    }
+                }
+            }
+        real* tsw = gcur; gcur = gnext; gnext = tsw;
+    }
+    for (int t = 0; t < T; ++t) {
+        real df[6] = {0};
+        for (int c = 0; c < C; ++c) {
+            real gp = gcur[t * C + c] * hswish_grad(pre[(0 * T + t) * C + c]);
+            dp[L->o_b0 + c] += gp;
+            for (int i = 0; i < 6; ++i) { dp[L->o_w0 + c * 6 + i] += gp * feat[t * 6 + i]; df[i] += gp * p[L->o_w0 + c * 6 + i]; }
+        }
+        if (dx) {
+            real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+            real da = df[2] + (real)3 * a * a * df[3] - (Q / a2) * df[4] - (I / a2) * df[5];
+            dx[2 * t] = dy[2 * t] + df[0] + df[5] / a + da * I / a;
+            dx[2 * t + 1] = dy[2 * t + 1] + df[1] + df[4] / a + da * Q / a;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* PGJANET: pgjanet.py:26-76                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int H; int64_t o_wa, o_ba, o_wp1, o_bp1, o_wp2, o_bp2, o_wf, o_bf, o_wg, o_bg, o_wo, o_bo; } pgj_layout_t;
+static void pgj_layout(const odpd_model_t* m, pgj_layout_t* g) {
+    int64_t H = m->hidden, o = 0;
+    g->H = (int)H;
+    g->o_wa = o; o += H * (H + 1); g->o_ba = o; o += H;
+    g->o_wp1 = o; o += H * (H + 1); g->o_bp1 = o; o += H;
+    g->o_wp2 = o; o += H * (H + 1); g->o_bp2 = o; o += H;
+    g->o_wf = o; o += H * 2 * H; g->o_bf = o; o += H;
+    g->o_wg = o; o += H * 2 * H; g->o_bg = o; o += H;
+    g->o_wo = o; o += 2 * H; g->o_bo = o; o += 2;
+}
+typedef struct { real amp, ct, st, hp[MAXH], an[MAXH], p1[MAXH], p2[MAXH], u[MAXH], f[MAXH], g[MAXH], h[MAXH]; } pgj_step_t;
+static void pgj_seq_fwd(const pgj_layout_t* L, const real* p, int T, const real* x, real* y, pgj_step_t* S) {
+    int H = L->H;
+    real h[MAXH] = {0};
+    pgj_step_t tmp;
+    for (int t = 0; t < T; ++t) {
+        pgj_step_t* s = S ? &S[t] : &tmp;
+        real I = x[2 * t], Q = x[2 * t + 1];
+        s->amp = (real)sqrt((double)(I * I + Q * Q));
+        real th = (real)atan2((double)Q, (double)I);
+        s->ct = (real)cos((double)th); s->st = (real)sin((double)th);
+        for (int j = 0; j < H; ++j) s->hp[j] = h[j];
+        for (int j = 0; j < H; ++j) {
+            real a = p[L->o_ba + j], b = p[L->o_bp1 + j], c = p[L->o_bp2 + j];
+            for (int i = 0; i < H; ++i) {
+                a += p[L->o_wa + j * (H + 1) + i] * h[i]; b += p[L->o_wp1 + j * (H + 1) + i] * h[i]; c += p[L->o_wp2 + j * (H + 1) + i] * h[i];
+            }
+            a += p[L->o_wa + j * (H + 1) + H] * s->amp; b += p[L->o_wp1 + j * (H + 1) + H] * s->ct; c += p[L->o_wp2 + j * (H + 1) + H] * s->st;
+            s->an[j] = tanhr(a); s->p1[j] = tanhr(b); s->p2[j] = tanhr(c);
+            s->u[j] = s->an[j] * s->p1[j] * s->p2[j] * ((real)1 - s->an[j]) * ((real)1 - s->p1[j]) * ((real)1 - s->p2[j]);
+        }
+        real hn[MAXH];
+        for (int j = 0; j < H; ++j) {
+            real a = p[L->o_bf + j], b = p[L->o_bg + j];
+            for (int i = 0; i < H; ++i) {
+                a += p[L->o_wf + j * 2 * H + i] * h[i] + p[L->o_wf + j * 2 * H + H + i] * s->u[i];
+                b += p[L->o_wg + j * 2 * H + i] * h[i] + p[L->o_wg + j * 2 * H + H + i] * s->u[i];
+            }
+            s->f[j] = sigm(a); s->g[j] = tanhr(b);
+            hn[j] = s->f[j] * h[j] + ((real)1 - s->f[j]) * s->g[j];
+        }
+        for (int j = 0; j < H; ++j) { h[j] = hn[j]; s->h[j] = hn[j]; }
+        for (int c = 0; c < 2; ++c) {
+            real a = p[L->o_bo + c];
+            for (int j = 0; j < H; ++j) a += p[L->o_wo + c * H + j] * h[j];
+            y[2 * t + c] = a;
+        }
+    }
+}
+static void pgj_seq_bwd(const pgj_layout_t* L, const real* p, int T, const real* x, const real* dy, const pgj_step_t* S,
+                        real* dp, real* dx) {
+    int H = L->H;
+    real dh[MAXH] = {0};
+    for (int t = T - 1; t >= 0; --t) {
+        const pgj_step_t* s = &S[t];
+        for (int c = 0; c < 2; ++c) {
+            real d = dy[2 * t + c];
+            dp[L->o_bo + c] += d;
+            for (int j = 0; j < H; ++j) { dp[L->o_wo + c * H + j] += d * s->h[j]; dh[j] += d * p[L->o_wo + c * H + j]; }
+        }
+        real dhp[MAXH] = {0}, du[MAXH] = {0};
+        for (int j = 0; j < H; ++j) {
+            real df = dh[j] * (s->hp[j] - s->g[j]), dg = dh[j] * ((real)1 - s->f[j]);
+            dhp[j] += dh[j] * s->f[j];
+            real dfp = df * s->f[j] * ((real)1 - s->f[j]), dgp = dg * ((real)1 - s->g[j] * s->g[j]);
+            dp[L->o_bf + j] += dfp; dp[L->o_bg + j] += dgp;
+            for (int i = 0; i < H; ++i) {
+                dp[L->o_wf + j * 2 * H + i] += dfp * s->hp[i]; dp[L->o_wf + j * 2 * H + H + i] += dfp * s->u[i];
+                dp[L->o_wg + j * 2 * H + i] += dgp * s->hp[i]; dp[L->o_wg + j * 2 * H + H + i] += dgp * s->u[i];
+                dhp[i] += dfp * p[L->o_wf + j * 2 * H + i] + dgp * p[L->o_wg + j * 2 * H + i];
+                du[i] += dfp * p[L->o_wf + j * 2 * H + H + i] + dgp * p[L->o_wg + j * 2 * H + H + i];
+            }
+        }
+        real damp = 0, dct = 0, dst = 0;
+        for (int j = 0; j < H; ++j) {
+            real a = s->an[j], b = s->p1[j], c = s->p2[j];
+            /* u = A(a) A(b) A(c), A(v) = v (1 - v), A'(v) = 1 - 2 v */
+            real Aa = a * ((real)1 - a), Ab = b * ((real)1 - b), Ac = c * ((real)1 - c);
+            real da = du[j] * ((real)1 - (real)2 * a) * Ab * Ac, db = du[j] * Aa * ((real)1 - (real)2 * b) * Ac,
+                 dc = du[j] * Aa * Ab * ((real)1 - (real)2 * c);
+            real dap = da * ((real)1 - a * a), dbp = db * ((real)1 - b * b), dcp = dc * ((real)1 - c * c);
+            dp[L->o_ba + j] += dap; dp[L->o_bp1 + j] += dbp; dp[L->o_bp2 + j] += dcp;
+            for (int i = 0; i < H; ++i) {
+                dp[L->o_wa + j * (H + 1) + i] += dap * s->hp[i]; dp[L->o_wp1 + j * (H + 1) + i] += dbp * s->hp[i]; dp[L->o_wp2 + j * (H + 1) + i] += dcp * s->hp[i];
+                dhp[i] += dap * p[L->o_wa + j * (H + 1) + i] + dbp * p[L->o_wp1 + j * (H + 1) + i] + dcp * p[L->o_wp2 + j * (H + 1) + i];
+            }
+            dp[L->o_wa + j * (H + 1) + H] += dap * s->amp; dp[L->o_wp1 + j * (H + 1) + H] += dbp * s->ct; dp[L->o_wp2 + j * (H + 1) + H] += dcp * s->st;
+            damp += dap * p[L->o_wa + j * (H + 1) + H]; dct += dbp * p[L->o_wp1 + j * (H + 1) + H]; dst += dcp * p[L->o_wp2 + j * (H + 1) + H];
+        }
+        for (int j = 0; j < H; ++j) dh[j] = dhp[j];
+        if (dx) {
+            /* theta = atan2(Q,I): dtheta = -sin dct + cos dst; dtheta/dI = -Q/a^2, dtheta/dQ = I/a^2 */
+            real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q;
+            real dth = -s->st * dct + s->ct * dst;
+            dx[2 * t] = damp * I / s->amp - dth * Q / a2;
+            dx[2 * t + 1] = damp * Q / s->amp + dth * I / a2;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* dispatch                                                                                     */
 /* ------------------------------------------------------------------------------------------ */
 static int is_gru_family(int bb) { return bb == ODPD_GRU || bb == ODPD_DGRU || bb == ODPD_QGRU || bb == ODPD_QGRU_AMP1; }
+static int is_lstm_family(int bb) { return bb == ODPD_LSTM || bb == ODPD_VDLSTM; }
+static int is_delta_family(int bb) { return bb == ODPD_DELTAGRU || bb == ODPD_TRES_DELTAGRU; }
 
-int oracle_backbone_fwd(const odpd_model_t* m, int B, int T, const real* params, const real* x, real* y, double* stats) {
-    if (!m || !params || !x || !y || B <= 0 || T <= 0 || m->hidden > MAXH) return ODPD_EINVAL;
-    (void)stats;
-    if (is_gru_family(m->backbone)) {
+/* generic per-sequence runner: fwd only (dy == NULL) or fwd + bwd */
+static void seq_run(const odpd_model_t* m, int T, const real* params, const real* x, real* y, const real* dy, real* dp, real* dx,
+                    double* stats, void* scratch) {
+    int bb = m->backbone;
+    if (is_gru_family(bb)) {
         gru_params_t g; gru_layout(m, params, &g);
-#pragma omp parallel for schedule(static)
-        for (int b = 0; b < B; ++b) gru_seq_fwd(m, &g, T, x + (int64_t)b * T * 2, y + (int64_t)b * T * 2, NULL);
-        return 0;
+        gru_step_t* S = (gru_step_t*)scratch;
+        gru_seq_fwd(m, &g, T, x, y, dy ? S : NULL);
+        if (dy) gru_seq_bwd(m, &g, T, x, dy, S, dp, dx);
+    } else if (is_lstm_family(bb)) {
+        lstm_layout_t L; lstm_layout(m, &L);
+        lstm_step_t* S = (lstm_step_t*)scratch;
+        lstm_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
+        if (dy) lstm_seq_bwd(&L, params, T, x, dy, S, dp, dx);
+    } else if (is_delta_family(bb)) {
+        delta_layout_t L; delta_layout(m, &L);
+        delta_step_t* S = (delta_step_t*)scratch;
+        delta_seq_fwd(m, &L, params, T, x, y, dy ? S : NULL, stats);
+        if (dy) delta_seq_bwd(m, &L, params, T, x, dy, S, dp, dx);
+    } else if (bb == ODPD_TCNN) {
+        tcnn_layout_t L; tcnn_layout(m, &L);
+        real* feat = (real*)scratch; real* pre = feat + (size_t)T * 6;
+        real* g1 = pre + (size_t)5 * T * L.C; real* g2 = g1 + (size_t)T * L.C;
+        tcnn_seq_fwd(&L, params, T, x, y, feat, pre);
+        if (dy) tcnn_seq_bwd(&L, params, T, x, dy, feat, pre, dp, dx, g1, g2);
+    } else if (bb == ODPD_PGJANET) {
+        pgj_layout_t L; pgj_layout(m, &L);
+        pgj_step_t* S = (pgj_step_t*)scratch;
+        pgj_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
+        if (dy) pgj_seq_bwd(&L, params, T, x, dy, S, dp, dx);
     }
-    return ODPD_EUNSUPPORTED;
+}
+static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
+    int bb = m->backbone;
+    if (is_gru_family(bb)) return sizeof(gru_step_t) * T;
+    if (is_lstm_family(bb)) return sizeof(lstm_step_t) * T;
+    if (is_delta_family(bb)) return sizeof(delta_step_t) * T;
+    if (bb == ODPD_TCNN) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
+    if (bb == ODPD_PGJANET) return sizeof(pgj_step_t) * T;
+    return 0;
 }
 
-/* dparams (P) is OVERWRITTEN with the sum over the batch; dx nullable. y (nullable) also returned. */
+int oracle_backbone_fwd(const odpd_model_t* m, int B, int T, const real* params, const real* x, real* y, double* stats) {
+    if (!m || !params || !x || !y || B <= 0 || T <= 0 || m->hidden > MAXH || m->hidden <= 0) return ODPD_EINVAL;
+    if (oracle_param_count(m) < 0 || !seq_scratch_bytes(m, T)) return ODPD_EUNSUPPORTED;
+    double st[4] = {0, 0, 0, 0};
+#pragma omp parallel
+    {
+        void* scratch = malloc(seq_scratch_bytes(m, T));
+        double lst[4] = {0, 0, 0, 0};
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b)
+            seq_run(m, T, params, x + (int64_t)b * T * 2, y + (int64_t)b * T * 2, NULL, NULL, NULL, lst, scratch);
+#pragma omp critical
+        for (int i = 0; i < 4; ++i) st[i] += lst[i];
+        free(scratch);
+    }
+    if (stats) for (int i = 0; i < 4; ++i) stats[i] += st[i];
+    return 0;
+}
+
+/* dparams (P) is OVERWRITTEN with the sum over the batch; dx nullable */
 int oracle_backbone_bwd(const odpd_model_t* m, int B, int T, const real* params, const real* x, const real* dy,
                         real* dparams, real* dx) {
-    if (!m || !params || !x || !dy || !dparams || B <= 0 || T <= 0 || m->hidden > MAXH) return ODPD_EINVAL;
+    if (!m || !params || !x || !dy || !dparams || B <= 0 || T <= 0 || m->hidden > MAXH || m->hidden <= 0) return ODPD_EINVAL;
     int64_t P = oracle_param_count(m);
-    if (P < 0) return ODPD_EUNSUPPORTED;
+    if (P < 0 || !seq_scratch_bytes(m, T)) return ODPD_EUNSUPPORTED;
     memset(dparams, 0, sizeof(real) * P);
-    if (is_gru_family(m->backbone)) {
-        gru_params_t g; gru_layout(m, params, &g);
 #pragma omp parallel
-        {
-            real* dp = (real*)calloc(P, sizeof(real));
-            gru_step_t* S = (gru_step_t*)malloc(sizeof(gru_step_t) * T);
-            real* ytmp = (real*)malloc(sizeof(real) * 2 * T);
+    {
+        real* dp = (real*)calloc(P, sizeof(real));
+        void* scratch = malloc(seq_scratch_bytes(m, T));
+        real* ytmp = (real*)malloc(sizeof(real) * 2 * T);
+        double lst[4] = {0, 0, 0, 0};
 #pragma omp for schedule(static)
-            for (int b = 0; b < B; ++b) {
-                const real* xb = x + (int64_t)b * T * 2;
-                gru_seq_fwd(m, &g, T, xb, ytmp, S);
-                gru_seq_bwd(m, &g, T, xb, dy + (int64_t)b * T * 2, S, dp, dx ? dx + (int64_t)b * T * 2 : NULL);
-            }
+        for (int b = 0; b < B; ++b)
+            seq_run(m, T, params, x + (int64_t)b * T * 2, ytmp, dy + (int64_t)b * T * 2, dp, dx ? dx + (int64_t)b * T * 2 : NULL,
+                    lst, scratch);
 #pragma omp critical
-            for (int64_t i = 0; i < P; ++i) dparams[i] += dp[i];
-            free(dp); free(S); free(ytmp);
-        }
-        return 0;
+        for (int64_t i = 0; i < P; ++i) dparams[i] += dp[i];
+        free(dp); free(scratch); free(ytmp);
     }
-    return ODPD_EUNSUPPORTED;
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -16,6 +16,10 @@ STEP_TOL = 2e-5    # parameters after AdamW steps, relative
 SINGLE = [
     ("gru_h11", "gru"), ("gru_h23", "gru"), ("dgru_h13", "dgru"), ("dgru_h8", "dgru"), ("dgru_h23", "dgru"),
     ("qgru_h10", "qgru"), ("qgru_h16", "qgru"), ("qgru_amp1_h10", "qgru_amp1"),
+    ("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm"),
+    ("deltagru_h15_dense", "deltagru"), ("deltagru_h15_th", "deltagru"),
+    ("tres_h15_dense", "deltagru_tcnskip"), ("tres_h15_th", "deltagru_tcnskip"),
+    ("tcnn_c35", "tcnn"), ("pgjanet_h11", "pgjanet"),
 ]
 
 
@@ -36,8 +40,12 @@ def test_forward_loss_grads(orc, orc64, name, bb):
     names = fx.keys("sd")
     p = fx.flat("sd", names)
     assert orc.param_count(m) == p.size == fx.meta["n_param"]
-    y, _ = orc.forward(m, p, fx["x"])
+    y, st = orc.forward(m, p, fx["x"])
     assert rel_err(y, fx["y"]) < FWD_TOL
+    if "stats" in fx:   # delta sparsity counters (deltagru.py:241-247): exact integer counts
+        assert np.array_equal(st, fx["stats"]), (st, fx["stats"])
+        _, sta = orc.forward(m, p, fx["xa"])
+        assert np.array_equal(sta, fx["stats_a"]), (sta, fx["stats_a"])
     # config-shaped frames (T=200, real APA_200MHz slices)
     ya, _ = orc.forward(m, p, fx["xa"])
     assert rel_err(ya, fx["ya"]) < FWD_TOL
@@ -57,7 +65,7 @@ def test_forward_loss_grads(orc, orc64, name, bb):
 @pytest.mark.parametrize("name,bb", SINGLE)
 def test_three_adamw_steps(orc, name, bb):
     fx = Fixture(name)
-    m = make_model(bb, fx.meta["hidden"])
+    m = make_model(bb, fx.meta["hidden"], fx.meta.get("thx", 0), fx.meta.get("thh", 0))
     names = fx.keys("sd")
     sizes = fx.sizes(names)
     p = fx.flat("sd", names).copy()
