@@ -22,7 +22,7 @@
 //                     one row of partial gradients per workgroup, fixed summation order.
 //   gru_train_kernel  forward (cell only) + backward with y / loss / dL/dy formed on the fly:
 //                     HBM traffic = x + target.
-#include "odpd_host.h"
+#include "odpd_seq.h"
 
 namespace odpd {
 
@@ -38,9 +38,6 @@ struct GruTabs {
     static constexpr int kRows = DG ? 8 * R : 6 * R;
     static constexpr int kFloats = kRows * 4 * 64 * 4;
 };
-
-// direction of row_ror measured with the instruction itself: lane col receives lane (col + dir*k) & 15
-__device__ __forceinline__ int rot_dir(int col) { return dpp_ror_i<1>(col) == ((col + 15) & 15) ? -1 : 1; }
 
 // Cooperative fill (all waves of the block; ends with __syncthreads()).
 template <int R, bool DG, bool WITH_T>
@@ -66,30 +63,6 @@ __device__ __forceinline__ void fill_gru_tabs(float* tab, const float* pl, const
         t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
-}
-
-// Returns the same pointer through an empty asm: the compiler can no longer prove that the table
-// loads of successive blocks read the same addresses, so it cannot hoist them out of the block loop
-// (which would pin W_hh and W_hh^T in registers at the same time again).
-__device__ __forceinline__ const float4* opaque(const float4* p) {
-    asm volatile("" : "+v"(p));
-    return p;
-}
-
-// pull one table row (16 rotated weights) / a gate triple into registers
-__device__ __forceinline__ void load_rot(float (&w)[16], const float4* trow) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = trow[q * 64];
-        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-    }
-}
-template <int R>
-__device__ __forceinline__ void load_rot3(float (&w)[3][R][16], const float4* tlane, int first_row) {
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int rb = 0; rb < R; ++rb) load_rot(w[g][rb], tlane + (first_row + g * R + rb) * 4 * 64);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -152,18 +125,6 @@ __device__ __forceinline__ void gru_cell_fwd(const GruW<R, FeatDim<FM>::F, DG>& 
     ghn = ah;
     n = tanhf_(__builtin_fmaf(r, ah, an));
     h = __builtin_fmaf(z, h - n, n);  // (1-z)*n + z*h
-}
-
-// acc + (table rows first_row.. of this lane) . h  — fc_hid pre-activation or its transpose product
-template <int R>
-__device__ __forceinline__ float tab_rotdot(float acc, const float4* tlane, int first_row, float h) {
-    const float4* t0 = tlane + first_row * 4 * 64;
-    float v = rotdot_quads(acc, [t0](int q) { return t0[q * 64]; }, h);
-    if constexpr (R == 2) {
-        const float4* t1 = t0 + 4 * 64;
-        v = rotdot_quads(v, [t1](int q) { return t1[q * 64]; }, swap16(h));
-    }
-    return v;
 }
 
 // y from the head inputs: DG: act = relu(fc_hid pre-activation), else act = h
@@ -389,51 +350,6 @@ __device__ __forceinline__ void gru_block_partials(float* smem, float* partials,
         prow[i] = v;
     }
 }
-
-// -------------------------------------------------------------------------------------------------
-// LDS staging of (B,T,2) streams: one chunk = kChunk steps of the wave's SPW sequences,
-// LDS layout [seq][kChunkPad] float2
-// -------------------------------------------------------------------------------------------------
-template <int SPW>
-__device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane,
-                                         float2 fill) {
-    const float2* g2 = reinterpret_cast<const float2*>(g);
-    constexpr int N = SPW * kChunk / 64;   // float2 per lane
-    static_assert(N >= 1 && (SPW * kChunk) % 64 == 0, "chunk must tile the wave");
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
-        float2 v = fill;
-        if (tt < len && b0 + m < B) v = g2[(size_t)(b0 + m) * T + t0 + tt];
-        lds[m * kChunkPad + tt] = v;
-    }
-}
-template <int SPW>
-__device__ __forceinline__ void stage_out(const float2* lds, float* g, int b0, int B, int T, int t0, int len, int lane) {
-    float2* g2 = reinterpret_cast<float2*>(g);
-    constexpr int N = SPW * kChunk / 64;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
-        if (tt < len && b0 + m < B) g2[(size_t)(b0 + m) * T + t0 + tt] = lds[m * kChunkPad + tt];
-    }
-}
-
-__device__ __forceinline__ void stage_params(float* pl, const float* params, int P) {
-    for (int i = threadIdx.x; i < P; i += blockDim.x) pl[i] = params[i];
-    __syncthreads();
-}
-
-// common kernel prologue: identifies the lane
-struct LaneId { int lane, wave, nwb, col, row, s; };
-template <int R>
-__device__ __forceinline__ LaneId lane_id() {
-    LaneId id;
-    id.lane = threadIdx.x & 63; id.wave = threadIdx.x >> 6; id.nwb = blockDim.x >> 6;
-    id.col = id.lane & 15; id.row = (id.lane >> 4) & (R - 1); id.s = id.lane / (16 * R);
-    return id;
-}
-__host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 
 // -------------------------------------------------------------------------------------------------
 // forward kernel
@@ -708,7 +624,6 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
 // -------------------------------------------------------------------------------------------------
 constexpr int kFwdWavesPerCU = 16;  // 4 waves per SIMD (forward kernels use <= 128 VGPRs for R = 1)
 static int bwd_waves_per_cu(int R) { return R == 1 ? 8 : 4; }
-constexpr size_t kMaxLds = 160 * 1024;
 
 static bool gru_cfg(const odpd_model_t* m, int& FM, bool& DG) {
     switch (m->backbone) {
@@ -720,20 +635,12 @@ static bool gru_cfg(const odpd_model_t* m, int& FM, bool& DG) {
     }
 }
 static int gru_tab_floats(int R, bool DG) { return (DG ? 8 * R : 6 * R) * 4 * 64 * 4; }
-static size_t reduce_scratch_bytes(int P, int waves) { return (size_t)waves * (P + kLossCols) * sizeof(float); }
 // dynamic LDS of a block: params + tables + per-wave region; never smaller than the reduce scratch
 static size_t gru_lds_bytes(int P, int R, bool DG, int waves, size_t wave_floats, bool reduce) {
     size_t n = ((size_t)pad4(P) + gru_tab_floats(R, DG) + (size_t)waves * wave_floats) * sizeof(float);
     if (reduce && n < reduce_scratch_bytes(P, waves)) n = reduce_scratch_bytes(P, waves);
     return n;
 }
-template <typename K>
-static int allow_big_lds(K kernel, size_t lds) {
-    if (lds <= 64 * 1024) return 0;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)kMaxLds);
-}
-
 // launch shape of the backward / fused kernels (also fixes the number of partial rows = grid)
 static LaunchShape bwd_shape(int R, int ngroups) { return persistent_shape(ngroups, bwd_waves_per_cu(R), R == 1 ? 8 : 4); }
 // the fused kernel additionally has to fit its LDS-resident checkpoints: shrink the block if needed

@@ -1,0 +1,104 @@
+// odpd_seq.h — device/host plumbing shared by the persistent sequence kernels (GRU, LSTM, delta, JANET
+// families): lane identification, LDS staging of (B,T,2) streams, rotated-quad weight-table access,
+// launch-shape helpers.
+#pragma once
+#include "odpd_host.h"
+
+namespace odpd {
+
+// direction of row_ror measured with the instruction itself: lane col receives lane (col + dir*k) & 15
+__device__ __forceinline__ int rot_dir(int col) { return dpp_ror_i<1>(col) == ((col + 15) & 15) ? -1 : 1; }
+
+// Returns the same pointer through an empty asm: the compiler can no longer prove that the table
+// loads of successive blocks read the same addresses, so it cannot hoist them out of the block loop
+// (which would pin W_hh and W_hh^T in registers at the same time again).
+__device__ __forceinline__ const float4* opaque(const float4* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+// pull one table row (16 rotated weights) / a gate triple into registers
+__device__ __forceinline__ void load_rot(float (&w)[16], const float4* trow) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = trow[q * 64];
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+}
+template <int R>
+__device__ __forceinline__ void load_rot3(float (&w)[3][R][16], const float4* tlane, int first_row) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int rb = 0; rb < R; ++rb) load_rot(w[g][rb], tlane + (first_row + g * R + rb) * 4 * 64);
+}
+
+// acc + (table rows first_row.. of this lane) . h  — fc_hid pre-activation or its transpose product
+template <int R>
+__device__ __forceinline__ float tab_rotdot(float acc, const float4* tlane, int first_row, float h) {
+    const float4* t0 = tlane + first_row * 4 * 64;
+    float v = rotdot_quads(acc, [t0](int q) { return t0[q * 64]; }, h);
+    if constexpr (R == 2) {
+        const float4* t1 = t0 + 4 * 64;
+        v = rotdot_quads(v, [t1](int q) { return t1[q * 64]; }, swap16(h));
+    }
+    return v;
+}
+
+// -------------------------------------------------------------------------------------------------
+// LDS staging of (B,T,2) streams: one chunk = kChunk steps of the wave's SPW sequences,
+// LDS layout [seq][kChunkPad] float2
+// -------------------------------------------------------------------------------------------------
+template <int SPW>
+__device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane,
+                                         float2 fill) {
+    const float2* g2 = reinterpret_cast<const float2*>(g);
+    constexpr int N = SPW * kChunk / 64;   // float2 per lane
+    static_assert(N >= 1 && (SPW * kChunk) % 64 == 0, "chunk must tile the wave");
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
+        float2 v = fill;
+        if (tt < len && b0 + m < B) v = g2[(size_t)(b0 + m) * T + t0 + tt];
+        lds[m * kChunkPad + tt] = v;
+    }
+}
+template <int SPW>
+__device__ __forceinline__ void stage_out(const float2* lds, float* g, int b0, int B, int T, int t0, int len, int lane) {
+    float2* g2 = reinterpret_cast<float2*>(g);
+    constexpr int N = SPW * kChunk / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
+        if (tt < len && b0 + m < B) g2[(size_t)(b0 + m) * T + t0 + tt] = lds[m * kChunkPad + tt];
+    }
+}
+
+__device__ __forceinline__ void stage_params(float* pl, const float* params, int P) {
+    for (int i = threadIdx.x; i < P; i += blockDim.x) pl[i] = params[i];
+    __syncthreads();
+}
+
+// common kernel prologue: identifies the lane
+struct LaneId { int lane, wave, nwb, col, row, s; };
+template <int R>
+__device__ __forceinline__ LaneId lane_id() {
+    LaneId id;
+    id.lane = threadIdx.x & 63; id.wave = threadIdx.x >> 6; id.nwb = blockDim.x >> 6;
+    id.col = id.lane & 15; id.row = (id.lane >> 4) & (R - 1); id.s = id.lane / (16 * R);
+    return id;
+}
+__host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+
+
+// ---- host side ---------------------------------------------------------------------------------
+constexpr size_t kMaxLds = 160 * 1024;
+template <typename K>
+static inline int allow_big_lds(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)kMaxLds);
+}
+static inline size_t reduce_scratch_bytes(int P, int waves) { return (size_t)waves * (P + kLossCols) * sizeof(float); }
+
+}  // namespace odpd

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from .backbones.native import NativeBackbone
-from .models import CoreModel
+from .models import CascadedModel, CoreModel
 
 
 def _loss_kind(criterion):
@@ -38,10 +38,18 @@ class FusedAdamW:
     ReduceLROnPlateau-style schedulers (project.py:289-296) can drive it."""
 
     def __init__(self, net, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, process_group=None):
-        if not (isinstance(net, CoreModel) and isinstance(net.backbone, NativeBackbone)):
-            raise TypeError("FusedAdamW needs a HIP-backed CoreModel")
+        # a CascadedModel trains its DPD only: the PA is frozen (models.py:169-171, train_dpd.py:60-63)
+        self.pa = None
+        trained = net
+        if isinstance(net, CascadedModel):
+            if any(p.requires_grad for p in net.pa_model.parameters()):
+                raise ValueError("FusedAdamW on a CascadedModel expects freeze_pa_model() to have been called")
+            trained, self.pa = net.dpd_model, net.pa_model.backbone
+        if not (isinstance(trained, CoreModel) and isinstance(trained.backbone, NativeBackbone)):
+            raise TypeError("FusedAdamW needs a HIP-backed CoreModel (or a CascadedModel of two)")
         self.net = net
-        self.backbone = net.backbone
+        self.trained = trained
+        self.backbone = trained.backbone
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
         self.process_group = process_group
         self.step_count = 0
@@ -57,6 +65,7 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros(P, dtype=torch.float32, device=device)
         self.norm = torch.zeros(1, dtype=torch.float32, device=device)
         self._partials = {}
+        self._cascade_bufs = {}
         self._state_dev = device
 
     def partials(self, B, T, device):
@@ -68,6 +77,32 @@ class FusedAdamW:
             self._partials[(B, T)] = torch.empty(rows, self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32,
                                                  device=device)
         return self._partials[(B, T)]
+
+    def bwd_partials(self, B, T, device):
+        """Partial-gradient rows of the split backward kernel (cascade path)."""
+        self._ensure(device)
+        key = (B, T, "bwd")
+        if key not in self._partials:
+            lib = _lib.load()
+            rows = int(lib.odpd_partial_rows(C.byref(self.backbone.desc), B, T, 0))
+            _lib.check(0 if rows > 0 else rows, "odpd_partial_rows")
+            self._partials[key] = torch.empty(rows, self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32,
+                                              device=device)
+        return self._partials[key]
+
+    def cascade_buffers(self, B, T, device):
+        """u = DPD(x), y = PA(u), dy, du, checkpoints, loss scratch — allocated once per batch shape."""
+        self._ensure(device)
+        if (B, T) not in self._cascade_bufs:
+            lib = _lib.load()
+            def ck(bb):
+                n = int(lib.odpd_ckpt_floats(C.byref(bb.desc), B, T))
+                _lib.check(0 if n >= 0 else n, "odpd_ckpt_floats")
+                return torch.empty(max(n, 1), dtype=torch.float32, device=device)
+            mk = lambda: torch.empty(B, T, 2, dtype=torch.float32, device=device)
+            self._cascade_bufs[(B, T)] = dict(u=mk(), y=mk(), dy=mk(), du=mk(), ck_d=ck(self.backbone), ck_p=ck(self.pa),
+                                              loss=torch.zeros(_lib.LOSS_WS, dtype=torch.float32, device=device))
+        return self._cascade_bufs[(B, T)]
 
     def zero_grad(self, set_to_none=True):
         for p in self.net.parameters():
@@ -99,7 +134,7 @@ class FusedAdamW:
 
     def step(self, max_norm=0.0):
         """Generic-path step: gathers p.grad (set by autograd) into the flat gradient, then apply()."""
-        ps = list(self.net.parameters())
+        ps = list(self.trained.parameters())
         self._ensure(ps[0].device)
         with torch.no_grad():
             torch.cat([p.grad.reshape(-1) for p in ps], out=self.grad[:self.backbone.n_flat])
@@ -116,6 +151,8 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     B, T = x.shape[0], x.shape[1]
     n = B * T * 2
     count = int(global_count or n)
+    if opt.pa is not None:
+        return _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count)
     part = opt.partials(B, T, x.device)
     flat = bb.flat_params()
     if timing is not None:
@@ -129,6 +166,36 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     _lib.check(rc, "odpd_reduce_partials")
     opt.allreduce_grad()
     loss = opt.grad[bb.n_flat] / count      # column P = sum of squared / absolute errors
+    opt.apply(grad_clip_val)
+    return loss
+
+
+def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
+    """train_dpd step (steps/train_dpd.py:60-63, models.py:173-176): y = PA(DPD(x)), PA frozen.
+    Five launches chained on the stream: DPD fwd, PA fwd, loss, PA bwd (dL/du only), DPD bwd."""
+    lib = _lib.load()
+    dpd, pa = opt.backbone, opt.pa
+    B, T = x.shape[0], x.shape[1]
+    buf = opt.cascade_buffers(B, T, x.device)
+    part = opt.bwd_partials(B, T, x.device)
+    st = _lib.stream_ptr()
+    fd, fp = dpd.flat_params(), pa.flat_params()
+    _lib.check(lib.odpd_backbone_fwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(buf["u"]),
+                                     _lib.ptr(buf["ck_d"]), _lib.ptr(dpd._stats_buffer(x.device))), "dpd fwd")
+    _lib.check(lib.odpd_backbone_fwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["y"]),
+                                     _lib.ptr(buf["ck_p"]), _lib.ptr(pa._stats_buffer(x.device))), "pa fwd")
+    _lib.check(lib.odpd_loss_fwd_bwd(st, _lib.LOSS_IDS[loss_kind], B * T * 2, count, _lib.ptr(buf["y"]), _lib.ptr(target),
+                                     _lib.ptr(buf["dy"]), _lib.ptr(buf["loss"])), "loss")
+    _lib.check(lib.odpd_backbone_bwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["dy"]),
+                                     _lib.ptr(buf["ck_p"]), None, _lib.ptr(buf["du"])), "pa bwd")
+    _lib.check(lib.odpd_backbone_bwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(buf["du"]),
+                                     _lib.ptr(buf["ck_d"]), _lib.ptr(part), None), "dpd bwd")
+    _lib.check(lib.odpd_reduce_partials(st, part.shape[0], dpd.n_flat, _lib.ptr(part), _lib.ptr(opt.grad), 0), "reduce")
+    # loss scalar travels with the gradient (column P) so that one all-reduce covers both:
+    # grad[P] = sum of errors of this rank = mean * count
+    opt.grad[dpd.n_flat] = buf["loss"][0] * count
+    opt.allreduce_grad()
+    loss = opt.grad[dpd.n_flat] / count
     opt.apply(grad_clip_val)
     return loss
 
