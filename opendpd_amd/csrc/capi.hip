@@ -5,10 +5,11 @@
 using namespace odpd;
 
 namespace {
-enum Family { FAM_NONE = 0, FAM_GRU };
+enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM };
 inline Family family_of(int bb) {
     switch (bb) {
     case ODPD_GRU: case ODPD_DGRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return FAM_GRU;
+    case ODPD_LSTM: case ODPD_VDLSTM: return FAM_LSTM;
     default: return FAM_NONE;
     }
 }
@@ -58,6 +59,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m->backbone)) {
     case FAM_GRU: return (int64_t)num_groups(B, R) * num_ckpt(T) * 64;
+    case FAM_LSTM: return (int64_t)num_groups(B, R) * num_ckpt(T) * 128;   // h and c
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -66,6 +68,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     switch (family_of(m->backbone)) {
     case FAM_GRU: return gru_family_rows(m, B, fused ? 1 : 0, T);
+    case FAM_LSTM: return fused ? (int64_t)ODPD_EUNSUPPORTED : lstm_family_rows(m, B);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -77,6 +80,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     a.params = params; a.x = x; a.y = y; a.ckpt = ckpt; a.stats = stats;
     switch (family_of(m->backbone)) {
     case FAM_GRU: return gru_family_fwd((hipStream_t)stream, m, a);
+    case FAM_LSTM: return lstm_family_fwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -90,6 +94,9 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_GRU:
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return gru_family_bwd((hipStream_t)stream, m, a);
+    case FAM_LSTM:
+        if (!ckpt && a.nck > 1) return ODPD_EINVAL;
+        return lstm_family_bwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }

@@ -1,0 +1,603 @@
+// lstm_family.hip — persistent-RNN kernels for the nn.LSTM based backbones of the reference:
+//   lstm    backbones/lstm.py:4-48     y = fc_out(LSTM(x)), initial (h,c) = (0,0)  (lstm.py:46 passes (h_0,h_0))
+//   vdlstm  backbones/vdlstm.py:5-111  input = |x| over a 4-sample window with CIRCULAR left padding
+//                                      (vdlstm.py:66-74), y = fc_out(cat(l1*cos, l2*sin)) with
+//                                      l1 = fc_lambda_1(h), l2 = fc_lambda_2(h)          (vdlstm.py:77-80)
+// nn.LSTM cell, gate order i,f,g,o:  c' = f*c + i*g,  h' = o*tanh(c').
+// Same structure as gru_family.hip: LDS rotated-quad tables for W_hh / W_hh^T pulled into registers
+// per phase, BPTT by checkpoint (h,c every kCkptStride steps) + block recompute, exact-fp32 MFMA
+// weight gradients, one partial-gradient row per workgroup.
+#include "odpd_seq.h"
+
+namespace odpd {
+
+struct LstmLayout {
+    int H, F, vd;
+    int o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_l1, o_b_l1, o_w_l2, o_b_l2, o_w_out, o_b_out, P;
+};
+__host__ __device__ inline LstmLayout lstm_layout(int H, int vd) {
+    LstmLayout L;
+    L.H = H; L.vd = vd; L.F = vd ? 4 : 2;
+    int o = 0;
+    L.o_w_ih = o; o += 4 * H * L.F;
+    L.o_w_hh = o; o += 4 * H * H;
+    L.o_b_ih = o; o += 4 * H;
+    L.o_b_hh = o; o += 4 * H;
+    L.o_w_l1 = L.o_b_l1 = L.o_w_l2 = L.o_b_l2 = 0;
+    if (vd) {
+        L.o_w_l1 = o; o += 4 * H; L.o_b_l1 = o; o += 4;
+        L.o_w_l2 = o; o += 4 * H; L.o_b_l2 = o; o += 4;
+        L.o_w_out = o; o += 16; L.o_b_out = o; o += 2;
+    } else {
+        L.o_w_out = o; o += 2 * H; L.o_b_out = o; o += 2;
+    }
+    L.P = o;
+    return L;
+}
+
+// table rows: kHH = g*R + rb (g = 0..3), kHHT = 4R + g*R + rb
+template <int R> struct LstmTabs {
+    static constexpr int kHH = 0, kHHT = 4 * R, kRows = 8 * R, kFloats = kRows * 4 * 64 * 4;
+};
+template <int R, bool WITH_T>
+__device__ __forceinline__ void fill_lstm_tabs(float* tab, const float* pl, const LstmLayout& L, int lane, int wave, int nwb) {
+    using T = LstmTabs<R>;
+    const int H = L.H, col = lane & 15, row = (lane >> 4) & (R - 1), o = 16 * row + col, dir = rot_dir(col);
+    float4* t4 = reinterpret_cast<float4*>(tab);
+    for (int idx = wave; idx < T::kRows * 4; idx += nwb) {
+        const int tr = idx >> 2, q = idx & 3;
+        const bool transposed = tr >= T::kHHT;
+        if (!WITH_T && transposed) continue;
+        const int local = transposed ? tr - T::kHHT : tr, g = local / R, rb = local % R;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 16 * ((row + rb) % R) + ((col + dir * (4 * q + e)) & 15);
+            const bool ok = o < H && m < H;
+            v[e] = ok ? pl[L.o_w_hh + g * H * H + (transposed ? m * H + o : o * H + m)] : 0.0f;
+        }
+        t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+}
+template <int R>
+__device__ __forceinline__ void load_rot4(float (&w)[4][R][16], const float4* tlane, int first_row) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int rb = 0; rb < R; ++rb) load_rot(w[g][rb], tlane + (first_row + g * R + rb) * 4 * 64);
+}
+
+template <int R, bool VD>
+struct LstmW {
+    float wih[4][VD ? 4 : 2];
+    float b[4];               // b_ih + b_hh per gate
+    float wout[2], bout[2];   // plain LSTM head
+    float wl1[4], wl2[4];     // VD: fc_lambda_{1,2}.weight[k][o]
+};
+template <int R, bool VD>
+__device__ __forceinline__ void load_lstm_w(LstmW<R, VD>& w, const float* pl, const LstmLayout& L, int row, int col) {
+    constexpr int F = VD ? 4 : 2;
+    const int H = L.H, o = 16 * row + col;
+    const bool vo = o < H;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < F; ++i) w.wih[g][i] = vo ? pl[L.o_w_ih + (g * H + o) * F + i] : 0.0f;
+        w.b[g] = vo ? pl[L.o_b_ih + g * H + o] + pl[L.o_b_hh + g * H + o] : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        w.wout[c] = (!VD && vo) ? pl[L.o_w_out + c * H + o] : 0.0f;
+        w.bout[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pl[L.o_b_out + c])));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w.wl1[k] = (VD && vo) ? pl[L.o_w_l1 + k * H + o] : 0.0f;
+        w.wl2[k] = (VD && vo) ? pl[L.o_w_l2 + k * H + o] : 0.0f;
+    }
+}
+__device__ __forceinline__ float uni(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// window of the VDLSTM input at one step
+struct VdWin { float a[4], cw[4], sw[4]; };
+__device__ __forceinline__ void vd_elem(float2 xv, float& a, float& cw, float& sw) {
+    const float a2 = __builtin_fmaf(xv.x, xv.x, xv.y * xv.y);
+    a = __builtin_amdgcn_sqrtf(a2);
+    const float ia = fast_rcp(a);
+    cw = xv.x * ia; sw = xv.y * ia;
+}
+
+template <int R, bool VD>
+__device__ __forceinline__ void lstm_cell_fwd(const LstmW<R, VD>& w, const float (&whh)[4][R][16],
+                                              const float (&xin)[VD ? 4 : 2], float& h, float& c, float& gi, float& gf,
+                                              float& gg, float& go, float& tc) {
+    constexpr int F = VD ? 4 : 2;
+    float a0 = w.b[0], a1 = w.b[1], a2 = w.b[2], a3 = w.b[3];
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        a0 = __builtin_fmaf(w.wih[0][i], xin[i], a0);
+        a1 = __builtin_fmaf(w.wih[1][i], xin[i], a1);
+        a2 = __builtin_fmaf(w.wih[2][i], xin[i], a2);
+        a3 = __builtin_fmaf(w.wih[3][i], xin[i], a3);
+    }
+    float z = 0.0f;
+    rotdot3(a0, a1, a2, whh[0][0], whh[1][0], whh[2][0], h);
+    a3 = rotdot(a3, whh[3][0], h);
+    if constexpr (R == 2) {
+        const float hx = swap16(h);
+        rotdot3(a0, a1, a2, whh[0][1], whh[1][1], whh[2][1], hx);
+        a3 = rotdot(a3, whh[3][1], hx);
+    }
+    (void)z;
+    gi = sigmoidf_(a0); gf = sigmoidf_(a1); gg = tanhf_(a2); go = sigmoidf_(a3);
+    c = __builtin_fmaf(gf, c, gi * gg);
+    tc = tanhf_(c);
+    h = go * tc;
+}
+
+// output head.  VD: y_c = sum_k Wo[c][k] cw[k] l1[k] + Wo[c][4+k] sw[k] l2[k] + bo[c], l = fc_lambda(h)
+template <int R, bool VD>
+__device__ __forceinline__ void lstm_head(const LstmW<R, VD>& w, const float* pl, const LstmLayout& L, float h,
+                                          const VdWin& win, float& y0, float& y1) {
+    if constexpr (VD) {
+        float q0 = 0.f, q1 = 0.f, c0 = w.bout[0], c1 = w.bout[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float u0 = pl[L.o_w_out + k] * win.cw[k], v0 = pl[L.o_w_out + 4 + k] * win.sw[k];
+            const float u1 = pl[L.o_w_out + 8 + k] * win.cw[k], v1 = pl[L.o_w_out + 12 + k] * win.sw[k];
+            q0 = __builtin_fmaf(u0, w.wl1[k], __builtin_fmaf(v0, w.wl2[k], q0));
+            q1 = __builtin_fmaf(u1, w.wl1[k], __builtin_fmaf(v1, w.wl2[k], q1));
+            c0 = __builtin_fmaf(u0, pl[L.o_b_l1 + k], __builtin_fmaf(v0, pl[L.o_b_l2 + k], c0));
+            c1 = __builtin_fmaf(u1, pl[L.o_b_l1 + k], __builtin_fmaf(v1, pl[L.o_b_l2 + k], c1));
+        }
+        y0 = seq_sum<R>(q0 * h) + c0;
+        y1 = seq_sum<R>(q1 * h) + c1;
+    } else {
+        y0 = seq_sum<R>(w.wout[0] * h) + w.bout[0];
+        y1 = seq_sum<R>(w.wout[1] * h) + w.bout[1];
+    }
+}
+
+// ---- staging with a 3-sample circular left halo (VDLSTM windows) --------------------------------
+constexpr int kHalo = 3;
+constexpr int kHaloStride = kChunk + kHalo + 2;   // float2 per sequence row (odd/2 -> conflict-free pairs)
+template <int SPW>
+__device__ __forceinline__ void stage_in_halo(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane) {
+    const float2* g2 = reinterpret_cast<const float2*>(g);
+    constexpr int PER = kChunk + kHalo, TOT = SPW * PER, N = (TOT + 63) / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j;
+        if (e < TOT) {
+            const int m = e / PER, pos = e % PER;
+            int tg = t0 - kHalo + pos;
+            if (tg < 0) tg += T;     // circular padding: the frame's own last samples (vdlstm.py:66-74)
+            float2 v = make_float2(0.5f, 0.5f);
+            if (pos < len + kHalo && b0 + m < B && tg < T) v = g2[(size_t)(b0 + m) * T + tg];
+            lds[m * kHaloStride + pos] = v;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward kernel
+// -------------------------------------------------------------------------------------------------
+template <int R, bool VD>
+__global__ __launch_bounds__(kMaxThreads) void lstm_fwd_kernel(SeqArgs a) {
+    constexpr int F = VD ? 4 : 2, SPW = 4 / R, LPS = 16 * R, S = kCkptStride;
+    using T = LstmTabs<R>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LaneId id = lane_id<R>();
+    const int lane = id.lane, s = id.s;
+    const LstmLayout L = lstm_layout(a.H, VD);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_lstm_tabs<R, false>(tab, pl, L, lane, id.wave, id.nwb);
+    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    float2* xs = reinterpret_cast<float2*>(tab + T::kFloats) + id.wave * (SPW * kHaloStride + SPW * kChunkPad);
+    float2* ys = xs + SPW * kHaloStride;
+    LstmW<R, VD> w;
+    load_lstm_w<R, VD>(w, pl, L, id.row, id.col);
+    float whh[4][R][16];
+    load_rot4<R>(whh, tlane, T::kHH);
+    const int nwaves = gridDim.x * id.nwb;
+    for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * SPW;
+        float h = 0.0f, c = 0.0f;
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            stage_in_halo<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane);
+            wave_lds_fence();
+            const float2* xr = xs + s * kHaloStride + kHalo;   // xr[tt] = x[t0 + tt], xr[-1..-3] = halo
+            VdWin win;
+            if constexpr (VD) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vd_elem(xr[k - 3], win.a[k + 1], win.cw[k + 1], win.sw[k + 1]);
+            }
+            for (int tt = 0; tt < len; ++tt) {
+                const float2 xv = xr[tt];
+                float xin[F];
+                if constexpr (VD) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { win.a[k] = win.a[k + 1]; win.cw[k] = win.cw[k + 1]; win.sw[k] = win.sw[k + 1]; }
+                    vd_elem(xv, win.a[3], win.cw[3], win.sw[3]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xin[k] = win.a[k];
+                } else { xin[0] = xv.x; xin[1] = xv.y; }
+                float gi, gf, gg, go, tc, y0, y1;
+                lstm_cell_fwd<R, VD>(w, whh, xin, h, c, gi, gf, gg, go, tc);
+                lstm_head<R, VD>(w, pl, L, h, win, y0, y1);
+                if ((lane & (LPS - 1)) == 0) ys[s * kChunkPad + tt] = make_float2(y0, y1);
+                const int t1 = t0 + tt + 1;
+                if (a.ckpt != nullptr && (t1 % S) == 0 && t1 < a.T) {
+                    float* ck = a.ckpt + ((size_t)grp * a.nck + t1 / S) * 128;
+                    ck[lane] = h; ck[64 + lane] = c;
+                }
+            }
+            wave_lds_fence();
+            stage_out<SPW>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+            wave_lds_fence();
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// backward
+// -------------------------------------------------------------------------------------------------
+template <int R, bool VD>
+struct LstmGrad {
+    f32x4 thh[4][R][R];   // dW_hh tiles
+    f32x4 tih[4][R];      // dW_ih | bias column F
+    float dwout[2], dbout[2];          // plain head
+    float dwl1[4], dwl2[4];            // VD: d fc_lambda weights (per lane column o)
+    float dbl1[4], dbl2[4], dwo[16];   // VD: uniform-per-sequence accumulators
+    __device__ __forceinline__ void zero() {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int x = 0; x < R; ++x) {
+                tih[g][x] = z4;
+#pragma unroll
+                for (int y = 0; y < R; ++y) thh[g][x][y] = z4;
+            }
+        dwout[0] = dwout[1] = dbout[0] = dbout[1] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dwl1[k] = dwl2[k] = dbl1[k] = dbl2[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dwo[k] = 0.f;
+    }
+};
+
+template <int R, bool VD, bool NW, bool DX, bool FULL>
+__device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, VD>& w, const float* pl, const LstmLayout& L,
+                                               const float4* tlane, LstmGrad<R, VD>& G, const LaneId& id, const float2* xr,
+                                               const float2* dys, float2* dxs, int tloc, int nstep, float h, float c,
+                                               float& dh, float& dc) {
+    constexpr int F = VD ? 4 : 2, LPS = 16 * R, S = kCkptStride;
+    using T = LstmTabs<R>;
+    const int lane = id.lane, col = id.col, row = id.row, s = id.s;
+    float hp_s[S], cp_s[S], i_s[S], f_s[S], g_s[S], o_s[S], tc_s[S];
+    tlane = opaque(tlane);
+    {
+        float whh[4][R][16];
+        load_rot4<R>(whh, tlane, T::kHH);
+        VdWin win;
+        if constexpr (VD) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vd_elem(xr[tloc + k - 3], win.a[k + 1], win.cw[k + 1], win.sw[k + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            if (FULL || i < nstep) {
+                const float2 xv = xr[tloc + i];
+                float xin[F];
+                if constexpr (VD) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) win.a[k] = win.a[k + 1];
+                    float cw_, sw_;
+                    vd_elem(xv, win.a[3], cw_, sw_);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xin[k] = win.a[k];
+                } else { xin[0] = xv.x; xin[1] = xv.y; }
+                hp_s[i] = h; cp_s[i] = c;
+                lstm_cell_fwd<R, VD>(w, whh, xin, h, c, i_s[i], f_s[i], g_s[i], o_s[i], tc_s[i]);
+            }
+        }
+    }
+    tlane = opaque(tlane);
+    float whhT[4][R][16];
+    load_rot4<R>(whhT, tlane, T::kHHT);
+#pragma unroll
+    for (int i = S - 1; i >= 0; --i) {
+        if (FULL || i < nstep) {
+            const int tt = tloc + i;
+            const float2 dyv = dys[s * kChunkPad + tt];
+            const float ht = o_s[i] * tc_s[i];
+            float xin[F];
+            VdWin win;
+            if constexpr (VD) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vd_elem(xr[tt + k - 3], win.a[k], win.cw[k], win.sw[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xin[k] = win.a[k];
+            } else { const float2 xv = xr[tt]; xin[0] = xv.x; xin[1] = xv.y; }
+            float dht = dh;
+            if constexpr (VD) {
+                // dz[k] = sum_c dy_c Wo[c][k];  dl1[k] = dz[k] cw[k];  dl2[k] = dz[4+k] sw[k]
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dz1 = __builtin_fmaf(dyv.x, pl[L.o_w_out + k], dyv.y * pl[L.o_w_out + 8 + k]);
+                    const float dz2 = __builtin_fmaf(dyv.x, pl[L.o_w_out + 4 + k], dyv.y * pl[L.o_w_out + 12 + k]);
+                    const float d1 = dz1 * win.cw[k], d2 = dz2 * win.sw[k];
+                    dht = __builtin_fmaf(d1, w.wl1[k], __builtin_fmaf(d2, w.wl2[k], dht));
+                    if constexpr (NW) {
+                        G.dwl1[k] = __builtin_fmaf(d1, ht, G.dwl1[k]);
+                        G.dwl2[k] = __builtin_fmaf(d2, ht, G.dwl2[k]);
+                        G.dbl1[k] += d1; G.dbl2[k] += d2;
+                        // fc_out weight gradient needs l1[k], l2[k] (reductions over the hidden units)
+                        const float l1 = seq_sum<R>(w.wl1[k] * ht) + pl[L.o_b_l1 + k];
+                        const float l2 = seq_sum<R>(w.wl2[k] * ht) + pl[L.o_b_l2 + k];
+                        const float z1 = l1 * win.cw[k], z2 = l2 * win.sw[k];
+                        G.dwo[k] = __builtin_fmaf(dyv.x, z1, G.dwo[k]);
+                        G.dwo[4 + k] = __builtin_fmaf(dyv.x, z2, G.dwo[4 + k]);
+                        G.dwo[8 + k] = __builtin_fmaf(dyv.y, z1, G.dwo[8 + k]);
+                        G.dwo[12 + k] = __builtin_fmaf(dyv.y, z2, G.dwo[12 + k]);
+                    }
+                }
+            } else {
+                dht = __builtin_fmaf(dyv.x, w.wout[0], __builtin_fmaf(dyv.y, w.wout[1], dht));
+                if constexpr (NW) {
+                    G.dwout[0] = __builtin_fmaf(dyv.x, ht, G.dwout[0]);
+                    G.dwout[1] = __builtin_fmaf(dyv.y, ht, G.dwout[1]);
+                }
+            }
+            if constexpr (NW) { G.dbout[0] += dyv.x; G.dbout[1] += dyv.y; }
+            // cell backward
+            const float dO = dht * tc_s[i];
+            const float dct = __builtin_fmaf(dht * o_s[i], __builtin_fmaf(-tc_s[i], tc_s[i], 1.0f), dc);
+            const float dpi = (dct * g_s[i]) * (i_s[i] * (1.0f - i_s[i]));
+            const float dpf = (dct * cp_s[i]) * (f_s[i] * (1.0f - f_s[i]));
+            const float dpg = (dct * i_s[i]) * __builtin_fmaf(-g_s[i], g_s[i], 1.0f);
+            const float dpo = dO * (o_s[i] * (1.0f - o_s[i]));
+            dc = dct * f_s[i];
+            if constexpr (NW) {
+                float fsx = (col == F) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int q = 0; q < F; ++q) fsx = (col == q) ? xin[q] : fsx;
+                const float hp = hp_s[i];
+                if constexpr (R == 1) {
+                    G.tih[0][0] = mfma4(dpi, fsx, G.tih[0][0]); G.tih[1][0] = mfma4(dpf, fsx, G.tih[1][0]);
+                    G.tih[2][0] = mfma4(dpg, fsx, G.tih[2][0]); G.tih[3][0] = mfma4(dpo, fsx, G.tih[3][0]);
+                    G.thh[0][0][0] = mfma4(dpi, hp, G.thh[0][0][0]); G.thh[1][0][0] = mfma4(dpf, hp, G.thh[1][0][0]);
+                    G.thh[2][0][0] = mfma4(dpg, hp, G.thh[2][0][0]); G.thh[3][0][0] = mfma4(dpo, hp, G.thh[3][0][0]);
+                } else {
+                    const float hpx = swap16(hp);
+#pragma unroll
+                    for (int qo = 0; qo < R; ++qo) {
+                        const bool mine = row == qo;
+                        const float d[4] = {mine ? dpi : 0.f, mine ? dpf : 0.f, mine ? dpg : 0.f, mine ? dpo : 0.f};
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            G.tih[g][qo] = mfma4(d[g], fsx, G.tih[g][qo]);
+#pragma unroll
+                            for (int qm = 0; qm < R; ++qm) G.thh[g][qo][qm] = mfma4(d[g], qm == qo ? hp : hpx, G.thh[g][qo][qm]);
+                        }
+                    }
+                }
+            }
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            rotdot3x(d0, d1, d2, whhT[0][0], whhT[1][0], whhT[2][0], dpi, dpf, dpg);
+            d0 = rotdot(d0, whhT[3][0], dpo);
+            if constexpr (R == 2) {
+                rotdot3x(d0, d1, d2, whhT[0][1], whhT[1][1], whhT[2][1], swap16(dpi), swap16(dpf), swap16(dpg));
+                d0 = rotdot(d0, whhT[3][1], swap16(dpo));
+            }
+            dh = d0 + d1 + d2;
+            if constexpr (DX && !VD) {
+                float dI = __builtin_fmaf(w.wih[0][0], dpi, __builtin_fmaf(w.wih[1][0], dpf, __builtin_fmaf(w.wih[2][0], dpg, w.wih[3][0] * dpo)));
+                float dQ = __builtin_fmaf(w.wih[0][1], dpi, __builtin_fmaf(w.wih[1][1], dpf, __builtin_fmaf(w.wih[2][1], dpg, w.wih[3][1] * dpo)));
+                dI = seq_sum<R>(dI); dQ = seq_sum<R>(dQ);
+                if ((lane & (LPS - 1)) == 0) dxs[s * kChunkPad + tt] = make_float2(dI, dQ);
+            }
+        }
+    }
+}
+
+template <int R, bool VD>
+__device__ __forceinline__ void lstm_write_partials(float* prow, const LstmLayout& L, LstmGrad<R, VD>& G, int lane, int row,
+                                                    int col) {
+    constexpr int F = VD ? 4 : 2;
+    const int H = L.H, o = 16 * row + col, seq = lane / (16 * R);
+    const int g4 = lane >> 4, c = lane & 15;
+    for (int i = lane; i < kLossCols; i += 64) prow[L.P + i] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int qo = 0; qo < R; ++qo)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 16 * qo + 4 * g4 + rr;
+                if (i < H) {
+                    const float v = G.tih[g][qo][rr];
+                    if (c < F) prow[L.o_w_ih + (g * H + i) * F + c] = v;
+                    else if (c == F) { prow[L.o_b_ih + g * H + i] = v; prow[L.o_b_hh + g * H + i] = v; }
+#pragma unroll
+                    for (int qm = 0; qm < R; ++qm) {
+                        const int j = 16 * qm + c;
+                        if (j < H) prow[L.o_w_hh + (g * H + i) * H + j] = G.thh[g][qo][qm][rr];
+                    }
+                }
+            }
+    const float db0 = across_seqs<R>(G.dbout[0]), db1 = across_seqs<R>(G.dbout[1]);
+    if (lane == 0) { prow[L.o_b_out] = db0; prow[L.o_b_out + 1] = db1; }
+    if constexpr (VD) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a1 = across_seqs<R>(G.dwl1[k]), a2 = across_seqs<R>(G.dwl2[k]);
+            const float b1 = across_seqs<R>(G.dbl1[k]), b2 = across_seqs<R>(G.dbl2[k]);
+            if (seq == 0 && o < H) { prow[L.o_w_l1 + k * H + o] = a1; prow[L.o_w_l2 + k * H + o] = a2; }
+            if (lane == 0) { prow[L.o_b_l1 + k] = b1; prow[L.o_b_l2 + k] = b2; }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float v = across_seqs<R>(G.dwo[k]);
+            if (lane == 0) prow[L.o_w_out + k] = v;
+        }
+    } else {
+        const float w0 = across_seqs<R>(G.dwout[0]), w1 = across_seqs<R>(G.dwout[1]);
+        if (seq == 0 && o < H) { prow[L.o_w_out + o] = w0; prow[L.o_w_out + H + o] = w1; }
+    }
+}
+
+template <int R, bool VD, bool NW, bool DX>
+__global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R == 1 && !VD) ? 2 : 1) void lstm_bwd_kernel(SeqArgs a) {
+    constexpr int SPW = 4 / R, S = kCkptStride;
+    using T = LstmTabs<R>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LaneId id = lane_id<R>();
+    const int lane = id.lane;
+    const LstmLayout L = lstm_layout(a.H, VD);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_lstm_tabs<R, true>(tab, pl, L, lane, id.wave, id.nwb);
+    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    float2* xs = reinterpret_cast<float2*>(tab + T::kFloats) + id.wave * (SPW * kHaloStride + 2 * SPW * kChunkPad);
+    float2* dys = xs + SPW * kHaloStride;
+    float2* dxs = dys + SPW * kChunkPad;
+    LstmW<R, VD> w;
+    load_lstm_w<R, VD>(w, pl, L, id.row, id.col);
+    LstmGrad<R, VD> G;
+    G.zero();
+    const int nwaves = gridDim.x * id.nwb;
+    for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * SPW;
+        float dh = 0.0f, dc = 0.0f;
+        int cur_chunk = -1;
+        for (int blk = a.nck - 1; blk >= 0; --blk) {
+            const int tb = blk * S, nstep = min(S, a.T - tb);
+            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            if (chunk != cur_chunk) {
+                if constexpr (DX) {
+                    if (cur_chunk >= 0) {
+                        const int pt0 = cur_chunk * kChunk;
+                        wave_lds_fence();
+                        stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                    }
+                }
+                wave_lds_fence();
+                const int len = min(kChunk, a.T - t0);
+                stage_in_halo<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane);
+                stage_in<SPW>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                wave_lds_fence();
+                cur_chunk = chunk;
+            }
+            const float* ck = a.ckpt + ((size_t)grp * a.nck + blk) * 128;
+            const float h0 = blk ? ck[lane] : 0.0f, c0 = blk ? ck[64 + lane] : 0.0f;
+            const float2* xr = xs + id.s * kHaloStride + kHalo;
+            if (nstep == S)
+                lstm_bwd_block<R, VD, NW, DX, true>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc);
+            else
+                lstm_bwd_block<R, VD, NW, DX, false>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc);
+        }
+        if constexpr (DX) {
+            if (cur_chunk >= 0) {
+                const int pt0 = cur_chunk * kChunk;
+                wave_lds_fence();
+                stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                wave_lds_fence();
+            }
+        }
+    }
+    if constexpr (NW) {
+        const int P4 = L.P + kLossCols;
+        __syncthreads();
+        lstm_write_partials<R, VD>(smem + id.wave * P4, L, G, lane, id.row, id.col);
+        __syncthreads();
+        float* prow = a.partials + (size_t)blockIdx.x * P4;
+        for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+            float v = smem[i];
+            for (int wv = 1; wv < id.nwb; ++wv) v += smem[wv * P4 + i];
+            prow[i] = v;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// launchers
+// -------------------------------------------------------------------------------------------------
+static size_t lstm_lds_bytes(int P, int R, int waves, size_t wave_floats, bool reduce) {
+    size_t n = ((size_t)pad4(P) + 8 * R * 4 * 64 * 4 + (size_t)waves * wave_floats) * sizeof(float);
+    if (reduce && n < reduce_scratch_bytes(P, waves)) n = reduce_scratch_bytes(P, waves);
+    return n;
+}
+static LaunchShape lstm_bwd_shape(int R, bool vd, int ngroups) {
+    const int w = (R == 1 && !vd) ? 8 : 4;   // VDLSTM / two-row models need > 256 registers: one wave per SIMD
+    return persistent_shape(ngroups, w, w);
+}
+
+template <int R, bool VD>
+static int lstm_launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
+    const LaunchShape ls = persistent_shape(a.ngroups, R == 1 ? 16 : 8);
+    const size_t lds = lstm_lds_bytes(P, R, ls.waves, 2 * ((4 / R) * kHaloStride + (4 / R) * kChunkPad), false);
+    auto k = lstm_fwd_kernel<R, VD>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <int R, bool VD, bool NW, bool DX>
+static int lstm_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
+    const LaunchShape ls = lstm_bwd_shape(R, VD, a.ngroups);
+    const size_t lds = lstm_lds_bytes(P, R, ls.waves, 2 * ((4 / R) * kHaloStride + 2 * (4 / R) * kChunkPad), NW);
+    auto k = lstm_bwd_kernel<R, VD, NW, DX>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <int R, bool VD>
+static int lstm_launch_bwd_mode(hipStream_t st, const SeqArgs& a, int P) {
+    const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
+    if (VD && dx) return ODPD_EUNSUPPORTED;   // dL/dx of the circular windows is not implemented yet
+    if (nw && !dx) return lstm_launch_bwd<R, VD, true, false>(st, a, P);
+    if constexpr (!VD) {
+        if (!nw && dx) return lstm_launch_bwd<R, VD, false, true>(st, a, P);
+        if (nw && dx) return lstm_launch_bwd<R, VD, true, true>(st, a, P);
+    }
+    return ODPD_EINVAL;
+}
+
+#define ODPD_LSTM_DISPATCH(FN, ...)                                   \
+    if (R == 1 && !vd) return FN<1, false>(__VA_ARGS__);               \
+    if (R == 2 && !vd) return FN<2, false>(__VA_ARGS__);               \
+    if (R == 1 && vd) return FN<1, true>(__VA_ARGS__);                 \
+    if (R == 2 && vd) return FN<2, true>(__VA_ARGS__);
+
+int lstm_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    const int R = rows_per_seq(m->hidden);
+    const bool vd = m->backbone == ODPD_VDLSTM;
+    if (!R) return ODPD_EUNSUPPORTED;
+    if (vd && a.T < kHalo) return ODPD_EINVAL;
+    const int P = lstm_layout(m->hidden, vd).P;
+    ODPD_LSTM_DISPATCH(lstm_launch_fwd, st, a, P)
+    return ODPD_EUNSUPPORTED;
+}
+int lstm_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    const int R = rows_per_seq(m->hidden);
+    const bool vd = m->backbone == ODPD_VDLSTM;
+    if (!R) return ODPD_EUNSUPPORTED;
+    const int P = lstm_layout(m->hidden, vd).P;
+    ODPD_LSTM_DISPATCH(lstm_launch_bwd_mode, st, a, P)
+    return ODPD_EUNSUPPORTED;
+}
+int lstm_family_rows(const odpd_model_t* m, int B) {
+    const int R = rows_per_seq(m->hidden);
+    if (!R) return ODPD_EUNSUPPORTED;
+    return lstm_bwd_shape(R, m->backbone == ODPD_VDLSTM, num_groups(B, R)).grid;
+}
+
+}  // namespace odpd

@@ -95,5 +95,8 @@ int gru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, int T);
+int lstm_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int lstm_family_rows(const odpd_model_t* m, int B);
 
 }  // namespace odpd

@@ -38,6 +38,10 @@ class CoreModel(nn.Module):
             self.backbone = B.QGRU(**kw)
         elif backbone_type == "qgru_amp1":
             self.backbone = B.QGRUAmp1(**kw)
+        elif backbone_type == "lstm":
+            self.backbone = B.LSTM(input_size=input_size, **kw)
+        elif backbone_type == "vdlstm":
+            self.backbone = B.VDLSTM(input_size=input_size, **kw)
         elif backbone_type in REFERENCE_BACKBONES:
             raise NotImplementedError(f"backbone '{backbone_type}' is a reference registry name that this build "
                                       f"does not provide as a HIP kernel yet")

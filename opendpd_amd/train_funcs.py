@@ -54,6 +54,7 @@ class FusedAdamW:
         self.process_group = process_group
         self.step_count = 0
         self._state_dev = None
+        self._fused_ok = {}
 
     # -- state -------------------------------------------------------------------------------
     def _ensure(self, device):
@@ -78,6 +79,14 @@ class FusedAdamW:
                                                  device=device)
         return self._partials[(B, T)]
 
+    def has_fused(self, B, T):
+        """True when the backbone has a single-launch fwd+loss+bwd kernel for this batch shape."""
+        key = (B, T, "has_fused")
+        if key not in self._fused_ok:
+            lib = _lib.load()
+            self._fused_ok[key] = int(lib.odpd_partial_rows(C.byref(self.backbone.desc), B, T, 1)) > 0
+        return self._fused_ok[key]
+
     def bwd_partials(self, B, T, device):
         """Partial-gradient rows of the split backward kernel (cascade path)."""
         self._ensure(device)
@@ -100,8 +109,11 @@ class FusedAdamW:
                 _lib.check(0 if n >= 0 else n, "odpd_ckpt_floats")
                 return torch.empty(max(n, 1), dtype=torch.float32, device=device)
             mk = lambda: torch.empty(B, T, 2, dtype=torch.float32, device=device)
-            self._cascade_bufs[(B, T)] = dict(u=mk(), y=mk(), dy=mk(), du=mk(), ck_d=ck(self.backbone), ck_p=ck(self.pa),
-                                              loss=torch.zeros(_lib.LOSS_WS, dtype=torch.float32, device=device))
+            d = dict(u=mk(), dy=mk(), ck_d=ck(self.backbone),
+                     loss=torch.zeros(_lib.LOSS_WS, dtype=torch.float32, device=device))
+            if self.pa is not None:
+                d.update(y=mk(), du=mk(), ck_p=ck(self.pa))
+            self._cascade_bufs[(B, T)] = d
         return self._cascade_bufs[(B, T)]
 
     def zero_grad(self, set_to_none=True):
@@ -151,7 +163,7 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     B, T = x.shape[0], x.shape[1]
     n = B * T * 2
     count = int(global_count or n)
-    if opt.pa is not None:
+    if opt.pa is not None or not opt.has_fused(B, T):
         return _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count)
     part = opt.partials(B, T, x.device)
     flat = bb.flat_params()
@@ -171,24 +183,30 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
 
 
 def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
-    """train_dpd step (steps/train_dpd.py:60-63, models.py:173-176): y = PA(DPD(x)), PA frozen.
-    Five launches chained on the stream: DPD fwd, PA fwd, loss, PA bwd (dL/du only), DPD bwd."""
+    """Split-kernel step.  With a frozen PA (train_dpd, steps/train_dpd.py:60-63, models.py:173-176):
+    y = PA(DPD(x)) as five launches chained on the stream — DPD fwd, PA fwd, loss, PA bwd (dL/du only),
+    DPD bwd.  Without a PA (backbones that have no fused kernel yet): fwd, loss, bwd."""
     lib = _lib.load()
     dpd, pa = opt.backbone, opt.pa
     B, T = x.shape[0], x.shape[1]
     buf = opt.cascade_buffers(B, T, x.device)
     part = opt.bwd_partials(B, T, x.device)
     st = _lib.stream_ptr()
-    fd, fp = dpd.flat_params(), pa.flat_params()
+    fd, fp = dpd.flat_params(), (pa.flat_params() if pa is not None else None)
     _lib.check(lib.odpd_backbone_fwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(buf["u"]),
                                      _lib.ptr(buf["ck_d"]), _lib.ptr(dpd._stats_buffer(x.device))), "dpd fwd")
-    _lib.check(lib.odpd_backbone_fwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["y"]),
-                                     _lib.ptr(buf["ck_p"]), _lib.ptr(pa._stats_buffer(x.device))), "pa fwd")
-    _lib.check(lib.odpd_loss_fwd_bwd(st, _lib.LOSS_IDS[loss_kind], B * T * 2, count, _lib.ptr(buf["y"]), _lib.ptr(target),
+    if pa is not None:
+        _lib.check(lib.odpd_backbone_fwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["y"]),
+                                         _lib.ptr(buf["ck_p"]), _lib.ptr(pa._stats_buffer(x.device))), "pa fwd")
+    y = buf["y"] if pa is not None else buf["u"]
+    _lib.check(lib.odpd_loss_fwd_bwd(st, _lib.LOSS_IDS[loss_kind], B * T * 2, count, _lib.ptr(y), _lib.ptr(target),
                                      _lib.ptr(buf["dy"]), _lib.ptr(buf["loss"])), "loss")
-    _lib.check(lib.odpd_backbone_bwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["dy"]),
-                                     _lib.ptr(buf["ck_p"]), None, _lib.ptr(buf["du"])), "pa bwd")
-    _lib.check(lib.odpd_backbone_bwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(buf["du"]),
+    du = buf["dy"]
+    if pa is not None:
+        _lib.check(lib.odpd_backbone_bwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["dy"]),
+                                         _lib.ptr(buf["ck_p"]), None, _lib.ptr(buf["du"])), "pa bwd")
+        du = buf["du"]
+    _lib.check(lib.odpd_backbone_bwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(du),
                                      _lib.ptr(buf["ck_d"]), _lib.ptr(part), None), "dpd bwd")
     _lib.check(lib.odpd_reduce_partials(st, part.shape[0], dpd.n_flat, _lib.ptr(part), _lib.ptr(opt.grad), 0), "reduce")
     # loss scalar travels with the gradient (column P) so that one all-reduce covers both:

@@ -1,0 +1,93 @@
+"""GPU parity of the LSTM-family kernels (lstm, vdlstm) against the reference golden vectors and
+the CPU oracle (ragged sizes), plus the split-kernel train step trajectory."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import Fixture, rel_err
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, GRAD_TOL = 2e-5, 3e-4
+
+
+def _model(fx, bb):
+    from opendpd_amd import CoreModel
+    net = CoreModel(2, fx.meta["hidden"], 1, bb)
+    net.load_state_dict({k: torch.from_numpy(fx["sd/" + k]) for k in fx.keys("sd")})
+    return net.cuda()
+
+
+@pytest.mark.parametrize("name,bb", [("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm")])
+def test_golden_forward_backward(name, bb):
+    fx = Fixture(name)
+    net = _model(fx, bb)
+    need_dx = bb == "lstm"
+    x = torch.from_numpy(fx["x"]).cuda().requires_grad_(need_dx)
+    y = net(x)
+    assert rel_err(y.detach().cpu().numpy(), fx["y"]) < FWD_TOL
+    loss = torch.nn.functional.mse_loss(y, torch.from_numpy(fx["tgt"]).cuda())
+    assert abs(loss.item() - fx["losses"][0]) < 1e-5 * max(1.0, fx["losses"][0])
+    loss.backward()
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), fx["g/" + k]) < GRAD_TOL, k
+    if need_dx:
+        assert rel_err(x.grad.cpu().numpy(), fx["gx"]) < GRAD_TOL
+    with torch.no_grad():
+        ya = net(torch.from_numpy(fx["xa"]).cuda())
+    assert rel_err(ya.cpu().numpy(), fx["ya"]) < FWD_TOL
+
+
+@pytest.mark.parametrize("bb,H", [("lstm", 14), ("lstm", 9), ("lstm", 20), ("vdlstm", 13), ("vdlstm", 8), ("vdlstm", 18)])
+@pytest.mark.parametrize("B,T", [(1, 3), (3, 5), (4, 32), (7, 33), (5, 200), (66, 63)])
+def test_against_oracle_ragged(bb, H, B, T):
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 100 + B + T)
+    net = CoreModel(2, H, 1, bb).cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    rng = np.random.RandomState(B * 11 + T)
+    amp = 0.05 + 0.85 * rng.rand(B, T, 1)
+    ph = 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    dy = rng.randn(B, T, 2).astype(np.float32)
+    need_dx = bb == "lstm"
+    xt = torch.from_numpy(x).cuda().requires_grad_(need_dx)
+    y = net(xt)
+    y.backward(torch.from_numpy(dy).cuda())
+    o = Oracle("f32")
+    m = make_model(bb, H)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    yo, _ = o.forward(m, p, x)
+    go, dxo = o.backward(m, p, x, dy)
+    g = np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()])
+    assert rel_err(y.detach().cpu().numpy(), yo) < FWD_TOL
+    assert rel_err(g, go) < GRAD_TOL
+    if need_dx:
+        assert rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
+
+
+@pytest.mark.parametrize("name,bb", [("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm")])
+def test_train_steps_follow_reference(name, bb):
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    fx = Fixture(name)
+    net = _model(fx, bb)
+    opt = FusedAdamW(net, lr=fx.meta["lr"])
+    x = torch.from_numpy(fx["x"]).cuda()
+    t = torch.from_numpy(fx["tgt"]).cuda()
+    names = fx.keys("sd")
+    for s in range(1, 4):
+        loss = fused_train_step(opt, x, t, "l2", fx.meta["clip"])
+        assert abs(loss.item() - fx["losses"][s - 1]) < 2e-5 * max(1.0, fx["losses"][s - 1])
+        got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in net.parameters()])
+        assert rel_err(got, fx.flat(f"p{s}", names)) < 3e-5, s
+
+
+def test_vdlstm_dx_is_refused_loudly():
+    from opendpd_amd import CoreModel
+    net = CoreModel(2, 8, 1, "vdlstm").cuda()
+    x = torch.rand(2, 16, 2, device="cuda").requires_grad_(True)
+    with pytest.raises(RuntimeError):
+        net(x).sum().backward()
