@@ -1,0 +1,526 @@
+// delta_family.hip — persistent-RNN kernels for the delta-network GRU backbones of the reference:
+//   deltagru          backbones/deltagru.py:10-276          feat=[I,Q,a,a^3,sin,cos]; nn.GRU weights with biases folded
+//                                                            into the accumulators' initial value (deltagru.py:165-170);
+//                                                            y = fc_out(h) (+bias)
+//   deltagru_tcnskip  backbones/deltagru_tcnskip.py:11-304  ("TRes-DeltaGRU") feat=[I,Q,a,a^3,I_next,Q_next] with
+//                                                            next = roll(x,-1) (:88-100); bias-free x2h/h2h, accumulators
+//                                                            start at 0; y = fc_out(h) (no bias) + TCN skip
+//                                                            (conv 2->3 k3 dil16 pad16, Hardswish, conv 3->2 k1, Hardswish)
+// Per step (deltagru.py:235-262):  dx = x - x_p, dh = h - h_p, masked to 0 where |d| < th;  x_p/h_p track the last
+// transmitted value;  dm += W_ih dx (+ W_hh dh for r,z),  dm_nh += (W_hh dh)_n;  r = s(dm_r), z = s(dm_z),
+// n = tanh(dm_n + r*dm_nh), h = (1-z) n + z h.  Sparsity counters (deltagru.py:241-247) are accumulated on device.
+//
+// The GPU computes the masked products densely (a 64-lane SIMD cannot skip per-lane zeros); what is kept
+// from the delta formulation is the exact arithmetic (thresholded memories and accumulators) and the counters.
+// Backward: the gradient through the x_p memory only reaches the INPUT (features carry no parameters), so the
+// parameter-gradient path needs the dh/h_p chain only.  dL/dx is not implemented for this family (a delta model
+// is used as the DPD, never as the frozen PA).  One 16-lane row per sequence: H <= 16.
+#include "odpd_seq.h"
+
+namespace odpd {
+
+struct DeltaLayout { int H, tres, o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_tcn0, o_tcn2, P; };
+__host__ __device__ inline DeltaLayout delta_layout(int H, int tres) {
+    DeltaLayout L;
+    L.H = H; L.tres = tres;
+    int o = 0;
+    L.o_w_ih = o; o += 3 * H * 6;
+    L.o_w_hh = o; o += 3 * H * H;
+    L.o_b_ih = L.o_b_hh = L.o_b_out = L.o_tcn0 = L.o_tcn2 = 0;
+    if (!tres) { L.o_b_ih = o; o += 3 * H; L.o_b_hh = o; o += 3 * H; }
+    L.o_w_out = o; o += 2 * H;
+    if (!tres) { L.o_b_out = o; o += 2; }
+    else { L.o_tcn0 = o; o += 18; L.o_tcn2 = o; o += 6; }
+    L.P = o;
+    return L;
+}
+
+constexpr int kDHalo = 16;                                  // TCN taps at t-16, t, t+16
+constexpr int kDStride = kChunk + 2 * kDHalo + 1;           // float2 per sequence row
+constexpr int kDTabFloats = 6 * 4 * 64 * 4;                 // W_hh (3 rows) + W_hh^T (3 rows)
+constexpr int kDState = 7;                                  // checkpoint: h, h_p, dm_r, dm_z, dm_n, dm_nh, x_p[col]
+
+template <bool WITH_T>
+__device__ __forceinline__ void fill_delta_tabs(float* tab, const float* pl, const DeltaLayout& L, int lane, int wave, int nwb) {
+    const int H = L.H, col = lane & 15, o = col, dir = rot_dir(col);
+    float4* t4 = reinterpret_cast<float4*>(tab);
+    for (int idx = wave; idx < 6 * 4; idx += nwb) {
+        const int tr = idx >> 2, q = idx & 3;
+        const bool transposed = tr >= 3;
+        if (!WITH_T && transposed) continue;
+        const int g = transposed ? tr - 3 : tr;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = (col + dir * (4 * q + e)) & 15;
+            const bool ok = o < H && m < H;
+            v[e] = ok ? pl[L.o_w_hh + g * H * H + (transposed ? m * H + o : o * H + m)] : 0.0f;
+        }
+        t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void load_rot3d(float (&w)[3][16], const float4* tlane, int first_row) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) load_rot(w[g], tlane + (first_row + g) * 4 * 64);
+}
+
+template <bool TRES>
+struct DeltaW {
+    float wih[3][6];
+    float wout[2], bout[2];
+    float w1[6];      // TRES: tcn.0.weight[c = min(col,2)][i][k]  (lanes col < 3 are meaningful)
+    float w2[2];      // TRES: tcn.2.weight[o][c]
+    float dm0[4];     // initial accumulators (biases for deltagru, 0 for TRES): r, z, n, nh
+};
+template <bool TRES>
+__device__ __forceinline__ void load_delta_w(DeltaW<TRES>& w, const float* pl, const DeltaLayout& L, int col) {
+    const int H = L.H, o = col;
+    const bool vo = o < H;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w.wih[g][i] = vo ? pl[L.o_w_ih + (g * H + o) * 6 + i] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        w.wout[c] = vo ? pl[L.o_w_out + c * H + o] : 0.0f;
+        w.bout[c] = TRES ? 0.0f : __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pl[L.o_b_out + c])));
+    }
+    const int cc = col < 3 ? col : 2;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w.w1[k] = TRES ? pl[L.o_tcn0 + cc * 6 + k] : 0.0f;
+#pragma unroll
+    for (int oo = 0; oo < 2; ++oo) w.w2[oo] = (TRES && col < 3) ? pl[L.o_tcn2 + oo * 3 + cc] : 0.0f;
+    if (TRES) { w.dm0[0] = w.dm0[1] = w.dm0[2] = w.dm0[3] = 0.0f; }
+    else {
+        w.dm0[0] = vo ? pl[L.o_b_ih + o] + pl[L.o_b_hh + o] : 0.0f;
+        w.dm0[1] = vo ? pl[L.o_b_ih + H + o] + pl[L.o_b_hh + H + o] : 0.0f;
+        w.dm0[2] = vo ? pl[L.o_b_ih + 2 * H + o] : 0.0f;
+        w.dm0[3] = vo ? pl[L.o_b_hh + 2 * H + o] : 0.0f;
+    }
+}
+
+// recurrent state of one lane (x_p is per sequence, replicated in every lane of the row)
+struct DeltaState { float h, hp, dmr, dmz, dmn, dmnh, xp[6]; };
+
+__device__ __forceinline__ float hswish_grad_(float v) { return v < -3.0f ? 0.0f : (v <= 3.0f ? __builtin_fmaf(v, 1.0f / 3.0f, 0.5f) : 1.0f); }
+
+template <bool TRES>
+__device__ __forceinline__ void delta_feat(float2 xv, float2 xn, float (&f)[6]) {
+    const float a2 = __builtin_fmaf(xv.x, xv.x, xv.y * xv.y), a = __builtin_amdgcn_sqrtf(a2);
+    f[0] = xv.x; f[1] = xv.y; f[2] = a; f[3] = a2 * a;
+    if constexpr (TRES) { f[4] = xn.x; f[5] = xn.y; }
+    else { const float ia = fast_rcp(a); f[4] = xv.y * ia; f[5] = xv.x * ia; }
+}
+
+// one forward step.  Outputs what the backward pass needs: hprev, dhm, mh (1/0), r, z, n, dmnh (post-update), and
+// fsx = masked dx of feature `col` (MFMA B operand).  zx/zh count exact zeros of the masked deltas.
+template <bool TRES>
+__device__ __forceinline__ void delta_cell_fwd(const DeltaW<TRES>& w, const float (&whh)[3][16], const float (&f)[6],
+                                               float thx, float thh, int col, bool vo, DeltaState& st, float& hprev,
+                                               float& dhm, float& mh, float& r, float& z, float& n, float& fsx,
+                                               float& zx, float& zh) {
+    float ar = st.dmr, az = st.dmz, an = st.dmn;
+    fsx = 0.0f;
+    float nzx = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const float d = f[i] - st.xp[i];
+        const bool keep = !(__builtin_fabsf(d) < thx);       // masked_fill(|d| < th, 0)  (deltagru.py:179-183)
+        const float dm = keep ? d : 0.0f;
+        st.xp[i] = (__builtin_fabsf(d) >= thx) ? f[i] : st.xp[i];
+        nzx += (dm == 0.0f) ? 1.0f : 0.0f;
+        fsx = (col == i) ? dm : fsx;
+        ar = __builtin_fmaf(w.wih[0][i], dm, ar);
+        az = __builtin_fmaf(w.wih[1][i], dm, az);
+        an = __builtin_fmaf(w.wih[2][i], dm, an);
+    }
+    const float dhv = st.h - st.hp;
+    const bool keeph = !(__builtin_fabsf(dhv) < thh);
+    dhm = keeph ? dhv : 0.0f;
+    mh = keeph ? 1.0f : 0.0f;
+    st.hp = (__builtin_fabsf(dhv) >= thh) ? st.h : st.hp;
+    zx += nzx;
+    zh += (vo && dhm == 0.0f) ? 1.0f : 0.0f;
+    float anh = st.dmnh;
+    rotdot3(ar, az, anh, whh[0], whh[1], whh[2], dhm);
+    st.dmr = ar; st.dmz = az; st.dmn = an; st.dmnh = anh;
+    r = sigmoidf_(ar); z = sigmoidf_(az);
+    n = tanhf_(__builtin_fmaf(r, anh, an));
+    hprev = st.h;
+    st.h = __builtin_fmaf(z, st.h - n, n);
+}
+
+// TCN skip pre-activations: s1 (lane col<3: channel col), s2[0..1] (all lanes)
+template <bool TRES>
+__device__ __forceinline__ void tcn_fwd(const DeltaW<TRES>& w, float2 xm, float2 xc, float2 xp16, int col, float& s1,
+                                        float& s2a, float& s2b) {
+    // weight order tcn.0.weight[c][i][k]: (i=0: k=0,1,2), (i=1: k=0,1,2); taps k=0 -> t-16, k=1 -> t, k=2 -> t+16
+    s1 = w.w1[0] * xm.x;
+    s1 = __builtin_fmaf(w.w1[1], xc.x, s1); s1 = __builtin_fmaf(w.w1[2], xp16.x, s1);
+    s1 = __builtin_fmaf(w.w1[3], xm.y, s1); s1 = __builtin_fmaf(w.w1[4], xc.y, s1); s1 = __builtin_fmaf(w.w1[5], xp16.y, s1);
+    const float hs = hardswishf_(s1);
+    s2a = row_sum16(w.w2[0] * hs);   // w2 is 0 on lanes col >= 3
+    s2b = row_sum16(w.w2[1] * hs);
+    (void)col;
+}
+
+template <int SPW, int HL>
+__device__ __forceinline__ void stage_in_halo2(float2* lds, const float* g, int b0, int B, int T, int t0, int lane) {
+    const float2* g2 = reinterpret_cast<const float2*>(g);
+    constexpr int PER = kChunk + 2 * HL, STR = kChunk + 2 * HL + 1, TOT = SPW * PER, N = (TOT + 63) / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j;
+        if (e < TOT) {
+            const int m = e / PER, pos = e % PER, tg = t0 - HL + pos;
+            const bool centre = pos >= HL && pos < HL + kChunk;
+            float2 v = centre ? make_float2(0.5f, 0.5f) : make_float2(0.0f, 0.0f);   // zero padding of the conv
+            if (tg >= 0 && tg < T && b0 + m < B) v = g2[(size_t)(b0 + m) * T + tg];
+            lds[m * STR + pos] = v;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward kernel
+// -------------------------------------------------------------------------------------------------
+template <bool TRES>
+__global__ __launch_bounds__(kMaxThreads) void delta_fwd_kernel(SeqArgs a) {
+    constexpr int SPW = 4, S = kCkptStride;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LaneId id = lane_id<1>();
+    const int lane = id.lane, col = id.col, s = id.s;
+    const DeltaLayout L = delta_layout(a.H, TRES);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_delta_tabs<false>(tab, pl, L, lane, id.wave, id.nwb);
+    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    float2* xs = reinterpret_cast<float2*>(tab + kDTabFloats) + id.wave * (SPW * kDStride + SPW * kChunkPad);
+    float2* ys = xs + SPW * kDStride;
+    DeltaW<TRES> w;
+    load_delta_w<TRES>(w, pl, L, col);
+    float whh[3][16];
+    load_rot3d(whh, tlane, 0);
+    const bool vo = col < a.H;
+    float zx = 0.0f, zh = 0.0f;
+    const int nwaves = gridDim.x * id.nwb;
+    for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * SPW;
+        const bool valid = b0 + s < a.B;
+        DeltaState st;
+        st.h = st.hp = 0.0f; st.dmr = w.dm0[0]; st.dmz = w.dm0[1]; st.dmn = w.dm0[2]; st.dmnh = w.dm0[3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st.xp[i] = 0.0f;
+        const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[(size_t)(b0 + s) * a.T] : make_float2(0.5f, 0.5f);
+        float zxs = 0.0f, zhs = 0.0f;
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            stage_in_halo2<SPW, kDHalo>(xs, a.x, b0, a.B, a.T, t0, lane);
+            wave_lds_fence();
+            const float2* xr = xs + s * kDStride + kDHalo;
+            for (int tt = 0; tt < len; ++tt) {
+                const float2 xv = xr[tt];
+                const float2 xn = (t0 + tt + 1 < a.T) ? xr[tt + 1] : x0;    // torch.roll(x, -1): last step sees sample 0
+                float f[6], hprev, dhm, mh, r, z, n, fsx;
+                delta_feat<TRES>(xv, xn, f);
+                delta_cell_fwd<TRES>(w, whh, f, a.thx, a.thh, col, vo, st, hprev, dhm, mh, r, z, n, fsx, zxs, zhs);
+                float y0 = row_sum16(w.wout[0] * st.h) + w.bout[0], y1 = row_sum16(w.wout[1] * st.h) + w.bout[1];
+                if constexpr (TRES) {
+                    float s1, s2a, s2b;
+                    tcn_fwd<TRES>(w, xr[tt - kDHalo], xv, xr[tt + kDHalo], col, s1, s2a, s2b);
+                    y0 += hardswishf_(s2a); y1 += hardswishf_(s2b);
+                }
+                if (col == 0) ys[s * kChunkPad + tt] = make_float2(y0, y1);
+                const int t1 = t0 + tt + 1;
+                if (a.ckpt != nullptr && (t1 % S) == 0 && t1 < a.T) {
+                    float* ck = a.ckpt + ((size_t)grp * a.nck + t1 / S) * (kDState * 64);
+                    ck[lane] = st.h; ck[64 + lane] = st.hp; ck[128 + lane] = st.dmr; ck[192 + lane] = st.dmz;
+                    ck[256 + lane] = st.dmn; ck[320 + lane] = st.dmnh;
+                    float xpc = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) xpc = (col == i) ? st.xp[i] : xpc;
+                    ck[384 + lane] = xpc;
+                }
+            }
+            wave_lds_fence();
+            stage_out<SPW>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+            wave_lds_fence();
+        }
+        if (valid) { zx += (col == 0) ? zxs : 0.0f; zh += zhs; }
+    }
+    if (a.stats != nullptr) {
+        // dx zeros are counted once per sequence (lane col 0), dh zeros per hidden unit
+        float tx = zx, th = zh;
+        for (int o = 32; o > 0; o >>= 1) { tx += __shfl_down(tx, o); th += __shfl_down(th, o); }
+        if (lane == 0) {
+            atomicAdd(&a.stats[0], (double)tx);
+            atomicAdd(&a.stats[2], (double)th);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicAdd(&a.stats[1], 6.0 * (double)a.B * (double)a.T);
+            atomicAdd(&a.stats[3], (double)a.H * (double)a.B * (double)a.T);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// backward kernel (parameter gradients only)
+// -------------------------------------------------------------------------------------------------
+template <bool TRES>
+struct DeltaGrad {
+    f32x4 thh[3], tih[3];
+    float dwout[2], dbout[2];
+    float db[4];          // deltagru: gradient w.r.t. the initial accumulators = bias gradients
+    float dw1[6], dw2[2]; // TRES TCN weights (lanes col < 3)
+    __device__ __forceinline__ void zero() {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { thh[g] = z4; tih[g] = z4; }
+        dwout[0] = dwout[1] = dbout[0] = dbout[1] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) db[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dw1[i] = 0.f;
+        dw2[0] = dw2[1] = 0.f;
+    }
+};
+// carried gradients of one lane
+struct DeltaCarry { float gh, ghp, gr, gz, gn, gnh; };
+
+template <bool TRES, bool FULL>
+__device__ __forceinline__ void delta_bwd_block(const SeqArgs& a, const DeltaW<TRES>& w, const float4* tlane, DeltaGrad<TRES>& G,
+                                                const LaneId& id, const float2* xr, const float2* dys, float2 x0, int tglob,
+                                                int tloc, int nstep, DeltaState st, DeltaCarry& C) {
+    constexpr int S = kCkptStride;
+    const int col = id.col, s = id.s;
+    const bool vo = col < a.H;
+    float hprev_s[S], dhm_s[S], mh_s[S], r_s[S], z_s[S], n_s[S], nh_s[S], fsx_s[S], ht_s[S];
+    tlane = opaque(tlane);
+    {
+        float whh[3][16];
+        load_rot3d(whh, tlane, 0);
+        float zx = 0.f, zh = 0.f;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            if (FULL || i < nstep) {
+                const float2 xv = xr[tloc + i];
+                const float2 xn = (tglob + i + 1 < a.T) ? xr[tloc + i + 1] : x0;
+                float f[6];
+                delta_feat<TRES>(xv, xn, f);
+                delta_cell_fwd<TRES>(w, whh, f, a.thx, a.thh, col, vo, st, hprev_s[i], dhm_s[i], mh_s[i], r_s[i], z_s[i],
+                                     n_s[i], fsx_s[i], zx, zh);
+                nh_s[i] = st.dmnh;
+                ht_s[i] = st.h;
+            }
+        }
+    }
+    tlane = opaque(tlane);
+    float whhT[3][16];
+    load_rot3d(whhT, tlane, 3);
+#pragma unroll
+    for (int i = S - 1; i >= 0; --i) {
+        if (FULL || i < nstep) {
+            const int tt = tloc + i;
+            const float2 dyv = dys[s * kChunkPad + tt];
+            float gh = C.gh + __builtin_fmaf(dyv.x, w.wout[0], dyv.y * w.wout[1]);
+            G.dwout[0] = __builtin_fmaf(dyv.x, ht_s[i], G.dwout[0]);
+            G.dwout[1] = __builtin_fmaf(dyv.y, ht_s[i], G.dwout[1]);
+            G.dbout[0] += dyv.x; G.dbout[1] += dyv.y;
+            if constexpr (TRES) {
+                float s1, s2a, s2b;
+                const float2 xm = xr[tt - kDHalo], xc = xr[tt], xq = xr[tt + kDHalo];
+                tcn_fwd<TRES>(w, xm, xc, xq, col, s1, s2a, s2b);
+                const float d2a = dyv.x * hswish_grad_(s2a), d2b = dyv.y * hswish_grad_(s2b);
+                const float hs = hardswishf_(s1);
+                G.dw2[0] = __builtin_fmaf(d2a, hs, G.dw2[0]);
+                G.dw2[1] = __builtin_fmaf(d2b, hs, G.dw2[1]);
+                const float d1 = __builtin_fmaf(d2a, w.w2[0], d2b * w.w2[1]) * hswish_grad_(s1);
+                G.dw1[0] = __builtin_fmaf(d1, xm.x, G.dw1[0]); G.dw1[1] = __builtin_fmaf(d1, xc.x, G.dw1[1]);
+                G.dw1[2] = __builtin_fmaf(d1, xq.x, G.dw1[2]); G.dw1[3] = __builtin_fmaf(d1, xm.y, G.dw1[3]);
+                G.dw1[4] = __builtin_fmaf(d1, xc.y, G.dw1[4]); G.dw1[5] = __builtin_fmaf(d1, xq.y, G.dw1[5]);
+            }
+            const float r = r_s[i], z = z_s[i], n = n_s[i];
+            const float dn = gh * (1.0f - z), dz = gh * (hprev_s[i] - n);
+            float ghprev = gh * z;
+            const float dpre = dn * __builtin_fmaf(-n, n, 1.0f);
+            C.gn += dpre;
+            C.gnh = __builtin_fmaf(dpre, r, C.gnh);
+            C.gr = __builtin_fmaf(dpre * nh_s[i], r * (1.0f - r), C.gr);
+            C.gz = __builtin_fmaf(dz, z * (1.0f - z), C.gz);
+            // weight gradients: dW_ih += G_dm (x) dx_masked, dW_hh += [G_dm_r, G_dm_z, G_nh] (x) dh_masked
+            G.tih[0] = mfma4(C.gr, fsx_s[i], G.tih[0]);
+            G.tih[1] = mfma4(C.gz, fsx_s[i], G.tih[1]);
+            G.tih[2] = mfma4(C.gn, fsx_s[i], G.tih[2]);
+            G.thh[0] = mfma4(C.gr, dhm_s[i], G.thh[0]);
+            G.thh[1] = mfma4(C.gz, dhm_s[i], G.thh[1]);
+            G.thh[2] = mfma4(C.gnh, dhm_s[i], G.thh[2]);
+            // data gradient to the masked dh
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            rotdot3x(d0, d1, d2, whhT[0], whhT[1], whhT[2], C.gr, C.gz, C.gnh);
+            const float ddh = d0 + d1 + d2, mk = mh_s[i];
+            ghprev = __builtin_fmaf(mk, ddh + C.ghp, ghprev);
+            C.ghp = __builtin_fmaf(-mk, ddh, (1.0f - mk) * C.ghp);
+            C.gh = ghprev;
+        }
+    }
+}
+
+template <bool TRES>
+__device__ __forceinline__ void delta_write_partials(float* prow, const DeltaLayout& L, DeltaGrad<TRES>& G, int lane, int col) {
+    const int H = L.H, o = col, seq = lane >> 4, g4 = lane >> 4, c = lane & 15;
+    for (int i = lane; i < kLossCols; i += 64) prow[L.P + i] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * g4 + rr;
+            if (i < H) {
+                if (c < 6) prow[L.o_w_ih + (g * H + i) * 6 + c] = G.tih[g][rr];
+                if (c < H) prow[L.o_w_hh + (g * H + i) * H + c] = G.thh[g][rr];
+            }
+        }
+    const float w0 = across_seqs<1>(G.dwout[0]), w1 = across_seqs<1>(G.dwout[1]);
+    if (seq == 0 && o < H) { prow[L.o_w_out + o] = w0; prow[L.o_w_out + H + o] = w1; }
+    if constexpr (TRES) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float v = across_seqs<1>(G.dw1[k]);
+            if (seq == 0 && col < 3) prow[L.o_tcn0 + col * 6 + k] = v;
+        }
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo) {
+            const float v = across_seqs<1>(G.dw2[oo]);
+            if (seq == 0 && col < 3) prow[L.o_tcn2 + oo * 3 + col] = v;
+        }
+    } else {
+        const float b0 = across_seqs<1>(G.dbout[0]), b1 = across_seqs<1>(G.dbout[1]);
+        if (lane == 0) { prow[L.o_b_out] = b0; prow[L.o_b_out + 1] = b1; }
+        float db[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) db[i] = across_seqs<1>(G.db[i]);
+        if (seq == 0 && o < H) {
+            prow[L.o_b_ih + o] = db[0]; prow[L.o_b_hh + o] = db[0];
+            prow[L.o_b_ih + H + o] = db[1]; prow[L.o_b_hh + H + o] = db[1];
+            prow[L.o_b_ih + 2 * H + o] = db[2]; prow[L.o_b_hh + 2 * H + o] = db[3];
+        }
+    }
+}
+
+template <bool TRES>
+__global__ __launch_bounds__(kMaxThreads / 2, 1) void delta_bwd_kernel(SeqArgs a) {
+    constexpr int SPW = 4, S = kCkptStride;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LaneId id = lane_id<1>();
+    const int lane = id.lane, col = id.col, s = id.s;
+    const DeltaLayout L = delta_layout(a.H, TRES);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_delta_tabs<true>(tab, pl, L, lane, id.wave, id.nwb);
+    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    float2* xs = reinterpret_cast<float2*>(tab + kDTabFloats) + id.wave * (SPW * kDStride + SPW * kChunkPad);
+    float2* dys = xs + SPW * kDStride;
+    DeltaW<TRES> w;
+    load_delta_w<TRES>(w, pl, L, col);
+    DeltaGrad<TRES> G;
+    G.zero();
+    const int nwaves = gridDim.x * id.nwb;
+    for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * SPW;
+        const bool valid = b0 + s < a.B;
+        const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[(size_t)(b0 + s) * a.T] : make_float2(0.5f, 0.5f);
+        DeltaCarry C = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int cur_chunk = -1;
+        for (int blk = a.nck - 1; blk >= 0; --blk) {
+            const int tb = blk * S, nstep = min(S, a.T - tb);
+            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            if (chunk != cur_chunk) {
+                wave_lds_fence();
+                const int len = min(kChunk, a.T - t0);
+                stage_in_halo2<SPW, kDHalo>(xs, a.x, b0, a.B, a.T, t0, lane);
+                stage_in<SPW>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                wave_lds_fence();
+                cur_chunk = chunk;
+            }
+            DeltaState st;
+            if (blk) {
+                const float* ck = a.ckpt + ((size_t)grp * a.nck + blk) * (kDState * 64);
+                st.h = ck[lane]; st.hp = ck[64 + lane]; st.dmr = ck[128 + lane]; st.dmz = ck[192 + lane];
+                st.dmn = ck[256 + lane]; st.dmnh = ck[320 + lane];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) st.xp[i] = ck[384 + (lane & 48) + i];
+            } else {
+                st.h = st.hp = 0.0f; st.dmr = w.dm0[0]; st.dmz = w.dm0[1]; st.dmn = w.dm0[2]; st.dmnh = w.dm0[3];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) st.xp[i] = 0.0f;
+            }
+            const float2* xr = xs + s * kDStride + kDHalo;
+            if (nstep == S) delta_bwd_block<TRES, true>(a, w, tlane, G, id, xr, dys, x0, tb, tb - t0, nstep, st, C);
+            else delta_bwd_block<TRES, false>(a, w, tlane, G, id, xr, dys, x0, tb, tb - t0, nstep, st, C);
+        }
+        // gradient w.r.t. the initial accumulators = bias gradients (deltagru.py:165-170)
+        G.db[0] += C.gr; G.db[1] += C.gz; G.db[2] += C.gn; G.db[3] += C.gnh;
+    }
+    const int P4 = L.P + kLossCols;
+    __syncthreads();
+    delta_write_partials<TRES>(smem + id.wave * P4, L, G, lane, col);
+    __syncthreads();
+    float* prow = a.partials + (size_t)blockIdx.x * P4;
+    for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+        float v = smem[i];
+        for (int wv = 1; wv < id.nwb; ++wv) v += smem[wv * P4 + i];
+        prow[i] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// launchers
+// -------------------------------------------------------------------------------------------------
+static size_t delta_lds_bytes(int P, int waves, bool reduce) {
+    size_t n = ((size_t)pad4(P) + kDTabFloats + (size_t)waves * 2 * (4 * kDStride + 4 * kChunkPad)) * sizeof(float);
+    if (reduce && n < reduce_scratch_bytes(P, waves)) n = reduce_scratch_bytes(P, waves);
+    return n;
+}
+static LaunchShape delta_bwd_shape(int ngroups) { return persistent_shape(ngroups, 4, 4); }
+
+template <bool TRES>
+static int delta_launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
+    const LaunchShape ls = persistent_shape(a.ngroups, 8);
+    const size_t lds = delta_lds_bytes(P, ls.waves, false);
+    auto k = delta_fwd_kernel<TRES>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <bool TRES>
+static int delta_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
+    if (a.dx != nullptr) return ODPD_EUNSUPPORTED;   // dL/dx of a delta backbone is not implemented
+    if (a.partials == nullptr) return ODPD_EINVAL;
+    const LaunchShape ls = delta_bwd_shape(a.ngroups);
+    const size_t lds = delta_lds_bytes(P, ls.waves, true);
+    auto k = delta_bwd_kernel<TRES>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
+    const int P = delta_layout(m->hidden, tres).P;
+    return tres ? delta_launch_fwd<true>(st, a, P) : delta_launch_fwd<false>(st, a, P);
+}
+int delta_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
+    const int P = delta_layout(m->hidden, tres).P;
+    return tres ? delta_launch_bwd<true>(st, a, P) : delta_launch_bwd<false>(st, a, P);
+}
+int delta_family_rows(const odpd_model_t* m, int B) {
+    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    return delta_bwd_shape(num_groups(B, 1)).grid;
+}
+
+}  // namespace odpd

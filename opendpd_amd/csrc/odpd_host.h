@@ -98,5 +98,8 @@ int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, 
 int lstm_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_rows(const odpd_model_t* m, int B);
+int delta_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int delta_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int delta_family_rows(const odpd_model_t* m, int B);
 
 }  // namespace odpd

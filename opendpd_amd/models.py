@@ -42,6 +42,12 @@ class CoreModel(nn.Module):
             self.backbone = B.LSTM(input_size=input_size, **kw)
         elif backbone_type == "vdlstm":
             self.backbone = B.VDLSTM(input_size=input_size, **kw)
+        elif backbone_type == "deltagru":
+            self.backbone = B.DeltaGRU(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers, thx=thx,
+                                       thh=thh, bias=True)
+        elif backbone_type == "deltagru_tcnskip":
+            self.backbone = B.TResDeltaGRU(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers,
+                                           thx=thx, thh=thh, bias=True)
         elif backbone_type in REFERENCE_BACKBONES:
             raise NotImplementedError(f"backbone '{backbone_type}' is a reference registry name that this build "
                                       f"does not provide as a HIP kernel yet")

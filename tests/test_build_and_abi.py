@@ -38,14 +38,15 @@ def test_param_counts_match_reference():
 
 @pytest.mark.parametrize("name,bb", [("gru_h11", "gru"), ("dgru_h13", "dgru"), ("dgru_h23", "dgru"),
                                      ("qgru_h10", "qgru"), ("qgru_amp1_h10", "qgru_amp1"),
-                                     ("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm")])
+                                     ("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm"),
+                                     ("deltagru_h15_th", "deltagru"), ("tres_h15_th", "deltagru_tcnskip")])
 def test_registry_init_is_bit_identical_to_reference(name, bb):
     """Same seed -> same RNG consumption -> identical initial state dict (keys, order, values)."""
     from opendpd_amd import CoreModel
     from tests.golden_util import Fixture
     fx = Fixture(name)
     torch.manual_seed(0)
-    net = CoreModel(2, fx.meta["hidden"], 1, bb)
+    net = CoreModel(2, fx.meta["hidden"], 1, bb, thx=fx.meta.get("thx", 0), thh=fx.meta.get("thh", 0))
     sd = net.state_dict()
     assert list(sd.keys()) == fx.keys("sd")
     for k in sd:
