@@ -128,8 +128,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=dev)
+        from opendpd_amd import dist as odist
+        odist.init("nccl", device=dev)     # one process per GPU, RCCL over xGMI
         dist = dist_mod
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
 

@@ -128,9 +128,8 @@ class FusedAdamW:
 
     def allreduce_grad(self):
         """The ONE collective of the data-parallel step: sum of P+4 floats (gradient + loss partial)."""
-        if self.world_size() > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.process_group)
+        from .dist import allreduce_sum_
+        allreduce_sum_(self.grad, self.process_group)
 
     def apply(self, max_norm):
         """clip (max_norm, 0 = off) + AdamW on the flat buffers; self.grad must hold the global gradient."""
