@@ -5,12 +5,13 @@
 using namespace odpd;
 
 namespace {
-enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA };
+enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET };
 inline Family family_of(int bb) {
     switch (bb) {
     case ODPD_GRU: case ODPD_DGRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return FAM_GRU;
     case ODPD_LSTM: case ODPD_VDLSTM: return FAM_LSTM;
     case ODPD_DELTAGRU: case ODPD_TRES_DELTAGRU: return FAM_DELTA;
+    case ODPD_PGJANET: return FAM_JANET;
     default: return FAM_NONE;
     }
 }
@@ -62,6 +63,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     case FAM_GRU: return (int64_t)num_groups(B, R) * num_ckpt(T) * 64;
     case FAM_LSTM: return (int64_t)num_groups(B, R) * num_ckpt(T) * 128;   // h and c
     case FAM_DELTA: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 7 * 64 : (int64_t)ODPD_EUNSUPPORTED;
+    case FAM_JANET: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 64 : (int64_t)ODPD_EUNSUPPORTED;
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -72,6 +74,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_GRU: return gru_family_rows(m, B, fused ? 1 : 0, T);
     case FAM_LSTM: return fused ? (int64_t)ODPD_EUNSUPPORTED : lstm_family_rows(m, B);
     case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B);
+    case FAM_JANET: return fused ? (int64_t)ODPD_EUNSUPPORTED : janet_family_rows(m, B);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -85,6 +88,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_GRU: return gru_family_fwd((hipStream_t)stream, m, a);
     case FAM_LSTM: return lstm_family_fwd((hipStream_t)stream, m, a);
     case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
+    case FAM_JANET: return janet_family_fwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -104,6 +108,9 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_DELTA:
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return delta_family_bwd((hipStream_t)stream, m, a);
+    case FAM_JANET:
+        if (!ckpt && a.nck > 1) return ODPD_EINVAL;
+        return janet_family_bwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }

@@ -1,0 +1,313 @@
+// janet_family.hip — persistent-RNN kernels for the PGJANET backbone (backbones/pgjanet.py:5-84).
+// Per step (pgjanet.py:33-72):  amp = |x|, (cos,sin) = (I,Q)/amp  [the reference takes cos/sin of atan2(Q,I)],
+//   a = tanh(W_a [h,amp] + b), p1 = tanh(W_p1 [h,cos] + b), p2 = tanh(W_p2 [h,sin] + b),
+//   u = a p1 p2 (1-a)(1-p1)(1-p2),  f = s(W_f [h,u] + b), g = tanh(W_g [h,u] + b),  h' = f h + (1-f) g,  y = W_o h' + b.
+// One 16-lane row per sequence (H <= 16).  The seven HxH blocks (W_a,W_p1,W_p2,W_f,W_g acting on h; W_f,W_g acting on u)
+// and their transposes live in LDS rotated-quad tables and are streamed per use (ds_read_b128 + 4 DPP FMAs),
+// so no weight matrix is pinned in registers.  BPTT: checkpoint of h every kCkptStride steps + block recompute;
+// weight gradients of the HxH blocks by exact-fp32 MFMA.  dL/dx is not implemented (PGJANET is used as a PA/DPD model
+// trained directly, never as the frozen PA of a cascade in the reference scripts).
+#include "odpd_seq.h"
+
+namespace odpd {
+
+struct JanetLayout { int H, o_wa, o_ba, o_wp1, o_bp1, o_wp2, o_bp2, o_wf, o_bf, o_wg, o_bg, o_wo, o_bo, P; };
+__host__ __device__ inline JanetLayout janet_layout(int H) {
+    JanetLayout L; L.H = H; int o = 0;
+    L.o_wa = o; o += H * (H + 1); L.o_ba = o; o += H;
+    L.o_wp1 = o; o += H * (H + 1); L.o_bp1 = o; o += H;
+    L.o_wp2 = o; o += H * (H + 1); L.o_bp2 = o; o += H;
+    L.o_wf = o; o += 2 * H * H; L.o_bf = o; o += H;
+    L.o_wg = o; o += 2 * H * H; L.o_bg = o; o += H;
+    L.o_wo = o; o += 2 * H; L.o_bo = o; o += 2;
+    L.P = o;
+    return L;
+}
+// table rows: 0 a_h, 1 p1_h, 2 p2_h, 3 f_h, 4 g_h, 5 f_u, 6 g_u; +7 = transposed
+constexpr int kJRows = 14, kJTabFloats = kJRows * 4 * 64 * 4;
+
+template <bool WITH_T>
+__device__ __forceinline__ void fill_janet_tabs(float* tab, const float* pl, const JanetLayout& L, int lane, int wave, int nwb) {
+    const int H = L.H, col = lane & 15, o = col, dir = rot_dir(col);
+    float4* t4 = reinterpret_cast<float4*>(tab);
+    for (int idx = wave; idx < kJRows * 4; idx += nwb) {
+        const int tr = idx >> 2, q = idx & 3;
+        const bool transposed = tr >= 7;
+        if (!WITH_T && transposed) continue;
+        const int r = transposed ? tr - 7 : tr;
+        // block r: base offset, row stride, column offset inside the reference weight
+        const int base = r == 0 ? L.o_wa : r == 1 ? L.o_wp1 : r == 2 ? L.o_wp2 : (r == 3 || r == 5) ? L.o_wf : L.o_wg;
+        const int ld = r < 3 ? H + 1 : 2 * H, coff = r >= 5 ? H : 0;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = (col + dir * (4 * q + e)) & 15;
+            const bool ok = o < H && m < H;
+            v[e] = ok ? pl[base + (transposed ? m * ld + coff + o : o * ld + coff + m)] : 0.0f;
+        }
+        t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+}
+
+struct JanetW { float sa, sp1, sp2, ba, bp1, bp2, bf, bg, wo[2], bo[2]; };   // scalar-input columns, biases, head
+__device__ __forceinline__ void load_janet_w(JanetW& w, const float* pl, const JanetLayout& L, int col) {
+    const int H = L.H, o = col;
+    const bool vo = o < H;
+    w.sa = vo ? pl[L.o_wa + o * (H + 1) + H] : 0.f; w.sp1 = vo ? pl[L.o_wp1 + o * (H + 1) + H] : 0.f;
+    w.sp2 = vo ? pl[L.o_wp2 + o * (H + 1) + H] : 0.f;
+    w.ba = vo ? pl[L.o_ba + o] : 0.f; w.bp1 = vo ? pl[L.o_bp1 + o] : 0.f; w.bp2 = vo ? pl[L.o_bp2 + o] : 0.f;
+    w.bf = vo ? pl[L.o_bf + o] : 0.f; w.bg = vo ? pl[L.o_bg + o] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        w.wo[c] = vo ? pl[L.o_wo + c * H + o] : 0.f;
+        w.bo[c] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pl[L.o_bo + c])));
+    }
+}
+
+__device__ __forceinline__ void janet_inputs(float2 xv, float& amp, float& ct, float& st) {
+    const float a2 = __builtin_fmaf(xv.x, xv.x, xv.y * xv.y);
+    amp = __builtin_amdgcn_sqrtf(a2);
+    const float ia = fast_rcp(amp);
+    ct = xv.x * ia; st = xv.y * ia;
+}
+
+// forward step; padded lanes (o >= H) have all-zero weights: a=p1=p2=0 -> u=0, f=0.5, g=0 -> h stays 0
+__device__ __forceinline__ void janet_cell_fwd(const JanetW& w, const float4* tlane, float amp, float ct, float st, float& h,
+                                               float& an, float& p1, float& p2, float& u, float& f, float& g) {
+    an = tanhf_(tab_rotdot<1>(__builtin_fmaf(w.sa, amp, w.ba), tlane, 0, h));
+    p1 = tanhf_(tab_rotdot<1>(__builtin_fmaf(w.sp1, ct, w.bp1), tlane, 1, h));
+    p2 = tanhf_(tab_rotdot<1>(__builtin_fmaf(w.sp2, st, w.bp2), tlane, 2, h));
+    u = (an * p1 * p2) * ((1.0f - an) * (1.0f - p1) * (1.0f - p2));
+    float pf = tab_rotdot<1>(w.bf, tlane, 3, h), pg = tab_rotdot<1>(w.bg, tlane, 4, h);
+    pf = tab_rotdot<1>(pf, tlane, 5, u); pg = tab_rotdot<1>(pg, tlane, 6, u);
+    f = sigmoidf_(pf); g = tanhf_(pg);
+    h = __builtin_fmaf(f, h - g, g);   // f h + (1 - f) g
+}
+
+// -------------------------------------------------------------------------------------------------
+template <int dummy = 0>
+__global__ __launch_bounds__(kMaxThreads) void janet_fwd_kernel(SeqArgs a) {
+    constexpr int SPW = 4, S = kCkptStride;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LaneId id = lane_id<1>();
+    const int lane = id.lane, col = id.col, s = id.s;
+    const JanetLayout L = janet_layout(a.H);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_janet_tabs<false>(tab, pl, L, lane, id.wave, id.nwb);
+    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    float2* xs = reinterpret_cast<float2*>(tab + kJTabFloats) + id.wave * (2 * SPW * kChunkPad);
+    float2* ys = xs + SPW * kChunkPad;
+    JanetW w;
+    load_janet_w(w, pl, L, col);
+    const int nwaves = gridDim.x * id.nwb;
+    for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * SPW;
+        float h = 0.0f;
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+            wave_lds_fence();
+            for (int tt = 0; tt < len; ++tt) {
+                float amp, ct, st, an, p1, p2, u, f, g;
+                janet_inputs(xs[s * kChunkPad + tt], amp, ct, st);
+                janet_cell_fwd(w, opaque(tlane), amp, ct, st, h, an, p1, p2, u, f, g);
+                const float y0 = row_sum16(w.wo[0] * h) + w.bo[0], y1 = row_sum16(w.wo[1] * h) + w.bo[1];
+                if (col == 0) ys[s * kChunkPad + tt] = make_float2(y0, y1);
+                const int t1 = t0 + tt + 1;
+                if (a.ckpt != nullptr && (t1 % S) == 0 && t1 < a.T) a.ckpt[((size_t)grp * a.nck + t1 / S) * 64 + lane] = h;
+            }
+            wave_lds_fence();
+            stage_out<SPW>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+            wave_lds_fence();
+        }
+    }
+}
+
+struct JanetGrad {
+    f32x4 t[7];                 // dW blocks in table order (a_h, p1_h, p2_h, f_h, g_h, f_u, g_u)
+    float ds[3], db[5];         // scalar-input columns (amp, cos, sin) and biases (a, p1, p2, f, g)
+    float dwo[2], dbo[2];
+    __device__ __forceinline__ void zero() {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 7; ++i) t[i] = z4;
+        ds[0] = ds[1] = ds[2] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) db[i] = 0.f;
+        dwo[0] = dwo[1] = dbo[0] = dbo[1] = 0.f;
+    }
+};
+
+template <bool FULL>
+__device__ __forceinline__ void janet_bwd_block(const SeqArgs& a, const JanetW& w, const float4* tlane, JanetGrad& G,
+                                                const LaneId& id, const float2* xs, const float2* dys, int tloc, int nstep,
+                                                float h, float& dh) {
+    constexpr int S = kCkptStride;
+    const int s = id.s;
+    float hp_s[S], an_s[S], p1_s[S], p2_s[S], u_s[S], f_s[S], g_s[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        if (FULL || i < nstep) {
+            float amp, ct, st;
+            janet_inputs(xs[s * kChunkPad + tloc + i], amp, ct, st);
+            hp_s[i] = h;
+            janet_cell_fwd(w, opaque(tlane), amp, ct, st, h, an_s[i], p1_s[i], p2_s[i], u_s[i], f_s[i], g_s[i]);
+        }
+    }
+#pragma unroll
+    for (int i = S - 1; i >= 0; --i) {
+        if (FULL || i < nstep) {
+            const int tt = tloc + i;
+            const float2 dyv = dys[s * kChunkPad + tt];
+            float amp, ct, st;
+            janet_inputs(xs[s * kChunkPad + tt], amp, ct, st);
+            const float hp = hp_s[i], f = f_s[i], g = g_s[i], u = u_s[i];
+            const float ht = __builtin_fmaf(f, hp - g, g);
+            const float dht = dh + __builtin_fmaf(dyv.x, w.wo[0], dyv.y * w.wo[1]);
+            G.dwo[0] = __builtin_fmaf(dyv.x, ht, G.dwo[0]); G.dwo[1] = __builtin_fmaf(dyv.y, ht, G.dwo[1]);
+            G.dbo[0] += dyv.x; G.dbo[1] += dyv.y;
+            const float dfp = (dht * (hp - g)) * (f * (1.0f - f));
+            const float dgp = (dht * (1.0f - f)) * __builtin_fmaf(-g, g, 1.0f);
+            G.db[3] += dfp; G.db[4] += dgp;
+            G.t[3] = mfma4(dfp, hp, G.t[3]); G.t[4] = mfma4(dgp, hp, G.t[4]);
+            G.t[5] = mfma4(dfp, u, G.t[5]); G.t[6] = mfma4(dgp, u, G.t[6]);
+            const float4* tl = opaque(tlane);
+            float dhp = tab_rotdot<1>(dht * f, tl, 7 + 3, dfp);
+            dhp = tab_rotdot<1>(dhp, tl, 7 + 4, dgp);
+            float du = tab_rotdot<1>(0.0f, tl, 7 + 5, dfp);
+            du = tab_rotdot<1>(du, tl, 7 + 6, dgp);
+            const float an = an_s[i], p1 = p1_s[i], p2 = p2_s[i];
+            const float Aa = an * (1.0f - an), Ab = p1 * (1.0f - p1), Ac = p2 * (1.0f - p2);
+            const float dap = (du * (1.0f - 2.0f * an) * Ab * Ac) * __builtin_fmaf(-an, an, 1.0f);
+            const float dbp = (du * Aa * (1.0f - 2.0f * p1) * Ac) * __builtin_fmaf(-p1, p1, 1.0f);
+            const float dcp = (du * Aa * Ab * (1.0f - 2.0f * p2)) * __builtin_fmaf(-p2, p2, 1.0f);
+            G.db[0] += dap; G.db[1] += dbp; G.db[2] += dcp;
+            G.ds[0] = __builtin_fmaf(dap, amp, G.ds[0]); G.ds[1] = __builtin_fmaf(dbp, ct, G.ds[1]);
+            G.ds[2] = __builtin_fmaf(dcp, st, G.ds[2]);
+            G.t[0] = mfma4(dap, hp, G.t[0]); G.t[1] = mfma4(dbp, hp, G.t[1]); G.t[2] = mfma4(dcp, hp, G.t[2]);
+            dhp = tab_rotdot<1>(dhp, tl, 7 + 0, dap);
+            dhp = tab_rotdot<1>(dhp, tl, 7 + 1, dbp);
+            dhp = tab_rotdot<1>(dhp, tl, 7 + 2, dcp);
+            dh = dhp;
+        }
+    }
+}
+
+__device__ __forceinline__ void janet_write_partials(float* prow, const JanetLayout& L, JanetGrad& G, int lane, int col) {
+    const int H = L.H, o = col, seq = lane >> 4, g4 = lane >> 4, c = lane & 15;
+    for (int i = lane; i < kLossCols; i += 64) prow[L.P + i] = 0.f;
+    const int base[7] = {L.o_wa, L.o_wp1, L.o_wp2, L.o_wf, L.o_wg, L.o_wf, L.o_wg};
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const int ld = r < 3 ? H + 1 : 2 * H, coff = r >= 5 ? H : 0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * g4 + rr;
+            if (i < H && c < H) prow[base[r] + i * ld + coff + c] = G.t[r][rr];
+        }
+    }
+    float ds[3], db[5];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ds[k] = across_seqs<1>(G.ds[k]);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) db[k] = across_seqs<1>(G.db[k]);
+    const float w0 = across_seqs<1>(G.dwo[0]), w1 = across_seqs<1>(G.dwo[1]);
+    const float b0 = across_seqs<1>(G.dbo[0]), b1 = across_seqs<1>(G.dbo[1]);
+    if (seq == 0 && o < H) {
+        prow[L.o_wa + o * (H + 1) + H] = ds[0]; prow[L.o_wp1 + o * (H + 1) + H] = ds[1]; prow[L.o_wp2 + o * (H + 1) + H] = ds[2];
+        prow[L.o_ba + o] = db[0]; prow[L.o_bp1 + o] = db[1]; prow[L.o_bp2 + o] = db[2];
+        prow[L.o_bf + o] = db[3]; prow[L.o_bg + o] = db[4];
+        prow[L.o_wo + o] = w0; prow[L.o_wo + H + o] = w1;
+    }
+    if (lane == 0) { prow[L.o_bo] = b0; prow[L.o_bo + 1] = b1; }
+}
+
+template <int dummy = 0>
+__global__ __launch_bounds__(kMaxThreads, 2) void janet_bwd_kernel(SeqArgs a) {
+    constexpr int SPW = 4, S = kCkptStride;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LaneId id = lane_id<1>();
+    const int lane = id.lane, col = id.col;
+    const JanetLayout L = janet_layout(a.H);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_janet_tabs<true>(tab, pl, L, lane, id.wave, id.nwb);
+    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    float2* xs = reinterpret_cast<float2*>(tab + kJTabFloats) + id.wave * (2 * SPW * kChunkPad);
+    float2* dys = xs + SPW * kChunkPad;
+    JanetW w;
+    load_janet_w(w, pl, L, col);
+    JanetGrad G;
+    G.zero();
+    const int nwaves = gridDim.x * id.nwb;
+    for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * SPW;
+        float dh = 0.0f;
+        int cur_chunk = -1;
+        for (int blk = a.nck - 1; blk >= 0; --blk) {
+            const int tb = blk * S, nstep = min(S, a.T - tb);
+            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            if (chunk != cur_chunk) {
+                wave_lds_fence();
+                const int len = min(kChunk, a.T - t0);
+                stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+                stage_in<SPW>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                wave_lds_fence();
+                cur_chunk = chunk;
+            }
+            const float h0 = blk ? a.ckpt[((size_t)grp * a.nck + blk) * 64 + lane] : 0.0f;
+            if (nstep == S) janet_bwd_block<true>(a, w, tlane, G, id, xs, dys, tb - t0, nstep, h0, dh);
+            else janet_bwd_block<false>(a, w, tlane, G, id, xs, dys, tb - t0, nstep, h0, dh);
+        }
+    }
+    const int P4 = L.P + kLossCols;
+    __syncthreads();
+    janet_write_partials(smem + id.wave * P4, L, G, lane, col);
+    __syncthreads();
+    float* prow = a.partials + (size_t)blockIdx.x * P4;
+    for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+        float v = smem[i];
+        for (int wv = 1; wv < id.nwb; ++wv) v += smem[wv * P4 + i];
+        prow[i] = v;
+    }
+}
+
+static size_t janet_lds_bytes(int P, int waves, bool reduce) {
+    size_t n = ((size_t)pad4(P) + kJTabFloats + (size_t)waves * 2 * (2 * 4 * kChunkPad)) * sizeof(float);
+    if (reduce && n < reduce_scratch_bytes(P, waves)) n = reduce_scratch_bytes(P, waves);
+    return n;
+}
+static LaunchShape janet_bwd_shape(int ngroups) { return persistent_shape(ngroups, 8, 8); }
+
+int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    const int P = janet_layout(m->hidden).P;
+    const LaunchShape ls = persistent_shape(a.ngroups, 16);
+    const size_t lds = janet_lds_bytes(P, ls.waves, false);
+    auto k = janet_fwd_kernel<0>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+int janet_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (a.dx != nullptr) return ODPD_EUNSUPPORTED;
+    if (a.partials == nullptr) return ODPD_EINVAL;
+    const int P = janet_layout(m->hidden).P;
+    const LaunchShape ls = janet_bwd_shape(a.ngroups);
+    const size_t lds = janet_lds_bytes(P, ls.waves, true);
+    auto k = janet_bwd_kernel<0>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+int janet_family_rows(const odpd_model_t* m, int B) {
+    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    return janet_bwd_shape(num_groups(B, 1)).grid;
+}
+
+}  // namespace odpd

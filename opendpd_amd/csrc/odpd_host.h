@@ -101,5 +101,8 @@ int lstm_family_rows(const odpd_model_t* m, int B);
 int delta_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int delta_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int delta_family_rows(const odpd_model_t* m, int B);
+int janet_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int janet_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int janet_family_rows(const odpd_model_t* m, int B);
 
 }  // namespace odpd

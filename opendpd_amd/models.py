@@ -48,6 +48,9 @@ class CoreModel(nn.Module):
         elif backbone_type == "deltagru_tcnskip":
             self.backbone = B.TResDeltaGRU(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers,
                                            thx=thx, thh=thh, bias=True)
+        elif backbone_type == "pgjanet":
+            # reference defect: models.py:109-114 passes window_size= to a ctor that has no such argument
+            self.backbone = B.PGJANET(hidden_size=hidden_size, output_size=2, bias=True)
         elif backbone_type in REFERENCE_BACKBONES:
             raise NotImplementedError(f"backbone '{backbone_type}' is a reference registry name that this build "
                                       f"does not provide as a HIP kernel yet")

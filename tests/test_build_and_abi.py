@@ -39,7 +39,8 @@ def test_param_counts_match_reference():
 @pytest.mark.parametrize("name,bb", [("gru_h11", "gru"), ("dgru_h13", "dgru"), ("dgru_h23", "dgru"),
                                      ("qgru_h10", "qgru"), ("qgru_amp1_h10", "qgru_amp1"),
                                      ("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm"),
-                                     ("deltagru_h15_th", "deltagru"), ("tres_h15_th", "deltagru_tcnskip")])
+                                     ("deltagru_h15_th", "deltagru"), ("tres_h15_th", "deltagru_tcnskip"),
+                                     ("pgjanet_h11", "pgjanet")])
 def test_registry_init_is_bit_identical_to_reference(name, bb):
     """Same seed -> same RNG consumption -> identical initial state dict (keys, order, values)."""
     from opendpd_amd import CoreModel

@@ -1,0 +1,92 @@
+"""GPU parity of the PGJANET (and TCNN) kernels against the reference golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import Fixture, rel_err
+
+pytestmark = pytest.mark.gpu
+FWD_TOL, GRAD_TOL = 2e-5, 3e-4
+GOLDEN = [("pgjanet_h11", "pgjanet"), ("tcnn_c35", "tcnn")]
+
+
+def _supported(bb):
+    from opendpd_amd.models import CoreModel
+    try:
+        CoreModel(2, 8, 1, bb)
+        return True
+    except NotImplementedError:
+        return False
+
+
+def _model(fx, bb):
+    from opendpd_amd import CoreModel
+    net = CoreModel(2, fx.meta["hidden"], 1, bb)
+    net.load_state_dict({k: torch.from_numpy(fx["sd/" + k]) for k in fx.keys("sd")})
+    return net.cuda()
+
+
+@pytest.mark.parametrize("name,bb", GOLDEN)
+def test_golden_forward_backward(name, bb):
+    if not _supported(bb):
+        pytest.skip(f"{bb} kernel not built yet")
+    fx = Fixture(name)
+    net = _model(fx, bb)
+    y = net(torch.from_numpy(fx["x"]).cuda())
+    assert rel_err(y.detach().cpu().numpy(), fx["y"]) < FWD_TOL
+    loss = torch.nn.functional.mse_loss(y, torch.from_numpy(fx["tgt"]).cuda())
+    assert abs(loss.item() - fx["losses"][0]) < 1e-5 * max(1.0, fx["losses"][0])
+    loss.backward()
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), fx["g/" + k]) < GRAD_TOL, k
+    with torch.no_grad():
+        ya = net(torch.from_numpy(fx["xa"]).cuda())
+    assert rel_err(ya.cpu().numpy(), fx["ya"]) < FWD_TOL
+
+
+@pytest.mark.parametrize("bb,H", [("pgjanet", 11), ("pgjanet", 8), ("pgjanet", 16), ("tcnn", 35), ("tcnn", 8), ("tcnn", 30)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 32), (7, 33), (5, 200), (66, 63)])
+def test_against_oracle_ragged(bb, H, B, T):
+    if not _supported(bb):
+        pytest.skip(f"{bb} kernel not built yet")
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 100 + B + T)
+    net = CoreModel(2, H, 1, bb).cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    rng = np.random.RandomState(B * 17 + T)
+    amp = 0.05 + 0.85 * rng.rand(B, T, 1)
+    ph = 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    dy = rng.randn(B, T, 2).astype(np.float32)
+    y = net(torch.from_numpy(x).cuda())
+    y.backward(torch.from_numpy(dy).cuda())
+    o = Oracle("f32")
+    m = make_model(bb, H)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    yo, _ = o.forward(m, p, x)
+    go, _ = o.backward(m, p, x, dy, need_dx=False)
+    g = np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()])
+    assert rel_err(y.detach().cpu().numpy(), yo) < FWD_TOL
+    assert rel_err(g, go) < GRAD_TOL
+
+
+@pytest.mark.parametrize("name,bb", GOLDEN)
+def test_train_steps_follow_reference(name, bb):
+    if not _supported(bb):
+        pytest.skip(f"{bb} kernel not built yet")
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    fx = Fixture(name)
+    net = _model(fx, bb)
+    opt = FusedAdamW(net, lr=fx.meta["lr"])
+    x = torch.from_numpy(fx["x"]).cuda()
+    t = torch.from_numpy(fx["tgt"]).cuda()
+    names = fx.keys("sd")
+    for s in range(1, 4):
+        loss = fused_train_step(opt, x, t, "l2", fx.meta["clip"])
+        assert abs(loss.item() - fx["losses"][s - 1]) < 2e-5 * max(1.0, fx["losses"][s - 1])
+        got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in net.parameters()])
+        assert rel_err(got, fx.flat(f"p{s}", names)) < 3e-5, s
