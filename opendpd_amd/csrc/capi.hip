@@ -5,13 +5,14 @@
 using namespace odpd;
 
 namespace {
-enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET };
+enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN };
 inline Family family_of(int bb) {
     switch (bb) {
     case ODPD_GRU: case ODPD_DGRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return FAM_GRU;
     case ODPD_LSTM: case ODPD_VDLSTM: return FAM_LSTM;
     case ODPD_DELTAGRU: case ODPD_TRES_DELTAGRU: return FAM_DELTA;
     case ODPD_PGJANET: return FAM_JANET;
+    case ODPD_TCNN: return FAM_TCNN;
     default: return FAM_NONE;
     }
 }
@@ -57,6 +58,7 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
 
 extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
+    if (family_of(m->backbone) == FAM_TCNN) return 0;   // not recurrent: nothing to checkpoint
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m->backbone)) {
@@ -75,6 +77,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_LSTM: return fused ? (int64_t)ODPD_EUNSUPPORTED : lstm_family_rows(m, B);
     case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B);
     case FAM_JANET: return fused ? (int64_t)ODPD_EUNSUPPORTED : janet_family_rows(m, B);
+    case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -89,6 +92,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_LSTM: return lstm_family_fwd((hipStream_t)stream, m, a);
     case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
     case FAM_JANET: return janet_family_fwd((hipStream_t)stream, m, a);
+    case FAM_TCNN: return tcnn_fwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -111,6 +115,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_JANET:
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return janet_family_bwd((hipStream_t)stream, m, a);
+    case FAM_TCNN: return tcnn_bwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }

@@ -104,5 +104,8 @@ int delta_family_rows(const odpd_model_t* m, int B);
 int janet_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int janet_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int janet_family_rows(const odpd_model_t* m, int B);
+int tcnn_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int tcnn_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int tcnn_rows(const odpd_model_t* m, int B, int T);
 
 }  // namespace odpd

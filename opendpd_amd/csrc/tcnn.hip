@@ -1,0 +1,211 @@
+// tcnn.hip — kernels for the TCNN backbone (backbones/tcnn.py:5-97):
+//   feat = [I,Q,a,a^3,sin,cos] -> Conv1d(6->C,k1,bias) -> Hardswish -> 4 x [depthwise Conv1d(C,C,k5,dil d,pad 2d,no bias)
+//   -> Hardswish], d = 1,2,4,8 -> Conv1d(C->2,k1,no bias);  y = net + [I,Q]                       (tcnn.py:82-96)
+// The network is separable per channel except for the last 1x1 sum, and non-recurrent: time is the parallel axis.
+//   forward : one workgroup per (sequence, time tile); thread = time step (tile + 32-step halo each side, receptive
+//             field 30); channels are looped INSIDE, two LDS line buffers per stage ping-pong, y accumulates in registers.
+//   backward: one workgroup per (channel, slice of the batch); for every sequence of the slice the five stages of that
+//             channel are recomputed into LDS, back-propagated, and the channel's 29 parameter gradients accumulate in
+//             per-thread registers; one block reduction at the end -> columns of partial row `slice`.
+// Zero padding semantics: every stage's activation is 0 outside [0,T) (PyTorch pads each conv input).  dL/dx is not
+// implemented (needs a cross-channel sum; TCNN is not used as a frozen PA in the reference scripts).
+#include "odpd_seq.h"
+
+namespace odpd {
+
+struct TcnnLayout { int C, o_w0, o_b0, o_dw[4], o_w5, P; };
+__host__ __device__ inline TcnnLayout tcnn_layout(int C) {
+    TcnnLayout L; L.C = C; int o = 0;
+    L.o_w0 = o; o += 6 * C; L.o_b0 = o; o += C;
+    for (int l = 0; l < 4; ++l) { L.o_dw[l] = o; o += 5 * C; }
+    L.o_w5 = o; o += 2 * C;
+    L.P = o;
+    return L;
+}
+constexpr int kTHalo = 32;   // >= receptive-field radius 2*(1+2+4+8) = 30
+
+struct TcnnTile { int nthreads, tile, ntiles; };
+inline TcnnTile tcnn_tiling(int T) {
+    TcnnTile t;
+    int want = (T < 960 ? T : 960) + 2 * kTHalo;
+    int nw = (want + 63) / 64; if (nw > 16) nw = 16;
+    t.nthreads = 64 * nw; t.tile = t.nthreads - 2 * kTHalo; t.ntiles = (T + t.tile - 1) / t.tile;
+    return t;
+}
+
+__device__ __forceinline__ float hsg(float v) { return v < -3.0f ? 0.0f : (v <= 3.0f ? __builtin_fmaf(v, 1.0f / 3.0f, 0.5f) : 1.0f); }
+__device__ __forceinline__ float ldz(const float* buf, int i, int n) { return (i >= 0 && i < n) ? buf[i] : 0.0f; }
+
+__device__ __forceinline__ void tcnn_feat(float2 xv, bool in, float (&f)[6]) {
+    if (!in) { f[0] = f[1] = f[2] = f[3] = f[4] = f[5] = 0.0f; return; }
+    const float a2 = __builtin_fmaf(xv.x, xv.x, xv.y * xv.y), a = __builtin_amdgcn_sqrtf(a2), ia = fast_rcp(a);
+    f[0] = xv.x; f[1] = xv.y; f[2] = a; f[3] = a2 * a; f[4] = xv.y * ia; f[5] = xv.x * ia;
+}
+
+// grid = (ntiles, B); block = nthreads; LDS = 2 * nthreads floats
+__global__ __launch_bounds__(1024) void tcnn_fwd_kernel(SeqArgs a, int tile) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = blockDim.x, pos = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * tile, t = t0 - kTHalo + pos;
+    const bool in = t >= 0 && t < a.T;
+    const TcnnLayout L = tcnn_layout(a.H);
+    const float* __restrict__ p = a.params;
+    const float2 xv = in ? reinterpret_cast<const float2*>(a.x)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
+    float f[6];
+    tcnn_feat(xv, in, f);
+    float* cur = smem; float* nxt = smem + n;
+    float y0 = 0.0f, y1 = 0.0f;
+    for (int c = 0; c < L.C; ++c) {
+        float v = p[L.o_b0 + c];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
+        float act = in ? hardswishf_(v) : 0.0f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int d = 1 << l;
+            __syncthreads();
+            cur[pos] = act;
+            __syncthreads();
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(cur, pos + d * (k - 2), n), s);
+            act = in ? hardswishf_(s) : 0.0f;
+            float* tsw = cur; cur = nxt; nxt = tsw;
+        }
+        y0 = __builtin_fmaf(p[L.o_w5 + c], act, y0);
+        y1 = __builtin_fmaf(p[L.o_w5 + L.C + c], act, y1);
+    }
+    if (in && pos >= kTHalo && pos < kTHalo + tile)
+        reinterpret_cast<float2*>(a.y)[(size_t)b * a.T + t] = make_float2(y0 + xv.x, y1 + xv.y);
+}
+
+// grid = (C, nslices); block = nthreads; LDS = 10 * nthreads floats (pre and act of 5 stages) + reduction scratch
+__global__ __launch_bounds__(1024) void tcnn_bwd_kernel(SeqArgs a, int tile, int ntiles, int nslices) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = blockDim.x, pos = threadIdx.x, c = blockIdx.x, slice = blockIdx.y;
+    const TcnnLayout L = tcnn_layout(a.H);
+    const float* __restrict__ p = a.params;
+    float* pre = smem;            // pre[l*n + pos], l = 0..4
+    float* act = smem + 5 * n;    // act[l*n + pos]
+    float w0[6], wd[4][5];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w0[i] = p[L.o_w0 + c * 6 + i];
+    const float b0 = p[L.o_b0 + c];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wd[l][k] = p[L.o_dw[l] + c * 5 + k];
+    const float w5a = p[L.o_w5 + c], w5b = p[L.o_w5 + L.C + c];
+    float g_w0[6] = {0, 0, 0, 0, 0, 0}, g_b0 = 0.f, g_wd[4][5], g_w5a = 0.f, g_w5b = 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) g_wd[l][k] = 0.f;
+
+    const int nwork = a.B * ntiles;
+    for (int wk = slice; wk < nwork; wk += nslices) {
+        const int b = wk / ntiles, t0 = (wk % ntiles) * tile, t = t0 - kTHalo + pos;
+        const bool in = t >= 0 && t < a.T, own = in && pos >= kTHalo && pos < kTHalo + tile;
+        const float2 xv = in ? reinterpret_cast<const float2*>(a.x)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
+        const float2 dyv = own ? reinterpret_cast<const float2*>(a.dy)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
+        float f[6];
+        tcnn_feat(xv, in, f);
+        // forward of this channel, all stages kept
+        float v = b0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v = __builtin_fmaf(w0[i], f[i], v);
+        __syncthreads();   // previous work item done with the buffers
+        pre[pos] = v; act[pos] = in ? hardswishf_(v) : 0.0f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int d = 1 << l;
+            __syncthreads();
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) s = __builtin_fmaf(wd[l][k], ldz(act + l * n, pos + d * (k - 2), n), s);
+            pre[(l + 1) * n + pos] = s; act[(l + 1) * n + pos] = in ? hardswishf_(s) : 0.0f;
+        }
+        // backward.  g = dL/d act_l ; gp = dL/d pre_l (masked outside the frame)
+        const float a4 = act[4 * n + pos];
+        g_w5a = __builtin_fmaf(dyv.x, a4, g_w5a); g_w5b = __builtin_fmaf(dyv.y, a4, g_w5b);
+        float g = __builtin_fmaf(dyv.x, w5a, dyv.y * w5b);
+#pragma unroll
+        for (int l = 3; l >= 0; --l) {
+            const int d = 1 << l;
+            const float gp = in ? g * hsg(pre[(l + 1) * n + pos]) : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) g_wd[l][k] = __builtin_fmaf(gp, ldz(act + l * n, pos + d * (k - 2), n), g_wd[l][k]);
+            __syncthreads();
+            pre[(l + 1) * n + pos] = gp;      // pre_{l+1} is no longer needed: reuse it to exchange gp
+            __syncthreads();
+            g = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) g = __builtin_fmaf(wd[l][k], ldz(pre + (l + 1) * n, pos - d * (k - 2), n), g);
+        }
+        const float gp0 = in ? g * hsg(pre[pos]) : 0.0f;
+        g_b0 += gp0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g_w0[i] = __builtin_fmaf(gp0, f[i], g_w0[i]);
+    }
+    // block reduction of the 29 accumulators -> partial row `slice`
+    __syncthreads();
+    float vals[29];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vals[i] = g_w0[i];
+    vals[6] = g_b0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) vals[7 + l * 5 + k] = g_wd[l][k];
+    vals[27] = g_w5a; vals[28] = g_w5b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 29; ++i) {
+        float s = vals[i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) smem[wave * 32 + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 29) {
+        float s = 0.0f;
+        for (int wv = 0; wv < nw; ++wv) s += smem[wv * 32 + threadIdx.x];
+        const int i = threadIdx.x;
+        int col;
+        if (i < 6) col = L.o_w0 + c * 6 + i;
+        else if (i == 6) col = L.o_b0 + c;
+        else if (i < 27) col = L.o_dw[(i - 7) / 5] + c * 5 + (i - 7) % 5;
+        else col = L.o_w5 + (i - 27) * L.C + c;
+        a.partials[(size_t)slice * (L.P + kLossCols) + col] = s;
+    }
+    if (c == 0 && threadIdx.x < kLossCols) a.partials[(size_t)slice * (L.P + kLossCols) + L.P + threadIdx.x] = 0.0f;
+}
+
+static int tcnn_slices(int B, int ntiles, int C) {
+    const int nwork = B * ntiles;
+    int want = (8 * device_cus() + C - 1) / C;     // ~8 blocks per CU overall
+    if (want < 1) want = 1;
+    return nwork < want ? nwork : want;
+}
+
+int tcnn_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (m->hidden > 64) return ODPD_EUNSUPPORTED;
+    const TcnnTile tl = tcnn_tiling(a.T);
+    hipLaunchKernelGGL(tcnn_fwd_kernel, dim3(tl.ntiles, a.B), dim3(tl.nthreads), 2 * tl.nthreads * sizeof(float), st, a, tl.tile);
+    return (int)hipGetLastError();
+}
+int tcnn_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (m->hidden > 64) return ODPD_EUNSUPPORTED;
+    if (a.dx != nullptr) return ODPD_EUNSUPPORTED;
+    if (a.partials == nullptr) return ODPD_EINVAL;
+    const TcnnTile tl = tcnn_tiling(a.T);
+    const int ns = tcnn_slices(a.B, tl.ntiles, m->hidden);
+    size_t lds = (size_t)10 * tl.nthreads * sizeof(float);
+    if (lds < 16 * 32 * sizeof(float)) lds = 16 * 32 * sizeof(float);
+    hipLaunchKernelGGL(tcnn_bwd_kernel, dim3(m->hidden, ns), dim3(tl.nthreads), lds, st, a, tl.tile, tl.ntiles, ns);
+    return (int)hipGetLastError();
+}
+int tcnn_rows(const odpd_model_t* m, int B, int T) {
+    if (m->hidden > 64) return ODPD_EUNSUPPORTED;
+    return tcnn_slices(B, tcnn_tiling(T).ntiles, m->hidden);
+}
+
+}  // namespace odpd

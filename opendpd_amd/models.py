@@ -51,6 +51,8 @@ class CoreModel(nn.Module):
         elif backbone_type == "pgjanet":
             # reference defect: models.py:109-114 passes window_size= to a ctor that has no such argument
             self.backbone = B.PGJANET(hidden_size=hidden_size, output_size=2, bias=True)
+        elif backbone_type == "tcnn":
+            self.backbone = B.TCNN(hidden_channels=hidden_size)
         elif backbone_type in REFERENCE_BACKBONES:
             raise NotImplementedError(f"backbone '{backbone_type}' is a reference registry name that this build "
                                       f"does not provide as a HIP kernel yet")

@@ -40,7 +40,7 @@ def test_param_counts_match_reference():
                                      ("qgru_h10", "qgru"), ("qgru_amp1_h10", "qgru_amp1"),
                                      ("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm"),
                                      ("deltagru_h15_th", "deltagru"), ("tres_h15_th", "deltagru_tcnskip"),
-                                     ("pgjanet_h11", "pgjanet")])
+                                     ("pgjanet_h11", "pgjanet"), ("tcnn_c35", "tcnn")])
 def test_registry_init_is_bit_identical_to_reference(name, bb):
     """Same seed -> same RNG consumption -> identical initial state dict (keys, order, values)."""
     from opendpd_amd import CoreModel
