@@ -227,6 +227,14 @@ def gen_quant():
             with torch.no_grad():
                 d["y_eval"] = qnet(torch.from_numpy(x)).numpy().copy()
             d.update(step_case(qnet, x, tgt))
+            # forward with the parameters reached after the three steps (non-zero biases, decayed scales)
+            qnet.train()
+            with torch.no_grad():
+                d["y_p3_train"] = qnet(torch.from_numpy(x)).numpy().copy()
+            qnet.eval()
+            with torch.no_grad():
+                d["y_p3_eval"] = qnet(torch.from_numpy(x)).numpy().copy()
+            d.update(sd_np(qnet, "sd3"))   # full state (params + buffers) after the steps
             save(f"quant_{bb}_h{H}_w{bits}a{bits}", d)
 
 

@@ -50,6 +50,8 @@ static int feat_dim(int bb) {
 
 int64_t oracle_param_count(const odpd_model_t* m) {
     int64_t H = m->hidden, F = feat_dim(m->backbone);
+    if (m->bits_w > 0 && (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1))
+        return 3 * H * F + 3 * H + 3 + 3 * H * H + 3 * H + 3 + 4 + 2 * H + 2 + 3;   /* + 13 quantiser scales */
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1:
         return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
@@ -786,6 +788,202 @@ static void pgj_seq_bwd(const pgj_layout_t* L, const real* p, int T, const real*
             dx[2 * t + 1] = damp * Q / s->amp + dth * I / a2;
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Quantisation-aware QGRU: quant/__init__.py:20-37 -> quant_envs.py:138-306 applied to qgru.py  */
+/*   INT_Quantizer (quantizers.py:15-85): s = 2^round(log2|scale|); q(x) = round(clamp(x/s,Qn,Qp))*s */
+/*   (clamp BEFORE round, round half to even), straight-through gradient inside the clamp range.   */
+/*   INT_Linear (quant_layers.py:48-85): F.linear(q_a(x), q_w(W), b), bias not quantised; the       */
+/*   16-bit out_quantizer applies to fc_out in eval mode only.                                      */
+/*   Cell (quant/modules/gru.py:43-59) with the shared op quantisers of quant_ops.py.               */
+/* Parameter order = named_parameters() of the quantised model:                                    */
+/*   x2h.{weight,bias,wq.scale,aq.scale,oq.scale}, h2h.{same}, sigmoid.q, tanh.q, add.q, mul.q,     */
+/*   fc_out.{weight,bias,wq.scale,aq.scale,oq.scale}                                                */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int H, F, bits_w, bits_a;
+    int64_t o_wx, o_bx, o_sxw, o_sxa, o_sxo, o_wh, o_bh, o_shw, o_sha, o_sho, o_ssig, o_stanh, o_sadd, o_smul,
+            o_wo, o_bo, o_sow, o_soa, o_soo;
+} qgru_layout_t;
+static void qgru_layout(const odpd_model_t* m, qgru_layout_t* g) {
+    int64_t H = m->hidden, F = 4, o = 0;
+    g->H = (int)H; g->F = (int)F; g->bits_w = m->bits_w; g->bits_a = m->bits_a;
+    g->o_wx = o; o += 3 * H * F; g->o_bx = o; o += 3 * H; g->o_sxw = o++; g->o_sxa = o++; g->o_sxo = o++;
+    g->o_wh = o; o += 3 * H * H; g->o_bh = o; o += 3 * H; g->o_shw = o++; g->o_sha = o++; g->o_sho = o++;
+    g->o_ssig = o++; g->o_stanh = o++; g->o_sadd = o++; g->o_smul = o++;
+    g->o_wo = o; o += 2 * H; g->o_bo = o; o += 2; g->o_sow = o++; g->o_soa = o++; g->o_soo = o++;
+}
+static inline real q_pow2(real scale) {   /* quantizers.py:56-65 */
+    float l = rintf(log2f(fabsf((float)scale)));
+    return (real)ldexp(1.0, (int)l);
+}
+/* returns q(x); *pass = 1 if x/s lies inside [Qn,Qp] (gradient passes), else 0 */
+static inline real q_apply(real x, real s, int bits, real* pass) {
+    real qn = -(real)(1 << (bits - 1)), qp = (real)((1 << (bits - 1)) - 1);
+    real v = x / s;
+    if (pass) *pass = (v >= qn && v <= qp) ? (real)1 : (real)0;
+    v = v < qn ? qn : (v > qp ? qp : v);
+    return (real)rint((double)v) * s;
+}
+typedef struct {
+    real f[4], px[4], hq[MAXH], ph[MAXH];                 /* features, pass masks of act quantisers, q_a(h) */
+    real hp[MAXH], xt[3 * MAXH], ht[3 * MAXH];
+    real p_ar[MAXH], p_az[MAXH], p_an[MAXH], p_ah[MAXH];  /* pass masks of the four add-quantiser uses */
+    real rf[MAXH], zf[MAXH], nf[MAXH];                    /* float sigmoid/tanh outputs (autograd saves these) */
+    real p_r[MAXH], p_z[MAXH], p_n[MAXH];
+    real r[MAXH], z[MAXH], n[MAXH];
+    real p_m1[MAXH], p_m2[MAXH], p_m3[MAXH];
+    real h[MAXH], ho[MAXH], p_ho[MAXH];                   /* new state, q_a(h') for fc_out and its mask */
+} qgru_step_t;
+
+static void qgru_seq_fwd(const odpd_model_t* m, const qgru_layout_t* L, const real* p, int T, const real* x, real* y,
+                         qgru_step_t* S, int eval_mode, const real* qwx, const real* qwh, const real* qwo) {
+    int H = L->H, F = L->F, ba = L->bits_a;
+    real sxa = q_pow2(p[L->o_sxa]), sha = q_pow2(p[L->o_sha]), soa = q_pow2(p[L->o_soa]), soo = q_pow2(p[L->o_soo]);
+    real ssig = q_pow2(p[L->o_ssig]), stanh = q_pow2(p[L->o_stanh]), sadd = q_pow2(p[L->o_sadd]), smul = q_pow2(p[L->o_smul]);
+    real h[MAXH] = {0};
+    qgru_step_t tmp;
+    for (int t = 0; t < T; ++t) {
+        qgru_step_t* s = S ? &S[t] : &tmp;
+        feat_fwd(m->backbone, x[2 * t], x[2 * t + 1], s->f);
+        real fq[4];
+        for (int i = 0; i < F; ++i) fq[i] = q_apply(s->f[i], sxa, ba, &s->px[i]);
+        for (int j = 0; j < H; ++j) { s->hp[j] = h[j]; s->hq[j] = q_apply(h[j], sha, ba, &s->ph[j]); }
+        for (int k = 0; k < 3 * H; ++k) {   /* exact grid sum, then the fp32 bias (matches F.linear bit for bit) */
+            double a = 0, b = 0;
+            for (int i = 0; i < F; ++i) a += (double)fq[i] * (double)qwx[k * F + i];
+            for (int i = 0; i < H; ++i) b += (double)s->hq[i] * (double)qwh[k * H + i];
+            s->xt[k] = (real)a + p[L->o_bx + k];
+            s->ht[k] = (real)b + p[L->o_bh + k];
+        }
+        for (int j = 0; j < H; ++j) {
+            real ar = q_apply(s->xt[j] + s->ht[j], sadd, ba, &s->p_ar[j]);
+            real az = q_apply(s->xt[H + j] + s->ht[H + j], sadd, ba, &s->p_az[j]);
+            s->rf[j] = sigm(ar); s->zf[j] = sigm(az);
+            s->r[j] = q_apply(s->rf[j], ssig, ba, &s->p_r[j]);
+            s->z[j] = q_apply(s->zf[j], ssig, ba, &s->p_z[j]);
+            real m1 = q_apply(s->r[j] * s->ht[2 * H + j], smul, ba, &s->p_m1[j]);
+            real an = q_apply(s->xt[2 * H + j] + m1, sadd, ba, &s->p_an[j]);
+            s->nf[j] = tanhr(an);
+            s->n[j] = q_apply(s->nf[j], stanh, ba, &s->p_n[j]);
+            real m2 = q_apply(s->z[j] * h[j], smul, ba, &s->p_m2[j]);
+            real m3 = q_apply(((real)1 - s->z[j]) * s->n[j], smul, ba, &s->p_m3[j]);
+            s->h[j] = q_apply(m2 + m3, sadd, ba, &s->p_ah[j]);
+        }
+        for (int j = 0; j < H; ++j) { h[j] = s->h[j]; s->ho[j] = q_apply(h[j], soa, ba, &s->p_ho[j]); }
+        for (int c = 0; c < 2; ++c) {
+            double a = 0;
+            for (int j = 0; j < H; ++j) a += (double)s->ho[j] * (double)qwo[c * H + j];
+            real v = (real)a + p[L->o_bo + c];
+            y[2 * t + c] = eval_mode ? q_apply(v, soo, 16, NULL) : v;
+        }
+    }
+}
+static void qgru_seq_bwd(const odpd_model_t* m, const qgru_layout_t* L, const real* p, int T, const real* x, const real* dy,
+                         const qgru_step_t* S, real* dp, real* dx, const real* qwx, const real* qwh, const real* qwo,
+                         real* dqwx, real* dqwh, real* dqwo) {
+    int H = L->H, F = L->F;
+    real dh[MAXH] = {0};
+    for (int t = T - 1; t >= 0; --t) {
+        const qgru_step_t* s = &S[t];
+        real dhn[MAXH];   /* gradient w.r.t. the new state h' */
+        for (int j = 0; j < H; ++j) dhn[j] = dh[j];
+        for (int c = 0; c < 2; ++c) {
+            real d = dy[2 * t + c];
+            dp[L->o_bo + c] += d;
+            for (int j = 0; j < H; ++j) { dqwo[c * H + j] += d * s->ho[j]; dhn[j] += d * qwo[c * H + j] * s->p_ho[j]; }
+        }
+        real dxt[3 * MAXH], dht[3 * MAXH], dhp[MAXH];
+        for (int j = 0; j < H; ++j) {
+            real g = dhn[j] * s->p_ah[j];              /* through q_add(m2 + m3) */
+            real dm2 = g * s->p_m2[j], dm3 = g * s->p_m3[j];
+            real dz = dm2 * s->hp[j] - dm3 * s->n[j];
+            dhp[j] = dm2 * s->z[j];
+            real dn = dm3 * ((real)1 - s->z[j]);
+            real dan = dn * s->p_n[j] * ((real)1 - s->nf[j] * s->nf[j]) * s->p_an[j];
+            dxt[2 * H + j] = dan;
+            real dm1 = dan * s->p_m1[j];
+            real dr = dm1 * s->ht[2 * H + j];
+            dht[2 * H + j] = dm1 * s->r[j];
+            real dar = dr * s->p_r[j] * s->rf[j] * ((real)1 - s->rf[j]) * s->p_ar[j];
+            real daz = dz * s->p_z[j] * s->zf[j] * ((real)1 - s->zf[j]) * s->p_az[j];
+            dxt[j] = dar; dht[j] = dar; dxt[H + j] = daz; dht[H + j] = daz;
+        }
+        real df[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 3 * H; ++k) {
+            dp[L->o_bx + k] += dxt[k]; dp[L->o_bh + k] += dht[k];
+            for (int i = 0; i < F; ++i) {
+                real fq = q_apply(s->f[i], q_pow2(p[L->o_sxa]), L->bits_a, NULL);
+                dqwx[k * F + i] += dxt[k] * fq;
+                df[i] += dxt[k] * qwx[k * F + i] * s->px[i];
+            }
+            for (int i = 0; i < H; ++i) { dqwh[k * H + i] += dht[k] * s->hq[i]; dhp[i] += dht[k] * qwh[k * H + i] * s->ph[i]; }
+        }
+        for (int j = 0; j < H; ++j) dh[j] = dhp[j];
+        if (dx) feat_bwd(m->backbone, x[2 * t], x[2 * t + 1], df, &dx[2 * t], &dx[2 * t + 1]);
+    }
+}
+/* quantised weights and their pass masks (STE to the float master weights) */
+static void qgru_quant_weights(const qgru_layout_t* L, const real* p, real* qwx, real* qwh, real* qwo, real* mx, real* mh, real* mo) {
+    int H = L->H, F = L->F;
+    real sx = q_pow2(p[L->o_sxw]), sh = q_pow2(p[L->o_shw]), so = q_pow2(p[L->o_sow]);
+    for (int i = 0; i < 3 * H * F; ++i) qwx[i] = q_apply(p[L->o_wx + i], sx, L->bits_w, mx ? &mx[i] : NULL);
+    for (int i = 0; i < 3 * H * H; ++i) qwh[i] = q_apply(p[L->o_wh + i], sh, L->bits_w, mh ? &mh[i] : NULL);
+    for (int i = 0; i < 2 * H; ++i) qwo[i] = q_apply(p[L->o_wo + i], so, L->bits_w, mo ? &mo[i] : NULL);
+}
+static int is_qat(const odpd_model_t* m) { return m->bits_w > 0 && (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1); }
+
+/* forward of the quantised model; eval_mode != 0 applies fc_out's 16-bit output quantiser (quant_layers.py:77-80) */
+int oracle_qat_fwd(const odpd_model_t* m, int B, int T, const real* params, const real* x, real* y, int eval_mode) {
+    if (!m || !is_qat(m) || !params || !x || !y || B <= 0 || T <= 0 || m->hidden > MAXH) return ODPD_EINVAL;
+    qgru_layout_t L; qgru_layout(m, &L);
+    int H = L.H;
+    real* qw = (real*)malloc(sizeof(real) * (3 * H * 4 + 3 * H * H + 2 * H));
+    real *qwx = qw, *qwh = qw + 3 * H * 4, *qwo = qwh + 3 * H * H;
+    qgru_quant_weights(&L, params, qwx, qwh, qwo, NULL, NULL, NULL);
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b)
+        qgru_seq_fwd(m, &L, params, T, x + (int64_t)b * T * 2, y + (int64_t)b * T * 2, NULL, eval_mode, qwx, qwh, qwo);
+    free(qw);
+    return 0;
+}
+/* train-mode backward; dparams (P) overwritten: scale entries get exactly 0 (round() kills their gradient) */
+int oracle_qat_bwd(const odpd_model_t* m, int B, int T, const real* params, const real* x, const real* dy, real* dparams, real* dx) {
+    if (!m || !is_qat(m) || !params || !x || !dy || !dparams || B <= 0 || T <= 0 || m->hidden > MAXH) return ODPD_EINVAL;
+    qgru_layout_t L; qgru_layout(m, &L);
+    int H = L.H, nx = 3 * H * 4, nh = 3 * H * H, no = 2 * H, nq = nx + nh + no;
+    int64_t P = oracle_param_count(m);
+    memset(dparams, 0, sizeof(real) * P);
+    real* qw = (real*)malloc(sizeof(real) * 2 * nq);
+    real *qwx = qw, *qwh = qw + nx, *qwo = qwh + nh, *mk = qw + nq;
+    qgru_quant_weights(&L, params, qwx, qwh, qwo, mk, mk + nx, mk + nx + nh);
+    real* dq = (real*)calloc(nq, sizeof(real));
+#pragma omp parallel
+    {
+        real* dp = (real*)calloc(P, sizeof(real));
+        real* dql = (real*)calloc(nq, sizeof(real));
+        qgru_step_t* S = (qgru_step_t*)malloc(sizeof(qgru_step_t) * T);
+        real* ytmp = (real*)malloc(sizeof(real) * 2 * T);
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            const real* xb = x + (int64_t)b * T * 2;
+            qgru_seq_fwd(m, &L, params, T, xb, ytmp, S, 0, qwx, qwh, qwo);
+            qgru_seq_bwd(m, &L, params, T, xb, dy + (int64_t)b * T * 2, S, dp, dx ? dx + (int64_t)b * T * 2 : NULL, qwx, qwh, qwo,
+                         dql, dql + nx, dql + nx + nh);
+        }
+#pragma omp critical
+        {
+            for (int64_t i = 0; i < P; ++i) dparams[i] += dp[i];
+            for (int i = 0; i < nq; ++i) dq[i] += dql[i];
+        }
+        free(dp); free(dql); free(S); free(ytmp);
+    }
+    for (int i = 0; i < nx; ++i) dparams[L.o_wx + i] = dq[i] * mk[i];
+    for (int i = 0; i < nh; ++i) dparams[L.o_wh + i] = dq[nx + i] * mk[nx + i];
+    for (int i = 0; i < no; ++i) dparams[L.o_wo + i] = dq[nx + nh + i] * mk[nx + nh + i];
+    free(qw); free(dq);
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */

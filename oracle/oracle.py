@@ -82,6 +82,29 @@ class Oracle:
             raise RuntimeError(f"oracle_backbone_bwd failed rc={rc}")
         return dp, dx
 
+    def qat_forward(self, m, params, x, eval_mode=False):
+        """Quantisation-aware QGRU (m.bits_w > 0): train-mode (float output) or eval-mode (16-bit output grid)."""
+        x = self._a(x)
+        params = self._a(params)
+        y = np.empty_like(x)
+        rc = self.lib.oracle_qat_fwd(C.byref(m), x.shape[0], x.shape[1], self._p(params), self._p(x), self._p(y),
+                                     1 if eval_mode else 0)
+        if rc:
+            raise RuntimeError(f"oracle_qat_fwd failed rc={rc}")
+        return y
+
+    def qat_backward(self, m, params, x, dy, need_dx=True):
+        x = self._a(x)
+        params = self._a(params)
+        dy = self._a(dy)
+        dp = np.zeros(self.param_count(m), dtype=self.dtype)
+        dx = np.zeros_like(x) if need_dx else None
+        rc = self.lib.oracle_qat_bwd(C.byref(m), x.shape[0], x.shape[1], self._p(params), self._p(x), self._p(dy),
+                                     self._p(dp), self._p(dx))
+        if rc:
+            raise RuntimeError(f"oracle_qat_bwd failed rc={rc}")
+        return dp, dx
+
     def loss(self, kind, y, target, count=None):
         y = self._a(y)
         target = self._a(target)

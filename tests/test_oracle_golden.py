@@ -96,3 +96,70 @@ def test_bad_args(orc):
     m = make_model("gru", 200)  # hidden too large for the oracle
     with pytest.raises(RuntimeError):
         orc.forward(m, np.zeros(10, np.float32), np.zeros((1, 4, 2), np.float32))
+
+
+# ---- quantisation-aware QGRU (quant/__init__.py:20-37 -> quant_envs.py:138-306) -----------------------------
+QAT = [("quant_qgru_h10_w8a8", "qgru", 8), ("quant_qgru_amp1_h10_w8a8", "qgru_amp1", 8),
+       ("quant_qgru_h10_w16a16", "qgru", 16), ("quant_qgru_amp1_h10_w16a16", "qgru_amp1", 16)]
+_BUFFERS = ("n_bits", "pow2_scale", "decimal_num", "integer_num")
+
+
+def qat_param_names(fx, prefix="sd"):
+    return [k for k in fx.keys(prefix) if not any(t in k for t in _BUFFERS)]
+
+
+@pytest.mark.parametrize("name,bb,bits", QAT)
+def test_qat_forward_and_grads(orc, name, bb, bits):
+    """INT8: the integer-grid restatement reproduces the reference BIT FOR BIT (train-mode float outputs, eval-mode
+    16-bit grid outputs, before and after three training steps).  INT16: fp32 accumulation order matters
+    (32-bit products), agreement to one output LSB (2^-14)."""
+    fx = Fixture(name)
+    m = make_model(bb, fx.meta["hidden"], bits_w=bits, bits_a=bits)
+    names = qat_param_names(fx)
+    p = fx.flat("sd", names)
+    assert orc.param_count(m) == p.size == fx.meta["n_param"]
+    p3 = fx.flat("sd3", names)
+    outs = [(orc.qat_forward(m, p, fx["x"]), fx["y"]), (orc.qat_forward(m, p, fx["x"], eval_mode=True), fx["y_eval"]),
+            (orc.qat_forward(m, p3, fx["x"]), fx["y_p3_train"]), (orc.qat_forward(m, p3, fx["x"], eval_mode=True), fx["y_p3_eval"])]
+    for got, ref in outs:
+        if bits == 8:
+            assert np.array_equal(got, ref)
+        else:
+            assert np.abs(got - ref).max() <= 2.0 ** -13
+    y = outs[0][0]
+    loss, dy = orc.loss("l2", y, fx["tgt"])
+    assert abs(loss - fx["losses"][0]) < 1e-5
+    dp, dx = orc.qat_backward(m, p, fx["x"], dy)
+    gref = np.concatenate([(fx["g/" + k].reshape(-1) if ("g/" + k) in fx else np.zeros(fx["sd/" + k].size, np.float32))
+                           for k in names])
+    assert rel_err(dp, gref) < (1e-5 if bits == 8 else 1e-4)
+    assert rel_err(dx, fx["gx"]) < (1e-5 if bits == 8 else 1e-4)
+    # the scale parameters receive an exact 0.0 gradient (round() kills it) — quantizers.py:56-65
+    off = 0
+    for k in names:
+        n = fx["sd/" + k].size
+        if "scale" in k:
+            assert dp[off] == 0.0
+        off += n
+
+
+@pytest.mark.parametrize("name,bb,bits", QAT[:2])
+def test_qat_three_adamw_steps(orc, name, bb, bits):
+    """AdamW decays the zero-gradient scales (weight decay) but skips the out_quantizer scales whose grad is None."""
+    fx = Fixture(name)
+    m = make_model(bb, fx.meta["hidden"], bits_w=bits, bits_a=bits)
+    names = qat_param_names(fx)
+    p = fx.flat("sd", names).copy()
+    skip = np.concatenate([np.full(fx["sd/" + k].size, "out_quantizer" in k) for k in names])
+    mom, var = np.zeros_like(p), np.zeros_like(p)
+    for s in range(1, 4):
+        y = orc.qat_forward(m, p, fx["x"])
+        loss, dy = orc.loss("l2", y, fx["tgt"])
+        assert abs(loss - fx["losses"][s - 1]) < 1e-5
+        g, _ = orc.qat_backward(m, p, fx["x"], dy, need_dx=False)
+        keep = p[skip].copy()
+        orc.clip_adamw(p, g, mom, var, s, fx.meta["lr"], fx.meta["clip"])
+        p[skip] = keep
+        mom[skip] = 0
+        var[skip] = 0
+        assert rel_err(p, fx.flat(f"p{s}", names)) < 2e-6
