@@ -55,7 +55,12 @@ typedef struct odpd_model {
     float thh;        /* delta threshold on hidden state */
     int32_t bits_w;   /* QAT weight bits (0 = float model) — quant/quant_envs.py:145 */
     int32_t bits_a;   /* QAT activation bits */
+    int32_t flags;    /* ODPD_FLAG_* */
 } odpd_model_t;
+
+/* eval-mode forward of a quantised model: fc_out's 16-bit output quantiser is active only when the reference
+ * module is not in training mode (quant/qmodules/quant_layers.py:77-80) */
+#define ODPD_FLAG_EVAL 1
 
 /* loss kinds — project.py:262-272 */
 enum odpd_loss { ODPD_LOSS_L2 = 0, ODPD_LOSS_L1 = 1 };

@@ -17,7 +17,7 @@ LOSS_WS = 1 + 256    # floats behind `loss_out` (result + per-block scratch)
 class ModelDesc(C.Structure):
     """odpd_model_t"""
     _fields_ = [("backbone", C.c_int32), ("hidden", C.c_int32), ("thx", C.c_float), ("thh", C.c_float),
-                ("bits_w", C.c_int32), ("bits_a", C.c_int32)]
+                ("bits_w", C.c_int32), ("bits_a", C.c_int32), ("flags", C.c_int32)]
 
 
 _EXPORTS = {

@@ -126,9 +126,10 @@ class NativeBackbone(nn.Module):
 
     backbone_name = None
 
-    def _finalize(self, hidden_size, thx=0.0, thh=0.0):
+    def _finalize(self, hidden_size, thx=0.0, thh=0.0, bits_w=0, bits_a=0):
         """Call at the end of __init__ once every parameter holder is registered."""
-        self.desc = _lib.ModelDesc(_lib.BACKBONE_IDS[self.backbone_name], int(hidden_size), float(thx), float(thh), 0, 0)
+        self.desc = _lib.ModelDesc(_lib.BACKBONE_IDS[self.backbone_name], int(hidden_size), float(thx), float(thh), int(bits_w),
+                                   int(bits_a), 0)
         self._slices = []
         off = 0
         for p in self.parameters():

@@ -5,7 +5,13 @@
 using namespace odpd;
 
 namespace {
-enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN };
+enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT };
+inline Family family_of(int bb);
+// a quantisation-aware model: qgru / qgru_amp1 with bits_w > 0 (quant/quant_envs.py:138-171)
+inline Family family_of(const odpd_model_t* m) {
+    if (m->bits_w > 0 && (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1)) return FAM_QAT;
+    return family_of((int)m->backbone);
+}
 inline Family family_of(int bb) {
     switch (bb) {
     case ODPD_GRU: case ODPD_DGRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return FAM_GRU;
@@ -42,6 +48,7 @@ extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     if (!model_ok(m)) return ODPD_EINVAL;
+    if (family_of(m) == FAM_QAT) return qgru_param_count(m);
     const int64_t H = m->hidden, F = feat_dim(m->backbone);
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
@@ -58,26 +65,27 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
 
 extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
-    if (family_of(m->backbone) == FAM_TCNN) return 0;   // not recurrent: nothing to checkpoint
+    if (family_of(m) == FAM_TCNN) return 0;   // not recurrent: nothing to checkpoint
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
-    switch (family_of(m->backbone)) {
+    switch (family_of(m)) {
     case FAM_GRU: return (int64_t)num_groups(B, R) * num_ckpt(T) * 64;
     case FAM_LSTM: return (int64_t)num_groups(B, R) * num_ckpt(T) * 128;   // h and c
     case FAM_DELTA: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 7 * 64 : (int64_t)ODPD_EUNSUPPORTED;
-    case FAM_JANET: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 64 : (int64_t)ODPD_EUNSUPPORTED;
+    case FAM_JANET: case FAM_QAT: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 64 : (int64_t)ODPD_EUNSUPPORTED;
     default: return ODPD_EUNSUPPORTED;
     }
 }
 
 extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fused) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
-    switch (family_of(m->backbone)) {
+    switch (family_of(m)) {
     case FAM_GRU: return gru_family_rows(m, B, fused ? 1 : 0, T);
     case FAM_LSTM: return fused ? (int64_t)ODPD_EUNSUPPORTED : lstm_family_rows(m, B);
     case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B);
     case FAM_JANET: return fused ? (int64_t)ODPD_EUNSUPPORTED : janet_family_rows(m, B);
     case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
+    case FAM_QAT: return fused ? (int64_t)ODPD_EUNSUPPORTED : qgru_family_rows(m, B);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -87,12 +95,13 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     if (!model_ok(m) || !params || !x || !y || B <= 0 || T <= 0) return ODPD_EINVAL;
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = x; a.y = y; a.ckpt = ckpt; a.stats = stats;
-    switch (family_of(m->backbone)) {
+    switch (family_of(m)) {
     case FAM_GRU: return gru_family_fwd((hipStream_t)stream, m, a);
     case FAM_LSTM: return lstm_family_fwd((hipStream_t)stream, m, a);
     case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
     case FAM_JANET: return janet_family_fwd((hipStream_t)stream, m, a);
     case FAM_TCNN: return tcnn_fwd((hipStream_t)stream, m, a);
+    case FAM_QAT: return qgru_family_fwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -102,7 +111,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
     if (!model_ok(m) || !params || !x || !dy || B <= 0 || T <= 0 || (!partials && !dx)) return ODPD_EINVAL;
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = x; a.dy = dy; a.ckpt = const_cast<float*>(ckpt); a.partials = partials; a.dx = dx;
-    switch (family_of(m->backbone)) {
+    switch (family_of(m)) {
     case FAM_GRU:
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return gru_family_bwd((hipStream_t)stream, m, a);
@@ -116,6 +125,9 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return janet_family_bwd((hipStream_t)stream, m, a);
     case FAM_TCNN: return tcnn_bwd((hipStream_t)stream, m, a);
+    case FAM_QAT:
+        if (!ckpt && a.nck > 1) return ODPD_EINVAL;
+        return qgru_family_bwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -126,7 +138,7 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = x; a.target = target; a.partials = partials;
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
-    switch (family_of(m->backbone)) {
+    switch (family_of(m)) {
     case FAM_GRU: return gru_family_train((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }

@@ -107,5 +107,9 @@ int janet_family_rows(const odpd_model_t* m, int B);
 int tcnn_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_rows(const odpd_model_t* m, int B, int T);
+int qgru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int qgru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int qgru_family_rows(const odpd_model_t* m, int B);
+int64_t qgru_param_count(const odpd_model_t* m);
 
 }  // namespace odpd

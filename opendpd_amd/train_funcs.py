@@ -137,11 +137,20 @@ class FusedAdamW:
         g = self.param_groups[0]
         self.step_count += 1
         flat = self.backbone.flat_params()
+        frozen = getattr(self.backbone, "frozen_mask", None)     # parameters torch.optim.AdamW would skip (grad is None)
+        if frozen is not None:
+            if frozen.device != flat.device:
+                self.backbone.frozen_mask = frozen = frozen.to(flat.device)
+            keep = flat[frozen].clone()
         rc = lib.odpd_clip_adamw_step(_lib.stream_ptr(), self.backbone.n_flat, _lib.ptr(flat), _lib.ptr(self.grad),
                                       _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.step_count,
                                       float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                       float(g["weight_decay"]), float(max_norm or 0.0), _lib.ptr(self.norm))
         _lib.check(rc, "odpd_clip_adamw_step")
+        if frozen is not None:
+            flat[frozen] = keep
+            self.exp_avg[frozen] = 0
+            self.exp_avg_sq[frozen] = 0
 
     def step(self, max_norm=0.0):
         """Generic-path step: gathers p.grad (set by autograd) into the flat gradient, then apply()."""

@@ -20,11 +20,11 @@ BACKBONES = {"gru": 0, "dgru": 1, "qgru": 2, "qgru_amp1": 3, "lstm": 4, "vdlstm"
 class Model(C.Structure):
     """Mirror of odpd_model_t (include/opendpd_hip.h)."""
     _fields_ = [("backbone", C.c_int32), ("hidden", C.c_int32), ("thx", C.c_float), ("thh", C.c_float),
-                ("bits_w", C.c_int32), ("bits_a", C.c_int32)]
+                ("bits_w", C.c_int32), ("bits_a", C.c_int32), ("flags", C.c_int32)]
 
 
 def make_model(backbone, hidden, thx=0.0, thh=0.0, bits_w=0, bits_a=0):
-    return Model(BACKBONES[backbone], int(hidden), float(thx), float(thh), int(bits_w), int(bits_a))
+    return Model(BACKBONES[backbone], int(hidden), float(thx), float(thh), int(bits_w), int(bits_a), 0)
 
 
 def build(force=False):

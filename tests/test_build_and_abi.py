@@ -32,7 +32,7 @@ def test_param_counts_match_reference():
     for bb, H, P in [("gru", 11, 519), ("gru", 23, 1911), ("dgru", 13, 1041), ("dgru", 23, 2751), ("lstm", 14, 1038),
                      ("vdlstm", 13, 1118), ("deltagru", 15, 1067), ("deltagru_tcnskip", 15, 999), ("tcnn", 35, 1015),
                      ("pgjanet", 11, 959), ("qgru", 10, 502), ("qgru_amp1", 16, 1090)]:
-        d = _lib.ModelDesc(_lib.BACKBONE_IDS[bb], H, 0, 0, 0, 0)
+        d = _lib.ModelDesc(_lib.BACKBONE_IDS[bb], H, 0, 0, 0, 0, 0)
         assert lib.odpd_param_count(C.byref(d)) == P, bb
 
 

@@ -102,7 +102,7 @@ def test_c_abi_direct_and_errors():
     from opendpd_amd import _lib
     lib = _lib.load()
     assert lib.odpd_abi_version() == 1 and lib.odpd_built_arch() == b"gfx950"
-    d = _lib.ModelDesc(_lib.BACKBONE_IDS["gru"], 11, 0.0, 0.0, 0, 0)
+    d = _lib.ModelDesc(_lib.BACKBONE_IDS["gru"], 11, 0.0, 0.0, 0, 0, 0)
     P = lib.odpd_param_count(C.byref(d))
     assert P == 519
     B, T = 4, 16
@@ -115,7 +115,7 @@ def test_c_abi_direct_and_errors():
     assert torch.isfinite(y).all()
     assert lib.odpd_backbone_fwd(_lib.stream_ptr(), C.byref(d), 0, T, _lib.ptr(params), _lib.ptr(x), _lib.ptr(y), None,
                                  None) == -1
-    bad = _lib.ModelDesc(_lib.BACKBONE_IDS["gru"], 100, 0.0, 0.0, 0, 0)
+    bad = _lib.ModelDesc(_lib.BACKBONE_IDS["gru"], 100, 0.0, 0.0, 0, 0, 0)
     assert lib.odpd_backbone_fwd(_lib.stream_ptr(), C.byref(bad), B, T, _lib.ptr(params), _lib.ptr(x), _lib.ptr(y),
                                  None, None) == -2
 
