@@ -1,0 +1,107 @@
+"""User-facing API with the reference's `opendpd.api` signatures and return dictionaries (opendpd/api.py:27-503):
+train_pa, train_dpd, run_dpd, load_dataset, create_dataset, OpenDPDTrainer."""
+import json
+import os
+
+import pandas as pd
+
+from . import data as D
+from .project import Project, run_run_dpd, run_train_dpd, run_train_pa
+
+
+def _need_name(fn, dataset_name, dataset_path):
+    if dataset_path:
+        raise ValueError(f"{fn} no longer accepts dataset_path. Please create an OpenDPD dataset (e.g., with "
+                         f"create_dataset) and pass its dataset_name instead.")
+    if not dataset_name:
+        raise ValueError(f"{fn} requires dataset_name. Create a dataset first with create_dataset().")
+
+
+def train_pa(dataset_name=None, dataset_path=None, PA_backbone="gru", PA_hidden_size=23, n_epochs=100, batch_size=256,
+             lr=5e-4, accelerator="cpu", frame_length=200, seed=0, **kwargs):
+    _need_name("train_pa", dataset_name, dataset_path)
+    proj = Project(step="train_pa", dataset_name=dataset_name, PA_backbone=PA_backbone, PA_hidden_size=PA_hidden_size,
+                   n_epochs=n_epochs, batch_size=batch_size, lr=lr, accelerator=accelerator, frame_length=frame_length,
+                   seed=seed, **kwargs)
+    run_train_pa(proj)
+    return {"status": "completed", "model_path": proj.path_save_file_best, "log_path": proj.path_log_file_best}
+
+
+def train_dpd(dataset_name=None, dataset_path=None, DPD_backbone="deltagru_tcnskip", DPD_hidden_size=15, PA_backbone="gru",
+              PA_hidden_size=23, n_epochs=100, batch_size=256, lr=5e-4, accelerator="cpu", frame_length=200, seed=0,
+              thx=0.0, thh=0.0, **kwargs):
+    _need_name("train_dpd", dataset_name, dataset_path)
+    proj = Project(step="train_dpd", dataset_name=dataset_name, DPD_backbone=DPD_backbone, DPD_hidden_size=DPD_hidden_size,
+                   PA_backbone=PA_backbone, PA_hidden_size=PA_hidden_size, n_epochs=n_epochs, batch_size=batch_size, lr=lr,
+                   accelerator=accelerator, frame_length=frame_length, seed=seed, thx=thx, thh=thh, **kwargs)
+    run_train_dpd(proj)
+    return {"status": "completed", "model_path": proj.path_save_file_best, "log_path": proj.path_log_file_best}
+
+
+def run_dpd(dataset_name=None, dataset_path=None, DPD_backbone="deltagru_tcnskip", DPD_hidden_size=15, PA_backbone="gru",
+            PA_hidden_size=23, accelerator="cpu", frame_length=200, seed=0, **kwargs):
+    _need_name("run_dpd", dataset_name, dataset_path)
+    proj = Project(step="run_dpd", dataset_name=dataset_name, DPD_backbone=DPD_backbone, DPD_hidden_size=DPD_hidden_size,
+                   PA_backbone=PA_backbone, PA_hidden_size=PA_hidden_size, accelerator=accelerator, frame_length=frame_length,
+                   seed=seed, **kwargs)
+    return {"status": "completed", "output_path": run_run_dpd(proj)}
+
+
+def load_dataset(dataset_path):
+    """-> dict of the six arrays (opendpd/api.py:263-313)."""
+    keys = ("X_train", "y_train", "X_val", "y_val", "X_test", "y_test")
+    return dict(zip(keys, D.load_dataset(dataset_path=dataset_path)))
+
+
+def create_dataset(csv_path, output_dir="datasets", dataset_name=None, train_ratio=0.6, val_ratio=0.2, test_ratio=0.2,
+                   dataset_format="single_csv", csv_filename=None, **spec_kwargs):
+    """Import a CSV with columns I_in,Q_in,I_out,Q_out as an OpenDPD dataset directory with a spec.json
+    (opendpd/api.py:316-431).  Returns the dataset directory."""
+    if abs(train_ratio + val_ratio + test_ratio - 1.0) > 1e-6:
+        raise ValueError("train/val/test ratios must sum to 1")
+    df = pd.read_csv(csv_path)
+    need = ["I_in", "Q_in", "I_out", "Q_out"]
+    if not all(c in df.columns for c in need):
+        raise ValueError(f"CSV must contain columns: {need}. Found: {df.columns.tolist()}")
+    name = dataset_name or os.path.splitext(os.path.basename(csv_path))[0]
+    out = os.path.join(output_dir, name)
+    os.makedirs(out, exist_ok=True)
+    spec = {"dataset_format": dataset_format, "split_ratios": {"train": train_ratio, "val": val_ratio, "test": test_ratio}}
+    spec.update(spec_kwargs)
+    if dataset_format == "single_csv":
+        fname = csv_filename or "data.csv"
+        df.to_csv(os.path.join(out, fname), index=False)
+        spec["csv_filename"] = fname
+    else:
+        n, a = len(df), int(len(df) * train_ratio)
+        b = a + int(n * val_ratio)
+        for split, part in (("train", df.iloc[:a]), ("val", df.iloc[a:b]), ("test", df.iloc[b:])):
+            part[["I_in", "Q_in"]].rename(columns={"I_in": "I", "Q_in": "Q"}).to_csv(os.path.join(out, f"{split}_input.csv"), index=False)
+            part[["I_out", "Q_out"]].rename(columns={"I_out": "I", "Q_out": "Q"}).to_csv(os.path.join(out, f"{split}_output.csv"), index=False)
+    json.dump(spec, open(os.path.join(out, "spec.json"), "w"), indent=4)
+    return out
+
+
+class OpenDPDTrainer:
+    """Convenience wrapper holding a configuration (opendpd/api.py:434-503)."""
+
+    def __init__(self, dataset_name=None, dataset_path=None, accelerator="cpu", **config):
+        self.dataset_name, self.dataset_path, self.accelerator, self.config = dataset_name, dataset_path, accelerator, config
+        self.results = {}
+
+    def _kw(self, extra):
+        kw = dict(self.config)
+        kw.update(extra)
+        return kw
+
+    def train_pa(self, **kw):
+        self.results["pa"] = train_pa(dataset_name=self.dataset_name, dataset_path=self.dataset_path, accelerator=self.accelerator, **self._kw(kw))
+        return self.results["pa"]
+
+    def train_dpd(self, **kw):
+        self.results["dpd"] = train_dpd(dataset_name=self.dataset_name, dataset_path=self.dataset_path, accelerator=self.accelerator, **self._kw(kw))
+        return self.results["dpd"]
+
+    def run_dpd(self, **kw):
+        self.results["run"] = run_dpd(dataset_name=self.dataset_name, dataset_path=self.dataset_path, accelerator=self.accelerator, **self._kw(kw))
+        return self.results["run"]

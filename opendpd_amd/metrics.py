@@ -1,0 +1,66 @@
+"""Host-side signal-quality metrics (numpy / scipy), restating the reference's utils/metrics.py:
+NMSE (:42-52), EVM (:55-108), ACLR (:111-151), power_spectrum via scipy.signal.welch (:154-187).
+They run once per epoch on (segments, nperseg, 2) arrays, so they stay on the host."""
+import numpy as np
+
+
+def IQ_to_complex(iq):
+    return iq[..., 0] + 1j * iq[..., 1]
+
+
+def NMSE(prediction, ground_truth):
+    """Mean over segments of 10 log10( mean|e|^2 / mean|truth|^2 )."""
+    err = np.square(ground_truth[..., 0] - prediction[..., 0]) + np.square(ground_truth[..., 1] - prediction[..., 1])
+    energy = np.square(ground_truth[..., 0]) + np.square(ground_truth[..., 1])
+    return np.mean(10 * np.log10(np.mean(err, axis=-1) / np.mean(energy, axis=-1)))
+
+
+def _main_channel_bins(freq, bw_main_ch, n_sub_ch):
+    lo = int(np.min(np.where(freq >= -bw_main_ch / 2)))
+    hi = int(np.max(np.where(freq <= bw_main_ch / 2)))
+    return lo, hi, int((hi - lo) / n_sub_ch)
+
+
+def EVM(prediction, ground_truth, sample_rate=int(800e6), bw_main_ch=200e6, n_sub_ch=10, nperseg=2560):
+    """20 log10 of the mean (over segments and sub-channels) relative spectral error inside the main channel."""
+    sp = np.fft.fftshift(np.fft.fft(IQ_to_complex(prediction), n=nperseg, axis=-1), axes=-1)
+    sg = np.fft.fftshift(np.fft.fft(IQ_to_complex(ground_truth), n=nperseg, axis=-1), axes=-1)
+    freq = np.fft.fftshift(np.fft.fftfreq(prediction.shape[1], d=1 / sample_rate))
+    lo, _, w = _main_channel_bins(freq, bw_main_ch, n_sub_ch)
+    err = np.zeros((prediction.shape[0], n_sub_ch))
+    for c in range(n_sub_ch):
+        sl = slice(lo + c * w, lo + (c + 1) * w)
+        err[:, c] = np.mean(np.abs(sp[:, sl] - sg[:, sl]), axis=-1) / np.mean(np.abs(sg[:, sl]), axis=-1)
+    return 20 * np.log10(np.mean(err.mean(axis=-1)))
+
+
+def power_spectrum(complex_signal, fs=800e6, nperseg=2560, axis=-1):
+    """Two-sided Welch spectrum ('spectrum' scaling), fft-shifted, averaged over segments."""
+    from scipy.signal import welch
+    freq, ps = welch(complex_signal, fs=fs, nperseg=nperseg, return_onesided=False, scaling="spectrum", axis=-1)
+    half = int(nperseg / 2)
+    freq = np.concatenate((freq[half:], freq[:half]))
+    ps = np.concatenate((ps[..., half:], ps[..., :half]), axis=-1)
+    return freq, np.mean(ps, axis=0)
+
+
+def ACLR(prediction, fs=800e6, nperseg=2560, bw_main_ch=200e6, n_sub_ch=10):
+    """(left, right) adjacent-channel power relative to the strongest main sub-channel, in dB."""
+    freq, psd = power_spectrum(IQ_to_complex(prediction), fs=fs, nperseg=nperseg, axis=-1)
+    lo, hi, w = _main_channel_bins(freq, bw_main_ch, n_sub_ch)
+    sub = np.array([np.sum(psd[lo + c * w:lo + (c + 1) * w]) for c in range(n_sub_ch)])
+    ref = sub.max()
+    left = np.mean(10 * np.log10(np.sum(psd[lo - w:lo]) / ref))
+    right = np.mean(10 * np.log10(np.sum(psd[hi:hi + w]) / ref))
+    return left, right
+
+
+def calculate_metrics(args, stat, prediction, ground_truth):
+    """modules/train_funcs.py:93-105."""
+    stat["NMSE"] = NMSE(prediction, ground_truth)
+    stat["EVM"] = EVM(prediction, ground_truth, bw_main_ch=args.bw_main_ch, n_sub_ch=args.n_sub_ch, nperseg=args.nperseg)
+    left, right = ACLR(prediction, fs=args.input_signal_fs, nperseg=args.nperseg, bw_main_ch=args.bw_main_ch,
+                       n_sub_ch=args.n_sub_ch)
+    stat["ACLR_L"], stat["ACLR_R"] = np.mean([left]), np.mean([right])
+    stat["ACLR_AVG"] = (stat["ACLR_L"] + stat["ACLR_R"]) / 2
+    return stat

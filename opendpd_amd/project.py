@@ -1,0 +1,276 @@
+"""Run orchestration: a compact restatement of the reference's arguments.py / project.py / steps/*.py / modules/paths.py /
+modules/loggers.py for the three steps train_pa, train_dpd, run_dpd — same hyper-parameter names and defaults, same
+`save/ log/ dpd_out/` layout and model-ID strings (project.py:57-92, paths.py:75-117), same CSV log columns
+(paths.py:9-72), same best-model rule (loggers.py:165-179: epoch 0 always, then strict <).
+
+What differs is where the work runs: the frames never leave the GPU (`DeviceFrameLoader` gathers each batch from the
+resident I/Q stream with the index order a reference DataLoader(shuffle=True) would draw), and the step is the fused
+HIP train step."""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import pandas as pd
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader
+
+from . import data as D
+from .metrics import calculate_metrics
+from .models import CascadedModel, CoreModel
+from .quant import get_quant_model
+from .train_funcs import FusedAdamW, net_eval, net_train
+
+DEFAULTS = dict(  # arguments.py:8-89
+    dataset_name=None, dataset_path=None, filename="", log_precision=8, step="run_dpd", eval_val=1, eval_test=1,
+    accelerator="cuda", devices=0, re_level="soft", use_segments=False, frame_length=200, frame_stride=1, seed=0,
+    loss_type="l2", opt_type="adamw", batch_size=256, batch_size_eval=256, n_epochs=100, lr_schedule=0, lr=5e-4,
+    lr_end=1e-4, decay_factor=0.1, patience=10, grad_clip_val=200, K=4, PA_backbone="gru", PA_hidden_size=23,
+    PA_num_layers=1, DPD_backbone="gru", DPD_hidden_size=15, DPD_num_layers=1, quant=False, n_bits_w=8, n_bits_a=8,
+    pretrained_model="", quant_dir_label="", q_pretrain=False, thx=0.0, thh=0.0, num_dvr_units=3, window_size=4)
+
+
+def count_net_params(net):
+    return sum(p.numel() for p in net.parameters())
+
+
+class DeviceFrameLoader:
+    """Iterates (features, targets) batches of frames gathered ON DEVICE from the resident I/Q streams.
+    The batch index order comes from a torch DataLoader over range(n) with shuffle=True, i.e. exactly the global-RNG
+    consumption of the reference's DataLoader(train_set, shuffle=True) (project.py:236)."""
+
+    def __init__(self, x, y, frame_length, stride, batch_size, device, shuffle=True):
+        self.x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device)
+        self.y = torch.as_tensor(np.asarray(y), dtype=torch.float32).to(device)
+        self.n = (len(x) - frame_length) // stride + 1
+        self.stride, self.device = stride, device
+        self.offs = torch.arange(frame_length, device=device)
+        self.index_loader = DataLoader(range(self.n), batch_size=batch_size, shuffle=shuffle)
+
+    def __len__(self):
+        return len(self.index_loader)
+
+    def __iter__(self):
+        for idx in self.index_loader:
+            rows = idx.to(self.device) * self.stride
+            g = rows[:, None] + self.offs[None, :]
+            yield self.x[g], self.y[g]
+
+
+class ReduceLROnPlateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', threshold=1e-4 rel) as configured in project.py:289-296."""
+
+    def __init__(self, optimizer, factor, patience, min_lr, threshold=1e-4):
+        self.opt, self.factor, self.patience, self.min_lr, self.threshold = optimizer, factor, patience, min_lr, threshold
+        self.best, self.bad = float("inf"), 0
+
+    def step(self, metric):
+        metric = float(metric)
+        if metric < self.best * (1 - self.threshold) if self.best > 0 else metric < self.best * (1 + self.threshold):
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            for g in self.opt.param_groups:
+                g["lr"] = max(g["lr"] * self.factor, self.min_lr)
+            self.bad = 0
+
+
+class CsvLogger:
+    """History / best CSV files with the reference's formatting (loggers.py:119-163)."""
+
+    def __init__(self, path_save_best, path_log_best, path_log_hist, precision=8):
+        self.path_save_best, self.path_log_best, self.path_log_hist, self.precision = path_save_best, path_log_best, path_log_hist, precision
+        self.headers, self.rows, self.best_val_metric = [], [], None
+
+    def write_log(self, stat):
+        self.headers = list(stat.keys())
+        fmt = "{:." + str(self.precision) + "f}"
+        self.rows.append([fmt.format(v) if isinstance(v, float) else v for v in stat.values()])
+        pd.DataFrame(self.rows, columns=self.headers).to_csv(self.path_log_hist, index=False)
+
+    def _write_best(self, idx):
+        pd.DataFrame([self.rows[idx]], columns=self.headers).to_csv(self.path_log_best, index=False)
+
+    def save_best_model(self, net, epoch, val_stat, metric_name):
+        crit = val_stat[metric_name]
+        if epoch == 0 or crit < self.best_val_metric:
+            self.best_val_metric = crit
+            torch.save(net.state_dict(), self.path_save_best)
+            self._write_best(epoch)
+
+
+class Project:
+    def __init__(self, **overrides):
+        hp = dict(DEFAULTS)
+        unknown = set(overrides) - set(hp)
+        if unknown:
+            raise TypeError(f"unknown arguments: {sorted(unknown)}")
+        hp.update(overrides)
+        self.args = argparse.Namespace(**hp)
+        self.hparams = vars(self.args)
+        for k, v in hp.items():
+            setattr(self, k, v)
+        for k, v in D.load_spec(self.dataset_name, self.dataset_path).items():     # project.py:163-166
+            setattr(self, k, v)
+            setattr(self.args, k, v)
+        self.log_train, self.log_val, self.log_test = {}, {}, {}
+        random.seed(self.seed); np.random.seed(self.seed); torch.manual_seed(self.seed)   # project.py:108-112
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(self.seed)
+        ds = self.dataset_name or os.path.splitext(os.path.basename(str(self.dataset_path)))[0]
+        self.dataset_label = ds
+        if self.step == "train_pa":
+            base = (ds, self.step, self.quant_dir_label)
+        else:
+            base = (ds, self.step, self.pa_dir_id(), self.quant_dir_label)
+        self.path_dir_save = os.path.join("./save", *base)
+        self.path_dir_log_hist = os.path.join("./log", *base, "history")
+        self.path_dir_log_best = os.path.join("./log", *base, "best")
+        for d in (self.path_dir_save, self.path_dir_log_hist, self.path_dir_log_best):
+            os.makedirs(d, exist_ok=True)
+
+    # ---- ids (project.py:57-92, paths.py:105-117) ----------------------------------------------------------------
+    def pa_dir_id(self):
+        return f"PA_S_{self.seed}_M_{self.PA_backbone.upper()}_H_{self.PA_hidden_size:d}_F_{self.frame_length:d}"
+
+    def gen_pa_model_id(self, n):
+        return f"{self.pa_dir_id()}_P_{n:d}"
+
+    def gen_dpd_model_id(self, n):
+        s = f"DPD_S_{self.seed}_M_{self.DPD_backbone.upper()}_H_{self.DPD_hidden_size:d}_F_{self.frame_length:d}_P_{n:d}"
+        if "delta" in self.DPD_backbone:
+            s += f"_THX_{self.thx:.3f}_THH_{self.thh:.3f}"
+        return s
+
+    def set_device(self):
+        if self.accelerator == "cuda" and torch.cuda.is_available():
+            dev = torch.device("cuda:" + str(self.devices))
+            torch.cuda.set_device(dev)
+        elif self.accelerator == "cpu":
+            raise ValueError("opendpd_amd runs on a HIP device only: pass accelerator='cuda' (there is no CPU fallback)")
+        else:
+            raise ValueError(f"The select device {self.accelerator} is not supported.")
+        self.device = dev
+        return dev
+
+    def build_dataloaders(self):
+        Xtr, ytr, Xv, yv, Xte, yte = D.load_dataset(self.dataset_name, self.dataset_path)
+        self.target_gain = D.set_target_gain(Xtr, ytr)
+        if self.step == "train_dpd":
+            ytr, yv, yte = self.target_gain * Xtr, self.target_gain * Xv, self.target_gain * Xte
+        train = DeviceFrameLoader(Xtr, ytr, self.frame_length, self.frame_stride, self.batch_size, self.device, shuffle=True)
+        val = DataLoader(D.IQSegmentDataset(Xv, yv, nperseg=self.args.nperseg), batch_size=self.batch_size_eval, shuffle=False)
+        test = DataLoader(D.IQSegmentDataset(Xte, yte, nperseg=self.args.nperseg), batch_size=self.batch_size_eval, shuffle=False)
+        return (train, val, test), Xtr.shape[-1]
+
+    def build_logger(self, model_id):
+        self.path_save_file_best = os.path.join(self.path_dir_save, model_id + ".pt")
+        self.path_log_file_hist = os.path.join(self.path_dir_log_hist, model_id + ".csv")
+        self.path_log_file_best = os.path.join(self.path_dir_log_best, model_id + ".csv")
+        self.logger = CsvLogger(self.path_save_file_best, self.path_log_file_best, self.path_log_file_hist, self.log_precision)
+
+    def build_criterion(self):
+        return {"l2": nn.MSELoss(), "l1": nn.L1Loss()}[self.loss_type]
+
+    def build_optimizer(self, net):
+        if self.opt_type == "adamw":
+            opt = FusedAdamW(net, lr=self.lr)
+        elif self.opt_type == "adam":
+            opt = torch.optim.Adam(net.parameters(), lr=self.lr)
+        elif self.opt_type == "sgd":
+            opt = torch.optim.SGD(net.parameters(), lr=self.lr, momentum=0.9)
+        elif self.opt_type == "rmsprop":
+            opt = torch.optim.RMSprop(net.parameters(), lr=self.lr)
+        else:
+            raise RuntimeError("Please use a valid optimizer.")
+        return opt, ReduceLROnPlateau(opt, self.decay_factor, self.patience, self.lr_end)
+
+    def gen_log_stat(self, elapsed, net, optimizer, epoch):
+        backbone, hidden = (self.PA_backbone, self.PA_hidden_size) if self.step == "train_pa" else (self.DPD_backbone, self.DPD_hidden_size)
+        stat = {"EPOCH": epoch, "N_EPOCH": self.n_epochs, "TIME:": elapsed, "LR": optimizer.param_groups[-1]["lr"],
+                "BATCH_SIZE": self.batch_size, "N_PARAM": count_net_params(net), "FRAME_LENGTH": self.frame_length,
+                "BACKBONE": backbone, "HIDDEN_SIZE": hidden}
+        if self.step == "train_dpd" and "delta" in net.dpd_model.backbone_type:
+            bb = net.dpd_model.backbone
+            stat["THX"], stat["THH"] = bb.thx, bb.thh
+            stat.update(bb.get_temporal_sparsity())
+            bb.set_debug(1)
+        for prefix, d in (("TRAIN", self.log_train), ("VAL", self.log_val), ("TEST", self.log_test)):
+            stat.update({f"{prefix}_{k.upper()}": (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in d.items()})
+        return stat
+
+    def train(self, net, criterion, optimizer, lr_scheduler, loaders, best_model_metric):
+        train_loader, val_loader, test_loader = loaders
+        start = time.time()
+        for epoch in range(self.n_epochs):
+            net = net_train(self.log_train, net, train_loader, optimizer, criterion, self.grad_clip_val, self.device)
+            if self.eval_val:
+                _, pred, truth = net_eval(self.log_val, net, val_loader, criterion, self.device)
+                self.log_val = calculate_metrics(self.args, self.log_val, pred, truth)
+            if self.eval_test:
+                _, pred, truth = net_eval(self.log_test, net, test_loader, criterion, self.device)
+                self.log_test = calculate_metrics(self.args, self.log_test, pred, truth)
+            self.log_all = self.gen_log_stat((time.time() - start) / 60.0, net, optimizer, epoch)
+            self.logger.write_log(self.log_all)
+            best_net = net.dpd_model if self.step == "train_dpd" else net
+            self.logger.save_best_model(best_net, epoch, self.log_val, best_model_metric)
+            if self.lr_schedule:
+                lr_scheduler.step(self.log_val[best_model_metric])
+
+
+def run_train_pa(proj):
+    """steps/train_pa.py:10-59"""
+    proj.set_device()
+    loaders, input_size = proj.build_dataloaders()
+    net = CoreModel(input_size, proj.PA_hidden_size, proj.PA_num_layers, proj.PA_backbone, window_size=proj.window_size,
+                    num_dvr_units=proj.num_dvr_units).to(proj.device)
+    proj.build_logger(proj.gen_pa_model_id(count_net_params(net)))
+    opt, sched = proj.build_optimizer(net)
+    proj.train(net, proj.build_criterion(), opt, sched, loaders, best_model_metric="NMSE")
+    return net
+
+
+def run_train_dpd(proj):
+    """steps/train_dpd.py:14-90"""
+    proj.set_device()
+    loaders, input_size = proj.build_dataloaders()
+    pa = CoreModel(input_size, proj.PA_hidden_size, proj.PA_num_layers, proj.PA_backbone, window_size=proj.window_size,
+                   num_dvr_units=proj.num_dvr_units)
+    pa_id = proj.gen_pa_model_id(count_net_params(pa))
+    pa.load_state_dict(torch.load(os.path.join("save", proj.dataset_label, "train_pa", pa_id + ".pt"), map_location="cpu"))
+    dpd = CoreModel(input_size, proj.DPD_hidden_size, proj.DPD_num_layers, proj.DPD_backbone, window_size=proj.window_size,
+                    num_dvr_units=proj.num_dvr_units, thx=proj.thx, thh=proj.thh)
+    dpd = get_quant_model(proj, dpd)
+    proj.build_logger(proj.gen_dpd_model_id(count_net_params(dpd)))
+    net = CascadedModel(dpd_model=dpd, pa_model=pa)
+    net.freeze_pa_model()
+    net = net.to(proj.device)
+    opt, sched = proj.build_optimizer(net)
+    proj.train(net, proj.build_criterion(), opt, sched, loaders, best_model_metric="ACLR_AVG")
+    return net
+
+
+def run_run_dpd(proj):
+    """steps/run_dpd.py:19-94: the whole test split as ONE sequence through the trained DPD -> dpd_out/<id>.csv.
+    (Like the reference, the DPD is rebuilt WITHOUT thx/thh here: delta models run dense at export time.)"""
+    proj.set_device()
+    X_test = D.load_dataset(proj.dataset_name, proj.dataset_path)[4]
+    os.makedirs("dpd_out", exist_ok=True)
+    pa = CoreModel(2, proj.PA_hidden_size, proj.PA_num_layers, proj.PA_backbone, num_dvr_units=proj.num_dvr_units)
+    pa_id = proj.gen_pa_model_id(count_net_params(pa))
+    dpd = get_quant_model(proj, CoreModel(2, proj.DPD_hidden_size, proj.DPD_num_layers, proj.DPD_backbone))
+    dpd_id = proj.gen_dpd_model_id(count_net_params(dpd))
+    sub = [proj.quant_dir_label] if proj.quant else []
+    path = os.path.join("save", proj.dataset_label, "train_dpd", pa_id.split("_P_")[0], *sub, dpd_id + ".pt")
+    dpd.load_state_dict(torch.load(path, map_location="cpu"))
+    dpd = dpd.to(proj.device).eval()
+    with torch.no_grad():
+        out = dpd(torch.Tensor(X_test).unsqueeze(0).to(proj.device)).squeeze(0).cpu().numpy()
+    out_dir = os.path.join("dpd_out", *sub)
+    os.makedirs(out_dir, exist_ok=True)
+    out_path = os.path.join(out_dir, dpd_id + ".csv")
+    pd.DataFrame({"I": X_test[:, 0], "Q": X_test[:, 1], "I_dpd": out[:, 0], "Q_dpd": out[:, 1]}).to_csv(out_path, index=False)
+    return out_path

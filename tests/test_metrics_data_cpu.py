@@ -1,0 +1,53 @@
+"""Host metrics and framing against known answers produced by the reference (tests/golden/metrics_framing.npz and,
+when the reference checkout with its bundled datasets is present, the dataset-level numbers of BASELINE.md §2)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from opendpd_amd import data, metrics
+from tests.golden_util import GOLDEN
+
+
+def _g():
+    return dict(np.load(os.path.join(GOLDEN, "metrics_framing.npz")))
+
+
+def test_metrics_known_answers():
+    g = _g()
+    assert abs(metrics.NMSE(g["pred"], g["truth"]) - float(g["NMSE"])) < 1e-6
+    assert abs(metrics.EVM(g["pred"], g["truth"], bw_main_ch=200e6, n_sub_ch=2, nperseg=512) - float(g["EVM"])) < 1e-6
+    al, ar = metrics.ACLR(g["pred"], fs=800e6, nperseg=512, bw_main_ch=200e6, n_sub_ch=2)
+    assert np.allclose([al, ar], g["ACLR"], atol=1e-6)
+
+
+def test_framing_and_segments():
+    g = _g()
+    for s in (1, 7):
+        f = data.frames(g["stream"], 50, s)
+        assert list(f.shape) == list(g[f"frames_s{s}_shape"])
+        assert np.array_equal(f[0].numpy(), g[f"frames_s{s}_first"]) and np.array_equal(f[-1].numpy(), g[f"frames_s{s}_last"])
+    assert np.array_equal(data.segments(g["stream"], 128).numpy(), g["segs"])
+    torch.manual_seed(0)
+    assert np.array_equal(torch.randperm(22991)[:16].numpy(), g["perm_head_22991"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/datasets/DPA_200MHz"), reason="reference datasets not present")
+def test_dataset_level_known_answers():
+    ans = json.load(open(os.path.join(GOLDEN, "dataset_known_answers.json")))
+    os.environ["OPENDPD_DATASETS"] = "/root/reference/datasets"
+    for ds, ref in ans.items():
+        spec = data.load_spec(dataset_name=ds)
+        Xtr, ytr, _, _, Xte, yte = data.load_dataset(dataset_name=ds)
+        g = data.set_target_gain(Xtr, ytr)
+        assert abs(g - ref["target_gain"]) < 1e-12
+        pred = data.segments(yte, spec["nperseg"]).numpy()
+        truth = data.segments(g * Xte, spec["nperseg"]).numpy()
+        assert list(pred.shape) == ref["seg_shape"]
+        assert abs(metrics.NMSE(pred, truth) - ref["NMSE"]) < 1e-5
+        assert abs(metrics.EVM(pred, truth, bw_main_ch=spec["bw_main_ch"], n_sub_ch=spec["n_sub_ch"], nperseg=spec["nperseg"]) - ref["EVM"]) < 1e-5
+        al, ar = metrics.ACLR(pred, fs=spec["input_signal_fs"], nperseg=spec["nperseg"], bw_main_ch=spec["bw_main_ch"],
+                              n_sub_ch=spec["n_sub_ch"])
+        assert abs(al - ref["ACLR_L"]) < 1e-5 and abs(ar - ref["ACLR_R"]) < 1e-5   # float32 spectra
