@@ -72,8 +72,15 @@ int64_t odpd_param_count(const odpd_model_t* m);
 int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T);
 /* rows of per-workgroup gradient partials that odpd_backbone_bwd (fused = 0) or odpd_train_fwd_bwd
  * (fused = 1) write for a (B,T,2) batch: partials is (rows, P+4).  ODPD_EUNSUPPORTED for fused = 1
- * when T is too long for LDS-resident BPTT state (use the split forward/backward calls then). */
+ * when the backbone has no fused kernel for this shape (use the split forward/backward calls then). */
 int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fused);
+/* floats of scratch `odpd_train_fwd_bwd` needs behind `workspace` for a (B,T,2) batch (0 = none: the
+ * small-batch kernel keeps its BPTT checkpoints in LDS; the large-batch kernel spills them to HBM). */
+int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T);
+/* Kernel-selection knobs (not needed for correct results; buffers must be re-sized with the size queries
+ * above after a change).  "s16_min_batch": smallest batch served by the 16-sequences-per-wave fused GRU
+ * kernel (-1 = built-in crossover, 0 = always when supported); "s16_occupancy": 1 or 2 waves per SIMD (0 = chosen by batch size). */
+int odpd_set_tuning(const char* key, int64_t value);
 /* library/ABI version, and the gfx arch string the code objects were built for */
 int odpd_abi_version(void);
 const char* odpd_built_arch(void);
@@ -106,10 +113,11 @@ int odpd_loss_fwd_bwd(void* stream, int kind, int64_t n, int64_t count, const fl
 /* ---- fused train step pieces (replaces train_funcs.py:33-44) ------------------------------ */
 /* One fused launch: forward + loss + backward for a single backbone on (B,T,2) frames.
  * Writes `partials` ((rows,P+4); column P holds the un-normalised loss partial sum). No y is
- * written, BPTT state stays on-chip (LDS).  `count` as in odpd_loss_fwd_bwd. */
+ * written; BPTT state stays in LDS or goes to `workspace` (odpd_train_workspace_floats floats, may be
+ * NULL when that is 0).  `count` as in odpd_loss_fwd_bwd. */
 int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_kind, int B, int T,
                        int64_t count, const float* params, const float* x, const float* target,
-                       float* partials);
+                       float* partials, float* workspace);
 /* clip_grad_norm_(max_norm) (0 = no clipping) + AdamW step over P parameters
  * (torch.optim.AdamW defaults project.py:283: betas .9/.999, eps 1e-8, weight_decay 0.01).
  * grad is scaled in place like clip_grad_norm_ does.  `step` is the 1-based step index.

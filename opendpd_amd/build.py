@@ -35,7 +35,10 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not is_stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", *extra_flags, *sources(),
+    # -fno-slp-vectorize: v_pk_{fma,mul,add}_f32 issue at half rate on gfx950 (profiles/r01/ubench_issue_costs.md),
+    # so SLP-formed packed math only costs v_mov shuffles and registers in these kernels
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
+           *extra_flags, *sources(),
            "-o", LIB]
     if verbose:
         print(" ".join(cmd))

@@ -43,7 +43,27 @@ inline SeqArgs make_args(const odpd_model_t* m, int B, int T) {
 }
 }  // namespace
 
-extern "C" int odpd_abi_version(void) { return 1; }
+#include <stdlib.h>
+#include <string.h>
+odpd::Tuning& odpd::tuning() {
+    static Tuning t = [] {
+        Tuning v;
+        const char* e = getenv("ODPD_S16_MIN_BATCH");
+        v.s16_min_batch = e ? atol(e) : -1;   // -1 = built-in crossover
+        e = getenv("ODPD_S16_OCCUPANCY");
+        v.s16_occupancy = e ? atoi(e) : 0;    // 0 = by batch size
+        return v;
+    }();
+    return t;
+}
+extern "C" int odpd_set_tuning(const char* key, int64_t value) {
+    if (!key) return ODPD_EINVAL;
+    if (!strcmp(key, "s16_min_batch")) { tuning().s16_min_batch = (long)value; return 0; }
+    if (!strcmp(key, "s16_occupancy")) { tuning().s16_occupancy = (int)value; return 0; }
+    return ODPD_EINVAL;
+}
+
+extern "C" int odpd_abi_version(void) { return 2; }
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
@@ -90,6 +110,12 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     }
 }
 
+extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T) {
+    if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
+    if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    return gru_train_uses_s16(m, B, T) ? gru_s16_workspace_floats(m, B, T) : 0;
+}
+
 extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int T, const float* params,
                                  const float* x, float* y, float* ckpt, double* stats) {
     if (!model_ok(m) || !params || !x || !y || B <= 0 || T <= 0) return ODPD_EINVAL;
@@ -133,13 +159,16 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
 }
 
 extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_kind, int B, int T, int64_t count,
-                                  const float* params, const float* x, const float* target, float* partials) {
+                                  const float* params, const float* x, const float* target, float* partials,
+                                  float* workspace) {
     if (!model_ok(m) || !params || !x || !target || !partials || B <= 0 || T <= 0 || count <= 0) return ODPD_EINVAL;
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = x; a.target = target; a.partials = partials;
-    a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
+    a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.ckpt = workspace;
     switch (family_of(m)) {
-    case FAM_GRU: return gru_family_train((hipStream_t)stream, m, a);
+    case FAM_GRU:
+        return gru_train_uses_s16(m, B, T) ? gru_s16_train((hipStream_t)stream, m, a)
+                                           : gru_family_train((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }

@@ -743,8 +743,23 @@ int gru_family_rows(const odpd_model_t* m, int B, int which, int T) {
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     const int ng = num_groups(B, R);
     if (!which) return bwd_shape(R, ng).grid;
+    if (gru_train_uses_s16(m, B, T)) return gru_s16_rows(m, B);
     const LaunchShape ls = train_shape(P, R, DG, ng, T, nullptr);
     return ls.grid > 0 ? ls.grid : ODPD_EUNSUPPORTED;
+}
+
+// Which fused kernel serves a (B,T) batch: the row-rotated kernel (4 sequences per wave, BPTT state in LDS)
+// has the shorter per-step latency and wins while the batch cannot fill the chip with 16-sequence waves; the
+// S16 kernel (gru_s16.hip) has ~1.7x the throughput once it can, and no frame-length limit.
+// odpd_set_tuning("s16_min_batch") / $ODPD_S16_MIN_BATCH override the crossover (0 = always S16 where
+// supported, a huge value = never).
+bool gru_train_uses_s16(const odpd_model_t* m, int B, int T) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P) || R != 1) return false;
+    long min_batch = tuning().s16_min_batch;
+    if (min_batch < 0) min_batch = 16L * 4 * device_cus();   // one 16-sequence wave per SIMD
+    if (B >= min_batch) return true;
+    return train_shape(P, R, DG, num_groups(B, R), T, nullptr).grid <= 0;   // frame too long for LDS checkpoints
 }
 
 }  // namespace odpd

@@ -1,0 +1,602 @@
+// gru_s16.hip — "S16" fused train kernel of the nn.GRU based backbones (gru, dgru, qgru, qgru_amp1 float
+// paths; reference backbones/{gru,dgru,qgru,qgru_amp1}.py + modules/train_funcs.py:33-39) for hidden <= 16
+// and batches large enough to fill the chip with 16-sequence wavefronts.
+//
+// Lane mapping (differs from gru_family.hip): a wavefront holds SIXTEEN sequences; lane l = (n, q) with
+// n = l & 15 the sequence and q = l >> 4 a quad of hidden units; the lane owns units 4q..4q+3 of sequence n
+// (state h[0..3] in registers).  With this mapping every mat-vec of the recurrence is an exact-fp32
+// v_mfma_f32_16x16x4_f32 with NO cross-lane data movement:
+//     D[m][n] += sum_k A[m][k] B[k][n],  lane feeds A[l&15][l>>4], B[l>>4][l&15], holds D[4(l>>4)+i][l&15]
+//   pre[u][n] = sum_v W[u][v] h_n[v]:  K-chunk c pairs k = q with hidden index v = 4q + c, so the B operand of
+//   chunk c is simply the lane's own h[c] and the A operand is the constant W[l&15][4q+c]; D lands as
+//   pre[4q+i][n] — exactly the units the lane owns.  16 sequences x (3 gates x 16 x 16) MACs = 12 MFMAs
+//   (360 issue cycles) instead of 4 x 45 half-rate v_fmac_dpp (4 x 190) in the row-rotated mapping.
+//   The input projection W_ih [I,Q,|x|,..] + b rides in (F+1+3)/4 more K-chunks (feature slot 4c+q; the
+//   slot after the last feature is the constant 1, which carries the bias).
+// Weight gradients are contractions over (sequence, time): the operands are needed with the sequence index
+// on K, i.e. transposed.  Each step the wave bounces d(gates), h and the feature slots through a private
+// LDS tile (float4 store, 4 conflict-free b32 loads; no VALU work) and accumulates
+//     dW_hh[g] += dg_g^T h_{t-1},  dW_ih|b[g] += dg_g^T [feat,1],  dW_hid += dhid^T h_t
+// with 4 MFMAs per 16x16 tile.
+// BPTT state: h checkpoints every kCkptStride steps go to an HBM workspace (one coalesced 1 KB store per
+// wave; the next block's checkpoint is prefetched a block ahead), blocks are recomputed into registers.
+#include "odpd_seq.h"
+
+namespace odpd {
+
+constexpr int kTilePitch = 20;                  // floats per sequence row of a transpose tile (16 + pad, 16 B aligned)
+constexpr int kTileFloats = 16 * kTilePitch;
+constexpr int kS16Tiles = 7;                    // drp dzp dnp dgh hp dhid feat
+constexpr int kS16WaveFloats = 2 * 2 * 16 * kChunkPad + kS16Tiles * kTileFloats;
+
+template <int FM> struct S16Cfg {
+    static constexpr int F = FeatDim<FM>::F;
+    static constexpr int NCH = (F + 4) / 4;     // K-chunks of the input projection (F features + constant-1 slot)
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Per-workgroup LDS weight table: entry [group][lane] is a float4 of MFMA operands of lane (m = lane & 15,
+// q = lane >> 4).  The forward groups and the backward groups time-share the same registers: a phase pulls
+// only its own set (ds_read_b128), like the rotated-quad tables of gru_family.hip.
+//   forward : 0-2 W_hg[m][4q+c]   3-4 W_ig|b slots (k = 4c+q)   5 b_hn[4q+i]
+//   backward: 6-8 W_hg[4q+c][m]   9 fc_hid[m][4q+c]   10 fc_hid[4q+c][m]   11 b_hid[4q+i]
+//             12-13 fc_out[c][4q+i]   14 fc_out feature/bias slots
+// ---------------------------------------------------------------------------------------------------
+constexpr int kS16Groups = 15;
+constexpr int kS16TabFloats = kS16Groups * 64 * 4;
+
+template <int FM, bool DG>
+__device__ __forceinline__ float s16_wih_slot(const float* pl, const GruLayout& L, int g, int c, int m, int q) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH;
+    const int H = L.H, k = 4 * c + q;
+    if (c >= NCH || m >= H) return 0.0f;
+    if (k < F) return pl[L.o_w_ih + (g * H + m) * F + k];
+    if (k == F) return pl[L.o_b_ih + g * H + m] + (g < 2 ? pl[L.o_b_hh + g * H + m] : 0.0f);
+    return 0.0f;
+}
+template <int FM, bool DG>
+__device__ __forceinline__ float s16_woutf_slot(const float* pl, const GruLayout& L, int cc, int c, int q) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH;
+    const int H = L.H, OW = DG ? H + 6 : H, k = 4 * c + q;
+    if (c >= NCH) return 0.0f;
+    if (DG && k < F) return pl[L.o_w_out + cc * OW + H + k];
+    if (k == F) return pl[L.o_b_out + cc];
+    return 0.0f;
+}
+template <int FM, bool DG>
+__device__ __forceinline__ float4 s16_table_entry(const float* pl, const GruLayout& L, int grp, int m, int q) {
+    const int H = L.H, OW = DG ? H + 6 : H;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * q + e;              // hidden index of K-slot e / own unit e
+        const bool mk = m < H && k < H;
+        if (grp < 3) v[e] = mk ? pl[L.o_w_hh + (grp * H + m) * H + k] : 0.0f;
+        else if (grp == 3) v[e] = s16_wih_slot<FM, DG>(pl, L, e >> 1, e & 1, m, q);
+        else if (grp == 4) v[e] = e < 2 ? s16_wih_slot<FM, DG>(pl, L, 2, e, m, q) : 0.0f;
+        else if (grp == 5) v[e] = k < H ? pl[L.o_b_hh + 2 * H + k] : 0.0f;
+        else if (grp < 9) v[e] = mk ? pl[L.o_w_hh + ((grp - 6) * H + k) * H + m] : 0.0f;
+        else if (grp == 9) v[e] = (DG && mk) ? pl[L.o_w_hid + m * H + k] : 0.0f;
+        else if (grp == 10) v[e] = (DG && mk) ? pl[L.o_w_hid + k * H + m] : 0.0f;
+        else if (grp == 11) v[e] = (DG && k < H) ? pl[L.o_b_hid + k] : 0.0f;
+        else if (grp < 14) v[e] = k < H ? pl[L.o_w_out + (grp - 12) * OW + k] : 0.0f;
+        else v[e] = s16_woutf_slot<FM, DG>(pl, L, e >> 1, e & 1, q);
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+template <int FM, bool DG>
+__device__ __forceinline__ void s16_fill_table(float* tab, const float* pl, const GruLayout& L, int lane, int wave, int nwb) {
+    float4* t4 = reinterpret_cast<float4*>(tab);
+    for (int grp = wave; grp < kS16Groups; grp += nwb)
+        if (DG || (grp < 9 || grp > 11)) t4[grp * 64 + lane] = s16_table_entry<FM, DG>(pl, L, grp, lane & 15, lane >> 4);
+    __syncthreads();
+}
+
+template <int FM>
+struct S16Fw {                     // operands of the forward / recompute phase
+    float whh[3][4];               // A: W_hg[m][4q+c]
+    float wih[3][2];               // A: slot k = 4c+q -> W_ig[m][k] | b_ig(+b_hg) | 0
+    f32x4 bhn;                     // C operand of the W_hn h accumulator
+};
+template <int FM, bool DG>
+struct S16Bw {                     // operands of the backward phase
+    float whhT[3][4];              // A: W_hg[4q+c][m]
+    float whid[4], whidT[4];       // DG: fc_hid[m][4q+c], fc_hid[4q+c][m]
+    f32x4 bhid;
+    f32x4 wout[2];                 // fc_out weights of the lane's own units
+    float woutf[2][2];             // fc_out weight of feature slot k (DG) | fc_out bias at the constant-1 slot
+};
+__device__ __forceinline__ f32x4 as_f32x4(const float4& v) { f32x4 r = {v.x, v.y, v.z, v.w}; return r; }
+
+template <int FM>
+__device__ __forceinline__ void s16_load_fw(S16Fw<FM>& w, const float4* tl) {
+    tl = opaque(tl);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float4 v = tl[g * 64];
+        w.whh[g][0] = v.x; w.whh[g][1] = v.y; w.whh[g][2] = v.z; w.whh[g][3] = v.w;
+    }
+    const float4 a = tl[3 * 64], b = tl[4 * 64];
+    w.wih[0][0] = a.x; w.wih[0][1] = a.y; w.wih[1][0] = a.z; w.wih[1][1] = a.w; w.wih[2][0] = b.x; w.wih[2][1] = b.y;
+    w.bhn = as_f32x4(tl[5 * 64]);
+}
+template <int FM, bool DG>
+__device__ __forceinline__ void s16_load_bw(S16Bw<FM, DG>& w, const float4* tl) {
+    tl = opaque(tl);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float4 v = tl[(6 + g) * 64];
+        w.whhT[g][0] = v.x; w.whhT[g][1] = v.y; w.whhT[g][2] = v.z; w.whhT[g][3] = v.w;
+    }
+    if constexpr (DG) {
+        const float4 a = tl[9 * 64], b = tl[10 * 64];
+        w.whid[0] = a.x; w.whid[1] = a.y; w.whid[2] = a.z; w.whid[3] = a.w;
+        w.whidT[0] = b.x; w.whidT[1] = b.y; w.whidT[2] = b.z; w.whidT[3] = b.w;
+        w.bhid = as_f32x4(tl[11 * 64]);
+    }
+    w.wout[0] = as_f32x4(tl[12 * 64]);
+    w.wout[1] = as_f32x4(tl[13 * 64]);
+    const float4 f = tl[14 * 64];
+    w.woutf[0][0] = f.x; w.woutf[0][1] = f.y; w.woutf[1][0] = f.z; w.woutf[1][1] = f.w;
+}
+
+// feature slots of the lane: fs[c] = slot 4c+q of [feat_0 .. feat_{F-1}, 1, 0, ..], selected branch-free with the
+// lane's one-hot quad indicator oh[e] = (q == e)  (exact: one non-zero term)
+template <int FM>
+__device__ __forceinline__ void s16_slots(float I, float Q, const float (&oh)[4], float (&fs)[S16Cfg<FM>::NCH]) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH;
+    float f[F];
+    feat_fwd<FM>(I, Q, f);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float acc = (F >= 4 * c && F < 4 * c + 4) ? oh[(F - 4 * c) & 3] : 0.0f;   // the constant-1 slot
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * c + e < F) acc = __builtin_fmaf(oh[e], f[(4 * c + e) < F ? (4 * c + e) : 0], acc);
+        fs[c] = acc;
+    }
+}
+
+template <int FM>
+__device__ __forceinline__ void s16_cell_fwd(const S16Fw<FM>& w, const float (&fs)[S16Cfg<FM>::NCH], f32x4& h, f32x4& r,
+                                             f32x4& z, f32x4& n, f32x4& g) {
+    constexpr int NCH = S16Cfg<FM>::NCH;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ar = zero, az = zero, an = zero, ah = w.bhn;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        ar = mfma4(w.wih[0][c], fs[c], ar);
+        az = mfma4(w.wih[1][c], fs[c], az);
+        an = mfma4(w.wih[2][c], fs[c], an);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        ar = mfma4(w.whh[0][c], h[c], ar);
+        az = mfma4(w.whh[1][c], h[c], az);
+        ah = mfma4(w.whh[2][c], h[c], ah);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r[i] = sigmoidf_(ar[i]);
+        z[i] = sigmoidf_(az[i]);
+        g[i] = ah[i];
+        n[i] = tanhf_(__builtin_fmaf(r[i], ah[i], an[i]));
+        h[i] = __builtin_fmaf(z[i], h[i] - n[i], n[i]);
+    }
+}
+
+// sum over the four quads of a sequence (lanes n, n+16, n+32, n+48); every lane gets the total
+__device__ __forceinline__ float quad_sum(float v) {
+    v += swap16(v);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// transpose tile: lane (n,q) stores X[n][4q..4q+3]; lane (u,k) loads X[4k+c][u], c = 0..3
+__device__ __forceinline__ void tile_put(float* tile, int n, int q, const f32x4& v) {
+    *reinterpret_cast<float4*>(tile + n * kTilePitch + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void tile_get(const float* tile, int u, int k, float (&out)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = tile[(4 * k + c) * kTilePitch + u];
+}
+
+template <bool DG>
+struct S16Grad {
+    f32x4 thh[3], tih[3], thid;
+    f32x4 db_hn, db_hid, dwout[2];
+    float dwf[2][2];
+    __device__ __forceinline__ void zero() {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { thh[g] = z4; tih[g] = z4; }
+        thid = z4; db_hn = z4; db_hid = z4; dwout[0] = z4; dwout[1] = z4;
+        dwf[0][0] = dwf[0][1] = dwf[1][0] = dwf[1][1] = 0.f;
+    }
+};
+
+// One block of <= S steps: recompute the forward pass into registers, then back-propagate.
+//   h    : state at the start of the block          dh  : in/out carry dL/dh
+//   hTn  : transposed h of the step after the current one (fc_hid weight gradient operand)
+template <int FM, bool DG, bool FULL>
+__device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, const float (&oh)[4], S16Grad<DG>& G,
+                                          const float2* xs, const float2* ts, float* tiles, int n, int q, int tloc, int nstep,
+                                          bool valid, bool last_blk, f32x4 h, f32x4& dh, float (&hTn)[4], float& loss_acc) {
+    constexpr int NCH = S16Cfg<FM>::NCH, S = kCkptStride;
+    f32x4 hp_s[S], r_s[S], z_s[S], n_s[S], g_s[S];
+    float fs_s[S][NCH];
+    {
+        S16Fw<FM> wf;
+        s16_load_fw<FM>(wf, tl);
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            if (FULL || i < nstep) {
+                const float2 xv = xs[n * kChunkPad + tloc + i];
+                s16_slots<FM>(xv.x, xv.y, oh, fs_s[i]);
+                hp_s[i] = h;
+                s16_cell_fwd<FM>(wf, fs_s[i], h, r_s[i], z_s[i], n_s[i], g_s[i]);
+            }
+        }
+    }
+    S16Bw<FM, DG> w;
+    s16_load_bw<FM, DG>(w, tl);
+    float* t_r = tiles, *t_z = tiles + kTileFloats, *t_n = tiles + 2 * kTileFloats, *t_g = tiles + 3 * kTileFloats;
+    float* t_h = tiles + 4 * kTileFloats, *t_d = tiles + 5 * kTileFloats, *t_f = tiles + 6 * kTileFloats;
+    if (DG && last_blk) {   // transposed final state of the frame: operand of the last step's dW_hid
+        wave_lds_fence();
+        tile_put(t_h, n, q, h);
+        wave_lds_fence();
+        tile_get(t_h, n, q, hTn);
+    }
+    const bool l2 = a.loss_kind == ODPD_LOSS_L2;
+    const float sc = valid ? a.inv_count : 0.0f;
+#pragma unroll
+    for (int i = S - 1; i >= 0; --i) {
+        if (FULL || i < nstep) {
+            const f32x4 hp = hp_s[i], r = r_s[i], z = z_s[i], nn = n_s[i], gh = g_s[i];
+            f32x4 ht, act, hid;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ht[e] = __builtin_fmaf(z[e], hp[e] - nn[e], nn[e]);
+            if constexpr (DG) {
+                hid = w.bhid;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hid = mfma4(w.whid[c], ht[c], hid);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) act[e] = __builtin_fmaxf(hid[e], 0.0f);
+            } else {
+                act = ht;
+            }
+            // y = fc_out(cat(act, feat)) (+ bias through the constant-1 slot), loss and dL/dy
+            float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                p0 = __builtin_fmaf(w.woutf[0][c], fs_s[i][c], p0);
+                p1 = __builtin_fmaf(w.woutf[1][c], fs_s[i][c], p1);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p0 = __builtin_fmaf(w.wout[0][e], act[e], p0);
+                p1 = __builtin_fmaf(w.wout[1][e], act[e], p1);
+            }
+            const float y0 = quad_sum(p0), y1 = quad_sum(p1);
+            const float2 tv = ts[n * kChunkPad + tloc + i];
+            const float d0 = y0 - tv.x, d1 = y1 - tv.y;
+            const float s0 = d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f), s1 = d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
+            const float dy0 = l2 ? 2.0f * sc * d0 : s0, dy1 = l2 ? 2.0f * sc * d1 : s1;
+            const float lv = l2 ? __builtin_fmaf(d0, d0, d1 * d1) : __builtin_fabsf(d0) + __builtin_fabsf(d1);
+            loss_acc += (valid && q == 0) ? lv : 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c < 2) {
+                    G.dwf[0][c] = __builtin_fmaf(dy0, fs_s[i][c], G.dwf[0][c]);
+                    G.dwf[1][c] = __builtin_fmaf(dy1, fs_s[i][c], G.dwf[1][c]);
+                }
+            }
+            f32x4 dht, dhid;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                G.dwout[0][e] = __builtin_fmaf(dy0, act[e], G.dwout[0][e]);
+                G.dwout[1][e] = __builtin_fmaf(dy1, act[e], G.dwout[1][e]);
+                const float dact = __builtin_fmaf(dy0, w.wout[0][e], dy1 * w.wout[1][e]);
+                if constexpr (DG) {
+                    dhid[e] = hid[e] > 0.0f ? dact : 0.0f;
+                    G.db_hid[e] += dhid[e];
+                } else {
+                    dht[e] = dh[e] + dact;
+                }
+            }
+            if constexpr (DG) {
+                dht = dh;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dht = mfma4(w.whidT[c], dhid[c], dht);
+            }
+            f32x4 drp, dzp, dnp, dgh, acc0, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dn = dht[e] * (1.0f - z[e]);
+                const float dz = dht[e] * (hp[e] - nn[e]);
+                dnp[e] = dn * __builtin_fmaf(-nn[e], nn[e], 1.0f);
+                dgh[e] = dnp[e] * r[e];
+                drp[e] = (dnp[e] * gh[e]) * (r[e] * (1.0f - r[e]));
+                dzp[e] = dz * (z[e] * (1.0f - z[e]));
+                G.db_hn[e] += dgh[e];
+                acc0[e] = dht[e] * z[e];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc0 = mfma4(w.whhT[0][c], drp[c], acc0);
+                acc1 = mfma4(w.whhT[1][c], dzp[c], acc1);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c & 1) acc1 = mfma4(w.whhT[2][c], dgh[c], acc1);
+                else acc0 = mfma4(w.whhT[2][c], dgh[c], acc0);
+            }
+            dh = acc0 + acc1;
+            // weight gradients: transpose through LDS (sequence index onto K), then rank-16 MFMA updates
+            wave_lds_fence();
+            tile_put(t_r, n, q, drp);
+            tile_put(t_z, n, q, dzp);
+            tile_put(t_n, n, q, dnp);
+            tile_put(t_g, n, q, dgh);
+            tile_put(t_h, n, q, hp);
+            if constexpr (DG) tile_put(t_d, n, q, dhid);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) t_f[n * kTilePitch + 4 * c + q] = fs_s[i][c];
+            wave_lds_fence();
+            float rT[4], zT[4], nT[4], gT[4], hT[4], dT[4], fT[4];
+            tile_get(t_r, n, q, rT);
+            tile_get(t_z, n, q, zT);
+            tile_get(t_n, n, q, nT);
+            tile_get(t_g, n, q, gT);
+            tile_get(t_h, n, q, hT);
+            tile_get(t_f, n, q, fT);
+            if constexpr (DG) tile_get(t_d, n, q, dT);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                G.thh[0] = mfma4(rT[c], hT[c], G.thh[0]);
+                G.thh[1] = mfma4(zT[c], hT[c], G.thh[1]);
+                G.thh[2] = mfma4(gT[c], hT[c], G.thh[2]);
+                G.tih[0] = mfma4(rT[c], fT[c], G.tih[0]);
+                G.tih[1] = mfma4(zT[c], fT[c], G.tih[1]);
+                G.tih[2] = mfma4(nT[c], fT[c], G.tih[2]);
+                if constexpr (DG) G.thid = mfma4(dT[c], hTn[c], G.thid);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hTn[c] = hT[c];
+        }
+    }
+}
+
+// the wave's row of partial gradients (every entry written), layout = flattened parameter order + 4 loss columns
+template <int FM, bool DG>
+__device__ __forceinline__ void s16_write_row(float* prow, const GruLayout& L, S16Grad<DG>& G, int n, int q, float loss_acc) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH;
+    const int H = L.H, OW = DG ? H + 6 : H;
+    // tiles: lane (c = n, g4 = q) holds rows 4q+rr, column c
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * q + rr;
+            if (i < H) {
+                const float v = G.tih[g][rr];
+                if (n < F) prow[L.o_w_ih + (g * H + i) * F + n] = v;
+                else if (n == F) {
+                    prow[L.o_b_ih + g * H + i] = v;
+                    if (g < 2) prow[L.o_b_hh + g * H + i] = v;
+                }
+                if (n < H) prow[L.o_w_hh + (g * H + i) * H + n] = G.thh[g][rr];
+            }
+        }
+    if constexpr (DG) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * q + rr;
+            if (i < H && n < H) prow[L.o_w_hid + i * H + n] = G.thid[rr];
+        }
+    }
+    // per-unit scalars: sum over the 16 sequences of the DPP row
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int u = 4 * q + e;
+        const float bhn = row_sum16(G.db_hn[e]), bhid = row_sum16(G.db_hid[e]);
+        const float w0 = row_sum16(G.dwout[0][e]), w1 = row_sum16(G.dwout[1][e]);
+        if (n == 0 && u < H) {
+            prow[L.o_b_hh + 2 * H + u] = bhn;
+            prow[L.o_w_out + u] = w0;
+            prow[L.o_w_out + OW + u] = w1;
+            if constexpr (DG) prow[L.o_b_hid + u] = bhid;
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = 4 * c + q;
+            const float v = row_sum16(G.dwf[cc][c < 2 ? c : 0]);
+            if (n == 0) {
+                if (DG && k < F) prow[L.o_w_out + cc * OW + H + k] = v;
+                else if (k == F) prow[L.o_b_out + cc] = v;
+            }
+        }
+    const float lp = row_sum16(loss_acc);
+    if (n == 0 && q == 0) {
+        prow[L.P] = lp;
+        prow[L.P + 1] = 0.f; prow[L.P + 2] = 0.f; prow[L.P + 3] = 0.f;
+    }
+}
+
+template <int FM, bool DG, int OCC>
+__global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs a) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
+    static_assert(NCH <= 2, "operand tables and dwf accumulators are sized for two K-chunks");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const GruLayout L = gru_layout(a.H, F, DG);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    s16_fill_table<FM, DG>(tab, pl, L, lane, wave, nwb);
+    const float4* tl = reinterpret_cast<const float4*>(tab) + lane;
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    float* wbase = tab + kS16TabFloats + (size_t)wave * kS16WaveFloats;
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* ts = xs + 16 * kChunkPad;
+    float* tiles = reinterpret_cast<float*>(ts + 16 * kChunkPad);
+    for (int i = lane; i < kTileFloats; i += 64) tiles[6 * kTileFloats + i] = 0.0f;   // unused feature columns stay 0
+    S16Grad<DG> G;
+    G.zero();
+    float loss_acc = 0.0f;
+    const int nwaves = gridDim.x * nwb;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        const bool valid = b0 + n < a.B;
+        float4* ck = reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * 64 + lane;
+        // ---- forward: cell only, checkpoint every S steps ----
+        {
+            S16Fw<FM> w;
+            s16_load_fw<FM>(w, tl);
+            f32x4 h = {0.f, 0.f, 0.f, 0.f};
+            for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+                const int len = min(kChunk, a.T - t0);
+                wave_lds_fence();
+                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+                wave_lds_fence();
+                int tt = 0;
+                for (; tt + S <= len; tt += S) {
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const float2 xv = xs[n * kChunkPad + tt + i];
+                        float fs[NCH];
+                        f32x4 r, z, nn, g;
+                        s16_slots<FM>(xv.x, xv.y, oh, fs);
+                        s16_cell_fwd<FM>(w, fs, h, r, z, nn, g);
+                    }
+                    const int t1 = t0 + tt + S;
+                    if (t1 < a.T) ck[(size_t)(t1 / S) * 64] = make_float4(h[0], h[1], h[2], h[3]);
+                }
+                for (; tt < len; ++tt) {
+                    const float2 xv = xs[n * kChunkPad + tt];
+                    float fs[NCH];
+                    f32x4 r, z, nn, g;
+                    s16_slots<FM>(xv.x, xv.y, oh, fs);
+                    s16_cell_fwd<FM>(w, fs, h, r, z, nn, g);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // own checkpoint stores precede the loads below
+        // ---- backward ----
+        f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+        float hTn[4] = {0.f, 0.f, 0.f, 0.f};
+        int cur_chunk = -1;
+        float4 h0n = a.nck > 1 ? ck[(size_t)(a.nck - 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int blk = a.nck - 1; blk >= 0; --blk) {
+            const int tb = blk * S, nstep = min(S, a.T - tb);
+            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            const f32x4 h0 = {h0n.x, h0n.y, h0n.z, h0n.w};
+            h0n = blk > 1 ? ck[(size_t)(blk - 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);   // prefetch a block ahead
+            if (chunk != cur_chunk) {
+                wave_lds_fence();
+                const int len = min(kChunk, a.T - t0);
+                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+                stage_in<16>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                wave_lds_fence();
+                cur_chunk = chunk;
+            }
+            if (nstep == S)
+                s16_block<FM, DG, true>(a, tl, oh, G, xs, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+            else
+                s16_block<FM, DG, false>(a, tl, oh, G, xs, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+        }
+    }
+    // ---- one row of partial gradients per workgroup (fixed summation order) ----
+    const int P4 = L.P + kLossCols;
+    __syncthreads();
+    s16_write_row<FM, DG>(smem + wave * P4, L, G, n, q, loss_acc);
+    __syncthreads();
+    float* prow = a.partials + (size_t)blockIdx.x * P4;
+    for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+        float v = smem[i];
+        for (int wv = 1; wv < nwb; ++wv) v += smem[wv * P4 + i];
+        prow[i] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+static bool s16_cfg(const odpd_model_t* m, int& FM, bool& DG) {
+    switch (m->backbone) {
+    case ODPD_GRU: FM = FEAT_RAW2; DG = false; return true;
+    case ODPD_DGRU: FM = FEAT_DGRU6; DG = true; return true;
+    case ODPD_QGRU: FM = FEAT_Q4; DG = false; return true;
+    case ODPD_QGRU_AMP1: FM = FEAT_A4; DG = false; return true;
+    default: return false;
+    }
+}
+static int s16_param_count(int H, int FM, bool DG) {
+    return gru_layout(H, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
+}
+static size_t s16_lds_bytes(int P, int waves) {
+    size_t nbytes = ((size_t)pad4(P) + kS16TabFloats + (size_t)waves * kS16WaveFloats) * sizeof(float);
+    const size_t red = reduce_scratch_bytes(P, waves);
+    return nbytes > red ? nbytes : red;
+}
+// waves per SIMD: forced by the tuning knob, else 1 while one wave per SIMD covers the batch (a lone wave runs
+// its task ~1.7x faster than two sharing a SIMD), 2 beyond that (+20 % throughput)
+static int s16_occupancy(int ngroups) {
+    const int forced = tuning().s16_occupancy;
+    if (forced == 1 || forced == 2) return forced;
+    return ngroups <= 4 * device_cus() ? 1 : 2;
+}
+// one workgroup per CU: 4 waves (1 per SIMD) or 8 waves (2 per SIMD) share one operand table
+static LaunchShape s16_shape(int ngroups) {
+    LaunchShape ls;
+    ls.waves = 4 * s16_occupancy(ngroups);
+    const int need = (ngroups + ls.waves - 1) / ls.waves, cap = device_cus();
+    ls.grid = need < cap ? need : cap;
+    return ls;
+}
+
+int gru_s16_groups(int B) { return (B + 15) / 16; }
+int64_t gru_s16_workspace_floats(const odpd_model_t* m, int B, int T) {
+    (void)m;
+    return (int64_t)gru_s16_groups(B) * num_ckpt(T) * 256;
+}
+int gru_s16_rows(const odpd_model_t* m, int B) {
+    (void)m;
+    return s16_shape(gru_s16_groups(B)).grid;
+}
+
+template <int FM, bool DG, int OCC>
+static int launch_s16(hipStream_t st, const SeqArgs& a, int P) {
+    const LaunchShape ls = s16_shape(a.ngroups);
+    const size_t lds = s16_lds_bytes(P, ls.waves);
+    auto k = gru16_train_kernel<FM, DG, OCC>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <int FM, bool DG>
+static int launch_s16_occ(hipStream_t st, const SeqArgs& a, int P) {
+    return s16_occupancy(a.ngroups) == 1 ? launch_s16<FM, DG, 1>(st, a, P) : launch_s16<FM, DG, 2>(st, a, P);
+}
+
+int gru_s16_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
+    int FM; bool DG;
+    if (!s16_cfg(m, FM, DG) || m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (!a0.ckpt) return ODPD_EINVAL;
+    SeqArgs a = a0;
+    a.ngroups = gru_s16_groups(a.B);
+    const int P = s16_param_count(m->hidden, FM, DG);
+    if (FM == FEAT_RAW2) return launch_s16_occ<FEAT_RAW2, false>(st, a, P);
+    if (FM == FEAT_DGRU6) return launch_s16_occ<FEAT_DGRU6, true>(st, a, P);
+    if (FM == FEAT_Q4) return launch_s16_occ<FEAT_Q4, false>(st, a, P);
+    return launch_s16_occ<FEAT_A4, false>(st, a, P);
+}
+
+}  // namespace odpd

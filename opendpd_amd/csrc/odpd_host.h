@@ -52,6 +52,10 @@ inline LaunchShape persistent_shape(int ngroups, int waves_per_cu, int max_waves
     return ls;
 }
 
+// run-time tuning knobs (odpd_set_tuning; initialised from $ODPD_S16_MIN_BATCH / $ODPD_S16_OCCUPANCY)
+struct Tuning { long s16_min_batch; int s16_occupancy; };
+Tuning& tuning();
+
 // ---- parameter layouts (flattened named_parameters() order of the reference modules) -------------
 struct GruLayout {
     int F, H, dgru;
@@ -95,6 +99,11 @@ int gru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, int T);
+// 16-sequences-per-wave fused kernel (gru_s16.hip) and the rule that selects it
+bool gru_train_uses_s16(const odpd_model_t* m, int B, int T);
+int gru_s16_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_s16_rows(const odpd_model_t* m, int B);
+int64_t gru_s16_workspace_floats(const odpd_model_t* m, int B, int T);
 int lstm_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_rows(const odpd_model_t* m, int B);

@@ -79,6 +79,17 @@ class FusedAdamW:
                                                  device=device)
         return self._partials[(B, T)]
 
+    def train_workspace(self, B, T, device):
+        """Scratch of the fused kernel (HBM BPTT checkpoints of the large-batch path; None when not needed)."""
+        self._ensure(device)
+        key = (B, T, "ws")
+        if key not in self._partials:
+            lib = _lib.load()
+            n = int(lib.odpd_train_workspace_floats(C.byref(self.backbone.desc), B, T))
+            _lib.check(0 if n >= 0 else n, "odpd_train_workspace_floats")
+            self._partials[key] = torch.empty(n, dtype=torch.float32, device=device) if n > 0 else None
+        return self._partials[key]
+
     def has_fused(self, B, T):
         """True when the backbone has a single-launch fwd+loss+bwd kernel for this batch shape."""
         key = (B, T, "has_fused")
@@ -174,11 +185,12 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     if opt.pa is not None or not opt.has_fused(B, T):
         return _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count)
     part = opt.partials(B, T, x.device)
+    ws = opt.train_workspace(B, T, x.device)
     flat = bb.flat_params()
     if timing is not None:
         timing[0].record()
     rc = lib.odpd_train_fwd_bwd(_lib.stream_ptr(), C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], B, T, count,
-                                _lib.ptr(flat), _lib.ptr(x), _lib.ptr(target), _lib.ptr(part))
+                                _lib.ptr(flat), _lib.ptr(x), _lib.ptr(target), _lib.ptr(part), _lib.ptr(ws))
     if timing is not None:
         timing[1].record()
     _lib.check(rc, f"odpd_train_fwd_bwd[{bb.backbone_name}]")

@@ -1,0 +1,138 @@
+"""GPU parity tests of the 16-sequences-per-wave fused GRU train kernel (csrc/gru_s16.hip).  The kernel is
+normally selected for batches >= 16 * 4 * CUs; here `odpd_set_tuning("s16_min_batch", 0)` forces it for every
+shape so that the golden trajectories, ragged shapes (B not a multiple of 16, T not a multiple of the checkpoint
+stride / staging chunk) and both occupancies are covered at sizes the split kernels and the fixtures check.
+
+Tolerances as in test_gru_family_gpu.py (fp32; sums in a different order than ATen)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import Fixture, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[1, 2], ids=["occ1", "occ2"])
+def force_s16(request):
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    assert lib.odpd_set_tuning(b"s16_min_batch", 0) == 0
+    assert lib.odpd_set_tuning(b"s16_occupancy", request.param) == 0
+    yield request.param
+    lib.odpd_set_tuning(b"s16_min_batch", -1)
+    lib.odpd_set_tuning(b"s16_occupancy", 0)
+
+
+def _model(fx, bb):
+    from opendpd_amd import CoreModel
+    net = CoreModel(2, fx.meta["hidden"], 1, bb)
+    net.load_state_dict({k: torch.from_numpy(fx["sd/" + k]) for k in fx.keys("sd")})
+    return net.cuda()
+
+
+def test_selection_and_workspace(force_s16):
+    import ctypes as C
+    from opendpd_amd import CoreModel, _lib
+    lib = _lib.load()
+    net = CoreModel(2, 13, 1, "dgru")
+    d = net.backbone.desc
+    assert lib.odpd_train_workspace_floats(C.byref(d), 33, 50) == 3 * 13 * 256     # 3 wave-tasks x 13 checkpoints
+    assert lib.odpd_partial_rows(C.byref(d), 33, 50, 1) == 1
+    big = CoreModel(2, 23, 1, "dgru").backbone.desc                                  # hidden > 16: row-rotated kernel
+    assert lib.odpd_train_workspace_floats(C.byref(big), 33, 50) == 0
+    lib.odpd_set_tuning(b"s16_min_batch", -1)
+    assert lib.odpd_train_workspace_floats(C.byref(d), 33, 50) == 0                  # small batch: LDS-resident path
+    assert lib.odpd_train_workspace_floats(C.byref(d), 65536, 200) == 4096 * 50 * 256
+    assert lib.odpd_set_tuning(b"no_such_knob", 1) == -1
+
+
+@pytest.mark.parametrize("name,bb", [("gru_h11", "gru"), ("dgru_h13", "dgru"), ("dgru_h8", "dgru"), ("qgru_h16", "qgru"),
+                                     ("qgru_h10", "qgru"), ("qgru_amp1_h10", "qgru_amp1")])
+def test_s16_follows_reference_trajectory(force_s16, name, bb):
+    """Three fused S16 steps reproduce the reference's losses and parameters (tests/golden p1..p3, m3, v3)."""
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    fx = Fixture(name)
+    net = _model(fx, bb)
+    opt = FusedAdamW(net, lr=fx.meta["lr"])
+    x = torch.from_numpy(fx["x"]).cuda()
+    t = torch.from_numpy(fx["tgt"]).cuda()
+    assert opt.train_workspace(x.shape[0], x.shape[1], x.device) is not None      # the S16 path is the one that runs
+    names = fx.keys("sd")
+    for s in range(1, 4):
+        loss = fused_train_step(opt, x, t, "l2", fx.meta["clip"])
+        assert abs(loss.item() - fx["losses"][s - 1]) < 2e-5 * max(1.0, fx["losses"][s - 1])
+        got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in net.parameters()])
+        assert rel_err(got, fx.flat(f"p{s}", names)) < 2e-5, s
+    assert rel_err(opt.exp_avg.cpu().numpy(), fx.flat("m3", names)) < 1e-3
+    assert rel_err(opt.exp_avg_sq.cpu().numpy(), fx.flat("v3", names)) < 1e-3
+
+
+@pytest.mark.parametrize("bb,H,B,T", [("dgru", 13, 256, 200), ("gru", 11, 37, 50), ("dgru", 16, 1027, 64), ("dgru", 9, 3, 333),
+                                      ("qgru", 12, 17, 5), ("qgru_amp1", 7, 1, 1), ("gru", 16, 130, 31), ("dgru", 1, 16, 4)])
+def test_s16_equals_unfused_gradients(force_s16, bb, H, B, T):
+    """S16 fused launch == fwd / loss / bwd chain of the row-rotated split kernels (themselves oracle-checked)."""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    torch.manual_seed(1)
+    net = CoreModel(2, H, 1, bb).cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    t = torch.randn(B, T, 2, device="cuda", generator=g) * 0.3
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    for kind, fn in (("l2", torch.nn.functional.mse_loss), ("l1", torch.nn.functional.l1_loss)):
+        for p in net.parameters():
+            p.grad = None
+        loss = fn(net(x), t)
+        loss.backward()
+        gref = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+        lf = fused_train_step(opt, x, t, kind, 0.0)
+        assert abs(lf.item() - loss.item()) < 1e-5 * max(1.0, loss.item()), kind
+        assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 2e-5, kind
+
+
+def test_s16_against_oracle(force_s16):
+    """Direct check against the CPU oracle's whole train step (fwd + loss + BPTT + clip + AdamW)."""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(3)
+    B, T, H = 50, 77, 13
+    net = CoreModel(2, H, 1, "dgru").cuda()
+    rng = np.random.default_rng(0)
+    x = (rng.uniform(0.05, 0.8, (B, T, 2)) * rng.choice([-1, 1], (B, T, 2))).astype(np.float32)
+    t = rng.normal(0, 0.3, (B, T, 2)).astype(np.float32)
+    orc = Oracle("f32")
+    m = make_model("dgru", H)
+    p = net.backbone.flat_params().detach().cpu().numpy().copy()
+    ea, eas = np.zeros_like(p), np.zeros_like(p)
+    opt = FusedAdamW(net, lr=1e-3)
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    for s in range(1, 3):
+        lo = orc.train_step(m, p, x, t, ea, eas, s, 1e-3, 200.0)
+        lg = fused_train_step(opt, xd, td, "l2", 200.0)
+        assert abs(lg.item() - lo) < 2e-5 * max(1.0, lo)
+        assert rel_err(net.backbone.flat_params().detach().cpu().numpy(), p) < 2e-5
+
+
+def test_s16_is_bit_repeatable_and_large(force_s16):
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(2)
+        net = CoreModel(2, 13, 1, "dgru").cuda()
+        opt = FusedAdamW(net, lr=1e-3)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        x = torch.rand(20000, 200, 2, device="cuda", generator=g) * 0.8 + 0.05     # > one task per wave
+        t = torch.rand(20000, 200, 2, device="cuda", generator=g)
+        for _s in range(2):
+            loss = fused_train_step(opt, x, t, "l2", 200.0)
+        assert torch.isfinite(loss)
+        outs.append(net.backbone.flat_params().clone())
+    assert torch.equal(outs[0], outs[1])

@@ -8,7 +8,7 @@ import sys
 
 src, key = sys.argv[1], sys.argv[2]
 minsz = int(sys.argv[3]) if len(sys.argv) > 3 else 60
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", "/tmp/_isa.s"],
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", "/tmp/_isa.s"] + [a for a in sys.argv[4:]],
                       stderr=subprocess.DEVNULL)
 s = open("/tmp/_isa.s").read()
 names = [m for m in re.findall(r"^(_Z\w+):", s, re.M) if key in m]
