@@ -11,9 +11,12 @@ RCCL all-reduce of P+4 floats per step).  Synthetic band-limited frames, random-
            --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 
 Prints ONE JSON line on rank 0.  `value` = whole-job IQ samples/s with inputs resident in HBM.
-`roofline` prices the dominant kernel (the fused fwd+loss+bwd launch) against HBM: algorithmic
-bytes = 16 B per IQ sample (fp32 I,Q input + fp32 I,Q target).  The path is vector-ALU
-bound (~360 flop/B), so the fp32-VALU fraction is reported next to the HBM fraction.
+`roofline` prices the dominant kernel (the fused fwd+loss+bwd launch).  The step is compute bound
+(~360 flop per algorithmic byte): the bound that binds is the exact-fp32 MFMA / vector rate (157.3
+TFLOP/s, the two are the same rate on gfx950), priced with ALGORITHMIC flops = 2 x 3 x 948 MACs per IQ
+sample (forward, data gradient, weight gradient of the DGRU-H13 cell + head; recompute and padding not
+counted).  The HBM figures (algorithmic bytes = 16 B per IQ sample: fp32 I,Q input + fp32 I,Q target,
+SURVEY §8d) are reported next to it under `roofline.hbm`, and `traffic` is the measured HBM bytes.
 `cpu_baseline` times the CPU oracle (a port of the reference step, oracle/odpd_oracle.c) on the host
 cores of the same box, on a bounded sample (rank 0, N = 1 only).
 """
@@ -30,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector fp32 peak
+VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak = exact-fp32 (f32-input) MFMA peak
 ALGO_BYTES_PER_SAMPLE = 16.0
 FLOP_PER_SAMPLE = {13: 2 * 3 * (39 * 19 + 169 + 38)}  # fwd+dgrad+wgrad MACs*2 for DGRU H13 (5.7 kflop)
 
@@ -163,6 +166,9 @@ def main():
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * B * T / (kern_ms * 1e-3) / 1e9
+        tflops = FLOP_PER_SAMPLE.get(H, 0) * B * T / (kern_ms * 1e-3) / 1e12
+        s16 = opt.train_workspace(B, T, dev) is not None     # which fused kernel served this batch (csrc/gru_family.hip)
+        kernel_name = "gru16_train_kernel<DGRU6,true> (16 seq/wave, MFMA)" if s16 else "gru_train_kernel<1,DGRU6,true> (4 seq/wave, DPP)"
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -178,13 +184,12 @@ def main():
                                    f"T={T}, fused fwd+MSE+BPTT+clip200+AdamW step",
                        "batch_per_gpu": B, "global_batch": world * B, "frame_length": T,
                        "parallelism": f"dp{world}", "loss": float(loss)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gru_train_kernel<1,DGRU6,true>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * B * T,
-                         "valu_fp32": {"achieved_tflops": FLOP_PER_SAMPLE.get(H, 0) * B * T / (kern_ms * 1e-3) / 1e12,
-                                       "peak_tflops": VALU_FP32_PEAK_TFLOPS,
-                                       "frac": FLOP_PER_SAMPLE.get(H, 0) * B * T / (kern_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS}},
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / VALU_FP32_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": kernel_name, "kernel_ms": kern_ms,
+                         "algorithmic_flops_per_launch": FLOP_PER_SAMPLE.get(H, 0) * B * T,
+                         "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * B * T}},
             "reference_batch": ref,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -63,6 +63,9 @@ __device__ __forceinline__ float s16_woutf_slot(const float* pl, const GruLayout
     if (k == F) return pl[L.o_b_out + cc];
     return 0.0f;
 }
+// The r and z gate operands (W_h{r,z}, W_i{r,z}, their biases) are stored pre-multiplied by -log2(e): the MFMA
+// accumulators then hold -log2(e) * pre-activation and sigmoid is exp2 / add / rcp with no scaling multiply.
+constexpr float kNegLog2e = -1.4426950408889634f;
 template <int FM, bool DG>
 __device__ __forceinline__ float4 s16_table_entry(const float* pl, const GruLayout& L, int grp, int m, int q) {
     const int H = L.H, OW = DG ? H + 6 : H;
@@ -71,8 +74,8 @@ __device__ __forceinline__ float4 s16_table_entry(const float* pl, const GruLayo
     for (int e = 0; e < 4; ++e) {
         const int k = 4 * q + e;              // hidden index of K-slot e / own unit e
         const bool mk = m < H && k < H;
-        if (grp < 3) v[e] = mk ? pl[L.o_w_hh + (grp * H + m) * H + k] : 0.0f;
-        else if (grp == 3) v[e] = s16_wih_slot<FM, DG>(pl, L, e >> 1, e & 1, m, q);
+        if (grp < 3) v[e] = mk ? pl[L.o_w_hh + (grp * H + m) * H + k] * (grp < 2 ? kNegLog2e : 1.0f) : 0.0f;
+        else if (grp == 3) v[e] = kNegLog2e * s16_wih_slot<FM, DG>(pl, L, e >> 1, e & 1, m, q);
         else if (grp == 4) v[e] = e < 2 ? s16_wih_slot<FM, DG>(pl, L, 2, e, m, q) : 0.0f;
         else if (grp == 5) v[e] = k < H ? pl[L.o_b_hh + 2 * H + k] : 0.0f;
         else if (grp < 9) v[e] = mk ? pl[L.o_w_hh + ((grp - 6) * H + k) * H + m] : 0.0f;
@@ -157,6 +160,66 @@ __device__ __forceinline__ void s16_slots(float I, float Q, const float (&oh)[4]
     }
 }
 
+// ---- stage-major 4-wide element-wise helpers (same arithmetic as sigmoidf_ / tanhf_ of odpd_device.h) ----
+#ifndef ODPD_STAGE_FENCE
+#define ODPD_STAGE_FENCE 0
+#endif
+#if ODPD_STAGE_FENCE
+#define ODPD_EACH4 __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int i = 0; i < 4; ++i)
+#else
+#define ODPD_EACH4 _Pragma("unroll") for (int i = 0; i < 4; ++i)
+#endif
+// relu of an MFMA result: one v_max_f32 (fmaxf() would first quiet a possible sNaN with a second v_max)
+__device__ __forceinline__ float relu_(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// per-element loops, NOT whole-vector arithmetic: <4 x float> IR ops become v_pk_*_f32, which issue at half
+// rate on gfx950 and measured 6 % slower here (profiles/r01/ubench_issue_costs.md)
+__device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
+__device__ __forceinline__ f32x4 fma4(const f32x4& a, const f32x4& b, const f32x4& c) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = __builtin_fmaf(a[i], b[i], c[i]);
+    return r;
+}
+__device__ __forceinline__ f32x4 mul4(const f32x4& a, const f32x4& b) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = a[i] * b[i];
+    return r;
+}
+__device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = a[i] + b[i];
+    return r;
+}
+__device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = a[i] - b[i];
+    return r;
+}
+__device__ __forceinline__ f32x4 exp2_4(const f32x4& v) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = __builtin_amdgcn_exp2f(v[i]);
+    return r;
+}
+__device__ __forceinline__ f32x4 rcp4(const f32x4& v) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = fast_rcp(v[i]);
+    return r;
+}
+// sigmoid of a pre-activation that arrives already multiplied by -log2(e)
+__device__ __forceinline__ f32x4 sigmoid4_prescaled(const f32x4& v) {
+    return rcp4(add4(exp2_4(v), splat4(1.0f)));
+}
+// tanh(v) = 1 - 2 / (exp2(2 log2(e) v) + 1): 5 VALU ops, |error| <= 1.9e-7 over the whole range (the row-rotated
+// kernels' tanhf_ adds a polynomial branch for |v| < 0.3 to reach 1.1e-7; both are far inside the 2e-5 parity
+// tolerance and of the size of one rounding of a value near 1)
+__device__ __forceinline__ f32x4 tanh4(const f32x4& v) {
+    const f32x4 e = add4(exp2_4(mul4(v, splat4(2.8853900817779268f))), splat4(1.0f));
+    return fma4(rcp4(e), splat4(-2.0f), splat4(1.0f));
+}
+
 template <int FM>
 __device__ __forceinline__ void s16_cell_fwd(const S16Fw<FM>& w, const float (&fs)[S16Cfg<FM>::NCH], f32x4& h, f32x4& r,
                                              f32x4& z, f32x4& n, f32x4& g) {
@@ -175,14 +238,13 @@ __device__ __forceinline__ void s16_cell_fwd(const S16Fw<FM>& w, const float (&f
         az = mfma4(w.whh[1][c], h[c], az);
         ah = mfma4(w.whh[2][c], h[c], ah);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        r[i] = sigmoidf_(ar[i]);
-        z[i] = sigmoidf_(az[i]);
-        g[i] = ah[i];
-        n[i] = tanhf_(__builtin_fmaf(r[i], ah[i], an[i]));
-        h[i] = __builtin_fmaf(z[i], h[i] - n[i], n[i]);
-    }
+    // stage-major element-wise code: every stage is four independent ops (one per owned unit), so a
+    // dependent VALU op never issues right behind its producer (8-cycle dependent-issue latency)
+    r = sigmoid4_prescaled(ar);
+    z = sigmoid4_prescaled(az);
+    g = ah;
+    n = tanh4(fma4(r, ah, an));
+    h = fma4(z, sub4(h, n), n);
 }
 
 // sum over the four quads of a sequence (lanes n, n+16, n+32, n+48); every lane gets the total
@@ -229,12 +291,12 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
         S16Fw<FM> wf;
         s16_load_fw<FM>(wf, tl);
 #pragma unroll
-        for (int i = 0; i < S; ++i) {
-            if (FULL || i < nstep) {
-                const float2 xv = xs[n * kChunkPad + tloc + i];
-                s16_slots<FM>(xv.x, xv.y, oh, fs_s[i]);
-                hp_s[i] = h;
-                s16_cell_fwd<FM>(wf, fs_s[i], h, r_s[i], z_s[i], n_s[i], g_s[i]);
+        for (int st = 0; st < S; ++st) {
+            if (FULL || st < nstep) {
+                const float2 xv = xs[n * kChunkPad + tloc + st];
+                s16_slots<FM>(xv.x, xv.y, oh, fs_s[st]);
+                hp_s[st] = h;
+                s16_cell_fwd<FM>(wf, fs_s[st], h, r_s[st], z_s[st], n_s[st], g_s[st]);
             }
         }
     }
@@ -251,18 +313,16 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
     const bool l2 = a.loss_kind == ODPD_LOSS_L2;
     const float sc = valid ? a.inv_count : 0.0f;
 #pragma unroll
-    for (int i = S - 1; i >= 0; --i) {
-        if (FULL || i < nstep) {
-            const f32x4 hp = hp_s[i], r = r_s[i], z = z_s[i], nn = n_s[i], gh = g_s[i];
-            f32x4 ht, act, hid;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ht[e] = __builtin_fmaf(z[e], hp[e] - nn[e], nn[e]);
+    for (int st = S - 1; st >= 0; --st) {
+        if (FULL || st < nstep) {
+            const f32x4 hp = hp_s[st], r = r_s[st], z = z_s[st], nn = n_s[st], gh = g_s[st];
+            f32x4 act, hid;
+            const f32x4 ht = fma4(z, sub4(hp, nn), nn);
             if constexpr (DG) {
                 hid = w.bhid;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) hid = mfma4(w.whid[c], ht[c], hid);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) act[e] = __builtin_fmaxf(hid[e], 0.0f);
+                ODPD_EACH4 act[i] = relu_(hid[i]);
             } else {
                 act = ht;
             }
@@ -270,8 +330,8 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
             float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                p0 = __builtin_fmaf(w.woutf[0][c], fs_s[i][c], p0);
-                p1 = __builtin_fmaf(w.woutf[1][c], fs_s[i][c], p1);
+                p0 = __builtin_fmaf(w.woutf[0][c], fs_s[st][c], p0);
+                p1 = __builtin_fmaf(w.woutf[1][c], fs_s[st][c], p1);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -279,7 +339,7 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
                 p1 = __builtin_fmaf(w.wout[1][e], act[e], p1);
             }
             const float y0 = quad_sum(p0), y1 = quad_sum(p1);
-            const float2 tv = ts[n * kChunkPad + tloc + i];
+            const float2 tv = ts[n * kChunkPad + tloc + st];
             const float d0 = y0 - tv.x, d1 = y1 - tv.y;
             const float s0 = d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f), s1 = d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
             const float dy0 = l2 ? 2.0f * sc * d0 : s0, dy1 = l2 ? 2.0f * sc * d1 : s1;
@@ -288,40 +348,37 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (c < 2) {
-                    G.dwf[0][c] = __builtin_fmaf(dy0, fs_s[i][c], G.dwf[0][c]);
-                    G.dwf[1][c] = __builtin_fmaf(dy1, fs_s[i][c], G.dwf[1][c]);
+                    G.dwf[0][c] = __builtin_fmaf(dy0, fs_s[st][c], G.dwf[0][c]);
+                    G.dwf[1][c] = __builtin_fmaf(dy1, fs_s[st][c], G.dwf[1][c]);
                 }
             }
             f32x4 dht, dhid;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                G.dwout[0][e] = __builtin_fmaf(dy0, act[e], G.dwout[0][e]);
-                G.dwout[1][e] = __builtin_fmaf(dy1, act[e], G.dwout[1][e]);
-                const float dact = __builtin_fmaf(dy0, w.wout[0][e], dy1 * w.wout[1][e]);
-                if constexpr (DG) {
-                    dhid[e] = hid[e] > 0.0f ? dact : 0.0f;
-                    G.db_hid[e] += dhid[e];
-                } else {
-                    dht[e] = dh[e] + dact;
-                }
-            }
+            G.dwout[0] = fma4(splat4(dy0), act, G.dwout[0]);
+            G.dwout[1] = fma4(splat4(dy1), act, G.dwout[1]);
+            const f32x4 dact = fma4(splat4(dy0), w.wout[0], mul4(w.wout[1], splat4(dy1)));
             if constexpr (DG) {
+                ODPD_EACH4 dhid[i] = hid[i] > 0.0f ? dact[i] : 0.0f;
+                G.db_hid = add4(G.db_hid, dhid);
                 dht = dh;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) dht = mfma4(w.whidT[c], dhid[c], dht);
+            } else {
+                dht = add4(dh, dact);
             }
-            f32x4 drp, dzp, dnp, dgh, acc0, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dn = dht[e] * (1.0f - z[e]);
-                const float dz = dht[e] * (hp[e] - nn[e]);
-                dnp[e] = dn * __builtin_fmaf(-nn[e], nn[e], 1.0f);
-                dgh[e] = dnp[e] * r[e];
-                drp[e] = (dnp[e] * gh[e]) * (r[e] * (1.0f - r[e]));
-                dzp[e] = dz * (z[e] * (1.0f - z[e]));
-                G.db_hn[e] += dgh[e];
-                acc0[e] = dht[e] * z[e];
-            }
+            // cell backward, stage-major (see s16_cell_fwd)
+            const f32x4 one = splat4(1.0f);
+            f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+            // dn = dht (1-z); dnp = dn (1-n^2); dgh = dnp r; drp = dgh ghn (1-r); dzp = (hp-n) z dn
+            const f32x4 omz = sub4(one, z), omr = sub4(one, r);
+            f32x4 omn2;
+            ODPD_EACH4 omn2[i] = __builtin_fmaf(-nn[i], nn[i], 1.0f);
+            const f32x4 dn = mul4(dht, omz);
+            f32x4 acc0 = mul4(dht, z);
+            const f32x4 dnp = mul4(dn, omn2);
+            const f32x4 dgh = mul4(dnp, r);
+            const f32x4 dzp = mul4(mul4(sub4(hp, nn), z), dn);
+            const f32x4 drp = mul4(mul4(dgh, gh), omr);
+            G.db_hn = add4(G.db_hn, dgh);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 acc0 = mfma4(w.whhT[0][c], drp[c], acc0);
@@ -332,7 +389,7 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
                 if (c & 1) acc1 = mfma4(w.whhT[2][c], dgh[c], acc1);
                 else acc0 = mfma4(w.whhT[2][c], dgh[c], acc0);
             }
-            dh = acc0 + acc1;
+            dh = add4(acc0, acc1);
             // weight gradients: transpose through LDS (sequence index onto K), then rank-16 MFMA updates
             wave_lds_fence();
             tile_put(t_r, n, q, drp);
@@ -342,7 +399,7 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
             tile_put(t_h, n, q, hp);
             if constexpr (DG) tile_put(t_d, n, q, dhid);
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) t_f[n * kTilePitch + 4 * c + q] = fs_s[i][c];
+            for (int c = 0; c < NCH; ++c) t_f[n * kTilePitch + 4 * c + q] = fs_s[st][c];
             wave_lds_fence();
             float rT[4], zT[4], nT[4], gT[4], hT[4], dT[4], fT[4];
             tile_get(t_r, n, q, rT);
