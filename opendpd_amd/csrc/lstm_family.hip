@@ -273,11 +273,30 @@ struct LstmGrad {
     }
 };
 
+// VDLSTM dL/dx: sample t feeds the windows of steps t..t+3 (slot 3..0), so its gradient w.r.t. (a, cos, sin)
+// is complete once the backward sweep (descending t) has processed step t.  `acc` is the sliding window of
+// partial sums for samples t-3..t (per sequence, replicated on the sequence's lanes); slot 3 is finalised
+// and the window shifts every step.  What is left in slots 1..3 after step 0 belongs to the circular halo
+// (samples T-3..T-1, vdlstm.py:66-74) and is added by vd_dx_wrap().
+struct VdAcc {
+    float a[4], c[4], s[4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = c[k] = s[k] = 0.0f;
+    }
+};
+// d(a, cos, sin)/d(I, Q) of one sample: a = |x|, cos = I/a, sin = Q/a
+__device__ __forceinline__ float2 vd_sample_bwd(float a_, float cw, float sw, float ga, float gc, float gs) {
+    const float ia = fast_rcp(a_);
+    const float cross = __builtin_fmaf(gc, sw, -gs * cw);      // gc*sin - gs*cos
+    return make_float2(__builtin_fmaf(ga, cw, cross * (sw * ia)), __builtin_fmaf(ga, sw, -cross * (cw * ia)));
+}
+
 template <int R, bool VD, bool NW, bool DX, bool FULL>
 __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, VD>& w, const float* pl, const LstmLayout& L,
                                                const float4* tlane, LstmGrad<R, VD>& G, const LaneId& id, const float2* xr,
                                                const float2* dys, float2* dxs, int tloc, int nstep, float h, float c,
-                                               float& dh, float& dc) {
+                                               float& dh, float& dc, VdAcc& acc) {
     constexpr int F = VD ? 4 : 2, LPS = 16 * R, S = kCkptStride;
     using T = LstmTabs<R>;
     const int lane = id.lane, col = id.col, row = id.row, s = id.s;
@@ -335,13 +354,20 @@ __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, 
                     const float dz2 = __builtin_fmaf(dyv.x, pl[L.o_w_out + 4 + k], dyv.y * pl[L.o_w_out + 12 + k]);
                     const float d1 = dz1 * win.cw[k], d2 = dz2 * win.sw[k];
                     dht = __builtin_fmaf(d1, w.wl1[k], __builtin_fmaf(d2, w.wl2[k], dht));
+                    float l1 = 0.0f, l2 = 0.0f;
+                    if constexpr (NW || DX) {
+                        // fc_out weight gradient and d/d(cos, sin) need l1[k], l2[k] (reductions over the hidden units)
+                        l1 = seq_sum<R>(w.wl1[k] * ht) + pl[L.o_b_l1 + k];
+                        l2 = seq_sum<R>(w.wl2[k] * ht) + pl[L.o_b_l2 + k];
+                    }
+                    if constexpr (DX) {
+                        acc.c[k] = __builtin_fmaf(dz1, l1, acc.c[k]);
+                        acc.s[k] = __builtin_fmaf(dz2, l2, acc.s[k]);
+                    }
                     if constexpr (NW) {
                         G.dwl1[k] = __builtin_fmaf(d1, ht, G.dwl1[k]);
                         G.dwl2[k] = __builtin_fmaf(d2, ht, G.dwl2[k]);
                         G.dbl1[k] += d1; G.dbl2[k] += d2;
-                        // fc_out weight gradient needs l1[k], l2[k] (reductions over the hidden units)
-                        const float l1 = seq_sum<R>(w.wl1[k] * ht) + pl[L.o_b_l1 + k];
-                        const float l2 = seq_sum<R>(w.wl2[k] * ht) + pl[L.o_b_l2 + k];
                         const float z1 = l1 * win.cw[k], z2 = l2 * win.sw[k];
                         G.dwo[k] = __builtin_fmaf(dyv.x, z1, G.dwo[k]);
                         G.dwo[4 + k] = __builtin_fmaf(dyv.x, z2, G.dwo[4 + k]);
@@ -398,6 +424,19 @@ __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, 
                 d0 = rotdot(d0, whhT[3][1], swap16(dpo));
             }
             dh = d0 + d1 + d2;
+            if constexpr (DX && VD) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float p = __builtin_fmaf(w.wih[0][k], dpi, __builtin_fmaf(w.wih[1][k], dpf,
+                                    __builtin_fmaf(w.wih[2][k], dpg, w.wih[3][k] * dpo)));
+                    acc.a[k] += seq_sum<R>(p);
+                }
+                const float2 g = vd_sample_bwd(win.a[3], win.cw[3], win.sw[3], acc.a[3], acc.c[3], acc.s[3]);
+                if ((lane & (LPS - 1)) == 0) dxs[s * kChunkPad + tt] = g;
+#pragma unroll
+                for (int k = 3; k > 0; --k) { acc.a[k] = acc.a[k - 1]; acc.c[k] = acc.c[k - 1]; acc.s[k] = acc.s[k - 1]; }
+                acc.a[0] = acc.c[0] = acc.s[0] = 0.0f;
+            }
             if constexpr (DX && !VD) {
                 float dI = __builtin_fmaf(w.wih[0][0], dpi, __builtin_fmaf(w.wih[1][0], dpf, __builtin_fmaf(w.wih[2][0], dpg, w.wih[3][0] * dpo)));
                 float dQ = __builtin_fmaf(w.wih[0][1], dpi, __builtin_fmaf(w.wih[1][1], dpf, __builtin_fmaf(w.wih[2][1], dpg, w.wih[3][1] * dpo)));
@@ -478,6 +517,8 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
     for (int grp = blockIdx.x * id.nwb + id.wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * SPW;
         float dh = 0.0f, dc = 0.0f;
+        VdAcc acc;
+        acc.zero();
         int cur_chunk = -1;
         for (int blk = a.nck - 1; blk >= 0; --blk) {
             const int tb = blk * S, nstep = min(S, a.T - tb);
@@ -501,9 +542,9 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
             const float h0 = blk ? ck[lane] : 0.0f, c0 = blk ? ck[64 + lane] : 0.0f;
             const float2* xr = xs + id.s * kHaloStride + kHalo;
             if (nstep == S)
-                lstm_bwd_block<R, VD, NW, DX, true>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc);
+                lstm_bwd_block<R, VD, NW, DX, true>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc, acc);
             else
-                lstm_bwd_block<R, VD, NW, DX, false>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc);
+                lstm_bwd_block<R, VD, NW, DX, false>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc, acc);
         }
         if constexpr (DX) {
             if (cur_chunk >= 0) {
@@ -511,6 +552,24 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
                 wave_lds_fence();
                 stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
                 wave_lds_fence();
+            }
+            if constexpr (VD) {
+                // circular halo: steps 0..2 also read samples T-3..T-1; their share is in window slots 1..3.
+                // One add per element, after this wave's own dx stores are acknowledged: deterministic.
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                const int seq = b0 + id.s;
+                if ((lane & (16 * R - 1)) == 0 && seq < a.B) {
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+                        const size_t e = (size_t)seq * a.T + (a.T - 4 + k);
+                        const float2 xv = reinterpret_cast<const float2*>(a.x)[e];
+                        float a_, cw, sw;
+                        vd_elem(xv, a_, cw, sw);
+                        const float2 g = vd_sample_bwd(a_, cw, sw, acc.a[k], acc.c[k], acc.s[k]);
+                        atomicAdd(a.dx + 2 * e, g.x);
+                        atomicAdd(a.dx + 2 * e + 1, g.y);
+                    }
+                }
             }
         }
     }
@@ -562,12 +621,9 @@ static int lstm_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
 template <int R, bool VD>
 static int lstm_launch_bwd_mode(hipStream_t st, const SeqArgs& a, int P) {
     const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
-    if (VD && dx) return ODPD_EUNSUPPORTED;   // dL/dx of the circular windows is not implemented yet
     if (nw && !dx) return lstm_launch_bwd<R, VD, true, false>(st, a, P);
-    if constexpr (!VD) {
-        if (!nw && dx) return lstm_launch_bwd<R, VD, false, true>(st, a, P);
-        if (nw && dx) return lstm_launch_bwd<R, VD, true, true>(st, a, P);
-    }
+    if (!nw && dx) return lstm_launch_bwd<R, VD, false, true>(st, a, P);
+    if (nw && dx) return lstm_launch_bwd<R, VD, true, true>(st, a, P);
     return ODPD_EINVAL;
 }
 
@@ -590,6 +646,7 @@ int lstm_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     const int R = rows_per_seq(m->hidden);
     const bool vd = m->backbone == ODPD_VDLSTM;
     if (!R) return ODPD_EUNSUPPORTED;
+    if (vd && a.T < kHalo) return ODPD_EINVAL;
     const int P = lstm_layout(m->hidden, vd).P;
     ODPD_LSTM_DISPATCH(lstm_launch_bwd_mode, st, a, P)
     return ODPD_EUNSUPPORTED;

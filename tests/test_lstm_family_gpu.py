@@ -21,7 +21,7 @@ def _model(fx, bb):
 def test_golden_forward_backward(name, bb):
     fx = Fixture(name)
     net = _model(fx, bb)
-    need_dx = bb == "lstm"
+    need_dx = True
     x = torch.from_numpy(fx["x"]).cuda().requires_grad_(need_dx)
     y = net(x)
     assert rel_err(y.detach().cpu().numpy(), fx["y"]) < FWD_TOL
@@ -53,7 +53,7 @@ def test_against_oracle_ragged(bb, H, B, T):
     ph = 2 * np.pi * rng.rand(B, T, 1)
     x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
     dy = rng.randn(B, T, 2).astype(np.float32)
-    need_dx = bb == "lstm"
+    need_dx = True
     xt = torch.from_numpy(x).cuda().requires_grad_(need_dx)
     y = net(xt)
     y.backward(torch.from_numpy(dy).cuda())
@@ -85,9 +85,29 @@ def test_train_steps_follow_reference(name, bb):
         assert rel_err(got, fx.flat(f"p{s}", names)) < 3e-5, s
 
 
-def test_vdlstm_dx_is_refused_loudly():
+@pytest.mark.parametrize("H,B,T", [(13, 5, 37), (8, 2, 3), (20, 9, 200)])
+def test_vdlstm_frozen_pa_gives_dx_only(H, B, T):
+    """vdlstm as the frozen PA of a cascade (models.py:169-171): dL/dx alone, circular-halo samples included."""
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H + T)
+    net = CoreModel(2, H, 1, "vdlstm").cuda()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    rng = np.random.RandomState(T)
+    x = (rng.uniform(0.05, 0.9, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    dy = rng.randn(B, T, 2).astype(np.float32)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    net(xt).backward(torch.from_numpy(dy).cuda())
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    _, dxo = Oracle("f32").backward(make_model("vdlstm", H), p, x, dy)
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
+    assert all(q.grad is None for q in net.parameters())
+
+
+def test_vdlstm_short_frame_is_refused_loudly():
+    """the reference pads with the frame's own last 3 samples (vdlstm.py:66-74): T < 3 has no meaning"""
     from opendpd_amd import CoreModel
     net = CoreModel(2, 8, 1, "vdlstm").cuda()
-    x = torch.rand(2, 16, 2, device="cuda").requires_grad_(True)
     with pytest.raises(RuntimeError):
-        net(x).sum().backward()
+        net(torch.rand(2, 2, 2, device="cuda"))
