@@ -5,8 +5,8 @@
 // One 16-lane row per sequence (H <= 16).  The seven HxH blocks (W_a,W_p1,W_p2,W_f,W_g acting on h; W_f,W_g acting on u)
 // and their transposes live in LDS rotated-quad tables and are streamed per use (ds_read_b128 + 4 DPP FMAs),
 // so no weight matrix is pinned in registers.  BPTT: checkpoint of h every kCkptStride steps + block recompute;
-// weight gradients of the HxH blocks by exact-fp32 MFMA.  dL/dx is not implemented (PGJANET is used as a PA/DPD model
-// trained directly, never as the frozen PA of a cascade in the reference scripts).
+// weight gradients of the HxH blocks by exact-fp32 MFMA; dL/dx (frozen PA of a cascade) through the three scalar
+// input columns and the polar features.
 #include "odpd_seq.h"
 
 namespace odpd {
@@ -141,10 +141,10 @@ struct JanetGrad {
     }
 };
 
-template <bool FULL>
+template <bool NW, bool DX, bool FULL>
 __device__ __forceinline__ void janet_bwd_block(const SeqArgs& a, const JanetW& w, const float4* tlane, JanetGrad& G,
-                                                const LaneId& id, const float2* xs, const float2* dys, int tloc, int nstep,
-                                                float h, float& dh) {
+                                                const LaneId& id, const float2* xs, const float2* dys, float2* dxs, int tloc,
+                                                int nstep, float h, float& dh) {
     constexpr int S = kCkptStride;
     const int s = id.s;
     float hp_s[S], an_s[S], p1_s[S], p2_s[S], u_s[S], f_s[S], g_s[S];
@@ -167,13 +167,15 @@ __device__ __forceinline__ void janet_bwd_block(const SeqArgs& a, const JanetW& 
             const float hp = hp_s[i], f = f_s[i], g = g_s[i], u = u_s[i];
             const float ht = __builtin_fmaf(f, hp - g, g);
             const float dht = dh + __builtin_fmaf(dyv.x, w.wo[0], dyv.y * w.wo[1]);
-            G.dwo[0] = __builtin_fmaf(dyv.x, ht, G.dwo[0]); G.dwo[1] = __builtin_fmaf(dyv.y, ht, G.dwo[1]);
-            G.dbo[0] += dyv.x; G.dbo[1] += dyv.y;
             const float dfp = (dht * (hp - g)) * (f * (1.0f - f));
             const float dgp = (dht * (1.0f - f)) * __builtin_fmaf(-g, g, 1.0f);
-            G.db[3] += dfp; G.db[4] += dgp;
-            G.t[3] = mfma4(dfp, hp, G.t[3]); G.t[4] = mfma4(dgp, hp, G.t[4]);
-            G.t[5] = mfma4(dfp, u, G.t[5]); G.t[6] = mfma4(dgp, u, G.t[6]);
+            if constexpr (NW) {
+                G.dwo[0] = __builtin_fmaf(dyv.x, ht, G.dwo[0]); G.dwo[1] = __builtin_fmaf(dyv.y, ht, G.dwo[1]);
+                G.dbo[0] += dyv.x; G.dbo[1] += dyv.y;
+                G.db[3] += dfp; G.db[4] += dgp;
+                G.t[3] = mfma4(dfp, hp, G.t[3]); G.t[4] = mfma4(dgp, hp, G.t[4]);
+                G.t[5] = mfma4(dfp, u, G.t[5]); G.t[6] = mfma4(dgp, u, G.t[6]);
+            }
             const float4* tl = opaque(tlane);
             float dhp = tab_rotdot<1>(dht * f, tl, 7 + 3, dfp);
             dhp = tab_rotdot<1>(dhp, tl, 7 + 4, dgp);
@@ -184,10 +186,17 @@ __device__ __forceinline__ void janet_bwd_block(const SeqArgs& a, const JanetW& 
             const float dap = (du * (1.0f - 2.0f * an) * Ab * Ac) * __builtin_fmaf(-an, an, 1.0f);
             const float dbp = (du * Aa * (1.0f - 2.0f * p1) * Ac) * __builtin_fmaf(-p1, p1, 1.0f);
             const float dcp = (du * Aa * Ab * (1.0f - 2.0f * p2)) * __builtin_fmaf(-p2, p2, 1.0f);
-            G.db[0] += dap; G.db[1] += dbp; G.db[2] += dcp;
-            G.ds[0] = __builtin_fmaf(dap, amp, G.ds[0]); G.ds[1] = __builtin_fmaf(dbp, ct, G.ds[1]);
-            G.ds[2] = __builtin_fmaf(dcp, st, G.ds[2]);
-            G.t[0] = mfma4(dap, hp, G.t[0]); G.t[1] = mfma4(dbp, hp, G.t[1]); G.t[2] = mfma4(dcp, hp, G.t[2]);
+            if constexpr (NW) {
+                G.db[0] += dap; G.db[1] += dbp; G.db[2] += dcp;
+                G.ds[0] = __builtin_fmaf(dap, amp, G.ds[0]); G.ds[1] = __builtin_fmaf(dbp, ct, G.ds[1]);
+                G.ds[2] = __builtin_fmaf(dcp, st, G.ds[2]);
+                G.t[0] = mfma4(dap, hp, G.t[0]); G.t[1] = mfma4(dbp, hp, G.t[1]); G.t[2] = mfma4(dcp, hp, G.t[2]);
+            }
+            if constexpr (DX) {
+                const float2 gx = polar_sample_bwd(amp, ct, st, row_sum16(w.sa * dap), row_sum16(w.sp1 * dbp),
+                                                   row_sum16(w.sp2 * dcp));
+                if (id.col == 0) dxs[s * kChunkPad + tt] = gx;
+            }
             dhp = tab_rotdot<1>(dhp, tl, 7 + 0, dap);
             dhp = tab_rotdot<1>(dhp, tl, 7 + 1, dbp);
             dhp = tab_rotdot<1>(dhp, tl, 7 + 2, dcp);
@@ -225,7 +234,7 @@ __device__ __forceinline__ void janet_write_partials(float* prow, const JanetLay
     if (lane == 0) { prow[L.o_bo] = b0; prow[L.o_bo + 1] = b1; }
 }
 
-template <int dummy = 0>
+template <bool NW, bool DX>
 __global__ __launch_bounds__(kMaxThreads, 2) void janet_bwd_kernel(SeqArgs a) {
     constexpr int SPW = 4, S = kCkptStride;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -237,8 +246,9 @@ __global__ __launch_bounds__(kMaxThreads, 2) void janet_bwd_kernel(SeqArgs a) {
     float* tab = smem + pad4(L.P);
     fill_janet_tabs<true>(tab, pl, L, lane, id.wave, id.nwb);
     const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
-    float2* xs = reinterpret_cast<float2*>(tab + kJTabFloats) + id.wave * (2 * SPW * kChunkPad);
+    float2* xs = reinterpret_cast<float2*>(tab + kJTabFloats) + id.wave * (3 * SPW * kChunkPad);
     float2* dys = xs + SPW * kChunkPad;
+    float2* dxs = dys + SPW * kChunkPad;
     JanetW w;
     load_janet_w(w, pl, L, col);
     JanetGrad G;
@@ -252,6 +262,13 @@ __global__ __launch_bounds__(kMaxThreads, 2) void janet_bwd_kernel(SeqArgs a) {
             const int tb = blk * S, nstep = min(S, a.T - tb);
             const int chunk = tb / kChunk, t0 = chunk * kChunk;
             if (chunk != cur_chunk) {
+                if constexpr (DX) {
+                    if (cur_chunk >= 0) {
+                        const int pt0 = cur_chunk * kChunk;
+                        wave_lds_fence();
+                        stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                    }
+                }
                 wave_lds_fence();
                 const int len = min(kChunk, a.T - t0);
                 stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
@@ -260,24 +277,34 @@ __global__ __launch_bounds__(kMaxThreads, 2) void janet_bwd_kernel(SeqArgs a) {
                 cur_chunk = chunk;
             }
             const float h0 = blk ? a.ckpt[((size_t)grp * a.nck + blk) * 64 + lane] : 0.0f;
-            if (nstep == S) janet_bwd_block<true>(a, w, tlane, G, id, xs, dys, tb - t0, nstep, h0, dh);
-            else janet_bwd_block<false>(a, w, tlane, G, id, xs, dys, tb - t0, nstep, h0, dh);
+            if (nstep == S) janet_bwd_block<NW, DX, true>(a, w, tlane, G, id, xs, dys, dxs, tb - t0, nstep, h0, dh);
+            else janet_bwd_block<NW, DX, false>(a, w, tlane, G, id, xs, dys, dxs, tb - t0, nstep, h0, dh);
+        }
+        if constexpr (DX) {
+            if (cur_chunk >= 0) {
+                const int pt0 = cur_chunk * kChunk;
+                wave_lds_fence();
+                stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                wave_lds_fence();
+            }
         }
     }
-    const int P4 = L.P + kLossCols;
-    __syncthreads();
-    janet_write_partials(smem + id.wave * P4, L, G, lane, col);
-    __syncthreads();
-    float* prow = a.partials + (size_t)blockIdx.x * P4;
-    for (int i = threadIdx.x; i < P4; i += blockDim.x) {
-        float v = smem[i];
-        for (int wv = 1; wv < id.nwb; ++wv) v += smem[wv * P4 + i];
-        prow[i] = v;
+    if constexpr (NW) {
+        const int P4 = L.P + kLossCols;
+        __syncthreads();
+        janet_write_partials(smem + id.wave * P4, L, G, lane, col);
+        __syncthreads();
+        float* prow = a.partials + (size_t)blockIdx.x * P4;
+        for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+            float v = smem[i];
+            for (int wv = 1; wv < id.nwb; ++wv) v += smem[wv * P4 + i];
+            prow[i] = v;
+        }
     }
 }
 
 static size_t janet_lds_bytes(int P, int waves, bool reduce) {
-    size_t n = ((size_t)pad4(P) + kJTabFloats + (size_t)waves * 2 * (2 * 4 * kChunkPad)) * sizeof(float);
+    size_t n = ((size_t)pad4(P) + kJTabFloats + (size_t)waves * 3 * (2 * 4 * kChunkPad)) * sizeof(float);
     if (reduce && n < reduce_scratch_bytes(P, waves)) n = reduce_scratch_bytes(P, waves);
     return n;
 }
@@ -295,15 +322,19 @@ int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 }
 int janet_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
-    if (a.dx != nullptr) return ODPD_EUNSUPPORTED;
-    if (a.partials == nullptr) return ODPD_EINVAL;
+    const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
+    if (!nw && !dx) return ODPD_EINVAL;
     const int P = janet_layout(m->hidden).P;
     const LaunchShape ls = janet_bwd_shape(a.ngroups);
-    const size_t lds = janet_lds_bytes(P, ls.waves, true);
-    auto k = janet_bwd_kernel<0>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
-    return (int)hipGetLastError();
+    const size_t lds = janet_lds_bytes(P, ls.waves, nw);
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    if (nw && dx) return launch(janet_bwd_kernel<true, true>);
+    if (nw) return launch(janet_bwd_kernel<true, false>);
+    return launch(janet_bwd_kernel<false, true>);
 }
 int janet_family_rows(const odpd_model_t* m, int B) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;

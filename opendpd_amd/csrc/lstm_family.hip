@@ -285,12 +285,6 @@ struct VdAcc {
         for (int k = 0; k < 4; ++k) a[k] = c[k] = s[k] = 0.0f;
     }
 };
-// d(a, cos, sin)/d(I, Q) of one sample: a = |x|, cos = I/a, sin = Q/a
-__device__ __forceinline__ float2 vd_sample_bwd(float a_, float cw, float sw, float ga, float gc, float gs) {
-    const float ia = fast_rcp(a_);
-    const float cross = __builtin_fmaf(gc, sw, -gs * cw);      // gc*sin - gs*cos
-    return make_float2(__builtin_fmaf(ga, cw, cross * (sw * ia)), __builtin_fmaf(ga, sw, -cross * (cw * ia)));
-}
 
 template <int R, bool VD, bool NW, bool DX, bool FULL>
 __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, VD>& w, const float* pl, const LstmLayout& L,
@@ -431,7 +425,7 @@ __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, 
                                     __builtin_fmaf(w.wih[2][k], dpg, w.wih[3][k] * dpo)));
                     acc.a[k] += seq_sum<R>(p);
                 }
-                const float2 g = vd_sample_bwd(win.a[3], win.cw[3], win.sw[3], acc.a[3], acc.c[3], acc.s[3]);
+                const float2 g = polar_sample_bwd(win.a[3], win.cw[3], win.sw[3], acc.a[3], acc.c[3], acc.s[3]);
                 if ((lane & (LPS - 1)) == 0) dxs[s * kChunkPad + tt] = g;
 #pragma unroll
                 for (int k = 3; k > 0; --k) { acc.a[k] = acc.a[k - 1]; acc.c[k] = acc.c[k - 1]; acc.s[k] = acc.s[k - 1]; }
@@ -565,7 +559,7 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
                         const float2 xv = reinterpret_cast<const float2*>(a.x)[e];
                         float a_, cw, sw;
                         vd_elem(xv, a_, cw, sw);
-                        const float2 g = vd_sample_bwd(a_, cw, sw, acc.a[k], acc.c[k], acc.s[k]);
+                        const float2 g = polar_sample_bwd(a_, cw, sw, acc.a[k], acc.c[k], acc.s[k]);
                         atomicAdd(a.dx + 2 * e, g.x);
                         atomicAdd(a.dx + 2 * e + 1, g.y);
                     }

@@ -276,6 +276,13 @@ __device__ __forceinline__ void feat_bwd(float I, float Q, const float (&df)[Fea
     }
     dI = gi; dQ = gq;
 }
+// gradient of the polar input features of one sample: a = |x|, cos = I/a, sin = Q/a (vdlstm.py:66-76,
+// pgjanet.py:38-44 via atan2) -> (dL/dI, dL/dQ) given dL/d(a, cos, sin)
+__device__ __forceinline__ float2 polar_sample_bwd(float a_, float cw, float sw, float ga, float gc, float gs) {
+    const float ia = fast_rcp(a_);
+    const float cross = __builtin_fmaf(gc, sw, -gs * cw);      // gc*sin - gs*cos
+    return make_float2(__builtin_fmaf(ga, cw, cross * (sw * ia)), __builtin_fmaf(ga, sw, -cross * (cw * ia)));
+}
 // per-lane selector: lane col j gets f[j] for j < F, `one` for j == F, 0 otherwise
 template <int F>
 __device__ __forceinline__ float feat_select(const float (&f)[F], int col, float one) {

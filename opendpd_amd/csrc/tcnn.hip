@@ -7,8 +7,10 @@
 //   backward: one workgroup per (channel, slice of the batch); for every sequence of the slice the five stages of that
 //             channel are recomputed into LDS, back-propagated, and the channel's 29 parameter gradients accumulate in
 //             per-thread registers; one block reduction at the end -> columns of partial row `slice`.
-// Zero padding semantics: every stage's activation is 0 outside [0,T) (PyTorch pads each conv input).  dL/dx is not
-// implemented (needs a cross-channel sum; TCNN is not used as a frozen PA in the reference scripts).
+//   dL/dx   : (frozen PA of a cascade) the forward tiling with a 64-step halo: dx[t] needs dL/d pre of the last stage at
+//             t +- 30, whose activations need x at +- 30 around them.  Channels are looped inside the workgroup, so the
+//             cross-channel sum sum_c gp0_c[t] W0[c][:] stays in six registers per thread: deterministic, no atomics.
+// Zero padding semantics: every stage's activation is 0 outside [0,T) (PyTorch pads each conv input).
 #include "odpd_seq.h"
 
 namespace odpd {
@@ -179,6 +181,71 @@ __global__ __launch_bounds__(1024) void tcnn_bwd_kernel(SeqArgs a, int tile, int
     if (c == 0 && threadIdx.x < kLossCols) a.partials[(size_t)slice * (L.P + kLossCols) + L.P + threadIdx.x] = 0.0f;
 }
 
+// grid = (ntiles, B); block = nthreads (tile + 64-step halo each side); LDS = 2 * nthreads floats
+constexpr int kTHaloDx = 64;
+__global__ __launch_bounds__(1024) void tcnn_dx_kernel(SeqArgs a, int tile) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = blockDim.x, pos = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * tile, t = t0 - kTHaloDx + pos;
+    const bool in = t >= 0 && t < a.T;
+    const TcnnLayout L = tcnn_layout(a.H);
+    const float* __restrict__ p = a.params;
+    const float2 xv = in ? reinterpret_cast<const float2*>(a.x)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
+    const float2 dyv = in ? reinterpret_cast<const float2*>(a.dy)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
+    float f[6], df[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    tcnn_feat(xv, in, f);
+    float* buf = smem; float* gbuf = smem + n;
+    for (int c = 0; c < L.C; ++c) {
+        // forward of channel c; the thread keeps its own pre-activations of the five stages
+        float pre[5];
+        float v = p[L.o_b0 + c];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
+        pre[0] = v;
+        float act = in ? hardswishf_(v) : 0.0f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int d = 1 << l;
+            __syncthreads();
+            buf[pos] = act;
+            __syncthreads();
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(buf, pos + d * (k - 2), n), s);
+            pre[l + 1] = s;
+            act = in ? hardswishf_(s) : 0.0f;
+        }
+        // backward of channel c down to the features
+        float g = __builtin_fmaf(dyv.x, p[L.o_w5 + c], dyv.y * p[L.o_w5 + L.C + c]);
+#pragma unroll
+        for (int l = 3; l >= 0; --l) {
+            const int d = 1 << l;
+            const float gp = in ? g * hsg(pre[l + 1]) : 0.0f;
+            __syncthreads();
+            gbuf[pos] = gp;
+            __syncthreads();
+            g = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) g = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(gbuf, pos - d * (k - 2), n), g);
+        }
+        const float gp0 = in ? g * hsg(pre[0]) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) df[i] = __builtin_fmaf(gp0, p[L.o_w0 + c * 6 + i], df[i]);
+    }
+    if (in && pos >= kTHaloDx && pos < kTHaloDx + tile) {
+        float dI, dQ;
+        feat_bwd<FEAT_DGRU6>(xv.x, xv.y, df, dI, dQ);
+        reinterpret_cast<float2*>(a.dx)[(size_t)b * a.T + t] = make_float2(dI + dyv.x, dQ + dyv.y);   // + residual path
+    }
+}
+struct TcnnTileDx { int nthreads, tile, ntiles; };
+inline TcnnTileDx tcnn_tiling_dx(int T) {
+    TcnnTileDx t;
+    int want = (T < 896 ? T : 896) + 2 * kTHaloDx;
+    int nw = (want + 63) / 64; if (nw > 16) nw = 16;
+    t.nthreads = 64 * nw; t.tile = t.nthreads - 2 * kTHaloDx; t.ntiles = (T + t.tile - 1) / t.tile;
+    return t;
+}
+
 static int tcnn_slices(int B, int ntiles, int C) {
     const int nwork = B * ntiles;
     int want = (8 * device_cus() + C - 1) / C;     // ~8 blocks per CU overall
@@ -194,13 +261,19 @@ int tcnn_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 }
 int tcnn_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
-    if (a.dx != nullptr) return ODPD_EUNSUPPORTED;
-    if (a.partials == nullptr) return ODPD_EINVAL;
-    const TcnnTile tl = tcnn_tiling(a.T);
-    const int ns = tcnn_slices(a.B, tl.ntiles, m->hidden);
-    size_t lds = (size_t)10 * tl.nthreads * sizeof(float);
-    if (lds < 16 * 32 * sizeof(float)) lds = 16 * 32 * sizeof(float);
-    hipLaunchKernelGGL(tcnn_bwd_kernel, dim3(m->hidden, ns), dim3(tl.nthreads), lds, st, a, tl.tile, tl.ntiles, ns);
+    if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
+    if (a.partials != nullptr) {
+        const TcnnTile tl = tcnn_tiling(a.T);
+        const int ns = tcnn_slices(a.B, tl.ntiles, m->hidden);
+        size_t lds = (size_t)10 * tl.nthreads * sizeof(float);
+        if (lds < 16 * 32 * sizeof(float)) lds = 16 * 32 * sizeof(float);
+        hipLaunchKernelGGL(tcnn_bwd_kernel, dim3(m->hidden, ns), dim3(tl.nthreads), lds, st, a, tl.tile, tl.ntiles, ns);
+        if (int e = (int)hipGetLastError()) return e;
+    }
+    if (a.dx != nullptr) {
+        const TcnnTileDx td = tcnn_tiling_dx(a.T);
+        hipLaunchKernelGGL(tcnn_dx_kernel, dim3(td.ntiles, a.B), dim3(td.nthreads), 2 * td.nthreads * sizeof(float), st, a, td.tile);
+    }
     return (int)hipGetLastError();
 }
 int tcnn_rows(const odpd_model_t* m, int B, int T) {

@@ -32,20 +32,22 @@ def test_golden_forward_backward(name, bb):
         pytest.skip(f"{bb} kernel not built yet")
     fx = Fixture(name)
     net = _model(fx, bb)
-    y = net(torch.from_numpy(fx["x"]).cuda())
+    x = torch.from_numpy(fx["x"]).cuda().requires_grad_(True)
+    y = net(x)
     assert rel_err(y.detach().cpu().numpy(), fx["y"]) < FWD_TOL
     loss = torch.nn.functional.mse_loss(y, torch.from_numpy(fx["tgt"]).cuda())
     assert abs(loss.item() - fx["losses"][0]) < 1e-5 * max(1.0, fx["losses"][0])
     loss.backward()
     for k, p in net.named_parameters():
         assert rel_err(p.grad.cpu().numpy(), fx["g/" + k]) < GRAD_TOL, k
+    assert rel_err(x.grad.cpu().numpy(), fx["gx"]) < GRAD_TOL
     with torch.no_grad():
         ya = net(torch.from_numpy(fx["xa"]).cuda())
     assert rel_err(ya.cpu().numpy(), fx["ya"]) < FWD_TOL
 
 
 @pytest.mark.parametrize("bb,H", [("pgjanet", 11), ("pgjanet", 8), ("pgjanet", 16), ("tcnn", 35), ("tcnn", 8), ("tcnn", 30)])
-@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 32), (7, 33), (5, 200), (66, 63)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 32), (7, 33), (5, 200), (66, 63), (2, 2100)])
 def test_against_oracle_ragged(bb, H, B, T):
     if not _supported(bb):
         pytest.skip(f"{bb} kernel not built yet")
@@ -62,16 +64,25 @@ def test_against_oracle_ragged(bb, H, B, T):
     ph = 2 * np.pi * rng.rand(B, T, 1)
     x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
     dy = rng.randn(B, T, 2).astype(np.float32)
-    y = net(torch.from_numpy(x).cuda())
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)     # (2, 2100): TCNN time tiles with halos, several BPTT chunks
+    y = net(xt)
     y.backward(torch.from_numpy(dy).cuda())
     o = Oracle("f32")
     m = make_model(bb, H)
     p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
     yo, _ = o.forward(m, p, x)
-    go, _ = o.backward(m, p, x, dy, need_dx=False)
+    go, dxo = o.backward(m, p, x, dy)
     g = np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()])
     assert rel_err(y.detach().cpu().numpy(), yo) < FWD_TOL
     assert rel_err(g, go) < GRAD_TOL
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
+    # frozen model (PA of a cascade): dL/dx alone
+    for q in net.parameters():
+        q.requires_grad_(False)
+        q.grad = None
+    xt2 = torch.from_numpy(x).cuda().requires_grad_(True)
+    net(xt2).backward(torch.from_numpy(dy).cuda())
+    assert rel_err(xt2.grad.cpu().numpy(), dxo) < GRAD_TOL
 
 
 @pytest.mark.parametrize("name,bb", GOLDEN)
