@@ -67,3 +67,37 @@ def test_cascade_fused_steps_follow_reference(name, dpd_bb, pa_bb):
         got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in net.dpd_model.parameters()])
         assert rel_err(got, fx.flat(f"p{s}", names)) < 3e-5, s
     assert torch.equal(pa_before, net.pa_model.backbone.flat_params())   # PA untouched
+
+
+@pytest.mark.parametrize("pa_bb,pa_h", [("lstm", 14), ("vdlstm", 13), ("pgjanet", 11), ("tcnn", 35), ("dgru", 23), ("qgru_amp1", 10)])
+@pytest.mark.parametrize("dpd_bb,dpd_h", [("dgru", 9), ("deltagru_tcnskip", 15)])
+def test_cascade_with_every_pa_backbone_against_oracle(pa_bb, pa_h, dpd_bb, dpd_h):
+    """Every float backbone with dL/dx can be the frozen PA of train_dpd: DPD gradient of the five-launch cascade step
+    == oracle composition (DPD fwd, PA fwd, MSE, PA backward for dL/du only, DPD backward)."""
+    from opendpd_amd import CascadedModel, CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(pa_h * 7 + dpd_h)
+    B, T = 6, 70
+    dpd = CoreModel(2, dpd_h, 1, dpd_bb)
+    pa = CoreModel(2, pa_h, 1, pa_bb)
+    net = CascadedModel(dpd_model=dpd, pa_model=pa)
+    net.freeze_pa_model()
+    net = net.cuda()
+    rng = np.random.RandomState(pa_h)
+    x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    o = Oracle("f32")
+    md, mp = make_model(dpd_bb, dpd_h), make_model(pa_bb, pa_h)
+    pd = dpd.backbone.flat_params().detach().cpu().numpy().copy()
+    pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
+    u, _ = o.forward(md, pd, x)
+    y, _ = o.forward(mp, pp, u)
+    lo, dy = o.loss("l2", y, t)
+    _, du = o.backward(mp, pp, u, dy)
+    gd, _ = o.backward(md, pd, x, du, need_dx=False)
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    lg = fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), "l2", 0.0)
+    assert abs(lg.item() - lo) < 2e-5 * max(1.0, lo)
+    assert rel_err(opt.grad[:-4].cpu().numpy(), gd) < 3e-4
+    assert torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp))
