@@ -1158,3 +1158,11 @@ int oracle_max_threads(void) {
     return 1;
 #endif
 }
+/* number of OpenMP threads the batch loops use from now on (bench.py: 1-thread and all-core baselines) */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -58,6 +58,9 @@ class Oracle:
     def max_threads(self):
         return int(self.lib.oracle_max_threads())
 
+    def set_threads(self, n):
+        self.lib.oracle_set_threads(int(n))
+
     def forward(self, m, params, x, stats=None):
         x = self._a(x)
         params = self._a(params)

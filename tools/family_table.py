@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Train-step and forward throughput of every HIP backbone (one process, HIP events) -> markdown table.
+usage (GPU box): PYTHONPATH=. python tools/family_table.py [--big 32768] [--out file.md]"""
+import argparse
+
+import torch
+
+from opendpd_amd import CascadedModel, CoreModel
+from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--big", type=int, default=32768)
+ap.add_argument("--T", type=int, default=200)
+ap.add_argument("--out", default=None)
+a = ap.parse_args()
+T = a.T
+
+
+def timeit(fn, n, w=2):
+    for _ in range(w):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def data(B):
+    g = torch.Generator(device="cuda").manual_seed(B)
+    x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    return x, torch.randn(B, T, 2, device="cuda", generator=g) * 0.3
+
+
+CASES = [("gru", 11, {}), ("dgru", 13, {}), ("dgru", 23, {}), ("qgru", 10, {}), ("lstm", 14, {}), ("vdlstm", 13, {}),
+         ("deltagru", 15, dict(thx=0.01, thh=0.05)), ("deltagru_tcnskip", 15, dict(thx=0.01, thh=0.05)), ("pgjanet", 11, {}),
+         ("tcnn", 35, {})]
+rows = []
+for bb, H, kw in CASES:
+    torch.manual_seed(0)
+    net = CoreModel(2, H, 1, bb, **kw).cuda()
+    P = sum(p.numel() for p in net.parameters())
+    opt = FusedAdamW(net, lr=1e-4)
+    cells = []
+    for B in (256, a.big):
+        x, t = data(B)
+        ms = timeit(lambda: fused_train_step(opt, x, t, "l2", 200.0), 20 if B <= 1024 else 5)
+        with torch.no_grad():
+            msf = timeit(lambda: net(x), 20 if B <= 1024 else 5)
+        cells += [ms, B * T / ms / 1e3, msf, B * T / msf / 1e3]
+    kind = "fused (1 launch)" if opt.has_fused(a.big, T) else "split (fwd, loss, bwd)"
+    rows.append((f"{bb} H{H}", P, kind, *cells))
+# train_dpd cascade of BASELINE config 3
+torch.manual_seed(0)
+casc = CascadedModel(dpd_model=CoreModel(2, 15, 1, "deltagru_tcnskip", thx=0.01, thh=0.05), pa_model=CoreModel(2, 23, 1, "dgru"))
+casc.freeze_pa_model()
+casc = casc.cuda()
+opt = FusedAdamW(casc, lr=1e-4)
+cells = []
+for B in (64, a.big):
+    x, t = data(B)
+    ms = timeit(lambda: fused_train_step(opt, x, t, "l2", 200.0), 20 if B <= 1024 else 5)
+    with torch.no_grad():
+        msf = timeit(lambda: casc(x), 20 if B <= 1024 else 5)
+    cells += [ms, B * T / ms / 1e3, msf, B * T / msf / 1e3]
+rows.append(("train_dpd: TRes-DeltaGRU15 -> frozen DGRU23 (B = 64 | big)", 999, "cascade (5 launches)", *cells))
+
+hdr = (f"| backbone | params | train step | B=256: step ms | M samples/s | fwd ms | M samples/s | B={a.big}: step ms | M samples/s | fwd ms "
+       f"| M samples/s |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+body = "".join(f"| {r[0]} | {r[1]} | {r[2]} | " + " | ".join(f"{v:.3f}" if i % 2 == 0 else f"{v:.0f}" for i, v in enumerate(r[3:])) + " |\n"
+               for r in rows)
+txt = (f"# Train-step (fwd + MSE + BPTT + clip 200 + AdamW) and forward-only throughput, T = {T}, fp32, 1 x MI355X\n\n"
+       "`tools/family_table.py`, HIP events around repeated calls, inputs resident in HBM.\n\n" + hdr + body)
+print(txt)
+if a.out:
+    open(a.out, "w").write(txt)
