@@ -138,6 +138,7 @@ class NativeBackbone(nn.Module):
         self.n_flat = off
         self._flat = None
         self._stats = None
+        self._sentinels = None
 
     # -- flat parameter buffer ---------------------------------------------------------------
     def _reflatten(self):
@@ -148,17 +149,26 @@ class NativeBackbone(nn.Module):
             for p, (o, n, shape) in zip(ps, self._slices):
                 p.data = flat[o:o + n].view(shape)
         self._flat = flat
+        # first and last parameter stand guard for the whole buffer on the per-step fast path
+        self._sentinels = ((ps[0], 0), (ps[-1], 4 * self._slices[-1][0]))
 
-    def flat_params(self):
-        """The contiguous parameter buffer (re-built if a parameter was re-pointed, e.g. by .to())."""
+    def flat_params(self, full_check=False):
+        """The contiguous parameter buffer (re-built if a parameter was re-pointed, e.g. by .to() — `_apply` drops it;
+        the per-call check looks at the first and last parameter only, `full_check` at every one)."""
         f = self._flat
         ok = f is not None
         if ok:
             base = f.data_ptr()
-            for p, (o, n, _) in zip(self.parameters(), self._slices):
-                if p.data_ptr() != base + 4 * o or p.device != f.device:
-                    ok = False
-                    break
+            if full_check:
+                for p, (o, n, _) in zip(self.parameters(), self._slices):
+                    if p.data_ptr() != base + 4 * o or p.device != f.device:
+                        ok = False
+                        break
+            else:
+                for p, off in self._sentinels:
+                    if p.data_ptr() != base + off:
+                        ok = False
+                        break
         if not ok:
             self._reflatten()
         return self._flat

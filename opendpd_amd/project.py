@@ -37,26 +37,31 @@ def count_net_params(net):
 
 
 class DeviceFrameLoader:
-    """Iterates (features, targets) batches of frames gathered ON DEVICE from the resident I/Q streams.
-    The batch index order comes from a torch DataLoader over range(n) with shuffle=True, i.e. exactly the global-RNG
-    consumption of the reference's DataLoader(train_set, shuffle=True) (project.py:236)."""
+    """Iterates (features, targets) batches of frames gathered ON DEVICE from the resident I/Q streams (no
+    materialised frame tensor: a frame is a start offset into the stream, data_collector.py:239-247).
+    The epoch's frame order comes from ONE pass of a torch DataLoader over range(n) with shuffle=True, i.e. exactly
+    the global-RNG consumption (base seed + sampler seed) and permutation of the reference's
+    DataLoader(train_set, shuffle=True) (project.py:236); each step is then two index_select launches on an
+    overlapping-window view of the stream and no host<->device traffic."""
 
     def __init__(self, x, y, frame_length, stride, batch_size, device, shuffle=True):
-        self.x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device)
-        self.y = torch.as_tensor(np.asarray(y), dtype=torch.float32).to(device)
+        self.x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device).contiguous()
+        self.y = torch.as_tensor(np.asarray(y), dtype=torch.float32).to(device).contiguous()
         self.n = (len(x) - frame_length) // stride + 1
-        self.stride, self.device = stride, device
-        self.offs = torch.arange(frame_length, device=device)
-        self.index_loader = DataLoader(range(self.n), batch_size=batch_size, shuffle=shuffle)
+        self.batch_size, self.device = batch_size, device
+        win = lambda s: torch.as_strided(s, (self.n, frame_length, 2), (2 * stride, 2, 1))
+        self.fx, self.fy = win(self.x), win(self.y)
+        self.order_loader = DataLoader(range(self.n), batch_size=self.n, shuffle=shuffle)
 
     def __len__(self):
-        return len(self.index_loader)
+        return (self.n + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
-        for idx in self.index_loader:
-            rows = idx.to(self.device) * self.stride
-            g = rows[:, None] + self.offs[None, :]
-            yield self.x[g], self.y[g]
+        (order,) = list(self.order_loader)
+        order = order.to(self.device)
+        for i in range(0, self.n, self.batch_size):
+            idx = order[i:i + self.batch_size]
+            yield self.fx.index_select(0, idx), self.fy.index_select(0, idx)
 
 
 class ReduceLROnPlateau:

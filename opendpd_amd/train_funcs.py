@@ -142,22 +142,25 @@ class FusedAdamW:
         from .dist import allreduce_sum_
         allreduce_sum_(self.grad, self.process_group)
 
-    def apply(self, max_norm):
+    def apply(self, max_norm, stream=None):
         """clip (max_norm, 0 = off) + AdamW on the flat buffers; self.grad must hold the global gradient."""
         lib = _lib.load()
         g = self.param_groups[0]
         self.step_count += 1
         flat = self.backbone.flat_params()
+        if stream is None:
+            stream = _lib.stream_ptr()
         frozen = getattr(self.backbone, "frozen_mask", None)     # parameters torch.optim.AdamW would skip (grad is None)
         if frozen is not None:
             if frozen.device != flat.device:
                 self.backbone.frozen_mask = frozen = frozen.to(flat.device)
             keep = flat[frozen].clone()
-        rc = lib.odpd_clip_adamw_step(_lib.stream_ptr(), self.backbone.n_flat, _lib.ptr(flat), _lib.ptr(self.grad),
+        rc = lib.odpd_clip_adamw_step(stream, self.backbone.n_flat, _lib.ptr(flat), _lib.ptr(self.grad),
                                       _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.step_count,
                                       float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                       float(g["weight_decay"]), float(max_norm or 0.0), _lib.ptr(self.norm))
-        _lib.check(rc, "odpd_clip_adamw_step")
+        if rc:
+            _lib.check(rc, "odpd_clip_adamw_step")
         if frozen is not None:
             flat[frozen] = keep
             self.exp_avg[frozen] = 0
@@ -187,18 +190,21 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     part = opt.partials(B, T, x.device)
     ws = opt.train_workspace(B, T, x.device)
     flat = bb.flat_params()
+    st = _lib.stream_ptr()
     if timing is not None:
         timing[0].record()
-    rc = lib.odpd_train_fwd_bwd(_lib.stream_ptr(), C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], B, T, count,
+    rc = lib.odpd_train_fwd_bwd(st, C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], B, T, count,
                                 _lib.ptr(flat), _lib.ptr(x), _lib.ptr(target), _lib.ptr(part), _lib.ptr(ws))
     if timing is not None:
         timing[1].record()
-    _lib.check(rc, f"odpd_train_fwd_bwd[{bb.backbone_name}]")
-    rc = lib.odpd_reduce_partials(_lib.stream_ptr(), part.shape[0], bb.n_flat, _lib.ptr(part), _lib.ptr(opt.grad), 0)
-    _lib.check(rc, "odpd_reduce_partials")
+    if rc:
+        _lib.check(rc, f"odpd_train_fwd_bwd[{bb.backbone_name}]")
+    rc = lib.odpd_reduce_partials(st, part.shape[0], bb.n_flat, _lib.ptr(part), _lib.ptr(opt.grad), 0)
+    if rc:
+        _lib.check(rc, "odpd_reduce_partials")
     opt.allreduce_grad()
     loss = opt.grad[bb.n_flat] / count      # column P = sum of squared / absolute errors
-    opt.apply(grad_clip_val)
+    opt.apply(grad_clip_val, st)
     return loss
 
 
