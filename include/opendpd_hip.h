@@ -118,6 +118,26 @@ int odpd_loss_fwd_bwd(void* stream, int kind, int64_t n, int64_t count, const fl
 int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_kind, int B, int T,
                        int64_t count, const float* params, const float* x, const float* target,
                        float* partials, float* workspace);
+/* Frames addressed as windows of resident I/Q streams — what IQFrameDataset materialises with np.stack
+ * (data_collector.py:239-247): frame f = samples [f*stride, f*stride + frame_length) of the (N,2) fp32 streams. */
+typedef struct odpd_frames {
+    const float* x_stream;  /* (N,2) device: model input stream */
+    const float* y_stream;  /* (N,2) device: target stream */
+    const int64_t* order;   /* device, n_frames frame indices in visiting order (the DataLoader's epoch permutation) */
+    int64_t n_frames;
+    int32_t frame_length;
+    int32_t stride;
+} odpd_frames_t;
+/* One training epoch of a single backbone that has a fused kernel (GRU family): for every batch of `batch`
+ * frames of fr->order (last one may be smaller) the step of train_funcs.py:33-44 — fused fwd+loss+bwd reading the
+ * frames straight from the streams, reduction, clip + AdamW with step index first_step + i — issued from C++ with
+ * no host synchronisation.  losses_out (device, ceil(n_frames/batch) floats) receives the per-batch mean losses
+ * (train_funcs.py:48-50 averages them).  partials / workspace sized for B = batch by odpd_partial_rows(.., 1) /
+ * odpd_train_workspace_floats.  Single process only (no all-reduce between reduction and optimiser step). */
+int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch,
+                     float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t first_step, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, double max_norm, float* partials,
+                     float* workspace, float* losses_out);
 /* clip_grad_norm_(max_norm) (0 = no clipping) + AdamW step over P parameters
  * (torch.optim.AdamW defaults project.py:283: betas .9/.999, eps 1e-8, weight_decay 0.01).
  * grad is scaled in place like clip_grad_norm_ does.  `step` is the 1-based step index.

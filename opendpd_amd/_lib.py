@@ -20,6 +20,12 @@ class ModelDesc(C.Structure):
                 ("bits_w", C.c_int32), ("bits_a", C.c_int32), ("flags", C.c_int32)]
 
 
+class Frames(C.Structure):
+    """odpd_frames_t"""
+    _fields_ = [("x_stream", C.c_void_p), ("y_stream", C.c_void_p), ("order", C.c_void_p), ("n_frames", C.c_int64),
+                ("frame_length", C.c_int32), ("stride", C.c_int32)]
+
+
 _EXPORTS = {
     # name: (restype, argtypes)
     "odpd_abi_version": (C.c_int, []),
@@ -38,6 +44,9 @@ _EXPORTS = {
     "odpd_train_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
     "odpd_train_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "odpd_train_epoch": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "odpd_clip_adamw_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                        C.c_void_p]),

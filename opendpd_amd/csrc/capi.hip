@@ -172,3 +172,41 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     default: return ODPD_EUNSUPPORTED;
     }
 }
+
+// Native epoch loop (replaces the Python `for batch in loader` of net_train, train_funcs.py:28-48, for a single
+// backbone with a fused kernel): every step = fused fwd+loss+bwd on frames addressed inside the resident streams,
+// reduction, clip + AdamW; three launches per step issued back to back from C++, no host synchronisation, no
+// gather kernels, no Python between steps.  losses_out[i] = mean loss of batch i (device).
+extern "C" int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch,
+                                float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t first_step, double lr,
+                                double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                                float* partials, float* workspace, float* losses_out) {
+    if (!model_ok(m) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
+        fr->stride <= 0 || batch <= 0 || !params || !grad || !exp_avg || !exp_avg_sq || !partials || !losses_out || first_step <= 0)
+        return ODPD_EINVAL;
+    if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    const int T = fr->frame_length;
+    const int64_t P = odpd_param_count(m);
+    hipStream_t st = (hipStream_t)stream;
+    int64_t step = first_step;
+    for (int64_t f0 = 0, i = 0; f0 < fr->n_frames; f0 += batch, ++i, ++step) {
+        const int B = (int)((fr->n_frames - f0) < batch ? (fr->n_frames - f0) : batch);
+        const int64_t rows = odpd_partial_rows(m, B, T, 1);
+        if (rows <= 0) return rows < 0 ? (int)rows : ODPD_EUNSUPPORTED;
+        SeqArgs a = make_args(m, B, T);
+        a.params = params; a.x = fr->x_stream; a.target = fr->y_stream; a.partials = partials; a.ckpt = workspace;
+        a.frame_idx = (const long long*)(fr->order + f0); a.frame_stride = fr->stride;
+        const int64_t count = (int64_t)B * T * 2;
+        a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
+        const bool s16 = gru_train_uses_s16(m, B, T);
+        if (s16 && !workspace) return ODPD_EINVAL;
+        int rc = s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a);
+        if (rc) return rc;
+        rc = odpd_reduce_partials(stream, rows, P, partials, grad, 0);
+        if (rc) return rc;
+        rc = launch_clip_adamw(st, P, params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, max_norm,
+                               nullptr, losses_out + i, a.inv_count);
+        if (rc) return rc;
+    }
+    return 0;
+}

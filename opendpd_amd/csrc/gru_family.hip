@@ -497,8 +497,11 @@ __device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, Fea
             }
             wave_lds_fence();
             const int len = min(kChunk, a.T - t0);
-            stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
-            stage_in<SPW>(dys, FUSED ? a.target : a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+            stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride);
+            if constexpr (FUSED)
+                stage_in<SPW>(dys, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride);
+            else
+                stage_in<SPW>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
             wave_lds_fence();
             cur_chunk = chunk;
         }
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
             for (int t0 = 0; t0 < a.T; t0 += kChunk) {
                 const int len = min(kChunk, a.T - t0);
                 wave_lds_fence();
-                stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+                stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride);
                 wave_lds_fence();
                 int tt = 0;
                 static_assert(kChunk % S == 0, "chunks start on a checkpoint boundary");

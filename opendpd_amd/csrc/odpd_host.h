@@ -88,6 +88,10 @@ struct SeqArgs {
     float* dx;            // (B,T,2), nullable
     const float* target;  // fused train step
     double* stats;        // delta sparsity counters (nullable)
+    // frames addressed as windows of a resident stream (IQFrameDataset, data_collector.py:239-247): when
+    // frame_idx != NULL, sequence b of x / target starts at sample frame_idx[b] * frame_stride of the (N,2) stream
+    const long long* frame_idx;
+    int frame_stride;
     float inv_count;      // 1 / global element count (fused loss)
     float thx, thh;
     int loss_kind;
@@ -103,6 +107,10 @@ int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, 
 bool gru_train_uses_s16(const odpd_model_t* m, int B, int T);
 int gru_s16_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_s16_rows(const odpd_model_t* m, int B);
+// optim.hip: clip + AdamW launch that also records loss = grad[P] * inv_count into loss_out (nullable)
+int launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t step,
+                      double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, float* norm_out,
+                      float* loss_out, float inv_count);
 int64_t gru_s16_workspace_floats(const odpd_model_t* m, int B, int T);
 int lstm_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);

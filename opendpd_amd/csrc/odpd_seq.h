@@ -49,9 +49,10 @@ __device__ __forceinline__ float tab_rotdot(float acc, const float4* tlane, int 
 // LDS staging of (B,T,2) streams: one chunk = kChunk steps of the wave's SPW sequences,
 // LDS layout [seq][kChunkPad] float2
 // -------------------------------------------------------------------------------------------------
+// `fidx` (nullable): frames are windows of a resident stream, row b starts at sample fidx[b] * fstride
 template <int SPW>
 __device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane,
-                                         float2 fill) {
+                                         float2 fill, const long long* fidx = nullptr, int fstride = 0) {
     const float2* g2 = reinterpret_cast<const float2*>(g);
     constexpr int N = SPW * kChunk / 64;   // float2 per lane
     static_assert(N >= 1 && (SPW * kChunk) % 64 == 0, "chunk must tile the wave");
@@ -59,7 +60,10 @@ __device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, in
     for (int j = 0; j < N; ++j) {
         const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
         float2 v = fill;
-        if (tt < len && b0 + m < B) v = g2[(size_t)(b0 + m) * T + t0 + tt];
+        if (tt < len && b0 + m < B) {
+            const size_t row = fidx ? (size_t)fidx[b0 + m] * fstride : (size_t)(b0 + m) * T;
+            v = g2[row + t0 + tt];
+        }
         lds[m * kChunkPad + tt] = v;
     }
 }

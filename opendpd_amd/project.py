@@ -48,7 +48,7 @@ class DeviceFrameLoader:
         self.x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device).contiguous()
         self.y = torch.as_tensor(np.asarray(y), dtype=torch.float32).to(device).contiguous()
         self.n = (len(x) - frame_length) // stride + 1
-        self.batch_size, self.device = batch_size, device
+        self.batch_size, self.device, self.frame_length, self.stride = batch_size, device, frame_length, stride
         win = lambda s: torch.as_strided(s, (self.n, frame_length, 2), (2 * stride, 2, 1))
         self.fx, self.fy = win(self.x), win(self.y)
         self.order_loader = DataLoader(range(self.n), batch_size=self.n, shuffle=shuffle)
@@ -56,9 +56,13 @@ class DeviceFrameLoader:
     def __len__(self):
         return (self.n + self.batch_size - 1) // self.batch_size
 
-    def __iter__(self):
+    def epoch_order(self):
+        """Frame indices of one epoch in visiting order (device int64); one call == one pass of the reference DataLoader."""
         (order,) = list(self.order_loader)
-        order = order.to(self.device)
+        return order.to(self.device)
+
+    def __iter__(self):
+        order = self.epoch_order()
         for i in range(0, self.n, self.batch_size):
             idx = order[i:i + self.batch_size]
             yield self.fx.index_select(0, idx), self.fy.index_select(0, idx)

@@ -166,6 +166,43 @@ class FusedAdamW:
             self.exp_avg[frozen] = 0
             self.exp_avg_sq[frozen] = 0
 
+    def can_run_epoch(self, loader):
+        """True when odpd_train_epoch can drive a whole epoch: single fused backbone, one process, resident streams."""
+        return (self.pa is None and self.world_size() == 1 and getattr(self.backbone, "frozen_mask", None) is None
+                and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size"))
+                and loader.x.is_cuda and self.has_fused(min(loader.batch_size, loader.n), loader.frame_length))
+
+    def train_epoch(self, loader, loss_kind, max_norm):
+        """One epoch through the native loop (odpd_train_epoch): returns the per-batch mean losses (device tensor)."""
+        lib = _lib.load()
+        dev, T, n = loader.x.device, loader.frame_length, loader.n
+        B = min(loader.batch_size, n)
+        self._ensure(dev)
+        n_steps = (n + B - 1) // B
+        last = n - (n_steps - 1) * B
+        key = (B, T, last, "epoch")
+        if key not in self._partials:
+            rows = [int(lib.odpd_partial_rows(C.byref(self.backbone.desc), b, T, 1)) for b in {B, last}]
+            _lib.check(0 if min(rows) > 0 else min(rows), "odpd_partial_rows")
+            ws = max(int(lib.odpd_train_workspace_floats(C.byref(self.backbone.desc), b, T)) for b in {B, last})
+            self._partials[key] = (torch.empty(max(rows), self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32, device=dev),
+                                   torch.empty(ws, dtype=torch.float32, device=dev) if ws > 0 else None)
+        part, ws = self._partials[key]
+        order = loader.epoch_order()
+        losses = torch.empty(n_steps, dtype=torch.float32, device=dev)
+        fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
+        g = self.param_groups[0]
+        flat = self.backbone.flat_params(full_check=True)
+        rc = lib.odpd_train_epoch(_lib.stream_ptr(), C.byref(self.backbone.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
+                                  _lib.ptr(flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                  self.step_count + 1, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                  float(g["eps"]), float(g["weight_decay"]), float(max_norm or 0.0), _lib.ptr(part),
+                                  _lib.ptr(ws), _lib.ptr(losses))
+        _lib.check(rc, "odpd_train_epoch")
+        self.step_count += n_steps
+        self._keepalive = order     # the launches read `order` asynchronously
+        return losses
+
     def step(self, max_norm=0.0):
         """Generic-path step: gathers p.grad (set by autograd) into the flat gradient, then apply()."""
         ps = list(self.trained.parameters())
@@ -250,6 +287,11 @@ def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device)
     losses = []
     kind = _loss_kind(criterion)
     fast = isinstance(optimizer, FusedAdamW) and optimizer.net is net and kind is not None
+    if fast and optimizer.can_run_epoch(dataloader):
+        # whole epoch in the native loop: frames read in place from the resident streams, 3 launches per step, no Python
+        losses = optimizer.train_epoch(dataloader, kind, grad_clip_val)
+        log["loss"] = float(losses.double().mean().item()) if losses.numel() else float("nan")
+        return net
     for features, targets in dataloader:
         features = features.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)

@@ -84,3 +84,36 @@ def test_train_dpd_and_run_dpd_match_reference(workdir):
     csv = pd.read_csv(out["output_path"])
     assert list(csv.columns) == ["I", "Q", "I_dpd", "Q_dpd"]
     assert np.abs(csv.to_numpy() - m["dpd_out"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("bb,H,F,B", [("dgru", 13, 50, 64), ("gru", 11, 200, 256), ("qgru", 10, 37, 100)])
+def test_native_epoch_loop_equals_per_step_loop(bb, H, F, B):
+    """odpd_train_epoch (frames read in place from the resident streams, C++ loop) == the Python per-batch loop over
+    gathered frame tensors: same kernels, same order, bit-identical parameters and per-epoch loss."""
+    import torch
+    from opendpd_amd import CoreModel
+    from opendpd_amd.project import DeviceFrameLoader
+    from opendpd_amd.train_funcs import FusedAdamW, net_train
+    rng = np.random.RandomState(3)
+    n = 3000
+    ph = np.cumsum(rng.randn(n) * 0.2)
+    amp = 0.1 + 0.7 * np.abs(np.sin(np.arange(n) * 0.01 + rng.rand()))
+    x = np.stack([amp * np.cos(ph), amp * np.sin(ph)], 1).astype(np.float32)
+    y = (x * (1.0 - 0.3 * (x ** 2).sum(1, keepdims=True))).astype(np.float32)
+    outs = []
+    for native in (True, False):
+        torch.manual_seed(11)
+        net = CoreModel(2, H, 1, bb).cuda()
+        opt = FusedAdamW(net, lr=2e-3)
+        loader = DeviceFrameLoader(x, y, F, 1, B, torch.device("cuda"), shuffle=True)
+        assert opt.can_run_epoch(loader)
+        log = {}
+        for _ in range(2):
+            if native:
+                net_train(log, net, loader, opt, torch.nn.MSELoss(), 200.0, torch.device("cuda"))
+            else:
+                net_train(log, net, iter(loader), opt, torch.nn.MSELoss(), 200.0, torch.device("cuda"))   # plain iterator: per-step path
+        outs.append((net.backbone.flat_params().clone(), log["loss"], opt.step_count))
+    assert outs[0][2] == outs[1][2] == 2 * ((n - F + 1 + B - 1) // B)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert abs(outs[0][1] - outs[1][1]) < 1e-6 * max(1.0, abs(outs[1][1]))
