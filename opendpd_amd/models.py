@@ -3,12 +3,15 @@
 `CoreModel(input_size, hidden_size, num_layers, backbone_type, window_size=None, num_dvr_units=None,
 thx=0, thh=0)` — same constructor, attributes, `forward(x, h_0=None)` contract and state-dict keys
 as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` as models.py:163-176.
-Backbones on the hot path run as HIP kernels; names that are out of this build's scope raise
-NotImplementedError (the reference raises ValueError only for unknown names, models.py:139-141).
+Backbones on the hot path run as HIP kernels (`backbone.native` is True); the remaining registry names (SURVEY §8 f4:
+gmp, rvtdcnn, apnrru, bojanet, deltajanet, dvrjanet, neuraltx, mcldnn) are torch restatements in backbones/extras.py that
+run through ATen (`backbone.native` is False) until they get kernels.  Unknown names raise ValueError (models.py:139-141).
 """
+import torch
 import torch.nn as nn
 
 from . import backbones as B
+from .backbones import extras as X
 
 # names the reference registry accepts (models.py:26-141)
 REFERENCE_BACKBONES = ("gmp", "gru", "dgru", "qgru", "qgru_amp1", "lstm", "vdlstm", "rvtdcnn", "apnrru", "bojanet",
@@ -53,9 +56,23 @@ class CoreModel(nn.Module):
             self.backbone = B.PGJANET(hidden_size=hidden_size, output_size=2, bias=True)
         elif backbone_type == "tcnn":
             self.backbone = B.TCNN(hidden_channels=hidden_size)
-        elif backbone_type in REFERENCE_BACKBONES:
-            raise NotImplementedError(f"backbone '{backbone_type}' is a reference registry name that this build "
-                                      f"does not provide as a HIP kernel yet")
+        elif backbone_type == "gmp":
+            self.backbone = X.GMP()
+        elif backbone_type == "rvtdcnn":
+            self.backbone = X.RVTDCNN(fc_hid_size=hidden_size)
+        elif backbone_type == "apnrru":
+            self.backbone = X.APNRRU(hidden_size=hidden_size, bias=True)
+        elif backbone_type == "bojanet":
+            self.backbone = X.BOJANET(hidden_size=hidden_size, output_size=2, bias=True)
+        elif backbone_type == "deltajanet":
+            self.backbone = X.DeltaJANET(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers, thx=thx,
+                                         thh=thh, bias=True)
+        elif backbone_type == "dvrjanet":
+            self.backbone = X.DVRJANET(hidden_size=hidden_size, output_size=2, num_dvr_units=num_dvr_units, bias=True)
+        elif backbone_type == "neuraltx":
+            self.backbone = X.NeuralTX(hidden_channels=hidden_size)
+        elif backbone_type == "mcldnn":
+            self.backbone = X.MCLDNN(hidden_size=hidden_size)
         else:
             raise ValueError(f"The backbone type '{backbone_type}' is not supported. Please add your own "
                              f"backbone under ./backbones and update models.py accordingly.")
@@ -65,6 +82,10 @@ class CoreModel(nn.Module):
             pass
 
     def forward(self, x, h_0=None):
+        if not getattr(self.backbone, "native", True):
+            if h_0 is None:  # models.py:154-155
+                h_0 = torch.zeros(self.num_layers, x.size(0), self.hidden_size, device=x.device, dtype=x.dtype)
+            return self.backbone(x, h_0)
         # the reference creates a zero h_0 (models.py:154-155); the kernels start from the zero state
         if h_0 is not None and bool((h_0 != 0).any()):
             raise NotImplementedError("non-zero initial hidden state is not supported by the HIP kernels")

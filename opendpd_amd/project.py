@@ -186,7 +186,10 @@ class Project:
 
     def build_optimizer(self, net):
         if self.opt_type == "adamw":
-            opt = FusedAdamW(net, lr=self.lr)
+            try:
+                opt = FusedAdamW(net, lr=self.lr)
+            except TypeError:   # a registry backbone without HIP kernels (backbones/extras.py): ATen path, torch optimiser
+                opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=self.lr)
         elif self.opt_type == "adam":
             opt = torch.optim.Adam(net.parameters(), lr=self.lr)
         elif self.opt_type == "sgd":

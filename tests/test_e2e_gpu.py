@@ -117,3 +117,17 @@ def test_native_epoch_loop_equals_per_step_loop(bb, H, F, B):
     assert outs[0][2] == outs[1][2] == 2 * ((n - F + 1 + B - 1) // B)
     assert torch.equal(outs[0][0], outs[1][0])
     assert abs(outs[0][1] - outs[1][1]) < 1e-6 * max(1.0, abs(outs[1][1]))
+
+
+@pytest.mark.parametrize("bb,H", [("rvtdcnn", 6), ("deltajanet", 10)])
+def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H):
+    """SURVEY §8 f4 names (backbones/extras.py) go through the same Project flow on the GPU: ATen forward/backward,
+    torch.optim.AdamW, device-resident frame loader, eval + metrics + checkpoint/log layout."""
+    import opendpd_amd as od
+    res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone=bb, PA_hidden_size=H, frame_length=50, batch_size=256, lr=2e-3,
+                      n_epochs=2, seed=0, accelerator="cuda")
+    assert res["status"] == "completed" and os.path.exists(res["model_path"])
+    hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
+    assert len(hist) == 2 and np.isfinite(hist["TRAIN_LOSS"]).all()
+    assert hist["TRAIN_LOSS"][1] < hist["TRAIN_LOSS"][0]
+    assert f"_M_{bb.upper()}_H_{H}_" in os.path.basename(res["model_path"])

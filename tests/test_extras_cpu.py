@@ -1,0 +1,56 @@
+"""Registry backbones without HIP kernels (opendpd_amd/backbones/extras.py): torch restatements pinned to
+vectors produced by running the reference (oracle/gen_golden_extras.py): a seeded construction reproduces the reference's
+initial state dict bit for bit (same parameter names, shapes, order and RNG consumption), and with the stored weights the
+output, loss, parameter gradients and input gradient match to fp32 round-off (1e-5 of the tensor's max magnitude)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import Fixture, rel_err
+
+CASES = [("gmp", 8), ("rvtdcnn", 6), ("apnrru", 8), ("bojanet", 8), ("bojanet", 15), ("deltajanet", 10), ("dvrjanet", 8),
+         ("neuraltx", 12), ("mcldnn", 8)]
+TOL = 1e-5
+
+
+def _build(bb, H):
+    from opendpd_amd import CoreModel
+    torch.manual_seed(0)
+    return CoreModel(2, H, 1, bb, window_size=4, num_dvr_units=4, thx=0.01, thh=0.05)
+
+
+@pytest.mark.parametrize("bb,H", CASES)
+def test_seeded_construction_matches_reference_state_dict(bb, H):
+    fx = Fixture(f"extra_{bb}_h{H}")
+    net = _build(bb, H)
+    after = float(torch.rand(1))
+    sd = net.state_dict()
+    assert list(sd.keys()) == fx.keys("sd")
+    for k in sd:
+        assert np.array_equal(sd[k].numpy(), fx["sd/" + k]), k
+    assert after == fx.meta["rng_after_init"]                     # the global RNG was advanced identically
+    assert sum(p.numel() for p in net.parameters()) == fx.meta["n_param"]
+    assert net.backbone.native is False
+
+
+@pytest.mark.parametrize("bb,H", CASES)
+def test_forward_backward_match_reference(bb, H):
+    fx = Fixture(f"extra_{bb}_h{H}")
+    net = _build(bb, H)
+    net.load_state_dict({k: torch.from_numpy(fx["sdu/" + k]) for k in fx.keys("sdu")})
+    x = torch.from_numpy(fx["x"]).requires_grad_(True)
+    y = net(x)
+    assert rel_err(y.detach().numpy(), fx["y"]) < TOL
+    loss = torch.nn.functional.mse_loss(y, torch.from_numpy(fx["tgt"]))
+    assert abs(float(loss) - fx.meta["loss"]) < 1e-6 * max(1.0, fx.meta["loss"])
+    loss.backward()
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.numpy(), fx["g/" + k]) < 10 * TOL, k
+    assert rel_err(x.grad.numpy(), fx["gx"]) < 10 * TOL
+
+
+def test_fused_optimizer_refuses_non_native_backbones_and_project_falls_back():
+    from opendpd_amd.train_funcs import FusedAdamW
+    net = _build("rvtdcnn", 6)
+    with pytest.raises(TypeError):
+        FusedAdamW(net)
