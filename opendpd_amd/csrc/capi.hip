@@ -89,7 +89,8 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
-    case FAM_GRU: return (int64_t)num_groups(B, R) * num_ckpt(T) * 64;
+    case FAM_GRU:   // [4-sequence group][ckpt][64 lanes], or [16-sequence task][ckpt][64 lanes][4] for the S16 kernels
+        return gru_split_uses_s16(m, B) ? (int64_t)((B + 15) / 16) * num_ckpt(T) * 256 : (int64_t)num_groups(B, R) * num_ckpt(T) * 64;
     case FAM_LSTM: return (int64_t)num_groups(B, R) * num_ckpt(T) * 128;   // h and c
     case FAM_DELTA: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 7 * 64 : (int64_t)ODPD_EUNSUPPORTED;
     case FAM_JANET: case FAM_QAT: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 64 : (int64_t)ODPD_EUNSUPPORTED;

@@ -722,15 +722,27 @@ static bool gru_setup(const odpd_model_t* m, int& FM, bool& DG, int& R, int& P) 
     return true;
 }
 
+// The split kernels switch to the 16-sequences-per-wave mapping at the same batch size as the fused one.  Forward
+// and backward of one (B,T) batch must agree (checkpoint layout), so the rule only looks at the model and B.
+bool gru_split_uses_s16(const odpd_model_t* m, int B) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P) || R != 1) return false;
+    long min_batch = tuning().s16_min_batch;
+    if (min_batch < 0) min_batch = 16L * 4 * device_cus();
+    return B >= min_batch;
+}
+
 int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    if (gru_split_uses_s16(m, a.B)) return gru_s16_fwd(st, m, a);
     ODPD_GRU_DISPATCH_ALL(launch_fwd, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
 int gru_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    if (gru_split_uses_s16(m, a.B)) return gru_s16_bwd(st, m, a);
     ODPD_GRU_DISPATCH_ALL(launch_bwd_mode, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
@@ -745,7 +757,7 @@ int gru_family_rows(const odpd_model_t* m, int B, int which, int T) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     const int ng = num_groups(B, R);
-    if (!which) return bwd_shape(R, ng).grid;
+    if (!which) return gru_split_uses_s16(m, B) ? gru_s16_bwd_rows(m, B) : bwd_shape(R, ng).grid;
     if (gru_train_uses_s16(m, B, T)) return gru_s16_rows(m, B);
     const LaunchShape ls = train_shape(P, R, DG, ng, T, nullptr);
     return ls.grid > 0 ? ls.grid : ODPD_EUNSUPPORTED;

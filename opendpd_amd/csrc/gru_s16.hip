@@ -42,8 +42,10 @@ template <int FM> struct S16Cfg {
 //   backward: 6-8 W_hg[4q+c][m]   9 fc_hid[m][4q+c]   10 fc_hid[4q+c][m]   11 b_hid[4q+i]
 //             12-13 fc_out[c][4q+i]   14 fc_out feature/bias slots
 // ---------------------------------------------------------------------------------------------------
-constexpr int kS16Groups = 15;
-constexpr int kS16TabFloats = kS16Groups * 64 * 4;
+//   dL/dx   : 15-17 W_ig[4q+c][m] (m = feature slot)   18-19 fc_out[cc][H + 4q+i] (feature part, D layout)
+constexpr int kS16Groups = 15;        // fused train / weight-gradient-only kernels
+constexpr int kS16GroupsDx = 20;      // kernels that also produce dL/dx
+__host__ __device__ constexpr int s16_tab_floats(int groups) { return groups * 64 * 4; }
 
 template <int FM, bool DG>
 __device__ __forceinline__ float s16_wih_slot(const float* pl, const GruLayout& L, int g, int c, int m, int q) {
@@ -83,14 +85,17 @@ __device__ __forceinline__ float4 s16_table_entry(const float* pl, const GruLayo
         else if (grp == 10) v[e] = (DG && mk) ? pl[L.o_w_hid + k * H + m] : 0.0f;
         else if (grp == 11) v[e] = (DG && k < H) ? pl[L.o_b_hid + k] : 0.0f;
         else if (grp < 14) v[e] = k < H ? pl[L.o_w_out + (grp - 12) * OW + k] : 0.0f;
-        else v[e] = s16_woutf_slot<FM, DG>(pl, L, e >> 1, e & 1, q);
+        else if (grp == 14) v[e] = s16_woutf_slot<FM, DG>(pl, L, e >> 1, e & 1, q);
+        else if (grp < 18) v[e] = (m < S16Cfg<FM>::F && k < H) ? pl[L.o_w_ih + ((grp - 15) * H + k) * S16Cfg<FM>::F + m] : 0.0f;
+        else v[e] = (DG && k < S16Cfg<FM>::F) ? pl[L.o_w_out + (grp - 18) * OW + H + k] : 0.0f;   // k = 4q+e is a slot here
     }
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 template <int FM, bool DG>
-__device__ __forceinline__ void s16_fill_table(float* tab, const float* pl, const GruLayout& L, int lane, int wave, int nwb) {
+__device__ __forceinline__ void s16_fill_table(float* tab, const float* pl, const GruLayout& L, int lane, int wave, int nwb,
+                                               int ngroups = kS16Groups) {
     float4* t4 = reinterpret_cast<float4*>(tab);
-    for (int grp = wave; grp < kS16Groups; grp += nwb)
+    for (int grp = wave; grp < ngroups; grp += nwb)
         if (DG || (grp < 9 || grp > 11)) t4[grp * 64 + lane] = s16_table_entry<FM, DG>(pl, L, grp, lane & 15, lane >> 4);
     __syncthreads();
 }
@@ -280,10 +285,13 @@ struct S16Grad {
 // One block of <= S steps: recompute the forward pass into registers, then back-propagate.
 //   h    : state at the start of the block          dh  : in/out carry dL/dh
 //   hTn  : transposed h of the step after the current one (fc_hid weight gradient operand)
-template <int FM, bool DG, bool FULL>
+//   FUSED: `ts` holds the target, y / loss / dL/dy are formed here;  else `ts` holds dL/dy
+//   NW   : accumulate weight gradients into G        DX : write dL/dx of the block's steps to dxs
+template <int FM, bool DG, bool FUSED, bool NW, bool DX, bool FULL>
 __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, const float (&oh)[4], S16Grad<DG>& G,
-                                          const float2* xs, const float2* ts, float* tiles, int n, int q, int tloc, int nstep,
-                                          bool valid, bool last_blk, f32x4 h, f32x4& dh, float (&hTn)[4], float& loss_acc) {
+                                          const float2* xs, const float2* ts, float2* dxs, float* tiles, int n, int q, int tloc,
+                                          int nstep, bool valid, bool last_blk, f32x4 h, f32x4& dh, float (&hTn)[4],
+                                          float& loss_acc) {
     constexpr int NCH = S16Cfg<FM>::NCH, S = kCkptStride;
     f32x4 hp_s[S], r_s[S], z_s[S], n_s[S], g_s[S];
     float fs_s[S][NCH];
@@ -304,7 +312,19 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
     s16_load_bw<FM, DG>(w, tl);
     float* t_r = tiles, *t_z = tiles + kTileFloats, *t_n = tiles + 2 * kTileFloats, *t_g = tiles + 3 * kTileFloats;
     float* t_h = tiles + 4 * kTileFloats, *t_d = tiles + 5 * kTileFloats, *t_f = tiles + 6 * kTileFloats;
-    if (DG && last_blk) {   // transposed final state of the frame: operand of the last step's dW_hid
+    float wihT[3][4];
+    f32x4 wfD[2];
+    if constexpr (DX) {
+        const float4* tx = opaque(tl);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float4 v = tx[(15 + g) * 64];
+            wihT[g][0] = v.x; wihT[g][1] = v.y; wihT[g][2] = v.z; wihT[g][3] = v.w;
+        }
+        wfD[0] = as_f32x4(tx[18 * 64]);
+        wfD[1] = as_f32x4(tx[19 * 64]);
+    }
+    if (NW && DG && last_blk) {   // transposed final state of the frame: operand of the last step's dW_hid
         wave_lds_fence();
         tile_put(t_h, n, q, h);
         wave_lds_fence();
@@ -326,39 +346,44 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
             } else {
                 act = ht;
             }
-            // y = fc_out(cat(act, feat)) (+ bias through the constant-1 slot), loss and dL/dy
-            float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                p0 = __builtin_fmaf(w.woutf[0][c], fs_s[st][c], p0);
-                p1 = __builtin_fmaf(w.woutf[1][c], fs_s[st][c], p1);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                p0 = __builtin_fmaf(w.wout[0][e], act[e], p0);
-                p1 = __builtin_fmaf(w.wout[1][e], act[e], p1);
-            }
-            const float y0 = quad_sum(p0), y1 = quad_sum(p1);
             const float2 tv = ts[n * kChunkPad + tloc + st];
-            const float d0 = y0 - tv.x, d1 = y1 - tv.y;
-            const float s0 = d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f), s1 = d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
-            const float dy0 = l2 ? 2.0f * sc * d0 : s0, dy1 = l2 ? 2.0f * sc * d1 : s1;
-            const float lv = l2 ? __builtin_fmaf(d0, d0, d1 * d1) : __builtin_fabsf(d0) + __builtin_fabsf(d1);
-            loss_acc += (valid && q == 0) ? lv : 0.0f;
+            float dy0 = tv.x, dy1 = tv.y;
+            if constexpr (FUSED) {
+                // y = fc_out(cat(act, feat)) (+ bias through the constant-1 slot), loss and dL/dy
+                float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c < 2) {
-                    G.dwf[0][c] = __builtin_fmaf(dy0, fs_s[st][c], G.dwf[0][c]);
-                    G.dwf[1][c] = __builtin_fmaf(dy1, fs_s[st][c], G.dwf[1][c]);
+                for (int c = 0; c < NCH; ++c) {
+                    p0 = __builtin_fmaf(w.woutf[0][c], fs_s[st][c], p0);
+                    p1 = __builtin_fmaf(w.woutf[1][c], fs_s[st][c], p1);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p0 = __builtin_fmaf(w.wout[0][e], act[e], p0);
+                    p1 = __builtin_fmaf(w.wout[1][e], act[e], p1);
+                }
+                const float y0 = quad_sum(p0), y1 = quad_sum(p1);
+                const float d0 = y0 - tv.x, d1 = y1 - tv.y;
+                const float s0 = d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f), s1 = d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
+                dy0 = l2 ? 2.0f * sc * d0 : s0; dy1 = l2 ? 2.0f * sc * d1 : s1;
+                const float lv = l2 ? __builtin_fmaf(d0, d0, d1 * d1) : __builtin_fabsf(d0) + __builtin_fabsf(d1);
+                loss_acc += (valid && q == 0) ? lv : 0.0f;
+            }
+            if constexpr (NW) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c < 2) {
+                        G.dwf[0][c] = __builtin_fmaf(dy0, fs_s[st][c], G.dwf[0][c]);
+                        G.dwf[1][c] = __builtin_fmaf(dy1, fs_s[st][c], G.dwf[1][c]);
+                    }
+                }
+                G.dwout[0] = fma4(splat4(dy0), act, G.dwout[0]);
+                G.dwout[1] = fma4(splat4(dy1), act, G.dwout[1]);
             }
             f32x4 dht, dhid;
-            G.dwout[0] = fma4(splat4(dy0), act, G.dwout[0]);
-            G.dwout[1] = fma4(splat4(dy1), act, G.dwout[1]);
             const f32x4 dact = fma4(splat4(dy0), w.wout[0], mul4(w.wout[1], splat4(dy1)));
             if constexpr (DG) {
                 ODPD_EACH4 dhid[i] = hid[i] > 0.0f ? dact[i] : 0.0f;
-                G.db_hid = add4(G.db_hid, dhid);
+                if constexpr (NW) G.db_hid = add4(G.db_hid, dhid);
                 dht = dh;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) dht = mfma4(w.whidT[c], dhid[c], dht);
@@ -378,7 +403,7 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
             const f32x4 dgh = mul4(dnp, r);
             const f32x4 dzp = mul4(mul4(sub4(hp, nn), z), dn);
             const f32x4 drp = mul4(mul4(dgh, gh), omr);
-            G.db_hn = add4(G.db_hn, dgh);
+            if constexpr (NW) G.db_hn = add4(G.db_hn, dgh);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 acc0 = mfma4(w.whhT[0][c], drp[c], acc0);
@@ -390,6 +415,32 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
                 else acc0 = mfma4(w.whhT[2][c], dgh[c], acc0);
             }
             dh = add4(acc0, acc1);
+            if constexpr (DX) {
+                // dL/d(feature slot j) of sequence n = sum_g sum_u W_ig[u][j] dpre_g[u] (+ fc_out feature columns): the
+                // same in-place MFMA pattern with the feature slots on M; D lands as slots 4q..4q+3 on lane (n,q)
+                f32x4 ds0 = {0.f, 0.f, 0.f, 0.f}, ds1 = ds0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ds0 = mfma4(wihT[0][c], drp[c], ds0);
+                    ds1 = mfma4(wihT[1][c], dzp[c], ds1);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c & 1) ds1 = mfma4(wihT[2][c], dnp[c], ds1);
+                    else ds0 = mfma4(wihT[2][c], dnp[c], ds0);
+                }
+                f32x4 ds = add4(ds0, ds1);
+                if constexpr (DG) ds = fma4(splat4(dy0), wfD[0], fma4(splat4(dy1), wfD[1], ds));
+                constexpr int F = S16Cfg<FM>::F;
+                float df[F];
+#pragma unroll
+                for (int j = 0; j < F; ++j) df[j] = j < 4 ? ds[j & 3] : swap16(ds[j & 3]);   // slots 4..7 live on quad 1
+                const float2 xv = xs[n * kChunkPad + tloc + st];
+                float dI, dQ;
+                feat_bwd<FM>(xv.x, xv.y, df, dI, dQ);
+                if (q == 0) dxs[n * kChunkPad + tloc + st] = make_float2(dI, dQ);
+            }
+            if constexpr (NW) {
             // weight gradients: transpose through LDS (sequence index onto K), then rank-16 MFMA updates
             wave_lds_fence();
             tile_put(t_r, n, q, drp);
@@ -421,6 +472,7 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) hTn[c] = hT[c];
+            }
         }
     }
 }
@@ -500,7 +552,7 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
     float oh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
-    float* wbase = tab + kS16TabFloats + (size_t)wave * kS16WaveFloats;
+    float* wbase = tab + s16_tab_floats(kS16Groups) + (size_t)wave * kS16WaveFloats;
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ts = xs + 16 * kChunkPad;
     float* tiles = reinterpret_cast<float*>(ts + 16 * kChunkPad);
@@ -565,9 +617,9 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
                 cur_chunk = chunk;
             }
             if (nstep == S)
-                s16_block<FM, DG, true>(a, tl, oh, G, xs, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+                s16_block<FM, DG, true, true, false, true>(a, tl, oh, G, xs, ts, nullptr, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
             else
-                s16_block<FM, DG, false>(a, tl, oh, G, xs, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+                s16_block<FM, DG, true, true, false, false>(a, tl, oh, G, xs, ts, nullptr, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
         }
     }
     // ---- one row of partial gradients per workgroup (fixed summation order) ----
@@ -580,6 +632,161 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
         float v = smem[i];
         for (int wv = 1; wv < nwb; ++wv) v += smem[wv * P4 + i];
         prow[i] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// split kernels (odpd_backbone_fwd / odpd_backbone_bwd at large batch: autograd path, cascades, inference)
+// -------------------------------------------------------------------------------------------------
+// forward: y for every step, optional checkpoints of h ([task][ckpt][lane] float4)
+template <int FM, bool DG>
+__global__ __launch_bounds__(1024) void gru16_fwd_kernel(SeqArgs a) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const GruLayout L = gru_layout(a.H, F, DG);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    s16_fill_table<FM, DG>(tab, pl, L, lane, wave, nwb);
+    const float4* tl = reinterpret_cast<const float4*>(tab) + lane;
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    float2* xs = reinterpret_cast<float2*>(tab + s16_tab_floats(kS16Groups)) + (size_t)wave * (2 * 16 * kChunkPad);
+    float2* ys = xs + 16 * kChunkPad;
+    S16Fw<FM> wf;
+    s16_load_fw<FM>(wf, tl);
+    S16Bw<FM, DG> wh;            // only the head operands (fc_hid, fc_out) are used here
+    s16_load_bw<FM, DG>(wh, tl);
+    const int nwaves = gridDim.x * nwb;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        float4* ck = a.ckpt ? reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * 64 + lane : nullptr;
+        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            wave_lds_fence();
+            stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+            wave_lds_fence();
+            for (int tt = 0; tt < len; ++tt) {
+                const float2 xv = xs[n * kChunkPad + tt];
+                float fs[NCH];
+                f32x4 r, z, nn, g, act;
+                s16_slots<FM>(xv.x, xv.y, oh, fs);
+                s16_cell_fwd<FM>(wf, fs, h, r, z, nn, g);
+                if constexpr (DG) {
+                    f32x4 hid = wh.bhid;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) hid = mfma4(wh.whid[c], h[c], hid);
+                    ODPD_EACH4 act[i] = relu_(hid[i]);
+                } else {
+                    act = h;
+                }
+                float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    p0 = __builtin_fmaf(wh.woutf[0][c], fs[c], p0);
+                    p1 = __builtin_fmaf(wh.woutf[1][c], fs[c], p1);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p0 = __builtin_fmaf(wh.wout[0][e], act[e], p0);
+                    p1 = __builtin_fmaf(wh.wout[1][e], act[e], p1);
+                }
+                const float y0 = quad_sum(p0), y1 = quad_sum(p1);
+                if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
+                const int t1 = t0 + tt + 1;
+                if (ck != nullptr && (t1 % S) == 0 && t1 < a.T) ck[(size_t)(t1 / S) * 64] = make_float4(h[0], h[1], h[2], h[3]);
+            }
+            wave_lds_fence();
+            stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+        }
+    }
+}
+
+// backward from dL/dy: weight-gradient partials (NW) and / or dL/dx (DX)
+template <int FM, bool DG, bool NW, bool DX, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gru16_bwd_kernel(SeqArgs a) {
+    constexpr int F = S16Cfg<FM>::F, S = kCkptStride;
+    constexpr int kGroups = DX ? kS16GroupsDx : kS16Groups;
+    constexpr int kWave = (DX ? 3 : 2) * 2 * 16 * kChunkPad + (NW ? kS16Tiles * kTileFloats : 0);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const GruLayout L = gru_layout(a.H, F, DG);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    s16_fill_table<FM, DG>(tab, pl, L, lane, wave, nwb, kGroups);
+    const float4* tl = reinterpret_cast<const float4*>(tab) + lane;
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    float* wbase = tab + s16_tab_floats(kGroups) + (size_t)wave * kWave;
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* dys = xs + 16 * kChunkPad;
+    float2* dxs = DX ? dys + 16 * kChunkPad : nullptr;
+    float* tiles = reinterpret_cast<float*>(dys + (DX ? 2 : 1) * 16 * kChunkPad);
+    if constexpr (NW)
+        for (int i = lane; i < kTileFloats; i += 64) tiles[6 * kTileFloats + i] = 0.0f;
+    S16Grad<DG> G;
+    G.zero();
+    float unused = 0.0f;
+    const int nwaves = gridDim.x * nwb;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        const float4* ck = reinterpret_cast<const float4*>(a.ckpt) + (size_t)grp * a.nck * 64 + lane;
+        f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+        float hTn[4] = {0.f, 0.f, 0.f, 0.f};
+        int cur_chunk = -1;
+        float4 h0n = a.nck > 1 ? ck[(size_t)(a.nck - 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int blk = a.nck - 1; blk >= 0; --blk) {
+            const int tb = blk * S, nstep = min(S, a.T - tb);
+            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            const f32x4 h0 = {h0n.x, h0n.y, h0n.z, h0n.w};
+            h0n = blk > 1 ? ck[(size_t)(blk - 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (chunk != cur_chunk) {
+                if constexpr (DX) {
+                    if (cur_chunk >= 0) {
+                        const int pt0 = cur_chunk * kChunk;
+                        wave_lds_fence();
+                        stage_out<16>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                    }
+                }
+                wave_lds_fence();
+                const int len = min(kChunk, a.T - t0);
+                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+                stage_in<16>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                wave_lds_fence();
+                cur_chunk = chunk;
+            }
+            if (nstep == S)
+                s16_block<FM, DG, false, NW, DX, true>(a, tl, oh, G, xs, dys, dxs, tiles, n, q, tb - t0, nstep, true, blk == a.nck - 1, h0, dh, hTn, unused);
+            else
+                s16_block<FM, DG, false, NW, DX, false>(a, tl, oh, G, xs, dys, dxs, tiles, n, q, tb - t0, nstep, true, blk == a.nck - 1, h0, dh, hTn, unused);
+        }
+        if constexpr (DX) {
+            if (cur_chunk >= 0) {
+                const int pt0 = cur_chunk * kChunk;
+                wave_lds_fence();
+                stage_out<16>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                wave_lds_fence();
+            }
+        }
+    }
+    if constexpr (NW) {
+        const int P4 = L.P + kLossCols;
+        __syncthreads();
+        s16_write_row<FM, DG>(smem + wave * P4, L, G, n, q, 0.0f);
+        __syncthreads();
+        float* prow = a.partials + (size_t)blockIdx.x * P4;
+        for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+            float v = smem[i];
+            for (int wv = 1; wv < nwb; ++wv) v += smem[wv * P4 + i];
+            prow[i] = v;
+        }
     }
 }
 
@@ -599,7 +806,7 @@ static int s16_param_count(int H, int FM, bool DG) {
     return gru_layout(H, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
 }
 static size_t s16_lds_bytes(int P, int waves) {
-    size_t nbytes = ((size_t)pad4(P) + kS16TabFloats + (size_t)waves * kS16WaveFloats) * sizeof(float);
+    size_t nbytes = ((size_t)pad4(P) + s16_tab_floats(kS16Groups) + (size_t)waves * kS16WaveFloats) * sizeof(float);
     const size_t red = reduce_scratch_bytes(P, waves);
     return nbytes > red ? nbytes : red;
 }
@@ -641,6 +848,87 @@ static int launch_s16(hipStream_t st, const SeqArgs& a, int P) {
 template <int FM, bool DG>
 static int launch_s16_occ(hipStream_t st, const SeqArgs& a, int P) {
     return s16_occupancy(a.ngroups) == 1 ? launch_s16<FM, DG, 1>(st, a, P) : launch_s16<FM, DG, 2>(st, a, P);
+}
+
+// ---- split kernels: launch shapes -----------------------------------------------------------------
+// one workgroup per CU; as many waves per workgroup (4, 8, 16 = 1, 2, 4 per SIMD) as the batch can feed
+static LaunchShape s16_fwd_shape(int ngroups) {
+    LaunchShape ls;
+    const int cus = device_cus();
+    ls.waves = 4;
+    while (ls.waves < 16 && ngroups > ls.waves * cus) ls.waves *= 2;
+    const int need = (ngroups + ls.waves - 1) / ls.waves;
+    ls.grid = need < cus ? need : cus;
+    return ls;
+}
+static LaunchShape s16_bwd_shape(int ngroups, bool nw, bool dx) {
+    LaunchShape ls;
+    const int cus = device_cus();
+    const int maxw = (nw && dx) ? 4 : 8;    // both outputs: the per-wave LDS only fits one wave per SIMD
+    ls.waves = ngroups <= 4 * cus ? 4 : maxw;
+    const int need = (ngroups + ls.waves - 1) / ls.waves;
+    ls.grid = need < cus ? need : cus;
+    return ls;
+}
+// rows of partials of the split backward: the grid of the weight-gradient-only shape, also used when dL/dx is
+// produced in the same launch (so the row count does not depend on whether dx was requested)
+int gru_s16_bwd_rows(const odpd_model_t* m, int B) {
+    (void)m;
+    return s16_bwd_shape(gru_s16_groups(B), true, false).grid;
+}
+
+template <int FM, bool DG>
+static int launch_s16_fwd(hipStream_t st, const SeqArgs& a, int P) {
+    const LaunchShape ls = s16_fwd_shape(a.ngroups);
+    const size_t lds = ((size_t)pad4(P) + s16_tab_floats(kS16Groups) + (size_t)ls.waves * 2 * 2 * 16 * kChunkPad) * sizeof(float);
+    auto k = gru16_fwd_kernel<FM, DG>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <int FM, bool DG, bool NW, bool DX, int WAVES>
+static int launch_s16_bwd(hipStream_t st, const SeqArgs& a, int P) {
+    // the number of partial rows must not depend on DX: a NW+DX launch keeps the grid of the NW-only shape
+    LaunchShape ls = s16_bwd_shape(a.ngroups, NW, DX);
+    if (NW) ls.grid = s16_bwd_shape(a.ngroups, true, false).grid;
+    const int waves = ls.waves < WAVES ? ls.waves : WAVES;
+    const int wave_floats = (DX ? 3 : 2) * 2 * 16 * kChunkPad + (NW ? kS16Tiles * kTileFloats : 0);
+    size_t lds = ((size_t)pad4(P) + s16_tab_floats(DX ? kS16GroupsDx : kS16Groups) + (size_t)waves * wave_floats) * sizeof(float);
+    if (NW && lds < reduce_scratch_bytes(P, waves)) lds = reduce_scratch_bytes(P, waves);
+    auto k = gru16_bwd_kernel<FM, DG, NW, DX, WAVES>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <int FM, bool DG>
+static int launch_s16_bwd_mode(hipStream_t st, const SeqArgs& a, int P) {
+    const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
+    if (nw && dx) return launch_s16_bwd<FM, DG, true, true, 4>(st, a, P);
+    if (nw) return launch_s16_bwd<FM, DG, true, false, 8>(st, a, P);
+    if (dx) return launch_s16_bwd<FM, DG, false, true, 8>(st, a, P);
+    return ODPD_EINVAL;
+}
+#define ODPD_S16_DISPATCH(FN, ...)                                                   \
+    if (FM == FEAT_RAW2) return FN<FEAT_RAW2, false>(__VA_ARGS__);                   \
+    if (FM == FEAT_DGRU6) return FN<FEAT_DGRU6, true>(__VA_ARGS__);                  \
+    if (FM == FEAT_Q4) return FN<FEAT_Q4, false>(__VA_ARGS__);                       \
+    return FN<FEAT_A4, false>(__VA_ARGS__);
+
+int gru_s16_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
+    int FM; bool DG;
+    if (!s16_cfg(m, FM, DG) || m->hidden > 16) return ODPD_EUNSUPPORTED;
+    SeqArgs a = a0;
+    a.ngroups = gru_s16_groups(a.B);
+    const int P = s16_param_count(m->hidden, FM, DG);
+    ODPD_S16_DISPATCH(launch_s16_fwd, st, a, P)
+}
+int gru_s16_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
+    int FM; bool DG;
+    if (!s16_cfg(m, FM, DG) || m->hidden > 16) return ODPD_EUNSUPPORTED;
+    SeqArgs a = a0;
+    a.ngroups = gru_s16_groups(a.B);
+    const int P = s16_param_count(m->hidden, FM, DG);
+    ODPD_S16_DISPATCH(launch_s16_bwd_mode, st, a, P)
 }
 
 int gru_s16_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {

@@ -107,6 +107,10 @@ int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, 
 bool gru_train_uses_s16(const odpd_model_t* m, int B, int T);
 int gru_s16_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_s16_rows(const odpd_model_t* m, int B);
+bool gru_split_uses_s16(const odpd_model_t* m, int B);
+int gru_s16_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_s16_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_s16_bwd_rows(const odpd_model_t* m, int B);
 // optim.hip: clip + AdamW launch that also records loss = grad[P] * inv_count into loss_out (nullable)
 int launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t step,
                       double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, float* norm_out,

@@ -136,3 +136,65 @@ def test_s16_is_bit_repeatable_and_large(force_s16):
         assert torch.isfinite(loss)
         outs.append(net.backbone.flat_params().clone())
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- split kernels (odpd_backbone_fwd / odpd_backbone_bwd) in the S16 mapping --------------------------------------
+R1_GOLDEN = [("gru_h11", "gru"), ("dgru_h13", "dgru"), ("dgru_h8", "dgru"), ("qgru_h10", "qgru"), ("qgru_h16", "qgru"),
+             ("qgru_amp1_h10", "qgru_amp1")]
+
+
+@pytest.mark.parametrize("name,bb", R1_GOLDEN)
+def test_s16_split_kernels_golden(force_s16, name, bb):
+    """forward, parameter gradients and dL/dx of the S16 split kernels against the reference vectors"""
+    from tests import test_gru_family_gpu as fam
+    fam.test_golden_forward_backward(name, bb)
+
+
+@pytest.mark.parametrize("bb,H", [("gru", 11), ("dgru", 13), ("gru", 16), ("qgru", 10), ("qgru_amp1", 7), ("dgru", 1)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (17, 64), (7, 65), (5, 200), (130, 63), (2, 333)])
+def test_s16_split_kernels_against_oracle_ragged(force_s16, bb, H, B, T):
+    from tests import test_gru_family_gpu as fam
+    fam.test_against_oracle_ragged(bb, H, B, T)
+
+
+def test_s16_frozen_model_gives_dx_only(force_s16):
+    from tests import test_gru_family_gpu as fam
+    fam.test_frozen_model_gives_dx_only()
+
+
+def test_s16_cascade_follows_reference(force_s16):
+    """train_dpd cascade with both models on the S16 split kernels (DPD fwd, PA fwd, loss, PA bwd dx-only, DPD bwd)"""
+    from tests import test_cascade_gpu as casc
+    casc.test_cascade_autograd_matches_reference("cascade_gru11_gru11", "gru", "gru")
+    casc.test_cascade_fused_steps_follow_reference("cascade_gru11_gru11", "gru", "gru")
+
+
+@pytest.mark.parametrize("bb,H", [("gru", 11), ("dgru", 13)])
+def test_s16_split_large_batch_matches_row_rotated(bb, H):
+    """default selection at B = 20000 (S16) against the row-rotated kernels forced by the tuning knob.  DGRU's
+    relu(fc_hid(h)) makes the map discontinuous: among 20000 x 40 x 13 pre-activations a few lie within rounding of 0
+    and flip their mask between the two arithmetic orders, so for dgru a handful of sequences may differ."""
+    from opendpd_amd import CoreModel, _lib
+    lib = _lib.load()
+    torch.manual_seed(4)
+    net = CoreModel(2, H, 1, bb).cuda()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = (torch.rand(20000, 40, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    dy = torch.randn(20000, 40, 2, device="cuda", generator=g)
+    res = []
+    for min_batch in (-1, 1 << 40):
+        lib.odpd_set_tuning(b"s16_min_batch", min_batch)
+        for p in net.parameters():
+            p.grad = None
+        xt = x.clone().requires_grad_(True)
+        y = net(xt)
+        y.backward(dy)
+        res.append((y.detach().clone(), xt.grad.clone(), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()))
+    lib.odpd_set_tuning(b"s16_min_batch", -1)
+    (y0, dx0, dp0), (y1, dx1, dp1) = res
+    assert rel_err(y0.cpu().numpy(), y1.cpu().numpy()) < 2e-5
+    per_seq = (dx0 - dx1).abs().amax(dim=(1, 2)) / dx1.abs().max()
+    flipped = int((per_seq > 2e-5).sum())
+    assert flipped <= (12 if bb == "dgru" else 0), flipped
+    assert rel_err(dp0.cpu().numpy(), dp1.cpu().numpy()) < (2e-3 if bb == "dgru" else 2e-4)
