@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=13)
     ap.add_argument("--frame-length", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cascade", action="store_true", help="skip the train_dpd (cascade) side figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,6 +175,22 @@ def main():
         ref = {"batch_per_gpu": args.ref_batch, "value": world * args.ref_batch * T * max(args.steps, 50) / float(elr_t.item()),
                "ms_per_step": 1e3 * float(elr_t.item()) / max(args.steps, 50)}
 
+    # side figure: the train_dpd step (models.py:163-176) — the same 1k-parameter DGRU as the DPD in front of a frozen
+    # DGRU PA model: DPD forward, PA forward, loss, PA backward (dL/du only), DPD backward, reduce, clip + AdamW
+    dpd = None
+    if world == 1 and not args.no_cascade:
+        from opendpd_amd import CascadedModel
+        torch.manual_seed(1)
+        casc = CascadedModel(dpd_model=CoreModel(2, H, 1, "dgru"), pa_model=CoreModel(2, H, 1, "dgru"))
+        casc.freeze_pa_model()
+        casc = casc.to(dev)
+        opt3 = FusedAdamW(casc, lr=5e-4)
+        n3 = max(3, min(args.steps, 10))
+        el3, _, loss3 = run_steps(opt3, x, x.clone(), n3, 2, world * B * T * 2, dist)
+        dpd = {"workload": f"train_dpd: DGRU H{H} DPD -> frozen DGRU H{H} PA (five-launch cascade step), target = x",
+               "value": B * T * n3 / el3, "unit": "IQ samples/s", "ms_per_step": 1e3 * el3 / n3, "loss": loss3}
+        del casc, opt3
+
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * B * T / (kern_ms * 1e-3) / 1e9
         tflops = FLOP_PER_SAMPLE.get(H, 0) * B * T / (kern_ms * 1e-3) / 1e12
@@ -201,6 +218,7 @@ def main():
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * B * T}},
             "reference_batch": ref,
+            "train_dpd": dpd,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, T)
