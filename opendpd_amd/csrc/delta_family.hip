@@ -60,7 +60,7 @@ __device__ __forceinline__ void fill_delta_tabs(float* tab, const float* pl, con
     }
     __syncthreads();
 }
-__device__ __forceinline__ void load_rot3d(float (&w)[3][16], const float4* tlane, int first_row) {
+__device__ __forceinline__ void load_rot3d(float (&w)[3][16], TabPtr tlane, int first_row) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) load_rot(w[g], tlane + (first_row + g) * 4 * 64);
 }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kMaxThreads) void delta_fwd_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_delta_tabs<false>(tab, pl, L, lane, id.wave, id.nwb);
-    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float2* xs = reinterpret_cast<float2*>(tab + kDTabFloats) + id.wave * (SPW * kDStride + SPW * kChunkPad);
     float2* ys = xs + SPW * kDStride;
     DeltaW<TRES> w;
@@ -291,7 +291,7 @@ struct DeltaGrad {
 struct DeltaCarry { float gh, ghp, gr, gz, gn, gnh; };
 
 template <bool TRES, bool FULL>
-__device__ __forceinline__ void delta_bwd_block(const SeqArgs& a, const DeltaW<TRES>& w, const float4* tlane, DeltaGrad<TRES>& G,
+__device__ __forceinline__ void delta_bwd_block(const SeqArgs& a, const DeltaW<TRES>& w, TabPtr tlane, DeltaGrad<TRES>& G,
                                                 const LaneId& id, const float2* xr, const float2* dys, float2 x0, int tglob,
                                                 int tloc, int nstep, DeltaState st, DeltaCarry& C) {
     constexpr int S = kCkptStride;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(kMaxThreads / 2, 1) void delta_bwd_kernel(SeqArgs a
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_delta_tabs<true>(tab, pl, L, lane, id.wave, id.nwb);
-    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float2* xs = reinterpret_cast<float2*>(tab + kDTabFloats) + id.wave * (SPW * kDStride + SPW * kChunkPad);
     float2* dys = xs + SPW * kDStride;
     DeltaW<TRES> w;

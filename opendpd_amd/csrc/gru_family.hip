@@ -174,7 +174,7 @@ struct GruGrad {
 // later steps).  Out: dh <- dL/dh_{t-1}; df (if DX) = dL/dfeat.
 template <int R, int FM, bool DG, bool NW, bool DX>
 __device__ __forceinline__ void gru_step_bwd(const GruW<R, FeatDim<FM>::F, DG>& w, const float (&whhT)[3][R][16],
-                                             const float4* tlane, GruGrad<R, DG>& G, const float (&f)[FeatDim<FM>::F],
+                                             TabPtr tlane, GruGrad<R, DG>& G, const float (&f)[FeatDim<FM>::F],
                                              float hp, float r, float z, float n, float ghn, float hid, float dy0,
                                              float dy1, int row, int col, float& dh, float (&df)[FeatDim<FM>::F]) {
     constexpr int F = FeatDim<FM>::F;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kMaxThreads) void gru_fwd_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_gru_tabs<R, DG, false>(tab, pl, L, lane, id.wave, id.nwb);
-    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float2* xs = reinterpret_cast<float2*>(tab + T::kFloats) + id.wave * (2 * SPW * kChunkPad);
     float2* ys = xs + SPW * kChunkPad;
     GruW<R, F, DG> w;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kMaxThreads) void gru_fwd_kernel(SeqArgs a) {
 // tloc = first step of the block relative to the staged chunk.
 // -------------------------------------------------------------------------------------------------
 template <int R, int FM, bool DG, bool NW, bool DX, bool FUSED, bool FULL>
-__device__ __forceinline__ void gru_bwd_block(const SeqArgs& a, const GruW<R, FeatDim<FM>::F, DG>& w, const float4* tlane,
+__device__ __forceinline__ void gru_bwd_block(const SeqArgs& a, const GruW<R, FeatDim<FM>::F, DG>& w, TabPtr tlane,
                                               GruGrad<R, DG>& G, const LaneId& id, const float2* xs, const float2* dys,
                                               float2* dxs, int tloc, int nstep, bool valid, float h, float& dh,
                                               float& loss_acc) {
@@ -476,7 +476,7 @@ __device__ __forceinline__ void gru_bwd_block(const SeqArgs& a, const GruW<R, Fe
 //   ck : checkpoints of this task, slot c at ck[c*64 + lane]  (HBM, or LDS if FUSED)
 // -------------------------------------------------------------------------------------------------
 template <int R, int FM, bool DG, bool NW, bool DX, bool FUSED>
-__device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, FeatDim<FM>::F, DG>& w, const float4* tlane,
+__device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, FeatDim<FM>::F, DG>& w, TabPtr tlane,
                                              GruGrad<R, DG>& G, int b0, const LaneId& id, float2* xs, float2* dys,
                                              float2* dxs, const float* ck, float& loss_acc) {
     constexpr int SPW = 4 / R, S = kCkptStride;
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_gru_tabs<R, DG, true>(tab, pl, L, id.lane, id.wave, id.nwb);
-    const float4* tlane = reinterpret_cast<const float4*>(tab) + id.lane;
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + id.lane);
     float2* xs = reinterpret_cast<float2*>(tab + T::kFloats) + id.wave * (3 * SPW * kChunkPad);
     float2* dys = xs + SPW * kChunkPad;
     float2* dxs = dys + SPW * kChunkPad;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_gru_tabs<R, DG, true>(tab, pl, L, lane, id.wave, id.nwb);
-    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float* wbase = tab + T::kFloats + (size_t)id.wave * train_wave_floats(a.T, R);
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ts = xs + SPW * kChunkPad;

@@ -117,34 +117,34 @@ struct S16Bw {                     // operands of the backward phase
 __device__ __forceinline__ f32x4 as_f32x4(const float4& v) { f32x4 r = {v.x, v.y, v.z, v.w}; return r; }
 
 template <int FM>
-__device__ __forceinline__ void s16_load_fw(S16Fw<FM>& w, const float4* tl) {
+__device__ __forceinline__ void s16_load_fw(S16Fw<FM>& w, TabPtr tl) {
     tl = opaque(tl);
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        const float4 v = tl[g * 64];
+        const float4 v = tab_ld(tl, g * 64);
         w.whh[g][0] = v.x; w.whh[g][1] = v.y; w.whh[g][2] = v.z; w.whh[g][3] = v.w;
     }
-    const float4 a = tl[3 * 64], b = tl[4 * 64];
+    const float4 a = tab_ld(tl, 3 * 64), b = tab_ld(tl, 4 * 64);
     w.wih[0][0] = a.x; w.wih[0][1] = a.y; w.wih[1][0] = a.z; w.wih[1][1] = a.w; w.wih[2][0] = b.x; w.wih[2][1] = b.y;
-    w.bhn = as_f32x4(tl[5 * 64]);
+    w.bhn = as_f32x4(tab_ld(tl, 5 * 64));
 }
 template <int FM, bool DG>
-__device__ __forceinline__ void s16_load_bw(S16Bw<FM, DG>& w, const float4* tl) {
+__device__ __forceinline__ void s16_load_bw(S16Bw<FM, DG>& w, TabPtr tl) {
     tl = opaque(tl);
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        const float4 v = tl[(6 + g) * 64];
+        const float4 v = tab_ld(tl, (6 + g) * 64);
         w.whhT[g][0] = v.x; w.whhT[g][1] = v.y; w.whhT[g][2] = v.z; w.whhT[g][3] = v.w;
     }
     if constexpr (DG) {
-        const float4 a = tl[9 * 64], b = tl[10 * 64];
+        const float4 a = tab_ld(tl, 9 * 64), b = tab_ld(tl, 10 * 64);
         w.whid[0] = a.x; w.whid[1] = a.y; w.whid[2] = a.z; w.whid[3] = a.w;
         w.whidT[0] = b.x; w.whidT[1] = b.y; w.whidT[2] = b.z; w.whidT[3] = b.w;
-        w.bhid = as_f32x4(tl[11 * 64]);
+        w.bhid = as_f32x4(tab_ld(tl, 11 * 64));
     }
-    w.wout[0] = as_f32x4(tl[12 * 64]);
-    w.wout[1] = as_f32x4(tl[13 * 64]);
-    const float4 f = tl[14 * 64];
+    w.wout[0] = as_f32x4(tab_ld(tl, 12 * 64));
+    w.wout[1] = as_f32x4(tab_ld(tl, 13 * 64));
+    const float4 f = tab_ld(tl, 14 * 64);
     w.woutf[0][0] = f.x; w.woutf[0][1] = f.y; w.woutf[1][0] = f.z; w.woutf[1][1] = f.w;
 }
 
@@ -288,7 +288,7 @@ struct S16Grad {
 //   FUSED: `ts` holds the target, y / loss / dL/dy are formed here;  else `ts` holds dL/dy
 //   NW   : accumulate weight gradients into G        DX : write dL/dx of the block's steps to dxs
 template <int FM, bool DG, bool FUSED, bool NW, bool DX, bool FULL>
-__device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, const float (&oh)[4], S16Grad<DG>& G,
+__device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const float (&oh)[4], S16Grad<DG>& G,
                                           const float2* xs, const float2* ts, float2* dxs, float* tiles, int n, int q, int tloc,
                                           int nstep, bool valid, bool last_blk, f32x4 h, f32x4& dh, float (&hTn)[4],
                                           float& loss_acc) {
@@ -315,14 +315,14 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, const float4* tl, co
     float wihT[3][4];
     f32x4 wfD[2];
     if constexpr (DX) {
-        const float4* tx = opaque(tl);
+        TabPtr tx = opaque(tl);
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-            const float4 v = tx[(15 + g) * 64];
+            const float4 v = tab_ld(tx, (15 + g) * 64);
             wihT[g][0] = v.x; wihT[g][1] = v.y; wihT[g][2] = v.z; wihT[g][3] = v.w;
         }
-        wfD[0] = as_f32x4(tx[18 * 64]);
-        wfD[1] = as_f32x4(tx[19 * 64]);
+        wfD[0] = as_f32x4(tab_ld(tx, 18 * 64));
+        wfD[1] = as_f32x4(tab_ld(tx, 19 * 64));
     }
     if (NW && DG && last_blk) {   // transposed final state of the frame: operand of the last step's dW_hid
         wave_lds_fence();
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     s16_fill_table<FM, DG>(tab, pl, L, lane, wave, nwb);
-    const float4* tl = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float oh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(1024) void gru16_fwd_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     s16_fill_table<FM, DG>(tab, pl, L, lane, wave, nwb);
-    const float4* tl = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float oh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gru16_bwd_kernel(SeqArg
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     s16_fill_table<FM, DG>(tab, pl, L, lane, wave, nwb, kGroups);
-    const float4* tl = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float oh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;

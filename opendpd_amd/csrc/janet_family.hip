@@ -73,7 +73,7 @@ __device__ __forceinline__ void janet_inputs(float2 xv, float& amp, float& ct, f
 }
 
 // forward step; padded lanes (o >= H) have all-zero weights: a=p1=p2=0 -> u=0, f=0.5, g=0 -> h stays 0
-__device__ __forceinline__ void janet_cell_fwd(const JanetW& w, const float4* tlane, float amp, float ct, float st, float& h,
+__device__ __forceinline__ void janet_cell_fwd(const JanetW& w, TabPtr tlane, float amp, float ct, float st, float& h,
                                                float& an, float& p1, float& p2, float& u, float& f, float& g) {
     an = tanhf_(tab_rotdot<1>(__builtin_fmaf(w.sa, amp, w.ba), tlane, 0, h));
     p1 = tanhf_(tab_rotdot<1>(__builtin_fmaf(w.sp1, ct, w.bp1), tlane, 1, h));
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kMaxThreads) void janet_fwd_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_janet_tabs<false>(tab, pl, L, lane, id.wave, id.nwb);
-    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float2* xs = reinterpret_cast<float2*>(tab + kJTabFloats) + id.wave * (2 * SPW * kChunkPad);
     float2* ys = xs + SPW * kChunkPad;
     JanetW w;
@@ -142,7 +142,7 @@ struct JanetGrad {
 };
 
 template <bool NW, bool DX, bool FULL>
-__device__ __forceinline__ void janet_bwd_block(const SeqArgs& a, const JanetW& w, const float4* tlane, JanetGrad& G,
+__device__ __forceinline__ void janet_bwd_block(const SeqArgs& a, const JanetW& w, TabPtr tlane, JanetGrad& G,
                                                 const LaneId& id, const float2* xs, const float2* dys, float2* dxs, int tloc,
                                                 int nstep, float h, float& dh) {
     constexpr int S = kCkptStride;
@@ -176,7 +176,7 @@ __device__ __forceinline__ void janet_bwd_block(const SeqArgs& a, const JanetW& 
                 G.t[3] = mfma4(dfp, hp, G.t[3]); G.t[4] = mfma4(dgp, hp, G.t[4]);
                 G.t[5] = mfma4(dfp, u, G.t[5]); G.t[6] = mfma4(dgp, u, G.t[6]);
             }
-            const float4* tl = opaque(tlane);
+            TabPtr tl = opaque(tlane);
             float dhp = tab_rotdot<1>(dht * f, tl, 7 + 3, dfp);
             dhp = tab_rotdot<1>(dhp, tl, 7 + 4, dgp);
             float du = tab_rotdot<1>(0.0f, tl, 7 + 5, dfp);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kMaxThreads, 2) void janet_bwd_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_janet_tabs<true>(tab, pl, L, lane, id.wave, id.nwb);
-    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float2* xs = reinterpret_cast<float2*>(tab + kJTabFloats) + id.wave * (3 * SPW * kChunkPad);
     float2* dys = xs + SPW * kChunkPad;
     float2* dxs = dys + SPW * kChunkPad;

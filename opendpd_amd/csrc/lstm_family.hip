@@ -61,7 +61,7 @@ __device__ __forceinline__ void fill_lstm_tabs(float* tab, const float* pl, cons
     __syncthreads();
 }
 template <int R>
-__device__ __forceinline__ void load_rot4(float (&w)[4][R][16], const float4* tlane, int first_row) {
+__device__ __forceinline__ void load_rot4(float (&w)[4][R][16], TabPtr tlane, int first_row) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kMaxThreads) void lstm_fwd_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_lstm_tabs<R, false>(tab, pl, L, lane, id.wave, id.nwb);
-    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float2* xs = reinterpret_cast<float2*>(tab + T::kFloats) + id.wave * (SPW * kHaloStride + SPW * kChunkPad);
     float2* ys = xs + SPW * kHaloStride;
     LstmW<R, VD> w;
@@ -288,7 +288,7 @@ struct VdAcc {
 
 template <int R, bool VD, bool NW, bool DX, bool FULL>
 __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, VD>& w, const float* pl, const LstmLayout& L,
-                                               const float4* tlane, LstmGrad<R, VD>& G, const LaneId& id, const float2* xr,
+                                               TabPtr tlane, LstmGrad<R, VD>& G, const LaneId& id, const float2* xr,
                                                const float2* dys, float2* dxs, int tloc, int nstep, float h, float c,
                                                float& dh, float& dc, VdAcc& acc) {
     constexpr int F = VD ? 4 : 2, LPS = 16 * R, S = kCkptStride;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_lstm_tabs<R, true>(tab, pl, L, lane, id.wave, id.nwb);
-    const float4* tlane = reinterpret_cast<const float4*>(tab) + lane;
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float2* xs = reinterpret_cast<float2*>(tab + T::kFloats) + id.wave * (SPW * kHaloStride + 2 * SPW * kChunkPad);
     float2* dys = xs + SPW * kHaloStride;
     float2* dxs = dys + SPW * kChunkPad;

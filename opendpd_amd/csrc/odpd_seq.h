@@ -12,21 +12,31 @@ __device__ __forceinline__ int rot_dir(int col) { return dpp_ror_i<1>(col) == ((
 // Returns the same pointer through an empty asm: the compiler can no longer prove that the table
 // loads of successive blocks read the same addresses, so it cannot hoist them out of the block loop
 // (which would pin W_hh and W_hh^T in registers at the same time again).
-__device__ __forceinline__ const float4* opaque(const float4* p) {
+// Weight-table pointers carry the LDS address space: the loads are ds_read_b128, not flat_load_dwordx4 (a generic
+// pointer into LDS is resolved at run time by the flat unit: longer latency, and it ties up both vmcnt and lgkmcnt).
+// (HIP's float4 is a class and cannot be copied out of a non-generic address space: the tables are read as the
+// builtin 4-float vector and converted.)
+typedef const __attribute__((address_space(3))) f32x4* TabPtr;
+__device__ __forceinline__ TabPtr to_tab(const float4* p) { return (TabPtr)reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float4 tab_ld(TabPtr p, int i) {
+    const f32x4 v = p[i];
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ TabPtr opaque(TabPtr p) {
     asm volatile("" : "+v"(p));
     return p;
 }
 
 // pull one table row (16 rotated weights) / a gate triple into registers
-__device__ __forceinline__ void load_rot(float (&w)[16], const float4* trow) {
+__device__ __forceinline__ void load_rot(float (&w)[16], TabPtr trow) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 v = trow[q * 64];
+        const float4 v = tab_ld(trow, q * 64);
         w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
     }
 }
 template <int R>
-__device__ __forceinline__ void load_rot3(float (&w)[3][R][16], const float4* tlane, int first_row) {
+__device__ __forceinline__ void load_rot3(float (&w)[3][R][16], TabPtr tlane, int first_row) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -35,12 +45,12 @@ __device__ __forceinline__ void load_rot3(float (&w)[3][R][16], const float4* tl
 
 // acc + (table rows first_row.. of this lane) . h  — fc_hid pre-activation or its transpose product
 template <int R>
-__device__ __forceinline__ float tab_rotdot(float acc, const float4* tlane, int first_row, float h) {
-    const float4* t0 = tlane + first_row * 4 * 64;
-    float v = rotdot_quads(acc, [t0](int q) { return t0[q * 64]; }, h);
+__device__ __forceinline__ float tab_rotdot(float acc, TabPtr tlane, int first_row, float h) {
+    TabPtr t0 = tlane + first_row * 4 * 64;
+    float v = rotdot_quads(acc, [t0](int q) { return tab_ld(t0, q * 64); }, h);
     if constexpr (R == 2) {
-        const float4* t1 = t0 + 4 * 64;
-        v = rotdot_quads(v, [t1](int q) { return t1[q * 64]; }, swap16(h));
+        TabPtr t1 = t0 + 4 * 64;
+        v = rotdot_quads(v, [t1](int q) { return tab_ld(t1, q * 64); }, swap16(h));
     }
     return v;
 }

@@ -173,7 +173,7 @@ __device__ __forceinline__ void load_qgru_w(QgruW& w, const float* pl, const Qgr
 // common prologue: params, tables, luts.  returns pointers
 template <bool WITH_T, bool LUT>
 __device__ __forceinline__ void qgru_prologue(const SeqArgs& a, float* smem, const QgruLayout& L, const LaneId& id, QgruW& w,
-                                              const float4*& tlane, const float*& lut, int& nlut, float*& wave_base,
+                                              TabPtr& tlane, const float*& lut, int& nlut, float*& wave_base,
                                               int wave_floats, int bits_w, int bits_a) {
     float* pl = smem;
     stage_params(pl, a.params, L.P);
@@ -184,7 +184,7 @@ __device__ __forceinline__ void qgru_prologue(const SeqArgs& a, float* smem, con
     nlut = LUT ? (1 << bits_a) : 0;
     if constexpr (LUT) fill_luts(lutw, w.qadd, bits_a);
     __syncthreads();
-    tlane = reinterpret_cast<const float4*>(tab) + id.lane;
+    tlane = to_tab(reinterpret_cast<const float4*>(tab) + id.lane);
     lut = lutw;
     wave_base = lutw + 2 * nlut + (size_t)id.wave * wave_floats;
 }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kMaxThreads) void qgru_fwd_kernel(SeqArgs a, int bi
     const LaneId id = lane_id<1>();
     const int lane = id.lane, col = id.col, s = id.s;
     const QgruLayout L = qgru_layout(a.H);
-    QgruW w; const float4* tlane; const float* lut; int nlut; float* wb;
+    QgruW w; TabPtr tlane; const float* lut; int nlut; float* wb;
     qgru_prologue<false, LUT>(a, smem, L, id, w, tlane, lut, nlut, wb, 2 * 2 * SPW * kChunkPad, bits_w, bits_a);
     float2* xs = reinterpret_cast<float2*>(wb);
     float2* ys = xs + SPW * kChunkPad;
@@ -242,7 +242,7 @@ struct QgruGrad {
 };
 
 template <bool AMP1, bool LUT, bool FULL>
-__device__ __forceinline__ void qgru_bwd_block(const SeqArgs& a, const QgruW& w, const float4* tlane, const float* lut, int nlut,
+__device__ __forceinline__ void qgru_bwd_block(const SeqArgs& a, const QgruW& w, TabPtr tlane, const float* lut, int nlut,
                                                QgruGrad& G, const LaneId& id, const float2* xs, const float2* dys, int tloc,
                                                int nstep, float h, float& dh) {
     constexpr int S = kCkptStride;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kMaxThreads / 2, 1) void qgru_bwd_kernel(SeqArgs a,
     const LaneId id = lane_id<1>();
     const int lane = id.lane, col = id.col;
     const QgruLayout L = qgru_layout(a.H);
-    QgruW w; const float4* tlane; const float* lut; int nlut; float* wb;
+    QgruW w; TabPtr tlane; const float* lut; int nlut; float* wb;
     qgru_prologue<true, LUT>(a, smem, L, id, w, tlane, lut, nlut, wb, 2 * 2 * SPW * kChunkPad, bits_w, bits_a);
     float2* xs = reinterpret_cast<float2*>(wb);
     float2* dys = xs + SPW * kChunkPad;
