@@ -27,10 +27,12 @@ __host__ __device__ inline TcnnLayout tcnn_layout(int C) {
 constexpr int kTHalo = 32;   // >= receptive-field radius 2*(1+2+4+8) = 30
 
 struct TcnnTile { int nthreads, tile, ntiles; };
-inline TcnnTile tcnn_tiling(int T) {
+// forward: up to 16 waves per workgroup; backward (116 gradient accumulators per thread): up to 8 waves = 256 VGPRs
+inline TcnnTile tcnn_tiling(int T, int max_waves = 16) {
     TcnnTile t;
-    int want = (T < 960 ? T : 960) + 2 * kTHalo;
-    int nw = (want + 63) / 64; if (nw > 16) nw = 16;
+    const int cap = 64 * max_waves - 2 * kTHalo;
+    int want = (T < cap ? T : cap) + 2 * kTHalo;
+    int nw = (want + 63) / 64; if (nw > max_waves) nw = max_waves;
     t.nthreads = 64 * nw; t.tile = t.nthreads - 2 * kTHalo; t.ntiles = (T + t.tile - 1) / t.tile;
     return t;
 }
@@ -44,7 +46,12 @@ __device__ __forceinline__ void tcnn_feat(float2 xv, bool in, float (&f)[6]) {
     f[0] = xv.x; f[1] = xv.y; f[2] = a; f[3] = a2 * a; f[4] = xv.y * ia; f[5] = xv.x * ia;
 }
 
-// grid = (ntiles, B); block = nthreads; LDS = 2 * nthreads floats
+// Channels are processed kCG at a time: one workgroup barrier per stage serves kCG channels (the stage buffers
+// ping-pong, so the write of stage l never races with the reads of stage l-1), and x / dy / the features are loaded
+// and formed once per group instead of once per channel.
+constexpr int kCG = 1;
+
+// grid = (ntiles, B); block = nthreads; LDS = 2 * kCG * nthreads floats
 __global__ __launch_bounds__(1024) void tcnn_fwd_kernel(SeqArgs a, int tile) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = blockDim.x, pos = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * tile, t = t0 - kTHalo + pos;
@@ -54,54 +61,60 @@ __global__ __launch_bounds__(1024) void tcnn_fwd_kernel(SeqArgs a, int tile) {
     const float2 xv = in ? reinterpret_cast<const float2*>(a.x)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
     float f[6];
     tcnn_feat(xv, in, f);
-    float* cur = smem; float* nxt = smem + n;
     float y0 = 0.0f, y1 = 0.0f;
-    for (int c = 0; c < L.C; ++c) {
-        float v = p[L.o_b0 + c];
+    int flip = 0;
+    for (int c0 = 0; c0 < L.C; c0 += kCG) {
+        float act[kCG];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
-        float act = in ? hardswishf_(v) : 0.0f;
+        for (int j = 0; j < kCG; ++j) {
+            const int c = min(c0 + j, L.C - 1);
+            float v = p[L.o_b0 + c];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
+            act[j] = in ? hardswishf_(v) : 0.0f;
+        }
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const int d = 1 << l;
-            __syncthreads();
-            cur[pos] = act;
-            __syncthreads();
-            float s = 0.0f;
+            float* buf = smem + (flip ^= 1) * kCG * n;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(cur, pos + d * (k - 2), n), s);
-            act = in ? hardswishf_(s) : 0.0f;
-            float* tsw = cur; cur = nxt; nxt = tsw;
+            for (int j = 0; j < kCG; ++j) buf[j * n + pos] = act[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kCG; ++j) {
+                const int c = min(c0 + j, L.C - 1);
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(buf + j * n, pos + d * (k - 2), n), s);
+                act[j] = in ? hardswishf_(s) : 0.0f;
+            }
         }
-        y0 = __builtin_fmaf(p[L.o_w5 + c], act, y0);
-        y1 = __builtin_fmaf(p[L.o_w5 + L.C + c], act, y1);
+#pragma unroll
+        for (int j = 0; j < kCG; ++j) {
+            if (c0 + j < L.C) {
+                y0 = __builtin_fmaf(p[L.o_w5 + c0 + j], act[j], y0);
+                y1 = __builtin_fmaf(p[L.o_w5 + L.C + c0 + j], act[j], y1);
+            }
+        }
     }
     if (in && pos >= kTHalo && pos < kTHalo + tile)
         reinterpret_cast<float2*>(a.y)[(size_t)b * a.T + t] = make_float2(y0 + xv.x, y1 + xv.y);
 }
 
-// grid = (C, nslices); block = nthreads; LDS = 10 * nthreads floats (pre and act of 5 stages) + reduction scratch
-__global__ __launch_bounds__(1024) void tcnn_bwd_kernel(SeqArgs a, int tile, int ntiles, int nslices) {
+// grid = (ceil(C / kCG), nslices); block = nthreads; LDS = 6 * kCG * nthreads floats (4 stage inputs kept for the
+// weight gradients + 2 ping-pong exchange buffers), re-used as reduction scratch at the end
+__global__ __launch_bounds__(512) void tcnn_bwd_kernel(SeqArgs a, int tile, int ntiles, int nslices) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int n = blockDim.x, pos = threadIdx.x, c = blockIdx.x, slice = blockIdx.y;
+    const int n = blockDim.x, pos = threadIdx.x, c0 = blockIdx.x * kCG, slice = blockIdx.y;
     const TcnnLayout L = tcnn_layout(a.H);
     const float* __restrict__ p = a.params;
-    float* pre = smem;            // pre[l*n + pos], l = 0..4
-    float* act = smem + 5 * n;    // act[l*n + pos]
-    float w0[6], wd[4][5];
+    float* act = smem;                    // act[(l * kCG + j) * n + pos], l = 0..3: inputs of the depthwise stages
+    float* xch = smem + 4 * kCG * n;      // two exchange buffers of kCG * n
+    float gacc[kCG][29];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) w0[i] = p[L.o_w0 + c * 6 + i];
-    const float b0 = p[L.o_b0 + c];
+    for (int j = 0; j < kCG; ++j)
 #pragma unroll
-    for (int l = 0; l < 4; ++l)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) wd[l][k] = p[L.o_dw[l] + c * 5 + k];
-    const float w5a = p[L.o_w5 + c], w5b = p[L.o_w5 + L.C + c];
-    float g_w0[6] = {0, 0, 0, 0, 0, 0}, g_b0 = 0.f, g_wd[4][5], g_w5a = 0.f, g_w5b = 0.f;
-#pragma unroll
-    for (int l = 0; l < 4; ++l)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) g_wd[l][k] = 0.f;
+        for (int i = 0; i < 29; ++i) gacc[j][i] = 0.0f;
 
     const int nwork = a.B * ntiles;
     for (int wk = slice; wk < nwork; wk += nslices) {
@@ -111,77 +124,103 @@ __global__ __launch_bounds__(1024) void tcnn_bwd_kernel(SeqArgs a, int tile, int
         const float2 dyv = own ? reinterpret_cast<const float2*>(a.dy)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
         float f[6];
         tcnn_feat(xv, in, f);
-        // forward of this channel, all stages kept
-        float v = b0;
+        float pre[kCG][5], cur[kCG];
+        __syncthreads();   // the previous work item is done with every buffer
+        // forward of the group's channels; act_l stays in LDS, the thread keeps its own pre-activations
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v = __builtin_fmaf(w0[i], f[i], v);
-        __syncthreads();   // previous work item done with the buffers
-        pre[pos] = v; act[pos] = in ? hardswishf_(v) : 0.0f;
+        for (int j = 0; j < kCG; ++j) {
+            const int c = min(c0 + j, L.C - 1);
+            float v = p[L.o_b0 + c];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
+            pre[j][0] = v;
+            cur[j] = in ? hardswishf_(v) : 0.0f;
+        }
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const int d = 1 << l;
-            __syncthreads();
-            float s = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) s = __builtin_fmaf(wd[l][k], ldz(act + l * n, pos + d * (k - 2), n), s);
-            pre[(l + 1) * n + pos] = s; act[(l + 1) * n + pos] = in ? hardswishf_(s) : 0.0f;
+            for (int j = 0; j < kCG; ++j) act[(l * kCG + j) * n + pos] = cur[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kCG; ++j) {
+                const int c = min(c0 + j, L.C - 1);
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(act + (l * kCG + j) * n, pos + d * (k - 2), n), s);
+                pre[j][l + 1] = s;
+                cur[j] = in ? hardswishf_(s) : 0.0f;
+            }
         }
         // backward.  g = dL/d act_l ; gp = dL/d pre_l (masked outside the frame)
-        const float a4 = act[4 * n + pos];
-        g_w5a = __builtin_fmaf(dyv.x, a4, g_w5a); g_w5b = __builtin_fmaf(dyv.y, a4, g_w5b);
-        float g = __builtin_fmaf(dyv.x, w5a, dyv.y * w5b);
+        float g[kCG];
+#pragma unroll
+        for (int j = 0; j < kCG; ++j) {
+            const int c = min(c0 + j, L.C - 1);
+            gacc[j][27] = __builtin_fmaf(dyv.x, cur[j], gacc[j][27]);
+            gacc[j][28] = __builtin_fmaf(dyv.y, cur[j], gacc[j][28]);
+            g[j] = __builtin_fmaf(dyv.x, p[L.o_w5 + c], dyv.y * p[L.o_w5 + L.C + c]);
+        }
 #pragma unroll
         for (int l = 3; l >= 0; --l) {
             const int d = 1 << l;
-            const float gp = in ? g * hsg(pre[(l + 1) * n + pos]) : 0.0f;
+            float* ex = xch + (l & 1) * kCG * n;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) g_wd[l][k] = __builtin_fmaf(gp, ldz(act + l * n, pos + d * (k - 2), n), g_wd[l][k]);
-            __syncthreads();
-            pre[(l + 1) * n + pos] = gp;      // pre_{l+1} is no longer needed: reuse it to exchange gp
-            __syncthreads();
-            g = 0.0f;
+            for (int j = 0; j < kCG; ++j) {
+                const float gp = in ? g[j] * hsg(pre[j][l + 1]) : 0.0f;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) g = __builtin_fmaf(wd[l][k], ldz(pre + (l + 1) * n, pos - d * (k - 2), n), g);
+                for (int k = 0; k < 5; ++k)
+                    gacc[j][7 + l * 5 + k] = __builtin_fmaf(gp, ldz(act + (l * kCG + j) * n, pos + d * (k - 2), n), gacc[j][7 + l * 5 + k]);
+                ex[j * n + pos] = gp;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kCG; ++j) {
+                const int c = min(c0 + j, L.C - 1);
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(ex + j * n, pos - d * (k - 2), n), s);
+                g[j] = s;
+            }
         }
-        const float gp0 = in ? g * hsg(pre[pos]) : 0.0f;
-        g_b0 += gp0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) g_w0[i] = __builtin_fmaf(gp0, f[i], g_w0[i]);
+        for (int j = 0; j < kCG; ++j) {
+            const float gp0 = in ? g[j] * hsg(pre[j][0]) : 0.0f;
+            gacc[j][6] += gp0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) gacc[j][i] = __builtin_fmaf(gp0, f[i], gacc[j][i]);
+        }
     }
-    // block reduction of the 29 accumulators -> partial row `slice`
+    // block reduction of the 29 accumulators of every channel of the group -> partial row `slice`
     __syncthreads();
-    float vals[29];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) vals[i] = g_w0[i];
-    vals[6] = g_b0;
-#pragma unroll
-    for (int l = 0; l < 4; ++l)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) vals[7 + l * 5 + k] = g_wd[l][k];
-    vals[27] = g_w5a; vals[28] = g_w5b;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 29; ++i) {
-        float s = vals[i];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if (lane == 0) smem[wave * 32 + i] = s;
-    }
+    for (int j = 0; j < kCG; ++j)
+#pragma unroll
+        for (int i = 0; i < 29; ++i) {
+            float s = gacc[j][i];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+            if (lane == 0) smem[(wave * kCG + j) * 32 + i] = s;
+        }
     __syncthreads();
-    if (threadIdx.x < 29) {
-        float s = 0.0f;
-        for (int wv = 0; wv < nw; ++wv) s += smem[wv * 32 + threadIdx.x];
-        const int i = threadIdx.x;
-        int col;
-        if (i < 6) col = L.o_w0 + c * 6 + i;
-        else if (i == 6) col = L.o_b0 + c;
-        else if (i < 27) col = L.o_dw[(i - 7) / 5] + c * 5 + (i - 7) % 5;
-        else col = L.o_w5 + (i - 27) * L.C + c;
-        a.partials[(size_t)slice * (L.P + kLossCols) + col] = s;
+    if (threadIdx.x < kCG * 32) {
+        const int j = threadIdx.x >> 5, i = threadIdx.x & 31, c = c0 + j;
+        if (i < 29 && c < L.C) {
+            float s = 0.0f;
+            for (int wv = 0; wv < nw; ++wv) s += smem[(wv * kCG + j) * 32 + i];
+            int col;
+            if (i < 6) col = L.o_w0 + c * 6 + i;
+            else if (i == 6) col = L.o_b0 + c;
+            else if (i < 27) col = L.o_dw[(i - 7) / 5] + c * 5 + (i - 7) % 5;
+            else col = L.o_w5 + (i - 27) * L.C + c;
+            a.partials[(size_t)slice * (L.P + kLossCols) + col] = s;
+        }
     }
-    if (c == 0 && threadIdx.x < kLossCols) a.partials[(size_t)slice * (L.P + kLossCols) + L.P + threadIdx.x] = 0.0f;
+    if (blockIdx.x == 0 && threadIdx.x < kLossCols) a.partials[(size_t)slice * (L.P + kLossCols) + L.P + threadIdx.x] = 0.0f;
 }
 
-// grid = (ntiles, B); block = nthreads (tile + 64-step halo each side); LDS = 2 * nthreads floats
+// grid = (ntiles, B); block = nthreads (tile + 64-step halo each side); LDS = 2 * kCG * nthreads floats
 constexpr int kTHaloDx = 64;
 __global__ __launch_bounds__(1024) void tcnn_dx_kernel(SeqArgs a, int tile) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -193,43 +232,66 @@ __global__ __launch_bounds__(1024) void tcnn_dx_kernel(SeqArgs a, int tile) {
     const float2 dyv = in ? reinterpret_cast<const float2*>(a.dy)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
     float f[6], df[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     tcnn_feat(xv, in, f);
-    float* buf = smem; float* gbuf = smem + n;
-    for (int c = 0; c < L.C; ++c) {
-        // forward of channel c; the thread keeps its own pre-activations of the five stages
-        float pre[5];
-        float v = p[L.o_b0 + c];
+    int flip = 0;
+    for (int c0 = 0; c0 < L.C; c0 += kCG) {
+        // forward of the group; the thread keeps its own pre-activations of the five stages
+        float pre[kCG][5], cur[kCG];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
-        pre[0] = v;
-        float act = in ? hardswishf_(v) : 0.0f;
+        for (int j = 0; j < kCG; ++j) {
+            const int c = min(c0 + j, L.C - 1);
+            float v = p[L.o_b0 + c];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
+            pre[j][0] = v;
+            cur[j] = in ? hardswishf_(v) : 0.0f;
+        }
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const int d = 1 << l;
-            __syncthreads();
-            buf[pos] = act;
-            __syncthreads();
-            float s = 0.0f;
+            float* buf = smem + (flip ^= 1) * kCG * n;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(buf, pos + d * (k - 2), n), s);
-            pre[l + 1] = s;
-            act = in ? hardswishf_(s) : 0.0f;
+            for (int j = 0; j < kCG; ++j) buf[j * n + pos] = cur[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kCG; ++j) {
+                const int c = min(c0 + j, L.C - 1);
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(buf + j * n, pos + d * (k - 2), n), s);
+                pre[j][l + 1] = s;
+                cur[j] = in ? hardswishf_(s) : 0.0f;
+            }
         }
-        // backward of channel c down to the features
-        float g = __builtin_fmaf(dyv.x, p[L.o_w5 + c], dyv.y * p[L.o_w5 + L.C + c]);
+        // backward of the group down to the features
+        float g[kCG];
+#pragma unroll
+        for (int j = 0; j < kCG; ++j) {
+            const int c = min(c0 + j, L.C - 1);
+            g[j] = c0 + j < L.C ? __builtin_fmaf(dyv.x, p[L.o_w5 + c], dyv.y * p[L.o_w5 + L.C + c]) : 0.0f;
+        }
 #pragma unroll
         for (int l = 3; l >= 0; --l) {
             const int d = 1 << l;
-            const float gp = in ? g * hsg(pre[l + 1]) : 0.0f;
-            __syncthreads();
-            gbuf[pos] = gp;
-            __syncthreads();
-            g = 0.0f;
+            float* buf = smem + (flip ^= 1) * kCG * n;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) g = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(gbuf, pos - d * (k - 2), n), g);
+            for (int j = 0; j < kCG; ++j) buf[j * n + pos] = in ? g[j] * hsg(pre[j][l + 1]) : 0.0f;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kCG; ++j) {
+                const int c = min(c0 + j, L.C - 1);
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(buf + j * n, pos - d * (k - 2), n), s);
+                g[j] = s;
+            }
         }
-        const float gp0 = in ? g * hsg(pre[0]) : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) df[i] = __builtin_fmaf(gp0, p[L.o_w0 + c * 6 + i], df[i]);
+        for (int j = 0; j < kCG; ++j) {
+            const int c = min(c0 + j, L.C - 1);
+            const float gp0 = in ? g[j] * hsg(pre[j][0]) : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) df[i] = __builtin_fmaf(gp0, p[L.o_w0 + c * 6 + i], df[i]);
+        }
     }
     if (in && pos >= kTHaloDx && pos < kTHaloDx + tile) {
         float dI, dQ;
@@ -247,8 +309,8 @@ inline TcnnTileDx tcnn_tiling_dx(int T) {
 }
 
 static int tcnn_slices(int B, int ntiles, int C) {
-    const int nwork = B * ntiles;
-    int want = (8 * device_cus() + C - 1) / C;     // ~8 blocks per CU overall
+    const int nwork = B * ntiles, ngrp = (C + kCG - 1) / kCG;
+    int want = (8 * device_cus() + ngrp - 1) / ngrp;     // ~8 blocks per CU overall
     if (want < 1) want = 1;
     return nwork < want ? nwork : want;
 }
@@ -256,29 +318,31 @@ static int tcnn_slices(int B, int ntiles, int C) {
 int tcnn_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
     const TcnnTile tl = tcnn_tiling(a.T);
-    hipLaunchKernelGGL(tcnn_fwd_kernel, dim3(tl.ntiles, a.B), dim3(tl.nthreads), 2 * tl.nthreads * sizeof(float), st, a, tl.tile);
+    hipLaunchKernelGGL(tcnn_fwd_kernel, dim3(tl.ntiles, a.B), dim3(tl.nthreads), 2 * kCG * tl.nthreads * sizeof(float), st, a, tl.tile);
     return (int)hipGetLastError();
 }
 int tcnn_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
     if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
     if (a.partials != nullptr) {
-        const TcnnTile tl = tcnn_tiling(a.T);
+        const TcnnTile tl = tcnn_tiling(a.T, 8);
         const int ns = tcnn_slices(a.B, tl.ntiles, m->hidden);
-        size_t lds = (size_t)10 * tl.nthreads * sizeof(float);
-        if (lds < 16 * 32 * sizeof(float)) lds = 16 * 32 * sizeof(float);
-        hipLaunchKernelGGL(tcnn_bwd_kernel, dim3(m->hidden, ns), dim3(tl.nthreads), lds, st, a, tl.tile, tl.ntiles, ns);
+        size_t lds = (size_t)6 * kCG * tl.nthreads * sizeof(float);
+        if (lds < (size_t)16 * kCG * 32 * sizeof(float)) lds = (size_t)16 * kCG * 32 * sizeof(float);
+        auto kb = tcnn_bwd_kernel;
+        if (int e = allow_big_lds(kb, lds)) return e;
+        hipLaunchKernelGGL(kb, dim3((m->hidden + kCG - 1) / kCG, ns), dim3(tl.nthreads), lds, st, a, tl.tile, tl.ntiles, ns);
         if (int e = (int)hipGetLastError()) return e;
     }
     if (a.dx != nullptr) {
         const TcnnTileDx td = tcnn_tiling_dx(a.T);
-        hipLaunchKernelGGL(tcnn_dx_kernel, dim3(td.ntiles, a.B), dim3(td.nthreads), 2 * td.nthreads * sizeof(float), st, a, td.tile);
+        hipLaunchKernelGGL(tcnn_dx_kernel, dim3(td.ntiles, a.B), dim3(td.nthreads), 2 * kCG * td.nthreads * sizeof(float), st, a, td.tile);
     }
     return (int)hipGetLastError();
 }
 int tcnn_rows(const odpd_model_t* m, int B, int T) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
-    return tcnn_slices(B, tcnn_tiling(T).ntiles, m->hidden);
+    return tcnn_slices(B, tcnn_tiling(T, 8).ntiles, m->hidden);
 }
 
 }  // namespace odpd
