@@ -198,3 +198,11 @@ def test_s16_split_large_batch_matches_row_rotated(bb, H):
     flipped = int((per_seq > 2e-5).sum())
     assert flipped <= (12 if bb == "dgru" else 0), flipped
     assert rel_err(dp0.cpu().numpy(), dp1.cpu().numpy()) < (2e-3 if bb == "dgru" else 2e-4)
+
+
+def test_s16_native_epoch_loop(force_s16):
+    """odpd_train_epoch with the S16 kernel: frames addressed in place inside the resident streams (frame_idx path of
+    the 16-sequence staging) == per-batch loop over gathered frame tensors, bit for bit."""
+    from tests import test_e2e_gpu as e2e
+    e2e.test_native_epoch_loop_equals_per_step_loop("dgru", 13, 50, 64)
+    e2e.test_native_epoch_loop_equals_per_step_loop("gru", 11, 200, 256)

@@ -38,11 +38,17 @@ def data(B):
 
 CASES = [("gru", 11, {}), ("dgru", 13, {}), ("dgru", 23, {}), ("qgru", 10, {}), ("lstm", 14, {}), ("vdlstm", 13, {}),
          ("deltagru", 15, dict(thx=0.01, thh=0.05)), ("deltagru_tcnskip", 15, dict(thx=0.01, thh=0.05)), ("pgjanet", 11, {}),
-         ("tcnn", 35, {})]
+         ("tcnn", 35, {}), ("qgru W8A8 (QAT)", 10, dict(qat=(8, 8))), ("qgru_amp1 W8A8 (QAT)", 10, dict(qat=(8, 8)))]
 rows = []
 for bb, H, kw in CASES:
     torch.manual_seed(0)
-    net = CoreModel(2, H, 1, bb, **kw).cuda()
+    qat = kw.pop("qat", None)
+    net = CoreModel(2, H, 1, bb.split()[0], **kw)
+    if qat:
+        from types import SimpleNamespace
+        from opendpd_amd.quant import get_quant_model
+        net = get_quant_model(SimpleNamespace(quant=True, n_bits_w=qat[0], n_bits_a=qat[1], pretrained_model=""), net)
+    net = net.cuda()
     P = sum(p.numel() for p in net.parameters())
     opt = FusedAdamW(net, lr=1e-4)
     cells = []
