@@ -1,6 +1,7 @@
-// gru_s16.hip — "S16" fused train kernel of the nn.GRU based backbones (gru, dgru, qgru, qgru_amp1 float
-// paths; reference backbones/{gru,dgru,qgru,qgru_amp1}.py + modules/train_funcs.py:33-39) for hidden <= 16
-// and batches large enough to fill the chip with 16-sequence wavefronts.
+// gru_s16.hip — "S16" kernels of the nn.GRU based backbones (gru, dgru, qgru, qgru_amp1 float paths; reference
+// backbones/{gru,dgru,qgru,qgru_amp1}.py + modules/train_funcs.py:33-39) for hidden <= 16 and batches large enough
+// to fill the chip with 16-sequence wavefronts: the fused train kernel (gru16_train_kernel) and the split forward /
+// backward kernels (gru16_fwd_kernel, gru16_bwd_kernel: weight-gradient partials and / or dL/dx).
 //
 // Lane mapping (differs from gru_family.hip): a wavefront holds SIXTEEN sequences; lane l = (n, q) with
 // n = l & 15 the sequence and q = l >> 4 a quad of hidden units; the lane owns units 4q..4q+3 of sequence n
@@ -166,14 +167,7 @@ __device__ __forceinline__ void s16_slots(float I, float Q, const float (&oh)[4]
 }
 
 // ---- stage-major 4-wide element-wise helpers (same arithmetic as sigmoidf_ / tanhf_ of odpd_device.h) ----
-#ifndef ODPD_STAGE_FENCE
-#define ODPD_STAGE_FENCE 0
-#endif
-#if ODPD_STAGE_FENCE
-#define ODPD_EACH4 __builtin_amdgcn_sched_barrier(0); _Pragma("unroll") for (int i = 0; i < 4; ++i)
-#else
 #define ODPD_EACH4 _Pragma("unroll") for (int i = 0; i < 4; ++i)
-#endif
 // relu of an MFMA result: one v_max_f32 (fmaxf() would first quiet a possible sNaN with a second v_max)
 __device__ __forceinline__ float relu_(float v) {
     float r;
