@@ -90,6 +90,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
     case FAM_GRU:   // [4-sequence group][ckpt][64 lanes], or [16-sequence task][ckpt][64 lanes][4] for the S16 kernels
+        if (gru_uses_s16n(m, B)) return gru_s16n_ckpt_floats(m, B, T);
         return gru_split_uses_s16(m, B) ? (int64_t)((B + 15) / 16) * num_ckpt(T) * 256 : (int64_t)num_groups(B, R) * num_ckpt(T) * 64;
     case FAM_LSTM: return (int64_t)num_groups(B, R) * num_ckpt(T) * 128;   // h and c
     case FAM_DELTA: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 7 * 64 : (int64_t)ODPD_EUNSUPPORTED;
@@ -114,6 +115,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
 extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    if (gru_uses_s16n(m, B)) return gru_s16n_ckpt_floats(m, B, T);
     return gru_train_uses_s16(m, B, T) ? gru_s16_workspace_floats(m, B, T) : 0;
 }
 
@@ -168,6 +170,7 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.ckpt = workspace;
     switch (family_of(m)) {
     case FAM_GRU:
+        if (gru_uses_s16n(m, B)) return gru_s16n_launch((hipStream_t)stream, m, a, 0);
         return gru_train_uses_s16(m, B, T) ? gru_s16_train((hipStream_t)stream, m, a)
                                            : gru_family_train((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
@@ -199,9 +202,9 @@ extern "C" int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_ki
         a.frame_idx = (const long long*)(fr->order + f0); a.frame_stride = fr->stride;
         const int64_t count = (int64_t)B * T * 2;
         a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
-        const bool s16 = gru_train_uses_s16(m, B, T);
-        if (s16 && !workspace) return ODPD_EINVAL;
-        int rc = s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a);
+        const bool s16n = gru_uses_s16n(m, B), s16 = !s16n && gru_train_uses_s16(m, B, T);
+        if ((s16 || s16n) && !workspace) return ODPD_EINVAL;
+        int rc = s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));
         if (rc) return rc;
         rc = odpd_reduce_partials(stream, rows, P, partials, grad, 0);
         if (rc) return rc;

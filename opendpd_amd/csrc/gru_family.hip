@@ -722,6 +722,15 @@ static bool gru_setup(const odpd_model_t* m, int& FM, bool& DG, int& R, int& P) 
     return true;
 }
 
+// hidden 17..32: the generic-tile S16 kernels (gru_s16n.hip) take over from the two-row DPP kernels at the same batch
+bool gru_uses_s16n(const odpd_model_t* m, int B) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P) || R != 2) return false;
+    long min_batch = tuning().s16_min_batch;
+    if (min_batch < 0) min_batch = 8L * 4 * device_cus();    // measured crossover (DGRU-23, T = 200): 1.54 vs 1.33 ms at 8192
+    return B >= min_batch;
+}
+
 // The split kernels switch to the 16-sequences-per-wave mapping at the same batch size as the fused one.  Forward
 // and backward of one (B,T) batch must agree (checkpoint layout), so the rule only looks at the model and B.
 bool gru_split_uses_s16(const odpd_model_t* m, int B) {
@@ -736,6 +745,7 @@ int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     if (gru_split_uses_s16(m, a.B)) return gru_s16_fwd(st, m, a);
+    if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 1);
     ODPD_GRU_DISPATCH_ALL(launch_fwd, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
@@ -743,6 +753,7 @@ int gru_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     if (gru_split_uses_s16(m, a.B)) return gru_s16_bwd(st, m, a);
+    if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 2);
     ODPD_GRU_DISPATCH_ALL(launch_bwd_mode, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
@@ -757,6 +768,7 @@ int gru_family_rows(const odpd_model_t* m, int B, int which, int T) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     const int ng = num_groups(B, R);
+    if (gru_uses_s16n(m, B)) return gru_s16n_rows(m, B);
     if (!which) return gru_split_uses_s16(m, B) ? gru_s16_bwd_rows(m, B) : bwd_shape(R, ng).grid;
     if (gru_train_uses_s16(m, B, T)) return gru_s16_rows(m, B);
     const LaunchShape ls = train_shape(P, R, DG, ng, T, nullptr);

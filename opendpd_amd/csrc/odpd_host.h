@@ -111,6 +111,11 @@ bool gru_split_uses_s16(const odpd_model_t* m, int B);
 int gru_s16_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_s16_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_s16_bwd_rows(const odpd_model_t* m, int B);
+// hidden 17..32 (gru_s16n.hip): mode 0 fused train (ckpt = workspace), 1 forward, 2 backward
+bool gru_uses_s16n(const odpd_model_t* m, int B);
+int gru_s16n_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
+int gru_s16n_rows(const odpd_model_t* m, int B);
+int64_t gru_s16n_ckpt_floats(const odpd_model_t* m, int B, int T);
 // optim.hip: clip + AdamW launch that also records loss = grad[P] * inv_count into loss_out (nullable)
 int launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t step,
                       double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, float* norm_out,

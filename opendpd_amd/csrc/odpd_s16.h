@@ -1,0 +1,131 @@
+// odpd_s16.h — building blocks shared by the 16-sequences-per-wave ("S16") kernels: gru_s16.hip (hidden <= 16, operands
+// pinned in registers) and gru_s16n.hip (hidden <= 16 * NT, operands streamed from LDS).  Lane l = (n = l & 15 sequence,
+// q = l >> 4 unit quad); see gru_s16.hip for the mapping and the MFMA operand layout.
+#pragma once
+#include "odpd_seq.h"
+
+namespace odpd {
+
+constexpr int kTilePitch = 20;                  // floats per sequence row of a transpose tile (16 + pad, 16 B aligned)
+constexpr int kTileFloats = 16 * kTilePitch;
+constexpr int kS16Tiles = 7;                    // drp dzp dnp dgh hp dhid feat
+constexpr int kS16WaveFloats = 2 * 2 * 16 * kChunkPad + kS16Tiles * kTileFloats;
+
+template <int FM> struct S16Cfg {
+    static constexpr int F = FeatDim<FM>::F;
+    static constexpr int NCH = (F + 4) / 4;     // K-chunks of the input projection (F features + constant-1 slot)
+};
+
+__host__ __device__ constexpr int s16_tab_floats(int groups) { return groups * 64 * 4; }
+
+template <int FM, bool DG>
+__device__ __forceinline__ float s16_wih_slot(const float* pl, const GruLayout& L, int g, int c, int m, int q) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH;
+    const int H = L.H, k = 4 * c + q;
+    if (c >= NCH || m >= H) return 0.0f;
+    if (k < F) return pl[L.o_w_ih + (g * H + m) * F + k];
+    if (k == F) return pl[L.o_b_ih + g * H + m] + (g < 2 ? pl[L.o_b_hh + g * H + m] : 0.0f);
+    return 0.0f;
+}
+template <int FM, bool DG>
+__device__ __forceinline__ float s16_woutf_slot(const float* pl, const GruLayout& L, int cc, int c, int q) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH;
+    const int H = L.H, OW = DG ? H + 6 : H, k = 4 * c + q;
+    if (c >= NCH) return 0.0f;
+    if (DG && k < F) return pl[L.o_w_out + cc * OW + H + k];
+    if (k == F) return pl[L.o_b_out + cc];
+    return 0.0f;
+}
+// The r and z gate operands (W_h{r,z}, W_i{r,z}, their biases) are stored pre-multiplied by -log2(e): the MFMA
+// accumulators then hold -log2(e) * pre-activation and sigmoid is exp2 / add / rcp with no scaling multiply.
+constexpr float kNegLog2e = -1.4426950408889634f;
+__device__ __forceinline__ f32x4 as_f32x4(const float4& v) { f32x4 r = {v.x, v.y, v.z, v.w}; return r; }
+
+// feature slots of the lane: fs[c] = slot 4c+q of [feat_0 .. feat_{F-1}, 1, 0, ..], selected branch-free with the
+// lane's one-hot quad indicator oh[e] = (q == e)  (exact: one non-zero term)
+template <int FM>
+__device__ __forceinline__ void s16_slots(float I, float Q, const float (&oh)[4], float (&fs)[S16Cfg<FM>::NCH]) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH;
+    float f[F];
+    feat_fwd<FM>(I, Q, f);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float acc = (F >= 4 * c && F < 4 * c + 4) ? oh[(F - 4 * c) & 3] : 0.0f;   // the constant-1 slot
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * c + e < F) acc = __builtin_fmaf(oh[e], f[(4 * c + e) < F ? (4 * c + e) : 0], acc);
+        fs[c] = acc;
+    }
+}
+
+// ---- stage-major 4-wide element-wise helpers (same arithmetic as sigmoidf_ / tanhf_ of odpd_device.h) ----
+#define ODPD_EACH4 _Pragma("unroll") for (int i = 0; i < 4; ++i)
+// relu of an MFMA result: one v_max_f32 (fmaxf() would first quiet a possible sNaN with a second v_max)
+__device__ __forceinline__ float relu_(float v) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// per-element loops, NOT whole-vector arithmetic: <4 x float> IR ops become v_pk_*_f32, which issue at half
+// rate on gfx950 and measured 6 % slower here (profiles/r01/ubench_issue_costs.md)
+__device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
+__device__ __forceinline__ f32x4 fma4(const f32x4& a, const f32x4& b, const f32x4& c) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = __builtin_fmaf(a[i], b[i], c[i]);
+    return r;
+}
+__device__ __forceinline__ f32x4 mul4(const f32x4& a, const f32x4& b) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = a[i] * b[i];
+    return r;
+}
+__device__ __forceinline__ f32x4 add4(const f32x4& a, const f32x4& b) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = a[i] + b[i];
+    return r;
+}
+__device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = a[i] - b[i];
+    return r;
+}
+__device__ __forceinline__ f32x4 exp2_4(const f32x4& v) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = __builtin_amdgcn_exp2f(v[i]);
+    return r;
+}
+__device__ __forceinline__ f32x4 rcp4(const f32x4& v) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = fast_rcp(v[i]);
+    return r;
+}
+// sigmoid of a pre-activation that arrives already multiplied by -log2(e)
+__device__ __forceinline__ f32x4 sigmoid4_prescaled(const f32x4& v) {
+    return rcp4(add4(exp2_4(v), splat4(1.0f)));
+}
+// tanh(v) = 1 - 2 / (exp2(2 log2(e) v) + 1): 5 VALU ops, |error| <= 1.9e-7 over the whole range (the row-rotated
+// kernels' tanhf_ adds a polynomial branch for |v| < 0.3 to reach 1.1e-7; both are far inside the 2e-5 parity
+// tolerance and of the size of one rounding of a value near 1)
+__device__ __forceinline__ f32x4 tanh4(const f32x4& v) {
+    const f32x4 e = add4(exp2_4(mul4(v, splat4(2.8853900817779268f))), splat4(1.0f));
+    return fma4(rcp4(e), splat4(-2.0f), splat4(1.0f));
+}
+
+// sum over the four quads of a sequence (lanes n, n+16, n+32, n+48); every lane gets the total
+__device__ __forceinline__ float quad_sum(float v) {
+    v += swap16(v);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// transpose tile: lane (n,q) stores X[n][4q..4q+3]; lane (u,k) loads X[4k+c][u], c = 0..3
+__device__ __forceinline__ void tile_put(float* tile, int n, int q, const f32x4& v) {
+    *reinterpret_cast<float4*>(tile + n * kTilePitch + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void tile_get(const float* tile, int u, int k, float (&out)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[c] = tile[(4 * k + c) * kTilePitch + u];
+}
+
+
+}  // namespace odpd

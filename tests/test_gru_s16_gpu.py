@@ -39,8 +39,8 @@ def test_selection_and_workspace(force_s16):
     d = net.backbone.desc
     assert lib.odpd_train_workspace_floats(C.byref(d), 33, 50) == 3 * 13 * 256     # 3 wave-tasks x 13 checkpoints
     assert lib.odpd_partial_rows(C.byref(d), 33, 50, 1) == 1
-    big = CoreModel(2, 23, 1, "dgru").backbone.desc                                  # hidden > 16: row-rotated kernel
-    assert lib.odpd_train_workspace_floats(C.byref(big), 33, 50) == 0
+    big = CoreModel(2, 23, 1, "dgru").backbone.desc                                  # hidden 17..32: two unit tiles per lane
+    assert lib.odpd_train_workspace_floats(C.byref(big), 33, 50) == 3 * 13 * 2 * 256
     lib.odpd_set_tuning(b"s16_min_batch", -1)
     assert lib.odpd_train_workspace_floats(C.byref(d), 33, 50) == 0                  # small batch: LDS-resident path
     assert lib.odpd_train_workspace_floats(C.byref(d), 65536, 200) == 4096 * 50 * 256
@@ -206,3 +206,60 @@ def test_s16_native_epoch_loop(force_s16):
     from tests import test_e2e_gpu as e2e
     e2e.test_native_epoch_loop_equals_per_step_loop("dgru", 13, 50, 64)
     e2e.test_native_epoch_loop_equals_per_step_loop("gru", 11, 200, 256)
+
+
+# ---- hidden 17..32: generic-tile S16 kernels (csrc/gru_s16n.hip) ------------------------------------------------------
+@pytest.fixture
+def force_s16n():
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    assert lib.odpd_set_tuning(b"s16_min_batch", 0) == 0
+    yield
+    lib.odpd_set_tuning(b"s16_min_batch", -1)
+
+
+@pytest.mark.parametrize("name,bb", [("gru_h23", "gru"), ("dgru_h23", "dgru")])
+def test_s16n_golden_forward_backward_and_trajectory(force_s16n, name, bb):
+    from tests import test_gru_family_gpu as fam
+    fam.test_golden_forward_backward(name, bb)
+    if name == "dgru_h23":
+        fam.test_fused_train_step_follows_reference_trajectory(name, bb)
+
+
+@pytest.mark.parametrize("bb,H", [("gru", 23), ("dgru", 23), ("dgru", 32), ("qgru", 17), ("qgru_amp1", 29), ("gru", 32)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (17, 64), (7, 65), (5, 200), (2, 333)])
+def test_s16n_against_oracle_ragged(force_s16n, bb, H, B, T):
+    from tests import test_gru_family_gpu as fam
+    fam.test_against_oracle_ragged(bb, H, B, T)
+
+
+@pytest.mark.parametrize("bb,H,B,T", [("dgru", 23, 256, 200), ("gru", 23, 37, 50), ("dgru", 32, 100, 64), ("qgru", 20, 3, 333)])
+def test_s16n_fused_equals_unfused(force_s16n, bb, H, B, T):
+    """fused S16N launch (L2 and L1) == autograd through the split S16N kernels (oracle-checked above)"""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    torch.manual_seed(1)
+    net = CoreModel(2, H, 1, bb).cuda()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    t = torch.randn(B, T, 2, device="cuda", generator=g) * 0.3
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.train_workspace(B, T, x.device) is not None
+    for kind, fn in (("l2", torch.nn.functional.mse_loss), ("l1", torch.nn.functional.l1_loss)):
+        for p in net.parameters():
+            p.grad = None
+        loss = fn(net(x), t)
+        loss.backward()
+        gref = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+        lf = fused_train_step(opt, x, t, kind, 0.0)
+        assert abs(lf.item() - loss.item()) < 1e-5 * max(1.0, loss.item()), kind
+        assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 2e-5, kind
+
+
+def test_s16n_cascades_follow_reference(force_s16n):
+    """BASELINE config 3: TRes-DeltaGRU DPD -> frozen DGRU H23 PA, and DGRU13 -> DGRU23, with the PA on the S16N kernels"""
+    from tests import test_cascade_gpu as casc
+    for name, d, p in (("cascade_dgru13_dgru23", "dgru", "dgru"), ("cascade_tres15_dgru23", "deltagru_tcnskip", "dgru")):
+        casc.test_cascade_autograd_matches_reference(name, d, p)
+        casc.test_cascade_fused_steps_follow_reference(name, d, p)
