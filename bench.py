@@ -38,10 +38,11 @@ ALGO_BYTES_PER_SAMPLE = 16.0
 FLOP_PER_SAMPLE = {13: 2 * 3 * (39 * 19 + 169 + 38)}  # fwd+dgrad+wgrad MACs*2 for DGRU H13 (5.7 kflop)
 
 
-def synth_frames(n_frames, T, seed, device):
+def synth_frames(n_frames, T, seed, device, materialize=True):
     """APA_200MHz-shaped synthetic frames: band-limited complex Gaussian stream (occupied bandwidth
     200/983.04 of fs), peak-normalised to 0.914, no sample with |x| < 1e-3, framed at stride 1 exactly as
-    IQFrameDataset does (data_collector.py:239-247); target = memory-polynomial PA-like map of x."""
+    IQFrameDataset does (data_collector.py:239-247); target = memory-polynomial PA-like map of x.
+    materialize=False returns the two (N,2) streams instead of the (n_frames,T,2) frame tensors."""
     g = torch.Generator(device=device).manual_seed(seed)
     n = n_frames + T - 1
     nfft = 1 << (n - 1).bit_length()
@@ -57,6 +58,8 @@ def synth_frames(n_frames, T, seed, device):
     y = x * (1.0 - 0.25 * a2 + 0.05 * a2 * a2) + 0.08 * xm1 * (1.0 - 0.3 * a2)
     xs = torch.view_as_real(x).float()
     ys = torch.view_as_real(y).float()
+    if not materialize:
+        return xs.contiguous(), ys.contiguous()
     fx = xs.unfold(0, T, 1).permute(0, 2, 1).contiguous()   # (n_frames, T, 2)
     fy = ys.unfold(0, T, 1).permute(0, 2, 1).contiguous()
     return fx, fy
@@ -128,6 +131,9 @@ def main():
     ap.add_argument("--ref-batch", type=int, default=256, help="reference batch (arguments.py:32) timed as a side figure")
     ap.add_argument("--hidden", type=int, default=13)
     ap.add_argument("--frame-length", type=int, default=200)
+    ap.add_argument("--materialized", action="store_true",
+                    help="feed (B,T,2) frame tensors (what IQFrameDataset materialises) instead of frames addressed in place "
+                         "inside the resident I/Q stream (SURVEY §8 f3; same kernels, same arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cascade", action="store_true", help="skip the train_dpd (cascade) side figure")
     args = ap.parse_args()
@@ -153,7 +159,13 @@ def main():
     torch.manual_seed(0)                      # identical replicas on every rank
     net = CoreModel(2, H, 1, "dgru").to(dev)
     opt = FusedAdamW(net, lr=5e-4)
-    x, t = synth_frames(B, T, seed=1000 + rank, device=dev)   # each rank owns its shard of the global batch
+    # each rank owns its shard of the global batch: B stride-1 frames of its own stream
+    if args.materialized:
+        x, t = synth_frames(B, T, seed=1000 + rank, device=dev)
+    else:
+        from opendpd_amd.train_funcs import FrameBatch
+        xs_, ys_ = synth_frames(B, T, seed=1000 + rank, device=dev, materialize=False)
+        x, t = FrameBatch(xs_, ys_, torch.arange(B, device=dev, dtype=torch.int64), T, 1), None
     count = world * B * T * 2
     el, kern_ms, loss = run_steps(opt, x, t, args.steps, args.warmup, count, dist, events=True)
     el_t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -167,7 +179,10 @@ def main():
     if args.ref_batch and args.ref_batch != B:
         net2 = CoreModel(2, H, 1, "dgru").to(dev)
         opt2 = FusedAdamW(net2, lr=5e-4)
-        xr, tr = x[:args.ref_batch].contiguous(), t[:args.ref_batch].contiguous()
+        if args.materialized:
+            xr, tr = x[:args.ref_batch].contiguous(), t[:args.ref_batch].contiguous()
+        else:
+            xr, tr = FrameBatch(xs_, ys_, torch.arange(args.ref_batch, device=dev, dtype=torch.int64), T, 1), None
         elr, _, _ = run_steps(opt2, xr, tr, max(args.steps, 50), args.warmup, world * args.ref_batch * T * 2, dist)
         elr_t = torch.tensor([elr], device=dev, dtype=torch.float64)
         if dist is not None:
@@ -186,7 +201,9 @@ def main():
         casc = casc.to(dev)
         opt3 = FusedAdamW(casc, lr=5e-4)
         n3 = max(3, min(args.steps, 10))
-        el3, _, loss3 = run_steps(opt3, x, x.clone(), n3, 2, world * B * T * 2, dist)
+        xc = x if args.materialized else xs_.unfold(0, T, 1)[:B].permute(0, 2, 1).contiguous()   # the cascade takes tensors
+        el3, _, loss3 = run_steps(opt3, xc, xc.clone(), n3, 2, world * B * T * 2, dist)
+        del xc
         dpd = {"workload": f"train_dpd: DGRU H{H} DPD -> frozen DGRU H{H} PA (five-launch cascade step), target = x",
                "value": B * T * n3 / el3, "unit": "IQ samples/s", "ms_per_step": 1e3 * el3 / n3, "loss": loss3}
         del casc, opt3
@@ -200,7 +217,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"dgru_h{H}_b{B}_t{T}", {}).get("hbm_bytes_per_launch")
+                key = f"dgru_h{H}_b{B}_t{T}" + ("_materialized" if args.materialized else "")
+                traffic = json.load(open(pmc)).get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -209,6 +227,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"train_pa DGRU H{H} ({net.backbone.n_flat} params) on APA_200MHz-shaped frames, "
                                    f"T={T}, fused fwd+MSE+BPTT+clip200+AdamW step",
+                       "inputs": "(B,T,2) frame tensors" if args.materialized else "stride-1 frames addressed in place in the resident I/Q stream",
                        "batch_per_gpu": B, "global_batch": world * B, "frame_length": T,
                        "parallelism": f"dp{world}", "loss": float(loss)},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -177,6 +177,26 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     }
 }
 
+// odpd_train_fwd_bwd on frames addressed inside resident streams (no materialised (B,T,2) tensors): batch = the B frames
+// fr->order[first .. first+B).  The caller finishes the step as usual (reduce, all-reduce when sharded, clip + AdamW).
+extern "C" int odpd_train_fwd_bwd_framed(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr,
+                                         int64_t first, int B, int64_t count, const float* params, float* partials,
+                                         float* workspace) {
+    if (!model_ok(m) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->frame_length <= 0 || fr->stride <= 0 ||
+        first < 0 || B <= 0 || first + B > fr->n_frames || count <= 0 || !params || !partials)
+        return ODPD_EINVAL;
+    if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    const int T = fr->frame_length;
+    SeqArgs a = make_args(m, B, T);
+    a.params = params; a.x = fr->x_stream; a.target = fr->y_stream; a.partials = partials; a.ckpt = workspace;
+    a.frame_idx = (const long long*)(fr->order + first); a.frame_stride = fr->stride;
+    a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
+    const bool s16n = gru_uses_s16n(m, B), s16 = !s16n && gru_train_uses_s16(m, B, T);
+    if ((s16 || s16n) && !workspace) return ODPD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    return s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));
+}
+
 // Native epoch loop (replaces the Python `for batch in loader` of net_train, train_funcs.py:28-48, for a single
 // backbone with a fused kernel): every step = fused fwd+loss+bwd on frames addressed inside the resident streams,
 // reduction, clip + AdamW; three launches per step issued back to back from C++, no host synchronisation, no

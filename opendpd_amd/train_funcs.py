@@ -213,16 +213,31 @@ class FusedAdamW:
         self.apply(max_norm)
 
 
+class FrameBatch:
+    """A batch given as frames of resident (N,2) streams: frame f = samples [f*stride, f*stride + T) (IQFrameDataset,
+    data_collector.py:239-247) — nothing is materialised, the fused kernels address the streams directly."""
+
+    def __init__(self, x_stream, y_stream, order, frame_length, stride=1):
+        self.x, self.y, self.order, self.T, self.stride = x_stream.contiguous(), y_stream.contiguous(), order.contiguous(), frame_length, stride
+        assert self.x.is_cuda and self.order.dtype == torch.int64
+        self.desc = _lib.Frames(self.x.data_ptr(), self.y.data_ptr(), self.order.data_ptr(), self.order.numel(), frame_length, stride)
+        self.shape = (self.order.numel(), frame_length, 2)
+        self.device = self.x.device
+
+
 def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_count=None, timing=None):
-    """One optimiser step (train_funcs.py:33-44) on device tensors x, target of shape (B,T,2).
-    Returns the loss as a 0-dim device tensor (no host sync).  `global_count` = number of target
-    elements of the GLOBAL batch when x is this rank's shard (default: this batch)."""
+    """One optimiser step (train_funcs.py:33-44) on device tensors x, target of shape (B,T,2) — or on a `FrameBatch`
+    passed as `x` (target ignored).  Returns the loss as a 0-dim device tensor (no host sync).  `global_count` =
+    number of target elements of the GLOBAL batch when x is this rank's shard (default: this batch)."""
     lib = _lib.load()
     bb = opt.backbone
     B, T = x.shape[0], x.shape[1]
     n = B * T * 2
     count = int(global_count or n)
+    framed = isinstance(x, FrameBatch)
     if opt.pa is not None or not opt.has_fused(B, T):
+        if framed:
+            raise RuntimeError("FrameBatch input needs a single backbone with a fused kernel (GRU family)")
         return _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count)
     part = opt.partials(B, T, x.device)
     ws = opt.train_workspace(B, T, x.device)
@@ -230,8 +245,12 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     st = _lib.stream_ptr()
     if timing is not None:
         timing[0].record()
-    rc = lib.odpd_train_fwd_bwd(st, C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], B, T, count,
-                                _lib.ptr(flat), _lib.ptr(x), _lib.ptr(target), _lib.ptr(part), _lib.ptr(ws))
+    if framed:
+        rc = lib.odpd_train_fwd_bwd_framed(st, C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], C.byref(x.desc), 0, B, count,
+                                           _lib.ptr(flat), _lib.ptr(part), _lib.ptr(ws))
+    else:
+        rc = lib.odpd_train_fwd_bwd(st, C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], B, T, count,
+                                    _lib.ptr(flat), _lib.ptr(x), _lib.ptr(target), _lib.ptr(part), _lib.ptr(ws))
     if timing is not None:
         timing[1].record()
     if rc:
