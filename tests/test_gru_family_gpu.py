@@ -222,3 +222,30 @@ def test_fused_step_is_bit_repeatable():
             fused_train_step(opt, x, t, "l2", 200.0)
         outs.append(net.backbone.flat_params().clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("bb,H,B,T,stride", [("dgru", 13, 300, 64, 1), ("gru", 23, 50, 33, 3), ("qgru", 10, 7, 200, 2)])
+def test_fused_step_on_frames_addressed_in_place(bb, H, B, T, stride):
+    """FrameBatch (frames = windows of resident streams, odpd_train_fwd_bwd_framed) == the same frames materialised as
+    (B,T,2) tensors: bit-identical parameters after three steps."""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FrameBatch, FusedAdamW, fused_train_step
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n = (B + 40) * stride + T
+    xs = (torch.rand(n, 2, device="cuda", generator=g) - 0.5) * 1.6
+    xs = xs + 0.05 * torch.sign(xs)
+    ys = torch.randn(n, 2, device="cuda", generator=g) * 0.3
+    order = torch.randperm(B + 40, device="cuda", generator=g)[:B].contiguous()
+    idx = (order * stride)[:, None] + torch.arange(T, device="cuda")[None, :]
+    outs = []
+    for framed in (True, False):
+        torch.manual_seed(2)
+        net = CoreModel(2, H, 1, bb).cuda()
+        opt = FusedAdamW(net, lr=1e-3)
+        for _ in range(3):
+            if framed:
+                loss = fused_train_step(opt, FrameBatch(xs, ys, order, T, stride), None, "l2", 200.0)
+            else:
+                loss = fused_train_step(opt, xs[idx].contiguous(), ys[idx].contiguous(), "l2", 200.0)
+        outs.append((net.backbone.flat_params().clone(), float(loss)))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
