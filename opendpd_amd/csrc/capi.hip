@@ -103,7 +103,9 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     switch (family_of(m)) {
     case FAM_GRU: return gru_family_rows(m, B, fused ? 1 : 0, T);
-    case FAM_LSTM: return fused ? (int64_t)ODPD_EUNSUPPORTED : lstm_family_rows(m, B);
+    case FAM_LSTM:
+        if (fused) return lstm_train_uses_s16(m, B) ? (int64_t)lstm_s16_rows(m, B) : (int64_t)ODPD_EUNSUPPORTED;
+        return lstm_family_rows(m, B);
     case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B);
     case FAM_JANET: return fused ? (int64_t)ODPD_EUNSUPPORTED : janet_family_rows(m, B);
     case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
@@ -114,6 +116,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
 
 extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
+    if (family_of(m) == FAM_LSTM) return lstm_train_uses_s16(m, B) ? lstm_s16_workspace_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
     if (gru_uses_s16n(m, B)) return gru_s16n_ckpt_floats(m, B, T);
     return gru_train_uses_s16(m, B, T) ? gru_s16_workspace_floats(m, B, T) : 0;
@@ -173,6 +176,8 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
         if (gru_uses_s16n(m, B)) return gru_s16n_launch((hipStream_t)stream, m, a, 0);
         return gru_train_uses_s16(m, B, T) ? gru_s16_train((hipStream_t)stream, m, a)
                                            : gru_family_train((hipStream_t)stream, m, a);
+    case FAM_LSTM:
+        return lstm_train_uses_s16(m, B) ? lstm_s16_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     default: return ODPD_EUNSUPPORTED;
     }
 }

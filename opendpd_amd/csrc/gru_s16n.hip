@@ -85,21 +85,6 @@ __device__ __forceinline__ void s16n_fill_table(float* tab, const float* pl, con
     __syncthreads();
 }
 
-// acc[mt] += sum_{kt, c} T[base + mt*NT + kt][c] (x) v[kt][c]    — one streamed ds_read_b128 per (mt, kt)
-template <int NT>
-__device__ __forceinline__ void s16n_matvec(TabPtr tl, int base, const f32x4 (&v)[NT], f32x4 (&acc)[NT]) {
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-            const float4 w = tab_ld(tl, (base + mt * NT + kt) * 64);
-            acc[mt] = mfma4(w.x, v[kt][0], acc[mt]);
-            acc[mt] = mfma4(w.y, v[kt][1], acc[mt]);
-            acc[mt] = mfma4(w.z, v[kt][2], acc[mt]);
-            acc[mt] = mfma4(w.w, v[kt][3], acc[mt]);
-        }
-}
-
 template <int FM, bool DG, int NT>
 __device__ __forceinline__ void s16n_cell_fwd(TabPtr tl, const float (&fs)[S16Cfg<FM>::NCH], f32x4 (&h)[NT], f32x4 (&r)[NT],
                                               f32x4 (&z)[NT], f32x4 (&n)[NT], f32x4 (&g)[NT]) {

@@ -11,30 +11,6 @@
 
 namespace odpd {
 
-struct LstmLayout {
-    int H, F, vd;
-    int o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_l1, o_b_l1, o_w_l2, o_b_l2, o_w_out, o_b_out, P;
-};
-__host__ __device__ inline LstmLayout lstm_layout(int H, int vd) {
-    LstmLayout L;
-    L.H = H; L.vd = vd; L.F = vd ? 4 : 2;
-    int o = 0;
-    L.o_w_ih = o; o += 4 * H * L.F;
-    L.o_w_hh = o; o += 4 * H * H;
-    L.o_b_ih = o; o += 4 * H;
-    L.o_b_hh = o; o += 4 * H;
-    L.o_w_l1 = L.o_b_l1 = L.o_w_l2 = L.o_b_l2 = 0;
-    if (vd) {
-        L.o_w_l1 = o; o += 4 * H; L.o_b_l1 = o; o += 4;
-        L.o_w_l2 = o; o += 4 * H; L.o_b_l2 = o; o += 4;
-        L.o_w_out = o; o += 16; L.o_b_out = o; o += 2;
-    } else {
-        L.o_w_out = o; o += 2 * H; L.o_b_out = o; o += 2;
-    }
-    L.P = o;
-    return L;
-}
-
 // table rows: kHH = g*R + rb (g = 0..3), kHHT = 4R + g*R + rb
 template <int R> struct LstmTabs {
     static constexpr int kHH = 0, kHHT = 4 * R, kRows = 8 * R, kFloats = kRows * 4 * 64 * 4;

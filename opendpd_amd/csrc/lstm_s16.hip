@@ -1,0 +1,574 @@
+// lstm_s16.hip — S16 fused train kernel (forward + loss + BPTT in one launch) of the nn.LSTM based backbones
+//   lstm    backbones/lstm.py:4-48     y = fc_out(LSTM(x)), (h,c) start at 0
+//   vdlstm  backbones/vdlstm.py:5-111  input = |x| over a 4-sample window with circular left padding, lambda heads
+// for batches large enough to fill the chip with 16-sequence wavefronts (train_funcs.py:33-39 for one backbone).
+// Mapping and machinery as in gru_s16n.hip: lane (n = sequence, q = unit quad) owns units 16kt + 4q + i of NT tiles; the
+// four gate mat-vecs are NT x NT tiles of exact-fp32 MFMA with the A operands streamed from an LDS table; the i, f, o
+// rows are stored pre-multiplied by -log2(e); weight gradients through per-step LDS transposes; (h, c) checkpoints
+// every kCkptStride steps in an HBM workspace ([task][ckpt][2 NT][lane] float4).  One wave per SIMD.
+// VDLSTM head: the eight lambda outputs are rows 0..7 of one more MFMA group (lanes q = 0 hold l1[0..3], q = 1 hold
+// l2[0..3]); the window trigonometry is per-sequence work replicated on the sequence's four lanes.
+// The split forward / backward entry points keep the row-rotated kernels (lstm_family.hip).
+#include "odpd_s16.h"
+
+namespace odpd {
+
+template <bool VD, int NT>
+struct L16 {
+    static constexpr int F = VD ? 4 : 2, NCH = (F + 4) / 4;
+    static constexpr int HH = 0;                       // (g*NT + mt)*NT + kt, g = i,f,g,o : W_hg[16mt+m][16kt+4q+e]
+    static constexpr int IH = HH + 4 * NT * NT;        // g*NT + mt : slot 4e+q of [W_ig | b_ig + b_hg]
+    static constexpr int HHT = IH + 4 * NT;            // (g*NT + mt)*NT + kt : W_hg[16kt+4q+e][16mt+m]
+    static constexpr int WOUT = HHT + 4 * NT * NT;     // plain: cc*NT + mt : fc_out[cc][16mt+4q+e]
+    static constexpr int BOUT = WOUT + 2 * NT;         // (b_out[0], b_out[1], 0, 0)
+    static constexpr int WL = BOUT + 1;                // VD: kt : m < 8 ? (m < 4 ? fc_lambda_1 : fc_lambda_2)[m & 3][16kt+4q+e]
+    static constexpr int WLT = WL + NT;                // VD: mt : q < 2 ? (q ? fc_lambda_2 : fc_lambda_1)[e][16mt+m]
+    static constexpr int BL = WLT + NT;                // VD: q < 2 ? (q ? b_l2 : b_l1)[e]
+    static constexpr int WO = BL + 1;                  // VD: cc : q < 2 ? fc_out[cc][4q+e]
+    static constexpr int NG = WO + 2;
+    static constexpr int kTiles = 5 * NT + 2;          // dpi dpf dpg dpo hp per unit tile + lambda-gradient tile + feature tile
+    static constexpr int kXFloats = 2 * 16 * (VD ? (kChunk + 3 + 2) : kChunkPad);   // one staged stream of float2
+};
+
+template <bool VD, int NT>
+__device__ __forceinline__ float4 l16_entry(const float* pl, const LstmLayout& L, int grp, int m, int q) {
+    using T = L16<VD, NT>;
+    const int H = L.H, F = T::F;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (grp < T::IH) {
+            const int g = grp / (NT * NT), mt = (grp / NT) % NT, kt = grp % NT, o = 16 * mt + m, k = 16 * kt + 4 * q + e;
+            v[e] = (o < H && k < H) ? pl[L.o_w_hh + (g * H + o) * H + k] * (g == 2 ? 1.0f : kNegLog2e) : 0.0f;
+        } else if (grp < T::HHT) {
+            const int g = (grp - T::IH) / NT, o = 16 * ((grp - T::IH) % NT) + m, k = 4 * e + q;
+            float w = 0.0f;
+            if (e < T::NCH && o < H) {
+                if (k < F) w = pl[L.o_w_ih + (g * H + o) * F + k];
+                else if (k == F) w = pl[L.o_b_ih + g * H + o] + pl[L.o_b_hh + g * H + o];
+            }
+            v[e] = w * (g == 2 ? 1.0f : kNegLog2e);
+        } else if (grp < T::WOUT) {
+            const int r = grp - T::HHT, g = r / (NT * NT), mt = (r / NT) % NT, kt = r % NT, i = 16 * mt + m, k = 16 * kt + 4 * q + e;
+            v[e] = (i < H && k < H) ? pl[L.o_w_hh + (g * H + k) * H + i] : 0.0f;
+        } else if (grp < T::BOUT) {
+            const int r = grp - T::WOUT, u = 16 * (r % NT) + 4 * q + e;
+            v[e] = (!VD && u < H) ? pl[L.o_w_out + (r / NT) * H + u] : 0.0f;
+        } else if (grp == T::BOUT) {
+            v[e] = e < 2 ? pl[L.o_b_out + e] : 0.0f;
+        } else if (grp < T::WLT) {
+            const int k = 16 * (grp - T::WL) + 4 * q + e;
+            v[e] = (VD && m < 8 && k < H) ? pl[(m < 4 ? L.o_w_l1 : L.o_w_l2) + (m & 3) * H + k] : 0.0f;
+        } else if (grp < T::BL) {
+            const int i = 16 * (grp - T::WLT) + m;
+            v[e] = (VD && q < 2 && i < H) ? pl[(q ? L.o_w_l2 : L.o_w_l1) + e * H + i] : 0.0f;
+        } else if (grp == T::BL) {
+            v[e] = (VD && q < 2) ? pl[(q ? L.o_b_l2 : L.o_b_l1) + e] : 0.0f;
+        } else {
+            v[e] = (VD && q < 2) ? pl[L.o_w_out + (grp - T::WO) * 8 + 4 * q + e] : 0.0f;
+        }
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// window of the VDLSTM input at one step (slot k <-> sample t-3+k)
+struct L16Win { float a[4], cw[4], sw[4]; };
+__device__ __forceinline__ void l16_elem(float2 xv, float& a, float& cw, float& sw) {
+    a = __builtin_amdgcn_sqrtf(__builtin_fmaf(xv.x, xv.x, xv.y * xv.y));
+    const float ia = fast_rcp(a);
+    cw = xv.x * ia; sw = xv.y * ia;
+}
+// feature slots of the lane: plain [I, Q, 1]; VD [a0, a1, a2, a3 | 1, 0, 0, 0]
+template <bool VD>
+__device__ __forceinline__ void l16_slots(float2 xv, const L16Win& win, const float (&oh)[4], float (&fs)[VD ? 2 : 1]) {
+    if constexpr (VD) {
+        fs[0] = __builtin_fmaf(oh[0], win.a[0], __builtin_fmaf(oh[1], win.a[1], __builtin_fmaf(oh[2], win.a[2], oh[3] * win.a[3])));
+        fs[1] = oh[0];
+    } else {
+        fs[0] = __builtin_fmaf(oh[0], xv.x, __builtin_fmaf(oh[1], xv.y, oh[2]));
+    }
+}
+
+template <bool VD, int NT>
+__device__ __forceinline__ void l16_cell_fwd(TabPtr tl, const float (&fs)[VD ? 2 : 1], f32x4 (&h)[NT], f32x4 (&c)[NT],
+                                             f32x4 (&gi)[NT], f32x4 (&gf)[NT], f32x4 (&gg)[NT], f32x4 (&go)[NT]) {
+    using T = L16<VD, NT>;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const float4 w = tab_ld(tl, (T::IH + g * NT + mt) * 64);
+            acc[g][mt] = mfma4(w.x, fs[0], zero);
+            if constexpr (VD) acc[g][mt] = mfma4(w.y, fs[1], acc[g][mt]);
+        }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s16n_matvec<NT>(tl, T::HH + g * NT * NT, h, acc[g]);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        gi[mt] = sigmoid4_prescaled(acc[0][mt]);
+        gf[mt] = sigmoid4_prescaled(acc[1][mt]);
+        gg[mt] = tanh4(acc[2][mt]);
+        go[mt] = sigmoid4_prescaled(acc[3][mt]);
+        c[mt] = fma4(gf[mt], c[mt], mul4(gi[mt], gg[mt]));
+        h[mt] = mul4(go[mt], tanh4(c[mt]));
+    }
+}
+
+template <bool VD, int NT>
+struct L16Grad {
+    f32x4 thh[4][NT][NT], tih[4][NT];
+    f32x4 dwout[2][NT];              // plain head
+    f32x4 tl[NT], dbl, dwo[2];       // VD: d fc_lambda weights (tile rows 0..7), their biases, d fc_out (2x8, on quads 0/1)
+    float dbo[2];
+    __device__ __forceinline__ void zero() {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            dwout[0][a] = z4; dwout[1][a] = z4; tl[a] = z4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                tih[g][a] = z4;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) thh[g][a][b] = z4;
+            }
+        }
+        dbl = z4; dwo[0] = z4; dwo[1] = z4; dbo[0] = dbo[1] = 0.f;
+    }
+};
+
+// xr: staged x of this lane's sequence; VD: xr[-3..-1] is the halo (circular for the first chunk)
+template <bool VD, int NT, bool FULL>
+__device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const float (&oh)[4], L16Grad<VD, NT>& G, const float2* xr,
+                                          const float2* tr, float* tiles, int n, int q, int tloc, int nstep, bool valid,
+                                          bool last_blk, const f32x4 (&h0)[NT], const f32x4 (&c0)[NT], f32x4 (&dh)[NT],
+                                          f32x4 (&dc)[NT], float (&hTn)[NT][4], float& loss_acc) {
+    using T = L16<VD, NT>;
+    constexpr int NCH = T::NCH, S = kCkptStride;
+    f32x4 h[NT], c[NT], hp_s[S][NT], cp_s[S][NT], i_s[S][NT], f_s[S][NT], g_s[S][NT], o_s[S][NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) { h[kt] = h0[kt]; c[kt] = c0[kt]; }
+    TabPtr tl = opaque(tl0);
+    {
+        L16Win win;
+        if constexpr (VD) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) l16_elem(xr[tloc + k - 3], win.a[k + 1], win.cw[k + 1], win.sw[k + 1]);
+        }
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            if (FULL || st < nstep) {
+                const float2 xv = xr[tloc + st];
+                if constexpr (VD) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) win.a[k] = win.a[k + 1];
+                    float cw_, sw_;
+                    l16_elem(xv, win.a[3], cw_, sw_);
+                }
+                float fs[NCH];
+                l16_slots<VD>(xv, win, oh, fs);
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) { hp_s[st][kt] = h[kt]; cp_s[st][kt] = c[kt]; }
+                l16_cell_fwd<VD, NT>(tl, fs, h, c, i_s[st], f_s[st], g_s[st], o_s[st]);
+            }
+        }
+    }
+    tl = opaque(tl0);
+    auto tile = [tiles](int qty, int kt) { return tiles + (qty * NT + kt) * kTileFloats; };   // qty: 0 dpi 1 dpf 2 dpg 3 dpo 4 hp
+    float* t_l = tiles + 5 * NT * kTileFloats;          // VD: lambda gradients (rows 0..7)
+    float* t_f = t_l + kTileFloats;
+    if (VD && last_blk) {   // transposed final state: operand of the last step's d fc_lambda
+        wave_lds_fence();
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) tile_put(tile(4, kt), n, q, h[kt]);
+        wave_lds_fence();
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) tile_get(tile(4, kt), n, q, hTn[kt]);
+    }
+    const bool l2 = a.loss_kind == ODPD_LOSS_L2;
+    const float sc = valid ? a.inv_count : 0.0f;
+    const float4 bo = tab_ld(tl, T::BOUT * 64);
+#pragma unroll
+    for (int st = S - 1; st >= 0; --st) {
+        if (FULL || st < nstep) {
+            const int tt = tloc + st;
+            const float2 xv = xr[tt];
+            L16Win win;
+            if constexpr (VD) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) l16_elem(xr[tt + k - 3], win.a[k], win.cw[k], win.sw[k]);
+            }
+            float fs[NCH];
+            l16_slots<VD>(xv, win, oh, fs);
+            f32x4 tc[NT], ht[NT];
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                tc[mt] = tanh4(fma4(f_s[st][mt], cp_s[st][mt], mul4(i_s[st][mt], g_s[st][mt])));
+                ht[mt] = mul4(o_s[st][mt], tc[mt]);
+            }
+            // ---- head forward, loss, dL/dy ----
+            float p0 = 0.0f, p1 = 0.0f;
+            f32x4 lam = {0.f, 0.f, 0.f, 0.f}, trig = lam, wo0 = lam, wo1 = lam;
+            if constexpr (VD) {
+                lam = as_f32x4(tab_ld(tl, T::BL * 64));
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    const float4 w = tab_ld(tl, (T::WL + kt) * 64);
+                    lam = mfma4(w.x, ht[kt][0], lam); lam = mfma4(w.y, ht[kt][1], lam);
+                    lam = mfma4(w.z, ht[kt][2], lam); lam = mfma4(w.w, ht[kt][3], lam);
+                }
+                ODPD_EACH4 trig[i] = __builtin_fmaf(oh[0], win.cw[i], oh[1] * win.sw[i]);
+                wo0 = as_f32x4(tab_ld(tl, (T::WO + 0) * 64));
+                wo1 = as_f32x4(tab_ld(tl, (T::WO + 1) * 64));
+                ODPD_EACH4 { const float zl = trig[i] * lam[i]; p0 = __builtin_fmaf(wo0[i], zl, p0); p1 = __builtin_fmaf(wo1[i], zl, p1); }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) {
+                    const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
+                    ODPD_EACH4 p0 = __builtin_fmaf(w0[i], ht[mt][i], p0);
+                    ODPD_EACH4 p1 = __builtin_fmaf(w1[i], ht[mt][i], p1);
+                }
+            }
+            const float y0 = quad_sum(p0) + bo.x, y1 = quad_sum(p1) + bo.y;
+            const float2 tv = tr[n * kChunkPad + tt];
+            const float d0 = y0 - tv.x, d1 = y1 - tv.y;
+            const float s0 = d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f), s1 = d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
+            const float dy0 = l2 ? 2.0f * sc * d0 : s0, dy1 = l2 ? 2.0f * sc * d1 : s1;
+            const float lv = l2 ? __builtin_fmaf(d0, d0, d1 * d1) : __builtin_fabsf(d0) + __builtin_fabsf(d1);
+            loss_acc += (valid && q == 0) ? lv : 0.0f;
+            G.dbo[0] += q == 0 ? dy0 : 0.0f;
+            G.dbo[1] += q == 0 ? dy1 : 0.0f;
+            // ---- head backward -> dht ----
+            f32x4 dht[NT], dl = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (VD) {
+                ODPD_EACH4 {
+                    const float zl = trig[i] * lam[i];
+                    G.dwo[0][i] = __builtin_fmaf(dy0, zl, G.dwo[0][i]);
+                    G.dwo[1][i] = __builtin_fmaf(dy1, zl, G.dwo[1][i]);
+                    dl[i] = __builtin_fmaf(dy0, wo0[i], dy1 * wo1[i]) * trig[i];
+                }
+                G.dbl = add4(G.dbl, dl);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) {
+                    const float4 w = tab_ld(tl, (T::WLT + mt) * 64);
+                    dht[mt] = dh[mt];
+                    dht[mt] = mfma4(w.x, dl[0], dht[mt]); dht[mt] = mfma4(w.y, dl[1], dht[mt]);
+                    dht[mt] = mfma4(w.z, dl[2], dht[mt]); dht[mt] = mfma4(w.w, dl[3], dht[mt]);
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) {
+                    const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
+                    G.dwout[0][mt] = fma4(splat4(dy0), ht[mt], G.dwout[0][mt]);
+                    G.dwout[1][mt] = fma4(splat4(dy1), ht[mt], G.dwout[1][mt]);
+                    dht[mt] = add4(dh[mt], fma4(splat4(dy0), w0, mul4(w1, splat4(dy1))));
+                }
+            }
+            // ---- cell backward ----
+            f32x4 dp[4][NT], acc[NT];
+            const f32x4 one = splat4(1.0f);
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                const f32x4 gi = i_s[st][mt], gf = f_s[st][mt], gg = g_s[st][mt], go = o_s[st][mt];
+                f32x4 omt2;
+                ODPD_EACH4 omt2[i] = __builtin_fmaf(-tc[mt][i], tc[mt][i], 1.0f);
+                const f32x4 dO = mul4(dht[mt], tc[mt]);
+                const f32x4 dct = fma4(mul4(dht[mt], go), omt2, dc[mt]);
+                f32x4 omg2;
+                ODPD_EACH4 omg2[i] = __builtin_fmaf(-gg[i], gg[i], 1.0f);
+                dp[0][mt] = mul4(mul4(dct, gg), mul4(gi, sub4(one, gi)));
+                dp[1][mt] = mul4(mul4(dct, cp_s[st][mt]), mul4(gf, sub4(one, gf)));
+                dp[2][mt] = mul4(mul4(dct, gi), omg2);
+                dp[3][mt] = mul4(dO, mul4(go, sub4(one, go)));
+                dc[mt] = mul4(dct, gf);
+                acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s16n_matvec<NT>(tl, T::HHT + g * NT * NT, dp[g], acc);
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) dh[mt] = acc[mt];
+            // ---- weight gradients: transposes through LDS, rank-16 MFMA updates ----
+            wave_lds_fence();
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) tile_put(tile(g, kt), n, q, dp[g][kt]);
+                tile_put(tile(4, kt), n, q, hp_s[st][kt]);
+            }
+            if constexpr (VD) tile_put(t_l, n, q, dl);
+#pragma unroll
+            for (int cch = 0; cch < NCH; ++cch) t_f[n * kTilePitch + 4 * cch + q] = fs[cch];
+            wave_lds_fence();
+            float fT[4], hT[NT][4], lT[4];
+            tile_get(t_f, n, q, fT);
+            if constexpr (VD) tile_get(t_l, n, q, lT);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) tile_get(tile(4, kt), n, q, hT[kt]);
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float dT[4];
+                    tile_get(tile(g, mt), n, q, dT);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        G.tih[g][mt] = mfma4(dT[cc], fT[cc], G.tih[g][mt]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) G.thh[g][mt][nt] = mfma4(dT[cc], hT[nt][cc], G.thh[g][mt][nt]);
+                    }
+                }
+                if constexpr (VD) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) G.tl[mt] = mfma4(lT[cc], hTn[mt][cc], G.tl[mt]);   // rows = lambda outputs, cols = units of tile mt
+                }
+            }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) hTn[kt][cc] = hT[kt][cc];
+        }
+    }
+}
+
+template <bool VD, int NT>
+__device__ __forceinline__ void l16_write_row(float* prow, const LstmLayout& L, L16Grad<VD, NT>& G, int n, int q, float loss_acc) {
+    constexpr int F = L16<VD, NT>::F;
+    const int H = L.H;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 16 * mt + 4 * q + rr;
+            if (i < H) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float v = G.tih[g][mt][rr];
+                    if (n < F) prow[L.o_w_ih + (g * H + i) * F + n] = v;
+                    else if (n == F) { prow[L.o_b_ih + g * H + i] = v; prow[L.o_b_hh + g * H + i] = v; }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        if (16 * nt + n < H) prow[L.o_w_hh + (g * H + i) * H + 16 * nt + n] = G.thh[g][mt][nt][rr];
+                }
+            }
+            if constexpr (!VD) {
+                const float w0 = row_sum16(G.dwout[0][mt][rr]), w1 = row_sum16(G.dwout[1][mt][rr]);
+                if (n == 0 && i < H) { prow[L.o_w_out + i] = w0; prow[L.o_w_out + H + i] = w1; }
+            } else {
+                // lambda weight tile: lane (n, q) holds rows 4q+rr (0..3 fc_lambda_1, 4..7 fc_lambda_2), column = unit 16mt + n
+                const int row = 4 * q + rr, u = 16 * mt + n;
+                if (row < 8 && u < H) prow[(row < 4 ? L.o_w_l1 : L.o_w_l2) + (row & 3) * H + u] = G.tl[mt][rr];
+            }
+        }
+    if constexpr (VD) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const float b = row_sum16(G.dbl[rr]), w0 = row_sum16(G.dwo[0][rr]), w1 = row_sum16(G.dwo[1][rr]);
+            if (n == 0 && q < 2) {
+                prow[(q ? L.o_b_l2 : L.o_b_l1) + rr] = b;
+                prow[L.o_w_out + 4 * q + rr] = w0;
+                prow[L.o_w_out + 8 + 4 * q + rr] = w1;
+            }
+        }
+    }
+    const float b0 = row_sum16(G.dbo[0]), b1 = row_sum16(G.dbo[1]), lp = row_sum16(loss_acc);
+    if (n == 0 && q == 0) {
+        prow[L.o_b_out] = b0; prow[L.o_b_out + 1] = b1;
+        prow[L.P] = lp; prow[L.P + 1] = 0.f; prow[L.P + 2] = 0.f; prow[L.P + 3] = 0.f;
+    }
+}
+
+// circular-halo staging of x for 16 sequences (VDLSTM): xs[seq][0..2] = samples t0-3..t0-1 (wrapping to the frame's end)
+constexpr int kL16HaloStride = kChunk + 3 + 2;
+__device__ __forceinline__ void l16_stage_halo(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane) {
+    const float2* g2 = reinterpret_cast<const float2*>(g);
+    constexpr int PER = kChunk + 3, TOT = 16 * PER, N = (TOT + 63) / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j;
+        if (e < TOT) {
+            const int m = e / PER, pos = e % PER;
+            int tg = t0 - 3 + pos;
+            if (tg < 0) tg += T;
+            float2 v = make_float2(0.5f, 0.5f);
+            if (pos < len + 3 && b0 + m < B && tg < T) v = g2[(size_t)(b0 + m) * T + tg];
+            lds[m * kL16HaloStride + pos] = v;
+        }
+    }
+}
+
+template <bool VD, int NT>
+__global__ __launch_bounds__(256, 1) void lstm16_train_kernel(SeqArgs a) {
+    using T = L16<VD, NT>;
+    constexpr int NCH = T::NCH, S = kCkptStride;
+    constexpr int kWave = T::kXFloats + 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const LstmLayout L = lstm_layout(a.H, VD);
+    float* tab = smem;
+    float* pl = tab + s16_tab_floats(T::NG);
+    stage_params(pl, a.params, L.P);
+    {
+        float4* t4 = reinterpret_cast<float4*>(tab);
+        for (int grp = wave; grp < T::NG; grp += nwb) t4[grp * 64 + lane] = l16_entry<VD, NT>(pl, L, grp, n, q);
+        __syncthreads();
+    }
+    const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* ts = reinterpret_cast<float2*>(wbase + T::kXFloats);
+    float* tiles = wbase + T::kXFloats + 2 * 16 * kChunkPad;
+    for (int i = lane; i < kTileFloats; i += 64) { tiles[(5 * NT + 1) * kTileFloats + i] = 0.0f; tiles[5 * NT * kTileFloats + i] = 0.0f; }
+    const float2* xr = VD ? xs + n * kL16HaloStride + 3 : xs + n * kChunkPad;
+    L16Grad<VD, NT> G;
+    G.zero();
+    float loss_acc = 0.0f;
+    const int nwaves = gridDim.x * nwb;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        const bool valid = b0 + n < a.B;
+        float4* ck = reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * 2 * NT * 64 + lane;   // [ckpt][h tiles | c tiles][lane]
+        auto stage_x = [&](int t0, int len) {
+            if constexpr (VD) l16_stage_halo(xs, a.x, b0, a.B, a.T, t0, len, lane);
+            else stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+        };
+        // ---- forward: cell only ----
+        {
+            f32x4 h[NT], c[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) { h[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; c[kt] = h[kt]; }
+            for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+                const int len = min(kChunk, a.T - t0);
+                wave_lds_fence();
+                stage_x(t0, len);
+                wave_lds_fence();
+                L16Win win;
+                if constexpr (VD) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) l16_elem(xr[k - 3], win.a[k + 1], win.cw[k + 1], win.sw[k + 1]);
+                }
+                for (int tt = 0; tt < len; ++tt) {
+                    const float2 xv = xr[tt];
+                    if constexpr (VD) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) win.a[k] = win.a[k + 1];
+                        float cw_, sw_;
+                        l16_elem(xv, win.a[3], cw_, sw_);
+                    }
+                    float fs[NCH];
+                    l16_slots<VD>(xv, win, oh, fs);
+                    f32x4 gi[NT], gf[NT], gg[NT], go[NT];
+                    l16_cell_fwd<VD, NT>(opaque(tl), fs, h, c, gi, gf, gg, go);
+                    const int t1 = t0 + tt + 1;
+                    if ((t1 % S) == 0 && t1 < a.T) {
+#pragma unroll
+                        for (int kt = 0; kt < NT; ++kt) {
+                            ck[((size_t)(t1 / S) * 2 * NT + kt) * 64] = make_float4(h[kt][0], h[kt][1], h[kt][2], h[kt][3]);
+                            ck[((size_t)(t1 / S) * 2 * NT + NT + kt) * 64] = make_float4(c[kt][0], c[kt][1], c[kt][2], c[kt][3]);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // ---- backward ----
+        f32x4 dh[NT], dc[NT];
+        float hTn[NT][4];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            dh[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dc[kt] = dh[kt];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) hTn[kt][cc] = 0.0f;
+        }
+        int cur_chunk = -1;
+        for (int blk = a.nck - 1; blk >= 0; --blk) {
+            const int tb = blk * S, nstep = min(S, a.T - tb);
+            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            f32x4 h0[NT], c0[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                h0[kt] = as_f32x4(blk ? ck[((size_t)blk * 2 * NT + kt) * 64] : z);
+                c0[kt] = as_f32x4(blk ? ck[((size_t)blk * 2 * NT + NT + kt) * 64] : z);
+            }
+            if (chunk != cur_chunk) {
+                wave_lds_fence();
+                const int len = min(kChunk, a.T - t0);
+                stage_x(t0, len);
+                stage_in<16>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                wave_lds_fence();
+                cur_chunk = chunk;
+            }
+            if (nstep == S)
+                l16_block<VD, NT, true>(a, tl, oh, G, xr, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, c0, dh, dc, hTn, loss_acc);
+            else
+                l16_block<VD, NT, false>(a, tl, oh, G, xr, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, c0, dh, dc, hTn, loss_acc);
+        }
+    }
+    const int P4 = L.P + kLossCols;
+    __syncthreads();
+    l16_write_row<VD, NT>(smem + wave * P4, L, G, n, q, loss_acc);
+    __syncthreads();
+    float* prow = a.partials + (size_t)blockIdx.x * P4;
+    for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+        float v = smem[i];
+        for (int wv = 1; wv < nwb; ++wv) v += smem[wv * P4 + i];
+        prow[i] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+static LaunchShape l16_shape(int ngroups) {
+    LaunchShape ls;
+    ls.waves = 4;
+    const int need = (ngroups + 3) / 4, cap = device_cus();
+    ls.grid = need < cap ? need : cap;
+    return ls;
+}
+bool lstm_train_uses_s16(const odpd_model_t* m, int B) {
+    if ((m->backbone != ODPD_LSTM && m->backbone != ODPD_VDLSTM) || m->hidden > 32) return false;
+    long min_batch = tuning().s16_min_batch;
+    if (min_batch < 0) min_batch = (m->hidden <= 16 ? 16L : 8L) * 4 * device_cus();
+    return B >= min_batch;
+}
+int lstm_s16_rows(const odpd_model_t* m, int B) {
+    (void)m;
+    return l16_shape((B + 15) / 16).grid;
+}
+int64_t lstm_s16_workspace_floats(const odpd_model_t* m, int B, int T) {
+    return (int64_t)((B + 15) / 16) * num_ckpt(T) * 2 * ((m->hidden + 15) / 16) * 256;
+}
+template <bool VD, int NT>
+static int launch_l16(hipStream_t st, const SeqArgs& a, int P) {
+    using T = L16<VD, NT>;
+    const LaunchShape ls = l16_shape(a.ngroups);
+    const int wave_floats = T::kXFloats + 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
+    size_t body = (size_t)ls.waves * wave_floats;
+    if (body < (size_t)pad4(P)) body = pad4(P);
+    size_t lds = ((size_t)s16_tab_floats(T::NG) + body) * sizeof(float);
+    if (lds < reduce_scratch_bytes(P, ls.waves)) lds = reduce_scratch_bytes(P, ls.waves);
+    if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+    auto k = lstm16_train_kernel<VD, NT>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+int lstm_s16_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
+    if (!a0.ckpt) return ODPD_EINVAL;
+    const bool vd = m->backbone == ODPD_VDLSTM;
+    if (vd && a0.T < 3) return ODPD_EINVAL;
+    SeqArgs a = a0;
+    a.ngroups = (a.B + 15) / 16;
+    const int P = lstm_layout(m->hidden, vd).P, nt = (m->hidden + 15) / 16;
+    if (nt == 1) return vd ? launch_l16<true, 1>(st, a, P) : launch_l16<false, 1>(st, a, P);
+    if (nt == 2) return vd ? launch_l16<true, 2>(st, a, P) : launch_l16<false, 2>(st, a, P);
+    return ODPD_EUNSUPPORTED;
+}
+
+}  // namespace odpd

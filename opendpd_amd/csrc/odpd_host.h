@@ -77,6 +77,30 @@ __host__ __device__ inline GruLayout gru_layout(int H, int F, int dgru) {
     return L;
 }
 
+struct LstmLayout {
+    int H, F, vd;
+    int o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_l1, o_b_l1, o_w_l2, o_b_l2, o_w_out, o_b_out, P;
+};
+__host__ __device__ inline LstmLayout lstm_layout(int H, int vd) {
+    LstmLayout L;
+    L.H = H; L.vd = vd; L.F = vd ? 4 : 2;
+    int o = 0;
+    L.o_w_ih = o; o += 4 * H * L.F;
+    L.o_w_hh = o; o += 4 * H * H;
+    L.o_b_ih = o; o += 4 * H;
+    L.o_b_hh = o; o += 4 * H;
+    L.o_w_l1 = L.o_b_l1 = L.o_w_l2 = L.o_b_l2 = 0;
+    if (vd) {
+        L.o_w_l1 = o; o += 4 * H; L.o_b_l1 = o; o += 4;
+        L.o_w_l2 = o; o += 4 * H; L.o_b_l2 = o; o += 4;
+        L.o_w_out = o; o += 16; L.o_b_out = o; o += 2;
+    } else {
+        L.o_w_out = o; o += 2 * H; L.o_b_out = o; o += 2;
+    }
+    L.P = o;
+    return L;
+}
+
 // kernel arguments shared by the sequence kernels
 struct SeqArgs {
     const float* params;
@@ -124,6 +148,11 @@ int64_t gru_s16_workspace_floats(const odpd_model_t* m, int B, int T);
 int lstm_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_rows(const odpd_model_t* m, int B);
+// 16-sequences-per-wave fused train kernel of lstm / vdlstm (lstm_s16.hip)
+bool lstm_train_uses_s16(const odpd_model_t* m, int B);
+int lstm_s16_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int lstm_s16_rows(const odpd_model_t* m, int B);
+int64_t lstm_s16_workspace_floats(const odpd_model_t* m, int B, int T);
 int delta_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int delta_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int delta_family_rows(const odpd_model_t* m, int B);

@@ -111,3 +111,51 @@ def test_vdlstm_short_frame_is_refused_loudly():
     net = CoreModel(2, 8, 1, "vdlstm").cuda()
     with pytest.raises(RuntimeError):
         net(torch.rand(2, 2, 2, device="cuda"))
+
+
+# ---- S16 fused train kernel (csrc/lstm_s16.hip), forced for every batch size with the tuning knob ----------------
+@pytest.fixture
+def force_s16():
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    assert lib.odpd_set_tuning(b"s16_min_batch", 0) == 0
+    yield
+    lib.odpd_set_tuning(b"s16_min_batch", -1)
+
+
+@pytest.mark.parametrize("name,bb", [("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm")])
+def test_s16_fused_steps_follow_reference(force_s16, name, bb):
+    from opendpd_amd.train_funcs import FusedAdamW
+    fx = Fixture(name)
+    opt = FusedAdamW(_model(fx, bb), lr=fx.meta["lr"])
+    assert opt.has_fused(fx["x"].shape[0], fx["x"].shape[1])          # the single-launch kernel is the one that runs
+    test_train_steps_follow_reference(name, bb)
+
+
+@pytest.mark.parametrize("bb,H,B,T", [("lstm", 14, 256, 200), ("vdlstm", 13, 37, 50), ("lstm", 9, 1027, 64), ("vdlstm", 8, 3, 333),
+                                      ("vdlstm", 16, 17, 3), ("lstm", 23, 40, 70), ("vdlstm", 20, 33, 65), ("lstm", 1, 16, 4)])
+def test_s16_fused_equals_unfused_gradients(force_s16, bb, H, B, T):
+    """single-launch S16 step (L2 and L1) == autograd through the row-rotated split kernels (oracle-checked above)"""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    torch.manual_seed(1)
+    net = CoreModel(2, H, 1, bb).cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    t = torch.randn(B, T, 2, device="cuda", generator=g) * 0.3
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.has_fused(B, T)
+    for kind, fn in (("l2", torch.nn.functional.mse_loss), ("l1", torch.nn.functional.l1_loss)):
+        for p in net.parameters():
+            p.grad = None
+        loss = fn(net(x), t)
+        loss.backward()
+        gref = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+        lf = fused_train_step(opt, x, t, kind, 0.0)
+        assert abs(lf.item() - loss.item()) < 1e-5 * max(1.0, loss.item()), kind
+        assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 3e-5, kind
