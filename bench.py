@@ -141,6 +141,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # functional test of the N > 1 path on a single-GPU box (tools/dist_smoke.sh): every rank on device 0, gloo backend
+    backend = os.environ.get("ODPD_BENCH_BACKEND", "nccl")
+    if os.environ.get("ODPD_BENCH_SINGLE_DEVICE"):
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback in the product path)")
     torch.cuda.set_device(local)
@@ -149,7 +153,7 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         from opendpd_amd import dist as odist
-        odist.init("nccl", device=dev)     # one process per GPU, RCCL over xGMI
+        odist.init(backend, device=dev)     # one process per GPU, RCCL over xGMI ("nccl" is RCCL on ROCm)
         dist = dist_mod
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
 
