@@ -19,22 +19,6 @@
 
 namespace odpd {
 
-struct DeltaLayout { int H, tres, o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_tcn0, o_tcn2, P; };
-__host__ __device__ inline DeltaLayout delta_layout(int H, int tres) {
-    DeltaLayout L;
-    L.H = H; L.tres = tres;
-    int o = 0;
-    L.o_w_ih = o; o += 3 * H * 6;
-    L.o_w_hh = o; o += 3 * H * H;
-    L.o_b_ih = L.o_b_hh = L.o_b_out = L.o_tcn0 = L.o_tcn2 = 0;
-    if (!tres) { L.o_b_ih = o; o += 3 * H; L.o_b_hh = o; o += 3 * H; }
-    L.o_w_out = o; o += 2 * H;
-    if (!tres) { L.o_b_out = o; o += 2; }
-    else { L.o_tcn0 = o; o += 18; L.o_tcn2 = o; o += 6; }
-    L.P = o;
-    return L;
-}
-
 constexpr int kDHalo = 16;                                  // TCN taps at t-16, t, t+16
 constexpr int kDStride = kChunk + 2 * kDHalo + 1;           // float2 per sequence row
 constexpr int kDTabFloats = 6 * 4 * 64 * 4;                 // W_hh (3 rows) + W_hh^T (3 rows)
@@ -509,18 +493,21 @@ static int delta_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
 
 int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (delta_uses_s16(m, a.B)) return delta_s16_launch(st, m, a, 1);
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
     const int P = delta_layout(m->hidden, tres).P;
     return tres ? delta_launch_fwd<true>(st, a, P) : delta_launch_fwd<false>(st, a, P);
 }
 int delta_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (delta_uses_s16(m, a.B)) return delta_s16_launch(st, m, a, 2);
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
     const int P = delta_layout(m->hidden, tres).P;
     return tres ? delta_launch_bwd<true>(st, a, P) : delta_launch_bwd<false>(st, a, P);
 }
 int delta_family_rows(const odpd_model_t* m, int B) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (delta_uses_s16(m, B)) return delta_s16_rows(m, B);
     return delta_bwd_shape(num_groups(B, 1)).grid;
 }
 

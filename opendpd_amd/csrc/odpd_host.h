@@ -101,6 +101,22 @@ __host__ __device__ inline LstmLayout lstm_layout(int H, int vd) {
     return L;
 }
 
+struct DeltaLayout { int H, tres, o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_tcn0, o_tcn2, P; };
+__host__ __device__ inline DeltaLayout delta_layout(int H, int tres) {
+    DeltaLayout L;
+    L.H = H; L.tres = tres;
+    int o = 0;
+    L.o_w_ih = o; o += 3 * H * 6;
+    L.o_w_hh = o; o += 3 * H * H;
+    L.o_b_ih = L.o_b_hh = L.o_b_out = L.o_tcn0 = L.o_tcn2 = 0;
+    if (!tres) { L.o_b_ih = o; o += 3 * H; L.o_b_hh = o; o += 3 * H; }
+    L.o_w_out = o; o += 2 * H;
+    if (!tres) { L.o_b_out = o; o += 2; }
+    else { L.o_tcn0 = o; o += 18; L.o_tcn2 = o; o += 6; }
+    L.P = o;
+    return L;
+}
+
 // kernel arguments shared by the sequence kernels
 struct SeqArgs {
     const float* params;
@@ -156,6 +172,11 @@ int64_t lstm_s16_workspace_floats(const odpd_model_t* m, int B, int T);
 int delta_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int delta_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int delta_family_rows(const odpd_model_t* m, int B);
+// 16-sequences-per-wave split kernels of the delta backbones (delta_s16.hip): mode 1 forward, 2 backward
+bool delta_uses_s16(const odpd_model_t* m, int B);
+int delta_s16_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
+int delta_s16_rows(const odpd_model_t* m, int B);
+int64_t delta_s16_ckpt_floats(const odpd_model_t* m, int B, int T);
 int janet_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int janet_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int janet_family_rows(const odpd_model_t* m, int B);

@@ -111,6 +111,13 @@ __device__ __forceinline__ f32x4 tanh4(const f32x4& v) {
     return fma4(rcp4(e), splat4(-2.0f), splat4(1.0f));
 }
 
+// tanh with the row-rotated kernels' accuracy (polynomial below 0.3): used where a rounding-level difference could
+// flip a threshold decision (delta backbones)
+__device__ __forceinline__ f32x4 tanh4_precise(const f32x4& v) {
+    f32x4 r;
+    ODPD_EACH4 r[i] = tanhf_(v[i]);
+    return r;
+}
 // sum over the four quads of a sequence (lanes n, n+16, n+32, n+48); every lane gets the total
 __device__ __forceinline__ float quad_sum(float v) {
     v += swap16(v);

@@ -107,3 +107,41 @@ def test_dx_is_refused_loudly():
     x = torch.rand(2, 16, 2, device="cuda").requires_grad_(True)
     with pytest.raises(RuntimeError):
         net(x).sum().backward()
+
+
+# ---- S16 split kernels (csrc/delta_s16.hip), forced for every batch size with the tuning knob ------------------------
+@pytest.fixture
+def force_s16():
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    assert lib.odpd_set_tuning(b"s16_min_batch", 0) == 0
+    yield
+    lib.odpd_set_tuning(b"s16_min_batch", -1)
+
+
+@pytest.mark.parametrize("name,bb", CASES)
+def test_s16_golden_forward_backward_and_counters(force_s16, name, bb):
+    """S16 kernels on the golden inputs: outputs, gradients and — on the dense (threshold 0) fixtures and on these
+    thresholded inputs — the exact sparsity counters (the MFMA summation order differs from ATen's, so a decision
+    within rounding of a threshold could in principle flip; on the golden inputs none does)."""
+    test_golden_forward_backward_and_counters(name, bb)
+
+
+@pytest.mark.parametrize("bb,H,thx,thh", [("deltagru", 15, 0.0, 0.0), ("deltagru", 15, 0.01, 0.05), ("deltagru", 8, 0.02, 0.1),
+                                          ("deltagru_tcnskip", 15, 0.01, 0.05), ("deltagru_tcnskip", 16, 0.0, 0.0),
+                                          ("deltagru_tcnskip", 9, 0.05, 0.02)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (17, 32), (7, 33), (5, 200), (66, 63)])
+def test_s16_against_oracle_ragged(force_s16, bb, H, thx, thh, B, T):
+    test_against_oracle_ragged(bb, H, thx, thh, B, T)
+
+
+@pytest.mark.parametrize("name,bb", [("deltagru_h15_th", "deltagru"), ("tres_h15_th", "deltagru_tcnskip")])
+def test_s16_train_steps_follow_reference(force_s16, name, bb):
+    test_train_steps_follow_reference(name, bb)
+
+
+def test_s16_cascade_config3_follows_reference(force_s16):
+    """BASELINE config 3 with every kernel in the S16 mapping: TRes-DeltaGRU (delta_s16) -> frozen DGRU H23 (gru_s16n)"""
+    from tests import test_cascade_gpu as casc
+    casc.test_cascade_autograd_matches_reference("cascade_tres15_dgru23", "deltagru_tcnskip", "dgru")
+    casc.test_cascade_fused_steps_follow_reference("cascade_tres15_dgru23", "deltagru_tcnskip", "dgru")
