@@ -94,7 +94,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
         return gru_split_uses_s16(m, B) ? (int64_t)((B + 15) / 16) * num_ckpt(T) * 256 : (int64_t)num_groups(B, R) * num_ckpt(T) * 64;
     case FAM_LSTM: return (int64_t)num_groups(B, R) * num_ckpt(T) * 128;   // h and c
     case FAM_DELTA:
-        if (R == 1 && delta_uses_s16(m, B)) return delta_s16_ckpt_floats(m, B, T);
+        if (delta_uses_s16(m, B)) return delta_s16_ckpt_floats(m, B, T);
         return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 7 * 64 : (int64_t)ODPD_EUNSUPPORTED;
     case FAM_JANET: case FAM_QAT: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 64 : (int64_t)ODPD_EUNSUPPORTED;
     default: return ODPD_EUNSUPPORTED;

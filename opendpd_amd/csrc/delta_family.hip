@@ -492,22 +492,22 @@ static int delta_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
 }
 
 int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
-    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     if (delta_uses_s16(m, a.B)) return delta_s16_launch(st, m, a, 1);
+    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
     const int P = delta_layout(m->hidden, tres).P;
     return tres ? delta_launch_fwd<true>(st, a, P) : delta_launch_fwd<false>(st, a, P);
 }
 int delta_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
-    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     if (delta_uses_s16(m, a.B)) return delta_s16_launch(st, m, a, 2);
+    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
     const int P = delta_layout(m->hidden, tres).P;
     return tres ? delta_launch_bwd<true>(st, a, P) : delta_launch_bwd<false>(st, a, P);
 }
 int delta_family_rows(const odpd_model_t* m, int B) {
-    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     if (delta_uses_s16(m, B)) return delta_s16_rows(m, B);
+    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     return delta_bwd_shape(num_groups(B, 1)).grid;
 }
 

@@ -4,47 +4,54 @@
 // for batches large enough to fill the chip with 16-sequence wavefronts (the DPD side of the train_dpd cascade at large
 // batch, BASELINE config 3).  Arithmetic as in delta_family.hip (thresholded deltas, accumulators `dm`, memories x_p /
 // h_p, device sparsity counters, carried accumulator gradients in the backward pass); mapping as in gru_s16.hip: lane
-// (n = sequence, q = unit quad), hidden <= 16, mat-vecs on the exact-fp32 MFMA with operands streamed from an LDS
-// table — the masked deltas are the B operands, the accumulators are the in-place C/D operands (r, z rows stored
-// pre-multiplied by -log2(e)).  Feature deltas live on the feature slots (slot 4c+q on lane q of chunk c).
-// Checkpoint per kCkptStride steps: h, h_p, dm_r, dm_z, dm_n, dm_nh (float4 per lane) + the two x_p slots.
+// (n = sequence, q = unit quad) owning units 16kt + 4q + i of NT tiles (hidden <= 16 NT; NT = 2 also lifts the
+// 16-unit limit of the row-rotated delta kernels: hidden 17..32 runs here at every batch size), mat-vecs on the exact-fp32
+// MFMA with operands streamed from an LDS table — the masked deltas are the B operands, the accumulators are the
+// in-place C/D operands (r, z rows stored pre-multiplied by -log2(e)).  Feature deltas live on the feature slots (slot
+// 4c+q on lane q of chunk c).  Checkpoint per kCkptStride steps: h, h_p, dm_r, dm_z, dm_n, dm_nh (float4 per lane and
+// unit tile) + the two x_p slots.
 #include "odpd_s16.h"
 
 namespace odpd {
 
 namespace d16 {
-constexpr int IH = 0;      // g   : (chunk 0, chunk 1) W_ig[m][4e+q]
-constexpr int HH = 3;      // g   : W_hg[m][4q+e]
-constexpr int HHT = 6;     // g   : W_hg[4q+e][m]
-constexpr int WOUT = 9;    // cc  : fc_out[cc][4q+e]
-constexpr int DM0 = 11;    // j   : initial accumulators r, z, n, nh at unit 4q+e
-constexpr int NG = 15;
 constexpr int kHalo = 16;                                   // TCN taps at t-16, t, t+16
 constexpr int kStride = kChunk + 2 * kHalo + 1;             // float2 per sequence row of the staged x
-constexpr int kCk = 7;                                      // float4 per lane per checkpoint
-constexpr int kTiles = 6;                                   // gr gz gn gnh dhm + feature-delta tile
 }  // namespace d16
+// table groups and sizes for NT tiles of 16 hidden units (hidden <= 16 NT)
+template <int NT>
+struct D16 {
+    static constexpr int IH = 0;                       // g*NT + mt           : (chunk 0, chunk 1) W_ig[16mt+m][4e+q]
+    static constexpr int HH = IH + 3 * NT;             // (g*NT + mt)*NT + kt : W_hg[16mt+m][16kt+4q+e]
+    static constexpr int HHT = HH + 3 * NT * NT;       // (g*NT + mt)*NT + kt : W_hg[16kt+4q+e][16mt+m]
+    static constexpr int WOUT = HHT + 3 * NT * NT;     // cc*NT + mt          : fc_out[cc][16mt+4q+e]
+    static constexpr int DM0 = WOUT + 2 * NT;          // j*NT + mt           : initial accumulators r, z, n, nh
+    static constexpr int NG = DM0 + 4 * NT;
+    static constexpr int kCk = 6 * NT + 1;             // float4 per lane per checkpoint
+    static constexpr int kTiles = 5 * NT + 1;          // gr gz gn gnh dhm per unit tile + feature-delta tile
+};
 
-template <bool TRES>
+template <bool TRES, int NT>
 __device__ __forceinline__ float4 d16_entry(const float* pl, const DeltaLayout& L, int grp, int m, int q) {
+    using T = D16<NT>;
     const int H = L.H;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int k = 4 * q + e;
-        if (grp < d16::HH) {
-            const int g = grp, slot = 4 * e + q;
-            v[e] = (e < 2 && slot < 6 && m < H) ? pl[L.o_w_ih + (g * H + m) * 6 + slot] * (g < 2 ? kNegLog2e : 1.0f) : 0.0f;
-        } else if (grp < d16::HHT) {
-            const int g = grp - d16::HH;
-            v[e] = (m < H && k < H) ? pl[L.o_w_hh + (g * H + m) * H + k] * (g < 2 ? kNegLog2e : 1.0f) : 0.0f;
-        } else if (grp < d16::WOUT) {
-            const int g = grp - d16::HHT;
-            v[e] = (m < H && k < H) ? pl[L.o_w_hh + (g * H + k) * H + m] : 0.0f;
-        } else if (grp < d16::DM0) {
-            v[e] = k < H ? pl[L.o_w_out + (grp - d16::WOUT) * H + k] : 0.0f;
+        if (grp < T::HH) {
+            const int g = grp / NT, o = 16 * (grp % NT) + m, slot = 4 * e + q;
+            v[e] = (e < 2 && slot < 6 && o < H) ? pl[L.o_w_ih + (g * H + o) * 6 + slot] * (g < 2 ? kNegLog2e : 1.0f) : 0.0f;
+        } else if (grp < T::HHT) {
+            const int r = grp - T::HH, g = r / (NT * NT), o = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            v[e] = (o < H && k < H) ? pl[L.o_w_hh + (g * H + o) * H + k] * (g < 2 ? kNegLog2e : 1.0f) : 0.0f;
+        } else if (grp < T::WOUT) {
+            const int r = grp - T::HHT, g = r / (NT * NT), i = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            v[e] = (i < H && k < H) ? pl[L.o_w_hh + (g * H + k) * H + i] : 0.0f;
+        } else if (grp < T::DM0) {
+            const int r = grp - T::WOUT, k = 16 * (r % NT) + 4 * q + e;
+            v[e] = k < H ? pl[L.o_w_out + (r / NT) * H + k] : 0.0f;
         } else {
-            const int j = grp - d16::DM0;
+            const int r = grp - T::DM0, j = r / NT, k = 16 * (r % NT) + 4 * q + e;
             float b = 0.0f;
             if (!TRES && k < H) {
                 if (j == 0) b = (pl[L.o_b_ih + k] + pl[L.o_b_hh + k]) * kNegLog2e;
@@ -77,7 +84,8 @@ struct D16Scalars {                 // per-sequence parameters, uniform across l
 };
 
 // recurrent state of one lane
-struct D16State { f32x4 h, hp, dmr, dmz, dmn, dmnh; float xp[2]; };
+template <int NT>
+struct D16State { f32x4 h[NT], hp[NT], dmr[NT], dmz[NT], dmn[NT], dmnh[NT]; float xp[2]; };
 
 template <bool TRES>
 __device__ __forceinline__ void d16_slots(float2 xv, float2 xn, const float (&oh)[4], float (&fs)[2]) {
@@ -89,11 +97,13 @@ __device__ __forceinline__ void d16_slots(float2 xv, float2 xn, const float (&oh
     fs[1] = __builtin_fmaf(oh[0], f4, oh[1] * f5);
 }
 
-// one forward step.  slot_ok[c]: the lane's slot of chunk c is a real feature; unit_ok[i]: a real hidden unit
-template <bool TRES>
+// one forward step.  slot_ok[c]: the lane's slot of chunk c is a real feature; unit_ok[kt][i]: a real hidden unit
+template <bool TRES, int NT>
 __device__ __forceinline__ void d16_cell_fwd(TabPtr tl, const float (&fs)[2], float thx, float thh, const bool (&slot_ok)[2],
-                                             const f32x4& unit_ok, D16State& st, f32x4& hprev, f32x4& dhm, f32x4& mh, f32x4& r,
-                                             f32x4& z, f32x4& n, float (&dxm)[2], float& zx, float& zh) {
+                                             const f32x4 (&unit_ok)[NT], D16State<NT>& st, f32x4 (&hprev)[NT], f32x4 (&dhm)[NT],
+                                             f32x4 (&mh)[NT], f32x4 (&r)[NT], f32x4 (&z)[NT], f32x4 (&n)[NT], float (&dxm)[2],
+                                             float& zx, float& zh) {
+    using T = D16<NT>;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const float d = fs[c] - st.xp[c];
@@ -102,27 +112,35 @@ __device__ __forceinline__ void d16_cell_fwd(TabPtr tl, const float (&fs)[2], fl
         st.xp[c] = (__builtin_fabsf(d) >= thx) ? fs[c] : st.xp[c];
         zx += (slot_ok[c] && dxm[c] == 0.0f) ? 1.0f : 0.0f;
     }
-    ODPD_EACH4 {
-        const float d = st.h[i] - st.hp[i];
-        const bool keep = !(__builtin_fabsf(d) < thh);
-        dhm[i] = keep ? d : 0.0f;
-        mh[i] = keep ? 1.0f : 0.0f;
-        st.hp[i] = (__builtin_fabsf(d) >= thh) ? st.h[i] : st.hp[i];
-        zh += (unit_ok[i] != 0.0f && dhm[i] == 0.0f) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+        ODPD_EACH4 {
+            const float d = st.h[kt][i] - st.hp[kt][i];
+            const bool keep = !(__builtin_fabsf(d) < thh);
+            dhm[kt][i] = keep ? d : 0.0f;
+            mh[kt][i] = keep ? 1.0f : 0.0f;
+            st.hp[kt][i] = (__builtin_fabsf(d) >= thh) ? st.h[kt][i] : st.hp[kt][i];
+            zh += (unit_ok[kt][i] != 0.0f && dhm[kt][i] == 0.0f) ? 1.0f : 0.0f;
+        }
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        const float4 wr = tab_ld(tl, (T::IH + 0 * NT + mt) * 64), wz = tab_ld(tl, (T::IH + 1 * NT + mt) * 64),
+                     wn = tab_ld(tl, (T::IH + 2 * NT + mt) * 64);
+        st.dmr[mt] = mfma4(wr.x, dxm[0], st.dmr[mt]); st.dmr[mt] = mfma4(wr.y, dxm[1], st.dmr[mt]);
+        st.dmz[mt] = mfma4(wz.x, dxm[0], st.dmz[mt]); st.dmz[mt] = mfma4(wz.y, dxm[1], st.dmz[mt]);
+        st.dmn[mt] = mfma4(wn.x, dxm[0], st.dmn[mt]); st.dmn[mt] = mfma4(wn.y, dxm[1], st.dmn[mt]);
     }
-    const float4 wr = tab_ld(tl, (d16::IH + 0) * 64), wz = tab_ld(tl, (d16::IH + 1) * 64), wn = tab_ld(tl, (d16::IH + 2) * 64);
-    st.dmr = mfma4(wr.x, dxm[0], st.dmr); st.dmr = mfma4(wr.y, dxm[1], st.dmr);
-    st.dmz = mfma4(wz.x, dxm[0], st.dmz); st.dmz = mfma4(wz.y, dxm[1], st.dmz);
-    st.dmn = mfma4(wn.x, dxm[0], st.dmn); st.dmn = mfma4(wn.y, dxm[1], st.dmn);
-    const float4 hr = tab_ld(tl, (d16::HH + 0) * 64), hz = tab_ld(tl, (d16::HH + 1) * 64), hn = tab_ld(tl, (d16::HH + 2) * 64);
-    st.dmr = mfma4(hr.x, dhm[0], st.dmr); st.dmr = mfma4(hr.y, dhm[1], st.dmr); st.dmr = mfma4(hr.z, dhm[2], st.dmr); st.dmr = mfma4(hr.w, dhm[3], st.dmr);
-    st.dmz = mfma4(hz.x, dhm[0], st.dmz); st.dmz = mfma4(hz.y, dhm[1], st.dmz); st.dmz = mfma4(hz.z, dhm[2], st.dmz); st.dmz = mfma4(hz.w, dhm[3], st.dmz);
-    st.dmnh = mfma4(hn.x, dhm[0], st.dmnh); st.dmnh = mfma4(hn.y, dhm[1], st.dmnh); st.dmnh = mfma4(hn.z, dhm[2], st.dmnh); st.dmnh = mfma4(hn.w, dhm[3], st.dmnh);
-    r = sigmoid4_prescaled(st.dmr);
-    z = sigmoid4_prescaled(st.dmz);
-    n = tanh4_precise(fma4(r, st.dmnh, st.dmn));
-    hprev = st.h;
-    st.h = fma4(z, sub4(st.h, n), n);
+    s16n_matvec<NT>(tl, T::HH + 0 * NT * NT, dhm, st.dmr);
+    s16n_matvec<NT>(tl, T::HH + 1 * NT * NT, dhm, st.dmz);
+    s16n_matvec<NT>(tl, T::HH + 2 * NT * NT, dhm, st.dmnh);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        r[mt] = sigmoid4_prescaled(st.dmr[mt]);
+        z[mt] = sigmoid4_prescaled(st.dmz[mt]);
+        n[mt] = tanh4_precise(fma4(r[mt], st.dmnh[mt], st.dmn[mt]));
+        hprev[mt] = st.h[mt];
+        st.h[mt] = fma4(z[mt], sub4(st.h[mt], n[mt]), n[mt]);
+    }
 }
 
 // TCN skip of one sample: s1[3] pre-activations of the first conv, s2[2] of the second
@@ -159,19 +177,26 @@ __device__ __forceinline__ void d16_stage_x(float2* lds, const float* g, int b0,
     }
 }
 
-__device__ __forceinline__ void d16_init_state(TabPtr tl, D16State& st) {
+template <int NT>
+__device__ __forceinline__ void d16_init_state(TabPtr tl, D16State<NT>& st) {
+    using T = D16<NT>;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    st.h = z4; st.hp = z4;
-    st.dmr = as_f32x4(tab_ld(tl, (d16::DM0 + 0) * 64)); st.dmz = as_f32x4(tab_ld(tl, (d16::DM0 + 1) * 64));
-    st.dmn = as_f32x4(tab_ld(tl, (d16::DM0 + 2) * 64)); st.dmnh = as_f32x4(tab_ld(tl, (d16::DM0 + 3) * 64));
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        st.h[mt] = z4; st.hp[mt] = z4;
+        st.dmr[mt] = as_f32x4(tab_ld(tl, (T::DM0 + 0 * NT + mt) * 64)); st.dmz[mt] = as_f32x4(tab_ld(tl, (T::DM0 + 1 * NT + mt) * 64));
+        st.dmn[mt] = as_f32x4(tab_ld(tl, (T::DM0 + 2 * NT + mt) * 64)); st.dmnh[mt] = as_f32x4(tab_ld(tl, (T::DM0 + 3 * NT + mt) * 64));
+    }
     st.xp[0] = st.xp[1] = 0.0f;
 }
+__device__ __forceinline__ float4 d16_f4(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
 // -------------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------------
-template <bool TRES>
-__global__ __launch_bounds__(512, 2) void delta16_fwd_kernel(SeqArgs a) {
+template <bool TRES, int NT>
+__global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_fwd_kernel(SeqArgs a) {
+    using T = D16<NT>;
     constexpr int S = kCkptStride;
     constexpr int kWave = 2 * 16 * d16::kStride + 2 * 16 * kChunkPad;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -183,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void delta16_fwd_kernel(SeqArgs a) {
     float* tab = smem + pad4(L.P);
     {
         float4* t4 = reinterpret_cast<float4*>(tab);
-        for (int grp = wave; grp < d16::NG; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES>(pl, L, grp, n, q);
+        for (int grp = wave; grp < T::NG; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES, NT>(pl, L, grp, n, q);
         __syncthreads();
     }
     const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
@@ -193,9 +218,10 @@ __global__ __launch_bounds__(512, 2) void delta16_fwd_kernel(SeqArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
     const bool slot_ok[2] = {true, q < 2};
-    f32x4 unit_ok;
-    ODPD_EACH4 unit_ok[i] = (4 * q + i < a.H) ? 1.0f : 0.0f;
-    float* wbase = tab + s16_tab_floats(d16::NG) + (size_t)wave * kWave;
+    f32x4 unit_ok[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) ODPD_EACH4 unit_ok[kt][i] = (16 * kt + 4 * q + i < a.H) ? 1.0f : 0.0f;
+    float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ys = xs + 16 * d16::kStride;
     const float2* xr = xs + n * d16::kStride + d16::kHalo;
@@ -204,10 +230,10 @@ __global__ __launch_bounds__(512, 2) void delta16_fwd_kernel(SeqArgs a) {
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
         const bool valid = b0 + n < a.B;
-        float4* ck = a.ckpt ? reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * d16::kCk * 64 + lane : nullptr;
+        float4* ck = a.ckpt ? reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * T::kCk * 64 + lane : nullptr;
         const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[(size_t)(b0 + n) * a.T] : make_float2(0.5f, 0.5f);
-        D16State st;
-        d16_init_state(tl, st);
+        D16State<NT> st;
+        d16_init_state<NT>(tl, st);
         float zxs = 0.0f, zhs = 0.0f;
         for (int t0 = 0; t0 < a.T; t0 += kChunk) {
             const int len = min(kChunk, a.T - t0);
@@ -218,12 +244,15 @@ __global__ __launch_bounds__(512, 2) void delta16_fwd_kernel(SeqArgs a) {
                 const float2 xv = xr[tt];
                 const float2 xn = (t0 + tt + 1 < a.T) ? xr[tt + 1] : x0;      // torch.roll(x, -1): the last step sees sample 0
                 float fs[2], dxm[2];
-                f32x4 hprev, dhm, mh, r, z, nn;
+                f32x4 hprev[NT], dhm[NT], mh[NT], r[NT], z[NT], nn[NT];
                 d16_slots<TRES>(xv, xn, oh, fs);
-                d16_cell_fwd<TRES>(opaque(tl), fs, a.thx, a.thh, slot_ok, unit_ok, st, hprev, dhm, mh, r, z, nn, dxm, zxs, zhs);
-                const f32x4 w0 = as_f32x4(tab_ld(tl, (d16::WOUT + 0) * 64)), w1 = as_f32x4(tab_ld(tl, (d16::WOUT + 1) * 64));
+                d16_cell_fwd<TRES, NT>(opaque(tl), fs, a.thx, a.thh, slot_ok, unit_ok, st, hprev, dhm, mh, r, z, nn, dxm, zxs, zhs);
                 float p0 = 0.0f, p1 = 0.0f;
-                ODPD_EACH4 { p0 = __builtin_fmaf(w0[i], st.h[i], p0); p1 = __builtin_fmaf(w1[i], st.h[i], p1); }
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) {
+                    const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
+                    ODPD_EACH4 { p0 = __builtin_fmaf(w0[i], st.h[mt][i], p0); p1 = __builtin_fmaf(w1[i], st.h[mt][i], p1); }
+                }
                 float y0 = quad_sum(p0) + sc.bout[0], y1 = quad_sum(p1) + sc.bout[1];
                 if constexpr (TRES) {
                     float s1[3], s2[2];
@@ -233,10 +262,14 @@ __global__ __launch_bounds__(512, 2) void delta16_fwd_kernel(SeqArgs a) {
                 if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
                 const int t1 = t0 + tt + 1;
                 if (ck != nullptr && (t1 % S) == 0 && t1 < a.T) {
-                    float4* c = ck + (size_t)(t1 / S) * d16::kCk * 64;
-                    auto f4 = [](const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); };
-                    c[0] = f4(st.h); c[64] = f4(st.hp); c[128] = f4(st.dmr); c[192] = f4(st.dmz); c[256] = f4(st.dmn); c[320] = f4(st.dmnh);
-                    c[384] = make_float4(st.xp[0], st.xp[1], 0.0f, 0.0f);
+                    float4* c = ck + (size_t)(t1 / S) * T::kCk * 64;
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) {
+                        c[(0 * NT + kt) * 64] = d16_f4(st.h[kt]); c[(1 * NT + kt) * 64] = d16_f4(st.hp[kt]);
+                        c[(2 * NT + kt) * 64] = d16_f4(st.dmr[kt]); c[(3 * NT + kt) * 64] = d16_f4(st.dmz[kt]);
+                        c[(4 * NT + kt) * 64] = d16_f4(st.dmn[kt]); c[(5 * NT + kt) * 64] = d16_f4(st.dmnh[kt]);
+                    }
+                    c[6 * NT * 64] = make_float4(st.xp[0], st.xp[1], 0.0f, 0.0f);
                 }
             }
             wave_lds_fence();
@@ -261,18 +294,25 @@ __global__ __launch_bounds__(512, 2) void delta16_fwd_kernel(SeqArgs a) {
 // -------------------------------------------------------------------------------------------------
 // backward (parameter gradients)
 // -------------------------------------------------------------------------------------------------
-template <bool TRES>
+template <bool TRES, int NT>
 struct D16Grad {
-    f32x4 thh[3], tih[3];
-    f32x4 dwout[2], db[4];
+    f32x4 thh[3][NT][NT], tih[3][NT];
+    f32x4 dwout[2][NT], db[4][NT];
     float dbout[2], dw1[18], dw2[6];
     __device__ __forceinline__ void zero() {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < 3; ++g) { thh[g] = z4; tih[g] = z4; }
-        dwout[0] = dwout[1] = z4;
+        for (int a = 0; a < NT; ++a) {
+            dwout[0][a] = dwout[1][a] = z4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) db[j] = z4;
+            for (int j = 0; j < 4; ++j) db[j][a] = z4;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                tih[g][a] = z4;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) thh[g][a][b] = z4;
+            }
+        }
         dbout[0] = dbout[1] = 0.f;
 #pragma unroll
         for (int i = 0; i < 18; ++i) dw1[i] = 0.f;
@@ -280,51 +320,51 @@ struct D16Grad {
         for (int i = 0; i < 6; ++i) dw2[i] = 0.f;
     }
 };
-struct D16Carry { f32x4 gh, ghp, gr, gz, gn, gnh; };
+template <int NT>
+struct D16Carry { f32x4 gh[NT], ghp[NT], gr[NT], gz[NT], gn[NT], gnh[NT]; };
 
-template <bool TRES, bool FULL>
+template <bool TRES, int NT, bool FULL>
 __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, const D16Scalars<TRES>& sc, const float (&oh)[4],
-                                              D16Grad<TRES>& G, const float2* xr, const float2* dys, float* tiles, float2 x0,
-                                              int n, int q, int tglob, int tloc, int nstep, D16State st, D16Carry& C) {
+                                              D16Grad<TRES, NT>& G, const float2* xr, const float2* dys, float* tiles, float2 x0,
+                                              int n, int q, int tglob, int tloc, int nstep, D16State<NT> st, D16Carry<NT>& C) {
+    using T = D16<NT>;
     constexpr int S = kCkptStride;
     const bool slot_ok[2] = {true, q < 2};
-    const f32x4 all_units = {1.f, 1.f, 1.f, 1.f};
-    f32x4 hprev_s[S], dhm_s[S], mh_s[S], r_s[S], z_s[S], n_s[S], nh_s[S], ht_s[S];
+    f32x4 all_units[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) all_units[kt] = f32x4{1.f, 1.f, 1.f, 1.f};
+    f32x4 hprev_s[S][NT], dhm_s[S][NT], mh_s[S][NT], r_s[S][NT], z_s[S][NT], n_s[S][NT], nh_s[S][NT];
     float dxm_s[S][2];
     TabPtr tl = opaque(tl0);
     {
         float zx = 0.f, zh = 0.f;
 #pragma unroll
-        for (int st_i = 0; st_i < S; ++st_i) {
-            if (FULL || st_i < nstep) {
-                const float2 xv = xr[tloc + st_i];
-                const float2 xn = (tglob + st_i + 1 < a.T) ? xr[tloc + st_i + 1] : x0;
+        for (int si = 0; si < S; ++si) {
+            if (FULL || si < nstep) {
+                const float2 xv = xr[tloc + si];
+                const float2 xn = (tglob + si + 1 < a.T) ? xr[tloc + si + 1] : x0;
                 float fs[2];
                 d16_slots<TRES>(xv, xn, oh, fs);
-                d16_cell_fwd<TRES>(tl, fs, a.thx, a.thh, slot_ok, all_units, st, hprev_s[st_i], dhm_s[st_i], mh_s[st_i], r_s[st_i],
-                                   z_s[st_i], n_s[st_i], dxm_s[st_i], zx, zh);
-                nh_s[st_i] = st.dmnh;
-                ht_s[st_i] = st.h;
+                d16_cell_fwd<TRES, NT>(tl, fs, a.thx, a.thh, slot_ok, all_units, st, hprev_s[si], dhm_s[si], mh_s[si], r_s[si],
+                                       z_s[si], n_s[si], dxm_s[si], zx, zh);
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) nh_s[si][kt] = st.dmnh[kt];
             }
         }
     }
     tl = opaque(tl0);
-    const f32x4 w0 = as_f32x4(tab_ld(tl, (d16::WOUT + 0) * 64)), w1 = as_f32x4(tab_ld(tl, (d16::WOUT + 1) * 64));
-    float* t_r = tiles, *t_z = tiles + kTileFloats, *t_n = tiles + 2 * kTileFloats, *t_g = tiles + 3 * kTileFloats;
-    float* t_h = tiles + 4 * kTileFloats, *t_f = tiles + 5 * kTileFloats;
+    auto tile = [tiles](int qty, int kt) { return tiles + (qty * NT + kt) * kTileFloats; };   // qty: 0 gr 1 gz 2 gn 3 gnh 4 dhm
+    float* t_f = tiles + 5 * NT * kTileFloats;
     const f32x4 one = splat4(1.0f);
 #pragma unroll
-    for (int st_i = S - 1; st_i >= 0; --st_i) {
-        if (FULL || st_i < nstep) {
-            const int tt = tloc + st_i;
+    for (int si = S - 1; si >= 0; --si) {
+        if (FULL || si < nstep) {
+            const int tt = tloc + si;
             const float2 dyv = dys[n * kChunkPad + tt];
-            const f32x4 gh = add4(C.gh, fma4(splat4(dyv.x), w0, mul4(w1, splat4(dyv.y))));
-            G.dwout[0] = fma4(splat4(dyv.x), ht_s[st_i], G.dwout[0]);
-            G.dwout[1] = fma4(splat4(dyv.y), ht_s[st_i], G.dwout[1]);
             G.dbout[0] += q == 0 ? dyv.x : 0.0f;
             G.dbout[1] += q == 0 ? dyv.y : 0.0f;
             if constexpr (TRES) {
-                if (q == 0) {    // per-sequence work: one lane of the four is enough (wave-uniform branch per quad row)
+                if (q == 0) {    // per-sequence work: one lane of the four is enough
                     float s1[3], s2[2];
                     const float2 xm = xr[tt - d16::kHalo], xc = xr[tt], xq = xr[tt + d16::kHalo];
                     d16_tcn<TRES>(sc, xm, xc, xq, s1, s2);
@@ -341,83 +381,108 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                     }
                 }
             }
-            const f32x4 r = r_s[st_i], z = z_s[st_i], nn = n_s[st_i];
-            const f32x4 dn = mul4(gh, sub4(one, z)), dz = mul4(gh, sub4(hprev_s[st_i], nn));
-            f32x4 ghprev = mul4(gh, z), omn2;
-            ODPD_EACH4 omn2[i] = __builtin_fmaf(-nn[i], nn[i], 1.0f);
-            const f32x4 dpre = mul4(dn, omn2);
-            C.gn = add4(C.gn, dpre);
-            C.gnh = fma4(dpre, r, C.gnh);
-            C.gr = fma4(mul4(dpre, nh_s[st_i]), mul4(r, sub4(one, r)), C.gr);
-            C.gz = fma4(dz, mul4(z, sub4(one, z)), C.gz);
-            // data gradient to the masked dh: W_hh^T [G_r, G_z, G_nh]
-            f32x4 ddh = {0.f, 0.f, 0.f, 0.f};
-            {
-                const float4 tr = tab_ld(tl, (d16::HHT + 0) * 64), tz = tab_ld(tl, (d16::HHT + 1) * 64), tn = tab_ld(tl, (d16::HHT + 2) * 64);
-                ddh = mfma4(tr.x, C.gr[0], ddh); ddh = mfma4(tr.y, C.gr[1], ddh); ddh = mfma4(tr.z, C.gr[2], ddh); ddh = mfma4(tr.w, C.gr[3], ddh);
-                ddh = mfma4(tz.x, C.gz[0], ddh); ddh = mfma4(tz.y, C.gz[1], ddh); ddh = mfma4(tz.z, C.gz[2], ddh); ddh = mfma4(tz.w, C.gz[3], ddh);
-                ddh = mfma4(tn.x, C.gnh[0], ddh); ddh = mfma4(tn.y, C.gnh[1], ddh); ddh = mfma4(tn.z, C.gnh[2], ddh); ddh = mfma4(tn.w, C.gnh[3], ddh);
+            f32x4 ghprev[NT];
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
+                const f32x4 r = r_s[si][mt], z = z_s[si][mt], nn = n_s[si][mt];
+                const f32x4 ht = fma4(z, sub4(hprev_s[si][mt], nn), nn);
+                const f32x4 gh = add4(C.gh[mt], fma4(splat4(dyv.x), w0, mul4(w1, splat4(dyv.y))));
+                G.dwout[0][mt] = fma4(splat4(dyv.x), ht, G.dwout[0][mt]);
+                G.dwout[1][mt] = fma4(splat4(dyv.y), ht, G.dwout[1][mt]);
+                const f32x4 dn = mul4(gh, sub4(one, z)), dz = mul4(gh, sub4(hprev_s[si][mt], nn));
+                ghprev[mt] = mul4(gh, z);
+                f32x4 omn2;
+                ODPD_EACH4 omn2[i] = __builtin_fmaf(-nn[i], nn[i], 1.0f);
+                const f32x4 dpre = mul4(dn, omn2);
+                C.gn[mt] = add4(C.gn[mt], dpre);
+                C.gnh[mt] = fma4(dpre, r, C.gnh[mt]);
+                C.gr[mt] = fma4(mul4(dpre, nh_s[si][mt]), mul4(r, sub4(one, r)), C.gr[mt]);
+                C.gz[mt] = fma4(dz, mul4(z, sub4(one, z)), C.gz[mt]);
             }
-            const f32x4 mk = mh_s[st_i];
-            ghprev = fma4(mk, add4(ddh, C.ghp), ghprev);
-            ODPD_EACH4 C.ghp[i] = __builtin_fmaf(-mk[i], ddh[i], (1.0f - mk[i]) * C.ghp[i]);
-            C.gh = ghprev;
+            // data gradient to the masked dh: W_hh^T [G_r, G_z, G_nh]
+            f32x4 ddh[NT];
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) ddh[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s16n_matvec<NT>(tl, T::HHT + 0 * NT * NT, C.gr, ddh);
+            s16n_matvec<NT>(tl, T::HHT + 1 * NT * NT, C.gz, ddh);
+            s16n_matvec<NT>(tl, T::HHT + 2 * NT * NT, C.gnh, ddh);
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                const f32x4 mk = mh_s[si][mt];
+                C.gh[mt] = fma4(mk, add4(ddh[mt], C.ghp[mt]), ghprev[mt]);
+                ODPD_EACH4 C.ghp[mt][i] = __builtin_fmaf(-mk[i], ddh[mt][i], (1.0f - mk[i]) * C.ghp[mt][i]);
+            }
             // weight gradients: dW_ih += G_dm^T (x) dx_masked, dW_hh += [G_r, G_z, G_nh]^T (x) dh_masked
             wave_lds_fence();
-            tile_put(t_r, n, q, C.gr);
-            tile_put(t_z, n, q, C.gz);
-            tile_put(t_n, n, q, C.gn);
-            tile_put(t_g, n, q, C.gnh);
-            tile_put(t_h, n, q, dhm_s[st_i]);
-            t_f[n * kTilePitch + q] = dxm_s[st_i][0];
-            t_f[n * kTilePitch + 4 + q] = dxm_s[st_i][1];      // slots 6, 7 are zero deltas (the lanes' features are 0 there)
-            wave_lds_fence();
-            float rT[4], zT[4], nT[4], gT[4], hT[4], fT[4];
-            tile_get(t_r, n, q, rT); tile_get(t_z, n, q, zT); tile_get(t_n, n, q, nT); tile_get(t_g, n, q, gT);
-            tile_get(t_h, n, q, hT); tile_get(t_f, n, q, fT);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                G.tih[0] = mfma4(rT[c], fT[c], G.tih[0]);
-                G.tih[1] = mfma4(zT[c], fT[c], G.tih[1]);
-                G.tih[2] = mfma4(nT[c], fT[c], G.tih[2]);
-                G.thh[0] = mfma4(rT[c], hT[c], G.thh[0]);
-                G.thh[1] = mfma4(zT[c], hT[c], G.thh[1]);
-                G.thh[2] = mfma4(gT[c], hT[c], G.thh[2]);
+            for (int kt = 0; kt < NT; ++kt) {
+                tile_put(tile(0, kt), n, q, C.gr[kt]);
+                tile_put(tile(1, kt), n, q, C.gz[kt]);
+                tile_put(tile(2, kt), n, q, C.gn[kt]);
+                tile_put(tile(3, kt), n, q, C.gnh[kt]);
+                tile_put(tile(4, kt), n, q, dhm_s[si][kt]);
+            }
+            t_f[n * kTilePitch + q] = dxm_s[si][0];
+            t_f[n * kTilePitch + 4 + q] = dxm_s[si][1];      // slots 6, 7 are zero deltas (the lanes' features are 0 there)
+            wave_lds_fence();
+            float fT[4], hT[NT][4];
+            tile_get(t_f, n, q, fT);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) tile_get(tile(4, kt), n, q, hT[kt]);
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                float rT[4], zT[4], nT[4], gT[4];
+                tile_get(tile(0, mt), n, q, rT); tile_get(tile(1, mt), n, q, zT);
+                tile_get(tile(2, mt), n, q, nT); tile_get(tile(3, mt), n, q, gT);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    G.tih[0][mt] = mfma4(rT[c], fT[c], G.tih[0][mt]);
+                    G.tih[1][mt] = mfma4(zT[c], fT[c], G.tih[1][mt]);
+                    G.tih[2][mt] = mfma4(nT[c], fT[c], G.tih[2][mt]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        G.thh[0][mt][nt] = mfma4(rT[c], hT[nt][c], G.thh[0][mt][nt]);
+                        G.thh[1][mt][nt] = mfma4(zT[c], hT[nt][c], G.thh[1][mt][nt]);
+                        G.thh[2][mt][nt] = mfma4(gT[c], hT[nt][c], G.thh[2][mt][nt]);
+                    }
+                }
             }
         }
     }
 }
 
-template <bool TRES>
-__device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L, D16Grad<TRES>& G, int lane, int n, int q) {
+template <bool TRES, int NT>
+__device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L, D16Grad<TRES, NT>& G, int lane, int n, int q) {
     const int H = L.H;
     for (int i = lane; i < kLossCols; i += 64) prow[L.P + i] = 0.f;
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int i = 4 * q + rr;
-            if (i < H) {
-                if (n < 6) prow[L.o_w_ih + (g * H + i) * 6 + n] = G.tih[g][rr];
-                if (n < H) prow[L.o_w_hh + (g * H + i) * H + n] = G.thh[g][rr];
+            const int u = 16 * mt + 4 * q + rr;
+            if (u < H) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (n < 6) prow[L.o_w_ih + (g * H + u) * 6 + n] = G.tih[g][mt][rr];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        if (16 * nt + n < H) prow[L.o_w_hh + (g * H + u) * H + 16 * nt + n] = G.thh[g][mt][nt][rr];
+                }
+            }
+            const float w0 = row_sum16(G.dwout[0][mt][rr]), w1 = row_sum16(G.dwout[1][mt][rr]);
+            float db[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) db[j] = row_sum16(G.db[j][mt][rr]);
+            if (n == 0 && u < H) {
+                prow[L.o_w_out + u] = w0; prow[L.o_w_out + H + u] = w1;
+                if constexpr (!TRES) {
+                    prow[L.o_b_ih + u] = db[0]; prow[L.o_b_hh + u] = db[0];
+                    prow[L.o_b_ih + H + u] = db[1]; prow[L.o_b_hh + H + u] = db[1];
+                    prow[L.o_b_ih + 2 * H + u] = db[2]; prow[L.o_b_hh + 2 * H + u] = db[3];
+                }
             }
         }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int u = 4 * q + rr;
-        const float w0 = row_sum16(G.dwout[0][rr]), w1 = row_sum16(G.dwout[1][rr]);
-        float db[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) db[j] = row_sum16(G.db[j][rr]);
-        if (n == 0 && u < H) {
-            prow[L.o_w_out + u] = w0; prow[L.o_w_out + H + u] = w1;
-            if constexpr (!TRES) {
-                prow[L.o_b_ih + u] = db[0]; prow[L.o_b_hh + u] = db[0];
-                prow[L.o_b_ih + H + u] = db[1]; prow[L.o_b_hh + H + u] = db[1];
-                prow[L.o_b_ih + 2 * H + u] = db[2]; prow[L.o_b_hh + 2 * H + u] = db[3];
-            }
-        }
-    }
     if constexpr (TRES) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
@@ -435,10 +500,11 @@ __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L,
     }
 }
 
-template <bool TRES>
+template <bool TRES, int NT>
 __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
+    using T = D16<NT>;
     constexpr int S = kCkptStride;
-    constexpr int kWave = 2 * 16 * d16::kStride + 2 * 16 * kChunkPad + d16::kTiles * kTileFloats;
+    constexpr int kWave = 2 * 16 * d16::kStride + 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -448,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     float* tab = smem + pad4(L.P);
     {
         float4* t4 = reinterpret_cast<float4*>(tab);
-        for (int grp = wave; grp < d16::NG; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES>(pl, L, grp, n, q);
+        for (int grp = wave; grp < T::NG; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES, NT>(pl, L, grp, n, q);
         __syncthreads();
     }
     const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
@@ -457,22 +523,24 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     float oh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
-    float* wbase = tab + s16_tab_floats(d16::NG) + (size_t)wave * kWave;
+    float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* dys = xs + 16 * d16::kStride;
     float* tiles = reinterpret_cast<float*>(dys + 16 * kChunkPad);
-    for (int i = lane; i < kTileFloats; i += 64) tiles[5 * kTileFloats + i] = 0.0f;
+    for (int i = lane; i < kTileFloats; i += 64) tiles[5 * NT * kTileFloats + i] = 0.0f;
     const float2* xr = xs + n * d16::kStride + d16::kHalo;
-    D16Grad<TRES> G;
+    D16Grad<TRES, NT> G;
     G.zero();
     const int nwaves = gridDim.x * nwb;
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
         const bool valid = b0 + n < a.B;
-        const float4* ck = reinterpret_cast<const float4*>(a.ckpt) + (size_t)grp * a.nck * d16::kCk * 64 + lane;
+        const float4* ck = reinterpret_cast<const float4*>(a.ckpt) + (size_t)grp * a.nck * T::kCk * 64 + lane;
         const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[(size_t)(b0 + n) * a.T] : make_float2(0.5f, 0.5f);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        D16Carry C = {z4, z4, z4, z4, z4, z4};
+        D16Carry<NT> C;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) { C.gh[kt] = z4; C.ghp[kt] = z4; C.gr[kt] = z4; C.gz[kt] = z4; C.gn[kt] = z4; C.gnh[kt] = z4; }
         int cur_chunk = -1;
         for (int blk = a.nck - 1; blk >= 0; --blk) {
             const int tb = blk * S, nstep = min(S, a.T - tb);
@@ -485,25 +553,33 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
                 wave_lds_fence();
                 cur_chunk = chunk;
             }
-            D16State st;
+            D16State<NT> st;
             if (blk) {
-                const float4* c = ck + (size_t)blk * d16::kCk * 64;
-                st.h = as_f32x4(c[0]); st.hp = as_f32x4(c[64]); st.dmr = as_f32x4(c[128]); st.dmz = as_f32x4(c[192]);
-                st.dmn = as_f32x4(c[256]); st.dmnh = as_f32x4(c[320]);
-                const float4 xp = c[384];
+                const float4* c = ck + (size_t)blk * T::kCk * 64;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    st.h[kt] = as_f32x4(c[(0 * NT + kt) * 64]); st.hp[kt] = as_f32x4(c[(1 * NT + kt) * 64]);
+                    st.dmr[kt] = as_f32x4(c[(2 * NT + kt) * 64]); st.dmz[kt] = as_f32x4(c[(3 * NT + kt) * 64]);
+                    st.dmn[kt] = as_f32x4(c[(4 * NT + kt) * 64]); st.dmnh[kt] = as_f32x4(c[(5 * NT + kt) * 64]);
+                }
+                const float4 xp = c[6 * NT * 64];
                 st.xp[0] = xp.x; st.xp[1] = xp.y;
             } else {
-                d16_init_state(tl, st);
+                d16_init_state<NT>(tl, st);
             }
-            if (nstep == S) d16_bwd_block<TRES, true>(a, tl, sc, oh, G, xr, dys, tiles, x0, n, q, tb, tb - t0, nstep, st, C);
-            else d16_bwd_block<TRES, false>(a, tl, sc, oh, G, xr, dys, tiles, x0, n, q, tb, tb - t0, nstep, st, C);
+            if (nstep == S) d16_bwd_block<TRES, NT, true>(a, tl, sc, oh, G, xr, dys, tiles, x0, n, q, tb, tb - t0, nstep, st, C);
+            else d16_bwd_block<TRES, NT, false>(a, tl, sc, oh, G, xr, dys, tiles, x0, n, q, tb, tb - t0, nstep, st, C);
         }
         // gradient w.r.t. the initial accumulators = bias gradients (deltagru.py:165-170)
-        G.db[0] = add4(G.db[0], C.gr); G.db[1] = add4(G.db[1], C.gz); G.db[2] = add4(G.db[2], C.gn); G.db[3] = add4(G.db[3], C.gnh);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            G.db[0][kt] = add4(G.db[0][kt], C.gr[kt]); G.db[1][kt] = add4(G.db[1][kt], C.gz[kt]);
+            G.db[2][kt] = add4(G.db[2][kt], C.gn[kt]); G.db[3][kt] = add4(G.db[3][kt], C.gnh[kt]);
+        }
     }
     const int P4 = L.P + kLossCols;
     __syncthreads();
-    d16_write_row<TRES>(smem + wave * P4, L, G, lane, n, q);
+    d16_write_row<TRES, NT>(smem + wave * P4, L, G, lane, n, q);
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * P4;
     for (int i = threadIdx.x; i < P4; i += blockDim.x) {
@@ -516,63 +592,73 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
+// hidden <= 16: from the batch size that fills the chip; hidden 17..32: always (the row-rotated delta kernels stop at 16)
 bool delta_uses_s16(const odpd_model_t* m, int B) {
-    if ((m->backbone != ODPD_DELTAGRU && m->backbone != ODPD_TRES_DELTAGRU) || m->hidden > 16) return false;
+    if ((m->backbone != ODPD_DELTAGRU && m->backbone != ODPD_TRES_DELTAGRU) || m->hidden > 32) return false;
+    if (m->hidden > 16) return true;
     long min_batch = tuning().s16_min_batch;
     if (min_batch < 0) min_batch = 16L * 4 * device_cus();
     return B >= min_batch;
 }
-static LaunchShape d16_fwd_shape(int ngroups) {
+static LaunchShape d16_fwd_shape(int ngroups, int nt) {
     LaunchShape ls;
     const int cus = device_cus();
-    ls.waves = ngroups <= 4 * cus ? 4 : 8;
+    ls.waves = (nt > 1 || ngroups <= 4 * cus) ? 4 : 8;
     const int need = (ngroups + ls.waves - 1) / ls.waves;
     ls.grid = need < cus ? need : cus;
     return ls;
 }
-static LaunchShape d16_bwd_shape(int ngroups) {
+static int d16_tiles(int H) { return (H + 15) / 16; }
+static size_t d16_bwd_lds(int P, int nt, int waves) {
+    const int groups = nt == 1 ? D16<1>::NG : D16<2>::NG, tiles = nt == 1 ? D16<1>::kTiles : D16<2>::kTiles;
+    size_t lds = ((size_t)pad4(P) + s16_tab_floats(groups) +
+                  (size_t)waves * (2 * 16 * d16::kStride + 2 * 16 * kChunkPad + tiles * kTileFloats)) * sizeof(float);
+    if (lds < reduce_scratch_bytes(P, waves)) lds = reduce_scratch_bytes(P, waves);
+    return lds;
+}
+// waves per block: as many (<= 4) as the LDS budget holds next to the staged parameters and the operand table
+static LaunchShape d16_bwd_shape(const odpd_model_t* m, int ngroups) {
     LaunchShape ls;
+    const int P = delta_layout(m->hidden, m->backbone == ODPD_TRES_DELTAGRU).P, nt = d16_tiles(m->hidden);
     ls.waves = 4;
-    const int need = (ngroups + 3) / 4, cus = device_cus();
+    while (ls.waves > 1 && d16_bwd_lds(P, nt, ls.waves) > kMaxLds) --ls.waves;
+    const int need = (ngroups + ls.waves - 1) / ls.waves, cus = device_cus();
     ls.grid = need < cus ? need : cus;
     return ls;
 }
-int delta_s16_rows(const odpd_model_t* m, int B) {
-    (void)m;
-    return d16_bwd_shape((B + 15) / 16).grid;
-}
+int delta_s16_rows(const odpd_model_t* m, int B) { return d16_bwd_shape(m, (B + 15) / 16).grid; }
 int64_t delta_s16_ckpt_floats(const odpd_model_t* m, int B, int T) {
-    (void)m;
-    return (int64_t)((B + 15) / 16) * num_ckpt(T) * d16::kCk * 256;
+    return (int64_t)((B + 15) / 16) * num_ckpt(T) * (6 * d16_tiles(m->hidden) + 1) * 256;
 }
-template <bool TRES>
-static int d16_launch(hipStream_t st, const SeqArgs& a, int P, int mode) {
+template <bool TRES, int NT>
+static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int P, int mode) {
+    using T = D16<NT>;
     if (mode == 1) {
-        const LaunchShape ls = d16_fwd_shape(a.ngroups);
-        const size_t lds = ((size_t)pad4(P) + s16_tab_floats(d16::NG) + (size_t)ls.waves * (2 * 16 * d16::kStride + 2 * 16 * kChunkPad)) * sizeof(float);
-        auto k = delta16_fwd_kernel<TRES>;
+        const LaunchShape ls = d16_fwd_shape(a.ngroups, NT);
+        const size_t lds = ((size_t)pad4(P) + s16_tab_floats(T::NG) + (size_t)ls.waves * (2 * 16 * d16::kStride + 2 * 16 * kChunkPad)) * sizeof(float);
+        auto k = delta16_fwd_kernel<TRES, NT>;
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
         return (int)hipGetLastError();
     }
     if (a.dx != nullptr) return ODPD_EUNSUPPORTED;   // dL/dx of a delta backbone is not implemented
     if (a.partials == nullptr) return ODPD_EINVAL;
-    const LaunchShape ls = d16_bwd_shape(a.ngroups);
-    size_t lds = ((size_t)pad4(P) + s16_tab_floats(d16::NG) +
-                  (size_t)ls.waves * (2 * 16 * d16::kStride + 2 * 16 * kChunkPad + d16::kTiles * kTileFloats)) * sizeof(float);
-    if (lds < reduce_scratch_bytes(P, ls.waves)) lds = reduce_scratch_bytes(P, ls.waves);
-    auto k = delta16_bwd_kernel<TRES>;
+    const LaunchShape ls = d16_bwd_shape(m, a.ngroups);
+    const size_t lds = d16_bwd_lds(P, NT, ls.waves);
+    if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+    auto k = delta16_bwd_kernel<TRES, NT>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
 }
 int delta_s16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int mode) {
-    if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     SeqArgs a = a0;
     a.ngroups = (a.B + 15) / 16;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
-    const int P = delta_layout(m->hidden, tres).P;
-    return tres ? d16_launch<true>(st, a, P, mode) : d16_launch<false>(st, a, P, mode);
+    const int P = delta_layout(m->hidden, tres).P, nt = d16_tiles(m->hidden);
+    if (nt == 1) return tres ? d16_launch<true, 1>(st, m, a, P, mode) : d16_launch<false, 1>(st, m, a, P, mode);
+    if (nt == 2) return tres ? d16_launch<true, 2>(st, m, a, P, mode) : d16_launch<false, 2>(st, m, a, P, mode);
+    return ODPD_EUNSUPPORTED;
 }
 
 }  // namespace odpd

@@ -141,7 +141,7 @@ def save(name, d):
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KB, {len(d)} arrays)")
 
 
-def gen_backbones():
+def gen_backbones(only=None):
     cases = [
         # name, backbone, H, thx, thh
         ("gru_h11", "gru", 11, 0, 0),
@@ -155,6 +155,8 @@ def gen_backbones():
         ("deltagru_h15_th", "deltagru", 15, 0.01, 0.05),
         ("tres_h15_dense", "deltagru_tcnskip", 15, 0.0, 0.0),
         ("tres_h15_th", "deltagru_tcnskip", 15, 0.01, 0.05),
+        ("deltagru_h24_th", "deltagru", 24, 0.01, 0.05),          # two unit tiles of the S16 mapping
+        ("tres_h30_th", "deltagru_tcnskip", 30, 0.005, 0.02),
         ("tcnn_c35", "tcnn", 35, 0, 0),
         ("pgjanet_h11", "pgjanet", 11, 0, 0),
         ("qgru_h10", "qgru", 10, 0, 0),
@@ -164,6 +166,8 @@ def gen_backbones():
     x, tgt = real_frames("DPA_200MHz", 5, 37, seed=1)       # ragged: B%4!=0, odd T
     xa, ta = real_frames("APA_200MHz", 8, 200, seed=2)      # config-shaped frames (T=200)
     for name, bb, H, thx, thh in cases:
+        if only and name not in only:
+            continue
         net = build(bb, H, seed=0, thx=thx, thh=thh)
         d = {"x": x, "tgt": tgt, "meta": np.array(json.dumps(
             {"backbone": bb, "hidden": H, "thx": thx, "thh": thh, "lr": LR, "clip": CLIP,
@@ -284,8 +288,9 @@ def gen_metrics_and_framing():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["backbones", "cascade", "quant", "metrics"]
+    only = [w.split("=", 1)[1].split(",") for w in which if w.startswith("only=")]      # e.g. backbones only=gru_h11,dgru_h8
     if "backbones" in which:
-        gen_backbones()
+        gen_backbones(only[0] if only else None)
     if "cascade" in which:
         gen_cascade()
     if "quant" in which:

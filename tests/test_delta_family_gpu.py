@@ -12,7 +12,7 @@ from tests.golden_util import Fixture, rel_err
 pytestmark = pytest.mark.gpu
 FWD_TOL, GRAD_TOL = 2e-5, 3e-4
 CASES = [("deltagru_h15_dense", "deltagru"), ("deltagru_h15_th", "deltagru"), ("tres_h15_dense", "deltagru_tcnskip"),
-         ("tres_h15_th", "deltagru_tcnskip")]
+         ("tres_h15_th", "deltagru_tcnskip"), ("deltagru_h24_th", "deltagru"), ("tres_h30_th", "deltagru_tcnskip")]
 
 
 def _model(fx, bb):
@@ -85,7 +85,8 @@ def test_against_oracle_ragged(bb, H, thx, thh, B, T):
     assert rel_err(g, go) < tol_g
 
 
-@pytest.mark.parametrize("name,bb", [("deltagru_h15_th", "deltagru"), ("tres_h15_th", "deltagru_tcnskip")])
+@pytest.mark.parametrize("name,bb", [("deltagru_h15_th", "deltagru"), ("tres_h15_th", "deltagru_tcnskip"),
+                                     ("deltagru_h24_th", "deltagru"), ("tres_h30_th", "deltagru_tcnskip")])
 def test_train_steps_follow_reference(name, bb):
     from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
     fx = Fixture(name)
@@ -145,3 +146,18 @@ def test_s16_cascade_config3_follows_reference(force_s16):
     from tests import test_cascade_gpu as casc
     casc.test_cascade_autograd_matches_reference("cascade_tres15_dgru23", "deltagru_tcnskip", "dgru")
     casc.test_cascade_fused_steps_follow_reference("cascade_tres15_dgru23", "deltagru_tcnskip", "dgru")
+
+
+# ---- hidden 17..32: two unit tiles of the S16 mapping, selected at every batch size ---------------------------------
+@pytest.mark.parametrize("bb,H,thx,thh", [("deltagru", 17, 0.0, 0.0), ("deltagru", 24, 0.01, 0.05), ("deltagru", 32, 0.02, 0.1),
+                                          ("deltagru_tcnskip", 23, 0.01, 0.05), ("deltagru_tcnskip", 32, 0.0, 0.0)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (17, 32), (7, 33), (5, 200), (66, 63)])
+def test_wide_hidden_against_oracle_ragged(bb, H, thx, thh, B, T):
+    test_against_oracle_ragged(bb, H, thx, thh, B, T)
+
+
+def test_hidden_above_32_is_refused_loudly():
+    from opendpd_amd import CoreModel
+    net = CoreModel(2, 33, 1, "deltagru").cuda()
+    with pytest.raises(RuntimeError):
+        net(torch.rand(2, 16, 2, device="cuda"))
