@@ -1,16 +1,26 @@
 // tcnn.hip — kernels for the TCNN backbone (backbones/tcnn.py:5-97):
 //   feat = [I,Q,a,a^3,sin,cos] -> Conv1d(6->C,k1,bias) -> Hardswish -> 4 x [depthwise Conv1d(C,C,k5,dil d,pad 2d,no bias)
 //   -> Hardswish], d = 1,2,4,8 -> Conv1d(C->2,k1,no bias);  y = net + [I,Q]                       (tcnn.py:82-96)
-// The network is separable per channel except for the last 1x1 sum, and non-recurrent: time is the parallel axis.
-//   forward : one workgroup per (sequence, time tile); thread = time step (tile + 32-step halo each side, receptive
-//             field 30); channels are looped INSIDE, two LDS line buffers per stage ping-pong, y accumulates in registers.
-//   backward: one workgroup per (channel, slice of the batch); for every sequence of the slice the five stages of that
-//             channel are recomputed into LDS, back-propagated, and the channel's 29 parameter gradients accumulate in
-//             per-thread registers; one block reduction at the end -> columns of partial row `slice`.
-//   dL/dx   : (frozen PA of a cascade) the forward tiling with a 64-step halo: dx[t] needs dL/d pre of the last stage at
-//             t +- 30, whose activations need x at +- 30 around them.  Channels are looped inside the workgroup, so the
-//             cross-channel sum sum_c gp0_c[t] W0[c][:] stays in six registers per thread: deterministic, no atomics.
-// Zero padding semantics: every stage's activation is 0 outside [0,T) (PyTorch pads each conv input).
+// The network is separable per channel except for the two 1x1 convolutions, and non-recurrent.
+//
+// Register-resident time tiles: a 16-lane DPP row owns one sequence (a wave = 4 sequences), lane r of the row owns the
+// R consecutive steps [R r, R r + R) of a 16 R-step tile in registers.  A dilated tap at offset o of element i is
+// element (i + o) mod R of lane r + floor((i + o) / R): in-lane taps are plain FMAs, cross-lane taps are ONE
+// v_fmac_f32_dpp (row_shr / row_shl, bound_ctrl:0) — no LDS exchange, no barriers, and lanes outside the row read 0,
+// which IS the zero padding of the convolutions when the tile holds the whole frame (T <= 256: R = ceil(T/16) from
+// {4, 8, 13, 16}; T = 200 -> R = 13, 96 % of the slots carry a sample).  Longer frames use R = 16 tiles with a 30-step
+// halo each side (receptive-field radius 2 (1+2+4+8) = 30; 60 for dL/dx).  Every stage's activation is 0 outside [0,T)
+// (PyTorch pads each conv input): out-of-frame pre-activations are stored as -100, for which hardswish and its
+// derivative are both exactly 0.
+//   forward : wave = (4 sequences, channel subset); channels looped inside, y accumulates in registers; for small
+//             batches the channels of a tile are split over up to 4 waves of the workgroup (LDS sum of y).
+//   backward: wave = (4 sequences, channel subset) x loop over tiles; per channel the five stages are recomputed
+//             (pre-activations stay in registers), back-propagated, the 29 per-channel gradients are reduced over the
+//             wave and added to the wave's accumulator row in LDS; block sum -> partial row blockIdx.x.
+//   dL/dx   : (frozen PA of a cascade) as backward without the weight gradients; dL/dfeat accumulates in registers.
+#include <type_traits>
+#include <utility>
+
 #include "odpd_seq.h"
 
 namespace odpd {
@@ -24,325 +34,425 @@ __host__ __device__ inline TcnnLayout tcnn_layout(int C) {
     L.P = o;
     return L;
 }
-constexpr int kTHalo = 32;   // >= receptive-field radius 2*(1+2+4+8) = 30
+constexpr int kTHalo = 30;     // receptive-field radius 2 * (1 + 2 + 4 + 8)
+constexpr int kTHaloDx = 60;   // dx[t] needs dL/dpre at t +- 30, whose activations need x at +- 30 around them
 
-struct TcnnTile { int nthreads, tile, ntiles; };
-// forward: up to 16 waves per workgroup; backward (116 gradient accumulators per thread): up to 8 waves = 256 VGPRs
-inline TcnnTile tcnn_tiling(int T, int max_waves = 16) {
-    TcnnTile t;
-    const int cap = 64 * max_waves - 2 * kTHalo;
-    int want = (T < cap ? T : cap) + 2 * kTHalo;
-    int nw = (want + 63) / 64; if (nw > max_waves) nw = max_waves;
-    t.nthreads = 64 * nw; t.tile = t.nthreads - 2 * kTHalo; t.ntiles = (T + t.tile - 1) / t.tile;
-    return t;
+// tile geometry: B * ntiles row-sized work items (sequence-major), four of them per wave
+struct TcnnGeom { int R, halo, tile, ntiles, ngroups; };
+inline TcnnGeom tcnn_geom(int B, int T, int halo) {
+    TcnnGeom g;
+    if (T <= 256) { g.R = T <= 64 ? 4 : (T <= 128 ? 8 : (T <= 208 ? 13 : 16)); g.halo = 0; g.tile = 16 * g.R; g.ntiles = 1; }
+    else { g.R = 16; g.halo = halo; g.tile = 256 - 2 * halo; g.ntiles = (T + g.tile - 1) / g.tile; }
+    g.ngroups = (B * g.ntiles + 3) / 4;
+    return g;
 }
 
-__device__ __forceinline__ float hsg(float v) { return v < -3.0f ? 0.0f : (v <= 3.0f ? __builtin_fmaf(v, 1.0f / 3.0f, 0.5f) : 1.0f); }
-__device__ __forceinline__ float ldz(const float* buf, int i, int n) { return (i >= 0 && i < n) ? buf[i] : 0.0f; }
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-__device__ __forceinline__ void tcnn_feat(float2 xv, bool in, float (&f)[6]) {
-    if (!in) { f[0] = f[1] = f[2] = f[3] = f[4] = f[5] = 0.0f; return; }
-    const float a2 = __builtin_fmaf(xv.x, xv.x, xv.y * xv.y), a = __builtin_amdgcn_sqrtf(a2), ia = fast_rcp(a);
-    f[0] = xv.x; f[1] = xv.y; f[2] = a; f[3] = a2 * a; f[4] = xv.y * ia; f[5] = xv.x * ia;
+__device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); }
+// hardswish(v) = v relu6(v + 3) / 6 and its derivative (0 | v/3 + 1/2 on [-3, 3] | 1)
+__device__ __forceinline__ float hs_(float v) { return v * clamp01(__builtin_fmaf(v, 1.0f / 6.0f, 0.5f)); }
+__device__ __forceinline__ float hsg_(float v) {
+    const float u = __builtin_fmaf(v, 1.0f / 3.0f, 0.5f);
+    return __builtin_fabsf(v) <= 3.0f ? u : clamp01(u);
+}
+constexpr float kDead = -100.0f;   // pre-activation of an out-of-frame step: hs_ = hsg_ = 0
+
+constexpr int fdiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+// acc += w * (element I + OFF of the row's tile, 0 outside the row).  The compiler does not model hazards inside asm:
+// a DPP read of a VGPR written by one of the two previous VALU instructions needs 2 wait states -> s_nop 1.
+template <int R, int I, int OFF>
+__device__ __forceinline__ void tap(float& acc, const float (&v)[R], float w) {
+    constexpr int idx = I + OFF, S = fdiv(idx, R), E = idx - S * R;
+    if constexpr (S == 0) acc = __builtin_fmaf(w, v[E], acc);
+    else if constexpr (S > 0 && S < 16)
+        asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_shl:%3 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(v[E]), "v"(w), "n"(S));
+    else if constexpr (S < 0 && S > -16)
+        asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_shr:%3 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(acc) : "v"(v[E]), "v"(w), "n"(-S));
+}
+// out[i] = sum_k w[k] in[i + SIGN d (k - 2)]
+template <int R, int D, int SIGN>
+__device__ __forceinline__ void conv5(float (&out)[R], const float (&in)[R], const float (&w)[5]) {
+    static_for<R>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        float s = w[2] * in[i];
+        tap<R, i, -2 * D * SIGN>(s, in, w[0]);
+        tap<R, i, -D * SIGN>(s, in, w[1]);
+        tap<R, i, D * SIGN>(s, in, w[3]);
+        tap<R, i, 2 * D * SIGN>(s, in, w[4]);
+        out[i] = s;
+    });
+}
+// gw[k] += sum_i gp[i] in[i + d (k - 2)]
+template <int R, int D>
+__device__ __forceinline__ void conv5_wgrad(float (&gw)[5], const float (&gp)[R], const float (&in)[R]) {
+    static_for<R>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        tap<R, i, -2 * D>(gw[0], in, gp[i]);
+        tap<R, i, -D>(gw[1], in, gp[i]);
+        gw[2] = __builtin_fmaf(gp[i], in[i], gw[2]);
+        tap<R, i, D>(gw[3], in, gp[i]);
+        tap<R, i, 2 * D>(gw[4], in, gp[i]);
+    });
 }
 
-// Channels are processed kCG at a time: one workgroup barrier per stage serves kCG channels (the stage buffers
-// ping-pong, so the write of stage l never races with the reads of stage l-1), and x / dy / the features are loaded
-// and formed once per group instead of once per channel.
-constexpr int kCG = 1;
+// one channel's parameters (wave-uniform)
+struct TcnnChan { float w0[6], b0, dw[4][5], w5[2]; };
+__device__ __forceinline__ TcnnChan tcnn_chan(const float* __restrict__ p, const TcnnLayout& L, int c) {
+    TcnnChan k;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) k.w0[i] = p[L.o_w0 + c * 6 + i];
+    k.b0 = p[L.o_b0 + c];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) k.dw[l][j] = p[L.o_dw[l] + c * 5 + j];
+    k.w5[0] = p[L.o_w5 + c]; k.w5[1] = p[L.o_w5 + L.C + c];
+    return k;
+}
 
-// grid = (ntiles, B); block = nthreads; LDS = 2 * kCG * nthreads floats
-__global__ __launch_bounds__(1024) void tcnn_fwd_kernel(SeqArgs a, int tile) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int n = blockDim.x, pos = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * tile, t = t0 - kTHalo + pos;
-    const bool in = t >= 0 && t < a.T;
-    const TcnnLayout L = tcnn_layout(a.H);
-    const float* __restrict__ p = a.params;
-    const float2 xv = in ? reinterpret_cast<const float2*>(a.x)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
-    float f[6];
-    tcnn_feat(xv, in, f);
-    float y0 = 0.0f, y1 = 0.0f;
-    int flip = 0;
-    for (int c0 = 0; c0 < L.C; c0 += kCG) {
-        float act[kCG];
+// the row's tile: sequence b, element i of lane r at time t0 + i
+template <int R>
+struct TcnnTile {
+    int b, t0, own0, own1;   // [own0, own1): steps this tile writes y / dx for and reads dy of (weight gradients)
+    bool bok;
+    float xi[R], xq[R], am[R], ia[R];
+    bool valid[R];
+    __device__ __forceinline__ void locate(const SeqArgs& a, const TcnnGeom& g, int grp, bool active, int lane) {
+        const int r = lane & 15, item = grp * 4 + (lane >> 4), ti = item % g.ntiles;
+        b = item / g.ntiles; bok = active && b < a.B;
+        own0 = ti * g.tile; own1 = min(own0 + g.tile, a.T);
+        t0 = own0 - g.halo + R * r;
+    }
+    __device__ __forceinline__ void load_x(const SeqArgs& a) {
+        const float2* x2 = reinterpret_cast<const float2*>(a.x) + (size_t)(bok ? b : 0) * a.T;
 #pragma unroll
-        for (int j = 0; j < kCG; ++j) {
-            const int c = min(c0 + j, L.C - 1);
-            float v = p[L.o_b0 + c];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
-            act[j] = in ? hardswishf_(v) : 0.0f;
-        }
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            const int d = 1 << l;
-            float* buf = smem + (flip ^= 1) * kCG * n;
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) buf[j * n + pos] = act[j];
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) {
-                const int c = min(c0 + j, L.C - 1);
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(buf + j * n, pos + d * (k - 2), n), s);
-                act[j] = in ? hardswishf_(s) : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kCG; ++j) {
-            if (c0 + j < L.C) {
-                y0 = __builtin_fmaf(p[L.o_w5 + c0 + j], act[j], y0);
-                y1 = __builtin_fmaf(p[L.o_w5 + L.C + c0 + j], act[j], y1);
-            }
+        for (int i = 0; i < R; ++i) {
+            const int t = t0 + i;
+            valid[i] = bok && t >= 0 && t < a.T;
+            const float2 v = valid[i] ? x2[t] : make_float2(1.0f, 0.0f);
+            xi[i] = v.x; xq[i] = v.y;
+            const float a2 = __builtin_fmaf(v.x, v.x, v.y * v.y);
+            am[i] = __builtin_amdgcn_sqrtf(a2); ia[i] = fast_rcp(am[i]);
         }
     }
-    if (in && pos >= kTHalo && pos < kTHalo + tile)
-        reinterpret_cast<float2*>(a.y)[(size_t)b * a.T + t] = make_float2(y0 + xv.x, y1 + xv.y);
+    // pre-activation of the 1x1 input conv; out-of-frame steps are dead
+    __device__ __forceinline__ float pre0(const TcnnChan& k, int i) const {
+        float v = __builtin_fmaf(k.w0[0], xi[i], k.b0);
+        v = __builtin_fmaf(k.w0[1], xq[i], v);
+        v = __builtin_fmaf(k.w0[2], am[i], v);
+        v = __builtin_fmaf(k.w0[3], am[i] * am[i] * am[i], v);
+        v = __builtin_fmaf(k.w0[4], xq[i] * ia[i], v);
+        v = __builtin_fmaf(k.w0[5], xi[i] * ia[i], v);
+        return valid[i] ? v : kDead;
+    }
+    __device__ __forceinline__ bool owns(int i) const { return valid[i] && t0 + i >= own0 && t0 + i < own1; }
+};
+
+// forward of one channel; pre[l] = pre-activation of stage l (0: input conv, 1..4: depthwise), returns act of stage 4
+template <int R, bool KEEP>
+__device__ __forceinline__ void tcnn_chan_fwd(const TcnnTile<R>& tl, const TcnnChan& k, float (&pre)[5][R], float (&act)[R]) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const float v = tl.pre0(k, i);
+        if constexpr (KEEP) pre[0][i] = v;
+        act[i] = hs_(v);
+    }
+    static_for<4>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        float s[R];
+        conv5<R, 1 << l, 1>(s, act, k.dw[l]);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float v = tl.valid[i] ? s[i] : kDead;
+            if constexpr (KEEP) pre[l + 1][i] = v;
+            act[i] = hs_(v);
+        }
+    });
 }
 
-// grid = (ceil(C / kCG), nslices); block = nthreads; LDS = 6 * kCG * nthreads floats (4 stage inputs kept for the
-// weight gradients + 2 ping-pong exchange buffers), re-used as reduction scratch at the end
-__global__ __launch_bounds__(512) void tcnn_bwd_kernel(SeqArgs a, int tile, int ntiles, int nslices) {
+// grid = ceil(ngroups * ncw / 4) blocks of 4 waves; ncw in {1, 2, 4} waves share a tile's channels (wave j takes
+// channels j, j + ncw, ...); LDS = 4 * 2R * 64 floats when ncw > 1
+template <int R>
+__global__ __launch_bounds__(256) void tcnn_fwd_kernel(SeqArgs a, TcnnGeom g, int ncw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int n = blockDim.x, pos = threadIdx.x, c0 = blockIdx.x * kCG, slice = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const TcnnLayout L = tcnn_layout(a.H);
-    const float* __restrict__ p = a.params;
-    float* act = smem;                    // act[(l * kCG + j) * n + pos], l = 0..3: inputs of the depthwise stages
-    float* xch = smem + 4 * kCG * n;      // two exchange buffers of kCG * n
-    float gacc[kCG][29];
+    const int gw = blockIdx.x * 4 + wave, grp = gw / ncw, cs = gw % ncw;
+    TcnnTile<R> tl;
+    tl.locate(a, g, grp, grp < g.ngroups, lane);
+    tl.load_x(a);
+    float y0[R], y1[R];
 #pragma unroll
-    for (int j = 0; j < kCG; ++j)
+    for (int i = 0; i < R; ++i) y0[i] = y1[i] = 0.0f;
+    for (int c = cs; c < L.C; c += ncw) {
+        const TcnnChan k = tcnn_chan(a.params, L, c);
+        float pre[5][R], act[R];
+        tcnn_chan_fwd<R, false>(tl, k, pre, act);
 #pragma unroll
-        for (int i = 0; i < 29; ++i) gacc[j][i] = 0.0f;
-
-    const int nwork = a.B * ntiles;
-    for (int wk = slice; wk < nwork; wk += nslices) {
-        const int b = wk / ntiles, t0 = (wk % ntiles) * tile, t = t0 - kTHalo + pos;
-        const bool in = t >= 0 && t < a.T, own = in && pos >= kTHalo && pos < kTHalo + tile;
-        const float2 xv = in ? reinterpret_cast<const float2*>(a.x)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
-        const float2 dyv = own ? reinterpret_cast<const float2*>(a.dy)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
-        float f[6];
-        tcnn_feat(xv, in, f);
-        float pre[kCG][5], cur[kCG];
-        __syncthreads();   // the previous work item is done with every buffer
-        // forward of the group's channels; act_l stays in LDS, the thread keeps its own pre-activations
-#pragma unroll
-        for (int j = 0; j < kCG; ++j) {
-            const int c = min(c0 + j, L.C - 1);
-            float v = p[L.o_b0 + c];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
-            pre[j][0] = v;
-            cur[j] = in ? hardswishf_(v) : 0.0f;
-        }
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            const int d = 1 << l;
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) act[(l * kCG + j) * n + pos] = cur[j];
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) {
-                const int c = min(c0 + j, L.C - 1);
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(act + (l * kCG + j) * n, pos + d * (k - 2), n), s);
-                pre[j][l + 1] = s;
-                cur[j] = in ? hardswishf_(s) : 0.0f;
-            }
-        }
-        // backward.  g = dL/d act_l ; gp = dL/d pre_l (masked outside the frame)
-        float g[kCG];
-#pragma unroll
-        for (int j = 0; j < kCG; ++j) {
-            const int c = min(c0 + j, L.C - 1);
-            gacc[j][27] = __builtin_fmaf(dyv.x, cur[j], gacc[j][27]);
-            gacc[j][28] = __builtin_fmaf(dyv.y, cur[j], gacc[j][28]);
-            g[j] = __builtin_fmaf(dyv.x, p[L.o_w5 + c], dyv.y * p[L.o_w5 + L.C + c]);
-        }
-#pragma unroll
-        for (int l = 3; l >= 0; --l) {
-            const int d = 1 << l;
-            float* ex = xch + (l & 1) * kCG * n;
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) {
-                const float gp = in ? g[j] * hsg(pre[j][l + 1]) : 0.0f;
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    gacc[j][7 + l * 5 + k] = __builtin_fmaf(gp, ldz(act + (l * kCG + j) * n, pos + d * (k - 2), n), gacc[j][7 + l * 5 + k]);
-                ex[j * n + pos] = gp;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) {
-                const int c = min(c0 + j, L.C - 1);
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(ex + j * n, pos - d * (k - 2), n), s);
-                g[j] = s;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kCG; ++j) {
-            const float gp0 = in ? g[j] * hsg(pre[j][0]) : 0.0f;
-            gacc[j][6] += gp0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) gacc[j][i] = __builtin_fmaf(gp0, f[i], gacc[j][i]);
+        for (int i = 0; i < R; ++i) {
+            y0[i] = __builtin_fmaf(k.w5[0], act[i], y0[i]);
+            y1[i] = __builtin_fmaf(k.w5[1], act[i], y1[i]);
         }
     }
-    // block reduction of the 29 accumulators of every channel of the group -> partial row `slice`
+    if (ncw > 1) {     // sum the channel subsets of the tile in wave order (deterministic)
+        float* mine = smem + wave * (2 * R * 64);
+#pragma unroll
+        for (int i = 0; i < R; ++i) { mine[(2 * i) * 64 + lane] = y0[i]; mine[(2 * i + 1) * 64 + lane] = y1[i]; }
+        __syncthreads();
+        if (cs != 0) return;
+        for (int j = 1; j < ncw; ++j) {
+            const float* o = smem + (wave + j) * (2 * R * 64);
+#pragma unroll
+            for (int i = 0; i < R; ++i) { y0[i] += o[(2 * i) * 64 + lane]; y1[i] += o[(2 * i + 1) * 64 + lane]; }
+        }
+    }
+    float2* y2 = reinterpret_cast<float2*>(a.y) + (size_t)(tl.bok ? tl.b : 0) * a.T;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        if (tl.owns(i)) y2[tl.t0 + i] = make_float2(y0[i] + tl.xi[i], y1[i] + tl.xq[i]);     // + residual [I, Q]
+}
+
+// back-propagation of one channel from g = dL/d act_4 down to gp0 = dL/d pre_0; GW: accumulate the weight gradients
+template <int R, bool GW>
+__device__ __forceinline__ void tcnn_chan_bwd(const TcnnChan& k, const float (&pre)[5][R], float (&g)[R], float (&gdw)[4][5]) {
+    static_for<4>([&](auto lc) {
+        constexpr int l = 3 - decltype(lc)::value;
+        float gp[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) gp[i] = g[i] * hsg_(pre[l + 1][i]);
+        if constexpr (GW) {
+            float in[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) in[i] = hs_(pre[l][i]);
+            conv5_wgrad<R, 1 << l>(gdw[l], gp, in);
+        }
+        conv5<R, 1 << l, -1>(g, gp, k.dw[l]);
+    });
+#pragma unroll
+    for (int i = 0; i < R; ++i) g[i] *= hsg_(pre[0][i]);
+}
+
+// gradient j of the channel: its sum over the row's 16 lanes is deposited on lane j & 15 of the row (A: j < 16, B: j >= 16)
+template <int J>
+__device__ __forceinline__ void tcnn_deposit(float v, int r, float& depA, float& depB) {
+    const float s = row_sum16(v);
+    if constexpr (J < 16) depA = r == J ? s : depA;
+    else depB = r == J - 16 ? s : depB;
+}
+// column of gradient j (0..5 w0, 6 b0, 7..26 depthwise taps, 27..28 w5) of channel c in the parameter row
+__device__ __forceinline__ int tcnn_col(const TcnnLayout& L, int c, int j) {
+    if (j < 6) return L.o_w0 + c * 6 + j;
+    if (j == 6) return L.o_b0 + c;
+    if (j < 27) return L.o_dw[0] + ((j - 7) / 5) * 5 * L.C + c * 5 + (j - 7) % 5;
+    return L.o_w5 + (j - 27) * L.C + c;
+}
+
+// grid = rows blocks of 4 waves; wave gw works on tiles gw / ncw, + nwaves / ncw, ... and channels gw % ncw, + ncw, ...
+// LDS per wave: accumulator row of P floats + the tile's dy (R float2 per lane, [i][lane]: conflict-free ds_read_b64)
+template <int R>
+__global__ __launch_bounds__(256, R <= 13 ? 2 : 1) void tcnn_bwd_kernel(SeqArgs a, TcnnGeom g, int ncw) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15;
+    const TcnnLayout L = tcnn_layout(a.H);
+    const int Pp = pad4(L.P);
+    float* row = smem + wave * Pp;
+    float2* dyl = reinterpret_cast<float2*>(smem + 4 * Pp) + wave * (R * 64) + lane;
+    for (int i = lane; i < L.P; i += 64) row[i] = 0.0f;
+    const int gw = blockIdx.x * 4 + wave, cs = gw % ncw, gstep = gridDim.x * 4 / ncw;
+    for (int grp = gw / ncw; grp < g.ngroups; grp += gstep) {
+        TcnnTile<R> tl;
+        tl.locate(a, g, grp, true, lane);
+        tl.load_x(a);
+        {
+            const float2* d2 = reinterpret_cast<const float2*>(a.dy) + (size_t)(tl.bok ? tl.b : 0) * a.T;
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < R; ++i) dyl[i * 64] = tl.owns(i) ? d2[tl.t0 + i] : make_float2(0.0f, 0.0f);
+            wave_lds_fence();
+        }
+        for (int c = cs; c < L.C; c += ncw) {
+            const TcnnChan k = tcnn_chan(a.params, L, c);
+            float pre[5][R], act[R], gg[R], gdw[4][5], gw5[2] = {0.0f, 0.0f};
+            tcnn_chan_fwd<R, true>(tl, k, pre, act);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) gdw[l][j] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const float2 dy = dyl[i * 64];
+                gw5[0] = __builtin_fmaf(dy.x, act[i], gw5[0]);
+                gw5[1] = __builtin_fmaf(dy.y, act[i], gw5[1]);
+                gg[i] = __builtin_fmaf(dy.x, k.w5[0], dy.y * k.w5[1]);
+            }
+            tcnn_chan_bwd<R, true>(k, pre, gg, gdw);
+            float gw0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gb0 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const float gp0 = gg[i];
+                gb0 += gp0;
+                gw0[0] = __builtin_fmaf(gp0, tl.xi[i], gw0[0]);
+                gw0[1] = __builtin_fmaf(gp0, tl.xq[i], gw0[1]);
+                gw0[2] = __builtin_fmaf(gp0, tl.am[i], gw0[2]);
+                gw0[3] = __builtin_fmaf(gp0, tl.am[i] * tl.am[i] * tl.am[i], gw0[3]);
+                gw0[4] = __builtin_fmaf(gp0, tl.xq[i] * tl.ia[i], gw0[4]);
+                gw0[5] = __builtin_fmaf(gp0, tl.xi[i] * tl.ia[i], gw0[5]);
+            }
+            // row sums deposited on lanes 0..15 (A) / 0..12 (B) of every row, then the four rows add to the wave's
+            // accumulator row one after the other (LDS operations of a wave execute in order: fixed summation order)
+            float depA = 0.0f, depB = 0.0f;
+            static_for<6>([&](auto jc) { tcnn_deposit<decltype(jc)::value>(gw0[decltype(jc)::value], r, depA, depB); });
+            tcnn_deposit<6>(gb0, r, depA, depB);
+            static_for<20>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                tcnn_deposit<7 + j>(gdw[j / 5][j % 5], r, depA, depB);
+            });
+            tcnn_deposit<27>(gw5[0], r, depA, depB);
+            tcnn_deposit<28>(gw5[1], r, depA, depB);
+            const int colA = tcnn_col(L, c, r), colB = tcnn_col(L, c, 16 + (r < 13 ? r : 12));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((lane >> 4) == q) {
+                    atomicAdd(&row[colA], depA);
+                    if (r < 13) atomicAdd(&row[colB], depB);
+                }
+        }
+    }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int j = 0; j < kCG; ++j)
-#pragma unroll
-        for (int i = 0; i < 29; ++i) {
-            float s = gacc[j][i];
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-            if (lane == 0) smem[(wave * kCG + j) * 32 + i] = s;
-        }
-    __syncthreads();
-    if (threadIdx.x < kCG * 32) {
-        const int j = threadIdx.x >> 5, i = threadIdx.x & 31, c = c0 + j;
-        if (i < 29 && c < L.C) {
-            float s = 0.0f;
-            for (int wv = 0; wv < nw; ++wv) s += smem[(wv * kCG + j) * 32 + i];
-            int col;
-            if (i < 6) col = L.o_w0 + c * 6 + i;
-            else if (i == 6) col = L.o_b0 + c;
-            else if (i < 27) col = L.o_dw[(i - 7) / 5] + c * 5 + (i - 7) % 5;
-            else col = L.o_w5 + (i - 27) * L.C + c;
-            a.partials[(size_t)slice * (L.P + kLossCols) + col] = s;
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x < kLossCols) a.partials[(size_t)slice * (L.P + kLossCols) + L.P + threadIdx.x] = 0.0f;
+    float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
+    for (int i = threadIdx.x; i < L.P + kLossCols; i += blockDim.x)
+        prow[i] = i < L.P ? (smem[i] + smem[Pp + i]) + (smem[2 * Pp + i] + smem[3 * Pp + i]) : 0.0f;
 }
 
-// grid = (ntiles, B); block = nthreads (tile + 64-step halo each side); LDS = 2 * kCG * nthreads floats
-constexpr int kTHaloDx = 64;
-__global__ __launch_bounds__(1024) void tcnn_dx_kernel(SeqArgs a, int tile) {
+// grid as the forward; dy is read over the whole tile (halo included); LDS = 4 * 6R * 64 floats when ncw > 1
+template <int R>
+__global__ __launch_bounds__(256, 1) void tcnn_dx_kernel(SeqArgs a, TcnnGeom g, int ncw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int n = blockDim.x, pos = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * tile, t = t0 - kTHaloDx + pos;
-    const bool in = t >= 0 && t < a.T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const TcnnLayout L = tcnn_layout(a.H);
-    const float* __restrict__ p = a.params;
-    const float2 xv = in ? reinterpret_cast<const float2*>(a.x)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
-    const float2 dyv = in ? reinterpret_cast<const float2*>(a.dy)[(size_t)b * a.T + t] : make_float2(0.f, 0.f);
-    float f[6], df[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    tcnn_feat(xv, in, f);
-    int flip = 0;
-    for (int c0 = 0; c0 < L.C; c0 += kCG) {
-        // forward of the group; the thread keeps its own pre-activations of the five stages
-        float pre[kCG][5], cur[kCG];
+    const int gw = blockIdx.x * 4 + wave, grp = gw / ncw, cs = gw % ncw;
+    TcnnTile<R> tl;
+    tl.locate(a, g, grp, grp < g.ngroups, lane);
+    tl.load_x(a);
+    float dy0[R], dy1[R], df[6][R];
+    {
+        const float2* d2 = reinterpret_cast<const float2*>(a.dy) + (size_t)(tl.bok ? tl.b : 0) * a.T;
 #pragma unroll
-        for (int j = 0; j < kCG; ++j) {
-            const int c = min(c0 + j, L.C - 1);
-            float v = p[L.o_b0 + c];
+        for (int i = 0; i < R; ++i) {
+            const float2 v = tl.valid[i] ? d2[tl.t0 + i] : make_float2(0.0f, 0.0f);
+            dy0[i] = v.x; dy1[i] = v.y;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) v = __builtin_fmaf(p[L.o_w0 + c * 6 + i], f[i], v);
-            pre[j][0] = v;
-            cur[j] = in ? hardswishf_(v) : 0.0f;
-        }
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            const int d = 1 << l;
-            float* buf = smem + (flip ^= 1) * kCG * n;
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) buf[j * n + pos] = cur[j];
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) {
-                const int c = min(c0 + j, L.C - 1);
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(buf + j * n, pos + d * (k - 2), n), s);
-                pre[j][l + 1] = s;
-                cur[j] = in ? hardswishf_(s) : 0.0f;
-            }
-        }
-        // backward of the group down to the features
-        float g[kCG];
-#pragma unroll
-        for (int j = 0; j < kCG; ++j) {
-            const int c = min(c0 + j, L.C - 1);
-            g[j] = c0 + j < L.C ? __builtin_fmaf(dyv.x, p[L.o_w5 + c], dyv.y * p[L.o_w5 + L.C + c]) : 0.0f;
-        }
-#pragma unroll
-        for (int l = 3; l >= 0; --l) {
-            const int d = 1 << l;
-            float* buf = smem + (flip ^= 1) * kCG * n;
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) buf[j * n + pos] = in ? g[j] * hsg(pre[j][l + 1]) : 0.0f;
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < kCG; ++j) {
-                const int c = min(c0 + j, L.C - 1);
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) s = __builtin_fmaf(p[L.o_dw[l] + c * 5 + k], ldz(buf + j * n, pos - d * (k - 2), n), s);
-                g[j] = s;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kCG; ++j) {
-            const int c = min(c0 + j, L.C - 1);
-            const float gp0 = in ? g[j] * hsg(pre[j][0]) : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) df[i] = __builtin_fmaf(gp0, p[L.o_w0 + c * 6 + i], df[i]);
+            for (int j = 0; j < 6; ++j) df[j][i] = 0.0f;
         }
     }
-    if (in && pos >= kTHaloDx && pos < kTHaloDx + tile) {
-        float dI, dQ;
-        feat_bwd<FEAT_DGRU6>(xv.x, xv.y, df, dI, dQ);
-        reinterpret_cast<float2*>(a.dx)[(size_t)b * a.T + t] = make_float2(dI + dyv.x, dQ + dyv.y);   // + residual path
+    for (int c = cs; c < L.C; c += ncw) {
+        const TcnnChan k = tcnn_chan(a.params, L, c);
+        float pre[5][R], act[R], gg[R], gdw[4][5];
+        tcnn_chan_fwd<R, true>(tl, k, pre, act);
+#pragma unroll
+        for (int i = 0; i < R; ++i) gg[i] = __builtin_fmaf(dy0[i], k.w5[0], dy1[i] * k.w5[1]);
+        tcnn_chan_bwd<R, false>(k, pre, gg, gdw);
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) df[j][i] = __builtin_fmaf(gg[i], k.w0[j], df[j][i]);
     }
-}
-struct TcnnTileDx { int nthreads, tile, ntiles; };
-inline TcnnTileDx tcnn_tiling_dx(int T) {
-    TcnnTileDx t;
-    int want = (T < 896 ? T : 896) + 2 * kTHaloDx;
-    int nw = (want + 63) / 64; if (nw > 16) nw = 16;
-    t.nthreads = 64 * nw; t.tile = t.nthreads - 2 * kTHaloDx; t.ntiles = (T + t.tile - 1) / t.tile;
-    return t;
+    if (ncw > 1) {
+        float* mine = smem + wave * (6 * R * 64);
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) mine[(6 * i + j) * 64 + lane] = df[j][i];
+        __syncthreads();
+        if (cs != 0) return;
+        for (int w = 1; w < ncw; ++w) {
+            const float* o = smem + (wave + w) * (6 * R * 64);
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) df[j][i] += o[(6 * i + j) * 64 + lane];
+        }
+    }
+    float2* dx2 = reinterpret_cast<float2*>(a.dx) + (size_t)(tl.bok ? tl.b : 0) * a.T;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        if (tl.owns(i)) {
+            float d6[6], dI, dQ;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d6[j] = df[j][i];
+            feat_bwd<FEAT_DGRU6>(tl.xi[i], tl.xq[i], d6, dI, dQ);
+            dx2[tl.t0 + i] = make_float2(dI + dy0[i], dQ + dy1[i]);   // + residual path
+        }
 }
 
-static int tcnn_slices(int B, int ntiles, int C) {
-    const int nwork = B * ntiles, ngrp = (C + kCG - 1) / kCG;
-    int want = (8 * device_cus() + ngrp - 1) / ngrp;     // ~8 blocks per CU overall
-    if (want < 1) want = 1;
-    return nwork < want ? nwork : want;
+// ---- host side -------------------------------------------------------------------------------------------------
+// channel split: the smallest power of two that puts >= 8 waves on every CU, capped at `cap`
+static int tcnn_split(int ngroups, int cap) {
+    const int want = 8 * device_cus();
+    int ncw = 1;
+    while (ncw < cap && ngroups * ncw < want) ncw *= 2;
+    return ncw;
+}
+struct TcnnBwdShape { int ncw, grid; };
+static TcnnBwdShape tcnn_bwd_shape(const TcnnGeom& g) {
+    TcnnBwdShape s;
+    s.ncw = tcnn_split(g.ngroups, 32);
+    const long waves = (long)g.ngroups * s.ncw;
+    long grid = (waves + 3) / 4;
+    const long cap = 2L * device_cus();
+    if (grid > cap) grid = cap;
+    s.grid = (int)((grid + 7) / 8 * 8);          // 4 * grid is a multiple of every ncw
+    return s;
+}
+template <int R>
+static int tcnn_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int mode) {
+    const int P = tcnn_layout(m->hidden).P;
+    if (mode == 0) {
+        const TcnnGeom g = tcnn_geom(a.B, a.T, kTHalo);
+        const int ncw = tcnn_split(g.ngroups, 4);
+        hipLaunchKernelGGL(tcnn_fwd_kernel<R>, dim3((g.ngroups * ncw + 3) / 4), dim3(256), ncw > 1 ? 4 * 2 * R * 64 * sizeof(float) : 0, st, a, g, ncw);
+    } else if (mode == 1) {
+        const TcnnGeom g = tcnn_geom(a.B, a.T, kTHalo);
+        const TcnnBwdShape s = tcnn_bwd_shape(g);
+        hipLaunchKernelGGL(tcnn_bwd_kernel<R>, dim3(s.grid), dim3(256), ((size_t)4 * pad4(P) + (size_t)4 * 2 * R * 64) * sizeof(float), st, a, g, s.ncw);
+    } else {
+        const TcnnGeom g = tcnn_geom(a.B, a.T, kTHaloDx);
+        const int ncw = tcnn_split(g.ngroups, 4);
+        const size_t lds = ncw > 1 ? (size_t)4 * 6 * R * 64 * sizeof(float) : 0;
+        auto k = tcnn_dx_kernel<R>;
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3((g.ngroups * ncw + 3) / 4), dim3(256), lds, st, a, g, ncw);
+    }
+    return (int)hipGetLastError();
+}
+static int tcnn_dispatch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int mode) {
+    switch (tcnn_geom(a.B, a.T, kTHalo).R) {
+    case 4: return tcnn_launch<4>(st, m, a, mode);
+    case 8: return tcnn_launch<8>(st, m, a, mode);
+    case 13: return tcnn_launch<13>(st, m, a, mode);
+    default: return tcnn_launch<16>(st, m, a, mode);
+    }
 }
 
 int tcnn_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
-    const TcnnTile tl = tcnn_tiling(a.T);
-    hipLaunchKernelGGL(tcnn_fwd_kernel, dim3(tl.ntiles, a.B), dim3(tl.nthreads), 2 * kCG * tl.nthreads * sizeof(float), st, a, tl.tile);
-    return (int)hipGetLastError();
+    return tcnn_dispatch(st, m, a, 0);
 }
 int tcnn_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
     if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
-    if (a.partials != nullptr) {
-        const TcnnTile tl = tcnn_tiling(a.T, 8);
-        const int ns = tcnn_slices(a.B, tl.ntiles, m->hidden);
-        size_t lds = (size_t)6 * kCG * tl.nthreads * sizeof(float);
-        if (lds < (size_t)16 * kCG * 32 * sizeof(float)) lds = (size_t)16 * kCG * 32 * sizeof(float);
-        auto kb = tcnn_bwd_kernel;
-        if (int e = allow_big_lds(kb, lds)) return e;
-        hipLaunchKernelGGL(kb, dim3((m->hidden + kCG - 1) / kCG, ns), dim3(tl.nthreads), lds, st, a, tl.tile, tl.ntiles, ns);
-        if (int e = (int)hipGetLastError()) return e;
-    }
-    if (a.dx != nullptr) {
-        const TcnnTileDx td = tcnn_tiling_dx(a.T);
-        hipLaunchKernelGGL(tcnn_dx_kernel, dim3(td.ntiles, a.B), dim3(td.nthreads), 2 * kCG * td.nthreads * sizeof(float), st, a, td.tile);
-    }
-    return (int)hipGetLastError();
+    if (a.partials != nullptr)
+        if (int e = tcnn_dispatch(st, m, a, 1)) return e;
+    if (a.dx != nullptr) return tcnn_dispatch(st, m, a, 2);
+    return 0;
 }
 int tcnn_rows(const odpd_model_t* m, int B, int T) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
-    return tcnn_slices(B, tcnn_tiling(T, 8).ntiles, m->hidden);
+    return tcnn_bwd_shape(tcnn_geom(B, T, kTHalo)).grid;
 }
 
 }  // namespace odpd

@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--big", type=int, default=32768)
 ap.add_argument("--T", type=int, default=200)
 ap.add_argument("--out", default=None)
+ap.add_argument("--only", default=None, help="comma-separated backbone names (skips the cascade row)")
 a = ap.parse_args()
 T = a.T
 
@@ -40,7 +41,10 @@ CASES = [("gru", 11, {}), ("dgru", 13, {}), ("dgru", 23, {}), ("qgru", 10, {}), 
          ("deltagru", 15, dict(thx=0.01, thh=0.05)), ("deltagru_tcnskip", 15, dict(thx=0.01, thh=0.05)), ("pgjanet", 11, {}),
          ("tcnn", 35, {}), ("qgru W8A8 (QAT)", 10, dict(qat=(8, 8))), ("qgru_amp1 W8A8 (QAT)", 10, dict(qat=(8, 8)))]
 rows = []
+only = a.only.split(",") if a.only else None
 for bb, H, kw in CASES:
+    if only and bb.split()[0] not in only:
+        continue
     torch.manual_seed(0)
     qat = kw.pop("qat", None)
     net = CoreModel(2, H, 1, bb.split()[0], **kw)
@@ -62,6 +66,10 @@ for bb, H, kw in CASES:
     rows.append((f"{bb} H{H}", P, kind, *cells))
 # train_dpd cascade of BASELINE config 3
 torch.manual_seed(0)
+if only:
+    for r in rows:
+        print(r)
+    raise SystemExit(0)
 casc = CascadedModel(dpd_model=CoreModel(2, 15, 1, "deltagru_tcnskip", thx=0.01, thh=0.05), pa_model=CoreModel(2, 23, 1, "dgru"))
 casc.freeze_pa_model()
 casc = casc.cuda()
