@@ -396,7 +396,7 @@ __device__ __forceinline__ void s16n_write_row(float* prow, const GruLayout& L, 
 // MODE 0: fused train (x, target -> partials; checkpoints in `ckpt` workspace)   1: forward (y, optional ckpt)
 // MODE 2: backward from dy (partials if NW, dx if DX)
 template <int FM, bool DG, int NT, int MODE, bool NW, bool DX>
-__global__ __launch_bounds__(256, 1) void gru16n_kernel(SeqArgs a) {
+__global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArgs a) {
     using T = S16N<NT>;
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
     constexpr int kGroups = (MODE == 2 && DX) ? T::NG_DX : T::NG;
@@ -565,7 +565,12 @@ int64_t gru_s16n_ckpt_floats(const odpd_model_t* m, int B, int T) {
 template <int FM, bool DG, int NT, int MODE, bool NW, bool DX>
 static int launch_s16n(hipStream_t st, const SeqArgs& a, int P) {
     using T = S16N<NT>;
-    LaunchShape ls = s16n_shape(a.ngroups);     // the grid (= rows of partials) never depends on the mode
+    LaunchShape ls = s16n_shape(a.ngroups);     // the grid (= rows of partials) never depends on the backward's flavour
+    if (MODE == 1) {                            // forward: small state, two waves per SIMD
+        ls.waves = 8;
+        const int need = (a.ngroups + 7) / 8, cap = device_cus();
+        ls.grid = need < cap ? need : cap;
+    }
     const int groups = (MODE == 2 && DX) ? T::NG_DX : T::NG;
     const int wave_floats = (MODE == 2 && DX ? 3 : 2) * 2 * 16 * kChunkPad + ((MODE != 1 && NW) ? T::kTiles * kTileFloats : 0);
     auto bytes = [&](int waves) {
