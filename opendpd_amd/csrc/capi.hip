@@ -96,7 +96,10 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     case FAM_DELTA:
         if (delta_uses_s16(m, B)) return delta_s16_ckpt_floats(m, B, T);
         return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 7 * 64 : (int64_t)ODPD_EUNSUPPORTED;
-    case FAM_JANET: case FAM_QAT: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 64 : (int64_t)ODPD_EUNSUPPORTED;
+    case FAM_JANET:
+        if (janet_uses_s16(m, B)) return janet_s16_ckpt_floats(m, B, T);
+        return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 64 : (int64_t)ODPD_EUNSUPPORTED;
+    case FAM_QAT: return R == 1 ? (int64_t)num_groups(B, 1) * num_ckpt(T) * 64 : (int64_t)ODPD_EUNSUPPORTED;
     default: return ODPD_EUNSUPPORTED;
     }
 }

@@ -11,18 +11,6 @@
 
 namespace odpd {
 
-struct JanetLayout { int H, o_wa, o_ba, o_wp1, o_bp1, o_wp2, o_bp2, o_wf, o_bf, o_wg, o_bg, o_wo, o_bo, P; };
-__host__ __device__ inline JanetLayout janet_layout(int H) {
-    JanetLayout L; L.H = H; int o = 0;
-    L.o_wa = o; o += H * (H + 1); L.o_ba = o; o += H;
-    L.o_wp1 = o; o += H * (H + 1); L.o_bp1 = o; o += H;
-    L.o_wp2 = o; o += H * (H + 1); L.o_bp2 = o; o += H;
-    L.o_wf = o; o += 2 * H * H; L.o_bf = o; o += H;
-    L.o_wg = o; o += 2 * H * H; L.o_bg = o; o += H;
-    L.o_wo = o; o += 2 * H; L.o_bo = o; o += 2;
-    L.P = o;
-    return L;
-}
 // table rows: 0 a_h, 1 p1_h, 2 p2_h, 3 f_h, 4 g_h, 5 f_u, 6 g_u; +7 = transposed
 constexpr int kJRows = 14, kJTabFloats = kJRows * 4 * 64 * 4;
 
@@ -312,6 +300,7 @@ static LaunchShape janet_bwd_shape(int ngroups) { return persistent_shape(ngroup
 
 int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (janet_uses_s16(m, a.B)) return janet_s16_launch(st, m, a, 1);
     const int P = janet_layout(m->hidden).P;
     const LaunchShape ls = persistent_shape(a.ngroups, 16);
     const size_t lds = janet_lds_bytes(P, ls.waves, false);
@@ -322,6 +311,7 @@ int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 }
 int janet_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (janet_uses_s16(m, a.B)) return janet_s16_launch(st, m, a, 2);
     const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
     if (!nw && !dx) return ODPD_EINVAL;
     const int P = janet_layout(m->hidden).P;
@@ -338,6 +328,7 @@ int janet_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 }
 int janet_family_rows(const odpd_model_t* m, int B) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (janet_uses_s16(m, B)) return janet_s16_rows(m, B);
     return janet_bwd_shape(num_groups(B, 1)).grid;
 }
 

@@ -177,9 +177,27 @@ bool delta_uses_s16(const odpd_model_t* m, int B);
 int delta_s16_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
 int delta_s16_rows(const odpd_model_t* m, int B);
 int64_t delta_s16_ckpt_floats(const odpd_model_t* m, int B, int T);
+// parameter layout of PGJANET (pgjanet.py:14-31)
+struct JanetLayout { int H, o_wa, o_ba, o_wp1, o_bp1, o_wp2, o_bp2, o_wf, o_bf, o_wg, o_bg, o_wo, o_bo, P; };
+__host__ __device__ inline JanetLayout janet_layout(int H) {
+    JanetLayout L; L.H = H; int o = 0;
+    L.o_wa = o; o += H * (H + 1); L.o_ba = o; o += H;
+    L.o_wp1 = o; o += H * (H + 1); L.o_bp1 = o; o += H;
+    L.o_wp2 = o; o += H * (H + 1); L.o_bp2 = o; o += H;
+    L.o_wf = o; o += 2 * H * H; L.o_bf = o; o += H;
+    L.o_wg = o; o += 2 * H * H; L.o_bg = o; o += H;
+    L.o_wo = o; o += 2 * H; L.o_bo = o; o += 2;
+    L.P = o;
+    return L;
+}
 int janet_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int janet_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int janet_family_rows(const odpd_model_t* m, int B);
+// 16-sequences-per-wave split kernels of PGJANET (janet_s16.hip): mode 1 forward, 2 backward
+bool janet_uses_s16(const odpd_model_t* m, int B);
+int janet_s16_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
+int janet_s16_rows(const odpd_model_t* m, int B);
+int64_t janet_s16_ckpt_floats(const odpd_model_t* m, int B, int T);
 int tcnn_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_rows(const odpd_model_t* m, int B, int T);

@@ -101,3 +101,24 @@ def test_train_steps_follow_reference(name, bb):
         assert abs(loss.item() - fx["losses"][s - 1]) < 2e-5 * max(1.0, fx["losses"][s - 1])
         got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in net.parameters()])
         assert rel_err(got, fx.flat(f"p{s}", names)) < 3e-5, s
+
+
+# ---- PGJANET S16 kernels (csrc/janet_s16.hip), forced for every batch size with the tuning knob -----------------------
+@pytest.fixture
+def force_s16():
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    assert lib.odpd_set_tuning(b"s16_min_batch", 0) == 0
+    yield
+    lib.odpd_set_tuning(b"s16_min_batch", -1)
+
+
+def test_s16_pgjanet_golden(force_s16):
+    test_golden_forward_backward("pgjanet_h11", "pgjanet")
+    test_train_steps_follow_reference("pgjanet_h11", "pgjanet")
+
+
+@pytest.mark.parametrize("H", [11, 8, 16])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (17, 32), (7, 33), (5, 200), (66, 63)])
+def test_s16_pgjanet_against_oracle_ragged(force_s16, H, B, T):
+    test_against_oracle_ragged("pgjanet", H, B, T)
