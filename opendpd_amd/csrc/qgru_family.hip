@@ -40,13 +40,14 @@ __device__ __forceinline__ Quant make_quant(float scale, int bits) {
     Quant q; q.s = pow2_scale(scale); q.inv = 1.0f / q.s; q.qn = -(float)(1 << (bits - 1)); q.qp = (float)((1 << (bits - 1)) - 1);
     return q;
 }
+// clamp as one v_med3_f32; the straight-through pass mask "Qn <= x/s <= Qp" is "the clamp left x/s unchanged": one compare
 __device__ __forceinline__ float qapply(float x, const Quant& q) {
     const float v = x * q.inv;
-    return rintf(fminf(fmaxf(v, q.qn), q.qp)) * q.s;
+    return rintf(__builtin_amdgcn_fmed3f(v, q.qn, q.qp)) * q.s;
 }
 __device__ __forceinline__ float qpass(float x, const Quant& q) {
     const float v = x * q.inv;
-    return (v >= q.qn && v <= q.qp) ? 1.0f : 0.0f;
+    return __builtin_amdgcn_fmed3f(v, q.qn, q.qp) == v ? 1.0f : 0.0f;
 }
 
 template <bool WITH_T>
