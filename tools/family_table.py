@@ -18,16 +18,18 @@ T = a.T
 
 
 def timeit(fn, n, w=2):
+    """median over n calls, each bracketed by its own pair of HIP events (robust against one-off allocator / clock hiccups)"""
     for _ in range(w):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for e0, e1 in ev:
+        e0.record()
         fn()
-    e1.record()
+        e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+    ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    return ts[len(ts) // 2]
 
 
 def data(B):
@@ -58,9 +60,9 @@ for bb, H, kw in CASES:
     cells = []
     for B in (256, a.big):
         x, t = data(B)
-        ms = timeit(lambda: fused_train_step(opt, x, t, "l2", 200.0), 20 if B <= 1024 else 5)
+        ms = timeit(lambda: fused_train_step(opt, x, t, "l2", 200.0), 21 if B <= 1024 else 7)
         with torch.no_grad():
-            msf = timeit(lambda: net(x), 20 if B <= 1024 else 5)
+            msf = timeit(lambda: net(x), 21 if B <= 1024 else 7)
         cells += [ms, B * T / ms / 1e3, msf, B * T / msf / 1e3]
     kind = "fused (1 launch)" if opt.has_fused(a.big, T) else "split (fwd, loss, bwd)"
     rows.append((f"{bb} H{H}", P, kind, *cells))
@@ -77,9 +79,9 @@ opt = FusedAdamW(casc, lr=1e-4)
 cells = []
 for B in (64, a.big):
     x, t = data(B)
-    ms = timeit(lambda: fused_train_step(opt, x, t, "l2", 200.0), 20 if B <= 1024 else 5)
+    ms = timeit(lambda: fused_train_step(opt, x, t, "l2", 200.0), 21 if B <= 1024 else 7)
     with torch.no_grad():
-        msf = timeit(lambda: casc(x), 20 if B <= 1024 else 5)
+        msf = timeit(lambda: casc(x), 21 if B <= 1024 else 7)
     cells += [ms, B * T / ms / 1e3, msf, B * T / msf / 1e3]
 rows.append(("train_dpd: TRes-DeltaGRU15 -> frozen DGRU23 (B = 64 | big)", 999, "cascade (5 launches)", *cells))
 
