@@ -125,6 +125,7 @@ class NativeBackbone(nn.Module):
     """nn.Module whose parameters are views into one flat fp32 buffer consumed by the HIP kernels."""
 
     backbone_name = None
+    native = True
 
     def _finalize(self, hidden_size, thx=0.0, thh=0.0, bits_w=0, bits_a=0):
         """Call at the end of __init__ once every parameter holder is registered."""

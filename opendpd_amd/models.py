@@ -3,7 +3,9 @@
 `CoreModel(input_size, hidden_size, num_layers, backbone_type, window_size=None, num_dvr_units=None,
 thx=0, thh=0)` — same constructor, attributes, `forward(x, h_0=None)` contract and state-dict keys
 as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` as models.py:163-176.
-Backbones on the hot path run as HIP kernels (`backbone.native` is True); the remaining registry names (SURVEY §8 f4:
+Backbones on the hot path run as HIP kernels (`backbone.native` is True) inside the kernels' envelope (one layer, hidden
+<= 32; pgjanet <= 16; tcnn <= 64 channels) and as ATen restatements (backbones/wide.py, `native` False, with a warning)
+beyond it; the remaining registry names (SURVEY §8 f4:
 gmp, rvtdcnn, apnrru, bojanet, deltajanet, dvrjanet, neuraltx, mcldnn) are torch restatements in backbones/extras.py that
 run through ATen (`backbone.native` is False) until they get kernels.  Unknown names raise ValueError (models.py:139-141).
 """
@@ -12,6 +14,7 @@ import torch.nn as nn
 
 from . import backbones as B
 from .backbones import extras as X
+from .backbones import wide as W
 
 # names the reference registry accepts (models.py:26-141)
 REFERENCE_BACKBONES = ("gmp", "gru", "dgru", "qgru", "qgru_amp1", "lstm", "vdlstm", "rvtdcnn", "apnrru", "bojanet",
@@ -33,7 +36,11 @@ class CoreModel(nn.Module):
 
         kw = dict(hidden_size=hidden_size, output_size=2, num_layers=num_layers, bidirectional=False,
                   batch_first=True, bias=True)
-        if backbone_type == "gru":
+        if W.outside_envelope(backbone_type, hidden_size, num_layers):
+            # beyond the kernels' hidden-size / layer-count envelope: same module through ATen (backbones/wide.py), said aloud
+            W.announce(backbone_type, hidden_size, num_layers)
+            self.backbone = W.build(backbone_type, input_size, hidden_size, num_layers, thx=thx, thh=thh)
+        elif backbone_type == "gru":
             self.backbone = B.GRU(input_size=input_size, **kw)
         elif backbone_type == "dgru":
             self.backbone = B.DGRU(**kw)

@@ -116,6 +116,8 @@ def get_quant_model(proj, model):
         raise NotImplementedError("quantisation-aware training is implemented for the qgru / qgru_amp1 backbones")
     bits_w, bits_a = int(getattr(proj, "n_bits_w", 8)), int(getattr(proj, "n_bits_a", 8))
     H = model.hidden_size
+    if H > 16 or model.num_layers != 1:
+        raise NotImplementedError("the QAT kernels cover one layer and hidden_size <= 16 (csrc/qgru_family.hip)")
     dev = next(model.parameters()).device
     # --- RNG consumption order of Base_GRUQuantEnv (quant_envs.py:156-171, 198-246, 290-306) ----------------------
     # 1. recur_rpls_gru: PYGRU -> GRUCell(4,H): two nn.Linear default inits, then GRUCell.reset_parameters (uniform over

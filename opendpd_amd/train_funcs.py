@@ -45,6 +45,8 @@ class FusedAdamW:
             if any(p.requires_grad for p in net.pa_model.parameters()):
                 raise ValueError("FusedAdamW on a CascadedModel expects freeze_pa_model() to have been called")
             trained, self.pa = net.dpd_model, net.pa_model.backbone
+            if not isinstance(self.pa, NativeBackbone):
+                raise TypeError("FusedAdamW needs a HIP-backed PA model (this one runs through ATen)")
         if not (isinstance(trained, CoreModel) and isinstance(trained.backbone, NativeBackbone)):
             raise TypeError("FusedAdamW needs a HIP-backed CoreModel (or a CascadedModel of two)")
         self.net = net

@@ -57,7 +57,7 @@ def real_frames(name, B, T, seed, split="train"):
     return x, t
 
 
-def build(backbone, hidden, seed, thx=0.0, thh=0.0):
+def build(backbone, hidden, seed, thx=0.0, thh=0.0, num_layers=1):
     torch.manual_seed(seed)
     if backbone == "pgjanet":
         # reference defect 1: registry passes window_size= which PGJANET.__init__ lacks -> construct directly
@@ -69,7 +69,7 @@ def build(backbone, hidden, seed, thx=0.0, thh=0.0):
         net.backbone = PGJANET(hidden_size=hidden, output_size=2, bias=True)
         net.backbone.reset_parameters()
         return net
-    return ref_models.CoreModel(input_size=2, hidden_size=hidden, num_layers=1, backbone_type=backbone,
+    return ref_models.CoreModel(input_size=2, hidden_size=hidden, num_layers=num_layers, backbone_type=backbone,
                                 thx=thx, thh=thh)
 
 
@@ -187,6 +187,23 @@ def gen_backbones(only=None):
         save(name, d)
 
 
+def gen_wide():
+    """Configurations beyond the HIP kernels' envelope (two layers / hidden > 32): pins backbones/wide.py to the reference."""
+    cases = [("wide_gru_h12_l2", "gru", 12, 2, 0, 0), ("wide_dgru_h40", "dgru", 40, 1, 0, 0), ("wide_lstm_h10_l2", "lstm", 10, 2, 0, 0),
+             ("wide_vdlstm_h36", "vdlstm", 36, 1, 0, 0), ("wide_qgru_amp1_h34", "qgru_amp1", 34, 1, 0, 0),
+             ("wide_deltagru_h34", "deltagru", 34, 1, 0.01, 0.05), ("wide_tres_h33", "deltagru_tcnskip", 33, 1, 0.01, 0.05),
+             ("wide_pgjanet_h18", "pgjanet", 18, 1, 0, 0), ("wide_tcnn_c66", "tcnn", 66, 1, 0, 0)]
+    x, tgt = real_frames("DPA_200MHz", 3, 21, seed=5)
+    for name, bb, H, L, thx, thh in cases:
+        net = build(bb, H, seed=0, thx=thx, thh=thh, num_layers=L)
+        d = {"x": x, "tgt": tgt, "meta": np.array(json.dumps(
+            {"backbone": bb, "hidden": H, "num_layers": L, "thx": thx, "thh": thh, "lr": LR, "clip": CLIP,
+             "n_param": int(sum(p.numel() for p in net.parameters()))}))}
+        d.update(sd_np(net, "sd"))
+        d.update(step_case(net, x, tgt, n_steps=1))
+        save(name, d)
+
+
 def gen_cascade():
     """train_dpd: DPD (TRes-DeltaGRU H15 / DGRU H13) -> frozen PA DGRU H23 (steps/train_dpd.py:28-63)."""
     x, _ = real_frames("APA_200MHz", 5, 37, seed=3)
@@ -291,6 +308,8 @@ if __name__ == "__main__":
     only = [w.split("=", 1)[1].split(",") for w in which if w.startswith("only=")]      # e.g. backbones only=gru_h11,dgru_h8
     if "backbones" in which:
         gen_backbones(only[0] if only else None)
+    if "wide" in which:
+        gen_wide()
     if "cascade" in which:
         gen_cascade()
     if "quant" in which:
