@@ -200,8 +200,7 @@ __device__ __forceinline__ void s16n_block(const SeqArgs& a, TabPtr tl0, const f
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) tile_get(tile(4, kt), n, q, hTn[kt]);
     }
-    const bool l2 = a.loss_kind == ODPD_LOSS_L2;
-    const float sc = valid ? a.inv_count : 0.0f;
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, valid ? a.inv_count : 0.0f, valid && q == 0);
 #pragma unroll
     for (int st = S - 1; st >= 0; --st) {
         if (FULL || st < nstep) {
@@ -215,10 +214,7 @@ __device__ __forceinline__ void s16n_block(const SeqArgs& a, TabPtr tl0, const f
             if constexpr (FUSED) {
                 const float y0 = quad_sum(p0), y1 = quad_sum(p1);
                 const float d0 = y0 - tv.x, d1 = y1 - tv.y;
-                const float s0 = d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f), s1 = d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
-                dy0 = l2 ? 2.0f * sc * d0 : s0; dy1 = l2 ? 2.0f * sc * d1 : s1;
-                const float lv = l2 ? __builtin_fmaf(d0, d0, d1 * d1) : __builtin_fabsf(d0) + __builtin_fabsf(d1);
-                loss_acc += (valid && q == 0) ? lv : 0.0f;
+                s16_loss(lossc, d0, d1, dy0, dy1, loss_acc);
             }
             if constexpr (NW) {
 #pragma unroll
@@ -237,7 +233,7 @@ __device__ __forceinline__ void s16n_block(const SeqArgs& a, TabPtr tl0, const f
                 }
                 const f32x4 dact = fma4(splat4(dy0), w0, mul4(w1, splat4(dy1)));
                 if constexpr (DG) {
-                    ODPD_EACH4 dhid[mt][i] = hid[mt][i] > 0.0f ? dact[i] : 0.0f;
+                    ODPD_EACH4 dhid[mt][i] = dact[i] * relu_gate(hid[mt][i]);
                     if constexpr (NW) G.db_hid[mt] = add4(G.db_hid[mt], dhid[mt]);
                     dht[mt] = dh[mt];
                 } else {

@@ -186,8 +186,8 @@ __device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const fl
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) tile_get(tile(4, kt), n, q, hTn[kt]);
     }
-    const bool l2 = a.loss_kind == ODPD_LOSS_L2;
-    const float sc = valid ? a.inv_count : 0.0f;
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, valid ? a.inv_count : 0.0f, valid && q == 0);
+    const float isq0 = q == 0 ? 1.0f : 0.0f;
     const float4 bo = tab_ld(tl, T::BOUT * 64);
 #pragma unroll
     for (int st = S - 1; st >= 0; --st) {
@@ -233,12 +233,10 @@ __device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const fl
             const float y0 = quad_sum(p0) + bo.x, y1 = quad_sum(p1) + bo.y;
             const float2 tv = tr[n * kChunkPad + tt];
             const float d0 = y0 - tv.x, d1 = y1 - tv.y;
-            const float s0 = d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f), s1 = d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
-            const float dy0 = l2 ? 2.0f * sc * d0 : s0, dy1 = l2 ? 2.0f * sc * d1 : s1;
-            const float lv = l2 ? __builtin_fmaf(d0, d0, d1 * d1) : __builtin_fabsf(d0) + __builtin_fabsf(d1);
-            loss_acc += (valid && q == 0) ? lv : 0.0f;
-            G.dbo[0] += q == 0 ? dy0 : 0.0f;
-            G.dbo[1] += q == 0 ? dy1 : 0.0f;
+            float dy0, dy1;
+            s16_loss(lossc, d0, d1, dy0, dy1, loss_acc);
+            G.dbo[0] = __builtin_fmaf(isq0, dy0, G.dbo[0]);
+            G.dbo[1] = __builtin_fmaf(isq0, dy1, G.dbo[1]);
             // ---- head backward -> dht ----
             f32x4 dht[NT], dl = {0.f, 0.f, 0.f, 0.f};
             if constexpr (VD) {

@@ -118,6 +118,29 @@ __device__ __forceinline__ f32x4 tanh4_precise(const f32x4& v) {
     ODPD_EACH4 r[i] = tanhf_(v[i]);
     return r;
 }
+// ---- loss and dL/dy of one I/Q sample without compares or selects --------------------------------------------------
+// (a VOP2 v_cndmask through vcc measured ~21 cycles next to the MFMA stream; these are plain multiplies / FMAs / one bfi)
+// L2: dy = 2 sc d, loss += d0^2 + d1^2;  L1: dy = sc sign(d) (0 at d = 0), loss += |d0| + |d1|.  `counts`: this lane
+// adds the sample to the loss sum (one quad per sequence).  For L2 the results are bit-identical to the select form.
+struct S16Loss { float c2, c1, w2, w1; };
+__device__ __forceinline__ S16Loss s16_loss_setup(bool l2, float sc, bool counts) {
+    S16Loss L;
+    L.c2 = l2 ? 2.0f * sc : 0.0f; L.c1 = l2 ? 0.0f : sc;
+    L.w2 = (l2 && counts) ? 1.0f : 0.0f; L.w1 = (!l2 && counts) ? 1.0f : 0.0f;
+    return L;
+}
+__device__ __forceinline__ float s16_sign(float d) {      // -1, 0, +1 (|d| < 2^-100 would give a fraction: never a loss residual)
+    return __builtin_copysignf(__builtin_amdgcn_fmed3f(__builtin_fabsf(d) * 0x1p100f, 0.0f, 1.0f), d);
+}
+__device__ __forceinline__ void s16_loss(const S16Loss& L, float d0, float d1, float& dy0, float& dy1, float& acc) {
+    dy0 = __builtin_fmaf(L.c1, s16_sign(d0), L.c2 * d0);
+    dy1 = __builtin_fmaf(L.c1, s16_sign(d1), L.c2 * d1);
+    acc = __builtin_fmaf(L.w2, __builtin_fmaf(d0, d0, d1 * d1), acc);
+    acc = __builtin_fmaf(L.w1, __builtin_fabsf(d0) + __builtin_fabsf(d1), acc);
+}
+// relu'(v) as a multiplier: 0 for v <= 0, 1 for v >= 2^-100 (v_mul with the clamp modifier instead of v_cmp + v_cndmask)
+__device__ __forceinline__ float relu_gate(float v) { return __builtin_amdgcn_fmed3f(v * 0x1p100f, 0.0f, 1.0f); }
+
 // sum over the four quads of a sequence (lanes n, n+16, n+32, n+48); every lane gets the total
 __device__ __forceinline__ float quad_sum(float v) {
     v += swap16(v);
