@@ -22,7 +22,7 @@
 //                     one row of partial gradients per workgroup, fixed summation order.
 //   gru_train_kernel  forward (cell only) + backward with y / loss / dL/dy formed on the fly:
 //                     HBM traffic = x + target.
-#include "odpd_seq.h"
+#include "odpd_s16.h"
 
 namespace odpd {
 
@@ -184,7 +184,7 @@ __device__ __forceinline__ void gru_step_bwd(const GruW<R, FeatDim<FM>::F, DG>& 
     const float g01 = __builtin_fmaf(dy0, w.wout[0], dy1 * w.wout[1]);
     if constexpr (DG) {
         const float a = __builtin_fmaxf(hid, 0.0f);
-        const float dhid = hid > 0.0f ? g01 : 0.0f;
+        const float dhid = g01 * relu_gate(hid);
         if constexpr (NW) {
             const float fs = feat_select<6>(f, col, 0.0f);
             G.dwout[0] = __builtin_fmaf(dy0, a, G.dwout[0]);
@@ -436,7 +436,7 @@ __device__ __forceinline__ void gru_bwd_block(const SeqArgs& a, const GruW<R, Fe
     tlane = opaque(tlane);
     float whhT[3][R][16];
     load_rot3<R>(whhT, tlane, T::kHHT);
-    const bool l2 = a.loss_kind == ODPD_LOSS_L2;
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, valid ? a.inv_count : 0.0f, valid && (lane & (LPS - 1)) == 0);
 #pragma unroll
     for (int i = S - 1; i >= 0; --i) {
         if (FULL || i < nstep) {
@@ -451,11 +451,7 @@ __device__ __forceinline__ void gru_bwd_block(const SeqArgs& a, const GruW<R, Fe
                 const float act = DG ? __builtin_fmaxf(hid_s[i], 0.0f) : __builtin_fmaf(z_s[i], hp_s[i] - n_s[i], n_s[i]);
                 gru_head_out<R, FM, DG>(w, act, f, col, y0, y1);
                 const float d0 = y0 - dyv.x, d1 = y1 - dyv.y;
-                const float sc = valid ? a.inv_count : 0.0f;
-                const float s0 = d0 > 0.f ? sc : (d0 < 0.f ? -sc : 0.f), s1 = d1 > 0.f ? sc : (d1 < 0.f ? -sc : 0.f);
-                dyv = make_float2(l2 ? 2.0f * sc * d0 : s0, l2 ? 2.0f * sc * d1 : s1);
-                const float lv = l2 ? __builtin_fmaf(d0, d0, d1 * d1) : __builtin_fabsf(d0) + __builtin_fabsf(d1);
-                loss_acc += (valid && (lane & (LPS - 1)) == 0) ? lv : 0.0f;
+                s16_loss(lossc, d0, d1, dyv.x, dyv.y, loss_acc);
             }
             gru_step_bwd<R, FM, DG, NW, DX>(w, whhT, tlane, G, f, hp_s[i], r_s[i], z_s[i], n_s[i], g_s[i], hid_s[i],
                                             dyv.x, dyv.y, row, col, dh, df);
