@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of every HIP backbone against the C oracle (GPU box): all hidden sizes of the kernels' envelope,
+random batch / frame length, both kernel mappings (row-rotated and S16 forced).  Prints the worst relative errors per backbone
+and every case beyond tolerance.  usage: PYTHONPATH=. python tools/parity_sweep.py [cases-per-size]"""
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+from opendpd_amd import CoreModel, _lib
+from oracle.oracle import Oracle, make_model
+
+n_per = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+lib = _lib.load()
+o = Oracle("f32")
+SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
+         "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
+         "tcnn": list(range(1, 40)) + [48, 63, 64]}
+rng = np.random.RandomState(0)
+bad, worst = [], {}
+for bb, sizes in SIZES.items():
+    for H in sizes:
+        for case in range(n_per):
+            for force in (False, True):
+                lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
+                B = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
+                T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 257, 300]))
+                if B * T > 6000:
+                    T = max(1, 6000 // B)
+                if bb == "vdlstm" and T < 3:
+                    T = 3       # the 3-sample circular pad needs T >= 3 (vdlstm.py:66-74); shorter frames are refused (EINVAL)
+                kw = dict(thx=float(rng.choice([0.0, 0.01, 0.05])), thh=float(rng.choice([0.0, 0.02, 0.1]))) if "delta" in bb else {}
+                torch.manual_seed(int(rng.randint(1 << 30)))
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    net = CoreModel(2, H, 1, bb, **kw).cuda()
+                with torch.no_grad():
+                    for k, p in net.named_parameters():
+                        if "bias" in k:
+                            p.uniform_(-0.3, 0.3)
+                amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
+                x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+                dy = rng.randn(B, T, 2).astype(np.float32)
+                need_dx = "delta" not in bb
+                xt = torch.from_numpy(x).cuda().requires_grad_(need_dx)
+                try:
+                    y = net(xt)
+                    y.backward(torch.from_numpy(dy).cuda())
+                except Exception as e:      # noqa: BLE001
+                    bad.append((bb, H, B, T, force, kw, f"EXC {e}"))
+                    continue
+                m = make_model(bb, H, kw.get("thx", 0), kw.get("thh", 0))
+                p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+                yo, so = o.forward(m, p, x)
+                go, dxo = o.backward(m, p, x, dy, need_dx=need_dx)
+                g = np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()])
+                rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+                ey, eg = rel(y.detach().cpu().numpy(), yo), rel(g, go)
+                ex = rel(xt.grad.cpu().numpy(), dxo) if need_dx else 0.0
+                flips = 0
+                if "delta" in bb:
+                    st = net.backbone.statistics
+                    flips = abs(st["num_dx_zeros"] - so[0]) + abs(st["num_dh_zeros"] - so[2])
+                tol_y, tol_g = (2e-5, 3e-4) if flips == 0 else (5e-3, 5e-2)
+                w = worst.setdefault(bb, [0.0, 0.0, 0.0])
+                if flips == 0:
+                    w[0], w[1], w[2] = max(w[0], ey), max(w[1], eg), max(w[2], ex)
+                if not (ey < tol_y and eg < tol_g and ex < tol_g) or not np.isfinite([ey, eg, ex]).all() or flips > 4:
+                    bad.append((bb, H, B, T, force, kw, f"y {ey:.2e} g {eg:.2e} dx {ex:.2e} flips {flips}"))
+    print(f"{bb:18s} worst rel err  y {worst[bb][0]:.2e}  grad {worst[bb][1]:.2e}  dx {worst[bb][2]:.2e}", flush=True)
+lib.odpd_set_tuning(b"s16_min_batch", -1)
+print(f"{len(bad)} case(s) beyond tolerance")
+for b in bad[:60]:
+    print("  ", b)
