@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the optimiser step (fwd + loss + BPTT + clip + AdamW through `fused_train_step`: single-launch kernels
+where they exist, the split chain elsewhere) against the C oracle's train step: every hidden size of the envelope, random batch /
+frame length / loss kind, both kernel mappings, two consecutive steps.  usage: PYTHONPATH=. python tools/train_sweep.py [cases-per-size]"""
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+from opendpd_amd import CoreModel, _lib
+from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+from oracle.oracle import Oracle, make_model
+
+n_per = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+lib = _lib.load()
+o = Oracle("f32")
+SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
+         "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
+         "tcnn": list(range(1, 40, 3)) + [64]}
+rng = np.random.RandomState(1)
+bad = []
+for bb, sizes in SIZES.items():
+    worst = [0.0, 0.0]
+    for H in sizes:
+        for case in range(n_per):
+            for force in (False, True):
+                lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
+                B = int(rng.choice([1, 3, 4, 15, 16, 17, 33, 64]))
+                T = int(rng.choice([3, 4, 5, 31, 32, 33, 50, 65, 200]))
+                if B * T > 5000:
+                    T = max(3, 5000 // B)
+                kind = str(rng.choice(["l2", "l1"]))
+                kw = dict(thx=float(rng.choice([0.0, 0.01])), thh=float(rng.choice([0.0, 0.03]))) if "delta" in bb else {}
+                torch.manual_seed(int(rng.randint(1 << 30)))
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    net = CoreModel(2, H, 1, bb, **kw).cuda()
+                with torch.no_grad():
+                    for k, p in net.named_parameters():
+                        if "bias" in k:
+                            p.uniform_(-0.3, 0.3)
+                amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
+                x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+                tgt = (0.7 * x + 0.1 * rng.randn(B, T, 2)).astype(np.float32)
+                p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()]).astype(np.float32)
+                m = make_model(bb, H, kw.get("thx", 0), kw.get("thh", 0))
+                ea, es = np.zeros_like(p), np.zeros_like(p)
+                opt = FusedAdamW(net, lr=1e-3)
+                xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+                try:
+                    for step in (1, 2):
+                        lo = o.train_step(m, p, x, tgt, ea, es, step, 1e-3, 200.0, kind)
+                        lg = float(fused_train_step(opt, xt, tt, kind, 200.0))
+                        got = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+                        el = abs(lg - lo) / max(abs(lo), 1e-30)
+                        ep = float(np.abs(got - p).max() / max(np.abs(p).max(), 1e-30))
+                        worst[0], worst[1] = max(worst[0], el), max(worst[1], ep)
+                        # AdamW's first steps move every parameter by ~lr * sign(g): a gradient entry within rounding of 0 may
+                        # flip its sign, so the parameter tolerance is a fraction of lr relative to the parameter scale
+                        if not (el < 5e-5 and ep < 2.5e-3) or not np.isfinite([el, ep]).all():
+                            bad.append((bb, H, B, T, kind, force, kw, step, f"loss {el:.2e} params {ep:.2e}"))
+                except Exception as e:      # noqa: BLE001
+                    bad.append((bb, H, B, T, kind, force, kw, 0, f"EXC {e}"))
+    print(f"{bb:18s} worst rel err  loss {worst[0]:.2e}  params after a step {worst[1]:.2e}", flush=True)
+lib.odpd_set_tuning(b"s16_min_batch", -1)
+print(f"{len(bad)} case(s) beyond tolerance")
+for b in bad[:60]:
+    print("  ", b)
