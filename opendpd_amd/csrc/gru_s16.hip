@@ -137,7 +137,7 @@ __device__ __forceinline__ void s16_cell_fwd(const S16Fw<FM>& w, const float (&f
     r = sigmoid4_prescaled(ar);
     z = sigmoid4_prescaled(az);
     g = ah;
-    n = tanh4(fma4(r, ah, an));
+    n = tanh4_for<FM>(fma4(r, ah, an));
     h = fma4(z, sub4(h, n), n);
 }
 

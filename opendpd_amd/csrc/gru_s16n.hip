@@ -111,7 +111,7 @@ __device__ __forceinline__ void s16n_cell_fwd(TabPtr tl, const float (&fs)[S16Cf
         r[mt] = sigmoid4_prescaled(ar[mt]);
         z[mt] = sigmoid4_prescaled(az[mt]);
         g[mt] = ah[mt];
-        n[mt] = tanh4(fma4(r[mt], ah[mt], an[mt]));
+        n[mt] = tanh4_for<FM>(fma4(r[mt], ah[mt], an[mt]));
         h[mt] = fma4(z[mt], sub4(h[mt], n[mt]), n[mt]);
     }
 }

@@ -109,10 +109,10 @@ __device__ __forceinline__ void l16_cell_fwd(TabPtr tl, const float (&fs)[VD ? 2
     for (int mt = 0; mt < NT; ++mt) {
         gi[mt] = sigmoid4_prescaled(acc[0][mt]);
         gf[mt] = sigmoid4_prescaled(acc[1][mt]);
-        gg[mt] = tanh4(acc[2][mt]);
+        gg[mt] = tanh4_rel(acc[2][mt]);
         go[mt] = sigmoid4_prescaled(acc[3][mt]);
         c[mt] = fma4(gf[mt], c[mt], mul4(gi[mt], gg[mt]));
-        h[mt] = mul4(go[mt], tanh4(c[mt]));
+        h[mt] = mul4(go[mt], tanh4_rel(c[mt]));
     }
 }
 
@@ -204,7 +204,7 @@ __device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const fl
             f32x4 tc[NT], ht[NT];
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) {
-                tc[mt] = tanh4(fma4(f_s[st][mt], cp_s[st][mt], mul4(i_s[st][mt], g_s[st][mt])));
+                tc[mt] = tanh4_rel(fma4(f_s[st][mt], cp_s[st][mt], mul4(i_s[st][mt], g_s[st][mt])));
                 ht[mt] = mul4(o_s[st][mt], tc[mt]);
             }
             // ---- head forward, loss, dL/dy ----

@@ -111,6 +111,32 @@ __device__ __forceinline__ f32x4 tanh4(const f32x4& v) {
     return fma4(rcp4(e), splat4(-2.0f), splat4(1.0f));
 }
 
+// tanh with RELATIVE accuracy near 0 (error < 1.2e-7 of the result): the single formula above has an ABSOLUTE error of
+// 1.9e-7, which is 1e-4 of tanh(1e-3) — visible (2e-5 in y) in the backbones whose features all scale with the signal
+// amplitude (gru, qgru*, lstm, vdlstm) when the whole signal is small; dgru's sin/cos features are O(1) and keep tanh4.
+// Below 0.3 the odd polynomial of tanhf_ takes over through an arithmetic blend (weight 0 or 1, no compare / select).
+__device__ __forceinline__ f32x4 tanh4_rel(const f32x4& v) {
+    f32x4 r;
+    ODPD_EACH4 {
+        const float x = v[i], x2 = x * x;
+        float p = __builtin_fmaf(x2, 0.021869488536155203f, -0.053968253968253971f);
+        p = __builtin_fmaf(x2, p, 0.13333333333333333f);
+        p = __builtin_fmaf(x2, p, -0.33333333333333333f);
+        p = __builtin_fmaf(x2 * x, p, x);
+        const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f;
+        const float t = __builtin_fmaf(fast_rcp(e), -2.0f, 1.0f);
+        const float w = __builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_fabsf(x), -0x1p100f, 0.3f * 0x1p100f), 0.0f, 1.0f);   // |x| < 0.3
+        r[i] = __builtin_fmaf(w, p - t, t);
+    }
+    return r;
+}
+// tanh of the amplitude-scaled backbones vs the O(1)-feature ones (FM = feature map of the GRU family)
+template <int FM>
+__device__ __forceinline__ f32x4 tanh4_for(const f32x4& v) {
+    if constexpr (FM == FEAT_DGRU6) return tanh4(v);
+    else return tanh4_rel(v);
+}
+
 // tanh with the row-rotated kernels' accuracy (polynomial below 0.3): used where a rounding-level difference could
 // flip a threshold decision (delta backbones)
 __device__ __forceinline__ f32x4 tanh4_precise(const f32x4& v) {
