@@ -90,24 +90,28 @@ class ReduceLROnPlateau:
 class CsvLogger:
     """History / best CSV files with the reference's formatting (loggers.py:119-163)."""
 
-    def __init__(self, path_save_best, path_log_best, path_log_hist, precision=8):
+    def __init__(self, path_save_best, path_log_best, path_log_hist, precision=8, writes=True):
         self.path_save_best, self.path_log_best, self.path_log_hist, self.precision = path_save_best, path_log_best, path_log_hist, precision
         self.headers, self.rows, self.best_val_metric = [], [], None
+        self.writes = writes          # data-parallel runs: every rank keeps the bookkeeping, rank 0 alone touches the files
 
     def write_log(self, stat):
         self.headers = list(stat.keys())
         fmt = "{:." + str(self.precision) + "f}"
         self.rows.append([fmt.format(v) if isinstance(v, float) else v for v in stat.values()])
-        pd.DataFrame(self.rows, columns=self.headers).to_csv(self.path_log_hist, index=False)
+        if self.writes:
+            pd.DataFrame(self.rows, columns=self.headers).to_csv(self.path_log_hist, index=False)
 
     def _write_best(self, idx):
-        pd.DataFrame([self.rows[idx]], columns=self.headers).to_csv(self.path_log_best, index=False)
+        if self.writes:
+            pd.DataFrame([self.rows[idx]], columns=self.headers).to_csv(self.path_log_best, index=False)
 
     def save_best_model(self, net, epoch, val_stat, metric_name):
         crit = val_stat[metric_name]
         if epoch == 0 or crit < self.best_val_metric:
             self.best_val_metric = crit
-            torch.save(net.state_dict(), self.path_save_best)
+            if self.writes:
+                torch.save(net.state_dict(), self.path_save_best)
             self._write_best(epoch)
 
 
@@ -155,9 +159,17 @@ class Project:
         return s
 
     def set_device(self):
+        """One process per GPU: under torchrun (WORLD_SIZE > 1) the process takes device LOCAL_RANK and joins the default
+        process group (backend nccl = RCCL; OPENDPD_DIST_BACKEND overrides, OPENDPD_DIST_SINGLE_DEVICE=1 keeps `devices` for
+        functional checks of the N > 1 path on a one-GPU box); a single process keeps the reference's `--devices` index."""
+        from . import dist as DP
+        self.rank, local, self.world = DP.env_world()
         if self.accelerator == "cuda" and torch.cuda.is_available():
-            dev = torch.device("cuda:" + str(self.devices))
+            index = local if (self.world > 1 and os.environ.get("OPENDPD_DIST_SINGLE_DEVICE") != "1") else self.devices
+            dev = torch.device("cuda:" + str(index))
             torch.cuda.set_device(dev)
+            if self.world > 1:
+                DP.init(os.environ.get("OPENDPD_DIST_BACKEND") or None, dev)
         elif self.accelerator == "cpu":
             raise ValueError("opendpd_amd runs on a HIP device only: pass accelerator='cuda' (there is no CPU fallback)")
         else:
@@ -179,7 +191,8 @@ class Project:
         self.path_save_file_best = os.path.join(self.path_dir_save, model_id + ".pt")
         self.path_log_file_hist = os.path.join(self.path_dir_log_hist, model_id + ".csv")
         self.path_log_file_best = os.path.join(self.path_dir_log_best, model_id + ".csv")
-        self.logger = CsvLogger(self.path_save_file_best, self.path_log_file_best, self.path_log_file_hist, self.log_precision)
+        self.logger = CsvLogger(self.path_save_file_best, self.path_log_file_best, self.path_log_file_hist, self.log_precision,
+                                writes=getattr(self, "rank", 0) == 0)
 
     def build_criterion(self):
         return {"l2": nn.MSELoss(), "l1": nn.L1Loss()}[self.loss_type]
@@ -188,7 +201,7 @@ class Project:
         if self.opt_type == "adamw":
             try:
                 opt = FusedAdamW(net, lr=self.lr)
-            except TypeError:   # a registry backbone without HIP kernels (backbones/extras.py): ATen path, torch optimiser
+            except TypeError:   # a registry backbone without HIP kernels (backbones/extras.py, wide.py): ATen path, torch optimiser
                 opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=self.lr)
         elif self.opt_type == "adam":
             opt = torch.optim.Adam(net.parameters(), lr=self.lr)
@@ -198,6 +211,9 @@ class Project:
             opt = torch.optim.RMSprop(net.parameters(), lr=self.lr)
         else:
             raise RuntimeError("Please use a valid optimizer.")
+        if getattr(self, "world", 1) > 1 and not isinstance(opt, FusedAdamW):
+            raise RuntimeError("data-parallel training (WORLD_SIZE > 1) runs through the fused HIP optimiser: --opt_type adamw on "
+                               "a kernel-backed model")
         return opt, ReduceLROnPlateau(opt, self.decay_factor, self.patience, self.lr_end)
 
     def gen_log_stat(self, elapsed, net, optimizer, epoch):

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import _lib
 from .backbones.native import NativeBackbone
+from .dist import shard_range
 from .models import CascadedModel, CoreModel
 
 
@@ -143,6 +144,16 @@ class FusedAdamW:
         """The ONE collective of the data-parallel step: sum of P+4 floats (gradient + loss partial)."""
         from .dist import allreduce_sum_
         allreduce_sum_(self.grad, self.process_group)
+
+    def empty_step(self, max_norm, count):
+        """A rank whose shard of the global batch is empty: zero gradient into the all-reduce, then the common update."""
+        dev = self.backbone.flat_params().device
+        self._ensure(dev)
+        self.grad.zero_()
+        self.allreduce_grad()
+        loss = self.grad[self.backbone.n_flat] / count
+        self.apply(max_norm)
+        return loss
 
     def apply(self, max_norm, stream=None):
         """clip (max_norm, 0 = off) + AdamW on the flat buffers; self.grad must hold the global gradient."""
@@ -313,12 +324,29 @@ def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device)
         losses = optimizer.train_epoch(dataloader, kind, grad_clip_val)
         log["loss"] = float(losses.double().mean().item()) if losses.numel() else float("nan")
         return net
+    world = optimizer.world_size() if isinstance(optimizer, FusedAdamW) else 1
+    if world > 1 and not fast:
+        raise RuntimeError("data-parallel training needs the fused step (FusedAdamW on this net, mean l1 / l2 loss)")
+    rank = 0
+    if world > 1:
+        import torch.distributed as dist
+        rank = dist.get_rank(optimizer.process_group)
     for features, targets in dataloader:
         features = features.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)
         if fast:
-            loss = fused_train_step(optimizer, features.contiguous().float(), targets.contiguous().float(), kind,
-                                    grad_clip_val)
+            count = None
+            if world > 1:
+                # every rank draws the same global batch (same seed, same loader) and keeps its contiguous shard; the loss
+                # gradient is normalised by the GLOBAL element count, so the all-reduced sum is the global-batch gradient
+                count = features.shape[0] * features.shape[1] * features.shape[2]
+                lo, hi = shard_range(features.shape[0], rank, world)
+                features, targets = features[lo:hi], targets[lo:hi]
+            if features.shape[0] == 0:      # fewer frames than ranks in the last batch: contribute zeros, stay in step
+                loss = optimizer.empty_step(grad_clip_val, count)
+            else:
+                loss = fused_train_step(optimizer, features.contiguous().float(), targets.contiguous().float(), kind,
+                                        grad_clip_val, global_count=count)
             losses.append(loss)
             continue
         optimizer.zero_grad()

@@ -154,3 +154,56 @@ def test_configuration_outside_the_kernel_envelope_trains_through_the_api(workdi
     assert res["status"] == "completed"
     hist = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), "history", os.path.basename(res["log_path"])))
     assert len(hist) == 1 and np.isfinite(hist["TRAIN_LOSS"]).all()
+
+
+_DP_SCRIPT = """
+import os, sys
+sys.path.insert(0, {root!r})
+os.environ["OPENDPD_DATASETS"] = {datasets!r}
+import opendpd_amd as od
+kw = dict(dataset_name="DPA_200MHz", PA_backbone="dgru", PA_hidden_size=9, frame_length=50, batch_size=64, lr=1e-3, seed=0,
+          accelerator="cuda", n_epochs=2)
+res = od.train_pa(**kw)
+if {dpd}:
+    res = od.train_dpd(DPD_backbone="deltagru_tcnskip", DPD_hidden_size=8, thx=0.01, thh=0.02, **kw)
+print("DONE", res["model_path"])
+"""
+
+
+@pytest.mark.parametrize("dpd", [False, True])
+def test_data_parallel_api_run_equals_single_process(workdir, dpd):
+    """§8e through the API: `torchrun --nproc-per-node 2` over train_pa / train_dpd — every rank draws the same global
+    batches, keeps its shard, ONE all-reduce of P+4 floats per step — gives the single-process result (same trajectory up to
+    the summation order of the two shard gradients).  Two ranks share this box's one GPU and talk over gloo; on a node with
+    one GPU per rank the same code runs over RCCL."""
+    import subprocess, sys, shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _DP_SCRIPT.format(root=root, datasets=os.environ["OPENDPD_DATASETS"], dpd=dpd)
+    outs = {}
+    for tag, world in (("single", 1), ("dp2", 2)):
+        wd = os.path.join(os.getcwd(), f"{tag}_{int(dpd)}")
+        os.makedirs(wd)
+        open(os.path.join(wd, "run.py"), "w").write(script)
+        env = dict(os.environ, OPENDPD_DIST_BACKEND="gloo", OPENDPD_DIST_SINGLE_DEVICE="1")
+        cmd = [sys.executable, "run.py"]
+        if world > 1:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                   "127.0.0.1", "--master-port", "29531", "run.py"]
+        r = subprocess.run(cmd, cwd=wd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DONE" in r.stdout, r.stderr[-3000:]
+        step = "train_dpd" if dpd else "train_pa"
+        hist = []
+        for dp, _, files in os.walk(os.path.join(wd, "log", "DPA_200MHz", step)):
+            hist += [os.path.join(dp, f) for f in files if dp.endswith("history")]
+        assert len(hist) == 1, hist                     # rank 0 alone writes the files
+        model = [os.path.join(dp, f) for dp, _, files in os.walk(os.path.join(wd, "save", "DPA_200MHz", step)) for f in files]
+        assert len(model) == 1
+        outs[tag] = (pd.read_csv(hist[0]), torch.load(model[0], map_location="cpu"))
+        shutil.rmtree(os.path.join(wd, "log"))
+    (h1, m1), (h2, m2) = outs["single"], outs["dp2"]
+    assert list(h1.columns) == list(h2.columns) and len(h1) == len(h2) == 2
+    assert np.allclose(h1["TRAIN_LOSS"], h2["TRAIN_LOSS"], rtol=2e-3)
+    assert np.allclose(h1["VAL_NMSE"], h2["VAL_NMSE"], atol=0.3)       # dB after 2 x 360 steps of diverging rounding
+    for k in m1:
+        a, b = m1[k].float(), m2[k].float()
+        assert (a - b).abs().max() <= 2e-2 * max(1.0, a.abs().max()), k
