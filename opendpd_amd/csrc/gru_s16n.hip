@@ -34,6 +34,17 @@ struct S16N {
     static constexpr int kWaveFloats = 2 * 2 * 16 * kChunkPad + kTiles * kTileFloats;
 };
 
+// Which hidden unit sits in slot s (= 4 q + e on the owning lane, = row / column s of a 16x16 operand tile) of unit tile t.
+// Full tiles: unit 16 t + s.  The LAST tile is filled element-major (slot 4 q + e <- rank 4 e + q), so that its H - 16 (NT-1)
+// units occupy the elements e < ceil((H - 16 (NT-1)) / 4) of every quad: the K-chunks above that count multiply zeros only
+// and are skipped (`nck` of s16n_matvec) — hidden 23 runs 6 of its 8 K-chunks.
+template <int NT>
+__device__ __forceinline__ int s16n_unit(int t, int s) {
+    return t < NT - 1 ? 16 * t + s : 16 * t + 4 * (s & 3) + (s >> 2);
+}
+template <int NT>
+__host__ __device__ inline int s16n_last_chunks(int H) { return (H - 16 * (NT - 1) + 3) / 4; }
+
 template <int FM, bool DG, int NT>
 __device__ __forceinline__ float4 s16n_entry(const float* pl, const GruLayout& L, int grp, int m, int q) {
     using T = S16N<NT>;
@@ -43,33 +54,33 @@ __device__ __forceinline__ float4 s16n_entry(const float* pl, const GruLayout& L
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (grp < T::IH) {
-            const int g = grp / (NT * NT), mt = (grp / NT) % NT, kt = grp % NT, o = 16 * mt + m, k = 16 * kt + 4 * q + e;
+            const int g = grp / (NT * NT), mt = (grp / NT) % NT, kt = grp % NT, o = s16n_unit<NT>(mt, m), k = s16n_unit<NT>(kt, 4 * q + e);
             v[e] = (o < H && k < H) ? pl[L.o_w_hh + (g * H + o) * H + k] * (g < 2 ? kNegLog2e : 1.0f) : 0.0f;
         } else if (grp < T::BHN) {
             const int g = (grp - T::IH) / NT, mt = (grp - T::IH) % NT;
-            v[e] = (g < 2 ? kNegLog2e : 1.0f) * s16_wih_slot<FM, DG>(pl, L, g, e, 16 * mt + m, q);
+            v[e] = (g < 2 ? kNegLog2e : 1.0f) * s16_wih_slot<FM, DG>(pl, L, g, e, s16n_unit<NT>(mt, m), q);
         } else if (grp < T::HHT) {
-            const int u = 16 * (grp - T::BHN) + 4 * q + e;
+            const int u = s16n_unit<NT>(grp - T::BHN, 4 * q + e);
             v[e] = u < H ? pl[L.o_b_hh + 2 * H + u] : 0.0f;
         } else if (grp < T::HID) {
-            const int r = grp - T::HHT, g = r / (NT * NT), mt = (r / NT) % NT, kt = r % NT, i = 16 * mt + m, k = 16 * kt + 4 * q + e;
+            const int r = grp - T::HHT, g = r / (NT * NT), mt = (r / NT) % NT, kt = r % NT, i = s16n_unit<NT>(mt, m), k = s16n_unit<NT>(kt, 4 * q + e);
             v[e] = (i < H && k < H) ? pl[L.o_w_hh + (g * H + k) * H + i] : 0.0f;
         } else if (grp < T::HIDT) {
-            const int r = grp - T::HID, o = 16 * (r / NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::HID, o = s16n_unit<NT>(r / NT, m), k = s16n_unit<NT>(r % NT, 4 * q + e);
             v[e] = (DG && o < H && k < H) ? pl[L.o_w_hid + o * H + k] : 0.0f;
         } else if (grp < T::BHID) {
-            const int r = grp - T::HIDT, i = 16 * (r / NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::HIDT, i = s16n_unit<NT>(r / NT, m), k = s16n_unit<NT>(r % NT, 4 * q + e);
             v[e] = (DG && i < H && k < H) ? pl[L.o_w_hid + k * H + i] : 0.0f;
         } else if (grp < T::WOUT) {
-            const int u = 16 * (grp - T::BHID) + 4 * q + e;
+            const int u = s16n_unit<NT>(grp - T::BHID, 4 * q + e);
             v[e] = (DG && u < H) ? pl[L.o_b_hid + u] : 0.0f;
         } else if (grp < T::WOUTF) {
-            const int r = grp - T::WOUT, u = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::WOUT, u = s16n_unit<NT>(r % NT, 4 * q + e);
             v[e] = u < H ? pl[L.o_w_out + (r / NT) * OW + u] : 0.0f;
         } else if (grp == T::WOUTF) {
             v[e] = s16_woutf_slot<FM, DG>(pl, L, e >> 1, e & 1, q);
         } else if (grp < T::WFD) {
-            const int r = grp - T::IHT, g = r / NT, k = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::IHT, g = r / NT, k = s16n_unit<NT>(r % NT, 4 * q + e);
             v[e] = (m < F && k < H) ? pl[L.o_w_ih + (g * H + k) * F + m] : 0.0f;
         } else {
             const int k = 4 * q + e;
@@ -85,7 +96,7 @@ __device__ __forceinline__ void s16n_fill_table(float* tab, const float* pl, con
     __syncthreads();
 }
 
-template <int FM, bool DG, int NT>
+template <int FM, bool DG, int NT, int NCK = 4>
 __device__ __forceinline__ void s16n_cell_fwd(TabPtr tl, const float (&fs)[S16Cfg<FM>::NCH], f32x4 (&h)[NT], f32x4 (&r)[NT],
                                               f32x4 (&z)[NT], f32x4 (&n)[NT], f32x4 (&g)[NT]) {
     using T = S16N<NT>;
@@ -103,9 +114,9 @@ __device__ __forceinline__ void s16n_cell_fwd(TabPtr tl, const float (&fs)[S16Cf
             ar[mt] = mfma4(wr.y, fs[NCH - 1], ar[mt]); az[mt] = mfma4(wz.y, fs[NCH - 1], az[mt]); an[mt] = mfma4(wn.y, fs[NCH - 1], an[mt]);
         }
     }
-    s16n_matvec<NT>(tl, T::HH + 0 * NT * NT, h, ar);
-    s16n_matvec<NT>(tl, T::HH + 1 * NT * NT, h, az);
-    s16n_matvec<NT>(tl, T::HH + 2 * NT * NT, h, ah);
+    s16n_matvec<NT, NCK>(tl, T::HH + 0 * NT * NT, h, ar);
+    s16n_matvec<NT, NCK>(tl, T::HH + 1 * NT * NT, h, az);
+    s16n_matvec<NT, NCK>(tl, T::HH + 2 * NT * NT, h, ah);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         r[mt] = sigmoid4_prescaled(ar[mt]);
@@ -117,7 +128,7 @@ __device__ __forceinline__ void s16n_cell_fwd(TabPtr tl, const float (&fs)[S16Cf
 }
 
 // head: act (relu(fc_hid h) for DGRU, h otherwise) and the two fc_out partial sums of the lane
-template <int FM, bool DG, int NT>
+template <int FM, bool DG, int NT, int NCK = 4>
 __device__ __forceinline__ void s16n_head(TabPtr tl, const f32x4 (&ht)[NT], const float (&fs)[S16Cfg<FM>::NCH], f32x4 (&hid)[NT],
                                           f32x4 (&act)[NT], float& p0, float& p1) {
     using T = S16N<NT>;
@@ -125,7 +136,7 @@ __device__ __forceinline__ void s16n_head(TabPtr tl, const f32x4 (&ht)[NT], cons
     if constexpr (DG) {
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) hid[mt] = as_f32x4(tab_ld(tl, (T::BHID + mt) * 64));
-        s16n_matvec<NT>(tl, T::HID, ht, hid);
+        s16n_matvec<NT, NCK>(tl, T::HID, ht, hid);
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) ODPD_EACH4 act[mt][i] = relu_(hid[mt][i]);
     } else {
@@ -167,7 +178,7 @@ struct S16NGrad {
 };
 
 // one block of <= S steps (see s16_block in gru_s16.hip for the argument conventions)
-template <int FM, bool DG, int NT, bool FUSED, bool NW, bool DX, bool FULL>
+template <int FM, bool DG, int NT, bool FUSED, bool NW, bool DX, bool FULL, int NCK = 4>
 __device__ __forceinline__ void s16n_block(const SeqArgs& a, TabPtr tl0, const float (&oh)[4], S16NGrad<DG, NT>& G,
                                            const float2* xs, const float2* ts, float2* dxs, float* tiles, int n, int q, int tloc,
                                            int nstep, bool valid, bool last_blk, const f32x4 (&h0)[NT], f32x4 (&dh)[NT],
@@ -186,7 +197,7 @@ __device__ __forceinline__ void s16n_block(const SeqArgs& a, TabPtr tl0, const f
             s16_slots<FM>(xv.x, xv.y, oh, fs_s[st]);
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) hp_s[st][kt] = h[kt];
-            s16n_cell_fwd<FM, DG, NT>(tl, fs_s[st], h, r_s[st], z_s[st], n_s[st], g_s[st]);
+            s16n_cell_fwd<FM, DG, NT, NCK>(tl, fs_s[st], h, r_s[st], z_s[st], n_s[st], g_s[st]);
         }
     }
     tl = opaque(tl0);
@@ -208,7 +219,7 @@ __device__ __forceinline__ void s16n_block(const SeqArgs& a, TabPtr tl0, const f
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) ht[kt] = fma4(z_s[st][kt], sub4(hp_s[st][kt], n_s[st][kt]), n_s[st][kt]);
             float p0, p1;
-            s16n_head<FM, DG, NT>(tl, ht, fs_s[st], hid, act, p0, p1);
+            s16n_head<FM, DG, NT, NCK>(tl, ht, fs_s[st], hid, act, p0, p1);
             const float2 tv = ts[n * kChunkPad + tloc + st];
             float dy0 = tv.x, dy1 = tv.y;
             if constexpr (FUSED) {
@@ -241,7 +252,7 @@ __device__ __forceinline__ void s16n_block(const SeqArgs& a, TabPtr tl0, const f
                     dhid[mt] = dact;
                 }
             }
-            if constexpr (DG) s16n_matvec<NT>(tl, T::HIDT, dhid, dht);
+            if constexpr (DG) s16n_matvec<NT, NCK>(tl, T::HIDT, dhid, dht);
             f32x4 drp[NT], dzp[NT], dnp[NT], dgh[NT], acc[NT];
             const f32x4 one = splat4(1.0f);
 #pragma unroll
@@ -258,9 +269,9 @@ __device__ __forceinline__ void s16n_block(const SeqArgs& a, TabPtr tl0, const f
                 drp[mt] = mul4(mul4(dgh[mt], g_s[st][mt]), omr);
                 if constexpr (NW) G.db_hn[mt] = add4(G.db_hn[mt], dgh[mt]);
             }
-            s16n_matvec<NT>(tl, T::HHT + 0 * NT * NT, drp, acc);
-            s16n_matvec<NT>(tl, T::HHT + 1 * NT * NT, dzp, acc);
-            s16n_matvec<NT>(tl, T::HHT + 2 * NT * NT, dgh, acc);
+            s16n_matvec<NT, NCK>(tl, T::HHT + 0 * NT * NT, drp, acc);
+            s16n_matvec<NT, NCK>(tl, T::HHT + 1 * NT * NT, dzp, acc);
+            s16n_matvec<NT, NCK>(tl, T::HHT + 2 * NT * NT, dgh, acc);
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) dh[mt] = acc[mt];
             if constexpr (DX) {
@@ -269,9 +280,12 @@ __device__ __forceinline__ void s16n_block(const SeqArgs& a, TabPtr tl0, const f
                 for (int kt = 0; kt < NT; ++kt) {
                     const float4 wr = tab_ld(tl, (T::IHT + 0 * NT + kt) * 64), wz = tab_ld(tl, (T::IHT + 1 * NT + kt) * 64),
                                  wn = tab_ld(tl, (T::IHT + 2 * NT + kt) * 64);
-                    ds = mfma4(wr.x, drp[kt][0], ds); ds = mfma4(wr.y, drp[kt][1], ds); ds = mfma4(wr.z, drp[kt][2], ds); ds = mfma4(wr.w, drp[kt][3], ds);
-                    ds = mfma4(wz.x, dzp[kt][0], ds); ds = mfma4(wz.y, dzp[kt][1], ds); ds = mfma4(wz.z, dzp[kt][2], ds); ds = mfma4(wz.w, dzp[kt][3], ds);
-                    ds = mfma4(wn.x, dnp[kt][0], ds); ds = mfma4(wn.y, dnp[kt][1], ds); ds = mfma4(wn.z, dnp[kt][2], ds); ds = mfma4(wn.w, dnp[kt][3], ds);
+                    const f32x4 wrv = as_f32x4(wr), wzv = as_f32x4(wz), wnv = as_f32x4(wn);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (kt < NT - 1 || c < NCK) {
+                            ds = mfma4(wrv[c], drp[kt][c], ds); ds = mfma4(wzv[c], dzp[kt][c], ds); ds = mfma4(wnv[c], dnp[kt][c], ds);
+                        }
                 }
                 if constexpr (DG) {
                     const f32x4 f0 = as_f32x4(tab_ld(tl, (T::WFD + 0) * 64)), f1 = as_f32x4(tab_ld(tl, (T::WFD + 1) * 64));
@@ -342,7 +356,7 @@ __device__ __forceinline__ void s16n_write_row(float* prow, const GruLayout& L, 
     for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int i = 16 * mt + 4 * q + rr;
+            const int i = s16n_unit<NT>(mt, 4 * q + rr);
             if (i < H) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
@@ -354,12 +368,12 @@ __device__ __forceinline__ void s16n_write_row(float* prow, const GruLayout& L, 
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        if (16 * nt + n < H) prow[L.o_w_hh + (g * H + i) * H + 16 * nt + n] = G.thh[g][mt][nt][rr];
+                        if (s16n_unit<NT>(nt, n) < H) prow[L.o_w_hh + (g * H + i) * H + s16n_unit<NT>(nt, n)] = G.thh[g][mt][nt][rr];
                 }
                 if constexpr (DG) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        if (16 * nt + n < H) prow[L.o_w_hid + i * H + 16 * nt + n] = G.thid[mt][nt][rr];
+                        if (s16n_unit<NT>(nt, n) < H) prow[L.o_w_hid + i * H + s16n_unit<NT>(nt, n)] = G.thid[mt][nt][rr];
                 }
             }
             const float bhn = row_sum16(G.db_hn[mt][rr]), bhid = row_sum16(G.db_hid[mt][rr]);
@@ -391,7 +405,7 @@ __device__ __forceinline__ void s16n_write_row(float* prow, const GruLayout& L, 
 
 // MODE 0: fused train (x, target -> partials; checkpoints in `ckpt` workspace)   1: forward (y, optional ckpt)
 // MODE 2: backward from dy (partials if NW, dx if DX)
-template <int FM, bool DG, int NT, int MODE, bool NW, bool DX>
+template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
 __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArgs a) {
     using T = S16N<NT>;
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
@@ -441,11 +455,11 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArg
                     float fs[NCH];
                     f32x4 r[NT], z[NT], nn[NT], g[NT];
                     s16_slots<FM>(xv.x, xv.y, oh, fs);
-                    s16n_cell_fwd<FM, DG, NT>(opaque(tl), fs, h, r, z, nn, g);
+                    s16n_cell_fwd<FM, DG, NT, NCK>(opaque(tl), fs, h, r, z, nn, g);
                     if constexpr (MODE == 1) {
                         f32x4 hid[NT], act[NT];
                         float p0, p1;
-                        s16n_head<FM, DG, NT>(opaque(tl), h, fs, hid, act, p0, p1);
+                        s16n_head<FM, DG, NT, NCK>(opaque(tl), h, fs, hid, act, p0, p1);
                         const float y0 = quad_sum(p0), y1 = quad_sum(p1);
                         if (q == 0) ts[n * kChunkPad + tt] = make_float2(y0, y1);
                     }
@@ -502,9 +516,9 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArg
                 }
                 constexpr bool FUSED = MODE == 0, NWm = MODE == 0 || NW, DXm = MODE == 2 && DX;
                 if (nstep == S)
-                    s16n_block<FM, DG, NT, FUSED, NWm, DXm, true>(a, tl, oh, G, xs, ts, dxs, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+                    s16n_block<FM, DG, NT, FUSED, NWm, DXm, true, NCK>(a, tl, oh, G, xs, ts, dxs, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
                 else
-                    s16n_block<FM, DG, NT, FUSED, NWm, DXm, false>(a, tl, oh, G, xs, ts, dxs, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+                    s16n_block<FM, DG, NT, FUSED, NWm, DXm, false, NCK>(a, tl, oh, G, xs, ts, dxs, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
             }
             if constexpr (MODE == 2 && DX) {
                 if (cur_chunk >= 0) {
@@ -558,7 +572,7 @@ int64_t gru_s16n_ckpt_floats(const odpd_model_t* m, int B, int T) {
     return (int64_t)((B + 15) / 16) * num_ckpt(T) * s16n_tiles(m->hidden) * 256;
 }
 
-template <int FM, bool DG, int NT, int MODE, bool NW, bool DX>
+template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
 static int launch_s16n(hipStream_t st, const SeqArgs& a, int P) {
     using T = S16N<NT>;
     LaunchShape ls = s16n_shape(a.ngroups);     // the grid (= rows of partials) never depends on the backward's flavour
@@ -579,20 +593,26 @@ static int launch_s16n(hipStream_t st, const SeqArgs& a, int P) {
     size_t lds = bytes(ls.waves);
     if (lds > kMaxLds) { ls.waves = 2; lds = bytes(2); }      // weight gradients + dL/dx in one launch: two waves per CU
     if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
-    auto k = gru16n_kernel<FM, DG, NT, MODE, NW, DX>;
+    auto k = gru16n_kernel<FM, DG, NT, MODE, NW, DX, NCK>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
 }
-template <int FM, bool DG, int NT>
+template <int FM, bool DG, int NT, int NCK>
 static int launch_s16n_mode(hipStream_t st, const SeqArgs& a, int P, int mode) {
-    if (mode == 0) return launch_s16n<FM, DG, NT, 0, true, false>(st, a, P);
-    if (mode == 1) return launch_s16n<FM, DG, NT, 1, false, false>(st, a, P);
+    if (mode == 0) return launch_s16n<FM, DG, NT, 0, true, false, NCK>(st, a, P);
+    if (mode == 1) return launch_s16n<FM, DG, NT, 1, false, false, NCK>(st, a, P);
     const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
-    if (nw && dx) return launch_s16n<FM, DG, NT, 2, true, true>(st, a, P);
-    if (nw) return launch_s16n<FM, DG, NT, 2, true, false>(st, a, P);
-    if (dx) return launch_s16n<FM, DG, NT, 2, false, true>(st, a, P);
+    if (nw && dx) return launch_s16n<FM, DG, NT, 2, true, true, NCK>(st, a, P);
+    if (nw) return launch_s16n<FM, DG, NT, 2, true, false, NCK>(st, a, P);
+    if (dx) return launch_s16n<FM, DG, NT, 2, false, true, NCK>(st, a, P);
     return ODPD_EINVAL;
+}
+// hidden 17..24: the last unit tile holds <= 8 units = two K-chunks (instantiated: 2 and 4 chunks)
+template <int FM, bool DG, int NT>
+static int launch_s16n_chunks(hipStream_t st, const SeqArgs& a, int P, int mode, int H) {
+    if (s16n_last_chunks<NT>(H) <= 2) return launch_s16n_mode<FM, DG, NT, 2>(st, a, P, mode);
+    return launch_s16n_mode<FM, DG, NT, 4>(st, a, P, mode);
 }
 
 // mode 0 fused train, 1 forward, 2 backward
@@ -603,10 +623,10 @@ int gru_s16n_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, in
     SeqArgs a = a0;
     a.ngroups = (a.B + 15) / 16;
     const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
-    if (FM == FEAT_RAW2) return launch_s16n_mode<FEAT_RAW2, false, 2>(st, a, P, mode);
-    if (FM == FEAT_DGRU6) return launch_s16n_mode<FEAT_DGRU6, true, 2>(st, a, P, mode);
-    if (FM == FEAT_Q4) return launch_s16n_mode<FEAT_Q4, false, 2>(st, a, P, mode);
-    return launch_s16n_mode<FEAT_A4, false, 2>(st, a, P, mode);
+    if (FM == FEAT_RAW2) return launch_s16n_chunks<FEAT_RAW2, false, 2>(st, a, P, mode, m->hidden);
+    if (FM == FEAT_DGRU6) return launch_s16n_chunks<FEAT_DGRU6, true, 2>(st, a, P, mode, m->hidden);
+    if (FM == FEAT_Q4) return launch_s16n_chunks<FEAT_Q4, false, 2>(st, a, P, mode, m->hidden);
+    return launch_s16n_chunks<FEAT_A4, false, 2>(st, a, P, mode, m->hidden);
 }
 
 }  // namespace odpd

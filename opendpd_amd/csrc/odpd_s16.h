@@ -185,18 +185,20 @@ __device__ __forceinline__ void tile_get(const float* tile, int u, int k, float 
 
 
 // ---- operands streamed from an LDS table ([group][lane] float4), NT x NT tiles of 16 units ----------------------
-// acc[mt] += sum_{kt, c} T[base + mt*NT + kt][c] (x) v[kt][c]    — one streamed ds_read_b128 per (mt, kt)
-template <int NT>
+// acc[mt] += sum_{kt, c} T[base + mt*NT + kt][c] (x) v[kt][c]    — one streamed ds_read_b128 per (mt, kt).
+// NCK: K-chunks of the LAST unit tile that hold real units (gru_s16n.hip packs that tile element-major); the rest multiply zeros
+template <int NT, int NCK = 4>
 __device__ __forceinline__ void s16n_matvec(TabPtr tl, int base, const f32x4 (&v)[NT], f32x4 (&acc)[NT]) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const float4 w = tab_ld(tl, (base + mt * NT + kt) * 64);
+            constexpr int kLast = NT - 1;
             acc[mt] = mfma4(w.x, v[kt][0], acc[mt]);
-            acc[mt] = mfma4(w.y, v[kt][1], acc[mt]);
-            acc[mt] = mfma4(w.z, v[kt][2], acc[mt]);
-            acc[mt] = mfma4(w.w, v[kt][3], acc[mt]);
+            if (kt < kLast || NCK > 1) acc[mt] = mfma4(w.y, v[kt][1], acc[mt]);
+            if (kt < kLast || NCK > 2) acc[mt] = mfma4(w.z, v[kt][2], acc[mt]);
+            if (kt < kLast || NCK > 3) acc[mt] = mfma4(w.w, v[kt][3], acc[mt]);
         }
 }
 
