@@ -207,10 +207,19 @@ def main():
         n3 = max(3, min(args.steps, 10))
         xc = x if args.materialized else xs_.unfold(0, T, 1)[:B].permute(0, 2, 1).contiguous()   # the cascade takes tensors
         el3, _, loss3 = run_steps(opt3, xc, xc.clone(), n3, 2, world * B * T * 2, dist)
-        del xc
         dpd = {"workload": f"train_dpd: DGRU H{H} DPD -> frozen DGRU H{H} PA (five-launch cascade step), target = x",
                "value": B * T * n3 / el3, "unit": "IQ samples/s", "ms_per_step": 1e3 * el3 / n3, "loss": loss3}
         del casc, opt3
+        # BASELINE configs[2]: TRes-DeltaGRU H15 (thx .01, thh .05) DPD in front of a frozen DGRU H23 PA, same batch
+        torch.manual_seed(2)
+        casc = CascadedModel(dpd_model=CoreModel(2, 15, 1, "deltagru_tcnskip", thx=0.01, thh=0.05), pa_model=CoreModel(2, 23, 1, "dgru"))
+        casc.freeze_pa_model()
+        casc = casc.to(dev)
+        opt4 = FusedAdamW(casc, lr=5e-4)
+        el4, _, loss4 = run_steps(opt4, xc, xc.clone(), n3, 2, world * B * T * 2, dist)
+        dpd["config3"] = {"workload": "train_dpd: TRes-DeltaGRU H15 (thx 0.01, thh 0.05) DPD -> frozen DGRU H23 PA, target = x",
+                          "value": B * T * n3 / el4, "unit": "IQ samples/s", "ms_per_step": 1e3 * el4 / n3, "loss": loss4}
+        del xc, casc, opt4
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * B * T / (kern_ms * 1e-3) / 1e9
