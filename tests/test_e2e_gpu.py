@@ -207,3 +207,41 @@ def test_data_parallel_api_run_equals_single_process(workdir, dpd):
     for k in m1:
         a, b = m1[k].float(), m2[k].float()
         assert (a - b).abs().max() <= 2e-2 * max(1.0, a.abs().max()), k
+
+
+@pytest.fixture(scope="module")
+def apa_workdir(tmp_path_factory):
+    wd = tmp_path_factory.mktemp("odpd_apa")
+    for tag, name in (("apa200", "APA_200MHz"), ("apa200b", "APA_200MHz_b")):
+        d = dict(np.load(os.path.join(GOLDEN, f"{tag}_dataset.npz")))
+        ds = wd / "datasets" / name
+        ds.mkdir(parents=True)
+        (ds / "spec.json").write_text(str(d.pop("spec")))
+        for k, v in d.items():
+            pd.DataFrame(v, columns=["I", "Q"]).to_csv(ds / f"{k}.csv", index=False)
+    old, old_ds = os.getcwd(), os.environ.get("OPENDPD_DATASETS")
+    os.chdir(wd)
+    os.environ["OPENDPD_DATASETS"] = str(wd / "datasets")
+    yield wd
+    os.chdir(old)
+    if old_ds is not None:
+        os.environ["OPENDPD_DATASETS"] = old_ds
+
+
+@pytest.mark.parametrize("key,ds,bb", [("dgru_apa200", "APA_200MHz", "dgru"), ("vdlstm_apa200b", "APA_200MHz_b", "vdlstm")])
+def test_baseline_config_2_and_4_epochs_match_reference_log(apa_workdir, key, ds, bb):
+    """BASELINE configs 2 and 4 on their own datasets: one epoch of train_pa (230 steps of 256 x 200 frames, last batch 157;
+    fused single-launch train kernels + native epoch loop) against the row the REFERENCE logged for the same command
+    (tests/golden/ref_runs_apa.json, oracle/gen_run_anchors_apa.py)."""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_apa.json")))[key]
+    res = od.train_pa(dataset_name=ds, PA_backbone=bb, PA_hidden_size=13, frame_length=200, batch_size=256, seed=0, n_epochs=1,
+                      accelerator="cuda")
+    assert os.path.basename(res["model_path"])[:-3] == ref["model_id"]
+    hist = pd.read_csv(os.path.join("log", ds, "train_pa", "history", os.path.basename(res["log_path"])))
+    rh = ref["hist"]
+    assert list(hist.columns) == list(rh.keys())
+    assert hist["N_PARAM"][0] == rh["N_PARAM"][0]
+    assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 2e-3 * rh["TRAIN_LOSS"][0]
+    for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_EVM", "TEST_ACLR_AVG"):
+        assert abs(hist[col][0] - rh[col][0]) < 0.05, (col, hist[col][0], rh[col][0])   # dB
