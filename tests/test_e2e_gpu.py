@@ -245,3 +245,26 @@ def test_baseline_config_2_and_4_epochs_match_reference_log(apa_workdir, key, ds
     assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 2e-3 * rh["TRAIN_LOSS"][0]
     for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_EVM", "TEST_ACLR_AVG"):
         assert abs(hist[col][0] - rh[col][0]) < 0.05, (col, hist[col][0], rh[col][0])   # dB
+
+
+def test_baseline_config_3_epoch_on_apa_matches_reference_log(apa_workdir):
+    """BASELINE config 3 on its own dataset: train_dpd of TRes-DeltaGRU H15 (thx .01, thh .05) in front of the frozen DGRU H23
+    PA the REFERENCE trained (its state dict is a fixture), 919 steps of 64 x 200 frames through the five-launch cascade step,
+    against the row the reference logged (tests/golden/ref_runs_apa.json).  Thresholded model: rounding-level differences
+    flip a few delta decisions over 919 steps, hence dB-level tolerances on the metrics."""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_apa.json")))["config3_apa200"]
+    m = dict(np.load(os.path.join(GOLDEN, "ref_runs_apa_models.npz")))
+    os.makedirs(os.path.dirname(ref["pa_model"]), exist_ok=True)
+    torch.save({k[3:]: torch.from_numpy(v) for k, v in m.items() if k.startswith("pa/")}, ref["pa_model"])
+    res = od.train_dpd(dataset_name="APA_200MHz", PA_backbone="dgru", PA_hidden_size=23, DPD_backbone="deltagru_tcnskip",
+                       DPD_hidden_size=15, thx=0.01, thh=0.05, frame_length=200, batch_size=64, seed=0, n_epochs=1, accelerator="cuda")
+    assert os.path.normpath(res["model_path"]) == os.path.normpath(ref["dpd_model"])
+    hist = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), "history", os.path.basename(res["log_path"])))
+    rh = ref["hist"]
+    assert list(hist.columns) == list(rh.keys())
+    assert hist["N_PARAM"][0] == rh["N_PARAM"][0] == 999 + 2751        # the log counts the whole cascade
+    assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 0.03 * rh["TRAIN_LOSS"][0]
+    assert abs(hist["SP_T_DX"][0] - rh["SP_T_DX"][0]) < 0.01 and abs(hist["SP_T_DH"][0] - rh["SP_T_DH"][0]) < 0.02
+    for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
+        assert abs(hist[col][0] - rh[col][0]) < 0.5, (col, hist[col][0], rh[col][0])
