@@ -268,3 +268,28 @@ def test_baseline_config_3_epoch_on_apa_matches_reference_log(apa_workdir):
     assert abs(hist["SP_T_DX"][0] - rh["SP_T_DX"][0]) < 0.01 and abs(hist["SP_T_DH"][0] - rh["SP_T_DH"][0]) < 0.02
     for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
         assert abs(hist[col][0] - rh[col][0]) < 0.5, (col, hist[col][0], rh[col][0])
+
+
+def test_baseline_config_5_qat_epoch_on_apa_matches_reference_log(apa_workdir):
+    """BASELINE config 5 on its own dataset: quantisation-aware train_dpd (QGRU H10, W8A8) in front of the frozen DGRU H23 PA
+    the REFERENCE trained, 919 steps of 64 x 200, against the row the reference logged (tests/golden/ref_runs_qat.json,
+    oracle/gen_run_anchor_qat.py).  The quantised cell is bit-exact per step (tests/test_quant_gpu.py); the float PA in the loop
+    differs at rounding level, which can move a value across a quantisation boundary: dB-level tolerances."""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_qat.json")))
+    m = dict(np.load(os.path.join(GOLDEN, "ref_runs_apa_models.npz")))
+    os.makedirs(os.path.dirname(ref["pa_model"]), exist_ok=True)
+    torch.save({k[3:]: torch.from_numpy(v) for k, v in m.items() if k.startswith("pa/")}, ref["pa_model"])
+    res = od.train_dpd(dataset_name="APA_200MHz", PA_backbone="dgru", PA_hidden_size=23, DPD_backbone="qgru", DPD_hidden_size=10,
+                       quant=True, n_bits_w=8, n_bits_a=8, frame_length=200, batch_size=64, seed=0, n_epochs=1, accelerator="cuda")
+    assert os.path.normpath(res["model_path"]) == os.path.normpath(ref["dpd_model"])
+    hist = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), "history", os.path.basename(res["log_path"])))
+    rh = ref["hist"]
+    assert list(hist.columns) == list(rh.keys())
+    assert hist["N_PARAM"][0] == rh["N_PARAM"][0]
+    assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 0.03 * rh["TRAIN_LOSS"][0]
+    for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
+        assert abs(hist[col][0] - rh[col][0]) < 0.5, (col, hist[col][0], rh[col][0])
+    sd = torch.load(res["model_path"], map_location="cpu")
+    want = {k[4:]: v for k, v in np.load(os.path.join(GOLDEN, "ref_runs_qat_models.npz")).items()}
+    assert list(sd.keys()) == list(want.keys())

@@ -28,6 +28,15 @@ h = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), 
 print(f"config 3 (train_dpd TRes-DeltaGRU15 -> frozen reference-trained DGRU23, 919 steps of 64 x 200): {dt:.2f} s wall")
 for c in ("TRAIN_LOSS", "SP_T_DX", "SP_T_DH", "VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
     print(f"   {c:14s} here {h[c][0]:.6f}   reference {c3['hist'][c][0]:.6f}")
+q = json.load(open(os.path.join(G, "ref_runs_qat.json")))
+t0 = time.time()
+res = od.train_dpd(dataset_name="APA_200MHz", PA_backbone="dgru", PA_hidden_size=23, DPD_backbone="qgru", DPD_hidden_size=10, quant=True,
+                   n_bits_w=8, n_bits_a=8, frame_length=200, batch_size=64, seed=0, n_epochs=1, accelerator="cuda")
+dt = time.time() - t0
+h = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), "history", os.path.basename(res["log_path"])))
+print(f"config 5 (QAT W8A8 train_dpd QGRU10 -> frozen reference-trained DGRU23, 919 steps of 64 x 200): {dt:.2f} s wall")
+for c in ("TRAIN_LOSS", "VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
+    print(f"   {c:14s} here {h[c][0]:.6f}   reference {q['hist'][c][0]:.6f}")
 for key, ds, bb in (("dgru_apa200", "APA_200MHz", "dgru"), ("vdlstm_apa200b", "APA_200MHz_b", "vdlstm")):
     t0 = time.time()
     res = od.train_pa(dataset_name=ds, PA_backbone=bb, PA_hidden_size=13, frame_length=200, batch_size=256, seed=0, n_epochs=1, accelerator="cuda")
