@@ -61,6 +61,9 @@ typedef struct odpd_model {
 /* eval-mode forward of a quantised model: fc_out's 16-bit output quantiser is active only when the reference
  * module is not in training mode (quant/qmodules/quant_layers.py:77-80) */
 #define ODPD_FLAG_EVAL 1
+/* delta backbones: the caller will ask odpd_backbone_bwd for dL/dx (frozen PA of a cascade, x.requires_grad): selects the kernels
+ * that provide it for forward, checkpoint sizing and backward alike; backward then also needs a `partials` buffer */
+#define ODPD_FLAG_NEED_DX 2
 
 /* loss kinds — project.py:262-272 */
 enum odpd_loss { ODPD_LOSS_L2 = 0, ODPD_LOSS_L1 = 1 };

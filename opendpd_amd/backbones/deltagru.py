@@ -56,6 +56,8 @@ class _GruLayerParams(nn.Module):
 
 
 class _DeltaBase(NativeBackbone):
+    dx_needs_flag = True
+
     def _setup_delta(self, hidden_size, thx, thh):
         self.thx, self.thh = thx, thh
         self._dstats = _DeltaStats()

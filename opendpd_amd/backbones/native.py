@@ -74,6 +74,11 @@ class _BackboneFn(torch.autograd.Function):
         B, T = x.shape[0], x.shape[1]
         flat = mod.flat_params()
         need_grad = any(ctx.needs_input_grad)
+        if mod.dx_needs_flag:
+            # delta backbones: dL/dx lives in the 16-sequences-per-wave kernels only; the flag routes forward, checkpoint sizing
+            # and backward of THIS call to them (include/opendpd_hip.h: ODPD_FLAG_NEED_DX)
+            mod.desc.flags = (mod.desc.flags & ~_lib.FLAG_NEED_DX) | (_lib.FLAG_NEED_DX if ctx.needs_input_grad[0] else 0)
+        ctx.flags = mod.desc.flags
         y = torch.empty_like(x)
         ckpt = None
         if need_grad:
@@ -99,7 +104,8 @@ class _BackboneFn(torch.autograd.Function):
         need_w = any(ctx.needs_input_grad[2:])
         P = mod.n_flat
         partials = grad = dx = None
-        if need_w:
+        mod.desc.flags = ctx.flags
+        if need_w or (need_dx and mod.dx_needs_flag):      # the delta kernels compute the weight gradients in every backward launch
             rows = int(lib.odpd_partial_rows(C.byref(mod.desc), B, T, 0))
             _lib.check(0 if rows > 0 else rows, "odpd_partial_rows")
             partials = torch.empty(rows, P + _lib.LOSS_COLS, dtype=torch.float32, device=x.device)
@@ -126,6 +132,7 @@ class NativeBackbone(nn.Module):
 
     backbone_name = None
     native = True
+    dx_needs_flag = False      # True for the delta backbones (ODPD_FLAG_NEED_DX)
 
     def _finalize(self, hidden_size, thx=0.0, thh=0.0, bits_w=0, bits_a=0):
         """Call at the end of __init__ once every parameter holder is registered."""

@@ -27,6 +27,8 @@ struct D16 {
     static constexpr int WOUT = HHT + 3 * NT * NT;     // cc*NT + mt          : fc_out[cc][16mt+4q+e]
     static constexpr int DM0 = WOUT + 2 * NT;          // j*NT + mt           : initial accumulators r, z, n, nh
     static constexpr int NG = DM0 + 4 * NT;
+    static constexpr int IHT = NG;                     // g*NT + kt : W_ig[16kt+4q+e][slot(m)], slot(m) = 4 (m & 3) + (m >> 2)  (dL/dx)
+    static constexpr int NG_DX = IHT + 3 * NT;
     static constexpr int kCk = 6 * NT + 1;             // float4 per lane per checkpoint
     static constexpr int kTiles = 5 * NT + 1;          // gr gz gn gnh dhm per unit tile + feature-delta tile
 };
@@ -50,6 +52,11 @@ __device__ __forceinline__ float4 d16_entry(const float* pl, const DeltaLayout& 
         } else if (grp < T::DM0) {
             const int r = grp - T::WOUT, k = 16 * (r % NT) + 4 * q + e;
             v[e] = k < H ? pl[L.o_w_out + (r / NT) * H + k] : 0.0f;
+        } else if (grp >= T::IHT) {
+            // transposed input weights with the output rows permuted so that D row 4 q' + i = slot 4 i + q': the MFMA result
+            // of lane (n, q) element c IS the gradient of the lane's own feature slot 4 c + q
+            const int r = grp - T::IHT, g = r / NT, k = 16 * (r % NT) + 4 * q + e, slot = 4 * (m & 3) + (m >> 2);
+            v[e] = (slot < 6 && k < H) ? pl[L.o_w_ih + (g * H + k) * 6 + slot] : 0.0f;
         } else {
             const int r = grp - T::DM0, j = r / NT, k = 16 * (r % NT) + 4 * q + e;
             float b = 0.0f;
@@ -102,13 +109,14 @@ template <bool TRES, int NT>
 __device__ __forceinline__ void d16_cell_fwd(TabPtr tl, const float (&fs)[2], float thx, float thh, const bool (&slot_ok)[2],
                                              const f32x4 (&unit_ok)[NT], D16State<NT>& st, f32x4 (&hprev)[NT], f32x4 (&dhm)[NT],
                                              f32x4 (&mh)[NT], f32x4 (&r)[NT], f32x4 (&z)[NT], f32x4 (&n)[NT], float (&dxm)[2],
-                                             float& zx, float& zh) {
+                                             float& zx, float& zh, float (&mx)[2]) {
     using T = D16<NT>;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const float d = fs[c] - st.xp[c];
         const bool keep = !(__builtin_fabsf(d) < thx);           // masked_fill(|d| < th, 0)  (deltagru.py:179-183)
         dxm[c] = keep ? d : 0.0f;
+        mx[c] = keep ? 1.0f : 0.0f;
         st.xp[c] = (__builtin_fabsf(d) >= thx) ? fs[c] : st.xp[c];
         zx += (slot_ok[c] && dxm[c] == 0.0f) ? 1.0f : 0.0f;
     }
@@ -243,10 +251,10 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
             for (int tt = 0; tt < len; ++tt) {
                 const float2 xv = xr[tt];
                 const float2 xn = (t0 + tt + 1 < a.T) ? xr[tt + 1] : x0;      // torch.roll(x, -1): the last step sees sample 0
-                float fs[2], dxm[2];
+                float fs[2], dxm[2], mx[2];
                 f32x4 hprev[NT], dhm[NT], mh[NT], r[NT], z[NT], nn[NT];
                 d16_slots<TRES>(xv, xn, oh, fs);
-                d16_cell_fwd<TRES, NT>(opaque(tl), fs, a.thx, a.thh, slot_ok, unit_ok, st, hprev, dhm, mh, r, z, nn, dxm, zxs, zhs);
+                d16_cell_fwd<TRES, NT>(opaque(tl), fs, a.thx, a.thh, slot_ok, unit_ok, st, hprev, dhm, mh, r, z, nn, dxm, zxs, zhs, mx);
                 float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
                 for (int mt = 0; mt < NT; ++mt) {
@@ -321,12 +329,13 @@ struct D16Grad {
     }
 };
 template <int NT>
-struct D16Carry { f32x4 gh[NT], ghp[NT], gr[NT], gz[NT], gn[NT], gnh[NT]; };
+struct D16Carry { f32x4 gh[NT], ghp[NT], gr[NT], gz[NT], gn[NT], gnh[NT]; float gxp[2], wrap[2]; };
 
-template <bool TRES, int NT, bool FULL>
+template <bool TRES, int NT, bool FULL, bool DX>
 __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, const D16Scalars<TRES>& sc, const float (&oh)[4],
-                                              D16Grad<TRES, NT>& G, const float2* xr, const float2* dys, float* tiles, float2 x0,
-                                              int n, int q, int tglob, int tloc, int nstep, D16State<NT> st, D16Carry<NT>& C) {
+                                              D16Grad<TRES, NT>& G, const float2* xr, const float2* dys, float2* dxs, float* tiles,
+                                              float2 x0, int n, int q, int tglob, int tloc, int nstep, int chunk_len, float* dxrow,
+                                              D16State<NT> st, D16Carry<NT>& C) {
     using T = D16<NT>;
     constexpr int S = kCkptStride;
     const bool slot_ok[2] = {true, q < 2};
@@ -334,7 +343,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) all_units[kt] = f32x4{1.f, 1.f, 1.f, 1.f};
     f32x4 hprev_s[S][NT], dhm_s[S][NT], mh_s[S][NT], r_s[S][NT], z_s[S][NT], n_s[S][NT], nh_s[S][NT];
-    float dxm_s[S][2];
+    float dxm_s[S][2], mx_s[S][2];
     TabPtr tl = opaque(tl0);
     {
         float zx = 0.f, zh = 0.f;
@@ -346,7 +355,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 float fs[2];
                 d16_slots<TRES>(xv, xn, oh, fs);
                 d16_cell_fwd<TRES, NT>(tl, fs, a.thx, a.thh, slot_ok, all_units, st, hprev_s[si], dhm_s[si], mh_s[si], r_s[si],
-                                       z_s[si], n_s[si], dxm_s[si], zx, zh);
+                                       z_s[si], n_s[si], dxm_s[si], zx, zh, mx_s[si]);
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) nh_s[si][kt] = st.dmnh[kt];
             }
@@ -412,6 +421,52 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 const f32x4 mk = mh_s[si][mt];
                 C.gh[mt] = fma4(mk, add4(ddh[mt], C.ghp[mt]), ghprev[mt]);
                 ODPD_EACH4 C.ghp[mt][i] = __builtin_fmaf(-mk[i], ddh[mt][i], (1.0f - mk[i]) * C.ghp[mt][i]);
+            }
+            if constexpr (DX) {
+                // dL/d(masked feature delta) = W_ih^T [G_r, G_z, G_n], landing on the lane's own feature slots; then the same
+                // keep / carry logic as for h (x_p <- x where kept):  dL/dfeat = m (g + G_xp),  G_xp <- -m g + (1 - m) G_xp
+                f32x4 ds = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    const f32x4 wr = as_f32x4(tab_ld(tl, (T::IHT + 0 * NT + kt) * 64)), wz = as_f32x4(tab_ld(tl, (T::IHT + 1 * NT + kt) * 64)),
+                                wn = as_f32x4(tab_ld(tl, (T::IHT + 2 * NT + kt) * 64));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ds = mfma4(wr[c], C.gr[kt][c], ds); ds = mfma4(wz[c], C.gz[kt][c], ds); ds = mfma4(wn[c], C.gn[kt][c], ds);
+                    }
+                }
+                float dfs[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float m = mx_s[si][c], g = ds[c];
+                    dfs[c] = m * (g + C.gxp[c]);
+                    C.gxp[c] = __builtin_fmaf(-m, g, (1.0f - m) * C.gxp[c]);
+                }
+                // feature Jacobian: every lane contributes its two slots (4 c + q), the sequence's four lanes are summed
+                const float2 xv = xr[tt];
+                float dI, dQ, nI = 0.0f, nQ = 0.0f;
+                if constexpr (TRES) {      // [I, Q, |x|, |x|^3, I_next, Q_next]: slots 4, 5 belong to sample t + 1
+                    const float df[4] = {oh[0] * dfs[0], oh[1] * dfs[0], oh[2] * dfs[0], oh[3] * dfs[0]};
+                    feat_bwd<FEAT_A4>(xv.x, xv.y, df, dI, dQ);
+                    nI = quad_sum(oh[0] * dfs[1]); nQ = quad_sum(oh[1] * dfs[1]);
+                } else {                   // [I, Q, |x|, |x|^3, sin, cos]
+                    const float df[6] = {oh[0] * dfs[0], oh[1] * dfs[0], oh[2] * dfs[0], oh[3] * dfs[0], oh[0] * dfs[1], oh[1] * dfs[1]};
+                    feat_bwd<FEAT_DGRU6>(xv.x, xv.y, df, dI, dQ);
+                }
+                dI = quad_sum(dI); dQ = quad_sum(dQ);
+                if (q == 0) {
+                    dxs[n * kChunkPad + tt] = make_float2(dI, dQ);
+                    if constexpr (TRES) {
+                        const int t1 = tglob + si + 1;
+                        if (t1 >= a.T) { C.wrap[0] = nI; C.wrap[1] = nQ; }                 // torch.roll: the last step's "next" is sample 0
+                        else if (tt + 1 < chunk_len) { dxs[n * kChunkPad + tt + 1].x += nI; dxs[n * kChunkPad + tt + 1].y += nQ; }
+                        else if (dxrow != nullptr) {   // sample t + 1 lives in the chunk this wave flushed before: add at L2
+                            __threadfence();
+                            atomicAdd(dxrow + 2 * t1, nI);
+                            atomicAdd(dxrow + 2 * t1 + 1, nQ);
+                        }
+                    }
+                }
             }
             // weight gradients: dW_ih += G_dm^T (x) dx_masked, dW_hh += [G_r, G_z, G_nh]^T (x) dh_masked
             wave_lds_fence();
@@ -500,11 +555,12 @@ __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L,
     }
 }
 
-template <bool TRES, int NT>
+template <bool TRES, int NT, bool DX>
 __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     using T = D16<NT>;
     constexpr int S = kCkptStride;
-    constexpr int kWave = 2 * 16 * d16::kStride + 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
+    constexpr int kWave = 2 * 16 * d16::kStride + (DX ? 2 : 1) * 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
+    constexpr int kGroups = DX ? T::NG_DX : T::NG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -514,7 +570,7 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     float* tab = smem + pad4(L.P);
     {
         float4* t4 = reinterpret_cast<float4*>(tab);
-        for (int grp = wave; grp < T::NG; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES, NT>(pl, L, grp, n, q);
+        for (int grp = wave; grp < kGroups; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES, NT>(pl, L, grp, n, q);
         __syncthreads();
     }
     const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
@@ -523,10 +579,11 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     float oh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
-    float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
+    float* wbase = tab + s16_tab_floats(kGroups) + (size_t)wave * kWave;
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* dys = xs + 16 * d16::kStride;
-    float* tiles = reinterpret_cast<float*>(dys + 16 * kChunkPad);
+    float2* dxs = dys + 16 * kChunkPad;                   // DX only
+    float* tiles = reinterpret_cast<float*>(dys + (DX ? 2 : 1) * 16 * kChunkPad);
     for (int i = lane; i < kTileFloats; i += 64) tiles[5 * NT * kTileFloats + i] = 0.0f;
     const float2* xr = xs + n * d16::kStride + d16::kHalo;
     D16Grad<TRES, NT> G;
@@ -541,13 +598,22 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
         D16Carry<NT> C;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) { C.gh[kt] = z4; C.ghp[kt] = z4; C.gr[kt] = z4; C.gz[kt] = z4; C.gn[kt] = z4; C.gnh[kt] = z4; }
-        int cur_chunk = -1;
+        C.gxp[0] = C.gxp[1] = C.wrap[0] = C.wrap[1] = 0.0f;
+        float* dxrow = (DX && valid) ? a.dx + (size_t)(b0 + n) * a.T * 2 : nullptr;
+        int cur_chunk = -1, cur_len = 0;
         for (int blk = a.nck - 1; blk >= 0; --blk) {
             const int tb = blk * S, nstep = min(S, a.T - tb);
             const int chunk = tb / kChunk, t0 = chunk * kChunk;
             if (chunk != cur_chunk) {
+                if constexpr (DX) {
+                    if (cur_chunk >= 0) {
+                        wave_lds_fence();
+                        stage_out<16>(dxs, a.dx, b0, a.B, a.T, cur_chunk * kChunk, cur_len, lane);
+                    }
+                }
                 wave_lds_fence();
                 const int len = min(kChunk, a.T - t0);
+                cur_len = len;
                 d16_stage_x(xs, a.x, b0, a.B, a.T, t0, lane);
                 stage_in<16>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
                 wave_lds_fence();
@@ -567,8 +633,15 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
             } else {
                 d16_init_state<NT>(tl, st);
             }
-            if (nstep == S) d16_bwd_block<TRES, NT, true>(a, tl, sc, oh, G, xr, dys, tiles, x0, n, q, tb, tb - t0, nstep, st, C);
-            else d16_bwd_block<TRES, NT, false>(a, tl, sc, oh, G, xr, dys, tiles, x0, n, q, tb, tb - t0, nstep, st, C);
+            if (nstep == S) d16_bwd_block<TRES, NT, true, DX>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+            else d16_bwd_block<TRES, NT, false, DX>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+        }
+        if constexpr (DX) {
+            wave_lds_fence();
+            if (q == 0) { dxs[n * kChunkPad].x += C.wrap[0]; dxs[n * kChunkPad].y += C.wrap[1]; }   // roll(x, -1): step T-1 saw sample 0
+            wave_lds_fence();
+            stage_out<16>(dxs, a.dx, b0, a.B, a.T, 0, cur_len, lane);
+            wave_lds_fence();
         }
         // gradient w.r.t. the initial accumulators = bias gradients (deltagru.py:165-170)
 #pragma unroll
@@ -589,13 +662,52 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     }
 }
 
+// dL/dx through the TRes skip path  skip = HS(conv2(HS(conv1(x)))), conv1: k3, dilation 16, zero padding (time-parallel):
+// dx[ch][t] += sum_k sum_c w1[c][ch][k] d1[c][t - 16 (k - 1)],  d1 = HS'(s1) (w2^T d2),  d2 = HS'(s2) dy
+__global__ __launch_bounds__(256) void tres_skip_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ params, float* __restrict__ dx, int B, int T, int H) {
+    const DeltaLayout L = delta_layout(H, true);
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * T) return;
+    const int b = (int)(idx / T), t = (int)(idx % T);
+    const float2* x2 = reinterpret_cast<const float2*>(x) + (size_t)b * T;
+    const float2* d2y = reinterpret_cast<const float2*>(dy) + (size_t)b * T;
+    const float* w1 = params + L.o_tcn0;
+    const float* w2 = params + L.o_tcn2;
+    auto at = [&](int p) { return (p >= 0 && p < T) ? x2[p] : make_float2(0.0f, 0.0f); };
+    float gI = 0.0f, gQ = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = t - 16 * (k - 1);
+        if (p < 0 || p >= T) continue;
+        const float2 xm = at(p - 16), xc = at(p), xq = at(p + 16), dyp = d2y[p];
+        float s1[3], s2[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s1[c] = w1[c * 6] * xm.x + w1[c * 6 + 1] * xc.x + w1[c * 6 + 2] * xq.x + w1[c * 6 + 3] * xm.y + w1[c * 6 + 4] * xc.y + w1[c * 6 + 5] * xq.y;
+            const float hs = hardswishf_(s1[c]);
+            s2[0] = __builtin_fmaf(w2[c], hs, s2[0]); s2[1] = __builtin_fmaf(w2[3 + c], hs, s2[1]);
+        }
+        const float e0 = dyp.x * d16_hsg(s2[0]), e1 = dyp.y * d16_hsg(s2[1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d1 = __builtin_fmaf(e0, w2[c], e1 * w2[3 + c]) * d16_hsg(s1[c]);
+            gI = __builtin_fmaf(w1[c * 6 + k], d1, gI);
+            gQ = __builtin_fmaf(w1[c * 6 + 3 + k], d1, gQ);
+        }
+    }
+    float2* o = reinterpret_cast<float2*>(dx) + (size_t)b * T + t;
+    const float2 cur = *o;
+    *o = make_float2(cur.x + gI, cur.y + gQ);
+}
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
 // hidden <= 16: from the batch size that fills the chip; hidden 17..32: always (the row-rotated delta kernels stop at 16)
 bool delta_uses_s16(const odpd_model_t* m, int B) {
     if ((m->backbone != ODPD_DELTAGRU && m->backbone != ODPD_TRES_DELTAGRU) || m->hidden > 32) return false;
-    if (m->hidden > 16) return true;
+    if (m->hidden > 16 || (m->flags & ODPD_FLAG_NEED_DX)) return true;      // dL/dx lives in these kernels only
     long min_batch = tuning().s16_min_batch;
     if (min_batch < 0) min_batch = 16L * 4 * device_cus();
     return B >= min_batch;
@@ -609,10 +721,11 @@ static LaunchShape d16_fwd_shape(int ngroups, int nt) {
     return ls;
 }
 static int d16_tiles(int H) { return (H + 15) / 16; }
-static size_t d16_bwd_lds(int P, int nt, int waves) {
-    const int groups = nt == 1 ? D16<1>::NG : D16<2>::NG, tiles = nt == 1 ? D16<1>::kTiles : D16<2>::kTiles;
+static size_t d16_bwd_lds(int P, int nt, int waves, bool dx) {
+    const int groups = nt == 1 ? (dx ? D16<1>::NG_DX : D16<1>::NG) : (dx ? D16<2>::NG_DX : D16<2>::NG);
+    const int tiles = nt == 1 ? D16<1>::kTiles : D16<2>::kTiles;
     size_t lds = ((size_t)pad4(P) + s16_tab_floats(groups) +
-                  (size_t)waves * (2 * 16 * d16::kStride + 2 * 16 * kChunkPad + tiles * kTileFloats)) * sizeof(float);
+                  (size_t)waves * (2 * 16 * d16::kStride + (dx ? 2 : 1) * 2 * 16 * kChunkPad + tiles * kTileFloats)) * sizeof(float);
     if (lds < reduce_scratch_bytes(P, waves)) lds = reduce_scratch_bytes(P, waves);
     return lds;
 }
@@ -620,8 +733,9 @@ static size_t d16_bwd_lds(int P, int nt, int waves) {
 static LaunchShape d16_bwd_shape(const odpd_model_t* m, int ngroups) {
     LaunchShape ls;
     const int P = delta_layout(m->hidden, m->backbone == ODPD_TRES_DELTAGRU).P, nt = d16_tiles(m->hidden);
+    const bool dx = (m->flags & ODPD_FLAG_NEED_DX) != 0;      // the shape (= rows of partials) is fixed by the model, not by the call
     ls.waves = 4;
-    while (ls.waves > 1 && d16_bwd_lds(P, nt, ls.waves) > kMaxLds) --ls.waves;
+    while (ls.waves > 1 && d16_bwd_lds(P, nt, ls.waves, dx) > kMaxLds) --ls.waves;
     const int need = (ngroups + ls.waves - 1) / ls.waves, cus = device_cus();
     ls.grid = need < cus ? need : cus;
     return ls;
@@ -641,14 +755,24 @@ static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, i
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
         return (int)hipGetLastError();
     }
-    if (a.dx != nullptr) return ODPD_EUNSUPPORTED;   // dL/dx of a delta backbone is not implemented
+    // the weight gradients ride along in every backward launch: partials are required (a frozen model passes a scratch buffer)
     if (a.partials == nullptr) return ODPD_EINVAL;
+    const bool dxf = (m->flags & ODPD_FLAG_NEED_DX) != 0;
+    if (a.dx != nullptr && !dxf) return ODPD_EINVAL;          // the forward must have run with ODPD_FLAG_NEED_DX as well
     const LaunchShape ls = d16_bwd_shape(m, a.ngroups);
-    const size_t lds = d16_bwd_lds(P, NT, ls.waves);
+    const size_t lds = d16_bwd_lds(P, NT, ls.waves, dxf);
     if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
-    auto k = delta16_bwd_kernel<TRES, NT>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    if (a.dx == nullptr) return launch(delta16_bwd_kernel<TRES, NT, false>);
+    if (int e = launch(delta16_bwd_kernel<TRES, NT, true>)) return e;
+    if (TRES) {
+        const long n = (long)a.B * a.T;
+        hipLaunchKernelGGL(tres_skip_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.x, a.dy, a.params, a.dx, a.B, a.T, a.H);
+    }
     return (int)hipGetLastError();
 }
 int delta_s16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int mode) {

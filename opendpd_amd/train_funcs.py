@@ -48,6 +48,8 @@ class FusedAdamW:
             trained, self.pa = net.dpd_model, net.pa_model.backbone
             if not isinstance(self.pa, NativeBackbone):
                 raise TypeError("FusedAdamW needs a HIP-backed PA model (this one runs through ATen)")
+            if self.pa.dx_needs_flag:       # a frozen delta PA is asked for dL/du in every step
+                self.pa.desc.flags |= _lib.FLAG_NEED_DX
         if not (isinstance(trained, CoreModel) and isinstance(trained.backbone, NativeBackbone)):
             raise TypeError("FusedAdamW needs a HIP-backed CoreModel (or a CascadedModel of two)")
         self.net = net
@@ -126,7 +128,11 @@ class FusedAdamW:
             d = dict(u=mk(), dy=mk(), ck_d=ck(self.backbone),
                      loss=torch.zeros(_lib.LOSS_WS, dtype=torch.float32, device=device))
             if self.pa is not None:
-                d.update(y=mk(), du=mk(), ck_p=ck(self.pa))
+                d.update(y=mk(), du=mk(), ck_p=ck(self.pa), pa_part=None)
+                if self.pa.dx_needs_flag:   # the delta backward kernels write their weight gradients in every launch: scratch
+                    rows = int(lib.odpd_partial_rows(C.byref(self.pa.desc), B, T, 0))
+                    _lib.check(0 if rows > 0 else rows, "odpd_partial_rows")
+                    d["pa_part"] = torch.empty(rows, self.pa.n_flat + _lib.LOSS_COLS, dtype=torch.float32, device=device)
             self._cascade_bufs[(B, T)] = d
         return self._cascade_bufs[(B, T)]
 
@@ -299,7 +305,7 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
     du = buf["dy"]
     if pa is not None:
         _lib.check(lib.odpd_backbone_bwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["dy"]),
-                                         _lib.ptr(buf["ck_p"]), None, _lib.ptr(buf["du"])), "pa bwd")
+                                         _lib.ptr(buf["ck_p"]), _lib.ptr(buf["pa_part"]), _lib.ptr(buf["du"])), "pa bwd")
         du = buf["du"]
     _lib.check(lib.odpd_backbone_bwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(du),
                                      _lib.ptr(buf["ck_d"]), _lib.ptr(part), None), "dpd bwd")
