@@ -13,8 +13,8 @@
 // The GPU computes the masked products densely (a 64-lane SIMD cannot skip per-lane zeros); what is kept
 // from the delta formulation is the exact arithmetic (thresholded memories and accumulators) and the counters.
 // Backward: the gradient through the x_p memory only reaches the INPUT (features carry no parameters), so the
-// parameter-gradient path needs the dh/h_p chain only.  dL/dx is not implemented for this family (a delta model
-// is used as the DPD, never as the frozen PA).  One 16-lane row per sequence: H <= 16.
+// parameter-gradient path needs the dh/h_p chain only.  dL/dx (delta model as the frozen PA, x.requires_grad) is provided by
+// the S16 kernels of delta_s16.hip, which ODPD_FLAG_NEED_DX selects at every batch size.  One 16-lane row per sequence: H <= 16.
 #include "odpd_seq.h"
 
 namespace odpd {

@@ -42,7 +42,7 @@ for bb, sizes in SIZES.items():
                 amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
                 x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
                 dy = rng.randn(B, T, 2).astype(np.float32)
-                need_dx = "delta" not in bb
+                need_dx = "delta" not in bb or force      # delta: dL/dx lives in the S16 kernels (ODPD_FLAG_NEED_DX routes there)
                 xt = torch.from_numpy(x).cuda().requires_grad_(need_dx)
                 try:
                     y = net(xt)
