@@ -12,7 +12,8 @@
 // lane/launch); for wider grids they are evaluated in double per element.  This file is compiled with FP contraction
 // off: a fused multiply-add would change roundings the reference does not have.
 // Backward = straight-through estimator (gradient passes where x/s lies inside [Qn,Qp]); the 13 scale parameters get an
-// exact 0 gradient.  One 16-lane row per sequence (H <= 16); dL/dx is not implemented (QGRU is the DPD).
+// exact 0 gradient.  One 16-lane row per sequence (H <= 16); dL/dx = the quantised W_x^T behind the straight-through mask of
+// the x2h activation quantiser and the feature Jacobian (QAT model as the frozen PA / x.requires_grad).
 #include "odpd_seq.h"
 
 #pragma clang fp contract(off)
@@ -242,10 +243,10 @@ struct QgruGrad {
     }
 };
 
-template <bool AMP1, bool LUT, bool FULL>
+template <bool AMP1, bool LUT, bool FULL, bool NW, bool DX>
 __device__ __forceinline__ void qgru_bwd_block(const SeqArgs& a, const QgruW& w, TabPtr tlane, const float* lut, int nlut,
-                                               QgruGrad& G, const LaneId& id, const float2* xs, const float2* dys, int tloc,
-                                               int nstep, float h, float& dh) {
+                                               QgruGrad& G, const LaneId& id, const float2* xs, const float2* dys, float2* dxs,
+                                               int tloc, int nstep, float h, float& dh) {
     constexpr int S = kCkptStride;
     const int col = id.col, s = id.s;
     QStep sv[S];
@@ -275,8 +276,10 @@ __device__ __forceinline__ void qgru_bwd_block(const SeqArgs& a, const QgruW& w,
             const unsigned mk = v.mask;
 #define QM(bit) ((mk & (bit)) ? 1.0f : 0.0f)
             const float ho = qapply(v.hnew, w.qoa), pho = qpass(v.hnew, w.qoa);
-            G.dwo[0] += dyv.x * ho; G.dwo[1] += dyv.y * ho;
-            G.dbo[0] += dyv.x; G.dbo[1] += dyv.y;
+            if constexpr (NW) {
+                G.dwo[0] += dyv.x * ho; G.dwo[1] += dyv.y * ho;
+                G.dbo[0] += dyv.x; G.dbo[1] += dyv.y;
+            }
             const float dhn = dh + (dyv.x * w.wo[0] + dyv.y * w.wo[1]) * pho;
             const float g = dhn * QM(M_AH);
             const float dm2 = g * QM(M_M2), dm3 = g * QM(M_M3);
@@ -287,9 +290,23 @@ __device__ __forceinline__ void qgru_bwd_block(const SeqArgs& a, const QgruW& w,
             const float dr = dm1 * v.htn, dhtn = dm1 * v.r;
             const float dar = dr * QM(M_R) * v.rf * (1.0f - v.rf) * QM(M_AR);
             const float daz = dz * QM(M_Z) * v.zf * (1.0f - v.zf) * QM(M_AZ);
-            G.dbhn += dhtn;
-            G.tih[0] = mfma4(dar, v.fsel, G.tih[0]); G.tih[1] = mfma4(daz, v.fsel, G.tih[1]); G.tih[2] = mfma4(dan, v.fsel, G.tih[2]);
-            G.thh[0] = mfma4(dar, v.hq, G.thh[0]); G.thh[1] = mfma4(daz, v.hq, G.thh[1]); G.thh[2] = mfma4(dhtn, v.hq, G.thh[2]);
+            if constexpr (NW) {
+                G.dbhn += dhtn;
+                G.tih[0] = mfma4(dar, v.fsel, G.tih[0]); G.tih[1] = mfma4(daz, v.fsel, G.tih[1]); G.tih[2] = mfma4(dan, v.fsel, G.tih[2]);
+                G.thh[0] = mfma4(dar, v.hq, G.thh[0]); G.thh[1] = mfma4(daz, v.hq, G.thh[1]); G.thh[2] = mfma4(dhtn, v.hq, G.thh[2]);
+            }
+            if constexpr (DX) {
+                // dL/dfeat_i = pass(feat_i) sum_o q_w(W_x)[g][o][i] d_g[o]  (straight-through over the x2h activation quantiser)
+                const float2 xv = xs[s * kChunkPad + tloc + i];
+                float f[4], df[4];
+                qgru_feat<AMP1>(xv, f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    df[j] = row_sum16(w.wx[0][j] * dar + w.wx[1][j] * daz + w.wx[2][j] * dan) * qpass(f[j], w.qxa);
+                float dI, dQ;
+                feat_bwd<AMP1 ? FEAT_A4 : FEAT_Q4>(xv.x, xv.y, df, dI, dQ);
+                if (col == 0) dxs[s * kChunkPad + tloc + i] = make_float2(dI, dQ);
+            }
             float d0 = 0.f, d1 = 0.f, d2 = 0.f;
             rotdot3x(d0, d1, d2, whT[0], whT[1], whT[2], dar, daz, dhtn);
             dh = dm2 * v.z + ((d0 + d1) + d2) * QM(M_PH);
@@ -331,7 +348,7 @@ __device__ __forceinline__ void qgru_write_partials(float* prow, const float* pl
     if (lane == 0) { prow[L.o_bo] = b0; prow[L.o_bo + 1] = b1; }
 }
 
-template <bool AMP1, bool LUT>
+template <bool AMP1, bool LUT, bool NW, bool DX>
 __global__ __launch_bounds__(kMaxThreads / 2, 1) void qgru_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
     constexpr int SPW = 4, S = kCkptStride;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -339,9 +356,10 @@ __global__ __launch_bounds__(kMaxThreads / 2, 1) void qgru_bwd_kernel(SeqArgs a,
     const int lane = id.lane, col = id.col;
     const QgruLayout L = qgru_layout(a.H);
     QgruW w; TabPtr tlane; const float* lut; int nlut; float* wb;
-    qgru_prologue<true, LUT>(a, smem, L, id, w, tlane, lut, nlut, wb, 2 * 2 * SPW * kChunkPad, bits_w, bits_a);
+    qgru_prologue<true, LUT>(a, smem, L, id, w, tlane, lut, nlut, wb, 3 * 2 * SPW * kChunkPad, bits_w, bits_a);
     float2* xs = reinterpret_cast<float2*>(wb);
     float2* dys = xs + SPW * kChunkPad;
+    float2* dxs = dys + SPW * kChunkPad;
     QgruGrad G;
     G.zero();
     const int nwaves = gridDim.x * id.nwb;
@@ -353,6 +371,13 @@ __global__ __launch_bounds__(kMaxThreads / 2, 1) void qgru_bwd_kernel(SeqArgs a,
             const int tb = blk * S, nstep = min(S, a.T - tb);
             const int chunk = tb / kChunk, t0 = chunk * kChunk;
             if (chunk != cur_chunk) {
+                if constexpr (DX) {
+                    if (cur_chunk >= 0) {
+                        const int pt0 = cur_chunk * kChunk;
+                        wave_lds_fence();
+                        stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                    }
+                }
                 wave_lds_fence();
                 const int len = min(kChunk, a.T - t0);
                 stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
@@ -361,10 +386,19 @@ __global__ __launch_bounds__(kMaxThreads / 2, 1) void qgru_bwd_kernel(SeqArgs a,
                 cur_chunk = chunk;
             }
             const float h0 = blk ? a.ckpt[((size_t)grp * a.nck + blk) * 64 + lane] : 0.0f;
-            if (nstep == S) qgru_bwd_block<AMP1, LUT, true>(a, w, tlane, lut, nlut, G, id, xs, dys, tb - t0, nstep, h0, dh);
-            else qgru_bwd_block<AMP1, LUT, false>(a, w, tlane, lut, nlut, G, id, xs, dys, tb - t0, nstep, h0, dh);
+            if (nstep == S) qgru_bwd_block<AMP1, LUT, true, NW, DX>(a, w, tlane, lut, nlut, G, id, xs, dys, dxs, tb - t0, nstep, h0, dh);
+            else qgru_bwd_block<AMP1, LUT, false, NW, DX>(a, w, tlane, lut, nlut, G, id, xs, dys, dxs, tb - t0, nstep, h0, dh);
+        }
+        if constexpr (DX) {
+            if (cur_chunk >= 0) {
+                const int pt0 = cur_chunk * kChunk;
+                wave_lds_fence();
+                stage_out<SPW>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                wave_lds_fence();
+            }
         }
     }
+    if constexpr (!NW) return;
     // the partial rows are built in LDS over the params/tables: keep a private copy of what write_partials reads
     const int P4 = L.P + kLossCols;
     __syncthreads();
@@ -380,7 +414,7 @@ __global__ __launch_bounds__(kMaxThreads / 2, 1) void qgru_bwd_kernel(SeqArgs a,
 }
 
 static size_t qgru_lds_bytes(int P, int waves, int bits_a, bool lut, bool reduce) {
-    size_t n = ((size_t)pad4(P) + kQTabFloats + (lut ? 2 * (1 << bits_a) : 0) + (size_t)waves * 2 * 2 * 4 * kChunkPad) * sizeof(float);
+    size_t n = ((size_t)pad4(P) + kQTabFloats + (lut ? 2 * (1 << bits_a) : 0) + (size_t)waves * 3 * 2 * 4 * kChunkPad) * sizeof(float);
     const size_t need = ((size_t)pad4(P) + (size_t)waves * (P + kLossCols)) * sizeof(float);
     if (reduce && n < need) n = need;
     return n;
@@ -403,10 +437,15 @@ template <bool AMP1, bool LUT>
 static int qgru_launch_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int P) {
     const LaunchShape ls = qgru_bwd_shape(a.ngroups);
     const size_t lds = qgru_lds_bytes(P, ls.waves, m->bits_a, LUT, true);
-    auto k = qgru_bwd_kernel<AMP1, LUT>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a, m->bits_w, m->bits_a);
-    return (int)hipGetLastError();
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a, m->bits_w, m->bits_a);
+        return (int)hipGetLastError();
+    };
+    const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
+    if (nw && dx) return launch(qgru_bwd_kernel<AMP1, LUT, true, true>);
+    if (nw) return launch(qgru_bwd_kernel<AMP1, LUT, true, false>);
+    return launch(qgru_bwd_kernel<AMP1, LUT, false, true>);
 }
 
 int qgru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
@@ -418,8 +457,7 @@ int qgru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 }
 int qgru_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!qat_ok(m)) return ODPD_EUNSUPPORTED;
-    if (a.dx != nullptr) return ODPD_EUNSUPPORTED;
-    if (a.partials == nullptr) return ODPD_EINVAL;
+    if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
     const int P = qgru_layout(m->hidden).P;
     const bool amp1 = m->backbone == ODPD_QGRU_AMP1, lut = m->bits_a <= 8;
     if (amp1) return lut ? qgru_launch_bwd<true, true>(st, m, a, P) : qgru_launch_bwd<true, false>(st, m, a, P);

@@ -94,3 +94,36 @@ def test_w8a8_matches_oracle_bitwise_on_ragged_sizes(bb, H, B, T):
     go, _ = o.qat_backward(m, p, x, dy, need_dx=False)
     g = np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy().reshape(-1) for v in q.parameters()])
     assert rel_err(g, go) < 2e-5
+
+
+@pytest.mark.parametrize("bb", ["qgru", "qgru_amp1"])
+@pytest.mark.parametrize("H,B,T", [(10, 3, 5), (16, 7, 33), (6, 66, 63), (13, 5, 200)])
+def test_w8a8_input_gradient_matches_oracle(bb, H, B, T):
+    """dL/dx of the quantised cell (straight-through over the x2h activation quantiser, quantised W_x^T, feature Jacobian):
+    together with the weight gradients and alone (frozen model = PA of a cascade)."""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.quant import get_quant_model
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H + B + T)
+    _Proj.n_bits_w = _Proj.n_bits_a = 8
+    q = get_quant_model(_Proj, CoreModel(2, H, 1, bb)).cuda()
+    rng = np.random.RandomState(B + T)
+    amp = 0.05 + 0.85 * rng.rand(B, T, 1)
+    ph = 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    dy = rng.randn(B, T, 2).astype(np.float32)
+    q.train()
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    q(xt).backward(torch.from_numpy(dy).cuda())
+    o = Oracle("f32")
+    m = make_model(bb, H, bits_w=8, bits_a=8)
+    p = np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in q.parameters()])
+    go, dxo = o.qat_backward(m, p, x, dy, need_dx=True)
+    g = np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy().reshape(-1) for v in q.parameters()])
+    assert rel_err(g, go) < 2e-5
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < 2e-5
+    for v in q.parameters():
+        v.requires_grad_(False)
+    xt2 = torch.from_numpy(x).cuda().requires_grad_(True)
+    q(xt2).backward(torch.from_numpy(dy).cuda())
+    assert rel_err(xt2.grad.cpu().numpy(), dxo) < 2e-5
