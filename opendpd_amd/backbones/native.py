@@ -117,6 +117,8 @@ class _BackboneFn(torch.autograd.Function):
                                    _lib.ptr(dy), _lib.ptr(ckpt) if ckpt.numel() else None, _lib.ptr(partials),
                                    _lib.ptr(dx))
         _lib.check(rc, f"odpd_backbone_bwd[{mod.backbone_name}]")
+        if mod.dx_needs_flag:
+            mod.desc.flags &= ~_lib.FLAG_NEED_DX       # per-call selection: nothing stale for the next user of the descriptor
         gparams = (None,) * (len(ctx.needs_input_grad) - 2)
         if need_w:
             grad = torch.empty(P + _lib.LOSS_COLS, dtype=torch.float32, device=x.device)

@@ -290,6 +290,12 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
     lib = _lib.load()
     dpd, pa = opt.backbone, opt.pa
     B, T = x.shape[0], x.shape[1]
+    # delta backbones: buffers and kernels are selected through the descriptor — pin the selection against a flag left behind
+    # by an autograd call on the same module (the trained model is never asked for dL/dx here, a frozen delta PA always is)
+    if dpd.dx_needs_flag:
+        dpd.desc.flags &= ~_lib.FLAG_NEED_DX
+    if pa is not None and pa.dx_needs_flag:
+        pa.desc.flags |= _lib.FLAG_NEED_DX
     buf = opt.cascade_buffers(B, T, x.device)
     part = opt.bwd_partials(B, T, x.device)
     st = _lib.stream_ptr()

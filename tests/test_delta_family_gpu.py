@@ -215,3 +215,25 @@ def test_hidden_above_32_is_refused_loudly():
     net = B.DeltaGRU(input_size=6, hidden_size=33, output_size=2, num_layers=1).cuda()
     with pytest.raises(RuntimeError):
         net(torch.rand(2, 16, 2, device="cuda"))
+
+
+def test_dx_flag_does_not_leak_between_autograd_and_fused_calls():
+    """ODPD_FLAG_NEED_DX is a per-call kernel selection: an autograd call that asked for dL/dx must not change which kernels
+    (and checkpoint layout) the fused trainer of the same module uses afterwards — the steps stay those of the reference."""
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    fx = Fixture("tres_h15_th")
+    net = _model(fx, "deltagru_tcnskip")
+    opt = FusedAdamW(net, lr=fx.meta["lr"])
+    x = torch.from_numpy(fx["x"]).cuda()
+    t = torch.from_numpy(fx["tgt"]).cuda()
+    names = fx.keys("sd")
+    for s in range(1, 4):
+        xg = x.clone().requires_grad_(True)            # an unrelated autograd pass with dL/dx in between
+        net(xg).sum().backward()
+        for p in net.parameters():
+            p.grad = None
+        assert net.backbone.desc.flags & 2 == 0
+        loss = fused_train_step(opt, x, t, "l2", fx.meta["clip"])
+        assert abs(loss.item() - fx["losses"][s - 1]) < 2e-5 * max(1.0, fx["losses"][s - 1])
+        got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in net.parameters()])
+        assert rel_err(got, fx.flat(f"p{s}", names)) < 3e-5, s
