@@ -36,7 +36,7 @@ namespace odpd {
 //   dL/dx   : 15-17 W_ig[4q+c][m] (m = feature slot)   18-19 fc_out[cc][H + 4q+i] (feature part, D layout)
 constexpr int kS16Groups = 15;        // fused train / weight-gradient-only kernels
 constexpr int kS16GroupsDx = 20;      // kernels that also produce dL/dx
-template <int FM, bool DG>
+template <int FM, bool DG, bool PACK = false>
 __device__ __forceinline__ float4 s16_table_entry(const float* pl, const GruLayout& L, int grp, int m, int q) {
     const int H = L.H, OW = DG ? H + 6 : H;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -44,7 +44,11 @@ __device__ __forceinline__ float4 s16_table_entry(const float* pl, const GruLayo
     for (int e = 0; e < 4; ++e) {
         const int k = 4 * q + e;              // hidden index of K-slot e / own unit e
         const bool mk = m < H && k < H;
-        if (grp < 3) v[e] = mk ? pl[L.o_w_hh + (grp * H + m) * H + k] * (grp < 2 ? kNegLog2e : 1.0f) : 0.0f;
+        if (grp < 3) {
+            v[e] = mk ? pl[L.o_w_hh + (grp * H + m) * H + k] * (grp < 2 ? kNegLog2e : 1.0f) : 0.0f;
+            // K-packing (H <= 13): K positions 13..15 carry the chunk-1 input slots 4..6 (odpd_s16.h: s16_slots_pk)
+            if (PACK && grp < 2 && k >= 13) v[e] = kNegLog2e * s16_wih_slot<FM, DG>(pl, L, grp, 1, m, k - 13);   // r, z only
+        }
         else if (grp == 3) v[e] = kNegLog2e * s16_wih_slot<FM, DG>(pl, L, e >> 1, e & 1, m, q);
         else if (grp == 4) v[e] = e < 2 ? s16_wih_slot<FM, DG>(pl, L, 2, e, m, q) : 0.0f;
         else if (grp == 5) v[e] = k < H ? pl[L.o_b_hh + 2 * H + k] : 0.0f;
@@ -59,12 +63,12 @@ __device__ __forceinline__ float4 s16_table_entry(const float* pl, const GruLayo
     }
     return make_float4(v[0], v[1], v[2], v[3]);
 }
-template <int FM, bool DG>
+template <int FM, bool DG, bool PACK = false>
 __device__ __forceinline__ void s16_fill_table(float* tab, const float* pl, const GruLayout& L, int lane, int wave, int nwb,
                                                int ngroups = kS16Groups) {
     float4* t4 = reinterpret_cast<float4*>(tab);
     for (int grp = wave; grp < ngroups; grp += nwb)
-        if (DG || (grp < 9 || grp > 11)) t4[grp * 64 + lane] = s16_table_entry<FM, DG>(pl, L, grp, lane & 15, lane >> 4);
+        if (DG || (grp < 9 || grp > 11)) t4[grp * 64 + lane] = s16_table_entry<FM, DG, PACK>(pl, L, grp, lane & 15, lane >> 4);
     __syncthreads();
 }
 
@@ -114,22 +118,28 @@ __device__ __forceinline__ void s16_load_bw(S16Bw<FM, DG>& w, TabPtr tl) {
     w.woutf[0][0] = f.x; w.woutf[0][1] = f.y; w.woutf[1][0] = f.z; w.woutf[1][1] = f.w;
 }
 
-template <int FM>
+template <int FM, bool PACK = false>
 __device__ __forceinline__ void s16_cell_fwd(const S16Fw<FM>& w, const float (&fs)[S16Cfg<FM>::NCH], f32x4& h, f32x4& r,
-                                             f32x4& z, f32x4& n, f32x4& g) {
+                                             f32x4& z, f32x4& n, f32x4& g, const float* pk = nullptr) {
     constexpr int NCH = S16Cfg<FM>::NCH;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 ar = zero, az = zero, an = zero, ah = w.bhn;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        ar = mfma4(w.wih[0][c], fs[c], ar);
-        az = mfma4(w.wih[1][c], fs[c], az);
+        if (!(PACK && c == 1)) {
+            ar = mfma4(w.wih[0][c], fs[c], ar);
+            az = mfma4(w.wih[1][c], fs[c], az);
+        }
         an = mfma4(w.wih[2][c], fs[c], an);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        ar = mfma4(w.whh[0][c], h[c], ar);
-        az = mfma4(w.whh[1][c], h[c], az);
+        // PACK: on the quad-3 lanes (own h identically 0 there) elements 1..3 carry the chunk-1 input slots of the r and z
+        // gates; the n gate keeps its own chunk (its input part must stay outside r (.) (W_hn h), and one chunk holds only
+        // one padded K position)
+        const float hb = (PACK && c >= 1) ? h[c] + pk[c - 1] : h[c];
+        ar = mfma4(w.whh[0][c], hb, ar);
+        az = mfma4(w.whh[1][c], hb, az);
         ah = mfma4(w.whh[2][c], h[c], ah);
     }
     // stage-major element-wise code: every stage is four independent ops (one per owned unit), so a
@@ -160,7 +170,7 @@ struct S16Grad {
 //   hTn  : transposed h of the step after the current one (fc_hid weight gradient operand)
 //   FUSED: `ts` holds the target, y / loss / dL/dy are formed here;  else `ts` holds dL/dy
 //   NW   : accumulate weight gradients into G        DX : write dL/dx of the block's steps to dxs
-template <int FM, bool DG, bool FUSED, bool NW, bool DX, bool FULL>
+template <int FM, bool DG, bool FUSED, bool NW, bool DX, bool FULL, bool PACK = false>
 __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const float (&oh)[4], S16Grad<DG>& G,
                                           const float2* xs, const float2* ts, float2* dxs, float* tiles, int n, int q, int tloc,
                                           int nstep, bool valid, bool last_blk, f32x4 h, f32x4& dh, float (&hTn)[4],
@@ -175,9 +185,15 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const flo
         for (int st = 0; st < S; ++st) {
             if (FULL || st < nstep) {
                 const float2 xv = xs[n * kChunkPad + tloc + st];
-                s16_slots<FM>(xv.x, xv.y, oh, fs_s[st]);
                 hp_s[st] = h;
-                s16_cell_fwd<FM>(wf, fs_s[st], h, r_s[st], z_s[st], n_s[st], g_s[st]);
+                if constexpr (PACK) {
+                    float pk[3];
+                    s16_slots_pk<FM>(xv.x, xv.y, oh, fs_s[st], pk);
+                    s16_cell_fwd<FM, true>(wf, fs_s[st], h, r_s[st], z_s[st], n_s[st], g_s[st], pk);
+                } else {
+                    s16_slots<FM>(xv.x, xv.y, oh, fs_s[st]);
+                    s16_cell_fwd<FM>(wf, fs_s[st], h, r_s[st], z_s[st], n_s[st], g_s[st]);
+                }
             }
         }
     }
@@ -405,7 +421,7 @@ __device__ __forceinline__ void s16_write_row(float* prow, const GruLayout& L, S
     }
 }
 
-template <int FM, bool DG, int OCC>
+template <int FM, bool DG, int OCC, bool PACK>
 __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs a) {
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
     static_assert(NCH <= 2, "operand tables and dwf accumulators are sized for two K-chunks");
@@ -416,7 +432,7 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
-    s16_fill_table<FM, DG>(tab, pl, L, lane, wave, nwb);
+    s16_fill_table<FM, DG, PACK>(tab, pl, L, lane, wave, nwb);
     TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float oh[4];
 #pragma unroll
@@ -451,8 +467,14 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
                         const float2 xv = xs[n * kChunkPad + tt + i];
                         float fs[NCH];
                         f32x4 r, z, nn, g;
-                        s16_slots<FM>(xv.x, xv.y, oh, fs);
-                        s16_cell_fwd<FM>(w, fs, h, r, z, nn, g);
+                        if constexpr (PACK) {
+                            float pk[3];
+                            s16_slots_pk<FM>(xv.x, xv.y, oh, fs, pk);
+                            s16_cell_fwd<FM, true>(w, fs, h, r, z, nn, g, pk);
+                        } else {
+                            s16_slots<FM>(xv.x, xv.y, oh, fs);
+                            s16_cell_fwd<FM>(w, fs, h, r, z, nn, g);
+                        }
                     }
                     const int t1 = t0 + tt + S;
                     if (t1 < a.T) ck[(size_t)(t1 / S) * 64] = make_float4(h[0], h[1], h[2], h[3]);
@@ -461,8 +483,14 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
                     const float2 xv = xs[n * kChunkPad + tt];
                     float fs[NCH];
                     f32x4 r, z, nn, g;
-                    s16_slots<FM>(xv.x, xv.y, oh, fs);
-                    s16_cell_fwd<FM>(w, fs, h, r, z, nn, g);
+                    if constexpr (PACK) {
+                        float pk[3];
+                        s16_slots_pk<FM>(xv.x, xv.y, oh, fs, pk);
+                        s16_cell_fwd<FM, true>(w, fs, h, r, z, nn, g, pk);
+                    } else {
+                        s16_slots<FM>(xv.x, xv.y, oh, fs);
+                        s16_cell_fwd<FM>(w, fs, h, r, z, nn, g);
+                    }
                 }
             }
         }
@@ -486,9 +514,9 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
                 cur_chunk = chunk;
             }
             if (nstep == S)
-                s16_block<FM, DG, true, true, false, true>(a, tl, oh, G, xs, ts, nullptr, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+                s16_block<FM, DG, true, true, false, true, PACK>(a, tl, oh, G, xs, ts, nullptr, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
             else
-                s16_block<FM, DG, true, true, false, false>(a, tl, oh, G, xs, ts, nullptr, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+                s16_block<FM, DG, true, true, false, false, PACK>(a, tl, oh, G, xs, ts, nullptr, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
         }
     }
     // ---- one row of partial gradients per workgroup (fixed summation order) ----
@@ -705,18 +733,23 @@ int gru_s16_rows(const odpd_model_t* m, int B) {
     return s16_shape(gru_s16_groups(B)).grid;
 }
 
-template <int FM, bool DG, int OCC>
+template <int FM, bool DG, int OCC, bool PACK>
 static int launch_s16(hipStream_t st, const SeqArgs& a, int P) {
     const LaunchShape ls = s16_shape(a.ngroups);
     const size_t lds = s16_lds_bytes(P, ls.waves);
-    auto k = gru16_train_kernel<FM, DG, OCC>;
+    auto k = gru16_train_kernel<FM, DG, OCC, PACK>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
 }
 template <int FM, bool DG>
 static int launch_s16_occ(hipStream_t st, const SeqArgs& a, int P) {
-    return s16_occupancy(a.ngroups) == 1 ? launch_s16<FM, DG, 1>(st, a, P) : launch_s16<FM, DG, 2>(st, a, P);
+    // K-packing: two input chunks and hidden <= 13 (three padded K positions free for the r / z chunk-1 slots)
+    constexpr bool kCanPack = S16Cfg<FM>::NCH == 2;
+    const bool pack = kCanPack && a.H <= 13;
+    if (s16_occupancy(a.ngroups) == 1) return launch_s16<FM, DG, 1, false>(st, a, P);
+    if constexpr (kCanPack) { if (pack) return launch_s16<FM, DG, 2, true>(st, a, P); }
+    return launch_s16<FM, DG, 2, false>(st, a, P);
 }
 
 // ---- split kernels: launch shapes -----------------------------------------------------------------

@@ -58,6 +58,26 @@ __device__ __forceinline__ void s16_slots(float I, float Q, const float (&oh)[4]
     }
 }
 
+// K-packing (hidden <= 13, two feature chunks): the chunk-1 slots [feat_4.., 1] ride in the three padded hidden K positions
+// 13, 14, 15 of the recurrent mat-vec — B operand elements 1..3 of the quad-3 lanes, whose own h is identically 0 — so the cell
+// needs one input-projection MFMA chunk instead of two.  pk[j] = value of slot 4 + j on the quad-3 lanes, 0 elsewhere.
+template <int FM>
+__device__ __forceinline__ void s16_slots_pk(float I, float Q, const float (&oh)[4], float (&fs)[S16Cfg<FM>::NCH], float (&pk)[3]) {
+    constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH;
+    float f[F];
+    feat_fwd<FM>(I, Q, f);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float acc = (F >= 4 * c && F < 4 * c + 4) ? oh[(F - 4 * c) & 3] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * c + e < F) acc = __builtin_fmaf(oh[e], f[(4 * c + e) < F ? (4 * c + e) : 0], acc);
+        fs[c] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pk[j] = (4 + j < F) ? oh[3] * f[(4 + j) < F ? (4 + j) : 0] : ((4 + j == F) ? oh[3] : 0.0f);
+}
+
 // ---- stage-major 4-wide element-wise helpers (same arithmetic as sigmoidf_ / tanhf_ of odpd_device.h) ----
 #define ODPD_EACH4 _Pragma("unroll") for (int i = 0; i < 4; ++i)
 // relu of an MFMA result: one v_max_f32 (fmaxf() would first quiet a possible sNaN with a second v_max)

@@ -14,6 +14,8 @@ from oracle.oracle import Oracle, make_model
 
 n_per = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 lib = _lib.load()
+if len(sys.argv) > 2:      # second argument: force the S16 occupancy variant (2 = the large-batch kernels, incl. K-packing)
+    lib.odpd_set_tuning(b"s16_occupancy", int(sys.argv[2]))
 o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
