@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
 // split kernels (odpd_backbone_fwd / odpd_backbone_bwd at large batch: autograd path, cascades, inference)
 // -------------------------------------------------------------------------------------------------
 // forward: y for every step, optional checkpoints of h ([task][ckpt][lane] float4)
-template <int FM, bool DG>
+template <int FM, bool DG, bool PACK>
 __global__ __launch_bounds__(1024) void gru16_fwd_kernel(SeqArgs a) {
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(1024) void gru16_fwd_kernel(SeqArgs a) {
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
-    s16_fill_table<FM, DG>(tab, pl, L, lane, wave, nwb);
+    s16_fill_table<FM, DG, PACK>(tab, pl, L, lane, wave, nwb);
     TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float oh[4];
 #pragma unroll
@@ -571,8 +571,14 @@ __global__ __launch_bounds__(1024) void gru16_fwd_kernel(SeqArgs a) {
                 const float2 xv = xs[n * kChunkPad + tt];
                 float fs[NCH];
                 f32x4 r, z, nn, g, act;
-                s16_slots<FM>(xv.x, xv.y, oh, fs);
-                s16_cell_fwd<FM>(wf, fs, h, r, z, nn, g);
+                if constexpr (PACK) {
+                    float pk[3];
+                    s16_slots_pk<FM>(xv.x, xv.y, oh, fs, pk);
+                    s16_cell_fwd<FM, true>(wf, fs, h, r, z, nn, g, pk);
+                } else {
+                    s16_slots<FM>(xv.x, xv.y, oh, fs);
+                    s16_cell_fwd<FM>(wf, fs, h, r, z, nn, g);
+                }
                 if constexpr (DG) {
                     f32x4 hid = wh.bhid;
 #pragma unroll
@@ -783,10 +789,13 @@ template <int FM, bool DG>
 static int launch_s16_fwd(hipStream_t st, const SeqArgs& a, int P) {
     const LaunchShape ls = s16_fwd_shape(a.ngroups);
     const size_t lds = ((size_t)pad4(P) + s16_tab_floats(kS16Groups) + (size_t)ls.waves * 2 * 2 * 16 * kChunkPad) * sizeof(float);
-    auto k = gru16_fwd_kernel<FM, DG>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
-    return (int)hipGetLastError();
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    if constexpr (S16Cfg<FM>::NCH == 2) { if (a.H <= 13) return launch(gru16_fwd_kernel<FM, DG, true>); }   // K-packing
+    return launch(gru16_fwd_kernel<FM, DG, false>);
 }
 template <int FM, bool DG, bool NW, bool DX, int WAVES>
 static int launch_s16_bwd(hipStream_t st, const SeqArgs& a, int P) {
