@@ -207,7 +207,7 @@ def main():
         n3 = max(3, min(args.steps, 10))
         xc = x if args.materialized else xs_.unfold(0, T, 1)[:B].permute(0, 2, 1).contiguous()   # the cascade takes tensors
         el3, _, loss3 = run_steps(opt3, xc, xc.clone(), n3, 2, world * B * T * 2, dist)
-        dpd = {"workload": f"train_dpd: DGRU H{H} DPD -> frozen DGRU H{H} PA (five-launch cascade step), target = x",
+        dpd = {"workload": f"train_dpd: DGRU H{H} DPD -> frozen DGRU H{H} PA (cascade step: DPD fwd, frozen-PA fwd + loss + dL/du in one launch, DPD bwd), target = x",
                "value": B * T * n3 / el3, "unit": "IQ samples/s", "ms_per_step": 1e3 * el3 / n3, "loss": loss3}
         del casc, opt3
         # BASELINE configs[2]: TRes-DeltaGRU H15 (thx .01, thh .05) DPD in front of a frozen DGRU H23 PA, same batch

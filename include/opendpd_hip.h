@@ -123,6 +123,15 @@ int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_kind, int B
                        float* partials, float* workspace);
 /* Frames addressed as windows of resident I/Q streams — what IQFrameDataset materialises with np.stack
  * (data_collector.py:239-247): frame f = samples [f*stride, f*stride + frame_length) of the (N,2) fp32 streams. */
+/* Frozen model in front of the loss — the PA of train_dpd (models.py:169-176, train_funcs.py:35-39): forward + loss + dL/du in
+ * one launch.  `loss_rows` is (rows, 4) with rows = odpd_frozen_loss_rows (column 0 = un-normalised loss partial sum; reduce
+ * with odpd_reduce_partials(rows, 0, ...)); `workspace` holds odpd_ckpt_floats(m, B, T) floats.  ODPD_EUNSUPPORTED (rows < 0)
+ * where no such kernel serves the model / batch: chain odpd_backbone_fwd, odpd_loss_fwd_bwd, odpd_backbone_bwd instead. */
+int64_t odpd_frozen_loss_rows(const odpd_model_t* m, int B, int T);
+int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss_kind, int B, int T, int64_t count,
+                        const float* params, const float* u, const float* target, float* du, float* loss_rows,
+                        float* workspace);
+
 typedef struct odpd_frames {
     const float* x_stream;  /* (N,2) device: model input stream */
     const float* y_stream;  /* (N,2) device: target stream */

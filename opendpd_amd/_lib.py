@@ -45,6 +45,9 @@ _EXPORTS = {
     "odpd_train_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
     "odpd_train_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "odpd_frozen_loss_rows": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "odpd_frozen_loss_dx": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "odpd_train_fwd_bwd_framed": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int64, C.c_int,
                                             C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "odpd_train_epoch": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int, C.c_void_p, C.c_void_p,

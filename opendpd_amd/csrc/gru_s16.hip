@@ -421,9 +421,13 @@ __device__ __forceinline__ void s16_write_row(float* prow, const GruLayout& L, S
     }
 }
 
-template <int FM, bool DG, int OCC, bool PACK>
+// NW: weight-gradient partials (train_pa / the trained model).  !NW && DX: the frozen PA of a cascade in one launch — forward,
+// loss and dL/dx (written to a.dx), one loss partial per workgroup in a.partials[blockIdx.x * kLossCols].
+template <int FM, bool DG, int OCC, bool PACK, bool NW = true, bool DX = false>
 __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs a) {
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
+    constexpr int kGroups = DX ? kS16GroupsDx : kS16Groups;
+    constexpr int kWave = (DX ? 3 : 2) * 2 * 16 * kChunkPad + (NW ? kS16Tiles * kTileFloats : 0);
     static_assert(NCH <= 2, "operand tables and dwf accumulators are sized for two K-chunks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
@@ -432,16 +436,18 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
-    s16_fill_table<FM, DG, PACK>(tab, pl, L, lane, wave, nwb);
+    s16_fill_table<FM, DG, PACK>(tab, pl, L, lane, wave, nwb, kGroups);
     TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float oh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
-    float* wbase = tab + s16_tab_floats(kS16Groups) + (size_t)wave * kS16WaveFloats;
+    float* wbase = tab + s16_tab_floats(kGroups) + (size_t)wave * kWave;
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ts = xs + 16 * kChunkPad;
-    float* tiles = reinterpret_cast<float*>(ts + 16 * kChunkPad);
-    for (int i = lane; i < kTileFloats; i += 64) tiles[6 * kTileFloats + i] = 0.0f;   // unused feature columns stay 0
+    float2* dxs = DX ? ts + 16 * kChunkPad : nullptr;
+    float* tiles = reinterpret_cast<float*>(ts + (DX ? 2 : 1) * 16 * kChunkPad);
+    if constexpr (NW)
+        for (int i = lane; i < kTileFloats; i += 64) tiles[6 * kTileFloats + i] = 0.0f;   // unused feature columns stay 0
     S16Grad<DG> G;
     G.zero();
     float loss_acc = 0.0f;
@@ -506,6 +512,13 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
             const f32x4 h0 = {h0n.x, h0n.y, h0n.z, h0n.w};
             h0n = blk > 1 ? ck[(size_t)(blk - 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);   // prefetch a block ahead
             if (chunk != cur_chunk) {
+                if constexpr (DX) {
+                    if (cur_chunk >= 0) {
+                        const int pt0 = cur_chunk * kChunk;
+                        wave_lds_fence();
+                        stage_out<16>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                    }
+                }
                 wave_lds_fence();
                 const int len = min(kChunk, a.T - t0);
                 stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride);
@@ -514,10 +527,31 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
                 cur_chunk = chunk;
             }
             if (nstep == S)
-                s16_block<FM, DG, true, true, false, true, PACK>(a, tl, oh, G, xs, ts, nullptr, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+                s16_block<FM, DG, true, NW, DX, true, PACK>(a, tl, oh, G, xs, ts, dxs, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
             else
-                s16_block<FM, DG, true, true, false, false, PACK>(a, tl, oh, G, xs, ts, nullptr, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
+                s16_block<FM, DG, true, NW, DX, false, PACK>(a, tl, oh, G, xs, ts, dxs, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
         }
+        if constexpr (DX) {
+            if (cur_chunk >= 0) {
+                const int pt0 = cur_chunk * kChunk;
+                wave_lds_fence();
+                stage_out<16>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                wave_lds_fence();
+            }
+        }
+    }
+    if constexpr (!NW) {      // loss partial of the workgroup (summed over its waves in order)
+        const float lp = row_sum16(loss_acc);          // accumulated on the q == 0 lanes
+        __syncthreads();
+        if (lane == 0) smem[wave] = lp;
+        __syncthreads();
+        if (threadIdx.x < kLossCols) {
+            float v = 0.0f;
+            if (threadIdx.x == 0)
+                for (int wv = 0; wv < nwb; ++wv) v += smem[wv];
+            a.partials[(size_t)blockIdx.x * kLossCols + threadIdx.x] = v;
+        }
+        return;
     }
     // ---- one row of partial gradients per workgroup (fixed summation order) ----
     const int P4 = L.P + kLossCols;
@@ -748,6 +782,23 @@ static int launch_s16(hipStream_t st, const SeqArgs& a, int P) {
     hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
 }
+// frozen PA of a cascade: forward + loss + dL/du in one launch (a.x = u, a.target, a.dx = du, a.partials = loss rows)
+template <int FM, bool DG, int OCC, bool PACK>
+static int launch_s16_lossdx(hipStream_t st, const SeqArgs& a, int P) {
+    const LaunchShape ls = s16_shape(a.ngroups);
+    const size_t lds = ((size_t)pad4(P) + s16_tab_floats(kS16GroupsDx) + (size_t)ls.waves * 3 * 2 * 16 * kChunkPad) * sizeof(float);
+    auto k = gru16_train_kernel<FM, DG, OCC, PACK, false, true>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <int FM, bool DG>
+static int launch_s16_lossdx_occ(hipStream_t st, const SeqArgs& a, int P) {
+    constexpr bool kCanPack = S16Cfg<FM>::NCH == 2;
+    if (s16_occupancy(a.ngroups) == 1) return launch_s16_lossdx<FM, DG, 1, false>(st, a, P);
+    if constexpr (kCanPack) { if (a.H <= 13) return launch_s16_lossdx<FM, DG, 2, true>(st, a, P); }
+    return launch_s16_lossdx<FM, DG, 2, false>(st, a, P);
+}
 template <int FM, bool DG>
 static int launch_s16_occ(hipStream_t st, const SeqArgs& a, int P) {
     // K-packing: two input chunks and hidden <= 13 (three padded K positions free for the r / z chunk-1 slots)
@@ -840,6 +891,16 @@ int gru_s16_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
     a.ngroups = gru_s16_groups(a.B);
     const int P = s16_param_count(m->hidden, FM, DG);
     ODPD_S16_DISPATCH(launch_s16_bwd_mode, st, a, P)
+}
+
+int gru_s16_lossdx(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
+    int FM; bool DG;
+    if (!s16_cfg(m, FM, DG) || m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (!a0.ckpt || !a0.dx || !a0.partials || !a0.target) return ODPD_EINVAL;
+    SeqArgs a = a0;
+    a.ngroups = gru_s16_groups(a.B);
+    const int P = s16_param_count(m->hidden, FM, DG);
+    ODPD_S16_DISPATCH(launch_s16_lossdx_occ, st, a, P)
 }
 
 int gru_s16_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {

@@ -409,8 +409,8 @@ template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
 __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArgs a) {
     using T = S16N<NT>;
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
-    constexpr int kGroups = (MODE == 2 && DX) ? T::NG_DX : T::NG;
-    constexpr int kWave = (MODE == 2 && DX ? 3 : 2) * 2 * 16 * kChunkPad + ((MODE != 1 && NW) ? T::kTiles * kTileFloats : 0);
+    constexpr int kGroups = (MODE != 1 && DX) ? T::NG_DX : T::NG;
+    constexpr int kWave = (MODE != 1 && DX ? 3 : 2) * 2 * 16 * kChunkPad + ((MODE != 1 && NW) ? T::kTiles * kTileFloats : 0);
     static_assert(NCH <= 2, "operand tables are sized for two feature K-chunks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArg
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ts = xs + 16 * kChunkPad;                     // target (fused), dy (backward), y (forward)
     float2* dxs = ts + 16 * kChunkPad;                    // backward with DX only
-    float* tiles = reinterpret_cast<float*>(ts + ((MODE == 2 && DX) ? 2 : 1) * 16 * kChunkPad);
+    float* tiles = reinterpret_cast<float*>(ts + ((MODE != 1 && DX) ? 2 : 1) * 16 * kChunkPad);
     if constexpr (MODE != 1 && NW)
         for (int i = lane; i < kTileFloats; i += 64) tiles[6 * NT * kTileFloats + i] = 0.0f;
     S16NGrad<DG, NT> G;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArg
                     h0[kt] = as_f32x4(v);
                 }
                 if (chunk != cur_chunk) {
-                    if constexpr (MODE == 2 && DX) {
+                    if constexpr (MODE != 1 && DX) {
                         if (cur_chunk >= 0) {
                             const int pt0 = cur_chunk * kChunk;
                             wave_lds_fence();
@@ -514,13 +514,13 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArg
                     wave_lds_fence();
                     cur_chunk = chunk;
                 }
-                constexpr bool FUSED = MODE == 0, NWm = MODE == 0 || NW, DXm = MODE == 2 && DX;
+                constexpr bool FUSED = MODE == 0, NWm = NW, DXm = MODE != 1 && DX;
                 if (nstep == S)
                     s16n_block<FM, DG, NT, FUSED, NWm, DXm, true, NCK>(a, tl, oh, G, xs, ts, dxs, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
                 else
                     s16n_block<FM, DG, NT, FUSED, NWm, DXm, false, NCK>(a, tl, oh, G, xs, ts, dxs, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, dh, hTn, loss_acc);
             }
-            if constexpr (MODE == 2 && DX) {
+            if constexpr (MODE != 1 && DX) {
                 if (cur_chunk >= 0) {
                     const int pt0 = cur_chunk * kChunk;
                     wave_lds_fence();
@@ -530,7 +530,19 @@ __global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArg
             }
         }
     }
-    if constexpr (MODE == 0 || (MODE == 2 && NW)) {
+    if constexpr (MODE == 0 && !NW) {      // frozen PA of a cascade: the loss partial of the workgroup, nothing else
+        const float lp = row_sum16(loss_acc);          // accumulated on the q == 0 lanes
+        __syncthreads();
+        if (lane == 0) smem[wave] = lp;
+        __syncthreads();
+        if (threadIdx.x < kLossCols) {
+            float v = 0.0f;
+            if (threadIdx.x == 0)
+                for (int wv = 0; wv < nwb; ++wv) v += smem[wv];
+            a.partials[(size_t)blockIdx.x * kLossCols + threadIdx.x] = v;
+        }
+    }
+    if constexpr (MODE != 1 && NW) {
         const int P4 = L.P + kLossCols;
         __syncthreads();
         s16n_write_row<FM, DG, NT>(smem + wave * P4, L, G, n, q, loss_acc);
@@ -581,8 +593,8 @@ static int launch_s16n(hipStream_t st, const SeqArgs& a, int P) {
         const int need = (a.ngroups + 7) / 8, cap = device_cus();
         ls.grid = need < cap ? need : cap;
     }
-    const int groups = (MODE == 2 && DX) ? T::NG_DX : T::NG;
-    const int wave_floats = (MODE == 2 && DX ? 3 : 2) * 2 * 16 * kChunkPad + ((MODE != 1 && NW) ? T::kTiles * kTileFloats : 0);
+    const int groups = (MODE != 1 && DX) ? T::NG_DX : T::NG;
+    const int wave_floats = (MODE != 1 && DX ? 3 : 2) * 2 * 16 * kChunkPad + ((MODE != 1 && NW) ? T::kTiles * kTileFloats : 0);
     auto bytes = [&](int waves) {
         size_t body = (size_t)waves * wave_floats;
         if (body < (size_t)pad4(P)) body = pad4(P);
@@ -601,6 +613,7 @@ static int launch_s16n(hipStream_t st, const SeqArgs& a, int P) {
 template <int FM, bool DG, int NT, int NCK>
 static int launch_s16n_mode(hipStream_t st, const SeqArgs& a, int P, int mode) {
     if (mode == 0) return launch_s16n<FM, DG, NT, 0, true, false, NCK>(st, a, P);
+    if (mode == 3) return launch_s16n<FM, DG, NT, 0, false, true, NCK>(st, a, P);      // forward + loss + dL/dx (frozen PA)
     if (mode == 1) return launch_s16n<FM, DG, NT, 1, false, false, NCK>(st, a, P);
     const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
     if (nw && dx) return launch_s16n<FM, DG, NT, 2, true, true, NCK>(st, a, P);
@@ -615,11 +628,12 @@ static int launch_s16n_chunks(hipStream_t st, const SeqArgs& a, int P, int mode,
     return launch_s16n_mode<FM, DG, NT, 4>(st, a, P, mode);
 }
 
-// mode 0 fused train, 1 forward, 2 backward
+// mode 0 fused train, 1 forward, 2 backward, 3 frozen-PA loss step (forward + loss + dL/dx, a.partials = loss rows)
 int gru_s16n_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int mode) {
     int FM; bool DG;
     if (!s16n_cfg(m, FM, DG) || s16n_tiles(m->hidden) != 2) return ODPD_EUNSUPPORTED;
-    if (mode == 0 && !a0.ckpt) return ODPD_EINVAL;
+    if ((mode == 0 || mode == 3) && !a0.ckpt) return ODPD_EINVAL;
+    if (mode == 3 && (!a0.dx || !a0.partials || !a0.target)) return ODPD_EINVAL;
     SeqArgs a = a0;
     a.ngroups = (a.B + 15) / 16;
     const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;

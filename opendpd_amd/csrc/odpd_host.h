@@ -146,6 +146,7 @@ int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, 
 // 16-sequences-per-wave fused kernel (gru_s16.hip) and the rule that selects it
 bool gru_train_uses_s16(const odpd_model_t* m, int B, int T);
 int gru_s16_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_s16_lossdx(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);   // frozen PA: forward + loss + dL/dx, loss rows in partials
 int gru_s16_rows(const odpd_model_t* m, int B);
 bool gru_split_uses_s16(const odpd_model_t* m, int B);
 int gru_s16_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);

@@ -146,7 +146,7 @@ extern "C" int odpd_loss_fwd_bwd(void* stream, int kind, int64_t n, int64_t coun
 
 extern "C" int odpd_reduce_partials(void* stream, int64_t rows, int64_t P, const float* partials, float* grad,
                                     int accumulate) {
-    if (!partials || !grad || rows <= 0 || P <= 0) return ODPD_EINVAL;
+    if (!partials || !grad || rows <= 0 || P < 0) return ODPD_EINVAL;      // P = 0: loss rows only (odpd_frozen_loss_dx)
     const int64_t cols = P + kLossCols;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, rows,
                        cols, partials, grad, accumulate);

@@ -128,7 +128,11 @@ class FusedAdamW:
             d = dict(u=mk(), dy=mk(), ck_d=ck(self.backbone),
                      loss=torch.zeros(_lib.LOSS_WS, dtype=torch.float32, device=device))
             if self.pa is not None:
-                d.update(y=mk(), du=mk(), ck_p=ck(self.pa), pa_part=None)
+                d.update(y=mk(), du=mk(), ck_p=ck(self.pa), pa_part=None, loss_rows=None)
+                rows = int(lib.odpd_frozen_loss_rows(C.byref(self.pa.desc), B, T))     # > 0: forward + loss + dL/du in one launch
+                if rows > 0:
+                    d["loss_rows"] = torch.empty(rows, _lib.LOSS_COLS, dtype=torch.float32, device=device)
+                    d["loss4"] = torch.zeros(_lib.LOSS_COLS, dtype=torch.float32, device=device)
                 if self.pa.dx_needs_flag:   # the delta backward kernels write their weight gradients in every launch: scratch
                     rows = int(lib.odpd_partial_rows(C.byref(self.pa.desc), B, T, 0))
                     _lib.check(0 if rows > 0 else rows, "odpd_partial_rows")
@@ -302,23 +306,33 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
     fd, fp = dpd.flat_params(), (pa.flat_params() if pa is not None else None)
     _lib.check(lib.odpd_backbone_fwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(buf["u"]),
                                      _lib.ptr(buf["ck_d"]), _lib.ptr(dpd._stats_buffer(x.device))), "dpd fwd")
-    if pa is not None:
-        _lib.check(lib.odpd_backbone_fwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["y"]),
-                                         _lib.ptr(buf["ck_p"]), _lib.ptr(pa._stats_buffer(x.device))), "pa fwd")
-    y = buf["y"] if pa is not None else buf["u"]
-    _lib.check(lib.odpd_loss_fwd_bwd(st, _lib.LOSS_IDS[loss_kind], B * T * 2, count, _lib.ptr(y), _lib.ptr(target),
-                                     _lib.ptr(buf["dy"]), _lib.ptr(buf["loss"])), "loss")
-    du = buf["dy"]
-    if pa is not None:
-        _lib.check(lib.odpd_backbone_bwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["dy"]),
-                                         _lib.ptr(buf["ck_p"]), _lib.ptr(buf["pa_part"]), _lib.ptr(buf["du"])), "pa bwd")
-        du = buf["du"]
+    loss_sum = None
+    if pa is not None and buf["loss_rows"] is not None:
+        # frozen PA in front of the loss: forward, loss and dL/du in one launch (16-sequences-per-wave GRU-family kernels)
+        _lib.check(lib.odpd_frozen_loss_dx(st, C.byref(pa.desc), _lib.LOSS_IDS[loss_kind], B, T, count, _lib.ptr(fp),
+                                           _lib.ptr(buf["u"]), _lib.ptr(target), _lib.ptr(buf["du"]), _lib.ptr(buf["loss_rows"]),
+                                           _lib.ptr(buf["ck_p"])), "pa fwd + loss + dL/du")
+        _lib.check(lib.odpd_reduce_partials(st, buf["loss_rows"].shape[0], 0, _lib.ptr(buf["loss_rows"]), _lib.ptr(buf["loss4"]), 0),
+                   "reduce loss rows")
+        loss_sum, du = buf["loss4"][0], buf["du"]
+    else:
+        if pa is not None:
+            _lib.check(lib.odpd_backbone_fwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["y"]),
+                                             _lib.ptr(buf["ck_p"]), _lib.ptr(pa._stats_buffer(x.device))), "pa fwd")
+        y = buf["y"] if pa is not None else buf["u"]
+        _lib.check(lib.odpd_loss_fwd_bwd(st, _lib.LOSS_IDS[loss_kind], B * T * 2, count, _lib.ptr(y), _lib.ptr(target),
+                                         _lib.ptr(buf["dy"]), _lib.ptr(buf["loss"])), "loss")
+        du = buf["dy"]
+        if pa is not None:
+            _lib.check(lib.odpd_backbone_bwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["dy"]),
+                                             _lib.ptr(buf["ck_p"]), _lib.ptr(buf["pa_part"]), _lib.ptr(buf["du"])), "pa bwd")
+            du = buf["du"]
     _lib.check(lib.odpd_backbone_bwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(du),
                                      _lib.ptr(buf["ck_d"]), _lib.ptr(part), None), "dpd bwd")
     _lib.check(lib.odpd_reduce_partials(st, part.shape[0], dpd.n_flat, _lib.ptr(part), _lib.ptr(opt.grad), 0), "reduce")
     # loss scalar travels with the gradient (column P) so that one all-reduce covers both:
     # grad[P] = sum of errors of this rank = mean * count
-    opt.grad[dpd.n_flat] = buf["loss"][0] * count
+    opt.grad[dpd.n_flat] = loss_sum if loss_sum is not None else buf["loss"][0] * count
     opt.allreduce_grad()
     loss = opt.grad[dpd.n_flat] / count
     opt.apply(grad_clip_val)

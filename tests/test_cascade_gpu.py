@@ -102,3 +102,50 @@ def test_cascade_with_every_pa_backbone_against_oracle(pa_bb, pa_h, dpd_bb, dpd_
     assert abs(lg.item() - lo) < 2e-5 * max(1.0, lo)
     assert rel_err(opt.grad[:-4].cpu().numpy(), gd) < 3e-4
     assert torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp))
+
+
+@pytest.fixture
+def force_s16():
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    assert lib.odpd_set_tuning(b"s16_min_batch", 0) == 0
+    yield
+    lib.odpd_set_tuning(b"s16_min_batch", -1)
+
+
+@pytest.mark.parametrize("pa_bb,pa_h", [("gru", 11), ("dgru", 13), ("dgru", 9), ("qgru", 10), ("qgru_amp1", 16), ("dgru", 23), ("gru", 30),
+                                         ("qgru", 20), ("dgru", 28)])
+@pytest.mark.parametrize("dpd_bb,dpd_h", [("dgru", 9), ("deltagru_tcnskip", 15)])
+@pytest.mark.parametrize("loss", ["l2", "l1"])
+def test_frozen_pa_single_launch_step_against_oracle(force_s16, pa_bb, pa_h, dpd_bb, dpd_h, loss):
+    """GRU-family PA on the 16-sequences-per-wave kernels: forward + loss + dL/du of the frozen PA run as ONE launch
+    (odpd_frozen_loss_dx: hidden <= 16 incl. the K-packed variant, hidden 17..32 with 2- and 4-chunk last tiles); DPD gradient
+    and loss of the cascade step == oracle composition."""
+    from opendpd_amd import CascadedModel, CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    import ctypes as C
+    torch.manual_seed(pa_h * 7 + dpd_h)
+    B, T = 37, 70
+    dpd, pa = CoreModel(2, dpd_h, 1, dpd_bb), CoreModel(2, pa_h, 1, pa_bb)
+    net = CascadedModel(dpd_model=dpd, pa_model=pa)
+    net.freeze_pa_model()
+    net = net.cuda()
+    assert _lib.load().odpd_frozen_loss_rows(C.byref(pa.backbone.desc), B, T) > 0
+    rng = np.random.RandomState(pa_h)
+    x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    o = Oracle("f32")
+    md, mp = make_model(dpd_bb, dpd_h), make_model(pa_bb, pa_h)
+    pd = dpd.backbone.flat_params().detach().cpu().numpy().copy()
+    pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
+    u, _ = o.forward(md, pd, x)
+    y, _ = o.forward(mp, pp, u)
+    lo, dy = o.loss(loss, y, t)
+    _, du = o.backward(mp, pp, u, dy)
+    gd, _ = o.backward(md, pd, x, du, need_dx=False)
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    lg = fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), loss, 0.0)
+    assert abs(lg.item() - lo) < 2e-5 * max(1.0, lo)
+    assert rel_err(opt.grad[:-4].cpu().numpy(), gd) < (3e-4 if loss == "l2" else 2e-3)
+    assert torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp))
