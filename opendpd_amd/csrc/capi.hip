@@ -187,15 +187,13 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     }
 }
 
-// Frozen model in front of the loss (the PA of train_dpd): forward + loss + dL/du in ONE launch.  Available where the
-// 16-sequences-per-wave GRU-family kernels serve the batch; everywhere else ODPD_EUNSUPPORTED (rows < 0) and the caller chains
-// odpd_backbone_fwd, odpd_loss_fwd_bwd, odpd_backbone_bwd.
+// Frozen model in front of the loss (the PA of train_dpd): forward + loss + dL/du in ONE launch.  Available for the GRU family
+// (row-rotated kernels with LDS-resident BPTT state at small batches, S16 / S16N at large ones); everywhere else
+// ODPD_EUNSUPPORTED (rows < 0) and the caller chains odpd_backbone_fwd, odpd_loss_fwd_bwd, odpd_backbone_bwd.
 extern "C" int64_t odpd_frozen_loss_rows(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
-    if (gru_uses_s16n(m, B)) return gru_s16n_rows(m, B);
-    if (gru_split_uses_s16(m, B)) return gru_s16_rows(m, B);
-    return ODPD_EUNSUPPORTED;
+    return gru_family_lossdx_rows(m, B, T);
 }
 extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss_kind, int B, int T, int64_t count,
                                    const float* params, const float* u, const float* target, float* du, float* loss_rows,
@@ -205,9 +203,7 @@ extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = u; a.target = target; a.dx = du; a.partials = loss_rows;
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.ckpt = workspace;
-    if (gru_uses_s16n(m, B)) return gru_s16n_launch((hipStream_t)stream, m, a, 3);
-    if (gru_split_uses_s16(m, B)) return gru_s16_lossdx((hipStream_t)stream, m, a);
-    return ODPD_EUNSUPPORTED;
+    return gru_family_lossdx((hipStream_t)stream, m, a);
 }
 
 // odpd_train_fwd_bwd on frames addressed inside resident streams (no materialised (B,T,2) tensors): batch = the B frames

@@ -553,11 +553,13 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
 // on the fly and back-propagates.  HBM traffic = x (twice, the second read is L2-resident) + target.
 // LDS per wave: x chunk, target chunk, checkpoints (nck x 64 floats).
 // -------------------------------------------------------------------------------------------------
-__host__ __device__ inline int train_wave_floats(int T, int R) {
-    return 2 * (2 * (4 / R) * kChunkPad) + num_ckpt_hd(T) * 64;
+__host__ __device__ inline int train_wave_floats(int T, int R, bool dx = false) {
+    return (dx ? 3 : 2) * (2 * (4 / R) * kChunkPad) + num_ckpt_hd(T) * 64;
 }
 
-template <int R, int FM, bool DG>
+// NW: weight-gradient partials (train_pa / trained model).  !NW && DX: the frozen PA of a cascade in one launch — forward, loss,
+// dL/dx into a.dx, one loss partial per workgroup in a.partials[blockIdx.x * kLossCols]
+template <int R, int FM, bool DG, bool NW = true, bool DX = false>
 __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 : 1) void gru_train_kernel(SeqArgs a) {
     constexpr int F = FeatDim<FM>::F, SPW = 4 / R, S = kCkptStride;
     using T = GruTabs<R, DG>;
@@ -570,10 +572,11 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
     float* tab = smem + pad4(L.P);
     fill_gru_tabs<R, DG, true>(tab, pl, L, lane, id.wave, id.nwb);
     TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
-    float* wbase = tab + T::kFloats + (size_t)id.wave * train_wave_floats(a.T, R);
+    float* wbase = tab + T::kFloats + (size_t)id.wave * train_wave_floats(a.T, R, DX);
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ts = xs + SPW * kChunkPad;
-    float* ck = reinterpret_cast<float*>(ts + SPW * kChunkPad);
+    float2* dxs = DX ? ts + SPW * kChunkPad : nullptr;
+    float* ck = reinterpret_cast<float*>(ts + (DX ? 2 : 1) * SPW * kChunkPad);
     GruW<R, F, DG> w;
     load_gru_w<R, F, DG>(w, pl, L, id.row, id.col);
     GruGrad<R, DG> G;
@@ -613,9 +616,23 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
             }
         }
         wave_lds_fence();
-        gru_bwd_task<R, FM, DG, true, false, true>(a, w, tlane, G, b0, id, xs, ts, nullptr, ck, loss_acc);
+        gru_bwd_task<R, FM, DG, NW, DX, true>(a, w, tlane, G, b0, id, xs, ts, dxs, ck, loss_acc);
     }
-    gru_block_partials<R, F, DG>(smem, a.partials, L, G, lane, id.wave, id.nwb, id.row, id.col, loss_acc);
+    if constexpr (NW) {
+        gru_block_partials<R, F, DG>(smem, a.partials, L, G, lane, id.wave, id.nwb, id.row, id.col, loss_acc);
+    } else {       // loss partial of the workgroup: lane sums in lane order, waves in wave order
+        float lp = loss_acc;                           // non-zero on the first lane of every sequence only
+        for (int o = 32; o > 0; o >>= 1) lp += __shfl_down(lp, o);
+        __syncthreads();
+        if (lane == 0) smem[id.wave] = lp;
+        __syncthreads();
+        if (threadIdx.x < kLossCols) {
+            float v = 0.0f;
+            if (threadIdx.x == 0)
+                for (int wv = 0; wv < id.nwb; ++wv) v += smem[wv];
+            a.partials[(size_t)blockIdx.x * kLossCols + threadIdx.x] = v;
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -643,10 +660,10 @@ static size_t gru_lds_bytes(int P, int R, bool DG, int waves, size_t wave_floats
 // launch shape of the backward / fused kernels (also fixes the number of partial rows = grid)
 static LaunchShape bwd_shape(int R, int ngroups) { return persistent_shape(ngroups, bwd_waves_per_cu(R), R == 1 ? 8 : 4); }
 // the fused kernel additionally has to fit its LDS-resident checkpoints: shrink the block if needed
-static LaunchShape train_shape(int P, int R, bool DG, int ngroups, int T, size_t* lds_out) {
+static LaunchShape train_shape(int P, int R, bool DG, int ngroups, int T, size_t* lds_out, bool dx = false) {
     LaunchShape ls = bwd_shape(R, ngroups);
     for (;;) {
-        size_t lds = gru_lds_bytes(P, R, DG, ls.waves, train_wave_floats(T, R), true);
+        size_t lds = gru_lds_bytes(P, R, DG, ls.waves, train_wave_floats(T, R, dx), true);
         if (lds <= kMaxLds || ls.waves == 1) {
             if (lds_out) *lds_out = lds;
             if (lds > kMaxLds) ls.grid = 0;   // does not fit at all
@@ -684,6 +701,18 @@ static int launch_train(hipStream_t st, const SeqArgs& a, int P) {
     const LaunchShape ls = train_shape(P, R, DG, a.ngroups, a.T, &lds);
     if (ls.grid <= 0) return ODPD_EUNSUPPORTED;  // frame too long for LDS-resident BPTT state
     auto k = gru_train_kernel<R, FM, DG>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+// frozen PA of a cascade: forward + loss + dL/du in one launch (a.x = u, a.target, a.dx = du, a.partials = loss rows)
+template <int R, int FM, bool DG>
+static int launch_lossdx(hipStream_t st, const SeqArgs& a, int P) {
+    size_t lds = 0;
+    const LaunchShape ls = train_shape(P, R, DG, a.ngroups, a.T, &lds, true);
+    if (ls.grid <= 0) return ODPD_EUNSUPPORTED;
+    auto k = gru_train_kernel<R, FM, DG, false, true>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
@@ -758,6 +787,23 @@ int gru_family_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     ODPD_GRU_DISPATCH_ALL(launch_train, st, a, P)
     return ODPD_EUNSUPPORTED;
+}
+// frozen PA of a cascade: forward + loss + dL/du in one launch; loss rows = (rows, kLossCols)
+int gru_family_lossdx(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 3);
+    if (gru_split_uses_s16(m, a.B)) return gru_s16_lossdx(st, m, a);
+    ODPD_GRU_DISPATCH_ALL(launch_lossdx, st, a, P)
+    return ODPD_EUNSUPPORTED;
+}
+int gru_family_lossdx_rows(const odpd_model_t* m, int B, int T) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    if (gru_uses_s16n(m, B)) return gru_s16n_rows(m, B);
+    if (gru_split_uses_s16(m, B)) return gru_s16_rows(m, B);
+    const LaunchShape ls = train_shape(P, R, DG, num_groups(B, R), T, nullptr, true);
+    return ls.grid > 0 ? ls.grid : ODPD_EUNSUPPORTED;      // frame too long for LDS-resident BPTT state: use the split calls
 }
 // rows of partials written by the backward (which = 0) or fused (which = 1, needs T) kernels
 int gru_family_rows(const odpd_model_t* m, int B, int which, int T) {

@@ -142,6 +142,8 @@ struct SeqArgs {
 int gru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_family_lossdx(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);        // frozen PA: forward + loss + dL/dx in one launch
+int gru_family_lossdx_rows(const odpd_model_t* m, int B, int T);
 int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, int T);
 // 16-sequences-per-wave fused kernel (gru_s16.hip) and the rule that selects it
 bool gru_train_uses_s16(const odpd_model_t* m, int B, int T);
