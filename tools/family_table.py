@@ -83,7 +83,7 @@ for B in (64, a.big):
     with torch.no_grad():
         msf = timeit(lambda: casc(x), 21 if B <= 1024 else 7)
     cells += [ms, B * T / ms / 1e3, msf, B * T / msf / 1e3]
-rows.append(("train_dpd: TRes-DeltaGRU15 -> frozen DGRU23 (B = 64 | big)", 999, "cascade (5 launches)", *cells))
+rows.append(("train_dpd: TRes-DeltaGRU15 -> frozen DGRU23 (B = 64 | big)", 999, "cascade (DPD fwd, frozen-PA fwd+loss+dL/du, DPD bwd)", *cells))
 
 hdr = (f"| backbone | params | train step | B=256: step ms | M samples/s | fwd ms | M samples/s | B={a.big}: step ms | M samples/s | fwd ms "
        f"| M samples/s |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
