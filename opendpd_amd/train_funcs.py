@@ -289,8 +289,8 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
 
 def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
     """Split-kernel step.  With a frozen PA (train_dpd, steps/train_dpd.py:60-63, models.py:173-176):
-    y = PA(DPD(x)) as five launches chained on the stream — DPD fwd, PA fwd, loss, PA bwd (dL/du only),
-    DPD bwd.  Without a PA (backbones that have no fused kernel yet): fwd, loss, bwd."""
+    y = PA(DPD(x)) chained on the stream — DPD fwd, then the frozen PA's forward + loss + dL/du as ONE launch where
+    odpd_frozen_loss_dx serves the PA (GRU family), else PA fwd, loss, PA bwd (dL/du only); then DPD bwd.  Without a PA (backbones that have no fused kernel yet): fwd, loss, bwd."""
     lib = _lib.load()
     dpd, pa = opt.backbone, opt.pa
     B, T = x.shape[0], x.shape[1]

@@ -1,5 +1,5 @@
 """train_dpd path: CascadedModel(DPD, frozen PA) — reference models.py:163-176, steps/train_dpd.py:60-63.
-Checks the autograd path and the fused five-launch step against the reference's cascade fixtures."""
+Checks the autograd path and the fused cascade step against the reference's cascade fixtures."""
 import numpy as np
 import pytest
 import torch
@@ -73,7 +73,7 @@ def test_cascade_fused_steps_follow_reference(name, dpd_bb, pa_bb):
                                          ("deltagru", 15), ("deltagru_tcnskip", 12)])
 @pytest.mark.parametrize("dpd_bb,dpd_h", [("dgru", 9), ("deltagru_tcnskip", 15)])
 def test_cascade_with_every_pa_backbone_against_oracle(pa_bb, pa_h, dpd_bb, dpd_h):
-    """Every float backbone with dL/dx can be the frozen PA of train_dpd: DPD gradient of the five-launch cascade step
+    """Every float backbone with dL/dx can be the frozen PA of train_dpd: DPD gradient of the cascade step
     == oracle composition (DPD fwd, PA fwd, MSE, PA backward for dL/du only, DPD backward)."""
     from opendpd_amd import CascadedModel, CoreModel
     from opendpd_amd.train_funcs import FusedAdamW, fused_train_step

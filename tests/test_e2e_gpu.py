@@ -249,7 +249,7 @@ def test_baseline_config_2_and_4_epochs_match_reference_log(apa_workdir, key, ds
 
 def test_baseline_config_3_epoch_on_apa_matches_reference_log(apa_workdir):
     """BASELINE config 3 on its own dataset: train_dpd of TRes-DeltaGRU H15 (thx .01, thh .05) in front of the frozen DGRU H23
-    PA the REFERENCE trained (its state dict is a fixture), 919 steps of 64 x 200 frames through the five-launch cascade step,
+    PA the REFERENCE trained (its state dict is a fixture), 919 steps of 64 x 200 frames through the cascade step,
     against the row the reference logged (tests/golden/ref_runs_apa.json).  Thresholded model: rounding-level differences
     flip a few delta decisions over 919 steps, hence dB-level tolerances on the metrics."""
     import opendpd_amd as od
