@@ -21,7 +21,7 @@ from . import data as D
 from .metrics import calculate_metrics
 from .models import CascadedModel, CoreModel
 from .quant import get_quant_model
-from .train_funcs import FusedAdamW, net_eval, net_train
+from .train_funcs import FusedAdamW, net_eval, net_eval_pair, net_train
 
 DEFAULTS = dict(  # arguments.py:8-89
     dataset_name=None, dataset_path=None, filename="", log_precision=8, step="run_dpd", eval_val=1, eval_test=1,
@@ -235,10 +235,14 @@ class Project:
         start = time.time()
         for epoch in range(self.n_epochs):
             net = net_train(self.log_train, net, train_loader, optimizer, criterion, self.grad_clip_val, self.device)
-            if self.eval_val:
+            if self.eval_val and self.eval_test:      # both splits in one forward launch (latency-bound tiny batches)
+                _, (pv, tv), (pt, tt) = net_eval_pair(self.log_val, self.log_test, net, val_loader, test_loader, criterion, self.device)
+                self.log_val = calculate_metrics(self.args, self.log_val, pv, tv)
+                self.log_test = calculate_metrics(self.args, self.log_test, pt, tt)
+            elif self.eval_val:
                 _, pred, truth = net_eval(self.log_val, net, val_loader, criterion, self.device)
                 self.log_val = calculate_metrics(self.args, self.log_val, pred, truth)
-            if self.eval_test:
+            elif self.eval_test:
                 _, pred, truth = net_eval(self.log_test, net, test_loader, criterion, self.device)
                 self.log_test = calculate_metrics(self.args, self.log_test, pred, truth)
             self.log_all = self.gen_log_stat((time.time() - start) / 60.0, net, optimizer, epoch)

@@ -391,6 +391,31 @@ def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device)
     return net
 
 
+def net_eval_pair(log_a, log_b, net, loader_a, loader_b, criterion, device):
+    """Validation and test evaluation in ONE forward launch per batch pair.  The recurrent kernels are latency-bound on these
+    tiny batches (1-3 long segments): running the two splits side by side costs the time of one.  Same results as two
+    net_eval calls (the sequences of a batch are independent); falls back to them when the splits do not pair up."""
+    batches_a, batches_b = list(loader_a), list(loader_b)
+    pairable = len(batches_a) == len(batches_b) and all(fa.shape[1:] == fb.shape[1:] for (fa, _), (fb, _) in zip(batches_a, batches_b))
+    if not pairable:
+        _, pa, ga = net_eval(log_a, net, batches_a, criterion, device)
+        _, pb, gb = net_eval(log_b, net, batches_b, criterion, device)
+        return net, (pa, ga), (pb, gb)
+    net = net.eval()
+    out = ([], [], []), ([], [], [])
+    with torch.no_grad():
+        for (fa, ta), (fb, tb) in zip(batches_a, batches_b):
+            fa, ta, fb, tb = fa.to(device), ta.to(device), fb.to(device), tb.to(device)
+            y = net(torch.cat((fa, fb), dim=0))
+            for (losses, pred, truth), o, t in ((out[0], y[:fa.shape[0]], ta), (out[1], y[fa.shape[0]:], tb)):
+                losses.append(criterion(o, t)); pred.append(o); truth.append(t)
+    res = []
+    for log, (losses, pred, truth) in ((log_a, out[0]), (log_b, out[1])):
+        log["loss"] = float(np.mean(torch.stack([l.float() for l in losses]).cpu().numpy())) if losses else float("nan")
+        res.append((torch.cat(pred, dim=0).cpu().numpy(), torch.cat(truth, dim=0).cpu().numpy()))
+    return net, res[0], res[1]
+
+
 def net_eval(log, net, dataloader, criterion, device):
     """Reference signature (train_funcs.py:57-61); returns (net, prediction, ground_truth) as numpy."""
     net = net.eval()
