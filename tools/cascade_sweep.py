@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the train_dpd step (models.py:163-176 + train_funcs.py:33-44): random DPD x frozen PA pairs over all HIP
+backbones and hidden sizes, random batch / frame length / loss kind, both kernel mappings; loss and DPD gradient of
+`fused_train_step` against the C oracle's composition (DPD fwd, PA fwd, loss, PA backward for dL/du, DPD backward), PA untouched.
+usage: PYTHONPATH=. python tools/cascade_sweep.py [cases]"""
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+from opendpd_amd import CascadedModel, CoreModel, _lib
+from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+from oracle.oracle import Oracle, make_model
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+lib = _lib.load()
+o = Oracle("f32")
+LIM = {"gru": 32, "dgru": 32, "qgru": 32, "qgru_amp1": 32, "lstm": 32, "vdlstm": 32, "deltagru": 32, "deltagru_tcnskip": 32, "pgjanet": 16,
+       "tcnn": 40}
+names = list(LIM)
+rng = np.random.RandomState(7)
+bad, worst, single = [], [0.0, 0.0], 0
+for case in range(n_cases):
+    dbb, pbb = names[rng.randint(len(names))], names[rng.randint(len(names))]
+    dh, ph = int(rng.randint(1, LIM[dbb] + 1)), int(rng.randint(1, LIM[pbb] + 1))
+    force = bool(rng.randint(2))
+    lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
+    B = int(rng.choice([1, 3, 4, 16, 17, 33, 64]))
+    T = int(rng.choice([3, 5, 31, 32, 33, 50, 65, 120]))
+    kind = str(rng.choice(["l2", "l1"]))
+    torch.manual_seed(int(rng.randint(1 << 30)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dpd, pa = CoreModel(2, dh, 1, dbb), CoreModel(2, ph, 1, pbb)          # delta thresholds 0: no discontinuities in the sweep
+    with torch.no_grad():
+        for net_ in (dpd, pa):
+            for k, p in net_.named_parameters():
+                if "bias" in k:
+                    p.uniform_(-0.2, 0.2)
+    net = CascadedModel(dpd_model=dpd, pa_model=pa)
+    net.freeze_pa_model()
+    net = net.cuda()
+    x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    md, mp = make_model(dbb, dh), make_model(pbb, ph)
+    pd = dpd.backbone.flat_params().detach().cpu().numpy().copy()
+    pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
+    u, _ = o.forward(md, pd, x)
+    # the PA divides by |u| (polar features): skip the rare draws where the random DPD maps a sample next to the origin
+    if "vdlstm" in pbb or pbb in ("dgru", "deltagru", "pgjanet", "tcnn", "qgru_amp1"):
+        if np.sqrt((u ** 2).sum(-1)).min() < 1e-3:
+            continue
+    y, _ = o.forward(mp, pp, u)
+    lo, dy = o.loss(kind, y, t)
+    _, du = o.backward(mp, pp, u, dy)
+    gd, _ = o.backward(md, pd, x, du, need_dx=False)
+    try:
+        opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+        lg = float(fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), kind, 0.0))
+        g = opt.grad[:-4].cpu().numpy()
+        single += int(opt.cascade_buffers(B, T, torch.device("cuda", 0))["loss_rows"] is not None)
+    except Exception as e:      # noqa: BLE001
+        bad.append((dbb, dh, pbb, ph, B, T, kind, force, f"EXC {e}"))
+        continue
+    el = abs(lg - lo) / max(abs(lo), 1e-30)
+    eg = float(np.abs(g - gd).max() / max(np.abs(gd).max(), 1e-30))
+    same = bool(torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp)))
+    worst[0], worst[1] = max(worst[0], el), max(worst[1], eg)
+    tol_g = 3e-4 if kind == "l2" else 5e-3        # l1: sign(y - t) of a residual within rounding of 0 may differ
+    if not (el < 3e-5 and eg < tol_g and same) or not np.isfinite([el, eg]).all():
+        bad.append((dbb, dh, pbb, ph, B, T, kind, force, f"loss {el:.2e} grad {eg:.2e} pa_untouched {same}"))
+lib.odpd_set_tuning(b"s16_min_batch", -1)
+print(f"{n_cases} random cascades ({single} through the single-launch frozen-PA step): worst rel err  loss {worst[0]:.2e}  DPD gradient {worst[1]:.2e}")
+print(f"{len(bad)} case(s) beyond tolerance")
+for b in bad[:40]:
+    print("  ", b)
