@@ -152,7 +152,8 @@ __device__ __forceinline__ void stage_in_halo(float2* lds, const float* g, int b
             int tg = t0 - kHalo + pos;
             if (tg < 0) tg += T;     // circular padding: the frame's own last samples (vdlstm.py:66-74)
             float2 v = make_float2(0.5f, 0.5f);
-            if (pos < len + kHalo && b0 + m < B && tg < T) v = g2[(size_t)(b0 + m) * T + tg];
+            // tg can stay negative for frames shorter than the halo (plain LSTM with T < 3: the halo is not used there)
+            if (pos < len + kHalo && b0 + m < B && tg >= 0 && tg < T) v = g2[(size_t)(b0 + m) * T + tg];
             lds[m * kHaloStride + pos] = v;
         }
     }

@@ -389,7 +389,7 @@ __device__ __forceinline__ void l16_stage_halo(float2* lds, const float* g, int 
             int tg = t0 - 3 + pos;
             if (tg < 0) tg += T;
             float2 v = make_float2(0.5f, 0.5f);
-            if (pos < len + 3 && b0 + m < B && tg < T) v = g2[(size_t)(b0 + m) * T + tg];
+            if (pos < len + 3 && b0 + m < B && tg >= 0 && tg < T) v = g2[(size_t)(b0 + m) * T + tg];   // tg < 0: frame shorter than the halo
             lds[m * kL16HaloStride + pos] = v;
         }
     }

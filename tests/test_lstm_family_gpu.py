@@ -69,6 +69,36 @@ def test_against_oracle_ragged(bb, H, B, T):
         assert rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
 
 
+@pytest.mark.parametrize("s16", [False, True])
+@pytest.mark.parametrize("H,B,T", [(14, 3, 2), (23, 16, 1), (27, 3, 2), (9, 1, 1)])
+def test_lstm_frames_shorter_than_the_halo(s16, H, B, T):
+    """plain lstm shares the 3-sample halo staging with vdlstm but never uses it: frames with T < 3 are legal and must
+    neither read before the frame start (found by tools/oob_hunt.py) nor differ from the oracle."""
+    from opendpd_amd import CoreModel, _lib
+    from oracle.oracle import Oracle, make_model
+    lib = _lib.load()
+    lib.odpd_set_tuning(b"s16_min_batch", 0 if s16 else -1)
+    try:
+        torch.manual_seed(H + B + T)
+        net = CoreModel(2, H, 1, "lstm").cuda()
+        rng = np.random.RandomState(H)
+        x = (rng.uniform(0.05, 0.9, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+        dy = rng.randn(B, T, 2).astype(np.float32)
+        xt = torch.from_numpy(x).cuda().requires_grad_(True)
+        y = net(xt)
+        y.backward(torch.from_numpy(dy).cuda())
+    finally:
+        lib.odpd_set_tuning(b"s16_min_batch", -1)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    m = make_model("lstm", H)
+    yo, _ = Oracle("f32").forward(m, p, x)
+    go, dxo = Oracle("f32").backward(m, p, x, dy)
+    g = np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()])
+    assert rel_err(y.detach().cpu().numpy(), yo) < FWD_TOL
+    assert rel_err(g, go) < GRAD_TOL
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
+
+
 @pytest.mark.parametrize("name,bb", [("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm")])
 def test_train_steps_follow_reference(name, bb):
     from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
