@@ -2,6 +2,8 @@
 """Out-of-bounds hunt (GPU box): every backbone forward + backward on random shapes with the input x and the output gradient dy
 placed at the very END of their own 2 MiB device allocations (caching allocator off), and x once more at the very START: a
 kernel that reads past either side of a tensor hits an unmapped page and dies with a memory access fault.
+The fused train step (x and target placed), the cascade step (random DPD in front of the backbone as frozen PA) and, for
+qgru / qgru_amp1, the W8A8 quantisation-aware cell run on the same shapes.
 usage: PYTORCH_NO_CUDA_MEMORY_CACHING=1 PYTHONPATH=. python tools/oob_hunt.py <backbone> <seed> [cases]"""
 import os
 import sys
@@ -11,7 +13,16 @@ import numpy as np
 import torch
 
 assert os.environ.get("PYTORCH_NO_CUDA_MEMORY_CACHING") == "1", "run with PYTORCH_NO_CUDA_MEMORY_CACHING=1"
-from opendpd_amd import CoreModel, _lib  # noqa: E402
+from opendpd_amd import CascadedModel, CoreModel, _lib  # noqa: E402
+from opendpd_amd.quant import get_quant_model  # noqa: E402
+from opendpd_amd.train_funcs import FusedAdamW, fused_train_step  # noqa: E402
+
+
+class _Proj:
+    quant = True
+    pretrained_model = ""
+    n_bits_w = n_bits_a = 8
+
 
 lib = _lib.load()
 bb, seed = sys.argv[1], int(sys.argv[2])
@@ -52,9 +63,26 @@ for it in range(cases):
     x0 = (torch.rand(B, T, 2) - 0.5) * 1.6
     x0 = x0 + 0.05 * torch.sign(x0)
     dy = at_end(torch.randn(B, T, 2))
+    tgt = torch.randn(B, T, 2) * 0.3
+    kw = {"thx": 0.01, "thh": 0.02}
+    dpd_bb = ["dgru", "deltagru_tcnskip", "gru", "lstm"][it % 4]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        casc = CascadedModel(dpd_model=CoreModel(2, int(rng.randint(2, 25)), 1, dpd_bb, **(kw if "delta" in dpd_bb else {})),
+                             pa_model=CoreModel(2, H, 1, bb, **(kw if "delta" in bb else {})))
+    casc.freeze_pa_model()
+    casc = casc.cuda()
+    opt, copt = FusedAdamW(net, lr=1e-3), FusedAdamW(casc, lr=1e-3)
+    qnet = get_quant_model(_Proj, CoreModel(2, min(H, 16), 1, bb)).cuda().train() if bb in ("qgru", "qgru_amp1") else None
     for place in (at_end, at_start):
         x = place(x0).requires_grad_(True)
         y = net(x)
         y.backward(dy)
+        fused_train_step(opt, place(x0), place(tgt), "l2", 200.0)
+        if T >= 3 or "vdlstm" not in (bb, dpd_bb):
+            fused_train_step(copt, place(x0), place(tgt), "l2", 200.0)
+        if qnet is not None:
+            xq = place(x0).requires_grad_(True)
+            qnet(xq).backward(dy)
         torch.cuda.synchronize()
 print("done")
