@@ -38,7 +38,8 @@ enum odpd_backbone {
     ODPD_TRES_DELTAGRU = 7, /* backbones/deltagru_tcnskip.py:11-304 ('deltagru_tcnskip') */
     ODPD_TCNN = 8,       /* backbones/tcnn.py:5-97 */
     ODPD_PGJANET = 9,    /* backbones/pgjanet.py:5-84 */
-    ODPD_BACKBONE_COUNT = 10
+    ODPD_GMP = 10,       /* backbones/gmp.py:5-50 (hidden = memory_length; degree 5 as built by models.py:26-28) */
+    ODPD_BACKBONE_COUNT = 11
 };
 
 enum odpd_error {

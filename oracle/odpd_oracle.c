@@ -32,6 +32,7 @@ typedef ODPD_REAL real;
 
 #define MAXH 64
 #define MAXF 8
+#define GMP_DEGREE 5     /* models.py:26-28 builds GMP() with the defaults memory_length 11, degree 5 (gmp.py:6) */
 
 static inline real sigm(real v) { return (real)1 / ((real)1 + (real)exp(-(double)v)); }
 static inline real tanhr(real v) { return (real)tanh((double)v); }
@@ -69,6 +70,8 @@ int64_t oracle_param_count(const odpd_model_t* m) {
         return 6 * H + H + 4 * 5 * H + 2 * H;
     case ODPD_PGJANET:
         return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
+    case ODPD_GMP:      /* gmp.py:10-11: memory_length * (1 + (degree - 1) * memory_length); hidden = memory_length, degree 5 */
+        return H * (1 + (GMP_DEGREE - 1) * H);
     default: return -1;
     }
 }
@@ -987,6 +990,68 @@ int oracle_qat_bwd(const odpd_model_t* m, int B, int T, const real* params, cons
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* GMP: gmp.py:18-50.  u = x delayed by M-1 (zero history, :26-27); amp = |u| delayed by M-1 once more (:33);
+ * per sample t the basis is [u[t+m]] (M terms) followed by u[t+m] * amp[t+i+m]^d for d = 1..D-1, i, m = 0..M-1
+ * (:41-44, flattened d-major, then i, then m); y[t] = sum basis * Weight (real weights on complex terms, :46-48).  */
+/* ------------------------------------------------------------------------------------------ */
+static inline real gmp_pow(real a, int d) { real a2 = a * a; return d == 1 ? a : d == 2 ? a2 : d == 3 ? a2 * a : a2 * a2; }
+static void gmp_windows(int M, int T, const real* x, real* u, real* amp) {
+    for (int k = 0; k < T + M - 1; ++k) {
+        int s = k - (M - 1);
+        u[2 * k] = s >= 0 ? x[2 * s] : (real)0;
+        u[2 * k + 1] = s >= 0 ? x[2 * s + 1] : (real)0;
+    }
+    for (int k = 0; k < T + 2 * M - 2; ++k) {
+        int s = k - (M - 1);
+        amp[k] = s >= 0 ? (real)sqrt((double)u[2 * s] * u[2 * s] + (double)u[2 * s + 1] * u[2 * s + 1]) : (real)0;
+    }
+}
+static void gmp_seq_fwd(int M, const real* w, int T, const real* x, real* y, real* u, real* amp) {
+    gmp_windows(M, T, x, u, amp);
+    for (int t = 0; t < T; ++t) {
+        real yr = 0, yi = 0;
+        for (int m = 0; m < M; ++m) {
+            real e = w[m];
+            for (int d = 1; d < GMP_DEGREE; ++d)
+                for (int i = 0; i < M; ++i) e += w[M + ((d - 1) * M + i) * M + m] * gmp_pow(amp[t + i + m], d);
+            yr += e * u[2 * (t + m)];
+            yi += e * u[2 * (t + m) + 1];
+        }
+        y[2 * t] = yr; y[2 * t + 1] = yi;
+    }
+}
+/* du / damp are scratch of T+M-1 complex / T+2M-2 real entries */
+static void gmp_seq_bwd(int M, const real* w, int T, const real* x, const real* dy, real* dp, real* dx, real* u, real* amp,
+                        real* du, real* damp) {
+    gmp_windows(M, T, x, u, amp);
+    memset(du, 0, sizeof(real) * 2 * (T + M - 1));
+    memset(damp, 0, sizeof(real) * (T + 2 * M - 2));
+    for (int t = 0; t < T; ++t)
+        for (int m = 0; m < M; ++m) {
+            const real ur = u[2 * (t + m)], ui = u[2 * (t + m) + 1];
+            const real g = dy[2 * t] * ur + dy[2 * t + 1] * ui;     /* d loss / d (real coefficient of u[t+m]) */
+            real e = w[m];
+            dp[m] += g;
+            for (int d = 1; d < GMP_DEGREE; ++d)
+                for (int i = 0; i < M; ++i) {
+                    const int k = M + ((d - 1) * M + i) * M + m;
+                    const real a = amp[t + i + m];
+                    e += w[k] * gmp_pow(a, d);
+                    dp[k] += g * gmp_pow(a, d);
+                    damp[t + i + m] += w[k] * g * (real)d * (d == 1 ? (real)1 : gmp_pow(a, d - 1));
+                }
+            du[2 * (t + m)] += dy[2 * t] * e;
+            du[2 * (t + m) + 1] += dy[2 * t + 1] * e;
+        }
+    if (!dx) return;
+    for (int k = 0; k < T + M - 1; ++k) {       /* amp[k + M-1] = |u[k]|; d|u|/du = u/|u| (0 at the origin, as torch.abs) */
+        const real a = amp[k + M - 1];
+        if (a > 0) { du[2 * k] += damp[k + M - 1] * u[2 * k] / a; du[2 * k + 1] += damp[k + M - 1] * u[2 * k + 1] / a; }
+    }
+    for (int s = 0; s < T; ++s) { dx[2 * s] = du[2 * (s + M - 1)]; dx[2 * s + 1] = du[2 * (s + M - 1) + 1]; }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* dispatch                                                                                     */
 /* ------------------------------------------------------------------------------------------ */
 static int is_gru_family(int bb) { return bb == ODPD_GRU || bb == ODPD_DGRU || bb == ODPD_QGRU || bb == ODPD_QGRU_AMP1; }
@@ -1023,6 +1088,12 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         pgj_step_t* S = (pgj_step_t*)scratch;
         pgj_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
         if (dy) pgj_seq_bwd(&L, params, T, x, dy, S, dp, dx);
+    } else if (bb == ODPD_GMP) {
+        const int M = m->hidden;
+        real* u = (real*)scratch; real* amp = u + 2 * (T + M - 1);
+        real* du = amp + (T + 2 * M - 2); real* damp = du + 2 * (T + M - 1);
+        if (dy) gmp_seq_bwd(M, params, T, x, dy, dp, dx, u, amp, du, damp);
+        else gmp_seq_fwd(M, params, T, x, y, u, amp);
     }
 }
 static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
@@ -1032,6 +1103,7 @@ static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
     if (is_delta_family(bb)) return sizeof(delta_step_t) * T;
     if (bb == ODPD_TCNN) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_PGJANET) return sizeof(pgj_step_t) * T;
+    if (bb == ODPD_GMP) return sizeof(real) * (size_t)(6 * (T + 2 * m->hidden));
     return 0;
 }
 

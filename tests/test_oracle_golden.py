@@ -20,7 +20,7 @@ SINGLE = [
     ("deltagru_h15_dense", "deltagru"), ("deltagru_h15_th", "deltagru"),
     ("tres_h15_dense", "deltagru_tcnskip"), ("tres_h15_th", "deltagru_tcnskip"),
     ("deltagru_h24_th", "deltagru"), ("tres_h30_th", "deltagru_tcnskip"),
-    ("tcnn_c35", "tcnn"), ("pgjanet_h11", "pgjanet"),
+    ("tcnn_c35", "tcnn"), ("pgjanet_h11", "pgjanet"), ("gmp_m11", "gmp"),
 ]
 
 
