@@ -51,7 +51,8 @@ enum odpd_error {
 /* Model descriptor: what `CoreModel.__init__` receives (models.py:11). */
 typedef struct odpd_model {
     int32_t backbone; /* enum odpd_backbone */
-    int32_t hidden;   /* hidden_size (channels for tcnn): <= 32 (pgjanet, QAT: <= 16; tcnn: <= 64), else ODPD_EUNSUPPORTED */
+    int32_t hidden;   /* hidden_size (channels for tcnn; memory_length for gmp): <= 32 (pgjanet, QAT: <= 16; tcnn: <= 64; gmp: 11),
+                         else ODPD_EUNSUPPORTED */
     float thx;        /* delta threshold on inputs  (deltagru*, models.py:11) */
     float thh;        /* delta threshold on hidden state */
     int32_t bits_w;   /* QAT weight bits (0 = float model) — quant/quant_envs.py:145 */

@@ -4,3 +4,4 @@ from .lstm import LSTM, VDLSTM  # noqa: F401
 from .deltagru import DeltaGRU, TResDeltaGRU  # noqa: F401
 from .pgjanet import PGJANET  # noqa: F401
 from .tcnn import TCNN  # noqa: F401
+from .gmp import GMP  # noqa: F401

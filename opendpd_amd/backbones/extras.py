@@ -1,5 +1,5 @@
-"""Registry backbones that do not have HIP kernels yet: gmp, rvtdcnn, neuraltx, mcldnn, bojanet, apnrru,
-dvrjanet, deltajanet.
+"""Registry backbones that do not have HIP kernels yet: rvtdcnn, neuraltx, mcldnn, bojanet, apnrru,
+dvrjanet, deltajanet (gmp moved to csrc/gmp.hip).
 
 These are plain torch restatements of what the reference modules compute (same parameter names / shapes / registration
 order so checkpoints interchange, same initialisation order so a seeded construction gives the reference's state dict;
@@ -29,34 +29,6 @@ def _circular_windows(x, size):
     """(B,T,C) -> (B,T,C,size): like _causal_windows but the frame's own last size-1 samples stand in front."""
     xp = torch.cat((x[:, -(size - 1):, :], x), dim=1)
     return xp.unfold(1, size, 1)
-
-
-class GMP(nn.Module):
-    """backbones/gmp.py:5-50 — y[t] = sum_m w0[m] u[t+m] + sum_{d,i,m} w[d,i,m] u[t+m] |u[t+i+m-(M-1)]|^(d+1) with
-    u = x delayed by M-1 (zero history), real weights acting on complex terms."""
-    native = False
-
-    def __init__(self, memory_length=11, degree=5):
-        super().__init__()
-        self.memory_length, self.degree = memory_length, degree
-        self.W = 1 + (degree - 1) * memory_length
-        self.Weight = nn.Parameter(torch.empty(1, memory_length * self.W))
-
-    def reset_parameters(self):
-        nn.init.xavier_uniform_(self.Weight)
-
-    def forward(self, x, h_0=None):
-        M, D = self.memory_length, self.degree
-        u = F.pad(torch.complex(x[..., 0], x[..., 1]), (M - 1, 0))          # (B, T+M-1)
-        amp = F.pad(u.abs(), (M - 1, 0))                                     # (B, T+2M-2)  ref quirk: padded twice
-        lin = u.unfold(1, M, 1)                                              # (B,T,M): u[t+m]
-        terms = [lin]
-        for d in range(1, D):
-            env = (amp ** d).unfold(1, 2 * M - 1, 1).unfold(2, M, 1)         # (B,T,M(i),M(m)): amp^d[t+i+m]
-            terms.append((lin.unsqueeze(2) * env).flatten(2))
-        basis = torch.cat(terms, dim=2)                                      # (B,T,M + (D-1) M^2)
-        y = (basis * self.Weight.reshape(1, 1, -1)).sum(-1)
-        return torch.stack((y.real, y.imag), dim=-1)
 
 
 class RVTDCNN(nn.Module):

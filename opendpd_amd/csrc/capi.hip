@@ -5,7 +5,7 @@
 using namespace odpd;
 
 namespace {
-enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT };
+enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP };
 inline Family family_of(int bb);
 // a quantisation-aware model: qgru / qgru_amp1 with bits_w > 0 (quant/quant_envs.py:138-171)
 inline Family family_of(const odpd_model_t* m) {
@@ -19,6 +19,7 @@ inline Family family_of(int bb) {
     case ODPD_DELTAGRU: case ODPD_TRES_DELTAGRU: return FAM_DELTA;
     case ODPD_PGJANET: return FAM_JANET;
     case ODPD_TCNN: return FAM_TCNN;
+    case ODPD_GMP: return FAM_GMP;
     default: return FAM_NONE;
     }
 }
@@ -79,13 +80,14 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_TRES_DELTAGRU: return 3 * H * 6 + 3 * H * H + 2 * H + 18 + 6;
     case ODPD_TCNN: return 6 * H + H + 4 * 5 * H + 2 * H;
     case ODPD_PGJANET: return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
+    case ODPD_GMP: return H == 11 ? H * (1 + 4 * H) : (int64_t)ODPD_EUNSUPPORTED;   // memory_length 11, degree 5 (models.py:26-28)
     default: return ODPD_EUNSUPPORTED;
     }
 }
 
 extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
-    if (family_of(m) == FAM_TCNN) return 0;   // not recurrent: nothing to checkpoint
+    if (family_of(m) == FAM_TCNN || family_of(m) == FAM_GMP) return 0;   // not recurrent: nothing to checkpoint
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
@@ -114,6 +116,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B);
     case FAM_JANET: return fused ? (int64_t)ODPD_EUNSUPPORTED : janet_family_rows(m, B);
     case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
+    case FAM_GMP: return fused ? (int64_t)ODPD_EUNSUPPORTED : gmp_rows(m, B, T);
     case FAM_QAT: return fused ? (int64_t)ODPD_EUNSUPPORTED : qgru_family_rows(m, B);
     default: return ODPD_EUNSUPPORTED;
     }
@@ -138,6 +141,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
     case FAM_JANET: return janet_family_fwd((hipStream_t)stream, m, a);
     case FAM_TCNN: return tcnn_fwd((hipStream_t)stream, m, a);
+    case FAM_GMP: return gmp_fwd((hipStream_t)stream, m, a);
     case FAM_QAT: return qgru_family_fwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
@@ -162,6 +166,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return janet_family_bwd((hipStream_t)stream, m, a);
     case FAM_TCNN: return tcnn_bwd((hipStream_t)stream, m, a);
+    case FAM_GMP: return gmp_bwd((hipStream_t)stream, m, a);
     case FAM_QAT:
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return qgru_family_bwd((hipStream_t)stream, m, a);

@@ -1,0 +1,364 @@
+// gmp.hip — generalised memory polynomial backbone (reference backbones/gmp.py:5-50, built as GMP() by models.py:26-28:
+// memory_length M = 11, degree 5 -> 495 real weights on complex terms).
+//
+// The reference writes y[t] = sum_m u[t+m] (w0[m] + sum_{d,i} w[d,i,m] amp[t+i+m]^d) over a signal delayed by M-1 and an
+// envelope delayed by 2(M-1) (gmp.py:26-33: zero history).  In sample coordinates, with r = M-1-m, k = M-1-i and
+// P_d[s] = |x[s]|^d (zero before the frame start), this is
+//     y[t]      = sum_r x[t-r] * Ec[t-r, r],      Ec[s, r] = w0[r] + sum_{d,k} w[d,k,r] P_d[s-k]
+// and everything a sample s contributes to is a function of ITS OWN look-back envelope (k = 0..10) and look-ahead output
+// gradient (r = 0..10):
+//     dL/dw[d,k,r] = sum_s G[s,r] P_d[s-k],        G[s,r] = Re(conj(x[s]) dy[s+r])          (dL/dw0[r] = sum_s G[s,r])
+//     dL/dx[s]     = sum_r dy[s+r] Ec[s,r] + (x[s]/|x[s]|) sum_d d |x[s]|^(d-1) sum_{k,r} w[d,k,r] G[s+k,r]
+// Not recurrent: one lane per sample, a workgroup stages whole frames (time chunks of <= 512 samples with a 20-sample halo on
+// both sides for long records) as [|x|, |x|^2, |x|^3, |x|^4] float4 + x (+ dy) in LDS and every lane reads its window from
+// there (ds_read_b128, conflict-free).  The 484 envelope weights are wave-uniform: they are read through the constant address
+// space, i.e. s_load_dwordx16 into SGPRs, and enter v_fmac as the scalar operand — no LDS or VGPR traffic for them.  The
+// weight gradient is an (11 x 45) = G^T [P | 1] contraction over samples: v_mfma_f32_16x16x4_f32, three 16x16 tiles per four
+// samples (exact fp32), operands fetched straight from the LDS arrays.
+#include <utility>
+
+#include "odpd_host.h"
+
+namespace odpd {
+namespace {
+
+template <class F, int... I>
+__device__ __forceinline__ void gmp_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void gmp_for(F&& f) { gmp_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int kM = 11;                       // memory_length
+constexpr int kNP = 4;                       // envelope powers 1 .. degree-1
+constexpr int kHalo = 2 * (kM - 1);          // look-back of the forward (envelope of the oldest tap) = look-ahead of dy in dL/dx
+constexpr int kGmpP = kM * (1 + kNP * kM);   // 495
+constexpr int kThreads = 256;
+constexpr int kGmpMaxChunk = 512;
+constexpr int kGradCols = 48;                // 44 (d,k) columns + the ones column (dL/dw0) padded to three MFMA tiles
+typedef const __attribute__((address_space(4))) float* WPtr;
+// a fresh name for the weight pointer: keeps the scalar loads of one window position together instead of hoisted out of
+// the sample loop (495 live SGPRs would spill)
+__device__ __forceinline__ WPtr gmp_fresh(WPtr w) { asm volatile("" : "+s"(w)); return w; }
+// the same, ordered after the arithmetic that produced `dep` (the scheduler would otherwise collect all fresh names, and
+// with them all loads, at the top of the unrolled block)
+__device__ __forceinline__ WPtr gmp_fresh_after(WPtr w, float (&e)[11]) {
+    asm volatile("" : "+s"(w), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]), "+v"(e[8]),
+                 "+v"(e[9]), "+v"(e[10]));
+    return w;
+}
+
+// flat index (gmp.py:41-44: [u[t+m]] then d-major, i, m) of w[d,k,r] / w0[r] in sample coordinates
+__host__ __device__ constexpr int gmp_w(int d, int k, int r) { return kM + ((d * kM + (kM - 1 - k)) * kM + (kM - 1 - r)); }
+__host__ __device__ constexpr int gmp_w0(int r) { return kM - 1 - r; }
+
+// items = (frame, time chunk); a workgroup works on `NI` items at a time (one "region" of LDS), E entries each
+struct GmpGeom { int TC, nchunk, nitems, NI, E, nregions; };
+
+struct GmpLds {
+    float4* P4; float2* X; float2* DY;
+    __device__ __forceinline__ GmpLds(float* smem, const GmpGeom& g, bool with_dy) {
+        P4 = reinterpret_cast<float4*>(smem);
+        X = reinterpret_cast<float2*>(P4 + (size_t)g.NI * g.E);
+        DY = with_dy ? X + (size_t)g.NI * g.E : nullptr;
+    }
+};
+
+template <bool WITH_DY>
+__device__ __forceinline__ void gmp_stage(const SeqArgs& a, const GmpGeom& g, int reg, const GmpLds& s) {
+    const float2* x2 = reinterpret_cast<const float2*>(a.x);
+    const float2* dy2 = reinterpret_cast<const float2*>(a.dy);
+    const int total = g.NI * g.E;
+    for (int e = threadIdx.x; e < total; e += kThreads) {
+        const int it = e / g.E, eo = e - it * g.E;
+        const int item = reg * g.NI + it;
+        const int b = item / g.nchunk, c = item - b * g.nchunk;
+        const int t = c * g.TC + eo - kHalo;
+        const bool in = item < g.nitems && t >= 0 && t < a.T;       // zero history (gmp.py:26-27,33) and nothing after the frame
+        float2 xv = make_float2(0.0f, 0.0f), dv = make_float2(0.0f, 0.0f);
+        if (in) {
+            xv = x2[(size_t)b * a.T + t];
+            if constexpr (WITH_DY) dv = dy2[(size_t)b * a.T + t];
+        }
+        const float am = __builtin_amdgcn_sqrtf(__builtin_fmaf(xv.x, xv.x, xv.y * xv.y));
+        const float a2 = am * am;
+        s.P4[e] = make_float4(am, a2, a2 * am, a2 * a2);
+        s.X[e] = xv;
+        if constexpr (WITH_DY) s.DY[e] = dv;
+    }
+}
+
+struct GmpLane { int e; size_t g; bool ok; };       // LDS entry of the lane's sample, its (b,t) offset in the tensors
+__device__ __forceinline__ GmpLane gmp_locate(const SeqArgs& a, const GmpGeom& g, int reg, int idx) {
+    GmpLane L;
+    const int it = idx / g.TC, off = idx - it * g.TC;
+    const int item = reg * g.NI + it;
+    const int b = item / g.nchunk, c = item - b * g.nchunk;
+    const int t = c * g.TC + off;
+    L.ok = it < g.NI && item < g.nitems && t < a.T;
+    L.e = L.ok ? it * g.E + off + kHalo : kHalo;
+    L.g = L.ok ? (size_t)b * a.T + t : 0;
+    return L;
+}
+
+// NS samples per lane share every scalar weight fetch
+template <int NS>
+__device__ __forceinline__ void gmp_fwd_samples(const SeqArgs& a, const GmpGeom& g, const GmpLds& s, WPtr w0, int reg, int base) {
+    WPtr w = gmp_fresh(w0);
+    GmpLane L[NS];
+    float ec[NS][kM];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        L[u] = gmp_locate(a, g, reg, base + u * kThreads + (int)threadIdx.x);
+#pragma unroll
+        for (int r = 0; r < kM; ++r) ec[u][r] = w[gmp_w0(r)];
+    }
+    // lane t needs Ec[t-r, r] = w0[r] + sum_{d,k} w[d,k,r] P_d[t-r-k]: the 21-sample envelope window sits in registers and the
+    // weights are walked in their native order (d, i, m: contiguous -> wide scalar loads)
+    float4 pw[NS][kHalo + 1];
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int j = 0; j <= kHalo; ++j) pw[u][j] = s.P4[L[u].e - j];
+    // one segment = the 11 weights w[d,k,0..10] (contiguous); the next segment's scalar loads are issued before this one's FMAs
+    float wc[kM], wn[kM];
+#pragma unroll
+    for (int r = 0; r < kM; ++r) wc[r] = w[gmp_w(0, kM - 1, r)];
+    gmp_for<kNP * kM>([&](auto sc) {
+        constexpr int seg = decltype(sc)::value, d = seg / kM, k = kM - 1 - seg % kM;
+        if constexpr (seg + 1 < kNP * kM) {
+            constexpr int dn = (seg + 1) / kM, kn = kM - 1 - (seg + 1) % kM;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) w = gmp_fresh_after(w, ec[u]);
+#pragma unroll
+            for (int r = 0; r < kM; ++r) wn[r] = w[gmp_w(dn, kn, r)];
+        }
+#pragma unroll
+        for (int r = kM - 1; r >= 0; --r)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                const float4 p = pw[u][r + k];
+                ec[u][r] = __builtin_fmaf(wc[r], d == 0 ? p.x : d == 1 ? p.y : d == 2 ? p.z : p.w, ec[u][r]);
+            }
+#pragma unroll
+        for (int r = 0; r < kM; ++r) wc[r] = wn[r];
+    });
+    float2* y2 = reinterpret_cast<float2*>(a.y);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        float yr = 0.0f, yi = 0.0f;
+#pragma unroll
+        for (int r = 0; r < kM; ++r) {
+            const float2 xv = s.X[L[u].e - r];
+            yr = __builtin_fmaf(ec[u][r], xv.x, yr);
+            yi = __builtin_fmaf(ec[u][r], xv.y, yi);
+        }
+        if (L[u].ok) y2[L[u].g] = make_float2(yr, yi);
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void gmp_fwd_kernel(SeqArgs a, GmpGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GmpLds s(smem, g, false);
+    const WPtr w = (WPtr)a.params;
+    const int nsamp = g.NI * g.TC;
+    for (int reg = blockIdx.x; reg < g.nregions; reg += gridDim.x) {
+        __syncthreads();
+        gmp_stage<false>(a, g, reg, s);
+        __syncthreads();
+        int base = 0;
+        for (; base + kThreads < nsamp; base += 2 * kThreads) gmp_fwd_samples<2>(a, g, s, w, reg, base);
+        if (base < nsamp) gmp_fwd_samples<1>(a, g, s, w, reg, base);
+    }
+}
+
+// dL/dW: every wave owns three 16 x 16 accumulator tiles [r][(d,k) | ones]; one partials row per workgroup
+__global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GmpLds s(smem, g, true);
+    const float* pf = reinterpret_cast<const float*>(s.P4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    int boff[3];
+    float bmul[3], badd[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        const int c = 16 * ct + n, d = c / kM, k = c - d * kM;
+        const bool env = c < kNP * kM;
+        boff[ct] = env ? d - 4 * k : 0;                  // float offset of P_d[s-k] from the sample's own float4
+        bmul[ct] = env ? 1.0f : 0.0f;
+        badd[ct] = c == kNP * kM ? 1.0f : 0.0f;          // ones column: dL/dw0[r] = sum_s G[s,r]
+    }
+    const float amask = n < kM ? 1.0f : 0.0f;
+    f32x4 acc[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int reg = blockIdx.x; reg < g.nregions; reg += gridDim.x) {
+        __syncthreads();
+        gmp_stage<true>(a, g, reg, s);
+        __syncthreads();
+        for (int it = 0; it < g.NI; ++it) {
+            const int item = reg * g.NI + it;
+            if (item >= g.nitems) break;
+            const int c = item % g.nchunk;
+            const int len = min(g.TC, a.T - c * g.TC);
+            for (int grp = wave; 4 * grp < len; grp += kThreads / 64) {
+                const int off = 4 * grp + q;
+                const bool ok = off < len;
+                const int e = it * g.E + kHalo + (ok ? off : 0);
+                const float2 xv = s.X[e], dv = s.DY[e + n];
+                const float gv = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y) * (ok ? amask : 0.0f);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) {
+                    const float bv = __builtin_fmaf(pf[4 * e + boff[ct]], bmul[ct], badd[ct]);
+                    acc[ct] = mfma4(gv, bv, acc[ct]);
+                }
+            }
+        }
+    }
+    // acc[ct][v] of lane (n, q) = D[r = 4q + v][col = 16 ct + n]
+    __syncthreads();
+    float* red = smem + wave * 16 * kGradCols;
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[(4 * q + v) * kGradCols + 16 * ct + n] = acc[ct][v];
+    __syncthreads();
+    float* prow = a.partials + (size_t)blockIdx.x * (kGmpP + kLossCols);
+    for (int i = threadIdx.x; i < kGmpP + kLossCols; i += kThreads) {
+        float v = 0.0f;
+        if (i < kGmpP) {
+            int r, c;
+            if (i < kM) { r = kM - 1 - i; c = kNP * kM; }
+            else {
+                const int f = i - kM, d = f / (kM * kM), ii = (f / kM) % kM, m = f % kM;
+                r = kM - 1 - m; c = d * kM + (kM - 1 - ii);
+            }
+            const float* p = smem + r * kGradCols + c;
+            v = (p[0] + p[16 * kGradCols]) + (p[2 * 16 * kGradCols] + p[3 * 16 * kGradCols]);
+        }
+        prow[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void gmp_dx_kernel(SeqArgs a, GmpGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GmpLds s(smem, g, true);
+    const WPtr w0 = (WPtr)a.params;
+    const int nsamp = g.NI * g.TC;
+    float2* dx2 = reinterpret_cast<float2*>(a.dx);
+    for (int reg = blockIdx.x; reg < g.nregions; reg += gridDim.x) {
+        __syncthreads();
+        gmp_stage<true>(a, g, reg, s);
+        __syncthreads();
+        for (int base = 0; base < nsamp; base += kThreads) {
+            const GmpLane L = gmp_locate(a, g, reg, base + (int)threadIdx.x);
+            WPtr w = gmp_fresh(w0);
+            float ec[kM];
+#pragma unroll
+            for (int r = 0; r < kM; ++r) ec[r] = w[gmp_w0(r)];
+#pragma unroll
+            for (int k = 0; k < kM; ++k) {
+                const float4 p = s.P4[L.e - k];
+                w = gmp_fresh(w);
+#pragma unroll
+                for (int r = 0; r < kM; ++r) {
+                    ec[r] = __builtin_fmaf(w[gmp_w(0, k, r)], p.x, ec[r]);
+                    ec[r] = __builtin_fmaf(w[gmp_w(1, k, r)], p.y, ec[r]);
+                    ec[r] = __builtin_fmaf(w[gmp_w(2, k, r)], p.z, ec[r]);
+                    ec[r] = __builtin_fmaf(w[gmp_w(3, k, r)], p.w, ec[r]);
+                }
+            }
+            float2 dv[kHalo + 1];
+#pragma unroll
+            for (int j = 0; j <= kHalo; ++j) dv[j] = s.DY[L.e + j];
+            float dr = 0.0f, di = 0.0f;                   // through the complex factor u[t+m] of every term
+#pragma unroll
+            for (int r = 0; r < kM; ++r) {
+                dr = __builtin_fmaf(dv[r].x, ec[r], dr);
+                di = __builtin_fmaf(dv[r].y, ec[r], di);
+            }
+            float dp[kNP] = {0.f, 0.f, 0.f, 0.f};        // dL/dP_d[s]: the terms whose envelope sample is s
+#pragma unroll
+            for (int k = 0; k < kM; ++k) {
+                const float2 xk = s.X[L.e + k];
+                w = gmp_fresh(w);
+#pragma unroll
+                for (int r = 0; r < kM; ++r) {
+                    const float gv = __builtin_fmaf(xk.x, dv[k + r].x, xk.y * dv[k + r].y);
+                    dp[0] = __builtin_fmaf(w[gmp_w(0, k, r)], gv, dp[0]);
+                    dp[1] = __builtin_fmaf(w[gmp_w(1, k, r)], gv, dp[1]);
+                    dp[2] = __builtin_fmaf(w[gmp_w(2, k, r)], gv, dp[2]);
+                    dp[3] = __builtin_fmaf(w[gmp_w(3, k, r)], gv, dp[3]);
+                }
+            }
+            const float4 p0 = s.P4[L.e];
+            const float2 xs = s.X[L.e];
+            float damp = dp[0];
+            damp = __builtin_fmaf(2.0f * p0.x, dp[1], damp);
+            damp = __builtin_fmaf(3.0f * p0.y, dp[2], damp);
+            damp = __builtin_fmaf(4.0f * p0.z, dp[3], damp);
+            const float ia = p0.x > 0.0f ? fast_rcp(p0.x) : 0.0f;      // d|x|/dx = x/|x|, 0 at the origin (torch.abs)
+            damp *= ia;
+            if (L.ok) dx2[L.g] = make_float2(__builtin_fmaf(damp, xs.x, dr), __builtin_fmaf(damp, xs.y, di));
+        }
+    }
+}
+
+// bytes of LDS per entry: float4 envelope powers + float2 x (+ float2 dy)
+GmpGeom gmp_geom(int B, int T, int entry_bytes) {
+    GmpGeom g;
+    g.TC = T <= kGmpMaxChunk ? T : kGmpMaxChunk;
+    g.nchunk = (T + g.TC - 1) / g.TC;
+    g.nitems = B * g.nchunk;
+    g.E = g.TC + 2 * kHalo;
+    const int budget = 60 * 1024;                       // two workgroups per CU
+    int ni_max = budget / (g.E * entry_bytes);
+    const int spread = g.nitems / (2 * device_cus());   // keep at least two regions per CU when the batch allows
+    if (ni_max > spread) ni_max = spread;
+    if (ni_max > g.nitems) ni_max = g.nitems;
+    if (ni_max < 1) ni_max = 1;
+    // lanes map to the NI * TC samples of a region in passes of 256: take the count with the fewest idle lanes
+    int best = ni_max;
+    double best_waste = 1e9;
+    for (int ni = ni_max; ni >= (ni_max + 1) / 2; --ni) {
+        const long n = (long)ni * g.TC, padded = (n + kThreads - 1) / kThreads * kThreads;
+        const double waste = (double)padded / (double)n;
+        if (waste < best_waste - 1e-9) { best_waste = waste; best = ni; }
+    }
+    g.NI = best;
+    g.nregions = (g.nitems + g.NI - 1) / g.NI;
+    return g;
+}
+int gmp_grid(const GmpGeom& g) {
+    const int cap = 2 * device_cus();
+    return g.nregions < cap ? g.nregions : cap;
+}
+size_t gmp_lds(const GmpGeom& g, int entry_bytes) {
+    const size_t stage = (size_t)g.NI * g.E * entry_bytes, red = (size_t)(kThreads / 64) * 16 * kGradCols * sizeof(float);
+    return stage > red ? stage : red;
+}
+bool gmp_ok(const odpd_model_t* m) { return m->hidden == kM; }
+
+}  // namespace
+
+int gmp_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (!gmp_ok(m)) return ODPD_EUNSUPPORTED;
+    const GmpGeom g = gmp_geom(a.B, a.T, 24);
+    hipLaunchKernelGGL(gmp_fwd_kernel, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 24), st, a, g);
+    return (int)hipGetLastError();
+}
+int gmp_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (!gmp_ok(m)) return ODPD_EUNSUPPORTED;
+    if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
+    const GmpGeom g = gmp_geom(a.B, a.T, 32);
+    if (a.partials != nullptr) {
+        hipLaunchKernelGGL(gmp_wgrad_kernel, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 32), st, a, g);
+        if (int e = (int)hipGetLastError()) return e;
+    }
+    if (a.dx != nullptr) hipLaunchKernelGGL(gmp_dx_kernel, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 32), st, a, g);
+    return (int)hipGetLastError();
+}
+int gmp_rows(const odpd_model_t* m, int B, int T) {
+    if (!gmp_ok(m)) return ODPD_EUNSUPPORTED;
+    return gmp_grid(gmp_geom(B, T, 32));
+}
+
+}  // namespace odpd

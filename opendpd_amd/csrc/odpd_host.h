@@ -204,6 +204,10 @@ int64_t janet_s16_ckpt_floats(const odpd_model_t* m, int B, int T);
 int tcnn_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_rows(const odpd_model_t* m, int B, int T);
+// gmp.hip (hidden = memory_length 11, degree 5)
+int gmp_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gmp_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gmp_rows(const odpd_model_t* m, int B, int T);
 int qgru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_rows(const odpd_model_t* m, int B);

@@ -70,8 +70,8 @@ def test_cascade_fused_steps_follow_reference(name, dpd_bb, pa_bb):
 
 
 @pytest.mark.parametrize("pa_bb,pa_h", [("lstm", 14), ("vdlstm", 13), ("pgjanet", 11), ("tcnn", 35), ("dgru", 23), ("qgru_amp1", 10),
-                                         ("deltagru", 15), ("deltagru_tcnskip", 12)])
-@pytest.mark.parametrize("dpd_bb,dpd_h", [("dgru", 9), ("deltagru_tcnskip", 15)])
+                                         ("deltagru", 15), ("deltagru_tcnskip", 12), ("gmp", 11)])
+@pytest.mark.parametrize("dpd_bb,dpd_h", [("dgru", 9), ("deltagru_tcnskip", 15), ("gmp", 11)])
 def test_cascade_with_every_pa_backbone_against_oracle(pa_bb, pa_h, dpd_bb, dpd_h):
     """Every float backbone with dL/dx can be the frozen PA of train_dpd: DPD gradient of the cascade step
     == oracle composition (DPD fwd, PA fwd, MSE, PA backward for dL/du only, DPD backward)."""

