@@ -142,11 +142,14 @@ typedef struct odpd_frames {
     int32_t frame_length;
     int32_t stride;
 } odpd_frames_t;
+/* 1 when the model's fused train kernel can address frames inside resident streams (GRU family, GMP), else 0: the two entry
+ * points below return ODPD_EUNSUPPORTED for the others (materialise the batch and call odpd_train_fwd_bwd). */
+int odpd_framed_train_supported(const odpd_model_t* m);
 /* odpd_train_fwd_bwd with the batch given as frames order[first .. first+B) of resident streams (no materialised
  * (B,T,2) tensors).  Same outputs; the caller finishes the step (odpd_reduce_partials, all-reduce, odpd_clip_adamw_step). */
 int odpd_train_fwd_bwd_framed(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int64_t first,
                               int B, int64_t count, const float* params, float* partials, float* workspace);
-/* One training epoch of a single backbone that has a fused kernel (GRU family): for every batch of `batch`
+/* One training epoch of a single backbone with odpd_framed_train_supported: for every batch of `batch`
  * frames of fr->order (last one may be smaller) the step of train_funcs.py:33-44 — fused fwd+loss+bwd reading the
  * frames straight from the streams, reduction, clip + AdamW with step index first_step + i — issued from C++ with
  * no host synchronisation.  losses_out (device, ceil(n_frames/batch) floats) receives the per-batch mean losses

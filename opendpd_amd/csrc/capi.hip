@@ -116,7 +116,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B);
     case FAM_JANET: return fused ? (int64_t)ODPD_EUNSUPPORTED : janet_family_rows(m, B);
     case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
-    case FAM_GMP: return fused ? (int64_t)ODPD_EUNSUPPORTED : gmp_rows(m, B, T);
+    case FAM_GMP: return gmp_rows(m, B, T);
     case FAM_QAT: return fused ? (int64_t)ODPD_EUNSUPPORTED : qgru_family_rows(m, B);
     default: return ODPD_EUNSUPPORTED;
     }
@@ -125,6 +125,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
 extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     if (family_of(m) == FAM_LSTM) return lstm_train_uses_s16(m, B) ? lstm_s16_workspace_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_GMP) return odpd_param_count(m) > 0 ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
     if (gru_uses_s16n(m, B)) return gru_s16n_ckpt_floats(m, B, T);
     return gru_train_uses_s16(m, B, T) ? gru_s16_workspace_floats(m, B, T) : 0;
@@ -188,6 +189,7 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
                                            : gru_family_train((hipStream_t)stream, m, a);
     case FAM_LSTM:
         return lstm_train_uses_s16(m, B) ? lstm_s16_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
+    case FAM_GMP: return gmp_train((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -211,6 +213,18 @@ extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss
     return gru_family_lossdx((hipStream_t)stream, m, a);
 }
 
+namespace {
+// backbones whose fused train kernel addresses frames inside resident streams (SeqArgs::frame_idx)
+inline bool framed_train_ok(const odpd_model_t* m) { return family_of(m) == FAM_GRU || family_of(m) == FAM_GMP; }
+inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (family_of(m) == FAM_GMP) return gmp_train(st, m, a);
+    const bool s16n = gru_uses_s16n(m, a.B), s16 = !s16n && gru_train_uses_s16(m, a.B, a.T);
+    if ((s16 || s16n) && !a.ckpt) return ODPD_EINVAL;
+    return s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));
+}
+}  // namespace
+extern "C" int odpd_framed_train_supported(const odpd_model_t* m) { return model_ok(m) && framed_train_ok(m) ? 1 : 0; }
+
 // odpd_train_fwd_bwd on frames addressed inside resident streams (no materialised (B,T,2) tensors): batch = the B frames
 // fr->order[first .. first+B).  The caller finishes the step as usual (reduce, all-reduce when sharded, clip + AdamW).
 extern "C" int odpd_train_fwd_bwd_framed(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr,
@@ -219,16 +233,13 @@ extern "C" int odpd_train_fwd_bwd_framed(void* stream, const odpd_model_t* m, in
     if (!model_ok(m) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->frame_length <= 0 || fr->stride <= 0 ||
         first < 0 || B <= 0 || first + B > fr->n_frames || count <= 0 || !params || !partials)
         return ODPD_EINVAL;
-    if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    if (!framed_train_ok(m)) return ODPD_EUNSUPPORTED;
     const int T = fr->frame_length;
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = fr->x_stream; a.target = fr->y_stream; a.partials = partials; a.ckpt = workspace;
     a.frame_idx = (const long long*)(fr->order + first); a.frame_stride = fr->stride;
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
-    const bool s16n = gru_uses_s16n(m, B), s16 = !s16n && gru_train_uses_s16(m, B, T);
-    if ((s16 || s16n) && !workspace) return ODPD_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    return s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));
+    return framed_train_launch((hipStream_t)stream, m, a);
 }
 
 // Native epoch loop (replaces the Python `for batch in loader` of net_train, train_funcs.py:28-48, for a single
@@ -242,7 +253,7 @@ extern "C" int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_ki
     if (!model_ok(m) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
         fr->stride <= 0 || batch <= 0 || !params || !grad || !exp_avg || !exp_avg_sq || !partials || !losses_out || first_step <= 0)
         return ODPD_EINVAL;
-    if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    if (!framed_train_ok(m)) return ODPD_EUNSUPPORTED;
     const int T = fr->frame_length;
     const int64_t P = odpd_param_count(m);
     hipStream_t st = (hipStream_t)stream;
@@ -256,9 +267,7 @@ extern "C" int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_ki
         a.frame_idx = (const long long*)(fr->order + f0); a.frame_stride = fr->stride;
         const int64_t count = (int64_t)B * T * 2;
         a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
-        const bool s16n = gru_uses_s16n(m, B), s16 = !s16n && gru_train_uses_s16(m, B, T);
-        if ((s16 || s16n) && !workspace) return ODPD_EINVAL;
-        int rc = s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));
+        int rc = framed_train_launch(st, m, a);
         if (rc) return rc;
         rc = odpd_reduce_partials(stream, rows, P, partials, grad, 0);
         if (rc) return rc;

@@ -18,6 +18,7 @@
 #include <utility>
 
 #include "odpd_host.h"
+#include "odpd_s16.h"
 
 namespace odpd {
 namespace {
@@ -62,38 +63,59 @@ struct GmpLds {
     }
 };
 
-template <bool WITH_DY>
+// SRC 0: x;  1: x and dy;  2: x and target of the fused train step (frames possibly addressed inside resident streams,
+// SeqArgs::frame_idx) — the second stream lands in the DY array
+template <int SRC>
 __device__ __forceinline__ void gmp_stage(const SeqArgs& a, const GmpGeom& g, int reg, const GmpLds& s) {
     const float2* x2 = reinterpret_cast<const float2*>(a.x);
-    const float2* dy2 = reinterpret_cast<const float2*>(a.dy);
+    const float2* d2 = reinterpret_cast<const float2*>(SRC == 2 ? a.target : a.dy);
     const int total = g.NI * g.E;
-    for (int e = threadIdx.x; e < total; e += kThreads) {
-        const int it = e / g.E, eo = e - it * g.E;
-        const int item = reg * g.NI + it;
-        const int b = item / g.nchunk, c = item - b * g.nchunk;
-        const int t = c * g.TC + eo - kHalo;
-        const bool in = item < g.nitems && t >= 0 && t < a.T;       // zero history (gmp.py:26-27,33) and nothing after the frame
-        float2 xv = make_float2(0.0f, 0.0f), dv = make_float2(0.0f, 0.0f);
-        if (in) {
-            xv = x2[(size_t)b * a.T + t];
-            if constexpr (WITH_DY) dv = dy2[(size_t)b * a.T + t];
+    constexpr int U = 4;                                   // entries per thread in flight: the global loads of a batch go first
+    for (int e0 = threadIdx.x; e0 < total; e0 += U * kThreads) {
+        float2 xv[U], dv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * kThreads;
+            const int it = e / g.E, eo = e - it * g.E;
+            const int item = reg * g.NI + it;
+            int b = item, c = 0;
+            if (g.nchunk > 1) { b = item / g.nchunk; c = item - b * g.nchunk; }
+            const int t = c * g.TC + eo - kHalo;
+            // zero history (gmp.py:26-27,33) and nothing after the frame
+            const bool in = e < total && item < g.nitems && t >= 0 && t < a.T;
+            xv[u] = make_float2(0.0f, 0.0f); dv[u] = make_float2(0.0f, 0.0f);
+            if (in) {
+                const size_t at = (SRC == 2 && a.frame_idx != nullptr) ? (size_t)a.frame_idx[b] * a.frame_stride + t : (size_t)b * a.T + t;
+                xv[u] = x2[at];
+                if constexpr (SRC != 0) dv[u] = d2[at];
+            }
         }
-        const float am = __builtin_amdgcn_sqrtf(__builtin_fmaf(xv.x, xv.x, xv.y * xv.y));
-        const float a2 = am * am;
-        s.P4[e] = make_float4(am, a2, a2 * am, a2 * a2);
-        s.X[e] = xv;
-        if constexpr (WITH_DY) s.DY[e] = dv;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * kThreads;
+            if (e < total) {
+                const float am = __builtin_amdgcn_sqrtf(__builtin_fmaf(xv[u].x, xv[u].x, xv[u].y * xv[u].y));
+                const float a2 = am * am;
+                s.P4[e] = make_float4(am, a2, a2 * am, a2 * a2);
+                s.X[e] = xv[u];
+                if constexpr (SRC != 0) s.DY[e] = dv[u];
+            }
+        }
     }
 }
 
-struct GmpLane { int e; size_t g; bool ok; };       // LDS entry of the lane's sample, its (b,t) offset in the tensors
-__device__ __forceinline__ GmpLane gmp_locate(const SeqArgs& a, const GmpGeom& g, int reg, int idx) {
+// LDS entry of the lane's sample, its (b,t) offset in the tensors; `own`: inside the item's chunk (the fused step also walks
+// the kM-1 samples after a chunk: their dy is needed by the chunk's weight gradient)
+struct GmpLane { int e; size_t g; bool ok, own; };
+__device__ __forceinline__ GmpLane gmp_locate(const SeqArgs& a, const GmpGeom& g, int reg, int idx, int span) {
     GmpLane L;
-    const int it = idx / g.TC, off = idx - it * g.TC;
+    const int it = idx / span, off = idx - it * span;
     const int item = reg * g.NI + it;
-    const int b = item / g.nchunk, c = item - b * g.nchunk;
+    int b = item, c = 0;
+    if (g.nchunk > 1) { b = item / g.nchunk; c = item - b * g.nchunk; }
     const int t = c * g.TC + off;
     L.ok = it < g.NI && item < g.nitems && t < a.T;
+    L.own = off < g.TC;
     L.e = L.ok ? it * g.E + off + kHalo : kHalo;
     L.g = L.ok ? (size_t)b * a.T + t : 0;
     return L;
@@ -101,16 +123,13 @@ __device__ __forceinline__ GmpLane gmp_locate(const SeqArgs& a, const GmpGeom& g
 
 // NS samples per lane share every scalar weight fetch
 template <int NS>
-__device__ __forceinline__ void gmp_fwd_samples(const SeqArgs& a, const GmpGeom& g, const GmpLds& s, WPtr w0, int reg, int base) {
+__device__ __forceinline__ void gmp_outputs(const GmpLds& s, WPtr w0, const GmpLane (&L)[NS], float (&yr)[NS], float (&yi)[NS]) {
     WPtr w = gmp_fresh(w0);
-    GmpLane L[NS];
     float ec[NS][kM];
 #pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        L[u] = gmp_locate(a, g, reg, base + u * kThreads + (int)threadIdx.x);
+    for (int u = 0; u < NS; ++u)
 #pragma unroll
         for (int r = 0; r < kM; ++r) ec[u][r] = w[gmp_w0(r)];
-    }
     // lane t needs Ec[t-r, r] = w0[r] + sum_{d,k} w[d,k,r] P_d[t-r-k]: the 21-sample envelope window sits in registers and the
     // weights are walked in their native order (d, i, m: contiguous -> wide scalar loads)
     float4 pw[NS][kHalo + 1];
@@ -118,18 +137,19 @@ __device__ __forceinline__ void gmp_fwd_samples(const SeqArgs& a, const GmpGeom&
     for (int u = 0; u < NS; ++u)
 #pragma unroll
         for (int j = 0; j <= kHalo; ++j) pw[u][j] = s.P4[L[u].e - j];
-    // one segment = the 11 weights w[d,k,0..10] (contiguous); the next segment's scalar loads are issued before this one's FMAs
-    float wc[kM], wn[kM];
+    // one segment = the 11 weights w[d,k,0..10] (contiguous); the scalar loads run two segments ahead of the FMAs
+    constexpr int kSegs = kNP * kM;
+    float wc[kM], wn[kM], wnn[kM];
 #pragma unroll
-    for (int r = 0; r < kM; ++r) wc[r] = w[gmp_w(0, kM - 1, r)];
-    gmp_for<kNP * kM>([&](auto sc) {
+    for (int r = 0; r < kM; ++r) { wc[r] = w[gmp_w(0, kM - 1, r)]; wn[r] = w[gmp_w(0, kM - 2, r)]; }
+    gmp_for<kSegs>([&](auto sc) {
         constexpr int seg = decltype(sc)::value, d = seg / kM, k = kM - 1 - seg % kM;
-        if constexpr (seg + 1 < kNP * kM) {
-            constexpr int dn = (seg + 1) / kM, kn = kM - 1 - (seg + 1) % kM;
+        if constexpr (seg + 2 < kSegs) {
+            constexpr int dn = (seg + 2) / kM, kn = kM - 1 - (seg + 2) % kM;
 #pragma unroll
             for (int u = 0; u < NS; ++u) w = gmp_fresh_after(w, ec[u]);
 #pragma unroll
-            for (int r = 0; r < kM; ++r) wn[r] = w[gmp_w(dn, kn, r)];
+            for (int r = 0; r < kM; ++r) wnn[r] = w[gmp_w(dn, kn, r)];
         }
 #pragma unroll
         for (int r = kM - 1; r >= 0; --r)
@@ -139,19 +159,47 @@ __device__ __forceinline__ void gmp_fwd_samples(const SeqArgs& a, const GmpGeom&
                 ec[u][r] = __builtin_fmaf(wc[r], d == 0 ? p.x : d == 1 ? p.y : d == 2 ? p.z : p.w, ec[u][r]);
             }
 #pragma unroll
-        for (int r = 0; r < kM; ++r) wc[r] = wn[r];
+        for (int r = 0; r < kM; ++r) { wc[r] = wn[r]; wn[r] = wnn[r]; }
     });
-    float2* y2 = reinterpret_cast<float2*>(a.y);
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-        float yr = 0.0f, yi = 0.0f;
+        yr[u] = 0.0f; yi[u] = 0.0f;
 #pragma unroll
         for (int r = 0; r < kM; ++r) {
             const float2 xv = s.X[L[u].e - r];
-            yr = __builtin_fmaf(ec[u][r], xv.x, yr);
-            yi = __builtin_fmaf(ec[u][r], xv.y, yi);
+            yr[u] = __builtin_fmaf(ec[u][r], xv.x, yr[u]);
+            yi[u] = __builtin_fmaf(ec[u][r], xv.y, yi[u]);
         }
-        if (L[u].ok) y2[L[u].g] = make_float2(yr, yi);
+    }
+}
+template <int NS>
+__device__ __forceinline__ void gmp_fwd_samples(const SeqArgs& a, const GmpGeom& g, const GmpLds& s, WPtr w, int reg, int base) {
+    GmpLane L[NS];
+    float yr[NS], yi[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) L[u] = gmp_locate(a, g, reg, base + u * kThreads + (int)threadIdx.x, g.TC);
+    gmp_outputs<NS>(s, w, L, yr, yi);
+    float2* y2 = reinterpret_cast<float2*>(a.y);
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+        if (L[u].ok) y2[L[u].g] = make_float2(yr[u], yi[u]);
+}
+// fused step: dy = dLoss/dy replaces the staged target in LDS, the loss of the chunk's own samples accumulates per lane
+template <int NS>
+__device__ __forceinline__ void gmp_loss_samples(const SeqArgs& a, const GmpGeom& g, const GmpLds& s, WPtr w, int reg, int base, int span,
+                                                 float& loss_acc) {
+    GmpLane L[NS];
+    float yr[NS], yi[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) L[u] = gmp_locate(a, g, reg, base + u * kThreads + (int)threadIdx.x, span);
+    gmp_outputs<NS>(s, w, L, yr, yi);
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+        const float2 tv = s.DY[L[u].e];
+        const S16Loss lc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, L[u].ok ? a.inv_count : 0.0f, L[u].ok && L[u].own);
+        float d0, d1;
+        s16_loss(lc, yr[u] - tv.x, yi[u] - tv.y, d0, d1, loss_acc);
+        if (L[u].ok) s.DY[L[u].e] = make_float2(d0, d1);
     }
 }
 
@@ -162,7 +210,7 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_fwd_kernel(SeqArgs a, GmpGeom
     const int nsamp = g.NI * g.TC;
     for (int reg = blockIdx.x; reg < g.nregions; reg += gridDim.x) {
         __syncthreads();
-        gmp_stage<false>(a, g, reg, s);
+        gmp_stage<0>(a, g, reg, s);
         __syncthreads();
         int base = 0;
         for (; base + kThreads < nsamp; base += 2 * kThreads) gmp_fwd_samples<2>(a, g, s, w, reg, base);
@@ -170,10 +218,16 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_fwd_kernel(SeqArgs a, GmpGeom
     }
 }
 
-// dL/dW: every wave owns three 16 x 16 accumulator tiles [r][(d,k) | ones]; one partials row per workgroup
+// dL/dW: every wave owns three 16 x 16 accumulator tiles [r][(d,k) | ones]; one partials row per workgroup.
+// FUSED: the whole train step of a region (x, target -> forward -> loss and dy in LDS -> weight gradient): x and target are
+// read once, nothing else touches HBM but the partials row (loss partial in column P).
+template <bool FUSED>
 __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GmpLds s(smem, g, true);
+    const WPtr w = (WPtr)a.params;
+    const int span = g.TC + (g.nchunk > 1 ? kM - 1 : 0), nsamp = g.NI * span;
+    float loss_acc = 0.0f;
     const float* pf = reinterpret_cast<const float*>(s.P4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     int boff[3];
@@ -192,24 +246,36 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
     for (int ct = 0; ct < 3; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int reg = blockIdx.x; reg < g.nregions; reg += gridDim.x) {
         __syncthreads();
-        gmp_stage<true>(a, g, reg, s);
+        gmp_stage<FUSED ? 2 : 1>(a, g, reg, s);
         __syncthreads();
+        if constexpr (FUSED) {
+            int base = 0;
+            for (; base + kThreads < nsamp; base += 2 * kThreads) gmp_loss_samples<2>(a, g, s, w, reg, base, span, loss_acc);
+            if (base < nsamp) gmp_loss_samples<1>(a, g, s, w, reg, base, span, loss_acc);
+            __syncthreads();
+        }
         for (int it = 0; it < g.NI; ++it) {
             const int item = reg * g.NI + it;
             if (item >= g.nitems) break;
             const int c = item % g.nchunk;
             const int len = min(g.TC, a.T - c * g.TC);
-            for (int grp = wave; 4 * grp < len; grp += kThreads / 64) {
-                const int off = 4 * grp + q;
-                const bool ok = off < len;
-                const int e = it * g.E + kHalo + (ok ? off : 0);
-                const float2 xv = s.X[e], dv = s.DY[e + n];
-                const float gv = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y) * (ok ? amask : 0.0f);
+            constexpr int GU = 4, kWaves = kThreads / 64;      // groups of 4 samples in flight per wave (their LDS reads go first)
+            for (int grp0 = wave; 4 * grp0 < len; grp0 += GU * kWaves) {
+                float gv[GU], bv[GU][3];
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) {
-                    const float bv = __builtin_fmaf(pf[4 * e + boff[ct]], bmul[ct], badd[ct]);
-                    acc[ct] = mfma4(gv, bv, acc[ct]);
+                for (int u = 0; u < GU; ++u) {
+                    const int off = 4 * (grp0 + u * kWaves) + q;
+                    const bool ok = off < len;
+                    const int e = it * g.E + kHalo + (ok ? off : 0);
+                    const float2 xv = s.X[e], dv = s.DY[e + n];
+                    gv[u] = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y) * (ok ? amask : 0.0f);
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) bv[u][ct] = __builtin_fmaf(pf[4 * e + boff[ct]], bmul[ct], badd[ct]);
                 }
+#pragma unroll
+                for (int u = 0; u < GU; ++u)
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma4(gv[u], bv[u][ct], acc[ct]);
             }
         }
     }
@@ -220,6 +286,12 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
         for (int v = 0; v < 4; ++v) red[(4 * q + v) * kGradCols + 16 * ct + n] = acc[ct][v];
+    float* lred = smem + (kThreads / 64) * 16 * kGradCols;
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) loss_acc += __shfl_xor(loss_acc, m);
+        if (lane == 0) lred[wave] = loss_acc;
+    }
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * (kGmpP + kLossCols);
     for (int i = threadIdx.x; i < kGmpP + kLossCols; i += kThreads) {
@@ -233,6 +305,8 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
             }
             const float* p = smem + r * kGradCols + c;
             v = (p[0] + p[16 * kGradCols]) + (p[2 * 16 * kGradCols] + p[3 * 16 * kGradCols]);
+        } else if (FUSED && i == kGmpP) {
+            v = (lred[0] + lred[1]) + (lred[2] + lred[3]);
         }
         prow[i] = v;
     }
@@ -246,10 +320,10 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_dx_kernel(SeqArgs a, GmpGeom 
     float2* dx2 = reinterpret_cast<float2*>(a.dx);
     for (int reg = blockIdx.x; reg < g.nregions; reg += gridDim.x) {
         __syncthreads();
-        gmp_stage<true>(a, g, reg, s);
+        gmp_stage<1>(a, g, reg, s);
         __syncthreads();
         for (int base = 0; base < nsamp; base += kThreads) {
-            const GmpLane L = gmp_locate(a, g, reg, base + (int)threadIdx.x);
+            const GmpLane L = gmp_locate(a, g, reg, base + (int)threadIdx.x, g.TC);
             WPtr w = gmp_fresh(w0);
             float ec[kM];
 #pragma unroll
@@ -332,7 +406,7 @@ int gmp_grid(const GmpGeom& g) {
     return g.nregions < cap ? g.nregions : cap;
 }
 size_t gmp_lds(const GmpGeom& g, int entry_bytes) {
-    const size_t stage = (size_t)g.NI * g.E * entry_bytes, red = (size_t)(kThreads / 64) * 16 * kGradCols * sizeof(float);
+    const size_t stage = (size_t)g.NI * g.E * entry_bytes, red = (size_t)((kThreads / 64) * 16 * kGradCols + 4) * sizeof(float);
     return stage > red ? stage : red;
 }
 bool gmp_ok(const odpd_model_t* m) { return m->hidden == kM; }
@@ -350,10 +424,17 @@ int gmp_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
     const GmpGeom g = gmp_geom(a.B, a.T, 32);
     if (a.partials != nullptr) {
-        hipLaunchKernelGGL(gmp_wgrad_kernel, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 32), st, a, g);
+        hipLaunchKernelGGL(gmp_wgrad_kernel<false>, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 32), st, a, g);
         if (int e = (int)hipGetLastError()) return e;
     }
     if (a.dx != nullptr) hipLaunchKernelGGL(gmp_dx_kernel, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 32), st, a, g);
+    return (int)hipGetLastError();
+}
+// fused train step: x, target (optionally framed) -> partials rows [dL/dW | loss partial]
+int gmp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (!gmp_ok(m)) return ODPD_EUNSUPPORTED;
+    const GmpGeom g = gmp_geom(a.B, a.T, 32);
+    hipLaunchKernelGGL(gmp_wgrad_kernel<true>, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 32), st, a, g);
     return (int)hipGetLastError();
 }
 int gmp_rows(const odpd_model_t* m, int B, int T) {

@@ -207,7 +207,8 @@ int tcnn_rows(const odpd_model_t* m, int B, int T);
 // gmp.hip (hidden = memory_length 11, degree 5)
 int gmp_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gmp_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
-int gmp_rows(const odpd_model_t* m, int B, int T);
+int gmp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);   // fused fwd + loss + dL/dW (frames addressable in streams)
+int gmp_rows(const odpd_model_t* m, int B, int T);                      // same grid for the split backward and the fused step
 int qgru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_rows(const odpd_model_t* m, int B);

@@ -193,7 +193,12 @@ class FusedAdamW:
         """True when odpd_train_epoch can drive a whole epoch: single fused backbone, one process, resident streams."""
         return (self.pa is None and self.world_size() == 1 and getattr(self.backbone, "frozen_mask", None) is None
                 and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size"))
-                and loader.x.is_cuda and self.has_fused(min(loader.batch_size, loader.n), loader.frame_length))
+                and loader.x.is_cuda and self.has_fused(min(loader.batch_size, loader.n), loader.frame_length)
+                and self.reads_frames())
+
+    def reads_frames(self):
+        """True when the backbone's fused kernel addresses frames inside resident streams (odpd_framed_train_supported)."""
+        return bool(_lib.load().odpd_framed_train_supported(C.byref(self.backbone.desc)))
 
     def train_epoch(self, loader, loss_kind, max_norm):
         """One epoch through the native loop (odpd_train_epoch): returns the per-batch mean losses (device tensor)."""
@@ -258,9 +263,9 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     n = B * T * 2
     count = int(global_count or n)
     framed = isinstance(x, FrameBatch)
+    if framed and (opt.pa is not None or not opt.has_fused(B, T) or not opt.reads_frames()):
+        raise RuntimeError("FrameBatch input needs a single backbone whose fused kernel reads frames from streams (GRU family, gmp)")
     if opt.pa is not None or not opt.has_fused(B, T):
-        if framed:
-            raise RuntimeError("FrameBatch input needs a single backbone with a fused kernel (GRU family)")
         return _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count)
     part = opt.partials(B, T, x.device)
     ws = opt.train_workspace(B, T, x.device)

@@ -109,3 +109,34 @@ def test_other_configurations_are_refused_loudly():
     from opendpd_amd import backbones as B
     with pytest.raises(NotImplementedError):
         B.GMP(memory_length=7)
+
+
+@pytest.mark.parametrize("B,T", [(5, 37), (256, 200), (3, 513), (2, 1300), (700, 50), (1, 1)])
+def test_fused_step_equals_split_kernels(B, T):
+    """single-launch train step (x, target -> forward -> loss and dy in LDS -> MFMA weight gradient; L2 and L1) == autograd through
+    the split kernels (oracle-checked above); records longer than one chunk walk the 10 samples after each chunk twice"""
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    torch.manual_seed(1)
+    net = _net()
+    with torch.no_grad():
+        net.backbone.Weight.mul_(4.0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    t = torch.randn(B, T, 2, device="cuda", generator=g) * 0.3
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.has_fused(B, T) and opt.train_workspace(B, T, x.device) is None
+    for kind, fn in (("l2", torch.nn.functional.mse_loss), ("l1", torch.nn.functional.l1_loss)):
+        net.backbone.Weight.grad = None
+        loss = fn(net(x), t)
+        loss.backward()
+        gref = net.backbone.Weight.grad.reshape(-1).cpu().numpy()
+        lf = fused_train_step(opt, x, t, kind, 0.0)
+        assert abs(lf.item() - loss.item()) < 1e-5 * max(1.0, loss.item()), kind
+        assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 2e-5, kind
+
+
+def test_native_epoch_loop_reads_frames_in_place():
+    from tests import test_e2e_gpu as e2e
+    e2e.test_native_epoch_loop_equals_per_step_loop("gmp", 11, 50, 64)
+    e2e.test_native_epoch_loop_equals_per_step_loop("gmp", 11, 200, 256)

@@ -46,11 +46,11 @@ def at_start(t):
 
 
 for it in range(cases):
-    H = int(rng.randint(1, (17 if bb == "pgjanet" else 41 if bb == "tcnn" else 33)))
+    H = 11 if bb == "gmp" else int(rng.randint(1, (17 if bb == "pgjanet" else 41 if bb == "tcnn" else 33)))
     force = bool(rng.randint(2))
     lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
     B = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
-    T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 257, 300]))
+    T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 257, 300] + ([513, 700, 1500] if bb == "gmp" else [])))
     if B * T > 6000:
         T = max(1, 6000 // B)
     if bb == "vdlstm" and T < 3:

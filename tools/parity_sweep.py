@@ -16,7 +16,7 @@ lib = _lib.load()
 o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
-         "tcnn": list(range(1, 40)) + [48, 63, 64]}
+         "tcnn": list(range(1, 40)) + [48, 63, 64], "gmp": [11] * 12}
 rng = np.random.RandomState(0)
 bad, worst = [], {}
 for bb, sizes in SIZES.items():
