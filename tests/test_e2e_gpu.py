@@ -119,6 +119,32 @@ def test_native_epoch_loop_equals_per_step_loop(bb, H, F, B):
     assert abs(outs[0][1] - outs[1][1]) < 1e-6 * max(1.0, abs(outs[1][1]))
 
 
+def test_gmp_train_pa_matches_reference_log(workdir):
+    """the polynomial baseline (gmp.py) through train_pa on the HIP kernels — fused single-launch step inside the native epoch loop,
+    long-segment evaluation (T = 2 560: five 512-sample chunks with halos) — against the rows the REFERENCE logged for the same
+    command (tests/golden/ref_runs_gmp.json, oracle/gen_run_anchor_gmp.py): same seed, same initial weights and shuffle order"""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_gmp.json")))
+    res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone="gmp", PA_hidden_size=11, frame_length=50, batch_size=64, lr=5e-3,
+                      n_epochs=2, seed=0, accelerator="cuda")
+    assert res["status"] == "completed"
+    assert os.path.normpath(res["model_path"]) == os.path.normpath(ref["model"])
+    hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
+    rh = ref["train_pa_hist"]
+    assert list(hist.columns) == list(rh.keys())
+    for col in ("N_PARAM", "BATCH_SIZE", "FRAME_LENGTH", "HIDDEN_SIZE", "N_EPOCH", "BACKBONE"):
+        assert list(hist[col]) == rh[col]
+    for ep in range(2):
+        assert abs(hist["TRAIN_LOSS"][ep] - rh["TRAIN_LOSS"][ep]) < 1e-3 * rh["TRAIN_LOSS"][ep]
+        for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_EVM", "TEST_ACLR_AVG"):
+            assert abs(hist[col][ep] - rh[col][ep]) < 0.05, (col, ep, hist[col][ep], rh[col][ep])   # dB
+    sd = torch.load(res["model_path"], map_location="cpu")
+    m = dict(np.load(os.path.join(GOLDEN, "ref_runs_gmp_model.npz")))
+    assert list(sd.keys()) == list(m.keys()) == ["backbone.Weight"]
+    w, wr = sd["backbone.Weight"].numpy(), m["backbone.Weight"]
+    assert np.abs(w - wr).max() < 2e-3 * np.abs(wr).max()
+
+
 @pytest.mark.parametrize("bb,H", [("rvtdcnn", 6), ("deltajanet", 10)])
 def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H):
     """SURVEY §8 f4 names (backbones/extras.py) go through the same Project flow on the GPU: ATen forward/backward,
