@@ -230,17 +230,15 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
     float loss_acc = 0.0f;
     const float* pf = reinterpret_cast<const float*>(s.P4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    // B operand of column c = 16 ct + n: P_d[s-k] for c = 11 d + k < 44, the constant 1 for c = 44 (dL/dw0[r] = sum_s G[s,r]);
+    // columns 45..47 and rows r = 11..15 of the tiles are never read back, so they may hold anything finite
     int boff[3];
-    float bmul[3], badd[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
         const int c = 16 * ct + n, d = c / kM, k = c - d * kM;
-        const bool env = c < kNP * kM;
-        boff[ct] = env ? d - 4 * k : 0;                  // float offset of P_d[s-k] from the sample's own float4
-        bmul[ct] = env ? 1.0f : 0.0f;
-        badd[ct] = c == kNP * kM ? 1.0f : 0.0f;          // ones column: dL/dw0[r] = sum_s G[s,r]
+        boff[ct] = c < kNP * kM ? d - 4 * k : 0;        // float offset of P_d[s-k] from the sample's own float4
     }
-    const float amask = n < kM ? 1.0f : 0.0f;
+    const float bmul2 = 32 + n < kNP * kM ? 1.0f : 0.0f, badd2 = 32 + n == kNP * kM ? 1.0f : 0.0f;
     f32x4 acc[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -259,23 +257,40 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
             if (item >= g.nitems) break;
             const int c = item % g.nchunk;
             const int len = min(g.TC, a.T - c * g.TC);
-            constexpr int GU = 4, kWaves = kThreads / 64;      // groups of 4 samples in flight per wave (their LDS reads go first)
-            for (int grp0 = wave; 4 * grp0 < len; grp0 += GU * kWaves) {
+            // a group = 4 consecutive samples (K of the MFMA); wave w takes groups w, w + 4, ...; four groups in flight so that
+            // their LDS reads (immediate offsets from per-iteration bases) go first; no masks until the ragged tail
+            constexpr int GU = 4, kWaves = kThreads / 64;
+            const int eb = it * g.E + kHalo + q, nfull = len >> 2;
+            const float2* xp = s.X + eb;
+            const float2* dp = s.DY + eb + n;
+            const float* p0 = pf + 4 * eb + boff[0];
+            const float* p1 = pf + 4 * eb + boff[1];
+            const float* p2 = pf + 4 * eb + boff[2];
+            int grp = wave;
+            for (; grp + (GU - 1) * kWaves < nfull; grp += GU * kWaves) {
                 float gv[GU], bv[GU][3];
 #pragma unroll
                 for (int u = 0; u < GU; ++u) {
-                    const int off = 4 * (grp0 + u * kWaves) + q;
-                    const bool ok = off < len;
-                    const int e = it * g.E + kHalo + (ok ? off : 0);
-                    const float2 xv = s.X[e], dv = s.DY[e + n];
-                    gv[u] = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y) * (ok ? amask : 0.0f);
-#pragma unroll
-                    for (int ct = 0; ct < 3; ++ct) bv[u][ct] = __builtin_fmaf(pf[4 * e + boff[ct]], bmul[ct], badd[ct]);
+                    const int o = 4 * (grp + u * kWaves);
+                    const float2 xv = xp[o], dv = dp[o];
+                    gv[u] = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y);
+                    bv[u][0] = p0[4 * o]; bv[u][1] = p1[4 * o];
+                    bv[u][2] = __builtin_fmaf(p2[4 * o], bmul2, badd2);
                 }
 #pragma unroll
                 for (int u = 0; u < GU; ++u)
 #pragma unroll
                     for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma4(gv[u], bv[u][ct], acc[ct]);
+            }
+            for (; 4 * grp < len; grp += kWaves) {
+                const int off = 4 * grp + q;
+                const float okf = __builtin_amdgcn_fmed3f((float)(len - off), 0.0f, 1.0f);     // 1 inside the chunk, 0 past its end
+                const int o = min(off, len - 1) - q;
+                const float2 xv = xp[o], dv = dp[o];
+                const float gvt = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y) * okf;
+                acc[0] = mfma4(gvt, p0[4 * o], acc[0]);
+                acc[1] = mfma4(gvt, p1[4 * o], acc[1]);
+                acc[2] = mfma4(gvt, __builtin_fmaf(p2[4 * o], bmul2, badd2), acc[2]);
             }
         }
     }
