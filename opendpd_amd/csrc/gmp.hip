@@ -9,12 +9,15 @@
 // gradient (r = 0..10):
 //     dL/dw[d,k,r] = sum_s G[s,r] P_d[s-k],        G[s,r] = Re(conj(x[s]) dy[s+r])          (dL/dw0[r] = sum_s G[s,r])
 //     dL/dx[s]     = sum_r dy[s+r] Ec[s,r] + (x[s]/|x[s]|) sum_d d |x[s]|^(d-1) sum_{k,r} w[d,k,r] G[s+k,r]
-// Not recurrent: one lane per sample, a workgroup stages whole frames (time chunks of <= 512 samples with a 20-sample halo on
-// both sides for long records) as [|x|, |x|^2, |x|^3, |x|^4] float4 + x (+ dy) in LDS and every lane reads its window from
-// there (ds_read_b128, conflict-free).  The 484 envelope weights are wave-uniform: they are read through the constant address
-// space, i.e. s_load_dwordx16 into SGPRs, and enter v_fmac as the scalar operand — no LDS or VGPR traffic for them.  The
-// weight gradient is an (11 x 45) = G^T [P | 1] contraction over samples: v_mfma_f32_16x16x4_f32, three 16x16 tiles per four
-// samples (exact fp32), operands fetched straight from the LDS arrays.
+// Not recurrent.  A workgroup stages whole frames (time chunks of <= 512 samples with a 20-sample halo on both sides for
+// long records) in LDS: the envelope powers [|x|, |x|^2, |x|^3, |x|^4] as float4 in RESIDUE-MAJOR order (entry e at plane
+// e mod 4, slot e / 4), x (+ dy / target) as float2 in natural order; the next region's global loads are in flight while
+// the current one is computed.  Forward: a lane owns 4 consecutive samples, so its 24-entry envelope window is read once
+// (ds_read_b128 with compile-time plane / slot offsets, conflict-free) and serves 4 x 484 FMAs.  The 484 envelope weights
+// are wave-uniform: they are read through the constant address space in their native (d, i, m) order — s_load_dwordx8/x2/x1
+// per 11-weight row, two rows ahead of their use — and enter v_fmac as the scalar operand: no LDS or VGPR traffic for them.
+// The weight gradient is the (11 x 45) contraction G^T [P | 1] over samples: v_mfma_f32_16x16x4_f32, three 16x16 tiles per
+// four samples (exact fp32), operands fetched straight from the LDS arrays.
 #include <utility>
 
 #include "odpd_host.h"
@@ -35,15 +38,22 @@ constexpr int kGmpP = kM * (1 + kNP * kM);   // 495
 constexpr int kThreads = 256;
 constexpr int kGmpMaxChunk = 512;
 constexpr int kGradCols = 48;                // 44 (d,k) columns + the ones column (dL/dw0) padded to three MFMA tiles
+constexpr int kR = 4;                        // consecutive samples per lane in the forward
+constexpr int kEPT = 8;                      // staged entries per thread at most (a region holds <= kEPT * kThreads entries)
 typedef const __attribute__((address_space(4))) float* WPtr;
-// a fresh name for the weight pointer: keeps the scalar loads of one window position together instead of hoisted out of
-// the sample loop (495 live SGPRs would spill)
+// a fresh name for the weight pointer: keeps the scalar loads of one weight row together instead of hoisted out of the
+// sample loop (495 live SGPRs would spill)
 __device__ __forceinline__ WPtr gmp_fresh(WPtr w) { asm volatile("" : "+s"(w)); return w; }
-// the same, ordered after the arithmetic that produced `dep` (the scheduler would otherwise collect all fresh names, and
-// with them all loads, at the top of the unrolled block)
+// the same, ordered after the arithmetic that produced `e` (the scheduler would otherwise collect all fresh names, and with
+// them all loads, at the top of the unrolled block)
 __device__ __forceinline__ WPtr gmp_fresh_after(WPtr w, float (&e)[11]) {
     asm volatile("" : "+s"(w), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]), "+v"(e[8]),
                  "+v"(e[9]), "+v"(e[10]));
+    return w;
+}
+
+__device__ __forceinline__ WPtr gmp_fresh_after4(WPtr w, float (&e)[4]) {
+    asm volatile("" : "+s"(w), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
     return w;
 }
 
@@ -51,93 +61,117 @@ __device__ __forceinline__ WPtr gmp_fresh_after(WPtr w, float (&e)[11]) {
 __host__ __device__ constexpr int gmp_w(int d, int k, int r) { return kM + ((d * kM + (kM - 1 - k)) * kM + (kM - 1 - r)); }
 __host__ __device__ constexpr int gmp_w0(int r) { return kM - 1 - r; }
 
-// items = (frame, time chunk); a workgroup works on `NI` items at a time (one "region" of LDS), E entries each
-struct GmpGeom { int TC, nchunk, nitems, NI, E, nregions; };
+// items = (frame, time chunk); a workgroup works on `NI` items at a time (one "region" of LDS), E entries each (multiple of 4:
+// every item starts on plane 0); Q = slots per plane, Q mod 16 = 4 so that the four planes start 16 banks apart
+struct GmpGeom { int TC, nchunk, nitems, NI, E, nregions, Q; };
 
 struct GmpLds {
     float4* P4; float2* X; float2* DY;
+    int Q;
     __device__ __forceinline__ GmpLds(float* smem, const GmpGeom& g, bool with_dy) {
         P4 = reinterpret_cast<float4*>(smem);
-        X = reinterpret_cast<float2*>(P4 + (size_t)g.NI * g.E);
+        X = reinterpret_cast<float2*>(P4 + 4 * (size_t)g.Q);
         DY = with_dy ? X + (size_t)g.NI * g.E : nullptr;
+        Q = g.Q;
     }
+    __device__ __forceinline__ int pos(int e) const { return (e & 3) * Q + (e >> 2); }
 };
 
+// ---- staging: global loads of a region (issued early, consumed one region later) and their deposit in LDS ----------------
 // SRC 0: x;  1: x and dy;  2: x and target of the fused train step (frames possibly addressed inside resident streams,
 // SeqArgs::frame_idx) — the second stream lands in the DY array
+struct GmpFetch { float2 x[kEPT], d[kEPT]; };
 template <int SRC>
-__device__ __forceinline__ void gmp_stage(const SeqArgs& a, const GmpGeom& g, int reg, const GmpLds& s) {
+__device__ __forceinline__ void gmp_fetch(const SeqArgs& a, const GmpGeom& g, int reg, GmpFetch& f) {
     const float2* x2 = reinterpret_cast<const float2*>(a.x);
     const float2* d2 = reinterpret_cast<const float2*>(SRC == 2 ? a.target : a.dy);
     const int total = g.NI * g.E;
-    constexpr int U = 4;                                   // entries per thread in flight: the global loads of a batch go first
-    for (int e0 = threadIdx.x; e0 < total; e0 += U * kThreads) {
-        float2 xv[U], dv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * kThreads;
-            const int it = e / g.E, eo = e - it * g.E;
-            const int item = reg * g.NI + it;
-            int b = item, c = 0;
-            if (g.nchunk > 1) { b = item / g.nchunk; c = item - b * g.nchunk; }
-            const int t = c * g.TC + eo - kHalo;
-            // zero history (gmp.py:26-27,33) and nothing after the frame
-            const bool in = e < total && item < g.nitems && t >= 0 && t < a.T;
-            xv[u] = make_float2(0.0f, 0.0f); dv[u] = make_float2(0.0f, 0.0f);
-            if (in) {
-                const size_t at = (SRC == 2 && a.frame_idx != nullptr) ? (size_t)a.frame_idx[b] * a.frame_stride + t : (size_t)b * a.T + t;
-                xv[u] = x2[at];
-                if constexpr (SRC != 0) dv[u] = d2[at];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * kThreads;
-            if (e < total) {
-                const float am = __builtin_amdgcn_sqrtf(__builtin_fmaf(xv[u].x, xv[u].x, xv[u].y * xv[u].y));
-                const float a2 = am * am;
-                s.P4[e] = make_float4(am, a2, a2 * am, a2 * a2);
-                s.X[e] = xv[u];
-                if constexpr (SRC != 0) s.DY[e] = dv[u];
-            }
+    for (int u = 0; u < kEPT; ++u) {
+        const int e = (int)threadIdx.x + u * kThreads;
+        const int it = e / g.E, eo = e - it * g.E;
+        const int item = reg * g.NI + it;
+        int b = item, c = 0;
+        if (g.nchunk > 1) { b = item / g.nchunk; c = item - b * g.nchunk; }
+        const int t = c * g.TC + eo - kHalo;
+        // zero history (gmp.py:26-27,33) and nothing after the frame
+        const bool in = e < total && item < g.nitems && t >= 0 && t < a.T;
+        f.x[u] = make_float2(0.0f, 0.0f); f.d[u] = make_float2(0.0f, 0.0f);
+        if (in) {
+            const size_t at = (SRC == 2 && a.frame_idx != nullptr) ? (size_t)a.frame_idx[b] * a.frame_stride + t : (size_t)b * a.T + t;
+            f.x[u] = x2[at];
+            if constexpr (SRC != 0) f.d[u] = d2[at];
         }
     }
 }
+template <int SRC>
+__device__ __forceinline__ void gmp_deposit(const GmpGeom& g, const GmpLds& s, const GmpFetch& f) {
+    const int total = g.NI * g.E;
+#pragma unroll
+    for (int u = 0; u < kEPT; ++u) {
+        const int e = (int)threadIdx.x + u * kThreads;
+        if (e < total) {
+            const float2 xv = f.x[u];
+            const float am = __builtin_amdgcn_sqrtf(__builtin_fmaf(xv.x, xv.x, xv.y * xv.y));
+            const float a2 = am * am;
+            s.P4[s.pos(e)] = make_float4(am, a2, a2 * am, a2 * a2);
+            s.X[e] = xv;
+            if constexpr (SRC != 0) s.DY[e] = f.d[u];
+        }
+    }
+}
+// region loop shared by the kernels: body(reg) runs with the region in LDS and the next region's loads in flight
+template <int SRC, class Body>
+__device__ __forceinline__ void gmp_regions(const SeqArgs& a, const GmpGeom& g, const GmpLds& s, Body&& body) {
+    GmpFetch f;
+    int reg = blockIdx.x;
+    if (reg < g.nregions) gmp_fetch<SRC>(a, g, reg, f);
+    for (; reg < g.nregions; reg += gridDim.x) {
+        __syncthreads();
+        gmp_deposit<SRC>(g, s, f);
+        __syncthreads();
+        if (reg + (int)gridDim.x < g.nregions) gmp_fetch<SRC>(a, g, reg + gridDim.x, f);
+        body(reg);
+    }
+}
 
-// LDS entry of the lane's sample, its (b,t) offset in the tensors; `own`: inside the item's chunk (the fused step also walks
-// the kM-1 samples after a chunk: their dy is needed by the chunk's weight gradient)
-struct GmpLane { int e; size_t g; bool ok, own; };
-__device__ __forceinline__ GmpLane gmp_locate(const SeqArgs& a, const GmpGeom& g, int reg, int idx, int span) {
-    GmpLane L;
-    const int it = idx / span, off = idx - it * span;
+// ---- forward: a lane owns the kR consecutive samples off .. off + kR - 1 of an item (off multiple of 4) ---------------------
+struct GmpTile {
+    int e0;            // natural LDS entry of the first sample (multiple of 4)
+    size_t g0;         // (b, t) offset of the first sample in the tensors
+    int nval, nown;    // samples of the tile inside the frame / inside the item's own chunk (the fused step also walks the
+                       // kM-1 samples after a chunk: their dy is needed by the chunk's weight gradient)
+};
+__device__ __forceinline__ GmpTile gmp_locate_tile(const SeqArgs& a, const GmpGeom& g, int reg, int ti, int ntile, int span) {
+    GmpTile L;
+    const int it = ti / ntile, off = kR * (ti - it * ntile);
     const int item = reg * g.NI + it;
     int b = item, c = 0;
     if (g.nchunk > 1) { b = item / g.nchunk; c = item - b * g.nchunk; }
-    const int t = c * g.TC + off;
-    L.ok = it < g.NI && item < g.nitems && t < a.T;
-    L.own = off < g.TC;
-    L.e = L.ok ? it * g.E + off + kHalo : kHalo;
-    L.g = L.ok ? (size_t)b * a.T + t : 0;
+    const int t0 = c * g.TC + off;
+    const bool ok = it < g.NI && item < g.nitems;
+    L.nval = ok ? max(0, min(kR, min(a.T - t0, span - off))) : 0;
+    L.nown = ok ? max(0, min(L.nval, g.TC - off)) : 0;
+    L.e0 = L.nval > 0 ? it * g.E + off + kHalo : kHalo;
+    L.g0 = L.nval > 0 ? (size_t)b * a.T + t0 : 0;
     return L;
 }
 
-// NS samples per lane share every scalar weight fetch
-template <int NS>
-__device__ __forceinline__ void gmp_outputs(const GmpLds& s, WPtr w0, const GmpLane (&L)[NS], float (&yr)[NS], float (&yi)[NS]) {
+__device__ __forceinline__ void gmp_tile_outputs(const GmpLds& s, WPtr w0, int e0, float (&yr)[kR], float (&yi)[kR]) {
     WPtr w = gmp_fresh(w0);
-    float ec[NS][kM];
+    float ec[kR][kM];
 #pragma unroll
-    for (int u = 0; u < NS; ++u)
+    for (int u = 0; u < kR; ++u)
 #pragma unroll
         for (int r = 0; r < kM; ++r) ec[u][r] = w[gmp_w0(r)];
-    // lane t needs Ec[t-r, r] = w0[r] + sum_{d,k} w[d,k,r] P_d[t-r-k]: the 21-sample envelope window sits in registers and the
-    // weights are walked in their native order (d, i, m: contiguous -> wide scalar loads)
-    float4 pw[NS][kHalo + 1];
+    // window entry m = natural entry e0 - kHalo + m, m = 0 .. kHalo + kR - 1: plane m mod 4 (e0, kHalo multiples of 4)
+    constexpr int kWin = kHalo + kR;
+    float4 pw[kWin];
+    const float4* pq = s.P4 + ((e0 - kHalo) >> 2);
 #pragma unroll
-    for (int u = 0; u < NS; ++u)
-#pragma unroll
-        for (int j = 0; j <= kHalo; ++j) pw[u][j] = s.P4[L[u].e - j];
-    // one segment = the 11 weights w[d,k,0..10] (contiguous); the scalar loads run two segments ahead of the FMAs
+    for (int m = 0; m < kWin; ++m) pw[m] = pq[(m & 3) * s.Q + (m >> 2)];
+    // sample u needs Ec[t-r, r] = w0[r] + sum_{d,k} w[d,k,r] P_d[t-r-k] -> window entry kHalo + u - (r + k).
+    // One segment = the 11 weights w[d,k,0..10] (contiguous in the reference's order); the scalar loads run two segments ahead
     constexpr int kSegs = kNP * kM;
     float wc[kM], wn[kM], wnn[kM];
 #pragma unroll
@@ -147,59 +181,31 @@ __device__ __forceinline__ void gmp_outputs(const GmpLds& s, WPtr w0, const GmpL
         if constexpr (seg + 2 < kSegs) {
             constexpr int dn = (seg + 2) / kM, kn = kM - 1 - (seg + 2) % kM;
 #pragma unroll
-            for (int u = 0; u < NS; ++u) w = gmp_fresh_after(w, ec[u]);
+            for (int u = 0; u < kR; ++u) w = gmp_fresh_after(w, ec[u]);
 #pragma unroll
             for (int r = 0; r < kM; ++r) wnn[r] = w[gmp_w(dn, kn, r)];
         }
 #pragma unroll
         for (int r = kM - 1; r >= 0; --r)
 #pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                const float4 p = pw[u][r + k];
+            for (int u = 0; u < kR; ++u) {
+                const float4 p = pw[kHalo + u - r - k];
                 ec[u][r] = __builtin_fmaf(wc[r], d == 0 ? p.x : d == 1 ? p.y : d == 2 ? p.z : p.w, ec[u][r]);
             }
 #pragma unroll
         for (int r = 0; r < kM; ++r) { wc[r] = wn[r]; wn[r] = wnn[r]; }
     });
+    float2 xw[kM - 1 + kR];                    // x[t0 - 10 .. t0 + 3]
 #pragma unroll
-    for (int u = 0; u < NS; ++u) {
+    for (int v = 0; v < kM - 1 + kR; ++v) xw[v] = s.X[e0 - (kM - 1) + v];
+#pragma unroll
+    for (int u = 0; u < kR; ++u) {
         yr[u] = 0.0f; yi[u] = 0.0f;
 #pragma unroll
         for (int r = 0; r < kM; ++r) {
-            const float2 xv = s.X[L[u].e - r];
-            yr[u] = __builtin_fmaf(ec[u][r], xv.x, yr[u]);
-            yi[u] = __builtin_fmaf(ec[u][r], xv.y, yi[u]);
+            yr[u] = __builtin_fmaf(ec[u][r], xw[kM - 1 + u - r].x, yr[u]);
+            yi[u] = __builtin_fmaf(ec[u][r], xw[kM - 1 + u - r].y, yi[u]);
         }
-    }
-}
-template <int NS>
-__device__ __forceinline__ void gmp_fwd_samples(const SeqArgs& a, const GmpGeom& g, const GmpLds& s, WPtr w, int reg, int base) {
-    GmpLane L[NS];
-    float yr[NS], yi[NS];
-#pragma unroll
-    for (int u = 0; u < NS; ++u) L[u] = gmp_locate(a, g, reg, base + u * kThreads + (int)threadIdx.x, g.TC);
-    gmp_outputs<NS>(s, w, L, yr, yi);
-    float2* y2 = reinterpret_cast<float2*>(a.y);
-#pragma unroll
-    for (int u = 0; u < NS; ++u)
-        if (L[u].ok) y2[L[u].g] = make_float2(yr[u], yi[u]);
-}
-// fused step: dy = dLoss/dy replaces the staged target in LDS, the loss of the chunk's own samples accumulates per lane
-template <int NS>
-__device__ __forceinline__ void gmp_loss_samples(const SeqArgs& a, const GmpGeom& g, const GmpLds& s, WPtr w, int reg, int base, int span,
-                                                 float& loss_acc) {
-    GmpLane L[NS];
-    float yr[NS], yi[NS];
-#pragma unroll
-    for (int u = 0; u < NS; ++u) L[u] = gmp_locate(a, g, reg, base + u * kThreads + (int)threadIdx.x, span);
-    gmp_outputs<NS>(s, w, L, yr, yi);
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-        const float2 tv = s.DY[L[u].e];
-        const S16Loss lc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, L[u].ok ? a.inv_count : 0.0f, L[u].ok && L[u].own);
-        float d0, d1;
-        s16_loss(lc, yr[u] - tv.x, yi[u] - tv.y, d0, d1, loss_acc);
-        if (L[u].ok) s.DY[L[u].e] = make_float2(d0, d1);
     }
 }
 
@@ -207,15 +213,18 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_fwd_kernel(SeqArgs a, GmpGeom
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GmpLds s(smem, g, false);
     const WPtr w = (WPtr)a.params;
-    const int nsamp = g.NI * g.TC;
-    for (int reg = blockIdx.x; reg < g.nregions; reg += gridDim.x) {
-        __syncthreads();
-        gmp_stage<0>(a, g, reg, s);
-        __syncthreads();
-        int base = 0;
-        for (; base + kThreads < nsamp; base += 2 * kThreads) gmp_fwd_samples<2>(a, g, s, w, reg, base);
-        if (base < nsamp) gmp_fwd_samples<1>(a, g, s, w, reg, base);
-    }
+    const int ntile = (g.TC + kR - 1) / kR, tiles = g.NI * ntile;
+    float2* y2 = reinterpret_cast<float2*>(a.y);
+    gmp_regions<0>(a, g, s, [&](int reg) {
+        for (int ti = threadIdx.x; ti < tiles; ti += kThreads) {
+            const GmpTile L = gmp_locate_tile(a, g, reg, ti, ntile, g.TC);
+            float yr[kR], yi[kR];
+            gmp_tile_outputs(s, w, L.e0, yr, yi);
+#pragma unroll
+            for (int u = 0; u < kR; ++u)
+                if (u < L.nval) y2[L.g0 + u] = make_float2(yr[u], yi[u]);
+        }
+    });
 }
 
 // dL/dW: every wave owns three 16 x 16 accumulator tiles [r][(d,k) | ones]; one partials row per workgroup.
@@ -226,30 +235,42 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GmpLds s(smem, g, true);
     const WPtr w = (WPtr)a.params;
-    const int span = g.TC + (g.nchunk > 1 ? kM - 1 : 0), nsamp = g.NI * span;
+    const int span = g.TC + (g.nchunk > 1 ? kM - 1 : 0), ntile = (span + kR - 1) / kR, tiles = g.NI * ntile;
     float loss_acc = 0.0f;
     const float* pf = reinterpret_cast<const float*>(s.P4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     // B operand of column c = 16 ct + n: P_d[s-k] for c = 11 d + k < 44, the constant 1 for c = 44 (dL/dw0[r] = sum_s G[s,r]);
-    // columns 45..47 and rows r = 11..15 of the tiles are never read back, so they may hold anything finite
+    // columns 45..47 and rows r = 11..15 of the tiles are never read back, so they may hold anything finite.
+    // Sample q of a group sits at natural entry eb + 4 grp + q (eb multiple of 4): P_d[s-k] is at plane (q-k) mod 4,
+    // slot eb/4 + grp + floor((q-k)/4) -> per-lane float offset boff, then 4 floats per group
     int boff[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
-        const int c = 16 * ct + n, d = c / kM, k = c - d * kM;
-        boff[ct] = c < kNP * kM ? d - 4 * k : 0;        // float offset of P_d[s-k] from the sample's own float4
+        const int c = 16 * ct + n, d = c < kNP * kM ? c / kM : 0, k = c < kNP * kM ? c % kM : 0;
+        const int rel = q - k;                                        // -10 .. 3
+        boff[ct] = 4 * (((rel + 12) & 3) * s.Q + ((rel + 12) >> 2) - 3) + d;
     }
     const float bmul2 = 32 + n < kNP * kM ? 1.0f : 0.0f, badd2 = 32 + n == kNP * kM ? 1.0f : 0.0f;
     f32x4 acc[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int reg = blockIdx.x; reg < g.nregions; reg += gridDim.x) {
-        __syncthreads();
-        gmp_stage<FUSED ? 2 : 1>(a, g, reg, s);
-        __syncthreads();
+    gmp_regions<FUSED ? 2 : 1>(a, g, s, [&](int reg) {
         if constexpr (FUSED) {
-            int base = 0;
-            for (; base + kThreads < nsamp; base += 2 * kThreads) gmp_loss_samples<2>(a, g, s, w, reg, base, span, loss_acc);
-            if (base < nsamp) gmp_loss_samples<1>(a, g, s, w, reg, base, span, loss_acc);
+            // forward of the region; dy = dLoss/dy replaces the staged target in LDS, the loss of the chunk's own samples
+            // accumulates per lane
+            for (int ti = threadIdx.x; ti < tiles; ti += kThreads) {
+                const GmpTile L = gmp_locate_tile(a, g, reg, ti, ntile, span);
+                float yr[kR], yi[kR];
+                gmp_tile_outputs(s, w, L.e0, yr, yi);
+#pragma unroll
+                for (int u = 0; u < kR; ++u) {
+                    const float2 tv = s.DY[L.e0 + u];
+                    const S16Loss lc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, u < L.nval ? a.inv_count : 0.0f, u < L.nown);
+                    float d0, d1;
+                    s16_loss(lc, yr[u] - tv.x, yi[u] - tv.y, d0, d1, loss_acc);
+                    if (u < L.nval) s.DY[L.e0 + u] = make_float2(d0, d1);
+                }
+            }
             __syncthreads();
         }
         for (int it = 0; it < g.NI; ++it) {
@@ -260,12 +281,12 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
             // a group = 4 consecutive samples (K of the MFMA); wave w takes groups w, w + 4, ...; four groups in flight so that
             // their LDS reads (immediate offsets from per-iteration bases) go first; no masks until the ragged tail
             constexpr int GU = 4, kWaves = kThreads / 64;
-            const int eb = it * g.E + kHalo + q, nfull = len >> 2;
-            const float2* xp = s.X + eb;
-            const float2* dp = s.DY + eb + n;
-            const float* p0 = pf + 4 * eb + boff[0];
-            const float* p1 = pf + 4 * eb + boff[1];
-            const float* p2 = pf + 4 * eb + boff[2];
+            const int eb = it * g.E + kHalo, nfull = len >> 2;
+            const float2* xp = s.X + eb + q;
+            const float2* dp = s.DY + eb + q + n;
+            const float* p0 = pf + eb + boff[0];           // 4 floats per slot, eb / 4 slots
+            const float* p1 = pf + eb + boff[1];
+            const float* p2 = pf + eb + boff[2];
             int grp = wave;
             for (; grp + (GU - 1) * kWaves < nfull; grp += GU * kWaves) {
                 float gv[GU], bv[GU][3];
@@ -274,26 +295,25 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
                     const int o = 4 * (grp + u * kWaves);
                     const float2 xv = xp[o], dv = dp[o];
                     gv[u] = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y);
-                    bv[u][0] = p0[4 * o]; bv[u][1] = p1[4 * o];
-                    bv[u][2] = __builtin_fmaf(p2[4 * o], bmul2, badd2);
+                    bv[u][0] = p0[o]; bv[u][1] = p1[o];
+                    bv[u][2] = __builtin_fmaf(p2[o], bmul2, badd2);
                 }
 #pragma unroll
                 for (int u = 0; u < GU; ++u)
 #pragma unroll
                     for (int ct = 0; ct < 3; ++ct) acc[ct] = mfma4(gv[u], bv[u][ct], acc[ct]);
             }
-            for (; 4 * grp < len; grp += kWaves) {
-                const int off = 4 * grp + q;
-                const float okf = __builtin_amdgcn_fmed3f((float)(len - off), 0.0f, 1.0f);     // 1 inside the chunk, 0 past its end
-                const int o = min(off, len - 1) - q;
+            for (; 4 * grp < len; grp += kWaves) {       // samples past the chunk's end are staged (halo) but do not count
+                const int o = 4 * grp;
+                const float okf = __builtin_amdgcn_fmed3f((float)(len - o - q), 0.0f, 1.0f);
                 const float2 xv = xp[o], dv = dp[o];
                 const float gvt = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y) * okf;
-                acc[0] = mfma4(gvt, p0[4 * o], acc[0]);
-                acc[1] = mfma4(gvt, p1[4 * o], acc[1]);
-                acc[2] = mfma4(gvt, __builtin_fmaf(p2[4 * o], bmul2, badd2), acc[2]);
+                acc[0] = mfma4(gvt, p0[o], acc[0]);
+                acc[1] = mfma4(gvt, p1[o], acc[1]);
+                acc[2] = mfma4(gvt, __builtin_fmaf(p2[o], bmul2, badd2), acc[2]);
             }
         }
-    }
+    });
     // acc[ct][v] of lane (n, q) = D[r = 4q + v][col = 16 ct + n]
     __syncthreads();
     float* red = smem + wave * 16 * kGradCols;
@@ -327,26 +347,30 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
     }
 }
 
+// dL/dx: one lane per sample
 __global__ __launch_bounds__(kThreads, 2) void gmp_dx_kernel(SeqArgs a, GmpGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GmpLds s(smem, g, true);
     const WPtr w0 = (WPtr)a.params;
     const int nsamp = g.NI * g.TC;
     float2* dx2 = reinterpret_cast<float2*>(a.dx);
-    for (int reg = blockIdx.x; reg < g.nregions; reg += gridDim.x) {
-        __syncthreads();
-        gmp_stage<1>(a, g, reg, s);
-        __syncthreads();
-        for (int base = 0; base < nsamp; base += kThreads) {
-            const GmpLane L = gmp_locate(a, g, reg, base + (int)threadIdx.x, g.TC);
+    gmp_regions<1>(a, g, s, [&](int reg) {
+        for (int idx = threadIdx.x; idx < nsamp; idx += kThreads) {
+            const int it = idx / g.TC, off = idx - it * g.TC;
+            const int item = reg * g.NI + it;
+            int b = item, c = 0;
+            if (g.nchunk > 1) { b = item / g.nchunk; c = item - b * g.nchunk; }
+            const int t = c * g.TC + off;
+            const bool ok = item < g.nitems && t < a.T;
+            const int e = ok ? it * g.E + off + kHalo : kHalo;
             WPtr w = gmp_fresh(w0);
             float ec[kM];
 #pragma unroll
             for (int r = 0; r < kM; ++r) ec[r] = w[gmp_w0(r)];
 #pragma unroll
             for (int k = 0; k < kM; ++k) {
-                const float4 p = s.P4[L.e - k];
-                w = gmp_fresh(w);
+                const float4 p = s.P4[s.pos(e - k)];
+                w = gmp_fresh_after(w, ec);
 #pragma unroll
                 for (int r = 0; r < kM; ++r) {
                     ec[r] = __builtin_fmaf(w[gmp_w(0, k, r)], p.x, ec[r]);
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_dx_kernel(SeqArgs a, GmpGeom 
             }
             float2 dv[kHalo + 1];
 #pragma unroll
-            for (int j = 0; j <= kHalo; ++j) dv[j] = s.DY[L.e + j];
+            for (int j = 0; j <= kHalo; ++j) dv[j] = s.DY[e + j];
             float dr = 0.0f, di = 0.0f;                   // through the complex factor u[t+m] of every term
 #pragma unroll
             for (int r = 0; r < kM; ++r) {
@@ -367,8 +391,8 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_dx_kernel(SeqArgs a, GmpGeom 
             float dp[kNP] = {0.f, 0.f, 0.f, 0.f};        // dL/dP_d[s]: the terms whose envelope sample is s
 #pragma unroll
             for (int k = 0; k < kM; ++k) {
-                const float2 xk = s.X[L.e + k];
-                w = gmp_fresh(w);
+                const float2 xk = s.X[e + k];
+                w = gmp_fresh_after4(w, dp);
 #pragma unroll
                 for (int r = 0; r < kM; ++r) {
                     const float gv = __builtin_fmaf(xk.x, dv[k + r].x, xk.y * dv[k + r].y);
@@ -378,50 +402,55 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_dx_kernel(SeqArgs a, GmpGeom 
                     dp[3] = __builtin_fmaf(w[gmp_w(3, k, r)], gv, dp[3]);
                 }
             }
-            const float4 p0 = s.P4[L.e];
-            const float2 xs = s.X[L.e];
+            const float4 p0 = s.P4[s.pos(e)];
+            const float2 xs = s.X[e];
             float damp = dp[0];
             damp = __builtin_fmaf(2.0f * p0.x, dp[1], damp);
             damp = __builtin_fmaf(3.0f * p0.y, dp[2], damp);
             damp = __builtin_fmaf(4.0f * p0.z, dp[3], damp);
             const float ia = p0.x > 0.0f ? fast_rcp(p0.x) : 0.0f;      // d|x|/dx = x/|x|, 0 at the origin (torch.abs)
             damp *= ia;
-            if (L.ok) dx2[L.g] = make_float2(__builtin_fmaf(damp, xs.x, dr), __builtin_fmaf(damp, xs.y, di));
+            if (ok) dx2[(size_t)b * a.T + t] = make_float2(__builtin_fmaf(damp, xs.x, dr), __builtin_fmaf(damp, xs.y, di));
         }
-    }
+    });
 }
 
-// bytes of LDS per entry: float4 envelope powers + float2 x (+ float2 dy)
-GmpGeom gmp_geom(int B, int T, int entry_bytes) {
+// aux_bytes: LDS per entry besides the float4 envelope powers (float2 x, + float2 dy / target)
+GmpGeom gmp_geom(int B, int T, int aux_bytes) {
     GmpGeom g;
     g.TC = T <= kGmpMaxChunk ? T : kGmpMaxChunk;
     g.nchunk = (T + g.TC - 1) / g.TC;
     g.nitems = B * g.nchunk;
-    g.E = g.TC + 2 * kHalo;
+    g.E = (g.TC + 2 * kHalo + 3) / 4 * 4;
     const int budget = 60 * 1024;                       // two workgroups per CU
-    int ni_max = budget / (g.E * entry_bytes);
+    int ni_max = budget / (g.E * (16 + aux_bytes) + 64);
+    if (ni_max > kEPT * kThreads / g.E) ni_max = kEPT * kThreads / g.E;
     const int spread = g.nitems / (2 * device_cus());   // keep at least two regions per CU when the batch allows
     if (ni_max > spread) ni_max = spread;
     if (ni_max > g.nitems) ni_max = g.nitems;
     if (ni_max < 1) ni_max = 1;
-    // lanes map to the NI * TC samples of a region in passes of 256: take the count with the fewest idle lanes
+    // forward lanes map to the NI * ceil(TC / 4) sample tiles of a region in passes of 256: fewest idle lanes wins
+    const int ntile = (g.TC + kR - 1) / kR;
     int best = ni_max;
     double best_waste = 1e9;
     for (int ni = ni_max; ni >= (ni_max + 1) / 2; --ni) {
-        const long n = (long)ni * g.TC, padded = (n + kThreads - 1) / kThreads * kThreads;
+        const long n = (long)ni * ntile, padded = (n + kThreads - 1) / kThreads * kThreads;
         const double waste = (double)padded / (double)n;
         if (waste < best_waste - 1e-9) { best_waste = waste; best = ni; }
     }
     g.NI = best;
     g.nregions = (g.nitems + g.NI - 1) / g.NI;
+    const int slots = g.NI * g.E / 4;
+    g.Q = slots + ((4 - slots % 16) + 16) % 16;         // Q mod 16 = 4
     return g;
 }
 int gmp_grid(const GmpGeom& g) {
     const int cap = 2 * device_cus();
     return g.nregions < cap ? g.nregions : cap;
 }
-size_t gmp_lds(const GmpGeom& g, int entry_bytes) {
-    const size_t stage = (size_t)g.NI * g.E * entry_bytes, red = (size_t)((kThreads / 64) * 16 * kGradCols + 4) * sizeof(float);
+size_t gmp_lds(const GmpGeom& g, int aux_bytes) {
+    const size_t stage = (size_t)4 * g.Q * 16 + (size_t)g.NI * g.E * aux_bytes;
+    const size_t red = (size_t)((kThreads / 64) * 16 * kGradCols + 4) * sizeof(float);
     return stage > red ? stage : red;
 }
 bool gmp_ok(const odpd_model_t* m) { return m->hidden == kM; }
@@ -430,31 +459,31 @@ bool gmp_ok(const odpd_model_t* m) { return m->hidden == kM; }
 
 int gmp_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!gmp_ok(m)) return ODPD_EUNSUPPORTED;
-    const GmpGeom g = gmp_geom(a.B, a.T, 24);
-    hipLaunchKernelGGL(gmp_fwd_kernel, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 24), st, a, g);
+    const GmpGeom g = gmp_geom(a.B, a.T, 8);
+    hipLaunchKernelGGL(gmp_fwd_kernel, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 8), st, a, g);
     return (int)hipGetLastError();
 }
 int gmp_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!gmp_ok(m)) return ODPD_EUNSUPPORTED;
     if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
-    const GmpGeom g = gmp_geom(a.B, a.T, 32);
+    const GmpGeom g = gmp_geom(a.B, a.T, 16);
     if (a.partials != nullptr) {
-        hipLaunchKernelGGL(gmp_wgrad_kernel<false>, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 32), st, a, g);
+        hipLaunchKernelGGL(gmp_wgrad_kernel<false>, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 16), st, a, g);
         if (int e = (int)hipGetLastError()) return e;
     }
-    if (a.dx != nullptr) hipLaunchKernelGGL(gmp_dx_kernel, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 32), st, a, g);
+    if (a.dx != nullptr) hipLaunchKernelGGL(gmp_dx_kernel, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 16), st, a, g);
     return (int)hipGetLastError();
 }
 // fused train step: x, target (optionally framed) -> partials rows [dL/dW | loss partial]
 int gmp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!gmp_ok(m)) return ODPD_EUNSUPPORTED;
-    const GmpGeom g = gmp_geom(a.B, a.T, 32);
-    hipLaunchKernelGGL(gmp_wgrad_kernel<true>, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 32), st, a, g);
+    const GmpGeom g = gmp_geom(a.B, a.T, 16);
+    hipLaunchKernelGGL(gmp_wgrad_kernel<true>, dim3(gmp_grid(g)), dim3(kThreads), gmp_lds(g, 16), st, a, g);
     return (int)hipGetLastError();
 }
 int gmp_rows(const odpd_model_t* m, int B, int T) {
     if (!gmp_ok(m)) return ODPD_EUNSUPPORTED;
-    return gmp_grid(gmp_geom(B, T, 32));
+    return gmp_grid(gmp_geom(B, T, 16));
 }
 
 }  // namespace odpd
