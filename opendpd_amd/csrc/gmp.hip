@@ -10,10 +10,10 @@
 //     dL/dw[d,k,r] = sum_s G[s,r] P_d[s-k],        G[s,r] = Re(conj(x[s]) dy[s+r])          (dL/dw0[r] = sum_s G[s,r])
 //     dL/dx[s]     = sum_r dy[s+r] Ec[s,r] + (x[s]/|x[s]|) sum_d d |x[s]|^(d-1) sum_{k,r} w[d,k,r] G[s+k,r]
 // Not recurrent.  A workgroup stages whole frames (time chunks of <= 512 samples with a 20-sample halo on both sides for
-// long records) in LDS: the envelope powers [|x|, |x|^2, |x|^3, |x|^4] as float4 in RESIDUE-MAJOR order (entry e at plane
+// long records) in LDS: the envelope powers |x|, |x|^2, |x|^3, |x|^4 as four arrays in RESIDUE-MAJOR order (entry e at plane
 // e mod 4, slot e / 4), x (+ dy / target) as float2 in natural order; the next region's global loads are in flight while
 // the current one is computed.  Forward: a lane owns 4 consecutive samples, so its 24-entry envelope window is read once
-// (ds_read_b128 with compile-time plane / slot offsets, conflict-free) and serves 4 x 484 FMAs.  The 484 envelope weights
+// (one power at a time, compile-time plane / slot offsets, conflict-free) and serves 4 x 484 FMAs at 3 waves per SIMD.  The 484 envelope weights
 // are wave-uniform: they are read through the constant address space in their native (d, i, m) order — s_load_dwordx8/x2/x1
 // per 11-weight row, two rows ahead of their use — and enter v_fmac as the scalar operand: no LDS or VGPR traffic for them.
 // The weight gradient is the (11 x 45) contraction G^T [P | 1] over samples: v_mfma_f32_16x16x4_f32, three 16x16 tiles per
@@ -66,15 +66,20 @@ __host__ __device__ constexpr int gmp_w0(int r) { return kM - 1 - r; }
 struct GmpGeom { int TC, nchunk, nitems, NI, E, nregions, Q; };
 
 struct GmpLds {
-    float4* P4; float2* X; float2* DY;
+    float* P;          // P[d][plane][slot]: |x|^(d+1) of entry e at d * 4Q + (e & 3) * Q + (e >> 2)
+    float2* X; float2* DY;
     int Q;
     __device__ __forceinline__ GmpLds(float* smem, const GmpGeom& g, bool with_dy) {
-        P4 = reinterpret_cast<float4*>(smem);
-        X = reinterpret_cast<float2*>(P4 + 4 * (size_t)g.Q);
+        P = smem;
+        X = reinterpret_cast<float2*>(P + 16 * (size_t)g.Q);
         DY = with_dy ? X + (size_t)g.NI * g.E : nullptr;
         Q = g.Q;
     }
     __device__ __forceinline__ int pos(int e) const { return (e & 3) * Q + (e >> 2); }
+    __device__ __forceinline__ float4 powers(int e) const {
+        const float* p = P + pos(e);
+        return make_float4(p[0], p[4 * Q], p[8 * Q], p[12 * Q]);
+    }
 };
 
 // ---- staging: global loads of a region (issued early, consumed one region later) and their deposit in LDS ----------------
@@ -114,7 +119,8 @@ __device__ __forceinline__ void gmp_deposit(const GmpGeom& g, const GmpLds& s, c
             const float2 xv = f.x[u];
             const float am = __builtin_amdgcn_sqrtf(__builtin_fmaf(xv.x, xv.x, xv.y * xv.y));
             const float a2 = am * am;
-            s.P4[s.pos(e)] = make_float4(am, a2, a2 * am, a2 * a2);
+            float* p = s.P + s.pos(e);
+            p[0] = am; p[4 * s.Q] = a2; p[8 * s.Q] = a2 * am; p[12 * s.Q] = a2 * a2;
             s.X[e] = xv;
             if constexpr (SRC != 0) s.DY[e] = f.d[u];
         }
@@ -157,55 +163,71 @@ __device__ __forceinline__ GmpTile gmp_locate_tile(const SeqArgs& a, const GmpGe
     return L;
 }
 
+// Packed fp32 (v_pk_fma_f32: two FMAs per lane and instruction — the rate the 157 TFLOP/s vector peak is quoted for): the
+// accumulators of samples (0,1) and (2,3) form register pairs; the envelope window is kept twice, as even- and odd-aligned pairs
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ WPtr gmp_fresh_after2(WPtr w, v2f (&e)[11]) {
+    asm volatile("" : "+s"(w), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]), "+v"(e[8]),
+                 "+v"(e[9]), "+v"(e[10]));
+    return w;
+}
 __device__ __forceinline__ void gmp_tile_outputs(const GmpLds& s, WPtr w0, int e0, float (&yr)[kR], float (&yi)[kR]) {
+    static_assert(kR == 4, "two sample pairs per lane");
     WPtr w = gmp_fresh(w0);
-    float ec[kR][kM];
+    v2f ec[2][kM];                             // [pair][r] = (Ec of sample 2 pair, Ec of sample 2 pair + 1)
 #pragma unroll
-    for (int u = 0; u < kR; ++u)
+    for (int up = 0; up < 2; ++up)
 #pragma unroll
-        for (int r = 0; r < kM; ++r) ec[u][r] = w[gmp_w0(r)];
-    // window entry m = natural entry e0 - kHalo + m, m = 0 .. kHalo + kR - 1: plane m mod 4 (e0, kHalo multiples of 4)
-    constexpr int kWin = kHalo + kR;
-    float4 pw[kWin];
-    const float4* pq = s.P4 + ((e0 - kHalo) >> 2);
-#pragma unroll
-    for (int m = 0; m < kWin; ++m) pw[m] = pq[(m & 3) * s.Q + (m >> 2)];
-    // sample u needs Ec[t-r, r] = w0[r] + sum_{d,k} w[d,k,r] P_d[t-r-k] -> window entry kHalo + u - (r + k).
+        for (int r = 0; r < kM; ++r) { const float v = w[gmp_w0(r)]; ec[up][r] = v2f{v, v}; }
+    // window entry m = natural entry e0 - kHalo + m, m = 0 .. kHalo + kR - 1: plane m mod 4 (e0, kHalo multiples of 4); one power
+    // at a time is held in registers (compile-time plane / slot offsets).
+    // Sample u needs Ec[t-r, r] = w0[r] + sum_{d,k} w[d,k,r] P_d[t-r-k] -> window entry kHalo + u - (r + k).
     // One segment = the 11 weights w[d,k,0..10] (contiguous in the reference's order); the scalar loads run two segments ahead
-    constexpr int kSegs = kNP * kM;
+    constexpr int kWin = kHalo + kR, kSegs = kNP * kM;
+    v2f pa[kWin / 2], pb[kWin / 2 - 1];        // (pw[2j], pw[2j+1]) and (pw[2j+1], pw[2j+2])
+    const float* pq = s.P + ((e0 - kHalo) >> 2);
     float wc[kM], wn[kM], wnn[kM];
 #pragma unroll
     for (int r = 0; r < kM; ++r) { wc[r] = w[gmp_w(0, kM - 1, r)]; wn[r] = w[gmp_w(0, kM - 2, r)]; }
     gmp_for<kSegs>([&](auto sc) {
         constexpr int seg = decltype(sc)::value, d = seg / kM, k = kM - 1 - seg % kM;
+        if constexpr (seg % kM == 0) {
+            auto at = [&](int m) { return pq[(4 * d + (m & 3)) * s.Q + (m >> 2)]; };
+#pragma unroll
+            for (int j = 0; j < kWin / 2; ++j) pa[j] = v2f{at(2 * j), at(2 * j + 1)};
+#pragma unroll
+            for (int j = 0; j < kWin / 2 - 1; ++j) pb[j] = v2f{at(2 * j + 1), at(2 * j + 2)};
+        }
         if constexpr (seg + 2 < kSegs) {
             constexpr int dn = (seg + 2) / kM, kn = kM - 1 - (seg + 2) % kM;
-#pragma unroll
-            for (int u = 0; u < kR; ++u) w = gmp_fresh_after(w, ec[u]);
+            w = gmp_fresh_after2(w, ec[0]);
+            w = gmp_fresh_after2(w, ec[1]);
 #pragma unroll
             for (int r = 0; r < kM; ++r) wnn[r] = w[gmp_w(dn, kn, r)];
         }
 #pragma unroll
         for (int r = kM - 1; r >= 0; --r)
 #pragma unroll
-            for (int u = 0; u < kR; ++u) {
-                const float4 p = pw[kHalo + u - r - k];
-                ec[u][r] = __builtin_fmaf(wc[r], d == 0 ? p.x : d == 1 ? p.y : d == 2 ? p.z : p.w, ec[u][r]);
+            for (int up = 0; up < 2; ++up) {
+                const int m = kHalo + 2 * up - r - k;
+                const v2f p = (m & 1) ? pb[m >> 1] : pa[m >> 1];
+                ec[up][r] = __builtin_elementwise_fma(v2f{wc[r], wc[r]}, p, ec[up][r]);
             }
 #pragma unroll
         for (int r = 0; r < kM; ++r) { wc[r] = wn[r]; wn[r] = wnn[r]; }
     });
-    float2 xw[kM - 1 + kR];                    // x[t0 - 10 .. t0 + 3]
+    v2f xw[kM - 1 + kR];                       // x[t0 - 10 .. t0 + 3] as (I, Q) pairs
 #pragma unroll
-    for (int v = 0; v < kM - 1 + kR; ++v) xw[v] = s.X[e0 - (kM - 1) + v];
+    for (int v = 0; v < kM - 1 + kR; ++v) { const float2 t = s.X[e0 - (kM - 1) + v]; xw[v] = v2f{t.x, t.y}; }
 #pragma unroll
     for (int u = 0; u < kR; ++u) {
-        yr[u] = 0.0f; yi[u] = 0.0f;
+        v2f y = {0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < kM; ++r) {
-            yr[u] = __builtin_fmaf(ec[u][r], xw[kM - 1 + u - r].x, yr[u]);
-            yi[u] = __builtin_fmaf(ec[u][r], xw[kM - 1 + u - r].y, yi[u]);
+            const float e = ec[u >> 1][r][u & 1];
+            y = __builtin_elementwise_fma(v2f{e, e}, xw[kM - 1 + u - r], y);
         }
+        yr[u] = y[0]; yi[u] = y[1];
     }
 }
 
@@ -231,24 +253,24 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_fwd_kernel(SeqArgs a, GmpGeom
 // FUSED: the whole train step of a region (x, target -> forward -> loss and dy in LDS -> weight gradient): x and target are
 // read once, nothing else touches HBM but the partials row (loss partial in column P).
 template <bool FUSED>
-__global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGeom g) {
+__global__ __launch_bounds__(kThreads, FUSED ? 2 : 3) void gmp_wgrad_kernel(SeqArgs a, GmpGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GmpLds s(smem, g, true);
     const WPtr w = (WPtr)a.params;
     const int span = g.TC + (g.nchunk > 1 ? kM - 1 : 0), ntile = (span + kR - 1) / kR, tiles = g.NI * ntile;
     float loss_acc = 0.0f;
-    const float* pf = reinterpret_cast<const float*>(s.P4);
+    const float* pf = s.P;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     // B operand of column c = 16 ct + n: P_d[s-k] for c = 11 d + k < 44, the constant 1 for c = 44 (dL/dw0[r] = sum_s G[s,r]);
     // columns 45..47 and rows r = 11..15 of the tiles are never read back, so they may hold anything finite.
-    // Sample q of a group sits at natural entry eb + 4 grp + q (eb multiple of 4): P_d[s-k] is at plane (q-k) mod 4,
-    // slot eb/4 + grp + floor((q-k)/4) -> per-lane float offset boff, then 4 floats per group
+    // Sample q of a group sits at natural entry eb + 4 grp + q (eb multiple of 4): P_d[s-k] is at plane (q-k) mod 4 of power d,
+    // slot eb/4 + grp + floor((q-k)/4) -> per-lane float offset boff, then one float per group
     int boff[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
         const int c = 16 * ct + n, d = c < kNP * kM ? c / kM : 0, k = c < kNP * kM ? c % kM : 0;
         const int rel = q - k;                                        // -10 .. 3
-        boff[ct] = 4 * (((rel + 12) & 3) * s.Q + ((rel + 12) >> 2) - 3) + d;
+        boff[ct] = (4 * d + ((rel + 12) & 3)) * s.Q + ((rel + 12) >> 2) - 3;
     }
     const float bmul2 = 32 + n < kNP * kM ? 1.0f : 0.0f, badd2 = 32 + n == kNP * kM ? 1.0f : 0.0f;
     f32x4 acc[3];
@@ -284,19 +306,19 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
             const int eb = it * g.E + kHalo, nfull = len >> 2;
             const float2* xp = s.X + eb + q;
             const float2* dp = s.DY + eb + q + n;
-            const float* p0 = pf + eb + boff[0];           // 4 floats per slot, eb / 4 slots
-            const float* p1 = pf + eb + boff[1];
-            const float* p2 = pf + eb + boff[2];
+            const float* p0 = pf + (eb >> 2) + boff[0];
+            const float* p1 = pf + (eb >> 2) + boff[1];
+            const float* p2 = pf + (eb >> 2) + boff[2];
             int grp = wave;
             for (; grp + (GU - 1) * kWaves < nfull; grp += GU * kWaves) {
                 float gv[GU], bv[GU][3];
 #pragma unroll
                 for (int u = 0; u < GU; ++u) {
-                    const int o = 4 * (grp + u * kWaves);
+                    const int gi = grp + u * kWaves, o = 4 * gi;
                     const float2 xv = xp[o], dv = dp[o];
                     gv[u] = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y);
-                    bv[u][0] = p0[o]; bv[u][1] = p1[o];
-                    bv[u][2] = __builtin_fmaf(p2[o], bmul2, badd2);
+                    bv[u][0] = p0[gi]; bv[u][1] = p1[gi];
+                    bv[u][2] = __builtin_fmaf(p2[gi], bmul2, badd2);
                 }
 #pragma unroll
                 for (int u = 0; u < GU; ++u)
@@ -308,9 +330,9 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
                 const float okf = __builtin_amdgcn_fmed3f((float)(len - o - q), 0.0f, 1.0f);
                 const float2 xv = xp[o], dv = dp[o];
                 const float gvt = __builtin_fmaf(xv.x, dv.x, xv.y * dv.y) * okf;
-                acc[0] = mfma4(gvt, p0[o], acc[0]);
-                acc[1] = mfma4(gvt, p1[o], acc[1]);
-                acc[2] = mfma4(gvt, __builtin_fmaf(p2[o], bmul2, badd2), acc[2]);
+                acc[0] = mfma4(gvt, p0[grp], acc[0]);
+                acc[1] = mfma4(gvt, p1[grp], acc[1]);
+                acc[2] = mfma4(gvt, __builtin_fmaf(p2[grp], bmul2, badd2), acc[2]);
             }
         }
     });
@@ -348,7 +370,7 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_wgrad_kernel(SeqArgs a, GmpGe
 }
 
 // dL/dx: one lane per sample
-__global__ __launch_bounds__(kThreads, 2) void gmp_dx_kernel(SeqArgs a, GmpGeom g) {
+__global__ __launch_bounds__(kThreads, 3) void gmp_dx_kernel(SeqArgs a, GmpGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GmpLds s(smem, g, true);
     const WPtr w0 = (WPtr)a.params;
@@ -369,7 +391,7 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_dx_kernel(SeqArgs a, GmpGeom 
             for (int r = 0; r < kM; ++r) ec[r] = w[gmp_w0(r)];
 #pragma unroll
             for (int k = 0; k < kM; ++k) {
-                const float4 p = s.P4[s.pos(e - k)];
+                const float4 p = s.powers(e - k);
                 w = gmp_fresh_after(w, ec);
 #pragma unroll
                 for (int r = 0; r < kM; ++r) {
@@ -402,7 +424,7 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_dx_kernel(SeqArgs a, GmpGeom 
                     dp[3] = __builtin_fmaf(w[gmp_w(3, k, r)], gv, dp[3]);
                 }
             }
-            const float4 p0 = s.P4[s.pos(e)];
+            const float4 p0 = s.powers(e);
             const float2 xs = s.X[e];
             float damp = dp[0];
             damp = __builtin_fmaf(2.0f * p0.x, dp[1], damp);
@@ -422,10 +444,10 @@ GmpGeom gmp_geom(int B, int T, int aux_bytes) {
     g.nchunk = (T + g.TC - 1) / g.TC;
     g.nitems = B * g.nchunk;
     g.E = (g.TC + 2 * kHalo + 3) / 4 * 4;
-    const int budget = 60 * 1024;                       // two workgroups per CU
+    const int budget = 48 * 1024;                       // three workgroups per CU
     int ni_max = budget / (g.E * (16 + aux_bytes) + 64);
     if (ni_max > kEPT * kThreads / g.E) ni_max = kEPT * kThreads / g.E;
-    const int spread = g.nitems / (2 * device_cus());   // keep at least two regions per CU when the batch allows
+    const int spread = g.nitems / (3 * device_cus());   // keep at least three regions per CU when the batch allows
     if (ni_max > spread) ni_max = spread;
     if (ni_max > g.nitems) ni_max = g.nitems;
     if (ni_max < 1) ni_max = 1;
@@ -445,7 +467,7 @@ GmpGeom gmp_geom(int B, int T, int aux_bytes) {
     return g;
 }
 int gmp_grid(const GmpGeom& g) {
-    const int cap = 2 * device_cus();
+    const int cap = 3 * device_cus();
     return g.nregions < cap ? g.nregions : cap;
 }
 size_t gmp_lds(const GmpGeom& g, int aux_bytes) {
