@@ -7,7 +7,6 @@ that surgery is a single HIP-backed backbone, `QuantQGRU`, with the same paramet
 (`backbone.rnn.rnn_cell_list.0.{x2h,h2h}.{weight,bias,weight_quantizer.scale,...}`, `...{sigmoid,tanh,add,mul}.quantizer.scale`,
 `backbone.fc_out.*`) so state dicts are interchangeable, and the same construction-time RNG consumption.
 Kernels: csrc/qgru_family.hip (integer-grid arithmetic bit-exact with the reference for 8-bit grids)."""
-import copy
 import math
 
 import numpy as np

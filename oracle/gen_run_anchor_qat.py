@@ -9,7 +9,6 @@ import glob
 import json
 import os
 import subprocess
-import sys
 import tempfile
 
 import numpy as np
@@ -21,7 +20,6 @@ C = ["--dataset_name", "APA_200MHz", "--accelerator", "cpu", "--frame_length", "
      "--PA_backbone", "dgru", "--PA_hidden_size", "23"]
 Q = ["--DPD_backbone", "qgru", "--DPD_hidden_size", "10", "--quant", "--n_bits_w", "8", "--n_bits_a", "8", "--batch_size", "64"]
 RUNNER = """
-import sys
 sys.path.insert(0, %r)
 sys.dont_write_bytecode = True
 import quant
