@@ -17,13 +17,14 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 lib = _lib.load()
 o = Oracle("f32")
 LIM = {"gru": 32, "dgru": 32, "qgru": 32, "qgru_amp1": 32, "lstm": 32, "vdlstm": 32, "deltagru": 32, "deltagru_tcnskip": 32, "pgjanet": 16,
-       "tcnn": 40}
+       "tcnn": 40, "gmp": 11}
 names = list(LIM)
 rng = np.random.RandomState(7)
 bad, worst, single = [], [0.0, 0.0], 0
 for case in range(n_cases):
     dbb, pbb = names[rng.randint(len(names))], names[rng.randint(len(names))]
     dh, ph = int(rng.randint(1, LIM[dbb] + 1)), int(rng.randint(1, LIM[pbb] + 1))
+    dh, ph = (11 if dbb == "gmp" else dh), (11 if pbb == "gmp" else ph)       # gmp: `hidden` is the memory length the registry builds
     force = bool(rng.randint(2))
     lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
     B = int(rng.choice([1, 3, 4, 16, 17, 33, 64]))
