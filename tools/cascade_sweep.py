@@ -16,11 +16,12 @@ from oracle.oracle import Oracle, make_model
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 lib = _lib.load()
 o = Oracle("f32")
+o64 = Oracle("f64")
 LIM = {"gru": 32, "dgru": 32, "qgru": 32, "qgru_amp1": 32, "lstm": 32, "vdlstm": 32, "deltagru": 32, "deltagru_tcnskip": 32, "pgjanet": 16,
        "tcnn": 40, "gmp": 11}
 names = list(LIM)
 rng = np.random.RandomState(7)
-bad, worst, single = [], [0.0, 0.0], 0
+bad, kinks, worst, single = [], [], [0.0, 0.0], 0
 for case in range(n_cases):
     dbb, pbb = names[rng.randint(len(names))], names[rng.randint(len(names))]
     dh, ph = int(rng.randint(1, LIM[dbb] + 1)), int(rng.randint(1, LIM[pbb] + 1))
@@ -67,12 +68,28 @@ for case in range(n_cases):
     el = abs(lg - lo) / max(abs(lo), 1e-30)
     eg = float(np.abs(g - gd).max() / max(np.abs(gd).max(), 1e-30))
     same = bool(torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp)))
-    worst[0], worst[1] = max(worst[0], el), max(worst[1], eg)
     tol_g = 3e-4 if kind == "l2" else 5e-3        # l1: sign(y - t) of a residual within rounding of 0 may differ
     if not (el < 3e-5 and eg < tol_g and same) or not np.isfinite([el, eg]).all():
+        # a relu / hardswish kink of the DPD or PA within rounding of 0 makes the gradient itself discontinuous: then the fp64
+        # ORACLE's gradient jumps by the same amount under a 2e-6 relative change of the input (or differs from the fp32 build),
+        # and the case says nothing about the kernels
+        def grad64(scale):
+            f8 = lambda a: np.asarray(a, dtype=np.float64)
+            u8, _ = o64.forward(md, f8(pd), f8(x) * scale)
+            y8, _ = o64.forward(mp, f8(pp), u8)
+            _, dy8 = o64.loss(kind, y8, f8(t))
+            _, du8 = o64.backward(mp, f8(pp), u8, dy8)
+            return o64.backward(md, f8(pd), f8(x) * scale, du8, need_dx=False)[0]
+        g8 = grad64(1.0)
+        jump = max(float(np.abs(v - g8).max() / max(np.abs(g8).max(), 1e-30)) for v in (gd, grad64(1 + 2e-6), grad64(1 - 2e-6)))
+        if same and el < 3e-5 and jump > 0.3 * eg:
+            kinks.append((dbb, dh, pbb, ph, B, T, kind, force, f"grad {eg:.2e}; the fp64 oracle's own gradient jumps by {jump:.2e}"))
+            continue
         bad.append((dbb, dh, pbb, ph, B, T, kind, force, f"loss {el:.2e} grad {eg:.2e} pa_untouched {same}"))
+    worst[0], worst[1] = max(worst[0], el), max(worst[1], eg)
 lib.odpd_set_tuning(b"s16_min_batch", -1)
 print(f"{n_cases} random cascades ({single} through the single-launch frozen-PA step): worst rel err  loss {worst[0]:.2e}  DPD gradient {worst[1]:.2e}")
+print(f"{len(kinks)} case(s) on an activation kink (the oracle's own gradient is discontinuous there): {kinks}")
 print(f"{len(bad)} case(s) beyond tolerance")
 for b in bad[:40]:
     print("  ", b)

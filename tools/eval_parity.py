@@ -13,7 +13,7 @@ o = Oracle("f64")
 o.set_threads(o.max_threads())
 for bb, H, kw in (("gru", 11, {}), ("dgru", 13, {}), ("dgru", 23, {}), ("qgru", 10, {}), ("qgru_amp1", 16, {}), ("lstm", 14, {}), ("vdlstm", 13, {}),
                   ("deltagru", 15, dict(thx=0.0, thh=0.0)), ("deltagru_tcnskip", 15, dict(thx=0.0, thh=0.0)), ("deltagru_tcnskip", 24, dict(thx=0.0, thh=0.0)),
-                  ("pgjanet", 11, {}), ("tcnn", 35, {})):
+                  ("pgjanet", 11, {}), ("tcnn", 35, {}), ("gmp", 11, {})):
     for B, T in ((3, 2560), (1, 19662)):
         torch.manual_seed(0)
         with warnings.catch_warnings():
