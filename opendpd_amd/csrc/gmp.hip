@@ -126,17 +126,19 @@ __device__ __forceinline__ void gmp_deposit(const GmpGeom& g, const GmpLds& s, c
         }
     }
 }
-// region loop shared by the kernels: body(reg) runs with the region in LDS and the next region's loads in flight
-template <int SRC, class Body>
+// region loop shared by the kernels: body(reg) runs with the region in LDS and (PREFETCH) the next region's loads in flight;
+// the fused train kernel trades the 32 prefetch registers for a third resident workgroup per CU
+template <int SRC, bool PREFETCH, class Body>
 __device__ __forceinline__ void gmp_regions(const SeqArgs& a, const GmpGeom& g, const GmpLds& s, Body&& body) {
     GmpFetch f;
     int reg = blockIdx.x;
-    if (reg < g.nregions) gmp_fetch<SRC>(a, g, reg, f);
+    if (PREFETCH && reg < g.nregions) gmp_fetch<SRC>(a, g, reg, f);
     for (; reg < g.nregions; reg += gridDim.x) {
+        if constexpr (!PREFETCH) gmp_fetch<SRC>(a, g, reg, f);
         __syncthreads();
         gmp_deposit<SRC>(g, s, f);
         __syncthreads();
-        if (reg + (int)gridDim.x < g.nregions) gmp_fetch<SRC>(a, g, reg + gridDim.x, f);
+        if (PREFETCH && reg + (int)gridDim.x < g.nregions) gmp_fetch<SRC>(a, g, reg + gridDim.x, f);
         body(reg);
     }
 }
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_fwd_kernel(SeqArgs a, GmpGeom
     const WPtr w = (WPtr)a.params;
     const int ntile = (g.TC + kR - 1) / kR, tiles = g.NI * ntile;
     float2* y2 = reinterpret_cast<float2*>(a.y);
-    gmp_regions<0>(a, g, s, [&](int reg) {
+    gmp_regions<0, true>(a, g, s, [&](int reg) {
         for (int ti = threadIdx.x; ti < tiles; ti += kThreads) {
             const GmpTile L = gmp_locate_tile(a, g, reg, ti, ntile, g.TC);
             float yr[kR], yi[kR];
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(kThreads, 2) void gmp_fwd_kernel(SeqArgs a, GmpGeom
 // FUSED: the whole train step of a region (x, target -> forward -> loss and dy in LDS -> weight gradient): x and target are
 // read once, nothing else touches HBM but the partials row (loss partial in column P).
 template <bool FUSED>
-__global__ __launch_bounds__(kThreads, FUSED ? 2 : 3) void gmp_wgrad_kernel(SeqArgs a, GmpGeom g) {
+__global__ __launch_bounds__(kThreads, 3) void gmp_wgrad_kernel(SeqArgs a, GmpGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GmpLds s(smem, g, true);
     const WPtr w = (WPtr)a.params;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(kThreads, FUSED ? 2 : 3) void gmp_wgrad_kernel(SeqA
     f32x4 acc[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gmp_regions<FUSED ? 2 : 1>(a, g, s, [&](int reg) {
+    gmp_regions<FUSED ? 2 : 1, !FUSED>(a, g, s, [&](int reg) {
         if constexpr (FUSED) {
             // forward of the region; dy = dLoss/dy replaces the staged target in LDS, the loss of the chunk's own samples
             // accumulates per lane
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(kThreads, 3) void gmp_dx_kernel(SeqArgs a, GmpGeom 
     const WPtr w0 = (WPtr)a.params;
     const int nsamp = g.NI * g.TC;
     float2* dx2 = reinterpret_cast<float2*>(a.dx);
-    gmp_regions<1>(a, g, s, [&](int reg) {
+    gmp_regions<1, true>(a, g, s, [&](int reg) {
         for (int idx = threadIdx.x; idx < nsamp; idx += kThreads) {
             const int it = idx / g.TC, off = idx - it * g.TC;
             const int item = reg * g.NI + it;
