@@ -145,6 +145,38 @@ def test_gmp_train_pa_matches_reference_log(workdir):
     assert np.abs(w - wr).max() < 2e-3 * np.abs(wr).max()
 
 
+def test_gmp_as_dpd_of_a_neural_pa_matches_reference(workdir):
+    """the classical use: GMP pre-distorter in front of a frozen GRU PA model — train_dpd (GMP forward, frozen-PA forward + loss +
+    dL/du in one launch, GMP MFMA weight gradient) and run_dpd against the reference's log row, weights and exported CSV
+    (tests/golden/ref_runs_gmp.json, ref_runs_gmp_dpd.npz; oracle/gen_run_anchor_gmp.py)"""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_gmp.json")))
+    m = dict(np.load(os.path.join(GOLDEN, "ref_runs_gmp_dpd.npz")))
+    os.makedirs(os.path.dirname(ref["paths"]["pa_model"]), exist_ok=True)
+    torch.save({k[3:]: torch.from_numpy(v) for k, v in m.items() if k.startswith("pa/")}, ref["paths"]["pa_model"])
+    kw = dict(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=11, DPD_backbone="gmp", DPD_hidden_size=11, frame_length=50,
+              seed=0, accelerator="cuda")
+    res = od.train_dpd(batch_size=64, lr=5e-3, n_epochs=1, **kw)
+    assert os.path.normpath(res["model_path"]) == os.path.normpath(ref["paths"]["dpd_model"])
+    hist = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), "history", os.path.basename(res["log_path"])))
+    rh = ref["train_dpd_hist"]
+    assert list(hist.columns) == list(rh.keys())
+    assert hist["N_PARAM"][0] == rh["N_PARAM"][0] == 1014
+    assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 2e-3 * rh["TRAIN_LOSS"][0]
+    for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_EVM", "TEST_ACLR_AVG"):
+        assert abs(hist[col][0] - rh[col][0]) < 0.05, (col, hist[col][0], rh[col][0])   # dB
+    sd = torch.load(res["model_path"], map_location="cpu")
+    w, wr = sd["backbone.Weight"].numpy(), m["dpd/backbone.Weight"]
+    assert np.abs(w - wr).max() < 3e-3 * np.abs(wr).max()
+    # run_dpd with the REFERENCE's trained GMP weights reproduces its exported CSV
+    torch.save({k[4:]: torch.from_numpy(v) for k, v in m.items() if k.startswith("dpd/")}, ref["paths"]["dpd_model"])
+    out = od.run_dpd(**kw)
+    assert os.path.normpath(out["output_path"]) == os.path.normpath(ref["paths"]["dpd_out"])
+    csv = pd.read_csv(out["output_path"])
+    assert list(csv.columns) == ["I", "Q", "I_dpd", "Q_dpd"]
+    assert np.abs(csv.to_numpy() - m["dpd_out"]).max() < 2e-5
+
+
 @pytest.mark.parametrize("bb,H", [("rvtdcnn", 6), ("deltajanet", 10)])
 def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H):
     """SURVEY §8 f4 names (backbones/extras.py) go through the same Project flow on the GPU: ATen forward/backward,
