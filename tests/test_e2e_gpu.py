@@ -145,6 +145,28 @@ def test_gmp_train_pa_matches_reference_log(workdir):
     assert np.abs(w - wr).max() < 2e-3 * np.abs(wr).max()
 
 
+@pytest.mark.parametrize("name,bb,H,extra", [("lstm", "lstm", 14, {}), ("tcnn", "tcnn", 35, {}), ("deltagru", "deltagru", 15, dict(thx=0.01, thh=0.05))])
+def test_more_backbones_follow_their_reference_logs(workdir, name, bb, H, extra):
+    """two train_pa epochs on DPA_200MHz (frame 50, batch 64, lr 2e-3, seed 0) for the backbones without an anchor of their own,
+    against the rows the REFERENCE logged for the same command (tests/golden/ref_runs_more.json, oracle/gen_run_anchors_more.py).
+    deltagru runs with its thresholds on (thx 0.01, thh 0.05)."""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_more.json")))[name]
+    res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone=bb, PA_hidden_size=H, frame_length=50, batch_size=64, lr=2e-3, n_epochs=2,
+                      seed=0, accelerator="cuda", **extra)
+    assert res["status"] == "completed"
+    assert os.path.normpath(res["model_path"]) == os.path.normpath(ref["model"])
+    hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
+    rh = ref["hist"]
+    assert list(hist.columns) == list(rh.keys())
+    for col in ("N_PARAM", "BATCH_SIZE", "FRAME_LENGTH", "HIDDEN_SIZE", "N_EPOCH", "BACKBONE"):
+        assert list(hist[col]) == rh[col]
+    for ep in range(2):       # measured: TRAIN_LOSS identical to the logged digits, metrics within 2e-4 dB (tcnn), 1e-5 dB (lstm, deltagru)
+        assert abs(hist["TRAIN_LOSS"][ep] - rh["TRAIN_LOSS"][ep]) < 2e-4 * rh["TRAIN_LOSS"][ep], ep
+        for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_EVM", "TEST_ACLR_AVG"):
+            assert abs(hist[col][ep] - rh[col][ep]) < 5e-3, (col, ep, hist[col][ep], rh[col][ep])   # dB
+
+
 def test_gmp_as_dpd_of_a_neural_pa_matches_reference(workdir):
     """the classical use: GMP pre-distorter in front of a frozen GRU PA model — train_dpd (GMP forward, frozen-PA forward + loss +
     dL/du in one launch, GMP MFMA weight gradient) and run_dpd against the reference's log row, weights and exported CSV
