@@ -69,21 +69,26 @@ class DeviceFrameLoader:
 
 
 class ReduceLROnPlateau:
-    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', threshold=1e-4 rel) as configured in project.py:289-296."""
+    """torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', threshold=1e-4, threshold_mode='rel', cooldown=0, eps=1e-8) as
+    configured in project.py:289-296, for optimisers that only expose `param_groups` (FusedAdamW).  Torch's rule is kept to the
+    letter: "better" means metric < best * (1 - threshold) whatever the sign of best — the monitored values are NMSE / ACLR in dB,
+    i.e. negative, where this lets a metric up to 0.01 % WORSE than the best still count as an improvement."""
 
-    def __init__(self, optimizer, factor, patience, min_lr, threshold=1e-4):
-        self.opt, self.factor, self.patience, self.min_lr, self.threshold = optimizer, factor, patience, min_lr, threshold
+    def __init__(self, optimizer, factor, patience, min_lr, threshold=1e-4, eps=1e-8):
+        self.opt, self.factor, self.patience, self.min_lr, self.threshold, self.eps = optimizer, factor, patience, min_lr, threshold, eps
         self.best, self.bad = float("inf"), 0
 
     def step(self, metric):
         metric = float(metric)
-        if metric < self.best * (1 - self.threshold) if self.best > 0 else metric < self.best * (1 + self.threshold):
+        if metric < self.best * (1.0 - self.threshold):
             self.best, self.bad = metric, 0
         else:
             self.bad += 1
         if self.bad > self.patience:
             for g in self.opt.param_groups:
-                g["lr"] = max(g["lr"] * self.factor, self.min_lr)
+                new_lr = max(float(g["lr"]) * self.factor, self.min_lr)
+                if float(g["lr"]) - new_lr > self.eps:
+                    g["lr"] = new_lr
             self.bad = 0
 
 

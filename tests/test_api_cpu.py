@@ -60,3 +60,55 @@ def test_device_frame_loader_matches_reference_dataloader_order():
 def test_cpu_accelerator_is_refused():
     from opendpd_amd.project import Project
     os.environ.pop("OPENDPD_DATASETS", None)
+
+
+def test_lr_scheduler_mirrors_torch_reduce_on_plateau():
+    """project.py:289-296 steps ReduceLROnPlateau(min, factor, patience, threshold 1e-4, min_lr) on NMSE / ACLR in dB — negative
+    numbers, where torch's relative threshold admits slightly worse values as improvements.  Same LR trajectory as torch's class
+    on dB-like, positive and mixed sequences."""
+    import numpy as np
+    import torch
+    from opendpd_amd.project import ReduceLROnPlateau
+
+    class Opt:
+        def __init__(self, lr):
+            self.param_groups = [{"lr": lr}]
+
+    rng = np.random.RandomState(0)
+    seqs = [(-20 - 3 * np.abs(np.sin(np.arange(60) / 3.0)) + 0.002 * rng.randn(60)).tolist(),      # dB plateau with tiny wobble
+            (-25 + 0.0015 * np.arange(40)).tolist(),                                                  # each value < 0.01 % worse
+            np.abs(rng.randn(50)).tolist(), (rng.randn(50) * 0.5).tolist(), [1.0] * 30, [-30.0] * 30]
+    for factor, patience, min_lr in ((0.1, 10, 1e-4), (0.5, 2, 1e-5), (0.3, 0, 1e-3)):
+        for seq in seqs:
+            w = torch.nn.Parameter(torch.zeros(1))
+            topt = torch.optim.SGD([w], lr=5e-3)
+            tsch = torch.optim.lr_scheduler.ReduceLROnPlateau(topt, mode="min", factor=factor, patience=patience, threshold=1e-4,
+                                                              min_lr=min_lr)
+            mine = Opt(5e-3)
+            msch = ReduceLROnPlateau(mine, factor, patience, min_lr)
+            for v in seq:
+                tsch.step(v)
+                msch.step(v)
+                assert mine.param_groups[0]["lr"] == topt.param_groups[0]["lr"], (factor, patience, v)
+
+
+def test_optimizer_choices_follow_the_reference():
+    """project.py:274-287: adam / sgd(momentum 0.9) / rmsprop are torch's classes with torch defaults; adamw is the fused HIP
+    optimiser for kernel-backed models; anything else raises like the reference."""
+    import pytest
+    import torch
+    from types import SimpleNamespace
+    from opendpd_amd import CoreModel
+    from opendpd_amd.project import Project
+    from opendpd_amd.train_funcs import FusedAdamW
+    net = CoreModel(2, 8, 1, "gru")
+    mk = lambda t: SimpleNamespace(opt_type=t, lr=2e-3, decay_factor=0.1, patience=10, lr_end=1e-4)
+    opt, sch = Project.build_optimizer(mk("sgd"), net)
+    assert isinstance(opt, torch.optim.SGD) and opt.param_groups[0]["momentum"] == 0.9 and opt.param_groups[0]["lr"] == 2e-3
+    assert isinstance(Project.build_optimizer(mk("adam"), net)[0], torch.optim.Adam)
+    assert isinstance(Project.build_optimizer(mk("rmsprop"), net)[0], torch.optim.RMSprop)
+    opt, sch = Project.build_optimizer(mk("adamw"), net)
+    assert isinstance(opt, FusedAdamW) and opt.param_groups[0]["lr"] == 2e-3 and opt.param_groups[0]["weight_decay"] == 0.01
+    assert (sch.factor, sch.patience, sch.min_lr) == (0.1, 10, 1e-4)
+    with pytest.raises(RuntimeError):
+        Project.build_optimizer(mk("lion"), net)
