@@ -53,32 +53,39 @@ def load_dataset(dataset_path):
     return dict(zip(keys, D.load_dataset(dataset_path=dataset_path)))
 
 
-def create_dataset(csv_path, output_dir="datasets", dataset_name=None, train_ratio=0.6, val_ratio=0.2, test_ratio=0.2,
-                   dataset_format="single_csv", csv_filename=None, **spec_kwargs):
-    """Import a CSV with columns I_in,Q_in,I_out,Q_out as an OpenDPD dataset directory with a spec.json
-    (opendpd/api.py:316-431).  Returns the dataset directory."""
-    if abs(train_ratio + val_ratio + test_ratio - 1.0) > 1e-6:
-        raise ValueError("train/val/test ratios must sum to 1")
-    df = pd.read_csv(csv_path)
+def create_dataset(csv_path, output_dir, dataset_name, train_ratio=0.6, val_ratio=0.2, test_ratio=0.2, dataset_format="single_csv",
+                   csv_filename=None, **spec_kwargs):
+    """Import a CSV with columns I_in,Q_in,I_out,Q_out as an OpenDPD dataset directory with a spec.json — the same files, byte for
+    byte, as opendpd/api.py:316-431 writes (spec key order and defaults `nperseg` 2560 / `n_sub_ch` 1, `split_indices` of the
+    single-CSV layout, column names of the six-file layout, no check that the ratios add up).  Returns the resolved directory."""
+    fmt = dataset_format.lower()
+    if fmt not in ("single_csv", "split_csv"):
+        raise ValueError("dataset_format must be 'single_csv' or 'split_csv'")
+    out = os.path.realpath(os.path.join(os.path.expanduser(str(output_dir)), dataset_name))
+    os.makedirs(out, exist_ok=True)
+    df = pd.read_csv(os.path.expanduser(str(csv_path)))
     need = ["I_in", "Q_in", "I_out", "Q_out"]
     if not all(c in df.columns for c in need):
         raise ValueError(f"CSV must contain columns: {need}. Found: {df.columns.tolist()}")
-    name = dataset_name or os.path.splitext(os.path.basename(csv_path))[0]
-    out = os.path.join(output_dir, name)
-    os.makedirs(out, exist_ok=True)
-    spec = {"dataset_format": dataset_format, "split_ratios": {"train": train_ratio, "val": val_ratio, "test": test_ratio}}
-    spec.update(spec_kwargs)
-    if dataset_format == "single_csv":
-        fname = csv_filename or "data.csv"
-        df.to_csv(os.path.join(out, fname), index=False)
-        spec["csv_filename"] = fname
+    n_train, n_val = int(len(df) * train_ratio), int(len(df) * val_ratio)
+    parts = {"train": df.iloc[:n_train], "val": df.iloc[n_train:n_train + n_val], "test": df.iloc[n_train + n_val:]}
+    spec = {"split_ratios": {"train": train_ratio, "val": val_ratio, "test": test_ratio}, "nperseg": 2560, "n_sub_ch": 1}
+    if fmt == "split_csv":
+        for split, part in parts.items():
+            part[["I_in", "Q_in"]].to_csv(os.path.join(out, f"{split}_input.csv"), index=False)
+            part[["I_out", "Q_out"]].to_csv(os.path.join(out, f"{split}_output.csv"), index=False)
     else:
-        n, a = len(df), int(len(df) * train_ratio)
-        b = a + int(n * val_ratio)
-        for split, part in (("train", df.iloc[:a]), ("val", df.iloc[a:b]), ("test", df.iloc[b:])):
-            part[["I_in", "Q_in"]].rename(columns={"I_in": "I", "Q_in": "Q"}).to_csv(os.path.join(out, f"{split}_input.csv"), index=False)
-            part[["I_out", "Q_out"]].rename(columns={"I_out": "I", "Q_out": "Q"}).to_csv(os.path.join(out, f"{split}_output.csv"), index=False)
-    json.dump(spec, open(os.path.join(out, "spec.json"), "w"), indent=4)
+        csv_filename = csv_filename or "data.csv"
+        pd.concat(list(parts.values()), axis=0).to_csv(os.path.join(out, csv_filename), index=False)
+        spec["csv_filename"] = csv_filename
+        spec["split_indices"] = {"train_end": len(parts["train"]), "val_end": len(parts["train"]) + len(parts["val"])}
+    spec.update(spec_kwargs)
+    spec["dataset_format"] = fmt
+    with open(os.path.join(out, "spec.json"), "w") as f:
+        json.dump(spec, f, indent=4)
+    print(f"Dataset created successfully at: {out}")
+    for label, split in (("Training", "train"), ("Validation", "val"), ("Test", "test")):
+        print(f"  - {label} samples: {len(parts[split])}")
     return out
 
 

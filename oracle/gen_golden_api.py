@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Wire-format vectors of opendpd.api.create_dataset (TEST INFRASTRUCTURE — build container only): runs the reference's function
+(opendpd/api.py:316-431, loaded from /root/reference) on a small seeded CSV for both layouts and stores every file it wrote as
+text, plus what its load_dataset returns (tests/golden/create_dataset_ref.json).  Usage: python oracle/gen_golden_api.py"""
+import importlib.util
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pandas as pd
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+KW = dict(train_ratio=0.55, val_ratio=0.25, test_ratio=0.2, input_signal_fs=800e6, bw_main_ch=200e6, n_sub_ch=10)
+
+
+def main():
+    spec = importlib.util.spec_from_file_location("ref_api", os.path.join(REF, "opendpd", "api.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.RandomState(0)
+    df = pd.DataFrame(rng.randn(23, 4), columns=["I_in", "Q_in", "I_out", "Q_out"])
+    out = {"csv": df.to_csv(index=False), "kwargs": KW, "cases": {}}
+    with tempfile.TemporaryDirectory() as tmp:
+        open(os.path.join(tmp, "in.csv"), "w").write(out["csv"])
+        for name, extra in (("single_csv", {}), ("split_csv", {}), ("single_named", {"dataset_format": "SINGLE_CSV", "csv_filename": "pa.csv"}),
+                            ("defaults", None)):
+            kw = {**dict(dataset_format=name), **KW, **extra} if extra is not None else {}
+            d = ref.create_dataset(os.path.join(tmp, "in.csv"), os.path.join(tmp, name), "MyPA", **kw)
+            loaded = ref.load_dataset(d)
+            out["cases"][name] = {"kwargs": kw, "files": {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d))},
+                                  "loaded": {k: np.asarray(v).tolist() for k, v in loaded.items()}}
+    json.dump(out, open(os.path.join(OUT, "create_dataset_ref.json"), "w"), indent=1)
+    print({k: sorted(v["files"]) for k, v in out["cases"].items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -21,20 +21,33 @@ def test_api_argument_contract():
         od.run_dpd()
 
 
-def test_create_and_load_dataset(tmp_path):
+def test_create_and_load_dataset_write_the_reference_files(tmp_path, capsys):
+    """opendpd.api.create_dataset / load_dataset (api.py:263-431): every file byte for byte what the REFERENCE's function wrote for
+    the same CSV and arguments (tests/golden/create_dataset_ref.json, oracle/gen_golden_api.py) — spec.json key order, defaults and
+    split_indices, column names of the six-file layout, case-insensitive format name — and the same six arrays loaded back."""
+    import json
+    import os
     import opendpd_amd as od
-    rng = np.random.RandomState(0)
-    df = pd.DataFrame(rng.randn(100, 4), columns=["I_in", "Q_in", "I_out", "Q_out"])
-    csv = tmp_path / "mypa.csv"
-    df.to_csv(csv, index=False)
-    for fmt in ("single_csv", "split_csv"):
-        p = od.create_dataset(str(csv), output_dir=str(tmp_path / fmt), dataset_name="MyPA", dataset_format=fmt,
-                              input_signal_fs=800e6, bw_main_ch=200e6, n_sub_ch=10, nperseg=16)
-        d = od.load_dataset(p)
-        assert d["X_train"].shape == (60, 2) and d["X_val"].shape == (20, 2) and d["y_test"].shape == (20, 2)
-        assert np.allclose(d["X_train"], df[["I_in", "Q_in"]].to_numpy()[:60])
+    from tests.golden_util import GOLDEN
+    ref = json.load(open(os.path.join(GOLDEN, "create_dataset_ref.json")))
+    csv = tmp_path / "in.csv"
+    csv.write_text(ref["csv"])
+    for name, case in ref["cases"].items():
+        d = od.create_dataset(str(csv), str(tmp_path / name), "MyPA", **case["kwargs"])
+        assert d == os.path.realpath(str(tmp_path / name / "MyPA"))
+        assert sorted(os.listdir(d)) == sorted(case["files"])
+        for f, text in case["files"].items():
+            assert open(os.path.join(d, f)).read() == text, (name, f)
+        loaded = od.load_dataset(d)
+        assert list(loaded) == list(case["loaded"])
+        for k, v in case["loaded"].items():
+            assert np.array_equal(np.asarray(loaded[k]), np.asarray(v)), (name, k)
+    assert "Dataset created successfully at:" in capsys.readouterr().out
     with pytest.raises(ValueError):
-        od.create_dataset(str(csv), train_ratio=0.5, val_ratio=0.2, test_ratio=0.2)
+        od.create_dataset(str(csv), str(tmp_path / "x"), "MyPA", dataset_format="parquet")
+    pd.DataFrame(np.zeros((4, 2)), columns=["I", "Q"]).to_csv(tmp_path / "bad.csv", index=False)
+    with pytest.raises(ValueError):
+        od.create_dataset(str(tmp_path / "bad.csv"), str(tmp_path / "y"), "MyPA")
 
 
 def test_device_frame_loader_matches_reference_dataloader_order():
