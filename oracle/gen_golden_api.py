@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Wire-format vectors of opendpd.api.create_dataset (TEST INFRASTRUCTURE — build container only): runs the reference's function
 (opendpd/api.py:316-431, loaded from /root/reference) on a small seeded CSV for both layouts and stores every file it wrote as
-text, plus what its load_dataset returns (tests/golden/create_dataset_ref.json).  Usage: python oracle/gen_golden_api.py"""
+text, plus what its load_dataset returns (tests/golden/create_dataset_ref.json); also the argparse defaults of arguments.py
+(tests/golden/argument_defaults.json).  Usage: python oracle/gen_golden_api.py"""
 import importlib.util
 import json
 import os
@@ -35,6 +36,10 @@ def main():
             out["cases"][name] = {"kwargs": kw, "files": {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d))},
                                   "loaded": {k: np.asarray(v).tolist() for k, v in loaded.items()}}
     json.dump(out, open(os.path.join(OUT, "create_dataset_ref.json"), "w"), indent=1)
+    # argparse defaults of the reference's CLI (arguments.py:8-89), what `Project` falls back to
+    sys.argv = ["main.py"]
+    import arguments
+    json.dump(vars(arguments.get_arguments()), open(os.path.join(OUT, "argument_defaults.json"), "w"), indent=1, sort_keys=True)
     print({k: sorted(v["files"]) for k, v in out["cases"].items()})
 
 

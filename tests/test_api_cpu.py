@@ -125,3 +125,15 @@ def test_optimizer_choices_follow_the_reference():
     assert (sch.factor, sch.patience, sch.min_lr) == (0.1, 10, 1e-4)
     with pytest.raises(RuntimeError):
         Project.build_optimizer(mk("lion"), net)
+
+
+def test_project_defaults_equal_the_reference_cli_defaults():
+    """arguments.py:8-89 (values and types), captured by oracle/gen_golden_api.py"""
+    import json
+    import os
+    from opendpd_amd.project import DEFAULTS
+    from tests.golden_util import GOLDEN
+    ref = json.load(open(os.path.join(GOLDEN, "argument_defaults.json")))
+    assert sorted(ref) == sorted(DEFAULTS)
+    for k, v in ref.items():
+        assert DEFAULTS[k] == v and type(DEFAULTS[k]) is type(v), (k, DEFAULTS[k], v)
