@@ -38,12 +38,10 @@ def train_dpd(dataset_name=None, dataset_path=None, DPD_backbone="deltagru_tcnsk
     return {"status": "completed", "model_path": proj.path_save_file_best, "log_path": proj.path_log_file_best}
 
 
-def run_dpd(dataset_name=None, dataset_path=None, DPD_backbone="deltagru_tcnskip", DPD_hidden_size=15, PA_backbone="gru",
-            PA_hidden_size=23, accelerator="cpu", frame_length=200, seed=0, **kwargs):
+def run_dpd(dataset_name=None, dataset_path=None, DPD_backbone="deltagru_tcnskip", DPD_hidden_size=15, accelerator="cpu", **kwargs):
     _need_name("run_dpd", dataset_name, dataset_path)
     proj = Project(step="run_dpd", dataset_name=dataset_name, DPD_backbone=DPD_backbone, DPD_hidden_size=DPD_hidden_size,
-                   PA_backbone=PA_backbone, PA_hidden_size=PA_hidden_size, accelerator=accelerator, frame_length=frame_length,
-                   seed=seed, **kwargs)
+                   accelerator=accelerator, **kwargs)
     return {"status": "completed", "output_path": run_run_dpd(proj)}
 
 
@@ -90,25 +88,38 @@ def create_dataset(csv_path, output_dir, dataset_name, train_ratio=0.6, val_rati
 
 
 class OpenDPDTrainer:
-    """Convenience wrapper holding a configuration (opendpd/api.py:434-503)."""
+    """Object-style front end (opendpd/api.py:434-503): a stored configuration merged under per-call keyword arguments;
+    `train_dpd` trains the PA first when that has not happened yet, `run` refuses before `train_dpd`."""
 
-    def __init__(self, dataset_name=None, dataset_path=None, accelerator="cpu", **config):
-        self.dataset_name, self.dataset_path, self.accelerator, self.config = dataset_name, dataset_path, accelerator, config
-        self.results = {}
+    def __init__(self, dataset_name=None, dataset_path=None, **kwargs):
+        self.dataset_name = dataset_name
+        self.dataset_path = dataset_path
+        self.config = kwargs
+        self.pa_trained = False
+        self.dpd_trained = False
 
-    def _kw(self, extra):
-        kw = dict(self.config)
-        kw.update(extra)
-        return kw
+    def _config(self, kwargs):
+        config = {**self.config, **kwargs}
+        if self.dataset_name:
+            config["dataset_name"] = self.dataset_name
+        elif self.dataset_path:
+            config["dataset_path"] = self.dataset_path
+        return config
 
-    def train_pa(self, **kw):
-        self.results["pa"] = train_pa(dataset_name=self.dataset_name, dataset_path=self.dataset_path, accelerator=self.accelerator, **self._kw(kw))
-        return self.results["pa"]
+    def train_pa(self, **kwargs):
+        result = train_pa(**self._config(kwargs))
+        self.pa_trained = True
+        return result
 
-    def train_dpd(self, **kw):
-        self.results["dpd"] = train_dpd(dataset_name=self.dataset_name, dataset_path=self.dataset_path, accelerator=self.accelerator, **self._kw(kw))
-        return self.results["dpd"]
+    def train_dpd(self, **kwargs):
+        if not self.pa_trained:
+            print("Warning: PA model not trained yet. Training PA model first...")
+            self.train_pa()
+        result = train_dpd(**self._config(kwargs))
+        self.dpd_trained = True
+        return result
 
-    def run_dpd(self, **kw):
-        self.results["run"] = run_dpd(dataset_name=self.dataset_name, dataset_path=self.dataset_path, accelerator=self.accelerator, **self._kw(kw))
-        return self.results["run"]
+    def run(self, **kwargs):
+        if not self.dpd_trained:
+            raise RuntimeError("DPD model not trained yet. Call train_dpd() first.")
+        return run_dpd(**self._config(kwargs))

@@ -2,7 +2,7 @@
 """Wire-format vectors of opendpd.api.create_dataset (TEST INFRASTRUCTURE — build container only): runs the reference's function
 (opendpd/api.py:316-431, loaded from /root/reference) on a small seeded CSV for both layouts and stores every file it wrote as
 text, plus what its load_dataset returns (tests/golden/create_dataset_ref.json); also the argparse defaults of arguments.py
-(tests/golden/argument_defaults.json).  Usage: python oracle/gen_golden_api.py"""
+(tests/golden/argument_defaults.json) and the call signatures of the public API (tests/golden/api_signatures.json).  Usage: python oracle/gen_golden_api.py"""
 import importlib.util
 import json
 import os
@@ -36,6 +36,13 @@ def main():
             out["cases"][name] = {"kwargs": kw, "files": {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d))},
                                   "loaded": {k: np.asarray(v).tolist() for k, v in loaded.items()}}
     json.dump(out, open(os.path.join(OUT, "create_dataset_ref.json"), "w"), indent=1)
+    # call signatures of the public API (opendpd/api.py): parameter names, order, defaults, kinds
+    import inspect
+    sig = lambda f: [[n, None if q.default is inspect._empty else q.default, str(q.kind)] for n, q in inspect.signature(f).parameters.items()]
+    sigs = {n: sig(getattr(ref, n)) for n in ("train_pa", "train_dpd", "run_dpd", "load_dataset", "create_dataset")}
+    sigs.update({"OpenDPDTrainer." + n: sig(getattr(ref.OpenDPDTrainer, n)) for n in ("__init__", "train_pa", "train_dpd", "run")})
+    sigs["OpenDPDTrainer.public"] = [n for n in dir(ref.OpenDPDTrainer) if not n.startswith("_")]
+    json.dump(sigs, open(os.path.join(OUT, "api_signatures.json"), "w"), indent=1)
     # argparse defaults of the reference's CLI (arguments.py:8-89), what `Project` falls back to
     sys.argv = ["main.py"]
     import arguments

@@ -137,3 +137,45 @@ def test_project_defaults_equal_the_reference_cli_defaults():
     assert sorted(ref) == sorted(DEFAULTS)
     for k, v in ref.items():
         assert DEFAULTS[k] == v and type(DEFAULTS[k]) is type(v), (k, DEFAULTS[k], v)
+
+
+def test_public_api_signatures_equal_the_reference():
+    """opendpd/api.py: same parameter names, order, defaults and kinds (a positional call binds the same way), same public
+    methods on OpenDPDTrainer — captured from the reference by oracle/gen_golden_api.py"""
+    import inspect
+    import json
+    import os
+    import opendpd_amd.api as api
+    from tests.golden_util import GOLDEN
+    ref = json.load(open(os.path.join(GOLDEN, "api_signatures.json")))
+    sig = lambda f: [[n, None if q.default is inspect._empty else q.default, str(q.kind)] for n, q in inspect.signature(f).parameters.items()]
+    for name, want in ref.items():
+        if name == "OpenDPDTrainer.public":
+            assert [n for n in dir(api.OpenDPDTrainer) if not n.startswith("_")] == want
+            continue
+        obj = api
+        for part in name.split("."):
+            obj = getattr(obj, part)
+        assert sig(obj) == want, name
+
+
+def test_trainer_object_follows_the_reference_flow(monkeypatch, capsys):
+    """api.py:449-503: stored config under per-call kwargs, dataset_name wins over dataset_path, train_dpd trains the PA first,
+    run() refuses before train_dpd"""
+    import opendpd_amd.api as api
+    calls = []
+    monkeypatch.setattr(api, "train_pa", lambda **kw: calls.append(("pa", kw)) or {"status": "completed"})
+    monkeypatch.setattr(api, "train_dpd", lambda **kw: calls.append(("dpd", kw)) or {"status": "completed"})
+    monkeypatch.setattr(api, "run_dpd", lambda **kw: calls.append(("run", kw)) or {"status": "completed"})
+    t = api.OpenDPDTrainer(dataset_name="DS", dataset_path="/x", n_epochs=3, lr=1e-3)
+    with pytest.raises(RuntimeError):
+        t.run()
+    t.train_dpd(lr=2e-3, DPD_backbone="gmp")
+    assert "PA model not trained yet" in capsys.readouterr().out
+    assert calls[0] == ("pa", {"n_epochs": 3, "lr": 1e-3, "dataset_name": "DS"})
+    assert calls[1] == ("dpd", {"n_epochs": 3, "lr": 2e-3, "DPD_backbone": "gmp", "dataset_name": "DS"})
+    t.run(accelerator="cuda")
+    assert calls[2] == ("run", {"n_epochs": 3, "lr": 1e-3, "accelerator": "cuda", "dataset_name": "DS"})
+    t2 = api.OpenDPDTrainer(dataset_path="/x")
+    t2.train_pa()
+    assert calls[3] == ("pa", {"dataset_path": "/x"}) and t2.pa_trained and not t2.dpd_trained
