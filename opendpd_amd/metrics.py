@@ -28,9 +28,10 @@ def EVM(prediction, ground_truth, sample_rate=int(800e6), bw_main_ch=200e6, n_su
     freq = np.fft.fftshift(np.fft.fftfreq(prediction.shape[1], d=1 / sample_rate))
     lo, _, w = _main_channel_bins(freq, bw_main_ch, n_sub_ch)
     err = np.zeros((prediction.shape[0], n_sub_ch))
-    for c in range(n_sub_ch):
+    for c in range(n_sub_ch):      # as metrics.py:92-103: the complex64 means land in the float64 array BEFORE the division
         sl = slice(lo + c * w, lo + (c + 1) * w)
-        err[:, c] = np.mean(np.abs(sp[:, sl] - sg[:, sl]), axis=-1) / np.mean(np.abs(sg[:, sl]), axis=-1)
+        err[:, c] = np.mean(np.abs(sp[:, sl] - sg[:, sl]), axis=-1)
+        err[:, c] = err[:, c] / np.mean(np.abs(sg[:, sl]), axis=-1)
     return 20 * np.log10(np.mean(err.mean(axis=-1)))
 
 
@@ -48,7 +49,9 @@ def ACLR(prediction, fs=800e6, nperseg=2560, bw_main_ch=200e6, n_sub_ch=10):
     """(left, right) adjacent-channel power relative to the strongest main sub-channel, in dB."""
     freq, psd = power_spectrum(IQ_to_complex(prediction), fs=fs, nperseg=nperseg, axis=-1)
     lo, hi, w = _main_channel_bins(freq, bw_main_ch, n_sub_ch)
-    sub = np.array([np.sum(psd[lo + c * w:lo + (c + 1) * w]) for c in range(n_sub_ch)])
+    sub = np.zeros(n_sub_ch)       # float64 like metrics.py:137-141: the ratio and its log are then taken in double
+    for c in range(n_sub_ch):
+        sub[c] = np.sum(psd[lo + c * w:lo + (c + 1) * w])
     ref = sub.max()
     left = np.mean(10 * np.log10(np.sum(psd[lo - w:lo]) / ref))
     right = np.mean(10 * np.log10(np.sum(psd[hi:hi + w]) / ref))

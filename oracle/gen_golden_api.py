@@ -36,6 +36,25 @@ def main():
             out["cases"][name] = {"kwargs": kw, "files": {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d))},
                                   "loaded": {k: np.asarray(v).tolist() for k, v in loaded.items()}}
     json.dump(out, open(os.path.join(OUT, "create_dataset_ref.json"), "w"), indent=1)
+    # utils/metrics.py on seeded random segments (inputs are re-drawn from the seed by the test): exact values as float.hex()
+    from utils import metrics as rm
+    cases = []
+    for trial in range(24):
+        rng = np.random.RandomState(1000 + trial)
+        nseg, n = int(rng.randint(1, 4)), int(rng.choice([256, 512, 1000, 2560]))
+        nperseg = int(rng.choice([64, 128, 256, n])) if trial % 2 else n
+        dt = "float32" if trial % 3 else "float64"
+        pred = (rng.randn(nseg, n, 2) * 0.3).astype(dt)
+        truth = (pred + 0.05 * rng.randn(nseg, n, 2)).astype(dt)
+        fs, bw, nsub = float(rng.choice([800e6, 983.04e6])), float(rng.choice([100e6, 200e6])), int(rng.choice([1, 2, 5, 10]))
+        if n != nperseg:
+            vals = (rm.NMSE(pred, truth), *rm.ACLR(pred, fs=fs, nperseg=nperseg, bw_main_ch=bw, n_sub_ch=nsub))
+        else:
+            vals = (rm.NMSE(pred, truth), *rm.ACLR(pred, fs=fs, nperseg=nperseg, bw_main_ch=bw, n_sub_ch=nsub),
+                    rm.EVM(pred, truth, bw_main_ch=bw, n_sub_ch=nsub, nperseg=nperseg))
+        cases.append({"seed": 1000 + trial, "trial": trial, "fs": fs, "bw": bw, "nsub": nsub, "nperseg": nperseg,
+                      "values": [float(v).hex() for v in vals], "types": [type(v).__name__ for v in vals]})
+    json.dump(cases, open(os.path.join(OUT, "metrics_exact.json"), "w"), indent=1)
     # call signatures of the public API (opendpd/api.py): parameter names, order, defaults, kinds
     import inspect
     sig = lambda f: [[n, None if q.default is inspect._empty else q.default, str(q.kind)] for n, q in inspect.signature(f).parameters.items()]

@@ -51,3 +51,27 @@ def test_dataset_level_known_answers():
         al, ar = metrics.ACLR(pred, fs=spec["input_signal_fs"], nperseg=spec["nperseg"], bw_main_ch=spec["bw_main_ch"],
                               n_sub_ch=spec["n_sub_ch"])
         assert abs(al - ref["ACLR_L"]) < 1e-5 and abs(ar - ref["ACLR_R"]) < 1e-5   # float32 spectra
+
+
+def test_metrics_are_bit_identical_with_the_reference():
+    """utils/metrics.py:42-187 on seeded random segments (float32 and float64 inputs, 1..10 sub-channels, Welch segments shorter
+    than the record): the same doubles and the same numpy scalar types as the REFERENCE's functions returned
+    (tests/golden/metrics_exact.json, oracle/gen_golden_api.py) — the history CSV prints them with 8 decimals."""
+    import json
+    import os
+    from opendpd_amd import metrics as M
+    from tests.golden_util import GOLDEN
+    for c in json.load(open(os.path.join(GOLDEN, "metrics_exact.json"))):
+        trial = c["trial"]
+        rng = np.random.RandomState(c["seed"])
+        nseg, n = int(rng.randint(1, 4)), int(rng.choice([256, 512, 1000, 2560]))
+        nperseg = int(rng.choice([64, 128, 256, n])) if trial % 2 else n
+        dt = "float32" if trial % 3 else "float64"
+        pred = (rng.randn(nseg, n, 2) * 0.3).astype(dt)
+        truth = (pred + 0.05 * rng.randn(nseg, n, 2)).astype(dt)
+        assert nperseg == c["nperseg"]
+        vals = [M.NMSE(pred, truth), *M.ACLR(pred, fs=c["fs"], nperseg=nperseg, bw_main_ch=c["bw"], n_sub_ch=c["nsub"])]
+        if n == nperseg:
+            vals.append(M.EVM(pred, truth, bw_main_ch=c["bw"], n_sub_ch=c["nsub"], nperseg=nperseg))
+        assert [float(v).hex() for v in vals] == c["values"], c
+        assert [type(v).__name__ for v in vals] == c["types"], c
