@@ -73,7 +73,7 @@ def load_dataset(dataset_name=None, dataset_path=None):
 
 def set_target_gain(x, y):
     amp = lambda v: np.sqrt(v[:, 0] ** 2 + v[:, 1] ** 2)
-    return float(np.mean(np.max(amp(y)) / np.max(amp(x))))
+    return np.mean(np.max(amp(y)) / np.max(amp(x)))      # a numpy scalar of the data's dtype, as utils/util.py:26-33 returns
 
 
 def frames(sequence, frame_length, stride=1):
