@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .backbones.native import NativeBackbone, init_gatewise
 from .models import CoreModel
 
@@ -27,6 +28,7 @@ class _QScale(nn.Module):
         self.register_buffer("pow2_scale", torch.Tensor([0.0]))
         self.register_buffer("decimal_num", torch.Tensor([1.0]))
         self.register_buffer("integer_num", torch.Tensor([bits - 1 - 1.0]))
+        self.exercised = False          # has a forward gone through this quantiser (see QuantQGRU.sync_mode)
 
     def refresh(self):
         """What INT_Quantizer.forward does to its buffers when the rounded exponent changes (quantizers.py:67-71)."""
@@ -93,12 +95,27 @@ class QuantQGRU(NativeBackbone):
         self._names = names
 
     def forward(self, x, h_0=None):
-        self.desc.flags = 0 if self.training else 1                  # ODPD_FLAG_EVAL: 16-bit output quantiser in eval only
+        self.sync_mode()
         return super().forward(x, h_0)
 
-    def refresh_buffers(self):
-        for m in self.modules():
+    def sync_mode(self):
+        """Before every kernel call on this model (autograd path and the direct-ABI train steps alike): the descriptor's
+        ODPD_FLAG_EVAL follows the module's mode — fc_out's 16-bit output quantiser is active in eval only
+        (quant_layers.py:77-80) — and the quantisers this call exercises are remembered for the checkpoint buffers."""
+        self.desc.flags = (self.desc.flags & ~_lib.FLAG_EVAL) | (0 if self.training else _lib.FLAG_EVAL)
+        for name, m in self.named_modules():
             if isinstance(m, _QScale):
+                # x2h / h2h never use their out_quantizer (out_quant is False there), fc_out's runs in eval mode only
+                if not name.endswith("out_quantizer") or (name == "fc_out.out_quantizer" and not self.training):
+                    m.exercised = True
+
+    def refresh_buffers(self):
+        """pow2_scale / decimal_num / integer_num are side effects of INT_Quantizer.forward (quantizers.py:67-71): a quantiser that
+        no forward has exercised keeps its construction-time values, as in the reference's checkpoints.  (They are refreshed
+        here, from the current scale, rather than at the forward itself — which would cost a device sync per step; the two
+        differ only if the rounded exponent flips between the last forward and the save.)"""
+        for m in self.modules():
+            if isinstance(m, _QScale) and m.exercised:
                 m.refresh()
 
     def state_dict(self, *args, **kwargs):

@@ -305,6 +305,9 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
         dpd.desc.flags &= ~_lib.FLAG_NEED_DX
     if pa is not None and pa.dx_needs_flag:
         pa.desc.flags |= _lib.FLAG_NEED_DX
+    for bb in (dpd, pa):       # quantised models: train / eval mode of the module -> ODPD_FLAG_EVAL (an evaluation pass may have left it set)
+        if hasattr(bb, "sync_mode"):
+            bb.sync_mode()
     buf = opt.cascade_buffers(B, T, x.device)
     part = opt.bwd_partials(B, T, x.device)
     st = _lib.stream_ptr()

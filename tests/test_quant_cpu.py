@@ -27,9 +27,7 @@ def test_quant_state_dict_matches_reference_bitwise():
         sd = q.state_dict()
         ref_keys = fx.keys("sd")
         assert list(sd.keys()) == ref_keys
-        for k in ref_keys:
-            if "pow2_scale" in k or "decimal_num" in k or "integer_num" in k:
-                continue     # side-effect buffers: the reference fills them during its first forward
+        for k in ref_keys:      # side-effect buffers included: no forward has run yet, they hold their construction-time values
             assert np.array_equal(sd[k].numpy(), fx["sd/" + k]), k
         assert sum(p.numel() for p in q.parameters()) == fx.meta["n_param"]
 

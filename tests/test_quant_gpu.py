@@ -127,3 +127,40 @@ def test_w8a8_input_gradient_matches_oracle(bb, H, B, T):
     xt2 = torch.from_numpy(x).cuda().requires_grad_(True)
     q(xt2).backward(torch.from_numpy(dy).cuda())
     assert rel_err(xt2.grad.cpu().numpy(), dxo) < 2e-5
+
+
+def test_checkpoint_buffers_and_mode_flag_follow_the_reference():
+    """(1) pow2_scale / decimal_num / integer_num are side effects of the reference's quantiser forwards: after training steps plus a
+    train-mode and an eval-mode forward every exercised quantiser holds its refreshed values, the never-used x2h / h2h
+    out_quantizers keep (0, 1, 14) — the whole state dict equals the reference's `sd3` fixture, buffers included.
+    (2) an evaluation pass must not leave ODPD_FLAG_EVAL behind for the next direct-ABI train step: a model that was evaluated
+    between two steps ends up bit-identical with one that was not."""
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    fx = Fixture("quant_qgru_h10_w8a8")
+    x, t = torch.from_numpy(fx["x"]).cuda(), torch.from_numpy(fx["tgt"]).cuda()
+    nets = []
+    for evaluate_between in (False, True):
+        q = _qmodel(fx, "qgru", 8)
+        opt = FusedAdamW(q, lr=fx.meta["lr"])
+        q.train()
+        for s in range(3):
+            fused_train_step(opt, x, t, "l2", fx.meta["clip"])
+            if evaluate_between:
+                q.eval()
+                with torch.no_grad():
+                    q(x)
+                q.train()
+        nets.append(q)
+    a, b = nets[0].backbone.flat_params(), nets[1].backbone.flat_params()
+    assert torch.equal(a, b)
+    q = nets[0]
+    sd_train_only = {k: v.cpu().numpy() for k, v in q.state_dict().items()}
+    assert sd_train_only["backbone.fc_out.out_quantizer.decimal_num"][0] == 1.0          # eval has not run on this one yet
+    assert sd_train_only["backbone.fc_out.weight_quantizer.decimal_num"][0] == 6.0
+    q.eval()
+    with torch.no_grad():
+        q(x)
+    sd = q.state_dict()
+    for k in fx.keys("sd3"):
+        tol = 0 if ("_num" in k or "pow2" in k or "n_bits" in k) else 3e-5
+        assert np.abs(sd[k].cpu().numpy() - fx["sd3/" + k]).max() <= tol * max(1.0, np.abs(fx["sd3/" + k]).max()), k
