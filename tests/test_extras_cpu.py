@@ -42,7 +42,7 @@ def test_forward_backward_match_reference(bb, H):
     y = net(x)
     assert rel_err(y.detach().numpy(), fx["y"]) < TOL
     loss = torch.nn.functional.mse_loss(y, torch.from_numpy(fx["tgt"]))
-    assert abs(float(loss) - fx.meta["loss"]) < 1e-6 * max(1.0, fx.meta["loss"])
+    assert abs(float(loss.detach()) - fx.meta["loss"]) < 1e-6 * max(1.0, fx.meta["loss"])
     loss.backward()
     for k, p in net.named_parameters():
         assert rel_err(p.grad.numpy(), fx["g/" + k]) < 10 * TOL, k
