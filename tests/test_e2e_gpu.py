@@ -201,6 +201,28 @@ def test_gmp_as_dpd_of_a_neural_pa_matches_reference(workdir):
     assert np.abs(csv.to_numpy() - m["dpd_out"]).max() < 2e-5
 
 
+def test_thresholded_dpd_two_epochs_match_reference_incl_sparsity_columns(workdir):
+    """train_dpd of the TRes-DeltaGRU (thx 0.01, thh 0.05) for TWO epochs: the temporal-sparsity columns come from counters that
+    the training AND the evaluation forwards feed and that are read (and reset) once per epoch (paths.py:49-59) — bookkeeping a
+    one-epoch run cannot pin.  Anchor: tests/golden/ref_runs_delta2.json (oracle/gen_run_anchor_delta2.py)."""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_delta2.json")))
+    pa = dict(np.load(os.path.join(GOLDEN, "ref_runs_delta2_pa.npz")))
+    os.makedirs(os.path.dirname(ref["pa_model"]), exist_ok=True)
+    torch.save({k: torch.from_numpy(v) for k, v in pa.items()}, ref["pa_model"])
+    res = od.train_dpd(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=11, DPD_backbone="deltagru_tcnskip", DPD_hidden_size=15,
+                       frame_length=50, seed=0, accelerator="cuda", batch_size=64, lr=1e-3, n_epochs=2, thx=0.01, thh=0.05)
+    assert os.path.normpath(res["model_path"]) == os.path.normpath(ref["dpd_model"])
+    hist = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), "history", os.path.basename(res["log_path"])))
+    rh = ref["hist"]
+    assert list(hist.columns) == list(rh.keys())
+    for ep in range(2):       # measured: loss equal to the logged digits, sparsity 2e-6, HW_PARAM 1e-3, NMSE 2e-3 dB, ACLR 0.09 dB
+        assert abs(hist["TRAIN_LOSS"][ep] - rh["TRAIN_LOSS"][ep]) < 1e-3 * rh["TRAIN_LOSS"][ep], ep
+        for col, tol in (("SP_T_DX", 1e-4), ("SP_T_DH", 1e-4), ("SP_T_DV", 1e-4), ("HW_PARAM", 0.05), ("VAL_NMSE", 0.05), ("TEST_NMSE", 0.05),
+                         ("VAL_ACLR_AVG", 0.3), ("TEST_ACLR_AVG", 0.3)):
+            assert abs(hist[col][ep] - rh[col][ep]) < tol, (col, ep, hist[col][ep], rh[col][ep])
+
+
 def test_quantised_flow_two_epochs_and_run_dpd_match_reference(workdir):
     """--quant --n_bits_w 8 --n_bits_a 8 --quant_dir_label w8a8 on DPA_200MHz: two train_dpd epochs of the QAT QGRU H10 in front of
     the reference's GRU PA (the second epoch trains AFTER an evaluation pass: the eval-only output quantiser must be off again), the
