@@ -201,6 +201,23 @@ def test_gmp_as_dpd_of_a_neural_pa_matches_reference(workdir):
     assert np.abs(csv.to_numpy() - m["dpd_out"]).max() < 2e-5
 
 
+def test_lr_schedule_run_matches_reference_log(workdir):
+    """--lr_schedule 1 --patience 0 --decay_factor 0.5 --lr_end 1e-3 at lr 5e-2 (eight train_pa epochs, gru H11): ReduceLROnPlateau on
+    the validation NMSE halves the rate after the third epoch in the reference's log; the LR column (logged before the scheduler
+    steps, project.py:343-362) and the trajectory must follow (tests/golden/ref_runs_lrsched.json, oracle/gen_run_anchor_lrsched.py)."""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_lrsched.json")))["hist"]
+    res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=11, frame_length=50, batch_size=64, lr=5e-2, lr_schedule=1,
+                      patience=0, decay_factor=0.5, lr_end=1e-3, n_epochs=8, seed=0, accelerator="cuda")
+    hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
+    assert list(hist.columns) == list(ref.keys())
+    assert list(hist["LR"]) == ref["LR"] and ref["LR"][2] == 0.05 and ref["LR"][3] == 0.025
+    for ep in range(8):       # measured: loss equal to the logged digits, NMSE within 7e-5 dB over all eight epochs
+        assert abs(hist["TRAIN_LOSS"][ep] - ref["TRAIN_LOSS"][ep]) < 2e-4 * ref["TRAIN_LOSS"][ep], ep
+        for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE"):
+            assert abs(hist[col][ep] - ref[col][ep]) < 2e-3, (col, ep, hist[col][ep], ref[col][ep])
+
+
 def test_thresholded_dpd_two_epochs_match_reference_incl_sparsity_columns(workdir):
     """train_dpd of the TRes-DeltaGRU (thx 0.01, thh 0.05) for TWO epochs: the temporal-sparsity columns come from counters that
     the training AND the evaluation forwards feed and that are read (and reset) once per epoch (paths.py:49-59) — bookkeeping a
