@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Anchors for the training options no other anchor exercises (TEST INFRASTRUCTURE — build container only): RUNS the reference on
+CPU, two train_pa epochs of gru H11 on DPA_200MHz (frame 50, batch 64, seed 0) with
+    l1     --loss_type l1 --lr 1e-3                 (nn.L1Loss through the fused kernels' L1 branch)
+    clip   --grad_clip_val 0.02 --lr 1e-3           (clip_grad_norm_ really clipping: the default 200 never does)
+    noclip --grad_clip_val 0 --lr 1e-3              (train_funcs.py:41: clipping skipped)
+    sgd    --opt_type sgd --lr 1e-2                 (torch.optim.SGD(momentum 0.9) on gradients from the HIP autograd path)
+    adam   --opt_type adam --lr 1e-3
+-> tests/golden/ref_runs_variants.json.  Usage: python oracle/gen_run_anchors_variants.py"""
+import glob
+import json
+import os
+import subprocess
+import tempfile
+
+import pandas as pd
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+BASE = ["--dataset_name", "DPA_200MHz", "--accelerator", "cpu", "--PA_backbone", "gru", "--PA_hidden_size", "11", "--frame_length", "50",
+        "--batch_size", "64", "--seed", "0", "--n_epochs", "2"]
+CASES = {"l1": ["--loss_type", "l1", "--lr", "1e-3"], "clip": ["--grad_clip_val", "0.02", "--lr", "1e-3"],
+         "noclip": ["--grad_clip_val", "0", "--lr", "1e-3"], "sgd": ["--opt_type", "sgd", "--lr", "1e-2"],
+         "adam": ["--opt_type", "adam", "--lr", "1e-3"]}
+
+
+def main():
+    out = {}
+    for name, extra in CASES.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            env = dict(os.environ, PYTHONPATH=REF, PYTHONDONTWRITEBYTECODE="1")
+            subprocess.check_call(["python", os.path.join(REF, "main.py"), "--step", "train_pa"] + BASE + extra, cwd=tmp, env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            hist = pd.read_csv(glob.glob(f"{tmp}/log/DPA_200MHz/train_pa/history/*.csv")[0])
+            out[name] = {"hist": hist.to_dict(orient="list"), "cmd": " ".join(BASE + extra)}
+            print(name, hist[["TRAIN_LOSS", "VAL_NMSE", "TEST_ACLR_AVG"]].to_numpy().tolist())
+    json.dump(out, open(os.path.join(OUT, "ref_runs_variants.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

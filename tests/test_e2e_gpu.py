@@ -201,6 +201,27 @@ def test_gmp_as_dpd_of_a_neural_pa_matches_reference(workdir):
     assert np.abs(csv.to_numpy() - m["dpd_out"]).max() < 2e-5
 
 
+@pytest.mark.parametrize("name,kw", [("l1", dict(loss_type="l1", lr=1e-3)), ("clip", dict(grad_clip_val=0.02, lr=1e-3)),
+                                     ("noclip", dict(grad_clip_val=0, lr=1e-3)), ("sgd", dict(opt_type="sgd", lr=1e-2)),
+                                     ("adam", dict(opt_type="adam", lr=1e-3))])
+def test_training_options_follow_their_reference_logs(workdir, name, kw):
+    """two train_pa epochs of gru H11 with the options no other anchor exercises — L1 loss, a gradient clip that really clips, no
+    clipping, torch's SGD(momentum 0.9) / Adam stepping on gradients from the HIP autograd path — against the rows the REFERENCE
+    logged (tests/golden/ref_runs_variants.json, oracle/gen_run_anchors_variants.py)"""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_variants.json")))[name]["hist"]
+    res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=11, frame_length=50, batch_size=64, n_epochs=2, seed=0,
+                      accelerator="cuda", **kw)
+    hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
+    assert list(hist.columns) == list(ref.keys())
+    # measured: loss 5e-6 relative, metrics 1e-5 dB (l1, whose gradient is a sign: 1.6e-4 / 2e-3 dB)
+    tol_l, tol_db = (1e-3, 0.02) if name == "l1" else (5e-5, 5e-4)
+    for ep in range(2):
+        assert abs(hist["TRAIN_LOSS"][ep] - ref["TRAIN_LOSS"][ep]) < tol_l * ref["TRAIN_LOSS"][ep], ep
+        for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
+            assert abs(hist[col][ep] - ref[col][ep]) < tol_db, (col, ep, hist[col][ep], ref[col][ep])
+
+
 def test_lr_schedule_run_matches_reference_log(workdir):
     """--lr_schedule 1 --patience 0 --decay_factor 0.5 --lr_end 1e-3 at lr 5e-2 (eight train_pa epochs, gru H11): ReduceLROnPlateau on
     the validation NMSE halves the rate after the third epoch in the reference's log; the LR column (logged before the scheduler
