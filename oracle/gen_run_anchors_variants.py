@@ -6,6 +6,8 @@ CPU, two train_pa epochs of gru H11 on DPA_200MHz (frame 50, batch 64, seed 0) w
     noclip --grad_clip_val 0 --lr 1e-3              (train_funcs.py:41: clipping skipped)
     sgd    --opt_type sgd --lr 1e-2                 (torch.optim.SGD(momentum 0.9) on gradients from the HIP autograd path)
     adam   --opt_type adam --lr 1e-3
+    stride7  dgru H8, --frame_length 37 --frame_stride 7 --batch_size 100   (strided frames addressed in place by the native epoch loop)
+    layers2  gru H8 --PA_num_layers 2      hidden40  dgru H40             (beyond the kernels' envelope: ATen restatements, torch AdamW)
 -> tests/golden/ref_runs_variants.json.  Usage: python oracle/gen_run_anchors_variants.py"""
 import glob
 import json
@@ -19,6 +21,10 @@ REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 BASE = ["--dataset_name", "DPA_200MHz", "--accelerator", "cpu", "--PA_backbone", "gru", "--PA_hidden_size", "11", "--frame_length", "50",
         "--batch_size", "64", "--seed", "0", "--n_epochs", "2"]
+# cases that replace parts of BASE (later flags win in argparse)
+CASES2 = {"stride7": ["--PA_backbone", "dgru", "--PA_hidden_size", "8", "--frame_length", "37", "--frame_stride", "7", "--batch_size", "100", "--lr", "2e-3"],
+          "layers2": ["--PA_backbone", "gru", "--PA_hidden_size", "8", "--PA_num_layers", "2", "--lr", "2e-3"],
+          "hidden40": ["--PA_backbone", "dgru", "--PA_hidden_size", "40", "--lr", "1e-3"]}
 CASES = {"l1": ["--loss_type", "l1", "--lr", "1e-3"], "clip": ["--grad_clip_val", "0.02", "--lr", "1e-3"],
          "noclip": ["--grad_clip_val", "0", "--lr", "1e-3"], "sgd": ["--opt_type", "sgd", "--lr", "1e-2"],
          "adam": ["--opt_type", "adam", "--lr", "1e-3"]}
@@ -26,7 +32,7 @@ CASES = {"l1": ["--loss_type", "l1", "--lr", "1e-3"], "clip": ["--grad_clip_val"
 
 def main():
     out = {}
-    for name, extra in CASES.items():
+    for name, extra in list(CASES.items()) + list(CASES2.items()):
         with tempfile.TemporaryDirectory() as tmp:
             env = dict(os.environ, PYTHONPATH=REF, PYTHONDONTWRITEBYTECODE="1")
             subprocess.check_call(["python", os.path.join(REF, "main.py"), "--step", "train_pa"] + BASE + extra, cwd=tmp, env=env,

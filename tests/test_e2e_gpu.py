@@ -222,6 +222,30 @@ def test_training_options_follow_their_reference_logs(workdir, name, kw):
             assert abs(hist[col][ep] - ref[col][ep]) < tol_db, (col, ep, hist[col][ep], ref[col][ep])
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("stride7", dict(PA_backbone="dgru", PA_hidden_size=8, frame_length=37, frame_stride=7, batch_size=100, lr=2e-3)),
+    ("layers2", dict(PA_backbone="gru", PA_hidden_size=8, PA_num_layers=2, frame_length=50, batch_size=64, lr=2e-3)),
+    ("hidden40", dict(PA_backbone="dgru", PA_hidden_size=40, frame_length=50, batch_size=64, lr=1e-3))])
+def test_framing_and_envelope_variants_follow_their_reference_logs(workdir, name, kw):
+    """strided frames (frame_stride 7: the native epoch loop addresses frame f at f * 7 of the resident stream) and two configurations
+    beyond the kernels' envelope (two GRU layers, hidden 40: ATen restatements of backbones/wide.py with torch's AdamW, announced by
+    a warning), two train_pa epochs each, against the REFERENCE's logged rows (ref_runs_variants.json)"""
+    import warnings
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_variants.json")))[name]["hist"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = od.train_pa(dataset_name="DPA_200MHz", n_epochs=2, seed=0, accelerator="cuda", **kw)
+    hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
+    assert list(hist.columns) == list(ref.keys())
+    for col in ("N_PARAM", "BATCH_SIZE", "FRAME_LENGTH", "HIDDEN_SIZE"):
+        assert list(hist[col]) == ref[col]
+    for ep in range(2):       # measured: loss 5e-6 relative, metrics 1e-5 dB (hidden 40: 2.3e-4 dB)
+        assert abs(hist["TRAIN_LOSS"][ep] - ref["TRAIN_LOSS"][ep]) < 5e-5 * ref["TRAIN_LOSS"][ep], ep
+        for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
+            assert abs(hist[col][ep] - ref[col][ep]) < 3e-3, (col, ep, hist[col][ep], ref[col][ep])
+
+
 def test_lr_schedule_run_matches_reference_log(workdir):
     """--lr_schedule 1 --patience 0 --decay_factor 0.5 --lr_end 1e-3 at lr 5e-2 (eight train_pa epochs, gru H11): ReduceLROnPlateau on
     the validation NMSE halves the rate after the third epoch in the reference's log; the LR column (logged before the scheduler
