@@ -164,7 +164,8 @@ def test_more_backbones_follow_their_reference_logs(workdir, name, bb, H, extra)
     for col in ("N_PARAM", "BATCH_SIZE", "FRAME_LENGTH", "HIDDEN_SIZE", "N_EPOCH", "BACKBONE"):
         assert list(hist[col]) == rh[col]
     for ep in range(2):       # measured: TRAIN_LOSS identical to the logged digits, metrics within 2e-4 dB (tcnn), 1e-5 dB (lstm, deltagru)
-        assert abs(hist["TRAIN_LOSS"][ep] - rh["TRAIN_LOSS"][ep]) < 2e-4 * rh["TRAIN_LOSS"][ep], ep
+        for col in ("TRAIN_LOSS", "VAL_LOSS", "TEST_LOSS"):       # the evaluation losses: mean over the evaluation batches (train_funcs.py:57-90)
+            assert abs(hist[col][ep] - rh[col][ep]) < 2e-4 * rh[col][ep] + 2e-8, (col, ep, hist[col][ep], rh[col][ep])
         for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_EVM", "TEST_ACLR_AVG"):
             assert abs(hist[col][ep] - rh[col][ep]) < 5e-3, (col, ep, hist[col][ep], rh[col][ep])   # dB
 
