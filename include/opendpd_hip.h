@@ -86,6 +86,9 @@ int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T);
  * above after a change).  "s16_min_batch": smallest batch served by the 16-sequences-per-wave fused GRU
  * kernel (-1 = built-in crossover, 0 = always when supported); "s16_occupancy": 1 or 2 waves per SIMD (0 = chosen by batch size). */
 int odpd_set_tuning(const char* key, int64_t value);
+/* Counter bumped by every successful odpd_set_tuning: buffers sized by the queries above are valid for the generation they were
+ * sized in (the row count / workspace layout of a (B,T) shape depends on the knobs). */
+int64_t odpd_tuning_generation(void);
 /* library/ABI version, and the gfx arch string the code objects were built for */
 int odpd_abi_version(void);
 const char* odpd_built_arch(void);
@@ -168,6 +171,14 @@ int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_kind, const o
 int odpd_clip_adamw_step(void* stream, int64_t P, float* params, float* grad, float* exp_avg,
                          float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2,
                          double eps, double weight_decay, double max_norm, float* norm_out);
+/* Same step with a per-parameter skip mask (device, P bytes, nullable = no mask): skip[i] != 0 marks a parameter whose .grad is
+ * None in the reference — torch.optim.AdamW leaves it and its state untouched (no weight decay either) and clip_grad_norm_ does
+ * not count it.  Used by the QAT models: the 16-bit out_quantizer scales never enter the train-mode graph
+ * (quant/qmodules/quant_layers.py:77-80). */
+int odpd_clip_adamw_step_masked(void* stream, int64_t P, float* params, float* grad, float* exp_avg,
+                                float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2,
+                                double eps, double weight_decay, double max_norm, float* norm_out,
+                                const unsigned char* skip);
 
 #ifdef __cplusplus
 }

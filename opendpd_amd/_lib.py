@@ -32,6 +32,7 @@ _EXPORTS = {
     "odpd_abi_version": (C.c_int, []),
     "odpd_built_arch": (C.c_char_p, []),
     "odpd_set_tuning": (C.c_int, [C.c_char_p, C.c_int64]),
+    "odpd_tuning_generation": (C.c_int64, []),
     "odpd_param_count": (C.c_int64, [C.POINTER(ModelDesc)]),
     "odpd_ckpt_floats": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
     "odpd_partial_rows": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int]),
@@ -57,6 +58,9 @@ _EXPORTS = {
     "odpd_clip_adamw_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                        C.c_void_p]),
+    "odpd_clip_adamw_step_masked": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                              C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

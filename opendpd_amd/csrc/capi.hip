@@ -57,12 +57,14 @@ odpd::Tuning& odpd::tuning() {
     }();
     return t;
 }
+static int64_t g_tuning_generation = 0;
 extern "C" int odpd_set_tuning(const char* key, int64_t value) {
     if (!key) return ODPD_EINVAL;
-    if (!strcmp(key, "s16_min_batch")) { tuning().s16_min_batch = (long)value; return 0; }
-    if (!strcmp(key, "s16_occupancy")) { tuning().s16_occupancy = (int)value; return 0; }
+    if (!strcmp(key, "s16_min_batch")) { tuning().s16_min_batch = (long)value; ++g_tuning_generation; return 0; }
+    if (!strcmp(key, "s16_occupancy")) { tuning().s16_occupancy = (int)value; ++g_tuning_generation; return 0; }
     return ODPD_EINVAL;
 }
+extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
 extern "C" int odpd_abi_version(void) { return 2; }
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }

@@ -162,7 +162,7 @@ int64_t gru_s16n_ckpt_floats(const odpd_model_t* m, int B, int T);
 // optim.hip: clip + AdamW launch that also records loss = grad[P] * inv_count into loss_out (nullable)
 int launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t step,
                       double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, float* norm_out,
-                      float* loss_out, float inv_count);
+                      float* loss_out, float inv_count, const unsigned char* skip = nullptr);
 int64_t gru_s16_workspace_floats(const odpd_model_t* m, int B, int T);
 int lstm_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);

@@ -98,12 +98,14 @@ __global__ __launch_bounds__(1024) void clip_adamw_kernel(int64_t P, float* __re
                                                           float* __restrict__ m, float* __restrict__ v, float step_size,
                                                           float bc2_sqrt, float decay, float w1, float b2, float w2,
                                                           float eps, float max_norm, float* __restrict__ norm_out,
-                                                          float* __restrict__ loss_out, float inv_count) {
+                                                          float* __restrict__ loss_out, float inv_count,
+                                                          const unsigned char* __restrict__ skip) {
     __shared__ float sh[16];
     __shared__ float coef_s;
     if (loss_out && threadIdx.x == 0) loss_out[0] = g[P] * inv_count;   // column P of the reduced row = loss partial sum
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < P; i += blockDim.x) acc += g[i] * g[i];
+    // skip[i] != 0: a parameter whose .grad is None in the reference — outside the norm, untouched by the update
+    for (int64_t i = threadIdx.x; i < P; i += blockDim.x) acc += (skip && skip[i]) ? 0.f : g[i] * g[i];
     float tot = block_sum(acc, sh);
     if (threadIdx.x == 0) {
         float nrm = sqrtf(tot);
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(1024) void clip_adamw_kernel(int64_t P, float* __re
     __syncthreads();
     const float coef = coef_s;
     for (int64_t i = threadIdx.x; i < P; i += blockDim.x) {
+        if (skip && skip[i]) continue;
         float gi = g[i];
         if (max_norm > 0.f) { gi *= coef; g[i] = gi; }
         float pi = p[i] * decay;
@@ -155,7 +158,7 @@ extern "C" int odpd_reduce_partials(void* stream, int64_t rows, int64_t P, const
 
 int odpd::launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq,
                             int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay,
-                            double max_norm, float* norm_out, float* loss_out, float inv_count) {
+                            double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip) {
     if (!params || !grad || !exp_avg || !exp_avg_sq || P <= 0 || step <= 0) return ODPD_EINVAL;
     // bias corrections in double like torch/optim/adam.py (_single_tensor_adam), rounded to fp32 once
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
@@ -163,7 +166,7 @@ int odpd::launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* gra
     const float decay = (float)(1.0 - lr * weight_decay);
     const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
     hipLaunchKernelGGL(clip_adamw_kernel, dim3(1), dim3(1024), 0, st, P, params, grad, exp_avg, exp_avg_sq, step_size, bc2s,
-                       decay, w1, (float)beta2, w2, (float)eps, (float)max_norm, norm_out, loss_out, inv_count);
+                       decay, w1, (float)beta2, w2, (float)eps, (float)max_norm, norm_out, loss_out, inv_count, skip);
     return (int)hipGetLastError();
 }
 
@@ -171,5 +174,12 @@ extern "C" int odpd_clip_adamw_step(void* stream, int64_t P, float* params, floa
                                     float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps,
                                     double weight_decay, double max_norm, float* norm_out) {
     return launch_clip_adamw((hipStream_t)stream, P, params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
-                             weight_decay, max_norm, norm_out, nullptr, 0.0f);
+                             weight_decay, max_norm, norm_out, nullptr, 0.0f, nullptr);
+}
+
+extern "C" int odpd_clip_adamw_step_masked(void* stream, int64_t P, float* params, float* grad, float* exp_avg,
+                                           float* exp_avg_sq, int64_t step, double lr, double beta1, double beta2, double eps,
+                                           double weight_decay, double max_norm, float* norm_out, const unsigned char* skip) {
+    return launch_clip_adamw((hipStream_t)stream, P, params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
+                             weight_decay, max_norm, norm_out, nullptr, 0.0f, skip);
 }

@@ -8,6 +8,7 @@ resident I/Q stream with the index order a reference DataLoader(shuffle=True) wo
 HIP train step."""
 import argparse
 import os
+import warnings
 import random
 import time
 
@@ -169,14 +170,21 @@ class Project:
         functional checks of the N > 1 path on a one-GPU box); a single process keeps the reference's `--devices` index."""
         from . import dist as DP
         self.rank, local, self.world = DP.env_world()
+        if self.accelerator == "cpu" and torch.cuda.is_available():
+            # the reference's default (arguments.py:20, opendpd/api.py:35) names the CPU; there is no CPU path here, and a call that
+            # relies on the mirrored defaults (od.train_pa(dataset_name=...), OpenDPDTrainer's implicit train_pa) must still run
+            warnings.warn("opendpd_amd has no CPU path: accelerator='cpu' (the reference's default) runs on the HIP device "
+                          f"cuda:{self.devices}; pass accelerator='cuda' to silence this", stacklevel=2)
+            self.accelerator = "cuda"
         if self.accelerator == "cuda" and torch.cuda.is_available():
             index = local if (self.world > 1 and os.environ.get("OPENDPD_DIST_SINGLE_DEVICE") != "1") else self.devices
             dev = torch.device("cuda:" + str(index))
             torch.cuda.set_device(dev)
             if self.world > 1:
                 DP.init(os.environ.get("OPENDPD_DIST_BACKEND") or None, dev)
-        elif self.accelerator == "cpu":
-            raise ValueError("opendpd_amd runs on a HIP device only: pass accelerator='cuda' (there is no CPU fallback)")
+        elif self.accelerator in ("cpu", "cuda"):
+            raise ValueError("opendpd_amd runs on a HIP device only and none is visible (torch.cuda.is_available() is False): "
+                             "there is no CPU fallback")
         else:
             raise ValueError(f"The select device {self.accelerator} is not supported.")
         self.device = dev

@@ -125,7 +125,14 @@ class QuantQGRU(NativeBackbone):
 
 def get_quant_model(proj, model):
     """Reference semantics (quant/__init__.py:20-37): identity unless `proj.quant`; otherwise the quantised model.
-    `proj` needs n_bits_w, n_bits_a and optionally pretrained_model (a state dict path with the quantised key names)."""
+    `proj` needs n_bits_w, n_bits_a and optionally pretrained_model.
+
+    `pretrained_model` follows Base_GRUQuantEnv.load_model (quant_envs.py:173-182): the checkpoint is strict-loaded into the FLOAT
+    holder (keys `backbone.rnn.rnn_cell_list.0.{x2h,h2h}.{weight,bias}`, `backbone.fc_out.{weight,bias}`) before quantisation;
+    INT_Linear then keeps the weights and draws fresh biases (quant_layers.py:48-56), the scales start at their defaults.  Any other
+    key set — the nn.GRU names of a float `train_dpd` checkpoint, or a quantised checkpoint with its scales and buffers — makes that
+    strict load raise in the reference, whose get_quant_model then warns and returns the float model it was given
+    (quant/__init__.py:35-37); the same happens here (pinned by tests/golden/quant_pretrained_qgru_h10.npz)."""
     if not getattr(proj, "quant", False):
         return model
     if not isinstance(model, CoreModel) or model.backbone_type not in ("qgru", "qgru_amp1"):
@@ -135,6 +142,19 @@ def get_quant_model(proj, model):
     if H > 16 or model.num_layers != 1:
         raise NotImplementedError("the QAT kernels cover one layer and hidden_size <= 16 (csrc/qgru_family.hip)")
     dev = next(model.parameters()).device
+    pre = getattr(proj, "pretrained_model", "")
+    pre_sd = None
+    if pre:
+        pre_sd = torch.load(pre, map_location="cpu")
+        cellp = "backbone.rnn.rnn_cell_list.0."
+        want = {cellp + "x2h.weight": (3 * H, 4), cellp + "x2h.bias": (3 * H,), cellp + "h2h.weight": (3 * H, H),
+                cellp + "h2h.bias": (3 * H,), "backbone.fc_out.weight": (2, H), "backbone.fc_out.bias": (2,)}
+        bad = set(pre_sd) != set(want) or any(tuple(pre_sd[k].shape) != s for k, s in want.items())
+        if bad:
+            missing, extra = sorted(set(want) - set(pre_sd)), sorted(set(pre_sd) - set(want))
+            print(f"[WARN] Quantization setup failed: Error(s) in loading state_dict for CoreModel: missing {missing[:4]}, "
+                  f"unexpected {extra[:4]}{' ...' if len(extra) > 4 else ''}. Using float model instead.")
+            return model
     # --- RNG consumption order of Base_GRUQuantEnv (quant_envs.py:156-171, 198-246, 290-306) ----------------------
     # 1. recur_rpls_gru: PYGRU -> GRUCell(4,H): two nn.Linear default inits, then GRUCell.reset_parameters (uniform over
     #    x2h.weight, x2h.bias, h2h.weight, h2h.bias — quant/modules/gru.py:24-29)
@@ -153,13 +173,14 @@ def get_quant_model(proj, model):
         cell.x2h.weight.copy_(holder.x2h.weight)
         cell.h2h.weight.copy_(holder.h2h.weight)
         bb.fc_out.weight.copy_(model.backbone.fc_out.weight.detach().cpu())
+        if pre_sd is not None:          # load_model ran between steps 2 and 3: the weights INT_Linear keeps are the checkpoint's
+            cell.x2h.weight.copy_(pre_sd[cellp + "x2h.weight"])
+            cell.h2h.weight.copy_(pre_sd[cellp + "h2h.weight"])
+            bb.fc_out.weight.copy_(pre_sd["backbone.fc_out.weight"])
     q = CoreModel.__new__(CoreModel)
     nn.Module.__init__(q)
     for k in ("output_size", "input_size", "hidden_size", "num_layers", "backbone_type", "thx", "thh", "window_size",
               "num_dvr_units", "batch_first", "bidirectional", "bias"):
         setattr(q, k, getattr(model, k))
     q.backbone = bb
-    pre = getattr(proj, "pretrained_model", "")
-    if pre:
-        q.load_state_dict(torch.load(pre, map_location="cpu"))
     return q.to(dev)

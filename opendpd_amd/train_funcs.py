@@ -59,10 +59,14 @@ class FusedAdamW:
         self.process_group = process_group
         self.step_count = 0
         self._state_dev = None
-        self._fused_ok = {}
+        self._tuning_gen = -1
+        self._fused_ok, self._partials, self._cascade_bufs = {}, {}, {}
 
     # -- state -------------------------------------------------------------------------------
     def _ensure(self, device):
+        # buffers sized by odpd_partial_rows / odpd_train_workspace_floats / odpd_ckpt_floats depend on the kernel-selection knobs
+        # as well as on (B, T): a knob change invalidates every cached one (a larger grid would write past a stale buffer)
+        self._check_tuning()
         if self._state_dev == device:
             return
         P = self.backbone.n_flat
@@ -73,6 +77,12 @@ class FusedAdamW:
         self._partials = {}
         self._cascade_bufs = {}
         self._state_dev = device
+
+    def _check_tuning(self):
+        gen = int(_lib.load().odpd_tuning_generation())
+        if gen != self._tuning_gen:
+            self._partials, self._cascade_bufs, self._fused_ok = {}, {}, {}
+            self._tuning_gen = gen
 
     def partials(self, B, T, device):
         self._ensure(device)
@@ -98,6 +108,7 @@ class FusedAdamW:
     def has_fused(self, B, T):
         """True when the backbone has a single-launch fwd+loss+bwd kernel for this batch shape."""
         key = (B, T, "has_fused")
+        self._check_tuning()
         if key not in self._fused_ok:
             lib = _lib.load()
             self._fused_ok[key] = int(lib.odpd_partial_rows(C.byref(self.backbone.desc), B, T, 1)) > 0
@@ -174,20 +185,16 @@ class FusedAdamW:
         if stream is None:
             stream = _lib.stream_ptr()
         frozen = getattr(self.backbone, "frozen_mask", None)     # parameters torch.optim.AdamW would skip (grad is None)
-        if frozen is not None:
-            if frozen.device != flat.device:
-                self.backbone.frozen_mask = frozen = frozen.to(flat.device)
-            keep = flat[frozen].clone()
-        rc = lib.odpd_clip_adamw_step(stream, self.backbone.n_flat, _lib.ptr(flat), _lib.ptr(self.grad),
-                                      _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.step_count,
-                                      float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                      float(g["weight_decay"]), float(max_norm or 0.0), _lib.ptr(self.norm))
+        if frozen is not None and (frozen.device != flat.device or frozen.dtype != torch.uint8):
+            # one byte per parameter, resident next to the parameters: the kernel skips those columns (no host sync, no extra launch)
+            self.backbone.frozen_mask = frozen = frozen.to(device=flat.device, dtype=torch.uint8).contiguous()
+        rc = lib.odpd_clip_adamw_step_masked(stream, self.backbone.n_flat, _lib.ptr(flat), _lib.ptr(self.grad),
+                                             _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.step_count,
+                                             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                             float(g["weight_decay"]), float(max_norm or 0.0), _lib.ptr(self.norm),
+                                             _lib.ptr(frozen) if frozen is not None else None)
         if rc:
             _lib.check(rc, "odpd_clip_adamw_step")
-        if frozen is not None:
-            flat[frozen] = keep
-            self.exp_avg[frozen] = 0
-            self.exp_avg_sq[frozen] = 0
 
     def can_run_epoch(self, loader):
         """True when odpd_train_epoch can drive a whole epoch: single fused backbone, one process, resident streams."""

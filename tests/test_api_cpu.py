@@ -70,9 +70,22 @@ def test_device_frame_loader_matches_reference_dataloader_order():
     assert torch.equal(r1, r2)
 
 
-def test_cpu_accelerator_is_refused():
+def test_without_a_hip_device_every_accelerator_is_refused():
+    """There is no CPU path: on a box without a HIP device (this container) the reference's default accelerator='cpu' and 'cuda' both
+    raise; on a GPU box 'cpu' is mapped to the HIP device with a warning (tests/test_e2e_gpu.py)."""
+    import pytest
+    import torch
     from opendpd_amd.project import Project
-    os.environ.pop("OPENDPD_DATASETS", None)
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a HIP device")
+    for acc in ("cpu", "cuda"):
+        proj = Project.__new__(Project)
+        proj.accelerator, proj.devices = acc, 0
+        with pytest.raises(ValueError, match="no CPU fallback"):
+            proj.set_device()
+    proj.accelerator = "mps"
+    with pytest.raises(ValueError, match="not supported"):
+        proj.set_device()
 
 
 def test_lr_scheduler_mirrors_torch_reduce_on_plateau():

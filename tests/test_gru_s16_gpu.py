@@ -263,3 +263,43 @@ def test_s16n_cascades_follow_reference(force_s16n):
     for name, d, p in (("cascade_dgru13_dgru23", "dgru", "dgru"), ("cascade_tres15_dgru23", "deltagru_tcnskip", "dgru")):
         casc.test_cascade_autograd_matches_reference(name, d, p)
         casc.test_cascade_fused_steps_follow_reference(name, d, p)
+
+
+def test_knob_change_between_steps_resizes_cached_buffers():
+    """The partial-row count and the workspace layout of a (B,T) shape depend on the kernel-selection knobs: an optimiser that has
+    stepped once must not keep the buffers of the previous selection (a larger grid would write past them).  Two steps with a knob
+    flip in between == the same two steps on fresh optimisers, bit for bit."""
+    from opendpd_amd import CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, T = 3000, 40
+    x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    t = torch.randn(B, T, 2, device="cuda", generator=g) * 0.3
+
+    def run(reuse):
+        torch.manual_seed(5)
+        net = CoreModel(2, 13, 1, "dgru").cuda()
+        opt = FusedAdamW(net, lr=1e-3)
+        losses, shapes = [], []
+        for i, mb in enumerate((-1, 0)):                 # row-rotated kernel (LDS checkpoints), then S16 (HBM workspace)
+            lib.odpd_set_tuning(b"s16_min_batch", mb)
+            if not reuse and i:
+                fresh = FusedAdamW(net, lr=1e-3)
+                fresh._ensure(x.device)
+                fresh.exp_avg.copy_(opt.exp_avg); fresh.exp_avg_sq.copy_(opt.exp_avg_sq)
+                fresh.step_count = opt.step_count
+                opt = fresh
+            losses.append(float(fused_train_step(opt, x, t, "l2", 200.0)))
+            ws = opt.train_workspace(B, T, x.device)
+            shapes.append((opt.partials(B, T, x.device).shape[0], 0 if ws is None else ws.numel()))
+        lib.odpd_set_tuning(b"s16_min_batch", -1)
+        return losses, shapes, net.backbone.flat_params().clone()
+    try:
+        l1, s1, p1 = run(reuse=True)
+        l2, s2, p2 = run(reuse=False)
+    finally:
+        lib.odpd_set_tuning(b"s16_min_batch", -1)
+    assert s1 == s2 and s1[0] != s1[1], (s1, s2)         # the two selections really need different buffers
+    assert l1 == l2 and torch.equal(p1, p2)

@@ -40,3 +40,49 @@ def test_identity_when_quant_off():
         quant = False
     net = CoreModel(2, 10, 1, "qgru")
     assert get_quant_model(P, net) is net
+
+
+def test_pretrained_model_follows_the_reference_load_path(tmp_path, capsys):
+    """quant_envs.py:173-182: a PyGRU-keyed float checkpoint is loaded BEFORE quantisation (weights kept, biases re-drawn, default
+    scales); nn.GRU-keyed float checkpoints and quantised checkpoints make the reference fall back to the float model with a warning."""
+    import json
+    from opendpd_amd import CoreModel
+    from opendpd_amd.quant import get_quant_model
+    fx = Fixture("quant_pretrained_qgru_h10")
+    H, bits = fx.meta["hidden"], fx.meta["bits"]
+    assert fx.meta["outcomes"] == {"pygru": "quantised", "nngru": "float model returned unchanged",
+                                   "quant": "float model returned unchanged"}
+
+    class P:
+        quant = True
+        n_bits_w = n_bits_a = bits
+    pre = tmp_path / "pygru.pt"
+    torch.save({k: torch.from_numpy(fx["pre/" + k]) for k in fx.keys("pre")}, pre)
+    P.pretrained_model = str(pre)
+    torch.manual_seed(0)
+    fnet = CoreModel(2, H, 1, "qgru")
+    torch.manual_seed(123)
+    q = get_quant_model(P, fnet)
+    assert q is not fnet
+    sd = q.state_dict()
+    assert list(sd.keys()) == fx.keys("sd")
+    for k in fx.keys("sd"):
+        assert np.array_equal(sd[k].numpy(), fx["sd/" + k]), k
+    # the weights are the checkpoint's, the biases are not (INT_Linear re-draws them)
+    assert np.array_equal(sd["backbone.fc_out.weight"].numpy(), fx["pre/backbone.fc_out.weight"])
+    assert not np.array_equal(sd["backbone.fc_out.bias"].numpy(), fx["pre/backbone.fc_out.bias"])
+    # the two refused kinds: a float nn.GRU checkpoint and a quantised checkpoint
+    torch.manual_seed(1)
+    nn_sd = CoreModel(2, H, 1, "qgru").state_dict()
+    assert list(nn_sd.keys()) == json.loads(str(fx["nngru_keys"]))
+    for name, ckpt in (("nngru", nn_sd), ("quant", sd)):
+        path = tmp_path / f"{name}.pt"
+        torch.save(ckpt, path)
+        P.pretrained_model = str(path)
+        torch.manual_seed(0)
+        fnet = CoreModel(2, H, 1, "qgru")
+        before = {k: v.clone() for k, v in fnet.state_dict().items()}
+        capsys.readouterr()
+        out = get_quant_model(P, fnet)
+        assert out is fnet and "[WARN] Quantization setup failed" in capsys.readouterr().out
+        assert all(torch.equal(before[k], v) for k, v in out.state_dict().items())
