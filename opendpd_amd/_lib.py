@@ -67,7 +67,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.LIB
+    """The in-tree library; $OPENDPD_HIP_LIB points at another build of the same ABI (kernel experiments, tools/exp_time.py)."""
+    return os.environ.get("OPENDPD_HIP_LIB") or _build.LIB
 
 
 def exported_symbols():
