@@ -39,7 +39,8 @@ enum odpd_backbone {
     ODPD_TCNN = 8,       /* backbones/tcnn.py:5-97 */
     ODPD_PGJANET = 9,    /* backbones/pgjanet.py:5-84 */
     ODPD_GMP = 10,       /* backbones/gmp.py:5-50 (hidden = memory_length; degree 5 as built by models.py:26-28) */
-    ODPD_BACKBONE_COUNT = 11
+    ODPD_RVTDCNN = 11,   /* backbones/rvtdcnn.py:9-62 (hidden = fc_hid_size, models.py:80-81; window 4, 3 conv channels) */
+    ODPD_BACKBONE_COUNT = 12
 };
 
 enum odpd_error {
@@ -51,7 +52,7 @@ enum odpd_error {
 /* Model descriptor: what `CoreModel.__init__` receives (models.py:11). */
 typedef struct odpd_model {
     int32_t backbone; /* enum odpd_backbone */
-    int32_t hidden;   /* hidden_size (channels for tcnn; memory_length for gmp): <= 32 (pgjanet, QAT: <= 16; tcnn: <= 64; gmp: 11),
+    int32_t hidden;   /* hidden_size (channels for tcnn; memory_length for gmp): <= 32 (pgjanet, QAT: <= 16; tcnn: <= 64; gmp: 11; rvtdcnn: fc_hid_size),
                          else ODPD_EUNSUPPORTED */
     float thx;        /* delta threshold on inputs  (deltagru*, models.py:11) */
     float thh;        /* delta threshold on hidden state */

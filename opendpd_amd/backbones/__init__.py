@@ -5,3 +5,4 @@ from .deltagru import DeltaGRU, TResDeltaGRU  # noqa: F401
 from .pgjanet import PGJANET  # noqa: F401
 from .tcnn import TCNN  # noqa: F401
 from .gmp import GMP  # noqa: F401
+from .rvtdcnn import RVTDCNN  # noqa: F401

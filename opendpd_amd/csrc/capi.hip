@@ -5,7 +5,7 @@
 using namespace odpd;
 
 namespace {
-enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP };
+enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP, FAM_RVTDCNN };
 inline Family family_of(int bb);
 // a quantisation-aware model: qgru / qgru_amp1 with bits_w > 0 (quant/quant_envs.py:138-171)
 inline Family family_of(const odpd_model_t* m) {
@@ -20,6 +20,7 @@ inline Family family_of(int bb) {
     case ODPD_PGJANET: return FAM_JANET;
     case ODPD_TCNN: return FAM_TCNN;
     case ODPD_GMP: return FAM_GMP;
+    case ODPD_RVTDCNN: return FAM_RVTDCNN;
     default: return FAM_NONE;
     }
 }
@@ -83,13 +84,14 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_TCNN: return 6 * H + H + 4 * 5 * H + 2 * H;
     case ODPD_PGJANET: return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
     case ODPD_GMP: return H == 11 ? H * (1 + 4 * H) : (int64_t)ODPD_EUNSUPPORTED;   // memory_length 11, degree 5 (models.py:26-28)
+    case ODPD_RVTDCNN: return H <= 32 ? 39 * H + 32 : (int64_t)ODPD_EUNSUPPORTED;  // conv 27+3, fc_hid 36H+H, fc_out 2H+2 (rvtdcnn.py:19-33)
     default: return ODPD_EUNSUPPORTED;
     }
 }
 
 extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
-    if (family_of(m) == FAM_TCNN || family_of(m) == FAM_GMP) return 0;   // not recurrent: nothing to checkpoint
+    if (family_of(m) == FAM_TCNN || family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN) return 0;   // not recurrent: nothing to checkpoint
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
@@ -119,6 +121,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_JANET: return fused ? (int64_t)ODPD_EUNSUPPORTED : janet_family_rows(m, B);
     case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
     case FAM_GMP: return gmp_rows(m, B, T);
+    case FAM_RVTDCNN: return fused ? rvtdcnn_train_rows(m, B, T) : rvtdcnn_rows(m, B, T);
     case FAM_QAT: return fused ? (int64_t)ODPD_EUNSUPPORTED : qgru_family_rows(m, B);
     default: return ODPD_EUNSUPPORTED;
     }
@@ -127,7 +130,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
 extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     if (family_of(m) == FAM_LSTM) return lstm_train_uses_s16(m, B) ? lstm_s16_workspace_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
-    if (family_of(m) == FAM_GMP) return odpd_param_count(m) > 0 ? 0 : (int64_t)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN) return odpd_param_count(m) > 0 ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
     if (gru_uses_s16n(m, B)) return gru_s16n_ckpt_floats(m, B, T);
     return gru_train_uses_s16(m, B, T) ? gru_s16_workspace_floats(m, B, T) : 0;
@@ -145,6 +148,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_JANET: return janet_family_fwd((hipStream_t)stream, m, a);
     case FAM_TCNN: return tcnn_fwd((hipStream_t)stream, m, a);
     case FAM_GMP: return gmp_fwd((hipStream_t)stream, m, a);
+    case FAM_RVTDCNN: return rvtdcnn_fwd((hipStream_t)stream, m, a);
     case FAM_QAT: return qgru_family_fwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
@@ -170,6 +174,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
         return janet_family_bwd((hipStream_t)stream, m, a);
     case FAM_TCNN: return tcnn_bwd((hipStream_t)stream, m, a);
     case FAM_GMP: return gmp_bwd((hipStream_t)stream, m, a);
+    case FAM_RVTDCNN: return rvtdcnn_bwd((hipStream_t)stream, m, a);
     case FAM_QAT:
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return qgru_family_bwd((hipStream_t)stream, m, a);
@@ -192,6 +197,7 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     case FAM_LSTM:
         return lstm_train_uses_s16(m, B) ? lstm_s16_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_GMP: return gmp_train((hipStream_t)stream, m, a);
+    case FAM_RVTDCNN: return rvtdcnn_train((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -217,9 +223,12 @@ extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss
 
 namespace {
 // backbones whose fused train kernel addresses frames inside resident streams (SeqArgs::frame_idx)
-inline bool framed_train_ok(const odpd_model_t* m) { return family_of(m) == FAM_GRU || family_of(m) == FAM_GMP; }
+inline bool framed_train_ok(const odpd_model_t* m) {
+    return family_of(m) == FAM_GRU || family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN;
+}
 inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (family_of(m) == FAM_GMP) return gmp_train(st, m, a);
+    if (family_of(m) == FAM_RVTDCNN) return rvtdcnn_train(st, m, a);
     const bool s16n = gru_uses_s16n(m, a.B), s16 = !s16n && gru_train_uses_s16(m, a.B, a.T);
     if ((s16 || s16n) && !a.ckpt) return ODPD_EINVAL;
     return s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));

@@ -209,6 +209,13 @@ int gmp_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gmp_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gmp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);   // fused fwd + loss + dL/dW (frames addressable in streams)
 int gmp_rows(const odpd_model_t* m, int B, int T);                      // same grid for the split backward and the fused step
+// rvtdcnn.hip (hidden = fc_hid_size <= 32)
+int rvtdcnn_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int rvtdcnn_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int rvtdcnn_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);  // fused fwd + loss + dL/dW (frames addressable in streams)
+int rvtdcnn_rows(const odpd_model_t* m, int B, int T);                       // partials rows of the split backward (with or without dL/dx)
+int rvtdcnn_train_rows(const odpd_model_t* m, int B, int T);                 // ... of the fused step
+int rvtdcnn_rows_for(int B, int T, bool dx);
 int qgru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_rows(const odpd_model_t* m, int B);

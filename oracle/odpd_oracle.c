@@ -72,6 +72,8 @@ int64_t oracle_param_count(const odpd_model_t* m) {
         return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
     case ODPD_GMP:      /* gmp.py:10-11: memory_length * (1 + (degree - 1) * memory_length); hidden = memory_length, degree 5 */
         return H * (1 + (GMP_DEGREE - 1) * H);
+    case ODPD_RVTDCNN:  /* rvtdcnn.py:19-33: Conv2d(1->3,k3) 27+3, fc_hid (H,36)+H, fc_out (2,H)+2; hidden = fc_hid_size (models.py:80-81) */
+        return 30 + 36 * H + H + 2 * H + 2;
     default: return -1;
     }
 }
@@ -1052,6 +1054,98 @@ static void gmp_seq_bwd(int M, const real* w, int T, const real* x, const real* 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* RVTDCNN: rvtdcnn.py:35-62.  Per sample t a 4 x 5 patch: window rows w = 0..3 hold the features [I,Q,a,a^2,a^3] (:41-46) of
+ * samples t-3+w, the frame's own LAST three samples standing in front of it (:51-53: circular, not zero history);
+ * Conv2d(1->3, k3, padding (1,0)) (:19-26) -> tanh -> flatten (channel, row, column) = 36 -> Linear(36->H) -> tanh ->
+ * Linear(H->2) (:57-61).  Parameter order: Conv2d.weight (3,1,3,3), Conv2d.bias, fc_hid.weight (H,36), fc_hid.bias,
+ * fc_out.weight (2,H), fc_out.bias. */
+/* ------------------------------------------------------------------------------------------ */
+#define RV_Z 36
+static inline int rv_idx(int t, int w, int T) { int j = t - 3 + w; return ((j % T) + T) % T; }
+static void rv_feat(const real* x, int s, real* f) {
+    const real I = x[2 * s], Q = x[2 * s + 1];
+    const real a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+    f[0] = I; f[1] = Q; f[2] = a; f[3] = a2; f[4] = a * a * a;
+}
+/* forward of one sample; z (36) and hid (H) are kept for the backward */
+static void rv_sample_fwd(int H, const real* p, int T, const real* x, int t, real in[4][5], real* z, real* hid, real* y) {
+    const real* K = p; const real* kb = p + 27; const real* wh = p + 30; const real* bh = wh + 36 * H;
+    const real* wo = bh + H; const real* bo = wo + 2 * H;
+    for (int w = 0; w < 4; ++w) rv_feat(x, rv_idx(t, w, T), in[w]);
+    for (int c = 0; c < 3; ++c)
+        for (int w = 0; w < 4; ++w)
+            for (int j = 0; j < 3; ++j) {
+                real acc = kb[c];
+                for (int dw = 0; dw < 3; ++dw) {
+                    const int r = w + dw - 1;
+                    if (r < 0 || r > 3) continue;                  /* zero padding of the window rows (padding=(1,0)) */
+                    for (int dj = 0; dj < 3; ++dj) acc += K[(c * 3 + dw) * 3 + dj] * in[r][j + dj];
+                }
+                z[(c * 4 + w) * 3 + j] = tanhr(acc);
+            }
+    for (int u = 0; u < H; ++u) {
+        real acc = bh[u];
+        for (int k = 0; k < RV_Z; ++k) acc += wh[u * RV_Z + k] * z[k];
+        hid[u] = tanhr(acc);
+    }
+    for (int c = 0; c < 2; ++c) {
+        real acc = bo[c];
+        for (int u = 0; u < H; ++u) acc += wo[c * H + u] * hid[u];
+        y[c] = acc;
+    }
+}
+static void rv_seq_fwd(int H, const real* p, int T, const real* x, real* y) {
+    real in[4][5], z[RV_Z], hid[MAXH];
+    for (int t = 0; t < T; ++t) rv_sample_fwd(H, p, T, x, t, in, z, hid, y + 2 * t);
+}
+/* dfeat: scratch of T x 5 reals (gradient w.r.t. the per-sample features, gathered over the <= 4 windows a sample sits in) */
+static void rv_seq_bwd(int H, const real* p, int T, const real* x, const real* dy, real* dp, real* dx, real* dfeat) {
+    const real* K = p; const real* wh = p + 30; const real* wo = wh + 36 * H + H;
+    real* dK = dp; real* dkb = dp + 27; real* dwh = dp + 30; real* dbh = dwh + 36 * H; real* dwo = dbh + H; real* dbo = dwo + 2 * H;
+    memset(dfeat, 0, sizeof(real) * 5 * T);
+    for (int t = 0; t < T; ++t) {
+        real in[4][5], z[RV_Z], hid[MAXH], yy[2], dz[RV_Z], din[4][5];
+        rv_sample_fwd(H, p, T, x, t, in, z, hid, yy);
+        const real d0 = dy[2 * t], d1 = dy[2 * t + 1];
+        dbo[0] += d0; dbo[1] += d1;
+        for (int k = 0; k < RV_Z; ++k) dz[k] = 0;
+        for (int u = 0; u < H; ++u) {
+            dwo[u] += d0 * hid[u]; dwo[H + u] += d1 * hid[u];
+            const real dh = (wo[u] * d0 + wo[H + u] * d1) * ((real)1 - hid[u] * hid[u]);
+            dbh[u] += dh;
+            for (int k = 0; k < RV_Z; ++k) { dwh[u * RV_Z + k] += dh * z[k]; dz[k] += wh[u * RV_Z + k] * dh; }
+        }
+        memset(din, 0, sizeof(din));
+        for (int c = 0; c < 3; ++c)
+            for (int w = 0; w < 4; ++w)
+                for (int j = 0; j < 3; ++j) {
+                    const int k = (c * 4 + w) * 3 + j;
+                    const real dc = dz[k] * ((real)1 - z[k] * z[k]);
+                    dkb[c] += dc;
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int r = w + dw - 1;
+                        if (r < 0 || r > 3) continue;
+                        for (int dj = 0; dj < 3; ++dj) {
+                            dK[(c * 3 + dw) * 3 + dj] += dc * in[r][j + dj];
+                            din[r][j + dj] += K[(c * 3 + dw) * 3 + dj] * dc;
+                        }
+                    }
+                }
+        for (int w = 0; w < 4; ++w)
+            for (int f = 0; f < 5; ++f) dfeat[5 * rv_idx(t, w, T) + f] += din[w][f];
+    }
+    if (!dx) return;
+    for (int s = 0; s < T; ++s) {      /* features [I,Q,a,a^2,a^3]: da/dI = I/a, da^2/dI = 2I, da^3/dI = 3 a I */
+        const real I = x[2 * s], Q = x[2 * s + 1];
+        const real a = (real)sqrt((double)(I * I + Q * Q));
+        const real* g = dfeat + 5 * s;
+        const real ga = g[2] / a + (real)2 * g[3] + (real)3 * a * g[4];
+        dx[2 * s] = g[0] + ga * I;
+        dx[2 * s + 1] = g[1] + ga * Q;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* dispatch                                                                                     */
 /* ------------------------------------------------------------------------------------------ */
 static int is_gru_family(int bb) { return bb == ODPD_GRU || bb == ODPD_DGRU || bb == ODPD_QGRU || bb == ODPD_QGRU_AMP1; }
@@ -1094,6 +1188,9 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         real* du = amp + (T + 2 * M - 2); real* damp = du + 2 * (T + M - 1);
         if (dy) gmp_seq_bwd(M, params, T, x, dy, dp, dx, u, amp, du, damp);
         else gmp_seq_fwd(M, params, T, x, y, u, amp);
+    } else if (bb == ODPD_RVTDCNN) {
+        if (dy) rv_seq_bwd(m->hidden, params, T, x, dy, dp, dx, (real*)scratch);
+        else rv_seq_fwd(m->hidden, params, T, x, y);
     }
 }
 static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
@@ -1104,6 +1201,7 @@ static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
     if (bb == ODPD_TCNN) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_PGJANET) return sizeof(pgj_step_t) * T;
     if (bb == ODPD_GMP) return sizeof(real) * (size_t)(6 * (T + 2 * m->hidden));
+    if (bb == ODPD_RVTDCNN) return T >= 3 ? sizeof(real) * (size_t)(5 * T) : 0;   /* the circular window needs 3 samples */
     return 0;
 }
 
