@@ -23,7 +23,6 @@ namespace {
 
 constexpr int kRvThreads = 256;
 constexpr int kRvZ = 36;                 // conv outputs per sample = fc_hid in_features (rvtdcnn.py:17)
-constexpr int kRvRound = 16;             // samples per MFMA round
 typedef const __attribute__((address_space(4))) float* WPtr;
 // a fresh name for the weight pointer: keeps the scalar loads of one weight row next to their use instead of hoisted out of
 // the sample loop (the 36 H weights of fc_hid would otherwise be live in SGPRs at once and spill)
@@ -35,12 +34,12 @@ __host__ __device__ inline RvLayout rv_layout(int H) {
     L.o_wh = 30; L.o_bh = 30 + kRvZ * H; L.o_wo = L.o_bh + H; L.o_bo = L.o_wo + 2 * H; L.P = L.o_bo + 2;
     return L;
 }
-// LDS row of one sample in an MFMA round: [dhp 16 HT | z 36 | 1 | dy0 dy1 0 | hid 16 HT]; row stride = 20 mod 32 floats (the
-// b128 row writes of 16 lanes then collide 2-way only, the column reads of the MFMA operands at most 2-way on 4 banks)
-template <int HT> struct RvRow {
-    static constexpr int oD = 0, oZ = 16 * HT, oOne = oZ + kRvZ, oDy = oOne + 1, oHid = oOne + 4, len = oHid + 16 * HT;
-    static constexpr int stride = HT == 1 ? 84 : 116;
-    static_assert(len <= stride && stride % 32 == 20 && oZ % 4 == 0 && oOne % 4 == 0, "row layout");
+// Per-wave LDS columns (sample = lane is the fast index; stride 68 = 4 mod 32 floats: the MFMA operand reads of lanes
+// (element m, sample 4c+k) land on banks 4m + k + const, 2-way at most): hid[u][s] (written by the forward row loop, read back by
+// the backward row loop AND as MFMA operands), z[k][s], dy[c][s].
+constexpr int kRvCol = 68;
+template <int HT> struct RvLds {
+    static constexpr int oHid = 0, oZ = 16 * HT * kRvCol, oDy = oZ + kRvZ * kRvCol, wave_floats = oDy + 2 * 64;
 };
 
 // tanh with relative accuracy near 0 (the conv pre-activations scale with the signal amplitude): polynomial below 0.3 blended
@@ -73,51 +72,78 @@ __device__ __forceinline__ void rv_patch(const float2* x2, size_t base, int t, i
     }
 }
 
-// forward of one sample (rvtdcnn.py:57-61): z = tanh(conv), hid = tanh(fc_hid z), y = fc_out hid
-template <int HT>
-__device__ __forceinline__ void rv_forward(WPtr w0, const RvLayout& L, const float (&in)[4][5], float (&z)[kRvZ], float (&hid)[16 * HT],
-                                           float& y0, float& y1) {
-    {
-        WPtr w = rv_fresh(w0);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    float acc = w[27 + c];
-#pragma unroll
-                    for (int dw = 0; dw < 3; ++dw)
-#pragma unroll
-                        for (int dj = 0; dj < 3; ++dj)
-                            if (r + dw - 1 >= 0 && r + dw - 1 <= 3)               // zero padding of the window rows
-                                acc = __builtin_fmaf(w[(c * 3 + dw) * 3 + dj], in[r + dw - 1][j + dj], acc);
-                    z[(c * 4 + r) * 3 + j] = rv_tanh(acc);
-                }
-    }
-#pragma unroll
-    for (int u = 0; u < 16 * HT; ++u) {
-        hid[u] = 0.0f;
-        if (u < L.H) {                                                          // wave-uniform
-            WPtr w = rv_fresh(w0);
-            float acc = w[L.o_bh + u];
-#pragma unroll
-            for (int k = 0; k < kRvZ; ++k) acc = __builtin_fmaf(w[30 + u * kRvZ + k], z[k], acc);
-            hid[u] = rv_tanh(acc);
-        }
-    }
+// z = tanh(Conv2d(patch)) (rvtdcnn.py:57-58); the 30 conv parameters are scalar operands, loaded here and dead afterwards
+__device__ __forceinline__ void rv_conv(WPtr w0, const float (&in)[4][5], float (&z)[kRvZ]) {
     WPtr w = rv_fresh(w0);
-    y0 = w[L.o_bo]; y1 = w[L.o_bo + 1];
 #pragma unroll
-    for (int u = 0; u < 16 * HT; ++u)
-        if (u < L.H) {
-            y0 = __builtin_fmaf(w[L.o_wo + u], hid[u], y0);
-            y1 = __builtin_fmaf(w[L.o_wo + L.H + u], hid[u], y1);
-        }
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float acc = w[27 + c];
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+                    for (int dj = 0; dj < 3; ++dj)
+                        if (r + dw - 1 >= 0 && r + dw - 1 <= 3)               // zero padding of the window rows
+                            acc = __builtin_fmaf(w[(c * 3 + dw) * 3 + dj], in[r + dw - 1][j + dj], acc);
+                z[(c * 4 + r) * 3 + j] = rv_tanh(acc);
+            }
 }
 
-template <int HT>
-__global__ __launch_bounds__(kRvThreads, 2) void rv_fwd_kernel(SeqArgs a) {
+// one row of fc_hid with what goes with unit u: its bias and the two fc_out weights — 39 scalars, loaded one row AHEAD of their use
+// (the row loops are run-time loops: the next row's s_loads are in flight while the current row's 36 FMAs issue)
+struct RvRowW { float w[kRvZ], b, o0, o1; };
+typedef float rv_f16 __attribute__((ext_vector_type(16), aligned(4)));
+typedef float rv_f4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void rv_load_row(WPtr w, const RvLayout& L, int u, RvRowW& r) {
+    // 36 consecutive weights as s_load_dwordx16 x 2 + s_load_dwordx4 (scalar loads need dword alignment only; left to itself the
+    // compiler issues 36 single-dword loads with an address computation each when the row index is a run-time value)
+    WPtr wr = w + 30 + u * kRvZ;
+    const rv_f16 v0 = *reinterpret_cast<const __attribute__((address_space(4))) rv_f16*>(wr);
+    const rv_f16 v1 = *reinterpret_cast<const __attribute__((address_space(4))) rv_f16*>(wr + 16);
+    const rv_f4 v2 = *reinterpret_cast<const __attribute__((address_space(4))) rv_f4*>(wr + 32);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { r.w[k] = v0[k]; r.w[16 + k] = v1[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.w[32 + k] = v2[k];
+    r.b = w[L.o_bh + u]; r.o0 = w[L.o_wo + u]; r.o1 = w[L.o_wo + L.H + u];
+}
+// hid_u = tanh(b_u + W_u . z) with four partial sums (a single accumulator is a 36-deep dependent chain)
+__device__ __forceinline__ float rv_hid(const RvRowW& r, const float (&z)[kRvZ]) {
+    float a0 = r.b, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRvZ; k += 4) {
+        a0 = __builtin_fmaf(r.w[k], z[k], a0); a1 = __builtin_fmaf(r.w[k + 1], z[k + 1], a1);
+        a2 = __builtin_fmaf(r.w[k + 2], z[k + 2], a2); a3 = __builtin_fmaf(r.w[k + 3], z[k + 3], a3);
+    }
+    return rv_tanh((a0 + a1) + (a2 + a3));
+}
+
+// Row loop with the scalar loads one row ahead.  Scalar loads return out of order, so any use of one waits for ALL outstanding
+// ones (s_waitcnt lgkmcnt(0)): a stage is therefore [wait for the current row] [issue the next row's loads] [36 FMAs of the
+// current row], with scheduling barriers so that the loads are not sunk below the arithmetic they are meant to overlap.  Two
+// register sets ping-pong (no copies); body(row, u) sees rows 0 .. H-1 in order.
+template <class Body>
+__device__ __forceinline__ void rv_rows(WPtr w, const RvLayout& L, Body&& body) {
+    RvRowW ra, rb;
+    rv_load_row(w, L, 0, ra);
+    for (int u = 0; u < L.H; u += 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rv_load_row(w, L, min(u + 1, L.H - 1), rb);
+        __builtin_amdgcn_sched_barrier(0);
+        body(ra, u);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rv_load_row(w, L, min(u + 2, L.H - 1), ra);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 1 < L.H) body(rb, u + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(kRvThreads, 6) void rv_fwd_kernel(SeqArgs a) {
     const RvLayout L = rv_layout(a.H);
     const WPtr w = (WPtr)a.params;
     const float2* x2 = reinterpret_cast<const float2*>(a.x);
@@ -125,10 +151,16 @@ __global__ __launch_bounds__(kRvThreads, 2) void rv_fwd_kernel(SeqArgs a) {
     const long long N = (long long)a.B * a.T;
     for (long long i = (long long)blockIdx.x * kRvThreads + threadIdx.x; i < N; i += (long long)gridDim.x * kRvThreads) {
         const int b = (int)(i / a.T), t = (int)(i - (long long)b * a.T);
-        float in[4][5], z[kRvZ], hid[16 * HT], y0, y1;
+        float in[4][5], z[kRvZ];
         float2 xv[4];
         rv_patch(x2, (size_t)b * a.T, t, a.T, in, xv);
-        rv_forward<HT>(w, L, in, z, hid, y0, y1);
+        rv_conv(w, in, z);
+        float y0 = w[L.o_bo], y1 = w[L.o_bo + 1];
+        rv_rows(w, L, [&](const RvRowW& r, int) {
+            const float h = rv_hid(r, z);
+            y0 = __builtin_fmaf(r.o0, h, y0);
+            y1 = __builtin_fmaf(r.o1, h, y1);
+        });
         y2[i] = make_float2(y0, y1);
     }
 }
@@ -158,13 +190,16 @@ static RvGeom rv_geom(int B, int T, bool dx) {
 // NW: weight-gradient partials (one row per workgroup)      DX: dL/dx
 template <int HT, bool FUSED, bool NW, bool DX>
 __global__ __launch_bounds__(kRvThreads, 2) void rv_bwd_kernel(SeqArgs a, RvGeom g) {
-    using Row = RvRow<HT>;
+    using Lds = RvLds<HT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RvLayout L = rv_layout(a.H);
     const WPtr w0 = (WPtr)a.params;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
-    float* tile = smem + (size_t)wave * kRvRound * Row::stride;                       // NW: the wave's MFMA round
-    float* din_x = smem + (NW ? (kRvThreads / 64) * kRvRound * Row::stride : 0);       // DX: patch gradients [thread][21]
+    float* wl = smem + (size_t)wave * Lds::wave_floats;
+    float* hidc = wl + Lds::oHid + lane;          // [u * kRvCol]
+    float* zc = wl + Lds::oZ + lane;              // [k * kRvCol]
+    float* dyc = wl + Lds::oDy;                   // [c * 64 + sample]
+    float* din_x = smem + Lds::oZ;                // DX: patch gradients [thread][21], over the z columns once the MFMAs have read them
     const float2* x2 = reinterpret_cast<const float2*>(a.x);
     const float2* d2 = reinterpret_cast<const float2*>(FUSED ? a.target : a.dy);
     float2* dx2 = reinterpret_cast<float2*>(a.dx);
@@ -172,6 +207,7 @@ __global__ __launch_bounds__(kRvThreads, 2) void rv_bwd_kernel(SeqArgs a, RvGeom
 
     f32x4 Dz[HT][3], Dh[HT];
     float dK[27], dkb[3], dbo[2] = {0.f, 0.f}, loss_acc = 0.0f;
+    float wo0[HT], wo1[HT];                       // fc_out weights of the units this lane feeds to the MFMA (element n of tile mt)
 #pragma unroll
     for (int i = 0; i < 27; ++i) dK[i] = 0.0f;
     dkb[0] = dkb[1] = dkb[2] = 0.0f;
@@ -180,6 +216,15 @@ __global__ __launch_bounds__(kRvThreads, 2) void rv_bwd_kernel(SeqArgs a, RvGeom
         Dh[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) Dz[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int u = 16 * mt + n;
+        wo0[mt] = u < L.H ? a.params[L.o_wo + u] : 0.0f;
+        wo1[mt] = u < L.H ? a.params[L.o_wo + L.H + u] : 0.0f;
+    }
+    // B-operand selectors of the third z tile (columns 32 + n): z[32..35], then the constant 1 (bias gradient), then nothing
+    const int zk2 = n < 4 ? 32 + n : 35;
+    const float zmul2 = n < 4 ? 1.0f : 0.0f, zadd2 = n == 4 ? 1.0f : 0.0f, ymask = n < 2 ? 1.0f : 0.0f;
+    if constexpr (NW) {       // units H .. 16 HT - 1 are never written by the row loops: their hid columns must read as numbers
+        for (int u = L.H; u < 16 * HT; ++u) hidc[u * kRvCol] = 0.0f;
     }
     const long long N = (long long)a.B * a.T;
 
@@ -201,14 +246,22 @@ __global__ __launch_bounds__(kRvThreads, 2) void rv_bwd_kernel(SeqArgs a, RvGeom
             active = owner = s < N;
             if (active) { b = (int)(s / a.T); t = (int)(s - (long long)b * a.T); }
         }
-        float z[kRvZ], hid[16 * HT], dhp[16 * HT], dy0 = 0.0f, dy1 = 0.0f;
-        float in[4][5];
+        float z[kRvZ], in[4][5], dy0, dy1;
         float2 xv[4];
+        const size_t base = rv_base(a, b);
+        rv_patch(x2, base, t, a.T, in, xv);
+        rv_conv(w0, in, z);
+        // ---- forward row loop: hid_u to its LDS column, y on the fly ----
+        if constexpr (DX) __syncthreads();             // the previous pass's patch-gradient gathers (over the z columns) are done
+        else wave_lds_fence();                         // ... MFMA operand reads
         {
-            const size_t base = rv_base(a, b);
-            rv_patch(x2, base, t, a.T, in, xv);
-            float y0, y1;
-            rv_forward<HT>(w0, L, in, z, hid, y0, y1);
+            float y0 = w0[L.o_bo], y1 = w0[L.o_bo + 1];
+            rv_rows(w0, L, [&](const RvRowW& r, int u) {
+                const float h = rv_hid(r, z);
+                hidc[u * kRvCol] = h;
+                y0 = __builtin_fmaf(r.o0, h, y0);
+                y1 = __builtin_fmaf(r.o1, h, y1);
+            });
             const float2 dv = d2[base + t];
             if constexpr (FUSED) {
                 float l = 0.0f;
@@ -219,64 +272,47 @@ __global__ __launch_bounds__(kRvThreads, 2) void rv_bwd_kernel(SeqArgs a, RvGeom
             }
             if (!active) { dy0 = 0.0f; dy1 = 0.0f; }       // an idle thread recomputes sample (0,0) and contributes zeros
         }
-        // ---- dL/d(fc_hid pre-activation) ----
-        {
-            WPtr w = rv_fresh(w0);
-#pragma unroll
-            for (int u = 0; u < 16 * HT; ++u) {
-                dhp[u] = 0.0f;
-                if (u < L.H)
-                    dhp[u] = __builtin_fmaf(w[L.o_wo + u], dy0, w[L.o_wo + L.H + u] * dy1) * __builtin_fmaf(-hid[u], hid[u], 1.0f);
-            }
-        }
-        // ---- weight gradients of fc_hid / fc_out: contraction over the wave's 64 samples, 16 at a time ----
+        // ---- weight gradients of fc_hid / fc_out: contraction over the wave's 64 samples on the MFMA, operands straight from
+        //      the LDS columns; dhp = (W_out^T dy) (1 - hid^2) is formed in the operand layout (element n of a tile, sample 4c+q)
         if constexpr (NW) {
             const float own = owner ? 1.0f : 0.0f;
             dbo[0] = __builtin_fmaf(own, dy0, dbo[0]); dbo[1] = __builtin_fmaf(own, dy1, dbo[1]);
-#pragma unroll 1
-            for (int r = 0; r < 4; ++r) {
-                wave_lds_fence();
-                if (q == r) {
-                    float4* row = reinterpret_cast<float4*>(tile + n * Row::stride);
 #pragma unroll
-                    for (int v = 0; v < 4 * HT; ++v)
-                        row[Row::oD / 4 + v] = make_float4(own * dhp[4 * v], own * dhp[4 * v + 1], own * dhp[4 * v + 2], own * dhp[4 * v + 3]);
+            for (int k = 0; k < kRvZ; ++k) zc[k * kRvCol] = z[k];
+            dyc[lane] = own * dy0; dyc[64 + lane] = own * dy1;     // halo / idle samples contribute zero rows
+            wave_lds_fence();
+#pragma unroll 4
+            for (int c = 0; c < 16; ++c) {
+                const int s = 4 * c + q;
+                const float e0 = dyc[s], e1 = dyc[64 + s];
+                const float ay = ymask * dyc[(n & 1) * 64 + s];
+                float hv[HT], ad[HT], bz[3];
 #pragma unroll
-                    for (int v = 0; v < kRvZ / 4; ++v) row[Row::oZ / 4 + v] = make_float4(z[4 * v], z[4 * v + 1], z[4 * v + 2], z[4 * v + 3]);
-                    row[Row::oOne / 4] = make_float4(1.0f, own * dy0, own * dy1, 0.0f);
-#pragma unroll
-                    for (int v = 0; v < 4 * HT; ++v) row[Row::oHid / 4 + v] = make_float4(hid[4 * v], hid[4 * v + 1], hid[4 * v + 2], hid[4 * v + 3]);
+                for (int mt = 0; mt < HT; ++mt) {
+                    hv[mt] = wl[Lds::oHid + (16 * mt + n) * kRvCol + s];
+                    ad[mt] = __builtin_fmaf(wo0[mt], e0, wo1[mt] * e1) * __builtin_fmaf(-hv[mt], hv[mt], 1.0f);
                 }
-                wave_lds_fence();
+                bz[0] = wl[Lds::oZ + n * kRvCol + s];
+                bz[1] = wl[Lds::oZ + (16 + n) * kRvCol + s];
+                bz[2] = __builtin_fmaf(wl[Lds::oZ + zk2 * kRvCol + s], zmul2, zadd2);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float* rp = tile + (4 * c + q) * Row::stride + n;      // sample 4c+q of the round, element n of a tile
-                    float ad[HT], bz[3], bh[HT];
-                    const float ay = rp[Row::oDy];
+                for (int mt = 0; mt < HT; ++mt) {
 #pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) { ad[mt] = rp[Row::oD + 16 * mt]; bh[mt] = rp[Row::oHid + 16 * mt]; }
-#pragma unroll
-                    for (int nt = 0; nt < 3; ++nt) bz[nt] = rp[Row::oZ + 16 * nt];
-#pragma unroll
-                    for (int mt = 0; mt < HT; ++mt) {
-#pragma unroll
-                        for (int nt = 0; nt < 3; ++nt) Dz[mt][nt] = mfma4(ad[mt], bz[nt], Dz[mt][nt]);
-                        Dh[mt] = mfma4(ay, bh[mt], Dh[mt]);
-                    }
+                    for (int nt = 0; nt < 3; ++nt) Dz[mt][nt] = mfma4(ad[mt], bz[nt], Dz[mt][nt]);
+                    Dh[mt] = mfma4(ay, hv[mt], Dh[mt]);
                 }
             }
         }
-        // ---- dL/dz = W_hid^T dhp, through tanh ----
+        // ---- backward row loop: dL/dz = W_hid^T dhp (36 independent accumulators), through tanh ----
         float dc[kRvZ];
 #pragma unroll
         for (int k = 0; k < kRvZ; ++k) dc[k] = 0.0f;
+        rv_rows(w0, L, [&](const RvRowW& r, int u) {
+            const float h = hidc[u * kRvCol];
+            const float dhp = __builtin_fmaf(r.o0, dy0, r.o1 * dy1) * __builtin_fmaf(-h, h, 1.0f);
 #pragma unroll
-        for (int u = 0; u < 16 * HT; ++u)
-            if (u < L.H) {
-                WPtr w = rv_fresh(w0);
-#pragma unroll
-                for (int k = 0; k < kRvZ; ++k) dc[k] = __builtin_fmaf(w[30 + u * kRvZ + k], dhp[u], dc[k]);
-            }
+            for (int k = 0; k < kRvZ; ++k) dc[k] = __builtin_fmaf(r.w[k], dhp, dc[k]);
+        });
 #pragma unroll
         for (int k = 0; k < kRvZ; ++k) dc[k] *= __builtin_fmaf(-z[k], z[k], 1.0f);
         // ---- convolution: weight gradients (per-lane accumulators) and patch gradient ----
@@ -320,7 +356,7 @@ __global__ __launch_bounds__(kRvThreads, 2) void rv_bwd_kernel(SeqArgs a, RvGeom
                                     if (r + dw - 1 >= 0 && r + dw - 1 <= 3)
                                         din[r + dw - 1][j + dj] = __builtin_fmaf(w[(c * 3 + dw) * 3 + dj], dc[(c * 4 + r) * 3 + j], din[r + dw - 1][j + dj]);
             }
-            __syncthreads();                                   // the previous pass's gathers are done
+            __syncthreads();                                   // every wave's MFMAs have read the z columns
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -387,15 +423,15 @@ __global__ __launch_bounds__(kRvThreads, 2) void rv_bwd_kernel(SeqArgs a, RvGeom
 }
 
 template <int HT> size_t rv_lds_bytes(int P, bool nw, bool dx) {
-    size_t n = 0;
-    if (nw) n += (size_t)(kRvThreads / 64) * kRvRound * RvRow<HT>::stride;
-    if (dx) n += (size_t)(kRvThreads + 3) * 21;
+    size_t n = (size_t)(kRvThreads / 64) * RvLds<HT>::wave_floats;
+    const size_t ex = dx ? (size_t)RvLds<HT>::oZ + (size_t)(kRvThreads + 3) * 21 : 0;     // patch-gradient exchange over the z columns
     const size_t rows = nw ? (size_t)(kRvThreads / 64) * (P + kLossCols) : 0;
+    n = n > ex ? n : ex;
     return (n > rows ? n : rows) * sizeof(float);
 }
 inline bool rv_ok(const odpd_model_t* m, int T) { return m->hidden >= 1 && m->hidden <= 32 && T >= 3; }
-inline int rv_grid(int npass) {
-    const int cap = device_cus() * 2;
+inline int rv_grid(int npass, int blocks_per_cu = 2) {
+    const int cap = device_cus() * blocks_per_cu;
     return npass < cap ? (npass < 1 ? 1 : npass) : cap;
 }
 
@@ -430,9 +466,8 @@ int rvtdcnn_rows(const odpd_model_t* m, int B, int T) {
 int rvtdcnn_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!rv_ok(m, a.T)) return ODPD_EUNSUPPORTED;
     const long long N = (long long)a.B * a.T;
-    const int grid = rv_grid((int)((N + kRvThreads - 1) / kRvThreads));
-    if (m->hidden <= 16) hipLaunchKernelGGL(rv_fwd_kernel<1>, dim3(grid), dim3(kRvThreads), 0, st, a);
-    else hipLaunchKernelGGL(rv_fwd_kernel<2>, dim3(grid), dim3(kRvThreads), 0, st, a);
+    const int grid = rv_grid((int)((N + kRvThreads - 1) / kRvThreads), 6);       // 59 VGPRs: six waves per SIMD hide the scalar loads
+    hipLaunchKernelGGL(rv_fwd_kernel, dim3(grid), dim3(kRvThreads), 0, st, a);
     return (int)hipGetLastError();
 }
 
