@@ -40,7 +40,8 @@ enum odpd_backbone {
     ODPD_PGJANET = 9,    /* backbones/pgjanet.py:5-84 */
     ODPD_GMP = 10,       /* backbones/gmp.py:5-50 (hidden = memory_length; degree 5 as built by models.py:26-28) */
     ODPD_RVTDCNN = 11,   /* backbones/rvtdcnn.py:9-62 (hidden = fc_hid_size, models.py:80-81; window 4, 3 conv channels) */
-    ODPD_BACKBONE_COUNT = 12
+    ODPD_NEURALTX = 12,  /* backbones/neuraltx.py:5-137 (hidden = hidden_channels; complex 5-tap FIR + the TCNN stack on 4 features) */
+    ODPD_BACKBONE_COUNT = 13
 };
 
 enum odpd_error {

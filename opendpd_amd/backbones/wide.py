@@ -1,7 +1,7 @@
 """ATen restatements of the kernel-backed backbones for configurations OUTSIDE the HIP kernels' envelope.
 
 The HIP kernels cover what the reference's scripts and BASELINE configs use: one recurrent layer, hidden size <= 32
-(pgjanet, QAT: <= 16; tcnn: <= 64 channels; rvtdcnn: fc_hid_size <= 32).  The reference's registry accepts any `hidden_size` / `num_layers`
+(pgjanet, QAT: <= 16; tcnn, neuraltx: <= 64 channels; rvtdcnn: fc_hid_size <= 32).  The reference's registry accepts any `hidden_size` / `num_layers`
 (models.py:11), so `CoreModel` builds one of the modules below for a configuration beyond those limits: same parameter
 names / shapes / initialisation and the same arithmetic as the reference class, executed by PyTorch-ROCm's own GPU
 operators (MIOpen RNN, ATen convolutions) — `native` is False, a warning says so once per configuration, the fused
@@ -20,7 +20,7 @@ from .native import init_gatewise, init_linear
 
 # largest hidden size (tcnn: channel count) the HIP kernels of a registry name run, single layer
 KERNEL_HIDDEN_LIMIT = {"gru": 32, "dgru": 32, "qgru": 32, "qgru_amp1": 32, "lstm": 32, "vdlstm": 32, "deltagru": 32,
-                       "deltagru_tcnskip": 32, "pgjanet": 16, "tcnn": 64, "rvtdcnn": 32}
+                       "deltagru_tcnskip": 32, "pgjanet": 16, "tcnn": 64, "rvtdcnn": 32, "neuraltx": 64}
 _warned = set()
 
 
@@ -28,7 +28,7 @@ def outside_envelope(backbone_type, hidden_size, num_layers):
     lim = KERNEL_HIDDEN_LIMIT.get(backbone_type)
     if lim is None:
         return False
-    return hidden_size > lim or (num_layers != 1 and backbone_type not in ("pgjanet", "tcnn", "rvtdcnn"))
+    return hidden_size > lim or (num_layers != 1 and backbone_type not in ("pgjanet", "tcnn", "rvtdcnn", "neuraltx"))
 
 
 def announce(backbone_type, hidden_size, num_layers):
@@ -363,4 +363,7 @@ def build(backbone_type, input_size, hidden_size, num_layers, thx=0, thh=0):
     if backbone_type == "rvtdcnn":
         from .extras import RVTDCNN         # the ATen restatement that served every size before csrc/rvtdcnn.hip
         return RVTDCNN(fc_hid_size=hidden_size)
+    if backbone_type == "neuraltx":
+        from .extras import NeuralTX
+        return NeuralTX(hidden_channels=hidden_size)
     raise ValueError(backbone_type)

@@ -18,7 +18,7 @@ inline Family family_of(int bb) {
     case ODPD_LSTM: case ODPD_VDLSTM: return FAM_LSTM;
     case ODPD_DELTAGRU: case ODPD_TRES_DELTAGRU: return FAM_DELTA;
     case ODPD_PGJANET: return FAM_JANET;
-    case ODPD_TCNN: return FAM_TCNN;
+    case ODPD_TCNN: case ODPD_NEURALTX: return FAM_TCNN;
     case ODPD_GMP: return FAM_GMP;
     case ODPD_RVTDCNN: return FAM_RVTDCNN;
     default: return FAM_NONE;
@@ -83,6 +83,7 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_TRES_DELTAGRU: return 3 * H * 6 + 3 * H * H + 2 * H + 18 + 6;
     case ODPD_TCNN: return 6 * H + H + 4 * 5 * H + 2 * H;
     case ODPD_PGJANET: return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
+    case ODPD_NEURALTX: return H <= 64 ? 27 * H + 14 : (int64_t)ODPD_EUNSUPPORTED;   // two 5-tap FIRs, 4->C (+bias), 4 x depthwise k5, C->2, IQ_match 2x2
     case ODPD_GMP: return H == 11 ? H * (1 + 4 * H) : (int64_t)ODPD_EUNSUPPORTED;   // memory_length 11, degree 5 (models.py:26-28)
     case ODPD_RVTDCNN: return H <= 32 ? 39 * H + 32 : (int64_t)ODPD_EUNSUPPORTED;  // conv 27+3, fc_hid 36H+H, fc_out 2H+2 (rvtdcnn.py:19-33)
     default: return ODPD_EUNSUPPORTED;

@@ -18,6 +18,11 @@
 //             (pre-activations stay in registers), back-propagated, the 29 per-channel gradients are reduced over the
 //             wave and added to the wave's accumulator row in LDS; block sum -> partial row blockIdx.x.
 //   dL/dx   : (frozen PA of a cascade) as backward without the weight gradients; dL/dfeat accumulates in registers.
+//
+// NTX = true: the NeuralTX backbone (backbones/neuraltx.py:5-137) on the same tiles — a complex 5-tap FIR in front (conv_I / conv_Q,
+// zero padding 2: the taps are the same DPP row shifts as the depthwise taps), the stack on the 4 features [f_I, f_Q, |f|, |f|^3]
+// of the FILTERED signal, and y = net + IQ_match f + f.  Its backward kernels additionally accumulate dL/dfeat over the wave's
+// channels and turn it into the FIR tap gradients (weights kernel) or, through the transposed FIR, into dL/dx (dx kernel).
 #include <type_traits>
 #include <utility>
 
@@ -25,17 +30,22 @@
 
 namespace odpd {
 
-struct TcnnLayout { int C, o_w0, o_b0, o_dw[4], o_w5, P; };
-__host__ __device__ inline TcnnLayout tcnn_layout(int C) {
-    TcnnLayout L; L.C = C; int o = 0;
-    L.o_w0 = o; o += 6 * C; L.o_b0 = o; o += C;
+struct TcnnLayout { int C, F, o_ci, o_cq, o_w0, o_b0, o_dw[4], o_w5, o_m, P; };
+__host__ __device__ inline TcnnLayout tcnn_layout(int C, bool ntx = false) {
+    TcnnLayout L; L.C = C; L.F = ntx ? 4 : 6; int o = 0;
+    L.o_ci = o; L.o_cq = o + 5;
+    if (ntx) o += 10;                                     // conv_I.weight, conv_Q.weight (neuraltx.py:18-19)
+    L.o_w0 = o; o += L.F * C; L.o_b0 = o; o += C;
     for (int l = 0; l < 4; ++l) { L.o_dw[l] = o; o += 5 * C; }
     L.o_w5 = o; o += 2 * C;
+    L.o_m = o;
+    if (ntx) o += 4;                                      // IQ_match.weight (2,2) (neuraltx.py:38)
     L.P = o;
     return L;
 }
 constexpr int kTHalo = 30;     // receptive-field radius 2 * (1 + 2 + 4 + 8)
 constexpr int kTHaloDx = 60;   // dx[t] needs dL/dpre at t +- 30, whose activations need x at +- 30 around them
+constexpr int kNtxFir = 2;     // NeuralTX: the FIR in front adds 2 steps each side (and 2 more for the transposed FIR of dL/dx)
 
 // tile geometry: B * ntiles row-sized work items (sequence-major), four of them per wave
 struct TcnnGeom { int R, halo, tile, ntiles, ngroups; };
@@ -104,7 +114,7 @@ struct TcnnChan { float w0[6], b0, dw[4][5], w5[2]; };
 __device__ __forceinline__ TcnnChan tcnn_chan(const float* __restrict__ p, const TcnnLayout& L, int c) {
     TcnnChan k;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) k.w0[i] = p[L.o_w0 + c * 6 + i];
+    for (int i = 0; i < 6; ++i) k.w0[i] = i < L.F ? p[L.o_w0 + c * L.F + i] : 0.0f;
     k.b0 = p[L.o_b0 + c];
 #pragma unroll
     for (int l = 0; l < 4; ++l)
@@ -114,12 +124,25 @@ __device__ __forceinline__ TcnnChan tcnn_chan(const float* __restrict__ p, const
     return k;
 }
 
-// the row's tile: sequence b, element i of lane r at time t0 + i
-template <int R>
+// NeuralTX parameters outside the channel stack (wave-uniform)
+struct NtxFir { float ci[5], cq[5], m[4]; };
+__device__ __forceinline__ NtxFir ntx_fir(const float* __restrict__ p, const TcnnLayout& L) {
+    NtxFir f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { f.ci[k] = p[L.o_ci + k]; f.cq[k] = p[L.o_cq + k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) f.m[k] = p[L.o_m + k];
+    return f;
+}
+
+// the row's tile: sequence b, element i of lane r at time t0 + i.  xi / xq = what the channel stack sees (NTX: the filtered
+// signal f); NTX keeps the raw samples in rxi / rxq (0 outside the frame = the FIR's zero padding)
+template <int R, bool NTX = false>
 struct TcnnTile {
     int b, t0, own0, own1;   // [own0, own1): steps this tile writes y / dx for and reads dy of (weight gradients)
     bool bok;
     float xi[R], xq[R], am[R], ia[R];
+    float rxi[NTX ? R : 1], rxq[NTX ? R : 1];
     bool valid[R];
     __device__ __forceinline__ void locate(const SeqArgs& a, const TcnnGeom& g, int grp, bool active, int lane) {
         const int r = lane & 15, item = grp * 4 + (lane >> 4), ti = item % g.ntiles;
@@ -127,15 +150,34 @@ struct TcnnTile {
         own0 = ti * g.tile; own1 = min(own0 + g.tile, a.T);
         t0 = own0 - g.halo + R * r;
     }
-    __device__ __forceinline__ void load_x(const SeqArgs& a) {
+    __device__ __forceinline__ void load_x(const SeqArgs& a, const NtxFir* fir = nullptr) {
         const float2* x2 = reinterpret_cast<const float2*>(a.x) + (size_t)(bok ? b : 0) * a.T;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int t = t0 + i;
             valid[i] = bok && t >= 0 && t < a.T;
-            const float2 v = valid[i] ? x2[t] : make_float2(1.0f, 0.0f);
+            const float2 v = valid[i] ? x2[t] : (NTX ? make_float2(0.0f, 0.0f) : make_float2(1.0f, 0.0f));
             xi[i] = v.x; xq[i] = v.y;
-            const float a2 = __builtin_fmaf(v.x, v.x, v.y * v.y);
+        }
+        if constexpr (NTX) {
+            // f_I = cI * xI - cQ * xQ,  f_Q = cQ * xI + cI * xQ   (neuraltx.py:122-123; Conv1d = cross-correlation, padding 2)
+            float nq[5], s0[R], s1[R];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) nq[k] = -fir->cq[k];
+#pragma unroll
+            for (int i = 0; i < R; ++i) { rxi[i] = xi[i]; rxq[i] = xq[i]; }
+            conv5<R, 1, 1>(s0, rxi, fir->ci);
+            conv5<R, 1, 1>(s1, rxq, nq);
+#pragma unroll
+            for (int i = 0; i < R; ++i) xi[i] = s0[i] + s1[i];
+            conv5<R, 1, 1>(s0, rxi, fir->cq);
+            conv5<R, 1, 1>(s1, rxq, fir->ci);
+#pragma unroll
+            for (int i = 0; i < R; ++i) xq[i] = s0[i] + s1[i];
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float a2 = __builtin_fmaf(xi[i], xi[i], xq[i] * xq[i]);
             am[i] = __builtin_amdgcn_sqrtf(a2); ia[i] = fast_rcp(am[i]);
         }
     }
@@ -145,16 +187,18 @@ struct TcnnTile {
         v = __builtin_fmaf(k.w0[1], xq[i], v);
         v = __builtin_fmaf(k.w0[2], am[i], v);
         v = __builtin_fmaf(k.w0[3], am[i] * am[i] * am[i], v);
-        v = __builtin_fmaf(k.w0[4], xq[i] * ia[i], v);
-        v = __builtin_fmaf(k.w0[5], xi[i] * ia[i], v);
+        if constexpr (!NTX) {
+            v = __builtin_fmaf(k.w0[4], xq[i] * ia[i], v);
+            v = __builtin_fmaf(k.w0[5], xi[i] * ia[i], v);
+        }
         return valid[i] ? v : kDead;
     }
     __device__ __forceinline__ bool owns(int i) const { return valid[i] && t0 + i >= own0 && t0 + i < own1; }
 };
 
 // forward of one channel; pre[l] = pre-activation of stage l (0: input conv, 1..4: depthwise), returns act of stage 4
-template <int R, bool KEEP>
-__device__ __forceinline__ void tcnn_chan_fwd(const TcnnTile<R>& tl, const TcnnChan& k, float (&pre)[5][R], float (&act)[R]) {
+template <int R, bool KEEP, bool NTX>
+__device__ __forceinline__ void tcnn_chan_fwd(const TcnnTile<R, NTX>& tl, const TcnnChan& k, float (&pre)[5][R], float (&act)[R]) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         const float v = tl.pre0(k, i);
@@ -176,15 +220,17 @@ __device__ __forceinline__ void tcnn_chan_fwd(const TcnnTile<R>& tl, const TcnnC
 
 // grid = ceil(ngroups * ncw / 4) blocks of 4 waves; ncw in {1, 2, 4} waves share a tile's channels (wave j takes
 // channels j, j + ncw, ...); LDS = 4 * 2R * 64 floats when ncw > 1
-template <int R>
+template <int R, bool NTX>
 __global__ __launch_bounds__(256) void tcnn_fwd_kernel(SeqArgs a, TcnnGeom g, int ncw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const TcnnLayout L = tcnn_layout(a.H);
+    const TcnnLayout L = tcnn_layout(a.H, NTX);
     const int gw = blockIdx.x * 4 + wave, grp = gw / ncw, cs = gw % ncw;
-    TcnnTile<R> tl;
+    TcnnTile<R, NTX> tl;
     tl.locate(a, g, grp, grp < g.ngroups, lane);
-    tl.load_x(a);
+    NtxFir fir;
+    if constexpr (NTX) fir = ntx_fir(a.params, L);
+    tl.load_x(a, &fir);
     float y0[R], y1[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) y0[i] = y1[i] = 0.0f;
@@ -213,7 +259,15 @@ __global__ __launch_bounds__(256) void tcnn_fwd_kernel(SeqArgs a, TcnnGeom g, in
     float2* y2 = reinterpret_cast<float2*>(a.y) + (size_t)(tl.bok ? tl.b : 0) * a.T;
 #pragma unroll
     for (int i = 0; i < R; ++i)
-        if (tl.owns(i)) y2[tl.t0 + i] = make_float2(y0[i] + tl.xi[i], y1[i] + tl.xq[i]);     // + residual [I, Q]
+        if (tl.owns(i)) {
+            if constexpr (NTX) {      // + IQ_match f + f (neuraltx.py:135)
+                const float r0 = __builtin_fmaf(fir.m[0], tl.xi[i], __builtin_fmaf(fir.m[1], tl.xq[i], tl.xi[i]));
+                const float r1 = __builtin_fmaf(fir.m[2], tl.xi[i], __builtin_fmaf(fir.m[3], tl.xq[i], tl.xq[i]));
+                y2[tl.t0 + i] = make_float2(y0[i] + r0, y1[i] + r1);
+            } else {
+                y2[tl.t0 + i] = make_float2(y0[i] + tl.xi[i], y1[i] + tl.xq[i]);     // + residual [I, Q]
+            }
+        }
 }
 
 // back-propagation of one channel from g = dL/d act_4 down to gp0 = dL/d pre_0; GW: accumulate the weight gradients
@@ -245,7 +299,7 @@ __device__ __forceinline__ void tcnn_deposit(float v, int r, float& depA, float&
 }
 // column of gradient j (0..5 w0, 6 b0, 7..26 depthwise taps, 27..28 w5) of channel c in the parameter row
 __device__ __forceinline__ int tcnn_col(const TcnnLayout& L, int c, int j) {
-    if (j < 6) return L.o_w0 + c * 6 + j;
+    if (j < 6) return L.o_w0 + c * L.F + (j < L.F ? j : 0);        // NeuralTX has 4 input features: columns 4, 5 carry zeros
     if (j == 6) return L.o_b0 + c;
     if (j < 27) return L.o_dw[0] + ((j - 7) / 5) * 5 * L.C + c * 5 + (j - 7) % 5;
     return L.o_w5 + (j - 27) * L.C + c;
@@ -253,20 +307,29 @@ __device__ __forceinline__ int tcnn_col(const TcnnLayout& L, int c, int j) {
 
 // grid = rows blocks of 4 waves; wave gw works on tiles gw / ncw, + nwaves / ncw, ... and channels gw % ncw, + ncw, ...
 // LDS per wave: accumulator row of P floats + the tile's dy (R float2 per lane, [i][lane]: conflict-free ds_read_b64)
-template <int R>
-__global__ __launch_bounds__(256, R <= 13 ? 2 : 1) void tcnn_bwd_kernel(SeqArgs a, TcnnGeom g, int ncw) {
+template <int R, bool NTX>
+__global__ __launch_bounds__(256, (R <= 13 && !NTX) ? 2 : 1) void tcnn_bwd_kernel(SeqArgs a, TcnnGeom g, int ncw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15;
-    const TcnnLayout L = tcnn_layout(a.H);
+    const TcnnLayout L = tcnn_layout(a.H, NTX);
+    NtxFir fir;
+    if constexpr (NTX) fir = ntx_fir(a.params, L);
     const int Pp = pad4(L.P);
     float* row = smem + wave * Pp;
     float2* dyl = reinterpret_cast<float2*>(smem + 4 * Pp) + wave * (R * 64) + lane;
     for (int i = lane; i < L.P; i += 64) row[i] = 0.0f;
     const int gw = blockIdx.x * 4 + wave, cs = gw % ncw, gstep = gridDim.x * 4 / ncw;
     for (int grp = gw / ncw; grp < g.ngroups; grp += gstep) {
-        TcnnTile<R> tl;
+        TcnnTile<R, NTX> tl;
         tl.locate(a, g, grp, true, lane);
-        tl.load_x(a);
+        tl.load_x(a, &fir);
+        float dfa[NTX ? 4 : 1][R];          // NTX: dL/d[f_I, f_Q, |f|, |f|^3] summed over this wave's channels
+        if constexpr (NTX) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < R; ++i) dfa[j][i] = 0.0f;
+        }
         {
             const float2* d2 = reinterpret_cast<const float2*>(a.dy) + (size_t)(tl.bok ? tl.b : 0) * a.T;
             wave_lds_fence();
@@ -299,8 +362,13 @@ __global__ __launch_bounds__(256, R <= 13 ? 2 : 1) void tcnn_bwd_kernel(SeqArgs 
                 gw0[1] = __builtin_fmaf(gp0, tl.xq[i], gw0[1]);
                 gw0[2] = __builtin_fmaf(gp0, tl.am[i], gw0[2]);
                 gw0[3] = __builtin_fmaf(gp0, tl.am[i] * tl.am[i] * tl.am[i], gw0[3]);
-                gw0[4] = __builtin_fmaf(gp0, tl.xq[i] * tl.ia[i], gw0[4]);
-                gw0[5] = __builtin_fmaf(gp0, tl.xi[i] * tl.ia[i], gw0[5]);
+                if constexpr (!NTX) {
+                    gw0[4] = __builtin_fmaf(gp0, tl.xq[i] * tl.ia[i], gw0[4]);
+                    gw0[5] = __builtin_fmaf(gp0, tl.xi[i] * tl.ia[i], gw0[5]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dfa[j][i] = __builtin_fmaf(gp0, k.w0[j], dfa[j][i]);
+                }
             }
             // row sums deposited on lanes 0..15 (A) / 0..12 (B) of every row, then the four rows add to the wave's
             // accumulator row one after the other (LDS operations of a wave execute in order: fixed summation order)
@@ -321,6 +389,35 @@ __global__ __launch_bounds__(256, R <= 13 ? 2 : 1) void tcnn_bwd_kernel(SeqArgs 
                     if (r < 13) atomicAdd(&row[colB], depB);
                 }
         }
+        if constexpr (NTX) {
+            // skip paths y = net + IQ_match f + f (one of the channel-split waves adds them), then dL/df through |f| and the FIR
+            // tap gradients dL/dcI[k] = sum_t gI[t] xI[t+k-2] + gQ[t] xQ[t+k-2], dL/dcQ[k] = sum_t gQ[t] xI[t+k-2] - gI[t] xQ[t+k-2]
+            float gm[4] = {0.f, 0.f, 0.f, 0.f}, gI[R], gQ[R], nI[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const float2 dy = cs == 0 ? dyl[i * 64] : make_float2(0.0f, 0.0f);
+                gm[0] = __builtin_fmaf(dy.x, tl.xi[i], gm[0]); gm[1] = __builtin_fmaf(dy.x, tl.xq[i], gm[1]);
+                gm[2] = __builtin_fmaf(dy.y, tl.xi[i], gm[2]); gm[3] = __builtin_fmaf(dy.y, tl.xq[i], gm[3]);
+                const float d4[4] = {dfa[0][i] + __builtin_fmaf(dy.x, fir.m[0], __builtin_fmaf(dy.y, fir.m[2], dy.x)),
+                                     dfa[1][i] + __builtin_fmaf(dy.x, fir.m[1], __builtin_fmaf(dy.y, fir.m[3], dy.y)), dfa[2][i], dfa[3][i]};
+                float dI, dQ;
+                feat_bwd<FEAT_A4>(tl.xi[i], tl.xq[i], d4, dI, dQ);
+                gI[i] = tl.valid[i] ? dI : 0.0f; gQ[i] = tl.valid[i] ? dQ : 0.0f; nI[i] = -gI[i];
+            }
+            float gci[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, gcq[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            conv5_wgrad<R, 1>(gci, gI, tl.rxi);
+            conv5_wgrad<R, 1>(gci, gQ, tl.rxq);
+            conv5_wgrad<R, 1>(gcq, gQ, tl.rxi);
+            conv5_wgrad<R, 1>(gcq, nI, tl.rxq);
+            float depA = 0.0f, depB = 0.0f;
+            static_for<5>([&](auto jc) { tcnn_deposit<decltype(jc)::value>(gci[decltype(jc)::value], r, depA, depB); });
+            static_for<5>([&](auto jc) { tcnn_deposit<5 + decltype(jc)::value>(gcq[decltype(jc)::value], r, depA, depB); });
+            static_for<4>([&](auto jc) { tcnn_deposit<10 + decltype(jc)::value>(gm[decltype(jc)::value], r, depA, depB); });
+            const int col = r < 10 ? L.o_ci + r : L.o_m + (r < 14 ? r - 10 : 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((lane >> 4) == q && r < 14) atomicAdd(&row[col], depA);
+        }
     }
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
@@ -329,16 +426,19 @@ __global__ __launch_bounds__(256, R <= 13 ? 2 : 1) void tcnn_bwd_kernel(SeqArgs 
 }
 
 // grid as the forward; dy is read over the whole tile (halo included); LDS = 4 * 6R * 64 floats when ncw > 1
-template <int R>
+template <int R, bool NTX>
 __global__ __launch_bounds__(256, 1) void tcnn_dx_kernel(SeqArgs a, TcnnGeom g, int ncw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const TcnnLayout L = tcnn_layout(a.H);
+    const TcnnLayout L = tcnn_layout(a.H, NTX);
+    constexpr int F = NTX ? 4 : 6;
     const int gw = blockIdx.x * 4 + wave, grp = gw / ncw, cs = gw % ncw;
-    TcnnTile<R> tl;
+    TcnnTile<R, NTX> tl;
     tl.locate(a, g, grp, grp < g.ngroups, lane);
-    tl.load_x(a);
-    float dy0[R], dy1[R], df[6][R];
+    NtxFir fir;
+    if constexpr (NTX) fir = ntx_fir(a.params, L);
+    tl.load_x(a, &fir);
+    float dy0[R], dy1[R], df[F][R];
     {
         const float2* d2 = reinterpret_cast<const float2*>(a.dy) + (size_t)(tl.bok ? tl.b : 0) * a.T;
 #pragma unroll
@@ -346,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void tcnn_dx_kernel(SeqArgs a, TcnnGeom g, 
             const float2 v = tl.valid[i] ? d2[tl.t0 + i] : make_float2(0.0f, 0.0f);
             dy0[i] = v.x; dy1[i] = v.y;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) df[j][i] = 0.0f;
+            for (int j = 0; j < F; ++j) df[j][i] = 0.0f;
         }
     }
     for (int c = cs; c < L.C; c += ncw) {
@@ -359,14 +459,14 @@ __global__ __launch_bounds__(256, 1) void tcnn_dx_kernel(SeqArgs a, TcnnGeom g, 
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) df[j][i] = __builtin_fmaf(gg[i], k.w0[j], df[j][i]);
+            for (int j = 0; j < F; ++j) df[j][i] = __builtin_fmaf(gg[i], k.w0[j], df[j][i]);
     }
     if (ncw > 1) {
         float* mine = smem + wave * (6 * R * 64);
 #pragma unroll
         for (int i = 0; i < R; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) mine[(6 * i + j) * 64 + lane] = df[j][i];
+            for (int j = 0; j < F; ++j) mine[(6 * i + j) * 64 + lane] = df[j][i];
         __syncthreads();
         if (cs != 0) return;
         for (int w = 1; w < ncw; ++w) {
@@ -374,19 +474,42 @@ __global__ __launch_bounds__(256, 1) void tcnn_dx_kernel(SeqArgs a, TcnnGeom g, 
 #pragma unroll
             for (int i = 0; i < R; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) df[j][i] += o[(6 * i + j) * 64 + lane];
+                for (int j = 0; j < F; ++j) df[j][i] += o[(6 * i + j) * 64 + lane];
         }
     }
     float2* dx2 = reinterpret_cast<float2*>(a.dx) + (size_t)(tl.bok ? tl.b : 0) * a.T;
+    if constexpr (NTX) {
+        // dL/df (skip paths + the channel stack through |f|), then the transposed FIR:
+        // dxI[s] = sum_k cI[k] gI[s-k+2] + cQ[k] gQ[s-k+2],  dxQ[s] = sum_k cI[k] gQ[s-k+2] - cQ[k] gI[s-k+2]
+        float gI[R], gQ[R], nq[5], s0[R], s1[R], s2[R], s3[R];
 #pragma unroll
-    for (int i = 0; i < R; ++i)
-        if (tl.owns(i)) {
-            float d6[6], dI, dQ;
+        for (int k = 0; k < 5; ++k) nq[k] = -fir.cq[k];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) d6[j] = df[j][i];
-            feat_bwd<FEAT_DGRU6>(tl.xi[i], tl.xq[i], d6, dI, dQ);
-            dx2[tl.t0 + i] = make_float2(dI + dy0[i], dQ + dy1[i]);   // + residual path
+        for (int i = 0; i < R; ++i) {
+            const float d4[4] = {df[0][i] + __builtin_fmaf(dy0[i], fir.m[0], __builtin_fmaf(dy1[i], fir.m[2], dy0[i])),
+                                 df[1][i] + __builtin_fmaf(dy0[i], fir.m[1], __builtin_fmaf(dy1[i], fir.m[3], dy1[i])), df[2][i], df[3][i]};
+            float dI, dQ;
+            feat_bwd<FEAT_A4>(tl.xi[i], tl.xq[i], d4, dI, dQ);
+            gI[i] = tl.valid[i] ? dI : 0.0f; gQ[i] = tl.valid[i] ? dQ : 0.0f;
         }
+        conv5<R, 1, -1>(s0, gI, fir.ci);
+        conv5<R, 1, -1>(s1, gQ, fir.cq);
+        conv5<R, 1, -1>(s2, gQ, fir.ci);
+        conv5<R, 1, -1>(s3, gI, nq);
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            if (tl.owns(i)) dx2[tl.t0 + i] = make_float2(s0[i] + s1[i], s2[i] + s3[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            if (tl.owns(i)) {
+                float d6[6], dI, dQ;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) d6[j] = df[j][i];
+                feat_bwd<FEAT_DGRU6>(tl.xi[i], tl.xq[i], d6, dI, dQ);
+                dx2[tl.t0 + i] = make_float2(dI + dy0[i], dQ + dy1[i]);   // + residual path
+            }
+    }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
@@ -408,51 +531,59 @@ static TcnnBwdShape tcnn_bwd_shape(const TcnnGeom& g) {
     s.grid = (int)((grid + 7) / 8 * 8);          // 4 * grid is a multiple of every ncw
     return s;
 }
-template <int R>
+template <int R, bool NTX>
 static int tcnn_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int mode) {
-    const int P = tcnn_layout(m->hidden).P;
+    const int P = tcnn_layout(m->hidden, NTX).P;
+    const int fir = NTX ? kNtxFir : 0;
     if (mode == 0) {
-        const TcnnGeom g = tcnn_geom(a.B, a.T, kTHalo);
+        const TcnnGeom g = tcnn_geom(a.B, a.T, kTHalo + fir);
         const int ncw = tcnn_split(g.ngroups, 4);
-        hipLaunchKernelGGL(tcnn_fwd_kernel<R>, dim3((g.ngroups * ncw + 3) / 4), dim3(256), ncw > 1 ? 4 * 2 * R * 64 * sizeof(float) : 0, st, a, g, ncw);
+        hipLaunchKernelGGL((tcnn_fwd_kernel<R, NTX>), dim3((g.ngroups * ncw + 3) / 4), dim3(256), ncw > 1 ? 4 * 2 * R * 64 * sizeof(float) : 0, st, a, g, ncw);
     } else if (mode == 1) {
-        const TcnnGeom g = tcnn_geom(a.B, a.T, kTHalo);
+        const TcnnGeom g = tcnn_geom(a.B, a.T, kTHalo + fir);
         const TcnnBwdShape s = tcnn_bwd_shape(g);
-        hipLaunchKernelGGL(tcnn_bwd_kernel<R>, dim3(s.grid), dim3(256), ((size_t)4 * pad4(P) + (size_t)4 * 2 * R * 64) * sizeof(float), st, a, g, s.ncw);
+        const size_t lds = ((size_t)4 * pad4(P) + (size_t)4 * 2 * R * 64) * sizeof(float);
+        auto k = tcnn_bwd_kernel<R, NTX>;
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(s.grid), dim3(256), lds, st, a, g, s.ncw);
     } else {
-        const TcnnGeom g = tcnn_geom(a.B, a.T, kTHaloDx);
+        const TcnnGeom g = tcnn_geom(a.B, a.T, kTHaloDx + 2 * fir);
         const int ncw = tcnn_split(g.ngroups, 4);
         const size_t lds = ncw > 1 ? (size_t)4 * 6 * R * 64 * sizeof(float) : 0;
-        auto k = tcnn_dx_kernel<R>;
+        auto k = tcnn_dx_kernel<R, NTX>;
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3((g.ngroups * ncw + 3) / 4), dim3(256), lds, st, a, g, ncw);
     }
     return (int)hipGetLastError();
 }
+template <bool NTX>
 static int tcnn_dispatch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int mode) {
     switch (tcnn_geom(a.B, a.T, kTHalo).R) {
-    case 4: return tcnn_launch<4>(st, m, a, mode);
-    case 8: return tcnn_launch<8>(st, m, a, mode);
-    case 13: return tcnn_launch<13>(st, m, a, mode);
-    default: return tcnn_launch<16>(st, m, a, mode);
+    case 4: return tcnn_launch<4, NTX>(st, m, a, mode);
+    case 8: return tcnn_launch<8, NTX>(st, m, a, mode);
+    case 13: return tcnn_launch<13, NTX>(st, m, a, mode);
+    default: return tcnn_launch<16, NTX>(st, m, a, mode);
     }
+}
+static int tcnn_any(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int mode) {
+    return m->backbone == ODPD_NEURALTX ? tcnn_dispatch<true>(st, m, a, mode) : tcnn_dispatch<false>(st, m, a, mode);
 }
 
 int tcnn_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
-    return tcnn_dispatch(st, m, a, 0);
+    return tcnn_any(st, m, a, 0);
 }
 int tcnn_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
     if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
     if (a.partials != nullptr)
-        if (int e = tcnn_dispatch(st, m, a, 1)) return e;
-    if (a.dx != nullptr) return tcnn_dispatch(st, m, a, 2);
+        if (int e = tcnn_any(st, m, a, 1)) return e;
+    if (a.dx != nullptr) return tcnn_any(st, m, a, 2);
     return 0;
 }
 int tcnn_rows(const odpd_model_t* m, int B, int T) {
     if (m->hidden > 64) return ODPD_EUNSUPPORTED;
-    return tcnn_bwd_shape(tcnn_geom(B, T, kTHalo)).grid;
+    return tcnn_bwd_shape(tcnn_geom(B, T, kTHalo + (m->backbone == ODPD_NEURALTX ? kNtxFir : 0))).grid;
 }
 
 }  // namespace odpd

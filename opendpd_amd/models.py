@@ -4,9 +4,9 @@
 thx=0, thh=0)` — same constructor, attributes, `forward(x, h_0=None)` contract and state-dict keys
 as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` as models.py:163-176.
 Backbones on the hot path run as HIP kernels (`backbone.native` is True) inside the kernels' envelope (one layer, hidden
-<= 32; pgjanet <= 16; tcnn <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32) and as ATen restatements (backbones/wide.py,
+<= 32; pgjanet <= 16; tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32) and as ATen restatements (backbones/wide.py,
 `native` False, with a warning) beyond it; the remaining registry names (SURVEY §8 f4:
-apnrru, bojanet, deltajanet, dvrjanet, neuraltx, mcldnn) are torch restatements in backbones/extras.py that
+apnrru, bojanet, deltajanet, dvrjanet, mcldnn) are torch restatements in backbones/extras.py that
 run through ATen (`backbone.native` is False) until they get kernels.  Unknown names raise ValueError (models.py:139-141).
 """
 import torch
@@ -77,7 +77,7 @@ class CoreModel(nn.Module):
         elif backbone_type == "dvrjanet":
             self.backbone = X.DVRJANET(hidden_size=hidden_size, output_size=2, num_dvr_units=num_dvr_units, bias=True)
         elif backbone_type == "neuraltx":
-            self.backbone = X.NeuralTX(hidden_channels=hidden_size)
+            self.backbone = B.NeuralTX(hidden_channels=hidden_size)
         elif backbone_type == "mcldnn":
             self.backbone = X.MCLDNN(hidden_size=hidden_size)
         else:

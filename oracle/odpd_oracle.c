@@ -72,6 +72,8 @@ int64_t oracle_param_count(const odpd_model_t* m) {
         return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
     case ODPD_GMP:      /* gmp.py:10-11: memory_length * (1 + (degree - 1) * memory_length); hidden = memory_length, degree 5 */
         return H * (1 + (GMP_DEGREE - 1) * H);
+    case ODPD_NEURALTX: /* neuraltx.py:18-38: two 5-tap FIRs, 4 -> C (bias), 4 depthwise k5, C -> 2, IQ_match (2,2); hidden = channels */
+        return 10 + 4 * H + H + 4 * 5 * H + 2 * H + 4;
     case ODPD_RVTDCNN:  /* rvtdcnn.py:19-33: Conv2d(1->3,k3) 27+3, fc_hid (H,36)+H, fc_out (2,H)+2; hidden = fc_hid_size (models.py:80-81) */
         return 30 + 36 * H + H + 2 * H + 2;
     default: return -1;
@@ -692,6 +694,124 @@ static void tcnn_seq_bwd(const tcnn_layout_t* L, const real* p, int T, const rea
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* NeuralTX: neuraltx.py:116-137.  (The torch.fft.fft of :118 runs over a trailing dimension of size 1: the identity.)
+ * Complex 5-tap FIR with zero padding 2 (:122-123: f_I = cI*xI - cQ*xQ, f_Q = cQ*xI + cI*xQ, Conv1d = cross-correlation);
+ * features [f_I, f_Q, a, a^3], a = |f| (:124-129); the TCNN stack 4 -> C (1x1, bias) HS, 4 x depthwise k5 dil 1,2,4,8 HS,
+ * C -> 2 (1x1) (:21-37); y = net + IQ_match f + f (:135).  Parameter order: conv_I.weight (5), conv_Q.weight (5),
+ * network.0.weight (C,4), network.0.bias (C), network.{2,4,6,8}.weight (C,5), network.10.weight (2,C), IQ_match.weight (2,2). */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int C; int64_t o_ci, o_cq, o_w0, o_b0, o_dw[4], o_w5, o_m; } ntx_layout_t;
+static void ntx_layout(const odpd_model_t* m, ntx_layout_t* g) {
+    int64_t C = m->hidden, o = 0;
+    g->C = (int)C;
+    g->o_ci = o; o += 5; g->o_cq = o; o += 5;
+    g->o_w0 = o; o += 4 * C; g->o_b0 = o; o += C;
+    for (int l = 0; l < 4; ++l) { g->o_dw[l] = o; o += 5 * C; }
+    g->o_w5 = o; o += 2 * C;
+    g->o_m = o;
+}
+/* feat (T,4) = [f_I, f_Q, a, a^3]; pre (5,T,C) pre-activations of the five stages */
+static void ntx_seq_fwd(const ntx_layout_t* L, const real* p, int T, const real* x, real* y, real* feat, real* pre) {
+    const int C = L->C;
+    for (int t = 0; t < T; ++t) {
+        real fi = 0, fq = 0;
+        for (int k = 0; k < 5; ++k) {
+            const int tt = t + k - 2;
+            if (tt < 0 || tt >= T) continue;
+            fi += p[L->o_ci + k] * x[2 * tt] - p[L->o_cq + k] * x[2 * tt + 1];
+            fq += p[L->o_cq + k] * x[2 * tt] + p[L->o_ci + k] * x[2 * tt + 1];
+        }
+        real* f = feat + t * 4;
+        const real a = (real)sqrt((double)(fi * fi + fq * fq));
+        f[0] = fi; f[1] = fq; f[2] = a; f[3] = a * a * a;
+        for (int c = 0; c < C; ++c) {
+            real v = p[L->o_b0 + c];
+            for (int i = 0; i < 4; ++i) v += p[L->o_w0 + c * 4 + i] * f[i];
+            pre[(0 * T + t) * C + c] = v;
+        }
+    }
+    for (int l = 0; l < 4; ++l) {
+        const int d = 1 << l;
+        for (int t = 0; t < T; ++t)
+            for (int c = 0; c < C; ++c) {
+                real v = 0;
+                for (int k = 0; k < 5; ++k) {
+                    const int tt = t + d * (k - 2);
+                    if (tt >= 0 && tt < T) v += p[L->o_dw[l] + c * 5 + k] * hswish(pre[(l * T + tt) * C + c]);
+                }
+                pre[((l + 1) * T + t) * C + c] = v;
+            }
+    }
+    for (int t = 0; t < T; ++t)
+        for (int o = 0; o < 2; ++o) {
+            real v = 0;
+            for (int c = 0; c < C; ++c) v += p[L->o_w5 + o * C + c] * hswish(pre[(4 * T + t) * C + c]);
+            const real* f = feat + t * 4;
+            y[2 * t + o] = v + p[L->o_m + 2 * o] * f[0] + p[L->o_m + 2 * o + 1] * f[1] + f[o];
+        }
+}
+/* dfq: scratch (T,2) for dL/d(f_I, f_Q) */
+static void ntx_seq_bwd(const ntx_layout_t* L, const real* p, int T, const real* x, const real* dy, const real* feat,
+                        const real* pre, real* dp, real* dx, real* gcur, real* gnext, real* dfq) {
+    const int C = L->C;
+    for (int t = 0; t < T; ++t)
+        for (int c = 0; c < C; ++c) {
+            real g = 0;
+            for (int o = 0; o < 2; ++o) { g += dy[2 * t + o] * p[L->o_w5 + o * C + c]; dp[L->o_w5 + o * C + c] += dy[2 * t + o] * hswish(pre[(4 * T + t) * C + c]); }
+            gcur[t * C + c] = g;
+        }
+    for (int l = 3; l >= 0; --l) {
+        const int d = 1 << l;
+        memset(gnext, 0, sizeof(real) * T * C);
+        for (int t = 0; t < T; ++t)
+            for (int c = 0; c < C; ++c) {
+                const real gp = gcur[t * C + c] * hswish_grad(pre[((l + 1) * T + t) * C + c]);
+                for (int k = 0; k < 5; ++k) {
+                    const int tt = t + d * (k - 2);
+                    if (tt >= 0 && tt < T) {
+                        dp[L->o_dw[l] + c * 5 + k] += gp * hswish(pre[(l * T + tt) * C + c]);
+                        gnext[tt * C + c] += gp * p[L->o_dw[l] + c * 5 + k];
+                    }
+                }
+            }
+        real* tsw = gcur; gcur = gnext; gnext = tsw;
+    }
+    for (int t = 0; t < T; ++t) {
+        real df[4] = {0, 0, 0, 0};
+        const real* f = feat + t * 4;
+        for (int c = 0; c < C; ++c) {
+            const real gp = gcur[t * C + c] * hswish_grad(pre[(0 * T + t) * C + c]);
+            dp[L->o_b0 + c] += gp;
+            for (int i = 0; i < 4; ++i) { dp[L->o_w0 + c * 4 + i] += gp * f[i]; df[i] += gp * p[L->o_w0 + c * 4 + i]; }
+        }
+        /* IQ_match and identity skip of f */
+        for (int o = 0; o < 2; ++o) {
+            dp[L->o_m + 2 * o] += dy[2 * t + o] * f[0];
+            dp[L->o_m + 2 * o + 1] += dy[2 * t + o] * f[1];
+            df[0] += dy[2 * t + o] * p[L->o_m + 2 * o];
+            df[1] += dy[2 * t + o] * p[L->o_m + 2 * o + 1];
+        }
+        df[0] += dy[2 * t]; df[1] += dy[2 * t + 1];
+        const real a = f[2], da = df[2] + (real)3 * a * a * df[3];      /* a = |f|: da/df = f / a */
+        dfq[2 * t] = df[0] + da * f[0] / a;
+        dfq[2 * t + 1] = df[1] + da * f[1] / a;
+    }
+    if (dx) memset(dx, 0, sizeof(real) * 2 * T);
+    for (int t = 0; t < T; ++t)
+        for (int k = 0; k < 5; ++k) {
+            const int tt = t + k - 2;
+            if (tt < 0 || tt >= T) continue;
+            const real gi = dfq[2 * t], gq = dfq[2 * t + 1], xi = x[2 * tt], xq = x[2 * tt + 1];
+            dp[L->o_ci + k] += gi * xi + gq * xq;
+            dp[L->o_cq + k] += gq * xi - gi * xq;
+            if (dx) {
+                dx[2 * tt] += p[L->o_ci + k] * gi + p[L->o_cq + k] * gq;
+                dx[2 * tt + 1] += p[L->o_ci + k] * gq - p[L->o_cq + k] * gi;
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* PGJANET: pgjanet.py:26-76                                                                    */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct { int H; int64_t o_wa, o_ba, o_wp1, o_bp1, o_wp2, o_bp2, o_wf, o_bf, o_wg, o_bg, o_wo, o_bo; } pgj_layout_t;
@@ -1188,6 +1308,12 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         real* du = amp + (T + 2 * M - 2); real* damp = du + 2 * (T + M - 1);
         if (dy) gmp_seq_bwd(M, params, T, x, dy, dp, dx, u, amp, du, damp);
         else gmp_seq_fwd(M, params, T, x, y, u, amp);
+    } else if (bb == ODPD_NEURALTX) {
+        ntx_layout_t L; ntx_layout(m, &L);
+        real* feat = (real*)scratch; real* pre = feat + (size_t)T * 4;
+        real* g1 = pre + (size_t)5 * T * L.C; real* g2 = g1 + (size_t)T * L.C; real* dfq = g2 + (size_t)T * L.C;
+        ntx_seq_fwd(&L, params, T, x, y, feat, pre);
+        if (dy) ntx_seq_bwd(&L, params, T, x, dy, feat, pre, dp, dx, g1, g2, dfq);
     } else if (bb == ODPD_RVTDCNN) {
         if (dy) rv_seq_bwd(m->hidden, params, T, x, dy, dp, dx, (real*)scratch);
         else rv_seq_fwd(m->hidden, params, T, x, y);
@@ -1201,6 +1327,7 @@ static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
     if (bb == ODPD_TCNN) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_PGJANET) return sizeof(pgj_step_t) * T;
     if (bb == ODPD_GMP) return sizeof(real) * (size_t)(6 * (T + 2 * m->hidden));
+    if (bb == ODPD_NEURALTX) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_RVTDCNN) return T >= 3 ? sizeof(real) * (size_t)(5 * T) : 0;   /* the circular window needs 3 samples */
     return 0;
 }

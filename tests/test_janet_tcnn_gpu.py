@@ -1,4 +1,5 @@
-"""GPU parity of the PGJANET (and TCNN) kernels against the reference golden vectors and the CPU oracle."""
+"""GPU parity of the PGJANET, TCNN and NeuralTX (the NTX instantiation of csrc/tcnn.hip) kernels against the reference golden
+vectors and the CPU oracle."""
 import numpy as np
 import pytest
 import torch
@@ -7,7 +8,7 @@ from tests.golden_util import Fixture, rel_err
 
 pytestmark = pytest.mark.gpu
 FWD_TOL, GRAD_TOL = 2e-5, 3e-4
-GOLDEN = [("pgjanet_h11", "pgjanet"), ("tcnn_c35", "tcnn")]
+GOLDEN = [("pgjanet_h11", "pgjanet"), ("tcnn_c35", "tcnn"), ("neuraltx_c36", "neuraltx"), ("neuraltx_c12", "neuraltx")]
 
 
 def _supported(bb):
@@ -46,8 +47,9 @@ def test_golden_forward_backward(name, bb):
     assert rel_err(ya.cpu().numpy(), fx["ya"]) < FWD_TOL
 
 
-@pytest.mark.parametrize("bb,H", [("pgjanet", 11), ("pgjanet", 8), ("pgjanet", 16), ("tcnn", 35), ("tcnn", 8), ("tcnn", 30)])
-@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 32), (7, 33), (5, 200), (66, 63), (2, 2100)])
+@pytest.mark.parametrize("bb,H", [("pgjanet", 11), ("pgjanet", 8), ("pgjanet", 16), ("tcnn", 35), ("tcnn", 8), ("tcnn", 30),
+                                   ("neuraltx", 36), ("neuraltx", 8), ("neuraltx", 64)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 32), (7, 33), (5, 200), (66, 63), (2, 2100), (3, 257), (1, 700)])
 def test_against_oracle_ragged(bb, H, B, T):
     if not _supported(bb):
         pytest.skip(f"{bb} kernel not built yet")
@@ -59,6 +61,8 @@ def test_against_oracle_ragged(bb, H, B, T):
         for k, p in net.named_parameters():
             if "bias" in k:
                 p.uniform_(-0.3, 0.3)
+            if k.startswith("backbone.conv_"):        # NeuralTX: FIR taps of a size that makes every path count (init gain is 0.1)
+                p.uniform_(-0.6, 0.6)
     rng = np.random.RandomState(B * 17 + T)
     amp = 0.05 + 0.85 * rng.rand(B, T, 1)
     ph = 2 * np.pi * rng.rand(B, T, 1)

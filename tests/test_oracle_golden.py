@@ -21,7 +21,7 @@ SINGLE = [
     ("tres_h15_dense", "deltagru_tcnskip"), ("tres_h15_th", "deltagru_tcnskip"),
     ("deltagru_h24_th", "deltagru"), ("tres_h30_th", "deltagru_tcnskip"),
     ("tcnn_c35", "tcnn"), ("pgjanet_h11", "pgjanet"), ("gmp_m11", "gmp"),
-    ("rvtdcnn_h25", "rvtdcnn"), ("rvtdcnn_h6", "rvtdcnn"),
+    ("rvtdcnn_h25", "rvtdcnn"), ("rvtdcnn_h6", "rvtdcnn"), ("neuraltx_c36", "neuraltx"), ("neuraltx_c12", "neuraltx"),
 ]
 
 
