@@ -86,9 +86,11 @@ def run_steps(opt, x, t, steps, warmup, count, dist, events=False):
     return el, kern_ms, float(loss.item())
 
 
-def cpu_baseline(H, T, budget_s=14.0, budget_1t_s=5.0):
-    """Reference-step port (oracle) on the host cores; bounded sample of the same workload.  All cores (OpenMP over
-    the sequences of the batch) is the headline; the single-thread rate of the same loop is reported beside it."""
+def cpu_baseline(H, T, budget_1t_s=4.0, budget_nt_s=2.5):
+    """Reference-step port (oracle) on the host cores; bounded sample of the same workload (~15-20 s in total).  OpenMP over the
+    sequences of a 256 x T batch: the thread count is swept (a 256-sequence batch does not scale to every core of a large host, and
+    a container may be granted fewer cores than it sees), `value` / `cores` report the best one, the single-thread rate and the
+    whole sweep are given beside it."""
     from oracle.oracle import Oracle, make_model
     o = Oracle("f32")
     m = make_model("dgru", H)
@@ -102,6 +104,10 @@ def cpu_baseline(H, T, budget_s=14.0, budget_1t_s=5.0):
     var = np.zeros(P, np.float32)
     scratch = (np.empty_like(x), np.empty_like(x), np.empty(P, np.float32))
     cores = o.max_threads()
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
 
     def timed(budget, max_steps):
         o.train_step(m, p, x, t, mom, var, 1, 5e-4, 200.0, scratch=scratch)  # warm-up
@@ -115,11 +121,20 @@ def cpu_baseline(H, T, budget_s=14.0, budget_1t_s=5.0):
 
     o.set_threads(1)
     n1, el1 = timed(budget_1t_s, 200)
-    o.set_threads(cores)
-    n, el = timed(budget_s, 2000)
-    return {"value": B * T * n / el, "unit": "IQ samples/s", "cores": cores, "kind": "port",
-            "value_1thread": B * T * n1 / el1,
-            "sample": f"{n} train steps of DGRU H{H} on a {B}x{T} synthetic batch ({el:.1f} s, OpenMP over sequences)"}
+    sweep = {1: B * T * n1 / el1}
+    steps = {1: (n1, el1)}
+    for nt in sorted({c for c in (4, 8, 16, 32, 64, cores) if 1 < c <= cores}):
+        o.set_threads(nt)
+        n, el = timed(budget_nt_s, 2000)
+        sweep[nt] = B * T * n / el
+        steps[nt] = (n, el)
+    best = max(sweep, key=sweep.get)
+    n, el = steps[best]
+    return {"value": sweep[best], "unit": "IQ samples/s", "cores": best, "kind": "port",
+            "value_1thread": sweep[1], "host_cores_visible": cores,
+            "threads_swept": {str(k): round(v) for k, v in sweep.items()},
+            "sample": f"{n} train steps of DGRU H{H} on a {B}x{T} synthetic batch ({el:.1f} s at {best} OpenMP threads over sequences; "
+                      f"{sum(v[1] for v in steps.values()):.0f} s of CPU sweep in total)"}
 
 
 def main():
