@@ -41,7 +41,8 @@ enum odpd_backbone {
     ODPD_GMP = 10,       /* backbones/gmp.py:5-50 (hidden = memory_length; degree 5 as built by models.py:26-28) */
     ODPD_RVTDCNN = 11,   /* backbones/rvtdcnn.py:9-62 (hidden = fc_hid_size, models.py:80-81; window 4, 3 conv channels) */
     ODPD_NEURALTX = 12,  /* backbones/neuraltx.py:5-137 (hidden = hidden_channels; complex 5-tap FIR + the TCNN stack on 4 features) */
-    ODPD_BACKBONE_COUNT = 13
+    ODPD_DELTAJANET = 13, /* backbones/deltajanet.py:11-274 (two-gate delta cell; the wrapper fixes both thresholds at 0) */
+    ODPD_BACKBONE_COUNT = 14
 };
 
 enum odpd_error {

@@ -1,7 +1,7 @@
 """HIP-backed backbones behind the reference's registry names (models.py:26-141)."""
 from .gru import GRU, DGRU, QGRU, QGRUAmp1  # noqa: F401
 from .lstm import LSTM, VDLSTM  # noqa: F401
-from .deltagru import DeltaGRU, TResDeltaGRU  # noqa: F401
+from .deltagru import DeltaGRU, DeltaJANET, TResDeltaGRU  # noqa: F401
 from .pgjanet import PGJANET  # noqa: F401
 from .tcnn import TCNN, NeuralTX  # noqa: F401
 from .gmp import GMP  # noqa: F401

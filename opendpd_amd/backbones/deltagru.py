@@ -138,3 +138,48 @@ class TResDeltaGRU(_DeltaBase):
 
     def get_temporal_sparsity(self):
         return self._sparsity(sum(p.numel() for p in self.fc_out.parameters()) + sum(p.numel() for p in self.tcn.parameters()))
+
+
+class _JanetLayerParams(nn.Module):
+    """Parameter holder equal to DeltaJANETLayer after its constructor (deltajanet.py:96-141): two gates [f; g], every weight
+    orthogonal as a whole (2H x k) matrix, zero biases."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        G = 2 * hidden_size
+        self.weight_ih_l0 = nn.Parameter(torch.empty(G, input_size))
+        self.weight_hh_l0 = nn.Parameter(torch.empty(G, hidden_size))
+        self.bias_ih_l0 = nn.Parameter(torch.empty(G))
+        self.bias_hh_l0 = nn.Parameter(torch.empty(G))
+        for name, p in self.named_parameters():
+            if "weight" in name:
+                nn.init.orthogonal_(p)
+            elif "bias" in name:
+                nn.init.constant_(p, 0)
+
+
+class DeltaJANET(_DeltaBase):
+    """Registry name 'deltajanet' (backbones/deltajanet.py:11-274): features as deltagru, a two-gate delta cell (f and g both sigmoids,
+    h = (1-f) g + f h), fc_out with bias.  The reference builds its layer with thx = thh = 0 whatever it is given (:23-27): the
+    thresholds are kept as attributes (the train_dpd log reads them) but the kernels run with 0, so nothing is ever masked and the
+    counters record exact repeats only.  Kernels: the JAN instantiation of csrc/delta_s16.hip (hidden <= 32, every batch size)."""
+    backbone_name = "deltajanet"
+
+    def __init__(self, input_size, hidden_size, output_size, num_layers, thx=0, thh=0, bias=True):
+        super().__init__()
+        _check_single_layer(num_layers, False)
+        self.hidden_size, self.input_size, self.output_size, self.num_layers, self.bias = hidden_size, 6, output_size, 1, bias
+        self.rnn = _JanetLayerParams(6, hidden_size)
+        self.fc_out = nn.Linear(hidden_size, output_size, bias=True)
+        self._setup_delta(hidden_size, 0.0, 0.0)
+        self.thx, self.thh = thx, thh
+
+    def reset_parameters(self):
+        init_gatewise(self.rnn, self.hidden_size)
+        init_linear(self.fc_out, "xavier")
+
+    def get_temporal_sparsity(self):
+        out = self._sparsity(0)
+        out.pop("HW_PARAM", None)          # the layer's own report (deltajanet.py:143-151) has the three ratios only
+        return out

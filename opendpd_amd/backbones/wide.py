@@ -20,7 +20,7 @@ from .native import init_gatewise, init_linear
 
 # largest hidden size (tcnn: channel count) the HIP kernels of a registry name run, single layer
 KERNEL_HIDDEN_LIMIT = {"gru": 32, "dgru": 32, "qgru": 32, "qgru_amp1": 32, "lstm": 32, "vdlstm": 32, "deltagru": 32,
-                       "deltagru_tcnskip": 32, "pgjanet": 16, "tcnn": 64, "rvtdcnn": 32, "neuraltx": 64}
+                       "deltagru_tcnskip": 32, "pgjanet": 16, "tcnn": 64, "rvtdcnn": 32, "neuraltx": 64, "deltajanet": 32}
 _warned = set()
 
 
@@ -366,4 +366,7 @@ def build(backbone_type, input_size, hidden_size, num_layers, thx=0, thh=0):
     if backbone_type == "neuraltx":
         from .extras import NeuralTX
         return NeuralTX(hidden_channels=hidden_size)
+    if backbone_type == "deltajanet":
+        from .extras import DeltaJANET
+        return DeltaJANET(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers, thx=thx, thh=thh, bias=True)
     raise ValueError(backbone_type)

@@ -16,7 +16,7 @@ inline Family family_of(int bb) {
     switch (bb) {
     case ODPD_GRU: case ODPD_DGRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return FAM_GRU;
     case ODPD_LSTM: case ODPD_VDLSTM: return FAM_LSTM;
-    case ODPD_DELTAGRU: case ODPD_TRES_DELTAGRU: return FAM_DELTA;
+    case ODPD_DELTAGRU: case ODPD_TRES_DELTAGRU: case ODPD_DELTAJANET: return FAM_DELTA;
     case ODPD_PGJANET: return FAM_JANET;
     case ODPD_TCNN: case ODPD_NEURALTX: return FAM_TCNN;
     case ODPD_GMP: return FAM_GMP;
@@ -27,7 +27,7 @@ inline Family family_of(int bb) {
 inline int feat_dim(int bb) {
     switch (bb) {
     case ODPD_GRU: case ODPD_LSTM: return 2;
-    case ODPD_DGRU: case ODPD_DELTAGRU: case ODPD_TRES_DELTAGRU: case ODPD_TCNN: return 6;
+    case ODPD_DGRU: case ODPD_DELTAGRU: case ODPD_TRES_DELTAGRU: case ODPD_DELTAJANET: case ODPD_TCNN: return 6;
     case ODPD_QGRU: case ODPD_QGRU_AMP1: case ODPD_VDLSTM: return 4;
     default: return 0;
     }
@@ -81,6 +81,7 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_VDLSTM: return 4 * H * 4 + 4 * H * H + 8 * H + 2 * (4 * H + 4) + 2 * 8 + 2;
     case ODPD_DELTAGRU: return 3 * H * 6 + 3 * H * H + 6 * H + 2 * H + 2;
     case ODPD_TRES_DELTAGRU: return 3 * H * 6 + 3 * H * H + 2 * H + 18 + 6;
+    case ODPD_DELTAJANET: return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2;      // two gates (deltajanet.py:96-111) + fc_out
     case ODPD_TCNN: return 6 * H + H + 4 * 5 * H + 2 * H;
     case ODPD_PGJANET: return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
     case ODPD_NEURALTX: return H <= 64 ? 27 * H + 14 : (int64_t)ODPD_EUNSUPPORTED;   // two 5-tap FIRs, 4->C (+bias), 4 x depthwise k5, C->2, IQ_match 2x2

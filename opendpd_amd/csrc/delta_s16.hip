@@ -1,6 +1,11 @@
 // delta_s16.hip — S16 split kernels (forward, backward for parameter gradients) of the delta-network GRU backbones
 //   deltagru          backbones/deltagru.py:10-276           feat = [I,Q,a,a^3,sin,cos]; biases = initial accumulators
 //   deltagru_tcnskip  backbones/deltagru_tcnskip.py:11-304   feat = [I,Q,a,a^3,I_next,Q_next]; bias-free; + TCN skip
+//   deltajanet        backbones/deltajanet.py:11-274         (JAN) feat as deltagru; TWO gates f, g, both sigmoids, both fed by the
+//                                                            input and the state deltas: h = (1-f) g + f h.  On the kernels' gate
+//                                                            slots (r, z, n) it is z = f, n = g with r == 1, the n accumulator taking
+//                                                            the state-delta product directly, sigmoid instead of tanh; the r slot
+//                                                            does not exist (its table groups are zero and its MFMAs are not issued)
 // for batches large enough to fill the chip with 16-sequence wavefronts (the DPD side of the train_dpd cascade at large
 // batch, BASELINE config 3).  Arithmetic as in delta_family.hip (thresholded deltas, accumulators `dm`, memories x_p /
 // h_p, device sparsity counters, carried accumulator gradients in the backward pass); mapping as in gru_s16.hip: lane
@@ -33,22 +38,26 @@ struct D16 {
     static constexpr int kTiles = 5 * NT + 1;          // gr gz gn gnh dhm per unit tile + feature-delta tile
 };
 
-template <bool TRES, int NT>
+// JAN: gate slot g (0 r, 1 z, 2 n) holds parameter gate g - 1 (f, g); slot 0 is empty; the n slot is a sigmoid gate as well
+template <bool TRES, int NT, bool JAN = false>
 __device__ __forceinline__ float4 d16_entry(const float* pl, const DeltaLayout& L, int grp, int m, int q) {
     using T = D16<NT>;
     const int H = L.H;
+    auto pg = [](int g) { return JAN ? g - 1 : g; };
+    auto has = [](int g) { return !JAN || g > 0; };
+    auto sc = [](int g) { return (g < 2 || JAN) ? kNegLog2e : 1.0f; };
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (grp < T::HH) {
             const int g = grp / NT, o = 16 * (grp % NT) + m, slot = 4 * e + q;
-            v[e] = (e < 2 && slot < 6 && o < H) ? pl[L.o_w_ih + (g * H + o) * 6 + slot] * (g < 2 ? kNegLog2e : 1.0f) : 0.0f;
+            v[e] = (has(g) && e < 2 && slot < 6 && o < H) ? pl[L.o_w_ih + (pg(g) * H + o) * 6 + slot] * sc(g) : 0.0f;
         } else if (grp < T::HHT) {
             const int r = grp - T::HH, g = r / (NT * NT), o = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
-            v[e] = (o < H && k < H) ? pl[L.o_w_hh + (g * H + o) * H + k] * (g < 2 ? kNegLog2e : 1.0f) : 0.0f;
+            v[e] = (has(g) && o < H && k < H) ? pl[L.o_w_hh + (pg(g) * H + o) * H + k] * sc(g) : 0.0f;
         } else if (grp < T::WOUT) {
             const int r = grp - T::HHT, g = r / (NT * NT), i = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
-            v[e] = (i < H && k < H) ? pl[L.o_w_hh + (g * H + k) * H + i] : 0.0f;
+            v[e] = (has(g) && i < H && k < H) ? pl[L.o_w_hh + (pg(g) * H + k) * H + i] : 0.0f;
         } else if (grp < T::DM0) {
             const int r = grp - T::WOUT, k = 16 * (r % NT) + 4 * q + e;
             v[e] = k < H ? pl[L.o_w_out + (r / NT) * H + k] : 0.0f;
@@ -56,11 +65,13 @@ __device__ __forceinline__ float4 d16_entry(const float* pl, const DeltaLayout& 
             // transposed input weights with the output rows permuted so that D row 4 q' + i = slot 4 i + q': the MFMA result
             // of lane (n, q) element c IS the gradient of the lane's own feature slot 4 c + q
             const int r = grp - T::IHT, g = r / NT, k = 16 * (r % NT) + 4 * q + e, slot = 4 * (m & 3) + (m >> 2);
-            v[e] = (slot < 6 && k < H) ? pl[L.o_w_ih + (g * H + k) * 6 + slot] : 0.0f;
+            v[e] = (has(g) && slot < 6 && k < H) ? pl[L.o_w_ih + (pg(g) * H + k) * 6 + slot] : 0.0f;
         } else {
             const int r = grp - T::DM0, j = r / NT, k = 16 * (r % NT) + 4 * q + e;
             float b = 0.0f;
-            if (!TRES && k < H) {
+            if (JAN) {       // dm_f, dm_g start at b_ih + b_hh (deltajanet.py:162-166)
+                if (k < H && (j == 1 || j == 2)) b = (pl[L.o_b_ih + (j - 1) * H + k] + pl[L.o_b_hh + (j - 1) * H + k]) * kNegLog2e;
+            } else if (!TRES && k < H) {
                 if (j == 0) b = (pl[L.o_b_ih + k] + pl[L.o_b_hh + k]) * kNegLog2e;
                 else if (j == 1) b = (pl[L.o_b_ih + H + k] + pl[L.o_b_hh + H + k]) * kNegLog2e;
                 else if (j == 2) b = pl[L.o_b_ih + 2 * H + k];
@@ -105,7 +116,7 @@ __device__ __forceinline__ void d16_slots(float2 xv, float2 xn, const float (&oh
 }
 
 // one forward step.  slot_ok[c]: the lane's slot of chunk c is a real feature; unit_ok[kt][i]: a real hidden unit
-template <bool TRES, int NT>
+template <bool TRES, int NT, bool JAN = false>
 __device__ __forceinline__ void d16_cell_fwd(TabPtr tl, const float (&fs)[2], float thx, float thh, const bool (&slot_ok)[2],
                                              const f32x4 (&unit_ok)[NT], D16State<NT>& st, f32x4 (&hprev)[NT], f32x4 (&dhm)[NT],
                                              f32x4 (&mh)[NT], f32x4 (&r)[NT], f32x4 (&z)[NT], f32x4 (&n)[NT], float (&dxm)[2],
@@ -134,18 +145,24 @@ __device__ __forceinline__ void d16_cell_fwd(TabPtr tl, const float (&fs)[2], fl
     for (int mt = 0; mt < NT; ++mt) {
         const float4 wr = tab_ld(tl, (T::IH + 0 * NT + mt) * 64), wz = tab_ld(tl, (T::IH + 1 * NT + mt) * 64),
                      wn = tab_ld(tl, (T::IH + 2 * NT + mt) * 64);
-        st.dmr[mt] = mfma4(wr.x, dxm[0], st.dmr[mt]); st.dmr[mt] = mfma4(wr.y, dxm[1], st.dmr[mt]);
+        if constexpr (!JAN) { st.dmr[mt] = mfma4(wr.x, dxm[0], st.dmr[mt]); st.dmr[mt] = mfma4(wr.y, dxm[1], st.dmr[mt]); }
         st.dmz[mt] = mfma4(wz.x, dxm[0], st.dmz[mt]); st.dmz[mt] = mfma4(wz.y, dxm[1], st.dmz[mt]);
         st.dmn[mt] = mfma4(wn.x, dxm[0], st.dmn[mt]); st.dmn[mt] = mfma4(wn.y, dxm[1], st.dmn[mt]);
     }
-    s16n_matvec<NT>(tl, T::HH + 0 * NT * NT, dhm, st.dmr);
+    if constexpr (!JAN) s16n_matvec<NT>(tl, T::HH + 0 * NT * NT, dhm, st.dmr);
     s16n_matvec<NT>(tl, T::HH + 1 * NT * NT, dhm, st.dmz);
-    s16n_matvec<NT>(tl, T::HH + 2 * NT * NT, dhm, st.dmnh);
+    if constexpr (JAN) s16n_matvec<NT>(tl, T::HH + 2 * NT * NT, dhm, st.dmn);       // dm = (dx W_ih^T + dm) + dh W_hh^T for both gates
+    else s16n_matvec<NT>(tl, T::HH + 2 * NT * NT, dhm, st.dmnh);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
-        r[mt] = sigmoid4_prescaled(st.dmr[mt]);
         z[mt] = sigmoid4_prescaled(st.dmz[mt]);
-        n[mt] = tanh4_precise(fma4(r[mt], st.dmnh[mt], st.dmn[mt]));
+        if constexpr (JAN) {
+            r[mt] = splat4(1.0f);
+            n[mt] = sigmoid4_prescaled(st.dmn[mt]);                                  // deltajanet.py:247: the candidate is a sigmoid
+        } else {
+            r[mt] = sigmoid4_prescaled(st.dmr[mt]);
+            n[mt] = tanh4_precise(fma4(r[mt], st.dmnh[mt], st.dmn[mt]));
+        }
         hprev[mt] = st.h[mt];
         st.h[mt] = fma4(z[mt], sub4(st.h[mt], n[mt]), n[mt]);
     }
@@ -202,7 +219,7 @@ __device__ __forceinline__ float4 d16_f4(const f32x4& v) { return make_float4(v[
 // -------------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------------
-template <bool TRES, int NT>
+template <bool TRES, int NT, bool JAN = false>
 __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_fwd_kernel(SeqArgs a) {
     using T = D16<NT>;
     constexpr int S = kCkptStride;
@@ -210,13 +227,13 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    const DeltaLayout L = delta_layout(a.H, TRES);
+    const DeltaLayout L = delta_layout(a.H, TRES, JAN ? 2 : 3);
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     {
         float4* t4 = reinterpret_cast<float4*>(tab);
-        for (int grp = wave; grp < T::NG; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES, NT>(pl, L, grp, n, q);
+        for (int grp = wave; grp < T::NG; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES, NT, JAN>(pl, L, grp, n, q);
         __syncthreads();
     }
     const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
@@ -254,7 +271,7 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
                 float fs[2], dxm[2], mx[2];
                 f32x4 hprev[NT], dhm[NT], mh[NT], r[NT], z[NT], nn[NT];
                 d16_slots<TRES>(xv, xn, oh, fs);
-                d16_cell_fwd<TRES, NT>(opaque(tl), fs, a.thx, a.thh, slot_ok, unit_ok, st, hprev, dhm, mh, r, z, nn, dxm, zxs, zhs, mx);
+                d16_cell_fwd<TRES, NT, JAN>(opaque(tl), fs, a.thx, a.thh, slot_ok, unit_ok, st, hprev, dhm, mh, r, z, nn, dxm, zxs, zhs, mx);
                 float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
                 for (int mt = 0; mt < NT; ++mt) {
@@ -331,7 +348,7 @@ struct D16Grad {
 template <int NT>
 struct D16Carry { f32x4 gh[NT], ghp[NT], gr[NT], gz[NT], gn[NT], gnh[NT]; float gxp[2], wrap[2]; };
 
-template <bool TRES, int NT, bool FULL, bool DX>
+template <bool TRES, int NT, bool FULL, bool DX, bool JAN = false>
 __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, const D16Scalars<TRES>& sc, const float (&oh)[4],
                                               D16Grad<TRES, NT>& G, const float2* xr, const float2* dys, float2* dxs, float* tiles,
                                               float2 x0, int n, int q, int tglob, int tloc, int nstep, int chunk_len, float* dxrow,
@@ -354,7 +371,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 const float2 xn = (tglob + si + 1 < a.T) ? xr[tloc + si + 1] : x0;
                 float fs[2];
                 d16_slots<TRES>(xv, xn, oh, fs);
-                d16_cell_fwd<TRES, NT>(tl, fs, a.thx, a.thh, slot_ok, all_units, st, hprev_s[si], dhm_s[si], mh_s[si], r_s[si],
+                d16_cell_fwd<TRES, NT, JAN>(tl, fs, a.thx, a.thh, slot_ok, all_units, st, hprev_s[si], dhm_s[si], mh_s[si], r_s[si],
                                        z_s[si], n_s[si], dxm_s[si], zx, zh, mx_s[si]);
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) nh_s[si][kt] = st.dmnh[kt];
@@ -402,18 +419,22 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 const f32x4 dn = mul4(gh, sub4(one, z)), dz = mul4(gh, sub4(hprev_s[si][mt], nn));
                 ghprev[mt] = mul4(gh, z);
                 f32x4 omn2;
-                ODPD_EACH4 omn2[i] = __builtin_fmaf(-nn[i], nn[i], 1.0f);
+                ODPD_EACH4 omn2[i] = JAN ? nn[i] * (1.0f - nn[i]) : __builtin_fmaf(-nn[i], nn[i], 1.0f);     // sigmoid' | tanh'
                 const f32x4 dpre = mul4(dn, omn2);
                 C.gn[mt] = add4(C.gn[mt], dpre);
-                C.gnh[mt] = fma4(dpre, r, C.gnh[mt]);
-                C.gr[mt] = fma4(mul4(dpre, nh_s[si][mt]), mul4(r, sub4(one, r)), C.gr[mt]);
+                if constexpr (JAN) {
+                    C.gnh[mt] = C.gn[mt];            // the state delta feeds the g accumulator itself: one carried gradient
+                } else {
+                    C.gnh[mt] = fma4(dpre, r, C.gnh[mt]);
+                    C.gr[mt] = fma4(mul4(dpre, nh_s[si][mt]), mul4(r, sub4(one, r)), C.gr[mt]);
+                }
                 C.gz[mt] = fma4(dz, mul4(z, sub4(one, z)), C.gz[mt]);
             }
             // data gradient to the masked dh: W_hh^T [G_r, G_z, G_nh]
             f32x4 ddh[NT];
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) ddh[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s16n_matvec<NT>(tl, T::HHT + 0 * NT * NT, C.gr, ddh);
+            if constexpr (!JAN) s16n_matvec<NT>(tl, T::HHT + 0 * NT * NT, C.gr, ddh);
             s16n_matvec<NT>(tl, T::HHT + 1 * NT * NT, C.gz, ddh);
             s16n_matvec<NT>(tl, T::HHT + 2 * NT * NT, C.gnh, ddh);
 #pragma unroll
@@ -432,7 +453,8 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                                 wn = as_f32x4(tab_ld(tl, (T::IHT + 2 * NT + kt) * 64));
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        ds = mfma4(wr[c], C.gr[kt][c], ds); ds = mfma4(wz[c], C.gz[kt][c], ds); ds = mfma4(wn[c], C.gn[kt][c], ds);
+                        if constexpr (!JAN) ds = mfma4(wr[c], C.gr[kt][c], ds);
+                        ds = mfma4(wz[c], C.gz[kt][c], ds); ds = mfma4(wn[c], C.gn[kt][c], ds);
                     }
                 }
                 float dfs[2];
@@ -472,7 +494,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
             wave_lds_fence();
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
-                tile_put(tile(0, kt), n, q, C.gr[kt]);
+                if constexpr (!JAN) tile_put(tile(0, kt), n, q, C.gr[kt]);
                 tile_put(tile(1, kt), n, q, C.gz[kt]);
                 tile_put(tile(2, kt), n, q, C.gn[kt]);
                 tile_put(tile(3, kt), n, q, C.gnh[kt]);
@@ -487,17 +509,18 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
             for (int kt = 0; kt < NT; ++kt) tile_get(tile(4, kt), n, q, hT[kt]);
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) {
-                float rT[4], zT[4], nT[4], gT[4];
-                tile_get(tile(0, mt), n, q, rT); tile_get(tile(1, mt), n, q, zT);
+                float rT[4] = {0.f, 0.f, 0.f, 0.f}, zT[4], nT[4], gT[4];
+                if constexpr (!JAN) tile_get(tile(0, mt), n, q, rT);
+                tile_get(tile(1, mt), n, q, zT);
                 tile_get(tile(2, mt), n, q, nT); tile_get(tile(3, mt), n, q, gT);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    G.tih[0][mt] = mfma4(rT[c], fT[c], G.tih[0][mt]);
+                    if constexpr (!JAN) G.tih[0][mt] = mfma4(rT[c], fT[c], G.tih[0][mt]);
                     G.tih[1][mt] = mfma4(zT[c], fT[c], G.tih[1][mt]);
                     G.tih[2][mt] = mfma4(nT[c], fT[c], G.tih[2][mt]);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        G.thh[0][mt][nt] = mfma4(rT[c], hT[nt][c], G.thh[0][mt][nt]);
+                        if constexpr (!JAN) G.thh[0][mt][nt] = mfma4(rT[c], hT[nt][c], G.thh[0][mt][nt]);
                         G.thh[1][mt][nt] = mfma4(zT[c], hT[nt][c], G.thh[1][mt][nt]);
                         G.thh[2][mt][nt] = mfma4(gT[c], hT[nt][c], G.thh[2][mt][nt]);
                     }
@@ -507,7 +530,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
     }
 }
 
-template <bool TRES, int NT>
+template <bool TRES, int NT, bool JAN = false>
 __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L, D16Grad<TRES, NT>& G, int lane, int n, int q) {
     const int H = L.H;
     for (int i = lane; i < kLossCols; i += 64) prow[L.P + i] = 0.f;
@@ -518,11 +541,12 @@ __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L,
             const int u = 16 * mt + 4 * q + rr;
             if (u < H) {
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    if (n < 6) prow[L.o_w_ih + (g * H + u) * 6 + n] = G.tih[g][mt][rr];
+                for (int g = JAN ? 1 : 0; g < 3; ++g) {
+                    const int pgt = JAN ? g - 1 : g;         // parameter gate of slot g
+                    if (n < 6) prow[L.o_w_ih + (pgt * H + u) * 6 + n] = G.tih[g][mt][rr];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        if (16 * nt + n < H) prow[L.o_w_hh + (g * H + u) * H + 16 * nt + n] = G.thh[g][mt][nt][rr];
+                        if (16 * nt + n < H) prow[L.o_w_hh + (pgt * H + u) * H + 16 * nt + n] = G.thh[g][mt][nt][rr];
                 }
             }
             const float w0 = row_sum16(G.dwout[0][mt][rr]), w1 = row_sum16(G.dwout[1][mt][rr]);
@@ -531,7 +555,10 @@ __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L,
             for (int j = 0; j < 4; ++j) db[j] = row_sum16(G.db[j][mt][rr]);
             if (n == 0 && u < H) {
                 prow[L.o_w_out + u] = w0; prow[L.o_w_out + H + u] = w1;
-                if constexpr (!TRES) {
+                if constexpr (JAN) {
+                    prow[L.o_b_ih + u] = db[1]; prow[L.o_b_hh + u] = db[1];
+                    prow[L.o_b_ih + H + u] = db[2]; prow[L.o_b_hh + H + u] = db[2];
+                } else if constexpr (!TRES) {
                     prow[L.o_b_ih + u] = db[0]; prow[L.o_b_hh + u] = db[0];
                     prow[L.o_b_ih + H + u] = db[1]; prow[L.o_b_hh + H + u] = db[1];
                     prow[L.o_b_ih + 2 * H + u] = db[2]; prow[L.o_b_hh + 2 * H + u] = db[3];
@@ -555,7 +582,7 @@ __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L,
     }
 }
 
-template <bool TRES, int NT, bool DX>
+template <bool TRES, int NT, bool DX, bool JAN = false>
 __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     using T = D16<NT>;
     constexpr int S = kCkptStride;
@@ -564,13 +591,13 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    const DeltaLayout L = delta_layout(a.H, TRES);
+    const DeltaLayout L = delta_layout(a.H, TRES, JAN ? 2 : 3);
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     {
         float4* t4 = reinterpret_cast<float4*>(tab);
-        for (int grp = wave; grp < kGroups; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES, NT>(pl, L, grp, n, q);
+        for (int grp = wave; grp < kGroups; grp += nwb) t4[grp * 64 + lane] = d16_entry<TRES, NT, JAN>(pl, L, grp, n, q);
         __syncthreads();
     }
     const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
@@ -633,8 +660,8 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
             } else {
                 d16_init_state<NT>(tl, st);
             }
-            if (nstep == S) d16_bwd_block<TRES, NT, true, DX>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
-            else d16_bwd_block<TRES, NT, false, DX>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+            if (nstep == S) d16_bwd_block<TRES, NT, true, DX, JAN>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+            else d16_bwd_block<TRES, NT, false, DX, JAN>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
         }
         if constexpr (DX) {
             wave_lds_fence();
@@ -652,7 +679,7 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     }
     const int P4 = L.P + kLossCols;
     __syncthreads();
-    d16_write_row<TRES, NT>(smem + wave * P4, L, G, lane, n, q);
+    d16_write_row<TRES, NT, JAN>(smem + wave * P4, L, G, lane, n, q);
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * P4;
     for (int i = threadIdx.x; i < P4; i += blockDim.x) {
@@ -706,6 +733,7 @@ __global__ __launch_bounds__(256) void tres_skip_dx_kernel(const float* __restri
 // -------------------------------------------------------------------------------------------------
 // hidden <= 16: from the batch size that fills the chip; hidden 17..32: always (the row-rotated delta kernels stop at 16)
 bool delta_uses_s16(const odpd_model_t* m, int B) {
+    if (m->backbone == ODPD_DELTAJANET) return m->hidden <= 32;               // deltajanet lives in these kernels only
     if ((m->backbone != ODPD_DELTAGRU && m->backbone != ODPD_TRES_DELTAGRU) || m->hidden > 32) return false;
     if (m->hidden > 16 || (m->flags & ODPD_FLAG_NEED_DX)) return true;      // dL/dx lives in these kernels only
     long min_batch = tuning().s16_min_batch;
@@ -732,7 +760,7 @@ static size_t d16_bwd_lds(int P, int nt, int waves, bool dx) {
 // waves per block: as many (<= 4) as the LDS budget holds next to the staged parameters and the operand table
 static LaunchShape d16_bwd_shape(const odpd_model_t* m, int ngroups) {
     LaunchShape ls;
-    const int P = delta_layout(m->hidden, m->backbone == ODPD_TRES_DELTAGRU).P, nt = d16_tiles(m->hidden);
+    const int P = delta_layout(m->hidden, m->backbone == ODPD_TRES_DELTAGRU, m->backbone == ODPD_DELTAJANET ? 2 : 3).P, nt = d16_tiles(m->hidden);
     const bool dx = (m->flags & ODPD_FLAG_NEED_DX) != 0;      // the shape (= rows of partials) is fixed by the model, not by the call
     ls.waves = 4;
     while (ls.waves > 1 && d16_bwd_lds(P, nt, ls.waves, dx) > kMaxLds) --ls.waves;
@@ -744,13 +772,13 @@ int delta_s16_rows(const odpd_model_t* m, int B) { return d16_bwd_shape(m, (B + 
 int64_t delta_s16_ckpt_floats(const odpd_model_t* m, int B, int T) {
     return (int64_t)((B + 15) / 16) * num_ckpt(T) * (6 * d16_tiles(m->hidden) + 1) * 256;
 }
-template <bool TRES, int NT>
+template <bool TRES, int NT, bool JAN = false>
 static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int P, int mode) {
     using T = D16<NT>;
     if (mode == 1) {
         const LaunchShape ls = d16_fwd_shape(a.ngroups, NT);
         const size_t lds = ((size_t)pad4(P) + s16_tab_floats(T::NG) + (size_t)ls.waves * (2 * 16 * d16::kStride + 2 * 16 * kChunkPad)) * sizeof(float);
-        auto k = delta16_fwd_kernel<TRES, NT>;
+        auto k = delta16_fwd_kernel<TRES, NT, JAN>;
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
         return (int)hipGetLastError();
@@ -767,8 +795,8 @@ static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, i
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
         return (int)hipGetLastError();
     };
-    if (a.dx == nullptr) return launch(delta16_bwd_kernel<TRES, NT, false>);
-    if (int e = launch(delta16_bwd_kernel<TRES, NT, true>)) return e;
+    if (a.dx == nullptr) return launch(delta16_bwd_kernel<TRES, NT, false, JAN>);
+    if (int e = launch(delta16_bwd_kernel<TRES, NT, true, JAN>)) return e;
     if (TRES) {
         const long n = (long)a.B * a.T;
         hipLaunchKernelGGL(tres_skip_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.x, a.dy, a.params, a.dx, a.B, a.T, a.H);
@@ -779,6 +807,12 @@ int delta_s16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, i
     SeqArgs a = a0;
     a.ngroups = (a.B + 15) / 16;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
+    if (m->backbone == ODPD_DELTAJANET) {
+        const int Pj = delta_layout(m->hidden, false, 2).P, ntj = d16_tiles(m->hidden);
+        if (ntj == 1) return d16_launch<false, 1, true>(st, m, a, Pj, mode);
+        if (ntj == 2) return d16_launch<false, 2, true>(st, m, a, Pj, mode);
+        return ODPD_EUNSUPPORTED;
+    }
     const int P = delta_layout(m->hidden, tres).P, nt = d16_tiles(m->hidden);
     if (nt == 1) return tres ? d16_launch<true, 1>(st, m, a, P, mode) : d16_launch<false, 1>(st, m, a, P, mode);
     if (nt == 2) return tres ? d16_launch<true, 2>(st, m, a, P, mode) : d16_launch<false, 2>(st, m, a, P, mode);

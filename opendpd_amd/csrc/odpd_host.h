@@ -101,15 +101,16 @@ __host__ __device__ inline LstmLayout lstm_layout(int H, int vd) {
     return L;
 }
 
-struct DeltaLayout { int H, tres, o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_tcn0, o_tcn2, P; };
-__host__ __device__ inline DeltaLayout delta_layout(int H, int tres) {
+struct DeltaLayout { int H, tres, G, o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_tcn0, o_tcn2, P; };
+// gates: 3 (r, z, n: deltagru / TRes-DeltaGRU) or 2 (f, g: deltajanet)
+__host__ __device__ inline DeltaLayout delta_layout(int H, int tres, int gates = 3) {
     DeltaLayout L;
-    L.H = H; L.tres = tres;
+    L.H = H; L.tres = tres; L.G = gates;
     int o = 0;
-    L.o_w_ih = o; o += 3 * H * 6;
-    L.o_w_hh = o; o += 3 * H * H;
+    L.o_w_ih = o; o += gates * H * 6;
+    L.o_w_hh = o; o += gates * H * H;
     L.o_b_ih = L.o_b_hh = L.o_b_out = L.o_tcn0 = L.o_tcn2 = 0;
-    if (!tres) { L.o_b_ih = o; o += 3 * H; L.o_b_hh = o; o += 3 * H; }
+    if (!tres) { L.o_b_ih = o; o += gates * H; L.o_b_hh = o; o += gates * H; }
     L.o_w_out = o; o += 2 * H;
     if (!tres) { L.o_b_out = o; o += 2; }
     else { L.o_tcn0 = o; o += 18; L.o_tcn2 = o; o += 6; }

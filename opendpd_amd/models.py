@@ -6,7 +6,7 @@ as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` 
 Backbones on the hot path run as HIP kernels (`backbone.native` is True) inside the kernels' envelope (one layer, hidden
 <= 32; pgjanet <= 16; tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32) and as ATen restatements (backbones/wide.py,
 `native` False, with a warning) beyond it; the remaining registry names (SURVEY §8 f4:
-apnrru, bojanet, deltajanet, dvrjanet, mcldnn) are torch restatements in backbones/extras.py that
+apnrru, bojanet, dvrjanet, mcldnn) are torch restatements in backbones/extras.py that
 run through ATen (`backbone.native` is False) until they get kernels.  Unknown names raise ValueError (models.py:139-141).
 """
 import torch
@@ -72,7 +72,7 @@ class CoreModel(nn.Module):
         elif backbone_type == "bojanet":
             self.backbone = X.BOJANET(hidden_size=hidden_size, output_size=2, bias=True)
         elif backbone_type == "deltajanet":
-            self.backbone = X.DeltaJANET(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers, thx=thx,
+            self.backbone = B.DeltaJANET(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers, thx=thx,
                                          thh=thh, bias=True)
         elif backbone_type == "dvrjanet":
             self.backbone = X.DVRJANET(hidden_size=hidden_size, output_size=2, num_dvr_units=num_dvr_units, bias=True)

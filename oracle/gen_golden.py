@@ -8,7 +8,7 @@ Only the vectors are committed; the reference never travels to the GPU box.
 What is pinned (reference file:line the vectors exercise):
   * backbones: gru.py:45-48, dgru.py:59-74, lstm.py:45-48, vdlstm.py:56-81,
     deltagru.py:59-77 + :211-264, deltagru_tcnskip.py:87-103 + :248-293,
-    tcnn.py:82-97, pgjanet.py:26-76, qgru.py:59-71, qgru_amp1.py:59-76, gmp.py:18-50, rvtdcnn.py:35-62, neuraltx.py:116-137
+    tcnn.py:82-97, pgjanet.py:26-76, qgru.py:59-71, qgru_amp1.py:59-76, gmp.py:18-50, rvtdcnn.py:35-62, neuraltx.py:116-137, deltajanet.py:50-64 + :211-274
   * registry models.py:10-160 (CoreModel) and models.py:163-176 (CascadedModel)
   * train step modules/train_funcs.py:33-44 (zero_grad, fwd, MSE, bwd, clip 200, AdamW)
   * quant path quant/__init__.py:20-37 -> quant_envs.py:138-306
@@ -81,11 +81,13 @@ def reset_stats(net):
     bb = getattr(net, "backbone", None)
     if bb is not None and hasattr(bb, "set_debug"):
         bb.set_debug(1)
+    elif bb is not None and hasattr(getattr(bb, "rnn", None), "set_debug"):      # DeltaJANET: only its layer has the counters
+        bb.rnn.set_debug(1)
 
 
 def read_stats(net):
     bb = getattr(net, "backbone", None)
-    if bb is None or not hasattr(bb, "get_temporal_sparsity"):
+    if bb is None or not (hasattr(bb, "get_temporal_sparsity") or hasattr(getattr(bb, "rnn", None), "get_temporal_sparsity")):
         return {}
     st = bb.rnn.statistics
     return {"stats": np.array([float(st["num_dx_zeros"]), float(st["num_dx_numel"]),
@@ -166,7 +168,9 @@ def gen_backbones(only=None):
         ("rvtdcnn_h25", "rvtdcnn", 25, 0, 0),                     # models.py:80-81: fc_hid_size = hidden_size; 1007 parameters
         ("rvtdcnn_h6", "rvtdcnn", 6, 0, 0),
         ("neuraltx_c36", "neuraltx", 36, 0, 0),                   # 986 parameters
-        ("neuraltx_c12", "neuraltx", 12, 0, 0),                       # the reference's own default fc_hid_size (rvtdcnn.py:11)
+        ("neuraltx_c12", "neuraltx", 12, 0, 0),
+        ("deltajanet_h15", "deltajanet", 15, 0.01, 0.05),         # the wrapper drops the thresholds (deltajanet.py:23-27): dense deltas
+        ("deltajanet_h22", "deltajanet", 22, 0, 0),               # 1366 parameters; two unit tiles of the S16 mapping                       # the reference's own default fc_hid_size (rvtdcnn.py:11)
     ]
     x, tgt = real_frames("DPA_200MHz", 5, 37, seed=1)       # ragged: B%4!=0, odd T
     xa, ta = real_frames("APA_200MHz", 8, 200, seed=2)      # config-shaped frames (T=200)

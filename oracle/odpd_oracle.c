@@ -72,6 +72,8 @@ int64_t oracle_param_count(const odpd_model_t* m) {
         return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
     case ODPD_GMP:      /* gmp.py:10-11: memory_length * (1 + (degree - 1) * memory_length); hidden = memory_length, degree 5 */
         return H * (1 + (GMP_DEGREE - 1) * H);
+    case ODPD_DELTAJANET: /* deltajanet.py:96-111: two gates */
+        return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2;
     case ODPD_NEURALTX: /* neuraltx.py:18-38: two 5-tap FIRs, 4 -> C (bias), 4 depthwise k5, C -> 2, IQ_match (2,2); hidden = channels */
         return 10 + 4 * H + H + 4 * 5 * H + 2 * H + 4;
     case ODPD_RVTDCNN:  /* rvtdcnn.py:19-33: Conv2d(1->3,k3) 27+3, fc_hid (H,36)+H, fc_out (2,H)+2; hidden = fc_hid_size (models.py:80-81) */
@@ -605,6 +607,91 @@ static void delta_seq_bwd(const odpd_model_t* m, const delta_layout_t* L, const 
             }
         }
     free(dfeat);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* DeltaJANET: deltajanet.py:50-64 (features [I,Q,a,a^3,sin,cos], fc_out with bias) around DeltaJANETLayer (:67-274): two
+ * gates [f; g] of H rows each (weight_ih_l0 (2H,6), weight_hh_l0 (2H,H), bias_ih_l0, bias_hh_l0); accumulator dm (2H) starts
+ * at bias_ih + bias_hh (:162-166); per step (:229-251) dx = x - x_p, dh = h - h_p (masked below the thresholds, which the
+ * wrapper fixes at 0: DeltaJANET builds its layer with thx = thh = 0, :23-27 — nothing is ever masked), x_p <- x, h_p <- h,
+ * dm = (dx W_ih^T + dm) + dh W_hh^T (:198-206), f = sigmoid(dm_f), g = sigmoid(dm_g) (:246-247: the candidate is a sigmoid too),
+ * h = (1 - f) g + f h (:250).  Counters num_d{x,h}_{zeros,numel} as deltagru.  Parameter order: rnn.weight_ih_l0,
+ * rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, fc_out.weight, fc_out.bias. */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int H; int64_t o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out; } dj_layout_t;
+static void dj_layout(const odpd_model_t* m, dj_layout_t* g) {
+    int64_t H = m->hidden, o = 0;
+    g->H = (int)H;
+    g->o_w_ih = o; o += 2 * H * 6; g->o_w_hh = o; o += 2 * H * H;
+    g->o_b_ih = o; o += 2 * H; g->o_b_hh = o; o += 2 * H;
+    g->o_w_out = o; o += 2 * H; g->o_b_out = o;
+}
+typedef struct { real f[6], dxm[6], hprev[MAXH], dhm[MAXH], fg[MAXH], gg[MAXH], h[MAXH]; } dj_step_t;
+static void dj_seq_fwd(const dj_layout_t* L, const real* p, int T, const real* x, real* y, dj_step_t* S, double* stats) {
+    const int H = L->H;
+    real xp[6] = {0}, h[MAXH] = {0}, hp[MAXH] = {0}, dm[2 * MAXH];
+    for (int j = 0; j < 2 * H; ++j) dm[j] = p[L->o_b_ih + j] + p[L->o_b_hh + j];
+    dj_step_t tmp;
+    double zx = 0, zh = 0;
+    for (int t = 0; t < T; ++t) {
+        dj_step_t* s = S ? &S[t] : &tmp;
+        const real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+        s->f[0] = I; s->f[1] = Q; s->f[2] = a; s->f[3] = a * a * a; s->f[4] = Q / a; s->f[5] = I / a;
+        for (int i = 0; i < 6; ++i) { s->dxm[i] = s->f[i] - xp[i]; if (s->dxm[i] == 0) zx += 1; xp[i] = s->f[i]; }
+        for (int j = 0; j < H; ++j) { s->hprev[j] = h[j]; s->dhm[j] = h[j] - hp[j]; if (s->dhm[j] == 0) zh += 1; hp[j] = h[j]; }
+        for (int j = 0; j < 2 * H; ++j) {
+            real ax = 0, ah = 0;
+            for (int i = 0; i < 6; ++i) ax += p[L->o_w_ih + j * 6 + i] * s->dxm[i];
+            for (int i = 0; i < H; ++i) ah += p[L->o_w_hh + j * H + i] * s->dhm[i];
+            dm[j] = (ax + dm[j]) + ah;
+        }
+        for (int j = 0; j < H; ++j) {
+            s->fg[j] = sigm(dm[j]); s->gg[j] = sigm(dm[H + j]);
+            h[j] = ((real)1 - s->fg[j]) * s->gg[j] + s->fg[j] * h[j];
+            s->h[j] = h[j];
+        }
+        for (int c = 0; c < 2; ++c) {
+            real acc = p[L->o_b_out + c];
+            for (int j = 0; j < H; ++j) acc += p[L->o_w_out + c * H + j] * h[j];
+            y[2 * t + c] = acc;
+        }
+    }
+    if (stats) { stats[0] += zx; stats[1] += 6.0 * T; stats[2] += zh; stats[3] += (double)H * T; }
+}
+/* back-propagation with carried accumulator gradients (d dm_t feeds every later step through the running sum) */
+static void dj_seq_bwd(const dj_layout_t* L, const real* p, int T, const real* x, const real* dy, const dj_step_t* S, real* dp, real* dx) {
+    const int H = L->H;
+    real Gh[MAXH] = {0}, Ghp[MAXH] = {0}, Gxp[6] = {0}, Gdm[2 * MAXH] = {0};
+    for (int t = T - 1; t >= 0; --t) {
+        const dj_step_t* s = &S[t];
+        for (int c = 0; c < 2; ++c) {
+            const real d = dy[2 * t + c];
+            dp[L->o_b_out + c] += d;
+            for (int j = 0; j < H; ++j) { dp[L->o_w_out + c * H + j] += d * s->h[j]; Gh[j] += d * p[L->o_w_out + c * H + j]; }
+        }
+        real Ghprev[MAXH];
+        for (int j = 0; j < H; ++j) {
+            const real dg = Gh[j] * ((real)1 - s->fg[j]), df = Gh[j] * (s->hprev[j] - s->gg[j]);
+            Ghprev[j] = Gh[j] * s->fg[j];
+            Gdm[j] += df * s->fg[j] * ((real)1 - s->fg[j]);
+            Gdm[H + j] += dg * s->gg[j] * ((real)1 - s->gg[j]);
+        }
+        real ddx[6] = {0}, ddh[MAXH] = {0};
+        for (int j = 0; j < 2 * H; ++j) {
+            const real g = Gdm[j];
+            for (int i = 0; i < 6; ++i) { dp[L->o_w_ih + j * 6 + i] += g * s->dxm[i]; ddx[i] += g * p[L->o_w_ih + j * 6 + i]; }
+            for (int i = 0; i < H; ++i) { dp[L->o_w_hh + j * H + i] += g * s->dhm[i]; ddh[i] += g * p[L->o_w_hh + j * H + i]; }
+        }
+        if (dx) {   /* dx_t = f_t - f_{t-1}: dL/df_t = ddx_t - ddx_{t+1} (Gxp carries -ddx_{t+1}) */
+            real df[6];
+            for (int i = 0; i < 6; ++i) { df[i] = ddx[i] + Gxp[i]; Gxp[i] = -ddx[i]; }
+            const real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+            const real da = df[2] + (real)3 * a * a * df[3] - (Q / a2) * df[4] - (I / a2) * df[5];
+            dx[2 * t] = df[0] + df[5] / a + da * I / a; dx[2 * t + 1] = df[1] + df[4] / a + da * Q / a;
+        }
+        for (int j = 0; j < H; ++j) { Gh[j] = Ghprev[j] + ddh[j] + Ghp[j]; Ghp[j] = -ddh[j]; }
+    }
+    for (int j = 0; j < 2 * H; ++j) { dp[L->o_b_ih + j] += Gdm[j]; dp[L->o_b_hh + j] += Gdm[j]; }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1308,6 +1395,11 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         real* du = amp + (T + 2 * M - 2); real* damp = du + 2 * (T + M - 1);
         if (dy) gmp_seq_bwd(M, params, T, x, dy, dp, dx, u, amp, du, damp);
         else gmp_seq_fwd(M, params, T, x, y, u, amp);
+    } else if (bb == ODPD_DELTAJANET) {
+        dj_layout_t L; dj_layout(m, &L);
+        dj_step_t* S = (dj_step_t*)scratch;
+        dj_seq_fwd(&L, params, T, x, y, dy ? S : NULL, stats);
+        if (dy) dj_seq_bwd(&L, params, T, x, dy, S, dp, dx);
     } else if (bb == ODPD_NEURALTX) {
         ntx_layout_t L; ntx_layout(m, &L);
         real* feat = (real*)scratch; real* pre = feat + (size_t)T * 4;
@@ -1327,6 +1419,7 @@ static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
     if (bb == ODPD_TCNN) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_PGJANET) return sizeof(pgj_step_t) * T;
     if (bb == ODPD_GMP) return sizeof(real) * (size_t)(6 * (T + 2 * m->hidden));
+    if (bb == ODPD_DELTAJANET) return sizeof(dj_step_t) * T;
     if (bb == ODPD_NEURALTX) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_RVTDCNN) return T >= 3 ? sizeof(real) * (size_t)(5 * T) : 0;   /* the circular window needs 3 samples */
     return 0;

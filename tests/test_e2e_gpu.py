@@ -372,7 +372,7 @@ def test_quantised_flow_two_epochs_and_run_dpd_match_reference(workdir):
     assert np.abs(csv.to_numpy() - m["dpd_out"]).max() <= 2.0 ** -14 + 1e-9
 
 
-@pytest.mark.parametrize("bb,H", [("mcldnn", 8), ("deltajanet", 10)])
+@pytest.mark.parametrize("bb,H", [("mcldnn", 8), ("dvrjanet", 8)])
 def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H):
     """SURVEY §8 f4 names (backbones/extras.py) go through the same Project flow on the GPU: ATen forward/backward,
     torch.optim.AdamW, device-resident frame loader, eval + metrics + checkpoint/log layout."""

@@ -8,7 +8,7 @@ import torch
 
 from tests.golden_util import Fixture, rel_err
 
-CASES = [("apnrru", 8), ("bojanet", 8), ("bojanet", 15), ("deltajanet", 10), ("dvrjanet", 8),
+CASES = [("apnrru", 8), ("bojanet", 8), ("bojanet", 15), ("dvrjanet", 8),
          ("mcldnn", 8)]
 TOL = 1e-5
 
@@ -111,6 +111,32 @@ def test_neuraltx_is_native_and_constructs_like_the_reference():
     assert wide.backbone.native is False
     from opendpd_amd.backbones.extras import NeuralTX
     ref = NeuralTX(hidden_channels=12)
+    ref.load_state_dict({k[len("backbone."):]: torch.from_numpy(fx["sdu/" + k]) for k in fx.keys("sdu")})
+    x = torch.from_numpy(fx["x"]).requires_grad_(True)
+    y = ref(x)
+    assert rel_err(y.detach().numpy(), fx["y"]) < TOL
+    torch.nn.functional.mse_loss(y, torch.from_numpy(fx["tgt"])).backward()
+    assert rel_err(x.grad.numpy(), fx["gx"]) < 10 * TOL
+
+
+def test_deltajanet_is_native_and_constructs_like_the_reference():
+    """deltajanet left this module for the JAN instantiation of csrc/delta_s16.hip (hidden <= 32); the seeded construction still
+    reproduces the reference's state dict and RNG consumption; beyond the envelope (or with more layers) the restatement serves it."""
+    fx = Fixture("extra_deltajanet_h10")
+    net = _build("deltajanet", 10)
+    after = float(torch.rand(1))
+    sd = net.state_dict()
+    assert list(sd.keys()) == fx.keys("sd")
+    for k in sd:
+        assert np.array_equal(sd[k].numpy(), fx["sd/" + k]), k
+    assert after == fx.meta["rng_after_init"]
+    assert net.backbone.native is True and sum(p.numel() for p in net.parameters()) == fx.meta["n_param"] == 2 * 100 + 18 * 10 + 2
+    assert (net.backbone.thx, net.backbone.thh) == (0.01, 0.05) and (net.backbone.desc.thx, net.backbone.desc.thh) == (0.0, 0.0)
+    with pytest.warns(UserWarning, match="outside"):
+        wide = _build("deltajanet", 40)
+    assert wide.backbone.native is False
+    from opendpd_amd.backbones.extras import DeltaJANET
+    ref = DeltaJANET(input_size=6, hidden_size=10, output_size=2, num_layers=1, thx=0.01, thh=0.05)
     ref.load_state_dict({k[len("backbone."):]: torch.from_numpy(fx["sdu/" + k]) for k in fx.keys("sdu")})
     x = torch.from_numpy(fx["x"]).requires_grad_(True)
     y = ref(x)

@@ -22,6 +22,7 @@ SINGLE = [
     ("deltagru_h24_th", "deltagru"), ("tres_h30_th", "deltagru_tcnskip"),
     ("tcnn_c35", "tcnn"), ("pgjanet_h11", "pgjanet"), ("gmp_m11", "gmp"),
     ("rvtdcnn_h25", "rvtdcnn"), ("rvtdcnn_h6", "rvtdcnn"), ("neuraltx_c36", "neuraltx"), ("neuraltx_c12", "neuraltx"),
+    ("deltajanet_h15", "deltajanet"), ("deltajanet_h22", "deltajanet"),
 ]
 
 

@@ -18,7 +18,7 @@ lib = _lib.load()
 o = Oracle("f32")
 o64 = Oracle("f64")
 LIM = {"gru": 32, "dgru": 32, "qgru": 32, "qgru_amp1": 32, "lstm": 32, "vdlstm": 32, "deltagru": 32, "deltagru_tcnskip": 32, "pgjanet": 16,
-       "tcnn": 40, "gmp": 11}
+       "tcnn": 40, "gmp": 11, "rvtdcnn": 32, "neuraltx": 40, "deltajanet": 32}
 names = list(LIM)
 rng = np.random.RandomState(7)
 bad, kinks, worst, single = [], [], [0.0, 0.0], 0
@@ -50,7 +50,7 @@ for case in range(n_cases):
     pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
     u, _ = o.forward(md, pd, x)
     # the PA divides by |u| (polar features): skip the rare draws where the random DPD maps a sample next to the origin
-    if "vdlstm" in pbb or pbb in ("dgru", "deltagru", "pgjanet", "tcnn", "qgru_amp1"):
+    if "vdlstm" in pbb or pbb in ("dgru", "deltagru", "pgjanet", "tcnn", "qgru_amp1", "rvtdcnn", "neuraltx", "deltajanet"):
         if np.sqrt((u ** 2).sum(-1)).min() < 1e-3:
             continue
     y, _ = o.forward(mp, pp, u)

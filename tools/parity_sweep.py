@@ -16,7 +16,8 @@ lib = _lib.load()
 o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
-         "tcnn": list(range(1, 40)) + [48, 63, 64], "gmp": [11] * 12}
+         "tcnn": list(range(1, 40)) + [48, 63, 64], "gmp": [11] * 12, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
+         "neuraltx": list(range(1, 40)) + [48, 63, 64]}
 rng = np.random.RandomState(0)
 bad, worst = [], {}
 for bb, sizes in SIZES.items():
@@ -28,7 +29,7 @@ for bb, sizes in SIZES.items():
                 T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 257, 300]))
                 if B * T > 6000:
                     T = max(1, 6000 // B)
-                if bb == "vdlstm" and T < 3:
+                if bb in ("vdlstm", "rvtdcnn") and T < 3:
                     T = 3       # the 3-sample circular pad needs T >= 3 (vdlstm.py:66-74); shorter frames are refused (EINVAL)
                 kw = dict(thx=float(rng.choice([0.0, 0.01, 0.05])), thh=float(rng.choice([0.0, 0.02, 0.1]))) if "delta" in bb else {}
                 torch.manual_seed(int(rng.randint(1 << 30)))
@@ -39,6 +40,8 @@ for bb, sizes in SIZES.items():
                     for k, p in net.named_parameters():
                         if "bias" in k:
                             p.uniform_(-0.3, 0.3)
+                        if k.startswith("backbone.conv_"):       # NeuralTX FIR taps: large enough for every path to count
+                            p.uniform_(-0.6, 0.6)
                 amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
                 x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
                 dy = rng.randn(B, T, 2).astype(np.float32)

@@ -19,7 +19,8 @@ if len(sys.argv) > 2:      # second argument: force the S16 occupancy variant (2
 o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
-         "tcnn": list(range(1, 40, 3)) + [64], "gmp": [11] * 16}
+         "tcnn": list(range(1, 40, 3)) + [64], "gmp": [11] * 16, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
+         "neuraltx": list(range(1, 40, 3)) + [64]}
 rng = np.random.RandomState(1)
 bad = []
 for bb, sizes in SIZES.items():
