@@ -67,7 +67,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 2; }
+extern "C" int odpd_abi_version(void) { return 3; }   // 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation; backbones 11..13
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {

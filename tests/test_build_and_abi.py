@@ -21,7 +21,7 @@ def test_library_builds_and_exports_header_symbols():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     assert declared == set(_lib.exported_symbols())
-    assert lib.odpd_abi_version() == 2
+    assert lib.odpd_abi_version() == 3
 
 
 def test_param_counts_match_reference():
@@ -31,7 +31,8 @@ def test_param_counts_match_reference():
     # N_PARAM values measured on the reference
     for bb, H, P in [("gru", 11, 519), ("gru", 23, 1911), ("dgru", 13, 1041), ("dgru", 23, 2751), ("lstm", 14, 1038),
                      ("vdlstm", 13, 1118), ("deltagru", 15, 1067), ("deltagru_tcnskip", 15, 999), ("tcnn", 35, 1015),
-                     ("pgjanet", 11, 959), ("qgru", 10, 502), ("qgru_amp1", 16, 1090)]:
+                     ("pgjanet", 11, 959), ("qgru", 10, 502), ("qgru_amp1", 16, 1090), ("gmp", 11, 495), ("rvtdcnn", 25, 1007),
+                     ("rvtdcnn", 6, 266), ("neuraltx", 36, 986), ("deltajanet", 15, 722), ("deltajanet", 22, 1366)]:
         d = _lib.ModelDesc(_lib.BACKBONE_IDS[bb], H, 0, 0, 0, 0, 0)
         assert lib.odpd_param_count(C.byref(d)) == P, bb
 
@@ -40,7 +41,8 @@ def test_param_counts_match_reference():
                                      ("qgru_h10", "qgru"), ("qgru_amp1_h10", "qgru_amp1"),
                                      ("lstm_h14", "lstm"), ("vdlstm_h13", "vdlstm"),
                                      ("deltagru_h15_th", "deltagru"), ("tres_h15_th", "deltagru_tcnskip"),
-                                     ("pgjanet_h11", "pgjanet"), ("tcnn_c35", "tcnn")])
+                                     ("pgjanet_h11", "pgjanet"), ("tcnn_c35", "tcnn"), ("gmp_m11", "gmp"),
+                                     ("rvtdcnn_h25", "rvtdcnn"), ("neuraltx_c36", "neuraltx"), ("deltajanet_h15", "deltajanet")])
 def test_registry_init_is_bit_identical_to_reference(name, bb):
     """Same seed -> same RNG consumption -> identical initial state dict (keys, order, values)."""
     from opendpd_amd import CoreModel
