@@ -254,6 +254,9 @@ __global__ __launch_bounds__(kRvThreads, 2) void rv_bwd_kernel(SeqArgs a, RvGeom
         // ---- forward row loop: hid_u to its LDS column, y on the fly ----
         if constexpr (DX) __syncthreads();             // the previous pass's patch-gradient gathers (over the z columns) are done
         else wave_lds_fence();                         // ... MFMA operand reads
+        if constexpr (NW && DX) {     // the patch-gradient exchange also ran over the padded hid columns: make them numbers again
+            for (int u = L.H; u < 16 * HT; ++u) hidc[u * kRvCol] = 0.0f;
+        }
         {
             float y0 = w0[L.o_bo], y1 = w0[L.o_bo + 1];
             rv_rows(w0, L, [&](const RvRowW& r, int u) {

@@ -46,14 +46,14 @@ def at_start(t):
 
 
 for it in range(cases):
-    H = 11 if bb == "gmp" else int(rng.randint(1, (17 if bb == "pgjanet" else 41 if bb == "tcnn" else 33)))
+    H = 11 if bb == "gmp" else int(rng.randint(1, (17 if bb == "pgjanet" else 41 if bb in ("tcnn", "neuraltx") else 33)))
     force = bool(rng.randint(2))
     lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
     B = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
-    T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 257, 300] + ([513, 700, 1500] if bb == "gmp" else [])))
+    T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 257, 300] + ([513, 700, 1500] if bb in ("gmp", "rvtdcnn", "neuraltx") else [])))
     if B * T > 6000:
         T = max(1, 6000 // B)
-    if bb == "vdlstm" and T < 3:
+    if bb in ("vdlstm", "rvtdcnn") and T < 3:
         T = 3
     print(it, bb, H, B, T, force, flush=True)
     torch.manual_seed(it)
@@ -79,7 +79,7 @@ for it in range(cases):
         y = net(x)
         y.backward(dy)
         fused_train_step(opt, place(x0), place(tgt), "l2", 200.0)
-        if T >= 3 or "vdlstm" not in (bb, dpd_bb):
+        if T >= 3 or not ({"vdlstm", "rvtdcnn"} & {bb, dpd_bb}):
             fused_train_step(copt, place(x0), place(tgt), "l2", 200.0)
         if qnet is not None:
             xq = place(x0).requires_grad_(True)
