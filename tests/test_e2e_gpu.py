@@ -372,6 +372,42 @@ def test_quantised_flow_two_epochs_and_run_dpd_match_reference(workdir):
     assert np.abs(csv.to_numpy() - m["dpd_out"]).max() <= 2.0 ** -14 + 1e-9
 
 
+def test_quantised_flow_with_pretrained_float_checkpoint_matches_reference(workdir):
+    """train_dpd --quant --pretrained_model <float checkpoint with the float holder's key names> (the q_pretrain -> QAT hand-over,
+    quant_envs.py:173-182): the checkpoint's weights go through quantisation, its biases are re-drawn by INT_Linear, the scales start at
+    their defaults.  One epoch against the reference's logged row and saved state (tests/golden/ref_runs_qat_pre.{json,npz},
+    oracle/gen_run_anchor_qat_pretrained.py); tolerances as in the flow without a checkpoint."""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_qat_pre.json")))
+    m = dict(np.load(os.path.join(GOLDEN, "ref_runs_qat_pre.npz")))
+    pa = dict(np.load(os.path.join(GOLDEN, "ref_runs_qat_dpa.npz")))
+    os.makedirs(os.path.dirname(ref["pa_model"]), exist_ok=True)
+    torch.save({k[3:]: torch.from_numpy(v) for k, v in pa.items() if k.startswith("pa/")}, ref["pa_model"])
+    torch.save({k[4:]: torch.from_numpy(v) for k, v in m.items() if k.startswith("pre/")}, "pygru.pt")
+    res = od.train_dpd(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=11, DPD_backbone="qgru", DPD_hidden_size=10, frame_length=50,
+                       seed=0, accelerator="cuda", quant=True, n_bits_w=8, n_bits_a=8, quant_dir_label="w8a8pre", pretrained_model="pygru.pt",
+                       batch_size=64, lr=1e-3, n_epochs=1)
+    assert os.path.normpath(res["model_path"]) == os.path.normpath(ref["dpd_model"])
+    hist = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), "history", os.path.basename(res["log_path"])))
+    rh = ref["hist"]
+    assert list(hist.columns) == list(rh.keys()) and list(hist["N_PARAM"]) == rh["N_PARAM"]
+    assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 0.02 * rh["TRAIN_LOSS"][0], (hist["TRAIN_LOSS"][0], rh["TRAIN_LOSS"][0])
+    for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
+        assert abs(hist[col][0] - rh[col][0]) < 0.4, (col, hist[col][0], rh[col][0])   # dB
+    sd = torch.load(res["model_path"], map_location="cpu")
+    ref_sd = {k[4:]: v for k, v in m.items() if k.startswith("dpd/")}
+    assert list(sd.keys()) == list(ref_sd.keys())
+    # 360 AdamW steps at lr 1e-3 move a weight by at most 0.36: the trained weights are still the checkpoint's, moved; the biases were
+    # re-drawn (uniform +-1/sqrt(fan_in)) and zero-gradient-free, so they are NOT the checkpoint's — in the reference's file and here
+    w, b = "backbone.rnn.rnn_cell_list.0.h2h.weight", "backbone.rnn.rnn_cell_list.0.x2h.bias"
+    for got in (sd[w].numpy(), ref_sd[w]):
+        assert np.abs(got - m["pre/" + w]).max() < 0.45
+        assert np.corrcoef(got.reshape(-1), m["pre/" + w].reshape(-1))[0, 1] > 0.5
+    for got in (sd[b].numpy(), ref_sd[b]):
+        assert np.abs(got - m["pre/" + b]).max() > 0.45
+    assert np.abs(sd[w].numpy() - ref_sd[w]).max() < 0.05          # and the two runs stay next to each other
+
+
 @pytest.mark.parametrize("bb,H", [("mcldnn", 8), ("dvrjanet", 8)])
 def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H):
     """SURVEY §8 f4 names (backbones/extras.py) go through the same Project flow on the GPU: ATen forward/backward,
