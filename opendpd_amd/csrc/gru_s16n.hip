@@ -405,8 +405,9 @@ __device__ __forceinline__ void s16n_write_row(float* prow, const GruLayout& L, 
 
 // MODE 0: fused train (x, target -> partials; checkpoints in `ckpt` workspace)   1: forward (y, optional ckpt)
 // MODE 2: backward from dy (partials if NW, dx if DX)
+// the frozen-model variants (no weight gradients: fewer accumulators) run two waves per SIMD like the forward kernel
 template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
-__global__ __launch_bounds__(MODE == 1 ? 512 : 256, 1) void gru16n_kernel(SeqArgs a) {
+__global__ __launch_bounds__((MODE == 1 || !NW) ? 512 : 256, (MODE != 1 && !NW) ? 2 : 1) void gru16n_kernel(SeqArgs a) {
     using T = S16N<NT>;
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
     constexpr int kGroups = (MODE != 1 && DX) ? T::NG_DX : T::NG;
@@ -588,7 +589,7 @@ template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
 static int launch_s16n(hipStream_t st, const SeqArgs& a, int P) {
     using T = S16N<NT>;
     LaunchShape ls = s16n_shape(a.ngroups);     // the grid (= rows of partials) never depends on the backward's flavour
-    if (MODE == 1) {                            // forward: small state, two waves per SIMD
+    if (MODE == 1 || !NW) {                     // forward / frozen model: two waves per SIMD
         ls.waves = 8;
         const int need = (a.ngroups + 7) / 8, cap = device_cus();
         ls.grid = need < cap ? need : cap;
@@ -603,6 +604,10 @@ static int launch_s16n(hipStream_t st, const SeqArgs& a, int P) {
         return nb;
     };
     size_t lds = bytes(ls.waves);
+    if (lds > kMaxLds && ls.waves == 8) {       // eight waves do not fit next to the table: back to one wave per SIMD
+        ls = s16n_shape(a.ngroups);
+        lds = bytes(ls.waves);
+    }
     if (lds > kMaxLds) { ls.waves = 2; lds = bytes(2); }      // weight gradients + dL/dx in one launch: two waves per CU
     if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
     auto k = gru16n_kernel<FM, DG, NT, MODE, NW, DX, NCK>;
