@@ -5,7 +5,7 @@
 // Mapping and machinery as in gru_s16n.hip: lane (n = sequence, q = unit quad) owns units 16kt + 4q + i of NT tiles; the
 // four gate mat-vecs are NT x NT tiles of exact-fp32 MFMA with the A operands streamed from an LDS table; the i, f, o
 // rows are stored pre-multiplied by -log2(e); weight gradients through per-step LDS transposes; (h, c) checkpoints
-// every kCkptStride steps in an HBM workspace ([task][ckpt][2 NT][lane] float4).  One wave per SIMD.
+// every kCkptStride steps in an HBM workspace ([task][ckpt][2 NT][lane] float4).  Two waves per SIMD for hidden <= 16, one beyond.
 // VDLSTM head: the eight lambda outputs are rows 0..7 of one more MFMA group (lanes q = 0 hold l1[0..3], q = 1 hold
 // l2[0..3]); the window trigonometry is per-sequence work replicated on the sequence's four lanes.
 // The split forward / backward entry points keep the row-rotated kernels (lstm_family.hip).
@@ -395,8 +395,10 @@ __device__ __forceinline__ void l16_stage_halo(float2* lds, const float* g, int 
     }
 }
 
+// hidden <= 16: two waves per SIMD (eight-wave workgroups sharing one operand table; 256 registers per wave, the VDLSTM variant
+// spills 68 of them to scratch and still gains: 32 768 x 200 lstm H14 1.29 -> 1.08 ms, vdlstm H13 1.54 -> 1.33 ms); hidden 17..32: one
 template <bool VD, int NT>
-__global__ __launch_bounds__(256, 1) void lstm16_train_kernel(SeqArgs a) {
+__global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void lstm16_train_kernel(SeqArgs a) {
     using T = L16<VD, NT>;
     constexpr int NCH = T::NCH, S = kCkptStride;
     constexpr int kWave = T::kXFloats + 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
@@ -522,10 +524,10 @@ __global__ __launch_bounds__(256, 1) void lstm16_train_kernel(SeqArgs a) {
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
-static LaunchShape l16_shape(int ngroups) {
+static LaunchShape l16_shape(int ngroups, int nt = 2) {
     LaunchShape ls;
-    ls.waves = 4;
-    const int need = (ngroups + 3) / 4, cap = device_cus();
+    ls.waves = nt == 1 ? 8 : 4;
+    const int need = (ngroups + ls.waves - 1) / ls.waves, cap = device_cus();
     ls.grid = need < cap ? need : cap;
     return ls;
 }
@@ -536,8 +538,7 @@ bool lstm_train_uses_s16(const odpd_model_t* m, int B) {
     return B >= min_batch;
 }
 int lstm_s16_rows(const odpd_model_t* m, int B) {
-    (void)m;
-    return l16_shape((B + 15) / 16).grid;
+    return l16_shape((B + 15) / 16, (m->hidden + 15) / 16).grid;
 }
 int64_t lstm_s16_workspace_floats(const odpd_model_t* m, int B, int T) {
     return (int64_t)((B + 15) / 16) * num_ckpt(T) * 2 * ((m->hidden + 15) / 16) * 256;
@@ -545,7 +546,7 @@ int64_t lstm_s16_workspace_floats(const odpd_model_t* m, int B, int T) {
 template <bool VD, int NT>
 static int launch_l16(hipStream_t st, const SeqArgs& a, int P) {
     using T = L16<VD, NT>;
-    const LaunchShape ls = l16_shape(a.ngroups);
+    const LaunchShape ls = l16_shape(a.ngroups, NT);
     const int wave_floats = T::kXFloats + 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
     size_t body = (size_t)ls.waves * wave_floats;
     if (body < (size_t)pad4(P)) body = pad4(P);
