@@ -349,7 +349,8 @@ __device__ __forceinline__ void qgru_write_partials(float* prow, const float* pl
 }
 
 template <bool AMP1, bool LUT, bool NW, bool DX>
-__global__ __launch_bounds__(kMaxThreads / 2, 1) void qgru_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
+// weight gradients OR dL/dx alone fit 256 registers: two four-wave workgroups per CU (two waves per SIMD); both together: one
+__global__ __launch_bounds__(kMaxThreads / 2, (NW && DX) ? 1 : 2) void qgru_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
     constexpr int SPW = 4, S = kCkptStride;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const LaneId id = lane_id<1>();
@@ -419,7 +420,8 @@ static size_t qgru_lds_bytes(int P, int waves, int bits_a, bool lut, bool reduce
     if (reduce && n < need) n = need;
     return n;
 }
-static LaunchShape qgru_bwd_shape(int ngroups) { return persistent_shape(ngroups, 4, 4); }
+// the grid (= rows of partials) is the same for every flavour of the backward: up to two workgroups per CU
+static LaunchShape qgru_bwd_shape(int ngroups) { return persistent_shape(ngroups, 8, 4); }
 static bool qat_ok(const odpd_model_t* m) {
     return m->hidden <= 16 && m->bits_w >= 2 && m->bits_w <= 16 && m->bits_a >= 2 && m->bits_a <= 16;
 }
