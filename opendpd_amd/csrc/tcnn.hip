@@ -308,7 +308,7 @@ __device__ __forceinline__ int tcnn_col(const TcnnLayout& L, int c, int j) {
 // grid = rows blocks of 4 waves; wave gw works on tiles gw / ncw, + nwaves / ncw, ... and channels gw % ncw, + ncw, ...
 // LDS per wave: accumulator row of P floats + the tile's dy (R float2 per lane, [i][lane]: conflict-free ds_read_b64)
 template <int R, bool NTX>
-__global__ __launch_bounds__(256, (R <= 13 && !NTX) ? 2 : 1) void tcnn_bwd_kernel(SeqArgs a, TcnnGeom g, int ncw) {
+__global__ __launch_bounds__(256, (R <= 8 || (R <= 13 && !NTX)) ? 2 : 1) void tcnn_bwd_kernel(SeqArgs a, TcnnGeom g, int ncw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15;
     const TcnnLayout L = tcnn_layout(a.H, NTX);
