@@ -42,7 +42,8 @@ enum odpd_backbone {
     ODPD_RVTDCNN = 11,   /* backbones/rvtdcnn.py:9-62 (hidden = fc_hid_size, models.py:80-81; window 4, 3 conv channels) */
     ODPD_NEURALTX = 12,  /* backbones/neuraltx.py:5-137 (hidden = hidden_channels; complex 5-tap FIR + the TCNN stack on 4 features) */
     ODPD_DELTAJANET = 13, /* backbones/deltajanet.py:11-274 (two-gate delta cell; the wrapper fixes both thresholds at 0) */
-    ODPD_BACKBONE_COUNT = 14
+    ODPD_DVRJANET = 14,  /* backbones/dvrjanet.py:5-112 (num_dvr_units rides in odpd_model_t::bits_w) */
+    ODPD_BACKBONE_COUNT = 15
 };
 
 enum odpd_error {
@@ -58,7 +59,7 @@ typedef struct odpd_model {
                          else ODPD_EUNSUPPORTED */
     float thx;        /* delta threshold on inputs  (deltagru*, models.py:11) */
     float thh;        /* delta threshold on hidden state */
-    int32_t bits_w;   /* QAT weight bits (0 = float model) — quant/quant_envs.py:145 */
+    int32_t bits_w;   /* QAT weight bits (0 = float model) — quant/quant_envs.py:145; dvrjanet: num_dvr_units (models.py:119) */
     int32_t bits_a;   /* QAT activation bits */
     int32_t flags;    /* ODPD_FLAG_* */
 } odpd_model_t;

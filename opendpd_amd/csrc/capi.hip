@@ -5,7 +5,7 @@
 using namespace odpd;
 
 namespace {
-enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP, FAM_RVTDCNN };
+enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP, FAM_RVTDCNN, FAM_DVR };
 inline Family family_of(int bb);
 // a quantisation-aware model: qgru / qgru_amp1 with bits_w > 0 (quant/quant_envs.py:138-171)
 inline Family family_of(const odpd_model_t* m) {
@@ -21,6 +21,7 @@ inline Family family_of(int bb) {
     case ODPD_TCNN: case ODPD_NEURALTX: return FAM_TCNN;
     case ODPD_GMP: return FAM_GMP;
     case ODPD_RVTDCNN: return FAM_RVTDCNN;
+    case ODPD_DVRJANET: return FAM_DVR;
     default: return FAM_NONE;
     }
 }
@@ -86,6 +87,7 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_PGJANET: return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
     case ODPD_NEURALTX: return H <= 64 ? 27 * H + 14 : (int64_t)ODPD_EUNSUPPORTED;   // two 5-tap FIRs, 4->C (+bias), 4 x depthwise k5, C->2, IQ_match 2x2
     case ODPD_GMP: return H == 11 ? H * (1 + 4 * H) : (int64_t)ODPD_EUNSUPPORTED;   // memory_length 11, degree 5 (models.py:26-28)
+    case ODPD_DVRJANET: return dvrjanet_param_count(m);   // K + 7H^2 + 7H + 2, K = bits_w (dvrjanet.py:11-30, 47-52)
     case ODPD_RVTDCNN: return H <= 32 ? 39 * H + 32 : (int64_t)ODPD_EUNSUPPORTED;  // conv 27+3, fc_hid 36H+H, fc_out 2H+2 (rvtdcnn.py:19-33)
     default: return ODPD_EUNSUPPORTED;
     }
@@ -94,6 +96,7 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
 extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     if (family_of(m) == FAM_TCNN || family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN) return 0;   // not recurrent: nothing to checkpoint
+    if (family_of(m) == FAM_DVR) return dvrjanet_ckpt_floats(m, B, T);
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
@@ -121,6 +124,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
         return lstm_family_rows(m, B);
     case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B);
     case FAM_JANET: return fused ? (int64_t)ODPD_EUNSUPPORTED : janet_family_rows(m, B);
+    case FAM_DVR: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)dvrjanet_rows(m, B);
     case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
     case FAM_GMP: return gmp_rows(m, B, T);
     case FAM_RVTDCNN: return fused ? rvtdcnn_train_rows(m, B, T) : rvtdcnn_rows(m, B, T);
@@ -148,6 +152,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_LSTM: return lstm_family_fwd((hipStream_t)stream, m, a);
     case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
     case FAM_JANET: return janet_family_fwd((hipStream_t)stream, m, a);
+    case FAM_DVR: return dvrjanet_launch((hipStream_t)stream, m, a, 1);
     case FAM_TCNN: return tcnn_fwd((hipStream_t)stream, m, a);
     case FAM_GMP: return gmp_fwd((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_fwd((hipStream_t)stream, m, a);
@@ -174,6 +179,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_JANET:
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return janet_family_bwd((hipStream_t)stream, m, a);
+    case FAM_DVR: return dvrjanet_launch((hipStream_t)stream, m, a, 2);
     case FAM_TCNN: return tcnn_bwd((hipStream_t)stream, m, a);
     case FAM_GMP: return gmp_bwd((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_bwd((hipStream_t)stream, m, a);

@@ -202,6 +202,11 @@ bool janet_uses_s16(const odpd_model_t* m, int B);
 int janet_s16_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
 int janet_s16_rows(const odpd_model_t* m, int B);
 int64_t janet_s16_ckpt_floats(const odpd_model_t* m, int B, int T);
+// dvrjanet_s16.hip (hidden <= 16, num_dvr_units = bits_w <= 8): mode 1 forward, 2 backward
+int dvrjanet_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
+int dvrjanet_rows(const odpd_model_t* m, int B);
+int64_t dvrjanet_param_count(const odpd_model_t* m);
+int64_t dvrjanet_ckpt_floats(const odpd_model_t* m, int B, int T);
 int tcnn_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_rows(const odpd_model_t* m, int B, int T);

@@ -4,9 +4,9 @@
 thx=0, thh=0)` — same constructor, attributes, `forward(x, h_0=None)` contract and state-dict keys
 as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` as models.py:163-176.
 Backbones on the hot path run as HIP kernels (`backbone.native` is True) inside the kernels' envelope (one layer, hidden
-<= 32; pgjanet <= 16; tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32) and as ATen restatements (backbones/wide.py,
+<= 32; pgjanet <= 16; tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32; dvrjanet <= 16 with <= 8 DVR units) and as ATen restatements (backbones/wide.py,
 `native` False, with a warning) beyond it; the remaining registry names (SURVEY §8 f4:
-apnrru, bojanet, dvrjanet, mcldnn) are torch restatements in backbones/extras.py that
+apnrru, bojanet, mcldnn) are torch restatements in backbones/extras.py that
 run through ATen (`backbone.native` is False) until they get kernels.  Unknown names raise ValueError (models.py:139-141).
 """
 import torch
@@ -75,7 +75,16 @@ class CoreModel(nn.Module):
             self.backbone = B.DeltaJANET(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers, thx=thx,
                                          thh=thh, bias=True)
         elif backbone_type == "dvrjanet":
-            self.backbone = X.DVRJANET(hidden_size=hidden_size, output_size=2, num_dvr_units=num_dvr_units, bias=True)
+            from .backbones import dvrjanet as D
+            if hidden_size <= D.MAX_HIDDEN and isinstance(num_dvr_units, int) and 1 <= num_dvr_units <= D.MAX_DVR_UNITS:
+                self.backbone = B.DVRJANET(hidden_size=hidden_size, output_size=2, num_dvr_units=num_dvr_units, bias=True)
+            else:
+                # beyond the kernel's envelope: the torch restatement through ATen, said aloud
+                import warnings
+                warnings.warn(f"opendpd_amd: backbone 'dvrjanet' with hidden_size={hidden_size}, num_dvr_units={num_dvr_units} is outside "
+                              f"the HIP kernel's envelope (hidden <= {D.MAX_HIDDEN}, num_dvr_units <= {D.MAX_DVR_UNITS}): running the "
+                              f"ATen restatement (backbones/extras.py)", stacklevel=2)
+                self.backbone = X.DVRJANET(hidden_size=hidden_size, output_size=2, num_dvr_units=num_dvr_units, bias=True)
         elif backbone_type == "neuraltx":
             self.backbone = B.NeuralTX(hidden_channels=hidden_size)
         elif backbone_type == "mcldnn":

@@ -8,7 +8,7 @@ Only the vectors are committed; the reference never travels to the GPU box.
 What is pinned (reference file:line the vectors exercise):
   * backbones: gru.py:45-48, dgru.py:59-74, lstm.py:45-48, vdlstm.py:56-81,
     deltagru.py:59-77 + :211-264, deltagru_tcnskip.py:87-103 + :248-293,
-    tcnn.py:82-97, pgjanet.py:26-76, qgru.py:59-71, qgru_amp1.py:59-76, gmp.py:18-50, rvtdcnn.py:35-62, neuraltx.py:116-137, deltajanet.py:50-64 + :211-274
+    tcnn.py:82-97, pgjanet.py:26-76, qgru.py:59-71, qgru_amp1.py:59-76, gmp.py:18-50, rvtdcnn.py:35-62, neuraltx.py:116-137, deltajanet.py:50-64 + :211-274, dvrjanet.py:44-101
   * registry models.py:10-160 (CoreModel) and models.py:163-176 (CascadedModel)
   * train step modules/train_funcs.py:33-44 (zero_grad, fwd, MSE, bwd, clip 200, AdamW)
   * quant path quant/__init__.py:20-37 -> quant_envs.py:138-306
@@ -57,7 +57,7 @@ def real_frames(name, B, T, seed, split="train"):
     return x, t
 
 
-def build(backbone, hidden, seed, thx=0.0, thh=0.0, num_layers=1):
+def build(backbone, hidden, seed, thx=0.0, thh=0.0, num_layers=1, num_dvr_units=None):
     torch.manual_seed(seed)
     if backbone == "pgjanet":
         # reference defect 1: registry passes window_size= which PGJANET.__init__ lacks -> construct directly
@@ -70,7 +70,7 @@ def build(backbone, hidden, seed, thx=0.0, thh=0.0, num_layers=1):
         net.backbone.reset_parameters()
         return net
     return ref_models.CoreModel(input_size=2, hidden_size=hidden, num_layers=num_layers, backbone_type=backbone,
-                                thx=thx, thh=thh)
+                                thx=thx, thh=thh, num_dvr_units=num_dvr_units)
 
 
 def sd_np(net, prefix):
@@ -166,20 +166,30 @@ def gen_backbones(only=None):
         ("qgru_amp1_h10", "qgru_amp1", 10, 0, 0),
         ("gmp_m11", "gmp", 11, 0, 0),                             # models.py:26-28: GMP() — memory 11, degree 5 whatever hidden_size is
         ("rvtdcnn_h25", "rvtdcnn", 25, 0, 0),                     # models.py:80-81: fc_hid_size = hidden_size; 1007 parameters
-        ("rvtdcnn_h6", "rvtdcnn", 6, 0, 0),
+        ("rvtdcnn_h6", "rvtdcnn", 6, 0, 0),                       # the reference's own default fc_hid_size (rvtdcnn.py:11)
         ("neuraltx_c36", "neuraltx", 36, 0, 0),                   # 986 parameters
         ("neuraltx_c12", "neuraltx", 12, 0, 0),
         ("deltajanet_h15", "deltajanet", 15, 0.01, 0.05),         # the wrapper drops the thresholds (deltajanet.py:23-27): dense deltas
-        ("deltajanet_h22", "deltajanet", 22, 0, 0),               # 1366 parameters; two unit tiles of the S16 mapping                       # the reference's own default fc_hid_size (rvtdcnn.py:11)
+        ("deltajanet_h22", "deltajanet", 22, 0, 0),               # 1366 parameters; two unit tiles of the S16 mapping
+        ("dvrjanet_h12_k3", "dvrjanet", 12, 0, 0),                # 1097 parameters at the CLI's default num_dvr_units = 3
+        ("dvrjanet_h8_k4", "dvrjanet", 8, 0, 0),
     ]
+    dvr_units = {"dvrjanet_h12_k3": 3, "dvrjanet_h8_k4": 4}
     x, tgt = real_frames("DPA_200MHz", 5, 37, seed=1)       # ragged: B%4!=0, odd T
     xa, ta = real_frames("APA_200MHz", 8, 200, seed=2)      # config-shaped frames (T=200)
     for name, bb, H, thx, thh in cases:
         if only and name not in only:
             continue
-        net = build(bb, H, seed=0, thx=thx, thh=thh)
+        net = build(bb, H, seed=0, thx=thx, thh=thh, num_dvr_units=dvr_units.get(name))
+        if bb == "dvrjanet":      # xavier weights and zero biases leave the DVR knots (k/K) far from W_ax |x| + W_ah hs: move some biases
+            with torch.no_grad():  # and scale the input columns so that every knot sees both signs
+                g = torch.Generator().manual_seed(5)
+                for k, p in net.named_parameters():
+                    if k.endswith("bias"):
+                        p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 0.4)
+                net.backbone.W_ax.weight.mul_(1.5)
         d = {"x": x, "tgt": tgt, "meta": np.array(json.dumps(
-            {"backbone": bb, "hidden": H, "thx": thx, "thh": thh, "lr": LR, "clip": CLIP,
+            {"backbone": bb, "hidden": H, "thx": thx, "thh": thh, "lr": LR, "clip": CLIP, "num_dvr_units": dvr_units.get(name, 0),
              "n_param": int(sum(p.numel() for p in net.parameters()))}))}
         d.update(sd_np(net, "sd"))
         # config-shaped forward + loss only (before any parameter update)

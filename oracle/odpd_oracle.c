@@ -32,6 +32,7 @@ typedef ODPD_REAL real;
 
 #define MAXH 64
 #define MAXF 8
+#define DVR_MAXK 16      /* largest num_dvr_units the restatement takes (dvrjanet.py:7; the CLI default is 3) */
 #define GMP_DEGREE 5     /* models.py:26-28 builds GMP() with the defaults memory_length 11, degree 5 (gmp.py:6) */
 
 static inline real sigm(real v) { return (real)1 / ((real)1 + (real)exp(-(double)v)); }
@@ -72,6 +73,8 @@ int64_t oracle_param_count(const odpd_model_t* m) {
         return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
     case ODPD_GMP:      /* gmp.py:10-11: memory_length * (1 + (degree - 1) * memory_length); hidden = memory_length, degree 5 */
         return H * (1 + (GMP_DEGREE - 1) * H);
+    case ODPD_DVRJANET: /* dvrjanet.py:13-30: cs (K = bits_w), seven HxH blocks, two H input columns, three H biases, two heads */
+        return (m->bits_w > 0 && m->bits_w <= DVR_MAXK) ? m->bits_w + 7 * H * H + 7 * H + 2 : -1;
     case ODPD_DELTAJANET: /* deltajanet.py:96-111: two gates */
         return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2;
     case ODPD_NEURALTX: /* neuraltx.py:18-38: two 5-tap FIRs, 4 -> C (bias), 4 depthwise k5, C -> 2, IQ_match (2,2); hidden = channels */
@@ -1003,6 +1006,126 @@ static void pgj_seq_bwd(const pgj_layout_t* L, const real* p, int T, const real*
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* DVRJANET: dvrjanet.py:44-101.  Two states h_I, h_Q (both start at h_0 = 0); per step, with hs = h_I + h_Q, mag = |x|,
+ * theta = atan2(Q, I) (:58-63):  th = W_ptheta theta + W_ph hs (:66);  a = DVR(W_ax mag + W_ah hs) with DVR(v) = sum_k c_k |v - k/K|,
+ * k = 1..K (:32-42, :69-72);  f = sigmoid(W_f hs + b) (:80);  g_c = tanh(W_ccos [h_I, a cos th] + b), g_s = tanh(W_csin [h_Q, a sin th]
+ * + b) (:83-86);  h_I = f h_I + (1-f) g_c, h_Q = f h_Q + (1-f) g_s (:89-90);  y = (W_o1 h_I + b, W_o2 h_Q + b) (:93-94).
+ * K = num_dvr_units rides in odpd_model_t::bits_w.  Parameter order (named_parameters: the module's own `cs` first): cs (K),
+ * W_ph (H,H), W_ptheta (H,1), W_ah (H,H), W_ax (H,1), W_f (H,H)+b, W_ccos (H,2H)+b, W_csin (H,2H)+b, W_o1 (1,H)+b, W_o2 (1,H)+b. */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int H, K; int64_t o_cs, o_wph, o_wpt, o_wah, o_wax, o_wf, o_bf, o_wcc, o_bcc, o_wcs, o_bcs, o_wo1, o_bo1, o_wo2, o_bo2, P; } dvr_layout_t;
+static void dvr_layout(const odpd_model_t* m, dvr_layout_t* g) {
+    int64_t H = m->hidden, K = m->bits_w, o = 0;
+    g->H = (int)H; g->K = (int)K;
+    g->o_cs = o; o += K;
+    g->o_wph = o; o += H * H; g->o_wpt = o; o += H; g->o_wah = o; o += H * H; g->o_wax = o; o += H;
+    g->o_wf = o; o += H * H; g->o_bf = o; o += H;
+    g->o_wcc = o; o += 2 * H * H; g->o_bcc = o; o += H;
+    g->o_wcs = o; o += 2 * H * H; g->o_bcs = o; o += H;
+    g->o_wo1 = o; o += H; g->o_bo1 = o; o += 1; g->o_wo2 = o; o += H; g->o_bo2 = o; o += 1;
+    g->P = o;
+}
+typedef struct { real mag, theta, hIp[MAXH], hQp[MAXH], th[MAXH], ap[MAXH], at[MAXH], f[MAXH], gc[MAXH], gs[MAXH], hI[MAXH], hQ[MAXH]; } dvr_step_t;
+static void dvr_seq_fwd(const dvr_layout_t* L, const real* p, int T, const real* x, real* y, dvr_step_t* S) {
+    const int H = L->H, K = L->K;
+    real hI[MAXH] = {0}, hQ[MAXH] = {0};
+    dvr_step_t tmp;
+    for (int t = 0; t < T; ++t) {
+        dvr_step_t* s = S ? &S[t] : &tmp;
+        const real I = x[2 * t], Q = x[2 * t + 1];
+        s->mag = (real)sqrt((double)(I * I + Q * Q));
+        s->theta = (real)atan2((double)Q, (double)I);
+        real hs[MAXH];
+        for (int j = 0; j < H; ++j) { s->hIp[j] = hI[j]; s->hQp[j] = hQ[j]; hs[j] = hI[j] + hQ[j]; }
+        for (int j = 0; j < H; ++j) {
+            real a0 = 0, a1 = 0, a2 = p[L->o_bf + j];
+            for (int i = 0; i < H; ++i) { a0 += p[L->o_wph + j * H + i] * hs[i]; a1 += p[L->o_wah + j * H + i] * hs[i]; a2 += p[L->o_wf + j * H + i] * hs[i]; }
+            s->th[j] = p[L->o_wpt + j] * s->theta + a0;
+            s->ap[j] = p[L->o_wax + j] * s->mag + a1;
+            real at = 0;
+            for (int k = 1; k <= K; ++k) at += (real)fabs((double)(s->ap[j] - (real)k / (real)K)) * p[L->o_cs + k - 1];
+            s->at[j] = at;
+            s->f[j] = sigm(a2);
+        }
+        real vc[MAXH], vs[MAXH];
+        for (int j = 0; j < H; ++j) { vc[j] = s->at[j] * (real)cos((double)s->th[j]); vs[j] = s->at[j] * (real)sin((double)s->th[j]); }
+        for (int j = 0; j < H; ++j) {
+            real c = p[L->o_bcc + j], q = p[L->o_bcs + j];
+            for (int i = 0; i < H; ++i) {
+                c += p[L->o_wcc + j * 2 * H + i] * hI[i] + p[L->o_wcc + j * 2 * H + H + i] * vc[i];
+                q += p[L->o_wcs + j * 2 * H + i] * hQ[i] + p[L->o_wcs + j * 2 * H + H + i] * vs[i];
+            }
+            s->gc[j] = tanhr(c); s->gs[j] = tanhr(q);
+        }
+        real y0 = p[L->o_bo1], y1 = p[L->o_bo2];
+        for (int j = 0; j < H; ++j) {
+            hI[j] = s->f[j] * hI[j] + ((real)1 - s->f[j]) * s->gc[j];
+            hQ[j] = s->f[j] * hQ[j] + ((real)1 - s->f[j]) * s->gs[j];
+            s->hI[j] = hI[j]; s->hQ[j] = hQ[j];
+            y0 += p[L->o_wo1 + j] * hI[j]; y1 += p[L->o_wo2 + j] * hQ[j];
+        }
+        y[2 * t] = y0; y[2 * t + 1] = y1;
+    }
+}
+static void dvr_seq_bwd(const dvr_layout_t* L, const real* p, int T, const real* x, const real* dy, const dvr_step_t* S, real* dp, real* dx) {
+    const int H = L->H, K = L->K;
+    real dhI[MAXH] = {0}, dhQ[MAXH] = {0};
+    for (int t = T - 1; t >= 0; --t) {
+        const dvr_step_t* s = &S[t];
+        const real d0 = dy[2 * t], d1 = dy[2 * t + 1];
+        dp[L->o_bo1] += d0; dp[L->o_bo2] += d1;
+        real dfp[MAXH], dgc[MAXH], dgs[MAXH], nI[MAXH], nQ[MAXH], hs[MAXH], vc[MAXH], vs[MAXH], co[MAXH], si[MAXH];
+        for (int j = 0; j < H; ++j) {
+            dp[L->o_wo1 + j] += d0 * s->hI[j]; dp[L->o_wo2 + j] += d1 * s->hQ[j];
+            const real gI = dhI[j] + d0 * p[L->o_wo1 + j], gQ = dhQ[j] + d1 * p[L->o_wo2 + j];
+            const real df = gI * (s->hIp[j] - s->gc[j]) + gQ * (s->hQp[j] - s->gs[j]);
+            dfp[j] = df * s->f[j] * ((real)1 - s->f[j]);
+            dgc[j] = gI * ((real)1 - s->f[j]) * ((real)1 - s->gc[j] * s->gc[j]);
+            dgs[j] = gQ * ((real)1 - s->f[j]) * ((real)1 - s->gs[j] * s->gs[j]);
+            nI[j] = gI * s->f[j]; nQ[j] = gQ * s->f[j];
+            hs[j] = s->hIp[j] + s->hQp[j];
+            co[j] = (real)cos((double)s->th[j]); si[j] = (real)sin((double)s->th[j]);
+            vc[j] = s->at[j] * co[j]; vs[j] = s->at[j] * si[j];
+            dp[L->o_bf + j] += dfp[j]; dp[L->o_bcc + j] += dgc[j]; dp[L->o_bcs + j] += dgs[j];
+        }
+        real dvc[MAXH] = {0}, dvs[MAXH] = {0};
+        for (int j = 0; j < H; ++j)
+            for (int i = 0; i < H; ++i) {
+                dp[L->o_wcc + j * 2 * H + i] += dgc[j] * s->hIp[i]; dp[L->o_wcc + j * 2 * H + H + i] += dgc[j] * vc[i];
+                dp[L->o_wcs + j * 2 * H + i] += dgs[j] * s->hQp[i]; dp[L->o_wcs + j * 2 * H + H + i] += dgs[j] * vs[i];
+                nI[i] += p[L->o_wcc + j * 2 * H + i] * dgc[j]; dvc[i] += p[L->o_wcc + j * 2 * H + H + i] * dgc[j];
+                nQ[i] += p[L->o_wcs + j * 2 * H + i] * dgs[j]; dvs[i] += p[L->o_wcs + j * 2 * H + H + i] * dgs[j];
+            }
+        real dth[MAXH], dap[MAXH], gth = 0, gmag = 0;
+        for (int j = 0; j < H; ++j) {
+            const real dat = dvc[j] * co[j] + dvs[j] * si[j];
+            dth[j] = s->at[j] * (dvs[j] * co[j] - dvc[j] * si[j]);
+            real slope = 0;
+            for (int k = 1; k <= K; ++k) {
+                const real u = s->ap[j] - (real)k / (real)K;
+                dp[L->o_cs + k - 1] += dat * (real)fabs((double)u);
+                slope += p[L->o_cs + k - 1] * (u > 0 ? (real)1 : (u < 0 ? (real)-1 : (real)0));     /* torch.abs: gradient 0 at 0 */
+            }
+            dap[j] = dat * slope;
+            dp[L->o_wpt + j] += dth[j] * s->theta; dp[L->o_wax + j] += dap[j] * s->mag;
+            gth += p[L->o_wpt + j] * dth[j]; gmag += p[L->o_wax + j] * dap[j];
+        }
+        for (int j = 0; j < H; ++j)
+            for (int i = 0; i < H; ++i) {
+                dp[L->o_wph + j * H + i] += dth[j] * hs[i]; dp[L->o_wah + j * H + i] += dap[j] * hs[i]; dp[L->o_wf + j * H + i] += dfp[j] * hs[i];
+                const real g = p[L->o_wph + j * H + i] * dth[j] + p[L->o_wah + j * H + i] * dap[j] + p[L->o_wf + j * H + i] * dfp[j];
+                nI[i] += g; nQ[i] += g;
+            }
+        for (int j = 0; j < H; ++j) { dhI[j] = nI[j]; dhQ[j] = nQ[j]; }
+        if (dx) {   /* mag = |x|: d/dI = I/mag;  theta = atan2(Q, I): d/dI = -Q/mag^2, d/dQ = I/mag^2 */
+            const real I = x[2 * t], Q = x[2 * t + 1], m2 = s->mag * s->mag;
+            dx[2 * t] = gmag * I / s->mag - gth * Q / m2;
+            dx[2 * t + 1] = gmag * Q / s->mag + gth * I / m2;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Quantisation-aware QGRU: quant/__init__.py:20-37 -> quant_envs.py:138-306 applied to qgru.py  */
 /*   INT_Quantizer (quantizers.py:15-85): s = 2^round(log2|scale|); q(x) = round(clamp(x/s,Qn,Qp))*s */
 /*   (clamp BEFORE round, round half to even), straight-through gradient inside the clamp range.   */
@@ -1395,6 +1518,11 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         real* du = amp + (T + 2 * M - 2); real* damp = du + 2 * (T + M - 1);
         if (dy) gmp_seq_bwd(M, params, T, x, dy, dp, dx, u, amp, du, damp);
         else gmp_seq_fwd(M, params, T, x, y, u, amp);
+    } else if (bb == ODPD_DVRJANET) {
+        dvr_layout_t L; dvr_layout(m, &L);
+        dvr_step_t* S = (dvr_step_t*)scratch;
+        dvr_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
+        if (dy) dvr_seq_bwd(&L, params, T, x, dy, S, dp, dx);
     } else if (bb == ODPD_DELTAJANET) {
         dj_layout_t L; dj_layout(m, &L);
         dj_step_t* S = (dj_step_t*)scratch;
@@ -1419,6 +1547,7 @@ static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
     if (bb == ODPD_TCNN) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_PGJANET) return sizeof(pgj_step_t) * T;
     if (bb == ODPD_GMP) return sizeof(real) * (size_t)(6 * (T + 2 * m->hidden));
+    if (bb == ODPD_DVRJANET) return sizeof(dvr_step_t) * T;
     if (bb == ODPD_DELTAJANET) return sizeof(dj_step_t) * T;
     if (bb == ODPD_NEURALTX) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_RVTDCNN) return T >= 3 ? sizeof(real) * (size_t)(5 * T) : 0;   /* the circular window needs 3 samples */

@@ -22,7 +22,7 @@ SINGLE = [
     ("deltagru_h24_th", "deltagru"), ("tres_h30_th", "deltagru_tcnskip"),
     ("tcnn_c35", "tcnn"), ("pgjanet_h11", "pgjanet"), ("gmp_m11", "gmp"),
     ("rvtdcnn_h25", "rvtdcnn"), ("rvtdcnn_h6", "rvtdcnn"), ("neuraltx_c36", "neuraltx"), ("neuraltx_c12", "neuraltx"),
-    ("deltajanet_h15", "deltajanet"), ("deltajanet_h22", "deltajanet"),
+    ("deltajanet_h15", "deltajanet"), ("deltajanet_h22", "deltajanet"), ("dvrjanet_h12_k3", "dvrjanet"), ("dvrjanet_h8_k4", "dvrjanet"),
 ]
 
 
@@ -39,7 +39,7 @@ def orc64():
 @pytest.mark.parametrize("name,bb", SINGLE)
 def test_forward_loss_grads(orc, orc64, name, bb):
     fx = Fixture(name)
-    m = make_model(bb, fx.meta["hidden"], fx.meta.get("thx", 0), fx.meta.get("thh", 0))
+    m = make_model(bb, fx.meta["hidden"], fx.meta.get("thx", 0), fx.meta.get("thh", 0), bits_w=fx.meta.get("num_dvr_units", 0))
     names = fx.keys("sd")
     p = fx.flat("sd", names)
     assert orc.param_count(m) == p.size == fx.meta["n_param"]
@@ -68,7 +68,7 @@ def test_forward_loss_grads(orc, orc64, name, bb):
 @pytest.mark.parametrize("name,bb", SINGLE)
 def test_three_adamw_steps(orc, name, bb):
     fx = Fixture(name)
-    m = make_model(bb, fx.meta["hidden"], fx.meta.get("thx", 0), fx.meta.get("thh", 0))
+    m = make_model(bb, fx.meta["hidden"], fx.meta.get("thx", 0), fx.meta.get("thh", 0), bits_w=fx.meta.get("num_dvr_units", 0))
     names = fx.keys("sd")
     sizes = fx.sizes(names)
     p = fx.flat("sd", names).copy()

@@ -18,7 +18,7 @@ lib = _lib.load()
 o = Oracle("f32")
 o64 = Oracle("f64")
 LIM = {"gru": 32, "dgru": 32, "qgru": 32, "qgru_amp1": 32, "lstm": 32, "vdlstm": 32, "deltagru": 32, "deltagru_tcnskip": 32, "pgjanet": 16,
-       "tcnn": 40, "gmp": 11, "rvtdcnn": 32, "neuraltx": 40, "deltajanet": 32}
+       "tcnn": 40, "gmp": 11, "rvtdcnn": 32, "neuraltx": 40, "deltajanet": 32, "dvrjanet": 16}
 names = list(LIM)
 rng = np.random.RandomState(7)
 bad, kinks, worst, single = [], [], [0.0, 0.0], 0
@@ -34,23 +34,25 @@ for case in range(n_cases):
     torch.manual_seed(int(rng.randint(1 << 30)))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        dpd, pa = CoreModel(2, dh, 1, dbb), CoreModel(2, ph, 1, pbb)          # delta thresholds 0: no discontinuities in the sweep
+        dpd, pa = CoreModel(2, dh, 1, dbb, num_dvr_units=3), CoreModel(2, ph, 1, pbb, num_dvr_units=3)          # delta thresholds 0: no discontinuities in the sweep
     with torch.no_grad():
         for net_ in (dpd, pa):
             for k, p in net_.named_parameters():
                 if "bias" in k:
                     p.uniform_(-0.2, 0.2)
+                if k == "backbone.cs":           # DVR coefficients: bounded gain (standard-normal ones make the recurrence chaotic)
+                    p.mul_(min(1.0, 1.5 / float(p.abs().sum())))
     net = CascadedModel(dpd_model=dpd, pa_model=pa)
     net.freeze_pa_model()
     net = net.cuda()
     x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
     t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
-    md, mp = make_model(dbb, dh), make_model(pbb, ph)
+    md, mp = make_model(dbb, dh, bits_w=3 * (dbb == "dvrjanet")), make_model(pbb, ph, bits_w=3 * (pbb == "dvrjanet"))
     pd = dpd.backbone.flat_params().detach().cpu().numpy().copy()
     pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
     u, _ = o.forward(md, pd, x)
     # the PA divides by |u| (polar features): skip the rare draws where the random DPD maps a sample next to the origin
-    if "vdlstm" in pbb or pbb in ("dgru", "deltagru", "pgjanet", "tcnn", "qgru_amp1", "rvtdcnn", "neuraltx", "deltajanet"):
+    if "vdlstm" in pbb or pbb in ("dgru", "deltagru", "pgjanet", "tcnn", "qgru_amp1", "rvtdcnn", "neuraltx", "deltajanet", "dvrjanet"):
         if np.sqrt((u ** 2).sum(-1)).min() < 1e-3:
             continue
     y, _ = o.forward(mp, pp, u)

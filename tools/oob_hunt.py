@@ -46,7 +46,7 @@ def at_start(t):
 
 
 for it in range(cases):
-    H = 11 if bb == "gmp" else int(rng.randint(1, (17 if bb == "pgjanet" else 41 if bb in ("tcnn", "neuraltx") else 33)))
+    H = 11 if bb == "gmp" else int(rng.randint(1, (17 if bb in ("pgjanet", "dvrjanet") else 41 if bb in ("tcnn", "neuraltx") else 33)))
     force = bool(rng.randint(2))
     lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
     B = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
@@ -59,7 +59,7 @@ for it in range(cases):
     torch.manual_seed(it)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        net = CoreModel(2, H, 1, bb, **({"thx": 0.01, "thh": 0.02} if "delta" in bb else {})).cuda()
+        net = CoreModel(2, H, 1, bb, num_dvr_units=1 + it % 8, **({"thx": 0.01, "thh": 0.02} if "delta" in bb else {})).cuda()
     x0 = (torch.rand(B, T, 2) - 0.5) * 1.6
     x0 = x0 + 0.05 * torch.sign(x0)
     dy = at_end(torch.randn(B, T, 2))
@@ -69,7 +69,7 @@ for it in range(cases):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         casc = CascadedModel(dpd_model=CoreModel(2, int(rng.randint(2, 25)), 1, dpd_bb, **(kw if "delta" in dpd_bb else {})),
-                             pa_model=CoreModel(2, H, 1, bb, **(kw if "delta" in bb else {})))
+                             pa_model=CoreModel(2, H, 1, bb, num_dvr_units=1 + it % 8, **(kw if "delta" in bb else {})))
     casc.freeze_pa_model()
     casc = casc.cuda()
     opt, copt = FusedAdamW(net, lr=1e-3), FusedAdamW(casc, lr=1e-3)

@@ -20,7 +20,7 @@ o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
          "tcnn": list(range(1, 40, 3)) + [64], "gmp": [11] * 16, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
-         "neuraltx": list(range(1, 40, 3)) + [64]}
+         "neuraltx": list(range(1, 40, 3)) + [64], "dvrjanet": range(1, 17)}
 rng = np.random.RandomState(1)
 bad = []
 for bb, sizes in SIZES.items():
@@ -35,19 +35,22 @@ for bb, sizes in SIZES.items():
                     T = max(3, 5000 // B)
                 kind = str(rng.choice(["l2", "l1"]))
                 kw = dict(thx=float(rng.choice([0.0, 0.01])), thh=float(rng.choice([0.0, 0.03]))) if "delta" in bb else {}
+                K = int(rng.randint(1, 9)) if bb == "dvrjanet" else 0
                 torch.manual_seed(int(rng.randint(1 << 30)))
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    net = CoreModel(2, H, 1, bb, **kw).cuda()
+                    net = CoreModel(2, H, 1, bb, num_dvr_units=K or None, **kw).cuda()
                 with torch.no_grad():
                     for k, p in net.named_parameters():
                         if "bias" in k:
                             p.uniform_(-0.3, 0.3)
+                        if k == "backbone.cs":                   # DVR coefficients: bounded gain (standard-normal ones make the recurrence chaotic)
+                            p.mul_(min(1.0, 1.5 / float(p.abs().sum())))
                 amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
                 x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
                 tgt = (0.7 * x + 0.1 * rng.randn(B, T, 2)).astype(np.float32)
                 p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()]).astype(np.float32)
-                m = make_model(bb, H, kw.get("thx", 0), kw.get("thh", 0))
+                m = make_model(bb, H, kw.get("thx", 0), kw.get("thh", 0), bits_w=K)
                 ea, es = np.zeros_like(p), np.zeros_like(p)
                 opt = FusedAdamW(net, lr=1e-3)
                 xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
