@@ -405,9 +405,13 @@ __device__ __forceinline__ void s16n_write_row(float* prow, const GruLayout& L, 
 
 // MODE 0: fused train (x, target -> partials; checkpoints in `ckpt` workspace)   1: forward (y, optional ckpt)
 // MODE 2: backward from dy (partials if NW, dx if DX)
-// the frozen-model variants (no weight gradients: fewer accumulators) run two waves per SIMD like the forward kernel
+// the backward of a frozen model (dL/dx only: no weight-gradient accumulators) runs two waves per SIMD like the forward kernel.
+// The fused frozen-PA step (MODE 0 without NW) does NOT: under the 256-register cap of an eight-wave workgroup it spills (up to
+// 220 B per lane) and its DGRU instantiation with four K-chunks in the last unit tile (hidden 29..32) then computes wrong losses /
+// gradients (1e-2 relative; the same source at one wave per SIMD is exact — tests/test_cascade_gpu.py pins it)
+constexpr bool s16n_two_waves_per_simd(int mode, bool nw) { return mode == 1 || (mode == 2 && !nw); }
 template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
-__global__ __launch_bounds__((MODE == 1 || !NW) ? 512 : 256, (MODE != 1 && !NW) ? 2 : 1) void gru16n_kernel(SeqArgs a) {
+__global__ __launch_bounds__(s16n_two_waves_per_simd(MODE, NW) ? 512 : 256, 1) void gru16n_kernel(SeqArgs a) {
     using T = S16N<NT>;
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
     constexpr int kGroups = (MODE != 1 && DX) ? T::NG_DX : T::NG;
@@ -589,7 +593,7 @@ template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
 static int launch_s16n(hipStream_t st, const SeqArgs& a, int P) {
     using T = S16N<NT>;
     LaunchShape ls = s16n_shape(a.ngroups);     // the grid (= rows of partials) never depends on the backward's flavour
-    if (MODE == 1 || !NW) {                     // forward / frozen model: two waves per SIMD
+    if (s16n_two_waves_per_simd(MODE, NW)) {      // forward / backward of a frozen model
         ls.waves = 8;
         const int need = (a.ngroups + 7) / 8, cap = device_cus();
         ls.grid = need < cap ? need : cap;

@@ -75,6 +75,9 @@ int64_t oracle_param_count(const odpd_model_t* m) {
         return H * (1 + (GMP_DEGREE - 1) * H);
     case ODPD_DVRJANET: /* dvrjanet.py:13-30: cs (K = bits_w), seven HxH blocks, two H input columns, three H biases, two heads */
         return (m->bits_w > 0 && m->bits_w <= DVR_MAXK) ? m->bits_w + 7 * H * H + 7 * H + 2 : -1;
+    case ODPD_BOJANET:  /* bojanet.py:15-26: two (6,16) FIR banks, two gates on the 12 envelopes (+bias) and the state, two heads; the phase
+                           re-rotation (:41-53) cannot be built beyond hidden 18 */
+        return H <= 18 ? 2 * H * H + 28 * H + 194 : -1;
     case ODPD_DELTAJANET: /* deltajanet.py:96-111: two gates */
         return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2;
     case ODPD_NEURALTX: /* neuraltx.py:18-38: two 5-tap FIRs, 4 -> C (bias), 4 depthwise k5, C -> 2, IQ_match (2,2); hidden = channels */
@@ -1126,6 +1129,113 @@ static void dvr_seq_bwd(const dvr_layout_t* L, const real* p, int T, const real*
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* BOJANET: bojanet.py:5-138.  M = 16-tap complex FIR bank of P = 6 filters over the zero-left-padded frame (:72-84):
+ *   fi[p] = sum_m bI[p][m] I[t-15+m] - bQ[p][m] Q[t-15+m],  fq[p] = sum_m bQ[p][m] I[t-15+m] + bI[p][m] Q[t-15+m];
+ * vector demodulator (:30-39): mag = sqrt(fi^2 + fq^2) + 1e-8, mag2 = mag^2, sin = fq / mag, cos = fi / mag;
+ * envelope e = [mag(6), mag2(6)] (:86-87);  JANET cell (:91-94): f = s(W_fi e + b + W_fh h), g = tanh(W_gi e + b + W_gh h),
+ * h = f h + (1 - f) g;  phase re-rotation (:41-53): unit j takes the phase of filter j mod 6 (hidden <= 18: the reference's
+ * concatenation cannot build more);  read-outs (:103-104): A = w_I . (h cos) + b_I, Bq = w_Q . (h sin) + b_Q, y = (A - Bq, Bq + A).
+ * Parameter order (named_parameters): fir_I (6,16), fir_Q (6,16), W_fi (H,12)+b, W_fh (H,H), W_gi (H,12)+b, W_gh (H,H),
+ * W_out_I (1,H)+b, W_out_Q (1,H)+b. */
+#define BOJ_P 6
+#define BOJ_M 16
+typedef struct { int H; int64_t o_bi, o_bq, o_wfi, o_bfi, o_wfh, o_wgi, o_bgi, o_wgh, o_woi, o_boi, o_woq, o_boq, P; } boj_layout_t;
+static void boj_layout(const odpd_model_t* m, boj_layout_t* g) {
+    int64_t H = m->hidden, o = 0;
+    g->H = (int)H;
+    g->o_bi = o; o += BOJ_P * BOJ_M; g->o_bq = o; o += BOJ_P * BOJ_M;
+    g->o_wfi = o; o += H * 2 * BOJ_P; g->o_bfi = o; o += H; g->o_wfh = o; o += H * H;
+    g->o_wgi = o; o += H * 2 * BOJ_P; g->o_bgi = o; o += H; g->o_wgh = o; o += H * H;
+    g->o_woi = o; o += H; g->o_boi = o; o += 1; g->o_woq = o; o += H; g->o_boq = o; o += 1;
+    g->P = o;
+}
+typedef struct { real fi[BOJ_P], fq[BOJ_P], m0[BOJ_P], mag[BOJ_P], hp[MAXH], f[MAXH], g[MAXH], h[MAXH]; } boj_step_t;
+static void boj_seq_fwd(const boj_layout_t* L, const real* p, int T, const real* x, real* y, boj_step_t* S) {
+    const int H = L->H;
+    real h[MAXH] = {0};
+    boj_step_t tmp;
+    for (int t = 0; t < T; ++t) {
+        boj_step_t* s = S ? &S[t] : &tmp;
+        real e[2 * BOJ_P], co[BOJ_P], si[BOJ_P];
+        for (int q = 0; q < BOJ_P; ++q) {
+            real fi = 0, fq = 0;
+            for (int m = 0; m < BOJ_M; ++m) {
+                const int tt = t - (BOJ_M - 1) + m;
+                if (tt < 0) continue;
+                const real I = x[2 * tt], Q = x[2 * tt + 1], bi = p[L->o_bi + q * BOJ_M + m], bq = p[L->o_bq + q * BOJ_M + m];
+                fi += bi * I - bq * Q; fq += bq * I + bi * Q;
+            }
+            s->fi[q] = fi; s->fq[q] = fq;
+            s->m0[q] = (real)sqrt((double)(fi * fi + fq * fq));
+            s->mag[q] = s->m0[q] + (real)1e-8;
+            e[q] = s->mag[q]; e[BOJ_P + q] = s->mag[q] * s->mag[q];
+            si[q] = fq / s->mag[q]; co[q] = fi / s->mag[q];
+        }
+        real y0 = p[L->o_boi], y1 = p[L->o_boq];
+        for (int j = 0; j < H; ++j) {
+            real pf = p[L->o_bfi + j], pg = p[L->o_bgi + j];
+            for (int k = 0; k < 2 * BOJ_P; ++k) { pf += p[L->o_wfi + j * 2 * BOJ_P + k] * e[k]; pg += p[L->o_wgi + j * 2 * BOJ_P + k] * e[k]; }
+            for (int k = 0; k < H; ++k) { pf += p[L->o_wfh + j * H + k] * h[k]; pg += p[L->o_wgh + j * H + k] * h[k]; }
+            s->f[j] = sigm(pf); s->g[j] = tanhr(pg);
+        }
+        for (int j = 0; j < H; ++j) {
+            s->hp[j] = h[j];
+            h[j] = s->f[j] * h[j] + ((real)1 - s->f[j]) * s->g[j];
+            s->h[j] = h[j];
+            y0 += p[L->o_woi + j] * (h[j] * co[j % BOJ_P]); y1 += p[L->o_woq + j] * (h[j] * si[j % BOJ_P]);
+        }
+        y[2 * t] = y0 - y1; y[2 * t + 1] = y1 + y0;
+    }
+}
+static void boj_seq_bwd(const boj_layout_t* L, const real* p, int T, const real* x, const real* dy, const boj_step_t* S, real* dp, real* dx) {
+    const int H = L->H;
+    real dh[MAXH] = {0};
+    if (dx) for (int t = 0; t < 2 * T; ++t) dx[t] = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const boj_step_t* s = &S[t];
+        const real dA = dy[2 * t] + dy[2 * t + 1], dB = dy[2 * t + 1] - dy[2 * t];
+        dp[L->o_boi] += dA; dp[L->o_boq] += dB;
+        real dco[BOJ_P] = {0}, dsi[BOJ_P] = {0}, de[2 * BOJ_P] = {0}, dfp[MAXH], dgp[MAXH], nh[MAXH];
+        for (int j = 0; j < H; ++j) {
+            const int q = j % BOJ_P;
+            const real co = s->fi[q] / s->mag[q], si = s->fq[q] / s->mag[q];
+            dp[L->o_woi + j] += dA * (s->h[j] * co); dp[L->o_woq + j] += dB * (s->h[j] * si);
+            const real gh = dh[j] + dA * p[L->o_woi + j] * co + dB * p[L->o_woq + j] * si;
+            dco[q] += dA * p[L->o_woi + j] * s->h[j]; dsi[q] += dB * p[L->o_woq + j] * s->h[j];
+            dfp[j] = gh * (s->hp[j] - s->g[j]) * s->f[j] * ((real)1 - s->f[j]);
+            dgp[j] = gh * ((real)1 - s->f[j]) * ((real)1 - s->g[j] * s->g[j]);
+            nh[j] = gh * s->f[j];
+            dp[L->o_bfi + j] += dfp[j]; dp[L->o_bgi + j] += dgp[j];
+        }
+        real e[2 * BOJ_P];
+        for (int q = 0; q < BOJ_P; ++q) { e[q] = s->mag[q]; e[BOJ_P + q] = s->mag[q] * s->mag[q]; }
+        for (int j = 0; j < H; ++j) {
+            for (int k = 0; k < 2 * BOJ_P; ++k) {
+                dp[L->o_wfi + j * 2 * BOJ_P + k] += dfp[j] * e[k]; dp[L->o_wgi + j * 2 * BOJ_P + k] += dgp[j] * e[k];
+                de[k] += p[L->o_wfi + j * 2 * BOJ_P + k] * dfp[j] + p[L->o_wgi + j * 2 * BOJ_P + k] * dgp[j];
+            }
+            for (int k = 0; k < H; ++k) {
+                dp[L->o_wfh + j * H + k] += dfp[j] * s->hp[k]; dp[L->o_wgh + j * H + k] += dgp[j] * s->hp[k];
+                nh[k] += p[L->o_wfh + j * H + k] * dfp[j] + p[L->o_wgh + j * H + k] * dgp[j];
+            }
+        }
+        for (int j = 0; j < H; ++j) dh[j] = nh[j];
+        for (int q = 0; q < BOJ_P; ++q) {
+            const real mag = s->mag[q];
+            const real dmag = de[q] + (real)2 * mag * de[BOJ_P + q] - (dsi[q] * s->fq[q] + dco[q] * s->fi[q]) / (mag * mag);
+            const real dfi = dco[q] / mag + dmag * s->fi[q] / s->m0[q], dfq = dsi[q] / mag + dmag * s->fq[q] / s->m0[q];
+            for (int m = 0; m < BOJ_M; ++m) {
+                const int tt = t - (BOJ_M - 1) + m;
+                if (tt < 0) continue;
+                const real I = x[2 * tt], Q = x[2 * tt + 1], bi = p[L->o_bi + q * BOJ_M + m], bq = p[L->o_bq + q * BOJ_M + m];
+                dp[L->o_bi + q * BOJ_M + m] += dfi * I + dfq * Q; dp[L->o_bq + q * BOJ_M + m] += dfq * I - dfi * Q;
+                if (dx) { dx[2 * tt] += dfi * bi + dfq * bq; dx[2 * tt + 1] += dfq * bi - dfi * bq; }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Quantisation-aware QGRU: quant/__init__.py:20-37 -> quant_envs.py:138-306 applied to qgru.py  */
 /*   INT_Quantizer (quantizers.py:15-85): s = 2^round(log2|scale|); q(x) = round(clamp(x/s,Qn,Qp))*s */
 /*   (clamp BEFORE round, round half to even), straight-through gradient inside the clamp range.   */
@@ -1523,6 +1633,11 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         dvr_step_t* S = (dvr_step_t*)scratch;
         dvr_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
         if (dy) dvr_seq_bwd(&L, params, T, x, dy, S, dp, dx);
+    } else if (bb == ODPD_BOJANET) {
+        boj_layout_t L; boj_layout(m, &L);
+        boj_step_t* S = (boj_step_t*)scratch;
+        boj_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
+        if (dy) boj_seq_bwd(&L, params, T, x, dy, S, dp, dx);
     } else if (bb == ODPD_DELTAJANET) {
         dj_layout_t L; dj_layout(m, &L);
         dj_step_t* S = (dj_step_t*)scratch;
@@ -1548,6 +1663,7 @@ static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
     if (bb == ODPD_PGJANET) return sizeof(pgj_step_t) * T;
     if (bb == ODPD_GMP) return sizeof(real) * (size_t)(6 * (T + 2 * m->hidden));
     if (bb == ODPD_DVRJANET) return sizeof(dvr_step_t) * T;
+    if (bb == ODPD_BOJANET) return T >= BOJ_M - 1 ? sizeof(boj_step_t) * T : 0;   /* bojanet.py:72-77 cannot frame fewer than 15 samples */
     if (bb == ODPD_DELTAJANET) return sizeof(dj_step_t) * T;
     if (bb == ODPD_NEURALTX) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_RVTDCNN) return T >= 3 ? sizeof(real) * (size_t)(5 * T) : 0;   /* the circular window needs 3 samples */

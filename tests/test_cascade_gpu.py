@@ -114,13 +114,14 @@ def force_s16():
 
 
 @pytest.mark.parametrize("pa_bb,pa_h", [("gru", 11), ("dgru", 13), ("dgru", 9), ("qgru", 10), ("qgru_amp1", 16), ("dgru", 23), ("gru", 30),
-                                         ("qgru", 20), ("dgru", 28)])
+                                         ("qgru", 20), ("dgru", 28), ("dgru", 29), ("dgru", 31), ("dgru", 32), ("gru", 32), ("qgru_amp1", 29)])
 @pytest.mark.parametrize("dpd_bb,dpd_h", [("dgru", 9), ("deltagru_tcnskip", 15)])
 @pytest.mark.parametrize("loss", ["l2", "l1"])
 def test_frozen_pa_single_launch_step_against_oracle(force_s16, pa_bb, pa_h, dpd_bb, dpd_h, loss):
     """GRU-family PA on the 16-sequences-per-wave kernels: forward + loss + dL/du of the frozen PA run as ONE launch
-    (odpd_frozen_loss_dx: hidden <= 16 incl. the K-packed variant, hidden 17..32 with 2- and 4-chunk last tiles); DPD gradient
-    and loss of the cascade step == oracle composition."""
+    (odpd_frozen_loss_dx: hidden <= 16 incl. the K-packed variant, hidden 17..32 with 2- and 4-chunk last tiles — hidden 29..32 are the
+    sizes whose fourth K-chunk holds real units: an eight-wave build of that instantiation spilled and computed 1e-2-wrong results in
+    r02, caught by tools/cascade_sweep.py); DPD gradient and loss of the cascade step == oracle composition."""
     from opendpd_amd import CascadedModel, CoreModel, _lib
     from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
     from oracle.oracle import Oracle, make_model

@@ -408,7 +408,7 @@ def test_quantised_flow_with_pretrained_float_checkpoint_matches_reference(workd
     assert np.abs(sd[w].numpy() - ref_sd[w]).max() < 0.05          # and the two runs stay next to each other
 
 
-@pytest.mark.parametrize("bb,H", [("mcldnn", 8), ("bojanet", 8)])
+@pytest.mark.parametrize("bb,H", [("mcldnn", 8), ("apnrru", 8)])
 def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H):
     """SURVEY §8 f4 names (backbones/extras.py) go through the same Project flow on the GPU: ATen forward/backward,
     torch.optim.AdamW, device-resident frame loader, eval + metrics + checkpoint/log layout."""

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Every launch flavour of the hidden-17..32 GRU-family kernels (csrc/gru_s16n.hip) against the C oracle, forced onto the S16 mapping
+at small batches: the frozen-PA single-launch step of a cascade (forward + loss + dL/dx), the frozen backward (dL/dx only), the
+weight-gradient backward, both together, and the fused train step — all four feature sets, hidden 17..32, ragged shapes.
+usage (GPU box): PYTHONPATH=. python tools/s16n_crosscheck.py"""
+import warnings
+
+import numpy as np
+import torch
+
+from opendpd_amd import CascadedModel, CoreModel, _lib
+from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+from oracle.oracle import Oracle, make_model
+
+lib = _lib.load()
+o = Oracle("f32")
+rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+rng = np.random.RandomState(3)
+lib.odpd_set_tuning(b"s16_min_batch", 0)
+bad, n = [], 0
+for pbb in ("dgru", "gru", "qgru", "qgru_amp1"):
+    worst = [0.0] * 5
+    for ph in range(17, 33):
+        for B, T in ((1, 5), (3, 32), (16, 33), (33, 65), (70, 9)):
+            torch.manual_seed(B * 100 + T + ph)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                dpd, pa = CoreModel(2, 6, 1, "gru"), CoreModel(2, ph, 1, pbb)
+            with torch.no_grad():
+                for k, p in pa.named_parameters():
+                    if "bias" in k:
+                        p.uniform_(-0.2, 0.2)
+            net = CascadedModel(dpd_model=dpd, pa_model=pa)
+            net.freeze_pa_model()
+            net = net.cuda()
+            md, mp = make_model("gru", 6), make_model(pbb, ph)
+            pd = dpd.backbone.flat_params().detach().cpu().numpy().copy()
+            pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
+            x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+            t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+            u, _ = o.forward(md, pd, x)
+            y, _ = o.forward(mp, pp, u)
+            lo, dy = o.loss("l2", y, t)
+            gp, du = o.backward(mp, pp, u, dy)
+            gd, _ = o.backward(md, pd, x, du, need_dx=False)
+            e = [0.0] * 5
+            # 1. cascade step (frozen PA: forward + loss + dL/dx in one launch)
+            opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+            lg = float(fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), "l2", 0.0))
+            e[0] = max(abs(lg - lo) / abs(lo) * 10, rel(opt.grad[:-4].cpu().numpy(), gd))
+            # 2. frozen backward through autograd (dL/dx only)
+            ut = torch.from_numpy(u).cuda().requires_grad_(True)
+            yg = pa(ut)
+            yg.backward(torch.from_numpy(dy).cuda())
+            e[1] = max(rel(ut.grad.cpu().numpy(), du), 10 * rel(yg.detach().cpu().numpy(), y))
+            # 3. / 4. weight gradients alone, and with dL/dx
+            for q in pa.parameters():
+                q.requires_grad_(True)
+            pa(torch.from_numpy(u).cuda()).backward(torch.from_numpy(dy).cuda())
+            e[2] = rel(np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in pa.parameters()]), gp)
+            for q in pa.parameters():
+                q.grad = None
+            ut = torch.from_numpy(u).cuda().requires_grad_(True)
+            pa(ut).backward(torch.from_numpy(dy).cuda())
+            e[3] = max(rel(np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in pa.parameters()]), gp), rel(ut.grad.cpu().numpy(), du))
+            # 5. fused train step of the model on its own
+            opt2 = FusedAdamW(pa, lr=0.0, weight_decay=0.0)
+            l2 = float(fused_train_step(opt2, torch.from_numpy(u).cuda(), torch.from_numpy(t).cuda(), "l2", 0.0))
+            e[4] = max(abs(l2 - lo) / abs(lo) * 10, rel(opt2.grad[:-4].cpu().numpy(), gp))
+            n += 1
+            worst = [max(a, b) for a, b in zip(worst, e)]
+            if max(e) > 3e-4 or not np.isfinite(e).all():
+                bad.append((pbb, ph, B, T, ["%.1e" % v for v in e]))
+    print(f"{pbb:10s} worst  cascade step {worst[0]:.2e}  frozen bwd {worst[1]:.2e}  wgrad {worst[2]:.2e}  wgrad+dx {worst[3]:.2e}  fused train {worst[4]:.2e}", flush=True)
+lib.odpd_set_tuning(b"s16_min_batch", -1)
+print(f"{n} cases, {len(bad)} beyond 3e-4")
+for b in bad[:40]:
+    print("  ", b)
