@@ -405,13 +405,14 @@ __device__ __forceinline__ void s16n_write_row(float* prow, const GruLayout& L, 
 
 // MODE 0: fused train (x, target -> partials; checkpoints in `ckpt` workspace)   1: forward (y, optional ckpt)
 // MODE 2: backward from dy (partials if NW, dx if DX)
-// the backward of a frozen model (dL/dx only: no weight-gradient accumulators) runs two waves per SIMD like the forward kernel.
-// The fused frozen-PA step (MODE 0 without NW) does NOT: under the 256-register cap of an eight-wave workgroup it spills (up to
-// 220 B per lane) and its DGRU instantiation with four K-chunks in the last unit tile (hidden 29..32) then computes wrong losses /
-// gradients (1e-2 relative; the same source at one wave per SIMD is exact — tests/test_cascade_gpu.py pins it)
-constexpr bool s16n_two_waves_per_simd(int mode, bool nw) { return mode == 1 || (mode == 2 && !nw); }
+// the frozen-model variants (no weight-gradient accumulators) run two waves per SIMD like the forward kernel — except the fused
+// frozen-PA step (MODE 0 without NW) with four K-chunks in the last unit tile (hidden 25..32): under the 256-register cap of an
+// eight-wave workgroup it spills 160..220 B per lane and its DGRU instantiation then computes wrong losses / gradients for hidden
+// 29..32 (1e-2 relative; the same source at one wave per SIMD is exact, as are the two-chunk builds at two).  tools/s16n_crosscheck.py
+// runs every flavour x feature set x hidden 17..32 against the oracle; tests/test_cascade_gpu.py pins hidden 29, 31, 32.
+constexpr bool s16n_two_waves_per_simd(int mode, bool nw, int nck) { return mode == 1 || (mode == 2 && !nw) || (mode == 0 && !nw && nck <= 2); }
 template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
-__global__ __launch_bounds__(s16n_two_waves_per_simd(MODE, NW) ? 512 : 256, 1) void gru16n_kernel(SeqArgs a) {
+__global__ __launch_bounds__(s16n_two_waves_per_simd(MODE, NW, NCK) ? 512 : 256, 1) void gru16n_kernel(SeqArgs a) {
     using T = S16N<NT>;
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
     constexpr int kGroups = (MODE != 1 && DX) ? T::NG_DX : T::NG;
@@ -593,10 +594,12 @@ template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
 static int launch_s16n(hipStream_t st, const SeqArgs& a, int P) {
     using T = S16N<NT>;
     LaunchShape ls = s16n_shape(a.ngroups);     // the grid (= rows of partials) never depends on the backward's flavour
-    if (s16n_two_waves_per_simd(MODE, NW)) {      // forward / backward of a frozen model
+    if (s16n_two_waves_per_simd(MODE, NW, NCK)) {      // forward / backward of a frozen model
         ls.waves = 8;
-        const int need = (a.ngroups + 7) / 8, cap = device_cus();
-        ls.grid = need < cap ? need : cap;
+        if (MODE != 0) {                        // the fused frozen-PA step writes one loss row per workgroup: its grid is the host's row count
+            const int need = (a.ngroups + 7) / 8, cap = device_cus();
+            ls.grid = need < cap ? need : cap;
+        }
     }
     const int groups = (MODE != 1 && DX) ? T::NG_DX : T::NG;
     const int wave_floats = (MODE != 1 && DX ? 3 : 2) * 2 * 16 * kChunkPad + ((MODE != 1 && NW) ? T::kTiles * kTileFloats : 0);
