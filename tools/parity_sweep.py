@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of every HIP backbone against the C oracle (GPU box): all hidden sizes of the kernels' envelope,
 random batch / frame length, both kernel mappings (row-rotated and S16 forced).  Prints the worst relative errors per backbone
-and every case beyond tolerance.  usage: PYTHONPATH=. python tools/parity_sweep.py [cases-per-size]"""
+and every case beyond tolerance.  usage: PYTHONPATH=. python tools/parity_sweep.py [cases-per-size] [mid]
+`mid`: batches of 300 / 1000 / 4803 sequences x 3..19 steps instead — tens to hundreds of 16-sequence groups, i.e. several workgroups
+and partial rows per launch, the range between the ragged small shapes and the full-size runs of tests/test_fullsize_gpu.py"""
 import sys
 import warnings
 
@@ -12,6 +14,7 @@ from opendpd_amd import CoreModel, _lib
 from oracle.oracle import Oracle, make_model
 
 n_per = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+MID = len(sys.argv) > 2 and sys.argv[2] == "mid"
 lib = _lib.load()
 o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
@@ -19,7 +22,7 @@ SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_
          "tcnn": list(range(1, 40)) + [48, 63, 64], "gmp": [11] * 12, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
          "neuraltx": list(range(1, 40)) + [48, 63, 64], "dvrjanet": range(1, 17), "bojanet": range(1, 17)}
 rng = np.random.RandomState(0)
-bad, worst = [], {}
+bad, kinks, illcond, worst = [], [], [], {}
 for bb, sizes in SIZES.items():
     for H in sizes:
         for case in range(n_per):
@@ -27,7 +30,9 @@ for bb, sizes in SIZES.items():
                 lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
                 B = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
                 T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 257, 300]))
-                if B * T > 6000:
+                if MID:
+                    B, T = int(rng.choice([300, 1000, 4803])), int(rng.choice([3, 4, 5, 8, 16, 19]))
+                elif B * T > 6000:
                     T = max(1, 6000 // B)
                 if bb in ("vdlstm", "rvtdcnn") and T < 3:
                     T = 3       # the 3-sample circular pad needs T >= 3 (vdlstm.py:66-74); shorter frames are refused (EINVAL)
@@ -88,9 +93,33 @@ for bb, sizes in SIZES.items():
                     nbad = int((per_seq > tol_y).sum())
                     if "delta" in bb and nbad <= 2 and ey < 5e-2 and eg < 5e-2:
                         continue
+                    # an activation kink (relu of the DGRU head, hardswish, |.| of the DVR, a demodulator output next to 0) within rounding
+                    # of its corner makes the GRADIENT of one sequence discontinuous while the outputs agree: the oracle's own fp64
+                    # gradient then moves by as much under a 2e-6 relative change of the input
+                    if need_dx and ey < tol_y:
+                        per_dx = np.abs(xt.grad.cpu().numpy() - dxo).reshape(B, -1).max(1) / max(np.abs(dxo).max(), 1e-30)
+                        if int((per_dx > tol_g).sum()) <= 2:
+                            o64 = Oracle("f64")
+                            f8 = lambda v: np.asarray(v, dtype=np.float64)
+                            g8 = [o64.backward(m, f8(p), f8(x) * sc, f8(dy))[1] for sc in (1.0, 1 + 2e-6, 1 - 2e-6)]
+                            jump = max(float(np.abs(v - g8[0]).max() / max(np.abs(g8[0]).max(), 1e-30)) for v in g8[1:])
+                            if jump > 0.3 * max(ex, eg):
+                                kinks.append((bb, H, B, T, force, f"g {eg:.2e} dx {ex:.2e} in {int((per_dx > tol_g).sum())} sequence(s); fp64 oracle jumps {jump:.2e}"))
+                                continue
+                    # a demodulator output / amplitude next to 0 somewhere in the batch: the fp32 oracle itself is then that far from fp64
+                    o64 = Oracle("f64")
+                    f8 = lambda v: np.asarray(v, dtype=np.float64)
+                    y8, _ = o64.forward(m, f8(p), f8(x))
+                    g8, dx8 = o64.backward(m, f8(p), f8(x), f8(dy), need_dx=need_dx)
+                    cy, cg, cx = rel(yo, y8), rel(go, g8), (rel(dxo, dx8) if need_dx else 0.0)
+                    if flips == 0 and ey < tol_y + 20 * cy and eg < tol_g + 20 * cg and ex < tol_g + 20 * cx:
+                        illcond.append((bb, H, B, T, force, f"y {ey:.2e} g {eg:.2e} dx {ex:.2e}; fp32 oracle vs fp64: y {cy:.2e} g {cg:.2e} dx {cx:.2e}"))
+                        continue
                     bad.append((bb, H, B, T, force, kw, f"y {ey:.2e} g {eg:.2e} dx {ex:.2e} flips {flips} sequences off {nbad}/{B}"))
     print(f"{bb:18s} worst rel err  y {worst[bb][0]:.2e}  grad {worst[bb][1]:.2e}  dx {worst[bb][2]:.2e}", flush=True)
 lib.odpd_set_tuning(b"s16_min_batch", -1)
+print(f"{len(kinks)} case(s) on an activation kink (the oracle's own gradient is discontinuous there): {kinks}")
+print(f"{len(illcond)} ill-conditioned case(s) (the fp32 oracle itself is that far from the fp64 one): {illcond}")
 print(f"{len(bad)} case(s) beyond tolerance")
 for b in bad[:60]:
     print("  ", b)
