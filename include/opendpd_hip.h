@@ -44,7 +44,8 @@ enum odpd_backbone {
     ODPD_DELTAJANET = 13, /* backbones/deltajanet.py:11-274 (two-gate delta cell; the wrapper fixes both thresholds at 0) */
     ODPD_DVRJANET = 14,  /* backbones/dvrjanet.py:5-112 (num_dvr_units rides in odpd_model_t::bits_w) */
     ODPD_BOJANET = 15,   /* backbones/bojanet.py:5-138 (16-tap complex FIR bank, vector demodulator, JANET cell, phase re-rotation; hidden <= 18) */
-    ODPD_BACKBONE_COUNT = 16
+    ODPD_APNRRU = 16,    /* backbones/apnrru.py:5-152 (3-filter FIR bank + raw sample, phase-normalised RRU cell on a complex state; hidden <= 14) */
+    ODPD_BACKBONE_COUNT = 17
 };
 
 enum odpd_error {

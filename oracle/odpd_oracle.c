@@ -78,6 +78,8 @@ int64_t oracle_param_count(const odpd_model_t* m) {
     case ODPD_BOJANET:  /* bojanet.py:15-26: two (6,16) FIR banks, two gates on the 12 envelopes (+bias) and the state, two heads; the phase
                            re-rotation (:41-53) cannot be built beyond hidden 18 */
         return H <= 18 ? 2 * H * H + 28 * H + 194 : -1;
+    case ODPD_APNRRU:   /* apnrru.py:13-19, 45-53: two (3,16) FIR banks, C, Z (n), W_u (16, 8+n)+b, W_h (n,16)+b, two bias-free heads; n = 2H+3 */
+        return 343 + 70 * H;
     case ODPD_DELTAJANET: /* deltajanet.py:96-111: two gates */
         return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2;
     case ODPD_NEURALTX: /* neuraltx.py:18-38: two 5-tap FIRs, 4 -> C (bias), 4 depthwise k5, C -> 2, IQ_match (2,2); hidden = channels */
@@ -1236,6 +1238,141 @@ static void boj_seq_bwd(const boj_layout_t* L, const real* p, int T, const real*
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* APNRRU: apnrru.py:5-152.  16-tap complex FIR bank of 3 filters over the zero-left-padded frame (:66-90) plus the raw sample as a
+ * fourth complex value; all four are rotated by r = conj(x_t) / |x_t| (:77-99) -> 8 features [re, im] x 4.  Complex state h (H) and
+ * envelope state h_A (3), all 0 at the start.  Per step (:101-128): h <- h r (into the normalised frame); s = [h_I, h_Q, h_A] (n = 2H+3);
+ * v = tanh(W_h tanh(W_u [feat, s] + b_u) + b_h);  s' = sigmoid(C s) + Z v  (RRU, :23-33; C scalar, Z (1,n));  h <- conj(r) s'_h (back);
+ * y = (A - Bq, Bq + A) with A = w_I . h_I, Bq = w_Q . h_Q (no biases, :124-125).
+ * Parameter order (named_parameters): fir_I (3,16), fir_Q (3,16), rru.C (1), rru.Z (1,n), rru.W_u (16, 8+n) + b (16),
+ * rru.W_h (n,16) + b (n), output_layer_I (1,H), output_layer_Q (1,H). */
+#define APN_F 3
+#define APN_M 16
+#define APN_NODE 16
+#define APN_MAXN (2 * MAXH + 3)
+typedef struct { int H, n; int64_t o_bi, o_bq, o_c, o_z, o_wu, o_bu, o_wh, o_bh, o_woi, o_woq, P; } apn_layout_t;
+static void apn_layout(const odpd_model_t* m, apn_layout_t* g) {
+    int64_t H = m->hidden, n = 2 * H + 3, o = 0;
+    g->H = (int)H; g->n = (int)n;
+    g->o_bi = o; o += APN_F * APN_M; g->o_bq = o; o += APN_F * APN_M;
+    g->o_c = o; o += 1; g->o_z = o; o += n;
+    g->o_wu = o; o += APN_NODE * (8 + n); g->o_bu = o; o += APN_NODE;
+    g->o_wh = o; o += n * APN_NODE; g->o_bh = o; o += n;
+    g->o_woi = o; o += H; g->o_woq = o; o += H;
+    g->P = o;
+}
+typedef struct { real fi[4], fq[4], rr, ri, mag, feat[8], sp[APN_MAXN], v1[APN_NODE], v[APN_MAXN], sn[APN_MAXN], hI0[MAXH], hQ0[MAXH], hI[MAXH], hQ[MAXH]; } apn_step_t;
+static void apn_seq_fwd(const apn_layout_t* L, const real* p, int T, const real* x, real* y, apn_step_t* S) {
+    const int H = L->H, n = L->n;
+    real hI[MAXH] = {0}, hQ[MAXH] = {0}, hA[3] = {0};
+    apn_step_t tmp;
+    for (int t = 0; t < T; ++t) {
+        apn_step_t* s = S ? &S[t] : &tmp;
+        const real I = x[2 * t], Q = x[2 * t + 1];
+        s->mag = (real)sqrt((double)(I * I + Q * Q));
+        s->rr = I / s->mag; s->ri = -Q / s->mag;
+        for (int q = 0; q < APN_F; ++q) {
+            real fi = 0, fq = 0;
+            for (int m = 0; m < APN_M; ++m) {
+                const int tt = t - (APN_M - 1) + m;
+                if (tt < 0) continue;
+                const real xi = x[2 * tt], xq = x[2 * tt + 1], bi = p[L->o_bi + q * APN_M + m], bq = p[L->o_bq + q * APN_M + m];
+                fi += bi * xi - bq * xq; fq += bq * xi + bi * xq;
+            }
+            s->fi[q] = fi; s->fq[q] = fq;
+        }
+        s->fi[3] = I; s->fq[3] = Q;
+        for (int k = 0; k < 4; ++k) {
+            s->feat[2 * k] = s->rr * s->fi[k] - s->ri * s->fq[k];
+            s->feat[2 * k + 1] = s->ri * s->fi[k] + s->rr * s->fq[k];
+        }
+        for (int j = 0; j < H; ++j) {
+            s->hI0[j] = hI[j]; s->hQ0[j] = hQ[j];
+            s->sp[j] = hI[j] * s->rr - hQ[j] * s->ri;
+            s->sp[H + j] = hI[j] * s->ri + hQ[j] * s->rr;
+        }
+        for (int j = 0; j < 3; ++j) s->sp[2 * H + j] = hA[j];
+        for (int o = 0; o < APN_NODE; ++o) {
+            real a = p[L->o_bu + o];
+            for (int k = 0; k < 8; ++k) a += p[L->o_wu + o * (8 + n) + k] * s->feat[k];
+            for (int k = 0; k < n; ++k) a += p[L->o_wu + o * (8 + n) + 8 + k] * s->sp[k];
+            s->v1[o] = tanhr(a);
+        }
+        for (int j = 0; j < n; ++j) {
+            real a = p[L->o_bh + j];
+            for (int o = 0; o < APN_NODE; ++o) a += p[L->o_wh + j * APN_NODE + o] * s->v1[o];
+            s->v[j] = tanhr(a);
+            s->sn[j] = sigm(p[L->o_c] * s->sp[j]) + p[L->o_z + j] * s->v[j];
+        }
+        real y0 = 0, y1 = 0;
+        for (int j = 0; j < H; ++j) {
+            hI[j] = s->sn[j] * s->rr + s->sn[H + j] * s->ri;
+            hQ[j] = s->sn[H + j] * s->rr - s->sn[j] * s->ri;
+            s->hI[j] = hI[j]; s->hQ[j] = hQ[j];
+            y0 += p[L->o_woi + j] * hI[j]; y1 += p[L->o_woq + j] * hQ[j];
+        }
+        for (int j = 0; j < 3; ++j) hA[j] = s->sn[2 * H + j];
+        y[2 * t] = y0 - y1; y[2 * t + 1] = y1 + y0;
+    }
+}
+static void apn_seq_bwd(const apn_layout_t* L, const real* p, int T, const real* x, const real* dy, const apn_step_t* S, real* dp, real* dx) {
+    const int H = L->H, n = L->n;
+    real dhI[MAXH] = {0}, dhQ[MAXH] = {0}, dhA[3] = {0};
+    if (dx) for (int t = 0; t < 2 * T; ++t) dx[t] = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const apn_step_t* s = &S[t];
+        const real dA = dy[2 * t] + dy[2 * t + 1], dB = dy[2 * t + 1] - dy[2 * t], C = p[L->o_c];
+        real dsn[APN_MAXN], dsp[APN_MAXN], dpre2[APN_MAXN], dv1[APN_NODE] = {0}, dpre1[APN_NODE], dfeat[8] = {0}, drr = 0, dri = 0;
+        for (int j = 0; j < H; ++j) {
+            dp[L->o_woi + j] += dA * s->hI[j]; dp[L->o_woq + j] += dB * s->hQ[j];
+            const real gI = dhI[j] + dA * p[L->o_woi + j], gQ = dhQ[j] + dB * p[L->o_woq + j];
+            /* h_I = sn_I rr + sn_Q ri,  h_Q = sn_Q rr - sn_I ri */
+            dsn[j] = gI * s->rr - gQ * s->ri; dsn[H + j] = gI * s->ri + gQ * s->rr;
+            drr += gI * s->sn[j] + gQ * s->sn[H + j]; dri += gI * s->sn[H + j] - gQ * s->sn[j];
+        }
+        for (int j = 0; j < 3; ++j) dsn[2 * H + j] = dhA[j];
+        for (int j = 0; j < n; ++j) {
+            const real sg = sigm(C * s->sp[j]), dsg = sg * ((real)1 - sg);
+            dp[L->o_z + j] += dsn[j] * s->v[j];
+            dp[L->o_c] += dsn[j] * dsg * s->sp[j];
+            dsp[j] = dsn[j] * dsg * C;
+            dpre2[j] = dsn[j] * p[L->o_z + j] * ((real)1 - s->v[j] * s->v[j]);
+            dp[L->o_bh + j] += dpre2[j];
+            for (int o = 0; o < APN_NODE; ++o) { dp[L->o_wh + j * APN_NODE + o] += dpre2[j] * s->v1[o]; dv1[o] += p[L->o_wh + j * APN_NODE + o] * dpre2[j]; }
+        }
+        for (int o = 0; o < APN_NODE; ++o) {
+            dpre1[o] = dv1[o] * ((real)1 - s->v1[o] * s->v1[o]);
+            dp[L->o_bu + o] += dpre1[o];
+            for (int k = 0; k < 8; ++k) { dp[L->o_wu + o * (8 + n) + k] += dpre1[o] * s->feat[k]; dfeat[k] += p[L->o_wu + o * (8 + n) + k] * dpre1[o]; }
+            for (int k = 0; k < n; ++k) { dp[L->o_wu + o * (8 + n) + 8 + k] += dpre1[o] * s->sp[k]; dsp[k] += p[L->o_wu + o * (8 + n) + 8 + k] * dpre1[o]; }
+        }
+        /* sp_I = h_I rr - h_Q ri,  sp_Q = h_I ri + h_Q rr (previous state into the normalised frame) */
+        for (int j = 0; j < H; ++j) {
+            dhI[j] = dsp[j] * s->rr + dsp[H + j] * s->ri; dhQ[j] = dsp[H + j] * s->rr - dsp[j] * s->ri;
+            drr += dsp[j] * s->hI0[j] + dsp[H + j] * s->hQ0[j]; dri += dsp[H + j] * s->hI0[j] - dsp[j] * s->hQ0[j];
+        }
+        for (int j = 0; j < 3; ++j) dhA[j] = dsp[2 * H + j];
+        /* feat_re = rr fi - ri fq,  feat_im = ri fi + rr fq */
+        real dfi[4], dfq[4];
+        for (int k = 0; k < 4; ++k) {
+            dfi[k] = dfeat[2 * k] * s->rr + dfeat[2 * k + 1] * s->ri; dfq[k] = dfeat[2 * k + 1] * s->rr - dfeat[2 * k] * s->ri;
+            drr += dfeat[2 * k] * s->fi[k] + dfeat[2 * k + 1] * s->fq[k]; dri += dfeat[2 * k + 1] * s->fi[k] - dfeat[2 * k] * s->fq[k];
+        }
+        for (int q = 0; q < APN_F; ++q)
+            for (int m = 0; m < APN_M; ++m) {
+                const int tt = t - (APN_M - 1) + m;
+                if (tt < 0) continue;
+                const real xi = x[2 * tt], xq = x[2 * tt + 1], bi = p[L->o_bi + q * APN_M + m], bq = p[L->o_bq + q * APN_M + m];
+                dp[L->o_bi + q * APN_M + m] += dfi[q] * xi + dfq[q] * xq; dp[L->o_bq + q * APN_M + m] += dfq[q] * xi - dfi[q] * xq;
+                if (dx) { dx[2 * tt] += dfi[q] * bi + dfq[q] * bq; dx[2 * tt + 1] += dfq[q] * bi - dfi[q] * bq; }
+            }
+        if (dx) {   /* the raw sample as the fourth value, and r = (I, -Q) / |x| */
+            const real I = x[2 * t], Q = x[2 * t + 1], m3 = s->mag * s->mag * s->mag, w = (drr * Q + dri * I) / m3;
+            dx[2 * t] += dfi[3] + Q * w; dx[2 * t + 1] += dfq[3] - I * w;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Quantisation-aware QGRU: quant/__init__.py:20-37 -> quant_envs.py:138-306 applied to qgru.py  */
 /*   INT_Quantizer (quantizers.py:15-85): s = 2^round(log2|scale|); q(x) = round(clamp(x/s,Qn,Qp))*s */
 /*   (clamp BEFORE round, round half to even), straight-through gradient inside the clamp range.   */
@@ -1638,6 +1775,11 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         boj_step_t* S = (boj_step_t*)scratch;
         boj_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
         if (dy) boj_seq_bwd(&L, params, T, x, dy, S, dp, dx);
+    } else if (bb == ODPD_APNRRU) {
+        apn_layout_t L; apn_layout(m, &L);
+        apn_step_t* S = (apn_step_t*)scratch;
+        apn_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
+        if (dy) apn_seq_bwd(&L, params, T, x, dy, S, dp, dx);
     } else if (bb == ODPD_DELTAJANET) {
         dj_layout_t L; dj_layout(m, &L);
         dj_step_t* S = (dj_step_t*)scratch;
@@ -1664,6 +1806,7 @@ static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
     if (bb == ODPD_GMP) return sizeof(real) * (size_t)(6 * (T + 2 * m->hidden));
     if (bb == ODPD_DVRJANET) return sizeof(dvr_step_t) * T;
     if (bb == ODPD_BOJANET) return T >= BOJ_M - 1 ? sizeof(boj_step_t) * T : 0;   /* bojanet.py:72-77 cannot frame fewer than 15 samples */
+    if (bb == ODPD_APNRRU) return T >= APN_M - 1 ? sizeof(apn_step_t) * T : 0;   /* apnrru.py:68-72 cannot frame fewer than 15 samples */
     if (bb == ODPD_DELTAJANET) return sizeof(dj_step_t) * T;
     if (bb == ODPD_NEURALTX) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_RVTDCNN) return T >= 3 ? sizeof(real) * (size_t)(5 * T) : 0;   /* the circular window needs 3 samples */

@@ -42,3 +42,15 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
+
+
+def apnrru_noise_mask(hidden):
+    """APNRRU (apnrru.py:77-99) feeds its cell the raw sample rotated by its own conjugate phase: the imaginary part of that
+    feature is 0 up to rounding (~1e-9), so the gradient of W_u's column 7 is rounding noise (~1e-10) and AdamW — which normalises
+    every gradient by its own magnitude — turns that noise into full-size steps.  Returns the flat-parameter mask of everything
+    BUT that column: optimiser trajectories are compared on it."""
+    n = 2 * hidden + 3
+    m = np.ones(343 + 70 * hidden, dtype=bool)
+    o_wu = 96 + 1 + n
+    m[o_wu + 7:o_wu + 16 * (8 + n):8 + n] = False
+    return m

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle.oracle import Oracle, make_model
-from tests.golden_util import Fixture, rel_err
+from tests.golden_util import Fixture, apnrru_noise_mask, rel_err
 
 # fp32 accumulate-order noise between ATen/oneDNN and straight C loops
 FWD_TOL = 2e-5     # relative to max|y|
@@ -22,7 +22,7 @@ SINGLE = [
     ("deltagru_h24_th", "deltagru"), ("tres_h30_th", "deltagru_tcnskip"),
     ("tcnn_c35", "tcnn"), ("pgjanet_h11", "pgjanet"), ("gmp_m11", "gmp"),
     ("rvtdcnn_h25", "rvtdcnn"), ("rvtdcnn_h6", "rvtdcnn"), ("neuraltx_c36", "neuraltx"), ("neuraltx_c12", "neuraltx"),
-    ("deltajanet_h15", "deltajanet"), ("deltajanet_h22", "deltajanet"), ("dvrjanet_h12_k3", "dvrjanet"), ("dvrjanet_h8_k4", "dvrjanet"), ("bojanet_h12", "bojanet"), ("bojanet_h16", "bojanet"), ("bojanet_h5", "bojanet"),
+    ("deltajanet_h15", "deltajanet"), ("deltajanet_h22", "deltajanet"), ("dvrjanet_h12_k3", "dvrjanet"), ("dvrjanet_h8_k4", "dvrjanet"), ("bojanet_h12", "bojanet"), ("bojanet_h16", "bojanet"), ("bojanet_h5", "bojanet"), ("apnrru_h8", "apnrru"), ("apnrru_h14", "apnrru"), ("apnrru_h5", "apnrru"),
 ]
 
 
@@ -75,15 +75,17 @@ def test_three_adamw_steps(orc, name, bb):
     mom = np.zeros_like(p)
     var = np.zeros_like(p)
     x, tgt = fx["x"], fx["tgt"]
+    # apnrru: one input feature is 0 up to rounding, AdamW makes full steps out of its noise gradient (golden_util.apnrru_noise_mask)
+    keep = apnrru_noise_mask(fx.meta["hidden"]) if bb == "apnrru" else np.ones(p.size, dtype=bool)
     for s in range(1, 4):
         y, _ = orc.forward(m, p, x)
         loss, dy = orc.loss("l2", y, tgt)
         assert abs(loss - fx["losses"][s - 1]) < 2e-5 * max(1.0, fx["losses"][s - 1])
         g, _ = orc.backward(m, p, x, dy, need_dx=False)
         orc.clip_adamw(p, g, mom, var, s, fx.meta["lr"], fx.meta["clip"], tensor_sizes=sizes)
-        assert rel_err(p, fx.flat(f"p{s}", names)) < STEP_TOL
-    assert rel_err(mom, fx.flat("m3", names)) < 1e-3
-    assert rel_err(var, fx.flat("v3", names)) < 1e-3
+        assert rel_err(p[keep], fx.flat(f"p{s}", names)[keep]) < STEP_TOL
+    assert rel_err(mom[keep], fx.flat("m3", names)[keep]) < 1e-3
+    assert rel_err(var[keep], fx.flat("v3", names)[keep]) < 1e-3
 
 
 def test_l1_loss(orc):
