@@ -4,9 +4,9 @@
 thx=0, thh=0)` — same constructor, attributes, `forward(x, h_0=None)` contract and state-dict keys
 as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` as models.py:163-176.
 Backbones on the hot path run as HIP kernels (`backbone.native` is True) inside the kernels' envelope (one layer, hidden
-<= 32; pgjanet <= 16; tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32; dvrjanet <= 16 with <= 8 DVR units; bojanet <= 16) and as ATen restatements (backbones/wide.py,
+<= 32; pgjanet <= 16; tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32; dvrjanet <= 16 with <= 8 DVR units; bojanet <= 16; apnrru <= 14) and as ATen restatements (backbones/wide.py,
 `native` False, with a warning) beyond it; the remaining registry names (SURVEY §8 f4:
-apnrru, mcldnn) are torch restatements in backbones/extras.py that
+mcldnn) is a torch restatements in backbones/extras.py that
 run through ATen (`backbone.native` is False) until they get kernels.  Unknown names raise ValueError (models.py:139-141).
 """
 import torch
@@ -68,7 +68,14 @@ class CoreModel(nn.Module):
         elif backbone_type == "rvtdcnn":
             self.backbone = B.RVTDCNN(fc_hid_size=hidden_size)
         elif backbone_type == "apnrru":
-            self.backbone = X.APNRRU(hidden_size=hidden_size, bias=True)
+            from .backbones import apnrru as AP
+            if hidden_size <= AP.MAX_HIDDEN:
+                self.backbone = B.APNRRU(hidden_size=hidden_size, bias=True)
+            else:
+                import warnings
+                warnings.warn(f"opendpd_amd: backbone 'apnrru' with hidden_size={hidden_size} is outside the HIP kernel's envelope "
+                              f"(hidden <= {AP.MAX_HIDDEN}): running the ATen restatement (backbones/extras.py)", stacklevel=2)
+                self.backbone = X.APNRRU(hidden_size=hidden_size, bias=True)
         elif backbone_type == "bojanet":
             from .backbones import bojanet as BJ
             if hidden_size <= BJ.MAX_HIDDEN:

@@ -410,8 +410,10 @@ def test_quantised_flow_with_pretrained_float_checkpoint_matches_reference(workd
 
 @pytest.mark.parametrize("bb,H", [("mcldnn", 8), ("apnrru", 8)])
 def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H):
-    """SURVEY §8 f4 names (backbones/extras.py) go through the same Project flow on the GPU: ATen forward/backward,
-    torch.optim.AdamW, device-resident frame loader, eval + metrics + checkpoint/log layout."""
+    """SURVEY §8 f4 names without a reference-logged anchor go through the same Project flow on the GPU — mcldnn (backbones/extras.py:
+    ATen forward/backward, torch.optim.AdamW) and apnrru (HIP kernels + fused AdamW; the reference's CLI does not list it among its
+    --PA_backbone choices, so there is no reference log to anchor it to): device-resident frame loader, eval + metrics +
+    checkpoint/log layout."""
     import opendpd_amd as od
     res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone=bb, PA_hidden_size=H, frame_length=50, batch_size=256, lr=2e-3,
                       n_epochs=2, seed=0, accelerator="cuda")

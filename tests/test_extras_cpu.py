@@ -8,7 +8,7 @@ import torch
 
 from tests.golden_util import Fixture, rel_err
 
-CASES = [("apnrru", 8), ("mcldnn", 8)]
+CASES = [("mcldnn", 8)]
 TOL = 1e-5
 
 
@@ -50,7 +50,7 @@ def test_forward_backward_match_reference(bb, H):
 
 def test_fused_optimizer_refuses_non_native_backbones_and_project_falls_back():
     from opendpd_amd.train_funcs import FusedAdamW
-    net = _build("apnrru", 8)
+    net = _build("mcldnn", 8)
     with pytest.raises(TypeError):
         FusedAdamW(net)
 
@@ -193,6 +193,34 @@ def test_bojanet_is_native_and_constructs_like_the_reference(H):
     assert wide.backbone.native is False
     from opendpd_amd.backbones.extras import BOJANET
     ref = BOJANET(hidden_size=H, output_size=2)
+    ref.load_state_dict({k[len("backbone."):]: torch.from_numpy(fx["sdu/" + k]) for k in fx.keys("sdu")})
+    x = torch.from_numpy(fx["x"]).requires_grad_(True)
+    y = ref(x)
+    assert rel_err(y.detach().numpy(), fx["y"]) < TOL
+    torch.nn.functional.mse_loss(y, torch.from_numpy(fx["tgt"])).backward()
+    for k, p in ref.named_parameters():
+        assert rel_err(p.grad.numpy(), fx["g/backbone." + k]) < 10 * TOL, k
+    assert rel_err(x.grad.numpy(), fx["gx"]) < 10 * TOL
+
+
+def test_apnrru_is_native_and_constructs_like_the_reference():
+    """apnrru left this module for csrc/apnrru_s16.hip (hidden <= 14); the seeded construction — including the reference's
+    reset_parameters() that stops at a missing attribute and leaves the read-outs at their default draw — still reproduces the
+    reference's state dict and RNG consumption; beyond the envelope the restatement serves it, and keeps computing what the reference does."""
+    fx = Fixture("extra_apnrru_h8")
+    net = _build("apnrru", 8)
+    after = float(torch.rand(1))
+    sd = net.state_dict()
+    assert list(sd.keys()) == fx.keys("sd")
+    for k in sd:
+        assert np.array_equal(sd[k].numpy(), fx["sd/" + k]), k
+    assert after == fx.meta["rng_after_init"]
+    assert net.backbone.native is True and sum(p.numel() for p in net.parameters()) == fx.meta["n_param"] == 343 + 70 * 8
+    with pytest.warns(UserWarning, match="envelope"):
+        wide = _build("apnrru", 15)
+    assert wide.backbone.native is False
+    from opendpd_amd.backbones.extras import APNRRU
+    ref = APNRRU(hidden_size=8)
     ref.load_state_dict({k[len("backbone."):]: torch.from_numpy(fx["sdu/" + k]) for k in fx.keys("sdu")})
     x = torch.from_numpy(fx["x"]).requires_grad_(True)
     y = ref(x)

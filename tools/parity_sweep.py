@@ -20,7 +20,7 @@ o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
          "tcnn": list(range(1, 40)) + [48, 63, 64], "gmp": [11] * 12, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
-         "neuraltx": list(range(1, 40)) + [48, 63, 64], "dvrjanet": range(1, 17), "bojanet": range(1, 17)}
+         "neuraltx": list(range(1, 40)) + [48, 63, 64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15)}
 rng = np.random.RandomState(0)
 bad, kinks, illcond, worst = [], [], [], {}
 for bb, sizes in SIZES.items():
@@ -36,7 +36,7 @@ for bb, sizes in SIZES.items():
                     T = max(1, 6000 // B)
                 if bb in ("vdlstm", "rvtdcnn") and T < 3:
                     T = 3       # the 3-sample circular pad needs T >= 3 (vdlstm.py:66-74); shorter frames are refused (EINVAL)
-                if bb == "bojanet" and T < 15:
+                if bb in ("bojanet", "apnrru") and T < 15:
                     T = 15 + T  # the reference cuts its 15-sample zero pad from the frame itself (bojanet.py:72-73)
                 kw = dict(thx=float(rng.choice([0.0, 0.01, 0.05])), thh=float(rng.choice([0.0, 0.02, 0.1]))) if "delta" in bb else {}
                 K = int(rng.randint(1, 9)) if bb == "dvrjanet" else 0
@@ -52,6 +52,8 @@ for bb, sizes in SIZES.items():
                             p.uniform_(-0.6, 0.6)
                         if k.startswith("backbone.fir_"):        # BOJANET taps (gain 0.1): let the envelopes reach the gates
                             p.mul_(4.0)
+                        if k == "backbone.rru.Z":                # APNRRU: Z = 0 at construction switches the deep cell off
+                            p.uniform_(-0.6, 0.6)
                         if k == "backbone.cs":                   # DVR coefficients: bounded gain (standard-normal ones make the recurrence chaotic)
                             p.mul_(min(1.0, 1.5 / float(p.abs().sum())))
                 amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)

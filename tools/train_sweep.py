@@ -20,7 +20,7 @@ o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
          "tcnn": list(range(1, 40, 3)) + [64], "gmp": [11] * 16, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
-         "neuraltx": list(range(1, 40, 3)) + [64], "dvrjanet": range(1, 17), "bojanet": range(1, 17)}
+         "neuraltx": list(range(1, 40, 3)) + [64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15)}
 rng = np.random.RandomState(1)
 bad = []
 for bb, sizes in SIZES.items():
@@ -33,7 +33,7 @@ for bb, sizes in SIZES.items():
                 T = int(rng.choice([3, 4, 5, 31, 32, 33, 50, 65, 200]))
                 if B * T > 5000:
                     T = max(3, 5000 // B)
-                if bb == "bojanet" and T < 15:
+                if bb in ("bojanet", "apnrru") and T < 15:
                     T = 15 + T
                 kind = str(rng.choice(["l2", "l1"]))
                 kw = dict(thx=float(rng.choice([0.0, 0.01])), thh=float(rng.choice([0.0, 0.03]))) if "delta" in bb else {}
@@ -46,6 +46,8 @@ for bb, sizes in SIZES.items():
                     for k, p in net.named_parameters():
                         if "bias" in k:
                             p.uniform_(-0.3, 0.3)
+                        if k == "backbone.rru.Z":                # APNRRU: Z = 0 at construction switches the deep cell off
+                            p.uniform_(-0.6, 0.6)
                         if k == "backbone.cs":                   # DVR coefficients: bounded gain (standard-normal ones make the recurrence chaotic)
                             p.mul_(min(1.0, 1.5 / float(p.abs().sum())))
                 amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
