@@ -45,7 +45,8 @@ enum odpd_backbone {
     ODPD_DVRJANET = 14,  /* backbones/dvrjanet.py:5-112 (num_dvr_units rides in odpd_model_t::bits_w) */
     ODPD_BOJANET = 15,   /* backbones/bojanet.py:5-138 (16-tap complex FIR bank, vector demodulator, JANET cell, phase re-rotation; hidden <= 18) */
     ODPD_APNRRU = 16,    /* backbones/apnrru.py:5-152 (3-filter FIR bank + raw sample, phase-normalised RRU cell on a complex state; hidden <= 14) */
-    ODPD_BACKBONE_COUNT = 17
+    ODPD_MCLDNN = 17,    /* backbones/mcldnn.py:9-134 (two conv branches on a 5x5 feature patch merged by a third, LSTM(5C -> 8), two linear layers; hidden = C) */
+    ODPD_BACKBONE_COUNT = 18
 };
 
 enum odpd_error {

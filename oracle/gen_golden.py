@@ -8,7 +8,7 @@ Only the vectors are committed; the reference never travels to the GPU box.
 What is pinned (reference file:line the vectors exercise):
   * backbones: gru.py:45-48, dgru.py:59-74, lstm.py:45-48, vdlstm.py:56-81,
     deltagru.py:59-77 + :211-264, deltagru_tcnskip.py:87-103 + :248-293,
-    tcnn.py:82-97, pgjanet.py:26-76, qgru.py:59-71, qgru_amp1.py:59-76, gmp.py:18-50, rvtdcnn.py:35-62, neuraltx.py:116-137, deltajanet.py:50-64 + :211-274, dvrjanet.py:44-101, bojanet.py:55-106, apnrru.py:54-131
+    tcnn.py:82-97, pgjanet.py:26-76, qgru.py:59-71, qgru_amp1.py:59-76, gmp.py:18-50, rvtdcnn.py:35-62, neuraltx.py:116-137, deltajanet.py:50-64 + :211-274, dvrjanet.py:44-101, bojanet.py:55-106, apnrru.py:54-131, mcldnn.py:99-134
   * registry models.py:10-160 (CoreModel) and models.py:163-176 (CascadedModel)
   * train step modules/train_funcs.py:33-44 (zero_grad, fwd, MSE, bwd, clip 200, AdamW)
   * quant path quant/__init__.py:20-37 -> quant_envs.py:138-306
@@ -179,6 +179,8 @@ def gen_backbones(only=None):
         ("apnrru_h8", "apnrru", 8, 0, 0),                         # 903 parameters; state of 2 x 8 + 3 = 19
         ("apnrru_h14", "apnrru", 14, 0, 0),                       # state of 31: the kernels' largest
         ("apnrru_h5", "apnrru", 5, 0, 0),
+        ("mcldnn_c8", "mcldnn", 8, 0, 0),                         # 2109 parameters
+        ("mcldnn_c3", "mcldnn", 3, 0, 0),
     ]
     dvr_units = {"dvrjanet_h12_k3": 3, "dvrjanet_h8_k4": 4}
     x, tgt = real_frames("DPA_200MHz", 5, 37, seed=1)       # ragged: B%4!=0, odd T
@@ -200,6 +202,12 @@ def gen_backbones(only=None):
                 net.backbone.rru.Z.copy_((torch.rand(net.backbone.rru.Z.shape, generator=g) - 0.5) * 1.2)
                 for k, p in net.named_parameters():
                     if k.endswith("bias"):
+                        p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 0.4)
+        if bb == "mcldnn":        # zero biases at construction
+            with torch.no_grad():
+                g = torch.Generator().manual_seed(8)
+                for k, p in net.named_parameters():
+                    if "bias" in k:
                         p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 0.4)
         if bb == "bojanet":       # zero biases at construction: give the bias gradients something to be checked against
             with torch.no_grad():

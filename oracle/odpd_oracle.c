@@ -80,6 +80,8 @@ int64_t oracle_param_count(const odpd_model_t* m) {
         return H <= 18 ? 2 * H * H + 28 * H + 194 : -1;
     case ODPD_APNRRU:   /* apnrru.py:13-19, 45-53: two (3,16) FIR banks, C, Z (n), W_u (16, 8+n)+b, W_h (n,16)+b, two bias-free heads; n = 2H+3 */
         return 343 + 70 * H;
+    case ODPD_MCLDNN:   /* mcldnn.py:21-27: conv2d_1 10C, conv1d 20C, conv2d_2 91, LSTM(5C -> 8) 160C + 320, fc 144 + 34 */
+        return 190 * H + 589;
     case ODPD_DELTAJANET: /* deltajanet.py:96-111: two gates */
         return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2;
     case ODPD_NEURALTX: /* neuraltx.py:18-38: two 5-tap FIRs, 4 -> C (bias), 4 depthwise k5, C -> 2, IQ_match (2,2); hidden = channels */
@@ -1373,6 +1375,203 @@ static void apn_seq_bwd(const apn_layout_t* L, const real* p, int T, const real*
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* MCLDNN: mcldnn.py:9-134.  Per step a 5 x 5 patch P[f][m]: features f = (I, Q, a, a^2, a^3) (:104-111) at the samples t-4+m, the
+ * frame's own last four samples standing in front of it (circular window, :115-118).  conv2d_1 = Conv2d(1 -> C, 3x3, pad 1) on P
+ * (:121);  conv1d = Conv1d(5 -> 5C, k3, pad 1, groups 5) along m, its (5C, 5) result RE-READ as (C, 5, 5): entry [c][f][m] is output
+ * channel 5c + f, which belongs to input feature (5c + f) / C (:122-123);  both stacked to 10 "channels" x (C x 5) (:124-126) and merged
+ * by conv2d_2 = Conv2d(10 -> 1, 3x3, pad 1) over (C, 5) -> z (5C, index 5c + m) (:126-127);  nn.LSTM(5C -> 8) from the zero state (h_0 is
+ * not passed, :128);  fc_out (8 -> 16), fc_out_2 (16 -> 2), no activation in between (:129-131).  hidden = C (models.py:131-132).
+ * Parameter order (named_parameters): conv2d_1 (C,1,3,3)+b, conv1d (5C,1,3)+b, conv2d_2 (1,10,3,3)+b, lstm W_ih (32,5C), W_hh (32,8),
+ * b_ih, b_hh, fc_out (16,8)+b, fc_out_2 (2,16)+b. */
+#define MCL_H 8
+#define MCL_MAXC MAXH
+typedef struct { int C; int64_t o_w1, o_b1, o_w1d, o_b1d, o_w2, o_b2, o_wih, o_whh, o_bih, o_bhh, o_wf1, o_bf1, o_wf2, o_bf2, P; } mcl_layout_t;
+static void mcl_layout(const odpd_model_t* m, mcl_layout_t* g) {
+    int64_t C = m->hidden, o = 0;
+    g->C = (int)C;
+    g->o_w1 = o; o += 9 * C; g->o_b1 = o; o += C;
+    g->o_w1d = o; o += 15 * C; g->o_b1d = o; o += 5 * C;
+    g->o_w2 = o; o += 90; g->o_b2 = o; o += 1;
+    g->o_wih = o; o += 4 * MCL_H * 5 * C; g->o_whh = o; o += 4 * MCL_H * MCL_H; g->o_bih = o; o += 4 * MCL_H; g->o_bhh = o; o += 4 * MCL_H;
+    g->o_wf1 = o; o += 16 * MCL_H; g->o_bf1 = o; o += 16; g->o_wf2 = o; o += 32; g->o_bf2 = o; o += 2;
+    g->P = o;
+}
+typedef struct { real gi[MCL_H], gf[MCL_H], gg[MCL_H], go[MCL_H], cp[MCL_H], c[MCL_H], hp[MCL_H], h[MCL_H]; } mcl_step_t;
+static void mcl_feat(const real* x, int s, real* f) {
+    const real I = x[2 * s], Q = x[2 * s + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+    f[0] = I; f[1] = Q; f[2] = a; f[3] = a2; f[4] = a * a * a;
+}
+/* patch of step t and the front end up to z; cat[ch][c][m] (ch < 5: conv2d_1 feature row ch, ch >= 5: the re-read conv1d) */
+static void mcl_front(const mcl_layout_t* L, const real* p, int T, const real* x, int t, real P[5][5], real* cat, real* z) {
+    const int C = L->C;
+    for (int m = 0; m < 5; ++m) {
+        real f[5];
+        mcl_feat(x, ((t - 4 + m) % T + T) % T, f);
+        for (int k = 0; k < 5; ++k) P[k][m] = f[k];
+    }
+    for (int c = 0; c < C; ++c)
+        for (int f = 0; f < 5; ++f)
+            for (int m = 0; m < 5; ++m) {
+                real a = p[L->o_b1 + c];
+                for (int df = 0; df < 3; ++df)
+                    for (int dm = 0; dm < 3; ++dm) {
+                        const int ff = f + df - 1, mm = m + dm - 1;
+                        if (ff >= 0 && ff < 5 && mm >= 0 && mm < 5) a += p[L->o_w1 + c * 9 + df * 3 + dm] * P[ff][mm];
+                    }
+                cat[(f * C + c) * 5 + m] = a;
+            }
+    for (int oc = 0; oc < 5 * C; ++oc)
+        for (int m = 0; m < 5; ++m) {
+            real a = p[L->o_b1d + oc];
+            for (int dm = 0; dm < 3; ++dm) {
+                const int mm = m + dm - 1;
+                if (mm >= 0 && mm < 5) a += p[L->o_w1d + oc * 3 + dm] * P[oc / C][mm];
+            }
+            cat[((5 + oc % 5) * C + oc / 5) * 5 + m] = a;
+        }
+    for (int c = 0; c < C; ++c)
+        for (int m = 0; m < 5; ++m) {
+            real a = p[L->o_b2];
+            for (int ch = 0; ch < 10; ++ch)
+                for (int dc = 0; dc < 3; ++dc)
+                    for (int dm = 0; dm < 3; ++dm) {
+                        const int cc = c + dc - 1, mm = m + dm - 1;
+                        if (cc >= 0 && cc < C && mm >= 0 && mm < 5) a += p[L->o_w2 + ch * 9 + dc * 3 + dm] * cat[(ch * C + cc) * 5 + mm];
+                    }
+            z[c * 5 + m] = a;
+        }
+}
+static void mcl_seq_fwd(const mcl_layout_t* L, const real* p, int T, const real* x, real* y, mcl_step_t* S, real* scratch) {
+    const int C = L->C, Z = 5 * C;
+    real h[MCL_H] = {0}, c[MCL_H] = {0};
+    real* cat = scratch; real* z = cat + 10 * C * 5;
+    mcl_step_t tmp;
+    for (int t = 0; t < T; ++t) {
+        mcl_step_t* s = S ? &S[t] : &tmp;
+        real P[5][5];
+        mcl_front(L, p, T, x, t, P, cat, z);
+        for (int j = 0; j < MCL_H; ++j) {
+            real pre[4];
+            for (int g = 0; g < 4; ++g) {
+                real a = p[L->o_bih + g * MCL_H + j] + p[L->o_bhh + g * MCL_H + j];
+                for (int k = 0; k < Z; ++k) a += p[L->o_wih + (g * MCL_H + j) * Z + k] * z[k];
+                for (int k = 0; k < MCL_H; ++k) a += p[L->o_whh + (g * MCL_H + j) * MCL_H + k] * h[k];
+                pre[g] = a;
+            }
+            s->gi[j] = sigm(pre[0]); s->gf[j] = sigm(pre[1]); s->gg[j] = tanhr(pre[2]); s->go[j] = sigm(pre[3]);
+        }
+        for (int j = 0; j < MCL_H; ++j) {
+            s->cp[j] = c[j]; s->hp[j] = h[j];
+            c[j] = s->gf[j] * c[j] + s->gi[j] * s->gg[j];
+            s->c[j] = c[j];
+        }
+        for (int j = 0; j < MCL_H; ++j) { h[j] = s->go[j] * tanhr(c[j]); s->h[j] = h[j]; }
+        real f1[16];
+        for (int o = 0; o < 16; ++o) {
+            real a = p[L->o_bf1 + o];
+            for (int k = 0; k < MCL_H; ++k) a += p[L->o_wf1 + o * MCL_H + k] * h[k];
+            f1[o] = a;
+        }
+        for (int o = 0; o < 2; ++o) {
+            real a = p[L->o_bf2 + o];
+            for (int k = 0; k < 16; ++k) a += p[L->o_wf2 + o * 16 + k] * f1[k];
+            y[2 * t + o] = a;
+        }
+    }
+}
+static void mcl_seq_bwd(const mcl_layout_t* L, const real* p, int T, const real* x, const real* dy, const mcl_step_t* S, real* dp, real* dx,
+                        real* scratch) {
+    const int C = L->C, Z = 5 * C;
+    real* cat = scratch; real* z = cat + 10 * C * 5; real* dcat = z + Z; real* dz = dcat + 10 * C * 5; real* dfeat = dz + Z;   /* dfeat: T x 5 */
+    real dh[MCL_H] = {0}, dc[MCL_H] = {0};
+    for (int i = 0; i < 5 * T; ++i) dfeat[i] = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const mcl_step_t* s = &S[t];
+        real P[5][5], f1[16], df1[16] = {0}, dpre[4][MCL_H], nh[MCL_H] = {0};
+        mcl_front(L, p, T, x, t, P, cat, z);
+        for (int o = 0; o < 16; ++o) {
+            real a = p[L->o_bf1 + o];
+            for (int k = 0; k < MCL_H; ++k) a += p[L->o_wf1 + o * MCL_H + k] * s->h[k];
+            f1[o] = a;
+        }
+        for (int o = 0; o < 2; ++o) {
+            dp[L->o_bf2 + o] += dy[2 * t + o];
+            for (int k = 0; k < 16; ++k) { dp[L->o_wf2 + o * 16 + k] += dy[2 * t + o] * f1[k]; df1[k] += p[L->o_wf2 + o * 16 + k] * dy[2 * t + o]; }
+        }
+        for (int o = 0; o < 16; ++o) {
+            dp[L->o_bf1 + o] += df1[o];
+            for (int k = 0; k < MCL_H; ++k) { dp[L->o_wf1 + o * MCL_H + k] += df1[o] * s->h[k]; dh[k] += p[L->o_wf1 + o * MCL_H + k] * df1[o]; }
+        }
+        for (int j = 0; j < MCL_H; ++j) {
+            const real tc = tanhr(s->c[j]);
+            const real dct = dc[j] + dh[j] * s->go[j] * ((real)1 - tc * tc);
+            dpre[3][j] = dh[j] * tc * s->go[j] * ((real)1 - s->go[j]);
+            dpre[0][j] = dct * s->gg[j] * s->gi[j] * ((real)1 - s->gi[j]);
+            dpre[1][j] = dct * s->cp[j] * s->gf[j] * ((real)1 - s->gf[j]);
+            dpre[2][j] = dct * s->gi[j] * ((real)1 - s->gg[j] * s->gg[j]);
+            dc[j] = dct * s->gf[j];
+        }
+        for (int k = 0; k < Z; ++k) dz[k] = 0;
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < MCL_H; ++j) {
+                const real d = dpre[g][j];
+                dp[L->o_bih + g * MCL_H + j] += d; dp[L->o_bhh + g * MCL_H + j] += d;
+                for (int k = 0; k < Z; ++k) { dp[L->o_wih + (g * MCL_H + j) * Z + k] += d * z[k]; dz[k] += p[L->o_wih + (g * MCL_H + j) * Z + k] * d; }
+                for (int k = 0; k < MCL_H; ++k) { dp[L->o_whh + (g * MCL_H + j) * MCL_H + k] += d * s->hp[k]; nh[k] += p[L->o_whh + (g * MCL_H + j) * MCL_H + k] * d; }
+            }
+        for (int j = 0; j < MCL_H; ++j) dh[j] = nh[j];
+        /* conv2d_2 */
+        for (int i = 0; i < 10 * C * 5; ++i) dcat[i] = 0;
+        for (int c = 0; c < C; ++c)
+            for (int m = 0; m < 5; ++m) {
+                const real d = dz[c * 5 + m];
+                dp[L->o_b2] += d;
+                for (int ch = 0; ch < 10; ++ch)
+                    for (int dcc = 0; dcc < 3; ++dcc)
+                        for (int dm = 0; dm < 3; ++dm) {
+                            const int cc = c + dcc - 1, mm = m + dm - 1;
+                            if (cc >= 0 && cc < C && mm >= 0 && mm < 5) {
+                                dp[L->o_w2 + ch * 9 + dcc * 3 + dm] += d * cat[(ch * C + cc) * 5 + mm];
+                                dcat[(ch * C + cc) * 5 + mm] += p[L->o_w2 + ch * 9 + dcc * 3 + dm] * d;
+                            }
+                        }
+            }
+        real dP[5][5] = {{0}};
+        for (int c = 0; c < C; ++c)
+            for (int f = 0; f < 5; ++f)
+                for (int m = 0; m < 5; ++m) {
+                    const real d = dcat[(f * C + c) * 5 + m];
+                    dp[L->o_b1 + c] += d;
+                    for (int df = 0; df < 3; ++df)
+                        for (int dm = 0; dm < 3; ++dm) {
+                            const int ff = f + df - 1, mm = m + dm - 1;
+                            if (ff >= 0 && ff < 5 && mm >= 0 && mm < 5) { dp[L->o_w1 + c * 9 + df * 3 + dm] += d * P[ff][mm]; dP[ff][mm] += p[L->o_w1 + c * 9 + df * 3 + dm] * d; }
+                        }
+                }
+        for (int oc = 0; oc < 5 * C; ++oc)
+            for (int m = 0; m < 5; ++m) {
+                const real d = dcat[((5 + oc % 5) * C + oc / 5) * 5 + m];
+                dp[L->o_b1d + oc] += d;
+                for (int dm = 0; dm < 3; ++dm) {
+                    const int mm = m + dm - 1;
+                    if (mm >= 0 && mm < 5) { dp[L->o_w1d + oc * 3 + dm] += d * P[oc / C][mm]; dP[oc / C][mm] += p[L->o_w1d + oc * 3 + dm] * d; }
+                }
+            }
+        for (int m = 0; m < 5; ++m) {
+            const int sidx = ((t - 4 + m) % T + T) % T;
+            for (int k = 0; k < 5; ++k) dfeat[sidx * 5 + k] += dP[k][m];
+        }
+    }
+    if (dx)
+        for (int t = 0; t < T; ++t) {   /* features (I, Q, a, a^2, a^3) */
+            const real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+            const real* d = dfeat + 5 * t;
+            const real da = d[2] + (real)2 * a * d[3] + (real)3 * a2 * d[4];
+            dx[2 * t] = d[0] + da * I / a; dx[2 * t + 1] = d[1] + da * Q / a;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Quantisation-aware QGRU: quant/__init__.py:20-37 -> quant_envs.py:138-306 applied to qgru.py  */
 /*   INT_Quantizer (quantizers.py:15-85): s = 2^round(log2|scale|); q(x) = round(clamp(x/s,Qn,Qp))*s */
 /*   (clamp BEFORE round, round half to even), straight-through gradient inside the clamp range.   */
@@ -1780,6 +1979,12 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         apn_step_t* S = (apn_step_t*)scratch;
         apn_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
         if (dy) apn_seq_bwd(&L, params, T, x, dy, S, dp, dx);
+    } else if (bb == ODPD_MCLDNN) {
+        mcl_layout_t L; mcl_layout(m, &L);
+        mcl_step_t* S = (mcl_step_t*)scratch;
+        real* work = (real*)(S + T);
+        mcl_seq_fwd(&L, params, T, x, y, dy ? S : NULL, work);
+        if (dy) mcl_seq_bwd(&L, params, T, x, dy, S, dp, dx, work);
     } else if (bb == ODPD_DELTAJANET) {
         dj_layout_t L; dj_layout(m, &L);
         dj_step_t* S = (dj_step_t*)scratch;
@@ -1807,6 +2012,8 @@ static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
     if (bb == ODPD_DVRJANET) return sizeof(dvr_step_t) * T;
     if (bb == ODPD_BOJANET) return T >= BOJ_M - 1 ? sizeof(boj_step_t) * T : 0;   /* bojanet.py:72-77 cannot frame fewer than 15 samples */
     if (bb == ODPD_APNRRU) return T >= APN_M - 1 ? sizeof(apn_step_t) * T : 0;   /* apnrru.py:68-72 cannot frame fewer than 15 samples */
+    if (bb == ODPD_MCLDNN)     /* the circular window needs its four samples (mcldnn.py:115-118) */
+        return T >= 4 ? sizeof(mcl_step_t) * T + sizeof(real) * (size_t)(2 * (10 * m->hidden * 5 + 5 * m->hidden) + 5 * T) : 0;
     if (bb == ODPD_DELTAJANET) return sizeof(dj_step_t) * T;
     if (bb == ODPD_NEURALTX) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
     if (bb == ODPD_RVTDCNN) return T >= 3 ? sizeof(real) * (size_t)(5 * T) : 0;   /* the circular window needs 3 samples */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
 
 BACKBONES = {"gru": 0, "dgru": 1, "qgru": 2, "qgru_amp1": 3, "lstm": 4, "vdlstm": 5, "deltagru": 6,
-             "deltagru_tcnskip": 7, "tcnn": 8, "pgjanet": 9, "gmp": 10, "rvtdcnn": 11, "neuraltx": 12, "deltajanet": 13, "dvrjanet": 14, "bojanet": 15, "apnrru": 16}
+             "deltagru_tcnskip": 7, "tcnn": 8, "pgjanet": 9, "gmp": 10, "rvtdcnn": 11, "neuraltx": 12, "deltajanet": 13, "dvrjanet": 14, "bojanet": 15, "apnrru": 16, "mcldnn": 17}
 
 
 class Model(C.Structure):

@@ -22,7 +22,7 @@ SINGLE = [
     ("deltagru_h24_th", "deltagru"), ("tres_h30_th", "deltagru_tcnskip"),
     ("tcnn_c35", "tcnn"), ("pgjanet_h11", "pgjanet"), ("gmp_m11", "gmp"),
     ("rvtdcnn_h25", "rvtdcnn"), ("rvtdcnn_h6", "rvtdcnn"), ("neuraltx_c36", "neuraltx"), ("neuraltx_c12", "neuraltx"),
-    ("deltajanet_h15", "deltajanet"), ("deltajanet_h22", "deltajanet"), ("dvrjanet_h12_k3", "dvrjanet"), ("dvrjanet_h8_k4", "dvrjanet"), ("bojanet_h12", "bojanet"), ("bojanet_h16", "bojanet"), ("bojanet_h5", "bojanet"), ("apnrru_h8", "apnrru"), ("apnrru_h14", "apnrru"), ("apnrru_h5", "apnrru"),
+    ("deltajanet_h15", "deltajanet"), ("deltajanet_h22", "deltajanet"), ("dvrjanet_h12_k3", "dvrjanet"), ("dvrjanet_h8_k4", "dvrjanet"), ("bojanet_h12", "bojanet"), ("bojanet_h16", "bojanet"), ("bojanet_h5", "bojanet"), ("apnrru_h8", "apnrru"), ("apnrru_h14", "apnrru"), ("apnrru_h5", "apnrru"), ("mcldnn_c8", "mcldnn"), ("mcldnn_c3", "mcldnn"),
 ]
 
 
