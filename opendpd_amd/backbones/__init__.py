@@ -6,6 +6,7 @@ from .pgjanet import PGJANET  # noqa: F401
 from .dvrjanet import DVRJANET  # noqa: F401
 from .bojanet import BOJANET  # noqa: F401
 from .apnrru import APNRRU  # noqa: F401
+from .mcldnn import MCLDNN  # noqa: F401
 from .tcnn import TCNN, NeuralTX  # noqa: F401
 from .gmp import GMP  # noqa: F401
 from .rvtdcnn import RVTDCNN  # noqa: F401

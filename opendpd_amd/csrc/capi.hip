@@ -5,7 +5,7 @@
 using namespace odpd;
 
 namespace {
-enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP, FAM_RVTDCNN, FAM_DVR, FAM_BOJ, FAM_APN };
+enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP, FAM_RVTDCNN, FAM_DVR, FAM_BOJ, FAM_APN, FAM_MCL };
 inline Family family_of(int bb);
 // a quantisation-aware model: qgru / qgru_amp1 with bits_w > 0 (quant/quant_envs.py:138-171)
 inline Family family_of(const odpd_model_t* m) {
@@ -24,6 +24,7 @@ inline Family family_of(int bb) {
     case ODPD_DVRJANET: return FAM_DVR;
     case ODPD_BOJANET: return FAM_BOJ;
     case ODPD_APNRRU: return FAM_APN;
+    case ODPD_MCLDNN: return FAM_MCL;
     default: return FAM_NONE;
     }
 }
@@ -70,7 +71,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 4; }   // 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..16
+extern "C" int odpd_abi_version(void) { return 4; }   // 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
@@ -90,6 +91,7 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_NEURALTX: return H <= 64 ? 27 * H + 14 : (int64_t)ODPD_EUNSUPPORTED;   // two 5-tap FIRs, 4->C (+bias), 4 x depthwise k5, C->2, IQ_match 2x2
     case ODPD_GMP: return H == 11 ? H * (1 + 4 * H) : (int64_t)ODPD_EUNSUPPORTED;   // memory_length 11, degree 5 (models.py:26-28)
     case ODPD_DVRJANET: return dvrjanet_param_count(m);   // K + 7H^2 + 7H + 2, K = bits_w (dvrjanet.py:11-30, 47-52)
+    case ODPD_MCLDNN: return mcldnn_param_count(m);       // 190C + 589 (mcldnn.py:21-27)
     case ODPD_APNRRU: return apnrru_param_count(m);       // 343 + 70H (apnrru.py:13-19, 45-53)
     case ODPD_BOJANET: return bojanet_param_count(m);     // 2H^2 + 28H + 194 (bojanet.py:15-26)
     case ODPD_RVTDCNN: return H <= 32 ? 39 * H + 32 : (int64_t)ODPD_EUNSUPPORTED;  // conv 27+3, fc_hid 36H+H, fc_out 2H+2 (rvtdcnn.py:19-33)
@@ -103,6 +105,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_DVR) return dvrjanet_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_BOJ) return bojanet_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_APN) return apnrru_ckpt_floats(m, B, T);
+    if (family_of(m) == FAM_MCL) return mcldnn_ckpt_floats(m, B, T);
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
@@ -133,6 +136,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_DVR: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)dvrjanet_rows(m, B);
     case FAM_BOJ: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)bojanet_rows(m, B);
     case FAM_APN: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)apnrru_rows(m, B);
+    case FAM_MCL: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)mcldnn_rows(m, B);
     case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
     case FAM_GMP: return gmp_rows(m, B, T);
     case FAM_RVTDCNN: return fused ? rvtdcnn_train_rows(m, B, T) : rvtdcnn_rows(m, B, T);
@@ -163,6 +167,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_DVR: return dvrjanet_launch((hipStream_t)stream, m, a, 1);
     case FAM_BOJ: return bojanet_launch((hipStream_t)stream, m, a, 1);
     case FAM_APN: return apnrru_launch((hipStream_t)stream, m, a, 1);
+    case FAM_MCL: return mcldnn_launch((hipStream_t)stream, m, a, 1);
     case FAM_TCNN: return tcnn_fwd((hipStream_t)stream, m, a);
     case FAM_GMP: return gmp_fwd((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_fwd((hipStream_t)stream, m, a);
@@ -192,6 +197,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_DVR: return dvrjanet_launch((hipStream_t)stream, m, a, 2);
     case FAM_BOJ: return bojanet_launch((hipStream_t)stream, m, a, 2);
     case FAM_APN: return apnrru_launch((hipStream_t)stream, m, a, 2);
+    case FAM_MCL: return mcldnn_launch((hipStream_t)stream, m, a, 2);
     case FAM_TCNN: return tcnn_bwd((hipStream_t)stream, m, a);
     case FAM_GMP: return gmp_bwd((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_bwd((hipStream_t)stream, m, a);

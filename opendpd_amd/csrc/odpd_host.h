@@ -207,6 +207,11 @@ int dvrjanet_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int 
 int dvrjanet_rows(const odpd_model_t* m, int B);
 int64_t dvrjanet_param_count(const odpd_model_t* m);
 int64_t dvrjanet_ckpt_floats(const odpd_model_t* m, int B, int T);
+// mcldnn.hip (hidden = channels <= 16): mode 1 forward, 2 backward
+int mcldnn_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
+int mcldnn_rows(const odpd_model_t* m, int B);
+int64_t mcldnn_param_count(const odpd_model_t* m);
+int64_t mcldnn_ckpt_floats(const odpd_model_t* m, int B, int T);
 // apnrru_s16.hip (hidden <= 14): mode 1 forward, 2 backward
 int apnrru_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
 int apnrru_rows(const odpd_model_t* m, int B);

@@ -5,9 +5,8 @@ thx=0, thh=0)` — same constructor, attributes, `forward(x, h_0=None)` contract
 as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` as models.py:163-176.
 Backbones on the hot path run as HIP kernels (`backbone.native` is True) inside the kernels' envelope (one layer, hidden
 <= 32; pgjanet <= 16; tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32; dvrjanet <= 16 with <= 8 DVR units; bojanet <= 16; apnrru <= 14) and as ATen restatements (backbones/wide.py,
-`native` False, with a warning) beyond it; the remaining registry names (SURVEY §8 f4:
-mcldnn) is a torch restatements in backbones/extras.py that
-run through ATen (`backbone.native` is False) until they get kernels.  Unknown names raise ValueError (models.py:139-141).
+`native` False, with a warning) beyond it — backbones/wide.py for the hot-path names, backbones/extras.py for the SURVEY §8 f4 ones;
+mcldnn: <= 16 channels.  All 18 registry names are HIP-backed inside their envelopes.  Unknown names raise ValueError (models.py:139-141).
 """
 import torch
 import torch.nn as nn
@@ -103,7 +102,14 @@ class CoreModel(nn.Module):
         elif backbone_type == "neuraltx":
             self.backbone = B.NeuralTX(hidden_channels=hidden_size)
         elif backbone_type == "mcldnn":
-            self.backbone = X.MCLDNN(hidden_size=hidden_size)
+            from .backbones import mcldnn as MC
+            if hidden_size <= MC.MAX_HIDDEN:
+                self.backbone = B.MCLDNN(hidden_size=hidden_size)
+            else:
+                import warnings
+                warnings.warn(f"opendpd_amd: backbone 'mcldnn' with hidden_size={hidden_size} is outside the HIP kernel's envelope "
+                              f"(channels <= {MC.MAX_HIDDEN}): running the ATen restatement (backbones/extras.py)", stacklevel=2)
+                self.backbone = X.MCLDNN(hidden_size=hidden_size)
         else:
             raise ValueError(f"The backbone type '{backbone_type}' is not supported. Please add your own "
                              f"backbone under ./backbones and update models.py accordingly.")

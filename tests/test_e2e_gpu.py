@@ -408,9 +408,9 @@ def test_quantised_flow_with_pretrained_float_checkpoint_matches_reference(workd
     assert np.abs(sd[w].numpy() - ref_sd[w]).max() < 0.05          # and the two runs stay next to each other
 
 
-@pytest.mark.parametrize("bb,H", [("mcldnn", 8), ("apnrru", 8)])
+@pytest.mark.parametrize("bb,H", [("mcldnn", 20), ("apnrru", 8)])
 def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H):
-    """SURVEY §8 f4 names without a reference-logged anchor go through the same Project flow on the GPU — mcldnn (backbones/extras.py:
+    """SURVEY §8 f4 names without a reference-logged anchor go through the same Project flow on the GPU — mcldnn with 20 channels (beyond the kernels' envelope: backbones/extras.py,
     ATen forward/backward, torch.optim.AdamW) and apnrru (HIP kernels + fused AdamW; the reference's CLI does not list it among its
     --PA_backbone choices, so there is no reference log to anchor it to): device-resident frame loader, eval + metrics +
     checkpoint/log layout."""

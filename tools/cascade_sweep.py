@@ -18,7 +18,7 @@ lib = _lib.load()
 o = Oracle("f32")
 o64 = Oracle("f64")
 LIM = {"gru": 32, "dgru": 32, "qgru": 32, "qgru_amp1": 32, "lstm": 32, "vdlstm": 32, "deltagru": 32, "deltagru_tcnskip": 32, "pgjanet": 16,
-       "tcnn": 40, "gmp": 11, "rvtdcnn": 32, "neuraltx": 40, "deltajanet": 32, "dvrjanet": 16, "bojanet": 16, "apnrru": 14}
+       "tcnn": 40, "gmp": 11, "rvtdcnn": 32, "neuraltx": 40, "deltajanet": 32, "dvrjanet": 16, "bojanet": 16, "apnrru": 14, "mcldnn": 16}
 names = list(LIM)
 rng = np.random.RandomState(7)
 bad, kinks, illcond, worst, single = [], [], [], [0.0, 0.0], 0
@@ -30,6 +30,8 @@ for case in range(n_cases):
     lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
     B = int(rng.choice([1, 3, 4, 16, 17, 33, 64]))
     T = int(rng.choice([3, 5, 31, 32, 33, 50, 65, 120]))
+    if "mcldnn" in (dbb, pbb) and T < 4:
+        T = 4
     if {"bojanet", "apnrru"} & {dbb, pbb} and T < 15:
         T = 15 + T           # bojanet.py:72-73 cannot frame fewer than 15 samples
     kind = str(rng.choice(["l2", "l1"]))
@@ -56,7 +58,7 @@ for case in range(n_cases):
     pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
     u, _ = o.forward(md, pd, x)
     # the PA divides by |u| (polar features): skip the rare draws where the random DPD maps a sample next to the origin
-    if "vdlstm" in pbb or pbb in ("dgru", "deltagru", "pgjanet", "tcnn", "qgru_amp1", "rvtdcnn", "neuraltx", "deltajanet", "dvrjanet", "bojanet", "apnrru"):
+    if "vdlstm" in pbb or pbb in ("dgru", "deltagru", "pgjanet", "tcnn", "qgru_amp1", "rvtdcnn", "neuraltx", "deltajanet", "dvrjanet", "bojanet", "apnrru", "mcldnn"):
         if np.sqrt((u ** 2).sum(-1)).min() < 1e-3:
             continue
     y, _ = o.forward(mp, pp, u)

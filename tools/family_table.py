@@ -41,7 +41,7 @@ def data(B):
 
 CASES = [("gru", 11, {}), ("dgru", 13, {}), ("dgru", 23, {}), ("qgru", 10, {}), ("lstm", 14, {}), ("vdlstm", 13, {}),
          ("deltagru", 15, dict(thx=0.01, thh=0.05)), ("deltagru_tcnskip", 15, dict(thx=0.01, thh=0.05)), ("pgjanet", 11, {}),
-         ("tcnn", 35, {}), ("gmp", 11, {}), ("rvtdcnn", 25, {}), ("rvtdcnn", 6, {}), ("neuraltx", 36, {}), ("deltajanet", 15, {}), ("dvrjanet", 12, dict(num_dvr_units=3)), ("bojanet", 12, {}), ("apnrru", 8, {}), ("qgru W8A8 (QAT)", 10, dict(qat=(8, 8))), ("qgru_amp1 W8A8 (QAT)", 10, dict(qat=(8, 8)))]
+         ("tcnn", 35, {}), ("gmp", 11, {}), ("rvtdcnn", 25, {}), ("rvtdcnn", 6, {}), ("neuraltx", 36, {}), ("deltajanet", 15, {}), ("dvrjanet", 12, dict(num_dvr_units=3)), ("bojanet", 12, {}), ("apnrru", 8, {}), ("mcldnn", 8, {}), ("qgru W8A8 (QAT)", 10, dict(qat=(8, 8))), ("qgru_amp1 W8A8 (QAT)", 10, dict(qat=(8, 8)))]
 rows = []
 only = a.only.split(",") if a.only else None
 for bb, H, kw in CASES:

@@ -46,7 +46,7 @@ def at_start(t):
 
 
 for it in range(cases):
-    H = 11 if bb == "gmp" else int(rng.randint(1, (15 if bb == "apnrru" else 17 if bb in ("pgjanet", "dvrjanet", "bojanet") else 41 if bb in ("tcnn", "neuraltx") else 33)))
+    H = 11 if bb == "gmp" else int(rng.randint(1, (15 if bb == "apnrru" else 17 if bb in ("pgjanet", "dvrjanet", "bojanet", "mcldnn") else 41 if bb in ("tcnn", "neuraltx") else 33)))
     force = bool(rng.randint(2))
     lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
     B = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
@@ -55,6 +55,8 @@ for it in range(cases):
         T = max(1, 6000 // B)
     if bb in ("vdlstm", "rvtdcnn") and T < 3:
         T = 3
+    if bb == "mcldnn" and T < 4:
+        T = 4
     if bb in ("bojanet", "apnrru") and T < 15:
         T = 15 + T
     print(it, bb, H, B, T, force, flush=True)

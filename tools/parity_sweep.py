@@ -20,7 +20,7 @@ o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
          "tcnn": list(range(1, 40)) + [48, 63, 64], "gmp": [11] * 12, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
-         "neuraltx": list(range(1, 40)) + [48, 63, 64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15)}
+         "neuraltx": list(range(1, 40)) + [48, 63, 64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15), "mcldnn": range(1, 17)}
 rng = np.random.RandomState(0)
 bad, kinks, illcond, worst = [], [], [], {}
 for bb, sizes in SIZES.items():
@@ -36,6 +36,8 @@ for bb, sizes in SIZES.items():
                     T = max(1, 6000 // B)
                 if bb in ("vdlstm", "rvtdcnn") and T < 3:
                     T = 3       # the 3-sample circular pad needs T >= 3 (vdlstm.py:66-74); shorter frames are refused (EINVAL)
+                if bb == "mcldnn" and T < 4:
+                    T = 4       # the circular window takes the frame's own last four samples (mcldnn.py:115-118)
                 if bb in ("bojanet", "apnrru") and T < 15:
                     T = 15 + T  # the reference cuts its 15-sample zero pad from the frame itself (bojanet.py:72-73)
                 kw = dict(thx=float(rng.choice([0.0, 0.01, 0.05])), thh=float(rng.choice([0.0, 0.02, 0.1]))) if "delta" in bb else {}

@@ -20,7 +20,7 @@ o = Oracle("f32")
 SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_amp1": range(1, 33), "lstm": range(1, 33),
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
          "tcnn": list(range(1, 40, 3)) + [64], "gmp": [11] * 16, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
-         "neuraltx": list(range(1, 40, 3)) + [64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15)}
+         "neuraltx": list(range(1, 40, 3)) + [64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15), "mcldnn": range(1, 17)}
 rng = np.random.RandomState(1)
 bad = []
 for bb, sizes in SIZES.items():
@@ -33,6 +33,8 @@ for bb, sizes in SIZES.items():
                 T = int(rng.choice([3, 4, 5, 31, 32, 33, 50, 65, 200]))
                 if B * T > 5000:
                     T = max(3, 5000 // B)
+                if bb == "mcldnn" and T < 4:
+                    T = 4
                 if bb in ("bojanet", "apnrru") and T < 15:
                     T = 15 + T
                 kind = str(rng.choice(["l2", "l1"]))
