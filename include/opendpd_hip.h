@@ -187,6 +187,15 @@ int odpd_clip_adamw_step_masked(void* stream, int64_t P, float* params, float* g
                                 double eps, double weight_decay, double max_norm, float* norm_out,
                                 const unsigned char* skip);
 
+/* The other optimisers of project.py:274-297, fused with clip_grad_norm_ the same way, with the hyper-parameters the reference
+ * constructs them with: ADAMW (betas .9/.999, eps 1e-8, weight_decay 0.01 — odpd_clip_adamw_step_masked), ADAM (the same without the
+ * decay), SGD (momentum 0.9: state1 = momentum buffer), RMSPROP (alpha 0.99, eps 1e-8: state2 = square average).  Both state
+ * buffers are P floats, zero before the first step.  (adabound, the fifth --opt_type choice, imports a package the reference does not
+ * ship: unavailable there and here.) */
+enum odpd_optimizer { ODPD_OPT_ADAMW = 0, ODPD_OPT_ADAM = 1, ODPD_OPT_SGD = 2, ODPD_OPT_RMSPROP = 3 };
+int odpd_clip_optim_step(void* stream, int kind, int64_t P, float* params, float* grad, float* state1, float* state2,
+                         int64_t step, double lr, double max_norm, float* norm_out, const unsigned char* skip);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,7 +61,10 @@ _EXPORTS = {
     "odpd_clip_adamw_step_masked": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                               C.c_void_p, C.c_void_p]),
+    "odpd_clip_optim_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
 }
+OPTIMIZER_IDS = {"adamw": 0, "adam": 1, "sgd": 2, "rmsprop": 3}      # enum odpd_optimizer
 
 _lib = None
 

@@ -93,13 +93,17 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(int64_t rows, int
     }
 }
 
-// single workgroup: P is ~1e3 (0.5-3 k parameters); everything stays in one CU
-__global__ __launch_bounds__(1024) void clip_adamw_kernel(int64_t P, float* __restrict__ p, float* __restrict__ g,
+// single workgroup: P is ~1e3 (0.5-3 k parameters); everything stays in one CU.
+// kind (enum odpd_optimizer): AdamW / Adam share the first branch (Adam = no decoupled decay);  SGD with momentum: buf = g at the first
+// step, then buf = momentum buf + g, p -= lr buf (torch/optim/sgd.py, dampening 0);  RMSprop: sq = alpha sq + (1 - alpha) g^2,
+// p -= lr g / (sqrt(sq) + eps) (torch/optim/rmsprop.py, no momentum, not centered).  Multiplies and adds are kept apart where torch
+// issues them as separate ATen ops.
+__global__ __launch_bounds__(1024) void clip_optim_kernel(int kind, int64_t P, float* __restrict__ p, float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, float step_size,
                                                           float bc2_sqrt, float decay, float w1, float b2, float w2,
                                                           float eps, float max_norm, float* __restrict__ norm_out,
                                                           float* __restrict__ loss_out, float inv_count,
-                                                          const unsigned char* __restrict__ skip) {
+                                                          const unsigned char* __restrict__ skip, int first_step) {
     __shared__ float sh[16];
     __shared__ float coef_s;
     if (loss_out && threadIdx.x == 0) loss_out[0] = g[P] * inv_count;   // column P of the reduced row = loss partial sum
@@ -120,12 +124,22 @@ __global__ __launch_bounds__(1024) void clip_adamw_kernel(int64_t P, float* __re
         if (skip && skip[i]) continue;
         float gi = g[i];
         if (max_norm > 0.f) { gi *= coef; g[i] = gi; }
-        float pi = p[i] * decay;
-        float mi = m[i] + (gi - m[i]) * w1;
-        float vi = v[i] * b2 + w2 * gi * gi;
-        float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi -= step_size * (mi / denom);
-        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (kind == ODPD_OPT_SGD) {             // step_size = lr, b2 = momentum
+            const float bi = first_step ? gi : __fadd_rn(__fmul_rn(m[i], b2), gi);
+            m[i] = bi;
+            p[i] = __fadd_rn(p[i], __fmul_rn(-step_size, bi));
+        } else if (kind == ODPD_OPT_RMSPROP) {  // step_size = lr, b2 = alpha, w2 = 1 - alpha
+            const float vi = __fadd_rn(__fmul_rn(v[i], b2), __fmul_rn(w2, __fmul_rn(gi, gi)));
+            v[i] = vi;
+            p[i] = __fadd_rn(p[i], __fmul_rn(-step_size, __fdiv_rn(gi, __fadd_rn(__fsqrt_rn(vi), eps))));
+        } else {
+            float pi = p[i] * decay;
+            float mi = m[i] + (gi - m[i]) * w1;
+            float vi = v[i] * b2 + w2 * gi * gi;
+            float denom = sqrtf(vi) / bc2_sqrt + eps;
+            pi -= step_size * (mi / denom);
+            p[i] = pi; m[i] = mi; v[i] = vi;
+        }
     }
 }
 
@@ -165,8 +179,26 @@ int odpd::launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* gra
     const float step_size = (float)(lr / bc1), bc2s = (float)sqrt(bc2);
     const float decay = (float)(1.0 - lr * weight_decay);
     const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
-    hipLaunchKernelGGL(clip_adamw_kernel, dim3(1), dim3(1024), 0, st, P, params, grad, exp_avg, exp_avg_sq, step_size, bc2s,
-                       decay, w1, (float)beta2, w2, (float)eps, (float)max_norm, norm_out, loss_out, inv_count, skip);
+    hipLaunchKernelGGL(clip_optim_kernel, dim3(1), dim3(1024), 0, st, (int)ODPD_OPT_ADAMW, P, params, grad, exp_avg, exp_avg_sq, step_size,
+                       bc2s, decay, w1, (float)beta2, w2, (float)eps, (float)max_norm, norm_out, loss_out, inv_count, skip, 0);
+    return (int)hipGetLastError();
+}
+
+// the optimisers of project.py:274-297 with the hyper-parameters the reference constructs them with
+extern "C" int odpd_clip_optim_step(void* stream, int kind, int64_t P, float* params, float* grad, float* state1, float* state2,
+                                    int64_t step, double lr, double max_norm, float* norm_out, const unsigned char* skip) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+    case ODPD_OPT_ADAMW: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.01, max_norm, norm_out, nullptr, 0.0f, skip);
+    case ODPD_OPT_ADAM: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.0, max_norm, norm_out, nullptr, 0.0f, skip);
+    case ODPD_OPT_SGD: case ODPD_OPT_RMSPROP: break;
+    default: return ODPD_EINVAL;
+    }
+    if (!params || !grad || !state1 || !state2 || P <= 0 || step <= 0) return ODPD_EINVAL;
+    const bool sgd = kind == ODPD_OPT_SGD;
+    const float b2 = sgd ? 0.9f : 0.99f, w2 = sgd ? 0.0f : (float)(1.0 - 0.99);
+    hipLaunchKernelGGL(clip_optim_kernel, dim3(1), dim3(1024), 0, st, kind, P, params, grad, state1, state2, (float)lr, 1.0f, 1.0f, 0.0f, b2, w2,
+                       1e-8f, (float)max_norm, norm_out, (float*)nullptr, 0.0f, skip, step == 1 ? 1 : 0);
     return (int)hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ from . import data as D
 from .metrics import calculate_metrics
 from .models import CascadedModel, CoreModel
 from .quant import get_quant_model
-from .train_funcs import FusedAdamW, net_eval, net_eval_pair, net_train
+from .train_funcs import FusedAdam, FusedAdamW, FusedRMSprop, FusedSGD, net_eval, net_eval_pair, net_train
 
 DEFAULTS = dict(  # arguments.py:8-89
     dataset_name=None, dataset_path=None, filename="", log_precision=8, step="run_dpd", eval_val=1, eval_test=1,
@@ -211,19 +211,20 @@ class Project:
         return {"l2": nn.MSELoss(), "l1": nn.L1Loss()}[self.loss_type]
 
     def build_optimizer(self, net):
-        if self.opt_type == "adamw":
-            try:
-                opt = FusedAdamW(net, lr=self.lr)
-            except TypeError:   # a registry backbone without HIP kernels (backbones/extras.py, wide.py): ATen path, torch optimiser
-                opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=self.lr)
-        elif self.opt_type == "adam":
-            opt = torch.optim.Adam(net.parameters(), lr=self.lr)
-        elif self.opt_type == "sgd":
-            opt = torch.optim.SGD(net.parameters(), lr=self.lr, momentum=0.9)
-        elif self.opt_type == "rmsprop":
-            opt = torch.optim.RMSprop(net.parameters(), lr=self.lr)
-        else:
+        # project.py:274-297.  A kernel-backed model steps through the fused HIP optimiser of its kind; a registry configuration beyond the
+        # kernels' envelope (backbones/extras.py, wide.py: ATen path) gets the torch optimiser the reference builds
+        fused = {"adamw": FusedAdamW, "adam": FusedAdam, "sgd": FusedSGD, "rmsprop": FusedRMSprop}
+        if self.opt_type == "adabound":
+            import adabound  # noqa: F401  — as the reference (project.py:284-286): a package it does not ship (ModuleNotFoundError there too)
+        if self.opt_type not in fused:
             raise RuntimeError("Please use a valid optimizer.")
+        try:
+            opt = fused[self.opt_type](net, lr=self.lr)
+        except TypeError:
+            params = [p for p in net.parameters() if p.requires_grad] if self.opt_type == "adamw" else net.parameters()
+            opt = {"adamw": lambda: torch.optim.AdamW(params, lr=self.lr), "adam": lambda: torch.optim.Adam(params, lr=self.lr),
+                   "sgd": lambda: torch.optim.SGD(params, lr=self.lr, momentum=0.9),
+                   "rmsprop": lambda: torch.optim.RMSprop(params, lr=self.lr)}[self.opt_type]()
         if getattr(self, "world", 1) > 1 and not isinstance(opt, FusedAdamW):
             raise RuntimeError("data-parallel training (WORLD_SIZE > 1) runs through the fused HIP optimiser: --opt_type adamw on "
                                "a kernel-backed model")

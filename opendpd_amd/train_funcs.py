@@ -38,6 +38,8 @@ class FusedAdamW:
     CoreModel, fused with clip_grad_norm_.  Exposes `param_groups[0]['lr']` like a torch optimizer so
     ReduceLROnPlateau-style schedulers (project.py:289-296) can drive it."""
 
+    kind = "adamw"
+
     def __init__(self, net, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, process_group=None):
         # a CascadedModel trains its DPD only: the PA is frozen (models.py:169-171, train_dpd.py:60-63)
         self.pa = None
@@ -188,6 +190,13 @@ class FusedAdamW:
         if frozen is not None and (frozen.device != flat.device or frozen.dtype != torch.uint8):
             # one byte per parameter, resident next to the parameters: the kernel skips those columns (no host sync, no extra launch)
             self.backbone.frozen_mask = frozen = frozen.to(device=flat.device, dtype=torch.uint8).contiguous()
+        if self.kind != "adamw":            # project.py:274-297's other optimisers, with the hyper-parameters the reference builds them with
+            rc = lib.odpd_clip_optim_step(stream, _lib.OPTIMIZER_IDS[self.kind], self.backbone.n_flat, _lib.ptr(flat), _lib.ptr(self.grad),
+                                          _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.step_count, float(g["lr"]),
+                                          float(max_norm or 0.0), _lib.ptr(self.norm), _lib.ptr(frozen) if frozen is not None else None)
+            if rc:
+                _lib.check(rc, "odpd_clip_optim_step")
+            return
         rc = lib.odpd_clip_adamw_step_masked(stream, self.backbone.n_flat, _lib.ptr(flat), _lib.ptr(self.grad),
                                              _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.step_count,
                                              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
@@ -198,7 +207,7 @@ class FusedAdamW:
 
     def can_run_epoch(self, loader):
         """True when odpd_train_epoch can drive a whole epoch: single fused backbone, one process, resident streams."""
-        return (self.pa is None and self.world_size() == 1 and getattr(self.backbone, "frozen_mask", None) is None
+        return (self.kind == "adamw" and self.pa is None and self.world_size() == 1 and getattr(self.backbone, "frozen_mask", None) is None
                 and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size"))
                 and loader.x.is_cuda and self.has_fused(min(loader.batch_size, loader.n), loader.frame_length)
                 and self.reads_frames())
@@ -258,6 +267,33 @@ class FrameBatch:
         self.desc = _lib.Frames(self.x.data_ptr(), self.y.data_ptr(), self.order.data_ptr(), self.order.numel(), frame_length, stride)
         self.shape = (self.order.numel(), frame_length, 2)
         self.device = self.x.device
+
+
+
+class FusedAdam(FusedAdamW):
+    """torch.optim.Adam(lr) as project.py:278-279 builds it (no weight decay) on the same fused step"""
+    kind = "adam"
+
+    def __init__(self, net, lr=5e-4, process_group=None):
+        super().__init__(net, lr=lr, weight_decay=0.0, process_group=process_group)
+
+
+class FusedSGD(FusedAdamW):
+    """torch.optim.SGD(lr, momentum=0.9) as project.py:276-277 builds it; `exp_avg` holds the momentum buffer"""
+    kind = "sgd"
+
+    def __init__(self, net, lr=5e-4, process_group=None):
+        super().__init__(net, lr=lr, weight_decay=0.0, process_group=process_group)
+        self.param_groups[0].update(momentum=0.9)
+
+
+class FusedRMSprop(FusedAdamW):
+    """torch.optim.RMSprop(lr) as project.py:287-288 builds it (alpha 0.99, eps 1e-8); `exp_avg_sq` holds the square average"""
+    kind = "rmsprop"
+
+    def __init__(self, net, lr=5e-4, process_group=None):
+        super().__init__(net, lr=lr, weight_decay=0.0, process_group=process_group)
+        self.param_groups[0].update(alpha=0.99)
 
 
 def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_count=None, timing=None):

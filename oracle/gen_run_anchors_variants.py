@@ -4,8 +4,9 @@ CPU, two train_pa epochs of gru H11 on DPA_200MHz (frame 50, batch 64, seed 0) w
     l1     --loss_type l1 --lr 1e-3                 (nn.L1Loss through the fused kernels' L1 branch)
     clip   --grad_clip_val 0.02 --lr 1e-3           (clip_grad_norm_ really clipping: the default 200 never does)
     noclip --grad_clip_val 0 --lr 1e-3              (train_funcs.py:41: clipping skipped)
-    sgd    --opt_type sgd --lr 1e-2                 (torch.optim.SGD(momentum 0.9) on gradients from the HIP autograd path)
+    sgd    --opt_type sgd --lr 1e-2                 (torch.optim.SGD(momentum 0.9): the fused HIP optimiser's SGD / Adam / RMSprop kinds since r02)
     adam   --opt_type adam --lr 1e-3
+    rmsprop --opt_type rmsprop --lr 1e-3
     stride7  dgru H8, --frame_length 37 --frame_stride 7 --batch_size 100   (strided frames addressed in place by the native epoch loop)
     layers2  gru H8 --PA_num_layers 2      hidden40  dgru H40             (beyond the kernels' envelope: ATen restatements, torch AdamW)
 -> tests/golden/ref_runs_variants.json.  Usage: python oracle/gen_run_anchors_variants.py"""
@@ -27,12 +28,17 @@ CASES2 = {"stride7": ["--PA_backbone", "dgru", "--PA_hidden_size", "8", "--frame
           "hidden40": ["--PA_backbone", "dgru", "--PA_hidden_size", "40", "--lr", "1e-3"]}
 CASES = {"l1": ["--loss_type", "l1", "--lr", "1e-3"], "clip": ["--grad_clip_val", "0.02", "--lr", "1e-3"],
          "noclip": ["--grad_clip_val", "0", "--lr", "1e-3"], "sgd": ["--opt_type", "sgd", "--lr", "1e-2"],
-         "adam": ["--opt_type", "adam", "--lr", "1e-3"]}
+         "adam": ["--opt_type", "adam", "--lr", "1e-3"], "rmsprop": ["--opt_type", "rmsprop", "--lr", "1e-3"]}
 
 
 def main():
-    out = {}
+    import sys
+    path = os.path.join(OUT, "ref_runs_variants.json")
+    only = sys.argv[1:]                                   # names to (re)generate; the others keep their stored rows
+    out = json.load(open(path)) if only and os.path.exists(path) else {}
     for name, extra in list(CASES.items()) + list(CASES2.items()):
+        if only and name not in only:
+            continue
         with tempfile.TemporaryDirectory() as tmp:
             env = dict(os.environ, PYTHONPATH=REF, PYTHONDONTWRITEBYTECODE="1")
             subprocess.check_call(["python", os.path.join(REF, "main.py"), "--step", "train_pa"] + BASE + extra, cwd=tmp, env=env,
@@ -40,7 +46,7 @@ def main():
             hist = pd.read_csv(glob.glob(f"{tmp}/log/DPA_200MHz/train_pa/history/*.csv")[0])
             out[name] = {"hist": hist.to_dict(orient="list"), "cmd": " ".join(BASE + extra)}
             print(name, hist[["TRAIN_LOSS", "VAL_NMSE", "TEST_ACLR_AVG"]].to_numpy().tolist())
-    json.dump(out, open(os.path.join(OUT, "ref_runs_variants.json"), "w"), indent=1)
+    json.dump(out, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -239,11 +239,11 @@ def test_gmp_as_dpd_of_a_neural_pa_matches_reference(workdir):
 
 @pytest.mark.parametrize("name,kw", [("l1", dict(loss_type="l1", lr=1e-3)), ("clip", dict(grad_clip_val=0.02, lr=1e-3)),
                                      ("noclip", dict(grad_clip_val=0, lr=1e-3)), ("sgd", dict(opt_type="sgd", lr=1e-2)),
-                                     ("adam", dict(opt_type="adam", lr=1e-3))])
+                                     ("adam", dict(opt_type="adam", lr=1e-3)), ("rmsprop", dict(opt_type="rmsprop", lr=1e-3))])
 def test_training_options_follow_their_reference_logs(workdir, name, kw):
     """two train_pa epochs of gru H11 with the options no other anchor exercises — L1 loss, a gradient clip that really clips, no
-    clipping, torch's SGD(momentum 0.9) / Adam stepping on gradients from the HIP autograd path — against the rows the REFERENCE
-    logged (tests/golden/ref_runs_variants.json, oracle/gen_run_anchors_variants.py)"""
+    clipping, and the SGD(momentum 0.9) / Adam / RMSprop kinds of the fused HIP optimiser (odpd_clip_optim_step) — against the rows the
+    REFERENCE logged (tests/golden/ref_runs_variants.json, oracle/gen_run_anchors_variants.py)"""
     import opendpd_amd as od
     ref = json.load(open(os.path.join(GOLDEN, "ref_runs_variants.json")))[name]["hist"]
     res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=11, frame_length=50, batch_size=64, n_epochs=2, seed=0,
