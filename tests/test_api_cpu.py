@@ -119,23 +119,35 @@ def test_lr_scheduler_mirrors_torch_reduce_on_plateau():
 
 
 def test_optimizer_choices_follow_the_reference():
-    """project.py:274-287: adam / sgd(momentum 0.9) / rmsprop are torch's classes with torch defaults; adamw is the fused HIP
-    optimiser for kernel-backed models; anything else raises like the reference."""
+    """project.py:274-287: adamw / adam / sgd(momentum 0.9) / rmsprop with torch's defaults — the fused HIP optimiser of that kind for a
+    kernel-backed model, torch's own class for a configuration beyond the kernels' envelope; adabound imports a package the reference
+    does not ship; anything else raises like the reference."""
+    import warnings
     import pytest
     import torch
     from types import SimpleNamespace
     from opendpd_amd import CoreModel
     from opendpd_amd.project import Project
-    from opendpd_amd.train_funcs import FusedAdamW
+    from opendpd_amd.train_funcs import FusedAdam, FusedAdamW, FusedRMSprop, FusedSGD
     net = CoreModel(2, 8, 1, "gru")
     mk = lambda t: SimpleNamespace(opt_type=t, lr=2e-3, decay_factor=0.1, patience=10, lr_end=1e-4)
     opt, sch = Project.build_optimizer(mk("sgd"), net)
-    assert isinstance(opt, torch.optim.SGD) and opt.param_groups[0]["momentum"] == 0.9 and opt.param_groups[0]["lr"] == 2e-3
-    assert isinstance(Project.build_optimizer(mk("adam"), net)[0], torch.optim.Adam)
-    assert isinstance(Project.build_optimizer(mk("rmsprop"), net)[0], torch.optim.RMSprop)
+    assert isinstance(opt, FusedSGD) and opt.kind == "sgd" and opt.param_groups[0]["momentum"] == 0.9 and opt.param_groups[0]["lr"] == 2e-3
+    assert isinstance(Project.build_optimizer(mk("adam"), net)[0], FusedAdam)
+    assert isinstance(Project.build_optimizer(mk("rmsprop"), net)[0], FusedRMSprop)
     opt, sch = Project.build_optimizer(mk("adamw"), net)
-    assert isinstance(opt, FusedAdamW) and opt.param_groups[0]["lr"] == 2e-3 and opt.param_groups[0]["weight_decay"] == 0.01
+    assert isinstance(opt, FusedAdamW) and opt.kind == "adamw" and opt.param_groups[0]["lr"] == 2e-3 and opt.param_groups[0]["weight_decay"] == 0.01
     assert (sch.factor, sch.patience, sch.min_lr) == (0.1, 10, 1e-4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wide = CoreModel(2, 40, 1, "gru")           # beyond the envelope: ATen restatement, torch's optimisers
+    opt, _ = Project.build_optimizer(mk("sgd"), wide)
+    assert isinstance(opt, torch.optim.SGD) and opt.param_groups[0]["momentum"] == 0.9 and opt.param_groups[0]["lr"] == 2e-3
+    assert isinstance(Project.build_optimizer(mk("adam"), wide)[0], torch.optim.Adam)
+    assert isinstance(Project.build_optimizer(mk("rmsprop"), wide)[0], torch.optim.RMSprop)
+    assert isinstance(Project.build_optimizer(mk("adamw"), wide)[0], torch.optim.AdamW)
+    with pytest.raises(ModuleNotFoundError):
+        Project.build_optimizer(mk("adabound"), net)
     with pytest.raises(RuntimeError):
         Project.build_optimizer(mk("lion"), net)
 
