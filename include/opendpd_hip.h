@@ -195,6 +195,10 @@ int odpd_clip_adamw_step_masked(void* stream, int64_t P, float* params, float* g
 enum odpd_optimizer { ODPD_OPT_ADAMW = 0, ODPD_OPT_ADAM = 1, ODPD_OPT_SGD = 2, ODPD_OPT_RMSPROP = 3 };
 int odpd_clip_optim_step(void* stream, int kind, int64_t P, float* params, float* grad, float* state1, float* state2,
                          int64_t step, double lr, double max_norm, float* norm_out, const unsigned char* skip);
+/* odpd_train_epoch stepping with one of these kinds */
+int odpd_train_epoch_opt(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, int opt_kind,
+                         float* params, float* grad, float* state1, float* state2, int64_t first_step, double lr, double max_norm,
+                         float* partials, float* workspace, float* losses_out);
 
 #ifdef __cplusplus
 }

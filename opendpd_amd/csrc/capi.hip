@@ -283,12 +283,12 @@ extern "C" int odpd_train_fwd_bwd_framed(void* stream, const odpd_model_t* m, in
 // backbone with a fused kernel): every step = fused fwd+loss+bwd on frames addressed inside the resident streams,
 // reduction, clip + AdamW; three launches per step issued back to back from C++, no host synchronisation, no
 // gather kernels, no Python between steps.  losses_out[i] = mean loss of batch i (device).
-extern "C" int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch,
-                                float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t first_step, double lr,
-                                double beta1, double beta2, double eps, double weight_decay, double max_norm,
-                                float* partials, float* workspace, float* losses_out) {
+// opt_kind < 0: AdamW with the given hyper-parameters; otherwise an enum odpd_optimizer kind with project.py's own
+static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, float* params, float* grad,
+                            float* state1, float* state2, int64_t first_step, int opt_kind, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, double max_norm, float* partials, float* workspace, float* losses_out) {
     if (!model_ok(m) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
-        fr->stride <= 0 || batch <= 0 || !params || !grad || !exp_avg || !exp_avg_sq || !partials || !losses_out || first_step <= 0)
+        fr->stride <= 0 || batch <= 0 || !params || !grad || !state1 || !state2 || !partials || !losses_out || first_step <= 0)
         return ODPD_EINVAL;
     if (!framed_train_ok(m)) return ODPD_EUNSUPPORTED;
     const int T = fr->frame_length;
@@ -308,9 +308,24 @@ extern "C" int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_ki
         if (rc) return rc;
         rc = odpd_reduce_partials(stream, rows, P, partials, grad, 0);
         if (rc) return rc;
-        rc = launch_clip_adamw(st, P, params, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, max_norm,
-                               nullptr, losses_out + i, a.inv_count);
+        rc = opt_kind < 0 ? launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
+                                              losses_out + i, a.inv_count)
+                          : launch_clip_optim(st, opt_kind, P, params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, a.inv_count);
         if (rc) return rc;
     }
     return 0;
+}
+extern "C" int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch,
+                                float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t first_step, double lr,
+                                double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                                float* partials, float* workspace, float* losses_out) {
+    return train_epoch_impl(stream, m, loss_kind, fr, batch, params, grad, exp_avg, exp_avg_sq, first_step, -1, lr, beta1, beta2, eps, weight_decay,
+                            max_norm, partials, workspace, losses_out);
+}
+extern "C" int odpd_train_epoch_opt(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, int opt_kind,
+                                    float* params, float* grad, float* state1, float* state2, int64_t first_step, double lr,
+                                    double max_norm, float* partials, float* workspace, float* losses_out) {
+    if (opt_kind < ODPD_OPT_ADAMW || opt_kind > ODPD_OPT_RMSPROP) return ODPD_EINVAL;
+    return train_epoch_impl(stream, m, loss_kind, fr, batch, params, grad, state1, state2, first_step, opt_kind, lr, 0, 0, 0, 0, max_norm, partials,
+                            workspace, losses_out);
 }

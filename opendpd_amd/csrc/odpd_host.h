@@ -164,6 +164,9 @@ int64_t gru_s16n_ckpt_floats(const odpd_model_t* m, int B, int T);
 int launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t step,
                       double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, float* norm_out,
                       float* loss_out, float inv_count, const unsigned char* skip = nullptr);
+// the same for the optimiser kinds of enum odpd_optimizer (project.py:274-297's hyper-parameters)
+int launch_clip_optim(hipStream_t st, int kind, int64_t P, float* params, float* grad, float* state1, float* state2, int64_t step, double lr,
+                      double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip = nullptr);
 int64_t gru_s16_workspace_floats(const odpd_model_t* m, int B, int T);
 int lstm_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);

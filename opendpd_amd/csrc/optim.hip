@@ -185,12 +185,11 @@ int odpd::launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* gra
 }
 
 // the optimisers of project.py:274-297 with the hyper-parameters the reference constructs them with
-extern "C" int odpd_clip_optim_step(void* stream, int kind, int64_t P, float* params, float* grad, float* state1, float* state2,
-                                    int64_t step, double lr, double max_norm, float* norm_out, const unsigned char* skip) {
-    hipStream_t st = (hipStream_t)stream;
+int odpd::launch_clip_optim(hipStream_t st, int kind, int64_t P, float* params, float* grad, float* state1, float* state2, int64_t step,
+                            double lr, double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip) {
     switch (kind) {
-    case ODPD_OPT_ADAMW: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.01, max_norm, norm_out, nullptr, 0.0f, skip);
-    case ODPD_OPT_ADAM: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.0, max_norm, norm_out, nullptr, 0.0f, skip);
+    case ODPD_OPT_ADAMW: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.01, max_norm, norm_out, loss_out, inv_count, skip);
+    case ODPD_OPT_ADAM: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.0, max_norm, norm_out, loss_out, inv_count, skip);
     case ODPD_OPT_SGD: case ODPD_OPT_RMSPROP: break;
     default: return ODPD_EINVAL;
     }
@@ -198,8 +197,12 @@ extern "C" int odpd_clip_optim_step(void* stream, int kind, int64_t P, float* pa
     const bool sgd = kind == ODPD_OPT_SGD;
     const float b2 = sgd ? 0.9f : 0.99f, w2 = sgd ? 0.0f : (float)(1.0 - 0.99);
     hipLaunchKernelGGL(clip_optim_kernel, dim3(1), dim3(1024), 0, st, kind, P, params, grad, state1, state2, (float)lr, 1.0f, 1.0f, 0.0f, b2, w2,
-                       1e-8f, (float)max_norm, norm_out, (float*)nullptr, 0.0f, skip, step == 1 ? 1 : 0);
+                       1e-8f, (float)max_norm, norm_out, loss_out, inv_count, skip, step == 1 ? 1 : 0);
     return (int)hipGetLastError();
+}
+extern "C" int odpd_clip_optim_step(void* stream, int kind, int64_t P, float* params, float* grad, float* state1, float* state2,
+                                    int64_t step, double lr, double max_norm, float* norm_out, const unsigned char* skip) {
+    return launch_clip_optim((hipStream_t)stream, kind, P, params, grad, state1, state2, step, lr, max_norm, norm_out, nullptr, 0.0f, skip);
 }
 
 extern "C" int odpd_clip_adamw_step(void* stream, int64_t P, float* params, float* grad, float* exp_avg,

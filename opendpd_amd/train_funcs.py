@@ -207,7 +207,7 @@ class FusedAdamW:
 
     def can_run_epoch(self, loader):
         """True when odpd_train_epoch can drive a whole epoch: single fused backbone, one process, resident streams."""
-        return (self.kind == "adamw" and self.pa is None and self.world_size() == 1 and getattr(self.backbone, "frozen_mask", None) is None
+        return (self.pa is None and self.world_size() == 1 and getattr(self.backbone, "frozen_mask", None) is None
                 and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size"))
                 and loader.x.is_cuda and self.has_fused(min(loader.batch_size, loader.n), loader.frame_length)
                 and self.reads_frames())
@@ -237,11 +237,17 @@ class FusedAdamW:
         fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
         g = self.param_groups[0]
         flat = self.backbone.flat_params(full_check=True)
-        rc = lib.odpd_train_epoch(_lib.stream_ptr(), C.byref(self.backbone.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
-                                  _lib.ptr(flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                                  self.step_count + 1, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                  float(g["eps"]), float(g["weight_decay"]), float(max_norm or 0.0), _lib.ptr(part),
-                                  _lib.ptr(ws), _lib.ptr(losses))
+        if self.kind == "adamw":
+            rc = lib.odpd_train_epoch(_lib.stream_ptr(), C.byref(self.backbone.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
+                                      _lib.ptr(flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                      self.step_count + 1, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                      float(g["eps"]), float(g["weight_decay"]), float(max_norm or 0.0), _lib.ptr(part),
+                                      _lib.ptr(ws), _lib.ptr(losses))
+        else:
+            rc = lib.odpd_train_epoch_opt(_lib.stream_ptr(), C.byref(self.backbone.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
+                                          _lib.OPTIMIZER_IDS[self.kind], _lib.ptr(flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
+                                          _lib.ptr(self.exp_avg_sq), self.step_count + 1, float(g["lr"]), float(max_norm or 0.0),
+                                          _lib.ptr(part), _lib.ptr(ws), _lib.ptr(losses))
         _lib.check(rc, "odpd_train_epoch")
         self.step_count += n_steps
         self._keepalive = order     # the launches read `order` asynchronously
