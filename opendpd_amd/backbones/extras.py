@@ -1,12 +1,13 @@
-"""Registry backbones that do not have HIP kernels yet: rvtdcnn, neuraltx, mcldnn, bojanet, apnrru,
-dvrjanet, deltajanet (gmp moved to csrc/gmp.hip).
+"""Torch restatements of the SURVEY §8 f4 registry backbones (rvtdcnn, neuraltx, mcldnn, bojanet, apnrru, dvrjanet, deltajanet) for
+configurations BEYOND their HIP kernels' envelopes (csrc/{rvtdcnn,tcnn,mcldnn,bojanet_s16,apnrru_s16,dvrjanet_s16,delta_s16}.hip: hidden /
+channel limits, see models.py) — inside the envelopes the registry builds the kernel-backed classes of this package.
 
-These are plain torch restatements of what the reference modules compute (same parameter names / shapes / registration
-order so checkpoints interchange, same initialisation order so a seeded construction gives the reference's state dict;
-`tests/test_extras_cpu.py` pins outputs and gradients to vectors produced by running the reference).  They run through
-ATen on whatever device their tensors live on — they are NOT part of the MI355X-native hot path, `FusedAdamW` refuses
-them and `Project.build_optimizer` gives them `torch.optim.AdamW`; `CoreModel(..).backbone.native` is False for them.
-Where the reference module has an observable quirk it is kept and marked `# ref quirk`.
+Plain restatements of what the reference modules compute (same parameter names / shapes / registration order so checkpoints
+interchange, same initialisation order so a seeded construction gives the reference's state dict; `tests/test_extras_cpu.py` pins
+outputs and gradients to vectors produced by running the reference).  They run through ATen on whatever device their tensors live
+on — they are NOT part of the MI355X-native hot path: `CoreModel(..).backbone.native` is False for them, a warning says so at
+construction, the fused optimisers refuse them and `Project.build_optimizer` gives them torch's.  Where the reference module has an
+observable quirk it is kept and marked `# ref quirk`.
 """
 import torch
 import torch.nn as nn
