@@ -408,7 +408,9 @@ __device__ __forceinline__ void s16n_write_row(float* prow, const GruLayout& L, 
 // the frozen-model variants (no weight-gradient accumulators) run two waves per SIMD like the forward kernel — except the fused
 // frozen-PA step (MODE 0 without NW) with four K-chunks in the last unit tile (hidden 25..32): under the 256-register cap of an
 // eight-wave workgroup it spills 160..220 B per lane and its DGRU instantiation then computes wrong losses / gradients for hidden
-// 29..32 (1e-2 relative; the same source at one wave per SIMD is exact, as are the two-chunk builds at two).  tools/s16n_crosscheck.py
+// 29..32 (1e-2 relative; the same source at one wave per SIMD is exact, as are the two-chunk builds at two; the eight-wave four-chunk build is
+// exact as well when compiled at -O1 or with `-mllvm -enable-post-misched=false`, i.e. the post-RA scheduler mis-orders something in that
+// spilling instantiation — disabling it for the whole library costs 1..10 % elsewhere, so the launch shape avoids the build instead).  tools/s16n_crosscheck.py
 // runs every flavour x feature set x hidden 17..32 against the oracle; tests/test_cascade_gpu.py pins hidden 29, 31, 32.
 constexpr bool s16n_two_waves_per_simd(int mode, bool nw, int nck) { return mode == 1 || (mode == 2 && !nw) || (mode == 0 && !nw && nck <= 2); }
 template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
