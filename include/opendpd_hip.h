@@ -43,7 +43,7 @@ enum odpd_backbone {
     ODPD_NEURALTX = 12,  /* backbones/neuraltx.py:5-137 (hidden = hidden_channels; complex 5-tap FIR + the TCNN stack on 4 features) */
     ODPD_DELTAJANET = 13, /* backbones/deltajanet.py:11-274 (two-gate delta cell; the wrapper fixes both thresholds at 0) */
     ODPD_DVRJANET = 14,  /* backbones/dvrjanet.py:5-112 (num_dvr_units rides in odpd_model_t::bits_w) */
-    ODPD_BOJANET = 15,   /* backbones/bojanet.py:5-138 (16-tap complex FIR bank, vector demodulator, JANET cell, phase re-rotation; hidden <= 18) */
+    ODPD_BOJANET = 15,   /* backbones/bojanet.py:5-138 (16-tap complex FIR bank, vector demodulator, JANET cell, phase re-rotation; hidden <= 16 — the reference's own forward stops at 18) */
     ODPD_APNRRU = 16,    /* backbones/apnrru.py:5-152 (3-filter FIR bank + raw sample, phase-normalised RRU cell on a complex state; hidden <= 14) */
     ODPD_MCLDNN = 17,    /* backbones/mcldnn.py:9-134 (two conv branches on a 5x5 feature patch merged by a third, LSTM(5C -> 8), two linear layers; hidden = C) */
     ODPD_BACKBONE_COUNT = 18
