@@ -20,9 +20,14 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 BASE = ["--dataset_name", "DPA_200MHz", "--accelerator", "cpu", "--frame_length", "50", "--batch_size", "64", "--seed", "0", "--lr", "2e-3",
         "--n_epochs", "1", "--PA_backbone", "gru", "--PA_hidden_size", "11"]
 CASES = {"rvtdcnn": 6, "bojanet": 8, "deltajanet": 10, "dvrjanet": 8, "neuraltx": 12, "mcldnn": 8}
+# `python oracle/gen_run_anchors_extras_dpd.py hot`: the hot-path backbones in the DPD role -> ref_runs_hot_dpd.{json,npz}
+HOT = {"gru": 11, "dgru": 9, "lstm": 10, "vdlstm": 9, "tcnn": 20, "qgru": 10, "qgru_amp1": 10, "deltagru": 12}
 
 
 def main():
+    import sys
+    hot = len(sys.argv) > 1 and sys.argv[1] == "hot"
+    cases, stem = (HOT, "ref_runs_hot_dpd") if hot else (CASES, "ref_runs_extras_dpd")
     out = {}
     env = dict(os.environ, PYTHONPATH=REF, PYTHONDONTWRITEBYTECODE="1")
     with tempfile.TemporaryDirectory() as tmp:
@@ -30,10 +35,10 @@ def main():
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
         pa = glob.glob(f"{tmp}/save/DPA_200MHz/train_pa/*.pt")[0]
         sd = torch.load(pa, map_location="cpu")
-        np.savez_compressed(os.path.join(OUT, "ref_runs_extras_dpd.npz"), **{"pa/" + k: v.numpy() for k, v in sd.items()})
+        np.savez_compressed(os.path.join(OUT, stem + ".npz"), **{"pa/" + k: v.numpy() for k, v in sd.items()})
         out["pa_model"] = os.path.relpath(pa, tmp)
-        for bb, H in CASES.items():
-            extra = ["--DPD_backbone", bb, "--DPD_hidden_size", str(H)]
+        for bb, H in cases.items():
+            extra = ["--DPD_backbone", bb, "--DPD_hidden_size", str(H)] + (["--thx", "0.01", "--thh", "0.03"] if bb == "deltagru" else [])
             for d in ("log/DPA_200MHz/train_dpd", "save/DPA_200MHz/train_dpd"):
                 shutil.rmtree(os.path.join(tmp, d), ignore_errors=True)
             try:
@@ -46,7 +51,7 @@ def main():
             model = glob.glob(f"{tmp}/save/DPA_200MHz/train_dpd/*/*.pt")[0]
             out[bb] = {"hist": hist.to_dict(orient="list"), "hidden": H, "model": os.path.relpath(model, tmp), "cmd": " ".join(BASE + extra)}
             print(bb, os.path.basename(model), hist.iloc[0].to_dict(), flush=True)
-    json.dump(out, open(os.path.join(OUT, "ref_runs_extras_dpd.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(OUT, stem + ".json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
