@@ -35,7 +35,7 @@ def main():
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
         pa = glob.glob(f"{tmp}/save/DPA_200MHz/train_pa/*.pt")[0]
         sd = torch.load(pa, map_location="cpu")
-        np.savez_compressed(os.path.join(OUT, stem + ".npz"), **{"pa/" + k: v.numpy() for k, v in sd.items()})
+        arrays = {"pa/" + k: v.numpy() for k, v in sd.items()}
         out["pa_model"] = os.path.relpath(pa, tmp)
         for bb, H in cases.items():
             extra = ["--DPD_backbone", bb, "--DPD_hidden_size", str(H)] + (["--thx", "0.01", "--thh", "0.03"] if bb == "deltagru" else [])
@@ -50,7 +50,20 @@ def main():
             hist = pd.read_csv(glob.glob(f"{tmp}/log/DPA_200MHz/train_dpd/*/history/*.csv")[0])
             model = glob.glob(f"{tmp}/save/DPA_200MHz/train_dpd/*/*.pt")[0]
             out[bb] = {"hist": hist.to_dict(orient="list"), "hidden": H, "model": os.path.relpath(model, tmp), "cmd": " ".join(BASE + extra)}
+            # the trained DPD and what main.py --step run_dpd exports with it (dpd_out/<id>.csv: I, Q, I_dpd, Q_dpd)
+            shutil.rmtree(os.path.join(tmp, "dpd_out"), ignore_errors=True)
+            try:
+                subprocess.check_call(["python", os.path.join(REF, "main.py"), "--step", "run_dpd"] + BASE + extra, cwd=tmp, env=env,
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1200)
+                csv = glob.glob(f"{tmp}/dpd_out/*.csv")[0]
+                out[bb]["dpd_out"] = os.path.relpath(csv, tmp)
+                arrays[f"{bb}/dpd_out"] = pd.read_csv(csv).to_numpy().astype(np.float64)
+                for k, v in torch.load(model, map_location="cpu").items():
+                    arrays[f"{bb}/sd/{k}"] = v.numpy()
+            except Exception as e:      # noqa: BLE001
+                print(bb, "run_dpd FAILED", e)
             print(bb, os.path.basename(model), hist.iloc[0].to_dict(), flush=True)
+        np.savez_compressed(os.path.join(OUT, stem + ".npz"), **arrays)
     json.dump(out, open(os.path.join(OUT, stem + ".json"), "w"), indent=1)
 
 

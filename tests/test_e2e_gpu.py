@@ -229,6 +229,20 @@ def test_f4_backbones_as_dpd_follow_their_reference_logs(workdir, bb):
     assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < tol_l * rh["TRAIN_LOSS"][0], (hist["TRAIN_LOSS"][0], rh["TRAIN_LOSS"][0])
     for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
         assert abs(hist[col][0] - rh[col][0]) < tol_db, (col, hist[col][0], rh[col][0])
+    _run_dpd_with_reference_weights(od, r, m, bb, dict(DPD_backbone=bb, DPD_hidden_size=r["hidden"]))
+
+
+def _run_dpd_with_reference_weights(od, r, m, bb, kw):
+    """run_dpd with the REFERENCE's trained DPD weights reproduces the CSV its own run_dpd exported (where the reference's run_dpd runs)"""
+    if "dpd_out" not in r:
+        return
+    torch.save({k[len(bb) + 4:]: torch.from_numpy(v) for k, v in m.items() if k.startswith(bb + "/sd/")}, r["model"])
+    out = od.run_dpd(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=11, frame_length=50, seed=0, accelerator="cuda", **kw)
+    assert os.path.normpath(out["output_path"]) == os.path.normpath(r["dpd_out"])
+    csv = pd.read_csv(out["output_path"])
+    assert list(csv.columns) == ["I", "Q", "I_dpd", "Q_dpd"]
+    ref_csv = m[bb + "/dpd_out"]
+    assert np.abs(csv.to_numpy() - ref_csv).max() < 2e-5 * max(1.0, np.abs(ref_csv).max())
 
 
 @pytest.mark.parametrize("bb", ["gru", "dgru", "lstm", "vdlstm", "tcnn", "deltagru"])
@@ -256,6 +270,7 @@ def test_hot_path_backbones_as_dpd_follow_their_reference_logs(workdir, bb):
         assert abs(hist[col][0] - rh[col][0]) < tol_db, (col, hist[col][0], rh[col][0])
     if bb == "deltagru":
         assert abs(hist["SP_T_DX"][0] - rh["SP_T_DX"][0]) < 0.01 and abs(hist["SP_T_DH"][0] - rh["SP_T_DH"][0]) < 0.02
+    _run_dpd_with_reference_weights(od, r, m, bb, dict(DPD_backbone=bb, DPD_hidden_size=r["hidden"], **kw))
 
 
 def test_gmp_as_dpd_of_a_neural_pa_matches_reference(workdir):
