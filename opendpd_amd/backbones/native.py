@@ -73,7 +73,9 @@ class _BackboneFn(torch.autograd.Function):
         x = x.contiguous().float()
         B, T = x.shape[0], x.shape[1]
         flat = mod.flat_params()
-        need_grad = any(ctx.needs_input_grad)
+        # (needs_input_grad looks at requires_grad only: under torch.no_grad() — net_eval, run_dpd — nothing will call backward, so no
+        # checkpoints are asked for and the kernels may take their inference path)
+        need_grad = mod._grad_mode and any(ctx.needs_input_grad)      # (autograd switches grad mode off inside forward: the module records it)
         if mod.dx_needs_flag:
             # delta backbones: dL/dx lives in the 16-sequences-per-wave kernels only; the flag routes forward, checkpoint sizing
             # and backward of THIS call to them (include/opendpd_hip.h: ODPD_FLAG_NEED_DX)
@@ -192,4 +194,5 @@ class NativeBackbone(nn.Module):
         return None
 
     def forward(self, x, h_0=None):
+        self._grad_mode = torch.is_grad_enabled()
         return _BackboneFn.apply(x, self, *self.parameters())

@@ -382,10 +382,21 @@ __global__ __launch_bounds__(kMaxThreads) void gru_fwd_kernel(SeqArgs a) {
             const int len = min(kChunk, a.T - t0);
             stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
             wave_lds_fence();
+            // the sample and its features are formed one step AHEAD of the step that consumes them: the LDS read, sqrt and rcp are then off
+            // the recurrence's dependent chain (a lone wave at small batch / evaluation is bound by that chain)
+            float fnext[F];
+            {
+                const float2 x0 = xs[s * kChunkPad];
+                feat_fwd<FM>(x0.x, x0.y, fnext);
+            }
             for (int tt = 0; tt < len; ++tt) {
-                const float2 xv = xs[s * kChunkPad + tt];
                 float f[F], r, z, n, ghn, y0, y1;
-                feat_fwd<FM>(xv.x, xv.y, f);
+#pragma unroll
+                for (int i = 0; i < F; ++i) f[i] = fnext[i];
+                {
+                    const float2 xn = xs[s * kChunkPad + min(tt + 1, len - 1)];
+                    feat_fwd<FM>(xn.x, xn.y, fnext);
+                }
                 gru_cell_fwd<R, FM, DG>(w, whh, f, h, r, z, n, ghn);
                 float act = h;
                 if constexpr (DG) act = __builtin_fmaxf(tab_rotdot<R>(w.bhid, tlane, T::kHID, h), 0.0f);
@@ -399,6 +410,117 @@ __global__ __launch_bounds__(kMaxThreads) void gru_fwd_kernel(SeqArgs a) {
             stage_out<SPW>(ys, a.y, b0, a.B, a.T, t0, len, lane);
             wave_lds_fence();
         }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// evaluation kernel (net_eval / run_dpd, train_funcs.py:57-90: a few very long sequences — (1, 19 662, 2), (3, 2 560, 2) — where one
+// wave per sequence runs alone on its SIMD and the step time is the whole cost; the row-rotated forward spends half of it on its 45
+// half-rate v_fmac_dpp).  Gate-parallel mapping, hidden <= 16, ONE sequence per wave: the four 16-lane rows of the wave hold the same h
+// and each does ONE of the step's four mat-vecs with its own rotated weights — row 0: r, row 1: n (W_in x apart from W_hn h), row 3: z,
+// row 2: the head of the PREVIOUS step (fc_hid for DGRU, fc_out) — so a step issues one rotated dot product (15 v_fmac_dpp) instead of
+// three or four.  The gates meet through three cross-row moves on the VALU (gfx950's v_permlane16_swap / v_permlane32_swap): r to the
+// n row, n <-> z between rows 1 and 3, h' from rows 1 / 3 to rows 0 / 2.  Same arithmetic per element as gru_cell_fwd (the recurrent
+// sums run as two chains instead of one).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float xor32(float v) {       // lane i <-> lane i ^ 32
+    const int iv = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);      // r[0] = (lo, lo), r[1] = (hi, hi)
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xor16(float v) {       // lane i <-> lane i ^ 16
+    const int iv = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);      // r[0] = rows (0, 0, 2, 2), r[1] = rows (1, 1, 3, 3)
+    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
+}
+template <int FM, bool DG>
+__global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
+    constexpr int F = FeatDim<FM>::F;
+    using T = GruTabs<1, DG>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // 0 r | 1 n | 2 head | 3 z
+    const GruLayout L = gru_layout(a.H, F, DG);
+    const int H = L.H, OW = DG ? H + 6 : H;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_gru_tabs<1, DG, false>(tab, pl, L, lane, 0, 1);
+    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    float2* xs = reinterpret_cast<float2*>(tab + T::kFloats);
+    float2* ys = xs + kChunkPad;
+    const bool vo = col < H;
+    // the row's own operands
+    const int gate = role == 0 ? 0 : role == 3 ? 1 : 2;
+    float win[F], wrec[16];
+#pragma unroll
+    for (int i = 0; i < F; ++i) win[i] = (vo && role != 2) ? pl[L.o_w_ih + (gate * H + col) * F + i] : 0.0f;
+    float b_in = 0.0f, b_rec = 0.0f;
+    if (vo) {
+        if (role == 0 || role == 3) b_in = pl[L.o_b_ih + gate * H + col] + pl[L.o_b_hh + gate * H + col];
+        if (role == 1) { b_in = pl[L.o_b_ih + 2 * H + col]; b_rec = pl[L.o_b_hh + 2 * H + col]; }
+        if (role == 2 && DG) b_rec = pl[L.o_b_hid + col];
+    }
+    if (role != 2 || DG) load_rot(wrec, tlane + (role == 2 ? T::kHID : T::kHH + gate) * 4 * 64);
+    else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wrec[k] = 0.0f;
+    }
+    const float wo0 = vo ? pl[L.o_w_out + col] : 0.0f, wo1 = vo ? pl[L.o_w_out + OW + col] : 0.0f;
+    const float wf0 = (DG && col < 6) ? pl[L.o_w_out + H + col] : 0.0f, wf1 = (DG && col < 6) ? pl[L.o_w_out + OW + H + col] : 0.0f;
+    const float bo0 = pl[L.o_b_out], bo1 = pl[L.o_b_out + 1];
+    const bool odd = role & 1;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        float h = 0.0f, fsp = 0.0f;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * a.T;
+        float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * a.T;
+        auto head = [&](float arec, float hcur, float& y0, float& y1) {     // row 2: y of the state `hcur` (arec = b_hid + fc_hid hcur)
+            const float act = DG ? __builtin_fmaxf(arec, 0.0f) : hcur;
+            y0 = row_sum16(__builtin_fmaf(wo0, act, wf0 * fsp)) + bo0;
+            y1 = row_sum16(__builtin_fmaf(wo1, act, wf1 * fsp)) + bo1;
+        };
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            wave_lds_fence();
+            if (lane < kChunk) xs[lane] = lane < len ? xg[t0 + lane] : make_float2(0.5f, 0.5f);
+            wave_lds_fence();
+            float fnext[F];
+            feat_fwd<FM>(xs[0].x, xs[0].y, fnext);
+            for (int tt = 0; tt < len; ++tt) {
+                float f[F];
+#pragma unroll
+                for (int i = 0; i < F; ++i) f[i] = fnext[i];
+                {
+                    const float2 xn = xs[min(tt + 1, len - 1)];        // the next step's sample and features, off the recurrence's chain
+                    feat_fwd<FM>(xn.x, xn.y, fnext);
+                }
+                float ain = b_in;
+#pragma unroll
+                for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[i], f[i], ain);
+                const float arec = rotdot(b_rec, wrec, h);
+                // head of the previous step rides on this step's mat-vec (row 2); ys[tt] <-> time t0 + tt - 1
+                float y0, y1;
+                head(arec, h, y0, y1);
+                if (lane == 32) ys[tt] = make_float2(y0, y1);
+                const float sg = sigmoidf_(ain + arec);                 // r (row 0), z (row 3)
+                const float r1 = xor16(sg);                             // row 1 <- r
+                const float n = tanhf_(__builtin_fmaf(r1, arec, ain));  // row 1
+                const float v = role == 1 ? n : sg;
+                const float o = xor32(v);                               // row 1 <- z, row 3 <- n
+                const float zz = role == 1 ? o : sg, nn = role == 1 ? n : o;
+                const float h13 = __builtin_fmaf(zz, h - nn, nn);       // rows 1 and 3: (1 - z) n + z h
+                const float h02 = xor16(h13);
+                h = odd ? h13 : h02;
+                if constexpr (DG) fsp = feat_select<6>(f, col, 0.0f);
+            }
+            wave_lds_fence();
+            if (lane < len && t0 + lane >= 1) yg[t0 + lane - 1] = ys[lane];
+        }
+        // the head of the last state
+        const float arec = rotdot(b_rec, wrec, h);
+        float y0, y1;
+        head(arec, h, y0, y1);
+        if (lane == 32) yg[a.T - 1] = make_float2(y0, y1);
     }
 }
 
@@ -766,9 +888,28 @@ bool gru_split_uses_s16(const odpd_model_t* m, int B) {
     return B >= min_batch;
 }
 
+// inference on a few long sequences (no checkpoints asked for): the gate-parallel evaluation kernel, one sequence per wave
+template <int FM, bool DG>
+static int launch_eval(hipStream_t st, const SeqArgs& a, int P) {
+    const size_t lds = ((size_t)pad4(P) + GruTabs<1, DG>::kFloats + 2 * 2 * kChunkPad) * sizeof(float);
+    auto k = gru_eval_kernel<FM, DG>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
+    return (int)hipGetLastError();
+}
+bool gru_uses_eval_kernel(const odpd_model_t* m, int B, int T, bool want_ckpt) {
+    int FM, R, P; bool DG;
+    return gru_setup(m, FM, DG, R, P) && R == 1 && !want_ckpt && B <= 8 && T >= 256 && tuning().s16_min_batch != 0;
+}
 int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    if (gru_uses_eval_kernel(m, a.B, a.T, a.ckpt != nullptr)) {
+        if (FM == FEAT_RAW2) return launch_eval<FEAT_RAW2, false>(st, a, P);
+        if (FM == FEAT_DGRU6) return launch_eval<FEAT_DGRU6, true>(st, a, P);
+        if (FM == FEAT_Q4) return launch_eval<FEAT_Q4, false>(st, a, P);
+        return launch_eval<FEAT_A4, false>(st, a, P);
+    }
     if (gru_split_uses_s16(m, a.B)) return gru_s16_fwd(st, m, a);
     if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 1);
     ODPD_GRU_DISPATCH_ALL(launch_fwd, st, a, P)

@@ -249,3 +249,31 @@ def test_fused_step_on_frames_addressed_in_place(bb, H, B, T, stride):
                 loss = fused_train_step(opt, xs[idx].contiguous(), ys[idx].contiguous(), "l2", 200.0)
         outs.append((net.backbone.flat_params().clone(), float(loss)))
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+
+
+@pytest.mark.parametrize("bb", ["gru", "dgru", "qgru", "qgru_amp1"])
+@pytest.mark.parametrize("H", [1, 8, 13, 16])
+@pytest.mark.parametrize("B,T", [(1, 700), (3, 2560), (2, 256), (8, 257)])
+def test_evaluation_kernel_matches_the_oracle(bb, H, B, T):
+    """inference on a few long sequences (net_eval / run_dpd shapes; torch.no_grad(), so no checkpoints are asked for) runs the
+    gate-parallel evaluation kernel (gru_eval_kernel: one sequence per wave, the four rows of the wave do r / n / head / z): against
+    the oracle, and against the row-rotated forward the same call takes when gradients are enabled"""
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 10 + B)
+    net = CoreModel(2, H, 1, bb).cuda().eval()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(T)
+    amp, ph = 0.05 + 0.85 * torch.rand(B, T, 1, generator=g), 2 * np.pi * torch.rand(B, T, 1, generator=g)
+    x = torch.cat((amp * torch.cos(ph), amp * torch.sin(ph)), -1)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    yo, _ = Oracle("f32").forward(make_model(bb, H), p, x.numpy())
+    with torch.no_grad():
+        y_eval = net(x.cuda()).cpu().numpy()
+    y_train = net(x.cuda().requires_grad_(True)).detach().cpu().numpy()        # gradients enabled: checkpoints -> the row-rotated forward
+    assert rel_err(y_eval, yo) < FWD_TOL and rel_err(y_train, yo) < FWD_TOL
+    assert rel_err(y_eval, y_train) < 5e-6
+    assert H == 1 or not np.array_equal(y_eval, y_train)          # two kernels: different summation order of the recurrent sums
