@@ -416,10 +416,10 @@ __global__ __launch_bounds__(kMaxThreads) void gru_fwd_kernel(SeqArgs a) {
 // -------------------------------------------------------------------------------------------------
 // evaluation kernel (net_eval / run_dpd, train_funcs.py:57-90: a few very long sequences — (1, 19 662, 2), (3, 2 560, 2) — where one
 // wave per sequence runs alone on its SIMD and the step time is the whole cost; the row-rotated forward spends half of it on its 45
-// half-rate v_fmac_dpp).  Gate-parallel mapping, hidden <= 16, ONE sequence per wave: the four 16-lane rows of the wave hold the same h
+// half-rate v_fmac_dpp).  Gate-parallel mapping, ONE sequence per wave: the four 16-lane rows of the wave hold the same h
 // and each does ONE of the step's four mat-vecs with its own rotated weights — row 0: r, row 1: n (W_in x apart from W_hn h), row 3: z,
 // row 2: the head of the PREVIOUS step (fc_hid for DGRU, fc_out) — so a step issues one rotated dot product (15 v_fmac_dpp) instead of
-// three or four.  The gates meet through three cross-row moves on the VALU (gfx950's v_permlane16_swap / v_permlane32_swap): r to the
+// three or four (hidden 17..32: four instead of sixteen).  The gates meet through three cross-row moves on the VALU (gfx950's v_permlane16_swap / v_permlane32_swap): r to the
 // n row, n <-> z between rows 1 and 3, h' from rows 1 / 3 to rows 0 / 2.  Same arithmetic per element as gru_cell_fwd (the recurrent
 // sums run as two chains instead of one).
 // -------------------------------------------------------------------------------------------------
@@ -433,10 +433,12 @@ __device__ __forceinline__ float xor16(float v) {       // lane i <-> lane i ^ 1
     const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);      // r[0] = rows (0, 0, 2, 2), r[1] = rows (1, 1, 3, 3)
     return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
 }
-template <int FM, bool DG>
+// NB = 1: hidden <= 16; NB = 2: hidden 17..32 — h is then two 16-unit blocks, both replicated on every row, and a row does its gate's
+// two output blocks (four rotated dot products instead of the twelve + four of the two-row forward)
+template <int NB, int FM, bool DG>
 __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
     constexpr int F = FeatDim<FM>::F;
-    using T = GruTabs<1, DG>;
+    using T = GruTabs<NB, DG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // 0 r | 1 n | 2 head | 3 z
     const GruLayout L = gru_layout(a.H, F, DG);
@@ -444,40 +446,64 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
-    fill_gru_tabs<1, DG, false>(tab, pl, L, lane, 0, 1);
-    TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    fill_gru_tabs<NB, DG, false>(tab, pl, L, lane, 0, 1);
     float2* xs = reinterpret_cast<float2*>(tab + T::kFloats);
     float2* ys = xs + kChunkPad;
-    const bool vo = col < H;
-    // the row's own operands
+    // the row's own operands: its gate's input weights and biases for both output blocks, and the rotated recurrent weights
+    // wrec[ob][kb] = rows 16 ob + col of the gate's matrix against K-block kb (the table holds them per (output block, relative K-block))
     const int gate = role == 0 ? 0 : role == 3 ? 1 : 2;
-    float win[F], wrec[16];
+    float win[NB][F], wrec[NB][NB][16], b_in[NB], b_rec[NB], wo0[NB], wo1[NB];
 #pragma unroll
-    for (int i = 0; i < F; ++i) win[i] = (vo && role != 2) ? pl[L.o_w_ih + (gate * H + col) * F + i] : 0.0f;
-    float b_in = 0.0f, b_rec = 0.0f;
-    if (vo) {
-        if (role == 0 || role == 3) b_in = pl[L.o_b_ih + gate * H + col] + pl[L.o_b_hh + gate * H + col];
-        if (role == 1) { b_in = pl[L.o_b_ih + 2 * H + col]; b_rec = pl[L.o_b_hh + 2 * H + col]; }
-        if (role == 2 && DG) b_rec = pl[L.o_b_hid + col];
-    }
-    if (role != 2 || DG) load_rot(wrec, tlane + (role == 2 ? T::kHID : T::kHH + gate) * 4 * 64);
-    else {
+    for (int ob = 0; ob < NB; ++ob) {
+        const int o = 16 * ob + col;
+        const bool vo = o < H;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) wrec[k] = 0.0f;
+        for (int i = 0; i < F; ++i) win[ob][i] = (vo && role != 2) ? pl[L.o_w_ih + (gate * H + o) * F + i] : 0.0f;
+        b_in[ob] = 0.0f; b_rec[ob] = 0.0f;
+        if (vo) {
+            if (role == 0 || role == 3) b_in[ob] = pl[L.o_b_ih + gate * H + o] + pl[L.o_b_hh + gate * H + o];
+            if (role == 1) { b_in[ob] = pl[L.o_b_ih + 2 * H + o]; b_rec[ob] = pl[L.o_b_hh + 2 * H + o]; }
+            if (role == 2 && DG) b_rec[ob] = pl[L.o_b_hid + o];
+        }
+        // table entries are per lane of the two-row layout: lanes 16 ob .. 16 ob + 15 hold output block ob; entry rb covers K-block (ob + rb) % NB
+        TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + 16 * ob + col);
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb) {
+            const int kb = (ob + rb) % NB;
+            if (role != 2 || DG) load_rot(wrec[ob][kb], tl + ((role == 2 ? T::kHID : T::kHH + gate * NB) + rb) * 4 * 64);
+            else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) wrec[ob][kb][k] = 0.0f;
+            }
+        }
+        wo0[ob] = vo ? pl[L.o_w_out + o] : 0.0f; wo1[ob] = vo ? pl[L.o_w_out + OW + o] : 0.0f;
     }
-    const float wo0 = vo ? pl[L.o_w_out + col] : 0.0f, wo1 = vo ? pl[L.o_w_out + OW + col] : 0.0f;
     const float wf0 = (DG && col < 6) ? pl[L.o_w_out + H + col] : 0.0f, wf1 = (DG && col < 6) ? pl[L.o_w_out + OW + H + col] : 0.0f;
     const float bo0 = pl[L.o_b_out], bo1 = pl[L.o_b_out + 1];
     const bool odd = role & 1;
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        float h = 0.0f, fsp = 0.0f;
+        float h[NB], fsp = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) h[kb] = 0.0f;
         const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * a.T;
         float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * a.T;
-        auto head = [&](float arec, float hcur, float& y0, float& y1) {     // row 2: y of the state `hcur` (arec = b_hid + fc_hid hcur)
-            const float act = DG ? __builtin_fmaxf(arec, 0.0f) : hcur;
-            y0 = row_sum16(__builtin_fmaf(wo0, act, wf0 * fsp)) + bo0;
-            y1 = row_sum16(__builtin_fmaf(wo1, act, wf1 * fsp)) + bo1;
+        auto matvec = [&](float (&arec)[NB]) {
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                arec[ob] = b_rec[ob];
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) arec[ob] = rotdot(arec[ob], wrec[ob][kb], h[kb]);
+            }
+        };
+        auto head = [&](const float (&arec)[NB], float& y0, float& y1) {     // row 2: y of the state h (arec = b_hid + fc_hid h)
+            float p0 = wf0 * fsp, p1 = wf1 * fsp;
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                const float act = DG ? __builtin_fmaxf(arec[ob], 0.0f) : h[ob];
+                p0 = __builtin_fmaf(wo0[ob], act, p0); p1 = __builtin_fmaf(wo1[ob], act, p1);
+            }
+            y0 = row_sum16(p0) + bo0; y1 = row_sum16(p1) + bo1;
         };
         for (int t0 = 0; t0 < a.T; t0 += kChunk) {
             const int len = min(kChunk, a.T - t0);
@@ -494,32 +520,36 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
                     const float2 xn = xs[min(tt + 1, len - 1)];        // the next step's sample and features, off the recurrence's chain
                     feat_fwd<FM>(xn.x, xn.y, fnext);
                 }
-                float ain = b_in;
-#pragma unroll
-                for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[i], f[i], ain);
-                const float arec = rotdot(b_rec, wrec, h);
+                float arec[NB];
+                matvec(arec);
                 // head of the previous step rides on this step's mat-vec (row 2); ys[tt] <-> time t0 + tt - 1
                 float y0, y1;
-                head(arec, h, y0, y1);
+                head(arec, y0, y1);
                 if (lane == 32) ys[tt] = make_float2(y0, y1);
-                const float sg = sigmoidf_(ain + arec);                 // r (row 0), z (row 3)
-                const float r1 = xor16(sg);                             // row 1 <- r
-                const float n = tanhf_(__builtin_fmaf(r1, arec, ain));  // row 1
-                const float v = role == 1 ? n : sg;
-                const float o = xor32(v);                               // row 1 <- z, row 3 <- n
-                const float zz = role == 1 ? o : sg, nn = role == 1 ? n : o;
-                const float h13 = __builtin_fmaf(zz, h - nn, nn);       // rows 1 and 3: (1 - z) n + z h
-                const float h02 = xor16(h13);
-                h = odd ? h13 : h02;
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    float ain = b_in[ob];
+#pragma unroll
+                    for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[ob][i], f[i], ain);
+                    const float sg = sigmoidf_(ain + arec[ob]);                 // r (row 0), z (row 3)
+                    const float r1 = xor16(sg);                                 // row 1 <- r
+                    const float n = tanhf_(__builtin_fmaf(r1, arec[ob], ain));  // row 1
+                    const float v = role == 1 ? n : sg;
+                    const float o = xor32(v);                                   // row 1 <- z, row 3 <- n
+                    const float zz = role == 1 ? o : sg, nn = role == 1 ? n : o;
+                    const float h13 = __builtin_fmaf(zz, h[ob] - nn, nn);       // rows 1 and 3: (1 - z) n + z h
+                    const float h02 = xor16(h13);
+                    h[ob] = odd ? h13 : h02;
+                }
                 if constexpr (DG) fsp = feat_select<6>(f, col, 0.0f);
             }
             wave_lds_fence();
             if (lane < len && t0 + lane >= 1) yg[t0 + lane - 1] = ys[lane];
         }
         // the head of the last state
-        const float arec = rotdot(b_rec, wrec, h);
-        float y0, y1;
-        head(arec, h, y0, y1);
+        float arec[NB], y0, y1;
+        matvec(arec);
+        head(arec, y0, y1);
         if (lane == 32) yg[a.T - 1] = make_float2(y0, y1);
     }
 }
@@ -889,26 +919,32 @@ bool gru_split_uses_s16(const odpd_model_t* m, int B) {
 }
 
 // inference on a few long sequences (no checkpoints asked for): the gate-parallel evaluation kernel, one sequence per wave
-template <int FM, bool DG>
+template <int NB, int FM, bool DG>
 static int launch_eval(hipStream_t st, const SeqArgs& a, int P) {
-    const size_t lds = ((size_t)pad4(P) + GruTabs<1, DG>::kFloats + 2 * 2 * kChunkPad) * sizeof(float);
-    auto k = gru_eval_kernel<FM, DG>;
+    const size_t lds = ((size_t)pad4(P) + GruTabs<NB, DG>::kFloats + 2 * 2 * kChunkPad) * sizeof(float);
+    auto k = gru_eval_kernel<NB, FM, DG>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
     return (int)hipGetLastError();
 }
 bool gru_uses_eval_kernel(const odpd_model_t* m, int B, int T, bool want_ckpt) {
     int FM, R, P; bool DG;
-    return gru_setup(m, FM, DG, R, P) && R == 1 && !want_ckpt && B <= 8 && T >= 256 && tuning().s16_min_batch != 0;
+    return gru_setup(m, FM, DG, R, P) && !want_ckpt && B <= 8 && T >= 256 && tuning().s16_min_batch != 0;
 }
 int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     if (gru_uses_eval_kernel(m, a.B, a.T, a.ckpt != nullptr)) {
-        if (FM == FEAT_RAW2) return launch_eval<FEAT_RAW2, false>(st, a, P);
-        if (FM == FEAT_DGRU6) return launch_eval<FEAT_DGRU6, true>(st, a, P);
-        if (FM == FEAT_Q4) return launch_eval<FEAT_Q4, false>(st, a, P);
-        return launch_eval<FEAT_A4, false>(st, a, P);
+        if (R == 1) {
+            if (FM == FEAT_RAW2) return launch_eval<1, FEAT_RAW2, false>(st, a, P);
+            if (FM == FEAT_DGRU6) return launch_eval<1, FEAT_DGRU6, true>(st, a, P);
+            if (FM == FEAT_Q4) return launch_eval<1, FEAT_Q4, false>(st, a, P);
+            return launch_eval<1, FEAT_A4, false>(st, a, P);
+        }
+        if (FM == FEAT_RAW2) return launch_eval<2, FEAT_RAW2, false>(st, a, P);
+        if (FM == FEAT_DGRU6) return launch_eval<2, FEAT_DGRU6, true>(st, a, P);
+        if (FM == FEAT_Q4) return launch_eval<2, FEAT_Q4, false>(st, a, P);
+        return launch_eval<2, FEAT_A4, false>(st, a, P);
     }
     if (gru_split_uses_s16(m, a.B)) return gru_s16_fwd(st, m, a);
     if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 1);

@@ -252,11 +252,12 @@ def test_fused_step_on_frames_addressed_in_place(bb, H, B, T, stride):
 
 
 @pytest.mark.parametrize("bb", ["gru", "dgru", "qgru", "qgru_amp1"])
-@pytest.mark.parametrize("H", [1, 8, 13, 16])
+@pytest.mark.parametrize("H", [1, 8, 13, 16, 17, 23, 32])
 @pytest.mark.parametrize("B,T", [(1, 700), (3, 2560), (2, 256), (8, 257)])
 def test_evaluation_kernel_matches_the_oracle(bb, H, B, T):
     """inference on a few long sequences (net_eval / run_dpd shapes; torch.no_grad(), so no checkpoints are asked for) runs the
-    gate-parallel evaluation kernel (gru_eval_kernel: one sequence per wave, the four rows of the wave do r / n / head / z): against
+    gate-parallel evaluation kernel (gru_eval_kernel: one sequence per wave, the four rows of the wave do r / n / head / z; hidden 17..32 as two
+    unit blocks per row): against
     the oracle, and against the row-rotated forward the same call takes when gradients are enabled"""
     from opendpd_amd import CoreModel
     from oracle.oracle import Oracle, make_model
