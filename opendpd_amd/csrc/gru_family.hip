@@ -423,16 +423,6 @@ __global__ __launch_bounds__(kMaxThreads) void gru_fwd_kernel(SeqArgs a) {
 // n row, n <-> z between rows 1 and 3, h' from rows 1 / 3 to rows 0 / 2.  Same arithmetic per element as gru_cell_fwd (the recurrent
 // sums run as two chains instead of one).
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float xor32(float v) {       // lane i <-> lane i ^ 32
-    const int iv = __builtin_bit_cast(int, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);      // r[0] = (lo, lo), r[1] = (hi, hi)
-    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
-}
-__device__ __forceinline__ float xor16(float v) {       // lane i <-> lane i ^ 16
-    const int iv = __builtin_bit_cast(int, v);
-    const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);      // r[0] = rows (0, 0, 2, 2), r[1] = rows (1, 1, 3, 3)
-    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
-}
 // NB = 1: hidden <= 16; NB = 2: hidden 17..32 — h is then two 16-unit blocks, both replicated on every row, and a row does its gate's
 // two output blocks (four rotated dot products instead of the twelve + four of the two-row forward)
 template <int NB, int FM, bool DG>

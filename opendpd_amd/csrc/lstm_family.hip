@@ -223,6 +223,132 @@ __global__ __launch_bounds__(kMaxThreads) void lstm_fwd_kernel(SeqArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): gate-parallel, ONE sequence per wave.
+// The four 16-lane rows hold the same (h, c); row k computes gate k (i, f, g, o) of every unit with its own rotated W_hh rows — one
+// rotated dot product per step instead of four (hidden 17..32: four instead of sixteen) — applies the gate's activation, and three
+// cross-row swaps hand all four gates to every row, which then updates (c, h) redundantly.  The head's two outputs are split over
+// rows 0 and 1.  Same arithmetic per element as lstm_cell_fwd / lstm_head.
+// -------------------------------------------------------------------------------------------------
+template <int NB, bool VD>
+__global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
+    constexpr int F = VD ? 4 : 2;
+    using T = LstmTabs<NB>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // gate i | f | g | o
+    const LstmLayout L = lstm_layout(a.H, VD);
+    const int H = L.H;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_lstm_tabs<NB, false>(tab, pl, L, lane, 0, 1);
+    float2* xs = reinterpret_cast<float2*>(tab + T::kFloats);
+    float* ys = reinterpret_cast<float*>(xs + kHaloStride);
+    const int c = role & 1;                                                    // the output this row's head share belongs to
+    float win[NB][F], bg[NB], wrec[NB][NB][16], wq[NB], wl1[NB][4], wl2[NB][4];
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+        const int o = 16 * ob + col;
+        const bool vo = o < H;
+#pragma unroll
+        for (int i = 0; i < F; ++i) win[ob][i] = vo ? pl[L.o_w_ih + (role * H + o) * F + i] : 0.0f;
+        bg[ob] = vo ? pl[L.o_b_ih + role * H + o] + pl[L.o_b_hh + role * H + o] : 0.0f;
+        TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + 16 * ob + col);
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb) load_rot(wrec[ob][(ob + rb) % NB], tl + (T::kHH + role * NB + rb) * 4 * 64);
+        wq[ob] = (!VD && vo) ? pl[L.o_w_out + c * H + o] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wl1[ob][k] = (VD && vo) ? pl[L.o_w_l1 + k * H + o] : 0.0f;
+            wl2[ob][k] = (VD && vo) ? pl[L.o_w_l2 + k * H + o] : 0.0f;
+        }
+    }
+    float woc[4], wos[4], bl1[4], bl2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        woc[k] = VD ? pl[L.o_w_out + 8 * c + k] : 0.0f; wos[k] = VD ? pl[L.o_w_out + 8 * c + 4 + k] : 0.0f;
+        bl1[k] = VD ? pl[L.o_b_l1 + k] : 0.0f; bl2[k] = VD ? pl[L.o_b_l2 + k] : 0.0f;
+    }
+    const float bq = pl[L.o_b_out + c];
+    const bool is_g = role == 2;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        float h[NB], cs[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) { h[kb] = 0.0f; cs[kb] = 0.0f; }
+        float* yg = a.y + (size_t)b * a.T * 2;
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            wave_lds_fence();
+            stage_in_halo<1>(xs, a.x, b, a.B, a.T, t0, len, lane);
+            wave_lds_fence();
+            const float2* xr = xs + kHalo;                                      // xr[tt] = x[t0 + tt], xr[-1..-3] = halo
+            VdWin w4;
+            float2 xnext = xr[0];
+            float na = 0.f, ncw = 0.f, nsw = 0.f;
+            if constexpr (VD) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vd_elem(xr[k - 3], w4.a[k + 1], w4.cw[k + 1], w4.sw[k + 1]);
+                vd_elem(xnext, na, ncw, nsw);
+            }
+            for (int tt = 0; tt < len; ++tt) {
+                float xin[F];
+                if constexpr (VD) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { w4.a[k] = w4.a[k + 1]; w4.cw[k] = w4.cw[k + 1]; w4.sw[k] = w4.sw[k + 1]; }
+                    w4.a[3] = na; w4.cw[3] = ncw; w4.sw[3] = nsw;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xin[k] = w4.a[k];
+                } else { xin[0] = xnext.x; xin[1] = xnext.y; }
+                xnext = xr[min(tt + 1, len - 1)];                               // the next step's sample, off the recurrence's chain
+                if constexpr (VD) vd_elem(xnext, na, ncw, nsw);
+                float p = 0.0f, pre[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    float acc = bg[ob];
+#pragma unroll
+                    for (int i = 0; i < F; ++i) acc = __builtin_fmaf(win[ob][i], xin[i], acc);
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) acc = rotdot(acc, wrec[ob][kb], h[kb]);
+                    pre[ob] = acc;
+                }
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    const float sg = sigmoidf_(pre[ob]), th = tanhf_(pre[ob]);
+                    float g[4];
+                    gather_rows(is_g ? th : sg, g);
+                    cs[ob] = __builtin_fmaf(g[1], cs[ob], g[0] * g[2]);
+                    h[ob] = g[3] * tanhf_(cs[ob]);
+                }
+                // head: row 0 -> y0, row 1 -> y1
+                float cc = bq;
+                if constexpr (VD) {
+                    float u[4], v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        u[k] = woc[k] * w4.cw[k]; v[k] = wos[k] * w4.sw[k];
+                        cc = __builtin_fmaf(u[k], bl1[k], __builtin_fmaf(v[k], bl2[k], cc));
+                    }
+#pragma unroll
+                    for (int ob = 0; ob < NB; ++ob) {
+                        float q = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) q = __builtin_fmaf(u[k], wl1[ob][k], __builtin_fmaf(v[k], wl2[ob][k], q));
+                        p = __builtin_fmaf(q, h[ob], p);
+                    }
+                } else {
+#pragma unroll
+                    for (int ob = 0; ob < NB; ++ob) p = __builtin_fmaf(wq[ob], h[ob], p);
+                }
+                const float y = row_sum16(p) + cc;
+                if (col == 0 && role < 2) ys[2 * tt + role] = y;
+            }
+            wave_lds_fence();
+            if (lane < len) reinterpret_cast<float2*>(yg)[t0 + lane] = reinterpret_cast<const float2*>(ys)[lane];
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // backward
 // -------------------------------------------------------------------------------------------------
 template <int R, bool VD>
@@ -580,6 +706,14 @@ static int lstm_launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
     hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
 }
+template <int NB, bool VD>
+static int lstm_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
+    const size_t lds = ((size_t)pad4(P) + LstmTabs<NB>::kFloats + 2 * (kHaloStride + kChunkPad)) * sizeof(float);
+    auto k = lstm_eval_kernel<NB, VD>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
+    return (int)hipGetLastError();
+}
 template <int R, bool VD, bool NW, bool DX>
 static int lstm_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
     const LaunchShape ls = lstm_bwd_shape(R, VD, a.ngroups);
@@ -610,6 +744,8 @@ int lstm_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!R) return ODPD_EUNSUPPORTED;
     if (vd && a.T < kHalo) return ODPD_EINVAL;
     const int P = lstm_layout(m->hidden, vd).P;
+    // inference on a few long sequences (no checkpoints asked for): the gate-parallel evaluation kernel
+    if (a.ckpt == nullptr && a.B <= 8 && a.T >= 256 && tuning().s16_min_batch != 0) { ODPD_LSTM_DISPATCH(lstm_launch_eval, st, a, P) }
     ODPD_LSTM_DISPATCH(lstm_launch_fwd, st, a, P)
     return ODPD_EUNSUPPORTED;
 }

@@ -56,6 +56,28 @@ __device__ __forceinline__ float row_sum16(float v) {
     v += dpp_ror<1>(v);
     return v;
 }
+__device__ __forceinline__ float xor32(float v) {       // lane i <-> lane i ^ 32
+    const int iv = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);      // r[0] = (lo, lo), r[1] = (hi, hi)
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xor16(float v) {       // lane i <-> lane i ^ 16
+    const int iv = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);      // r[0] = rows (0, 0, 2, 2), r[1] = rows (1, 1, 3, 3)
+    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
+}
+// every row of the wave receives all four rows' values: g[k] = v of row k, same column (three cross-row swaps)
+__device__ __forceinline__ void gather_rows(float v, float (&g)[4]) {
+    const int iv = __builtin_bit_cast(int, v);
+    const auto h = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);        // h[0] = rows (0, 1, 0, 1), h[1] = rows (2, 3, 2, 3)
+    const int h0 = h[0], h1 = h[1];
+    const auto lo = __builtin_amdgcn_permlane16_swap(h0, h0, false, false);       // (0, 0, 0, 0) | (1, 1, 1, 1)
+    const auto hi = __builtin_amdgcn_permlane16_swap(h1, h1, false, false);       // (2, 2, 2, 2) | (3, 3, 3, 3)
+    // elements through scalar copies: __builtin_bit_cast applied to a vector-element lvalue reads element 0 whatever the index (clang 20)
+    const int g0 = lo[0], g1 = lo[1], g2 = hi[0], g3 = hi[1];
+    g[0] = __builtin_bit_cast(float, g0); g[1] = __builtin_bit_cast(float, g1);
+    g[2] = __builtin_bit_cast(float, g2); g[3] = __builtin_bit_cast(float, g3);
+}
 // sum over the R rows of one sequence (R = 1 or 2)
 template <int R>
 __device__ __forceinline__ float seq_sum(float v) {

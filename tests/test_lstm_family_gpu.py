@@ -189,3 +189,31 @@ def test_s16_fused_equals_unfused_gradients(force_s16, bb, H, B, T):
         lf = fused_train_step(opt, x, t, kind, 0.0)
         assert abs(lf.item() - loss.item()) < 1e-5 * max(1.0, loss.item()), kind
         assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 3e-5, kind
+
+
+@pytest.mark.parametrize("bb", ["lstm", "vdlstm"])
+@pytest.mark.parametrize("H", [1, 8, 13, 16, 17, 23, 32])
+@pytest.mark.parametrize("B,T", [(1, 700), (3, 2560), (2, 256), (8, 257)])
+def test_evaluation_kernel_matches_the_oracle(bb, H, B, T):
+    """inference on a few long sequences (net_eval / run_dpd shapes; torch.no_grad(), so no checkpoints are asked for) runs the
+    gate-parallel evaluation kernel (lstm_eval_kernel: one sequence per wave, row k of the wave computes gate k, three cross-row swaps
+    hand every row all four; hidden 17..32 as two unit blocks per row): against the oracle, and against the row-rotated forward the same
+    call takes when gradients are enabled"""
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 10 + B)
+    net = CoreModel(2, H, 1, bb).cuda().eval()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(T)
+    amp, ph = 0.05 + 0.85 * torch.rand(B, T, 1, generator=g), 2 * np.pi * torch.rand(B, T, 1, generator=g)
+    x = torch.cat((amp * torch.cos(ph), amp * torch.sin(ph)), -1)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    yo, _ = Oracle("f32").forward(make_model(bb, H), p, x.numpy())
+    with torch.no_grad():
+        y_eval = net(x.cuda()).cpu().numpy()
+    y_train = net(x.cuda().requires_grad_(True)).detach().cpu().numpy()        # gradients enabled: checkpoints -> the row-rotated forward
+    assert rel_err(y_eval, yo) < FWD_TOL and rel_err(y_train, yo) < FWD_TOL
+    assert rel_err(y_eval, y_train) < 5e-6
