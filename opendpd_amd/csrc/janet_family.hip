@@ -114,6 +114,74 @@ __global__ __launch_bounds__(kMaxThreads) void janet_fwd_kernel(SeqArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): ONE sequence per wave, the seven H x H
+// products of a step in two rounds of one register-resident rotated dot product per 16-lane row instead of seven streamed from LDS.
+// Round A on h: rows a | p1 | p2 | f (its h half); round B: row 0 continues f on u, row 1 g on u, row 2 g on h.  Two three-swap gathers
+// hand every row (a, p1, p2, f_h) and then (f, g_u, g_h); h' is updated redundantly on all rows; the head's outputs are split over
+// rows 0 and 1.  Same arithmetic per element as janet_cell_fwd apart from g's pre-activation, summed as (b + W_gh h) + W_gu u.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;
+    const JanetLayout L = janet_layout(a.H);
+    const int H = L.H;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_janet_tabs<false>(tab, pl, L, lane, 0, 1);
+    float2* xs = reinterpret_cast<float2*>(tab + kJTabFloats);
+    float* ys = reinterpret_cast<float*>(xs + kChunkPad);
+    TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    const bool vo = col < H;
+    float wa[16], wb[16];
+    load_rot(wa, tl + role * 4 * 64);                                           // a_h | p1_h | p2_h | f_h
+    load_rot(wb, tl + (role == 0 ? 5 : role == 1 ? 6 : 4) * 4 * 64);            // f_u | g_u | g_h | -
+    if (role == 3) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wb[k] = 0.0f;
+    }
+    const int o_w = role == 0 ? L.o_wa : role == 1 ? L.o_wp1 : L.o_wp2, o_b = role == 0 ? L.o_ba : role == 1 ? L.o_bp1 : role == 2 ? L.o_bp2 : L.o_bf;
+    const float sw = (vo && role < 3) ? pl[o_w + col * (H + 1) + H] : 0.0f;    // the row's scalar-input column
+    const float ba = vo ? pl[o_b + col] : 0.0f;
+    const float bg = (vo && role == 2) ? pl[L.o_bg + col] : 0.0f;
+    const int c = role & 1;
+    const float wq = vo ? pl[L.o_wo + c * H + col] : 0.0f, bq = pl[L.o_bo + c];
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        float h = 0.0f;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * a.T;
+        float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * a.T;
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            wave_lds_fence();
+            if (lane < kChunk) xs[lane] = lane < len ? xg[t0 + lane] : make_float2(0.5f, 0.5f);
+            wave_lds_fence();
+            float amp, ct, st;
+            janet_inputs(xs[0], amp, ct, st);
+            float sc = role == 0 ? amp : role == 1 ? ct : st;
+            for (int tt = 0; tt < len; ++tt) {
+                const float sc0 = sc;
+                janet_inputs(xs[min(tt + 1, len - 1)], amp, ct, st);            // the next step's inputs, off the recurrence's chain
+                sc = role == 0 ? amp : role == 1 ? ct : st;
+                const float pa = rotdot(__builtin_fmaf(sw, sc0, ba), wa, h);
+                float g4[4];
+                gather_rows(role == 3 ? pa : tanhf_(pa), g4);
+                const float an = g4[0], p1 = g4[1], p2 = g4[2];
+                const float u = (an * p1 * p2) * ((1.0f - an) * (1.0f - p1) * (1.0f - p2));
+                const float pb = rotdot(role == 0 ? g4[3] : bg, wb, role < 2 ? u : h);
+                gather_rows(pb, g4);
+                const float f = sigmoidf_(g4[0]), g = tanhf_(g4[2] + g4[1]);
+                h = __builtin_fmaf(f, h - g, g);
+                const float y = row_sum16(wq * h) + bq;
+                if (col == 0 && role < 2) ys[2 * tt + role] = y;
+            }
+            wave_lds_fence();
+            if (lane < len) yg[t0 + lane] = reinterpret_cast<const float2*>(ys)[lane];
+        }
+    }
+}
+
 struct JanetGrad {
     f32x4 t[7];                 // dW blocks in table order (a_h, p1_h, p2_h, f_h, g_h, f_u, g_u)
     float ds[3], db[5];         // scalar-input columns (amp, cos, sin) and biases (a, p1, p2, f, g)
@@ -302,6 +370,12 @@ int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     if (janet_uses_s16(m, a.B)) return janet_s16_launch(st, m, a, 1);
     const int P = janet_layout(m->hidden).P;
+    if (a.ckpt == nullptr && a.B <= 8 && a.T >= 256 && tuning().s16_min_batch != 0) {     // inference on a few long sequences
+        const size_t lds = ((size_t)pad4(P) + kJTabFloats + 4 * kChunkPad) * sizeof(float);
+        if (int e = allow_big_lds(janet_eval_kernel, lds)) return e;
+        hipLaunchKernelGGL(janet_eval_kernel, dim3(a.B), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    }
     const LaunchShape ls = persistent_shape(a.ngroups, 16);
     const size_t lds = janet_lds_bytes(P, ls.waves, false);
     auto k = janet_fwd_kernel<0>;

@@ -144,3 +144,30 @@ def test_s16_pgjanet_keeps_relative_accuracy_at_small_arguments(force_s16):
     with torch.no_grad():
         y = net(x.cuda()).cpu().numpy()
     assert rel_err(y, yo) < 2e-6
+
+
+@pytest.mark.parametrize("H", [1, 8, 11, 13, 16])
+@pytest.mark.parametrize("B,T", [(1, 700), (3, 2560), (2, 256), (8, 257)])
+def test_pgjanet_evaluation_kernel_matches_the_oracle(H, B, T):
+    """inference on a few long sequences (net_eval / run_dpd shapes; torch.no_grad(), so no checkpoints are asked for) runs
+    janet_eval_kernel (one sequence per wave, the step's seven H x H products as two rounds of one rotated dot product per row):
+    against the oracle, and against the row-rotated forward the same call takes when gradients are enabled"""
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 10 + B)
+    net = CoreModel(2, H, 1, "pgjanet").cuda().eval()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(T)
+    amp, ph = 0.05 + 0.85 * torch.rand(B, T, 1, generator=g), 2 * np.pi * torch.rand(B, T, 1, generator=g)
+    x = torch.cat((amp * torch.cos(ph), amp * torch.sin(ph)), -1)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    yo, _ = Oracle("f32").forward(make_model("pgjanet", H), p, x.numpy())
+    with torch.no_grad():
+        y_eval = net(x.cuda()).cpu().numpy()
+    y_train = net(x.cuda().requires_grad_(True)).detach().cpu().numpy()        # gradients enabled: checkpoints -> the row-rotated forward
+    assert rel_err(y_eval, yo) < FWD_TOL and rel_err(y_train, yo) < FWD_TOL
+    assert rel_err(y_eval, y_train) < 5e-6
+    assert H == 1 or not np.array_equal(y_eval, y_train)          # two kernels: g's pre-activation is summed in a different order

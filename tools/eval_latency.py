@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
-"""Forward-only (net_eval / run_dpd shape) latency: B segments of T samples through each backbone.
-usage (GPU box): PYTHONPATH=. python tools/eval_latency.py"""
+"""Latency of one evaluation pass (net_eval / run_dpd shapes, train_funcs.py:57-90) per recurrent backbone: torch.no_grad() (the
+gate-parallel evaluation kernels where a family has one) beside the same call with gradients enabled (the row-rotated forward that
+also writes BPTT checkpoints).  usage: PYTHONPATH=. python tools/eval_latency.py"""
+import time
+
 import torch
 
 from opendpd_amd import CoreModel
 
-for bb, H in (("gru", 11), ("dgru", 13), ("dgru", 23), ("lstm", 14), ("vdlstm", 13), ("deltagru", 15), ("deltagru_tcnskip", 15),
-              ("pgjanet", 11), ("tcnn", 35), ("qgru", 10)):
-    kw = dict(thx=0.01, thh=0.05) if "delta" in bb else {}
-    net = CoreModel(2, H, 1, bb, **kw).cuda().eval()
+for bb, H in (("gru", 11), ("dgru", 13), ("dgru", 23), ("qgru", 10), ("qgru_amp1", 16), ("lstm", 14), ("lstm", 24), ("vdlstm", 13), ("vdlstm", 24),
+              ("pgjanet", 11), ("deltagru", 15), ("deltagru_tcnskip", 15), ("deltajanet", 15)):
     for B, T in ((1, 19662), (3, 2560)):
-        x = (torch.rand(B, T, 2, device="cuda") - 0.5) * 1.6
-        x = x + 0.05 * torch.sign(x)
-        with torch.no_grad():
-            for _ in range(2):
-                y = net(x)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                y = net(x)
-            e1.record()
-            torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
-        print(f"{bb:18s} H{H:<3d} B={B} T={T:6d}: {ms:8.3f} ms  = {1e3 * ms / T:6.3f} us/step   {B * T / ms / 1e3:8.2f} M samples/s")
+        torch.manual_seed(0)
+        net = CoreModel(2, H, 1, bb).cuda().eval()
+        x = torch.randn(B, T, 2).cuda() * 0.3
+        xg = x.clone().requires_grad_(True)
+        best = {}
+        for grad in (False, True):
+            ts = []
+            for _ in range(8):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                if grad:
+                    net(xg)
+                else:
+                    with torch.no_grad():
+                        net(x)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t)
+            best[grad] = min(ts) * 1e3
+        print(f"{bb:17s} H{H:<3d} ({B}, {T:5d}, 2): no_grad {best[False]:6.2f} ms   with checkpoints {best[True]:6.2f} ms   ({best[True] / best[False]:.2f}x)", flush=True)
