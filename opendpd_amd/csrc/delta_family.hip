@@ -251,6 +251,143 @@ __global__ __launch_bounds__(kMaxThreads) void delta_fwd_kernel(SeqArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): ONE sequence per wave.
+//  * gate-parallel: rows 0 / 1 / 2 of the wave accumulate r / z / n with their own rotated W_hh rows — one rotated dot product per
+//    step instead of three; r reaches the n row and (z, n) every row through four cross-row swaps, h' is updated redundantly;
+//  * everything that does not depend on the state is computed once per 64-step chunk with lane = time step — the six features and
+//    the TRes skip (TCN 2->3->2 with its two Hardswish) — and parked in LDS; the raw samples of the next chunk are already in
+//    flight while the current one is stepped;
+//  * the x-side delta memory is kept one feature per lane (lanes 0..5 of a row: d, mask, x_p in one pass instead of six), the six
+//    masked deltas reach the gates as wave-uniform operands (v_readlane).
+// Same thresholded arithmetic per element as delta_cell_fwd (accumulation order included); the sparsity counters are kept.
+// -------------------------------------------------------------------------------------------------
+template <bool TRES>
+__global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // r | z | n | -
+    const DeltaLayout L = delta_layout(a.H, TRES);
+    const int H = L.H, T = a.T;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_delta_tabs<false>(tab, pl, L, lane, 0, 1);
+    float* feat = tab + kDTabFloats;                                           // [kChunk][8]: f0..f5, skip0, skip1
+    float* ys = feat + kChunk * 8;
+    const bool vo = col < H, gate_row = role < 3;
+    float wrec[16], wih[6];
+    load_rot(wrec, to_tab(reinterpret_cast<const float4*>(tab) + lane) + (gate_row ? role : 0) * 4 * 64);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wrec[k] = gate_row ? wrec[k] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wih[i] = (vo && gate_row) ? pl[L.o_w_ih + (role * H + col) * 6 + i] : 0.0f;
+    float accx0 = 0.0f, acch0 = 0.0f;
+    if (!TRES && vo) {
+        if (role < 2) accx0 = pl[L.o_b_ih + role * H + col] + pl[L.o_b_hh + role * H + col];
+        if (role == 2) { accx0 = pl[L.o_b_ih + 2 * H + col]; acch0 = pl[L.o_b_hh + 2 * H + col]; }
+    }
+    const int c = role & 1, fc = col < 6 ? col : 5;
+    const float wq = vo ? pl[L.o_w_out + c * H + col] : 0.0f, bq = TRES ? 0.0f : pl[L.o_b_out + c];
+    float w1[3][6], w2[2][3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w1[ch][k] = TRES ? pl[L.o_tcn0 + ch * 6 + k] : 0.0f;
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo) w2[oo][ch] = TRES ? pl[L.o_tcn2 + oo * 3 + ch] : 0.0f;
+    }
+    const float thx = a.thx, thh = a.thh;
+    float zx = 0.0f, zh = 0.0f;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
+        float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * T;
+        float h = 0.0f, hp = 0.0f, xp = 0.0f, accx = accx0, acch = acch0;
+        // raw samples of a chunk, lane = time step: x[t], and for TRes x[t + 1] (torch.roll: the last step sees sample 0) and the TCN taps
+        float2 rc, rn, rm, rp;
+        auto load_raw = [&](int t0) {
+            const int t = t0 + lane;
+            const float2 zero = make_float2(0.0f, 0.0f);
+            rc = t < T ? xg[t] : make_float2(0.5f, 0.5f);
+            if constexpr (TRES) {
+                rn = t + 1 < T ? xg[t + 1] : xg[0];
+                rm = (t - kDHalo >= 0 && t - kDHalo < T) ? xg[t - kDHalo] : zero;
+                rp = t + kDHalo < T ? xg[t + kDHalo] : zero;
+            }
+        };
+        load_raw(0);
+        for (int t0 = 0; t0 < T; t0 += kChunk) {
+            const int len = min(kChunk, T - t0);
+            {
+                float f[6];
+                delta_feat<TRES>(rc, rn, f);
+                float sk[2] = {0.0f, 0.0f};
+                if constexpr (TRES) {
+                    float s2[2] = {0.0f, 0.0f};
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        float s1 = w1[ch][0] * rm.x;
+                        s1 = __builtin_fmaf(w1[ch][1], rc.x, s1); s1 = __builtin_fmaf(w1[ch][2], rp.x, s1);
+                        s1 = __builtin_fmaf(w1[ch][3], rm.y, s1); s1 = __builtin_fmaf(w1[ch][4], rc.y, s1); s1 = __builtin_fmaf(w1[ch][5], rp.y, s1);
+                        const float hs = hardswishf_(s1);
+                        s2[0] = __builtin_fmaf(w2[0][ch], hs, s2[0]); s2[1] = __builtin_fmaf(w2[1][ch], hs, s2[1]);
+                    }
+                    sk[0] = hardswishf_(s2[0]); sk[1] = hardswishf_(s2[1]);
+                }
+                wave_lds_fence();
+                reinterpret_cast<float4*>(feat)[2 * lane] = make_float4(f[0], f[1], f[2], f[3]);
+                reinterpret_cast<float4*>(feat)[2 * lane + 1] = make_float4(f[4], f[5], sk[0], sk[1]);
+                wave_lds_fence();
+            }
+            if (t0 + kChunk < T) load_raw(t0 + kChunk);
+            for (int tt = 0; tt < len; ++tt) {
+                // x side, one feature per lane
+                const float fv = feat[tt * 8 + fc];
+                const float d = fv - xp, ad = __builtin_fabsf(d);
+                const float dm = !(ad < thx) ? d : 0.0f;                          // masked_fill(|d| < th, 0)  (deltagru.py:179-183)
+                xp = (ad >= thx) ? fv : xp;
+                zx += (dm == 0.0f) ? 1.0f : 0.0f;
+                float ax = accx;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    ax = __builtin_fmaf(wih[i], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dm), i)), ax);
+                // h side
+                const float dhv = h - hp, adh = __builtin_fabsf(dhv);
+                const float dhm = !(adh < thh) ? dhv : 0.0f;
+                hp = (adh >= thh) ? h : hp;
+                zh += (vo && dhm == 0.0f) ? 1.0f : 0.0f;
+                const bool nrow = role == 2;
+                const float res = rotdot(nrow ? acch : ax, wrec, dhm);            // rows r, z: dm += W_ih dx + W_hh dh; row n: dm_nh += W_hn dh
+                accx = nrow ? ax : res; acch = nrow ? res : acch;
+                const float sg = sigmoidf_(res);
+                const float r = xor32(sg);                                        // row 2 <- r of row 0
+                const float n = tanhf_(__builtin_fmaf(r, res, ax));               // row 2
+                float g4[4];
+                gather_rows(nrow ? n : sg, g4);
+                h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
+                float y = row_sum16(wq * h) + bq;
+                if constexpr (TRES) y += feat[tt * 8 + 6 + c];
+                if (col == 0 && role < 2) ys[2 * tt + role] = y;
+            }
+            wave_lds_fence();
+            if (lane < len) yg[t0 + lane] = reinterpret_cast<const float2*>(ys)[lane];
+        }
+    }
+    if (a.stats != nullptr) {
+        // dx zeros: the six feature lanes of row 0; dh zeros: the hidden units of row 0
+        float tx = (role == 0 && col < 6) ? zx : 0.0f, th = role == 0 ? zh : 0.0f;
+        for (int o = 32; o > 0; o >>= 1) { tx += __shfl_down(tx, o); th += __shfl_down(th, o); }
+        if (lane == 0) {
+            atomicAdd(&a.stats[0], (double)tx);
+            atomicAdd(&a.stats[2], (double)th);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicAdd(&a.stats[1], 6.0 * (double)a.B * (double)a.T);
+            atomicAdd(&a.stats[3], (double)a.H * (double)a.B * (double)a.T);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // backward kernel (parameter gradients only)
 // -------------------------------------------------------------------------------------------------
 template <bool TRES>
@@ -480,6 +617,14 @@ static int delta_launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
     return (int)hipGetLastError();
 }
 template <bool TRES>
+static int delta_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
+    const size_t lds = ((size_t)pad4(P) + kDTabFloats + kChunk * 8 + 2 * kChunkPad) * sizeof(float);
+    auto k = delta_eval_kernel<TRES>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <bool TRES>
 static int delta_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
     if (a.dx != nullptr) return ODPD_EUNSUPPORTED;   // dL/dx of a delta backbone is not implemented
     if (a.partials == nullptr) return ODPD_EINVAL;
@@ -496,6 +641,8 @@ int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
     const int P = delta_layout(m->hidden, tres).P;
+    if (a.ckpt == nullptr && a.B <= 8 && a.T >= 256 && tuning().s16_min_batch != 0)          // inference on a few long sequences
+        return tres ? delta_launch_eval<true>(st, a, P) : delta_launch_eval<false>(st, a, P);
     return tres ? delta_launch_fwd<true>(st, a, P) : delta_launch_fwd<false>(st, a, P);
 }
 int delta_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {

@@ -237,3 +237,43 @@ def test_dx_flag_does_not_leak_between_autograd_and_fused_calls():
         assert abs(loss.item() - fx["losses"][s - 1]) < 2e-5 * max(1.0, fx["losses"][s - 1])
         got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in net.parameters()])
         assert rel_err(got, fx.flat(f"p{s}", names)) < 3e-5, s
+
+
+@pytest.mark.parametrize("bb,H,thx,thh", [("deltagru", 15, 0.0, 0.0), ("deltagru", 15, 0.01, 0.05), ("deltagru", 8, 0.02, 0.1), ("deltagru", 1, 0.01, 0.05),
+                                          ("deltagru_tcnskip", 15, 0.01, 0.05), ("deltagru_tcnskip", 16, 0.0, 0.0),
+                                          ("deltagru_tcnskip", 9, 0.05, 0.02)])
+@pytest.mark.parametrize("B,T", [(1, 700), (3, 2560), (2, 256), (8, 257)])
+def test_evaluation_kernel_matches_the_oracle_and_keeps_the_counters(bb, H, thx, thh, B, T):
+    """inference on a few long sequences (net_eval / run_dpd shapes; torch.no_grad(), so no checkpoints are asked for) runs
+    delta_eval_kernel (one sequence per wave; rows r / z / n, features and the TRes skip computed per chunk with lane = time step, the
+    x-side delta memory one feature per lane): the same thresholded arithmetic as the row-rotated forward and the oracle — sparsity counters
+    and outputs (a rounding-level difference can flip a threshold decision; a handful of flips are allowed for)"""
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 10 + B)
+    net = CoreModel(2, H, 1, bb, thx=thx, thh=thh).cuda().eval()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(T)
+    amp, ph = 0.05 + 0.85 * torch.rand(B, T, 1, generator=g), 2 * np.pi * torch.rand(B, T, 1, generator=g)
+    x = torch.cat((amp * torch.cos(ph), amp * torch.sin(ph)), -1)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    yo, so = Oracle("f32").forward(make_model(bb, H, thx, thh), p, x.numpy())
+    keys = ("num_dx_zeros", "num_dx_numel", "num_dh_zeros", "num_dh_numel")
+    net.backbone.set_debug(1)
+    with torch.no_grad():
+        y_eval = net(x.cuda()).cpu().numpy()
+    st_eval = [net.backbone.statistics[k] for k in keys]
+    net.backbone.set_debug(1)
+    y_train = net(x.cuda().requires_grad_(True)).detach().cpu().numpy()        # gradients enabled: checkpoints -> the row-rotated forward
+    st_train = [net.backbone.statistics[k] for k in keys]
+    assert st_eval[1] == st_train[1] and st_eval[3] == st_train[3]
+    same = st_eval == st_train              # the recurrent sums run in a different order: a |dh| within rounding of th_h can flip a mask
+    assert abs(st_eval[0] - st_train[0]) + abs(st_eval[2] - st_train[2]) <= 4
+    assert rel_err(y_eval, y_train) < (FWD_TOL if same else 5e-3)      # the accumulators integrate rounding over T steps
+    assert st_eval[1] == so[1] and st_eval[3] == so[3]
+    flips = abs(st_eval[0] - so[0]) + abs(st_eval[2] - so[2])
+    assert flips <= 4
+    assert rel_err(y_eval, yo) < (FWD_TOL if flips == 0 else 5e-3)
