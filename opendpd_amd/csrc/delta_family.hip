@@ -271,8 +271,8 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_delta_tabs<false>(tab, pl, L, lane, 0, 1);
-    float* feat = tab + kDTabFloats;                                           // [kChunk][8]: f0..f5, skip0, skip1
-    float* ys = feat + kChunk * 8;
+    float* feat = tab + kDTabFloats;                                           // [kEvalChunk][8]: f0..f5, skip0, skip1
+    float* ys = feat + kEvalChunk * 8;
     const bool vo = col < H, gate_row = role < 3;
     float wrec[16], wih[6];
     load_rot(wrec, to_tab(reinterpret_cast<const float4*>(tab) + lane) + (gate_row ? role : 0) * 4 * 64);
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
             }
         };
         load_raw(0);
-        for (int t0 = 0; t0 < T; t0 += kChunk) {
-            const int len = min(kChunk, T - t0);
+        for (int t0 = 0; t0 < T; t0 += kEvalChunk) {
+            const int len = min(kEvalChunk, T - t0);
             {
                 float f[6];
                 delta_feat<TRES>(rc, rn, f);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
                 reinterpret_cast<float4*>(feat)[2 * lane + 1] = make_float4(f[4], f[5], sk[0], sk[1]);
                 wave_lds_fence();
             }
-            if (t0 + kChunk < T) load_raw(t0 + kChunk);
+            if (t0 + kEvalChunk < T) load_raw(t0 + kEvalChunk);
             for (int tt = 0; tt < len; ++tt) {
                 // x side, one feature per lane
                 const float fv = feat[tt * 8 + fc];
@@ -618,7 +618,7 @@ static int delta_launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
 }
 template <bool TRES>
 static int delta_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
-    const size_t lds = ((size_t)pad4(P) + kDTabFloats + kChunk * 8 + 2 * kChunkPad) * sizeof(float);
+    const size_t lds = ((size_t)pad4(P) + kDTabFloats + kEvalChunk * 8 + 2 * kEvalChunk) * sizeof(float);
     auto k = delta_eval_kernel<TRES>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);

@@ -423,11 +423,20 @@ __global__ __launch_bounds__(kMaxThreads) void gru_fwd_kernel(SeqArgs a) {
 // n row, n <-> z between rows 1 and 3, h' from rows 1 / 3 to rows 0 / 2.  Same arithmetic per element as gru_cell_fwd (the recurrent
 // sums run as two chains instead of one).
 // -------------------------------------------------------------------------------------------------
+template <int NB> struct GruEvalLds {
+    static constexpr int kHistStride = 64 * NB + 4;      // one float per lane and unit block; + 4: the per-chunk reads (lane = time step) spread over the banks
+    static constexpr int kHeadFloats = 2 * 16 * NB + 16;
+    static constexpr int kFloats = (kEvalChunk + 1) * 8 + kEvalChunk * kHistStride + kHeadFloats;
+};
 // NB = 1: hidden <= 16; NB = 2: hidden 17..32 — h is then two 16-unit blocks, both replicated on every row, and a row does its gate's
-// two output blocks (four rotated dot products instead of the twelve + four of the two-row forward)
+// two output blocks (four rotated dot products instead of the twelve + four of the two-row forward).
+// What does not depend on the state leaves the step loop: the features of a 64-step chunk are computed with lane = time step and
+// parked in LDS (a step reads them as wave-uniform operands), and so is fc_out — a step only parks the head's input (h, or relu(fc_hid h)
+// from row 2) and the chunk's 64 outputs are formed afterwards, one time step per lane.  The next chunk's samples are in flight
+// while the current one is stepped.
 template <int NB, int FM, bool DG>
 __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
-    constexpr int F = FeatDim<FM>::F;
+    constexpr int F = FeatDim<FM>::F, EC = kEvalChunk, HS = GruEvalLds<NB>::kHistStride;
     using T = GruTabs<NB, DG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // 0 r | 1 n | 2 head | 3 z
@@ -437,8 +446,16 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_gru_tabs<NB, DG, false>(tab, pl, L, lane, 0, 1);
-    float2* xs = reinterpret_cast<float2*>(tab + T::kFloats);
-    float2* ys = xs + kChunkPad;
+    float* ftab = tab + T::kFloats;                    // [EC + 1][8]: entry 1 + i = features of time t0 + i, entry 0 = of time t0 - 1
+    float* hist = ftab + (EC + 1) * 8;                 // [EC][HS]: entry i = the head's input of time t0 + i - 1, every lane's copy
+    float* hw = hist + EC * HS;                        // fc_out: [2][16 NB] hidden columns (zero padded) | [2][8] feature columns
+    for (int i = lane; i < GruEvalLds<NB>::kHeadFloats; i += 64) {
+        float v = 0.0f;
+        if (i < 32 * NB) { const int c = i / (16 * NB), u = i % (16 * NB); if (u < H) v = pl[L.o_w_out + c * OW + u]; }
+        else { const int j = i - 32 * NB, c = j >> 3, k = j & 7; if (DG && k < 6) v = pl[L.o_w_out + c * OW + H + k]; }
+        hw[i] = v;
+    }
+    wave_lds_fence();
     // the row's own operands: its gate's input weights and biases for both output blocks, and the rotated recurrent weights
     // wrec[ob][kb] = rows 16 ob + col of the gate's matrix against K-block kb (the table holds them per (output block, relative K-block))
     const int gate = role == 0 ? 0 : role == 3 ? 1 : 2;
@@ -471,9 +488,10 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
     const float wf0 = (DG && col < 6) ? pl[L.o_w_out + H + col] : 0.0f, wf1 = (DG && col < 6) ? pl[L.o_w_out + OW + H + col] : 0.0f;
     const float bo0 = pl[L.o_b_out], bo1 = pl[L.o_b_out + 1];
     const bool odd = role & 1;
+    const float4* ftab4 = reinterpret_cast<const float4*>(ftab);
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        float h[NB], fsp = 0.0f;
+        float h[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) h[kb] = 0.0f;
         const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * a.T;
@@ -486,36 +504,34 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
                 for (int kb = 0; kb < NB; ++kb) arec[ob] = rotdot(arec[ob], wrec[ob][kb], h[kb]);
             }
         };
-        auto head = [&](const float (&arec)[NB], float& y0, float& y1) {     // row 2: y of the state h (arec = b_hid + fc_hid h)
-            float p0 = wf0 * fsp, p1 = wf1 * fsp;
+        float2 raw = lane < a.T ? xg[lane] : make_float2(0.5f, 0.5f);
+        for (int t0 = 0; t0 < a.T; t0 += EC) {
+            const int len = min(EC, a.T - t0);
+            {
+                float f[F];
+                feat_fwd<FM>(raw.x, raw.y, f);
+                float f8[8];
 #pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-                const float act = DG ? __builtin_fmaxf(arec[ob], 0.0f) : h[ob];
-                p0 = __builtin_fmaf(wo0[ob], act, p0); p1 = __builtin_fmaf(wo1[ob], act, p1);
+                for (int i = 0; i < 8; ++i) f8[i] = i < F ? f[i] : 0.0f;
+                wave_lds_fence();
+                reinterpret_cast<float4*>(ftab)[2 * (1 + lane)] = make_float4(f8[0], f8[1], f8[2], f8[3]);
+                reinterpret_cast<float4*>(ftab)[2 * (1 + lane) + 1] = make_float4(f8[4], f8[5], f8[6], f8[7]);
+                wave_lds_fence();
             }
-            y0 = row_sum16(p0) + bo0; y1 = row_sum16(p1) + bo1;
-        };
-        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
-            const int len = min(kChunk, a.T - t0);
-            wave_lds_fence();
-            if (lane < kChunk) xs[lane] = lane < len ? xg[t0 + lane] : make_float2(0.5f, 0.5f);
-            wave_lds_fence();
-            float fnext[F];
-            feat_fwd<FM>(xs[0].x, xs[0].y, fnext);
+            raw = t0 + EC + lane < a.T ? xg[t0 + EC + lane] : make_float2(0.5f, 0.5f);
             for (int tt = 0; tt < len; ++tt) {
                 float f[F];
-#pragma unroll
-                for (int i = 0; i < F; ++i) f[i] = fnext[i];
                 {
-                    const float2 xn = xs[min(tt + 1, len - 1)];        // the next step's sample and features, off the recurrence's chain
-                    feat_fwd<FM>(xn.x, xn.y, fnext);
+                    const float4 fa = ftab4[2 * (1 + tt)];
+                    f[0] = fa.x; f[1] = fa.y;
+                    if constexpr (F > 2) { f[2] = fa.z; f[3] = fa.w; }
+                    if constexpr (F > 4) { const float4 fb = ftab4[2 * (1 + tt) + 1]; f[4] = fb.x; f[5] = fb.y; }
                 }
                 float arec[NB];
                 matvec(arec);
-                // head of the previous step rides on this step's mat-vec (row 2); ys[tt] <-> time t0 + tt - 1
-                float y0, y1;
-                head(arec, y0, y1);
-                if (lane == 32) ys[tt] = make_float2(y0, y1);
+                // the head's input of the PREVIOUS step rides on this step's mat-vec (row 2): parked, fc_out follows per chunk
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) hist[tt * HS + 64 * ob + lane] = DG ? __builtin_fmaxf(arec[ob], 0.0f) : h[ob];
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) {
                     float ain = b_in[ob];
@@ -531,16 +547,51 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
                     const float h02 = xor16(h13);
                     h[ob] = odd ? h13 : h02;
                 }
-                if constexpr (DG) fsp = feat_select<6>(f, col, 0.0f);
             }
             wave_lds_fence();
-            if (lane < len && t0 + lane >= 1) yg[t0 + lane - 1] = ys[lane];
+            // fc_out of the chunk, lane = time step: entry `lane` of hist / ftab belongs to time t0 + lane - 1
+            if (lane < len && t0 + lane >= 1) {
+                const float4* hv4 = reinterpret_cast<const float4*>(hist + lane * HS + 32);        // row 2's copy
+                const float4* hw4 = reinterpret_cast<const float4*>(hw);
+                float y0 = bo0, y1 = bo1;
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 hv = hv4[16 * ob + q], w0 = hw4[4 * ob + q], w1 = hw4[4 * NB + 4 * ob + q];
+                        y0 = __builtin_fmaf(w0.x, hv.x, y0); y0 = __builtin_fmaf(w0.y, hv.y, y0); y0 = __builtin_fmaf(w0.z, hv.z, y0); y0 = __builtin_fmaf(w0.w, hv.w, y0);
+                        y1 = __builtin_fmaf(w1.x, hv.x, y1); y1 = __builtin_fmaf(w1.y, hv.y, y1); y1 = __builtin_fmaf(w1.z, hv.z, y1); y1 = __builtin_fmaf(w1.w, hv.w, y1);
+                    }
+                if constexpr (DG) {
+                    const float4 fa = ftab4[2 * lane], fb = ftab4[2 * lane + 1];
+                    const float4 u0 = hw4[8 * NB], u1 = hw4[8 * NB + 1], v0 = hw4[8 * NB + 2], v1 = hw4[8 * NB + 3];
+                    y0 = __builtin_fmaf(u0.x, fa.x, y0); y0 = __builtin_fmaf(u0.y, fa.y, y0); y0 = __builtin_fmaf(u0.z, fa.z, y0); y0 = __builtin_fmaf(u0.w, fa.w, y0);
+                    y0 = __builtin_fmaf(u1.x, fb.x, y0); y0 = __builtin_fmaf(u1.y, fb.y, y0);
+                    y1 = __builtin_fmaf(v0.x, fa.x, y1); y1 = __builtin_fmaf(v0.y, fa.y, y1); y1 = __builtin_fmaf(v0.z, fa.z, y1); y1 = __builtin_fmaf(v0.w, fa.w, y1);
+                    y1 = __builtin_fmaf(v1.x, fb.x, y1); y1 = __builtin_fmaf(v1.y, fb.y, y1);
+                }
+                yg[t0 + lane - 1] = make_float2(y0, y1);
+            }
+            // the chunk's last features become entry 0 of the next one
+            float carry = 0.0f;
+            if (lane < 8) carry = ftab[len * 8 + lane];
+            wave_lds_fence();
+            if (lane < 8) ftab[lane] = carry;
         }
-        // the head of the last state
-        float arec[NB], y0, y1;
+        wave_lds_fence();
+        // the head of the last state (time T - 1: its features are entry 0 now)
+        float arec[NB];
         matvec(arec);
-        head(arec, y0, y1);
+        float p0 = 0.0f, p1 = 0.0f;
+        if constexpr (DG) { const float fsp = col < 6 ? ftab[col] : 0.0f; p0 = wf0 * fsp; p1 = wf1 * fsp; }
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            const float act = DG ? __builtin_fmaxf(arec[ob], 0.0f) : h[ob];
+            p0 = __builtin_fmaf(wo0[ob], act, p0); p1 = __builtin_fmaf(wo1[ob], act, p1);
+        }
+        const float y0 = row_sum16(p0) + bo0, y1 = row_sum16(p1) + bo1;
         if (lane == 32) yg[a.T - 1] = make_float2(y0, y1);
+        wave_lds_fence();
     }
 }
 
@@ -911,7 +962,7 @@ bool gru_split_uses_s16(const odpd_model_t* m, int B) {
 // inference on a few long sequences (no checkpoints asked for): the gate-parallel evaluation kernel, one sequence per wave
 template <int NB, int FM, bool DG>
 static int launch_eval(hipStream_t st, const SeqArgs& a, int P) {
-    const size_t lds = ((size_t)pad4(P) + GruTabs<NB, DG>::kFloats + 2 * 2 * kChunkPad) * sizeof(float);
+    const size_t lds = ((size_t)pad4(P) + GruTabs<NB, DG>::kFloats + GruEvalLds<NB>::kFloats) * sizeof(float);
     auto k = gru_eval_kernel<NB, FM, DG>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
     float* tab = smem + pad4(L.P);
     fill_janet_tabs<false>(tab, pl, L, lane, 0, 1);
     float2* xs = reinterpret_cast<float2*>(tab + kJTabFloats);
-    float* ys = reinterpret_cast<float*>(xs + kChunkPad);
+    float* ys = reinterpret_cast<float*>(xs + kEvalChunk);
     TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     const bool vo = col < H;
     float wa[16], wb[16];
@@ -152,11 +152,14 @@ __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
         float h = 0.0f;
         const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * a.T;
         float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * a.T;
-        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
-            const int len = min(kChunk, a.T - t0);
+        // the samples of a chunk are fetched while the previous one is stepped (lane = time step)
+        float2 raw = lane < a.T ? xg[lane] : make_float2(0.5f, 0.5f);
+        for (int t0 = 0; t0 < a.T; t0 += kEvalChunk) {
+            const int len = min(kEvalChunk, a.T - t0);
             wave_lds_fence();
-            if (lane < kChunk) xs[lane] = lane < len ? xg[t0 + lane] : make_float2(0.5f, 0.5f);
+            xs[lane] = raw;
             wave_lds_fence();
+            raw = t0 + kEvalChunk + lane < a.T ? xg[t0 + kEvalChunk + lane] : make_float2(0.5f, 0.5f);
             float amp, ct, st;
             janet_inputs(xs[0], amp, ct, st);
             float sc = role == 0 ? amp : role == 1 ? ct : st;
@@ -371,7 +374,7 @@ int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (janet_uses_s16(m, a.B)) return janet_s16_launch(st, m, a, 1);
     const int P = janet_layout(m->hidden).P;
     if (a.ckpt == nullptr && a.B <= 8 && a.T >= 256 && tuning().s16_min_batch != 0) {     // inference on a few long sequences
-        const size_t lds = ((size_t)pad4(P) + kJTabFloats + 4 * kChunkPad) * sizeof(float);
+        const size_t lds = ((size_t)pad4(P) + kJTabFloats + 4 * kEvalChunk) * sizeof(float);
         if (int e = allow_big_lds(janet_eval_kernel, lds)) return e;
         hipLaunchKernelGGL(janet_eval_kernel, dim3(a.B), dim3(64), lds, st, a);
         return (int)hipGetLastError();

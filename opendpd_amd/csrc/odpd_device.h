@@ -25,6 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWave = 64;
 constexpr int kCkptStride = 4;   // S: recurrent state is checkpointed every S steps for BPTT
 constexpr int kChunk = 32;       // time steps staged in LDS per chunk (multiple of kCkptStride)
+constexpr int kEvalChunk = 64;   // the evaluation kernels (one sequence per wave) stage one time step per lane
 constexpr int kChunkPad = kChunk + 1;  // float2 row stride in LDS (breaks the 2-way bank conflict)
 constexpr int kMaxWavesPerBlock = 8;   // waves per workgroup is a launch-time choice (1,2,4,8)
 constexpr int kMaxThreads = kWave * kMaxWavesPerBlock;
