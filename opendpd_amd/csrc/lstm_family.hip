@@ -226,12 +226,19 @@ __global__ __launch_bounds__(kMaxThreads) void lstm_fwd_kernel(SeqArgs a) {
 // evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): gate-parallel, ONE sequence per wave.
 // The four 16-lane rows hold the same (h, c); row k computes gate k (i, f, g, o) of every unit with its own rotated W_hh rows — one
 // rotated dot product per step instead of four (hidden 17..32: four instead of sixteen) — applies the gate's activation, and three
-// cross-row swaps hand all four gates to every row, which then updates (c, h) redundantly.  The head's two outputs are split over
-// rows 0 and 1.  Same arithmetic per element as lstm_cell_fwd / lstm_head.
+// cross-row swaps hand all four gates to every row, which then updates (c, h) redundantly.  What does not depend on the state
+// leaves the step loop: the inputs of a 64-step chunk (I, Q, or |x| and its unit phasor for the VDLSTM window) are computed with
+// lane = time step and parked in LDS, a step parks h, and the chunk's 64 outputs (fc_out; VD: fc_lambda_1/2, the phasor products,
+// fc_out) are formed afterwards, one time step per lane.  The next chunk's samples are in flight while the current one is stepped.
 // -------------------------------------------------------------------------------------------------
+template <int NB> struct LstmEvalLds {
+    static constexpr int kHistStride = 64 * NB + 4;
+    static constexpr int kHeadFloats = 8 * 16 * NB;          // plain: fc_out rows 0..1; VD: fc_lambda_1 rows 0..3, fc_lambda_2 rows 4..7 (zero padded)
+    static constexpr int kFloats = (kEvalChunk + kHalo) * 4 + kEvalChunk * kHistStride + kHeadFloats;
+};
 template <int NB, bool VD>
 __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
-    constexpr int F = VD ? 4 : 2;
+    constexpr int F = VD ? 4 : 2, EC = kEvalChunk, HS = LstmEvalLds<NB>::kHistStride;
     using T = LstmTabs<NB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // gate i | f | g | o
@@ -241,10 +248,20 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_lstm_tabs<NB, false>(tab, pl, L, lane, 0, 1);
-    float2* xs = reinterpret_cast<float2*>(tab + T::kFloats);
-    float* ys = reinterpret_cast<float*>(xs + kHaloStride);
-    const int c = role & 1;                                                    // the output this row's head share belongs to
-    float win[NB][F], bg[NB], wrec[NB][NB][16], wq[NB], wl1[NB][4], wl2[NB][4];
+    float* ftab = tab + T::kFloats;                    // [kHalo + EC][4]: entry kHalo + i = inputs of time t0 + i; entries 0..2 = the three before
+    float* hist = ftab + (kHalo + EC) * 4;             // [EC][HS]: entry i = h of time t0 + i, every lane's copy
+    float* hw = hist + EC * HS;
+    for (int i = lane; i < LstmEvalLds<NB>::kHeadFloats; i += 64) {
+        const int r = i / (16 * NB), u = i % (16 * NB);
+        float v = 0.0f;
+        if (u < H) {
+            if (VD) v = r < 4 ? pl[L.o_w_l1 + r * H + u] : pl[L.o_w_l2 + (r - 4) * H + u];
+            else if (r < 2) v = pl[L.o_w_out + r * H + u];
+        }
+        hw[i] = v;
+    }
+    wave_lds_fence();
+    float win[NB][F], bg[NB], wrec[NB][NB][16];
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
         const int o = 16 * ob + col;
@@ -255,53 +272,40 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
         TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + 16 * ob + col);
 #pragma unroll
         for (int rb = 0; rb < NB; ++rb) load_rot(wrec[ob][(ob + rb) % NB], tl + (T::kHH + role * NB + rb) * 4 * 64);
-        wq[ob] = (!VD && vo) ? pl[L.o_w_out + c * H + o] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            wl1[ob][k] = (VD && vo) ? pl[L.o_w_l1 + k * H + o] : 0.0f;
-            wl2[ob][k] = (VD && vo) ? pl[L.o_w_l2 + k * H + o] : 0.0f;
-        }
     }
-    float woc[4], wos[4], bl1[4], bl2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        woc[k] = VD ? pl[L.o_w_out + 8 * c + k] : 0.0f; wos[k] = VD ? pl[L.o_w_out + 8 * c + 4 + k] : 0.0f;
-        bl1[k] = VD ? pl[L.o_b_l1 + k] : 0.0f; bl2[k] = VD ? pl[L.o_b_l2 + k] : 0.0f;
-    }
-    const float bq = pl[L.o_b_out + c];
     const bool is_g = role == 2;
+    const float4* hw4 = reinterpret_cast<const float4*>(hw);
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         float h[NB], cs[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) { h[kb] = 0.0f; cs[kb] = 0.0f; }
-        float* yg = a.y + (size_t)b * a.T * 2;
-        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
-            const int len = min(kChunk, a.T - t0);
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * a.T;
+        float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * a.T;
+        auto park = [&](int entry, float2 xv) {           // inputs of one time step
+            float4 e = make_float4(xv.x, xv.y, 0.0f, 0.0f);
+            if constexpr (VD) vd_elem(xv, e.x, e.y, e.z);
+            reinterpret_cast<float4*>(ftab)[entry] = e;
+        };
+        float2 raw = lane < a.T ? xg[lane] : make_float2(0.5f, 0.5f);
+        wave_lds_fence();
+        if (VD && lane < kHalo) park(lane, xg[a.T - kHalo + lane]);      // circular left padding: the frame's own last samples (vdlstm.py:66-74)
+        for (int t0 = 0; t0 < a.T; t0 += EC) {
+            const int len = min(EC, a.T - t0);
             wave_lds_fence();
-            stage_in_halo<1>(xs, a.x, b, a.B, a.T, t0, len, lane);
+            park(kHalo + lane, raw);
             wave_lds_fence();
-            const float2* xr = xs + kHalo;                                      // xr[tt] = x[t0 + tt], xr[-1..-3] = halo
-            VdWin w4;
-            float2 xnext = xr[0];
-            float na = 0.f, ncw = 0.f, nsw = 0.f;
-            if constexpr (VD) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) vd_elem(xr[k - 3], w4.a[k + 1], w4.cw[k + 1], w4.sw[k + 1]);
-                vd_elem(xnext, na, ncw, nsw);
-            }
+            raw = t0 + EC + lane < a.T ? xg[t0 + EC + lane] : make_float2(0.5f, 0.5f);
             for (int tt = 0; tt < len; ++tt) {
                 float xin[F];
                 if constexpr (VD) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { w4.a[k] = w4.a[k + 1]; w4.cw[k] = w4.cw[k + 1]; w4.sw[k] = w4.sw[k + 1]; }
-                    w4.a[3] = na; w4.cw[3] = ncw; w4.sw[3] = nsw;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) xin[k] = w4.a[k];
-                } else { xin[0] = xnext.x; xin[1] = xnext.y; }
-                xnext = xr[min(tt + 1, len - 1)];                               // the next step's sample, off the recurrence's chain
-                if constexpr (VD) vd_elem(xnext, na, ncw, nsw);
-                float p = 0.0f, pre[NB];
+                    for (int k = 0; k < 4; ++k) xin[k] = ftab[(tt + k) * 4];          // |x| of times t - 3 .. t
+                } else {
+                    const float2 xv = *reinterpret_cast<const float2*>(ftab + (kHalo + tt) * 4);
+                    xin[0] = xv.x; xin[1] = xv.y;
+                }
+                float pre[NB];
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) {
                     float acc = bg[ob];
@@ -318,33 +322,49 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
                     gather_rows(is_g ? th : sg, g);
                     cs[ob] = __builtin_fmaf(g[1], cs[ob], g[0] * g[2]);
                     h[ob] = g[3] * tanhf_(cs[ob]);
+                    hist[tt * HS + 64 * ob + lane] = h[ob];
                 }
-                // head: row 0 -> y0, row 1 -> y1
-                float cc = bq;
-                if constexpr (VD) {
-                    float u[4], v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        u[k] = woc[k] * w4.cw[k]; v[k] = wos[k] * w4.sw[k];
-                        cc = __builtin_fmaf(u[k], bl1[k], __builtin_fmaf(v[k], bl2[k], cc));
-                    }
-#pragma unroll
-                    for (int ob = 0; ob < NB; ++ob) {
-                        float q = 0.0f;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) q = __builtin_fmaf(u[k], wl1[ob][k], __builtin_fmaf(v[k], wl2[ob][k], q));
-                        p = __builtin_fmaf(q, h[ob], p);
-                    }
-                } else {
-#pragma unroll
-                    for (int ob = 0; ob < NB; ++ob) p = __builtin_fmaf(wq[ob], h[ob], p);
-                }
-                const float y = row_sum16(p) + cc;
-                if (col == 0 && role < 2) ys[2 * tt + role] = y;
             }
             wave_lds_fence();
-            if (lane < len) reinterpret_cast<float2*>(yg)[t0 + lane] = reinterpret_cast<const float2*>(ys)[lane];
+            // the chunk's outputs, lane = time step
+            if (lane < len) {
+                const float4* hv4 = reinterpret_cast<const float4*>(hist + lane * HS);             // row 0's copy
+                float acc[VD ? 8 : 2];
+#pragma unroll
+                for (int r = 0; r < (VD ? 8 : 2); ++r) acc[r] = VD ? (r < 4 ? pl[L.o_b_l1 + r] : pl[L.o_b_l2 + r - 4]) : pl[L.o_b_out + r];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 hv = hv4[16 * ob + q];
+#pragma unroll
+                        for (int r = 0; r < (VD ? 8 : 2); ++r) {
+                            const float4 w = hw4[4 * NB * r + 4 * ob + q];
+                            acc[r] = __builtin_fmaf(w.x, hv.x, acc[r]); acc[r] = __builtin_fmaf(w.y, hv.y, acc[r]);
+                            acc[r] = __builtin_fmaf(w.z, hv.z, acc[r]); acc[r] = __builtin_fmaf(w.w, hv.w, acc[r]);
+                        }
+                    }
+                float y0, y1;
+                if constexpr (VD) {
+                    // y = fc_out(cat(l1 * cos, l2 * sin)) over the four-sample window (vdlstm.py:77-80)
+                    y0 = pl[L.o_b_out]; y1 = pl[L.o_b_out + 1];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 e = reinterpret_cast<const float4*>(ftab)[lane + k];
+                        const float lc = acc[k] * e.y, ls = acc[4 + k] * e.z;
+                        y0 = __builtin_fmaf(pl[L.o_w_out + k], lc, __builtin_fmaf(pl[L.o_w_out + 4 + k], ls, y0));
+                        y1 = __builtin_fmaf(pl[L.o_w_out + 8 + k], lc, __builtin_fmaf(pl[L.o_w_out + 12 + k], ls, y1));
+                    }
+                } else { y0 = acc[0]; y1 = acc[1]; }
+                yg[t0 + lane] = make_float2(y0, y1);
+            }
+            // the chunk's last three inputs become the next one's halo
+            float4 carry = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < kHalo) carry = reinterpret_cast<const float4*>(ftab)[len + lane];
+            wave_lds_fence();
+            if (lane < kHalo) reinterpret_cast<float4*>(ftab)[lane] = carry;
         }
+        wave_lds_fence();
     }
 }
 
@@ -708,7 +728,7 @@ static int lstm_launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
 }
 template <int NB, bool VD>
 static int lstm_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
-    const size_t lds = ((size_t)pad4(P) + LstmTabs<NB>::kFloats + 2 * (kHaloStride + kChunkPad)) * sizeof(float);
+    const size_t lds = ((size_t)pad4(P) + LstmTabs<NB>::kFloats + LstmEvalLds<NB>::kFloats) * sizeof(float);
     auto k = lstm_eval_kernel<NB, VD>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
