@@ -253,7 +253,8 @@ __global__ __launch_bounds__(kMaxThreads) void delta_fwd_kernel(SeqArgs a) {
 // -------------------------------------------------------------------------------------------------
 // evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): ONE sequence per wave.
 //  * gate-parallel: rows 0 / 1 / 2 of the wave accumulate r / z / n with their own rotated W_hh rows — one rotated dot product per
-//    step instead of three; r reaches the n row and (z, n) every row through four cross-row swaps, h' is updated redundantly;
+//    step instead of three; r reaches the n row and (z, n) every row through four cross-row swaps, h' is updated redundantly and
+//    parked — fc_out of a chunk follows with lane = time step;
 //  * everything that does not depend on the state is computed once per 64-step chunk with lane = time step — the six features and
 //    the TRes skip (TCN 2->3->2 with its two Hardswish) — and parked in LDS; the raw samples of the next chunk are already in
 //    flight while the current one is stepped;
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(kMaxThreads) void delta_fwd_kernel(SeqArgs a) {
 //    masked deltas reach the gates as wave-uniform operands (v_readlane).
 // Same thresholded arithmetic per element as delta_cell_fwd (accumulation order included); the sparsity counters are kept.
 // -------------------------------------------------------------------------------------------------
+constexpr int kDEvalHistStride = 64 + 4;
 template <bool TRES>
 __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -271,8 +273,12 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_delta_tabs<false>(tab, pl, L, lane, 0, 1);
+    constexpr int HS = kDEvalHistStride;
     float* feat = tab + kDTabFloats;                                           // [kEvalChunk][8]: f0..f5, skip0, skip1
-    float* ys = feat + kEvalChunk * 8;
+    float* hist = feat + kEvalChunk * 8;                                       // [kEvalChunk][HS]: h of time t0 + i, every lane's copy
+    float* hw = hist + kEvalChunk * HS;                                        // fc_out [2][16], zero padded
+    if (lane < 32) hw[lane] = (lane & 15) < L.H ? pl[L.o_w_out + (lane >> 4) * L.H + (lane & 15)] : 0.0f;
+    wave_lds_fence();
     const bool vo = col < H, gate_row = role < 3;
     float wrec[16], wih[6];
     load_rot(wrec, to_tab(reinterpret_cast<const float4*>(tab) + lane) + (gate_row ? role : 0) * 4 * 64);
@@ -285,8 +291,8 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
         if (role < 2) accx0 = pl[L.o_b_ih + role * H + col] + pl[L.o_b_hh + role * H + col];
         if (role == 2) { accx0 = pl[L.o_b_ih + 2 * H + col]; acch0 = pl[L.o_b_hh + 2 * H + col]; }
     }
-    const int c = role & 1, fc = col < 6 ? col : 5;
-    const float wq = vo ? pl[L.o_w_out + c * H + col] : 0.0f, bq = TRES ? 0.0f : pl[L.o_b_out + c];
+    const int fc = col < 6 ? col : 5;
+    const float bo0 = TRES ? 0.0f : pl[L.o_b_out], bo1 = TRES ? 0.0f : pl[L.o_b_out + 1];
     float w1[3][6], w2[2][3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -364,13 +370,25 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
                 float g4[4];
                 gather_rows(nrow ? n : sg, g4);
                 h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
-                float y = row_sum16(wq * h) + bq;
-                if constexpr (TRES) y += feat[tt * 8 + 6 + c];
-                if (col == 0 && role < 2) ys[2 * tt + role] = y;
+                hist[tt * HS + lane] = h;
             }
             wave_lds_fence();
-            if (lane < len) yg[t0 + lane] = reinterpret_cast<const float2*>(ys)[lane];
+            // fc_out (+ the skip) of the chunk, lane = time step
+            if (lane < len) {
+                const float4* hv4 = reinterpret_cast<const float4*>(hist + lane * HS);
+                const float4* hw4 = reinterpret_cast<const float4*>(hw);
+                float y0 = bo0, y1 = bo1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 hv = hv4[q], w0 = hw4[q], w1 = hw4[4 + q];
+                    y0 = __builtin_fmaf(w0.x, hv.x, y0); y0 = __builtin_fmaf(w0.y, hv.y, y0); y0 = __builtin_fmaf(w0.z, hv.z, y0); y0 = __builtin_fmaf(w0.w, hv.w, y0);
+                    y1 = __builtin_fmaf(w1.x, hv.x, y1); y1 = __builtin_fmaf(w1.y, hv.y, y1); y1 = __builtin_fmaf(w1.z, hv.z, y1); y1 = __builtin_fmaf(w1.w, hv.w, y1);
+                }
+                if constexpr (TRES) { y0 += feat[lane * 8 + 6]; y1 += feat[lane * 8 + 7]; }
+                yg[t0 + lane] = make_float2(y0, y1);
+            }
         }
+        wave_lds_fence();
     }
     if (a.stats != nullptr) {
         // dx zeros: the six feature lanes of row 0; dh zeros: the hidden units of row 0
@@ -618,7 +636,7 @@ static int delta_launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
 }
 template <bool TRES>
 static int delta_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
-    const size_t lds = ((size_t)pad4(P) + kDTabFloats + kEvalChunk * 8 + 2 * kEvalChunk) * sizeof(float);
+    const size_t lds = ((size_t)pad4(P) + kDTabFloats + kEvalChunk * 8 + kEvalChunk * kDEvalHistStride + 32) * sizeof(float);
     auto k = delta_eval_kernel<TRES>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);

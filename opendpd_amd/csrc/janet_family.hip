@@ -118,10 +118,13 @@ __global__ __launch_bounds__(kMaxThreads) void janet_fwd_kernel(SeqArgs a) {
 // evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): ONE sequence per wave, the seven H x H
 // products of a step in two rounds of one register-resident rotated dot product per 16-lane row instead of seven streamed from LDS.
 // Round A on h: rows a | p1 | p2 | f (its h half); round B: row 0 continues f on u, row 1 g on u, row 2 g on h.  Two three-swap gathers
-// hand every row (a, p1, p2, f_h) and then (f, g_u, g_h); h' is updated redundantly on all rows; the head's outputs are split over
-// rows 0 and 1.  Same arithmetic per element as janet_cell_fwd apart from g's pre-activation, summed as (b + W_gh h) + W_gu u.
+// hand every row (a, p1, p2, f_h) and then (f, g_u, g_h); h' is updated redundantly on all rows.  Same arithmetic per element as janet_cell_fwd apart from g's pre-activation, summed as (b + W_gh h) + W_gu u.
+// The step keeps only the recurrence: |x|, cos, sin of a 64-step chunk are computed with lane = time step and parked in LDS, a step
+// parks h, and fc_out of the chunk follows, one time step per lane.
 // -------------------------------------------------------------------------------------------------
+constexpr int kJEvalHistStride = 64 + 4;
 __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
+    constexpr int EC = kEvalChunk, HS = kJEvalHistStride;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;
     const JanetLayout L = janet_layout(a.H);
@@ -130,8 +133,11 @@ __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_janet_tabs<false>(tab, pl, L, lane, 0, 1);
-    float2* xs = reinterpret_cast<float2*>(tab + kJTabFloats);
-    float* ys = reinterpret_cast<float*>(xs + kEvalChunk);
+    float* ftab = tab + kJTabFloats;                   // [EC][4]: |x|, cos, sin of time t0 + i
+    float* hist = ftab + EC * 4;                       // [EC][HS]: h of time t0 + i, every lane's copy
+    float* hw = hist + EC * HS;                        // fc_out [2][16], zero padded
+    if (lane < 32) hw[lane] = (lane & 15) < H ? pl[L.o_wo + (lane >> 4) * H + (lane & 15)] : 0.0f;
+    wave_lds_fence();
     TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     const bool vo = col < H;
     float wa[16], wb[16];
@@ -145,8 +151,7 @@ __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
     const float sw = (vo && role < 3) ? pl[o_w + col * (H + 1) + H] : 0.0f;    // the row's scalar-input column
     const float ba = vo ? pl[o_b + col] : 0.0f;
     const float bg = (vo && role == 2) ? pl[L.o_bg + col] : 0.0f;
-    const int c = role & 1;
-    const float wq = vo ? pl[L.o_wo + c * H + col] : 0.0f, bq = pl[L.o_bo + c];
+    const int fsel = role < 3 ? role : 2;
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         float h = 0.0f;
@@ -154,20 +159,19 @@ __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
         float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * a.T;
         // the samples of a chunk are fetched while the previous one is stepped (lane = time step)
         float2 raw = lane < a.T ? xg[lane] : make_float2(0.5f, 0.5f);
-        for (int t0 = 0; t0 < a.T; t0 += kEvalChunk) {
-            const int len = min(kEvalChunk, a.T - t0);
-            wave_lds_fence();
-            xs[lane] = raw;
-            wave_lds_fence();
-            raw = t0 + kEvalChunk + lane < a.T ? xg[t0 + kEvalChunk + lane] : make_float2(0.5f, 0.5f);
-            float amp, ct, st;
-            janet_inputs(xs[0], amp, ct, st);
-            float sc = role == 0 ? amp : role == 1 ? ct : st;
+        for (int t0 = 0; t0 < a.T; t0 += EC) {
+            const int len = min(EC, a.T - t0);
+            {
+                float amp, ct, st;
+                janet_inputs(raw, amp, ct, st);
+                wave_lds_fence();
+                reinterpret_cast<float4*>(ftab)[lane] = make_float4(amp, ct, st, 0.0f);
+                wave_lds_fence();
+            }
+            raw = t0 + EC + lane < a.T ? xg[t0 + EC + lane] : make_float2(0.5f, 0.5f);
             for (int tt = 0; tt < len; ++tt) {
-                const float sc0 = sc;
-                janet_inputs(xs[min(tt + 1, len - 1)], amp, ct, st);            // the next step's inputs, off the recurrence's chain
-                sc = role == 0 ? amp : role == 1 ? ct : st;
-                const float pa = rotdot(__builtin_fmaf(sw, sc0, ba), wa, h);
+                const float sc = ftab[tt * 4 + fsel];                           // the row's scalar input: |x| | cos | sin
+                const float pa = rotdot(__builtin_fmaf(sw, sc, ba), wa, h);
                 float g4[4];
                 gather_rows(role == 3 ? pa : tanhf_(pa), g4);
                 const float an = g4[0], p1 = g4[1], p2 = g4[2];
@@ -176,12 +180,24 @@ __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
                 gather_rows(pb, g4);
                 const float f = sigmoidf_(g4[0]), g = tanhf_(g4[2] + g4[1]);
                 h = __builtin_fmaf(f, h - g, g);
-                const float y = row_sum16(wq * h) + bq;
-                if (col == 0 && role < 2) ys[2 * tt + role] = y;
+                hist[tt * HS + lane] = h;
             }
             wave_lds_fence();
-            if (lane < len) yg[t0 + lane] = reinterpret_cast<const float2*>(ys)[lane];
+            // fc_out of the chunk, lane = time step
+            if (lane < len) {
+                const float4* hv4 = reinterpret_cast<const float4*>(hist + lane * HS);
+                const float4* hw4 = reinterpret_cast<const float4*>(hw);
+                float y0 = pl[L.o_bo], y1 = pl[L.o_bo + 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 hv = hv4[q], w0 = hw4[q], w1 = hw4[4 + q];
+                    y0 = __builtin_fmaf(w0.x, hv.x, y0); y0 = __builtin_fmaf(w0.y, hv.y, y0); y0 = __builtin_fmaf(w0.z, hv.z, y0); y0 = __builtin_fmaf(w0.w, hv.w, y0);
+                    y1 = __builtin_fmaf(w1.x, hv.x, y1); y1 = __builtin_fmaf(w1.y, hv.y, y1); y1 = __builtin_fmaf(w1.z, hv.z, y1); y1 = __builtin_fmaf(w1.w, hv.w, y1);
+                }
+                yg[t0 + lane] = make_float2(y0, y1);
+            }
         }
+        wave_lds_fence();
     }
 }
 
@@ -374,7 +390,7 @@ int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (janet_uses_s16(m, a.B)) return janet_s16_launch(st, m, a, 1);
     const int P = janet_layout(m->hidden).P;
     if (a.ckpt == nullptr && a.B <= 8 && a.T >= 256 && tuning().s16_min_batch != 0) {     // inference on a few long sequences
-        const size_t lds = ((size_t)pad4(P) + kJTabFloats + 4 * kEvalChunk) * sizeof(float);
+        const size_t lds = ((size_t)pad4(P) + kJTabFloats + kEvalChunk * 4 + kEvalChunk * kJEvalHistStride + 32) * sizeof(float);
         if (int e = allow_big_lds(janet_eval_kernel, lds)) return e;
         hipLaunchKernelGGL(janet_eval_kernel, dim3(a.B), dim3(64), lds, st, a);
         return (int)hipGetLastError();
