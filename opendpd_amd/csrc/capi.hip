@@ -58,6 +58,8 @@ odpd::Tuning& odpd::tuning() {
         v.s16_min_batch = e ? atol(e) : -1;   // -1 = built-in crossover
         e = getenv("ODPD_S16_OCCUPANCY");
         v.s16_occupancy = e ? atoi(e) : 0;    // 0 = by batch size
+        e = getenv("ODPD_GP_MAX_BATCH");
+        v.gp_max_batch = e ? atol(e) : -1;    // -1 = built-in crossover, 0 = never the gate-parallel fused train kernel
         return v;
     }();
     return t;
@@ -67,6 +69,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
     if (!key) return ODPD_EINVAL;
     if (!strcmp(key, "s16_min_batch")) { tuning().s16_min_batch = (long)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "s16_occupancy")) { tuning().s16_occupancy = (int)value; ++g_tuning_generation; return 0; }
+    if (!strcmp(key, "gp_max_batch")) { tuning().gp_max_batch = (long)value; ++g_tuning_generation; return 0; }
     return ODPD_EINVAL;
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }

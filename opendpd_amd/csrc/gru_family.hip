@@ -829,6 +829,300 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
 }
 
 // -------------------------------------------------------------------------------------------------
+// Gate-parallel fused train kernel for the reference's own batch sizes (64 .. ~1 000 frames of 50 / 200 samples, train_funcs.py:28-48):
+// there a wave is alone on its SIMD and the T-serial chain is the whole cost, so ONE sequence per wave (one wave per workgroup) and
+// only the recurrence in the step loops.  hidden <= 16.
+//   forward   gate-parallel as gru_eval_kernel (rows r | n | head | z, one rotated dot product per step); every h(t) — and, DGRU,
+//             every relu(fc_hid h(t)) from the head row — is parked in LDS, features come per 64-step chunk with lane = time step;
+//   head      fc_out, the loss and dL/dy of all T steps with lane = time step;
+//   backward  per step ONE rotated dot product with the forward weights (gates recomputed from the parked h(t-1): no serial
+//             recompute chain) and ONE with the transposed weights — rows r | n | z multiply their own gate's pre-activation gradient,
+//             the head row multiplies fc_hid^T dhid of the step below, and the cross-row sum is dL/dh(t-1) complete;
+//             the weight gradients of a step are TWO 4-block MFMAs (v_mfma_f32_16x16x1_4b_f32: block k = the outer product of row k's
+//             operands): (d_r | d_gh | d_hid | d_z) x (h(t-1) | h(t-1) | h(t) | h(t-1)) and (d_r | d_n | 0 | d_z) x (features | 1).
+// LDS per wave: parameters + max(weight tables — read once into registers —, the per-time buffers: 8 + 16 (+ 16) + 2 floats per step).
+// One partial-gradient row per workgroup.
+// -------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <bool DG>
+__host__ __device__ inline int gp_buffer_floats(int T, bool pg) {
+    const int Tp = (T + 63) & ~63;
+    const int buf = Tp * 8 + (Tp + 2) * 16 + (DG ? Tp * 16 : 0) + Tp * 2 + 256 + 48 + (pg ? Tp * 64 : 0);
+    const int tabf = GruTabs<1, DG>::kFloats;
+    return buf > tabf ? buf : tabf;
+}
+// PG: the forward pass also parks (r, W_hn h + b, z, n) of every step (16 B per unit and step) and the backward pass reads them back instead
+// of recomputing the gates — taken while the frame's buffers fit the CU's LDS share
+template <int FM, bool DG, bool PG>
+__global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
+    constexpr int F = FeatDim<FM>::F;
+    using TB = GruTabs<1, DG>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // 0 r | 1 n | 2 head | 3 z
+    const GruLayout L = gru_layout(a.H, F, DG);
+    const int H = L.H, OW = DG ? H + 6 : H, T = a.T, Tp = (T + 63) & ~63;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_gru_tabs<1, DG, true>(tab, pl, L, lane, 0, 1);
+    const int gate = role == 0 ? 0 : role == 3 ? 1 : 2;
+    const bool vo = col < H, head_row = role == 2;
+    // the row's rotated weights, forward and transposed (head row: fc_hid for DGRU, nothing otherwise)
+    float wF[16], wT[16];
+    {
+        TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + col);
+        int rf = TB::kHH + gate, rt = TB::kHHT + gate;
+        if constexpr (DG) { if (head_row) { rf = TB::kHID; rt = TB::kHIDT; } }
+        load_rot(wF, tl + rf * 4 * 64);
+        load_rot(wT, tl + rt * 4 * 64);
+        if (!DG && head_row) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { wF[k] = 0.0f; wT[k] = 0.0f; }
+        }
+    }
+    float win[F], b_in = 0.0f, b_rec = 0.0f;
+#pragma unroll
+    for (int i = 0; i < F; ++i) win[i] = (vo && !head_row) ? pl[L.o_w_ih + (gate * H + col) * F + i] : 0.0f;
+    if (vo) {
+        if (role == 0 || role == 3) b_in = pl[L.o_b_ih + gate * H + col] + pl[L.o_b_hh + gate * H + col];
+        if (role == 1) { b_in = pl[L.o_b_ih + 2 * H + col]; b_rec = pl[L.o_b_hh + 2 * H + col]; }
+        if (head_row && DG) b_rec = pl[L.o_b_hid + col];
+    }
+    const float wo0 = vo ? pl[L.o_w_out + col] : 0.0f, wo1 = vo ? pl[L.o_w_out + OW + col] : 0.0f;
+    const float bo0 = pl[L.o_b_out], bo1 = pl[L.o_b_out + 1];
+    wave_lds_fence();
+    // per-time buffers over the tables
+    float* ftab = tab;                                  // [Tp][8]   features of step t
+    float* hist = ftab + Tp * 8;                        // [Tp + 2][16]   entry t + 1 = h(t), entry 0 = h(-1) = 0
+    float* actb = hist + (Tp + 2) * 16;                 // DGRU: [Tp][16]   relu(fc_hid h(t) + b)
+    float* dyb = actb + (DG ? Tp * 16 : 0);             // [Tp][2]   dL/dy(t)
+    float* dump = dyb + Tp * 2;                         // [256]
+    float* hw = dump + 256;                             // fc_out: [2][16] hidden columns (zero padded) | [2][8] feature columns
+    float* gpk = hw + 48;                               // PG: [Tp][16][4]   r, W_hn h + b_hn, z, n of step t (written by the n row)
+    if (lane < 48) {
+        float v = 0.0f;
+        if (lane < 32) { const int c = lane >> 4, u = lane & 15; if (u < H) v = pl[L.o_w_out + c * OW + u]; }
+        else { const int j = lane - 32, c = j >> 3, k = j & 7; if (DG && k < 6) v = pl[L.o_w_out + c * OW + H + k]; }
+        hw[lane] = v;
+    }
+    if (lane < 16) hist[lane] = 0.0f;
+    const float4* ftab4 = reinterpret_cast<const float4*>(ftab);
+    const float4* hw4 = reinterpret_cast<const float4*>(hw);
+    const bool odd = role & 1;
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
+    // the per-step store of the forward pass: row 1 parks h(t), the head row parks relu(fc_hid h(t-1)), rows 0 / 3 hit the dump
+    const int park0 = role == 1 ? (int)(hist - smem) + 16 + col : (head_row && DG) ? (int)(actb - smem) - 16 + col : (int)(dump - smem) + lane;
+    const int park_step = (role == 1 || (head_row && DG)) ? 16 : 0;
+    const int gpark0 = role == 1 ? (int)(gpk - smem) + 4 * col : (int)(dump - smem) + 4 * lane, gpark_step = role == 1 ? 64 : 0;
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
+    float dmisc = 0.0f, dwo0 = 0.0f, dwo1 = 0.0f, dwf0 = 0.0f, dwf1 = 0.0f, dbo0 = 0.0f, dbo1 = 0.0f, loss_acc = 0.0f;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        // ---- forward ----
+        {
+            float h = 0.0f;
+            int park = park0, gpark = gpark0;
+            float2 raw = lane < T ? xg[lane] : make_float2(0.5f, 0.5f);
+            for (int t0 = 0; t0 < T; t0 += kEvalChunk) {
+                const int len = min(kEvalChunk, T - t0);
+                {
+                    float f[F];
+                    feat_fwd<FM>(raw.x, raw.y, f);
+                    float f8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f8[i] = i < F ? f[i] : 0.0f;
+                    wave_lds_fence();
+                    reinterpret_cast<float4*>(ftab)[2 * (t0 + lane)] = make_float4(f8[0], f8[1], f8[2], f8[3]);
+                    reinterpret_cast<float4*>(ftab)[2 * (t0 + lane) + 1] = make_float4(f8[4], f8[5], f8[6], f8[7]);
+                    wave_lds_fence();
+                }
+                raw = t0 + kEvalChunk + lane < T ? xg[t0 + kEvalChunk + lane] : make_float2(0.5f, 0.5f);
+                for (int tt = 0; tt < len; ++tt) {
+                    const int t = t0 + tt;
+                    float f[F];
+                    {
+                        const float4 fa = ftab4[2 * t];
+                        f[0] = fa.x; f[1] = fa.y;
+                        if constexpr (F > 2) { f[2] = fa.z; f[3] = fa.w; }
+                        if constexpr (F > 4) { const float4 fb = ftab4[2 * t + 1]; f[4] = fb.x; f[5] = fb.y; }
+                    }
+                    const float arec = rotdot(b_rec, wF, h);
+                    const float parked = __builtin_fmaxf(arec, 0.0f);             // head row: relu(fc_hid h(t-1) + b)
+                    float ain = b_in;
+#pragma unroll
+                    for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[i], f[i], ain);
+                    const float sg = sigmoidf_(ain + arec);                     // r (row 0), z (row 3)
+                    const float r1 = xor16(sg);                                 // row 1 <- r
+                    const float n = tanhf_(__builtin_fmaf(r1, arec, ain));      // row 1
+                    const float v = role == 1 ? n : sg;
+                    const float o = xor32(v);                                   // row 1 <- z, row 3 <- n
+                    const float zz = role == 1 ? o : sg, nn = role == 1 ? n : o;
+                    const float h13 = __builtin_fmaf(zz, h - nn, nn);           // rows 1 and 3: (1 - z) n + z h
+                    const float h02 = xor16(h13);
+                    h = odd ? h13 : h02;
+                    smem[park] = head_row ? parked : h;          // (the head row's first store, act(-1), lands in hist's pad entry)
+                    park += park_step;
+                    if constexpr (PG) {
+                        *reinterpret_cast<float4*>(smem + gpark) = make_float4(r1, arec, zz, nn);
+                        gpark += gpark_step;
+                    }
+                }
+            }
+            if constexpr (DG) {
+                const float arec = rotdot(b_rec, wF, h);
+                if (head_row) actb[(T - 1) * 16 + col] = __builtin_fmaxf(arec, 0.0f);
+            }
+            wave_lds_fence();
+        }
+        // ---- fc_out, loss and dL/dy of every step, lane = time step ----
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < T) {
+                const float4* hv4 = reinterpret_cast<const float4*>(DG ? actb + t * 16 : hist + (t + 1) * 16);
+                float y0 = bo0, y1 = bo1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 hv = hv4[q], w0 = hw4[q], w1 = hw4[4 + q];
+                    y0 = __builtin_fmaf(w0.x, hv.x, y0); y0 = __builtin_fmaf(w0.y, hv.y, y0); y0 = __builtin_fmaf(w0.z, hv.z, y0); y0 = __builtin_fmaf(w0.w, hv.w, y0);
+                    y1 = __builtin_fmaf(w1.x, hv.x, y1); y1 = __builtin_fmaf(w1.y, hv.y, y1); y1 = __builtin_fmaf(w1.z, hv.z, y1); y1 = __builtin_fmaf(w1.w, hv.w, y1);
+                }
+                if constexpr (DG) {
+                    const float4 fa = ftab4[2 * t], fb = ftab4[2 * t + 1];
+                    const float4 u0 = hw4[8], u1 = hw4[9], v0 = hw4[10], v1 = hw4[11];
+                    y0 = __builtin_fmaf(u0.x, fa.x, y0); y0 = __builtin_fmaf(u0.y, fa.y, y0); y0 = __builtin_fmaf(u0.z, fa.z, y0); y0 = __builtin_fmaf(u0.w, fa.w, y0);
+                    y0 = __builtin_fmaf(u1.x, fb.x, y0); y0 = __builtin_fmaf(u1.y, fb.y, y0);
+                    y1 = __builtin_fmaf(v0.x, fa.x, y1); y1 = __builtin_fmaf(v0.y, fa.y, y1); y1 = __builtin_fmaf(v0.z, fa.z, y1); y1 = __builtin_fmaf(v0.w, fa.w, y1);
+                    y1 = __builtin_fmaf(v1.x, fb.x, y1); y1 = __builtin_fmaf(v1.y, fb.y, y1);
+                }
+                const float2 tv = tg[t];
+                float dy0, dy1;
+                s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+                *reinterpret_cast<float2*>(dyb + 2 * t) = make_float2(dy0, dy1);
+            }
+        }
+        wave_lds_fence();
+        // ---- backward ----
+        {
+            float carry = 0.0f, dhid_cur = 0.0f;       // carry = dL/dh(t) complete (cell path + head path)
+            if constexpr (DG) {
+                const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * (T - 1));
+                const float at = actb[(T - 1) * 16 + col];
+                dhid_cur = __builtin_fmaf(dyv.x, wo0, dyv.y * wo1) * relu_gate(at);
+                float part = rotdot(0.0f, wT, head_row ? dhid_cur : 0.0f);
+                part += xor16(part);
+                part += xor32(part);
+                carry = part;
+            }
+            for (int t = T - 1; t >= 0; --t) {
+                const float hp = hist[t * 16 + col], ht = hist[(t + 1) * 16 + col];
+                const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
+                float f[F];
+                {
+                    const float4 fa = ftab4[2 * t];
+                    f[0] = fa.x; f[1] = fa.y;
+                    if constexpr (F > 2) { f[2] = fa.z; f[3] = fa.w; }
+                    if constexpr (F > 4) { const float4 fb = ftab4[2 * t + 1]; f[4] = fb.x; f[5] = fb.y; }
+                }
+                const float fsx = col < F ? ftab[t * 8 + col] : (col == F ? 1.0f : 0.0f);
+                // the gates of step t: parked by the forward pass, or again from the parked h(t-1)
+                float arec, r1, zz, nn;                                             // rows 1 and 3: z, n; row 1: r, W_hn h + b_hn
+                if constexpr (PG) {
+                    const float4 g = reinterpret_cast<const float4*>(gpk)[t * 16 + col];
+                    r1 = g.x; arec = g.y; zz = g.z; nn = g.w;
+                } else {
+                    arec = rotdot(b_rec, wF, hp);
+                    float ain = b_in;
+#pragma unroll
+                    for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[i], f[i], ain);
+                    const float sg = sigmoidf_(ain + arec);
+                    r1 = xor16(sg);
+                    const float n = tanhf_(__builtin_fmaf(r1, arec, ain));
+                    const float v = role == 1 ? n : sg;
+                    const float o = xor32(v);
+                    zz = role == 1 ? o : sg; nn = role == 1 ? n : o;
+                }
+                // dL/dh(t) and the pre-activation gradients (rows 1 / 3; row 0 receives d_r from row 1)
+                const float g01 = __builtin_fmaf(dyv.x, wo0, dyv.y * wo1);
+                const float dht = DG ? carry : carry + g01;
+                const float dn = dht * (1.0f - zz), dz = dht * (hp - nn);
+                const float dnp = dn * __builtin_fmaf(-nn, nn, 1.0f);
+                const float dgh = dnp * r1;
+                const float drp1 = (dnp * arec) * (r1 * (1.0f - r1));
+                const float dzp = dz * (zz * (1.0f - zz));
+                const float drp0 = xor16(drp1);
+                float dhid_prev = 0.0f;
+                if constexpr (DG) {
+                    const int tm = t > 0 ? t - 1 : 0;
+                    const float2 dyp = *reinterpret_cast<const float2*>(dyb + 2 * tm);
+                    const float atp = actb[tm * 16 + col];
+                    dhid_prev = t > 0 ? __builtin_fmaf(dyp.x, wo0, dyp.y * wo1) * relu_gate(atp) : 0.0f;
+                }
+                const float d_row = role == 0 ? drp0 : role == 1 ? dgh : role == 3 ? dzp : dhid_prev;
+                float part = rotdot(role == 3 ? dht * zz : 0.0f, wT, d_row);
+                part += xor16(part);
+                part += xor32(part);
+                carry = part;                                                      // dL/dh(t-1): W_hh^T d + z dL/dh(t) + fc_hid^T dhid(t-1)
+                // weight gradients
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(head_row ? dhid_cur : d_row, head_row ? ht : hp, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(role == 1 ? dnp : (head_row ? 0.0f : d_row), fsx, acc2, 0, 0, 0);
+                dmisc += role == 1 ? dgh : dhid_cur;                               // row 1: db_hn, head row: db_hid
+                const float at = DG ? actb[t * 16 + col] : ht;
+                dwo0 = __builtin_fmaf(dyv.x, at, dwo0); dwo1 = __builtin_fmaf(dyv.y, at, dwo1);
+                if constexpr (DG) {
+                    const float fs = col < 6 ? fsx : 0.0f;
+                    dwf0 = __builtin_fmaf(dyv.x, fs, dwf0); dwf1 = __builtin_fmaf(dyv.y, fs, dwf1);
+                }
+                dbo0 += dyv.x; dbo1 += dyv.y;
+                dhid_cur = dhid_prev;
+            }
+        }
+        wave_lds_fence();
+    }
+    // ---- the workgroup's row of partial gradients (every entry written) ----
+    float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
+    float lp = loss_acc;
+    for (int o = 32; o > 0; o >>= 1) lp += __shfl_down(lp, o);
+    if (vo) {
+        if (role == 1) prow[L.o_b_hh + 2 * H + col] = dmisc;
+        if (DG && head_row) prow[L.o_b_hid + col] = dmisc;
+        if (role == 0) { prow[L.o_w_out + col] = dwo0; prow[L.o_w_out + OW + col] = dwo1; }
+    }
+    if (DG && role == 0 && col < 6) { prow[L.o_w_out + H + col] = dwf0; prow[L.o_w_out + OW + H + col] = dwf1; }
+    if (lane == 0) {
+        prow[L.o_b_out] = dbo0; prow[L.o_b_out + 1] = dbo1;
+        prow[L.P] = lp; prow[L.P + 1] = 0.0f; prow[L.P + 2] = 0.0f; prow[L.P + 3] = 0.0f;
+    }
+    // MFMA blocks: 0 = r, 1 = n, 2 = fc_hid, 3 = z; register 4 blk + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        const int g = blk == 0 ? 0 : blk == 3 ? 1 : 2;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * role + rr, c = col;
+            if (i < H) {
+                if (blk == 2) {
+                    if (DG && c < H) prow[L.o_w_hid + i * H + c] = acc1[4 * blk + rr];
+                } else {
+                    if (c < H) prow[L.o_w_hh + (g * H + i) * H + c] = acc1[4 * blk + rr];
+                    const float v = acc2[4 * blk + rr];
+                    if (c < F) prow[L.o_w_ih + (g * H + i) * F + c] = v;
+                    else if (c == F) {
+                        prow[L.o_b_ih + g * H + i] = v;
+                        if (g < 2) prow[L.o_b_hh + g * H + i] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
 constexpr int kFwdWavesPerCU = 16;  // 4 waves per SIMD (forward kernels use <= 128 VGPRs for R = 1)
@@ -1000,9 +1294,51 @@ int gru_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     ODPD_GRU_DISPATCH_ALL(launch_bwd_mode, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
+// the gate-parallel fused train kernel: one sequence per single-wave workgroup, BPTT state of the whole frame in LDS
+static size_t gp_lds_bytes(int P, bool DG, int T, bool pg) {
+    return ((size_t)pad4(P) + (DG ? gp_buffer_floats<true>(T, pg) : gp_buffer_floats<false>(T, pg))) * sizeof(float);
+}
+// workgroups of a CU that the frame's LDS-resident BPTT state allows (at most one per SIMD)
+static int gp_blocks_per_cu(int P, bool DG, int T, bool pg) {
+    const size_t lds = gp_lds_bytes(P, DG, T, pg);
+    const int n = lds > kMaxLds ? 0 : (int)(kMaxLds / lds);
+    return n < 4 ? n : 4;
+}
+// the variant that parks the gates is taken while every sequence of the batch still gets its own SIMD
+static bool gp_parks_gates(int P, bool DG, int B, int T) { return (long)B <= (long)device_cus() * gp_blocks_per_cu(P, DG, T, true); }
+bool gru_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P) || R != 1 || gru_train_uses_s16(m, B, T)) return false;
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0) return B <= max_batch && gp_blocks_per_cu(P, DG, T, false) > 0;
+    return (long)B <= (long)device_cus() * gp_blocks_per_cu(P, DG, T, false);        // one sequence per SIMD, all resident at once
+}
+static int gp_grid(int P, bool DG, int B, int T) {
+    const bool pg = gp_parks_gates(P, DG, B, T);
+    const long cap = (long)device_cus() * (kMaxLds / gp_lds_bytes(P, DG, T, pg));
+    return B < cap ? B : (int)cap;
+}
+template <int FM, bool DG>
+static int launch_gp_train(hipStream_t st, const SeqArgs& a, int P) {
+    const bool pg = gp_parks_gates(P, DG, a.B, a.T);
+    const size_t lds = gp_lds_bytes(P, DG, a.T, pg);
+    const int grid = gp_grid(P, DG, a.B, a.T);
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    return pg ? launch(gru_gp_train_kernel<FM, DG, true>) : launch(gru_gp_train_kernel<FM, DG, false>);
+}
 int gru_family_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
+    if (gru_train_uses_gp(m, a.B, a.T)) {
+        if (FM == FEAT_RAW2) return launch_gp_train<FEAT_RAW2, false>(st, a, P);
+        if (FM == FEAT_DGRU6) return launch_gp_train<FEAT_DGRU6, true>(st, a, P);
+        if (FM == FEAT_Q4) return launch_gp_train<FEAT_Q4, false>(st, a, P);
+        return launch_gp_train<FEAT_A4, false>(st, a, P);
+    }
     ODPD_GRU_DISPATCH_ALL(launch_train, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
@@ -1031,6 +1367,7 @@ int gru_family_rows(const odpd_model_t* m, int B, int which, int T) {
     if (gru_uses_s16n(m, B)) return gru_s16n_rows(m, B);
     if (!which) return gru_split_uses_s16(m, B) ? gru_s16_bwd_rows(m, B) : bwd_shape(R, ng).grid;
     if (gru_train_uses_s16(m, B, T)) return gru_s16_rows(m, B);
+    if (gru_train_uses_gp(m, B, T)) return gp_grid(P, DG, B, T);
     const LaunchShape ls = train_shape(P, R, DG, ng, T, nullptr);
     return ls.grid > 0 ? ls.grid : ODPD_EUNSUPPORTED;
 }
