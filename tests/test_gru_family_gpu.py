@@ -252,6 +252,51 @@ def test_fused_step_on_frames_addressed_in_place(bb, H, B, T, stride):
 
 
 @pytest.mark.parametrize("bb", ["gru", "dgru", "qgru", "qgru_amp1"])
+@pytest.mark.parametrize("H", [1, 5, 13, 16])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (7, 63), (5, 64), (2, 65), (64, 50), (9, 200), (300, 200), (5, 130)])
+def test_gate_parallel_train_kernel(bb, H, B, T):
+    """the reference's own batch sizes run gru_gp_train_kernel (one sequence per wave, rows r / n / head / z; fc_out, loss and features with
+    lane = time step; weight gradients as 4-block MFMAs; (300, 200) does not park the gates, the smaller batches do): loss and gradient
+    against the oracle (L2 and L1), and against the row-rotated fused kernel (odpd_set_tuning gp_max_batch = 0) on the same batch"""
+    import ctypes as C
+    from opendpd_amd import CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    lib = _lib.load()
+    torch.manual_seed(H * 100 + B + T)
+    net = CoreModel(2, H, 1, bb).cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    rng = np.random.RandomState(B * 13 + T)
+    amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    tgt = (0.4 * rng.randn(B, T, 2)).astype(np.float32)
+    xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    o, m = Oracle("f32"), make_model(bb, H)
+    yo, _ = o.forward(m, p, x)
+    try:
+        for kind in ("l2", "l1"):
+            d = yo - tgt
+            lo = float((d * d).mean()) if kind == "l2" else float(np.abs(d).mean())
+            dy = (2 * d / d.size if kind == "l2" else np.sign(d) / d.size).astype(np.float32)
+            go, _ = o.backward(m, p, x, dy, need_dx=False)
+            got = {}
+            for gp in (-1, 0):
+                lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(gp))
+                opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+                loss = fused_train_step(opt, xt, tt, kind, 0.0)
+                got[gp] = (float(loss), opt.grad[:-4].cpu().numpy().copy())
+            assert abs(got[-1][0] - lo) < 2e-5 * max(1.0, lo) and abs(got[-1][0] - got[0][0]) < 1e-6 * max(1.0, lo)
+            assert rel_err(got[-1][1], go) < GRAD_TOL and rel_err(got[-1][1], got[0][1]) < 2e-5
+            assert T < 50 or not np.array_equal(got[-1][1], got[0][1])          # two kernels: different summation orders
+    finally:
+        lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
+
+
+@pytest.mark.parametrize("bb", ["gru", "dgru", "qgru", "qgru_amp1"])
 @pytest.mark.parametrize("H", [1, 8, 13, 16, 17, 23, 32])
 @pytest.mark.parametrize("B,T", [(1, 700), (3, 2560), (2, 256), (8, 257)])
 def test_evaluation_kernel_matches_the_oracle(bb, H, B, T):
