@@ -8,6 +8,7 @@
 // per phase, BPTT by checkpoint (h,c every kCkptStride steps) + block recompute, exact-fp32 MFMA
 // weight gradients, one partial-gradient row per workgroup.
 #include "odpd_seq.h"
+#include "odpd_s16.h"
 
 namespace odpd {
 
@@ -366,6 +367,290 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
         }
         wave_lds_fence();
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Gate-parallel fused train kernel for the reference's own batch sizes (train_funcs.py:28-48; a wave is alone on its SIMD there and the
+// T-serial chain is the whole cost): ONE sequence per wave (one wave per workgroup), hidden <= 16, only the recurrence in the step loops.
+//   forward   as lstm_eval_kernel (row k = gate k); h(t), c(t), tanh c(t) — and, PG, the four gates — of every step are parked in LDS;
+//   head      outputs, loss, dL/dy (VD: dL/d lambda_1/2, the fc_out gradient) of all T steps with lane = time step;
+//   backward  per step ONE rotated dot product with the transposed weights: every row multiplies its own gate's pre-activation gradient,
+//             the cross-row sum is dL/dh(t-1); the weight gradients of a step are TWO 4-block MFMAs (v_mfma_f32_16x16x1_4b_f32, block k =
+//             gate k): (d_i | d_f | d_g | d_o) x h(t-1) and x (inputs | 1).  !PG recomputes the gates from the parked h(t-1).
+// One partial-gradient row per workgroup.
+// -------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <bool VD>
+__host__ __device__ inline int lstm_gp_buffer_floats(int T, bool pg) {
+    const int Tp = (T + 63) & ~63;
+    const int buf = (Tp + 4) * 4 + 3 * (Tp + 2) * 16 + Tp * 2 + (VD ? Tp * 8 : 0) + 256 + 8 * 16 + (pg ? Tp * 64 : 0);
+    const int tabf = LstmTabs<1>::kFloats;
+    return buf > tabf ? buf : tabf;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <bool VD, bool PG>
+__global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
+    constexpr int F = VD ? 4 : 2, NH = VD ? 8 : 2;
+    using TB = LstmTabs<1>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // gate i | f | g | o
+    const LstmLayout L = lstm_layout(a.H, VD);
+    const int H = L.H, T = a.T, Tp = (T + 63) & ~63;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_lstm_tabs<1, true>(tab, pl, L, lane, 0, 1);
+    const bool vo = col < H, is_g = role == 2;
+    float wF[16], wT[16];
+    {
+        TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + col);
+        load_rot(wF, tl + (TB::kHH + role) * 4 * 64);
+        load_rot(wT, tl + (TB::kHHT + role) * 4 * 64);
+    }
+    float win[F];
+#pragma unroll
+    for (int i = 0; i < F; ++i) win[i] = vo ? pl[L.o_w_ih + (role * H + col) * F + i] : 0.0f;
+    const float bg = vo ? pl[L.o_b_ih + role * H + col] + pl[L.o_b_hh + role * H + col] : 0.0f;
+    // head operands of a unit: plain fc_out columns, or the fc_lambda_1/2 columns of the VDLSTM
+    float wh[NH];
+#pragma unroll
+    for (int r = 0; r < NH; ++r)
+        wh[r] = !vo ? 0.0f : VD ? (r < 4 ? pl[L.o_w_l1 + r * H + col] : pl[L.o_w_l2 + (r - 4) * H + col]) : pl[L.o_w_out + r * H + col];
+    wave_lds_fence();
+    // per-time buffers over the tables
+    float* ftab = tab;                                  // [Tp + 4][4]   entry 3 + t = inputs of step t (I, Q | |x|, cos, sin); entries 0..2 = the circular halo
+    float* hist = ftab + (Tp + 4) * 4;                  // [Tp + 2][16]  entry t + 1 = h(t), entry 0 = 0
+    float* cpk = hist + (Tp + 2) * 16;                  // [Tp + 2][16]  entry t + 1 = c(t), entry 0 = 0
+    float* tpk = cpk + (Tp + 2) * 16;                   // [Tp + 2][16]  entry t + 1 = tanh c(t)
+    float* dyb = tpk + (Tp + 2) * 16;                   // [Tp][2]       dL/dy(t)
+    float* dlb = dyb + Tp * 2;                          // VD: [Tp][8]   dL/d lambda_1[0..3], lambda_2[0..3] of step t
+    float* dump = dlb + (VD ? Tp * 8 : 0);              // [256]
+    float* hw = dump + 256;                             // head rows [8][16], zero padded (as lstm_eval_kernel)
+    float* gpk = hw + 8 * 16;                           // PG: [Tp][16][4]  i, f, g, o of step t
+    for (int i = lane; i < 8 * 16; i += 64) {
+        const int r = i >> 4, u = i & 15;
+        float v = 0.0f;
+        if (u < H) {
+            if (VD) v = r < 4 ? pl[L.o_w_l1 + r * H + u] : pl[L.o_w_l2 + (r - 4) * H + u];
+            else if (r < 2) v = pl[L.o_w_out + r * H + u];
+        }
+        hw[i] = v;
+    }
+    if (lane < 16) { hist[lane] = 0.0f; cpk[lane] = 0.0f; tpk[lane] = 0.0f; }
+    const float4* hw4 = reinterpret_cast<const float4*>(hw);
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
+    // the per-step stores of the forward pass: row 1 parks h, row 2 c, row 3 tanh c (row 0 hits the dump); PG: row 0 parks the gates
+    const int park0 = role == 0 ? (int)(dump - smem) + lane : (int)((role == 1 ? hist : role == 2 ? cpk : tpk) - smem) + 16 + col;
+    const int park_step = role == 0 ? 0 : 16;
+    const int gpark0 = role == 0 ? (int)(gpk - smem) + 4 * col : (int)(dump - smem) + 4 * lane, gpark_step = role == 0 ? 64 : 0;
+    const int xcol = VD ? 4 * col : 4 * 3 + col;                               // input `col` of step t: ftab[4 t + xcol]
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
+    float dwh[NH], tacc[VD ? 26 : 2], loss_acc = 0.0f;     // per unit: head-row gradients; per time lane: fc_out (VD) and head bias gradients
+#pragma unroll
+    for (int r = 0; r < NH; ++r) dwh[r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < (VD ? 26 : 2); ++r) tacc[r] = 0.0f;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        auto park_in = [&](int entry, float2 xv) {
+            float4 e = make_float4(xv.x, xv.y, 0.0f, 0.0f);
+            if constexpr (VD) vd_elem(xv, e.x, e.y, e.z);
+            reinterpret_cast<float4*>(ftab)[entry] = e;
+        };
+        // ---- forward ----
+        {
+            float h = 0.0f, c = 0.0f;
+            int park = park0, gpark = gpark0;
+            float2 raw = lane < T ? xg[lane] : make_float2(0.5f, 0.5f);
+            wave_lds_fence();
+            if (VD && lane < kHalo) park_in(lane, xg[T - kHalo + lane]);         // circular left padding (vdlstm.py:66-74)
+            for (int t0 = 0; t0 < T; t0 += kEvalChunk) {
+                const int len = min(kEvalChunk, T - t0);
+                wave_lds_fence();
+                park_in(kHalo + t0 + lane, raw);
+                wave_lds_fence();
+                raw = t0 + kEvalChunk + lane < T ? xg[t0 + kEvalChunk + lane] : make_float2(0.5f, 0.5f);
+                for (int tt = 0; tt < len; ++tt) {
+                    const int t = t0 + tt;
+                    float xin[F];
+                    if constexpr (VD) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xin[k] = ftab[(t + k) * 4];
+                    } else {
+                        const float2 xv = *reinterpret_cast<const float2*>(ftab + (kHalo + t) * 4);
+                        xin[0] = xv.x; xin[1] = xv.y;
+                    }
+                    float acc = bg;
+#pragma unroll
+                    for (int i = 0; i < F; ++i) acc = __builtin_fmaf(win[i], xin[i], acc);
+                    acc = rotdot(acc, wF, h);
+                    const float sg = sigmoidf_(acc), th = tanhf_(acc);
+                    float g[4];
+                    gather_rows(is_g ? th : sg, g);
+                    c = __builtin_fmaf(g[1], c, g[0] * g[2]);
+                    const float tc = tanhf_(c);
+                    h = g[3] * tc;
+                    smem[park] = role == 2 ? c : role == 3 ? tc : h;
+                    park += park_step;
+                    if constexpr (PG) {
+                        *reinterpret_cast<float4*>(smem + gpark) = make_float4(g[0], g[1], g[2], g[3]);
+                        gpark += gpark_step;
+                    }
+                }
+            }
+            wave_lds_fence();
+        }
+        // ---- outputs, loss and the head's gradients of every step, lane = time step ----
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < T) {
+                const float4* hv4 = reinterpret_cast<const float4*>(hist + (t + 1) * 16);
+                float acc[NH];
+#pragma unroll
+                for (int r = 0; r < NH; ++r) acc[r] = VD ? (r < 4 ? pl[L.o_b_l1 + r] : pl[L.o_b_l2 + r - 4]) : pl[L.o_b_out + r];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 hv = hv4[q];
+#pragma unroll
+                    for (int r = 0; r < NH; ++r) {
+                        const float4 w = hw4[4 * r + q];
+                        acc[r] = __builtin_fmaf(w.x, hv.x, acc[r]); acc[r] = __builtin_fmaf(w.y, hv.y, acc[r]);
+                        acc[r] = __builtin_fmaf(w.z, hv.z, acc[r]); acc[r] = __builtin_fmaf(w.w, hv.w, acc[r]);
+                    }
+                }
+                const float2 tv = tg[t];
+                float dy0, dy1;
+                if constexpr (VD) {
+                    // y = fc_out(cat(l1 * cos, l2 * sin)) over the four-sample window (vdlstm.py:77-80)
+                    float y0 = pl[L.o_b_out], y1 = pl[L.o_b_out + 1], lc[4], ls[4], cw[4], sw[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 e = reinterpret_cast<const float4*>(ftab)[t + k];
+                        cw[k] = e.y; sw[k] = e.z;
+                        lc[k] = acc[k] * e.y; ls[k] = acc[4 + k] * e.z;
+                        y0 = __builtin_fmaf(pl[L.o_w_out + k], lc[k], __builtin_fmaf(pl[L.o_w_out + 4 + k], ls[k], y0));
+                        y1 = __builtin_fmaf(pl[L.o_w_out + 8 + k], lc[k], __builtin_fmaf(pl[L.o_w_out + 12 + k], ls[k], y1));
+                    }
+                    s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+                    float dl[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        dl[k] = __builtin_fmaf(dy0, pl[L.o_w_out + k], dy1 * pl[L.o_w_out + 8 + k]) * cw[k];
+                        dl[4 + k] = __builtin_fmaf(dy0, pl[L.o_w_out + 4 + k], dy1 * pl[L.o_w_out + 12 + k]) * sw[k];
+                        tacc[k] = __builtin_fmaf(dy0, lc[k], tacc[k]); tacc[4 + k] = __builtin_fmaf(dy0, ls[k], tacc[4 + k]);      // fc_out row 0
+                        tacc[8 + k] = __builtin_fmaf(dy1, lc[k], tacc[8 + k]); tacc[12 + k] = __builtin_fmaf(dy1, ls[k], tacc[12 + k]);
+                        tacc[18 + k] += dl[k]; tacc[22 + k] += dl[4 + k];                                                           // fc_lambda biases
+                    }
+                    tacc[16] += dy0; tacc[17] += dy1;
+                    reinterpret_cast<float4*>(dlb)[2 * t] = make_float4(dl[0], dl[1], dl[2], dl[3]);
+                    reinterpret_cast<float4*>(dlb)[2 * t + 1] = make_float4(dl[4], dl[5], dl[6], dl[7]);
+                } else {
+                    s16_loss(lossc, acc[0] - tv.x, acc[1] - tv.y, dy0, dy1, loss_acc);
+                    tacc[0] += dy0; tacc[1] += dy1;
+                }
+                *reinterpret_cast<float2*>(dyb + 2 * t) = make_float2(dy0, dy1);
+            }
+        }
+        wave_lds_fence();
+        // ---- backward ----
+        {
+            float dh = 0.0f, dc = 0.0f;
+            for (int t = T - 1; t >= 0; --t) {
+                const float hp = hist[t * 16 + col], ht = hist[(t + 1) * 16 + col];
+                const float cp = cpk[t * 16 + col], tc = tpk[(t + 1) * 16 + col];
+                float hg[NH];                                                       // dL/d(head rows) of step t: dy, or d lambda_1/2
+                if constexpr (VD) {
+                    const float4 d0 = reinterpret_cast<const float4*>(dlb)[2 * t], d1 = reinterpret_cast<const float4*>(dlb)[2 * t + 1];
+                    hg[0] = d0.x; hg[1] = d0.y; hg[2] = d0.z; hg[3] = d0.w; hg[4] = d1.x; hg[5] = d1.y; hg[6] = d1.z; hg[7] = d1.w;
+                } else {
+                    const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
+                    hg[0] = dyv.x; hg[1] = dyv.y;
+                }
+                float g[4];
+                if constexpr (PG) {
+                    const float4 gv = reinterpret_cast<const float4*>(gpk)[t * 16 + col];
+                    g[0] = gv.x; g[1] = gv.y; g[2] = gv.z; g[3] = gv.w;
+                } else {
+                    float xin[F];
+                    if constexpr (VD) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xin[k] = ftab[(t + k) * 4];
+                    } else {
+                        const float2 xv = *reinterpret_cast<const float2*>(ftab + (kHalo + t) * 4);
+                        xin[0] = xv.x; xin[1] = xv.y;
+                    }
+                    float acc = bg;
+#pragma unroll
+                    for (int i = 0; i < F; ++i) acc = __builtin_fmaf(win[i], xin[i], acc);
+                    acc = rotdot(acc, wF, hp);
+                    const float sg = sigmoidf_(acc), th = tanhf_(acc);
+                    gather_rows(is_g ? th : sg, g);
+                }
+                float dht = dh;
+#pragma unroll
+                for (int r = 0; r < NH; ++r) { dht = __builtin_fmaf(hg[r], wh[r], dht); dwh[r] = __builtin_fmaf(hg[r], ht, dwh[r]); }
+                const float dct = __builtin_fmaf(dht * g[3], __builtin_fmaf(-tc, tc, 1.0f), dc);       // dL/dc(t)
+                dc = dct * g[1];
+                // the row's own pre-activation gradient: d_i = dc g i (1 - i), d_f = dc c(t-1) f (1 - f), d_g = dc i (1 - g^2), d_o = dh tanh c o (1 - o)
+                const float own = role == 0 ? g[0] : role == 1 ? g[1] : role == 2 ? g[2] : g[3];
+                const float mul = role == 0 ? g[2] : role == 1 ? cp : role == 2 ? g[0] : tc;
+                const float up = (role == 3 ? dht : dct) * mul;
+                const float d_row = up * (is_g ? __builtin_fmaf(-own, own, 1.0f) : own * (1.0f - own));
+                float part = rotdot(0.0f, wT, d_row);
+                part += xor16(part);
+                part += xor32(part);
+                dh = part;
+                const float xsx = col < F ? ftab[4 * t + xcol] : (col == F ? 1.0f : 0.0f);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_row, hp, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_row, xsx, acc2, 0, 0, 0);
+            }
+        }
+        wave_lds_fence();
+    }
+    // ---- the workgroup's row of partial gradients (every entry written) ----
+    float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
+    const float lp = wave_sum(loss_acc);
+#pragma unroll
+    for (int r = 0; r < (VD ? 26 : 2); ++r) tacc[r] = wave_sum(tacc[r]);
+    if (vo && role == 0) {
+#pragma unroll
+        for (int r = 0; r < NH; ++r) {
+            if (VD) prow[(r < 4 ? L.o_w_l1 + r * H : L.o_w_l2 + (r - 4) * H) + col] = dwh[r];
+            else prow[L.o_w_out + r * H + col] = dwh[r];
+        }
+    }
+    if (lane == 0) {
+        if constexpr (VD) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) prow[L.o_w_out + k] = tacc[k];
+            prow[L.o_b_out] = tacc[16]; prow[L.o_b_out + 1] = tacc[17];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { prow[L.o_b_l1 + k] = tacc[18 + k]; prow[L.o_b_l2 + k] = tacc[22 + k]; }
+        } else { prow[L.o_b_out] = tacc[0]; prow[L.o_b_out + 1] = tacc[1]; }
+        prow[L.P] = lp; prow[L.P + 1] = 0.0f; prow[L.P + 2] = 0.0f; prow[L.P + 3] = 0.0f;
+    }
+    // MFMA block k = gate k; register 4 k + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * role + rr;
+            if (i < H) {
+                if (col < H) prow[L.o_w_hh + (k * H + i) * H + col] = acc1[4 * k + rr];
+                const float v = acc2[4 * k + rr];
+                if (col < F) prow[L.o_w_ih + (k * H + i) * F + col] = v;
+                else if (col == F) { prow[L.o_b_ih + k * H + i] = v; prow[L.o_b_hh + k * H + i] = v; }
+            }
+        }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -758,6 +1043,47 @@ static int lstm_launch_bwd_mode(hipStream_t st, const SeqArgs& a, int P) {
     if (R == 1 && vd) return FN<1, true>(__VA_ARGS__);                 \
     if (R == 2 && vd) return FN<2, true>(__VA_ARGS__);
 
+// the gate-parallel fused train kernel: one sequence per single-wave workgroup, BPTT state of the whole frame in LDS
+static size_t lstm_gp_lds_bytes(int P, bool vd, int T, bool pg) {
+    return ((size_t)pad4(P) + (vd ? lstm_gp_buffer_floats<true>(T, pg) : lstm_gp_buffer_floats<false>(T, pg))) * sizeof(float);
+}
+static int lstm_gp_blocks_per_cu(int P, bool vd, int T, bool pg) {
+    const size_t lds = lstm_gp_lds_bytes(P, vd, T, pg);
+    const int n = lds > kMaxLds ? 0 : (int)(kMaxLds / lds);
+    return n < 4 ? n : 4;
+}
+static bool lstm_gp_parks_gates(int P, bool vd, int B, int T) { return (long)B <= (long)device_cus() * lstm_gp_blocks_per_cu(P, vd, T, true); }
+bool lstm_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    if ((m->backbone != ODPD_LSTM && m->backbone != ODPD_VDLSTM) || m->hidden > 16 || lstm_train_uses_s16(m, B)) return false;
+    const bool vd = m->backbone == ODPD_VDLSTM;
+    if (vd && T < kHalo) return false;
+    const int P = lstm_layout(m->hidden, vd).P;
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0) return B <= max_batch && lstm_gp_blocks_per_cu(P, vd, T, false) > 0;
+    // up to two rounds of workgroups: the alternative here is the forward / loss / backward chain of the row-rotated kernels
+    return (long)B <= 2L * device_cus() * lstm_gp_blocks_per_cu(P, vd, T, false);
+}
+int lstm_gp_rows(const odpd_model_t* m, int B, int T) {
+    const bool vd = m->backbone == ODPD_VDLSTM;
+    const int P = lstm_layout(m->hidden, vd).P;
+    const bool pg = lstm_gp_parks_gates(P, vd, B, T);
+    const long cap = (long)device_cus() * (kMaxLds / lstm_gp_lds_bytes(P, vd, T, pg));
+    return B < cap ? B : (int)cap;
+}
+int lstm_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    const bool vd = m->backbone == ODPD_VDLSTM;
+    const int P = lstm_layout(m->hidden, vd).P;
+    const bool pg = lstm_gp_parks_gates(P, vd, a.B, a.T);
+    const size_t lds = lstm_gp_lds_bytes(P, vd, a.T, pg);
+    const int grid = lstm_gp_rows(m, a.B, a.T);
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    if (vd) return pg ? launch(lstm_gp_train_kernel<true, true>) : launch(lstm_gp_train_kernel<true, false>);
+    return pg ? launch(lstm_gp_train_kernel<false, true>) : launch(lstm_gp_train_kernel<false, false>);
+}
 int lstm_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     const int R = rows_per_seq(m->hidden);
     const bool vd = m->backbone == ODPD_VDLSTM;

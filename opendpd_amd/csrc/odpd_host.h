@@ -173,6 +173,10 @@ int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_rows(const odpd_model_t* m, int B);
 // 16-sequences-per-wave fused train kernel of lstm / vdlstm (lstm_s16.hip)
 bool lstm_train_uses_s16(const odpd_model_t* m, int B);
+// gate-parallel fused train kernel of lstm / vdlstm at the reference's batch sizes (lstm_family.hip)
+bool lstm_train_uses_gp(const odpd_model_t* m, int B, int T);
+int lstm_gp_rows(const odpd_model_t* m, int B, int T);
+int lstm_gp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_s16_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_s16_rows(const odpd_model_t* m, int B);
 int64_t lstm_s16_workspace_floats(const odpd_model_t* m, int B, int T);

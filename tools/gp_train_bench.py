@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Fused train step (fwd + loss + BPTT + clip + AdamW) at the reference's own batch sizes: the gate-parallel kernel (gru_gp_train_kernel,
-one sequence per wave) beside the row-rotated one (four sequences per wave; odpd_set_tuning gp_max_batch = 0).
+one sequence per wave; lstm_gp_train_kernel for lstm / vdlstm) beside the row-rotated kernels (four sequences per wave: fused for the GRU
+family, forward / loss / backward launches for the LSTM family; odpd_set_tuning gp_max_batch = 0).
 usage: PYTHONPATH=. python tools/gp_train_bench.py"""
 import ctypes as C
 import time
@@ -17,25 +18,26 @@ lib = _lib.load()
 
 def step_ms(bb, H, B, T, gp_max_batch):
     lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(gp_max_batch))
-    xs, ys = bench.synth_frames(B, T, 0, dev, materialize=False)
+    framed = bb not in ("lstm", "vdlstm")            # the LSTM family takes materialised (B, T, 2) frames
+    xs, ys = bench.synth_frames(B, T, 0, dev, materialize=not framed)
     torch.manual_seed(0)
     net = CoreModel(2, H, 1, bb).to(dev)
     opt = FusedAdamW(net, lr=5e-4)
-    fb = FrameBatch(xs, ys, torch.arange(B, device=dev), T, 1)
+    fb, ys = (FrameBatch(xs, ys, torch.arange(B, device=dev), T, 1), None) if framed else (xs, ys)
     for _ in range(5):
-        loss = fused_train_step(opt, fb, None, "l2", 200.0)
+        loss = fused_train_step(opt, fb, ys, "l2", 200.0)
     best = 1e9
     for _ in range(5):
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(20):
-            loss = fused_train_step(opt, fb, None, "l2", 200.0)
+            loss = fused_train_step(opt, fb, ys, "l2", 200.0)
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t) / 20 * 1e3)
     return best, float(loss)
 
 
-for bb, H in (("gru", 11), ("dgru", 13), ("qgru", 10), ("qgru_amp1", 16)):
+for bb, H in (("gru", 11), ("dgru", 13), ("qgru", 10), ("qgru_amp1", 16), ("lstm", 14), ("vdlstm", 13)):
     for B, T in ((64, 50), (256, 50), (1024, 50), (64, 200), (256, 200), (512, 200), (768, 200), (1024, 200), (2048, 200)):
         a, la = step_ms(bb, H, B, T, 0)
         g, lg = step_ms(bb, H, B, T, 1 << 30)
