@@ -659,7 +659,7 @@ int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
     const int P = delta_layout(m->hidden, tres).P;
-    if (a.ckpt == nullptr && a.B <= 8 && a.T >= 256 && tuning().s16_min_batch != 0)          // inference on a few long sequences
+    if (a.ckpt == nullptr && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0)          // inference on sequences that each get a SIMD of their own
         return tres ? delta_launch_eval<true>(st, a, P) : delta_launch_eval<false>(st, a, P);
     return tres ? delta_launch_fwd<true>(st, a, P) : delta_launch_fwd<false>(st, a, P);
 }

@@ -1264,7 +1264,9 @@ static int launch_eval(hipStream_t st, const SeqArgs& a, int P) {
 }
 bool gru_uses_eval_kernel(const odpd_model_t* m, int B, int T, bool want_ckpt) {
     int FM, R, P; bool DG;
-    return gru_setup(m, FM, DG, R, P) && !want_ckpt && B <= 8 && T >= 256 && tuning().s16_min_batch != 0;
+    if (!gru_setup(m, FM, DG, R, P) || want_ckpt || tuning().s16_min_batch == 0) return false;
+    // a few long sequences (net_eval / run_dpd), or any batch whose sequences each get a SIMD of their own before the S16 kernels take over
+    return (B <= 8 && T >= 256) || (B <= 2 * device_cus() && !gru_split_uses_s16(m, B) && !gru_uses_s16n(m, B));
 }
 int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;

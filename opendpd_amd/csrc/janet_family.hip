@@ -389,7 +389,7 @@ int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     if (janet_uses_s16(m, a.B)) return janet_s16_launch(st, m, a, 1);
     const int P = janet_layout(m->hidden).P;
-    if (a.ckpt == nullptr && a.B <= 8 && a.T >= 256 && tuning().s16_min_batch != 0) {     // inference on a few long sequences
+    if (a.ckpt == nullptr && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0) {     // inference on sequences that each get a SIMD of their own
         const size_t lds = ((size_t)pad4(P) + kJTabFloats + kEvalChunk * 4 + kEvalChunk * kJEvalHistStride + 32) * sizeof(float);
         if (int e = allow_big_lds(janet_eval_kernel, lds)) return e;
         hipLaunchKernelGGL(janet_eval_kernel, dim3(a.B), dim3(64), lds, st, a);

@@ -1091,7 +1091,7 @@ int lstm_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (vd && a.T < kHalo) return ODPD_EINVAL;
     const int P = lstm_layout(m->hidden, vd).P;
     // inference on a few long sequences (no checkpoints asked for): the gate-parallel evaluation kernel
-    if (a.ckpt == nullptr && a.B <= 8 && a.T >= 256 && tuning().s16_min_batch != 0) { ODPD_LSTM_DISPATCH(lstm_launch_eval, st, a, P) }
+    if (a.ckpt == nullptr && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0) { ODPD_LSTM_DISPATCH(lstm_launch_eval, st, a, P) }
     ODPD_LSTM_DISPATCH(lstm_launch_fwd, st, a, P)
     return ODPD_EUNSUPPORTED;
 }

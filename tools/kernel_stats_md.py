@@ -8,7 +8,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if "odpd::" in r["Name"]]
 rows.sort(key=lambda r: -float(r["Percentage"]))
 print(f"# {sys.argv[2]}\n")
 print("Per kernel: calls, average / min / max duration (us), share of total GPU time of the run.  Row-rotated kernels (`gru_*`, "
-      "`lstm_*`, `delta_*`, `janet_*`, `qgru_*`) serve B = 256, the S16 kernels (`gru16*`, `lstm16*`, `delta16*`, `janet16*`) "
+      "`lstm_*`, `delta_*`, `janet_*`, `qgru_*`) and the gate-parallel train kernels (`*_gp_train_kernel`) serve B = 256, the S16 kernels (`gru16*`, `lstm16*`, `delta16*`, `janet16*`) "
       "B = 32768; `tcnn_*<R>` both.\n")
 print("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
 for r in rows:

@@ -2,7 +2,7 @@
 """Out-of-bounds hunt (GPU box): every backbone forward + backward on random shapes with the input x and the output gradient dy
 placed at the very END of their own 2 MiB device allocations (caching allocator off), and x once more at the very START: a
 kernel that reads past either side of a tensor hits an unmapped page and dies with a memory access fault.
-The fused train step (x and target placed), the cascade step (random DPD in front of the backbone as frozen PA) and, for
+An inference call (torch.no_grad(): the evaluation kernels where the shape selects them), the fused train step (x and target placed), the cascade step (random DPD in front of the backbone as frozen PA) and, for
 qgru / qgru_amp1, the W8A8 quantisation-aware cell run on the same shapes.
 usage: PYTORCH_NO_CUDA_MEMORY_CACHING=1 PYTHONPATH=. python tools/oob_hunt.py <backbone> <seed> [cases]"""
 import os
@@ -50,7 +50,7 @@ for it in range(cases):
     force = bool(rng.randint(2))
     lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
     B = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
-    T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 257, 300] + ([513, 700, 1500] if bb in ("gmp", "rvtdcnn", "neuraltx") else [])))
+    T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 256, 257, 300, 321] + ([513, 700, 1500] if bb in ("gmp", "rvtdcnn", "neuraltx") else [])))
     if B * T > 6000:
         T = max(1, 6000 // B)
     if bb in ("vdlstm", "rvtdcnn") and T < 3:
@@ -82,6 +82,8 @@ for it in range(cases):
         x = place(x0).requires_grad_(True)
         y = net(x)
         y.backward(dy)
+        with torch.no_grad():           # inference call: the evaluation kernels on few long sequences
+            net(place(x0))
         fused_train_step(opt, place(x0), place(tgt), "l2", 200.0)
         if T >= 3 or not ({"vdlstm", "rvtdcnn"} & {bb, dpd_bb}):
             fused_train_step(copt, place(x0), place(tgt), "l2", 200.0)
