@@ -93,7 +93,8 @@ int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T);
  * above after a change).  "s16_min_batch": smallest batch served by the 16-sequences-per-wave fused GRU
  * kernel (-1 = built-in crossover, 0 = always when supported); "s16_occupancy": 1 or 2 waves per SIMD (0 = chosen by batch size);
  * "gp_max_batch": largest batch served by the one-sequence-per-wave fused train kernels of the GRU / LSTM families (-1 = built-in: while every
- * sequence gets a SIMD of its own and the frame's BPTT state fits the CU's LDS share; 0 = never). */
+ * sequence gets a SIMD of its own and the frame's BPTT state fits the CU's LDS share; 0 = never, which also keeps the one-sequence-per-wave
+ * forward kernels off). */
 int odpd_set_tuning(const char* key, int64_t value);
 /* Counter bumped by every successful odpd_set_tuning: buffers sized by the queries above are valid for the generation they were
  * sized in (the row count / workspace layout of a (B,T) shape depends on the knobs). */

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kMaxThreads) void delta_fwd_kernel(SeqArgs a) {
 // Same thresholded arithmetic per element as delta_cell_fwd (accumulation order included); the sparsity counters are kept.
 // -------------------------------------------------------------------------------------------------
 constexpr int kDEvalHistStride = 64 + 4;
-template <bool TRES>
+template <bool TRES, bool CK>      // CK: also writes the BPTT checkpoints (the forward of the split train path)
 __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // r | z | n | -
@@ -371,6 +371,15 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
                 gather_rows(nrow ? n : sg, g4);
                 h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
                 hist[tt * HS + lane] = h;
+                if constexpr (CK) {                  // BPTT checkpoints in the layout of the row-rotated backward (lane = 16 s + col, kDState planes)
+                    const int t1 = t0 + tt + 1;
+                    if ((t1 % kCkptStride) == 0 && t1 < T) {
+                        float* ck = a.ckpt + ((size_t)(b >> 2) * a.nck + t1 / kCkptStride) * (kDState * 64) + 16 * (b & 3) + col;
+                        if (role == 0) { ck[0] = h; ck[64] = hp; ck[128] = accx; ck[384] = col < 6 ? xp : 0.0f; }
+                        if (role == 1) ck[192] = accx;
+                        if (role == 2) { ck[256] = accx; ck[320] = acch; }
+                    }
+                }
             }
             wave_lds_fence();
             // fc_out (+ the skip) of the chunk, lane = time step
@@ -637,10 +646,12 @@ static int delta_launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
 template <bool TRES>
 static int delta_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
     const size_t lds = ((size_t)pad4(P) + kDTabFloats + kEvalChunk * 8 + kEvalChunk * kDEvalHistStride + 32) * sizeof(float);
-    auto k = delta_eval_kernel<TRES>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
-    return (int)hipGetLastError();
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    return a.ckpt ? launch(delta_eval_kernel<TRES, true>) : launch(delta_eval_kernel<TRES, false>);
 }
 template <bool TRES>
 static int delta_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
@@ -659,7 +670,7 @@ int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
     const int P = delta_layout(m->hidden, tres).P;
-    if (a.ckpt == nullptr && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0)          // inference on sequences that each get a SIMD of their own
+    if (a.B <= 2 * device_cus() && tuning().s16_min_batch != 0 && tuning().gp_max_batch != 0)          // sequences that each get a SIMD of their own (inference / checkpoint-writing forward)
         return tres ? delta_launch_eval<true>(st, a, P) : delta_launch_eval<false>(st, a, P);
     return tres ? delta_launch_fwd<true>(st, a, P) : delta_launch_fwd<false>(st, a, P);
 }

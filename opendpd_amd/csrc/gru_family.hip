@@ -434,7 +434,8 @@ template <int NB> struct GruEvalLds {
 // parked in LDS (a step reads them as wave-uniform operands), and so is fc_out — a step only parks the head's input (h, or relu(fc_hid h)
 // from row 2) and the chunk's 64 outputs are formed afterwards, one time step per lane.  The next chunk's samples are in flight
 // while the current one is stepped.
-template <int NB, int FM, bool DG>
+// CK: also writes the BPTT checkpoints (the forward of the split train path)
+template <int NB, int FM, bool DG, bool CK>
 __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
     constexpr int F = FeatDim<FM>::F, EC = kEvalChunk, HS = GruEvalLds<NB>::kHistStride;
     using T = GruTabs<NB, DG>;
@@ -546,6 +547,15 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
                     const float h13 = __builtin_fmaf(zz, h[ob] - nn, nn);       // rows 1 and 3: (1 - z) n + z h
                     const float h02 = xor16(h13);
                     h[ob] = odd ? h13 : h02;
+                }
+                // BPTT checkpoints in the layout of the row-rotated backward (4 / NB sequences per wave-task, lane = 16 NB s + 16 ob + col)
+                if constexpr (CK) {
+                    const int t1 = t0 + tt + 1;
+                    if ((t1 % kCkptStride) == 0 && t1 < a.T && role == 0) {
+                        float* ck = a.ckpt + ((size_t)(b / (4 / NB)) * a.nck + t1 / kCkptStride) * 64 + 16 * NB * (b % (4 / NB)) + col;
+#pragma unroll
+                        for (int ob = 0; ob < NB; ++ob) ck[16 * ob] = h[ob];
+                    }
                 }
             }
             wave_lds_fence();
@@ -1257,16 +1267,19 @@ bool gru_split_uses_s16(const odpd_model_t* m, int B) {
 template <int NB, int FM, bool DG>
 static int launch_eval(hipStream_t st, const SeqArgs& a, int P) {
     const size_t lds = ((size_t)pad4(P) + GruTabs<NB, DG>::kFloats + GruEvalLds<NB>::kFloats) * sizeof(float);
-    auto k = gru_eval_kernel<NB, FM, DG>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
-    return (int)hipGetLastError();
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    return a.ckpt ? launch(gru_eval_kernel<NB, FM, DG, true>) : launch(gru_eval_kernel<NB, FM, DG, false>);
 }
 bool gru_uses_eval_kernel(const odpd_model_t* m, int B, int T, bool want_ckpt) {
     int FM, R, P; bool DG;
-    if (!gru_setup(m, FM, DG, R, P) || want_ckpt || tuning().s16_min_batch == 0) return false;
+    if (!gru_setup(m, FM, DG, R, P) || tuning().s16_min_batch == 0 || tuning().gp_max_batch == 0) return false;
     // a few long sequences (net_eval / run_dpd), or any batch whose sequences each get a SIMD of their own before the S16 kernels take over
-    return (B <= 8 && T >= 256) || (B <= 2 * device_cus() && !gru_split_uses_s16(m, B) && !gru_uses_s16n(m, B));
+    // (then also as the checkpoint-writing forward of the split train path)
+    return (!want_ckpt && B <= 8 && T >= 256) || (B <= 2 * device_cus() && !gru_split_uses_s16(m, B) && !gru_uses_s16n(m, B));
 }
 int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;

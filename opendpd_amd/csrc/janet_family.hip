@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kMaxThreads) void janet_fwd_kernel(SeqArgs a) {
 // parks h, and fc_out of the chunk follows, one time step per lane.
 // -------------------------------------------------------------------------------------------------
 constexpr int kJEvalHistStride = 64 + 4;
+template <bool CK>      // CK: also writes the BPTT checkpoints (the forward of the split train path)
 __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
     constexpr int EC = kEvalChunk, HS = kJEvalHistStride;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -181,6 +182,11 @@ __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
                 const float f = sigmoidf_(g4[0]), g = tanhf_(g4[2] + g4[1]);
                 h = __builtin_fmaf(f, h - g, g);
                 hist[tt * HS + lane] = h;
+                if constexpr (CK) {                  // BPTT checkpoints in the layout of the row-rotated backward (lane = 16 s + col)
+                    const int t1 = t0 + tt + 1;
+                    if ((t1 % kCkptStride) == 0 && t1 < a.T && role == 0)
+                        a.ckpt[((size_t)(b >> 2) * a.nck + t1 / kCkptStride) * 64 + 16 * (b & 3) + col] = h;
+                }
             }
             wave_lds_fence();
             // fc_out of the chunk, lane = time step
@@ -389,11 +395,14 @@ int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     if (janet_uses_s16(m, a.B)) return janet_s16_launch(st, m, a, 1);
     const int P = janet_layout(m->hidden).P;
-    if (a.ckpt == nullptr && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0) {     // inference on sequences that each get a SIMD of their own
+    if (a.B <= 2 * device_cus() && tuning().s16_min_batch != 0 && tuning().gp_max_batch != 0) {     // sequences that each get a SIMD of their own (inference / checkpoint-writing forward)
         const size_t lds = ((size_t)pad4(P) + kJTabFloats + kEvalChunk * 4 + kEvalChunk * kJEvalHistStride + 32) * sizeof(float);
-        if (int e = allow_big_lds(janet_eval_kernel, lds)) return e;
-        hipLaunchKernelGGL(janet_eval_kernel, dim3(a.B), dim3(64), lds, st, a);
-        return (int)hipGetLastError();
+        auto launch = [&](auto k) {
+            if (int e = allow_big_lds(k, lds)) return e;
+            hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
+            return (int)hipGetLastError();
+        };
+        return a.ckpt ? launch(janet_eval_kernel<true>) : launch(janet_eval_kernel<false>);
     }
     const LaunchShape ls = persistent_shape(a.ngroups, 16);
     const size_t lds = janet_lds_bytes(P, ls.waves, false);

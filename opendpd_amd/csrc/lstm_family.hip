@@ -237,7 +237,7 @@ template <int NB> struct LstmEvalLds {
     static constexpr int kHeadFloats = 8 * 16 * NB;          // plain: fc_out rows 0..1; VD: fc_lambda_1 rows 0..3, fc_lambda_2 rows 4..7 (zero padded)
     static constexpr int kFloats = (kEvalChunk + kHalo) * 4 + kEvalChunk * kHistStride + kHeadFloats;
 };
-template <int NB, bool VD>
+template <int NB, bool VD, bool CK>      // CK: also writes the BPTT checkpoints (the forward of the split train path)
 __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
     constexpr int F = VD ? 4 : 2, EC = kEvalChunk, HS = LstmEvalLds<NB>::kHistStride;
     using T = LstmTabs<NB>;
@@ -324,6 +324,15 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
                     cs[ob] = __builtin_fmaf(g[1], cs[ob], g[0] * g[2]);
                     h[ob] = g[3] * tanhf_(cs[ob]);
                     hist[tt * HS + 64 * ob + lane] = h[ob];
+                }
+                // BPTT checkpoints in the layout of the row-rotated backward (4 / NB sequences per wave-task, lane = 16 NB s + 16 ob + col)
+                if constexpr (CK) {
+                    const int t1 = t0 + tt + 1;
+                    if ((t1 % kCkptStride) == 0 && t1 < a.T && role == 0) {
+                        float* ck = a.ckpt + ((size_t)(b / (4 / NB)) * a.nck + t1 / kCkptStride) * 128 + 16 * NB * (b % (4 / NB)) + col;
+#pragma unroll
+                        for (int ob = 0; ob < NB; ++ob) { ck[16 * ob] = h[ob]; ck[64 + 16 * ob] = cs[ob]; }
+                    }
                 }
             }
             wave_lds_fence();
@@ -1014,10 +1023,12 @@ static int lstm_launch_fwd(hipStream_t st, const SeqArgs& a, int P) {
 template <int NB, bool VD>
 static int lstm_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
     const size_t lds = ((size_t)pad4(P) + LstmTabs<NB>::kFloats + LstmEvalLds<NB>::kFloats) * sizeof(float);
-    auto k = lstm_eval_kernel<NB, VD>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
-    return (int)hipGetLastError();
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    return a.ckpt ? launch(lstm_eval_kernel<NB, VD, true>) : launch(lstm_eval_kernel<NB, VD, false>);
 }
 template <int R, bool VD, bool NW, bool DX>
 static int lstm_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
@@ -1090,8 +1101,8 @@ int lstm_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!R) return ODPD_EUNSUPPORTED;
     if (vd && a.T < kHalo) return ODPD_EINVAL;
     const int P = lstm_layout(m->hidden, vd).P;
-    // inference on a few long sequences (no checkpoints asked for): the gate-parallel evaluation kernel
-    if (a.ckpt == nullptr && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0) { ODPD_LSTM_DISPATCH(lstm_launch_eval, st, a, P) }
+    // sequences that each get a SIMD of their own (inference, and the checkpoint-writing forward of the split train path): the gate-parallel kernel
+    if (a.B <= 2 * device_cus() && tuning().s16_min_batch != 0 && tuning().gp_max_batch != 0) { ODPD_LSTM_DISPATCH(lstm_launch_eval, st, a, P) }
     ODPD_LSTM_DISPATCH(lstm_launch_fwd, st, a, P)
     return ODPD_EUNSUPPORTED;
 }

@@ -266,9 +266,15 @@ def test_evaluation_kernel_matches_the_oracle_and_keeps_the_counters(bb, H, thx,
     with torch.no_grad():
         y_eval = net(x.cuda()).cpu().numpy()
     st_eval = [net.backbone.statistics[k] for k in keys]
-    net.backbone.set_debug(1)
-    y_train = net(x.cuda().requires_grad_(True)).detach().cpu().numpy()        # gradients enabled: checkpoints -> the row-rotated forward
-    st_train = [net.backbone.statistics[k] for k in keys]
+    import ctypes as C
+    from opendpd_amd import _lib
+    _lib.load().odpd_set_tuning(b"gp_max_batch", C.c_int64(0))                 # one-sequence-per-wave kernels off: the row-rotated forward
+    try:
+        net.backbone.set_debug(1)
+        y_train = net(x.cuda().requires_grad_(True)).detach().cpu().numpy()
+        st_train = [net.backbone.statistics[k] for k in keys]
+    finally:
+        _lib.load().odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
     assert st_eval[1] == st_train[1] and st_eval[3] == st_train[3]
     same = st_eval == st_train              # the recurrent sums run in a different order: a |dh| within rounding of th_h can flip a mask
     assert abs(st_eval[0] - st_train[0]) + abs(st_eval[2] - st_train[2]) <= 4

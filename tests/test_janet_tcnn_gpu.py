@@ -165,9 +165,17 @@ def test_pgjanet_evaluation_kernel_matches_the_oracle(H, B, T):
     x = torch.cat((amp * torch.cos(ph), amp * torch.sin(ph)), -1)
     p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
     yo, _ = Oracle("f32").forward(make_model("pgjanet", H), p, x.numpy())
+    import ctypes as C
+    from opendpd_amd import _lib
     with torch.no_grad():
         y_eval = net(x.cuda()).cpu().numpy()
-    y_train = net(x.cuda().requires_grad_(True)).detach().cpu().numpy()        # gradients enabled: checkpoints -> the row-rotated forward
+    y_ckpt = net(x.cuda().requires_grad_(True)).detach().cpu().numpy()         # gradients enabled: the same kernel also writes the BPTT checkpoints
+    _lib.load().odpd_set_tuning(b"gp_max_batch", C.c_int64(0))                 # one-sequence-per-wave kernels off: the row-rotated forward
+    try:
+        y_train = net(x.cuda().requires_grad_(True)).detach().cpu().numpy()
+    finally:
+        _lib.load().odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
     assert rel_err(y_eval, yo) < FWD_TOL and rel_err(y_train, yo) < FWD_TOL
+    assert np.array_equal(y_eval, y_ckpt)
     assert rel_err(y_eval, y_train) < 5e-6
     assert H == 1 or not np.array_equal(y_eval, y_train)          # two kernels: g's pre-activation is summed in a different order

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Latency of one evaluation pass (net_eval / run_dpd shapes, train_funcs.py:57-90) per recurrent backbone: torch.no_grad() (the
-gate-parallel evaluation kernels where a family has one) beside the same call with gradients enabled (the row-rotated forward that
-also writes BPTT checkpoints).  usage: PYTHONPATH=. python tools/eval_latency.py"""
+gate-parallel evaluation kernels where a family has one) beside the same call with gradients enabled (the same kernels writing BPTT
+checkpoints on the way; the delta backbones asked for dL/dx take their S16 kernels).  usage: PYTHONPATH=. python tools/eval_latency.py"""
 import time
 
 import torch
