@@ -854,19 +854,21 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
 // One partial-gradient row per workgroup.
 // -------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <bool DG>
+template <int NB, bool DG>
 __host__ __device__ inline int gp_buffer_floats(int T, bool pg) {
     const int Tp = (T + 63) & ~63;
-    const int buf = Tp * 8 + (Tp + 2) * 16 + (DG ? Tp * 16 : 0) + Tp * 2 + 256 + 48 + (pg ? Tp * 64 : 0);
-    const int tabf = GruTabs<1, DG>::kFloats;
+    const int buf = Tp * 8 + (Tp + 2) * 16 * NB + (DG ? Tp * 16 * NB : 0) + Tp * 2 + 256 * NB + 32 * NB + 16 + (pg ? Tp * 64 * NB : 0);
+    const int tabf = GruTabs<NB, DG>::kFloats;
     return buf > tabf ? buf : tabf;
 }
+// NB = 2: hidden 17..32 — h is two 16-unit blocks replicated on every row, a row does both output blocks of its gate (as gru_eval_kernel);
+// the W_hh / fc_hid gradients are one 4-block MFMA per (output block, input block) pair.
 // PG: the forward pass also parks (r, W_hn h + b, z, n) of every step (16 B per unit and step) and the backward pass reads them back instead
 // of recomputing the gates — taken while the frame's buffers fit the CU's LDS share
-template <int FM, bool DG, bool PG>
+template <int NB, int FM, bool DG, bool PG>
 __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
-    constexpr int F = FeatDim<FM>::F;
-    using TB = GruTabs<1, DG>;
+    constexpr int F = FeatDim<FM>::F, HB = 16 * NB;
+    using TB = GruTabs<NB, DG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // 0 r | 1 n | 2 head | 3 z
     const GruLayout L = gru_layout(a.H, F, DG);
@@ -874,61 +876,106 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
-    fill_gru_tabs<1, DG, true>(tab, pl, L, lane, 0, 1);
+    fill_gru_tabs<NB, DG, true>(tab, pl, L, lane, 0, 1);
     const int gate = role == 0 ? 0 : role == 3 ? 1 : 2;
-    const bool vo = col < H, head_row = role == 2;
-    // the row's rotated weights, forward and transposed (head row: fc_hid for DGRU, nothing otherwise)
-    float wF[16], wT[16];
-    {
-        TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + col);
-        int rf = TB::kHH + gate, rt = TB::kHHT + gate;
+    const bool head_row = role == 2;
+    // the row's rotated weights, forward and transposed (head row: fc_hid for DGRU, nothing otherwise): [output block][input block]
+    float wF[NB][NB][16], wT[NB][NB][16];
+    float win[NB][F], b_in[NB], b_rec[NB], wo0[NB], wo1[NB];
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+        const int o = 16 * ob + col;
+        const bool vo = o < H;
+        TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + 16 * ob + col);
+        int rf = TB::kHH + gate * NB, rt = TB::kHHT + gate * NB;
         if constexpr (DG) { if (head_row) { rf = TB::kHID; rt = TB::kHIDT; } }
-        load_rot(wF, tl + rf * 4 * 64);
-        load_rot(wT, tl + rt * 4 * 64);
-        if (!DG && head_row) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { wF[k] = 0.0f; wT[k] = 0.0f; }
+        for (int rb = 0; rb < NB; ++rb) {
+            const int kb = (ob + rb) % NB;
+            load_rot(wF[ob][kb], tl + (rf + rb) * 4 * 64);
+            load_rot(wT[ob][kb], tl + (rt + rb) * 4 * 64);
+            if (!DG && head_row) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { wF[ob][kb][k] = 0.0f; wT[ob][kb][k] = 0.0f; }
+            }
         }
-    }
-    float win[F], b_in = 0.0f, b_rec = 0.0f;
 #pragma unroll
-    for (int i = 0; i < F; ++i) win[i] = (vo && !head_row) ? pl[L.o_w_ih + (gate * H + col) * F + i] : 0.0f;
-    if (vo) {
-        if (role == 0 || role == 3) b_in = pl[L.o_b_ih + gate * H + col] + pl[L.o_b_hh + gate * H + col];
-        if (role == 1) { b_in = pl[L.o_b_ih + 2 * H + col]; b_rec = pl[L.o_b_hh + 2 * H + col]; }
-        if (head_row && DG) b_rec = pl[L.o_b_hid + col];
+        for (int i = 0; i < F; ++i) win[ob][i] = (vo && !head_row) ? pl[L.o_w_ih + (gate * H + o) * F + i] : 0.0f;
+        b_in[ob] = 0.0f; b_rec[ob] = 0.0f;
+        if (vo) {
+            if (role == 0 || role == 3) b_in[ob] = pl[L.o_b_ih + gate * H + o] + pl[L.o_b_hh + gate * H + o];
+            if (role == 1) { b_in[ob] = pl[L.o_b_ih + 2 * H + o]; b_rec[ob] = pl[L.o_b_hh + 2 * H + o]; }
+            if (head_row && DG) b_rec[ob] = pl[L.o_b_hid + o];
+        }
+        wo0[ob] = vo ? pl[L.o_w_out + o] : 0.0f; wo1[ob] = vo ? pl[L.o_w_out + OW + o] : 0.0f;
     }
-    const float wo0 = vo ? pl[L.o_w_out + col] : 0.0f, wo1 = vo ? pl[L.o_w_out + OW + col] : 0.0f;
     const float bo0 = pl[L.o_b_out], bo1 = pl[L.o_b_out + 1];
     wave_lds_fence();
     // per-time buffers over the tables
     float* ftab = tab;                                  // [Tp][8]   features of step t
-    float* hist = ftab + Tp * 8;                        // [Tp + 2][16]   entry t + 1 = h(t), entry 0 = h(-1) = 0
-    float* actb = hist + (Tp + 2) * 16;                 // DGRU: [Tp][16]   relu(fc_hid h(t) + b)
-    float* dyb = actb + (DG ? Tp * 16 : 0);             // [Tp][2]   dL/dy(t)
-    float* dump = dyb + Tp * 2;                         // [256]
-    float* hw = dump + 256;                             // fc_out: [2][16] hidden columns (zero padded) | [2][8] feature columns
-    float* gpk = hw + 48;                               // PG: [Tp][16][4]   r, W_hn h + b_hn, z, n of step t (written by the n row)
-    if (lane < 48) {
+    float* hist = ftab + Tp * 8;                        // [Tp + 2][HB]   entry t + 1 = h(t) (unit u at 16 ob + col), entry 0 = h(-1) = 0
+    float* actb = hist + (Tp + 2) * HB;                 // DGRU: [Tp][HB]   relu(fc_hid h(t) + b)
+    float* dyb = actb + (DG ? Tp * HB : 0);             // [Tp][2]   dL/dy(t)
+    float* dump = dyb + Tp * 2;                         // [256 NB]
+    float* hw = dump + 256 * NB;                        // fc_out: [2][HB] hidden columns (zero padded) | [2][8] feature columns
+    float* gpk = hw + 2 * HB + 16;                      // PG: [Tp][NB][16][4]   r, W_hn h + b_hn, z, n of step t (written by the n row)
+    for (int i = lane; i < 2 * HB + 16; i += 64) {
         float v = 0.0f;
-        if (lane < 32) { const int c = lane >> 4, u = lane & 15; if (u < H) v = pl[L.o_w_out + c * OW + u]; }
-        else { const int j = lane - 32, c = j >> 3, k = j & 7; if (DG && k < 6) v = pl[L.o_w_out + c * OW + H + k]; }
-        hw[lane] = v;
+        if (i < 2 * HB) { const int c = i / HB, u = i % HB; if (u < H) v = pl[L.o_w_out + c * OW + u]; }
+        else { const int j = i - 2 * HB, c = j >> 3, k = j & 7; if (DG && k < 6) v = pl[L.o_w_out + c * OW + H + k]; }
+        hw[i] = v;
     }
-    if (lane < 16) hist[lane] = 0.0f;
+    if (lane < HB) hist[lane] = 0.0f;
     const float4* ftab4 = reinterpret_cast<const float4*>(ftab);
     const float4* hw4 = reinterpret_cast<const float4*>(hw);
     const bool odd = role & 1;
     const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
-    // the per-step store of the forward pass: row 1 parks h(t), the head row parks relu(fc_hid h(t-1)), rows 0 / 3 hit the dump
-    const int park0 = role == 1 ? (int)(hist - smem) + 16 + col : (head_row && DG) ? (int)(actb - smem) - 16 + col : (int)(dump - smem) + lane;
-    const int park_step = (role == 1 || (head_row && DG)) ? 16 : 0;
-    const int gpark0 = role == 1 ? (int)(gpk - smem) + 4 * col : (int)(dump - smem) + 4 * lane, gpark_step = role == 1 ? 64 : 0;
+    // the per-step stores of the forward pass: row 1 parks h(t), the head row parks relu(fc_hid h(t-1)), rows 0 / 3 hit the dump
+    const int park0 = role == 1 ? (int)(hist - smem) + HB + col : (head_row && DG) ? (int)(actb - smem) - HB + col : (int)(dump - smem) + lane;
+    const int park_step = (role == 1 || (head_row && DG)) ? HB : 0;
+    const int gpark0 = role == 1 ? (int)(gpk - smem) + 4 * col : (int)(dump - smem) + 4 * lane, gpark_step = role == 1 ? 64 * NB : 0;
 
-    f32x16 acc1, acc2;
+    f32x16 acc1[NB][NB], acc2[NB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
-    float dmisc = 0.0f, dwo0 = 0.0f, dwo1 = 0.0f, dwf0 = 0.0f, dwf1 = 0.0f, dbo0 = 0.0f, dbo1 = 0.0f, loss_acc = 0.0f;
+    for (int ob = 0; ob < NB; ++ob) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc2[ob][i] = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) acc1[ob][kb][i] = 0.0f;
+        }
+    }
+    float dmisc[NB], dwo0[NB], dwo1[NB], dwf0 = 0.0f, dwf1 = 0.0f, dbo0 = 0.0f, dbo1 = 0.0f, loss_acc = 0.0f;
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) { dmisc[ob] = 0.0f; dwo0[ob] = 0.0f; dwo1[ob] = 0.0f; }
+
+    // the gates of one step from h(t-1): arec = W h + b of the row's gate, rows 1 and 3 end with (z, n), row 1 also with r
+    auto gates = [&](const float (&f)[F], const float (&hin)[NB], float (&arec)[NB], float (&r1)[NB], float (&zz)[NB], float (&nn)[NB]) {
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            arec[ob] = b_rec[ob];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) arec[ob] = rotdot(arec[ob], wF[ob][kb], hin[kb]);
+        }
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            float ain = b_in[ob];
+#pragma unroll
+            for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[ob][i], f[i], ain);
+            const float sg = sigmoidf_(ain + arec[ob]);                     // r (row 0), z (row 3)
+            r1[ob] = xor16(sg);                                             // row 1 <- r
+            const float n = tanhf_(__builtin_fmaf(r1[ob], arec[ob], ain));  // row 1
+            const float v = role == 1 ? n : sg;
+            const float o = xor32(v);                                       // row 1 <- z, row 3 <- n
+            zz[ob] = role == 1 ? o : sg; nn[ob] = role == 1 ? n : o;
+        }
+    };
+    auto load_feat = [&](int t, float (&f)[F]) {
+        const float4 fa = ftab4[2 * t];
+        f[0] = fa.x; f[1] = fa.y;
+        if constexpr (F > 2) { f[2] = fa.z; f[3] = fa.w; }
+        if constexpr (F > 4) { const float4 fb = ftab4[2 * t + 1]; f[4] = fb.x; f[5] = fb.y; }
+    };
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
@@ -936,7 +983,9 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
         const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
         // ---- forward ----
         {
-            float h = 0.0f;
+            float h[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) h[kb] = 0.0f;
             int park = park0, gpark = gpark0;
             float2 raw = lane < T ? xg[lane] : make_float2(0.5f, 0.5f);
             for (int t0 = 0; t0 < T; t0 += kEvalChunk) {
@@ -954,39 +1003,30 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                 }
                 raw = t0 + kEvalChunk + lane < T ? xg[t0 + kEvalChunk + lane] : make_float2(0.5f, 0.5f);
                 for (int tt = 0; tt < len; ++tt) {
-                    const int t = t0 + tt;
-                    float f[F];
-                    {
-                        const float4 fa = ftab4[2 * t];
-                        f[0] = fa.x; f[1] = fa.y;
-                        if constexpr (F > 2) { f[2] = fa.z; f[3] = fa.w; }
-                        if constexpr (F > 4) { const float4 fb = ftab4[2 * t + 1]; f[4] = fb.x; f[5] = fb.y; }
-                    }
-                    const float arec = rotdot(b_rec, wF, h);
-                    const float parked = __builtin_fmaxf(arec, 0.0f);             // head row: relu(fc_hid h(t-1) + b)
-                    float ain = b_in;
+                    float f[F], arec[NB], r1[NB], zz[NB], nn[NB];
+                    load_feat(t0 + tt, f);
+                    gates(f, h, arec, r1, zz, nn);
 #pragma unroll
-                    for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[i], f[i], ain);
-                    const float sg = sigmoidf_(ain + arec);                     // r (row 0), z (row 3)
-                    const float r1 = xor16(sg);                                 // row 1 <- r
-                    const float n = tanhf_(__builtin_fmaf(r1, arec, ain));      // row 1
-                    const float v = role == 1 ? n : sg;
-                    const float o = xor32(v);                                   // row 1 <- z, row 3 <- n
-                    const float zz = role == 1 ? o : sg, nn = role == 1 ? n : o;
-                    const float h13 = __builtin_fmaf(zz, h - nn, nn);           // rows 1 and 3: (1 - z) n + z h
-                    const float h02 = xor16(h13);
-                    h = odd ? h13 : h02;
-                    smem[park] = head_row ? parked : h;          // (the head row's first store, act(-1), lands in hist's pad entry)
-                    park += park_step;
-                    if constexpr (PG) {
-                        *reinterpret_cast<float4*>(smem + gpark) = make_float4(r1, arec, zz, nn);
-                        gpark += gpark_step;
+                    for (int ob = 0; ob < NB; ++ob) {
+                        const float h13 = __builtin_fmaf(zz[ob], h[ob] - nn[ob], nn[ob]);       // rows 1 and 3: (1 - z) n + z h
+                        const float h02 = xor16(h13);
+                        h[ob] = odd ? h13 : h02;
+                        // (the head row's first store, act(-1), lands in hist's pad entry)
+                        smem[park + 16 * ob] = head_row ? __builtin_fmaxf(arec[ob], 0.0f) : h[ob];
+                        if constexpr (PG) *reinterpret_cast<float4*>(smem + gpark + 64 * ob) = make_float4(r1[ob], arec[ob], zz[ob], nn[ob]);
                     }
+                    park += park_step;
+                    if constexpr (PG) gpark += gpark_step;
                 }
             }
             if constexpr (DG) {
-                const float arec = rotdot(b_rec, wF, h);
-                if (head_row) actb[(T - 1) * 16 + col] = __builtin_fmaxf(arec, 0.0f);
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    float arec = b_rec[ob];
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) arec = rotdot(arec, wF[ob][kb], h[kb]);
+                    if (head_row) actb[(T - 1) * HB + 16 * ob + col] = __builtin_fmaxf(arec, 0.0f);
+                }
             }
             wave_lds_fence();
         }
@@ -994,17 +1034,17 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
         for (int t0 = 0; t0 < T; t0 += 64) {
             const int t = t0 + lane;
             if (t < T) {
-                const float4* hv4 = reinterpret_cast<const float4*>(DG ? actb + t * 16 : hist + (t + 1) * 16);
+                const float4* hv4 = reinterpret_cast<const float4*>(DG ? actb + t * HB : hist + (t + 1) * HB);
                 float y0 = bo0, y1 = bo1;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 hv = hv4[q], w0 = hw4[q], w1 = hw4[4 + q];
+                for (int q = 0; q < 4 * NB; ++q) {
+                    const float4 hv = hv4[q], w0 = hw4[q], w1 = hw4[4 * NB + q];
                     y0 = __builtin_fmaf(w0.x, hv.x, y0); y0 = __builtin_fmaf(w0.y, hv.y, y0); y0 = __builtin_fmaf(w0.z, hv.z, y0); y0 = __builtin_fmaf(w0.w, hv.w, y0);
                     y1 = __builtin_fmaf(w1.x, hv.x, y1); y1 = __builtin_fmaf(w1.y, hv.y, y1); y1 = __builtin_fmaf(w1.z, hv.z, y1); y1 = __builtin_fmaf(w1.w, hv.w, y1);
                 }
                 if constexpr (DG) {
                     const float4 fa = ftab4[2 * t], fb = ftab4[2 * t + 1];
-                    const float4 u0 = hw4[8], u1 = hw4[9], v0 = hw4[10], v1 = hw4[11];
+                    const float4 u0 = hw4[8 * NB], u1 = hw4[8 * NB + 1], v0 = hw4[8 * NB + 2], v1 = hw4[8 * NB + 3];
                     y0 = __builtin_fmaf(u0.x, fa.x, y0); y0 = __builtin_fmaf(u0.y, fa.y, y0); y0 = __builtin_fmaf(u0.z, fa.z, y0); y0 = __builtin_fmaf(u0.w, fa.w, y0);
                     y0 = __builtin_fmaf(u1.x, fb.x, y0); y0 = __builtin_fmaf(u1.y, fb.y, y0);
                     y1 = __builtin_fmaf(v0.x, fa.x, y1); y1 = __builtin_fmaf(v0.y, fa.y, y1); y1 = __builtin_fmaf(v0.z, fa.z, y1); y1 = __builtin_fmaf(v0.w, fa.w, y1);
@@ -1019,77 +1059,95 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
         wave_lds_fence();
         // ---- backward ----
         {
-            float carry = 0.0f, dhid_cur = 0.0f;       // carry = dL/dh(t) complete (cell path + head path)
+            float carry[NB], dhid_cur[NB];       // carry = dL/dh(t) complete (cell path + head path)
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) { carry[ob] = 0.0f; dhid_cur[ob] = 0.0f; }
             if constexpr (DG) {
                 const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * (T - 1));
-                const float at = actb[(T - 1) * 16 + col];
-                dhid_cur = __builtin_fmaf(dyv.x, wo0, dyv.y * wo1) * relu_gate(at);
-                float part = rotdot(0.0f, wT, head_row ? dhid_cur : 0.0f);
-                part += xor16(part);
-                part += xor32(part);
-                carry = part;
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob)
+                    dhid_cur[ob] = __builtin_fmaf(dyv.x, wo0[ob], dyv.y * wo1[ob]) * relu_gate(actb[(T - 1) * HB + 16 * ob + col]);
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    float part = 0.0f;
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) part = rotdot(part, wT[ob][kb], head_row ? dhid_cur[kb] : 0.0f);
+                    part += xor16(part);
+                    part += xor32(part);
+                    carry[ob] = part;
+                }
             }
             for (int t = T - 1; t >= 0; --t) {
-                const float hp = hist[t * 16 + col], ht = hist[(t + 1) * 16 + col];
-                const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
-                float f[F];
-                {
-                    const float4 fa = ftab4[2 * t];
-                    f[0] = fa.x; f[1] = fa.y;
-                    if constexpr (F > 2) { f[2] = fa.z; f[3] = fa.w; }
-                    if constexpr (F > 4) { const float4 fb = ftab4[2 * t + 1]; f[4] = fb.x; f[5] = fb.y; }
+                float hp[NB], ht[NB], at[NB];
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    hp[ob] = hist[t * HB + 16 * ob + col]; ht[ob] = hist[(t + 1) * HB + 16 * ob + col];
+                    at[ob] = DG ? actb[t * HB + 16 * ob + col] : ht[ob];
                 }
+                const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
                 const float fsx = col < F ? ftab[t * 8 + col] : (col == F ? 1.0f : 0.0f);
                 // the gates of step t: parked by the forward pass, or again from the parked h(t-1)
-                float arec, r1, zz, nn;                                             // rows 1 and 3: z, n; row 1: r, W_hn h + b_hn
+                float arec[NB], r1[NB], zz[NB], nn[NB];                              // rows 1 and 3: z, n; row 1: r, W_hn h + b_hn
                 if constexpr (PG) {
-                    const float4 g = reinterpret_cast<const float4*>(gpk)[t * 16 + col];
-                    r1 = g.x; arec = g.y; zz = g.z; nn = g.w;
-                } else {
-                    arec = rotdot(b_rec, wF, hp);
-                    float ain = b_in;
 #pragma unroll
-                    for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[i], f[i], ain);
-                    const float sg = sigmoidf_(ain + arec);
-                    r1 = xor16(sg);
-                    const float n = tanhf_(__builtin_fmaf(r1, arec, ain));
-                    const float v = role == 1 ? n : sg;
-                    const float o = xor32(v);
-                    zz = role == 1 ? o : sg; nn = role == 1 ? n : o;
+                    for (int ob = 0; ob < NB; ++ob) {
+                        const float4 g = reinterpret_cast<const float4*>(gpk)[(t * NB + ob) * 16 + col];
+                        r1[ob] = g.x; arec[ob] = g.y; zz[ob] = g.z; nn[ob] = g.w;
+                    }
+                } else {
+                    float f[F];
+                    load_feat(t, f);
+                    gates(f, hp, arec, r1, zz, nn);
                 }
                 // dL/dh(t) and the pre-activation gradients (rows 1 / 3; row 0 receives d_r from row 1)
-                const float g01 = __builtin_fmaf(dyv.x, wo0, dyv.y * wo1);
-                const float dht = DG ? carry : carry + g01;
-                const float dn = dht * (1.0f - zz), dz = dht * (hp - nn);
-                const float dnp = dn * __builtin_fmaf(-nn, nn, 1.0f);
-                const float dgh = dnp * r1;
-                const float drp1 = (dnp * arec) * (r1 * (1.0f - r1));
-                const float dzp = dz * (zz * (1.0f - zz));
-                const float drp0 = xor16(drp1);
-                float dhid_prev = 0.0f;
-                if constexpr (DG) {
-                    const int tm = t > 0 ? t - 1 : 0;
-                    const float2 dyp = *reinterpret_cast<const float2*>(dyb + 2 * tm);
-                    const float atp = actb[tm * 16 + col];
-                    dhid_prev = t > 0 ? __builtin_fmaf(dyp.x, wo0, dyp.y * wo1) * relu_gate(atp) : 0.0f;
+                float d_row[NB], dnp[NB], dhid_prev[NB], zterm[NB];
+                float2 dyp = make_float2(0.0f, 0.0f);
+                const int tm = t > 0 ? t - 1 : 0;
+                if constexpr (DG) dyp = *reinterpret_cast<const float2*>(dyb + 2 * tm);
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    const float g01 = __builtin_fmaf(dyv.x, wo0[ob], dyv.y * wo1[ob]);
+                    const float dht = DG ? carry[ob] : carry[ob] + g01;
+                    const float dn = dht * (1.0f - zz[ob]), dz = dht * (hp[ob] - nn[ob]);
+                    dnp[ob] = dn * __builtin_fmaf(-nn[ob], nn[ob], 1.0f);
+                    const float dgh = dnp[ob] * r1[ob];
+                    const float drp1 = (dnp[ob] * arec[ob]) * (r1[ob] * (1.0f - r1[ob]));
+                    const float dzp = dz * (zz[ob] * (1.0f - zz[ob]));
+                    const float drp0 = xor16(drp1);
+                    dhid_prev[ob] = 0.0f;
+                    if constexpr (DG) {
+                        const float atp = actb[tm * HB + 16 * ob + col];
+                        dhid_prev[ob] = t > 0 ? __builtin_fmaf(dyp.x, wo0[ob], dyp.y * wo1[ob]) * relu_gate(atp) : 0.0f;
+                    }
+                    d_row[ob] = role == 0 ? drp0 : role == 1 ? dgh : role == 3 ? dzp : dhid_prev[ob];
+                    zterm[ob] = role == 3 ? dht * zz[ob] : 0.0f;
+                    dmisc[ob] += role == 1 ? dgh : dhid_cur[ob];                     // row 1: db_hn, head row: db_hid
+                    dwo0[ob] = __builtin_fmaf(dyv.x, at[ob], dwo0[ob]); dwo1[ob] = __builtin_fmaf(dyv.y, at[ob], dwo1[ob]);
                 }
-                const float d_row = role == 0 ? drp0 : role == 1 ? dgh : role == 3 ? dzp : dhid_prev;
-                float part = rotdot(role == 3 ? dht * zz : 0.0f, wT, d_row);
-                part += xor16(part);
-                part += xor32(part);
-                carry = part;                                                      // dL/dh(t-1): W_hh^T d + z dL/dh(t) + fc_hid^T dhid(t-1)
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    float part = zterm[ob];
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) part = rotdot(part, wT[ob][kb], d_row[kb]);
+                    part += xor16(part);
+                    part += xor32(part);
+                    carry[ob] = part;                                                // dL/dh(t-1): W_hh^T d + z dL/dh(t) + fc_hid^T dhid(t-1)
+                }
                 // weight gradients
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(head_row ? dhid_cur : d_row, head_row ? ht : hp, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(role == 1 ? dnp : (head_row ? 0.0f : d_row), fsx, acc2, 0, 0, 0);
-                dmisc += role == 1 ? dgh : dhid_cur;                               // row 1: db_hn, head row: db_hid
-                const float at = DG ? actb[t * 16 + col] : ht;
-                dwo0 = __builtin_fmaf(dyv.x, at, dwo0); dwo1 = __builtin_fmaf(dyv.y, at, dwo1);
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    const float a1 = head_row ? dhid_cur[ob] : d_row[ob];
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb)
+                        acc1[ob][kb] = __builtin_amdgcn_mfma_f32_16x16x1f32(a1, head_row ? ht[kb] : hp[kb], acc1[ob][kb], 0, 0, 0);
+                    acc2[ob] = __builtin_amdgcn_mfma_f32_16x16x1f32(role == 1 ? dnp[ob] : (head_row ? 0.0f : d_row[ob]), fsx, acc2[ob], 0, 0, 0);
+                    dhid_cur[ob] = dhid_prev[ob];
+                }
                 if constexpr (DG) {
                     const float fs = col < 6 ? fsx : 0.0f;
                     dwf0 = __builtin_fmaf(dyv.x, fs, dwf0); dwf1 = __builtin_fmaf(dyv.y, fs, dwf1);
                 }
                 dbo0 += dyv.x; dbo1 += dyv.y;
-                dhid_cur = dhid_prev;
             }
         }
         wave_lds_fence();
@@ -1098,10 +1156,14 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
     float lp = loss_acc;
     for (int o = 32; o > 0; o >>= 1) lp += __shfl_down(lp, o);
-    if (vo) {
-        if (role == 1) prow[L.o_b_hh + 2 * H + col] = dmisc;
-        if (DG && head_row) prow[L.o_b_hid + col] = dmisc;
-        if (role == 0) { prow[L.o_w_out + col] = dwo0; prow[L.o_w_out + OW + col] = dwo1; }
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+        const int o = 16 * ob + col;
+        if (o < H) {
+            if (role == 1) prow[L.o_b_hh + 2 * H + o] = dmisc[ob];
+            if (DG && head_row) prow[L.o_b_hid + o] = dmisc[ob];
+            if (role == 0) { prow[L.o_w_out + o] = dwo0[ob]; prow[L.o_w_out + OW + o] = dwo1[ob]; }
+        }
     }
     if (DG && role == 0 && col < 6) { prow[L.o_w_out + H + col] = dwf0; prow[L.o_w_out + OW + H + col] = dwf1; }
     if (lane == 0) {
@@ -1110,26 +1172,33 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     }
     // MFMA blocks: 0 = r, 1 = n, 2 = fc_hid, 3 = z; register 4 blk + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
-        const int g = blk == 0 ? 0 : blk == 3 ? 1 : 2;
+    for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int i = 4 * role + rr, c = col;
-            if (i < H) {
-                if (blk == 2) {
-                    if (DG && c < H) prow[L.o_w_hid + i * H + c] = acc1[4 * blk + rr];
-                } else {
-                    if (c < H) prow[L.o_w_hh + (g * H + i) * H + c] = acc1[4 * blk + rr];
-                    const float v = acc2[4 * blk + rr];
-                    if (c < F) prow[L.o_w_ih + (g * H + i) * F + c] = v;
-                    else if (c == F) {
-                        prow[L.o_b_ih + g * H + i] = v;
-                        if (g < 2) prow[L.o_b_hh + g * H + i] = v;
+        for (int blk = 0; blk < 4; ++blk) {
+            const int g = blk == 0 ? 0 : blk == 3 ? 1 : 2;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 16 * ob + 4 * role + rr;
+                if (i < H) {
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) {
+                        const int j = 16 * kb + col;
+                        if (j < H) {
+                            if (blk == 2) { if (DG) prow[L.o_w_hid + i * H + j] = acc1[ob][kb][4 * blk + rr]; }
+                            else prow[L.o_w_hh + (g * H + i) * H + j] = acc1[ob][kb][4 * blk + rr];
+                        }
+                    }
+                    if (blk != 2) {
+                        const float v = acc2[ob][4 * blk + rr];
+                        if (col < F) prow[L.o_w_ih + (g * H + i) * F + col] = v;
+                        else if (col == F) {
+                            prow[L.o_b_ih + g * H + i] = v;
+                            if (g < 2) prow[L.o_b_hh + g * H + i] = v;
+                        }
                     }
                 }
             }
         }
-    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1310,50 +1379,47 @@ int gru_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     return ODPD_EUNSUPPORTED;
 }
 // the gate-parallel fused train kernel: one sequence per single-wave workgroup, BPTT state of the whole frame in LDS
-static size_t gp_lds_bytes(int P, bool DG, int T, bool pg) {
-    return ((size_t)pad4(P) + (DG ? gp_buffer_floats<true>(T, pg) : gp_buffer_floats<false>(T, pg))) * sizeof(float);
+static size_t gp_lds_bytes(int P, int R, bool DG, int T, bool pg) {
+    const int buf = R == 1 ? (DG ? gp_buffer_floats<1, true>(T, pg) : gp_buffer_floats<1, false>(T, pg))
+                           : (DG ? gp_buffer_floats<2, true>(T, pg) : gp_buffer_floats<2, false>(T, pg));
+    return ((size_t)pad4(P) + buf) * sizeof(float);
 }
 // workgroups of a CU that the frame's LDS-resident BPTT state allows (at most one per SIMD)
-static int gp_blocks_per_cu(int P, bool DG, int T, bool pg) {
-    const size_t lds = gp_lds_bytes(P, DG, T, pg);
+static int gp_blocks_per_cu(int P, int R, bool DG, int T, bool pg) {
+    const size_t lds = gp_lds_bytes(P, R, DG, T, pg);
     const int n = lds > kMaxLds ? 0 : (int)(kMaxLds / lds);
     return n < 4 ? n : 4;
 }
 // the variant that parks the gates is taken while every sequence of the batch still gets its own SIMD
-static bool gp_parks_gates(int P, bool DG, int B, int T) { return (long)B <= (long)device_cus() * gp_blocks_per_cu(P, DG, T, true); }
+static bool gp_parks_gates(int P, int R, bool DG, int B, int T) { return (long)B <= (long)device_cus() * gp_blocks_per_cu(P, R, DG, T, true); }
 bool gru_train_uses_gp(const odpd_model_t* m, int B, int T) {
     int FM, R, P; bool DG;
-    if (!gru_setup(m, FM, DG, R, P) || R != 1 || gru_train_uses_s16(m, B, T)) return false;
+    if (!gru_setup(m, FM, DG, R, P) || gru_uses_s16n(m, B) || gru_train_uses_s16(m, B, T)) return false;
     const long max_batch = tuning().gp_max_batch;
-    if (max_batch >= 0) return B <= max_batch && gp_blocks_per_cu(P, DG, T, false) > 0;
-    return (long)B <= (long)device_cus() * gp_blocks_per_cu(P, DG, T, false);        // one sequence per SIMD, all resident at once
+    if (max_batch >= 0) return B <= max_batch && gp_blocks_per_cu(P, R, DG, T, false) > 0;
+    return (long)B <= (long)device_cus() * gp_blocks_per_cu(P, R, DG, T, false);        // one sequence per SIMD, all resident at once
 }
-static int gp_grid(int P, bool DG, int B, int T) {
-    const bool pg = gp_parks_gates(P, DG, B, T);
-    const long cap = (long)device_cus() * (kMaxLds / gp_lds_bytes(P, DG, T, pg));
+static int gp_grid(int P, int R, bool DG, int B, int T) {
+    const bool pg = gp_parks_gates(P, R, DG, B, T);
+    const long cap = (long)device_cus() * (kMaxLds / gp_lds_bytes(P, R, DG, T, pg));
     return B < cap ? B : (int)cap;
 }
-template <int FM, bool DG>
+template <int R, int FM, bool DG>
 static int launch_gp_train(hipStream_t st, const SeqArgs& a, int P) {
-    const bool pg = gp_parks_gates(P, DG, a.B, a.T);
-    const size_t lds = gp_lds_bytes(P, DG, a.T, pg);
-    const int grid = gp_grid(P, DG, a.B, a.T);
+    const bool pg = gp_parks_gates(P, R, DG, a.B, a.T);
+    const size_t lds = gp_lds_bytes(P, R, DG, a.T, pg);
+    const int grid = gp_grid(P, R, DG, a.B, a.T);
     auto launch = [&](auto k) {
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, a);
         return (int)hipGetLastError();
     };
-    return pg ? launch(gru_gp_train_kernel<FM, DG, true>) : launch(gru_gp_train_kernel<FM, DG, false>);
+    return pg ? launch(gru_gp_train_kernel<R, FM, DG, true>) : launch(gru_gp_train_kernel<R, FM, DG, false>);
 }
 int gru_family_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
-    if (gru_train_uses_gp(m, a.B, a.T)) {
-        if (FM == FEAT_RAW2) return launch_gp_train<FEAT_RAW2, false>(st, a, P);
-        if (FM == FEAT_DGRU6) return launch_gp_train<FEAT_DGRU6, true>(st, a, P);
-        if (FM == FEAT_Q4) return launch_gp_train<FEAT_Q4, false>(st, a, P);
-        return launch_gp_train<FEAT_A4, false>(st, a, P);
-    }
+    if (gru_train_uses_gp(m, a.B, a.T)) { ODPD_GRU_DISPATCH_ALL(launch_gp_train, st, a, P) }
     ODPD_GRU_DISPATCH_ALL(launch_train, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
@@ -1382,7 +1448,7 @@ int gru_family_rows(const odpd_model_t* m, int B, int which, int T) {
     if (gru_uses_s16n(m, B)) return gru_s16n_rows(m, B);
     if (!which) return gru_split_uses_s16(m, B) ? gru_s16_bwd_rows(m, B) : bwd_shape(R, ng).grid;
     if (gru_train_uses_s16(m, B, T)) return gru_s16_rows(m, B);
-    if (gru_train_uses_gp(m, B, T)) return gp_grid(P, DG, B, T);
+    if (gru_train_uses_gp(m, B, T)) return gp_grid(P, R, DG, B, T);
     const LaunchShape ls = train_shape(P, R, DG, ng, T, nullptr);
     return ls.grid > 0 ? ls.grid : ODPD_EUNSUPPORTED;
 }

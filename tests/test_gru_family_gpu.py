@@ -252,11 +252,12 @@ def test_fused_step_on_frames_addressed_in_place(bb, H, B, T, stride):
 
 
 @pytest.mark.parametrize("bb", ["gru", "dgru", "qgru", "qgru_amp1"])
-@pytest.mark.parametrize("H", [1, 5, 13, 16])
+@pytest.mark.parametrize("H", [1, 5, 13, 16, 17, 23, 32])
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (7, 63), (5, 64), (2, 65), (64, 50), (9, 200), (300, 200), (5, 130)])
 def test_gate_parallel_train_kernel(bb, H, B, T):
     """the reference's own batch sizes run gru_gp_train_kernel (one sequence per wave, rows r / n / head / z; fc_out, loss and features with
-    lane = time step; weight gradients as 4-block MFMAs; (300, 200) does not park the gates, the smaller batches do): loss and gradient
+    lane = time step; weight gradients as 4-block MFMAs; hidden 17..32 as two unit blocks per row; the gates are parked while LDS allows — not at
+    (300, 200), nor for two unit blocks at 200 steps): loss and gradient
     against the oracle (L2 and L1), and against the row-rotated fused kernel (odpd_set_tuning gp_max_batch = 0) on the same batch"""
     import ctypes as C
     from opendpd_amd import CoreModel, _lib
@@ -291,7 +292,8 @@ def test_gate_parallel_train_kernel(bb, H, B, T):
                 got[gp] = (float(loss), opt.grad[:-4].cpu().numpy().copy())
             assert abs(got[-1][0] - lo) < 2e-5 * max(1.0, lo) and abs(got[-1][0] - got[0][0]) < 1e-6 * max(1.0, lo)
             assert rel_err(got[-1][1], go) < GRAD_TOL and rel_err(got[-1][1], got[0][1]) < 2e-5
-            assert T < 50 or not np.array_equal(got[-1][1], got[0][1])          # two kernels: different summation orders
+            # two kernels: different summation orders ((300, 200) with two unit blocks exceeds one sequence per SIMD: row-rotated by default too)
+            assert T < 50 or (H > 16 and B > 256) or not np.array_equal(got[-1][1], got[0][1])
     finally:
         lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
 
