@@ -929,6 +929,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     const float4* ftab4 = reinterpret_cast<const float4*>(ftab);
     const float4* hw4 = reinterpret_cast<const float4*>(hw);
     const bool odd = role & 1;
+    const RowMasks rm = row_masks();
     const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
     // the per-step stores of the forward pass: row 1 parks h(t), the head row parks relu(fc_hid h(t-1)), rows 0 / 3 hit the dump
     const int park0 = role == 1 ? (int)(hist - smem) + HB + col : (head_row && DG) ? (int)(actb - smem) - HB + col : (int)(dump - smem) + lane;
@@ -1119,9 +1120,10 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                         const float atp = actb[tm * HB + 16 * ob + col];
                         dhid_prev[ob] = t > 0 ? __builtin_fmaf(dyp.x, wo0[ob], dyp.y * wo1[ob]) * relu_gate(atp) : 0.0f;
                     }
-                    d_row[ob] = role == 0 ? drp0 : role == 1 ? dgh : role == 3 ? dzp : dhid_prev[ob];
-                    zterm[ob] = role == 3 ? dht * zz[ob] : 0.0f;
-                    dmisc[ob] += role == 1 ? dgh : dhid_cur[ob];                     // row 1: db_hn, head row: db_hid
+                    // (vsel: a plain ?: on the row index comes out as exec-mask branches here)
+                    d_row[ob] = vsel(rm.m[0], drp0, vsel(rm.m[1], dgh, vsel(rm.m[3], dzp, dhid_prev[ob])));
+                    zterm[ob] = vsel(rm.m[3], dht * zz[ob], 0.0f);
+                    dmisc[ob] += vsel(rm.m[1], dgh, dhid_cur[ob]);               // row 1: db_hn, head row: db_hid
                     dwo0[ob] = __builtin_fmaf(dyv.x, at[ob], dwo0[ob]); dwo1[ob] = __builtin_fmaf(dyv.y, at[ob], dwo1[ob]);
                 }
 #pragma unroll
@@ -1136,11 +1138,11 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                 // weight gradients
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) {
-                    const float a1 = head_row ? dhid_cur[ob] : d_row[ob];
+                    const float a1 = vsel(rm.m[2], dhid_cur[ob], d_row[ob]);
 #pragma unroll
                     for (int kb = 0; kb < NB; ++kb)
-                        acc1[ob][kb] = __builtin_amdgcn_mfma_f32_16x16x1f32(a1, head_row ? ht[kb] : hp[kb], acc1[ob][kb], 0, 0, 0);
-                    acc2[ob] = __builtin_amdgcn_mfma_f32_16x16x1f32(role == 1 ? dnp[ob] : (head_row ? 0.0f : d_row[ob]), fsx, acc2[ob], 0, 0, 0);
+                        acc1[ob][kb] = __builtin_amdgcn_mfma_f32_16x16x1f32(a1, vsel(rm.m[2], ht[kb], hp[kb]), acc1[ob][kb], 0, 0, 0);
+                    acc2[ob] = __builtin_amdgcn_mfma_f32_16x16x1f32(vsel(rm.m[1], dnp[ob], vsel(rm.m[2], 0.0f, d_row[ob])), fsx, acc2[ob], 0, 0, 0);
                     dhid_cur[ob] = dhid_prev[ob];
                 }
                 if constexpr (DG) {

@@ -67,6 +67,21 @@ __device__ __forceinline__ float xor16(float v) {       // lane i <-> lane i ^ 1
     const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);      // r[0] = rows (0, 0, 2, 2), r[1] = rows (1, 1, 3, 3)
     return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
 }
+// Row select without control flow: a ?: on the row index can come out as exec-mask branches inside a step loop, and an inline-asm
+// v_cndmask hides its VGPR write from the compiler's MFMA hazard handling (a following v_mfma read the stale operand).  So: per-lane
+// all-ones / zero masks, made opaque once at kernel start, and a bitwise blend (one v_bfi_b32).
+struct RowMasks { int m[4]; };
+__device__ __forceinline__ RowMasks row_masks() {
+    RowMasks r;
+    const int role = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.m[k] = role == k ? -1 : 0;
+    asm volatile("" : "+v"(r.m[0]), "+v"(r.m[1]), "+v"(r.m[2]), "+v"(r.m[3]));
+    return r;
+}
+__device__ __forceinline__ float vsel(int m, float t, float f) {      // m = all ones: t, m = 0: f
+    return __builtin_bit_cast(float, (m & __builtin_bit_cast(int, t)) | (~m & __builtin_bit_cast(int, f)));
+}
 // every row of the wave receives all four rows' values: g[k] = v of row k, same column (three cross-row swaps)
 __device__ __forceinline__ void gather_rows(float v, float (&g)[4]) {
     const int iv = __builtin_bit_cast(int, v);
