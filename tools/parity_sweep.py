@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of every HIP backbone against the C oracle (GPU box): all hidden sizes of the kernels' envelope,
-random batch / frame length, both kernel mappings (row-rotated and S16 forced).  Prints the worst relative errors per backbone
+random batch / frame length, the three kernel mappings (default dispatch — the one-sequence-per-wave kernels at these shapes —, S16 forced, row-rotated forced).  Prints the worst relative errors per backbone
 and every case beyond tolerance.  usage: PYTHONPATH=. python tools/parity_sweep.py [cases-per-size] [mid]
 `mid`: batches of 300 / 1000 / 4803 sequences x 3..19 steps instead — tens to hundreds of 16-sequence groups, i.e. several workgroups
 and partial rows per launch, the range between the ragged small shapes and the full-size runs of tests/test_fullsize_gpu.py"""
@@ -26,8 +26,9 @@ bad, kinks, illcond, worst = [], [], [], {}
 for bb, sizes in SIZES.items():
     for H in sizes:
         for case in range(n_per):
-            for force in (False, True):
-                lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
+            for force in (False, True, "row-rotated"):      # default dispatch (one-sequence-per-wave kernels at these shapes) | S16 forced | four-sequence waves
+                lib.odpd_set_tuning(b"s16_min_batch", 0 if force is True else -1)
+                lib.odpd_set_tuning(b"gp_max_batch", 0 if force == "row-rotated" else -1)
                 B = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
                 T = int(rng.choice([1, 2, 3, 4, 5, 7, 31, 32, 33, 50, 64, 65, 200, 257, 300]))
                 if MID:
@@ -61,7 +62,7 @@ for bb, sizes in SIZES.items():
                 amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
                 x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
                 dy = rng.randn(B, T, 2).astype(np.float32)
-                need_dx = "delta" not in bb or force      # delta: dL/dx lives in the S16 kernels (ODPD_FLAG_NEED_DX routes there)
+                need_dx = "delta" not in bb or force is True      # delta: dL/dx lives in the S16 kernels (ODPD_FLAG_NEED_DX routes there)
                 xt = torch.from_numpy(x).cuda().requires_grad_(need_dx)
                 try:
                     y = net(xt)
@@ -122,6 +123,7 @@ for bb, sizes in SIZES.items():
                     bad.append((bb, H, B, T, force, kw, f"y {ey:.2e} g {eg:.2e} dx {ex:.2e} flips {flips} sequences off {nbad}/{B}"))
     print(f"{bb:18s} worst rel err  y {worst[bb][0]:.2e}  grad {worst[bb][1]:.2e}  dx {worst[bb][2]:.2e}", flush=True)
 lib.odpd_set_tuning(b"s16_min_batch", -1)
+lib.odpd_set_tuning(b"gp_max_batch", -1)
 print(f"{len(kinks)} case(s) on an activation kink (the oracle's own gradient is discontinuous there): {kinks}")
 print(f"{len(illcond)} ill-conditioned case(s) (the fp32 oracle itself is that far from the fp64 one): {illcond}")
 print(f"{len(bad)} case(s) beyond tolerance")

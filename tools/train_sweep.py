@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of the optimiser step (fwd + loss + BPTT + clip + AdamW through `fused_train_step`: single-launch kernels
 where they exist, the split chain elsewhere) against the C oracle's train step: every hidden size of the envelope, random batch /
-frame length / loss kind, both kernel mappings, two consecutive steps.  usage: PYTHONPATH=. python tools/train_sweep.py [cases-per-size]"""
+frame length / loss kind, the three kernel mappings (default dispatch, S16 forced, row-rotated forced), two consecutive steps.  usage: PYTHONPATH=. python tools/train_sweep.py [cases-per-size]"""
 import sys
 import warnings
 
@@ -27,8 +27,9 @@ for bb, sizes in SIZES.items():
     worst = [0.0, 0.0]
     for H in sizes:
         for case in range(n_per):
-            for force in (False, True):
-                lib.odpd_set_tuning(b"s16_min_batch", 0 if force else -1)
+            for force in (False, True, "row-rotated"):      # default dispatch (one-sequence-per-wave kernels at these shapes) | S16 forced | four-sequence waves
+                lib.odpd_set_tuning(b"s16_min_batch", 0 if force is True else -1)
+                lib.odpd_set_tuning(b"gp_max_batch", 0 if force == "row-rotated" else -1)
                 B = int(rng.choice([1, 3, 4, 15, 16, 17, 33, 64]))
                 T = int(rng.choice([3, 4, 5, 31, 32, 33, 50, 65, 200]))
                 if B * T > 5000:
