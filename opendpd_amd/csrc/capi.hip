@@ -136,7 +136,9 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
                                                     : lstm_train_uses_gp(m, B, T) ? (int64_t)lstm_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return lstm_family_rows(m, B);
     case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B);
-    case FAM_JANET: return fused ? (int64_t)ODPD_EUNSUPPORTED : janet_family_rows(m, B);
+    case FAM_JANET:
+        if (fused) return janet_train_uses_gp(m, B, T) ? (int64_t)janet_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+        return janet_family_rows(m, B);
     case FAM_DVR: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)dvrjanet_rows(m, B);
     case FAM_BOJ: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)bojanet_rows(m, B);
     case FAM_APN: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)apnrru_rows(m, B);
@@ -153,6 +155,7 @@ extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     if (family_of(m) == FAM_LSTM)
         return lstm_train_uses_s16(m, B) ? lstm_s16_workspace_floats(m, B, T) : lstm_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_JANET) return janet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN) return odpd_param_count(m) > 0 ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
     if (gru_uses_s16n(m, B)) return gru_s16n_ckpt_floats(m, B, T);
@@ -228,6 +231,7 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     case FAM_LSTM:
         return lstm_train_uses_s16(m, B) ? lstm_s16_train((hipStream_t)stream, m, a)
                                          : lstm_train_uses_gp(m, B, T) ? lstm_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
+    case FAM_JANET: return janet_train_uses_gp(m, B, T) ? janet_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_GMP: return gmp_train((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_train((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;

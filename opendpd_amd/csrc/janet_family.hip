@@ -8,6 +8,7 @@
 // weight gradients of the HxH blocks by exact-fp32 MFMA; dL/dx (frozen PA of a cascade) through the three scalar
 // input columns and the polar features.
 #include "odpd_seq.h"
+#include "odpd_s16.h"
 
 namespace odpd {
 
@@ -207,6 +208,200 @@ __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Gate-parallel fused train kernel for the reference's own batch sizes (train_funcs.py:28-48; a wave is alone on its SIMD there): ONE
+// sequence per wave (one wave per workgroup), only the recurrence in the step loops.
+//   forward   as janet_eval_kernel (two rounds of one rotated dot product per row); h(t), (a, p1, p2, f) and (g, u) of every step are parked in LDS;
+//   head      fc_out, the loss and dL/dy of all T steps with lane = time step;
+//   backward  two rounds with the transposed weights: rows (W_fu^T d_f | W_gu^T d_g | W_gh^T d_g | W_fh^T d_f) — the first pair sums to dL/du, the
+//             second to h(t-1)'s share — then rows (W_a^T d_a | W_p1^T d_p1 | W_p2^T d_p2 | -); the weight gradients of a step are TWO 4-block
+//             MFMAs (v_mfma_f32_16x16x1_4b_f32): (d_f | d_g | d_g | d_f) x (u | u | h(t-1) | h(t-1)) and (d_a | d_p1 | d_p2 | 0) x h(t-1).
+// One partial-gradient row per workgroup.  Taken while the frame's parked state fits the CU's LDS share.
+// -------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__host__ __device__ inline int janet_gp_buffer_floats(int T) {
+    const int Tp = (T + 63) & ~63;
+    const int buf = Tp * 4 + (Tp + 1) * 16 + Tp * 64 + Tp * 32 + Tp * 2 + 256 + 32;
+    return buf > kJTabFloats ? buf : kJTabFloats;
+}
+__global__ __launch_bounds__(64) void janet_gp_train_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;
+    const JanetLayout L = janet_layout(a.H);
+    const int H = L.H, T = a.T, Tp = (T + 63) & ~63;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_janet_tabs<true>(tab, pl, L, lane, 0, 1);
+    TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    const bool vo = col < H;
+    // forward: round A a_h | p1_h | p2_h | f_h, round B f_u | g_u | g_h | -; backward (transposed): round B' f_u | g_u | g_h | f_h, round A' a_h | p1_h | p2_h | -
+    float wa[16], wb[16], wtb[16], wta[16];
+    load_rot(wa, tl + role * 4 * 64);
+    load_rot(wb, tl + (role == 0 ? 5 : role == 1 ? 6 : 4) * 4 * 64);
+    load_rot(wtb, tl + (7 + (role == 0 ? 5 : role == 1 ? 6 : role == 2 ? 4 : 3)) * 4 * 64);
+    load_rot(wta, tl + (7 + (role < 3 ? role : 0)) * 4 * 64);
+    if (role == 3) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { wb[k] = 0.0f; wta[k] = 0.0f; }
+    }
+    const int o_w = role == 0 ? L.o_wa : role == 1 ? L.o_wp1 : L.o_wp2, o_b = role == 0 ? L.o_ba : role == 1 ? L.o_bp1 : role == 2 ? L.o_bp2 : L.o_bf;
+    const float sw = (vo && role < 3) ? pl[o_w + col * (H + 1) + H] : 0.0f;    // the row's scalar-input column
+    const float ba = vo ? pl[o_b + col] : 0.0f;
+    const float bg = (vo && role == 2) ? pl[L.o_bg + col] : 0.0f;
+    const float wo0 = vo ? pl[L.o_wo + col] : 0.0f, wo1 = vo ? pl[L.o_wo + H + col] : 0.0f;
+    const float bo0 = pl[L.o_bo], bo1 = pl[L.o_bo + 1];
+    const int fsel = role < 3 ? role : 2;
+    wave_lds_fence();
+    // per-time buffers over the tables
+    float* ftab = tab;                                  // [Tp][4]   |x|, cos, sin of step t
+    float* hist = ftab + Tp * 4;                        // [Tp + 1][16]   entry t + 1 = h(t), entry 0 = 0
+    float* gpk = hist + (Tp + 1) * 16;                  // [Tp][16][4]   a, p1, p2, f of step t
+    float* gu = gpk + Tp * 64;                          // [Tp][16][2]   g, u of step t
+    float* dyb = gu + Tp * 32;                          // [Tp][2]   dL/dy(t)
+    float* dump = dyb + Tp * 2;                         // [256]
+    float* hw = dump + 256;                             // fc_out [2][16], zero padded
+    if (lane < 32) hw[lane] = (lane & 15) < H ? pl[L.o_wo + (lane >> 4) * H + (lane & 15)] : 0.0f;
+    if (lane < 16) hist[lane] = 0.0f;
+    const RowMasks rm = row_masks();
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
+    // per-step stores of the forward pass: row 0 parks (a, p1, p2, f), row 1 (g, u), row 2 h(t); the other rows hit the dump
+    const int dmp = (int)(dump - smem);
+    const int p4_0 = role == 0 ? (int)(gpk - smem) + 4 * col : dmp + 4 * lane, p4_step = role == 0 ? 64 : 0;
+    const int p2_0 = role == 1 ? (int)(gu - smem) + 2 * col : dmp + 2 * lane, p2_step = role == 1 ? 32 : 0;
+    const int p1_0 = role == 2 ? (int)(hist - smem) + 16 + col : dmp + lane, p1_step = role == 2 ? 16 : 0;
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
+    float dsc = 0.0f, db1 = 0.0f, dbg = 0.0f, dwo0 = 0.0f, dwo1 = 0.0f, dbo0 = 0.0f, dbo1 = 0.0f, loss_acc = 0.0f;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        // ---- forward ----
+        {
+            float h = 0.0f;
+            int q4 = p4_0, q2 = p2_0, q1 = p1_0;
+            float2 raw = lane < T ? xg[lane] : make_float2(0.5f, 0.5f);
+            for (int t0 = 0; t0 < T; t0 += kEvalChunk) {
+                const int len = min(kEvalChunk, T - t0);
+                {
+                    float amp, ct, st;
+                    janet_inputs(raw, amp, ct, st);
+                    wave_lds_fence();
+                    reinterpret_cast<float4*>(ftab)[t0 + lane] = make_float4(amp, ct, st, 0.0f);
+                    wave_lds_fence();
+                }
+                raw = t0 + kEvalChunk + lane < T ? xg[t0 + kEvalChunk + lane] : make_float2(0.5f, 0.5f);
+                for (int tt = 0; tt < len; ++tt) {
+                    const float sc = ftab[(t0 + tt) * 4 + fsel];                  // the row's scalar input: |x| | cos | sin
+                    const float pa = rotdot(__builtin_fmaf(sw, sc, ba), wa, h);
+                    float g4[4];
+                    gather_rows(role == 3 ? pa : tanhf_(pa), g4);
+                    const float an = g4[0], p1 = g4[1], p2 = g4[2];
+                    const float u = (an * p1 * p2) * ((1.0f - an) * (1.0f - p1) * (1.0f - p2));
+                    const float pb = rotdot(role == 0 ? g4[3] : bg, wb, role < 2 ? u : h);
+                    gather_rows(pb, g4);
+                    const float f = sigmoidf_(g4[0]), g = tanhf_(g4[2] + g4[1]);
+                    h = __builtin_fmaf(f, h - g, g);
+                    *reinterpret_cast<float4*>(smem + q4) = make_float4(an, p1, p2, f);
+                    *reinterpret_cast<float2*>(smem + q2) = make_float2(g, u);
+                    smem[q1] = h;
+                    q4 += p4_step; q2 += p2_step; q1 += p1_step;
+                }
+            }
+            wave_lds_fence();
+        }
+        // ---- fc_out, loss and dL/dy of every step, lane = time step ----
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < T) {
+                const float4* hv4 = reinterpret_cast<const float4*>(hist + (t + 1) * 16);
+                const float4* hw4 = reinterpret_cast<const float4*>(hw);
+                float y0 = bo0, y1 = bo1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 hv = hv4[q], w0 = hw4[q], w1 = hw4[4 + q];
+                    y0 = __builtin_fmaf(w0.x, hv.x, y0); y0 = __builtin_fmaf(w0.y, hv.y, y0); y0 = __builtin_fmaf(w0.z, hv.z, y0); y0 = __builtin_fmaf(w0.w, hv.w, y0);
+                    y1 = __builtin_fmaf(w1.x, hv.x, y1); y1 = __builtin_fmaf(w1.y, hv.y, y1); y1 = __builtin_fmaf(w1.z, hv.z, y1); y1 = __builtin_fmaf(w1.w, hv.w, y1);
+                }
+                const float2 tv = tg[t];
+                float dy0, dy1;
+                s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+                dbo0 += dy0; dbo1 += dy1;
+                *reinterpret_cast<float2*>(dyb + 2 * t) = make_float2(dy0, dy1);
+            }
+        }
+        wave_lds_fence();
+        // ---- backward ----
+        {
+            float carry = 0.0f;
+            for (int t = T - 1; t >= 0; --t) {
+                const float hp = hist[t * 16 + col], ht = hist[(t + 1) * 16 + col];
+                const float4 ga = reinterpret_cast<const float4*>(gpk)[t * 16 + col];
+                const float2 gg = reinterpret_cast<const float2*>(gu)[t * 16 + col];
+                const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
+                const float sc = ftab[t * 4 + fsel];
+                const float an = ga.x, p1 = ga.y, p2 = ga.z, f = ga.w, g = gg.x, u = gg.y;
+                const float dht = carry + __builtin_fmaf(dyv.x, wo0, dyv.y * wo1);
+                dwo0 = __builtin_fmaf(dyv.x, ht, dwo0); dwo1 = __builtin_fmaf(dyv.y, ht, dwo1);
+                const float dfp = (dht * (hp - g)) * (f * (1.0f - f));
+                const float dgp = (dht * (1.0f - f)) * __builtin_fmaf(-g, g, 1.0f);
+                // round B': rows 0 / 1 sum to dL/du, rows 2 / 3 to h(t-1)'s share through W_gh, W_fh
+                const float dsel = vsel(rm.m[0] | rm.m[3], dfp, dgp);
+                float pb = rotdot(0.0f, wtb, dsel);
+                pb += xor16(pb);                                                   // rows 0, 1: du | rows 2, 3: the h share
+                const float px = xor32(pb);
+                const float du = vsel(rm.m[0] | rm.m[1], pb, px), dhb = vsel(rm.m[0] | rm.m[1], px, pb);
+                const float Aa = an * (1.0f - an), Ab = p1 * (1.0f - p1), Ac = p2 * (1.0f - p2);
+                const float dap = (du * (1.0f - 2.0f * an) * Ab * Ac) * __builtin_fmaf(-an, an, 1.0f);
+                const float dbp = (du * Aa * (1.0f - 2.0f * p1) * Ac) * __builtin_fmaf(-p1, p1, 1.0f);
+                const float dcp = (du * Aa * Ab * (1.0f - 2.0f * p2)) * __builtin_fmaf(-p2, p2, 1.0f);
+                const float d_a = vsel(rm.m[0], dap, vsel(rm.m[1], dbp, vsel(rm.m[2], dcp, 0.0f)));
+                float pa = rotdot(0.0f, wta, d_a);
+                pa += xor16(pa);
+                pa += xor32(pa);
+                carry = __builtin_fmaf(dht, f, dhb) + pa;
+                // weight gradients
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(dsel, vsel(rm.m[0] | rm.m[1], u, hp), acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_a, hp, acc2, 0, 0, 0);
+                dsc = __builtin_fmaf(d_a, sc, dsc);                               // rows 0..2: the scalar-input column of W_a / W_p1 / W_p2
+                db1 += vsel(rm.m[3], dfp, d_a);                                    // rows 0..2: b_a / b_p1 / b_p2, row 3: b_f
+                dbg += dgp;
+            }
+        }
+        wave_lds_fence();
+    }
+    // ---- the workgroup's row of partial gradients (every entry written) ----
+    float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
+    float lp = loss_acc, t0s = dbo0, t1s = dbo1;
+    for (int o = 32; o > 0; o >>= 1) { lp += __shfl_xor(lp, o); t0s += __shfl_xor(t0s, o); t1s += __shfl_xor(t1s, o); }
+    if (vo) {
+        if (role < 3) { prow[o_w + col * (H + 1) + H] = dsc; prow[o_b + col] = db1; }
+        else prow[L.o_bf + col] = db1;
+        if (role == 0) { prow[L.o_bg + col] = dbg; prow[L.o_wo + col] = dwo0; prow[L.o_wo + H + col] = dwo1; }
+    }
+    if (lane == 0) {
+        prow[L.o_bo] = t0s; prow[L.o_bo + 1] = t1s;
+        prow[L.P] = lp; prow[L.P + 1] = 0.0f; prow[L.P + 2] = 0.0f; prow[L.P + 3] = 0.0f;
+    }
+    // MFMA 1 blocks: W_f[:, H + j] | W_g[:, H + j] | W_g[:, j] | W_f[:, j]; MFMA 2 blocks: W_a | W_p1 | W_p2 | -
+    // register 4 blk + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * role + rr;
+            if (i < H && col < H) {
+                const int b1 = (blk == 0 || blk == 3) ? L.o_wf : L.o_wg, coff = blk < 2 ? H : 0;
+                prow[b1 + i * 2 * H + coff + col] = acc1[4 * blk + rr];
+                if (blk < 3) prow[(blk == 0 ? L.o_wa : blk == 1 ? L.o_wp1 : L.o_wp2) + i * (H + 1) + col] = acc2[4 * blk + rr];
+            }
+        }
+}
+
 struct JanetGrad {
     f32x4 t[7];                 // dW blocks in table order (a_h, p1_h, p2_h, f_h, g_h, f_u, g_u)
     float ds[3], db[5];         // scalar-input columns (amp, cos, sin) and biases (a, p1, p2, f, g)
@@ -391,6 +586,33 @@ static size_t janet_lds_bytes(int P, int waves, bool reduce) {
 }
 static LaunchShape janet_bwd_shape(int ngroups) { return persistent_shape(ngroups, 8, 8); }
 
+// the gate-parallel fused train kernel: one sequence per single-wave workgroup, the frame's parked state in LDS
+static size_t janet_gp_lds_bytes(int P, int T) { return ((size_t)pad4(P) + janet_gp_buffer_floats(T)) * sizeof(float); }
+static int janet_gp_blocks_per_cu(int P, int T) {
+    const size_t lds = janet_gp_lds_bytes(P, T);
+    const int n = lds > kMaxLds ? 0 : (int)(kMaxLds / lds);
+    return n < 4 ? n : 4;
+}
+bool janet_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    if (m->backbone != ODPD_PGJANET || m->hidden > 16 || janet_uses_s16(m, B)) return false;
+    const int P = janet_layout(m->hidden).P;
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0) return B <= max_batch && janet_gp_blocks_per_cu(P, T) > 0;
+    // up to two rounds of workgroups: the alternative is the forward / loss / backward chain of the row-rotated kernels
+    return (long)B <= 2L * device_cus() * janet_gp_blocks_per_cu(P, T);
+}
+int janet_gp_rows(const odpd_model_t* m, int B, int T) {
+    const int P = janet_layout(m->hidden).P;
+    const long cap = (long)device_cus() * (kMaxLds / janet_gp_lds_bytes(P, T));
+    return B < cap ? B : (int)cap;
+}
+int janet_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    const int P = janet_layout(m->hidden).P;
+    const size_t lds = janet_gp_lds_bytes(P, a.T);
+    if (int e = allow_big_lds(janet_gp_train_kernel, lds)) return e;
+    hipLaunchKernelGGL(janet_gp_train_kernel, dim3(janet_gp_rows(m, a.B, a.T)), dim3(64), lds, st, a);
+    return (int)hipGetLastError();
+}
 int janet_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     if (janet_uses_s16(m, a.B)) return janet_s16_launch(st, m, a, 1);

@@ -204,6 +204,10 @@ __host__ __device__ inline JanetLayout janet_layout(int H) {
 int janet_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int janet_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int janet_family_rows(const odpd_model_t* m, int B);
+// gate-parallel fused train kernel of PGJANET at the reference's batch sizes (janet_family.hip)
+bool janet_train_uses_gp(const odpd_model_t* m, int B, int T);
+int janet_gp_rows(const odpd_model_t* m, int B, int T);
+int janet_gp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // 16-sequences-per-wave split kernels of PGJANET (janet_s16.hip): mode 1 forward, 2 backward
 bool janet_uses_s16(const odpd_model_t* m, int B);
 int janet_s16_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);

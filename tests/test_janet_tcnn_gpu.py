@@ -179,3 +179,55 @@ def test_pgjanet_evaluation_kernel_matches_the_oracle(H, B, T):
     assert np.array_equal(y_eval, y_ckpt)
     assert rel_err(y_eval, y_train) < 5e-6
     assert H == 1 or not np.array_equal(y_eval, y_train)          # two kernels: g's pre-activation is summed in a different order
+
+
+@pytest.mark.parametrize("H", [1, 5, 11, 16])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (7, 63), (5, 64), (2, 65), (64, 50), (9, 200), (300, 200), (5, 130)])
+def test_pgjanet_gate_parallel_train_kernel(H, B, T):
+    """the reference's own batch sizes run janet_gp_train_kernel (one sequence per wave; two forward and two transposed rounds of one rotated
+    dot product per row, the step's seven weight gradients as two 4-block MFMAs; fc_out, loss and dL/dy with lane = time step): loss and
+    gradient against the oracle (L2 and L1), and against the split forward / loss / backward kernels (odpd_set_tuning gp_max_batch = 0)"""
+    import ctypes as C
+    from opendpd_amd import CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    lib = _lib.load()
+    torch.manual_seed(H * 100 + B + T)
+    net = CoreModel(2, H, 1, "pgjanet").cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    rng = np.random.RandomState(B * 13 + T)
+    amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    tgt = (0.4 * rng.randn(B, T, 2)).astype(np.float32)
+    xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    o, m = Oracle("f32"), make_model("pgjanet", H)
+    yo, _ = o.forward(m, p, x)
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.has_fused(B, T)
+    try:
+        for kind in ("l2", "l1"):
+            d = yo - tgt
+            lo = float((d * d).mean()) if kind == "l2" else float(np.abs(d).mean())
+            dy = (2 * d / d.size if kind == "l2" else np.sign(d) / d.size).astype(np.float32)
+            go, _ = o.backward(m, p, x, dy, need_dx=False)
+            loss = fused_train_step(opt, xt, tt, kind, 0.0)
+            got = opt.grad[:-4].cpu().numpy().copy()
+            assert abs(float(loss) - lo) < 2e-5 * max(1.0, lo)
+            assert rel_err(got, go) < GRAD_TOL
+            lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(0))
+            opt2 = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+            assert not opt2.has_fused(B, T)
+            for q in net.parameters():
+                q.grad = None
+            y = net(xt)
+            l2 = torch.nn.functional.mse_loss(y, tt) if kind == "l2" else torch.nn.functional.l1_loss(y, tt)
+            l2.backward()
+            gs = torch.cat([q.grad.reshape(-1) for q in net.parameters()]).cpu().numpy()
+            assert abs(float(loss) - l2.item()) < 1e-5 * max(1.0, lo) and rel_err(got, gs) < 2e-5
+            lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
+    finally:
+        lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
