@@ -64,7 +64,9 @@ for bb, H, kw in CASES:
         with torch.no_grad():
             msf = timeit(lambda: net(x), 21 if B <= 1024 else 7)
         cells += [ms, B * T / ms / 1e3, msf, B * T / msf / 1e3]
-    kind = "fused (1 launch)" if opt.has_fused(a.big, T) else "split (fwd, loss, bwd)"
+    f256, fbig = opt.has_fused(256, T), opt.has_fused(a.big, T)
+    kind = ("fused (1 launch)" if f256 and fbig else "split (fwd, loss, bwd)" if not (f256 or fbig)
+            else "fused at 256, split at the large batch" if f256 else "split at 256, fused at the large batch")
     rows.append((f"{bb} H{H}", P, kind, *cells))
 # train_dpd cascade of BASELINE config 3
 torch.manual_seed(0)
