@@ -209,6 +209,36 @@ def main():
         ref = {"batch_per_gpu": args.ref_batch, "value": world * args.ref_batch * T * max(args.steps, 50) / float(elr_t.item()),
                "ms_per_step": 1e3 * float(elr_t.item()) / max(args.steps, 50)}
 
+    # side figures of the reference's own shapes (latency regime, one sequence per wave): one evaluation pass over the APA_200MHz test
+    # segment (net_eval, train_funcs.py:57-90: (1, 19 662, 2)) and the train step of the other recurrent families at the reference batch
+    ref_shapes = None
+    if world == 1 and ref is not None and not args.materialized:
+        import time as _time
+        ref_shapes = {}
+        with torch.no_grad():
+            xe = xs_[:19662].reshape(1, 19662, 2).contiguous() if xs_.shape[0] >= 19662 else None
+            if xe is not None:
+                net2.eval()
+                for _ in range(3):
+                    net2(xe)
+                torch.cuda.synchronize()
+                t0_ = _time.perf_counter()
+                for _ in range(10):
+                    net2(xe)
+                torch.cuda.synchronize()
+                ms = (_time.perf_counter() - t0_) / 10 * 1e3
+                ref_shapes["eval_pass"] = {"workload": f"net_eval forward of DGRU H{H} on one (1, 19662, 2) segment", "ms": ms, "value": 19662 / ms * 1e3,
+                                           "unit": "IQ samples/s"}
+        xm = xs_.unfold(0, T, 1)[:args.ref_batch].permute(0, 2, 1).contiguous()
+        tm = ys_.unfold(0, T, 1)[:args.ref_batch].permute(0, 2, 1).contiguous()
+        steps_ = {}
+        for bb_, h_ in (("gru", 11), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11)):
+            torch.manual_seed(2)
+            opt_ = FusedAdamW(CoreModel(2, h_, 1, bb_).to(dev), lr=5e-4)
+            el_ = min(run_steps(opt_, xm, tm, 50, args.warmup, args.ref_batch * T * 2, None)[0] for _ in range(3))   # best of three: a one-off stall is 50 steps' worth here
+            steps_[f"{bb_} H{h_}"] = {"ms_per_step": 1e3 * el_ / 50, "value": args.ref_batch * T * 50 / el_}
+        ref_shapes["train_step"] = {"batch_per_gpu": args.ref_batch, "frame_length": T, "unit": "IQ samples/s", "backbones": steps_}
+
     # side figure: the train_dpd step (models.py:163-176) — the same 1k-parameter DGRU as the DPD in front of a frozen
     # DGRU PA model: DPD forward, PA forward, loss, PA backward (dL/du only), DPD backward, reduce, clip + AdamW
     dpd = None
@@ -265,6 +295,7 @@ def main():
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * B * T}},
             "reference_batch": ref,
+            "reference_shapes": ref_shapes,
             "train_dpd": dpd,
         }
         if world == 1 and not args.no_cpu_baseline:
