@@ -333,3 +333,41 @@ def test_evaluation_kernel_matches_the_oracle(bb, H, B, T):
     assert np.array_equal(y_eval, y_ckpt)
     assert rel_err(y_eval, y_train) < 5e-6
     assert H == 1 or not np.array_equal(y_eval, y_train)          # two kernels: different summation order of the recurrent sums
+
+
+@pytest.mark.parametrize("bb,H", [("gru", 13), ("dgru", 13), ("dgru", 23), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11)])
+def test_gate_parallel_train_kernels_loop_over_sequences(bb, H):
+    """more sequences than resident single-wave workgroups (1 100 frames of 300 samples, forced with gp_max_batch): a workgroup then runs
+    several sequences in turn, accumulating into the same partial-gradient row — same loss and gradient as the four-sequence-per-wave path"""
+    import ctypes as C
+    from opendpd_amd import CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    lib = _lib.load()
+    B, T = 1100, 300
+    torch.manual_seed(3)
+    net = CoreModel(2, H, 1, bb).cuda()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    t = torch.randn(B, T, 2, device="cuda", generator=g) * 0.3
+    got = {}
+    try:
+        for gp in (1 << 30, 0):
+            lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(gp))
+            opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+            if gp:
+                assert opt.has_fused(B, T)
+                rows = int(lib.odpd_partial_rows(C.byref(net.backbone.desc), B, T, 1))
+                assert 0 < rows < B                     # fewer workgroups than sequences
+                loss = fused_train_step(opt, x, t, "l2", 0.0)
+                got[gp] = (float(loss), opt.grad[:-4].cpu().numpy().copy())
+            else:
+                for q in net.parameters():
+                    q.grad = None
+                l2 = torch.nn.functional.mse_loss(net(x), t)
+                l2.backward()
+                got[gp] = (l2.item(), torch.cat([q.grad.reshape(-1) for q in net.parameters()]).cpu().numpy())
+    finally:
+        lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
+    assert abs(got[1 << 30][0] - got[0][0]) < 1e-5 * max(1.0, got[0][0])
+    assert rel_err(got[1 << 30][1], got[0][1]) < 2e-5
