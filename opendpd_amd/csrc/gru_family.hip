@@ -853,7 +853,6 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
 // LDS per wave: parameters + max(weight tables — read once into registers —, the per-time buffers: 8 + 16 (+ 16) + 2 floats per step).
 // One partial-gradient row per workgroup.
 // -------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int NB, bool DG>
 __host__ __device__ inline int gp_buffer_floats(int T, bool pg) {
     const int Tp = (T + 63) & ~63;

@@ -218,7 +218,6 @@ __global__ __launch_bounds__(64) void janet_eval_kernel(SeqArgs a) {
 //             MFMAs (v_mfma_f32_16x16x1_4b_f32): (d_f | d_g | d_g | d_f) x (u | u | h(t-1) | h(t-1)) and (d_a | d_p1 | d_p2 | 0) x h(t-1).
 // One partial-gradient row per workgroup.  Taken while the frame's parked state fits the CU's LDS share.
 // -------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 __host__ __device__ inline int janet_gp_buffer_floats(int T) {
     const int Tp = (T + 63) & ~63;
     const int buf = Tp * 4 + (Tp + 1) * 16 + Tp * 64 + Tp * 32 + Tp * 2 + 256 + 32;

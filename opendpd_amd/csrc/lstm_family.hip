@@ -388,7 +388,6 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
 //             gate k): (d_i | d_f | d_g | d_o) x h(t-1) and x (inputs | 1).  !PG recomputes the gates from the parked h(t-1).
 // One partial-gradient row per workgroup.
 // -------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <bool VD>
 __host__ __device__ inline int lstm_gp_buffer_floats(int T, bool pg) {
     const int Tp = (T + 63) & ~63;

@@ -21,6 +21,7 @@
 namespace odpd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));   // accumulator of the 4-block MFMA (v_mfma_f32_16x16x1_4b_f32)
 
 constexpr int kWave = 64;
 constexpr int kCkptStride = 4;   // S: recurrent state is checkpointed every S steps for BPTT
