@@ -40,9 +40,9 @@ def count_net_params(net):
 class DeviceFrameLoader:
     """Iterates (features, targets) batches of frames gathered ON DEVICE from the resident I/Q streams (no
     materialised frame tensor: a frame is a start offset into the stream, data_collector.py:239-247).
-    The epoch's frame order comes from ONE pass of a torch DataLoader over range(n) with shuffle=True, i.e. exactly
+    The epoch's frame order is what ONE pass of a torch DataLoader over range(n) with shuffle=True yields, with exactly
     the global-RNG consumption (base seed + sampler seed) and permutation of the reference's
-    DataLoader(train_set, shuffle=True) (project.py:236); each step is then two index_select launches on an
+    DataLoader(train_set, shuffle=True) (project.py:236) — tests/test_api_cpu.py compares it with a real DataLoader; each step is then two index_select launches on an
     overlapping-window view of the stream and no host<->device traffic."""
 
     def __init__(self, x, y, frame_length, stride, batch_size, device, shuffle=True):
@@ -52,15 +52,22 @@ class DeviceFrameLoader:
         self.batch_size, self.device, self.frame_length, self.stride = batch_size, device, frame_length, stride
         win = lambda s: torch.as_strided(s, (self.n, frame_length, 2), (2 * stride, 2, 1))
         self.fx, self.fy = win(self.x), win(self.y)
-        self.order_loader = DataLoader(range(self.n), batch_size=self.n, shuffle=shuffle)
+        self.shuffle = shuffle
 
     def __len__(self):
         return (self.n + self.batch_size - 1) // self.batch_size
 
     def epoch_order(self):
         """Frame indices of one epoch in visiting order (device int64); one call == one pass of the reference DataLoader."""
-        (order,) = list(self.order_loader)
-        return order.to(self.device)
+        # What one pass of DataLoader(range(n), shuffle=...) does to the global RNG and yields, without iterating n Python ints:
+        # the iterator draws its base seed (dataloader.py _BaseDataLoaderIter.__init__), RandomSampler then draws the seed of a
+        # private generator and yields torch.randperm(n, generator) (sampler.py RandomSampler.__iter__, num_samples == n)
+        torch.empty((), dtype=torch.int64).random_()
+        if not self.shuffle:
+            return torch.arange(self.n, device=self.device)
+        g = torch.Generator()
+        g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        return torch.randperm(self.n, generator=g).to(self.device)
 
     def __iter__(self):
         order = self.epoch_order()

@@ -68,6 +68,19 @@ def test_device_frame_loader_matches_reference_dataloader_order():
     torch.manual_seed(0)
     list(DeviceFrameLoader(x, y, 50, 1, 64, torch.device("cpu"), shuffle=True)); r2 = torch.rand(1)
     assert torch.equal(r1, r2)
+    # three consecutive epochs, and the unshuffled loader (whose iterator still draws its base seed)
+    for shuffle in (True, False):
+        torch.manual_seed(5)
+        dl = DataLoader(IQFrameDataset(x, y, 50, 1), batch_size=64, shuffle=shuffle)
+        ref = [[a.clone() for a, _ in dl] for _ in range(3)]
+        r1 = torch.rand(1)
+        torch.manual_seed(5)
+        mine = DeviceFrameLoader(x, y, 50, 1, 64, torch.device("cpu"), shuffle=shuffle)
+        ours = [[a.clone() for a, _ in mine] for _ in range(3)]
+        r2 = torch.rand(1)
+        assert torch.equal(r1, r2)
+        for ea, eb in zip(ref, ours):
+            assert len(ea) == len(eb) and all(torch.equal(a, b) for a, b in zip(ea, eb))
 
 
 def test_without_a_hip_device_every_accelerator_is_refused():
