@@ -1,3 +1,6 @@
+// Probe of the register layout of v_mfma_f32_16x16x1_4b_f32 (the 4-block MFMA behind the gate-parallel train kernels' weight gradients):
+// block k multiplies lanes 16k..16k+15 of A and B; register 4 k + r of lane l = A[16 k + 4 (l / 16) + r] * B[16 k + l % 16].
+// build + run on the GPU box: hipcc --offload-arch=gfx950 -O2 tools/probes/mfma_16x16x1_4b_layout.hip -o /tmp/probe && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
