@@ -160,6 +160,8 @@ typedef struct odpd_frames {
 /* 1 when the model's fused train kernel can address frames inside resident streams (GRU family, GMP), else 0: the two entry
  * points below return ODPD_EUNSUPPORTED for the others (materialise the batch and call odpd_train_fwd_bwd). */
 int odpd_framed_train_supported(const odpd_model_t* m);
+/* the same question for one batch shape: also 1 for lstm / vdlstm / pgjanet where their one-sequence-per-wave fused kernels serve (B, T) */
+int odpd_framed_train_supported_shape(const odpd_model_t* m, int B, int T);
 /* odpd_train_fwd_bwd with the batch given as frames order[first .. first+B) of resident streams (no materialised
  * (B,T,2) tensors).  Same outputs; the caller finishes the step (odpd_reduce_partials, all-reduce, odpd_clip_adamw_step). */
 int odpd_train_fwd_bwd_framed(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int64_t first,

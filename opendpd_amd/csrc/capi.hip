@@ -74,7 +74,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 4; }   // 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17
+extern "C" int odpd_abi_version(void) { return 5; }   // 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
@@ -262,15 +262,27 @@ namespace {
 inline bool framed_train_ok(const odpd_model_t* m) {
     return family_of(m) == FAM_GRU || family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN;
 }
+// ... for this batch shape: also the one-sequence-per-wave fused kernels of lstm / vdlstm / pgjanet (their large-batch kernels take tensors)
+inline bool framed_train_ok_shape(const odpd_model_t* m, int B, int T) {
+    if (framed_train_ok(m)) return true;
+    if (family_of(m) == FAM_LSTM) return !lstm_train_uses_s16(m, B) && lstm_train_uses_gp(m, B, T);
+    if (family_of(m) == FAM_JANET) return janet_train_uses_gp(m, B, T);
+    return false;
+}
 inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (family_of(m) == FAM_GMP) return gmp_train(st, m, a);
     if (family_of(m) == FAM_RVTDCNN) return rvtdcnn_train(st, m, a);
+    if (family_of(m) == FAM_LSTM) return framed_train_ok_shape(m, a.B, a.T) ? lstm_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_JANET) return framed_train_ok_shape(m, a.B, a.T) ? janet_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     const bool s16n = gru_uses_s16n(m, a.B), s16 = !s16n && gru_train_uses_s16(m, a.B, a.T);
     if ((s16 || s16n) && !a.ckpt) return ODPD_EINVAL;
     return s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));
 }
 }  // namespace
 extern "C" int odpd_framed_train_supported(const odpd_model_t* m) { return model_ok(m) && framed_train_ok(m) ? 1 : 0; }
+extern "C" int odpd_framed_train_supported_shape(const odpd_model_t* m, int B, int T) {
+    return model_ok(m) && B > 0 && T > 0 && framed_train_ok_shape(m, B, T) ? 1 : 0;
+}
 
 // odpd_train_fwd_bwd on frames addressed inside resident streams (no materialised (B,T,2) tensors): batch = the B frames
 // fr->order[first .. first+B).  The caller finishes the step as usual (reduce, all-reduce when sharded, clip + AdamW).
@@ -280,8 +292,8 @@ extern "C" int odpd_train_fwd_bwd_framed(void* stream, const odpd_model_t* m, in
     if (!model_ok(m) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->frame_length <= 0 || fr->stride <= 0 ||
         first < 0 || B <= 0 || first + B > fr->n_frames || count <= 0 || !params || !partials)
         return ODPD_EINVAL;
-    if (!framed_train_ok(m)) return ODPD_EUNSUPPORTED;
     const int T = fr->frame_length;
+    if (!framed_train_ok_shape(m, B, T)) return ODPD_EUNSUPPORTED;
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = fr->x_stream; a.target = fr->y_stream; a.partials = partials; a.ckpt = workspace;
     a.frame_idx = (const long long*)(fr->order + first); a.frame_stride = fr->stride;
@@ -300,8 +312,13 @@ static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, 
     if (!model_ok(m) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
         fr->stride <= 0 || batch <= 0 || !params || !grad || !state1 || !state2 || !partials || !losses_out || first_step <= 0)
         return ODPD_EINVAL;
-    if (!framed_train_ok(m)) return ODPD_EUNSUPPORTED;
     const int T = fr->frame_length;
+    {   // every batch of the epoch (the full ones and the tail) must have a frame-reading fused kernel
+        const int64_t tail = fr->n_frames % batch;
+        if (!framed_train_ok_shape(m, (int)(fr->n_frames < batch ? fr->n_frames : batch), T) ||
+            (tail && !framed_train_ok_shape(m, (int)tail, T)))
+            return ODPD_EUNSUPPORTED;
+    }
     const int64_t P = odpd_param_count(m);
     hipStream_t st = (hipStream_t)stream;
     int64_t step = first_step;

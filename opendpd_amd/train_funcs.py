@@ -209,12 +209,19 @@ class FusedAdamW:
         """True when odpd_train_epoch can drive a whole epoch: single fused backbone, one process, resident streams."""
         return (self.pa is None and self.world_size() == 1 and getattr(self.backbone, "frozen_mask", None) is None
                 and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size"))
-                and loader.x.is_cuda and self.has_fused(min(loader.batch_size, loader.n), loader.frame_length)
-                and self.reads_frames())
+                and loader.x.is_cuda and all(self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length)
+                                             for b in self._epoch_batches(loader)))
 
-    def reads_frames(self):
-        """True when the backbone's fused kernel addresses frames inside resident streams (odpd_framed_train_supported)."""
-        return bool(_lib.load().odpd_framed_train_supported(C.byref(self.backbone.desc)))
+    @staticmethod
+    def _epoch_batches(loader):
+        """the batch sizes of one epoch: the full batches and the tail"""
+        B = min(loader.batch_size, loader.n)
+        return {B, loader.n - (loader.n - 1) // B * B}
+
+    def reads_frames(self, B, T):
+        """True when the backbone's fused kernel for this batch shape addresses frames inside resident streams
+        (odpd_framed_train_supported_shape)."""
+        return bool(_lib.load().odpd_framed_train_supported_shape(C.byref(self.backbone.desc), B, T))
 
     def train_epoch(self, loader, loss_kind, max_norm):
         """One epoch through the native loop (odpd_train_epoch): returns the per-batch mean losses (device tensor)."""
@@ -312,8 +319,9 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     n = B * T * 2
     count = int(global_count or n)
     framed = isinstance(x, FrameBatch)
-    if framed and (opt.pa is not None or not opt.has_fused(B, T) or not opt.reads_frames()):
-        raise RuntimeError("FrameBatch input needs a single backbone whose fused kernel reads frames from streams (GRU family, gmp)")
+    if framed and (opt.pa is not None or not opt.has_fused(B, T) or not opt.reads_frames(B, T)):
+        raise RuntimeError("FrameBatch input needs a single backbone whose fused kernel for this batch shape reads frames from streams "
+                           "(GRU family, gmp, rvtdcnn; lstm / vdlstm / pgjanet at the reference's batch sizes)")
     if opt.pa is not None or not opt.has_fused(B, T):
         return _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count)
     part = opt.partials(B, T, x.device)

@@ -101,7 +101,7 @@ def test_c_abi_direct_and_errors():
     """Calls the C ABI without the nn.Module layer; bad arguments return error codes."""
     from opendpd_amd import _lib
     lib = _lib.load()
-    assert lib.odpd_abi_version() == 4 and lib.odpd_built_arch() == b"gfx950"
+    assert lib.odpd_abi_version() == 5 and lib.odpd_built_arch() == b"gfx950"
     d = _lib.ModelDesc(_lib.BACKBONE_IDS["gru"], 11, 0.0, 0.0, 0, 0, 0)
     P = lib.odpd_param_count(C.byref(d))
     assert P == 519
@@ -224,7 +224,8 @@ def test_fused_step_is_bit_repeatable():
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("bb,H,B,T,stride", [("dgru", 13, 300, 64, 1), ("gru", 23, 50, 33, 3), ("qgru", 10, 7, 200, 2)])
+@pytest.mark.parametrize("bb,H,B,T,stride", [("dgru", 13, 300, 64, 1), ("gru", 23, 50, 33, 3), ("qgru", 10, 7, 200, 2), ("lstm", 14, 300, 64, 1),
+                                             ("vdlstm", 13, 50, 33, 3), ("pgjanet", 11, 7, 200, 2)])
 def test_fused_step_on_frames_addressed_in_place(bb, H, B, T, stride):
     """FrameBatch (frames = windows of resident streams, odpd_train_fwd_bwd_framed) == the same frames materialised as
     (B,T,2) tensors: bit-identical parameters after three steps."""

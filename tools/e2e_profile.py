@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-side profile of a train_pa run through opendpd_amd.api (where does an epoch's wall-clock go once the
-kernels are fast?).  usage (GPU box): python tools/e2e_profile.py [epochs]"""
+kernels are fast?).  usage (GPU box): [E2E_BACKBONE=lstm E2E_HIDDEN=14] python tools/e2e_profile.py [epochs]"""
 import cProfile, io, os, pstats, sys, tempfile, time
 import numpy as np, pandas as pd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,8 @@ for k, v in d.items():
 os.environ["OPENDPD_DATASETS"] = os.path.join(wd, "datasets")
 import opendpd_amd as od
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-kw = dict(dataset_name="DPA_200MHz", PA_backbone="dgru", PA_hidden_size=13, frame_length=50, batch_size=64, lr=1e-3, seed=0, accelerator="cuda")
+kw = dict(dataset_name="DPA_200MHz", PA_backbone=os.environ.get("E2E_BACKBONE", "dgru"), PA_hidden_size=int(os.environ.get("E2E_HIDDEN", "13")), frame_length=50,
+          batch_size=64, lr=1e-3, seed=0, accelerator="cuda")
 od.train_pa(n_epochs=1, **kw)   # warm-up: library load, first-touch
 pr = cProfile.Profile()
 t0 = time.time(); pr.enable()
