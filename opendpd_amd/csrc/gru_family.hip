@@ -22,6 +22,10 @@
 //                     one row of partial gradients per workgroup, fixed summation order.
 //   gru_train_kernel  forward (cell only) + backward with y / loss / dL/dy formed on the fly:
 //                     HBM traffic = x + target.
+// One-sequence-per-wave ("gate-parallel") kernels for batches whose sequences each get a SIMD of their own (the reference's 64 .. 256
+// frames, the evaluation segments): the four 16-lane rows of a wave take one gate each, only the recurrence stays in the step loop:
+//   gru_eval_kernel      forward (inference; CK: also the checkpoint-writing forward of the split train path)
+//   gru_gp_train_kernel  fused train step with the frame's BPTT state in LDS and the weight gradients as 4-block MFMAs
 #include "odpd_s16.h"
 
 namespace odpd {
