@@ -207,6 +207,18 @@ int odpd_train_epoch_opt(void* stream, const odpd_model_t* m, int loss_kind, con
                          float* params, float* grad, float* state1, float* state2, int64_t first_step, double lr, double max_norm,
                          float* partials, float* workspace, float* losses_out);
 
+/* The epoch loop for a backbone WITHOUT a fused train kernel at this batch shape: per step the frames are gathered into (B,T,2)
+ * buffers, then odpd_backbone_fwd, odpd_loss_fwd_bwd, odpd_backbone_bwd, odpd_reduce_partials and the optimiser (opt_kind < 0: AdamW
+ * with the given hyper-parameters, else an enum odpd_optimizer kind; `skip` as in odpd_clip_adamw_step_masked, nullable) run back to
+ * back from C++ — the same launches as the caller-driven chain, without the caller between them.  Buffers (device): xbuf, tbuf, ybuf,
+ * dybuf = batch*T*2 floats; ckpt = odpd_ckpt_floats; partials = odpd_partial_rows(m, B, T, 0) rows (largest of the full and the
+ * tail batch); loss_scratch = 1 + 256 floats; stats = the delta backbones' counters (nullable); losses_out[i] = mean loss of batch i. */
+int odpd_train_epoch_split(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, int opt_kind,
+                           float* params, float* grad, float* state1, float* state2, int64_t first_step, double lr, double beta1,
+                           double beta2, double eps, double weight_decay, double max_norm, const unsigned char* skip,
+                           float* xbuf, float* tbuf, float* ybuf, float* dybuf, float* ckpt, float* partials, float* loss_scratch,
+                           double* stats, float* losses_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,10 @@ _EXPORTS = {
                                               C.c_void_p, C.c_void_p]),
     "odpd_train_epoch_opt": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "odpd_train_epoch_split": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
     "odpd_clip_optim_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
 }

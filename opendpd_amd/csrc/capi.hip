@@ -74,7 +74,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 5; }   // 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape
+extern "C" int odpd_abi_version(void) { return 6; }   // 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
@@ -338,6 +338,62 @@ static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, 
         rc = opt_kind < 0 ? launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
                                               losses_out + i, a.inv_count)
                           : launch_clip_optim(st, opt_kind, P, params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, a.inv_count);
+        if (rc) return rc;
+    }
+    return 0;
+}
+// ---- native epoch loop for backbones without a fused train kernel at this shape (the split chain of train_funcs.py:33-44) ----------
+namespace {
+// frames order[f0 .. f0 + B) of the two streams gathered into (B,T,2) tensors (what IQFrameDataset + the DataLoader's collate build)
+__global__ void gather_frames_kernel(const float2* __restrict__ xs, const float2* __restrict__ ys, const long long* __restrict__ order,
+                                     int stride, int B, int T, float2* __restrict__ xo, float2* __restrict__ yo) {
+    const long long n = (long long)B * T;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / T), t = (int)(i % T);
+        const long long src = order[b] * stride + t;
+        xo[i] = xs[src]; yo[i] = ys[src];
+    }
+}
+// grad[P] = mean loss * count: the loss travels with the gradient (column P) exactly as in the Python-driven step
+__global__ void loss_sum_kernel(float* grad_p, const float* loss_mean, float count) { grad_p[0] = loss_mean[0] * count; }
+}  // namespace
+extern "C" int odpd_train_epoch_split(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, int opt_kind,
+                                      float* params, float* grad, float* state1, float* state2, int64_t first_step, double lr, double beta1,
+                                      double beta2, double eps, double weight_decay, double max_norm, const unsigned char* skip,
+                                      float* xbuf, float* tbuf, float* ybuf, float* dybuf, float* ckpt, float* partials, float* loss_scratch,
+                                      double* stats, float* losses_out) {
+    if (!model_ok(m) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
+        fr->stride <= 0 || batch <= 0 || !params || !grad || !state1 || !state2 || !xbuf || !tbuf || !ybuf || !dybuf || !partials ||
+        !loss_scratch || !losses_out || first_step <= 0 || opt_kind > ODPD_OPT_RMSPROP)
+        return ODPD_EINVAL;
+    const int T = fr->frame_length;
+    const int64_t P = odpd_param_count(m);
+    if (P <= 0) return P < 0 ? (int)P : ODPD_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t step = first_step;
+    for (int64_t f0 = 0, i = 0; f0 < fr->n_frames; f0 += batch, ++i, ++step) {
+        const int B = (int)((fr->n_frames - f0) < batch ? (fr->n_frames - f0) : batch);
+        const int64_t rows = odpd_partial_rows(m, B, T, 0), n = (int64_t)B * T * 2;
+        if (rows <= 0) return rows < 0 ? (int)rows : ODPD_EUNSUPPORTED;
+        const long long work = (long long)B * T;
+        const int grid = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
+        hipLaunchKernelGGL(gather_frames_kernel, dim3(grid), dim3(256), 0, st, (const float2*)fr->x_stream, (const float2*)fr->y_stream,
+                           (const long long*)(fr->order + f0), fr->stride, B, T, (float2*)xbuf, (float2*)tbuf);
+        int rc = (int)hipGetLastError();
+        if (rc) return rc;
+        rc = odpd_backbone_fwd(stream, m, B, T, params, xbuf, ybuf, ckpt, stats);
+        if (rc) return rc;
+        rc = odpd_loss_fwd_bwd(stream, loss_kind, n, n, ybuf, tbuf, dybuf, loss_scratch);
+        if (rc) return rc;
+        rc = odpd_backbone_bwd(stream, m, B, T, params, xbuf, dybuf, ckpt, partials, nullptr);
+        if (rc) return rc;
+        rc = odpd_reduce_partials(stream, rows, P, partials, grad, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1), 0, st, grad + P, loss_scratch, (float)n);
+        const float inv = (float)(1.0 / (double)n);
+        rc = opt_kind < 0 ? launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
+                                              losses_out + i, inv, skip)
+                          : launch_clip_optim(st, opt_kind, P, params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, inv, skip);
         if (rc) return rc;
     }
     return 0;

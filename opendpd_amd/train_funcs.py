@@ -223,6 +223,57 @@ class FusedAdamW:
         (odpd_framed_train_supported_shape)."""
         return bool(_lib.load().odpd_framed_train_supported_shape(C.byref(self.backbone.desc), B, T))
 
+    def can_run_split_epoch(self, loader):
+        """True when odpd_train_epoch_split can drive a whole epoch: a single backbone WITHOUT a frame-reading fused kernel for the
+        epoch's batch shapes, one process, resident streams (the forward / loss / backward / reduce / optimiser chain per step then
+        runs from C++ instead of from Python)."""
+        return (self.pa is None and self.world_size() == 1 and not self.can_run_epoch(loader)
+                and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size"))
+                and loader.x.is_cuda and hasattr(self.backbone, "desc"))
+
+    def train_epoch_split(self, loader, loss_kind, max_norm):
+        """One epoch through odpd_train_epoch_split: returns the per-batch mean losses (device tensor)."""
+        lib = _lib.load()
+        bb = self.backbone
+        dev, T, n = loader.x.device, loader.frame_length, loader.n
+        B = min(loader.batch_size, n)
+        self._ensure(dev)
+        n_steps = (n + B - 1) // B
+        last = n - (n_steps - 1) * B
+        if bb.dx_needs_flag:               # as _cascade_train_step: the trained model is never asked for dL/dx here
+            bb.desc.flags &= ~_lib.FLAG_NEED_DX
+        if hasattr(bb, "sync_mode"):
+            bb.sync_mode()
+        key = (B, T, last, "split-epoch")
+        if key not in self._partials:
+            rows = [int(lib.odpd_partial_rows(C.byref(bb.desc), b, T, 0)) for b in {B, last}]
+            _lib.check(0 if min(rows) > 0 else min(rows), "odpd_partial_rows")
+            mk = lambda: torch.empty(B, T, 2, dtype=torch.float32, device=dev)
+            self._partials[key] = (torch.empty(max(rows), bb.n_flat + _lib.LOSS_COLS, dtype=torch.float32, device=dev), mk(), mk())
+        part, xbuf, tbuf = self._partials[key]
+        buf = self.cascade_buffers(B, T, dev)
+        order = loader.epoch_order()
+        losses = torch.empty(n_steps, dtype=torch.float32, device=dev)
+        fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
+        g = self.param_groups[0]
+        flat = bb.flat_params(full_check=True)
+        frozen = getattr(bb, "frozen_mask", None)
+        if frozen is not None and (frozen.device != flat.device or frozen.dtype != torch.uint8):
+            bb.frozen_mask = frozen = frozen.to(device=flat.device, dtype=torch.uint8).contiguous()
+        adamw = self.kind == "adamw"
+        rc = lib.odpd_train_epoch_split(_lib.stream_ptr(), C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
+                                        -1 if adamw else _lib.OPTIMIZER_IDS[self.kind], _lib.ptr(flat), _lib.ptr(self.grad),
+                                        _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.step_count + 1, float(g["lr"]),
+                                        float(g["betas"][0]) if adamw else 0.0, float(g["betas"][1]) if adamw else 0.0,
+                                        float(g["eps"]) if adamw else 0.0, float(g["weight_decay"]) if adamw else 0.0,
+                                        float(max_norm or 0.0), _lib.ptr(frozen) if frozen is not None else None,
+                                        _lib.ptr(xbuf), _lib.ptr(tbuf), _lib.ptr(buf["u"]), _lib.ptr(buf["dy"]), _lib.ptr(buf["ck_d"]),
+                                        _lib.ptr(part), _lib.ptr(buf["loss"]), _lib.ptr(bb._stats_buffer(dev)), _lib.ptr(losses))
+        _lib.check(rc, "odpd_train_epoch_split")
+        self.step_count += n_steps
+        self._keepalive = order     # the launches read `order` asynchronously
+        return losses
+
     def train_epoch(self, loader, loss_kind, max_norm):
         """One epoch through the native loop (odpd_train_epoch): returns the per-batch mean losses (device tensor)."""
         lib = _lib.load()
@@ -413,6 +464,11 @@ def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device)
     if fast and optimizer.can_run_epoch(dataloader):
         # whole epoch in the native loop: frames read in place from the resident streams, 3 launches per step, no Python
         losses = optimizer.train_epoch(dataloader, kind, grad_clip_val)
+        log["loss"] = float(losses.double().mean().item()) if losses.numel() else float("nan")
+        return net
+    if fast and optimizer.can_run_split_epoch(dataloader):
+        # no fused kernel for these batch shapes: the split chain of every step, issued from the native loop as well
+        losses = optimizer.train_epoch_split(dataloader, kind, grad_clip_val)
         log["loss"] = float(losses.double().mean().item()) if losses.numel() else float("nan")
         return net
     world = optimizer.world_size() if isinstance(optimizer, FusedAdamW) else 1

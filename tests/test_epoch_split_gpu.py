@@ -1,0 +1,57 @@
+"""The native epoch loop of the backbones without a fused train kernel (odpd_train_epoch_split): the same launches as the
+Python-driven chain of fused_train_step — forward, loss, backward, reduce, clip + optimiser per step — issued from C++."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(bb, H, kw):
+    from opendpd_amd import CoreModel
+    torch.manual_seed(3)
+    if bb.endswith(":qat"):           # the W8A8 quantisation-aware cell (frozen 16-bit output scales: masked optimiser step)
+        from types import SimpleNamespace
+        from opendpd_amd.quant import get_quant_model
+        net = get_quant_model(SimpleNamespace(quant=True, n_bits_w=8, n_bits_a=8, pretrained_model=""), CoreModel(2, H, 1, bb[:-4]))
+        return net.cuda().train()
+    return CoreModel(2, H, 1, bb, **kw).cuda()
+
+
+@pytest.mark.parametrize("bb,H,kw", [("deltagru", 15, dict(thx=0.01, thh=0.05)), ("deltagru_tcnskip", 9, dict(thx=0.02, thh=0.02)), ("tcnn", 12, {}),
+                                     ("neuraltx", 8, {}), ("deltajanet", 7, {}), ("mcldnn", 4, {}), ("qgru:qat", 10, {}), ("qgru_amp1:qat", 6, {})])
+@pytest.mark.parametrize("opt_kind", ["adamw", "sgd"])
+def test_split_epoch_loop_equals_the_python_driven_steps(bb, H, kw, opt_kind):
+    from opendpd_amd.project import DeviceFrameLoader
+    from opendpd_amd.train_funcs import FusedAdamW, FusedSGD, fused_train_step
+    rng = np.random.RandomState(5)
+    n_s, T, B = 700, 24, 64
+    amp, ph = 0.05 + 0.85 * rng.rand(n_s), 2 * np.pi * rng.rand(n_s)
+    x = np.stack([amp * np.cos(ph), amp * np.sin(ph)], -1)
+    y = 0.7 * x + 0.05 * rng.randn(n_s, 2)
+    dev = torch.device("cuda")
+    results = []
+    for native in (True, False):
+        net = _net(bb, H, kw)
+        opt = (FusedAdamW if opt_kind == "adamw" else FusedSGD)(net, lr=2e-3)
+        loader = DeviceFrameLoader(x, y, T, 1, B, dev, shuffle=True)
+        if hasattr(net.backbone, "set_debug"):
+            net.backbone.set_debug(1)
+        torch.manual_seed(11)
+        if native:
+            assert opt.can_run_split_epoch(loader) and not opt.can_run_epoch(loader)
+            losses = [opt.train_epoch_split(loader, "l2", 200.0) for _ in range(2)]
+            losses = torch.cat(losses)
+        else:
+            losses = []
+            for _ in range(2):
+                for fx, fy in loader:
+                    losses.append(fused_train_step(opt, fx.contiguous(), fy.contiguous(), "l2", 200.0))
+            losses = torch.stack(losses)
+        stats = dict(net.backbone.statistics) if hasattr(net.backbone, "set_debug") else None
+        results.append((net.backbone.flat_params().clone(), losses.cpu().numpy(), opt.step_count, stats))
+    (pa, la, sa, sta), (pb, lb, sb, stb) = results
+    assert sa == sb == 2 * ((n_s - T + 1 + B - 1) // B)
+    assert torch.equal(pa, pb)
+    assert np.allclose(la, lb, rtol=1e-6, atol=0)
+    assert sta == stb
