@@ -135,7 +135,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
         if (fused) return lstm_train_uses_s16(m, B) ? (int64_t)lstm_s16_rows(m, B)
                                                     : lstm_train_uses_gp(m, B, T) ? (int64_t)lstm_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return lstm_family_rows(m, B);
-    case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B);
+    case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B, T);
     case FAM_JANET:
         if (fused) return janet_train_uses_gp(m, B, T) ? (int64_t)janet_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return janet_family_rows(m, B);

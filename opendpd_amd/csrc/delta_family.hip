@@ -16,9 +16,14 @@
 // parameter-gradient path needs the dh/h_p chain only.  dL/dx (delta model as the frozen PA, x.requires_grad) is provided by
 // the S16 kernels of delta_s16.hip, which ODPD_FLAG_NEED_DX selects at every batch size.  One 16-lane row per sequence: H <= 16.
 #include "odpd_seq.h"
+#include "odpd_s16.h"
 
 namespace odpd {
 
+__device__ __forceinline__ float wave_sum_(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 constexpr int kDHalo = 16;                                  // TCN taps at t-16, t, t+16
 constexpr int kDStride = kChunk + 2 * kDHalo + 1;           // float2 per sequence row
 constexpr int kDTabFloats = 6 * 4 * 64 * 4;                 // W_hh (3 rows) + W_hh^T (3 rows)
@@ -625,6 +630,240 @@ __global__ __launch_bounds__(kMaxThreads / 2, 1) void delta_bwd_kernel(SeqArgs a
 }
 
 // -------------------------------------------------------------------------------------------------
+// Gate-parallel backward kernel for the reference's own batch sizes (the split train path — train_pa of a delta backbone, the DPD half of a
+// train_dpd step — where a wave is alone on its SIMD): ONE sequence per wave (one wave per workgroup), hidden <= 16.  It runs the forward
+// pass of delta_eval_kernel again, parking in LDS what the backward step needs of every step — (r, z, n, dm_nh), the masked dh and its mask,
+// h(t), the six masked dx — instead of reading checkpoints; dL/dy and the TRes TCN gradient (no state in it) are taken with lane = time
+// step; then per step ONE rotated dot product with the transposed weights (rows r | z | n multiply their own accumulator gradient, the
+// cross-row sum is the gradient to the masked dh) and TWO 4-block MFMAs: (G_r | G_z | G_nh | -) x masked dh and (G_r | G_z | G_n | -) x masked dx.
+// Same arithmetic per element as delta_bwd_block.  One partial-gradient row per workgroup; weight gradients only (dL/dx lives in delta_s16.hip).
+// -------------------------------------------------------------------------------------------------
+__host__ __device__ inline int delta_gp_buffer_floats(int T) {
+    const int Tp = (T + 63) & ~63;
+    const int buf = Tp * 8 + (Tp + 1) * 16 + Tp * 64 + Tp * 32 + Tp * 8 + Tp * 2 + 256;
+    return buf > kDTabFloats ? buf : kDTabFloats;
+}
+template <bool TRES>
+__global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // r | z | n | -
+    const DeltaLayout L = delta_layout(a.H, TRES);
+    const int H = L.H, T = a.T, Tp = (T + 63) & ~63;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    fill_delta_tabs<true>(tab, pl, L, lane, 0, 1);
+    const bool vo = col < H, gate_row = role < 3;
+    float wrec[16], wT[16], wih[6];
+    {
+        TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+        load_rot(wrec, tl + (gate_row ? role : 0) * 4 * 64);
+        load_rot(wT, tl + (3 + (gate_row ? role : 0)) * 4 * 64);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { wrec[k] = gate_row ? wrec[k] : 0.0f; wT[k] = gate_row ? wT[k] : 0.0f; }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wih[i] = (vo && gate_row) ? pl[L.o_w_ih + (role * H + col) * 6 + i] : 0.0f;
+    float accx0 = 0.0f, acch0 = 0.0f;
+    if (!TRES && vo) {
+        if (role < 2) accx0 = pl[L.o_b_ih + role * H + col] + pl[L.o_b_hh + role * H + col];
+        if (role == 2) { accx0 = pl[L.o_b_ih + 2 * H + col]; acch0 = pl[L.o_b_hh + 2 * H + col]; }
+    }
+    const int fc = col < 6 ? col : 5;
+    const float wo0 = vo ? pl[L.o_w_out + col] : 0.0f, wo1 = vo ? pl[L.o_w_out + H + col] : 0.0f;
+    float w1[3][6], w2[2][3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w1[ch][k] = TRES ? pl[L.o_tcn0 + ch * 6 + k] : 0.0f;
+#pragma unroll
+        for (int oo = 0; oo < 2; ++oo) w2[oo][ch] = TRES ? pl[L.o_tcn2 + oo * 3 + ch] : 0.0f;
+    }
+    const float thx = a.thx, thh = a.thh;
+    wave_lds_fence();
+    // per-time buffers over the tables
+    float* feat = tab;                                  // [Tp][8]   f0..f5 of step t
+    float* hist = feat + Tp * 8;                        // [Tp + 1][16]   entry t + 1 = h(t), entry 0 = 0
+    float* gpk = hist + (Tp + 1) * 16;                  // [Tp][16][4]   r, z, n, dm_nh of step t
+    float* dm2 = gpk + Tp * 64;                         // [Tp][16][2]   masked dh, its mask (1 / 0)
+    float* dmx = dm2 + Tp * 32;                         // [Tp][8]   the six masked dx
+    float* dyb = dmx + Tp * 8;                          // [Tp][2]   dL/dy(t)
+    float* dump = dyb + Tp * 2;                         // [256]
+    if (lane < 16) hist[lane] = 0.0f;
+    const RowMasks rm = row_masks();
+    const int dmp = (int)(dump - smem);
+    // per-step stores of the forward pass: row 2 parks (r, z, n, dm_nh), row 1 (masked dh, mask), row 3 h(t), row 0 the masked dx of its lanes 0..7
+    const int p4_0 = role == 2 ? (int)(gpk - smem) + 4 * col : dmp + 4 * lane, p4_step = role == 2 ? 64 : 0;
+    const int p2_0 = role == 1 ? (int)(dm2 - smem) + 2 * col : dmp + 2 * lane, p2_step = role == 1 ? 32 : 0;
+    const int p1_0 = role == 3 ? (int)(hist - smem) + 16 + col : (role == 0 && col < 8) ? (int)(dmx - smem) + col : dmp + lane;
+    const int p1_step = role == 3 ? 16 : (role == 0 && col < 8) ? 8 : 0;
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
+    float dwo0 = 0.0f, dwo1 = 0.0f, dbo0 = 0.0f, dbo1 = 0.0f, dbg = 0.0f, dbn = 0.0f, tw1[3][6], tw2[2][3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) tw1[ch][k] = 0.0f;
+        tw2[0][ch] = 0.0f; tw2[1][ch] = 0.0f;
+    }
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
+        const float2* dyg = reinterpret_cast<const float2*>(a.dy) + (size_t)b * T;
+        // ---- forward, as delta_eval_kernel ----
+        {
+            float h = 0.0f, hp = 0.0f, xp = 0.0f, accx = accx0, acch = acch0;
+            int q4 = p4_0, q2 = p2_0, q1 = p1_0;
+            float2 rc, rn = make_float2(0.0f, 0.0f);
+            auto load_raw = [&](int t0) {
+                const int t = t0 + lane;
+                rc = t < T ? xg[t] : make_float2(0.5f, 0.5f);
+                if constexpr (TRES) rn = t + 1 < T ? xg[t + 1] : xg[0];
+            };
+            load_raw(0);
+            for (int t0 = 0; t0 < T; t0 += kEvalChunk) {
+                const int len = min(kEvalChunk, T - t0);
+                {
+                    float f[6];
+                    delta_feat<TRES>(rc, rn, f);
+                    wave_lds_fence();
+                    reinterpret_cast<float4*>(feat)[2 * (t0 + lane)] = make_float4(f[0], f[1], f[2], f[3]);
+                    reinterpret_cast<float4*>(feat)[2 * (t0 + lane) + 1] = make_float4(f[4], f[5], 0.0f, 0.0f);
+                    wave_lds_fence();
+                }
+                if (t0 + kEvalChunk < T) load_raw(t0 + kEvalChunk);
+                for (int tt = 0; tt < len; ++tt) {
+                    const float fv = feat[(t0 + tt) * 8 + fc];
+                    const float d = fv - xp, ad = __builtin_fabsf(d);
+                    const float dm = !(ad < thx) ? d : 0.0f;
+                    xp = (ad >= thx) ? fv : xp;
+                    float ax = accx;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+                        ax = __builtin_fmaf(wih[i], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dm), i)), ax);
+                    const float dhv = h - hp, adh = __builtin_fabsf(dhv);
+                    const bool keeph = !(adh < thh);
+                    const float dhm = keeph ? dhv : 0.0f;
+                    hp = (adh >= thh) ? h : hp;
+                    const bool nrow = role == 2;
+                    const float res = rotdot(nrow ? acch : ax, wrec, dhm);
+                    accx = nrow ? ax : res; acch = nrow ? res : acch;
+                    const float sg = sigmoidf_(res);
+                    const float r = xor32(sg);                                        // row 2 <- r of row 0
+                    const float n = tanhf_(__builtin_fmaf(r, res, ax));               // row 2
+                    float g4[4];
+                    gather_rows(nrow ? n : sg, g4);
+                    h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
+                    *reinterpret_cast<float4*>(smem + q4) = make_float4(r, g4[1], g4[2], res);
+                    *reinterpret_cast<float2*>(smem + q2) = make_float2(dhm, keeph ? 1.0f : 0.0f);
+                    smem[q1] = role == 3 ? h : dm;
+                    q4 += p4_step; q2 += p2_step; q1 += p1_step;
+                }
+            }
+            wave_lds_fence();
+        }
+        // ---- dL/dy of every step and the TCN gradient (state-free), lane = time step ----
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < T) {
+                const float2 dyv = dyg[t];
+                *reinterpret_cast<float2*>(dyb + 2 * t) = dyv;
+                dbo0 += dyv.x; dbo1 += dyv.y;
+                if constexpr (TRES) {
+                    const float2 zero = make_float2(0.0f, 0.0f);
+                    const float2 xc = xg[t], xm = t - kDHalo >= 0 ? xg[t - kDHalo] : zero, xq = t + kDHalo < T ? xg[t + kDHalo] : zero;
+                    float s1[3], hs[3], s2a = 0.0f, s2b = 0.0f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        s1[ch] = w1[ch][0] * xm.x;
+                        s1[ch] = __builtin_fmaf(w1[ch][1], xc.x, s1[ch]); s1[ch] = __builtin_fmaf(w1[ch][2], xq.x, s1[ch]);
+                        s1[ch] = __builtin_fmaf(w1[ch][3], xm.y, s1[ch]); s1[ch] = __builtin_fmaf(w1[ch][4], xc.y, s1[ch]);
+                        s1[ch] = __builtin_fmaf(w1[ch][5], xq.y, s1[ch]);
+                        hs[ch] = hardswishf_(s1[ch]);
+                        s2a = __builtin_fmaf(w2[0][ch], hs[ch], s2a); s2b = __builtin_fmaf(w2[1][ch], hs[ch], s2b);
+                    }
+                    const float d2a = dyv.x * hswish_grad_(s2a), d2b = dyv.y * hswish_grad_(s2b);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        tw2[0][ch] = __builtin_fmaf(d2a, hs[ch], tw2[0][ch]); tw2[1][ch] = __builtin_fmaf(d2b, hs[ch], tw2[1][ch]);
+                        const float d1 = __builtin_fmaf(d2a, w2[0][ch], d2b * w2[1][ch]) * hswish_grad_(s1[ch]);
+                        tw1[ch][0] = __builtin_fmaf(d1, xm.x, tw1[ch][0]); tw1[ch][1] = __builtin_fmaf(d1, xc.x, tw1[ch][1]);
+                        tw1[ch][2] = __builtin_fmaf(d1, xq.x, tw1[ch][2]); tw1[ch][3] = __builtin_fmaf(d1, xm.y, tw1[ch][3]);
+                        tw1[ch][4] = __builtin_fmaf(d1, xc.y, tw1[ch][4]); tw1[ch][5] = __builtin_fmaf(d1, xq.y, tw1[ch][5]);
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+        // ---- backward ----
+        {
+            float gh_c = 0.0f, ghp = 0.0f, accg = 0.0f, gn = 0.0f;      // carried: dL/dh, dL/dh_p, the row's accumulator gradient (G_r | G_z | G_nh), G_n
+            for (int t = T - 1; t >= 0; --t) {
+                const float hprev = hist[t * 16 + col], ht = hist[(t + 1) * 16 + col];
+                const float4 g = reinterpret_cast<const float4*>(gpk)[t * 16 + col];
+                const float2 dd = reinterpret_cast<const float2*>(dm2)[t * 16 + col];
+                const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
+                const float fsx = col < 6 ? dmx[t * 8 + col] : 0.0f;
+                const float r = g.x, z = g.y, n = g.z, nh = g.w, dhm = dd.x, mk = dd.y;
+                const float gh = gh_c + __builtin_fmaf(dyv.x, wo0, dyv.y * wo1);
+                dwo0 = __builtin_fmaf(dyv.x, ht, dwo0); dwo1 = __builtin_fmaf(dyv.y, ht, dwo1);
+                const float dn = gh * (1.0f - z), dz = gh * (hprev - n);
+                float ghprev = gh * z;
+                const float dpre = dn * __builtin_fmaf(-n, n, 1.0f);
+                gn += dpre;
+                const float c_nh = __builtin_fmaf(dpre, r, accg), c_r = __builtin_fmaf(dpre * nh, r * (1.0f - r), accg),
+                            c_z = __builtin_fmaf(dz, z * (1.0f - z), accg);
+                accg = vsel(rm.m[0], c_r, vsel(rm.m[1], c_z, c_nh));
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(accg, dhm, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(vsel(rm.m[2], gn, accg), fsx, acc2, 0, 0, 0);
+                float ddh = rotdot(0.0f, wT, accg);
+                ddh += xor16(ddh);
+                ddh += xor32(ddh);
+                ghprev = __builtin_fmaf(mk, ddh + ghp, ghprev);
+                ghp = __builtin_fmaf(-mk, ddh, (1.0f - mk) * ghp);
+                gh_c = ghprev;
+            }
+            // gradient w.r.t. the initial accumulators = bias gradients (deltagru.py:165-170)
+            dbg += accg; dbn += gn;
+        }
+        wave_lds_fence();
+    }
+    // ---- the workgroup's row of partial gradients (every entry written) ----
+    float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
+    if (lane < kLossCols) prow[L.P + lane] = 0.0f;
+    if (vo && role == 0) { prow[L.o_w_out + col] = dwo0; prow[L.o_w_out + H + col] = dwo1; }
+    if constexpr (TRES) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { const float v = wave_sum_(tw1[ch][k]); if (lane == 0) prow[L.o_tcn0 + ch * 6 + k] = v; }
+#pragma unroll
+            for (int oo = 0; oo < 2; ++oo) { const float v = wave_sum_(tw2[oo][ch]); if (lane == 0) prow[L.o_tcn2 + oo * 3 + ch] = v; }
+        }
+    } else {
+        const float b0 = wave_sum_(dbo0), b1 = wave_sum_(dbo1);
+        if (lane == 0) { prow[L.o_b_out] = b0; prow[L.o_b_out + 1] = b1; }
+        if (vo) {
+            if (role < 2) { prow[L.o_b_ih + role * H + col] = dbg; prow[L.o_b_hh + role * H + col] = dbg; }
+            if (role == 2) { prow[L.o_b_ih + 2 * H + col] = dbn; prow[L.o_b_hh + 2 * H + col] = dbg; }
+        }
+    }
+    // MFMA block k = gate k (r, z, n); register 4 k + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * role + rr;
+            if (i < H) {
+                if (col < H) prow[L.o_w_hh + (k * H + i) * H + col] = acc1[4 * k + rr];
+                if (col < 6) prow[L.o_w_ih + (k * H + i) * 6 + col] = acc2[4 * k + rr];
+            }
+        }
+}
+
+// -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
 static size_t delta_lds_bytes(int P, int waves, bool reduce) {
@@ -665,6 +904,34 @@ static int delta_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
     return (int)hipGetLastError();
 }
 
+// the gate-parallel backward kernel: one sequence per single-wave workgroup, the frame's parked state in LDS
+static size_t delta_gp_lds_bytes(int P, int T) { return ((size_t)pad4(P) + delta_gp_buffer_floats(T)) * sizeof(float); }
+static int delta_gp_blocks_per_cu(int P, int T) {
+    const size_t lds = delta_gp_lds_bytes(P, T);
+    const int n = lds > kMaxLds ? 0 : (int)(kMaxLds / lds);
+    return n < 4 ? n : 4;
+}
+static bool delta_bwd_uses_gp(const odpd_model_t* m, int B, int T) {
+    if (m->hidden > 16 || delta_uses_s16(m, B) || tuning().s16_min_batch == 0) return false;
+    const int P = delta_layout(m->hidden, m->backbone == ODPD_TRES_DELTAGRU).P;
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0) return B <= max_batch && delta_gp_blocks_per_cu(P, T) > 0;
+    return (long)B <= (long)device_cus() * delta_gp_blocks_per_cu(P, T);      // every sequence resident at once
+}
+static int delta_gp_rows(const odpd_model_t* m, int B, int T) {
+    const int P = delta_layout(m->hidden, m->backbone == ODPD_TRES_DELTAGRU).P;
+    const long cap = (long)device_cus() * (kMaxLds / delta_gp_lds_bytes(P, T));
+    return B < cap ? B : (int)cap;
+}
+template <bool TRES>
+static int delta_launch_gp_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int P) {
+    const size_t lds = delta_gp_lds_bytes(P, a.T);
+    auto k = delta_gp_bwd_kernel<TRES>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(delta_gp_rows(m, a.B, a.T)), dim3(64), lds, st, a);
+    return (int)hipGetLastError();
+}
+
 int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (delta_uses_s16(m, a.B)) return delta_s16_launch(st, m, a, 1);
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
@@ -679,11 +946,14 @@ int delta_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
     const int P = delta_layout(m->hidden, tres).P;
+    if (a.dx == nullptr && a.partials != nullptr && delta_bwd_uses_gp(m, a.B, a.T))
+        return tres ? delta_launch_gp_bwd<true>(st, m, a, P) : delta_launch_gp_bwd<false>(st, m, a, P);
     return tres ? delta_launch_bwd<true>(st, a, P) : delta_launch_bwd<false>(st, a, P);
 }
-int delta_family_rows(const odpd_model_t* m, int B) {
+int delta_family_rows(const odpd_model_t* m, int B, int T) {
     if (delta_uses_s16(m, B)) return delta_s16_rows(m, B);
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
+    if (delta_bwd_uses_gp(m, B, T)) return delta_gp_rows(m, B, T);
     return delta_bwd_shape(num_groups(B, 1)).grid;
 }
 

@@ -182,7 +182,7 @@ int lstm_s16_rows(const odpd_model_t* m, int B);
 int64_t lstm_s16_workspace_floats(const odpd_model_t* m, int B, int T);
 int delta_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int delta_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
-int delta_family_rows(const odpd_model_t* m, int B);
+int delta_family_rows(const odpd_model_t* m, int B, int T);
 // 16-sequences-per-wave split kernels of the delta backbones (delta_s16.hip): mode 1 forward, 2 backward
 bool delta_uses_s16(const odpd_model_t* m, int B);
 int delta_s16_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);

@@ -283,3 +283,46 @@ def test_evaluation_kernel_matches_the_oracle_and_keeps_the_counters(bb, H, thx,
     flips = abs(st_eval[0] - so[0]) + abs(st_eval[2] - so[2])
     assert flips <= 4
     assert rel_err(y_eval, yo) < (FWD_TOL if flips == 0 else 5e-3)
+
+
+@pytest.mark.parametrize("bb,H,thx,thh", [("deltagru", 15, 0.01, 0.05), ("deltagru", 8, 0.0, 0.0), ("deltagru", 1, 0.02, 0.1),
+                                          ("deltagru_tcnskip", 15, 0.01, 0.05), ("deltagru_tcnskip", 16, 0.0, 0.0), ("deltagru_tcnskip", 9, 0.05, 0.02)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 17), (7, 63), (5, 64), (2, 65), (64, 50), (9, 200), (600, 200)])
+def test_gate_parallel_backward_kernel(bb, H, thx, thh, B, T):
+    """the split train path at the reference's batch sizes runs delta_gp_bwd_kernel (one sequence per wave; it runs the forward again and
+    parks the step state in LDS instead of reading checkpoints; (600, 200): several sequences per workgroup): parameter gradients against
+    the oracle and against the four-sequence-per-wave backward (odpd_set_tuning gp_max_batch = 0) of the same batch"""
+    import ctypes as C
+    from opendpd_amd import CoreModel, _lib
+    from oracle.oracle import Oracle, make_model
+    lib = _lib.load()
+    torch.manual_seed(H * 100 + B + T)
+    net = CoreModel(2, H, 1, bb, thx=thx, thh=thh).cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    rng = np.random.RandomState(B * 13 + T)
+    amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    dy = rng.randn(B, T, 2).astype(np.float32)
+    got = {}
+    try:
+        for gp in (1 << 30, 0):      # one-sequence-per-wave kernels forced on / off
+            lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(gp))
+            for q in net.parameters():
+                q.grad = None
+            net(torch.from_numpy(x).cuda()).backward(torch.from_numpy(dy).cuda())
+            got[gp] = torch.cat([q.grad.reshape(-1) for q in net.parameters()]).cpu().numpy()
+    finally:
+        lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
+    # thresholded: the two mappings sum in different orders, a |dh| within rounding of th_h can flip a mask somewhere in B x T x H decisions
+    assert rel_err(got[1 << 30], got[0]) < (2e-5 if thx == 0.0 and thh == 0.0 else 5e-3)
+    assert T < 50 or not np.array_equal(got[1 << 30], got[0])          # two kernels
+    if B * T <= 3000:
+        o, m = Oracle("f32"), make_model(bb, H, thx, thh)
+        p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+        _, so = o.forward(m, p, x)
+        go, _ = o.backward(m, p, x, dy, need_dx=False)
+        # a rounding-level difference can flip a threshold decision (see test_against_oracle_ragged)
+        assert rel_err(got[1 << 30], go) < (GRAD_TOL if thx == 0.0 and thh == 0.0 else 5e-2)
