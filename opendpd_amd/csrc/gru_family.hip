@@ -1035,6 +1035,10 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
             wave_lds_fence();
         }
         // ---- fc_out, loss and dL/dy of every step, lane = time step ----
+        if (a.dy != nullptr) {            // split train path: dL/dy comes from the caller (the loss kernel, or the PA half of a cascade)
+            const float2* dyg = reinterpret_cast<const float2*>(a.dy) + (size_t)b * T;
+            for (int t = lane; t < T; t += 64) *reinterpret_cast<float2*>(dyb + 2 * t) = dyg[t];
+        } else
         for (int t0 = 0; t0 < T; t0 += 64) {
             const int t = t0 + lane;
             if (t < T) {
@@ -1375,11 +1379,25 @@ int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     ODPD_GRU_DISPATCH_ALL(launch_fwd, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
+static bool gru_bwd_uses_gp(const odpd_model_t* m, int B, int T);
+static int gp_grid(int P, int R, bool DG, int B, int T);
+template <int R, int FM, bool DG>
+static int launch_gp_train(hipStream_t st, const SeqArgs& a, int P);
 int gru_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     if (gru_split_uses_s16(m, a.B)) return gru_s16_bwd(st, m, a);
     if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 2);
+    if (gru_bwd_uses_gp(m, a.B, a.T)) {
+        // weight gradients only: the fused one-sequence-per-wave kernel with dL/dy given (it runs its own forward; the checkpoints stay unread)
+        if (a.partials != nullptr && a.dx == nullptr) { ODPD_GRU_DISPATCH_ALL(launch_gp_train, st, a, P) }
+        // dL/dx asked for: the row-rotated kernel writes fewer rows than the caller's buffer holds — the rest are zero
+        if (a.partials != nullptr) {
+            const int have = bwd_shape(R, a.ngroups).grid, rows = gp_grid(P, R, DG, a.B, a.T);
+            if (rows > have)
+                ODPD_CHECK_HIP(hipMemsetAsync(a.partials + (size_t)have * (P + kLossCols), 0, (size_t)(rows - have) * (P + kLossCols) * sizeof(float), st));
+        }
+    }
     ODPD_GRU_DISPATCH_ALL(launch_bwd_mode, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
@@ -1403,6 +1421,12 @@ bool gru_train_uses_gp(const odpd_model_t* m, int B, int T) {
     const long max_batch = tuning().gp_max_batch;
     if (max_batch >= 0) return B <= max_batch && gp_blocks_per_cu(P, R, DG, T, false) > 0;
     return (long)B <= (long)device_cus() * gp_blocks_per_cu(P, R, DG, T, false);        // one sequence per SIMD, all resident at once
+}
+// the split backward (dL/dy given) on the same kernel: hidden <= 16, every sequence resident at once
+static bool gru_bwd_uses_gp(const odpd_model_t* m, int B, int T) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P) || R != 1 || gru_split_uses_s16(m, B) || tuning().gp_max_batch == 0 || tuning().s16_min_batch == 0) return false;
+    return (long)B <= (long)device_cus() * gp_blocks_per_cu(P, R, DG, T, false);
 }
 static int gp_grid(int P, int R, bool DG, int B, int T) {
     const bool pg = gp_parks_gates(P, R, DG, B, T);
@@ -1451,7 +1475,12 @@ int gru_family_rows(const odpd_model_t* m, int B, int which, int T) {
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     const int ng = num_groups(B, R);
     if (gru_uses_s16n(m, B)) return gru_s16n_rows(m, B);
-    if (!which) return gru_split_uses_s16(m, B) ? gru_s16_bwd_rows(m, B) : bwd_shape(R, ng).grid;
+    if (!which) {
+        if (gru_split_uses_s16(m, B)) return gru_s16_bwd_rows(m, B);
+        const int have = bwd_shape(R, ng).grid;
+        if (gru_bwd_uses_gp(m, B, T)) { const int rows = gp_grid(P, R, DG, B, T); return rows > have ? rows : have; }
+        return have;
+    }
     if (gru_train_uses_s16(m, B, T)) return gru_s16_rows(m, B);
     if (gru_train_uses_gp(m, B, T)) return gp_grid(P, R, DG, B, T);
     const LaunchShape ls = train_shape(P, R, DG, ng, T, nullptr);

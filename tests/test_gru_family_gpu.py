@@ -372,3 +372,46 @@ def test_gate_parallel_train_kernels_loop_over_sequences(bb, H):
         lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
     assert abs(got[1 << 30][0] - got[0][0]) < 1e-5 * max(1.0, got[0][0])
     assert rel_err(got[1 << 30][1], got[0][1]) < 2e-5
+
+
+@pytest.mark.parametrize("bb,H", [("gru", 11), ("dgru", 13), ("qgru", 10), ("qgru_amp1", 16), ("dgru", 1)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 17), (5, 64), (2, 65), (64, 50), (9, 200), (300, 130)])
+@pytest.mark.parametrize("need_dx", [False, True])
+def test_split_backward_on_the_gate_parallel_kernel(bb, H, B, T, need_dx):
+    """autograd / cascade backward at the reference's batch sizes: with weight gradients only, the one-sequence-per-wave fused kernel runs
+    with dL/dy given (its own forward, checkpoints unread); with dL/dx asked for, the row-rotated kernel fills the first rows of the
+    (larger) partials buffer and the rest is zeroed.  Same gradients as with the one-sequence-per-wave kernels off, and as the oracle's."""
+    import ctypes as C
+    from opendpd_amd import CoreModel, _lib
+    from oracle.oracle import Oracle, make_model
+    lib = _lib.load()
+    torch.manual_seed(H * 100 + B + T)
+    net = CoreModel(2, H, 1, bb).cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    rng = np.random.RandomState(B * 13 + T)
+    amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    dy = rng.randn(B, T, 2).astype(np.float32)
+    got = {}
+    try:
+        for gp in (-1, 0):
+            lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(gp))
+            for q in net.parameters():
+                q.grad = None
+            xt = torch.from_numpy(x).cuda().requires_grad_(need_dx)
+            net(xt).backward(torch.from_numpy(dy).cuda())
+            got[gp] = (torch.cat([q.grad.reshape(-1) for q in net.parameters()]).cpu().numpy(), xt.grad.cpu().numpy() if need_dx else None)
+    finally:
+        lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
+    assert rel_err(got[-1][0], got[0][0]) < 2e-5
+    if need_dx:
+        assert rel_err(got[-1][1], got[0][1]) < 2e-5
+    o, m = Oracle("f32"), make_model(bb, H)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    go, dxo = o.backward(m, p, x, dy, need_dx=need_dx)
+    assert rel_err(got[-1][0], go) < GRAD_TOL
+    if need_dx:
+        assert rel_err(got[-1][1], dxo) < GRAD_TOL
