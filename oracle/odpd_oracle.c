@@ -50,10 +50,10 @@ static int feat_dim(int bb) {
     }
 }
 
+static int64_t qat_param_count(const odpd_model_t* m);
 int64_t oracle_param_count(const odpd_model_t* m) {
     int64_t H = m->hidden, F = feat_dim(m->backbone);
-    if (m->bits_w > 0 && (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1))
-        return 3 * H * F + 3 * H + 3 + 3 * H * H + 3 * H + 3 + 4 + 2 * H + 2 + 3;   /* + 13 quantiser scales */
+    if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET) return qat_param_count(m);   /* quantised models: + the quantiser scales */
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1:
         return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
@@ -1572,29 +1572,51 @@ static void mcl_seq_bwd(const mcl_layout_t* L, const real* p, int T, const real*
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* Quantisation-aware QGRU: quant/__init__.py:20-37 -> quant_envs.py:138-306 applied to qgru.py  */
+/* Quantisation-aware models: quant/__init__.py:20-37 -> quant_envs.py:138-306, the GENERIC surgery */
+/*   (nn.GRU -> Python GRU of GRUCells :114-130; every Sigmoid / Tanh / Add / Mul module and every   */
+/*   nn.Linear swapped :290-306) applied to gru.py, dgru.py, qgru.py, qgru_amp1.py (GRUCell,         */
+/*   quant/modules/gru.py:43-59) and to deltagru_tcnskip.py (its DeltaGRULayer :156-162, 266-291).    */
 /*   INT_Quantizer (quantizers.py:15-85): s = 2^round(log2|scale|); q(x) = round(clamp(x/s,Qn,Qp))*s */
 /*   (clamp BEFORE round, round half to even), straight-through gradient inside the clamp range.   */
 /*   INT_Linear (quant_layers.py:48-85): F.linear(q_a(x), q_w(W), b), bias not quantised; the       */
 /*   16-bit out_quantizer applies to fc_out in eval mode only.                                      */
-/*   Cell (quant/modules/gru.py:43-59) with the shared op quantisers of quant_ops.py.               */
 /* Parameter order = named_parameters() of the quantised model:                                    */
-/*   x2h.{weight,bias,wq.scale,aq.scale,oq.scale}, h2h.{same}, sigmoid.q, tanh.q, add.q, mul.q,     */
-/*   fc_out.{weight,bias,wq.scale,aq.scale,oq.scale}                                                */
+/*   GRUCell models: x2h.{weight,bias,wq.scale,aq.scale,oq.scale}, h2h.{same}, sigmoid.q, tanh.q,   */
+/*     add.q, mul.q, fc_out.{weight,bias,wq,aq,oq} [, dgru: fc_hid.{weight,bias,wq,aq,oq}]           */
+/*   deltagru_tcnskip: x2h.{weight,wq,aq,oq}, h2h.{same}, add.q, mul.q, sigmoid.q, tanh.q,           */
+/*     fc_out.{weight,wq,aq,oq}, tcn.0.weight, tcn.2.weight                                          */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
-    int H, F, bits_w, bits_a;
+    int H, F, OW, bits_w, bits_a, dgru, tres;
     int64_t o_wx, o_bx, o_sxw, o_sxa, o_sxo, o_wh, o_bh, o_shw, o_sha, o_sho, o_ssig, o_stanh, o_sadd, o_smul,
-            o_wo, o_bo, o_sow, o_soa, o_soo;
+            o_wo, o_bo, o_sow, o_soa, o_soo, o_whid, o_bhid, o_shidw, o_shida, o_shido, o_tcn0, o_tcn2, P;
 } qgru_layout_t;
-static void qgru_layout(const odpd_model_t* m, qgru_layout_t* g) {
-    int64_t H = m->hidden, F = 4, o = 0;
-    g->H = (int)H; g->F = (int)F; g->bits_w = m->bits_w; g->bits_a = m->bits_a;
-    g->o_wx = o; o += 3 * H * F; g->o_bx = o; o += 3 * H; g->o_sxw = o++; g->o_sxa = o++; g->o_sxo = o++;
-    g->o_wh = o; o += 3 * H * H; g->o_bh = o; o += 3 * H; g->o_shw = o++; g->o_sha = o++; g->o_sho = o++;
-    g->o_ssig = o++; g->o_stanh = o++; g->o_sadd = o++; g->o_smul = o++;
-    g->o_wo = o; o += 2 * H; g->o_bo = o; o += 2; g->o_sow = o++; g->o_soa = o++; g->o_soo = o++;
+static int is_qat(const odpd_model_t* m) {
+    return m->bits_w > 0 && (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1 || m->backbone == ODPD_GRU ||
+                             m->backbone == ODPD_DGRU || m->backbone == ODPD_TRES_DELTAGRU);
 }
+static void qgru_layout(const odpd_model_t* m, qgru_layout_t* g) {
+    int64_t H = m->hidden, F = feat_dim(m->backbone), o = 0;
+    memset(g, 0xff, sizeof(*g));
+    g->H = (int)H; g->F = (int)F; g->bits_w = m->bits_w; g->bits_a = m->bits_a;
+    g->dgru = m->backbone == ODPD_DGRU; g->tres = m->backbone == ODPD_TRES_DELTAGRU;
+    g->OW = (int)(g->dgru ? H + 6 : H);
+    if (g->tres) {
+        g->o_wx = o; o += 3 * H * F; g->o_sxw = o++; g->o_sxa = o++; g->o_sxo = o++;
+        g->o_wh = o; o += 3 * H * H; g->o_shw = o++; g->o_sha = o++; g->o_sho = o++;
+        g->o_sadd = o++; g->o_smul = o++; g->o_ssig = o++; g->o_stanh = o++;
+        g->o_wo = o; o += 2 * H; g->o_sow = o++; g->o_soa = o++; g->o_soo = o++;
+        g->o_tcn0 = o; o += 18; g->o_tcn2 = o; o += 6;
+    } else {
+        g->o_wx = o; o += 3 * H * F; g->o_bx = o; o += 3 * H; g->o_sxw = o++; g->o_sxa = o++; g->o_sxo = o++;
+        g->o_wh = o; o += 3 * H * H; g->o_bh = o; o += 3 * H; g->o_shw = o++; g->o_sha = o++; g->o_sho = o++;
+        g->o_ssig = o++; g->o_stanh = o++; g->o_sadd = o++; g->o_smul = o++;
+        g->o_wo = o; o += 2 * g->OW; g->o_bo = o; o += 2; g->o_sow = o++; g->o_soa = o++; g->o_soo = o++;
+        if (g->dgru) { g->o_whid = o; o += H * H; g->o_bhid = o; o += H; g->o_shidw = o++; g->o_shida = o++; g->o_shido = o++; }
+    }
+    g->P = o;
+}
+static int64_t qat_param_count(const odpd_model_t* m) { qgru_layout_t L; qgru_layout(m, &L); return L.P; }
 static inline real q_pow2(real scale) {   /* quantizers.py:56-65 */
     float l = rintf(log2f(fabsf((float)scale)));
     return (real)ldexp(1.0, (int)l);
@@ -1608,32 +1630,35 @@ static inline real q_apply(real x, real s, int bits, real* pass) {
     return (real)rint((double)v) * s;
 }
 typedef struct {
-    real f[4], px[4], hq[MAXH], ph[MAXH];                 /* features, pass masks of act quantisers, q_a(h) */
+    real f[MAXF], fq[MAXF], px[MAXF], hq[MAXH], ph[MAXH];  /* features, q_a(features), pass masks of act quantisers, q_a(h) */
     real hp[MAXH], xt[3 * MAXH], ht[3 * MAXH];
     real p_ar[MAXH], p_az[MAXH], p_an[MAXH], p_ah[MAXH];  /* pass masks of the four add-quantiser uses */
     real rf[MAXH], zf[MAXH], nf[MAXH];                    /* float sigmoid/tanh outputs (autograd saves these) */
     real p_r[MAXH], p_z[MAXH], p_n[MAXH];
     real r[MAXH], z[MAXH], n[MAXH];
     real p_m1[MAXH], p_m2[MAXH], p_m3[MAXH];
-    real h[MAXH], ho[MAXH], p_ho[MAXH];                   /* new state, q_a(h') for fc_out and its mask */
+    real h[MAXH], ho[MAXH + 6], p_ho[MAXH + 6];           /* new state, q_a(fc_out input) and its mask */
+    real h2[MAXH], p_h2[MAXH], hidpre[MAXH];              /* dgru: q_a(h') of fc_hid, its mask, fc_hid pre-activation */
+    /* delta cell (deltagru_tcnskip) */
+    real mx[MAXF], dxm[MAXF], mh[MAXH], dhm[MAXH], dmnh[MAXH], omz[MAXH], p_omz[MAXH], s1[3], s2[2];
 } qgru_step_t;
 
 static void qgru_seq_fwd(const odpd_model_t* m, const qgru_layout_t* L, const real* p, int T, const real* x, real* y,
-                         qgru_step_t* S, int eval_mode, const real* qwx, const real* qwh, const real* qwo) {
-    int H = L->H, F = L->F, ba = L->bits_a;
+                         qgru_step_t* S, int eval_mode, const real* qwx, const real* qwh, const real* qwo, const real* qwhid) {
+    int H = L->H, F = L->F, ba = L->bits_a, OW = L->OW;
     real sxa = q_pow2(p[L->o_sxa]), sha = q_pow2(p[L->o_sha]), soa = q_pow2(p[L->o_soa]), soo = q_pow2(p[L->o_soo]);
     real ssig = q_pow2(p[L->o_ssig]), stanh = q_pow2(p[L->o_stanh]), sadd = q_pow2(p[L->o_sadd]), smul = q_pow2(p[L->o_smul]);
+    real shida = L->dgru ? q_pow2(p[L->o_shida]) : (real)1;
     real h[MAXH] = {0};
     qgru_step_t tmp;
     for (int t = 0; t < T; ++t) {
         qgru_step_t* s = S ? &S[t] : &tmp;
         feat_fwd(m->backbone, x[2 * t], x[2 * t + 1], s->f);
-        real fq[4];
-        for (int i = 0; i < F; ++i) fq[i] = q_apply(s->f[i], sxa, ba, &s->px[i]);
+        for (int i = 0; i < F; ++i) s->fq[i] = q_apply(s->f[i], sxa, ba, &s->px[i]);
         for (int j = 0; j < H; ++j) { s->hp[j] = h[j]; s->hq[j] = q_apply(h[j], sha, ba, &s->ph[j]); }
         for (int k = 0; k < 3 * H; ++k) {   /* exact grid sum, then the fp32 bias (matches F.linear bit for bit) */
             double a = 0, b = 0;
-            for (int i = 0; i < F; ++i) a += (double)fq[i] * (double)qwx[k * F + i];
+            for (int i = 0; i < F; ++i) a += (double)s->fq[i] * (double)qwx[k * F + i];
             for (int i = 0; i < H; ++i) b += (double)s->hq[i] * (double)qwh[k * H + i];
             s->xt[k] = (real)a + p[L->o_bx + k];
             s->ht[k] = (real)b + p[L->o_bh + k];
@@ -1652,10 +1677,24 @@ static void qgru_seq_fwd(const odpd_model_t* m, const qgru_layout_t* L, const re
             real m3 = q_apply(((real)1 - s->z[j]) * s->n[j], smul, ba, &s->p_m3[j]);
             s->h[j] = q_apply(m2 + m3, sadd, ba, &s->p_ah[j]);
         }
-        for (int j = 0; j < H; ++j) { h[j] = s->h[j]; s->ho[j] = q_apply(h[j], soa, ba, &s->p_ho[j]); }
+        for (int j = 0; j < H; ++j) h[j] = s->h[j];
+        if (L->dgru) {   /* dgru.py:70-73 with fc_hid / fc_out as INT_Linear: relu(fc_hid(out)), cat with the float features */
+            for (int j = 0; j < H; ++j) s->h2[j] = q_apply(h[j], shida, ba, &s->p_h2[j]);
+            real cat[MAXH + 6];
+            for (int j = 0; j < H; ++j) {
+                double a = 0;
+                for (int k = 0; k < H; ++k) a += (double)s->h2[k] * (double)qwhid[j * H + k];
+                s->hidpre[j] = (real)a + p[L->o_bhid + j];
+                cat[j] = s->hidpre[j] > 0 ? s->hidpre[j] : (real)0;
+            }
+            for (int i = 0; i < 6; ++i) cat[H + i] = s->f[i];
+            for (int k = 0; k < OW; ++k) s->ho[k] = q_apply(cat[k], soa, ba, &s->p_ho[k]);
+        } else {
+            for (int j = 0; j < H; ++j) s->ho[j] = q_apply(h[j], soa, ba, &s->p_ho[j]);
+        }
         for (int c = 0; c < 2; ++c) {
             double a = 0;
-            for (int j = 0; j < H; ++j) a += (double)s->ho[j] * (double)qwo[c * H + j];
+            for (int j = 0; j < OW; ++j) a += (double)s->ho[j] * (double)qwo[c * OW + j];
             real v = (real)a + p[L->o_bo + c];
             y[2 * t + c] = eval_mode ? q_apply(v, soo, 16, NULL) : v;
         }
@@ -1663,17 +1702,29 @@ static void qgru_seq_fwd(const odpd_model_t* m, const qgru_layout_t* L, const re
 }
 static void qgru_seq_bwd(const odpd_model_t* m, const qgru_layout_t* L, const real* p, int T, const real* x, const real* dy,
                          const qgru_step_t* S, real* dp, real* dx, const real* qwx, const real* qwh, const real* qwo,
-                         real* dqwx, real* dqwh, real* dqwo) {
-    int H = L->H, F = L->F;
+                         const real* qwhid, real* dqwx, real* dqwh, real* dqwo, real* dqwhid) {
+    int H = L->H, F = L->F, OW = L->OW;
     real dh[MAXH] = {0};
     for (int t = T - 1; t >= 0; --t) {
         const qgru_step_t* s = &S[t];
         real dhn[MAXH];   /* gradient w.r.t. the new state h' */
+        real df[MAXF] = {0};
         for (int j = 0; j < H; ++j) dhn[j] = dh[j];
+        real dcat[MAXH + 6] = {0};
         for (int c = 0; c < 2; ++c) {
             real d = dy[2 * t + c];
             dp[L->o_bo + c] += d;
-            for (int j = 0; j < H; ++j) { dqwo[c * H + j] += d * s->ho[j]; dhn[j] += d * qwo[c * H + j] * s->p_ho[j]; }
+            for (int j = 0; j < OW; ++j) { dqwo[c * OW + j] += d * s->ho[j]; dcat[j] += d * qwo[c * OW + j] * s->p_ho[j]; }
+        }
+        if (L->dgru) {
+            for (int i = 0; i < 6; ++i) df[i] += dcat[H + i];
+            for (int j = 0; j < H; ++j) {
+                real dpre = s->hidpre[j] > 0 ? dcat[j] : (real)0;
+                dp[L->o_bhid + j] += dpre;
+                for (int k = 0; k < H; ++k) { dqwhid[j * H + k] += dpre * s->h2[k]; dhn[k] += dpre * qwhid[j * H + k] * s->p_h2[k]; }
+            }
+        } else {
+            for (int j = 0; j < H; ++j) dhn[j] += dcat[j];
         }
         real dxt[3 * MAXH], dht[3 * MAXH], dhp[MAXH];
         for (int j = 0; j < H; ++j) {
@@ -1691,12 +1742,10 @@ static void qgru_seq_bwd(const odpd_model_t* m, const qgru_layout_t* L, const re
             real daz = dz * s->p_z[j] * s->zf[j] * ((real)1 - s->zf[j]) * s->p_az[j];
             dxt[j] = dar; dht[j] = dar; dxt[H + j] = daz; dht[H + j] = daz;
         }
-        real df[4] = {0, 0, 0, 0};
         for (int k = 0; k < 3 * H; ++k) {
             dp[L->o_bx + k] += dxt[k]; dp[L->o_bh + k] += dht[k];
             for (int i = 0; i < F; ++i) {
-                real fq = q_apply(s->f[i], q_pow2(p[L->o_sxa]), L->bits_a, NULL);
-                dqwx[k * F + i] += dxt[k] * fq;
+                dqwx[k * F + i] += dxt[k] * s->fq[i];
                 df[i] += dxt[k] * qwx[k * F + i] * s->px[i];
             }
             for (int i = 0; i < H; ++i) { dqwh[k * H + i] += dht[k] * s->hq[i]; dhp[i] += dht[k] * qwh[k * H + i] * s->ph[i]; }
@@ -1705,27 +1754,203 @@ static void qgru_seq_bwd(const odpd_model_t* m, const qgru_layout_t* L, const re
         if (dx) feat_bwd(m->backbone, x[2 * t], x[2 * t + 1], df, &dx[2 * t], &dx[2 * t + 1]);
     }
 }
-/* quantised weights and their pass masks (STE to the float master weights) */
-static void qgru_quant_weights(const qgru_layout_t* L, const real* p, real* qwx, real* qwh, real* qwo, real* mx, real* mh, real* mo) {
-    int H = L->H, F = L->F;
-    real sx = q_pow2(p[L->o_sxw]), sh = q_pow2(p[L->o_shw]), so = q_pow2(p[L->o_sow]);
-    for (int i = 0; i < 3 * H * F; ++i) qwx[i] = q_apply(p[L->o_wx + i], sx, L->bits_w, mx ? &mx[i] : NULL);
-    for (int i = 0; i < 3 * H * H; ++i) qwh[i] = q_apply(p[L->o_wh + i], sh, L->bits_w, mh ? &mh[i] : NULL);
-    for (int i = 0; i < 2 * H; ++i) qwo[i] = q_apply(p[L->o_wo + i], so, L->bits_w, mo ? &mo[i] : NULL);
-}
-static int is_qat(const odpd_model_t* m) { return m->bits_w > 0 && (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1); }
 
-/* forward of the quantised model; eval_mode != 0 applies fc_out's 16-bit output quantiser (quant_layers.py:77-80) */
-int oracle_qat_fwd(const odpd_model_t* m, int B, int T, const real* params, const real* x, real* y, int eval_mode) {
+/* deltagru_tcnskip under the surgery: x2h / h2h bias-free INT_Linear on the thresholded deltas, accumulators in fp32,
+ * gate_r = Qsig(dm_r), gate_z = Qsig(dm_z), gate_n = Qtanh(Qadd(dm_n, Qmul(gate_r, dm_nh))),
+ * h = Qadd(Qmul(Qadd(1, -gate_z), gate_n), Qmul(gate_z, h))  (deltagru_tcnskip.py:266-291), y = fc_out(h) [eval: 16-bit] + skip */
+static void qtres_seq_fwd(const odpd_model_t* m, const qgru_layout_t* L, const real* p, int T, const real* x, real* y,
+                          qgru_step_t* S, int eval_mode, const real* qwx, const real* qwh, const real* qwo, double* stats) {
+    int H = L->H, ba = L->bits_a;
+    const real thx = (real)(float)m->thx, thh = (real)(float)m->thh;
+    real sxa = q_pow2(p[L->o_sxa]), sha = q_pow2(p[L->o_sha]), soa = q_pow2(p[L->o_soa]), soo = q_pow2(p[L->o_soo]);
+    real ssig = q_pow2(p[L->o_ssig]), stanh = q_pow2(p[L->o_stanh]), sadd = q_pow2(p[L->o_sadd]), smul = q_pow2(p[L->o_smul]);
+    real xp[6] = {0}, h[MAXH] = {0}, hp[MAXH] = {0}, dm[3 * MAXH] = {0}, dmnh[MAXH] = {0};
+    delta_layout_t DL; DL.tres = 1; DL.H = H;
+    qgru_step_t tmp;
+    double zx = 0, zh = 0;
+    for (int t = 0; t < T; ++t) {
+        qgru_step_t* s = S ? &S[t] : &tmp;
+        delta_feat(&DL, x, t, T, s->f);
+        for (int i = 0; i < 6; ++i) {
+            real d = s->f[i] - xp[i], ad = (real)fabs((double)d);
+            s->mx[i] = (ad < thx) ? (real)0 : (real)1;
+            s->dxm[i] = s->mx[i] != 0 ? d : (real)0;
+            if (s->dxm[i] == 0) zx += 1;
+            if (ad >= thx) xp[i] = s->f[i];
+            s->fq[i] = q_apply(s->dxm[i], sxa, ba, &s->px[i]);
+        }
+        for (int j = 0; j < H; ++j) {
+            real d = h[j] - hp[j], ad = (real)fabs((double)d);
+            s->hp[j] = h[j];
+            s->mh[j] = (ad < thh) ? (real)0 : (real)1;
+            s->dhm[j] = s->mh[j] != 0 ? d : (real)0;
+            if (s->dhm[j] == 0) zh += 1;
+            if (ad >= thh) hp[j] = h[j];
+            s->hq[j] = q_apply(s->dhm[j], sha, ba, &s->ph[j]);
+        }
+        for (int j = 0; j < H; ++j) {
+            real mx[3], mh[3];
+            for (int k = 0; k < 3; ++k) {
+                double a = 0, b = 0;
+                for (int i = 0; i < 6; ++i) a += (double)s->fq[i] * (double)qwx[(k * H + j) * 6 + i];
+                for (int i = 0; i < H; ++i) b += (double)s->hq[i] * (double)qwh[(k * H + j) * H + i];
+                mx[k] = (real)a + dm[k * H + j]; mh[k] = (real)b;
+            }
+            dm[j] = mx[0] + mh[0]; dm[H + j] = mx[1] + mh[1]; dm[2 * H + j] = mx[2];
+            dmnh[j] = mh[2] + dmnh[j];
+            s->dmnh[j] = dmnh[j];
+            s->rf[j] = sigm(dm[j]); s->zf[j] = sigm(dm[H + j]);
+            s->r[j] = q_apply(s->rf[j], ssig, ba, &s->p_r[j]);
+            s->z[j] = q_apply(s->zf[j], ssig, ba, &s->p_z[j]);
+            real m1 = q_apply(s->r[j] * dmnh[j], smul, ba, &s->p_m1[j]);
+            real an = q_apply(dm[2 * H + j] + m1, sadd, ba, &s->p_an[j]);
+            s->nf[j] = tanhr(an);
+            s->n[j] = q_apply(s->nf[j], stanh, ba, &s->p_n[j]);
+            s->omz[j] = q_apply((real)1 + (-s->z[j]), sadd, ba, &s->p_omz[j]);
+            real m3 = q_apply(s->omz[j] * s->n[j], smul, ba, &s->p_m3[j]);
+            real m2 = q_apply(s->z[j] * h[j], smul, ba, &s->p_m2[j]);
+            s->h[j] = q_apply(m3 + m2, sadd, ba, &s->p_ah[j]);
+        }
+        for (int j = 0; j < H; ++j) { h[j] = s->h[j]; s->ho[j] = q_apply(h[j], soa, ba, &s->p_ho[j]); }
+        for (int c = 0; c < 2; ++c) {
+            double a = 0;
+            for (int j = 0; j < H; ++j) a += (double)s->ho[j] * (double)qwo[c * H + j];
+            y[2 * t + c] = eval_mode ? q_apply((real)a, soo, 16, NULL) : (real)a;
+        }
+        for (int c = 0; c < 3; ++c) {   /* the TCN skip stays float (Conv1d / Hardswish are not swapped) */
+            real a = 0;
+            for (int i = 0; i < 2; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    int tt = t + 16 * (k - 1);
+                    if (tt >= 0 && tt < T) a += p[L->o_tcn0 + (c * 2 + i) * 3 + k] * x[2 * tt + i];
+                }
+            s->s1[c] = a;
+        }
+        for (int o = 0; o < 2; ++o) {
+            real a = 0;
+            for (int c = 0; c < 3; ++c) a += p[L->o_tcn2 + o * 3 + c] * hswish(s->s1[c]);
+            s->s2[o] = a;
+            y[2 * t + o] += hswish(a);
+        }
+    }
+    if (stats) { stats[0] += zx; stats[1] += 6.0 * T; stats[2] += zh; stats[3] += (double)H * T; }
+}
+static void qtres_seq_bwd(const odpd_model_t* m, const qgru_layout_t* L, const real* p, int T, const real* x, const real* dy,
+                          const qgru_step_t* S, real* dp, real* dx, const real* qwx, const real* qwh, const real* qwo,
+                          real* dqwx, real* dqwh, real* dqwo) {
+    int H = L->H;
+    (void)m;
+    real Gh[MAXH] = {0}, Ghp[MAXH] = {0}, Gxp[6] = {0}, Gdm[3 * MAXH] = {0}, Gnh[MAXH] = {0};
+    real* dfeat = (real*)calloc((size_t)T * 6, sizeof(real));
+    if (dx) memset(dx, 0, sizeof(real) * 2 * T);
+    for (int t = T - 1; t >= 0; --t) {
+        const qgru_step_t* s = &S[t];
+        for (int c = 0; c < 2; ++c) {
+            real d = dy[2 * t + c];
+            for (int j = 0; j < H; ++j) { dqwo[c * H + j] += d * s->ho[j]; Gh[j] += d * qwo[c * H + j] * s->p_ho[j]; }
+        }
+        {
+            real dh1[3] = {0};
+            for (int o = 0; o < 2; ++o) {
+                real d2 = dy[2 * t + o] * hswish_grad(s->s2[o]);
+                for (int c = 0; c < 3; ++c) { dp[L->o_tcn2 + o * 3 + c] += d2 * hswish(s->s1[c]); dh1[c] += d2 * p[L->o_tcn2 + o * 3 + c]; }
+            }
+            for (int c = 0; c < 3; ++c) {
+                real d1 = dh1[c] * hswish_grad(s->s1[c]);
+                for (int i = 0; i < 2; ++i)
+                    for (int k = 0; k < 3; ++k) {
+                        int tt = t + 16 * (k - 1);
+                        if (tt >= 0 && tt < T) {
+                            dp[L->o_tcn0 + (c * 2 + i) * 3 + k] += d1 * x[2 * tt + i];
+                            if (dx) dx[2 * tt + i] += d1 * p[L->o_tcn0 + (c * 2 + i) * 3 + k];
+                        }
+                    }
+            }
+        }
+        real Ghprev[MAXH];
+        for (int j = 0; j < H; ++j) {
+            real g = Gh[j] * s->p_ah[j];
+            real dm3 = g * s->p_m3[j], dm2 = g * s->p_m2[j];
+            real domz = dm3 * s->n[j], dn = dm3 * s->omz[j];
+            real dz = dm2 * s->hp[j] - domz * s->p_omz[j];
+            Ghprev[j] = dm2 * s->z[j];
+            real dan = dn * s->p_n[j] * ((real)1 - s->nf[j] * s->nf[j]) * s->p_an[j];
+            Gdm[2 * H + j] += dan;
+            real dm1 = dan * s->p_m1[j];
+            real dr = dm1 * s->dmnh[j];
+            Gnh[j] += dm1 * s->r[j];
+            Gdm[j] += dr * s->p_r[j] * s->rf[j] * ((real)1 - s->rf[j]);
+            Gdm[H + j] += dz * s->p_z[j] * s->zf[j] * ((real)1 - s->zf[j]);
+        }
+        real ddx[6] = {0}, ddh[MAXH] = {0};
+        for (int j = 0; j < H; ++j)
+            for (int k = 0; k < 3; ++k) {
+                real gx = Gdm[k * H + j], gh = (k < 2) ? Gdm[k * H + j] : Gnh[j];
+                for (int i = 0; i < 6; ++i) { dqwx[(k * H + j) * 6 + i] += gx * s->fq[i]; ddx[i] += gx * qwx[(k * H + j) * 6 + i]; }
+                for (int i = 0; i < H; ++i) { dqwh[(k * H + j) * H + i] += gh * s->hq[i]; ddh[i] += gh * qwh[(k * H + j) * H + i]; }
+            }
+        for (int i = 0; i < 6; ++i) {
+            real mk = s->mx[i], g = ddx[i] * s->px[i];
+            dfeat[t * 6 + i] += mk * g + mk * Gxp[i];
+            Gxp[i] = ((real)1 - mk) * Gxp[i] - mk * g;
+        }
+        for (int j = 0; j < H; ++j) {
+            real mk = s->mh[j], g = ddh[j] * s->ph[j];
+            Ghprev[j] += mk * g + mk * Ghp[j];
+            Ghp[j] = ((real)1 - mk) * Ghp[j] - mk * g;
+            Gh[j] = Ghprev[j];
+        }
+    }
+    if (dx)
+        for (int t = 0; t < T; ++t) {
+            const real* df = dfeat + t * 6;
+            real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q, a = (real)sqrt((double)a2);
+            real da = df[2] + (real)3 * a * a * df[3];
+            dx[2 * t] += df[0] + da * I / a; dx[2 * t + 1] += df[1] + da * Q / a;
+            int tn = (t + 1) % T;
+            dx[2 * tn] += df[4]; dx[2 * tn + 1] += df[5];
+        }
+    free(dfeat);
+}
+/* quantised weights and their pass masks (STE to the float master weights); order: x2h, h2h, fc_out, fc_hid */
+static int qat_nq(const qgru_layout_t* L, int* nx, int* nh, int* no, int* nhid) {
+    *nx = 3 * L->H * L->F; *nh = 3 * L->H * L->H; *no = 2 * L->OW; *nhid = L->dgru ? L->H * L->H : 0;
+    return *nx + *nh + *no + *nhid;
+}
+static void qgru_quant_weights(const qgru_layout_t* L, const real* p, real* qw, real* mk) {
+    int nx, nh, no, nhid; qat_nq(L, &nx, &nh, &no, &nhid);
+    real sx = q_pow2(p[L->o_sxw]), sh = q_pow2(p[L->o_shw]), so = q_pow2(p[L->o_sow]);
+    for (int i = 0; i < nx; ++i) qw[i] = q_apply(p[L->o_wx + i], sx, L->bits_w, mk ? &mk[i] : NULL);
+    for (int i = 0; i < nh; ++i) qw[nx + i] = q_apply(p[L->o_wh + i], sh, L->bits_w, mk ? &mk[nx + i] : NULL);
+    for (int i = 0; i < no; ++i) qw[nx + nh + i] = q_apply(p[L->o_wo + i], so, L->bits_w, mk ? &mk[nx + nh + i] : NULL);
+    if (nhid) {
+        real shd = q_pow2(p[L->o_shidw]);
+        for (int i = 0; i < nhid; ++i) qw[nx + nh + no + i] = q_apply(p[L->o_whid + i], shd, L->bits_w, mk ? &mk[nx + nh + no + i] : NULL);
+    }
+}
+
+/* forward of the quantised model; eval_mode != 0 applies fc_out's 16-bit output quantiser (quant_layers.py:77-80);
+ * stats (nullable, 4 doubles) accumulates the delta cell's sparsity counters */
+int oracle_qat_fwd(const odpd_model_t* m, int B, int T, const real* params, const real* x, real* y, int eval_mode, double* stats) {
     if (!m || !is_qat(m) || !params || !x || !y || B <= 0 || T <= 0 || m->hidden > MAXH) return ODPD_EINVAL;
     qgru_layout_t L; qgru_layout(m, &L);
-    int H = L.H;
-    real* qw = (real*)malloc(sizeof(real) * (3 * H * 4 + 3 * H * H + 2 * H));
-    real *qwx = qw, *qwh = qw + 3 * H * 4, *qwo = qwh + 3 * H * H;
-    qgru_quant_weights(&L, params, qwx, qwh, qwo, NULL, NULL, NULL);
-#pragma omp parallel for schedule(static)
-    for (int b = 0; b < B; ++b)
-        qgru_seq_fwd(m, &L, params, T, x + (int64_t)b * T * 2, y + (int64_t)b * T * 2, NULL, eval_mode, qwx, qwh, qwo);
+    int nx, nh, no, nhid, nq = qat_nq(&L, &nx, &nh, &no, &nhid);
+    real* qw = (real*)malloc(sizeof(real) * nq);
+    real *qwx = qw, *qwh = qw + nx, *qwo = qwh + nh, *qwhid = qwo + no;
+    qgru_quant_weights(&L, params, qw, NULL);
+    double st[4] = {0, 0, 0, 0};
+#pragma omp parallel
+    {
+        double sl[4] = {0, 0, 0, 0};
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b) {
+            if (L.tres) qtres_seq_fwd(m, &L, params, T, x + (int64_t)b * T * 2, y + (int64_t)b * T * 2, NULL, eval_mode, qwx, qwh, qwo, sl);
+            else qgru_seq_fwd(m, &L, params, T, x + (int64_t)b * T * 2, y + (int64_t)b * T * 2, NULL, eval_mode, qwx, qwh, qwo, qwhid);
+        }
+#pragma omp critical
+        for (int i = 0; i < 4; ++i) st[i] += sl[i];
+    }
+    if (stats) for (int i = 0; i < 4; ++i) stats[i] += st[i];
     free(qw);
     return 0;
 }
@@ -1733,12 +1958,12 @@ int oracle_qat_fwd(const odpd_model_t* m, int B, int T, const real* params, cons
 int oracle_qat_bwd(const odpd_model_t* m, int B, int T, const real* params, const real* x, const real* dy, real* dparams, real* dx) {
     if (!m || !is_qat(m) || !params || !x || !dy || !dparams || B <= 0 || T <= 0 || m->hidden > MAXH) return ODPD_EINVAL;
     qgru_layout_t L; qgru_layout(m, &L);
-    int H = L.H, nx = 3 * H * 4, nh = 3 * H * H, no = 2 * H, nq = nx + nh + no;
-    int64_t P = oracle_param_count(m);
+    int nx, nh, no, nhid, nq = qat_nq(&L, &nx, &nh, &no, &nhid);
+    int64_t P = L.P;
     memset(dparams, 0, sizeof(real) * P);
     real* qw = (real*)malloc(sizeof(real) * 2 * nq);
-    real *qwx = qw, *qwh = qw + nx, *qwo = qwh + nh, *mk = qw + nq;
-    qgru_quant_weights(&L, params, qwx, qwh, qwo, mk, mk + nx, mk + nx + nh);
+    real *qwx = qw, *qwh = qw + nx, *qwo = qwh + nh, *qwhid = qwo + no, *mk = qw + nq;
+    qgru_quant_weights(&L, params, qw, mk);
     real* dq = (real*)calloc(nq, sizeof(real));
 #pragma omp parallel
     {
@@ -1749,9 +1974,15 @@ int oracle_qat_bwd(const odpd_model_t* m, int B, int T, const real* params, cons
 #pragma omp for schedule(static)
         for (int b = 0; b < B; ++b) {
             const real* xb = x + (int64_t)b * T * 2;
-            qgru_seq_fwd(m, &L, params, T, xb, ytmp, S, 0, qwx, qwh, qwo);
-            qgru_seq_bwd(m, &L, params, T, xb, dy + (int64_t)b * T * 2, S, dp, dx ? dx + (int64_t)b * T * 2 : NULL, qwx, qwh, qwo,
-                         dql, dql + nx, dql + nx + nh);
+            real* dxb = dx ? dx + (int64_t)b * T * 2 : NULL;
+            if (L.tres) {
+                qtres_seq_fwd(m, &L, params, T, xb, ytmp, S, 0, qwx, qwh, qwo, NULL);
+                qtres_seq_bwd(m, &L, params, T, xb, dy + (int64_t)b * T * 2, S, dp, dxb, qwx, qwh, qwo, dql, dql + nx, dql + nx + nh);
+            } else {
+                qgru_seq_fwd(m, &L, params, T, xb, ytmp, S, 0, qwx, qwh, qwo, qwhid);
+                qgru_seq_bwd(m, &L, params, T, xb, dy + (int64_t)b * T * 2, S, dp, dxb, qwx, qwh, qwo, qwhid,
+                             dql, dql + nx, dql + nx + nh, dql + nx + nh + no);
+            }
         }
 #pragma omp critical
         {
@@ -1763,6 +1994,7 @@ int oracle_qat_bwd(const odpd_model_t* m, int B, int T, const real* params, cons
     for (int i = 0; i < nx; ++i) dparams[L.o_wx + i] = dq[i] * mk[i];
     for (int i = 0; i < nh; ++i) dparams[L.o_wh + i] = dq[nx + i] * mk[nx + i];
     for (int i = 0; i < no; ++i) dparams[L.o_wo + i] = dq[nx + nh + i] * mk[nx + nh + i];
+    for (int i = 0; i < nhid; ++i) dparams[L.o_whid + i] = dq[nx + nh + no + i] * mk[nx + nh + no + i];
     free(qw); free(dq);
     return 0;
 }

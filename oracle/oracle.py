@@ -85,13 +85,14 @@ class Oracle:
             raise RuntimeError(f"oracle_backbone_bwd failed rc={rc}")
         return dp, dx
 
-    def qat_forward(self, m, params, x, eval_mode=False):
-        """Quantisation-aware QGRU (m.bits_w > 0): train-mode (float output) or eval-mode (16-bit output grid)."""
+    def qat_forward(self, m, params, x, eval_mode=False, stats=None):
+        """Quantised model (m.bits_w > 0; gru, dgru, qgru, qgru_amp1, deltagru_tcnskip): train-mode (float output) or eval-mode
+        (16-bit output grid).  `stats` (4 doubles) accumulates the delta cell's sparsity counters."""
         x = self._a(x)
         params = self._a(params)
         y = np.empty_like(x)
         rc = self.lib.oracle_qat_fwd(C.byref(m), x.shape[0], x.shape[1], self._p(params), self._p(x), self._p(y),
-                                     1 if eval_mode else 0)
+                                     1 if eval_mode else 0, self._p(stats))
         if rc:
             raise RuntimeError(f"oracle_qat_fwd failed rc={rc}")
         return y
