@@ -58,11 +58,14 @@ enum odpd_error {
 /* Model descriptor: what `CoreModel.__init__` receives (models.py:11). */
 typedef struct odpd_model {
     int32_t backbone; /* enum odpd_backbone */
-    int32_t hidden;   /* hidden_size (channels for tcnn; memory_length for gmp): <= 32 (pgjanet, QAT: <= 16; tcnn: <= 64; gmp: 11; rvtdcnn: fc_hid_size),
+    int32_t hidden;   /* hidden_size (channels for tcnn; memory_length for gmp): <= 32 (pgjanet: <= 16; tcnn: <= 64; gmp: 11; rvtdcnn: fc_hid_size),
                          else ODPD_EUNSUPPORTED */
     float thx;        /* delta threshold on inputs  (deltagru*, models.py:11) */
     float thh;        /* delta threshold on hidden state */
-    int32_t bits_w;   /* QAT weight bits (0 = float model) — quant/quant_envs.py:145; dvrjanet: num_dvr_units (models.py:119) */
+    int32_t bits_w;   /* QAT weight bits (0 = float model) — quant/quant_envs.py:145: > 0 on gru, dgru, qgru, qgru_amp1 or deltagru_tcnskip selects the
+                         model the reference's surgery makes of it (quant_envs.py:114-130, 290-306: GRU of GRUCells / quantised delta layer,
+                         INT_Linear heads; `params` then follows THAT model's named_parameters(), quantiser scales included);
+                         dvrjanet: num_dvr_units (models.py:119) */
     int32_t bits_a;   /* QAT activation bits */
     int32_t flags;    /* ODPD_FLAG_* */
 } odpd_model_t;

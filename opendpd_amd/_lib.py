@@ -13,6 +13,7 @@ LOSS_IDS = {"l2": 0, "l1": 1}
 FLAG_EVAL, FLAG_NEED_DX = 1, 2      # odpd_model_t.flags (include/opendpd_hip.h)
 LOSS_COLS = 4        # extra columns of a partials row (column P = loss partial sum)
 LOSS_WS = 1 + 256    # floats behind `loss_out` (result + per-block scratch)
+ABI_VERSION = 7      # odpd_abi_version() of the library these argument lists belong to
 
 
 class ModelDesc(C.Structure):
@@ -101,6 +102,11 @@ def load():
         fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # the argument lists above are those of ONE ABI: a stale build (e.g. an experiment library behind $OPENDPD_HIP_LIB) would be
+    # called with mismatched arguments through ctypes without any complaint
+    if lib.odpd_abi_version() != ABI_VERSION or lib.odpd_built_arch() != b"gfx950":
+        raise RuntimeError(f"{path}: ABI version {lib.odpd_abi_version()} / arch {lib.odpd_built_arch()!r}, this package binds ABI "
+                           f"{ABI_VERSION} for gfx950 — rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
 

@@ -7,10 +7,22 @@ using namespace odpd;
 namespace {
 enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP, FAM_RVTDCNN, FAM_DVR, FAM_BOJ, FAM_APN, FAM_MCL };
 inline Family family_of(int bb);
-// a quantisation-aware model: qgru / qgru_amp1 with bits_w > 0 (quant/quant_envs.py:138-171)
+// a quantisation-aware model: bits_w > 0 on one of the backbones the reference's surgery turns into a quantised cell
+// (quant/quant_envs.py:114-130, 290-306: gru, dgru, qgru, qgru_amp1 through the GRU swap; deltagru_tcnskip through its op modules)
 inline Family family_of(const odpd_model_t* m) {
-    if (m->bits_w > 0 && (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1)) return FAM_QAT;
+    if (m->bits_w > 0 && (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1 || m->backbone == ODPD_GRU || m->backbone == ODPD_DGRU ||
+                          m->backbone == ODPD_TRES_DELTAGRU))
+        return FAM_QAT;
     return family_of((int)m->backbone);
+}
+// which QAT kernels serve a batch: the row-rotated ones (qgru_family.hip: qgru / qgru_amp1, hidden <= 16, 4 sequences per wave) while
+// the batch leaves the chip mostly empty, the 16-sequences-per-wave ones (qat_s16.hip) otherwise and for every other kind / hidden size
+inline bool qat_uses_s16(const odpd_model_t* m, int B) {
+    const bool rot_ok = (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1) && m->hidden <= 16;
+    if (!rot_ok) return true;
+    long min_batch = tuning().s16_min_batch;
+    if (min_batch < 0) min_batch = 16L * 2 * device_cus();
+    return B >= min_batch;
 }
 inline Family family_of(int bb) {
     switch (bb) {
@@ -74,12 +86,12 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 6; }   // 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
+extern "C" int odpd_abi_version(void) { return 7; }   // 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     if (!model_ok(m)) return ODPD_EINVAL;
-    if (family_of(m) == FAM_QAT) return qgru_param_count(m);
+    if (family_of(m) == FAM_QAT) return qat_s16_param_count(m);
     const int64_t H = m->hidden, F = feat_dim(m->backbone);
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
@@ -109,6 +121,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_BOJ) return bojanet_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_APN) return apnrru_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_MCL) return mcldnn_ckpt_floats(m, B, T);
+    if (family_of(m) == FAM_QAT && qat_uses_s16(m, B)) return qat_s16_ckpt_floats(m, B, T);
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
@@ -146,7 +159,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
     case FAM_GMP: return gmp_rows(m, B, T);
     case FAM_RVTDCNN: return fused ? rvtdcnn_train_rows(m, B, T) : rvtdcnn_rows(m, B, T);
-    case FAM_QAT: return fused ? (int64_t)ODPD_EUNSUPPORTED : qgru_family_rows(m, B);
+    case FAM_QAT: return fused ? (int64_t)ODPD_EUNSUPPORTED : (qat_uses_s16(m, B) ? (int64_t)qat_s16_rows(m, B) : (int64_t)qgru_family_rows(m, B));
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -179,7 +192,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_TCNN: return tcnn_fwd((hipStream_t)stream, m, a);
     case FAM_GMP: return gmp_fwd((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_fwd((hipStream_t)stream, m, a);
-    case FAM_QAT: return qgru_family_fwd((hipStream_t)stream, m, a);
+    case FAM_QAT: return qat_uses_s16(m, B) ? qat_s16_launch((hipStream_t)stream, m, a, 1) : qgru_family_fwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -210,6 +223,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_GMP: return gmp_bwd((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_bwd((hipStream_t)stream, m, a);
     case FAM_QAT:
+        if (qat_uses_s16(m, B)) return qat_s16_launch((hipStream_t)stream, m, a, 2);      // (checks its own checkpoint count)
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return qgru_family_bwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;

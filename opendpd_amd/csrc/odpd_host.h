@@ -252,5 +252,11 @@ int qgru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_rows(const odpd_model_t* m, int B);
 int64_t qgru_param_count(const odpd_model_t* m);
+// quantised gru / dgru / qgru / qgru_amp1 / deltagru_tcnskip on the 16-sequences-per-wave mapping, hidden <= 32 (qat_s16.hip): mode 1 forward, 2 backward
+bool qat_s16_supported(const odpd_model_t* m);
+int qat_s16_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
+int qat_s16_rows(const odpd_model_t* m, int B);
+int64_t qat_s16_param_count(const odpd_model_t* m);
+int64_t qat_s16_ckpt_floats(const odpd_model_t* m, int B, int T);
 
 }  // namespace odpd

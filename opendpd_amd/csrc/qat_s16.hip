@@ -1,0 +1,1371 @@
+// qat_s16.hip — quantisation-aware models on the 16-sequences-per-wave ("S16") mapping.
+//
+// The reference's surgery is generic (quant/quant_envs.py:114-130 swaps every nn.GRU for the Python GRU of GRUCells,
+// :290-306 every Sigmoid / Tanh / Add / Mul module and every nn.Linear), so `--quant` applies to
+//   gru               backbones/gru.py        GRUCell on [I,Q]                      + INT_Linear fc_out
+//   dgru              backbones/dgru.py       GRUCell on [I,Q,a,a^3,sin,cos]        + INT_Linear fc_hid, relu, cat, INT_Linear fc_out
+//   qgru / qgru_amp1  backbones/qgru*.py      GRUCell on 4 features, ANY hidden size (bash_scripts/quant_qgru_dpd_regr.sh:74)
+//   deltagru_tcnskip  backbones/deltagru_tcnskip.py:156-162, 266-291: its delta layer routes the gate arithmetic through
+//                     such modules — the OpenDPDv2 recipe (bash_scripts/OpenDPDv2.sh:84-117, W16A16 from a float checkpoint)
+// GRUCell (quant/modules/gru.py:43-59):  x_t = x2h(x), h_t = h2h(h)  (INT_Linear: F.linear(q_a(in), q_w(W), b), quant_layers.py:70-76)
+//   r = Qsig(Qadd(x_r + h_r)), z likewise, n = Qtanh(Qadd(x_n + Qmul(r h_n))), h' = Qadd(Qmul(z h) + Qmul((1 - z) n))
+// delta layer:  dm += x2h(q_a(dx)) + h2h(q_a(dh)) on the thresholded deltas (fp32 accumulators, bias-free),
+//   r = Qsig(dm_r), z = Qsig(dm_z), n = Qtanh(Qadd(dm_n + Qmul(r dm_nh))), h' = Qadd(Qmul(Qadd(1 - z) n) + Qmul(z h)),
+//   y = fc_out(h') [+ 16-bit output quantiser in eval mode] + float TCN skip.
+// Quantiser (quantizers.py:15-97): s = 2^round(log2|scale|), q(x) = rint(clamp(x / s, Qn, Qp)) s, straight-through gradient
+// inside the clamp range, exactly 0 for the scale parameters.
+//
+// Mapping as in gru_s16n.hip / delta_s16.hip: lane (n = sequence, q = unit quad) owns units 16 kt + 4 q + i of NT tiles
+// (hidden <= 16 NT, NT <= 2); every mat-vec is an exact-fp32 v_mfma_f32_16x16x4_f32 whose A operand is the QUANTISED weight
+// (streamed from an LDS table) and whose B operand is the lane's own quantised activation.  On 8-bit grids every product and
+// every partial sum is an integer multiple of 2^-(e_a + e_w) below 2^24: the accumulations are exact in any order, the fp32 bias
+// is added once afterwards like F.linear does, and the results are BIT-IDENTICAL with the reference's.  (16-bit grids: 32-bit
+// products, the summation order becomes visible at the level of one LSB — in the reference as well.)
+// Gates: for <= 8 activation bits sigmoid / tanh inputs on the add-quantiser grid are looked up in 2^bits-entry LDS tables
+// (evaluated in double at kernel start); the delta cell's sigmoids take the raw accumulators: their QUANTISED value is found
+// exactly from a table of the rounding boundaries logit((k - 1/2) s) around an fp32 first guess.  Wider grids: double per element.
+// This file is compiled with FP contraction off: a fused multiply-add would change roundings the reference does not have.
+#include <type_traits>
+
+#include "odpd_s16.h"
+
+#pragma clang fp contract(off)
+
+namespace odpd {
+namespace q16 {
+
+enum { K_GRU = 0, K_DGRU = 1, K_Q4 = 2, K_A4 = 3, K_TRES = 4 };
+constexpr int kHalo = 16;                                   // TCN taps at t-16, t, t+16
+
+template <int MK> struct Kind {
+    static constexpr bool TRES = MK == K_TRES, DGRU = MK == K_DGRU;
+    static constexpr int F = MK == K_GRU ? 2 : ((MK == K_Q4 || MK == K_A4) ? 4 : 6);
+    static constexpr int NCH = (F + 3) / 4;                 // feature-slot chunks (slot 4c+q on quad q)
+    static constexpr int HALO = TRES ? kHalo : 0;
+    static constexpr int XSTRIDE = kChunk + 2 * HALO + 1;   // float2 per sequence row of the staged x
+};
+
+// parameter layout = named_parameters() of the quantised model (see oracle/odpd_oracle.c::qgru_layout)
+struct QatLayout {
+    int kind, H, F, OW;
+    int o_wx, o_bx, o_sxw, o_sxa, o_sxo, o_wh, o_bh, o_shw, o_sha, o_sho, o_ssig, o_stanh, o_sadd, o_smul, o_wo, o_bo, o_sow, o_soa,
+        o_soo, o_whid, o_bhid, o_shidw, o_shida, o_shido, o_tcn0, o_tcn2, P;
+};
+__host__ __device__ inline QatLayout qat_layout(int kind, int H) {
+    QatLayout L;
+    L.kind = kind; L.H = H;
+    L.F = kind == K_GRU ? 2 : ((kind == K_Q4 || kind == K_A4) ? 4 : 6);
+    L.OW = kind == K_DGRU ? H + 6 : H;
+    const int F = L.F;
+    int o = 0;
+    L.o_bx = L.o_bh = L.o_bo = L.o_whid = L.o_bhid = L.o_shidw = L.o_shida = L.o_shido = L.o_tcn0 = L.o_tcn2 = 0;
+    if (kind == K_TRES) {
+        L.o_wx = o; o += 3 * H * F; L.o_sxw = o++; L.o_sxa = o++; L.o_sxo = o++;
+        L.o_wh = o; o += 3 * H * H; L.o_shw = o++; L.o_sha = o++; L.o_sho = o++;
+        L.o_sadd = o++; L.o_smul = o++; L.o_ssig = o++; L.o_stanh = o++;
+        L.o_wo = o; o += 2 * H; L.o_sow = o++; L.o_soa = o++; L.o_soo = o++;
+        L.o_tcn0 = o; o += 18; L.o_tcn2 = o; o += 6;
+    } else {
+        L.o_wx = o; o += 3 * H * F; L.o_bx = o; o += 3 * H; L.o_sxw = o++; L.o_sxa = o++; L.o_sxo = o++;
+        L.o_wh = o; o += 3 * H * H; L.o_bh = o; o += 3 * H; L.o_shw = o++; L.o_sha = o++; L.o_sho = o++;
+        L.o_ssig = o++; L.o_stanh = o++; L.o_sadd = o++; L.o_smul = o++;
+        L.o_wo = o; o += 2 * L.OW; L.o_bo = o; o += 2; L.o_sow = o++; L.o_soa = o++; L.o_soo = o++;
+        if (kind == K_DGRU) { L.o_whid = o; o += H * H; L.o_bhid = o; o += H; L.o_shidw = o++; L.o_shida = o++; L.o_shido = o++; }
+    }
+    L.P = o;
+    return L;
+}
+
+__device__ __forceinline__ float pow2_scale(float scale) { return exp2f(rintf(log2f(fabsf(scale)))); }
+struct Quant { float s, inv, qn, qp; };
+__device__ __forceinline__ Quant make_quant(float scale, int bits) {
+    Quant q; q.s = pow2_scale(scale); q.inv = 1.0f / q.s; q.qn = -(float)(1 << (bits - 1)); q.qp = (float)((1 << (bits - 1)) - 1);
+    return q;
+}
+// clamp as one v_med3_f32; the straight-through pass mask "Qn <= x/s <= Qp" is "the clamp left x/s unchanged"
+__device__ __forceinline__ float qapply(float x, const Quant& q) {
+    const float v = x * q.inv;
+    return rintf(__builtin_amdgcn_fmed3f(v, q.qn, q.qp)) * q.s;
+}
+__device__ __forceinline__ bool qpassb(float x, const Quant& q) {
+    const float v = x * q.inv;
+    return __builtin_amdgcn_fmed3f(v, q.qn, q.qp) == v;
+}
+__device__ __forceinline__ float qpass(float x, const Quant& q) { return qpassb(x, q) ? 1.0f : 0.0f; }
+// activation-side quantisers (wave-uniform)
+struct QSc { Quant xa, ha, oa, sig, tnh, add, mul, out, hida; };
+
+// table groups ([group][lane] float4) and sizes for NT tiles of 16 hidden units
+template <int MK, int NT> struct QT {
+    using K = Kind<MK>;
+    static constexpr int NB = K::TRES ? 0 : 3 * NT;
+    static constexpr int IH = 0;                          // g*NT + mt           : (chunk 0, chunk 1) q_w(W_x)[g][16mt+m][4e+q]
+    static constexpr int HH = IH + 3 * NT;                // (g*NT + mt)*NT + kt : q_w(W_h)[g][16mt+m][16kt+4q+e]
+    static constexpr int BX = HH + 3 * NT * NT;           // g*NT + mt           : b_x[g][16mt+4q+e]   (GRUCell)
+    static constexpr int BH = BX + NB;                    //                       b_h
+    static constexpr int WOUT = BH + NB;                  // cc*NT + mt          : q_w(fc_out)[cc][16mt+4q+e]
+    static constexpr int HID = WOUT + 2 * NT;             // mt*NT + kt          : q_w(fc_hid)[16mt+m][16kt+4q+e]   (dgru)
+    static constexpr int BHID = HID + (K::DGRU ? NT * NT : 0);
+    static constexpr int WOF = BHID + (K::DGRU ? NT : 0); // one group: q_w(fc_out)[0][H+q], [0][H+4+q], [1][H+q], [1][H+4+q]
+    static constexpr int NG_FWD = WOF + (K::DGRU ? 1 : 0);
+    static constexpr int HHT = NG_FWD;                    // (g*NT + mt)*NT + kt : q_w(W_h)[g][16kt+4q+e][16mt+m]
+    static constexpr int HIDT = HHT + 3 * NT * NT;        // mt*NT + kt          : q_w(fc_hid)[16kt+4q+e][16mt+m]
+    static constexpr int NG_BWD = HIDT + (K::DGRU ? NT * NT : 0);
+    static constexpr int IHT = NG_BWD;                    // g*NT + kt : q_w(W_x)[g][16kt+4q+e][slot(m)], slot(m) = 4 (m & 3) + (m >> 2)
+    static constexpr int NG_DX = IHT + 3 * NT;
+    static constexpr int S = NT == 1 ? 2 : 1;             // BPTT checkpoint stride of this family (what the 512-register file holds)
+    static constexpr int kCk = K::TRES ? 6 * NT + 1 : NT; // float4 per lane per checkpoint
+    static constexpr int kTiles = 5 * NT + 1 + (K::DGRU ? 2 * NT : 0);
+};
+
+struct WQ { Quant x, h, o, hid; };       // weight quantisers
+__device__ __forceinline__ WQ make_wq(const float* pl, const QatLayout& L, int bits_w) {
+    WQ w;
+    w.x = make_quant(pl[L.o_sxw], bits_w); w.h = make_quant(pl[L.o_shw], bits_w); w.o = make_quant(pl[L.o_sow], bits_w);
+    w.hid = L.kind == K_DGRU ? make_quant(pl[L.o_shidw], bits_w) : w.o;
+    return w;
+}
+
+template <int MK, int NT>
+__device__ __forceinline__ float4 q16_entry(const float* pl, const QatLayout& L, const WQ& wq, int grp, int m, int q) {
+    using T = QT<MK, NT>;
+    using K = Kind<MK>;
+    constexpr int F = K::F;
+    const int H = L.H;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (K::DGRU && grp == T::WOF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int cc = e >> 1, slot = 4 * (e & 1) + q;
+            v[e] = slot < 6 ? qapply(pl[L.o_wo + cc * L.OW + H + slot], wq.o) : 0.0f;
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (grp < T::HH) {
+            const int g = grp / NT, o = 16 * (grp % NT) + m, slot = 4 * e + q;
+            v[e] = (e < K::NCH && slot < F && o < H) ? qapply(pl[L.o_wx + (g * H + o) * F + slot], wq.x) : 0.0f;
+        } else if (grp < T::BX) {
+            const int r = grp - T::HH, g = r / (NT * NT), o = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            v[e] = (o < H && k < H) ? qapply(pl[L.o_wh + (g * H + o) * H + k], wq.h) : 0.0f;
+        } else if (grp < T::BH) {
+            const int r = grp - T::BX, u = 16 * (r % NT) + 4 * q + e;
+            v[e] = u < H ? pl[L.o_bx + (r / NT) * H + u] : 0.0f;
+        } else if (grp < T::WOUT) {
+            const int r = grp - T::BH, u = 16 * (r % NT) + 4 * q + e;
+            v[e] = u < H ? pl[L.o_bh + (r / NT) * H + u] : 0.0f;
+        } else if (grp < T::HID) {
+            const int r = grp - T::WOUT, u = 16 * (r % NT) + 4 * q + e;
+            v[e] = u < H ? qapply(pl[L.o_wo + (r / NT) * L.OW + u], wq.o) : 0.0f;
+        } else if (grp < T::BHID) {
+            const int r = grp - T::HID, o = 16 * (r / NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            v[e] = (o < H && k < H) ? qapply(pl[L.o_whid + o * H + k], wq.hid) : 0.0f;
+        } else if (grp < T::WOF) {
+            const int u = 16 * (grp - T::BHID) + 4 * q + e;
+            v[e] = u < H ? pl[L.o_bhid + u] : 0.0f;
+        } else if (grp < T::HIDT) {
+            const int r = grp - T::HHT, g = r / (NT * NT), i = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            v[e] = (i < H && k < H) ? qapply(pl[L.o_wh + (g * H + k) * H + i], wq.h) : 0.0f;
+        } else if (grp < T::IHT) {
+            const int r = grp - T::HIDT, i = 16 * (r / NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            v[e] = (i < H && k < H) ? qapply(pl[L.o_whid + k * H + i], wq.hid) : 0.0f;
+        } else {
+            // transposed input weights with the output rows permuted so that D row 4 q' + i = slot 4 i + q': the MFMA result of
+            // lane (n, q) element c IS the gradient of the lane's own feature slot 4 c + q
+            const int r = grp - T::IHT, g = r / NT, k = 16 * (r % NT) + 4 * q + e, slot = 4 * (m & 3) + (m >> 2);
+            v[e] = (slot < F && k < H) ? qapply(pl[L.o_wx + (g * H + k) * F + slot], wq.x) : 0.0f;
+        }
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---- gate functions ----------------------------------------------------------------------------------------------------
+// LDS: lut[0 .. n) sigmoid, lut[n .. 2n) tanh over the add-quantiser grid (index = integer grid value - Qn), then (delta cell)
+// thr[0 .. K+1]: thr[0] = -inf, thr[k] = smallest float x with rint(sigmoid(x) / s_sig) >= k, thr[K+1] = +inf
+constexpr int kMaxThr = 132;
+__device__ __forceinline__ int sig_levels(const Quant& qsig) {      // K: quantised sigmoid values above 0 that can occur
+    if (qsig.s > 1.0f) return 0;
+    const float n = qsig.inv;                                      // 1 / s, an integer
+    return (int)(n < qsig.qp ? n : qsig.qp);
+}
+__device__ __forceinline__ void fill_luts(float* lut, const Quant& qadd, int bits, const Quant& qsig, bool with_thr) {
+    const int n = 1 << bits;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double x = (double)((float)(i + (int)qadd.qn) * qadd.s);
+        lut[i] = (float)(1.0 / (1.0 + exp(-x)));
+        lut[n + i] = (float)tanh(x);
+    }
+    if (with_thr) {
+        float* thr = lut + 2 * n;
+        const int K = sig_levels(qsig);
+        for (int k = threadIdx.x; k <= K + 1; k += blockDim.x) {
+            float t;
+            if (k == 0) t = -__builtin_inff();
+            else if (k == K + 1) t = __builtin_inff();
+            else {
+                const double p = ((double)k - 0.5) * (double)qsig.s;
+                if (p >= 1.0) t = __builtin_inff();
+                else {
+                    const double b = log(p / (1.0 - p));
+                    t = (float)b;
+                    if ((double)t < b) {                                                     // smallest float >= b
+                        const int bits = __builtin_bit_cast(int, t);
+                        t = __builtin_bit_cast(float, t > 0.0f ? bits + 1 : (t < 0.0f ? bits - 1 : 1));
+                    }
+                }
+            }
+            thr[k] = t;
+        }
+    }
+}
+template <bool LUT>
+__device__ __forceinline__ float sig_grid(float a, const QSc& qs, const float* lut) {
+    if constexpr (LUT) return lut[(int)(a * qs.add.inv) - (int)qs.add.qn];
+    else return (float)(1.0 / (1.0 + exp(-(double)a)));
+}
+template <bool LUT>
+__device__ __forceinline__ float tanh_grid(float a, const QSc& qs, const float* lut, int nlut) {
+    if constexpr (LUT) return lut[nlut + (int)(a * qs.add.inv) - (int)qs.add.qn];
+    else return (float)tanh((double)a);
+}
+// quantised sigmoid of an arbitrary float: rf = float sigmoid (for the derivative), r = q_sig(sigmoid(x)) exactly, pass mask
+template <bool LUT>
+__device__ __forceinline__ void sig_any(float x, const QSc& qs, const float* thr, int K, float& rf, float& r, bool& pass) {
+    if constexpr (LUT) {
+        rf = sigmoidf_(x);
+        const float v = rf * qs.sig.inv;
+        int k = (int)rintf(__builtin_amdgcn_fmed3f(v, 0.0f, (float)K));
+        k += (x >= thr[k + 1]) ? 1 : 0;
+        k -= (x < thr[k]) ? 1 : 0;
+        r = (float)k * qs.sig.s;
+        pass = v <= qs.sig.qp;
+    } else {
+        rf = (float)(1.0 / (1.0 + exp(-(double)x)));
+        r = qapply(rf, qs.sig);
+        pass = qpassb(rf, qs.sig);
+    }
+}
+
+// ---- features on the lane's slots ------------------------------------------------------------------------------------
+// fs[c] = feature 4c+q of the lane's sequence (0 beyond F), computed with the reference's operation order (torch.pow(i,2) +
+// torch.pow(q,2), sqrt, pow(amp,3) = a*a*a, true divisions) — the values are about to be rounded onto a grid
+template <int MK>
+__device__ __forceinline__ void q16_slots(float2 xv, float2 xn, const float (&oh)[4], float (&fs)[Kind<MK>::NCH]) {
+    const float I = xv.x, Q = xv.y;
+    if constexpr (MK == K_GRU) {
+        fs[0] = oh[0] * I + oh[1] * Q;
+    } else if constexpr (MK == K_Q4) {
+        const float a2 = I * I + Q * Q;
+        fs[0] = (oh[0] * I + oh[1] * Q) + (oh[2] * a2 + oh[3] * (a2 * a2));
+    } else {
+        const float a2 = I * I + Q * Q, a = sqrtf(a2), a3 = a * a * a;
+        fs[0] = (oh[0] * I + oh[1] * Q) + (oh[2] * a + oh[3] * a3);
+        if constexpr (MK == K_DGRU) fs[1] = oh[0] * (Q / a) + oh[1] * (I / a);        // sin, cos (dgru.py:66-68)
+        if constexpr (MK == K_TRES) fs[1] = oh[0] * xn.x + oh[1] * xn.y;              // torch.roll(x, -1) (deltagru_tcnskip.py:91-100)
+    }
+}
+
+enum { M_PH = 1, M_AR = 2, M_AZ = 4, M_R = 8, M_Z = 16, M_M1 = 32, M_AN = 64, M_N = 128, M_M2 = 256, M_M3 = 512, M_AH = 1024,
+       M_OMZ = 2048, M_MH = 4096 };
+#define QBIT(cond, bit) ((cond) ? (bit) : 0)
+
+// ---- GRUCell step ----------------------------------------------------------------------------------------------------
+template <int NT> struct SaveS { f32x4 hp[NT], hn[NT], r[NT], z[NT], n[NT], rf[NT], zf[NT], nf[NT], hnew[NT]; int mk[NT][4]; };
+
+template <int MK, int NT, bool LUT>
+__device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const float* lut, int nlut, const float (&fq)[Kind<MK>::NCH],
+                                         f32x4 (&h)[NT], SaveS<NT>& sv) {
+    using T = QT<MK, NT>;
+    constexpr int NCH = Kind<MK>::NCH;
+    f32x4 hq[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+        ODPD_EACH4 {
+            hq[kt][i] = qapply(h[kt][i], qs.ha);
+            sv.mk[kt][i] = QBIT(qpassb(h[kt][i], qs.ha), M_PH);
+        }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 xs[3][NT], hs[3][NT];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const float4 w = tab_ld(tl, (T::IH + g * NT + mt) * 64);
+            xs[g][mt] = mfma4(w.x, fq[0], z4);
+            if constexpr (NCH > 1) xs[g][mt] = mfma4(w.y, fq[1], xs[g][mt]);
+            hs[g][mt] = z4;
+        }
+        s16n_matvec<NT>(tl, T::HH + g * NT * NT, hq, hs[g]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        const float4 bxr = tab_ld(tl, (T::BX + 0 * NT + mt) * 64), bxz = tab_ld(tl, (T::BX + 1 * NT + mt) * 64),
+                     bxn = tab_ld(tl, (T::BX + 2 * NT + mt) * 64);
+        const float4 bhr = tab_ld(tl, (T::BH + 0 * NT + mt) * 64), bhz = tab_ld(tl, (T::BH + 1 * NT + mt) * 64),
+                     bhn = tab_ld(tl, (T::BH + 2 * NT + mt) * 64);
+        const f32x4 Bxr = as_f32x4(bxr), Bxz = as_f32x4(bxz), Bxn = as_f32x4(bxn), Bhr = as_f32x4(bhr), Bhz = as_f32x4(bhz), Bhn = as_f32x4(bhn);
+        ODPD_EACH4 {
+            const float hv = h[mt][i];
+            const float xr = xs[0][mt][i] + Bxr[i], xz = xs[1][mt][i] + Bxz[i], xn = xs[2][mt][i] + Bxn[i];
+            const float hr = hs[0][mt][i] + Bhr[i], hz = hs[1][mt][i] + Bhz[i], hn = hs[2][mt][i] + Bhn[i];
+            const float vr = xr + hr, vz = xz + hz;
+            const float ar = qapply(vr, qs.add), az = qapply(vz, qs.add);
+            int mk = sv.mk[mt][i];
+            mk |= QBIT(qpassb(vr, qs.add), M_AR) | QBIT(qpassb(vz, qs.add), M_AZ);
+            const float rf = sig_grid<LUT>(ar, qs, lut), zf = sig_grid<LUT>(az, qs, lut);
+            const float r = qapply(rf, qs.sig), z = qapply(zf, qs.sig);
+            mk |= QBIT(qpassb(rf, qs.sig), M_R) | QBIT(qpassb(zf, qs.sig), M_Z);
+            const float pm1 = r * hn, m1 = qapply(pm1, qs.mul);
+            mk |= QBIT(qpassb(pm1, qs.mul), M_M1);
+            const float vn = xn + m1, an = qapply(vn, qs.add);
+            mk |= QBIT(qpassb(vn, qs.add), M_AN);
+            const float nf = tanh_grid<LUT>(an, qs, lut, nlut);
+            const float n = qapply(nf, qs.tnh);
+            mk |= QBIT(qpassb(nf, qs.tnh), M_N);
+            const float pm2 = z * hv, pm3 = (1.0f - z) * n;
+            const float m2 = qapply(pm2, qs.mul), m3 = qapply(pm3, qs.mul);
+            mk |= QBIT(qpassb(pm2, qs.mul), M_M2) | QBIT(qpassb(pm3, qs.mul), M_M3);
+            const float vh = m2 + m3, hnew = qapply(vh, qs.add);
+            mk |= QBIT(qpassb(vh, qs.add), M_AH);
+            sv.hp[mt][i] = hv; sv.hn[mt][i] = hn; sv.r[mt][i] = r; sv.z[mt][i] = z; sv.n[mt][i] = n;
+            sv.rf[mt][i] = rf; sv.zf[mt][i] = zf; sv.nf[mt][i] = nf; sv.hnew[mt][i] = hnew; sv.mk[mt][i] = mk;
+            h[mt][i] = hnew;
+        }
+    }
+}
+
+// ---- delta cell step -------------------------------------------------------------------------------------------------
+template <int NT> struct StateD { f32x4 h[NT], hp[NT], dmr[NT], dmz[NT], dmn[NT], dmnh[NT]; float xp[2]; };
+template <int NT> struct SaveD {
+    f32x4 hp[NT], qdh[NT], nh[NT], r[NT], z[NT], n[NT], rf[NT], zf[NT], nf[NT], omz[NT], hnew[NT];
+    int mk[NT][4];
+    float fq[2];
+    int xm;                      // bit c: dx slot kept by the threshold; bit 2+c: its activation quantiser passes
+};
+
+template <int NT, bool LUT>
+__device__ __forceinline__ void delta_cell(TabPtr tl, const QSc& qs, const float* lut, int nlut, int K, const float (&fs)[2], float thx,
+                                           float thh, const bool (&slot_ok)[2], const f32x4 (&unit_ok)[NT], StateD<NT>& st,
+                                           SaveD<NT>& sv, float& zx, float& zh) {
+    using T = QT<K_TRES, NT>;
+    const float* thr = lut + 2 * nlut;
+    int xm = 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float d = fs[c] - st.xp[c];
+        const bool keep = !(__builtin_fabsf(d) < thx);                 // masked_fill(|d| < th, 0)  (deltagru_tcnskip.py:218-228)
+        const float dxm = keep ? d : 0.0f;
+        st.xp[c] = (__builtin_fabsf(d) >= thx) ? fs[c] : st.xp[c];
+        zx += (slot_ok[c] && dxm == 0.0f) ? 1.0f : 0.0f;
+        sv.fq[c] = qapply(dxm, qs.xa);
+        xm |= QBIT(keep, 1 << c) | QBIT(qpassb(dxm, qs.xa), 4 << c);
+    }
+    sv.xm = xm;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+        ODPD_EACH4 {
+            const float d = st.h[kt][i] - st.hp[kt][i];
+            const bool keep = !(__builtin_fabsf(d) < thh);
+            const float dhm = keep ? d : 0.0f;
+            st.hp[kt][i] = (__builtin_fabsf(d) >= thh) ? st.h[kt][i] : st.hp[kt][i];
+            zh += (unit_ok[kt][i] != 0.0f && dhm == 0.0f) ? 1.0f : 0.0f;
+            sv.qdh[kt][i] = qapply(dhm, qs.ha);
+            sv.mk[kt][i] = QBIT(keep, M_MH) | QBIT(qpassb(dhm, qs.ha), M_PH);
+        }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 xs[3][NT], hs[3][NT];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const float4 w = tab_ld(tl, (T::IH + g * NT + mt) * 64);
+            xs[g][mt] = mfma4(w.x, sv.fq[0], z4);
+            xs[g][mt] = mfma4(w.y, sv.fq[1], xs[g][mt]);
+            hs[g][mt] = z4;
+        }
+        s16n_matvec<NT>(tl, T::HH + g * NT * NT, sv.qdh, hs[g]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+        ODPD_EACH4 {
+            const float hv = st.h[mt][i];
+            // mac_x = x2h(dx) + dm; dm_r = mac_x_r + mac_h_r, dm_n = mac_x_n, dm_nh = mac_h_n + dm_nh  (deltagru_tcnskip.py:236-246)
+            const float dmr = (xs[0][mt][i] + st.dmr[mt][i]) + hs[0][mt][i];
+            const float dmz = (xs[1][mt][i] + st.dmz[mt][i]) + hs[1][mt][i];
+            const float dmn = xs[2][mt][i] + st.dmn[mt][i];
+            const float dmnh = hs[2][mt][i] + st.dmnh[mt][i];
+            st.dmr[mt][i] = dmr; st.dmz[mt][i] = dmz; st.dmn[mt][i] = dmn; st.dmnh[mt][i] = dmnh;
+            int mk = sv.mk[mt][i];
+            float rf, r, zf, z;
+            bool pr, pz;
+            sig_any<LUT>(dmr, qs, thr, K, rf, r, pr);
+            sig_any<LUT>(dmz, qs, thr, K, zf, z, pz);
+            mk |= QBIT(pr, M_R) | QBIT(pz, M_Z);
+            const float pm1 = r * dmnh, m1 = qapply(pm1, qs.mul);
+            mk |= QBIT(qpassb(pm1, qs.mul), M_M1);
+            const float vn = dmn + m1, an = qapply(vn, qs.add);
+            mk |= QBIT(qpassb(vn, qs.add), M_AN);
+            const float nf = tanh_grid<LUT>(an, qs, lut, nlut);
+            const float n = qapply(nf, qs.tnh);
+            mk |= QBIT(qpassb(nf, qs.tnh), M_N);
+            const float vo = 1.0f + (-z), omz = qapply(vo, qs.add);     // self.add(1, -gate_z)  (deltagru_tcnskip.py:290)
+            mk |= QBIT(qpassb(vo, qs.add), M_OMZ);
+            const float pm3 = omz * n, pm2 = z * hv;
+            const float m3 = qapply(pm3, qs.mul), m2 = qapply(pm2, qs.mul);
+            mk |= QBIT(qpassb(pm3, qs.mul), M_M3) | QBIT(qpassb(pm2, qs.mul), M_M2);
+            const float vh = m3 + m2, hnew = qapply(vh, qs.add);
+            mk |= QBIT(qpassb(vh, qs.add), M_AH);
+            sv.hp[mt][i] = hv; sv.nh[mt][i] = dmnh; sv.r[mt][i] = r; sv.z[mt][i] = z; sv.n[mt][i] = n; sv.rf[mt][i] = rf;
+            sv.zf[mt][i] = zf; sv.nf[mt][i] = nf; sv.omz[mt][i] = omz; sv.hnew[mt][i] = hnew; sv.mk[mt][i] = mk;
+            st.h[mt][i] = hnew;
+        }
+}
+
+// ---- heads -----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float q16_uni(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float q16_hsg(float v) { return v < -3.0f ? 0.0f : (v <= 3.0f ? v * (1.0f / 3.0f) + 0.5f : 1.0f); }
+template <int MK>
+struct Scalars {                 // wave-uniform parameters
+    float bout[2], w1[18], w2[6];
+    __device__ __forceinline__ void load(const float* pl, const QatLayout& L) {
+        constexpr bool TRES = Kind<MK>::TRES;
+        bout[0] = TRES ? 0.0f : q16_uni(pl[L.o_bo]);
+        bout[1] = TRES ? 0.0f : q16_uni(pl[L.o_bo + 1]);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) w1[i] = TRES ? q16_uni(pl[L.o_tcn0 + i]) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w2[i] = TRES ? q16_uni(pl[L.o_tcn2 + i]) : 0.0f;
+    }
+};
+// TCN skip of one sample: s1[3] pre-activations of the first conv, s2[2] of the second (float path, Conv1d / Hardswish are not swapped)
+template <int MK>
+__device__ __forceinline__ void q16_tcn(const Scalars<MK>& sc, float2 xm, float2 xc, float2 xq, float (&s1)[3], float (&s2)[2]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = sc.w1[c * 6] * xm.x;
+        v = __builtin_fmaf(sc.w1[c * 6 + 1], xc.x, v); v = __builtin_fmaf(sc.w1[c * 6 + 2], xq.x, v);
+        v = __builtin_fmaf(sc.w1[c * 6 + 3], xm.y, v); v = __builtin_fmaf(sc.w1[c * 6 + 4], xc.y, v);
+        s1[c] = __builtin_fmaf(sc.w1[c * 6 + 5], xq.y, v);
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        float v = sc.w2[o * 3] * hardswishf_(s1[0]);
+        v = __builtin_fmaf(sc.w2[o * 3 + 1], hardswishf_(s1[1]), v);
+        s2[o] = __builtin_fmaf(sc.w2[o * 3 + 2], hardswishf_(s1[2]), v);
+    }
+}
+
+// everything the head's backward needs from its forward (recomputed there)
+template <int MK, int NT> struct HeadOut {
+    f32x4 ho[NT];            // q_a(fc_out input) on the units (dgru: of relu(fc_hid))
+    f32x4 pho[NT];           // its pass mask
+    f32x4 h2[NT], ph2[NT], hidpre[NT];     // dgru: q_a(h') of fc_hid, mask, pre-activation
+    float cof[2], pcof[2];   // dgru: q_a(feature slot) of fc_out, mask
+};
+// y (before bias / output quantiser / skip) of one step; `fs` = the lane's FLOAT feature slots (dgru's cat)
+template <int MK, int NT>
+__device__ __forceinline__ void head_fwd(TabPtr tl, const QSc& qs, const f32x4 (&h)[NT], const float (&fs)[Kind<MK>::NCH], HeadOut<MK, NT>& ho,
+                                         float& y0, float& y1) {
+    using T = QT<MK, NT>;
+    float p0 = 0.0f, p1 = 0.0f;
+    if constexpr (Kind<MK>::DGRU) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            acc[kt] = z4;
+            ODPD_EACH4 { ho.h2[kt][i] = qapply(h[kt][i], qs.hida); ho.ph2[kt][i] = qpass(h[kt][i], qs.hida); }
+        }
+        s16n_matvec<NT>(tl, T::HID, ho.h2, acc);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const f32x4 b = as_f32x4(tab_ld(tl, (T::BHID + mt) * 64));
+            const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
+            ODPD_EACH4 {
+                const float pre = acc[mt][i] + b[i], hid = pre > 0.0f ? pre : 0.0f;      // torch.relu
+                ho.hidpre[mt][i] = pre;
+                ho.ho[mt][i] = qapply(hid, qs.oa); ho.pho[mt][i] = qpass(hid, qs.oa);
+                p0 = __builtin_fmaf(w0[i], ho.ho[mt][i], p0); p1 = __builtin_fmaf(w1[i], ho.ho[mt][i], p1);
+            }
+        }
+        const float4 wf = tab_ld(tl, T::WOF * 64);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { ho.cof[c] = qapply(fs[c], qs.oa); ho.pcof[c] = qpass(fs[c], qs.oa); }
+        p0 = __builtin_fmaf(wf.x, ho.cof[0], p0); p0 = __builtin_fmaf(wf.y, ho.cof[1], p0);
+        p1 = __builtin_fmaf(wf.z, ho.cof[0], p1); p1 = __builtin_fmaf(wf.w, ho.cof[1], p1);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
+            ODPD_EACH4 {
+                ho.ho[mt][i] = qapply(h[mt][i], qs.oa); ho.pho[mt][i] = qpass(h[mt][i], qs.oa);
+                p0 = __builtin_fmaf(w0[i], ho.ho[mt][i], p0); p1 = __builtin_fmaf(w1[i], ho.ho[mt][i], p1);
+            }
+        }
+    }
+    y0 = quad_sum(p0); y1 = quad_sum(p1);
+}
+
+template <int MK>
+__device__ __forceinline__ void q16_stage_x(float2* lds, const float* g, int b0, int B, int T, int t0, int lane) {
+    using K = Kind<MK>;
+    const float2* g2 = reinterpret_cast<const float2*>(g);
+    constexpr int PER = kChunk + 2 * K::HALO, TOT = 16 * PER, N = (TOT + 63) / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j;
+        if (e < TOT) {
+            const int m = e / PER, pos = e % PER, tg = t0 - K::HALO + pos;
+            float2 v = make_float2(0.0f, 0.0f);          // outside the frame: the conv's zero padding
+            if (tg >= 0 && tg < T) v = (b0 + m < B) ? g2[(size_t)(b0 + m) * T + tg] : make_float2(0.5f, 0.5f);
+            else if (!K::TRES) v = make_float2(0.5f, 0.5f);
+            lds[m * K::XSTRIDE + pos] = v;
+        }
+    }
+}
+__device__ __forceinline__ float4 q16_f4(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
+
+template <int MK>
+__device__ __forceinline__ QSc load_qsc(const float* pl, const QatLayout& L, int bits_a) {
+    QSc q;
+    q.xa = make_quant(pl[L.o_sxa], bits_a); q.ha = make_quant(pl[L.o_sha], bits_a); q.oa = make_quant(pl[L.o_soa], bits_a);
+    q.sig = make_quant(pl[L.o_ssig], bits_a); q.tnh = make_quant(pl[L.o_stanh], bits_a);
+    q.add = make_quant(pl[L.o_sadd], bits_a); q.mul = make_quant(pl[L.o_smul], bits_a);
+    q.out = make_quant(pl[L.o_soo], 16);
+    q.hida = Kind<MK>::DGRU ? make_quant(pl[L.o_shida], bits_a) : q.oa;
+    return q;
+}
+template <int NT>
+__device__ __forceinline__ void init_state(StateD<NT>& st) {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) { st.h[mt] = z4; st.hp[mt] = z4; st.dmr[mt] = z4; st.dmz[mt] = z4; st.dmn[mt] = z4; st.dmnh[mt] = z4; }
+    st.xp[0] = st.xp[1] = 0.0f;
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward
+// -------------------------------------------------------------------------------------------------
+template <int MK, int NT, bool LUT>
+__global__ __launch_bounds__(256) void qat16_fwd_kernel(SeqArgs a, int bits_w, int bits_a, int eval_mode) {
+    using T = QT<MK, NT>;
+    using K = Kind<MK>;
+    constexpr int S = T::S, NCH = K::NCH;
+    constexpr int kWaveF = 2 * 16 * K::XSTRIDE + 2 * 16 * kChunkPad;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const QatLayout L = qat_layout(MK, a.H);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    const QSc qs = load_qsc<MK>(pl, L, bits_a);
+    const int nlut = LUT ? (1 << bits_a) : 0;
+    float* lut = tab + s16_tab_floats(T::NG_FWD);
+    {
+        const WQ wq = make_wq(pl, L, bits_w);
+        float4* t4 = reinterpret_cast<float4*>(tab);
+        for (int grp = wave; grp < T::NG_FWD; grp += nwb) t4[grp * 64 + lane] = q16_entry<MK, NT>(pl, L, wq, grp, n, q);
+        if constexpr (LUT) fill_luts(lut, qs.add, bits_a, qs.sig, K::TRES);
+        __syncthreads();
+    }
+    const int Ksig = sig_levels(qs.sig);
+    const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    Scalars<MK> sc;
+    sc.load(pl, L);
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    const bool slot_ok[2] = {true, q < 2};
+    f32x4 unit_ok[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) ODPD_EACH4 unit_ok[kt][i] = (16 * kt + 4 * q + i < a.H) ? 1.0f : 0.0f;
+    float* wbase = lut + (LUT ? 2 * nlut + kMaxThr : 0) + (size_t)wave * kWaveF;
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* ys = xs + 16 * K::XSTRIDE;
+    const float2* xr = xs + n * K::XSTRIDE + K::HALO;
+    float zx = 0.0f, zh = 0.0f;
+    const int nwaves = gridDim.x * nwb;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        const bool valid = b0 + n < a.B;
+        float4* ck = a.ckpt ? reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * T::kCk * 64 + lane : nullptr;
+        const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[(size_t)(b0 + n) * a.T] : make_float2(0.5f, 0.5f);
+        StateD<NT> st;
+        init_state<NT>(st);
+        float zxs = 0.0f, zhs = 0.0f;
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            wave_lds_fence();
+            q16_stage_x<MK>(xs, a.x, b0, a.B, a.T, t0, lane);
+            wave_lds_fence();
+            for (int tt = 0; tt < len; ++tt) {
+                const float2 xv = xr[tt];
+                float2 xn = make_float2(0.f, 0.f);
+                if constexpr (K::TRES) xn = (t0 + tt + 1 < a.T) ? xr[tt + 1] : x0;      // torch.roll(x, -1): the last step sees sample 0
+                float fs[NCH];
+                q16_slots<MK>(xv, xn, oh, fs);
+                const TabPtr tlo = opaque(tl);
+                if constexpr (K::TRES) {
+                    SaveD<NT> sv;
+                    delta_cell<NT, LUT>(tlo, qs, lut, nlut, Ksig, fs, a.thx, a.thh, slot_ok, unit_ok, st, sv, zxs, zhs);
+                } else {
+                    float fq[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) fq[c] = qapply(fs[c], qs.xa);
+                    SaveS<NT> sv;
+                    std_cell<MK, NT, LUT>(tlo, qs, lut, nlut, fq, st.h, sv);
+                }
+                HeadOut<MK, NT> ho;
+                float y0, y1;
+                head_fwd<MK, NT>(tlo, qs, st.h, fs, ho, y0, y1);
+                y0 += sc.bout[0]; y1 += sc.bout[1];
+                if (eval_mode) { y0 = qapply(y0, qs.out); y1 = qapply(y1, qs.out); }   // fc_out's 16-bit out_quantizer (quant_layers.py:77-80)
+                if constexpr (K::TRES) {
+                    float s1[3], s2[2];
+                    q16_tcn<MK>(sc, xr[tt - kHalo], xv, xr[tt + kHalo], s1, s2);
+                    y0 += hardswishf_(s2[0]); y1 += hardswishf_(s2[1]);
+                }
+                if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
+                const int t1 = t0 + tt + 1;
+                if (ck != nullptr && (t1 % S) == 0 && t1 < a.T) {
+                    float4* c = ck + (size_t)(t1 / S) * T::kCk * 64;
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) {
+                        c[kt * 64] = q16_f4(st.h[kt]);
+                        if constexpr (K::TRES) {
+                            c[(1 * NT + kt) * 64] = q16_f4(st.hp[kt]);
+                            c[(2 * NT + kt) * 64] = q16_f4(st.dmr[kt]); c[(3 * NT + kt) * 64] = q16_f4(st.dmz[kt]);
+                            c[(4 * NT + kt) * 64] = q16_f4(st.dmn[kt]); c[(5 * NT + kt) * 64] = q16_f4(st.dmnh[kt]);
+                        }
+                    }
+                    if constexpr (K::TRES) c[6 * NT * 64] = make_float4(st.xp[0], st.xp[1], 0.0f, 0.0f);
+                }
+            }
+            wave_lds_fence();
+            stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+        }
+        if (valid) { zx += zxs; zh += zhs; }
+    }
+    if constexpr (K::TRES) {
+        if (a.stats != nullptr) {
+            float tx = zx, th = zh;
+            for (int o = 32; o > 0; o >>= 1) { tx += __shfl_down(tx, o); th += __shfl_down(th, o); }
+            if (lane == 0) {
+                atomicAdd(&a.stats[0], (double)tx);
+                atomicAdd(&a.stats[2], (double)th);
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                atomicAdd(&a.stats[1], 6.0 * (double)a.B * (double)a.T);
+                atomicAdd(&a.stats[3], (double)a.H * (double)a.B * (double)a.T);
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// backward
+// -------------------------------------------------------------------------------------------------
+template <int MK, int NT>
+struct Grad {
+    f32x4 tih[3][NT], thh[3][NT][NT];
+    f32x4 dwout[2][NT], dbhn[NT];
+    f32x4 thid[NT][NT], dbhid[NT];
+    float dbout[2], dwof[2][2], dw1[18], dw2[6];
+    __device__ __forceinline__ void zero() {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            dwout[0][a] = dwout[1][a] = dbhn[a] = dbhid[a] = z4;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) thid[a][b] = z4;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                tih[g][a] = z4;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) thh[g][a][b] = z4;
+            }
+        }
+        dbout[0] = dbout[1] = dwof[0][0] = dwof[0][1] = dwof[1][0] = dwof[1][1] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) dw1[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dw2[i] = 0.f;
+    }
+};
+template <int NT> struct Carry { f32x4 gh[NT], ghp[NT], gr[NT], gz[NT], gn[NT], gnh[NT]; float gxp[2], wrap[2]; };
+
+#define QM(mk, bit) (((mk) & (bit)) ? 1.0f : 0.0f)
+
+// head backward of one step: accumulates the head's parameter gradients, returns dL/dh' (added to gh) and, for dgru, the head's
+// share of dL/d(feature slot)
+template <int MK, int NT>
+__device__ __forceinline__ void head_bwd(TabPtr tl, const QSc& qs, Grad<MK, NT>& G, const HeadOut<MK, NT>& ho, float2 dyv, int q,
+                                         f32x4 (&gh)[NT], float (&dfs)[2], float* tiles) {
+    using T = QT<MK, NT>;
+    G.dbout[0] += q == 0 ? dyv.x : 0.0f;
+    G.dbout[1] += q == 0 ? dyv.y : 0.0f;
+    if constexpr (Kind<MK>::DGRU) {
+        const float4 wf = tab_ld(tl, T::WOF * 64);
+        dfs[0] = (dyv.x * wf.x + dyv.y * wf.z) * ho.pcof[0];
+        dfs[1] = (dyv.x * wf.y + dyv.y * wf.w) * ho.pcof[1];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { G.dwof[0][c] = __builtin_fmaf(dyv.x, ho.cof[c], G.dwof[0][c]); G.dwof[1][c] = __builtin_fmaf(dyv.y, ho.cof[c], G.dwof[1][c]); }
+        f32x4 dpre[NT], back[NT];
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
+            back[mt] = z4;
+            ODPD_EACH4 {
+                G.dwout[0][mt][i] = __builtin_fmaf(dyv.x, ho.ho[mt][i], G.dwout[0][mt][i]);
+                G.dwout[1][mt][i] = __builtin_fmaf(dyv.y, ho.ho[mt][i], G.dwout[1][mt][i]);
+                const float dcat = (dyv.x * w0[i] + dyv.y * w1[i]) * ho.pho[mt][i];
+                dpre[mt][i] = ho.hidpre[mt][i] > 0.0f ? dcat : 0.0f;
+                G.dbhid[mt][i] += dpre[mt][i];
+            }
+        }
+        s16n_matvec<NT>(tl, T::HIDT, dpre, back);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) ODPD_EACH4 gh[mt][i] += back[mt][i] * ho.ph2[mt][i];
+        // dW_hid += dpre^T (x) h2 through the transpose tiles (slots 5 NT + 1 ..)
+        float* tp = tiles + (5 * NT + 1) * kTileFloats;
+        const int n = threadIdx.x & 15;
+        wave_lds_fence();
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) { tile_put(tp + kt * kTileFloats, n, q, dpre[kt]); tile_put(tp + (NT + kt) * kTileFloats, n, q, ho.h2[kt]); }
+        wave_lds_fence();
+        float hT[NT][4];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) tile_get(tp + (NT + kt) * kTileFloats, n, q, hT[kt]);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            float dT[4];
+            tile_get(tp + mt * kTileFloats, n, q, dT);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) G.thid[mt][nt] = mfma4(dT[c], hT[nt][c], G.thid[mt][nt]);
+        }
+    } else {
+        dfs[0] = dfs[1] = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
+            ODPD_EACH4 {
+                G.dwout[0][mt][i] = __builtin_fmaf(dyv.x, ho.ho[mt][i], G.dwout[0][mt][i]);
+                G.dwout[1][mt][i] = __builtin_fmaf(dyv.y, ho.ho[mt][i], G.dwout[1][mt][i]);
+                gh[mt][i] += (dyv.x * w0[i] + dyv.y * w1[i]) * ho.pho[mt][i];
+            }
+        }
+    }
+}
+
+// weight-gradient MFMAs of one step: dW_x[g] += d_x[g]^T (x) fslot, dW_h[g] += d_h[g]^T (x) hq, through the transpose tiles
+// (d_x = d_h for r, z; for the n gate d_x[2] = gate gradient, d_h[2] = gradient of the state-side term)
+template <int MK, int NT>
+__device__ __forceinline__ void wgrad_tiles(Grad<MK, NT>& G, float* tiles, int n, int q, const f32x4 (&dr)[NT], const f32x4 (&dz)[NT],
+                                            const f32x4 (&dn)[NT], const f32x4 (&dnh)[NT], const f32x4 (&hq)[NT], float f0, float f1) {
+    auto tile = [tiles](int qty, int kt) { return tiles + (qty * NT + kt) * kTileFloats; };   // 0 dr 1 dz 2 dn 3 dnh 4 hq
+    float* t_f = tiles + 5 * NT * kTileFloats;
+    wave_lds_fence();
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        tile_put(tile(0, kt), n, q, dr[kt]); tile_put(tile(1, kt), n, q, dz[kt]); tile_put(tile(2, kt), n, q, dn[kt]);
+        tile_put(tile(3, kt), n, q, dnh[kt]); tile_put(tile(4, kt), n, q, hq[kt]);
+    }
+    t_f[n * kTilePitch + q] = f0;
+    t_f[n * kTilePitch + 4 + q] = f1;
+    wave_lds_fence();
+    float fT[4], hT[NT][4];
+    tile_get(t_f, n, q, fT);
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) tile_get(tile(4, kt), n, q, hT[kt]);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        float rT[4], zT[4], nT[4], gT[4];
+        tile_get(tile(0, mt), n, q, rT); tile_get(tile(1, mt), n, q, zT);
+        tile_get(tile(2, mt), n, q, nT); tile_get(tile(3, mt), n, q, gT);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            G.tih[0][mt] = mfma4(rT[c], fT[c], G.tih[0][mt]);
+            G.tih[1][mt] = mfma4(zT[c], fT[c], G.tih[1][mt]);
+            G.tih[2][mt] = mfma4(nT[c], fT[c], G.tih[2][mt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                G.thh[0][mt][nt] = mfma4(rT[c], hT[nt][c], G.thh[0][mt][nt]);
+                G.thh[1][mt][nt] = mfma4(zT[c], hT[nt][c], G.thh[1][mt][nt]);
+                G.thh[2][mt][nt] = mfma4(gT[c], hT[nt][c], G.thh[2][mt][nt]);
+            }
+        }
+    }
+}
+
+// dL/d(lane's feature slots) -> dL/dI, dL/dQ of the sample (summed over the sequence's four lanes); TRES: (nI, nQ) = the share of
+// sample t + 1 (features I_next, Q_next)
+template <int MK>
+__device__ __forceinline__ void slots_bwd(float2 xv, const float (&oh)[4], const float (&dfs)[2], float& dI, float& dQ, float& nI, float& nQ) {
+    nI = nQ = 0.0f;
+    if constexpr (MK == K_GRU) {
+        dI = oh[0] * dfs[0]; dQ = oh[1] * dfs[0];
+    } else if constexpr (MK == K_Q4 || MK == K_A4) {
+        const float df[4] = {oh[0] * dfs[0], oh[1] * dfs[0], oh[2] * dfs[0], oh[3] * dfs[0]};
+        feat_bwd<MK == K_Q4 ? FEAT_Q4 : FEAT_A4>(xv.x, xv.y, df, dI, dQ);
+    } else if constexpr (MK == K_DGRU) {
+        const float df[6] = {oh[0] * dfs[0], oh[1] * dfs[0], oh[2] * dfs[0], oh[3] * dfs[0], oh[0] * dfs[1], oh[1] * dfs[1]};
+        feat_bwd<FEAT_DGRU6>(xv.x, xv.y, df, dI, dQ);
+    } else {
+        const float df[4] = {oh[0] * dfs[0], oh[1] * dfs[0], oh[2] * dfs[0], oh[3] * dfs[0]};
+        feat_bwd<FEAT_A4>(xv.x, xv.y, df, dI, dQ);
+        nI = quad_sum(oh[0] * dfs[1]); nQ = quad_sum(oh[1] * dfs[1]);
+    }
+    dI = quad_sum(dI); dQ = quad_sum(dQ);
+}
+
+template <int MK, int NT, bool LUT, bool FULL, bool DX>
+__device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, const QSc& qs, const float* lut, int nlut, int Ksig,
+                                              const Scalars<MK>& sc, const float (&oh)[4], Grad<MK, NT>& G, const float2* xr,
+                                              const float2* dys, float2* dxs, float* tiles, float2 x0, int n, int q, int tglob, int tloc,
+                                              int nstep, int chunk_len, float* dxrow, StateD<NT> st, Carry<NT>& C) {
+    using T = QT<MK, NT>;
+    using K = Kind<MK>;
+    constexpr int S = T::S, NCH = K::NCH;
+    const bool slot_ok[2] = {true, q < 2};
+    f32x4 all_units[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) all_units[kt] = f32x4{1.f, 1.f, 1.f, 1.f};
+    typedef typename std::conditional<K::TRES, SaveD<NT>, SaveS<NT>>::type Save;
+    Save sv[S];
+    float fq_s[S][2];
+    int px_s[S];
+    TabPtr tl = opaque(tl0);
+    {
+        float zx = 0.f, zh = 0.f;
+#pragma unroll
+        for (int si = 0; si < S; ++si) {
+            if (FULL || si < nstep) {
+                const float2 xv = xr[tloc + si];
+                float2 xn = make_float2(0.f, 0.f);
+                if constexpr (K::TRES) xn = (tglob + si + 1 < a.T) ? xr[tloc + si + 1] : x0;
+                float fs[NCH];
+                q16_slots<MK>(xv, xn, oh, fs);
+                if constexpr (K::TRES) {
+                    delta_cell<NT, LUT>(tl, qs, lut, nlut, Ksig, fs, a.thx, a.thh, slot_ok, all_units, st, sv[si], zx, zh);
+                } else {
+                    float fq[NCH];
+                    int px = 0;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) { fq[c] = qapply(fs[c], qs.xa); px |= QBIT(qpassb(fs[c], qs.xa), 1 << c); }
+                    fq_s[si][0] = fq[0]; fq_s[si][1] = NCH > 1 ? fq[NCH - 1] : 0.0f;
+                    px_s[si] = px;
+                    std_cell<MK, NT, LUT>(tl, qs, lut, nlut, fq, st.h, sv[si]);
+                }
+            }
+        }
+    }
+    tl = opaque(tl0);
+    const int F = K::F;
+    // the constant-1 slot of the feature tile (column F of tih = the x-side bias gradient of the GRUCell)
+    const float one_c0 = (!K::TRES && F < 4 && q == F) ? 1.0f : 0.0f, one_c1 = (!K::TRES && F >= 4 && 4 + q == F) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int si = S - 1; si >= 0; --si) {
+        if (FULL || si < nstep) {
+            const int tt = tloc + si;
+            const float2 dyv = dys[n * kChunkPad + tt];
+            const float2 xv = xr[tt];
+            float2 xn = make_float2(0.f, 0.f);
+            if constexpr (K::TRES) xn = (tglob + si + 1 < a.T) ? xr[tt + 1] : x0;
+            float fs[NCH];
+            q16_slots<MK>(xv, xn, oh, fs);
+            if constexpr (K::TRES) {
+                if (q == 0) {    // TCN skip gradients: per-sequence work, one lane of the four
+                    float s1[3], s2[2];
+                    const float2 xm = xr[tt - kHalo], xc = xr[tt], xq = xr[tt + kHalo];
+                    q16_tcn<MK>(sc, xm, xc, xq, s1, s2);
+                    const float d2[2] = {dyv.x * q16_hsg(s2[0]), dyv.y * q16_hsg(s2[1])};
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float hs = hardswishf_(s1[c]);
+                        G.dw2[c] = __builtin_fmaf(d2[0], hs, G.dw2[c]);
+                        G.dw2[3 + c] = __builtin_fmaf(d2[1], hs, G.dw2[3 + c]);
+                        const float d1 = __builtin_fmaf(d2[0], sc.w2[c], d2[1] * sc.w2[3 + c]) * q16_hsg(s1[c]);
+                        G.dw1[c * 6 + 0] = __builtin_fmaf(d1, xm.x, G.dw1[c * 6 + 0]); G.dw1[c * 6 + 1] = __builtin_fmaf(d1, xc.x, G.dw1[c * 6 + 1]);
+                        G.dw1[c * 6 + 2] = __builtin_fmaf(d1, xq.x, G.dw1[c * 6 + 2]); G.dw1[c * 6 + 3] = __builtin_fmaf(d1, xm.y, G.dw1[c * 6 + 3]);
+                        G.dw1[c * 6 + 4] = __builtin_fmaf(d1, xc.y, G.dw1[c * 6 + 4]); G.dw1[c * 6 + 5] = __builtin_fmaf(d1, xq.y, G.dw1[c * 6 + 5]);
+                    }
+                }
+            }
+            // head: recomputed from the step's new state
+            HeadOut<MK, NT> ho;
+            {
+                float y0, y1;
+                head_fwd<MK, NT>(tl, qs, sv[si].hnew, fs, ho, y0, y1);
+            }
+            float dfs_head[2];
+            head_bwd<MK, NT>(tl, qs, G, ho, dyv, q, C.gh, dfs_head, tiles);
+            float dfs[2] = {0.0f, 0.0f};
+            if constexpr (K::TRES) {
+                const SaveD<NT>& v = sv[si];
+                f32x4 ghprev[NT];
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+                    ODPD_EACH4 {
+                        const int mk = v.mk[mt][i];
+                        const float g = C.gh[mt][i] * QM(mk, M_AH);
+                        const float dm3 = g * QM(mk, M_M3), dm2 = g * QM(mk, M_M2);
+                        const float domz = dm3 * v.n[mt][i], dn = dm3 * v.omz[mt][i];
+                        const float dz = dm2 * v.hp[mt][i] - domz * QM(mk, M_OMZ);
+                        ghprev[mt][i] = dm2 * v.z[mt][i];
+                        const float dan = dn * QM(mk, M_N) * (1.0f - v.nf[mt][i] * v.nf[mt][i]) * QM(mk, M_AN);
+                        C.gn[mt][i] += dan;
+                        const float dm1 = dan * QM(mk, M_M1);
+                        C.gnh[mt][i] += dm1 * v.r[mt][i];
+                        C.gr[mt][i] += dm1 * v.nh[mt][i] * QM(mk, M_R) * (v.rf[mt][i] * (1.0f - v.rf[mt][i]));
+                        C.gz[mt][i] += dz * QM(mk, M_Z) * (v.zf[mt][i] * (1.0f - v.zf[mt][i]));
+                    }
+                f32x4 ddh[NT];
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) ddh[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s16n_matvec<NT>(tl, T::HHT + 0 * NT * NT, C.gr, ddh);
+                s16n_matvec<NT>(tl, T::HHT + 1 * NT * NT, C.gz, ddh);
+                s16n_matvec<NT>(tl, T::HHT + 2 * NT * NT, C.gnh, ddh);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+                    ODPD_EACH4 {
+                        const int mk = v.mk[mt][i];
+                        const float m = QM(mk, M_MH), g2 = ddh[mt][i] * QM(mk, M_PH);
+                        C.gh[mt][i] = ghprev[mt][i] + m * (g2 + C.ghp[mt][i]);
+                        C.ghp[mt][i] = (1.0f - m) * C.ghp[mt][i] - m * g2;
+                    }
+                if constexpr (DX) {
+                    f32x4 ds = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) {
+                        const f32x4 wr = as_f32x4(tab_ld(tl, (T::IHT + 0 * NT + kt) * 64)), wz = as_f32x4(tab_ld(tl, (T::IHT + 1 * NT + kt) * 64)),
+                                    wn = as_f32x4(tab_ld(tl, (T::IHT + 2 * NT + kt) * 64));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            ds = mfma4(wr[c], C.gr[kt][c], ds); ds = mfma4(wz[c], C.gz[kt][c], ds); ds = mfma4(wn[c], C.gn[kt][c], ds);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float m = (v.xm & (1 << c)) ? 1.0f : 0.0f, g = ds[c] * ((v.xm & (4 << c)) ? 1.0f : 0.0f);
+                        dfs[c] = m * (g + C.gxp[c]);
+                        C.gxp[c] = (1.0f - m) * C.gxp[c] - m * g;
+                    }
+                }
+                wgrad_tiles<MK, NT>(G, tiles, n, q, C.gr, C.gz, C.gn, C.gnh, v.qdh, v.fq[0], v.fq[1]);
+            } else {
+                const SaveS<NT>& v = sv[si];
+                f32x4 dar[NT], daz[NT], dan[NT], dhtn[NT], dhdir[NT], hq[NT];
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+                    ODPD_EACH4 {
+                        const int mk = v.mk[mt][i];
+                        const float g = C.gh[mt][i] * QM(mk, M_AH);
+                        const float dm2 = g * QM(mk, M_M2), dm3 = g * QM(mk, M_M3);
+                        const float dz = dm2 * v.hp[mt][i] - dm3 * v.n[mt][i];
+                        const float dn = dm3 * (1.0f - v.z[mt][i]);
+                        const float da = dn * QM(mk, M_N) * (1.0f - v.nf[mt][i] * v.nf[mt][i]) * QM(mk, M_AN);
+                        const float dm1 = da * QM(mk, M_M1);
+                        const float dr = dm1 * v.hn[mt][i];
+                        dan[mt][i] = da;
+                        dhtn[mt][i] = dm1 * v.r[mt][i];
+                        dar[mt][i] = dr * QM(mk, M_R) * v.rf[mt][i] * (1.0f - v.rf[mt][i]) * QM(mk, M_AR);
+                        daz[mt][i] = dz * QM(mk, M_Z) * v.zf[mt][i] * (1.0f - v.zf[mt][i]) * QM(mk, M_AZ);
+                        dhdir[mt][i] = dm2 * v.z[mt][i];
+                        hq[mt][i] = qapply(v.hp[mt][i], qs.ha);
+                        G.dbhn[mt][i] += dhtn[mt][i];
+                    }
+                f32x4 ddh[NT];
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) ddh[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s16n_matvec<NT>(tl, T::HHT + 0 * NT * NT, dar, ddh);
+                s16n_matvec<NT>(tl, T::HHT + 1 * NT * NT, daz, ddh);
+                s16n_matvec<NT>(tl, T::HHT + 2 * NT * NT, dhtn, ddh);
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt) ODPD_EACH4 C.gh[mt][i] = dhdir[mt][i] + ddh[mt][i] * QM(v.mk[mt][i], M_PH);
+                if constexpr (DX) {
+                    f32x4 ds = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt) {
+                        const f32x4 wr = as_f32x4(tab_ld(tl, (T::IHT + 0 * NT + kt) * 64)), wz = as_f32x4(tab_ld(tl, (T::IHT + 1 * NT + kt) * 64)),
+                                    wn = as_f32x4(tab_ld(tl, (T::IHT + 2 * NT + kt) * 64));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            ds = mfma4(wr[c], dar[kt][c], ds); ds = mfma4(wz[c], daz[kt][c], ds); ds = mfma4(wn[c], dan[kt][c], ds);
+                        }
+                    }
+                    dfs[0] = ds[0] * ((px_s[si] & 1) ? 1.0f : 0.0f) + dfs_head[0];
+                    dfs[1] = (NCH > 1 ? ds[1] * ((px_s[si] & 2) ? 1.0f : 0.0f) : 0.0f) + dfs_head[1];
+                }
+                wgrad_tiles<MK, NT>(G, tiles, n, q, dar, daz, dan, dhtn, hq, fq_s[si][0] + one_c0, (NCH > 1 ? fq_s[si][1] : 0.0f) + one_c1);
+            }
+            if constexpr (DX) {
+                float dI, dQ, nI, nQ;
+                slots_bwd<MK>(xv, oh, dfs, dI, dQ, nI, nQ);
+                if (q == 0) {
+                    dxs[n * kChunkPad + tt] = make_float2(dI, dQ);
+                    if constexpr (K::TRES) {
+                        const int t1 = tglob + si + 1;
+                        if (t1 >= a.T) { C.wrap[0] = nI; C.wrap[1] = nQ; }                 // torch.roll: the last step's "next" is sample 0
+                        else if (tt + 1 < chunk_len) { dxs[n * kChunkPad + tt + 1].x += nI; dxs[n * kChunkPad + tt + 1].y += nQ; }
+                        else if (dxrow != nullptr) {   // sample t + 1 lives in the chunk this wave flushed before: add at L2
+                            __threadfence();
+                            atomicAdd(dxrow + 2 * t1, nI);
+                            atomicAdd(dxrow + 2 * t1 + 1, nQ);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MK, int NT>
+__device__ __forceinline__ void q16_write_row(float* prow, const float* pl, const QatLayout& L, const WQ& wq, Grad<MK, NT>& G, int lane,
+                                              int n, int q) {
+    using K = Kind<MK>;
+    constexpr int F = K::F;
+    const int H = L.H;
+    for (int i = lane; i < L.P + kLossCols; i += 64) prow[i] = 0.f;       // incl. the scale parameters: exact zero gradient
+    wave_lds_fence();
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int u = 16 * mt + 4 * q + rr;
+            if (u < H) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    if (n < F) { const int k = L.o_wx + (g * H + u) * F + n; prow[k] = G.tih[g][mt][rr] * qpass(pl[k], wq.x); }
+                    if (!K::TRES && n == F) { prow[L.o_bx + g * H + u] = G.tih[g][mt][rr]; if (g < 2) prow[L.o_bh + g * H + u] = G.tih[g][mt][rr]; }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        if (16 * nt + n < H) { const int k = L.o_wh + (g * H + u) * H + 16 * nt + n; prow[k] = G.thh[g][mt][nt][rr] * qpass(pl[k], wq.h); }
+                }
+                if constexpr (K::DGRU) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        if (16 * nt + n < H) { const int k = L.o_whid + u * H + 16 * nt + n; prow[k] = G.thid[mt][nt][rr] * qpass(pl[k], wq.hid); }
+                }
+            }
+            const float w0 = row_sum16(G.dwout[0][mt][rr]), w1 = row_sum16(G.dwout[1][mt][rr]);
+            const float bn = row_sum16(G.dbhn[mt][rr]), bhid = row_sum16(G.dbhid[mt][rr]);
+            if (n == 0 && u < H) {
+                prow[L.o_wo + u] = w0 * qpass(pl[L.o_wo + u], wq.o);
+                prow[L.o_wo + L.OW + u] = w1 * qpass(pl[L.o_wo + L.OW + u], wq.o);
+                if constexpr (!K::TRES) prow[L.o_bh + 2 * H + u] = bn;
+                if constexpr (K::DGRU) prow[L.o_bhid + u] = bhid;
+            }
+        }
+    if constexpr (K::DGRU) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float v = row_sum16(G.dwof[cc][c]);
+                const int slot = 4 * c + q;
+                if (n == 0 && slot < 6) { const int k = L.o_wo + cc * L.OW + H + slot; prow[k] = v * qpass(pl[k], wq.o); }
+            }
+    }
+    if constexpr (K::TRES) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const float v = row_sum16(G.dw1[i]);
+            if (n == 0 && q == 0) prow[L.o_tcn0 + i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float v = row_sum16(G.dw2[i]);
+            if (n == 0 && q == 0) prow[L.o_tcn2 + i] = v;
+        }
+    } else {
+        const float b0 = row_sum16(G.dbout[0]), b1 = row_sum16(G.dbout[1]);
+        if (n == 0 && q == 0) { prow[L.o_bo] = b0; prow[L.o_bo + 1] = b1; }
+    }
+}
+
+template <int MK, int NT, bool LUT, bool DX>
+__global__ __launch_bounds__(256, 1) void qat16_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
+    using T = QT<MK, NT>;
+    using K = Kind<MK>;
+    constexpr int S = T::S;
+    constexpr int kWaveF = 2 * 16 * K::XSTRIDE + (DX ? 2 : 1) * 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
+    constexpr int kGroups = DX ? T::NG_DX : T::NG_BWD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const QatLayout L = qat_layout(MK, a.H);
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* tab = smem + pad4(L.P);
+    const QSc qs = load_qsc<MK>(pl, L, bits_a);
+    const WQ wq = make_wq(pl, L, bits_w);
+    const int nlut = LUT ? (1 << bits_a) : 0;
+    float* lut = tab + s16_tab_floats(kGroups);
+    {
+        float4* t4 = reinterpret_cast<float4*>(tab);
+        for (int grp = wave; grp < kGroups; grp += nwb) t4[grp * 64 + lane] = q16_entry<MK, NT>(pl, L, wq, grp, n, q);
+        if constexpr (LUT) fill_luts(lut, qs.add, bits_a, qs.sig, K::TRES);
+        __syncthreads();
+    }
+    const int Ksig = sig_levels(qs.sig);
+    const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    Scalars<MK> sc;
+    sc.load(pl, L);
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    float* wbase = lut + (LUT ? 2 * nlut + kMaxThr : 0) + (size_t)wave * kWaveF;
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* dys = xs + 16 * K::XSTRIDE;
+    float2* dxs = dys + 16 * kChunkPad;                   // DX only
+    float* tiles = reinterpret_cast<float*>(dys + (DX ? 2 : 1) * 16 * kChunkPad);
+    for (int i = lane; i < kTileFloats; i += 64) tiles[5 * NT * kTileFloats + i] = 0.0f;       // feature tile: columns 8..15 stay 0
+    const float2* xr = xs + n * K::XSTRIDE + K::HALO;
+    Grad<MK, NT> G;
+    G.zero();
+    const int nwaves = gridDim.x * nwb;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        const bool valid = b0 + n < a.B;
+        const float4* ck = reinterpret_cast<const float4*>(a.ckpt) + (size_t)grp * a.nck * T::kCk * 64 + lane;
+        const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[(size_t)(b0 + n) * a.T] : make_float2(0.5f, 0.5f);
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        Carry<NT> C;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) { C.gh[kt] = z4; C.ghp[kt] = z4; C.gr[kt] = z4; C.gz[kt] = z4; C.gn[kt] = z4; C.gnh[kt] = z4; }
+        C.gxp[0] = C.gxp[1] = C.wrap[0] = C.wrap[1] = 0.0f;
+        float* dxrow = (DX && valid) ? a.dx + (size_t)(b0 + n) * a.T * 2 : nullptr;
+        int cur_chunk = -1, cur_len = 0;
+        for (int blk = a.nck - 1; blk >= 0; --blk) {
+            const int tb = blk * S, nstep = min(S, a.T - tb);
+            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            if (chunk != cur_chunk) {
+                if constexpr (DX) {
+                    if (cur_chunk >= 0) {
+                        wave_lds_fence();
+                        stage_out<16>(dxs, a.dx, b0, a.B, a.T, cur_chunk * kChunk, cur_len, lane);
+                    }
+                }
+                wave_lds_fence();
+                const int len = min(kChunk, a.T - t0);
+                cur_len = len;
+                q16_stage_x<MK>(xs, a.x, b0, a.B, a.T, t0, lane);
+                stage_in<16>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                wave_lds_fence();
+                cur_chunk = chunk;
+            }
+            StateD<NT> st;
+            init_state<NT>(st);
+            if (blk) {
+                const float4* c = ck + (size_t)blk * T::kCk * 64;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    st.h[kt] = as_f32x4(c[kt * 64]);
+                    if constexpr (K::TRES) {
+                        st.hp[kt] = as_f32x4(c[(1 * NT + kt) * 64]);
+                        st.dmr[kt] = as_f32x4(c[(2 * NT + kt) * 64]); st.dmz[kt] = as_f32x4(c[(3 * NT + kt) * 64]);
+                        st.dmn[kt] = as_f32x4(c[(4 * NT + kt) * 64]); st.dmnh[kt] = as_f32x4(c[(5 * NT + kt) * 64]);
+                    }
+                }
+                if constexpr (K::TRES) {
+                    const float4 xp = c[6 * NT * 64];
+                    st.xp[0] = xp.x; st.xp[1] = xp.y;
+                }
+            }
+            if (nstep == S) q16_bwd_block<MK, NT, LUT, true, DX>(a, tl, qs, lut, nlut, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+            else q16_bwd_block<MK, NT, LUT, false, DX>(a, tl, qs, lut, nlut, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+        }
+        if constexpr (DX) {
+            wave_lds_fence();
+            if constexpr (K::TRES) {
+                if (q == 0) { dxs[n * kChunkPad].x += C.wrap[0]; dxs[n * kChunkPad].y += C.wrap[1]; }   // roll(x, -1): step T-1 saw sample 0
+                wave_lds_fence();
+            }
+            stage_out<16>(dxs, a.dx, b0, a.B, a.T, 0, cur_len, lane);
+            wave_lds_fence();
+        }
+    }
+    if (a.partials == nullptr) return;
+    // the partial rows are built in LDS over the tables: the staged parameters (smem[0 .. P)) stay for the pass masks
+    const int P4 = L.P + kLossCols;
+    __syncthreads();
+    float* rows = smem + pad4(L.P);
+    q16_write_row<MK, NT>(rows + wave * P4, pl, L, wq, G, lane, n, q);
+    __syncthreads();
+    float* prow = a.partials + (size_t)blockIdx.x * P4;
+    for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+        float v = rows[i];
+        for (int wv = 1; wv < nwb; ++wv) v += rows[wv * P4 + i];
+        prow[i] = v;
+    }
+}
+
+// dL/dx through the TRes skip path  skip = HS(conv2(HS(conv1(x)))), conv1: k3, dilation 16, zero padding (time-parallel)
+__global__ __launch_bounds__(256) void qtres_skip_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w1,
+                                                            const float* __restrict__ w2, float* __restrict__ dx, int B, int T) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * T) return;
+    const int b = (int)(idx / T), t = (int)(idx % T);
+    const float2* x2 = reinterpret_cast<const float2*>(x) + (size_t)b * T;
+    const float2* d2y = reinterpret_cast<const float2*>(dy) + (size_t)b * T;
+    auto at = [&](int p) { return (p >= 0 && p < T) ? x2[p] : make_float2(0.0f, 0.0f); };
+    float gI = 0.0f, gQ = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = t - 16 * (k - 1);
+        if (p < 0 || p >= T) continue;
+        const float2 xm = at(p - 16), xc = at(p), xq = at(p + 16), dyp = d2y[p];
+        float s1[3], s2[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s1[c] = w1[c * 6] * xm.x + w1[c * 6 + 1] * xc.x + w1[c * 6 + 2] * xq.x + w1[c * 6 + 3] * xm.y + w1[c * 6 + 4] * xc.y + w1[c * 6 + 5] * xq.y;
+            const float hs = hardswishf_(s1[c]);
+            s2[0] = __builtin_fmaf(w2[c], hs, s2[0]); s2[1] = __builtin_fmaf(w2[3 + c], hs, s2[1]);
+        }
+        const float e0 = dyp.x * q16_hsg(s2[0]), e1 = dyp.y * q16_hsg(s2[1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d1 = __builtin_fmaf(e0, w2[c], e1 * w2[3 + c]) * q16_hsg(s1[c]);
+            gI = __builtin_fmaf(w1[c * 6 + k], d1, gI);
+            gQ = __builtin_fmaf(w1[c * 6 + 3 + k], d1, gQ);
+        }
+    }
+    float2* o = reinterpret_cast<float2*>(dx) + (size_t)b * T + t;
+    const float2 cur = *o;
+    *o = make_float2(cur.x + gI, cur.y + gQ);
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+static int kind_of(const odpd_model_t* m) {
+    switch (m->backbone) {
+    case ODPD_GRU: return K_GRU;
+    case ODPD_DGRU: return K_DGRU;
+    case ODPD_QGRU: return K_Q4;
+    case ODPD_QGRU_AMP1: return K_A4;
+    case ODPD_TRES_DELTAGRU: return K_TRES;
+    default: return -1;
+    }
+}
+static int tiles_of(int H) { return (H + 15) / 16; }
+static bool model_ok(const odpd_model_t* m) {
+    return kind_of(m) >= 0 && m->hidden >= 1 && m->hidden <= 32 && m->bits_w >= 2 && m->bits_w <= 16 && m->bits_a >= 2 && m->bits_a <= 16;
+}
+static int stride_of(int nt) { return nt == 1 ? 2 : 1; }
+template <int MK, int NT> static int groups(bool bwd, bool dx) { return !bwd ? QT<MK, NT>::NG_FWD : (dx ? QT<MK, NT>::NG_DX : QT<MK, NT>::NG_BWD); }
+template <int MK, int NT>
+static size_t lds_bytes(int P, int waves, int bits_a, bool lut, bool bwd, bool dx) {
+    using K = Kind<MK>;
+    const size_t per_wave = bwd ? 2 * 16 * K::XSTRIDE + (dx ? 2 : 1) * 2 * 16 * kChunkPad + QT<MK, NT>::kTiles * kTileFloats
+                                : 2 * 16 * K::XSTRIDE + 2 * 16 * kChunkPad;
+    size_t n = ((size_t)pad4(P) + s16_tab_floats(groups<MK, NT>(bwd, dx)) + (lut ? 2 * (1 << bits_a) + kMaxThr : 0) + (size_t)waves * per_wave) * sizeof(float);
+    const size_t need = ((size_t)pad4(P) + (size_t)waves * (P + kLossCols)) * sizeof(float);
+    if (bwd && n < need) n = need;
+    return n;
+}
+template <int MK, int NT>
+static LaunchShape shape(const odpd_model_t* m, int ngroups, bool bwd, bool dx) {
+    const int P = qat_layout(MK, m->hidden).P, cus = device_cus();
+    const bool lut = m->bits_a <= 8;
+    LaunchShape ls;
+    ls.waves = 4;
+    while (ls.waves > 1 && lds_bytes<MK, NT>(P, ls.waves, m->bits_a, lut, bwd, dx) > kMaxLds) --ls.waves;
+    const int need = (ngroups + ls.waves - 1) / ls.waves;
+    ls.grid = need < cus ? need : cus;
+    if (ls.grid < 1) ls.grid = 1;
+    return ls;
+}
+template <int MK, int NT, bool LUT>
+static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
+    using T = QT<MK, NT>;
+    const int P = qat_layout(MK, m->hidden).P;
+    a.nck = (a.T + T::S - 1) / T::S;
+    if (mode == 1) {
+        const LaunchShape ls = shape<MK, NT>(m, a.ngroups, false, false);
+        const size_t lds = lds_bytes<MK, NT>(P, ls.waves, m->bits_a, LUT, false, false);
+        if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+        auto k = qat16_fwd_kernel<MK, NT, LUT>;
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a, m->bits_w, m->bits_a, (m->flags & ODPD_FLAG_EVAL) ? 1 : 0);
+        return (int)hipGetLastError();
+    }
+    if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
+    if (!a.ckpt && a.nck > 1) return ODPD_EINVAL;
+    const bool dx = a.dx != nullptr;
+    // the grid (= rows of partials) must not depend on whether dL/dx is asked for: sized for the larger (dx) footprint
+    const LaunchShape ls = shape<MK, NT>(m, a.ngroups, true, true);
+    const size_t lds = lds_bytes<MK, NT>(P, ls.waves, m->bits_a, LUT, true, dx);
+    if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+    auto go = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a, m->bits_w, m->bits_a);
+        return (int)hipGetLastError();
+    };
+    if (!dx) return go(qat16_bwd_kernel<MK, NT, LUT, false>);
+    if (int e = go(qat16_bwd_kernel<MK, NT, LUT, true>)) return e;
+    if (MK == K_TRES) {
+        const QatLayout L = qat_layout(MK, m->hidden);
+        const long n = (long)a.B * a.T;
+        hipLaunchKernelGGL(qtres_skip_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.x, a.dy, a.params + L.o_tcn0,
+                           a.params + L.o_tcn2, a.dx, a.B, a.T);
+    }
+    return (int)hipGetLastError();
+}
+template <int MK>
+static int launch_kind(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int mode) {
+    const int nt = tiles_of(m->hidden);
+    const bool lut = m->bits_a <= 8;
+    if (nt == 1) return lut ? launch<MK, 1, true>(st, m, a, mode) : launch<MK, 1, false>(st, m, a, mode);
+    if (nt == 2) return lut ? launch<MK, 2, true>(st, m, a, mode) : launch<MK, 2, false>(st, m, a, mode);
+    return ODPD_EUNSUPPORTED;
+}
+template <int MK>
+static int rows_kind(const odpd_model_t* m, int ngroups) {
+    return tiles_of(m->hidden) == 1 ? shape<MK, 1>(m, ngroups, true, true).grid : shape<MK, 2>(m, ngroups, true, true).grid;
+}
+}  // namespace q16
+
+bool qat_s16_supported(const odpd_model_t* m) { return q16::model_ok(m); }
+int64_t qat_s16_param_count(const odpd_model_t* m) {
+    return q16::model_ok(m) ? (int64_t)q16::qat_layout(q16::kind_of(m), m->hidden).P : (int64_t)ODPD_EUNSUPPORTED;
+}
+int64_t qat_s16_ckpt_floats(const odpd_model_t* m, int B, int T) {
+    if (!q16::model_ok(m)) return ODPD_EUNSUPPORTED;
+    const int nt = q16::tiles_of(m->hidden), S = q16::stride_of(nt);
+    const int per = m->backbone == ODPD_TRES_DELTAGRU ? 6 * nt + 1 : nt;
+    return (int64_t)((B + 15) / 16) * ((T + S - 1) / S) * per * 256;
+}
+int qat_s16_rows(const odpd_model_t* m, int B) {
+    if (!q16::model_ok(m)) return ODPD_EUNSUPPORTED;
+    const int ng = (B + 15) / 16;
+    switch (q16::kind_of(m)) {
+    case q16::K_GRU: return q16::rows_kind<q16::K_GRU>(m, ng);
+    case q16::K_DGRU: return q16::rows_kind<q16::K_DGRU>(m, ng);
+    case q16::K_Q4: return q16::rows_kind<q16::K_Q4>(m, ng);
+    case q16::K_A4: return q16::rows_kind<q16::K_A4>(m, ng);
+    default: return q16::rows_kind<q16::K_TRES>(m, ng);
+    }
+}
+// mode 1 forward, 2 backward
+int qat_s16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int mode) {
+    if (!q16::model_ok(m)) return ODPD_EUNSUPPORTED;
+    SeqArgs a = a0;
+    a.ngroups = (a.B + 15) / 16;
+    switch (q16::kind_of(m)) {
+    case q16::K_GRU: return q16::launch_kind<q16::K_GRU>(st, m, a, mode);
+    case q16::K_DGRU: return q16::launch_kind<q16::K_DGRU>(st, m, a, mode);
+    case q16::K_Q4: return q16::launch_kind<q16::K_Q4>(st, m, a, mode);
+    case q16::K_A4: return q16::launch_kind<q16::K_A4>(st, m, a, mode);
+    default: return q16::launch_kind<q16::K_TRES>(st, m, a, mode);
+    }
+}
+
+}  // namespace odpd

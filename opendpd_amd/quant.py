@@ -1,12 +1,13 @@
-"""Quantisation-aware QGRU: drop-in for the reference's `quant.get_quant_model` (quant/__init__.py:20-37) applied to a
-`CoreModel('qgru' | 'qgru_amp1')`.
+"""Quantisation-aware training: drop-in for the reference's `quant.get_quant_model` (quant/__init__.py:20-37).
 
 The reference performs model surgery (quant/quant_envs.py:138-306): nn.GRU -> Python GRU of GRUCells (re-initialised),
-nn.Linear -> INT_Linear, Sigmoid/Tanh/Add/Mul -> Quant_* with one power-of-two scale parameter each.  Here the result of
-that surgery is a single HIP-backed backbone, `QuantQGRU`, with the same parameter / buffer names
-(`backbone.rnn.rnn_cell_list.0.{x2h,h2h}.{weight,bias,weight_quantizer.scale,...}`, `...{sigmoid,tanh,add,mul}.quantizer.scale`,
-`backbone.fc_out.*`) so state dicts are interchangeable, and the same construction-time RNG consumption.
-Kernels: csrc/qgru_family.hip (integer-grid arithmetic bit-exact with the reference for 8-bit grids)."""
+nn.Linear -> INT_Linear, Sigmoid/Tanh/Add/Mul modules -> Quant_* with one power-of-two scale parameter each.  Here the result of
+that surgery is a single HIP-backed backbone — `QuantGRUCellModel` for gru / dgru / qgru / qgru_amp1, `QuantTResDeltaGRU` for
+deltagru_tcnskip — with the same parameter / buffer names (`backbone.rnn.rnn_cell_list.0.{x2h,h2h}.{weight,bias,
+weight_quantizer.scale,...}`, `...{sigmoid,tanh,add,mul}.quantizer.scale`, `backbone.fc_out.*`, ...) so state dicts are
+interchangeable, and the same construction-time RNG consumption.
+Kernels: csrc/qat_s16.hip (16 sequences per wave, every kind, hidden <= 32) and csrc/qgru_family.hip (qgru / qgru_amp1 at hidden <= 16
+and small batches); integer-grid arithmetic bit-exact with the reference for 8-bit grids."""
 import math
 
 import numpy as np
@@ -44,10 +45,12 @@ class _QScale(nn.Module):
 class _QLinear(nn.Module):
     """INT_Linear state (quant_layers.py:48-85): weight, bias, n_bits buffers, weight/act/out quantisers."""
 
-    def __init__(self, in_features, out_features, bits_w, bits_a):
+    def __init__(self, in_features, out_features, bits_w, bits_a, bias=True):
         super().__init__()
-        lin = nn.Linear(in_features, out_features, bias=True)       # same default-init RNG draws as INT_Linear.__init__
-        self.weight, self.bias = lin.weight, lin.bias
+        lin = nn.Linear(in_features, out_features, bias=bias)       # same default-init RNG draws as INT_Linear.__init__
+        self.weight = lin.weight
+        if bias:
+            self.bias = lin.bias
         self.register_buffer("n_bits_w", torch.Tensor([bits_w]))
         self.register_buffer("n_bits_a", torch.Tensor([bits_a]))
         self.weight_quantizer = _QScale(bits_w, 2.0 ** (2 - bits_w))
@@ -76,23 +79,15 @@ class _QRnn(nn.Module):
         self.rnn_cell_list = nn.ModuleList([_QCell(input_size, hidden_size, bits_w, bits_a)])
 
 
-class QuantQGRU(NativeBackbone):
-    """Quantised qgru / qgru_amp1 backbone."""
+class _QuantBase(NativeBackbone):
+    """What the quantised backbones share: the optimiser's skip mask, the mode flag, the checkpoint buffers."""
 
-    def __init__(self, backbone_name, hidden_size, bits_w, bits_a):
-        super().__init__()
-        self.backbone_name = backbone_name
-        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, 4, 2, 1
+    def _finish(self, hidden_size, bits_w, bits_a, thx=0.0, thh=0.0):
         self.n_bits_w, self.n_bits_a = bits_w, bits_a
-        self.rnn = _QRnn(4, hidden_size, bits_w, bits_a)
-        self.fc_out = _QLinear(hidden_size, 2, bits_w, bits_a)
-        self.fc_out.out_quant = True                                 # quant_envs.py:304
-        self._finalize(hidden_size, bits_w=bits_w, bits_a=bits_a)
-        names = [n for n, _ in self.named_parameters()]
+        self._finalize(hidden_size, thx, thh, bits_w=bits_w, bits_a=bits_a)
         # AdamW skips parameters whose grad is None: the out_quantizer scales never enter the train-mode graph
-        self.frozen_mask = torch.tensor(np.concatenate([np.full(p.numel(), "out_quantizer" in n)
-                                                        for n, p in self.named_parameters()]))
-        self._names = names
+        self.frozen_mask = torch.tensor(np.concatenate([np.full(p.numel(), "out_quantizer" in n) for n, p in self.named_parameters()]))
+        self._names = [n for n, _ in self.named_parameters()]
 
     def forward(self, x, h_0=None):
         self.sync_mode()
@@ -105,7 +100,7 @@ class QuantQGRU(NativeBackbone):
         self.desc.flags = (self.desc.flags & ~_lib.FLAG_EVAL) | (0 if self.training else _lib.FLAG_EVAL)
         for name, m in self.named_modules():
             if isinstance(m, _QScale):
-                # x2h / h2h never use their out_quantizer (out_quant is False there), fc_out's runs in eval mode only
+                # only fc_out has out_quant set (quant_envs.py:278-287), and its output quantiser runs in eval mode only
                 if not name.endswith("out_quantizer") or (name == "fc_out.out_quantizer" and not self.training):
                     m.exercised = True
 
@@ -123,60 +118,202 @@ class QuantQGRU(NativeBackbone):
         return super().state_dict(*args, **kwargs)
 
 
+_CELL_FEATURES = {"gru": 2, "dgru": 6, "qgru": 4, "qgru_amp1": 4}
+
+
+class QuantGRUCellModel(_QuantBase):
+    """gru / dgru / qgru / qgru_amp1 after the surgery: nn.GRU -> GRU of GRUCells (quant_envs.py:114-130), its Linears and the
+    backbone's fc_out (dgru: and fc_hid) -> INT_Linear (:290-306).  Parameter registration order = the reference's
+    named_parameters(): rnn, fc_out, fc_hid (dgru.py:22-32)."""
+
+    def __init__(self, backbone_name, hidden_size, bits_w, bits_a):
+        super().__init__()
+        self.backbone_name = backbone_name
+        F = _CELL_FEATURES[backbone_name]
+        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, F, 2, 1
+        self.rnn = _QRnn(F, hidden_size, bits_w, bits_a)
+        self.fc_out = _QLinear(hidden_size + (6 if backbone_name == "dgru" else 0), 2, bits_w, bits_a)
+        self.fc_out.out_quant = True                                 # quant_envs.py:304
+        if backbone_name == "dgru":
+            self.fc_hid = _QLinear(hidden_size, hidden_size, bits_w, bits_a)
+        self._finish(hidden_size, bits_w, bits_a)
+
+
+QuantQGRU = QuantGRUCellModel      # the r01 / r02 name
+
+
+class _QDeltaLayer(nn.Module):
+    """DeltaGRULayer of deltagru_tcnskip.py:133-162 after the surgery: bias-free INT_Linear x2h / h2h, Quant_add / mult / sigmoid /
+    tanh in the layer's own registration order."""
+
+    def __init__(self, hidden_size, bits_w, bits_a):
+        super().__init__()
+        self.x2h = _QLinear(6, 3 * hidden_size, bits_w, bits_a, bias=False)
+        self.h2h = _QLinear(hidden_size, 3 * hidden_size, bits_w, bits_a, bias=False)
+        self.add, self.mul, self.sigmoid, self.tanh = _QOp(bits_a), _QOp(bits_a), _QOp(bits_a), _QOp(bits_a)
+
+
+class _Weight(nn.Module):
+    """A convolution's weight without the convolution (and without its default-init RNG draws: the reference deep-copies these)."""
+
+    def __init__(self, *shape):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(*shape))
+
+
+class QuantTResDeltaGRU(_QuantBase):
+    """deltagru_tcnskip after the surgery (the OpenDPDv2 QAT stage, bash_scripts/OpenDPDv2.sh:84-117): quantised delta cell and
+    fc_out, float TCN skip (Conv1d / Hardswish are not swapped).  Same thresholds / sparsity interface as the float backbone."""
+    backbone_name = "deltagru_tcnskip"
+
+    def __init__(self, hidden_size, bits_w, bits_a, thx=0.0, thh=0.0):
+        super().__init__()
+        from .backbones.deltagru import _DeltaStats
+        self.hidden_size, self.input_size, self.output_size, self.num_layers, self.bias = hidden_size, 6, 2, 1, True
+        self.rnn = _QDeltaLayer(hidden_size, bits_w, bits_a)
+        self.fc_out = _QLinear(hidden_size, 2, bits_w, bits_a, bias=False)
+        self.fc_out.out_quant = True
+        self.tcn = nn.Sequential(_Weight(3, 2, 3), nn.Identity(), _Weight(2, 3, 1), nn.Identity())
+        self.thx, self.thh = thx, thh
+        self._dstats = _DeltaStats()
+        self.debug = 1
+        self._finish(hidden_size, bits_w, bits_a, thx, thh)
+
+    def _stats_buffer(self, device):
+        return self._dstats.buffer(device) if self.debug else None
+
+    def set_debug(self, value):
+        self.debug = value
+        self._dstats.reset()
+
+    @property
+    def statistics(self):
+        return self._dstats.as_dict()
+
+    def get_temporal_sparsity(self):
+        """deltagru_tcnskip.py:105-129 on the quantised module: the 'weight' / 'bias' name tests see the quantiser scales too."""
+        st = self._dstats.as_dict()
+        out = {}
+        if self.debug and st["num_dx_numel"] > 0:
+            rnn_w = sum(p.numel() for n, p in self.rnn.named_parameters() if "weight" in n)
+            rnn_b = sum(p.numel() for n, p in self.rnn.named_parameters() if "bias" in n)
+            fc = sum(p.numel() for p in self.fc_out.parameters()) + sum(p.numel() for p in self.tcn.parameters())
+            tz, tn = st["num_dx_zeros"] + st["num_dh_zeros"], st["num_dx_numel"] + st["num_dh_numel"]
+            out["SP_T_DX"] = float(st["num_dx_zeros"] / st["num_dx_numel"])
+            out["SP_T_DH"] = float(st["num_dh_zeros"] / st["num_dh_numel"])
+            out["SP_T_DV"] = float(tz / tn)
+            out["HW_PARAM"] = float(fc + rnn_w * (1 - float(tz / tn)) + rnn_b)
+        return out
+
+
+MAX_HIDDEN = 32          # csrc/qat_s16.hip: two 16-unit tiles
+_UNTOUCHED = ("gmp", "tcnn")       # no nn.GRU, no nn.Linear, no op modules: the surgery returns an identical deep copy
+_PARTIAL = ("lstm", "vdlstm", "rvtdcnn", "apnrru", "bojanet", "deltajanet", "dvrjanet", "neuraltx", "mcldnn", "pgjanet")
+
+
+def _warn_float(exc, model):
+    print(f"[WARN] Quantization setup failed: {exc}. Using float model instead.")
+    return model
+
+
 def get_quant_model(proj, model):
     """Reference semantics (quant/__init__.py:20-37): identity unless `proj.quant`; otherwise the quantised model.
     `proj` needs n_bits_w, n_bits_a and optionally pretrained_model.
 
+    The surgery is generic (quant_envs.py:114-130, 290-306).  HIP-backed here: gru, dgru, qgru, qgru_amp1 (GRU of GRUCells, INT_Linear
+    heads) and deltagru_tcnskip (its layer's Linears and op modules), one layer, hidden <= 32; gmp and tcnn contain nothing the surgery
+    swaps (the reference hands back an identical copy: the model itself is returned).  deltagru's layer IS an nn.GRU subclass, the
+    reference swaps it for a plain GRU and then fails in forward (TypeError, deltagru.py:74-77): refused here at construction.  The
+    backbones in which only some nn.Linear become INT_Linear (lstm, vdlstm, rvtdcnn, ...) have no quantised kernels yet.
+
     `pretrained_model` follows Base_GRUQuantEnv.load_model (quant_envs.py:173-182): the checkpoint is strict-loaded into the FLOAT
-    holder (keys `backbone.rnn.rnn_cell_list.0.{x2h,h2h}.{weight,bias}`, `backbone.fc_out.{weight,bias}`) before quantisation;
-    INT_Linear then keeps the weights and draws fresh biases (quant_layers.py:48-56), the scales start at their defaults.  Any other
-    key set — the nn.GRU names of a float `train_dpd` checkpoint, or a quantised checkpoint with its scales and buffers — makes that
-    strict load raise in the reference, whose get_quant_model then warns and returns the float model it was given
-    (quant/__init__.py:35-37); the same happens here (pinned by tests/golden/quant_pretrained_qgru_h10.npz)."""
+    holder before quantisation — for the GRU-cell models its keys are `backbone.rnn.rnn_cell_list.0.{x2h,h2h}.{weight,bias}`,
+    `backbone.fc_out.*` (+ `backbone.fc_hid.*`), for deltagru_tcnskip the float model's own keys (so a float `train_dpd` checkpoint
+    loads: the OpenDPDv2 flow).  INT_Linear then keeps the weights and draws fresh biases (quant_layers.py:48-56), the scales start at
+    their defaults.  Any failure on the way (unreadable file, other key set, other shapes) raises inside the reference's try block:
+    it warns and returns the float model it was given (quant/__init__.py:35-37), after the RNG draws made up to that point — the
+    same happens here (tests/golden/quant_pretrained_qgru_h10.npz)."""
     if not getattr(proj, "quant", False):
         return model
-    if not isinstance(model, CoreModel) or model.backbone_type not in ("qgru", "qgru_amp1"):
-        raise NotImplementedError("quantisation-aware training is implemented for the qgru / qgru_amp1 backbones")
+    bt = getattr(model, "backbone_type", None)
+    if not isinstance(model, CoreModel) or bt is None:
+        raise NotImplementedError("quantisation-aware training takes a CoreModel")
+    if bt in _UNTOUCHED:
+        return model
+    if bt == "deltagru":
+        raise RuntimeError("--quant on 'deltagru': its layer subclasses nn.GRU, the reference's surgery replaces it by a plain GRU and the "
+                           "model then fails in forward (TypeError); use 'deltagru_tcnskip'")
+    if bt in _PARTIAL:
+        raise NotImplementedError(f"--quant on '{bt}' (only its nn.Linear layers become INT_Linear in the reference) has no HIP kernels yet")
     bits_w, bits_a = int(getattr(proj, "n_bits_w", 8)), int(getattr(proj, "n_bits_a", 8))
     H = model.hidden_size
-    if H > 16 or model.num_layers != 1:
-        raise NotImplementedError("the QAT kernels cover one layer and hidden_size <= 16 (csrc/qgru_family.hip)")
+    if H > MAX_HIDDEN or model.num_layers != 1:
+        raise NotImplementedError(f"the QAT kernels cover one layer and hidden_size <= {MAX_HIDDEN} (csrc/qat_s16.hip)")
     dev = next(model.parameters()).device
     pre = getattr(proj, "pretrained_model", "")
+    tres = bt == "deltagru_tcnskip"
+    holder = None
+    if not tres:
+        # --- RNG consumption order of Base_GRUQuantEnv (quant_envs.py:156-171, 198-246, 290-306) ----------------------
+        # 1. recur_rpls_gru: PYGRU -> GRUCell(F,H): two nn.Linear default inits, then GRUCell.reset_parameters (uniform over
+        #    x2h.weight, x2h.bias, h2h.weight, h2h.bias — quant/modules/gru.py:24-29)
+        F = _CELL_FEATURES[bt]
+        std = 1.0 / math.sqrt(H)
+        holder = nn.Module()
+        holder.x2h, holder.h2h = nn.Linear(F, 3 * H), nn.Linear(H, 3 * H)
+        for w in holder.parameters():
+            nn.init.uniform_(w, -std, std)
+        # 2. _reset_pygru: biases 0, gate blocks orthogonal, x2h.weight gate blocks xavier (quant_envs.py:205-227)
+        init_gatewise(holder, H, xavier_suffix="x2h.weight")
     pre_sd = None
     if pre:
-        pre_sd = torch.load(pre, map_location="cpu")
-        cellp = "backbone.rnn.rnn_cell_list.0."
-        want = {cellp + "x2h.weight": (3 * H, 4), cellp + "x2h.bias": (3 * H,), cellp + "h2h.weight": (3 * H, H),
-                cellp + "h2h.bias": (3 * H,), "backbone.fc_out.weight": (2, H), "backbone.fc_out.bias": (2,)}
-        bad = set(pre_sd) != set(want) or any(tuple(pre_sd[k].shape) != s for k, s in want.items())
+        # load_model runs after create_pygru_model, inside get_quant_model's try block
+        try:
+            pre_sd = torch.load(pre, map_location="cpu")
+        except Exception as exc:
+            return _warn_float(exc, model)
+        if tres:
+            want = {"backbone.rnn.x2h.weight": (3 * H, 6), "backbone.rnn.h2h.weight": (3 * H, H), "backbone.fc_out.weight": (2, H),
+                    "backbone.tcn.0.weight": (3, 2, 3), "backbone.tcn.2.weight": (2, 3, 1)}
+        else:
+            cellp = "backbone.rnn.rnn_cell_list.0."
+            OW = H + 6 if bt == "dgru" else H
+            want = {cellp + "x2h.weight": (3 * H, F), cellp + "x2h.bias": (3 * H,), cellp + "h2h.weight": (3 * H, H),
+                    cellp + "h2h.bias": (3 * H,), "backbone.fc_out.weight": (2, OW), "backbone.fc_out.bias": (2,)}
+            if bt == "dgru":
+                want.update({"backbone.fc_hid.weight": (H, H), "backbone.fc_hid.bias": (H,)})
+        bad = not isinstance(pre_sd, dict) or set(pre_sd) != set(want) or any(tuple(pre_sd[k].shape) != s for k, s in want.items())
         if bad:
-            missing, extra = sorted(set(want) - set(pre_sd)), sorted(set(pre_sd) - set(want))
-            print(f"[WARN] Quantization setup failed: Error(s) in loading state_dict for CoreModel: missing {missing[:4]}, "
-                  f"unexpected {extra[:4]}{' ...' if len(extra) > 4 else ''}. Using float model instead.")
-            return model
-    # --- RNG consumption order of Base_GRUQuantEnv (quant_envs.py:156-171, 198-246, 290-306) ----------------------
-    # 1. recur_rpls_gru: PYGRU -> GRUCell(4,H): two nn.Linear default inits, then GRUCell.reset_parameters (uniform over
-    #    x2h.weight, x2h.bias, h2h.weight, h2h.bias — quant/modules/gru.py:24-29)
-    std = 1.0 / math.sqrt(H)
-    holder = nn.Module()
-    holder.x2h, holder.h2h = nn.Linear(4, 3 * H), nn.Linear(H, 3 * H)
-    for w in holder.parameters():
-        nn.init.uniform_(w, -std, std)
-    # 2. _reset_pygru: biases 0, gate blocks orthogonal, x2h.weight gate blocks xavier (quant_envs.py:205-227)
-    init_gatewise(holder, H, xavier_suffix="x2h.weight")
-    # 3. create_quantized_model: INT_Linear(m) for x2h, h2h, then fc_out: each draws a fresh default nn.Linear init and keeps
-    #    only m.weight — the bias stays the freshly drawn one (quant_layers.py:48-56)
-    bb = QuantQGRU(model.backbone_type, H, bits_w, bits_a)
-    cell = bb.rnn.rnn_cell_list[0]
+            keys = set(pre_sd) if isinstance(pre_sd, dict) else set()
+            missing, extra = sorted(set(want) - keys), sorted(keys - set(want))
+            return _warn_float(f"Error(s) in loading state_dict for CoreModel: missing {missing[:4]}, unexpected {extra[:4]}"
+                               f"{' ...' if len(extra) > 4 else ''}", model)
+    # 3. create_quantized_model: INT_Linear(m) for every nn.Linear in named_children order (x2h, h2h, fc_out, fc_hid): each draws a
+    #    fresh default nn.Linear init and keeps only m.weight — a bias stays the freshly drawn one (quant_layers.py:48-56)
+    fb = model.backbone
     with torch.no_grad():
-        cell.x2h.weight.copy_(holder.x2h.weight)
-        cell.h2h.weight.copy_(holder.h2h.weight)
-        bb.fc_out.weight.copy_(model.backbone.fc_out.weight.detach().cpu())
-        if pre_sd is not None:          # load_model ran between steps 2 and 3: the weights INT_Linear keeps are the checkpoint's
-            cell.x2h.weight.copy_(pre_sd[cellp + "x2h.weight"])
-            cell.h2h.weight.copy_(pre_sd[cellp + "h2h.weight"])
-            bb.fc_out.weight.copy_(pre_sd["backbone.fc_out.weight"])
+        if tres:
+            bb = QuantTResDeltaGRU(H, bits_w, bits_a, thx=model.thx, thh=model.thh)
+            src = pre_sd if pre_sd is not None else {"backbone." + k: v.detach().cpu() for k, v in fb.state_dict().items()}
+            bb.rnn.x2h.weight.copy_(src["backbone.rnn.x2h.weight"])
+            bb.rnn.h2h.weight.copy_(src["backbone.rnn.h2h.weight"])
+            bb.fc_out.weight.copy_(src["backbone.fc_out.weight"])
+            bb.tcn[0].weight.copy_(src["backbone.tcn.0.weight"])
+            bb.tcn[2].weight.copy_(src["backbone.tcn.2.weight"])
+        else:
+            bb = QuantGRUCellModel(bt, H, bits_w, bits_a)
+            cell = bb.rnn.rnn_cell_list[0]
+            cell.x2h.weight.copy_(holder.x2h.weight)
+            cell.h2h.weight.copy_(holder.h2h.weight)
+            bb.fc_out.weight.copy_(fb.fc_out.weight.detach().cpu())
+            if bt == "dgru":
+                bb.fc_hid.weight.copy_(fb.fc_hid.weight.detach().cpu())
+            if pre_sd is not None:          # load_model ran between steps 2 and 3: the weights INT_Linear keeps are the checkpoint's
+                cell.x2h.weight.copy_(pre_sd[cellp + "x2h.weight"])
+                cell.h2h.weight.copy_(pre_sd[cellp + "h2h.weight"])
+                bb.fc_out.weight.copy_(pre_sd["backbone.fc_out.weight"])
+                if bt == "dgru":
+                    bb.fc_hid.weight.copy_(pre_sd["backbone.fc_hid.weight"])
     q = CoreModel.__new__(CoreModel)
     nn.Module.__init__(q)
     for k in ("output_size", "input_size", "hidden_size", "num_layers", "backbone_type", "thx", "thh", "window_size",

@@ -21,7 +21,18 @@ def test_library_builds_and_exports_header_symbols():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     assert declared == set(_lib.exported_symbols())
-    assert lib.odpd_abi_version() == 6
+    assert lib.odpd_abi_version() == 7
+
+
+def test_no_kernel_spills_beyond_the_recorded_allowance():
+    """Every instantiation's register / scratch usage is recorded at build time (-Rpass-analysis=kernel-resource-usage ->
+    lib/kernel_resources.json).  A kernel that starts to spill, or spills more than when it was validated
+    (csrc/known_scratch.json), is where a compiler bump changes schedules silently: fail here, re-validate, then re-record."""
+    import __graft_entry__ as g
+    g.build()
+    from opendpd_amd import build as hb
+    assert os.path.exists(hb.RESOURCES)
+    assert hb.unexpected_scratch() == []
 
 
 def test_param_counts_match_reference():
@@ -34,6 +45,11 @@ def test_param_counts_match_reference():
                      ("pgjanet", 11, 959), ("qgru", 10, 502), ("qgru_amp1", 16, 1090), ("gmp", 11, 495), ("rvtdcnn", 25, 1007),
                      ("rvtdcnn", 6, 266), ("neuraltx", 36, 986), ("deltajanet", 15, 722), ("deltajanet", 22, 1366)]:
         d = _lib.ModelDesc(_lib.BACKBONE_IDS[bb], H, 0, 0, 0, 0, 0)
+        assert lib.odpd_param_count(C.byref(d)) == P, bb
+    # quantised models (bits_w > 0): + the quantiser scales of the surgery's result [measured on the reference: tests/golden/quant_*.npz]
+    for bb, H, P in [("qgru", 10, 515), ("gru", 11, 532), ("gru", 23, 1924), ("dgru", 13, 1057), ("dgru", 23, 2767), ("qgru", 20, 1615),
+                     ("qgru", 30, 3315), ("deltagru_tcnskip", 15, 1012), ("deltagru_tcnskip", 30, 3337)]:
+        d = _lib.ModelDesc(_lib.BACKBONE_IDS[bb], H, 0, 0, 8, 8, 0)
         assert lib.odpd_param_count(C.byref(d)) == P, bb
 
 

@@ -10,14 +10,18 @@ class _Proj:
     pretrained_model = ""
 
 
-def _build(bb, H, bits):
+def _build(bb, H, bits, thx=0.0, thh=0.0, pretrained=""):
     from opendpd_amd import CoreModel
     from opendpd_amd.quant import get_quant_model
     torch.manual_seed(0)
-    fnet = CoreModel(2, H, 1, bb)
+    fnet = CoreModel(2, H, 1, bb, thx=thx, thh=thh)
     _Proj.n_bits_w = _Proj.n_bits_a = bits
+    _Proj.pretrained_model = pretrained
     torch.manual_seed(123)       # the fixture generator seeds here, before the reference's get_quant_model
-    return get_quant_model(_Proj, fnet)
+    try:
+        return get_quant_model(_Proj, fnet)
+    finally:
+        _Proj.pretrained_model = ""
 
 
 def test_quant_state_dict_matches_reference_bitwise():
@@ -30,6 +34,45 @@ def test_quant_state_dict_matches_reference_bitwise():
         for k in ref_keys:      # side-effect buffers included: no forward has run yet, they hold their construction-time values
             assert np.array_equal(sd[k].numpy(), fx["sd/" + k]), k
         assert sum(p.numel() for p in q.parameters()) == fx.meta["n_param"]
+
+
+def test_general_surgery_state_dicts_and_rng_match_the_reference(tmp_path):
+    """gru / dgru (GRU swap + INT_Linear heads), qgru beyond 16 units, deltagru_tcnskip (its op modules and Linears; also from a float
+    `--pretrained_model` checkpoint = the OpenDPDv2 flow): identical keys, order, values (parameters AND buffers) and the same global
+    RNG state afterwards as the reference's get_quant_model (oracle/gen_golden_quant_more.py)."""
+    from tests.test_oracle_golden import QAT_MORE
+    for name, bb, bits in QAT_MORE:
+        fx = Fixture(name)
+        pre = ""
+        if fx.meta["pretrained"]:
+            pre = str(tmp_path / (name + ".pt"))
+            torch.save({k: torch.from_numpy(fx["pre/" + k]) for k in fx.keys("pre")}, pre)
+        q = _build(bb, fx.meta["hidden"], bits, fx.meta["thx"], fx.meta["thh"], pre)
+        rng_after = torch.rand(4).numpy()
+        sd = q.state_dict()
+        assert list(sd.keys()) == fx.keys("sd"), name
+        for k in fx.keys("sd"):
+            assert np.array_equal(sd[k].numpy(), fx["sd/" + k]), (name, k)
+        assert sum(p.numel() for p in q.parameters()) == fx.meta["n_param"]
+        assert np.array_equal(rng_after, fx["rng_after"]), name
+        if fx.meta["pretrained"]:
+            assert np.array_equal(sd["backbone.rnn.x2h.weight"].numpy(), fx["pre/backbone.rnn.x2h.weight"])
+
+
+def test_surgery_on_the_other_backbones():
+    """gmp / tcnn hold nothing the surgery swaps (the reference returns an identical copy); deltagru's quantised model cannot run in
+    the reference either; the partially swapped backbones and configurations beyond the kernels say so."""
+    import pytest
+    from opendpd_amd import CoreModel
+    from opendpd_amd.quant import get_quant_model
+    _Proj.n_bits_w = _Proj.n_bits_a = 8
+    for bb in ("gmp", "tcnn"):
+        net = CoreModel(2, 11, 1, bb)
+        assert get_quant_model(_Proj, net) is net
+    with pytest.raises(RuntimeError):
+        get_quant_model(_Proj, CoreModel(2, 8, 1, "deltagru"))
+    with pytest.raises(NotImplementedError):
+        get_quant_model(_Proj, CoreModel(2, 8, 1, "lstm"))
 
 
 def test_identity_when_quant_off():

@@ -1,0 +1,223 @@
+"""GPU parity of the general quantisation-aware kernels (csrc/qat_s16.hip): gru / dgru through the GRU swap, qgru beyond 16 hidden
+units, deltagru_tcnskip (the OpenDPDv2 QAT stage) — against vectors produced by RUNNING the reference's surgery
+(oracle/gen_golden_quant_more.py) and against the oracle on ragged shapes.  8-bit grids: bit-exact (deltagru_tcnskip adds its
+float skip path to the grid-valued fc_out result: 1 ulp of that sum, three orders below one grid step); 16-bit grids: one LSB."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import Fixture, rel_err
+from tests.test_oracle_golden import QAT_MORE, qat_param_names
+
+pytestmark = pytest.mark.gpu
+
+
+class _Proj:
+    quant = True
+    pretrained_model = ""
+
+
+def _fresh(bb, H, bits, thx=0.0, thh=0.0):
+    from opendpd_amd import CoreModel
+    from opendpd_amd.quant import get_quant_model
+    _Proj.n_bits_w = _Proj.n_bits_a = bits
+    return get_quant_model(_Proj, CoreModel(2, H, 1, bb, thx=thx, thh=thh))
+
+
+def _qmodel(fx, bb, bits, prefix="sd"):
+    q = _fresh(bb, fx.meta["hidden"], bits, fx.meta["thx"], fx.meta["thh"])
+    q.load_state_dict({k: torch.from_numpy(fx[f"{prefix}/" + k]) for k in fx.keys(prefix)})
+    return q.cuda()
+
+
+def _stats(q):
+    s = q.backbone.statistics
+    return np.array([s["num_dx_zeros"], s["num_dx_numel"], s["num_dh_zeros"], s["num_dh_numel"]])
+
+
+@pytest.mark.parametrize("name,bb,bits", QAT_MORE)
+def test_forward_train_eval_match_the_reference(name, bb, bits):
+    fx = Fixture(name)
+    tres = bb == "deltagru_tcnskip"
+    tol = (2.5e-7 if tres else 0.0) if bits == 8 else 2.0 ** -12
+    x = torch.from_numpy(fx["x"]).cuda()
+    for prefix, ytr, yev in (("sd", "y", "y_eval"), ("sd3", "y_p3_train", "y_p3_eval")):
+        q = _qmodel(fx, bb, bits, prefix)
+        q.train()
+        if tres:
+            q.backbone.set_debug(1)
+        with torch.no_grad():
+            yt = q(x).cpu().numpy()
+        if tres and prefix == "sd":      # exact sparsity counters of the train-mode forward
+            assert np.abs(_stats(q) - fx["stats"]).max() <= (0 if bits == 8 else 2), (_stats(q), fx["stats"])
+        q.eval()
+        with torch.no_grad():
+            ye = q(x).cpu().numpy()
+        assert np.abs(yt - fx[ytr]).max() <= tol, (prefix, np.abs(yt - fx[ytr]).max())
+        assert np.abs(ye - fx[yev]).max() <= tol, (prefix, np.abs(ye - fx[yev]).max())
+    # config-shaped frames (T = 200), eval mode
+    q = _qmodel(fx, bb, bits)
+    q.eval()
+    if tres:
+        q.backbone.set_debug(1)
+    with torch.no_grad():
+        ya = q(torch.from_numpy(fx["xa"]).cuda()).cpu().numpy()
+    if bits == 8:
+        assert np.abs(ya - fx["ya_eval"]).max() <= tol
+        if tres:
+            assert np.array_equal(_stats(q), fx["stats_a"])
+    else:   # 16-bit grids: a flipped threshold decision sends THAT sequence onto another trajectory (as between two reference builds)
+        bad = np.abs(ya - fx["ya_eval"]).reshape(ya.shape[0], -1).max(1) > 2.0 ** -11
+        flips = np.abs(_stats(q) - fx["stats_a"]).max() if tres else 0
+        assert bad.sum() <= flips, (bad, flips)
+
+
+@pytest.mark.parametrize("name,bb,bits", QAT_MORE)
+def test_gradients_and_trajectory(name, bb, bits):
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    fx = Fixture(name)
+    q = _qmodel(fx, bb, bits)
+    q.train()
+    x = torch.from_numpy(fx["x"]).cuda().requires_grad_(True)
+    t = torch.from_numpy(fx["tgt"]).cuda()
+    loss = torch.nn.functional.mse_loss(q(x), t)
+    loss.backward()
+    assert abs(loss.item() - fx["losses"][0]) < (2e-6 if bits == 8 else 1e-4)
+    tol = 2e-5 if bits == 8 else 3e-3
+    for k, p in q.named_parameters():
+        if ("g/" + k) in fx:
+            assert rel_err(p.grad.cpu().numpy(), fx["g/" + k]) < tol or np.abs(fx["g/" + k]).max() == 0, k
+            if "scale" in k:
+                assert float(p.grad.abs().max()) == 0.0
+    assert rel_err(x.grad.cpu().numpy(), fx["gx"]) < tol
+    names = qat_param_names(fx)
+    opt = FusedAdamW(q, lr=fx.meta["lr"])
+    xd = x.detach()
+    for s in range(1, 4):
+        l = fused_train_step(opt, xd, t, "l2", fx.meta["clip"])
+        assert abs(l.item() - fx["losses"][s - 1]) < (2e-6 if bits == 8 else 1e-4)
+        got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in q.parameters()])
+        assert rel_err(got, fx.flat(f"p{s}", names)) < (3e-6 if bits == 8 else 1e-4), s
+
+
+def _signal(B, T, seed):
+    rng = np.random.RandomState(seed)
+    amp = 0.05 + 0.85 * rng.rand(B, T, 1)
+    ph = 2 * np.pi * rng.rand(B, T, 1)
+    # a slowly varying component so that thresholded deltas see both kept and dropped samples
+    amp = 0.5 * amp + 0.5 * np.repeat(amp[:, ::4], 4, axis=1)[:, :T]
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    return x, rng.randn(B, T, 2).astype(np.float32)
+
+
+RAGGED = [("gru", 11, 3, 5), ("gru", 16, 7, 33), ("gru", 23, 17, 40), ("gru", 32, 5, 66),
+          ("dgru", 13, 5, 37), ("dgru", 8, 33, 21), ("dgru", 23, 18, 35), ("dgru", 30, 3, 70),
+          ("qgru", 10, 19, 63), ("qgru", 20, 6, 33), ("qgru", 30, 35, 17), ("qgru_amp1", 20, 7, 50), ("qgru_amp1", 17, 16, 9),
+          ("deltagru_tcnskip", 15, 5, 37), ("deltagru_tcnskip", 9, 34, 50), ("deltagru_tcnskip", 16, 3, 130),
+          ("deltagru_tcnskip", 24, 7, 45), ("deltagru_tcnskip", 30, 19, 33)]
+
+
+@pytest.mark.parametrize("bb,H,B,T", RAGGED)
+def test_w8a8_matches_the_oracle_on_ragged_sizes(bb, H, B, T):
+    """Forward bit for bit (train and eval mode), weight gradients and dL/dx — together, and dL/dx alone (frozen model = the PA of a
+    cascade) — against the oracle, at hidden sizes on both sides of the 16-unit tile boundary."""
+    from oracle.oracle import Oracle, make_model
+    tres = bb == "deltagru_tcnskip"
+    thx, thh = (0.01, 0.05) if tres else (0.0, 0.0)
+    torch.manual_seed(H + B + T)
+    q = _fresh(bb, H, 8, thx, thh).cuda()
+    with torch.no_grad():      # biases and scales off their defaults: clamps and pass masks get exercised
+        g = torch.Generator().manual_seed(H)
+        for k, p in q.named_parameters():
+            if k.endswith("bias"):
+                p.copy_(((torch.rand(p.shape, generator=g) - 0.5) * 0.6).cuda())
+            elif k.endswith("weight") and p.dim() == 2:
+                p.mul_(1.7)
+    x, dy = _signal(B, T, B + T)
+    o = Oracle("f32")
+    m = make_model(bb, H, thx, thh, bits_w=8, bits_a=8)
+    p = np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in q.parameters()])
+    assert o.param_count(m) == p.size
+    tol = 2.5e-7 if tres else 0.0
+    q.eval()
+    with torch.no_grad():
+        ye = q(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.abs(ye - o.qat_forward(m, p, x, eval_mode=True)).max() <= tol
+    q.train()
+    if tres:
+        q.backbone.set_debug(1)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = q(xt)
+    st = np.zeros(4)
+    yo = o.qat_forward(m, p, x, stats=st)
+    assert np.abs(y.detach().cpu().numpy() - yo).max() <= tol
+    if tres:
+        assert np.array_equal(_stats(q), st)
+    y.backward(torch.from_numpy(dy).cuda())
+    go, dxo = o.qat_backward(m, p, x, dy, need_dx=True)
+    g = np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy().reshape(-1) for v in q.parameters()])
+    sizes = [v.numel() for v in q.parameters()]
+    off = 0
+    for (k, _), n in zip(q.named_parameters(), sizes):      # per tensor: every parameter tensor on its own scale
+        ref = go[off:off + n]
+        if np.abs(ref).max() > 0:
+            assert rel_err(g[off:off + n], ref) < 3e-5, k
+        else:
+            assert np.abs(g[off:off + n]).max() == 0, k
+        off += n
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < 3e-5
+    for v in q.parameters():
+        v.requires_grad_(False)
+    xt2 = torch.from_numpy(x).cuda().requires_grad_(True)
+    q(xt2).backward(torch.from_numpy(dy).cuda())
+    assert rel_err(xt2.grad.cpu().numpy(), dxo) < 3e-5
+
+
+@pytest.mark.parametrize("bb,H", [("qgru", 10), ("qgru_amp1", 16)])
+def test_both_kernel_mappings_agree_bitwise(bb, H):
+    """qgru / qgru_amp1 at hidden <= 16 are served by the row-rotated kernels at small batches and by the 16-sequences-per-wave
+    kernels at large ones: same outputs bit for bit, same gradients up to summation order."""
+    import ctypes as C
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(3)
+    q = _fresh(bb, H, 8).cuda()
+    x, dy = _signal(37, 41, 9)
+    outs = []
+    try:
+        for min_batch in (1 << 30, 0):
+            _lib.check(lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(min_batch)), "set_tuning")
+            for v in q.parameters():
+                v.grad = None
+            q.train()
+            y = q(torch.from_numpy(x).cuda())
+            y.backward(torch.from_numpy(dy).cuda())
+            outs.append((y.detach().cpu().numpy(), np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy().reshape(-1)
+                                                                   for v in q.parameters()])))
+    finally:
+        lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(-1))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert rel_err(outs[0][1], outs[1][1]) < 2e-5
+
+
+def test_openDPDv2_quantisation_stage_from_a_float_checkpoint(tmp_path):
+    """bash_scripts/OpenDPDv2.sh:84-117 in small: a float deltagru_tcnskip checkpoint -> `--quant --n_bits_w 16 --n_bits_a 16
+    --pretrained_model ...` -> the quantised model's outputs equal the reference's (to one 2^-14 LSB of its output grid)."""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.quant import get_quant_model
+    fx = Fixture("quant_tres_h15_w16a16_pre")
+    pre = tmp_path / "float.pt"
+    torch.save({k: torch.from_numpy(fx["pre/" + k]) for k in fx.keys("pre")}, pre)
+
+    class P:
+        quant = True
+        n_bits_w = n_bits_a = 16
+        pretrained_model = str(pre)
+    torch.manual_seed(0)
+    fnet = CoreModel(2, 15, 1, "deltagru_tcnskip", thx=fx.meta["thx"], thh=fx.meta["thh"])
+    torch.manual_seed(123)
+    q = get_quant_model(P, fnet).cuda()
+    q.eval()
+    with torch.no_grad():
+        y = q(torch.from_numpy(fx["x"]).cuda()).cpu().numpy()
+    assert np.abs(y - fx["y_eval"]).max() <= 2.0 ** -12
