@@ -21,7 +21,7 @@ inline bool qat_uses_s16(const odpd_model_t* m, int B) {
     const bool rot_ok = (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1) && m->hidden <= 16;
     if (!rot_ok) return true;
     long min_batch = tuning().s16_min_batch;
-    if (min_batch < 0) min_batch = 16L * 2 * device_cus();
+    if (min_batch < 0) min_batch = 16L * 3 * device_cus();
     return B >= min_batch;
 }
 inline Family family_of(int bb) {

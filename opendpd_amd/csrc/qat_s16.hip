@@ -94,6 +94,23 @@ __device__ __forceinline__ bool qpassb(float x, const Quant& q) {
 __device__ __forceinline__ float qpass(float x, const Quant& q) { return qpassb(x, q) ? 1.0f : 0.0f; }
 // activation-side quantisers (wave-uniform)
 struct QSc { Quant xa, ha, oa, sig, tnh, add, mul, out, hida; };
+// GRID UNITS.  Inside the kernels a quantised value travels as the integer k of q(x) = k s (an integer-valued float): the trailing
+// "* s" of every quantiser and the leading "/ s" of the next one fold into power-of-two constants (exact), the LUTs return gate values
+// already quantised and pre-scaled, and the mat-vecs run on integers (weights k_w, activations k_a), their scale s_a s_w being applied
+// by the one FMA that adds the fp32 bias:  fl(k S + b) == fl(fl(k S) + b)  because k S is exact.  Every rounding the reference makes
+// is made here too, on the same real number.
+struct QK {
+    float qn, qp;                               // activation clamp (bits_a)
+    float inv_xa, inv_ha, inv_oa, inv_hida, inv_add;
+    float Sx, Sh, So, Shid;                     // s_act * s_weight of x2h, h2h, fc_out, fc_hid
+    float s_add, s_mul, c_ma;                   // c_ma = s_mul / s_add
+    float c_sm, c_tm;                           // s_sig / s_mul, s_tanh / s_mul
+    float s_xa, s_ha, s_oa, s_hida;             // weight-gradient scales
+    float s_xw, s_hw, s_ow, s_hidw;             // data-gradient scales (ride on the pass masks)
+    float inv_sig, inv_tnh;
+};
+__device__ __forceinline__ float gk(float v, const QK& k) { return rintf(__builtin_amdgcn_fmed3f(v, k.qn, k.qp)); }      // v = x / s
+__device__ __forceinline__ float gm(float v, const QK& k) { return __builtin_amdgcn_fmed3f(v, k.qn, k.qp); }
 
 // table groups ([group][lane] float4) and sizes for NT tiles of 16 hidden units
 template <int MK, int NT> struct QT {
@@ -126,6 +143,7 @@ __device__ __forceinline__ WQ make_wq(const float* pl, const QatLayout& L, int b
     return w;
 }
 
+__device__ __forceinline__ float kq(float w, const Quant& q) { return rintf(__builtin_amdgcn_fmed3f(w * q.inv, q.qn, q.qp)); }   // weight in grid units
 template <int MK, int NT>
 __device__ __forceinline__ float4 q16_entry(const float* pl, const QatLayout& L, const WQ& wq, int grp, int m, int q) {
     using T = QT<MK, NT>;
@@ -137,7 +155,7 @@ __device__ __forceinline__ float4 q16_entry(const float* pl, const QatLayout& L,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int cc = e >> 1, slot = 4 * (e & 1) + q;
-            v[e] = slot < 6 ? qapply(pl[L.o_wo + cc * L.OW + H + slot], wq.o) : 0.0f;
+            v[e] = slot < 6 ? kq(pl[L.o_wo + cc * L.OW + H + slot], wq.o) : 0.0f;
         }
         return make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -145,10 +163,10 @@ __device__ __forceinline__ float4 q16_entry(const float* pl, const QatLayout& L,
     for (int e = 0; e < 4; ++e) {
         if (grp < T::HH) {
             const int g = grp / NT, o = 16 * (grp % NT) + m, slot = 4 * e + q;
-            v[e] = (e < K::NCH && slot < F && o < H) ? qapply(pl[L.o_wx + (g * H + o) * F + slot], wq.x) : 0.0f;
+            v[e] = (e < K::NCH && slot < F && o < H) ? kq(pl[L.o_wx + (g * H + o) * F + slot], wq.x) : 0.0f;
         } else if (grp < T::BX) {
             const int r = grp - T::HH, g = r / (NT * NT), o = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
-            v[e] = (o < H && k < H) ? qapply(pl[L.o_wh + (g * H + o) * H + k], wq.h) : 0.0f;
+            v[e] = (o < H && k < H) ? kq(pl[L.o_wh + (g * H + o) * H + k], wq.h) : 0.0f;
         } else if (grp < T::BH) {
             const int r = grp - T::BX, u = 16 * (r % NT) + 4 * q + e;
             v[e] = u < H ? pl[L.o_bx + (r / NT) * H + u] : 0.0f;
@@ -157,93 +175,112 @@ __device__ __forceinline__ float4 q16_entry(const float* pl, const QatLayout& L,
             v[e] = u < H ? pl[L.o_bh + (r / NT) * H + u] : 0.0f;
         } else if (grp < T::HID) {
             const int r = grp - T::WOUT, u = 16 * (r % NT) + 4 * q + e;
-            v[e] = u < H ? qapply(pl[L.o_wo + (r / NT) * L.OW + u], wq.o) : 0.0f;
+            v[e] = u < H ? kq(pl[L.o_wo + (r / NT) * L.OW + u], wq.o) : 0.0f;
         } else if (grp < T::BHID) {
             const int r = grp - T::HID, o = 16 * (r / NT) + m, k = 16 * (r % NT) + 4 * q + e;
-            v[e] = (o < H && k < H) ? qapply(pl[L.o_whid + o * H + k], wq.hid) : 0.0f;
+            v[e] = (o < H && k < H) ? kq(pl[L.o_whid + o * H + k], wq.hid) : 0.0f;
         } else if (grp < T::WOF) {
             const int u = 16 * (grp - T::BHID) + 4 * q + e;
             v[e] = u < H ? pl[L.o_bhid + u] : 0.0f;
         } else if (grp < T::HIDT) {
             const int r = grp - T::HHT, g = r / (NT * NT), i = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
-            v[e] = (i < H && k < H) ? qapply(pl[L.o_wh + (g * H + k) * H + i], wq.h) : 0.0f;
+            v[e] = (i < H && k < H) ? kq(pl[L.o_wh + (g * H + k) * H + i], wq.h) : 0.0f;
         } else if (grp < T::IHT) {
             const int r = grp - T::HIDT, i = 16 * (r / NT) + m, k = 16 * (r % NT) + 4 * q + e;
-            v[e] = (i < H && k < H) ? qapply(pl[L.o_whid + k * H + i], wq.hid) : 0.0f;
+            v[e] = (i < H && k < H) ? kq(pl[L.o_whid + k * H + i], wq.hid) : 0.0f;
         } else {
             // transposed input weights with the output rows permuted so that D row 4 q' + i = slot 4 i + q': the MFMA result of
             // lane (n, q) element c IS the gradient of the lane's own feature slot 4 c + q
             const int r = grp - T::IHT, g = r / NT, k = 16 * (r % NT) + 4 * q + e, slot = 4 * (m & 3) + (m >> 2);
-            v[e] = (slot < F && k < H) ? qapply(pl[L.o_wx + (g * H + k) * F + slot], wq.x) : 0.0f;
+            v[e] = (slot < F && k < H) ? kq(pl[L.o_wx + (g * H + k) * F + slot], wq.x) : 0.0f;
         }
     }
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // ---- gate functions ----------------------------------------------------------------------------------------------------
-// LDS: lut[0 .. n) sigmoid, lut[n .. 2n) tanh over the add-quantiser grid (index = integer grid value - Qn), then (delta cell)
-// thr[0 .. K+1]: thr[0] = -inf, thr[k] = smallest float x with rint(sigmoid(x) / s_sig) >= k, thr[K+1] = +inf
+// LDS (LUT builds, <= 8 activation bits): one float4 per add-quantiser grid point x = k s_add (index = k - Qn):
+//   .x = q_sig(sigmoid(x)) / s_mul      .y = pass_sig  sigmoid'(x)      (pass = the value lies inside the quantiser's clamp range)
+//   .z = q_tanh(tanh(x)) / s_mul        .w = pass_tanh tanh'(x)
+// evaluated in double at kernel start (sigmoid / tanh rounded to fp32 like the reference's activations, then quantised).  Behind
+// it (delta cell) thr[0 .. K+1]: thr[0] = -inf, thr[k] = smallest float x with rint(sigmoid(x) / s_sig) >= k, thr[K+1] = +inf.
 constexpr int kMaxThr = 132;
+struct Gate { float c, d; };            // quantised value / s_mul, masked derivative
 __device__ __forceinline__ int sig_levels(const Quant& qsig) {      // K: quantised sigmoid values above 0 that can occur
     if (qsig.s > 1.0f) return 0;
     const float n = qsig.inv;                                      // 1 / s, an integer
     return (int)(n < qsig.qp ? n : qsig.qp);
 }
-__device__ __forceinline__ void fill_luts(float* lut, const Quant& qadd, int bits, const Quant& qsig, bool with_thr) {
+__device__ __forceinline__ Gate sig_gate(float rf, const QSc& qs, const QK& k) {
+    const float v = rf * qs.sig.inv, m = __builtin_amdgcn_fmed3f(v, qs.sig.qn, qs.sig.qp);
+    Gate g;
+    g.c = rintf(m) * k.c_sm;
+    g.d = m == v ? rf * (1.0f - rf) : 0.0f;
+    return g;
+}
+__device__ __forceinline__ Gate tanh_gate(float nf, const QSc& qs, const QK& k) {
+    const float v = nf * qs.tnh.inv, m = __builtin_amdgcn_fmed3f(v, qs.tnh.qn, qs.tnh.qp);
+    Gate g;
+    g.c = rintf(m) * k.c_tm;
+    g.d = m == v ? 1.0f - nf * nf : 0.0f;
+    return g;
+}
+__device__ __forceinline__ void fill_luts(float* lut, const QSc& qs, const QK& k, int bits, bool with_thr) {
     const int n = 1 << bits;
+    float4* l4 = reinterpret_cast<float4*>(lut);
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const double x = (double)((float)(i + (int)qadd.qn) * qadd.s);
-        lut[i] = (float)(1.0 / (1.0 + exp(-x)));
-        lut[n + i] = (float)tanh(x);
+        const double x = (double)((float)(i + (int)qs.add.qn) * qs.add.s);
+        const Gate gs = sig_gate((float)(1.0 / (1.0 + exp(-x))), qs, k), gt = tanh_gate((float)tanh(x), qs, k);
+        l4[i] = make_float4(gs.c, gs.d, gt.c, gt.d);
     }
     if (with_thr) {
-        float* thr = lut + 2 * n;
-        const int K = sig_levels(qsig);
-        for (int k = threadIdx.x; k <= K + 1; k += blockDim.x) {
+        float* thr = lut + 4 * n;
+        const int K = sig_levels(qs.sig);
+        for (int j = threadIdx.x; j <= K + 1; j += blockDim.x) {
             float t;
-            if (k == 0) t = -__builtin_inff();
-            else if (k == K + 1) t = __builtin_inff();
+            if (j == 0) t = -__builtin_inff();
+            else if (j == K + 1) t = __builtin_inff();
             else {
-                const double p = ((double)k - 0.5) * (double)qsig.s;
+                const double p = ((double)j - 0.5) * (double)qs.sig.s;
                 if (p >= 1.0) t = __builtin_inff();
                 else {
                     const double b = log(p / (1.0 - p));
                     t = (float)b;
                     if ((double)t < b) {                                                     // smallest float >= b
-                        const int bits = __builtin_bit_cast(int, t);
-                        t = __builtin_bit_cast(float, t > 0.0f ? bits + 1 : (t < 0.0f ? bits - 1 : 1));
+                        const int bits32 = __builtin_bit_cast(int, t);
+                        t = __builtin_bit_cast(float, t > 0.0f ? bits32 + 1 : (t < 0.0f ? bits32 - 1 : 1));
                     }
                 }
             }
-            thr[k] = t;
+            thr[j] = t;
         }
     }
 }
+// gates of a value on the add grid, given as its integer ak (lutq = table base shifted by -Qn entries)
 template <bool LUT>
-__device__ __forceinline__ float sig_grid(float a, const QSc& qs, const float* lut) {
-    if constexpr (LUT) return lut[(int)(a * qs.add.inv) - (int)qs.add.qn];
-    else return (float)(1.0 / (1.0 + exp(-(double)a)));
+__device__ __forceinline__ Gate sig_grid(float ak, const QSc& qs, const QK& k, const float4* lutq) {
+    if constexpr (LUT) { const float2 e = *reinterpret_cast<const float2*>(&lutq[(int)ak]); Gate g; g.c = e.x; g.d = e.y; return g; }
+    else return sig_gate((float)(1.0 / (1.0 + exp(-(double)(ak * k.s_add)))), qs, k);
 }
 template <bool LUT>
-__device__ __forceinline__ float tanh_grid(float a, const QSc& qs, const float* lut, int nlut) {
-    if constexpr (LUT) return lut[nlut + (int)(a * qs.add.inv) - (int)qs.add.qn];
-    else return (float)tanh((double)a);
+__device__ __forceinline__ Gate tanh_grid(float ak, const QSc& qs, const QK& k, const float4* lutq) {
+    if constexpr (LUT) { const float2 e = *(reinterpret_cast<const float2*>(&lutq[(int)ak]) + 1); Gate g; g.c = e.x; g.d = e.y; return g; }
+    else return tanh_gate((float)tanh((double)(ak * k.s_add)), qs, k);
 }
-// quantised sigmoid of an arbitrary float: rf = float sigmoid (for the derivative), r = q_sig(sigmoid(x)) exactly, pass mask
+// quantised sigmoid of an arbitrary float (the delta cell's accumulators): exact through the boundary table around an fp32 guess
 template <bool LUT>
-__device__ __forceinline__ void sig_any(float x, const QSc& qs, const float* thr, int K, float& rf, float& r, bool& pass) {
+__device__ __forceinline__ Gate sig_any(float x, const QSc& qs, const QK& k, const float* thr, int K) {
     if constexpr (LUT) {
-        rf = sigmoidf_(x);
-        const float v = rf * qs.sig.inv;
-        int k = (int)rintf(__builtin_amdgcn_fmed3f(v, 0.0f, (float)K));
-        k += (x >= thr[k + 1]) ? 1 : 0;
-        k -= (x < thr[k]) ? 1 : 0;
-        r = (float)k * qs.sig.s;
-        pass = v <= qs.sig.qp;
+        const float rf = sigmoidf_(x), v = rf * qs.sig.inv;
+        int j = (int)rintf(__builtin_amdgcn_fmed3f(v, 0.0f, (float)K));
+        j += (x >= thr[j + 1]) ? 1 : 0;
+        j -= (x < thr[j]) ? 1 : 0;
+        Gate g;
+        g.c = (float)j * k.c_sm;
+        g.d = v <= qs.sig.qp ? rf * (1.0f - rf) : 0.0f;
+        return g;
     } else {
-        rf = (float)(1.0 / (1.0 + exp(-(double)x)));
-        r = qapply(rf, qs.sig);
-        pass = qpassb(rf, qs.sig);
+        return sig_gate((float)(1.0 / (1.0 + exp(-(double)x))), qs, k);
     }
 }
 
@@ -266,24 +303,24 @@ __device__ __forceinline__ void q16_slots(float2 xv, float2 xn, const float (&oh
     }
 }
 
-enum { M_PH = 1, M_AR = 2, M_AZ = 4, M_R = 8, M_Z = 16, M_M1 = 32, M_AN = 64, M_N = 128, M_M2 = 256, M_M3 = 512, M_AH = 1024,
-       M_OMZ = 2048, M_MH = 4096 };
-#define QBIT(cond, bit) ((cond) ? (bit) : 0)
-
 // ---- GRUCell step ----------------------------------------------------------------------------------------------------
-template <int NT> struct SaveS { f32x4 hp[NT], hn[NT], r[NT], z[NT], n[NT], rf[NT], zf[NT], nf[NT], hnew[NT]; int mk[NT][4]; };
+// what the backward of one step needs, with the straight-through masks already multiplied into the factors they gate:
+//   c2 = p_ah p_m2, c3 = p_ah p_m3, An = p_n tanh' p_an, Az = p_z sig' p_az, B1 = p_m1 r, B2A = p_m1 h_n (p_r sig' p_ar),
+//   pph = p(q_a(h)) s_hw  (the weight scale of the transposed mat-vec rides on the mask)
+template <int NT> struct SaveS { f32x4 hp[NT], hqk[NT], n[NT], z[NT], c2[NT], c3[NT], An[NT], Az[NT], B1[NT], B2A[NT], pph[NT], hnew[NT]; };
 
-template <int MK, int NT, bool LUT>
-__device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const float* lut, int nlut, const float (&fq)[Kind<MK>::NCH],
+template <int MK, int NT, bool LUT, bool SAVE>
+__device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const QK& k, const float4* lutq, const float (&fqk)[Kind<MK>::NCH],
                                          f32x4 (&h)[NT], SaveS<NT>& sv) {
     using T = QT<MK, NT>;
     constexpr int NCH = Kind<MK>::NCH;
-    f32x4 hq[NT];
+    f32x4 hqk[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
         ODPD_EACH4 {
-            hq[kt][i] = qapply(h[kt][i], qs.ha);
-            sv.mk[kt][i] = QBIT(qpassb(h[kt][i], qs.ha), M_PH);
+            const float v = h[kt][i] * k.inv_ha, m = gm(v, k);
+            hqk[kt][i] = rintf(m);
+            if constexpr (SAVE) { sv.hqk[kt][i] = hqk[kt][i]; sv.pph[kt][i] = m == v ? k.s_hw : 0.0f; }
         }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 xs[3][NT], hs[3][NT];
@@ -292,44 +329,46 @@ __device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const float* 
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const float4 w = tab_ld(tl, (T::IH + g * NT + mt) * 64);
-            xs[g][mt] = mfma4(w.x, fq[0], z4);
-            if constexpr (NCH > 1) xs[g][mt] = mfma4(w.y, fq[1], xs[g][mt]);
+            xs[g][mt] = mfma4(w.x, fqk[0], z4);
+            if constexpr (NCH > 1) xs[g][mt] = mfma4(w.y, fqk[1], xs[g][mt]);
             hs[g][mt] = z4;
         }
-        s16n_matvec<NT>(tl, T::HH + g * NT * NT, hq, hs[g]);
+        s16n_matvec<NT>(tl, T::HH + g * NT * NT, hqk, hs[g]);
     }
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
-        const float4 bxr = tab_ld(tl, (T::BX + 0 * NT + mt) * 64), bxz = tab_ld(tl, (T::BX + 1 * NT + mt) * 64),
-                     bxn = tab_ld(tl, (T::BX + 2 * NT + mt) * 64);
-        const float4 bhr = tab_ld(tl, (T::BH + 0 * NT + mt) * 64), bhz = tab_ld(tl, (T::BH + 1 * NT + mt) * 64),
-                     bhn = tab_ld(tl, (T::BH + 2 * NT + mt) * 64);
-        const f32x4 Bxr = as_f32x4(bxr), Bxz = as_f32x4(bxz), Bxn = as_f32x4(bxn), Bhr = as_f32x4(bhr), Bhz = as_f32x4(bhz), Bhn = as_f32x4(bhn);
+        const f32x4 Bxr = as_f32x4(tab_ld(tl, (T::BX + 0 * NT + mt) * 64)), Bxz = as_f32x4(tab_ld(tl, (T::BX + 1 * NT + mt) * 64)),
+                    Bxn = as_f32x4(tab_ld(tl, (T::BX + 2 * NT + mt) * 64)), Bhr = as_f32x4(tab_ld(tl, (T::BH + 0 * NT + mt) * 64)),
+                    Bhz = as_f32x4(tab_ld(tl, (T::BH + 1 * NT + mt) * 64)), Bhn = as_f32x4(tab_ld(tl, (T::BH + 2 * NT + mt) * 64));
         ODPD_EACH4 {
             const float hv = h[mt][i];
-            const float xr = xs[0][mt][i] + Bxr[i], xz = xs[1][mt][i] + Bxz[i], xn = xs[2][mt][i] + Bxn[i];
-            const float hr = hs[0][mt][i] + Bhr[i], hz = hs[1][mt][i] + Bhz[i], hn = hs[2][mt][i] + Bhn[i];
-            const float vr = xr + hr, vz = xz + hz;
-            const float ar = qapply(vr, qs.add), az = qapply(vz, qs.add);
-            int mk = sv.mk[mt][i];
-            mk |= QBIT(qpassb(vr, qs.add), M_AR) | QBIT(qpassb(vz, qs.add), M_AZ);
-            const float rf = sig_grid<LUT>(ar, qs, lut), zf = sig_grid<LUT>(az, qs, lut);
-            const float r = qapply(rf, qs.sig), z = qapply(zf, qs.sig);
-            mk |= QBIT(qpassb(rf, qs.sig), M_R) | QBIT(qpassb(zf, qs.sig), M_Z);
-            const float pm1 = r * hn, m1 = qapply(pm1, qs.mul);
-            mk |= QBIT(qpassb(pm1, qs.mul), M_M1);
-            const float vn = xn + m1, an = qapply(vn, qs.add);
-            mk |= QBIT(qpassb(vn, qs.add), M_AN);
-            const float nf = tanh_grid<LUT>(an, qs, lut, nlut);
-            const float n = qapply(nf, qs.tnh);
-            mk |= QBIT(qpassb(nf, qs.tnh), M_N);
-            const float pm2 = z * hv, pm3 = (1.0f - z) * n;
-            const float m2 = qapply(pm2, qs.mul), m3 = qapply(pm3, qs.mul);
-            mk |= QBIT(qpassb(pm2, qs.mul), M_M2) | QBIT(qpassb(pm3, qs.mul), M_M3);
-            const float vh = m2 + m3, hnew = qapply(vh, qs.add);
-            mk |= QBIT(qpassb(vh, qs.add), M_AH);
-            sv.hp[mt][i] = hv; sv.hn[mt][i] = hn; sv.r[mt][i] = r; sv.z[mt][i] = z; sv.n[mt][i] = n;
-            sv.rf[mt][i] = rf; sv.zf[mt][i] = zf; sv.nf[mt][i] = nf; sv.hnew[mt][i] = hnew; sv.mk[mt][i] = mk;
+            // x_t = x2h(x), h_t = h2h(h): exact integer sums, scale and fp32 bias in one FMA (== F.linear's result)
+            const float xr = __builtin_fmaf(xs[0][mt][i], k.Sx, Bxr[i]), hr = __builtin_fmaf(hs[0][mt][i], k.Sh, Bhr[i]);
+            const float xz = __builtin_fmaf(xs[1][mt][i], k.Sx, Bxz[i]), hz = __builtin_fmaf(hs[1][mt][i], k.Sh, Bhz[i]);
+            const float xn = __builtin_fmaf(xs[2][mt][i], k.Sx, Bxn[i]), hn = __builtin_fmaf(hs[2][mt][i], k.Sh, Bhn[i]);
+            const float vr = (xr + hr) * k.inv_add, vz = (xz + hz) * k.inv_add;
+            const float mr = gm(vr, k), mz = gm(vz, k);
+            const Gate Gr = sig_grid<LUT>(rintf(mr), qs, k, lutq), Gz = sig_grid<LUT>(rintf(mz), qs, k, lutq);
+            const float pm1 = Gr.c * hn, mm1 = gm(pm1, k);                                     // Qmul(r h_n)
+            const float vn = __builtin_fmaf(rintf(mm1), k.s_mul, xn) * k.inv_add, mn = gm(vn, k);      // Qadd(x_n + .)
+            const Gate Gn = tanh_grid<LUT>(rintf(mn), qs, k, lutq);
+            const float omz = __builtin_fmaf(Gz.c, -k.s_mul, 1.0f);                             // 1 - z, plain
+            const float pm2 = Gz.c * hv, pm3 = omz * Gn.c;
+            const float mm2 = gm(pm2, k), mm3 = gm(pm3, k);
+            const float vh = (rintf(mm2) + rintf(mm3)) * k.c_ma, mh = gm(vh, k);
+            const float hnew = rintf(mh) * k.s_add;
+            if constexpr (SAVE) {
+                const bool pah = mh == vh;
+                sv.c2[mt][i] = (pah && mm2 == pm2) ? 1.0f : 0.0f;
+                sv.c3[mt][i] = (pah && mm3 == pm3) ? 1.0f : 0.0f;
+                sv.An[mt][i] = mn == vn ? Gn.d : 0.0f;
+                sv.Az[mt][i] = mz == vz ? Gz.d : 0.0f;
+                const float Ar = mr == vr ? Gr.d : 0.0f;
+                const bool p1 = mm1 == pm1;
+                sv.B1[mt][i] = p1 ? Gr.c * k.s_mul : 0.0f;
+                sv.B2A[mt][i] = p1 ? hn * Ar : 0.0f;
+                sv.hp[mt][i] = hv; sv.n[mt][i] = Gn.c * k.s_mul; sv.z[mt][i] = Gz.c * k.s_mul; sv.hnew[mt][i] = hnew;
+            }
             h[mt][i] = hnew;
         }
     }
@@ -337,20 +376,18 @@ __device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const float* 
 
 // ---- delta cell step -------------------------------------------------------------------------------------------------
 template <int NT> struct StateD { f32x4 h[NT], hp[NT], dmr[NT], dmz[NT], dmn[NT], dmnh[NT]; float xp[2]; };
+//   npo = n p_omz, mh = threshold keep mask of dh, pph = p(q_a(dh)) s_hw; mx / px likewise for the two feature slots (px carries s_xw)
 template <int NT> struct SaveD {
-    f32x4 hp[NT], qdh[NT], nh[NT], r[NT], z[NT], n[NT], rf[NT], zf[NT], nf[NT], omz[NT], hnew[NT];
-    int mk[NT][4];
-    float fq[2];
-    int xm;                      // bit c: dx slot kept by the threshold; bit 2+c: its activation quantiser passes
+    f32x4 hp[NT], qdhk[NT], n[NT], npo[NT], omz[NT], z[NT], c2[NT], c3[NT], An[NT], Az[NT], B1[NT], B2A[NT], mh[NT], pph[NT], hnew[NT];
+    float fqk[2], mx[2], px[2];
 };
 
-template <int NT, bool LUT>
-__device__ __forceinline__ void delta_cell(TabPtr tl, const QSc& qs, const float* lut, int nlut, int K, const float (&fs)[2], float thx,
-                                           float thh, const bool (&slot_ok)[2], const f32x4 (&unit_ok)[NT], StateD<NT>& st,
-                                           SaveD<NT>& sv, float& zx, float& zh) {
+template <int NT, bool LUT, bool SAVE>
+__device__ __forceinline__ void delta_cell(TabPtr tl, const QSc& qs, const QK& k, const float4* lutq, const float* thr, int K,
+                                           const float (&fs)[2], float thx, float thh, const bool (&slot_ok)[2], const f32x4 (&unit_ok)[NT],
+                                           StateD<NT>& st, SaveD<NT>& sv, float& zx, float& zh) {
     using T = QT<K_TRES, NT>;
-    const float* thr = lut + 2 * nlut;
-    int xm = 0;
+    float fqk[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const float d = fs[c] - st.xp[c];
@@ -358,10 +395,11 @@ __device__ __forceinline__ void delta_cell(TabPtr tl, const QSc& qs, const float
         const float dxm = keep ? d : 0.0f;
         st.xp[c] = (__builtin_fabsf(d) >= thx) ? fs[c] : st.xp[c];
         zx += (slot_ok[c] && dxm == 0.0f) ? 1.0f : 0.0f;
-        sv.fq[c] = qapply(dxm, qs.xa);
-        xm |= QBIT(keep, 1 << c) | QBIT(qpassb(dxm, qs.xa), 4 << c);
+        const float v = dxm * k.inv_xa, m = gm(v, k);
+        fqk[c] = rintf(m);
+        if constexpr (SAVE) { sv.fqk[c] = fqk[c]; sv.mx[c] = keep ? 1.0f : 0.0f; sv.px[c] = m == v ? k.s_xw : 0.0f; }
     }
-    sv.xm = xm;
+    f32x4 qdhk[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
         ODPD_EACH4 {
@@ -370,8 +408,9 @@ __device__ __forceinline__ void delta_cell(TabPtr tl, const QSc& qs, const float
             const float dhm = keep ? d : 0.0f;
             st.hp[kt][i] = (__builtin_fabsf(d) >= thh) ? st.h[kt][i] : st.hp[kt][i];
             zh += (unit_ok[kt][i] != 0.0f && dhm == 0.0f) ? 1.0f : 0.0f;
-            sv.qdh[kt][i] = qapply(dhm, qs.ha);
-            sv.mk[kt][i] = QBIT(keep, M_MH) | QBIT(qpassb(dhm, qs.ha), M_PH);
+            const float v = dhm * k.inv_ha, m = gm(v, k);
+            qdhk[kt][i] = rintf(m);
+            if constexpr (SAVE) { sv.qdhk[kt][i] = qdhk[kt][i]; sv.mh[kt][i] = keep ? 1.0f : 0.0f; sv.pph[kt][i] = m == v ? k.s_hw : 0.0f; }
         }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 xs[3][NT], hs[3][NT];
@@ -380,44 +419,45 @@ __device__ __forceinline__ void delta_cell(TabPtr tl, const QSc& qs, const float
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const float4 w = tab_ld(tl, (T::IH + g * NT + mt) * 64);
-            xs[g][mt] = mfma4(w.x, sv.fq[0], z4);
-            xs[g][mt] = mfma4(w.y, sv.fq[1], xs[g][mt]);
+            xs[g][mt] = mfma4(w.x, fqk[0], z4);
+            xs[g][mt] = mfma4(w.y, fqk[1], xs[g][mt]);
             hs[g][mt] = z4;
         }
-        s16n_matvec<NT>(tl, T::HH + g * NT * NT, sv.qdh, hs[g]);
+        s16n_matvec<NT>(tl, T::HH + g * NT * NT, qdhk, hs[g]);
     }
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt)
         ODPD_EACH4 {
             const float hv = st.h[mt][i];
             // mac_x = x2h(dx) + dm; dm_r = mac_x_r + mac_h_r, dm_n = mac_x_n, dm_nh = mac_h_n + dm_nh  (deltagru_tcnskip.py:236-246)
-            const float dmr = (xs[0][mt][i] + st.dmr[mt][i]) + hs[0][mt][i];
-            const float dmz = (xs[1][mt][i] + st.dmz[mt][i]) + hs[1][mt][i];
-            const float dmn = xs[2][mt][i] + st.dmn[mt][i];
-            const float dmnh = hs[2][mt][i] + st.dmnh[mt][i];
+            const float dmr = __builtin_fmaf(hs[0][mt][i], k.Sh, __builtin_fmaf(xs[0][mt][i], k.Sx, st.dmr[mt][i]));
+            const float dmz = __builtin_fmaf(hs[1][mt][i], k.Sh, __builtin_fmaf(xs[1][mt][i], k.Sx, st.dmz[mt][i]));
+            const float dmn = __builtin_fmaf(xs[2][mt][i], k.Sx, st.dmn[mt][i]);
+            const float dmnh = __builtin_fmaf(hs[2][mt][i], k.Sh, st.dmnh[mt][i]);
             st.dmr[mt][i] = dmr; st.dmz[mt][i] = dmz; st.dmn[mt][i] = dmn; st.dmnh[mt][i] = dmnh;
-            int mk = sv.mk[mt][i];
-            float rf, r, zf, z;
-            bool pr, pz;
-            sig_any<LUT>(dmr, qs, thr, K, rf, r, pr);
-            sig_any<LUT>(dmz, qs, thr, K, zf, z, pz);
-            mk |= QBIT(pr, M_R) | QBIT(pz, M_Z);
-            const float pm1 = r * dmnh, m1 = qapply(pm1, qs.mul);
-            mk |= QBIT(qpassb(pm1, qs.mul), M_M1);
-            const float vn = dmn + m1, an = qapply(vn, qs.add);
-            mk |= QBIT(qpassb(vn, qs.add), M_AN);
-            const float nf = tanh_grid<LUT>(an, qs, lut, nlut);
-            const float n = qapply(nf, qs.tnh);
-            mk |= QBIT(qpassb(nf, qs.tnh), M_N);
-            const float vo = 1.0f + (-z), omz = qapply(vo, qs.add);     // self.add(1, -gate_z)  (deltagru_tcnskip.py:290)
-            mk |= QBIT(qpassb(vo, qs.add), M_OMZ);
-            const float pm3 = omz * n, pm2 = z * hv;
-            const float m3 = qapply(pm3, qs.mul), m2 = qapply(pm2, qs.mul);
-            mk |= QBIT(qpassb(pm3, qs.mul), M_M3) | QBIT(qpassb(pm2, qs.mul), M_M2);
-            const float vh = m3 + m2, hnew = qapply(vh, qs.add);
-            mk |= QBIT(qpassb(vh, qs.add), M_AH);
-            sv.hp[mt][i] = hv; sv.nh[mt][i] = dmnh; sv.r[mt][i] = r; sv.z[mt][i] = z; sv.n[mt][i] = n; sv.rf[mt][i] = rf;
-            sv.zf[mt][i] = zf; sv.nf[mt][i] = nf; sv.omz[mt][i] = omz; sv.hnew[mt][i] = hnew; sv.mk[mt][i] = mk;
+            const Gate Gr = sig_any<LUT>(dmr, qs, k, thr, K), Gz = sig_any<LUT>(dmz, qs, k, thr, K);
+            const float pm1 = Gr.c * dmnh, mm1 = gm(pm1, k);
+            const float vn = __builtin_fmaf(rintf(mm1), k.s_mul, dmn) * k.inv_add, mn = gm(vn, k);
+            const Gate Gn = tanh_grid<LUT>(rintf(mn), qs, k, lutq);
+            const float vo = __builtin_fmaf(Gz.c, -k.s_mul, 1.0f) * k.inv_add, mo = gm(vo, k);          // self.add(1, -gate_z)  (deltagru_tcnskip.py:290)
+            const float omz = rintf(mo) * k.s_add;
+            const float pm3 = omz * Gn.c, pm2 = Gz.c * hv;
+            const float mm3 = gm(pm3, k), mm2 = gm(pm2, k);
+            const float vh = (rintf(mm3) + rintf(mm2)) * k.c_ma, mhv = gm(vh, k);
+            const float hnew = rintf(mhv) * k.s_add;
+            if constexpr (SAVE) {
+                const bool pah = mhv == vh;
+                sv.c2[mt][i] = (pah && mm2 == pm2) ? 1.0f : 0.0f;
+                sv.c3[mt][i] = (pah && mm3 == pm3) ? 1.0f : 0.0f;
+                sv.An[mt][i] = mn == vn ? Gn.d : 0.0f;
+                sv.Az[mt][i] = Gz.d;
+                const bool p1 = mm1 == pm1;
+                sv.B1[mt][i] = p1 ? Gr.c * k.s_mul : 0.0f;
+                sv.B2A[mt][i] = p1 ? dmnh * Gr.d : 0.0f;
+                const float nt = Gn.c * k.s_mul;
+                sv.hp[mt][i] = hv; sv.n[mt][i] = nt; sv.npo[mt][i] = mo == vo ? nt : 0.0f; sv.omz[mt][i] = omz; sv.z[mt][i] = Gz.c * k.s_mul;
+                sv.hnew[mt][i] = hnew;
+            }
             st.h[mt][i] = hnew;
         }
 }
@@ -458,16 +498,16 @@ __device__ __forceinline__ void q16_tcn(const Scalars<MK>& sc, float2 xm, float2
     }
 }
 
-// everything the head's backward needs from its forward (recomputed there)
+// everything the head's backward needs from its forward (recomputed there); masks carry the weight scale of the way back
 template <int MK, int NT> struct HeadOut {
-    f32x4 ho[NT];            // q_a(fc_out input) on the units (dgru: of relu(fc_hid))
-    f32x4 pho[NT];           // its pass mask
-    f32x4 h2[NT], ph2[NT], hidpre[NT];     // dgru: q_a(h') of fc_hid, mask, pre-activation
-    float cof[2], pcof[2];   // dgru: q_a(feature slot) of fc_out, mask
+    f32x4 hok[NT];           // q_a(fc_out input) on the units (dgru: of relu(fc_hid)), grid units
+    f32x4 pho[NT];           // its pass mask * s_ow
+    f32x4 h2k[NT], ph2[NT], hidpre[NT];     // dgru: q_a(h') of fc_hid (grid units), mask * s_hidw, pre-activation
+    float cofk[2], pcof[2];  // dgru: q_a(feature slot) of fc_out, mask * s_ow
 };
-// y (before bias / output quantiser / skip) of one step; `fs` = the lane's FLOAT feature slots (dgru's cat)
-template <int MK, int NT>
-__device__ __forceinline__ void head_fwd(TabPtr tl, const QSc& qs, const f32x4 (&h)[NT], const float (&fs)[Kind<MK>::NCH], HeadOut<MK, NT>& ho,
+// y (scaled, before bias / output quantiser / skip) of one step; `fs` = the lane's FLOAT feature slots (dgru's cat)
+template <int MK, int NT, bool SAVE>
+__device__ __forceinline__ void head_fwd(TabPtr tl, const QK& k, const f32x4 (&h)[NT], const float (&fs)[Kind<MK>::NCH], HeadOut<MK, NT>& ho,
                                          float& y0, float& y1) {
     using T = QT<MK, NT>;
     float p0 = 0.0f, p1 = 0.0f;
@@ -477,36 +517,47 @@ __device__ __forceinline__ void head_fwd(TabPtr tl, const QSc& qs, const f32x4 (
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             acc[kt] = z4;
-            ODPD_EACH4 { ho.h2[kt][i] = qapply(h[kt][i], qs.hida); ho.ph2[kt][i] = qpass(h[kt][i], qs.hida); }
+            ODPD_EACH4 {
+                const float v = h[kt][i] * k.inv_hida, m = gm(v, k);
+                ho.h2k[kt][i] = rintf(m);
+                if constexpr (SAVE) ho.ph2[kt][i] = m == v ? k.s_hidw : 0.0f;
+            }
         }
-        s16n_matvec<NT>(tl, T::HID, ho.h2, acc);
+        s16n_matvec<NT>(tl, T::HID, ho.h2k, acc);
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const f32x4 b = as_f32x4(tab_ld(tl, (T::BHID + mt) * 64));
             const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
             ODPD_EACH4 {
-                const float pre = acc[mt][i] + b[i], hid = pre > 0.0f ? pre : 0.0f;      // torch.relu
-                ho.hidpre[mt][i] = pre;
-                ho.ho[mt][i] = qapply(hid, qs.oa); ho.pho[mt][i] = qpass(hid, qs.oa);
-                p0 = __builtin_fmaf(w0[i], ho.ho[mt][i], p0); p1 = __builtin_fmaf(w1[i], ho.ho[mt][i], p1);
+                const float pre = __builtin_fmaf(acc[mt][i], k.Shid, b[i]), hid = pre > 0.0f ? pre : 0.0f;      // torch.relu
+                const float v = hid * k.inv_oa, m = gm(v, k);
+                ho.hok[mt][i] = rintf(m);
+                if constexpr (SAVE) { ho.hidpre[mt][i] = pre; ho.pho[mt][i] = m == v ? k.s_ow : 0.0f; }
+                p0 = __builtin_fmaf(w0[i], ho.hok[mt][i], p0); p1 = __builtin_fmaf(w1[i], ho.hok[mt][i], p1);
             }
         }
         const float4 wf = tab_ld(tl, T::WOF * 64);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) { ho.cof[c] = qapply(fs[c], qs.oa); ho.pcof[c] = qpass(fs[c], qs.oa); }
-        p0 = __builtin_fmaf(wf.x, ho.cof[0], p0); p0 = __builtin_fmaf(wf.y, ho.cof[1], p0);
-        p1 = __builtin_fmaf(wf.z, ho.cof[0], p1); p1 = __builtin_fmaf(wf.w, ho.cof[1], p1);
+        for (int c = 0; c < 2; ++c) {
+            const float v = fs[c] * k.inv_oa, m = gm(v, k);
+            ho.cofk[c] = rintf(m);
+            if constexpr (SAVE) ho.pcof[c] = m == v ? k.s_ow : 0.0f;
+        }
+        p0 = __builtin_fmaf(wf.x, ho.cofk[0], p0); p0 = __builtin_fmaf(wf.y, ho.cofk[1], p0);
+        p1 = __builtin_fmaf(wf.z, ho.cofk[0], p1); p1 = __builtin_fmaf(wf.w, ho.cofk[1], p1);
     } else {
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
             ODPD_EACH4 {
-                ho.ho[mt][i] = qapply(h[mt][i], qs.oa); ho.pho[mt][i] = qpass(h[mt][i], qs.oa);
-                p0 = __builtin_fmaf(w0[i], ho.ho[mt][i], p0); p1 = __builtin_fmaf(w1[i], ho.ho[mt][i], p1);
+                const float v = h[mt][i] * k.inv_oa, m = gm(v, k);
+                ho.hok[mt][i] = rintf(m);
+                if constexpr (SAVE) ho.pho[mt][i] = m == v ? k.s_ow : 0.0f;
+                p0 = __builtin_fmaf(w0[i], ho.hok[mt][i], p0); p1 = __builtin_fmaf(w1[i], ho.hok[mt][i], p1);
             }
         }
     }
-    y0 = quad_sum(p0); y1 = quad_sum(p1);
+    y0 = quad_sum(p0); y1 = quad_sum(p1);      // exact integer sums on 8-bit grids: any order
 }
 
 template <int MK>
@@ -538,6 +589,18 @@ __device__ __forceinline__ QSc load_qsc(const float* pl, const QatLayout& L, int
     q.hida = Kind<MK>::DGRU ? make_quant(pl[L.o_shida], bits_a) : q.oa;
     return q;
 }
+__device__ __forceinline__ QK make_qk(const QSc& q, const WQ& w) {
+    QK k;
+    k.qn = q.add.qn; k.qp = q.add.qp;
+    k.inv_xa = q.xa.inv; k.inv_ha = q.ha.inv; k.inv_oa = q.oa.inv; k.inv_hida = q.hida.inv; k.inv_add = q.add.inv;
+    k.Sx = q.xa.s * w.x.s; k.Sh = q.ha.s * w.h.s; k.So = q.oa.s * w.o.s; k.Shid = q.hida.s * w.hid.s;
+    k.s_add = q.add.s; k.s_mul = q.mul.s; k.c_ma = q.mul.s * q.add.inv;
+    k.c_sm = q.sig.s * q.mul.inv; k.c_tm = q.tnh.s * q.mul.inv;
+    k.s_xa = q.xa.s; k.s_ha = q.ha.s; k.s_oa = q.oa.s; k.s_hida = q.hida.s;
+    k.s_xw = w.x.s; k.s_hw = w.h.s; k.s_ow = w.o.s; k.s_hidw = w.hid.s;
+    k.inv_sig = q.sig.inv; k.inv_tnh = q.tnh.inv;
+    return k;
+}
 template <int NT>
 __device__ __forceinline__ void init_state(StateD<NT>& st) {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -550,7 +613,7 @@ __device__ __forceinline__ void init_state(StateD<NT>& st) {
 // forward
 // -------------------------------------------------------------------------------------------------
 template <int MK, int NT, bool LUT>
-__global__ __launch_bounds__(256) void qat16_fwd_kernel(SeqArgs a, int bits_w, int bits_a, int eval_mode) {
+__global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, int bits_a, int eval_mode) {
     using T = QT<MK, NT>;
     using K = Kind<MK>;
     constexpr int S = T::S, NCH = K::NCH;
@@ -563,16 +626,19 @@ __global__ __launch_bounds__(256) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     const QSc qs = load_qsc<MK>(pl, L, bits_a);
+    const WQ wq = make_wq(pl, L, bits_w);
+    const QK k = make_qk(qs, wq);
     const int nlut = LUT ? (1 << bits_a) : 0;
     float* lut = tab + s16_tab_floats(T::NG_FWD);
     {
-        const WQ wq = make_wq(pl, L, bits_w);
         float4* t4 = reinterpret_cast<float4*>(tab);
         for (int grp = wave; grp < T::NG_FWD; grp += nwb) t4[grp * 64 + lane] = q16_entry<MK, NT>(pl, L, wq, grp, n, q);
-        if constexpr (LUT) fill_luts(lut, qs.add, bits_a, qs.sig, K::TRES);
+        if constexpr (LUT) fill_luts(lut, qs, k, bits_a, K::TRES);
         __syncthreads();
     }
     const int Ksig = sig_levels(qs.sig);
+    const float4* lutq = reinterpret_cast<const float4*>(lut) - (int)qs.add.qn;
+    const float* thr = lut + 4 * nlut;
     const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     Scalars<MK> sc;
     sc.load(pl, L);
@@ -583,7 +649,7 @@ __global__ __launch_bounds__(256) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
     f32x4 unit_ok[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) ODPD_EACH4 unit_ok[kt][i] = (16 * kt + 4 * q + i < a.H) ? 1.0f : 0.0f;
-    float* wbase = lut + (LUT ? 2 * nlut + kMaxThr : 0) + (size_t)wave * kWaveF;
+    float* wbase = lut + (LUT ? 4 * nlut + kMaxThr : 0) + (size_t)wave * kWaveF;
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ys = xs + 16 * K::XSTRIDE;
     const float2* xr = xs + n * K::XSTRIDE + K::HALO;
@@ -611,18 +677,18 @@ __global__ __launch_bounds__(256) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
                 const TabPtr tlo = opaque(tl);
                 if constexpr (K::TRES) {
                     SaveD<NT> sv;
-                    delta_cell<NT, LUT>(tlo, qs, lut, nlut, Ksig, fs, a.thx, a.thh, slot_ok, unit_ok, st, sv, zxs, zhs);
+                    delta_cell<NT, LUT, false>(tlo, qs, k, lutq, thr, Ksig, fs, a.thx, a.thh, slot_ok, unit_ok, st, sv, zxs, zhs);
                 } else {
-                    float fq[NCH];
+                    float fqk[NCH];
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) fq[c] = qapply(fs[c], qs.xa);
+                    for (int c = 0; c < NCH; ++c) fqk[c] = gk(fs[c] * k.inv_xa, k);
                     SaveS<NT> sv;
-                    std_cell<MK, NT, LUT>(tlo, qs, lut, nlut, fq, st.h, sv);
+                    std_cell<MK, NT, LUT, false>(tlo, qs, k, lutq, fqk, st.h, sv);
                 }
                 HeadOut<MK, NT> ho;
                 float y0, y1;
-                head_fwd<MK, NT>(tlo, qs, st.h, fs, ho, y0, y1);
-                y0 += sc.bout[0]; y1 += sc.bout[1];
+                head_fwd<MK, NT, false>(tlo, k, st.h, fs, ho, y0, y1);
+                y0 = __builtin_fmaf(y0, k.So, sc.bout[0]); y1 = __builtin_fmaf(y1, k.So, sc.bout[1]);
                 if (eval_mode) { y0 = qapply(y0, qs.out); y1 = qapply(y1, qs.out); }   // fc_out's 16-bit out_quantizer (quant_layers.py:77-80)
                 if constexpr (K::TRES) {
                     float s1[3], s2[2];
@@ -669,6 +735,7 @@ __global__ __launch_bounds__(256) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
 // -------------------------------------------------------------------------------------------------
 // backward
 // -------------------------------------------------------------------------------------------------
+// weight-gradient accumulators hold sum(d (x) k_a) with the activation in grid units: the activation scale is applied once, at write-out
 template <int MK, int NT>
 struct Grad {
     f32x4 tih[3][NT], thh[3][NT][NT];
@@ -698,13 +765,11 @@ struct Grad {
 };
 template <int NT> struct Carry { f32x4 gh[NT], ghp[NT], gr[NT], gz[NT], gn[NT], gnh[NT]; float gxp[2], wrap[2]; };
 
-#define QM(mk, bit) (((mk) & (bit)) ? 1.0f : 0.0f)
-
-// head backward of one step: accumulates the head's parameter gradients, returns dL/dh' (added to gh) and, for dgru, the head's
+// head backward of one step: accumulates the head's parameter gradients, adds dL/dh' to gh and, for dgru, returns the head's
 // share of dL/d(feature slot)
 template <int MK, int NT>
-__device__ __forceinline__ void head_bwd(TabPtr tl, const QSc& qs, Grad<MK, NT>& G, const HeadOut<MK, NT>& ho, float2 dyv, int q,
-                                         f32x4 (&gh)[NT], float (&dfs)[2], float* tiles) {
+__device__ __forceinline__ void head_bwd(TabPtr tl, Grad<MK, NT>& G, const HeadOut<MK, NT>& ho, float2 dyv, int q, f32x4 (&gh)[NT],
+                                         float (&dfs)[2], float* tiles) {
     using T = QT<MK, NT>;
     G.dbout[0] += q == 0 ? dyv.x : 0.0f;
     G.dbout[1] += q == 0 ? dyv.y : 0.0f;
@@ -713,7 +778,7 @@ __device__ __forceinline__ void head_bwd(TabPtr tl, const QSc& qs, Grad<MK, NT>&
         dfs[0] = (dyv.x * wf.x + dyv.y * wf.z) * ho.pcof[0];
         dfs[1] = (dyv.x * wf.y + dyv.y * wf.w) * ho.pcof[1];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) { G.dwof[0][c] = __builtin_fmaf(dyv.x, ho.cof[c], G.dwof[0][c]); G.dwof[1][c] = __builtin_fmaf(dyv.y, ho.cof[c], G.dwof[1][c]); }
+        for (int c = 0; c < 2; ++c) { G.dwof[0][c] = __builtin_fmaf(dyv.x, ho.cofk[c], G.dwof[0][c]); G.dwof[1][c] = __builtin_fmaf(dyv.y, ho.cofk[c], G.dwof[1][c]); }
         f32x4 dpre[NT], back[NT];
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -721,8 +786,8 @@ __device__ __forceinline__ void head_bwd(TabPtr tl, const QSc& qs, Grad<MK, NT>&
             const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
             back[mt] = z4;
             ODPD_EACH4 {
-                G.dwout[0][mt][i] = __builtin_fmaf(dyv.x, ho.ho[mt][i], G.dwout[0][mt][i]);
-                G.dwout[1][mt][i] = __builtin_fmaf(dyv.y, ho.ho[mt][i], G.dwout[1][mt][i]);
+                G.dwout[0][mt][i] = __builtin_fmaf(dyv.x, ho.hok[mt][i], G.dwout[0][mt][i]);
+                G.dwout[1][mt][i] = __builtin_fmaf(dyv.y, ho.hok[mt][i], G.dwout[1][mt][i]);
                 const float dcat = (dyv.x * w0[i] + dyv.y * w1[i]) * ho.pho[mt][i];
                 dpre[mt][i] = ho.hidpre[mt][i] > 0.0f ? dcat : 0.0f;
                 G.dbhid[mt][i] += dpre[mt][i];
@@ -736,7 +801,7 @@ __device__ __forceinline__ void head_bwd(TabPtr tl, const QSc& qs, Grad<MK, NT>&
         const int n = threadIdx.x & 15;
         wave_lds_fence();
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) { tile_put(tp + kt * kTileFloats, n, q, dpre[kt]); tile_put(tp + (NT + kt) * kTileFloats, n, q, ho.h2[kt]); }
+        for (int kt = 0; kt < NT; ++kt) { tile_put(tp + kt * kTileFloats, n, q, dpre[kt]); tile_put(tp + (NT + kt) * kTileFloats, n, q, ho.h2k[kt]); }
         wave_lds_fence();
         float hT[NT][4];
 #pragma unroll
@@ -756,8 +821,8 @@ __device__ __forceinline__ void head_bwd(TabPtr tl, const QSc& qs, Grad<MK, NT>&
         for (int mt = 0; mt < NT; ++mt) {
             const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
             ODPD_EACH4 {
-                G.dwout[0][mt][i] = __builtin_fmaf(dyv.x, ho.ho[mt][i], G.dwout[0][mt][i]);
-                G.dwout[1][mt][i] = __builtin_fmaf(dyv.y, ho.ho[mt][i], G.dwout[1][mt][i]);
+                G.dwout[0][mt][i] = __builtin_fmaf(dyv.x, ho.hok[mt][i], G.dwout[0][mt][i]);
+                G.dwout[1][mt][i] = __builtin_fmaf(dyv.y, ho.hok[mt][i], G.dwout[1][mt][i]);
                 gh[mt][i] += (dyv.x * w0[i] + dyv.y * w1[i]) * ho.pho[mt][i];
             }
         }
@@ -826,8 +891,8 @@ __device__ __forceinline__ void slots_bwd(float2 xv, const float (&oh)[4], const
 }
 
 template <int MK, int NT, bool LUT, bool FULL, bool DX>
-__device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, const QSc& qs, const float* lut, int nlut, int Ksig,
-                                              const Scalars<MK>& sc, const float (&oh)[4], Grad<MK, NT>& G, const float2* xr,
+__device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, const QSc& qs, const QK& k, const float4* lutq, const float* thr,
+                                              int Ksig, const Scalars<MK>& sc, const float (&oh)[4], Grad<MK, NT>& G, const float2* xr,
                                               const float2* dys, float2* dxs, float* tiles, float2 x0, int n, int q, int tglob, int tloc,
                                               int nstep, int chunk_len, float* dxrow, StateD<NT> st, Carry<NT>& C) {
     using T = QT<MK, NT>;
@@ -839,8 +904,7 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
     for (int kt = 0; kt < NT; ++kt) all_units[kt] = f32x4{1.f, 1.f, 1.f, 1.f};
     typedef typename std::conditional<K::TRES, SaveD<NT>, SaveS<NT>>::type Save;
     Save sv[S];
-    float fq_s[S][2];
-    int px_s[S];
+    float fq_s[S][2], px_s[S][2];
     TabPtr tl = opaque(tl0);
     {
         float zx = 0.f, zh = 0.f;
@@ -853,23 +917,25 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 float fs[NCH];
                 q16_slots<MK>(xv, xn, oh, fs);
                 if constexpr (K::TRES) {
-                    delta_cell<NT, LUT>(tl, qs, lut, nlut, Ksig, fs, a.thx, a.thh, slot_ok, all_units, st, sv[si], zx, zh);
+                    delta_cell<NT, LUT, true>(tl, qs, k, lutq, thr, Ksig, fs, a.thx, a.thh, slot_ok, all_units, st, sv[si], zx, zh);
                 } else {
-                    float fq[NCH];
-                    int px = 0;
+                    float fqk[NCH];
+                    fq_s[si][1] = 0.0f; px_s[si][1] = 0.0f;
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) { fq[c] = qapply(fs[c], qs.xa); px |= QBIT(qpassb(fs[c], qs.xa), 1 << c); }
-                    fq_s[si][0] = fq[0]; fq_s[si][1] = NCH > 1 ? fq[NCH - 1] : 0.0f;
-                    px_s[si] = px;
-                    std_cell<MK, NT, LUT>(tl, qs, lut, nlut, fq, st.h, sv[si]);
+                    for (int c = 0; c < NCH; ++c) {
+                        const float v = fs[c] * k.inv_xa, m = gm(v, k);
+                        fqk[c] = rintf(m);
+                        fq_s[si][c] = fqk[c]; px_s[si][c] = m == v ? k.s_xw : 0.0f;
+                    }
+                    std_cell<MK, NT, LUT, true>(tl, qs, k, lutq, fqk, st.h, sv[si]);
                 }
             }
         }
     }
     tl = opaque(tl0);
     const int F = K::F;
-    // the constant-1 slot of the feature tile (column F of tih = the x-side bias gradient of the GRUCell)
-    const float one_c0 = (!K::TRES && F < 4 && q == F) ? 1.0f : 0.0f, one_c1 = (!K::TRES && F >= 4 && 4 + q == F) ? 1.0f : 0.0f;
+    // the constant slot of the feature tile (column F of tih = the x-side bias gradient of the GRUCell; the tile is in units of s_xa)
+    const float one_c0 = (!K::TRES && F < 4 && q == F) ? k.inv_xa : 0.0f, one_c1 = (!K::TRES && F >= 4 && 4 + q == F) ? k.inv_xa : 0.0f;
 #pragma unroll
     for (int si = S - 1; si >= 0; --si) {
         if (FULL || si < nstep) {
@@ -902,10 +968,10 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
             HeadOut<MK, NT> ho;
             {
                 float y0, y1;
-                head_fwd<MK, NT>(tl, qs, sv[si].hnew, fs, ho, y0, y1);
+                head_fwd<MK, NT, true>(tl, k, sv[si].hnew, fs, ho, y0, y1);
             }
             float dfs_head[2];
-            head_bwd<MK, NT>(tl, qs, G, ho, dyv, q, C.gh, dfs_head, tiles);
+            head_bwd<MK, NT>(tl, G, ho, dyv, q, C.gh, dfs_head, tiles);
             float dfs[2] = {0.0f, 0.0f};
             if constexpr (K::TRES) {
                 const SaveD<NT>& v = sv[si];
@@ -913,18 +979,14 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
 #pragma unroll
                 for (int mt = 0; mt < NT; ++mt)
                     ODPD_EACH4 {
-                        const int mk = v.mk[mt][i];
-                        const float g = C.gh[mt][i] * QM(mk, M_AH);
-                        const float dm3 = g * QM(mk, M_M3), dm2 = g * QM(mk, M_M2);
-                        const float domz = dm3 * v.n[mt][i], dn = dm3 * v.omz[mt][i];
-                        const float dz = dm2 * v.hp[mt][i] - domz * QM(mk, M_OMZ);
-                        ghprev[mt][i] = dm2 * v.z[mt][i];
-                        const float dan = dn * QM(mk, M_N) * (1.0f - v.nf[mt][i] * v.nf[mt][i]) * QM(mk, M_AN);
+                        const float g2 = C.gh[mt][i] * v.c2[mt][i], g3 = C.gh[mt][i] * v.c3[mt][i];
+                        const float dz = g2 * v.hp[mt][i] - g3 * v.npo[mt][i];
+                        const float dan = g3 * v.omz[mt][i] * v.An[mt][i];
+                        ghprev[mt][i] = g2 * v.z[mt][i];
                         C.gn[mt][i] += dan;
-                        const float dm1 = dan * QM(mk, M_M1);
-                        C.gnh[mt][i] += dm1 * v.r[mt][i];
-                        C.gr[mt][i] += dm1 * v.nh[mt][i] * QM(mk, M_R) * (v.rf[mt][i] * (1.0f - v.rf[mt][i]));
-                        C.gz[mt][i] += dz * QM(mk, M_Z) * (v.zf[mt][i] * (1.0f - v.zf[mt][i]));
+                        C.gnh[mt][i] += dan * v.B1[mt][i];
+                        C.gr[mt][i] += dan * v.B2A[mt][i];
+                        C.gz[mt][i] += dz * v.Az[mt][i];
                     }
                 f32x4 ddh[NT];
 #pragma unroll
@@ -935,8 +997,7 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
 #pragma unroll
                 for (int mt = 0; mt < NT; ++mt)
                     ODPD_EACH4 {
-                        const int mk = v.mk[mt][i];
-                        const float m = QM(mk, M_MH), g2 = ddh[mt][i] * QM(mk, M_PH);
+                        const float m = v.mh[mt][i], g2 = ddh[mt][i] * v.pph[mt][i];
                         C.gh[mt][i] = ghprev[mt][i] + m * (g2 + C.ghp[mt][i]);
                         C.ghp[mt][i] = (1.0f - m) * C.ghp[mt][i] - m * g2;
                     }
@@ -953,32 +1014,26 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                     }
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        const float m = (v.xm & (1 << c)) ? 1.0f : 0.0f, g = ds[c] * ((v.xm & (4 << c)) ? 1.0f : 0.0f);
+                        const float m = v.mx[c], g = ds[c] * v.px[c];
                         dfs[c] = m * (g + C.gxp[c]);
                         C.gxp[c] = (1.0f - m) * C.gxp[c] - m * g;
                     }
                 }
-                wgrad_tiles<MK, NT>(G, tiles, n, q, C.gr, C.gz, C.gn, C.gnh, v.qdh, v.fq[0], v.fq[1]);
+                wgrad_tiles<MK, NT>(G, tiles, n, q, C.gr, C.gz, C.gn, C.gnh, v.qdhk, v.fqk[0], v.fqk[1]);
             } else {
                 const SaveS<NT>& v = sv[si];
-                f32x4 dar[NT], daz[NT], dan[NT], dhtn[NT], dhdir[NT], hq[NT];
+                f32x4 dar[NT], daz[NT], dan[NT], dhtn[NT], dhdir[NT];
 #pragma unroll
                 for (int mt = 0; mt < NT; ++mt)
                     ODPD_EACH4 {
-                        const int mk = v.mk[mt][i];
-                        const float g = C.gh[mt][i] * QM(mk, M_AH);
-                        const float dm2 = g * QM(mk, M_M2), dm3 = g * QM(mk, M_M3);
-                        const float dz = dm2 * v.hp[mt][i] - dm3 * v.n[mt][i];
-                        const float dn = dm3 * (1.0f - v.z[mt][i]);
-                        const float da = dn * QM(mk, M_N) * (1.0f - v.nf[mt][i] * v.nf[mt][i]) * QM(mk, M_AN);
-                        const float dm1 = da * QM(mk, M_M1);
-                        const float dr = dm1 * v.hn[mt][i];
+                        const float g2 = C.gh[mt][i] * v.c2[mt][i], g3 = C.gh[mt][i] * v.c3[mt][i];
+                        const float dz = g2 * v.hp[mt][i] - g3 * v.n[mt][i];
+                        const float da = g3 * (1.0f - v.z[mt][i]) * v.An[mt][i];
                         dan[mt][i] = da;
-                        dhtn[mt][i] = dm1 * v.r[mt][i];
-                        dar[mt][i] = dr * QM(mk, M_R) * v.rf[mt][i] * (1.0f - v.rf[mt][i]) * QM(mk, M_AR);
-                        daz[mt][i] = dz * QM(mk, M_Z) * v.zf[mt][i] * (1.0f - v.zf[mt][i]) * QM(mk, M_AZ);
-                        dhdir[mt][i] = dm2 * v.z[mt][i];
-                        hq[mt][i] = qapply(v.hp[mt][i], qs.ha);
+                        dhtn[mt][i] = da * v.B1[mt][i];
+                        dar[mt][i] = da * v.B2A[mt][i];
+                        daz[mt][i] = dz * v.Az[mt][i];
+                        dhdir[mt][i] = g2 * v.z[mt][i];
                         G.dbhn[mt][i] += dhtn[mt][i];
                     }
                 f32x4 ddh[NT];
@@ -988,7 +1043,7 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 s16n_matvec<NT>(tl, T::HHT + 1 * NT * NT, daz, ddh);
                 s16n_matvec<NT>(tl, T::HHT + 2 * NT * NT, dhtn, ddh);
 #pragma unroll
-                for (int mt = 0; mt < NT; ++mt) ODPD_EACH4 C.gh[mt][i] = dhdir[mt][i] + ddh[mt][i] * QM(v.mk[mt][i], M_PH);
+                for (int mt = 0; mt < NT; ++mt) ODPD_EACH4 C.gh[mt][i] = dhdir[mt][i] + ddh[mt][i] * v.pph[mt][i];
                 if constexpr (DX) {
                     f32x4 ds = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1000,10 +1055,10 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                             ds = mfma4(wr[c], dar[kt][c], ds); ds = mfma4(wz[c], daz[kt][c], ds); ds = mfma4(wn[c], dan[kt][c], ds);
                         }
                     }
-                    dfs[0] = ds[0] * ((px_s[si] & 1) ? 1.0f : 0.0f) + dfs_head[0];
-                    dfs[1] = (NCH > 1 ? ds[1] * ((px_s[si] & 2) ? 1.0f : 0.0f) : 0.0f) + dfs_head[1];
+                    dfs[0] = ds[0] * px_s[si][0] + dfs_head[0];
+                    dfs[1] = (NCH > 1 ? ds[1] * px_s[si][1] : 0.0f) + dfs_head[1];
                 }
-                wgrad_tiles<MK, NT>(G, tiles, n, q, dar, daz, dan, dhtn, hq, fq_s[si][0] + one_c0, (NCH > 1 ? fq_s[si][1] : 0.0f) + one_c1);
+                wgrad_tiles<MK, NT>(G, tiles, n, q, dar, daz, dan, dhtn, v.hqk, fq_s[si][0] + one_c0, fq_s[si][1] + one_c1);
             }
             if constexpr (DX) {
                 float dI, dQ, nI, nQ;
@@ -1027,8 +1082,8 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
 }
 
 template <int MK, int NT>
-__device__ __forceinline__ void q16_write_row(float* prow, const float* pl, const QatLayout& L, const WQ& wq, Grad<MK, NT>& G, int lane,
-                                              int n, int q) {
+__device__ __forceinline__ void q16_write_row(float* prow, const float* pl, const QatLayout& L, const WQ& wq, const QK& k, Grad<MK, NT>& G,
+                                              int lane, int n, int q) {
     using K = Kind<MK>;
     constexpr int F = K::F;
     const int H = L.H;
@@ -1042,19 +1097,20 @@ __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, cons
             if (u < H) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    if (n < F) { const int k = L.o_wx + (g * H + u) * F + n; prow[k] = G.tih[g][mt][rr] * qpass(pl[k], wq.x); }
-                    if (!K::TRES && n == F) { prow[L.o_bx + g * H + u] = G.tih[g][mt][rr]; if (g < 2) prow[L.o_bh + g * H + u] = G.tih[g][mt][rr]; }
+                    const float tx = G.tih[g][mt][rr] * k.s_xa;
+                    if (n < F) { const int j = L.o_wx + (g * H + u) * F + n; prow[j] = tx * qpass(pl[j], wq.x); }
+                    if (!K::TRES && n == F) { prow[L.o_bx + g * H + u] = tx; if (g < 2) prow[L.o_bh + g * H + u] = tx; }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        if (16 * nt + n < H) { const int k = L.o_wh + (g * H + u) * H + 16 * nt + n; prow[k] = G.thh[g][mt][nt][rr] * qpass(pl[k], wq.h); }
+                        if (16 * nt + n < H) { const int j = L.o_wh + (g * H + u) * H + 16 * nt + n; prow[j] = G.thh[g][mt][nt][rr] * k.s_ha * qpass(pl[j], wq.h); }
                 }
                 if constexpr (K::DGRU) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        if (16 * nt + n < H) { const int k = L.o_whid + u * H + 16 * nt + n; prow[k] = G.thid[mt][nt][rr] * qpass(pl[k], wq.hid); }
+                        if (16 * nt + n < H) { const int j = L.o_whid + u * H + 16 * nt + n; prow[j] = G.thid[mt][nt][rr] * k.s_hida * qpass(pl[j], wq.hid); }
                 }
             }
-            const float w0 = row_sum16(G.dwout[0][mt][rr]), w1 = row_sum16(G.dwout[1][mt][rr]);
+            const float w0 = row_sum16(G.dwout[0][mt][rr]) * k.s_oa, w1 = row_sum16(G.dwout[1][mt][rr]) * k.s_oa;
             const float bn = row_sum16(G.dbhn[mt][rr]), bhid = row_sum16(G.dbhid[mt][rr]);
             if (n == 0 && u < H) {
                 prow[L.o_wo + u] = w0 * qpass(pl[L.o_wo + u], wq.o);
@@ -1068,9 +1124,9 @@ __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, cons
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const float v = row_sum16(G.dwof[cc][c]);
+                const float v = row_sum16(G.dwof[cc][c]) * k.s_oa;
                 const int slot = 4 * c + q;
-                if (n == 0 && slot < 6) { const int k = L.o_wo + cc * L.OW + H + slot; prow[k] = v * qpass(pl[k], wq.o); }
+                if (n == 0 && slot < 6) { const int j = L.o_wo + cc * L.OW + H + slot; prow[j] = v * qpass(pl[j], wq.o); }
             }
     }
     if constexpr (K::TRES) {
@@ -1090,8 +1146,11 @@ __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, cons
     }
 }
 
+// two waves per SIMD (eight-wave workgroups, 256 registers) where the block state fits without spilling: the GRUCell kinds at one unit
+// tile without dL/dx; the others keep the whole 512-register file (one wave per SIMD)
+template <int MK, int NT, bool DX> struct BwdOcc { static constexpr bool W2 = NT == 1 && !Kind<MK>::TRES && !Kind<MK>::DGRU && !DX; };
 template <int MK, int NT, bool LUT, bool DX>
-__global__ __launch_bounds__(256, 1) void qat16_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
+__global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
     using T = QT<MK, NT>;
     using K = Kind<MK>;
     constexpr int S = T::S;
@@ -1106,22 +1165,25 @@ __global__ __launch_bounds__(256, 1) void qat16_bwd_kernel(SeqArgs a, int bits_w
     float* tab = smem + pad4(L.P);
     const QSc qs = load_qsc<MK>(pl, L, bits_a);
     const WQ wq = make_wq(pl, L, bits_w);
+    const QK k = make_qk(qs, wq);
     const int nlut = LUT ? (1 << bits_a) : 0;
     float* lut = tab + s16_tab_floats(kGroups);
     {
         float4* t4 = reinterpret_cast<float4*>(tab);
         for (int grp = wave; grp < kGroups; grp += nwb) t4[grp * 64 + lane] = q16_entry<MK, NT>(pl, L, wq, grp, n, q);
-        if constexpr (LUT) fill_luts(lut, qs.add, bits_a, qs.sig, K::TRES);
+        if constexpr (LUT) fill_luts(lut, qs, k, bits_a, K::TRES);
         __syncthreads();
     }
     const int Ksig = sig_levels(qs.sig);
+    const float4* lutq = reinterpret_cast<const float4*>(lut) - (int)qs.add.qn;
+    const float* thr = lut + 4 * nlut;
     const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     Scalars<MK> sc;
     sc.load(pl, L);
     float oh[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
-    float* wbase = lut + (LUT ? 2 * nlut + kMaxThr : 0) + (size_t)wave * kWaveF;
+    float* wbase = lut + (LUT ? 4 * nlut + kMaxThr : 0) + (size_t)wave * kWaveF;
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* dys = xs + 16 * K::XSTRIDE;
     float2* dxs = dys + 16 * kChunkPad;                   // DX only
@@ -1179,8 +1241,8 @@ __global__ __launch_bounds__(256, 1) void qat16_bwd_kernel(SeqArgs a, int bits_w
                     st.xp[0] = xp.x; st.xp[1] = xp.y;
                 }
             }
-            if (nstep == S) q16_bwd_block<MK, NT, LUT, true, DX>(a, tl, qs, lut, nlut, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
-            else q16_bwd_block<MK, NT, LUT, false, DX>(a, tl, qs, lut, nlut, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+            if (nstep == S) q16_bwd_block<MK, NT, LUT, true, DX>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+            else q16_bwd_block<MK, NT, LUT, false, DX>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
         }
         if constexpr (DX) {
             wave_lds_fence();
@@ -1197,7 +1259,7 @@ __global__ __launch_bounds__(256, 1) void qat16_bwd_kernel(SeqArgs a, int bits_w
     const int P4 = L.P + kLossCols;
     __syncthreads();
     float* rows = smem + pad4(L.P);
-    q16_write_row<MK, NT>(rows + wave * P4, pl, L, wq, G, lane, n, q);
+    q16_write_row<MK, NT>(rows + wave * P4, pl, L, wq, k, G, lane, n, q);
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * P4;
     for (int i = threadIdx.x; i < P4; i += blockDim.x) {
@@ -1266,30 +1328,36 @@ static size_t lds_bytes(int P, int waves, int bits_a, bool lut, bool bwd, bool d
     using K = Kind<MK>;
     const size_t per_wave = bwd ? 2 * 16 * K::XSTRIDE + (dx ? 2 : 1) * 2 * 16 * kChunkPad + QT<MK, NT>::kTiles * kTileFloats
                                 : 2 * 16 * K::XSTRIDE + 2 * 16 * kChunkPad;
-    size_t n = ((size_t)pad4(P) + s16_tab_floats(groups<MK, NT>(bwd, dx)) + (lut ? 2 * (1 << bits_a) + kMaxThr : 0) + (size_t)waves * per_wave) * sizeof(float);
+    size_t n = ((size_t)pad4(P) + s16_tab_floats(groups<MK, NT>(bwd, dx)) + (lut ? 4 * (1 << bits_a) + kMaxThr : 0) + (size_t)waves * per_wave) * sizeof(float);
     const size_t need = ((size_t)pad4(P) + (size_t)waves * (P + kLossCols)) * sizeof(float);
     if (bwd && n < need) n = need;
     return n;
 }
+// waves per workgroup: one per CU while the batch leaves CUs idle (latency regime), then up to `max_waves` sharing one operand table,
+// as many as the LDS holds; the grid never exceeds the CU count (persistent waves)
 template <int MK, int NT>
-static LaunchShape shape(const odpd_model_t* m, int ngroups, bool bwd, bool dx) {
+static LaunchShape shape(const odpd_model_t* m, int ngroups, bool bwd, bool dx, int max_waves) {
     const int P = qat_layout(MK, m->hidden).P, cus = device_cus();
     const bool lut = m->bits_a <= 8;
     LaunchShape ls;
-    ls.waves = 4;
+    ls.waves = 1;
+    while (ls.waves < max_waves && ngroups > ls.waves * cus) ls.waves *= 2;
     while (ls.waves > 1 && lds_bytes<MK, NT>(P, ls.waves, m->bits_a, lut, bwd, dx) > kMaxLds) --ls.waves;
     const int need = (ngroups + ls.waves - 1) / ls.waves;
     ls.grid = need < cus ? need : cus;
     if (ls.grid < 1) ls.grid = 1;
     return ls;
 }
+// the backward's grid (= rows of partials) must not depend on whether dL/dx is asked for: it is the grid of the launch WITHOUT dL/dx
+template <int MK, int NT>
+static int bwd_grid(const odpd_model_t* m, int ngroups) { return shape<MK, NT>(m, ngroups, true, false, BwdOcc<MK, NT, false>::W2 ? 8 : 4).grid; }
 template <int MK, int NT, bool LUT>
 static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
     using T = QT<MK, NT>;
     const int P = qat_layout(MK, m->hidden).P;
     a.nck = (a.T + T::S - 1) / T::S;
     if (mode == 1) {
-        const LaunchShape ls = shape<MK, NT>(m, a.ngroups, false, false);
+        const LaunchShape ls = shape<MK, NT>(m, a.ngroups, false, false, 8);
         const size_t lds = lds_bytes<MK, NT>(P, ls.waves, m->bits_a, LUT, false, false);
         if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
         auto k = qat16_fwd_kernel<MK, NT, LUT>;
@@ -1300,8 +1368,8 @@ static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
     if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
     if (!a.ckpt && a.nck > 1) return ODPD_EINVAL;
     const bool dx = a.dx != nullptr;
-    // the grid (= rows of partials) must not depend on whether dL/dx is asked for: sized for the larger (dx) footprint
-    const LaunchShape ls = shape<MK, NT>(m, a.ngroups, true, true);
+    LaunchShape ls = shape<MK, NT>(m, a.ngroups, true, dx, (dx ? BwdOcc<MK, NT, true>::W2 : BwdOcc<MK, NT, false>::W2) ? 8 : 4);
+    ls.grid = bwd_grid<MK, NT>(m, a.ngroups);
     const size_t lds = lds_bytes<MK, NT>(P, ls.waves, m->bits_a, LUT, true, dx);
     if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
     auto go = [&](auto k) {
@@ -1329,7 +1397,7 @@ static int launch_kind(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, 
 }
 template <int MK>
 static int rows_kind(const odpd_model_t* m, int ngroups) {
-    return tiles_of(m->hidden) == 1 ? shape<MK, 1>(m, ngroups, true, true).grid : shape<MK, 2>(m, ngroups, true, true).grid;
+    return tiles_of(m->hidden) == 1 ? bwd_grid<MK, 1>(m, ngroups) : bwd_grid<MK, 2>(m, ngroups);
 }
 }  // namespace q16
 
