@@ -52,7 +52,8 @@ enum odpd_backbone {
 enum odpd_error {
     ODPD_OK = 0,
     ODPD_EINVAL = -1,      /* bad argument (null pointer, B<=0, ...) */
-    ODPD_EUNSUPPORTED = -2 /* backbone / hidden size not supported by the kernels */
+    ODPD_EUNSUPPORTED = -2, /* backbone / hidden size not supported by the kernels */
+    ODPD_ECOMM = -3         /* the collective library (RCCL) is missing or returned an error */
 };
 
 /* Model descriptor: what `CoreModel.__init__` receives (models.py:11). */
@@ -221,6 +222,33 @@ int odpd_train_epoch_split(void* stream, const odpd_model_t* m, int loss_kind, c
                            double beta2, double eps, double weight_decay, double max_norm, const unsigned char* skip,
                            float* xbuf, float* tbuf, float* ybuf, float* dybuf, float* ckpt, float* partials, float* loss_scratch,
                            double* stats, float* losses_out);
+
+/* ---- data parallel: the batch of frames sharded over the GPUs of a node, one process per GPU -------------------
+ * The reference is single-device; this is the boundary a multi-GPU binding of train_funcs.py:16-54 would call.  Every rank holds a
+ * replica of the parameters and of the optimiser state, takes the contiguous shard [lo, hi) = shard of each global batch (sizes differ
+ * by at most one, odpd_shard_range), normalises its loss gradient by the GLOBAL element count, and ONE in-place all-reduce (sum) of
+ * the P + 4 floats behind `grad` (gradient + loss partial sum) over RCCL / xGMI per optimiser step makes every rank apply the same
+ * clip + optimiser update.  librccl is loaded on first use (dlopen); ODPD_ECOMM when it is missing or fails. */
+/* rank 0: 128 bytes identifying a new communicator; hand them to every rank (any host channel), then all call odpd_comm_init */
+int odpd_comm_unique_id(void* id128);
+/* collective over `world` processes, each with its GPU current (hipSetDevice): *comm_out = opaque handle.  world == 1 is valid */
+int odpd_comm_init(const void* id128, int world, int rank, void** comm_out);
+int odpd_comm_destroy(void* comm);
+/* in-place sum over the ranks of n fp32 values, enqueued on `stream` (asynchronous like every other call here) */
+int odpd_comm_allreduce_sum(void* stream, void* comm, float* buf, int64_t n);
+/* contiguous shard [*lo, *hi) of n items for `rank` of `world` (the split of train_funcs.py's batch across ranks) */
+void odpd_shard_range(int64_t n, int rank, int world, int64_t* lo, int64_t* hi);
+/* odpd_train_epoch / odpd_train_epoch_opt (opt_kind < 0: AdamW with the given hyper-parameters) with every GLOBAL batch of `batch`
+ * frames of fr->order sharded over the ranks of `comm`: per step the fused fwd+loss+bwd kernel on this rank's frames (a rank whose
+ * shard of a short last batch is empty contributes zeros), the partial-row reduction, the all-reduce of grad[0 .. P+4) on the same
+ * stream, the clip + optimiser step — issued back to back from C++, no host synchronisation, no Python between steps.  Every rank
+ * passes the same fr->order (same seeded permutation), batch and hyper-parameters and its own replica buffers.  partials /
+ * workspace sized for the largest shard (odpd_partial_rows / odpd_train_workspace_floats at B = ceil(batch / world)).
+ * losses_out[i] = mean loss of GLOBAL batch i (identical on every rank). */
+int odpd_train_epoch_dp(void* stream, void* comm, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, int opt_kind,
+                        float* params, float* grad, float* state1, float* state2, int64_t first_step, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, double max_norm, float* partials, float* workspace,
+                        float* losses_out);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ LOSS_IDS = {"l2": 0, "l1": 1}
 FLAG_EVAL, FLAG_NEED_DX = 1, 2      # odpd_model_t.flags (include/opendpd_hip.h)
 LOSS_COLS = 4        # extra columns of a partials row (column P = loss partial sum)
 LOSS_WS = 1 + 256    # floats behind `loss_out` (result + per-block scratch)
-ABI_VERSION = 7      # odpd_abi_version() of the library these argument lists belong to
+ABI_VERSION = 8      # odpd_abi_version() of the library these argument lists belong to
 
 
 class ModelDesc(C.Structure):
@@ -69,6 +69,14 @@ _EXPORTS = {
                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
+    "odpd_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "odpd_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "odpd_comm_destroy": (C.c_int, [C.c_void_p]),
+    "odpd_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "odpd_shard_range": (None, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "odpd_train_epoch_dp": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "odpd_clip_optim_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
 }
@@ -113,7 +121,7 @@ def load():
 
 def check(rc, what):
     if rc != 0:
-        kind = {-1: "invalid argument", -2: "unsupported backbone/hidden size"}.get(rc, f"hipError {rc}")
+        kind = {-1: "invalid argument", -2: "unsupported backbone/hidden size", -3: "RCCL missing or failed"}.get(rc, f"hipError {rc}")
         raise RuntimeError(f"{what} failed: {kind}")
 
 

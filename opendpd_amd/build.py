@@ -106,7 +106,7 @@ def build(force=False, verbose=False, extra_flags=(), jobs=None, out=None):
     resources = {}
     for _, r in results:
         resources.update(r)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-ldl", "-o", lib]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

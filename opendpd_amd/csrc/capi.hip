@@ -86,7 +86,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 7; }   // 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
+extern "C" int odpd_abi_version(void) { return 8; }   // 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
@@ -320,35 +320,61 @@ extern "C" int odpd_train_fwd_bwd_framed(void* stream, const odpd_model_t* m, in
 // reduction, clip + AdamW; three launches per step issued back to back from C++, no host synchronisation, no
 // gather kernels, no Python between steps.  losses_out[i] = mean loss of batch i (device).
 // opt_kind < 0: AdamW with the given hyper-parameters; otherwise an enum odpd_optimizer kind with project.py's own
+extern "C" void odpd_shard_range(int64_t n, int rank, int world, int64_t* lo, int64_t* hi) {
+    const int64_t base = n / world, rem = n % world;
+    *lo = rank * base + (rank < rem ? rank : rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+// comm != NULL: every global batch sharded over the communicator's ranks, one all-reduce of grad[0 .. P+4) per step
 static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, float* params, float* grad,
                             float* state1, float* state2, int64_t first_step, int opt_kind, double lr, double beta1, double beta2, double eps,
-                            double weight_decay, double max_norm, float* partials, float* workspace, float* losses_out) {
+                            double weight_decay, double max_norm, float* partials, float* workspace, float* losses_out, void* comm = nullptr) {
     if (!model_ok(m) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
         fr->stride <= 0 || batch <= 0 || !params || !grad || !state1 || !state2 || !partials || !losses_out || first_step <= 0)
         return ODPD_EINVAL;
     const int T = fr->frame_length;
-    {   // every batch of the epoch (the full ones and the tail) must have a frame-reading fused kernel
-        const int64_t tail = fr->n_frames % batch;
-        if (!framed_train_ok_shape(m, (int)(fr->n_frames < batch ? fr->n_frames : batch), T) ||
-            (tail && !framed_train_ok_shape(m, (int)tail, T)))
-            return ODPD_EUNSUPPORTED;
+    const int rank = comm ? comm_rank(comm) : 0, world = comm ? comm_world(comm) : 1;
+    {   // every (shard of a) batch of the epoch — the full ones and the tail — must have a frame-reading fused kernel
+        const int64_t full = fr->n_frames < batch ? fr->n_frames : batch, tail = fr->n_frames % batch;
+        for (int64_t gb : {full, tail}) {
+            if (!gb) continue;
+            int64_t lo, hi;
+            odpd_shard_range(gb, rank, world, &lo, &hi);
+            if (hi > lo && !framed_train_ok_shape(m, (int)(hi - lo), T)) return ODPD_EUNSUPPORTED;
+        }
     }
     const int64_t P = odpd_param_count(m);
     hipStream_t st = (hipStream_t)stream;
     int64_t step = first_step;
     for (int64_t f0 = 0, i = 0; f0 < fr->n_frames; f0 += batch, ++i, ++step) {
-        const int B = (int)((fr->n_frames - f0) < batch ? (fr->n_frames - f0) : batch);
-        const int64_t rows = odpd_partial_rows(m, B, T, 1);
-        if (rows <= 0) return rows < 0 ? (int)rows : ODPD_EUNSUPPORTED;
-        SeqArgs a = make_args(m, B, T);
-        a.params = params; a.x = fr->x_stream; a.target = fr->y_stream; a.partials = partials; a.ckpt = workspace;
-        a.frame_idx = (const long long*)(fr->order + f0); a.frame_stride = fr->stride;
-        const int64_t count = (int64_t)B * T * 2;
-        a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
-        int rc = framed_train_launch(st, m, a);
-        if (rc) return rc;
-        rc = odpd_reduce_partials(stream, rows, P, partials, grad, 0);
-        if (rc) return rc;
+        const int64_t GB = (fr->n_frames - f0) < batch ? (fr->n_frames - f0) : batch;      // the global batch
+        int64_t lo, hi;
+        odpd_shard_range(GB, rank, world, &lo, &hi);
+        const int B = (int)(hi - lo);                                                       // this rank's frames of it
+        const int64_t count = GB * T * 2;                                                   // loss mean over the GLOBAL batch
+        const float inv_count = (float)(1.0 / (double)count);
+        int rc;
+        if (B > 0) {
+            const int64_t rows = odpd_partial_rows(m, B, T, 1);
+            if (rows <= 0) return rows < 0 ? (int)rows : ODPD_EUNSUPPORTED;
+            SeqArgs a = make_args(m, B, T);
+            a.params = params; a.x = fr->x_stream; a.target = fr->y_stream; a.partials = partials; a.ckpt = workspace;
+            a.frame_idx = (const long long*)(fr->order + f0 + lo); a.frame_stride = fr->stride;
+            a.inv_count = inv_count; a.loss_kind = loss_kind;
+            rc = framed_train_launch(st, m, a);
+            if (rc) return rc;
+            rc = odpd_reduce_partials(stream, rows, P, partials, grad, 0);
+            if (rc) return rc;
+        } else {      // an empty shard of a short last batch: zeros into the sum
+            rc = (int)hipMemsetAsync(grad, 0, (size_t)(P + kLossCols) * sizeof(float), st);
+            if (rc) return rc;
+        }
+        if (comm) {
+            rc = comm_allreduce(st, comm, grad, P + kLossCols);
+            if (rc) return rc;
+        }
+        SeqArgs a{};
+        a.inv_count = inv_count;
         rc = opt_kind < 0 ? launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
                                               losses_out + i, a.inv_count)
                           : launch_clip_optim(st, opt_kind, P, params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, a.inv_count);
@@ -418,6 +444,14 @@ extern "C" int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_ki
                                 float* partials, float* workspace, float* losses_out) {
     return train_epoch_impl(stream, m, loss_kind, fr, batch, params, grad, exp_avg, exp_avg_sq, first_step, -1, lr, beta1, beta2, eps, weight_decay,
                             max_norm, partials, workspace, losses_out);
+}
+extern "C" int odpd_train_epoch_dp(void* stream, void* comm, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, int opt_kind,
+                                   float* params, float* grad, float* state1, float* state2, int64_t first_step, double lr, double beta1,
+                                   double beta2, double eps, double weight_decay, double max_norm, float* partials, float* workspace,
+                                   float* losses_out) {
+    if (!comm || opt_kind > ODPD_OPT_RMSPROP) return ODPD_EINVAL;
+    return train_epoch_impl(stream, m, loss_kind, fr, batch, params, grad, state1, state2, first_step, opt_kind < 0 ? -1 : opt_kind, lr, beta1, beta2,
+                            eps, weight_decay, max_norm, partials, workspace, losses_out, comm);
 }
 extern "C" int odpd_train_epoch_opt(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, int opt_kind,
                                     float* params, float* grad, float* state1, float* state2, int64_t first_step, double lr,

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/opendpd_hip.h"
 #include "odpd_device.h"
@@ -138,6 +139,11 @@ struct SeqArgs {
     int loss_kind;
     int B, T, H, ngroups, nck;
 };
+
+// comm.hip: RCCL communicator of the data-parallel step
+int comm_allreduce(hipStream_t st, void* comm, float* buf, int64_t n);     // in-place sum of n floats over the ranks, on the stream
+int comm_rank(void* comm);
+int comm_world(void* comm);
 
 // family entry points (defined in the family .hip files)
 int gru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);

@@ -57,3 +57,66 @@ def broadcast_params_(module, src=0, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         for p in module.parameters():
             dist.broadcast(p.data, src=src, group=group)
+
+
+class NativeComm:
+    """RCCL communicator owned by libopendpd_hip.so (csrc/comm.hip): the step's one all-reduce is then enqueued from C++ on the step's
+    own stream — `odpd_comm_allreduce_sum` per step, or the whole sharded epoch through `odpd_train_epoch_dp` — instead of going
+    through torch.distributed from Python.  Created collectively: rank 0 draws the 128-byte id, the default process group carries it
+    to the other ranks (the only use torch.distributed has on this path)."""
+
+    def __init__(self, device):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        lib = _lib.load()
+        self.rank, _, self.world = env_world()
+        if dist.is_available() and dist.is_initialized():
+            self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_ubyte * 128)()
+            _lib.check(lib.odpd_comm_unique_id(C.cast(buf, C.c_void_p)), "odpd_comm_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if self.world > 1:
+            carrier = ident.to(device) if dist.get_backend() == "nccl" else ident
+            dist.broadcast(carrier, src=0)
+            ident = carrier.cpu()
+        raw = (C.c_ubyte * 128)(*ident.tolist())
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.odpd_comm_init(C.cast(raw, C.c_void_p), self.world, self.rank, C.byref(handle)), "odpd_comm_init")
+        self.handle, self._lib = handle, lib
+
+    def allreduce_sum_(self, t):
+        from . import _lib
+        _lib.check(self._lib.odpd_comm_allreduce_sum(_lib.stream_ptr(), self.handle, _lib.ptr(t), t.numel()), "odpd_comm_allreduce_sum")
+        return t
+
+    def close(self):
+        if self.handle:
+            self._lib.odpd_comm_destroy(self.handle)
+            self.handle = None
+
+
+_native = None
+
+
+def native_comm(device=None):
+    """The process-wide NativeComm, created on first use when the default process group runs on RCCL ("nccl" backend: one process per
+    GPU) — or for a single process when $ODPD_NATIVE_COMM=1 (exercises the RCCL path on a one-GPU box).  None otherwise (gloo groups:
+    several ranks may share a device, which RCCL refuses) or when RCCL cannot be initialised: the caller then uses torch.distributed."""
+    global _native
+    import torch.distributed as dist
+    if _native is not None:
+        return _native or None
+    want = os.environ.get("ODPD_NATIVE_COMM")
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if want == "0" or (not multi and want != "1") or (multi and dist.get_backend() != "nccl"):
+        return None
+    try:
+        _native = NativeComm(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    except Exception as exc:      # missing librccl, refused topology: announce and fall back
+        print(f"[opendpd_amd] native RCCL communicator unavailable ({exc}); using torch.distributed for the gradient all-reduce")
+        _native = False
+    return _native or None

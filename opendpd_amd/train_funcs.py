@@ -163,10 +163,33 @@ class FusedAdamW:
             return dist.get_world_size(self.process_group)
         return 1
 
+    def native_comm(self):
+        """The library-owned RCCL communicator (dist.native_comm) when the default group runs on RCCL, else None."""
+        if self.process_group is not None:
+            return None
+        from .dist import native_comm
+        return native_comm(self.backbone.flat_params().device)
+
     def allreduce_grad(self):
-        """The ONE collective of the data-parallel step: sum of P+4 floats (gradient + loss partial)."""
+        """The ONE collective of the data-parallel step: sum of P+4 floats (gradient + loss partial) — enqueued by the library on
+        the step's stream when it owns an RCCL communicator, through torch.distributed otherwise (gloo groups of the CPU / one-GPU tests)."""
+        comm = self.native_comm()
+        if comm is not None:
+            comm.allreduce_sum_(self.grad)
+            return
         from .dist import allreduce_sum_
         allreduce_sum_(self.grad, self.process_group)
+
+    def _shard_sizes(self, loader):
+        """this rank's share of the epoch's global batch sizes (full batches and tail) under the native data-parallel loop"""
+        comm = self.native_comm()
+        sizes = set()
+        lo, hi = C.c_int64(), C.c_int64()
+        for gb in self._epoch_batches(loader):
+            _lib.load().odpd_shard_range(gb, comm.rank, comm.world, C.byref(lo), C.byref(hi))
+            if hi.value > lo.value:
+                sizes.add(hi.value - lo.value)
+        return sizes
 
     def empty_step(self, max_norm, count):
         """A rank whose shard of the global batch is empty: zero gradient into the all-reduce, then the common update."""
@@ -207,10 +230,14 @@ class FusedAdamW:
 
     def can_run_epoch(self, loader):
         """True when odpd_train_epoch can drive a whole epoch: single fused backbone, one process, resident streams."""
-        return (self.pa is None and self.world_size() == 1 and getattr(self.backbone, "frozen_mask", None) is None
-                and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size"))
-                and loader.x.is_cuda and all(self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length)
-                                             for b in self._epoch_batches(loader)))
+        if not (self.pa is None and getattr(self.backbone, "frozen_mask", None) is None
+                and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size")) and loader.x.is_cuda):
+            return False
+        if self.world_size() > 1 or self.native_comm() is not None:
+            # sharded epoch from C++ (odpd_train_epoch_dp): needs the library-owned RCCL communicator and fused kernels for this rank's shards
+            return self.native_comm() is not None and all(self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length)
+                                                          for b in self._shard_sizes(loader))
+        return all(self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length) for b in self._epoch_batches(loader))
 
     @staticmethod
     def _epoch_batches(loader):
@@ -282,11 +309,13 @@ class FusedAdamW:
         self._ensure(dev)
         n_steps = (n + B - 1) // B
         last = n - (n_steps - 1) * B
-        key = (B, T, last, "epoch")
+        comm = self.native_comm()
+        key = (B, T, last, "epoch", comm is not None)
         if key not in self._partials:
-            rows = [int(lib.odpd_partial_rows(C.byref(self.backbone.desc), b, T, 1)) for b in {B, last}]
+            sizes = self._shard_sizes(loader) if comm is not None else {B, last}
+            rows = [int(lib.odpd_partial_rows(C.byref(self.backbone.desc), b, T, 1)) for b in sizes] or [1]
             _lib.check(0 if min(rows) > 0 else min(rows), "odpd_partial_rows")
-            ws = max(int(lib.odpd_train_workspace_floats(C.byref(self.backbone.desc), b, T)) for b in {B, last})
+            ws = max([int(lib.odpd_train_workspace_floats(C.byref(self.backbone.desc), b, T)) for b in sizes] or [0])
             self._partials[key] = (torch.empty(max(rows), self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32, device=dev),
                                    torch.empty(ws, dtype=torch.float32, device=dev) if ws > 0 else None)
         part, ws = self._partials[key]
@@ -295,7 +324,15 @@ class FusedAdamW:
         fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
         g = self.param_groups[0]
         flat = self.backbone.flat_params(full_check=True)
-        if self.kind == "adamw":
+        if comm is not None:
+            adamw = self.kind == "adamw"
+            rc = lib.odpd_train_epoch_dp(_lib.stream_ptr(), comm.handle, C.byref(self.backbone.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
+                                         -1 if adamw else _lib.OPTIMIZER_IDS[self.kind], _lib.ptr(flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
+                                         _lib.ptr(self.exp_avg_sq), self.step_count + 1, float(g["lr"]), float(g["betas"][0]) if adamw else 0.0,
+                                         float(g["betas"][1]) if adamw else 0.0, float(g["eps"]) if adamw else 0.0,
+                                         float(g["weight_decay"]) if adamw else 0.0, float(max_norm or 0.0), _lib.ptr(part), _lib.ptr(ws),
+                                         _lib.ptr(losses))
+        elif self.kind == "adamw":
             rc = lib.odpd_train_epoch(_lib.stream_ptr(), C.byref(self.backbone.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
                                       _lib.ptr(flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                                       self.step_count + 1, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
