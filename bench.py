@@ -35,7 +35,29 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak = exact-fp32 (f32-input) MFMA peak
 ALGO_BYTES_PER_SAMPLE = 16.0
-FLOP_PER_SAMPLE = {13: 2 * 3 * (39 * 19 + 169 + 38)}  # fwd+dgrad+wgrad MACs*2 for DGRU H13 (5.7 kflop)
+
+
+def dgru_macs(H):
+    """forward multiply-accumulates of one IQ sample through DGRU(H): W_ih (3H x 6), W_hh (3H x H), fc_hid (H x H), fc_out (2 x (H + 6))"""
+    return 3 * H * 6 + 3 * H * H + H * H + 2 * (H + 6)
+
+
+def flops_train_pa_dgru(H):
+    """algorithmic flops of the train_pa step per IQ sample: forward + data gradient + weight gradient = 2 x 3 x MACs, MINUS the data
+    gradient through the input projection and through fc_out's feature columns (2 x (3H x 6 + 2 x 6)): train_pa never needs dL/dx."""
+    return 2 * 3 * dgru_macs(H) - 2 * (3 * H * 6 + 2 * 6)
+
+
+def flops_frozen_dgru(H):
+    """frozen PA inside train_dpd: forward + full data gradient (down to dL/du), no weight gradient"""
+    return 2 * 2 * dgru_macs(H)
+
+
+TRES15_MACS = 3 * 15 * 6 + 3 * 15 * 15 + 2 * 15 + (2 * 3 * 3 + 3 * 2)      # x2h, h2h, fc_out, TCN skip = 999 (= its parameter count)
+FLOPS_TRAIN_TRES15 = 2 * 3 * TRES15_MACS - 2 * (3 * 15 * 6 + 2 * 3 * 3)         # trained DPD: no dL/dx through x2h / the first conv
+QGRU10_MACS = 3 * 10 * 4 + 3 * 10 * 10 + 2 * 10
+FLOPS_TRAIN_QGRU10 = 2 * 3 * QGRU10_MACS - 2 * (3 * 10 * 4)
+FLOP_PER_SAMPLE = {13: flops_train_pa_dgru(13)}     # 5 196 (r01 / r02 counted 5 688: with the input data gradient train_pa does not compute)
 
 
 def synth_frames(n_frames, T, seed, device, materialize=True):
@@ -63,6 +85,19 @@ def synth_frames(n_frames, T, seed, device, materialize=True):
     fx = xs.unfold(0, T, 1).permute(0, 2, 1).contiguous()   # (n_frames, T, 2)
     fy = ys.unfold(0, T, 1).permute(0, 2, 1).contiguous()
     return fx, fy
+
+
+def cascade_spans(opt, x, t, count, n=5):
+    """mean HIP-event time (ms) of every launch group of the cascade step (train_funcs._cascade_train_step), over n steps"""
+    from opendpd_amd.train_funcs import fused_train_step
+    spans = []
+    for _ in range(n):
+        fused_train_step(opt, x, t, "l2", 200.0, count, timing=spans)
+    torch.cuda.synchronize()
+    out = {}
+    for name, a, b in spans:
+        out.setdefault(name, []).append(a.elapsed_time(b))
+    return {k: float(np.mean(v)) for k, v in out.items()}
 
 
 def run_steps(opt, x, t, steps, warmup, count, dist, events=False):
@@ -137,6 +172,15 @@ def cpu_baseline(H, T, budget_1t_s=4.0, budget_nt_s=2.5):
                       f"{sum(v[1] for v in steps.values()):.0f} s of CPU sweep in total)"}
 
 
+def kernel_source_sha1():
+    """identifies the build of the headline kernel: sha1 over its sources"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("gru_s16.hip", "odpd_s16.h", "odpd_device.h", "odpd_seq.h"):
+        h.update(open(os.path.join(ROOT, "opendpd_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +236,36 @@ def main():
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
     el = float(el_t.item())
     value = world * B * T * args.steps / el
+
+    # side figure: the same step back to back for >= 2 s (the headline's timed region is 20 steps = ~32 ms: this one is at steady clocks)
+    sustained = None
+    if not os.environ.get("ODPD_BENCH_NO_SUSTAINED"):
+        n_s = max(args.steps, int(2.0 / (el / args.steps)) + 1)
+        el_s, _, _ = run_steps(opt, x, t, n_s, 0, count, dist)
+        el_s_t = torch.tensor([el_s], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(el_s_t, op=dist.ReduceOp.MAX)
+        sustained = {"steps": n_s, "seconds": float(el_s_t.item()), "ms_per_step": 1e3 * float(el_s_t.item()) / n_s,
+                     "value": world * B * T * n_s / float(el_s_t.item()), "unit": "IQ samples/s"}
+
+    # side figure: BASELINE configs[3] — train_pa VDLSTM H13, the same batch per GPU, sharded the same way (tensor inputs: its
+    # large-batch kernel takes (B,T,2) frames)
+    cfg4 = None
+    if not args.no_cascade:
+        torch.manual_seed(4)
+        net4 = CoreModel(2, 13, 1, "vdlstm").to(dev)
+        opt4_ = FusedAdamW(net4, lr=5e-4)
+        B4 = min(B, 32768)
+        x4, t4 = synth_frames(B4, T, seed=2000 + rank, device=dev)
+        n4 = max(3, min(args.steps, 10))
+        el4_, _, loss4_ = run_steps(opt4_, x4, t4, n4, 2, world * B4 * T * 2, dist)
+        el4_t = torch.tensor([el4_], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(el4_t, op=dist.ReduceOp.MAX)
+        cfg4 = {"workload": f"train_pa VDLSTM H13 ({net4.backbone.n_flat} params), T={T}, {B4} frames per GPU", "batch_per_gpu": B4,
+                "value": world * B4 * T * n4 / float(el4_t.item()), "unit": "IQ samples/s", "ms_per_step": 1e3 * float(el4_t.item()) / n4,
+                "loss": loss4_}
+        del net4, opt4_, x4, t4
 
     # side figure: the reference batch size (launch/latency-bound regime)
     ref = None
@@ -251,9 +325,23 @@ def main():
         opt3 = FusedAdamW(casc, lr=5e-4)
         n3 = max(3, min(args.steps, 10))
         xc = x if args.materialized else xs_.unfold(0, T, 1)[:B].permute(0, 2, 1).contiguous()   # the cascade takes tensors
-        el3, _, loss3 = run_steps(opt3, xc, xc.clone(), n3, 2, world * B * T * 2, dist)
+        tc = xc.clone()
+        el3, _, loss3 = run_steps(opt3, xc, tc, n3, 2, world * B * T * 2, dist)
+
+        def priced(flops_per_sample, el_, n_, spans, kernels):
+            """the cascade step against the fp32 MFMA / vector roof: algorithmic flops (DPD fwd + hidden-side dgrad + wgrad, frozen PA fwd +
+            dgrad) over the whole step's time; `kernels` = the launch groups with their HIP-event times"""
+            tf = flops_per_sample * B * T / (el_ / n_) / 1e12
+            return {"bound": "mfma", "achieved": tf, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_FP32_PEAK_TFLOPS,
+                    "algorithmic_flops_per_sample": flops_per_sample, "kernels": kernels, "kernel_ms": spans,
+                    "hbm": {"achieved": ALGO_BYTES_PER_SAMPLE * B * T / (el_ / n_) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ALGO_BYTES_PER_SAMPLE * B * T / (el_ / n_) / 1e9 / HBM_PEAK_GBS}}
+
         dpd = {"workload": f"train_dpd: DGRU H{H} DPD -> frozen DGRU H{H} PA (cascade step: DPD fwd, frozen-PA fwd + loss + dL/du in one launch, DPD bwd), target = x",
-               "value": B * T * n3 / el3, "unit": "IQ samples/s", "ms_per_step": 1e3 * el3 / n3, "loss": loss3}
+               "value": B * T * n3 / el3, "unit": "IQ samples/s", "ms_per_step": 1e3 * el3 / n3, "loss": loss3,
+               "roofline": priced(flops_train_pa_dgru(H) + flops_frozen_dgru(H), el3, n3, cascade_spans(opt3, xc, tc, world * B * T * 2),
+                                  {"dpd_fwd": "gru16_fwd_kernel<DGRU6>", "pa_fwd_loss_dx": "gru16_train_kernel<DGRU6, frozen: loss + dL/du>",
+                                   "dpd_bwd": "gru16_bwd_kernel<DGRU6>", "reduce_clip_optimiser": "reduce_partials_kernel + clip_adamw_kernel"})}
         del casc, opt3
         # BASELINE configs[2]: TRes-DeltaGRU H15 (thx .01, thh .05) DPD in front of a frozen DGRU H23 PA, same batch
         torch.manual_seed(2)
@@ -261,22 +349,46 @@ def main():
         casc.freeze_pa_model()
         casc = casc.to(dev)
         opt4 = FusedAdamW(casc, lr=5e-4)
-        el4, _, loss4 = run_steps(opt4, xc, xc.clone(), n3, 2, world * B * T * 2, dist)
+        el4, _, loss4 = run_steps(opt4, xc, tc, n3, 2, world * B * T * 2, dist)
         dpd["config3"] = {"workload": "train_dpd: TRes-DeltaGRU H15 (thx 0.01, thh 0.05) DPD -> frozen DGRU H23 PA, target = x",
-                          "value": B * T * n3 / el4, "unit": "IQ samples/s", "ms_per_step": 1e3 * el4 / n3, "loss": loss4}
-        del xc, casc, opt4
+                          "value": B * T * n3 / el4, "unit": "IQ samples/s", "ms_per_step": 1e3 * el4 / n3, "loss": loss4,
+                          "roofline": priced(FLOPS_TRAIN_TRES15 + flops_frozen_dgru(23), el4, n3, cascade_spans(opt4, xc, tc, world * B * T * 2),
+                                             {"dpd_fwd": "delta16_fwd_kernel<TRES>", "pa_fwd_loss_dx": "gru16n_kernel<DGRU6, frozen: loss + dL/du>",
+                                              "dpd_bwd": "delta16_bwd_kernel<TRES>", "reduce_clip_optimiser": "reduce_partials_kernel + clip_adamw_kernel"})}
+        del casc, opt4
+        # BASELINE configs[4]: quantisation-aware QGRU H10 (W8A8) DPD in front of the frozen DGRU H23 PA (integer-grid cell, csrc/qat_s16.hip)
+        from types import SimpleNamespace
+        from opendpd_amd.quant import get_quant_model
+        torch.manual_seed(3)
+        qdpd = get_quant_model(SimpleNamespace(quant=True, n_bits_w=8, n_bits_a=8, pretrained_model=""), CoreModel(2, 10, 1, "qgru"))
+        casc = CascadedModel(dpd_model=qdpd, pa_model=CoreModel(2, 23, 1, "dgru"))
+        casc.freeze_pa_model()
+        casc = casc.to(dev)
+        casc.train()
+        opt5 = FusedAdamW(casc, lr=5e-4)
+        el5, _, loss5 = run_steps(opt5, xc, tc, n3, 2, world * B * T * 2, dist)
+        dpd["config5"] = {"workload": "train_dpd: quantisation-aware QGRU H10 (W8A8, 515 params) DPD -> frozen DGRU H23 PA, target = x",
+                          "value": B * T * n3 / el5, "unit": "IQ samples/s", "ms_per_step": 1e3 * el5 / n3, "loss": loss5,
+                          "roofline": priced(FLOPS_TRAIN_QGRU10 + flops_frozen_dgru(23), el5, n3, cascade_spans(opt5, xc, tc, world * B * T * 2),
+                                             {"dpd_fwd": "qat16_fwd_kernel<Q4, NT 1, LUT>", "pa_fwd_loss_dx": "gru16n_kernel<DGRU6, frozen: loss + dL/du>",
+                                              "dpd_bwd": "qat16_bwd_kernel<Q4, NT 1, LUT>", "reduce_clip_optimiser": "reduce_partials_kernel + clip_adamw_kernel"})}
+        del xc, tc, casc, opt5
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * B * T / (kern_ms * 1e-3) / 1e9
         tflops = FLOP_PER_SAMPLE.get(H, 0) * B * T / (kern_ms * 1e-3) / 1e12
         s16 = opt.train_workspace(B, T, dev) is not None     # which fused kernel served this batch (csrc/gru_family.hip)
         kernel_name = "gru16_train_kernel<DGRU6,true> (16 seq/wave, MFMA)" if s16 else "gru_train_kernel<1,DGRU6,true> (4 seq/wave, DPP)"
+        # HBM bytes per launch from the PMC passes of tools/profile_pmc.sh (rocprofv3 cannot run inside this process): valid for the
+        # kernel SOURCE it was measured on — the entry carries the sha1 of csrc/gru_s16.hip + odpd_s16.h, a changed kernel reports null
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 key = f"dgru_h{H}_b{B}_t{T}" + ("_materialized" if args.materialized else "")
-                traffic = json.load(open(pmc)).get(key, {}).get("hbm_bytes_per_launch")
+                ent = json.load(open(pmc)).get(key, {})
+                if ent.get("source_sha1") == kernel_source_sha1():
+                    traffic = ent.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -292,11 +404,18 @@ def main():
                          "frac": tflops / VALU_FP32_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": FLOP_PER_SAMPLE.get(H, 0) * B * T,
+                         "algorithmic_flops_per_sample": FLOP_PER_SAMPLE.get(H, 0),
+                         "kernel_source_sha1": kernel_source_sha1(),
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * B * T}},
+            "sustained": sustained,
             "reference_batch": ref,
+            "config4": cfg4,
             "reference_shapes": ref_shapes,
             "train_dpd": dpd,
+            "collective": ("none (one GPU)" if world == 1 else
+                           ("RCCL all-reduce of P+4 floats per step, enqueued by libopendpd_hip.so on the step's stream (csrc/comm.hip)"
+                            if opt.native_comm() is not None else "torch.distributed all_reduce of P+4 floats per step")),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, T)

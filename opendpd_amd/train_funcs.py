@@ -411,7 +411,7 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
         raise RuntimeError("FrameBatch input needs a single backbone whose fused kernel for this batch shape reads frames from streams "
                            "(GRU family, gmp, rvtdcnn; lstm / vdlstm / pgjanet at the reference's batch sizes)")
     if opt.pa is not None or not opt.has_fused(B, T):
-        return _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count)
+        return _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count, timing if isinstance(timing, list) else None)
     part = opt.partials(B, T, x.device)
     ws = opt.train_workspace(B, T, x.device)
     flat = bb.flat_params()
@@ -437,8 +437,9 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     return loss
 
 
-def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
-    """Split-kernel step.  With a frozen PA (train_dpd, steps/train_dpd.py:60-63, models.py:173-176):
+def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count, timing=None):
+    """Split-kernel step.  `timing` (a list): (name, start event, end event) of every launch group is appended (bench.py prices the
+    cascade's kernels one by one with it).  With a frozen PA (train_dpd, steps/train_dpd.py:60-63, models.py:173-176):
     y = PA(DPD(x)) chained on the stream — DPD fwd, then the frozen PA's forward + loss + dL/du as ONE launch where
     odpd_frozen_loss_dx serves the PA (GRU family), else PA fwd, loss, PA bwd (dL/du only); then DPD bwd.  Without a PA (backbones that have no fused kernel yet): fwd, loss, bwd."""
     lib = _lib.load()
@@ -457,8 +458,22 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
     part = opt.bwd_partials(B, T, x.device)
     st = _lib.stream_ptr()
     fd, fp = dpd.flat_params(), (pa.flat_params() if pa is not None else None)
+
+    def mark(name=None, _open=[]):
+        """open / close a timed span (no-op without `timing`)"""
+        if timing is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if _open:
+            timing.append((_open.pop(), _open.pop(), ev))
+        if name is not None:
+            _open.extend([ev, name])
+
+    mark("dpd_fwd")
     _lib.check(lib.odpd_backbone_fwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(buf["u"]),
                                      _lib.ptr(buf["ck_d"]), _lib.ptr(dpd._stats_buffer(x.device))), "dpd fwd")
+    mark("pa_fwd_loss_dx" if pa is not None else "loss")
     loss_sum = None
     if pa is not None and buf["loss_rows"] is not None:
         # frozen PA in front of the loss: forward, loss and dL/du in one launch (16-sequences-per-wave GRU-family kernels)
@@ -480,8 +495,10 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
             _lib.check(lib.odpd_backbone_bwd(st, C.byref(pa.desc), B, T, _lib.ptr(fp), _lib.ptr(buf["u"]), _lib.ptr(buf["dy"]),
                                              _lib.ptr(buf["ck_p"]), _lib.ptr(buf["pa_part"]), _lib.ptr(buf["du"])), "pa bwd")
             du = buf["du"]
+    mark("dpd_bwd")
     _lib.check(lib.odpd_backbone_bwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(du),
                                      _lib.ptr(buf["ck_d"]), _lib.ptr(part), None), "dpd bwd")
+    mark("reduce_clip_optimiser")
     _lib.check(lib.odpd_reduce_partials(st, part.shape[0], dpd.n_flat, _lib.ptr(part), _lib.ptr(opt.grad), 0), "reduce")
     # loss scalar travels with the gradient (column P) so that one all-reduce covers both:
     # grad[P] = sum of errors of this rank = mean * count
@@ -489,6 +506,7 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count):
     opt.allreduce_grad()
     loss = opt.grad[dpd.n_flat] / count
     opt.apply(grad_clip_val)
+    mark()
     return loss
 
 
