@@ -80,11 +80,9 @@ class CoreModel(nn.Module):
             if hidden_size <= BJ.MAX_HIDDEN:
                 self.backbone = B.BOJANET(hidden_size=hidden_size, output_size=2, bias=True)
             else:
-                # hidden 17, 18 (beyond 18 the reference's own forward fails): the torch restatement through ATen, said aloud
-                import warnings
-                warnings.warn(f"opendpd_amd: backbone 'bojanet' with hidden_size={hidden_size} is outside the HIP kernel's envelope "
-                              f"(hidden <= {BJ.MAX_HIDDEN}): running the ATen restatement (backbones/extras.py)", stacklevel=2)
-                self.backbone = X.BOJANET(hidden_size=hidden_size, output_size=2, bias=True)
+                # hidden 17, 18 (beyond 18 the reference's own forward fails, bojanet.py:41-53): outside the kernel's one unit tile
+                raise NotImplementedError(f"bojanet: the HIP kernel covers hidden_size <= {BJ.MAX_HIDDEN} (csrc/bojanet_s16.hip); "
+                                          f"hidden_size={hidden_size} is not implemented")
         elif backbone_type == "deltajanet":
             self.backbone = B.DeltaJANET(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers, thx=thx,
                                          thh=thh, bias=True)

@@ -172,15 +172,11 @@ def test_cascade_roles():
         assert rel_err(opt.grad[:-4].cpu().numpy(), gd) < GRAD_TOL, (dpd_bb, pa_bb)
 
 
-def test_outside_the_envelope_runs_the_restatement():
-    """hidden 17, 18: the torch restatement, announced (beyond 18 the reference's own forward cannot run)"""
+def test_outside_the_envelope_is_refused():
+    """hidden 17, 18 (beyond 18 the reference's own forward cannot run): no kernel, no ATen stand-in"""
     from opendpd_amd import CoreModel
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        net = CoreModel(2, 18, 1, "bojanet").cuda()
-    assert not net.backbone.native and any("envelope" in str(i.message) for i in w)
-    y = net(torch.randn(3, 20, 2, device="cuda") * 0.3)
-    assert y.shape == (3, 20, 2) and bool(torch.isfinite(y).all())
+    with pytest.raises(NotImplementedError):
+        CoreModel(2, 18, 1, "bojanet")
 
 
 def test_frames_shorter_than_the_window_are_refused():
