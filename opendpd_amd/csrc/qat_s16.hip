@@ -561,7 +561,8 @@ __device__ __forceinline__ void head_fwd(TabPtr tl, const QK& k, const f32x4 (&h
 }
 
 template <int MK>
-__device__ __forceinline__ void q16_stage_x(float2* lds, const float* g, int b0, int B, int T, int t0, int lane) {
+__device__ __forceinline__ void q16_stage_x(float2* lds, const float* g, int b0, int B, int T, int t0, int lane, const long long* fidx = nullptr,
+                                            int fstride = 0) {
     using K = Kind<MK>;
     const float2* g2 = reinterpret_cast<const float2*>(g);
     constexpr int PER = kChunk + 2 * K::HALO, TOT = 16 * PER, N = (TOT + 63) / 64;
@@ -571,7 +572,7 @@ __device__ __forceinline__ void q16_stage_x(float2* lds, const float* g, int b0,
         if (e < TOT) {
             const int m = e / PER, pos = e % PER, tg = t0 - K::HALO + pos;
             float2 v = make_float2(0.0f, 0.0f);          // outside the frame: the conv's zero padding
-            if (tg >= 0 && tg < T) v = (b0 + m < B) ? g2[(size_t)(b0 + m) * T + tg] : make_float2(0.5f, 0.5f);
+            if (tg >= 0 && tg < T) v = (b0 + m < B) ? g2[(fidx ? (size_t)fidx[b0 + m] * fstride : (size_t)(b0 + m) * T) + tg] : make_float2(0.5f, 0.5f);
             else if (!K::TRES) v = make_float2(0.5f, 0.5f);
             lds[m * K::XSTRIDE + pos] = v;
         }
@@ -659,14 +660,14 @@ __global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
         const int b0 = grp * 16;
         const bool valid = b0 + n < a.B;
         float4* ck = a.ckpt ? reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * T::kCk * 64 + lane : nullptr;
-        const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[(size_t)(b0 + n) * a.T] : make_float2(0.5f, 0.5f);
+        const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[a.frame_idx ? (size_t)a.frame_idx[b0 + n] * a.frame_stride : (size_t)(b0 + n) * a.T] : make_float2(0.5f, 0.5f);
         StateD<NT> st;
         init_state<NT>(st);
         float zxs = 0.0f, zhs = 0.0f;
         for (int t0 = 0; t0 < a.T; t0 += kChunk) {
             const int len = min(kChunk, a.T - t0);
             wave_lds_fence();
-            q16_stage_x<MK>(xs, a.x, b0, a.B, a.T, t0, lane);
+            q16_stage_x<MK>(xs, a.x, b0, a.B, a.T, t0, lane, a.frame_idx, a.frame_stride);
             wave_lds_fence();
             for (int tt = 0; tt < len; ++tt) {
                 const float2 xv = xr[tt];
@@ -685,17 +686,19 @@ __global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
                     SaveS<NT> sv;
                     std_cell<MK, NT, LUT, false>(tlo, qs, k, lutq, fqk, st.h, sv);
                 }
-                HeadOut<MK, NT> ho;
-                float y0, y1;
-                head_fwd<MK, NT, false>(tlo, k, st.h, fs, ho, y0, y1);
-                y0 = __builtin_fmaf(y0, k.So, sc.bout[0]); y1 = __builtin_fmaf(y1, k.So, sc.bout[1]);
-                if (eval_mode) { y0 = qapply(y0, qs.out); y1 = qapply(y1, qs.out); }   // fc_out's 16-bit out_quantizer (quant_layers.py:77-80)
-                if constexpr (K::TRES) {
-                    float s1[3], s2[2];
-                    q16_tcn<MK>(sc, xr[tt - kHalo], xv, xr[tt + kHalo], s1, s2);
-                    y0 += hardswishf_(s2[0]); y1 += hardswishf_(s2[1]);
+                if (a.y != nullptr) {      // (the fused train step's forward launch wants the checkpoints only: no head)
+                    HeadOut<MK, NT> ho;
+                    float y0, y1;
+                    head_fwd<MK, NT, false>(tlo, k, st.h, fs, ho, y0, y1);
+                    y0 = __builtin_fmaf(y0, k.So, sc.bout[0]); y1 = __builtin_fmaf(y1, k.So, sc.bout[1]);
+                    if (eval_mode) { y0 = qapply(y0, qs.out); y1 = qapply(y1, qs.out); }   // fc_out's 16-bit out_quantizer (quant_layers.py:77-80)
+                    if constexpr (K::TRES) {
+                        float s1[3], s2[2];
+                        q16_tcn<MK>(sc, xr[tt - kHalo], xv, xr[tt + kHalo], s1, s2);
+                        y0 += hardswishf_(s2[0]); y1 += hardswishf_(s2[1]);
+                    }
+                    if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
                 }
-                if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
                 const int t1 = t0 + tt + 1;
                 if (ck != nullptr && (t1 % S) == 0 && t1 < a.T) {
                     float4* c = ck + (size_t)(t1 / S) * T::kCk * 64;
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
                 }
             }
             wave_lds_fence();
-            stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+            if (a.y != nullptr) stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);      // (the fused train step needs the checkpoints only)
         }
         if (valid) { zx += zxs; zh += zhs; }
     }
@@ -830,10 +833,14 @@ __device__ __forceinline__ void head_bwd(TabPtr tl, Grad<MK, NT>& G, const HeadO
 }
 
 // weight-gradient MFMAs of one step: dW_x[g] += d_x[g]^T (x) fslot, dW_h[g] += d_h[g]^T (x) hq, through the transpose tiles
-// (d_x = d_h for r, z; for the n gate d_x[2] = gate gradient, d_h[2] = gradient of the state-side term)
-template <int MK, int NT>
+// (d_x = d_h for r, z; for the n gate d_x[2] = gate gradient, d_h[2] = gradient of the state-side term).
+// `fcol` >= 0 (one unit tile, hidden + F + 1 <= 16): the feature slots ride in the padded unit columns fcol .. fcol + F of the hq tile,
+// so ONE product per gradient row covers both weight blocks — r and z need no input-side MFMAs at all (their tih stays 0 and
+// write-out reads those columns of thh), the n gate multiplies its two different gradients with the same tile: 16 MFMAs instead of 24.
+template <int MK, int NT, bool MERGE>
 __device__ __forceinline__ void wgrad_tiles(Grad<MK, NT>& G, float* tiles, int n, int q, const f32x4 (&dr)[NT], const f32x4 (&dz)[NT],
                                             const f32x4 (&dn)[NT], const f32x4 (&dnh)[NT], const f32x4 (&hq)[NT], float f0, float f1) {
+    constexpr int fcol = 16 - (Kind<MK>::F + 1);
     auto tile = [tiles](int qty, int kt) { return tiles + (qty * NT + kt) * kTileFloats; };   // 0 dr 1 dz 2 dn 3 dnh 4 hq
     float* t_f = tiles + 5 * NT * kTileFloats;
     wave_lds_fence();
@@ -842,13 +849,32 @@ __device__ __forceinline__ void wgrad_tiles(Grad<MK, NT>& G, float* tiles, int n
         tile_put(tile(0, kt), n, q, dr[kt]); tile_put(tile(1, kt), n, q, dz[kt]); tile_put(tile(2, kt), n, q, dn[kt]);
         tile_put(tile(3, kt), n, q, dnh[kt]); tile_put(tile(4, kt), n, q, hq[kt]);
     }
-    t_f[n * kTilePitch + q] = f0;
-    t_f[n * kTilePitch + 4 + q] = f1;
+    if constexpr (MERGE) {          // (after the float4 stores of the same wave: LDS operations of a wave complete in order)
+        float* th = tile(4, 0);
+        if (fcol + q < 16) th[n * kTilePitch + fcol + q] = f0;
+        if (fcol + 4 + q < 16) th[n * kTilePitch + fcol + 4 + q] = f1;
+    } else {
+        t_f[n * kTilePitch + q] = f0;
+        t_f[n * kTilePitch + 4 + q] = f1;
+    }
     wave_lds_fence();
-    float fT[4], hT[NT][4];
-    tile_get(t_f, n, q, fT);
+    float hT[NT][4];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) tile_get(tile(4, kt), n, q, hT[kt]);
+    if constexpr (MERGE) {
+        float rT[4], zT[4], nT[4], gT[4];
+        tile_get(tile(0, 0), n, q, rT); tile_get(tile(1, 0), n, q, zT);
+        tile_get(tile(2, 0), n, q, nT); tile_get(tile(3, 0), n, q, gT);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            G.thh[0][0][0] = mfma4(rT[c], hT[0][c], G.thh[0][0][0]);
+            G.thh[1][0][0] = mfma4(zT[c], hT[0][c], G.thh[1][0][0]);
+            G.thh[2][0][0] = mfma4(gT[c], hT[0][c], G.thh[2][0][0]);
+            G.tih[2][0] = mfma4(nT[c], hT[0][c], G.tih[2][0]);
+        }
+    } else {
+    float fT[4];
+    tile_get(t_f, n, q, fT);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         float rT[4], zT[4], nT[4], gT[4];
@@ -867,7 +893,12 @@ __device__ __forceinline__ void wgrad_tiles(Grad<MK, NT>& G, float* tiles, int n
             }
         }
     }
+    }
 }
+// the feature slots can share the hq tile when one unit tile leaves F + 1 padded columns: hidden + F + 1 <= 16 (a launch-time choice
+// of the kernel instantiation)
+template <int MK>
+__host__ __device__ constexpr int merge_max_hidden() { return 16 - (Kind<MK>::F + 1); }
 
 // dL/d(lane's feature slots) -> dL/dI, dL/dQ of the sample (summed over the sequence's four lanes); TRES: (nI, nQ) = the share of
 // sample t + 1 (features I_next, Q_next)
@@ -890,11 +921,12 @@ __device__ __forceinline__ void slots_bwd(float2 xv, const float (&oh)[4], const
     dI = quad_sum(dI); dQ = quad_sum(dQ);
 }
 
-template <int MK, int NT, bool LUT, bool FULL, bool DX>
+template <int MK, int NT, bool LUT, bool FULL, bool DX, bool LOSS, bool MERGE>
 __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, const QSc& qs, const QK& k, const float4* lutq, const float* thr,
                                               int Ksig, const Scalars<MK>& sc, const float (&oh)[4], Grad<MK, NT>& G, const float2* xr,
                                               const float2* dys, float2* dxs, float* tiles, float2 x0, int n, int q, int tglob, int tloc,
-                                              int nstep, int chunk_len, float* dxrow, StateD<NT> st, Carry<NT>& C) {
+                                              int nstep, int chunk_len, float* dxrow, StateD<NT> st, Carry<NT>& C, const S16Loss& lossc,
+                                              float& loss_acc) {
     using T = QT<MK, NT>;
     using K = Kind<MK>;
     constexpr int S = T::S, NCH = K::NCH;
@@ -940,12 +972,29 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
     for (int si = S - 1; si >= 0; --si) {
         if (FULL || si < nstep) {
             const int tt = tloc + si;
-            const float2 dyv = dys[n * kChunkPad + tt];
+            float2 dyv = dys[n * kChunkPad + tt];            // LOSS: the staged TARGET, turned into dL/dy below
             const float2 xv = xr[tt];
             float2 xn = make_float2(0.f, 0.f);
             if constexpr (K::TRES) xn = (tglob + si + 1 < a.T) ? xr[tt + 1] : x0;
             float fs[NCH];
             q16_slots<MK>(xv, xn, oh, fs);
+            // head: recomputed from the step's new state
+            HeadOut<MK, NT> ho;
+            {
+                float y0, y1;
+                head_fwd<MK, NT, true>(tl, k, sv[si].hnew, fs, ho, y0, y1);
+                if constexpr (LOSS) {      // train-mode output of the step, the loss and dL/dy on the fly (no y / dy round trip through HBM)
+                    y0 = __builtin_fmaf(y0, k.So, sc.bout[0]); y1 = __builtin_fmaf(y1, k.So, sc.bout[1]);
+                    if constexpr (K::TRES) {
+                        float s1[3], s2[2];
+                        q16_tcn<MK>(sc, xr[tt - kHalo], xv, xr[tt + kHalo], s1, s2);
+                        y0 += hardswishf_(s2[0]); y1 += hardswishf_(s2[1]);
+                    }
+                    float d0, d1;
+                    s16_loss(lossc, y0 - dyv.x, y1 - dyv.y, d0, d1, loss_acc);
+                    dyv = make_float2(d0, d1);
+                }
+            }
             if constexpr (K::TRES) {
                 if (q == 0) {    // TCN skip gradients: per-sequence work, one lane of the four
                     float s1[3], s2[2];
@@ -963,12 +1012,6 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                         G.dw1[c * 6 + 4] = __builtin_fmaf(d1, xc.y, G.dw1[c * 6 + 4]); G.dw1[c * 6 + 5] = __builtin_fmaf(d1, xq.y, G.dw1[c * 6 + 5]);
                     }
                 }
-            }
-            // head: recomputed from the step's new state
-            HeadOut<MK, NT> ho;
-            {
-                float y0, y1;
-                head_fwd<MK, NT, true>(tl, k, sv[si].hnew, fs, ho, y0, y1);
             }
             float dfs_head[2];
             head_bwd<MK, NT>(tl, G, ho, dyv, q, C.gh, dfs_head, tiles);
@@ -1019,7 +1062,7 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                         C.gxp[c] = (1.0f - m) * C.gxp[c] - m * g;
                     }
                 }
-                wgrad_tiles<MK, NT>(G, tiles, n, q, C.gr, C.gz, C.gn, C.gnh, v.qdhk, v.fqk[0], v.fqk[1]);
+                wgrad_tiles<MK, NT, MERGE>(G, tiles, n, q, C.gr, C.gz, C.gn, C.gnh, v.qdhk, v.fqk[0], v.fqk[1]);
             } else {
                 const SaveS<NT>& v = sv[si];
                 f32x4 dar[NT], daz[NT], dan[NT], dhtn[NT], dhdir[NT];
@@ -1058,7 +1101,7 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                     dfs[0] = ds[0] * px_s[si][0] + dfs_head[0];
                     dfs[1] = (NCH > 1 ? ds[1] * px_s[si][1] : 0.0f) + dfs_head[1];
                 }
-                wgrad_tiles<MK, NT>(G, tiles, n, q, dar, daz, dan, dhtn, v.hqk, fq_s[si][0] + one_c0, fq_s[si][1] + one_c1);
+                wgrad_tiles<MK, NT, MERGE>(G, tiles, n, q, dar, daz, dan, dhtn, v.hqk, fq_s[si][0] + one_c0, fq_s[si][1] + one_c1);
             }
             if constexpr (DX) {
                 float dI, dQ, nI, nQ;
@@ -1081,12 +1124,13 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
     }
 }
 
-template <int MK, int NT>
+template <int MK, int NT, bool MERGE>
 __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, const QatLayout& L, const WQ& wq, const QK& k, Grad<MK, NT>& G,
                                               int lane, int n, int q) {
     using K = Kind<MK>;
     constexpr int F = K::F;
     const int H = L.H;
+    constexpr int fcol = MERGE ? 16 - (F + 1) : -1;
     for (int i = lane; i < L.P + kLossCols; i += 64) prow[i] = 0.f;       // incl. the scale parameters: exact zero gradient
     wave_lds_fence();
 #pragma unroll
@@ -1097,9 +1141,11 @@ __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, cons
             if (u < H) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    const float tx = G.tih[g][mt][rr] * k.s_xa;
-                    if (n < F) { const int j = L.o_wx + (g * H + u) * F + n; prow[j] = tx * qpass(pl[j], wq.x); }
-                    if (!K::TRES && n == F) { prow[L.o_bx + g * H + u] = tx; if (g < 2) prow[L.o_bh + g * H + u] = tx; }
+                    // merged tiles (fcol >= 0): slot j of gate g sits in column fcol + j of thh[g] (r, z) / of tih[2] (n)
+                    const int fs = fcol >= 0 ? n - fcol : n;
+                    const float tx = ((fcol >= 0 && g < 2) ? G.thh[g][mt][0][rr] : G.tih[g][mt][rr]) * k.s_xa;
+                    if (fs >= 0 && fs < F) { const int j = L.o_wx + (g * H + u) * F + fs; prow[j] = tx * qpass(pl[j], wq.x); }
+                    if (!K::TRES && fs == F) { prow[L.o_bx + g * H + u] = tx; if (g < 2) prow[L.o_bh + g * H + u] = tx; }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         if (16 * nt + n < H) { const int j = L.o_wh + (g * H + u) * H + 16 * nt + n; prow[j] = G.thh[g][mt][nt][rr] * k.s_ha * qpass(pl[j], wq.h); }
@@ -1149,7 +1195,8 @@ __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, cons
 // two waves per SIMD (eight-wave workgroups, 256 registers) where the block state fits without spilling: the GRUCell kinds at one unit
 // tile without dL/dx; the others keep the whole 512-register file (one wave per SIMD)
 template <int MK, int NT, bool DX> struct BwdOcc { static constexpr bool W2 = NT == 1 && !Kind<MK>::TRES && !Kind<MK>::DGRU && !DX; };
-template <int MK, int NT, bool LUT, bool DX>
+// LOSS: `a.target` instead of `a.dy` — the step's output, the loss and dL/dy are formed inside (the fused train step's second launch)
+template <int MK, int NT, bool LUT, bool DX, bool LOSS = false, bool MERGE = false>
 __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
     using T = QT<MK, NT>;
     using K = Kind<MK>;
@@ -1192,12 +1239,14 @@ __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bw
     const float2* xr = xs + n * K::XSTRIDE + K::HALO;
     Grad<MK, NT> G;
     G.zero();
+    float loss_acc = 0.0f;
     const int nwaves = gridDim.x * nwb;
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
         const bool valid = b0 + n < a.B;
+        const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, valid ? a.inv_count : 0.0f, valid && q == 0);
         const float4* ck = reinterpret_cast<const float4*>(a.ckpt) + (size_t)grp * a.nck * T::kCk * 64 + lane;
-        const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[(size_t)(b0 + n) * a.T] : make_float2(0.5f, 0.5f);
+        const float2 x0 = valid ? reinterpret_cast<const float2*>(a.x)[a.frame_idx ? (size_t)a.frame_idx[b0 + n] * a.frame_stride : (size_t)(b0 + n) * a.T] : make_float2(0.5f, 0.5f);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         Carry<NT> C;
 #pragma unroll
@@ -1218,8 +1267,8 @@ __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bw
                 wave_lds_fence();
                 const int len = min(kChunk, a.T - t0);
                 cur_len = len;
-                q16_stage_x<MK>(xs, a.x, b0, a.B, a.T, t0, lane);
-                stage_in<16>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                q16_stage_x<MK>(xs, a.x, b0, a.B, a.T, t0, lane, a.frame_idx, a.frame_stride);
+                stage_in<16>(dys, LOSS ? a.target : a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride);
                 wave_lds_fence();
                 cur_chunk = chunk;
             }
@@ -1241,8 +1290,8 @@ __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bw
                     st.xp[0] = xp.x; st.xp[1] = xp.y;
                 }
             }
-            if (nstep == S) q16_bwd_block<MK, NT, LUT, true, DX>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
-            else q16_bwd_block<MK, NT, LUT, false, DX>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+            if (nstep == S) q16_bwd_block<MK, NT, LUT, true, DX, LOSS, MERGE>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C, lossc, loss_acc);
+            else q16_bwd_block<MK, NT, LUT, false, DX, LOSS, MERGE>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C, lossc, loss_acc);
         }
         if constexpr (DX) {
             wave_lds_fence();
@@ -1259,7 +1308,13 @@ __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bw
     const int P4 = L.P + kLossCols;
     __syncthreads();
     float* rows = smem + pad4(L.P);
-    q16_write_row<MK, NT>(rows + wave * P4, pl, L, wq, k, G, lane, n, q);
+    q16_write_row<MK, NT, MERGE>(rows + wave * P4, pl, L, wq, k, G, lane, n, q);
+    if constexpr (LOSS) {      // column P of the row: the un-normalised loss sum of the wave's sequences
+        float ls = loss_acc;
+        for (int o = 32; o > 0; o >>= 1) ls += __shfl_down(ls, o);
+        wave_lds_fence();
+        if (lane == 0) rows[wave * P4 + L.P] = ls;
+    }
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * P4;
     for (int i = threadIdx.x; i < P4; i += blockDim.x) {
@@ -1356,6 +1411,9 @@ static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
     using T = QT<MK, NT>;
     const int P = qat_layout(MK, m->hidden).P;
     a.nck = (a.T + T::S - 1) / T::S;
+    // (MERGE = true instantiations of the backward — input-side weight gradients inside the hq tile's padded columns, hidden <=
+    // merge_max_hidden: 16 instead of 24 weight-gradient MFMAs per step — are not launched: at two waves per SIMD they spill ~200 B per
+    // lane and measured 1.011 -> 0.995 ms only (profiles/r03/README.md); the code path stays for a register-leaner backward)
     if (mode == 1) {
         const LaunchShape ls = shape<MK, NT>(m, a.ngroups, false, false, 8);
         const size_t lds = lds_bytes<MK, NT>(P, ls.waves, m->bits_a, LUT, false, false);
@@ -1364,6 +1422,24 @@ static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a, m->bits_w, m->bits_a, (m->flags & ODPD_FLAG_EVAL) ? 1 : 0);
         return (int)hipGetLastError();
+    }
+    if (mode == 0) {       // fused train step: forward (checkpoints only) + backward with the loss formed inside — two launches, no y / dy
+        if (!a.partials || !a.target || (!a.ckpt && a.nck > 1)) return ODPD_EINVAL;
+        SeqArgs f = a;
+        f.y = nullptr; f.stats = nullptr;
+        if (int e = launch<MK, NT, LUT>(st, m, f, 1)) return e;
+        LaunchShape ls = shape<MK, NT>(m, a.ngroups, true, false, BwdOcc<MK, NT, false>::W2 ? 8 : 4);
+        ls.grid = bwd_grid<MK, NT>(m, a.ngroups);
+        const size_t lds = lds_bytes<MK, NT>(P, ls.waves, m->bits_a, LUT, true, false);
+        if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+        SeqArgs b = a;
+        b.dx = nullptr;
+        auto go = [&](auto k) {
+            if (int e = allow_big_lds(k, lds)) return e;
+            hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, b, m->bits_w, m->bits_a);
+            return (int)hipGetLastError();
+        };
+        return go(qat16_bwd_kernel<MK, NT, LUT, false, true, false>);
     }
     if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
     if (!a.ckpt && a.nck > 1) return ODPD_EINVAL;
@@ -1422,7 +1498,7 @@ int qat_s16_rows(const odpd_model_t* m, int B) {
     default: return q16::rows_kind<q16::K_TRES>(m, ng);
     }
 }
-// mode 1 forward, 2 backward
+// mode 0 fused train step (a.ckpt = workspace of qat_s16_ckpt_floats, a.target, a.partials), 1 forward, 2 backward
 int qat_s16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int mode) {
     if (!q16::model_ok(m)) return ODPD_EUNSUPPORTED;
     SeqArgs a = a0;

@@ -416,7 +416,9 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     ws = opt.train_workspace(B, T, x.device)
     flat = bb.flat_params()
     st = _lib.stream_ptr()
-    if timing is not None:
+    if hasattr(bb, "sync_mode"):      # quantised models: train / eval mode of the module -> ODPD_FLAG_EVAL
+        bb.sync_mode()
+    if timing is not None and not isinstance(timing, list):
         timing[0].record()
     if framed:
         rc = lib.odpd_train_fwd_bwd_framed(st, C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], C.byref(x.desc), 0, B, count,
@@ -424,7 +426,7 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     else:
         rc = lib.odpd_train_fwd_bwd(st, C.byref(bb.desc), _lib.LOSS_IDS[loss_kind], B, T, count,
                                     _lib.ptr(flat), _lib.ptr(x), _lib.ptr(target), _lib.ptr(part), _lib.ptr(ws))
-    if timing is not None:
+    if timing is not None and not isinstance(timing, list):
         timing[1].record()
     if rc:
         _lib.check(rc, f"odpd_train_fwd_bwd[{bb.backbone_name}]")
