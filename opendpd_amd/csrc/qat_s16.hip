@@ -23,7 +23,7 @@
 // products, the summation order becomes visible at the level of one LSB — in the reference as well.)
 // Gates: for <= 8 activation bits sigmoid / tanh inputs on the add-quantiser grid are looked up in 2^bits-entry LDS tables
 // (evaluated in double at kernel start); the delta cell's sigmoids take the raw accumulators: their QUANTISED value is found
-// exactly from a table of the rounding boundaries logit((k - 1/2) s) around an fp32 first guess.  Wider grids: double per element.
+// exactly from a table of the rounding boundaries logit((k - 1/2) s) around an fp32 first guess.  Wider grids: ~2-ulp fp32 evaluations.
 // This file is compiled with FP contraction off: a fused multiply-add would change roundings the reference does not have.
 #include <type_traits>
 
@@ -211,6 +211,22 @@ __device__ __forceinline__ int sig_levels(const Quant& qsig) {      // K: quanti
     const float n = qsig.inv;                                      // 1 / s, an integer
     return (int)(n < qsig.qp ? n : qsig.qp);
 }
+// Gates of the wider grids (no table): fp32 evaluations good to ~2 ulp — the argument product x log2(e) in two pieces (its rounding
+// error would otherwise be amplified by |x|), v_exp_f32, one Newton step on v_rcp_f32.  On a 16-bit grid that leaves the rounded
+// result open only within ~4e-3 LSB of a rounding boundary — the same order as the reference's own fp32 sigmoid / tanh (torch's
+// vectorised kernels are 1-2 ulp off the real value too), so an evaluation in double (r01 - r03 first build: 2.4 x the step time)
+// bought no parity: agreement for W16A16 is to one LSB either way.
+__device__ __forceinline__ float sigmoid_acc(float x) {
+    const float c_hi = -1.4426950216293335f, c_lo = -1.925963033500259e-8f;
+    const float t_hi = x * c_hi, t_lo = __builtin_fmaf(x, c_hi, -t_hi) + x * c_lo;
+    float e = __builtin_amdgcn_exp2f(t_hi);
+    e = __builtin_fmaf(e, t_lo * 0.6931471805599453f, e);
+    const float d = 1.0f + e;
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return e < 3.0e38f ? r : 0.0f;            // (d = inf: the Newton step would form inf * 0)
+}
+__device__ __forceinline__ float tanh_acc(float x) { return __builtin_fmaf(2.0f, sigmoid_acc(2.0f * x), -1.0f); }
 __device__ __forceinline__ Gate sig_gate(float rf, const QSc& qs, const QK& k) {
     const float v = rf * qs.sig.inv, m = __builtin_amdgcn_fmed3f(v, qs.sig.qn, qs.sig.qp);
     Gate g;
@@ -260,12 +276,12 @@ __device__ __forceinline__ void fill_luts(float* lut, const QSc& qs, const QK& k
 template <bool LUT>
 __device__ __forceinline__ Gate sig_grid(float ak, const QSc& qs, const QK& k, const float4* lutq) {
     if constexpr (LUT) { const float2 e = *reinterpret_cast<const float2*>(&lutq[(int)ak]); Gate g; g.c = e.x; g.d = e.y; return g; }
-    else return sig_gate((float)(1.0 / (1.0 + exp(-(double)(ak * k.s_add)))), qs, k);
+    else return sig_gate(sigmoid_acc(ak * k.s_add), qs, k);
 }
 template <bool LUT>
 __device__ __forceinline__ Gate tanh_grid(float ak, const QSc& qs, const QK& k, const float4* lutq) {
     if constexpr (LUT) { const float2 e = *(reinterpret_cast<const float2*>(&lutq[(int)ak]) + 1); Gate g; g.c = e.x; g.d = e.y; return g; }
-    else return tanh_gate((float)tanh((double)(ak * k.s_add)), qs, k);
+    else return tanh_gate(tanh_acc(ak * k.s_add), qs, k);
 }
 // quantised sigmoid of an arbitrary float (the delta cell's accumulators): exact through the boundary table around an fp32 guess
 template <bool LUT>
@@ -280,7 +296,7 @@ __device__ __forceinline__ Gate sig_any(float x, const QSc& qs, const QK& k, con
         g.d = v <= qs.sig.qp ? rf * (1.0f - rf) : 0.0f;
         return g;
     } else {
-        return sig_gate((float)(1.0 / (1.0 + exp(-(double)x))), qs, k);
+        return sig_gate(sigmoid_acc(x), qs, k);
     }
 }
 
