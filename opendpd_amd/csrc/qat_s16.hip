@@ -124,7 +124,8 @@ template <int MK, int NT> struct QT {
     static constexpr int HID = WOUT + 2 * NT;             // mt*NT + kt          : q_w(fc_hid)[16mt+m][16kt+4q+e]   (dgru)
     static constexpr int BHID = HID + (K::DGRU ? NT * NT : 0);
     static constexpr int WOF = BHID + (K::DGRU ? NT : 0); // one group: q_w(fc_out)[0][H+q], [0][H+4+q], [1][H+q], [1][H+4+q]
-    static constexpr int NG_FWD = WOF + (K::DGRU ? 1 : 0);
+    static constexpr int I8W = WOF + (K::DGRU ? 1 : 0);   // NT == 1: two groups of int8-packed weights for the integer matrix pipe (see I8Ops)
+    static constexpr int NG_FWD = I8W + (NT == 1 ? 2 : 0);
     static constexpr int HHT = NG_FWD;                    // (g*NT + mt)*NT + kt : q_w(W_h)[g][16kt+4q+e][16mt+m]
     static constexpr int HIDT = HHT + 3 * NT * NT;        // mt*NT + kt          : q_w(fc_hid)[16kt+4q+e][16mt+m]
     static constexpr int NG_BWD = HIDT + (K::DGRU ? NT * NT : 0);
@@ -151,6 +152,23 @@ __device__ __forceinline__ float4 q16_entry(const float* pl, const QatLayout& L,
     constexpr int F = K::F;
     const int H = L.H;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (NT == 1 && (grp == T::I8W || grp == T::I8W + 1)) {
+        // v_mfma_i32_16x16x32_i8 A operands of lane (m, q): byte j <-> K index 8 q + j.  h part: bytes 0..3 = k_w(W_h)[g][m][4q+j];
+        // x part: bytes 4, 5 = k_w(W_x)[g][m][slot 4c+q], c = 0, 1.  Entry = {wh_r, wx_r, wh_z, wx_z} | {wh_n, wx_n, 0, 0} as bit patterns.
+        auto byte_of = [](float kf) { return (unsigned)((int)kf) & 0xffu; };
+        auto wh = [&](int g) {
+            unsigned w = 0;
+            for (int j = 0; j < 4; ++j) { const int u = 4 * q + j; if (m < H && u < H) w |= byte_of(kq(pl[L.o_wh + (g * H + m) * H + u], wq.h)) << (8 * j); }
+            return w;
+        };
+        auto wx = [&](int g) {
+            unsigned w = 0;
+            for (int c = 0; c < K::NCH; ++c) { const int slot = 4 * c + q; if (m < H && slot < F) w |= byte_of(kq(pl[L.o_wx + (g * H + m) * F + slot], wq.x)) << (8 * c); }
+            return w;
+        };
+        if (grp == T::I8W) return make_float4(__uint_as_float(wh(0)), __uint_as_float(wx(0)), __uint_as_float(wh(1)), __uint_as_float(wx(1)));
+        return make_float4(__uint_as_float(wh(2)), __uint_as_float(wx(2)), 0.0f, 0.0f);
+    }
     if (K::DGRU && grp == T::WOF) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -319,6 +337,35 @@ __device__ __forceinline__ void q16_slots(float2 xv, float2 xn, const float (&oh
     }
 }
 
+// ---- integer matrix pipe (W8A8, one unit tile) -------------------------------------------------------------------------
+// The mat-vecs of the forward / recompute run on v_mfma_i32_16x16x32_i8 when weights AND activations are 8-bit grids: K = 32 covers the
+// lane quad's 4 own units (bytes 0..3 of the quad's 8-byte K group) and its feature slots (bytes 4, 5); lane (n, q) feeds its own packed
+// k_a as the B operand — no cross-lane movement, as in the fp32 mapping — and the A operand holds k_w of EITHER the h part OR the x part
+// (the two sums are needed separately: each gets its own scale and fp32 bias).  6 instructions of 16 cycles on the matrix pipe instead of
+// 15 f32 MFMAs of 32 cycles on the FMA lanes; int32 accumulation is exact.  (tools/probes/mfma_i32_16x16x32_i8_layout.hip: layout, cost.)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr float kRneMagic = 12582912.0f;          // 1.5 x 2^23: (v + magic) rounds v to the nearest-even integer, which sits in the low mantissa bits
+__device__ __forceinline__ int i8_bits(float clamped) { return __builtin_bit_cast(int, clamped + kRneMagic); }       // low byte = int8 of rint(v)
+__device__ __forceinline__ int i8_pack4(int b0, int b1, int b2, int b3) {
+    const unsigned lo = __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u), hi = __builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x04000c0cu);
+    return (int)(lo | hi);
+}
+__device__ __forceinline__ long i8_operand(int lo, int hi) { return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo); }
+// xs[g], hs[g] (g = r, z, n) of the lane's four units from the packed activations: bh = its 4 own units, bx = its (<= 2) feature slots
+__device__ __forceinline__ void i8_matvecs(TabPtr tl, int base, int bh, int bx, f32x4 (&xs)[3], f32x4 (&hs)[3]) {
+    const float4 w0 = tab_ld(tl, base * 64), w1 = tab_ld(tl, (base + 1) * 64);
+    const int wh[3] = {__builtin_bit_cast(int, w0.x), __builtin_bit_cast(int, w0.z), __builtin_bit_cast(int, w1.x)};
+    const int wx[3] = {__builtin_bit_cast(int, w0.y), __builtin_bit_cast(int, w0.w), __builtin_bit_cast(int, w1.y)};
+    const long b = i8_operand(bh, bx);
+    const i32x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const i32x4 dh = __builtin_amdgcn_mfma_i32_16x16x32_i8(i8_operand(wh[g], 0), b, z4, 0, 0, 0);
+        const i32x4 dx = __builtin_amdgcn_mfma_i32_16x16x32_i8(i8_operand(0, wx[g]), b, z4, 0, 0, 0);
+        ODPD_EACH4 { hs[g][i] = (float)dh[i]; xs[g][i] = (float)dx[i]; }
+    }
+}
+
 // ---- GRUCell step ----------------------------------------------------------------------------------------------------
 // what the backward of one step needs, with the straight-through masks already multiplied into the factors they gate:
 //   c2 = p_ah p_m2, c3 = p_ah p_m3, An = p_n tanh' p_an, Az = p_z sig' p_az, B1 = p_m1 r, B2A = p_m1 h_n (p_r sig' p_ar),
@@ -330,16 +377,31 @@ __device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const QK& k, 
                                          f32x4 (&h)[NT], SaveS<NT>& sv) {
     using T = QT<MK, NT>;
     constexpr int NCH = Kind<MK>::NCH;
+    constexpr bool I8 = LUT && NT == 1;       // 8-bit weights and activations, one unit tile: the integer matrix pipe
     f32x4 hqk[NT];
+    int hb[4];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
         ODPD_EACH4 {
             const float v = h[kt][i] * k.inv_ha, m = gm(v, k);
-            hqk[kt][i] = rintf(m);
+            if constexpr (I8) {
+                hb[i] = i8_bits(m);
+                if constexpr (SAVE) hqk[kt][i] = __builtin_bit_cast(float, hb[i]) - kRneMagic;
+            } else {
+                hqk[kt][i] = rintf(m);
+            }
             if constexpr (SAVE) { sv.hqk[kt][i] = hqk[kt][i]; sv.pph[kt][i] = m == v ? k.s_hw : 0.0f; }
         }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 xs[3][NT], hs[3][NT];
+    if constexpr (I8) {
+        f32x4 x1[3], h1[3];
+        const int bx = NCH > 1 ? (int)__builtin_amdgcn_perm((unsigned)i8_bits(fqk[NCH - 1]), (unsigned)i8_bits(fqk[0]), 0x0c0c0400u)
+                               : (i8_bits(fqk[0]) & 0xff);
+        i8_matvecs(tl, T::I8W, i8_pack4(hb[0], hb[1], hb[2], hb[3]), bx, x1, h1);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { xs[g][0] = x1[g]; hs[g][0] = h1[g]; }
+    } else {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
 #pragma unroll
@@ -350,6 +412,7 @@ __device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const QK& k, 
             hs[g][mt] = z4;
         }
         s16n_matvec<NT>(tl, T::HH + g * NT * NT, hqk, hs[g]);
+    }
     }
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
@@ -415,7 +478,9 @@ __device__ __forceinline__ void delta_cell(TabPtr tl, const QSc& qs, const QK& k
         fqk[c] = rintf(m);
         if constexpr (SAVE) { sv.fqk[c] = fqk[c]; sv.mx[c] = keep ? 1.0f : 0.0f; sv.px[c] = m == v ? k.s_xw : 0.0f; }
     }
+    constexpr bool I8 = LUT && NT == 1;       // 8-bit weights and activations, one unit tile: the integer matrix pipe
     f32x4 qdhk[NT];
+    int hb[4];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
         ODPD_EACH4 {
@@ -425,11 +490,23 @@ __device__ __forceinline__ void delta_cell(TabPtr tl, const QSc& qs, const QK& k
             st.hp[kt][i] = (__builtin_fabsf(d) >= thh) ? st.h[kt][i] : st.hp[kt][i];
             zh += (unit_ok[kt][i] != 0.0f && dhm == 0.0f) ? 1.0f : 0.0f;
             const float v = dhm * k.inv_ha, m = gm(v, k);
-            qdhk[kt][i] = rintf(m);
+            if constexpr (I8) {
+                hb[i] = i8_bits(m);
+                if constexpr (SAVE) qdhk[kt][i] = __builtin_bit_cast(float, hb[i]) - kRneMagic;
+            } else {
+                qdhk[kt][i] = rintf(m);
+            }
             if constexpr (SAVE) { sv.qdhk[kt][i] = qdhk[kt][i]; sv.mh[kt][i] = keep ? 1.0f : 0.0f; sv.pph[kt][i] = m == v ? k.s_hw : 0.0f; }
         }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 xs[3][NT], hs[3][NT];
+    if constexpr (I8) {
+        f32x4 x1[3], h1[3];
+        const int bx = (int)__builtin_amdgcn_perm((unsigned)i8_bits(fqk[1]), (unsigned)i8_bits(fqk[0]), 0x0c0c0400u);
+        i8_matvecs(tl, T::I8W, i8_pack4(hb[0], hb[1], hb[2], hb[3]), bx, x1, h1);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { xs[g][0] = x1[g]; hs[g][0] = h1[g]; }
+    } else {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
 #pragma unroll
@@ -440,6 +517,7 @@ __device__ __forceinline__ void delta_cell(TabPtr tl, const QSc& qs, const QK& k
             hs[g][mt] = z4;
         }
         s16n_matvec<NT>(tl, T::HH + g * NT * NT, qdhk, hs[g]);
+    }
     }
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt)
@@ -1409,7 +1487,7 @@ static size_t lds_bytes(int P, int waves, int bits_a, bool lut, bool bwd, bool d
 template <int MK, int NT>
 static LaunchShape shape(const odpd_model_t* m, int ngroups, bool bwd, bool dx, int max_waves) {
     const int P = qat_layout(MK, m->hidden).P, cus = device_cus();
-    const bool lut = m->bits_a <= 8;
+    const bool lut = m->bits_a <= 8 && m->bits_w <= 8;
     LaunchShape ls;
     ls.waves = 1;
     while (ls.waves < max_waves && ngroups > ls.waves * cus) ls.waves *= 2;
@@ -1482,7 +1560,9 @@ static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
 template <int MK>
 static int launch_kind(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int mode) {
     const int nt = tiles_of(m->hidden);
-    const bool lut = m->bits_a <= 8;
+    // the table / integer-pipe build needs 8-bit activations AND (for the int8 operands of one unit tile) 8-bit weights; any other
+    // combination runs the table-free build (fp32 gates, fp32 MFMAs), which is exact for every grid width
+    const bool lut = m->bits_a <= 8 && m->bits_w <= 8;
     if (nt == 1) return lut ? launch<MK, 1, true>(st, m, a, mode) : launch<MK, 1, false>(st, m, a, mode);
     if (nt == 2) return lut ? launch<MK, 2, true>(st, m, a, mode) : launch<MK, 2, false>(st, m, a, mode);
     return ODPD_EUNSUPPORTED;
