@@ -13,6 +13,9 @@
 
 namespace odpd {
 
+// BPTT checkpoint stride of an instantiation: the VDLSTM variant at one unit tile keeps a block of 2 steps (its 4-step block spilled 68
+// registers under the 256-register cap of two waves per SIMD), the others kCkptStride
+__host__ __device__ constexpr int l16_stride(bool vd, int nt) { return (vd && nt == 1) ? 2 : kCkptStride; }
 template <bool VD, int NT>
 struct L16 {
     static constexpr int F = VD ? 4 : 2, NCH = (F + 4) / 4;
@@ -145,7 +148,7 @@ __device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const fl
                                           bool last_blk, const f32x4 (&h0)[NT], const f32x4 (&c0)[NT], f32x4 (&dh)[NT],
                                           f32x4 (&dc)[NT], float (&hTn)[NT][4], float& loss_acc) {
     using T = L16<VD, NT>;
-    constexpr int NCH = T::NCH, S = kCkptStride;
+    constexpr int NCH = T::NCH, S = l16_stride(VD, NT);
     f32x4 h[NT], c[NT], hp_s[S][NT], cp_s[S][NT], i_s[S][NT], f_s[S][NT], g_s[S][NT], o_s[S][NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) { h[kt] = h0[kt]; c[kt] = c0[kt]; }
@@ -400,7 +403,7 @@ __device__ __forceinline__ void l16_stage_halo(float2* lds, const float* g, int 
 template <bool VD, int NT>
 __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void lstm16_train_kernel(SeqArgs a) {
     using T = L16<VD, NT>;
-    constexpr int NCH = T::NCH, S = kCkptStride;
+    constexpr int NCH = T::NCH, S = l16_stride(VD, NT);
     constexpr int kWave = T::kXFloats + 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
@@ -541,7 +544,8 @@ int lstm_s16_rows(const odpd_model_t* m, int B) {
     return l16_shape((B + 15) / 16, (m->hidden + 15) / 16).grid;
 }
 int64_t lstm_s16_workspace_floats(const odpd_model_t* m, int B, int T) {
-    return (int64_t)((B + 15) / 16) * num_ckpt(T) * 2 * ((m->hidden + 15) / 16) * 256;
+    const int nt = (m->hidden + 15) / 16, S = l16_stride(m->backbone == ODPD_VDLSTM, nt);
+    return (int64_t)((B + 15) / 16) * ((T + S - 1) / S) * 2 * nt * 256;
 }
 template <bool VD, int NT>
 static int launch_l16(hipStream_t st, const SeqArgs& a, int P) {
@@ -565,6 +569,8 @@ int lstm_s16_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
     SeqArgs a = a0;
     a.ngroups = (a.B + 15) / 16;
     const int P = lstm_layout(m->hidden, vd).P, nt = (m->hidden + 15) / 16;
+    const int S = l16_stride(vd, nt);
+    a.nck = (a.T + S - 1) / S;
     if (nt == 1) return vd ? launch_l16<true, 1>(st, a, P) : launch_l16<false, 1>(st, a, P);
     if (nt == 2) return vd ? launch_l16<true, 2>(st, a, P) : launch_l16<false, 2>(st, a, P);
     return ODPD_EUNSUPPORTED;
