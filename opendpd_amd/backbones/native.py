@@ -66,7 +66,7 @@ class _BackboneFn(torch.autograd.Function):
     """y = backbone(x) through odpd_backbone_fwd / odpd_backbone_bwd."""
 
     @staticmethod
-    def forward(ctx, x, mod, *params):
+    def forward(ctx, x, mod, grad_mode, *params):
         lib = _lib.load()
         if not x.is_cuda:
             raise RuntimeError("opendpd_amd backbones run on a HIP device only (no CPU fallback)")
@@ -75,7 +75,7 @@ class _BackboneFn(torch.autograd.Function):
         flat = mod.flat_params()
         # (needs_input_grad looks at requires_grad only: under torch.no_grad() — net_eval, run_dpd — nothing will call backward, so no
         # checkpoints are asked for and the kernels may take their inference path)
-        need_grad = mod._grad_mode and any(ctx.needs_input_grad)      # (autograd switches grad mode off inside forward: the module records it)
+        need_grad = grad_mode and any(ctx.needs_input_grad)      # (autograd switches grad mode off inside forward: the caller passes it)
         if mod.dx_needs_flag:
             # delta backbones: dL/dx lives in the 16-sequences-per-wave kernels only; the flag routes forward, checkpoint sizing
             # and backward of THIS call to them (include/opendpd_hip.h: ODPD_FLAG_NEED_DX)
@@ -103,7 +103,7 @@ class _BackboneFn(torch.autograd.Function):
         B, T = x.shape[0], x.shape[1]
         dy = dy.contiguous().float()
         need_dx = ctx.needs_input_grad[0]
-        need_w = any(ctx.needs_input_grad[2:])
+        need_w = any(ctx.needs_input_grad[3:])
         P = mod.n_flat
         partials = grad = dx = None
         mod.desc.flags = ctx.flags
@@ -114,21 +114,21 @@ class _BackboneFn(torch.autograd.Function):
         if need_dx:
             dx = torch.empty_like(x)
         if not (need_w or need_dx):
-            return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+            return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
         rc = lib.odpd_backbone_bwd(_lib.stream_ptr(), C.byref(mod.desc), B, T, _lib.ptr(flat), _lib.ptr(x),
                                    _lib.ptr(dy), _lib.ptr(ckpt) if ckpt.numel() else None, _lib.ptr(partials),
                                    _lib.ptr(dx))
         _lib.check(rc, f"odpd_backbone_bwd[{mod.backbone_name}]")
         if mod.dx_needs_flag:
             mod.desc.flags &= ~_lib.FLAG_NEED_DX       # per-call selection: nothing stale for the next user of the descriptor
-        gparams = (None,) * (len(ctx.needs_input_grad) - 2)
+        gparams = (None,) * (len(ctx.needs_input_grad) - 3)
         if need_w:
             grad = torch.empty(P + _lib.LOSS_COLS, dtype=torch.float32, device=x.device)
             rc = lib.odpd_reduce_partials(_lib.stream_ptr(), partials.shape[0], P, _lib.ptr(partials), _lib.ptr(grad), 0)
             _lib.check(rc, "odpd_reduce_partials")
             gparams = tuple(grad[o:o + n].view(shape) if need else None
-                            for (o, n, shape), need in zip(mod._slices, ctx.needs_input_grad[2:]))
-        return (dx, None) + gparams
+                            for (o, n, shape), need in zip(mod._slices, ctx.needs_input_grad[3:]))
+        return (dx, None, None) + gparams
 
 
 class NativeBackbone(nn.Module):
@@ -194,5 +194,4 @@ class NativeBackbone(nn.Module):
         return None
 
     def forward(self, x, h_0=None):
-        self._grad_mode = torch.is_grad_enabled()
-        return _BackboneFn.apply(x, self, *self.parameters())
+        return _BackboneFn.apply(x, self, torch.is_grad_enabled(), *self.parameters())

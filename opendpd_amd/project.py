@@ -223,6 +223,7 @@ class Project:
         fused = {"adamw": FusedAdamW, "adam": FusedAdam, "sgd": FusedSGD, "rmsprop": FusedRMSprop}
         if self.opt_type == "adabound":
             import adabound  # noqa: F401  — as the reference (project.py:284-286): a package it does not ship (ModuleNotFoundError there too)
+            raise NotImplementedError("--opt_type adabound: the reference builds adabound.AdaBound (project.py:284-286); there is no fused HIP step of that kind")
         if self.opt_type not in fused:
             raise RuntimeError("Please use a valid optimizer.")
         try:

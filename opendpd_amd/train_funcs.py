@@ -214,6 +214,13 @@ class FusedAdamW:
             # one byte per parameter, resident next to the parameters: the kernel skips those columns (no host sync, no extra launch)
             self.backbone.frozen_mask = frozen = frozen.to(device=flat.device, dtype=torch.uint8).contiguous()
         if self.kind != "adamw":            # project.py:274-297's other optimisers, with the hyper-parameters the reference builds them with
+            # (those hyper-parameters are constants of the kernel: an edited param_group other than `lr` would be ignored — say so)
+            fixed = {"adam": dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0), "sgd": dict(momentum=0.9, weight_decay=0.0),
+                     "rmsprop": dict(alpha=0.99, eps=1e-8, weight_decay=0.0)}[self.kind]
+            for key, val in fixed.items():
+                if key in g and g[key] != val:
+                    raise NotImplementedError(f"Fused{self.kind.upper()}: param_groups[0]['{key}'] = {g[key]!r}, but the fused step is built with the "
+                                              f"reference's {key} = {val!r} (project.py:274-297); only 'lr' can be changed")
             rc = lib.odpd_clip_optim_step(stream, _lib.OPTIMIZER_IDS[self.kind], self.backbone.n_flat, _lib.ptr(flat), _lib.ptr(self.grad),
                                           _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.step_count, float(g["lr"]),
                                           float(max_norm or 0.0), _lib.ptr(self.norm), _lib.ptr(frozen) if frozen is not None else None)

@@ -79,9 +79,18 @@ def main():
             P.pretrained_model = pth
             fnet = float_model(0)
             before = {k: v.clone() for k, v in fnet.state_dict().items()}
+            torch.manual_seed(321)
             out = quant.get_quant_model(P, fnet)
+            d[f"rng_after_refused_{kind}"] = torch.rand(4).numpy()      # the surgery's RNG draws up to the failing load have happened
             same = out is fnet and all(torch.equal(before[k], v) for k, v in out.state_dict().items())
             outcomes[kind] = "float model returned unchanged" if same else "other"
+        # an unreadable checkpoint: torch.load raises inside the same try block
+        P.pretrained_model = os.path.join(tmp, "missing.pt")
+        fnet = float_model(0)
+        torch.manual_seed(321)
+        out = quant.get_quant_model(P, fnet)
+        outcomes["missing"] = "float model returned unchanged" if out is fnet else "other"
+        d["rng_after_refused_missing"] = torch.rand(4).numpy()
         d["nngru_keys"] = np.array(json.dumps(list(torch.load(nn_path).keys())))
     d["meta"] = np.array(json.dumps({"backbone": "qgru", "hidden": H, "bits": BITS, "outcomes": outcomes,
                                      "n_param": int(sum(p.numel() for p in q.parameters()))}))

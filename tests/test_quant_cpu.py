@@ -94,7 +94,7 @@ def test_pretrained_model_follows_the_reference_load_path(tmp_path, capsys):
     fx = Fixture("quant_pretrained_qgru_h10")
     H, bits = fx.meta["hidden"], fx.meta["bits"]
     assert fx.meta["outcomes"] == {"pygru": "quantised", "nngru": "float model returned unchanged",
-                                   "quant": "float model returned unchanged"}
+                                   "quant": "float model returned unchanged", "missing": "float model returned unchanged"}
 
     class P:
         quant = True
@@ -126,6 +126,17 @@ def test_pretrained_model_follows_the_reference_load_path(tmp_path, capsys):
         fnet = CoreModel(2, H, 1, "qgru")
         before = {k: v.clone() for k, v in fnet.state_dict().items()}
         capsys.readouterr()
+        torch.manual_seed(321)
         out = get_quant_model(P, fnet)
         assert out is fnet and "[WARN] Quantization setup failed" in capsys.readouterr().out
         assert all(torch.equal(before[k], v) for k, v in out.state_dict().items())
+        # the reference had already built (and re-initialised) the GRU of GRUCells when its strict load failed: same RNG state afterwards,
+        # i.e. the same DataLoader shuffle order in the train_dpd that follows
+        assert np.array_equal(torch.rand(4).numpy(), fx[f"rng_after_refused_{name}"]), name
+    # an unreadable file: warned about and refused the same way (torch.load raises inside the reference's try block)
+    P.pretrained_model = str(tmp_path / "missing.pt")
+    torch.manual_seed(0)
+    fnet = CoreModel(2, H, 1, "qgru")
+    torch.manual_seed(321)
+    assert get_quant_model(P, fnet) is fnet and "[WARN] Quantization setup failed" in capsys.readouterr().out
+    assert np.array_equal(torch.rand(4).numpy(), fx["rng_after_refused_missing"])
