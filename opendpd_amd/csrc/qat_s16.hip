@@ -1288,6 +1288,7 @@ __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, cons
 
 // two waves per SIMD (eight-wave workgroups, 256 registers) where the block state fits without spilling: the GRUCell kinds at one unit
 // tile without dL/dx; the others keep the whole 512-register file (one wave per SIMD)
+// (the dgru kind at two waves per SIMD spills 110 .. 170 B per lane and measured 1.46 -> 1.82 ms: it stays at one)
 template <int MK, int NT, bool DX> struct BwdOcc { static constexpr bool W2 = NT == 1 && !Kind<MK>::TRES && !Kind<MK>::DGRU && !DX; };
 // LOSS: `a.target` instead of `a.dy` — the step's output, the loss and dL/dy are formed inside (the fused train step's second launch)
 template <int MK, int NT, bool LUT, bool DX, bool LOSS = false, bool MERGE = false>

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""HIP-event time of every launch group of the train_dpd cascade step at the reference's batch sizes (latency regime).
+usage (GPU box): PYTHONPATH=. python tools/cascade_spans.py"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+import bench
+from opendpd_amd import CascadedModel, CoreModel
+from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+
+T = 200
+for name, dpd_kw, pa_kw, B in (("config 3: TRes-DeltaGRU15 -> frozen DGRU23", dict(hidden_size=15, backbone_type="deltagru_tcnskip", thx=0.01, thh=0.05), dict(hidden_size=23, backbone_type="dgru"), 64),
+                               ("default: GRU15 -> frozen GRU23", dict(hidden_size=15, backbone_type="gru"), dict(hidden_size=23, backbone_type="gru"), 256),
+                               ("DGRU13 -> frozen DGRU13", dict(hidden_size=13, backbone_type="dgru"), dict(hidden_size=13, backbone_type="dgru"), 256)):
+    torch.manual_seed(0)
+    casc = CascadedModel(dpd_model=CoreModel(2, num_layers=1, **dpd_kw), pa_model=CoreModel(2, num_layers=1, **pa_kw))
+    casc.freeze_pa_model()
+    casc = casc.cuda()
+    opt = FusedAdamW(casc, lr=1e-4)
+    x, _ = bench.synth_frames(B, T, seed=1, device=torch.device("cuda"))
+    t = x.clone()
+    for _ in range(5):
+        fused_train_step(opt, x, t, "l2", 200.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        fused_train_step(opt, x, t, "l2", 200.0)
+    e1.record()
+    torch.cuda.synchronize()
+    spans = bench.cascade_spans(opt, x, t, B * T * 2, n=20)
+    print(f"{name}, {B} x {T}: {e0.elapsed_time(e1) / 50:.3f} ms per step; launch groups (ms): " + ", ".join(f"{k} {v:.3f}" for k, v in spans.items()), flush=True)
