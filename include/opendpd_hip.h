@@ -153,6 +153,18 @@ int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss_kind, int 
                         const float* params, const float* u, const float* target, float* du, float* loss_rows,
                         float* workspace);
 
+/* The whole train_dpd step body — y = PA(DPD(x)) with the PA frozen, loss, dL/d(DPD parameters) — in ONE launch, for the reference's own
+ * batch sizes (64 .. 256 frames, train_funcs.py:28-48): the DPD and the PA of a frame run as the two waves of a workgroup and hand the
+ * frame over through LDS (csrc/gru_cascade.hip).  Served: float gru / dgru / qgru / qgru_amp1 DPD of hidden <= 16 in front of a float
+ * gru / dgru PA of hidden <= 32, batches whose frames are all resident at once (odpd_cascade_rows > 0); otherwise
+ * ODPD_EUNSUPPORTED: chain odpd_backbone_fwd, odpd_frozen_loss_dx, odpd_backbone_bwd.  `partials` is (rows, P_dpd + 4), column
+ * P_dpd = un-normalised loss partial sum; `frame_idx` (device, may be NULL) addresses x / target as windows of resident streams:
+ * frame b starts at sample frame_idx[b] * frame_stride. */
+int64_t odpd_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T);
+int odpd_cascade_fwd_bwd(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, int B, int T, int64_t count,
+                         const float* dpd_params, const float* pa_params, const float* x, const float* target,
+                         const int64_t* frame_idx, int frame_stride, float* partials);
+
 typedef struct odpd_frames {
     const float* x_stream;  /* (N,2) device: model input stream */
     const float* y_stream;  /* (N,2) device: target stream */

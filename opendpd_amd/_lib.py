@@ -13,7 +13,7 @@ LOSS_IDS = {"l2": 0, "l1": 1}
 FLAG_EVAL, FLAG_NEED_DX = 1, 2      # odpd_model_t.flags (include/opendpd_hip.h)
 LOSS_COLS = 4        # extra columns of a partials row (column P = loss partial sum)
 LOSS_WS = 1 + 256    # floats behind `loss_out` (result + per-block scratch)
-ABI_VERSION = 8      # odpd_abi_version() of the library these argument lists belong to
+ABI_VERSION = 9      # odpd_abi_version() of the library these argument lists belong to
 
 
 class ModelDesc(C.Structure):
@@ -50,6 +50,9 @@ _EXPORTS = {
     "odpd_frozen_loss_rows": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
     "odpd_frozen_loss_dx": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "odpd_cascade_rows": (C.c_int64, [C.POINTER(ModelDesc), C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "odpd_cascade_fwd_bwd": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "odpd_framed_train_supported": (C.c_int, [C.POINTER(ModelDesc)]),
     "odpd_framed_train_supported_shape": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
     "odpd_train_fwd_bwd_framed": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int64, C.c_int,

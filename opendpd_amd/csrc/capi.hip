@@ -86,7 +86,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 8; }   // 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
+extern "C" int odpd_abi_version(void) { return 9; }   // 9: + odpd_cascade_rows, odpd_cascade_fwd_bwd (train_dpd step body in one launch); 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
@@ -273,6 +273,24 @@ extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss
     a.params = params; a.x = u; a.target = target; a.dx = du; a.partials = loss_rows;
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.ckpt = workspace;
     return gru_family_lossdx((hipStream_t)stream, m, a);
+}
+
+extern "C" int64_t odpd_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T) {
+    if (!model_ok(dpd) || !model_ok(pa) || B <= 0 || T <= 0) return ODPD_EINVAL;
+    if (family_of(dpd) != FAM_GRU || family_of(pa) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    return gru_cascade_rows(dpd, pa, B, T);
+}
+extern "C" int odpd_cascade_fwd_bwd(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, int B, int T, int64_t count,
+                                    const float* dpd_params, const float* pa_params, const float* x, const float* target,
+                                    const int64_t* frame_idx, int frame_stride, float* partials) {
+    if (!model_ok(dpd) || !model_ok(pa) || !dpd_params || !pa_params || !x || !target || !partials || B <= 0 || T <= 0 || count <= 0)
+        return ODPD_EINVAL;
+    if (family_of(dpd) != FAM_GRU || family_of(pa) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    CascArgs a{};
+    a.dpd_params = dpd_params; a.pa_params = pa_params; a.x = x; a.target = target; a.partials = partials;
+    a.frame_idx = reinterpret_cast<const long long*>(frame_idx); a.frame_stride = frame_stride;
+    a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.B = B; a.T = T; a.Hd = dpd->hidden; a.Hp = pa->hidden;
+    return gru_cascade_train((hipStream_t)stream, dpd, pa, a);
 }
 
 namespace {

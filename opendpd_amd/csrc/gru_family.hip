@@ -26,48 +26,9 @@
 // frames, the evaluation segments): the four 16-lane rows of a wave take one gate each, only the recurrence stays in the step loop:
 //   gru_eval_kernel      forward (inference; CK: also the checkpoint-writing forward of the split train path)
 //   gru_gp_train_kernel  fused train step with the frame's BPTT state in LDS and the weight gradients as 4-block MFMAs
-#include "odpd_s16.h"
+#include "odpd_gru.h"
 
 namespace odpd {
-
-// -------------------------------------------------------------------------------------------------
-// LDS rotated-quad weight tables
-// -------------------------------------------------------------------------------------------------
-template <int R, bool DG>
-struct GruTabs {
-    static constexpr int kHH = 0;            // rows g*R + rb           : W_hg[o][16*blk + src]
-    static constexpr int kHHT = 3 * R;       // rows 3R + g*R + rb      : W_hg[16*blk + src][o]
-    static constexpr int kHID = 6 * R;       // rows 6R + rb            : fc_hid[o][16*blk + src]
-    static constexpr int kHIDT = 7 * R;      // rows 7R + rb            : fc_hid[16*blk + src][o]
-    static constexpr int kRows = DG ? 8 * R : 6 * R;
-    static constexpr int kFloats = kRows * 4 * 64 * 4;
-};
-
-// Cooperative fill (all waves of the block; ends with __syncthreads()).
-template <int R, bool DG, bool WITH_T>
-__device__ __forceinline__ void fill_gru_tabs(float* tab, const float* pl, const GruLayout& L, int lane, int wave, int nwb) {
-    using T = GruTabs<R, DG>;
-    const int H = L.H, col = lane & 15, row = (lane >> 4) & (R - 1), o = 16 * row + col, dir = rot_dir(col);
-    float4* t4 = reinterpret_cast<float4*>(tab);
-    for (int idx = wave; idx < T::kRows * 4; idx += nwb) {
-        const int tr = idx >> 2, q = idx & 3;
-        const bool transposed = (tr >= T::kHHT && tr < T::kHID) || tr >= T::kHIDT;
-        if (!WITH_T && transposed) continue;
-        const bool hid = tr >= T::kHID;
-        const int local = hid ? (tr - (transposed ? T::kHIDT : T::kHID)) : (tr - (transposed ? T::kHHT : T::kHH));
-        const int g = hid ? 0 : local / R, rb = hid ? local : local % R;
-        const int base = hid ? L.o_w_hid : L.o_w_hh + g * H * H;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = 16 * ((row + rb) % R) + ((col + dir * (4 * q + e)) & 15);
-            const bool ok = o < H && m < H;
-            v[e] = ok ? pl[base + (transposed ? m * H + o : o * H + m)] : 0.0f;
-        }
-        t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    __syncthreads();
-}
 
 // -------------------------------------------------------------------------------------------------
 // register-resident small weights
@@ -857,10 +818,13 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
 // LDS per wave: parameters + max(weight tables — read once into registers —, the per-time buffers: 8 + 16 (+ 16) + 2 floats per step).
 // One partial-gradient row per workgroup.
 // -------------------------------------------------------------------------------------------------
+// frozen-model variant: pitch of a unit's row in the parked pre-activation gradients (odd: the 16 lanes of a row hit 16 banks)
+__host__ __device__ inline int gp_dx_pitch(int T) { return T | 1; }
 template <int NB, bool DG>
-__host__ __device__ inline int gp_buffer_floats(int T, bool pg) {
-    const int Tp = (T + 63) & ~63;
-    const int buf = Tp * 8 + (Tp + 2) * 16 * NB + (DG ? Tp * 16 * NB : 0) + Tp * 2 + 256 * NB + 32 * NB + 16 + (pg ? Tp * 64 * NB : 0);
+__host__ __device__ inline int gp_buffer_floats(int T, bool pg, bool fz = false) {
+    const int Tp = (T + 63) & ~63, Th = fz ? T : Tp;
+    const int buf = Tp * 8 + (Th + 2) * 16 * NB + (DG ? Th * 16 * NB : 0) + Tp * 2 + 256 * NB + 32 * NB + 16 + (pg ? Tp * 64 * NB : 0) +
+                    (fz ? 3 * 16 * NB * gp_dx_pitch(T) : 0);
     const int tabf = GruTabs<NB, DG>::kFloats;
     return buf > tabf ? buf : tabf;
 }
@@ -868,14 +832,18 @@ __host__ __device__ inline int gp_buffer_floats(int T, bool pg) {
 // the W_hh / fc_hid gradients are one 4-block MFMA per (output block, input block) pair.
 // PG: the forward pass also parks (r, W_hn h + b, z, n) of every step (16 B per unit and step) and the backward pass reads them back instead
 // of recomputing the gates — taken while the frame's buffers fit the CU's LDS share
-template <int NB, int FM, bool DG, bool PG>
+// FZ: the frozen model in front of the loss (the PA of train_dpd at the reference's batch sizes): no weight gradients; the backward
+// steps park the three pre-activation gradients of every unit instead ([gate][unit][t], 12 B per unit and step) and dL/dx of all T steps
+// follows with lane = time step (W_ih^T d, the fc_out feature columns, the feature Jacobian).  partials = loss rows (grid, kLossCols).
+template <int NB, int FM, bool DG, bool PG, bool FZ = false>
 __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
+    static_assert(!(PG && FZ), "the frozen variant recomputes the gates");
     constexpr int F = FeatDim<FM>::F, HB = 16 * NB;
     using TB = GruTabs<NB, DG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // 0 r | 1 n | 2 head | 3 z
     const GruLayout L = gru_layout(a.H, F, DG);
-    const int H = L.H, OW = DG ? H + 6 : H, T = a.T, Tp = (T + 63) & ~63;
+    const int H = L.H, OW = DG ? H + 6 : H, T = a.T, Tp = (T + 63) & ~63, Th = FZ ? T : Tp;
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
@@ -917,11 +885,13 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     // per-time buffers over the tables
     float* ftab = tab;                                  // [Tp][8]   features of step t
     float* hist = ftab + Tp * 8;                        // [Tp + 2][HB]   entry t + 1 = h(t) (unit u at 16 ob + col), entry 0 = h(-1) = 0
-    float* actb = hist + (Tp + 2) * HB;                 // DGRU: [Tp][HB]   relu(fc_hid h(t) + b)
-    float* dyb = actb + (DG ? Tp * HB : 0);             // [Tp][2]   dL/dy(t)
+    float* actb = hist + (Th + 2) * HB;                 // DGRU: [Tp][HB]   relu(fc_hid h(t) + b)
+    float* dyb = actb + (DG ? Th * HB : 0);             // [Tp][2]   dL/dy(t)
     float* dump = dyb + Tp * 2;                         // [256 NB]
     float* hw = dump + 256 * NB;                        // fc_out: [2][HB] hidden columns (zero padded) | [2][8] feature columns
     float* gpk = hw + 2 * HB + 16;                      // PG: [Tp][NB][16][4]   r, W_hn h + b_hn, z, n of step t (written by the n row)
+    float* dpk = gpk;                                   // FZ: [3][HB][pitch]   d_r, d_z, d_n of unit u at step t (written by the n row)
+    const int pitch = gp_dx_pitch(T);
     for (int i = lane; i < 2 * HB + 16; i += 64) {
         float v = 0.0f;
         if (i < 2 * HB) { const int c = i / HB, u = i % HB; if (u < H) v = pl[L.o_w_out + c * OW + u]; }
@@ -938,6 +908,9 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     const int park0 = role == 1 ? (int)(hist - smem) + HB + col : (head_row && DG) ? (int)(actb - smem) - HB + col : (int)(dump - smem) + lane;
     const int park_step = (role == 1 || (head_row && DG)) ? HB : 0;
     const int gpark0 = role == 1 ? (int)(gpk - smem) + 4 * col : (int)(dump - smem) + 4 * lane, gpark_step = role == 1 ? 64 * NB : 0;
+    // FZ, backward: row 1 parks (d_r, d_z, d_n) of its unit, the other rows hit the dump
+    const int dpark0 = role == 1 ? (int)(dpk - smem) + col * pitch : (int)(dump - smem) + lane;
+    const int dpark_gate = role == 1 ? HB * pitch : 0, dpark_ob = role == 1 ? 16 * pitch : 0, dpark_t = role == 1 ? 1 : 0;
 
     f32x16 acc1[NB][NB], acc2[NB];
 #pragma unroll
@@ -1130,8 +1103,13 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                     // (vsel: a plain ?: on the row index comes out as exec-mask branches here)
                     d_row[ob] = vsel(rm.m[0], drp0, vsel(rm.m[1], dgh, vsel(rm.m[3], dzp, dhid_prev[ob])));
                     zterm[ob] = vsel(rm.m[3], dht * zz[ob], 0.0f);
-                    dmisc[ob] += vsel(rm.m[1], dgh, dhid_cur[ob]);               // row 1: db_hn, head row: db_hid
-                    dwo0[ob] = __builtin_fmaf(dyv.x, at[ob], dwo0[ob]); dwo1[ob] = __builtin_fmaf(dyv.y, at[ob], dwo1[ob]);
+                    if constexpr (FZ) {
+                        const int dp = dpark0 + ob * dpark_ob + t * dpark_t;
+                        smem[dp] = drp1; smem[dp + dpark_gate] = dzp; smem[dp + 2 * dpark_gate] = dnp[ob];
+                    } else {
+                        dmisc[ob] += vsel(rm.m[1], dgh, dhid_cur[ob]);               // row 1: db_hn, head row: db_hid
+                        dwo0[ob] = __builtin_fmaf(dyv.x, at[ob], dwo0[ob]); dwo1[ob] = __builtin_fmaf(dyv.y, at[ob], dwo1[ob]);
+                    }
                 }
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) {
@@ -1145,21 +1123,63 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                 // weight gradients
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob) {
-                    const float a1 = vsel(rm.m[2], dhid_cur[ob], d_row[ob]);
+                    if constexpr (!FZ) {
+                        const float a1 = vsel(rm.m[2], dhid_cur[ob], d_row[ob]);
 #pragma unroll
-                    for (int kb = 0; kb < NB; ++kb)
-                        acc1[ob][kb] = __builtin_amdgcn_mfma_f32_16x16x1f32(a1, vsel(rm.m[2], ht[kb], hp[kb]), acc1[ob][kb], 0, 0, 0);
-                    acc2[ob] = __builtin_amdgcn_mfma_f32_16x16x1f32(vsel(rm.m[1], dnp[ob], vsel(rm.m[2], 0.0f, d_row[ob])), fsx, acc2[ob], 0, 0, 0);
+                        for (int kb = 0; kb < NB; ++kb)
+                            acc1[ob][kb] = __builtin_amdgcn_mfma_f32_16x16x1f32(a1, vsel(rm.m[2], ht[kb], hp[kb]), acc1[ob][kb], 0, 0, 0);
+                        acc2[ob] = __builtin_amdgcn_mfma_f32_16x16x1f32(vsel(rm.m[1], dnp[ob], vsel(rm.m[2], 0.0f, d_row[ob])), fsx, acc2[ob], 0, 0, 0);
+                    }
                     dhid_cur[ob] = dhid_prev[ob];
                 }
-                if constexpr (DG) {
-                    const float fs = col < 6 ? fsx : 0.0f;
-                    dwf0 = __builtin_fmaf(dyv.x, fs, dwf0); dwf1 = __builtin_fmaf(dyv.y, fs, dwf1);
+                if constexpr (!FZ) {
+                    if constexpr (DG) {
+                        const float fs = col < 6 ? fsx : 0.0f;
+                        dwf0 = __builtin_fmaf(dyv.x, fs, dwf0); dwf1 = __builtin_fmaf(dyv.y, fs, dwf1);
+                    }
+                    dbo0 += dyv.x; dbo1 += dyv.y;
                 }
-                dbo0 += dyv.x; dbo1 += dyv.y;
             }
         }
         wave_lds_fence();
+        if constexpr (FZ) {
+            // ---- dL/dx of every step, lane = time step: W_ih^T (d_r | d_z | d_n)(t) [+ the fc_out feature columns x dL/dy(t)], then the
+            //      feature Jacobian at x(t) ----
+            float2* dxg = reinterpret_cast<float2*>(a.dx) + (size_t)b * T;
+            for (int t0 = 0; t0 < T; t0 += 64) {
+                const int t = t0 + lane;
+                if (t < T) {
+                    float df[F];
+#pragma unroll
+                    for (int i = 0; i < F; ++i) df[i] = 0.0f;
+                    for (int u = 0; u < H; ++u) {
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const float d = dpk[(g * HB + u) * pitch + t];
+                            const float* wr = pl + L.o_w_ih + (g * H + u) * F;
+#pragma unroll
+                            for (int i = 0; i < F; ++i) df[i] = __builtin_fmaf(wr[i], d, df[i]);
+                        }
+                    }
+                    if constexpr (DG) {
+                        const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) df[i] += __builtin_fmaf(dyv.x, hw[2 * HB + i], dyv.y * hw[2 * HB + 8 + i]);
+                    }
+                    const float2 xv = xg[t];
+                    float dI, dQ;
+                    feat_bwd<FM>(xv.x, xv.y, df, dI, dQ);
+                    dxg[t] = make_float2(dI, dQ);
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+    if constexpr (FZ) {      // the workgroup's loss row
+        float lp = loss_acc;
+        for (int o = 32; o > 0; o >>= 1) lp += __shfl_down(lp, o);
+        if (lane < kLossCols) a.partials[(size_t)blockIdx.x * kLossCols + lane] = lane == 0 ? lp : 0.0f;
+        return;
     }
     // ---- the workgroup's row of partial gradients (every entry written) ----
     float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
@@ -1445,6 +1465,37 @@ static int launch_gp_train(hipStream_t st, const SeqArgs& a, int P) {
     };
     return pg ? launch(gru_gp_train_kernel<R, FM, DG, true>) : launch(gru_gp_train_kernel<R, FM, DG, false>);
 }
+// the frozen-model variant (forward + loss + dL/dx): taken while every sequence of the batch is resident at once
+static size_t gp_fz_lds_bytes(int P, int R, bool DG, int T) {
+    const int buf = R == 1 ? (DG ? gp_buffer_floats<1, true>(T, false, true) : gp_buffer_floats<1, false>(T, false, true))
+                           : (DG ? gp_buffer_floats<2, true>(T, false, true) : gp_buffer_floats<2, false>(T, false, true));
+    return ((size_t)pad4(P) + buf) * sizeof(float);
+}
+static int gp_fz_grid(int P, int R, bool DG, int B, int T) {
+    const size_t lds = gp_fz_lds_bytes(P, R, DG, T);
+    if (lds > kMaxLds) return 0;
+    const int per_cu = (int)(kMaxLds / lds);
+    const long cap = (long)device_cus() * (per_cu < 4 ? per_cu : 4);
+    return B <= cap ? B : 0;
+}
+static bool gru_lossdx_uses_gp(const odpd_model_t* m, int B, int T) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P) || gru_uses_s16n(m, B) || gru_split_uses_s16(m, B)) return false;
+    // hidden 17..32 without the fc_hid head: the two-block steps leave nothing to gain over the row-rotated kernel (0.97x measured,
+    // profiles/r03/frozen_pa_bench.md); with it 1.25x, hidden <= 16 1.35-1.85x
+    if (R == 2 && !DG && tuning().gp_max_batch < 0) return false;
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0 && B > max_batch) return false;
+    return gp_fz_grid(P, R, DG, B, T) > 0;
+}
+template <int R, int FM, bool DG>
+static int launch_gp_lossdx(hipStream_t st, const SeqArgs& a, int P) {
+    const size_t lds = gp_fz_lds_bytes(P, R, DG, a.T);
+    auto k = gru_gp_train_kernel<R, FM, DG, false, true>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(gp_fz_grid(P, R, DG, a.B, a.T)), dim3(64), lds, st, a);
+    return (int)hipGetLastError();
+}
 int gru_family_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
@@ -1458,6 +1509,7 @@ int gru_family_lossdx(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 3);
     if (gru_split_uses_s16(m, a.B)) return gru_s16_lossdx(st, m, a);
+    if (gru_lossdx_uses_gp(m, a.B, a.T)) { ODPD_GRU_DISPATCH_ALL(launch_gp_lossdx, st, a, P) }
     ODPD_GRU_DISPATCH_ALL(launch_lossdx, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
@@ -1466,6 +1518,7 @@ int gru_family_lossdx_rows(const odpd_model_t* m, int B, int T) {
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     if (gru_uses_s16n(m, B)) return gru_s16n_rows(m, B);
     if (gru_split_uses_s16(m, B)) return gru_s16_rows(m, B);
+    if (gru_lossdx_uses_gp(m, B, T)) return gp_fz_grid(P, R, DG, B, T);
     const LaunchShape ls = train_shape(P, R, DG, num_groups(B, R), T, nullptr, true);
     return ls.grid > 0 ? ls.grid : ODPD_EUNSUPPORTED;      // frame too long for LDS-resident BPTT state: use the split calls
 }

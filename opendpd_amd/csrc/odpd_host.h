@@ -152,6 +152,20 @@ int gru_family_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_lossdx(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);        // frozen PA: forward + loss + dL/dx in one launch
 int gru_family_lossdx_rows(const odpd_model_t* m, int B, int T);
 int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, int T);
+// train_dpd at the reference's batch sizes as one launch (gru_cascade.hip): DPD wave + frozen-PA wave per frame
+struct CascArgs {
+    const float* dpd_params;
+    const float* pa_params;
+    const float* x;            // (B,T,2), or the stream the frames index into
+    const float* target;
+    float* partials;           // (rows, P_dpd + kLossCols)
+    const long long* frame_idx;
+    int frame_stride;
+    float inv_count;
+    int loss_kind, B, T, Hd, Hp;
+};
+int gru_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T);
+int gru_cascade_train(hipStream_t s, const odpd_model_t* dpd, const odpd_model_t* pa, const CascArgs& a);
 // 16-sequences-per-wave fused kernel (gru_s16.hip) and the rule that selects it
 bool gru_train_uses_s16(const odpd_model_t* m, int B, int T);
 int gru_s16_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);

@@ -128,6 +128,19 @@ class FusedAdamW:
                                               device=device)
         return self._partials[key]
 
+    def cascade_one_launch(self, B, T, device):
+        """Partial-gradient rows of the one-launch cascade step (odpd_cascade_fwd_bwd: DPD wave + frozen-PA wave per frame), or None
+        where the pair of models / the batch shape is not served by it."""
+        self._ensure(device)
+        key = (B, T, "casc")
+        if key not in self._partials:
+            rows = -1
+            if self.pa is not None and self.pa.native and self.backbone.native:
+                rows = int(_lib.load().odpd_cascade_rows(C.byref(self.backbone.desc), C.byref(self.pa.desc), B, T))
+            self._partials[key] = (torch.empty(rows, self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32, device=device)
+                                   if rows > 0 else None)
+        return self._partials[key]
+
     def cascade_buffers(self, B, T, device):
         """u = DPD(x), y = PA(u), dy, du, checkpoints, loss scratch — allocated once per batch shape."""
         self._ensure(device)
@@ -463,8 +476,6 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count, timing=
     for bb in (dpd, pa):       # quantised models: train / eval mode of the module -> ODPD_FLAG_EVAL (an evaluation pass may have left it set)
         if hasattr(bb, "sync_mode"):
             bb.sync_mode()
-    buf = opt.cascade_buffers(B, T, x.device)
-    part = opt.bwd_partials(B, T, x.device)
     st = _lib.stream_ptr()
     fd, fp = dpd.flat_params(), (pa.flat_params() if pa is not None else None)
 
@@ -479,6 +490,22 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count, timing=
         if name is not None:
             _open.extend([ev, name])
 
+    one = opt.cascade_one_launch(B, T, x.device)
+    if one is not None:
+        # the reference's own batch sizes, GRU-family DPD and PA: the whole step body as one launch (csrc/gru_cascade.hip)
+        mark("cascade_fwd_loss_bwd")
+        _lib.check(lib.odpd_cascade_fwd_bwd(st, C.byref(dpd.desc), C.byref(pa.desc), _lib.LOSS_IDS[loss_kind], B, T, count, _lib.ptr(fd),
+                                            _lib.ptr(fp), _lib.ptr(x), _lib.ptr(target), None, 0, _lib.ptr(one)), "cascade fwd + loss + bwd")
+        mark("reduce_clip_optimiser")
+        # (column P of the rows = loss partial sums: the reduced loss travels with the gradient through the one all-reduce)
+        _lib.check(lib.odpd_reduce_partials(st, one.shape[0], dpd.n_flat, _lib.ptr(one), _lib.ptr(opt.grad), 0), "reduce")
+        opt.allreduce_grad()
+        loss = opt.grad[dpd.n_flat] / count
+        opt.apply(grad_clip_val)
+        mark()
+        return loss
+    buf = opt.cascade_buffers(B, T, x.device)
+    part = opt.bwd_partials(B, T, x.device)
     mark("dpd_fwd")
     _lib.check(lib.odpd_backbone_fwd(st, C.byref(dpd.desc), B, T, _lib.ptr(fd), _lib.ptr(x), _lib.ptr(buf["u"]),
                                      _lib.ptr(buf["ck_d"]), _lib.ptr(dpd._stats_buffer(x.device))), "dpd fwd")

@@ -150,3 +150,118 @@ def test_frozen_pa_single_launch_step_against_oracle(force_s16, pa_bb, pa_h, dpd
     assert abs(lg.item() - lo) < 2e-5 * max(1.0, lo)
     assert rel_err(opt.grad[:-4].cpu().numpy(), gd) < (3e-4 if loss == "l2" else 2e-3)
     assert torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp))
+
+
+@pytest.mark.parametrize("pa_bb,pa_h", [("gru", 11), ("gru", 16), ("dgru", 13), ("dgru", 5), ("qgru", 10), ("qgru_amp1", 16), ("gru", 23),
+                                         ("dgru", 23), ("dgru", 17), ("qgru", 20), ("dgru", 32), ("gru", 32), ("qgru_amp1", 29)])
+@pytest.mark.parametrize("B,T", [(64, 200), (5, 1), (3, 65), (2, 50)])
+@pytest.mark.parametrize("loss", ["l2", "l1"])
+@pytest.mark.parametrize("force_gp", [False, True])
+def test_frozen_pa_at_reference_batches_against_oracle(pa_bb, pa_h, B, T, loss, force_gp):
+    """odpd_frozen_loss_dx at the reference's own batch sizes (64 frames of 200 / 50 samples): the one-sequence-per-wave gate-parallel
+    kernel's frozen variant — forward, loss, the BPTT recurrence parking the pre-activation gradients, dL/du of all steps with lane =
+    time step.  Loss and dL/du == oracle (PA forward, loss, PA backward for dL/du only), directly at the C ABI.  `force_gp`: also where
+    the built-in choice keeps the row-rotated kernel (plain GRU cells of 17..32 units)."""
+    import ctypes as C
+    from opendpd_amd import CoreModel, _lib
+    from oracle.oracle import Oracle, make_model
+    lib = _lib.load()
+    torch.manual_seed(pa_h * 3 + T)
+    pa = CoreModel(2, pa_h, 1, pa_bb).cuda()
+    desc = pa.backbone.desc
+    rng = np.random.RandomState(pa_h + T)
+    u = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    o = Oracle("f32")
+    mp = make_model(pa_bb, pa_h)
+    pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
+    y, _ = o.forward(mp, pp, u)
+    lo, dy = o.loss(loss, y, t)
+    _, du = o.backward(mp, pp, u, dy)
+    if force_gp:
+        assert lib.odpd_set_tuning(b"gp_max_batch", 1 << 20) == 0
+    try:
+        rows = int(lib.odpd_frozen_loss_rows(C.byref(desc), B, T))
+        assert rows > 0
+        _frozen_call(lib, desc, pa, loss, B, T, rows, u, t, lo, du)
+    finally:
+        lib.odpd_set_tuning(b"gp_max_batch", -1)
+
+
+def _frozen_call(lib, desc, pa, loss, B, T, rows, u, t, lo, du):
+    import ctypes as C
+    from opendpd_amd import _lib
+    ug, tg = torch.from_numpy(u).cuda(), torch.from_numpy(t).cuda()
+    dug = torch.full_like(ug, float("nan"))
+    lrows = torch.full((rows, _lib.LOSS_COLS), float("nan"), device="cuda")
+    n = int(lib.odpd_train_workspace_floats(C.byref(desc), B, T))
+    ws = torch.empty(max(n, 1), device="cuda")
+    rc = lib.odpd_frozen_loss_dx(_lib.stream_ptr(), C.byref(desc), _lib.LOSS_IDS[loss], B, T, B * T * 2, _lib.ptr(pa.backbone.flat_params()),
+                                 _lib.ptr(ug), _lib.ptr(tg), _lib.ptr(dug), _lib.ptr(lrows), _lib.ptr(ws))
+    assert rc == 0
+    got = lrows[:, 0].double().sum().item() / (B * T * 2)       # rows hold partial sums; the mean is taken where they are reduced
+    assert torch.isfinite(lrows).all() and abs(got - lo) < 2e-5 * max(1.0, lo)
+    assert rel_err(dug.cpu().numpy(), du) < (2e-5 if loss == "l2" else 2e-4)
+
+
+@pytest.mark.parametrize("pa_bb,pa_h", [("gru", 11), ("dgru", 13), ("gru", 23), ("dgru", 23), ("dgru", 32), ("gru", 17)])
+@pytest.mark.parametrize("dpd_bb,dpd_h", [("gru", 11), ("dgru", 13), ("qgru", 10), ("qgru_amp1", 16), ("dgru", 5)])
+@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50), (7, 128)])
+@pytest.mark.parametrize("loss", ["l2", "l1"])
+def test_one_launch_cascade_step_against_oracle(pa_bb, pa_h, dpd_bb, dpd_h, B, T, loss):
+    """odpd_cascade_fwd_bwd (csrc/gru_cascade.hip): DPD wave and frozen-PA wave of every frame in one workgroup, 64-step hand-offs through
+    LDS — frame lengths of one step, one chunk + 1, exact chunks, the reference's 50 and 200.  Loss and DPD gradient == oracle
+    composition (DPD fwd, PA fwd, loss, PA backward for dL/du only, DPD backward); the PA's parameters are not touched."""
+    from opendpd_amd import CascadedModel, CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(pa_h * 7 + dpd_h + T)
+    dpd, pa = CoreModel(2, dpd_h, 1, dpd_bb), CoreModel(2, pa_h, 1, pa_bb)
+    net = CascadedModel(dpd_model=dpd, pa_model=pa)
+    net.freeze_pa_model()
+    net = net.cuda()
+    rng = np.random.RandomState(pa_h + T)
+    x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    o = Oracle("f32")
+    md, mp = make_model(dpd_bb, dpd_h), make_model(pa_bb, pa_h)
+    pd = dpd.backbone.flat_params().detach().cpu().numpy().copy()
+    pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
+    u, _ = o.forward(md, pd, x)
+    y, _ = o.forward(mp, pp, u)
+    lo, dy = o.loss(loss, y, t)
+    _, du = o.backward(mp, pp, u, dy)
+    gd, _ = o.backward(md, pd, x, du, need_dx=False)
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.cascade_one_launch(B, T, torch.device("cuda", 0)) is not None
+    lg = fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), loss, 0.0)
+    assert abs(lg.item() - lo) < 2e-5 * max(1.0, lo)
+    assert rel_err(opt.grad[:-4].cpu().numpy(), gd) < (3e-4 if loss == "l2" else 2e-3)
+    assert torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp))
+
+
+def test_one_launch_cascade_follows_the_chained_launches():
+    """Same AdamW trajectory over 5 steps as the chained launches (odpd_set_tuning("gp_max_batch", 0) switches the one-launch step and the
+    other one-sequence-per-wave kernels off), DGRU13 -> frozen DGRU23 at 64 x 200."""
+    from opendpd_amd import CascadedModel, CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    lib = _lib.load()
+    x = (torch.rand(64, 200, 2, device="cuda") - 0.5) * 1.2
+    t = torch.randn(64, 200, 2, device="cuda") * 0.4
+    traj = []
+    try:
+        for knob in (-1, 0):
+            assert lib.odpd_set_tuning(b"gp_max_batch", knob) == 0
+            torch.manual_seed(3)
+            net = CascadedModel(dpd_model=CoreModel(2, 13, 1, "dgru"), pa_model=CoreModel(2, 23, 1, "dgru"))
+            net.freeze_pa_model()
+            net = net.cuda()
+            opt = FusedAdamW(net, lr=1e-3)
+            assert (opt.cascade_one_launch(64, 200, x.device) is not None) == (knob == -1)
+            losses = [fused_train_step(opt, x, t, "l2", 200.0).item() for _ in range(5)]
+            traj.append((losses, net.dpd_model.backbone.flat_params().clone()))
+    finally:
+        lib.odpd_set_tuning(b"gp_max_batch", -1)
+    for a, b in zip(*[tr[0] for tr in traj]):
+        assert abs(a - b) < 1e-6 * max(1.0, abs(a))
+    assert rel_err(traj[0][1].cpu().numpy(), traj[1][1].cpu().numpy()) < 1e-5

@@ -101,7 +101,7 @@ def test_c_abi_direct_and_errors():
     """Calls the C ABI without the nn.Module layer; bad arguments return error codes."""
     from opendpd_amd import _lib
     lib = _lib.load()
-    assert lib.odpd_abi_version() == 8 and lib.odpd_built_arch() == b"gfx950"
+    assert lib.odpd_abi_version() == _lib.ABI_VERSION and lib.odpd_built_arch() == b"gfx950"
     d = _lib.ModelDesc(_lib.BACKBONE_IDS["gru"], 11, 0.0, 0.0, 0, 0, 0)
     P = lib.odpd_param_count(C.byref(d))
     assert P == 519
