@@ -98,7 +98,8 @@ int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T);
  * kernel (-1 = built-in crossover, 0 = always when supported); "s16_occupancy": 1 or 2 waves per SIMD (0 = chosen by batch size);
  * "gp_max_batch": largest batch served by the one-sequence-per-wave fused train kernels of the GRU / LSTM families (-1 = built-in: while every
  * sequence gets a SIMD of its own and the frame's BPTT state fits the CU's LDS share; 0 = never, which also keeps the one-sequence-per-wave
- * forward kernels off). */
+ * forward kernels off); "cascade_one_launch": 0 = odpd_cascade_rows answers ODPD_EUNSUPPORTED (train_dpd steps as chained launches),
+ * 1 = built-in choice. */
 int odpd_set_tuning(const char* key, int64_t value);
 /* Counter bumped by every successful odpd_set_tuning: buffers sized by the queries above are valid for the generation they were
  * sized in (the row count / workspace layout of a (B,T) shape depends on the knobs). */
@@ -222,6 +223,16 @@ int odpd_clip_optim_step(void* stream, int kind, int64_t P, float* params, float
 int odpd_train_epoch_opt(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, int opt_kind,
                          float* params, float* grad, float* state1, float* state2, int64_t first_step, double lr, double max_norm,
                          float* partials, float* workspace, float* losses_out);
+/* A whole train_dpd epoch of one-launch cascade steps from C++ (net_train's loop, train_funcs.py:28-48, for a CascadedModel with a frozen
+ * PA): per step odpd_cascade_fwd_bwd on the frames `order[f0 .. f0 + B)` read in place, row reduction, clip + optimiser step
+ * (opt_kind < 0: AdamW with the given betas / eps / weight_decay; else ODPD_OPT_*), mean loss of step i -> losses_out[i].
+ * ODPD_EUNSUPPORTED unless odpd_cascade_rows > 0 for the epoch's full batch and its tail. `partials`: max over those of
+ * (rows, P_dpd + 4). */
+int odpd_train_epoch_cascade(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, const odpd_frames_t* fr,
+                             int batch, int opt_kind, float* dpd_params, const float* pa_params, float* grad, float* state1,
+                             float* state2, int64_t first_step, double lr, double beta1, double beta2, double eps, double weight_decay,
+                             double max_norm, float* partials, float* losses_out);
+
 
 /* The epoch loop for a backbone WITHOUT a fused train kernel at this batch shape: per step the frames are gathered into (B,T,2)
  * buffers, then odpd_backbone_fwd, odpd_loss_fwd_bwd, odpd_backbone_bwd, odpd_reduce_partials and the optimiser (opt_kind < 0: AdamW

@@ -72,6 +72,8 @@ odpd::Tuning& odpd::tuning() {
         v.s16_occupancy = e ? atoi(e) : 0;    // 0 = by batch size
         e = getenv("ODPD_GP_MAX_BATCH");
         v.gp_max_batch = e ? atol(e) : -1;    // -1 = built-in crossover, 0 = never the gate-parallel fused train kernel
+        e = getenv("ODPD_CASCADE_ONE_LAUNCH");
+        v.cascade_one_launch = e ? atoi(e) : 1;   // 0 = train_dpd steps always as chained launches
         return v;
     }();
     return t;
@@ -82,6 +84,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
     if (!strcmp(key, "s16_min_batch")) { tuning().s16_min_batch = (long)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "s16_occupancy")) { tuning().s16_occupancy = (int)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "gp_max_batch")) { tuning().gp_max_batch = (long)value; ++g_tuning_generation; return 0; }
+    if (!strcmp(key, "cascade_one_launch")) { tuning().cascade_one_launch = (int)value; ++g_tuning_generation; return 0; }
     return ODPD_EINVAL;
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
@@ -402,6 +405,38 @@ static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, 
         rc = opt_kind < 0 ? launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
                                               losses_out + i, a.inv_count)
                           : launch_clip_optim(st, opt_kind, P, params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, a.inv_count);
+        if (rc) return rc;
+    }
+    return 0;
+}
+// ---- native epoch loop of train_dpd at the reference's batch sizes: the one-launch cascade step (gru_cascade.hip) on frames read in place ----
+extern "C" int odpd_train_epoch_cascade(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, const odpd_frames_t* fr,
+                                        int batch, int opt_kind, float* dpd_params, const float* pa_params, float* grad, float* state1,
+                                        float* state2, int64_t first_step, double lr, double beta1, double beta2, double eps,
+                                        double weight_decay, double max_norm, float* partials, float* losses_out) {
+    if (!model_ok(dpd) || !model_ok(pa) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
+        fr->stride <= 0 || batch <= 0 || !dpd_params || !pa_params || !grad || !state1 || !state2 || !partials || !losses_out || first_step <= 0 ||
+        opt_kind > ODPD_OPT_RMSPROP)
+        return ODPD_EINVAL;
+    const int T = fr->frame_length;
+    const int64_t full = fr->n_frames < batch ? fr->n_frames : batch, tail = fr->n_frames % batch;
+    for (int64_t gb : {full, tail})
+        if (gb && odpd_cascade_rows(dpd, pa, (int)gb, T) <= 0) return ODPD_EUNSUPPORTED;
+    const int64_t P = odpd_param_count(dpd);
+    hipStream_t st = (hipStream_t)stream;
+    int64_t step = first_step;
+    for (int64_t f0 = 0, i = 0; f0 < fr->n_frames; f0 += batch, ++i, ++step) {
+        const int B = (int)((fr->n_frames - f0) < batch ? (fr->n_frames - f0) : batch);
+        const int64_t count = (int64_t)B * T * 2;
+        const float inv_count = (float)(1.0 / (double)count);
+        int rc = odpd_cascade_fwd_bwd(stream, dpd, pa, loss_kind, B, T, count, dpd_params, pa_params, fr->x_stream, fr->y_stream, fr->order + f0,
+                                      fr->stride, partials);
+        if (rc) return rc;
+        rc = odpd_reduce_partials(stream, odpd_cascade_rows(dpd, pa, B, T), P, partials, grad, 0);
+        if (rc) return rc;
+        rc = opt_kind < 0 ? launch_clip_adamw(st, P, dpd_params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
+                                              losses_out + i, inv_count)
+                          : launch_clip_optim(st, opt_kind, P, dpd_params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, inv_count);
         if (rc) return rc;
     }
     return 0;

@@ -581,7 +581,7 @@ int casc_launch(hipStream_t st, const CascArgs& a, const CascCfg& c) {
 // rows of partials (> 0) if the pair of models and the batch shape are served by the one-launch cascade step, else ODPD_EUNSUPPORTED
 int gru_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T) {
     CascCfg c;
-    if (!casc_cfg(dpd, pa, c) || tuning().gp_max_batch == 0) return ODPD_EUNSUPPORTED;
+    if (!casc_cfg(dpd, pa, c) || tuning().gp_max_batch == 0 || !tuning().cascade_one_launch) return ODPD_EUNSUPPORTED;
     const int g = casc_grid(c, B, T);
     return g > 0 ? g : (int)ODPD_EUNSUPPORTED;
 }

@@ -321,6 +321,42 @@ class FusedAdamW:
         self._keepalive = order     # the launches read `order` asynchronously
         return losses
 
+    def can_run_cascade_epoch(self, loader):
+        """True when odpd_train_epoch_cascade can drive a whole train_dpd epoch: frozen PA behind the trained DPD, every batch of the epoch
+        served by the one-launch cascade step, one process, resident streams."""
+        if not (self.pa is not None and getattr(self.backbone, "frozen_mask", None) is None
+                and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size")) and loader.x.is_cuda):
+            return False
+        if self.world_size() > 1 or self.native_comm() is not None:
+            return False
+        dev = loader.x.device
+        return all(self.cascade_one_launch(b, loader.frame_length, dev) is not None for b in self._epoch_batches(loader))
+
+    def train_epoch_cascade(self, loader, loss_kind, max_norm):
+        """One train_dpd epoch through odpd_train_epoch_cascade: returns the per-batch mean losses (device tensor)."""
+        lib = _lib.load()
+        dpd, pa = self.backbone, self.pa
+        dev, T, n = loader.x.device, loader.frame_length, loader.n
+        B = min(loader.batch_size, n)
+        self._ensure(dev)
+        n_steps = (n + B - 1) // B
+        part = max((self.cascade_one_launch(b, T, dev) for b in self._epoch_batches(loader)), key=lambda p: p.shape[0])
+        order = loader.epoch_order()
+        losses = torch.empty(n_steps, dtype=torch.float32, device=dev)
+        fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
+        g = self.param_groups[0]
+        adamw = self.kind == "adamw"
+        rc = lib.odpd_train_epoch_cascade(_lib.stream_ptr(), C.byref(dpd.desc), C.byref(pa.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
+                                          -1 if adamw else _lib.OPTIMIZER_IDS[self.kind], _lib.ptr(dpd.flat_params(full_check=True)),
+                                          _lib.ptr(pa.flat_params(full_check=True)), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
+                                          _lib.ptr(self.exp_avg_sq), self.step_count + 1, float(g["lr"]), float(g["betas"][0]) if adamw else 0.0,
+                                          float(g["betas"][1]) if adamw else 0.0, float(g["eps"]) if adamw else 0.0,
+                                          float(g["weight_decay"]) if adamw else 0.0, float(max_norm or 0.0), _lib.ptr(part), _lib.ptr(losses))
+        _lib.check(rc, "odpd_train_epoch_cascade")
+        self.step_count += n_steps
+        self._keepalive = order     # the launches read `order` asynchronously
+        return losses
+
     def train_epoch(self, loader, loss_kind, max_norm):
         """One epoch through the native loop (odpd_train_epoch): returns the per-batch mean losses (device tensor)."""
         lib = _lib.load()
@@ -555,6 +591,11 @@ def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device)
     if fast and optimizer.can_run_epoch(dataloader):
         # whole epoch in the native loop: frames read in place from the resident streams, 3 launches per step, no Python
         losses = optimizer.train_epoch(dataloader, kind, grad_clip_val)
+        log["loss"] = float(losses.double().mean().item()) if losses.numel() else float("nan")
+        return net
+    if fast and optimizer.can_run_cascade_epoch(dataloader):
+        # train_dpd at the reference's batch sizes, GRU-family DPD and PA: one launch per step body, the epoch issued from the native loop
+        losses = optimizer.train_epoch_cascade(dataloader, kind, grad_clip_val)
         log["loss"] = float(losses.double().mean().item()) if losses.numel() else float("nan")
         return net
     if fast and optimizer.can_run_split_epoch(dataloader):

@@ -265,3 +265,49 @@ def test_one_launch_cascade_follows_the_chained_launches():
     for a, b in zip(*[tr[0] for tr in traj]):
         assert abs(a - b) < 1e-6 * max(1.0, abs(a))
     assert rel_err(traj[0][1].cpu().numpy(), traj[1][1].cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("dpd_bb,dpd_h,pa_bb,pa_h", [("gru", 15, "gru", 23), ("dgru", 13, "dgru", 13), ("qgru", 10, "dgru", 23)])
+@pytest.mark.parametrize("opt_kind", ["adamw", "sgd"])
+def test_native_cascade_epoch_equals_the_python_driven_steps(dpd_bb, dpd_h, pa_bb, pa_h, opt_kind):
+    """odpd_train_epoch_cascade (frames read in place from the resident streams, every step issued from C++) against fused_train_step on the
+    loader's gathered batches: same launches, same order -> bit-identical parameters; a full batch and a shorter tail; net_train takes it."""
+    from opendpd_amd import CascadedModel, CoreModel
+    from opendpd_amd.project import DeviceFrameLoader
+    from opendpd_amd.train_funcs import FusedAdamW, FusedSGD, fused_train_step, net_train
+    rng = np.random.RandomState(5)
+    n_s, T, B = 700, 50, 64
+    amp, ph = 0.05 + 0.85 * rng.rand(n_s), 2 * np.pi * rng.rand(n_s)
+    x = np.stack([amp * np.cos(ph), amp * np.sin(ph)], -1)
+    y = 0.7 * x + 0.05 * rng.randn(n_s, 2)
+    dev = torch.device("cuda")
+    results = []
+    for native in (True, False, "net_train"):
+        torch.manual_seed(3)
+        net = CascadedModel(dpd_model=CoreModel(2, dpd_h, 1, dpd_bb), pa_model=CoreModel(2, pa_h, 1, pa_bb))
+        net.freeze_pa_model()
+        net = net.cuda()
+        opt = (FusedAdamW if opt_kind == "adamw" else FusedSGD)(net, lr=2e-3)
+        loader = DeviceFrameLoader(x, y, T, 1, B, dev, shuffle=True)
+        torch.manual_seed(11)
+        if native == "net_train":
+            log = {}
+            for _ in range(2):
+                net_train(log, net, loader, opt, torch.nn.MSELoss(), 200.0, dev)
+            losses = None
+        elif native:
+            assert opt.can_run_cascade_epoch(loader) and not opt.can_run_epoch(loader)
+            losses = torch.cat([opt.train_epoch_cascade(loader, "l2", 200.0) for _ in range(2)])
+        else:
+            losses = []
+            for _ in range(2):
+                for fx, fy in loader:
+                    losses.append(fused_train_step(opt, fx.contiguous(), fy.contiguous(), "l2", 200.0))
+            losses = torch.stack(losses)
+        results.append((net.dpd_model.backbone.flat_params().clone(), None if losses is None else losses.cpu().numpy(), opt.step_count,
+                        net.pa_model.backbone.flat_params().clone()))
+    (pa, la, sa, qa), (pb, lb, sb, qb), (pc, _, sc, qc) = results
+    assert sa == sb == sc == 2 * ((n_s - T + 1 + B - 1) // B)
+    assert torch.equal(pa, pb) and torch.equal(pa, pc)
+    assert np.allclose(la, lb, rtol=1e-6, atol=0)
+    assert torch.equal(qa, qb) and torch.equal(qa, qc)
