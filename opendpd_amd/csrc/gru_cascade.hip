@@ -21,10 +21,11 @@ constexpr int kCascChunk = 32;
 constexpr int kDxPitch = kCascChunk + 1;       // odd: the 16 lanes of a row hit 16 banks
 
 // One model of the cascade on one wave.  TRAIN: weight gradients (the DPD); else frozen, dL/dx out (the PA).
-// PG: the forward steps also park (r, W_hn h + b, z, n) of every step (16 B per unit and step) and the backward steps read them back
-// instead of recomputing the gates.
-template <int NB, int FM, bool DG, bool TRAIN, bool PG = false>
+// HALF (frozen, NB = 2, hidden 17..24 — the reference's default PA has 23 units): the second block holds its <= 8 units twice, so the
+// rotated dot products over it take 8 rotations instead of 16 (odpd_gru.h, fill_gru_tabs<.., HALF>): 48 of the 192 DPP FMAs of a time step.
+template <int NB, int FM, bool DG, bool TRAIN, bool HALF = false>
 struct GpSeq {
+    static_assert(!HALF || (NB == 2 && !TRAIN), "half-block layout: frozen two-block models");
     static constexpr int F = FeatDim<FM>::F, HB = 16 * NB;
     using TB = GruTabs<NB, DG>;
     // ---- LDS region: parameters | max(weight tables, per-time buffers) ----
@@ -36,8 +37,7 @@ struct GpSeq {
     __host__ __device__ static int off_hw(int T) { return off_dump(T) + 256 * NB; }
     __host__ __device__ static int off_dpk(int T) { return off_hw(T) + 2 * HB + 16; }
     __host__ __device__ static int off_ubuf(int T) { return off_dpk(T) + (TRAIN ? 0 : 3 * HB * kDxPitch); }
-    __host__ __device__ static int off_gpk(int T) { return off_ubuf(T) + (TRAIN ? 0 : tp(T) * 2); }
-    __host__ __device__ static int buf_floats(int T) { return off_gpk(T) + (PG ? T * 64 * NB : 0); }
+    __host__ __device__ static int buf_floats(int T) { return off_ubuf(T) + (TRAIN ? 0 : tp(T) * 2); }
     __host__ __device__ static int region_floats(int T, int P) {
         const int buf = buf_floats(T), tabf = TB::kFloats;
         return pad4(P) + (buf > tabf ? buf : tabf);
@@ -49,12 +49,18 @@ struct GpSeq {
     f32x16 acc1[NB][NB], acc2[NB];
     float dmisc[NB], dwo0[NB], dwo1[NB], dwf0, dwf1, dbo0, dbo1;
     float h[NB], carry[NB], dhid_cur[NB];
-    float *smem, *pl, *ftab, *hist, *actb, *dyb, *dump, *hw, *dpk, *gpk;
+    float *smem, *pl, *ftab, *hist, *actb, *dyb, *dump, *hw, *dpk;
     GruLayout L;
     RowMasks rm;
-    int H, OW, T, lane, col, role, park0, park_step, park, dpark0, dpark_gate, dpark_ob, dpark_t, gpark0, gpark_step, gpark;
+    int H, OW, T, lane, col, role, park0, park_step, park, dpark0, dpark_gate, dpark_ob, dpark_t;
     bool head_row, odd;
 
+    // the unit a lane of output block ob carries
+    __device__ __forceinline__ int unit(int ob) const { return 16 * ob + ((HALF && ob == 1) ? (col & 7) : col); }
+    // rotated dot product over input block kb
+    __device__ __forceinline__ static float rd(float acc, const float (&w)[16], float v, int kb) {
+        return (HALF && kb == 1) ? rotdot8(acc, w, v) : rotdot(acc, w, v);
+    }
     // (one workgroup barrier inside: fill_gru_tabs)
     __device__ __forceinline__ void setup(float* base, float* region, const float* params, int Hm, int T_) {
         smem = base;
@@ -65,12 +71,12 @@ struct GpSeq {
         for (int i = lane; i < L.P; i += 64) pl[i] = params[i];
         wave_lds_fence();
         float* tab = region + pad4(L.P);
-        fill_gru_tabs<NB, DG, true>(tab, pl, L, lane, 0, 1);
+        fill_gru_tabs<NB, DG, true, HALF>(tab, pl, L, lane, 0, 1);
         const int gate = role == 0 ? 0 : role == 3 ? 1 : 2;
         head_row = role == 2; odd = role & 1;
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) {
-            const int o = 16 * ob + col;
+            const int o = unit(ob);
             const bool vo = o < H;
             TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + 16 * ob + col);
             int rf = TB::kHH + gate * NB, rt = TB::kHHT + gate * NB;
@@ -105,7 +111,6 @@ struct GpSeq {
         dump = tab + off_dump(T);
         hw = tab + off_hw(T);                        // fc_out: [2][HB] hidden columns (zero padded) | [2][8] feature columns
         dpk = tab + off_dpk(T);                      // frozen: [3][HB][kDxPitch]   d_r, d_z, d_n of unit u at step t0 + i
-        gpk = tab + off_gpk(T);                      // PG: [T][NB][16][4]   r, W_hn h + b_hn, z, n of step t (written by the n row)
         for (int i = lane; i < 2 * HB + 16; i += 64) {
             float v = 0.0f;
             if (i < 2 * HB) { const int c = i / HB, u = i % HB; if (u < H) v = pl[L.o_w_out + c * OW + u]; }
@@ -117,7 +122,6 @@ struct GpSeq {
         // the per-step stores of the forward pass: row 1 parks h(t), the head row parks relu(fc_hid h(t-1)), rows 0 / 3 hit the dump
         park0 = role == 1 ? (int)(hist - smem) + HB + col : (head_row && DG) ? (int)(actb - smem) - HB + col : (int)(dump - smem) + lane;
         park_step = (role == 1 || (head_row && DG)) ? HB : 0;
-        gpark0 = role == 1 ? (int)(gpk - smem) + 4 * col : (int)(dump - smem) + 4 * lane; gpark_step = role == 1 ? 64 * NB : 0;
         // frozen, backward: row 1 parks (d_r, d_z, d_n) of its unit, the other rows hit the dump
         dpark0 = role == 1 ? (int)(dpk - smem) + col * kDxPitch : (int)(dump - smem) + lane;
         dpark_gate = role == 1 ? HB * kDxPitch : 0; dpark_ob = role == 1 ? 16 * kDxPitch : 0; dpark_t = role == 1 ? 1 : 0;
@@ -142,7 +146,7 @@ struct GpSeq {
         for (int ob = 0; ob < NB; ++ob) {
             arec[ob] = b_rec[ob];
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) arec[ob] = rotdot(arec[ob], wF[ob][kb], hin[kb]);
+            for (int kb = 0; kb < NB; ++kb) arec[ob] = rd(arec[ob], wF[ob][kb], hin[kb], kb);
         }
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) {
@@ -177,7 +181,7 @@ struct GpSeq {
     __device__ __forceinline__ void fwd_begin() {
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) h[kb] = 0.0f;
-        park = park0; gpark = gpark0;
+        park = park0;
     }
     // steps t0 .. t0 + len - 1 of the recurrence (features in ftab)
     __device__ __forceinline__ void fwd_steps(int t0, int len) {
@@ -192,10 +196,8 @@ struct GpSeq {
                 h[ob] = odd ? h13 : h02;
                 // (the head row's first store, act(-1), lands in hist's pad entry)
                 smem[park + 16 * ob] = head_row ? __builtin_fmaxf(arec[ob], 0.0f) : h[ob];
-                if constexpr (PG) *reinterpret_cast<float4*>(smem + gpark + 64 * ob) = make_float4(r1[ob], arec[ob], zz[ob], nn[ob]);
             }
             park += park_step;
-            if constexpr (PG) gpark += gpark_step;
         }
     }
     // DGRU: relu(fc_hid h(t)) of the step just done (the head row runs one step behind)
@@ -205,7 +207,7 @@ struct GpSeq {
             for (int ob = 0; ob < NB; ++ob) {
                 float arec = b_rec[ob];
 #pragma unroll
-                for (int kb = 0; kb < NB; ++kb) arec = rotdot(arec, wF[ob][kb], h[kb]);
+                for (int kb = 0; kb < NB; ++kb) arec = rd(arec, wF[ob][kb], h[kb], kb);
                 if (head_row) actb[t * HB + 16 * ob + col] = __builtin_fmaxf(arec, 0.0f);
             }
         }
@@ -249,7 +251,7 @@ struct GpSeq {
             for (int ob = 0; ob < NB; ++ob) {
                 float part = 0.0f;
 #pragma unroll
-                for (int kb = 0; kb < NB; ++kb) part = rotdot(part, wT[ob][kb], head_row ? dhid_cur[kb] : 0.0f);
+                for (int kb = 0; kb < NB; ++kb) part = rd(part, wT[ob][kb], head_row ? dhid_cur[kb] : 0.0f, kb);
                 part += xor16(part);
                 part += xor32(part);
                 carry[ob] = part;
@@ -267,15 +269,9 @@ struct GpSeq {
             }
             const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
             const float fsx = col < F ? ftab[t * 8 + col] : (col == F ? 1.0f : 0.0f);
-            // the gates of step t: parked by the forward pass, or again from the parked h(t-1)
+            // the gates of step t again, from the parked h(t-1) (off the carry chain: it fills the chain's stalls)
             float arec[NB], r1[NB], zz[NB], nn[NB];                              // rows 1 and 3: z, n; row 1: r, W_hn h + b_hn
-            if constexpr (PG) {
-#pragma unroll
-                for (int ob = 0; ob < NB; ++ob) {
-                    const float4 g = reinterpret_cast<const float4*>(gpk)[(t * NB + ob) * 16 + col];
-                    r1[ob] = g.x; arec[ob] = g.y; zz[ob] = g.z; nn[ob] = g.w;
-                }
-            } else {
+            {
                 float f[F];
                 load_feat(t, f);
                 gates(f, hp, arec, r1, zz, nn);
@@ -314,7 +310,7 @@ struct GpSeq {
             for (int ob = 0; ob < NB; ++ob) {
                 float part = zterm[ob];
 #pragma unroll
-                for (int kb = 0; kb < NB; ++kb) part = rotdot(part, wT[ob][kb], d_row[kb]);
+                for (int kb = 0; kb < NB; ++kb) part = rd(part, wT[ob][kb], d_row[kb], kb);
                 part += xor16(part);
                 part += xor32(part);
                 carry[ob] = part;                                                // dL/dh(t-1): W_hh^T d + z dL/dh(t) + fc_hid^T dhid(t-1)
@@ -416,10 +412,11 @@ struct GpSeq {
     }
 };
 
-template <int FMD, bool DGD, int NBP, int FMP, bool DGP>
+// PA variants: PV = 0 hidden <= 16 | 1 hidden 17..24 (two blocks, the second held twice) | 2 hidden 25..32
+template <int FMD, bool DGD, int PV, int FMP, bool DGP>
 __global__ __launch_bounds__(128) void gru_cascade_kernel(CascArgs a) {
     using D = GpSeq<1, FMD, DGD, true>;
-    using P = GpSeq<NBP, FMP, DGP, false, NBP == 1>;      // (the parked gates of a 32-unit PA would not fit beside the rest)
+    using P = GpSeq<PV == 0 ? 1 : 2, FMP, DGP, false, PV == 1>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int T = a.T, NC = (T + kCascChunk - 1) / kCascChunk;
@@ -517,7 +514,7 @@ __global__ __launch_bounds__(128) void gru_cascade_kernel(CascArgs a) {
 // host side
 // -------------------------------------------------------------------------------------------------
 namespace {
-struct CascCfg { int fmd, fmp, nbp, Pd, Pp; bool dgd, dgp; };
+struct CascCfg { int fmd, fmp, pv, Pd, Pp; bool dgd, dgp; };
 bool casc_model(const odpd_model_t* m, int& fm, bool& dg) {
     if (m->bits_w > 0) return false;
     switch (m->backbone) {
@@ -533,21 +530,24 @@ bool casc_cfg(const odpd_model_t* dpd, const odpd_model_t* pa, CascCfg& c) {
     if (!casc_model(dpd, c.fmd, c.dgd) || !casc_model(pa, c.fmp, c.dgp)) return false;
     if (dpd->hidden < 1 || dpd->hidden > 16 || pa->hidden < 1 || pa->hidden > 32) return false;
     if (c.fmp != FEAT_RAW2 && c.fmp != FEAT_DGRU6) return false;      // PAs of the reference's scripts: gru, dgru
-    c.nbp = pa->hidden > 16 ? 2 : 1;
+    c.pv = pa->hidden > 24 ? 2 : pa->hidden > 16 ? 1 : 0;
     c.Pd = gru_layout(dpd->hidden, feat_dim(c.fmd), c.dgd).P;
     c.Pp = gru_layout(pa->hidden, feat_dim(c.fmp), c.dgp).P;
     return true;
 }
-template <int FMD, bool DGD, int NBP, int FMP, bool DGP>
+template <int FMD, bool DGD, int PV, int FMP, bool DGP>
 size_t casc_lds(int T, int Pd, int Pp) {
-    return ((size_t)GpSeq<1, FMD, DGD, true>::region_floats(T, Pd) + GpSeq<NBP, FMP, DGP, false, NBP == 1>::region_floats(T, Pp) + 4) * sizeof(float);
+    return ((size_t)GpSeq<1, FMD, DGD, true>::region_floats(T, Pd) + GpSeq<PV == 0 ? 1 : 2, FMP, DGP, false, PV == 1>::region_floats(T, Pp) + 4) *
+           sizeof(float);
 }
 #define ODPD_CASC_PA(FMD_, DGD_, CALL)                                                                  \
     if (c.fmd == FMD_) {                                                                                \
-        if (c.nbp == 1 && c.fmp == FEAT_RAW2) return CALL(FMD_, DGD_, 1, FEAT_RAW2, false);             \
-        if (c.nbp == 2 && c.fmp == FEAT_RAW2) return CALL(FMD_, DGD_, 2, FEAT_RAW2, false);             \
-        if (c.nbp == 1 && c.fmp == FEAT_DGRU6) return CALL(FMD_, DGD_, 1, FEAT_DGRU6, true);            \
-        if (c.nbp == 2 && c.fmp == FEAT_DGRU6) return CALL(FMD_, DGD_, 2, FEAT_DGRU6, true);            \
+        if (c.pv == 0 && c.fmp == FEAT_RAW2) return CALL(FMD_, DGD_, 0, FEAT_RAW2, false);              \
+        if (c.pv == 1 && c.fmp == FEAT_RAW2) return CALL(FMD_, DGD_, 1, FEAT_RAW2, false);              \
+        if (c.pv == 2 && c.fmp == FEAT_RAW2) return CALL(FMD_, DGD_, 2, FEAT_RAW2, false);              \
+        if (c.pv == 0 && c.fmp == FEAT_DGRU6) return CALL(FMD_, DGD_, 0, FEAT_DGRU6, true);             \
+        if (c.pv == 1 && c.fmp == FEAT_DGRU6) return CALL(FMD_, DGD_, 1, FEAT_DGRU6, true);             \
+        if (c.pv == 2 && c.fmp == FEAT_DGRU6) return CALL(FMD_, DGD_, 2, FEAT_DGRU6, true);             \
     }
 #define ODPD_CASC_ALL(CALL)                 \
     ODPD_CASC_PA(FEAT_RAW2, false, CALL)    \
@@ -556,7 +556,7 @@ size_t casc_lds(int T, int Pd, int Pp) {
     ODPD_CASC_PA(FEAT_A4, false, CALL)
 
 size_t casc_lds_bytes(const CascCfg& c, int T) {
-#define ODPD_CASC_LDS(FMD_, DGD_, NBP_, FMP_, DGP_) casc_lds<FMD_, DGD_, NBP_, FMP_, DGP_>(T, c.Pd, c.Pp)
+#define ODPD_CASC_LDS(FMD_, DGD_, PV_, FMP_, DGP_) casc_lds<FMD_, DGD_, PV_, FMP_, DGP_>(T, c.Pd, c.Pp)
     ODPD_CASC_ALL(ODPD_CASC_LDS)
 #undef ODPD_CASC_LDS
     return 0;
@@ -568,10 +568,10 @@ int casc_grid(const CascCfg& c, int B, int T) {
     const long cap = (long)device_cus() * (per_cu < 2 ? per_cu : 2);        // a workgroup = two waves, on SIMDs of their own
     return B <= cap ? B : 0;                                               // every frame resident at once
 }
-template <int FMD, bool DGD, int NBP, int FMP, bool DGP>
+template <int FMD, bool DGD, int PV, int FMP, bool DGP>
 int casc_launch(hipStream_t st, const CascArgs& a, const CascCfg& c) {
-    const size_t lds = casc_lds<FMD, DGD, NBP, FMP, DGP>(a.T, c.Pd, c.Pp);
-    auto k = gru_cascade_kernel<FMD, DGD, NBP, FMP, DGP>;
+    const size_t lds = casc_lds<FMD, DGD, PV, FMP, DGP>(a.T, c.Pd, c.Pp);
+    auto k = gru_cascade_kernel<FMD, DGD, PV, FMP, DGP>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(casc_grid(c, a.B, a.T)), dim3(128), lds, st, a);
     return (int)hipGetLastError();
@@ -588,7 +588,7 @@ int gru_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int
 int gru_cascade_train(hipStream_t st, const odpd_model_t* dpd, const odpd_model_t* pa, const CascArgs& a) {
     CascCfg c;
     if (!casc_cfg(dpd, pa, c) || casc_grid(c, a.B, a.T) <= 0) return ODPD_EUNSUPPORTED;
-#define ODPD_CASC_LAUNCH(FMD_, DGD_, NBP_, FMP_, DGP_) casc_launch<FMD_, DGD_, NBP_, FMP_, DGP_>(st, a, c)
+#define ODPD_CASC_LAUNCH(FMD_, DGD_, PV_, FMP_, DGP_) casc_launch<FMD_, DGD_, PV_, FMP_, DGP_>(st, a, c)
     ODPD_CASC_ALL(ODPD_CASC_LAUNCH)
 #undef ODPD_CASC_LAUNCH
     return ODPD_EUNSUPPORTED;

@@ -835,9 +835,13 @@ __host__ __device__ inline int gp_buffer_floats(int T, bool pg, bool fz = false)
 // FZ: the frozen model in front of the loss (the PA of train_dpd at the reference's batch sizes): no weight gradients; the backward
 // steps park the three pre-activation gradients of every unit instead ([gate][unit][t], 12 B per unit and step) and dL/dx of all T steps
 // follows with lane = time step (W_ih^T d, the fc_out feature columns, the feature Jacobian).  partials = loss rows (grid, kLossCols).
-template <int NB, int FM, bool DG, bool PG, bool FZ = false>
+// HALF (NB = 2, hidden 17..24 — the reference's default PA has 23 units): the second 16-lane block holds its <= 8 units twice (odpd_gru.h,
+// fill_gru_tabs<.., HALF>), the rotated dot products over it take 8 rotations instead of 16: 48 of the 192 DPP FMAs of a time step.  The
+// replica lanes carry unit indices >= 24 in every per-unit write-out and in the MFMA blocks' rows / columns, which hidden <= 24 masks off.
+template <int NB, int FM, bool DG, bool PG, bool FZ = false, bool HALF = false>
 __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     static_assert(!(PG && FZ), "the frozen variant recomputes the gates");
+    static_assert(!HALF || NB == 2, "half-block layout: two-block models");
     constexpr int F = FeatDim<FM>::F, HB = 16 * NB;
     using TB = GruTabs<NB, DG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
-    fill_gru_tabs<NB, DG, true>(tab, pl, L, lane, 0, 1);
+    fill_gru_tabs<NB, DG, true, HALF>(tab, pl, L, lane, 0, 1);
     const int gate = role == 0 ? 0 : role == 3 ? 1 : 2;
     const bool head_row = role == 2;
     // the row's rotated weights, forward and transposed (head row: fc_hid for DGRU, nothing otherwise): [output block][input block]
@@ -855,7 +859,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     float win[NB][F], b_in[NB], b_rec[NB], wo0[NB], wo1[NB];
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
-        const int o = 16 * ob + col;
+        const int o = 16 * ob + ((HALF && ob == 1) ? (col & 7) : col);      // the unit this lane carries in output block ob
         const bool vo = o < H;
         TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + 16 * ob + col);
         int rf = TB::kHH + gate * NB, rt = TB::kHHT + gate * NB;
@@ -881,6 +885,8 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
         wo0[ob] = vo ? pl[L.o_w_out + o] : 0.0f; wo1[ob] = vo ? pl[L.o_w_out + OW + o] : 0.0f;
     }
     const float bo0 = pl[L.o_b_out], bo1 = pl[L.o_b_out + 1];
+    // rotated dot product over input block kb
+    auto rd = [](float acc, const float (&w)[16], float v, int kb) { return (HALF && kb == 1) ? rotdot8(acc, w, v) : rotdot(acc, w, v); };
     wave_lds_fence();
     // per-time buffers over the tables
     float* ftab = tab;                                  // [Tp][8]   features of step t
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
         for (int ob = 0; ob < NB; ++ob) {
             arec[ob] = b_rec[ob];
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) arec[ob] = rotdot(arec[ob], wF[ob][kb], hin[kb]);
+            for (int kb = 0; kb < NB; ++kb) arec[ob] = rd(arec[ob], wF[ob][kb], hin[kb], kb);
         }
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) {
@@ -1001,7 +1007,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                 for (int ob = 0; ob < NB; ++ob) {
                     float arec = b_rec[ob];
 #pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) arec = rotdot(arec, wF[ob][kb], h[kb]);
+                    for (int kb = 0; kb < NB; ++kb) arec = rd(arec, wF[ob][kb], h[kb], kb);
                     if (head_row) actb[(T - 1) * HB + 16 * ob + col] = __builtin_fmaxf(arec, 0.0f);
                 }
             }
@@ -1052,7 +1058,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                 for (int ob = 0; ob < NB; ++ob) {
                     float part = 0.0f;
 #pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) part = rotdot(part, wT[ob][kb], head_row ? dhid_cur[kb] : 0.0f);
+                    for (int kb = 0; kb < NB; ++kb) part = rd(part, wT[ob][kb], head_row ? dhid_cur[kb] : 0.0f, kb);
                     part += xor16(part);
                     part += xor32(part);
                     carry[ob] = part;
@@ -1115,7 +1121,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                 for (int ob = 0; ob < NB; ++ob) {
                     float part = zterm[ob];
 #pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) part = rotdot(part, wT[ob][kb], d_row[kb]);
+                    for (int kb = 0; kb < NB; ++kb) part = rd(part, wT[ob][kb], d_row[kb], kb);
                     part += xor16(part);
                     part += xor32(part);
                     carry[ob] = part;                                                // dL/dh(t-1): W_hh^T d + z dL/dh(t) + fc_hid^T dhid(t-1)
@@ -1463,6 +1469,8 @@ static int launch_gp_train(hipStream_t st, const SeqArgs& a, int P) {
         hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, a);
         return (int)hipGetLastError();
     };
+    if constexpr (R == 2)
+        if (a.H <= 24) return pg ? launch(gru_gp_train_kernel<R, FM, DG, true, false, true>) : launch(gru_gp_train_kernel<R, FM, DG, false, false, true>);
     return pg ? launch(gru_gp_train_kernel<R, FM, DG, true>) : launch(gru_gp_train_kernel<R, FM, DG, false>);
 }
 // the frozen-model variant (forward + loss + dL/dx): taken while every sequence of the batch is resident at once
@@ -1481,9 +1489,9 @@ static int gp_fz_grid(int P, int R, bool DG, int B, int T) {
 static bool gru_lossdx_uses_gp(const odpd_model_t* m, int B, int T) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P) || gru_uses_s16n(m, B) || gru_split_uses_s16(m, B)) return false;
-    // hidden 17..32 without the fc_hid head: the two-block steps leave nothing to gain over the row-rotated kernel (0.97x measured,
-    // profiles/r03/frozen_pa_bench.md); with it 1.25x, hidden <= 16 1.35-1.85x
-    if (R == 2 && !DG && tuning().gp_max_batch < 0) return false;
+    // hidden 25..32 without the fc_hid head: the two-block steps leave nothing to gain over the row-rotated kernel (0.97x measured,
+    // profiles/r03/frozen_pa_bench.md); 17..24 (second block held twice, 8-rotation dot products) 1.07x, with the head 1.2-1.3x, hidden <= 16 1.35-1.85x
+    if (R == 2 && !DG && m->hidden > 24 && tuning().gp_max_batch < 0) return false;
     const long max_batch = tuning().gp_max_batch;
     if (max_batch >= 0 && B > max_batch) return false;
     return gp_fz_grid(P, R, DG, B, T) > 0;
@@ -1491,10 +1499,14 @@ static bool gru_lossdx_uses_gp(const odpd_model_t* m, int B, int T) {
 template <int R, int FM, bool DG>
 static int launch_gp_lossdx(hipStream_t st, const SeqArgs& a, int P) {
     const size_t lds = gp_fz_lds_bytes(P, R, DG, a.T);
-    auto k = gru_gp_train_kernel<R, FM, DG, false, true>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(gp_fz_grid(P, R, DG, a.B, a.T)), dim3(64), lds, st, a);
-    return (int)hipGetLastError();
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(gp_fz_grid(P, R, DG, a.B, a.T)), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    if constexpr (R == 2)
+        if (a.H <= 24) return launch(gru_gp_train_kernel<R, FM, DG, false, true, true>);
+    return launch(gru_gp_train_kernel<R, FM, DG, false, true>);
 }
 int gru_family_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;

@@ -169,6 +169,23 @@ __device__ __forceinline__ float rotdot(float acc, const float (&w)[16], float h
     return a0 + a1;
 }
 
+// ... over rotations 0..7 only (a block whose 8 units are held twice: odpd_gru.h, fill_gru_tabs<.., HALF>)
+__device__ __forceinline__ float rotdot8(float acc, const float (&w)[16], float h) {
+    float a0 = __builtin_fmaf(w[0], h, acc), a1 = 0.0f;
+#if ODPD_DPP_ASM
+    asm("s_nop 1\n\t"
+        ODPD_DPPF(1, 2, 3, 1) ODPD_DPPF(0, 2, 4, 2) ODPD_DPPF(1, 2, 5, 3) ODPD_DPPF(0, 2, 6, 4)
+        ODPD_DPPF(1, 2, 7, 5) ODPD_DPPF(0, 2, 8, 6) ODPD_DPPF(1, 2, 9, 7)
+        : "+v"(a0), "+v"(a1)
+        : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+#else
+#define ODPD_R1(K, A) A = __builtin_fmaf(w[K], dpp_ror<K>(h), A);
+    ODPD_R1(1, a1) ODPD_R1(2, a0) ODPD_R1(3, a1) ODPD_R1(4, a0) ODPD_R1(5, a1) ODPD_R1(6, a0) ODPD_R1(7, a1)
+#undef ODPD_R1
+#endif
+    return a0 + a1;
+}
+
 // Rotated dot product with the 16 weights delivered as four quads (e.g. ds_read_b128 from an LDS
 // master copy: only 4-8 weight registers are live at a time).  Two accumulator chains.
 #define ODPD_ROTQ_GROUP(K0, K1, K2, K3, Q)                                                          \

@@ -18,10 +18,14 @@ struct GruTabs {
 };
 
 // Cooperative fill (all waves of the block; ends with __syncthreads()).
-template <int R, bool DG, bool WITH_T>
+// HALF (R = 2, hidden 17..24): the second 16-lane block holds its <= 8 units twice (lane c and lane c ^ 8 both carry unit 16 + c % 8), so that
+// a rotated dot product over that block needs rotations 0..7 only — whichever 8 consecutive positions a lane sees, they are the 8 units.
+template <int R, bool DG, bool WITH_T, bool HALF = false>
 __device__ __forceinline__ void fill_gru_tabs(float* tab, const float* pl, const GruLayout& L, int lane, int wave, int nwb) {
     using T = GruTabs<R, DG>;
-    const int H = L.H, col = lane & 15, row = (lane >> 4) & (R - 1), o = 16 * row + col, dir = rot_dir(col);
+    static_assert(!HALF || R == 2, "the half-block layout is for two-block models");
+    const int H = L.H, col = lane & 15, row = (lane >> 4) & (R - 1), dir = rot_dir(col);
+    const int o = 16 * row + ((HALF && row == 1) ? (col & 7) : col);
     float4* t4 = reinterpret_cast<float4*>(tab);
     for (int idx = wave; idx < T::kRows * 4; idx += nwb) {
         const int tr = idx >> 2, q = idx & 3;
@@ -34,7 +38,8 @@ __device__ __forceinline__ void fill_gru_tabs(float* tab, const float* pl, const
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int m = 16 * ((row + rb) % R) + ((col + dir * (4 * q + e)) & 15);
+            const int mb = (row + rb) % R, mp = (col + dir * (4 * q + e)) & 15;
+            const int m = 16 * mb + ((HALF && mb == 1) ? (mp & 7) : mp);
             const bool ok = o < H && m < H;
             v[e] = ok ? pl[base + (transposed ? m * H + o : o * H + m)] : 0.0f;
         }
