@@ -400,8 +400,10 @@ template <int NB> struct GruEvalLds {
 // from row 2) and the chunk's 64 outputs are formed afterwards, one time step per lane.  The next chunk's samples are in flight
 // while the current one is stepped.
 // CK: also writes the BPTT checkpoints (the forward of the split train path)
-template <int NB, int FM, bool DG, bool CK>
+// HALF (NB = 2, hidden 17..24): the second block holds its <= 8 units twice, 8-rotation dot products over it (fill_gru_tabs<.., HALF>)
+template <int NB, int FM, bool DG, bool CK, bool HALF = false>
 __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
+    static_assert(!HALF || NB == 2, "half-block layout: two-block models");
     constexpr int F = FeatDim<FM>::F, EC = kEvalChunk, HS = GruEvalLds<NB>::kHistStride;
     using T = GruTabs<NB, DG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
-    fill_gru_tabs<NB, DG, false>(tab, pl, L, lane, 0, 1);
+    fill_gru_tabs<NB, DG, false, HALF>(tab, pl, L, lane, 0, 1);
     float* ftab = tab + T::kFloats;                    // [EC + 1][8]: entry 1 + i = features of time t0 + i, entry 0 = of time t0 - 1
     float* hist = ftab + (EC + 1) * 8;                 // [EC][HS]: entry i = the head's input of time t0 + i - 1, every lane's copy
     float* hw = hist + EC * HS;                        // fc_out: [2][16 NB] hidden columns (zero padded) | [2][8] feature columns
@@ -428,7 +430,8 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
     float win[NB][F], wrec[NB][NB][16], b_in[NB], b_rec[NB], wo0[NB], wo1[NB];
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
-        const int o = 16 * ob + col;
+        const bool replica = HALF && ob == 1 && col >= 8;                  // the lane carries a second copy of unit 16 + col % 8
+        const int o = 16 * ob + ((HALF && ob == 1) ? (col & 7) : col);
         const bool vo = o < H;
 #pragma unroll
         for (int i = 0; i < F; ++i) win[ob][i] = (vo && role != 2) ? pl[L.o_w_ih + (gate * H + o) * F + i] : 0.0f;
@@ -449,7 +452,8 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
                 for (int k = 0; k < 16; ++k) wrec[ob][kb][k] = 0.0f;
             }
         }
-        wo0[ob] = vo ? pl[L.o_w_out + o] : 0.0f; wo1[ob] = vo ? pl[L.o_w_out + OW + o] : 0.0f;
+        // (fc_out of the last step is a sum over the row's lanes: a replica must not count twice)
+        wo0[ob] = (vo && !replica) ? pl[L.o_w_out + o] : 0.0f; wo1[ob] = (vo && !replica) ? pl[L.o_w_out + OW + o] : 0.0f;
     }
     const float wf0 = (DG && col < 6) ? pl[L.o_w_out + H + col] : 0.0f, wf1 = (DG && col < 6) ? pl[L.o_w_out + OW + H + col] : 0.0f;
     const float bo0 = pl[L.o_b_out], bo1 = pl[L.o_b_out + 1];
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
             for (int ob = 0; ob < NB; ++ob) {
                 arec[ob] = b_rec[ob];
 #pragma unroll
-                for (int kb = 0; kb < NB; ++kb) arec[ob] = rotdot(arec[ob], wrec[ob][kb], h[kb]);
+                for (int kb = 0; kb < NB; ++kb) arec[ob] = (HALF && kb == 1) ? rotdot8(arec[ob], wrec[ob][kb], h[kb]) : rotdot(arec[ob], wrec[ob][kb], h[kb]);
             }
         };
         float2 raw = lane < a.T ? xg[lane] : make_float2(0.5f, 0.5f);
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
                     if ((t1 % kCkptStride) == 0 && t1 < a.T && role == 0) {
                         float* ck = a.ckpt + ((size_t)(b / (4 / NB)) * a.nck + t1 / kCkptStride) * 64 + 16 * NB * (b % (4 / NB)) + col;
 #pragma unroll
-                        for (int ob = 0; ob < NB; ++ob) ck[16 * ob] = h[ob];
+                        for (int ob = 0; ob < NB; ++ob) ck[16 * ob] = (HALF && ob == 1 && col >= 8) ? 0.0f : h[ob];      // (replica lanes: padding units there)
                     }
                 }
             }
@@ -1376,6 +1380,8 @@ static int launch_eval(hipStream_t st, const SeqArgs& a, int P) {
         hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
         return (int)hipGetLastError();
     };
+    if constexpr (NB == 2)
+        if (a.H <= 24) return a.ckpt ? launch(gru_eval_kernel<NB, FM, DG, true, true>) : launch(gru_eval_kernel<NB, FM, DG, false, true>);
     return a.ckpt ? launch(gru_eval_kernel<NB, FM, DG, true>) : launch(gru_eval_kernel<NB, FM, DG, false>);
 }
 bool gru_uses_eval_kernel(const odpd_model_t* m, int B, int T, bool want_ckpt) {

@@ -300,7 +300,7 @@ def test_gate_parallel_train_kernel(bb, H, B, T):
 
 
 @pytest.mark.parametrize("bb", ["gru", "dgru", "qgru", "qgru_amp1"])
-@pytest.mark.parametrize("H", [1, 8, 13, 16, 17, 23, 32])
+@pytest.mark.parametrize("H", [1, 8, 13, 16, 17, 23, 24, 25, 32])
 @pytest.mark.parametrize("B,T", [(1, 700), (3, 2560), (2, 256), (8, 257)])
 def test_evaluation_kernel_matches_the_oracle(bb, H, B, T):
     """inference on a few long sequences (net_eval / run_dpd shapes; torch.no_grad(), so no checkpoints are asked for) runs the
