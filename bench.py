@@ -373,6 +373,28 @@ def main():
                                              {"dpd_fwd": "qat16_fwd_kernel<Q4, NT 1, LUT>", "pa_fwd_loss_dx": "gru16n_kernel<DGRU6, frozen: loss + dL/du>",
                                               "dpd_bwd": "qat16_bwd_kernel<Q4, NT 1, LUT>", "reduce_clip_optimiser": "reduce_partials_kernel + clip_adamw_kernel"})}
         del xc, tc, casc, opt5
+        # the same step at the reference's own batch size (latency regime): GRU-family pairs run the one-launch cascade step
+        # (csrc/gru_cascade.hip: DPD wave + frozen-PA wave per frame), the others the chained one-sequence-per-wave launches
+        if args.ref_batch and args.ref_batch != B:
+            rb = args.ref_batch
+            xr_ = xs_.unfold(0, T, 1)[:rb].permute(0, 2, 1).contiguous()
+            tr_ = xr_.clone()
+            small = {}
+            for name_, dkw, pkw in (("GRU15 -> frozen GRU23 (the registry's default sizes)", dict(hidden_size=15, backbone_type="gru"), dict(hidden_size=23, backbone_type="gru")),
+                                    (f"DGRU{H} -> frozen DGRU{H}", dict(hidden_size=H, backbone_type="dgru"), dict(hidden_size=H, backbone_type="dgru")),
+                                    ("config3: TRes-DeltaGRU15 -> frozen DGRU23", dict(hidden_size=15, backbone_type="deltagru_tcnskip", thx=0.01, thh=0.05),
+                                     dict(hidden_size=23, backbone_type="dgru"))):
+                torch.manual_seed(4)
+                casc = CascadedModel(dpd_model=CoreModel(2, num_layers=1, **dkw), pa_model=CoreModel(2, num_layers=1, **pkw))
+                casc.freeze_pa_model()
+                casc = casc.to(dev)
+                o_ = FusedAdamW(casc, lr=5e-4)
+                el_ = min(run_steps(o_, xr_, tr_, 50, 3, rb * T * 2, None)[0] for _ in range(3))
+                small[name_] = {"ms_per_step": 1e3 * el_ / 50, "value": rb * T * 50 / el_,
+                                "launches": "one (DPD wave + PA wave per frame)" if o_.cascade_one_launch(rb, T, dev) is not None else "chained"}
+                del casc, o_
+            dpd["reference_batch"] = {"batch_per_gpu": rb, "frame_length": T, "unit": "IQ samples/s", "cascades": small}
+            del xr_, tr_
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * B * T / (kern_ms * 1e-3) / 1e9

@@ -314,3 +314,31 @@ def test_native_cascade_epoch_equals_the_python_driven_steps(dpd_bb, dpd_h, pa_b
     assert torch.equal(pa, pb) and torch.equal(pa, pc)
     assert np.allclose(la, lb, rtol=1e-6, atol=0)
     assert torch.equal(qa, qb) and torch.equal(qa, qc)
+
+
+@pytest.mark.parametrize("B,T,one", [(256, 200, True), (257, 200, False), (16, 700, False), (256, 50, True), (300, 50, False)])
+def test_one_launch_cascade_envelope(B, T, one):
+    """The one-launch step serves batches whose frames are all resident at once (LDS: both models' parameters, weight tables and per-frame state -> one workgroup per
+    CU: 256 frames); beyond that — more frames, frames too long for LDS — the chained launches take the step, with the same results."""
+    from opendpd_amd import CascadedModel, CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    lib = _lib.load()
+    rng = np.random.RandomState(B + T)
+    x = torch.from_numpy((rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)).cuda()
+    t = torch.from_numpy((0.4 * rng.randn(B, T, 2)).astype(np.float32)).cuda()
+    res = []
+    try:
+        for knob in (1, 0):
+            assert lib.odpd_set_tuning(b"cascade_one_launch", knob) == 0
+            torch.manual_seed(5)
+            net = CascadedModel(dpd_model=CoreModel(2, 13, 1, "dgru"), pa_model=CoreModel(2, 23, 1, "dgru"))
+            net.freeze_pa_model()
+            net = net.cuda()
+            opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+            assert (opt.cascade_one_launch(B, T, x.device) is not None) == (one and knob == 1)
+            loss = fused_train_step(opt, x, t, "l2", 0.0).item()
+            res.append((loss, opt.grad[:-4].clone()))
+    finally:
+        lib.odpd_set_tuning(b"cascade_one_launch", 1)
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * max(1.0, abs(res[0][0]))
+    assert rel_err(res[0][1].cpu().numpy(), res[1][1].cpu().numpy()) < (1e-4 if one else 1e-12)

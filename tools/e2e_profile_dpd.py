@@ -17,6 +17,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 pa = dict(dataset_name="DPA_200MHz", PA_backbone="dgru", PA_hidden_size=23, frame_length=200, batch_size=64, lr=1e-3, seed=0, accelerator="cuda")
 od.train_pa(n_epochs=2, **pa)
 kw = dict(pa, DPD_backbone="deltagru_tcnskip", DPD_hidden_size=15, thx=0.01, thh=0.05)
+if len(sys.argv) > 2 and sys.argv[2] == "gru":      # GRU-family pair: the one-launch cascade step + native epoch loop
+    kw = dict(pa, DPD_backbone="dgru", DPD_hidden_size=13)
 od.train_dpd(n_epochs=1, **kw)   # warm-up
 pr = cProfile.Profile()
 t0 = time.time(); pr.enable()
