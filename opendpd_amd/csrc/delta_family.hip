@@ -42,7 +42,7 @@ __device__ __forceinline__ void fill_delta_tabs(float* tab, const float* pl, con
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int m = (col + dir * (4 * q + e)) & 15;
-            const bool ok = o < H && m < H;
+            const bool ok = o < H && m < H && g < L.G;
             v[e] = ok ? pl[L.o_w_hh + g * H * H + (transposed ? m * H + o : o * H + m)] : 0.0f;
         }
         t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
@@ -268,11 +268,14 @@ __global__ __launch_bounds__(kMaxThreads) void delta_fwd_kernel(SeqArgs a) {
 // Same thresholded arithmetic per element as delta_cell_fwd (accumulation order included); the sparsity counters are kept.
 // -------------------------------------------------------------------------------------------------
 constexpr int kDEvalHistStride = 64 + 4;
-template <bool TRES, bool CK>      // CK: also writes the BPTT checkpoints (the forward of the split train path)
+// JAN: deltajanet (backbones/deltajanet.py:229-251) — the same delta formulation with TWO gates, rows f | g | - | -: f = sigmoid(dm_f),
+// g = sigmoid(dm_g), h = (1 - f) g + f h; its thresholds are fixed at 0 (deltajanet.py:23-27), fc_out has a bias, no TCN skip.
+template <bool TRES, bool CK, bool JAN = false>      // CK: also writes the BPTT checkpoints (the forward of the split train path)
 __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
+    static_assert(!(JAN && (TRES || CK)), "deltajanet: plain head, no row-rotated backward to write checkpoints for");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // r | z | n | -
-    const DeltaLayout L = delta_layout(a.H, TRES);
+    const DeltaLayout L = delta_layout(a.H, TRES, JAN ? 2 : 3);
     const int H = L.H, T = a.T;
     float* pl = smem;
     stage_params(pl, a.params, L.P);
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
     float* hw = hist + kEvalChunk * HS;                                        // fc_out [2][16], zero padded
     if (lane < 32) hw[lane] = (lane & 15) < L.H ? pl[L.o_w_out + (lane >> 4) * L.H + (lane & 15)] : 0.0f;
     wave_lds_fence();
-    const bool vo = col < H, gate_row = role < 3;
+    const bool vo = col < H, gate_row = role < (JAN ? 2 : 3);
     float wrec[16], wih[6];
     load_rot(wrec, to_tab(reinterpret_cast<const float4*>(tab) + lane) + (gate_row ? role : 0) * 4 * 64);
 #pragma unroll
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
     float accx0 = 0.0f, acch0 = 0.0f;
     if (!TRES && vo) {
         if (role < 2) accx0 = pl[L.o_b_ih + role * H + col] + pl[L.o_b_hh + role * H + col];
-        if (role == 2) { accx0 = pl[L.o_b_ih + 2 * H + col]; acch0 = pl[L.o_b_hh + 2 * H + col]; }
+        if (role == 2 && !JAN) { accx0 = pl[L.o_b_ih + 2 * H + col]; acch0 = pl[L.o_b_hh + 2 * H + col]; }
     }
     const int fc = col < 6 ? col : 5;
     const float bo0 = TRES ? 0.0f : pl[L.o_b_out], bo1 = TRES ? 0.0f : pl[L.o_b_out + 1];
@@ -366,15 +369,20 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
                 const float dhm = !(adh < thh) ? dhv : 0.0f;
                 hp = (adh >= thh) ? h : hp;
                 zh += (vo && dhm == 0.0f) ? 1.0f : 0.0f;
-                const bool nrow = role == 2;
+                const bool nrow = !JAN && role == 2;
                 const float res = rotdot(nrow ? acch : ax, wrec, dhm);            // rows r, z: dm += W_ih dx + W_hh dh; row n: dm_nh += W_hn dh
                 accx = nrow ? ax : res; acch = nrow ? res : acch;
                 const float sg = sigmoidf_(res);
-                const float r = xor32(sg);                                        // row 2 <- r of row 0
-                const float n = tanhf_(__builtin_fmaf(r, res, ax));               // row 2
                 float g4[4];
-                gather_rows(nrow ? n : sg, g4);
-                h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
+                if constexpr (JAN) {
+                    gather_rows(sg, g4);                                          // f, g on every row
+                    h = __builtin_fmaf(g4[0], h - g4[1], g4[1]);                  // (1 - f) g + f h
+                } else {
+                    const float r = xor32(sg);                                    // row 2 <- r of row 0
+                    const float n = tanhf_(__builtin_fmaf(r, res, ax));           // row 2
+                    gather_rows(nrow ? n : sg, g4);
+                    h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
+                }
                 hist[tt * HS + lane] = h;
                 if constexpr (CK) {                  // BPTT checkpoints in the layout of the row-rotated backward (lane = 16 s + col, kDState planes)
                     const int t1 = t0 + tt + 1;
@@ -643,17 +651,20 @@ __host__ __device__ inline int delta_gp_buffer_floats(int T) {
     const int buf = Tp * 8 + (Tp + 1) * 16 + Tp * 64 + Tp * 32 + Tp * 8 + Tp * 2 + 256;
     return buf > kDTabFloats ? buf : kDTabFloats;
 }
-template <bool TRES>
+// JAN: deltajanet, rows f | g | - | - (as delta_eval_kernel<.., JAN>): accumulator gradients G_f += dL/dh (h(t-1) - g) f (1 - f),
+// G_g += dL/dh (1 - f) g (1 - g), dL/dh(t-1) = f dL/dh + the delta path.
+template <bool TRES, bool JAN = false>
 __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
+    static_assert(!(JAN && TRES), "deltajanet: plain head");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // r | z | n | -
-    const DeltaLayout L = delta_layout(a.H, TRES);
+    const DeltaLayout L = delta_layout(a.H, TRES, JAN ? 2 : 3);
     const int H = L.H, T = a.T, Tp = (T + 63) & ~63;
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
     fill_delta_tabs<true>(tab, pl, L, lane, 0, 1);
-    const bool vo = col < H, gate_row = role < 3;
+    const bool vo = col < H, gate_row = role < (JAN ? 2 : 3);
     float wrec[16], wT[16], wih[6];
     {
         TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
     float accx0 = 0.0f, acch0 = 0.0f;
     if (!TRES && vo) {
         if (role < 2) accx0 = pl[L.o_b_ih + role * H + col] + pl[L.o_b_hh + role * H + col];
-        if (role == 2) { accx0 = pl[L.o_b_ih + 2 * H + col]; acch0 = pl[L.o_b_hh + 2 * H + col]; }
+        if (role == 2 && !JAN) { accx0 = pl[L.o_b_ih + 2 * H + col]; acch0 = pl[L.o_b_hh + 2 * H + col]; }
     }
     const int fc = col < 6 ? col : 5;
     const float wo0 = vo ? pl[L.o_w_out + col] : 0.0f, wo1 = vo ? pl[L.o_w_out + H + col] : 0.0f;
@@ -747,16 +758,22 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
                     const bool keeph = !(adh < thh);
                     const float dhm = keeph ? dhv : 0.0f;
                     hp = (adh >= thh) ? h : hp;
-                    const bool nrow = role == 2;
+                    const bool nrow = !JAN && role == 2;
                     const float res = rotdot(nrow ? acch : ax, wrec, dhm);
                     accx = nrow ? ax : res; acch = nrow ? res : acch;
                     const float sg = sigmoidf_(res);
-                    const float r = xor32(sg);                                        // row 2 <- r of row 0
-                    const float n = tanhf_(__builtin_fmaf(r, res, ax));               // row 2
                     float g4[4];
-                    gather_rows(nrow ? n : sg, g4);
-                    h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
-                    *reinterpret_cast<float4*>(smem + q4) = make_float4(r, g4[1], g4[2], res);
+                    if constexpr (JAN) {
+                        gather_rows(sg, g4);
+                        h = __builtin_fmaf(g4[0], h - g4[1], g4[1]);
+                        *reinterpret_cast<float4*>(smem + q4) = make_float4(g4[0], g4[1], 0.0f, 0.0f);       // f, g
+                    } else {
+                        const float r = xor32(sg);                                    // row 2 <- r of row 0
+                        const float n = tanhf_(__builtin_fmaf(r, res, ax));           // row 2
+                        gather_rows(nrow ? n : sg, g4);
+                        h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
+                        *reinterpret_cast<float4*>(smem + q4) = make_float4(r, g4[1], g4[2], res);
+                    }
                     *reinterpret_cast<float2*>(smem + q2) = make_float2(dhm, keeph ? 1.0f : 0.0f);
                     smem[q1] = role == 3 ? h : dm;
                     q4 += p4_step; q2 += p2_step; q1 += p1_step;
@@ -806,18 +823,30 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
                 const float2 dd = reinterpret_cast<const float2*>(dm2)[t * 16 + col];
                 const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
                 const float fsx = col < 6 ? dmx[t * 8 + col] : 0.0f;
-                const float r = g.x, z = g.y, n = g.z, nh = g.w, dhm = dd.x, mk = dd.y;
+                const float dhm = dd.x, mk = dd.y;
                 const float gh = gh_c + __builtin_fmaf(dyv.x, wo0, dyv.y * wo1);
                 dwo0 = __builtin_fmaf(dyv.x, ht, dwo0); dwo1 = __builtin_fmaf(dyv.y, ht, dwo1);
-                const float dn = gh * (1.0f - z), dz = gh * (hprev - n);
-                float ghprev = gh * z;
-                const float dpre = dn * __builtin_fmaf(-n, n, 1.0f);
-                gn += dpre;
-                const float c_nh = __builtin_fmaf(dpre, r, accg), c_r = __builtin_fmaf(dpre * nh, r * (1.0f - r), accg),
-                            c_z = __builtin_fmaf(dz, z * (1.0f - z), accg);
-                accg = vsel(rm.m[0], c_r, vsel(rm.m[1], c_z, c_nh));
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(accg, dhm, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(vsel(rm.m[2], gn, accg), fsx, acc2, 0, 0, 0);
+                float ghprev;
+                if constexpr (JAN) {
+                    const float f = g.x, gg = g.y;
+                    const float dg = gh * (1.0f - f), df = gh * (hprev - gg);
+                    ghprev = gh * f;
+                    const float c_f = __builtin_fmaf(df, f * (1.0f - f), accg), c_g = __builtin_fmaf(dg, gg * (1.0f - gg), accg);
+                    accg = vsel(rm.m[0], c_f, vsel(rm.m[1], c_g, 0.0f));
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(accg, dhm, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(accg, fsx, acc2, 0, 0, 0);
+                } else {
+                    const float r = g.x, z = g.y, n = g.z, nh = g.w;
+                    const float dn = gh * (1.0f - z), dz = gh * (hprev - n);
+                    ghprev = gh * z;
+                    const float dpre = dn * __builtin_fmaf(-n, n, 1.0f);
+                    gn += dpre;
+                    const float c_nh = __builtin_fmaf(dpre, r, accg), c_r = __builtin_fmaf(dpre * nh, r * (1.0f - r), accg),
+                                c_z = __builtin_fmaf(dz, z * (1.0f - z), accg);
+                    accg = vsel(rm.m[0], c_r, vsel(rm.m[1], c_z, c_nh));
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(accg, dhm, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(vsel(rm.m[2], gn, accg), fsx, acc2, 0, 0, 0);
+                }
                 float ddh = rotdot(0.0f, wT, accg);
                 ddh += xor16(ddh);
                 ddh += xor32(ddh);
@@ -847,12 +876,12 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
         if (lane == 0) { prow[L.o_b_out] = b0; prow[L.o_b_out + 1] = b1; }
         if (vo) {
             if (role < 2) { prow[L.o_b_ih + role * H + col] = dbg; prow[L.o_b_hh + role * H + col] = dbg; }
-            if (role == 2) { prow[L.o_b_ih + 2 * H + col] = dbn; prow[L.o_b_hh + 2 * H + col] = dbg; }
+            if (role == 2 && !JAN) { prow[L.o_b_ih + 2 * H + col] = dbn; prow[L.o_b_hh + 2 * H + col] = dbg; }
         }
     }
     // MFMA block k = gate k (r, z, n); register 4 k + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < (JAN ? 2 : 3); ++k)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int i = 4 * role + rr;
@@ -932,7 +961,35 @@ static int delta_launch_gp_bwd(hipStream_t st, const odpd_model_t* m, const SeqA
     return (int)hipGetLastError();
 }
 
+// deltajanet's home is delta_s16.hip (every batch, dL/dx, hidden <= 32); at the reference's own batch sizes — every sequence on a SIMD of its
+// own — hidden <= 16 without dL/dx takes the one-sequence-per-wave kernels: delta_eval_kernel<.., JAN> as the forward (it writes no
+// checkpoints: the backward below runs the forward again) and delta_gp_bwd_kernel<.., JAN>
+static int jan_P(const odpd_model_t* m) { return delta_layout(m->hidden, 0, 2).P; }
+static bool jan_gp_ok(const odpd_model_t* m) {
+    return m->backbone == ODPD_DELTAJANET && m->hidden <= 16 && !(m->flags & ODPD_FLAG_NEED_DX) && tuning().s16_min_batch != 0 &&
+           tuning().gp_max_batch != 0;
+}
+static bool jan_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    if (!jan_gp_ok(m)) return false;
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0) return B <= max_batch && delta_gp_blocks_per_cu(jan_P(m), T) > 0;
+    // up to three frames per workgroup in turn: still ahead of the 16-sequence waves there (768 x 200: 0.31 vs 0.44 ms, profiles/r03/gp_train_bench.txt)
+    return (long)B <= 3L * device_cus() * delta_gp_blocks_per_cu(jan_P(m), T);
+}
+static int jan_gp_rows(const odpd_model_t* m, int B, int T) {
+    const long cap = (long)device_cus() * (kMaxLds / delta_gp_lds_bytes(jan_P(m), T));
+    return B < cap ? B : (int)cap;
+}
+static int jan_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
+    const size_t lds = ((size_t)pad4(P) + kDTabFloats + kEvalChunk * 8 + kEvalChunk * kDEvalHistStride + 32) * sizeof(float);
+    auto k = delta_eval_kernel<false, false, true>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
+    return (int)hipGetLastError();
+}
 int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (jan_gp_ok(m) && ((a.ckpt == nullptr && a.B <= 2 * device_cus()) || (a.ckpt != nullptr && jan_train_uses_gp(m, a.B, a.T))))
+        return jan_launch_eval(st, a, jan_P(m));
     if (delta_uses_s16(m, a.B)) return delta_s16_launch(st, m, a, 1);
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
@@ -942,6 +999,14 @@ int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     return tres ? delta_launch_fwd<true>(st, a, P) : delta_launch_fwd<false>(st, a, P);
 }
 int delta_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (a.dx == nullptr && a.partials != nullptr && jan_train_uses_gp(m, a.B, a.T)) {
+        const int P = jan_P(m);
+        const size_t lds = delta_gp_lds_bytes(P, a.T);
+        auto k = delta_gp_bwd_kernel<false, true>;
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(jan_gp_rows(m, a.B, a.T)), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    }
     if (delta_uses_s16(m, a.B)) return delta_s16_launch(st, m, a, 2);
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     const bool tres = m->backbone == ODPD_TRES_DELTAGRU;
@@ -951,6 +1016,7 @@ int delta_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     return tres ? delta_launch_bwd<true>(st, a, P) : delta_launch_bwd<false>(st, a, P);
 }
 int delta_family_rows(const odpd_model_t* m, int B, int T) {
+    if (jan_train_uses_gp(m, B, T)) return jan_gp_rows(m, B, T);
     if (delta_uses_s16(m, B)) return delta_s16_rows(m, B);
     if (m->hidden > 16) return ODPD_EUNSUPPORTED;
     if (delta_bwd_uses_gp(m, B, T)) return delta_gp_rows(m, B, T);

@@ -8,6 +8,8 @@ import time
 
 import torch
 
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from opendpd_amd import CoreModel, _lib
 from opendpd_amd.train_funcs import FrameBatch, FusedAdamW, fused_train_step
@@ -18,7 +20,7 @@ lib = _lib.load()
 
 def step_ms(bb, H, B, T, gp_max_batch):
     lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(gp_max_batch))
-    framed = bb not in ("lstm", "vdlstm", "pgjanet", "deltagru", "deltagru_tcnskip")            # the LSTM family takes materialised (B, T, 2) frames
+    framed = bb not in ("lstm", "vdlstm", "pgjanet", "deltagru", "deltagru_tcnskip", "deltajanet")            # the LSTM family takes materialised (B, T, 2) frames
     xs, ys = bench.synth_frames(B, T, 0, dev, materialize=not framed)
     torch.manual_seed(0)
     net = CoreModel(2, H, 1, bb).to(dev)
@@ -37,7 +39,7 @@ def step_ms(bb, H, B, T, gp_max_batch):
     return best, float(loss)
 
 
-for bb, H in (("gru", 11), ("dgru", 13), ("dgru", 23), ("gru", 23), ("qgru", 10), ("qgru_amp1", 16), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11), ("deltagru", 15), ("deltagru_tcnskip", 15)):
+for bb, H in (("gru", 11), ("dgru", 13), ("dgru", 23), ("gru", 23), ("qgru", 10), ("qgru_amp1", 16), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11), ("deltagru", 15), ("deltagru_tcnskip", 15), ("deltajanet", 15)):
     for B, T in ((64, 50), (256, 50), (1024, 50), (64, 200), (256, 200), (512, 200), (768, 200), (1024, 200), (2048, 200)):
         a, la = step_ms(bb, H, B, T, 0)
         g, lg = step_ms(bb, H, B, T, 1 << 30)
