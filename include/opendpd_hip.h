@@ -156,15 +156,16 @@ int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss_kind, int 
 
 /* The whole train_dpd step body — y = PA(DPD(x)) with the PA frozen, loss, dL/d(DPD parameters) — in ONE launch, for the reference's own
  * batch sizes (64 .. 256 frames, train_funcs.py:28-48): the DPD and the PA of a frame run as the two waves of a workgroup and hand the
- * frame over through LDS (csrc/gru_cascade.hip).  Served: float gru / dgru / qgru / qgru_amp1 DPD of hidden <= 16 in front of a float
- * gru / dgru PA of hidden <= 32, batches whose frames are all resident at once (odpd_cascade_rows > 0); otherwise
- * ODPD_EUNSUPPORTED: chain odpd_backbone_fwd, odpd_frozen_loss_dx, odpd_backbone_bwd.  `partials` is (rows, P_dpd + 4), column
- * P_dpd = un-normalised loss partial sum; `frame_idx` (device, may be NULL) addresses x / target as windows of resident streams:
- * frame b starts at sample frame_idx[b] * frame_stride. */
+ * frame over through LDS (csrc/gru_cascade.hip).  Served: float gru / dgru / qgru / qgru_amp1 / deltagru / deltagru_tcnskip DPD of
+ * hidden <= 16 in front of a float gru / dgru PA of hidden <= 32, batches whose frames are all resident at once
+ * (odpd_cascade_rows > 0); otherwise ODPD_EUNSUPPORTED: chain odpd_backbone_fwd, odpd_frozen_loss_dx, odpd_backbone_bwd.
+ * `partials` is (rows, P_dpd + 4), column P_dpd = un-normalised loss partial sum; `frame_idx` (device, may be NULL) addresses x /
+ * target as windows of resident streams: frame b starts at sample frame_idx[b] * frame_stride; `dpd_stats` (may be NULL): the four
+ * sparsity counters of a delta DPD's forward passes, as odpd_backbone_fwd's `stats`. */
 int64_t odpd_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T);
 int odpd_cascade_fwd_bwd(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, int B, int T, int64_t count,
                          const float* dpd_params, const float* pa_params, const float* x, const float* target,
-                         const int64_t* frame_idx, int frame_stride, float* partials);
+                         const int64_t* frame_idx, int frame_stride, float* partials, double* dpd_stats);
 
 typedef struct odpd_frames {
     const float* x_stream;  /* (N,2) device: model input stream */
@@ -231,7 +232,7 @@ int odpd_train_epoch_opt(void* stream, const odpd_model_t* m, int loss_kind, con
 int odpd_train_epoch_cascade(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, const odpd_frames_t* fr,
                              int batch, int opt_kind, float* dpd_params, const float* pa_params, float* grad, float* state1,
                              float* state2, int64_t first_step, double lr, double beta1, double beta2, double eps, double weight_decay,
-                             double max_norm, float* partials, float* losses_out);
+                             double max_norm, float* partials, double* dpd_stats, float* losses_out);
 
 
 /* The epoch loop for a backbone WITHOUT a fused train kernel at this batch shape: per step the frames are gathered into (B,T,2)

@@ -278,18 +278,23 @@ extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss
     return gru_family_lossdx((hipStream_t)stream, m, a);
 }
 
+// DPDs of the one-launch cascade step: the float GRU family and the float delta-GRU backbones (gru_cascade.hip)
+static bool cascade_dpd_family(const odpd_model_t* m) {
+    return family_of(m) == FAM_GRU || (family_of(m) == FAM_DELTA && m->backbone != ODPD_DELTAJANET);
+}
 extern "C" int64_t odpd_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T) {
     if (!model_ok(dpd) || !model_ok(pa) || B <= 0 || T <= 0) return ODPD_EINVAL;
-    if (family_of(dpd) != FAM_GRU || family_of(pa) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    if (!cascade_dpd_family(dpd) || family_of(pa) != FAM_GRU) return ODPD_EUNSUPPORTED;
     return gru_cascade_rows(dpd, pa, B, T);
 }
 extern "C" int odpd_cascade_fwd_bwd(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, int B, int T, int64_t count,
                                     const float* dpd_params, const float* pa_params, const float* x, const float* target,
-                                    const int64_t* frame_idx, int frame_stride, float* partials) {
+                                    const int64_t* frame_idx, int frame_stride, float* partials, double* dpd_stats) {
     if (!model_ok(dpd) || !model_ok(pa) || !dpd_params || !pa_params || !x || !target || !partials || B <= 0 || T <= 0 || count <= 0)
         return ODPD_EINVAL;
-    if (family_of(dpd) != FAM_GRU || family_of(pa) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    if (!cascade_dpd_family(dpd) || family_of(pa) != FAM_GRU) return ODPD_EUNSUPPORTED;
     CascArgs a{};
+    a.thx = dpd->thx; a.thh = dpd->thh; a.stats = dpd_stats;
     a.dpd_params = dpd_params; a.pa_params = pa_params; a.x = x; a.target = target; a.partials = partials;
     a.frame_idx = reinterpret_cast<const long long*>(frame_idx); a.frame_stride = frame_stride;
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.B = B; a.T = T; a.Hd = dpd->hidden; a.Hp = pa->hidden;
@@ -413,7 +418,7 @@ static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, 
 extern "C" int odpd_train_epoch_cascade(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, const odpd_frames_t* fr,
                                         int batch, int opt_kind, float* dpd_params, const float* pa_params, float* grad, float* state1,
                                         float* state2, int64_t first_step, double lr, double beta1, double beta2, double eps,
-                                        double weight_decay, double max_norm, float* partials, float* losses_out) {
+                                        double weight_decay, double max_norm, float* partials, double* dpd_stats, float* losses_out) {
     if (!model_ok(dpd) || !model_ok(pa) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
         fr->stride <= 0 || batch <= 0 || !dpd_params || !pa_params || !grad || !state1 || !state2 || !partials || !losses_out || first_step <= 0 ||
         opt_kind > ODPD_OPT_RMSPROP)
@@ -430,7 +435,7 @@ extern "C" int odpd_train_epoch_cascade(void* stream, const odpd_model_t* dpd, c
         const int64_t count = (int64_t)B * T * 2;
         const float inv_count = (float)(1.0 / (double)count);
         int rc = odpd_cascade_fwd_bwd(stream, dpd, pa, loss_kind, B, T, count, dpd_params, pa_params, fr->x_stream, fr->y_stream, fr->order + f0,
-                                      fr->stride, partials);
+                                      fr->stride, partials, dpd_stats);
         if (rc) return rc;
         rc = odpd_reduce_partials(stream, odpd_cascade_rows(dpd, pa, B, T), P, partials, grad, 0);
         if (rc) return rc;

@@ -162,6 +162,8 @@ struct CascArgs {
     const long long* frame_idx;
     int frame_stride;
     float inv_count;
+    float thx, thh;            // delta DPD: its thresholds
+    double* stats;             // delta DPD: sparsity counters of the forward passes (nullable)
     int loss_kind, B, T, Hd, Hp;
 };
 int gru_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T);

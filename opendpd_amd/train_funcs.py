@@ -351,7 +351,8 @@ class FusedAdamW:
                                           _lib.ptr(pa.flat_params(full_check=True)), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
                                           _lib.ptr(self.exp_avg_sq), self.step_count + 1, float(g["lr"]), float(g["betas"][0]) if adamw else 0.0,
                                           float(g["betas"][1]) if adamw else 0.0, float(g["eps"]) if adamw else 0.0,
-                                          float(g["weight_decay"]) if adamw else 0.0, float(max_norm or 0.0), _lib.ptr(part), _lib.ptr(losses))
+                                          float(g["weight_decay"]) if adamw else 0.0, float(max_norm or 0.0), _lib.ptr(part),
+                                          _lib.ptr(dpd._stats_buffer(dev)), _lib.ptr(losses))
         _lib.check(rc, "odpd_train_epoch_cascade")
         self.step_count += n_steps
         self._keepalive = order     # the launches read `order` asynchronously
@@ -531,7 +532,8 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count, timing=
         # the reference's own batch sizes, GRU-family DPD and PA: the whole step body as one launch (csrc/gru_cascade.hip)
         mark("cascade_fwd_loss_bwd")
         _lib.check(lib.odpd_cascade_fwd_bwd(st, C.byref(dpd.desc), C.byref(pa.desc), _lib.LOSS_IDS[loss_kind], B, T, count, _lib.ptr(fd),
-                                            _lib.ptr(fp), _lib.ptr(x), _lib.ptr(target), None, 0, _lib.ptr(one)), "cascade fwd + loss + bwd")
+                                            _lib.ptr(fp), _lib.ptr(x), _lib.ptr(target), None, 0, _lib.ptr(one), _lib.ptr(dpd._stats_buffer(x.device))),
+                   "cascade fwd + loss + bwd")
         mark("reduce_clip_optimiser")
         # (column P of the rows = loss partial sums: the reduced loss travels with the gradient through the one all-reduce)
         _lib.check(lib.odpd_reduce_partials(st, one.shape[0], dpd.n_flat, _lib.ptr(one), _lib.ptr(opt.grad), 0), "reduce")

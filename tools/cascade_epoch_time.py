@@ -26,7 +26,8 @@ print("| cascade | frames x length, batch | chained launches from Python (ms / e
 print("|---|---|---|---|---|")
 for dpd_kw, pa_kw in ((dict(hidden_size=15, backbone_type="gru"), dict(hidden_size=23, backbone_type="gru")),
                       (dict(hidden_size=13, backbone_type="dgru"), dict(hidden_size=13, backbone_type="dgru")),
-                      (dict(hidden_size=8, backbone_type="dgru"), dict(hidden_size=8, backbone_type="dgru"))):
+                      (dict(hidden_size=8, backbone_type="dgru"), dict(hidden_size=8, backbone_type="dgru")),
+                      (dict(hidden_size=15, backbone_type="deltagru_tcnskip", thx=0.01, thh=0.05), dict(hidden_size=23, backbone_type="dgru"))):
     for T, B in ((50, 64), (200, 64), (200, 256)):
         times = []
         for knob in (0, 1):
