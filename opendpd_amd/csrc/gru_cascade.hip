@@ -13,6 +13,7 @@
 // The per-step arithmetic is gru_gp_train_kernel's (same gate-parallel mapping: rows r | n | head | z of a wave, one rotated dot
 // product per step and orientation); the DPD has hidden <= 16, the PA hidden <= 32 (two 16-unit blocks).
 // One partial-gradient row per workgroup: (P_dpd + kLossCols), column P_dpd = the loss partial sum.
+// delta_cascade_kernel: the same workgroup with a deltagru / TRes-DeltaGRU DPD (odpd_deltaseq.h).
 #include "odpd_gpseq.h"
 #include "odpd_deltaseq.h"
 
