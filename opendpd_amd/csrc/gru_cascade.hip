@@ -70,9 +70,10 @@ __device__ __forceinline__ void casc_pa_wave(const CascArgs& a, float* smem, flo
 }
 
 // PA variants: PV = 0 hidden <= 16 | 1 hidden 17..24 (two blocks, the second held twice) | 2 hidden 25..32
-template <int FMD, bool DGD, int PV, int FMP, bool DGP>
+// NBD: unit blocks of the DPD (1: hidden <= 16, 2: hidden 17..32 — e.g. the qgru H20 / H30 of quant_qgru_dpd_regr.sh's float stage)
+template <int NBD, int FMD, bool DGD, int PV, int FMP, bool DGP>
 __global__ __launch_bounds__(128) void gru_cascade_kernel(CascArgs a) {
-    using D = GpSeq<1, FMD, DGD, true>;
+    using D = GpSeq<NBD, FMD, DGD, true>;
     using P = GpSeq<PV == 0 ? 1 : 2, FMP, DGP, false, PV == 1>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(128) void delta_cascade_kernel(CascArgs a) {
 // -------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kDpdDelta = 100, kDpdTres = 101;      // CascCfg::fmd of the delta DPDs (the GRU-family ones carry their feature mode)
-struct CascCfg { int fmd, fmp, pv, Pd, Pp; bool dgd, dgp; };
+struct CascCfg { int fmd, fmp, pv, nbd, Pd, Pp; bool dgd, dgp; };
 bool casc_model(const odpd_model_t* m, int& fm, bool& dg) {
     if (m->bits_w > 0) return false;
     switch (m->backbone) {
@@ -201,7 +202,8 @@ bool casc_cfg(const odpd_model_t* dpd, const odpd_model_t* pa, CascCfg& c) {
     const bool delta = dpd->bits_w == 0 && (dpd->backbone == ODPD_DELTAGRU || dpd->backbone == ODPD_TRES_DELTAGRU);
     if (delta) { c.fmd = dpd->backbone == ODPD_TRES_DELTAGRU ? kDpdTres : kDpdDelta; c.dgd = false; }
     else if (!casc_model(dpd, c.fmd, c.dgd)) return false;
-    if (dpd->hidden < 1 || dpd->hidden > 16 || pa->hidden < 1 || pa->hidden > 32) return false;
+    if (dpd->hidden < 1 || dpd->hidden > (delta ? 16 : 32) || pa->hidden < 1 || pa->hidden > 32) return false;
+    c.nbd = dpd->hidden > 16 ? 2 : 1;
     if (c.fmp != FEAT_RAW2 && c.fmp != FEAT_DGRU6) return false;      // PAs of the reference's scripts: gru, dgru
     c.pv = pa->hidden > 24 ? 2 : pa->hidden > 16 ? 1 : 0;
     c.Pd = delta ? delta_layout(dpd->hidden, c.fmd == kDpdTres).P : gru_layout(dpd->hidden, feat_dim(c.fmd), c.dgd).P;
@@ -209,33 +211,37 @@ bool casc_cfg(const odpd_model_t* dpd, const odpd_model_t* pa, CascCfg& c) {
     return true;
 }
 // the DPD engine of a CascCfg::fmd
-template <int FMD, bool DGD> struct DpdEngine { using type = GpSeq<1, FMD, DGD, true>; };
-template <> struct DpdEngine<kDpdDelta, false> { using type = DeltaSeq<false>; };
-template <> struct DpdEngine<kDpdTres, false> { using type = DeltaSeq<true>; };
-template <int FMD, bool DGD, int PV, int FMP, bool DGP>
+template <int NBD, int FMD, bool DGD> struct DpdEngine { using type = GpSeq<NBD, FMD, DGD, true>; };
+template <> struct DpdEngine<1, kDpdDelta, false> { using type = DeltaSeq<false>; };
+template <> struct DpdEngine<1, kDpdTres, false> { using type = DeltaSeq<true>; };
+template <int NBD, int FMD, bool DGD, int PV, int FMP, bool DGP>
 size_t casc_lds(int T, int Pd, int Pp) {
-    return ((size_t)DpdEngine<FMD, DGD>::type::region_floats(T, Pd) + GpSeq<PV == 0 ? 1 : 2, FMP, DGP, false, PV == 1>::region_floats(T, Pp) + 4) *
+    return ((size_t)DpdEngine<NBD, FMD, DGD>::type::region_floats(T, Pd) + GpSeq<PV == 0 ? 1 : 2, FMP, DGP, false, PV == 1>::region_floats(T, Pp) + 4) *
            sizeof(float);
 }
-#define ODPD_CASC_PA(FMD_, DGD_, CALL)                                                                  \
-    if (c.fmd == FMD_) {                                                                                \
-        if (c.pv == 0 && c.fmp == FEAT_RAW2) return CALL(FMD_, DGD_, 0, FEAT_RAW2, false);              \
-        if (c.pv == 1 && c.fmp == FEAT_RAW2) return CALL(FMD_, DGD_, 1, FEAT_RAW2, false);              \
-        if (c.pv == 2 && c.fmp == FEAT_RAW2) return CALL(FMD_, DGD_, 2, FEAT_RAW2, false);              \
-        if (c.pv == 0 && c.fmp == FEAT_DGRU6) return CALL(FMD_, DGD_, 0, FEAT_DGRU6, true);             \
-        if (c.pv == 1 && c.fmp == FEAT_DGRU6) return CALL(FMD_, DGD_, 1, FEAT_DGRU6, true);             \
-        if (c.pv == 2 && c.fmp == FEAT_DGRU6) return CALL(FMD_, DGD_, 2, FEAT_DGRU6, true);             \
+#define ODPD_CASC_PA(NBD_, FMD_, DGD_, CALL)                                                            \
+    if (c.nbd == NBD_ && c.fmd == FMD_) {                                                               \
+        if (c.pv == 0 && c.fmp == FEAT_RAW2) return CALL(NBD_, FMD_, DGD_, 0, FEAT_RAW2, false);        \
+        if (c.pv == 1 && c.fmp == FEAT_RAW2) return CALL(NBD_, FMD_, DGD_, 1, FEAT_RAW2, false);        \
+        if (c.pv == 2 && c.fmp == FEAT_RAW2) return CALL(NBD_, FMD_, DGD_, 2, FEAT_RAW2, false);        \
+        if (c.pv == 0 && c.fmp == FEAT_DGRU6) return CALL(NBD_, FMD_, DGD_, 0, FEAT_DGRU6, true);       \
+        if (c.pv == 1 && c.fmp == FEAT_DGRU6) return CALL(NBD_, FMD_, DGD_, 1, FEAT_DGRU6, true);       \
+        if (c.pv == 2 && c.fmp == FEAT_DGRU6) return CALL(NBD_, FMD_, DGD_, 2, FEAT_DGRU6, true);       \
     }
-#define ODPD_CASC_ALL(CALL)                 \
-    ODPD_CASC_PA(FEAT_RAW2, false, CALL)    \
-    ODPD_CASC_PA(FEAT_DGRU6, true, CALL)    \
-    ODPD_CASC_PA(FEAT_Q4, false, CALL)      \
-    ODPD_CASC_PA(FEAT_A4, false, CALL)      \
-    ODPD_CASC_PA(kDpdDelta, false, CALL)    \
-    ODPD_CASC_PA(kDpdTres, false, CALL)
+#define ODPD_CASC_ALL(CALL)                    \
+    ODPD_CASC_PA(1, FEAT_RAW2, false, CALL)    \
+    ODPD_CASC_PA(1, FEAT_DGRU6, true, CALL)    \
+    ODPD_CASC_PA(1, FEAT_Q4, false, CALL)      \
+    ODPD_CASC_PA(1, FEAT_A4, false, CALL)      \
+    ODPD_CASC_PA(2, FEAT_RAW2, false, CALL)    \
+    ODPD_CASC_PA(2, FEAT_DGRU6, true, CALL)    \
+    ODPD_CASC_PA(2, FEAT_Q4, false, CALL)      \
+    ODPD_CASC_PA(2, FEAT_A4, false, CALL)      \
+    ODPD_CASC_PA(1, kDpdDelta, false, CALL)    \
+    ODPD_CASC_PA(1, kDpdTres, false, CALL)
 
 size_t casc_lds_bytes(const CascCfg& c, int T) {
-#define ODPD_CASC_LDS(FMD_, DGD_, PV_, FMP_, DGP_) casc_lds<FMD_, DGD_, PV_, FMP_, DGP_>(T, c.Pd, c.Pp)
+#define ODPD_CASC_LDS(NBD_, FMD_, DGD_, PV_, FMP_, DGP_) casc_lds<NBD_, FMD_, DGD_, PV_, FMP_, DGP_>(T, c.Pd, c.Pp)
     ODPD_CASC_ALL(ODPD_CASC_LDS)
 #undef ODPD_CASC_LDS
     return 0;
@@ -247,16 +253,16 @@ int casc_grid(const CascCfg& c, int B, int T) {
     const long cap = (long)device_cus() * (per_cu < 2 ? per_cu : 2);        // a workgroup = two waves, on SIMDs of their own
     return B <= cap ? B : 0;                                               // every frame resident at once
 }
-template <int FMD, bool DGD, int PV, int FMP, bool DGP>
+template <int NBD, int FMD, bool DGD, int PV, int FMP, bool DGP>
 int casc_launch(hipStream_t st, const CascArgs& a, const CascCfg& c) {
-    const size_t lds = casc_lds<FMD, DGD, PV, FMP, DGP>(a.T, c.Pd, c.Pp);
+    const size_t lds = casc_lds<NBD, FMD, DGD, PV, FMP, DGP>(a.T, c.Pd, c.Pp);
     auto launch = [&](auto k) {
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3(casc_grid(c, a.B, a.T)), dim3(128), lds, st, a);
         return (int)hipGetLastError();
     };
     if constexpr (FMD == kDpdDelta || FMD == kDpdTres) return launch(delta_cascade_kernel<FMD == kDpdTres, PV, FMP, DGP>);
-    else return launch(gru_cascade_kernel<FMD, DGD, PV, FMP, DGP>);
+    else return launch(gru_cascade_kernel<NBD, FMD, DGD, PV, FMP, DGP>);
 }
 }  // namespace
 
@@ -270,7 +276,7 @@ int gru_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int
 int gru_cascade_train(hipStream_t st, const odpd_model_t* dpd, const odpd_model_t* pa, const CascArgs& a) {
     CascCfg c;
     if (!casc_cfg(dpd, pa, c) || casc_grid(c, a.B, a.T) <= 0) return ODPD_EUNSUPPORTED;
-#define ODPD_CASC_LAUNCH(FMD_, DGD_, PV_, FMP_, DGP_) casc_launch<FMD_, DGD_, PV_, FMP_, DGP_>(st, a, c)
+#define ODPD_CASC_LAUNCH(NBD_, FMD_, DGD_, PV_, FMP_, DGP_) casc_launch<NBD_, FMD_, DGD_, PV_, FMP_, DGP_>(st, a, c)
     ODPD_CASC_ALL(ODPD_CASC_LAUNCH)
 #undef ODPD_CASC_LAUNCH
     return ODPD_EUNSUPPORTED;

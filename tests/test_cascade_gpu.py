@@ -389,3 +389,48 @@ def test_one_launch_cascade_with_a_delta_dpd_against_oracle(pa_bb, pa_h, dpd_bb,
     # (a masked delta sits on a threshold comparison of fp32 values: the counters agree unless a |delta| lands within an ulp of it)
     assert abs(st["num_dx_zeros"] - su[0]) <= 2 and abs(st["num_dh_zeros"] - su[2]) <= 2
     assert torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp))
+
+
+@pytest.mark.parametrize("dpd_bb,dpd_h,pa_bb,pa_h", [("qgru", 20, "dgru", 8), ("qgru", 30, "dgru", 8), ("dgru", 23, "dgru", 13), ("gru", 32, "gru", 23),
+                                                     ("qgru_amp1", 17, "gru", 32), ("dgru", 17, "gru", 24)])
+@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50)])
+@pytest.mark.parametrize("loss", ["l2", "l1"])
+def test_one_launch_cascade_with_a_two_block_dpd_against_oracle(dpd_bb, dpd_h, pa_bb, pa_h, B, T, loss):
+    """DPDs of 17..32 units (two 16-unit blocks per gate row, weight gradients as one 4-block MFMA per block pair) in the one-launch step —
+    e.g. the float stage of quant_qgru_dpd_regr.sh's qgru H20 / H30 in front of a dgru PA."""
+    from opendpd_amd import CascadedModel, CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(pa_h * 7 + dpd_h + T)
+    dpd, pa = CoreModel(2, dpd_h, 1, dpd_bb), CoreModel(2, pa_h, 1, pa_bb)
+    net = CascadedModel(dpd_model=dpd, pa_model=pa)
+    net.freeze_pa_model()
+    net = net.cuda()
+    rng = np.random.RandomState(pa_h + T)
+    x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    o = Oracle("f32")
+    md, mp = make_model(dpd_bb, dpd_h), make_model(pa_bb, pa_h)
+    pd = dpd.backbone.flat_params().detach().cpu().numpy().copy()
+    pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
+    u, _ = o.forward(md, pd, x)
+    y, _ = o.forward(mp, pp, u)
+    lo, dy = o.loss(loss, y, t)
+    _, du = o.backward(mp, pp, u, dy)
+    gd, _ = o.backward(md, pd, x, du, need_dx=False)
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.cascade_one_launch(B, T, torch.device("cuda", 0)) is not None
+    lg = fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), loss, 0.0)
+    assert abs(lg.item() - lo) < 2e-5 * max(1.0, lo)
+    assert rel_err(opt.grad[:-4].cpu().numpy(), gd) < (3e-4 if loss == "l2" else 2e-3)
+
+
+def test_one_launch_cascade_lds_envelope_of_two_block_pairs():
+    """two 23-unit DGRUs (parameters + per-frame state of both: > 160 KB at 200 samples) keep the chained launches; at 50 samples they fit"""
+    from opendpd_amd import CascadedModel, CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW
+    net = CascadedModel(dpd_model=CoreModel(2, 23, 1, "dgru"), pa_model=CoreModel(2, 23, 1, "dgru"))
+    net.freeze_pa_model()
+    opt = FusedAdamW(net.cuda(), lr=1e-3)
+    assert opt.cascade_one_launch(64, 200, torch.device("cuda", 0)) is None
+    assert opt.cascade_one_launch(64, 50, torch.device("cuda", 0)) is not None

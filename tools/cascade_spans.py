@@ -13,7 +13,12 @@ from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
 T = 200
 for name, dpd_kw, pa_kw, B in (("config 3: TRes-DeltaGRU15 -> frozen DGRU23", dict(hidden_size=15, backbone_type="deltagru_tcnskip", thx=0.01, thh=0.05), dict(hidden_size=23, backbone_type="dgru"), 64),
                                ("default: GRU15 -> frozen GRU23", dict(hidden_size=15, backbone_type="gru"), dict(hidden_size=23, backbone_type="gru"), 256),
-                               ("DGRU13 -> frozen DGRU13", dict(hidden_size=13, backbone_type="dgru"), dict(hidden_size=13, backbone_type="dgru"), 256)):
+                               ("DGRU13 -> frozen DGRU13", dict(hidden_size=13, backbone_type="dgru"), dict(hidden_size=13, backbone_type="dgru"), 256),
+                               ("quant_qgru_dpd_regr.sh's float stage: QGRU20 -> frozen DGRU8", dict(hidden_size=20, backbone_type="qgru"), dict(hidden_size=8, backbone_type="dgru"), 64),
+                               ("the same, chained launches", dict(hidden_size=20, backbone_type="qgru"), dict(hidden_size=8, backbone_type="dgru"), -64)):
+    from opendpd_amd import _lib
+    _lib.load().odpd_set_tuning(b"cascade_one_launch", 0 if B < 0 else 1)
+    B = abs(B)
     torch.manual_seed(0)
     casc = CascadedModel(dpd_model=CoreModel(2, num_layers=1, **dpd_kw), pa_model=CoreModel(2, num_layers=1, **pa_kw))
     casc.freeze_pa_model()
