@@ -278,9 +278,9 @@ extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss
     return gru_family_lossdx((hipStream_t)stream, m, a);
 }
 
-// DPDs of the one-launch cascade step: the float GRU family and the float delta-GRU backbones (gru_cascade.hip)
+// DPDs of the one-launch cascade step: the float GRU family, the float delta-GRU backbones and the plain LSTM (gru_cascade.hip)
 static bool cascade_dpd_family(const odpd_model_t* m) {
-    return family_of(m) == FAM_GRU || (family_of(m) == FAM_DELTA && m->backbone != ODPD_DELTAJANET);
+    return family_of(m) == FAM_GRU || (family_of(m) == FAM_DELTA && m->backbone != ODPD_DELTAJANET) || m->backbone == ODPD_LSTM;
 }
 extern "C" int64_t odpd_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T) {
     if (!model_ok(dpd) || !model_ok(pa) || B <= 0 || T <= 0) return ODPD_EINVAL;

@@ -9,34 +9,10 @@
 // weight gradients, one partial-gradient row per workgroup.
 #include "odpd_seq.h"
 #include "odpd_s16.h"
+#include "odpd_lstm.h"
 
 namespace odpd {
 
-// table rows: kHH = g*R + rb (g = 0..3), kHHT = 4R + g*R + rb
-template <int R> struct LstmTabs {
-    static constexpr int kHH = 0, kHHT = 4 * R, kRows = 8 * R, kFloats = kRows * 4 * 64 * 4;
-};
-template <int R, bool WITH_T>
-__device__ __forceinline__ void fill_lstm_tabs(float* tab, const float* pl, const LstmLayout& L, int lane, int wave, int nwb) {
-    using T = LstmTabs<R>;
-    const int H = L.H, col = lane & 15, row = (lane >> 4) & (R - 1), o = 16 * row + col, dir = rot_dir(col);
-    float4* t4 = reinterpret_cast<float4*>(tab);
-    for (int idx = wave; idx < T::kRows * 4; idx += nwb) {
-        const int tr = idx >> 2, q = idx & 3;
-        const bool transposed = tr >= T::kHHT;
-        if (!WITH_T && transposed) continue;
-        const int local = transposed ? tr - T::kHHT : tr, g = local / R, rb = local % R;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = 16 * ((row + rb) % R) + ((col + dir * (4 * q + e)) & 15);
-            const bool ok = o < H && m < H;
-            v[e] = ok ? pl[L.o_w_hh + g * H * H + (transposed ? m * H + o : o * H + m)] : 0.0f;
-        }
-        t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    __syncthreads();
-}
 template <int R>
 __device__ __forceinline__ void load_rot4(float (&w)[4][R][16], TabPtr tlane, int first_row) {
 #pragma unroll

@@ -434,3 +434,41 @@ def test_one_launch_cascade_lds_envelope_of_two_block_pairs():
     opt = FusedAdamW(net.cuda(), lr=1e-3)
     assert opt.cascade_one_launch(64, 200, torch.device("cuda", 0)) is None
     assert opt.cascade_one_launch(64, 50, torch.device("cuda", 0)) is not None
+
+
+@pytest.mark.parametrize("pa_bb,pa_h", [("dgru", 8), ("gru", 11), ("dgru", 23), ("gru", 23), ("dgru", 32)])
+@pytest.mark.parametrize("dpd_h", [9, 14, 16, 1])
+@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50), (4, 33)])
+@pytest.mark.parametrize("loss", ["l2", "l1"])
+def test_one_launch_cascade_with_an_lstm_dpd_against_oracle(pa_bb, pa_h, dpd_h, B, T, loss):
+    """train_all_dpd.sh's lstm DPD in front of its dgru PA (and relatives) in the one-launch step (lstm_cascade_kernel, LstmSeq): loss and DPD
+    gradient == oracle composition."""
+    from opendpd_amd import CascadedModel, CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(pa_h * 7 + dpd_h + T)
+    dpd, pa = CoreModel(2, dpd_h, 1, "lstm"), CoreModel(2, pa_h, 1, pa_bb)
+    net = CascadedModel(dpd_model=dpd, pa_model=pa)
+    net.freeze_pa_model()
+    net = net.cuda()
+    rng = np.random.RandomState(pa_h + T)
+    x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    if dpd_h == 1:      # one unit and the zero-initialised fc_out bias: |u| would wander through 0, where a DGRU PA's 1 / |u| features are ill-conditioned
+        with torch.no_grad():
+            dpd.backbone.fc_out.bias.copy_(torch.tensor([0.45, -0.35]))
+    o = Oracle("f32")
+    md, mp = make_model("lstm", dpd_h), make_model(pa_bb, pa_h)
+    pd = dpd.backbone.flat_params().detach().cpu().numpy().copy()
+    pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
+    u, _ = o.forward(md, pd, x)
+    y, _ = o.forward(mp, pp, u)
+    lo, dy = o.loss(loss, y, t)
+    _, du = o.backward(mp, pp, u, dy)
+    gd, _ = o.backward(md, pd, x, du, need_dx=False)
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.cascade_one_launch(B, T, torch.device("cuda", 0)) is not None
+    lg = fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), loss, 0.0)
+    assert abs(lg.item() - lo) < 2e-5 * max(1.0, lo)
+    assert rel_err(opt.grad[:-4].cpu().numpy(), gd) < (3e-4 if loss == "l2" else 2e-3)
+    assert torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp))

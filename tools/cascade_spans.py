@@ -15,7 +15,9 @@ for name, dpd_kw, pa_kw, B in (("config 3: TRes-DeltaGRU15 -> frozen DGRU23", di
                                ("default: GRU15 -> frozen GRU23", dict(hidden_size=15, backbone_type="gru"), dict(hidden_size=23, backbone_type="gru"), 256),
                                ("DGRU13 -> frozen DGRU13", dict(hidden_size=13, backbone_type="dgru"), dict(hidden_size=13, backbone_type="dgru"), 256),
                                ("quant_qgru_dpd_regr.sh's float stage: QGRU20 -> frozen DGRU8", dict(hidden_size=20, backbone_type="qgru"), dict(hidden_size=8, backbone_type="dgru"), 64),
-                               ("the same, chained launches", dict(hidden_size=20, backbone_type="qgru"), dict(hidden_size=8, backbone_type="dgru"), -64)):
+                               ("the same, chained launches", dict(hidden_size=20, backbone_type="qgru"), dict(hidden_size=8, backbone_type="dgru"), -64),
+                               ("train_all_dpd.sh: LSTM9 -> frozen DGRU8", dict(hidden_size=9, backbone_type="lstm"), dict(hidden_size=8, backbone_type="dgru"), 64),
+                               ("the same, chained launches", dict(hidden_size=9, backbone_type="lstm"), dict(hidden_size=8, backbone_type="dgru"), -64)):
     from opendpd_amd import _lib
     _lib.load().odpd_set_tuning(b"cascade_one_launch", 0 if B < 0 else 1)
     B = abs(B)
