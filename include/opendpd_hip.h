@@ -228,8 +228,9 @@ int odpd_train_epoch_opt(void* stream, const odpd_model_t* m, int loss_kind, con
  * PA): per step odpd_cascade_fwd_bwd on the frames `order[f0 .. f0 + B)` read in place, row reduction, clip + optimiser step
  * (opt_kind < 0: AdamW with the given betas / eps / weight_decay; else ODPD_OPT_*), mean loss of step i -> losses_out[i].
  * ODPD_EUNSUPPORTED unless odpd_cascade_rows > 0 for the epoch's full batch and its tail. `partials`: max over those of
- * (rows, P_dpd + 4). */
-int odpd_train_epoch_cascade(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, const odpd_frames_t* fr,
+ * (rows, P_dpd + 4).  `comm` (odpd_comm_init; may be NULL = one process): as odpd_train_epoch_dp — every global batch sharded over the
+ * communicator's ranks (odpd_shard_range), the loss mean over the GLOBAL batch, one RCCL all-reduce of P_dpd + 4 floats per step. */
+int odpd_train_epoch_cascade(void* stream, void* comm, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, const odpd_frames_t* fr,
                              int batch, int opt_kind, float* dpd_params, const float* pa_params, float* grad, float* state1,
                              float* state2, int64_t first_step, double lr, double beta1, double beta2, double eps, double weight_decay,
                              double max_norm, float* partials, double* dpd_stats, float* losses_out);

@@ -415,30 +415,49 @@ static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, 
     return 0;
 }
 // ---- native epoch loop of train_dpd at the reference's batch sizes: the one-launch cascade step (gru_cascade.hip) on frames read in place ----
-extern "C" int odpd_train_epoch_cascade(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, const odpd_frames_t* fr,
-                                        int batch, int opt_kind, float* dpd_params, const float* pa_params, float* grad, float* state1,
-                                        float* state2, int64_t first_step, double lr, double beta1, double beta2, double eps,
+// comm != NULL: every global batch sharded over the communicator's ranks (as train_epoch_impl), one all-reduce of grad[0 .. P+4) per step
+extern "C" int odpd_train_epoch_cascade(void* stream, void* comm, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind,
+                                        const odpd_frames_t* fr, int batch, int opt_kind, float* dpd_params, const float* pa_params, float* grad,
+                                        float* state1, float* state2, int64_t first_step, double lr, double beta1, double beta2, double eps,
                                         double weight_decay, double max_norm, float* partials, double* dpd_stats, float* losses_out) {
     if (!model_ok(dpd) || !model_ok(pa) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
         fr->stride <= 0 || batch <= 0 || !dpd_params || !pa_params || !grad || !state1 || !state2 || !partials || !losses_out || first_step <= 0 ||
         opt_kind > ODPD_OPT_RMSPROP)
         return ODPD_EINVAL;
     const int T = fr->frame_length;
+    const int rank = comm ? comm_rank(comm) : 0, world = comm ? comm_world(comm) : 1;
     const int64_t full = fr->n_frames < batch ? fr->n_frames : batch, tail = fr->n_frames % batch;
-    for (int64_t gb : {full, tail})
-        if (gb && odpd_cascade_rows(dpd, pa, (int)gb, T) <= 0) return ODPD_EUNSUPPORTED;
+    for (int64_t gb : {full, tail}) {
+        if (!gb) continue;
+        int64_t lo, hi;
+        odpd_shard_range(gb, rank, world, &lo, &hi);
+        if (hi > lo && odpd_cascade_rows(dpd, pa, (int)(hi - lo), T) <= 0) return ODPD_EUNSUPPORTED;
+    }
     const int64_t P = odpd_param_count(dpd);
     hipStream_t st = (hipStream_t)stream;
     int64_t step = first_step;
     for (int64_t f0 = 0, i = 0; f0 < fr->n_frames; f0 += batch, ++i, ++step) {
-        const int B = (int)((fr->n_frames - f0) < batch ? (fr->n_frames - f0) : batch);
-        const int64_t count = (int64_t)B * T * 2;
+        const int64_t GB = (fr->n_frames - f0) < batch ? (fr->n_frames - f0) : batch;      // the global batch
+        int64_t lo, hi;
+        odpd_shard_range(GB, rank, world, &lo, &hi);
+        const int B = (int)(hi - lo);                                                       // this rank's frames of it
+        const int64_t count = GB * T * 2;                                                   // loss mean over the GLOBAL batch
         const float inv_count = (float)(1.0 / (double)count);
-        int rc = odpd_cascade_fwd_bwd(stream, dpd, pa, loss_kind, B, T, count, dpd_params, pa_params, fr->x_stream, fr->y_stream, fr->order + f0,
-                                      fr->stride, partials, dpd_stats);
-        if (rc) return rc;
-        rc = odpd_reduce_partials(stream, odpd_cascade_rows(dpd, pa, B, T), P, partials, grad, 0);
-        if (rc) return rc;
+        int rc;
+        if (B > 0) {
+            rc = odpd_cascade_fwd_bwd(stream, dpd, pa, loss_kind, B, T, count, dpd_params, pa_params, fr->x_stream, fr->y_stream,
+                                      fr->order + f0 + lo, fr->stride, partials, dpd_stats);
+            if (rc) return rc;
+            rc = odpd_reduce_partials(stream, odpd_cascade_rows(dpd, pa, B, T), P, partials, grad, 0);
+            if (rc) return rc;
+        } else {      // an empty shard of a short last batch: zeros into the sum
+            rc = (int)hipMemsetAsync(grad, 0, (size_t)(P + kLossCols) * sizeof(float), st);
+            if (rc) return rc;
+        }
+        if (comm) {
+            rc = comm_allreduce(st, comm, grad, P + kLossCols);
+            if (rc) return rc;
+        }
         rc = opt_kind < 0 ? launch_clip_adamw(st, P, dpd_params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
                                               losses_out + i, inv_count)
                           : launch_clip_optim(st, opt_kind, P, dpd_params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, inv_count);

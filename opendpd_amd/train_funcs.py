@@ -327,9 +327,11 @@ class FusedAdamW:
         if not (self.pa is not None and getattr(self.backbone, "frozen_mask", None) is None
                 and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size")) and loader.x.is_cuda):
             return False
-        if self.world_size() > 1 or self.native_comm() is not None:
-            return False
         dev = loader.x.device
+        if self.world_size() > 1 or self.native_comm() is not None:
+            # sharded epoch from C++: needs the library-owned RCCL communicator and the one-launch step for this rank's shards
+            return self.native_comm() is not None and all(self.cascade_one_launch(b, loader.frame_length, dev) is not None
+                                                          for b in self._shard_sizes(loader))
         return all(self.cascade_one_launch(b, loader.frame_length, dev) is not None for b in self._epoch_batches(loader))
 
     def train_epoch_cascade(self, loader, loss_kind, max_norm):
@@ -340,13 +342,15 @@ class FusedAdamW:
         B = min(loader.batch_size, n)
         self._ensure(dev)
         n_steps = (n + B - 1) // B
-        part = max((self.cascade_one_launch(b, T, dev) for b in self._epoch_batches(loader)), key=lambda p: p.shape[0])
+        comm = self.native_comm()
+        sizes = self._shard_sizes(loader) if comm is not None else self._epoch_batches(loader)
+        part = max((self.cascade_one_launch(b, T, dev) for b in sizes), key=lambda p: p.shape[0])
         order = loader.epoch_order()
         losses = torch.empty(n_steps, dtype=torch.float32, device=dev)
         fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
         g = self.param_groups[0]
         adamw = self.kind == "adamw"
-        rc = lib.odpd_train_epoch_cascade(_lib.stream_ptr(), C.byref(dpd.desc), C.byref(pa.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
+        rc = lib.odpd_train_epoch_cascade(_lib.stream_ptr(), comm.handle if comm is not None else None, C.byref(dpd.desc), C.byref(pa.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
                                           -1 if adamw else _lib.OPTIMIZER_IDS[self.kind], _lib.ptr(dpd.flat_params(full_check=True)),
                                           _lib.ptr(pa.flat_params(full_check=True)), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
                                           _lib.ptr(self.exp_avg_sq), self.step_count + 1, float(g["lr"]), float(g["betas"][0]) if adamw else 0.0,

@@ -128,3 +128,29 @@ def test_two_rank_sum_of_hip_shard_gradients_equals_the_full_batch_gradient(bb, 
     # identical replicas after the step, equal to the single-process result up to the summation order of the two shards
     assert np.array_equal(ranks[0]["params"], ranks[1]["params"])
     assert np.abs(ranks[0]["params"] - ref_p).max() <= 2e-6 * np.abs(ref_p).max()
+
+
+@pytest.mark.parametrize("dpd_bb,dpd_h,pa_bb,pa_h", [("gru", 15, "gru", 23), ("deltagru_tcnskip", 15, "dgru", 23)])
+def test_sharded_cascade_epoch_loop_with_a_communicator_of_one_rank(dpd_bb, dpd_h, pa_bb, pa_h, monkeypatch):
+    """train_dpd under the library-owned communicator: odpd_train_epoch_cascade with comm != NULL (shard ranges, global loss count, the
+    all-reduce enqueued between row reduction and optimiser) reproduces the single-process cascade epoch bit for bit on a world of one."""
+    from opendpd_amd import CascadedModel, CoreModel, dist as odist
+    from opendpd_amd.train_funcs import FusedAdamW
+    x, y = _stream(1000, 3)
+    T = 50
+    res = []
+    for native in (False, True):
+        monkeypatch.setenv("ODPD_NATIVE_COMM", "1" if native else "0")
+        odist._native = None
+        torch.manual_seed(0)
+        net = CascadedModel(dpd_model=CoreModel(2, dpd_h, 1, dpd_bb, thx=0.01, thh=0.05), pa_model=CoreModel(2, pa_h, 1, pa_bb))
+        net.freeze_pa_model()
+        net = net.cuda()
+        opt = FusedAdamW(net, lr=1e-3)
+        loader = _Loader(x, y, T, 64, seed=5)
+        assert opt.can_run_cascade_epoch(loader)
+        assert (opt.native_comm() is not None) == native
+        losses = opt.train_epoch_cascade(loader, "l2", 200.0)
+        res.append((losses.cpu().numpy(), net.dpd_model.backbone.flat_params().cpu().numpy().copy()))
+    odist._native = None
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
