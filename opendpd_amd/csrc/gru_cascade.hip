@@ -1,6 +1,6 @@
 // gru_cascade.hip — train_dpd (steps/train_dpd.py:60-63, models.py:163-176: y = PA(DPD(x)), PA frozen) at the reference's own batch
 // sizes (64 .. 256 frames of 50 / 200 samples, train_funcs.py:28-48) as ONE launch: the DPD and the frozen PA of a frame run as the two
-// waves of a workgroup, on SIMDs of their own, and hand the frame over through LDS 64 steps at a time.
+// waves of a workgroup, on SIMDs of their own, and hand the frame over through LDS 32 steps (kCascChunk) at a time.
 //
 // At these batches a sequence has a SIMD to itself and the T-serial dependency chains are the whole cost (gru_family.hip,
 // gru_gp_train_kernel).  Chained launches pay DPD forward + PA forward + PA backward + DPD forward again + DPD backward; here
@@ -8,7 +8,7 @@
 //              PA wave:  chunk k - 1 (recurrence)                                              — one workgroup barrier per chunk
 //   loss       PA wave: fc_out, loss and dL/dy of all T steps, lane = time step
 //   backward   PA wave:  chunk c (recurrence, parking the pre-activation gradients; then dL/du of the chunk, lane = time step -> LDS)
-//              DPD wave: the 64 steps above it (recurrence + weight gradients as 4-block MFMAs)  — one barrier per chunk
+//              DPD wave: the chunk above it (recurrence + weight gradients as 4-block MFMAs)  — one barrier per chunk
 // so the DPD's chains hide behind the PA's but for one chunk at either end, the DPD's forward runs once, and u / dL/du never leave LDS.
 // The per-step arithmetic is gru_gp_train_kernel's (same gate-parallel mapping: rows r | n | head | z of a wave, one rotated dot
 // product per step and orientation); the DPD has hidden <= 16, the PA hidden <= 32 (two 16-unit blocks).
