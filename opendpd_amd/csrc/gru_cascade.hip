@@ -11,9 +11,10 @@
 //              DPD wave: the chunk above it (recurrence + weight gradients as 4-block MFMAs)  — one barrier per chunk
 // so the DPD's chains hide behind the PA's but for one chunk at either end, the DPD's forward runs once, and u / dL/du never leave LDS.
 // The per-step arithmetic is gru_gp_train_kernel's (same gate-parallel mapping: rows r | n | head | z of a wave, one rotated dot
-// product per step and orientation); the DPD has hidden <= 16, the PA hidden <= 32 (two 16-unit blocks).
+// product per step and orientation); DPD and PA of <= 32 units (two 16-unit blocks above 16; PAs of 17..24 on the half-block layout).
 // One partial-gradient row per workgroup: (P_dpd + kLossCols), column P_dpd = the loss partial sum.
-// delta_cascade_kernel: the same workgroup with a deltagru / TRes-DeltaGRU DPD (odpd_deltaseq.h).
+// delta_cascade_kernel / lstm_cascade_kernel: the same workgroup with a deltagru / TRes-DeltaGRU (odpd_deltaseq.h) or a plain LSTM
+// (odpd_lstm.h) of <= 16 units as the DPD.
 #include "odpd_gpseq.h"
 #include "odpd_deltaseq.h"
 #include "odpd_lstm.h"
