@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the one-launch cascade step (csrc/gru_cascade.hip) against the chained launches it replaces
+(odpd_set_tuning("cascade_one_launch", 0)): random DPD / PA kinds and sizes, thresholds, batch and frame shapes, both losses; loss and DPD
+gradient of one step.  usage (GPU box): PYTHONPATH=. python tools/cascade_one_launch_sweep.py [cases] [seed]"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from opendpd_amd import CascadedModel, CoreModel, _lib
+from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+
+lib = _lib.load()
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst, served = 0.0, 0
+for it in range(cases):
+    dpd_bb = ["gru", "dgru", "qgru", "qgru_amp1", "deltagru", "deltagru_tcnskip", "lstm"][rng.randint(7)]
+    pa_bb = ["gru", "dgru"][rng.randint(2)]
+    dH = int(rng.randint(1, 33 if dpd_bb in ("gru", "dgru", "qgru", "qgru_amp1") else 17))
+    pH = int(rng.randint(1, 33))
+    B = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 256]))
+    T = int(rng.choice([1, 2, 5, 31, 32, 33, 50, 63, 64, 65, 96, 128, 199, 200, 250]))
+    if B * T > 30000:
+        B = max(1, 30000 // T)
+    loss = ["l2", "l1"][rng.randint(2)]
+    kw = dict(thx=float(rng.choice([0.0, 0.01, 0.03])), thh=float(rng.choice([0.0, 0.02, 0.05]))) if "delta" in dpd_bb else {}
+    x = torch.from_numpy((rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)).cuda()
+    t = torch.from_numpy((0.4 * rng.randn(B, T, 2)).astype(np.float32)).cuda()
+    res = []
+    one = None
+    for knob in (1, 0):
+        lib.odpd_set_tuning(b"cascade_one_launch", knob)
+        torch.manual_seed(it)
+        net = CascadedModel(dpd_model=CoreModel(2, dH, 1, dpd_bb, **kw), pa_model=CoreModel(2, pH, 1, pa_bb))
+        with torch.no_grad():      # keep |u| away from 0 (a DGRU PA's 1 / |u| features) and the biases alive
+            for k_, p_ in net.dpd_model.named_parameters():
+                if "bias" in k_:
+                    p_.uniform_(-0.3, 0.3)
+            net.dpd_model.backbone.fc_out.bias.copy_(torch.tensor([0.45, -0.35])) if hasattr(net.dpd_model.backbone.fc_out, "bias") and net.dpd_model.backbone.fc_out.bias is not None else None
+        net.freeze_pa_model()
+        net = net.cuda()
+        opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+        if knob == 1:
+            one = opt.cascade_one_launch(B, T, x.device) is not None
+        res.append((fused_train_step(opt, x, t, loss, 0.0).item(), opt.grad[:-4].clone()))
+    lib.odpd_set_tuning(b"cascade_one_launch", 1)
+    served += bool(one)
+    dl = abs(res[0][0] - res[1][0]) / max(1.0, abs(res[1][0]))
+    dg = ((res[0][1] - res[1][1]).abs().max() / res[1][1].abs().max().clamp_min(1e-30)).item()
+    worst = max(worst, dg)
+    flag = "" if (dl < 2e-5 and dg < (1e-3 if loss == "l1" else 3e-4)) else "   <-- MISMATCH"
+    if flag or it % 25 == 0:
+        print(f"{it:4d} {dpd_bb:16s} H{dH:2d} -> {pa_bb:4s} H{pH:2d}  {B:3d} x {T:3d} {loss} one-launch={one}: loss diff {dl:.1e}, grad diff {dg:.1e}{flag}", flush=True)
+print(f"{cases} cases, {served} served by the one-launch step, worst gradient difference {worst:.2e}")
