@@ -280,7 +280,8 @@ extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss
 
 // DPDs of the one-launch cascade step: the float GRU family, the float delta-GRU backbones and the plain LSTM (gru_cascade.hip)
 static bool cascade_dpd_family(const odpd_model_t* m) {
-    return family_of(m) == FAM_GRU || (family_of(m) == FAM_DELTA && m->backbone != ODPD_DELTAJANET) || m->backbone == ODPD_LSTM;
+    return family_of(m) == FAM_GRU || (family_of(m) == FAM_DELTA && m->backbone != ODPD_DELTAJANET) || m->backbone == ODPD_LSTM ||
+           (family_of(m) == FAM_QAT && (m->backbone == ODPD_GRU || m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1));
 }
 extern "C" int64_t odpd_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T) {
     if (!model_ok(dpd) || !model_ok(pa) || B <= 0 || T <= 0) return ODPD_EINVAL;
@@ -294,7 +295,7 @@ extern "C" int odpd_cascade_fwd_bwd(void* stream, const odpd_model_t* dpd, const
         return ODPD_EINVAL;
     if (!cascade_dpd_family(dpd) || family_of(pa) != FAM_GRU) return ODPD_EUNSUPPORTED;
     CascArgs a{};
-    a.thx = dpd->thx; a.thh = dpd->thh; a.stats = dpd_stats;
+    a.thx = dpd->thx; a.thh = dpd->thh; a.stats = dpd_stats; a.bits_w = dpd->bits_w; a.bits_a = dpd->bits_a;
     a.dpd_params = dpd_params; a.pa_params = pa_params; a.x = x; a.target = target; a.partials = partials;
     a.frame_idx = reinterpret_cast<const long long*>(frame_idx); a.frame_stride = frame_stride;
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.B = B; a.T = T; a.Hd = dpd->hidden; a.Hp = pa->hidden;

@@ -164,6 +164,7 @@ struct CascArgs {
     float inv_count;
     float thx, thh;            // delta DPD: its thresholds
     double* stats;             // delta DPD: sparsity counters of the forward passes (nullable)
+    int bits_w, bits_a;        // quantised DPD
     int loss_kind, B, T, Hd, Hp;
 };
 int gru_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T);

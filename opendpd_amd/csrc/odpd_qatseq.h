@@ -1,0 +1,277 @@
+// odpd_qatseq.h — a quantisation-aware GRUCell model (the surgery's result on gru / qgru / qgru_amp1: quant/modules/gru.py:43-59, INT_Linear
+// fc_out) as the trained DPD of a cascade on ONE wave (BASELINE config 5: QGRU INT8 train_dpd) — the per-unit arithmetic of qat_s16.hip's
+// std_cell / head_fwd / head_bwd / backward block in grid units (odpd_qat.h: every rounding the reference makes is made on the same real
+// number; on 8-bit grids the integer mat-vec sums are exact in any order, so the results stay bit-identical with the reference's), on the
+// gate-parallel mapping of the one-sequence-per-wave kernels: rows r | z | n | - of the wave hold one gate each — the row's quantised
+// input weights as wave-uniform FMAs on the step's quantised features, its quantised recurrent weights as one rotated dot product on the
+// quantised state — the three gates' sums meet on every row through cross-row swaps and the quantiser chain of a unit runs redundantly on
+// the four rows.  The cell state (h only) is kept at every chunk start; a backward chunk runs its forward steps again from there, parking
+// the step's pre-combined straight-through factors (qat_s16.hip, SaveS) for its 32 steps, then back-propagates: one transposed rotated dot
+// product per step, weight gradients as two 4-block MFMAs on grid-unit operands, scaled (and masked by the weight quantisers' pass
+// ranges) once at write-out; the scale parameters get an exact 0.  hidden <= 16.
+#pragma once
+#include "odpd_qat.h"
+#include "odpd_seq.h"
+
+namespace odpd {
+namespace q16 {
+
+template <int MK, bool LUT>
+struct QatSeq {
+    static_assert(MK == K_GRU || MK == K_Q4 || MK == K_A4, "GRUCell kinds with a plain INT_Linear head");
+    static constexpr int F = Kind<MK>::F, C = 32;      // C = kCascChunk (odpd_gpseq.h)
+    static constexpr int NSV = 14;                      // parked per unit and step: hp hqk n z c2 c3 An Az B1 B2A pph hnew hok pho
+    static constexpr int kTabFloats = 6 * 4 * 64 * 4;   // q_w(W_h) rotated rows r, z, n + transposed
+    __host__ __device__ static int tp(int T) { return (T + 63) & ~63; }
+    __host__ __device__ static int nchunks(int T) { return (T + C - 1) / C; }
+    __host__ __device__ static int off_buf() { return LUT ? 4 * 256 : 0; }                         // LUT builds (<= 8 activation bits): [256][4] first; tables | buffers start here
+    __host__ __device__ static int off_ck(int T) { return tp(T) * 4; }                             // fq [Tp][4]: quantised features (grid units)
+    __host__ __device__ static int off_dyb(int T) { return off_ck(T) + nchunks(T) * 64; }          // ck [chunks][64]: h at the chunk start
+    __host__ __device__ static int off_sv(int T) { return off_dyb(T) + tp(T) * 2; }                // dyb [Tp][2]: dL/du(t), written by the PA wave
+    __host__ __device__ static int off_hist(int T) { return off_sv(T) + C * 16 * NSV; }            // sv [C][NSV][16]
+    __host__ __device__ static int off_dump(int T) { return off_hist(T) + (C + 1) * 16; }          // hist [C + 1][16]: entry i + 1 = h(t0 + i)
+    __host__ __device__ static int off_hw(int T) { return off_dump(T) + 512; }       // dump: where the rows that park nothing store
+    __host__ __device__ static int buf_floats(int T) { return off_hw(T) + 32; }
+    __host__ __device__ static int region_floats(int T, int P) {
+        const int buf = buf_floats(T);
+        return pad4(P) + off_buf() + (buf > kTabFloats ? buf : kTabFloats);
+    }
+    // (dL/du buffer of the region, for the PA wave)
+    __host__ __device__ static int off_dyb_region(int T, int P) { return pad4(P) + off_buf() + off_dyb(T); }
+
+    // ---- registers ----
+    float wrec[16], wT[16], wx[F], bx[3], bh[3], wo0, wo1, bo0, bo1;
+    QSc qs;
+    QK k;
+    WQ wq;
+    QatLayout L;
+    float h, gh;                              // cell state (replicated on every row); backward carry dL/dh
+    f32x16 acc1, acc2;
+    float dwo0, dwo1, dbo0, dbo1, dbhn;
+    float *smem, *pl, *fq, *ck, *dyb, *sv, *hist, *dump, *hw;
+    const float4* lutq;
+    RowMasks rm;
+    int H, T, lane, col, role, bits_a, svp0, svp_step, hp0, hp_step;
+    bool vo;
+
+    // (one workgroup barrier inside)
+    __device__ __forceinline__ void setup(float* base, float* region, const float* params, int Hm, int T_, int bits_w, int bits_a_) {
+        smem = base;
+        lane = threadIdx.x & 63; col = lane & 15; role = lane >> 4;      // r | z | n | -
+        L = qat_layout(MK, Hm);
+        H = L.H; T = T_; bits_a = bits_a_;
+        pl = region;
+        for (int i = lane; i < L.P; i += 64) pl[i] = params[i];
+        wave_lds_fence();
+        qs = load_qsc<MK>(pl, L, bits_a);
+        wq = make_wq(pl, L, bits_w);
+        k = make_qk(qs, wq);
+        float* lut = region + pad4(L.P);
+        float* tab = lut + off_buf();
+        vo = col < H;
+        const bool gate_row = role < 3;
+        const int g = gate_row ? role : 0;
+        if constexpr (LUT) {      // as fill_luts (odpd_qat.h), one wave
+            float4* l4 = reinterpret_cast<float4*>(lut);
+            for (int i = lane; i < (1 << bits_a); i += 64) {
+                const double x = (double)((float)(i + (int)qs.add.qn) * qs.add.s);
+                const Gate gs = sig_gate((float)(1.0 / (1.0 + exp(-x))), qs, k), gt = tanh_gate((float)tanh(x), qs, k);
+                l4[i] = make_float4(gs.c, gs.d, gt.c, gt.d);
+            }
+        }
+        lutq = reinterpret_cast<const float4*>(lut) - (int)qs.add.qn;
+        {   // rotated-quad tables of the quantised recurrent weights (grid units): rows 0..2 q_w(W_h)[g][o][m], rows 3..5 transposed
+            const int dir = rot_dir(col);
+            float4* t4 = reinterpret_cast<float4*>(tab);
+            for (int idx = 0; idx < 6 * 4; ++idx) {
+                const int tr = idx >> 2, q = idx & 3, gg = tr % 3;
+                const bool transposed = tr >= 3;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = (col + dir * (4 * q + e)) & 15;
+                    const bool ok = col < H && m < H;
+                    v[e] = ok ? kq(pl[L.o_wh + (gg * H + (transposed ? m : col)) * H + (transposed ? col : m)], wq.h) : 0.0f;
+                }
+                t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        {
+            TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+            load_rot(wrec, tl + g * 4 * 64);
+            load_rot(wT, tl + (3 + g) * 4 * 64);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { wrec[i] = gate_row ? wrec[i] : 0.0f; wT[i] = gate_row ? wT[i] : 0.0f; }
+        }
+#pragma unroll
+        for (int i = 0; i < F; ++i) wx[i] = (vo && gate_row) ? kq(pl[L.o_wx + (g * H + col) * F + i], wq.x) : 0.0f;
+#pragma unroll
+        for (int gg = 0; gg < 3; ++gg) { bx[gg] = vo ? pl[L.o_bx + gg * H + col] : 0.0f; bh[gg] = vo ? pl[L.o_bh + gg * H + col] : 0.0f; }
+        wo0 = vo ? kq(pl[L.o_wo + col], wq.o) : 0.0f; wo1 = vo ? kq(pl[L.o_wo + L.OW + col], wq.o) : 0.0f;
+        bo0 = pl[L.o_bo]; bo1 = pl[L.o_bo + 1];
+        wave_lds_fence();
+        fq = tab; ck = tab + off_ck(T); dyb = tab + off_dyb(T); sv = tab + off_sv(T); hist = tab + off_hist(T); dump = tab + off_dump(T);
+        hw = tab + off_hw(T);
+        if (lane < 32) hw[lane] = (lane & 15) < H ? kq(pl[L.o_wo + (lane >> 4) * L.OW + (lane & 15)], wq.o) : 0.0f;
+        rm = row_masks();
+        // the recomputed steps' stores: row 0 parks the unit's NSV factors, row 3 h(t) (the others hit the dump)
+        svp0 = role == 0 ? (int)(sv - smem) + col : (int)(dump - smem) + lane; svp_step = role == 0 ? 16 * NSV : 0;
+        hp0 = role == 3 ? (int)(hist - smem) + 16 + col : (int)(dump - smem) + 320 + lane; hp_step = role == 3 ? 16 : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
+        dwo0 = 0.0f; dwo1 = 0.0f; dbo0 = 0.0f; dbo1 = 0.0f; dbhn = 0.0f;
+        wave_lds_fence();
+    }
+
+    // the model's quantised input features of one sample, grid units (qat_s16.hip: q16_slots' operation order, then q_a)
+    __device__ __forceinline__ float4 features(float2 xv) const {
+        const float I = xv.x, Q = xv.y;
+        float f[4] = {I, Q, 0.0f, 0.0f};
+        if constexpr (MK == K_Q4) { const float a2 = I * I + Q * Q; f[2] = a2; f[3] = a2 * a2; }
+        if constexpr (MK == K_A4) { const float a2 = I * I + Q * Q, a = sqrtf(a2); f[2] = a; f[3] = a * a * a; }
+        float r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = i < F ? gk(f[i] * k.inv_xa, k) : 0.0f;
+        return make_float4(r[0], r[1], r[2], r[3]);
+    }
+
+    __device__ __forceinline__ void fwd_begin() { h = 0.0f; }
+
+    // one GRUCell step (std_cell, qat_s16.hip) at time t.  SAVE: parks the backward's factors of the step at `sp` / h(t) at `hq`
+    template <bool SAVE>
+    __device__ __forceinline__ void step(int t, int sp, int hq_) {
+        const float hv = h;
+        const float v0 = hv * k.inv_ha, m0 = gm(v0, k), hqk = rintf(m0);
+        const float4 f4 = reinterpret_cast<const float4*>(fq)[t];
+        const float ff[4] = {f4.x, f4.y, f4.z, f4.w};
+        float xsum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < F; ++i) xsum = __builtin_fmaf(wx[i], ff[i], xsum);
+        const float hsum = rotdot(0.0f, wrec, hqk);
+        float X[4], Hs[4];
+        gather_rows(xsum, X);
+        gather_rows(hsum, Hs);
+        // x_t = x2h(x), h_t = h2h(h): exact integer sums, scale and fp32 bias in one FMA (== F.linear's result)
+        const float xr = __builtin_fmaf(X[0], k.Sx, bx[0]), hr = __builtin_fmaf(Hs[0], k.Sh, bh[0]);
+        const float xz = __builtin_fmaf(X[1], k.Sx, bx[1]), hz = __builtin_fmaf(Hs[1], k.Sh, bh[1]);
+        const float xn = __builtin_fmaf(X[2], k.Sx, bx[2]), hn = __builtin_fmaf(Hs[2], k.Sh, bh[2]);
+        const float vr = (xr + hr) * k.inv_add, vz = (xz + hz) * k.inv_add;
+        const float mr = gm(vr, k), mz = gm(vz, k);
+        const Gate Gr = sig_grid<LUT>(rintf(mr), qs, k, lutq), Gz = sig_grid<LUT>(rintf(mz), qs, k, lutq);
+        const float pm1 = Gr.c * hn, mm1 = gm(pm1, k);                                     // Qmul(r h_n)
+        const float vn = __builtin_fmaf(rintf(mm1), k.s_mul, xn) * k.inv_add, mn = gm(vn, k);      // Qadd(x_n + .)
+        const Gate Gn = tanh_grid<LUT>(rintf(mn), qs, k, lutq);
+        const float omz = __builtin_fmaf(Gz.c, -k.s_mul, 1.0f);                             // 1 - z, plain
+        const float pm2 = Gz.c * hv, pm3 = omz * Gn.c;
+        const float mm2 = gm(pm2, k), mm3 = gm(pm3, k);
+        const float vh = (rintf(mm2) + rintf(mm3)) * k.c_ma, mh = gm(vh, k);
+        const float hnew = rintf(mh) * k.s_add;
+        if constexpr (SAVE) {
+            const bool pah = mh == vh;
+            const float Ar = mr == vr ? Gr.d : 0.0f;
+            const bool p1 = mm1 == pm1;
+            const float vo_ = hnew * k.inv_oa, mo = gm(vo_, k);
+            float* s = smem + sp;
+            s[0 * 16] = hv; s[1 * 16] = hqk; s[2 * 16] = Gn.c * k.s_mul; s[3 * 16] = Gz.c * k.s_mul;
+            s[4 * 16] = (pah && mm2 == pm2) ? 1.0f : 0.0f; s[5 * 16] = (pah && mm3 == pm3) ? 1.0f : 0.0f;
+            s[6 * 16] = mn == vn ? Gn.d : 0.0f; s[7 * 16] = mz == vz ? Gz.d : 0.0f;
+            s[8 * 16] = p1 ? Gr.c * k.s_mul : 0.0f; s[9 * 16] = p1 ? hn * Ar : 0.0f;
+            s[10 * 16] = m0 == v0 ? k.s_hw : 0.0f; s[11 * 16] = hnew;
+            s[12 * 16] = rintf(mo); s[13 * 16] = mo == vo_ ? k.s_ow : 0.0f;
+        }
+        h = hnew;
+        smem[hq_] = hnew;
+    }
+
+    // forward chunk c: quantised features with lane = time step, the cell state kept, the recurrence, fc_out with lane = time step
+    template <typename Sink>
+    __device__ __forceinline__ void fwd_chunk(int c, int t0, int len, const float2* xg, Sink sink) {
+        if (lane < len) reinterpret_cast<float4*>(fq)[t0 + lane] = features(xg[t0 + lane]);
+        ck[c * 64 + lane] = h;
+        wave_lds_fence();
+        int hq_ = hp0;
+        for (int tt = 0; tt < len; ++tt) { step<false>(t0 + tt, 0, hq_); hq_ += hp_step; }
+        wave_lds_fence();
+        if (lane < len) {
+            const float* hv = hist + (lane + 1) * 16;
+            float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float hok = gk(hv[u] * k.inv_oa, k);
+                p0 = __builtin_fmaf(hw[u], hok, p0); p1 = __builtin_fmaf(hw[16 + u], hok, p1);
+            }
+            sink(t0 + lane, __builtin_fmaf(p0, k.So, bo0), __builtin_fmaf(p1, k.So, bo1));        // train mode: no output quantiser
+        }
+        wave_lds_fence();
+    }
+
+    __device__ __forceinline__ void bwd_begin() { gh = 0.0f; }
+
+    // backward chunk c: forward steps again from the kept state (parking the factors), then the steps t0 + len - 1 .. t0
+    __device__ __forceinline__ void bwd_chunk(int c, int t0, int len) {
+        h = ck[c * 64 + lane];
+        wave_lds_fence();
+        {
+            int sp = svp0, hq_ = hp0;
+            for (int tt = 0; tt < len; ++tt) { step<true>(t0 + tt, sp, hq_); sp += svp_step; hq_ += hp_step; }
+        }
+        wave_lds_fence();
+        for (int tt = len - 1; tt >= 0; --tt) {
+            const float* s = sv + tt * 16 * NSV + col;
+            const float hp_ = s[0], hqk = s[16], n = s[2 * 16], z = s[3 * 16], c2 = s[4 * 16], c3 = s[5 * 16], An = s[6 * 16], Az = s[7 * 16],
+                        B1 = s[8 * 16], B2A = s[9 * 16], pph = s[10 * 16], hok = s[12 * 16], pho = s[13 * 16];
+            const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * (t0 + tt));
+            // head (head_bwd): fc_out's parameter gradients, dL/dh' through the activation quantiser's pass mask (carrying s_ow)
+            dbo0 += dyv.x; dbo1 += dyv.y;
+            dwo0 = __builtin_fmaf(dyv.x, hok, dwo0); dwo1 = __builtin_fmaf(dyv.y, hok, dwo1);
+            const float g = gh + (dyv.x * wo0 + dyv.y * wo1) * pho;
+            const float g2 = g * c2, g3 = g * c3;
+            const float dz = g2 * hp_ - g3 * n;
+            const float da = g3 * (1.0f - z) * An;
+            const float dhtn = da * B1, dar = da * B2A, daz = dz * Az, dhdir = g2 * z;
+            dbhn += dhtn;
+            const float d_h = vsel(rm.m[0], dar, vsel(rm.m[1], daz, vsel(rm.m[2], dhtn, 0.0f)));
+            const float d_x = vsel(rm.m[0], dar, vsel(rm.m[1], daz, vsel(rm.m[2], da, 0.0f)));
+            float ddh = rotdot(0.0f, wT, d_h);
+            ddh += xor16(ddh);
+            ddh += xor32(ddh);
+            gh = dhdir + ddh * pph;
+            // weight gradients on grid-unit operands: (d_r | d_z | d_hn) x q_a(h), (d_r | d_z | d_n) x (q_a(features) | 1 / s_xa)
+            const float4 f4 = reinterpret_cast<const float4*>(fq)[t0 + tt];
+            const float fsx = col == 0 ? f4.x : col == 1 ? f4.y : (col == 2 && F > 2) ? f4.z : (col == 3 && F > 3) ? f4.w : (col == F ? k.inv_xa : 0.0f);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_h, hqk, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_x, fsx, acc2, 0, 0, 0);
+        }
+        wave_lds_fence();
+    }
+
+    // the workgroup's row of partial gradients (q16_write_row): activation scales and weight pass masks applied here, scale parameters 0
+    __device__ __forceinline__ void write_partials(float* prow, float loss) {
+        for (int i = lane; i < L.P + kLossCols; i += 64) prow[i] = 0.0f;
+        wave_lds_fence();
+        __builtin_amdgcn_s_waitcnt(0);
+        if (vo && role == 0) {
+            prow[L.o_wo + col] = dwo0 * k.s_oa * qpass(pl[L.o_wo + col], wq.o);
+            prow[L.o_wo + L.OW + col] = dwo1 * k.s_oa * qpass(pl[L.o_wo + L.OW + col], wq.o);
+            prow[L.o_bh + 2 * H + col] = dbhn;
+        }
+        if (lane == 0) { prow[L.o_bo] = dbo0; prow[L.o_bo + 1] = dbo1; prow[L.P] = loss; }
+        // MFMA block g = gate g (r, z, n); register 4 g + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 4 * role + rr;
+                if (i < H) {
+                    if (col < H) { const int j = L.o_wh + (g * H + i) * H + col; prow[j] = acc1[4 * g + rr] * k.s_ha * qpass(pl[j], wq.h); }
+                    const float tx = acc2[4 * g + rr] * k.s_xa;
+                    if (col < F) { const int j = L.o_wx + (g * H + i) * F + col; prow[j] = tx * qpass(pl[j], wq.x); }
+                    else if (col == F) { prow[L.o_bx + g * H + i] = tx; if (g < 2) prow[L.o_bh + g * H + i] = tx; }
+                }
+            }
+    }
+};
+
+}  // namespace q16
+}  // namespace odpd

@@ -472,3 +472,61 @@ def test_one_launch_cascade_with_an_lstm_dpd_against_oracle(pa_bb, pa_h, dpd_h, 
     assert abs(lg.item() - lo) < 2e-5 * max(1.0, lo)
     assert rel_err(opt.grad[:-4].cpu().numpy(), gd) < (3e-4 if loss == "l2" else 2e-3)
     assert torch.equal(pa.backbone.flat_params().cpu(), torch.from_numpy(pp))
+
+
+@pytest.mark.parametrize("pa_bb,pa_h", [("dgru", 23), ("gru", 11), ("dgru", 8)])
+@pytest.mark.parametrize("dpd_bb,dpd_h,bits", [("qgru", 10, 8), ("qgru_amp1", 16, 8), ("gru", 11, 8), ("qgru", 7, 16), ("qgru", 1, 8)])
+@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50), (4, 33)])
+@pytest.mark.parametrize("loss", ["l2", "l1"])
+def test_one_launch_cascade_with_a_quantised_dpd_against_oracle(pa_bb, pa_h, dpd_bb, dpd_h, bits, B, T, loss):
+    """BASELINE config 5's pair (quantisation-aware QGRU W8A8 DPD -> frozen DGRU PA) and its relatives in the one-launch step
+    (qat_cascade_kernel, QatSeq): loss and per-tensor DPD gradient == oracle composition (quantised DPD forward, PA forward, loss, PA backward
+    for dL/du only, quantised DPD backward); the quantiser scales get an exact 0."""
+    from types import SimpleNamespace
+    from opendpd_amd import CascadedModel, CoreModel
+    from opendpd_amd.quant import get_quant_model
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(pa_h * 7 + dpd_h + T)
+    dpd = get_quant_model(SimpleNamespace(quant=True, n_bits_w=bits, n_bits_a=bits, pretrained_model=""), CoreModel(2, dpd_h, 1, dpd_bb))
+    pa = CoreModel(2, pa_h, 1, pa_bb)
+    with torch.no_grad():      # biases and weights off their defaults: clamps and pass masks get exercised
+        g = torch.Generator().manual_seed(dpd_h)
+        for k, p in dpd.named_parameters():
+            if k.endswith("bias"):
+                p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 0.6)
+            elif k.endswith("weight") and p.dim() == 2:
+                p.mul_(1.7)
+        dpd.backbone.fc_out.bias.copy_(torch.tensor([0.45, -0.35]))       # |u| away from 0 (a DGRU PA's 1 / |u| features)
+    net = CascadedModel(dpd_model=dpd, pa_model=pa)
+    net.freeze_pa_model()
+    net = net.cuda()
+    net.train()
+    rng = np.random.RandomState(pa_h + T)
+    x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    o = Oracle("f32")
+    md, mp = make_model(dpd_bb, dpd_h, bits_w=bits, bits_a=bits), make_model(pa_bb, pa_h)
+    pd = np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in dpd.parameters()])
+    pp = pa.backbone.flat_params().detach().cpu().numpy().copy()
+    u = o.qat_forward(md, pd, x)
+    y, _ = o.forward(mp, pp, u)
+    lo, dy = o.loss(loss, y, t)
+    _, du = o.backward(mp, pp, u, dy)
+    gd, _ = o.qat_backward(md, pd, x, du, need_dx=False)
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.cascade_one_launch(B, T, torch.device("cuda", 0)) is not None
+    lg = fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), loss, 0.0)
+    # 8-bit grids: the integer sums are exact in any order; 16-bit grids: the summation order shows at the level of one LSB (qat_s16.hip)
+    wide = bits > 8
+    assert abs(lg.item() - lo) < (3e-4 if wide else 2e-5) * max(1.0, lo)
+    got = opt.grad[:-4].cpu().numpy()
+    off = 0
+    for k, v in dpd.named_parameters():
+        n = v.numel()
+        ref = gd[off:off + n]
+        if np.abs(ref).max() > 0:
+            assert rel_err(got[off:off + n], ref) < (5e-3 if wide else 3e-4 if loss == "l2" else 2e-3), k
+        else:
+            assert np.abs(got[off:off + n]).max() == 0, k
+        off += n
