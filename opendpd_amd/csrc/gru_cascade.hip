@@ -285,12 +285,64 @@ __global__ __launch_bounds__(128) void qat_cascade_kernel(CascArgs a) {
     }
 }
 
+// ... and the quantised TRes-DeltaGRU (the OpenDPDv2 QAT stage; QatDeltaSeq)
+template <bool LUT, int PV, int FMP, bool DGP>
+__global__ __launch_bounds__(128) void qat_delta_cascade_kernel(CascArgs a) {
+    using D = q16::QatDeltaSeq<LUT>;
+    using P = GpSeq<PV == 0 ? 1 : 2, FMP, DGP, false, PV == 1>;
+    static_assert(D::C == kCascChunk, "one hand-off granularity");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int T = a.T, NC = (T + kCascChunk - 1) / kCascChunk;
+    const int Pd = q16::qat_layout(q16::K_TRES, a.Hd).P, Pp = gru_layout(a.Hp, P::F, DGP).P;
+    float* rd = smem;
+    float* rp = rd + D::region_floats(T, Pd);
+    float* xch = rp + P::region_floats(T, Pp);
+    float* pa_ftab = rp + pad4(Pp);
+    float2* pa_ubuf = reinterpret_cast<float2*>(rp + pad4(Pp) + P::off_ubuf(T));
+    float2* dpd_dyb = reinterpret_cast<float2*>(rd + D::off_dyb_region(T, Pd));
+    if (wave == 0) {
+        D e;
+        e.setup(smem, rd, a.dpd_params, a.Hd, T, a.bits_w, a.bits_a, a.thx, a.thh);
+        __syncthreads();
+        for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+            const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+            const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+            e.fwd_begin();
+            for (int k = 0; k <= NC; ++k) {
+                if (k < NC) {
+                    const int t0 = k * kCascChunk;
+                    e.fwd_chunk(k, t0, min(kCascChunk, T - t0), xg, [&](int t, float y0, float y1) {
+                        pa_ubuf[t] = make_float2(y0, y1);
+                        P::write_feat(pa_ftab, t, y0, y1);
+                    });
+                }
+                __syncthreads();
+            }
+            e.bwd_begin();
+            for (int k = 0; k <= NC; ++k) {
+                if (k >= 1) {
+                    const int c = NC - k, t0 = c * kCascChunk;
+                    e.bwd_chunk(c, t0, min(kCascChunk, T - t0), xg);
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        e.write_partials(a.partials + (size_t)blockIdx.x * (Pd + kLossCols), xch[0]);
+        e.add_stats(a.stats, a.B);
+    } else {
+        casc_pa_wave<P>(a, smem, rp, pa_ubuf, dpd_dyb, xch);
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kDpdDelta = 100, kDpdTres = 101, kDpdLstm = 102;
-constexpr int kDpdQat = 200;       // + 2 * kind (q16::K_GRU / K_Q4 / K_A4) + (LUT gates: <= 8 bits)      // CascCfg::fmd of the delta DPDs (the GRU-family ones carry their feature mode)
+constexpr int kDpdQat = 200;       // + 2 * kind (q16::K_GRU / K_Q4 / K_A4) + (LUT gates: <= 8 bits)
+constexpr int kDpdQatTres = 300;   // + (LUT gates)      // CascCfg::fmd of the delta DPDs (the GRU-family ones carry their feature mode)
 struct CascCfg { int fmd, fmp, pv, nbd, Pd, Pp; bool dgd, dgp; };
 bool casc_model(const odpd_model_t* m, int& fm, bool& dg) {
     if (m->bits_w > 0) return false;
@@ -309,15 +361,17 @@ bool casc_cfg(const odpd_model_t* dpd, const odpd_model_t* pa, CascCfg& c) {
     const bool lstm = dpd->bits_w == 0 && dpd->backbone == ODPD_LSTM;
     const bool qat = dpd->bits_w > 0 && dpd->bits_a > 0 && (dpd->backbone == ODPD_GRU || dpd->backbone == ODPD_QGRU || dpd->backbone == ODPD_QGRU_AMP1);
     const int qkind = dpd->backbone == ODPD_GRU ? q16::K_GRU : dpd->backbone == ODPD_QGRU ? q16::K_Q4 : q16::K_A4;
+    const bool qtres = dpd->bits_w > 0 && dpd->bits_a > 0 && dpd->backbone == ODPD_TRES_DELTAGRU;
     if (delta) { c.fmd = dpd->backbone == ODPD_TRES_DELTAGRU ? kDpdTres : kDpdDelta; c.dgd = false; }
     else if (lstm) { c.fmd = kDpdLstm; c.dgd = false; }
     else if (qat) { c.fmd = kDpdQat + 2 * qkind + ((dpd->bits_w <= 8 && dpd->bits_a <= 8) ? 1 : 0); c.dgd = false; }
+    else if (qtres) { c.fmd = kDpdQatTres + ((dpd->bits_w <= 8 && dpd->bits_a <= 8) ? 1 : 0); c.dgd = false; }
     else if (!casc_model(dpd, c.fmd, c.dgd)) return false;
-    if (dpd->hidden < 1 || dpd->hidden > ((delta || lstm || qat) ? 16 : 32) || pa->hidden < 1 || pa->hidden > 32) return false;
+    if (dpd->hidden < 1 || dpd->hidden > ((delta || lstm || qat || qtres) ? 16 : 32) || pa->hidden < 1 || pa->hidden > 32) return false;
     c.nbd = dpd->hidden > 16 ? 2 : 1;
     if (c.fmp != FEAT_RAW2 && c.fmp != FEAT_DGRU6) return false;      // PAs of the reference's scripts: gru, dgru
     c.pv = pa->hidden > 24 ? 2 : pa->hidden > 16 ? 1 : 0;
-    c.Pd = delta ? delta_layout(dpd->hidden, c.fmd == kDpdTres).P : lstm ? lstm_layout(dpd->hidden, 0).P : qat ? q16::qat_layout(qkind, dpd->hidden).P
+    c.Pd = delta ? delta_layout(dpd->hidden, c.fmd == kDpdTres).P : lstm ? lstm_layout(dpd->hidden, 0).P : qat ? q16::qat_layout(qkind, dpd->hidden).P : qtres ? q16::qat_layout(q16::K_TRES, dpd->hidden).P
                                                                      : gru_layout(dpd->hidden, feat_dim(c.fmd), c.dgd).P;
     c.Pp = gru_layout(pa->hidden, feat_dim(c.fmp), c.dgp).P;
     return true;
@@ -332,6 +386,8 @@ template <> struct DpdEngine<1, kDpdLstm, false> { using type = LstmSeq; };
     template <> struct DpdEngine<1, kDpdQat + 2 * MK_ + 1, false> { using type = q16::QatSeq<MK_, true>; };
 ODPD_QAT_ENGINE(q16::K_GRU) ODPD_QAT_ENGINE(q16::K_Q4) ODPD_QAT_ENGINE(q16::K_A4)
 #undef ODPD_QAT_ENGINE
+template <> struct DpdEngine<1, kDpdQatTres, false> { using type = q16::QatDeltaSeq<false>; };
+template <> struct DpdEngine<1, kDpdQatTres + 1, false> { using type = q16::QatDeltaSeq<true>; };
 template <int NBD, int FMD, bool DGD, int PV, int FMP, bool DGP>
 size_t casc_lds(int T, int Pd, int Pp) {
     return ((size_t)DpdEngine<NBD, FMD, DGD>::type::region_floats(T, Pd) + GpSeq<PV == 0 ? 1 : 2, FMP, DGP, false, PV == 1>::region_floats(T, Pp) + 4) *
@@ -360,7 +416,8 @@ size_t casc_lds(int T, int Pd, int Pp) {
     ODPD_CASC_PA(1, kDpdLstm, false, CALL)     \
     ODPD_CASC_PA(1, kDpdQat + 2 * q16::K_GRU, false, CALL) ODPD_CASC_PA(1, kDpdQat + 2 * q16::K_GRU + 1, false, CALL) \
     ODPD_CASC_PA(1, kDpdQat + 2 * q16::K_Q4, false, CALL)  ODPD_CASC_PA(1, kDpdQat + 2 * q16::K_Q4 + 1, false, CALL)  \
-    ODPD_CASC_PA(1, kDpdQat + 2 * q16::K_A4, false, CALL)  ODPD_CASC_PA(1, kDpdQat + 2 * q16::K_A4 + 1, false, CALL)
+    ODPD_CASC_PA(1, kDpdQat + 2 * q16::K_A4, false, CALL)  ODPD_CASC_PA(1, kDpdQat + 2 * q16::K_A4 + 1, false, CALL)  \
+    ODPD_CASC_PA(1, kDpdQatTres, false, CALL)              ODPD_CASC_PA(1, kDpdQatTres + 1, false, CALL)
 
 size_t casc_lds_bytes(const CascCfg& c, int T) {
 #define ODPD_CASC_LDS(NBD_, FMD_, DGD_, PV_, FMP_, DGP_) casc_lds<NBD_, FMD_, DGD_, PV_, FMP_, DGP_>(T, c.Pd, c.Pp)
@@ -385,6 +442,7 @@ int casc_launch(hipStream_t st, const CascArgs& a, const CascCfg& c) {
     };
     if constexpr (FMD == kDpdDelta || FMD == kDpdTres) return launch(delta_cascade_kernel<FMD == kDpdTres, PV, FMP, DGP>);
     else if constexpr (FMD == kDpdLstm) return launch(lstm_cascade_kernel<PV, FMP, DGP>);
+    else if constexpr (FMD >= kDpdQatTres) return launch(qat_delta_cascade_kernel<FMD == kDpdQatTres + 1, PV, FMP, DGP>);
     else if constexpr (FMD >= kDpdQat) return launch(qat_cascade_kernel<(FMD - kDpdQat) / 2, ((FMD - kDpdQat) & 1) != 0, PV, FMP, DGP>);
     else return launch(gru_cascade_kernel<NBD, FMD, DGD, PV, FMP, DGP>);
 }

@@ -273,5 +273,368 @@ struct QatSeq {
     }
 };
 
+
+// The quantised TRes-DeltaGRU (the OpenDPDv2 recipe: deltagru_tcnskip.py:156-162, 266-291 under the surgery; qat_s16.hip delta_cell) as the
+// DPD wave: thresholded deltas of the six features (one feature per lane, as DeltaSeq) and of the state, quantised (q_a) and multiplied with
+// the quantised bias-free x2h / h2h weights — integer sums, scaled by one FMA each into the four fp32 accumulators of a unit —, sigmoids of
+// the raw accumulators through the boundary table (LUT builds), Qadd(1, -z), the float TCN skip with lane = time step.  The cell state
+// (h, h_p, the four accumulators, x_p: 7 floats per lane) is kept at every chunk start; a backward chunk runs its forward steps again from
+// there and parks the step's factors (SaveD), then back-propagates with CARRIED accumulator gradients (G_r, G_z, G_n, G_nh: the
+// accumulators are running sums, so their gradients are, backwards).  hidden <= 16.
+template <bool LUT>
+struct QatDeltaSeq {
+    static constexpr int F = 6, C = 32;
+    static constexpr int NSV = 15;                      // parked per unit and step: hp qdhk npo omz z c2 c3 An Az B1 B2A mh pph hok pho
+    static constexpr int kTabFloats = 6 * 4 * 64 * 4;
+    __host__ __device__ static int tp(int T) { return (T + 63) & ~63; }
+    __host__ __device__ static int nchunks(int T) { return (T + C - 1) / C; }
+    __host__ __device__ static int off_buf() { return LUT ? 4 * 256 + kMaxThr + 4 : 0; }              // LUT | boundary table first; tables | buffers start here
+    __host__ __device__ static int off_ck(int T) { return tp(T) * 8; }                                // feat [Tp][8]: f0..f5 (float), skip0, skip1
+    __host__ __device__ static int off_dyb(int T) { return off_ck(T) + nchunks(T) * 7 * 64; }         // ck [chunks][7][64]
+    __host__ __device__ static int off_sv(int T) { return off_dyb(T) + tp(T) * 2; }
+    __host__ __device__ static int off_fqs(int T) { return off_sv(T) + C * 16 * NSV; }                // sv [C][NSV][16]
+    __host__ __device__ static int off_hist(int T) { return off_fqs(T) + C * 8; }                     // fqs [C][8]: the step's six quantised masked dx
+    __host__ __device__ static int off_dump(int T) { return off_hist(T) + (C + 1) * 16; }
+    __host__ __device__ static int off_hw(int T) { return off_dump(T) + 512; }
+    __host__ __device__ static int buf_floats(int T) { return off_hw(T) + 32; }
+    __host__ __device__ static int region_floats(int T, int P) {
+        const int buf = buf_floats(T);
+        return pad4(P) + off_buf() + (buf > kTabFloats ? buf : kTabFloats);
+    }
+    __host__ __device__ static int off_dyb_region(int T, int P) { return pad4(P) + off_buf() + off_dyb(T); }
+
+    float wrec[16], wT[16], wx[F], wo0, wo1, w1[18], w2[6], thx, thh;
+    QSc qs;
+    QK k;
+    WQ wq;
+    QatLayout L;
+    float h, hp, xp, dmr, dmz, dmn, dmnh;             // cell state (replicated on every row; x_p: feature `fc` of the lane)
+    float gh, ghp, gr, gz, gn, gnh;                   // backward carries
+    f32x16 acc1, acc2;
+    float dwo0, dwo1, tw1[18], tw2[6], zx, zh;
+    float *smem, *pl, *feat, *ck, *dyb, *sv, *fqs, *hist, *dump, *hw;
+    const float4* lutq;
+    const float* thr;
+    RowMasks rm;
+    int H, T, lane, col, role, fc, Ksig, svp0, svp_step, hp0, hp_step, fq0, fq_step;
+    bool vo;
+
+    // (one workgroup barrier inside)
+    __device__ __forceinline__ void setup(float* base, float* region, const float* params, int Hm, int T_, int bits_w, int bits_a, float thx_,
+                                          float thh_) {
+        smem = base;
+        lane = threadIdx.x & 63; col = lane & 15; role = lane >> 4;      // r | z | n | -
+        L = qat_layout(K_TRES, Hm);
+        H = L.H; T = T_; thx = thx_; thh = thh_;
+        pl = region;
+        for (int i = lane; i < L.P; i += 64) pl[i] = params[i];
+        wave_lds_fence();
+        qs = load_qsc<K_TRES>(pl, L, bits_a);
+        wq = make_wq(pl, L, bits_w);
+        k = make_qk(qs, wq);
+        Ksig = sig_levels(qs.sig);
+        float* lut = region + pad4(L.P);
+        float* tab = lut + off_buf();
+        vo = col < H;
+        const bool gate_row = role < 3;
+        const int g = gate_row ? role : 0;
+        if constexpr (LUT) {      // as fill_luts (odpd_qat.h) with the sigmoid boundary table, one wave
+            float4* l4 = reinterpret_cast<float4*>(lut);
+            for (int i = lane; i < (1 << bits_a); i += 64) {
+                const double x = (double)((float)(i + (int)qs.add.qn) * qs.add.s);
+                const Gate gs = sig_gate((float)(1.0 / (1.0 + exp(-x))), qs, k), gt = tanh_gate((float)tanh(x), qs, k);
+                l4[i] = make_float4(gs.c, gs.d, gt.c, gt.d);
+            }
+            float* th = lut + 4 * 256;
+            for (int j = lane; j <= Ksig + 1; j += 64) {
+                float t;
+                if (j == 0) t = -__builtin_inff();
+                else if (j == Ksig + 1) t = __builtin_inff();
+                else {
+                    const double p = ((double)j - 0.5) * (double)qs.sig.s;
+                    if (p >= 1.0) t = __builtin_inff();
+                    else {
+                        const double b = log(p / (1.0 - p));
+                        t = (float)b;
+                        if ((double)t < b) {                                                     // smallest float >= b
+                            const int bits32 = __builtin_bit_cast(int, t);
+                            t = __builtin_bit_cast(float, t > 0.0f ? bits32 + 1 : (t < 0.0f ? bits32 - 1 : 1));
+                        }
+                    }
+                }
+                th[j] = t;
+            }
+        }
+        lutq = reinterpret_cast<const float4*>(lut) - (int)qs.add.qn;
+        thr = lut + 4 * 256;
+        {
+            const int dir = rot_dir(col);
+            float4* t4 = reinterpret_cast<float4*>(tab);
+            for (int idx = 0; idx < 6 * 4; ++idx) {
+                const int tr = idx >> 2, q = idx & 3, gg = tr % 3;
+                const bool transposed = tr >= 3;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = (col + dir * (4 * q + e)) & 15;
+                    const bool ok = col < H && m < H;
+                    v[e] = ok ? kq(pl[L.o_wh + (gg * H + (transposed ? m : col)) * H + (transposed ? col : m)], wq.h) : 0.0f;
+                }
+                t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        {
+            TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+            load_rot(wrec, tl + g * 4 * 64);
+            load_rot(wT, tl + (3 + g) * 4 * 64);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { wrec[i] = gate_row ? wrec[i] : 0.0f; wT[i] = gate_row ? wT[i] : 0.0f; }
+        }
+#pragma unroll
+        for (int i = 0; i < F; ++i) wx[i] = (vo && gate_row) ? kq(pl[L.o_wx + (g * H + col) * F + i], wq.x) : 0.0f;
+        wo0 = vo ? kq(pl[L.o_wo + col], wq.o) : 0.0f; wo1 = vo ? kq(pl[L.o_wo + L.OW + col], wq.o) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) { w1[i] = pl[L.o_tcn0 + i]; tw1[i] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { w2[i] = pl[L.o_tcn2 + i]; tw2[i] = 0.0f; }
+        fc = col < 6 ? col : 5;
+        wave_lds_fence();
+        feat = tab; ck = tab + off_ck(T); dyb = tab + off_dyb(T); sv = tab + off_sv(T); fqs = tab + off_fqs(T); hist = tab + off_hist(T);
+        dump = tab + off_dump(T); hw = tab + off_hw(T);
+        if (lane < 32) hw[lane] = (lane & 15) < H ? kq(pl[L.o_wo + (lane >> 4) * L.OW + (lane & 15)], wq.o) : 0.0f;
+        rm = row_masks();
+        // the recomputed steps' stores: row 0 parks the unit's NSV factors, row 3 h(t), row 1's lanes 0..7 the quantised masked dx
+        svp0 = role == 0 ? (int)(sv - smem) + col : (int)(dump - smem) + lane; svp_step = role == 0 ? 16 * NSV : 0;
+        hp0 = role == 3 ? (int)(hist - smem) + 16 + col : (int)(dump - smem) + 320 + lane; hp_step = role == 3 ? 16 : 0;
+        fq0 = (role == 1 && col < 8) ? (int)(fqs - smem) + col : (int)(dump - smem) + 384 + lane; fq_step = (role == 1 && col < 8) ? 8 : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
+        dwo0 = 0.0f; dwo1 = 0.0f; zx = 0.0f; zh = 0.0f;
+        wave_lds_fence();
+    }
+    // TCN skip pre-activations of one sample (q16_tcn, qat_s16.hip): float path, Conv1d / Hardswish are not swapped
+    __device__ __forceinline__ void tcn(float2 xm, float2 xc, float2 xq, float (&s1)[3], float (&s2)[2]) const {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = w1[c * 6] * xm.x;
+            v = __builtin_fmaf(w1[c * 6 + 1], xc.x, v); v = __builtin_fmaf(w1[c * 6 + 2], xq.x, v);
+            v = __builtin_fmaf(w1[c * 6 + 3], xm.y, v); v = __builtin_fmaf(w1[c * 6 + 4], xc.y, v);
+            s1[c] = __builtin_fmaf(w1[c * 6 + 5], xq.y, v);
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float v = w2[o * 3] * hardswishf_(s1[0]);
+            v = __builtin_fmaf(w2[o * 3 + 1], hardswishf_(s1[1]), v);
+            s2[o] = __builtin_fmaf(w2[o * 3 + 2], hardswishf_(s1[2]), v);
+        }
+    }
+
+    __device__ __forceinline__ void fwd_begin() { h = 0.0f; hp = 0.0f; xp = 0.0f; dmr = 0.0f; dmz = 0.0f; dmn = 0.0f; dmnh = 0.0f; }
+
+    // one quantised delta-cell step (delta_cell, qat_s16.hip) at time t.  SAVE: parks the backward's factors
+    template <bool SAVE>
+    __device__ __forceinline__ void step(int t, int sp, int hq_, int fqp) {
+        // x side, one feature per lane: thresholded delta, its quantised value in grid units
+        const float fv = feat[t * 8 + fc];
+        const float d = fv - xp;
+        const bool keep = !(__builtin_fabsf(d) < thx);                 // masked_fill(|d| < th, 0)  (deltagru_tcnskip.py:218-228)
+        const float dxm = keep ? d : 0.0f;
+        xp = (__builtin_fabsf(d) >= thx) ? fv : xp;
+        if constexpr (!SAVE) zx += (dxm == 0.0f) ? 1.0f : 0.0f;
+        const float vx = dxm * k.inv_xa, fqk = rintf(gm(vx, k));
+        float xsum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < F; ++i)
+            xsum = __builtin_fmaf(wx[i], __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fqk), i)), xsum);
+        // h side
+        const float hv = h;
+        const float dh_ = hv - hp;
+        const bool keeph = !(__builtin_fabsf(dh_) < thh);
+        const float dhm = keeph ? dh_ : 0.0f;
+        hp = (__builtin_fabsf(dh_) >= thh) ? hv : hp;
+        if constexpr (!SAVE) zh += (vo && dhm == 0.0f) ? 1.0f : 0.0f;
+        const float v0 = dhm * k.inv_ha, m0 = gm(v0, k), qdhk = rintf(m0);
+        const float hsum = rotdot(0.0f, wrec, qdhk);
+        float X[4], Hs[4];
+        gather_rows(xsum, X);
+        gather_rows(hsum, Hs);
+        // mac_x = x2h(dx) + dm; dm_r = mac_x_r + mac_h_r, dm_n = mac_x_n, dm_nh = mac_h_n + dm_nh  (deltagru_tcnskip.py:236-246)
+        dmr = __builtin_fmaf(Hs[0], k.Sh, __builtin_fmaf(X[0], k.Sx, dmr));
+        dmz = __builtin_fmaf(Hs[1], k.Sh, __builtin_fmaf(X[1], k.Sx, dmz));
+        dmn = __builtin_fmaf(X[2], k.Sx, dmn);
+        dmnh = __builtin_fmaf(Hs[2], k.Sh, dmnh);
+        const Gate Gr = sig_any<LUT>(dmr, qs, k, thr, Ksig), Gz = sig_any<LUT>(dmz, qs, k, thr, Ksig);
+        const float pm1 = Gr.c * dmnh, mm1 = gm(pm1, k);
+        const float vn = __builtin_fmaf(rintf(mm1), k.s_mul, dmn) * k.inv_add, mn = gm(vn, k);
+        const Gate Gn = tanh_grid<LUT>(rintf(mn), qs, k, lutq);
+        const float vo_ = __builtin_fmaf(Gz.c, -k.s_mul, 1.0f) * k.inv_add, mo = gm(vo_, k);          // self.add(1, -gate_z)  (deltagru_tcnskip.py:290)
+        const float omz = rintf(mo) * k.s_add;
+        const float pm3 = omz * Gn.c, pm2 = Gz.c * hv;
+        const float mm3 = gm(pm3, k), mm2 = gm(pm2, k);
+        const float vh = (rintf(mm3) + rintf(mm2)) * k.c_ma, mhv = gm(vh, k);
+        const float hnew = rintf(mhv) * k.s_add;
+        if constexpr (SAVE) {
+            const bool pah = mhv == vh;
+            const bool p1 = mm1 == pm1;
+            const float nt = Gn.c * k.s_mul;
+            const float vq = hnew * k.inv_oa, mq = gm(vq, k);
+            float* s = smem + sp;
+            s[0 * 16] = hv; s[1 * 16] = qdhk; s[2 * 16] = mo == vo_ ? nt : 0.0f; s[3 * 16] = omz; s[4 * 16] = Gz.c * k.s_mul;
+            s[5 * 16] = (pah && mm2 == pm2) ? 1.0f : 0.0f; s[6 * 16] = (pah && mm3 == pm3) ? 1.0f : 0.0f;
+            s[7 * 16] = mn == vn ? Gn.d : 0.0f; s[8 * 16] = Gz.d;
+            s[9 * 16] = p1 ? Gr.c * k.s_mul : 0.0f; s[10 * 16] = p1 ? dmnh * Gr.d : 0.0f;
+            s[11 * 16] = keeph ? 1.0f : 0.0f; s[12 * 16] = m0 == v0 ? k.s_hw : 0.0f;
+            s[13 * 16] = rintf(mq); s[14 * 16] = mq == vq ? k.s_ow : 0.0f;
+            smem[fqp] = fqk;
+        }
+        h = hnew;
+        smem[hq_] = hnew;
+    }
+
+    // forward chunk c: features and the TCN skip with lane = time step, the cell state kept, the recurrence, fc_out + skip with lane = time step
+    template <typename Sink>
+    __device__ __forceinline__ void fwd_chunk(int c, int t0, int len, const float2* xg, Sink sink) {
+        {
+            const int t = t0 + lane;
+            const float2 zero = make_float2(0.0f, 0.0f);
+            const float2 rc = t < T ? xg[t] : make_float2(0.5f, 0.5f);
+            const float2 rn = t + 1 < T ? xg[t + 1] : xg[0];                       // torch.roll(x, -1): the last step sees sample 0
+            const float2 rm_ = (t - kHalo >= 0 && t - kHalo < T) ? xg[t - kHalo] : zero;
+            const float2 rp = t + kHalo < T ? xg[t + kHalo] : zero;
+            const float a2 = rc.x * rc.x + rc.y * rc.y, a = sqrtf(a2), a3 = a * a * a;      // (q16_slots' operation order)
+            float s1[3], s2[2];
+            tcn(rm_, rc, rp, s1, s2);
+            if (lane < len) {
+                reinterpret_cast<float4*>(feat)[2 * t] = make_float4(rc.x, rc.y, a, a3);
+                reinterpret_cast<float4*>(feat)[2 * t + 1] = make_float4(rn.x, rn.y, hardswishf_(s2[0]), hardswishf_(s2[1]));
+            }
+            float* kk = ck + c * 7 * 64 + lane;
+            kk[0] = h; kk[64] = hp; kk[128] = xp; kk[192] = dmr; kk[256] = dmz; kk[320] = dmn; kk[384] = dmnh;
+        }
+        wave_lds_fence();
+        int hq_ = hp0;
+        for (int tt = 0; tt < len; ++tt) { step<false>(t0 + tt, 0, hq_, 0); hq_ += hp_step; }
+        wave_lds_fence();
+        if (lane < len) {
+            const int t = t0 + lane;
+            const float* hv = hist + (lane + 1) * 16;
+            float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float hok = gk(hv[u] * k.inv_oa, k);
+                p0 = __builtin_fmaf(hw[u], hok, p0); p1 = __builtin_fmaf(hw[16 + u], hok, p1);
+            }
+            float y0 = __builtin_fmaf(p0, k.So, 0.0f), y1 = __builtin_fmaf(p1, k.So, 0.0f);       // bias-free fc_out; train mode: no output quantiser
+            y0 += feat[t * 8 + 6]; y1 += feat[t * 8 + 7];
+            sink(t, y0, y1);
+        }
+        wave_lds_fence();
+    }
+
+    __device__ __forceinline__ void bwd_begin() { gh = 0.0f; ghp = 0.0f; gr = 0.0f; gz = 0.0f; gn = 0.0f; gnh = 0.0f; }
+
+    __device__ __forceinline__ void bwd_chunk(int c, int t0, int len, const float2* xg) {
+        {
+            const float* kk = ck + c * 7 * 64 + lane;
+            h = kk[0]; hp = kk[64]; xp = kk[128]; dmr = kk[192]; dmz = kk[256]; dmn = kk[320]; dmnh = kk[384];
+        }
+        wave_lds_fence();
+        {
+            int sp = svp0, hq_ = hp0, fqp = fq0;
+            for (int tt = 0; tt < len; ++tt) { step<true>(t0 + tt, sp, hq_, fqp); sp += svp_step; hq_ += hp_step; fqp += fq_step; }
+        }
+        wave_lds_fence();
+        if (lane < len) {      // TCN skip gradients (float), lane = time step
+            const int t = t0 + lane;
+            const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * t);
+            const float2 zero = make_float2(0.0f, 0.0f);
+            const float2 xc = xg[t], xm = t - kHalo >= 0 ? xg[t - kHalo] : zero, xq = t + kHalo < T ? xg[t + kHalo] : zero;
+            float s1[3], s2[2];
+            tcn(xm, xc, xq, s1, s2);
+            const float d2[2] = {dyv.x * q16_hsg_(s2[0]), dyv.y * q16_hsg_(s2[1])};
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const float hs = hardswishf_(s1[cc]);
+                tw2[cc] = __builtin_fmaf(d2[0], hs, tw2[cc]);
+                tw2[3 + cc] = __builtin_fmaf(d2[1], hs, tw2[3 + cc]);
+                const float d1 = __builtin_fmaf(d2[0], w2[cc], d2[1] * w2[3 + cc]) * q16_hsg_(s1[cc]);
+                tw1[cc * 6 + 0] = __builtin_fmaf(d1, xm.x, tw1[cc * 6 + 0]); tw1[cc * 6 + 1] = __builtin_fmaf(d1, xc.x, tw1[cc * 6 + 1]);
+                tw1[cc * 6 + 2] = __builtin_fmaf(d1, xq.x, tw1[cc * 6 + 2]); tw1[cc * 6 + 3] = __builtin_fmaf(d1, xm.y, tw1[cc * 6 + 3]);
+                tw1[cc * 6 + 4] = __builtin_fmaf(d1, xc.y, tw1[cc * 6 + 4]); tw1[cc * 6 + 5] = __builtin_fmaf(d1, xq.y, tw1[cc * 6 + 5]);
+            }
+        }
+        for (int tt = len - 1; tt >= 0; --tt) {
+            const float* s = sv + tt * 16 * NSV + col;
+            const float hp_ = s[0], qdhk = s[16], npo = s[2 * 16], omz = s[3 * 16], z = s[4 * 16], c2 = s[5 * 16], c3 = s[6 * 16], An = s[7 * 16],
+                        Az = s[8 * 16], B1 = s[9 * 16], B2A = s[10 * 16], mh = s[11 * 16], pph = s[12 * 16], hok = s[13 * 16], pho = s[14 * 16];
+            const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * (t0 + tt));
+            dwo0 = __builtin_fmaf(dyv.x, hok, dwo0); dwo1 = __builtin_fmaf(dyv.y, hok, dwo1);
+            const float g = gh + (dyv.x * wo0 + dyv.y * wo1) * pho;
+            const float g2 = g * c2, g3 = g * c3;
+            const float dz = g2 * hp_ - g3 * npo;
+            const float dan = g3 * omz * An;
+            const float ghprev = g2 * z;
+            gn += dan; gnh += dan * B1; gr += dan * B2A; gz += dz * Az;
+            const float d_h = vsel(rm.m[0], gr, vsel(rm.m[1], gz, vsel(rm.m[2], gnh, 0.0f)));
+            const float d_x = vsel(rm.m[0], gr, vsel(rm.m[1], gz, vsel(rm.m[2], gn, 0.0f)));
+            float ddh = rotdot(0.0f, wT, d_h);
+            ddh += xor16(ddh);
+            ddh += xor32(ddh);
+            const float g2b = ddh * pph;
+            gh = ghprev + mh * (g2b + ghp);
+            ghp = (1.0f - mh) * ghp - mh * g2b;
+            const float fsx = col < 6 ? fqs[tt * 8 + col] : 0.0f;
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_h, qdhk, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_x, fsx, acc2, 0, 0, 0);
+        }
+        wave_lds_fence();
+    }
+
+    __device__ __forceinline__ void write_partials(float* prow, float loss) {
+        for (int i = lane; i < L.P + kLossCols; i += 64) prow[i] = 0.0f;
+        wave_lds_fence();
+        __builtin_amdgcn_s_waitcnt(0);
+        if (vo && role == 0) {
+            prow[L.o_wo + col] = dwo0 * k.s_oa * qpass(pl[L.o_wo + col], wq.o);
+            prow[L.o_wo + L.OW + col] = dwo1 * k.s_oa * qpass(pl[L.o_wo + L.OW + col], wq.o);
+        }
+#pragma unroll
+        for (int i = 0; i < 18; ++i) { const float v = wsum(tw1[i]); if (lane == 0) prow[L.o_tcn0 + i] = v; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const float v = wsum(tw2[i]); if (lane == 0) prow[L.o_tcn2 + i] = v; }
+        if (lane == 0) prow[L.P] = loss;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 4 * role + rr;
+                if (i < H) {
+                    if (col < H) { const int j = L.o_wh + (g * H + i) * H + col; prow[j] = acc1[4 * g + rr] * k.s_ha * qpass(pl[j], wq.h); }
+                    if (col < F) { const int j = L.o_wx + (g * H + i) * F + col; prow[j] = acc2[4 * g + rr] * k.s_xa * qpass(pl[j], wq.x); }
+                }
+            }
+    }
+    __device__ __forceinline__ static float wsum(float v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    }
+    __device__ __forceinline__ static float q16_hsg_(float v) { return v < -3.0f ? 0.0f : (v <= 3.0f ? v * (1.0f / 3.0f) + 0.5f : 1.0f); }
+    // sparsity counters of the forward passes: dx zeros = the six feature lanes of row 0, dh zeros = the hidden units of row 0
+    __device__ __forceinline__ void add_stats(double* stats, int B) {
+        if (stats == nullptr) return;
+        float tx = (role == 0 && col < 6) ? zx : 0.0f, th = role == 0 ? zh : 0.0f;
+        for (int o = 32; o > 0; o >>= 1) { tx += __shfl_down(tx, o); th += __shfl_down(th, o); }
+        if (lane == 0) {
+            atomicAdd(&stats[0], (double)tx);
+            atomicAdd(&stats[2], (double)th);
+        }
+        if (blockIdx.x == 0 && lane == 0) {
+            atomicAdd(&stats[1], 6.0 * (double)B * (double)T);
+            atomicAdd(&stats[3], (double)H * (double)B * (double)T);
+        }
+    }
+};
+
 }  // namespace q16
 }  // namespace odpd
