@@ -383,11 +383,19 @@ def main():
             for name_, dkw, pkw in (("GRU15 -> frozen GRU23 (the registry's default sizes)", dict(hidden_size=15, backbone_type="gru"), dict(hidden_size=23, backbone_type="gru")),
                                     (f"DGRU{H} -> frozen DGRU{H}", dict(hidden_size=H, backbone_type="dgru"), dict(hidden_size=H, backbone_type="dgru")),
                                     ("config3: TRes-DeltaGRU15 -> frozen DGRU23", dict(hidden_size=15, backbone_type="deltagru_tcnskip", thx=0.01, thh=0.05),
-                                     dict(hidden_size=23, backbone_type="dgru"))):
+                                     dict(hidden_size=23, backbone_type="dgru")),
+                                    ("config5: quantisation-aware QGRU10 W8A8 -> frozen DGRU23", dict(hidden_size=10, backbone_type="qgru", bits=8),
+                                     dict(hidden_size=23, backbone_type="dgru")),
+                                    ("OpenDPDv2 QAT stage: quantisation-aware TRes-DeltaGRU15 W16A16 -> frozen DGRU23",
+                                     dict(hidden_size=15, backbone_type="deltagru_tcnskip", thx=0.01, thh=0.05, bits=16), dict(hidden_size=23, backbone_type="dgru"))):
                 torch.manual_seed(4)
-                casc = CascadedModel(dpd_model=CoreModel(2, num_layers=1, **dkw), pa_model=CoreModel(2, num_layers=1, **pkw))
+                dm = CoreModel(2, num_layers=1, **{k_: v_ for k_, v_ in dkw.items() if k_ != "bits"})
+                if "bits" in dkw:      # quantisation-aware DPD: the reference's surgery on the float model (quant/__init__.py:20-37)
+                    dm = get_quant_model(SimpleNamespace(quant=True, n_bits_w=dkw["bits"], n_bits_a=dkw["bits"], pretrained_model=""), dm)
+                casc = CascadedModel(dpd_model=dm, pa_model=CoreModel(2, num_layers=1, **pkw))
                 casc.freeze_pa_model()
                 casc = casc.to(dev)
+                casc.train()
                 o_ = FusedAdamW(casc, lr=5e-4)
                 el_ = min(run_steps(o_, xr_, tr_, 50, 3, rb * T * 2, None)[0] for _ in range(3))
                 small[name_] = {"ms_per_step": 1e3 * el_ / 50, "value": rb * T * 50 / el_,

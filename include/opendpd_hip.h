@@ -229,11 +229,13 @@ int odpd_train_epoch_opt(void* stream, const odpd_model_t* m, int loss_kind, con
  * (opt_kind < 0: AdamW with the given betas / eps / weight_decay; else ODPD_OPT_*), mean loss of step i -> losses_out[i].
  * ODPD_EUNSUPPORTED unless odpd_cascade_rows > 0 for the epoch's full batch and its tail. `partials`: max over those of
  * (rows, P_dpd + 4).  `comm` (odpd_comm_init; may be NULL = one process): as odpd_train_epoch_dp — every global batch sharded over the
- * communicator's ranks (odpd_shard_range), the loss mean over the GLOBAL batch, one RCCL all-reduce of P_dpd + 4 floats per step. */
+ * communicator's ranks (odpd_shard_range), the loss mean over the GLOBAL batch, one RCCL all-reduce of P_dpd + 4 floats per step.
+ * `skip` (may be NULL): one byte per DPD parameter, non-zero = left out of the norm and of the update, as odpd_clip_adamw_step_masked
+ * (the quantised models' 16-bit output-quantiser scales, whose .grad is None in the reference). */
 int odpd_train_epoch_cascade(void* stream, void* comm, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, const odpd_frames_t* fr,
                              int batch, int opt_kind, float* dpd_params, const float* pa_params, float* grad, float* state1,
                              float* state2, int64_t first_step, double lr, double beta1, double beta2, double eps, double weight_decay,
-                             double max_norm, float* partials, double* dpd_stats, float* losses_out);
+                             double max_norm, const unsigned char* skip, float* partials, double* dpd_stats, float* losses_out);
 
 
 /* The epoch loop for a backbone WITHOUT a fused train kernel at this batch shape: per step the frames are gathered into (B,T,2)

@@ -55,7 +55,7 @@ _EXPORTS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "odpd_train_epoch_cascade": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ModelDesc), C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
-                                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "odpd_framed_train_supported": (C.c_int, [C.POINTER(ModelDesc)]),
     "odpd_framed_train_supported_shape": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
     "odpd_train_fwd_bwd_framed": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int64, C.c_int,

@@ -421,7 +421,8 @@ static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, 
 extern "C" int odpd_train_epoch_cascade(void* stream, void* comm, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind,
                                         const odpd_frames_t* fr, int batch, int opt_kind, float* dpd_params, const float* pa_params, float* grad,
                                         float* state1, float* state2, int64_t first_step, double lr, double beta1, double beta2, double eps,
-                                        double weight_decay, double max_norm, float* partials, double* dpd_stats, float* losses_out) {
+                                        double weight_decay, double max_norm, const unsigned char* skip, float* partials, double* dpd_stats,
+                                        float* losses_out) {
     if (!model_ok(dpd) || !model_ok(pa) || !fr || !fr->x_stream || !fr->y_stream || !fr->order || fr->n_frames <= 0 || fr->frame_length <= 0 ||
         fr->stride <= 0 || batch <= 0 || !dpd_params || !pa_params || !grad || !state1 || !state2 || !partials || !losses_out || first_step <= 0 ||
         opt_kind > ODPD_OPT_RMSPROP)
@@ -461,8 +462,9 @@ extern "C" int odpd_train_epoch_cascade(void* stream, void* comm, const odpd_mod
             if (rc) return rc;
         }
         rc = opt_kind < 0 ? launch_clip_adamw(st, P, dpd_params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
-                                              losses_out + i, inv_count)
-                          : launch_clip_optim(st, opt_kind, P, dpd_params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, inv_count);
+                                              losses_out + i, inv_count, skip)
+                          : launch_clip_optim(st, opt_kind, P, dpd_params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, inv_count,
+                                              skip);
         if (rc) return rc;
     }
     return 0;

@@ -324,7 +324,7 @@ class FusedAdamW:
     def can_run_cascade_epoch(self, loader):
         """True when odpd_train_epoch_cascade can drive a whole train_dpd epoch: frozen PA behind the trained DPD, every batch of the epoch
         served by the one-launch cascade step, one process, resident streams."""
-        if not (self.pa is not None and getattr(self.backbone, "frozen_mask", None) is None
+        if not (self.pa is not None
                 and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size")) and loader.x.is_cuda):
             return False
         dev = loader.x.device
@@ -350,12 +350,20 @@ class FusedAdamW:
         fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
         g = self.param_groups[0]
         adamw = self.kind == "adamw"
+        flat = dpd.flat_params(full_check=True)
+        frozen = getattr(dpd, "frozen_mask", None)     # parameters torch.optim.AdamW would skip (grad is None): the QAT models' 16-bit output scales
+        if frozen is not None and (frozen.device != flat.device or frozen.dtype != torch.uint8):
+            dpd.frozen_mask = frozen = frozen.to(device=flat.device, dtype=torch.uint8).contiguous()
+        for bb in (dpd, pa):       # quantised models: train / eval mode of the module -> ODPD_FLAG_EVAL
+            if hasattr(bb, "sync_mode"):
+                bb.sync_mode()
         rc = lib.odpd_train_epoch_cascade(_lib.stream_ptr(), comm.handle if comm is not None else None, C.byref(dpd.desc), C.byref(pa.desc), _lib.LOSS_IDS[loss_kind], C.byref(fr), B,
                                           -1 if adamw else _lib.OPTIMIZER_IDS[self.kind], _lib.ptr(dpd.flat_params(full_check=True)),
                                           _lib.ptr(pa.flat_params(full_check=True)), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
                                           _lib.ptr(self.exp_avg_sq), self.step_count + 1, float(g["lr"]), float(g["betas"][0]) if adamw else 0.0,
                                           float(g["betas"][1]) if adamw else 0.0, float(g["eps"]) if adamw else 0.0,
-                                          float(g["weight_decay"]) if adamw else 0.0, float(max_norm or 0.0), _lib.ptr(part),
+                                          float(g["weight_decay"]) if adamw else 0.0, float(max_norm or 0.0),
+                                          _lib.ptr(frozen) if frozen is not None else None, _lib.ptr(part),
                                           _lib.ptr(dpd._stats_buffer(dev)), _lib.ptr(losses))
         _lib.check(rc, "odpd_train_epoch_cascade")
         self.step_count += n_steps

@@ -270,7 +270,8 @@ def test_one_launch_cascade_follows_the_chained_launches():
     assert rel_err(traj[0][1].cpu().numpy(), traj[1][1].cpu().numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("dpd_bb,dpd_h,pa_bb,pa_h", [("gru", 15, "gru", 23), ("dgru", 13, "dgru", 13), ("qgru", 10, "dgru", 23), ("deltagru_tcnskip", 15, "dgru", 23)])
+@pytest.mark.parametrize("dpd_bb,dpd_h,pa_bb,pa_h", [("gru", 15, "gru", 23), ("dgru", 13, "dgru", 13), ("qgru", 10, "dgru", 23), ("deltagru_tcnskip", 15, "dgru", 23),
+                                                     ("qgru:w8a8", 10, "dgru", 23), ("deltagru_tcnskip:w16a16", 15, "dgru", 23)])
 @pytest.mark.parametrize("opt_kind", ["adamw", "sgd"])
 def test_native_cascade_epoch_equals_the_python_driven_steps(dpd_bb, dpd_h, pa_bb, pa_h, opt_kind):
     """odpd_train_epoch_cascade (frames read in place from the resident streams, every step issued from C++) against fused_train_step on the
@@ -287,9 +288,16 @@ def test_native_cascade_epoch_equals_the_python_driven_steps(dpd_bb, dpd_h, pa_b
     results = []
     for native in (True, False, "net_train"):
         torch.manual_seed(3)
-        net = CascadedModel(dpd_model=CoreModel(2, dpd_h, 1, dpd_bb, thx=0.01, thh=0.05), pa_model=CoreModel(2, pa_h, 1, pa_bb))
+        dm = CoreModel(2, dpd_h, 1, dpd_bb.split(":")[0], thx=0.01, thh=0.05)
+        if ":" in dpd_bb:      # quantisation-aware DPD (its 16-bit output-quantiser scale is skipped by the optimiser: the native loop's skip mask)
+            from types import SimpleNamespace
+            from opendpd_amd.quant import get_quant_model
+            bits = 8 if dpd_bb.endswith("w8a8") else 16
+            dm = get_quant_model(SimpleNamespace(quant=True, n_bits_w=bits, n_bits_a=bits, pretrained_model=""), dm)
+        net = CascadedModel(dpd_model=dm, pa_model=CoreModel(2, pa_h, 1, pa_bb))
         net.freeze_pa_model()
         net = net.cuda()
+        net.train()
         if hasattr(net.dpd_model.backbone, "set_debug"):
             net.dpd_model.backbone.set_debug(1)
         opt = (FusedAdamW if opt_kind == "adamw" else FusedSGD)(net, lr=2e-3)
