@@ -7,7 +7,10 @@ import torch
 
 sys.path.insert(0, ".")
 import bench
+from types import SimpleNamespace
+
 from opendpd_amd import CascadedModel, CoreModel
+from opendpd_amd.quant import get_quant_model
 from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
 
 T = 200
@@ -17,14 +20,24 @@ for name, dpd_kw, pa_kw, B in (("config 3: TRes-DeltaGRU15 -> frozen DGRU23", di
                                ("quant_qgru_dpd_regr.sh's float stage: QGRU20 -> frozen DGRU8", dict(hidden_size=20, backbone_type="qgru"), dict(hidden_size=8, backbone_type="dgru"), 64),
                                ("the same, chained launches", dict(hidden_size=20, backbone_type="qgru"), dict(hidden_size=8, backbone_type="dgru"), -64),
                                ("train_all_dpd.sh: LSTM9 -> frozen DGRU8", dict(hidden_size=9, backbone_type="lstm"), dict(hidden_size=8, backbone_type="dgru"), 64),
-                               ("the same, chained launches", dict(hidden_size=9, backbone_type="lstm"), dict(hidden_size=8, backbone_type="dgru"), -64)):
+                               ("the same, chained launches", dict(hidden_size=9, backbone_type="lstm"), dict(hidden_size=8, backbone_type="dgru"), -64),
+                               ("config 5: quantisation-aware QGRU10 W8A8 -> frozen DGRU23", dict(hidden_size=10, backbone_type="qgru", bits=8), dict(hidden_size=23, backbone_type="dgru"), 64),
+                               ("the same, chained launches", dict(hidden_size=10, backbone_type="qgru", bits=8), dict(hidden_size=23, backbone_type="dgru"), -64),
+                               ("OpenDPDv2 QAT stage: quantisation-aware TRes-DeltaGRU15 W16A16 -> frozen DGRU23",
+                                dict(hidden_size=15, backbone_type="deltagru_tcnskip", thx=0.01, thh=0.05, bits=16), dict(hidden_size=23, backbone_type="dgru"), 64),
+                               ("the same, chained launches", dict(hidden_size=15, backbone_type="deltagru_tcnskip", thx=0.01, thh=0.05, bits=16),
+                                dict(hidden_size=23, backbone_type="dgru"), -64)):
     from opendpd_amd import _lib
     _lib.load().odpd_set_tuning(b"cascade_one_launch", 0 if B < 0 else 1)
     B = abs(B)
     torch.manual_seed(0)
-    casc = CascadedModel(dpd_model=CoreModel(2, num_layers=1, **dpd_kw), pa_model=CoreModel(2, num_layers=1, **pa_kw))
+    dm = CoreModel(2, num_layers=1, **{k: v for k, v in dpd_kw.items() if k != "bits"})
+    if "bits" in dpd_kw:
+        dm = get_quant_model(SimpleNamespace(quant=True, n_bits_w=dpd_kw["bits"], n_bits_a=dpd_kw["bits"], pretrained_model=""), dm)
+    casc = CascadedModel(dpd_model=dm, pa_model=CoreModel(2, num_layers=1, **pa_kw))
     casc.freeze_pa_model()
     casc = casc.cuda()
+    casc.train()
     opt = FusedAdamW(casc, lr=1e-4)
     x, _ = bench.synth_frames(B, T, seed=1, device=torch.device("cuda"))
     t = x.clone()
