@@ -198,7 +198,9 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_TCNN: return tcnn_fwd((hipStream_t)stream, m, a);
     case FAM_GMP: return gmp_fwd((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_fwd((hipStream_t)stream, m, a);
-    case FAM_QAT: return qat_uses_s16(m, B) ? qat_s16_launch((hipStream_t)stream, m, a, 1) : qgru_family_fwd((hipStream_t)stream, m, a);
+    case FAM_QAT:
+        if (qat_uses_gp_eval(m, B, ckpt != nullptr)) return qat_gp_eval((hipStream_t)stream, m, a);
+        return qat_uses_s16(m, B) ? qat_s16_launch((hipStream_t)stream, m, a, 1) : qgru_family_fwd((hipStream_t)stream, m, a);
     default: return ODPD_EUNSUPPORTED;
     }
 }

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(128) void qat_cascade_kernel(CascArgs a) {
     float2* dpd_dyb = reinterpret_cast<float2*>(rd + D::off_dyb_region(T, Pd));
     if (wave == 0) {
         D e;
-        e.setup(smem, rd, a.dpd_params, a.Hd, T, a.bits_w, a.bits_a);
+        e.setup(smem, rd, a.dpd_params, a.Hd, T, T, a.bits_w, a.bits_a);
         __syncthreads();
         for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
             const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(128) void qat_delta_cascade_kernel(CascArgs a) {
     float2* dpd_dyb = reinterpret_cast<float2*>(rd + D::off_dyb_region(T, Pd));
     if (wave == 0) {
         D e;
-        e.setup(smem, rd, a.dpd_params, a.Hd, T, a.bits_w, a.bits_a, a.thx, a.thh);
+        e.setup(smem, rd, a.dpd_params, a.Hd, T, T, a.bits_w, a.bits_a, a.thx, a.thh);
         __syncthreads();
         for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
             const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
@@ -334,6 +334,26 @@ __global__ __launch_bounds__(128) void qat_delta_cascade_kernel(CascArgs a) {
     } else {
         casc_pa_wave<P>(a, smem, rp, pa_ubuf, dpd_dyb, xch);
     }
+}
+
+// Evaluation passes of the quantised models (net_eval / run_dpd shapes: a few long sequences, torch.no_grad()) on the same engines: ONE
+// sequence per single-wave workgroup, forward chunks only on a one-chunk ring of buffers, fc_out's 16-bit output quantiser in eval mode.
+template <typename E, bool TRES>
+__global__ __launch_bounds__(64) void qat_eval_kernel(SeqArgs a, int bits_w, int bits_a, int eval_mode) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = a.T;
+    E e;
+    if constexpr (TRES) e.setup(smem, smem, a.params, a.H, T, kCascChunk, bits_w, bits_a, a.thx, a.thh);
+    else e.setup(smem, smem, a.params, a.H, T, kCascChunk, bits_w, bits_a);
+    e.ring = true; e.eval_out = eval_mode != 0;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
+        float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * T;
+        e.fwd_begin();
+        for (int t0 = 0; t0 < T; t0 += kCascChunk)
+            e.fwd_chunk(0, t0, min(kCascChunk, T - t0), xg, [&](int t, float y0, float y1) { yg[t] = make_float2(y0, y1); });
+    }
+    if constexpr (TRES) e.add_stats(a.stats, a.B);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -461,6 +481,39 @@ int gru_cascade_train(hipStream_t st, const odpd_model_t* dpd, const odpd_model_
 #define ODPD_CASC_LAUNCH(NBD_, FMD_, DGD_, PV_, FMP_, DGP_) casc_launch<NBD_, FMD_, DGD_, PV_, FMP_, DGP_>(st, a, c)
     ODPD_CASC_ALL(ODPD_CASC_LAUNCH)
 #undef ODPD_CASC_LAUNCH
+    return ODPD_EUNSUPPORTED;
+}
+
+
+// evaluation passes of the quantised models on the one-sequence-per-wave engines: no checkpoints asked for, every sequence on a SIMD of its own
+bool qat_uses_gp_eval(const odpd_model_t* m, int B, bool want_ckpt) {
+    if (want_ckpt || m->bits_w <= 0 || m->bits_a <= 0 || m->hidden < 1 || m->hidden > 16 || tuning().gp_max_batch == 0 || tuning().s16_min_batch == 0) return false;
+    if (m->backbone != ODPD_GRU && m->backbone != ODPD_QGRU && m->backbone != ODPD_QGRU_AMP1 && m->backbone != ODPD_TRES_DELTAGRU) return false;
+    return B <= 2 * device_cus();
+}
+namespace {
+template <typename E, bool TRES>
+int qat_eval_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int P) {
+    const size_t lds = (size_t)E::region_floats(kCascChunk, P) * sizeof(float);
+    auto k = qat_eval_kernel<E, TRES>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a, (int)m->bits_w, (int)m->bits_a, (m->flags & ODPD_FLAG_EVAL) ? 1 : 0);
+    return (int)hipGetLastError();
+}
+}  // namespace
+int qat_gp_eval(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    const bool lut = m->bits_w <= 8 && m->bits_a <= 8;
+    if (m->backbone == ODPD_TRES_DELTAGRU) {
+        const int P = q16::qat_layout(q16::K_TRES, m->hidden).P;
+        return lut ? qat_eval_launch<q16::QatDeltaSeq<true>, true>(st, m, a, P) : qat_eval_launch<q16::QatDeltaSeq<false>, true>(st, m, a, P);
+    }
+#define ODPD_QAT_EVAL(BB_, MK_)                                                                                                     \
+    if (m->backbone == BB_) {                                                                                                       \
+        const int P = q16::qat_layout(MK_, m->hidden).P;                                                                           \
+        return lut ? qat_eval_launch<q16::QatSeq<MK_, true>, false>(st, m, a, P) : qat_eval_launch<q16::QatSeq<MK_, false>, false>(st, m, a, P); \
+    }
+    ODPD_QAT_EVAL(ODPD_GRU, q16::K_GRU) ODPD_QAT_EVAL(ODPD_QGRU, q16::K_Q4) ODPD_QAT_EVAL(ODPD_QGRU_AMP1, q16::K_A4)
+#undef ODPD_QAT_EVAL
     return ODPD_EUNSUPPORTED;
 }
 

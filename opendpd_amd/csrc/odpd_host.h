@@ -168,6 +168,9 @@ struct CascArgs {
     int loss_kind, B, T, Hd, Hp;
 };
 int gru_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T);
+// evaluation passes of the quantised models, one sequence per wave (gru_cascade.hip)
+bool qat_uses_gp_eval(const odpd_model_t* m, int B, bool want_ckpt);
+int qat_gp_eval(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_cascade_train(hipStream_t s, const odpd_model_t* dpd, const odpd_model_t* pa, const CascArgs& a);
 // 16-sequences-per-wave fused kernel (gru_s16.hip) and the rule that selects it
 bool gru_train_uses_s16(const odpd_model_t* m, int B, int T);

@@ -51,12 +51,12 @@ struct QatSeq {
     float *smem, *pl, *fq, *ck, *dyb, *sv, *hist, *dump, *hw;
     const float4* lutq;
     RowMasks rm;
-    int H, T, lane, col, role, bits_a, svp0, svp_step, hp0, hp_step;
-    bool vo;
+    int H, T, lane, col, role, bits_a, svp0, svp_step, hp0, hp_step, fbase;
+    bool vo, ring, eval_out;        // ring: forward-only use on frames of any length (buffers of ONE chunk); eval_out: fc_out's 16-bit output quantiser
 
-    // (one workgroup barrier inside)
-    __device__ __forceinline__ void setup(float* base, float* region, const float* params, int Hm, int T_, int bits_w, int bits_a_) {
-        smem = base;
+    // (one workgroup barrier inside)  Tb: the frame length the buffers are laid out for (T, or one chunk for forward-only use)
+    __device__ __forceinline__ void setup(float* base, float* region, const float* params, int Hm, int T_, int Tb, int bits_w, int bits_a_) {
+        smem = base; ring = false; eval_out = false; fbase = 0;
         lane = threadIdx.x & 63; col = lane & 15; role = lane >> 4;      // r | z | n | -
         L = qat_layout(MK, Hm);
         H = L.H; T = T_; bits_a = bits_a_;
@@ -111,8 +111,8 @@ struct QatSeq {
         wo0 = vo ? kq(pl[L.o_wo + col], wq.o) : 0.0f; wo1 = vo ? kq(pl[L.o_wo + L.OW + col], wq.o) : 0.0f;
         bo0 = pl[L.o_bo]; bo1 = pl[L.o_bo + 1];
         wave_lds_fence();
-        fq = tab; ck = tab + off_ck(T); dyb = tab + off_dyb(T); sv = tab + off_sv(T); hist = tab + off_hist(T); dump = tab + off_dump(T);
-        hw = tab + off_hw(T);
+        fq = tab; ck = tab + off_ck(Tb); dyb = tab + off_dyb(Tb); sv = tab + off_sv(Tb); hist = tab + off_hist(Tb); dump = tab + off_dump(Tb);
+        hw = tab + off_hw(Tb);
         if (lane < 32) hw[lane] = (lane & 15) < H ? kq(pl[L.o_wo + (lane >> 4) * L.OW + (lane & 15)], wq.o) : 0.0f;
         rm = row_masks();
         // the recomputed steps' stores: row 0 parks the unit's NSV factors, row 3 h(t) (the others hit the dump)
@@ -143,7 +143,7 @@ struct QatSeq {
     __device__ __forceinline__ void step(int t, int sp, int hq_) {
         const float hv = h;
         const float v0 = hv * k.inv_ha, m0 = gm(v0, k), hqk = rintf(m0);
-        const float4 f4 = reinterpret_cast<const float4*>(fq)[t];
+        const float4 f4 = reinterpret_cast<const float4*>(fq)[t - fbase];
         const float ff[4] = {f4.x, f4.y, f4.z, f4.w};
         float xsum = 0.0f;
 #pragma unroll
@@ -187,8 +187,9 @@ struct QatSeq {
     // forward chunk c: quantised features with lane = time step, the cell state kept, the recurrence, fc_out with lane = time step
     template <typename Sink>
     __device__ __forceinline__ void fwd_chunk(int c, int t0, int len, const float2* xg, Sink sink) {
-        if (lane < len) reinterpret_cast<float4*>(fq)[t0 + lane] = features(xg[t0 + lane]);
-        ck[c * 64 + lane] = h;
+        fbase = ring ? t0 : 0;
+        if (lane < len) reinterpret_cast<float4*>(fq)[t0 + lane - fbase] = features(xg[t0 + lane]);
+        ck[(ring ? 0 : c) * 64 + lane] = h;
         wave_lds_fence();
         int hq_ = hp0;
         for (int tt = 0; tt < len; ++tt) { step<false>(t0 + tt, 0, hq_); hq_ += hp_step; }
@@ -201,7 +202,9 @@ struct QatSeq {
                 const float hok = gk(hv[u] * k.inv_oa, k);
                 p0 = __builtin_fmaf(hw[u], hok, p0); p1 = __builtin_fmaf(hw[16 + u], hok, p1);
             }
-            sink(t0 + lane, __builtin_fmaf(p0, k.So, bo0), __builtin_fmaf(p1, k.So, bo1));        // train mode: no output quantiser
+            float y0 = __builtin_fmaf(p0, k.So, bo0), y1 = __builtin_fmaf(p1, k.So, bo1);
+            if (eval_out) { y0 = qapply(y0, qs.out); y1 = qapply(y1, qs.out); }                   // fc_out's 16-bit out_quantizer, eval mode only (quant_layers.py:77-80)
+            sink(t0 + lane, y0, y1);
         }
         wave_lds_fence();
     }
@@ -316,13 +319,13 @@ struct QatDeltaSeq {
     const float4* lutq;
     const float* thr;
     RowMasks rm;
-    int H, T, lane, col, role, fc, Ksig, svp0, svp_step, hp0, hp_step, fq0, fq_step;
-    bool vo;
+    int H, T, lane, col, role, fc, Ksig, svp0, svp_step, hp0, hp_step, fq0, fq_step, fbase;
+    bool vo, ring, eval_out;
 
-    // (one workgroup barrier inside)
-    __device__ __forceinline__ void setup(float* base, float* region, const float* params, int Hm, int T_, int bits_w, int bits_a, float thx_,
+    // (one workgroup barrier inside)  Tb: the frame length the buffers are laid out for (T, or one chunk for forward-only use)
+    __device__ __forceinline__ void setup(float* base, float* region, const float* params, int Hm, int T_, int Tb, int bits_w, int bits_a, float thx_,
                                           float thh_) {
-        smem = base;
+        smem = base; ring = false; eval_out = false; fbase = 0;
         lane = threadIdx.x & 63; col = lane & 15; role = lane >> 4;      // r | z | n | -
         L = qat_layout(K_TRES, Hm);
         H = L.H; T = T_; thx = thx_; thh = thh_;
@@ -400,8 +403,8 @@ struct QatDeltaSeq {
         for (int i = 0; i < 6; ++i) { w2[i] = pl[L.o_tcn2 + i]; tw2[i] = 0.0f; }
         fc = col < 6 ? col : 5;
         wave_lds_fence();
-        feat = tab; ck = tab + off_ck(T); dyb = tab + off_dyb(T); sv = tab + off_sv(T); fqs = tab + off_fqs(T); hist = tab + off_hist(T);
-        dump = tab + off_dump(T); hw = tab + off_hw(T);
+        feat = tab; ck = tab + off_ck(Tb); dyb = tab + off_dyb(Tb); sv = tab + off_sv(Tb); fqs = tab + off_fqs(Tb); hist = tab + off_hist(Tb);
+        dump = tab + off_dump(Tb); hw = tab + off_hw(Tb);
         if (lane < 32) hw[lane] = (lane & 15) < H ? kq(pl[L.o_wo + (lane >> 4) * L.OW + (lane & 15)], wq.o) : 0.0f;
         rm = row_masks();
         // the recomputed steps' stores: row 0 parks the unit's NSV factors, row 3 h(t), row 1's lanes 0..7 the quantised masked dx
@@ -436,7 +439,7 @@ struct QatDeltaSeq {
     template <bool SAVE>
     __device__ __forceinline__ void step(int t, int sp, int hq_, int fqp) {
         // x side, one feature per lane: thresholded delta, its quantised value in grid units
-        const float fv = feat[t * 8 + fc];
+        const float fv = feat[(t - fbase) * 8 + fc];
         const float d = fv - xp;
         const bool keep = !(__builtin_fabsf(d) < thx);                 // masked_fill(|d| < th, 0)  (deltagru_tcnskip.py:218-228)
         const float dxm = keep ? d : 0.0f;
@@ -505,11 +508,12 @@ struct QatDeltaSeq {
             const float a2 = rc.x * rc.x + rc.y * rc.y, a = sqrtf(a2), a3 = a * a * a;      // (q16_slots' operation order)
             float s1[3], s2[2];
             tcn(rm_, rc, rp, s1, s2);
+            fbase = ring ? t0 : 0;
             if (lane < len) {
-                reinterpret_cast<float4*>(feat)[2 * t] = make_float4(rc.x, rc.y, a, a3);
-                reinterpret_cast<float4*>(feat)[2 * t + 1] = make_float4(rn.x, rn.y, hardswishf_(s2[0]), hardswishf_(s2[1]));
+                reinterpret_cast<float4*>(feat)[2 * (t - fbase)] = make_float4(rc.x, rc.y, a, a3);
+                reinterpret_cast<float4*>(feat)[2 * (t - fbase) + 1] = make_float4(rn.x, rn.y, hardswishf_(s2[0]), hardswishf_(s2[1]));
             }
-            float* kk = ck + c * 7 * 64 + lane;
+            float* kk = ck + (ring ? 0 : c) * 7 * 64 + lane;
             kk[0] = h; kk[64] = hp; kk[128] = xp; kk[192] = dmr; kk[256] = dmz; kk[320] = dmn; kk[384] = dmnh;
         }
         wave_lds_fence();
@@ -525,8 +529,9 @@ struct QatDeltaSeq {
                 const float hok = gk(hv[u] * k.inv_oa, k);
                 p0 = __builtin_fmaf(hw[u], hok, p0); p1 = __builtin_fmaf(hw[16 + u], hok, p1);
             }
-            float y0 = __builtin_fmaf(p0, k.So, 0.0f), y1 = __builtin_fmaf(p1, k.So, 0.0f);       // bias-free fc_out; train mode: no output quantiser
-            y0 += feat[t * 8 + 6]; y1 += feat[t * 8 + 7];
+            float y0 = __builtin_fmaf(p0, k.So, 0.0f), y1 = __builtin_fmaf(p1, k.So, 0.0f);       // bias-free fc_out
+            if (eval_out) { y0 = qapply(y0, qs.out); y1 = qapply(y1, qs.out); }                   // its 16-bit out_quantizer, eval mode only (quant_layers.py:77-80)
+            y0 += feat[(t - fbase) * 8 + 6]; y1 += feat[(t - fbase) * 8 + 7];
             sink(t, y0, y1);
         }
         wave_lds_fence();
