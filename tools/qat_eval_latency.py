@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Latency of one evaluation pass (net_eval / run_dpd shapes) of the quantisation-aware models — they run their 16-sequences-per-wave kernels
-(qgru / qgru_amp1 of <= 16 units: the row-rotated ones) at every batch: no one-sequence-per-wave mapping yet.
+"""Latency of one evaluation pass (net_eval / run_dpd shapes) of the quantisation-aware models: gru / qgru / qgru_amp1 / deltagru_tcnskip of
+<= 16 units on the one-sequence-per-wave engines (csrc/gru_cascade.hip: qat_eval_kernel), the quantised dgru on its 16-sequences-per-wave kernels.
 usage (GPU box): PYTHONPATH=. python tools/qat_eval_latency.py"""
 import time, torch
 from types import SimpleNamespace
