@@ -401,4 +401,54 @@ struct GpSeq {
     }
 };
 
+// The frozen PA's wave of a cascade workgroup.  One workgroup barrier per hand-off (the DPD wave executes the same number): forward
+// chunk k - 1 while the DPD wave produces chunk k; loss; backward chunk c + dL/du of the chunk into the DPD wave's dL/dy buffer.
+template <typename P>
+__device__ __forceinline__ void casc_pa_wave(const CascArgs& a, float* smem, float* rp, float2* pa_ubuf, float2* dpd_dyb, float* xch) {
+    const int lane = threadIdx.x & 63, T = a.T, NC = (T + kCascChunk - 1) / kCascChunk;
+    P e;
+    e.setup(smem, rp, a.pa_params, a.Hp, T);
+    __syncthreads();
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
+    float2* pa_dyb = reinterpret_cast<float2*>(e.dyb);
+    float loss_acc = 0.0f;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        e.fwd_begin();
+        for (int k = 0; k <= NC; ++k) {
+            if (k >= 1) {
+                const int t0 = (k - 1) * kCascChunk;
+                e.fwd_steps(t0, min(kCascChunk, T - t0));
+            }
+            __syncthreads();
+        }
+        e.store_act(T - 1);
+        wave_lds_fence();
+        for (int t0 = 0; t0 < T; t0 += kCascChunk)
+            e.head_chunk(t0, min(kCascChunk, T - t0), [&](int t, float y0, float y1) {
+                const float2 tv = tg[t];
+                float dy0, dy1;
+                s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+                pa_dyb[t] = make_float2(dy0, dy1);
+            });
+        wave_lds_fence();
+        e.bwd_begin();
+        for (int k = 0; k <= NC; ++k) {
+            if (k < NC) {
+                const int c = NC - 1 - k, t0 = c * kCascChunk, len = min(kCascChunk, T - t0);
+                e.bwd_steps(t0 + len - 1, t0, t0);
+                wave_lds_fence();
+                e.dx_chunk(t0, len, pa_ubuf, dpd_dyb);
+                wave_lds_fence();
+            }
+            __syncthreads();
+        }
+    }
+    float lp = loss_acc;
+    for (int o = 32; o > 0; o >>= 1) lp += __shfl_down(lp, o);
+    if (lane == 0) xch[0] = lp;
+    __syncthreads();
+}
+
 }  // namespace odpd

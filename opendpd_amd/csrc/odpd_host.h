@@ -168,7 +168,10 @@ struct CascArgs {
     int loss_kind, B, T, Hd, Hp;
 };
 int gru_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T);
-// evaluation passes of the quantised models, one sequence per wave (gru_cascade.hip)
+// quantised DPDs of the one-launch cascade step (qat_cascade.hip): LDS bytes of the workgroup (0 = not served), launch
+size_t qat_casc_lds_bytes(const odpd_model_t* dpd, int pv, bool dgp, int T, int Pp);
+int qat_casc_launch(hipStream_t s, const odpd_model_t* dpd, int pv, bool dgp, int grid, const CascArgs& a, int Pp);
+// evaluation passes of the quantised models, one sequence per wave (qat_cascade.hip)
 bool qat_uses_gp_eval(const odpd_model_t* m, int B, bool want_ckpt);
 int qat_gp_eval(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_cascade_train(hipStream_t s, const odpd_model_t* dpd, const odpd_model_t* pa, const CascArgs& a);

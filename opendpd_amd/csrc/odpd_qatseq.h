@@ -16,22 +16,23 @@
 namespace odpd {
 namespace q16 {
 
-template <int MK, bool LUT>
+// NB: unit blocks (1: hidden <= 16; 2: hidden 17..32 — two 16-unit blocks per gate row, as GpSeq)
+template <int MK, bool LUT, int NB = 1>
 struct QatSeq {
     static_assert(MK == K_GRU || MK == K_Q4 || MK == K_A4, "GRUCell kinds with a plain INT_Linear head");
-    static constexpr int F = Kind<MK>::F, C = 32;      // C = kCascChunk (odpd_gpseq.h)
+    static constexpr int F = Kind<MK>::F, C = 32, HB = 16 * NB;      // C = kCascChunk (odpd_gpseq.h)
     static constexpr int NSV = 14;                      // parked per unit and step: hp hqk n z c2 c3 An Az B1 B2A pph hnew hok pho
-    static constexpr int kTabFloats = 6 * 4 * 64 * 4;   // q_w(W_h) rotated rows r, z, n + transposed
+    static constexpr int kTabFloats = 6 * NB * 4 * 64 * 4;   // q_w(W_h) rotated rows (gate, relative input block) + transposed
     __host__ __device__ static int tp(int T) { return (T + 63) & ~63; }
     __host__ __device__ static int nchunks(int T) { return (T + C - 1) / C; }
     __host__ __device__ static int off_buf() { return LUT ? 4 * 256 : 0; }                         // LUT builds (<= 8 activation bits): [256][4] first; tables | buffers start here
     __host__ __device__ static int off_ck(int T) { return tp(T) * 4; }                             // fq [Tp][4]: quantised features (grid units)
-    __host__ __device__ static int off_dyb(int T) { return off_ck(T) + nchunks(T) * 64; }          // ck [chunks][64]: h at the chunk start
+    __host__ __device__ static int off_dyb(int T) { return off_ck(T) + nchunks(T) * 64 * NB; }     // ck [chunks][NB][64]: h at the chunk start
     __host__ __device__ static int off_sv(int T) { return off_dyb(T) + tp(T) * 2; }                // dyb [Tp][2]: dL/du(t), written by the PA wave
-    __host__ __device__ static int off_hist(int T) { return off_sv(T) + C * 16 * NSV; }            // sv [C][NSV][16]
-    __host__ __device__ static int off_dump(int T) { return off_hist(T) + (C + 1) * 16; }          // hist [C + 1][16]: entry i + 1 = h(t0 + i)
-    __host__ __device__ static int off_hw(int T) { return off_dump(T) + 512; }       // dump: where the rows that park nothing store
-    __host__ __device__ static int buf_floats(int T) { return off_hw(T) + 32; }
+    __host__ __device__ static int off_hist(int T) { return off_sv(T) + C * HB * NSV; }            // sv [C][NSV][HB]
+    __host__ __device__ static int off_dump(int T) { return off_hist(T) + (C + 1) * HB; }          // hist [C + 1][HB]: entry i + 1 = h(t0 + i)
+    __host__ __device__ static int off_hw(int T) { return off_dump(T) + 512 * NB; }                // dump: where the rows that park nothing store
+    __host__ __device__ static int buf_floats(int T) { return off_hw(T) + 2 * HB; }
     __host__ __device__ static int region_floats(int T, int P) {
         const int buf = buf_floats(T);
         return pad4(P) + off_buf() + (buf > kTabFloats ? buf : kTabFloats);
@@ -40,19 +41,19 @@ struct QatSeq {
     __host__ __device__ static int off_dyb_region(int T, int P) { return pad4(P) + off_buf() + off_dyb(T); }
 
     // ---- registers ----
-    float wrec[16], wT[16], wx[F], bx[3], bh[3], wo0, wo1, bo0, bo1;
+    float wrec[NB][NB][16], wT[NB][NB][16], wx[NB][F], bx[NB][3], bh[NB][3], wo0[NB], wo1[NB], bo0, bo1;
     QSc qs;
     QK k;
     WQ wq;
     QatLayout L;
-    float h, gh;                              // cell state (replicated on every row); backward carry dL/dh
-    f32x16 acc1, acc2;
-    float dwo0, dwo1, dbo0, dbo1, dbhn;
+    float h[NB], gh[NB];                      // cell state (replicated on every row); backward carry dL/dh
+    f32x16 acc1[NB][NB], acc2[NB];
+    float dwo0[NB], dwo1[NB], dbo0, dbo1, dbhn[NB];
     float *smem, *pl, *fq, *ck, *dyb, *sv, *hist, *dump, *hw;
     const float4* lutq;
     RowMasks rm;
     int H, T, lane, col, role, bits_a, svp0, svp_step, hp0, hp_step, fbase;
-    bool vo, ring, eval_out;        // ring: forward-only use on frames of any length (buffers of ONE chunk); eval_out: fc_out's 16-bit output quantiser
+    bool vo[NB], ring, eval_out;        // ring: forward-only use on frames of any length (buffers of ONE chunk); eval_out: fc_out's 16-bit output quantiser
 
     // (one workgroup barrier inside)  Tb: the frame length the buffers are laid out for (T, or one chunk for forward-only use)
     __device__ __forceinline__ void setup(float* base, float* region, const float* params, int Hm, int T_, int Tb, int bits_w, int bits_a_) {
@@ -68,7 +69,6 @@ struct QatSeq {
         k = make_qk(qs, wq);
         float* lut = region + pad4(L.P);
         float* tab = lut + off_buf();
-        vo = col < H;
         const bool gate_row = role < 3;
         const int g = gate_row ? role : 0;
         if constexpr (LUT) {      // as fill_luts (odpd_qat.h), one wave
@@ -80,47 +80,64 @@ struct QatSeq {
             }
         }
         lutq = reinterpret_cast<const float4*>(lut) - (int)qs.add.qn;
-        {   // rotated-quad tables of the quantised recurrent weights (grid units): rows 0..2 q_w(W_h)[g][o][m], rows 3..5 transposed
-            const int dir = rot_dir(col);
+        {   // rotated-quad tables of the quantised recurrent weights (grid units), the layout of fill_gru_tabs (odpd_gru.h): lane (ob = its
+            // 16-lane row & (NB - 1), col) holds output unit 16 ob + col; row gg NB + rb: against input block (ob + rb) % NB; rows 3 NB ..: transposed
+            const int dir = rot_dir(col), ob = (lane >> 4) & (NB - 1), o = 16 * ob + col;
             float4* t4 = reinterpret_cast<float4*>(tab);
-            for (int idx = 0; idx < 6 * 4; ++idx) {
-                const int tr = idx >> 2, q = idx & 3, gg = tr % 3;
-                const bool transposed = tr >= 3;
+            for (int idx = 0; idx < 6 * NB * 4; ++idx) {
+                const int tr = idx >> 2, q = idx & 3;
+                const bool transposed = tr >= 3 * NB;
+                const int local = transposed ? tr - 3 * NB : tr, gg = local / NB, rb = local % NB;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int m = (col + dir * (4 * q + e)) & 15;
-                    const bool ok = col < H && m < H;
-                    v[e] = ok ? kq(pl[L.o_wh + (gg * H + (transposed ? m : col)) * H + (transposed ? col : m)], wq.h) : 0.0f;
+                    const int m = 16 * ((ob + rb) % NB) + ((col + dir * (4 * q + e)) & 15);
+                    const bool ok = o < H && m < H;
+                    v[e] = ok ? kq(pl[L.o_wh + (gg * H + (transposed ? m : o)) * H + (transposed ? o : m)], wq.h) : 0.0f;
                 }
                 t4[idx * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
         __syncthreads();
-        {
-            TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
-            load_rot(wrec, tl + g * 4 * 64);
-            load_rot(wT, tl + (3 + g) * 4 * 64);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { wrec[i] = gate_row ? wrec[i] : 0.0f; wT[i] = gate_row ? wT[i] : 0.0f; }
+        for (int ob = 0; ob < NB; ++ob) {
+            const int o = 16 * ob + col;
+            vo[ob] = o < H;
+            TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + 16 * ob + col);
+#pragma unroll
+            for (int rb = 0; rb < NB; ++rb) {
+                const int kb = (ob + rb) % NB;
+                load_rot(wrec[ob][kb], tl + (g * NB + rb) * 4 * 64);
+                load_rot(wT[ob][kb], tl + (3 * NB + g * NB + rb) * 4 * 64);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { wrec[ob][kb][i] = gate_row ? wrec[ob][kb][i] : 0.0f; wT[ob][kb][i] = gate_row ? wT[ob][kb][i] : 0.0f; }
+            }
+#pragma unroll
+            for (int i = 0; i < F; ++i) wx[ob][i] = (vo[ob] && gate_row) ? kq(pl[L.o_wx + (g * H + o) * F + i], wq.x) : 0.0f;
+#pragma unroll
+            for (int gg = 0; gg < 3; ++gg) { bx[ob][gg] = vo[ob] ? pl[L.o_bx + gg * H + o] : 0.0f; bh[ob][gg] = vo[ob] ? pl[L.o_bh + gg * H + o] : 0.0f; }
+            wo0[ob] = vo[ob] ? kq(pl[L.o_wo + o], wq.o) : 0.0f; wo1[ob] = vo[ob] ? kq(pl[L.o_wo + L.OW + o], wq.o) : 0.0f;
         }
-#pragma unroll
-        for (int i = 0; i < F; ++i) wx[i] = (vo && gate_row) ? kq(pl[L.o_wx + (g * H + col) * F + i], wq.x) : 0.0f;
-#pragma unroll
-        for (int gg = 0; gg < 3; ++gg) { bx[gg] = vo ? pl[L.o_bx + gg * H + col] : 0.0f; bh[gg] = vo ? pl[L.o_bh + gg * H + col] : 0.0f; }
-        wo0 = vo ? kq(pl[L.o_wo + col], wq.o) : 0.0f; wo1 = vo ? kq(pl[L.o_wo + L.OW + col], wq.o) : 0.0f;
         bo0 = pl[L.o_bo]; bo1 = pl[L.o_bo + 1];
         wave_lds_fence();
         fq = tab; ck = tab + off_ck(Tb); dyb = tab + off_dyb(Tb); sv = tab + off_sv(Tb); hist = tab + off_hist(Tb); dump = tab + off_dump(Tb);
         hw = tab + off_hw(Tb);
-        if (lane < 32) hw[lane] = (lane & 15) < H ? kq(pl[L.o_wo + (lane >> 4) * L.OW + (lane & 15)], wq.o) : 0.0f;
+        for (int i = lane; i < 2 * HB; i += 64) hw[i] = (i % HB) < H ? kq(pl[L.o_wo + (i / HB) * L.OW + (i % HB)], wq.o) : 0.0f;
         rm = row_masks();
         // the recomputed steps' stores: row 0 parks the unit's NSV factors, row 3 h(t) (the others hit the dump)
-        svp0 = role == 0 ? (int)(sv - smem) + col : (int)(dump - smem) + lane; svp_step = role == 0 ? 16 * NSV : 0;
-        hp0 = role == 3 ? (int)(hist - smem) + 16 + col : (int)(dump - smem) + 320 + lane; hp_step = role == 3 ? 16 : 0;
+        svp0 = role == 0 ? (int)(sv - smem) + col : (int)(dump - smem) + lane; svp_step = role == 0 ? HB * NSV : 0;
+        hp0 = role == 3 ? (int)(hist - smem) + HB + col : (int)(dump - smem) + 320 * NB + lane; hp_step = role == 3 ? HB : 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
-        dwo0 = 0.0f; dwo1 = 0.0f; dbo0 = 0.0f; dbo1 = 0.0f; dbhn = 0.0f;
+        for (int ob = 0; ob < NB; ++ob) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc2[ob][i] = 0.0f;
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) acc1[ob][kb][i] = 0.0f;
+            }
+            dwo0[ob] = 0.0f; dwo1[ob] = 0.0f; dbhn[ob] = 0.0f;
+        }
+        dbo0 = 0.0f; dbo1 = 0.0f;
         wave_lds_fence();
     }
 
@@ -136,52 +153,62 @@ struct QatSeq {
         return make_float4(r[0], r[1], r[2], r[3]);
     }
 
-    __device__ __forceinline__ void fwd_begin() { h = 0.0f; }
+    __device__ __forceinline__ void fwd_begin() {
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) h[ob] = 0.0f;
+    }
 
     // one GRUCell step (std_cell, qat_s16.hip) at time t.  SAVE: parks the backward's factors of the step at `sp` / h(t) at `hq`
     template <bool SAVE>
     __device__ __forceinline__ void step(int t, int sp, int hq_) {
-        const float hv = h;
-        const float v0 = hv * k.inv_ha, m0 = gm(v0, k), hqk = rintf(m0);
         const float4 f4 = reinterpret_cast<const float4*>(fq)[t - fbase];
         const float ff[4] = {f4.x, f4.y, f4.z, f4.w};
-        float xsum = 0.0f;
+        float v0[NB], m0[NB], hqk[NB];
 #pragma unroll
-        for (int i = 0; i < F; ++i) xsum = __builtin_fmaf(wx[i], ff[i], xsum);
-        const float hsum = rotdot(0.0f, wrec, hqk);
-        float X[4], Hs[4];
-        gather_rows(xsum, X);
-        gather_rows(hsum, Hs);
-        // x_t = x2h(x), h_t = h2h(h): exact integer sums, scale and fp32 bias in one FMA (== F.linear's result)
-        const float xr = __builtin_fmaf(X[0], k.Sx, bx[0]), hr = __builtin_fmaf(Hs[0], k.Sh, bh[0]);
-        const float xz = __builtin_fmaf(X[1], k.Sx, bx[1]), hz = __builtin_fmaf(Hs[1], k.Sh, bh[1]);
-        const float xn = __builtin_fmaf(X[2], k.Sx, bx[2]), hn = __builtin_fmaf(Hs[2], k.Sh, bh[2]);
-        const float vr = (xr + hr) * k.inv_add, vz = (xz + hz) * k.inv_add;
-        const float mr = gm(vr, k), mz = gm(vz, k);
-        const Gate Gr = sig_grid<LUT>(rintf(mr), qs, k, lutq), Gz = sig_grid<LUT>(rintf(mz), qs, k, lutq);
-        const float pm1 = Gr.c * hn, mm1 = gm(pm1, k);                                     // Qmul(r h_n)
-        const float vn = __builtin_fmaf(rintf(mm1), k.s_mul, xn) * k.inv_add, mn = gm(vn, k);      // Qadd(x_n + .)
-        const Gate Gn = tanh_grid<LUT>(rintf(mn), qs, k, lutq);
-        const float omz = __builtin_fmaf(Gz.c, -k.s_mul, 1.0f);                             // 1 - z, plain
-        const float pm2 = Gz.c * hv, pm3 = omz * Gn.c;
-        const float mm2 = gm(pm2, k), mm3 = gm(pm3, k);
-        const float vh = (rintf(mm2) + rintf(mm3)) * k.c_ma, mh = gm(vh, k);
-        const float hnew = rintf(mh) * k.s_add;
-        if constexpr (SAVE) {
-            const bool pah = mh == vh;
-            const float Ar = mr == vr ? Gr.d : 0.0f;
-            const bool p1 = mm1 == pm1;
-            const float vo_ = hnew * k.inv_oa, mo = gm(vo_, k);
-            float* s = smem + sp;
-            s[0 * 16] = hv; s[1 * 16] = hqk; s[2 * 16] = Gn.c * k.s_mul; s[3 * 16] = Gz.c * k.s_mul;
-            s[4 * 16] = (pah && mm2 == pm2) ? 1.0f : 0.0f; s[5 * 16] = (pah && mm3 == pm3) ? 1.0f : 0.0f;
-            s[6 * 16] = mn == vn ? Gn.d : 0.0f; s[7 * 16] = mz == vz ? Gz.d : 0.0f;
-            s[8 * 16] = p1 ? Gr.c * k.s_mul : 0.0f; s[9 * 16] = p1 ? hn * Ar : 0.0f;
-            s[10 * 16] = m0 == v0 ? k.s_hw : 0.0f; s[11 * 16] = hnew;
-            s[12 * 16] = rintf(mo); s[13 * 16] = mo == vo_ ? k.s_ow : 0.0f;
+        for (int ob = 0; ob < NB; ++ob) { v0[ob] = h[ob] * k.inv_ha; m0[ob] = gm(v0[ob], k); hqk[ob] = rintf(m0[ob]); }
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            const float hv = h[ob];
+            float xsum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < F; ++i) xsum = __builtin_fmaf(wx[ob][i], ff[i], xsum);
+            float hsum = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) hsum = rotdot(hsum, wrec[ob][kb], hqk[kb]);
+            float X[4], Hs[4];
+            gather_rows(xsum, X);
+            gather_rows(hsum, Hs);
+            // x_t = x2h(x), h_t = h2h(h): exact integer sums, scale and fp32 bias in one FMA (== F.linear's result)
+            const float xr = __builtin_fmaf(X[0], k.Sx, bx[ob][0]), hr = __builtin_fmaf(Hs[0], k.Sh, bh[ob][0]);
+            const float xz = __builtin_fmaf(X[1], k.Sx, bx[ob][1]), hz = __builtin_fmaf(Hs[1], k.Sh, bh[ob][1]);
+            const float xn = __builtin_fmaf(X[2], k.Sx, bx[ob][2]), hn = __builtin_fmaf(Hs[2], k.Sh, bh[ob][2]);
+            const float vr = (xr + hr) * k.inv_add, vz = (xz + hz) * k.inv_add;
+            const float mr = gm(vr, k), mz = gm(vz, k);
+            const Gate Gr = sig_grid<LUT>(rintf(mr), qs, k, lutq), Gz = sig_grid<LUT>(rintf(mz), qs, k, lutq);
+            const float pm1 = Gr.c * hn, mm1 = gm(pm1, k);                                     // Qmul(r h_n)
+            const float vn = __builtin_fmaf(rintf(mm1), k.s_mul, xn) * k.inv_add, mn = gm(vn, k);      // Qadd(x_n + .)
+            const Gate Gn = tanh_grid<LUT>(rintf(mn), qs, k, lutq);
+            const float omz = __builtin_fmaf(Gz.c, -k.s_mul, 1.0f);                             // 1 - z, plain
+            const float pm2 = Gz.c * hv, pm3 = omz * Gn.c;
+            const float mm2 = gm(pm2, k), mm3 = gm(pm3, k);
+            const float vh = (rintf(mm2) + rintf(mm3)) * k.c_ma, mh = gm(vh, k);
+            const float hnew = rintf(mh) * k.s_add;
+            if constexpr (SAVE) {
+                const bool pah = mh == vh;
+                const float Ar = mr == vr ? Gr.d : 0.0f;
+                const bool p1 = mm1 == pm1;
+                const float vo_ = hnew * k.inv_oa, mo = gm(vo_, k);
+                float* s = smem + sp + 16 * ob;
+                s[0 * HB] = hv; s[1 * HB] = hqk[ob]; s[2 * HB] = Gn.c * k.s_mul; s[3 * HB] = Gz.c * k.s_mul;
+                s[4 * HB] = (pah && mm2 == pm2) ? 1.0f : 0.0f; s[5 * HB] = (pah && mm3 == pm3) ? 1.0f : 0.0f;
+                s[6 * HB] = mn == vn ? Gn.d : 0.0f; s[7 * HB] = mz == vz ? Gz.d : 0.0f;
+                s[8 * HB] = p1 ? Gr.c * k.s_mul : 0.0f; s[9 * HB] = p1 ? hn * Ar : 0.0f;
+                s[10 * HB] = m0[ob] == v0[ob] ? k.s_hw : 0.0f; s[11 * HB] = hnew;
+                s[12 * HB] = rintf(mo); s[13 * HB] = mo == vo_ ? k.s_ow : 0.0f;
+            }
+            h[ob] = hnew;
+            smem[hq_ + 16 * ob] = hnew;
         }
-        h = hnew;
-        smem[hq_] = hnew;
     }
 
     // forward chunk c: quantised features with lane = time step, the cell state kept, the recurrence, fc_out with lane = time step
@@ -189,18 +216,19 @@ struct QatSeq {
     __device__ __forceinline__ void fwd_chunk(int c, int t0, int len, const float2* xg, Sink sink) {
         fbase = ring ? t0 : 0;
         if (lane < len) reinterpret_cast<float4*>(fq)[t0 + lane - fbase] = features(xg[t0 + lane]);
-        ck[(ring ? 0 : c) * 64 + lane] = h;
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) ck[((ring ? 0 : c) * NB + ob) * 64 + lane] = h[ob];
         wave_lds_fence();
         int hq_ = hp0;
         for (int tt = 0; tt < len; ++tt) { step<false>(t0 + tt, 0, hq_); hq_ += hp_step; }
         wave_lds_fence();
         if (lane < len) {
-            const float* hv = hist + (lane + 1) * 16;
+            const float* hv = hist + (lane + 1) * HB;
             float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < HB; ++u) {
                 const float hok = gk(hv[u] * k.inv_oa, k);
-                p0 = __builtin_fmaf(hw[u], hok, p0); p1 = __builtin_fmaf(hw[16 + u], hok, p1);
+                p0 = __builtin_fmaf(hw[u], hok, p0); p1 = __builtin_fmaf(hw[HB + u], hok, p1);
             }
             float y0 = __builtin_fmaf(p0, k.So, bo0), y1 = __builtin_fmaf(p1, k.So, bo1);
             if (eval_out) { y0 = qapply(y0, qs.out); y1 = qapply(y1, qs.out); }                   // fc_out's 16-bit out_quantizer, eval mode only (quant_layers.py:77-80)
@@ -209,11 +237,15 @@ struct QatSeq {
         wave_lds_fence();
     }
 
-    __device__ __forceinline__ void bwd_begin() { gh = 0.0f; }
+    __device__ __forceinline__ void bwd_begin() {
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) gh[ob] = 0.0f;
+    }
 
     // backward chunk c: forward steps again from the kept state (parking the factors), then the steps t0 + len - 1 .. t0
     __device__ __forceinline__ void bwd_chunk(int c, int t0, int len) {
-        h = ck[c * 64 + lane];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) h[ob] = ck[(c * NB + ob) * 64 + lane];
         wave_lds_fence();
         {
             int sp = svp0, hq_ = hp0;
@@ -221,30 +253,45 @@ struct QatSeq {
         }
         wave_lds_fence();
         for (int tt = len - 1; tt >= 0; --tt) {
-            const float* s = sv + tt * 16 * NSV + col;
-            const float hp_ = s[0], hqk = s[16], n = s[2 * 16], z = s[3 * 16], c2 = s[4 * 16], c3 = s[5 * 16], An = s[6 * 16], Az = s[7 * 16],
-                        B1 = s[8 * 16], B2A = s[9 * 16], pph = s[10 * 16], hok = s[12 * 16], pho = s[13 * 16];
             const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * (t0 + tt));
-            // head (head_bwd): fc_out's parameter gradients, dL/dh' through the activation quantiser's pass mask (carrying s_ow)
             dbo0 += dyv.x; dbo1 += dyv.y;
-            dwo0 = __builtin_fmaf(dyv.x, hok, dwo0); dwo1 = __builtin_fmaf(dyv.y, hok, dwo1);
-            const float g = gh + (dyv.x * wo0 + dyv.y * wo1) * pho;
-            const float g2 = g * c2, g3 = g * c3;
-            const float dz = g2 * hp_ - g3 * n;
-            const float da = g3 * (1.0f - z) * An;
-            const float dhtn = da * B1, dar = da * B2A, daz = dz * Az, dhdir = g2 * z;
-            dbhn += dhtn;
-            const float d_h = vsel(rm.m[0], dar, vsel(rm.m[1], daz, vsel(rm.m[2], dhtn, 0.0f)));
-            const float d_x = vsel(rm.m[0], dar, vsel(rm.m[1], daz, vsel(rm.m[2], da, 0.0f)));
-            float ddh = rotdot(0.0f, wT, d_h);
-            ddh += xor16(ddh);
-            ddh += xor32(ddh);
-            gh = dhdir + ddh * pph;
+            float d_h[NB], d_x[NB], dhdir[NB], pph[NB], hqk[NB];
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                const float* s = sv + tt * HB * NSV + 16 * ob + col;
+                const float hp_ = s[0], n = s[2 * HB], z = s[3 * HB], c2 = s[4 * HB], c3 = s[5 * HB], An = s[6 * HB], Az = s[7 * HB],
+                            B1 = s[8 * HB], B2A = s[9 * HB], hok = s[12 * HB], pho = s[13 * HB];
+                hqk[ob] = s[HB]; pph[ob] = s[10 * HB];
+                // head (head_bwd): fc_out's parameter gradients, dL/dh' through the activation quantiser's pass mask (carrying s_ow)
+                dwo0[ob] = __builtin_fmaf(dyv.x, hok, dwo0[ob]); dwo1[ob] = __builtin_fmaf(dyv.y, hok, dwo1[ob]);
+                const float g = gh[ob] + (dyv.x * wo0[ob] + dyv.y * wo1[ob]) * pho;
+                const float g2 = g * c2, g3 = g * c3;
+                const float dz = g2 * hp_ - g3 * n;
+                const float da = g3 * (1.0f - z) * An;
+                const float dhtn = da * B1, dar = da * B2A, daz = dz * Az;
+                dhdir[ob] = g2 * z;
+                dbhn[ob] += dhtn;
+                d_h[ob] = vsel(rm.m[0], dar, vsel(rm.m[1], daz, vsel(rm.m[2], dhtn, 0.0f)));
+                d_x[ob] = vsel(rm.m[0], dar, vsel(rm.m[1], daz, vsel(rm.m[2], da, 0.0f)));
+            }
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                float ddh = 0.0f;
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) ddh = rotdot(ddh, wT[ob][kb], d_h[kb]);
+                ddh += xor16(ddh);
+                ddh += xor32(ddh);
+                gh[ob] = dhdir[ob] + ddh * pph[ob];
+            }
             // weight gradients on grid-unit operands: (d_r | d_z | d_hn) x q_a(h), (d_r | d_z | d_n) x (q_a(features) | 1 / s_xa)
             const float4 f4 = reinterpret_cast<const float4*>(fq)[t0 + tt];
             const float fsx = col == 0 ? f4.x : col == 1 ? f4.y : (col == 2 && F > 2) ? f4.z : (col == 3 && F > 3) ? f4.w : (col == F ? k.inv_xa : 0.0f);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_h, hqk, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_x, fsx, acc2, 0, 0, 0);
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) acc1[ob][kb] = __builtin_amdgcn_mfma_f32_16x16x1f32(d_h[ob], hqk[kb], acc1[ob][kb], 0, 0, 0);
+                acc2[ob] = __builtin_amdgcn_mfma_f32_16x16x1f32(d_x[ob], fsx, acc2[ob], 0, 0, 0);
+            }
         }
         wave_lds_fence();
     }
@@ -254,28 +301,37 @@ struct QatSeq {
         for (int i = lane; i < L.P + kLossCols; i += 64) prow[i] = 0.0f;
         wave_lds_fence();
         __builtin_amdgcn_s_waitcnt(0);
-        if (vo && role == 0) {
-            prow[L.o_wo + col] = dwo0 * k.s_oa * qpass(pl[L.o_wo + col], wq.o);
-            prow[L.o_wo + L.OW + col] = dwo1 * k.s_oa * qpass(pl[L.o_wo + L.OW + col], wq.o);
-            prow[L.o_bh + 2 * H + col] = dbhn;
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+            const int o = 16 * ob + col;
+            if (vo[ob] && role == 0) {
+                prow[L.o_wo + o] = dwo0[ob] * k.s_oa * qpass(pl[L.o_wo + o], wq.o);
+                prow[L.o_wo + L.OW + o] = dwo1[ob] * k.s_oa * qpass(pl[L.o_wo + L.OW + o], wq.o);
+                prow[L.o_bh + 2 * H + o] = dbhn[ob];
+            }
         }
         if (lane == 0) { prow[L.o_bo] = dbo0; prow[L.o_bo + 1] = dbo1; prow[L.P] = loss; }
         // MFMA block g = gate g (r, z, n); register 4 g + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int i = 4 * role + rr;
-                if (i < H) {
-                    if (col < H) { const int j = L.o_wh + (g * H + i) * H + col; prow[j] = acc1[4 * g + rr] * k.s_ha * qpass(pl[j], wq.h); }
-                    const float tx = acc2[4 * g + rr] * k.s_xa;
-                    if (col < F) { const int j = L.o_wx + (g * H + i) * F + col; prow[j] = tx * qpass(pl[j], wq.x); }
-                    else if (col == F) { prow[L.o_bx + g * H + i] = tx; if (g < 2) prow[L.o_bh + g * H + i] = tx; }
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int i = 16 * ob + 4 * role + rr;
+                    if (i < H) {
+#pragma unroll
+                        for (int kb = 0; kb < NB; ++kb) {
+                            const int jc = 16 * kb + col;
+                            if (jc < H) { const int j = L.o_wh + (g * H + i) * H + jc; prow[j] = acc1[ob][kb][4 * g + rr] * k.s_ha * qpass(pl[j], wq.h); }
+                        }
+                        const float tx = acc2[ob][4 * g + rr] * k.s_xa;
+                        if (col < F) { const int j = L.o_wx + (g * H + i) * F + col; prow[j] = tx * qpass(pl[j], wq.x); }
+                        else if (col == F) { prow[L.o_bx + g * H + i] = tx; if (g < 2) prow[L.o_bh + g * H + i] = tx; }
+                    }
                 }
-            }
     }
 };
-
 
 // The quantised TRes-DeltaGRU (the OpenDPDv2 recipe: deltagru_tcnskip.py:156-162, 266-291 under the surgery; qat_s16.hip delta_cell) as the
 // DPD wave: thresholded deltas of the six features (one feature per lane, as DeltaSeq) and of the state, quantised (q_a) and multiplied with
