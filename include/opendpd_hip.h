@@ -157,7 +157,7 @@ int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss_kind, int 
 /* The whole train_dpd step body — y = PA(DPD(x)) with the PA frozen, loss, dL/d(DPD parameters) — in ONE launch, for the reference's own
  * batch sizes (64 .. 256 frames, train_funcs.py:28-48): the DPD and the PA of a frame run as the two waves of a workgroup and hand the
  * frame over through LDS (csrc/gru_cascade.hip).  Served: float gru / dgru / qgru / qgru_amp1 DPD of hidden <= 32 or deltagru /
- * deltagru_tcnskip / lstm DPD of hidden <= 16, or a quantised (bits_w > 0) gru / qgru / qgru_amp1 / deltagru_tcnskip DPD of hidden <= 16, in front of a float gru / dgru PA of hidden <= 32, batches whose frames are all resident at once
+ * deltagru_tcnskip / lstm DPD of hidden <= 16, or a quantised (bits_w > 0) gru / qgru / qgru_amp1 DPD of hidden <= 32 / deltagru_tcnskip DPD of hidden <= 16, in front of a float gru / dgru PA of hidden <= 32, batches whose frames are all resident at once
  * (odpd_cascade_rows > 0); otherwise ODPD_EUNSUPPORTED: chain odpd_backbone_fwd, odpd_frozen_loss_dx, odpd_backbone_bwd.
  * `partials` is (rows, P_dpd + 4), column P_dpd = un-normalised loss partial sum; `frame_idx` (device, may be NULL) addresses x /
  * target as windows of resident streams: frame b starts at sample frame_idx[b] * frame_stride; `dpd_stats` (may be NULL): the four
