@@ -469,6 +469,298 @@ int b16_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
     return (int)hipGetLastError();
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Gate-parallel fused train kernel for the reference's own batch sizes (train_funcs.py:28-48: 64 .. 256 frames, every frame gets a SIMD of
+// its own): ONE sequence per single-wave workgroup, only the recurrence in the step loops — everything that does not depend on h runs with
+// lane = time step over the whole frame:
+//   front     the FIR bank, the demodulator and the input halves of both gates (W_fi e + b, W_gi e + b) of every step;
+//   forward   rows f | g | f | g of the wave: one rotated dot product with the row's own W_.h, one cross-row swap, h' on every row; f, g, h
+//             of the frame parked in LDS;
+//   head      phase re-rotation, both read-outs, loss, dL/dy, the read-outs' share of dL/dh(t) and dL/dcos, dL/dsin of every step;
+//   backward  rows d_f | d_g | 0 | 0: one transposed rotated dot product, the step's two H x H weight gradients as ONE 4-block MFMA
+//             (v_mfma_f32_16x16x1_4b_f32), d_f, d_g parked;
+//   back end  dL/de through W_fi, W_gi, the demodulator's gradient (lane = time step); then the sums over time on the matrix pipe: W_fi |
+//             b_fi, W_gi | b_gi as (d_f, d_g)^T [e, 1], both FIR banks as (d_fi, d_fq)^T [I window], [Q window].
+// Weight gradients only (the frozen-PA role stays on the S16 kernels).  Taken while the frame's state fits the CU's LDS.
+// -------------------------------------------------------------------------------------------------
+constexpr int kBgpP16 = 17, kBgpP32 = 33;         // row pitches of the [time][unit] buffers: conflict-free for lane = unit AND for lane = time
+struct BgpBuf { int xw, fiq, env, xs, fg, hist, dhh, dcs, dump, total; };
+__host__ __device__ inline BgpBuf bgp_buf(int T) {
+    const int Tp = (T + 3) & ~3;
+    BgpBuf b; int o = 0;
+    b.xw = o; o += 2 * (Tp + 16);            // float2 [16 + Tp]: index i <-> time i - 16 (zero before the frame)
+    b.fiq = o; o += 12 * Tp;                 // [12][Tp]: fi_p, fq_p
+    b.env = o; o += 16 * Tp;                 // [16][Tp]: mag_p, mag_p^2, 1, 0, 0, 0 (zero columns past the frame)
+    b.xs = o; o += kBgpP32 * Tp;             // [Tp][33]: input halves of f | g; overwritten by d_f | d_g in the backward steps
+    b.fg = o; o += kBgpP32 * Tp;             // f | g of step t
+    b.hist = o; o += kBgpP16 * (Tp + 1);     // entry t + 1 = h(t), entry 0 = 0
+    b.dhh = o; o += kBgpP16 * Tp;            // the read-outs' share of dL/dh(t)
+    b.dcs = o; o += 12 * Tp;                 // [12][Tp]: dL/dcos_p, dL/dsin_p, then dL/dfi_p, dL/dfq_p
+    b.dump = o; o += 512;
+    b.total = o;
+    return b;
+}
+__global__ __launch_bounds__(64) void boj_gp_train_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;
+    const BojLayout L = boj_layout(a.H);
+    const int H = L.H, T = a.T, Tp = (T + 3) & ~3;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    const BgpBuf O = bgp_buf(T);
+    float* buf = smem + pad4(L.P);
+    float2* xw = reinterpret_cast<float2*>(buf + O.xw);
+    float *fiq = buf + O.fiq, *env = buf + O.env, *xs = buf + O.xs, *fg = buf + O.fg, *hist = buf + O.hist, *dhh = buf + O.dhh;
+    float *dcs = buf + O.dcs, *dump = buf + O.dump;
+    // the row's recurrent block (rows 0, 2: W_fh, rows 1, 3: W_gh) and its transpose (rows 0, 1 only), rotated for this lane
+    float wF[16], wT[16];
+    {
+        const int dir = rot_dir(col), ow = (role & 1) ? L.o_wgh : L.o_wfh;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = (col + dir * k) & 15;
+            const bool ok = col < H && m < H;
+            wF[k] = ok ? pl[ow + col * H + m] : 0.0f;
+            wT[k] = (ok && role < 2) ? pl[ow + m * H + col] : 0.0f;
+        }
+    }
+    const bool is_f = (role & 1) == 0;
+    const RowMasks rm = row_masks();
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
+    const int xoff = (role & 1) * 16 + col;
+    const int dmp = (int)(dump - smem) + lane;
+    const int pk0 = role == 0 ? (int)(fg - smem) + col : role == 1 ? (int)(fg - smem) + 16 + col : role == 2 ? (int)(hist - smem) + kBgpP16 + col : dmp;
+    const int pk_step = role < 2 ? kBgpP32 : role == 2 ? kBgpP16 : 0;
+    const int dk0 = role < 2 ? (int)(xs - smem) + role * 16 + col : dmp;
+    const int dk_step = role < 2 ? kBgpP32 : 0;
+    if (lane < 16) { xw[lane] = make_float2(0.0f, 0.0f); hist[lane] = 0.0f; }
+    if (lane == 0) hist[16] = 0.0f;
+
+    f32x16 acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc1[i] = 0.0f;
+    f32x4 accF = {0.f, 0.f, 0.f, 0.f}, accG = accF, accI = accF, accQ = accF;
+    float dwi[16], dwq[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { dwi[j] = 0.0f; dwq[j] = 0.0f; }
+    float dboi = 0.0f, dboq = 0.0f, loss_acc = 0.0f;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        wave_lds_fence();
+        for (int t = lane; t < Tp; t += 64) xw[16 + t] = t < T ? xg[t] : make_float2(0.0f, 0.0f);
+        wave_lds_fence();
+        // ---- front: FIR bank, demodulator, input halves of the gates; lane = time step ----
+        for (int t0 = 0; t0 < Tp; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < Tp) {
+                const bool live = t < T;
+                float fi[kBojP], fq[kBojP];
+#pragma unroll
+                for (int p = 0; p < kBojP; ++p) { fi[p] = 0.0f; fq[p] = 0.0f; }
+#pragma unroll
+                for (int m = 0; m < kBojM; ++m) {
+                    const float2 xv = xw[t + 1 + m];                             // time t - 15 + m
+#pragma unroll
+                    for (int p = 0; p < kBojP; ++p) {
+                        const float bi = pl[L.o_bi + p * kBojM + m], bq = pl[L.o_bq + p * kBojM + m];
+                        fi[p] += bi * xv.x - bq * xv.y;
+                        fq[p] += bq * xv.x + bi * xv.y;
+                    }
+                }
+                float e[2 * kBojP];
+#pragma unroll
+                for (int p = 0; p < kBojP; ++p) {
+                    const float mag = sqrtf(fi[p] * fi[p] + fq[p] * fq[p]) + 1e-8f;
+                    e[p] = mag; e[kBojP + p] = mag * mag;
+                    fiq[p * Tp + t] = fi[p]; fiq[(kBojP + p) * Tp + t] = fq[p];
+                    env[p * Tp + t] = live ? mag : 0.0f; env[(kBojP + p) * Tp + t] = live ? mag * mag : 0.0f;
+                }
+                env[12 * Tp + t] = live ? 1.0f : 0.0f;
+                env[13 * Tp + t] = 0.0f; env[14 * Tp + t] = 0.0f; env[15 * Tp + t] = 0.0f;
+                for (int u = 0; u < 16; ++u) {
+                    float pf = 0.0f, pg = 0.0f;
+                    if (u < H) {
+                        pf = pl[L.o_bfi + u]; pg = pl[L.o_bgi + u];
+#pragma unroll
+                        for (int k = 0; k < 2 * kBojP; ++k) {
+                            pf = __builtin_fmaf(pl[L.o_wfi + u * 2 * kBojP + k], e[k], pf);
+                            pg = __builtin_fmaf(pl[L.o_wgi + u * 2 * kBojP + k], e[k], pg);
+                        }
+                    }
+                    xs[t * kBgpP32 + u] = live ? pf : 0.0f;
+                    xs[t * kBgpP32 + 16 + u] = live ? pg : 0.0f;
+                }
+            }
+        }
+        wave_lds_fence();
+        // ---- forward recurrence ----
+        {
+            float h = 0.0f;
+            int pk = pk0;
+            for (int t = 0; t < T; ++t) {
+                const float acc = rotdot(xs[t * kBgpP32 + xoff], wF, h);
+                const float sg = sigmoidf_(acc), th = tanhf_(acc);
+                const float v = is_f ? sg : th, o = xor16(v);
+                const float f = is_f ? v : o, g = is_f ? o : v;
+                h = __builtin_fmaf(f, h - g, g);
+                smem[pk] = vsel(rm.m[0], f, vsel(rm.m[1], g, h));
+                pk += pk_step;
+            }
+        }
+        wave_lds_fence();
+        // ---- phase re-rotation, read-outs, loss and dL/dy of every step; lane = time step ----
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < T) {
+                float co[kBojP], si[kBojP], dco[kBojP], dsi[kBojP];
+#pragma unroll
+                for (int p = 0; p < kBojP; ++p) {
+                    const float fi = fiq[p * Tp + t], fq = fiq[(kBojP + p) * Tp + t];
+                    const float mag = sqrtf(fi * fi + fq * fq) + 1e-8f;
+                    co[p] = fi / mag; si[p] = fq / mag; dco[p] = 0.0f; dsi[p] = 0.0f;
+                }
+                const float* hv = hist + (t + 1) * kBgpP16;
+                float A = pl[L.o_boi], Bq = pl[L.o_boq];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < H) {
+                        A = __builtin_fmaf(pl[L.o_woi + j], hv[j] * co[j % kBojP], A);
+                        Bq = __builtin_fmaf(pl[L.o_woq + j], hv[j] * si[j % kBojP], Bq);
+                    }
+                const float2 tv = tg[t];
+                float dy0, dy1;
+                s16_loss(lossc, (A - Bq) - tv.x, (Bq + A) - tv.y, dy0, dy1, loss_acc);
+                const float dA = dy0 + dy1, dB = dy1 - dy0;
+                dboi += dA; dboq += dB;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float dh = 0.0f;
+                    if (j < H) {
+                        const int q = j % kBojP;
+                        const float wi = pl[L.o_woi + j], wq = pl[L.o_woq + j], hj = hv[j];
+                        dwi[j] = __builtin_fmaf(dA, hj * co[q], dwi[j]);
+                        dwq[j] = __builtin_fmaf(dB, hj * si[q], dwq[j]);
+                        dh = __builtin_fmaf(dA * wi, co[q], (dB * wq) * si[q]);
+                        dco[q] = __builtin_fmaf(dA * wi, hj, dco[q]);
+                        dsi[q] = __builtin_fmaf(dB * wq, hj, dsi[q]);
+                    }
+                    dhh[t * kBgpP16 + j] = dh;
+                }
+#pragma unroll
+                for (int p = 0; p < kBojP; ++p) { dcs[p * Tp + t] = dco[p]; dcs[(kBojP + p) * Tp + t] = dsi[p]; }
+            }
+        }
+        wave_lds_fence();
+        // ---- backward recurrence ----
+        {
+            float carry = 0.0f;
+            int dk = dk0 + (T - 1) * dk_step;
+            for (int t = T - 1; t >= 0; --t) {
+                const float hp = hist[t * kBgpP16 + col], f = fg[t * kBgpP32 + col], g = fg[t * kBgpP32 + 16 + col];
+                const float gh = carry + dhh[t * kBgpP16 + col];
+                const float dfp = (gh * (hp - g)) * (f * (1.0f - f));
+                const float dgp = (gh * (1.0f - f)) * __builtin_fmaf(-g, g, 1.0f);
+                const float d_row = vsel(rm.m[0], dfp, vsel(rm.m[1], dgp, 0.0f));
+                float part = rotdot(0.0f, wT, d_row);
+                part += xor16(part);
+                part += xor32(part);
+                carry = __builtin_fmaf(gh, f, part);
+                smem[dk] = d_row;
+                dk -= dk_step;
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_row, hp, acc1, 0, 0, 0);
+            }
+        }
+        wave_lds_fence();
+        // ---- dL/de through W_fi, W_gi and the demodulator's gradient; lane = time step ----
+        for (int t0 = 0; t0 < Tp; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < Tp) {
+                const bool live = t < T;
+                float de[2 * kBojP];
+#pragma unroll
+                for (int k = 0; k < 2 * kBojP; ++k) de[k] = 0.0f;
+                for (int u = 0; u < H; ++u) {
+                    const float df = xs[t * kBgpP32 + u], dg = xs[t * kBgpP32 + 16 + u];
+#pragma unroll
+                    for (int k = 0; k < 2 * kBojP; ++k) {
+                        de[k] = __builtin_fmaf(pl[L.o_wfi + u * 2 * kBojP + k], df, de[k]);
+                        de[k] = __builtin_fmaf(pl[L.o_wgi + u * 2 * kBojP + k], dg, de[k]);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < kBojP; ++p) {
+                    const float fi = fiq[p * Tp + t], fq = fiq[(kBojP + p) * Tp + t];
+                    const float m0 = sqrtf(fi * fi + fq * fq), mag = m0 + 1e-8f;
+                    const float dco = dcs[p * Tp + t], dsi = dcs[(kBojP + p) * Tp + t];
+                    const float dmag = de[p] + 2.0f * mag * de[kBojP + p] - (dsi * fq + dco * fi) / (mag * mag);
+                    const float im0 = m0 > 0.0f ? 1.0f / m0 : 0.0f;            // (a filter output of exactly 0: the term is dropped, as in the S16 kernels)
+                    const float dfi = dco / mag + dmag * fi * im0, dfq = dsi / mag + dmag * fq * im0;
+                    dcs[p * Tp + t] = live ? dfi : 0.0f; dcs[(kBojP + p) * Tp + t] = live ? dfq : 0.0f;
+                }
+            }
+        }
+        wave_lds_fence();
+        // ---- the sums over time on the matrix pipe: lane (i = col, k = role) feeds A[i][k], B[k][col] of a 4-step slice ----
+        {
+            const int arow = (col < 12 ? col : 11) * Tp;
+            const float amask = col < 12 ? 1.0f : 0.0f;
+            for (int t = role; t < Tp; t += 4) {
+                const float af = xs[t * kBgpP32 + col], ag = xs[t * kBgpP32 + 16 + col], be = env[col * Tp + t];
+                accF = mfma4(af, be, accF);
+                accG = mfma4(ag, be, accG);
+                const float ad = dcs[arow + t] * amask;
+                const float2 xv = xw[t + 1 + col];                               // tap m = col of step t: time t - 15 + m
+                accI = mfma4(ad, xv.x, accI);
+                accQ = mfma4(ad, xv.y, accQ);
+            }
+        }
+    }
+    // ---- the workgroup's row of partial gradients (every entry written) ----
+    float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
+    wave_lds_fence();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = 4 * role + rr;
+        dump[i * 16 + col] = accI[rr];
+        dump[256 + i * 16 + col] = accQ[rr];
+        if (i < H) {
+            if (col < 2 * kBojP) { prow[L.o_wfi + i * 2 * kBojP + col] = accF[rr]; prow[L.o_wgi + i * 2 * kBojP + col] = accG[rr]; }
+            else if (col == 2 * kBojP) { prow[L.o_bfi + i] = accF[rr]; prow[L.o_bgi + i] = accG[rr]; }
+            // 4-block MFMA: block 0 = d_f (x) h(t-1), block 1 = d_g (x) h(t-1); register 4 blk + rr of lane l = entry (4 (l / 16) + rr, l % 16)
+            if (col < H) { prow[L.o_wfh + i * H + col] = acc1[rr]; prow[L.o_wgh + i * H + col] = acc1[4 + rr]; }
+        }
+    }
+    wave_lds_fence();
+    for (int idx = lane; idx < kBojP * kBojM; idx += 64) {
+        const int p = idx / kBojM, m = idx % kBojM;
+        prow[L.o_bi + idx] = dump[p * 16 + m] + dump[256 + (kBojP + p) * 16 + m];
+        prow[L.o_bq + idx] = dump[(kBojP + p) * 16 + m] - dump[256 + p * 16 + m];
+    }
+    float lp = loss_acc, s0 = dboi, s1 = dboq;
+    for (int o = 32; o > 0; o >>= 1) { lp += __shfl_xor(lp, o); s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float vi = dwi[j], vq = dwq[j];
+        for (int o = 32; o > 0; o >>= 1) { vi += __shfl_xor(vi, o); vq += __shfl_xor(vq, o); }
+        if (lane == 0 && j < H) { prow[L.o_woi + j] = vi; prow[L.o_woq + j] = vq; }
+    }
+    if (lane == 0) {
+        prow[L.o_boi] = s0; prow[L.o_boq] = s1;
+        prow[L.P] = lp; prow[L.P + 1] = 0.0f; prow[L.P + 2] = 0.0f; prow[L.P + 3] = 0.0f;
+    }
+}
+
+static size_t boj_gp_lds_bytes(int P, int T) { return ((size_t)pad4(P) + bgp_buf(T).total) * sizeof(float); }
+static int boj_gp_blocks_per_cu(int P, int T) {
+    const size_t lds = boj_gp_lds_bytes(P, T);
+    const int n = lds > kMaxLds ? 0 : (int)(kMaxLds / lds);
+    return n < 4 ? n : 4;
+}
+
 }  // namespace
 
 bool bojanet_ok(const odpd_model_t* m) { return m->hidden >= 1 && m->hidden <= 16; }
@@ -482,6 +774,25 @@ int bojanet_rows(const odpd_model_t* m, int B) {
 int64_t bojanet_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!bojanet_ok(m)) return ODPD_EUNSUPPORTED;
     return (int64_t)((B + 15) / 16) * num_ckpt(T) * 256;
+}
+// the gate-parallel fused train kernel: one sequence per single-wave workgroup, the frame's state in LDS
+bool bojanet_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    if (!bojanet_ok(m) || T < kBojM - 1) return false;
+    const int per_cu = boj_gp_blocks_per_cu(boj_layout(m->hidden).P, T);
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0) return B <= max_batch && per_cu > 0;
+    // up to five rounds of workgroups (measured: profiles/r03/gp_train_bench_f4.txt): the alternative is the forward / loss / backward chain of the S16 kernels
+    return (long)B <= 5L * device_cus() * per_cu;
+}
+int bojanet_gp_rows(const odpd_model_t* m, int B, int T) {
+    const long cap = (long)device_cus() * boj_gp_blocks_per_cu(boj_layout(m->hidden).P, T);
+    return B < cap ? B : (int)cap;
+}
+int bojanet_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    const size_t lds = boj_gp_lds_bytes(boj_layout(m->hidden).P, a.T);
+    if (int e = allow_big_lds(boj_gp_train_kernel, lds)) return e;
+    hipLaunchKernelGGL(boj_gp_train_kernel, dim3(bojanet_gp_rows(m, a.B, a.T)), dim3(64), lds, st, a);
+    return (int)hipGetLastError();
 }
 // mode 1 forward, 2 backward
 int bojanet_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int mode) {

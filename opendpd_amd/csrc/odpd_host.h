@@ -262,6 +262,10 @@ int bojanet_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int m
 int bojanet_rows(const odpd_model_t* m, int B);
 int64_t bojanet_param_count(const odpd_model_t* m);
 int64_t bojanet_ckpt_floats(const odpd_model_t* m, int B, int T);
+// ... its gate-parallel fused train kernel (one sequence per wave: the reference's own batch sizes)
+bool bojanet_train_uses_gp(const odpd_model_t* m, int B, int T);
+int bojanet_gp_rows(const odpd_model_t* m, int B, int T);
+int bojanet_gp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int tcnn_rows(const odpd_model_t* m, int B, int T);

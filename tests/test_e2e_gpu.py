@@ -483,7 +483,8 @@ def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H
     --PA_backbone choices, so there is no reference log to anchor it to): device-resident frame loader, eval + metrics +
     checkpoint/log layout."""
     import opendpd_amd as od
-    res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone=bb, PA_hidden_size=H, frame_length=50, batch_size=256, lr=2e-3,
+    # (the ATen restatement of mcldnn steps through its 50 samples op by op, ~0.5 s per train step: a larger batch keeps the flow check short)
+    res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone=bb, PA_hidden_size=H, frame_length=50, batch_size=2048 if bb == "mcldnn" else 256, lr=2e-3,
                       n_epochs=2, seed=0, accelerator="cuda")
     assert res["status"] == "completed" and os.path.exists(res["model_path"])
     hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))

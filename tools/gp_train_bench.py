@@ -2,7 +2,8 @@
 """Fused train step (fwd + loss + BPTT + clip + AdamW) at the reference's own batch sizes: the gate-parallel kernel (gru_gp_train_kernel,
 one sequence per wave; lstm_gp_train_kernel for lstm / vdlstm) beside the row-rotated kernels (four sequences per wave: fused for the GRU
 family, forward / loss / backward launches for the LSTM family; the delta backbones: split chain either way, their one-sequence-per-wave forward and backward beside the row-rotated ones; odpd_set_tuning gp_max_batch = 0).
-usage: PYTHONPATH=. python tools/gp_train_bench.py"""
+(bojanet: boj_gp_train_kernel beside the split S16 chain)
+usage: PYTHONPATH=. python tools/gp_train_bench.py [backbone:hidden ...]"""
 import ctypes as C
 import time
 
@@ -20,7 +21,7 @@ lib = _lib.load()
 
 def step_ms(bb, H, B, T, gp_max_batch):
     lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(gp_max_batch))
-    framed = bb not in ("lstm", "vdlstm", "pgjanet", "deltagru", "deltagru_tcnskip", "deltajanet")            # the LSTM family takes materialised (B, T, 2) frames
+    framed = bb not in ("lstm", "vdlstm", "pgjanet", "deltagru", "deltagru_tcnskip", "deltajanet", "bojanet")            # the LSTM family takes materialised (B, T, 2) frames
     xs, ys = bench.synth_frames(B, T, 0, dev, materialize=not framed)
     torch.manual_seed(0)
     net = CoreModel(2, H, 1, bb).to(dev)
@@ -39,7 +40,11 @@ def step_ms(bb, H, B, T, gp_max_batch):
     return best, float(loss)
 
 
-for bb, H in (("gru", 11), ("dgru", 13), ("dgru", 23), ("gru", 23), ("qgru", 10), ("qgru_amp1", 16), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11), ("deltagru", 15), ("deltagru_tcnskip", 15), ("deltajanet", 15)):
+CASES = (("gru", 11), ("dgru", 13), ("dgru", 23), ("gru", 23), ("qgru", 10), ("qgru_amp1", 16), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11), ("deltagru", 15), ("deltagru_tcnskip", 15),
+         ("deltajanet", 15), ("bojanet", 12))
+if len(sys.argv) > 1:       # e.g. bojanet:12
+    CASES = tuple((s.split(":")[0], int(s.split(":")[1])) for s in sys.argv[1:])
+for bb, H in CASES:
     for B, T in ((64, 50), (256, 50), (1024, 50), (64, 200), (256, 200), (512, 200), (768, 200), (1024, 200), (2048, 200)):
         a, la = step_ms(bb, H, B, T, 0)
         g, lg = step_ms(bb, H, B, T, 1 << 30)
