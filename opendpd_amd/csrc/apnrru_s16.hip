@@ -529,6 +529,305 @@ int a16_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
     return (int)hipGetLastError();
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Gate-parallel fused train kernel for the reference's own batch sizes (train_funcs.py:28-48; every frame gets a SIMD of its own): ONE
+// sequence per single-wave workgroup; rows 0, 2 of the wave hold tile 0 of the state vector (h_I | h_A[2] | h_A[0]), rows 1, 3 tile 1 (h_Q |
+// h_A[1]) — apn_unit() —, every lane carries h_I AND h_Q of its slot, so both complex rotations are local.  Only the recurrence is in the
+// step loops; with lane = time step over the whole frame:
+//   front     r = conj(x) / |x|, the FIR bank, the 8 rotated features and their share of W_u's pre-activation;
+//   forward   v1: one rotated dot product per tile, summed across the row pair; v: one per slot over the 16 nodes; s' = sigmoid(C s) + Z v; one
+//             cross-row swap hands the partner's s'; s, v, v1 and h of the frame parked in LDS;
+//   head      both read-outs, loss, dL/dy;
+//   backward  the two transposed rotated dot products, the step's weight gradients (W_h, the state columns of W_u) as TWO 4-block MFMAs;
+//   back end  dL/dfeat -> dL/dfi, dL/dfq (lane = time step), then the sums over time on the matrix pipe: W_u's feature columns | b_u as
+//             d_pre1^T [feat, 1], both FIR banks as (d_fi, d_fq)^T [I window], [Q window].
+// Weight gradients only (the frozen-PA role stays on the S16 kernels).  Taken while the frame's state fits the CU's LDS.
+// -------------------------------------------------------------------------------------------------
+constexpr int kAgpP16 = 17, kAgpP32 = 33;
+struct AgpBuf { int xw, rt, fiq, fe, au, sp, v, v1, hh, dab, dump, total; };
+__host__ __device__ inline AgpBuf agp_buf(int T) {
+    const int Tp = (T + 3) & ~3;
+    AgpBuf b; int o = 0;
+    b.xw = o; o += 2 * (Tp + 16);            // float2 [16 + Tp]: index i <-> time i - 16 (zero before the frame)
+    b.rt = o; o += 2 * Tp;                   // float2 [Tp]: (rr, ri) of step t
+    b.fiq = o; o += 6 * Tp;                  // [6][Tp]: fi_q, fq_q of the three filters; then dL/dfi_q, dL/dfq_q
+    b.fe = o; o += 16 * Tp;                  // [16][Tp]: the 8 features, 1, 0 ... (zero columns past the frame)
+    b.au = o; o += kAgpP16 * Tp;             // [Tp][17]: the features' share of W_u's pre-activation (+ b_u); overwritten by d_pre1 in the backward steps
+    b.sp = o; o += kAgpP32 * Tp;             // the rotated state s of step t (tile 0 | tile 1)
+    b.v = o; o += kAgpP32 * Tp;              // v of step t
+    b.v1 = o; o += kAgpP16 * Tp;             // v1 of step t
+    b.hh = o; o += kAgpP32 * Tp;             // h_I | h_Q after step t
+    b.dab = o; o += 2 * Tp;                  // float2 [Tp]: dL/dA, dL/dBq
+    b.dump = o; o += 512;
+    b.total = o;
+    return b;
+}
+__global__ __launch_bounds__(64) void apn_gp_train_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4, tile = role & 1;
+    const ApnLayout L = apn_layout(a.H);
+    const int H = L.H, n = L.n, T = a.T, Tp = (T + 3) & ~3, WU = 8 + n;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    const AgpBuf O = agp_buf(T);
+    float* buf = smem + pad4(L.P);
+    float2* xw = reinterpret_cast<float2*>(buf + O.xw);
+    float2* rt = reinterpret_cast<float2*>(buf + O.rt);
+    float2* dab = reinterpret_cast<float2*>(buf + O.dab);
+    float *fiq = buf + O.fiq, *fe = buf + O.fe, *au = buf + O.au, *spk = buf + O.sp, *vpk = buf + O.v, *v1pk = buf + O.v1, *hh = buf + O.hh;
+    float* dump = buf + O.dump;
+    // rotated weights of this lane: W_u's state columns of the row's tile (node = col), W_h's row of the lane's slot, and both transposed
+    float wU[16], wH[16], wUT[16], wHT[16];
+    const int unit = apn_unit(H, tile, col);
+    {
+        const int dir = rot_dir(col);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = (col + dir * k) & 15, um = apn_unit(H, tile, m);
+            wU[k] = um >= 0 ? pl[L.o_wu + col * WU + 8 + um] : 0.0f;                  // node col  <- slot m
+            wH[k] = unit >= 0 ? pl[L.o_wh + unit * kApnNode + m] : 0.0f;              // slot col  <- node m
+            wUT[k] = unit >= 0 ? pl[L.o_wu + m * WU + 8 + unit] : 0.0f;               // slot col  <- d_pre1 of node m
+            wHT[k] = um >= 0 ? pl[L.o_wh + um * kApnNode + col] : 0.0f;               // node col  <- d_pre2 of slot m
+        }
+    }
+    const bool is_h = col < H, live_slot = unit >= 0;
+    const float Cc = pl[L.o_c], zz = live_slot ? pl[L.o_z + unit] : 0.0f, bh = live_slot ? pl[L.o_bh + unit] : 0.0f;
+    const float woi = is_h ? pl[L.o_woi + col] : 0.0f, woq = is_h ? pl[L.o_woq + col] : 0.0f;
+    const float t0m = tile == 0 ? 1.0f : 0.0f;                                        // 1 on the h_I rows
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
+    const int dmp = (int)(dump - smem) + lane;
+    // per-step stores: A rows 0, 1: s -> spk, rows 2, 3: h_I / h_Q -> hh;  B rows 0, 1: v -> vpk, row 2: v1 -> v1pk
+    const int pa0 = role < 2 ? (int)(spk - smem) + tile * 16 + col : (int)(hh - smem) + tile * 16 + col, pa_step = kAgpP32;
+    const int pb0 = role < 2 ? (int)(vpk - smem) + tile * 16 + col : role == 2 ? (int)(v1pk - smem) + col : dmp;
+    const int pb_step = role < 2 ? kAgpP32 : role == 2 ? kAgpP16 : 0;
+    const int dk0 = role == 0 ? (int)(au - smem) + col : dmp, dk_step = role == 0 ? kAgpP16 : 0;
+    if (lane < 16) xw[lane] = make_float2(0.0f, 0.0f);
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
+    f32x4 accU = {0.f, 0.f, 0.f, 0.f}, accI = accU, accQ = accU;
+    float dwi[14], dwq[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) { dwi[j] = 0.0f; dwq[j] = 0.0f; }
+    float dZ = 0.0f, dC = 0.0f, dbh = 0.0f, loss_acc = 0.0f;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        wave_lds_fence();
+        for (int t = lane; t < Tp; t += 64) xw[16 + t] = t < T ? xg[t] : make_float2(0.0f, 0.0f);
+        wave_lds_fence();
+        // ---- front: r, FIR bank, rotated features, their share of W_u; lane = time step ----
+        for (int t0 = 0; t0 < Tp; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < Tp) {
+                const bool live = t < T;
+                const float2 x0 = live ? xw[16 + t] : make_float2(1.0f, 0.0f);
+                const float mag = sqrtf(x0.x * x0.x + x0.y * x0.y), rr = x0.x / mag, ri = -x0.y / mag;
+                float fi[4], fq[4];
+#pragma unroll
+                for (int q = 0; q < kApnF; ++q) { fi[q] = 0.0f; fq[q] = 0.0f; }
+#pragma unroll
+                for (int m = 0; m < kApnM; ++m) {
+                    const float2 xv = xw[t + 1 + m];                             // time t - 15 + m
+#pragma unroll
+                    for (int q = 0; q < kApnF; ++q) {
+                        const float bi = pl[L.o_bi + q * kApnM + m], bq = pl[L.o_bq + q * kApnM + m];
+                        fi[q] += bi * xv.x - bq * xv.y;
+                        fq[q] += bq * xv.x + bi * xv.y;
+                    }
+                }
+                fi[3] = x0.x; fq[3] = x0.y;
+                float feat[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    feat[2 * k] = rr * fi[k] - ri * fq[k];
+                    feat[2 * k + 1] = ri * fi[k] + rr * fq[k];
+                }
+                rt[t] = make_float2(rr, ri);
+#pragma unroll
+                for (int q = 0; q < kApnF; ++q) { fiq[q * Tp + t] = fi[q]; fiq[(kApnF + q) * Tp + t] = fq[q]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) fe[k * Tp + t] = live ? feat[k] : 0.0f;
+                fe[8 * Tp + t] = live ? 1.0f : 0.0f;
+#pragma unroll
+                for (int k = 9; k < 16; ++k) fe[k * Tp + t] = 0.0f;
+                for (int o = 0; o < kApnNode; ++o) {
+                    float acc = pl[L.o_bu + o];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc = __builtin_fmaf(pl[L.o_wu + o * WU + k], feat[k], acc);
+                    au[t * kAgpP16 + o] = live ? acc : 0.0f;
+                }
+            }
+        }
+        wave_lds_fence();
+        // ---- forward recurrence ----
+        {
+            float hI = 0.0f, hQ = 0.0f, hA = 0.0f;
+            int pa = pa0, pb = pb0;
+            for (int t = 0; t < T; ++t) {
+                const float2 r = rt[t];
+                // into the normalised frame: s_I = h_I rr - h_Q ri, s_Q = h_I ri + h_Q rr
+                const float rot = tile == 0 ? __builtin_fmaf(hI, r.x, -(hQ * r.y)) : __builtin_fmaf(hI, r.y, hQ * r.x);
+                const float sp = is_h ? rot : hA;
+                float p1 = rotdot(0.0f, wU, sp);
+                p1 += xor16(p1);
+                const float v1 = tanhf_(p1 + au[t * kAgpP16 + col]);
+                const float v = tanhf_(rotdot(bh, wH, v1));
+                const float sn = live_slot ? sigmoidf_(Cc * sp) + zz * v : 0.0f;
+                const float osn = xor16(sn);
+                const float snI = tile == 0 ? sn : osn, snQ = tile == 0 ? osn : sn;
+                // back: h_I = s'_I rr + s'_Q ri, h_Q = s'_Q rr - s'_I ri
+                hI = __builtin_fmaf(snI, r.x, snQ * r.y);
+                hQ = __builtin_fmaf(snQ, r.x, -(snI * r.y));
+                hA = sn;
+                smem[pa] = role < 2 ? sp : (tile == 0 ? hI : hQ);
+                smem[pb] = role < 2 ? v : v1;
+                pa += pa_step; pb += pb_step;
+            }
+        }
+        wave_lds_fence();
+        // ---- read-outs, loss and dL/dy of every step; lane = time step ----
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < T) {
+                const float* hv = hh + t * kAgpP32;
+                float y0 = 0.0f, y1 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 14; ++j)
+                    if (j < H) {
+                        y0 = __builtin_fmaf(pl[L.o_woi + j], hv[j], y0);
+                        y1 = __builtin_fmaf(pl[L.o_woq + j], hv[16 + j], y1);
+                    }
+                const float2 tv = tg[t];
+                float dy0, dy1;
+                s16_loss(lossc, (y0 - y1) - tv.x, (y1 + y0) - tv.y, dy0, dy1, loss_acc);
+                const float dA = dy0 + dy1, dB = dy1 - dy0;
+                dab[t] = make_float2(dA, dB);
+#pragma unroll
+                for (int j = 0; j < 14; ++j)
+                    if (j < H) {
+                        dwi[j] = __builtin_fmaf(dA, hv[j], dwi[j]);
+                        dwq[j] = __builtin_fmaf(dB, hv[16 + j], dwq[j]);
+                    }
+            }
+        }
+        wave_lds_fence();
+        // ---- backward recurrence ----
+        {
+            float dhI = 0.0f, dhQ = 0.0f, dhA = 0.0f;
+            int dk = dk0 + (T - 1) * dk_step;
+            for (int t = T - 1; t >= 0; --t) {
+                const float2 r = rt[t], dd = dab[t];
+                const float sp = spk[t * kAgpP32 + tile * 16 + col], v = vpk[t * kAgpP32 + tile * 16 + col], v1 = v1pk[t * kAgpP16 + col];
+                const float gI = __builtin_fmaf(dd.x, woi, dhI), gQ = __builtin_fmaf(dd.y, woq, dhQ);
+                const float drot = tile == 0 ? __builtin_fmaf(gI, r.x, -(gQ * r.y)) : __builtin_fmaf(gI, r.y, gQ * r.x);
+                const float dsn = is_h ? drot : (live_slot ? dhA : 0.0f);
+                const float sg = sigmoidf_(Cc * sp), dsg = sg * (1.0f - sg);
+                dZ = __builtin_fmaf(dsn, v, dZ);
+                dC = __builtin_fmaf(dsn * dsg, sp, dC);
+                const float dpre2 = (dsn * zz) * __builtin_fmaf(-v, v, 1.0f);
+                dbh += dpre2;
+                float dv1 = rotdot(0.0f, wHT, dpre2);
+                dv1 += xor16(dv1);
+                const float dpre1 = dv1 * __builtin_fmaf(-v1, v1, 1.0f);
+                const float dsp = rotdot((dsn * dsg) * Cc, wUT, dpre1);
+                const float odsp = xor16(dsp);
+                const float dspI = tile == 0 ? dsp : odsp, dspQ = tile == 0 ? odsp : dsp;
+                dhI = __builtin_fmaf(dspI, r.x, dspQ * r.y);
+                dhQ = __builtin_fmaf(dspQ, r.x, -(dspI * r.y));
+                dhA = dsp;
+                smem[dk] = dpre1;
+                dk -= dk_step;
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(dpre2, v1, acc1, 0, 0, 0);       // blocks 0, 1: d_pre2 of tile 0 | 1  (x) v1
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(dpre1, sp, acc2, 0, 0, 0);       // blocks 0, 1: d_pre1 (x) s of tile 0 | 1
+            }
+        }
+        wave_lds_fence();
+        // ---- dL/dfeat -> dL/dfi, dL/dfq of the three filters; lane = time step ----
+        for (int t0 = 0; t0 < Tp; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < Tp) {
+                const bool live = t < T;
+                float df[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) df[k] = 0.0f;
+                for (int o = 0; o < kApnNode; ++o) {
+                    const float d1 = au[t * kAgpP16 + o];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) df[k] = __builtin_fmaf(pl[L.o_wu + o * WU + k], d1, df[k]);
+                }
+                const float2 r = rt[t];
+#pragma unroll
+                for (int q = 0; q < kApnF; ++q) {
+                    const float dfi = df[2 * q] * r.x + df[2 * q + 1] * r.y, dfq = df[2 * q + 1] * r.x - df[2 * q] * r.y;
+                    fiq[q * Tp + t] = live ? dfi : 0.0f; fiq[(kApnF + q) * Tp + t] = live ? dfq : 0.0f;
+                }
+            }
+        }
+        wave_lds_fence();
+        // ---- the sums over time on the matrix pipe: lane (i = col, k = role) feeds A[i][k], B[k][col] of a 4-step slice ----
+        {
+            const int arow = (col < 6 ? col : 5) * Tp;
+            const float amask = col < 6 ? 1.0f : 0.0f;
+            for (int t = role; t < Tp; t += 4) {
+                accU = mfma4(au[t * kAgpP16 + col], fe[col * Tp + t], accU);
+                const float ad = fiq[arow + t] * amask;
+                const float2 xv = xw[t + 1 + col];                               // tap m = col of step t: time t - 15 + m
+                accI = mfma4(ad, xv.x, accI);
+                accQ = mfma4(ad, xv.y, accQ);
+            }
+        }
+    }
+    // ---- the workgroup's row of partial gradients (every entry written) ----
+    float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
+    wave_lds_fence();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = 4 * role + rr;
+        dump[i * 16 + col] = accI[rr];
+        dump[256 + i * 16 + col] = accQ[rr];
+        if (col < 8) prow[L.o_wu + i * WU + col] = accU[rr];
+        else if (col == 8) prow[L.o_bu + i] = accU[rr];
+        // 4-block MFMAs: register 4 blk + rr of lane l = entry (4 (l / 16) + rr, l % 16) of block blk
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int ui = apn_unit(H, blk, i), uc = apn_unit(H, blk, col);
+            if (ui >= 0) prow[L.o_wh + ui * kApnNode + col] = acc1[4 * blk + rr];
+            if (uc >= 0) prow[L.o_wu + i * WU + 8 + uc] = acc2[4 * blk + rr];
+        }
+    }
+    wave_lds_fence();
+    for (int idx = lane; idx < kApnF * kApnM; idx += 64) {
+        const int q = idx / kApnM, m = idx % kApnM;
+        prow[L.o_bi + idx] = dump[q * 16 + m] + dump[256 + (kApnF + q) * 16 + m];
+        prow[L.o_bq + idx] = dump[(kApnF + q) * 16 + m] - dump[256 + q * 16 + m];
+    }
+    if (role < 2 && live_slot) { prow[L.o_z + unit] = dZ; prow[L.o_bh + unit] = dbh; }
+    float lp = loss_acc, sc = role < 2 ? dC : 0.0f;
+    for (int o = 32; o > 0; o >>= 1) { lp += __shfl_xor(lp, o); sc += __shfl_xor(sc, o); }
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        float vi = dwi[j], vq = dwq[j];
+        for (int o = 32; o > 0; o >>= 1) { vi += __shfl_xor(vi, o); vq += __shfl_xor(vq, o); }
+        if (lane == 0 && j < H) { prow[L.o_woi + j] = vi; prow[L.o_woq + j] = vq; }
+    }
+    if (lane == 0) {
+        prow[L.o_c] = sc;
+        prow[L.P] = lp; prow[L.P + 1] = 0.0f; prow[L.P + 2] = 0.0f; prow[L.P + 3] = 0.0f;
+    }
+}
+
+static size_t apn_gp_lds_bytes(int P, int T) { return ((size_t)pad4(P) + agp_buf(T).total) * sizeof(float); }
+static int apn_gp_blocks_per_cu(int P, int T) {
+    const size_t lds = apn_gp_lds_bytes(P, T);
+    const int n = lds > kMaxLds ? 0 : (int)(kMaxLds / lds);
+    return n < 4 ? n : 4;
+}
+
 }  // namespace
 
 bool apnrru_ok(const odpd_model_t* m) { return m->hidden >= 1 && m->hidden <= 14; }
@@ -542,6 +841,25 @@ int apnrru_rows(const odpd_model_t* m, int B) {
 int64_t apnrru_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!apnrru_ok(m)) return ODPD_EUNSUPPORTED;
     return (int64_t)((B + 15) / 16) * num_ckpt(T) * 2 * 256;
+}
+// the gate-parallel fused train kernel: one sequence per single-wave workgroup, the frame's state in LDS
+bool apnrru_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    if (!apnrru_ok(m) || T < kApnM - 1) return false;
+    const int per_cu = apn_gp_blocks_per_cu(apn_layout(m->hidden).P, T);
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0) return B <= max_batch && per_cu > 0;
+    // up to five rounds of workgroups (measured: profiles/r03/gp_train_bench_f4.txt): the alternative is the forward / loss / backward chain of the S16 kernels
+    return (long)B <= 5L * device_cus() * per_cu;
+}
+int apnrru_gp_rows(const odpd_model_t* m, int B, int T) {
+    const long cap = (long)device_cus() * apn_gp_blocks_per_cu(apn_layout(m->hidden).P, T);
+    return B < cap ? B : (int)cap;
+}
+int apnrru_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    const size_t lds = apn_gp_lds_bytes(apn_layout(m->hidden).P, a.T);
+    if (int e = allow_big_lds(apn_gp_train_kernel, lds)) return e;
+    hipLaunchKernelGGL(apn_gp_train_kernel, dim3(apnrru_gp_rows(m, a.B, a.T)), dim3(64), lds, st, a);
+    return (int)hipGetLastError();
 }
 // mode 1 forward, 2 backward
 int apnrru_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int mode) {

@@ -257,6 +257,9 @@ int apnrru_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mo
 int apnrru_rows(const odpd_model_t* m, int B);
 int64_t apnrru_param_count(const odpd_model_t* m);
 int64_t apnrru_ckpt_floats(const odpd_model_t* m, int B, int T);
+bool apnrru_train_uses_gp(const odpd_model_t* m, int B, int T);       // (as bojanet's)
+int apnrru_gp_rows(const odpd_model_t* m, int B, int T);
+int apnrru_gp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // bojanet_s16.hip (hidden <= 16): mode 1 forward, 2 backward
 int bojanet_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
 int bojanet_rows(const odpd_model_t* m, int B);
