@@ -155,7 +155,9 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_JANET:
         if (fused) return janet_train_uses_gp(m, B, T) ? (int64_t)janet_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return janet_family_rows(m, B);
-    case FAM_DVR: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)dvrjanet_rows(m, B);
+    case FAM_DVR:
+        if (fused) return dvrjanet_train_uses_gp(m, B, T) ? (int64_t)dvrjanet_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+        return (int64_t)dvrjanet_rows(m, B);
     case FAM_BOJ:
         if (fused) return bojanet_train_uses_gp(m, B, T) ? (int64_t)bojanet_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return (int64_t)bojanet_rows(m, B);
@@ -180,6 +182,7 @@ extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int
     if (family_of(m) == FAM_JANET) return janet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_BOJ) return bojanet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_APN) return apnrru_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_DVR) return dvrjanet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN) return odpd_param_count(m) > 0 ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_QAT) return qat_uses_s16(m, B) ? qat_s16_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
@@ -262,6 +265,7 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     case FAM_JANET: return janet_train_uses_gp(m, B, T) ? janet_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_BOJ: return bojanet_train_uses_gp(m, B, T) ? bojanet_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_APN: return apnrru_train_uses_gp(m, B, T) ? apnrru_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
+    case FAM_DVR: return dvrjanet_train_uses_gp(m, B, T) ? dvrjanet_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_GMP: return gmp_train((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_train((hipStream_t)stream, m, a);
     case FAM_QAT: return qat_uses_s16(m, B) ? qat_s16_launch((hipStream_t)stream, m, a, 0) : (int)ODPD_EUNSUPPORTED;
@@ -326,6 +330,7 @@ inline bool framed_train_ok_shape(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_JANET) return janet_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_BOJ) return bojanet_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_APN) return apnrru_train_uses_gp(m, B, T);
+    if (family_of(m) == FAM_DVR) return dvrjanet_train_uses_gp(m, B, T);
     return false;
 }
 inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
@@ -336,6 +341,7 @@ inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqA
     if (family_of(m) == FAM_JANET) return framed_train_ok_shape(m, a.B, a.T) ? janet_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_BOJ) return framed_train_ok_shape(m, a.B, a.T) ? bojanet_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_APN) return framed_train_ok_shape(m, a.B, a.T) ? apnrru_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_DVR) return framed_train_ok_shape(m, a.B, a.T) ? dvrjanet_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     const bool s16n = gru_uses_s16n(m, a.B), s16 = !s16n && gru_train_uses_s16(m, a.B, a.T);
     if ((s16 || s16n) && !a.ckpt) return ODPD_EINVAL;
     return s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));

@@ -471,6 +471,226 @@ int v16_launch_bwd(hipStream_t st, const SeqArgs& a, int P, int K) {
     return (int)hipGetLastError();
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Gate-parallel fused train kernel for the reference's own batch sizes (train_funcs.py:28-48; every frame gets a SIMD of its own): ONE
+// sequence per single-wave workgroup, every row of the wave carries h_I and h_Q of the 16 units.
+//   front     |x| and atan2 of the frame, lane = time step;
+//   forward   round A on hs = h_I + h_Q: rows W_ph | W_ah | W_f | -, one rotated dot product per row, the three results handed to every row;
+//             the DVR, sin / cos; round B: rows W_cc|h on h_I, W_cc|a on a cos, W_cs|h on h_Q, W_cs|a on a sin, summed across the row
+//             pairs, the other pair's tanh by one swap; a step record (cos, sin, a, ap, f, g_c, g_s, h_I, h_Q) parked in LDS;
+//   head      both read-outs, loss, dL/dy with lane = time step;
+//   backward  the two rounds with the transposed blocks; the step's seven H x H weight gradients as TWO 4-block MFMAs
+//             (v_mfma_f32_16x16x1_4b_f32): (d_gc | d_gc | d_gs | d_gs) x (h_I | a cos | h_Q | a sin) and (d_th | d_ap | d_f | 0) x hs.
+// Weight gradients only (the frozen-PA role stays on the S16 kernels).  Taken while the frame's records fit the CU's LDS.
+// -------------------------------------------------------------------------------------------------
+constexpr int kVgpRec = 9 * 16 + 1;          // floats per step record (odd: conflict-free with lane = unit and with lane = time step)
+__host__ __device__ inline int vgp_buffer_floats(int T) { return kVgpRec * (T + 1) + 4 * ((T + 3) & ~3) + 256; }
+__global__ __launch_bounds__(64) void dvr_gp_train_kernel(SeqArgs a, int K, DvrKnots kn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;
+    const DvrLayout L = dvr_layout(a.H, K);
+    const int H = L.H, T = a.T, Tp = (T + 3) & ~3;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* rec = smem + pad4(L.P);                                   // record t + 1 = step t; record 0: h_I = h_Q = 0
+    float2* mt = reinterpret_cast<float2*>(rec + kVgpRec * (T + 1)); // (|x|, theta) of step t
+    float2* dyb = mt + Tp;
+    float* dump = reinterpret_cast<float*>(dyb + Tp);
+    V16Uni U;
+    U.load(pl, L, kn);
+    float wA[16], wB[16], wAT[16], wBT[16];
+    {
+        const int dir = rot_dir(col);
+        const int oa = role == 0 ? L.o_wph : role == 1 ? L.o_wah : L.o_wf;
+        const int ob = (role < 2 ? L.o_wcc : L.o_wcs) + (role & 1) * H;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = (col + dir * k) & 15;
+            const bool ok = col < H && m < H;
+            wA[k] = (ok && role < 3) ? pl[oa + col * H + m] : 0.0f;
+            wAT[k] = (ok && role < 3) ? pl[oa + m * H + col] : 0.0f;
+            wB[k] = ok ? pl[ob + col * 2 * H + m] : 0.0f;
+            wBT[k] = ok ? pl[ob + m * 2 * H + col] : 0.0f;
+        }
+    }
+    const bool vo = col < H;
+    const float sA = vo ? (role == 0 ? pl[L.o_wpt + col] : role == 1 ? pl[L.o_wax + col] : 0.0f) : 0.0f;      // the row's scalar-input column
+    const float bA = (vo && role == 2) ? pl[L.o_bf + col] : 0.0f;
+    const float bB = vo ? pl[(role < 2 ? L.o_bcc : L.o_bcs) + col] : 0.0f;
+    const float wo1 = vo ? pl[L.o_wo1 + col] : 0.0f, wo2 = vo ? pl[L.o_wo2 + col] : 0.0f;
+    const RowMasks rm = row_masks();
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
+    // the record fields a row parks: row 0 cos, sin, a | row 1 ap, f | row 2 g_c, g_s | row 3 h_I, h_Q
+    const int f0 = role == 0 ? 0 : role == 1 ? 3 : role == 2 ? 5 : 7;
+    const int pk0 = (int)(rec - smem) + kVgpRec + f0 * 16 + col;
+    const int pk2 = role == 0 ? pk0 + 32 : (int)(dump - smem) + lane;
+    if (lane < 32) rec[7 * 16 + lane] = 0.0f;
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc1[i] = 0.0f; acc2[i] = 0.0f; }
+    float dcs[kDvrMaxK], dw1[16], dw2[16];
+#pragma unroll
+    for (int k = 0; k < kDvrMaxK; ++k) dcs[k] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { dw1[j] = 0.0f; dw2[j] = 0.0f; }
+    float dsA = 0.0f, dbf = 0.0f, dbcc = 0.0f, dbcs = 0.0f, dbo1 = 0.0f, dbo2 = 0.0f, loss_acc = 0.0f;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        wave_lds_fence();
+        for (int t = lane; t < T; t += 64) {
+            float mag, theta;
+            v16_inputs(xg[t], mag, theta);
+            mt[t] = make_float2(mag, theta);
+        }
+        wave_lds_fence();
+        // ---- forward recurrence ----
+        {
+            float hI = 0.0f, hQ = 0.0f;
+            int pk = pk0, pk_c = pk2;
+            for (int t = 0; t < T; ++t) {
+                const float2 in = mt[t];
+                const float pa = rotdot(0.0f, wA, hI + hQ);
+                const float own = __builtin_fmaf(sA, vsel(rm.m[0], in.y, in.x), pa) + bA;
+                float g4[4];
+                gather_rows(vsel(rm.m[2], sigmoidf_(own), own), g4);
+                const float th = g4[0], ap = g4[1], f = g4[2];
+                float at = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kDvrMaxK; ++k) at = __builtin_fmaf(__builtin_fabsf(ap - U.knot[k]), U.cs[k], at);
+                float si, co;
+                v16_sincos(th, si, co);
+                const float vc = at * co, vs = at * si;
+                const float opnd = vsel(rm.m[0], hI, vsel(rm.m[1], vc, vsel(rm.m[2], hQ, vs)));
+                float pb = rotdot(0.0f, wB, opnd);
+                pb += xor16(pb);
+                const float gv = tanhf_(pb + bB), ogv = xor32(gv);
+                const float gc = vsel(rm.m[0] | rm.m[1], gv, ogv), gs = vsel(rm.m[0] | rm.m[1], ogv, gv);
+                hI = __builtin_fmaf(f, hI - gc, gc);
+                hQ = __builtin_fmaf(f, hQ - gs, gs);
+                smem[pk] = vsel(rm.m[0], co, vsel(rm.m[1], ap, vsel(rm.m[2], gc, hI)));
+                smem[pk + 16] = vsel(rm.m[0], si, vsel(rm.m[1], f, vsel(rm.m[2], gs, hQ)));
+                smem[pk_c] = at;
+                pk += kVgpRec;
+                pk_c += role == 0 ? kVgpRec : 0;
+            }
+        }
+        wave_lds_fence();
+        // ---- read-outs, loss and dL/dy of every step; lane = time step ----
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < T) {
+                const float* hv = rec + (t + 1) * kVgpRec + 7 * 16;
+                float y0 = U.bo1, y1 = U.bo2;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < H) {
+                        y0 = __builtin_fmaf(pl[L.o_wo1 + j], hv[j], y0);
+                        y1 = __builtin_fmaf(pl[L.o_wo2 + j], hv[16 + j], y1);
+                    }
+                const float2 tv = tg[t];
+                float dy0, dy1;
+                s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+                dbo1 += dy0; dbo2 += dy1;
+                dyb[t] = make_float2(dy0, dy1);
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < H) {
+                        dw1[j] = __builtin_fmaf(dy0, hv[j], dw1[j]);
+                        dw2[j] = __builtin_fmaf(dy1, hv[16 + j], dw2[j]);
+                    }
+            }
+        }
+        wave_lds_fence();
+        // ---- backward recurrence ----
+        {
+            float dhI = 0.0f, dhQ = 0.0f;
+            for (int t = T - 1; t >= 0; --t) {
+                const float* r1 = rec + (t + 1) * kVgpRec + col;
+                const float co = r1[0], si = r1[16], at = r1[32], ap = r1[48], f = r1[64], gc = r1[80], gs = r1[96];
+                const float hIp = r1[7 * 16 - kVgpRec], hQp = r1[8 * 16 - kVgpRec];
+                const float2 in = mt[t], dyv = dyb[t];
+                const float gI = __builtin_fmaf(dyv.x, wo1, dhI), gQ = __builtin_fmaf(dyv.y, wo2, dhQ);
+                const float df = __builtin_fmaf(gI, hIp - gc, gQ * (hQp - gs));
+                const float dfp = df * (f * (1.0f - f));
+                const float dgc = (gI * (1.0f - f)) * __builtin_fmaf(-gc, gc, 1.0f);
+                const float dgs = (gQ * (1.0f - f)) * __builtin_fmaf(-gs, gs, 1.0f);
+                const float dB_row = vsel(rm.m[0] | rm.m[1], dgc, dgs);
+                float g4[4];
+                gather_rows(rotdot(0.0f, wBT, dB_row), g4);                       // h_I's share | dL/d(a cos) | h_Q's share | dL/d(a sin)
+                const float dvc = g4[1], dvs = g4[3];
+                const float dat = __builtin_fmaf(dvc, co, dvs * si);
+                const float dth = at * __builtin_fmaf(dvs, co, -(dvc * si));
+                float slope = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kDvrMaxK; ++k) {
+                    const float u = ap - U.knot[k];
+                    dcs[k] = __builtin_fmaf(dat, __builtin_fabsf(u), dcs[k]);
+                    slope = __builtin_fmaf(U.cs[k], s16_sign(u), slope);
+                }
+                const float dap = dat * slope;
+                const float dA_row = vsel(rm.m[0], dth, vsel(rm.m[1], dap, vsel(rm.m[2], dfp, 0.0f)));
+                float pat = rotdot(0.0f, wAT, dA_row);
+                pat += xor16(pat);
+                pat += xor32(pat);
+                dhI = __builtin_fmaf(gI, f, g4[0]) + pat;
+                dhQ = __builtin_fmaf(gQ, f, g4[2]) + pat;
+                const float opnd = vsel(rm.m[0], hIp, vsel(rm.m[1], at * co, vsel(rm.m[2], hQp, at * si)));
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(dB_row, opnd, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(dA_row, hIp + hQp, acc2, 0, 0, 0);
+                dsA = __builtin_fmaf(dA_row, vsel(rm.m[0], in.y, in.x), dsA);      // row 0: W_ptheta, row 1: W_ax
+                dbf += dfp; dbcc += dgc; dbcs += dgs;
+            }
+        }
+    }
+    // ---- the workgroup's row of partial gradients (every entry written) ----
+    float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
+    float lp = loss_acc, s0 = dbo1, s1 = dbo2;
+    for (int o = 32; o > 0; o >>= 1) { lp += __shfl_xor(lp, o); s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float v1 = dw1[j], v2 = dw2[j];
+        for (int o = 32; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o); v2 += __shfl_xor(v2, o); }
+        if (lane == 0 && j < H) { prow[L.o_wo1 + j] = v1; prow[L.o_wo2 + j] = v2; }
+    }
+#pragma unroll
+    for (int k = 0; k < kDvrMaxK; ++k) {
+        float v = (role == 0 && vo) ? dcs[k] : 0.0f;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && k < K) prow[L.o_cs + k] = v;
+    }
+    if (vo) {
+        if (role == 0) { prow[L.o_wpt + col] = dsA; prow[L.o_bf + col] = dbf; prow[L.o_bcc + col] = dbcc; prow[L.o_bcs + col] = dbcs; }
+        if (role == 1) prow[L.o_wax + col] = dsA;
+    }
+    if (lane == 0) {
+        prow[L.o_bo1] = s0; prow[L.o_bo2] = s1;
+        prow[L.P] = lp; prow[L.P + 1] = 0.0f; prow[L.P + 2] = 0.0f; prow[L.P + 3] = 0.0f;
+    }
+    // 4-block MFMAs: register 4 blk + rr of lane l = entry (4 (l / 16) + rr, l % 16) of block blk
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int i = 4 * role + rr;
+            if (i < H && col < H) {
+                prow[(blk < 2 ? L.o_wcc : L.o_wcs) + i * 2 * H + (blk & 1) * H + col] = acc1[4 * blk + rr];
+                if (blk < 3) prow[(blk == 0 ? L.o_wph : blk == 1 ? L.o_wah : L.o_wf) + i * H + col] = acc2[4 * blk + rr];
+            }
+        }
+}
+
+static size_t dvr_gp_lds_bytes(int P, int T) { return ((size_t)pad4(P) + vgp_buffer_floats(T)) * sizeof(float); }
+static int dvr_gp_blocks_per_cu(int P, int T) {
+    const size_t lds = dvr_gp_lds_bytes(P, T);
+    const int n = lds > kMaxLds ? 0 : (int)(kMaxLds / lds);
+    return n < 4 ? n : 4;
+}
+
 }  // namespace
 
 bool dvrjanet_ok(const odpd_model_t* m) { return m->hidden >= 1 && m->hidden <= 16 && m->bits_w >= 1 && m->bits_w <= kDvrMaxK; }
@@ -484,6 +704,26 @@ int dvrjanet_rows(const odpd_model_t* m, int B) {
 int64_t dvrjanet_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!dvrjanet_ok(m)) return ODPD_EUNSUPPORTED;
     return (int64_t)((B + 15) / 16) * num_ckpt(T) * 2 * 256;
+}
+// the gate-parallel fused train kernel: one sequence per single-wave workgroup, the frame's step records in LDS
+bool dvrjanet_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    if (!dvrjanet_ok(m)) return false;
+    const int per_cu = dvr_gp_blocks_per_cu(dvr_layout(m->hidden, m->bits_w).P, T);
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0) return B <= max_batch && per_cu > 0;
+    // up to five rounds of workgroups (measured: profiles/r03/gp_train_bench_f4.txt): the alternative is the forward / loss / backward chain of the S16 kernels
+    return (long)B <= 5L * device_cus() * per_cu;
+}
+int dvrjanet_gp_rows(const odpd_model_t* m, int B, int T) {
+    const long cap = (long)device_cus() * dvr_gp_blocks_per_cu(dvr_layout(m->hidden, m->bits_w).P, T);
+    return B < cap ? B : (int)cap;
+}
+int dvrjanet_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    const int K = m->bits_w;
+    const size_t lds = dvr_gp_lds_bytes(dvr_layout(m->hidden, K).P, a.T);
+    if (int e = allow_big_lds(dvr_gp_train_kernel, lds)) return e;
+    hipLaunchKernelGGL(dvr_gp_train_kernel, dim3(dvrjanet_gp_rows(m, a.B, a.T)), dim3(64), lds, st, a, K, dvr_knots(K));
+    return (int)hipGetLastError();
 }
 // mode 1 forward, 2 backward
 int dvrjanet_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int mode) {

@@ -247,6 +247,9 @@ int dvrjanet_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int 
 int dvrjanet_rows(const odpd_model_t* m, int B);
 int64_t dvrjanet_param_count(const odpd_model_t* m);
 int64_t dvrjanet_ckpt_floats(const odpd_model_t* m, int B, int T);
+bool dvrjanet_train_uses_gp(const odpd_model_t* m, int B, int T);     // (as bojanet's)
+int dvrjanet_gp_rows(const odpd_model_t* m, int B, int T);
+int dvrjanet_gp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // mcldnn.hip (hidden = channels <= 16): mode 1 forward, 2 backward
 int mcldnn_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
 int mcldnn_rows(const odpd_model_t* m, int B);

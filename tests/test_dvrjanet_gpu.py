@@ -110,6 +110,73 @@ def test_against_oracle_ragged(H, K, B, T):
     assert rel_err(xt2.grad.cpu().numpy(), dxo) < GRAD_TOL
 
 
+@pytest.mark.parametrize("H,K", [(1, 1), (3, 8), (7, 3), (12, 3), (15, 5), (16, 4), (16, 8)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (7, 63), (5, 64), (2, 65), (64, 50), (9, 200), (300, 200), (5, 130), (3, 240)])
+def test_gate_parallel_train_kernel(H, K, B, T):
+    """the reference's own batch sizes run dvr_gp_train_kernel (one sequence per wave; two forward and two transposed rounds of one rotated
+    dot product per row, the step's seven weight gradients as two 4-block MFMAs; read-outs, loss and dL/dy with lane = time step): loss
+    and gradient against the oracle (L2 and L1), and against the split forward / loss / backward S16 kernels (gp_max_batch = 0)"""
+    import ctypes as C
+    from opendpd_amd import _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    lib = _lib.load()
+    torch.manual_seed(H * 100 + B + T + K)
+    net = _net(H, K)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+        net.backbone.W_ax.weight.mul_(1.5)
+        net.backbone.cs.mul_(min(1.0, 1.5 / float(net.backbone.cs.abs().sum())))      # (see test_against_oracle_ragged)
+    rng = np.random.RandomState(B * 13 + T)
+    x = _iq(rng, B, T)
+    tgt = (0.4 * rng.randn(B, T, 2)).astype(np.float32)
+    xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    o, o64, m = Oracle("f32"), Oracle("f64"), make_model("dvrjanet", H, bits_w=K)
+    yo, _ = o.forward(m, p, x)
+    y64, _ = o64.forward(m, p.astype(np.float64), x.astype(np.float64))
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.has_fused(B, T)
+    try:
+        for kind in ("l2", "l1"):
+            d = yo - tgt
+            lo = float((d * d).mean()) if kind == "l2" else float(np.abs(d).mean())
+            dy = (2 * d / d.size if kind == "l2" else np.sign(d) / d.size).astype(np.float32)
+            go, _ = o.backward(m, p, x, dy, need_dx=False)
+            g64, _ = o64.backward(m, p.astype(np.float64), x.astype(np.float64), dy.astype(np.float64), need_dx=False)
+            cond = max(rel_err(yo, y64), rel_err(go, g64) / 15)
+            assert cond < 1e-4, "ill-conditioned case: pick other weights"
+            tol = max(GRAD_TOL, 90 * cond)
+            loss = fused_train_step(opt, xt, tt, kind, 0.0)
+            got = opt.grad[:-4].cpu().numpy().copy()
+            assert abs(float(loss) - lo) < max(2e-5, 6 * cond) * max(1.0, lo)
+            assert rel_err(got, go) < tol
+            assert rel_err(got[:K], go[:K]) < tol                        # the DVR coefficients on their own scale
+            lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(0))
+            opt2 = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+            assert not opt2.has_fused(B, T)
+            for q in net.parameters():
+                q.grad = None
+            y = net(xt)
+            l2 = torch.nn.functional.mse_loss(y, tt) if kind == "l2" else torch.nn.functional.l1_loss(y, tt)
+            l2.backward()
+            gs = torch.cat([q.grad.reshape(-1) for q in net.parameters()]).cpu().numpy()
+            assert abs(float(loss) - l2.item()) < max(1e-5, 6 * cond) * max(1.0, lo) and rel_err(got, gs) < max(1e-4, 30 * cond)
+            lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
+    finally:
+        lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
+
+
+def test_gate_parallel_envelope():
+    """frames whose step records do not fit a CU's LDS, and batches past a few rounds of workgroups, stay on the split S16 chain"""
+    from opendpd_amd.train_funcs import FusedAdamW
+    opt = FusedAdamW(_net(12, 3), lr=0.0)
+    assert opt.has_fused(256, 200) and opt.has_fused(64, 50)
+    assert not opt.has_fused(4, 400) and not opt.has_fused(20000, 50)
+
+
 def test_large_batch_every_wave_slot():
     """more 16-sequence groups than one pass of the grid: 2 groups per wave on the forward's 8-wave blocks"""
     from oracle.oracle import Oracle, make_model

@@ -24,7 +24,7 @@ def step_ms(bb, H, B, T, gp_max_batch):
     framed = bb not in ("lstm", "vdlstm", "pgjanet", "deltagru", "deltagru_tcnskip", "deltajanet", "bojanet", "apnrru", "dvrjanet", "mcldnn")            # the LSTM family takes materialised (B, T, 2) frames
     xs, ys = bench.synth_frames(B, T, 0, dev, materialize=not framed)
     torch.manual_seed(0)
-    net = CoreModel(2, H, 1, bb).to(dev)
+    net = CoreModel(2, H, 1, bb, **({"num_dvr_units": 3} if bb == "dvrjanet" else {})).to(dev)
     opt = FusedAdamW(net, lr=5e-4)
     fb, ys = (FrameBatch(xs, ys, torch.arange(B, device=dev), T, 1), None) if framed else (xs, ys)
     for _ in range(5):
@@ -41,7 +41,7 @@ def step_ms(bb, H, B, T, gp_max_batch):
 
 
 CASES = (("gru", 11), ("dgru", 13), ("dgru", 23), ("gru", 23), ("qgru", 10), ("qgru_amp1", 16), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11), ("deltagru", 15), ("deltagru_tcnskip", 15),
-         ("deltajanet", 15), ("bojanet", 12), ("apnrru", 8))
+         ("deltajanet", 15), ("bojanet", 12), ("apnrru", 8), ("dvrjanet", 12))
 if len(sys.argv) > 1:       # e.g. bojanet:12
     CASES = tuple((s.split(":")[0], int(s.split(":")[1])) for s in sys.argv[1:])
 for bb, H in CASES:
