@@ -164,7 +164,9 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_APN:
         if (fused) return apnrru_train_uses_gp(m, B, T) ? (int64_t)apnrru_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return (int64_t)apnrru_rows(m, B);
-    case FAM_MCL: return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)mcldnn_rows(m, B);
+    case FAM_MCL:
+        if (fused) return mcldnn_train_uses_gp(m, B, T) ? (int64_t)mcldnn_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+        return (int64_t)mcldnn_rows(m, B);
     case FAM_TCNN: return fused ? (int64_t)ODPD_EUNSUPPORTED : tcnn_rows(m, B, T);
     case FAM_GMP: return gmp_rows(m, B, T);
     case FAM_RVTDCNN: return fused ? rvtdcnn_train_rows(m, B, T) : rvtdcnn_rows(m, B, T);
@@ -183,6 +185,7 @@ extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int
     if (family_of(m) == FAM_BOJ) return bojanet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_APN) return apnrru_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_DVR) return dvrjanet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_MCL) return mcldnn_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN) return odpd_param_count(m) > 0 ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_QAT) return qat_uses_s16(m, B) ? qat_s16_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
@@ -266,6 +269,7 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     case FAM_BOJ: return bojanet_train_uses_gp(m, B, T) ? bojanet_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_APN: return apnrru_train_uses_gp(m, B, T) ? apnrru_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_DVR: return dvrjanet_train_uses_gp(m, B, T) ? dvrjanet_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
+    case FAM_MCL: return mcldnn_train_uses_gp(m, B, T) ? mcldnn_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_GMP: return gmp_train((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_train((hipStream_t)stream, m, a);
     case FAM_QAT: return qat_uses_s16(m, B) ? qat_s16_launch((hipStream_t)stream, m, a, 0) : (int)ODPD_EUNSUPPORTED;
@@ -331,6 +335,7 @@ inline bool framed_train_ok_shape(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_BOJ) return bojanet_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_APN) return apnrru_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_DVR) return dvrjanet_train_uses_gp(m, B, T);
+    if (family_of(m) == FAM_MCL) return mcldnn_train_uses_gp(m, B, T);
     return false;
 }
 inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
@@ -342,6 +347,7 @@ inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqA
     if (family_of(m) == FAM_BOJ) return framed_train_ok_shape(m, a.B, a.T) ? bojanet_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_APN) return framed_train_ok_shape(m, a.B, a.T) ? apnrru_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_DVR) return framed_train_ok_shape(m, a.B, a.T) ? dvrjanet_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_MCL) return framed_train_ok_shape(m, a.B, a.T) ? mcldnn_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     const bool s16n = gru_uses_s16n(m, a.B), s16 = !s16n && gru_train_uses_s16(m, a.B, a.T);
     if ((s16 || s16n) && !a.ckpt) return ODPD_EINVAL;
     return s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));

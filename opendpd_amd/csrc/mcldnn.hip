@@ -595,6 +595,244 @@ int m16_launch_bwd(hipStream_t st, const SeqArgs& a, int P, int C) {
     return (int)hipGetLastError();
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Fused train kernel for the reference's own batch sizes (train_funcs.py:28-48; a frame gets a CU of its own): ONE sequence per four-wave
+// workgroup.  Wave 0 runs the LSTM(8) recurrences gate-parallel (row k of the wave = gate k — i | f | g | o —, one rotated dot product per
+// step and orientation, gates / h / c / tanh c of the frame parked in LDS, the step's W_hh gradient as one 4-block MFMA); everything that
+// does not depend on h is spread over the 256 threads with thread = time step: the feature table, gates_in = A vec(P) + b of every step,
+// the read-out with loss and dL/dy, and — on the matrix pipe, a quarter of the frame per wave — dA | db = sum_t d_gates(t) (x) [P(t), 1].
+// The prologue composes A, b, W_fc (mcl_compose), the epilogue takes dA, db, dW_hh, dW_fc, db_fc back to the gradients of the
+// convolutions, W_ih, the biases and the two linear layers (m16_param_grad), all four waves at work.  Weight gradients only (the
+// frozen-PA role stays on the S16 kernels).  Taken while the frame's state fits the CU's LDS.
+// -------------------------------------------------------------------------------------------------
+constexpr int kMgpP16 = 17, kMgpP32 = 33;
+struct MgpBuf { int ft, gin, gts, hist, cpk, tpk, dyb, dump, total; };
+__host__ __device__ inline MgpBuf mgp_buf(int T, int C) {
+    MgpBuf b; int o = 0;
+    b.ft = o; o += 5 * (T + kMclHalo) + 3;   // [(T + 4)][5]: row i <-> time i - 4 (the frame's last four samples in front); patch of step t = 25 floats from row t
+    b.gin = o; o += kMgpP32 * T;             // [T][33]: gates_in, gate k at 8 k + unit; overwritten by d_gates in the backward steps
+    b.gts = o; o += kMgpP32 * T;             // the four gates of step t
+    b.hist = o; o += kMgpP16 * (T + 1);      // entry t + 1 = h(t), entry 0 = 0
+    b.cpk = o; o += kMgpP16 * (T + 1);       // c likewise
+    b.tpk = o; o += kMgpP16 * T;             // tanh c(t)
+    b.dyb = o; o += 2 * T + 2;               // float2 [T]
+    b.dump = o; o += 256;
+    const int tail = 4 * kMclRaw + 5 * C * kMclPP + 8;      // the epilogue's [wave][raw] and Gz share the frame buffers
+    b.total = o > tail ? o : tail;
+    return b;
+}
+__global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, role = lane >> 4, cu = col & 7;
+    const MclLayout L = mcl_layout(a.H);
+    const int T = a.T, C = L.C, Z = 5 * C;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    const MclComp K = mcl_comp(pl + pad4(L.P), C);
+    mcl_compose(K, pl, L);
+    float* buf = pl + pad4(L.P) + pad4(mcl_comp_floats(C) + 4);
+    const MgpBuf O = mgp_buf(T, C);
+    float *ft = buf + O.ft, *gin = buf + O.gin, *gts = buf + O.gts, *hist = buf + O.hist, *cpk = buf + O.cpk, *tpk = buf + O.tpk;
+    float2* dyb = reinterpret_cast<float2*>(buf + ((O.dyb + 1) & ~1));
+    float* dump = buf + O.dump;
+    float* loss4 = K.bfc + 2;                               // (four floats of padding after the composed operands)
+    // wave 0: the row's recurrent block W_hh[gate][unit][:] and its transpose, rotated for this lane
+    float wF[16], wT[16];
+    {
+        const int dir = rot_dir(col);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = (col + dir * k) & 15;
+            const bool ok = col < kMclH && m < kMclH;
+            wF[k] = ok ? pl[L.o_whh + (role * kMclH + col) * kMclH + m] : 0.0f;
+            wT[k] = ok ? pl[L.o_whh + (role * kMclH + m) * kMclH + col] : 0.0f;
+        }
+    }
+    const bool vo = col < kMclH, is_g = role == 2;
+    const float wfc0 = vo ? K.wfc[col] : 0.0f, wfc1 = vo ? K.wfc[kMclH + col] : 0.0f;
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
+    const int dmp = (int)(dump - smem) + lane;
+    // per-step stores of the forward pass: every valid lane its own gate; row 1 h, row 2 c, row 3 tanh c
+    const int pg0 = vo ? (int)(gts - smem) + role * kMclH + col : dmp, pg_step = vo ? kMgpP32 : 0;
+    const int ps0 = role == 1 ? (int)(hist - smem) + kMgpP16 + col : role == 2 ? (int)(cpk - smem) + kMgpP16 + col : role == 3 ? (int)(tpk - smem) + col : dmp;
+    const int ps_step = role == 0 ? 0 : kMgpP16;
+    const int dg0 = vo ? (int)(gin - smem) + role * kMclH + col : dmp, dg_step = vo ? kMgpP32 : 0;
+
+    f32x16 acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc1[i] = 0.0f;
+    f32x4 dA[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dA[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dwfc[2][kMclH], dbfc0 = 0.0f, dbfc1 = 0.0f, loss_acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kMclH; ++j) { dwfc[0][j] = 0.0f; dwfc[1][j] = 0.0f; }
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        __syncthreads();
+        // ---- the feature table (circular window: mcldnn.py:115-118) ----
+        for (int i = tid; i < T + kMclHalo; i += 256) {
+            const int t = i - kMclHalo;
+            const float2 xv = xg[t < 0 ? t + T : t];
+            const float a2 = __builtin_fmaf(xv.x, xv.x, xv.y * xv.y), am = __builtin_amdgcn_sqrtf(a2);
+            float* d = ft + 5 * i;
+            d[0] = xv.x; d[1] = xv.y; d[2] = am; d[3] = a2; d[4] = a2 * am;
+        }
+        if (tid < 16) { hist[tid] = 0.0f; cpk[tid] = 0.0f; }
+        __syncthreads();
+        // ---- gates_in of every step; thread = time step ----
+        for (int t = tid; t < T; t += 256) {
+            float pv[kMclP];
+#pragma unroll
+            for (int p = 0; p < kMclP; ++p) pv[p] = ft[5 * t + p];
+            for (int g = 0; g < kMclG; ++g) {
+                const float* ar = K.A + g * kMclPP;
+                float acc = ar[kMclP];
+#pragma unroll
+                for (int p = 0; p < kMclP; ++p) acc = __builtin_fmaf(ar[p], pv[p], acc);
+                gin[t * kMgpP32 + g] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- forward recurrence (wave 0) ----
+        if (wave == 0) {
+            float h = 0.0f, c = 0.0f;
+            int pg = pg0, ps = ps0;
+            for (int t = 0; t < T; ++t) {
+                const float acc = rotdot(gin[t * kMgpP32 + role * kMclH + cu], wF, h);
+                const float sg = sigmoidf_(acc), th = tanhf_(acc);
+                const float v = is_g ? th : sg;
+                float g4[4];
+                gather_rows(v, g4);
+                c = __builtin_fmaf(g4[1], c, g4[0] * g4[2]);
+                const float tc = tanhf_(c);
+                h = g4[3] * tc;
+                smem[pg] = v;
+                smem[ps] = role == 1 ? h : role == 2 ? c : tc;
+                pg += pg_step; ps += ps_step;
+            }
+        }
+        __syncthreads();
+        // ---- read-out, loss and dL/dy of every step; thread = time step ----
+        for (int t = tid; t < T; t += 256) {
+            const float* hv = hist + (t + 1) * kMgpP16;
+            float y0 = K.bfc[0], y1 = K.bfc[1];
+#pragma unroll
+            for (int j = 0; j < kMclH; ++j) { y0 = __builtin_fmaf(K.wfc[j], hv[j], y0); y1 = __builtin_fmaf(K.wfc[kMclH + j], hv[j], y1); }
+            const float2 tv = tg[t];
+            float dy0, dy1;
+            s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+            dbfc0 += dy0; dbfc1 += dy1;
+            dyb[t] = make_float2(dy0, dy1);
+#pragma unroll
+            for (int j = 0; j < kMclH; ++j) { dwfc[0][j] = __builtin_fmaf(dy0, hv[j], dwfc[0][j]); dwfc[1][j] = __builtin_fmaf(dy1, hv[j], dwfc[1][j]); }
+        }
+        __syncthreads();
+        // ---- backward recurrence (wave 0) ----
+        if (wave == 0) {
+            float dh = 0.0f, dc = 0.0f;
+            int dg = dg0 + (T - 1) * dg_step;
+            for (int t = T - 1; t >= 0; --t) {
+                const float* gr = gts + t * kMgpP32 + cu;
+                const float gi = gr[0], gf = gr[kMclH], gg = gr[2 * kMclH], go = gr[3 * kMclH];
+                const float hp = hist[t * kMgpP16 + col], cp = cpk[t * kMgpP16 + col], tc = tpk[t * kMgpP16 + col];
+                const float2 dyv = dyb[t];
+                const float dht = __builtin_fmaf(dyv.y, wfc1, __builtin_fmaf(dyv.x, wfc0, dh));
+                const float dct = __builtin_fmaf(dht * go, __builtin_fmaf(-tc, tc, 1.0f), dc);
+                dc = dct * gf;
+                // the row's own pre-activation gradient: d_i = dc g i (1 - i), d_f = dc c(t-1) f (1 - f), d_g = dc i (1 - g^2), d_o = dh tanh c o (1 - o)
+                const float own = role == 0 ? gi : role == 1 ? gf : role == 2 ? gg : go;
+                const float mul = role == 0 ? gg : role == 1 ? cp : role == 2 ? gi : tc;
+                const float up = (role == 3 ? dht : dct) * mul;
+                const float d_row = vo ? up * (is_g ? __builtin_fmaf(-own, own, 1.0f) : own * (1.0f - own)) : 0.0f;
+                float part = rotdot(0.0f, wT, d_row);
+                part += xor16(part);
+                part += xor32(part);
+                dh = part;
+                smem[dg] = d_row;
+                dg -= dg_step;
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_row, hp, acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        // ---- dA | db: sum over time of d_gates (x) [patch, 1] on the matrix pipe, a quarter of the 4-step slices per wave ----
+        for (int t4 = 4 * wave; t4 < T; t4 += 16) {
+            const int t = t4 + role;
+            const bool ok = t < T;
+            const int tc_ = ok ? t : 0;
+            const float a0 = ok ? gin[tc_ * kMgpP32 + col] : 0.0f, a1 = ok ? gin[tc_ * kMgpP32 + 16 + col] : 0.0f;
+            const float b0 = ok ? ft[5 * tc_ + col] : 0.0f;
+            const float b1 = !ok ? 0.0f : (col < kMclP - 16 ? ft[5 * tc_ + 16 + col] : (col == kMclP - 16 ? 1.0f : 0.0f));
+            dA[0][0] = mfma4(a0, b0, dA[0][0]); dA[0][1] = mfma4(a0, b1, dA[0][1]);
+            dA[1][0] = mfma4(a1, b0, dA[1][0]); dA[1][1] = mfma4(a1, b1, dA[1][1]);
+        }
+    }
+    // ---- epilogue: the waves' raw sums, then the chain rule back to the parameters (as mcl16_bwd_kernel) ----
+    __syncthreads();
+    float* raw = buf;                                       // [wave][kMclRaw], then Gz
+    float* Gz = raw + 4 * kMclRaw;
+    {
+        float* rw = raw + wave * kMclRaw;
+        float* rA = rw; float* rb = rA + kMclG * kMclP; float* rhh = rb + kMclG; float* rfc = rhh + kMclG * kMclH; float* rbf = rfc + 2 * kMclH;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int g = 16 * mt + 4 * role + rr, p = 16 * nt + col;
+                    if (p < kMclP) rA[g * kMclP + p] = dA[mt][nt][rr];
+                    else if (p == kMclP) rb[g] = dA[mt][nt][rr];
+                }
+        // 4-block MFMA: block k = gate k; register 4 k + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int i = 4 * role + rr;
+                if (i < kMclH && col < kMclH) rhh[(k * kMclH + i) * kMclH + col] = wave == 0 ? acc1[4 * k + rr] : 0.0f;
+            }
+        float lp = loss_acc, s0 = dbfc0, s1 = dbfc1;
+        for (int o = 32; o > 0; o >>= 1) { lp += __shfl_xor(lp, o); s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+#pragma unroll
+        for (int j = 0; j < kMclH; ++j) {
+            float v0 = dwfc[0][j], v1 = dwfc[1][j];
+            for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
+            if (lane == 0) { rfc[j] = v0; rfc[kMclH + j] = v1; }
+        }
+        if (lane == 0) { rbf[0] = s0; rbf[1] = s1; loss4[wave] = lp; }
+    }
+    __syncthreads();
+    for (int i = tid; i < kMclRaw; i += 256) raw[i] = (raw[i] + raw[kMclRaw + i]) + (raw[2 * kMclRaw + i] + raw[3 * kMclRaw + i]);
+    __syncthreads();
+    for (int i = tid; i < Z * kMclPP; i += 256) {
+        const int zi = i / kMclPP, pp = i % kMclPP;
+        float acc = 0.0f;
+        for (int g = 0; g < kMclG; ++g) acc = __builtin_fmaf(pl[L.o_wih + g * Z + zi], pp < kMclP ? raw[g * kMclP + pp] : raw[kMclG * kMclP + g], acc);
+        Gz[i] = acc;
+    }
+    __syncthreads();
+    const int P4 = L.P + kLossCols;
+    float* prow = a.partials + (size_t)blockIdx.x * P4;
+    for (int i = tid; i < P4; i += 256)
+        prow[i] = i < L.P ? m16_param_grad(i, raw, Gz, K, pl, L) : (i == L.P ? (loss4[0] + loss4[1]) + (loss4[2] + loss4[3]) : 0.0f);
+}
+
+static size_t mcl_gp_lds_bytes(int C, int T) {
+    return ((size_t)pad4(mcl_layout(C).P) + pad4(mcl_comp_floats(C) + 4) + mgp_buf(T, C).total) * sizeof(float);
+}
+static int mcl_gp_blocks_per_cu(int C, int T) {
+    const size_t lds = mcl_gp_lds_bytes(C, T);
+    const int n = lds > kMaxLds ? 0 : (int)(kMaxLds / lds);
+    return n < 2 ? n : 2;
+}
+
 }  // namespace
 
 bool mcldnn_ok(const odpd_model_t* m) { return m->hidden >= 1 && m->hidden <= kMclMaxC; }
@@ -608,6 +846,25 @@ int mcldnn_rows(const odpd_model_t* m, int B) {
 int64_t mcldnn_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!mcldnn_ok(m)) return ODPD_EUNSUPPORTED;
     return (int64_t)((B + 15) / 16) * num_ckpt(T) * 2 * 256;
+}
+// the fused train kernel of the reference's batch sizes: one sequence per four-wave workgroup, the frame's state in LDS
+bool mcldnn_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    if (!mcldnn_ok(m) || T < kMclHalo) return false;
+    const int per_cu = mcl_gp_blocks_per_cu(m->hidden, T);
+    const long max_batch = tuning().gp_max_batch;
+    if (max_batch >= 0) return B <= max_batch && per_cu > 0;
+    // up to four rounds of workgroups (measured: profiles/r03/gp_train_bench_f4.txt): the alternative is the forward / loss / backward chain of the S16 kernels
+    return (long)B <= 4L * device_cus() * per_cu;
+}
+int mcldnn_gp_rows(const odpd_model_t* m, int B, int T) {
+    const long cap = (long)device_cus() * mcl_gp_blocks_per_cu(m->hidden, T);
+    return B < cap ? B : (int)cap;
+}
+int mcldnn_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    const size_t lds = mcl_gp_lds_bytes(m->hidden, a.T);
+    if (int e = allow_big_lds(mcl_gp_train_kernel, lds)) return e;
+    hipLaunchKernelGGL(mcl_gp_train_kernel, dim3(mcldnn_gp_rows(m, a.B, a.T)), dim3(256), lds, st, a);
+    return (int)hipGetLastError();
 }
 // mode 1 forward, 2 backward
 int mcldnn_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int mode) {

@@ -111,6 +111,9 @@ __device__ __forceinline__ float across_seqs(float v) {
 }
 
 // ---- rotated dot products ----------------------------------------------------------------------
+// The accumulators of these multi-instruction groups are EARLY-CLOBBER operands ("+&v"): without it the register allocator may give an
+// input that holds the same value at entry (a weight the compiler proved to be the constant 0 and an accumulator that starts at 0) the
+// accumulator's own register, and a later instruction of the group then reads the running sum as its weight.
 // hipcc (ROCm 7.2) folds v_mov_dpp into v_add/v_mul but not into v_fmac, so the DPP FMAs are
 // written as inline asm.  The compiler does not model hazards inside asm: a DPP read of a VGPR
 // written by the previous VALU needs 2 wait states (gfx9 hazard table), hence every asm group
@@ -122,7 +125,7 @@ __device__ __forceinline__ float across_seqs(float v) {
 #define ODPD_ROT3_GROUP(K1, K2, K3, K4, K5)                                                        \
     asm("s_nop 1\n\t" ODPD_F3(K1, 4, 5, 6) ODPD_F3(K2, 7, 8, 9) ODPD_F3(K3, 10, 11, 12)            \
             ODPD_F3(K4, 13, 14, 15) ODPD_F3(K5, 16, 17, 18)                                        \
-        : "+v"(a0), "+v"(a1), "+v"(a2)                                                             \
+        : "+&v"(a0), "+&v"(a1), "+&v"(a2)                                                             \
         : "v"(h), "v"(w0[K1]), "v"(w1[K1]), "v"(w2[K1]), "v"(w0[K2]), "v"(w1[K2]), "v"(w2[K2]),    \
           "v"(w0[K3]), "v"(w1[K3]), "v"(w2[K3]), "v"(w0[K4]), "v"(w1[K4]), "v"(w2[K4]),            \
           "v"(w0[K5]), "v"(w1[K5]), "v"(w2[K5]))
@@ -156,7 +159,7 @@ __device__ __forceinline__ float rotdot(float acc, const float (&w)[16], float h
         ODPD_DPPF(1, 2, 7, 5) ODPD_DPPF(0, 2, 8, 6) ODPD_DPPF(1, 2, 9, 7) ODPD_DPPF(0, 2, 10, 8)
         ODPD_DPPF(1, 2, 11, 9) ODPD_DPPF(0, 2, 12, 10) ODPD_DPPF(1, 2, 13, 11) ODPD_DPPF(0, 2, 14, 12)
         ODPD_DPPF(1, 2, 15, 13) ODPD_DPPF(0, 2, 16, 14) ODPD_DPPF(1, 2, 17, 15)
-        : "+v"(a0), "+v"(a1)
+        : "+&v"(a0), "+&v"(a1)
         : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]),
           "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
 #else
@@ -176,7 +179,7 @@ __device__ __forceinline__ float rotdot8(float acc, const float (&w)[16], float 
     asm("s_nop 1\n\t"
         ODPD_DPPF(1, 2, 3, 1) ODPD_DPPF(0, 2, 4, 2) ODPD_DPPF(1, 2, 5, 3) ODPD_DPPF(0, 2, 6, 4)
         ODPD_DPPF(1, 2, 7, 5) ODPD_DPPF(0, 2, 8, 6) ODPD_DPPF(1, 2, 9, 7)
-        : "+v"(a0), "+v"(a1)
+        : "+&v"(a0), "+&v"(a1)
         : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
 #else
 #define ODPD_R1(K, A) A = __builtin_fmaf(w[K], dpp_ror<K>(h), A);
@@ -191,7 +194,7 @@ __device__ __forceinline__ float rotdot8(float acc, const float (&w)[16], float 
 #define ODPD_ROTQ_GROUP(K0, K1, K2, K3, Q)                                                          \
     asm("s_nop 1\n\t" ODPD_DPPF(0, 2, 3, K0) ODPD_DPPF(1, 2, 4, K1) ODPD_DPPF(0, 2, 5, K2)          \
             ODPD_DPPF(1, 2, 6, K3)                                                                  \
-        : "+v"(a0), "+v"(a1) : "v"(h), "v"(Q.x), "v"(Q.y), "v"(Q.z), "v"(Q.w))
+        : "+&v"(a0), "+&v"(a1) : "v"(h), "v"(Q.x), "v"(Q.y), "v"(Q.z), "v"(Q.w))
 template <typename QuadSrc>
 __device__ __forceinline__ float rotdot_quads(float acc, QuadSrc quad, float h) {
     float a0, a1;
@@ -201,7 +204,7 @@ __device__ __forceinline__ float rotdot_quads(float acc, QuadSrc quad, float h) 
         a1 = 0.0f;
 #if ODPD_DPP_ASM
         asm("s_nop 1\n\t" ODPD_DPPF(1, 2, 3, 1) ODPD_DPPF(0, 2, 4, 2) ODPD_DPPF(1, 2, 5, 3)
-            : "+v"(a0), "+v"(a1) : "v"(h), "v"(q.y), "v"(q.z), "v"(q.w));
+            : "+&v"(a0), "+&v"(a1) : "v"(h), "v"(q.y), "v"(q.z), "v"(q.w));
 #else
         a1 = __builtin_fmaf(q.y, dpp_ror<1>(h), a1);
         a0 = __builtin_fmaf(q.z, dpp_ror<2>(h), a0);
@@ -228,7 +231,7 @@ __device__ __forceinline__ float rotdot_quads(float acc, QuadSrc quad, float h) 
 #define ODPD_ROT3X_GROUP(K1, K2, K3, K4, K5)                                                       \
     asm("s_nop 1\n\t" ODPD_F3X(K1, 6, 7, 8) ODPD_F3X(K2, 9, 10, 11) ODPD_F3X(K3, 12, 13, 14)       \
             ODPD_F3X(K4, 15, 16, 17) ODPD_F3X(K5, 18, 19, 20)                                      \
-        : "+v"(a0), "+v"(a1), "+v"(a2)                                                             \
+        : "+&v"(a0), "+&v"(a1), "+&v"(a2)                                                             \
         : "v"(h0), "v"(h1), "v"(h2), "v"(w0[K1]), "v"(w1[K1]), "v"(w2[K1]), "v"(w0[K2]),           \
           "v"(w1[K2]), "v"(w2[K2]), "v"(w0[K3]), "v"(w1[K3]), "v"(w2[K3]), "v"(w0[K4]),            \
           "v"(w1[K4]), "v"(w2[K4]), "v"(w0[K5]), "v"(w1[K5]), "v"(w2[K5]))

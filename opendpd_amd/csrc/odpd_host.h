@@ -255,6 +255,9 @@ int mcldnn_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mo
 int mcldnn_rows(const odpd_model_t* m, int B);
 int64_t mcldnn_param_count(const odpd_model_t* m);
 int64_t mcldnn_ckpt_floats(const odpd_model_t* m, int B, int T);
+bool mcldnn_train_uses_gp(const odpd_model_t* m, int B, int T);       // (as bojanet's; one sequence per four-wave workgroup)
+int mcldnn_gp_rows(const odpd_model_t* m, int B, int T);
+int mcldnn_gp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // apnrru_s16.hip (hidden <= 14): mode 1 forward, 2 backward
 int apnrru_launch(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int mode);
 int apnrru_rows(const odpd_model_t* m, int B);

@@ -100,6 +100,67 @@ def test_against_oracle_ragged(C, B, T):
     assert rel_err(xt2.grad.cpu().numpy(), dxo) < GRAD_TOL
 
 
+@pytest.mark.parametrize("C", [1, 2, 3, 5, 8, 11, 16])
+@pytest.mark.parametrize("B,T", [(1, 4), (3, 5), (7, 63), (5, 64), (2, 65), (64, 50), (9, 200), (300, 200), (5, 130), (3, 260)])
+def test_gate_parallel_train_kernel(C, B, T):
+    """the reference's own batch sizes run mcl_gp_train_kernel (one sequence per four-wave workgroup: wave 0 the LSTM(8) recurrences gate-
+    parallel, the feature table, gates_in, the read-out and dA | db over all 256 threads, composition / chain rule as the S16 kernels): loss
+    and gradient — every tensor on its own scale — against the oracle (L2 and L1), and against the split S16 chain (gp_max_batch = 0)"""
+    import ctypes as C_
+    from opendpd_amd import _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    lib = _lib.load()
+    torch.manual_seed(C * 100 + B + T)
+    net = _net(C)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    rng = np.random.RandomState(B * 13 + T)
+    x = _iq(rng, B, T)
+    tgt = (0.4 * rng.randn(B, T, 2)).astype(np.float32)
+    xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    o, m = Oracle("f32"), make_model("mcldnn", C)
+    yo, _ = o.forward(m, p, x)
+    offs = np.cumsum([0] + [q.numel() for q in net.parameters()])
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.has_fused(B, T)
+    try:
+        for kind in ("l2", "l1"):
+            d = yo - tgt
+            lo = float((d * d).mean()) if kind == "l2" else float(np.abs(d).mean())
+            dy = (2 * d / d.size if kind == "l2" else np.sign(d) / d.size).astype(np.float32)
+            go, _ = o.backward(m, p, x, dy, need_dx=False)
+            loss = fused_train_step(opt, xt, tt, kind, 0.0)
+            got = opt.grad[:-4].cpu().numpy().copy()
+            assert abs(float(loss) - lo) < 2e-5 * max(1.0, lo)
+            for (k, _), a, b in zip(net.named_parameters(), offs[:-1], offs[1:]):
+                assert rel_err(got[a:b], go[a:b]) < GRAD_TOL, k
+            lib.odpd_set_tuning(b"gp_max_batch", C_.c_int64(0))
+            opt2 = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+            assert not opt2.has_fused(B, T)
+            for q in net.parameters():
+                q.grad = None
+            y = net(xt)
+            l2 = torch.nn.functional.mse_loss(y, tt) if kind == "l2" else torch.nn.functional.l1_loss(y, tt)
+            l2.backward()
+            gs = torch.cat([q.grad.reshape(-1) for q in net.parameters()]).cpu().numpy()
+            assert abs(float(loss) - l2.item()) < 1e-5 * max(1.0, lo) and rel_err(got, gs) < 1e-4
+            lib.odpd_set_tuning(b"gp_max_batch", C_.c_int64(-1))
+    finally:
+        lib.odpd_set_tuning(b"gp_max_batch", C_.c_int64(-1))
+
+
+def test_gate_parallel_envelope():
+    """frames whose state does not fit a CU's LDS, and batches past a few rounds of workgroups, stay on the split S16 chain"""
+    from opendpd_amd.train_funcs import FusedAdamW
+    opt = FusedAdamW(_net(8), lr=0.0)
+    assert opt.has_fused(256, 200) and opt.has_fused(64, 50)
+    assert not opt.has_fused(4, 400) and not opt.has_fused(20000, 50)
+
+
 def test_large_batch_every_wave_slot():
     from oracle.oracle import Oracle, make_model
     torch.manual_seed(5)

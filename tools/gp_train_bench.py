@@ -41,7 +41,7 @@ def step_ms(bb, H, B, T, gp_max_batch):
 
 
 CASES = (("gru", 11), ("dgru", 13), ("dgru", 23), ("gru", 23), ("qgru", 10), ("qgru_amp1", 16), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11), ("deltagru", 15), ("deltagru_tcnskip", 15),
-         ("deltajanet", 15), ("bojanet", 12), ("apnrru", 8), ("dvrjanet", 12))
+         ("deltajanet", 15), ("bojanet", 12), ("apnrru", 8), ("dvrjanet", 12), ("mcldnn", 8))
 if len(sys.argv) > 1:       # e.g. bojanet:12
     CASES = tuple((s.split(":")[0], int(s.split(":")[1])) for s in sys.argv[1:])
 for bb, H in CASES:
