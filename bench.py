@@ -306,9 +306,9 @@ def main():
         xm = xs_.unfold(0, T, 1)[:args.ref_batch].permute(0, 2, 1).contiguous()
         tm = ys_.unfold(0, T, 1)[:args.ref_batch].permute(0, 2, 1).contiguous()
         steps_ = {}
-        for bb_, h_ in (("gru", 11), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11)):
+        for bb_, h_ in (("gru", 11), ("lstm", 14), ("vdlstm", 13), ("pgjanet", 11), ("deltajanet", 15), ("bojanet", 12), ("apnrru", 8), ("dvrjanet", 12), ("mcldnn", 8)):
             torch.manual_seed(2)
-            opt_ = FusedAdamW(CoreModel(2, h_, 1, bb_).to(dev), lr=5e-4)
+            opt_ = FusedAdamW(CoreModel(2, h_, 1, bb_, **({"num_dvr_units": 3} if bb_ == "dvrjanet" else {})).to(dev), lr=5e-4)
             el_ = min(run_steps(opt_, xm, tm, 50, args.warmup, args.ref_batch * T * 2, None)[0] for _ in range(3))   # best of three: a one-off stall is 50 steps' worth here
             steps_[f"{bb_} H{h_}"] = {"ms_per_step": 1e3 * el_ / 50, "value": args.ref_batch * T * 50 / el_}
         ref_shapes["train_step"] = {"batch_per_gpu": args.ref_batch, "frame_length": T, "unit": "IQ samples/s", "backbones": steps_}

@@ -821,6 +821,118 @@ __global__ __launch_bounds__(64) void apn_gp_train_kernel(SeqArgs a) {
     }
 }
 
+// Evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): ONE sequence per wave, the forward half of
+// apn_gp_train_kernel in chunks of kAevChunk steps; no checkpoints.
+constexpr int kAevChunk = 256;
+constexpr int kAevFloats = 2 * (kAevChunk + 16) + 2 * kAevChunk + kAgpP16 * kAevChunk + kAgpP32 * kAevChunk + 64;
+__global__ __launch_bounds__(64) void apn_gp_eval_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int Tc = kAevChunk;
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4, tile = role & 1;
+    const ApnLayout L = apn_layout(a.H);
+    const int H = L.H, n = L.n, T = a.T, WU = 8 + n;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* buf = smem + pad4(L.P);
+    float2* xw = reinterpret_cast<float2*>(buf);                    // [16 + Tc]: index i <-> time t0 - 16 + i
+    float2* rt = xw + Tc + 16;                                       // (rr, ri) of step tt
+    float* au = reinterpret_cast<float*>(rt + Tc);                   // [Tc][17]
+    float* hh = au + kAgpP16 * Tc;                                   // [Tc][33]: h_I | h_Q after step tt
+    float* dump = hh + kAgpP32 * Tc;
+    float wU[16], wH[16];
+    const int unit = apn_unit(H, tile, col);
+    {
+        const int dir = rot_dir(col);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = (col + dir * k) & 15, um = apn_unit(H, tile, m);
+            wU[k] = um >= 0 ? pl[L.o_wu + col * WU + 8 + um] : 0.0f;
+            wH[k] = unit >= 0 ? pl[L.o_wh + unit * kApnNode + m] : 0.0f;
+        }
+    }
+    const bool is_h = col < H, live_slot = unit >= 0;
+    const float Cc = pl[L.o_c], zz = live_slot ? pl[L.o_z + unit] : 0.0f, bh = live_slot ? pl[L.o_bh + unit] : 0.0f;
+    const int pk0 = role >= 2 ? (int)(hh - smem) + tile * 16 + col : (int)(dump - smem) + lane, pk_step = role >= 2 ? kAgpP32 : 0;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
+        float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * T;
+        float hI = 0.0f, hQ = 0.0f, hA = 0.0f;
+        for (int t0 = 0; t0 < T; t0 += Tc) {
+            const int len = min(Tc, T - t0);
+            wave_lds_fence();
+            for (int i = lane; i < len + 16; i += 64) {
+                const int t = t0 - 16 + i;
+                xw[i] = t >= 0 ? xg[t] : make_float2(0.0f, 0.0f);
+            }
+            wave_lds_fence();
+            for (int tt = lane; tt < len; tt += 64) {
+                const float2 x0 = xw[16 + tt];
+                const float mag = sqrtf(x0.x * x0.x + x0.y * x0.y), rr = x0.x / mag, ri = -x0.y / mag;
+                float fi[4], fq[4];
+#pragma unroll
+                for (int q = 0; q < kApnF; ++q) { fi[q] = 0.0f; fq[q] = 0.0f; }
+#pragma unroll
+                for (int m = 0; m < kApnM; ++m) {
+                    const float2 xv = xw[tt + 1 + m];
+#pragma unroll
+                    for (int q = 0; q < kApnF; ++q) {
+                        const float bi = pl[L.o_bi + q * kApnM + m], bq = pl[L.o_bq + q * kApnM + m];
+                        fi[q] += bi * xv.x - bq * xv.y;
+                        fq[q] += bq * xv.x + bi * xv.y;
+                    }
+                }
+                fi[3] = x0.x; fq[3] = x0.y;
+                float feat[8];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    feat[2 * k4] = rr * fi[k4] - ri * fq[k4];
+                    feat[2 * k4 + 1] = ri * fi[k4] + rr * fq[k4];
+                }
+                rt[tt] = make_float2(rr, ri);
+                for (int o = 0; o < kApnNode; ++o) {
+                    float acc = pl[L.o_bu + o];
+#pragma unroll
+                    for (int k8 = 0; k8 < 8; ++k8) acc = __builtin_fmaf(pl[L.o_wu + o * WU + k8], feat[k8], acc);
+                    au[tt * kAgpP16 + o] = acc;
+                }
+            }
+            wave_lds_fence();
+            {
+                int pk = pk0;
+                for (int tt = 0; tt < len; ++tt) {
+                    const float2 r = rt[tt];
+                    const float rot = tile == 0 ? __builtin_fmaf(hI, r.x, -(hQ * r.y)) : __builtin_fmaf(hI, r.y, hQ * r.x);
+                    const float sp = is_h ? rot : hA;
+                    float p1 = rotdot(0.0f, wU, sp);
+                    p1 += xor16(p1);
+                    const float v1 = tanhf_(p1 + au[tt * kAgpP16 + col]);
+                    const float v = tanhf_(rotdot(bh, wH, v1));
+                    const float sn = live_slot ? sigmoidf_(Cc * sp) + zz * v : 0.0f;
+                    const float osn = xor16(sn);
+                    const float snI = tile == 0 ? sn : osn, snQ = tile == 0 ? osn : sn;
+                    hI = __builtin_fmaf(snI, r.x, snQ * r.y);
+                    hQ = __builtin_fmaf(snQ, r.x, -(snI * r.y));
+                    hA = sn;
+                    smem[pk] = tile == 0 ? hI : hQ;
+                    pk += pk_step;
+                }
+            }
+            wave_lds_fence();
+            for (int tt = lane; tt < len; tt += 64) {
+                const float* hv = hh + tt * kAgpP32;
+                float y0 = 0.0f, y1 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 14; ++j)
+                    if (j < H) {
+                        y0 = __builtin_fmaf(pl[L.o_woi + j], hv[j], y0);
+                        y1 = __builtin_fmaf(pl[L.o_woq + j], hv[16 + j], y1);
+                    }
+                yg[t0 + tt] = make_float2(y0 - y1, y1 + y0);
+            }
+        }
+    }
+}
+
 static size_t apn_gp_lds_bytes(int P, int T) { return ((size_t)pad4(P) + agp_buf(T).total) * sizeof(float); }
 static int apn_gp_blocks_per_cu(int P, int T) {
     const size_t lds = apn_gp_lds_bytes(P, T);
@@ -868,6 +980,13 @@ int apnrru_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int 
     SeqArgs a = a0;
     a.ngroups = (a.B + 15) / 16;
     const int P = apn_layout(m->hidden).P;
+    if (mode == 1 && !a.ckpt && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0 && tuning().gp_max_batch != 0) {
+        // sequences that each get a SIMD of their own (inference: no checkpoints)
+        const size_t lds = ((size_t)pad4(P) + kAevFloats) * sizeof(float);
+        if (int e = allow_big_lds(apn_gp_eval_kernel, lds)) return e;
+        hipLaunchKernelGGL(apn_gp_eval_kernel, dim3(a.B), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    }
     if (mode == 1) {
         const LaunchShape ls = a16_shape(a.ngroups, a.ngroups <= 4 * device_cus() ? 4 : 8);
         const size_t lds = ((size_t)pad4(P) + s16_tab_floats(A16::NG) + (size_t)ls.waves * (2 * 16 * kApnRow + 2 * 16 * kChunkPad)) * sizeof(float);

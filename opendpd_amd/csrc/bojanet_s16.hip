@@ -754,6 +754,119 @@ __global__ __launch_bounds__(64) void boj_gp_train_kernel(SeqArgs a) {
     }
 }
 
+// Evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): ONE sequence per wave, the forward half of
+// boj_gp_train_kernel in chunks of kBevChunk steps (front with lane = time step, the recurrence, the read-outs with lane = time step); no checkpoints.
+constexpr int kBevChunk = 256;
+constexpr int kBevFloats = 2 * (kBevChunk + 16) + 12 * kBevChunk + kBgpP32 * kBevChunk + kBgpP16 * (kBevChunk + 1) + 64;
+__global__ __launch_bounds__(64) void boj_gp_eval_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int Tc = kBevChunk;
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;
+    const BojLayout L = boj_layout(a.H);
+    const int H = L.H, T = a.T;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float* buf = smem + pad4(L.P);
+    float2* xw = reinterpret_cast<float2*>(buf);                    // [16 + Tc]: index i <-> time t0 - 16 + i
+    float* fiq = buf + 2 * (Tc + 16);                                // [12][Tc]
+    float* xs = fiq + 12 * Tc;                                       // [Tc][33]
+    float* hist = xs + kBgpP32 * Tc;                                 // [Tc + 1][17]: entry tt + 1 = h(t0 + tt)
+    float* dump = hist + kBgpP16 * (Tc + 1);
+    float wF[16];
+    {
+        const int dir = rot_dir(col), ow = (role & 1) ? L.o_wgh : L.o_wfh;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = (col + dir * k) & 15;
+            wF[k] = (col < H && m < H) ? pl[ow + col * H + m] : 0.0f;
+        }
+    }
+    const bool is_f = (role & 1) == 0;
+    const int xoff = (role & 1) * 16 + col;
+    const int pk0 = role == 0 ? (int)(hist - smem) + kBgpP16 + col : (int)(dump - smem) + lane, pk_step = role == 0 ? kBgpP16 : 0;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
+        float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * T;
+        float h = 0.0f;
+        for (int t0 = 0; t0 < T; t0 += Tc) {
+            const int len = min(Tc, T - t0);
+            wave_lds_fence();
+            for (int i = lane; i < len + 16; i += 64) {
+                const int t = t0 - 16 + i;
+                xw[i] = t >= 0 ? xg[t] : make_float2(0.0f, 0.0f);
+            }
+            wave_lds_fence();
+            for (int tt = lane; tt < len; tt += 64) {
+                float fi[kBojP], fq[kBojP];
+#pragma unroll
+                for (int p = 0; p < kBojP; ++p) { fi[p] = 0.0f; fq[p] = 0.0f; }
+#pragma unroll
+                for (int m = 0; m < kBojM; ++m) {
+                    const float2 xv = xw[tt + 1 + m];
+#pragma unroll
+                    for (int p = 0; p < kBojP; ++p) {
+                        const float bi = pl[L.o_bi + p * kBojM + m], bq = pl[L.o_bq + p * kBojM + m];
+                        fi[p] += bi * xv.x - bq * xv.y;
+                        fq[p] += bq * xv.x + bi * xv.y;
+                    }
+                }
+                float e[2 * kBojP];
+#pragma unroll
+                for (int p = 0; p < kBojP; ++p) {
+                    const float mag = sqrtf(fi[p] * fi[p] + fq[p] * fq[p]) + 1e-8f;
+                    e[p] = mag; e[kBojP + p] = mag * mag;
+                    fiq[p * Tc + tt] = fi[p]; fiq[(kBojP + p) * Tc + tt] = fq[p];
+                }
+                for (int u = 0; u < 16; ++u) {
+                    float pf = 0.0f, pg = 0.0f;
+                    if (u < H) {
+                        pf = pl[L.o_bfi + u]; pg = pl[L.o_bgi + u];
+#pragma unroll
+                        for (int k = 0; k < 2 * kBojP; ++k) {
+                            pf = __builtin_fmaf(pl[L.o_wfi + u * 2 * kBojP + k], e[k], pf);
+                            pg = __builtin_fmaf(pl[L.o_wgi + u * 2 * kBojP + k], e[k], pg);
+                        }
+                    }
+                    xs[tt * kBgpP32 + u] = pf;
+                    xs[tt * kBgpP32 + 16 + u] = pg;
+                }
+            }
+            wave_lds_fence();
+            {
+                int pk = pk0;
+                for (int tt = 0; tt < len; ++tt) {
+                    const float acc = rotdot(xs[tt * kBgpP32 + xoff], wF, h);
+                    const float sg = sigmoidf_(acc), th = tanhf_(acc);
+                    const float v = is_f ? sg : th, o = xor16(v);
+                    const float f = is_f ? v : o, g = is_f ? o : v;
+                    h = __builtin_fmaf(f, h - g, g);
+                    smem[pk] = h;
+                    pk += pk_step;
+                }
+            }
+            wave_lds_fence();
+            for (int tt = lane; tt < len; tt += 64) {
+                float co[kBojP], si[kBojP];
+#pragma unroll
+                for (int p = 0; p < kBojP; ++p) {
+                    const float fi = fiq[p * Tc + tt], fq = fiq[(kBojP + p) * Tc + tt];
+                    const float mag = sqrtf(fi * fi + fq * fq) + 1e-8f;
+                    co[p] = fi / mag; si[p] = fq / mag;
+                }
+                const float* hv = hist + (tt + 1) * kBgpP16;
+                float A = pl[L.o_boi], Bq = pl[L.o_boq];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < H) {
+                        A = __builtin_fmaf(pl[L.o_woi + j], hv[j] * co[j % kBojP], A);
+                        Bq = __builtin_fmaf(pl[L.o_woq + j], hv[j] * si[j % kBojP], Bq);
+                    }
+                yg[t0 + tt] = make_float2(A - Bq, Bq + A);
+            }
+        }
+    }
+}
+
 static size_t boj_gp_lds_bytes(int P, int T) { return ((size_t)pad4(P) + bgp_buf(T).total) * sizeof(float); }
 static int boj_gp_blocks_per_cu(int P, int T) {
     const size_t lds = boj_gp_lds_bytes(P, T);
@@ -801,6 +914,13 @@ int bojanet_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int
     SeqArgs a = a0;
     a.ngroups = (a.B + 15) / 16;
     const int P = boj_layout(m->hidden).P;
+    if (mode == 1 && !a.ckpt && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0 && tuning().gp_max_batch != 0) {
+        // sequences that each get a SIMD of their own (inference: no checkpoints)
+        const size_t lds = ((size_t)pad4(P) + kBevFloats) * sizeof(float);
+        if (int e = allow_big_lds(boj_gp_eval_kernel, lds)) return e;
+        hipLaunchKernelGGL(boj_gp_eval_kernel, dim3(a.B), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    }
     if (mode == 1) {
         const LaunchShape ls = b16_shape(a.ngroups, a.ngroups <= 4 * device_cus() ? 4 : 8);
         const size_t lds = ((size_t)pad4(P) + s16_tab_floats(B16::NG) + (size_t)ls.waves * (2 * 16 * kBojRow + 2 * 16 * kChunkPad)) * sizeof(float);

@@ -684,6 +684,96 @@ __global__ __launch_bounds__(64) void dvr_gp_train_kernel(SeqArgs a, int K, DvrK
         }
 }
 
+// Evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): ONE sequence per wave, the forward half of
+// dvr_gp_train_kernel in chunks of kVevChunk steps; no checkpoints.
+constexpr int kVevChunk = 256, kVevPitch = 33;
+constexpr int kVevFloats = 2 * kVevChunk + kVevPitch * kVevChunk + 64;
+__global__ __launch_bounds__(64) void dvr_gp_eval_kernel(SeqArgs a, int K, DvrKnots kn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int Tc = kVevChunk;
+    const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;
+    const DvrLayout L = dvr_layout(a.H, K);
+    const int H = L.H, T = a.T;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    float2* mt = reinterpret_cast<float2*>(smem + pad4(L.P));       // (|x|, theta) of step tt
+    float* hh = reinterpret_cast<float*>(mt + Tc);                   // [Tc][33]: h_I | h_Q after step tt
+    float* dump = hh + kVevPitch * Tc;
+    V16Uni U;
+    U.load(pl, L, kn);
+    float wA[16], wB[16];
+    {
+        const int dir = rot_dir(col);
+        const int oa = role == 0 ? L.o_wph : role == 1 ? L.o_wah : L.o_wf;
+        const int ob = (role < 2 ? L.o_wcc : L.o_wcs) + (role & 1) * H;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = (col + dir * k) & 15;
+            const bool ok = col < H && m < H;
+            wA[k] = (ok && role < 3) ? pl[oa + col * H + m] : 0.0f;
+            wB[k] = ok ? pl[ob + col * 2 * H + m] : 0.0f;
+        }
+    }
+    const bool vo = col < H;
+    const float sA = vo ? (role == 0 ? pl[L.o_wpt + col] : role == 1 ? pl[L.o_wax + col] : 0.0f) : 0.0f;
+    const float bA = (vo && role == 2) ? pl[L.o_bf + col] : 0.0f;
+    const float bB = vo ? pl[(role < 2 ? L.o_bcc : L.o_bcs) + col] : 0.0f;
+    const RowMasks rm = row_masks();
+    const int pk0 = role < 2 ? (int)(hh - smem) + role * 16 + col : (int)(dump - smem) + lane, pk_step = role < 2 ? kVevPitch : 0;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
+        float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * T;
+        float hI = 0.0f, hQ = 0.0f;
+        for (int t0 = 0; t0 < T; t0 += Tc) {
+            const int len = min(Tc, T - t0);
+            wave_lds_fence();
+            for (int tt = lane; tt < len; tt += 64) {
+                float mag, theta;
+                v16_inputs(xg[t0 + tt], mag, theta);
+                mt[tt] = make_float2(mag, theta);
+            }
+            wave_lds_fence();
+            {
+                int pk = pk0;
+                for (int tt = 0; tt < len; ++tt) {
+                    const float2 in = mt[tt];
+                    const float pa = rotdot(0.0f, wA, hI + hQ);
+                    const float own = __builtin_fmaf(sA, vsel(rm.m[0], in.y, in.x), pa) + bA;
+                    float g4[4];
+                    gather_rows(vsel(rm.m[2], sigmoidf_(own), own), g4);
+                    const float th = g4[0], ap = g4[1], f = g4[2];
+                    float at = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < kDvrMaxK; ++k) at = __builtin_fmaf(__builtin_fabsf(ap - U.knot[k]), U.cs[k], at);
+                    float si, co;
+                    v16_sincos(th, si, co);
+                    const float opnd = vsel(rm.m[0], hI, vsel(rm.m[1], at * co, vsel(rm.m[2], hQ, at * si)));
+                    float pb = rotdot(0.0f, wB, opnd);
+                    pb += xor16(pb);
+                    const float gv = tanhf_(pb + bB), ogv = xor32(gv);
+                    const float gc = vsel(rm.m[0] | rm.m[1], gv, ogv), gs = vsel(rm.m[0] | rm.m[1], ogv, gv);
+                    hI = __builtin_fmaf(f, hI - gc, gc);
+                    hQ = __builtin_fmaf(f, hQ - gs, gs);
+                    smem[pk] = vsel(rm.m[0], hI, hQ);
+                    pk += pk_step;
+                }
+            }
+            wave_lds_fence();
+            for (int tt = lane; tt < len; tt += 64) {
+                const float* hv = hh + tt * kVevPitch;
+                float y0 = U.bo1, y1 = U.bo2;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < H) {
+                        y0 = __builtin_fmaf(pl[L.o_wo1 + j], hv[j], y0);
+                        y1 = __builtin_fmaf(pl[L.o_wo2 + j], hv[16 + j], y1);
+                    }
+                yg[t0 + tt] = make_float2(y0, y1);
+            }
+        }
+    }
+}
+
 static size_t dvr_gp_lds_bytes(int P, int T) { return ((size_t)pad4(P) + vgp_buffer_floats(T)) * sizeof(float); }
 static int dvr_gp_blocks_per_cu(int P, int T) {
     const size_t lds = dvr_gp_lds_bytes(P, T);
@@ -731,6 +821,13 @@ int dvrjanet_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, in
     SeqArgs a = a0;
     a.ngroups = (a.B + 15) / 16;
     const int K = m->bits_w, P = dvr_layout(m->hidden, K).P;
+    if (mode == 1 && !a.ckpt && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0 && tuning().gp_max_batch != 0) {
+        // sequences that each get a SIMD of their own (inference: no checkpoints)
+        const size_t lds = ((size_t)pad4(P) + kVevFloats) * sizeof(float);
+        if (int e = allow_big_lds(dvr_gp_eval_kernel, lds)) return e;
+        hipLaunchKernelGGL(dvr_gp_eval_kernel, dim3(a.B), dim3(64), lds, st, a, K, dvr_knots(K));
+        return (int)hipGetLastError();
+    }
     if (mode == 1) {
         const LaunchShape ls = v16_shape(a.ngroups, a.ngroups <= 4 * device_cus() ? 4 : 8);
         const size_t lds = ((size_t)pad4(P) + s16_tab_floats(V16::NG) + (size_t)ls.waves * (2 * 2 * 16 * kChunkPad)) * sizeof(float);

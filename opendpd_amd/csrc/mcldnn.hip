@@ -824,6 +824,89 @@ __global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
         prow[i] = i < L.P ? m16_param_grad(i, raw, Gz, K, pl, L) : (i == L.P ? (loss4[0] + loss4[1]) + (loss4[2] + loss4[3]) : 0.0f);
 }
 
+// Evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): ONE sequence per four-wave workgroup, the forward
+// half of mcl_gp_train_kernel in chunks of kMevChunk steps (feature table, gates_in and the read-out with thread = time step, the recurrence on wave 0);
+// no checkpoints.
+constexpr int kMevChunk = 256;
+constexpr int kMevFloats = 5 * (kMevChunk + kMclHalo) + 3 + kMgpP32 * kMevChunk + kMgpP16 * kMevChunk + 64;
+__global__ __launch_bounds__(256) void mcl_gp_eval_kernel(SeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int Tc = kMevChunk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, role = lane >> 4, cu = col & 7;
+    const MclLayout L = mcl_layout(a.H);
+    const int T = a.T, C = L.C;
+    float* pl = smem;
+    stage_params(pl, a.params, L.P);
+    const MclComp K = mcl_comp(pl + pad4(L.P), C);
+    mcl_compose(K, pl, L);
+    float* ft = pl + pad4(L.P) + pad4(mcl_comp_floats(C) + 4);     // [(Tc + 4)][5]: row i <-> time t0 - 4 + i
+    float* gin = ft + 5 * (Tc + kMclHalo) + 3;                      // [Tc][33]
+    float* hist = gin + kMgpP32 * Tc;                               // [Tc][17]: h(t0 + tt)
+    float* dump = hist + kMgpP16 * Tc;
+    float wF[16];
+    {
+        const int dir = rot_dir(col);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int m = (col + dir * k) & 15;
+            wF[k] = (col < kMclH && m < kMclH) ? pl[L.o_whh + (role * kMclH + col) * kMclH + m] : 0.0f;
+        }
+    }
+    const bool is_g = role == 2;
+    const int pk0 = role == 0 ? (int)(hist - smem) + col : (int)(dump - smem) + lane, pk_step = role == 0 ? kMgpP16 : 0;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
+        float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * T;
+        float h = 0.0f, c = 0.0f;
+        for (int t0 = 0; t0 < T; t0 += Tc) {
+            const int len = min(Tc, T - t0);
+            __syncthreads();
+            for (int i = tid; i < len + kMclHalo; i += 256) {
+                const int t = t0 - kMclHalo + i;
+                const float2 xv = xg[t < 0 ? t + T : t];
+                const float a2 = __builtin_fmaf(xv.x, xv.x, xv.y * xv.y), am = __builtin_amdgcn_sqrtf(a2);
+                float* d = ft + 5 * i;
+                d[0] = xv.x; d[1] = xv.y; d[2] = am; d[3] = a2; d[4] = a2 * am;
+            }
+            __syncthreads();
+            for (int tt = tid; tt < len; tt += 256) {
+                float pv[kMclP];
+#pragma unroll
+                for (int p = 0; p < kMclP; ++p) pv[p] = ft[5 * tt + p];
+                for (int g = 0; g < kMclG; ++g) {
+                    const float* ar = K.A + g * kMclPP;
+                    float acc = ar[kMclP];
+#pragma unroll
+                    for (int p = 0; p < kMclP; ++p) acc = __builtin_fmaf(ar[p], pv[p], acc);
+                    gin[tt * kMgpP32 + g] = acc;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                int pk = pk0;
+                for (int tt = 0; tt < len; ++tt) {
+                    const float acc = rotdot(gin[tt * kMgpP32 + role * kMclH + cu], wF, h);
+                    const float sg = sigmoidf_(acc), th = tanhf_(acc);
+                    float g4[4];
+                    gather_rows(is_g ? th : sg, g4);
+                    c = __builtin_fmaf(g4[1], c, g4[0] * g4[2]);
+                    h = g4[3] * tanhf_(c);
+                    smem[pk] = h;
+                    pk += pk_step;
+                }
+            }
+            __syncthreads();
+            for (int tt = tid; tt < len; tt += 256) {
+                const float* hv = hist + tt * kMgpP16;
+                float y0 = K.bfc[0], y1 = K.bfc[1];
+#pragma unroll
+                for (int j = 0; j < kMclH; ++j) { y0 = __builtin_fmaf(K.wfc[j], hv[j], y0); y1 = __builtin_fmaf(K.wfc[kMclH + j], hv[j], y1); }
+                yg[t0 + tt] = make_float2(y0, y1);
+            }
+        }
+    }
+}
+
 static size_t mcl_gp_lds_bytes(int C, int T) {
     return ((size_t)pad4(mcl_layout(C).P) + pad4(mcl_comp_floats(C) + 4) + mgp_buf(T, C).total) * sizeof(float);
 }
@@ -873,6 +956,13 @@ int mcldnn_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int 
     SeqArgs a = a0;
     a.ngroups = (a.B + 15) / 16;
     const int C = m->hidden, P = mcl_layout(C).P;
+    if (mode == 1 && !a.ckpt && a.B <= 2 * device_cus() && tuning().s16_min_batch != 0 && tuning().gp_max_batch != 0) {
+        // sequences that each get a CU of their own (inference: no checkpoints)
+        const size_t lds = ((size_t)pad4(P) + pad4(mcl_comp_floats(C) + 4) + kMevFloats) * sizeof(float);
+        if (int e = allow_big_lds(mcl_gp_eval_kernel, lds)) return e;
+        hipLaunchKernelGGL(mcl_gp_eval_kernel, dim3(a.B), dim3(256), lds, st, a);
+        return (int)hipGetLastError();
+    }
     if (mode == 1) {
         const LaunchShape ls = m16_shape(a.ngroups, a.ngroups <= 4 * device_cus() ? 4 : 8);
         size_t body = (size_t)ls.waves * (16 * kMclRowF + 2 * 16 * kChunkPad);

@@ -9,10 +9,10 @@ import torch
 from opendpd_amd import CoreModel
 
 for bb, H in (("gru", 11), ("dgru", 13), ("dgru", 23), ("qgru", 10), ("qgru_amp1", 16), ("lstm", 14), ("lstm", 24), ("vdlstm", 13), ("vdlstm", 24),
-              ("pgjanet", 11), ("deltagru", 15), ("deltagru_tcnskip", 15), ("deltajanet", 15)):
+              ("pgjanet", 11), ("deltagru", 15), ("deltagru_tcnskip", 15), ("deltajanet", 15), ("bojanet", 12), ("apnrru", 8), ("dvrjanet", 12), ("mcldnn", 8)):
     for B, T in ((1, 19662), (3, 2560)):
         torch.manual_seed(0)
-        net = CoreModel(2, H, 1, bb).cuda().eval()
+        net = CoreModel(2, H, 1, bb, **({"num_dvr_units": 3} if bb == "dvrjanet" else {})).cuda().eval()
         x = torch.randn(B, T, 2).cuda() * 0.3
         xg = x.clone().requires_grad_(True)
         best = {}
