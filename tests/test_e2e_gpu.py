@@ -115,10 +115,12 @@ def test_train_dpd_and_run_dpd_match_reference(workdir):
     assert np.abs(csv.to_numpy() - m["dpd_out"]).max() < 2e-5
 
 
-@pytest.mark.parametrize("bb,H,F,B", [("dgru", 13, 50, 64), ("gru", 11, 200, 256), ("qgru", 10, 37, 100)])
+@pytest.mark.parametrize("bb,H,F,B", [("dgru", 13, 50, 64), ("gru", 11, 200, 256), ("qgru", 10, 37, 100), ("bojanet", 12, 50, 64), ("apnrru", 8, 50, 64),
+                                      ("dvrjanet", 12, 50, 64), ("mcldnn", 8, 50, 64), ("mcldnn", 5, 200, 256)])
 def test_native_epoch_loop_equals_per_step_loop(bb, H, F, B):
     """odpd_train_epoch (frames read in place from the resident streams, C++ loop) == the Python per-batch loop over
-    gathered frame tensors: same kernels, same order, bit-identical parameters and per-epoch loss."""
+    gathered frame tensors: same kernels, same order, bit-identical parameters and per-epoch loss.  (bojanet / apnrru / dvrjanet / mcldnn:
+    their one-frame-per-workgroup fused kernels address the frames in place too.)"""
     import torch
     from opendpd_amd import CoreModel
     from opendpd_amd.project import DeviceFrameLoader
@@ -132,7 +134,7 @@ def test_native_epoch_loop_equals_per_step_loop(bb, H, F, B):
     outs = []
     for native in (True, False):
         torch.manual_seed(11)
-        net = CoreModel(2, H, 1, bb).cuda()
+        net = CoreModel(2, H, 1, bb, **({"num_dvr_units": 3} if bb == "dvrjanet" else {})).cuda()
         opt = FusedAdamW(net, lr=2e-3)
         loader = DeviceFrameLoader(x, y, F, 1, B, torch.device("cuda"), shuffle=True)
         assert opt.can_run_epoch(loader)
