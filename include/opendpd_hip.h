@@ -139,7 +139,9 @@ int odpd_loss_fwd_bwd(void* stream, int kind, int64_t n, int64_t count, const fl
  * written; BPTT state stays in LDS or goes to `workspace` (odpd_train_workspace_floats floats, may be
  * NULL when that is 0).  `count` as in odpd_loss_fwd_bwd.
  * Available (odpd_partial_rows(m, B, T, 1) > 0): GRU family at every batch; lstm / vdlstm at the reference's batch sizes (one sequence
- * per wave, hidden <= 16) and at large batches (16 sequences per wave); pgjanet at the reference's batch sizes; gmp; rvtdcnn. */
+ * per wave, hidden <= 16) and at large batches (16 sequences per wave); pgjanet, bojanet, apnrru, dvrjanet and mcldnn at the reference's
+ * batch sizes (one frame per workgroup while the frame's state fits a CU's LDS: frames up to ~230 .. 270 samples); gmp; rvtdcnn;
+ * the quantised GRU-cell / delta models at large batches. */
 int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_kind, int B, int T,
                        int64_t count, const float* params, const float* x, const float* target,
                        float* partials, float* workspace);
