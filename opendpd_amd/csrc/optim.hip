@@ -55,6 +55,39 @@ __global__ __launch_bounds__(256) void loss_kernel(int kind, int64_t n, float in
     float tot = block_sum(acc, sh);
     if (threadIdx.x == 0) ws[blockIdx.x] = tot;
 }
+// the same for small batches (the reference's 64 x 50 frames: 6 400 elements) as ONE launch of one 1024-thread workgroup: per-thread sums over the
+// grid-stride elements, one block sum, the mean written directly
+__global__ __launch_bounds__(1024) void loss_single_kernel(int kind, int64_t n, float inv_count, const float* __restrict__ y,
+                                                           const float* __restrict__ t, float* __restrict__ dy, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    const float4* t4 = reinterpret_cast<const float4*>(t);
+    float4* d4 = reinterpret_cast<float4*>(dy);
+    for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        float4 a = y4[i], b = t4[i], g;
+        float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+        if (kind == ODPD_LOSS_L2) {
+            acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            const float s = 2.0f * inv_count;
+            g = make_float4(d0 * s, d1 * s, d2 * s, d3 * s);
+        } else {
+            acc += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+            auto sg = [inv_count](float d) { return d > 0.f ? inv_count : (d < 0.f ? -inv_count : 0.f); };
+            g = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
+        }
+        if (dy) d4[i] = g;
+    }
+    if (threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float d = y[i] - t[i];
+        if (kind == ODPD_LOSS_L2) { acc += d * d; if (dy) dy[i] = 2.0f * inv_count * d; }
+        else { acc += fabsf(d); if (dy) dy[i] = d > 0.f ? inv_count : (d < 0.f ? -inv_count : 0.f); }
+    }
+    float tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[0] = tot * inv_count;
+}
 __global__ __launch_bounds__(256) void loss_final_kernel(int nblk, float inv_count, const float* __restrict__ ws,
                                                          float* __restrict__ out) {
     __shared__ float sh[4];
@@ -155,6 +188,10 @@ extern "C" int odpd_loss_fwd_bwd(void* stream, int kind, int64_t n, int64_t coun
     int64_t want = (n / 4 + 255) / 256;
     int nblk = (int)(want < 1 ? 1 : (want > kLossBlocks ? kLossBlocks : want));
     float inv = (float)(1.0 / (double)count);
+    if (n <= 32768) {       // one workgroup, one launch
+        hipLaunchKernelGGL(loss_single_kernel, dim3(1), dim3(1024), 0, st, kind, n, inv, y, target, dy, loss_out);
+        return (int)hipGetLastError();
+    }
     // loss_out[1..256] is scratch for the per-block sums (see header)
     hipLaunchKernelGGL(loss_kernel, dim3(nblk), dim3(256), 0, st, kind, n, inv, y, target, dy, loss_out + 1);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, nblk, inv, loss_out + 1, loss_out);
