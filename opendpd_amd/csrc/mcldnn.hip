@@ -597,16 +597,17 @@ int m16_launch_bwd(hipStream_t st, const SeqArgs& a, int P, int C) {
 
 
 // -------------------------------------------------------------------------------------------------
-// Fused train kernel for the reference's own batch sizes (train_funcs.py:28-48; a frame gets a CU of its own): ONE sequence per four-wave
+// Fused train kernel for the reference's own batch sizes (train_funcs.py:28-48; a frame gets a CU of its own): ONE sequence per eight-wave
 // workgroup.  Wave 0 runs the LSTM(8) recurrences gate-parallel (row k of the wave = gate k — i | f | g | o —, one rotated dot product per
 // step and orientation, gates / h / c / tanh c of the frame parked in LDS, the step's W_hh gradient as one 4-block MFMA); everything that
-// does not depend on h is spread over the 256 threads with thread = time step: the feature table, gates_in = A vec(P) + b of every step,
-// the read-out with loss and dL/dy, and — on the matrix pipe, a quarter of the frame per wave — dA | db = sum_t d_gates(t) (x) [P(t), 1].
+// does not depend on h is spread over the 512 threads with thread = time step: the feature table, gates_in = A vec(P) + b of every step,
+// the read-out with loss and dL/dy, and — on the matrix pipe, an eighth of the frame per wave — dA | db = sum_t d_gates(t) (x) [P(t), 1].
 // The prologue composes A, b, W_fc (mcl_compose), the epilogue takes dA, db, dW_hh, dW_fc, db_fc back to the gradients of the
 // convolutions, W_ih, the biases and the two linear layers (m16_param_grad), all four waves at work.  Weight gradients only (the
 // frozen-PA role stays on the S16 kernels).  Taken while the frame's state fits the CU's LDS.
 // -------------------------------------------------------------------------------------------------
 constexpr int kMgpP16 = 17, kMgpP32 = 33;
+constexpr int kMgpWaves = 8, kMgpThreads = 64 * kMgpWaves;     // waves of the train kernel's workgroup (wave 0: the recurrences; all: everything else)
 struct MgpBuf { int ft, gin, gts, hist, cpk, tpk, dyb, dump, total; };
 __host__ __device__ inline MgpBuf mgp_buf(int T, int C) {
     MgpBuf b; int o = 0;
@@ -618,11 +619,11 @@ __host__ __device__ inline MgpBuf mgp_buf(int T, int C) {
     b.tpk = o; o += kMgpP16 * T;             // tanh c(t)
     b.dyb = o; o += 2 * T + 2;               // float2 [T]
     b.dump = o; o += 256;
-    const int tail = 4 * kMclRaw + 5 * C * kMclPP + 8;      // the epilogue's [wave][raw] and Gz share the frame buffers
+    const int tail = kMgpWaves * kMclRaw + 5 * C * kMclPP + 8;      // the epilogue's [wave][raw] and Gz share the frame buffers
     b.total = o > tail ? o : tail;
     return b;
 }
-__global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
+__global__ __launch_bounds__(kMgpThreads) void mcl_gp_train_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, role = lane >> 4, cu = col & 7;
     const MclLayout L = mcl_layout(a.H);
@@ -631,12 +632,12 @@ __global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
     stage_params(pl, a.params, L.P);
     const MclComp K = mcl_comp(pl + pad4(L.P), C);
     mcl_compose(K, pl, L);
-    float* buf = pl + pad4(L.P) + pad4(mcl_comp_floats(C) + 4);
+    float* buf = pl + pad4(L.P) + pad4(mcl_comp_floats(C) + kMgpWaves);
     const MgpBuf O = mgp_buf(T, C);
     float *ft = buf + O.ft, *gin = buf + O.gin, *gts = buf + O.gts, *hist = buf + O.hist, *cpk = buf + O.cpk, *tpk = buf + O.tpk;
     float2* dyb = reinterpret_cast<float2*>(buf + ((O.dyb + 1) & ~1));
     float* dump = buf + O.dump;
-    float* loss4 = K.bfc + 2;                               // (four floats of padding after the composed operands)
+    float* loss4 = K.bfc + 2;                               // (kMgpWaves floats of padding after the composed operands)
     // wave 0: the row's recurrent block W_hh[gate][unit][:] and its transpose, rotated for this lane
     float wF[16], wT[16];
     {
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
         const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
         __syncthreads();
         // ---- the feature table (circular window: mcldnn.py:115-118) ----
-        for (int i = tid; i < T + kMclHalo; i += 256) {
+        for (int i = tid; i < T + kMclHalo; i += kMgpThreads) {
             const int t = i - kMclHalo;
             const float2 xv = xg[t < 0 ? t + T : t];
             const float a2 = __builtin_fmaf(xv.x, xv.x, xv.y * xv.y), am = __builtin_amdgcn_sqrtf(a2);
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
         if (tid < 16) { hist[tid] = 0.0f; cpk[tid] = 0.0f; }
         __syncthreads();
         // ---- gates_in of every step; thread = time step ----
-        for (int t = tid; t < T; t += 256) {
+        for (int t = tid; t < T; t += kMgpThreads) {
             float pv[kMclP];
 #pragma unroll
             for (int p = 0; p < kMclP; ++p) pv[p] = ft[5 * t + p];
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
         }
         __syncthreads();
         // ---- read-out, loss and dL/dy of every step; thread = time step ----
-        for (int t = tid; t < T; t += 256) {
+        for (int t = tid; t < T; t += kMgpThreads) {
             const float* hv = hist + (t + 1) * kMgpP16;
             float y0 = K.bfc[0], y1 = K.bfc[1];
 #pragma unroll
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
         }
         __syncthreads();
         // ---- dA | db: sum over time of d_gates (x) [patch, 1] on the matrix pipe, a quarter of the 4-step slices per wave ----
-        for (int t4 = 4 * wave; t4 < T; t4 += 16) {
+        for (int t4 = 4 * wave; t4 < T; t4 += 4 * kMgpWaves) {
             const int t = t4 + role;
             const bool ok = t < T;
             const int tc_ = ok ? t : 0;
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
     // ---- epilogue: the waves' raw sums, then the chain rule back to the parameters (as mcl16_bwd_kernel) ----
     __syncthreads();
     float* raw = buf;                                       // [wave][kMclRaw], then Gz
-    float* Gz = raw + 4 * kMclRaw;
+    float* Gz = raw + kMgpWaves * kMclRaw;
     {
         float* rw = raw + wave * kMclRaw;
         float* rA = rw; float* rb = rA + kMclG * kMclP; float* rhh = rb + kMclG; float* rfc = rhh + kMclG * kMclH; float* rbf = rfc + 2 * kMclH;
@@ -809,9 +810,14 @@ __global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
         if (lane == 0) { rbf[0] = s0; rbf[1] = s1; loss4[wave] = lp; }
     }
     __syncthreads();
-    for (int i = tid; i < kMclRaw; i += 256) raw[i] = (raw[i] + raw[kMclRaw + i]) + (raw[2 * kMclRaw + i] + raw[3 * kMclRaw + i]);
+    for (int i = tid; i < kMclRaw; i += kMgpThreads) {
+        float v = raw[i];
+#pragma unroll
+        for (int w = 1; w < kMgpWaves; ++w) v += raw[w * kMclRaw + i];
+        raw[i] = v;
+    }
     __syncthreads();
-    for (int i = tid; i < Z * kMclPP; i += 256) {
+    for (int i = tid; i < Z * kMclPP; i += kMgpThreads) {
         const int zi = i / kMclPP, pp = i % kMclPP;
         float acc = 0.0f;
         for (int g = 0; g < kMclG; ++g) acc = __builtin_fmaf(pl[L.o_wih + g * Z + zi], pp < kMclP ? raw[g * kMclP + pp] : raw[kMclG * kMclP + g], acc);
@@ -820,8 +826,10 @@ __global__ __launch_bounds__(256) void mcl_gp_train_kernel(SeqArgs a) {
     __syncthreads();
     const int P4 = L.P + kLossCols;
     float* prow = a.partials + (size_t)blockIdx.x * P4;
-    for (int i = tid; i < P4; i += 256)
-        prow[i] = i < L.P ? m16_param_grad(i, raw, Gz, K, pl, L) : (i == L.P ? (loss4[0] + loss4[1]) + (loss4[2] + loss4[3]) : 0.0f);
+    float loss_total = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kMgpWaves; ++w) loss_total += loss4[w];
+    for (int i = tid; i < P4; i += kMgpThreads) prow[i] = i < L.P ? m16_param_grad(i, raw, Gz, K, pl, L) : (i == L.P ? loss_total : 0.0f);
 }
 
 // Evaluation kernel (net_eval / run_dpd on a few very long sequences, train_funcs.py:57-90): ONE sequence per four-wave workgroup, the forward
@@ -908,7 +916,7 @@ __global__ __launch_bounds__(256) void mcl_gp_eval_kernel(SeqArgs a) {
 }
 
 static size_t mcl_gp_lds_bytes(int C, int T) {
-    return ((size_t)pad4(mcl_layout(C).P) + pad4(mcl_comp_floats(C) + 4) + mgp_buf(T, C).total) * sizeof(float);
+    return ((size_t)pad4(mcl_layout(C).P) + pad4(mcl_comp_floats(C) + kMgpWaves) + mgp_buf(T, C).total) * sizeof(float);
 }
 static int mcl_gp_blocks_per_cu(int C, int T) {
     const size_t lds = mcl_gp_lds_bytes(C, T);
@@ -946,7 +954,7 @@ int mcldnn_gp_rows(const odpd_model_t* m, int B, int T) {
 int mcldnn_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     const size_t lds = mcl_gp_lds_bytes(m->hidden, a.T);
     if (int e = allow_big_lds(mcl_gp_train_kernel, lds)) return e;
-    hipLaunchKernelGGL(mcl_gp_train_kernel, dim3(mcldnn_gp_rows(m, a.B, a.T)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(mcl_gp_train_kernel, dim3(mcldnn_gp_rows(m, a.B, a.T)), dim3(kMgpThreads), lds, st, a);
     return (int)hipGetLastError();
 }
 // mode 1 forward, 2 backward
