@@ -98,3 +98,40 @@ def test_flat_buffer_survives_load_and_move():
     net = net.double().float()   # _apply re-points every parameter
     cat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     assert torch.equal(cat, net.backbone.flat_params())
+
+
+def _asm_statements(text):
+    """the parenthesised bodies of the asm statements of a source text (balanced parentheses; macro continuations joined)"""
+    import re
+    text = text.replace("\\\n", " ")
+    out = []
+    for m in re.finditer(r"\basm\b\s*(?:volatile\s*)?\(", text):
+        depth, j = 1, m.end()
+        while depth and j < len(text):
+            depth += {"(": 1, ")": -1}.get(text[j], 0)
+            j += 1
+        out.append(text[m.end():j - 1])
+    return out
+
+
+def test_multi_instruction_asm_groups_take_early_clobber_accumulators():
+    """The rotated-dot-product groups of csrc/odpd_device.h are several v_fmac_f32_dpp in ONE asm statement: an accumulator declared "+v" may
+    be given the register of an input that holds the same value at entry (a weight proved to be the constant 0 next to an accumulator that
+    starts at 0 — found in r03: rotation 8 of an 8-unit LSTM multiplied by the running sum).  Every asm statement with more
+    than one instruction must declare its read-write operands early-clobber ("+&v")."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "opendpd_amd", "csrc")
+
+    def offenders(text):
+        bad = []
+        for body in _asm_statements(text):
+            n_instr = body.count("v_fmac_f32_dpp") + len(re.findall(r"ODPD_DPPF\(", body)) + 3 * len(re.findall(r"ODPD_F3\(", body))
+            if n_instr > 1 and '"+v"' in body:
+                bad.append(body[:80])
+        return bad
+
+    dev = open(os.path.join(csrc, "odpd_device.h")).read()
+    assert offenders(dev.replace('"+&v"', '"+v"')), "the check must see the groups"        # (self-test on the pre-fix form)
+    for path in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip"))):
+        assert not offenders(open(path).read()), os.path.basename(path)
