@@ -121,55 +121,111 @@ def run_steps(opt, x, t, steps, warmup, count, dist, events=False):
     return el, kern_ms, float(loss.item())
 
 
-def cpu_baseline(H, T, budget_1t_s=4.0, budget_nt_s=2.5):
-    """Reference-step port (oracle) on the host cores; bounded sample of the same workload (~15-20 s in total).  OpenMP over the
-    sequences of a 256 x T batch: the thread count is swept (a 256-sequence batch does not scale to every core of a large host, and
-    a container may be granted fewer cores than it sees), `value` / `cores` report the best one, the single-thread rate and the
-    whole sweep are given beside it."""
+class _EpochLoader:
+    """what FusedAdamW.train_epoch reads from project.DeviceFrameLoader: resident streams + the epoch's frame order"""
+
+    def __init__(self, xs, ys, T, batch, n_frames):
+        self.x, self.y, self.frame_length, self.stride, self.batch_size, self.n = xs, ys, T, 1, batch, n_frames
+        self._order = torch.randperm(n_frames, generator=torch.Generator().manual_seed(11)).to(xs.device)
+
+    def epoch_order(self):
+        return self._order
+
+
+def strong_scaling_epoch(H, T, global_batch, dev, dist, world, steps=200):
+    """`steps` train_pa steps of DGRU(H) at a FIXED global batch sharded over the ranks, through the native epoch loop; max over ranks"""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.train_funcs import FusedAdamW
+    torch.manual_seed(5)
+    net = CoreModel(2, H, 1, "dgru").to(dev)
+    opt = FusedAdamW(net, lr=5e-4)
+    n_frames = global_batch * steps
+    xs, ys = synth_frames(n_frames, T, seed=77, device=dev, materialize=False)     # the same stream on every rank
+    loader = _EpochLoader(xs, ys, T, global_batch, n_frames)
+    if not opt.can_run_epoch(loader):
+        return {"skipped": "no native epoch loop for this shard size / collective"}
+    best = None
+    for it in range(3):          # first pass = warm-up; best of the other two
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses = opt.train_epoch(loader, "l2", 200.0)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        if it and (best is None or float(el.item()) < best):
+            best = float(el.item())
+    return {"global_batch": global_batch, "frames_per_gpu": global_batch / world, "steps": steps, "ms_per_step": 1e3 * best / steps,
+            "value": global_batch * T * steps / best, "unit": "IQ samples/s", "loss_last": float(losses[-1].item())}
+
+
+def cpu_baseline(H, T, budget_1t_s=4.0, budget_nt_s=2.0, big_batch=8192):
+    """Reference-step port (oracle) on the host cores; bounded sample of the same workload (~25-30 s in total).  OpenMP over the
+    sequences of a batch.  Two batches: the reference's 256 x T (arguments.py:32) — where a 256-sequence batch does not scale to every
+    core of a large host, so the thread count is swept — and a CPU-saturating `big_batch` x T at the thread counts that did best.
+    `value` / `cores` report the best rate over both; `by_batch` keeps each batch's own best, so that GPU / CPU ratios are formed at
+    MATCHED batch (main() adds them)."""
     from oracle.oracle import Oracle, make_model
     o = Oracle("f32")
     m = make_model("dgru", H)
-    B = 256
     rng = np.random.RandomState(0)
-    x = (0.05 + 0.8 * rng.rand(B, T, 2)).astype(np.float32)
-    t = rng.rand(B, T, 2).astype(np.float32)
     P = o.param_count(m)
-    p = (rng.randn(P) * 0.2).astype(np.float32)
-    mom = np.zeros(P, np.float32)
-    var = np.zeros(P, np.float32)
-    scratch = (np.empty_like(x), np.empty_like(x), np.empty(P, np.float32))
     cores = o.max_threads()
     try:
         cores = min(cores, len(os.sched_getaffinity(0)))
     except AttributeError:
         pass
 
-    def timed(budget, max_steps):
-        o.train_step(m, p, x, t, mom, var, 1, 5e-4, 200.0, scratch=scratch)  # warm-up
+    def make(B):
+        x = (0.05 + 0.8 * rng.rand(B, T, 2)).astype(np.float32)
+        t = rng.rand(B, T, 2).astype(np.float32)
+        return dict(B=B, x=x, t=t, p=(rng.randn(P) * 0.2).astype(np.float32), mom=np.zeros(P, np.float32), var=np.zeros(P, np.float32),
+                    scratch=(np.empty_like(x), np.empty_like(x), np.empty(P, np.float32)))
+
+    def timed(w, budget, max_steps):
+        o.train_step(m, w["p"], w["x"], w["t"], w["mom"], w["var"], 1, 5e-4, 200.0, scratch=w["scratch"])  # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
-            o.train_step(m, p, x, t, mom, var, n + 2, 5e-4, 200.0, scratch=scratch)
+            o.train_step(m, w["p"], w["x"], w["t"], w["mom"], w["var"], n + 2, 5e-4, 200.0, scratch=w["scratch"])
             n += 1
             el = time.perf_counter() - t0
             if el > budget or n >= max_steps:
                 return n, el
 
+    small = make(256)
     o.set_threads(1)
-    n1, el1 = timed(budget_1t_s, 200)
-    sweep = {1: B * T * n1 / el1}
+    n1, el1 = timed(small, budget_1t_s, 200)
+    sweep = {1: 256 * T * n1 / el1}
     steps = {1: (n1, el1)}
     for nt in sorted({c for c in (4, 8, 16, 32, 64, cores) if 1 < c <= cores}):
         o.set_threads(nt)
-        n, el = timed(budget_nt_s, 2000)
-        sweep[nt] = B * T * n / el
+        n, el = timed(small, budget_nt_s, 2000)
+        sweep[nt] = 256 * T * n / el
         steps[nt] = (n, el)
     best = max(sweep, key=sweep.get)
-    n, el = steps[best]
-    return {"value": sweep[best], "unit": "IQ samples/s", "cores": best, "kind": "port",
-            "value_1thread": sweep[1], "host_cores_visible": cores,
-            "threads_swept": {str(k): round(v) for k, v in sweep.items()},
-            "sample": f"{n} train steps of DGRU H{H} on a {B}x{T} synthetic batch ({el:.1f} s at {best} OpenMP threads over sequences; "
-                      f"{sum(v[1] for v in steps.values()):.0f} s of CPU sweep in total)"}
+    total = sum(v[1] for v in steps.values())
+    by_batch = {"256": {"value": sweep[best], "cores": best, "steps": steps[best][0], "seconds": steps[best][1]}}
+    # the CPU-saturating batch: every core has >= 64 sequences; thread counts = all cores and the two best of the small sweep
+    big = make(big_batch)
+    big_sweep = {}
+    for nt in sorted({cores, *sorted(sweep, key=sweep.get)[-2:]} - {1}) or [1]:
+        o.set_threads(nt)
+        n, el = timed(big, budget_nt_s, 50)
+        big_sweep[nt] = (big_batch * T * n / el, n, el)
+        total += el
+    bbest = max(big_sweep, key=lambda k: big_sweep[k][0])
+    by_batch[str(big_batch)] = {"value": big_sweep[bbest][0], "cores": bbest, "steps": big_sweep[bbest][1], "seconds": big_sweep[bbest][2],
+                                "threads_swept": {str(k): round(v[0]) for k, v in big_sweep.items()}}
+    top = max(by_batch, key=lambda k: by_batch[k]["value"])
+    return {"value": by_batch[top]["value"], "unit": "IQ samples/s", "cores": by_batch[top]["cores"], "kind": "port",
+            "value_1thread": sweep[1], "host_cores_visible": cores, "batch": int(top),
+            "threads_swept": {str(k): round(v) for k, v in sweep.items()}, "by_batch": by_batch,
+            "sample": f"{by_batch[top]['steps']} train steps of DGRU H{H} on a {top}x{T} synthetic batch ({by_batch[top]['seconds']:.1f} s at "
+                      f"{by_batch[top]['cores']} OpenMP threads over sequences; thread sweep at 256x{T} and {big_batch}x{T}: {total:.0f} s of CPU in total)"}
 
 
 def kernel_source_sha1():
@@ -195,6 +251,7 @@ def main():
                          "inside the resident I/Q stream (SURVEY §8 f3; same kernels, same arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cascade", action="store_true", help="skip the train_dpd (cascade) side figure")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling figures at the reference's global batch sizes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,11 +266,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
+        # one process per GPU, RCCL process group over xGMI ("nccl" is RCCL on ROCm).  Under torchrun a world of ONE rank goes through
+        # the same rendezvous / process group / barriers as a real job (tests/test_dp_gpu.py runs that on the one-GPU box)
         import torch.distributed as dist_mod
         from opendpd_amd import dist as odist
-        odist.init(backend, device=dev)     # one process per GPU, RCCL over xGMI ("nccl" is RCCL on ROCm)
-        dist = dist_mod
+        odist.init(backend, device=dev, single=True)
+        dist = dist_mod if dist_mod.is_initialized() else None
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
 
     from opendpd_amd import CoreModel
@@ -283,6 +342,16 @@ def main():
         ref = {"batch_per_gpu": args.ref_batch, "value": world * args.ref_batch * T * max(args.steps, 50) / float(elr_t.item()),
                "ms_per_step": 1e3 * float(elr_t.item()) / max(args.steps, 50)}
 
+    # side figure: the same step at 8 192 frames (the batch at which the CPU baseline saturates the host's cores: matched-batch ratio)
+    matched_8192 = None
+    if world == 1 and not args.no_cpu_baseline and not args.materialized:
+        net8 = CoreModel(2, H, 1, "dgru").to(dev)
+        opt8 = FusedAdamW(net8, lr=5e-4)
+        x8 = FrameBatch(xs_, ys_, torch.arange(8192, device=dev, dtype=torch.int64), T, 1)
+        el8 = min(run_steps(opt8, x8, None, 30, 3, 8192 * T * 2, None)[0] for _ in range(2))
+        matched_8192 = 8192 * T * 30 / el8
+        del net8, opt8, x8
+
     # side figures of the reference's own shapes (latency regime, one sequence per wave): one evaluation pass over the APA_200MHz test
     # segment (net_eval, train_funcs.py:57-90: (1, 19 662, 2)) and the train step of the other recurrent families at the reference batch
     ref_shapes = None
@@ -343,6 +412,20 @@ def main():
                                   {"dpd_fwd": "gru16_fwd_kernel<DGRU6>", "pa_fwd_loss_dx": "gru16_train_kernel<DGRU6, frozen: loss + dL/du>",
                                    "dpd_bwd": "gru16_bwd_kernel<DGRU6>", "reduce_clip_optimiser": "reduce_partials_kernel + clip_adamw_kernel"})}
         del casc, opt3
+        # north_star's target sentence: "IQ samples/sec in the train_dpd step for a ~1k-param DGRU" — the 1 041-parameter DGRU H13 as the
+        # DPD in front of the frozen PA model the reference's OpenDPDv2 flow trains first (bash_scripts/OpenDPDv2.sh: dgru, hidden 23)
+        torch.manual_seed(1)
+        casc = CascadedModel(dpd_model=CoreModel(2, H, 1, "dgru"), pa_model=CoreModel(2, 23, 1, "dgru"))
+        casc.freeze_pa_model()
+        casc = casc.to(dev)
+        optn = FusedAdamW(casc, lr=5e-4)
+        eln, _, lossn = min((run_steps(optn, xc, tc, n3, 2, world * B * T * 2, dist) for _ in range(2)), key=lambda r: r[0])
+        dpd["north_star"] = {"workload": f"train_dpd: DGRU H{H} ({net.backbone.n_flat} params) DPD -> frozen DGRU H23 PA (OpenDPDv2's PA), target = x",
+                             "value": B * T * n3 / eln, "unit": "IQ samples/s", "ms_per_step": 1e3 * eln / n3, "loss": lossn,
+                             "roofline": priced(flops_train_pa_dgru(H) + flops_frozen_dgru(23), eln, n3, cascade_spans(optn, xc, tc, world * B * T * 2),
+                                                {"dpd_fwd": "gru16_fwd_kernel<DGRU6>", "pa_fwd_loss_dx": "gru16n_kernel<DGRU6, frozen: loss + dL/du>",
+                                                 "dpd_bwd": "gru16_bwd_kernel<DGRU6>", "reduce_clip_optimiser": "reduce_partials_kernel + clip_adamw_kernel"})}
+        del casc, optn
         # BASELINE configs[2]: TRes-DeltaGRU H15 (thx .01, thh .05) DPD in front of a frozen DGRU H23 PA, same batch
         torch.manual_seed(2)
         casc = CascadedModel(dpd_model=CoreModel(2, 15, 1, "deltagru_tcnskip", thx=0.01, thh=0.05), pa_model=CoreModel(2, 23, 1, "dgru"))
@@ -404,6 +487,22 @@ def main():
             dpd["reference_batch"] = {"batch_per_gpu": rb, "frame_length": T, "unit": "IQ samples/s", "cascades": small}
             del xr_, tr_
 
+    # which collective carried the gradient (identical on every rank: the communicator is built collectively)
+    nc = opt.native_comm()
+    collective = {"kind": nc.kind if nc is not None else ("torch" if world > 1 else "none"),
+                  "description": nc.describe() if nc is not None else ("torch.distributed all_reduce of P+4 floats per step" if world > 1 else "none (one GPU)"),
+                  "process_group": dist.get_backend() if dist is not None else None, "message_floats": net.backbone.n_flat + 4,
+                  "timeouts": nc.errors() if nc is not None else 0}
+    # STRONG scaling at the reference's own global batch sizes (arguments.py:32 default 256; the scripts' 64): the global batch is
+    # fixed and sharded over the N ranks (256 / N frames per GPU), whole epochs of steps issued by the native loop (odpd_train_epoch /
+    # odpd_train_epoch_dp: no Python between steps) — the regime in which the reference trains and in which the ~4 KB collective is a
+    # visible share of the step.  `value` = global IQ samples/s.
+    strong = None
+    if not args.no_strong:
+        strong = {}
+        for gb in (256, 64):
+            strong[f"global_batch_{gb}"] = strong_scaling_epoch(H, T, gb, dev, dist, world)
+
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * B * T / (kern_ms * 1e-3) / 1e9
         tflops = FLOP_PER_SAMPLE.get(H, 0) * B * T / (kern_ms * 1e-3) / 1e12
@@ -429,13 +528,19 @@ def main():
                                    f"T={T}, fused fwd+MSE+BPTT+clip200+AdamW step",
                        "inputs": "(B,T,2) frame tensors" if args.materialized else "stride-1 frames addressed in place in the resident I/Q stream",
                        "batch_per_gpu": B, "global_batch": world * B, "frame_length": T,
-                       "parallelism": f"dp{world}", "loss": float(loss)},
+                       "parallelism": f"dp{world}", "loss": float(loss),
+                       # the train_dpd step of north_star's target sentence, same batch (details under "train_dpd")
+                       "train_dpd_workload": dpd["north_star"]["workload"] if dpd else None,
+                       "train_dpd_value": dpd["north_star"]["value"] if dpd else None,
+                       "train_dpd_ms_per_step": dpd["north_star"]["ms_per_step"] if dpd else None},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / VALU_FP32_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms": kern_ms,
                          "algorithmic_flops_per_launch": FLOP_PER_SAMPLE.get(H, 0) * B * T,
                          "algorithmic_flops_per_sample": FLOP_PER_SAMPLE.get(H, 0),
                          "kernel_source_sha1": kernel_source_sha1(),
+                         "train_dpd_frac": dpd["north_star"]["roofline"]["frac"] if dpd else None,
+                         "train_dpd_hbm_frac": dpd["north_star"]["roofline"]["hbm"]["frac"] if dpd else None,
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * B * T}},
             "sustained": sustained,
@@ -443,12 +548,16 @@ def main():
             "config4": cfg4,
             "reference_shapes": ref_shapes,
             "train_dpd": dpd,
-            "collective": ("none (one GPU)" if world == 1 else
-                           ("RCCL all-reduce of P+4 floats per step, enqueued by libopendpd_hip.so on the step's stream (csrc/comm.hip)"
-                            if opt.native_comm() is not None else "torch.distributed all_reduce of P+4 floats per step")),
+            "collective": collective,
+            "strong_scaling": strong,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H, T)
+            cb = cpu_baseline(H, T)
+            # GPU / CPU at MATCHED batch (the headline's 65 536-frame batch is a different regime from a 256-frame CPU step)
+            gpu_at = {"256": ref["value"] if ref is not None and args.ref_batch == 256 else None, "8192": matched_8192}
+            cb["gpu_over_cpu_at_matched_batch"] = {k: (gpu_at.get(k) / v["value"] if gpu_at.get(k) else None) for k, v in cb["by_batch"].items()}
+            cb["gpu_value_at_matched_batch"] = gpu_at
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -169,13 +169,22 @@ int odpd_cascade_fwd_bwd(void* stream, const odpd_model_t* dpd, const odpd_model
                          const float* dpd_params, const float* pa_params, const float* x, const float* target,
                          const int64_t* frame_idx, int frame_stride, float* partials, double* dpd_stats);
 
+enum odpd_sample_format {
+    ODPD_SAMPLES_F32 = 0,   /* (I, Q) as two fp32: 8 bytes per sample — what the reference's datasets hold (data_collector.py:239-247) */
+    ODPD_SAMPLES_BF16 = 1   /* (I, Q) as two bf16 in one 32-bit word (I in the low half): 4 bytes per sample.  BASELINE configs[1]'s "bf16"
+                               frame storage: the kernels widen each value exactly and compute in fp32 — results equal the fp32 path run on
+                               the bf16-rounded streams; against the unrounded data the inputs carry a relative rounding of 2^-9.
+                               Opt-in; served by the GRU-family fused train kernels (ODPD_EUNSUPPORTED elsewhere). */
+};
 typedef struct odpd_frames {
-    const float* x_stream;  /* (N,2) device: model input stream */
-    const float* y_stream;  /* (N,2) device: target stream */
+    const float* x_stream;  /* (N,2) device: model input stream (fp32 pairs, or N 32-bit words when sample_format = ODPD_SAMPLES_BF16) */
+    const float* y_stream;  /* (N,2) device: target stream, same format */
     const int64_t* order;   /* device, n_frames frame indices in visiting order (the DataLoader's epoch permutation) */
     int64_t n_frames;
     int32_t frame_length;
     int32_t stride;
+    int32_t sample_format;  /* enum odpd_sample_format */
+    int32_t reserved;       /* 0 */
 } odpd_frames_t;
 /* 1 when the model's fused train kernel can address frames inside resident streams (GRU family, GMP), else 0: the two entry
  * points below return ODPD_EUNSUPPORTED for the others (materialise the batch and call odpd_train_fwd_bwd). */
@@ -256,7 +265,7 @@ int odpd_train_epoch_split(void* stream, const odpd_model_t* m, int loss_kind, c
  * The reference is single-device; this is the boundary a multi-GPU binding of train_funcs.py:16-54 would call.  Every rank holds a
  * replica of the parameters and of the optimiser state, takes the contiguous shard [lo, hi) = shard of each global batch (sizes differ
  * by at most one, odpd_shard_range), normalises its loss gradient by the GLOBAL element count, and ONE in-place all-reduce (sum) of
- * the P + 4 floats behind `grad` (gradient + loss partial sum) over RCCL / xGMI per optimiser step makes every rank apply the same
+ * the P + 4 floats behind `grad` (gradient + loss partial sum) over xGMI per optimiser step — RCCL, or the one-shot exchange below — makes every rank apply the same
  * clip + optimiser update.  librccl is loaded on first use (dlopen); ODPD_ECOMM when it is missing or fails. */
 /* rank 0: 128 bytes identifying a new communicator; hand them to every rank (any host channel), then all call odpd_comm_init */
 int odpd_comm_unique_id(void* id128);
@@ -265,6 +274,32 @@ int odpd_comm_init(const void* id128, int world, int rank, void** comm_out);
 int odpd_comm_destroy(void* comm);
 /* in-place sum over the ranks of n fp32 values, enqueued on `stream` (asynchronous like every other call here) */
 int odpd_comm_allreduce_sum(void* stream, void* comm, float* buf, int64_t n);
+/* ---- the one-shot exchange: a communicator WITHOUT RCCL for the step's ~4 KB vector (one-shot direct / LL over ring) ----
+ * Every rank owns slots (2 parities x world rows x 8192 words) that the peers map; an all-reduce = every rank stores its vector as
+ * (sequence, fp32) 8-byte words into its row of every peer's slots and sums the rows arriving in its own, in rank order (replicas
+ * stay bit-identical).  Transports: shm_name == NULL — uncached device memory shared through hipIpc (peer HBM over xGMI; also two
+ * processes on one GPU); shm_name != NULL — one POSIX shared-memory segment of that name, registered with HIP, for GPUs without peer
+ * access.  world <= 8, vectors <= 8192 floats per exchange.
+ *   odpd_xchg_create : local part.  *handle64_out = 64 bytes to hand to every rank (hipIpc transport; any host channel).
+ *   odpd_xchg_connect: after EVERY rank created: `handles` = world x 64 bytes in rank order (ignored for shared memory).
+ *   odpd_xchg_unlink : after EVERY rank connected (shared-memory transport): drops the segment's name.
+ * The handle then serves odpd_comm_allreduce_sum, odpd_train_epoch_dp, odpd_train_epoch_cascade, odpd_clip_optim_step_dp and
+ * odpd_comm_destroy like an RCCL one.  A peer that does not arrive within $ODPD_XCHG_TIMEOUT_MS (5000) poisons the sum with NaN and
+ * counts in odpd_comm_errors — a lost rank ends in NaN losses, never in a hung GPU. */
+int odpd_xchg_create(int world, int rank, const char* shm_name, void** comm_out, void* handle64_out);
+int odpd_xchg_connect(void* comm, const void* handles);
+int odpd_xchg_unlink(void* comm);
+/* 0 = RCCL, 1 = one-shot exchange over hipIpc device memory, 2 = one-shot exchange over host shared memory */
+int odpd_comm_kind(void* comm);
+/* exchanges of this rank that timed out so far (synchronises the device); 0 for RCCL communicators */
+int odpd_comm_errors(void* comm);
+/* The tail of a data-parallel step in one call: all-reduce of grad[0 .. P+4) over `comm` (NULL = no collective), then
+ * clip_grad_norm_(max_norm) + the optimiser step as odpd_clip_adamw_step_masked (opt_kind < 0: AdamW with these hyper-parameters)
+ * or odpd_clip_optim_step (an enum odpd_optimizer kind).  With a one-shot communicator the exchange is the optimiser kernel's
+ * prologue — ONE launch for collective + clip + update; with RCCL the all-reduce is enqueued in front of it. */
+int odpd_clip_optim_step_dp(void* stream, void* comm, int opt_kind, int64_t P, float* params, float* grad, float* state1, float* state2,
+                            int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                            float* norm_out, const unsigned char* skip);
 /* contiguous shard [*lo, *hi) of n items for `rank` of `world` (the split of train_funcs.py's batch across ranks) */
 void odpd_shard_range(int64_t n, int rank, int world, int64_t* lo, int64_t* hi);
 /* odpd_train_epoch / odpd_train_epoch_opt (opt_kind < 0: AdamW with the given hyper-parameters) with every GLOBAL batch of `batch`

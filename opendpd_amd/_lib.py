@@ -13,7 +13,7 @@ LOSS_IDS = {"l2": 0, "l1": 1}
 FLAG_EVAL, FLAG_NEED_DX = 1, 2      # odpd_model_t.flags (include/opendpd_hip.h)
 LOSS_COLS = 4        # extra columns of a partials row (column P = loss partial sum)
 LOSS_WS = 1 + 256    # floats behind `loss_out` (result + per-block scratch)
-ABI_VERSION = 9      # odpd_abi_version() of the library these argument lists belong to
+ABI_VERSION = 10     # odpd_abi_version() of the library these argument lists belong to
 
 
 class ModelDesc(C.Structure):
@@ -25,7 +25,10 @@ class ModelDesc(C.Structure):
 class Frames(C.Structure):
     """odpd_frames_t"""
     _fields_ = [("x_stream", C.c_void_p), ("y_stream", C.c_void_p), ("order", C.c_void_p), ("n_frames", C.c_int64),
-                ("frame_length", C.c_int32), ("stride", C.c_int32)]
+                ("frame_length", C.c_int32), ("stride", C.c_int32), ("sample_format", C.c_int32), ("reserved", C.c_int32)]
+
+
+SAMPLES_F32, SAMPLES_BF16 = 0, 1     # enum odpd_sample_format
 
 
 _EXPORTS = {
@@ -79,6 +82,13 @@ _EXPORTS = {
     "odpd_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "odpd_comm_destroy": (C.c_int, [C.c_void_p]),
     "odpd_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "odpd_xchg_create": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "odpd_xchg_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "odpd_xchg_unlink": (C.c_int, [C.c_void_p]),
+    "odpd_comm_kind": (C.c_int, [C.c_void_p]),
+    "odpd_comm_errors": (C.c_int, [C.c_void_p]),
+    "odpd_clip_optim_step_dp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "odpd_shard_range": (None, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "odpd_train_epoch_dp": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -127,7 +137,7 @@ def load():
 
 def check(rc, what):
     if rc != 0:
-        kind = {-1: "invalid argument", -2: "unsupported backbone/hidden size", -3: "RCCL missing or failed"}.get(rc, f"hipError {rc}")
+        kind = {-1: "invalid argument", -2: "unsupported backbone/hidden size", -3: "collective failed (RCCL missing / refused, or the one-shot exchange could not map its peers)"}.get(rc, f"hipError {rc}")
         raise RuntimeError(f"{what} failed: {kind}")
 
 

@@ -68,7 +68,8 @@ def unexpected_scratch(resources=None):
 
 
 def build(force=False, verbose=False, extra_flags=(), jobs=None, out=None):
-    """hipcc --offload-arch=gfx950 -fPIC -c per source (in parallel), then one -shared link; returns the library path.
+    """hipcc --offload-arch=gfx950 -fPIC -c per source (in parallel; a source whose object is newer than everything it includes is
+    not recompiled unless force=True), then one -shared link; returns the library path.
     `extra_flags` / `out`: experiment builds (tools/exp_time.py) get their own object directory (keyed by the flags) and library path,
     so that they neither race with nor overwrite the in-tree build."""
     lib = out or LIB
@@ -86,9 +87,27 @@ def build(force=False, verbose=False, extra_flags=(), jobs=None, out=None):
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-Rpass-analysis=kernel-resource-usage", *extra_flags]
     hipcc = _hipcc()
 
+    def up_to_date(obj):
+        """object, its resource record and every file of its dependency list (-MD) older than it, same flags"""
+        dep, res = obj + ".d", obj + ".res.json"
+        if force or not all(os.path.exists(f) for f in (obj, dep, res)):
+            return None
+        try:
+            rec = json.load(open(res))
+            names = open(dep).read().replace("\\\n", " ").split(":", 1)[1].split()
+            t = os.path.getmtime(obj)
+            if rec.get("flags") != flags or any(os.path.getmtime(n) > t for n in names):
+                return None
+            return rec["resources"]
+        except (OSError, ValueError, KeyError, IndexError):
+            return None
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        cached = up_to_date(obj)
+        if cached is not None:
+            return obj, cached
+        cmd = [hipcc, *flags, "-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -97,7 +116,9 @@ def build(force=False, verbose=False, extra_flags=(), jobs=None, out=None):
         noise = [l for l in p.stderr.splitlines() if "remark:" not in l and "[-Rpass-analysis" not in l and l.strip()]
         if noise and verbose:
             print("\n".join(noise))
-        return obj, _parse_resources(p.stderr)
+        resources = _parse_resources(p.stderr)
+        json.dump({"flags": flags, "resources": resources}, open(obj + ".res.json", "w"))
+        return obj, resources
 
     jobs = jobs or max(1, min(8, os.cpu_count() or 1))
     with ThreadPoolExecutor(max_workers=jobs) as pool:

@@ -1,6 +1,7 @@
 // capi.hip — the extern "C" surface declared in include/opendpd_hip.h: argument validation and
 // dispatch to the backbone families.
 #include "odpd_host.h"
+#include "odpd_xchg.h"
 
 using namespace odpd;
 
@@ -74,6 +75,8 @@ odpd::Tuning& odpd::tuning() {
         v.gp_max_batch = e ? atol(e) : -1;    // -1 = built-in crossover, 0 = never the gate-parallel fused train kernel
         e = getenv("ODPD_CASCADE_ONE_LAUNCH");
         v.cascade_one_launch = e ? atoi(e) : 1;   // 0 = train_dpd steps always as chained launches
+        e = getenv("ODPD_XCHG_FUSED");
+        v.xchg_fused = e ? atoi(e) : 1;           // 0 = the one-shot exchange as its own launch instead of the optimiser kernel's prologue
         return v;
     }();
     return t;
@@ -85,11 +88,12 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
     if (!strcmp(key, "s16_occupancy")) { tuning().s16_occupancy = (int)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "gp_max_batch")) { tuning().gp_max_batch = (long)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "cascade_one_launch")) { tuning().cascade_one_launch = (int)value; ++g_tuning_generation; return 0; }
+    if (!strcmp(key, "xchg_fused")) { tuning().xchg_fused = (int)value; return 0; }      // (no buffer depends on it)
     return ODPD_EINVAL;
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 9; }   // 9: + odpd_cascade_rows, odpd_cascade_fwd_bwd (train_dpd step body in one launch); 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
+extern "C" int odpd_abi_version(void) { return 10; }   // 10: + odpd_xchg_* (one-shot gradient exchange over peer-mapped slots), odpd_clip_optim_step_dp, odpd_comm_kind / _errors; 9: + odpd_cascade_rows, odpd_cascade_fwd_bwd (train_dpd step body in one launch); 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
@@ -352,6 +356,11 @@ inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqA
     if ((s16 || s16n) && !a.ckpt) return ODPD_EINVAL;
     return s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));
 }
+// bf16 sample storage is read by the float GRU family's fused train kernels (stage_in / ld_iq); every other path wants fp32 streams
+inline bool frames_format_ok(const odpd_model_t* m, const odpd_frames_t* fr) {
+    if (fr->sample_format == ODPD_SAMPLES_F32) return true;
+    return fr->sample_format == ODPD_SAMPLES_BF16 && family_of(m) == FAM_GRU;
+}
 }  // namespace
 extern "C" int odpd_framed_train_supported(const odpd_model_t* m) { return model_ok(m) && framed_train_ok(m) ? 1 : 0; }
 extern "C" int odpd_framed_train_supported_shape(const odpd_model_t* m, int B, int T) {
@@ -367,10 +376,10 @@ extern "C" int odpd_train_fwd_bwd_framed(void* stream, const odpd_model_t* m, in
         first < 0 || B <= 0 || first + B > fr->n_frames || count <= 0 || !params || !partials)
         return ODPD_EINVAL;
     const int T = fr->frame_length;
-    if (!framed_train_ok_shape(m, B, T)) return ODPD_EUNSUPPORTED;
+    if (!framed_train_ok_shape(m, B, T) || !frames_format_ok(m, fr)) return ODPD_EUNSUPPORTED;
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = fr->x_stream; a.target = fr->y_stream; a.partials = partials; a.ckpt = workspace;
-    a.frame_idx = (const long long*)(fr->order + first); a.frame_stride = fr->stride;
+    a.frame_idx = (const long long*)(fr->order + first); a.frame_stride = fr->stride; a.frames_bf16 = fr->sample_format == ODPD_SAMPLES_BF16;
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind;
     return framed_train_launch((hipStream_t)stream, m, a);
 }
@@ -385,6 +394,29 @@ extern "C" void odpd_shard_range(int64_t n, int rank, int world, int64_t* lo, in
     *lo = rank * base + (rank < rem ? rank : rem);
     *hi = *lo + base + (rank < rem ? 1 : 0);
 }
+// the tail of every data-parallel step: all-reduce of grad[0 .. P+4) over `comm` (NULL = one process), then clip + optimiser
+// (opt_kind < 0: AdamW with the given hyper-parameters, else an enum odpd_optimizer kind).  A one-shot communicator's exchange runs as
+// the optimiser kernel's prologue (one launch for both); RCCL's all-reduce is enqueued in front of it.
+static int dp_clip_step(hipStream_t st, void* comm, int opt_kind, int64_t P, float* params, float* grad, float* state1, float* state2,
+                        int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, float* norm_out,
+                        float* loss_out, float inv_count, const unsigned char* skip) {
+    XchgDev xd;
+    const XchgDev* xp = nullptr;
+    if (comm) {
+        if (tuning().xchg_fused && comm_next_xchg(comm, P + kLossCols, &xd)) xp = &xd;
+        else if (int rc = comm_allreduce(st, comm, grad, P + kLossCols)) return rc;
+    }
+    return opt_kind < 0 ? launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, norm_out,
+                                            loss_out, inv_count, skip, xp)
+                        : launch_clip_optim(st, opt_kind, P, params, grad, state1, state2, step, lr, max_norm, norm_out, loss_out, inv_count, skip, xp);
+}
+extern "C" int odpd_clip_optim_step_dp(void* stream, void* comm, int opt_kind, int64_t P, float* params, float* grad, float* state1, float* state2,
+                                       int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                                       float* norm_out, const unsigned char* skip) {
+    if (opt_kind > ODPD_OPT_RMSPROP) return ODPD_EINVAL;
+    return dp_clip_step((hipStream_t)stream, comm, opt_kind < 0 ? -1 : opt_kind, P, params, grad, state1, state2, step, lr, beta1, beta2, eps,
+                        weight_decay, max_norm, norm_out, nullptr, 0.0f, skip);
+}
 // comm != NULL: every global batch sharded over the communicator's ranks, one all-reduce of grad[0 .. P+4) per step
 static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch, float* params, float* grad,
                             float* state1, float* state2, int64_t first_step, int opt_kind, double lr, double beta1, double beta2, double eps,
@@ -393,6 +425,7 @@ static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, 
         fr->stride <= 0 || batch <= 0 || !params || !grad || !state1 || !state2 || !partials || !losses_out || first_step <= 0)
         return ODPD_EINVAL;
     const int T = fr->frame_length;
+    if (!frames_format_ok(m, fr)) return ODPD_EUNSUPPORTED;
     const int rank = comm ? comm_rank(comm) : 0, world = comm ? comm_world(comm) : 1;
     {   // every (shard of a) batch of the epoch — the full ones and the tail — must have a frame-reading fused kernel
         const int64_t full = fr->n_frames < batch ? fr->n_frames : batch, tail = fr->n_frames % batch;
@@ -420,6 +453,7 @@ static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, 
             SeqArgs a = make_args(m, B, T);
             a.params = params; a.x = fr->x_stream; a.target = fr->y_stream; a.partials = partials; a.ckpt = workspace;
             a.frame_idx = (const long long*)(fr->order + f0 + lo); a.frame_stride = fr->stride;
+            a.frames_bf16 = fr->sample_format == ODPD_SAMPLES_BF16;
             a.inv_count = inv_count; a.loss_kind = loss_kind;
             rc = framed_train_launch(st, m, a);
             if (rc) return rc;
@@ -429,15 +463,8 @@ static int train_epoch_impl(void* stream, const odpd_model_t* m, int loss_kind, 
             rc = (int)hipMemsetAsync(grad, 0, (size_t)(P + kLossCols) * sizeof(float), st);
             if (rc) return rc;
         }
-        if (comm) {
-            rc = comm_allreduce(st, comm, grad, P + kLossCols);
-            if (rc) return rc;
-        }
-        SeqArgs a{};
-        a.inv_count = inv_count;
-        rc = opt_kind < 0 ? launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
-                                              losses_out + i, a.inv_count)
-                          : launch_clip_optim(st, opt_kind, P, params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, a.inv_count);
+        rc = dp_clip_step(st, comm, opt_kind, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
+                          losses_out + i, inv_count, nullptr);
         if (rc) return rc;
     }
     return 0;
@@ -453,6 +480,7 @@ extern "C" int odpd_train_epoch_cascade(void* stream, void* comm, const odpd_mod
         fr->stride <= 0 || batch <= 0 || !dpd_params || !pa_params || !grad || !state1 || !state2 || !partials || !losses_out || first_step <= 0 ||
         opt_kind > ODPD_OPT_RMSPROP)
         return ODPD_EINVAL;
+    if (fr->sample_format != ODPD_SAMPLES_F32) return ODPD_EUNSUPPORTED;
     const int T = fr->frame_length;
     const int rank = comm ? comm_rank(comm) : 0, world = comm ? comm_world(comm) : 1;
     const int64_t full = fr->n_frames < batch ? fr->n_frames : batch, tail = fr->n_frames % batch;
@@ -483,14 +511,8 @@ extern "C" int odpd_train_epoch_cascade(void* stream, void* comm, const odpd_mod
             rc = (int)hipMemsetAsync(grad, 0, (size_t)(P + kLossCols) * sizeof(float), st);
             if (rc) return rc;
         }
-        if (comm) {
-            rc = comm_allreduce(st, comm, grad, P + kLossCols);
-            if (rc) return rc;
-        }
-        rc = opt_kind < 0 ? launch_clip_adamw(st, P, dpd_params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
-                                              losses_out + i, inv_count, skip)
-                          : launch_clip_optim(st, opt_kind, P, dpd_params, grad, state1, state2, step, lr, max_norm, nullptr, losses_out + i, inv_count,
-                                              skip);
+        rc = dp_clip_step(st, comm, opt_kind, P, dpd_params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, nullptr,
+                          losses_out + i, inv_count, skip);
         if (rc) return rc;
     }
     return 0;
@@ -519,6 +541,7 @@ extern "C" int odpd_train_epoch_split(void* stream, const odpd_model_t* m, int l
         fr->stride <= 0 || batch <= 0 || !params || !grad || !state1 || !state2 || !xbuf || !tbuf || !ybuf || !dybuf || !partials ||
         !loss_scratch || !losses_out || first_step <= 0 || opt_kind > ODPD_OPT_RMSPROP)
         return ODPD_EINVAL;
+    if (fr->sample_format != ODPD_SAMPLES_F32) return ODPD_EUNSUPPORTED;
     const int T = fr->frame_length;
     const int64_t P = odpd_param_count(m);
     if (P <= 0) return P < 0 ? (int)P : ODPD_EUNSUPPORTED;

@@ -665,9 +665,9 @@ __device__ __forceinline__ void gru_bwd_task(const SeqArgs& a, const GruW<R, Fea
             }
             wave_lds_fence();
             const int len = min(kChunk, a.T - t0);
-            stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride);
+            stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
             if constexpr (FUSED)
-                stage_in<SPW>(dys, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride);
+                stage_in<SPW>(dys, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
             else
                 stage_in<SPW>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
             wave_lds_fence();
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(R == 1 ? kMaxThreads : kMaxThreads / 2, R == 1 ? 2 
             for (int t0 = 0; t0 < a.T; t0 += kChunk) {
                 const int len = min(kChunk, a.T - t0);
                 wave_lds_fence();
-                stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride);
+                stage_in<SPW>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
                 wave_lds_fence();
                 int tt = 0;
                 static_assert(kChunk % S == 0, "chunks start on a checkpoint boundary");
@@ -966,15 +966,16 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
 
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
-        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
-        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        const bool bf = a.frame_idx != nullptr && a.frames_bf16 != 0;          // bf16 sample storage of the resident streams
+        auto xg = [&](int i) { return ld_iq(a.x, base + i, bf); };
+        auto tg = [&](int i) { return ld_iq(a.target, base + i, bf); };
         // ---- forward ----
         {
             float h[NB];
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) h[kb] = 0.0f;
             int park = park0, gpark = gpark0;
-            float2 raw = lane < T ? xg[lane] : make_float2(0.5f, 0.5f);
+            float2 raw = lane < T ? xg(lane) : make_float2(0.5f, 0.5f);
             for (int t0 = 0; t0 < T; t0 += kEvalChunk) {
                 const int len = min(kEvalChunk, T - t0);
                 {
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                     reinterpret_cast<float4*>(ftab)[2 * (t0 + lane) + 1] = make_float4(f8[4], f8[5], f8[6], f8[7]);
                     wave_lds_fence();
                 }
-                raw = t0 + kEvalChunk + lane < T ? xg[t0 + kEvalChunk + lane] : make_float2(0.5f, 0.5f);
+                raw = t0 + kEvalChunk + lane < T ? xg(t0 + kEvalChunk + lane) : make_float2(0.5f, 0.5f);
                 for (int tt = 0; tt < len; ++tt) {
                     float f[F], arec[NB], r1[NB], zz[NB], nn[NB];
                     load_feat(t0 + tt, f);
@@ -1041,7 +1042,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                     y1 = __builtin_fmaf(v0.x, fa.x, y1); y1 = __builtin_fmaf(v0.y, fa.y, y1); y1 = __builtin_fmaf(v0.z, fa.z, y1); y1 = __builtin_fmaf(v0.w, fa.w, y1);
                     y1 = __builtin_fmaf(v1.x, fb.x, y1); y1 = __builtin_fmaf(v1.y, fb.y, y1);
                 }
-                const float2 tv = tg[t];
+                const float2 tv = tg(t);
                 float dy0, dy1;
                 s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
                 *reinterpret_cast<float2*>(dyb + 2 * t) = make_float2(dy0, dy1);
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
 #pragma unroll
                         for (int i = 0; i < 6; ++i) df[i] += __builtin_fmaf(dyv.x, hw[2 * HB + i], dyv.y * hw[2 * HB + 8 + i]);
                     }
-                    const float2 xv = xg[t];
+                    const float2 xv = xg(t);
                     float dI, dQ;
                     feat_bwd<FM>(xv.x, xv.y, df, dI, dQ);
                     dxg[t] = make_float2(dI, dQ);

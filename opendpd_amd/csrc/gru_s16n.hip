@@ -456,7 +456,7 @@ __global__ __launch_bounds__(s16n_two_waves_per_simd(MODE, NW, NCK) ? 512 : 256,
             for (int t0 = 0; t0 < a.T; t0 += kChunk) {
                 const int len = min(kChunk, a.T - t0);
                 wave_lds_fence();
-                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride);
+                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
                 wave_lds_fence();
                 for (int tt = 0; tt < len; ++tt) {
                     const float2 xv = xs[n * kChunkPad + tt];
@@ -514,9 +514,9 @@ __global__ __launch_bounds__(s16n_two_waves_per_simd(MODE, NW, NCK) ? 512 : 256,
                     }
                     wave_lds_fence();
                     const int len = min(kChunk, a.T - t0);
-                    stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride);
+                    stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
                     if constexpr (MODE == 0)
-                        stage_in<16>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride);
+                        stage_in<16>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
                     else
                         stage_in<16>(ts, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
                     wave_lds_fence();

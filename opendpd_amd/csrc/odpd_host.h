@@ -54,7 +54,7 @@ inline LaunchShape persistent_shape(int ngroups, int waves_per_cu, int max_waves
 }
 
 // run-time tuning knobs (odpd_set_tuning; initialised from $ODPD_S16_MIN_BATCH / $ODPD_S16_OCCUPANCY)
-struct Tuning { long s16_min_batch; int s16_occupancy; long gp_max_batch; int cascade_one_launch; };
+struct Tuning { long s16_min_batch; int s16_occupancy; long gp_max_batch; int cascade_one_launch; int xchg_fused; };
 Tuning& tuning();
 
 // ---- parameter layouts (flattened named_parameters() order of the reference modules) -------------
@@ -134,16 +134,21 @@ struct SeqArgs {
     // frame_idx != NULL, sequence b of x / target starts at sample frame_idx[b] * frame_stride of the (N,2) stream
     const long long* frame_idx;
     int frame_stride;
+    int frames_bf16;      // frame_idx != NULL: the streams hold bf16 (I, Q) pairs, 4 bytes per sample (odpd_frames_t::sample_format)
     float inv_count;      // 1 / global element count (fused loss)
     float thx, thh;
     int loss_kind;
     int B, T, H, ngroups, nck;
 };
 
-// comm.hip: RCCL communicator of the data-parallel step
+// comm.hip: communicator of the data-parallel step (one-shot exchange over peer-mapped slots, or RCCL)
+struct XchgDev;                                                          // odpd_xchg.h
 int comm_allreduce(hipStream_t st, void* comm, float* buf, int64_t n);     // in-place sum of n floats over the ranks, on the stream
 int comm_rank(void* comm);
 int comm_world(void* comm);
+// one-shot communicators: the NEXT exchange as a kernel argument, for a kernel that folds it into its prologue (optim.hip) — false
+// for an RCCL communicator or n > kXchgMaxFloats (the caller then enqueues comm_allreduce).  Advances the sequence: call once per step.
+bool comm_next_xchg(void* comm, int64_t n, XchgDev* out);
 
 // family entry points (defined in the family .hip files)
 int gru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
@@ -192,10 +197,12 @@ int64_t gru_s16n_ckpt_floats(const odpd_model_t* m, int B, int T);
 // optim.hip: clip + AdamW launch that also records loss = grad[P] * inv_count into loss_out (nullable)
 int launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t step,
                       double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, float* norm_out,
-                      float* loss_out, float inv_count, const unsigned char* skip = nullptr);
+                      float* loss_out, float inv_count, const unsigned char* skip = nullptr, const XchgDev* xchg = nullptr);
+// (xchg != NULL: the kernel first all-reduces grad[0 .. P+4) over the ranks through the one-shot exchange)
 // the same for the optimiser kinds of enum odpd_optimizer (project.py:274-297's hyper-parameters)
 int launch_clip_optim(hipStream_t st, int kind, int64_t P, float* params, float* grad, float* state1, float* state2, int64_t step, double lr,
-                      double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip = nullptr);
+                      double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip = nullptr,
+                      const XchgDev* xchg = nullptr);
 int64_t gru_s16_workspace_floats(const odpd_model_t* m, int B, int T);
 int lstm_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);

@@ -59,10 +59,19 @@ __device__ __forceinline__ float tab_rotdot(float acc, TabPtr tlane, int first_r
 // LDS staging of (B,T,2) streams: one chunk = kChunk steps of the wave's SPW sequences,
 // LDS layout [seq][kChunkPad] float2
 // -------------------------------------------------------------------------------------------------
-// `fidx` (nullable): frames are windows of a resident stream, row b starts at sample fidx[b] * fstride
+// one (I, Q) sample of a stream: fp32 pair, or (bf16 storage, BASELINE configs[1]) one 32-bit word = bf16 I | bf16 Q << 16, widened
+// exactly — the arithmetic stays fp32 on the values the stream holds
+__device__ __forceinline__ float2 ld_iq(const float* g, size_t i, bool bf16) {
+    if (bf16) {
+        const unsigned w = reinterpret_cast<const unsigned*>(g)[i];
+        return make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
+    }
+    return reinterpret_cast<const float2*>(g)[i];
+}
+// `fidx` (nullable): frames are windows of a resident stream, row b starts at sample fidx[b] * fstride; `bf16`: its sample format
 template <int SPW>
 __device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane,
-                                         float2 fill, const long long* fidx = nullptr, int fstride = 0) {
+                                         float2 fill, const long long* fidx = nullptr, int fstride = 0, bool bf16 = false) {
     const float2* g2 = reinterpret_cast<const float2*>(g);
     constexpr int N = SPW * kChunk / 64;   // float2 per lane
     static_assert(N >= 1 && (SPW * kChunk) % 64 == 0, "chunk must tile the wave");
@@ -72,7 +81,7 @@ __device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, in
         float2 v = fill;
         if (tt < len && b0 + m < B) {
             const size_t row = fidx ? (size_t)fidx[b0 + m] * fstride : (size_t)(b0 + m) * T;
-            v = g2[row + t0 + tt];
+            v = bf16 ? ld_iq(g, row + t0 + tt, true) : g2[row + t0 + tt];
         }
         lds[m * kChunkPad + tt] = v;
     }

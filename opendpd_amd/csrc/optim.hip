@@ -4,6 +4,7 @@
 //               torch.optim.AdamW single-tensor update (project.py:283; torch/optim/adam.py
 //               _single_tensor_adam: lerp_, addcmul_, bias corrections in double, addcdiv_).
 #include "odpd_host.h"
+#include "odpd_xchg.h"
 
 namespace odpd {
 
@@ -136,9 +137,13 @@ __global__ __launch_bounds__(1024) void clip_optim_kernel(int kind, int64_t P, f
                                                           float bc2_sqrt, float decay, float w1, float b2, float w2,
                                                           float eps, float max_norm, float* __restrict__ norm_out,
                                                           float* __restrict__ loss_out, float inv_count,
-                                                          const unsigned char* __restrict__ skip, int first_step) {
+                                                          const unsigned char* __restrict__ skip, int first_step, int n_xchg,
+                                                          XchgDev xd) {
     __shared__ float sh[16];
     __shared__ float coef_s;
+    // data parallel over a one-shot communicator: the step's collective is this kernel's prologue — g[0 .. P+4) becomes the sum over
+    // the ranks (gradient + loss partial sum), identical bits on every rank
+    if (n_xchg > 0) xchg_allreduce_block(xd, g, n_xchg);
     if (loss_out && threadIdx.x == 0) loss_out[0] = g[P] * inv_count;   // column P of the reduced row = loss partial sum
     float acc = 0.f;
     // skip[i] != 0: a parameter whose .grad is None in the reference — outside the norm, untouched by the update
@@ -209,7 +214,7 @@ extern "C" int odpd_reduce_partials(void* stream, int64_t rows, int64_t P, const
 
 int odpd::launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq,
                             int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay,
-                            double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip) {
+                            double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip, const XchgDev* xchg) {
     if (!params || !grad || !exp_avg || !exp_avg_sq || P <= 0 || step <= 0) return ODPD_EINVAL;
     // bias corrections in double like torch/optim/adam.py (_single_tensor_adam), rounded to fp32 once
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
@@ -217,16 +222,18 @@ int odpd::launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* gra
     const float decay = (float)(1.0 - lr * weight_decay);
     const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
     hipLaunchKernelGGL(clip_optim_kernel, dim3(1), dim3(1024), 0, st, (int)ODPD_OPT_ADAMW, P, params, grad, exp_avg, exp_avg_sq, step_size,
-                       bc2s, decay, w1, (float)beta2, w2, (float)eps, (float)max_norm, norm_out, loss_out, inv_count, skip, 0);
+                       bc2s, decay, w1, (float)beta2, w2, (float)eps, (float)max_norm, norm_out, loss_out, inv_count, skip, 0,
+                       xchg ? (int)(P + kLossCols) : 0, xchg ? *xchg : XchgDev{});
     return (int)hipGetLastError();
 }
 
 // the optimisers of project.py:274-297 with the hyper-parameters the reference constructs them with
 int odpd::launch_clip_optim(hipStream_t st, int kind, int64_t P, float* params, float* grad, float* state1, float* state2, int64_t step,
-                            double lr, double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip) {
+                            double lr, double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip,
+                            const XchgDev* xchg) {
     switch (kind) {
-    case ODPD_OPT_ADAMW: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.01, max_norm, norm_out, loss_out, inv_count, skip);
-    case ODPD_OPT_ADAM: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.0, max_norm, norm_out, loss_out, inv_count, skip);
+    case ODPD_OPT_ADAMW: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.01, max_norm, norm_out, loss_out, inv_count, skip, xchg);
+    case ODPD_OPT_ADAM: return launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, 0.9, 0.999, 1e-8, 0.0, max_norm, norm_out, loss_out, inv_count, skip, xchg);
     case ODPD_OPT_SGD: case ODPD_OPT_RMSPROP: break;
     default: return ODPD_EINVAL;
     }
@@ -234,7 +241,8 @@ int odpd::launch_clip_optim(hipStream_t st, int kind, int64_t P, float* params, 
     const bool sgd = kind == ODPD_OPT_SGD;
     const float b2 = sgd ? 0.9f : 0.99f, w2 = sgd ? 0.0f : (float)(1.0 - 0.99);
     hipLaunchKernelGGL(clip_optim_kernel, dim3(1), dim3(1024), 0, st, kind, P, params, grad, state1, state2, (float)lr, 1.0f, 1.0f, 0.0f, b2, w2,
-                       1e-8f, (float)max_norm, norm_out, loss_out, inv_count, skip, step == 1 ? 1 : 0);
+                       1e-8f, (float)max_norm, norm_out, loss_out, inv_count, skip, step == 1 ? 1 : 0, xchg ? (int)(P + kLossCols) : 0,
+                       xchg ? *xchg : XchgDev{});
     return (int)hipGetLastError();
 }
 extern "C" int odpd_clip_optim_step(void* stream, int kind, int64_t P, float* params, float* grad, float* state1, float* state2,

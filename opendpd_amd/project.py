@@ -30,7 +30,10 @@ DEFAULTS = dict(  # arguments.py:8-89
     loss_type="l2", opt_type="adamw", batch_size=256, batch_size_eval=256, n_epochs=100, lr_schedule=0, lr=5e-4,
     lr_end=1e-4, decay_factor=0.1, patience=10, grad_clip_val=200, K=4, PA_backbone="gru", PA_hidden_size=23,
     PA_num_layers=1, DPD_backbone="gru", DPD_hidden_size=15, DPD_num_layers=1, quant=False, n_bits_w=8, n_bits_a=8,
-    pretrained_model="", quant_dir_label="", q_pretrain=False, thx=0.0, thh=0.0, num_dvr_units=3, window_size=4)
+    pretrained_model="", quant_dir_label="", q_pretrain=False, thx=0.0, thh=0.0, num_dvr_units=3, window_size=4,
+    # not in the reference: storage of the resident TRAINING streams on the device — "fp32" (the reference's data, default) or "bf16"
+    # (BASELINE configs[1]: 4 bytes per I/Q sample; the kernels widen exactly and compute in fp32; GRU-family train_pa only)
+    frame_storage="fp32")
 
 
 def count_net_params(net):
@@ -45,14 +48,19 @@ class DeviceFrameLoader:
     DataLoader(train_set, shuffle=True) (project.py:236) — tests/test_api_cpu.py compares it with a real DataLoader; each step is then two index_select launches on an
     overlapping-window view of the stream and no host<->device traffic."""
 
-    def __init__(self, x, y, frame_length, stride, batch_size, device, shuffle=True):
-        self.x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device).contiguous()
-        self.y = torch.as_tensor(np.asarray(y), dtype=torch.float32).to(device).contiguous()
+    def __init__(self, x, y, frame_length, stride, batch_size, device, shuffle=True, storage="fp32"):
+        if storage not in ("fp32", "bf16"):
+            raise ValueError(f"frame_storage={storage!r}: expected 'fp32' or 'bf16'")
+        # storage="bf16": the resident streams hold bf16 (I, Q) pairs (round-to-nearest-even of the data, 4 bytes per sample); the
+        # fused kernels read them in place (odpd_frames_t.sample_format) and batches gathered for the generic path are widened to fp32
+        dt = torch.bfloat16 if storage == "bf16" else torch.float32
+        self.x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device).to(dt).contiguous()
+        self.y = torch.as_tensor(np.asarray(y), dtype=torch.float32).to(device).to(dt).contiguous()
         self.n = (len(x) - frame_length) // stride + 1
         self.batch_size, self.device, self.frame_length, self.stride = batch_size, device, frame_length, stride
         win = lambda s: torch.as_strided(s, (self.n, frame_length, 2), (2 * stride, 2, 1))
         self.fx, self.fy = win(self.x), win(self.y)
-        self.shuffle = shuffle
+        self.shuffle, self.storage = shuffle, storage
 
     def __len__(self):
         return (self.n + self.batch_size - 1) // self.batch_size
@@ -73,7 +81,7 @@ class DeviceFrameLoader:
         order = self.epoch_order()
         for i in range(0, self.n, self.batch_size):
             idx = order[i:i + self.batch_size]
-            yield self.fx.index_select(0, idx), self.fy.index_select(0, idx)
+            yield self.fx.index_select(0, idx).float(), self.fy.index_select(0, idx).float()
 
 
 class ReduceLROnPlateau:
@@ -202,7 +210,8 @@ class Project:
         self.target_gain = D.set_target_gain(Xtr, ytr)
         if self.step == "train_dpd":
             ytr, yv, yte = self.target_gain * Xtr, self.target_gain * Xv, self.target_gain * Xte
-        train = DeviceFrameLoader(Xtr, ytr, self.frame_length, self.frame_stride, self.batch_size, self.device, shuffle=True)
+        train = DeviceFrameLoader(Xtr, ytr, self.frame_length, self.frame_stride, self.batch_size, self.device, shuffle=True,
+                                  storage=self.frame_storage)
         val = DataLoader(D.IQSegmentDataset(Xv, yv, nperseg=self.args.nperseg), batch_size=self.batch_size_eval, shuffle=False)
         test = DataLoader(D.IQSegmentDataset(Xte, yte, nperseg=self.args.nperseg), batch_size=self.batch_size_eval, shuffle=False)
         return (train, val, test), Xtr.shape[-1]

@@ -23,6 +23,13 @@ from .dist import shard_range
 from .models import CascadedModel, CoreModel
 
 
+def _sample_format(x_stream, y_stream):
+    """enum odpd_sample_format of a pair of resident (N,2) streams: fp32, or bf16 pairs (one 32-bit word per I/Q sample)"""
+    if x_stream.dtype != y_stream.dtype or x_stream.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"resident streams must both be float32 or both bfloat16 (got {x_stream.dtype}, {y_stream.dtype})")
+    return _lib.SAMPLES_BF16 if x_stream.dtype == torch.bfloat16 else _lib.SAMPLES_F32
+
+
 def _loss_kind(criterion):
     if isinstance(criterion, nn.MSELoss) and criterion.reduction == "mean":
         return "l2"
@@ -209,19 +216,41 @@ class FusedAdamW:
         dev = self.backbone.flat_params().device
         self._ensure(dev)
         self.grad.zero_()
-        self.allreduce_grad()
-        loss = self.grad[self.backbone.n_flat] / count
-        self.apply(max_norm)
-        return loss
+        self.reduce_and_apply(max_norm)
+        return self.grad[self.backbone.n_flat] / count
 
-    def apply(self, max_norm, stream=None):
-        """clip (max_norm, 0 = off) + AdamW on the flat buffers; self.grad must hold the global gradient."""
+    def reduce_and_apply(self, max_norm, stream=None):
+        """The tail of a data-parallel step: all-reduce of self.grad (this rank's gradient + loss partial sum) over the ranks, then
+        clip + optimiser.  With a library-owned communicator both go to the library in ONE call (odpd_clip_optim_step_dp: the one-shot
+        exchange is the optimiser kernel's prologue; RCCL's all-reduce is enqueued in front of it); else torch.distributed, then apply()."""
+        comm = self.native_comm()
+        if comm is None:
+            self.allreduce_grad()
+        self.apply(max_norm, stream, comm=comm)
+
+    def apply(self, max_norm, stream=None, comm=None):
+        """clip (max_norm, 0 = off) + AdamW on the flat buffers; self.grad must hold the global gradient — or, with `comm` (a
+        dist.NativeComm), this rank's share of it: the library then sums over the ranks first."""
         lib = _lib.load()
         g = self.param_groups[0]
         self.step_count += 1
         flat = self.backbone.flat_params()
         if stream is None:
             stream = _lib.stream_ptr()
+        if comm is not None:
+            frozen = getattr(self.backbone, "frozen_mask", None)
+            if frozen is not None and (frozen.device != flat.device or frozen.dtype != torch.uint8):
+                self.backbone.frozen_mask = frozen = frozen.to(device=flat.device, dtype=torch.uint8).contiguous()
+            adamw = self.kind == "adamw"
+            rc = lib.odpd_clip_optim_step_dp(stream, comm.handle, -1 if adamw else _lib.OPTIMIZER_IDS[self.kind], self.backbone.n_flat,
+                                             _lib.ptr(flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                             self.step_count, float(g["lr"]), float(g["betas"][0]) if adamw else 0.0,
+                                             float(g["betas"][1]) if adamw else 0.0, float(g["eps"]) if adamw else 0.0,
+                                             float(g["weight_decay"]) if adamw else 0.0, float(max_norm or 0.0), _lib.ptr(self.norm),
+                                             _lib.ptr(frozen) if frozen is not None else None)
+            if rc:
+                _lib.check(rc, "odpd_clip_optim_step_dp")
+            return
         frozen = getattr(self.backbone, "frozen_mask", None)     # parameters torch.optim.AdamW would skip (grad is None)
         if frozen is not None and (frozen.device != flat.device or frozen.dtype != torch.uint8):
             # one byte per parameter, resident next to the parameters: the kernel skips those columns (no host sync, no extra launch)
@@ -253,6 +282,8 @@ class FusedAdamW:
         if not (self.pa is None and getattr(self.backbone, "frozen_mask", None) is None
                 and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size")) and loader.x.is_cuda):
             return False
+        if loader.x.dtype == torch.bfloat16 and not self.reads_bf16_frames():
+            return False
         if self.world_size() > 1 or self.native_comm() is not None:
             # sharded epoch from C++ (odpd_train_epoch_dp): needs the library-owned RCCL communicator and fused kernels for this rank's shards
             return self.native_comm() is not None and all(self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length)
@@ -270,13 +301,17 @@ class FusedAdamW:
         (odpd_framed_train_supported_shape)."""
         return bool(_lib.load().odpd_framed_train_supported_shape(C.byref(self.backbone.desc), B, T))
 
+    def reads_bf16_frames(self):
+        """bf16 sample storage is read in place by the float GRU family's fused train kernels only"""
+        return self.pa is None and self.backbone.backbone_name in ("gru", "dgru", "qgru", "qgru_amp1") and self.backbone.desc.bits_w == 0
+
     def can_run_split_epoch(self, loader):
         """True when odpd_train_epoch_split can drive a whole epoch: a single backbone WITHOUT a frame-reading fused kernel for the
         epoch's batch shapes, one process, resident streams (the forward / loss / backward / reduce / optimiser chain per step then
         runs from C++ instead of from Python)."""
         return (self.pa is None and self.world_size() == 1 and not self.can_run_epoch(loader)
                 and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size"))
-                and loader.x.is_cuda and hasattr(self.backbone, "desc"))
+                and loader.x.is_cuda and loader.x.dtype == torch.float32 and hasattr(self.backbone, "desc"))
 
     def train_epoch_split(self, loader, loss_kind, max_norm):
         """One epoch through odpd_train_epoch_split: returns the per-batch mean losses (device tensor)."""
@@ -301,7 +336,7 @@ class FusedAdamW:
         buf = self.cascade_buffers(B, T, dev)
         order = loader.epoch_order()
         losses = torch.empty(n_steps, dtype=torch.float32, device=dev)
-        fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
+        fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride, _sample_format(loader.x, loader.y), 0)
         g = self.param_groups[0]
         flat = bb.flat_params(full_check=True)
         frozen = getattr(bb, "frozen_mask", None)
@@ -325,7 +360,8 @@ class FusedAdamW:
         """True when odpd_train_epoch_cascade can drive a whole train_dpd epoch: frozen PA behind the trained DPD, every batch of the epoch
         served by the one-launch cascade step, one process, resident streams."""
         if not (self.pa is not None
-                and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size")) and loader.x.is_cuda):
+                and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size")) and loader.x.is_cuda
+                and loader.x.dtype == torch.float32):
             return False
         dev = loader.x.device
         if self.world_size() > 1 or self.native_comm() is not None:
@@ -344,10 +380,13 @@ class FusedAdamW:
         n_steps = (n + B - 1) // B
         comm = self.native_comm()
         sizes = self._shard_sizes(loader) if comm is not None else self._epoch_batches(loader)
-        part = max((self.cascade_one_launch(b, T, dev) for b in sizes), key=lambda p: p.shape[0])
+        if sizes:
+            part = max((self.cascade_one_launch(b, T, dev) for b in sizes), key=lambda p: p.shape[0])
+        else:       # a rank all of whose shards are empty (global batch smaller than the world): it still joins every all-reduce
+            part = torch.empty(1, dpd.n_flat + _lib.LOSS_COLS, dtype=torch.float32, device=dev)
         order = loader.epoch_order()
         losses = torch.empty(n_steps, dtype=torch.float32, device=dev)
-        fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
+        fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride, _sample_format(loader.x, loader.y), 0)
         g = self.param_groups[0]
         adamw = self.kind == "adamw"
         flat = dpd.flat_params(full_check=True)
@@ -390,7 +429,7 @@ class FusedAdamW:
         part, ws = self._partials[key]
         order = loader.epoch_order()
         losses = torch.empty(n_steps, dtype=torch.float32, device=dev)
-        fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride)
+        fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride, _sample_format(loader.x, loader.y), 0)
         g = self.param_groups[0]
         flat = self.backbone.flat_params(full_check=True)
         if comm is not None:
@@ -423,8 +462,7 @@ class FusedAdamW:
         self._ensure(ps[0].device)
         with torch.no_grad():
             torch.cat([p.grad.reshape(-1) for p in ps], out=self.grad[:self.backbone.n_flat])
-        self.allreduce_grad()
-        self.apply(max_norm)
+        self.reduce_and_apply(max_norm)
 
 
 class FrameBatch:
@@ -434,7 +472,8 @@ class FrameBatch:
     def __init__(self, x_stream, y_stream, order, frame_length, stride=1):
         self.x, self.y, self.order, self.T, self.stride = x_stream.contiguous(), y_stream.contiguous(), order.contiguous(), frame_length, stride
         assert self.x.is_cuda and self.order.dtype == torch.int64
-        self.desc = _lib.Frames(self.x.data_ptr(), self.y.data_ptr(), self.order.data_ptr(), self.order.numel(), frame_length, stride)
+        self.desc = _lib.Frames(self.x.data_ptr(), self.y.data_ptr(), self.order.data_ptr(), self.order.numel(), frame_length, stride,
+                                _sample_format(self.x, self.y), 0)
         self.shape = (self.order.numel(), frame_length, 2)
         self.device = self.x.device
 
@@ -502,10 +541,8 @@ def fused_train_step(opt, x, target, loss_kind="l2", grad_clip_val=0.0, global_c
     rc = lib.odpd_reduce_partials(st, part.shape[0], bb.n_flat, _lib.ptr(part), _lib.ptr(opt.grad), 0)
     if rc:
         _lib.check(rc, "odpd_reduce_partials")
-    opt.allreduce_grad()
-    loss = opt.grad[bb.n_flat] / count      # column P = sum of squared / absolute errors
-    opt.apply(grad_clip_val, st)
-    return loss
+    opt.reduce_and_apply(grad_clip_val, st)
+    return opt.grad[bb.n_flat] / count      # column P = sum of squared / absolute errors (summed over the ranks with the gradient)
 
 
 def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count, timing=None):
@@ -549,9 +586,8 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count, timing=
         mark("reduce_clip_optimiser")
         # (column P of the rows = loss partial sums: the reduced loss travels with the gradient through the one all-reduce)
         _lib.check(lib.odpd_reduce_partials(st, one.shape[0], dpd.n_flat, _lib.ptr(one), _lib.ptr(opt.grad), 0), "reduce")
-        opt.allreduce_grad()
+        opt.reduce_and_apply(grad_clip_val)
         loss = opt.grad[dpd.n_flat] / count
-        opt.apply(grad_clip_val)
         mark()
         return loss
     buf = opt.cascade_buffers(B, T, x.device)
@@ -589,9 +625,8 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count, timing=
     # loss scalar travels with the gradient (column P) so that one all-reduce covers both:
     # grad[P] = sum of errors of this rank = mean * count
     opt.grad[dpd.n_flat] = loss_sum if loss_sum is not None else buf["loss"][0] * count
-    opt.allreduce_grad()
+    opt.reduce_and_apply(grad_clip_val)
     loss = opt.grad[dpd.n_flat] / count
-    opt.apply(grad_clip_val)
     mark()
     return loss
 

@@ -85,3 +85,110 @@ def test_shard_ranges_cover_batch():
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- building the library-owned communicator is a COLLECTIVE decision (a rank that fell back on its own would meet its peers
+# in mismatched collectives) ------------------------------------------------------------------------------------------------------------
+class _FakeLib:
+    """stands in for libopendpd_hip.so: every stage's return code is scripted per rank; records what was called"""
+
+    def __init__(self, rank, script):
+        self.rank, self.script, self.calls = rank, script, []
+
+    def _rc(self, name):
+        self.calls.append(name)
+        return self.script.get(name, {}).get(self.rank, 0)
+
+    def odpd_comm_unique_id(self, buf):
+        return self._rc("unique_id")
+
+    def odpd_comm_init(self, raw, world, rank, out):
+        out._obj.value = 0x1000          # (a non-NULL handle, as the library hands out)
+        return self._rc("init")
+
+    def odpd_xchg_create(self, world, rank, name, out, h64):
+        out._obj.value = 0x1000
+        return self._rc("create")
+
+    def odpd_xchg_connect(self, handle, raw):
+        return self._rc("connect")
+
+    def odpd_xchg_unlink(self, handle):
+        return self._rc("unlink")
+
+    def odpd_comm_destroy(self, handle):
+        return self._rc("destroy")
+
+    def odpd_comm_errors(self, handle):
+        return self._rc("errors")
+
+    def odpd_comm_allreduce_sum(self, *a):
+        return self._rc("allreduce")
+
+
+def _comm_worker(rank, world, port, kind, script, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ODPD_COMM=kind)
+    from opendpd_amd import _lib
+    odist.init("gloo")
+    fake = _FakeLib(rank, script)
+    _lib.load = lambda: fake
+    _lib.stream_ptr = lambda: None
+    _lib.ptr = lambda t: None
+    comm = odist.native_comm(torch.device("cpu"))
+    # whatever was decided, the ranks are still in step: a collective on the default group completes with the right sum
+    buf = torch.full((5,), float(rank + 1))
+    odist.allreduce_sum_(buf)
+    q.put((rank, comm is not None, list(fake.calls), buf.tolist()))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,script,stage_reached", [
+    ("xchg", {"create": {1: -3}}, "create"),            # rank 1 cannot allocate / export its slots
+    ("xchg", {"connect": {0: -3}}, "connect"),          # rank 0 cannot map a peer
+    ("rccl", {"unique_id": {0: -3}}, "unique_id"),      # rank 0 has no librccl: nobody may enter ncclCommInitRank
+    ("rccl", {"init": {1: -3}}, "init"),
+    ("xchg_shm", {"errors": {1: 2}}, "errors"),         # the self-test saw time-outs on rank 1
+])
+def test_a_failure_on_one_rank_makes_every_rank_fall_back_together(kind, script, stage_reached):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, kind, script, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, has_comm, calls, buf in res:
+        assert not has_comm, (rank, calls)                       # the common verdict: no library-owned communicator
+        assert buf == [3.0] * 5                                   # and the default group still works (nobody is stuck in another collective)
+        if stage_reached == "unique_id":
+            assert "init" not in calls
+        if stage_reached == "create":
+            assert "connect" not in calls
+    # a rank whose own stage succeeded tore its half down again
+    ok_rank = [r for r in res if script[stage_reached].get(r[0], 0) == 0]
+    if stage_reached in ("connect", "init", "errors"):
+        assert all("destroy" in r[2] for r in res if stage_reached != "init" or r in ok_rank)
+
+
+def test_comm_candidates_policy(monkeypatch):
+    monkeypatch.delenv("ODPD_NATIVE_COMM", raising=False)
+    monkeypatch.delenv("ODPD_COMM", raising=False)
+    assert odist.comm_candidates("nccl", True) == ["xchg", "rccl"]
+    assert odist.comm_candidates("gloo", True) == []
+    assert odist.comm_candidates(None, False) == []
+    monkeypatch.setenv("ODPD_NATIVE_COMM", "1")
+    assert odist.comm_candidates(None, False) == ["rccl"]
+    monkeypatch.setenv("ODPD_NATIVE_COMM", "0")
+    assert odist.comm_candidates("nccl", True) == []
+    monkeypatch.delenv("ODPD_NATIVE_COMM")
+    for mode in ("xchg", "xchg_shm", "rccl"):
+        monkeypatch.setenv("ODPD_COMM", mode)
+        assert odist.comm_candidates("gloo", True) == [mode] and odist.comm_candidates(None, False) == [mode]
+    monkeypatch.setenv("ODPD_COMM", "torch")
+    assert odist.comm_candidates("nccl", True) == []
+    monkeypatch.setenv("ODPD_COMM", "bogus")
+    with pytest.raises(ValueError):
+        odist.comm_candidates("nccl", True)

@@ -1,8 +1,13 @@
-"""Data-parallel step on the GPU (§8e).  (1) The library-owned RCCL communicator (csrc/comm.hip) on this one-GPU box: a world of one
-rank — librccl is loaded, a communicator initialised, the all-reduce enqueued on the step's stream, and the sharded native epoch loop
-(odpd_train_epoch_dp) reproduces the single-process loop bit for bit.  (2) Two ranks sharing the GPU over gloo: the all-reduced sum of
-the two HIP shard gradients (each normalised by the GLOBAL element count) equals the single-process HIP gradient of the whole batch,
-and both replicas hold bit-identical parameters after the step."""
+"""Data-parallel step on the GPU (§8e).
+(1) One rank, every library-owned communicator (one-shot exchange over hipIpc slots, over host shared memory, RCCL): the collective is
+    really enqueued — ncclAllReduce for a world of one too — and the sharded native epoch loops (odpd_train_epoch_dp,
+    odpd_train_epoch_cascade) reproduce the single-process loops bit for bit.
+(2) Two ranks SHARING the GPU, data plane = the one-shot exchange (control plane gloo): the per-step path and the sharded native epoch
+    loops with world = 2 — frame_idx + shard offsets, uneven and empty shards, the global loss count, the exchange folded into the
+    optimiser kernel — equal the single-process run up to the summation order of the two shards; replicas bit-identical.
+(3) torch.distributed.run with the nccl backend on this one GPU: bench.py's N-rank code path (rendezvous, RCCL process group, id
+    broadcast, communicator, barriers, rank-0 JSON) as the driver launches it.
+(4) Two GPUs (skipped on a one-GPU box): the same comparisons over real RCCL and over the hipIpc exchange between two devices."""
 import ctypes as C
 import json
 import os
@@ -13,55 +18,87 @@ import numpy as np
 import pytest
 import torch
 
+from tests import dp_worker as W
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_PORT = [29540]
 
 
-def _stream(n, seed):
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    x = (torch.rand(n, 2, device="cuda", generator=g) - 0.5) * 1.4
-    x = x + 0.05 * torch.sign(x)
-    y = x * (1.0 - 0.2 * (x * x).sum(-1, keepdim=True)) + 0.05 * torch.roll(x, 1, 0)
-    return x.contiguous(), y.contiguous()
+def _torchrun(nproc, script_args, env, timeout=600):
+    _PORT[0] += 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_PORT[0]), *script_args]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return r
 
 
-class _Loader:
-    """the attributes FusedAdamW.train_epoch reads from project.DeviceFrameLoader"""
+def _ranks(specs, tmp_path, world, comm, backend="gloo", share_gpu=True):
+    """the specs run one after the other by `world` ranks of ONE launch: [spec][rank] -> result dict"""
+    job = dict(specs=specs, backend=backend, share_gpu=share_gpu, out=str(tmp_path / "r"))
+    path = tmp_path / "job.json"
+    path.write_text(json.dumps(job))
+    env = dict(os.environ, ODPD_COMM=comm, ODPD_XCHG_TIMEOUT_MS="20000")
+    env.pop("ODPD_NATIVE_COMM", None)
+    _torchrun(world, [os.path.join(ROOT, "tests", "dp_worker.py"), str(path)], env)
+    return [[dict(np.load(job["out"] + f"_{i}_{k}.npz")) for k in range(world)] for i in range(len(specs))]
 
-    def __init__(self, x, y, T, batch, seed):
-        self.x, self.y, self.frame_length, self.stride, self.batch_size = x, y, T, 1, batch
-        self.n = x.shape[0] - T + 1
-        self._order = torch.randperm(self.n, generator=torch.Generator().manual_seed(seed)).cuda()
 
-    def epoch_order(self):
-        return self._order
+def _single(spec, monkeypatch):
+    from opendpd_amd import dist as odist
+    monkeypatch.setenv("ODPD_COMM", "torch")
+    odist.reset_native_comm()
+    return W.run(spec, torch.device("cuda", 0))
 
 
-@pytest.mark.parametrize("bb,H,batch", [("dgru", 13, 64), ("gru", 11, 37), ("vdlstm", 13, 48)])
-def test_rccl_communicator_of_one_rank_and_the_sharded_epoch_loop(bb, H, batch, monkeypatch):
-    from opendpd_amd import CoreModel, _lib, dist as odist
-    from opendpd_amd.train_funcs import FusedAdamW
+def _check(ranks, ref, comm, what=""):
+    P = len(ref["params"])
+    for r in ranks:
+        assert str(r["comm"]) in (comm if isinstance(comm, tuple) else (comm,)) and int(r["errors"]) == 0, (what, str(r["comm"]), int(r["errors"]))
+    # every rank holds the same bits: reduced buffer, per-step global losses, parameters
+    for k in ("grad", "losses", "params"):
+        for r in ranks[1:]:
+            assert np.array_equal(ranks[0][k], r[k]), (what, k)
+    # ... equal to the single-process run up to the summation order of the shards
+    assert np.abs(ranks[0]["losses"] - ref["losses"]).max() <= 2e-6 * np.abs(ref["losses"]).max(), what
+    assert np.abs(ranks[0]["params"] - ref["params"]).max() <= 3e-6 * np.abs(ref["params"]).max(), what
+    if len(ref["losses"]) == 1:      # one step: the all-reduced gradient itself
+        scale = np.abs(ref["grad"][:P]).max()
+        assert np.abs(ranks[0]["grad"][:P] - ref["grad"][:P]).max() <= 1e-6 * scale, what
+
+
+def _name(s):
+    return f"{s['mode']}-{s['bb']}{s['H']}-B{s['B']}"
+
+
+# ---- (1) one rank -------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("comm", ["xchg", "xchg_shm", "rccl"])
+@pytest.mark.parametrize("spec", [dict(mode="epoch", bb="dgru", H=13, B=64), dict(mode="epoch", bb="gru", H=11, B=37), dict(mode="epoch", bb="vdlstm", H=13, B=48),
+                                  dict(mode="cascade_epoch", bb="gru", H=15, pa_bb="gru", pa_H=23, B=64),
+                                  dict(mode="cascade_epoch", bb="deltagru_tcnskip", H=15, pa_bb="dgru", pa_H=23, B=64)],
+                         ids=lambda s: f"{s['mode']}-{s['bb']}{s['H']}")
+def test_communicator_of_one_rank_and_the_sharded_epoch_loops(spec, comm, monkeypatch):
+    from opendpd_amd import _lib, dist as odist
+    spec = dict(spec, T=50, n=1000)
+    ref = _single(spec, monkeypatch)
+    monkeypatch.setenv("ODPD_COMM", comm)
+    odist.reset_native_comm()
+    got = W.run(spec, torch.device("cuda", 0))
+    assert str(got["comm"]) == comm and int(got["errors"]) == 0
+    assert np.array_equal(got["losses"], ref["losses"]) and np.array_equal(got["params"], ref["params"])
+    # the collective itself, on a buffer: a sum over one rank — through ncclAllReduce / the exchange kernel, not around them
+    native = odist.native_comm()
+    assert native is not None and _lib.load().odpd_comm_kind(native.handle) == {"rccl": 0, "xchg": 1, "xchg_shm": 2}[comm]
+    buf = torch.arange(3000, dtype=torch.float32, device="cuda")
+    native.allreduce_sum_(buf)
+    assert torch.equal(buf.cpu(), torch.arange(3000, dtype=torch.float32))
+    odist.reset_native_comm()
+
+
+def test_shard_ranges_of_the_library_match_the_host_side():
+    from opendpd_amd import _lib, dist as odist
     lib = _lib.load()
-    x, y = _stream(1000, 3)
-    T = 50
-    res = []
-    for native in (False, True):
-        monkeypatch.setenv("ODPD_NATIVE_COMM", "1" if native else "0")
-        odist._native = None
-        torch.manual_seed(0)
-        net = CoreModel(2, H, 1, bb).cuda()
-        opt = FusedAdamW(net, lr=1e-3)
-        loader = _Loader(x, y, T, batch, seed=5)
-        assert opt.can_run_epoch(loader)
-        assert (opt.native_comm() is not None) == native
-        losses = opt.train_epoch(loader, "l2", 200.0)
-        if native:      # the collective itself, on a buffer: a sum over one rank
-            buf = torch.arange(10, dtype=torch.float32, device="cuda")
-            opt.native_comm().allreduce_sum_(buf)
-            assert torch.equal(buf.cpu(), torch.arange(10, dtype=torch.float32))
-        res.append((losses.cpu().numpy(), net.backbone.flat_params().cpu().numpy().copy()))
-    odist._native = None
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     lo, hi = C.c_int64(), C.c_int64()
     got = []
     for r in range(3):
@@ -70,87 +107,72 @@ def test_rccl_communicator_of_one_rank_and_the_sharded_epoch_loop(bb, H, batch, 
     assert got == [odist.shard_range(157, r, 3) for r in range(3)] == [(0, 53), (53, 105), (105, 157)]
 
 
-_WORKER = r"""
-import os, sys, json
-sys.path.insert(0, {root!r})
-import numpy as np, torch
-from opendpd_amd import CoreModel, dist as odist
-from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
-rank, _, world = odist.env_world()
-torch.cuda.set_device(0)
-odist.init("gloo")
-bb, H, B, T = {bb!r}, {H}, {B}, {T}
-g = torch.Generator().manual_seed(7)
-x = ((torch.rand(B, T, 2, generator=g) - 0.5) * 1.4)
-x = (x + 0.05 * torch.sign(x)).cuda()
-t = (torch.rand(B, T, 2, generator=g) - 0.5).cuda()
-torch.manual_seed(0)
-net = CoreModel(2, H, 1, bb).cuda()
-opt = FusedAdamW(net, lr=1e-3)
-lo, hi = odist.shard_range(B, rank, world)
-loss = fused_train_step(opt, x[lo:hi].contiguous(), t[lo:hi].contiguous(), "l2", 200.0, global_count=B * T * 2)
-torch.cuda.synchronize()
-np.savez({out!r} + f"_{{rank}}.npz", grad=opt.grad.cpu().numpy(), params=net.backbone.flat_params().cpu().numpy(), loss=float(loss.item()))
-torch.distributed.destroy_process_group()
-"""
+def test_fused_and_standalone_exchange_agree(monkeypatch):
+    """odpd_set_tuning("xchg_fused", 0): the exchange as its own launch in front of the optimiser kernel — same bits as the prologue form"""
+    from opendpd_amd import _lib, dist as odist
+    spec = dict(mode="epoch", bb="dgru", H=13, B=64, T=50, n=600)
+    monkeypatch.setenv("ODPD_COMM", "xchg")
+    out = []
+    for fused in (1, 0):
+        odist.reset_native_comm()
+        _lib.load().odpd_set_tuning(b"xchg_fused", fused)
+        out.append(W.run(spec, torch.device("cuda", 0)))
+    _lib.load().odpd_set_tuning(b"xchg_fused", 1)
+    odist.reset_native_comm()
+    assert np.array_equal(out[0]["losses"], out[1]["losses"]) and np.array_equal(out[0]["params"], out[1]["params"])
 
 
-@pytest.mark.parametrize("bb,H,B", [("dgru", 13, 64), ("dgru", 13, 7), ("deltagru_tcnskip", 15, 33), ("vdlstm", 13, 50)])
-def test_two_rank_sum_of_hip_shard_gradients_equals_the_full_batch_gradient(bb, H, B, tmp_path):
-    from opendpd_amd import CoreModel
-    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
-    T = 40
-    out = str(tmp_path / "r")
-    script = tmp_path / "w.py"
-    script.write_text(_WORKER.format(root=ROOT, bb=bb, H=H, B=B, T=T, out=out))
-    env = dict(os.environ, ODPD_NATIVE_COMM="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29543", str(script)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    ranks = [dict(np.load(out + f"_{k}.npz")) for k in range(2)]
-    # the single-process step on the whole batch
-    g = torch.Generator().manual_seed(7)
-    x = ((torch.rand(B, T, 2, generator=g) - 0.5) * 1.4)
-    x = (x + 0.05 * torch.sign(x)).cuda()
-    t = (torch.rand(B, T, 2, generator=g) - 0.5).cuda()
-    torch.manual_seed(0)
-    net = CoreModel(2, H, 1, bb).cuda()
-    opt = FusedAdamW(net, lr=1e-3)
-    loss = fused_train_step(opt, x, t, "l2", 200.0)
-    torch.cuda.synchronize()
-    P = net.backbone.n_flat
-    ref_g, ref_p = opt.grad.cpu().numpy(), net.backbone.flat_params().cpu().numpy()
-    # after the all-reduce both ranks hold the same buffer: the global-batch gradient (+ the loss sum in column P)
-    assert np.array_equal(ranks[0]["grad"], ranks[1]["grad"])
-    scale = np.abs(ref_g[:P]).max()
-    assert np.abs(ranks[0]["grad"][:P] - ref_g[:P]).max() <= 1e-6 * scale, np.abs(ranks[0]["grad"][:P] - ref_g[:P]).max() / scale
-    assert abs(ranks[0]["loss"] - float(loss.item())) <= 1e-6 * abs(float(loss.item()))
-    # identical replicas after the step, equal to the single-process result up to the summation order of the two shards
-    assert np.array_equal(ranks[0]["params"], ranks[1]["params"])
-    assert np.abs(ranks[0]["params"] - ref_p).max() <= 2e-6 * np.abs(ref_p).max()
+# ---- (2) two ranks sharing the GPU over the one-shot exchange -------------------------------------------------------------------------
+_STEP_SPECS = [dict(mode="step", bb="dgru", H=13, B=64), dict(mode="step", bb="dgru", H=13, B=7), dict(mode="step", bb="deltagru_tcnskip", H=15, B=33),
+               dict(mode="step", bb="vdlstm", H=13, B=50), dict(mode="step", bb="dgru", H=13, B=1, steps=3),
+               dict(mode="cascade_step", bb="deltagru_tcnskip", H=15, pa_bb="dgru", pa_H=23, B=33)]
+_EPOCH_SPECS = [dict(mode="epoch", bb="dgru", H=13, B=64, n=600), dict(mode="epoch", bb="gru", H=11, B=37, n=500), dict(mode="epoch", bb="vdlstm", H=13, B=49, n=500),
+                dict(mode="epoch", bb="dgru", H=13, B=50, n=140),        # 101 frames: the last global batch is ONE frame -> rank 1's shard is empty
+                dict(mode="cascade_epoch", bb="gru", H=15, pa_bb="gru", pa_H=23, B=64, n=500),
+                dict(mode="cascade_epoch", bb="deltagru_tcnskip", H=15, pa_bb="dgru", pa_H=23, B=33, n=400)]
 
 
-@pytest.mark.parametrize("dpd_bb,dpd_h,pa_bb,pa_h", [("gru", 15, "gru", 23), ("deltagru_tcnskip", 15, "dgru", 23)])
-def test_sharded_cascade_epoch_loop_with_a_communicator_of_one_rank(dpd_bb, dpd_h, pa_bb, pa_h, monkeypatch):
-    """train_dpd under the library-owned communicator: odpd_train_epoch_cascade with comm != NULL (shard ranges, global loss count, the
-    all-reduce enqueued between row reduction and optimiser) reproduces the single-process cascade epoch bit for bit on a world of one."""
-    from opendpd_amd import CascadedModel, CoreModel, dist as odist
-    from opendpd_amd.train_funcs import FusedAdamW
-    x, y = _stream(1000, 3)
-    T = 50
-    res = []
-    for native in (False, True):
-        monkeypatch.setenv("ODPD_NATIVE_COMM", "1" if native else "0")
-        odist._native = None
-        torch.manual_seed(0)
-        net = CascadedModel(dpd_model=CoreModel(2, dpd_h, 1, dpd_bb, thx=0.01, thh=0.05), pa_model=CoreModel(2, pa_h, 1, pa_bb))
-        net.freeze_pa_model()
-        net = net.cuda()
-        opt = FusedAdamW(net, lr=1e-3)
-        loader = _Loader(x, y, T, 64, seed=5)
-        assert opt.can_run_cascade_epoch(loader)
-        assert (opt.native_comm() is not None) == native
-        losses = opt.train_epoch_cascade(loader, "l2", 200.0)
-        res.append((losses.cpu().numpy(), net.dpd_model.backbone.flat_params().cpu().numpy().copy()))
-    odist._native = None
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+@pytest.mark.parametrize("comm", ["xchg", "xchg_shm"])
+def test_two_ranks_on_one_gpu_equal_the_single_process_run(comm, tmp_path, monkeypatch):
+    specs = _STEP_SPECS + _EPOCH_SPECS
+    if comm == "xchg_shm":      # the shared-memory transport runs the same kernels: a subset of the cases covers it
+        specs = [_STEP_SPECS[0], _EPOCH_SPECS[0], _EPOCH_SPECS[3], _EPOCH_SPECS[5]]
+    specs = [dict(s, T=40) for s in specs]
+    got = _ranks(specs, tmp_path, 2, comm)
+    for spec, ranks in zip(specs, got):
+        _check(ranks, _single(spec, monkeypatch), comm, _name(spec))
+
+
+def test_two_ranks_over_gloo_fall_back_to_torch_distributed(tmp_path, monkeypatch):
+    """ODPD_COMM=auto on a gloo group: no library-owned communicator, the per-step torch.distributed all-reduce — same contract"""
+    spec = dict(mode="step", bb="dgru", H=13, B=64, T=40)
+    (ranks,) = _ranks([spec], tmp_path, 2, "auto")
+    _check(ranks, _single(spec, monkeypatch), "torch")
+
+
+# ---- (3) the driver's launch line on one GPU, RCCL process group -------------------------------------------------------------------
+@pytest.mark.parametrize("comm", ["rccl", "xchg"])
+def test_bench_under_torchrun_with_the_nccl_backend_on_one_rank(comm):
+    env = dict(os.environ, ODPD_COMM=comm, ODPD_BENCH_NO_SUSTAINED="1")
+    env.pop("ODPD_NATIVE_COMM", None)
+    r = _torchrun(1, [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4096", "--no-cascade",
+                      "--no-cpu-baseline", "--ref-batch", "0"], env)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and np.isfinite(line["config"]["loss"])
+    assert line["collective"]["kind"] == comm and line["collective"]["process_group"] == "nccl"
+
+
+# ---- (4) two GPUs: RCCL and the hipIpc exchange between devices ------------------------------------------------------------------------
+_TWO_GPU_SPECS = [dict(mode="step", bb="dgru", H=13, B=64), dict(mode="epoch", bb="dgru", H=13, B=64, n=600), dict(mode="epoch", bb="vdlstm", H=13, B=49, n=500),
+                  dict(mode="epoch", bb="dgru", H=13, B=50, n=140),
+                  dict(mode="cascade_epoch", bb="deltagru_tcnskip", H=15, pa_bb="dgru", pa_H=23, B=33, n=400)]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("comm", ["auto", "rccl", "xchg"])
+def test_two_gpus_equal_the_single_process_run(comm, tmp_path, monkeypatch):
+    """dgru, cfg 4's vdlstm and cfg 3's cascade on two devices: all-reduced result == single process, replicas bit-identical"""
+    specs = [dict(s, T=40) for s in _TWO_GPU_SPECS]
+    got = _ranks(specs, tmp_path, 2, comm, backend="nccl", share_gpu=False)
+    for spec, ranks in zip(specs, got):
+        _check(ranks, _single(spec, monkeypatch), ("xchg", "rccl") if comm == "auto" else comm, _name(spec))
