@@ -307,6 +307,23 @@ def main():
         sustained = {"steps": n_s, "seconds": float(el_s_t.item()), "ms_per_step": 1e3 * float(el_s_t.item()) / n_s,
                      "value": world * B * T * n_s / float(el_s_t.item()), "unit": "IQ samples/s"}
 
+    # side figure: BASELINE configs[1]'s "bf16" — the same step with the resident streams STORED as bf16 pairs (4 bytes per I/Q sample,
+    # odpd_frames_t.sample_format; widened exactly, fp32 arithmetic): halves the algorithmic bytes of a step that is compute bound
+    bf16_frames = None
+    if not args.materialized:
+        netb = CoreModel(2, H, 1, "dgru").to(dev)
+        optb = FusedAdamW(netb, lr=5e-4)
+        xb = FrameBatch(xs_.to(torch.bfloat16), ys_.to(torch.bfloat16), torch.arange(B, device=dev, dtype=torch.int64), T, 1)
+        elb, kernb, lossb = run_steps(optb, xb, None, max(3, min(args.steps, 10)), 2, count, dist, events=True)
+        elb_t = torch.tensor([elb], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(elb_t, op=dist.ReduceOp.MAX)
+        nb = max(3, min(args.steps, 10))
+        bf16_frames = {"workload": "the headline step on bf16-stored streams (fp32 arithmetic on the stored values)", "value": world * B * T * nb / float(elb_t.item()),
+                       "unit": "IQ samples/s", "ms_per_step": 1e3 * float(elb_t.item()) / nb, "kernel_ms": kernb, "loss": lossb,
+                       "algorithmic_bytes_per_sample": 8.0}
+        del netb, optb, xb
+
     # side figure: BASELINE configs[3] — train_pa VDLSTM H13, the same batch per GPU, sharded the same way (tensor inputs: its
     # large-batch kernel takes (B,T,2) frames)
     cfg4 = None
@@ -544,6 +561,7 @@ def main():
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * B * T}},
             "sustained": sustained,
+            "bf16_frame_storage": bf16_frames,
             "reference_batch": ref,
             "config4": cfg4,
             "reference_shapes": ref_shapes,

@@ -13,8 +13,13 @@
 // 16-unit limit of the row-rotated delta kernels: hidden 17..32 runs here at every batch size), mat-vecs on the exact-fp32
 // MFMA with operands streamed from an LDS table — the masked deltas are the B operands, the accumulators are the
 // in-place C/D operands (r, z rows stored pre-multiplied by -log2(e)).  Feature deltas live on the feature slots (slot
-// 4c+q on lane q of chunk c).  Checkpoint per kCkptStride steps: h, h_p, dm_r, dm_z, dm_n, dm_nh (float4 per lane and
-// unit tile) + the two x_p slots.
+// 4c+q on lane q of chunk c).
+// Checkpoint per block of kCkptStride steps (r04: 3 float4 per lane at one unit tile instead of 7): h and h_p at the block's start
+// (float4 per lane and unit tile) + ONE float4 = (x_p slot 0, x_p slot 1, mask word 0, mask word 1): the block's own threshold
+// decisions, one bit each.  The four accumulators are NOT stored.  A masked delta moves its memory by exactly what it adds to the
+// accumulator's operand, so the sums telescope: dm(t) = dm(0) + W_x x_p(t) + W_h h_p(t) — the backward pass rebuilds them with one
+// step's worth of MFMAs per block and REPLAYS the forward pass's decisions from the mask bits, so a rounding-level difference of
+// the rebuilt accumulators (summation order: ~1e-6 relative after 200 steps) can never flip a threshold between the two passes.
 #include "odpd_s16.h"
 
 namespace odpd {
@@ -34,7 +39,7 @@ struct D16 {
     static constexpr int NG = DM0 + 4 * NT;
     static constexpr int IHT = NG;                     // g*NT + kt : W_ig[16kt+4q+e][slot(m)], slot(m) = 4 (m & 3) + (m >> 2)  (dL/dx)
     static constexpr int NG_DX = IHT + 3 * NT;
-    static constexpr int kCk = 6 * NT + 1;             // float4 per lane per checkpoint
+    static constexpr int kCk = 2 * NT + 1;             // float4 per lane per checkpoint: h, h_p per unit tile + (x_p0, x_p1, masks)
     static constexpr int kTiles = 5 * NT + 1;          // gr gz gn gnh dhm per unit tile + feature-delta tile
 };
 
@@ -115,32 +120,15 @@ __device__ __forceinline__ void d16_slots(float2 xv, float2 xn, const float (&oh
     fs[1] = __builtin_fmaf(oh[0], f4, oh[1] * f5);
 }
 
-// one forward step.  slot_ok[c]: the lane's slot of chunk c is a real feature; unit_ok[kt][i]: a real hidden unit
-template <bool TRES, int NT, bool JAN = false>
-__device__ __forceinline__ void d16_cell_fwd(TabPtr tl, const float (&fs)[2], float thx, float thh, const bool (&slot_ok)[2],
-                                             const f32x4 (&unit_ok)[NT], D16State<NT>& st, f32x4 (&hprev)[NT], f32x4 (&dhm)[NT],
-                                             f32x4 (&mh)[NT], f32x4 (&r)[NT], f32x4 (&z)[NT], f32x4 (&n)[NT], float (&dxm)[2],
-                                             float& zx, float& zh, float (&mx)[2]) {
+// threshold decisions of one block of kCkptStride steps, one bit each, as the forward pass took them (checkpoint float4 .z / .w):
+// word kt, bit 4 s + i: hidden unit 16 kt + 4 q + i of step s was kept;  word 0, bit 16 + 2 s + c: feature slot c of step s.
+// The forward pass builds the words in float arithmetic (24 bits: exact), the backward pass converts them once per block.
+__device__ __forceinline__ bool d16_bit(unsigned w, int pos) { return ((w >> pos) & 1u) != 0u; }
+
+// the accumulators take one set of masked deltas: dm += W_x dx + W_h dh  (JAN: both gates' state parts go to dm itself)
+template <int NT, bool JAN>
+__device__ __forceinline__ void d16_accumulate(TabPtr tl, const float (&dxm)[2], const f32x4 (&dhm)[NT], D16State<NT>& st) {
     using T = D16<NT>;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const float d = fs[c] - st.xp[c];
-        const bool keep = !(__builtin_fabsf(d) < thx);           // masked_fill(|d| < th, 0)  (deltagru.py:179-183)
-        dxm[c] = keep ? d : 0.0f;
-        mx[c] = keep ? 1.0f : 0.0f;
-        st.xp[c] = (__builtin_fabsf(d) >= thx) ? fs[c] : st.xp[c];
-        zx += (slot_ok[c] && dxm[c] == 0.0f) ? 1.0f : 0.0f;
-    }
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-        ODPD_EACH4 {
-            const float d = st.h[kt][i] - st.hp[kt][i];
-            const bool keep = !(__builtin_fabsf(d) < thh);
-            dhm[kt][i] = keep ? d : 0.0f;
-            mh[kt][i] = keep ? 1.0f : 0.0f;
-            st.hp[kt][i] = (__builtin_fabsf(d) >= thh) ? st.h[kt][i] : st.hp[kt][i];
-            zh += (unit_ok[kt][i] != 0.0f && dhm[kt][i] == 0.0f) ? 1.0f : 0.0f;
-        }
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         const float4 wr = tab_ld(tl, (T::IH + 0 * NT + mt) * 64), wz = tab_ld(tl, (T::IH + 1 * NT + mt) * 64),
@@ -153,6 +141,37 @@ __device__ __forceinline__ void d16_cell_fwd(TabPtr tl, const float (&fs)[2], fl
     s16n_matvec<NT>(tl, T::HH + 1 * NT * NT, dhm, st.dmz);
     if constexpr (JAN) s16n_matvec<NT>(tl, T::HH + 2 * NT * NT, dhm, st.dmn);       // dm = (dx W_ih^T + dm) + dh W_hh^T for both gates
     else s16n_matvec<NT>(tl, T::HH + 2 * NT * NT, dhm, st.dmnh);
+}
+
+// one forward step.  slot_ok[c]: the lane's slot of chunk c is a real feature; unit_ok[kt][i]: a real hidden unit.
+// REPLAY (backward recompute): the keep / drop decisions are not taken but read from the block's mask words, step `sidx` of the block
+template <bool TRES, int NT, bool JAN = false, bool REPLAY = false>
+__device__ __forceinline__ void d16_cell_fwd(TabPtr tl, const float (&fs)[2], float thx, float thh, const bool (&slot_ok)[2],
+                                             const f32x4 (&unit_ok)[NT], D16State<NT>& st, f32x4 (&hprev)[NT], f32x4 (&dhm)[NT],
+                                             f32x4 (&mh)[NT], f32x4 (&r)[NT], f32x4 (&z)[NT], f32x4 (&n)[NT], float (&dxm)[2],
+                                             float& zx, float& zh, float (&mx)[2], const unsigned* mw = nullptr, int sidx = 0) {
+    using T = D16<NT>;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float d = fs[c] - st.xp[c];
+        // masked_fill(|d| < th, 0)  (deltagru.py:179-183); x_p follows where the delta was kept (|d| >= th: the same predicate)
+        const bool keep = REPLAY ? d16_bit(mw[0], 16 + 2 * sidx + c) : !(__builtin_fabsf(d) < thx);
+        dxm[c] = keep ? d : 0.0f;
+        mx[c] = keep ? 1.0f : 0.0f;
+        st.xp[c] = keep ? fs[c] : st.xp[c];
+        if constexpr (!REPLAY) zx += (slot_ok[c] && dxm[c] == 0.0f) ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+        ODPD_EACH4 {
+            const float d = st.h[kt][i] - st.hp[kt][i];
+            const bool keep = REPLAY ? d16_bit(mw[kt], 4 * sidx + i) : !(__builtin_fabsf(d) < thh);
+            dhm[kt][i] = keep ? d : 0.0f;
+            mh[kt][i] = keep ? 1.0f : 0.0f;
+            st.hp[kt][i] = keep ? st.h[kt][i] : st.hp[kt][i];
+            if constexpr (!REPLAY) zh += (unit_ok[kt][i] != 0.0f && dhm[kt][i] == 0.0f) ? 1.0f : 0.0f;
+        }
+    d16_accumulate<NT, JAN>(tl, dxm, dhm, st);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         z[mt] = sigmoid4_prescaled(st.dmz[mt]);
@@ -260,6 +279,10 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
         D16State<NT> st;
         d16_init_state<NT>(tl, st);
         float zxs = 0.0f, zhs = 0.0f;
+        // mask words of the running block (float arithmetic on integers < 2^24: exact), x_p at its start, 16^s and 2^(16 + 2 s) of step s
+        float mwf[NT], xps[2] = {st.xp[0], st.xp[1]}, scale = 1.0f, scale_x = 65536.0f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) mwf[kt] = 0.0f;
         for (int t0 = 0; t0 < a.T; t0 += kChunk) {
             const int len = min(kChunk, a.T - t0);
             wave_lds_fence();
@@ -286,15 +309,26 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
                 }
                 if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
                 const int t1 = t0 + tt + 1;
-                if (ck != nullptr && (t1 % S) == 0 && t1 < a.T) {
-                    float4* c = ck + (size_t)(t1 / S) * T::kCk * 64;
+                if (ck != nullptr) {
+                    // this step's decisions into the block's mask words: unit bits 4 s + i (weight 16^s 2^i), slot bits 16 + 2 s + c
 #pragma unroll
                     for (int kt = 0; kt < NT; ++kt) {
-                        c[(0 * NT + kt) * 64] = d16_f4(st.h[kt]); c[(1 * NT + kt) * 64] = d16_f4(st.hp[kt]);
-                        c[(2 * NT + kt) * 64] = d16_f4(st.dmr[kt]); c[(3 * NT + kt) * 64] = d16_f4(st.dmz[kt]);
-                        c[(4 * NT + kt) * 64] = d16_f4(st.dmn[kt]); c[(5 * NT + kt) * 64] = d16_f4(st.dmnh[kt]);
+                        const float nib = __builtin_fmaf(mh[kt][3], 8.0f, __builtin_fmaf(mh[kt][2], 4.0f, __builtin_fmaf(mh[kt][1], 2.0f, mh[kt][0])));
+                        mwf[kt] = __builtin_fmaf(nib, scale, mwf[kt]);
                     }
-                    c[6 * NT * 64] = make_float4(st.xp[0], st.xp[1], 0.0f, 0.0f);
+                    mwf[0] = __builtin_fmaf(__builtin_fmaf(mx[1], 2.0f, mx[0]), scale_x, mwf[0]);
+                    scale *= 16.0f; scale_x *= 4.0f;
+                    if ((t1 % S) == 0 || t1 == a.T) {          // the block ends: its masks + x_p at its start; the next block's start state
+                        ck[(size_t)((t1 - 1) / S) * T::kCk * 64 + 2 * NT * 64] = make_float4(xps[0], xps[1], mwf[0], NT > 1 ? mwf[NT - 1] : 0.0f);
+                        if (t1 < a.T) {
+                            float4* c = ck + (size_t)(t1 / S) * T::kCk * 64;
+#pragma unroll
+                            for (int kt = 0; kt < NT; ++kt) { c[(0 * NT + kt) * 64] = d16_f4(st.h[kt]); c[(1 * NT + kt) * 64] = d16_f4(st.hp[kt]); }
+                        }
+                        xps[0] = st.xp[0]; xps[1] = st.xp[1]; scale = 1.0f; scale_x = 65536.0f;
+#pragma unroll
+                        for (int kt = 0; kt < NT; ++kt) mwf[kt] = 0.0f;
+                    }
                 }
             }
             wave_lds_fence();
@@ -352,7 +386,7 @@ template <bool TRES, int NT, bool FULL, bool DX, bool JAN = false>
 __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, const D16Scalars<TRES>& sc, const float (&oh)[4],
                                               D16Grad<TRES, NT>& G, const float2* xr, const float2* dys, float2* dxs, float* tiles,
                                               float2 x0, int n, int q, int tglob, int tloc, int nstep, int chunk_len, float* dxrow,
-                                              D16State<NT> st, D16Carry<NT>& C) {
+                                              D16State<NT> st, D16Carry<NT>& C, const unsigned (&mw)[NT]) {
     using T = D16<NT>;
     constexpr int S = kCkptStride;
     const bool slot_ok[2] = {true, q < 2};
@@ -371,8 +405,8 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 const float2 xn = (tglob + si + 1 < a.T) ? xr[tloc + si + 1] : x0;
                 float fs[2];
                 d16_slots<TRES>(xv, xn, oh, fs);
-                d16_cell_fwd<TRES, NT, JAN>(tl, fs, a.thx, a.thh, slot_ok, all_units, st, hprev_s[si], dhm_s[si], mh_s[si], r_s[si],
-                                       z_s[si], n_s[si], dxm_s[si], zx, zh, mx_s[si]);
+                d16_cell_fwd<TRES, NT, JAN, true>(tl, fs, a.thx, a.thh, slot_ok, all_units, st, hprev_s[si], dhm_s[si], mh_s[si], r_s[si],
+                                                  z_s[si], n_s[si], dxm_s[si], zx, zh, mx_s[si], mw, si);
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) nh_s[si][kt] = st.dmnh[kt];
             }
@@ -647,21 +681,22 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
                 cur_chunk = chunk;
             }
             D16State<NT> st;
+            d16_init_state<NT>(tl, st);                       // h = h_p = x_p = 0, accumulators = their initial values (the biases)
+            const float4* c = ck + (size_t)blk * T::kCk * 64;
+            const float4 aux = c[2 * NT * 64];                // (x_p0, x_p1, mask words) of this block
+            unsigned mw[NT];
+            mw[0] = (unsigned)aux.z;
+            if constexpr (NT > 1) mw[NT - 1] = (unsigned)aux.w;
             if (blk) {
-                const float4* c = ck + (size_t)blk * T::kCk * 64;
+                // state at the block's start: h, h_p, x_p from the checkpoint; the accumulators rebuilt from the telescoped sums of the
+                // masked deltas, dm = dm(0) + W_x x_p + W_h h_p (one step's MFMAs; x_p / h_p start at 0)
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt) {
-                    st.h[kt] = as_f32x4(c[(0 * NT + kt) * 64]); st.hp[kt] = as_f32x4(c[(1 * NT + kt) * 64]);
-                    st.dmr[kt] = as_f32x4(c[(2 * NT + kt) * 64]); st.dmz[kt] = as_f32x4(c[(3 * NT + kt) * 64]);
-                    st.dmn[kt] = as_f32x4(c[(4 * NT + kt) * 64]); st.dmnh[kt] = as_f32x4(c[(5 * NT + kt) * 64]);
-                }
-                const float4 xp = c[6 * NT * 64];
-                st.xp[0] = xp.x; st.xp[1] = xp.y;
-            } else {
-                d16_init_state<NT>(tl, st);
+                for (int kt = 0; kt < NT; ++kt) { st.h[kt] = as_f32x4(c[(0 * NT + kt) * 64]); st.hp[kt] = as_f32x4(c[(1 * NT + kt) * 64]); }
+                st.xp[0] = aux.x; st.xp[1] = aux.y;
+                d16_accumulate<NT, JAN>(opaque(tl), st.xp, st.hp, st);
             }
-            if (nstep == S) d16_bwd_block<TRES, NT, true, DX, JAN>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
-            else d16_bwd_block<TRES, NT, false, DX, JAN>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C);
+            if (nstep == S) d16_bwd_block<TRES, NT, true, DX, JAN>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C, mw);
+            else d16_bwd_block<TRES, NT, false, DX, JAN>(a, tl, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C, mw);
         }
         if constexpr (DX) {
             wave_lds_fence();
@@ -770,7 +805,7 @@ static LaunchShape d16_bwd_shape(const odpd_model_t* m, int ngroups) {
 }
 int delta_s16_rows(const odpd_model_t* m, int B) { return d16_bwd_shape(m, (B + 15) / 16).grid; }
 int64_t delta_s16_ckpt_floats(const odpd_model_t* m, int B, int T) {
-    return (int64_t)((B + 15) / 16) * num_ckpt(T) * (6 * d16_tiles(m->hidden) + 1) * 256;
+    return (int64_t)((B + 15) / 16) * num_ckpt(T) * (2 * d16_tiles(m->hidden) + 1) * 256;
 }
 template <bool TRES, int NT, bool JAN = false>
 static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int P, int mode) {
@@ -785,6 +820,7 @@ static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, i
     }
     // the weight gradients ride along in every backward launch: partials are required (a frozen model passes a scratch buffer)
     if (a.partials == nullptr) return ODPD_EINVAL;
+    if (a.ckpt == nullptr) return ODPD_EINVAL;                // every block's threshold decisions live there, also for T <= kCkptStride
     const bool dxf = (m->flags & ODPD_FLAG_NEED_DX) != 0;
     if (a.dx != nullptr && !dxf) return ODPD_EINVAL;          // the forward must have run with ODPD_FLAG_NEED_DX as well
     const LaunchShape ls = d16_bwd_shape(m, a.ngroups);

@@ -227,9 +227,17 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const flo
             f32x4 act, hid;
             const f32x4 ht = fma4(z, sub4(hp, nn), nn);
             if constexpr (DG) {
+#ifdef ODPD_EXP_HEAD2      // timing experiment: two accumulator chains instead of one dependent 4-chunk chain
+                f32x4 hid1 = {0.f, 0.f, 0.f, 0.f};
+                hid = w.bhid;
+                hid = mfma4(w.whid[0], ht[0], hid); hid1 = mfma4(w.whid[1], ht[1], hid1);
+                hid = mfma4(w.whid[2], ht[2], hid); hid1 = mfma4(w.whid[3], ht[3], hid1);
+                hid = add4(hid, hid1);
+#else
                 hid = w.bhid;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) hid = mfma4(w.whid[c], ht[c], hid);
+#endif
                 ODPD_EACH4 act[i] = relu_(hid[i]);
             } else {
                 act = ht;
@@ -269,9 +277,17 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const flo
             if constexpr (DG) {
                 ODPD_EACH4 dhid[i] = dact[i] * relu_gate(hid[i]);
                 if constexpr (NW) G.db_hid = add4(G.db_hid, dhid);
+#ifdef ODPD_EXP_HEAD2
+                f32x4 dht1 = {0.f, 0.f, 0.f, 0.f};
+                dht = dh;
+                dht = mfma4(w.whidT[0], dhid[0], dht); dht1 = mfma4(w.whidT[1], dhid[1], dht1);
+                dht = mfma4(w.whidT[2], dhid[2], dht); dht1 = mfma4(w.whidT[3], dhid[3], dht1);
+                dht = add4(dht, dht1);
+#else
                 dht = dh;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) dht = mfma4(w.whidT[c], dhid[c], dht);
+#endif
             } else {
                 dht = add4(dh, dact);
             }
@@ -452,6 +468,9 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
     G.zero();
     float loss_acc = 0.0f;
     const int nwaves = gridDim.x * nwb;
+#ifdef ODPD_EXP_PRIO       // timing experiment: static priority for the second-dispatched half of an eight-wave workgroup
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
         const bool valid = b0 + n < a.B;

@@ -405,14 +405,20 @@ __device__ __forceinline__ void s16n_write_row(float* prow, const GruLayout& L, 
 
 // MODE 0: fused train (x, target -> partials; checkpoints in `ckpt` workspace)   1: forward (y, optional ckpt)
 // MODE 2: backward from dy (partials if NW, dx if DX)
-// the frozen-model variants (no weight-gradient accumulators) run two waves per SIMD like the forward kernel — except the fused
-// frozen-PA step (MODE 0 without NW) with four K-chunks in the last unit tile (hidden 25..32): under the 256-register cap of an
-// eight-wave workgroup it spills 160..220 B per lane and its DGRU instantiation then computes wrong losses / gradients for hidden
-// 29..32 (1e-2 relative; the same source at one wave per SIMD is exact, as are the two-chunk builds at two; the eight-wave four-chunk build is
-// exact as well when compiled at -O1 or with `-mllvm -enable-post-misched=false`, i.e. the post-RA scheduler mis-orders something in that
-// spilling instantiation — disabling it for the whole library costs 1..10 % elsewhere, so the launch shape avoids the build instead).  tools/s16n_crosscheck.py
-// runs every flavour x feature set x hidden 17..32 against the oracle; tests/test_cascade_gpu.py pins hidden 29, 31, 32.
+// the frozen-model variants (no weight-gradient accumulators) run two waves per SIMD like the forward kernel.
+// History of the one exception that r02/r03 carried here: the fused frozen-PA step (MODE 0 without NW) with four K-chunks in the last unit
+// tile (hidden 25..32) spills 160..220 B per lane under the 256-register cap of an eight-wave workgroup, and its DGRU instantiation
+// computed 1e-2 .. 2e-1 wrong losses / gradients in that build (exact at one wave per SIMD, at -O1, with -enable-post-misched=false), so the
+// launch shape kept those sizes at one wave per SIMD.  r04 root cause (tools/asm_mfma_hazards.py, tools/exp_s16n8w.py): relu_ was an
+// inline-asm v_max_f32 with a write-only output; in exactly that instantiation the allocator gave the output the register that a v_mfma
+// issued three slots earlier was still reading as its C operand, and the hazard recognizer does not look inside asm.  With relu_ as a
+// builtin (odpd_s16.h) the build is exact (448 sweep cases x 5 flavours) and 14 % faster than the four-wave launch: 2.20 -> 1.89 ms at
+// 32 768 x 200, hidden 25 .. 32 (profiles/r04/s16n_eight_wave.txt).  ODPD_EXP_S16N_4W restores the old launch shape for comparisons.
+#ifdef ODPD_EXP_S16N_4W
 constexpr bool s16n_two_waves_per_simd(int mode, bool nw, int nck) { return mode == 1 || (mode == 2 && !nw) || (mode == 0 && !nw && nck <= 2); }
+#else
+constexpr bool s16n_two_waves_per_simd(int mode, bool nw, int nck) { return mode == 1 || (mode == 2 && !nw) || (mode == 0 && !nw); }
+#endif
 template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
 __global__ __launch_bounds__(s16n_two_waves_per_simd(MODE, NW, NCK) ? 512 : 256, 1) void gru16n_kernel(SeqArgs a) {
     using T = S16N<NT>;

@@ -80,11 +80,21 @@ __device__ __forceinline__ void s16_slots_pk(float I, float Q, const float (&oh)
 
 // ---- stage-major 4-wide element-wise helpers (same arithmetic as sigmoidf_ / tanhf_ of odpd_device.h) ----
 #define ODPD_EACH4 _Pragma("unroll") for (int i = 0; i < 4; ++i)
-// relu of an MFMA result: one v_max_f32 (fmaxf() would first quiet a possible sNaN with a second v_max)
+// relu of an MFMA result in ONE VALU op: v_med3_f32(v, 0, +inf) (fmaxf() would first quiet a possible sNaN with a second v_max).
+// NOT inline asm (r01..r03: `asm("v_max_f32 %0, 0, %1")`): the operand is an MFMA result, and the wait states a VALU read of an
+// in-flight XDL result needs are inserted by the compiler's hazard recognizer only for instructions it can see — an asm statement is
+// opaque to it, so whenever the post-RA scheduler moved the asm directly behind the last v_mfma of the fc_hid chain it read the
+// accumulator before the write-back.  That was the r02 "wrong-result build" (spilling eight-wave gru16n_kernel<DGRU, frozen-PA,
+// four K-chunks>: DGRU only — the only kernels with a relu —, schedule dependent, gone with -enable-post-misched=false; r04:
+// tools/exp_s16n8w.py).  #ifdef ODPD_RELU_ASM keeps the old form for that reproduction.
 __device__ __forceinline__ float relu_(float v) {
+#ifdef ODPD_RELU_ASM
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
     return r;
+#else
+    return __builtin_amdgcn_fmed3f(v, 0.0f, __builtin_inff());
+#endif
 }
 // per-element loops, NOT whole-vector arithmetic: <4 x float> IR ops become v_pk_*_f32, which issue at half
 // rate on gfx950 and measured 6 % slower here (profiles/r01/ubench_issue_costs.md)
@@ -187,11 +197,25 @@ __device__ __forceinline__ void s16_loss(const S16Loss& L, float d0, float d1, f
 // relu'(v) as a multiplier: 0 for v <= 0, 1 for v >= 2^-100 (v_mul with the clamp modifier instead of v_cmp + v_cndmask)
 __device__ __forceinline__ float relu_gate(float v) { return __builtin_amdgcn_fmed3f(v * 0x1p100f, 0.0f, 1.0f); }
 
-// sum over the four quads of a sequence (lanes n, n+16, n+32, n+48); every lane gets the total
+// sum over the four quads of a sequence (lanes n, n+16, n+32, n+48); every lane gets the total.
+// Two VALU cross-row swaps (gfx950 v_permlane16_swap / v_permlane32_swap: both results of a swap of v with itself are the two partner
+// rows' values on EVERY lane, so no select is needed) instead of ds_swizzle + ds_bpermute: no LDS-pipe round trips inside the step loops.
+// Same additions in the same order as the swizzle form ((own + row partner) + (the other half's pair)): bit-identical sums.
 __device__ __forceinline__ float quad_sum(float v) {
+#ifdef ODPD_QUAD_SUM_LDS
     v += swap16(v);
     v += __shfl_xor(v, 32);
     return v;
+#else
+    const int iv = __builtin_bit_cast(int, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);      // a[0] = rows (0, 0, 2, 2), a[1] = rows (1, 1, 3, 3)
+    const int a0 = a[0], a1 = a[1];
+    const float s = __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+    const int is = __builtin_bit_cast(int, s);
+    const auto b = __builtin_amdgcn_permlane32_swap(is, is, false, false);      // b[0] = halves (lo, lo), b[1] = (hi, hi)
+    const int b0 = b[0], b1 = b[1];
+    return __builtin_bit_cast(float, b0) + __builtin_bit_cast(float, b1);
+#endif
 }
 
 // transpose tile: lane (n,q) stores X[n][4q..4q+3]; lane (u,k) loads X[4k+c][u], c = 0..3

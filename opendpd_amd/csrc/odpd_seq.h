@@ -72,16 +72,32 @@ __device__ __forceinline__ float2 ld_iq(const float* g, size_t i, bool bf16) {
 template <int SPW>
 __device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane,
                                          float2 fill, const long long* fidx = nullptr, int fstride = 0, bool bf16 = false) {
-    const float2* g2 = reinterpret_cast<const float2*>(g);
     constexpr int N = SPW * kChunk / 64;   // float2 per lane
     static_assert(N >= 1 && (SPW * kChunk) % 64 == 0, "chunk must tile the wave");
+#ifndef ODPD_NO_BF16_FRAMES     // (timing experiments: the library without the bf16 branch, tools/exp_time.py)
+    if (bf16) {      // (its own wave-uniform loop: the fp32 path keeps the code — and the register allocation — it had)
+        const unsigned* g1 = reinterpret_cast<const unsigned*>(g);
+#pragma unroll 1
+        for (int j = 0; j < N; ++j) {
+            const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
+            float2 v = fill;
+            if (tt < len && b0 + m < B) {
+                const unsigned w = g1[(size_t)fidx[b0 + m] * fstride + t0 + tt];
+                v = make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
+            }
+            lds[m * kChunkPad + tt] = v;
+        }
+        return;
+    }
+#endif
+    const float2* g2 = reinterpret_cast<const float2*>(g);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
         float2 v = fill;
         if (tt < len && b0 + m < B) {
             const size_t row = fidx ? (size_t)fidx[b0 + m] * fstride : (size_t)(b0 + m) * T;
-            v = bf16 ? ld_iq(g, row + t0 + tt, true) : g2[row + t0 + tt];
+            v = g2[row + t0 + tt];
         }
         lds[m * kChunkPad + tt] = v;
     }

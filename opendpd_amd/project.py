@@ -30,10 +30,11 @@ DEFAULTS = dict(  # arguments.py:8-89
     loss_type="l2", opt_type="adamw", batch_size=256, batch_size_eval=256, n_epochs=100, lr_schedule=0, lr=5e-4,
     lr_end=1e-4, decay_factor=0.1, patience=10, grad_clip_val=200, K=4, PA_backbone="gru", PA_hidden_size=23,
     PA_num_layers=1, DPD_backbone="gru", DPD_hidden_size=15, DPD_num_layers=1, quant=False, n_bits_w=8, n_bits_a=8,
-    pretrained_model="", quant_dir_label="", q_pretrain=False, thx=0.0, thh=0.0, num_dvr_units=3, window_size=4,
-    # not in the reference: storage of the resident TRAINING streams on the device — "fp32" (the reference's data, default) or "bf16"
-    # (BASELINE configs[1]: 4 bytes per I/Q sample; the kernels widen exactly and compute in fp32; GRU-family train_pa only)
-    frame_storage="fp32")
+    pretrained_model="", quant_dir_label="", q_pretrain=False, thx=0.0, thh=0.0, num_dvr_units=3, window_size=4)
+# arguments the reference does not have (kept apart: DEFAULTS mirrors arguments.py exactly, tests/test_api_cpu.py).
+#   frame_storage: storage of the resident TRAINING streams on the device — "fp32" (the reference's data) or "bf16" (BASELINE
+#   configs[1]: 4 bytes per I/Q sample, widened exactly, fp32 arithmetic; read in place by the GRU-family train kernels)
+EXTENSIONS = dict(frame_storage="fp32")
 
 
 def count_net_params(net):
@@ -138,7 +139,7 @@ class CsvLogger:
 
 class Project:
     def __init__(self, **overrides):
-        hp = dict(DEFAULTS)
+        hp = dict(DEFAULTS, **EXTENSIONS)
         unknown = set(overrides) - set(hp)
         if unknown:
             raise TypeError(f"unknown arguments: {sorted(unknown)}")

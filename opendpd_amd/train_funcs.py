@@ -640,16 +640,19 @@ def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device)
     if fast and optimizer.can_run_epoch(dataloader):
         # whole epoch in the native loop: frames read in place from the resident streams, 3 launches per step, no Python
         losses = optimizer.train_epoch(dataloader, kind, grad_clip_val)
+        optimizer.last_epoch_losses = losses          # per-step mean losses of the epoch (device tensor): the reference only logs their mean
         log["loss"] = float(losses.double().mean().item()) if losses.numel() else float("nan")
         return net
     if fast and optimizer.can_run_cascade_epoch(dataloader):
         # train_dpd at the reference's batch sizes, GRU-family DPD and PA: one launch per step body, the epoch issued from the native loop
         losses = optimizer.train_epoch_cascade(dataloader, kind, grad_clip_val)
+        optimizer.last_epoch_losses = losses          # per-step mean losses of the epoch (device tensor): the reference only logs their mean
         log["loss"] = float(losses.double().mean().item()) if losses.numel() else float("nan")
         return net
     if fast and optimizer.can_run_split_epoch(dataloader):
         # no fused kernel for these batch shapes: the split chain of every step, issued from the native loop as well
         losses = optimizer.train_epoch_split(dataloader, kind, grad_clip_val)
+        optimizer.last_epoch_losses = losses          # per-step mean losses of the epoch (device tensor): the reference only logs their mean
         log["loss"] = float(losses.double().mean().item()) if losses.numel() else float("nan")
         return net
     world = optimizer.world_size() if isinstance(optimizer, FusedAdamW) else 1
@@ -689,7 +692,10 @@ def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device)
             optimizer.step()
         losses.append(loss.detach())
     # one host sync per epoch instead of one .item() per step (train_funcs.py:48)
-    log["loss"] = float(np.mean(torch.stack([l.float() for l in losses]).cpu().numpy())) if losses else float("nan")
+    stacked = torch.stack([l.float() for l in losses]) if losses else None
+    if fast:
+        optimizer.last_epoch_losses = stacked
+    log["loss"] = float(np.mean(stacked.cpu().numpy())) if losses else float("nan")
     return net
 
 

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""First-steps trajectory anchors for BASELINE configs 3 and 5 (TEST INFRASTRUCTURE — build container only).
+
+The epoch-level rows of those two runs (tests/golden/ref_runs_apa.json, ref_runs_qat.json) can only be matched to dB-level tolerances:
+over 919 steps a rounding-level difference eventually flips a delta-threshold decision / moves a value across a quantisation boundary.
+The FIRST steps have no such freedom yet, so this script records the reference's per-step training losses of the first N steps of
+
+    main.py --step train_dpd --dataset_name APA_200MHz --PA_backbone dgru --PA_hidden_size 23 --frame_length 200 --seed 0
+            --DPD_backbone deltagru_tcnskip --DPD_hidden_size 15 --thx 0.01 --thh 0.05 --batch_size 64              (config 3)
+            --DPD_backbone qgru --DPD_hidden_size 10 --quant --n_bits_w 8 --n_bits_a 8 --batch_size 64              (config 5)
+
+by RUNNING the reference (CPU) with its own Project / dataloader / optimiser; the frozen PA is the state dict the reference trained for
+the epoch anchors (tests/golden/ref_runs_apa_models.npz, written where train_dpd looks for it).  The only harness-side change is a
+`net_train` that is the reference's loop verbatim in behaviour (train_funcs.py:28-48) plus "remember every loss, stop after N steps".
+Output: tests/golden/ref_first_steps.json {config3: {losses: [...], cmd}, config5: {...}}.   Usage: python oracle/gen_run_anchor_first_steps.py"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+N_STEPS = 20
+C = ["--dataset_name", "APA_200MHz", "--accelerator", "cpu", "--frame_length", "200", "--seed", "0", "--n_epochs", "1",
+     "--PA_backbone", "dgru", "--PA_hidden_size", "23", "--batch_size", "64"]
+RUNS = {"config3": ["--DPD_backbone", "deltagru_tcnskip", "--DPD_hidden_size", "15", "--thx", "0.01", "--thh", "0.05"],
+        "config5": ["--DPD_backbone", "qgru", "--DPD_hidden_size", "10", "--quant", "--n_bits_w", "8", "--n_bits_a", "8"]}
+RUNNER = """
+import json, sys
+sys.path.insert(0, %r)
+sys.dont_write_bytecode = True
+import torch.nn as nn
+import quant
+from quant.modules.ops import Sqrt, Pow
+quant.Sqrt, quant.Pow = Sqrt, Pow                      # the reference's import defect (SURVEY §0 item 2), bridged harness-side
+import project
+
+
+class _Done(Exception):
+    pass
+
+
+def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device):
+    net = net.train()
+    losses = []
+    for features, targets in dataloader:
+        features, targets = features.to(device), targets.to(device)
+        optimizer.zero_grad()
+        out = net(features)
+        loss = criterion(out, targets)
+        loss.backward()
+        if grad_clip_val != 0:
+            nn.utils.clip_grad_norm_(net.parameters(), grad_clip_val)
+        optimizer.step()
+        losses.append(loss.item())
+        if len(losses) == %d:
+            break
+    json.dump(losses, open("first_steps.json", "w"))
+    raise _Done
+
+
+project.net_train = net_train
+from steps import train_dpd
+try:
+    train_dpd.main(project.Project())
+except _Done:
+    pass
+""" % (REF, N_STEPS)
+
+
+def main():
+    import torch
+    env = dict(os.environ, PYTHONPATH=REF, PYTHONDONTWRITEBYTECODE="1")
+    pa = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "ref_runs_apa_models.npz")).items() if k.startswith("pa/")}
+    pa_rel = json.load(open(os.path.join(OUT, "ref_runs_apa.json")))["config3_apa200"]["pa_model"]
+    out = {"n_steps": N_STEPS}
+    for key, args in RUNS.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            os.makedirs(os.path.join(tmp, os.path.dirname(pa_rel)), exist_ok=True)
+            torch.save(pa, os.path.join(tmp, pa_rel))
+            open(os.path.join(tmp, "_runner.py"), "w").write(RUNNER)
+            subprocess.check_call([sys.executable, "_runner.py", "--step", "train_dpd"] + C + args, cwd=tmp, env=env, stdout=subprocess.DEVNULL)
+            out[key] = {"losses": json.load(open(os.path.join(tmp, "first_steps.json"))), "cmd": " ".join(["--step", "train_dpd"] + C + args)}
+            print(key, out[key]["losses"][:3], "...", out[key]["losses"][-1])
+    json.dump(out, open(os.path.join(OUT, "ref_first_steps.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

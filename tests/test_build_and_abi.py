@@ -135,3 +135,47 @@ def test_multi_instruction_asm_groups_take_early_clobber_accumulators():
     assert offenders(dev.replace('"+&v"', '"+v"')), "the check must see the groups"        # (self-test on the pre-fix form)
     for path in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip"))):
         assert not offenders(open(path).read()), os.path.basename(path)
+
+
+def test_instruction_bearing_asm_never_has_a_pure_vgpr_output():
+    """Root cause of the r02 wrong-result build (r04, tools/asm_mfma_hazards.py): `relu_` was `asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v))`.
+    A write-only asm output is the FIRST writer of whatever register the allocator picks — possibly the C operand of a v_mfma issued a
+    few slots earlier, which the XDL pipeline is still reading; the compiler's hazard recognizer does not look inside asm, so no wait
+    state is inserted (a read-write "+v" operand always has a compiler-visible definition in between, which pays the wait).  Rule: an
+    asm statement that contains an instruction may not declare "=v" / "=&v" outputs."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "opendpd_amd", "csrc")
+
+    def offenders(text):
+        bad = []
+        for body in _asm_statements(text):
+            template = body.split(":")[0]
+            has_instr = bool(re.search(r"\b[vs]_[a-z0-9_]+", template)) or "ODPD_" in template
+            if has_instr and re.search(r'"=&?v"', body):
+                bad.append(body[:90])
+        return bad
+
+    assert offenders('asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));'), "the check must see the r03 form of relu_"
+    assert not offenders('asm volatile("" : "+v"(p));') and not offenders('asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2" : "+&v"(a) : "v"(b), "v"(c));')
+    for path in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip"))):
+        text = open(path).read()
+        # (the reproduction switch ODPD_RELU_ASM keeps the old form behind an #ifdef that no build defines)
+        text = re.sub(r"#ifdef ODPD_RELU_ASM.*?#else", "", text, flags=re.S)
+        assert not offenders(text), os.path.basename(path)
+
+
+def test_isa_scan_finds_the_r02_hazard_in_its_reproduction_build():
+    """tools/asm_mfma_hazards.py on csrc/gru_s16n.hip compiled as the avoided r02 flavour (-DODPD_RELU_ASM): exactly
+    one kernel — gru16n_kernel<DGRU, fused frozen-PA step, four K-chunks>, the one that computed wrong results — has an inline-asm
+    instruction overwriting the C operand of an in-flight v_mfma; the source as built today has none."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("haz", os.path.join(ROOT, "tools", "asm_mfma_hazards.py"))
+    haz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(haz)
+    src = os.path.join(ROOT, "opendpd_amd", "csrc", "gru_s16n.hip")
+    findings, n_asm = haz.scan(haz.isa_of(src, ("ODPD_RELU_ASM",)), 18, 3)
+    war = {f[0] for f in findings if f[1] == "WAR-SrcC"}
+    assert n_asm > 100 and war == {"_ZN4odpd13gru16n_kernelILi1ELb1ELi2ELi0ELb0ELb1ELi4EEEvNS_7SeqArgsE"}, war
+    findings, n_asm = haz.scan(haz.isa_of(src), 18, 3)
+    assert n_asm == 0 and not findings

@@ -478,16 +478,37 @@ def test_quantised_flow_with_pretrained_float_checkpoint_matches_reference(workd
     assert np.abs(sd[w].numpy() - ref_sd[w]).max() < 0.05          # and the two runs stay next to each other
 
 
+@pytest.fixture
+def tiny_workdir(tmp_path):
+    """DPA_200MHz cut down to 4 000 training samples and ONE 2 560-sample validation / test segment (for flows that run op by op in ATen)"""
+    d = dict(np.load(os.path.join(GOLDEN, "dpa200_dataset.npz")))
+    ds = tmp_path / "datasets" / "DPA_200MHz"
+    ds.mkdir(parents=True)
+    (ds / "spec.json").write_text(str(d.pop("spec")))
+    for k, v in d.items():
+        pd.DataFrame(v[:4000 if k.startswith("train") else 2560], columns=["I", "Q"]).to_csv(ds / f"{k}.csv", index=False)
+    old, old_ds = os.getcwd(), os.environ.get("OPENDPD_DATASETS")
+    os.chdir(tmp_path)
+    os.environ["OPENDPD_DATASETS"] = str(tmp_path / "datasets")
+    yield tmp_path
+    os.chdir(old)
+    if old_ds is not None:
+        os.environ["OPENDPD_DATASETS"] = old_ds
+    else:
+        os.environ.pop("OPENDPD_DATASETS", None)
+
+
 @pytest.mark.parametrize("bb,H", [("mcldnn", 20), ("apnrru", 8)])
-def test_registry_backbone_without_kernels_trains_through_the_api(workdir, bb, H):
+def test_registry_backbone_without_kernels_trains_through_the_api(tiny_workdir, bb, H):
     """SURVEY §8 f4 names without a reference-logged anchor go through the same Project flow on the GPU — mcldnn with 20 channels (beyond the kernels' envelope: backbones/extras.py,
     ATen forward/backward, torch.optim.AdamW) and apnrru (HIP kernels + fused AdamW; the reference's CLI does not list it among its
     --PA_backbone choices, so there is no reference log to anchor it to): device-resident frame loader, eval + metrics +
     checkpoint/log layout."""
     import opendpd_amd as od
-    # (the ATen restatement of mcldnn steps through its 50 samples op by op, ~0.5 s per train step: a larger batch keeps the flow check short)
-    res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone=bb, PA_hidden_size=H, frame_length=50, batch_size=2048 if bb == "mcldnn" else 256, lr=2e-3,
-                      n_epochs=2, seed=0, accelerator="cuda")
+    # (the ATen restatement of mcldnn steps through its samples op by op — ~0.5 s per train step, ~40 s per pass over the full validation
+    # split: 387 s of the r03 suite were this one case — hence the cut-down dataset and a large batch)
+    res = od.train_pa(dataset_name="DPA_200MHz", PA_backbone=bb, PA_hidden_size=H, frame_length=50, lr=2e-3, n_epochs=2, seed=0, accelerator="cuda",
+                      batch_size=1024 if bb == "mcldnn" else 256)
     assert res["status"] == "completed" and os.path.exists(res["model_path"])
     hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
     assert len(hist) == 2 and np.isfinite(hist["TRAIN_LOSS"]).all()
@@ -609,7 +630,7 @@ def test_baseline_config_2_and_4_epochs_match_reference_log(apa_workdir, key, ds
         assert abs(hist[col][0] - rh[col][0]) < 0.05, (col, hist[col][0], rh[col][0])   # dB
 
 
-def test_baseline_config_3_epoch_on_apa_matches_reference_log(apa_workdir):
+def test_baseline_config_3_epoch_on_apa_matches_reference_log(apa_workdir, steps_seen):
     """BASELINE config 3 on its own dataset: train_dpd of TRes-DeltaGRU H15 (thx .01, thh .05) in front of the frozen DGRU H23
     PA the REFERENCE trained (its state dict is a fixture), 919 steps of 64 x 200 frames through the cascade step,
     against the row the reference logged (tests/golden/ref_runs_apa.json).  Thresholded model: rounding-level differences
@@ -626,13 +647,46 @@ def test_baseline_config_3_epoch_on_apa_matches_reference_log(apa_workdir):
     rh = ref["hist"]
     assert list(hist.columns) == list(rh.keys())
     assert hist["N_PARAM"][0] == rh["N_PARAM"][0] == 999 + 2751        # the log counts the whole cascade
-    assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 0.03 * rh["TRAIN_LOSS"][0]
-    assert abs(hist["SP_T_DX"][0] - rh["SP_T_DX"][0]) < 0.01 and abs(hist["SP_T_DH"][0] - rh["SP_T_DH"][0]) < 0.02
+    print("[config3] gaps:", {c: abs(hist[c][0] - rh[c][0]) / (abs(rh[c][0]) if c == "TRAIN_LOSS" else 1.0)
+                              for c in ("TRAIN_LOSS", "SP_T_DX", "SP_T_DH", "VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG")})
+    # measured gaps (r04 box): TRAIN_LOSS 6.1e-4 relative, SP_T_DX 0, SP_T_DH 7e-5, metrics <= 0.045 dB — the bounds are ~3 x those (r03: 3 % / 0.5 dB)
+    assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 2e-3 * rh["TRAIN_LOSS"][0]
+    assert abs(hist["SP_T_DX"][0] - rh["SP_T_DX"][0]) < 1e-4 and abs(hist["SP_T_DH"][0] - rh["SP_T_DH"][0]) < 3e-4
     for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
-        assert abs(hist[col][0] - rh[col][0]) < 0.5, (col, hist[col][0], rh[col][0])
+        assert abs(hist[col][0] - rh[col][0]) < 0.15, (col, hist[col][0], rh[col][0])
+    # the first steps, before any threshold decision has been taken differently: the reference's own per-step losses (measured: <= 2.1e-7 up to
+    # step 12, then a first delta decision differs — 192 000 of them per step, each a compare of a rounding-level-different value — and
+    # the trajectories part at the 1e-5 .. 5e-4 level)
+    _check_first_steps("config3", steps_seen["losses"], n_exact=10)
 
 
-def test_baseline_config_5_qat_epoch_on_apa_matches_reference_log(apa_workdir):
+def _check_first_steps(key, losses, n_exact, rel_exact=1e-6, rel_all=2e-3):
+    """the reference's per-step losses of the first 20 steps (oracle/gen_run_anchor_first_steps.py): the first `n_exact` to rounding level —
+    no threshold decision / quantisation boundary has been crossed differently yet —, all 20 within the epoch's tolerance"""
+    ref = np.asarray(json.load(open(os.path.join(GOLDEN, "ref_first_steps.json")))[key]["losses"])
+    got = losses[:len(ref)].cpu().numpy()
+    err = np.abs(got - ref) / ref
+    print(f"[{key}] first {len(ref)} steps, relative loss deviation per step:", " ".join(f"{e:.1e}" for e in err))
+    assert err[:n_exact].max() <= rel_exact, (key, err)
+    assert err.max() <= rel_all, (key, err)
+
+
+@pytest.fixture
+def steps_seen(monkeypatch):
+    """per-step losses of the (one) training epoch a test runs: FusedAdamW.last_epoch_losses of the optimiser net_train was given"""
+    from opendpd_amd import project
+    seen = {}
+    inner = project.net_train
+
+    def spy(log, net, loader, optimizer, *a, **k):
+        out = inner(log, net, loader, optimizer, *a, **k)
+        seen["losses"] = optimizer.last_epoch_losses
+        return out
+    monkeypatch.setattr(project, "net_train", spy)
+    return seen
+
+
+def test_baseline_config_5_qat_epoch_on_apa_matches_reference_log(apa_workdir, steps_seen):
     """BASELINE config 5 on its own dataset: quantisation-aware train_dpd (QGRU H10, W8A8) in front of the frozen DGRU H23 PA
     the REFERENCE trained, 919 steps of 64 x 200, against the row the reference logged (tests/golden/ref_runs_qat.json,
     oracle/gen_run_anchor_qat.py).  The quantised cell is bit-exact per step (tests/test_quant_gpu.py); the float PA in the loop
@@ -649,9 +703,14 @@ def test_baseline_config_5_qat_epoch_on_apa_matches_reference_log(apa_workdir):
     rh = ref["hist"]
     assert list(hist.columns) == list(rh.keys())
     assert hist["N_PARAM"][0] == rh["N_PARAM"][0]
-    assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 0.03 * rh["TRAIN_LOSS"][0]
+    print("[config5] gaps:", {c: abs(hist[c][0] - rh[c][0]) / (abs(rh[c][0]) if c == "TRAIN_LOSS" else 1.0)
+                              for c in ("TRAIN_LOSS", "VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG")})
+    # measured gaps (r04 box): TRAIN_LOSS 1.8e-3 relative, metrics <= 0.055 dB (a rounding-level difference in the float PA moves a value across a
+    # quantisation boundary now and then) — the bounds are 3 x those
+    assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 6e-3 * rh["TRAIN_LOSS"][0]
     for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
-        assert abs(hist[col][0] - rh[col][0]) < 0.5, (col, hist[col][0], rh[col][0])
+        assert abs(hist[col][0] - rh[col][0]) < 0.2, (col, hist[col][0], rh[col][0])
+    _check_first_steps("config5", steps_seen["losses"], n_exact=15)        # (measured: <= 2.9e-7 up to step 19, 3.3e-5 at step 20)
     sd = torch.load(res["model_path"], map_location="cpu")
     want = {k[4:]: v for k, v in np.load(os.path.join(GOLDEN, "ref_runs_qat_models.npz")).items()}
     assert list(sd.keys()) == list(want.keys())
