@@ -141,7 +141,9 @@ int odpd_loss_fwd_bwd(void* stream, int kind, int64_t n, int64_t count, const fl
  * Available (odpd_partial_rows(m, B, T, 1) > 0): GRU family at every batch; lstm / vdlstm at the reference's batch sizes (one sequence
  * per wave, hidden <= 16) and at large batches (16 sequences per wave); pgjanet, bojanet, apnrru, dvrjanet and mcldnn at the reference's
  * batch sizes (one frame per workgroup while the frame's state fits a CU's LDS: frames up to ~230 .. 270 samples); gmp; rvtdcnn;
- * the quantised GRU-cell / delta models at large batches. */
+ * the quantised GRU-cell / delta models at large batches.  Delta backbones (deltagru, deltagru_tcnskip, deltajanet; fused at the
+ * reference's batch sizes, odpd_partial_rows(.., 1) > 0): `workspace` is not scratch but the four sparsity counters of the step's forward
+ * pass, double[4] as odpd_backbone_fwd's `stats` (may be NULL); the same holds for the `workspace` of the framed / epoch entry points. */
 int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_kind, int B, int T,
                        int64_t count, const float* params, const float* x, const float* target,
                        float* partials, float* workspace);

@@ -155,7 +155,9 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
         if (fused) return lstm_train_uses_s16(m, B) ? (int64_t)lstm_s16_rows(m, B)
                                                     : lstm_train_uses_gp(m, B, T) ? (int64_t)lstm_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return lstm_family_rows(m, B);
-    case FAM_DELTA: return fused ? (int64_t)ODPD_EUNSUPPORTED : delta_family_rows(m, B, T);
+    case FAM_DELTA:
+        if (fused) return delta_train_uses_gp(m, B, T) ? (int64_t)delta_gp_train_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+        return delta_family_rows(m, B, T);
     case FAM_JANET:
         if (fused) return janet_train_uses_gp(m, B, T) ? (int64_t)janet_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return janet_family_rows(m, B);
@@ -186,6 +188,7 @@ extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int
     if (family_of(m) == FAM_LSTM)
         return lstm_train_uses_s16(m, B) ? lstm_s16_workspace_floats(m, B, T) : lstm_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_JANET) return janet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_DELTA) return delta_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;   // (`workspace` then carries the counters)
     if (family_of(m) == FAM_BOJ) return bojanet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_APN) return apnrru_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_DVR) return dvrjanet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
@@ -270,6 +273,9 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
         return lstm_train_uses_s16(m, B) ? lstm_s16_train((hipStream_t)stream, m, a)
                                          : lstm_train_uses_gp(m, B, T) ? lstm_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_JANET: return janet_train_uses_gp(m, B, T) ? janet_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
+    case FAM_DELTA:      // delta backbones: `workspace` = the four sparsity counters of the step's forward pass (double[4], may be NULL)
+        a.stats = reinterpret_cast<double*>(workspace); a.ckpt = nullptr;
+        return delta_gp_train((hipStream_t)stream, m, a);
     case FAM_BOJ: return bojanet_train_uses_gp(m, B, T) ? bojanet_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_APN: return apnrru_train_uses_gp(m, B, T) ? apnrru_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_DVR: return dvrjanet_train_uses_gp(m, B, T) ? dvrjanet_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
@@ -309,6 +315,9 @@ static bool cascade_dpd_family(const odpd_model_t* m) {
 extern "C" int64_t odpd_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T) {
     if (!model_ok(dpd) || !model_ok(pa) || B <= 0 || T <= 0) return ODPD_EINVAL;
     if (!cascade_dpd_family(dpd) || family_of(pa) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    // a quantised DPD whose module is in eval() (ODPD_FLAG_EVAL: the 16-bit output quantiser of fc_out is active): the one-launch step
+    // only carries the train-mode arithmetic, the chained launches honour the flag — so the step goes to them
+    if (family_of(dpd) == FAM_QAT && (dpd->flags & ODPD_FLAG_EVAL)) return ODPD_EUNSUPPORTED;
     return gru_cascade_rows(dpd, pa, B, T);
 }
 extern "C" int odpd_cascade_fwd_bwd(void* stream, const odpd_model_t* dpd, const odpd_model_t* pa, int loss_kind, int B, int T, int64_t count,
@@ -336,6 +345,7 @@ inline bool framed_train_ok_shape(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_QAT) return qat_uses_s16(m, B);
     if (family_of(m) == FAM_LSTM) return !lstm_train_uses_s16(m, B) && lstm_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_JANET) return janet_train_uses_gp(m, B, T);
+    if (family_of(m) == FAM_DELTA) return delta_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_BOJ) return bojanet_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_APN) return apnrru_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_DVR) return dvrjanet_train_uses_gp(m, B, T);
@@ -348,6 +358,11 @@ inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqA
     if (family_of(m) == FAM_RVTDCNN) return rvtdcnn_train(st, m, a);
     if (family_of(m) == FAM_LSTM) return framed_train_ok_shape(m, a.B, a.T) ? lstm_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_JANET) return framed_train_ok_shape(m, a.B, a.T) ? janet_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_DELTA) {     // the `workspace` pointer of the framed entry points carries the sparsity counters here
+        SeqArgs b = a;
+        b.stats = reinterpret_cast<double*>(a.ckpt); b.ckpt = nullptr;
+        return delta_gp_train(st, m, b);
+    }
     if (family_of(m) == FAM_BOJ) return framed_train_ok_shape(m, a.B, a.T) ? bojanet_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_APN) return framed_train_ok_shape(m, a.B, a.T) ? apnrru_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_DVR) return framed_train_ok_shape(m, a.B, a.T) ? dvrjanet_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;

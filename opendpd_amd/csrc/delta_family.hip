@@ -614,7 +614,11 @@ __host__ __device__ inline int delta_gp_buffer_floats(int T) {
 }
 // JAN: deltajanet, rows f | g | - | - (as delta_eval_kernel<.., JAN>): accumulator gradients G_f += dL/dh (h(t-1) - g) f (1 - f),
 // G_g += dL/dh (1 - f) g (1 - g), dL/dh(t-1) = f dL/dh + the delta path.
-template <bool TRES, bool JAN = false>
+// FUSED (r04): the whole train_pa step of a delta backbone in this one launch (odpd_train_fwd_bwd) — the forward pass that the kernel
+// runs anyway also counts the sparsity statistics (a.stats), and the state-free phase forms y(t) = fc_out h(t) (+ b_out, + the TRes
+// skip), the loss and dL/dy itself with lane = time step instead of reading dL/dy: no forward launch, no loss launch, no y / dy round
+// trip; frames are addressed in place inside resident streams (a.frame_idx).  Column P of the partial row = the loss partial sum.
+template <bool TRES, bool JAN = false, bool FUSED = false>
 __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
     static_assert(!(JAN && TRES), "deltajanet: plain head");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -681,9 +685,12 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
         tw2[0][ch] = 0.0f; tw2[1][ch] = 0.0f;
     }
 
+    float zx = 0.0f, zh = 0.0f, loss_acc = 0.0f;
+    const float bo0 = (FUSED && !TRES) ? pl[L.o_b_out] : 0.0f, bo1 = (FUSED && !TRES) ? pl[L.o_b_out + 1] : 0.0f;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
-        const float2* dyg = reinterpret_cast<const float2*>(a.dy) + (size_t)b * T;
+        const size_t base = (FUSED && a.frame_idx) ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+        const float2* dyg = reinterpret_cast<const float2*>(FUSED ? a.target : a.dy) + base;      // FUSED: the target
         // ---- forward, as delta_eval_kernel ----
         {
             float h = 0.0f, hp = 0.0f, xp = 0.0f, accx = accx0, acch = acch0;
@@ -711,6 +718,7 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
                     const float d = fv - xp, ad = __builtin_fabsf(d);
                     const float dm = !(ad < thx) ? d : 0.0f;
                     xp = (ad >= thx) ? fv : xp;
+                    if constexpr (FUSED) zx += (dm == 0.0f) ? 1.0f : 0.0f;
                     float ax = accx;
 #pragma unroll
                     for (int i = 0; i < 6; ++i)
@@ -719,6 +727,7 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
                     const bool keeph = !(adh < thh);
                     const float dhm = keeph ? dhv : 0.0f;
                     hp = (adh >= thh) ? h : hp;
+                    if constexpr (FUSED) zh += (vo && dhm == 0.0f) ? 1.0f : 0.0f;
                     const bool nrow = !JAN && role == 2;
                     const float res = rotdot(nrow ? acch : ax, wrec, dhm);
                     accx = nrow ? ax : res; acch = nrow ? res : acch;
@@ -746,13 +755,12 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
         for (int t0 = 0; t0 < T; t0 += 64) {
             const int t = t0 + lane;
             if (t < T) {
-                const float2 dyv = dyg[t];
-                *reinterpret_cast<float2*>(dyb + 2 * t) = dyv;
-                dbo0 += dyv.x; dbo1 += dyv.y;
+                float2 dyv = dyg[t];                                   // dL/dy(t) — FUSED: the target of step t for now
+                float2 xc, xm, xq;
+                float s1[3], hs[3], s2a = 0.0f, s2b = 0.0f;
                 if constexpr (TRES) {
                     const float2 zero = make_float2(0.0f, 0.0f);
-                    const float2 xc = xg[t], xm = t - kDHalo >= 0 ? xg[t - kDHalo] : zero, xq = t + kDHalo < T ? xg[t + kDHalo] : zero;
-                    float s1[3], hs[3], s2a = 0.0f, s2b = 0.0f;
+                    xc = xg[t]; xm = t - kDHalo >= 0 ? xg[t - kDHalo] : zero; xq = t + kDHalo < T ? xg[t + kDHalo] : zero;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         s1[ch] = w1[ch][0] * xm.x;
@@ -762,6 +770,28 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
                         hs[ch] = hardswishf_(s1[ch]);
                         s2a = __builtin_fmaf(w2[0][ch], hs[ch], s2a); s2b = __builtin_fmaf(w2[1][ch], hs[ch], s2b);
                     }
+                }
+                if constexpr (FUSED) {
+                    // y(t) = fc_out h(t) (+ bias | + the skip), in delta_eval_kernel's order; then the loss term and dL/dy of the step
+                    float y0 = bo0, y1 = bo1;
+                    const float* hrow = hist + (t + 1) * 16;
+                    for (int c = 0; c < H; ++c) {
+                        const float hv = hrow[c];
+                        y0 = __builtin_fmaf(pl[L.o_w_out + c], hv, y0); y1 = __builtin_fmaf(pl[L.o_w_out + H + c], hv, y1);
+                    }
+                    if constexpr (TRES) { y0 += hardswishf_(s2a); y1 += hardswishf_(s2b); }
+                    const float d0 = y0 - dyv.x, d1 = y1 - dyv.y;
+                    if (a.loss_kind == ODPD_LOSS_L2) {
+                        loss_acc += __builtin_fmaf(d0, d0, d1 * d1);
+                        dyv = make_float2(2.0f * a.inv_count * d0, 2.0f * a.inv_count * d1);
+                    } else {
+                        loss_acc += __builtin_fabsf(d0) + __builtin_fabsf(d1);
+                        dyv = make_float2(d0 > 0.0f ? a.inv_count : (d0 < 0.0f ? -a.inv_count : 0.0f), d1 > 0.0f ? a.inv_count : (d1 < 0.0f ? -a.inv_count : 0.0f));
+                    }
+                }
+                *reinterpret_cast<float2*>(dyb + 2 * t) = dyv;
+                dbo0 += dyv.x; dbo1 += dyv.y;
+                if constexpr (TRES) {
                     const float d2a = dyv.x * hswish_grad_(s2a), d2b = dyv.y * hswish_grad_(s2b);
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
@@ -822,7 +852,24 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
     }
     // ---- the workgroup's row of partial gradients (every entry written) ----
     float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
-    if (lane < kLossCols) prow[L.P + lane] = 0.0f;
+    {
+        const float lp = FUSED ? wave_sum_(loss_acc) : 0.0f;
+        if (lane < kLossCols) prow[L.P + lane] = lane == 0 ? lp : 0.0f;
+    }
+    if constexpr (FUSED) {
+        if (a.stats != nullptr) {      // as delta_eval_kernel: dx zeros on the six feature lanes of row 0, dh zeros on the hidden units of row 0
+            float tx = (role == 0 && col < 6) ? zx : 0.0f, th = role == 0 ? zh : 0.0f;
+            for (int o = 32; o > 0; o >>= 1) { tx += __shfl_down(tx, o); th += __shfl_down(th, o); }
+            if (lane == 0) {
+                atomicAdd(&a.stats[0], (double)tx);
+                atomicAdd(&a.stats[2], (double)th);
+            }
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                atomicAdd(&a.stats[1], 6.0 * (double)a.B * (double)a.T);
+                atomicAdd(&a.stats[3], (double)a.H * (double)a.B * (double)a.T);
+            }
+        }
+    }
     if (vo && role == 0) { prow[L.o_w_out + col] = dwo0; prow[L.o_w_out + H + col] = dwo1; }
     if constexpr (TRES) {
 #pragma unroll
@@ -947,6 +994,30 @@ static int jan_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
     return (int)hipGetLastError();
+}
+// ---- fused train step at the reference's batch sizes (one frame per single-wave workgroup): delta_gp_bwd_kernel<.., FUSED> ----
+bool delta_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    if (m->flags & ODPD_FLAG_NEED_DX) return false;
+    if (m->backbone == ODPD_DELTAJANET) return jan_train_uses_gp(m, B, T);
+    if (m->backbone != ODPD_DELTAGRU && m->backbone != ODPD_TRES_DELTAGRU) return false;
+    return delta_bwd_uses_gp(m, B, T);
+}
+int delta_gp_train_rows(const odpd_model_t* m, int B, int T) {
+    return m->backbone == ODPD_DELTAJANET ? jan_gp_rows(m, B, T) : delta_gp_rows(m, B, T);
+}
+// a.stats: the four sparsity counters of the step's forward pass (nullable); a.x / a.target: (B,T,2) tensors or frames of resident streams
+int delta_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (!delta_train_uses_gp(m, a.B, a.T)) return ODPD_EUNSUPPORTED;
+    const bool jan = m->backbone == ODPD_DELTAJANET, tres = m->backbone == ODPD_TRES_DELTAGRU;
+    const int P = jan ? jan_P(m) : delta_layout(m->hidden, tres).P;
+    const size_t lds = delta_gp_lds_bytes(P, a.T);
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(delta_gp_train_rows(m, a.B, a.T)), dim3(64), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    if (jan) return launch(delta_gp_bwd_kernel<false, true, true>);
+    return tres ? launch(delta_gp_bwd_kernel<true, false, true>) : launch(delta_gp_bwd_kernel<false, false, true>);
 }
 int delta_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (jan_gp_ok(m) && ((a.ckpt == nullptr && a.B <= 2 * device_cus()) || (a.ckpt != nullptr && jan_train_uses_gp(m, a.B, a.T))))

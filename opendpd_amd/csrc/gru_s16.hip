@@ -156,14 +156,30 @@ struct S16Grad {
     f32x4 thh[3], tih[3], thid;
     f32x4 db_hn, db_hid, dwout[2];
     float dwf[2][2];
+    // K-packed weight gradient (s16_packgrad): dW_i{r,z} of feature slots 0..3 as per-lane sums over the lane's four sequences
+    // (transposed domain: lane (u, k) holds unit u, sequences 4k..4k+3); tih[0], tih[1] are then unused
+    float vr[4], vz[4];
     __device__ __forceinline__ void zero() {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 3; ++g) { thh[g] = z4; tih[g] = z4; }
         thid = z4; db_hn = z4; db_hid = z4; dwout[0] = z4; dwout[1] = z4;
         dwf[0][0] = dwf[0][1] = dwf[1][0] = dwf[1][1] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vr[j] = vz[j] = 0.f;
     }
 };
+// K-packing of the WEIGHT GRADIENT (r04; the forward's K-packing is s16_slots_pk): hidden <= 13 leaves columns 13..15 of the
+// W_hh-gradient tiles empty, and the r / z gates' dW_hh and dW_ih tiles share their A operand (the transposed gate gradient).  So
+// feature slots 4, 5, 6 (f4, f5 and the constant 1 that carries the bias gradient) ride in columns 13..15 of the h tile — three b32
+// LDS stores per step — and come out of the SAME MFMAs as dW_hh; slots 0..3 are 32 plain FMAs in the transposed domain on a
+// broadcast float4 of the feature tile.  The two dW_ih tiles of r and z (8 of the 28 weight-gradient MFMAs of a step) disappear; the n
+// gate keeps its tile (its dW_hh tile contracts r (.) dnp, not dnp).
+#ifdef ODPD_NO_PACKGRAD
+constexpr bool s16_packgrad(bool pack, bool nw) { return false; }
+#else
+constexpr bool s16_packgrad(bool pack, bool nw) { return pack && nw; }
+#endif
 
 // One block of <= S steps: recompute the forward pass into registers, then back-propagate.
 //   h    : state at the start of the block          dh  : in/out carry dL/dh
@@ -227,17 +243,9 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const flo
             f32x4 act, hid;
             const f32x4 ht = fma4(z, sub4(hp, nn), nn);
             if constexpr (DG) {
-#ifdef ODPD_EXP_HEAD2      // timing experiment: two accumulator chains instead of one dependent 4-chunk chain
-                f32x4 hid1 = {0.f, 0.f, 0.f, 0.f};
-                hid = w.bhid;
-                hid = mfma4(w.whid[0], ht[0], hid); hid1 = mfma4(w.whid[1], ht[1], hid1);
-                hid = mfma4(w.whid[2], ht[2], hid); hid1 = mfma4(w.whid[3], ht[3], hid1);
-                hid = add4(hid, hid1);
-#else
                 hid = w.bhid;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) hid = mfma4(w.whid[c], ht[c], hid);
-#endif
                 ODPD_EACH4 act[i] = relu_(hid[i]);
             } else {
                 act = ht;
@@ -277,17 +285,11 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const flo
             if constexpr (DG) {
                 ODPD_EACH4 dhid[i] = dact[i] * relu_gate(hid[i]);
                 if constexpr (NW) G.db_hid = add4(G.db_hid, dhid);
-#ifdef ODPD_EXP_HEAD2
-                f32x4 dht1 = {0.f, 0.f, 0.f, 0.f};
-                dht = dh;
-                dht = mfma4(w.whidT[0], dhid[0], dht); dht1 = mfma4(w.whidT[1], dhid[1], dht1);
-                dht = mfma4(w.whidT[2], dhid[2], dht); dht1 = mfma4(w.whidT[3], dhid[3], dht1);
-                dht = add4(dht, dht1);
-#else
+                // (r04 timing experiments, profiles/r04/headline_experiments.md: opening the chain at 0 and adding the carried dL/dh
+                // afterwards — one add instead of four MFMAs on the step-to-step chain — changes nothing: +0.3 %, noise)
                 dht = dh;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) dht = mfma4(w.whidT[c], dhid[c], dht);
-#endif
             } else {
                 dht = add4(dh, dact);
             }
@@ -305,6 +307,33 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const flo
             const f32x4 dzp = mul4(mul4(sub4(hp, nn), z), dn);
             const f32x4 drp = mul4(mul4(dgh, gh), omr);
             if constexpr (NW) G.db_hn = add4(G.db_hn, dgh);
+            float rT[4], zT[4], nT[4], gT[4], hT[4], dT[4], fT[4];
+            constexpr bool PG = s16_packgrad(PACK, NW);
+            // the step's transposes through LDS (sequence index onto K): tile stores, then the loads of the transposed operands
+            auto transposes = [&]() {
+                wave_lds_fence();
+                tile_put(t_r, n, q, drp);
+                tile_put(t_z, n, q, dzp);
+                tile_put(t_n, n, q, dnp);
+                tile_put(t_g, n, q, dgh);
+                tile_put(t_h, n, q, hp);
+                if constexpr (PG) {      // columns 13..15 of the h tile (units 13..15: identically 0) <- feature slots 4, 5, 6 of the sequence
+                    t_h[n * kTilePitch + 13 + q] = fs_s[st][1];      // (quad 3 holds slot 7 = 0 and lands in the row's pad column 16: no exec masking)
+                }
+                if constexpr (DG) tile_put(t_d, n, q, dhid);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) t_f[n * kTilePitch + 4 * c + q] = fs_s[st][c];
+                wave_lds_fence();
+                tile_get(t_r, n, q, rT);
+                tile_get(t_z, n, q, zT);
+                tile_get(t_n, n, q, nT);
+                tile_get(t_g, n, q, gT);
+                tile_get(t_h, n, q, hT);
+                tile_get(t_f, n, q, fT);
+                if constexpr (DG) tile_get(t_d, n, q, dT);
+            };
+            // (issued HERE, in front of the 12 W_hh^T MFMAs that could cover the LDS round trip, and pinned with a sched_barrier, the step
+            // got 1 % SLOWER: 28 more live registers across those MFMAs, scratch 212 -> 252 B per lane — profiles/r04/headline_experiments.md)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 acc0 = mfma4(w.whhT[0][c], drp[c], acc0);
@@ -343,33 +372,28 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const flo
             }
             if constexpr (NW) {
             // weight gradients: transpose through LDS (sequence index onto K), then rank-16 MFMA updates
-            wave_lds_fence();
-            tile_put(t_r, n, q, drp);
-            tile_put(t_z, n, q, dzp);
-            tile_put(t_n, n, q, dnp);
-            tile_put(t_g, n, q, dgh);
-            tile_put(t_h, n, q, hp);
-            if constexpr (DG) tile_put(t_d, n, q, dhid);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) t_f[n * kTilePitch + 4 * c + q] = fs_s[st][c];
-            wave_lds_fence();
-            float rT[4], zT[4], nT[4], gT[4], hT[4], dT[4], fT[4];
-            tile_get(t_r, n, q, rT);
-            tile_get(t_z, n, q, zT);
-            tile_get(t_n, n, q, nT);
-            tile_get(t_g, n, q, gT);
-            tile_get(t_h, n, q, hT);
-            tile_get(t_f, n, q, fT);
-            if constexpr (DG) tile_get(t_d, n, q, dT);
+            transposes();
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 G.thh[0] = mfma4(rT[c], hT[c], G.thh[0]);
                 G.thh[1] = mfma4(zT[c], hT[c], G.thh[1]);
                 G.thh[2] = mfma4(gT[c], hT[c], G.thh[2]);
-                G.tih[0] = mfma4(rT[c], fT[c], G.tih[0]);
-                G.tih[1] = mfma4(zT[c], fT[c], G.tih[1]);
+                if constexpr (!PG) {
+                    G.tih[0] = mfma4(rT[c], fT[c], G.tih[0]);
+                    G.tih[1] = mfma4(zT[c], fT[c], G.tih[1]);
+                }
                 G.tih[2] = mfma4(nT[c], fT[c], G.tih[2]);
                 if constexpr (DG) G.thid = mfma4(dT[c], hTn[c], G.thid);
+            }
+            if constexpr (PG) {      // slots 0..3 of sequence 4q + c: one broadcast float4 per c (all 16 unit lanes read the same address)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 f = *reinterpret_cast<const float4*>(t_f + (4 * q + c) * kTilePitch);
+                    G.vr[0] = __builtin_fmaf(rT[c], f.x, G.vr[0]); G.vr[1] = __builtin_fmaf(rT[c], f.y, G.vr[1]);
+                    G.vr[2] = __builtin_fmaf(rT[c], f.z, G.vr[2]); G.vr[3] = __builtin_fmaf(rT[c], f.w, G.vr[3]);
+                    G.vz[0] = __builtin_fmaf(zT[c], f.x, G.vz[0]); G.vz[1] = __builtin_fmaf(zT[c], f.y, G.vz[1]);
+                    G.vz[2] = __builtin_fmaf(zT[c], f.z, G.vz[2]); G.vz[3] = __builtin_fmaf(zT[c], f.w, G.vz[3]);
+                }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) hTn[c] = hT[c];
@@ -379,7 +403,7 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const flo
 }
 
 // the wave's row of partial gradients (every entry written), layout = flattened parameter order + 4 loss columns
-template <int FM, bool DG>
+template <int FM, bool DG, bool PG = false>
 __device__ __forceinline__ void s16_write_row(float* prow, const GruLayout& L, S16Grad<DG>& G, int n, int q, float loss_acc) {
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH;
     const int H = L.H, OW = DG ? H + 6 : H;
@@ -390,15 +414,28 @@ __device__ __forceinline__ void s16_write_row(float* prow, const GruLayout& L, S
         for (int rr = 0; rr < 4; ++rr) {
             const int i = 4 * q + rr;
             if (i < H) {
-                const float v = G.tih[g][rr];
-                if (n < F) prow[L.o_w_ih + (g * H + i) * F + n] = v;
-                else if (n == F) {
-                    prow[L.o_b_ih + g * H + i] = v;
-                    if (g < 2) prow[L.o_b_hh + g * H + i] = v;
+                if (PG && g < 2) {       // K-packed: slots 4, 5, 6 of the r / z gates sit in columns 13, 14, 15 of their dW_hh tiles
+                    const float v = G.thh[g][rr];
+                    if (n >= 13 && n - 9 < F) prow[L.o_w_ih + (g * H + i) * F + n - 9] = v;
+                    else if (n - 9 == F) { prow[L.o_b_ih + g * H + i] = v; prow[L.o_b_hh + g * H + i] = v; }
+                } else {
+                    const float v = G.tih[g][rr];
+                    if (n < F) prow[L.o_w_ih + (g * H + i) * F + n] = v;
+                    else if (n == F) {
+                        prow[L.o_b_ih + g * H + i] = v;
+                        if (g < 2) prow[L.o_b_hh + g * H + i] = v;
+                    }
                 }
                 if (n < H) prow[L.o_w_hh + (g * H + i) * H + n] = G.thh[g][rr];
             }
         }
+    if constexpr (PG) {      // slots 0..3: lane (u = n, k = q) summed its sequences 4k..4k+3; the four k of a unit meet here
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r = quad_sum(G.vr[j]), z = quad_sum(G.vz[j]);
+            if (q == 0 && n < H) { prow[L.o_w_ih + (0 * H + n) * F + j] = r; prow[L.o_w_ih + (1 * H + n) * F + j] = z; }
+        }
+    }
     if constexpr (DG) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
@@ -468,9 +505,6 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
     G.zero();
     float loss_acc = 0.0f;
     const int nwaves = gridDim.x * nwb;
-#ifdef ODPD_EXP_PRIO       // timing experiment: static priority for the second-dispatched half of an eight-wave workgroup
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
         const bool valid = b0 + n < a.B;
@@ -575,7 +609,7 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
     // ---- one row of partial gradients per workgroup (fixed summation order) ----
     const int P4 = L.P + kLossCols;
     __syncthreads();
-    s16_write_row<FM, DG>(smem + wave * P4, L, G, n, q, loss_acc);
+    s16_write_row<FM, DG, s16_packgrad(PACK, NW)>(smem + wave * P4, L, G, n, q, loss_acc);
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * P4;
     for (int i = threadIdx.x; i < P4; i += blockDim.x) {

@@ -204,6 +204,10 @@ int launch_clip_optim(hipStream_t st, int kind, int64_t P, float* params, float*
                       double max_norm, float* norm_out, float* loss_out, float inv_count, const unsigned char* skip = nullptr,
                       const XchgDev* xchg = nullptr);
 int64_t gru_s16_workspace_floats(const odpd_model_t* m, int B, int T);
+// fused train step of the delta backbones at the reference's batch sizes (delta_family.hip: delta_gp_bwd_kernel<.., FUSED>)
+bool delta_train_uses_gp(const odpd_model_t* m, int B, int T);
+int delta_gp_train_rows(const odpd_model_t* m, int B, int T);
+int delta_gp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_family_rows(const odpd_model_t* m, int B);

@@ -112,12 +112,18 @@ class FusedAdamW:
             n = int(lib.odpd_train_workspace_floats(C.byref(self.backbone.desc), B, T))
             _lib.check(0 if n >= 0 else n, "odpd_train_workspace_floats")
             self._partials[key] = torch.empty(n, dtype=torch.float32, device=device) if n > 0 else None
+        if self._partials[key] is None and self.backbone.dx_needs_flag:
+            # delta backbones: the fused step's `workspace` argument carries the four sparsity counters of its forward pass (double[4];
+            # None while the module's statistics are switched off) — include/opendpd_hip.h, odpd_train_fwd_bwd
+            return self.backbone._stats_buffer(device)
         return self._partials[key]
 
     def has_fused(self, B, T):
         """True when the backbone has a single-launch fwd+loss+bwd kernel for this batch shape."""
         key = (B, T, "has_fused")
         self._check_tuning()
+        if self.backbone.dx_needs_flag:      # delta backbones: the trained model is never asked for dL/dx by this optimiser — a flag left behind by an
+            self.backbone.desc.flags &= ~_lib.FLAG_NEED_DX      # autograd call on the same module would route it to the dL/dx kernels
         if key not in self._fused_ok:
             lib = _lib.load()
             self._fused_ok[key] = int(lib.odpd_partial_rows(C.byref(self.backbone.desc), B, T, 1)) > 0
@@ -139,7 +145,7 @@ class FusedAdamW:
         """Partial-gradient rows of the one-launch cascade step (odpd_cascade_fwd_bwd: DPD wave + frozen-PA wave per frame), or None
         where the pair of models / the batch shape is not served by it."""
         self._ensure(device)
-        key = (B, T, "casc")
+        key = (B, T, "casc", int(self.backbone.desc.flags))     # (a quantised DPD in eval() is not served by the one-launch step)
         if key not in self._partials:
             rows = -1
             if self.pa is not None and self.pa.native and self.backbone.native:
@@ -363,6 +369,9 @@ class FusedAdamW:
                 and all(hasattr(loader, k) for k in ("epoch_order", "x", "y", "frame_length", "stride", "batch_size")) and loader.x.is_cuda
                 and loader.x.dtype == torch.float32):
             return False
+        for bb in (self.backbone, self.pa):       # quantised models: the descriptor's ODPD_FLAG_EVAL must say what the module says NOW
+            if hasattr(bb, "sync_mode"):          # (an evaluation pass leaves it set; the one-launch step serves train mode only)
+                bb.sync_mode()
         dev = loader.x.device
         if self.world_size() > 1 or self.native_comm() is not None:
             # sharded epoch from C++: needs the library-owned RCCL communicator and the one-launch step for this rank's shards
@@ -427,6 +436,8 @@ class FusedAdamW:
             self._partials[key] = (torch.empty(max(rows), self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32, device=dev),
                                    torch.empty(ws, dtype=torch.float32, device=dev) if ws > 0 else None)
         part, ws = self._partials[key]
+        if ws is None and self.backbone.dx_needs_flag:      # delta backbones: `workspace` = the sparsity counters (see train_workspace)
+            ws = self.backbone._stats_buffer(dev)
         order = loader.epoch_order()
         losses = torch.empty(n_steps, dtype=torch.float32, device=dev)
         fr = _lib.Frames(loader.x.data_ptr(), loader.y.data_ptr(), order.data_ptr(), n, T, loader.stride, _sample_format(loader.x, loader.y), 0)

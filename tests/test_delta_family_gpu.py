@@ -326,3 +326,68 @@ def test_gate_parallel_backward_kernel(bb, H, thx, thh, B, T):
         go, _ = o.backward(m, p, x, dy, need_dx=False)
         # a rounding-level difference can flip a threshold decision (see test_against_oracle_ragged)
         assert rel_err(got[1 << 30], go) < (GRAD_TOL if thx == 0.0 and thh == 0.0 else 5e-2)
+
+
+@pytest.mark.parametrize("bb,H,thx,thh", [("deltagru", 15, 0.01, 0.05), ("deltagru", 8, 0.0, 0.0), ("deltagru_tcnskip", 15, 0.01, 0.05), ("deltagru_tcnskip", 9, 0.05, 0.02),
+                                          ("deltajanet", 15, 0.0, 0.0), ("deltajanet", 7, 0.0, 0.0)])
+@pytest.mark.parametrize("B,T,loss", [(1, 1, "l2"), (3, 17, "l2"), (7, 65, "l1"), (64, 50, "l2"), (9, 200, "l2"), (256, 200, "l2"), (600, 50, "l1")])
+def test_fused_train_step_equals_the_split_chain(bb, H, thx, thh, B, T, loss):
+    """r04: the train_pa step of a delta backbone at the reference's batch sizes as ONE launch (delta_gp_bwd_kernel<.., FUSED>: its forward
+    pass counts the statistics, y / loss / dL/dy are formed inside with lane = time step) against the chain it replaces — evaluation
+    kernel, loss kernel, the same backward kernel fed with dL/dy: bit-identical gradients and parameters (same arithmetic in the same
+    order; TRes to 1e-7: its Hardswish is contracted differently), equal counters; loss and gradients against the oracle."""
+    from opendpd_amd import CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, _cascade_train_step, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    kw = dict(thx=thx, thh=thh) if bb != "deltajanet" else {}
+    rng = np.random.RandomState(B * 13 + T)
+    amp, ph = 0.05 + 0.85 * rng.rand(B, T, 1), 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    out = []
+    for fused in (True, False):
+        torch.manual_seed(H * 100 + B + T)
+        net = CoreModel(2, H, 1, bb, **kw).cuda()
+        with torch.no_grad():
+            for k, p in net.named_parameters():
+                if "bias" in k:
+                    p.uniform_(-0.3, 0.3)
+        p0 = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+        net.backbone.set_debug(1)
+        opt = FusedAdamW(net, lr=1e-3)
+        assert opt.has_fused(B, T)
+        xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+        lv = fused_train_step(opt, xt, tt, loss, 200.0) if fused else _cascade_train_step(opt, xt, tt, loss, 200.0, B * T * 2)
+        torch.cuda.synchronize()
+        st = net.backbone.statistics
+        out.append((float(lv.item()), opt.grad.cpu().numpy().copy(), net.backbone.flat_params().cpu().numpy().copy(),
+                    [st["num_dx_zeros"], st["num_dx_numel"], st["num_dh_zeros"], st["num_dh_numel"]]))
+    P = len(p0)
+    if B <= 512 and bb != "deltagru_tcnskip":      # (beyond 2 x CUs frames the chain's forward is the four-sequences-per-wave kernel: same values, another summation order)
+        assert np.array_equal(out[0][1][:P], out[1][1][:P]) and np.array_equal(out[0][2], out[1][2])
+    elif B <= 512:      # TRes: the compiler contracts Hardswish differently where the skip, its gradient and the loss meet in one kernel (1e-7 relative)
+        assert rel_err(out[0][1][:P], out[1][1][:P]) < (2e-6 if thx == 0.0 and thh == 0.0 else 5e-3) and rel_err(out[0][2], out[1][2]) < 1e-5
+    else:
+        assert rel_err(out[0][1][:P], out[1][1][:P]) < (2e-5 if thx == 0.0 and thh == 0.0 else 5e-3)
+    assert out[0][3][1] == out[1][3][1] == 6 * B * T and out[0][3][3] == out[1][3][3] == H * B * T
+    if B <= 512:
+        assert out[0][3] == out[1][3]
+    else:
+        assert all(abs(a - b) <= 1e-4 * max(b, 1) for a, b in zip(out[0][3], out[1][3]))
+    assert abs(out[0][0] - out[1][0]) <= 1e-6 * abs(out[1][0])
+    if B * T <= 3000:
+        o, m = Oracle("f32"), make_model(bb, H, *((thx, thh) if bb != "deltajanet" else ()))
+        yo, _ = o.forward(m, p0, x)
+        lo, dy = o.loss(loss, yo, t)
+        go, _ = o.backward(m, p0, x, dy, need_dx=False)
+        dense = thx == 0.0 and thh == 0.0
+        assert abs(out[0][0] - lo) <= (2e-5 if dense else 2e-2) * max(1.0, abs(lo))
+        assert rel_err(out[0][1][:P], go) < (GRAD_TOL if dense else 5e-2)
+
+
+def test_fused_delta_step_reads_frames_in_place_and_runs_the_native_epoch_loop():
+    """delta backbones now have a frame-reading fused kernel at the reference's batch sizes: net_train drives whole epochs through
+    odpd_train_epoch (the `workspace` argument carrying the sparsity counters) — same result as the per-step Python loop over gathered frames"""
+    import tests.test_e2e_gpu as e2e
+    e2e.test_native_epoch_loop_equals_per_step_loop("deltagru_tcnskip", 15, 50, 64)
+    e2e.test_native_epoch_loop_equals_per_step_loop("deltagru", 8, 200, 256)
