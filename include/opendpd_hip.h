@@ -286,11 +286,15 @@ int odpd_comm_allreduce_sum(void* stream, void* comm, float* buf, int64_t n);
  *   odpd_xchg_connect: after EVERY rank created: `handles` = world x 64 bytes in rank order (ignored for shared memory).
  *   odpd_xchg_unlink : after EVERY rank connected (shared-memory transport): drops the segment's name.
  * The handle then serves odpd_comm_allreduce_sum, odpd_train_epoch_dp, odpd_train_epoch_cascade, odpd_clip_optim_step_dp and
- * odpd_comm_destroy like an RCCL one.  A peer that does not arrive within $ODPD_XCHG_TIMEOUT_MS (5000) poisons the sum with NaN and
+ * odpd_comm_destroy like an RCCL one.  A peer that does not arrive within $ODPD_XCHG_TIMEOUT_MS (600 000: ten minutes, a collective's allowance under torch's NCCL
+ * watchdog) poisons the sum with NaN and
  * counts in odpd_comm_errors — a lost rank ends in NaN losses, never in a hung GPU. */
 int odpd_xchg_create(int world, int rank, const char* shm_name, void** comm_out, void* handle64_out);
 int odpd_xchg_connect(void* comm, const void* handles);
 int odpd_xchg_unlink(void* comm);
+/* how long an exchange waits for a peer's row before it gives up (ms <= 0: back to $ODPD_XCHG_TIMEOUT_MS / ten minutes); the
+ * communicator's builder uses a few seconds for its self-test, where the ranks have just met */
+int odpd_comm_set_timeout_ms(void* comm, int64_t ms);
 /* 0 = RCCL, 1 = one-shot exchange over hipIpc device memory, 2 = one-shot exchange over host shared memory */
 int odpd_comm_kind(void* comm);
 /* exchanges of this rank that timed out so far (synchronises the device); 0 for RCCL communicators */

@@ -85,6 +85,7 @@ _EXPORTS = {
     "odpd_xchg_create": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "odpd_xchg_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "odpd_xchg_unlink": (C.c_int, [C.c_void_p]),
+    "odpd_comm_set_timeout_ms": (C.c_int, [C.c_void_p, C.c_int64]),
     "odpd_comm_kind": (C.c_int, [C.c_void_p]),
     "odpd_comm_errors": (C.c_int, [C.c_void_p]),
     "odpd_clip_optim_step_dp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -136,9 +136,11 @@ extern "C" int odpd_comm_init(const void* id128, int world, int rank, void** com
 
 // ---- one-shot exchange: create (local slots) -> hand the 64-byte handles round (any host channel) -> connect ------------------------
 static long long xchg_timeout_ticks() {
+    // default 10 minutes — what torch.distributed's NCCL watchdog allows a collective: a rank that is merely late (rank 0 writing the
+    // epoch's checkpoint and logs) must not poison the step; a rank that is gone ends the wait, and the run, in NaN losses
     const char* e = getenv("ODPD_XCHG_TIMEOUT_MS");
-    const long long ms = e ? atoll(e) : 5000;
-    return (ms > 0 ? ms : 5000) * 100000LL;        // wall_clock64() counts at 100 MHz
+    const long long ms = e ? atoll(e) : 600000;
+    return (ms > 0 ? ms : 600000) * 100000LL;      // wall_clock64() counts at 100 MHz
 }
 extern "C" int odpd_xchg_create(int world, int rank, const char* shm_name, void** comm_out, void* handle64_out) {
     if (!comm_out || world < 1 || world > kXchgMaxWorld || rank < 0 || rank >= world) return ODPD_EINVAL;
@@ -234,6 +236,13 @@ extern "C" int odpd_comm_destroy(void* comm) {
     }
     delete cm;
     return rc;
+}
+// time-out of the one-shot exchange's wait for a peer (ms <= 0: back to $ODPD_XCHG_TIMEOUT_MS / the default); no-op for RCCL communicators
+extern "C" int odpd_comm_set_timeout_ms(void* comm, int64_t ms) {
+    Comm* cm = static_cast<Comm*>(comm);
+    if (!cm) return ODPD_EINVAL;
+    cm->timeout_ticks = ms > 0 ? ms * 100000LL : xchg_timeout_ticks();
+    return 0;
 }
 extern "C" int odpd_comm_kind(void* comm) { return comm ? static_cast<Comm*>(comm)->kind : ODPD_EINVAL; }
 // exchanges of this rank in which a peer's row did not arrive within the time-out (their sums were poisoned with NaN); synchronises

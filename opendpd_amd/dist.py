@@ -154,7 +154,10 @@ class NativeComm:
                     return
                 lib.odpd_xchg_unlink(self.handle)
             # self-test before the communicator is trusted with a gradient: three sums (both slot parities) of known vectors
+            # (the ranks have just met in _agree: a peer that does not show up within seconds here never will)
             good = True
+            if kind != "rccl":
+                lib.odpd_comm_set_timeout_ms(self.handle, int(os.environ.get("ODPD_XCHG_SELFTEST_TIMEOUT_MS", "10000")))
             try:
                 n = 1045
                 base = torch.arange(n, dtype=torch.float32, device=device)
@@ -170,6 +173,8 @@ class NativeComm:
                 self.why = self.why or "self-test all-reduce returned a wrong sum / timed out on a rank"
                 self.close(sync=False)
                 return
+            if kind != "rccl":
+                lib.odpd_comm_set_timeout_ms(self.handle, 0)       # from here on: $ODPD_XCHG_TIMEOUT_MS / ten minutes
         self.ok = True
 
     _count = 0

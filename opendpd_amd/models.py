@@ -120,7 +120,11 @@ class CoreModel(nn.Module):
         if not getattr(self.backbone, "native", True):
             if h_0 is None:  # models.py:154-155
                 h_0 = torch.zeros(self.num_layers, x.size(0), self.hidden_size, device=x.device, dtype=x.dtype)
-            return self.backbone(x, h_0)
+            # ATen restatement (outside the HIP kernels' envelope): its nn.GRU / nn.LSTM / conv layers run on ATen's own kernels, not
+            # through MIOpen — whose per-shape solver search and kernel compilation on a fresh box cost minutes (285 s of the r04 GPU suite
+            # were ONE such model) for layers of a few hundred parameters; the backward runs under autograd with the same setting recorded
+            with torch.backends.cudnn.flags(enabled=False):
+                return self.backbone(x, h_0)
         # the reference creates a zero h_0 (models.py:154-155); the kernels start from the zero state
         if h_0 is not None and bool((h_0 != 0).any()):
             raise NotImplementedError("non-zero initial hidden state is not supported by the HIP kernels")

@@ -125,6 +125,9 @@ class _FakeLib:
     def odpd_comm_allreduce_sum(self, *a):
         return self._rc("allreduce")
 
+    def odpd_comm_set_timeout_ms(self, handle, ms):
+        return 0
+
 
 def _comm_worker(rank, world, port, kind, script, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ODPD_COMM=kind)

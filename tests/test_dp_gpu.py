@@ -176,3 +176,26 @@ def test_two_gpus_equal_the_single_process_run(comm, tmp_path, monkeypatch):
     got = _ranks(specs, tmp_path, 2, comm, backend="nccl", share_gpu=False)
     for spec, ranks in zip(specs, got):
         _check(ranks, _single(spec, monkeypatch), ("xchg", "rccl") if comm == "auto" else comm, _name(spec))
+
+
+def test_a_peer_that_never_arrives_ends_in_nan_and_an_error_count_not_in_a_hung_gpu():
+    """rank 0 of a two-rank shared-memory communicator whose rank 1 does not exist: the exchange gives up after the communicator's time-out,
+    poisons the sum with NaN (so the step's loss and parameters say what happened) and counts the event"""
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    comm, h = C.c_void_p(), (C.c_ubyte * 64)()
+    name = f"/odpd_xchg_test_{os.getpid()}".encode()
+    assert lib.odpd_xchg_create(2, 0, name, C.byref(comm), C.cast(h, C.c_void_p)) == 0
+    try:
+        assert lib.odpd_xchg_connect(comm, None) == 0 and lib.odpd_xchg_unlink(comm) == 0
+        assert lib.odpd_comm_set_timeout_ms(comm, 200) == 0
+        buf = torch.arange(1045, dtype=torch.float32, device="cuda")
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        assert lib.odpd_comm_allreduce_sum(_lib.stream_ptr(), comm, _lib.ptr(buf), buf.numel()) == 0
+        t1.record()
+        torch.cuda.synchronize()
+        assert 150.0 <= t0.elapsed_time(t1) <= 2000.0
+        assert bool(torch.isnan(buf).all()) and lib.odpd_comm_errors(comm) == 1045
+    finally:
+        lib.odpd_comm_destroy(comm)
