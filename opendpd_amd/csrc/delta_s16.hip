@@ -301,13 +301,24 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
                     const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
                     ODPD_EACH4 { p0 = __builtin_fmaf(w0[i], st.h[mt][i], p0); p1 = __builtin_fmaf(w1[i], st.h[mt][i], p1); }
                 }
-                float y0 = quad_sum(p0) + sc.bout[0], y1 = quad_sum(p1) + sc.bout[1];
-                if constexpr (TRES) {
-                    float s1[3], s2[2];
-                    d16_tcn<TRES>(sc, xr[tt - d16::kHalo], xv, xr[tt + d16::kHalo], s1, s2);
-                    y0 += hardswishf_(s2[0]); y1 += hardswishf_(s2[1]);
-                }
+                const float y0 = quad_sum(p0) + sc.bout[0], y1 = quad_sum(p1) + sc.bout[1];
                 if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
+                if constexpr (TRES) {
+                    // the TCN skip has no state: instead of all four quads of a sequence evaluating the same 44 instructions every step
+                    // (r01..r03), quad q evaluates step q of each block of four steps and adds it to the parked output
+                    if ((tt & 3) == 3 || tt == len - 1) {
+                        const int ts = (tt & ~3) + q;
+                        wave_lds_fence();
+                        if (ts <= tt) {
+                            float s1[3], s2[2];
+                            d16_tcn<TRES>(sc, xr[ts - d16::kHalo], xr[ts], xr[ts + d16::kHalo], s1, s2);
+                            float2 yv = ys[n * kChunkPad + ts];
+                            yv.x += hardswishf_(s2[0]); yv.y += hardswishf_(s2[1]);
+                            ys[n * kChunkPad + ts] = yv;
+                        }
+                        wave_lds_fence();
+                    }
+                }
                 const int t1 = t0 + tt + 1;
                 if (ck != nullptr) {
                     // this step's decisions into the block's mask words: unit bits 4 s + i (weight 16^s 2^i), slot bits 16 + 2 s + c
@@ -416,6 +427,28 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
     auto tile = [tiles](int qty, int kt) { return tiles + (qty * NT + kt) * kTileFloats; };   // qty: 0 gr 1 gz 2 gn 3 gnh 4 dhm
     float* t_f = tiles + 5 * NT * kTileFloats;
     const f32x4 one = splat4(1.0f);
+    if constexpr (TRES) {
+        // TCN skip gradient (no state in it): quad q takes step q of the block — one evaluation per sequence and step instead of one
+        // exec-masked pass per step on a quarter of the lanes (r01..r03: ~108 of the step's ~450 VALU instructions)
+        if (q < nstep) {
+            const int tt = tloc + q;
+            const float2 dyv = dys[n * kChunkPad + tt];
+            float s1[3], s2[2];
+            const float2 xm = xr[tt - d16::kHalo], xc = xr[tt], xq = xr[tt + d16::kHalo];
+            d16_tcn<TRES>(sc, xm, xc, xq, s1, s2);
+            const float d2[2] = {dyv.x * d16_hsg(s2[0]), dyv.y * d16_hsg(s2[1])};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float hs = hardswishf_(s1[c]);
+                G.dw2[c] = __builtin_fmaf(d2[0], hs, G.dw2[c]);
+                G.dw2[3 + c] = __builtin_fmaf(d2[1], hs, G.dw2[3 + c]);
+                const float d1 = __builtin_fmaf(d2[0], sc.w2[c], d2[1] * sc.w2[3 + c]) * d16_hsg(s1[c]);
+                G.dw1[c * 6 + 0] = __builtin_fmaf(d1, xm.x, G.dw1[c * 6 + 0]); G.dw1[c * 6 + 1] = __builtin_fmaf(d1, xc.x, G.dw1[c * 6 + 1]);
+                G.dw1[c * 6 + 2] = __builtin_fmaf(d1, xq.x, G.dw1[c * 6 + 2]); G.dw1[c * 6 + 3] = __builtin_fmaf(d1, xm.y, G.dw1[c * 6 + 3]);
+                G.dw1[c * 6 + 4] = __builtin_fmaf(d1, xc.y, G.dw1[c * 6 + 4]); G.dw1[c * 6 + 5] = __builtin_fmaf(d1, xq.y, G.dw1[c * 6 + 5]);
+            }
+        }
+    }
 #pragma unroll
     for (int si = S - 1; si >= 0; --si) {
         if (FULL || si < nstep) {
@@ -423,24 +456,6 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
             const float2 dyv = dys[n * kChunkPad + tt];
             G.dbout[0] += q == 0 ? dyv.x : 0.0f;
             G.dbout[1] += q == 0 ? dyv.y : 0.0f;
-            if constexpr (TRES) {
-                if (q == 0) {    // per-sequence work: one lane of the four is enough
-                    float s1[3], s2[2];
-                    const float2 xm = xr[tt - d16::kHalo], xc = xr[tt], xq = xr[tt + d16::kHalo];
-                    d16_tcn<TRES>(sc, xm, xc, xq, s1, s2);
-                    const float d2[2] = {dyv.x * d16_hsg(s2[0]), dyv.y * d16_hsg(s2[1])};
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float hs = hardswishf_(s1[c]);
-                        G.dw2[c] = __builtin_fmaf(d2[0], hs, G.dw2[c]);
-                        G.dw2[3 + c] = __builtin_fmaf(d2[1], hs, G.dw2[3 + c]);
-                        const float d1 = __builtin_fmaf(d2[0], sc.w2[c], d2[1] * sc.w2[3 + c]) * d16_hsg(s1[c]);
-                        G.dw1[c * 6 + 0] = __builtin_fmaf(d1, xm.x, G.dw1[c * 6 + 0]); G.dw1[c * 6 + 1] = __builtin_fmaf(d1, xc.x, G.dw1[c * 6 + 1]);
-                        G.dw1[c * 6 + 2] = __builtin_fmaf(d1, xq.x, G.dw1[c * 6 + 2]); G.dw1[c * 6 + 3] = __builtin_fmaf(d1, xm.y, G.dw1[c * 6 + 3]);
-                        G.dw1[c * 6 + 4] = __builtin_fmaf(d1, xc.y, G.dw1[c * 6 + 4]); G.dw1[c * 6 + 5] = __builtin_fmaf(d1, xq.y, G.dw1[c * 6 + 5]);
-                    }
-                }
-            }
             f32x4 ghprev[NT];
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) {
@@ -602,12 +617,12 @@ __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L,
     if constexpr (TRES) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
-            const float v = row_sum16(G.dw1[i]);
+            const float v = quad_sum(row_sum16(G.dw1[i]));        // (every quad took a quarter of the steps)
             if (n == 0 && q == 0) prow[L.o_tcn0 + i] = v;
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const float v = row_sum16(G.dw2[i]);
+            const float v = quad_sum(row_sum16(G.dw2[i]));
             if (n == 0 && q == 0) prow[L.o_tcn2 + i] = v;
         }
     } else {
