@@ -206,9 +206,10 @@ __device__ __forceinline__ void d16_tcn(const D16Scalars<TRES>& sc, float2 xm, f
     }
 }
 
+template <int CH = kChunk>
 __device__ __forceinline__ void d16_stage_x(float2* lds, const float* g, int b0, int B, int T, int t0, int lane) {
     const float2* g2 = reinterpret_cast<const float2*>(g);
-    constexpr int PER = kChunk + 2 * d16::kHalo, TOT = 16 * PER, N = (TOT + 63) / 64;
+    constexpr int PER = CH + 2 * d16::kHalo, TOT = 16 * PER, N = (TOT + 63) / 64, STR = CH + 2 * d16::kHalo + 1;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int e = lane + 64 * j;
@@ -216,10 +217,34 @@ __device__ __forceinline__ void d16_stage_x(float2* lds, const float* g, int b0,
             const int m = e / PER, pos = e % PER, tg = t0 - d16::kHalo + pos;
             float2 v = make_float2(0.0f, 0.0f);          // outside the frame: the conv's zero padding
             if (tg >= 0 && tg < T) v = (b0 + m < B) ? g2[(size_t)(b0 + m) * T + tg] : make_float2(0.5f, 0.5f);
-            lds[m * d16::kStride + pos] = v;
+            lds[m * STR + pos] = v;
         }
     }
 }
+// stage_in / stage_out of odpd_seq.h for a kernel-local chunk length CH ([16 sequences][CH + 1] float2)
+template <int CH>
+__device__ __forceinline__ void d16_stage_in(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane, float2 fill) {
+    const float2* g2 = reinterpret_cast<const float2*>(g);
+    constexpr int N = 16 * CH / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / CH, tt = e % CH;
+        lds[m * (CH + 1) + tt] = (tt < len && b0 + m < B) ? g2[(size_t)(b0 + m) * T + t0 + tt] : fill;
+    }
+}
+template <int CH>
+__device__ __forceinline__ void d16_stage_out(const float2* lds, float* g, int b0, int B, int T, int t0, int len, int lane) {
+    float2* g2 = reinterpret_cast<float2*>(g);
+    constexpr int N = 16 * CH / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / CH, tt = e % CH;
+        if (tt < len && b0 + m < B) g2[(size_t)(b0 + m) * T + t0 + tt] = lds[m * (CH + 1) + tt];
+    }
+}
+// chunk length of the backward kernel.  (r04 experiment, profiles/r04/headline_experiments.md: with 16 steps per chunk eight waves fit the
+// LDS; under the 256-register cap of two waves per SIMD the kernel then spills 470 B per lane and is still 4 % faster — not shipped.)
+constexpr int kD16BwdCh = kChunk;
 
 template <int NT>
 __device__ __forceinline__ void d16_init_state(TabPtr tl, D16State<NT>& st) {
@@ -404,8 +429,14 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
     f32x4 all_units[NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) all_units[kt] = f32x4{1.f, 1.f, 1.f, 1.f};
-    f32x4 hprev_s[S][NT], dhm_s[S][NT], mh_s[S][NT], r_s[S][NT], z_s[S][NT], n_s[S][NT], nh_s[S][NT];
-    float dxm_s[S][2], mx_s[S][2];
+    // saved per step: the gates, the n-gate's state accumulator and the masked input deltas.  NOT saved (r04; they were 16 more registers
+    // per step): the masks — read back from the block's decision bits where they are used —, and h(t-1) / the masked state delta, which
+    // follow from the block's start state and the saved gates with a few VALU operations (hprev / dhm below)
+    f32x4 r_s[S][NT], z_s[S][NT], n_s[S][NT], nh_s[S][NT];
+    float dxm_s[S][2];
+    f32x4 h0[NT], hp0[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) { h0[kt] = st.h[kt]; hp0[kt] = st.hp[kt]; }
     TabPtr tl = opaque(tl0);
     {
         float zx = 0.f, zh = 0.f;
@@ -416,8 +447,10 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 const float2 xn = (tglob + si + 1 < a.T) ? xr[tloc + si + 1] : x0;
                 float fs[2];
                 d16_slots<TRES>(xv, xn, oh, fs);
-                d16_cell_fwd<TRES, NT, JAN, true>(tl, fs, a.thx, a.thh, slot_ok, all_units, st, hprev_s[si], dhm_s[si], mh_s[si], r_s[si],
-                                                  z_s[si], n_s[si], dxm_s[si], zx, zh, mx_s[si], mw, si);
+                f32x4 hprev_[NT], dhm_[NT], mh_[NT];
+                float mx_[2];
+                d16_cell_fwd<TRES, NT, JAN, true>(tl, fs, a.thx, a.thh, slot_ok, all_units, st, hprev_, dhm_, mh_, r_s[si],
+                                                  z_s[si], n_s[si], dxm_s[si], zx, zh, mx_, mw, si);
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) nh_s[si][kt] = st.dmnh[kt];
             }
@@ -432,7 +465,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
         // exec-masked pass per step on a quarter of the lanes (r01..r03: ~108 of the step's ~450 VALU instructions)
         if (q < nstep) {
             const int tt = tloc + q;
-            const float2 dyv = dys[n * kChunkPad + tt];
+            const float2 dyv = dys[n * (kD16BwdCh + 1) + tt];
             float s1[3], s2[2];
             const float2 xm = xr[tt - d16::kHalo], xc = xr[tt], xq = xr[tt + d16::kHalo];
             d16_tcn<TRES>(sc, xm, xc, xq, s1, s2);
@@ -453,19 +486,40 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
     for (int si = S - 1; si >= 0; --si) {
         if (FULL || si < nstep) {
             const int tt = tloc + si;
-            const float2 dyv = dys[n * kChunkPad + tt];
+            const float2 dyv = dys[n * (kD16BwdCh + 1) + tt];
             G.dbout[0] += q == 0 ? dyv.x : 0.0f;
             G.dbout[1] += q == 0 ? dyv.y : 0.0f;
+            __builtin_amdgcn_sched_barrier(0);      // keep every step's work together (the block is fully unrolled: measured -1.8 %)
+            // h(t-1), h_p before the step and the masked state delta of step si: the forward recurrences h <- z (h - n) + n and
+            // h_p <- kept ? h : h_p replayed over the block's earlier steps (same operations on the same values: the same bits)
+            f32x4 hprev[NT], dhm[NT], mhk[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x4 hh = h0[kt], pp = hp0[kt];
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    if (k < si) {
+                        ODPD_EACH4 pp[i] = d16_bit(mw[kt], 4 * k + i) ? hh[i] : pp[i];
+                        hh = fma4(z_s[k][kt], sub4(hh, n_s[k][kt]), n_s[k][kt]);
+                    }
+                }
+                hprev[kt] = hh;
+                ODPD_EACH4 {
+                    const bool keep = d16_bit(mw[kt], 4 * si + i);
+                    dhm[kt][i] = keep ? hh[i] - pp[i] : 0.0f;
+                    mhk[kt][i] = keep ? 1.0f : 0.0f;
+                }
+            }
             f32x4 ghprev[NT];
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) {
                 const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
                 const f32x4 r = r_s[si][mt], z = z_s[si][mt], nn = n_s[si][mt];
-                const f32x4 ht = fma4(z, sub4(hprev_s[si][mt], nn), nn);
+                const f32x4 ht = fma4(z, sub4(hprev[mt], nn), nn);
                 const f32x4 gh = add4(C.gh[mt], fma4(splat4(dyv.x), w0, mul4(w1, splat4(dyv.y))));
                 G.dwout[0][mt] = fma4(splat4(dyv.x), ht, G.dwout[0][mt]);
                 G.dwout[1][mt] = fma4(splat4(dyv.y), ht, G.dwout[1][mt]);
-                const f32x4 dn = mul4(gh, sub4(one, z)), dz = mul4(gh, sub4(hprev_s[si][mt], nn));
+                const f32x4 dn = mul4(gh, sub4(one, z)), dz = mul4(gh, sub4(hprev[mt], nn));
                 ghprev[mt] = mul4(gh, z);
                 f32x4 omn2;
                 ODPD_EACH4 omn2[i] = JAN ? nn[i] * (1.0f - nn[i]) : __builtin_fmaf(-nn[i], nn[i], 1.0f);     // sigmoid' | tanh'
@@ -488,7 +542,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
             s16n_matvec<NT>(tl, T::HHT + 2 * NT * NT, C.gnh, ddh);
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt) {
-                const f32x4 mk = mh_s[si][mt];
+                const f32x4 mk = mhk[mt];
                 C.gh[mt] = fma4(mk, add4(ddh[mt], C.ghp[mt]), ghprev[mt]);
                 ODPD_EACH4 C.ghp[mt][i] = __builtin_fmaf(-mk[i], ddh[mt][i], (1.0f - mk[i]) * C.ghp[mt][i]);
             }
@@ -509,7 +563,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 float dfs[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const float m = mx_s[si][c], g = ds[c];
+                    const float m = d16_bit(mw[0], 16 + 2 * si + c) ? 1.0f : 0.0f, g = ds[c];
                     dfs[c] = m * (g + C.gxp[c]);
                     C.gxp[c] = __builtin_fmaf(-m, g, (1.0f - m) * C.gxp[c]);
                 }
@@ -526,11 +580,11 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 }
                 dI = quad_sum(dI); dQ = quad_sum(dQ);
                 if (q == 0) {
-                    dxs[n * kChunkPad + tt] = make_float2(dI, dQ);
+                    dxs[n * (kD16BwdCh + 1) + tt] = make_float2(dI, dQ);
                     if constexpr (TRES) {
                         const int t1 = tglob + si + 1;
                         if (t1 >= a.T) { C.wrap[0] = nI; C.wrap[1] = nQ; }                 // torch.roll: the last step's "next" is sample 0
-                        else if (tt + 1 < chunk_len) { dxs[n * kChunkPad + tt + 1].x += nI; dxs[n * kChunkPad + tt + 1].y += nQ; }
+                        else if (tt + 1 < chunk_len) { dxs[n * (kD16BwdCh + 1) + tt + 1].x += nI; dxs[n * (kD16BwdCh + 1) + tt + 1].y += nQ; }
                         else if (dxrow != nullptr) {   // sample t + 1 lives in the chunk this wave flushed before: add at L2
                             __threadfence();
                             atomicAdd(dxrow + 2 * t1, nI);
@@ -547,7 +601,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 tile_put(tile(1, kt), n, q, C.gz[kt]);
                 tile_put(tile(2, kt), n, q, C.gn[kt]);
                 tile_put(tile(3, kt), n, q, C.gnh[kt]);
-                tile_put(tile(4, kt), n, q, dhm_s[si][kt]);
+                tile_put(tile(4, kt), n, q, dhm[kt]);
             }
             t_f[n * kTilePitch + q] = dxm_s[si][0];
             t_f[n * kTilePitch + 4 + q] = dxm_s[si][1];      // slots 6, 7 are zero deltas (the lanes' features are 0 there)
@@ -635,7 +689,7 @@ template <bool TRES, int NT, bool DX, bool JAN = false>
 __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     using T = D16<NT>;
     constexpr int S = kCkptStride;
-    constexpr int kWave = 2 * 16 * d16::kStride + (DX ? 2 : 1) * 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
+    constexpr int kWave = 2 * 16 * (kD16BwdCh + 2 * d16::kHalo + 1) + (DX ? 2 : 1) * 2 * 16 * (kD16BwdCh + 1) + T::kTiles * kTileFloats;
     constexpr int kGroups = DX ? T::NG_DX : T::NG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
@@ -657,11 +711,11 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
     float* wbase = tab + s16_tab_floats(kGroups) + (size_t)wave * kWave;
     float2* xs = reinterpret_cast<float2*>(wbase);
-    float2* dys = xs + 16 * d16::kStride;
-    float2* dxs = dys + 16 * kChunkPad;                   // DX only
-    float* tiles = reinterpret_cast<float*>(dys + (DX ? 2 : 1) * 16 * kChunkPad);
+    float2* dys = xs + 16 * (kD16BwdCh + 2 * d16::kHalo + 1);
+    float2* dxs = dys + 16 * (kD16BwdCh + 1);                   // DX only
+    float* tiles = reinterpret_cast<float*>(dys + (DX ? 2 : 1) * 16 * (kD16BwdCh + 1));
     for (int i = lane; i < kTileFloats; i += 64) tiles[5 * NT * kTileFloats + i] = 0.0f;
-    const float2* xr = xs + n * d16::kStride + d16::kHalo;
+    const float2* xr = xs + n * (kD16BwdCh + 2 * d16::kHalo + 1) + d16::kHalo;
     D16Grad<TRES, NT> G;
     G.zero();
     const int nwaves = gridDim.x * nwb;
@@ -679,19 +733,19 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
         int cur_chunk = -1, cur_len = 0;
         for (int blk = a.nck - 1; blk >= 0; --blk) {
             const int tb = blk * S, nstep = min(S, a.T - tb);
-            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            const int chunk = tb / kD16BwdCh, t0 = chunk * kD16BwdCh;
             if (chunk != cur_chunk) {
                 if constexpr (DX) {
                     if (cur_chunk >= 0) {
                         wave_lds_fence();
-                        stage_out<16>(dxs, a.dx, b0, a.B, a.T, cur_chunk * kChunk, cur_len, lane);
+                        d16_stage_out<kD16BwdCh>(dxs, a.dx, b0, a.B, a.T, cur_chunk * kD16BwdCh, cur_len, lane);
                     }
                 }
                 wave_lds_fence();
-                const int len = min(kChunk, a.T - t0);
+                const int len = min(kD16BwdCh, a.T - t0);
                 cur_len = len;
-                d16_stage_x(xs, a.x, b0, a.B, a.T, t0, lane);
-                stage_in<16>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                d16_stage_x<kD16BwdCh>(xs, a.x, b0, a.B, a.T, t0, lane);
+                d16_stage_in<kD16BwdCh>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
                 wave_lds_fence();
                 cur_chunk = chunk;
             }
@@ -715,9 +769,9 @@ __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
         }
         if constexpr (DX) {
             wave_lds_fence();
-            if (q == 0) { dxs[n * kChunkPad].x += C.wrap[0]; dxs[n * kChunkPad].y += C.wrap[1]; }   // roll(x, -1): step T-1 saw sample 0
+            if (q == 0) { dxs[n * (kD16BwdCh + 1)].x += C.wrap[0]; dxs[n * (kD16BwdCh + 1)].y += C.wrap[1]; }   // roll(x, -1): step T-1 saw sample 0
             wave_lds_fence();
-            stage_out<16>(dxs, a.dx, b0, a.B, a.T, 0, cur_len, lane);
+            d16_stage_out<kD16BwdCh>(dxs, a.dx, b0, a.B, a.T, 0, cur_len, lane);
             wave_lds_fence();
         }
         // gradient w.r.t. the initial accumulators = bias gradients (deltagru.py:165-170)
@@ -803,7 +857,7 @@ static size_t d16_bwd_lds(int P, int nt, int waves, bool dx) {
     const int groups = nt == 1 ? (dx ? D16<1>::NG_DX : D16<1>::NG) : (dx ? D16<2>::NG_DX : D16<2>::NG);
     const int tiles = nt == 1 ? D16<1>::kTiles : D16<2>::kTiles;
     size_t lds = ((size_t)pad4(P) + s16_tab_floats(groups) +
-                  (size_t)waves * (2 * 16 * d16::kStride + (dx ? 2 : 1) * 2 * 16 * kChunkPad + tiles * kTileFloats)) * sizeof(float);
+                  (size_t)waves * (2 * 16 * (kD16BwdCh + 2 * d16::kHalo + 1) + (dx ? 2 : 1) * 2 * 16 * (kD16BwdCh + 1) + tiles * kTileFloats)) * sizeof(float);
     if (lds < reduce_scratch_bytes(P, waves)) lds = reduce_scratch_bytes(P, waves);
     return lds;
 }
