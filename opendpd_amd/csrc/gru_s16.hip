@@ -239,6 +239,7 @@ __device__ __forceinline__ void s16_block(const SeqArgs& a, TabPtr tl, const flo
 #pragma unroll
     for (int st = S - 1; st >= 0; --st) {
         if (FULL || st < nstep) {
+            __builtin_amdgcn_sched_barrier(0);      // keep every backward step's work together in the unrolled block (r04: -0.8 %, same bits)
             const f32x4 hp = hp_s[st], r = r_s[st], z = z_s[st], nn = n_s[st], gh = g_s[st];
             f32x4 act, hid;
             const f32x4 ht = fma4(z, sub4(hp, nn), nn);

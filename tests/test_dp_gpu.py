@@ -61,11 +61,12 @@ def _check(ranks, ref, comm, what=""):
         for r in ranks[1:]:
             assert np.array_equal(ranks[0][k], r[k]), (what, k)
     # ... equal to the single-process run up to the summation order of the shards
-    assert np.abs(ranks[0]["losses"] - ref["losses"]).max() <= 2e-6 * np.abs(ref["losses"]).max(), what
-    assert np.abs(ranks[0]["params"] - ref["params"]).max() <= 3e-6 * np.abs(ref["params"]).max(), what
+    k = 1 + len(ranks) // 4       # (more shards: more re-associated partial sums in the gradient)
+    assert np.abs(ranks[0]["losses"] - ref["losses"]).max() <= k * 2e-6 * np.abs(ref["losses"]).max(), what
+    assert np.abs(ranks[0]["params"] - ref["params"]).max() <= k * 3e-6 * np.abs(ref["params"]).max(), what
     if len(ref["losses"]) == 1:      # one step: the all-reduced gradient itself
         scale = np.abs(ref["grad"][:P]).max()
-        assert np.abs(ranks[0]["grad"][:P] - ref["grad"][:P]).max() <= 1e-6 * scale, what
+        assert np.abs(ranks[0]["grad"][:P] - ref["grad"][:P]).max() <= k * 1e-6 * scale, what
 
 
 def _name(s):
@@ -199,3 +200,20 @@ def test_a_peer_that_never_arrives_ends_in_nan_and_an_error_count_not_in_a_hung_
         assert bool(torch.isnan(buf).all()) and lib.odpd_comm_errors(comm) == 1045
     finally:
         lib.odpd_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("comm", ["xchg", "xchg_shm"])
+def test_eight_ranks_on_one_gpu_equal_the_single_process_run(comm, tmp_path, monkeypatch):
+    """The driver's N = 8 shape on the one-GPU box: eight processes share the device, data plane = the one-shot exchange with a world of
+    eight (slot rows of eight sources, both parities, rank-order sums), shards of 8 / 4 / 1 / 0 frames per rank, whole sharded epochs from
+    the native loops — against the single-process run."""
+    specs = [dict(mode="step", bb="dgru", H=13, B=64, steps=3), dict(mode="step", bb="dgru", H=13, B=5, steps=2),       # B = 5: ranks 5..7 hold empty shards
+             dict(mode="epoch", bb="dgru", H=13, B=64, n=360), dict(mode="epoch", bb="vdlstm", H=13, B=37, n=200)]
+    if comm == "xchg":
+        specs.append(dict(mode="cascade_epoch", bb="deltagru_tcnskip", H=15, pa_bb="dgru", pa_H=23, B=32, n=170))
+    specs = [dict(s, T=40) for s in specs]
+    got = _ranks(specs, tmp_path, 8, comm)
+    for spec, ranks in zip(specs, got):
+        ref = _single(spec, monkeypatch)
+        assert len(ranks) == 8
+        _check(ranks, ref, comm, _name(spec))
