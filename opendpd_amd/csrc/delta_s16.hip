@@ -40,6 +40,10 @@ struct D16 {
     static constexpr int IHT = NG;                     // g*NT + kt : W_ig[16kt+4q+e][slot(m)], slot(m) = 4 (m & 3) + (m >> 2)  (dL/dx)
     static constexpr int NG_DX = IHT + 3 * NT;
     static constexpr int kCk = 2 * NT + 1;             // float4 per lane per checkpoint: h, h_p per unit tile + (x_p0, x_p1, masks)
+    // steps per checkpoint block.  Two unit tiles (hidden 17..32): two steps — the backward's per-step saved state x four steps x two
+    // tiles does not fit the register file even at one wave per SIMD (r03: 430 .. 630 B of scratch per lane), and since r04 a checkpoint
+    // is five float4, so halving the block costs 80 B per sequence and step of HBM traffic, not 208
+    static constexpr int S = NT == 1 ? kCkptStride : 2;
     static constexpr int kTiles = 5 * NT + 1;          // gr gz gn gnh dhm per unit tile + feature-delta tile
 };
 
@@ -266,7 +270,7 @@ __device__ __forceinline__ float4 d16_f4(const f32x4& v) { return make_float4(v[
 template <bool TRES, int NT, bool JAN = false>
 __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_fwd_kernel(SeqArgs a) {
     using T = D16<NT>;
-    constexpr int S = kCkptStride;
+    constexpr int S = D16<NT>::S;
     constexpr int kWave = 2 * 16 * d16::kStride + 2 * 16 * kChunkPad;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
@@ -424,7 +428,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                                               float2 x0, int n, int q, int tglob, int tloc, int nstep, int chunk_len, float* dxrow,
                                               D16State<NT> st, D16Carry<NT>& C, const unsigned (&mw)[NT]) {
     using T = D16<NT>;
-    constexpr int S = kCkptStride;
+    constexpr int S = D16<NT>::S;
     const bool slot_ok[2] = {true, q < 2};
     f32x4 all_units[NT];
 #pragma unroll
@@ -688,7 +692,7 @@ __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L,
 template <bool TRES, int NT, bool DX, bool JAN = false>
 __global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
     using T = D16<NT>;
-    constexpr int S = kCkptStride;
+    constexpr int S = D16<NT>::S;
     constexpr int kWave = 2 * 16 * (kD16BwdCh + 2 * d16::kHalo + 1) + (DX ? 2 : 1) * 2 * 16 * (kD16BwdCh + 1) + T::kTiles * kTileFloats;
     constexpr int kGroups = DX ? T::NG_DX : T::NG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -874,11 +878,14 @@ static LaunchShape d16_bwd_shape(const odpd_model_t* m, int ngroups) {
 }
 int delta_s16_rows(const odpd_model_t* m, int B) { return d16_bwd_shape(m, (B + 15) / 16).grid; }
 int64_t delta_s16_ckpt_floats(const odpd_model_t* m, int B, int T) {
-    return (int64_t)((B + 15) / 16) * num_ckpt(T) * (2 * d16_tiles(m->hidden) + 1) * 256;
+    const int nt = d16_tiles(m->hidden), S = nt == 1 ? D16<1>::S : D16<2>::S;
+    return (int64_t)((B + 15) / 16) * ((T + S - 1) / S) * (2 * nt + 1) * 256;
 }
 template <bool TRES, int NT, bool JAN = false>
-static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int P, int mode) {
+static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int P, int mode) {
     using T = D16<NT>;
+    SeqArgs a = a0;
+    a.nck = (a.T + T::S - 1) / T::S;                          // checkpoint blocks of this tile count (the generic count is for four steps)
     if (mode == 1) {
         const LaunchShape ls = d16_fwd_shape(a.ngroups, NT);
         const size_t lds = ((size_t)pad4(P) + s16_tab_floats(T::NG) + (size_t)ls.waves * (2 * 16 * d16::kStride + 2 * 16 * kChunkPad)) * sizeof(float);

@@ -15,7 +15,8 @@ namespace odpd {
 
 // BPTT checkpoint stride of an instantiation: the VDLSTM variant at one unit tile keeps a block of 2 steps (its 4-step block spilled 68
 // registers under the 256-register cap of two waves per SIMD), the others kCkptStride
-__host__ __device__ constexpr int l16_stride(bool vd, int nt) { return (vd && nt == 1) ? 2 : kCkptStride; }
+// (r04: two steps for the vdlstm at two unit tiles as well — four left lstm16_train_kernel<true, 2> with 336 B of scratch per lane at 512 registers)
+__host__ __device__ constexpr int l16_stride(bool vd, int nt) { return vd ? 2 : kCkptStride; }
 template <bool VD, int NT>
 struct L16 {
     static constexpr int F = VD ? 4 : 2, NCH = (F + 4) / 4;
