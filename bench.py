@@ -519,6 +519,22 @@ def main():
         strong = {}
         for gb in (256, 64):
             strong[f"global_batch_{gb}"] = strong_scaling_epoch(H, T, gb, dev, dist, world)
+        # N > 1: the same epochs over the OTHER library-owned collective (one-shot exchange vs RCCL), so that one run of the driver's
+        # command prices both at the batch size where the collective is a visible share of the step.  Built collectively like the first.
+        if world > 1 and nc is not None and nc.kind in ("xchg", "rccl") and not os.environ.get("ODPD_BENCH_NO_COMM_AB"):
+            from opendpd_amd import dist as odist
+            other = "rccl" if nc.kind == "xchg" else "xchg"
+            alt = odist.NativeComm(dev, other)
+            if alt.ok:
+                keep, odist._native = odist._native, alt
+                try:
+                    strong[f"collective_{other}"] = {f"global_batch_{gb}": strong_scaling_epoch(H, T, gb, dev, dist, world) for gb in (256, 64)}
+                finally:
+                    odist._native = keep
+                    alt.close()
+            else:
+                strong[f"collective_{other}"] = {"unavailable": alt.why}
+            strong["collective_of_the_figures_above"] = nc.kind
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * B * T / (kern_ms * 1e-3) / 1e9
