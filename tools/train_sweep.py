@@ -22,7 +22,7 @@ SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_
          "tcnn": list(range(1, 40, 3)) + [64], "gmp": [11] * 16, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
          "neuraltx": list(range(1, 40, 3)) + [64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15), "mcldnn": range(1, 17)}
 rng = np.random.RandomState(1)
-bad = []
+bad, flips = [], []
 for bb, sizes in SIZES.items():
     worst = [0.0, 0.0]
     for H in sizes:
@@ -61,6 +61,7 @@ for bb, sizes in SIZES.items():
                 ea, es = np.zeros_like(p), np.zeros_like(p)
                 opt = FusedAdamW(net, lr=1e-3)
                 xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(tgt).cuda()
+                prev_off = None
                 try:
                     for step in (1, 2):
                         lo = o.train_step(m, p, x, tgt, ea, es, step, 1e-3, 200.0, kind)
@@ -72,11 +73,26 @@ for bb, sizes in SIZES.items():
                         # AdamW's first steps move every parameter by ~lr * sign(g): a gradient entry within rounding of 0 may
                         # flip its sign, so the parameter tolerance is a fraction of lr relative to the parameter scale
                         if not (el < 5e-5 and ep < 2.5e-3) or not np.isfinite([el, ep]).all():
-                            bad.append((bb, H, B, T, kind, force, kw, step, f"loss {el:.2e} params {ep:.2e}"))
+                            # is it that flip?  The entries that moved differently must be entries whose (clipped) gradient is within
+                            # rounding of 0 in the ORACLE as well, and every other entry must agree tightly.  (Adam's first steps move an
+                            # entry by lr * g / (|g| + eps): a flip needs |g| ~ eps = 1e-8.)
+                            scale = max(np.abs(p).max(), 1e-30)
+                            off = np.abs(got - p) > 2e-4 * scale
+                            m1 = ea / (1.0 - 0.9 ** step)                      # bias-corrected first moment ~ the gradients so far
+                            tiny = np.abs(m1[off]) < 1e-6 * max(np.abs(m1).max(), 1e-30) if off.any() else np.array([False])
+                            rest = float(np.abs(got - p)[~off].max() / scale) if (~off).any() else 0.0
+                            carried = step > 1 and prev_off is not None and not (off & ~prev_off).any()      # the step-1 flip, one step on
+                            if np.isfinite([el, ep]).all() and el < 5e-5 and off.sum() <= 3 and (tiny.all() or carried) and rest < 2e-4:
+                                prev_off = off if prev_off is None else (prev_off | off)
+                                flips.append((bb, H, B, T, kind, force, step, f"{int(off.sum())} entr{'y' if off.sum() == 1 else 'ies'} with a gradient within 1e-6 of the "
+                                              f"largest moved the other way ({ep:.2e} of the parameter scale); all others within {rest:.1e}"))
+                            else:
+                                bad.append((bb, H, B, T, kind, force, kw, step, f"loss {el:.2e} params {ep:.2e}"))
                 except Exception as e:      # noqa: BLE001
                     bad.append((bb, H, B, T, kind, force, kw, 0, f"EXC {e}"))
     print(f"{bb:18s} worst rel err  loss {worst[0]:.2e}  params after a step {worst[1]:.2e}", flush=True)
 lib.odpd_set_tuning(b"s16_min_batch", -1)
+print(f"{len(flips)} step(s) in which a gradient entry within rounding of 0 took the other sign (AdamW then moves it by ~lr the other way): {flips}")
 print(f"{len(bad)} case(s) beyond tolerance")
 for b in bad[:60]:
     print("  ", b)
