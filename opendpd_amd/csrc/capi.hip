@@ -177,6 +177,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
     case FAM_GMP: return gmp_rows(m, B, T);
     case FAM_RVTDCNN: return fused ? rvtdcnn_train_rows(m, B, T) : rvtdcnn_rows(m, B, T);
     case FAM_QAT:      // fused: forward-with-checkpoints + backward-with-loss launches of the 16-sequences-per-wave kernels (same rows as their backward)
+        if (fused && qat_train_uses_gp(m, B, T)) return (int64_t)qat_gp_train_rows(m, B, T);      // (one frame per wave: the reference's batch sizes)
         if (fused) return qat_uses_s16(m, B) ? (int64_t)qat_s16_rows(m, B) : (int64_t)ODPD_EUNSUPPORTED;
         return qat_uses_s16(m, B) ? (int64_t)qat_s16_rows(m, B) : (int64_t)qgru_family_rows(m, B);
     default: return ODPD_EUNSUPPORTED;
@@ -194,7 +195,10 @@ extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int
     if (family_of(m) == FAM_DVR) return dvrjanet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_MCL) return mcldnn_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN) return odpd_param_count(m) > 0 ? 0 : (int64_t)ODPD_EUNSUPPORTED;
-    if (family_of(m) == FAM_QAT) return qat_uses_s16(m, B) ? qat_s16_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_QAT) {      // (one frame per wave: no scratch — `workspace` then carries the quantised TRes-DeltaGRU's counters)
+        if (qat_train_uses_gp(m, B, T)) return 0;
+        return qat_uses_s16(m, B) ? qat_s16_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+    }
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
     if (gru_uses_s16n(m, B)) return gru_s16n_ckpt_floats(m, B, T);
     return gru_train_uses_s16(m, B, T) ? gru_s16_workspace_floats(m, B, T) : 0;
@@ -282,7 +286,12 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     case FAM_MCL: return mcldnn_train_uses_gp(m, B, T) ? mcldnn_gp_train((hipStream_t)stream, m, a) : (int)ODPD_EUNSUPPORTED;
     case FAM_GMP: return gmp_train((hipStream_t)stream, m, a);
     case FAM_RVTDCNN: return rvtdcnn_train((hipStream_t)stream, m, a);
-    case FAM_QAT: return qat_uses_s16(m, B) ? qat_s16_launch((hipStream_t)stream, m, a, 0) : (int)ODPD_EUNSUPPORTED;
+    case FAM_QAT:
+        if (qat_train_uses_gp(m, B, T)) {
+            a.stats = m->backbone == ODPD_TRES_DELTAGRU ? reinterpret_cast<double*>(workspace) : nullptr; a.ckpt = nullptr;
+            return qat_gp_train((hipStream_t)stream, m, a);
+        }
+        return qat_uses_s16(m, B) ? qat_s16_launch((hipStream_t)stream, m, a, 0) : (int)ODPD_EUNSUPPORTED;
     default: return ODPD_EUNSUPPORTED;
     }
 }
@@ -342,7 +351,7 @@ inline bool framed_train_ok(const odpd_model_t* m) {
 // ... for this batch shape: also the one-sequence-per-wave fused kernels of lstm / vdlstm / pgjanet (their large-batch kernels take tensors)
 inline bool framed_train_ok_shape(const odpd_model_t* m, int B, int T) {
     if (framed_train_ok(m)) return true;
-    if (family_of(m) == FAM_QAT) return qat_uses_s16(m, B);
+    if (family_of(m) == FAM_QAT) return qat_train_uses_gp(m, B, T) || qat_uses_s16(m, B);
     if (family_of(m) == FAM_LSTM) return !lstm_train_uses_s16(m, B) && lstm_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_JANET) return janet_train_uses_gp(m, B, T);
     if (family_of(m) == FAM_DELTA) return delta_train_uses_gp(m, B, T);
@@ -353,7 +362,14 @@ inline bool framed_train_ok_shape(const odpd_model_t* m, int B, int T) {
     return false;
 }
 inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
-    if (family_of(m) == FAM_QAT) return framed_train_ok_shape(m, a.B, a.T) ? qat_s16_launch(st, m, a, 0) : (int)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_QAT) {
+        if (qat_train_uses_gp(m, a.B, a.T)) {      // (the `workspace` pointer of the framed entry points: the counters, as for the delta backbones)
+            SeqArgs b = a;
+            b.stats = m->backbone == ODPD_TRES_DELTAGRU ? reinterpret_cast<double*>(a.ckpt) : nullptr; b.ckpt = nullptr;
+            return qat_gp_train(st, m, b);
+        }
+        return framed_train_ok_shape(m, a.B, a.T) ? qat_s16_launch(st, m, a, 0) : (int)ODPD_EUNSUPPORTED;
+    }
     if (family_of(m) == FAM_GMP) return gmp_train(st, m, a);
     if (family_of(m) == FAM_RVTDCNN) return rvtdcnn_train(st, m, a);
     if (family_of(m) == FAM_LSTM) return framed_train_ok_shape(m, a.B, a.T) ? lstm_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;

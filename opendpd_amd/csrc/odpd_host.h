@@ -179,6 +179,9 @@ int qat_casc_launch(hipStream_t s, const odpd_model_t* dpd, int pv, bool dgp, in
 // evaluation passes of the quantised models, one sequence per wave (qat_cascade.hip)
 bool qat_uses_gp_eval(const odpd_model_t* m, int B, bool want_ckpt);
 int qat_gp_eval(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+bool qat_train_uses_gp(const odpd_model_t* m, int B, int T);      // train_pa --quant at the reference's batch sizes: one launch, one frame per wave
+int qat_gp_train_rows(const odpd_model_t* m, int B, int T);
+int qat_gp_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_cascade_train(hipStream_t s, const odpd_model_t* dpd, const odpd_model_t* pa, const CascArgs& a);
 // 16-sequences-per-wave fused kernel (gru_s16.hip) and the rule that selects it
 bool gru_train_uses_s16(const odpd_model_t* m, int B, int T);

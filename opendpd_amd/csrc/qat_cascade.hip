@@ -129,6 +129,47 @@ __global__ __launch_bounds__(64) void qat_eval_kernel(SeqArgs a, int bits_w, int
 }
 
 
+// The whole train step of a quantised model trained ALONE (train_pa --quant; Base_GRUQuantEnv models behind net_train, train_funcs.py:28-48) at
+// the reference's batch sizes: ONE frame per single-wave workgroup on the same engines — forward chunks (y into the loss: residual, loss
+// term, dL/dy parked in the engine's dL/du buffer, lane = time step), then the backward chunks in reverse, one row of partial gradients
+// per workgroup with the loss sum in column P.  Frames are read in place (tensors or resident streams).
+template <typename E, bool TRES>
+__global__ __launch_bounds__(64) void qat_gp_train_kernel(SeqArgs a, int bits_w, int bits_a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = a.T, NC = (T + kCascChunk - 1) / kCascChunk;
+    E e;
+    if constexpr (TRES) e.setup(smem, smem, a.params, a.H, T, T, bits_w, bits_a, a.thx, a.thh);
+    else e.setup(smem, smem, a.params, a.H, T, T, bits_w, bits_a);
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
+    float2* dyb = reinterpret_cast<float2*>(e.dyb);
+    float loss_acc = 0.0f;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
+        const float2* xg = reinterpret_cast<const float2*>(a.x) + base;
+        const float2* tg = reinterpret_cast<const float2*>(a.target) + base;
+        e.fwd_begin();
+        for (int k = 0; k < NC; ++k) {
+            const int t0 = k * kCascChunk;
+            e.fwd_chunk(k, t0, min(kCascChunk, T - t0), xg, [&](int t, float y0, float y1) {
+                const float2 tv = tg[t];
+                float d0, d1;
+                s16_loss(lossc, y0 - tv.x, y1 - tv.y, d0, d1, loss_acc);
+                dyb[t] = make_float2(d0, d1);
+            });
+        }
+        e.bwd_begin();
+        for (int c = NC - 1; c >= 0; --c) {
+            const int t0 = c * kCascChunk;
+            if constexpr (TRES) e.bwd_chunk(c, t0, min(kCascChunk, T - t0), xg);
+            else e.bwd_chunk(c, t0, min(kCascChunk, T - t0));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) loss_acc += __shfl_xor(loss_acc, o);
+    e.write_partials(a.partials + (size_t)blockIdx.x * (e.L.P + kLossCols), loss_acc);
+    if constexpr (TRES) e.add_stats(a.stats, a.B);
+}
+
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
@@ -235,5 +276,47 @@ int qat_gp_eval(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     return ODPD_EUNSUPPORTED;
 }
 
+
+// the train step of a quantised model trained alone, at the reference's batch sizes: every frame on a SIMD of its own (qat_gp_train_kernel)
+namespace {
+template <typename E, bool TRES> struct QatEngine { using type = E; static constexpr bool tres = TRES; };
+// f(QatEngine<engine, TRES>{}, parameter count) for the engine of a quantised model
+template <typename Fn>
+int64_t qat_with_engine(const odpd_model_t* m, Fn&& f) {
+    const bool lut = m->bits_w <= 8 && m->bits_a <= 8;
+    if (m->backbone == ODPD_TRES_DELTAGRU) {
+        const int P = q16::qat_layout(q16::K_TRES, m->hidden).P;
+        return lut ? f(QatEngine<q16::QatDeltaSeq<true>, true>{}, P) : f(QatEngine<q16::QatDeltaSeq<false>, true>{}, P);
+    }
+#define ODPD_QAT_ENGINE(BB_, MK_)                                                                                                    \
+    if (m->backbone == BB_) {                                                                                                        \
+        const int P = q16::qat_layout(MK_, m->hidden).P;                                                                            \
+        if (m->hidden > 16)                                                                                                         \
+            return lut ? f(QatEngine<q16::QatSeq<MK_, true, 2>, false>{}, P) : f(QatEngine<q16::QatSeq<MK_, false, 2>, false>{}, P); \
+        return lut ? f(QatEngine<q16::QatSeq<MK_, true, 1>, false>{}, P) : f(QatEngine<q16::QatSeq<MK_, false, 1>, false>{}, P);     \
+    }
+    ODPD_QAT_ENGINE(ODPD_GRU, q16::K_GRU) ODPD_QAT_ENGINE(ODPD_QGRU, q16::K_Q4) ODPD_QAT_ENGINE(ODPD_QGRU_AMP1, q16::K_A4)
+#undef ODPD_QAT_ENGINE
+    return ODPD_EUNSUPPORTED;
+}
+}  // namespace
+bool qat_train_uses_gp(const odpd_model_t* m, int B, int T) {
+    if (!qat_uses_gp_eval(m, B, false) || (m->flags & (ODPD_FLAG_NEED_DX | ODPD_FLAG_EVAL))) return false;
+    const int64_t lds = qat_with_engine(m, [&](auto eng, int P) { return (int64_t)decltype(eng)::type::region_floats(T, P) * (int64_t)sizeof(float); });
+    return lds > 0 && lds <= (int64_t)kMaxLds;
+}
+int qat_gp_train_rows(const odpd_model_t*, int B, int) { return B; }
+// a.stats: the sparsity counters of the quantised TRes-DeltaGRU's forward pass (nullable)
+int qat_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (!qat_train_uses_gp(m, a.B, a.T)) return ODPD_EUNSUPPORTED;
+    return (int)qat_with_engine(m, [&](auto eng, int P) {
+        using Eng = decltype(eng);
+        const size_t lds = (size_t)Eng::type::region_floats(a.T, P) * sizeof(float);
+        auto k = qat_gp_train_kernel<typename Eng::type, Eng::tres>;
+        if (int e = allow_big_lds(k, lds)) return (int64_t)e;
+        hipLaunchKernelGGL(k, dim3(qat_gp_train_rows(m, a.B, a.T)), dim3(64), lds, st, a, (int)m->bits_w, (int)m->bits_a);
+        return (int64_t)hipGetLastError();
+    });
+}
 
 }  // namespace odpd

@@ -165,6 +165,7 @@ class QuantTResDeltaGRU(_QuantBase):
     """deltagru_tcnskip after the surgery (the OpenDPDv2 QAT stage, bash_scripts/OpenDPDv2.sh:84-117): quantised delta cell and
     fc_out, float TCN skip (Conv1d / Hardswish are not swapped).  Same thresholds / sparsity interface as the float backbone."""
     backbone_name = "deltagru_tcnskip"
+    fused_stats = True      # the one-launch train step counts the sparsity statistics through its `workspace` argument (train_funcs.train_workspace)
 
     def __init__(self, hidden_size, bits_w, bits_a, thx=0.0, thh=0.0):
         super().__init__()

@@ -93,26 +93,32 @@ class FusedAdamW:
             self._partials, self._cascade_bufs, self._fused_ok = {}, {}, {}
             self._tuning_gen = gen
 
+    def _mode(self):
+        """Descriptor flags that take part in the kernel selection (quantised models: ODPD_FLAG_EVAL follows the module's mode)."""
+        if hasattr(self.backbone, "sync_mode"):
+            self.backbone.sync_mode()
+        return int(self.backbone.desc.flags) & _lib.FLAG_EVAL
+
     def partials(self, B, T, device):
         self._ensure(device)
-        if (B, T) not in self._partials:
+        key = (B, T, "fused", self._mode())
+        if key not in self._partials:
             lib = _lib.load()
             rows = int(lib.odpd_partial_rows(C.byref(self.backbone.desc), B, T, 1))
             _lib.check(0 if rows > 0 else rows, "odpd_partial_rows")
-            self._partials[(B, T)] = torch.empty(rows, self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32,
-                                                 device=device)
-        return self._partials[(B, T)]
+            self._partials[key] = torch.empty(rows, self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32, device=device)
+        return self._partials[key]
 
     def train_workspace(self, B, T, device):
         """Scratch of the fused kernel (HBM BPTT checkpoints of the large-batch path; None when not needed)."""
         self._ensure(device)
-        key = (B, T, "ws")
+        key = (B, T, "ws", self._mode())
         if key not in self._partials:
             lib = _lib.load()
             n = int(lib.odpd_train_workspace_floats(C.byref(self.backbone.desc), B, T))
             _lib.check(0 if n >= 0 else n, "odpd_train_workspace_floats")
             self._partials[key] = torch.empty(n, dtype=torch.float32, device=device) if n > 0 else None
-        if self._partials[key] is None and self.backbone.dx_needs_flag:
+        if self._partials[key] is None and (self.backbone.dx_needs_flag or getattr(self.backbone, "fused_stats", False)):
             # delta backbones: the fused step's `workspace` argument carries the four sparsity counters of its forward pass (double[4];
             # None while the module's statistics are switched off) — include/opendpd_hip.h, odpd_train_fwd_bwd
             return self.backbone._stats_buffer(device)
@@ -124,6 +130,7 @@ class FusedAdamW:
         self._check_tuning()
         if self.backbone.dx_needs_flag:      # delta backbones: the trained model is never asked for dL/dx by this optimiser — a flag left behind by an
             self.backbone.desc.flags &= ~_lib.FLAG_NEED_DX      # autograd call on the same module would route it to the dL/dx kernels
+        key = key + (self._mode(),)      # quantised models: the module's train / eval mode selects the kernel too (ODPD_FLAG_EVAL)
         if key not in self._fused_ok:
             lib = _lib.load()
             self._fused_ok[key] = int(lib.odpd_partial_rows(C.byref(self.backbone.desc), B, T, 1)) > 0
@@ -427,7 +434,7 @@ class FusedAdamW:
         n_steps = (n + B - 1) // B
         last = n - (n_steps - 1) * B
         comm = self.native_comm()
-        key = (B, T, last, "epoch", comm is not None)
+        key = (B, T, last, "epoch", comm is not None, self._mode())
         if key not in self._partials:
             sizes = self._shard_sizes(loader) if comm is not None else {B, last}
             rows = [int(lib.odpd_partial_rows(C.byref(self.backbone.desc), b, T, 1)) for b in sizes] or [1]
@@ -436,7 +443,7 @@ class FusedAdamW:
             self._partials[key] = (torch.empty(max(rows), self.backbone.n_flat + _lib.LOSS_COLS, dtype=torch.float32, device=dev),
                                    torch.empty(ws, dtype=torch.float32, device=dev) if ws > 0 else None)
         part, ws = self._partials[key]
-        if ws is None and self.backbone.dx_needs_flag:      # delta backbones: `workspace` = the sparsity counters (see train_workspace)
+        if ws is None and (self.backbone.dx_needs_flag or getattr(self.backbone, "fused_stats", False)):      # delta backbones: `workspace` = the sparsity counters (see train_workspace)
             ws = self.backbone._stats_buffer(dev)
         order = loader.epoch_order()
         losses = torch.empty(n_steps, dtype=torch.float32, device=dev)

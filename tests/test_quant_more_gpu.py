@@ -223,40 +223,76 @@ def test_openDPDv2_quantisation_stage_from_a_float_checkpoint(tmp_path):
     assert np.abs(y - fx["y_eval"]).max() <= 2.0 ** -12
 
 
-@pytest.mark.parametrize("bb,H,bits,B,T", [("qgru", 20, 8, 37, 41), ("gru", 11, 8, 5, 66), ("dgru", 13, 8, 19, 33), ("deltagru_tcnskip", 15, 8, 21, 50),
-                                            ("deltagru_tcnskip", 24, 16, 7, 35), ("qgru_amp1", 10, 16, 33, 20)])
-def test_fused_train_step_equals_the_split_chain(bb, H, bits, B, T):
-    """odpd_train_fwd_bwd on a quantised model = forward-with-checkpoints launch + backward launch that forms the output, the loss and
-    dL/dy inside (no y / dy round trip, no loss kernel): same loss and gradients as autograd through the split kernels (L2 and L1), also
-    with the batch given as frames of resident streams."""
+def _fused_equals_split(bb, H, bits, B, T, expect_one_launch):
     import ctypes as C
     from opendpd_amd import _lib
     from opendpd_amd.train_funcs import FrameBatch, FusedAdamW, fused_train_step
     lib = _lib.load()
+    tres = bb == "deltagru_tcnskip"
+    torch.manual_seed(B)
+    q = _fresh(bb, H, bits, *((0.01, 0.05) if tres else (0.0, 0.0))).cuda()
+    q.train()
+    g = torch.Generator(device="cuda").manual_seed(B + T)
+    xs = (torch.rand(B + T - 1, 2, device="cuda", generator=g) - 0.5) * 1.4
+    xs = (xs + 0.05 * torch.sign(xs)).contiguous()
+    ys = (torch.rand(B + T - 1, 2, device="cuda", generator=g) - 0.5).contiguous()
+    order = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+    x = torch.stack([xs[int(o):int(o) + T] for o in order]).contiguous()
+    t = torch.stack([ys[int(o):int(o) + T] for o in order]).contiguous()
+    q.eval()      # an evaluation pass first (net_eval between the epochs): the mode flag it leaves on the descriptor must not pick the step's kernels
+    with torch.no_grad():
+        q(x)
+    q.train()
+    opt = FusedAdamW(q, lr=0.0, weight_decay=0.0)
+    assert opt.has_fused(B, T)
+    one_launch = int(lib.odpd_train_workspace_floats(C.byref(q.backbone.desc), B, T)) == 0
+    assert one_launch == expect_one_launch
+    if one_launch:
+        assert int(lib.odpd_partial_rows(C.byref(q.backbone.desc), B, T, 1)) == B      # one frame per single-wave workgroup
+    for kind, fn in (("l2", torch.nn.functional.mse_loss), ("l1", torch.nn.functional.l1_loss)):
+        for p in q.parameters():
+            p.grad = None
+        if tres:
+            q.backbone.set_debug(1)
+        loss = fn(q(x), t)
+        loss.backward()
+        st_ref = _stats(q) if tres else None
+        gref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in q.parameters()]).cpu().numpy()
+        for inp, tgt in ((x, t), (FrameBatch(xs, ys, order, T, 1), None)):
+            if tres:
+                q.backbone.set_debug(1)
+            lf = fused_train_step(opt, inp, tgt, kind, 0.0)
+            assert abs(lf.item() - loss.item()) < 2e-6 * max(1.0, abs(loss.item())), kind
+            assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 2e-5, kind
+            if tres and one_launch:      # the one-launch step counts the forward pass's delta statistics as the module's forward does
+                assert np.array_equal(_stats(q), st_ref)
+
+
+@pytest.mark.parametrize("bb,H,bits,B,T", [("qgru", 20, 8, 37, 41), ("gru", 11, 8, 5, 66), ("dgru", 13, 8, 19, 33), ("deltagru_tcnskip", 15, 8, 21, 50),
+                                            ("deltagru_tcnskip", 24, 16, 7, 35), ("qgru_amp1", 10, 16, 33, 20)])
+def test_fused_train_step_equals_the_split_chain(bb, H, bits, B, T):
+    """odpd_train_fwd_bwd on a quantised model (sixteen sequences per wave) = forward-with-checkpoints launch + backward launch that forms the
+    output, the loss and dL/dy inside (no y / dy round trip, no loss kernel): same loss and gradients as autograd through the split kernels
+    (L2 and L1), also with the batch given as frames of resident streams."""
+    import ctypes as C
+    from opendpd_amd import _lib
+    lib = _lib.load()
     lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(0))
     try:
-        tres = bb == "deltagru_tcnskip"
-        torch.manual_seed(B)
-        q = _fresh(bb, H, bits, *((0.01, 0.05) if tres else (0.0, 0.0))).cuda()
-        q.train()
-        g = torch.Generator(device="cuda").manual_seed(B + T)
-        xs = (torch.rand(B + T - 1, 2, device="cuda", generator=g) - 0.5) * 1.4
-        xs = (xs + 0.05 * torch.sign(xs)).contiguous()
-        ys = (torch.rand(B + T - 1, 2, device="cuda", generator=g) - 0.5).contiguous()
-        order = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
-        x = torch.stack([xs[int(o):int(o) + T] for o in order]).contiguous()
-        t = torch.stack([ys[int(o):int(o) + T] for o in order]).contiguous()
-        opt = FusedAdamW(q, lr=0.0, weight_decay=0.0)
-        assert opt.has_fused(B, T)
-        for kind, fn in (("l2", torch.nn.functional.mse_loss), ("l1", torch.nn.functional.l1_loss)):
-            for p in q.parameters():
-                p.grad = None
-            loss = fn(q(x), t)
-            loss.backward()
-            gref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in q.parameters()]).cpu().numpy()
-            for inp, tgt in ((x, t), (FrameBatch(xs, ys, order, T, 1), None)):
-                lf = fused_train_step(opt, inp, tgt, kind, 0.0)
-                assert abs(lf.item() - loss.item()) < 2e-6 * max(1.0, abs(loss.item())), kind
-                assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 2e-5, kind
+        _fused_equals_split(bb, H, bits, B, T, False)
     finally:
         lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(-1))
+
+
+@pytest.mark.parametrize("bb,H,bits,B,T", [("qgru", 10, 8, 64, 50), ("qgru", 20, 8, 37, 41), ("gru", 11, 8, 5, 66), ("gru", 30, 16, 9, 40),
+                                            ("qgru_amp1", 16, 16, 33, 20), ("qgru_amp1", 10, 8, 256, 200),
+                                            ("deltagru_tcnskip", 15, 8, 64, 200), ("deltagru_tcnskip", 9, 16, 7, 35), ("deltagru_tcnskip", 16, 8, 300, 33)])
+def test_one_launch_train_step_at_the_reference_batch_sizes(bb, H, bits, B, T):
+    """train_pa --quant at the reference's batch sizes: the whole step body (forward, loss, backward) of a quantised model is ONE launch with
+    one frame per wave (csrc/qat_cascade.hip qat_gp_train_kernel; no checkpoint scratch) — same loss, gradients and sparsity counters as
+    autograd through the split kernels; quantised dgru has no such engine and keeps the two-launch step."""
+    _fused_equals_split(bb, H, bits, B, T, True)
+
+
+def test_quantised_dgru_keeps_the_two_launch_step():
+    _fused_equals_split("dgru", 13, 8, 19, 33, False)
