@@ -7,7 +7,8 @@ INT_Linear), on qgru at any hidden size (bash_scripts/quant_qgru_dpd_regr.sh:74 
 layer routes its gate arithmetic through such modules (deltagru_tcnskip.py:156-162, 286-290) — the OpenDPDv2 recipe
 (bash_scripts/OpenDPDv2.sh:84-117: W16A16 from a float checkpoint).  This script RUNS the reference for those models and
 stores inputs, train- / eval-mode outputs, gradients, three clip + AdamW steps, the sparsity counters (delta) and, for
-deltagru_tcnskip, the same from a `--pretrained_model` float checkpoint.
+deltagru_tcnskip, the same from a `--pretrained_model` float checkpoint.  The same is stored for lstm / vdlstm, where the surgery
+swaps only the nn.Linear heads (fc_out; fc_lambda_1 / fc_lambda_2 / fc_out) and the nn.LSTM core stays float.
 
 Usage:  python oracle/gen_golden_quant_more.py [name ...]
 """
@@ -41,6 +42,12 @@ CASES = [
     ("quant_tres_h30_w8a8_th", "deltagru_tcnskip", 30, 8, 0.005, 0.02, False),
     ("quant_tres_h15_w16a16_pre", "deltagru_tcnskip", 15, 16, 0.01, 0.05, True),
     ("quant_tres_h15_w8a8_pre", "deltagru_tcnskip", 15, 8, 0.01, 0.05, True),
+    # backbones in which the surgery finds only nn.Linear layers to swap (quant_envs.py:40-60): float nn.LSTM core, INT_Linear heads
+    ("quant_lstm_h14_w8a8", "lstm", 14, 8, 0, 0, False),
+    ("quant_lstm_h14_w16a16", "lstm", 14, 16, 0, 0, False),
+    ("quant_lstm_h24_w8a8", "lstm", 24, 8, 0, 0, False),
+    ("quant_vdlstm_h13_w8a8", "vdlstm", 13, 8, 0, 0, False),
+    ("quant_vdlstm_h13_w16a16", "vdlstm", 13, 16, 0, 0, False),
 ]
 
 

@@ -51,8 +51,10 @@ static int feat_dim(int bb) {
 }
 
 static int64_t qat_param_count(const odpd_model_t* m);
+static int64_t lstm_param_count(const odpd_model_t* m);
 int64_t oracle_param_count(const odpd_model_t* m) {
     int64_t H = m->hidden, F = feat_dim(m->backbone);
+    if (m->bits_w > 0 && (m->backbone == ODPD_LSTM || m->backbone == ODPD_VDLSTM)) return lstm_param_count(m);   /* quantised head(s) */
     if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET) return qat_param_count(m);   /* quantised models: + the quantiser scales */
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1:
@@ -287,27 +289,73 @@ static void gru_seq_bwd(const odpd_model_t* m, const gru_params_t* g, int T, con
 /* ------------------------------------------------------------------------------------------ */
 /* LSTM family: lstm.py:45-48 (h0 = c0 = 0), vdlstm.py:56-81.  nn.LSTM gate order i,f,g,o.     */
 /* ------------------------------------------------------------------------------------------ */
+static inline real q_pow2(real scale) {   /* quantizers.py:56-65 */
+    float l = rintf(log2f(fabsf((float)scale)));
+    return (real)ldexp(1.0, (int)l);
+}
+/* returns q(x); *pass = 1 if x/s lies inside [Qn,Qp] (gradient passes), else 0 */
+static inline real q_apply(real x, real s, int bits, real* pass) {
+    real qn = -(real)(1 << (bits - 1)), qp = (real)((1 << (bits - 1)) - 1);
+    real v = x / s;
+    if (pass) *pass = (v >= qn && v <= qp) ? (real)1 : (real)0;
+    v = v < qn ? qn : (v > qp ? qp : v);
+    return (real)rint((double)v) * s;
+}
+/* An nn.Linear of a backbone the reference's surgery leaves otherwise alone (lstm, vdlstm: quant_envs.py:40-60, 290-306 swap only their
+ * nn.Linear layers) as INT_Linear (quant_layers.py:48-85): y = q_w(W) q_a(in) + b on exact grid sums; the three scale parameters
+ * (weight_quantizer, act_quantizer, out_quantizer) sit behind the layer's weight and bias in named_parameters() order and get zero
+ * gradients (round() inside round_scale2pow2, quantizers.py:56-65). */
+static void qlin_fwd(const real* p, int64_t o_w, int64_t o_b, int64_t o_q, int n_out, int n_in, int bw, int ba, const real* in,
+                     real* inq, real* pass, real* out) {
+    real sw = q_pow2(p[o_q]), sa = q_pow2(p[o_q + 1]);
+    for (int j = 0; j < n_in; ++j) inq[j] = q_apply(in[j], sa, ba, &pass[j]);
+    for (int o = 0; o < n_out; ++o) {
+        double a = 0;
+        for (int j = 0; j < n_in; ++j) a += (double)inq[j] * (double)q_apply(p[o_w + o * n_in + j], sw, bw, NULL);
+        out[o] = (real)a + p[o_b + o];
+    }
+}
+/* dp[w] += dout x q_a(in) through the weight quantiser's pass mask, dp[b] += dout, din += pass x q_w(W)^T dout */
+static void qlin_bwd(const real* p, int64_t o_w, int64_t o_b, int64_t o_q, int n_out, int n_in, int bw, const real* dout,
+                     const real* inq, const real* pass, real* dp, real* din) {
+    real sw = q_pow2(p[o_q]);
+    for (int o = 0; o < n_out; ++o) {
+        dp[o_b + o] += dout[o];
+        for (int j = 0; j < n_in; ++j) {
+            real mk, wq = q_apply(p[o_w + o * n_in + j], sw, bw, &mk);
+            dp[o_w + o * n_in + j] += dout[o] * inq[j] * mk;
+            din[j] += pass[j] * dout[o] * wq;
+        }
+    }
+}
 typedef struct {
-    int H, F, vd;
-    int64_t o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_w_l1, o_b_l1, o_w_l2, o_b_l2;
+    int H, F, vd, q, bits_w, bits_a, eval;      /* q: the nn.Linear layers are INT_Linear (bits_w > 0); eval: ODPD_FLAG_EVAL */
+    int64_t o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_w_l1, o_b_l1, o_w_l2, o_b_l2, o_q_out, o_q_l1, o_q_l2, P;
 } lstm_layout_t;
 static void lstm_layout(const odpd_model_t* m, lstm_layout_t* g) {
     int64_t H = m->hidden, o = 0;
     g->H = (int)H; g->vd = (m->backbone == ODPD_VDLSTM); g->F = g->vd ? 4 : 2;
+    g->q = m->bits_w > 0; g->bits_w = m->bits_w; g->bits_a = m->bits_a; g->eval = (m->flags & 1);
+    g->o_q_out = g->o_q_l1 = g->o_q_l2 = -1;
     g->o_w_ih = o; o += 4 * H * g->F;
     g->o_w_hh = o; o += 4 * H * H;
     g->o_b_ih = o; o += 4 * H;
     g->o_b_hh = o; o += 4 * H;
     if (g->vd) {   /* fc_lambda_1, fc_lambda_2, fc_out (vdlstm.py:35-43) */
-        g->o_w_l1 = o; o += 4 * H; g->o_b_l1 = o; o += 4;
-        g->o_w_l2 = o; o += 4 * H; g->o_b_l2 = o; o += 4;
-        g->o_w_out = o; o += 2 * 8; g->o_b_out = o; o += 2;
+        g->o_w_l1 = o; o += 4 * H; g->o_b_l1 = o; o += 4; if (g->q) { g->o_q_l1 = o; o += 3; }
+        g->o_w_l2 = o; o += 4 * H; g->o_b_l2 = o; o += 4; if (g->q) { g->o_q_l2 = o; o += 3; }
+        g->o_w_out = o; o += 2 * 8; g->o_b_out = o; o += 2; if (g->q) { g->o_q_out = o; o += 3; }
     } else {
         g->o_w_l1 = g->o_b_l1 = g->o_w_l2 = g->o_b_l2 = 0;
-        g->o_w_out = o; o += 2 * H; g->o_b_out = o; o += 2;
+        g->o_w_out = o; o += 2 * H; g->o_b_out = o; o += 2; if (g->q) { g->o_q_out = o; o += 3; }
     }
+    g->P = o;
 }
-typedef struct { real xin[4], cw[4], sw[4], hp[MAXH], cp[MAXH], i[MAXH], f[MAXH], g[MAXH], o[MAXH], tc[MAXH], h[MAXH], l1[4], l2[4]; } lstm_step_t;
+static int64_t lstm_param_count(const odpd_model_t* m) { lstm_layout_t L; lstm_layout(m, &L); return L.P; }
+typedef struct {
+    real xin[4], cw[4], sw[4], hp[MAXH], cp[MAXH], i[MAXH], f[MAXH], g[MAXH], o[MAXH], tc[MAXH], h[MAXH], l1[4], l2[4];
+    real hq[MAXH], ph[MAXH], hq2[MAXH], ph2[MAXH], zq[8], pz[8];      /* quantised heads: q_a(inputs) and pass masks of the INT_Linear layers */
+} lstm_step_t;
 
 /* vdlstm.py:60-76: windows over the frame with CIRCULAR left padding: element k of window t is
  * sample (t - 3 + k) mod T */
@@ -341,7 +389,18 @@ static void lstm_seq_fwd(const lstm_layout_t* L, const real* p, int T, const rea
             h[j] = s->o[j] * s->tc[j];
             s->h[j] = h[j];
         }
-        if (L->vd) {   /* vdlstm.py:78-80 */
+        if (L->q) {      /* the heads as INT_Linear; fc_out's 16-bit output quantiser in eval mode only (quant_layers.py:77-80) */
+            real z[8];
+            if (L->vd) {
+                qlin_fwd(p, L->o_w_l1, L->o_b_l1, L->o_q_l1, 4, H, L->bits_w, L->bits_a, h, s->hq, s->ph, s->l1);
+                qlin_fwd(p, L->o_w_l2, L->o_b_l2, L->o_q_l2, 4, H, L->bits_w, L->bits_a, h, s->hq2, s->ph2, s->l2);
+                for (int k = 0; k < 4; ++k) { z[k] = s->l1[k] * s->cw[k]; z[4 + k] = s->l2[k] * s->sw[k]; }
+                qlin_fwd(p, L->o_w_out, L->o_b_out, L->o_q_out, 2, 8, L->bits_w, L->bits_a, z, s->zq, s->pz, &y[2 * t]);
+            } else {
+                qlin_fwd(p, L->o_w_out, L->o_b_out, L->o_q_out, 2, H, L->bits_w, L->bits_a, h, s->hq, s->ph, &y[2 * t]);
+            }
+            if (L->eval) for (int cc = 0; cc < 2; ++cc) y[2 * t + cc] = q_apply(y[2 * t + cc], q_pow2(p[L->o_q_out + 2]), 16, NULL);
+        } else if (L->vd) {   /* vdlstm.py:78-80 */
             real z[8];
             for (int k = 0; k < 4; ++k) {
                 real a = p[L->o_b_l1 + k], b = p[L->o_b_l2 + k];
@@ -372,7 +431,20 @@ static void lstm_seq_bwd(const lstm_layout_t* L, const real* p, int T, const rea
         const lstm_step_t* s = &S[t];
         real dht[MAXH], dxin[4] = {0}, dcw[4] = {0}, dsw[4] = {0};
         for (int j = 0; j < H; ++j) dht[j] = dh[j];
-        if (L->vd) {
+        if (L->q) {
+            if (L->vd) {
+                real dz[8] = {0}, d1[4], d2[4];
+                qlin_bwd(p, L->o_w_out, L->o_b_out, L->o_q_out, 2, 8, L->bits_w, &dy[2 * t], s->zq, s->pz, dp, dz);
+                for (int k = 0; k < 4; ++k) {
+                    d1[k] = dz[k] * s->cw[k]; d2[k] = dz[4 + k] * s->sw[k];
+                    dcw[k] = dz[k] * s->l1[k]; dsw[k] = dz[4 + k] * s->l2[k];
+                }
+                qlin_bwd(p, L->o_w_l1, L->o_b_l1, L->o_q_l1, 4, H, L->bits_w, d1, s->hq, s->ph, dp, dht);
+                qlin_bwd(p, L->o_w_l2, L->o_b_l2, L->o_q_l2, 4, H, L->bits_w, d2, s->hq2, s->ph2, dp, dht);
+            } else {
+                qlin_bwd(p, L->o_w_out, L->o_b_out, L->o_q_out, 2, H, L->bits_w, &dy[2 * t], s->hq, s->ph, dp, dht);
+            }
+        } else if (L->vd) {
             real dz[8] = {0};
             for (int cc = 0; cc < 2; ++cc) {
                 real d = dy[2 * t + cc];
@@ -1617,18 +1689,6 @@ static void qgru_layout(const odpd_model_t* m, qgru_layout_t* g) {
     g->P = o;
 }
 static int64_t qat_param_count(const odpd_model_t* m) { qgru_layout_t L; qgru_layout(m, &L); return L.P; }
-static inline real q_pow2(real scale) {   /* quantizers.py:56-65 */
-    float l = rintf(log2f(fabsf((float)scale)));
-    return (real)ldexp(1.0, (int)l);
-}
-/* returns q(x); *pass = 1 if x/s lies inside [Qn,Qp] (gradient passes), else 0 */
-static inline real q_apply(real x, real s, int bits, real* pass) {
-    real qn = -(real)(1 << (bits - 1)), qp = (real)((1 << (bits - 1)) - 1);
-    real v = x / s;
-    if (pass) *pass = (v >= qn && v <= qp) ? (real)1 : (real)0;
-    v = v < qn ? qn : (v > qp ? qp : v);
-    return (real)rint((double)v) * s;
-}
 typedef struct {
     real f[MAXF], fq[MAXF], px[MAXF], hq[MAXH], ph[MAXH];  /* features, q_a(features), pass masks of act quantisers, q_a(h) */
     real hp[MAXH], xt[3 * MAXH], ht[3 * MAXH];

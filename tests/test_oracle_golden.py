@@ -114,6 +114,9 @@ QAT_MORE = [("quant_gru_h11_w8a8", "gru", 8), ("quant_gru_h23_w8a8", "gru", 8), 
             ("quant_tres_h15_w8a8_th", "deltagru_tcnskip", 8), ("quant_tres_h15_w8a8_dense", "deltagru_tcnskip", 8),
             ("quant_tres_h15_w16a16_th", "deltagru_tcnskip", 16), ("quant_tres_h30_w8a8_th", "deltagru_tcnskip", 8),
             ("quant_tres_h15_w16a16_pre", "deltagru_tcnskip", 16), ("quant_tres_h15_w8a8_pre", "deltagru_tcnskip", 8)]
+# float nn.LSTM core, INT_Linear heads (the surgery finds only nn.Linear layers to swap in these backbones)
+QAT_HEADS = [("quant_lstm_h14_w8a8", "lstm", 8), ("quant_lstm_h14_w16a16", "lstm", 16), ("quant_lstm_h24_w8a8", "lstm", 8),
+             ("quant_vdlstm_h13_w8a8", "vdlstm", 8), ("quant_vdlstm_h13_w16a16", "vdlstm", 16)]
 _BUFFERS = ("n_bits", "pow2_scale", "decimal_num", "integer_num")
 
 
@@ -172,6 +175,44 @@ def test_qat_forward_and_grads(orc, name, bb, bits):
         if "scale" in k:
             assert dp[off] == 0.0
         off += n
+
+
+def grid_close(got, ref, step, flips=2, tol=2e-6):
+    """Outputs of a quantised head behind a FLOAT recurrent core: equal to fp32 rounding, except where a state within ~1e-7 of a rounding
+    boundary of the activation grid lands on the other side (then that sample moves by a few weight x grid-step products)."""
+    d = np.abs(got - ref)
+    return (d > tol).sum() <= flips and d.max() <= step
+
+
+@pytest.mark.parametrize("name,bb,bits", QAT_HEADS)
+def test_quantised_heads_forward_and_grads(orc, name, bb, bits):
+    """lstm / vdlstm under --quant: the surgery (quant_envs.py:40-60, 290-306) swaps only fc_out (vdlstm: fc_lambda_1, fc_lambda_2, fc_out)
+    for INT_Linear; nn.LSTM stays float.  Fixtures from the reference: train- and eval-mode outputs before and after three steps, loss,
+    gradients (scale parameters: exactly 0; out_quantizer scales: no gradient), input gradient."""
+    fx = Fixture(name)
+    m = make_model(bb, fx.meta["hidden"], bits_w=bits, bits_a=bits)
+    names = qat_param_names(fx)
+    p = fx.flat("sd", names)
+    assert orc.param_count(m) == p.size == fx.meta["n_param"]
+    p3 = fx.flat("sd3", names)
+    step = 2.0 ** (2 - bits) * 4
+    for got, ref in [(orc.qat_forward(m, p, fx["x"]), fx["y"]), (orc.qat_forward(m, p, fx["x"], eval_mode=True), fx["y_eval"]),
+                     (orc.qat_forward(m, p3, fx["x"]), fx["y_p3_train"]), (orc.qat_forward(m, p3, fx["x"], eval_mode=True), fx["y_p3_eval"]),
+                     (orc.qat_forward(m, p, fx["xa"], eval_mode=True), fx["ya_eval"])]:
+        # (16-bit grids are 256 x finer: a 1e-7 difference of the float core crosses a rounding boundary that much more often)
+        assert grid_close(got, ref, step, flips=2 if bits == 8 else got.size // 50), np.abs(got - ref).max()
+    y = orc.qat_forward(m, p, fx["x"])
+    loss, dy = orc.loss("l2", y, fx["tgt"])
+    assert abs(loss - fx["losses"][0]) < 1e-5
+    dp, dx = orc.qat_backward(m, p, fx["x"], dy)
+    gref = np.concatenate([(fx["g/" + k].reshape(-1) if ("g/" + k) in fx else np.zeros(fx["sd/" + k].size, np.float32)) for k in names])
+    assert rel_err(dp, gref) < 2e-5
+    assert rel_err(dx, fx["gx"]) < 2e-5
+    off = 0
+    for k in names:
+        if "scale" in k:
+            assert dp[off] == 0.0
+        off += fx["sd/" + k].size
 
 
 @pytest.mark.parametrize("name,bb,bits", QAT[:2] + [c for c in QAT_MORE if c[2] == 8])
