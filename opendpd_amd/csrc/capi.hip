@@ -58,6 +58,7 @@ inline SeqArgs make_args(const odpd_model_t* m, int B, int T) {
     a.ngroups = num_groups(B, rows_per_seq(m->hidden) ? rows_per_seq(m->hidden) : 1);
     a.nck = num_ckpt(T);
     a.thx = m->thx; a.thh = m->thh;
+    a.bits_w = m->bits_w; a.bits_a = m->bits_a; a.eval_out = (m->flags & ODPD_FLAG_EVAL) ? 1 : 0;
     return a;
 }
 }  // namespace
@@ -103,8 +104,9 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
     case ODPD_DGRU: return 3 * H * F + 3 * H * H + 6 * H + 2 * (H + 6) + 2 + H * H + H;
-    case ODPD_LSTM: return 4 * H * F + 4 * H * H + 8 * H + 2 * H + 2;
-    case ODPD_VDLSTM: return 4 * H * 4 + 4 * H * H + 8 * H + 2 * (4 * H + 4) + 2 * 8 + 2;
+    // bits_w > 0 on lstm / vdlstm: their nn.Linear heads are INT_Linear (+ three scale parameters each; quant_envs.py:40-60)
+    case ODPD_LSTM: return 4 * H * F + 4 * H * H + 8 * H + 2 * H + 2 + (m->bits_w > 0 ? 3 : 0);
+    case ODPD_VDLSTM: return 4 * H * 4 + 4 * H * H + 8 * H + 2 * (4 * H + 4) + 2 * 8 + 2 + (m->bits_w > 0 ? 9 : 0);
     case ODPD_DELTAGRU: return 3 * H * 6 + 3 * H * H + 6 * H + 2 * H + 2;
     case ODPD_TRES_DELTAGRU: return 3 * H * 6 + 3 * H * H + 2 * H + 18 + 6;
     case ODPD_DELTAJANET: return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2;      // two gates (deltajanet.py:96-111) + fc_out

@@ -10,6 +10,7 @@
 #include "odpd_seq.h"
 #include "odpd_s16.h"
 #include "odpd_lstm.h"
+#include "odpd_quant.h"
 
 namespace odpd {
 
@@ -27,7 +28,17 @@ struct LstmW {
     float b[4];               // b_ih + b_hh per gate
     float wout[2], bout[2];   // plain LSTM head
     float wl1[4], wl2[4];     // VD: fc_lambda_{1,2}.weight[k][o]
+    q16::Quant qa;            // quantised head (lstm_quantise_head): fc_out's activation quantiser; wout = q_w(weight), woutm = its pass mask
+    float woutm[2];
 };
+// fc_out as INT_Linear (`--quant` on lstm: quant_layers.py:48-85): the lane's head columns become their quantised values
+template <int R, bool VD>
+__device__ __forceinline__ void lstm_quantise_head(LstmW<R, VD>& w, const float* pl, const LstmLayout& L, int bits_w, int bits_a) {
+    const q16::Quant qw = q16::make_quant(pl[L.o_q_out], bits_w);
+    w.qa = q16::make_quant(pl[L.o_q_out + 1], bits_a);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { w.woutm[c] = q16::qpass(w.wout[c], qw); w.wout[c] = q16::qapply(w.wout[c], qw); }
+}
 template <int R, bool VD>
 __device__ __forceinline__ void load_lstm_w(LstmW<R, VD>& w, const float* pl, const LstmLayout& L, int row, int col) {
     constexpr int F = VD ? 4 : 2;
@@ -213,13 +224,17 @@ template <int NB> struct LstmEvalLds {
     static constexpr int kHeadFloats = 8 * 16 * NB;          // plain: fc_out rows 0..1; VD: fc_lambda_1 rows 0..3, fc_lambda_2 rows 4..7 (zero padded)
     static constexpr int kFloats = (kEvalChunk + kHalo) * 4 + kEvalChunk * kHistStride + kHeadFloats;
 };
-template <int NB, bool VD, bool CK>      // CK: also writes the BPTT checkpoints (the forward of the split train path)
+// QH (plain lstm): fc_out is an INT_Linear (`--quant`, quant_layers.py:48-85) — the head table holds the weights' grid indices, the chunk's h
+// values are quantised with lane = time step, the integer sum takes its scale s_a s_w and the fp32 bias in one FMA; eval mode adds the
+// 16-bit output quantiser.
+template <int NB, bool VD, bool CK, bool QH = false>      // CK: also writes the BPTT checkpoints (the forward of the split train path)
 __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
+    static_assert(!(QH && VD), "quantised heads: plain lstm");
     constexpr int F = VD ? 4 : 2, EC = kEvalChunk, HS = LstmEvalLds<NB>::kHistStride;
     using T = LstmTabs<NB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // gate i | f | g | o
-    const LstmLayout L = lstm_layout(a.H, VD);
+    const LstmLayout L = lstm_layout(a.H, VD, QH);
     const int H = L.H;
     float* pl = smem;
     stage_params(pl, a.params, L.P);
@@ -228,12 +243,16 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
     float* ftab = tab + T::kFloats;                    // [kHalo + EC][4]: entry kHalo + i = inputs of time t0 + i; entries 0..2 = the three before
     float* hist = ftab + (kHalo + EC) * 4;             // [EC][HS]: entry i = h of time t0 + i, every lane's copy
     float* hw = hist + EC * HS;
+    q16::Quant qw{}, qa{}, qo{};
+    if constexpr (QH) {
+        qw = q16::make_quant(pl[L.o_q_out], a.bits_w); qa = q16::make_quant(pl[L.o_q_out + 1], a.bits_a); qo = q16::make_quant(pl[L.o_q_out + 2], 16);
+    }
     for (int i = lane; i < LstmEvalLds<NB>::kHeadFloats; i += 64) {
         const int r = i / (16 * NB), u = i % (16 * NB);
         float v = 0.0f;
         if (u < H) {
             if (VD) v = r < 4 ? pl[L.o_w_l1 + r * H + u] : pl[L.o_w_l2 + (r - 4) * H + u];
-            else if (r < 2) v = pl[L.o_w_out + r * H + u];
+            else if (r < 2) v = QH ? q16::qgrid(pl[L.o_w_out + r * H + u], qw) : pl[L.o_w_out + r * H + u];
         }
         hw[i] = v;
     }
@@ -317,12 +336,13 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
                 const float4* hv4 = reinterpret_cast<const float4*>(hist + lane * HS);             // row 0's copy
                 float acc[VD ? 8 : 2];
 #pragma unroll
-                for (int r = 0; r < (VD ? 8 : 2); ++r) acc[r] = VD ? (r < 4 ? pl[L.o_b_l1 + r] : pl[L.o_b_l2 + r - 4]) : pl[L.o_b_out + r];
+                for (int r = 0; r < (VD ? 8 : 2); ++r) acc[r] = QH ? 0.0f : VD ? (r < 4 ? pl[L.o_b_l1 + r] : pl[L.o_b_l2 + r - 4]) : pl[L.o_b_out + r];
 #pragma unroll
                 for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 hv = hv4[16 * ob + q];
+                        float4 hv = hv4[16 * ob + q];
+                        if constexpr (QH) hv = make_float4(q16::qgrid(hv.x, qa), q16::qgrid(hv.y, qa), q16::qgrid(hv.z, qa), q16::qgrid(hv.w, qa));
 #pragma unroll
                         for (int r = 0; r < (VD ? 8 : 2); ++r) {
                             const float4 w = hw4[4 * NB * r + 4 * ob + q];
@@ -341,6 +361,10 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
                         y0 = __builtin_fmaf(pl[L.o_w_out + k], lc, __builtin_fmaf(pl[L.o_w_out + 4 + k], ls, y0));
                         y1 = __builtin_fmaf(pl[L.o_w_out + 8 + k], lc, __builtin_fmaf(pl[L.o_w_out + 12 + k], ls, y1));
                     }
+                } else if constexpr (QH) {
+                    const float S = qa.s * qw.s;
+                    y0 = __builtin_fmaf(acc[0], S, pl[L.o_b_out]); y1 = __builtin_fmaf(acc[1], S, pl[L.o_b_out + 1]);
+                    if (a.eval_out) { y0 = q16::qapply(y0, qo); y1 = q16::qapply(y1, qo); }
                 } else { y0 = acc[0]; y1 = acc[1]; }
                 yg[t0 + lane] = make_float2(y0, y1);
             }
@@ -375,13 +399,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-template <bool VD, bool PG>
+template <bool VD, bool PG, bool QH = false>      // QH: fc_out as INT_Linear (see lstm_eval_kernel); train mode
 __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
+    static_assert(!(QH && VD), "quantised heads: plain lstm");
     constexpr int F = VD ? 4 : 2, NH = VD ? 8 : 2;
     using TB = LstmTabs<1>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, role = lane >> 4;      // gate i | f | g | o
-    const LstmLayout L = lstm_layout(a.H, VD);
+    const LstmLayout L = lstm_layout(a.H, VD, QH);
     const int H = L.H, T = a.T, Tp = (T + 63) & ~63;
     float* pl = smem;
     stage_params(pl, a.params, L.P);
@@ -403,6 +428,13 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
 #pragma unroll
     for (int r = 0; r < NH; ++r)
         wh[r] = !vo ? 0.0f : VD ? (r < 4 ? pl[L.o_w_l1 + r * H + col] : pl[L.o_w_l2 + (r - 4) * H + col]) : pl[L.o_w_out + r * H + col];
+    q16::Quant qw{}, qa{};
+    [[maybe_unused]] float whm[NH];                  // QH: the weight quantiser's pass mask of the unit's head columns
+    if constexpr (QH) {
+        qw = q16::make_quant(pl[L.o_q_out], a.bits_w); qa = q16::make_quant(pl[L.o_q_out + 1], a.bits_a);
+#pragma unroll
+        for (int r = 0; r < NH; ++r) { whm[r] = q16::qpass(wh[r], qw); wh[r] = q16::qapply(wh[r], qw); }
+    }
     wave_lds_fence();
     // per-time buffers over the tables
     float* ftab = tab;                                  // [Tp + 4][4]   entry 3 + t = inputs of step t (I, Q | |x|, cos, sin); entries 0..2 = the circular halo
@@ -419,7 +451,7 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
         float v = 0.0f;
         if (u < H) {
             if (VD) v = r < 4 ? pl[L.o_w_l1 + r * H + u] : pl[L.o_w_l2 + (r - 4) * H + u];
-            else if (r < 2) v = pl[L.o_w_out + r * H + u];
+            else if (r < 2) v = QH ? q16::qgrid(pl[L.o_w_out + r * H + u], qw) : pl[L.o_w_out + r * H + u];
         }
         hw[i] = v;
     }
@@ -500,10 +532,11 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
                 const float4* hv4 = reinterpret_cast<const float4*>(hist + (t + 1) * 16);
                 float acc[NH];
 #pragma unroll
-                for (int r = 0; r < NH; ++r) acc[r] = VD ? (r < 4 ? pl[L.o_b_l1 + r] : pl[L.o_b_l2 + r - 4]) : pl[L.o_b_out + r];
+                for (int r = 0; r < NH; ++r) acc[r] = QH ? 0.0f : VD ? (r < 4 ? pl[L.o_b_l1 + r] : pl[L.o_b_l2 + r - 4]) : pl[L.o_b_out + r];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 hv = hv4[q];
+                    float4 hv = hv4[q];
+                    if constexpr (QH) hv = make_float4(q16::qgrid(hv.x, qa), q16::qgrid(hv.y, qa), q16::qgrid(hv.z, qa), q16::qgrid(hv.w, qa));
 #pragma unroll
                     for (int r = 0; r < NH; ++r) {
                         const float4 w = hw4[4 * r + q];
@@ -538,6 +571,10 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
                     reinterpret_cast<float4*>(dlb)[2 * t] = make_float4(dl[0], dl[1], dl[2], dl[3]);
                     reinterpret_cast<float4*>(dlb)[2 * t + 1] = make_float4(dl[4], dl[5], dl[6], dl[7]);
                 } else {
+                    if constexpr (QH) {      // integer sums: scale s_a s_w and the fp32 bias in one FMA
+                        const float S = qa.s * qw.s;
+                        acc[0] = __builtin_fmaf(acc[0], S, pl[L.o_b_out]); acc[1] = __builtin_fmaf(acc[1], S, pl[L.o_b_out + 1]);
+                    }
                     s16_loss(lossc, acc[0] - tv.x, acc[1] - tv.y, dy0, dy1, loss_acc);
                     tacc[0] += dy0; tacc[1] += dy1;
                 }
@@ -580,8 +617,16 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
                     gather_rows(is_g ? th : sg, g);
                 }
                 float dht = dh;
+                if constexpr (QH) {      // dL/dW on q_a(h), dL/dh through the activation quantiser's pass mask
+                    const float hq = q16::qapply(ht, qa);
+                    float hd = 0.0f;
 #pragma unroll
-                for (int r = 0; r < NH; ++r) { dht = __builtin_fmaf(hg[r], wh[r], dht); dwh[r] = __builtin_fmaf(hg[r], ht, dwh[r]); }
+                    for (int r = 0; r < NH; ++r) { hd = __builtin_fmaf(hg[r], wh[r], hd); dwh[r] = __builtin_fmaf(hg[r], hq, dwh[r]); }
+                    dht += q16::qpassb(ht, qa) ? hd : 0.0f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NH; ++r) { dht = __builtin_fmaf(hg[r], wh[r], dht); dwh[r] = __builtin_fmaf(hg[r], ht, dwh[r]); }
+                }
                 const float dct = __builtin_fmaf(dht * g[3], __builtin_fmaf(-tc, tc, 1.0f), dc);       // dL/dc(t)
                 dc = dct * g[1];
                 // the row's own pre-activation gradient: d_i = dc g i (1 - i), d_f = dc c(t-1) f (1 - f), d_g = dc i (1 - g^2), d_o = dh tanh c o (1 - o)
@@ -609,10 +654,11 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
 #pragma unroll
         for (int r = 0; r < NH; ++r) {
             if (VD) prow[(r < 4 ? L.o_w_l1 + r * H : L.o_w_l2 + (r - 4) * H) + col] = dwh[r];
-            else prow[L.o_w_out + r * H + col] = dwh[r];
+            else prow[L.o_w_out + r * H + col] = QH ? dwh[r] * whm[r] : dwh[r];
         }
     }
     if (lane == 0) {
+        if constexpr (QH) { prow[L.o_q_out] = 0.0f; prow[L.o_q_out + 1] = 0.0f; prow[L.o_q_out + 2] = 0.0f; }      // the scales: zero gradients (quantizers.py:56-65)
         if constexpr (VD) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) prow[L.o_w_out + k] = tacc[k];
@@ -678,7 +724,7 @@ struct VdAcc {
     }
 };
 
-template <int R, bool VD, bool NW, bool DX, bool FULL>
+template <int R, bool VD, bool NW, bool DX, bool FULL, bool QH = false>
 __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, VD>& w, const float* pl, const LstmLayout& L,
                                                TabPtr tlane, LstmGrad<R, VD>& G, const LaneId& id, const float2* xr,
                                                const float2* dys, float2* dxs, int tloc, int nstep, float h, float c,
@@ -761,6 +807,14 @@ __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, 
                         G.dwo[12 + k] = __builtin_fmaf(dyv.y, z2, G.dwo[12 + k]);
                     }
                 }
+            } else if constexpr (QH) {      // dL/dW on q_a(h), dL/dh through the activation quantiser's pass mask
+                const float hd = __builtin_fmaf(dyv.x, w.wout[0], dyv.y * w.wout[1]);
+                dht += q16::qpassb(ht, w.qa) ? hd : 0.0f;
+                if constexpr (NW) {
+                    const float hq = q16::qapply(ht, w.qa);
+                    G.dwout[0] = __builtin_fmaf(dyv.x, hq, G.dwout[0]);
+                    G.dwout[1] = __builtin_fmaf(dyv.y, hq, G.dwout[1]);
+                }
             } else {
                 dht = __builtin_fmaf(dyv.x, w.wout[0], __builtin_fmaf(dyv.y, w.wout[1], dht));
                 if constexpr (NW) {
@@ -833,9 +887,9 @@ __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, 
     }
 }
 
-template <int R, bool VD>
+template <int R, bool VD, bool QH = false>
 __device__ __forceinline__ void lstm_write_partials(float* prow, const LstmLayout& L, LstmGrad<R, VD>& G, int lane, int row,
-                                                    int col) {
+                                                    int col, const LstmW<R, VD>* w = nullptr) {
     constexpr int F = VD ? 4 : 2;
     const int H = L.H, o = 16 * row + col, seq = lane / (16 * R);
     const int g4 = lane >> 4, c = lane & 15;
@@ -874,19 +928,24 @@ __device__ __forceinline__ void lstm_write_partials(float* prow, const LstmLayou
             if (lane == 0) prow[L.o_w_out + k] = v;
         }
     } else {
-        const float w0 = across_seqs<R>(G.dwout[0]), w1 = across_seqs<R>(G.dwout[1]);
+        float w0 = across_seqs<R>(G.dwout[0]), w1 = across_seqs<R>(G.dwout[1]);
+        if constexpr (QH) {      // the weight quantiser's pass mask; the three scales get zero gradients (quantizers.py:56-65)
+            w0 *= w->woutm[0]; w1 *= w->woutm[1];
+            if (lane < 3) prow[L.o_q_out + lane] = 0.0f;
+        }
         if (seq == 0 && o < H) { prow[L.o_w_out + o] = w0; prow[L.o_w_out + H + o] = w1; }
     }
 }
 
-template <int R, bool VD, bool NW, bool DX>
+template <int R, bool VD, bool NW, bool DX, bool QH = false>
 __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R == 1 && !VD) ? 2 : 1) void lstm_bwd_kernel(SeqArgs a) {
+    static_assert(!(QH && VD), "quantised heads: plain lstm");
     constexpr int SPW = 4 / R, S = kCkptStride;
     using T = LstmTabs<R>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const LaneId id = lane_id<R>();
     const int lane = id.lane;
-    const LstmLayout L = lstm_layout(a.H, VD);
+    const LstmLayout L = lstm_layout(a.H, VD, QH);
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
@@ -897,6 +956,7 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
     float2* dxs = dys + SPW * kChunkPad;
     LstmW<R, VD> w;
     load_lstm_w<R, VD>(w, pl, L, id.row, id.col);
+    if constexpr (QH) lstm_quantise_head<R, VD>(w, pl, L, a.bits_w, a.bits_a);
     LstmGrad<R, VD> G;
     G.zero();
     const int nwaves = gridDim.x * id.nwb;
@@ -928,9 +988,9 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
             const float h0 = blk ? ck[lane] : 0.0f, c0 = blk ? ck[64 + lane] : 0.0f;
             const float2* xr = xs + id.s * kHaloStride + kHalo;
             if (nstep == S)
-                lstm_bwd_block<R, VD, NW, DX, true>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc, acc);
+                lstm_bwd_block<R, VD, NW, DX, true, QH>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc, acc);
             else
-                lstm_bwd_block<R, VD, NW, DX, false>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc, acc);
+                lstm_bwd_block<R, VD, NW, DX, false, QH>(a, w, pl, L, tlane, G, id, xr, dys, dxs, tb - t0, nstep, h0, c0, dh, dc, acc);
         }
         if constexpr (DX) {
             if (cur_chunk >= 0) {
@@ -962,7 +1022,7 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
     if constexpr (NW) {
         const int P4 = L.P + kLossCols;
         __syncthreads();
-        lstm_write_partials<R, VD>(smem + id.wave * P4, L, G, lane, id.row, id.col);
+        lstm_write_partials<R, VD, QH>(smem + id.wave * P4, L, G, lane, id.row, id.col, &w);
         __syncthreads();
         float* prow = a.partials + (size_t)blockIdx.x * P4;
         for (int i = threadIdx.x; i < P4; i += blockDim.x) {
@@ -1003,16 +1063,24 @@ static int lstm_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
         hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
         return (int)hipGetLastError();
     };
+    if constexpr (!VD) {
+        if (a.bits_w > 0) return a.ckpt ? launch(lstm_eval_kernel<NB, false, true, true>) : launch(lstm_eval_kernel<NB, false, false, true>);
+    }
     return a.ckpt ? launch(lstm_eval_kernel<NB, VD, true>) : launch(lstm_eval_kernel<NB, VD, false>);
 }
 template <int R, bool VD, bool NW, bool DX>
 static int lstm_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
     const LaunchShape ls = lstm_bwd_shape(R, VD, a.ngroups);
     const size_t lds = lstm_lds_bytes(P, R, ls.waves, 2 * ((4 / R) * kHaloStride + 2 * (4 / R) * kChunkPad), NW);
-    auto k = lstm_bwd_kernel<R, VD, NW, DX>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
-    return (int)hipGetLastError();
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    if constexpr (!VD) {
+        if (a.bits_w > 0) return launch(lstm_bwd_kernel<R, false, NW, DX, true>);
+    }
+    return launch(lstm_bwd_kernel<R, VD, NW, DX>);
 }
 template <int R, bool VD>
 static int lstm_launch_bwd_mode(hipStream_t st, const SeqArgs& a, int P) {
@@ -1042,8 +1110,8 @@ static bool lstm_gp_parks_gates(int P, bool vd, int B, int T) { return (long)B <
 bool lstm_train_uses_gp(const odpd_model_t* m, int B, int T) {
     if ((m->backbone != ODPD_LSTM && m->backbone != ODPD_VDLSTM) || m->hidden > 16 || lstm_train_uses_s16(m, B)) return false;
     const bool vd = m->backbone == ODPD_VDLSTM;
-    if (vd && T < kHalo) return false;
-    const int P = lstm_layout(m->hidden, vd).P;
+    if ((vd && T < kHalo) || (vd && m->bits_w > 0)) return false;
+    const int P = lstm_layout(m->hidden, vd, m->bits_w > 0).P;
     const long max_batch = tuning().gp_max_batch;
     if (max_batch >= 0) return B <= max_batch && lstm_gp_blocks_per_cu(P, vd, T, false) > 0;
     // up to two rounds of workgroups: the alternative here is the forward / loss / backward chain of the row-rotated kernels
@@ -1051,14 +1119,14 @@ bool lstm_train_uses_gp(const odpd_model_t* m, int B, int T) {
 }
 int lstm_gp_rows(const odpd_model_t* m, int B, int T) {
     const bool vd = m->backbone == ODPD_VDLSTM;
-    const int P = lstm_layout(m->hidden, vd).P;
+    const int P = lstm_layout(m->hidden, vd, m->bits_w > 0).P;
     const bool pg = lstm_gp_parks_gates(P, vd, B, T);
     const long cap = (long)device_cus() * (kMaxLds / lstm_gp_lds_bytes(P, vd, T, pg));
     return B < cap ? B : (int)cap;
 }
 int lstm_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     const bool vd = m->backbone == ODPD_VDLSTM;
-    const int P = lstm_layout(m->hidden, vd).P;
+    const int P = lstm_layout(m->hidden, vd, m->bits_w > 0).P;
     const bool pg = lstm_gp_parks_gates(P, vd, a.B, a.T);
     const size_t lds = lstm_gp_lds_bytes(P, vd, a.T, pg);
     const int grid = lstm_gp_rows(m, a.B, a.T);
@@ -1068,25 +1136,26 @@ int lstm_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
         return (int)hipGetLastError();
     };
     if (vd) return pg ? launch(lstm_gp_train_kernel<true, true>) : launch(lstm_gp_train_kernel<true, false>);
+    if (m->bits_w > 0) return pg ? launch(lstm_gp_train_kernel<false, true, true>) : launch(lstm_gp_train_kernel<false, false, true>);
     return pg ? launch(lstm_gp_train_kernel<false, true>) : launch(lstm_gp_train_kernel<false, false>);
 }
 int lstm_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     const int R = rows_per_seq(m->hidden);
     const bool vd = m->backbone == ODPD_VDLSTM;
-    if (!R) return ODPD_EUNSUPPORTED;
+    if (!R || (vd && m->bits_w > 0)) return ODPD_EUNSUPPORTED;      // (quantised heads: plain lstm only)
     if (vd && a.T < kHalo) return ODPD_EINVAL;
-    const int P = lstm_layout(m->hidden, vd).P;
+    const int P = lstm_layout(m->hidden, vd, m->bits_w > 0).P;
     // sequences that each get a SIMD of their own (inference, and the checkpoint-writing forward of the split train path): the gate-parallel kernel
-    if (a.B <= 2 * device_cus() && tuning().s16_min_batch != 0 && tuning().gp_max_batch != 0) { ODPD_LSTM_DISPATCH(lstm_launch_eval, st, a, P) }
+    if (m->bits_w > 0 || (a.B <= 2 * device_cus() && tuning().s16_min_batch != 0 && tuning().gp_max_batch != 0)) { ODPD_LSTM_DISPATCH(lstm_launch_eval, st, a, P) }
     ODPD_LSTM_DISPATCH(lstm_launch_fwd, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
 int lstm_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     const int R = rows_per_seq(m->hidden);
     const bool vd = m->backbone == ODPD_VDLSTM;
-    if (!R) return ODPD_EUNSUPPORTED;
+    if (!R || (vd && m->bits_w > 0)) return ODPD_EUNSUPPORTED;      // (quantised heads: plain lstm only)
     if (vd && a.T < kHalo) return ODPD_EINVAL;
-    const int P = lstm_layout(m->hidden, vd).P;
+    const int P = lstm_layout(m->hidden, vd, m->bits_w > 0).P;
     ODPD_LSTM_DISPATCH(lstm_launch_bwd_mode, st, a, P)
     return ODPD_EUNSUPPORTED;
 }

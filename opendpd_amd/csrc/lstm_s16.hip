@@ -537,6 +537,7 @@ static LaunchShape l16_shape(int ngroups, int nt = 2) {
 }
 bool lstm_train_uses_s16(const odpd_model_t* m, int B) {
     if ((m->backbone != ODPD_LSTM && m->backbone != ODPD_VDLSTM) || m->hidden > 32) return false;
+    if (m->bits_w > 0) return false;      // quantised heads (`--quant`): lstm_family.hip's kernels at every batch size
     long min_batch = tuning().s16_min_batch;
     if (min_batch < 0) min_batch = (m->hidden <= 16 ? 16L : 8L) * 4 * device_cus();
     return B >= min_batch;

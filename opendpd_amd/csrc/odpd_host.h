@@ -78,13 +78,16 @@ __host__ __device__ inline GruLayout gru_layout(int H, int F, int dgru) {
     return L;
 }
 
+// qh: the nn.Linear heads are INT_Linear (`--quant` on lstm / vdlstm: the surgery swaps only those, quant/quant_envs.py:40-60) — three scale
+// parameters (weight_quantizer, act_quantizer, out_quantizer) behind each head's weight and bias, the named_parameters() order
 struct LstmLayout {
     int H, F, vd;
-    int o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_l1, o_b_l1, o_w_l2, o_b_l2, o_w_out, o_b_out, P;
+    int o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_l1, o_b_l1, o_w_l2, o_b_l2, o_w_out, o_b_out, o_q_l1, o_q_l2, o_q_out, P;
 };
-__host__ __device__ inline LstmLayout lstm_layout(int H, int vd) {
+__host__ __device__ inline LstmLayout lstm_layout(int H, int vd, int qh = 0) {
     LstmLayout L;
     L.H = H; L.vd = vd; L.F = vd ? 4 : 2;
+    L.o_q_l1 = L.o_q_l2 = L.o_q_out = 0;
     int o = 0;
     L.o_w_ih = o; o += 4 * H * L.F;
     L.o_w_hh = o; o += 4 * H * H;
@@ -92,12 +95,13 @@ __host__ __device__ inline LstmLayout lstm_layout(int H, int vd) {
     L.o_b_hh = o; o += 4 * H;
     L.o_w_l1 = L.o_b_l1 = L.o_w_l2 = L.o_b_l2 = 0;
     if (vd) {
-        L.o_w_l1 = o; o += 4 * H; L.o_b_l1 = o; o += 4;
-        L.o_w_l2 = o; o += 4 * H; L.o_b_l2 = o; o += 4;
+        L.o_w_l1 = o; o += 4 * H; L.o_b_l1 = o; o += 4; if (qh) { L.o_q_l1 = o; o += 3; }
+        L.o_w_l2 = o; o += 4 * H; L.o_b_l2 = o; o += 4; if (qh) { L.o_q_l2 = o; o += 3; }
         L.o_w_out = o; o += 16; L.o_b_out = o; o += 2;
     } else {
         L.o_w_out = o; o += 2 * H; L.o_b_out = o; o += 2;
     }
+    if (qh) { L.o_q_out = o; o += 3; }
     L.P = o;
     return L;
 }
@@ -139,6 +143,7 @@ struct SeqArgs {
     float thx, thh;
     int loss_kind;
     int B, T, H, ngroups, nck;
+    int bits_w, bits_a, eval_out;      // quantised heads (lstm): grid widths; eval_out: ODPD_FLAG_EVAL (fc_out's 16-bit output quantiser)
 };
 
 // comm.hip: communicator of the data-parallel step (one-shot exchange over peer-mapped slots, or RCCL)

@@ -3,6 +3,7 @@
 // roundings the reference does not have (an including file that wants contraction back says `#pragma clang fp contract(fast)` after it).
 #pragma once
 #include "odpd_s16.h"
+#include "odpd_quant.h"
 
 #pragma clang fp contract(off)
 
@@ -51,22 +52,6 @@ __host__ __device__ inline QatLayout qat_layout(int kind, int H) {
     return L;
 }
 
-__device__ __forceinline__ float pow2_scale(float scale) { return exp2f(rintf(log2f(fabsf(scale)))); }
-struct Quant { float s, inv, qn, qp; };
-__device__ __forceinline__ Quant make_quant(float scale, int bits) {
-    Quant q; q.s = pow2_scale(scale); q.inv = 1.0f / q.s; q.qn = -(float)(1 << (bits - 1)); q.qp = (float)((1 << (bits - 1)) - 1);
-    return q;
-}
-// clamp as one v_med3_f32; the straight-through pass mask "Qn <= x/s <= Qp" is "the clamp left x/s unchanged"
-__device__ __forceinline__ float qapply(float x, const Quant& q) {
-    const float v = x * q.inv;
-    return rintf(__builtin_amdgcn_fmed3f(v, q.qn, q.qp)) * q.s;
-}
-__device__ __forceinline__ bool qpassb(float x, const Quant& q) {
-    const float v = x * q.inv;
-    return __builtin_amdgcn_fmed3f(v, q.qn, q.qp) == v;
-}
-__device__ __forceinline__ float qpass(float x, const Quant& q) { return qpassb(x, q) ? 1.0f : 0.0f; }
 // activation-side quantisers (wave-uniform)
 struct QSc { Quant xa, ha, oa, sig, tnh, add, mul, out, hida; };
 // GRID UNITS.  Inside the kernels a quantised value travels as the integer k of q(x) = k s (an integer-valued float): the trailing

@@ -142,6 +142,23 @@ class QuantGRUCellModel(_QuantBase):
 QuantQGRU = QuantGRUCellModel      # the r01 / r02 name
 
 
+class QuantHeadLSTM(_QuantBase):
+    """lstm after the surgery: it holds no nn.GRU and no op modules, so only `fc_out` changes — nn.Linear -> INT_Linear
+    (quant_envs.py:40-60, 290-306) with out_quant set (`set_last_layer_quant`, :278-287); nn.LSTM stays float.  Kernels: the
+    quantised-head instantiations of csrc/lstm_family.hip (lstm_eval_kernel / lstm_gp_train_kernel / lstm_bwd_kernel <.., QH>)."""
+    backbone_name = "lstm"
+
+    def __init__(self, rnn, bits_w, bits_a):
+        """`rnn`: the float model's parameter holder (taken over as it is: the surgery deep-copies nn.LSTM, no RNG draws)."""
+        super().__init__()
+        hidden_size = rnn.hidden_size
+        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, 2, 2, 1
+        self.rnn = rnn
+        self.fc_out = _QLinear(hidden_size, 2, bits_w, bits_a)
+        self.fc_out.out_quant = True
+        self._finish(hidden_size, bits_w, bits_a)
+
+
 class _QDeltaLayer(nn.Module):
     """DeltaGRULayer of deltagru_tcnskip.py:133-162 after the surgery: bias-free INT_Linear x2h / h2h, Quant_add / mult / sigmoid /
     tanh in the layer's own registration order."""
@@ -209,12 +226,48 @@ class QuantTResDeltaGRU(_QuantBase):
 
 MAX_HIDDEN = 32          # csrc/qat_s16.hip: two 16-unit tiles
 _UNTOUCHED = ("gmp", "tcnn")       # no nn.GRU, no nn.Linear, no op modules: the surgery returns an identical deep copy
-_PARTIAL = ("lstm", "vdlstm", "rvtdcnn", "apnrru", "bojanet", "deltajanet", "dvrjanet", "neuraltx", "mcldnn", "pgjanet")
+_PARTIAL = ("vdlstm", "rvtdcnn", "apnrru", "bojanet", "deltajanet", "dvrjanet", "neuraltx", "mcldnn", "pgjanet")
+_HEAD_ONLY = ("lstm",)             # only nn.Linear heads to swap, and kernels with a quantised head exist
 
 
 def _warn_float(exc, model):
     print(f"[WARN] Quantization setup failed: {exc}. Using float model instead.")
     return model
+
+
+def _wrap(model, bb, dev):
+    q = CoreModel.__new__(CoreModel)
+    nn.Module.__init__(q)
+    for k in ("output_size", "input_size", "hidden_size", "num_layers", "backbone_type", "thx", "thh", "window_size",
+              "num_dvr_units", "batch_first", "bidirectional", "bias"):
+        setattr(q, k, getattr(model, k))
+    q.backbone = bb
+    return q.to(dev)
+
+
+def _quantise_heads(model, bits_w, bits_a, pre, dev):
+    """lstm: create_pygru_model finds no nn.GRU (no RNG draws), load_model strict-loads a float checkpoint of the model's own keys,
+    create_quantized_model swaps fc_out — INT_Linear keeps the weight and draws a fresh default-init bias (quant_layers.py:48-56)."""
+    import copy
+    fb = model.backbone
+    if pre:
+        try:
+            pre_sd = torch.load(pre, map_location="cpu")
+            want = {"backbone." + k: tuple(v.shape) for k, v in fb.state_dict().items()}
+            if not isinstance(pre_sd, dict) or set(pre_sd) != set(want) or any(tuple(pre_sd[k].shape) != s for k, s in want.items()):
+                raise RuntimeError("Error(s) in loading state_dict for CoreModel")
+        except Exception as exc:
+            return _warn_float(exc, model)
+    with torch.no_grad():
+        rnn = copy.deepcopy(fb.rnn).cpu()
+        fc_w = fb.fc_out.weight.detach().cpu()
+        if pre:
+            for k, p in rnn.named_parameters():
+                p.copy_(pre_sd["backbone.rnn." + k])
+            fc_w = pre_sd["backbone.fc_out.weight"]
+        bb = QuantHeadLSTM(rnn, bits_w, bits_a)
+        bb.fc_out.weight.copy_(fc_w)
+    return _wrap(model, bb, dev)
 
 
 def get_quant_model(proj, model):
@@ -252,6 +305,8 @@ def get_quant_model(proj, model):
         raise NotImplementedError(f"the QAT kernels cover one layer and hidden_size <= {MAX_HIDDEN} (csrc/qat_s16.hip)")
     dev = next(model.parameters()).device
     pre = getattr(proj, "pretrained_model", "")
+    if bt in _HEAD_ONLY:
+        return _quantise_heads(model, bits_w, bits_a, pre, dev)
     tres = bt == "deltagru_tcnskip"
     holder = None
     if not tres:
@@ -315,10 +370,4 @@ def get_quant_model(proj, model):
                 bb.fc_out.weight.copy_(pre_sd["backbone.fc_out.weight"])
                 if bt == "dgru":
                     bb.fc_hid.weight.copy_(pre_sd["backbone.fc_hid.weight"])
-    q = CoreModel.__new__(CoreModel)
-    nn.Module.__init__(q)
-    for k in ("output_size", "input_size", "hidden_size", "num_layers", "backbone_type", "thx", "thh", "window_size",
-              "num_dvr_units", "batch_first", "bidirectional", "bias"):
-        setattr(q, k, getattr(model, k))
-    q.backbone = bb
-    return q.to(dev)
+    return _wrap(model, bb, dev)

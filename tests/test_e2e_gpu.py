@@ -442,6 +442,44 @@ def test_quantised_flow_two_epochs_and_run_dpd_match_reference(workdir):
     assert np.abs(csv.to_numpy() - m["dpd_out"]).max() <= 2.0 ** -14 + 1e-9
 
 
+def test_quantised_head_lstm_flow_matches_reference(workdir):
+    """--quant with an lstm DPD: the surgery swaps only fc_out (nn.LSTM stays float, quant_envs.py:40-60).  Two train_dpd epochs in front of
+    the reference's GRU PA, the checkpoint (keys incl. the quantisers' side-effect buffers, file name with the 3 scale parameters counted)
+    and run_dpd's CSV with the REFERENCE's trained weights, against tests/golden/ref_runs_qat_lstm.{json,npz}
+    (oracle/gen_run_anchor_qat_lstm.py).  Tolerances as in the qgru flow; run_dpd: outputs on the 2^-14 grid, a float state next to a
+    rounding boundary of the 8-bit activation grid may move single samples by a weight x 2^-6 product."""
+    import opendpd_amd as od
+    ref = json.load(open(os.path.join(GOLDEN, "ref_runs_qat_lstm.json")))
+    m = dict(np.load(os.path.join(GOLDEN, "ref_runs_qat_lstm.npz")))
+    pa = dict(np.load(os.path.join(GOLDEN, "ref_runs_qat_dpa.npz")))
+    os.makedirs(os.path.dirname(ref["pa_model"]), exist_ok=True)
+    torch.save({k[3:]: torch.from_numpy(v) for k, v in pa.items() if k.startswith("pa/")}, ref["pa_model"])
+    kw = dict(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=11, DPD_backbone="lstm", DPD_hidden_size=12, frame_length=50,
+              seed=0, accelerator="cuda", quant=True, n_bits_w=8, n_bits_a=8, quant_dir_label="w8a8")
+    res = od.train_dpd(batch_size=64, lr=1e-3, n_epochs=2, **kw)
+    assert os.path.normpath(res["model_path"]) == os.path.normpath(ref["dpd_model"])
+    hist = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), "history", os.path.basename(res["log_path"])))
+    rh = ref["hist"]
+    assert list(hist.columns) == list(rh.keys()) and list(hist["N_PARAM"]) == rh["N_PARAM"]
+    for ep in range(2):
+        assert abs(hist["TRAIN_LOSS"][ep] - rh["TRAIN_LOSS"][ep]) < 0.02 * rh["TRAIN_LOSS"][ep], (ep, hist["TRAIN_LOSS"][ep], rh["TRAIN_LOSS"][ep])
+        for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
+            assert abs(hist[col][ep] - rh[col][ep]) < 0.4, (col, ep, hist[col][ep], rh[col][ep])   # dB
+    sd = torch.load(res["model_path"], map_location="cpu")
+    ref_sd = {k[4:]: v for k, v in m.items() if k.startswith("dpd/")}
+    assert list(sd.keys()) == list(ref_sd.keys())
+    for k, v in ref_sd.items():
+        if "_num" in k or "pow2_scale" in k or "n_bits" in k:
+            assert np.array_equal(sd[k].numpy(), v), k
+    torch.save({k: torch.from_numpy(v) for k, v in ref_sd.items()}, ref["dpd_model"])
+    out = od.run_dpd(**kw)
+    assert os.path.normpath(out["output_path"]) == os.path.normpath(ref["dpd_out"])
+    csv = pd.read_csv(out["output_path"])
+    assert list(csv.columns) == ["I", "Q", "I_dpd", "Q_dpd"]
+    d = np.abs(csv.to_numpy() - m["dpd_out"])
+    assert (d > 2.0 ** -14 + 1e-9).sum() <= 4 and d.max() < 2.0 ** -5, ((d > 2.0 ** -14 + 1e-9).sum(), d.max())
+
+
 def test_quantised_flow_with_pretrained_float_checkpoint_matches_reference(workdir):
     """train_dpd --quant --pretrained_model <float checkpoint with the float holder's key names> (the q_pretrain -> QAT hand-over,
     quant_envs.py:173-182): the checkpoint's weights go through quantisation, its biases are re-drawn by INT_Linear, the scales start at

@@ -72,7 +72,27 @@ def test_surgery_on_the_other_backbones():
     with pytest.raises(RuntimeError):
         get_quant_model(_Proj, CoreModel(2, 8, 1, "deltagru"))
     with pytest.raises(NotImplementedError):
-        get_quant_model(_Proj, CoreModel(2, 8, 1, "lstm"))
+        get_quant_model(_Proj, CoreModel(2, 8, 1, "vdlstm"))
+
+
+def test_head_only_surgery_state_dict_and_rng_match_the_reference():
+    """lstm: the surgery finds only fc_out to swap (nn.LSTM stays float) — identical keys, order, values (parameters and buffers) and the
+    same global RNG state afterwards as the reference's get_quant_model (oracle/gen_golden_quant_more.py)."""
+    from tests.test_oracle_golden import QAT_HEADS
+    for name, bb, bits in QAT_HEADS:
+        if bb != "lstm":
+            continue
+        fx = Fixture(name)
+        q = _build(bb, fx.meta["hidden"], bits)
+        rng_after = torch.rand(4).numpy()
+        sd = q.state_dict()
+        assert list(sd.keys()) == fx.keys("sd"), name
+        for k in fx.keys("sd"):
+            assert np.array_equal(sd[k].numpy(), fx["sd/" + k]), (name, k)
+        assert sum(p.numel() for p in q.parameters()) == fx.meta["n_param"] == q.backbone.n_flat
+        assert np.array_equal(rng_after, fx["rng_after"]), name
+        assert [n for n, _ in q.named_parameters()][-5:] == ["backbone.fc_out.weight", "backbone.fc_out.bias", "backbone.fc_out.weight_quantizer.scale",
+                                                            "backbone.fc_out.act_quantizer.scale", "backbone.fc_out.out_quantizer.scale"]
 
 
 def test_identity_when_quant_off():

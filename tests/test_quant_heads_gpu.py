@@ -1,0 +1,155 @@
+"""`--quant` on lstm: the reference's surgery finds only `fc_out` to swap (nn.Linear -> INT_Linear, quant/quant_envs.py:40-60, 290-306;
+quant/qmodules/quant_layers.py:48-85), the nn.LSTM core stays float.  HIP path: the quantised-head instantiations of csrc/lstm_family.hip
+(lstm_eval_kernel / lstm_gp_train_kernel / lstm_bwd_kernel <.., QH>) against vectors produced by RUNNING the reference
+(oracle/gen_golden_quant_more.py) and against the oracle on ragged shapes.
+
+Tolerances: the head's grid arithmetic is exact, but it sits behind a float recurrence whose states differ from torch's by ~1e-7 — a state
+that close to a rounding boundary of the activation grid lands on the other side (`grid_close`: a few samples may move by weight x
+grid-step products, everything else agrees to fp32 rounding)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import Fixture, rel_err
+from tests.test_oracle_golden import QAT_HEADS, grid_close, qat_param_names
+from tests.test_quant_more_gpu import _fresh, _qmodel, _signal
+
+pytestmark = pytest.mark.gpu
+LSTM_HEADS = [c for c in QAT_HEADS if c[1] == "lstm"]
+
+
+def _flips(bits, n):
+    return 2 if bits == 8 else n // 50
+
+
+@pytest.mark.parametrize("name,bb,bits", LSTM_HEADS)
+def test_forward_gradients_and_trajectory_match_the_reference(name, bb, bits):
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    fx = Fixture(name)
+    step = 2.0 ** (2 - bits) * 4
+    x = torch.from_numpy(fx["x"]).cuda()
+    for prefix, ytr, yev in (("sd", "y", "y_eval"), ("sd3", "y_p3_train", "y_p3_eval")):
+        q = _qmodel(fx, bb, bits, prefix)
+        q.train()
+        with torch.no_grad():
+            yt = q(x).cpu().numpy()
+        q.eval()
+        with torch.no_grad():
+            ye = q(x).cpu().numpy()
+        assert grid_close(yt, fx[ytr], step, _flips(bits, yt.size)), (prefix, np.abs(yt - fx[ytr]).max())
+        assert grid_close(ye, fx[yev], step, _flips(bits, ye.size)), (prefix, np.abs(ye - fx[yev]).max())
+    q = _qmodel(fx, bb, bits)
+    q.eval()
+    with torch.no_grad():      # config-shaped frames (T = 200), eval mode: on the 16-bit output grid
+        ya = q(torch.from_numpy(fx["xa"]).cuda()).cpu().numpy()
+    assert grid_close(ya, fx["ya_eval"], step, _flips(bits, ya.size))
+    assert np.abs(ya * 2.0 ** 14 - np.rint(ya * 2.0 ** 14)).max() == 0.0
+    # gradients through autograd (checkpoint-writing forward + row-rotated backward with dL/dx)
+    q.train()
+    xg = x.clone().requires_grad_(True)
+    t = torch.from_numpy(fx["tgt"]).cuda()
+    loss = torch.nn.functional.mse_loss(q(xg), t)
+    loss.backward()
+    assert abs(loss.item() - fx["losses"][0]) < 2e-6
+    for k, p in q.named_parameters():
+        if ("g/" + k) in fx:
+            assert rel_err(p.grad.cpu().numpy(), fx["g/" + k]) < 3e-5 or np.abs(fx["g/" + k]).max() == 0, k
+            if "scale" in k:
+                assert float(p.grad.abs().max()) == 0.0
+    assert rel_err(xg.grad.cpu().numpy(), fx["gx"]) < 3e-5
+    # three clip + AdamW steps (one launch per step body at this batch size); AdamW decays the zero-gradient scales, skips out_quantizer's
+    names = qat_param_names(fx)
+    opt = FusedAdamW(q, lr=fx.meta["lr"])
+    for s in range(1, 4):
+        l = fused_train_step(opt, x, t, "l2", fx.meta["clip"])
+        assert abs(l.item() - fx["losses"][s - 1]) < 3e-6
+        got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in q.parameters()])
+        assert rel_err(got, fx.flat(f"p{s}", names)) < 5e-6, s
+
+
+@pytest.mark.parametrize("H,B,T,bits", [(14, 5, 37, 8), (9, 64, 50, 8), (16, 3, 130, 8), (24, 7, 45, 8), (30, 19, 33, 8), (11, 33, 21, 16),
+                                         (14, 700, 20, 8), (20, 600, 17, 8)])
+def test_matches_the_oracle_on_ragged_sizes(H, B, T, bits):
+    """Train- and eval-mode forward, weight gradients and dL/dx against the oracle with scales and weights moved so that both clamps and
+    both pass masks are exercised; hidden sizes on both sides of the 16-unit boundary, batches beyond one frame per wave."""
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H + B + T)
+    q = _fresh("lstm", H, bits).cuda()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(H)
+        q.backbone.fc_out.bias.copy_(((torch.rand(2, generator=g) - 0.5) * 0.6).cuda())
+        q.backbone.fc_out.weight.mul_(6.0)                                 # some weights beyond the weight grid's range (+-2)
+        q.backbone.fc_out.act_quantizer.scale.mul_(0.25)                   # activation range +-0.5: states beyond it are clamped and masked
+    x, dy = _signal(B, T, B + T)
+    o = Oracle("f32")
+    m = make_model("lstm", H, bits_w=bits, bits_a=bits)
+    p = np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in q.parameters()])
+    assert o.param_count(m) == p.size
+    step = 2.0 ** (2 - bits) * 8
+    q.eval()
+    with torch.no_grad():
+        ye = q(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert grid_close(ye, o.qat_forward(m, p, x, eval_mode=True), step, _flips(bits, ye.size) + B // 100)
+    q.train()
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = q(xt)
+    assert grid_close(y.detach().cpu().numpy(), o.qat_forward(m, p, x), step, _flips(bits, ye.size) + B // 100)
+    y.backward(torch.from_numpy(dy).cuda())
+    go, dxo = o.qat_backward(m, p, x, dy, need_dx=True)
+    off = 0
+    # (one state on the other side of a rounding boundary moves a head-weight gradient by |dy| s_a: 14 000 samples see a few of those)
+    tol = 1e-4 if B < 100 else 1e-3
+    for k, v in q.named_parameters():
+        n = v.numel()
+        ref = go[off:off + n]
+        got = (v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy().reshape(-1)
+        if np.abs(ref).max() > 0:
+            assert rel_err(got, ref) < tol, k
+        else:
+            assert np.abs(got).max() == 0, k
+        off += n
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < tol
+    gw = q.backbone.fc_out.weight.grad.cpu().numpy()
+    clipped = np.abs(q.backbone.fc_out.weight.detach().cpu().numpy()) > 2.0
+    assert clipped.any() and np.all(gw[clipped] == 0.0)      # the weight quantiser's pass mask
+
+
+@pytest.mark.parametrize("H,bits,B,T", [(14, 8, 64, 50), (10, 16, 33, 20), (16, 8, 256, 200), (12, 8, 5, 66)])
+def test_one_launch_train_step_equals_the_split_chain(H, bits, B, T):
+    from tests.test_quant_more_gpu import _fused_equals_split
+    _fused_equals_split("lstm", H, bits, B, T, True)
+
+
+def test_larger_batches_and_hidden_sizes_run_the_split_chain():
+    """hidden 17..32 and batches beyond two rounds of one frame per wave: checkpoint-writing forward, loss, row-rotated backward."""
+    from opendpd_amd import _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    lib = _lib.load()
+    for H, B, T in ((24, 64, 50), (12, 5000, 20)):
+        torch.manual_seed(1)
+        q = _fresh("lstm", H, 8).cuda()
+        q.train()
+        assert int(lib.odpd_partial_rows(C.byref(q.backbone.desc), B, T, 1)) < 0
+        x, t = _signal(B, T, 3)
+        x, t = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+        loss = torch.nn.functional.mse_loss(q(x), t)
+        loss.backward()
+        gref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in q.parameters()]).cpu().numpy()
+        opt = FusedAdamW(q, lr=0.0, weight_decay=0.0)
+        lf = fused_train_step(opt, x, t, "l2", 0.0)
+        assert abs(lf.item() - loss.item()) < 2e-6 * max(1.0, abs(loss.item()))
+        assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 2e-5
+
+
+def test_quantised_vdlstm_is_refused():
+    from opendpd_amd import CoreModel
+    from opendpd_amd.quant import get_quant_model
+
+    class P:
+        quant = True
+        n_bits_w = n_bits_a = 8
+        pretrained_model = ""
+    with pytest.raises(NotImplementedError):
+        get_quant_model(P, CoreModel(2, 13, 1, "vdlstm"))
