@@ -66,6 +66,8 @@ typedef struct odpd_model {
     int32_t bits_w;   /* QAT weight bits (0 = float model) — quant/quant_envs.py:145: > 0 on gru, dgru, qgru, qgru_amp1 or deltagru_tcnskip selects the
                          model the reference's surgery makes of it (quant_envs.py:114-130, 290-306: GRU of GRUCells / quantised delta layer,
                          INT_Linear heads; `params` then follows THAT model's named_parameters(), quantiser scales included);
+                         > 0 on lstm / vdlstm: the surgery finds only their nn.Linear heads to swap (quant_envs.py:40-60) — float nn.LSTM core,
+                         fc_out (vdlstm: fc_lambda_1, fc_lambda_2, fc_out) as INT_Linear, three scale parameters behind each head's weight and bias;
                          dvrjanet: num_dvr_units (models.py:119) */
     int32_t bits_a;   /* QAT activation bits */
     int32_t flags;    /* ODPD_FLAG_* */

@@ -22,6 +22,27 @@ __device__ __forceinline__ void load_rot4(float (&w)[4][R][16], TabPtr tlane, in
         for (int rb = 0; rb < R; ++rb) load_rot(w[g][rb], tlane + (first_row + g * R + rb) * 4 * 64);
 }
 
+// VDLSTM under `--quant`: fc_lambda_1, fc_lambda_2 and fc_out are INT_Linear layers with their own weight / activation / output scales
+struct VdQuant { q16::Quant w1, a1, w2, a2, wo, ao, oo; };
+__device__ __forceinline__ VdQuant vd_quantisers(const float* pl, const LstmLayout& L, int bits_w, int bits_a) {
+    VdQuant q;
+    q.w1 = q16::make_quant(pl[L.o_q_l1], bits_w); q.a1 = q16::make_quant(pl[L.o_q_l1 + 1], bits_a);
+    q.w2 = q16::make_quant(pl[L.o_q_l2], bits_w); q.a2 = q16::make_quant(pl[L.o_q_l2 + 1], bits_a);
+    q.wo = q16::make_quant(pl[L.o_q_out], bits_w); q.ao = q16::make_quant(pl[L.o_q_out + 1], bits_a); q.oo = q16::make_quant(pl[L.o_q_out + 2], 16);
+    return q;
+}
+// the staged copies of the three heads' weights become q_w(W) in place: every later read of them — tables, per-lane columns, the uniform fc_out
+// reads — sees the quantised value; the weight quantisers' pass masks are formed from the global copy when the gradients are written.
+// (call between stage_params and the barrier that ends fill_lstm_tabs)
+__device__ __forceinline__ void vd_quantise_staged(float* pl, const LstmLayout& L, const VdQuant& q) {
+    const int H = L.H;      // (three loops: a select between the quantisers inside one loop would put the struct in scratch)
+    for (int i = threadIdx.x; i < 4 * H; i += blockDim.x) pl[L.o_w_l1 + i] = q16::qapply(pl[L.o_w_l1 + i], q.w1);
+    for (int i = threadIdx.x; i < 4 * H; i += blockDim.x) pl[L.o_w_l2 + i] = q16::qapply(pl[L.o_w_l2 + i], q.w2);
+    for (int i = threadIdx.x; i < 16; i += blockDim.x) pl[L.o_w_out + i] = q16::qapply(pl[L.o_w_out + i], q.wo);
+}
+__device__ __forceinline__ float4 qapply4(float4 v, const q16::Quant& q) {
+    return make_float4(q16::qapply(v.x, q), q16::qapply(v.y, q), q16::qapply(v.z, q), q16::qapply(v.w, q));
+}
 template <int R, bool VD>
 struct LstmW {
     float wih[4][VD ? 4 : 2];
@@ -30,6 +51,7 @@ struct LstmW {
     float wl1[4], wl2[4];     // VD: fc_lambda_{1,2}.weight[k][o]
     q16::Quant qa;            // quantised head (lstm_quantise_head): fc_out's activation quantiser; wout = q_w(weight), woutm = its pass mask
     float woutm[2];
+    VdQuant vq;               // VD quantised heads (weights quantised in the staged copy: vd_quantise_staged)
 };
 // fc_out as INT_Linear (`--quant` on lstm: quant_layers.py:48-85): the lane's head columns become their quantised values
 template <int R, bool VD>
@@ -229,7 +251,6 @@ template <int NB> struct LstmEvalLds {
 // 16-bit output quantiser.
 template <int NB, bool VD, bool CK, bool QH = false>      // CK: also writes the BPTT checkpoints (the forward of the split train path)
 __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
-    static_assert(!(QH && VD), "quantised heads: plain lstm");
     constexpr int F = VD ? 4 : 2, EC = kEvalChunk, HS = LstmEvalLds<NB>::kHistStride;
     using T = LstmTabs<NB>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -238,13 +259,15 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
     const int H = L.H;
     float* pl = smem;
     stage_params(pl, a.params, L.P);
+    VdQuant vq{};
+    if constexpr (QH && VD) { vq = vd_quantisers(pl, L, a.bits_w, a.bits_a); vd_quantise_staged(pl, L, vq); }
     float* tab = smem + pad4(L.P);
     fill_lstm_tabs<NB, false>(tab, pl, L, lane, 0, 1);
     float* ftab = tab + T::kFloats;                    // [kHalo + EC][4]: entry kHalo + i = inputs of time t0 + i; entries 0..2 = the three before
     float* hist = ftab + (kHalo + EC) * 4;             // [EC][HS]: entry i = h of time t0 + i, every lane's copy
     float* hw = hist + EC * HS;
     q16::Quant qw{}, qa{}, qo{};
-    if constexpr (QH) {
+    if constexpr (QH && !VD) {
         qw = q16::make_quant(pl[L.o_q_out], a.bits_w); qa = q16::make_quant(pl[L.o_q_out + 1], a.bits_a); qo = q16::make_quant(pl[L.o_q_out + 2], 16);
     }
     for (int i = lane; i < LstmEvalLds<NB>::kHeadFloats; i += 64) {
@@ -341,25 +364,37 @@ __global__ __launch_bounds__(64) void lstm_eval_kernel(SeqArgs a) {
                 for (int ob = 0; ob < NB; ++ob)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        float4 hv = hv4[16 * ob + q];
-                        if constexpr (QH) hv = make_float4(q16::qgrid(hv.x, qa), q16::qgrid(hv.y, qa), q16::qgrid(hv.z, qa), q16::qgrid(hv.w, qa));
+                        float4 hv = hv4[16 * ob + q], hv2 = hv;
+                        if constexpr (QH && !VD) hv = make_float4(q16::qgrid(hv.x, qa), q16::qgrid(hv.y, qa), q16::qgrid(hv.z, qa), q16::qgrid(hv.w, qa));
+                        if constexpr (QH && VD) { hv = qapply4(hv2, vq.a1); hv2 = qapply4(hv2, vq.a2); }      // fc_lambda_1 / _2: their own activation grids
 #pragma unroll
                         for (int r = 0; r < (VD ? 8 : 2); ++r) {
                             const float4 w = hw4[4 * NB * r + 4 * ob + q];
-                            acc[r] = __builtin_fmaf(w.x, hv.x, acc[r]); acc[r] = __builtin_fmaf(w.y, hv.y, acc[r]);
-                            acc[r] = __builtin_fmaf(w.z, hv.z, acc[r]); acc[r] = __builtin_fmaf(w.w, hv.w, acc[r]);
+                            const float4 hx = (QH && VD && r >= 4) ? hv2 : hv;
+                            acc[r] = __builtin_fmaf(w.x, hx.x, acc[r]); acc[r] = __builtin_fmaf(w.y, hx.y, acc[r]);
+                            acc[r] = __builtin_fmaf(w.z, hx.z, acc[r]); acc[r] = __builtin_fmaf(w.w, hx.w, acc[r]);
                         }
                     }
                 float y0, y1;
                 if constexpr (VD) {
                     // y = fc_out(cat(l1 * cos, l2 * sin)) over the four-sample window (vdlstm.py:77-80)
-                    y0 = pl[L.o_b_out]; y1 = pl[L.o_b_out + 1];
+                    // QH: every sum is an exact grid sum (started at 0), its fp32 bias added once at the end
+                    if constexpr (QH) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) acc[r] += r < 4 ? pl[L.o_b_l1 + r] : pl[L.o_b_l2 + r - 4];
+                    }
+                    y0 = QH ? 0.0f : pl[L.o_b_out]; y1 = QH ? 0.0f : pl[L.o_b_out + 1];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float4 e = reinterpret_cast<const float4*>(ftab)[lane + k];
-                        const float lc = acc[k] * e.y, ls = acc[4 + k] * e.z;
+                        float lc = acc[k] * e.y, ls = acc[4 + k] * e.z;
+                        if constexpr (QH) { lc = q16::qapply(lc, vq.ao); ls = q16::qapply(ls, vq.ao); }
                         y0 = __builtin_fmaf(pl[L.o_w_out + k], lc, __builtin_fmaf(pl[L.o_w_out + 4 + k], ls, y0));
                         y1 = __builtin_fmaf(pl[L.o_w_out + 8 + k], lc, __builtin_fmaf(pl[L.o_w_out + 12 + k], ls, y1));
+                    }
+                    if constexpr (QH) {
+                        y0 += pl[L.o_b_out]; y1 += pl[L.o_b_out + 1];
+                        if (a.eval_out) { y0 = q16::qapply(y0, vq.oo); y1 = q16::qapply(y1, vq.oo); }
                     }
                 } else if constexpr (QH) {
                     const float S = qa.s * qw.s;
@@ -401,7 +436,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 template <bool VD, bool PG, bool QH = false>      // QH: fc_out as INT_Linear (see lstm_eval_kernel); train mode
 __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
-    static_assert(!(QH && VD), "quantised heads: plain lstm");
     constexpr int F = VD ? 4 : 2, NH = VD ? 8 : 2;
     using TB = LstmTabs<1>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -410,6 +444,8 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
     const int H = L.H, T = a.T, Tp = (T + 63) & ~63;
     float* pl = smem;
     stage_params(pl, a.params, L.P);
+    VdQuant vq{};
+    if constexpr (QH && VD) { vq = vd_quantisers(pl, L, a.bits_w, a.bits_a); vd_quantise_staged(pl, L, vq); }
     float* tab = smem + pad4(L.P);
     fill_lstm_tabs<1, true>(tab, pl, L, lane, 0, 1);
     const bool vo = col < H, is_g = role == 2;
@@ -430,10 +466,15 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
         wh[r] = !vo ? 0.0f : VD ? (r < 4 ? pl[L.o_w_l1 + r * H + col] : pl[L.o_w_l2 + (r - 4) * H + col]) : pl[L.o_w_out + r * H + col];
     q16::Quant qw{}, qa{};
     [[maybe_unused]] float whm[NH];                  // QH: the weight quantiser's pass mask of the unit's head columns
-    if constexpr (QH) {
+    if constexpr (QH && !VD) {
         qw = q16::make_quant(pl[L.o_q_out], a.bits_w); qa = q16::make_quant(pl[L.o_q_out + 1], a.bits_a);
 #pragma unroll
         for (int r = 0; r < NH; ++r) { whm[r] = q16::qpass(wh[r], qw); wh[r] = q16::qapply(wh[r], qw); }
+    }
+    if constexpr (QH && VD) {      // (wh: already the quantised values, vd_quantise_staged) the masks from the global copy
+#pragma unroll
+        for (int r = 0; r < NH; ++r)
+            whm[r] = vo ? q16::qpass(a.params[(r < 4 ? L.o_w_l1 + r * H : L.o_w_l2 + (r - 4) * H) + col], r < 4 ? vq.w1 : vq.w2) : 0.0f;
     }
     wave_lds_fence();
     // per-time buffers over the tables
@@ -535,34 +576,49 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
                 for (int r = 0; r < NH; ++r) acc[r] = QH ? 0.0f : VD ? (r < 4 ? pl[L.o_b_l1 + r] : pl[L.o_b_l2 + r - 4]) : pl[L.o_b_out + r];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float4 hv = hv4[q];
-                    if constexpr (QH) hv = make_float4(q16::qgrid(hv.x, qa), q16::qgrid(hv.y, qa), q16::qgrid(hv.z, qa), q16::qgrid(hv.w, qa));
+                    float4 hv = hv4[q], hv2 = hv;
+                    if constexpr (QH && !VD) hv = make_float4(q16::qgrid(hv.x, qa), q16::qgrid(hv.y, qa), q16::qgrid(hv.z, qa), q16::qgrid(hv.w, qa));
+                    if constexpr (QH && VD) { hv = qapply4(hv2, vq.a1); hv2 = qapply4(hv2, vq.a2); }
 #pragma unroll
                     for (int r = 0; r < NH; ++r) {
                         const float4 w = hw4[4 * r + q];
-                        acc[r] = __builtin_fmaf(w.x, hv.x, acc[r]); acc[r] = __builtin_fmaf(w.y, hv.y, acc[r]);
-                        acc[r] = __builtin_fmaf(w.z, hv.z, acc[r]); acc[r] = __builtin_fmaf(w.w, hv.w, acc[r]);
+                        const float4 hx = (QH && VD && r >= 4) ? hv2 : hv;
+                        acc[r] = __builtin_fmaf(w.x, hx.x, acc[r]); acc[r] = __builtin_fmaf(w.y, hx.y, acc[r]);
+                        acc[r] = __builtin_fmaf(w.z, hx.z, acc[r]); acc[r] = __builtin_fmaf(w.w, hx.w, acc[r]);
                     }
                 }
                 const float2 tv = tg[t];
                 float dy0, dy1;
                 if constexpr (VD) {
                     // y = fc_out(cat(l1 * cos, l2 * sin)) over the four-sample window (vdlstm.py:77-80)
-                    float y0 = pl[L.o_b_out], y1 = pl[L.o_b_out + 1], lc[4], ls[4], cw[4], sw[4];
+                    // QH: the three heads as INT_Linear — exact grid sums started at 0, the fp32 bias added once; fc_out's inputs (l cos, l sin)
+                    // quantised on its activation grid, whose pass mask gates their gradients
+                    float y0 = QH ? 0.0f : pl[L.o_b_out], y1 = QH ? 0.0f : pl[L.o_b_out + 1], lc[4], ls[4], cw[4], sw[4];
+                    [[maybe_unused]] float pzc[4], pzs[4];
+                    if constexpr (QH) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) acc[r] += r < 4 ? pl[L.o_b_l1 + r] : pl[L.o_b_l2 + r - 4];
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float4 e = reinterpret_cast<const float4*>(ftab)[t + k];
                         cw[k] = e.y; sw[k] = e.z;
                         lc[k] = acc[k] * e.y; ls[k] = acc[4 + k] * e.z;
+                        if constexpr (QH) {
+                            pzc[k] = q16::qpass(lc[k], vq.ao); pzs[k] = q16::qpass(ls[k], vq.ao);
+                            lc[k] = q16::qapply(lc[k], vq.ao); ls[k] = q16::qapply(ls[k], vq.ao);
+                        }
                         y0 = __builtin_fmaf(pl[L.o_w_out + k], lc[k], __builtin_fmaf(pl[L.o_w_out + 4 + k], ls[k], y0));
                         y1 = __builtin_fmaf(pl[L.o_w_out + 8 + k], lc[k], __builtin_fmaf(pl[L.o_w_out + 12 + k], ls[k], y1));
                     }
+                    if constexpr (QH) { y0 += pl[L.o_b_out]; y1 += pl[L.o_b_out + 1]; }
                     s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
                     float dl[8];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         dl[k] = __builtin_fmaf(dy0, pl[L.o_w_out + k], dy1 * pl[L.o_w_out + 8 + k]) * cw[k];
                         dl[4 + k] = __builtin_fmaf(dy0, pl[L.o_w_out + 4 + k], dy1 * pl[L.o_w_out + 12 + k]) * sw[k];
+                        if constexpr (QH) { dl[k] *= pzc[k]; dl[4 + k] *= pzs[k]; }
                         tacc[k] = __builtin_fmaf(dy0, lc[k], tacc[k]); tacc[4 + k] = __builtin_fmaf(dy0, ls[k], tacc[4 + k]);      // fc_out row 0
                         tacc[8 + k] = __builtin_fmaf(dy1, lc[k], tacc[8 + k]); tacc[12 + k] = __builtin_fmaf(dy1, ls[k], tacc[12 + k]);
                         tacc[18 + k] += dl[k]; tacc[22 + k] += dl[4 + k];                                                           // fc_lambda biases
@@ -617,7 +673,16 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
                     gather_rows(is_g ? th : sg, g);
                 }
                 float dht = dh;
-                if constexpr (QH) {      // dL/dW on q_a(h), dL/dh through the activation quantiser's pass mask
+                if constexpr (QH && VD) {      // fc_lambda_1 / _2: each on its own activation grid
+                    const float hq1 = q16::qapply(ht, vq.a1), hq2 = q16::qapply(ht, vq.a2);
+                    float hd1 = 0.0f, hd2 = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        hd1 = __builtin_fmaf(hg[r], wh[r], hd1); dwh[r] = __builtin_fmaf(hg[r], hq1, dwh[r]);
+                        hd2 = __builtin_fmaf(hg[4 + r], wh[4 + r], hd2); dwh[4 + r] = __builtin_fmaf(hg[4 + r], hq2, dwh[4 + r]);
+                    }
+                    dht += (q16::qpassb(ht, vq.a1) ? hd1 : 0.0f) + (q16::qpassb(ht, vq.a2) ? hd2 : 0.0f);
+                } else if constexpr (QH) {      // dL/dW on q_a(h), dL/dh through the activation quantiser's pass mask
                     const float hq = q16::qapply(ht, qa);
                     float hd = 0.0f;
 #pragma unroll
@@ -653,15 +718,21 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
     if (vo && role == 0) {
 #pragma unroll
         for (int r = 0; r < NH; ++r) {
-            if (VD) prow[(r < 4 ? L.o_w_l1 + r * H : L.o_w_l2 + (r - 4) * H) + col] = dwh[r];
+            if (VD) prow[(r < 4 ? L.o_w_l1 + r * H : L.o_w_l2 + (r - 4) * H) + col] = QH ? dwh[r] * whm[r] : dwh[r];
             else prow[L.o_w_out + r * H + col] = QH ? dwh[r] * whm[r] : dwh[r];
         }
     }
     if (lane == 0) {
-        if constexpr (QH) { prow[L.o_q_out] = 0.0f; prow[L.o_q_out + 1] = 0.0f; prow[L.o_q_out + 2] = 0.0f; }      // the scales: zero gradients (quantizers.py:56-65)
+        if constexpr (QH) {      // the scales: zero gradients (quantizers.py:56-65)
+            prow[L.o_q_out] = 0.0f; prow[L.o_q_out + 1] = 0.0f; prow[L.o_q_out + 2] = 0.0f;
+            if constexpr (VD) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { prow[L.o_q_l1 + k] = 0.0f; prow[L.o_q_l2 + k] = 0.0f; }
+            }
+        }
         if constexpr (VD) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) prow[L.o_w_out + k] = tacc[k];
+            for (int k = 0; k < 16; ++k) prow[L.o_w_out + k] = QH ? tacc[k] * q16::qpass(a.params[L.o_w_out + k], vq.wo) : tacc[k];
             prow[L.o_b_out] = tacc[16]; prow[L.o_b_out + 1] = tacc[17];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { prow[L.o_b_l1 + k] = tacc[18 + k]; prow[L.o_b_l2 + k] = tacc[22 + k]; }
@@ -778,7 +849,36 @@ __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, 
                 for (int k = 0; k < 4; ++k) xin[k] = win.a[k];
             } else { const float2 xv = xr[tt]; xin[0] = xv.x; xin[1] = xv.y; }
             float dht = dh;
-            if constexpr (VD) {
+            if constexpr (VD && QH) {
+                // the three heads as INT_Linear (weights already quantised in the staged copy): fc_lambda_1 / _2 on q_a(h) of their own grids,
+                // fc_out on q_a(l cos), q_a(l sin); every activation quantiser's pass mask gates the gradient that flows back through it
+                const float hq1 = q16::qapply(ht, w.vq.a1), hq2 = q16::qapply(ht, w.vq.a2);
+                float hd1 = 0.0f, hd2 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float l1 = seq_sum<R>(w.wl1[k] * hq1) + pl[L.o_b_l1 + k], l2 = seq_sum<R>(w.wl2[k] * hq2) + pl[L.o_b_l2 + k];
+                    const float z1 = l1 * win.cw[k], z2 = l2 * win.sw[k];
+                    const float dz1 = q16::qpass(z1, w.vq.ao) * __builtin_fmaf(dyv.x, pl[L.o_w_out + k], dyv.y * pl[L.o_w_out + 8 + k]);
+                    const float dz2 = q16::qpass(z2, w.vq.ao) * __builtin_fmaf(dyv.x, pl[L.o_w_out + 4 + k], dyv.y * pl[L.o_w_out + 12 + k]);
+                    const float d1 = dz1 * win.cw[k], d2 = dz2 * win.sw[k];
+                    hd1 = __builtin_fmaf(d1, w.wl1[k], hd1); hd2 = __builtin_fmaf(d2, w.wl2[k], hd2);
+                    if constexpr (DX) {
+                        acc.c[k] = __builtin_fmaf(dz1, l1, acc.c[k]);
+                        acc.s[k] = __builtin_fmaf(dz2, l2, acc.s[k]);
+                    }
+                    if constexpr (NW) {
+                        G.dwl1[k] = __builtin_fmaf(d1, hq1, G.dwl1[k]);
+                        G.dwl2[k] = __builtin_fmaf(d2, hq2, G.dwl2[k]);
+                        G.dbl1[k] += d1; G.dbl2[k] += d2;
+                        const float zq1 = q16::qapply(z1, w.vq.ao), zq2 = q16::qapply(z2, w.vq.ao);
+                        G.dwo[k] = __builtin_fmaf(dyv.x, zq1, G.dwo[k]);
+                        G.dwo[4 + k] = __builtin_fmaf(dyv.x, zq2, G.dwo[4 + k]);
+                        G.dwo[8 + k] = __builtin_fmaf(dyv.y, zq1, G.dwo[8 + k]);
+                        G.dwo[12 + k] = __builtin_fmaf(dyv.y, zq2, G.dwo[12 + k]);
+                    }
+                }
+                dht += (q16::qpassb(ht, w.vq.a1) ? hd1 : 0.0f) + (q16::qpassb(ht, w.vq.a2) ? hd2 : 0.0f);
+            } else if constexpr (VD) {
                 // dz[k] = sum_c dy_c Wo[c][k];  dl1[k] = dz[k] cw[k];  dl2[k] = dz[4+k] sw[k]
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -889,7 +989,7 @@ __device__ __forceinline__ void lstm_bwd_block(const SeqArgs& a, const LstmW<R, 
 
 template <int R, bool VD, bool QH = false>
 __device__ __forceinline__ void lstm_write_partials(float* prow, const LstmLayout& L, LstmGrad<R, VD>& G, int lane, int row,
-                                                    int col, const LstmW<R, VD>* w = nullptr) {
+                                                    int col, const LstmW<R, VD>* w = nullptr, const float* gparams = nullptr) {
     constexpr int F = VD ? 4 : 2;
     const int H = L.H, o = 16 * row + col, seq = lane / (16 * R);
     const int g4 = lane >> 4, c = lane & 15;
@@ -917,15 +1017,22 @@ __device__ __forceinline__ void lstm_write_partials(float* prow, const LstmLayou
     if constexpr (VD) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a1 = across_seqs<R>(G.dwl1[k]), a2 = across_seqs<R>(G.dwl2[k]);
+            float a1 = across_seqs<R>(G.dwl1[k]), a2 = across_seqs<R>(G.dwl2[k]);
             const float b1 = across_seqs<R>(G.dbl1[k]), b2 = across_seqs<R>(G.dbl2[k]);
+            if constexpr (QH) {      // the weight quantisers' pass masks, from the global (unquantised) copy
+                if (o < H) { a1 *= q16::qpass(gparams[L.o_w_l1 + k * H + o], w->vq.w1); a2 *= q16::qpass(gparams[L.o_w_l2 + k * H + o], w->vq.w2); }
+            }
             if (seq == 0 && o < H) { prow[L.o_w_l1 + k * H + o] = a1; prow[L.o_w_l2 + k * H + o] = a2; }
             if (lane == 0) { prow[L.o_b_l1 + k] = b1; prow[L.o_b_l2 + k] = b2; }
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const float v = across_seqs<R>(G.dwo[k]);
+            float v = across_seqs<R>(G.dwo[k]);
+            if constexpr (QH) v *= q16::qpass(gparams[L.o_w_out + k], w->vq.wo);
             if (lane == 0) prow[L.o_w_out + k] = v;
+        }
+        if constexpr (QH) {      // the nine scales: zero gradients (quantizers.py:56-65)
+            if (lane < 3) { prow[L.o_q_l1 + lane] = 0.0f; prow[L.o_q_l2 + lane] = 0.0f; prow[L.o_q_out + lane] = 0.0f; }
         }
     } else {
         float w0 = across_seqs<R>(G.dwout[0]), w1 = across_seqs<R>(G.dwout[1]);
@@ -939,7 +1046,6 @@ __device__ __forceinline__ void lstm_write_partials(float* prow, const LstmLayou
 
 template <int R, bool VD, bool NW, bool DX, bool QH = false>
 __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R == 1 && !VD) ? 2 : 1) void lstm_bwd_kernel(SeqArgs a) {
-    static_assert(!(QH && VD), "quantised heads: plain lstm");
     constexpr int SPW = 4 / R, S = kCkptStride;
     using T = LstmTabs<R>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -948,15 +1054,16 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
     const LstmLayout L = lstm_layout(a.H, VD, QH);
     float* pl = smem;
     stage_params(pl, a.params, L.P);
+    LstmW<R, VD> w;
+    if constexpr (QH && VD) { w.vq = vd_quantisers(pl, L, a.bits_w, a.bits_a); vd_quantise_staged(pl, L, w.vq); }
     float* tab = smem + pad4(L.P);
     fill_lstm_tabs<R, true>(tab, pl, L, lane, id.wave, id.nwb);
     TabPtr tlane = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float2* xs = reinterpret_cast<float2*>(tab + T::kFloats) + id.wave * (SPW * kHaloStride + 2 * SPW * kChunkPad);
     float2* dys = xs + SPW * kHaloStride;
     float2* dxs = dys + SPW * kChunkPad;
-    LstmW<R, VD> w;
     load_lstm_w<R, VD>(w, pl, L, id.row, id.col);
-    if constexpr (QH) lstm_quantise_head<R, VD>(w, pl, L, a.bits_w, a.bits_a);
+    if constexpr (QH && !VD) lstm_quantise_head<R, VD>(w, pl, L, a.bits_w, a.bits_a);
     LstmGrad<R, VD> G;
     G.zero();
     const int nwaves = gridDim.x * id.nwb;
@@ -1022,7 +1129,7 @@ __global__ __launch_bounds__((R == 1 && !VD) ? kMaxThreads : kMaxThreads / 2, (R
     if constexpr (NW) {
         const int P4 = L.P + kLossCols;
         __syncthreads();
-        lstm_write_partials<R, VD, QH>(smem + id.wave * P4, L, G, lane, id.row, id.col, &w);
+        lstm_write_partials<R, VD, QH>(smem + id.wave * P4, L, G, lane, id.row, id.col, &w, a.params);
         __syncthreads();
         float* prow = a.partials + (size_t)blockIdx.x * P4;
         for (int i = threadIdx.x; i < P4; i += blockDim.x) {
@@ -1063,9 +1170,7 @@ static int lstm_launch_eval(hipStream_t st, const SeqArgs& a, int P) {
         hipLaunchKernelGGL(k, dim3(a.B), dim3(64), lds, st, a);
         return (int)hipGetLastError();
     };
-    if constexpr (!VD) {
-        if (a.bits_w > 0) return a.ckpt ? launch(lstm_eval_kernel<NB, false, true, true>) : launch(lstm_eval_kernel<NB, false, false, true>);
-    }
+    if (a.bits_w > 0) return a.ckpt ? launch(lstm_eval_kernel<NB, VD, true, true>) : launch(lstm_eval_kernel<NB, VD, false, true>);
     return a.ckpt ? launch(lstm_eval_kernel<NB, VD, true>) : launch(lstm_eval_kernel<NB, VD, false>);
 }
 template <int R, bool VD, bool NW, bool DX>
@@ -1077,9 +1182,7 @@ static int lstm_launch_bwd(hipStream_t st, const SeqArgs& a, int P) {
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
         return (int)hipGetLastError();
     };
-    if constexpr (!VD) {
-        if (a.bits_w > 0) return launch(lstm_bwd_kernel<R, false, NW, DX, true>);
-    }
+    if (a.bits_w > 0) return launch(lstm_bwd_kernel<R, VD, NW, DX, true>);
     return launch(lstm_bwd_kernel<R, VD, NW, DX>);
 }
 template <int R, bool VD>
@@ -1110,7 +1213,7 @@ static bool lstm_gp_parks_gates(int P, bool vd, int B, int T) { return (long)B <
 bool lstm_train_uses_gp(const odpd_model_t* m, int B, int T) {
     if ((m->backbone != ODPD_LSTM && m->backbone != ODPD_VDLSTM) || m->hidden > 16 || lstm_train_uses_s16(m, B)) return false;
     const bool vd = m->backbone == ODPD_VDLSTM;
-    if ((vd && T < kHalo) || (vd && m->bits_w > 0)) return false;
+    if (vd && T < kHalo) return false;
     const int P = lstm_layout(m->hidden, vd, m->bits_w > 0).P;
     const long max_batch = tuning().gp_max_batch;
     if (max_batch >= 0) return B <= max_batch && lstm_gp_blocks_per_cu(P, vd, T, false) > 0;
@@ -1135,6 +1238,7 @@ int lstm_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
         hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, st, a);
         return (int)hipGetLastError();
     };
+    if (vd && m->bits_w > 0) return pg ? launch(lstm_gp_train_kernel<true, true, true>) : launch(lstm_gp_train_kernel<true, false, true>);
     if (vd) return pg ? launch(lstm_gp_train_kernel<true, true>) : launch(lstm_gp_train_kernel<true, false>);
     if (m->bits_w > 0) return pg ? launch(lstm_gp_train_kernel<false, true, true>) : launch(lstm_gp_train_kernel<false, false, true>);
     return pg ? launch(lstm_gp_train_kernel<false, true>) : launch(lstm_gp_train_kernel<false, false>);
@@ -1142,7 +1246,7 @@ int lstm_gp_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 int lstm_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     const int R = rows_per_seq(m->hidden);
     const bool vd = m->backbone == ODPD_VDLSTM;
-    if (!R || (vd && m->bits_w > 0)) return ODPD_EUNSUPPORTED;      // (quantised heads: plain lstm only)
+    if (!R) return ODPD_EUNSUPPORTED;
     if (vd && a.T < kHalo) return ODPD_EINVAL;
     const int P = lstm_layout(m->hidden, vd, m->bits_w > 0).P;
     // sequences that each get a SIMD of their own (inference, and the checkpoint-writing forward of the split train path): the gate-parallel kernel
@@ -1153,7 +1257,7 @@ int lstm_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 int lstm_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     const int R = rows_per_seq(m->hidden);
     const bool vd = m->backbone == ODPD_VDLSTM;
-    if (!R || (vd && m->bits_w > 0)) return ODPD_EUNSUPPORTED;      // (quantised heads: plain lstm only)
+    if (!R) return ODPD_EUNSUPPORTED;
     if (vd && a.T < kHalo) return ODPD_EINVAL;
     const int P = lstm_layout(m->hidden, vd, m->bits_w > 0).P;
     ODPD_LSTM_DISPATCH(lstm_launch_bwd_mode, st, a, P)

@@ -142,6 +142,24 @@ class QuantGRUCellModel(_QuantBase):
 QuantQGRU = QuantGRUCellModel      # the r01 / r02 name
 
 
+class QuantHeadVDLSTM(_QuantBase):
+    """vdlstm after the surgery: fc_lambda_1, fc_lambda_2 and fc_out (named_children order, vdlstm.py:29-43) become INT_Linear, each with its
+    own three scales; `set_last_layer_quant` marks fc_out.  nn.LSTM stays float.  Kernels: csrc/lstm_family.hip <VD, QH>."""
+    backbone_name = "vdlstm"
+
+    def __init__(self, rnn, bits_w, bits_a):
+        super().__init__()
+        hidden_size = rnn.hidden_size
+        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, 4, 2, 1
+        self.window_length, self.stride, self.pad_size = 4, 1, 3
+        self.rnn = rnn
+        self.fc_lambda_1 = _QLinear(hidden_size, 4, bits_w, bits_a)
+        self.fc_lambda_2 = _QLinear(hidden_size, 4, bits_w, bits_a)
+        self.fc_out = _QLinear(8, 2, bits_w, bits_a)
+        self.fc_out.out_quant = True
+        self._finish(hidden_size, bits_w, bits_a)
+
+
 class QuantHeadLSTM(_QuantBase):
     """lstm after the surgery: it holds no nn.GRU and no op modules, so only `fc_out` changes — nn.Linear -> INT_Linear
     (quant_envs.py:40-60, 290-306) with out_quant set (`set_last_layer_quant`, :278-287); nn.LSTM stays float.  Kernels: the
@@ -226,8 +244,8 @@ class QuantTResDeltaGRU(_QuantBase):
 
 MAX_HIDDEN = 32          # csrc/qat_s16.hip: two 16-unit tiles
 _UNTOUCHED = ("gmp", "tcnn")       # no nn.GRU, no nn.Linear, no op modules: the surgery returns an identical deep copy
-_PARTIAL = ("vdlstm", "rvtdcnn", "apnrru", "bojanet", "deltajanet", "dvrjanet", "neuraltx", "mcldnn", "pgjanet")
-_HEAD_ONLY = ("lstm",)             # only nn.Linear heads to swap, and kernels with a quantised head exist
+_PARTIAL = ("rvtdcnn", "apnrru", "bojanet", "deltajanet", "dvrjanet", "neuraltx", "mcldnn", "pgjanet")
+_HEAD_ONLY = ("lstm", "vdlstm")    # only nn.Linear heads to swap, and kernels with quantised heads exist
 
 
 def _warn_float(exc, model):
@@ -246,8 +264,9 @@ def _wrap(model, bb, dev):
 
 
 def _quantise_heads(model, bits_w, bits_a, pre, dev):
-    """lstm: create_pygru_model finds no nn.GRU (no RNG draws), load_model strict-loads a float checkpoint of the model's own keys,
-    create_quantized_model swaps fc_out — INT_Linear keeps the weight and draws a fresh default-init bias (quant_layers.py:48-56)."""
+    """lstm / vdlstm: create_pygru_model finds no nn.GRU (no RNG draws), load_model strict-loads a float checkpoint of the model's own keys,
+    create_quantized_model swaps the nn.Linear heads in named_children order — each INT_Linear keeps the weight and draws a fresh
+    default-init bias (quant_layers.py:48-56)."""
     import copy
     fb = model.backbone
     if pre:
@@ -258,15 +277,17 @@ def _quantise_heads(model, bits_w, bits_a, pre, dev):
                 raise RuntimeError("Error(s) in loading state_dict for CoreModel")
         except Exception as exc:
             return _warn_float(exc, model)
+    heads = ("fc_lambda_1", "fc_lambda_2", "fc_out") if model.backbone_type == "vdlstm" else ("fc_out",)
     with torch.no_grad():
         rnn = copy.deepcopy(fb.rnn).cpu()
-        fc_w = fb.fc_out.weight.detach().cpu()
+        fc_w = {h: getattr(fb, h).weight.detach().cpu() for h in heads}
         if pre:
             for k, p in rnn.named_parameters():
                 p.copy_(pre_sd["backbone.rnn." + k])
-            fc_w = pre_sd["backbone.fc_out.weight"]
-        bb = QuantHeadLSTM(rnn, bits_w, bits_a)
-        bb.fc_out.weight.copy_(fc_w)
+            fc_w = {h: pre_sd[f"backbone.{h}.weight"] for h in heads}
+        bb = (QuantHeadVDLSTM if model.backbone_type == "vdlstm" else QuantHeadLSTM)(rnn, bits_w, bits_a)
+        for h in heads:
+            getattr(bb, h).weight.copy_(fc_w[h])
     return _wrap(model, bb, dev)
 
 

@@ -72,16 +72,14 @@ def test_surgery_on_the_other_backbones():
     with pytest.raises(RuntimeError):
         get_quant_model(_Proj, CoreModel(2, 8, 1, "deltagru"))
     with pytest.raises(NotImplementedError):
-        get_quant_model(_Proj, CoreModel(2, 8, 1, "vdlstm"))
+        get_quant_model(_Proj, CoreModel(2, 8, 1, "pgjanet"))
 
 
 def test_head_only_surgery_state_dict_and_rng_match_the_reference():
-    """lstm: the surgery finds only fc_out to swap (nn.LSTM stays float) — identical keys, order, values (parameters and buffers) and the
+    """lstm / vdlstm: the surgery finds only the nn.Linear heads to swap (nn.LSTM stays float) — identical keys, order, values (parameters and buffers) and the
     same global RNG state afterwards as the reference's get_quant_model (oracle/gen_golden_quant_more.py)."""
     from tests.test_oracle_golden import QAT_HEADS
     for name, bb, bits in QAT_HEADS:
-        if bb != "lstm":
-            continue
         fx = Fixture(name)
         q = _build(bb, fx.meta["hidden"], bits)
         rng_after = torch.rand(4).numpy()

@@ -1,5 +1,5 @@
-"""`--quant` on lstm: the reference's surgery finds only `fc_out` to swap (nn.Linear -> INT_Linear, quant/quant_envs.py:40-60, 290-306;
-quant/qmodules/quant_layers.py:48-85), the nn.LSTM core stays float.  HIP path: the quantised-head instantiations of csrc/lstm_family.hip
+"""`--quant` on lstm / vdlstm: the reference's surgery finds only the heads to swap (fc_out; vdlstm: fc_lambda_1, fc_lambda_2, fc_out: nn.Linear ->
+INT_Linear, quant/quant_envs.py:40-60, 290-306; quant/qmodules/quant_layers.py:48-85), the nn.LSTM core stays float.  HIP path: the quantised-head instantiations of csrc/lstm_family.hip
 (lstm_eval_kernel / lstm_gp_train_kernel / lstm_bwd_kernel <.., QH>) against vectors produced by RUNNING the reference
 (oracle/gen_golden_quant_more.py) and against the oracle on ragged shapes.
 
@@ -17,7 +17,7 @@ from tests.test_oracle_golden import QAT_HEADS, grid_close, qat_param_names
 from tests.test_quant_more_gpu import _fresh, _qmodel, _signal
 
 pytestmark = pytest.mark.gpu
-LSTM_HEADS = [c for c in QAT_HEADS if c[1] == "lstm"]
+LSTM_HEADS = QAT_HEADS
 
 
 def _flips(bits, n):
@@ -69,22 +69,32 @@ def test_forward_gradients_and_trajectory_match_the_reference(name, bb, bits):
         assert rel_err(got, fx.flat(f"p{s}", names)) < 5e-6, s
 
 
+@pytest.mark.parametrize("bb", ["lstm", "vdlstm"])
 @pytest.mark.parametrize("H,B,T,bits", [(14, 5, 37, 8), (9, 64, 50, 8), (16, 3, 130, 8), (24, 7, 45, 8), (30, 19, 33, 8), (11, 33, 21, 16),
                                          (14, 700, 20, 8), (20, 600, 17, 8)])
-def test_matches_the_oracle_on_ragged_sizes(H, B, T, bits):
+def test_matches_the_oracle_on_ragged_sizes(bb, H, B, T, bits):
     """Train- and eval-mode forward, weight gradients and dL/dx against the oracle with scales and weights moved so that both clamps and
     both pass masks are exercised; hidden sizes on both sides of the 16-unit boundary, batches beyond one frame per wave."""
     from oracle.oracle import Oracle, make_model
     torch.manual_seed(H + B + T)
-    q = _fresh("lstm", H, bits).cuda()
+    q = _fresh(bb, H, bits).cuda()
+    vd = bb == "vdlstm"
     with torch.no_grad():
         g = torch.Generator().manual_seed(H)
         q.backbone.fc_out.bias.copy_(((torch.rand(2, generator=g) - 0.5) * 0.6).cuda())
-        q.backbone.fc_out.weight.mul_(6.0)                                 # some weights beyond the weight grid's range (+-2)
-        q.backbone.fc_out.act_quantizer.scale.mul_(0.25)                   # activation range +-0.5: states beyond it are clamped and masked
+        q.backbone.fc_out.weight.mul_(3.0 if vd else 6.0)                  # some weights beyond the weight grid's range (+-2)
+        if vd:      # fc_lambda_1 / _2 on grids of their own, fc_out's inputs (l cos, l sin) partly beyond its activation range
+            q.backbone.fc_lambda_1.weight.mul_(5.0)
+            q.backbone.fc_lambda_2.weight.mul_(5.0)
+            q.backbone.fc_lambda_1.act_quantizer.scale.mul_(0.25)
+            q.backbone.fc_lambda_2.act_quantizer.scale.mul_(0.5)
+            q.backbone.fc_lambda_1.bias.copy_(((torch.rand(4, generator=g) - 0.5) * 0.8).cuda())
+            q.backbone.fc_out.act_quantizer.scale.mul_(0.5)
+        else:
+            q.backbone.fc_out.act_quantizer.scale.mul_(0.25)               # activation range +-0.5: states beyond it are clamped and masked
     x, dy = _signal(B, T, B + T)
     o = Oracle("f32")
-    m = make_model("lstm", H, bits_w=bits, bits_a=bits)
+    m = make_model(bb, H, bits_w=bits, bits_a=bits)
     p = np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in q.parameters()])
     assert o.param_count(m) == p.size
     step = 2.0 ** (2 - bits) * 8
@@ -113,13 +123,18 @@ def test_matches_the_oracle_on_ragged_sizes(H, B, T, bits):
     assert rel_err(xt.grad.cpu().numpy(), dxo) < tol
     gw = q.backbone.fc_out.weight.grad.cpu().numpy()
     clipped = np.abs(q.backbone.fc_out.weight.detach().cpu().numpy()) > 2.0
-    assert clipped.any() and np.all(gw[clipped] == 0.0)      # the weight quantiser's pass mask
+    assert (clipped.any() or vd) and np.all(gw[clipped] == 0.0)      # the weight quantiser's pass mask
+    if vd:
+        g1 = q.backbone.fc_lambda_1.weight.grad.cpu().numpy()
+        c1 = np.abs(q.backbone.fc_lambda_1.weight.detach().cpu().numpy()) > 2.0
+        assert c1.any() and np.all(g1[c1] == 0.0) and np.abs(g1[~c1]).max() > 0
 
 
+@pytest.mark.parametrize("bb", ["lstm", "vdlstm"])
 @pytest.mark.parametrize("H,bits,B,T", [(14, 8, 64, 50), (10, 16, 33, 20), (16, 8, 256, 200), (12, 8, 5, 66)])
-def test_one_launch_train_step_equals_the_split_chain(H, bits, B, T):
+def test_one_launch_train_step_equals_the_split_chain(bb, H, bits, B, T):
     from tests.test_quant_more_gpu import _fused_equals_split
-    _fused_equals_split("lstm", H, bits, B, T, True)
+    _fused_equals_split(bb, H, bits, B, T, True)
 
 
 def test_larger_batches_and_hidden_sizes_run_the_split_chain():
@@ -127,9 +142,9 @@ def test_larger_batches_and_hidden_sizes_run_the_split_chain():
     from opendpd_amd import _lib
     from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
     lib = _lib.load()
-    for H, B, T in ((24, 64, 50), (12, 5000, 20)):
+    for bb, H, B, T in (("lstm", 24, 64, 50), ("lstm", 12, 5000, 20), ("vdlstm", 20, 33, 40), ("vdlstm", 13, 3000, 20)):
         torch.manual_seed(1)
-        q = _fresh("lstm", H, 8).cuda()
+        q = _fresh(bb, H, 8).cuda()
         q.train()
         assert int(lib.odpd_partial_rows(C.byref(q.backbone.desc), B, T, 1)) < 0
         x, t = _signal(B, T, 3)
@@ -143,7 +158,7 @@ def test_larger_batches_and_hidden_sizes_run_the_split_chain():
         assert rel_err(opt.grad[:-4].cpu().numpy(), gref) < 2e-5
 
 
-def test_quantised_vdlstm_is_refused():
+def test_backbones_without_quantised_head_kernels_are_refused():
     from opendpd_amd import CoreModel
     from opendpd_amd.quant import get_quant_model
 
@@ -152,4 +167,4 @@ def test_quantised_vdlstm_is_refused():
         n_bits_w = n_bits_a = 8
         pretrained_model = ""
     with pytest.raises(NotImplementedError):
-        get_quant_model(P, CoreModel(2, 13, 1, "vdlstm"))
+        get_quant_model(P, CoreModel(2, 11, 1, "pgjanet"))
