@@ -26,9 +26,9 @@ def test_split_epoch_loop_equals_the_python_driven_steps(bb, H, kw, opt_kind):
     from opendpd_amd import _lib
     from opendpd_amd.project import DeviceFrameLoader
     from opendpd_amd.train_funcs import FusedAdamW, FusedSGD, fused_train_step
-    if bb in ("mcldnn", "deltagru", "deltagru_tcnskip", "deltajanet"):
+    if bb in ("mcldnn", "deltagru", "deltagru_tcnskip", "deltajanet") or bb.endswith(":qat"):
         # their one-frame-per-workgroup fused kernels would take these batches (native epoch loop: test_e2e_gpu.py, test_delta_family_gpu.py;
-        # the delta backbones since r04): keep the split chain of the other mappings under test here
+        # the delta backbones and the quantised cells since r04): keep the split chain of the other mappings under test here
         _lib.load().odpd_set_tuning(b"gp_max_batch", C.c_int64(0))
     try:
         _split_epoch_case(bb, H, kw, opt_kind)
