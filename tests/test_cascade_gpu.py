@@ -8,6 +8,12 @@ from tests.golden_util import Fixture, rel_err
 
 pytestmark = pytest.mark.gpu
 
+
+def _shapes_and_losses(shapes):
+    """Every shape with the L2 loss, the first two also with L1: the loss kind only changes the residual -> (loss term, dL/dy) map of the
+    frozen-PA wave, which does not depend on the pair of backbones — the full cross product doubled the suite for no extra coverage."""
+    return [(B, T, "l2") for B, T in shapes] + [(B, T, "l1") for B, T in shapes[:2]]
+
 CASES = [("cascade_gru11_gru11", "gru", "gru"), ("cascade_dgru13_dgru23", "dgru", "dgru"),
          ("cascade_tres15_dgru23", "deltagru_tcnskip", "dgru")]
 
@@ -154,8 +160,7 @@ def test_frozen_pa_single_launch_step_against_oracle(force_s16, pa_bb, pa_h, dpd
 
 @pytest.mark.parametrize("pa_bb,pa_h", [("gru", 11), ("gru", 16), ("dgru", 13), ("dgru", 5), ("qgru", 10), ("qgru_amp1", 16), ("gru", 23),
                                          ("dgru", 23), ("dgru", 17), ("qgru", 20), ("dgru", 32), ("gru", 32), ("qgru_amp1", 29)])
-@pytest.mark.parametrize("B,T", [(64, 200), (5, 1), (3, 65), (2, 50)])
-@pytest.mark.parametrize("loss", ["l2", "l1"])
+@pytest.mark.parametrize("B,T,loss", _shapes_and_losses([(64, 200), (5, 1), (3, 65), (2, 50)]))
 @pytest.mark.parametrize("force_gp", [False, True])
 def test_frozen_pa_at_reference_batches_against_oracle(pa_bb, pa_h, B, T, loss, force_gp):
     """odpd_frozen_loss_dx at the reference's own batch sizes (64 frames of 200 / 50 samples): the one-sequence-per-wave gate-parallel
@@ -207,8 +212,7 @@ def _frozen_call(lib, desc, pa, loss, B, T, rows, u, t, lo, du):
 @pytest.mark.parametrize("pa_bb,pa_h", [("gru", 11), ("dgru", 13), ("gru", 23), ("dgru", 23), ("dgru", 32), ("gru", 17), ("gru", 24), ("dgru", 24),
                                          ("dgru", 20), ("dgru", 25), ("gru", 16)])
 @pytest.mark.parametrize("dpd_bb,dpd_h", [("gru", 11), ("dgru", 13), ("qgru", 10), ("qgru_amp1", 16), ("dgru", 5)])
-@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50), (7, 128)])
-@pytest.mark.parametrize("loss", ["l2", "l1"])
+@pytest.mark.parametrize("B,T,loss", _shapes_and_losses([(64, 200), (3, 65), (5, 1), (2, 50), (7, 128)]))
 def test_one_launch_cascade_step_against_oracle(pa_bb, pa_h, dpd_bb, dpd_h, B, T, loss):
     """odpd_cascade_fwd_bwd (csrc/gru_cascade.hip): DPD wave and frozen-PA wave of every frame in one workgroup, 64-step hand-offs through
     LDS — frame lengths of one step, two chunks + 1, exact chunks, the reference's 50 and 200; PAs of <= 16 units, of 17..24 (second block held
@@ -360,8 +364,7 @@ def test_one_launch_cascade_envelope(B, T, one):
 @pytest.mark.parametrize("pa_bb,pa_h", [("dgru", 23), ("gru", 11), ("dgru", 13), ("gru", 23), ("dgru", 32)])
 @pytest.mark.parametrize("dpd_bb,dpd_h,thx,thh", [("deltagru_tcnskip", 15, 0.01, 0.05), ("deltagru", 15, 0.02, 0.03), ("deltagru_tcnskip", 9, 0.0, 0.0),
                                                    ("deltagru", 16, 0.0, 0.0), ("deltagru_tcnskip", 1, 0.01, 0.01)])
-@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50), (7, 128), (4, 33)])
-@pytest.mark.parametrize("loss", ["l2", "l1"])
+@pytest.mark.parametrize("B,T,loss", _shapes_and_losses([(64, 200), (3, 65), (5, 1), (2, 50), (7, 128), (4, 33)]))
 def test_one_launch_cascade_with_a_delta_dpd_against_oracle(pa_bb, pa_h, dpd_bb, dpd_h, thx, thh, B, T, loss):
     """BASELINE config 3's pair (TRes-DeltaGRU DPD -> frozen DGRU PA) and its relatives in the one-launch step (delta_cascade_kernel): the
     delta cell's forward chunks, the kept cell state, the recomputed forward steps of every backward chunk, the TCN skip and its gradient,
@@ -401,8 +404,7 @@ def test_one_launch_cascade_with_a_delta_dpd_against_oracle(pa_bb, pa_h, dpd_bb,
 
 @pytest.mark.parametrize("dpd_bb,dpd_h,pa_bb,pa_h", [("qgru", 20, "dgru", 8), ("qgru", 30, "dgru", 8), ("dgru", 23, "dgru", 13), ("gru", 32, "gru", 23),
                                                      ("qgru_amp1", 17, "gru", 32), ("dgru", 17, "gru", 24)])
-@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50)])
-@pytest.mark.parametrize("loss", ["l2", "l1"])
+@pytest.mark.parametrize("B,T,loss", _shapes_and_losses([(64, 200), (3, 65), (5, 1), (2, 50)]))
 def test_one_launch_cascade_with_a_two_block_dpd_against_oracle(dpd_bb, dpd_h, pa_bb, pa_h, B, T, loss):
     """DPDs of 17..32 units (two 16-unit blocks per gate row, weight gradients as one 4-block MFMA per block pair) in the one-launch step —
     e.g. the float stage of quant_qgru_dpd_regr.sh's qgru H20 / H30 in front of a dgru PA."""
@@ -446,8 +448,7 @@ def test_one_launch_cascade_lds_envelope_of_two_block_pairs():
 
 @pytest.mark.parametrize("pa_bb,pa_h", [("dgru", 8), ("gru", 11), ("dgru", 23), ("gru", 23), ("dgru", 32)])
 @pytest.mark.parametrize("dpd_h", [9, 14, 16, 1])
-@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50), (4, 33)])
-@pytest.mark.parametrize("loss", ["l2", "l1"])
+@pytest.mark.parametrize("B,T,loss", _shapes_and_losses([(64, 200), (3, 65), (5, 1), (2, 50), (4, 33)]))
 def test_one_launch_cascade_with_an_lstm_dpd_against_oracle(pa_bb, pa_h, dpd_h, B, T, loss):
     """train_all_dpd.sh's lstm DPD in front of its dgru PA (and relatives) in the one-launch step (lstm_cascade_kernel, LstmSeq): loss and DPD
     gradient == oracle composition."""
@@ -485,8 +486,7 @@ def test_one_launch_cascade_with_an_lstm_dpd_against_oracle(pa_bb, pa_h, dpd_h, 
 @pytest.mark.parametrize("pa_bb,pa_h", [("dgru", 23), ("gru", 11), ("dgru", 8)])
 @pytest.mark.parametrize("dpd_bb,dpd_h,bits", [("qgru", 10, 8), ("qgru_amp1", 16, 8), ("gru", 11, 8), ("qgru", 7, 16), ("qgru", 1, 8),
                                                 ("qgru", 20, 16), ("qgru", 30, 8), ("qgru_amp1", 17, 8), ("gru", 32, 8)])
-@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50), (4, 33)])
-@pytest.mark.parametrize("loss", ["l2", "l1"])
+@pytest.mark.parametrize("B,T,loss", _shapes_and_losses([(64, 200), (3, 65), (5, 1), (2, 50), (4, 33)]))
 def test_one_launch_cascade_with_a_quantised_dpd_against_oracle(pa_bb, pa_h, dpd_bb, dpd_h, bits, B, T, loss):
     """BASELINE config 5's pair (quantisation-aware QGRU W8A8 DPD -> frozen DGRU PA) and its relatives in the one-launch step
     (qat_cascade_kernel, QatSeq): loss and per-tensor DPD gradient == oracle composition (quantised DPD forward, PA forward, loss, PA backward
@@ -547,8 +547,7 @@ def test_one_launch_cascade_with_a_quantised_dpd_against_oracle(pa_bb, pa_h, dpd
 
 @pytest.mark.parametrize("pa_bb,pa_h", [("dgru", 23), ("gru", 11), ("dgru", 8)])
 @pytest.mark.parametrize("dpd_h,bits,thx,thh", [(15, 8, 0.01, 0.05), (15, 16, 0.01, 0.05), (9, 8, 0.0, 0.0), (16, 8, 0.02, 0.02), (1, 8, 0.01, 0.01)])
-@pytest.mark.parametrize("B,T", [(64, 200), (3, 65), (5, 1), (2, 50), (4, 33)])
-@pytest.mark.parametrize("loss", ["l2", "l1"])
+@pytest.mark.parametrize("B,T,loss", _shapes_and_losses([(64, 200), (3, 65), (5, 1), (2, 50), (4, 33)]))
 def test_one_launch_cascade_with_the_quantised_tres_deltagru_against_oracle(pa_bb, pa_h, dpd_h, bits, thx, thh, B, T, loss):
     """The OpenDPDv2 QAT stage's pair (quantised TRes-DeltaGRU DPD, W16A16 in the recipe, -> frozen DGRU PA) in the one-launch step
     (qat_delta_cascade_kernel, QatDeltaSeq): loss, per-tensor DPD gradient (quantiser scales: exact 0) and the four sparsity counters ==
