@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""First-steps trajectory anchors for BASELINE configs 3 and 5 (TEST INFRASTRUCTURE — build container only).
+"""First-steps trajectory anchors for BASELINE configs 2 .. 5 (TEST INFRASTRUCTURE — build container only).
 
 The epoch-level rows of those two runs (tests/golden/ref_runs_apa.json, ref_runs_qat.json) can only be matched to dB-level tolerances:
 over 919 steps a rounding-level difference eventually flips a delta-threshold decision / moves a value across a quantisation boundary.
@@ -9,7 +9,7 @@ The FIRST steps have no such freedom yet, so this script records the reference's
             --DPD_backbone deltagru_tcnskip --DPD_hidden_size 15 --thx 0.01 --thh 0.05 --batch_size 64              (config 3)
             --DPD_backbone qgru --DPD_hidden_size 10 --quant --n_bits_w 8 --n_bits_a 8 --batch_size 64              (config 5)
 
-by RUNNING the reference (CPU) with its own Project / dataloader / optimiser; the frozen PA is the state dict the reference trained for
+and of the train_pa runs of configs 2 (dgru H13, APA_200MHz, 256 x 200) and 4 (vdlstm H13, APA_200MHz_b) by RUNNING the reference (CPU) with its own Project / dataloader / optimiser; the frozen PA is the state dict the reference trained for
 the epoch anchors (tests/golden/ref_runs_apa_models.npz, written where train_dpd looks for it).  The only harness-side change is a
 `net_train` that is the reference's loop verbatim in behaviour (train_funcs.py:28-48) plus "remember every loss, stop after N steps".
 Output: tests/golden/ref_first_steps.json {config3: {losses: [...], cmd}, config5: {...}}.   Usage: python oracle/gen_run_anchor_first_steps.py"""
@@ -28,6 +28,11 @@ C = ["--dataset_name", "APA_200MHz", "--accelerator", "cpu", "--frame_length", "
      "--PA_backbone", "dgru", "--PA_hidden_size", "23", "--batch_size", "64"]
 RUNS = {"config3": ["--DPD_backbone", "deltagru_tcnskip", "--DPD_hidden_size", "15", "--thx", "0.01", "--thh", "0.05"],
         "config5": ["--DPD_backbone", "qgru", "--DPD_hidden_size", "10", "--quant", "--n_bits_w", "8", "--n_bits_a", "8"]}
+# train_pa runs (the commands of tests/golden/ref_runs_apa.json: BASELINE configs 2 and 4) — full argument lists, no PA checkpoint needed
+PA_RUNS = {"config2": ["--dataset_name", "APA_200MHz", "--PA_backbone", "dgru", "--PA_hidden_size", "13", "--accelerator", "cpu", "--frame_length", "200",
+                       "--batch_size", "256", "--seed", "0", "--n_epochs", "1"],
+           "config4": ["--dataset_name", "APA_200MHz_b", "--PA_backbone", "vdlstm", "--PA_hidden_size", "13", "--accelerator", "cpu", "--frame_length",
+                       "200", "--batch_size", "256", "--seed", "0", "--n_epochs", "1"]}
 RUNNER = """
 import json, sys
 sys.path.insert(0, %r)
@@ -63,9 +68,10 @@ def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device)
 
 
 project.net_train = net_train
-from steps import train_dpd
+import importlib
+step = importlib.import_module("steps." + sys.argv[sys.argv.index("--step") + 1])
 try:
-    train_dpd.main(project.Project())
+    step.main(project.Project())
 except _Done:
     pass
 """ % (REF, N_STEPS)
@@ -84,6 +90,12 @@ def main():
             open(os.path.join(tmp, "_runner.py"), "w").write(RUNNER)
             subprocess.check_call([sys.executable, "_runner.py", "--step", "train_dpd"] + C + args, cwd=tmp, env=env, stdout=subprocess.DEVNULL)
             out[key] = {"losses": json.load(open(os.path.join(tmp, "first_steps.json"))), "cmd": " ".join(["--step", "train_dpd"] + C + args)}
+            print(key, out[key]["losses"][:3], "...", out[key]["losses"][-1])
+    for key, args in PA_RUNS.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            open(os.path.join(tmp, "_runner.py"), "w").write(RUNNER)
+            subprocess.check_call([sys.executable, "_runner.py", "--step", "train_pa"] + args, cwd=tmp, env=env, stdout=subprocess.DEVNULL)
+            out[key] = {"losses": json.load(open(os.path.join(tmp, "first_steps.json"))), "cmd": " ".join(["--step", "train_pa"] + args)}
             print(key, out[key]["losses"][:3], "...", out[key]["losses"][-1])
     json.dump(out, open(os.path.join(OUT, "ref_first_steps.json"), "w"), indent=1)
 

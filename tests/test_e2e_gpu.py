@@ -649,11 +649,12 @@ def apa_workdir(tmp_path_factory):
         os.environ["OPENDPD_DATASETS"] = old_ds
 
 
-@pytest.mark.parametrize("key,ds,bb", [("dgru_apa200", "APA_200MHz", "dgru"), ("vdlstm_apa200b", "APA_200MHz_b", "vdlstm")])
-def test_baseline_config_2_and_4_epochs_match_reference_log(apa_workdir, key, ds, bb):
+@pytest.mark.parametrize("key,ds,bb,cfg", [("dgru_apa200", "APA_200MHz", "dgru", "config2"), ("vdlstm_apa200b", "APA_200MHz_b", "vdlstm", "config4")])
+def test_baseline_config_2_and_4_epochs_match_reference_log(apa_workdir, steps_seen, key, ds, bb, cfg):
     """BASELINE configs 2 and 4 on their own datasets: one epoch of train_pa (230 steps of 256 x 200 frames, last batch 157;
     fused single-launch train kernels + native epoch loop) against the row the REFERENCE logged for the same command
-    (tests/golden/ref_runs_apa.json, oracle/gen_run_anchors_apa.py)."""
+    (tests/golden/ref_runs_apa.json, oracle/gen_run_anchors_apa.py), and the reference's own per-step losses of the first 20 steps
+    (tests/golden/ref_first_steps.json): float models without thresholds or grids, so all 20 to rounding level."""
     import opendpd_amd as od
     ref = json.load(open(os.path.join(GOLDEN, "ref_runs_apa.json")))[key]
     res = od.train_pa(dataset_name=ds, PA_backbone=bb, PA_hidden_size=13, frame_length=200, batch_size=256, seed=0, n_epochs=1,
@@ -666,6 +667,7 @@ def test_baseline_config_2_and_4_epochs_match_reference_log(apa_workdir, key, ds
     assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 2e-3 * rh["TRAIN_LOSS"][0]
     for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_EVM", "TEST_ACLR_AVG"):
         assert abs(hist[col][0] - rh[col][0]) < 0.05, (col, hist[col][0], rh[col][0])   # dB
+    _check_first_steps(cfg, steps_seen["losses"], n_exact=20, rel_exact=2e-6, rel_all=2e-6)      # (measured: <= 3.6e-7 on every step)
 
 
 def test_baseline_config_3_epoch_on_apa_matches_reference_log(apa_workdir, steps_seen):
