@@ -162,6 +162,12 @@ int gru_family_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_lossdx(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);        // frozen PA: forward + loss + dL/dx in one launch
 int gru_family_lossdx_rows(const odpd_model_t* m, int B, int T);
 int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, int T);
+// gru_wide.hip: float gru / dgru / qgru / qgru_amp1 of 33 .. 64 hidden units (one sequence per wave, lane = unit; per-step records in `ckpt`)
+bool gru_wide_ok(const odpd_model_t* m);
+int64_t gru_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
+int gru_wide_rows(const odpd_model_t* m, int B);
+int gru_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // train_dpd at the reference's batch sizes as one launch (gru_cascade.hip): DPD wave + frozen-PA wave per frame
 struct CascArgs {
     const float* dpd_params;

@@ -330,9 +330,10 @@ def test_training_options_follow_their_reference_logs(workdir, name, kw):
     ("layers2", dict(PA_backbone="gru", PA_hidden_size=8, PA_num_layers=2, frame_length=50, batch_size=64, lr=2e-3)),
     ("hidden40", dict(PA_backbone="dgru", PA_hidden_size=40, frame_length=50, batch_size=64, lr=1e-3))])
 def test_framing_and_envelope_variants_follow_their_reference_logs(workdir, name, kw):
-    """strided frames (frame_stride 7: the native epoch loop addresses frame f at f * 7 of the resident stream) and two configurations
-    beyond the kernels' envelope (two GRU layers, hidden 40: ATen restatements of backbones/wide.py with torch's AdamW, announced by
-    a warning), two train_pa epochs each, against the REFERENCE's logged rows (ref_runs_variants.json)"""
+    """strided frames (frame_stride 7: the native epoch loop addresses frame f at f * 7 of the resident stream), two GRU layers (beyond the
+    kernels' envelope: ATen restatement of backbones/wide.py with torch's AdamW, announced by a warning) and dgru with 40 hidden units (since
+    r04 on csrc/gru_wide.hip: record-writing forward, loss, backward, fused optimiser), two train_pa epochs each, against the REFERENCE's
+    logged rows (ref_runs_variants.json)"""
     import warnings
     import opendpd_amd as od
     ref = json.load(open(os.path.join(GOLDEN, "ref_runs_variants.json")))[name]["hist"]
@@ -343,7 +344,10 @@ def test_framing_and_envelope_variants_follow_their_reference_logs(workdir, name
     assert list(hist.columns) == list(ref.keys())
     for col in ("N_PARAM", "BATCH_SIZE", "FRAME_LENGTH", "HIDDEN_SIZE"):
         assert list(hist[col]) == ref[col]
-    _rows_match(hist, ref, 2, 5e-5, 3e-3)       # measured: loss 5e-6 relative, metrics 1e-5 dB (hidden 40: 2.3e-4 dB)
+    if name == "hidden40":      # 720 steps on the lane-per-unit kernels (their own sigmoid / tanh evaluations): measured 1.2e-4 on VAL_LOSS of epoch 2
+        _rows_match(hist, ref, 2, 6e-4, 6e-3)
+    else:
+        _rows_match(hist, ref, 2, 5e-5, 3e-3)       # measured: loss 5e-6 relative, metrics 1e-5 dB
 
 
 @pytest.mark.parametrize("bb", ["rvtdcnn", "bojanet", "deltajanet", "dvrjanet", "neuraltx", "mcldnn"])
@@ -555,18 +559,18 @@ def test_registry_backbone_without_kernels_trains_through_the_api(tiny_workdir, 
 
 
 def test_configuration_outside_the_kernel_envelope_trains_through_the_api(workdir):
-    """hidden_size 40 / two layers are beyond the HIP kernels: CoreModel builds the ATen restatement (backbones/wide.py) with
+    """an lstm with 40 hidden units is beyond the HIP kernels: CoreModel builds the ATen restatement (backbones/wide.py) with
     a warning and the same Project flow runs — train_pa of a wide PA, then train_dpd of a kernel-backed DPD (HIP autograd
     bridge) through that ATen PA with torch.optim.AdamW."""
     import warnings
     import opendpd_amd as od
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        kw = dict(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=40, frame_length=50, batch_size=256, lr=2e-3, seed=0,
+        kw = dict(dataset_name="DPA_200MHz", PA_backbone="lstm", PA_hidden_size=40, frame_length=50, batch_size=256, lr=2e-3, seed=0,
                   accelerator="cuda")
         res = od.train_pa(n_epochs=2, **kw)
         assert any("outside the HIP kernels' envelope" in str(m.message) for m in w)
-    assert res["status"] == "completed" and "_M_GRU_H_40_" in os.path.basename(res["model_path"])
+    assert res["status"] == "completed" and "_M_LSTM_H_40_" in os.path.basename(res["model_path"])
     hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
     assert len(hist) == 2 and hist["TRAIN_LOSS"][1] < hist["TRAIN_LOSS"][0]
     with warnings.catch_warnings():

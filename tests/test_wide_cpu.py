@@ -12,13 +12,32 @@ CASES = ["wide_gru_h12_l2", "wide_dgru_h40", "wide_lstm_h10_l2", "wide_vdlstm_h3
          "wide_tres_h33", "wide_pgjanet_h18", "wide_tcnn_c66"]
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _aten_only():
+    """gru / dgru / qgru / qgru_amp1 of 33 .. 64 units are kernel-backed since r04 (csrc/gru_wide.hip; GPU tests: test_gru_wide_gpu.py, with these
+    same fixtures): here the registry is told to build their ATen restatements all the same — they still serve hidden > 64 and two layers, and
+    stay pinned to the reference's vectors."""
+    from opendpd_amd.backbones import wide as W
+    old = dict(W.KERNEL_HIDDEN_LIMIT)
+    W.KERNEL_HIDDEN_LIMIT.update(gru=32, dgru=32, qgru=32, qgru_amp1=32)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            yield
+    finally:
+        W.KERNEL_HIDDEN_LIMIT.clear()
+        W.KERNEL_HIDDEN_LIMIT.update(old)
+
+
 def _model(fx, seed=None):
     from opendpd_amd import CoreModel
     m = fx.meta
     if seed is not None:
         torch.manual_seed(seed)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
+    with _aten_only():
         net = CoreModel(2, m["hidden"], m["num_layers"], m["backbone"], thx=m["thx"], thh=m["thh"])
     assert net.backbone.native is False
     return net
@@ -77,8 +96,7 @@ def test_against_oracle(bb, H):
     from oracle.oracle import Oracle, make_model
     torch.manual_seed(H)
     kw = dict(thx=0.01, thh=0.02) if "delta" in bb else {}
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
+    with _aten_only():
         net = CoreModel(2, H, 1, bb, **kw)
     rng = np.random.RandomState(H)
     amp, ph = 0.05 + 0.85 * rng.rand(3, 19, 1), 2 * np.pi * rng.rand(3, 19, 1)
@@ -102,10 +120,13 @@ def test_against_oracle(bb, H):
 def test_inside_the_envelope_the_kernels_are_used_and_outside_a_warning_is_raised():
     from opendpd_amd import CoreModel
     assert CoreModel(2, 32, 1, "dgru").backbone.native is True
+    assert CoreModel(2, 64, 1, "dgru").backbone.native is True          # 33 .. 64 units: csrc/gru_wide.hip (r04)
     assert CoreModel(2, 16, 1, "pgjanet").backbone.native is True
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
-        net = CoreModel(2, 33, 1, "dgru")
+        net = CoreModel(2, 65, 1, "dgru")
     assert net.backbone.native is False
+    with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
+        assert CoreModel(2, 33, 1, "lstm").backbone.native is False
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
         assert CoreModel(2, 8, 2, "gru").backbone.native is False
 
@@ -115,7 +136,7 @@ def test_fused_optimiser_declines_wide_models():
     from opendpd_amd.train_funcs import FusedAdamW
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        wide = CoreModel(2, 40, 1, "gru")
+        wide = CoreModel(2, 40, 1, "lstm")
         with pytest.raises(TypeError):
             FusedAdamW(wide)
         casc = CascadedModel(dpd_model=CoreModel(2, 8, 1, "dgru"), pa_model=wide)
