@@ -132,6 +132,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_MCL) return mcldnn_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_QAT && qat_uses_s16(m, B)) return qat_s16_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_GRU && gru_wide_ok(m)) return gru_wide_ckpt_floats(m, B, T);      // 33 .. 64 units: the per-step records of gru_wide.hip
+    if (family_of(m) == FAM_LSTM && lstm_wide_ok(m)) return lstm_wide_ckpt_floats(m, B, T);    // ... of lstm_wide.hip
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
@@ -157,6 +158,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
         if (gru_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)gru_wide_rows(m, B);
         return gru_family_rows(m, B, fused ? 1 : 0, T);
     case FAM_LSTM:
+        if (lstm_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)lstm_wide_rows(m, B);
         if (fused) return lstm_train_uses_s16(m, B) ? (int64_t)lstm_s16_rows(m, B)
                                                     : lstm_train_uses_gp(m, B, T) ? (int64_t)lstm_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return lstm_family_rows(m, B);
@@ -216,7 +218,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     a.params = params; a.x = x; a.y = y; a.ckpt = ckpt; a.stats = stats;
     switch (family_of(m)) {
     case FAM_GRU: return gru_wide_ok(m) ? gru_wide_fwd((hipStream_t)stream, m, a) : gru_family_fwd((hipStream_t)stream, m, a);
-    case FAM_LSTM: return lstm_family_fwd((hipStream_t)stream, m, a);
+    case FAM_LSTM: return lstm_wide_ok(m) ? lstm_wide_fwd((hipStream_t)stream, m, a) : lstm_family_fwd((hipStream_t)stream, m, a);
     case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
     case FAM_JANET: return janet_family_fwd((hipStream_t)stream, m, a);
     case FAM_DVR: return dvrjanet_launch((hipStream_t)stream, m, a, 1);
@@ -244,6 +246,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return gru_family_bwd((hipStream_t)stream, m, a);
     case FAM_LSTM:
+        if (lstm_wide_ok(m)) return lstm_wide_bwd((hipStream_t)stream, m, a);
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return lstm_family_bwd((hipStream_t)stream, m, a);
     case FAM_DELTA:

@@ -168,6 +168,12 @@ int64_t gru_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
 int gru_wide_rows(const odpd_model_t* m, int B);
 int gru_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+// lstm_wide.hip: float lstm of 33 .. 64 hidden units (same mapping)
+bool lstm_wide_ok(const odpd_model_t* m);
+int64_t lstm_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
+int lstm_wide_rows(const odpd_model_t* m, int B);
+int lstm_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int lstm_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // train_dpd at the reference's batch sizes as one launch (gru_cascade.hip): DPD wave + frozen-PA wave per frame
 struct CascArgs {
     const float* dpd_params;

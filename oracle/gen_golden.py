@@ -233,9 +233,13 @@ def gen_backbones(only=None):
         save(name, d)
 
 
-def gen_wide():
+# single-layer models of 33 .. 64 units that moved onto kernels in r04 (csrc/gru_wide.hip, lstm_wide.hip; `wide_more`): same recipe as gen_wide
+WIDE_MORE = [("wide_gru_h48", "gru", 48, 1, 0, 0), ("wide_dgru_h64", "dgru", 64, 1, 0, 0), ("wide_lstm_h40", "lstm", 40, 1, 0, 0)]
+
+
+def gen_wide(cases=None):
     """Configurations beyond the HIP kernels' envelope (two layers / hidden > 32): pins backbones/wide.py to the reference."""
-    cases = [("wide_gru_h12_l2", "gru", 12, 2, 0, 0), ("wide_dgru_h40", "dgru", 40, 1, 0, 0), ("wide_lstm_h10_l2", "lstm", 10, 2, 0, 0),
+    cases = cases or [("wide_gru_h12_l2", "gru", 12, 2, 0, 0), ("wide_dgru_h40", "dgru", 40, 1, 0, 0), ("wide_lstm_h10_l2", "lstm", 10, 2, 0, 0),
              ("wide_vdlstm_h36", "vdlstm", 36, 1, 0, 0), ("wide_qgru_amp1_h34", "qgru_amp1", 34, 1, 0, 0),
              ("wide_deltagru_h34", "deltagru", 34, 1, 0.01, 0.05), ("wide_tres_h33", "deltagru_tcnskip", 33, 1, 0.01, 0.05),
              ("wide_pgjanet_h18", "pgjanet", 18, 1, 0, 0), ("wide_tcnn_c66", "tcnn", 66, 1, 0, 0)]
@@ -356,6 +360,8 @@ if __name__ == "__main__":
         gen_backbones(only[0] if only else None)
     if "wide" in which:
         gen_wide()
+    if "wide_more" in which:
+        gen_wide(WIDE_MORE)
     if "cascade" in which:
         gen_cascade()
     if "quant" in which:

@@ -1,5 +1,6 @@
-"""gru / dgru / qgru / qgru_amp1 with 33 .. 64 hidden units (`hidden_size` is a free argument of the reference's backbones: gru.py:4-48,
-dgru.py:9-74, qgru.py:9-71, qgru_amp1.py:9-76; arguments.py:49-60): csrc/gru_wide.hip — one sequence per wave, lane = hidden unit — against
+"""gru / dgru / qgru / qgru_amp1 / lstm with 33 .. 64 hidden units (`hidden_size` is a free argument of the reference's backbones: gru.py:4-48,
+dgru.py:9-74, qgru.py:9-71, qgru_amp1.py:9-76, lstm.py:4-48; arguments.py:49-60): csrc/gru_wide.hip, csrc/lstm_wide.hip — one sequence per wave,
+lane = hidden unit — against
 the oracle: forward (inference and record-writing), weight gradients and dL/dx together and each alone, batches beyond the grid (the
 workgroups loop over sequences), frames that are not a multiple of the 64-step chunk; a train step through the fused optimiser; the registry
 builds these sizes as HIP-backed modules (until r04: ATen restatements with a warning)."""
@@ -36,7 +37,8 @@ def _net(bb, H, seed):
     return net
 
 
-@pytest.mark.parametrize("bb,H", [("gru", 33), ("gru", 48), ("gru", 64), ("dgru", 40), ("dgru", 64), ("dgru", 33), ("qgru", 36), ("qgru_amp1", 50)])
+@pytest.mark.parametrize("bb,H", [("gru", 33), ("gru", 48), ("gru", 64), ("dgru", 40), ("dgru", 64), ("dgru", 33), ("qgru", 36), ("qgru_amp1", 50),
+                                  ("lstm", 33), ("lstm", 47), ("lstm", 64)])
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 64), (5, 70), (2, 200), (70, 33)])
 def test_against_oracle_ragged(bb, H, B, T):
     from oracle.oracle import Oracle, make_model
@@ -74,7 +76,7 @@ def test_against_oracle_ragged(bb, H, B, T):
     assert rel_err(xt2.grad.cpu().numpy(), dxo) < GRAD_TOL
 
 
-@pytest.mark.parametrize("bb,H", [("gru", 40), ("dgru", 48)])
+@pytest.mark.parametrize("bb,H", [("gru", 40), ("dgru", 48), ("lstm", 40)])
 def test_more_sequences_than_workgroups(bb, H):
     """B beyond 4 x CUs: every workgroup walks several sequences, its row of partial gradients accumulates over them"""
     from oracle.oracle import Oracle, make_model
@@ -93,7 +95,7 @@ def test_more_sequences_than_workgroups(bb, H):
     assert rel_err(y.detach().cpu().numpy(), yo) < FWD_TOL and rel_err(g, go) < GRAD_TOL and rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
 
 
-@pytest.mark.parametrize("bb,H", [("gru", 40), ("dgru", 64)])
+@pytest.mark.parametrize("bb,H", [("gru", 40), ("dgru", 64), ("lstm", 50)])
 def test_train_steps_follow_the_oracle(bb, H):
     """three clip + AdamW steps through the fused optimiser (forward with records, loss, backward, reduction, one-workgroup optimiser step)"""
     from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
@@ -149,7 +151,7 @@ def test_the_api_trains_a_wide_model_on_the_kernels(tmp_path):
             os.environ.pop("OPENDPD_DATASETS", None)
 
 
-@pytest.mark.parametrize("name", ["wide_dgru_h40", "wide_qgru_amp1_h34"])
+@pytest.mark.parametrize("name", ["wide_dgru_h40", "wide_qgru_amp1_h34", "wide_gru_h48", "wide_dgru_h64", "wide_lstm_h40"])
 def test_reference_fixtures_of_wide_models(name):
     """vectors produced by RUNNING the reference at these hidden sizes (oracle/gen_golden.py wide; until r04 they pinned the ATen restatements
     only): outputs, loss, every parameter's gradient, dL/dx and one clip + AdamW step on the kernels"""

@@ -9,7 +9,7 @@ import torch
 from tests.golden_util import Fixture, rel_err
 
 CASES = ["wide_gru_h12_l2", "wide_dgru_h40", "wide_lstm_h10_l2", "wide_vdlstm_h36", "wide_qgru_amp1_h34", "wide_deltagru_h34",
-         "wide_tres_h33", "wide_pgjanet_h18", "wide_tcnn_c66"]
+         "wide_tres_h33", "wide_pgjanet_h18", "wide_tcnn_c66", "wide_gru_h48", "wide_dgru_h64", "wide_lstm_h40"]
 
 
 import contextlib
@@ -17,12 +17,12 @@ import contextlib
 
 @contextlib.contextmanager
 def _aten_only():
-    """gru / dgru / qgru / qgru_amp1 of 33 .. 64 units are kernel-backed since r04 (csrc/gru_wide.hip; GPU tests: test_gru_wide_gpu.py, with these
+    """gru / dgru / qgru / qgru_amp1 / lstm of 33 .. 64 units are kernel-backed since r04 (csrc/gru_wide.hip, lstm_wide.hip; GPU tests: test_gru_wide_gpu.py, with these
     same fixtures): here the registry is told to build their ATen restatements all the same — they still serve hidden > 64 and two layers, and
     stay pinned to the reference's vectors."""
     from opendpd_amd.backbones import wide as W
     old = dict(W.KERNEL_HIDDEN_LIMIT)
-    W.KERNEL_HIDDEN_LIMIT.update(gru=32, dgru=32, qgru=32, qgru_amp1=32)
+    W.KERNEL_HIDDEN_LIMIT.update(gru=32, dgru=32, qgru=32, qgru_amp1=32, lstm=32)
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -126,7 +126,7 @@ def test_inside_the_envelope_the_kernels_are_used_and_outside_a_warning_is_raise
         net = CoreModel(2, 65, 1, "dgru")
     assert net.backbone.native is False
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
-        assert CoreModel(2, 33, 1, "lstm").backbone.native is False
+        assert CoreModel(2, 33, 1, "vdlstm").backbone.native is False
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
         assert CoreModel(2, 8, 2, "gru").backbone.native is False
 
@@ -136,7 +136,7 @@ def test_fused_optimiser_declines_wide_models():
     from opendpd_amd.train_funcs import FusedAdamW
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        wide = CoreModel(2, 40, 1, "lstm")
+        wide = CoreModel(2, 40, 1, "vdlstm")
         with pytest.raises(TypeError):
             FusedAdamW(wide)
         casc = CascadedModel(dpd_model=CoreModel(2, 8, 1, "dgru"), pa_model=wide)
