@@ -10,10 +10,10 @@ from . import build as _build
 BACKBONE_IDS = {"gru": 0, "dgru": 1, "qgru": 2, "qgru_amp1": 3, "lstm": 4, "vdlstm": 5, "deltagru": 6,
                 "deltagru_tcnskip": 7, "tcnn": 8, "pgjanet": 9, "gmp": 10, "rvtdcnn": 11, "neuraltx": 12, "deltajanet": 13, "dvrjanet": 14, "bojanet": 15, "apnrru": 16, "mcldnn": 17}
 LOSS_IDS = {"l2": 0, "l1": 1}
-FLAG_EVAL, FLAG_NEED_DX = 1, 2      # odpd_model_t.flags (include/opendpd_hip.h)
+FLAG_EVAL, FLAG_NEED_DX, FLAG_TWO_LAYERS = 1, 2, 4      # odpd_model_t.flags (include/opendpd_hip.h)
 LOSS_COLS = 4        # extra columns of a partials row (column P = loss partial sum)
 LOSS_WS = 1 + 256    # floats behind `loss_out` (result + per-block scratch)
-ABI_VERSION = 10     # odpd_abi_version() of the library these argument lists belong to
+ABI_VERSION = 11     # odpd_abi_version() of the library these argument lists belong to
 
 
 class ModelDesc(C.Structure):

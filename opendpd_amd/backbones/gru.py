@@ -8,7 +8,15 @@ The time recurrence, feature extraction and output heads run in opendpd_amd/csrc
 """
 import torch.nn as nn
 
+from .. import _lib
+
 from .native import NativeBackbone, RnnParams, init_gatewise, init_linear
+
+
+def _check_layers(num_layers, bidirectional, hidden_size):
+    """one layer, or two stacked layers of <= 32 units (csrc/gru_layers2.hip: both layers in one wave, time-skewed)"""
+    if bidirectional or num_layers not in (1, 2) or (num_layers == 2 and hidden_size > 32):
+        raise NotImplementedError("the HIP GRU kernels implement one layer, or two layers of <= 32 units, unidirectional")
 
 
 def _check_single_layer(num_layers, bidirectional):
@@ -23,13 +31,15 @@ class GRU(NativeBackbone):
     def __init__(self, input_size, hidden_size, output_size, num_layers, bidirectional=False, batch_first=True,
                  bias=True):
         super().__init__()
-        _check_single_layer(num_layers, bidirectional)
+        _check_layers(num_layers, bidirectional, hidden_size)
         if input_size != 2 or output_size != 2 or not bias:
             raise NotImplementedError("gru backbone: input/output are I/Q pairs with bias (models.py:12-24)")
-        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, input_size, output_size, 1
-        self.rnn = RnnParams(input_size, hidden_size, gates=3)
+        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, input_size, output_size, num_layers
+        self.rnn = RnnParams(input_size, hidden_size, gates=3, num_layers=num_layers)
         self.fc_out = nn.Linear(hidden_size, output_size, bias=True)
         self._finalize(hidden_size)
+        if num_layers == 2:
+            self.desc.flags |= _lib.FLAG_TWO_LAYERS
 
     def reset_parameters(self):
         init_gatewise(self.rnn, self.hidden_size)
@@ -60,11 +70,13 @@ class QGRU(NativeBackbone):
 
     def __init__(self, hidden_size, output_size, num_layers, bidirectional=False, batch_first=True, bias=True):
         super().__init__()
-        _check_single_layer(num_layers, bidirectional)
-        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, 4, output_size, 1
-        self.rnn = RnnParams(4, hidden_size, gates=3)
+        _check_layers(num_layers, bidirectional, hidden_size)
+        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, 4, output_size, num_layers
+        self.rnn = RnnParams(4, hidden_size, gates=3, num_layers=num_layers)
         self.fc_out = nn.Linear(hidden_size, output_size, bias=True)
         self._finalize(hidden_size)
+        if num_layers == 2:
+            self.desc.flags |= _lib.FLAG_TWO_LAYERS
 
     def reset_parameters(self):
         # qgru.py:37-57: rnn + fc_out are re-initialised, then the reference touches a non-existent

@@ -20,14 +20,19 @@ class RnnParams(nn.Module):
     (uniform(-1/sqrt(H), 1/sqrt(H)) over weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0 in that
     order), so that `reset_parameters()` afterwards sees the same generator state as the reference."""
 
-    def __init__(self, input_size, hidden_size, gates):
+    def __init__(self, input_size, hidden_size, gates, num_layers=1):
         super().__init__()
-        self.input_size, self.hidden_size, self.gates = input_size, hidden_size, gates
+        self.input_size, self.hidden_size, self.gates, self.num_layers = input_size, hidden_size, gates, num_layers
         G = gates * hidden_size
         self.weight_ih_l0 = nn.Parameter(torch.empty(G, input_size))
         self.weight_hh_l0 = nn.Parameter(torch.empty(G, hidden_size))
         self.bias_ih_l0 = nn.Parameter(torch.empty(G))
         self.bias_hh_l0 = nn.Parameter(torch.empty(G))
+        for layer in range(1, num_layers):      # torch.nn.RNNBase registers (and initialises) layer after layer; a layer's input is the one below's state
+            setattr(self, f"weight_ih_l{layer}", nn.Parameter(torch.empty(G, hidden_size)))
+            setattr(self, f"weight_hh_l{layer}", nn.Parameter(torch.empty(G, hidden_size)))
+            setattr(self, f"bias_ih_l{layer}", nn.Parameter(torch.empty(G)))
+            setattr(self, f"bias_hh_l{layer}", nn.Parameter(torch.empty(G)))
         stdv = 1.0 / math.sqrt(hidden_size) if hidden_size > 0 else 0
         for w in self.parameters():
             nn.init.uniform_(w, -stdv, stdv)

@@ -6,11 +6,14 @@
 using namespace odpd;
 
 namespace {
-enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP, FAM_RVTDCNN, FAM_DVR, FAM_BOJ, FAM_APN, FAM_MCL };
+enum Family { FAM_NONE = 0, FAM_GRU, FAM_LSTM, FAM_DELTA, FAM_JANET, FAM_TCNN, FAM_QAT, FAM_GMP, FAM_RVTDCNN, FAM_DVR, FAM_BOJ, FAM_APN, FAM_MCL, FAM_GRU2 };
 inline Family family_of(int bb);
 // a quantisation-aware model: bits_w > 0 on one of the backbones the reference's surgery turns into a quantised cell
 // (quant/quant_envs.py:114-130, 290-306: gru, dgru, qgru, qgru_amp1 through the GRU swap; deltagru_tcnskip through its op modules)
 inline Family family_of(const odpd_model_t* m) {
+    // two recurrent layers: a family of its own (gru_layers2.hip: forward / backward) — every entry point written for the one-layer kernels
+    // tests `family_of(m) == FAM_...` and so answers ODPD_EUNSUPPORTED for these descriptors instead of misreading their parameter buffer
+    if (m->flags & ODPD_FLAG_TWO_LAYERS) return FAM_GRU2;
     if (m->bits_w > 0 && (m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1 || m->backbone == ODPD_GRU || m->backbone == ODPD_DGRU ||
                           m->backbone == ODPD_TRES_DELTAGRU))
         return FAM_QAT;
@@ -94,11 +97,12 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 10; }   // 10: + odpd_xchg_* (one-shot gradient exchange over peer-mapped slots), odpd_clip_optim_step_dp, odpd_comm_kind / _errors; 9: + odpd_cascade_rows, odpd_cascade_fwd_bwd (train_dpd step body in one launch); 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
+extern "C" int odpd_abi_version(void) { return 11; }   // 11: + ODPD_FLAG_TWO_LAYERS (gru / qgru / qgru_amp1 with two recurrent layers), hidden 33 .. 64 for the GRU family and lstm, bits_w > 0 on lstm / vdlstm (INT_Linear heads); 10: + odpd_xchg_* (one-shot gradient exchange over peer-mapped slots), odpd_clip_optim_step_dp, odpd_comm_kind / _errors; 9: + odpd_cascade_rows, odpd_cascade_fwd_bwd (train_dpd step body in one launch); 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     if (!model_ok(m)) return ODPD_EINVAL;
+    if (family_of(m) == FAM_GRU2) return gru2_ok(m) ? gru2_param_count(m) : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_QAT) return qat_s16_param_count(m);
     const int64_t H = m->hidden, F = feat_dim(m->backbone);
     switch (m->backbone) {
@@ -131,6 +135,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_APN) return apnrru_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_MCL) return mcldnn_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_QAT && qat_uses_s16(m, B)) return qat_s16_ckpt_floats(m, B, T);
+    if (family_of(m) == FAM_GRU2) return gru2_ok(m) ? gru2_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_GRU && gru_wide_ok(m)) return gru_wide_ckpt_floats(m, B, T);      // 33 .. 64 units: the per-step records of gru_wide.hip
     if (family_of(m) == FAM_LSTM && lstm_wide_ok(m)) return lstm_wide_ckpt_floats(m, B, T);    // ... of lstm_wide.hip
     const int R = rows_per_seq(m->hidden);
@@ -154,6 +159,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
 extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fused) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     switch (family_of(m)) {
+    case FAM_GRU2: return (fused || !gru2_ok(m)) ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)gru2_rows(m, B);
     case FAM_GRU:
         if (gru_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)gru_wide_rows(m, B);
         return gru_family_rows(m, B, fused ? 1 : 0, T);
@@ -217,6 +223,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = x; a.y = y; a.ckpt = ckpt; a.stats = stats;
     switch (family_of(m)) {
+    case FAM_GRU2: return gru2_fwd((hipStream_t)stream, m, a);
     case FAM_GRU: return gru_wide_ok(m) ? gru_wide_fwd((hipStream_t)stream, m, a) : gru_family_fwd((hipStream_t)stream, m, a);
     case FAM_LSTM: return lstm_wide_ok(m) ? lstm_wide_fwd((hipStream_t)stream, m, a) : lstm_family_fwd((hipStream_t)stream, m, a);
     case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
@@ -241,6 +248,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = x; a.dy = dy; a.ckpt = const_cast<float*>(ckpt); a.partials = partials; a.dx = dx;
     switch (family_of(m)) {
+    case FAM_GRU2: return gru2_bwd((hipStream_t)stream, m, a);
     case FAM_GRU:
         if (gru_wide_ok(m)) return gru_wide_bwd((hipStream_t)stream, m, a);
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;

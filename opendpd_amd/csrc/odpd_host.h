@@ -168,6 +168,13 @@ int64_t gru_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
 int gru_wide_rows(const odpd_model_t* m, int B);
 int gru_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+// gru_layers2.hip: gru / qgru / qgru_amp1 with two recurrent layers (ODPD_FLAG_TWO_LAYERS), both layers in one wave, time-skewed
+bool gru2_ok(const odpd_model_t* m);
+int64_t gru2_param_count(const odpd_model_t* m);
+int64_t gru2_ckpt_floats(const odpd_model_t* m, int B, int T);
+int gru2_rows(const odpd_model_t* m, int B);
+int gru2_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru2_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // lstm_wide.hip: float lstm of 33 .. 64 hidden units (same mapping)
 bool lstm_wide_ok(const odpd_model_t* m);
 int64_t lstm_wide_ckpt_floats(const odpd_model_t* m, int B, int T);

@@ -21,8 +21,9 @@ def _aten_only():
     same fixtures): here the registry is told to build their ATen restatements all the same — they still serve hidden > 64 and two layers, and
     stay pinned to the reference's vectors."""
     from opendpd_amd.backbones import wide as W
-    old = dict(W.KERNEL_HIDDEN_LIMIT)
+    old, old2 = dict(W.KERNEL_HIDDEN_LIMIT), W.TWO_LAYER_KERNELS
     W.KERNEL_HIDDEN_LIMIT.update(gru=32, dgru=32, qgru=32, qgru_amp1=32, lstm=32)
+    W.TWO_LAYER_KERNELS = ()
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -30,6 +31,7 @@ def _aten_only():
     finally:
         W.KERNEL_HIDDEN_LIMIT.clear()
         W.KERNEL_HIDDEN_LIMIT.update(old)
+        W.TWO_LAYER_KERNELS = old2
 
 
 def _model(fx, seed=None):
@@ -127,8 +129,11 @@ def test_inside_the_envelope_the_kernels_are_used_and_outside_a_warning_is_raise
     assert net.backbone.native is False
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
         assert CoreModel(2, 33, 1, "vdlstm").backbone.native is False
+    assert CoreModel(2, 8, 2, "gru").backbone.native is True            # two layers of <= 32 units: csrc/gru_layers2.hip (r04)
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
-        assert CoreModel(2, 8, 2, "gru").backbone.native is False
+        assert CoreModel(2, 8, 2, "dgru").backbone.native is False
+    with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
+        assert CoreModel(2, 8, 3, "gru").backbone.native is False
 
 
 def test_fused_optimiser_declines_wide_models():
@@ -143,3 +148,19 @@ def test_fused_optimiser_declines_wide_models():
         casc.freeze_pa_model()
         with pytest.raises(TypeError):
             FusedAdamW(casc)
+
+
+def test_two_layer_kernel_module_has_the_reference_state_dict_and_init():
+    """gru with num_layers 2 as the kernel-backed module (csrc/gru_layers2.hip): same keys, shapes and — from the same seed — initial values as the
+    reference's constructor (nn.GRU initialises layer after layer; only weight_ih_l0 is re-drawn xavier: gru.py:27-43)"""
+    from opendpd_amd import CoreModel
+    fx = Fixture("wide_gru_h12_l2")
+    torch.manual_seed(0)
+    net = CoreModel(2, 12, 2, "gru")
+    assert net.backbone.native is True
+    sd = net.state_dict()
+    assert list(sd.keys()) == fx.keys("sd")
+    for k in fx.keys("sd"):
+        assert tuple(sd[k].shape) == fx["sd/" + k].shape, k
+        assert np.allclose(sd[k].numpy(), fx["sd/" + k], rtol=0, atol=2e-6), k
+    assert sum(p.numel() for p in net.parameters()) == fx.meta["n_param"] == net.backbone.n_flat
