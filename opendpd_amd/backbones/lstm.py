@@ -9,7 +9,8 @@ Kernels: opendpd_amd/csrc/lstm_family.hip.
 """
 import torch.nn as nn
 
-from .gru import _check_single_layer
+from .. import _lib
+from .gru import _check_layers, _check_single_layer
 from .native import NativeBackbone, RnnParams, init_gatewise, init_linear
 
 
@@ -19,13 +20,15 @@ class LSTM(NativeBackbone):
     def __init__(self, input_size, hidden_size, output_size, num_layers, bidirectional=False, batch_first=True,
                  bias=True):
         super().__init__()
-        _check_single_layer(num_layers, bidirectional)
+        _check_layers(num_layers, bidirectional, hidden_size)      # one layer, or two of <= 32 units (csrc/lstm_layers2.hip)
         if input_size != 2 or output_size != 2 or not bias:
             raise NotImplementedError("lstm backbone: input/output are I/Q pairs with bias (models.py:12-24)")
-        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, input_size, output_size, 1
-        self.rnn = RnnParams(input_size, hidden_size, gates=4)
+        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, input_size, output_size, num_layers
+        self.rnn = RnnParams(input_size, hidden_size, gates=4, num_layers=num_layers)
         self.fc_out = nn.Linear(hidden_size, output_size, bias=True)
         self._finalize(hidden_size)
+        if num_layers == 2:
+            self.desc.flags |= _lib.FLAG_TWO_LAYERS
 
     def reset_parameters(self):
         init_gatewise(self.rnn, self.hidden_size)

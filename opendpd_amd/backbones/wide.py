@@ -21,7 +21,7 @@ from .native import init_gatewise, init_linear
 # largest hidden size (tcnn: channel count) the HIP kernels of a registry name run, single layer
 KERNEL_HIDDEN_LIMIT = {"gru": 64, "dgru": 64, "qgru": 64, "qgru_amp1": 64, "lstm": 64, "vdlstm": 32, "deltagru": 32,
                        "deltagru_tcnskip": 32, "pgjanet": 16, "tcnn": 64, "rvtdcnn": 32, "neuraltx": 64, "deltajanet": 32}
-TWO_LAYER_KERNELS = ("gru", "qgru", "qgru_amp1")      # two stacked recurrent layers of <= 32 units run on kernels
+TWO_LAYER_KERNELS = ("gru", "qgru", "qgru_amp1", "lstm")      # two stacked recurrent layers of <= 32 units run on kernels
 _warned = set()
 
 
@@ -29,7 +29,7 @@ def outside_envelope(backbone_type, hidden_size, num_layers):
     lim = KERNEL_HIDDEN_LIMIT.get(backbone_type)
     if lim is None:
         return False
-    if num_layers == 2 and backbone_type in TWO_LAYER_KERNELS and hidden_size <= 32:      # csrc/gru_layers2.hip
+    if num_layers == 2 and backbone_type in TWO_LAYER_KERNELS and hidden_size <= 32:      # csrc/gru_layers2.hip, lstm_layers2.hip
         return False
     return hidden_size > lim or (num_layers != 1 and backbone_type not in ("pgjanet", "tcnn", "rvtdcnn", "neuraltx"))
 

@@ -102,7 +102,7 @@ extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     if (!model_ok(m)) return ODPD_EINVAL;
-    if (family_of(m) == FAM_GRU2) return gru2_ok(m) ? gru2_param_count(m) : (int64_t)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_GRU2) return gru2_ok(m) ? gru2_param_count(m) : lstm2_ok(m) ? lstm2_param_count(m) : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_QAT) return qat_s16_param_count(m);
     const int64_t H = m->hidden, F = feat_dim(m->backbone);
     switch (m->backbone) {
@@ -135,7 +135,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_APN) return apnrru_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_MCL) return mcldnn_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_QAT && qat_uses_s16(m, B)) return qat_s16_ckpt_floats(m, B, T);
-    if (family_of(m) == FAM_GRU2) return gru2_ok(m) ? gru2_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+    if (family_of(m) == FAM_GRU2) return gru2_ok(m) ? gru2_ckpt_floats(m, B, T) : lstm2_ok(m) ? lstm2_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_GRU && gru_wide_ok(m)) return gru_wide_ckpt_floats(m, B, T);      // 33 .. 64 units: the per-step records of gru_wide.hip
     if (family_of(m) == FAM_LSTM && lstm_wide_ok(m)) return lstm_wide_ckpt_floats(m, B, T);    // ... of lstm_wide.hip
     const int R = rows_per_seq(m->hidden);
@@ -159,7 +159,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
 extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fused) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
     switch (family_of(m)) {
-    case FAM_GRU2: return (fused || !gru2_ok(m)) ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)gru2_rows(m, B);
+    case FAM_GRU2: return fused ? (int64_t)ODPD_EUNSUPPORTED : gru2_ok(m) ? (int64_t)gru2_rows(m, B) : lstm2_ok(m) ? (int64_t)lstm2_rows(m, B) : (int64_t)ODPD_EUNSUPPORTED;
     case FAM_GRU:
         if (gru_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)gru_wide_rows(m, B);
         return gru_family_rows(m, B, fused ? 1 : 0, T);
@@ -223,7 +223,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = x; a.y = y; a.ckpt = ckpt; a.stats = stats;
     switch (family_of(m)) {
-    case FAM_GRU2: return gru2_fwd((hipStream_t)stream, m, a);
+    case FAM_GRU2: return lstm2_ok(m) ? lstm2_fwd((hipStream_t)stream, m, a) : gru2_fwd((hipStream_t)stream, m, a);
     case FAM_GRU: return gru_wide_ok(m) ? gru_wide_fwd((hipStream_t)stream, m, a) : gru_family_fwd((hipStream_t)stream, m, a);
     case FAM_LSTM: return lstm_wide_ok(m) ? lstm_wide_fwd((hipStream_t)stream, m, a) : lstm_family_fwd((hipStream_t)stream, m, a);
     case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
@@ -248,7 +248,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = x; a.dy = dy; a.ckpt = const_cast<float*>(ckpt); a.partials = partials; a.dx = dx;
     switch (family_of(m)) {
-    case FAM_GRU2: return gru2_bwd((hipStream_t)stream, m, a);
+    case FAM_GRU2: return lstm2_ok(m) ? lstm2_bwd((hipStream_t)stream, m, a) : gru2_bwd((hipStream_t)stream, m, a);
     case FAM_GRU:
         if (gru_wide_ok(m)) return gru_wide_bwd((hipStream_t)stream, m, a);
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;

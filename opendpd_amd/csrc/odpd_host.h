@@ -175,6 +175,13 @@ int64_t gru2_ckpt_floats(const odpd_model_t* m, int B, int T);
 int gru2_rows(const odpd_model_t* m, int B);
 int gru2_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru2_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+// lstm_layers2.hip: lstm with two recurrent layers (same arrangement)
+bool lstm2_ok(const odpd_model_t* m);
+int64_t lstm2_param_count(const odpd_model_t* m);
+int64_t lstm2_ckpt_floats(const odpd_model_t* m, int B, int T);
+int lstm2_rows(const odpd_model_t* m, int B);
+int lstm2_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int lstm2_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // lstm_wide.hip: float lstm of 33 .. 64 hidden units (same mapping)
 bool lstm_wide_ok(const odpd_model_t* m);
 int64_t lstm_wide_ckpt_floats(const odpd_model_t* m, int B, int T);

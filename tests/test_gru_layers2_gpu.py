@@ -1,6 +1,6 @@
-"""gru / qgru / qgru_amp1 with TWO recurrent layers (nn.GRU num_layers = 2: backbones/gru.py:17-21; `--PA_num_layers 2`), hidden <= 32, on
-csrc/gru_layers2.hip (both layers in one wave, time-skewed by one step): against the vectors the REFERENCE produced for a two-layer gru
-(tests/golden/wide_gru_h12_l2.npz) and, on ragged shapes, against the ATen restatement of the same module (backbones/wide.py: torch's own
+"""gru / qgru / qgru_amp1 / lstm with TWO recurrent layers (nn.GRU / nn.LSTM num_layers = 2: backbones/gru.py:17-21, lstm.py:17-21;
+`--PA_num_layers 2`), hidden <= 32, on csrc/gru_layers2.hip, lstm_layers2.hip (both layers in one wave, time-skewed by one step): against the
+vectors the REFERENCE produced for a two-layer gru and a two-layer lstm (tests/golden/wide_gru_h12_l2.npz, wide_lstm_h10_l2.npz) and, on ragged shapes, against the ATen restatement of the same module (backbones/wide.py: torch's own
 nn.GRU, pinned to the reference's vectors by tests/test_wide_cpu.py; the C oracle has no second layer)."""
 import contextlib
 import warnings
@@ -27,10 +27,11 @@ def _aten_only():
         W.TWO_LAYER_KERNELS = old
 
 
-def test_reference_fixture_of_a_two_layer_gru():
+@pytest.mark.parametrize("name", ["wide_gru_h12_l2", "wide_lstm_h10_l2"])
+def test_reference_fixture_of_a_two_layer_model(name):
     from opendpd_amd import CoreModel
     from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
-    fx = Fixture("wide_gru_h12_l2")
+    fx = Fixture(name)
     m = fx.meta
     assert m["num_layers"] == 2
     with warnings.catch_warnings():
@@ -55,7 +56,7 @@ def test_reference_fixture_of_a_two_layer_gru():
         assert rel_err(p.detach().cpu().numpy(), fx["p1/" + k]) < 3e-5, k
 
 
-@pytest.mark.parametrize("bb,H", [("gru", 8), ("gru", 17), ("gru", 32), ("qgru", 10), ("qgru_amp1", 23)])
+@pytest.mark.parametrize("bb,H", [("gru", 8), ("gru", 17), ("gru", 32), ("qgru", 10), ("qgru_amp1", 23), ("lstm", 9), ("lstm", 20), ("lstm", 32)])
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 63), (4, 64), (5, 70), (2, 200), (1100, 7)])
 def test_against_the_aten_restatement_on_ragged_shapes(bb, H, B, T):
     from opendpd_amd import CoreModel

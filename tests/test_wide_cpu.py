@@ -150,13 +150,14 @@ def test_fused_optimiser_declines_wide_models():
             FusedAdamW(casc)
 
 
-def test_two_layer_kernel_module_has_the_reference_state_dict_and_init():
-    """gru with num_layers 2 as the kernel-backed module (csrc/gru_layers2.hip): same keys, shapes and — from the same seed — initial values as the
-    reference's constructor (nn.GRU initialises layer after layer; only weight_ih_l0 is re-drawn xavier: gru.py:27-43)"""
+@pytest.mark.parametrize("name,bb,H", [("wide_gru_h12_l2", "gru", 12), ("wide_lstm_h10_l2", "lstm", 10)])
+def test_two_layer_kernel_module_has_the_reference_state_dict_and_init(name, bb, H):
+    """gru / lstm with num_layers 2 as the kernel-backed module (csrc/gru_layers2.hip, lstm_layers2.hip): same keys, shapes and — from the same seed —
+    initial values as the reference's constructor (nn.GRU / nn.LSTM initialise layer after layer; only weight_ih_l0 is re-drawn xavier: gru.py:27-43)"""
     from opendpd_amd import CoreModel
-    fx = Fixture("wide_gru_h12_l2")
+    fx = Fixture(name)
     torch.manual_seed(0)
-    net = CoreModel(2, 12, 2, "gru")
+    net = CoreModel(2, H, 2, bb)
     assert net.backbone.native is True
     sd = net.state_dict()
     assert list(sd.keys()) == fx.keys("sd")
