@@ -179,3 +179,43 @@ def test_reference_fixtures_of_wide_models(name):
     fused_train_step(opt, x.detach(), t, "l2", m["clip"])
     for k, p in net.named_parameters():
         assert rel_err(p.detach().cpu().numpy(), fx["p1/" + k]) < 3e-5, k
+
+
+def test_train_dpd_with_a_wide_dpd_in_front_of_a_two_layer_pa(tmp_path):
+    """both models of a cascade on the lane-per-unit kernels: train_pa of a two-layer gru, then train_dpd of a 40-unit dgru in front of it
+    (DPD forward with records, frozen-PA forward with records, loss, PA backward for dL/du only, DPD backward, fused optimiser), then run_dpd —
+    no ATen fallback anywhere (warnings are errors), losses finite and falling"""
+    import os
+    import pandas as pd
+    import opendpd_amd as od
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d = dict(np.load(os.path.join(golden, "dpa200_dataset.npz")))
+    ds = tmp_path / "datasets" / "DPA_200MHz"
+    ds.mkdir(parents=True)
+    (ds / "spec.json").write_text(str(d.pop("spec")))
+    for k, v in d.items():
+        pd.DataFrame(v, columns=["I", "Q"]).to_csv(ds / f"{k}.csv", index=False)
+    old, old_ds = os.getcwd(), os.environ.get("OPENDPD_DATASETS")
+    os.chdir(tmp_path)
+    os.environ["OPENDPD_DATASETS"] = str(tmp_path / "datasets")
+    try:
+        kw = dict(dataset_name="DPA_200MHz", PA_backbone="gru", PA_hidden_size=12, PA_num_layers=2, frame_length=50, batch_size=64, lr=2e-3, seed=0,
+                  accelerator="cuda")
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", UserWarning)
+            res = od.train_pa(n_epochs=2, **kw)
+            assert res["status"] == "completed"
+            hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
+            assert len(hist) == 2 and np.isfinite(hist["TRAIN_LOSS"]).all() and hist["TRAIN_LOSS"][1] < hist["TRAIN_LOSS"][0]
+            res = od.train_dpd(n_epochs=2, DPD_backbone="dgru", DPD_hidden_size=40, **kw)
+            assert res["status"] == "completed"
+            hist = pd.read_csv(os.path.join(os.path.dirname(os.path.dirname(res["log_path"])), "history", os.path.basename(res["log_path"])))
+            assert len(hist) == 2 and np.isfinite(hist["TRAIN_LOSS"]).all() and hist["TRAIN_LOSS"][1] < hist["TRAIN_LOSS"][0]
+            out = od.run_dpd(DPD_backbone="dgru", DPD_hidden_size=40, **kw)
+            assert out["status"] == "completed" and np.isfinite(pd.read_csv(out["output_path"]).to_numpy()).all()
+    finally:
+        os.chdir(old)
+        if old_ds is not None:
+            os.environ["OPENDPD_DATASETS"] = old_ds
+        else:
+            os.environ.pop("OPENDPD_DATASETS", None)
