@@ -79,10 +79,10 @@ typedef struct odpd_model {
 /* delta backbones: the caller will ask odpd_backbone_bwd for dL/dx (frozen PA of a cascade, x.requires_grad): selects the kernels
  * that provide it for forward, checkpoint sizing and backward alike; backward then also needs a `partials` buffer */
 #define ODPD_FLAG_NEED_DX 2
-/* two stacked recurrent layers (nn.GRU / nn.LSTM num_layers = 2: backbones/gru.py:17-21, lstm.py:17-21, `--PA_num_layers 2`): gru / qgru /
- * qgru_amp1 / lstm of <= 32 hidden units;
+/* two stacked recurrent layers (nn.GRU / nn.LSTM num_layers = 2: backbones/gru.py:17-21, lstm.py:17-21, `--PA_num_layers 2`): gru / dgru /
+ * qgru / qgru_amp1 / lstm of <= 32 hidden units;
  * `params` follows named_parameters() of the two-layer module (weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0, weight_ih_l1 (3H x H),
- * weight_hh_l1, bias_ih_l1, bias_hh_l1, fc_out.weight, fc_out.bias).  Forward / backward only (odpd_backbone_fwd / _bwd); every fused entry point
+ * weight_hh_l1, bias_ih_l1, bias_hh_l1, fc_out.weight, fc_out.bias[, dgru: fc_hid.weight, fc_hid.bias]).  Forward / backward only (odpd_backbone_fwd / _bwd); every fused entry point
  * answers ODPD_EUNSUPPORTED and the caller chains forward, loss, backward. */
 #define ODPD_FLAG_TWO_LAYERS 4
 

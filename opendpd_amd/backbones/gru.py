@@ -51,12 +51,14 @@ class DGRU(NativeBackbone):
 
     def __init__(self, hidden_size, output_size, num_layers, bidirectional=False, batch_first=True, bias=True):
         super().__init__()
-        _check_single_layer(num_layers, bidirectional)
-        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, 6, output_size, 1
-        self.rnn = RnnParams(6, hidden_size, gates=3)
+        _check_layers(num_layers, bidirectional, hidden_size)
+        self.hidden_size, self.input_size, self.output_size, self.num_layers = hidden_size, 6, output_size, num_layers
+        self.rnn = RnnParams(6, hidden_size, gates=3, num_layers=num_layers)
         self.fc_out = nn.Linear(hidden_size + 6, output_size, bias=True)
         self.fc_hid = nn.Linear(hidden_size, hidden_size, bias=True)
         self._finalize(hidden_size)
+        if num_layers == 2:
+            self.desc.flags |= _lib.FLAG_TWO_LAYERS
 
     def reset_parameters(self):
         init_gatewise(self.rnn, self.hidden_size)

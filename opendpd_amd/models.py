@@ -3,7 +3,7 @@
 `CoreModel(input_size, hidden_size, num_layers, backbone_type, window_size=None, num_dvr_units=None,
 thx=0, thh=0)` — same constructor, attributes, `forward(x, h_0=None)` contract and state-dict keys
 as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` as models.py:163-176.
-Backbones on the hot path run as HIP kernels (`backbone.native` is True) inside the kernels' envelope (one layer — gru / qgru /
+Backbones on the hot path run as HIP kernels (`backbone.native` is True) inside the kernels' envelope (one layer — gru / dgru / qgru /
 qgru_amp1 / lstm also two layers of <= 32 units, csrc/gru_layers2.hip, lstm_layers2.hip —, hidden
 <= 32 — gru / dgru / qgru / qgru_amp1 / lstm: <= 64, csrc/gru_wide.hip, lstm_wide.hip; pgjanet <= 16; tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32; dvrjanet <= 16 with <= 8 DVR units; bojanet <= 16; apnrru <= 14) and as ATen restatements (backbones/wide.py,
 `native` False, with a warning) beyond it — backbones/wide.py for the hot-path names, backbones/extras.py for the SURVEY §8 f4 ones;

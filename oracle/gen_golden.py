@@ -233,8 +233,9 @@ def gen_backbones(only=None):
         save(name, d)
 
 
-# single-layer models of 33 .. 64 units that moved onto kernels in r04 (csrc/gru_wide.hip, lstm_wide.hip; `wide_more`): same recipe as gen_wide
-WIDE_MORE = [("wide_gru_h48", "gru", 48, 1, 0, 0), ("wide_dgru_h64", "dgru", 64, 1, 0, 0), ("wide_lstm_h40", "lstm", 40, 1, 0, 0)]
+# models that moved onto kernels in r04 (csrc/gru_wide.hip, lstm_wide.hip: one layer of 33 .. 64 units; gru_layers2.hip: two layers; `wide_more`): same recipe as gen_wide
+WIDE_MORE = [("wide_gru_h48", "gru", 48, 1, 0, 0), ("wide_dgru_h64", "dgru", 64, 1, 0, 0), ("wide_lstm_h40", "lstm", 40, 1, 0, 0),
+             ("wide_dgru_h13_l2", "dgru", 13, 2, 0, 0)]
 
 
 def gen_wide(cases=None):

@@ -27,7 +27,7 @@ def _aten_only():
         W.TWO_LAYER_KERNELS = old
 
 
-@pytest.mark.parametrize("name", ["wide_gru_h12_l2", "wide_lstm_h10_l2"])
+@pytest.mark.parametrize("name", ["wide_gru_h12_l2", "wide_lstm_h10_l2", "wide_dgru_h13_l2"])
 def test_reference_fixture_of_a_two_layer_model(name):
     from opendpd_amd import CoreModel
     from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
@@ -56,7 +56,8 @@ def test_reference_fixture_of_a_two_layer_model(name):
         assert rel_err(p.detach().cpu().numpy(), fx["p1/" + k]) < 3e-5, k
 
 
-@pytest.mark.parametrize("bb,H", [("gru", 8), ("gru", 17), ("gru", 32), ("qgru", 10), ("qgru_amp1", 23), ("lstm", 9), ("lstm", 20), ("lstm", 32)])
+@pytest.mark.parametrize("bb,H", [("gru", 8), ("gru", 17), ("gru", 32), ("qgru", 10), ("qgru_amp1", 23), ("lstm", 9), ("lstm", 20), ("lstm", 32),
+                                  ("dgru", 7), ("dgru", 13), ("dgru", 24), ("dgru", 32)])
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 63), (4, 64), (5, 70), (2, 200), (1100, 7)])
 def test_against_the_aten_restatement_on_ragged_shapes(bb, H, B, T):
     from opendpd_amd import CoreModel
@@ -107,5 +108,5 @@ def test_entry_points_written_for_one_layer_refuse_the_descriptor():
     assert int(lib.odpd_partial_rows(C.byref(d), 64, 50, 1)) < 0            # no fused step
     assert int(lib.odpd_frozen_loss_rows(C.byref(d), 64, 50)) < 0
     assert int(lib.odpd_train_workspace_floats(C.byref(d), 64, 50)) < 0
-    d3 = _lib.ModelDesc(_lib.BACKBONE_IDS["dgru"], 8, 0.0, 0.0, 0, 0, _lib.FLAG_TWO_LAYERS)
-    assert int(lib.odpd_param_count(C.byref(d3))) < 0                       # dgru: one layer only
+    d3 = _lib.ModelDesc(_lib.BACKBONE_IDS["vdlstm"], 8, 0.0, 0.0, 0, 0, _lib.FLAG_TWO_LAYERS)
+    assert int(lib.odpd_param_count(C.byref(d3))) < 0                       # vdlstm: one layer only

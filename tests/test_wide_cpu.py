@@ -9,7 +9,7 @@ import torch
 from tests.golden_util import Fixture, rel_err
 
 CASES = ["wide_gru_h12_l2", "wide_dgru_h40", "wide_lstm_h10_l2", "wide_vdlstm_h36", "wide_qgru_amp1_h34", "wide_deltagru_h34",
-         "wide_tres_h33", "wide_pgjanet_h18", "wide_tcnn_c66", "wide_gru_h48", "wide_dgru_h64", "wide_lstm_h40"]
+         "wide_tres_h33", "wide_pgjanet_h18", "wide_tcnn_c66", "wide_gru_h48", "wide_dgru_h64", "wide_lstm_h40", "wide_dgru_h13_l2"]
 
 
 import contextlib
@@ -131,7 +131,7 @@ def test_inside_the_envelope_the_kernels_are_used_and_outside_a_warning_is_raise
         assert CoreModel(2, 33, 1, "vdlstm").backbone.native is False
     assert CoreModel(2, 8, 2, "gru").backbone.native is True            # two layers of <= 32 units: csrc/gru_layers2.hip (r04)
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
-        assert CoreModel(2, 8, 2, "dgru").backbone.native is False
+        assert CoreModel(2, 8, 2, "vdlstm").backbone.native is False
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
         assert CoreModel(2, 8, 3, "gru").backbone.native is False
 
@@ -150,7 +150,7 @@ def test_fused_optimiser_declines_wide_models():
             FusedAdamW(casc)
 
 
-@pytest.mark.parametrize("name,bb,H", [("wide_gru_h12_l2", "gru", 12), ("wide_lstm_h10_l2", "lstm", 10)])
+@pytest.mark.parametrize("name,bb,H", [("wide_gru_h12_l2", "gru", 12), ("wide_lstm_h10_l2", "lstm", 10), ("wide_dgru_h13_l2", "dgru", 13)])
 def test_two_layer_kernel_module_has_the_reference_state_dict_and_init(name, bb, H):
     """gru / lstm with num_layers 2 as the kernel-backed module (csrc/gru_layers2.hip, lstm_layers2.hip): same keys, shapes and — from the same seed —
     initial values as the reference's constructor (nn.GRU / nn.LSTM initialise layer after layer; only weight_ih_l0 is re-drawn xavier: gru.py:27-43)"""
