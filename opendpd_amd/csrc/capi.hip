@@ -138,6 +138,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_GRU2) return gru2_ok(m) ? gru2_ckpt_floats(m, B, T) : lstm2_ok(m) ? lstm2_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_GRU && gru_wide_ok(m)) return gru_wide_ckpt_floats(m, B, T);      // 33 .. 64 units: the per-step records of gru_wide.hip
     if (family_of(m) == FAM_LSTM && lstm_wide_ok(m)) return lstm_wide_ckpt_floats(m, B, T);    // ... of lstm_wide.hip
+    if (family_of(m) == FAM_LSTM && vdlstm_wide_ok(m)) return vdlstm_wide_ckpt_floats(m, B, T);
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
@@ -165,6 +166,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
         return gru_family_rows(m, B, fused ? 1 : 0, T);
     case FAM_LSTM:
         if (lstm_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)lstm_wide_rows(m, B);
+        if (vdlstm_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)vdlstm_wide_rows(m, B);
         if (fused) return lstm_train_uses_s16(m, B) ? (int64_t)lstm_s16_rows(m, B)
                                                     : lstm_train_uses_gp(m, B, T) ? (int64_t)lstm_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return lstm_family_rows(m, B);
@@ -225,7 +227,9 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     switch (family_of(m)) {
     case FAM_GRU2: return lstm2_ok(m) ? lstm2_fwd((hipStream_t)stream, m, a) : gru2_fwd((hipStream_t)stream, m, a);
     case FAM_GRU: return gru_wide_ok(m) ? gru_wide_fwd((hipStream_t)stream, m, a) : gru_family_fwd((hipStream_t)stream, m, a);
-    case FAM_LSTM: return lstm_wide_ok(m) ? lstm_wide_fwd((hipStream_t)stream, m, a) : lstm_family_fwd((hipStream_t)stream, m, a);
+    case FAM_LSTM:
+        if (vdlstm_wide_ok(m)) return vdlstm_wide_fwd((hipStream_t)stream, m, a);
+        return lstm_wide_ok(m) ? lstm_wide_fwd((hipStream_t)stream, m, a) : lstm_family_fwd((hipStream_t)stream, m, a);
     case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
     case FAM_JANET: return janet_family_fwd((hipStream_t)stream, m, a);
     case FAM_DVR: return dvrjanet_launch((hipStream_t)stream, m, a, 1);
@@ -255,6 +259,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
         return gru_family_bwd((hipStream_t)stream, m, a);
     case FAM_LSTM:
         if (lstm_wide_ok(m)) return lstm_wide_bwd((hipStream_t)stream, m, a);
+        if (vdlstm_wide_ok(m)) return vdlstm_wide_bwd((hipStream_t)stream, m, a);
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return lstm_family_bwd((hipStream_t)stream, m, a);
     case FAM_DELTA:

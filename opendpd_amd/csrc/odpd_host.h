@@ -188,6 +188,12 @@ int64_t lstm_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
 int lstm_wide_rows(const odpd_model_t* m, int B);
 int lstm_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int lstm_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+// vdlstm_wide.hip: float vdlstm of 33 .. 64 hidden units (same mapping; window inputs, lambda heads)
+bool vdlstm_wide_ok(const odpd_model_t* m);
+int64_t vdlstm_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
+int vdlstm_wide_rows(const odpd_model_t* m, int B);
+int vdlstm_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int vdlstm_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // train_dpd at the reference's batch sizes as one launch (gru_cascade.hip): DPD wave + frozen-PA wave per frame
 struct CascArgs {
     const float* dpd_params;

@@ -38,10 +38,12 @@ def _net(bb, H, seed):
 
 
 @pytest.mark.parametrize("bb,H", [("gru", 33), ("gru", 48), ("gru", 64), ("dgru", 40), ("dgru", 64), ("dgru", 33), ("qgru", 36), ("qgru_amp1", 50),
-                                  ("lstm", 33), ("lstm", 47), ("lstm", 64)])
+                                  ("lstm", 33), ("lstm", 47), ("lstm", 64), ("vdlstm", 33), ("vdlstm", 50), ("vdlstm", 64)])
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 64), (5, 70), (2, 200), (70, 33)])
 def test_against_oracle_ragged(bb, H, B, T):
     from oracle.oracle import Oracle, make_model
+    if bb == "vdlstm":
+        T = max(T, 3)      # the circular pad takes the frame's own last three samples (vdlstm.py:66-74)
     net = _net(bb, H, H * 1000 + B * 10 + T)
     x, dy = _data(B, T, B * 7 + T)
     o = Oracle("f32")
@@ -76,7 +78,7 @@ def test_against_oracle_ragged(bb, H, B, T):
     assert rel_err(xt2.grad.cpu().numpy(), dxo) < GRAD_TOL
 
 
-@pytest.mark.parametrize("bb,H", [("gru", 40), ("dgru", 48), ("lstm", 40)])
+@pytest.mark.parametrize("bb,H", [("gru", 40), ("dgru", 48), ("lstm", 40), ("vdlstm", 36)])
 def test_more_sequences_than_workgroups(bb, H):
     """B beyond 4 x CUs: every workgroup walks several sequences, its row of partial gradients accumulates over them"""
     from oracle.oracle import Oracle, make_model
@@ -95,7 +97,7 @@ def test_more_sequences_than_workgroups(bb, H):
     assert rel_err(y.detach().cpu().numpy(), yo) < FWD_TOL and rel_err(g, go) < GRAD_TOL and rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
 
 
-@pytest.mark.parametrize("bb,H", [("gru", 40), ("dgru", 64), ("lstm", 50)])
+@pytest.mark.parametrize("bb,H", [("gru", 40), ("dgru", 64), ("lstm", 50), ("vdlstm", 40)])
 def test_train_steps_follow_the_oracle(bb, H):
     """three clip + AdamW steps through the fused optimiser (forward with records, loss, backward, reduction, one-workgroup optimiser step)"""
     from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
@@ -151,7 +153,7 @@ def test_the_api_trains_a_wide_model_on_the_kernels(tmp_path):
             os.environ.pop("OPENDPD_DATASETS", None)
 
 
-@pytest.mark.parametrize("name", ["wide_dgru_h40", "wide_qgru_amp1_h34", "wide_gru_h48", "wide_dgru_h64", "wide_lstm_h40"])
+@pytest.mark.parametrize("name", ["wide_dgru_h40", "wide_qgru_amp1_h34", "wide_gru_h48", "wide_dgru_h64", "wide_lstm_h40", "wide_vdlstm_h36"])
 def test_reference_fixtures_of_wide_models(name):
     """vectors produced by RUNNING the reference at these hidden sizes (oracle/gen_golden.py wide; until r04 they pinned the ATen restatements
     only): outputs, loss, every parameter's gradient, dL/dx and one clip + AdamW step on the kernels"""
