@@ -139,6 +139,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_GRU && gru_wide_ok(m)) return gru_wide_ckpt_floats(m, B, T);      // 33 .. 64 units: the per-step records of gru_wide.hip
     if (family_of(m) == FAM_LSTM && lstm_wide_ok(m)) return lstm_wide_ckpt_floats(m, B, T);    // ... of lstm_wide.hip
     if (family_of(m) == FAM_LSTM && vdlstm_wide_ok(m)) return vdlstm_wide_ckpt_floats(m, B, T);
+    if (family_of(m) == FAM_DELTA && delta_wide_ok(m)) return delta_wide_ckpt_floats(m, B, T);
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
@@ -171,6 +172,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
                                                     : lstm_train_uses_gp(m, B, T) ? (int64_t)lstm_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return lstm_family_rows(m, B);
     case FAM_DELTA:
+        if (delta_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)delta_wide_rows(m, B);
         if (fused) return delta_train_uses_gp(m, B, T) ? (int64_t)delta_gp_train_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return delta_family_rows(m, B, T);
     case FAM_JANET:
@@ -230,7 +232,7 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_LSTM:
         if (vdlstm_wide_ok(m)) return vdlstm_wide_fwd((hipStream_t)stream, m, a);
         return lstm_wide_ok(m) ? lstm_wide_fwd((hipStream_t)stream, m, a) : lstm_family_fwd((hipStream_t)stream, m, a);
-    case FAM_DELTA: return delta_family_fwd((hipStream_t)stream, m, a);
+    case FAM_DELTA: return delta_wide_ok(m) ? delta_wide_fwd((hipStream_t)stream, m, a) : delta_family_fwd((hipStream_t)stream, m, a);
     case FAM_JANET: return janet_family_fwd((hipStream_t)stream, m, a);
     case FAM_DVR: return dvrjanet_launch((hipStream_t)stream, m, a, 1);
     case FAM_BOJ: return bojanet_launch((hipStream_t)stream, m, a, 1);
@@ -263,6 +265,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return lstm_family_bwd((hipStream_t)stream, m, a);
     case FAM_DELTA:
+        if (delta_wide_ok(m)) return delta_wide_bwd((hipStream_t)stream, m, a);
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return delta_family_bwd((hipStream_t)stream, m, a);
     case FAM_JANET:

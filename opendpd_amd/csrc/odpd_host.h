@@ -194,6 +194,12 @@ int64_t vdlstm_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
 int vdlstm_wide_rows(const odpd_model_t* m, int B);
 int vdlstm_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int vdlstm_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+// delta_wide.hip: float deltagru / deltagru_tcnskip of 33 .. 64 hidden units (same mapping around the delta cell)
+bool delta_wide_ok(const odpd_model_t* m);
+int64_t delta_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
+int delta_wide_rows(const odpd_model_t* m, int B);
+int delta_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int delta_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // train_dpd at the reference's batch sizes as one launch (gru_cascade.hip): DPD wave + frozen-PA wave per frame
 struct CascArgs {
     const float* dpd_params;

@@ -153,7 +153,8 @@ def test_the_api_trains_a_wide_model_on_the_kernels(tmp_path):
             os.environ.pop("OPENDPD_DATASETS", None)
 
 
-@pytest.mark.parametrize("name", ["wide_dgru_h40", "wide_qgru_amp1_h34", "wide_gru_h48", "wide_dgru_h64", "wide_lstm_h40", "wide_vdlstm_h36"])
+@pytest.mark.parametrize("name", ["wide_dgru_h40", "wide_qgru_amp1_h34", "wide_gru_h48", "wide_dgru_h64", "wide_lstm_h40", "wide_vdlstm_h36",
+                                  "wide_deltagru_h34", "wide_tres_h33"])
 def test_reference_fixtures_of_wide_models(name):
     """vectors produced by RUNNING the reference at these hidden sizes (oracle/gen_golden.py wide; until r04 they pinned the ATen restatements
     only): outputs, loss, every parameter's gradient, dL/dx and one clip + AdamW step on the kernels"""
@@ -163,14 +164,19 @@ def test_reference_fixtures_of_wide_models(name):
     fx = Fixture(name)
     m = fx.meta
     assert m["num_layers"] == 1
-    net = CoreModel(2, m["hidden"], 1, m["backbone"])
+    net = CoreModel(2, m["hidden"], 1, m["backbone"], thx=m["thx"], thh=m["thh"])
     assert net.backbone.native
     net.load_state_dict({k: torch.from_numpy(fx["sd/" + k]) for k in fx.keys("sd")})
     net = net.cuda()
     x = torch.from_numpy(fx["x"]).cuda().requires_grad_(True)
     t = torch.from_numpy(fx["tgt"]).cuda()
+    if hasattr(net.backbone, "set_debug"):
+        net.backbone.set_debug(1)
     y = net(x)
     assert rel_err(y.detach().cpu().numpy(), fx["y"]) < 2e-5
+    if "stats" in fx.d:      # the delta backbones' sparsity counters of this forward pass: exact
+        st = net.backbone.statistics
+        assert np.array_equal(np.array([st["num_dx_zeros"], st["num_dx_numel"], st["num_dh_zeros"], st["num_dh_numel"]]), fx["stats"])
     loss = torch.nn.functional.mse_loss(y, t)
     assert abs(loss.item() - fx["losses"][0]) < 1e-5 * max(1.0, fx["losses"][0])
     loss.backward()
@@ -221,3 +227,46 @@ def test_train_dpd_with_a_wide_dpd_in_front_of_a_two_layer_pa(tmp_path):
             os.environ["OPENDPD_DATASETS"] = old_ds
         else:
             os.environ.pop("OPENDPD_DATASETS", None)
+
+
+@pytest.mark.parametrize("bb,H", [("deltagru", 33), ("deltagru", 50), ("deltagru", 64), ("deltagru_tcnskip", 40), ("deltagru_tcnskip", 64)])
+@pytest.mark.parametrize("thx,thh", [(0.0, 0.0), (0.01, 0.05)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 64), (5, 70), (2, 200), (70, 33)])
+def test_delta_backbones_against_oracle(bb, H, thx, thh, B, T):
+    """deltagru / TRes-DeltaGRU of 33 .. 64 units (csrc/delta_wide.hip): outputs, exact sparsity counters, weight gradients and dL/dx"""
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 1000 + B * 10 + T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        net = CoreModel(2, H, 1, bb, thx=thx, thh=thh).cuda()
+    assert net.backbone.native
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    rng = np.random.RandomState(B * 7 + T)
+    amp = 0.05 + 0.85 * rng.rand(B, T, 1)
+    amp = 0.5 * amp + 0.5 * np.repeat(amp[:, ::4], 4, axis=1)[:, :T]      # slowly varying: kept and dropped deltas both occur
+    ph = 2 * np.pi * rng.rand(B, T, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    dy = rng.randn(B, T, 2).astype(np.float32)
+    o = Oracle("f32")
+    m = make_model(bb, H, thx, thh)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    st = np.zeros(4)
+    yo = o.forward(m, p, x, stats=st)
+    go, dxo = o.backward(m, p, x, dy)
+    net.backbone.set_debug(1)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = net(xt)
+    s = net.backbone.statistics
+    got = np.array([s["num_dx_zeros"], s["num_dx_numel"], s["num_dh_zeros"], s["num_dh_numel"]])
+    assert np.abs(got - st).max() <= (0 if thh == 0 else 2), (got, st)      # (a delta within rounding of its threshold may be taken differently)
+    y.backward(torch.from_numpy(dy).cuda())
+    g = np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()])
+    flips = np.abs(got - st).max()
+    tol_y, tol_g = (FWD_TOL, GRAD_TOL) if flips == 0 else (5e-2, 5e-1)
+    assert rel_err(y.detach().cpu().numpy(), yo) < tol_y
+    assert rel_err(g, go) < tol_g
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < tol_g
