@@ -208,11 +208,14 @@ def test_wide_hidden_against_oracle_ragged(bb, H, thx, thh, B, T):
     test_against_oracle_ragged(bb, H, thx, thh, B, T)
 
 
-def test_hidden_above_32_is_refused_loudly():
-    """the kernels themselves refuse a hidden size beyond their envelope (the registry routes such a configuration to the
-    ATen restatement instead, with a warning: tests/test_wide_cpu.py)"""
+def test_hidden_above_64_is_refused_loudly():
+    """the kernels themselves refuse a hidden size beyond their envelope — 64 units since r04 (csrc/delta_wide.hip) — (the registry routes
+    such a configuration to the ATen restatement instead, with a warning: tests/test_wide_cpu.py)"""
     from opendpd_amd import backbones as B
-    net = B.DeltaGRU(input_size=6, hidden_size=33, output_size=2, num_layers=1).cuda()
+    net = B.DeltaGRU(input_size=6, hidden_size=65, output_size=2, num_layers=1).cuda()
+    with pytest.raises(RuntimeError):
+        net(torch.rand(2, 16, 2, device="cuda"))
+    net = B.DeltaJANET(input_size=6, hidden_size=33, output_size=2, num_layers=1).cuda()
     with pytest.raises(RuntimeError):
         net(torch.rand(2, 16, 2, device="cuda"))
 
