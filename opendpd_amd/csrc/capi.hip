@@ -52,6 +52,9 @@ inline int feat_dim(int bb) {
     default: return 0;
     }
 }
+// models served by the lane-per-unit kernels (gru_wide.hip, lstm_wide.hip, vdlstm_wide.hip, delta_wide.hip: 33 .. 64 hidden units): forward / backward
+// only — the fused entry points answer ODPD_EUNSUPPORTED for them and the caller chains forward, loss, backward
+inline bool lane_per_unit_model(const odpd_model_t* m) { return gru_wide_ok(m) || lstm_wide_ok(m) || vdlstm_wide_ok(m) || delta_wide_ok(m); }
 inline bool model_ok(const odpd_model_t* m) {
     return m && m->backbone >= 0 && m->backbone < ODPD_BACKBONE_COUNT && m->hidden > 0;
 }
@@ -203,6 +206,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
 
 extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
+    if (lane_per_unit_model(m)) return ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_LSTM)
         return lstm_train_uses_s16(m, B) ? lstm_s16_workspace_floats(m, B, T) : lstm_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_JANET) return janet_train_uses_gp(m, B, T) ? 0 : (int64_t)ODPD_EUNSUPPORTED;
@@ -290,6 +294,7 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
                                   const float* params, const float* x, const float* target, float* partials,
                                   float* workspace) {
     if (!model_ok(m) || !params || !x || !target || !partials || B <= 0 || T <= 0 || count <= 0) return ODPD_EINVAL;
+    if (lane_per_unit_model(m)) return ODPD_EUNSUPPORTED;
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = x; a.target = target; a.partials = partials;
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.ckpt = workspace;
@@ -326,14 +331,14 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
 // ODPD_EUNSUPPORTED (rows < 0) and the caller chains odpd_backbone_fwd, odpd_loss_fwd_bwd, odpd_backbone_bwd.
 extern "C" int64_t odpd_frozen_loss_rows(const odpd_model_t* m, int B, int T) {
     if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
-    if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    if (family_of(m) != FAM_GRU || lane_per_unit_model(m)) return ODPD_EUNSUPPORTED;
     return gru_family_lossdx_rows(m, B, T);
 }
 extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss_kind, int B, int T, int64_t count,
                                    const float* params, const float* u, const float* target, float* du, float* loss_rows,
                                    float* workspace) {
     if (!model_ok(m) || !params || !u || !target || !du || !loss_rows || !workspace || B <= 0 || T <= 0 || count <= 0) return ODPD_EINVAL;
-    if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
+    if (family_of(m) != FAM_GRU || lane_per_unit_model(m)) return ODPD_EUNSUPPORTED;
     SeqArgs a = make_args(m, B, T);
     a.params = params; a.x = u; a.target = target; a.dx = du; a.partials = loss_rows;
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.ckpt = workspace;
@@ -371,10 +376,11 @@ extern "C" int odpd_cascade_fwd_bwd(void* stream, const odpd_model_t* dpd, const
 namespace {
 // backbones whose fused train kernel addresses frames inside resident streams (SeqArgs::frame_idx)
 inline bool framed_train_ok(const odpd_model_t* m) {
-    return family_of(m) == FAM_GRU || family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN;
+    return (!lane_per_unit_model(m) && family_of(m) == FAM_GRU) || family_of(m) == FAM_GMP || family_of(m) == FAM_RVTDCNN;
 }
 // ... for this batch shape: also the one-sequence-per-wave fused kernels of lstm / vdlstm / pgjanet (their large-batch kernels take tensors)
 inline bool framed_train_ok_shape(const odpd_model_t* m, int B, int T) {
+    if (lane_per_unit_model(m)) return false;
     if (framed_train_ok(m)) return true;
     if (family_of(m) == FAM_QAT) return qat_train_uses_gp(m, B, T) || qat_uses_s16(m, B);
     if (family_of(m) == FAM_LSTM) return !lstm_train_uses_s16(m, B) && lstm_train_uses_gp(m, B, T);

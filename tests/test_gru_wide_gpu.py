@@ -270,3 +270,22 @@ def test_delta_backbones_against_oracle(bb, H, thx, thh, B, T):
     assert rel_err(y.detach().cpu().numpy(), yo) < tol_y
     assert rel_err(g, go) < tol_g
     assert rel_err(xt.grad.cpu().numpy(), dxo) < tol_g
+
+
+def test_fused_entry_points_refuse_the_lane_per_unit_models():
+    """forward / backward only: every fused entry point says ODPD_EUNSUPPORTED for a model these kernels serve (never a misread parameter buffer)"""
+    import ctypes as C
+    from opendpd_amd import CoreModel, _lib
+    lib = _lib.load()
+    for bb, H in (("gru", 48), ("dgru", 40), ("lstm", 50), ("vdlstm", 36), ("deltagru", 40), ("deltagru_tcnskip", 64)):
+        net = CoreModel(2, H, 1, bb).cuda()
+        d = net.backbone.desc
+        assert int(lib.odpd_partial_rows(C.byref(d), 64, 50, 0)) == 64 and int(lib.odpd_partial_rows(C.byref(d), 64, 50, 1)) < 0
+        assert int(lib.odpd_train_workspace_floats(C.byref(d), 64, 50)) < 0
+        assert int(lib.odpd_frozen_loss_rows(C.byref(d), 64, 50)) < 0
+        assert int(lib.odpd_framed_train_supported_shape(C.byref(d), 64, 50)) == 0
+        x = torch.rand(4, 20, 2, device="cuda")
+        part = torch.empty(8, net.backbone.n_flat + _lib.LOSS_COLS, device="cuda")
+        rc = lib.odpd_train_fwd_bwd(_lib.stream_ptr(), C.byref(d), 0, 4, 20, 160, _lib.ptr(net.backbone.flat_params()), _lib.ptr(x), _lib.ptr(x),
+                                    _lib.ptr(part), None)
+        assert rc == _lib.EUNSUPPORTED if hasattr(_lib, "EUNSUPPORTED") else rc != 0
