@@ -59,8 +59,9 @@ enum odpd_error {
 /* Model descriptor: what `CoreModel.__init__` receives (models.py:11). */
 typedef struct odpd_model {
     int32_t backbone; /* enum odpd_backbone */
-    int32_t hidden;   /* hidden_size (channels for tcnn; memory_length for gmp): <= 32 (pgjanet: <= 16; tcnn: <= 64; gmp: 11; rvtdcnn: fc_hid_size),
-                         else ODPD_EUNSUPPORTED */
+    int32_t hidden;   /* hidden_size (channels for tcnn; memory_length for gmp): <= 32 — float gru / dgru / qgru / qgru_amp1 / lstm / vdlstm / deltagru /
+                         deltagru_tcnskip: <= 64 (33 .. 64: forward / backward only, the fused entry points answer ODPD_EUNSUPPORTED) — (pgjanet: <= 16;
+                         tcnn: <= 64; gmp: 11; rvtdcnn: fc_hid_size), else ODPD_EUNSUPPORTED */
     float thx;        /* delta threshold on inputs  (deltagru*, models.py:11) */
     float thh;        /* delta threshold on hidden state */
     int32_t bits_w;   /* QAT weight bits (0 = float model) — quant/quant_envs.py:145: > 0 on gru, dgru, qgru, qgru_amp1 or deltagru_tcnskip selects the
