@@ -153,7 +153,7 @@ def test_optimizer_choices_follow_the_reference():
     assert (sch.factor, sch.patience, sch.min_lr) == (0.1, 10, 1e-4)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        wide = CoreModel(2, 24, 1, "pgjanet")       # beyond the envelope: ATen restatement, torch's optimisers
+        wide = CoreModel(2, 40, 1, "pgjanet")       # beyond the envelope: ATen restatement, torch's optimisers
     opt, _ = Project.build_optimizer(mk("sgd"), wide)
     assert isinstance(opt, torch.optim.SGD) and opt.param_groups[0]["momentum"] == 0.9 and opt.param_groups[0]["lr"] == 2e-3
     assert isinstance(Project.build_optimizer(mk("adam"), wide)[0], torch.optim.Adam)

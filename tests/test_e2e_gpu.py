@@ -559,18 +559,18 @@ def test_registry_backbone_without_kernels_trains_through_the_api(tiny_workdir, 
 
 
 def test_configuration_outside_the_kernel_envelope_trains_through_the_api(workdir):
-    """a pgjanet with 24 hidden units is beyond the HIP kernels: CoreModel builds the ATen restatement (backbones/wide.py) with
+    """a pgjanet with 40 hidden units is beyond the HIP kernels: CoreModel builds the ATen restatement (backbones/wide.py) with
     a warning and the same Project flow runs — train_pa of a wide PA, then train_dpd of a kernel-backed DPD (HIP autograd
     bridge) through that ATen PA with torch.optim.AdamW."""
     import warnings
     import opendpd_amd as od
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        kw = dict(dataset_name="DPA_200MHz", PA_backbone="pgjanet", PA_hidden_size=24, frame_length=50, batch_size=256, lr=2e-3, seed=0,
+        kw = dict(dataset_name="DPA_200MHz", PA_backbone="pgjanet", PA_hidden_size=40, frame_length=50, batch_size=256, lr=2e-3, seed=0,
                   accelerator="cuda")
         res = od.train_pa(n_epochs=2, **kw)
         assert any("outside the HIP kernels' envelope" in str(m.message) for m in w)
-    assert res["status"] == "completed" and "_M_PGJANET_H_24_" in os.path.basename(res["model_path"])
+    assert res["status"] == "completed" and "_M_PGJANET_H_40_" in os.path.basename(res["model_path"])
     hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
     assert len(hist) == 2 and hist["TRAIN_LOSS"][1] < hist["TRAIN_LOSS"][0]
     with warnings.catch_warnings():

@@ -154,7 +154,7 @@ def test_the_api_trains_a_wide_model_on_the_kernels(tmp_path):
 
 
 @pytest.mark.parametrize("name", ["wide_dgru_h40", "wide_qgru_amp1_h34", "wide_gru_h48", "wide_dgru_h64", "wide_lstm_h40", "wide_vdlstm_h36",
-                                  "wide_deltagru_h34", "wide_tres_h33"])
+                                  "wide_deltagru_h34", "wide_tres_h33", "wide_pgjanet_h18"])
 def test_reference_fixtures_of_wide_models(name):
     """vectors produced by RUNNING the reference at these hidden sizes (oracle/gen_golden.py wide; until r04 they pinned the ATen restatements
     only): outputs, loss, every parameter's gradient, dL/dx and one clip + AdamW step on the kernels"""
@@ -289,3 +289,41 @@ def test_fused_entry_points_refuse_the_lane_per_unit_models():
         rc = lib.odpd_train_fwd_bwd(_lib.stream_ptr(), C.byref(d), 0, 4, 20, 160, _lib.ptr(net.backbone.flat_params()), _lib.ptr(x), _lib.ptr(x),
                                     _lib.ptr(part), None)
         assert rc == _lib.EUNSUPPORTED if hasattr(_lib, "EUNSUPPORTED") else rc != 0
+
+
+@pytest.mark.parametrize("H", [17, 18, 24, 31, 32])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 64), (5, 70), (2, 200), (70, 33), (1100, 6)])
+def test_pgjanet_17_to_32_units_against_oracle(H, B, T):
+    """pgjanet beyond one 16-unit tile (csrc/janet_wide.hip: lane = hidden unit, the wave's halves sharing a unit's gates): outputs, every parameter's
+    gradient and dL/dx against the oracle, together and each alone"""
+    from oracle.oracle import Oracle, make_model
+    net = _net("pgjanet", H, H * 1000 + B * 10 + T)
+    x, dy = _data(B, T, B * 7 + T)
+    o = Oracle("f32")
+    m = make_model("pgjanet", H)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    assert o.param_count(m) == p.size
+    yo, _ = o.forward(m, p, x)
+    go, dxo = o.backward(m, p, x, dy)
+    with torch.no_grad():
+        assert rel_err(net(torch.from_numpy(x).cuda()).cpu().numpy(), yo) < FWD_TOL
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = net(xt)
+    y.backward(torch.from_numpy(dy).cuda())
+    assert rel_err(y.detach().cpu().numpy(), yo) < FWD_TOL
+    off = 0
+    g = np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()])
+    for k, q in net.named_parameters():
+        n = q.numel()
+        assert rel_err(g[off:off + n], go[off:off + n]) < GRAD_TOL, k
+        off += n
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
+    for q in net.parameters():
+        q.grad = None
+    net(torch.from_numpy(x).cuda()).backward(torch.from_numpy(dy).cuda())
+    assert rel_err(np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()]), go) < GRAD_TOL
+    for q in net.parameters():
+        q.requires_grad_(False)
+    xt2 = torch.from_numpy(x).cuda().requires_grad_(True)
+    net(xt2).backward(torch.from_numpy(dy).cuda())
+    assert rel_err(xt2.grad.cpu().numpy(), dxo) < GRAD_TOL

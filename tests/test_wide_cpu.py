@@ -22,7 +22,7 @@ def _aten_only():
     stay pinned to the reference's vectors."""
     from opendpd_amd.backbones import wide as W
     old, old2 = dict(W.KERNEL_HIDDEN_LIMIT), W.TWO_LAYER_KERNELS
-    W.KERNEL_HIDDEN_LIMIT.update(gru=32, dgru=32, qgru=32, qgru_amp1=32, lstm=32, vdlstm=32, deltagru=32, deltagru_tcnskip=32)
+    W.KERNEL_HIDDEN_LIMIT.update(gru=32, dgru=32, qgru=32, qgru_amp1=32, lstm=32, vdlstm=32, deltagru=32, deltagru_tcnskip=32, pgjanet=16)
     W.TWO_LAYER_KERNELS = ()
     try:
         with warnings.catch_warnings():
@@ -124,11 +124,12 @@ def test_inside_the_envelope_the_kernels_are_used_and_outside_a_warning_is_raise
     assert CoreModel(2, 32, 1, "dgru").backbone.native is True
     assert CoreModel(2, 64, 1, "dgru").backbone.native is True          # 33 .. 64 units: csrc/gru_wide.hip (r04)
     assert CoreModel(2, 16, 1, "pgjanet").backbone.native is True
+    assert CoreModel(2, 32, 1, "pgjanet").backbone.native is True            # 17 .. 32 units: csrc/janet_wide.hip (r04)
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
         net = CoreModel(2, 65, 1, "dgru")
     assert net.backbone.native is False
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
-        assert CoreModel(2, 17, 1, "pgjanet").backbone.native is False
+        assert CoreModel(2, 33, 1, "pgjanet").backbone.native is False
     assert CoreModel(2, 8, 2, "gru").backbone.native is True            # two layers of <= 32 units: csrc/gru_layers2.hip (r04)
     with pytest.warns(UserWarning, match="outside the HIP kernels' envelope"):
         assert CoreModel(2, 8, 2, "vdlstm").backbone.native is False
@@ -141,7 +142,7 @@ def test_fused_optimiser_declines_wide_models():
     from opendpd_amd.train_funcs import FusedAdamW
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        wide = CoreModel(2, 24, 1, "pgjanet")
+        wide = CoreModel(2, 40, 1, "pgjanet")
         with pytest.raises(TypeError):
             FusedAdamW(wide)
         casc = CascadedModel(dpd_model=CoreModel(2, 8, 1, "dgru"), pa_model=wide)

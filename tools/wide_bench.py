@@ -25,7 +25,7 @@ def timeit(fn, n=10, w=2):
 
 
 print("| model | B x T | kernels: step ms | ATen restatement: step ms |\n|---|---|---|---|")
-for bb, H, NL in (("gru", 48, 1), ("dgru", 40, 1), ("dgru", 64, 1), ("qgru", 36, 1), ("lstm", 48, 1), ("vdlstm", 40, 1), ("deltagru", 40, 1), ("deltagru_tcnskip", 48, 1), ("gru", 8, 2), ("gru", 23, 2), ("qgru", 32, 2)):
+for bb, H, NL in (("gru", 48, 1), ("dgru", 40, 1), ("dgru", 64, 1), ("qgru", 36, 1), ("lstm", 48, 1), ("vdlstm", 40, 1), ("deltagru", 40, 1), ("deltagru_tcnskip", 48, 1), ("pgjanet", 24, 1), ("gru", 8, 2), ("gru", 23, 2), ("qgru", 32, 2)):
     for B, T in ((64, 50), (256, 200), (2048, 200)):
         g = torch.Generator(device="cuda").manual_seed(B)
         x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
@@ -38,7 +38,7 @@ for bb, H, NL in (("gru", 48, 1), ("dgru", 40, 1), ("dgru", 64, 1), ("qgru", 36,
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             old = dict(W.KERNEL_HIDDEN_LIMIT)
-            W.KERNEL_HIDDEN_LIMIT.update(gru=32, dgru=32, qgru=32, qgru_amp1=32, lstm=32, vdlstm=32, deltagru=32, deltagru_tcnskip=32)
+            W.KERNEL_HIDDEN_LIMIT.update(gru=32, dgru=32, qgru=32, qgru_amp1=32, lstm=32, vdlstm=32, deltagru=32, deltagru_tcnskip=32, pgjanet=16)
             old2, W.TWO_LAYER_KERNELS = W.TWO_LAYER_KERNELS, ()
             ref = CoreModel(2, H, NL, bb, **({"thx": 0.01, "thh": 0.05} if "delta" in bb else {})).cuda()
             W.KERNEL_HIDDEN_LIMIT.update(old)
