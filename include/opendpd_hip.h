@@ -60,7 +60,7 @@ enum odpd_error {
 typedef struct odpd_model {
     int32_t backbone; /* enum odpd_backbone */
     int32_t hidden;   /* hidden_size (channels for tcnn; memory_length for gmp): <= 32 — float gru / dgru / qgru / qgru_amp1 / lstm / vdlstm / deltagru /
-                         deltagru_tcnskip: <= 64 (33 .. 64: forward / backward only, the fused entry points answer ODPD_EUNSUPPORTED) — (pgjanet: <= 32, its 17 .. 32 likewise;
+                         deltagru_tcnskip / deltajanet: <= 64 (33 .. 64: forward / backward only, the fused entry points answer ODPD_EUNSUPPORTED) — (pgjanet: <= 32, its 17 .. 32 likewise;
                          tcnn: <= 64; gmp: 11; rvtdcnn: fc_hid_size), else ODPD_EUNSUPPORTED */
     float thx;        /* delta threshold on inputs  (deltagru*, models.py:11) */
     float thh;        /* delta threshold on hidden state */

@@ -20,7 +20,7 @@ from .native import init_gatewise, init_linear
 
 # largest hidden size (tcnn: channel count) the HIP kernels of a registry name run, single layer
 KERNEL_HIDDEN_LIMIT = {"gru": 64, "dgru": 64, "qgru": 64, "qgru_amp1": 64, "lstm": 64, "vdlstm": 64, "deltagru": 64,
-                       "deltagru_tcnskip": 64, "pgjanet": 32, "tcnn": 64, "rvtdcnn": 32, "neuraltx": 64, "deltajanet": 32}
+                       "deltagru_tcnskip": 64, "pgjanet": 32, "tcnn": 64, "rvtdcnn": 32, "neuraltx": 64, "deltajanet": 64}
 TWO_LAYER_KERNELS = ("gru", "dgru", "qgru", "qgru_amp1", "lstm")      # two stacked recurrent layers of <= 32 units run on kernels
 _warned = set()
 

@@ -55,7 +55,7 @@ inline int feat_dim(int bb) {
 // models served by the lane-per-unit kernels (gru_wide.hip, lstm_wide.hip, vdlstm_wide.hip, delta_wide.hip: 33 .. 64 hidden units; janet_wide.hip: pgjanet 17 .. 32): forward / backward
 // only — the fused entry points answer ODPD_EUNSUPPORTED for them and the caller chains forward, loss, backward
 inline bool lane_per_unit_model(const odpd_model_t* m) {
-    return gru_wide_ok(m) || lstm_wide_ok(m) || vdlstm_wide_ok(m) || delta_wide_ok(m) || pgjanet_wide_ok(m);
+    return gru_wide_ok(m) || lstm_wide_ok(m) || vdlstm_wide_ok(m) || delta_wide_ok(m) || pgjanet_wide_ok(m) || deltajanet_wide_ok(m);
 }
 inline bool model_ok(const odpd_model_t* m) {
     return m && m->backbone >= 0 && m->backbone < ODPD_BACKBONE_COUNT && m->hidden > 0;
@@ -145,6 +145,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_LSTM && lstm_wide_ok(m)) return lstm_wide_ckpt_floats(m, B, T);    // ... of lstm_wide.hip
     if (family_of(m) == FAM_LSTM && vdlstm_wide_ok(m)) return vdlstm_wide_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_DELTA && delta_wide_ok(m)) return delta_wide_ckpt_floats(m, B, T);
+    if (family_of(m) == FAM_DELTA && deltajanet_wide_ok(m)) return deltajanet_wide_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_JANET && pgjanet_wide_ok(m)) return pgjanet_wide_ckpt_floats(m, B, T);
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
@@ -179,6 +180,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
         return lstm_family_rows(m, B);
     case FAM_DELTA:
         if (delta_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)delta_wide_rows(m, B);
+        if (deltajanet_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)deltajanet_wide_rows(m, B);
         if (fused) return delta_train_uses_gp(m, B, T) ? (int64_t)delta_gp_train_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return delta_family_rows(m, B, T);
     case FAM_JANET:
@@ -240,7 +242,9 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_LSTM:
         if (vdlstm_wide_ok(m)) return vdlstm_wide_fwd((hipStream_t)stream, m, a);
         return lstm_wide_ok(m) ? lstm_wide_fwd((hipStream_t)stream, m, a) : lstm_family_fwd((hipStream_t)stream, m, a);
-    case FAM_DELTA: return delta_wide_ok(m) ? delta_wide_fwd((hipStream_t)stream, m, a) : delta_family_fwd((hipStream_t)stream, m, a);
+    case FAM_DELTA:
+        if (deltajanet_wide_ok(m)) return deltajanet_wide_fwd((hipStream_t)stream, m, a);
+        return delta_wide_ok(m) ? delta_wide_fwd((hipStream_t)stream, m, a) : delta_family_fwd((hipStream_t)stream, m, a);
     case FAM_JANET: return pgjanet_wide_ok(m) ? pgjanet_wide_fwd((hipStream_t)stream, m, a) : janet_family_fwd((hipStream_t)stream, m, a);
     case FAM_DVR: return dvrjanet_launch((hipStream_t)stream, m, a, 1);
     case FAM_BOJ: return bojanet_launch((hipStream_t)stream, m, a, 1);
@@ -274,6 +278,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
         return lstm_family_bwd((hipStream_t)stream, m, a);
     case FAM_DELTA:
         if (delta_wide_ok(m)) return delta_wide_bwd((hipStream_t)stream, m, a);
+        if (deltajanet_wide_ok(m)) return deltajanet_wide_bwd((hipStream_t)stream, m, a);
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return delta_family_bwd((hipStream_t)stream, m, a);
     case FAM_JANET:

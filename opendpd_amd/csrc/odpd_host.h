@@ -200,6 +200,12 @@ int64_t delta_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
 int delta_wide_rows(const odpd_model_t* m, int B);
 int delta_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int delta_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+// deltajanet_wide.hip: deltajanet of 33 .. 64 hidden units
+bool deltajanet_wide_ok(const odpd_model_t* m);
+int64_t deltajanet_wide_ckpt_floats(const odpd_model_t* m, int B, int T);
+int deltajanet_wide_rows(const odpd_model_t* m, int B);
+int deltajanet_wide_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int deltajanet_wide_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // janet_wide.hip: pgjanet of 17 .. 32 hidden units (lane = hidden unit, the wave's halves sharing a unit's gates)
 bool pgjanet_wide_ok(const odpd_model_t* m);
 int64_t pgjanet_wide_ckpt_floats(const odpd_model_t* m, int B, int T);

@@ -5,7 +5,7 @@ thx=0, thh=0)` — same constructor, attributes, `forward(x, h_0=None)` contract
 as models.py:10-160; `CascadedModel(dpd_model, pa_model)` + `freeze_pa_model()` as models.py:163-176.
 Backbones on the hot path run as HIP kernels (`backbone.native` is True) inside the kernels' envelope (one layer — gru / dgru / qgru /
 qgru_amp1 / lstm also two layers of <= 32 units, csrc/gru_layers2.hip, lstm_layers2.hip —, hidden
-<= 32 — gru / dgru / qgru / qgru_amp1 / lstm / vdlstm / deltagru / deltagru_tcnskip: <= 64, csrc/*_wide.hip; pgjanet <= 32 (janet_wide.hip); tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32; dvrjanet <= 16 with <= 8 DVR units; bojanet <= 16; apnrru <= 14) and as ATen restatements (backbones/wide.py,
+<= 32 — gru / dgru / qgru / qgru_amp1 / lstm / vdlstm / deltagru / deltagru_tcnskip / deltajanet: <= 64, csrc/*_wide.hip; pgjanet <= 32 (janet_wide.hip); tcnn, neuraltx <= 64 channels; gmp as the registry builds it; rvtdcnn fc_hid_size <= 32; dvrjanet <= 16 with <= 8 DVR units; bojanet <= 16; apnrru <= 14) and as ATen restatements (backbones/wide.py,
 `native` False, with a warning) beyond it — backbones/wide.py for the hot-path names, backbones/extras.py for the SURVEY §8 f4 ones;
 mcldnn: <= 16 channels.  All 18 registry names are HIP-backed inside their envelopes.  Unknown names raise ValueError (models.py:139-141).
 """

@@ -215,7 +215,7 @@ def test_hidden_above_64_is_refused_loudly():
     net = B.DeltaGRU(input_size=6, hidden_size=65, output_size=2, num_layers=1).cuda()
     with pytest.raises(RuntimeError):
         net(torch.rand(2, 16, 2, device="cuda"))
-    net = B.DeltaJANET(input_size=6, hidden_size=33, output_size=2, num_layers=1).cuda()
+    net = B.DeltaJANET(input_size=6, hidden_size=65, output_size=2, num_layers=1).cuda()
     with pytest.raises(RuntimeError):
         net(torch.rand(2, 16, 2, device="cuda"))
 

@@ -327,3 +327,42 @@ def test_pgjanet_17_to_32_units_against_oracle(H, B, T):
     xt2 = torch.from_numpy(x).cuda().requires_grad_(True)
     net(xt2).backward(torch.from_numpy(dy).cuda())
     assert rel_err(xt2.grad.cpu().numpy(), dxo) < GRAD_TOL
+
+
+@pytest.mark.parametrize("H", [33, 40, 64])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 5), (4, 64), (5, 70), (2, 200), (70, 33)])
+def test_deltajanet_33_to_64_units_against_oracle(H, B, T):
+    """deltajanet beyond two unit tiles (csrc/deltajanet_wide.hip): outputs, exact repeat counters, every parameter's gradient and dL/dx"""
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 1000 + B * 10 + T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        net = CoreModel(2, H, 1, "deltajanet").cuda()
+    assert net.backbone.native
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    x, dy = _data(B, T, B * 7 + T)
+    if T > 3:
+        x[:, 2] = x[:, 1]      # an exact repeat: its feature deltas are counted
+    o = Oracle("f32")
+    m = make_model("deltajanet", H)
+    p = np.concatenate([q.detach().cpu().numpy().reshape(-1) for q in net.parameters()])
+    st = np.zeros(4)
+    yo = o.forward(m, p, x, stats=st)
+    go, dxo = o.backward(m, p, x, dy)
+    net.backbone.set_debug(1)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    y = net(xt)
+    s = net.backbone.statistics
+    assert np.array_equal(np.array([s["num_dx_zeros"], s["num_dx_numel"], s["num_dh_zeros"], s["num_dh_numel"]]), st)
+    y.backward(torch.from_numpy(dy).cuda())
+    g = np.concatenate([q.grad.cpu().numpy().reshape(-1) for q in net.parameters()])
+    assert rel_err(y.detach().cpu().numpy(), yo) < FWD_TOL and rel_err(g, go) < GRAD_TOL and rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
+    for q in net.parameters():
+        q.requires_grad_(False)
+    xt2 = torch.from_numpy(x).cuda().requires_grad_(True)
+    net(xt2).backward(torch.from_numpy(dy).cuda())
+    assert rel_err(xt2.grad.cpu().numpy(), dxo) < GRAD_TOL

@@ -20,12 +20,13 @@ o = Oracle("f32")
 WIDE = len(sys.argv) > 2 and sys.argv[2] == "wide"      # `wide`: only the sizes the lane-per-unit kernels serve (33 .. 64 units: csrc/*_wide.hip)
 SIZES = {"gru": range(1, 65), "dgru": range(1, 65), "qgru": range(1, 65), "qgru_amp1": range(1, 65), "lstm": range(1, 65),
          "vdlstm": range(1, 65), "deltagru": range(1, 65), "deltagru_tcnskip": range(1, 65), "pgjanet": range(1, 33),
-         "tcnn": list(range(1, 40)) + [48, 63, 64], "gmp": [11] * 12, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
+         "tcnn": list(range(1, 40)) + [48, 63, 64], "gmp": [11] * 12, "rvtdcnn": range(1, 33), "deltajanet": range(1, 65),
          "neuraltx": list(range(1, 40)) + [48, 63, 64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15), "mcldnn": range(1, 17)}
 rng = np.random.RandomState(0)
 bad, kinks, illcond, worst = [], [], [], {}
 if WIDE:
-    SIZES = {k: range(33, 65) for k in ("gru", "dgru", "qgru", "qgru_amp1", "lstm", "vdlstm", "deltagru", "deltagru_tcnskip")}
+    SIZES = {k: range(33, 65) for k in ("gru", "dgru", "qgru", "qgru_amp1", "lstm", "vdlstm", "deltagru", "deltagru_tcnskip", "deltajanet")}
+    SIZES["pgjanet"] = range(17, 33)
 for bb, sizes in SIZES.items():
     for H in sizes:
         for case in range(n_per):
