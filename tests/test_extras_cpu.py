@@ -102,8 +102,9 @@ def test_deltajanet_is_native_and_constructs_like_the_reference():
     assert after == fx.meta["rng_after_init"]
     assert net.backbone.native is True and sum(p.numel() for p in net.parameters()) == fx.meta["n_param"] == 2 * 100 + 18 * 10 + 2
     assert (net.backbone.thx, net.backbone.thh) == (0.01, 0.05) and (net.backbone.desc.thx, net.backbone.desc.thh) == (0.0, 0.0)
+    assert _build("deltajanet", 40).backbone.native is True          # 33 .. 64 units: csrc/deltajanet_wide.hip (r04)
     with pytest.warns(UserWarning, match="outside"):
-        wide = _build("deltajanet", 40)
+        wide = _build("deltajanet", 70)
     assert wide.backbone.native is False
     from opendpd_amd.backbones.extras import DeltaJANET
     ref = DeltaJANET(input_size=6, hidden_size=10, output_size=2, num_layers=1, thx=0.01, thh=0.05)
