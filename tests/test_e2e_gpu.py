@@ -328,23 +328,38 @@ def test_training_options_follow_their_reference_logs(workdir, name, kw):
 @pytest.mark.parametrize("name,kw", [
     ("stride7", dict(PA_backbone="dgru", PA_hidden_size=8, frame_length=37, frame_stride=7, batch_size=100, lr=2e-3)),
     ("layers2", dict(PA_backbone="gru", PA_hidden_size=8, PA_num_layers=2, frame_length=50, batch_size=64, lr=2e-3)),
-    ("hidden40", dict(PA_backbone="dgru", PA_hidden_size=40, frame_length=50, batch_size=64, lr=1e-3))])
+    ("hidden40", dict(PA_backbone="dgru", PA_hidden_size=40, frame_length=50, batch_size=64, lr=1e-3)),
+    ("lstm_layers2", dict(PA_backbone="lstm", PA_hidden_size=10, PA_num_layers=2, frame_length=50, batch_size=64, lr=2e-3)),
+    ("dgru_layers2", dict(PA_backbone="dgru", PA_hidden_size=9, PA_num_layers=2, frame_length=50, batch_size=64, lr=2e-3)),
+    ("gru_h48", dict(PA_backbone="gru", PA_hidden_size=48, frame_length=50, batch_size=64, lr=1e-3)),
+    ("lstm_h48", dict(PA_backbone="lstm", PA_hidden_size=48, frame_length=50, batch_size=64, lr=1e-3)),
+    ("vdlstm_h40", dict(PA_backbone="vdlstm", PA_hidden_size=40, frame_length=50, batch_size=64, lr=1e-3)),
+    ("deltagru_h40", dict(PA_backbone="deltagru", PA_hidden_size=40, thx=0.01, thh=0.05, frame_length=50, batch_size=64, lr=1e-3))])
 def test_framing_and_envelope_variants_follow_their_reference_logs(workdir, name, kw):
-    """strided frames (frame_stride 7: the native epoch loop addresses frame f at f * 7 of the resident stream), two GRU layers (beyond the
-    kernels' envelope: ATen restatement of backbones/wide.py with torch's AdamW, announced by a warning) and dgru with 40 hidden units (since
-    r04 on csrc/gru_wide.hip: record-writing forward, loss, backward, fused optimiser), two train_pa epochs each, against the REFERENCE's
-    logged rows (ref_runs_variants.json)"""
+    """strided frames (frame_stride 7: the native epoch loop addresses frame f at f * 7 of the resident stream) and the configurations that
+    left the ATen restatements in r04 — two layers (gru, lstm, dgru: csrc/*_layers2.hip) and 33 .. 64 hidden units (dgru 40, gru 48, lstm 48,
+    vdlstm 40, deltagru 40 with thresholds: csrc/*_wide.hip; record-writing forward, loss, backward, fused optimiser) —, two train_pa epochs
+    each, against the REFERENCE's logged rows (ref_runs_variants.json)"""
     import warnings
     import opendpd_amd as od
     ref = json.load(open(os.path.join(GOLDEN, "ref_runs_variants.json")))[name]["hist"]
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
         res = od.train_pa(dataset_name="DPA_200MHz", n_epochs=2, seed=0, accelerator="cuda", **kw)
     hist = pd.read_csv(os.path.join("log", "DPA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
     assert list(hist.columns) == list(ref.keys())
     for col in ("N_PARAM", "BATCH_SIZE", "FRAME_LENGTH", "HIDDEN_SIZE"):
         assert list(hist[col]) == ref[col]
-    if name == "hidden40":      # 720 steps on the lane-per-unit kernels (their own sigmoid / tanh evaluations): measured 1.2e-4 on VAL_LOSS of epoch 2
+    if name == "layers2":       # since r04 on csrc/gru_layers2.hip: no warning any more
+        assert not any("outside the HIP kernels' envelope" in str(m.message) for m in caught)
+    if name == "deltagru_h40":      # thresholded: 720 steps of rounding-level differences flip a few delta decisions (as config 3)
+        print("[deltagru_h40] rows:", hist[["TRAIN_LOSS", "VAL_NMSE", "TEST_ACLR_AVG"]].to_numpy().tolist())
+        for ep in range(2):
+            assert abs(hist["TRAIN_LOSS"][ep] - ref["TRAIN_LOSS"][ep]) < 2e-3 * ref["TRAIN_LOSS"][ep]      # (measured: equal to the logged 7 digits)
+            for col in ("VAL_NMSE", "TEST_NMSE", "VAL_ACLR_AVG", "TEST_ACLR_AVG"):
+                assert abs(hist[col][ep] - ref[col][ep]) < 0.05, (col, ep, hist[col][ep], ref[col][ep])
+    elif name in ("hidden40", "lstm_layers2", "dgru_layers2", "gru_h48", "lstm_h48", "vdlstm_h40"):
+        # 720 steps on the lane-per-unit / two-layer kernels (their own sigmoid / tanh evaluations): measured 1.2e-4 on VAL_LOSS of epoch 2 (hidden40)
         _rows_match(hist, ref, 2, 6e-4, 6e-3)
     else:
         _rows_match(hist, ref, 2, 5e-5, 3e-3)       # measured: loss 5e-6 relative, metrics 1e-5 dB
