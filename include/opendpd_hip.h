@@ -69,6 +69,8 @@ typedef struct odpd_model {
                          INT_Linear heads; `params` then follows THAT model's named_parameters(), quantiser scales included);
                          > 0 on lstm / vdlstm: the surgery finds only their nn.Linear heads to swap (quant_envs.py:40-60) — float nn.LSTM core,
                          fc_out (vdlstm: fc_lambda_1, fc_lambda_2, fc_out) as INT_Linear, three scale parameters behind each head's weight and bias;
+                         > 0 on deltajanet (hidden <= 64): likewise — the cell's gates are nn.Parameter tensors (deltajanet.py:100-113), fc_out becomes
+                         INT_Linear, three scales behind fc_out.bias;
                          dvrjanet: num_dvr_units (models.py:119) */
     int32_t bits_a;   /* QAT activation bits */
     int32_t flags;    /* ODPD_FLAG_* */

@@ -118,7 +118,7 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_VDLSTM: return 4 * H * 4 + 4 * H * H + 8 * H + 2 * (4 * H + 4) + 2 * 8 + 2 + (m->bits_w > 0 ? 9 : 0);
     case ODPD_DELTAGRU: return 3 * H * 6 + 3 * H * H + 6 * H + 2 * H + 2;
     case ODPD_TRES_DELTAGRU: return 3 * H * 6 + 3 * H * H + 2 * H + 18 + 6;
-    case ODPD_DELTAJANET: return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2;      // two gates (deltajanet.py:96-111) + fc_out
+    case ODPD_DELTAJANET: return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2 + (m->bits_w > 0 ? 3 : 0);      // two gates (deltajanet.py:96-111) + fc_out (bits_w > 0: INT_Linear, + three scales)
     case ODPD_TCNN: return 6 * H + H + 4 * 5 * H + 2 * H;
     case ODPD_PGJANET: return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
     case ODPD_NEURALTX: return H <= 64 ? 27 * H + 14 : (int64_t)ODPD_EUNSUPPORTED;   // two 5-tap FIRs, 4->C (+bias), 4 x depthwise k5, C->2, IQ_match 2x2

@@ -5,8 +5,13 @@
 //   records   f, g, h and the state delta of every step, and (lanes 0..5 of a fifth slot) the feature deltas: B x T x 5 x 64 floats in `ckpt`.
 //   backward  carried accumulator gradients G_f, G_g; with every delta kept, the reference-value gradients reduce to G_hp(t) = -W_hh^T G(t+1) and
 //             G_xp(t) = -W_ih^T G(t+1) (the oracle's dj_seq_bwd); dW_hh as rotated 4-block MFMA outer products against the state delta.
+//   --quant   (QH; bits_w > 0, EVERY hidden size up to 64 — the tile kernels of delta_family.hip / delta_s16.hip serve float models only): the
+//             surgery finds one nn.Linear in this backbone, fc_out (the gates are nn.Parameter tensors, deltajanet.py:100-113), and makes it an
+//             INT_Linear (quant_layers.py:48-85): y = q_w(W) q_a(h) + b, three scale parameters behind fc_out.bias (gradients exactly 0),
+//             ODPD_FLAG_EVAL: the 16-bit output grid.  The recurrent cell stays float.
 #include "odpd_seq.h"
 #include "odpd_delta.h"
+#include "odpd_quant.h"
 
 namespace odpd {
 namespace {
@@ -23,15 +28,15 @@ __device__ __forceinline__ void dj_stage_features(float* ftab, const float2* xg,
     reinterpret_cast<float4*>(ftab)[2 * lane + 1] = make_float4(f[4], f[5], 0.0f, 0.0f);
 }
 
-template <bool SAVE>
+template <bool SAVE, bool QH>
 __global__ __launch_bounds__(64) void wide_deltajanet_fwd_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const DeltaLayout L = delta_layout(a.H, 0, 2);
-    const int H = L.H, T = a.T;
+    const int H = L.H, T = a.T, P = L.P + (QH ? 3 : 0);
     float* pl = smem;
-    stage_params(pl, a.params, L.P);
-    float* ftab = smem + pad4(L.P);            // [64][8]: features of the chunk's steps
+    stage_params(pl, a.params, P);
+    float* ftab = smem + pad4(P);              // [64][8]: features of the chunk's steps
     float* hb = ftab + kQC * 8;                // [64]: the state deltas, for the broadcast reads
     float* hist = hb + 64;                     // [64][65]: h of the chunk's steps
     const bool vo = lane < H;
@@ -43,6 +48,14 @@ __global__ __launch_bounds__(64) void wide_deltajanet_fwd_kernel(SeqArgs a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) wih[g][i] = vo ? pl[L.o_w_ih + (g * H + lane) * 6 + i] : 0.0f;
         dm0[g] = vo ? pl[L.o_b_ih + g * H + lane] + pl[L.o_b_hh + g * H + lane] : 0.0f;
+    }
+    q16::Quant qa{}, qo{};
+    if constexpr (QH) {      // fc_out's weights become their quantised values in the staged copy
+        const q16::Quant qw = q16::make_quant(pl[L.P], a.bits_w);
+        qa = q16::make_quant(pl[L.P + 1], a.bits_a);
+        qo = q16::make_quant(pl[L.P + 2], 16);
+        wave_lds_fence();
+        for (int i = lane; i < 2 * H; i += 64) pl[L.o_w_out + i] = q16::qapply(pl[L.o_w_out + i], qw);
     }
     wave_lds_fence();
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -98,10 +111,14 @@ __global__ __launch_bounds__(64) void wide_deltajanet_fwd_kernel(SeqArgs a) {
             }
             if (lane < len) {      // the chunk's outputs, lane = time step
                 const float* hr = hist + lane * kQS;
-                float y0 = pl[L.o_b_out], y1 = pl[L.o_b_out + 1];
+                float y0 = QH ? 0.0f : pl[L.o_b_out], y1 = QH ? 0.0f : pl[L.o_b_out + 1];
                 for (int j = 0; j < H; ++j) {
-                    const float hv = hr[j];
+                    const float hv = QH ? q16::qapply(hr[j], qa) : hr[j];
                     y0 = __builtin_fmaf(pl[L.o_w_out + j], hv, y0); y1 = __builtin_fmaf(pl[L.o_w_out + H + j], hv, y1);
+                }
+                if constexpr (QH) {      // grid sums first, then the float bias (INT_Linear: F.linear(q_a(x), q_w(W), b))
+                    y0 += pl[L.o_b_out]; y1 += pl[L.o_b_out + 1];
+                    if (a.eval_out) { y0 = q16::qapply(y0, qo); y1 = q16::qapply(y1, qo); }
                 }
                 yg[t0 + lane] = make_float2(y0, y1);
             }
@@ -117,15 +134,15 @@ __global__ __launch_bounds__(64) void wide_deltajanet_fwd_kernel(SeqArgs a) {
     }
 }
 
-template <bool NW, bool DX>
+template <bool NW, bool DX, bool QH>
 __global__ __launch_bounds__(64) void wide_deltajanet_bwd_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, quad = lane >> 4;
     const DeltaLayout L = delta_layout(a.H, 0, 2);
-    const int H = L.H, T = a.T, NC = (T + kQC - 1) / kQC;
+    const int H = L.H, T = a.T, NC = (T + kQC - 1) / kQC, P = L.P + (QH ? 3 : 0);
     float* pl = smem;
-    stage_params(pl, a.params, L.P);
-    float* ftab = smem + pad4(L.P);            // [64][8]  features of the chunk's steps (for dL/dx)
+    stage_params(pl, a.params, P);
+    float* ftab = smem + pad4(P);              // [64][8]  features of the chunk's steps (for dL/dx)
     float* dxb = ftab + kQC * 8;               // [64][2]  dL/dx of the chunk's steps
     float* dyb = dxb + kQC * 2;                // [64][2]  dL/dy of the chunk's steps
     float* dgb = dyb + kQC * 2;                // [2][64]  the step's G_f, G_g, for the broadcast reads
@@ -137,7 +154,14 @@ __global__ __launch_bounds__(64) void wide_deltajanet_bwd_kernel(SeqArgs a) {
     for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int i = 0; i < 6; ++i) wih[g][i] = vo ? pl[L.o_w_ih + (g * H + lane) * 6 + i] : 0.0f;
-    const float wo0 = vo ? pl[L.o_w_out + lane] : 0.0f, wo1 = vo ? pl[L.o_w_out + H + lane] : 0.0f;
+    float wo0 = vo ? pl[L.o_w_out + lane] : 0.0f, wo1 = vo ? pl[L.o_w_out + H + lane] : 0.0f, wm0 = 1.0f, wm1 = 1.0f;
+    q16::Quant qa{};
+    if constexpr (QH) {      // the head columns as quantised values, their straight-through masks for dW_out
+        const q16::Quant qw = q16::make_quant(pl[L.P], a.bits_w);
+        qa = q16::make_quant(pl[L.P + 1], a.bits_a);
+        wm0 = q16::qpass(wo0, qw); wm1 = q16::qpass(wo1, qw);
+        wo0 = q16::qapply(wo0, qw); wo1 = q16::qapply(wo1, qw);
+    }
     f32x16 acc[2][4];
 #pragma unroll
     for (int g = 0; g < 2; ++g)
@@ -181,8 +205,14 @@ __global__ __launch_bounds__(64) void wide_deltajanet_bwd_kernel(SeqArgs a) {
                 }
                 const float hprev = hs[tt * kQS + lane], ht = hs[(tt + 1) * kQS + lane];
                 const float2 d = reinterpret_cast<const float2*>(dyb)[tt];
-                Gh = __builtin_fmaf(d.x, wo0, __builtin_fmaf(d.y, wo1, Gh));
-                if constexpr (NW) { dwo0 = __builtin_fmaf(d.x, ht, dwo0); dwo1 = __builtin_fmaf(d.y, ht, dwo1); }
+                if constexpr (QH) {      // q_a(h) feeds the head; dL/dh passes where h lies inside the activation grid
+                    const float hq = q16::qapply(ht, qa);
+                    Gh = __builtin_fmaf(q16::qpass(ht, qa), __builtin_fmaf(d.x, wo0, d.y * wo1), Gh);
+                    if constexpr (NW) { dwo0 = __builtin_fmaf(d.x, hq, dwo0); dwo1 = __builtin_fmaf(d.y, hq, dwo1); }
+                } else {
+                    Gh = __builtin_fmaf(d.x, wo0, __builtin_fmaf(d.y, wo1, Gh));
+                    if constexpr (NW) { dwo0 = __builtin_fmaf(d.x, ht, dwo0); dwo1 = __builtin_fmaf(d.y, ht, dwo1); }
+                }
                 const float dg = Gh * (1.0f - fg), df = Gh * (hprev - gg);
                 Gf += vo ? df * (fg * (1.0f - fg)) : 0.0f;
                 Gg += vo ? dg * (gg * (1.0f - gg)) : 0.0f;
@@ -246,14 +276,14 @@ __global__ __launch_bounds__(64) void wide_deltajanet_bwd_kernel(SeqArgs a) {
         wave_lds_fence();
     }
     if constexpr (NW) {
-        float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
-        for (int i = lane; i < L.P + kLossCols; i += 64) prow[i] = 0.0f;
+        float* prow = a.partials + (size_t)blockIdx.x * (P + kLossCols);      // (the scale parameters' columns stay 0: round() inside the quantiser)
+        for (int i = lane; i < P + kLossCols; i += 64) prow[i] = 0.0f;
         __builtin_amdgcn_s_waitcnt(0);
         wave_lds_fence();
         for (int o = 32; o > 0; o >>= 1) { tb0 += __shfl_xor(tb0, o); tb1 += __shfl_xor(tb1, o); }
         if (lane == 0) { prow[L.o_b_out] = tb0; prow[L.o_b_out + 1] = tb1; }
         if (vo) {
-            prow[L.o_w_out + lane] = dwo0; prow[L.o_w_out + H + lane] = dwo1;
+            prow[L.o_w_out + lane] = dwo0 * wm0; prow[L.o_w_out + H + lane] = dwo1 * wm1;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -283,25 +313,37 @@ int dj_launch(hipStream_t st, K k, int grid, size_t lds, const SeqArgs& a) {
 }
 }  // namespace
 
-// deltajanet of 33 .. 64 hidden units
-bool deltajanet_wide_ok(const odpd_model_t* m) { return m->backbone == ODPD_DELTAJANET && m->bits_w == 0 && m->hidden > 32 && m->hidden <= 64; }
+// deltajanet of 33 .. 64 hidden units; with a quantised head (bits_w > 0): every hidden size up to 64
+bool deltajanet_wide_ok(const odpd_model_t* m) {
+    if (m->backbone != ODPD_DELTAJANET || m->hidden > 64 || (m->flags & ODPD_FLAG_TWO_LAYERS)) return false;
+    if (m->bits_w > 0) return m->bits_w <= 16 && m->bits_a > 0 && m->bits_a <= 16;
+    return m->hidden > 32;
+}
+static int dj_params(const odpd_model_t* m) { return delta_layout(m->hidden, 0, 2).P + (m->bits_w > 0 ? 3 : 0); }
 int64_t deltajanet_wide_ckpt_floats(const odpd_model_t*, int B, int T) { return (int64_t)B * T * kQNS * 64; }
 int deltajanet_wide_rows(const odpd_model_t*, int B) { const int cap = 4 * device_cus(); return B < cap ? B : cap; }
 int deltajanet_wide_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!deltajanet_wide_ok(m)) return ODPD_EUNSUPPORTED;
-    const size_t lds = (size_t)dj_fwd_floats(delta_layout(m->hidden, 0, 2).P) * sizeof(float);
+    const size_t lds = (size_t)dj_fwd_floats(dj_params(m)) * sizeof(float);
     const int grid = deltajanet_wide_rows(m, a.B);
-    return a.ckpt ? dj_launch(st, wide_deltajanet_fwd_kernel<true>, grid, lds, a) : dj_launch(st, wide_deltajanet_fwd_kernel<false>, grid, lds, a);
+    if (m->bits_w > 0)
+        return a.ckpt ? dj_launch(st, wide_deltajanet_fwd_kernel<true, true>, grid, lds, a) : dj_launch(st, wide_deltajanet_fwd_kernel<false, true>, grid, lds, a);
+    return a.ckpt ? dj_launch(st, wide_deltajanet_fwd_kernel<true, false>, grid, lds, a) : dj_launch(st, wide_deltajanet_fwd_kernel<false, false>, grid, lds, a);
 }
 int deltajanet_wide_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!deltajanet_wide_ok(m)) return ODPD_EUNSUPPORTED;
     if (!a.ckpt) return ODPD_EINVAL;
-    const size_t lds = (size_t)dj_bwd_floats(delta_layout(m->hidden, 0, 2).P) * sizeof(float);
+    const size_t lds = (size_t)dj_bwd_floats(dj_params(m)) * sizeof(float);
     const int grid = deltajanet_wide_rows(m, a.B);
     const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
-    if (nw && dx) return dj_launch(st, wide_deltajanet_bwd_kernel<true, true>, grid, lds, a);
-    if (nw) return dj_launch(st, wide_deltajanet_bwd_kernel<true, false>, grid, lds, a);
-    return dj_launch(st, wide_deltajanet_bwd_kernel<false, true>, grid, lds, a);
+    if (m->bits_w > 0) {
+        if (nw && dx) return dj_launch(st, wide_deltajanet_bwd_kernel<true, true, true>, grid, lds, a);
+        if (nw) return dj_launch(st, wide_deltajanet_bwd_kernel<true, false, true>, grid, lds, a);
+        return dj_launch(st, wide_deltajanet_bwd_kernel<false, true, true>, grid, lds, a);
+    }
+    if (nw && dx) return dj_launch(st, wide_deltajanet_bwd_kernel<true, true, false>, grid, lds, a);
+    if (nw) return dj_launch(st, wide_deltajanet_bwd_kernel<true, false, false>, grid, lds, a);
+    return dj_launch(st, wide_deltajanet_bwd_kernel<false, true, false>, grid, lds, a);
 }
 
 }  // namespace odpd

@@ -177,6 +177,45 @@ class QuantHeadLSTM(_QuantBase):
         self._finish(hidden_size, bits_w, bits_a)
 
 
+class QuantHeadDeltaJANET(_QuantBase):
+    """deltajanet after the surgery: the cell's gates are nn.Parameter tensors of DeltaJANETLayer (deltajanet.py:100-113), so the one module
+    the surgery finds is `fc_out` -> INT_Linear with out_quant set.  The sparsity counters and their report stay the float layer's
+    (:143-151).  Kernels: the quantised-head instantiations of csrc/deltajanet_wide.hip (one sequence per wave; every hidden size <= 64)."""
+    backbone_name = "deltajanet"
+
+    def __init__(self, rnn, bits_w, bits_a, thx=0.0, thh=0.0):
+        super().__init__()
+        from .backbones.deltagru import _DeltaStats
+        hidden_size = rnn.hidden_size
+        self.hidden_size, self.input_size, self.output_size, self.num_layers, self.bias = hidden_size, 6, 2, 1, True
+        self.rnn = rnn
+        self.fc_out = _QLinear(hidden_size, 2, bits_w, bits_a)
+        self.fc_out.out_quant = True
+        self._dstats = _DeltaStats()
+        self.debug = 1
+        self._finish(hidden_size, bits_w, bits_a)      # the layer is built with thx = thh = 0 whatever the model was given (:23-27)
+        self.thx, self.thh = thx, thh
+
+    def _stats_buffer(self, device):
+        return self._dstats.buffer(device) if self.debug else None
+
+    def set_debug(self, value):
+        self.debug = value
+        self._dstats.reset()
+
+    @property
+    def statistics(self):
+        return self._dstats.as_dict()
+
+    def get_temporal_sparsity(self):
+        st, out = self._dstats.as_dict(), {}
+        if self.debug and st["num_dx_numel"] > 0:
+            out["SP_T_DX"] = float(st["num_dx_zeros"] / st["num_dx_numel"])
+            out["SP_T_DH"] = float(st["num_dh_zeros"] / st["num_dh_numel"])
+            out["SP_T_DV"] = float((st["num_dx_zeros"] + st["num_dh_zeros"]) / (st["num_dx_numel"] + st["num_dh_numel"]))
+        return out
+
+
 class _QDeltaLayer(nn.Module):
     """DeltaGRULayer of deltagru_tcnskip.py:133-162 after the surgery: bias-free INT_Linear x2h / h2h, Quant_add / mult / sigmoid /
     tanh in the layer's own registration order."""
@@ -244,8 +283,9 @@ class QuantTResDeltaGRU(_QuantBase):
 
 MAX_HIDDEN = 32          # csrc/qat_s16.hip: two 16-unit tiles
 _UNTOUCHED = ("gmp", "tcnn")       # no nn.GRU, no nn.Linear, no op modules: the surgery returns an identical deep copy
-_PARTIAL = ("rvtdcnn", "apnrru", "bojanet", "deltajanet", "dvrjanet", "neuraltx", "mcldnn", "pgjanet")
-_HEAD_ONLY = ("lstm", "vdlstm")    # only nn.Linear heads to swap, and kernels with quantised heads exist
+_PARTIAL = ("rvtdcnn", "apnrru", "bojanet", "dvrjanet", "neuraltx", "mcldnn", "pgjanet")
+_HEAD_ONLY = ("lstm", "vdlstm", "deltajanet")    # only nn.Linear heads to swap, and kernels with quantised heads exist
+_HEAD_MAX_HIDDEN = {"deltajanet": 64}            # csrc/deltajanet_wide.hip serves the quantised head at every hidden size it covers
 
 
 def _warn_float(exc, model):
@@ -264,7 +304,7 @@ def _wrap(model, bb, dev):
 
 
 def _quantise_heads(model, bits_w, bits_a, pre, dev):
-    """lstm / vdlstm: create_pygru_model finds no nn.GRU (no RNG draws), load_model strict-loads a float checkpoint of the model's own keys,
+    """lstm / vdlstm / deltajanet: create_pygru_model finds no nn.GRU (no RNG draws), load_model strict-loads a float checkpoint of the model's own keys,
     create_quantized_model swaps the nn.Linear heads in named_children order — each INT_Linear keeps the weight and draws a fresh
     default-init bias (quant_layers.py:48-56)."""
     import copy
@@ -285,7 +325,10 @@ def _quantise_heads(model, bits_w, bits_a, pre, dev):
             for k, p in rnn.named_parameters():
                 p.copy_(pre_sd["backbone.rnn." + k])
             fc_w = {h: pre_sd[f"backbone.{h}.weight"] for h in heads}
-        bb = (QuantHeadVDLSTM if model.backbone_type == "vdlstm" else QuantHeadLSTM)(rnn, bits_w, bits_a)
+        if model.backbone_type == "deltajanet":
+            bb = QuantHeadDeltaJANET(rnn, bits_w, bits_a, model.thx, model.thh)
+        else:
+            bb = (QuantHeadVDLSTM if model.backbone_type == "vdlstm" else QuantHeadLSTM)(rnn, bits_w, bits_a)
         for h in heads:
             getattr(bb, h).weight.copy_(fc_w[h])
     return _wrap(model, bb, dev)
@@ -298,8 +341,10 @@ def get_quant_model(proj, model):
     The surgery is generic (quant_envs.py:114-130, 290-306).  HIP-backed here: gru, dgru, qgru, qgru_amp1 (GRU of GRUCells, INT_Linear
     heads) and deltagru_tcnskip (its layer's Linears and op modules), one layer, hidden <= 32; gmp and tcnn contain nothing the surgery
     swaps (the reference hands back an identical copy: the model itself is returned).  deltagru's layer IS an nn.GRU subclass, the
-    reference swaps it for a plain GRU and then fails in forward (TypeError, deltagru.py:74-77): refused here at construction.  The
-    backbones in which only some nn.Linear become INT_Linear (lstm, vdlstm, rvtdcnn, ...) have no quantised kernels yet.
+    reference swaps it for a plain GRU and then fails in forward (TypeError, deltagru.py:74-77): refused here at construction.  In lstm,
+    vdlstm and deltajanet the surgery finds only nn.Linear HEADS (float recurrent core, INT_Linear heads: `_quantise_heads`; deltajanet
+    up to 64 hidden units); the backbones whose gates or convolutions are themselves nn.Linear / nn.Conv2d modules (`_PARTIAL`) have no
+    quantised kernels yet.
 
     `pretrained_model` follows Base_GRUQuantEnv.load_model (quant_envs.py:173-182): the checkpoint is strict-loaded into the FLOAT
     holder before quantisation — for the GRU-cell models its keys are `backbone.rnn.rnn_cell_list.0.{x2h,h2h}.{weight,bias}`,
@@ -322,8 +367,9 @@ def get_quant_model(proj, model):
         raise NotImplementedError(f"--quant on '{bt}' (only its nn.Linear layers become INT_Linear in the reference) has no HIP kernels yet")
     bits_w, bits_a = int(getattr(proj, "n_bits_w", 8)), int(getattr(proj, "n_bits_a", 8))
     H = model.hidden_size
-    if H > MAX_HIDDEN or model.num_layers != 1:
-        raise NotImplementedError(f"the QAT kernels cover one layer and hidden_size <= {MAX_HIDDEN} (csrc/qat_s16.hip)")
+    max_h = _HEAD_MAX_HIDDEN.get(bt, MAX_HIDDEN)
+    if H > max_h or model.num_layers != 1:
+        raise NotImplementedError(f"the QAT kernels cover one layer and hidden_size <= {max_h} (csrc/qat_s16.hip; csrc/deltajanet_wide.hip)")
     dev = next(model.parameters()).device
     pre = getattr(proj, "pretrained_model", "")
     if bt in _HEAD_ONLY:

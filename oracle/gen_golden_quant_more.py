@@ -48,6 +48,8 @@ CASES = [
     ("quant_lstm_h24_w8a8", "lstm", 24, 8, 0, 0, False),
     ("quant_vdlstm_h13_w8a8", "vdlstm", 13, 8, 0, 0, False),
     ("quant_vdlstm_h13_w16a16", "vdlstm", 13, 16, 0, 0, False),
+    ("quant_deltajanet_h12_w8a8", "deltajanet", 12, 8, 0, 0, False),       # custom float cell (nn.Parameter gates), INT_Linear fc_out
+    ("quant_deltajanet_h40_w16a16", "deltajanet", 40, 16, 0, 0, False),
 ]
 
 

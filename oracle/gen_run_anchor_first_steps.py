@@ -12,7 +12,8 @@ The FIRST steps have no such freedom yet, so this script records the reference's
 and of the train_pa runs of configs 2 (dgru H13, APA_200MHz, 256 x 200) and 4 (vdlstm H13, APA_200MHz_b) by RUNNING the reference (CPU) with its own Project / dataloader / optimiser; the frozen PA is the state dict the reference trained for
 the epoch anchors (tests/golden/ref_runs_apa_models.npz, written where train_dpd looks for it).  The only harness-side change is a
 `net_train` that is the reference's loop verbatim in behaviour (train_funcs.py:28-48) plus "remember every loss, stop after N steps".
-Output: tests/golden/ref_first_steps.json {config3: {losses: [...], cmd}, config5: {...}}.   Usage: python oracle/gen_run_anchor_first_steps.py"""
+Output: tests/golden/ref_first_steps.json {config3: {losses: [...], cmd}, config5: {...}}.   Usage: python oracle/gen_run_anchor_first_steps.py [key ...]
+(with keys: only those runs are made and merged into the existing file)"""
 import json
 import os
 import subprocess
@@ -27,7 +28,12 @@ N_STEPS = 20
 C = ["--dataset_name", "APA_200MHz", "--accelerator", "cpu", "--frame_length", "200", "--seed", "0", "--n_epochs", "1",
      "--PA_backbone", "dgru", "--PA_hidden_size", "23", "--batch_size", "64"]
 RUNS = {"config3": ["--DPD_backbone", "deltagru_tcnskip", "--DPD_hidden_size", "15", "--thx", "0.01", "--thh", "0.05"],
-        "config5": ["--DPD_backbone", "qgru", "--DPD_hidden_size", "10", "--quant", "--n_bits_w", "8", "--n_bits_a", "8"]}
+        "config5": ["--DPD_backbone", "qgru", "--DPD_hidden_size", "10", "--quant", "--n_bits_w", "8", "--n_bits_a", "8"],
+        # deltajanet as the DPD: the reference's train_dpd trains the epoch and then fails while logging it (modules/paths.py:56 asks the
+        # wrapper for get_temporal_sparsity, which only its layer has) — no epoch row exists, the per-step losses do.  Float, and under --quant
+        # (the surgery swaps fc_out only)
+        "deltajanet": ["--DPD_backbone", "deltajanet", "--DPD_hidden_size", "12"],
+        "deltajanet_w8a8": ["--DPD_backbone", "deltajanet", "--DPD_hidden_size", "12", "--quant", "--n_bits_w", "8", "--n_bits_a", "8"]}
 # train_pa runs (the commands of tests/golden/ref_runs_apa.json: BASELINE configs 2 and 4) — full argument lists, no PA checkpoint needed
 PA_RUNS = {"config2": ["--dataset_name", "APA_200MHz", "--PA_backbone", "dgru", "--PA_hidden_size", "13", "--accelerator", "cpu", "--frame_length", "200",
                        "--batch_size", "256", "--seed", "0", "--n_epochs", "1"],
@@ -82,8 +88,12 @@ def main():
     env = dict(os.environ, PYTHONPATH=REF, PYTHONDONTWRITEBYTECODE="1")
     pa = {k[3:]: torch.from_numpy(v) for k, v in np.load(os.path.join(OUT, "ref_runs_apa_models.npz")).items() if k.startswith("pa/")}
     pa_rel = json.load(open(os.path.join(OUT, "ref_runs_apa.json")))["config3_apa200"]["pa_model"]
-    out = {"n_steps": N_STEPS}
+    only = sys.argv[1:]
+    path = os.path.join(OUT, "ref_first_steps.json")
+    out = json.load(open(path)) if only else {"n_steps": N_STEPS}
     for key, args in RUNS.items():
+        if only and key not in only:
+            continue
         with tempfile.TemporaryDirectory() as tmp:
             os.makedirs(os.path.join(tmp, os.path.dirname(pa_rel)), exist_ok=True)
             torch.save(pa, os.path.join(tmp, pa_rel))
@@ -92,12 +102,14 @@ def main():
             out[key] = {"losses": json.load(open(os.path.join(tmp, "first_steps.json"))), "cmd": " ".join(["--step", "train_dpd"] + C + args)}
             print(key, out[key]["losses"][:3], "...", out[key]["losses"][-1])
     for key, args in PA_RUNS.items():
+        if only and key not in only:
+            continue
         with tempfile.TemporaryDirectory() as tmp:
             open(os.path.join(tmp, "_runner.py"), "w").write(RUNNER)
             subprocess.check_call([sys.executable, "_runner.py", "--step", "train_pa"] + args, cwd=tmp, env=env, stdout=subprocess.DEVNULL)
             out[key] = {"losses": json.load(open(os.path.join(tmp, "first_steps.json"))), "cmd": " ".join(["--step", "train_pa"] + args)}
             print(key, out[key]["losses"][:3], "...", out[key]["losses"][-1])
-    json.dump(out, open(os.path.join(OUT, "ref_first_steps.json"), "w"), indent=1)
+    json.dump(out, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -55,7 +55,7 @@ static int64_t lstm_param_count(const odpd_model_t* m);
 int64_t oracle_param_count(const odpd_model_t* m) {
     int64_t H = m->hidden, F = feat_dim(m->backbone);
     if (m->bits_w > 0 && (m->backbone == ODPD_LSTM || m->backbone == ODPD_VDLSTM)) return lstm_param_count(m);   /* quantised head(s) */
-    if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET) return qat_param_count(m);   /* quantised models: + the quantiser scales */
+    if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET && m->backbone != ODPD_DELTAJANET) return qat_param_count(m);   /* quantised models: + the quantiser scales */
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1:
         return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
@@ -85,7 +85,7 @@ int64_t oracle_param_count(const odpd_model_t* m) {
     case ODPD_MCLDNN:   /* mcldnn.py:21-27: conv2d_1 10C, conv1d 20C, conv2d_2 91, LSTM(5C -> 8) 160C + 320, fc 144 + 34 */
         return 190 * H + 589;
     case ODPD_DELTAJANET: /* deltajanet.py:96-111: two gates */
-        return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2;
+        return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2 + (m->bits_w > 0 ? 3 : 0);      /* + the INT_Linear head's scales */
     case ODPD_NEURALTX: /* neuraltx.py:18-38: two 5-tap FIRs, 4 -> C (bias), 4 depthwise k5, C -> 2, IQ_match (2,2); hidden = channels */
         return 10 + 4 * H + H + 4 * 5 * H + 2 * H + 4;
     case ODPD_RVTDCNN:  /* rvtdcnn.py:19-33: Conv2d(1->3,k3) 27+3, fc_hid (H,36)+H, fc_out (2,H)+2; hidden = fc_hid_size (models.py:80-81) */
@@ -700,15 +700,21 @@ static void delta_seq_bwd(const odpd_model_t* m, const delta_layout_t* L, const 
  * h = (1 - f) g + f h (:250).  Counters num_d{x,h}_{zeros,numel} as deltagru.  Parameter order: rnn.weight_ih_l0,
  * rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, fc_out.weight, fc_out.bias. */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { int H; int64_t o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out; } dj_layout_t;
+/* `--quant` (bits_w > 0): the surgery finds one nn.Linear, fc_out (the cell's gates are nn.Parameter tensors, deltajanet.py:100-113),
+ * and makes it an INT_Linear (qlin_fwd / qlin_bwd above; three scale parameters behind fc_out.bias; ODPD_FLAG_EVAL: 16-bit output grid). */
+typedef struct { int H, q, bits_w, bits_a, eval; int64_t o_w_ih, o_w_hh, o_b_ih, o_b_hh, o_w_out, o_b_out, o_q_out, P; } dj_layout_t;
 static void dj_layout(const odpd_model_t* m, dj_layout_t* g) {
     int64_t H = m->hidden, o = 0;
     g->H = (int)H;
+    g->q = m->bits_w > 0; g->bits_w = m->bits_w; g->bits_a = m->bits_a; g->eval = (m->flags & 1);
     g->o_w_ih = o; o += 2 * H * 6; g->o_w_hh = o; o += 2 * H * H;
     g->o_b_ih = o; o += 2 * H; g->o_b_hh = o; o += 2 * H;
-    g->o_w_out = o; o += 2 * H; g->o_b_out = o;
+    g->o_w_out = o; o += 2 * H; g->o_b_out = o; o += 2;
+    g->o_q_out = -1;
+    if (g->q) { g->o_q_out = o; o += 3; }
+    g->P = o;
 }
-typedef struct { real f[6], dxm[6], hprev[MAXH], dhm[MAXH], fg[MAXH], gg[MAXH], h[MAXH]; } dj_step_t;
+typedef struct { real f[6], dxm[6], hprev[MAXH], dhm[MAXH], fg[MAXH], gg[MAXH], h[MAXH], hq[MAXH], ph[MAXH]; } dj_step_t;
 static void dj_seq_fwd(const dj_layout_t* L, const real* p, int T, const real* x, real* y, dj_step_t* S, double* stats) {
     const int H = L->H;
     real xp[6] = {0}, h[MAXH] = {0}, hp[MAXH] = {0}, dm[2 * MAXH];
@@ -732,7 +738,10 @@ static void dj_seq_fwd(const dj_layout_t* L, const real* p, int T, const real* x
             h[j] = ((real)1 - s->fg[j]) * s->gg[j] + s->fg[j] * h[j];
             s->h[j] = h[j];
         }
-        for (int c = 0; c < 2; ++c) {
+        if (L->q) {
+            qlin_fwd(p, L->o_w_out, L->o_b_out, L->o_q_out, 2, H, L->bits_w, L->bits_a, h, s->hq, s->ph, &y[2 * t]);
+            if (L->eval) for (int c = 0; c < 2; ++c) y[2 * t + c] = q_apply(y[2 * t + c], q_pow2(p[L->o_q_out + 2]), 16, NULL);
+        } else for (int c = 0; c < 2; ++c) {
             real acc = p[L->o_b_out + c];
             for (int j = 0; j < H; ++j) acc += p[L->o_w_out + c * H + j] * h[j];
             y[2 * t + c] = acc;
@@ -746,7 +755,8 @@ static void dj_seq_bwd(const dj_layout_t* L, const real* p, int T, const real* x
     real Gh[MAXH] = {0}, Ghp[MAXH] = {0}, Gxp[6] = {0}, Gdm[2 * MAXH] = {0};
     for (int t = T - 1; t >= 0; --t) {
         const dj_step_t* s = &S[t];
-        for (int c = 0; c < 2; ++c) {
+        if (L->q) qlin_bwd(p, L->o_w_out, L->o_b_out, L->o_q_out, 2, H, L->bits_w, &dy[2 * t], s->hq, s->ph, dp, Gh);
+        else for (int c = 0; c < 2; ++c) {
             const real d = dy[2 * t + c];
             dp[L->o_b_out + c] += d;
             for (int j = 0; j < H; ++j) { dp[L->o_w_out + c * H + j] += d * s->h[j]; Gh[j] += d * p[L->o_w_out + c * H + j]; }

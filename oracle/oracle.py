@@ -17,7 +17,7 @@ BACKBONES = {"gru": 0, "dgru": 1, "qgru": 2, "qgru_amp1": 3, "lstm": 4, "vdlstm"
              "deltagru_tcnskip": 7, "tcnn": 8, "pgjanet": 9, "gmp": 10, "rvtdcnn": 11, "neuraltx": 12, "deltajanet": 13, "dvrjanet": 14, "bojanet": 15, "apnrru": 16, "mcldnn": 17}
 
 
-_HEAD_ONLY = (BACKBONES["lstm"], BACKBONES["vdlstm"])      # --quant swaps only their nn.Linear heads (quant_envs.py:40-60)
+_HEAD_ONLY = (BACKBONES["lstm"], BACKBONES["vdlstm"], BACKBONES["deltajanet"])      # --quant swaps only their nn.Linear heads (quant_envs.py:40-60)
 
 
 class Model(C.Structure):
@@ -91,7 +91,7 @@ class Oracle:
     def qat_forward(self, m, params, x, eval_mode=False, stats=None):
         """Quantised model (m.bits_w > 0; gru, dgru, qgru, qgru_amp1, deltagru_tcnskip): train-mode (float output) or eval-mode
         (16-bit output grid).  `stats` (4 doubles) accumulates the delta cell's sparsity counters."""
-        if m.backbone in _HEAD_ONLY:      # lstm / vdlstm: only the nn.Linear heads are quantised; ODPD_FLAG_EVAL = eval mode
+        if m.backbone in _HEAD_ONLY:      # lstm / vdlstm / deltajanet: only the nn.Linear heads are quantised; ODPD_FLAG_EVAL = eval mode
             m2 = Model(m.backbone, m.hidden, m.thx, m.thh, m.bits_w, m.bits_a, 1 if eval_mode else 0)
             return self.forward(m2, params, x, stats=np.zeros(4))
         x = self._a(x)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of the optimiser step (fwd + loss + BPTT + clip + AdamW through `fused_train_step`: single-launch kernels
 where they exist, the split chain elsewhere) against the C oracle's train step: every hidden size of the envelope, random batch /
-frame length / loss kind, the three kernel mappings (default dispatch, S16 forced, row-rotated forced), two consecutive steps.  usage: PYTHONPATH=. python tools/train_sweep.py [cases-per-size]"""
+frame length / loss kind, the three kernel mappings (default dispatch, S16 forced, row-rotated forced), two consecutive steps.  usage: PYTHONPATH=. python tools/train_sweep.py [wide] [cases-per-size]"""
 import sys
 import warnings
 
@@ -12,6 +12,9 @@ from opendpd_amd import CoreModel, _lib
 from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
 from oracle.oracle import Oracle, make_model
 
+wide = len(sys.argv) > 1 and sys.argv[1] == "wide"      # `wide [n]`: the lane-per-unit kernels' hidden sizes (docs/design/wide.md)
+if wide:
+    del sys.argv[1]
 n_per = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 lib = _lib.load()
 if len(sys.argv) > 2:      # second argument: force the S16 occupancy variant (2 = the large-batch kernels, incl. K-packing)
@@ -21,13 +24,16 @@ SIZES = {"gru": range(1, 33), "dgru": range(1, 33), "qgru": range(1, 33), "qgru_
          "vdlstm": range(1, 33), "deltagru": range(1, 33), "deltagru_tcnskip": range(1, 33), "pgjanet": range(1, 17),
          "tcnn": list(range(1, 40, 3)) + [64], "gmp": [11] * 16, "rvtdcnn": range(1, 33), "deltajanet": range(1, 33),
          "neuraltx": list(range(1, 40, 3)) + [64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15), "mcldnn": range(1, 17)}
+if wide:
+    SIZES = {bb: range(33, 65) for bb in ("gru", "dgru", "qgru", "qgru_amp1", "lstm", "vdlstm", "deltagru", "deltagru_tcnskip", "deltajanet")}
+    SIZES["pgjanet"] = range(17, 33)
 rng = np.random.RandomState(1)
 bad, flips = [], []
 for bb, sizes in SIZES.items():
     worst = [0.0, 0.0]
     for H in sizes:
         for case in range(n_per):
-            for force in (False, True, "row-rotated"):      # default dispatch (one-sequence-per-wave kernels at these shapes) | S16 forced | four-sequence waves
+            for force in ((False,) if wide else (False, True, "row-rotated")):      # default dispatch (one-sequence-per-wave kernels at these shapes) | S16 forced | four-sequence waves
                 lib.odpd_set_tuning(b"s16_min_batch", 0 if force is True else -1)
                 lib.odpd_set_tuning(b"gp_max_batch", 0 if force == "row-rotated" else -1)
                 B = int(rng.choice([1, 3, 4, 15, 16, 17, 33, 64]))
