@@ -9,6 +9,11 @@
 // the step's pre-combined straight-through factors (qat_s16.hip, SaveS) for its 32 steps, then back-propagates: one transposed rotated dot
 // product per step, weight gradients as two 4-block MFMAs on grid-unit operands, scaled (and masked by the weight quantisers' pass
 // ranges) once at write-out; the scale parameters get an exact 0.  hidden <= 16.
+// K_DGRU (r04): the quantised dgru (GRUCell on the six features, fc_hid + relu + cat([hid, features]) + fc_out, all INT_Linear: dgru.py:59-74
+// under the surgery) for evaluation passes and the train_pa step.  Its head runs with LANE = TIME STEP on the chunk (dg_head): q_a(h) on
+// fc_hid's grid, the H x H integer mat-vec against q_w(W_hid) read as LDS broadcasts, scale + bias in one FMA, relu, fc_out's activation
+// grid on [hid | features]; backwards the same lanes form dL/d(pre-activation) and W_hid^T of it (handed to the serial loop through LDS),
+// dW_hid is a 16 x 16 x 4 MFMA over the chunk's time steps, the head's vectors are summed with lane = unit.
 #pragma once
 #include "odpd_qat.h"
 #include "odpd_seq.h"
@@ -19,20 +24,23 @@ namespace q16 {
 // NB: unit blocks (1: hidden <= 16; 2: hidden 17..32 — two 16-unit blocks per gate row, as GpSeq)
 template <int MK, bool LUT, int NB = 1>
 struct QatSeq {
-    static_assert(MK == K_GRU || MK == K_Q4 || MK == K_A4, "GRUCell kinds with a plain INT_Linear head");
+    static_assert(MK == K_GRU || MK == K_Q4 || MK == K_A4 || MK == K_DGRU, "GRUCell kinds");
+    static constexpr bool DG = MK == K_DGRU;
     static constexpr int F = Kind<MK>::F, C = 32, HB = 16 * NB;      // C = kCascChunk (odpd_gpseq.h)
+    static constexpr int FQ = DG ? 16 : 4;              // floats per step in fq: the cell's quantised features (DG: [0..5]; [8..13] = the same six on fc_out's grid)
+    static constexpr int kDgFloats = DG ? 16 + HB + HB * HB + 4 * C * HB : 0;      // wof [2][8] | bhid [HB] | q_w(W_hid) [HB][HB] | dpre, hok, headg, h2k [C][HB]
     static constexpr int NSV = 14;                      // parked per unit and step: hp hqk n z c2 c3 An Az B1 B2A pph hnew hok pho
     static constexpr int kTabFloats = 6 * NB * 4 * 64 * 4;   // q_w(W_h) rotated rows (gate, relative input block) + transposed
     __host__ __device__ static int tp(int T) { return (T + 63) & ~63; }
     __host__ __device__ static int nchunks(int T) { return (T + C - 1) / C; }
     __host__ __device__ static int off_buf() { return LUT ? 4 * 256 : 0; }                         // LUT builds (<= 8 activation bits): [256][4] first; tables | buffers start here
-    __host__ __device__ static int off_ck(int T) { return tp(T) * 4; }                             // fq [Tp][4]: quantised features (grid units)
+    __host__ __device__ static int off_ck(int T) { return tp(T) * FQ; }                            // fq [Tp][FQ]: quantised features (grid units)
     __host__ __device__ static int off_dyb(int T) { return off_ck(T) + nchunks(T) * 64 * NB; }     // ck [chunks][NB][64]: h at the chunk start
     __host__ __device__ static int off_sv(int T) { return off_dyb(T) + tp(T) * 2; }                // dyb [Tp][2]: dL/du(t), written by the PA wave
     __host__ __device__ static int off_hist(int T) { return off_sv(T) + C * HB * NSV; }            // sv [C][NSV][HB]
     __host__ __device__ static int off_dump(int T) { return off_hist(T) + (C + 1) * HB; }          // hist [C + 1][HB]: entry i + 1 = h(t0 + i)
     __host__ __device__ static int off_hw(int T) { return off_dump(T) + 512 * NB; }                // dump: where the rows that park nothing store
-    __host__ __device__ static int buf_floats(int T) { return off_hw(T) + 2 * HB; }
+    __host__ __device__ static int buf_floats(int T) { return off_hw(T) + 2 * HB + kDgFloats; }
     __host__ __device__ static int region_floats(int T, int P) {
         const int buf = buf_floats(T);
         return pad4(P) + off_buf() + (buf > kTabFloats ? buf : kTabFloats);
@@ -41,6 +49,9 @@ struct QatSeq {
     __host__ __device__ static int off_dyb_region(int T, int P) { return pad4(P) + off_buf() + off_dyb(T); }
 
     // ---- registers ----
+    float *wofp, *bhidp, *whidp, *dpreb, *hokb, *headg, *h2kb;      // DG: the head's LDS tables and chunk buffers
+    f32x4 thid[NB][NB];                                             // DG: dW_hid tiles (dpre x q_a(h), grid units on the B side)
+    float dg_w0, dg_w1, dg_bh;                                      // DG: lane = unit (lanes 32 .. 37: feature slot): fc_out column / fc_hid bias gradients
     float wrec[NB][NB][16], wT[NB][NB][16], wx[NB][F], bx[NB][3], bh[NB][3], wo0[NB], wo1[NB], bo0, bo1;
     QSc qs;
     QK k;
@@ -123,6 +134,19 @@ struct QatSeq {
         fq = tab; ck = tab + off_ck(Tb); dyb = tab + off_dyb(Tb); sv = tab + off_sv(Tb); hist = tab + off_hist(Tb); dump = tab + off_dump(Tb);
         hw = tab + off_hw(Tb);
         for (int i = lane; i < 2 * HB; i += 64) hw[i] = (i % HB) < H ? kq(pl[L.o_wo + (i / HB) * L.OW + (i % HB)], wq.o) : 0.0f;
+        if constexpr (DG) {
+            wofp = hw + 2 * HB; bhidp = wofp + 16; whidp = bhidp + HB; dpreb = whidp + HB * HB; hokb = dpreb + C * HB; headg = hokb + C * HB;
+            h2kb = headg + C * HB;
+            if (lane < 16) wofp[lane] = (lane & 7) < 6 ? kq(pl[L.o_wo + (lane >> 3) * L.OW + H + (lane & 7)], wq.o) : 0.0f;
+            for (int i = lane; i < HB; i += 64) bhidp[i] = i < H ? pl[L.o_bhid + i] : 0.0f;
+            for (int i = lane; i < HB * HB; i += 64) whidp[i] = ((i / HB) < H && (i % HB) < H) ? kq(pl[L.o_whid + (i / HB) * H + (i % HB)], wq.hid) : 0.0f;
+            for (int i = lane; i < 4 * C * HB; i += 64) dpreb[i] = 0.0f;      // (columns >= H are never written again: zero operands of the dW_hid tiles)
+#pragma unroll
+            for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NB; ++nt) thid[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            dg_w0 = 0.0f; dg_w1 = 0.0f; dg_bh = 0.0f;
+        }
         rm = row_masks();
         // the recomputed steps' stores: row 0 parks the unit's NSV factors, row 3 h(t) (the others hit the dump)
         svp0 = role == 0 ? (int)(sv - smem) + col : (int)(dump - smem) + lane; svp_step = role == 0 ? HB * NSV : 0;
@@ -142,15 +166,23 @@ struct QatSeq {
     }
 
     // the model's quantised input features of one sample, grid units (qat_s16.hip: q16_slots' operation order, then q_a)
-    __device__ __forceinline__ float4 features(float2 xv) const {
+    __device__ __forceinline__ void put_features(float* dst, float2 xv) const {
         const float I = xv.x, Q = xv.y;
-        float f[4] = {I, Q, 0.0f, 0.0f};
+        float f[8] = {I, Q, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (MK == K_Q4) { const float a2 = I * I + Q * Q; f[2] = a2; f[3] = a2 * a2; }
         if constexpr (MK == K_A4) { const float a2 = I * I + Q * Q, a = sqrtf(a2); f[2] = a; f[3] = a * a * a; }
-        float r[4];
+        if constexpr (DG) { const float a2 = I * I + Q * Q, a = sqrtf(a2); f[2] = a; f[3] = a * a * a; f[4] = Q / a; f[5] = I / a; }      // dgru.py:61-68
+        float r[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = i < F ? gk(f[i] * k.inv_xa, k) : 0.0f;
-        return make_float4(r[0], r[1], r[2], r[3]);
+        for (int i = 0; i < 8; ++i) r[i] = i < F ? gk(f[i] * k.inv_xa, k) : 0.0f;
+        reinterpret_cast<float4*>(dst)[0] = make_float4(r[0], r[1], r[2], r[3]);
+        if constexpr (DG) {      // ... and as fc_out's inputs (the cat's feature part on fc_out's activation grid)
+            reinterpret_cast<float4*>(dst)[1] = make_float4(r[4], r[5], 0.0f, 0.0f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = i < F ? gk(f[i] * k.inv_oa, k) : 0.0f;
+            reinterpret_cast<float4*>(dst)[2] = make_float4(r[0], r[1], r[2], r[3]);
+            reinterpret_cast<float4*>(dst)[3] = make_float4(r[4], r[5], 0.0f, 0.0f);
+        }
     }
 
     __device__ __forceinline__ void fwd_begin() {
@@ -161,8 +193,9 @@ struct QatSeq {
     // one GRUCell step (std_cell, qat_s16.hip) at time t.  SAVE: parks the backward's factors of the step at `sp` / h(t) at `hq`
     template <bool SAVE>
     __device__ __forceinline__ void step(int t, int sp, int hq_) {
-        const float4 f4 = reinterpret_cast<const float4*>(fq)[t - fbase];
-        const float ff[4] = {f4.x, f4.y, f4.z, f4.w};
+        const float4* fp4 = reinterpret_cast<const float4*>(fq + (t - fbase) * FQ);
+        const float4 f4 = fp4[0], f5 = DG ? fp4[1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float ff[8] = {f4.x, f4.y, f4.z, f4.w, f5.x, f5.y, 0.0f, 0.0f};
         float v0[NB], m0[NB], hqk[NB];
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) { v0[ob] = h[ob] * k.inv_ha; m0[ob] = gm(v0[ob], k); hqk[ob] = rintf(m0[ob]); }
@@ -211,18 +244,94 @@ struct QatSeq {
         }
     }
 
+    // dgru's head on the chunk's steps, LANE = TIME STEP (head_fwd / head_bwd of qat_s16.hip per step): forward -> sink(t, y0, y1);
+    // BWD: dL/dpre (fc_hid's pre-activation) and q_a(relu) of every unit -> dpreb / hokb, q_a(h) -> h2kb, W_hid^T dL/dpre through fc_hid's
+    // activation mask (carrying s_hidw) -> headg, rows of steps beyond the chunk's length zero
+    template <bool BWD, typename Sink>
+    __device__ __forceinline__ void dg_head(int t0, int len, Sink sink) {
+        const bool on = lane < len;
+        const int tl = on ? lane : 0;
+        const float* hv = hist + (tl + 1) * HB;
+        float h2k[HB], back[HB];
+#pragma unroll
+        for (int u = 0; u < HB; ++u) { h2k[u] = gk(hv[u] * k.inv_hida, k); back[u] = 0.0f; }
+        float2 dyv = make_float2(0.0f, 0.0f);
+        if constexpr (BWD) dyv = *reinterpret_cast<const float2*>(dyb + 2 * (t0 + tl));
+        float p0 = 0.0f, p1 = 0.0f;
+        for (int m = 0; m < H; ++m) {
+            const float4* wr = reinterpret_cast<const float4*>(whidp + m * HB);
+            float w[HB];
+#pragma unroll
+            for (int q = 0; q < HB / 4; ++q) { const float4 w4 = wr[q]; w[4 * q] = w4.x; w[4 * q + 1] = w4.y; w[4 * q + 2] = w4.z; w[4 * q + 3] = w4.w; }
+            float acc = 0.0f;
+#pragma unroll
+            for (int u = 0; u < HB; ++u) acc = __builtin_fmaf(w[u], h2k[u], acc);
+            const float pre = __builtin_fmaf(acc, k.Shid, bhidp[m]), hid = pre > 0.0f ? pre : 0.0f;      // torch.relu
+            const float v = hid * k.inv_oa, mm = gm(v, k), hok = rintf(mm);
+            if constexpr (!BWD) { p0 = __builtin_fmaf(hw[m], hok, p0); p1 = __builtin_fmaf(hw[HB + m], hok, p1); }
+            else {
+                const float pho = mm == v ? k.s_ow : 0.0f;
+                const float dcat = (dyv.x * hw[m] + dyv.y * hw[HB + m]) * pho;
+                const float dpre = (on && pre > 0.0f) ? dcat : 0.0f;
+                if (lane < C) { dpreb[lane * HB + m] = dpre; hokb[lane * HB + m] = on ? hok : 0.0f; }
+#pragma unroll
+                for (int u = 0; u < HB; ++u) back[u] = __builtin_fmaf(w[u], dpre, back[u]);
+            }
+        }
+        if constexpr (!BWD) {
+            const float* fr = fq + (t0 + tl - fbase) * FQ + 8;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { p0 = __builtin_fmaf(wofp[c], fr[c], p0); p1 = __builtin_fmaf(wofp[8 + c], fr[c], p1); }
+            float y0 = __builtin_fmaf(p0, k.So, bo0), y1 = __builtin_fmaf(p1, k.So, bo1);
+            if (eval_out) { y0 = qapply(y0, qs.out); y1 = qapply(y1, qs.out); }
+            if (on) sink(t0 + lane, y0, y1);
+        } else if (lane < C) {
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const float v = hv[u] * k.inv_hida;
+                headg[lane * HB + u] = back[u] * (gm(v, k) == v ? k.s_hidw : 0.0f);
+                h2kb[lane * HB + u] = h2k[u];
+            }
+        }
+    }
+    // ... and the head's parameter gradients of the chunk: dW_hid as 16 x 16 x 4 MFMAs over the time steps (A = dL/dpre, B = q_a(h)), the
+    // vectors with lane = unit (lanes 32 .. 37: fc_out's feature columns)
+    __device__ __forceinline__ void dg_reduce(int t0, int len) {
+#pragma unroll
+        for (int kk = 0; kk < C / 4; ++kk) {
+            float av[NB], bv[NB];
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) { av[ob] = dpreb[(4 * kk + role) * HB + 16 * ob + col]; bv[ob] = h2kb[(4 * kk + role) * HB + 16 * ob + col]; }
+#pragma unroll
+            for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NB; ++nt) thid[mt][nt] = mfma4(av[mt], bv[nt], thid[mt][nt]);
+        }
+        const int fslot = lane - 32;
+        const bool isu = lane < HB, isf = fslot >= 0 && fslot < 6;
+        if (isu || isf) {
+            for (int tt = 0; tt < len; ++tt) {
+                const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * (t0 + tt));
+                const float a = isu ? hokb[tt * HB + lane] : fq[(t0 + tt) * FQ + 8 + fslot];
+                dg_w0 = __builtin_fmaf(dyv.x, a, dg_w0); dg_w1 = __builtin_fmaf(dyv.y, a, dg_w1);
+                if (isu) dg_bh += dpreb[tt * HB + lane];
+            }
+        }
+    }
+
     // forward chunk c: quantised features with lane = time step, the cell state kept, the recurrence, fc_out with lane = time step
     template <typename Sink>
     __device__ __forceinline__ void fwd_chunk(int c, int t0, int len, const float2* xg, Sink sink) {
         fbase = ring ? t0 : 0;
-        if (lane < len) reinterpret_cast<float4*>(fq)[t0 + lane - fbase] = features(xg[t0 + lane]);
+        if (lane < len) put_features(fq + (t0 + lane - fbase) * FQ, xg[t0 + lane]);
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) ck[((ring ? 0 : c) * NB + ob) * 64 + lane] = h[ob];
         wave_lds_fence();
         int hq_ = hp0;
         for (int tt = 0; tt < len; ++tt) { step<false>(t0 + tt, 0, hq_); hq_ += hp_step; }
         wave_lds_fence();
-        if (lane < len) {
+        if constexpr (DG) dg_head<false>(t0, len, sink);
+        else if (lane < len) {
             const float* hv = hist + (lane + 1) * HB;
             float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
@@ -252,6 +361,11 @@ struct QatSeq {
             for (int tt = 0; tt < len; ++tt) { step<true>(t0 + tt, sp, hq_); sp += svp_step; hq_ += hp_step; }
         }
         wave_lds_fence();
+        if constexpr (DG) {
+            dg_head<true>(t0, len, [](int, float, float) {});
+            wave_lds_fence();
+            dg_reduce(t0, len);
+        }
         for (int tt = len - 1; tt >= 0; --tt) {
             const float2 dyv = *reinterpret_cast<const float2*>(dyb + 2 * (t0 + tt));
             dbo0 += dyv.x; dbo1 += dyv.y;
@@ -263,8 +377,12 @@ struct QatSeq {
                             B1 = s[8 * HB], B2A = s[9 * HB], hok = s[12 * HB], pho = s[13 * HB];
                 hqk[ob] = s[HB]; pph[ob] = s[10 * HB];
                 // head (head_bwd): fc_out's parameter gradients, dL/dh' through the activation quantiser's pass mask (carrying s_ow)
-                dwo0[ob] = __builtin_fmaf(dyv.x, hok, dwo0[ob]); dwo1[ob] = __builtin_fmaf(dyv.y, hok, dwo1[ob]);
-                const float g = gh[ob] + (dyv.x * wo0[ob] + dyv.y * wo1[ob]) * pho;
+                float g;
+                if constexpr (DG) g = gh[ob] + headg[tt * HB + 16 * ob + col];      // (dg_head: W_hid^T dL/dpre through fc_hid's activation mask)
+                else {
+                    dwo0[ob] = __builtin_fmaf(dyv.x, hok, dwo0[ob]); dwo1[ob] = __builtin_fmaf(dyv.y, hok, dwo1[ob]);
+                    g = gh[ob] + (dyv.x * wo0[ob] + dyv.y * wo1[ob]) * pho;
+                }
                 const float g2 = g * c2, g3 = g * c3;
                 const float dz = g2 * hp_ - g3 * n;
                 const float da = g3 * (1.0f - z) * An;
@@ -284,8 +402,12 @@ struct QatSeq {
                 gh[ob] = dhdir[ob] + ddh * pph[ob];
             }
             // weight gradients on grid-unit operands: (d_r | d_z | d_hn) x q_a(h), (d_r | d_z | d_n) x (q_a(features) | 1 / s_xa)
-            const float4 f4 = reinterpret_cast<const float4*>(fq)[t0 + tt];
-            const float fsx = col == 0 ? f4.x : col == 1 ? f4.y : (col == 2 && F > 2) ? f4.z : (col == 3 && F > 3) ? f4.w : (col == F ? k.inv_xa : 0.0f);
+            float fsx;
+            if constexpr (DG) fsx = col < F ? fq[(t0 + tt) * FQ + col] : (col == F ? k.inv_xa : 0.0f);
+            else {
+                const float4 f4 = reinterpret_cast<const float4*>(fq)[t0 + tt];
+                fsx = col == 0 ? f4.x : col == 1 ? f4.y : (col == 2 && F > 2) ? f4.z : (col == 3 && F > 3) ? f4.w : (col == F ? k.inv_xa : 0.0f);
+            }
 #pragma unroll
             for (int ob = 0; ob < NB; ++ob) {
 #pragma unroll
@@ -305,10 +427,30 @@ struct QatSeq {
         for (int ob = 0; ob < NB; ++ob) {
             const int o = 16 * ob + col;
             if (vo[ob] && role == 0) {
-                prow[L.o_wo + o] = dwo0[ob] * k.s_oa * qpass(pl[L.o_wo + o], wq.o);
-                prow[L.o_wo + L.OW + o] = dwo1[ob] * k.s_oa * qpass(pl[L.o_wo + L.OW + o], wq.o);
+                if constexpr (!DG) {
+                    prow[L.o_wo + o] = dwo0[ob] * k.s_oa * qpass(pl[L.o_wo + o], wq.o);
+                    prow[L.o_wo + L.OW + o] = dwo1[ob] * k.s_oa * qpass(pl[L.o_wo + L.OW + o], wq.o);
+                }
                 prow[L.o_bh + 2 * H + o] = dbhn[ob];
             }
+        }
+        if constexpr (DG) {
+            const int fslot = lane - 32;
+            const int oc = lane < HB ? (lane < H ? lane : -1) : ((fslot >= 0 && fslot < 6) ? H + fslot : -1);      // fc_out column of the lane: unit | feature slot
+            if (oc >= 0) {
+                prow[L.o_wo + oc] = dg_w0 * k.s_oa * qpass(pl[L.o_wo + oc], wq.o);
+                prow[L.o_wo + L.OW + oc] = dg_w1 * k.s_oa * qpass(pl[L.o_wo + L.OW + oc], wq.o);
+                if (oc < H) prow[L.o_bhid + oc] = dg_bh;
+            }
+#pragma unroll
+            for (int mt = 0; mt < NB; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NB; ++nt)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int mrow = 16 * mt + 4 * role + rr, ucol = 16 * nt + col;
+                        if (mrow < H && ucol < H) { const int j = L.o_whid + mrow * H + ucol; prow[j] = thid[mt][nt][rr] * k.s_hida * qpass(pl[j], wq.hid); }
+                    }
         }
         if (lane == 0) { prow[L.o_bo] = dbo0; prow[L.o_bo + 1] = dbo1; prow[L.P] = loss; }
         // MFMA block g = gate g (r, z, n); register 4 g + rr of lane l = entry (4 (l / 16) + rr, l % 16) of the block

@@ -245,7 +245,8 @@ int qat_casc_launch(hipStream_t st, const odpd_model_t* dpd, int pv, bool dgp, i
 // evaluation passes of the quantised models on the one-sequence-per-wave engines: no checkpoints asked for, every sequence on a SIMD of its own
 bool qat_uses_gp_eval(const odpd_model_t* m, int B, bool want_ckpt) {
     if (want_ckpt || m->bits_w <= 0 || m->bits_a <= 0 || m->hidden < 1 || m->hidden > (m->backbone == ODPD_TRES_DELTAGRU ? 16 : 32) || tuning().gp_max_batch == 0 || tuning().s16_min_batch == 0) return false;
-    if (m->backbone != ODPD_GRU && m->backbone != ODPD_QGRU && m->backbone != ODPD_QGRU_AMP1 && m->backbone != ODPD_TRES_DELTAGRU) return false;
+    if (m->backbone != ODPD_GRU && m->backbone != ODPD_QGRU && m->backbone != ODPD_QGRU_AMP1 && m->backbone != ODPD_TRES_DELTAGRU && m->backbone != ODPD_DGRU)
+        return false;
     return B <= 2 * device_cus();
 }
 namespace {
@@ -271,7 +272,7 @@ int qat_gp_eval(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
             return lut ? qat_eval_launch<q16::QatSeq<MK_, true, 2>, false>(st, m, a, P) : qat_eval_launch<q16::QatSeq<MK_, false, 2>, false>(st, m, a, P); \
         return lut ? qat_eval_launch<q16::QatSeq<MK_, true, 1>, false>(st, m, a, P) : qat_eval_launch<q16::QatSeq<MK_, false, 1>, false>(st, m, a, P); \
     }
-    ODPD_QAT_EVAL(ODPD_GRU, q16::K_GRU) ODPD_QAT_EVAL(ODPD_QGRU, q16::K_Q4) ODPD_QAT_EVAL(ODPD_QGRU_AMP1, q16::K_A4)
+    ODPD_QAT_EVAL(ODPD_GRU, q16::K_GRU) ODPD_QAT_EVAL(ODPD_QGRU, q16::K_Q4) ODPD_QAT_EVAL(ODPD_QGRU_AMP1, q16::K_A4) ODPD_QAT_EVAL(ODPD_DGRU, q16::K_DGRU)
 #undef ODPD_QAT_EVAL
     return ODPD_EUNSUPPORTED;
 }
@@ -295,7 +296,7 @@ int64_t qat_with_engine(const odpd_model_t* m, Fn&& f) {
             return lut ? f(QatEngine<q16::QatSeq<MK_, true, 2>, false>{}, P) : f(QatEngine<q16::QatSeq<MK_, false, 2>, false>{}, P); \
         return lut ? f(QatEngine<q16::QatSeq<MK_, true, 1>, false>{}, P) : f(QatEngine<q16::QatSeq<MK_, false, 1>, false>{}, P);     \
     }
-    ODPD_QAT_ENGINE(ODPD_GRU, q16::K_GRU) ODPD_QAT_ENGINE(ODPD_QGRU, q16::K_Q4) ODPD_QAT_ENGINE(ODPD_QGRU_AMP1, q16::K_A4)
+    ODPD_QAT_ENGINE(ODPD_GRU, q16::K_GRU) ODPD_QAT_ENGINE(ODPD_QGRU, q16::K_Q4) ODPD_QAT_ENGINE(ODPD_QGRU_AMP1, q16::K_A4) ODPD_QAT_ENGINE(ODPD_DGRU, q16::K_DGRU)
 #undef ODPD_QAT_ENGINE
     return ODPD_EUNSUPPORTED;
 }

@@ -286,13 +286,83 @@ def test_fused_train_step_equals_the_split_chain(bb, H, bits, B, T):
 
 @pytest.mark.parametrize("bb,H,bits,B,T", [("qgru", 10, 8, 64, 50), ("qgru", 20, 8, 37, 41), ("gru", 11, 8, 5, 66), ("gru", 30, 16, 9, 40),
                                             ("qgru_amp1", 16, 16, 33, 20), ("qgru_amp1", 10, 8, 256, 200),
-                                            ("deltagru_tcnskip", 15, 8, 64, 200), ("deltagru_tcnskip", 9, 16, 7, 35), ("deltagru_tcnskip", 16, 8, 300, 33)])
+                                            ("deltagru_tcnskip", 15, 8, 64, 200), ("deltagru_tcnskip", 9, 16, 7, 35), ("deltagru_tcnskip", 16, 8, 300, 33),
+                                            ("dgru", 13, 8, 19, 33), ("dgru", 13, 8, 256, 200), ("dgru", 23, 8, 64, 50), ("dgru", 16, 16, 33, 20), ("dgru", 32, 8, 7, 70),
+                                            ("dgru", 1, 8, 3, 5), ("dgru", 17, 16, 5, 131)])
 def test_one_launch_train_step_at_the_reference_batch_sizes(bb, H, bits, B, T):
     """train_pa --quant at the reference's batch sizes: the whole step body (forward, loss, backward) of a quantised model is ONE launch with
     one frame per wave (csrc/qat_cascade.hip qat_gp_train_kernel; no checkpoint scratch) — same loss, gradients and sparsity counters as
-    autograd through the split kernels; quantised dgru has no such engine and keeps the two-launch step."""
+    autograd through the split kernels.  dgru (r04): its fc_hid + relu + cat + fc_out head runs with lane = time step inside the engine
+    (odpd_qatseq.h dg_head / dg_reduce)."""
     _fused_equals_split(bb, H, bits, B, T, True)
 
 
-def test_quantised_dgru_keeps_the_two_launch_step():
-    _fused_equals_split("dgru", 13, 8, 19, 33, False)
+@pytest.mark.parametrize("H,bits,B,T", [(13, 8, 64, 50), (8, 8, 33, 21), (23, 8, 18, 35), (30, 8, 3, 70), (16, 8, 256, 200), (21, 16, 9, 40)])
+def test_dgru_one_launch_step_matches_the_oracle(H, bits, B, T):
+    """The quantised dgru engine's train step (loss + gradients of one launch) against the ORACLE, with biases, weights and scales moved off
+    their defaults so that clamps, relu and every pass mask of the fc_hid / fc_out head are exercised; then an evaluation pass on the same
+    engine (bit for bit on 8-bit grids)."""
+    import ctypes as C
+    from opendpd_amd import _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H + B + T)
+    q = _fresh("dgru", H, bits).cuda()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(H)
+        for k, p in q.named_parameters():
+            if k.endswith("bias"):
+                p.copy_(((torch.rand(p.shape, generator=g) - 0.5) * 0.6).cuda())
+            elif k.endswith("weight") and p.dim() == 2:
+                p.mul_(1.7)
+        q.backbone.fc_hid.act_quantizer.scale.mul_(0.5)         # states beyond fc_hid's activation range
+        q.backbone.fc_out.act_quantizer.scale.mul_(0.5)
+    x, t = _signal(B, T, B + T)
+    o = Oracle("f32")
+    m = make_model("dgru", H, bits_w=bits, bits_a=bits)
+    p = np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in q.parameters()])
+    q.train()
+    assert int(_lib.load().odpd_train_workspace_floats(C.byref(q.backbone.desc), B, T)) == 0      # the one-launch step
+    yo = o.qat_forward(m, p, x)
+    lo, dy = o.loss("l2", yo, t)
+    go, _ = o.qat_backward(m, p, x, dy, need_dx=False)
+    opt = FusedAdamW(q, lr=0.0, weight_decay=0.0)
+    lf = fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), "l2", 0.0)
+    assert abs(lf.item() - lo) < (2e-6 if bits == 8 else 2e-4) * max(1.0, abs(lo))
+    got = opt.grad[:-4].cpu().numpy()
+    off = 0
+    for k, v in q.named_parameters():
+        n = v.numel()
+        ref = go[off:off + n]
+        if np.abs(ref).max() > 0:
+            assert rel_err(got[off:off + n], ref) < (3e-5 if bits == 8 else 2e-3), k
+        else:
+            assert np.abs(got[off:off + n]).max() == 0, k
+        off += n
+    whid = q.backbone.fc_hid.weight.detach().cpu().numpy()
+    names = [k for k, _ in q.named_parameters()]
+    sizes = [v.numel() for v in q.parameters()]
+    o_hid = int(np.sum(sizes[:names.index("backbone.fc_hid.weight")]))
+    ghid = got[o_hid:o_hid + whid.size].reshape(whid.shape)
+    lim = 2.0 ** (bits - 1) * 2.0 ** (2 - bits)
+    assert np.all(ghid[np.abs(whid) > lim] == 0.0) and np.abs(ghid).max() > 0
+    q.eval()
+    with torch.no_grad():
+        ye = q(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = o.qat_forward(m, p, x, eval_mode=True)
+    # (16-bit grids: 32-bit products summed in fp32 — the summation order decides single roundings, and with the scales moved as above a few of
+    # them travel through fc_hid and fc_out: measured 6.1e-4 at most, the same for the sixteen-sequences-per-wave kernels, which the engine
+    # matches bit for bit)
+    assert np.abs(ye - ref).max() <= (0.0 if bits == 8 else 2.0 ** -10)
+    lib = _lib.load()
+    lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(0))
+    try:
+        with torch.no_grad():
+            ys = q(torch.from_numpy(x).cuda()).cpu().numpy()
+    finally:
+        lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(-1))
+    assert np.array_equal(ye, ys)
+
+
+def test_quantised_dgru_beyond_one_frame_per_simd_keeps_the_two_launch_step():
+    _fused_equals_split("dgru", 13, 8, 600, 9, False)
