@@ -358,8 +358,7 @@ extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss
 // DPDs of the one-launch cascade step: the float GRU family, the float delta-GRU backbones and the plain LSTM (gru_cascade.hip)
 static bool cascade_dpd_family(const odpd_model_t* m) {
     return family_of(m) == FAM_GRU || (family_of(m) == FAM_DELTA && m->backbone != ODPD_DELTAJANET) || m->backbone == ODPD_LSTM ||
-           (family_of(m) == FAM_QAT && (m->backbone == ODPD_GRU || m->backbone == ODPD_QGRU || m->backbone == ODPD_QGRU_AMP1 ||
-                                        m->backbone == ODPD_TRES_DELTAGRU));
+           family_of(m) == FAM_QAT;      // (every quantised kind: gru, dgru, qgru, qgru_amp1, deltagru_tcnskip)
 }
 extern "C" int64_t odpd_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T) {
     if (!model_ok(dpd) || !model_ok(pa) || B <= 0 || T <= 0) return ODPD_EINVAL;

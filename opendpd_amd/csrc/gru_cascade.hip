@@ -203,7 +203,8 @@ bool casc_cfg(const odpd_model_t* dpd, const odpd_model_t* pa, CascCfg& c) {
     if (!casc_model(pa, c.fmp, c.dgp)) return false;
     const bool delta = dpd->bits_w == 0 && (dpd->backbone == ODPD_DELTAGRU || dpd->backbone == ODPD_TRES_DELTAGRU);
     const bool lstm = dpd->bits_w == 0 && dpd->backbone == ODPD_LSTM;
-    const bool qat = dpd->bits_w > 0 && dpd->bits_a > 0 && (dpd->backbone == ODPD_GRU || dpd->backbone == ODPD_QGRU || dpd->backbone == ODPD_QGRU_AMP1);
+    const bool qat = dpd->bits_w > 0 && dpd->bits_a > 0 &&
+                     (dpd->backbone == ODPD_GRU || dpd->backbone == ODPD_QGRU || dpd->backbone == ODPD_QGRU_AMP1 || dpd->backbone == ODPD_DGRU);
     const bool qtres = dpd->bits_w > 0 && dpd->bits_a > 0 && dpd->backbone == ODPD_TRES_DELTAGRU;
     if (delta) { c.fmd = dpd->backbone == ODPD_TRES_DELTAGRU ? kDpdTres : kDpdDelta; c.dgd = false; }
     else if (lstm) { c.fmd = kDpdLstm; c.dgd = false; }

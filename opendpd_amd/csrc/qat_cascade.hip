@@ -178,7 +178,7 @@ struct QSel { int mk, nbd; bool lut, tres; };
 QSel qsel(const odpd_model_t* m) {
     QSel s;
     s.tres = m->backbone == ODPD_TRES_DELTAGRU;
-    s.mk = s.tres ? q16::K_TRES : m->backbone == ODPD_GRU ? q16::K_GRU : m->backbone == ODPD_QGRU ? q16::K_Q4 : q16::K_A4;
+    s.mk = s.tres ? q16::K_TRES : m->backbone == ODPD_GRU ? q16::K_GRU : m->backbone == ODPD_QGRU ? q16::K_Q4 : m->backbone == ODPD_DGRU ? q16::K_DGRU : q16::K_A4;
     s.nbd = m->hidden > 16 ? 2 : 1;
     s.lut = m->bits_w <= 8 && m->bits_a <= 8;
     return s;
@@ -211,6 +211,7 @@ size_t qat_casc_lds_bytes(const odpd_model_t* dpd, int pv, bool dgp, int T, int 
     if (s.tres) return s.lut ? lds_of<q16::QatDeltaSeq<true>>(pv, dgp, T, Pd, Pp) : lds_of<q16::QatDeltaSeq<false>>(pv, dgp, T, Pd, Pp);
     if (s.mk == q16::K_GRU) return lds_kind<q16::K_GRU>(s, pv, dgp, T, Pd, Pp);
     if (s.mk == q16::K_Q4) return lds_kind<q16::K_Q4>(s, pv, dgp, T, Pd, Pp);
+    if (s.mk == q16::K_DGRU) return lds_kind<q16::K_DGRU>(s, pv, dgp, T, Pd, Pp);
     return lds_kind<q16::K_A4>(s, pv, dgp, T, Pd, Pp);
 }
 int qat_casc_launch(hipStream_t st, const odpd_model_t* dpd, int pv, bool dgp, int grid, const CascArgs& a, int Pp) {
@@ -226,7 +227,7 @@ int qat_casc_launch(hipStream_t st, const odpd_model_t* dpd, int pv, bool dgp, i
         if (s.nbd == 1) { if (s.lut) { ODPD_QAT_ALLPA(MK_, true, 1) } else { ODPD_QAT_ALLPA(MK_, false, 1) } } \
         else { if (s.lut) { ODPD_QAT_ALLPA(MK_, true, 2) } else { ODPD_QAT_ALLPA(MK_, false, 2) } }  \
     }
-    ODPD_QAT_KIND(q16::K_GRU) ODPD_QAT_KIND(q16::K_Q4) ODPD_QAT_KIND(q16::K_A4)
+    ODPD_QAT_KIND(q16::K_GRU) ODPD_QAT_KIND(q16::K_Q4) ODPD_QAT_KIND(q16::K_A4) ODPD_QAT_KIND(q16::K_DGRU)
 #undef ODPD_QAT_KIND
 #undef ODPD_QAT_ALLPA
 #undef ODPD_QAT_PA
