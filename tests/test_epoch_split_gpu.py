@@ -15,6 +15,13 @@ def _net(bb, H, kw):
         from opendpd_amd.quant import get_quant_model
         net = get_quant_model(SimpleNamespace(quant=True, n_bits_w=8, n_bits_a=8, pretrained_model=""), CoreModel(2, H, 1, bb[:-4]))
         return net.cuda().train()
+    if bb.endswith(":l2"):            # two recurrent layers (csrc/gru_layers2.hip, lstm_layers2.hip)
+        return CoreModel(2, H, 2, bb[:-3], **kw).cuda()
+    if bb.endswith(":w8a8"):          # quantised head behind a float recurrence (heads-only surgery)
+        from types import SimpleNamespace
+        from opendpd_amd.quant import get_quant_model
+        net = get_quant_model(SimpleNamespace(quant=True, n_bits_w=8, n_bits_a=8, pretrained_model=""), CoreModel(2, H, 1, bb[:-5]))
+        return net.cuda().train()
     return CoreModel(2, H, 1, bb, **kw).cuda()
 
 
@@ -34,6 +41,15 @@ def test_split_epoch_loop_equals_the_python_driven_steps(bb, H, kw, opt_kind):
         _split_epoch_case(bb, H, kw, opt_kind)
     finally:
         _lib.load().odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
+
+
+@pytest.mark.parametrize("bb,H,kw", [("gru", 48, {}), ("dgru", 40, {}), ("lstm", 40, {}), ("vdlstm", 35, {}), ("deltagru", 40, dict(thx=0.01, thh=0.03)),
+                                     ("deltagru_tcnskip", 33, dict(thx=0.01, thh=0.02)), ("deltajanet", 64, {}), ("pgjanet", 24, {}),
+                                     ("dgru:l2", 13, {}), ("lstm:l2", 20, {}), ("deltajanet:w8a8", 12, {}), ("lstm:w8a8", 24, {})])
+def test_split_epoch_loop_serves_the_lane_per_unit_and_two_layer_kernels(bb, H, kw):
+    """The r04 kernels beyond the tile envelope (hidden 33 .. 64, pgjanet 17 .. 32, two layers, quantised heads on the split chain) have no
+    fused step: their epochs run from the native split loop — same parameters, losses and sparsity counters as the Python-driven steps."""
+    _split_epoch_case(bb, H, kw, "adamw")
 
 
 def _split_epoch_case(bb, H, kw, opt_kind):
