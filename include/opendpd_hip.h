@@ -70,7 +70,9 @@ typedef struct odpd_model {
                          > 0 on lstm / vdlstm: the surgery finds only their nn.Linear heads to swap (quant_envs.py:40-60) — float nn.LSTM core,
                          fc_out (vdlstm: fc_lambda_1, fc_lambda_2, fc_out) as INT_Linear, three scale parameters behind each head's weight and bias;
                          > 0 on deltajanet (hidden <= 64): likewise — the cell's gates are nn.Parameter tensors (deltajanet.py:100-113), fc_out becomes
-                         INT_Linear, three scales behind fc_out.bias;
+                         INT_Linear, three scales behind fc_out.bias; > 0 on neuraltx: IQ_match (the one nn.Linear; the Conv1d layers are not in the
+                         surgery's layer map, quant_envs.py:145-148) becomes a bias-free INT_Linear, three scales behind IQ_match.weight, no
+                         output quantiser in either mode (no module is named fc_out);
                          dvrjanet: num_dvr_units (models.py:119) */
     int32_t bits_a;   /* QAT activation bits */
     int32_t flags;    /* ODPD_FLAG_* */

@@ -121,7 +121,7 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_DELTAJANET: return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2 + (m->bits_w > 0 ? 3 : 0);      // two gates (deltajanet.py:96-111) + fc_out (bits_w > 0: INT_Linear, + three scales)
     case ODPD_TCNN: return 6 * H + H + 4 * 5 * H + 2 * H;
     case ODPD_PGJANET: return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
-    case ODPD_NEURALTX: return H <= 64 ? 27 * H + 14 : (int64_t)ODPD_EUNSUPPORTED;   // two 5-tap FIRs, 4->C (+bias), 4 x depthwise k5, C->2, IQ_match 2x2
+    case ODPD_NEURALTX: return H <= 64 ? 27 * H + 14 + (m->bits_w > 0 ? 3 : 0) : (int64_t)ODPD_EUNSUPPORTED;   // two 5-tap FIRs, 4->C (+bias), 4 x depthwise k5, C->2, IQ_match 2x2 (bits_w > 0: INT_Linear, + three scales)
     case ODPD_GMP: return H == 11 ? H * (1 + 4 * H) : (int64_t)ODPD_EUNSUPPORTED;   // memory_length 11, degree 5 (models.py:26-28)
     case ODPD_DVRJANET: return dvrjanet_param_count(m);   // K + 7H^2 + 7H + 2, K = bits_w (dvrjanet.py:11-30, 47-52)
     case ODPD_MCLDNN: return mcldnn_param_count(m);       // 190C + 589 (mcldnn.py:21-27)

@@ -27,11 +27,14 @@
 #include <utility>
 
 #include "odpd_seq.h"
+#include "odpd_quant.h"
 
 namespace odpd {
 
 struct TcnnLayout { int C, F, o_ci, o_cq, o_w0, o_b0, o_dw[4], o_w5, o_m, P; };
-__host__ __device__ inline TcnnLayout tcnn_layout(int C, bool ntx = false) {
+// qh: `--quant` on neuraltx — IQ_match is an INT_Linear (the one layer the surgery's Conv2d / Linear map finds, quant_envs.py:145-148):
+// its weight, activation and (never used: no module is named fc_out) output scales behind IQ_match.weight
+__host__ __device__ inline TcnnLayout tcnn_layout(int C, bool ntx = false, bool qh = false) {
     TcnnLayout L; L.C = C; L.F = ntx ? 4 : 6; int o = 0;
     L.o_ci = o; L.o_cq = o + 5;
     if (ntx) o += 10;                                     // conv_I.weight, conv_Q.weight (neuraltx.py:18-19)
@@ -40,6 +43,7 @@ __host__ __device__ inline TcnnLayout tcnn_layout(int C, bool ntx = false) {
     L.o_w5 = o; o += 2 * C;
     L.o_m = o;
     if (ntx) o += 4;                                      // IQ_match.weight (2,2) (neuraltx.py:38)
+    if (ntx && qh) o += 3;
     L.P = o;
     return L;
 }
@@ -125,13 +129,24 @@ __device__ __forceinline__ TcnnChan tcnn_chan(const float* __restrict__ p, const
 }
 
 // NeuralTX parameters outside the channel stack (wave-uniform)
-struct NtxFir { float ci[5], cq[5], m[4]; };
-__device__ __forceinline__ NtxFir ntx_fir(const float* __restrict__ p, const TcnnLayout& L) {
+// q (bits_w > 0): m = q_w(IQ_match.weight), mm = the weight quantiser's pass mask, qa = IQ_match's activation quantiser
+struct NtxFir { float ci[5], cq[5], m[4], mm[4]; q16::Quant qa; bool q; };
+__device__ __forceinline__ NtxFir ntx_fir(const float* __restrict__ p, const TcnnLayout& L, int bits_w, int bits_a) {
     NtxFir f;
 #pragma unroll
     for (int k = 0; k < 5; ++k) { f.ci[k] = p[L.o_ci + k]; f.cq[k] = p[L.o_cq + k]; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) f.m[k] = p[L.o_m + k];
+    for (int k = 0; k < 4; ++k) { f.m[k] = p[L.o_m + k]; f.mm[k] = 1.0f; }
+    f.q = bits_w > 0;
+    f.qa = q16::Quant{1.0f, 1.0f, 0.0f, 0.0f};
+    if (f.q) {      // (wave-uniform values formed on the VALU: moved to scalar registers, the hot loops are register-bound)
+        auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+        const q16::Quant qw = q16::make_quant(p[L.o_m + 4], bits_w);
+        const q16::Quant qa = q16::make_quant(p[L.o_m + 5], bits_a);
+        f.qa = q16::Quant{uni(qa.s), uni(qa.inv), uni(qa.qn), uni(qa.qp)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f.mm[k] = uni(q16::qpass(f.m[k], qw)); f.m[k] = uni(q16::qapply(f.m[k], qw)); }
+    }
     return f;
 }
 
@@ -224,12 +239,12 @@ template <int R, bool NTX>
 __global__ __launch_bounds__(256) void tcnn_fwd_kernel(SeqArgs a, TcnnGeom g, int ncw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const TcnnLayout L = tcnn_layout(a.H, NTX);
+    const TcnnLayout L = tcnn_layout(a.H, NTX, NTX && a.bits_w > 0);
     const int gw = blockIdx.x * 4 + wave, grp = gw / ncw, cs = gw % ncw;
     TcnnTile<R, NTX> tl;
     tl.locate(a, g, grp, grp < g.ngroups, lane);
     NtxFir fir;
-    if constexpr (NTX) fir = ntx_fir(a.params, L);
+    if constexpr (NTX) fir = ntx_fir(a.params, L, a.bits_w, a.bits_a);
     tl.load_x(a, &fir);
     float y0[R], y1[R];
 #pragma unroll
@@ -261,8 +276,9 @@ __global__ __launch_bounds__(256) void tcnn_fwd_kernel(SeqArgs a, TcnnGeom g, in
     for (int i = 0; i < R; ++i)
         if (tl.owns(i)) {
             if constexpr (NTX) {      // + IQ_match f + f (neuraltx.py:135)
-                const float r0 = __builtin_fmaf(fir.m[0], tl.xi[i], __builtin_fmaf(fir.m[1], tl.xq[i], tl.xi[i]));
-                const float r1 = __builtin_fmaf(fir.m[2], tl.xi[i], __builtin_fmaf(fir.m[3], tl.xq[i], tl.xq[i]));
+                const float fi = fir.q ? q16::qapply(tl.xi[i], fir.qa) : tl.xi[i], fq = fir.q ? q16::qapply(tl.xq[i], fir.qa) : tl.xq[i];
+                const float r0 = __builtin_fmaf(fir.m[0], fi, __builtin_fmaf(fir.m[1], fq, tl.xi[i]));
+                const float r1 = __builtin_fmaf(fir.m[2], fi, __builtin_fmaf(fir.m[3], fq, tl.xq[i]));
                 y2[tl.t0 + i] = make_float2(y0[i] + r0, y1[i] + r1);
             } else {
                 y2[tl.t0 + i] = make_float2(y0[i] + tl.xi[i], y1[i] + tl.xq[i]);     // + residual [I, Q]
@@ -311,9 +327,9 @@ template <int R, bool NTX>
 __global__ __launch_bounds__(256, (R <= 8 || (R <= 13 && !NTX)) ? 2 : 1) void tcnn_bwd_kernel(SeqArgs a, TcnnGeom g, int ncw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15;
-    const TcnnLayout L = tcnn_layout(a.H, NTX);
+    const TcnnLayout L = tcnn_layout(a.H, NTX, NTX && a.bits_w > 0);
     NtxFir fir;
-    if constexpr (NTX) fir = ntx_fir(a.params, L);
+    if constexpr (NTX) fir = ntx_fir(a.params, L, a.bits_w, a.bits_a);
     const int Pp = pad4(L.P);
     float* row = smem + wave * Pp;
     float2* dyl = reinterpret_cast<float2*>(smem + 4 * Pp) + wave * (R * 64) + lane;
@@ -396,10 +412,15 @@ __global__ __launch_bounds__(256, (R <= 8 || (R <= 13 && !NTX)) ? 2 : 1) void tc
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const float2 dy = cs == 0 ? dyl[i * 64] : make_float2(0.0f, 0.0f);
-                gm[0] = __builtin_fmaf(dy.x, tl.xi[i], gm[0]); gm[1] = __builtin_fmaf(dy.x, tl.xq[i], gm[1]);
-                gm[2] = __builtin_fmaf(dy.y, tl.xi[i], gm[2]); gm[3] = __builtin_fmaf(dy.y, tl.xq[i], gm[3]);
-                const float d4[4] = {dfa[0][i] + __builtin_fmaf(dy.x, fir.m[0], __builtin_fmaf(dy.y, fir.m[2], dy.x)),
-                                     dfa[1][i] + __builtin_fmaf(dy.x, fir.m[1], __builtin_fmaf(dy.y, fir.m[3], dy.y)), dfa[2][i], dfa[3][i]};
+                const float fi = fir.q ? q16::qapply(tl.xi[i], fir.qa) : tl.xi[i], fq = fir.q ? q16::qapply(tl.xq[i], fir.qa) : tl.xq[i];
+                gm[0] = __builtin_fmaf(dy.x, fi, gm[0]); gm[1] = __builtin_fmaf(dy.x, fq, gm[1]);
+                gm[2] = __builtin_fmaf(dy.y, fi, gm[2]); gm[3] = __builtin_fmaf(dy.y, fq, gm[3]);
+                float d4[4] = {dfa[0][i] + __builtin_fmaf(dy.x, fir.m[0], __builtin_fmaf(dy.y, fir.m[2], dy.x)),
+                               dfa[1][i] + __builtin_fmaf(dy.x, fir.m[1], __builtin_fmaf(dy.y, fir.m[3], dy.y)), dfa[2][i], dfa[3][i]};
+                if (fir.q) {      // dL/df through IQ_match's activation quantiser: its pass mask on the INT_Linear share only
+                    d4[0] = dfa[0][i] + __builtin_fmaf(q16::qpass(tl.xi[i], fir.qa), __builtin_fmaf(dy.x, fir.m[0], dy.y * fir.m[2]), dy.x);
+                    d4[1] = dfa[1][i] + __builtin_fmaf(q16::qpass(tl.xq[i], fir.qa), __builtin_fmaf(dy.x, fir.m[1], dy.y * fir.m[3]), dy.y);
+                }
                 float dI, dQ;
                 feat_bwd<FEAT_A4>(tl.xi[i], tl.xq[i], d4, dI, dQ);
                 gI[i] = tl.valid[i] ? dI : 0.0f; gQ[i] = tl.valid[i] ? dQ : 0.0f; nI[i] = -gI[i];
@@ -412,7 +433,7 @@ __global__ __launch_bounds__(256, (R <= 8 || (R <= 13 && !NTX)) ? 2 : 1) void tc
             float depA = 0.0f, depB = 0.0f;
             static_for<5>([&](auto jc) { tcnn_deposit<decltype(jc)::value>(gci[decltype(jc)::value], r, depA, depB); });
             static_for<5>([&](auto jc) { tcnn_deposit<5 + decltype(jc)::value>(gcq[decltype(jc)::value], r, depA, depB); });
-            static_for<4>([&](auto jc) { tcnn_deposit<10 + decltype(jc)::value>(gm[decltype(jc)::value], r, depA, depB); });
+            static_for<4>([&](auto jc) { tcnn_deposit<10 + decltype(jc)::value>(gm[decltype(jc)::value] * fir.mm[decltype(jc)::value], r, depA, depB); });
             const int col = r < 10 ? L.o_ci + r : L.o_m + (r < 14 ? r - 10 : 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -430,13 +451,13 @@ template <int R, bool NTX>
 __global__ __launch_bounds__(256, 1) void tcnn_dx_kernel(SeqArgs a, TcnnGeom g, int ncw) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const TcnnLayout L = tcnn_layout(a.H, NTX);
+    const TcnnLayout L = tcnn_layout(a.H, NTX, NTX && a.bits_w > 0);
     constexpr int F = NTX ? 4 : 6;
     const int gw = blockIdx.x * 4 + wave, grp = gw / ncw, cs = gw % ncw;
     TcnnTile<R, NTX> tl;
     tl.locate(a, g, grp, grp < g.ngroups, lane);
     NtxFir fir;
-    if constexpr (NTX) fir = ntx_fir(a.params, L);
+    if constexpr (NTX) fir = ntx_fir(a.params, L, a.bits_w, a.bits_a);
     tl.load_x(a, &fir);
     float dy0[R], dy1[R], df[F][R];
     {
@@ -486,8 +507,12 @@ __global__ __launch_bounds__(256, 1) void tcnn_dx_kernel(SeqArgs a, TcnnGeom g, 
         for (int k = 0; k < 5; ++k) nq[k] = -fir.cq[k];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const float d4[4] = {df[0][i] + __builtin_fmaf(dy0[i], fir.m[0], __builtin_fmaf(dy1[i], fir.m[2], dy0[i])),
-                                 df[1][i] + __builtin_fmaf(dy0[i], fir.m[1], __builtin_fmaf(dy1[i], fir.m[3], dy1[i])), df[2][i], df[3][i]};
+            float d4[4] = {df[0][i] + __builtin_fmaf(dy0[i], fir.m[0], __builtin_fmaf(dy1[i], fir.m[2], dy0[i])),
+                           df[1][i] + __builtin_fmaf(dy0[i], fir.m[1], __builtin_fmaf(dy1[i], fir.m[3], dy1[i])), df[2][i], df[3][i]};
+            if (fir.q) {
+                d4[0] = df[0][i] + __builtin_fmaf(q16::qpass(tl.xi[i], fir.qa), __builtin_fmaf(dy0[i], fir.m[0], dy1[i] * fir.m[2]), dy0[i]);
+                d4[1] = df[1][i] + __builtin_fmaf(q16::qpass(tl.xq[i], fir.qa), __builtin_fmaf(dy0[i], fir.m[1], dy1[i] * fir.m[3]), dy1[i]);
+            }
             float dI, dQ;
             feat_bwd<FEAT_A4>(tl.xi[i], tl.xq[i], d4, dI, dQ);
             gI[i] = tl.valid[i] ? dI : 0.0f; gQ[i] = tl.valid[i] ? dQ : 0.0f;
@@ -533,7 +558,7 @@ static TcnnBwdShape tcnn_bwd_shape(const TcnnGeom& g) {
 }
 template <int R, bool NTX>
 static int tcnn_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, int mode) {
-    const int P = tcnn_layout(m->hidden, NTX).P;
+    const int P = tcnn_layout(m->hidden, NTX, NTX && m->bits_w > 0).P;
     const int fir = NTX ? kNtxFir : 0;
     if (mode == 0) {
         const TcnnGeom g = tcnn_geom(a.B, a.T, kTHalo + fir);

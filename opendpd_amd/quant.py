@@ -216,6 +216,22 @@ class QuantHeadDeltaJANET(_QuantBase):
         return out
 
 
+class QuantHeadNeuralTX(_QuantBase):
+    """neuraltx after the surgery: its layer map holds nn.Conv2d and nn.Linear (quant_envs.py:145-148), so the Conv1d FIRs and the Conv1d /
+    Hardswish stack stay float and `IQ_match` becomes a bias-free INT_Linear.  No module is named fc_out: set_last_layer_quant (:276-284)
+    marks nothing, the 16-bit output quantiser exists (state dict, skipped by the optimiser) but never runs.  Kernels: csrc/tcnn.hip <.., NTX>
+    with the descriptor's bits_w > 0."""
+    backbone_name = "neuraltx"
+
+    def __init__(self, conv_I, conv_Q, network, bits_w, bits_a):
+        super().__init__()
+        C = self.hidden_channels = network[0].out_channels
+        self.in_channels, self.out_channels, self.kernel_size, self.window_size = 4, 2, 5, 5
+        self.conv_I, self.conv_Q, self.network = conv_I, conv_Q, network
+        self.IQ_match = _QLinear(2, 2, bits_w, bits_a, bias=False)
+        self._finish(C, bits_w, bits_a)
+
+
 class _QDeltaLayer(nn.Module):
     """DeltaGRULayer of deltagru_tcnskip.py:133-162 after the surgery: bias-free INT_Linear x2h / h2h, Quant_add / mult / sigmoid /
     tanh in the layer's own registration order."""
@@ -283,9 +299,11 @@ class QuantTResDeltaGRU(_QuantBase):
 
 MAX_HIDDEN = 32          # csrc/qat_s16.hip: two 16-unit tiles
 _UNTOUCHED = ("gmp", "tcnn")       # no nn.GRU, no nn.Linear, no op modules: the surgery returns an identical deep copy
-_PARTIAL = ("rvtdcnn", "apnrru", "bojanet", "dvrjanet", "neuraltx", "mcldnn", "pgjanet")
-_HEAD_ONLY = ("lstm", "vdlstm", "deltajanet")    # only nn.Linear heads to swap, and kernels with quantised heads exist
-_HEAD_MAX_HIDDEN = {"deltajanet": 64}            # csrc/deltajanet_wide.hip serves the quantised head at every hidden size it covers
+_PARTIAL = ("rvtdcnn", "apnrru", "bojanet", "dvrjanet", "mcldnn", "pgjanet")
+_HEAD_ONLY = ("lstm", "vdlstm", "deltajanet", "neuraltx")    # only nn.Linear heads to swap, and kernels with quantised heads exist
+_HEAD_MAX_HIDDEN = {"deltajanet": 64, "neuraltx": 64}        # csrc/deltajanet_wide.hip / csrc/tcnn.hip serve the quantised head at every size they cover
+_HEAD_LAYERS = {"lstm": ("fc_out",), "vdlstm": ("fc_lambda_1", "fc_lambda_2", "fc_out"), "deltajanet": ("fc_out",), "neuraltx": ("IQ_match",)}
+_FLOAT_CORE = {"neuraltx": ("conv_I", "conv_Q", "network")}   # (the others: "rnn")
 
 
 def _warn_float(exc, model):
@@ -304,7 +322,7 @@ def _wrap(model, bb, dev):
 
 
 def _quantise_heads(model, bits_w, bits_a, pre, dev):
-    """lstm / vdlstm / deltajanet: create_pygru_model finds no nn.GRU (no RNG draws), load_model strict-loads a float checkpoint of the model's own keys,
+    """lstm / vdlstm / deltajanet / neuraltx: create_pygru_model finds no nn.GRU (no RNG draws), load_model strict-loads a float checkpoint of the model's own keys,
     create_quantized_model swaps the nn.Linear heads in named_children order — each INT_Linear keeps the weight and draws a fresh
     default-init bias (quant_layers.py:48-56)."""
     import copy
@@ -317,15 +335,19 @@ def _quantise_heads(model, bits_w, bits_a, pre, dev):
                 raise RuntimeError("Error(s) in loading state_dict for CoreModel")
         except Exception as exc:
             return _warn_float(exc, model)
-    heads = ("fc_lambda_1", "fc_lambda_2", "fc_out") if model.backbone_type == "vdlstm" else ("fc_out",)
+    heads = _HEAD_LAYERS[model.backbone_type]
     with torch.no_grad():
-        rnn = copy.deepcopy(fb.rnn).cpu()
+        core = {c: copy.deepcopy(getattr(fb, c)).cpu() for c in _FLOAT_CORE.get(model.backbone_type, ("rnn",))}
         fc_w = {h: getattr(fb, h).weight.detach().cpu() for h in heads}
         if pre:
-            for k, p in rnn.named_parameters():
-                p.copy_(pre_sd["backbone.rnn." + k])
+            for c, mod in core.items():
+                for k, p in mod.named_parameters():
+                    p.copy_(pre_sd[f"backbone.{c}.{k}"])
             fc_w = {h: pre_sd[f"backbone.{h}.weight"] for h in heads}
-        if model.backbone_type == "deltajanet":
+        rnn = core.get("rnn")
+        if model.backbone_type == "neuraltx":
+            bb = QuantHeadNeuralTX(core["conv_I"], core["conv_Q"], core["network"], bits_w, bits_a)
+        elif model.backbone_type == "deltajanet":
             bb = QuantHeadDeltaJANET(rnn, bits_w, bits_a, model.thx, model.thh)
         else:
             bb = (QuantHeadVDLSTM if model.backbone_type == "vdlstm" else QuantHeadLSTM)(rnn, bits_w, bits_a)
@@ -342,8 +364,8 @@ def get_quant_model(proj, model):
     heads) and deltagru_tcnskip (its layer's Linears and op modules), one layer, hidden <= 32; gmp and tcnn contain nothing the surgery
     swaps (the reference hands back an identical copy: the model itself is returned).  deltagru's layer IS an nn.GRU subclass, the
     reference swaps it for a plain GRU and then fails in forward (TypeError, deltagru.py:74-77): refused here at construction.  In lstm,
-    vdlstm and deltajanet the surgery finds only nn.Linear HEADS (float recurrent core, INT_Linear heads: `_quantise_heads`; deltajanet
-    up to 64 hidden units); the backbones whose gates or convolutions are themselves nn.Linear / nn.Conv2d modules (`_PARTIAL`) have no
+    vdlstm, deltajanet and neuraltx the surgery finds only nn.Linear HEADS (float core, INT_Linear heads: `_quantise_heads`; deltajanet
+    and neuraltx up to 64 units / channels); the backbones whose gates or convolutions are themselves nn.Linear / nn.Conv2d modules (`_PARTIAL`) have no
     quantised kernels yet.
 
     `pretrained_model` follows Base_GRUQuantEnv.load_model (quant_envs.py:173-182): the checkpoint is strict-loaded into the FLOAT

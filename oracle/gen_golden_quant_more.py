@@ -50,6 +50,9 @@ CASES = [
     ("quant_vdlstm_h13_w16a16", "vdlstm", 13, 16, 0, 0, False),
     ("quant_deltajanet_h12_w8a8", "deltajanet", 12, 8, 0, 0, False),       # custom float cell (nn.Parameter gates), INT_Linear fc_out
     ("quant_deltajanet_h40_w16a16", "deltajanet", 40, 16, 0, 0, False),
+    # neuraltx: the surgery's layer map holds nn.Conv2d and nn.Linear (quant_envs.py:145-148) — the Conv1d stack stays float, IQ_match -> INT_Linear
+    ("quant_neuraltx_h12_w8a8", "neuraltx", 12, 8, 0, 0, False),
+    ("quant_neuraltx_h20_w16a16", "neuraltx", 20, 16, 0, 0, False),
 ]
 
 

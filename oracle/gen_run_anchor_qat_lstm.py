@@ -6,7 +6,8 @@ runs the REFERENCE (CPU) for
     ... --step run_dpd   (same flags)
 in front of the GRU PA the reference trained for tests/golden/ref_runs_qat_dpa.npz (written where train_dpd looks for it), and stores the
 logged rows, the saved state dict (float nn.LSTM + INT_Linear fc_out: parameters AND side-effect buffers) and the exported CSV in
-tests/golden/ref_runs_qat_lstm.{json,npz}.   Usage: python oracle/gen_run_anchor_qat_lstm.py"""
+tests/golden/ref_runs_qat_lstm.{json,npz}.   Usage: python oracle/gen_run_anchor_qat_lstm.py [backbone]
+(`neuraltx`: the same run with --DPD_backbone neuraltx -> ref_runs_qat_neuraltx.{json,npz}: float Conv1d stack + INT_Linear IQ_match)"""
 import glob
 import json
 import os
@@ -20,7 +21,8 @@ import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gen_run_anchor_qat_dpa import C, OUT, REF, RUNNER  # noqa: E402
 
-Q = ["--DPD_backbone", "lstm", "--DPD_hidden_size", "12", "--quant", "--n_bits_w", "8", "--n_bits_a", "8", "--quant_dir_label", "w8a8"]
+BB = sys.argv[1] if len(sys.argv) > 1 else "lstm"
+Q = ["--DPD_backbone", BB, "--DPD_hidden_size", "12", "--quant", "--n_bits_w", "8", "--n_bits_a", "8", "--quant_dir_label", "w8a8"]
 
 
 def main():
@@ -40,8 +42,8 @@ def main():
         csv = glob.glob(f"{tmp}/dpd_out/**/*.csv", recursive=True)[0]
         out = {"hist": pd.read_csv(hist).to_dict(orient="list"), "hist_path": os.path.relpath(hist, tmp),
                "dpd_model": os.path.relpath(dpd_path, tmp), "pa_model": pa_rel, "dpd_out": os.path.relpath(csv, tmp), "cmd": " ".join(C + Q)}
-        json.dump(out, open(os.path.join(OUT, "ref_runs_qat_lstm.json"), "w"), indent=1)
-        np.savez_compressed(os.path.join(OUT, "ref_runs_qat_lstm.npz"), **{"dpd/" + k: v.numpy() for k, v in torch.load(dpd_path).items()},
+        json.dump(out, open(os.path.join(OUT, f"ref_runs_qat_{BB}.json"), "w"), indent=1)
+        np.savez_compressed(os.path.join(OUT, f"ref_runs_qat_{BB}.npz"), **{"dpd/" + k: v.numpy() for k, v in torch.load(dpd_path).items()},
                             dpd_out=pd.read_csv(csv).to_numpy().astype(np.float64))
         print(json.dumps({k: out["hist"][k] for k in ("TRAIN_LOSS", "VAL_NMSE", "VAL_ACLR_AVG", "N_PARAM")}), out["dpd_model"], out["dpd_out"])
 

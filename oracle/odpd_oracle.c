@@ -55,7 +55,7 @@ static int64_t lstm_param_count(const odpd_model_t* m);
 int64_t oracle_param_count(const odpd_model_t* m) {
     int64_t H = m->hidden, F = feat_dim(m->backbone);
     if (m->bits_w > 0 && (m->backbone == ODPD_LSTM || m->backbone == ODPD_VDLSTM)) return lstm_param_count(m);   /* quantised head(s) */
-    if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET && m->backbone != ODPD_DELTAJANET) return qat_param_count(m);   /* quantised models: + the quantiser scales */
+    if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET && m->backbone != ODPD_DELTAJANET && m->backbone != ODPD_NEURALTX) return qat_param_count(m);   /* quantised models: + the quantiser scales */
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1:
         return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
@@ -87,7 +87,7 @@ int64_t oracle_param_count(const odpd_model_t* m) {
     case ODPD_DELTAJANET: /* deltajanet.py:96-111: two gates */
         return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2 + (m->bits_w > 0 ? 3 : 0);      /* + the INT_Linear head's scales */
     case ODPD_NEURALTX: /* neuraltx.py:18-38: two 5-tap FIRs, 4 -> C (bias), 4 depthwise k5, C -> 2, IQ_match (2,2); hidden = channels */
-        return 10 + 4 * H + H + 4 * 5 * H + 2 * H + 4;
+        return 10 + 4 * H + H + 4 * 5 * H + 2 * H + 4 + (m->bits_w > 0 ? 3 : 0);     /* + the INT_Linear IQ_match's scales */
     case ODPD_RVTDCNN:  /* rvtdcnn.py:19-33: Conv2d(1->3,k3) 27+3, fc_hid (H,36)+H, fc_out (2,H)+2; hidden = fc_hid_size (models.py:80-81) */
         return 30 + 36 * H + H + 2 * H + 2;
     default: return -1;
@@ -879,10 +879,14 @@ static void tcnn_seq_bwd(const tcnn_layout_t* L, const real* p, int T, const rea
  * C -> 2 (1x1) (:21-37); y = net + IQ_match f + f (:135).  Parameter order: conv_I.weight (5), conv_Q.weight (5),
  * network.0.weight (C,4), network.0.bias (C), network.{2,4,6,8}.weight (C,5), network.10.weight (2,C), IQ_match.weight (2,2). */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { int C; int64_t o_ci, o_cq, o_w0, o_b0, o_dw[4], o_w5, o_m; } ntx_layout_t;
+/* `--quant` (bits_w > 0): the surgery's layer map holds nn.Conv2d and nn.Linear (quant_envs.py:145-148), so the Conv1d FIRs and stack stay
+ * float and IQ_match becomes a bias-free INT_Linear (its three scales behind IQ_match.weight).  No module is named fc_out, so
+ * set_last_layer_quant (:276-284) marks nothing: the 16-bit output quantiser never runs, train and eval mode compute the same. */
+typedef struct { int C, q, bits_w, bits_a; int64_t o_ci, o_cq, o_w0, o_b0, o_dw[4], o_w5, o_m; } ntx_layout_t;
 static void ntx_layout(const odpd_model_t* m, ntx_layout_t* g) {
     int64_t C = m->hidden, o = 0;
     g->C = (int)C;
+    g->q = m->bits_w > 0; g->bits_w = m->bits_w; g->bits_a = m->bits_a;
     g->o_ci = o; o += 5; g->o_cq = o; o += 5;
     g->o_w0 = o; o += 4 * C; g->o_b0 = o; o += C;
     for (int l = 0; l < 4; ++l) { g->o_dw[l] = o; o += 5 * C; }
@@ -926,6 +930,12 @@ static void ntx_seq_fwd(const ntx_layout_t* L, const real* p, int T, const real*
             real v = 0;
             for (int c = 0; c < C; ++c) v += p[L->o_w5 + o * C + c] * hswish(pre[(4 * T + t) * C + c]);
             const real* f = feat + t * 4;
+            if (L->q) {      /* (out + IQ_match(q_a(f))) + f, the INT_Linear on exact grid sums */
+                const real sw = q_pow2(p[L->o_m + 4]), sa = q_pow2(p[L->o_m + 5]);
+                const double lin = (double)q_apply(p[L->o_m + 2 * o], sw, L->bits_w, NULL) * (double)q_apply(f[0], sa, L->bits_a, NULL) +
+                                   (double)q_apply(p[L->o_m + 2 * o + 1], sw, L->bits_w, NULL) * (double)q_apply(f[1], sa, L->bits_a, NULL);
+                y[2 * t + o] = (v + (real)lin) + f[o];
+            } else
             y[2 * t + o] = v + p[L->o_m + 2 * o] * f[0] + p[L->o_m + 2 * o + 1] * f[1] + f[o];
         }
 }
@@ -964,6 +974,17 @@ static void ntx_seq_bwd(const ntx_layout_t* L, const real* p, int T, const real*
             for (int i = 0; i < 4; ++i) { dp[L->o_w0 + c * 4 + i] += gp * f[i]; df[i] += gp * p[L->o_w0 + c * 4 + i]; }
         }
         /* IQ_match and identity skip of f */
+        if (L->q) {
+            const real sw = q_pow2(p[L->o_m + 4]), sa = q_pow2(p[L->o_m + 5]);
+            real pass[2], fq[2];
+            for (int j = 0; j < 2; ++j) fq[j] = q_apply(f[j], sa, L->bits_a, &pass[j]);
+            for (int o = 0; o < 2; ++o)
+                for (int j = 0; j < 2; ++j) {
+                    real mk, wq = q_apply(p[L->o_m + 2 * o + j], sw, L->bits_w, &mk);
+                    dp[L->o_m + 2 * o + j] += dy[2 * t + o] * fq[j] * mk;
+                    df[j] += pass[j] * dy[2 * t + o] * wq;
+                }
+        } else
         for (int o = 0; o < 2; ++o) {
             dp[L->o_m + 2 * o] += dy[2 * t + o] * f[0];
             dp[L->o_m + 2 * o + 1] += dy[2 * t + o] * f[1];

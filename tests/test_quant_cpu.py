@@ -76,7 +76,7 @@ def test_surgery_on_the_other_backbones():
 
 
 def test_head_only_surgery_state_dict_and_rng_match_the_reference():
-    """lstm / vdlstm / deltajanet: the surgery finds only the nn.Linear heads to swap (the recurrent core stays float) — identical keys, order, values (parameters and buffers) and the
+    """lstm / vdlstm / deltajanet / neuraltx: the surgery finds only the nn.Linear heads to swap (the recurrent core stays float) — identical keys, order, values (parameters and buffers) and the
     same global RNG state afterwards as the reference's get_quant_model (oracle/gen_golden_quant_more.py)."""
     from tests.test_oracle_golden import QAT_HEADS
     for name, bb, bits in QAT_HEADS:
@@ -92,8 +92,10 @@ def test_head_only_surgery_state_dict_and_rng_match_the_reference():
             assert same, (name, k)
         assert sum(p.numel() for p in q.parameters()) == fx.meta["n_param"] == q.backbone.n_flat
         assert np.array_equal(rng_after, fx["rng_after"]), name
-        assert [n for n, _ in q.named_parameters()][-5:] == ["backbone.fc_out.weight", "backbone.fc_out.bias", "backbone.fc_out.weight_quantizer.scale",
-                                                            "backbone.fc_out.act_quantizer.scale", "backbone.fc_out.out_quantizer.scale"]
+        last = "IQ_match" if bb == "neuraltx" else "fc_out"      # (neuraltx: bias-free, and the last named_children entry)
+        tail = [f"backbone.{last}.weight"] + ([] if bb == "neuraltx" else [f"backbone.{last}.bias"]) + [
+            f"backbone.{last}.weight_quantizer.scale", f"backbone.{last}.act_quantizer.scale", f"backbone.{last}.out_quantizer.scale"]
+        assert [n for n, _ in q.named_parameters()][-len(tail):] == tail
 
 
 def test_identity_when_quant_off():

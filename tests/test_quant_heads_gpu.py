@@ -1,4 +1,4 @@
-"""`--quant` on lstm / vdlstm / deltajanet: the reference's surgery finds only the heads to swap (fc_out; vdlstm: fc_lambda_1, fc_lambda_2, fc_out:
+"""`--quant` on lstm / vdlstm / deltajanet / neuraltx: the reference's surgery finds only the heads to swap (fc_out; vdlstm: fc_lambda_1, fc_lambda_2, fc_out:
 nn.Linear -> INT_Linear, quant/quant_envs.py:40-60, 290-306; quant/qmodules/quant_layers.py:48-85), the recurrent core (nn.LSTM; deltajanet's
 nn.Parameter cell) stays float.  HIP path: the quantised-head instantiations of csrc/lstm_family.hip (lstm_eval_kernel / lstm_gp_train_kernel /
 lstm_bwd_kernel <.., QH>) and csrc/deltajanet_wide.hip (<.., QH>) against vectors produced by RUNNING the reference
@@ -46,7 +46,8 @@ def test_forward_gradients_and_trajectory_match_the_reference(name, bb, bits):
     with torch.no_grad():      # config-shaped frames (T = 200), eval mode: on the 16-bit output grid
         ya = q(torch.from_numpy(fx["xa"]).cuda()).cpu().numpy()
     assert grid_close(ya, fx["ya_eval"], step, _flips(bits, ya.size))
-    assert np.abs(ya * 2.0 ** 14 - np.rint(ya * 2.0 ** 14)).max() == 0.0
+    if bb != "neuraltx":      # (neuraltx has no module named fc_out: its output quantiser never runs, quant_envs.py:276-284)
+        assert np.abs(ya * 2.0 ** 14 - np.rint(ya * 2.0 ** 14)).max() == 0.0
     if bb == "deltajanet":      # the float cell's sparsity counters (exact repeats only: the layer runs with thx = thh = 0)
         s = q.backbone.statistics
         assert [s["num_dx_zeros"], s["num_dx_numel"], s["num_dh_zeros"], s["num_dh_numel"]] == list(fx["stats_a"])
@@ -89,6 +90,48 @@ def test_deltajanet_matches_the_oracle_on_ragged_sizes(H, B, T, bits):
     """The lane-per-unit kernels with the quantised head at every hidden size 1 .. 64 (csrc/deltajanet_wide.hip <.., QH>), batches beyond one
     sequence per workgroup."""
     _ragged("deltajanet", H, B, T, bits)
+
+
+@pytest.mark.parametrize("C,B,T,bits", [(12, 5, 37, 8), (1, 4, 9, 8), (7, 64, 50, 8), (20, 3, 300, 8), (33, 3, 131, 16), (64, 9, 200, 8), (16, 700, 20, 8)])
+def test_neuraltx_matches_the_oracle_on_ragged_sizes(C, B, T, bits):
+    """neuraltx with IQ_match as INT_Linear (csrc/tcnn.hip <.., NTX>, bits_w > 0): forward (train = eval: no output quantiser), weight
+    gradients and dL/dx against the oracle; IQ_match's weights partly beyond the weight grid, its activation range narrowed so that
+    filtered samples are clamped and masked; every tile shape (T <= 64 .. > 256)."""
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(C + B + T)
+    q = _fresh("neuraltx", C, bits).cuda()
+    with torch.no_grad():
+        q.backbone.IQ_match.weight.copy_(torch.tensor([[2.6, -0.7], [0.4, -2.3]]).cuda())
+        q.backbone.IQ_match.act_quantizer.scale.mul_(0.125)
+        q.backbone.conv_I.weight.mul_(8.0)                               # (xavier with gain 0.1: the filtered signal would be ~0.05 x)
+    x, dy = _signal(B, T, B + T)
+    o = Oracle("f32")
+    m = make_model("neuraltx", C, bits_w=bits, bits_a=bits)
+    p = np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in q.parameters()])
+    assert o.param_count(m) == p.size
+    step = 2.0 ** (2 - bits) * 8
+    nflip = 2 + B // 100 if bits == 8 else B * T // 10
+    for mode in (q.eval, q.train):
+        mode()
+        with torch.no_grad():
+            y = q(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert grid_close(y, o.qat_forward(m, p, x, eval_mode=mode == q.eval), step, nflip)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    q(xt).backward(torch.from_numpy(dy).cuda())
+    go, dxo = o.qat_backward(m, p, x, dy, need_dx=True)
+    off = 0
+    for k, v in q.named_parameters():
+        n = v.numel()
+        ref = go[off:off + n]
+        got = (v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy().reshape(-1)
+        if np.abs(ref).max() > 0:
+            assert rel_err(got, ref) < 1e-3, k
+        else:
+            assert np.abs(got).max() == 0, k
+        off += n
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < 1e-3
+    gm = q.backbone.IQ_match.weight.grad.cpu().numpy()
+    assert gm[0, 0] == 0.0 and gm[1, 1] == 0.0 and abs(gm[0, 1]) > 0 and abs(gm[1, 0]) > 0      # the weight quantiser's pass mask (|w| > 2)
 
 
 def _ragged(bb, H, B, T, bits):
