@@ -9,6 +9,7 @@
 //             the state rotated by 0 / 16 / 32 / 48 lanes (4 gates x 4 rotations x 16 accumulators = the whole AGPR file), dW_ih, the
 //             biases and fc_out on the VALU.  One row of partial gradients per workgroup (every entry written).
 #include "odpd_seq.h"
+#include "odpd_quant.h"
 
 namespace odpd {
 namespace {
@@ -24,7 +25,7 @@ template <bool SAVE>
 __global__ __launch_bounds__(64) void wide_lstm_fwd_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
-    const LstmLayout L = lstm_layout(a.H, 0);
+    const LstmLayout L = lstm_layout(a.H, 0, a.bits_w > 0);
     const int H = L.H, T = a.T;
     float* pl = smem;
     stage_params(pl, a.params, L.P);
@@ -36,6 +37,18 @@ __global__ __launch_bounds__(64) void wide_lstm_fwd_kernel(SeqArgs a) {
     for (int i = lane; i < 64 * kLS; i += 64) {
         const int j = i / kLS, k = i % kLS;
         wop[i] = (j < H && k < H) ? pl[L.o_w_hh + (3 * H + j) * H + k] : 0.0f;
+    }
+    // `--quant` (bits_w > 0; run-time, wave-uniform): fc_out is an INT_Linear (quant_layers.py:48-85) — its weights become their quantised
+    // values in the staged copy, the chunk's states are quantised where the head reads them, ODPD_FLAG_EVAL adds the 16-bit output grid
+    const bool qh = a.bits_w > 0;
+    q16::Quant qa{1.0f, 1.0f, 0.0f, 0.0f}, qo{1.0f, 1.0f, 0.0f, 0.0f};
+    if (qh) {
+        const q16::Quant qw = q16::make_quant(pl[L.o_q_out], a.bits_w);
+        qa = q16::make_quant(pl[L.o_q_out + 1], a.bits_a);
+        qo = q16::make_quant(pl[L.o_q_out + 2], 16);
+        wave_lds_fence();
+        for (int i = lane; i < 2 * H; i += 64) pl[L.o_w_out + i] = q16::qapply(pl[L.o_w_out + i], qw);
+        wave_lds_fence();
     }
     float whh[3][64], wih[4][2], bg[4];
 #pragma unroll
@@ -92,10 +105,14 @@ __global__ __launch_bounds__(64) void wide_lstm_fwd_kernel(SeqArgs a) {
             }
             if (lane < len) {      // the chunk's outputs, lane = time step
                 const float* hr = hist + lane * kLS;
-                float y0 = pl[L.o_b_out], y1 = pl[L.o_b_out + 1];
+                float y0 = qh ? 0.0f : pl[L.o_b_out], y1 = qh ? 0.0f : pl[L.o_b_out + 1];
                 for (int j = 0; j < H; ++j) {
-                    const float hv = hr[j];
+                    const float hv = qh ? q16::qapply(hr[j], qa) : hr[j];
                     y0 = __builtin_fmaf(pl[L.o_w_out + j], hv, y0); y1 = __builtin_fmaf(pl[L.o_w_out + H + j], hv, y1);
+                }
+                if (qh) {      // grid sums first, then the float bias (F.linear(q_a(h), q_w(W), b))
+                    y0 += pl[L.o_b_out]; y1 += pl[L.o_b_out + 1];
+                    if (a.eval_out) { y0 = q16::qapply(y0, qo); y1 = q16::qapply(y1, qo); }
                 }
                 yg[t0 + lane] = make_float2(y0, y1);
             }
@@ -108,7 +125,7 @@ template <bool NW, bool DX>
 __global__ __launch_bounds__(64) void wide_lstm_bwd_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, col = lane & 15, quad = lane >> 4;
-    const LstmLayout L = lstm_layout(a.H, 0);
+    const LstmLayout L = lstm_layout(a.H, 0, a.bits_w > 0);
     const int H = L.H, T = a.T, NC = (T + kLC - 1) / kLC;
     float* pl = smem;
     stage_params(pl, a.params, L.P);
@@ -124,7 +141,16 @@ __global__ __launch_bounds__(64) void wide_lstm_bwd_kernel(SeqArgs a) {
         wih[g][0] = vo ? pl[L.o_w_ih + (g * H + lane) * 2] : 0.0f;
         wih[g][1] = vo ? pl[L.o_w_ih + (g * H + lane) * 2 + 1] : 0.0f;
     }
-    const float wo0 = vo ? pl[L.o_w_out + lane] : 0.0f, wo1 = vo ? pl[L.o_w_out + H + lane] : 0.0f;
+    float wo0 = vo ? pl[L.o_w_out + lane] : 0.0f, wo1 = vo ? pl[L.o_w_out + H + lane] : 0.0f, wm0 = 1.0f, wm1 = 1.0f;
+    const bool qh = a.bits_w > 0;      // quantised head (see the forward kernel): q_w(W) columns, their pass masks for dW_out
+    float qa_inv = 1.0f, qa_s = 1.0f, qa_qn = 0.0f, qa_qp = 0.0f;
+    if (qh) {
+        const q16::Quant qw = q16::make_quant(pl[L.o_q_out], a.bits_w), qa = q16::make_quant(pl[L.o_q_out + 1], a.bits_a);
+        wm0 = q16::qpass(wo0, qw); wm1 = q16::qpass(wo1, qw);
+        wo0 = q16::qapply(wo0, qw); wo1 = q16::qapply(wo1, qw);
+        auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+        qa_inv = uni(qa.inv); qa_s = uni(qa.s); qa_qn = uni(qa.qn); qa_qp = uni(qa.qp);
+    }
     f32x16 acc[4][4];                          // dW_hh: gate g, the state rotated by 16 r lanes
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -169,8 +195,13 @@ __global__ __launch_bounds__(64) void wide_lstm_bwd_kernel(SeqArgs a) {
                 }
                 const float hp = hs[tt * kLS + lane], ht = hs[(tt + 1) * kLS + lane];
                 const float2 d = reinterpret_cast<const float2*>(dyb)[tt];
-                const float dht = __builtin_fmaf(d.x, wo0, __builtin_fmaf(d.y, wo1, dh));
-                if constexpr (NW) { dwo0 = __builtin_fmaf(d.x, ht, dwo0); dwo1 = __builtin_fmaf(d.y, ht, dwo1); }
+                float dht, hhead = ht;
+                if (qh) {      // the head saw q_a(h); dL/dh passes where h lies inside the activation grid
+                    const float v = ht * qa_inv, m = __builtin_amdgcn_fmed3f(v, qa_qn, qa_qp);
+                    hhead = rintf(m) * qa_s;
+                    dht = __builtin_fmaf(m == v ? 1.0f : 0.0f, __builtin_fmaf(d.x, wo0, d.y * wo1), dh);
+                } else dht = __builtin_fmaf(d.x, wo0, __builtin_fmaf(d.y, wo1, dh));
+                if constexpr (NW) { dwo0 = __builtin_fmaf(d.x, hhead, dwo0); dwo1 = __builtin_fmaf(d.y, hhead, dwo1); }
                 const float tc = tanhf_(ct);
                 const float dct = __builtin_fmaf(dht * go, __builtin_fmaf(-tc, tc, 1.0f), dc);      // dL/dc(t)
                 const float dpi = vo ? (dct * gg) * (gi * (1.0f - gi)) : 0.0f;
@@ -238,7 +269,7 @@ __global__ __launch_bounds__(64) void wide_lstm_bwd_kernel(SeqArgs a) {
         for (int o = 32; o > 0; o >>= 1) { tb0 += __shfl_xor(tb0, o); tb1 += __shfl_xor(tb1, o); }
         if (lane == 0) { prow[L.o_b_out] = tb0; prow[L.o_b_out + 1] = tb1; }
         if (vo) {
-            prow[L.o_w_out + lane] = dwo0; prow[L.o_w_out + H + lane] = dwo1;
+            prow[L.o_w_out + lane] = dwo0 * wm0; prow[L.o_w_out + H + lane] = dwo1 * wm1;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 prow[L.o_w_ih + (g * H + lane) * 2] = dwih[g][0]; prow[L.o_w_ih + (g * H + lane) * 2 + 1] = dwih[g][1];
@@ -268,20 +299,23 @@ int lstmw_launch(hipStream_t st, K k, int grid, size_t lds, const SeqArgs& a) {
 }
 }  // namespace
 
-// float lstm of 33 .. 64 hidden units (vdlstm and the quantised heads keep the 32-unit envelope)
-bool lstm_wide_ok(const odpd_model_t* m) { return m->backbone == ODPD_LSTM && m->bits_w == 0 && m->hidden > 32 && m->hidden <= 64; }
+// lstm of 33 .. 64 hidden units, float or with a quantised head (bits_w > 0: fc_out as INT_Linear; vdlstm's quantised heads keep the 32-unit envelope)
+bool lstm_wide_ok(const odpd_model_t* m) {
+    return m->backbone == ODPD_LSTM && m->hidden > 32 && m->hidden <= 64 && !(m->flags & ODPD_FLAG_TWO_LAYERS) &&
+           (m->bits_w == 0 || (m->bits_w <= 16 && m->bits_a > 0 && m->bits_a <= 16));
+}
 int64_t lstm_wide_ckpt_floats(const odpd_model_t*, int B, int T) { return (int64_t)B * T * kLNS * 64; }
 int lstm_wide_rows(const odpd_model_t*, int B) { const int cap = 4 * device_cus(); return B < cap ? B : cap; }
 int lstm_wide_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!lstm_wide_ok(m)) return ODPD_EUNSUPPORTED;
-    const size_t lds = (size_t)lstmw_fwd_floats(lstm_layout(m->hidden, 0).P) * sizeof(float);
+    const size_t lds = (size_t)lstmw_fwd_floats(lstm_layout(m->hidden, 0, m->bits_w > 0).P) * sizeof(float);
     const int grid = lstm_wide_rows(m, a.B);
     return a.ckpt ? lstmw_launch(st, wide_lstm_fwd_kernel<true>, grid, lds, a) : lstmw_launch(st, wide_lstm_fwd_kernel<false>, grid, lds, a);
 }
 int lstm_wide_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!lstm_wide_ok(m)) return ODPD_EUNSUPPORTED;
     if (!a.ckpt) return ODPD_EINVAL;
-    const size_t lds = (size_t)lstmw_bwd_floats(lstm_layout(m->hidden, 0).P) * sizeof(float);
+    const size_t lds = (size_t)lstmw_bwd_floats(lstm_layout(m->hidden, 0, m->bits_w > 0).P) * sizeof(float);
     const int grid = lstm_wide_rows(m, a.B);
     const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
     if (nw && dx) return lstmw_launch(st, wide_lstm_bwd_kernel<true, true>, grid, lds, a);

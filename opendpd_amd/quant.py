@@ -301,7 +301,7 @@ MAX_HIDDEN = 32          # csrc/qat_s16.hip: two 16-unit tiles
 _UNTOUCHED = ("gmp", "tcnn")       # no nn.GRU, no nn.Linear, no op modules: the surgery returns an identical deep copy
 _PARTIAL = ("rvtdcnn", "apnrru", "bojanet", "dvrjanet", "mcldnn", "pgjanet")
 _HEAD_ONLY = ("lstm", "vdlstm", "deltajanet", "neuraltx")    # only nn.Linear heads to swap, and kernels with quantised heads exist
-_HEAD_MAX_HIDDEN = {"deltajanet": 64, "neuraltx": 64}        # csrc/deltajanet_wide.hip / csrc/tcnn.hip serve the quantised head at every size they cover
+_HEAD_MAX_HIDDEN = {"deltajanet": 64, "neuraltx": 64, "lstm": 64}      # csrc/deltajanet_wide.hip, tcnn.hip, lstm_wide.hip (33 .. 64) carry the quantised head
 _HEAD_LAYERS = {"lstm": ("fc_out",), "vdlstm": ("fc_lambda_1", "fc_lambda_2", "fc_out"), "deltajanet": ("fc_out",), "neuraltx": ("IQ_match",)}
 _FLOAT_CORE = {"neuraltx": ("conv_I", "conv_Q", "network")}   # (the others: "rnn")
 

@@ -46,6 +46,7 @@ CASES = [
     ("quant_lstm_h14_w8a8", "lstm", 14, 8, 0, 0, False),
     ("quant_lstm_h14_w16a16", "lstm", 14, 16, 0, 0, False),
     ("quant_lstm_h24_w8a8", "lstm", 24, 8, 0, 0, False),
+    ("quant_lstm_h40_w8a8", "lstm", 40, 8, 0, 0, False),
     ("quant_vdlstm_h13_w8a8", "vdlstm", 13, 8, 0, 0, False),
     ("quant_vdlstm_h13_w16a16", "vdlstm", 13, 16, 0, 0, False),
     ("quant_deltajanet_h12_w8a8", "deltajanet", 12, 8, 0, 0, False),       # custom float cell (nn.Parameter gates), INT_Linear fc_out

@@ -115,7 +115,7 @@ QAT_MORE = [("quant_gru_h11_w8a8", "gru", 8), ("quant_gru_h23_w8a8", "gru", 8), 
             ("quant_tres_h15_w16a16_th", "deltagru_tcnskip", 16), ("quant_tres_h30_w8a8_th", "deltagru_tcnskip", 8),
             ("quant_tres_h15_w16a16_pre", "deltagru_tcnskip", 16), ("quant_tres_h15_w8a8_pre", "deltagru_tcnskip", 8)]
 # float recurrent core (nn.LSTM; deltajanet's nn.Parameter cell), INT_Linear heads (the surgery finds only nn.Linear layers to swap)
-QAT_HEADS = [("quant_lstm_h14_w8a8", "lstm", 8), ("quant_lstm_h14_w16a16", "lstm", 16), ("quant_lstm_h24_w8a8", "lstm", 8),
+QAT_HEADS = [("quant_lstm_h14_w8a8", "lstm", 8), ("quant_lstm_h14_w16a16", "lstm", 16), ("quant_lstm_h24_w8a8", "lstm", 8), ("quant_lstm_h40_w8a8", "lstm", 8),
              ("quant_vdlstm_h13_w8a8", "vdlstm", 8), ("quant_vdlstm_h13_w16a16", "vdlstm", 16),
              ("quant_deltajanet_h12_w8a8", "deltajanet", 8), ("quant_deltajanet_h40_w16a16", "deltajanet", 16),
              ("quant_neuraltx_h12_w8a8", "neuraltx", 8), ("quant_neuraltx_h20_w16a16", "neuraltx", 16)]

@@ -84,6 +84,12 @@ def test_matches_the_oracle_on_ragged_sizes(bb, H, B, T, bits):
     _ragged(bb, H, B, T, bits)
 
 
+@pytest.mark.parametrize("H,B,T,bits", [(33, 3, 131, 8), (40, 7, 45, 8), (48, 64, 50, 8), (64, 19, 33, 8), (37, 5, 70, 16), (56, 1300, 12, 8)])
+def test_lstm_beyond_32_units_matches_the_oracle_on_ragged_sizes(H, B, T, bits):
+    """lstm with a quantised head at 33 .. 64 hidden units: the lane-per-unit kernels (csrc/lstm_wide.hip) read bits_w at run time."""
+    _ragged("lstm", H, B, T, bits)
+
+
 @pytest.mark.parametrize("H,B,T,bits", [(12, 5, 37, 8), (1, 4, 9, 8), (7, 64, 50, 8), (16, 3, 130, 8), (33, 3, 131, 8), (40, 7, 45, 16), (64, 19, 33, 8),
                                          (17, 1300, 20, 8), (32, 9, 64, 8)])
 def test_deltajanet_matches_the_oracle_on_ragged_sizes(H, B, T, bits):
@@ -143,7 +149,7 @@ def _ragged(bb, H, B, T, bits):
         g = torch.Generator().manual_seed(H)
         q.backbone.fc_out.bias.copy_(((torch.rand(2, generator=g) - 0.5) * 0.6).cuda())
         q.backbone.fc_out.weight.mul_(3.0 if vd else 6.0)                  # some weights beyond the weight grid's range (+-2)
-        if bb == "deltajanet":
+        if bb == "deltajanet" or H > 32:      # (xavier bounds shrink with the width: keep some weights beyond the grid's +-2)
             q.backbone.fc_out.weight.mul_(3.0 / float(q.backbone.fc_out.weight.abs().max()))
         if vd:      # fc_lambda_1 / _2 on grids of their own, fc_out's inputs (l cos, l sin) partly beyond its activation range
             q.backbone.fc_lambda_1.weight.mul_(5.0)
@@ -176,13 +182,15 @@ def _ragged(bb, H, B, T, bits):
     off = 0
     # (one state on the other side of a rounding boundary moves a head-weight gradient by |dy| s_a: 14 000 samples see a few of those)
     # (deltajanet's running-sum accumulators differ from the oracle's by ~1e-6 rather than 1e-7: a flip at a few thousand samples already)
-    tol = 1e-4 if (B < 100 and bb != "deltajanet") else 1e-3
+    tol = 1e-4 if (B < 100 and bb != "deltajanet" and H <= 32) else 1e-3
     for k, v in q.named_parameters():
         n = v.numel()
         ref = go[off:off + n]
         got = (v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy().reshape(-1)
         if np.abs(ref).max() > 0:
-            assert rel_err(got, ref) < tol, k
+            # (beyond 32 units a batch holds that many more states next to a rounding boundary: two or three single-state flips in the head's
+            # weight gradient, each |dy| s_a = 4e-3 here against entries of ~5)
+            assert rel_err(got, ref) < (3e-3 if (H > 32 and k.endswith("fc_out.weight")) else tol), k
         else:
             assert np.abs(got).max() == 0, k
         off += n

