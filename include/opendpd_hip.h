@@ -73,7 +73,9 @@ typedef struct odpd_model {
                          INT_Linear, three scales behind fc_out.bias; > 0 on neuraltx: IQ_match (the one nn.Linear; the Conv1d layers are not in the
                          surgery's layer map, quant_envs.py:145-148) becomes a bias-free INT_Linear, three scales behind IQ_match.weight, no
                          output quantiser in either mode (no module is named fc_out);
-                         dvrjanet: num_dvr_units (models.py:119) */
+                         dvrjanet: num_dvr_units (models.py:119);
+                         > 0 on any other backbone (no quantised kernels: pgjanet, rvtdcnn, apnrru, bojanet, mcldnn, deltagru; nothing to
+                         quantise: gmp, tcnn): every entry point answers ODPD_EINVAL — never the float kernels */
     int32_t bits_a;   /* QAT activation bits */
     int32_t flags;    /* ODPD_FLAG_* */
 } odpd_model_t;

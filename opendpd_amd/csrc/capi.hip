@@ -57,8 +57,19 @@ inline int feat_dim(int bb) {
 inline bool lane_per_unit_model(const odpd_model_t* m) {
     return gru_wide_ok(m) || lstm_wide_ok(m) || vdlstm_wide_ok(m) || delta_wide_ok(m) || pgjanet_wide_ok(m) || deltajanet_wide_ok(m);
 }
+// bits_w > 0 selects a quantised model only where one exists (include/opendpd_hip.h, odpd_model_t::bits_w); on every other backbone
+// the descriptor is refused outright — no entry point may answer it with the float kernels on a float parameter layout
+inline bool quant_desc_ok(const odpd_model_t* m) {
+    if (m->bits_w <= 0 || m->backbone == ODPD_DVRJANET) return true;      // (dvrjanet: bits_w carries num_dvr_units)
+    switch (m->backbone) {
+    case ODPD_GRU: case ODPD_DGRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: case ODPD_TRES_DELTAGRU:      // the surgery's quantised cells
+    case ODPD_LSTM: case ODPD_VDLSTM: case ODPD_DELTAJANET: case ODPD_NEURALTX:                      // float core, INT_Linear heads
+        return m->bits_a > 0;
+    default: return false;
+    }
+}
 inline bool model_ok(const odpd_model_t* m) {
-    return m && m->backbone >= 0 && m->backbone < ODPD_BACKBONE_COUNT && m->hidden > 0;
+    return m && m->backbone >= 0 && m->backbone < ODPD_BACKBONE_COUNT && m->hidden > 0 && quant_desc_ok(m);
 }
 inline SeqArgs make_args(const odpd_model_t* m, int B, int T) {
     SeqArgs a{};
