@@ -64,6 +64,7 @@ inline bool quant_desc_ok(const odpd_model_t* m) {
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_DGRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: case ODPD_TRES_DELTAGRU:      // the surgery's quantised cells
     case ODPD_LSTM: case ODPD_VDLSTM: case ODPD_DELTAJANET: case ODPD_NEURALTX:                      // float core, INT_Linear heads
+    case ODPD_RVTDCNN:                                                                               // INT_Conv2D + INT_Linear layers (rvtdcnn_q.hip)
         return m->bits_a > 0;
     default: return false;
     }
@@ -138,7 +139,7 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_MCLDNN: return mcldnn_param_count(m);       // 190C + 589 (mcldnn.py:21-27)
     case ODPD_APNRRU: return apnrru_param_count(m);       // 343 + 70H (apnrru.py:13-19, 45-53)
     case ODPD_BOJANET: return bojanet_param_count(m);     // 2H^2 + 28H + 194 (bojanet.py:15-26)
-    case ODPD_RVTDCNN: return H <= 32 ? 39 * H + 32 : (int64_t)ODPD_EUNSUPPORTED;  // conv 27+3, fc_hid 36H+H, fc_out 2H+2 (rvtdcnn.py:19-33)
+    case ODPD_RVTDCNN: return H <= 32 ? (m->bits_w > 0 ? rvtdcnn_q_param_count(m) : 39 * H + 32) : (int64_t)ODPD_EUNSUPPORTED;  // conv 27+3, fc_hid 36H+H, fc_out 2H+2 (rvtdcnn.py:19-33)
     default: return ODPD_EUNSUPPORTED;
     }
 }

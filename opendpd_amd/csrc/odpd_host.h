@@ -359,6 +359,12 @@ int rvtdcnn_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);  // f
 int rvtdcnn_rows(const odpd_model_t* m, int B, int T);                       // partials rows of the split backward (with or without dL/dx)
 int rvtdcnn_train_rows(const odpd_model_t* m, int B, int T);                 // ... of the fused step
 int rvtdcnn_rows_for(int B, int T, bool dx);
+// the quantised rvtdcnn (bits_w > 0; csrc/rvtdcnn_q.hip)
+bool rvtdcnn_q_ok(const odpd_model_t* m, int T);
+int64_t rvtdcnn_q_param_count(const odpd_model_t* m);
+int rvtdcnn_q_rows(const odpd_model_t* m, int B, int T);
+int rvtdcnn_q_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int rvtdcnn_q_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, bool fused);
 int qgru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int qgru_family_rows(const odpd_model_t* m, int B);

@@ -459,7 +459,9 @@ int rv_launch_bwd(hipStream_t st, const SeqArgs& a, bool nw, bool dx) {
 // rows of partials = workgroups of the backward / fused launch for this shape (dx: the chunk + halo thread layout)
 int rvtdcnn_rows_for(int B, int T, bool dx) { return rv_grid(rv_geom(B, T, dx).npass); }
 
+// bits_w > 0: the quantised model (INT_Conv2D + INT_Linear layers) on its own kernels, csrc/rvtdcnn_q.hip
 int rvtdcnn_rows(const odpd_model_t* m, int B, int T) {
+    if (m->bits_w > 0) return rvtdcnn_q_ok(m, T) ? rvtdcnn_q_rows(m, B, T) : ODPD_EUNSUPPORTED;
     if (!rv_ok(m, T)) return ODPD_EUNSUPPORTED;
     // the split backward may be asked for dL/dx as well: size for the larger of the two grids
     const int r0 = rvtdcnn_rows_for(B, T, false), r1 = rvtdcnn_rows_for(B, T, true);
@@ -467,6 +469,7 @@ int rvtdcnn_rows(const odpd_model_t* m, int B, int T) {
 }
 
 int rvtdcnn_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (m->bits_w > 0) return rvtdcnn_q_fwd(st, m, a);
     if (!rv_ok(m, a.T)) return ODPD_EUNSUPPORTED;
     const long long N = (long long)a.B * a.T;
     const int grid = rv_grid((int)((N + kRvThreads - 1) / kRvThreads), 6);       // 59 VGPRs: six waves per SIMD hide the scalar loads
@@ -477,9 +480,10 @@ int rvtdcnn_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 // dy -> partials (weight gradients) and / or dx.  A partials buffer sized by rvtdcnn_rows() may have more rows than this launch's
 // grid writes: the unused rows are zeroed so that odpd_reduce_partials can sum all of them.
 int rvtdcnn_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
+    if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
+    if (m->bits_w > 0) return rvtdcnn_q_bwd(st, m, a, false);
     if (!rv_ok(m, a.T)) return ODPD_EUNSUPPORTED;
     const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
-    if (!nw && !dx) return ODPD_EINVAL;
     if (nw) {
         const int used = rvtdcnn_rows_for(a.B, a.T, dx), all = rvtdcnn_rows(m, a.B, a.T);
         const size_t P4 = rv_layout(a.H).P + kLossCols;
@@ -490,11 +494,13 @@ int rvtdcnn_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 
 // fused train step: forward + loss + weight gradients in one launch; frames may be addressed inside resident streams
 int rvtdcnn_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
-    if (!rv_ok(m, a.T)) return ODPD_EUNSUPPORTED;
     if (!a.partials || !a.target) return ODPD_EINVAL;
+    if (m->bits_w > 0) return rvtdcnn_q_bwd(st, m, a, true);
+    if (!rv_ok(m, a.T)) return ODPD_EUNSUPPORTED;
     return m->hidden <= 16 ? rv_launch_bwd<1, true>(st, a, true, false) : rv_launch_bwd<2, true>(st, a, true, false);
 }
 int rvtdcnn_train_rows(const odpd_model_t* m, int B, int T) {
+    if (m->bits_w > 0) return rvtdcnn_q_ok(m, T) ? rvtdcnn_q_rows(m, B, T) : ODPD_EUNSUPPORTED;
     if (!rv_ok(m, T)) return ODPD_EUNSUPPORTED;
     return rvtdcnn_rows_for(B, T, false);
 }

@@ -59,6 +59,25 @@ class _QLinear(nn.Module):
         self.out_quant = False
 
 
+class _QConv2d(nn.Module):
+    """INT_Conv2D state (quant_layers.py:10-45): the float layer's weight, a freshly drawn default-init bias (the constructor builds a new
+    nn.Conv2d and takes over only the weight), n_bits buffers, weight / activation quantisers — the weight scale starts at
+    2 mean|w| / sqrt(Qp) (init_step_size: a 0-dim parameter), no output quantiser."""
+
+    def __init__(self, conv, bits_w, bits_a):
+        super().__init__()
+        fresh = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, stride=conv.stride, padding=conv.padding,
+                          dilation=conv.dilation, groups=conv.groups, bias=conv.bias is not None)       # same RNG draws as INT_Conv2D.__init__
+        self.weight = nn.Parameter(conv.weight.detach().clone())
+        if conv.bias is not None:
+            self.bias = fresh.bias
+        self.register_buffer("n_bits_w", torch.Tensor([bits_w]))
+        self.register_buffer("n_bits_a", torch.Tensor([bits_a]))
+        self.weight_quantizer = _QScale(bits_w, 1.0)
+        self.weight_quantizer.scale = nn.Parameter(conv.weight.detach().abs().mean() * 2 / (2 ** (bits_w - 1) - 1) ** 0.5)
+        self.act_quantizer = _QScale(bits_a, 2.0 ** (2 - bits_a))
+
+
 class _QOp(nn.Module):
     def __init__(self, bits):
         super().__init__()
@@ -232,6 +251,22 @@ class QuantHeadNeuralTX(_QuantBase):
         self._finish(C, bits_w, bits_a)
 
 
+class QuantRVTDCNN(_QuantBase):
+    """rvtdcnn after the surgery (feed-forward: every layer is in the surgery's map, quant_envs.py:145-148): Conv2d -> INT_Conv2D, fc_hid and
+    fc_out -> INT_Linear (fc_out with out_quant: set_last_layer_quant), the functional tanh calls stay float.  Kernels: csrc/rvtdcnn_q.hip."""
+    backbone_name = "rvtdcnn"
+
+    def __init__(self, conv, fc_hid_size, bits_w, bits_a):
+        super().__init__()
+        self.window_size, self.out_channels, self.fc_hid_size = 4, 3, fc_hid_size
+        self.stride, self.feature_size_new, self.fc_in_features = 1, 3, 36
+        self.Conv2d = _QConv2d(conv, bits_w, bits_a)             # (the surgery walks the layer map type by type: Conv2d first, then the Linears)
+        self.fc_hid = _QLinear(36, fc_hid_size, bits_w, bits_a)
+        self.fc_out = _QLinear(fc_hid_size, 2, bits_w, bits_a)
+        self.fc_out.out_quant = True
+        self._finish(fc_hid_size, bits_w, bits_a)
+
+
 class _QDeltaLayer(nn.Module):
     """DeltaGRULayer of deltagru_tcnskip.py:133-162 after the surgery: bias-free INT_Linear x2h / h2h, Quant_add / mult / sigmoid /
     tanh in the layer's own registration order."""
@@ -299,11 +334,11 @@ class QuantTResDeltaGRU(_QuantBase):
 
 MAX_HIDDEN = 32          # csrc/qat_s16.hip: two 16-unit tiles
 _UNTOUCHED = ("gmp", "tcnn")       # no nn.GRU, no nn.Linear, no op modules: the surgery returns an identical deep copy
-_PARTIAL = ("rvtdcnn", "apnrru", "bojanet", "dvrjanet", "mcldnn", "pgjanet")
-_HEAD_ONLY = ("lstm", "vdlstm", "deltajanet", "neuraltx")    # only nn.Linear heads to swap, and kernels with quantised heads exist
+_PARTIAL = ("apnrru", "bojanet", "dvrjanet", "mcldnn", "pgjanet")
+_HEAD_ONLY = ("lstm", "vdlstm", "deltajanet", "neuraltx", "rvtdcnn")    # only nn.Linear / nn.Conv2d layers to swap, and kernels for the result exist
 _HEAD_MAX_HIDDEN = {"deltajanet": 64, "neuraltx": 64, "lstm": 64}      # csrc/deltajanet_wide.hip, tcnn.hip, lstm_wide.hip (33 .. 64) carry the quantised head
-_HEAD_LAYERS = {"lstm": ("fc_out",), "vdlstm": ("fc_lambda_1", "fc_lambda_2", "fc_out"), "deltajanet": ("fc_out",), "neuraltx": ("IQ_match",)}
-_FLOAT_CORE = {"neuraltx": ("conv_I", "conv_Q", "network")}   # (the others: "rnn")
+_HEAD_LAYERS = {"rvtdcnn": ("Conv2d", "fc_hid", "fc_out"), "lstm": ("fc_out",), "vdlstm": ("fc_lambda_1", "fc_lambda_2", "fc_out"), "deltajanet": ("fc_out",), "neuraltx": ("IQ_match",)}
+_FLOAT_CORE = {"neuraltx": ("conv_I", "conv_Q", "network"), "rvtdcnn": ()}   # (the others: "rnn")
 
 
 def _warn_float(exc, model):
@@ -345,7 +380,11 @@ def _quantise_heads(model, bits_w, bits_a, pre, dev):
                     p.copy_(pre_sd[f"backbone.{c}.{k}"])
             fc_w = {h: pre_sd[f"backbone.{h}.weight"] for h in heads}
         rnn = core.get("rnn")
-        if model.backbone_type == "neuraltx":
+        if model.backbone_type == "rvtdcnn":
+            conv = copy.deepcopy(fb.Conv2d).cpu()
+            conv.weight.copy_(fc_w["Conv2d"])
+            bb = QuantRVTDCNN(conv, fb.fc_hid_size, bits_w, bits_a)
+        elif model.backbone_type == "neuraltx":
             bb = QuantHeadNeuralTX(core["conv_I"], core["conv_Q"], core["network"], bits_w, bits_a)
         elif model.backbone_type == "deltajanet":
             bb = QuantHeadDeltaJANET(rnn, bits_w, bits_a, model.thx, model.thh)

@@ -54,6 +54,11 @@ CASES = [
     # neuraltx: the surgery's layer map holds nn.Conv2d and nn.Linear (quant_envs.py:145-148) — the Conv1d stack stays float, IQ_match -> INT_Linear
     ("quant_neuraltx_h12_w8a8", "neuraltx", 12, 8, 0, 0, False),
     ("quant_neuraltx_h20_w16a16", "neuraltx", 20, 16, 0, 0, False),
+    # rvtdcnn (feed-forward): Conv2d -> INT_Conv2D (weight scale from the weights: init_step_size; two scales), fc_hid / fc_out -> INT_Linear;
+    # the functional tanh calls stay float
+    ("quant_rvtdcnn_h12_w8a8", "rvtdcnn", 12, 8, 0, 0, False),
+    ("quant_rvtdcnn_h6_w16a16", "rvtdcnn", 6, 16, 0, 0, False),
+    ("quant_rvtdcnn_h32_w8a8", "rvtdcnn", 32, 8, 0, 0, False),
 ]
 
 

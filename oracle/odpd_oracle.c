@@ -55,7 +55,7 @@ static int64_t lstm_param_count(const odpd_model_t* m);
 int64_t oracle_param_count(const odpd_model_t* m) {
     int64_t H = m->hidden, F = feat_dim(m->backbone);
     if (m->bits_w > 0 && (m->backbone == ODPD_LSTM || m->backbone == ODPD_VDLSTM)) return lstm_param_count(m);   /* quantised head(s) */
-    if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET && m->backbone != ODPD_DELTAJANET && m->backbone != ODPD_NEURALTX) return qat_param_count(m);   /* quantised models: + the quantiser scales */
+    if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET && m->backbone != ODPD_DELTAJANET && m->backbone != ODPD_NEURALTX && m->backbone != ODPD_RVTDCNN) return qat_param_count(m);   /* quantised models: + the quantiser scales */
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1:
         return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
@@ -89,7 +89,7 @@ int64_t oracle_param_count(const odpd_model_t* m) {
     case ODPD_NEURALTX: /* neuraltx.py:18-38: two 5-tap FIRs, 4 -> C (bias), 4 depthwise k5, C -> 2, IQ_match (2,2); hidden = channels */
         return 10 + 4 * H + H + 4 * 5 * H + 2 * H + 4 + (m->bits_w > 0 ? 3 : 0);     /* + the INT_Linear IQ_match's scales */
     case ODPD_RVTDCNN:  /* rvtdcnn.py:19-33: Conv2d(1->3,k3) 27+3, fc_hid (H,36)+H, fc_out (2,H)+2; hidden = fc_hid_size (models.py:80-81) */
-        return 30 + 36 * H + H + 2 * H + 2;
+        return 30 + 36 * H + H + 2 * H + 2 + (m->bits_w > 0 ? 8 : 0);      /* + INT_Conv2D's two and the INT_Linears' three scales each */
     default: return -1;
     }
 }
@@ -2244,6 +2244,112 @@ static void rv_seq_bwd(int H, const real* p, int T, const real* x, const real* d
     }
 }
 
+/* `--quant` on rvtdcnn (bits_w > 0): Conv2d -> INT_Conv2D (quant_layers.py:10-45: weight and activation quantisers; the weight scale
+ * starts at 2 mean|w| / sqrt(Qp), init_step_size, and is rounded to a power of two like every scale), fc_hid / fc_out -> INT_Linear
+ * (:48-85), fc_out with the 16-bit output quantiser in eval mode; the functional tanh calls stay float.  Parameter order: Conv2d.weight,
+ * Conv2d.bias, its two scales; fc_hid.weight, .bias, three scales; fc_out.weight, .bias, three scales.  Scale gradients: exactly 0. */
+typedef struct { int H, bw, ba, eval; int64_t oK, okb, oqc, owh, obh, oqh, owo, obo, oqo, P; } rvq_layout_t;
+static void rvq_layout(const odpd_model_t* m, rvq_layout_t* g) {
+    int64_t H = m->hidden, o = 0;
+    g->H = (int)H; g->bw = m->bits_w; g->ba = m->bits_a; g->eval = m->flags & 1;
+    g->oK = o; o += 27; g->okb = o; o += 3; g->oqc = o; o += 2;
+    g->owh = o; o += 36 * H; g->obh = o; o += H; g->oqh = o; o += 3;
+    g->owo = o; o += 2 * H; g->obo = o; o += 2; g->oqo = o; o += 3;
+    g->P = o;
+}
+typedef struct { real inq[4][5], pin[4][5], z[RV_Z], zq[RV_Z], pz[RV_Z], hid[MAXH], hq[MAXH], ph[MAXH]; } rvq_sample_t;
+static void rvq_sample_fwd(const rvq_layout_t* L, const real* p, int T, const real* x, int t, rvq_sample_t* s, real* y) {
+    const int H = L->H;
+    const real scw = q_pow2(p[L->oqc]), sca = q_pow2(p[L->oqc + 1]), shw = q_pow2(p[L->oqh]), sha = q_pow2(p[L->oqh + 1]);
+    const real sow = q_pow2(p[L->oqo]), soa = q_pow2(p[L->oqo + 1]);
+    for (int w = 0; w < 4; ++w) {
+        real f[5];
+        rv_feat(x, rv_idx(t, w, T), f);
+        for (int j = 0; j < 5; ++j) s->inq[w][j] = q_apply(f[j], sca, L->ba, &s->pin[w][j]);
+    }
+    for (int c = 0; c < 3; ++c)
+        for (int w = 0; w < 4; ++w)
+            for (int j = 0; j < 3; ++j) {
+                double acc = 0;
+                for (int dw = 0; dw < 3; ++dw) {
+                    const int r = w + dw - 1;
+                    if (r < 0 || r > 3) continue;
+                    for (int dj = 0; dj < 3; ++dj) acc += (double)q_apply(p[L->oK + (c * 3 + dw) * 3 + dj], scw, L->bw, NULL) * (double)s->inq[r][j + dj];
+                }
+                s->z[(c * 4 + w) * 3 + j] = tanhr((real)acc + p[L->okb + c]);
+            }
+    for (int k = 0; k < RV_Z; ++k) s->zq[k] = q_apply(s->z[k], sha, L->ba, &s->pz[k]);
+    for (int u = 0; u < H; ++u) {
+        double acc = 0;
+        for (int k = 0; k < RV_Z; ++k) acc += (double)q_apply(p[L->owh + u * RV_Z + k], shw, L->bw, NULL) * (double)s->zq[k];
+        s->hid[u] = tanhr((real)acc + p[L->obh + u]);
+        s->hq[u] = q_apply(s->hid[u], soa, L->ba, &s->ph[u]);
+    }
+    for (int c = 0; c < 2; ++c) {
+        double acc = 0;
+        for (int u = 0; u < H; ++u) acc += (double)q_apply(p[L->owo + c * H + u], sow, L->bw, NULL) * (double)s->hq[u];
+        y[c] = (real)acc + p[L->obo + c];
+        if (L->eval) y[c] = q_apply(y[c], q_pow2(p[L->oqo + 2]), 16, NULL);
+    }
+}
+static void rvq_seq(const rvq_layout_t* L, const real* p, int T, const real* x, real* y, const real* dy, real* dp, real* dx, real* dfeat) {
+    const int H = L->H;
+    const real scw = q_pow2(p[L->oqc]), shw = q_pow2(p[L->oqh]), sow = q_pow2(p[L->oqo]);
+    rvq_sample_t s;
+    if (!dy) { for (int t = 0; t < T; ++t) rvq_sample_fwd(L, p, T, x, t, &s, y + 2 * t); return; }
+    memset(dfeat, 0, sizeof(real) * 5 * T);
+    for (int t = 0; t < T; ++t) {
+        real yy[2], dz[RV_Z], din[4][5];
+        rvq_sample_fwd(L, p, T, x, t, &s, yy);
+        const real d[2] = {dy[2 * t], dy[2 * t + 1]};
+        dp[L->obo] += d[0]; dp[L->obo + 1] += d[1];
+        for (int k = 0; k < RV_Z; ++k) dz[k] = 0;
+        for (int u = 0; u < H; ++u) {
+            real dhq = 0;
+            for (int c = 0; c < 2; ++c) {
+                real mk, wq = q_apply(p[L->owo + c * H + u], sow, L->bw, &mk);
+                dp[L->owo + c * H + u] += d[c] * s.hq[u] * mk;
+                dhq += wq * d[c];
+            }
+            const real dh = dhq * s.ph[u] * ((real)1 - s.hid[u] * s.hid[u]);
+            dp[L->obh + u] += dh;
+            for (int k = 0; k < RV_Z; ++k) {
+                real mk, wq = q_apply(p[L->owh + u * RV_Z + k], shw, L->bw, &mk);
+                dp[L->owh + u * RV_Z + k] += dh * s.zq[k] * mk;
+                dz[k] += wq * dh;
+            }
+        }
+        memset(din, 0, sizeof(din));
+        for (int c = 0; c < 3; ++c)
+            for (int w = 0; w < 4; ++w)
+                for (int j = 0; j < 3; ++j) {
+                    const int k = (c * 4 + w) * 3 + j;
+                    const real dc = dz[k] * s.pz[k] * ((real)1 - s.z[k] * s.z[k]);
+                    dp[L->okb + c] += dc;
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int r = w + dw - 1;
+                        if (r < 0 || r > 3) continue;
+                        for (int dj = 0; dj < 3; ++dj) {
+                            real mk, wq = q_apply(p[L->oK + (c * 3 + dw) * 3 + dj], scw, L->bw, &mk);
+                            dp[L->oK + (c * 3 + dw) * 3 + dj] += dc * s.inq[r][j + dj] * mk;
+                            din[r][j + dj] += wq * dc;
+                        }
+                    }
+                }
+        for (int w = 0; w < 4; ++w)
+            for (int f = 0; f < 5; ++f) dfeat[5 * rv_idx(t, w, T) + f] += din[w][f] * s.pin[w][f];
+    }
+    if (!dx) return;
+    for (int sx = 0; sx < T; ++sx) {
+        const real I = x[2 * sx], Q = x[2 * sx + 1];
+        const real a = (real)sqrt((double)(I * I + Q * Q));
+        const real* g = dfeat + 5 * sx;
+        const real ga = g[2] / a + (real)2 * g[3] + (real)3 * a * g[4];
+        dx[2 * sx] = g[0] + ga * I;
+        dx[2 * sx + 1] = g[1] + ga * Q;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* dispatch                                                                                     */
 /* ------------------------------------------------------------------------------------------ */
@@ -2319,6 +2425,9 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         real* g1 = pre + (size_t)5 * T * L.C; real* g2 = g1 + (size_t)T * L.C; real* dfq = g2 + (size_t)T * L.C;
         ntx_seq_fwd(&L, params, T, x, y, feat, pre);
         if (dy) ntx_seq_bwd(&L, params, T, x, dy, feat, pre, dp, dx, g1, g2, dfq);
+    } else if (bb == ODPD_RVTDCNN && m->bits_w > 0) {
+        rvq_layout_t L; rvq_layout(m, &L);
+        rvq_seq(&L, params, T, x, y, dy, dp, dx, (real*)scratch);
     } else if (bb == ODPD_RVTDCNN) {
         if (dy) rv_seq_bwd(m->hidden, params, T, x, dy, dp, dx, (real*)scratch);
         else rv_seq_fwd(m->hidden, params, T, x, y);

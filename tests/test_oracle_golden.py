@@ -118,7 +118,8 @@ QAT_MORE = [("quant_gru_h11_w8a8", "gru", 8), ("quant_gru_h23_w8a8", "gru", 8), 
 QAT_HEADS = [("quant_lstm_h14_w8a8", "lstm", 8), ("quant_lstm_h14_w16a16", "lstm", 16), ("quant_lstm_h24_w8a8", "lstm", 8), ("quant_lstm_h40_w8a8", "lstm", 8),
              ("quant_vdlstm_h13_w8a8", "vdlstm", 8), ("quant_vdlstm_h13_w16a16", "vdlstm", 16),
              ("quant_deltajanet_h12_w8a8", "deltajanet", 8), ("quant_deltajanet_h40_w16a16", "deltajanet", 16),
-             ("quant_neuraltx_h12_w8a8", "neuraltx", 8), ("quant_neuraltx_h20_w16a16", "neuraltx", 16)]
+             ("quant_neuraltx_h12_w8a8", "neuraltx", 8), ("quant_neuraltx_h20_w16a16", "neuraltx", 16),
+             ("quant_rvtdcnn_h12_w8a8", "rvtdcnn", 8), ("quant_rvtdcnn_h6_w16a16", "rvtdcnn", 16), ("quant_rvtdcnn_h32_w8a8", "rvtdcnn", 8)]
 _BUFFERS = ("n_bits", "pow2_scale", "decimal_num", "integer_num")
 
 

@@ -1,4 +1,4 @@
-"""`--quant` on lstm / vdlstm / deltajanet / neuraltx: the reference's surgery finds only the heads to swap (fc_out; vdlstm: fc_lambda_1, fc_lambda_2, fc_out:
+"""`--quant` on lstm / vdlstm / deltajanet / neuraltx / rvtdcnn: the reference's surgery finds only Linear / Conv2d layers to swap (fc_out; vdlstm: fc_lambda_1, fc_lambda_2, fc_out:
 nn.Linear -> INT_Linear, quant/quant_envs.py:40-60, 290-306; quant/qmodules/quant_layers.py:48-85), the recurrent core (nn.LSTM; deltajanet's
 nn.Parameter cell) stays float.  HIP path: the quantised-head instantiations of csrc/lstm_family.hip (lstm_eval_kernel / lstm_gp_train_kernel /
 lstm_bwd_kernel <.., QH>) and csrc/deltajanet_wide.hip (<.., QH>) against vectors produced by RUNNING the reference
@@ -138,6 +138,67 @@ def test_neuraltx_matches_the_oracle_on_ragged_sizes(C, B, T, bits):
     assert rel_err(xt.grad.cpu().numpy(), dxo) < 1e-3
     gm = q.backbone.IQ_match.weight.grad.cpu().numpy()
     assert gm[0, 0] == 0.0 and gm[1, 1] == 0.0 and abs(gm[0, 1]) > 0 and abs(gm[1, 0]) > 0      # the weight quantiser's pass mask (|w| > 2)
+
+
+@pytest.mark.parametrize("H,B,T,bits", [(12, 5, 37, 8), (1, 4, 9, 8), (6, 64, 50, 8), (32, 3, 300, 8), (25, 7, 45, 16), (16, 700, 20, 8), (20, 2, 3, 8)])
+def test_rvtdcnn_matches_the_oracle_on_ragged_sizes(H, B, T, bits):
+    """rvtdcnn with INT_Conv2D / INT_Linear layers (csrc/rvtdcnn_q.hip): forward in both modes, weight gradients and dL/dx against the oracle;
+    every weight tensor partly beyond its grid and every activation range narrowed, so all six pass masks are exercised."""
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H + B + T)
+    q = _fresh("rvtdcnn", H, bits).cuda()
+    bb = q.backbone
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(H)
+        for lay in (bb.Conv2d, bb.fc_hid, bb.fc_out):
+            lay.bias.copy_(((torch.rand(lay.bias.shape, generator=g) - 0.5) * 0.4).cuda())
+            lay.act_quantizer.scale.mul_(0.25)
+        bb.Conv2d.weight_quantizer.scale.mul_(0.125)
+        bb.Conv2d.weight.mul_(3.0)
+        bb.fc_hid.weight.mul_(4.0)
+        bb.fc_hid.weight_quantizer.scale.mul_(0.25)
+        bb.fc_out.weight.mul_(3.0 / float(bb.fc_out.weight.abs().max()))
+    x, dy = _signal(B, T, B + T)
+    o = Oracle("f32")
+    m = make_model("rvtdcnn", H, bits_w=bits, bits_a=bits)
+    p = np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in q.parameters()])
+    assert o.param_count(m) == p.size
+    step = 2.0 ** (2 - bits) * 8
+    # (16-bit grids with the ranges narrowed as above: a sample has 20 + 36 + H values next to grids of 4e-6 .. 1.5e-5 — most outputs hold
+    # one that rounded the other way; the bound is then the size of those moves, the reference fixtures carry the tight 16-bit check)
+    nflip = 4 + B * T // 2000 if bits == 8 else 2 * B * T
+    for mode in (q.eval, q.train):
+        mode()
+        with torch.no_grad():
+            y = q(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert grid_close(y, o.qat_forward(m, p, x, eval_mode=mode == q.eval), step, nflip)
+    xt = torch.from_numpy(x).cuda().requires_grad_(True)
+    q(xt).backward(torch.from_numpy(dy).cuda())
+    go, dxo = o.qat_backward(m, p, x, dy, need_dx=True)
+    off = 0
+    for k, v in q.named_parameters():
+        n = v.numel()
+        ref = go[off:off + n]
+        got = (v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy().reshape(-1)
+        if np.abs(ref).max() > 0:
+            assert rel_err(got, ref) < 3e-3, k
+        else:
+            assert np.abs(got).max() == 0, k
+        off += n
+    assert rel_err(xt.grad.cpu().numpy(), dxo) < 3e-3
+    for lay, lim in ((bb.Conv2d, None), (bb.fc_hid, None), (bb.fc_out, 2.0)):
+        w, gw = lay.weight.detach().cpu().numpy(), lay.weight.grad.cpu().numpy()
+        s = 2.0 ** np.rint(np.log2(abs(float(lay.weight_quantizer.scale.detach()))))
+        clipped = (w / s > 2 ** (bits - 1) - 1) | (w / s < -2 ** (bits - 1))
+        if bits == 8:
+            assert clipped.any(), lay
+        assert np.all(gw[clipped] == 0.0)
+    # dL/dx alone (the frozen-PA role)
+    for v in q.parameters():
+        v.requires_grad_(False)
+    xt2 = torch.from_numpy(x).cuda().requires_grad_(True)
+    q(xt2).backward(torch.from_numpy(dy).cuda())
+    assert rel_err(xt2.grad.cpu().numpy(), dxo) < 3e-3
 
 
 def _ragged(bb, H, B, T, bits):
