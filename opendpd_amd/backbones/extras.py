@@ -88,6 +88,76 @@ class NeuralTX(nn.Module):
         return z + self.IQ_match(iq) + iq
 
 
+class BOJANET(nn.Module):
+    """backbones/bojanet.py:5-138 — 16-tap complex FIR bank (6 filters) -> vector demodulator (|.|, |.|^2, phase) ->
+    JANET cell on the envelopes -> phase re-rotation of the state -> two linear read-outs.  ATen restatement for hidden 17 and 18 — the
+    two sizes between the HIP kernel's one unit tile (csrc/bojanet_s16.hip, <= 16) and the point where the reference's own phase
+    re-rotation stops building (bojanet.py:41-53, > 18); retired in r03, restored in r04."""
+    native = False
+
+    def __init__(self, hidden_size, output_size=2, bias=True):
+        super().__init__()
+        self.hidden_size, self.output_size, self.window_size, self.num_vd_units = hidden_size, output_size, 16, 6
+        H, P = hidden_size, 6
+        self.fir_I = nn.Linear(16, P, bias=False)
+        self.fir_Q = nn.Linear(16, P, bias=False)
+        self.W_fi = nn.Linear(2 * P, H, bias=bias)
+        self.W_fh = nn.Linear(H, H, bias=False)
+        self.W_gi = nn.Linear(2 * P, H, bias=bias)
+        self.W_gh = nn.Linear(H, H, bias=False)
+        self.W_out_I = nn.Linear(H, 1, bias=bias)
+        self.W_out_Q = nn.Linear(H, 1, bias=bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for m in (self.fir_I, self.fir_Q):
+            nn.init.xavier_uniform_(m.weight, gain=0.1)
+        for m in (self.W_fi, self.W_gi):
+            nn.init.xavier_uniform_(m.weight, gain=1.0)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        for m in (self.W_fh, self.W_gh):
+            nn.init.orthogonal_(m.weight, gain=1.0)
+        for m in (self.W_out_I, self.W_out_Q):
+            nn.init.xavier_uniform_(m.weight, gain=1.0)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x, h_0=None):
+        # The cell divides by the FIR outputs' magnitude (gain-0.1 taps): training amplifies rounding-level differences within tens
+        # of steps, so the ATen calls below are issued in the reference's own order and grouping (per-step gate projections, the
+        # same window tensor layout) — on the same device the trajectory is then bit-identical (bojanet.py:55-111).
+        B, T, H, P, M = x.shape[0], x.shape[1], self.hidden_size, self.num_vd_units, self.window_size
+        h = x.new_zeros(B, H) if h_0 is None else (h_0[0] if h_0.dim() == 3 else h_0)
+        xp = torch.cat((torch.zeros_like(x[:, -(M - 1):, :]), x), dim=1)
+        win = xp.unfold(dimension=1, size=M, step=1).transpose(2, 3).unsqueeze(2).contiguous().view(-1, T, M, x.size(2))
+        fi = (self.fir_I(win[:, :, :, 0]) - self.fir_Q(win[:, :, :, 1])).contiguous().view(-1, T, P)
+        fq = (self.fir_Q(win[:, :, :, 0]) + self.fir_I(win[:, :, :, 1])).contiguous().view(-1, T, P)
+        mag = torch.sqrt(torch.pow(fi, 2) + torch.pow(fq, 2)) + 1e-8
+        mag2 = mag ** 2
+        sin, cos = fq / mag, fi / mag
+        env = torch.stack([mag, mag2], dim=2).view(-1, T, 2 * P)
+        hs = []
+        for t in range(T):
+            e = env[:, t, :]
+            f = torch.sigmoid(self.W_fi(e) + self.W_fh(h))
+            g = torch.tanh(self.W_gi(e) + self.W_gh(h))
+            h = f * h + (1 - f) * g
+            hs.append(h)
+        hs = torch.stack(hs, dim=1).view(-1, T, H)
+        if P >= H:
+            cos, sin = cos[:, :, :H], sin[:, :, :H]
+        elif H <= 2 * P:
+            cos, sin = torch.cat([cos, cos[:, :, :H - P]], dim=-1), torch.cat([sin, sin[:, :, :H - P]], dim=-1)
+        else:
+            cos = torch.cat([cos, cos, cos[:, :, :H - 2 * P]], dim=-1)
+            sin = torch.cat([sin, sin, sin[:, :, :H - 2 * P]], dim=-1)
+        i_rot, q_rot = hs * cos, hs * sin
+        out_i = self.W_out_I(i_rot) - self.W_out_Q(q_rot)
+        out_q = self.W_out_Q(q_rot) + self.W_out_I(i_rot)       # ref quirk: both outputs mix the two read-outs
+        return torch.cat([out_i, out_q], dim=-1)
+
+
 class MCLDNN(nn.Module):
     """backbones/mcldnn.py:9-134 — per step a 5x5 patch [(I,Q,a,a^2,a^3) x memory]: Conv2d branch and grouped Conv1d branch,
     merged by a second Conv2d, then nn.LSTM(5C->8) over time and two Linear layers."""

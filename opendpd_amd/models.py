@@ -9,6 +9,8 @@ qgru_amp1 / lstm also two layers of <= 32 units, csrc/gru_layers2.hip, lstm_laye
 `native` False, with a warning) beyond it — backbones/wide.py for the hot-path names, backbones/extras.py for the SURVEY §8 f4 ones;
 mcldnn: <= 16 channels.  All 18 registry names are HIP-backed inside their envelopes.  Unknown names raise ValueError (models.py:139-141).
 """
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -72,7 +74,6 @@ class CoreModel(nn.Module):
             if hidden_size <= AP.MAX_HIDDEN:
                 self.backbone = B.APNRRU(hidden_size=hidden_size, bias=True)
             else:
-                import warnings
                 warnings.warn(f"opendpd_amd: backbone 'apnrru' with hidden_size={hidden_size} is outside the HIP kernel's envelope "
                               f"(hidden <= {AP.MAX_HIDDEN}): running the ATen restatement (backbones/extras.py)", stacklevel=2)
                 self.backbone = X.APNRRU(hidden_size=hidden_size, bias=True)
@@ -82,8 +83,9 @@ class CoreModel(nn.Module):
                 self.backbone = B.BOJANET(hidden_size=hidden_size, output_size=2, bias=True)
             else:
                 # hidden 17, 18 (beyond 18 the reference's own forward fails, bojanet.py:41-53): outside the kernel's one unit tile
-                raise NotImplementedError(f"bojanet: the HIP kernel covers hidden_size <= {BJ.MAX_HIDDEN} (csrc/bojanet_s16.hip); "
-                                          f"hidden_size={hidden_size} is not implemented")
+                warnings.warn(f"opendpd_amd: backbone 'bojanet' with hidden_size={hidden_size} is outside the HIP kernel's envelope "
+                              f"(hidden <= {BJ.MAX_HIDDEN}): running the ATen restatement (backbones/extras.py)", stacklevel=2)
+                self.backbone = X.BOJANET(hidden_size=hidden_size, output_size=2, bias=True)
         elif backbone_type == "deltajanet":
             self.backbone = B.DeltaJANET(input_size=6, hidden_size=hidden_size, output_size=2, num_layers=num_layers, thx=thx,
                                          thh=thh, bias=True)
@@ -93,7 +95,6 @@ class CoreModel(nn.Module):
                 self.backbone = B.DVRJANET(hidden_size=hidden_size, output_size=2, num_dvr_units=num_dvr_units, bias=True)
             else:
                 # beyond the kernel's envelope: the torch restatement through ATen, said aloud
-                import warnings
                 warnings.warn(f"opendpd_amd: backbone 'dvrjanet' with hidden_size={hidden_size}, num_dvr_units={num_dvr_units} is outside "
                               f"the HIP kernel's envelope (hidden <= {D.MAX_HIDDEN}, num_dvr_units <= {D.MAX_DVR_UNITS}): running the "
                               f"ATen restatement (backbones/extras.py)", stacklevel=2)
@@ -105,7 +106,6 @@ class CoreModel(nn.Module):
             if hidden_size <= MC.MAX_HIDDEN:
                 self.backbone = B.MCLDNN(hidden_size=hidden_size)
             else:
-                import warnings
                 warnings.warn(f"opendpd_amd: backbone 'mcldnn' with hidden_size={hidden_size} is outside the HIP kernel's envelope "
                               f"(channels <= {MC.MAX_HIDDEN}): running the ATen restatement (backbones/extras.py)", stacklevel=2)
                 self.backbone = X.MCLDNN(hidden_size=hidden_size)

@@ -149,7 +149,7 @@ def test_dvrjanet_is_native_and_constructs_like_the_reference():
 @pytest.mark.parametrize("H", [8, 15])
 def test_bojanet_is_native_and_constructs_like_the_reference(H):
     """bojanet left this module for csrc/bojanet_s16.hip (hidden <= 16); the seeded construction — the constructor's own draw and the
-    registry's second reset_parameters() — still reproduces the reference's state dict and RNG consumption; hidden 17, 18 are refused."""
+    registry's second reset_parameters() — still reproduces the reference's state dict and RNG consumption; hidden 17, 18 run the announced ATen restatement."""
     fx = Fixture(f"extra_bojanet_h{H}")
     net = _build("bojanet", H)
     after = float(torch.rand(1))
@@ -159,8 +159,27 @@ def test_bojanet_is_native_and_constructs_like_the_reference(H):
         assert np.array_equal(sd[k].numpy(), fx["sd/" + k]), k
     assert after == fx.meta["rng_after_init"]
     assert net.backbone.native is True and sum(p.numel() for p in net.parameters()) == fx.meta["n_param"] == 2 * H * H + 28 * H + 194
-    with pytest.raises(NotImplementedError):          # hidden 17, 18: beyond the kernel's unit tile (the torch restatement is gone)
-        _build("bojanet", 18)
+    # hidden 17, 18: beyond the kernel's unit tile — the announced ATen restatement (restored in r04), checked against the oracle
+    from oracle.oracle import Oracle, make_model
+    with pytest.warns(UserWarning, match="outside the HIP kernel's envelope"):
+        wide = _build("bojanet", 18)
+    assert wide.backbone.native is False and sum(p.numel() for p in wide.parameters()) == 2 * 18 * 18 + 28 * 18 + 194
+    rng = np.random.RandomState(3)
+    amp, ph = 0.1 + 0.8 * rng.rand(2, 40, 1), 2 * np.pi * rng.rand(2, 40, 1)
+    x = np.concatenate([amp * np.cos(ph), amp * np.sin(ph)], -1).astype(np.float32)
+    p = np.concatenate([v.detach().numpy().reshape(-1) for v in wide.parameters()])
+    xt = torch.from_numpy(x).requires_grad_(True)
+    y = wide(xt)
+    o, m = Oracle("f32"), make_model("bojanet", 18)
+    yo, _ = o.forward(m, p, x)
+    assert np.abs(y.detach().numpy() - yo).max() < 2e-5 * max(1.0, np.abs(yo).max())
+    dy = rng.randn(2, 40, 2).astype(np.float32)
+    y.backward(torch.from_numpy(dy))
+    go, dxo = o.backward(m, p, x, dy, need_dx=True)
+    g = np.concatenate([v.grad.numpy().reshape(-1) for v in wide.parameters()])
+    assert np.abs(g - go).max() < 2e-4 * np.abs(go).max() and np.abs(xt.grad.numpy() - dxo).max() < 2e-4 * np.abs(dxo).max()
+    with pytest.raises(Exception):                    # beyond 18 the reference's own phase re-rotation cannot be built (bojanet.py:41-53)
+        _build("bojanet", 19)(torch.from_numpy(x))
 
 
 def test_apnrru_is_native_and_constructs_like_the_reference():
