@@ -7,9 +7,10 @@
 // Mapping: ONE LANE PER SAMPLE (as csrc/rvtdcnn.hip), but a plain kernel: the workgroup stages the parameters in LDS and quantises the three
 // weight tensors IN PLACE there (every later read is a broadcast of q_w(W)); a sample's patch, conv outputs and their quantised values live in
 // registers; the fc_hid rows are visited twice (forward, then backward with the row's activation recomputed) so that nothing per-unit is kept.
-// Weight gradients: per unit the lane's 36 + 3 products are summed over the wave (DPP + two cross-row shuffles) into the wave's own LDS row,
-// the four rows are added in fixed order at the end (deterministic); the 27 + 3 convolution gradients and the fc_out bias are per-lane
-// accumulators reduced once.  The weight quantisers' pass masks are applied at write-out from the global (unquantised) weights, the eight
+// Weight gradients of fc_hid / fc_out are contractions over SAMPLES: each wave parks its 64 samples' columns [dL/dpre_u | q_a(z) | dy | q_a(hid)]
+// in a private LDS tile and accumulates the 16 x 16 output tiles with v_mfma_f32_16x16x4_f32 (exact fp32; the sample index is K — the operand
+// layout of csrc/rvtdcnn.hip); the 27 + 3 convolution gradients and the fc_out bias are per-lane accumulators reduced once; every wave
+// deposits its sums in its own LDS row and the four rows are added in fixed order at the end (deterministic).  The weight quantisers' pass masks are applied at write-out from the global (unquantised) weights, the eight
 // scale columns stay 0 (round() inside the quantiser: quantizers.py:56-65).  dL/dx in gather form: the lane of sample s repeats the forward
 // and backward of the four samples whose patch holds s (rows 3 .. 0) and keeps its own row of each patch gradient — no atomics, no exchange.
 #include <type_traits>
@@ -38,6 +39,9 @@ __host__ __device__ inline RvqLayout rvq_layout(int H) {
     return L;
 }
 struct RvqQ { q16::Quant ca, ha, oa, out; };      // the three activation quantisers, fc_out's output quantiser
+// per-wave LDS tile of MODE 1 (sample = lane is the fast index; stride 68 = 4 mod 32 floats: the MFMA operand reads of lanes (element n,
+// sample 4c + q) land on banks 4n + q + const): dhp[u][s] (32 units), hq[u][s], zq[k][s] (36), dy[c][s]
+constexpr int kQCol = 68, kQoDh = 0, kQoHq = 32 * kQCol, kQoZ = 64 * kQCol, kQoDy = kQoZ + kQZ * kQCol, kQTile = kQoDy + 2 * 64;
 
 __device__ __forceinline__ float rvq_wsum(float v) {
     v = row_sum16(v);
@@ -108,7 +112,7 @@ __device__ __forceinline__ void rvq_head(const float* pl, const RvqLayout& L, co
     }
     y0 = p0 + pl[L.obo]; y1 = p1 + pl[L.obo + 1];
 }
-// dL/dz of one sample (through fc_out, the tanh of fc_hid and the quantisers' pass masks); NW: the unit's weight gradients go to `row`
+// dL/dz of one sample (through fc_out, the tanh of fc_hid and the quantisers' pass masks); NW: the unit's columns go to the wave's tile `row`
 template <bool NW>
 __device__ __forceinline__ void rvq_back_rows(const float* pl, const RvqLayout& L, const RvqQ& Q, const float (&zq)[kQZ], float d0, float d1, float own,
                                               float* row, int lane, float (&dz)[kQZ]) {
@@ -121,15 +125,9 @@ __device__ __forceinline__ void rvq_back_rows(const float* pl, const RvqLayout& 
         const float dh = ((pl[L.owo + u] * d0 + pl[L.owo + L.H + u] * d1) * ph) * (1.0f - hid * hid);
 #pragma unroll
         for (int k = 0; k < kQZ; ++k) dz[k] = __builtin_fmaf(w[k], dh, dz[k]);
-        if constexpr (NW) {
-            const float dho = own * dh;
-#pragma unroll
-            for (int k = 0; k < kQZ; ++k) {
-                const float v = rvq_wsum(dho * zq[k]);
-                if (lane == 0) row[L.owh + u * kQZ + k] += v;
-            }
-            const float vb = rvq_wsum(dho), v0 = rvq_wsum(own * d0 * hq), v1 = rvq_wsum(own * d1 * hq);
-            if (lane == 0) { row[L.obh + u] += vb; row[L.owo + u] += v0; row[L.owo + L.H + u] += v1; }
+        if constexpr (NW) {      // `row` = the wave's tile: this unit's columns (d0 / d1 carry `own`, so idle samples contribute zeros)
+            row[kQoDh + u * kQCol + lane] = own * dh;
+            row[kQoHq + u * kQCol + lane] = hq;
         }
     }
 }
@@ -143,9 +141,12 @@ __global__ __launch_bounds__(kQT) void rvq_kernel(SeqArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P4 = pad4(L.P + kLossCols);
     float* pl = smem;
     float* row = smem + pad4(L.P) + wave * P4;          // MODE 1: this wave's gradient row
+    float* tile = smem + pad4(L.P) + 4 * P4 + wave * kQTile;      // ... and its operand tile
     for (int i = tid; i < L.P; i += kQT) pl[i] = a.params[i];
-    if constexpr (MODE == 1)
+    if constexpr (MODE == 1) {
         for (int i = tid; i < 4 * P4; i += kQT) smem[pad4(L.P) + i] = 0.0f;
+        for (int i = tid; i < 4 * kQTile; i += kQT) smem[pad4(L.P) + 4 * P4 + i] = 0.0f;      // (units >= H are never written: zero operands)
+    }
     __syncthreads();
     RvqQ Q;
     Q.ca = q16::make_quant(pl[L.oqc + 1], a.bits_a); Q.ha = q16::make_quant(pl[L.oqh + 1], a.bits_a);
@@ -161,6 +162,17 @@ __global__ __launch_bounds__(kQT) void rvq_kernel(SeqArgs a) {
     const float2* x2 = reinterpret_cast<const float2*>(a.x);
     const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, a.inv_count, true);
     float dK[27], dkb[3] = {0.f, 0.f, 0.f}, dbo[2] = {0.f, 0.f}, loss_acc = 0.0f;
+    f32x4 Dz[2][3], Dh[2];                             // MODE 1: dW_hid | db_hid tiles (units x (36 z columns + the constant 1)), dW_out tiles
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        Dh[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) Dz[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int n = lane & 15, q = lane >> 4;
+    // B-operand selectors of the third z tile (columns 32 + n): z[32 .. 35], then the constant 1 (bias gradient), then nothing
+    const int zk2 = n < 4 ? 32 + n : 35;
+    const float zmul2 = n < 4 ? 1.0f : 0.0f, zadd2 = n == 4 ? 1.0f : 0.0f, ymask = n < 2 ? 1.0f : 0.0f;
 #pragma unroll
     for (int i = 0; i < 27; ++i) dK[i] = 0.0f;
     const long long N = (long long)a.B * a.T;
@@ -194,7 +206,29 @@ __global__ __launch_bounds__(kQT) void rvq_kernel(SeqArgs a) {
             }
             d0 *= own; d1 *= own;
             dbo[0] += d0; dbo[1] += d1;
-            rvq_back_rows<true>(pl, L, Q, zq, d0, d1, own, row, lane, dz);
+            wave_lds_fence();                                  // the previous pass's MFMA operand reads are done
+#pragma unroll
+            for (int k = 0; k < kQZ; ++k) tile[kQoZ + k * kQCol + lane] = zq[k];
+            tile[kQoDy + lane] = d0; tile[kQoDy + 64 + lane] = d1;
+            rvq_back_rows<true>(pl, L, Q, zq, d0, d1, own, tile, lane, dz);
+            wave_lds_fence();
+#pragma unroll 4
+            for (int c = 0; c < 16; ++c) {                     // K = the wave's 64 samples, four per MFMA
+                const int sm = 4 * c + q;
+                const float ay = ymask * tile[kQoDy + (n & 1) * 64 + sm];
+                float ad[2], hv[2], bz[3];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) { ad[mt] = tile[kQoDh + (16 * mt + n) * kQCol + sm]; hv[mt] = tile[kQoHq + (16 * mt + n) * kQCol + sm]; }
+                bz[0] = tile[kQoZ + n * kQCol + sm];
+                bz[1] = tile[kQoZ + (16 + n) * kQCol + sm];
+                bz[2] = __builtin_fmaf(tile[kQoZ + zk2 * kQCol + sm], zmul2, zadd2);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) Dz[mt][nt] = mfma4(ad[mt], bz[nt], Dz[mt][nt]);
+                    Dh[mt] = mfma4(ay, hv[mt], Dh[mt]);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -250,6 +284,24 @@ __global__ __launch_bounds__(kQT) void rvq_kernel(SeqArgs a) {
         }
     }
     if constexpr (MODE == 1) {
+        // element i of a tile on lane (n, q): row 4 q + i, column n.  Dz[mt][nt]: unit 16 mt + 4 q + i x z column 16 nt + n (column 36: the bias);
+        // Dh[mt]: output channel 4 q + i x unit 16 mt + n
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = 16 * mt + 4 * q + i;
+                if (u < L.H) {
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) {
+                        const int k = 16 * nt + n;
+                        if (k < kQZ) row[L.owh + u * kQZ + k] = Dz[mt][nt][i];
+                        else if (k == kQZ) row[L.obh + u] = Dz[mt][nt][i];
+                    }
+                }
+                const int c = 4 * q + i, uo = 16 * mt + n;
+                if (c < 2 && uo < L.H) row[L.owo + c * L.H + uo] = Dh[mt][i];
+            }
 #pragma unroll
         for (int i = 0; i < 27; ++i) { const float v = rvq_wsum(dK[i]); if (lane == 0) row[L.oK + i] = v; }
 #pragma unroll
@@ -301,7 +353,7 @@ int rvtdcnn_q_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, bool 
     const RvqLayout L = rvq_layout(m->hidden);
     const int grid = rvq_grid(a.B, a.T);
     if (a.partials != nullptr) {
-        const size_t lds = (size_t)(pad4(L.P) + 4 * pad4(L.P + kLossCols)) * sizeof(float);
+        const size_t lds = (size_t)(pad4(L.P) + 4 * pad4(L.P + kLossCols) + 4 * kQTile) * sizeof(float);
         if (int e = fused ? rvq_launch(st, rvq_kernel<1, true>, grid, lds, a) : rvq_launch(st, rvq_kernel<1, false>, grid, lds, a)) return e;
     }
     if (a.dx != nullptr && !fused) return rvq_launch(st, rvq_kernel<2, false>, grid, (size_t)pad4(L.P) * sizeof(float), a);
