@@ -75,7 +75,8 @@ typedef struct odpd_model {
                          output quantiser in either mode (no module is named fc_out);
                          dvrjanet: num_dvr_units (models.py:119);
                          > 0 on rvtdcnn: Conv2d as INT_Conv2D (two scales behind its bias), fc_hid / fc_out as INT_Linear (three scales each);
-                         > 0 on any other backbone (no quantised kernels: pgjanet, apnrru, bojanet, mcldnn, deltagru; nothing to
+                         > 0 on pgjanet (hidden <= 32): its six nn.Linear as INT_Linear, three scales behind each layer's bias;
+                         > 0 on any other backbone (no quantised kernels: apnrru, bojanet, mcldnn, deltagru; nothing to
                          quantise: gmp, tcnn): every entry point answers ODPD_EINVAL — never the float kernels */
     int32_t bits_a;   /* QAT activation bits */
     int32_t flags;    /* ODPD_FLAG_* */

@@ -55,7 +55,7 @@ inline int feat_dim(int bb) {
 // models served by the lane-per-unit kernels (gru_wide.hip, lstm_wide.hip, vdlstm_wide.hip, delta_wide.hip: 33 .. 64 hidden units; janet_wide.hip: pgjanet 17 .. 32): forward / backward
 // only — the fused entry points answer ODPD_EUNSUPPORTED for them and the caller chains forward, loss, backward
 inline bool lane_per_unit_model(const odpd_model_t* m) {
-    return gru_wide_ok(m) || lstm_wide_ok(m) || vdlstm_wide_ok(m) || delta_wide_ok(m) || pgjanet_wide_ok(m) || deltajanet_wide_ok(m);
+    return gru_wide_ok(m) || lstm_wide_ok(m) || vdlstm_wide_ok(m) || delta_wide_ok(m) || pgjanet_wide_ok(m) || deltajanet_wide_ok(m) || pgjanet_q_ok(m);
 }
 // bits_w > 0 selects a quantised model only where one exists (include/opendpd_hip.h, odpd_model_t::bits_w); on every other backbone
 // the descriptor is refused outright — no entry point may answer it with the float kernels on a float parameter layout
@@ -65,6 +65,7 @@ inline bool quant_desc_ok(const odpd_model_t* m) {
     case ODPD_GRU: case ODPD_DGRU: case ODPD_QGRU: case ODPD_QGRU_AMP1: case ODPD_TRES_DELTAGRU:      // the surgery's quantised cells
     case ODPD_LSTM: case ODPD_VDLSTM: case ODPD_DELTAJANET: case ODPD_NEURALTX:                      // float core, INT_Linear heads
     case ODPD_RVTDCNN:                                                                               // INT_Conv2D + INT_Linear layers (rvtdcnn_q.hip)
+    case ODPD_PGJANET:                                                                               // six INT_Linear (pgjanet_q.hip)
         return m->bits_a > 0;
     default: return false;
     }
@@ -132,7 +133,8 @@ extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
     case ODPD_TRES_DELTAGRU: return 3 * H * 6 + 3 * H * H + 2 * H + 18 + 6;
     case ODPD_DELTAJANET: return 2 * H * 6 + 2 * H * H + 4 * H + 2 * H + 2 + (m->bits_w > 0 ? 3 : 0);      // two gates (deltajanet.py:96-111) + fc_out (bits_w > 0: INT_Linear, + three scales)
     case ODPD_TCNN: return 6 * H + H + 4 * 5 * H + 2 * H;
-    case ODPD_PGJANET: return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
+    case ODPD_PGJANET: return m->bits_w > 0 ? (pgjanet_q_ok(m) ? pgjanet_q_param_count(m) : (int64_t)ODPD_EUNSUPPORTED)
+                                            : 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
     case ODPD_NEURALTX: return H <= 64 ? 27 * H + 14 + (m->bits_w > 0 ? 3 : 0) : (int64_t)ODPD_EUNSUPPORTED;   // two 5-tap FIRs, 4->C (+bias), 4 x depthwise k5, C->2, IQ_match 2x2 (bits_w > 0: INT_Linear, + three scales)
     case ODPD_GMP: return H == 11 ? H * (1 + 4 * H) : (int64_t)ODPD_EUNSUPPORTED;   // memory_length 11, degree 5 (models.py:26-28)
     case ODPD_DVRJANET: return dvrjanet_param_count(m);   // K + 7H^2 + 7H + 2, K = bits_w (dvrjanet.py:11-30, 47-52)
@@ -158,6 +160,7 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (family_of(m) == FAM_LSTM && vdlstm_wide_ok(m)) return vdlstm_wide_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_DELTA && delta_wide_ok(m)) return delta_wide_ckpt_floats(m, B, T);
     if (family_of(m) == FAM_DELTA && deltajanet_wide_ok(m)) return deltajanet_wide_ckpt_floats(m, B, T);
+    if (family_of(m) == FAM_JANET && m->bits_w > 0) return pgjanet_q_ok(m) ? pgjanet_q_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
     if (family_of(m) == FAM_JANET && pgjanet_wide_ok(m)) return pgjanet_wide_ckpt_floats(m, B, T);
     const int R = rows_per_seq(m->hidden);
     if (!R) return ODPD_EUNSUPPORTED;
@@ -196,6 +199,7 @@ extern "C" int64_t odpd_partial_rows(const odpd_model_t* m, int B, int T, int fu
         if (fused) return delta_train_uses_gp(m, B, T) ? (int64_t)delta_gp_train_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return delta_family_rows(m, B, T);
     case FAM_JANET:
+        if (m->bits_w > 0) return (fused || !pgjanet_q_ok(m)) ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)pgjanet_q_rows(m, B);
         if (pgjanet_wide_ok(m)) return fused ? (int64_t)ODPD_EUNSUPPORTED : (int64_t)pgjanet_wide_rows(m, B);
         if (fused) return janet_train_uses_gp(m, B, T) ? (int64_t)janet_gp_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
         return janet_family_rows(m, B);
@@ -257,7 +261,9 @@ extern "C" int odpd_backbone_fwd(void* stream, const odpd_model_t* m, int B, int
     case FAM_DELTA:
         if (deltajanet_wide_ok(m)) return deltajanet_wide_fwd((hipStream_t)stream, m, a);
         return delta_wide_ok(m) ? delta_wide_fwd((hipStream_t)stream, m, a) : delta_family_fwd((hipStream_t)stream, m, a);
-    case FAM_JANET: return pgjanet_wide_ok(m) ? pgjanet_wide_fwd((hipStream_t)stream, m, a) : janet_family_fwd((hipStream_t)stream, m, a);
+    case FAM_JANET:
+        if (m->bits_w > 0) return pgjanet_q_fwd((hipStream_t)stream, m, a);      // `--quant`: six INT_Linear (pgjanet_q.hip)
+        return pgjanet_wide_ok(m) ? pgjanet_wide_fwd((hipStream_t)stream, m, a) : janet_family_fwd((hipStream_t)stream, m, a);
     case FAM_DVR: return dvrjanet_launch((hipStream_t)stream, m, a, 1);
     case FAM_BOJ: return bojanet_launch((hipStream_t)stream, m, a, 1);
     case FAM_APN: return apnrru_launch((hipStream_t)stream, m, a, 1);
@@ -294,6 +300,7 @@ extern "C" int odpd_backbone_bwd(void* stream, const odpd_model_t* m, int B, int
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return delta_family_bwd((hipStream_t)stream, m, a);
     case FAM_JANET:
+        if (m->bits_w > 0) return pgjanet_q_bwd((hipStream_t)stream, m, a);
         if (pgjanet_wide_ok(m)) return pgjanet_wide_bwd((hipStream_t)stream, m, a);
         if (!ckpt && a.nck > 1) return ODPD_EINVAL;
         return janet_family_bwd((hipStream_t)stream, m, a);

@@ -359,6 +359,13 @@ int rvtdcnn_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);  // f
 int rvtdcnn_rows(const odpd_model_t* m, int B, int T);                       // partials rows of the split backward (with or without dL/dx)
 int rvtdcnn_train_rows(const odpd_model_t* m, int B, int T);                 // ... of the fused step
 int rvtdcnn_rows_for(int B, int T, bool dx);
+// the quantised pgjanet (bits_w > 0; csrc/pgjanet_q.hip): forward / backward, hidden <= 32
+bool pgjanet_q_ok(const odpd_model_t* m);
+int64_t pgjanet_q_param_count(const odpd_model_t* m);
+int64_t pgjanet_q_ckpt_floats(const odpd_model_t* m, int B, int T);
+int pgjanet_q_rows(const odpd_model_t* m, int B);
+int pgjanet_q_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int pgjanet_q_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 // the quantised rvtdcnn (bits_w > 0; csrc/rvtdcnn_q.hip)
 bool rvtdcnn_q_ok(const odpd_model_t* m, int T);
 int64_t rvtdcnn_q_param_count(const odpd_model_t* m);

@@ -267,6 +267,22 @@ class QuantRVTDCNN(_QuantBase):
         self._finish(fc_hid_size, bits_w, bits_a)
 
 
+class QuantPGJANET(_QuantBase):
+    """pgjanet after the surgery: its six nn.Linear — the gates W_a, W_p1, W_p2, W_f, W_g and the read-out W_o (pgjanet.py:11-21) — become
+    INT_Linear in named_children order, each with three scales; the functional tanh / sigmoid calls stay float; no module is named fc_out, so
+    no output quantiser runs.  Kernels: csrc/pgjanet_q.hip (hidden <= 32)."""
+    backbone_name = "pgjanet"
+
+    def __init__(self, hidden_size, bits_w, bits_a):
+        super().__init__()
+        H = self.hidden_size = hidden_size
+        self.output_size, self.bias = 2, True
+        self.W_a, self.W_p1, self.W_p2 = (_QLinear(H + 1, H, bits_w, bits_a) for _ in range(3))
+        self.W_f, self.W_g = _QLinear(2 * H, H, bits_w, bits_a), _QLinear(2 * H, H, bits_w, bits_a)
+        self.W_o = _QLinear(H, 2, bits_w, bits_a)
+        self._finish(H, bits_w, bits_a)
+
+
 class _QDeltaLayer(nn.Module):
     """DeltaGRULayer of deltagru_tcnskip.py:133-162 after the surgery: bias-free INT_Linear x2h / h2h, Quant_add / mult / sigmoid /
     tanh in the layer's own registration order."""
@@ -334,11 +350,11 @@ class QuantTResDeltaGRU(_QuantBase):
 
 MAX_HIDDEN = 32          # csrc/qat_s16.hip: two 16-unit tiles
 _UNTOUCHED = ("gmp", "tcnn")       # no nn.GRU, no nn.Linear, no op modules: the surgery returns an identical deep copy
-_PARTIAL = ("apnrru", "bojanet", "dvrjanet", "mcldnn", "pgjanet")
-_HEAD_ONLY = ("lstm", "vdlstm", "deltajanet", "neuraltx", "rvtdcnn")    # only nn.Linear / nn.Conv2d layers to swap, and kernels for the result exist
+_PARTIAL = ("apnrru", "bojanet", "dvrjanet", "mcldnn")
+_HEAD_ONLY = ("lstm", "vdlstm", "deltajanet", "neuraltx", "rvtdcnn", "pgjanet")    # only nn.Linear / nn.Conv2d layers to swap, and kernels for the result exist
 _HEAD_MAX_HIDDEN = {"deltajanet": 64, "neuraltx": 64, "lstm": 64}      # csrc/deltajanet_wide.hip, tcnn.hip, lstm_wide.hip (33 .. 64) carry the quantised head
-_HEAD_LAYERS = {"rvtdcnn": ("Conv2d", "fc_hid", "fc_out"), "lstm": ("fc_out",), "vdlstm": ("fc_lambda_1", "fc_lambda_2", "fc_out"), "deltajanet": ("fc_out",), "neuraltx": ("IQ_match",)}
-_FLOAT_CORE = {"neuraltx": ("conv_I", "conv_Q", "network"), "rvtdcnn": ()}   # (the others: "rnn")
+_HEAD_LAYERS = {"pgjanet": ("W_a", "W_p1", "W_p2", "W_f", "W_g", "W_o"), "rvtdcnn": ("Conv2d", "fc_hid", "fc_out"), "lstm": ("fc_out",), "vdlstm": ("fc_lambda_1", "fc_lambda_2", "fc_out"), "deltajanet": ("fc_out",), "neuraltx": ("IQ_match",)}
+_FLOAT_CORE = {"neuraltx": ("conv_I", "conv_Q", "network"), "rvtdcnn": (), "pgjanet": ()}   # (the others: "rnn")
 
 
 def _warn_float(exc, model):
@@ -380,7 +396,9 @@ def _quantise_heads(model, bits_w, bits_a, pre, dev):
                     p.copy_(pre_sd[f"backbone.{c}.{k}"])
             fc_w = {h: pre_sd[f"backbone.{h}.weight"] for h in heads}
         rnn = core.get("rnn")
-        if model.backbone_type == "rvtdcnn":
+        if model.backbone_type == "pgjanet":
+            bb = QuantPGJANET(fb.hidden_size, bits_w, bits_a)
+        elif model.backbone_type == "rvtdcnn":
             conv = copy.deepcopy(fb.Conv2d).cpu()
             conv.weight.copy_(fc_w["Conv2d"])
             bb = QuantRVTDCNN(conv, fb.fc_hid_size, bits_w, bits_a)

@@ -59,6 +59,10 @@ CASES = [
     ("quant_rvtdcnn_h12_w8a8", "rvtdcnn", 12, 8, 0, 0, False),
     ("quant_rvtdcnn_h6_w16a16", "rvtdcnn", 6, 16, 0, 0, False),
     ("quant_rvtdcnn_h32_w8a8", "rvtdcnn", 32, 8, 0, 0, False),
+    # pgjanet: its six nn.Linear (the gates of the cell and the read-out) -> INT_Linear; functional tanh / sigmoid stay float
+    ("quant_pgjanet_h11_w8a8", "pgjanet", 11, 8, 0, 0, False),
+    ("quant_pgjanet_h9_w16a16", "pgjanet", 9, 16, 0, 0, False),
+    ("quant_pgjanet_h24_w8a8", "pgjanet", 24, 8, 0, 0, False),
 ]
 
 

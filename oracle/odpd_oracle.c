@@ -55,7 +55,7 @@ static int64_t lstm_param_count(const odpd_model_t* m);
 int64_t oracle_param_count(const odpd_model_t* m) {
     int64_t H = m->hidden, F = feat_dim(m->backbone);
     if (m->bits_w > 0 && (m->backbone == ODPD_LSTM || m->backbone == ODPD_VDLSTM)) return lstm_param_count(m);   /* quantised head(s) */
-    if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET && m->backbone != ODPD_DELTAJANET && m->backbone != ODPD_NEURALTX && m->backbone != ODPD_RVTDCNN) return qat_param_count(m);   /* quantised models: + the quantiser scales */
+    if (m->bits_w > 0 && m->backbone != ODPD_DVRJANET && m->backbone != ODPD_DELTAJANET && m->backbone != ODPD_NEURALTX && m->backbone != ODPD_RVTDCNN && m->backbone != ODPD_PGJANET) return qat_param_count(m);   /* quantised models: + the quantiser scales */
     switch (m->backbone) {
     case ODPD_GRU: case ODPD_QGRU: case ODPD_QGRU_AMP1:
         return 3 * H * F + 3 * H * H + 6 * H + 2 * H + 2;
@@ -72,7 +72,7 @@ int64_t oracle_param_count(const odpd_model_t* m) {
     case ODPD_TCNN:
         return 6 * H + H + 4 * 5 * H + 2 * H;
     case ODPD_PGJANET:
-        return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2;
+        return 3 * (H * (H + 1) + H) + 2 * (H * 2 * H + H) + 2 * H + 2 + (m->bits_w > 0 ? 18 : 0);      /* + three scales per INT_Linear */
     case ODPD_GMP:      /* gmp.py:10-11: memory_length * (1 + (degree - 1) * memory_length); hidden = memory_length, degree 5 */
         return H * (1 + (GMP_DEGREE - 1) * H);
     case ODPD_DVRJANET: /* dvrjanet.py:13-30: cs (K = bits_w), seven HxH blocks, two H input columns, three H biases, two heads */
@@ -1111,6 +1111,93 @@ static void pgj_seq_bwd(const pgj_layout_t* L, const real* p, int T, const real*
             real dth = -s->st * dct + s->ct * dst;
             dx[2 * t] = damp * I / s->amp - dth * Q / a2;
             dx[2 * t + 1] = damp * Q / s->amp + dth * I / a2;
+        }
+    }
+}
+
+/* `--quant` on pgjanet (bits_w > 0): its six nn.Linear (W_a, W_p1, W_p2 on [h, scalar]; W_f, W_g on [h, u]; W_o on h) become INT_Linear
+ * (qlin_fwd / qlin_bwd: each quantises its input on an activation grid of its own), three scales behind each layer's bias; the tanh / sigmoid
+ * calls are functional and stay float; no module is named fc_out, so no output quantiser runs in either mode (quant_envs.py:276-284). */
+typedef struct { int H, bw, ba; int64_t ow[6], ob[6], oq[6], P; } pgq_layout_t;      /* 0 W_a 1 W_p1 2 W_p2 3 W_f 4 W_g 5 W_o */
+static void pgq_layout(const odpd_model_t* m, pgq_layout_t* g) {
+    int64_t H = m->hidden, o = 0;
+    g->H = (int)H; g->bw = m->bits_w; g->ba = m->bits_a;
+    for (int l = 0; l < 6; ++l) {
+        const int64_t nin = l < 3 ? H + 1 : (l < 5 ? 2 * H : H), nout = l < 5 ? H : 2;
+        g->ow[l] = o; o += nout * nin; g->ob[l] = o; o += nout; g->oq[l] = o; o += 3;
+    }
+    g->P = o;
+}
+typedef struct {
+    real amp, ct, st, hp[MAXH], an[MAXH], p1[MAXH], p2[MAXH], f[MAXH], g[MAXH];
+    real inq[6][2 * MAXH], pass[6][2 * MAXH];      /* q_a(input), pass mask of each INT_Linear */
+} pgq_step_t;
+static void pgq_seq_fwd(const pgq_layout_t* L, const real* p, int T, const real* x, real* y, pgq_step_t* S) {
+    const int H = L->H;
+    real h[MAXH] = {0};
+    pgq_step_t tmp;
+    for (int t = 0; t < T; ++t) {
+        pgq_step_t* s = S ? &S[t] : &tmp;
+        const real I = x[2 * t], Q = x[2 * t + 1];
+        s->amp = (real)sqrt((double)(I * I + Q * Q));
+        const real th = (real)atan2((double)Q, (double)I);
+        s->ct = (real)cos((double)th); s->st = (real)sin((double)th);
+        real in[2 * MAXH], pre[3][MAXH], u[MAXH];
+        for (int j = 0; j < H; ++j) { s->hp[j] = h[j]; in[j] = h[j]; }
+        const real sc[3] = {s->amp, s->ct, s->st};
+        for (int l = 0; l < 3; ++l) {
+            in[H] = sc[l];
+            qlin_fwd(p, L->ow[l], L->ob[l], L->oq[l], H, H + 1, L->bw, L->ba, in, s->inq[l], s->pass[l], pre[l]);
+        }
+        for (int j = 0; j < H; ++j) {
+            s->an[j] = tanhr(pre[0][j]); s->p1[j] = tanhr(pre[1][j]); s->p2[j] = tanhr(pre[2][j]);
+            u[j] = s->an[j] * s->p1[j] * s->p2[j] * ((real)1 - s->an[j]) * ((real)1 - s->p1[j]) * ((real)1 - s->p2[j]);
+            in[H + j] = u[j];
+        }
+        qlin_fwd(p, L->ow[3], L->ob[3], L->oq[3], H, 2 * H, L->bw, L->ba, in, s->inq[3], s->pass[3], pre[0]);
+        qlin_fwd(p, L->ow[4], L->ob[4], L->oq[4], H, 2 * H, L->bw, L->ba, in, s->inq[4], s->pass[4], pre[1]);
+        for (int j = 0; j < H; ++j) {
+            s->f[j] = sigm(pre[0][j]); s->g[j] = tanhr(pre[1][j]);
+            h[j] = s->f[j] * h[j] + ((real)1 - s->f[j]) * s->g[j];
+        }
+        qlin_fwd(p, L->ow[5], L->ob[5], L->oq[5], 2, H, L->bw, L->ba, h, s->inq[5], s->pass[5], &y[2 * t]);
+    }
+}
+static void pgq_seq_bwd(const pgq_layout_t* L, const real* p, int T, const real* x, const real* dy, const pgq_step_t* S, real* dp, real* dx) {
+    const int H = L->H;
+    real dh[MAXH] = {0};
+    for (int t = T - 1; t >= 0; --t) {
+        const pgq_step_t* s = &S[t];
+        qlin_bwd(p, L->ow[5], L->ob[5], L->oq[5], 2, H, L->bw, &dy[2 * t], s->inq[5], s->pass[5], dp, dh);
+        real dhp[MAXH] = {0}, dfp[MAXH], dgp[MAXH], din[2 * MAXH] = {0};
+        for (int j = 0; j < H; ++j) {
+            const real df = dh[j] * (s->hp[j] - s->g[j]), dg = dh[j] * ((real)1 - s->f[j]);
+            dhp[j] += dh[j] * s->f[j];
+            dfp[j] = df * s->f[j] * ((real)1 - s->f[j]); dgp[j] = dg * ((real)1 - s->g[j] * s->g[j]);
+        }
+        qlin_bwd(p, L->ow[3], L->ob[3], L->oq[3], H, 2 * H, L->bw, dfp, s->inq[3], s->pass[3], dp, din);
+        qlin_bwd(p, L->ow[4], L->ob[4], L->oq[4], H, 2 * H, L->bw, dgp, s->inq[4], s->pass[4], dp, din);
+        real dpre[3][MAXH], dsc[3];
+        for (int j = 0; j < H; ++j) {
+            dhp[j] += din[j];
+            const real du = din[H + j], a = s->an[j], b = s->p1[j], c = s->p2[j];
+            const real Aa = a * ((real)1 - a), Ab = b * ((real)1 - b), Ac = c * ((real)1 - c);
+            dpre[0][j] = du * ((real)1 - (real)2 * a) * Ab * Ac * ((real)1 - a * a);
+            dpre[1][j] = du * Aa * ((real)1 - (real)2 * b) * Ac * ((real)1 - b * b);
+            dpre[2][j] = du * Aa * Ab * ((real)1 - (real)2 * c) * ((real)1 - c * c);
+        }
+        for (int l = 0; l < 3; ++l) {
+            real d1[MAXH + 1] = {0};
+            qlin_bwd(p, L->ow[l], L->ob[l], L->oq[l], H, H + 1, L->bw, dpre[l], s->inq[l], s->pass[l], dp, d1);
+            for (int j = 0; j < H; ++j) dhp[j] += d1[j];
+            dsc[l] = d1[H];
+        }
+        for (int j = 0; j < H; ++j) dh[j] = dhp[j];
+        if (dx) {
+            const real I = x[2 * t], Q = x[2 * t + 1], a2 = I * I + Q * Q;
+            const real dth = -s->st * dsc[1] + s->ct * dsc[2];
+            dx[2 * t] = dsc[0] * I / s->amp - dth * Q / a2;
+            dx[2 * t + 1] = dsc[0] * Q / s->amp + dth * I / a2;
         }
     }
 }
@@ -2382,6 +2469,11 @@ static void seq_run(const odpd_model_t* m, int T, const real* params, const real
         real* g1 = pre + (size_t)5 * T * L.C; real* g2 = g1 + (size_t)T * L.C;
         tcnn_seq_fwd(&L, params, T, x, y, feat, pre);
         if (dy) tcnn_seq_bwd(&L, params, T, x, dy, feat, pre, dp, dx, g1, g2);
+    } else if (bb == ODPD_PGJANET && m->bits_w > 0) {
+        pgq_layout_t L; pgq_layout(m, &L);
+        pgq_step_t* S = (pgq_step_t*)scratch;
+        pgq_seq_fwd(&L, params, T, x, y, dy ? S : NULL);
+        if (dy) pgq_seq_bwd(&L, params, T, x, dy, S, dp, dx);
     } else if (bb == ODPD_PGJANET) {
         pgj_layout_t L; pgj_layout(m, &L);
         pgj_step_t* S = (pgj_step_t*)scratch;
@@ -2439,7 +2531,7 @@ static size_t seq_scratch_bytes(const odpd_model_t* m, int T) {
     if (is_lstm_family(bb)) return sizeof(lstm_step_t) * T;
     if (is_delta_family(bb)) return sizeof(delta_step_t) * T;
     if (bb == ODPD_TCNN) return sizeof(real) * ((size_t)T * 6 + (size_t)7 * T * m->hidden);
-    if (bb == ODPD_PGJANET) return sizeof(pgj_step_t) * T;
+    if (bb == ODPD_PGJANET) return (m->bits_w > 0 ? sizeof(pgq_step_t) : sizeof(pgj_step_t)) * T;
     if (bb == ODPD_GMP) return sizeof(real) * (size_t)(6 * (T + 2 * m->hidden));
     if (bb == ODPD_DVRJANET) return sizeof(dvr_step_t) * T;
     if (bb == ODPD_BOJANET) return T >= BOJ_M - 1 ? sizeof(boj_step_t) * T : 0;   /* bojanet.py:72-77 cannot frame fewer than 15 samples */

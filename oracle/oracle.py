@@ -17,7 +17,7 @@ BACKBONES = {"gru": 0, "dgru": 1, "qgru": 2, "qgru_amp1": 3, "lstm": 4, "vdlstm"
              "deltagru_tcnskip": 7, "tcnn": 8, "pgjanet": 9, "gmp": 10, "rvtdcnn": 11, "neuraltx": 12, "deltajanet": 13, "dvrjanet": 14, "bojanet": 15, "apnrru": 16, "mcldnn": 17}
 
 
-_HEAD_ONLY = (BACKBONES["lstm"], BACKBONES["vdlstm"], BACKBONES["deltajanet"], BACKBONES["neuraltx"], BACKBONES["rvtdcnn"])      # --quant swaps only their nn.Linear heads (quant_envs.py:40-60)
+_HEAD_ONLY = (BACKBONES["lstm"], BACKBONES["vdlstm"], BACKBONES["deltajanet"], BACKBONES["neuraltx"], BACKBONES["rvtdcnn"], BACKBONES["pgjanet"])      # --quant swaps only their nn.Linear heads (quant_envs.py:40-60)
 
 
 class Model(C.Structure):

@@ -53,11 +53,11 @@ def test_param_counts_match_reference():
         assert lib.odpd_param_count(C.byref(d)) == P, bb
     # ... the heads-only surgeries (float core + INT_Linear heads: three scales per head) [tests/golden/quant_{lstm,vdlstm,deltajanet,neuraltx,rvtdcnn}_*.npz]
     for bb, H, P in [("lstm", 14, 1041), ("lstm", 40, 7125), ("vdlstm", 13, 1127), ("deltajanet", 12, 509), ("neuraltx", 12, 341), ("rvtdcnn", 12, 508),
-                     ("rvtdcnn", 32, 1288)]:
+                     ("rvtdcnn", 32, 1288), ("pgjanet", 11, 977), ("pgjanet", 24, 4292)]:
         d = _lib.ModelDesc(_lib.BACKBONE_IDS[bb], H, 0, 0, 8, 8, 0)
         assert lib.odpd_param_count(C.byref(d)) == P, bb
     # bits_w > 0 on a backbone without a quantised model is refused (never answered with the float kernels); dvrjanet's bits_w is its DVR count
-    for bb in ("pgjanet", "apnrru", "bojanet", "mcldnn", "deltagru", "gmp", "tcnn"):
+    for bb in ("apnrru", "bojanet", "mcldnn", "deltagru", "gmp", "tcnn"):
         d = _lib.ModelDesc(_lib.BACKBONE_IDS[bb], 11, 0, 0, 8, 8, 0)
         assert lib.odpd_param_count(C.byref(d)) == -1, bb      # ODPD_EINVAL
         assert lib.odpd_partial_rows(C.byref(d), 4, 10, 0) == -1, bb

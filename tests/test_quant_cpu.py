@@ -72,7 +72,7 @@ def test_surgery_on_the_other_backbones():
     with pytest.raises(RuntimeError):
         get_quant_model(_Proj, CoreModel(2, 8, 1, "deltagru"))
     with pytest.raises(NotImplementedError):
-        get_quant_model(_Proj, CoreModel(2, 8, 1, "pgjanet"))
+        get_quant_model(_Proj, CoreModel(2, 8, 1, "apnrru"))
 
 
 def test_head_only_surgery_state_dict_and_rng_match_the_reference():
@@ -92,7 +92,7 @@ def test_head_only_surgery_state_dict_and_rng_match_the_reference():
             assert same, (name, k)
         assert sum(p.numel() for p in q.parameters()) == fx.meta["n_param"] == q.backbone.n_flat
         assert np.array_equal(rng_after, fx["rng_after"]), name
-        last = "IQ_match" if bb == "neuraltx" else "fc_out"      # (neuraltx: bias-free, and the last named_children entry)
+        last = "IQ_match" if bb == "neuraltx" else "W_o" if bb == "pgjanet" else "fc_out"      # (neuraltx: bias-free, and the last named_children entry)
         tail = [f"backbone.{last}.weight"] + ([] if bb == "neuraltx" else [f"backbone.{last}.bias"]) + [
             f"backbone.{last}.weight_quantizer.scale", f"backbone.{last}.act_quantizer.scale", f"backbone.{last}.out_quantizer.scale"]
         assert [n for n, _ in q.named_parameters()][-len(tail):] == tail
