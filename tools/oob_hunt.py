@@ -6,7 +6,7 @@ An inference call (torch.no_grad(): the evaluation kernels where the shape selec
 qgru / qgru_amp1, the W8A8 quantisation-aware cell run on the same shapes.
 r04: `wide` as the fourth argument draws hidden sizes of the lane-per-unit kernels (33 .. 64; pgjanet 17 .. 32) and, for the backbones that
 have them, two stacked layers in every other case; every backbone the surgery has kernels for (gru, dgru, qgru, qgru_amp1, deltagru_tcnskip,
-lstm, vdlstm, deltajanet, neuraltx, rvtdcnn) also runs its `--quant` model (forward + backward, inference call, train step).
+lstm, vdlstm, deltajanet, neuraltx, rvtdcnn, pgjanet) also runs its `--quant` model (forward + backward, inference call, train step).
 usage: PYTORCH_NO_CUDA_MEMORY_CACHING=1 PYTHONPATH=. python tools/oob_hunt.py <backbone> <seed> [cases] [wide]"""
 import os
 import sys
@@ -34,7 +34,7 @@ wide = len(sys.argv) > 4 and sys.argv[4] == "wide"
 WIDE_BB = ("gru", "dgru", "qgru", "qgru_amp1", "lstm", "vdlstm", "deltagru", "deltagru_tcnskip", "deltajanet", "pgjanet")
 TWO_LAYER_BB = ("gru", "dgru", "qgru", "qgru_amp1", "lstm")
 QUANT_MAX_H = {"gru": 32, "dgru": 32, "qgru": 32, "qgru_amp1": 32, "deltagru_tcnskip": 32, "lstm": 64, "vdlstm": 32, "deltajanet": 64, "neuraltx": 64,
-               "rvtdcnn": 32}
+               "rvtdcnn": 32, "pgjanet": 32}
 assert not wide or bb in WIDE_BB, "no lane-per-unit kernels for this backbone"
 rng = np.random.RandomState(seed)
 SEG = 2 * 1024 * 1024 // 4

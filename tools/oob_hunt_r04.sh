@@ -9,7 +9,7 @@ for bb in gru dgru qgru qgru_amp1 lstm vdlstm deltagru deltagru_tcnskip deltajan
     timeout 600 python tools/oob_hunt.py $bb 7 $N wide > /tmp/oob_$bb.log 2>&1; rc=$?
     echo "wide  $bb: rc=$rc last: $(tail -1 /tmp/oob_$bb.log)" >> $OUT
 done
-for bb in gru dgru qgru deltagru_tcnskip lstm vdlstm deltajanet neuraltx rvtdcnn; do
+for bb in gru dgru qgru deltagru_tcnskip lstm vdlstm deltajanet neuraltx rvtdcnn pgjanet; do
     timeout 600 python tools/oob_hunt.py $bb 11 $N > /tmp/oobq_$bb.log 2>&1; rc=$?
     echo "quant $bb: rc=$rc last: $(tail -1 /tmp/oobq_$bb.log)" >> $OUT
 done
