@@ -7,7 +7,8 @@ runs the REFERENCE (CPU) for
 in front of the GRU PA the reference trained for tests/golden/ref_runs_qat_dpa.npz (written where train_dpd looks for it), and stores the
 logged rows, the saved state dict (float nn.LSTM + INT_Linear fc_out: parameters AND side-effect buffers) and the exported CSV in
 tests/golden/ref_runs_qat_lstm.{json,npz}.   Usage: python oracle/gen_run_anchor_qat_lstm.py [backbone]
-(`neuraltx`: the same run with --DPD_backbone neuraltx -> ref_runs_qat_neuraltx.{json,npz}: float Conv1d stack + INT_Linear IQ_match)"""
+(`neuraltx` / `rvtdcnn` / `pgjanet`: the same run with that --DPD_backbone -> ref_runs_qat_<backbone>.{json,npz}; pgjanet through the
+harness-side bridge of the reference's constructor defect)"""
 import glob
 import json
 import os
@@ -22,6 +23,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gen_run_anchor_qat_dpa import C, OUT, REF, RUNNER  # noqa: E402
 
 BB = sys.argv[1] if len(sys.argv) > 1 else "lstm"
+if BB == "pgjanet":      # the reference's CoreModel hands PGJANET a keyword it does not take (SURVEY §0 defect 1): bridged harness-side, as
+    # oracle/gen_run_anchors_more.py does for the float run
+    RUNNER = RUNNER.replace("import importlib\n", "import importlib\nimport backbones.pgjanet as pj\n_init = pj.PGJANET.__init__\n"
+                            "pj.PGJANET.__init__ = lambda self, hidden_size, output_size, bias=True, window_size=None: _init(self, hidden_size, output_size, bias)\n")
 Q = ["--DPD_backbone", BB, "--DPD_hidden_size", "12", "--quant", "--n_bits_w", "8", "--n_bits_a", "8", "--quant_dir_label", "w8a8"]
 
 
