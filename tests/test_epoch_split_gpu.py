@@ -45,7 +45,8 @@ def test_split_epoch_loop_equals_the_python_driven_steps(bb, H, kw, opt_kind):
 
 @pytest.mark.parametrize("bb,H,kw", [("gru", 48, {}), ("dgru", 40, {}), ("lstm", 40, {}), ("vdlstm", 35, {}), ("deltagru", 40, dict(thx=0.01, thh=0.03)),
                                      ("deltagru_tcnskip", 33, dict(thx=0.01, thh=0.02)), ("deltajanet", 64, {}), ("pgjanet", 24, {}),
-                                     ("dgru:l2", 13, {}), ("lstm:l2", 20, {}), ("deltajanet:w8a8", 12, {}), ("lstm:w8a8", 24, {})])
+                                     ("dgru:l2", 13, {}), ("lstm:l2", 20, {}), ("deltajanet:w8a8", 12, {}), ("lstm:w8a8", 24, {}),
+                                     ("neuraltx:w8a8", 8, {}), ("pgjanet:w8a8", 9, {}), ("lstm:w8a8", 40, {})])
 def test_split_epoch_loop_serves_the_lane_per_unit_and_two_layer_kernels(bb, H, kw):
     """The r04 kernels beyond the tile envelope (hidden 33 .. 64, pgjanet 17 .. 32, two layers, quantised heads on the split chain) have no
     fused step: their epochs run from the native split loop — same parameters, losses and sparsity counters as the Python-driven steps."""
