@@ -1,5 +1,6 @@
 """CPU checks of the QAT model surgery (opendpd_amd/quant.py): same names, same RNG consumption, identical initial state."""
 import numpy as np
+import pytest
 import torch
 
 from tests.golden_util import Fixture
@@ -96,6 +97,52 @@ def test_head_only_surgery_state_dict_and_rng_match_the_reference():
         tail = [f"backbone.{last}.weight"] + ([] if bb == "neuraltx" else [f"backbone.{last}.bias"]) + [
             f"backbone.{last}.weight_quantizer.scale", f"backbone.{last}.act_quantizer.scale", f"backbone.{last}.out_quantizer.scale"]
         assert [n for n, _ in q.named_parameters()][-len(tail):] == tail
+
+
+@pytest.mark.parametrize("bb,H", [("lstm", 14), ("vdlstm", 9), ("deltajanet", 12), ("neuraltx", 10), ("rvtdcnn", 7), ("pgjanet", 6)])
+def test_pretrained_float_checkpoint_reaches_the_layer_surgeries(tmp_path, capsys, bb, H):
+    """--pretrained_model on the backbones whose surgery swaps Linear / Conv2d layers (quant_envs.py:173-182: the checkpoint is strict-loaded
+    into the float model BEFORE the swap): every weight of the result is the checkpoint's — also the float core's —, the swapped layers'
+    biases are re-drawn by the INT layers' constructors, rvtdcnn's INT_Conv2D takes its weight scale from the LOADED weights (init_step_size),
+    and a checkpoint with other keys makes the call fall back to the float model with the reference's warning."""
+    from opendpd_amd import CoreModel
+    from opendpd_amd.quant import _HEAD_LAYERS, get_quant_model
+
+    class P:
+        quant = True
+        n_bits_w = n_bits_a = 8
+    torch.manual_seed(5)
+    src = CoreModel(2, H, 1, bb)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(0.01)                                  # biases start at 0 in several backbones: make "re-drawn" visible
+    ckpt = tmp_path / "float.pt"
+    torch.save(src.state_dict(), ckpt)
+    P.pretrained_model = str(ckpt)
+    torch.manual_seed(0)
+    fnet = CoreModel(2, H, 1, bb)
+    torch.manual_seed(123)
+    q = get_quant_model(P, fnet)
+    assert q is not fnet and q.backbone.desc.bits_w == 8
+    sd, ref = q.state_dict(), src.state_dict()
+    heads = _HEAD_LAYERS[bb]
+    for k, v in ref.items():
+        layer = k.split(".")[1]
+        if k.endswith("bias") and layer in heads:
+            assert not torch.equal(sd[k], v), k           # INT_Linear / INT_Conv2D draw a fresh default-init bias
+        else:
+            assert torch.equal(sd[k], v), k
+    if bb == "rvtdcnn":
+        want = ref["backbone.Conv2d.weight"].abs().mean() * 2 / 127 ** 0.5
+        assert torch.equal(sd["backbone.Conv2d.weight_quantizer.scale"], want) and sd["backbone.Conv2d.weight_quantizer.scale"].dim() == 0
+    # a quantised checkpoint is not a float checkpoint: other keys -> the float model comes back, with the warning
+    bad = tmp_path / "quant.pt"
+    torch.save(sd, bad)
+    P.pretrained_model = str(bad)
+    torch.manual_seed(0)
+    fnet = CoreModel(2, H, 1, bb)
+    capsys.readouterr()
+    assert get_quant_model(P, fnet) is fnet and "[WARN] Quantization setup failed" in capsys.readouterr().out
 
 
 def test_identity_when_quant_off():
