@@ -95,6 +95,7 @@ __global__ __launch_bounds__(64) void pgq_fwd_kernel(SeqArgs a) {
                 for (int l = 0; l < 3; ++l) {
                     const float* wr = pl + L.ow[l] + j * H1;
                     float acc = 0.0f;
+#pragma unroll 8
                     for (int k = 0; k < H; ++k) acc = __builtin_fmaf(wr[k], vq[l * 32 + k], acc);
                     acc = __builtin_fmaf(wr[H], q16::qapply(sc[l], Q.a[l]), acc);
                     gate[l] = tanhf_(acc + pl[L.ob[l] + j]);
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(64) void pgq_fwd_kernel(SeqArgs a) {
                 for (int l = 0; l < 2; ++l) {
                     const float* wr = pl + L.ow[3 + l] + j * H2;
                     float acc = 0.0f;
+#pragma unroll 8
                     for (int k = 0; k < H; ++k) acc = __builtin_fmaf(wr[k], vq[(3 + l) * 32 + k], acc);
+#pragma unroll 8
                     for (int k = 0; k < H; ++k) acc = __builtin_fmaf(wr[H + k], vq[(5 + l) * 32 + k], acc);
                     pre[l] = acc + pl[L.ob[3 + l] + j];
                 }
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(64) void pgq_fwd_kernel(SeqArgs a) {
             if (lane < len) {      // the chunk's outputs, lane = time step: W_o on q_5(h)
                 const float* hr = hist + lane * kPS;
                 float y0 = 0.0f, y1 = 0.0f;
+#pragma unroll 8
                 for (int k = 0; k < H; ++k) {
                     const float hv = q16::qapply(hr[k], Q.a[5]);
                     y0 = __builtin_fmaf(pl[L.ow[5] + k], hv, y0); y1 = __builtin_fmaf(pl[L.ow[5] + H + k], hv, y1);
@@ -204,6 +208,7 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
 #pragma unroll
                     for (int l = 0; l < 2; ++l) {
                         const float* wc = pl + L.ow[3 + l] + j;
+#pragma unroll 8
                         for (int r = 0; r < H; ++r) {
                             const float dv = vb[(7 + l) * 32 + r];
                             ah[l] = __builtin_fmaf(wc[r * H2], dv, ah[l]); au[l] = __builtin_fmaf(wc[r * H2 + H], dv, au[l]);
@@ -228,6 +233,7 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
                 for (int l = 0; l < 3; ++l) {
                     const float* wc = pl + L.ow[l] + j;
                     float ah = 0.0f;
+#pragma unroll 8
                     for (int r = 0; r < H; ++r) ah = __builtin_fmaf(wc[r * H1], vb[(9 + l) * 32 + r], ah);
                     dhp = __builtin_fmaf(q16::qpass(hp, Q.a[l]), ah, dhp);
                     if constexpr (DX) {      // the scalar input's column: sum over the units
@@ -241,6 +247,7 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
 #pragma unroll
                         for (int l = 0; l < 3; ++l) {
                             float* gr = gw + L.ow[l] + j * H1;
+#pragma unroll 8
                             for (int k = 0; k < H; ++k) gr[k] = __builtin_fmaf(dpre[l], vb[l * 32 + k], gr[k]);
                             gr[H] = __builtin_fmaf(dpre[l], q16::qapply(sc[l], Q.a[l]), gr[H]);
                             db[l] += dpre[l];
@@ -249,7 +256,9 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
                         for (int l = 0; l < 2; ++l) {
                             float* gr = gw + L.ow[3 + l] + j * H2;
                             const float dv = l == 0 ? dfp : dgp;
+#pragma unroll 8
                             for (int k = 0; k < H; ++k) gr[k] = __builtin_fmaf(dv, vb[(3 + l) * 32 + k], gr[k]);
+#pragma unroll 8
                             for (int k = 0; k < H; ++k) gr[H + k] = __builtin_fmaf(dv, vb[(5 + l) * 32 + k], gr[H + k]);
                             db[3 + l] += dv;
                         }
