@@ -9,7 +9,7 @@
 // reads: lanes stride H + 1 / 2 H floats apart; transposed reads in the backward pass: consecutive lanes, consecutive addresses).  The
 // forward pass records (a_n, p1, p2, u, f, g, h') per step in HBM (`ckpt`: B x T x 8 x 64 floats) when a backward pass follows.  Backward:
 // reverse steps, the gate gradients broadcast through LDS, the transposed mat-vecs with every layer's activation pass mask, the weight
-// gradients accumulated row by row in a second LDS copy of the parameter layout (lane j owns its rows: no conflicts, fixed order), the weight
+// gradients accumulated in the registers of the lane that owns the rows (deposited in a second LDS copy of the parameter layout at the end), the weight
 // quantisers' pass masks applied at write-out from the unquantised weights, the 18 scale columns exact zeros.
 #include "odpd_seq.h"
 #include "odpd_quant.h"
@@ -162,6 +162,16 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
     const int j = vo ? lane : 0;
     const float wo0 = vo ? pl[L.ow[5] + j] : 0.0f, wo1 = vo ? pl[L.ow[5] + H + j] : 0.0f;
     float db[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, dwo0 = 0.0f, dwo1 = 0.0f, tb0 = 0.0f, tb1 = 0.0f;
+    // the weight-gradient rows of unit j in registers (padded to 32 columns: the broadcast vectors are zero beyond H); written to `gw` at the end
+    float ga[3][33], gfu[2][64];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int k = 0; k < 33; ++k) ga[l][k] = 0.0f;
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int k = 0; k < 64; ++k) gfu[l][k] = 0.0f;
     wave_lds_fence();
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
@@ -242,26 +252,33 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
                         dsc[l] = v * q16::qpass(sc[l], Q.a[l]);
                     }
                 }
-                if constexpr (NW) {      // the rows of unit j: d (x) q_l(input)
-                    if (vo) {
+                if constexpr (NW) {      // the rows of unit j: d (x) q_l(input) (dpre / dfp / dgp are 0 on lanes without a unit)
 #pragma unroll
-                        for (int l = 0; l < 3; ++l) {
-                            float* gr = gw + L.ow[l] + j * H1;
-#pragma unroll 8
-                            for (int k = 0; k < H; ++k) gr[k] = __builtin_fmaf(dpre[l], vb[l * 32 + k], gr[k]);
-                            gr[H] = __builtin_fmaf(dpre[l], q16::qapply(sc[l], Q.a[l]), gr[H]);
-                            db[l] += dpre[l];
-                        }
+                    for (int l = 0; l < 3; ++l) {
+                        const float4* v4 = reinterpret_cast<const float4*>(vb + l * 32);
 #pragma unroll
-                        for (int l = 0; l < 2; ++l) {
-                            float* gr = gw + L.ow[3 + l] + j * H2;
-                            const float dv = l == 0 ? dfp : dgp;
-#pragma unroll 8
-                            for (int k = 0; k < H; ++k) gr[k] = __builtin_fmaf(dv, vb[(3 + l) * 32 + k], gr[k]);
-#pragma unroll 8
-                            for (int k = 0; k < H; ++k) gr[H + k] = __builtin_fmaf(dv, vb[(5 + l) * 32 + k], gr[H + k]);
-                            db[3 + l] += dv;
+                        for (int q4 = 0; q4 < 8; ++q4) {
+                            const float4 v = v4[q4];
+                            ga[l][4 * q4] = __builtin_fmaf(dpre[l], v.x, ga[l][4 * q4]); ga[l][4 * q4 + 1] = __builtin_fmaf(dpre[l], v.y, ga[l][4 * q4 + 1]);
+                            ga[l][4 * q4 + 2] = __builtin_fmaf(dpre[l], v.z, ga[l][4 * q4 + 2]); ga[l][4 * q4 + 3] = __builtin_fmaf(dpre[l], v.w, ga[l][4 * q4 + 3]);
                         }
+                        ga[l][32] = __builtin_fmaf(dpre[l], q16::qapply(sc[l], Q.a[l]), ga[l][32]);
+                        db[l] += dpre[l];
+                    }
+#pragma unroll
+                    for (int l = 0; l < 2; ++l) {
+                        const float dv = l == 0 ? dfp : dgp;
+                        const float4* h4 = reinterpret_cast<const float4*>(vb + (3 + l) * 32);
+                        const float4* u4 = reinterpret_cast<const float4*>(vb + (5 + l) * 32);
+#pragma unroll
+                        for (int q4 = 0; q4 < 8; ++q4) {
+                            const float4 v = h4[q4], w = u4[q4];
+                            gfu[l][4 * q4] = __builtin_fmaf(dv, v.x, gfu[l][4 * q4]); gfu[l][4 * q4 + 1] = __builtin_fmaf(dv, v.y, gfu[l][4 * q4 + 1]);
+                            gfu[l][4 * q4 + 2] = __builtin_fmaf(dv, v.z, gfu[l][4 * q4 + 2]); gfu[l][4 * q4 + 3] = __builtin_fmaf(dv, v.w, gfu[l][4 * q4 + 3]);
+                            gfu[l][32 + 4 * q4] = __builtin_fmaf(dv, w.x, gfu[l][32 + 4 * q4]); gfu[l][32 + 4 * q4 + 1] = __builtin_fmaf(dv, w.y, gfu[l][32 + 4 * q4 + 1]);
+                            gfu[l][32 + 4 * q4 + 2] = __builtin_fmaf(dv, w.z, gfu[l][32 + 4 * q4 + 2]); gfu[l][32 + 4 * q4 + 3] = __builtin_fmaf(dv, w.w, gfu[l][32 + 4 * q4 + 3]);
+                        }
+                        db[3 + l] += dv;
                     }
                 }
                 if constexpr (DX) {
@@ -285,6 +302,16 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
         float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
         for (int o = 32; o > 0; o >>= 1) { tb0 += __shfl_xor(tb0, o); tb1 += __shfl_xor(tb1, o); }
         if (vo) {
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) if (k < H) gw[L.ow[l] + j * H1 + k] = ga[l][k];
+                gw[L.ow[l] + j * H1 + H] = ga[l][32];
+            }
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+#pragma unroll
+                for (int k = 0; k < 32; ++k) if (k < H) { gw[L.ow[3 + l] + j * H2 + k] = gfu[l][k]; gw[L.ow[3 + l] + j * H2 + H + k] = gfu[l][32 + k]; }
 #pragma unroll
             for (int l = 0; l < 5; ++l) gw[L.ob[l] + j] = db[l];
             gw[L.ow[5] + j] = dwo0; gw[L.ow[5] + H + j] = dwo1;
