@@ -1526,7 +1526,7 @@ int gru_family_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
 int gru_family_lossdx(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
-    if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 3);
+    if (gru_uses_s16n(m, a.B)) return gru_s16x_ok(m) ? gru_s16x_lossdx(st, m, a, gru_s16n_rows(m, a.B)) : gru_s16n_launch(st, m, a, 3);
     if (gru_split_uses_s16(m, a.B)) return gru_s16_lossdx(st, m, a);
     if (gru_lossdx_uses_gp(m, a.B, a.T)) { ODPD_GRU_DISPATCH_ALL(launch_gp_lossdx, st, a, P) }
     ODPD_GRU_DISPATCH_ALL(launch_lossdx, st, a, P)

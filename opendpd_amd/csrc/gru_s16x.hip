@@ -1,0 +1,564 @@
+// gru_s16x.hip — the frozen-PA step (forward + loss + dL/du, modules/train_funcs.py:33-39 behind models.py:163-176) of the GRU family
+// (backbones/{gru,dgru,qgru,qgru_amp1}.py) for hidden 17 .. 24 — the reference's default PA size is 23 — on the bf16 MATRIX pipe with
+// three-way operand splits ("bf16x3"): every fp32 operand v is carried as three bf16 terms v = v1 + v2 + v3 (round-to-nearest residuals,
+// exact), and a product a.b is the six term products of weight 2^-16 and above (a1b3, a3b1, a2b2, a1b2, a2b1, a1b1) accumulated in
+// fp32 by v_mfma_f32_16x16x32_bf16: what is dropped is below 2^-23 |a||b| — the size of one fp32 rounding of the product.
+//
+// Why (profiles/r05/frozen_pa.md): the exact-fp32 v_mfma_f32_16x16x4_f32 of gru_s16n.hip issues on the VALU lanes at the vector
+// rate (32 cycles per 16x16x4 tile, nothing overlaps with it) and needs 16-unit M tiles: hidden 23 ran 174 of them per 16-sequence step
+// (5 568 issue cycles of a ~9 000-cycle step, 2.2x the algorithmic flops).  The bf16 instruction does a 16 x 16 x 32 tile in 16 cycles on
+// the matrix pipe, BESIDE the VALU, and its K = 32 is exactly [24 hidden units | 8 feature slots]: one instruction per M tile and term
+// product.  A frozen model has no weight gradient, so every A operand is a constant that is split once per launch; only the B operands
+// (h, the features, d(hid), d(gates)) are split at run time, 5.5 VALU instructions per value.
+//
+// Lane mapping: a wave holds 16 sequences, lane l = (n = l & 15 sequence, q = l >> 4); the lane owns U = 6 hidden units 6q .. 6q+5
+// (units >= H are padding whose weights are zero) and TWO of the eight feature slots [feat_0 .. feat_{F-1}, 1, 0 ..] (slots 2q, 2q+1;
+// the constant-1 slot carries every bias).  The instruction's operand layout (lane l holds A[l & 15][8 (l >> 4) + i], B[8 (l >> 4) + i]
+// [l & 15], D[4 (l >> 4) + r][l & 15]) then reads the lane's OWN eight values [h_0 .. h_5, f_0, f_1] as its B operand — no cross-lane
+// movement — and delivers four result rows per M tile to the lane, so the M rows are permuted at table-build time such that quad q
+// receives the gates of ITS units: the 4 x 6 gate slots (r, z, W_hn h, W_in x) of a quad fill SIX tiles exactly (the exact-fp32 kernel
+// pads 3 x 23 rows to 3 x 32); relu(fc_hid h) of the previous step rides along as two more tiles on the same B operand.
+// The backward product packs K the same way: the lane's 24 values [d r_pre | d z_pre | d(W_hn h) | d n_pre] are three K = 32 operands;
+// the two output tiles hold dL/dh(t-1) (six slots per quad) and, in the two free slots per quad, the feature gradient that dL/du needs.
+//
+// BPTT: h checkpoints every S steps in the HBM workspace ([16-sequence task][checkpoint][2][lane] float4), block recompute into
+// registers.  Two waves per SIMD (256 registers).  Parity: tests/test_gru_s16x_gpu.py (against the oracle and against gru_s16n.hip).
+#include "odpd_s16.h"
+
+namespace odpd {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- bf16x3 splits -------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even): a in the low half
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// (a, b) -> three packed bf16 pairs; the residual subtractions are exact (a bf16 term has at most 8 of the operand's 24 bits)
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xffff0000u);
+    p3 = pk_bf16(sa, sb);
+}
+struct Split3 { u32x4 t[3]; };      // one K = 32 B operand: the lane's eight values as three bf16x8 terms
+__device__ __forceinline__ Split3 split8(const float (&v)[8]) {
+    Split3 s;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned a, b, c;
+        split_pair(v[2 * p], v[2 * p + 1], a, b, c);
+        s.t[0][p] = a; s.t[1][p] = b; s.t[2][p] = c;
+    }
+    return s;
+}
+__device__ __forceinline__ f32x4 mfma32(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 tabx_ld(TabPtr p, int i) { return __builtin_bit_cast(u32x4, p[i]); }
+// acc[t] += A(group grp0 + 3 t .. + 2: the three terms of tile t) . B, smallest products first
+template <int NT>
+__device__ __forceinline__ void mm6(TabPtr tl, int grp0, const Split3& B, f32x4 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const u32x4 a1 = tabx_ld(tl, (grp0 + 3 * t) * 64), a2 = tabx_ld(tl, (grp0 + 3 * t + 1) * 64), a3 = tabx_ld(tl, (grp0 + 3 * t + 2) * 64);
+        f32x4 c = acc[t];
+        c = mfma32(a1, B.t[2], c);
+        c = mfma32(a3, B.t[0], c);
+        c = mfma32(a2, B.t[1], c);
+        c = mfma32(a1, B.t[1], c);
+        c = mfma32(a2, B.t[0], c);
+        c = mfma32(a1, B.t[0], c);
+        acc[t] = c;
+    }
+}
+
+// ---- operand tables ------------------------------------------------------------------------------------------------------------------
+// groups of 64 lanes x 16 B.  bf16 groups hold A[row m = lane & 15][k = 8 (lane >> 4) + i], i < 8, as one term of the split.
+template <bool DG, int U>
+struct S16X {
+    static_assert(U == 6, "tile bookkeeping below is written for six units per lane");
+    static constexpr int NFS = 8 - U;                   // feature slots per lane
+    static constexpr int NTF = U;                       // cell tiles: slots [r | z | W_hn h | W_in x] x U per quad = 4 U rows per quad
+    static constexpr int NTH = DG ? (U + 3) / 4 : 0;    // fc_hid tiles (slot j of the quad = unit U q + j)
+    static constexpr int NTO = (U + NFS + 3) / 4;       // backward output tiles: U slots dL/dh(t-1), then NFS slots feature gradient
+    static constexpr int NM = U / 2;                    // K = 32 operands of the backward product (4 U values per lane)
+    static constexpr int FW = 0;                        // 3 (tile) + term, tiles [cell | fc_hid]
+    static constexpr int HT = FW + 3 * (NTF + NTH);     // 3 (tile) + term: fc_hid^T
+    static constexpr int BW = HT + 3 * NTH;             // 3 (tile * NM + c) + term
+    static constexpr int VW = BW + 3 * NTO * NM;        // fp32 groups: fc_out weights of the lane's units, then of its feature slots
+    static constexpr int NVW = (2 * U + 3) / 4 + 1;
+    static constexpr int NG = VW + NVW;
+    static constexpr int NQ = (U + 3) / 4;              // float4 per lane and checkpoint
+};
+
+// value of one A element.  kind 0: cell / fc_hid tiles (grp = tile), 1: fc_hid^T, 2: backward (grp = tile * NM + c)
+template <int FM, bool DG, int U>
+__device__ __forceinline__ float s16x_weight(const float* pl, const GruLayout& L, int kind, int grp, int m, int kq, int i) {
+    using T = S16X<DG, U>;
+    constexpr int F = S16Cfg<FM>::F;
+    const int H = L.H, mq = m >> 2, mr = m & 3;
+    if (kind == 0) {
+        const bool hid = grp >= T::NTF;
+        const int s = hid ? 4 * (grp - T::NTF) + mr : 4 * grp + mr;            // slot of quad mq
+        const int gate = hid ? 4 : s / U, j = hid ? s : s % U;
+        if (j >= U) return 0.0f;
+        const int u = U * mq + j;
+        if (u >= H) return 0.0f;
+        const float sc = gate < 2 ? kNegLog2e : 1.0f;
+        if (i < U) {                                                           // K slot = hidden unit U kq + i
+            const int k = U * kq + i;
+            if (k >= H || gate == 3) return 0.0f;
+            if (gate == 4) return pl[L.o_w_hid + u * H + k];
+            return sc * pl[L.o_w_hh + (gate * H + u) * H + k];
+        }
+        const int fsl = T::NFS * kq + (i - U);                                  // K slot = feature slot
+        if (fsl > F) return 0.0f;
+        if (gate == 4) return fsl == F ? pl[L.o_b_hid + u] : 0.0f;
+        if (gate == 2) return fsl == F ? pl[L.o_b_hh + 2 * H + u] : 0.0f;
+        const int g = gate == 3 ? 2 : gate;
+        if (fsl < F) return sc * pl[L.o_w_ih + (g * H + u) * F + fsl];
+        return gate < 2 ? sc * (pl[L.o_b_ih + g * H + u] + pl[L.o_b_hh + g * H + u]) : pl[L.o_b_ih + 2 * H + u];
+    }
+    if (kind == 1) {                                                            // dht[k_out] += sum_u fc_hid[u][k_out] dhid[u]
+        const int j = 4 * grp + mr, ko = U * mq + j, u = U * kq + i;
+        if (j >= U || i >= U || ko >= H || u >= H) return 0.0f;
+        return pl[L.o_w_hid + u * H + ko];
+    }
+    const int tile = grp / T::NM, c = grp % T::NM;
+    const int s = 4 * tile + mr;                                                // output slot of quad mq: < U dL/dh, then feature slots
+    const int e = 8 * c + i, ge = e / U, u = U * kq + e % U;                    // K element: value e of the lane's [drp | dzp | dgh | dnp]
+    if (u >= H) return 0.0f;
+    if (s < U) {
+        const int ko = U * mq + s;
+        if (ko >= H || ge == 3) return 0.0f;
+        return pl[L.o_w_hh + (ge * H + u) * H + ko];
+    }
+    const int fsl = T::NFS * mq + (s - U);
+    if (s >= U + T::NFS || fsl >= F || ge == 2) return 0.0f;
+    return pl[L.o_w_ih + ((ge == 3 ? 2 : ge) * H + u) * F + fsl];
+}
+template <int FM, bool DG, int U>
+__device__ __forceinline__ void s16x_fill_table(float* tab, const float* pl, const GruLayout& L, int lane, int wave, int nwb) {
+    using T = S16X<DG, U>;
+    constexpr int F = S16Cfg<FM>::F;
+    u32x4* t4 = reinterpret_cast<u32x4*>(tab);
+    const int m = lane & 15, kq = lane >> 4, H = L.H, OW = DG ? H + 6 : H;
+    constexpr int nA = T::VW / 3;                                               // split operands (one per tile / tile x chunk)
+    for (int op = wave; op < nA; op += nwb) {
+        const int kind = 3 * op < T::HT ? 0 : (3 * op < T::BW ? 1 : 2);
+        const int grp = op - (kind == 0 ? 0 : (kind == 1 ? T::HT / 3 : T::BW / 3));
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = s16x_weight<FM, DG, U>(pl, L, kind, grp, m, kq, i);
+        const Split3 s = split8(v);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) t4[(3 * op + t) * 64 + lane] = s.t[t];
+    }
+    // fp32 groups: [w_out[0][U q + j], j < U | w_out[1][..]] packed, then {wf[0][0], wf[0][1], wf[1][0], wf[1][1]} of the lane's feature slots
+    for (int g = wave; g < T::NVW; g += nwb) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (g < T::NVW - 1) {
+                const int idx = 4 * g + e, cc = idx / U, u = U * kq + idx % U;
+                v[e] = (idx < 2 * U && u < H) ? pl[L.o_w_out + cc * OW + u] : 0.0f;
+            } else {
+                const int cc = e >> 1, fsl = T::NFS * kq + (e & 1);
+                v[e] = (DG && fsl < F) ? pl[L.o_w_out + cc * OW + H + fsl] : (fsl == F ? pl[L.o_b_out + cc] : 0.0f);
+            }
+        }
+        reinterpret_cast<float4*>(tab)[(T::VW + g) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+}
+
+// the lane's feature slots: slot NFS q + e of [feat_0 .. feat_{F-1}, 1, 0, ..] (one-hot arithmetic, no selects)
+template <int FM, int U>
+__device__ __forceinline__ void s16x_feats(float I, float Q, const float (&oh)[4], float (&fs)[8 - U]) {
+    constexpr int F = S16Cfg<FM>::F, NFS = 8 - U;
+    float f[F];
+    feat_fwd<FM>(I, Q, f);
+#pragma unroll
+    for (int e = 0; e < NFS; ++e) {
+        float acc = 0.0f;
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int sl = NFS * k + e;
+            if (sl < F) { acc = first ? oh[k] * f[sl < F ? sl : 0] : __builtin_fmaf(oh[k], f[sl < F ? sl : 0], acc); first = false; }
+            else if (sl == F) { acc = first ? oh[k] : acc + oh[k]; first = false; }
+        }
+        fs[e] = acc;
+    }
+}
+
+__device__ __forceinline__ float sig_ps(float v) { return fast_rcp(__builtin_amdgcn_exp2f(v) + 1.0f); }      // v = -log2(e) * pre-activation
+template <int FM>
+__device__ __forceinline__ float tanh_x(float x) {      // tanh4 / tanh4_rel of odpd_s16.h, one element
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f;
+    const float t = __builtin_fmaf(fast_rcp(e), -2.0f, 1.0f);
+    if constexpr (FM == FEAT_DGRU6) return t;
+    else {
+        const float x2 = x * x;
+        float p = __builtin_fmaf(x2, 0.021869488536155203f, -0.053968253968253971f);
+        p = __builtin_fmaf(x2, p, 0.13333333333333333f);
+        p = __builtin_fmaf(x2, p, -0.33333333333333333f);
+        p = __builtin_fmaf(x2 * x, p, x);
+        const float w = __builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_fabsf(x), -0x1p100f, 0.3f * 0x1p100f), 0.0f, 1.0f);
+        return __builtin_fmaf(w, p - t, t);
+    }
+}
+
+// B operand of a cell step: [h_0 .. h_{U-1}, f_0 .. f_{NFS-1}]
+template <int U>
+__device__ __forceinline__ Split3 s16x_operand(const float (&h)[U], const float (&fs)[8 - U]) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < U; ++i) v[i] = h[i];
+#pragma unroll
+    for (int i = U; i < 8; ++i) v[i] = fs[i - U];
+    return split8(v);
+}
+// gates of one step from the tile results; h <- h(t).  WITH_HID: the fc_hid tiles ride on the same operand (they are the hidden
+// layer of the operand's h, i.e. of the PREVIOUS step)
+template <int FM, bool DG, int U, bool WITH_HID>
+__device__ __forceinline__ void s16x_cell(TabPtr tl, const Split3& B, float (&h)[U], float (&r)[U], float (&z)[U], float (&n)[U], float (&nh)[U],
+                                          float (&hid_prev)[U]) {
+    using T = S16X<DG, U>;
+    constexpr int NT = T::NTF + (WITH_HID ? T::NTH : 0);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mm6<NT>(tl, T::FW, B, acc);
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const int sr = j, sz = U + j, sh = 2 * U + j, si = 3 * U + j;
+        r[j] = sig_ps(acc[sr / 4][sr % 4]);
+        z[j] = sig_ps(acc[sz / 4][sz % 4]);
+        nh[j] = acc[sh / 4][sh % 4];
+        n[j] = tanh_x<FM>(__builtin_fmaf(r[j], nh[j], acc[si / 4][si % 4]));
+        h[j] = __builtin_fmaf(z[j], h[j] - n[j], n[j]);
+        if constexpr (WITH_HID) hid_prev[j] = acc[T::NTF + j / 4][j % 4];
+    }
+}
+template <bool DG, int U>
+__device__ __forceinline__ void s16x_hid(TabPtr tl, const Split3& B, float (&hid)[U]) {
+    using T = S16X<DG, U>;
+    f32x4 acc[T::NTH];
+#pragma unroll
+    for (int t = 0; t < T::NTH; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mm6<T::NTH>(tl, T::FW + 3 * T::NTF, B, acc);
+#pragma unroll
+    for (int j = 0; j < U; ++j) hid[j] = acc[j / 4][j % 4];
+}
+
+// one block of <= S steps of the backward pass: recompute from the checkpoint h0, then loss, dL/dy and BPTT down to dL/du
+template <int FM, bool DG, int U, int S, bool FULL>
+__device__ __forceinline__ void s16x_block(const SeqArgs& a, TabPtr tl0, const float (&oh)[4], const float2* xs, const float2* ts, float2* dxs,
+                                           int n, int q, int tloc, int nstep, bool valid, const float (&h0)[U], float (&dh)[U], float& loss_acc) {
+    using T = S16X<DG, U>;
+    constexpr int F = S16Cfg<FM>::F, NFS = T::NFS;
+    float h[U], hp_s[S][U], r_s[S][U], z_s[S][U], n_s[S][U], nh_s[S][U], hid_s[S][U], fs_s[S][NFS];
+#pragma unroll
+    for (int j = 0; j < U; ++j) h[j] = h0[j];
+    TabPtr tl = opaque(tl0);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+        if (FULL || st < nstep) {
+            const float2 xv = xs[n * kChunkPad + tloc + st];
+            s16x_feats<FM, U>(xv.x, xv.y, oh, fs_s[st]);
+#pragma unroll
+            for (int j = 0; j < U; ++j) hp_s[st][j] = h[j];
+            const Split3 B = s16x_operand<U>(h, fs_s[st]);
+            if constexpr (DG && FULL) {
+                if (st > 0) s16x_cell<FM, DG, U, true>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[st > 0 ? st - 1 : 0]);
+                else s16x_cell<FM, DG, U, false>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[0]);
+            } else {
+                s16x_cell<FM, DG, U, false>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[st]);
+                if constexpr (DG) {      // (ragged tail block: the hidden layer of every step on an operand of its own)
+                    const Split3 B2 = s16x_operand<U>(h, fs_s[st]);
+                    s16x_hid<DG, U>(tl, B2, hid_s[st]);
+                }
+            }
+        }
+    }
+    if constexpr (DG && FULL) {
+        const Split3 B2 = s16x_operand<U>(h, fs_s[S - 1]);
+        s16x_hid<DG, U>(tl, B2, hid_s[S - 1]);
+    }
+    tl = opaque(tl0);
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, valid ? a.inv_count : 0.0f, valid && q == 0);
+#pragma unroll
+    for (int st = S - 1; st >= 0; --st) {
+        if (FULL || st < nstep) {
+            // ---- head: y, loss, dL/dy ----
+            float w0[U], w1[U];
+            {
+                float wv[4 * (T::NVW - 1)];
+#pragma unroll
+                for (int g = 0; g < T::NVW - 1; ++g) {
+                    const float4 v = tab_ld(tl, (T::VW + g) * 64);
+                    wv[4 * g] = v.x; wv[4 * g + 1] = v.y; wv[4 * g + 2] = v.z; wv[4 * g + 3] = v.w;
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) { w0[j] = wv[j]; w1[j] = wv[U + j]; }
+            }
+            const float4 wf = tab_ld(tl, (T::VW + T::NVW - 1) * 64);
+            float act[U];
+            if constexpr (DG) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) act[j] = relu_(hid_s[st][j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) act[j] = __builtin_fmaf(z_s[st][j], hp_s[st][j] - n_s[st][j], n_s[st][j]);      // h(t)
+            }
+            float p0 = wf.x * fs_s[st][0], p1 = wf.z * fs_s[st][0];
+            if constexpr (NFS > 1) { p0 = __builtin_fmaf(wf.y, fs_s[st][1], p0); p1 = __builtin_fmaf(wf.w, fs_s[st][1], p1); }
+#pragma unroll
+            for (int j = 0; j < U; ++j) { p0 = __builtin_fmaf(w0[j], act[j], p0); p1 = __builtin_fmaf(w1[j], act[j], p1); }
+            const float2 tv = ts[n * kChunkPad + tloc + st];
+            const float y0 = quad_sum(p0), y1 = quad_sum(p1);
+            float dy0, dy1;
+            s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+            // ---- dL/dh(t) ----
+            float dht[U];
+            if constexpr (DG) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < U; ++j) v[j] = __builtin_fmaf(dy0, w0[j], w1[j] * dy1) * relu_gate(hid_s[st][j]);
+#pragma unroll
+                for (int j = U; j < 8; ++j) v[j] = 0.0f;
+                const Split3 Bd = split8(v);
+                f32x4 acc[T::NTH];
+#pragma unroll
+                for (int t = 0; t < T::NTH; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][e] = 4 * t + e < U ? dh[4 * t + e] : 0.0f;
+                mm6<T::NTH>(tl, T::HT, Bd, acc);
+#pragma unroll
+                for (int j = 0; j < U; ++j) dht[j] = acc[j / 4][j % 4];
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) dht[j] = dh[j] + __builtin_fmaf(dy0, w0[j], w1[j] * dy1);
+            }
+            // ---- gate derivatives: v = [d r_pre | d z_pre | d(W_hn h) | d n_pre] ----
+            float v[4 * U];
+            f32x4 acc[T::NTO];
+#pragma unroll
+            for (int t = 0; t < T::NTO; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const float r = r_s[st][j], z = z_s[st][j], nn = n_s[st][j];
+                const float dn = dht[j] * (1.0f - z);
+                const float dnp = dn * __builtin_fmaf(-nn, nn, 1.0f);
+                const float dgh = dnp * r;
+                v[j] = dgh * nh_s[st][j] * (1.0f - r);
+                v[U + j] = (hp_s[st][j] - nn) * z * dn;
+                v[2 * U + j] = dgh;
+                v[3 * U + j] = dnp;
+                acc[j / 4][j % 4] = dht[j] * z;
+            }
+#pragma unroll
+            for (int c = 0; c < T::NM; ++c) {
+                float vc[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vc[i] = v[8 * c + i];
+                const Split3 Bg = split8(vc);
+                // tile t of chunk c: groups BW + 3 (t * NM + c)
+#pragma unroll
+                for (int t = 0; t < T::NTO; ++t) {
+                    f32x4 one[1] = {acc[t]};
+                    mm6<1>(tl, T::BW + 3 * (t * T::NM + c), Bg, one);
+                    acc[t] = one[0];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) dh[j] = acc[j / 4][j % 4];
+            // ---- dL/du: feature gradient of the lane's slots, gathered over the quads ----
+            float dfs[NFS];
+#pragma unroll
+            for (int e = 0; e < NFS; ++e) {
+                dfs[e] = acc[(U + e) / 4][(U + e) % 4];
+                if constexpr (DG) dfs[e] = __builtin_fmaf(dy0, e ? wf.y : wf.x, __builtin_fmaf(dy1, e ? wf.w : wf.z, dfs[e]));
+            }
+            float df[F];
+            {
+                float g0[4], g1[4];
+                gather_rows(dfs[0], g0);
+                if constexpr (F > 1 && NFS > 1) gather_rows(dfs[1], g1);
+#pragma unroll
+                for (int f = 0; f < F; ++f) df[f] = (f % NFS) ? g1[f / NFS] : g0[f / NFS];
+            }
+            const float2 xv = xs[n * kChunkPad + tloc + st];
+            float dI, dQ;
+            feat_bwd<FM>(xv.x, xv.y, df, dI, dQ);
+            if (q == 0) dxs[n * kChunkPad + tloc + st] = make_float2(dI, dQ);
+        }
+    }
+}
+
+template <int FM, bool DG, int U, int S>
+__global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
+    using T = S16X<DG, U>;
+    constexpr int F = S16Cfg<FM>::F, NFS = T::NFS, NQ = T::NQ;
+    constexpr int kWave = 3 * 2 * 16 * kChunkPad;
+    static_assert(kChunk % S == 0, "a block never straddles two staged chunks");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const GruLayout L = gru_layout(a.H, F, DG);
+    float* tab = smem;
+    float* pl = tab + s16_tab_floats(T::NG);
+    stage_params(pl, a.params, L.P);
+    s16x_fill_table<FM, DG, U>(tab, pl, L, lane, wave, nwb);
+    const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* ts = xs + 16 * kChunkPad;
+    float2* dxs = ts + 16 * kChunkPad;
+    float loss_acc = 0.0f;
+    const int nwaves = gridDim.x * nwb, nblk = (a.T + S - 1) / S;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        const bool valid = b0 + n < a.B;
+        float4* ck = reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * nblk * NQ * 64 + lane;      // [block][NQ][lane]
+        {
+            // ---- forward: h checkpoints only ----
+            float h[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) h[j] = 0.0f;
+            for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+                const int len = min(kChunk, a.T - t0);
+                wave_lds_fence();
+                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+                wave_lds_fence();
+                for (int tt = 0; tt < len; ++tt) {
+                    const float2 xv = xs[n * kChunkPad + tt];
+                    float fs[NFS], r[U], z[U], nn[U], nh[U], hd[U];
+                    s16x_feats<FM, U>(xv.x, xv.y, oh, fs);
+                    const Split3 B = s16x_operand<U>(h, fs);
+                    s16x_cell<FM, DG, U, false>(opaque(tl), B, h, r, z, nn, nh, hd);
+                    const int t1 = t0 + tt + 1;
+                    if ((t1 % S) == 0 && t1 < a.T) {
+#pragma unroll
+                        for (int i = 0; i < NQ; ++i)
+                            ck[((size_t)(t1 / S) * NQ + i) * 64] = make_float4(h[4 * i], 4 * i + 1 < U ? h[4 * i + 1] : 0.f, 4 * i + 2 < U ? h[(4 * i + 2) < U ? 4 * i + 2 : 0] : 0.f,
+                                                                             4 * i + 3 < U ? h[(4 * i + 3) < U ? 4 * i + 3 : 0] : 0.f);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        {
+            // ---- backward ----
+            float dh[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) dh[j] = 0.0f;
+            int cur_chunk = -1;
+            for (int blk = nblk - 1; blk >= 0; --blk) {
+                const int tb = blk * S, nstep = min(S, a.T - tb);
+                const int chunk = tb / kChunk, t0 = chunk * kChunk;
+                float h0[U];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const float4 v = blk ? ck[((size_t)blk * NQ + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    h0[4 * i] = v.x;
+                    if (4 * i + 1 < U) h0[(4 * i + 1) < U ? 4 * i + 1 : 0] = v.y;
+                    if (4 * i + 2 < U) h0[(4 * i + 2) < U ? 4 * i + 2 : 0] = v.z;
+                    if (4 * i + 3 < U) h0[(4 * i + 3) < U ? 4 * i + 3 : 0] = v.w;
+                }
+                if (chunk != cur_chunk) {
+                    if (cur_chunk >= 0) {
+                        const int pt0 = cur_chunk * kChunk;
+                        wave_lds_fence();
+                        stage_out<16>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                    }
+                    wave_lds_fence();
+                    const int len = min(kChunk, a.T - t0);
+                    stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+                    stage_in<16>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+                    wave_lds_fence();
+                    cur_chunk = chunk;
+                }
+                if (nstep == S) s16x_block<FM, DG, U, S, true>(a, tl, oh, xs, ts, dxs, n, q, tb - t0, nstep, valid, h0, dh, loss_acc);
+                else s16x_block<FM, DG, U, S, false>(a, tl, oh, xs, ts, dxs, n, q, tb - t0, nstep, valid, h0, dh, loss_acc);
+            }
+            if (cur_chunk >= 0) {
+                const int pt0 = cur_chunk * kChunk;
+                wave_lds_fence();
+                stage_out<16>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                wave_lds_fence();
+            }
+        }
+    }
+    // the loss partial of the workgroup (one row of kLossCols per workgroup)
+    const float lp = row_sum16(loss_acc);          // accumulated on the q == 0 lanes
+    __syncthreads();
+    if (lane == 0) smem[wave] = lp;
+    __syncthreads();
+    if (threadIdx.x < kLossCols) {
+        float v = 0.0f;
+        if (threadIdx.x == 0)
+            for (int wv = 0; wv < nwb; ++wv) v += smem[wv];
+        a.partials[(size_t)blockIdx.x * kLossCols + threadIdx.x] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+constexpr int kS16xStride = 2;      // checkpoint stride of this kernel (its own: the workspace is private to the launch)
+static bool s16x_cfg(const odpd_model_t* m, int& FM, bool& DG) {
+    switch (m->backbone) {
+    case ODPD_GRU: FM = FEAT_RAW2; DG = false; return true;
+    case ODPD_DGRU: FM = FEAT_DGRU6; DG = true; return true;
+    case ODPD_QGRU: FM = FEAT_Q4; DG = false; return true;
+    case ODPD_QGRU_AMP1: FM = FEAT_A4; DG = false; return true;
+    default: return false;
+    }
+}
+bool gru_s16x_ok(const odpd_model_t* m) {
+    int FM; bool DG;
+    return s16x_cfg(m, FM, DG) && m->hidden >= 17 && m->hidden <= 24 && m->bits_w == 0 && !(m->flags & ODPD_FLAG_TWO_LAYERS) &&
+           tuning().s16x != 0;
+}
+int64_t gru_s16x_ckpt_floats(const odpd_model_t* m, int B, int T) {
+    (void)m;
+    return (int64_t)((B + 15) / 16) * ((T + kS16xStride - 1) / kS16xStride) * 2 * 256;
+}
+template <int FM, bool DG>
+static int launch_s16x(hipStream_t st, const SeqArgs& a, int P, int grid) {
+    using T = S16X<DG, 6>;
+    constexpr int kWave = 3 * 2 * 16 * kChunkPad;
+    size_t body = (size_t)8 * kWave;
+    if (body < (size_t)pad4(P)) body = pad4(P);
+    const size_t lds = ((size_t)s16_tab_floats(T::NG) + body) * sizeof(float);
+    if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+    auto k = gru16x_lossdx_kernel<FM, DG, 6, kS16xStride>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+    return (int)hipGetLastError();
+}
+// frozen-PA loss step; the grid (= loss rows the host reduces) is gru_s16n_rows(m, B), the same as the exact-fp32 kernel's
+int gru_s16x_lossdx(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int grid) {
+    int FM; bool DG;
+    if (!s16x_cfg(m, FM, DG) || !gru_s16x_ok(m)) return ODPD_EUNSUPPORTED;
+    if (!a0.ckpt || !a0.dx || !a0.partials || !a0.target) return ODPD_EINVAL;
+    SeqArgs a = a0;
+    a.ngroups = (a.B + 15) / 16;
+    const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
+    if (FM == FEAT_RAW2) return launch_s16x<FEAT_RAW2, false>(st, a, P, grid);
+    if (FM == FEAT_DGRU6) return launch_s16x<FEAT_DGRU6, true>(st, a, P, grid);
+    if (FM == FEAT_Q4) return launch_s16x<FEAT_Q4, false>(st, a, P, grid);
+    return launch_s16x<FEAT_A4, false>(st, a, P, grid);
+}
+
+}  // namespace odpd
