@@ -77,6 +77,24 @@ __device__ __forceinline__ void mm6(TabPtr tl, int grp0, const Split3& B, f32x4 
     }
 }
 
+// The same with the A operands already in registers (forward loop: the six cell tiles stay pinned — a ds_read_b128 costs the SIMD ~16
+// cycles that nothing overlaps, tools/ubench/mfma_lds.hip), two tiles at a time with their products interleaved
+template <int NT>
+__device__ __forceinline__ void mm6r(const u32x4 (&A)[NT][3], const Split3& B, f32x4 (&acc)[NT]) {
+    static_assert(NT % 2 == 0, "tiles go in pairs");
+#pragma unroll
+    for (int t = 0; t < NT; t += 2) {
+        f32x4 c = acc[t], d = acc[t + 1];
+        c = mfma32(A[t][0], B.t[2], c); d = mfma32(A[t + 1][0], B.t[2], d);
+        c = mfma32(A[t][2], B.t[0], c); d = mfma32(A[t + 1][2], B.t[0], d);
+        c = mfma32(A[t][1], B.t[1], c); d = mfma32(A[t + 1][1], B.t[1], d);
+        c = mfma32(A[t][0], B.t[1], c); d = mfma32(A[t + 1][0], B.t[1], d);
+        c = mfma32(A[t][1], B.t[0], c); d = mfma32(A[t + 1][1], B.t[0], d);
+        c = mfma32(A[t][0], B.t[0], c); d = mfma32(A[t + 1][0], B.t[0], d);
+        acc[t] = c; acc[t + 1] = d;
+    }
+}
+
 // ---- operand tables ------------------------------------------------------------------------------------------------------------------
 // groups of 64 lanes x 16 B.  bf16 groups hold A[row m = lane & 15][k = 8 (lane >> 4) + i], i < 8, as one term of the split.
 template <bool DG, int U>
@@ -431,7 +449,15 @@ __global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
         const bool valid = b0 + n < a.B;
         float4* ck = reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * nblk * NQ * 64 + lane;      // [block][NQ][lane]
         {
-            // ---- forward: h checkpoints only ----
+            // ---- forward: h checkpoints only; the cell tiles stay in registers ----
+            u32x4 A[T::NTF][3];
+            {
+                TabPtr tp = opaque(tl);
+#pragma unroll
+                for (int t = 0; t < T::NTF; ++t)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) A[t][k] = tabx_ld(tp, (T::FW + 3 * t + k) * 64);
+            }
             float h[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) h[j] = 0.0f;
@@ -442,10 +468,20 @@ __global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
                 wave_lds_fence();
                 for (int tt = 0; tt < len; ++tt) {
                     const float2 xv = xs[n * kChunkPad + tt];
-                    float fs[NFS], r[U], z[U], nn[U], nh[U], hd[U];
+                    float fs[NFS];
                     s16x_feats<FM, U>(xv.x, xv.y, oh, fs);
                     const Split3 B = s16x_operand<U>(h, fs);
-                    s16x_cell<FM, DG, U, false>(opaque(tl), B, h, r, z, nn, nh, hd);
+                    f32x4 acc[T::NTF];
+#pragma unroll
+                    for (int t = 0; t < T::NTF; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mm6r<T::NTF>(A, B, acc);
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        const int sr = j, sz = U + j, sh = 2 * U + j, si = 3 * U + j;
+                        const float r = sig_ps(acc[sr / 4][sr % 4]), z = sig_ps(acc[sz / 4][sz % 4]);
+                        const float nn = tanh_x<FM>(__builtin_fmaf(r, acc[sh / 4][sh % 4], acc[si / 4][si % 4]));
+                        h[j] = __builtin_fmaf(z, h[j] - nn, nn);
+                    }
                     const int t1 = t0 + tt + 1;
                     if ((t1 % S) == 0 && t1 < a.T) {
 #pragma unroll
