@@ -379,7 +379,10 @@ extern "C" int odpd_frozen_loss_dx(void* stream, const odpd_model_t* m, int loss
 
 // DPDs of the one-launch cascade step: the float GRU family, the float delta-GRU backbones and the plain LSTM (gru_cascade.hip)
 static bool cascade_dpd_family(const odpd_model_t* m) {
-    return family_of(m) == FAM_GRU || (family_of(m) == FAM_DELTA && m->backbone != ODPD_DELTAJANET) || m->backbone == ODPD_LSTM ||
+    // (family_of answers FAM_GRU2 for ODPD_FLAG_TWO_LAYERS descriptors — the one-launch step only knows one-layer parameter layouts, so a
+    // two-layer lstm must not slip in through its backbone id: ADVICE r04)
+    return family_of(m) == FAM_GRU || (family_of(m) == FAM_DELTA && m->backbone != ODPD_DELTAJANET) ||
+           (family_of(m) == FAM_LSTM && m->backbone == ODPD_LSTM) ||
            family_of(m) == FAM_QAT;      // (every quantised kind: gru, dgru, qgru, qgru_amp1, deltagru_tcnskip)
 }
 extern "C" int64_t odpd_cascade_rows(const odpd_model_t* dpd, const odpd_model_t* pa, int B, int T) {
@@ -499,9 +502,11 @@ static int dp_clip_step(hipStream_t st, void* comm, int opt_kind, int64_t P, flo
         if (tuning().xchg_fused && comm_next_xchg(comm, P + kLossCols, &xd)) xp = &xd;
         else if (int rc = comm_allreduce(st, comm, grad, P + kLossCols)) return rc;
     }
-    return opt_kind < 0 ? launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, norm_out,
-                                            loss_out, inv_count, skip, xp)
-                        : launch_clip_optim(st, opt_kind, P, params, grad, state1, state2, step, lr, max_norm, norm_out, loss_out, inv_count, skip, xp);
+    const int rc = opt_kind < 0 ? launch_clip_adamw(st, P, params, grad, state1, state2, step, lr, beta1, beta2, eps, weight_decay, max_norm, norm_out,
+                                                    loss_out, inv_count, skip, xp)
+                                : launch_clip_optim(st, opt_kind, P, params, grad, state1, state2, step, lr, max_norm, norm_out, loss_out, inv_count, skip, xp);
+    if (rc != 0 && xp) comm_xchg_rollback(comm);      // the launch that was to carry the exchange failed: stay in step with the peers
+    return rc;
 }
 extern "C" int odpd_clip_optim_step_dp(void* stream, void* comm, int opt_kind, int64_t P, float* params, float* grad, float* state1, float* state2,
                                        int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm,

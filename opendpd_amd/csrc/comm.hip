@@ -58,6 +58,7 @@ struct Comm {
     RcclComm c = nullptr;
     // one-shot exchange
     unsigned seq = 0;                              // advanced per exchange, the same sequence on every rank
+    unsigned prev_seq = 0;                         // ... its value before the last advance (comm_xchg_rollback)
     unsigned long long* slots[kXchgMaxWorld] = {};  // every rank's slot base as mapped in this process (slots[rank] = own)
     bool opened[kXchgMaxWorld] = {};               // hipIpcOpenMemHandle mappings to close
     int* err = nullptr;
@@ -79,7 +80,10 @@ int comm_world(void* comm) { return static_cast<Comm*>(comm)->world; }
 bool comm_next_xchg(void* comm, int64_t n, XchgDev* out) {
     Comm* cm = static_cast<Comm*>(comm);
     if (!cm || cm->kind == KIND_RCCL || !cm->connected || n <= 0 || n > kXchgMaxFloats) return false;
-    if (++cm->seq == 0) cm->seq = 1;               // 0 is the state of a fresh slot
+    // 0 is the state of a fresh slot.  The wrap goes to 2, not 1: 0xFFFFFFFF is odd, and two consecutive exchanges on the same parity would
+    // break the two-parity overwrite argument of odpd_xchg.h
+    cm->prev_seq = cm->seq;
+    if (++cm->seq == 0) cm->seq = 2;
     const unsigned par = cm->seq & 1u;
     XchgDev xd{};
     for (int r = 0; r < cm->world; ++r) xd.dst[r] = cm->slots[r] + ((size_t)par * cm->world + cm->rank) * kXchgMaxFloats;
@@ -92,6 +96,14 @@ bool comm_next_xchg(void* comm, int64_t n, XchgDev* out) {
     return true;
 }
 
+// the exchange handed out last was never launched (the launch itself failed): give its sequence number back, so that this rank does not
+// run one exchange ahead of its peers (they would spin until the time-out)
+void comm_xchg_rollback(void* comm) {
+    Comm* cm = static_cast<Comm*>(comm);
+    if (!cm || cm->kind == KIND_RCCL) return;
+    cm->seq = cm->prev_seq;
+}
+
 int comm_allreduce(hipStream_t st, void* comm, float* buf, int64_t n) {
     Comm* cm = static_cast<Comm*>(comm);
     if (!cm || !buf || n <= 0) return ODPD_EINVAL;
@@ -102,7 +114,7 @@ int comm_allreduce(hipStream_t st, void* comm, float* buf, int64_t n) {
             XchgDev xd;
             if (!comm_next_xchg(comm, len, &xd)) return ODPD_ECOMM;
             hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(1), dim3(1024), 0, st, xd, buf + o, (int)len);
-            ODPD_CHECK_HIP(hipGetLastError());
+            if (hipError_t e = hipGetLastError()) { comm_xchg_rollback(comm); return (int)e; }
         }
         return 0;
     }

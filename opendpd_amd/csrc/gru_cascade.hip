@@ -200,6 +200,7 @@ bool casc_model(const odpd_model_t* m, int& fm, bool& dg) {
 }
 int feat_dim(int fm) { return fm == FEAT_RAW2 ? 2 : fm == FEAT_DGRU6 ? 6 : 4; }
 bool casc_cfg(const odpd_model_t* dpd, const odpd_model_t* pa, CascCfg& c) {
+    if ((dpd->flags | pa->flags) & ODPD_FLAG_TWO_LAYERS) return false;      // one-layer parameter layouts only (two layers: the chained launches)
     if (!casc_model(pa, c.fmp, c.dgp)) return false;
     const bool delta = dpd->bits_w == 0 && (dpd->backbone == ODPD_DELTAGRU || dpd->backbone == ODPD_TRES_DELTAGRU);
     const bool lstm = dpd->bits_w == 0 && dpd->backbone == ODPD_LSTM;

@@ -154,6 +154,7 @@ int comm_world(void* comm);
 // one-shot communicators: the NEXT exchange as a kernel argument, for a kernel that folds it into its prologue (optim.hip) — false
 // for an RCCL communicator or n > kXchgMaxFloats (the caller then enqueues comm_allreduce).  Advances the sequence: call once per step.
 bool comm_next_xchg(void* comm, int64_t n, XchgDev* out);
+void comm_xchg_rollback(void* comm);      // ... undone: the kernel that was to carry the exchange could not be launched
 
 // family entry points (defined in the family .hip files)
 int gru_family_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);

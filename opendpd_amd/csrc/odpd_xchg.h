@@ -34,6 +34,7 @@ __device__ __forceinline__ void xchg_allreduce_block(const XchgDev& xd, float* _
         for (int r = 0; r < kXchgMaxWorld; ++r)
             if (r < xd.world && r != xd.rank) __hip_atomic_store(xd.dst[r] + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    bool any_late = false;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         float acc = 0.f;
         bool late = false;
@@ -51,9 +52,11 @@ __device__ __forceinline__ void xchg_allreduce_block(const XchgDev& xd, float* _
             }
             acc += v;
         }
-        if (late) { acc = __uint_as_float(0x7fc00000u); atomicAdd(xd.err, 1); }
+        if (late) { acc = __uint_as_float(0x7fc00000u); any_late = true; }
         g[i] = acc;
     }
+    // the counter counts EXCHANGES that timed out, not elements: one increment per call, by thread 0 after a block-wide OR
+    if (__syncthreads_or(any_late) && threadIdx.x == 0) atomicAdd(xd.err, 1);
     __syncthreads();
 }
 

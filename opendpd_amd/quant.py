@@ -447,7 +447,10 @@ def get_quant_model(proj, model):
     bits_w, bits_a = int(getattr(proj, "n_bits_w", 8)), int(getattr(proj, "n_bits_a", 8))
     H = model.hidden_size
     max_h = _HEAD_MAX_HIDDEN.get(bt, MAX_HIDDEN)
-    if H > max_h or model.num_layers != 1:
+    # pgjanet, rvtdcnn and neuraltx ignore num_layers (models.py:26-141 never hands it to them; wide.outside_envelope treats them the same way):
+    # `--quant --DPD_num_layers 2` on them runs in the reference and must run here; the check is for the recurrent cores
+    layers_matter = bt not in ("pgjanet", "rvtdcnn", "neuraltx")
+    if H > max_h or (layers_matter and model.num_layers != 1):
         raise NotImplementedError(f"the QAT kernels cover one layer and hidden_size <= {max_h} (csrc/qat_s16.hip; csrc/deltajanet_wide.hip)")
     dev = next(model.parameters()).device
     pre = getattr(proj, "pretrained_model", "")

@@ -299,9 +299,22 @@ class FusedAdamW:
             return False
         if self.world_size() > 1 or self.native_comm() is not None:
             # sharded epoch from C++ (odpd_train_epoch_dp): needs the library-owned RCCL communicator and fused kernels for this rank's shards
-            return self.native_comm() is not None and all(self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length)
-                                                          for b in self._shard_sizes(loader))
-        return all(self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length) for b in self._epoch_batches(loader))
+            sizes = self._shard_sizes(loader)
+            return self.native_comm() is not None and self._one_workspace_meaning(sizes, loader.frame_length) and all(
+                self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length) for b in sizes)
+        sizes = self._epoch_batches(loader)
+        return self._one_workspace_meaning(sizes, loader.frame_length) and all(
+            self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length) for b in sizes)
+
+    def _one_workspace_meaning(self, sizes, T):
+        """The `workspace` argument of the epoch entry points is ONE pointer for every batch of the epoch.  For backbones with sparsity
+        counters it carries the counters when a batch runs on a one-frame-per-wave kernel (workspace floats = 0) and checkpoint scratch when
+        it runs on a 16-sequences-per-wave kernel (> 0): an epoch whose full and tail batches fall on different sides cannot be served by one
+        pointer — the tail's counters would land in the scratch — and goes through the per-step path instead."""
+        if not (self.backbone.dx_needs_flag or getattr(self.backbone, "fused_stats", False)):
+            return True
+        ws = [int(_lib.load().odpd_train_workspace_floats(C.byref(self.backbone.desc), b, T)) for b in sizes]
+        return not (any(w > 0 for w in ws) and any(w == 0 for w in ws))
 
     @staticmethod
     def _epoch_batches(loader):
@@ -649,8 +662,29 @@ def _cascade_train_step(opt, x, target, loss_kind, grad_clip_val, count, timing=
     return loss
 
 
+def _check_exchange_health(optimizer):
+    """Data-parallel runs: a one-shot exchange that timed out on SOME rank poisoned that rank's gradient sum with NaN while its peers
+    carried on with a valid one — the replicas have diverged and nothing downstream would notice.  Once per epoch (the epoch's
+    loss read-back has synchronised the device already) every rank reads its time-out counter, the ranks agree on the verdict, and ALL of
+    them raise together when any of them saw a time-out."""
+    comm = optimizer.native_comm() if isinstance(optimizer, FusedAdamW) else None
+    if comm is None:
+        return
+    from .dist import _agree
+    mine = comm.errors()
+    if not _agree(mine == 0, optimizer.backbone.flat_params().device):
+        raise RuntimeError(f"data-parallel gradient exchange timed out during this epoch (this rank: {mine} exchange(s)); a peer was lost or "
+                           "stalled — the replicas are no longer identical, the run cannot be continued")
+
+
 def net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device):
     """Reference signature (train_funcs.py:16-22)."""
+    net = _net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device)
+    _check_exchange_health(optimizer)
+    return net
+
+
+def _net_train(log, net, dataloader, optimizer, criterion, grad_clip_val, device):
     net = net.train()
     losses = []
     kind = _loss_kind(criterion)

@@ -110,3 +110,40 @@ def test_entry_points_written_for_one_layer_refuse_the_descriptor():
     assert int(lib.odpd_train_workspace_floats(C.byref(d), 64, 50)) < 0
     d3 = _lib.ModelDesc(_lib.BACKBONE_IDS["vdlstm"], 8, 0.0, 0.0, 0, 0, _lib.FLAG_TWO_LAYERS)
     assert int(lib.odpd_param_count(C.byref(d3))) < 0                       # vdlstm: one layer only
+
+
+@pytest.mark.parametrize("dpd_bb,H", [("lstm", 12), ("gru", 11), ("dgru", 9)])
+def test_two_layer_dpd_in_train_dpd_takes_the_chained_launches(dpd_bb, H):
+    """`--DPD_backbone lstm --DPD_num_layers 2` in front of a gru / dgru PA.  The one-launch cascade step only knows
+    one-layer parameter layouts: odpd_cascade_rows must refuse the two-layer descriptor (it used to admit the lstm through its backbone id
+    and ran the ONE-layer layout over the two-layer buffer), and the chained step's loss / DPD gradient must equal the ATen restatement's."""
+    import ctypes as C
+    from opendpd_amd import CascadedModel, CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    lib = _lib.load()
+    torch.manual_seed(H)
+    B, T = 24, 40
+    dpd, pa = CoreModel(2, H, 2, dpd_bb), CoreModel(2, 11, 1, "dgru")
+    assert dpd.backbone.native
+    net = CascadedModel(dpd_model=dpd, pa_model=pa)
+    net.freeze_pa_model()
+    net = net.cuda()
+    assert int(lib.odpd_cascade_rows(C.byref(dpd.backbone.desc), C.byref(pa.backbone.desc), B, T)) < 0
+    rng = np.random.RandomState(H)
+    x = (rng.uniform(0.1, 0.8, (B, T, 2)) * rng.choice([-1.0, 1.0], (B, T, 2))).astype(np.float32)
+    t = (0.5 * rng.randn(B, T, 2)).astype(np.float32)
+    with _aten_only():
+        ref_dpd = CoreModel(2, H, 2, dpd_bb)
+    ref_dpd.load_state_dict(dpd.state_dict())
+    ref_pa = CoreModel(2, 11, 1, "dgru")
+    ref_pa.load_state_dict(pa.state_dict())
+    xr = torch.from_numpy(x)
+    with _aten_only():
+        loss_ref = torch.nn.functional.mse_loss(ref_pa.cuda()(ref_dpd.cuda()(xr.cuda())), torch.from_numpy(t).cuda())
+        loss_ref.backward()
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    lg = fused_train_step(opt, torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda(), "l2", 0.0)
+    assert abs(lg.item() - loss_ref.item()) < 2e-5 * max(1.0, loss_ref.item())
+    got = opt.grad[:-4].cpu().numpy()
+    want = np.concatenate([p.grad.detach().cpu().numpy().reshape(-1) for p in ref_dpd.parameters()])
+    assert rel_err(got, want) < 3e-4

@@ -74,6 +74,16 @@ def test_surgery_on_the_other_backbones():
         get_quant_model(_Proj, CoreModel(2, 8, 1, "deltagru"))
     with pytest.raises(NotImplementedError):
         get_quant_model(_Proj, CoreModel(2, 8, 1, "apnrru"))
+    # num_layers means nothing to pgjanet / rvtdcnn / neuraltx (models.py never hands it to them): `--quant --DPD_num_layers 2` runs in the
+    # reference and here; for a recurrent core it is outside the kernels
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for bb in ("pgjanet", "rvtdcnn", "neuraltx"):
+            q = get_quant_model(_Proj, CoreModel(2, 8, 2, bb))
+            assert any("quantizer" in k for k in q.state_dict()), bb
+        with pytest.raises(NotImplementedError):
+            get_quant_model(_Proj, CoreModel(2, 8, 2, "lstm"))
 
 
 def test_head_only_surgery_state_dict_and_rng_match_the_reference():
