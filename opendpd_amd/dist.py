@@ -90,6 +90,10 @@ class NativeComm:
     handles and the verdicts (the only use torch.distributed has on this path)."""
 
     def __init__(self, device, kind):
+        self._build(device, kind)
+        candidate_log.append({"kind": kind, "ok": bool(self.ok), "why": self.why})
+
+    def _build(self, device, kind):
         import ctypes as C
         import torch.distributed as dist
         from . import _lib
@@ -209,6 +213,7 @@ class NativeComm:
 
 
 _native = None
+candidate_log = []      # every NativeComm this process built: {"kind", "ok", "why"} (bench.py prints it: which candidate failed, and where)
 
 
 def comm_candidates(backend, multi):
