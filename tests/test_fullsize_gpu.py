@@ -89,6 +89,31 @@ def test_full_size_forward_against_the_oracle_on_drawn_frames(workload):
     assert abs((float(y[:cut].double().sum()) + float(y[cut:].double().sum())) / y.numel() - m) < 1e-9
 
 
+def test_full_size_gradient_against_the_oracle_on_drawn_frames(workload):
+    """The GRADIENT of the full-size launch against the oracle (only additivity and a forward spot check reached this size).
+    256 drawn frames, each placed 256 times at shuffled positions of a 65 536-frame batch: the launch is the bench's (same grid, same
+    16-sequences-per-wave kernel, same reduction over 256 partial rows), its loss and gradient are the mean over identical copies — i.e.
+    the oracle's loss and gradient of the 256 drawn frames."""
+    from oracle.oracle import Oracle, make_model
+    net, xs, ys = workload
+    dev = xs.device
+    rng = np.random.RandomState(3)
+    idx = np.sort(rng.choice(B, 256, replace=False))
+    order = torch.from_numpy(rng.permutation(np.repeat(idx, B // 256))).to(dev)
+    l, g, opt = _grad(net, xs, ys, order, B * T * 2)
+    assert opt.train_workspace(B, T, dev) is not None                 # the 16-sequences-per-wave kernel served it
+    x = xs.unfold(0, T, 1).permute(0, 2, 1)[torch.from_numpy(idx).to(dev)].contiguous().cpu().numpy()
+    t = ys.unfold(0, T, 1).permute(0, 2, 1)[torch.from_numpy(idx).to(dev)].contiguous().cpu().numpy()
+    o = Oracle("f32")
+    m = make_model("dgru", H)
+    p = net.backbone.flat_params().detach().cpu().numpy()
+    y, _ = o.forward(m, p, x)
+    lo, dy = o.loss("l2", y, t)
+    go, _ = o.backward(m, p, x, dy, need_dx=False)
+    assert abs(l - lo) < 2e-6 * abs(lo)
+    assert rel_err(g.cpu().numpy(), go) < 3e-4                        # the small-shape gradient tolerance of tests/test_gru_family_gpu.py
+
+
 def test_cascade_gradient_is_additive_at_config_3_size():
     """BASELINE config 3 shape at a saturating batch (TRes-DeltaGRU H15 with its thresholds -> frozen DGRU H23, 16 384 x 200): the DPD
     gradient of the train_dpd step is the sum of the gradients of a ragged split (thresholded deltas act per sequence)"""

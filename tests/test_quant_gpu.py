@@ -1,6 +1,7 @@
 """GPU parity of the quantisation-aware QGRU kernels (csrc/qgru_family.hip).  For 8-bit grids the HIP path must be
 BIT-EXACT with the reference (train-mode float outputs, eval-mode outputs on the 2^-14 grid, before and after training);
-for 16-bit grids (32-bit products, fp32 accumulation order matters) agreement is to one output LSB."""
+for 16-bit grids (32-bit products, fp32 accumulation order matters) qgru is bit-exact as well and qgru_amp1 agrees to <= 2.5 LSB of the
+2^-14 output grid on <= 8 % of the outputs (measured: 2.19 LSB, 6 %)."""
 import numpy as np
 import pytest
 import torch
@@ -41,7 +42,17 @@ def test_forward_train_eval_bit_exact(name, bb, bits):
             assert np.array_equal(yt, fx[ytr]), (prefix, np.abs(yt - fx[ytr]).max())
             assert np.array_equal(ye, fx[yev]), prefix
         else:
-            assert np.abs(yt - fx[ytr]).max() <= 2.0 ** -12 and np.abs(ye - fx[yev]).max() <= 2.0 ** -12
+            # 16-bit grids: 32-bit products summed in fp32, so the summation order decides the last bit of a pre-activation; where that lands
+            # within rounding reach of a 2^-14 grid boundary the quantised value moves by one grid step and the recurrence carries it on.
+            # Measured (tools/probe_w16.py): qgru bit-exact; qgru_amp1 <= 1 LSB on 7 of 370 outputs at initialisation, <= 2.19 LSB on 22 of
+            # 370 after three training steps.  Asserted: <= 2.5 LSB of the 2^-14 output grid, on at most 8 % of the outputs
+            lsb = 2.0 ** -14
+            for got, want in ((yt, fx[ytr]), (ye, fx[yev])):
+                d = np.abs(got - want)
+                assert d.max() <= 2.5 * lsb, (name, prefix, d.max() / lsb)
+                assert (d > 0.5 * lsb).mean() <= 0.08, (name, prefix, (d > 0.5 * lsb).mean())
+            if bb == "qgru":
+                assert np.array_equal(yt, fx[ytr]) and np.array_equal(ye, fx[yev]), prefix
 
 
 @pytest.mark.parametrize("name,bb,bits", QAT)
