@@ -224,6 +224,46 @@ int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_kind, const o
                      float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t first_step, double lr,
                      double beta1, double beta2, double eps, double weight_decay, double max_norm, float* partials,
                      float* workspace, float* losses_out);
+/* ---- lockstep sweeps: K independent runs of ONE model shape advancing together (the seeds x backbones loops of the reference's
+ * bash_scripts/train_all_pa.sh:26-57 and train_all_dpd.sh start one process per run; at the reference's batch sizes one run fills 256 of the
+ * chip's >= 8 192 wave slots).  Per step ONE fused train launch carries all K runs (run k owns workgroups [k G, (k + 1) G) and sees exactly the
+ * launch it would have had alone), one row reduction and one clip + AdamW launch follow: every run is bit-identical to its solo
+ * odpd_train_epoch.  All pointers of a run are device pointers; `runs` itself is a HOST array (copied into `scratch`, device memory of
+ * odpd_sweep_scratch_bytes(K, steps of the epoch) bytes, which must stay untouched until the stream has drained).
+ * Served: the float GRU family where odpd_sweep_train_supported / odpd_sweep_fwd_supported say so (the one-sequence-per-wave kernels of the
+ * reference's own batch sizes); otherwise ODPD_EUNSUPPORTED and the caller loops over odpd_train_epoch. */
+typedef struct {
+    float* params;            /* P floats */
+    float* grad;              /* P + 4 */
+    float* exp_avg;           /* P */
+    float* exp_avg_sq;        /* P */
+    float* partials;          /* (odpd_partial_rows(m, batch, T, 1), P + 4) */
+    float* losses_out;        /* ceil(n_frames / batch): mean loss of every step */
+    float* y;                 /* odpd_backbone_fwd_sweep: (B, T, 2) output of this run (else unused) */
+    float* workspace;         /* ODPD_SWEEP_S16: odpd_sweep_workspace_floats floats of BPTT checkpoint scratch of this run (else unused) */
+    const int64_t* order;     /* the run's epoch order: n_frames frame indices (fr->order is ignored) */
+    double lr;                /* the run's learning rate of this epoch (the plateau schedulers of the runs are independent) */
+} odpd_sweep_run_t;
+/* flags of odpd_train_epoch_sweep.  Default (0): every run on the kernel its solo step uses at this batch size — the one-sequence-per-wave kernel
+ * whose frame state lives in LDS (bit-identical to the solo run; ~110 KB of LDS per frame, so one CU hosts one frame and K runs cost K solo
+ * epochs).  ODPD_SWEEP_S16: the 16-sequences-per-wave MFMA kernel whatever the batch size (hidden <= 16) — K x ceil(B / 16) waves fill the
+ * chip; every run then equals its solo run with that kernel forced (odpd_set_tuning("s16_min_batch", 0)) bit for bit, and the default
+ * solo run to float tolerance (another summation order). */
+#define ODPD_SWEEP_S16 1
+int64_t odpd_sweep_scratch_bytes(int K, int64_t n_steps);
+int odpd_sweep_s16_supported(const odpd_model_t* m);
+int64_t odpd_sweep_partial_rows(const odpd_model_t* m, int B, int T, int flags);      /* rows of a run's `partials` */
+int64_t odpd_sweep_workspace_floats(const odpd_model_t* m, int B, int T, int flags);  /* floats of a run's `workspace` (0: none needed) */
+int odpd_sweep_train_supported(const odpd_model_t* m, int B, int T);
+int odpd_sweep_fwd_supported(const odpd_model_t* m, int B, int T);
+/* one epoch of K runs: as odpd_train_epoch (AdamW with the given hyper-parameters, clip at max_norm), step index first_step + i */
+int odpd_train_epoch_sweep(void* stream, const odpd_model_t* m, int K, const odpd_sweep_run_t* runs, int loss_kind, const odpd_frames_t* fr,
+                           int batch, int64_t first_step, double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                           int flags, void* scratch);
+/* the evaluation pass of K models of one shape on the same (B, T, 2) sequences x (net_eval, train_funcs.py:57-90): runs[k].y = model_k(x) */
+int odpd_backbone_fwd_sweep(void* stream, const odpd_model_t* m, int K, const odpd_sweep_run_t* runs, int B, int T, const float* x,
+                            void* scratch);
+
 /* clip_grad_norm_(max_norm) (0 = no clipping) + AdamW step over P parameters
  * (torch.optim.AdamW defaults project.py:283: betas .9/.999, eps 1e-8, weight_decay 0.01).
  * grad is scaled in place like clip_grad_norm_ does.  `step` is the 1-based step index.

@@ -13,7 +13,7 @@ LOSS_IDS = {"l2": 0, "l1": 1}
 FLAG_EVAL, FLAG_NEED_DX, FLAG_TWO_LAYERS = 1, 2, 4      # odpd_model_t.flags (include/opendpd_hip.h)
 LOSS_COLS = 4        # extra columns of a partials row (column P = loss partial sum)
 LOSS_WS = 1 + 256    # floats behind `loss_out` (result + per-block scratch)
-ABI_VERSION = 11     # odpd_abi_version() of the library these argument lists belong to
+ABI_VERSION = 12     # odpd_abi_version() of the library these argument lists belong to
 
 
 class ModelDesc(C.Structure):
@@ -29,6 +29,13 @@ class Frames(C.Structure):
 
 
 SAMPLES_F32, SAMPLES_BF16 = 0, 1     # enum odpd_sample_format
+SWEEP_S16 = 1                        # flags of odpd_train_epoch_sweep
+
+
+class SweepRun(C.Structure):
+    """odpd_sweep_run_t"""
+    _fields_ = [("params", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("partials", C.c_void_p),
+                ("losses_out", C.c_void_p), ("y", C.c_void_p), ("workspace", C.c_void_p), ("order", C.c_void_p), ("lr", C.c_double)]
 
 
 _EXPORTS = {
@@ -94,6 +101,15 @@ _EXPORTS = {
     "odpd_train_epoch_dp": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(Frames), C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "odpd_sweep_scratch_bytes": (C.c_int64, [C.c_int, C.c_int64]),
+    "odpd_sweep_train_supported": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "odpd_sweep_fwd_supported": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "odpd_train_epoch_sweep": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(SweepRun), C.c_int, C.POINTER(Frames), C.c_int, C.c_int64,
+                                         C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "odpd_sweep_s16_supported": (C.c_int, [C.POINTER(ModelDesc)]),
+    "odpd_sweep_partial_rows": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int]),
+    "odpd_sweep_workspace_floats": (C.c_int64, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int]),
+    "odpd_backbone_fwd_sweep": (C.c_int, [C.c_void_p, C.POINTER(ModelDesc), C.c_int, C.POINTER(SweepRun), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "odpd_clip_optim_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
 }

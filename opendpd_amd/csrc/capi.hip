@@ -86,6 +86,7 @@ inline SeqArgs make_args(const odpd_model_t* m, int B, int T) {
 
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 odpd::Tuning& odpd::tuning() {
     static Tuning t = [] {
         Tuning v;
@@ -118,7 +119,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 11; }   // 11: + ODPD_FLAG_TWO_LAYERS (gru / qgru / qgru_amp1 with two recurrent layers), hidden 33 .. 64 for the GRU family and lstm, bits_w > 0 on lstm / vdlstm (INT_Linear heads); 10: + odpd_xchg_* (one-shot gradient exchange over peer-mapped slots), odpd_clip_optim_step_dp, odpd_comm_kind / _errors; 9: + odpd_cascade_rows, odpd_cascade_fwd_bwd (train_dpd step body in one launch); 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
+extern "C" int odpd_abi_version(void) { return 12; }   // 12: + odpd_sweep_* / odpd_train_epoch_sweep / odpd_backbone_fwd_sweep (K runs of one model shape in lockstep: one launch per step carries them all); 11: + ODPD_FLAG_TWO_LAYERS (gru / qgru / qgru_amp1 with two recurrent layers), hidden 33 .. 64 for the GRU family and lstm, bits_w > 0 on lstm / vdlstm (INT_Linear heads); 10: + odpd_xchg_* (one-shot gradient exchange over peer-mapped slots), odpd_clip_optim_step_dp, odpd_comm_kind / _errors; 9: + odpd_cascade_rows, odpd_cascade_fwd_bwd (train_dpd step body in one launch); 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {
@@ -672,6 +673,101 @@ extern "C" int odpd_train_epoch_split(void* stream, const odpd_model_t* m, int l
     }
     return 0;
 }
+// ---- lockstep sweeps: K independent runs of ONE model shape (the seeds of bash_scripts/train_all_pa.sh:26-57) advance together — per step
+// one fused train launch of K x grid workgroups, one row reduction, one clip + AdamW launch; each run bit-identical to its solo epoch ----
+extern "C" int64_t odpd_sweep_scratch_bytes(int K, int64_t n_steps) {
+    if (K <= 0 || n_steps < 0) return ODPD_EINVAL;
+    return (int64_t)K * (int64_t)sizeof(SweepRun) + (int64_t)K * n_steps * (int64_t)sizeof(float) + 256;
+}
+static int upload_sweep(hipStream_t st, int K, const odpd_sweep_run_t* runs, double weight_decay, void* scratch, SweepRun** dev_out) {
+    std::vector<SweepRun> h((size_t)K);
+    for (int k = 0; k < K; ++k) {
+        const odpd_sweep_run_t& r = runs[k];
+        SweepRun& d = h[(size_t)k];
+        d.params = r.params; d.grad = r.grad; d.state1 = r.exp_avg; d.state2 = r.exp_avg_sq; d.partials = r.partials; d.losses = r.losses_out;
+        d.y = r.y; d.workspace = r.workspace; d.order = (const long long*)r.order; d.decay = (float)(1.0 - r.lr * weight_decay); d.pad = 0.0f;
+    }
+    *dev_out = reinterpret_cast<SweepRun*>(scratch);
+    return (int)hipMemcpyAsync(scratch, h.data(), (size_t)K * sizeof(SweepRun), hipMemcpyHostToDevice, st);      // (pageable source: staged before the call returns)
+}
+extern "C" int odpd_sweep_train_supported(const odpd_model_t* m, int B, int T) {
+    return model_ok(m) && family_of(m) == FAM_GRU && !lane_per_unit_model(m) && gru_sweep_train_ok(m, B, T) ? 1 : 0;
+}
+extern "C" int odpd_sweep_fwd_supported(const odpd_model_t* m, int B, int T) {
+    return model_ok(m) && family_of(m) == FAM_GRU && !lane_per_unit_model(m) && gru_sweep_eval_ok(m, B, T) ? 1 : 0;
+}
+extern "C" int odpd_sweep_s16_supported(const odpd_model_t* m) {
+    return model_ok(m) && family_of(m) == FAM_GRU && !lane_per_unit_model(m) && gru_s16_sweep_ok(m) ? 1 : 0;
+}
+extern "C" int64_t odpd_sweep_partial_rows(const odpd_model_t* m, int B, int T, int flags) {
+    if (!model_ok(m) || B <= 0 || T <= 0 || family_of(m) != FAM_GRU || lane_per_unit_model(m)) return ODPD_EUNSUPPORTED;
+    if (flags & ODPD_SWEEP_S16) return gru_s16_sweep_ok(m) ? gru_s16_rows(m, B) : (int64_t)ODPD_EUNSUPPORTED;
+    return gru_sweep_train_ok(m, B, T) ? gru_sweep_train_rows(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+}
+extern "C" int64_t odpd_sweep_workspace_floats(const odpd_model_t* m, int B, int T, int flags) {
+    if (!model_ok(m) || B <= 0 || T <= 0) return ODPD_EINVAL;
+    if (!(flags & ODPD_SWEEP_S16)) return 0;
+    return odpd_sweep_s16_supported(m) ? gru_s16_workspace_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
+}
+extern "C" int odpd_train_epoch_sweep(void* stream, const odpd_model_t* m, int K, const odpd_sweep_run_t* runs, int loss_kind, const odpd_frames_t* fr,
+                                      int batch, int64_t first_step, double beta1, double beta2, double eps, double weight_decay, double max_norm,
+                                      int flags, void* scratch) {
+    if (!model_ok(m) || K <= 0 || !runs || !fr || !fr->x_stream || !fr->y_stream || fr->n_frames <= 0 || fr->frame_length <= 0 || fr->stride <= 0 ||
+        batch <= 0 || first_step <= 0 || !scratch)
+        return ODPD_EINVAL;
+    for (int k = 0; k < K; ++k)
+        if (!runs[k].params || !runs[k].grad || !runs[k].exp_avg || !runs[k].exp_avg_sq || !runs[k].partials || !runs[k].losses_out || !runs[k].order)
+            return ODPD_EINVAL;
+    const int T = fr->frame_length;
+    const int64_t n = fr->n_frames, n_steps = (n + batch - 1) / batch, tail = n - (n_steps - 1) * batch;
+    const bool s16 = (flags & ODPD_SWEEP_S16) != 0;
+    if (family_of(m) != FAM_GRU || lane_per_unit_model(m) || !frames_format_ok(m, fr)) return ODPD_EUNSUPPORTED;
+    if (s16) {
+        if (!gru_s16_sweep_ok(m)) return ODPD_EUNSUPPORTED;
+        for (int k = 0; k < K; ++k)
+            if (!runs[k].workspace) return ODPD_EINVAL;
+    } else if (!gru_sweep_train_ok(m, (int)(n < batch ? n : batch), T) || !gru_sweep_train_ok(m, (int)tail, T)) {
+        return ODPD_EUNSUPPORTED;
+    }
+    const int64_t P = odpd_param_count(m);
+    hipStream_t st = (hipStream_t)stream;
+    SweepRun* dev = nullptr;
+    if (int rc = upload_sweep(st, K, runs, weight_decay, scratch, &dev)) return rc;
+    // per-step, per-run step sizes lr_k / (1 - beta1^step): double arithmetic rounded once, exactly launch_clip_adamw's
+    float* ss_dev = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (((size_t)K * sizeof(SweepRun) + 255) & ~(size_t)255));
+    std::vector<float> ss((size_t)(K * n_steps));
+    for (int64_t i = 0; i < n_steps; ++i) {
+        const double bc1 = 1.0 - pow(beta1, (double)(first_step + i));
+        for (int k = 0; k < K; ++k) ss[(size_t)(i * K + k)] = (float)(runs[k].lr / bc1);
+    }
+    ODPD_CHECK_HIP(hipMemcpyAsync(ss_dev, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    for (int64_t f0 = 0, i = 0; f0 < n; f0 += batch, ++i) {
+        const int B = (int)((n - f0) < batch ? (n - f0) : batch);
+        SeqArgs a = make_args(m, B, T);
+        a.x = fr->x_stream; a.target = fr->y_stream; a.frame_stride = fr->stride; a.frames_bf16 = fr->sample_format == ODPD_SAMPLES_BF16;
+        const float inv_count = (float)(1.0 / (double)((int64_t)B * T * 2));
+        a.inv_count = inv_count; a.loss_kind = loss_kind;
+        if (s16) a.nck = num_ckpt(T);
+        if (int rc = s16 ? gru_s16_sweep_train(st, m, a, dev, K, (long long)f0) : gru_sweep_train(st, m, a, dev, K, (long long)f0)) return rc;
+        if (int rc = launch_reduce_sweep(st, dev, K, s16 ? gru_s16_rows(m, B) : gru_sweep_train_rows(m, B, T), P)) return rc;
+        if (int rc = launch_clip_adamw_sweep(st, dev, K, P, ss_dev + i * K, first_step + i, i, beta1, beta2, eps, max_norm, inv_count)) return rc;
+    }
+    return 0;
+}
+extern "C" int odpd_backbone_fwd_sweep(void* stream, const odpd_model_t* m, int K, const odpd_sweep_run_t* runs, int B, int T, const float* x,
+                                       void* scratch) {
+    if (!model_ok(m) || K <= 0 || !runs || !x || B <= 0 || T <= 0 || !scratch) return ODPD_EINVAL;
+    for (int k = 0; k < K; ++k)
+        if (!runs[k].params || !runs[k].y) return ODPD_EINVAL;
+    if (family_of(m) != FAM_GRU || lane_per_unit_model(m) || !gru_sweep_eval_ok(m, B, T)) return ODPD_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    SweepRun* dev = nullptr;
+    if (int rc = upload_sweep(st, K, runs, 0.0, scratch, &dev)) return rc;
+    SeqArgs a = make_args(m, B, T);
+    a.x = x;
+    return gru_sweep_eval(st, m, a, dev, K);
+}
+
 extern "C" int odpd_train_epoch(void* stream, const odpd_model_t* m, int loss_kind, const odpd_frames_t* fr, int batch,
                                 float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t first_step, double lr,
                                 double beta1, double beta2, double eps, double weight_decay, double max_norm,

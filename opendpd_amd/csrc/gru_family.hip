@@ -402,7 +402,7 @@ template <int NB> struct GruEvalLds {
 // CK: also writes the BPTT checkpoints (the forward of the split train path)
 // HALF (NB = 2, hidden 17..24): the second block holds its <= 8 units twice, 8-rotation dot products over it (fill_gru_tabs<.., HALF>)
 template <int NB, int FM, bool DG, bool CK, bool HALF = false>
-__global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
+__device__ __forceinline__ void gru_eval_body(const SeqArgs& a, const int bid, const int nbl) {
     static_assert(!HALF || NB == 2, "half-block layout: two-block models");
     constexpr int F = FeatDim<FM>::F, EC = kEvalChunk, HS = GruEvalLds<NB>::kHistStride;
     using T = GruTabs<NB, DG>;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
     const bool odd = role & 1;
     const float4* ftab4 = reinterpret_cast<const float4*>(ftab);
 
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    for (int b = bid; b < a.B; b += nbl) {
         float h[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) h[kb] = 0.0f;
@@ -572,6 +572,17 @@ __global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
         if (lane == 32) yg[a.T - 1] = make_float2(y0, y1);
         wave_lds_fence();
     }
+}
+template <int NB, int FM, bool DG, bool CK, bool HALF = false>
+__global__ __launch_bounds__(64) void gru_eval_kernel(SeqArgs a) {
+    gru_eval_body<NB, FM, DG, CK, HALF>(a, blockIdx.x, gridDim.x);
+}
+// the evaluation pass of K models of one shape on the same sequences (odpd_backbone_fwd_sweep): model k owns workgroups [k G, (k + 1) G)
+template <int NB, int FM, bool DG, bool HALF>
+__global__ __launch_bounds__(64) void gru_eval_sweep_kernel(SeqArgs a, const SweepRun* __restrict__ runs, int G) {
+    const SweepRun r = runs[blockIdx.x / G];
+    a.params = r.params; a.y = r.y;
+    gru_eval_body<NB, FM, DG, false, HALF>(a, blockIdx.x % G, G);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -842,8 +853,9 @@ __host__ __device__ inline int gp_buffer_floats(int T, bool pg, bool fz = false)
 // HALF (NB = 2, hidden 17..24 — the reference's default PA has 23 units): the second 16-lane block holds its <= 8 units twice (odpd_gru.h,
 // fill_gru_tabs<.., HALF>), the rotated dot products over it take 8 rotations instead of 16: 48 of the 192 DPP FMAs of a time step.  The
 // replica lanes carry unit indices >= 24 in every per-unit write-out and in the MFMA blocks' rows / columns, which hidden <= 24 masks off.
+// (the body takes its workgroup index and count as arguments: the sweep launch below runs it for K models side by side)
 template <int NB, int FM, bool DG, bool PG, bool FZ = false, bool HALF = false>
-__global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
+__device__ __forceinline__ void gru_gp_train_body(const SeqArgs& a, const int bid, const int nbl) {
     static_assert(!(PG && FZ), "the frozen variant recomputes the gates");
     static_assert(!HALF || NB == 2, "half-block layout: two-block models");
     constexpr int F = FeatDim<FM>::F, HB = 16 * NB;
@@ -964,7 +976,7 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
         if constexpr (F > 4) { const float4 fb = ftab4[2 * t + 1]; f[4] = fb.x; f[5] = fb.y; }
     };
 
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    for (int b = bid; b < a.B; b += nbl) {
         const size_t base = a.frame_idx ? (size_t)a.frame_idx[b] * a.frame_stride : (size_t)b * T;
         const bool bf = a.frame_idx != nullptr && a.frames_bf16 != 0;          // bf16 sample storage of the resident streams
         auto xg = [&](int i) { return ld_iq(a.x, base + i, bf); };
@@ -1189,11 +1201,11 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
     if constexpr (FZ) {      // the workgroup's loss row
         float lp = loss_acc;
         for (int o = 32; o > 0; o >>= 1) lp += __shfl_down(lp, o);
-        if (lane < kLossCols) a.partials[(size_t)blockIdx.x * kLossCols + lane] = lane == 0 ? lp : 0.0f;
+        if (lane < kLossCols) a.partials[(size_t)bid * kLossCols + lane] = lane == 0 ? lp : 0.0f;
         return;
     }
     // ---- the workgroup's row of partial gradients (every entry written) ----
-    float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
+    float* prow = a.partials + (size_t)bid * (L.P + kLossCols);
     float lp = loss_acc;
     for (int o = 32; o > 0; o >>= 1) lp += __shfl_down(lp, o);
 #pragma unroll
@@ -1239,6 +1251,18 @@ __global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
                 }
             }
         }
+}
+template <int NB, int FM, bool DG, bool PG, bool FZ = false, bool HALF = false>
+__global__ __launch_bounds__(64) void gru_gp_train_kernel(SeqArgs a) {
+    gru_gp_train_body<NB, FM, DG, PG, FZ, HALF>(a, blockIdx.x, gridDim.x);
+}
+// K independent runs of one model shape in lockstep (odpd_train_epoch_sweep: seeds of a sweep, bash_scripts/train_all_pa.sh:26-57): run k owns
+// workgroups [k G, (k + 1) G) and sees exactly the launch it would have had alone — its parameters, its epoch order, its partial rows
+template <int NB, int FM, bool DG, bool PG, bool HALF>
+__global__ __launch_bounds__(64) void gru_gp_train_sweep_kernel(SeqArgs a, const SweepRun* __restrict__ runs, int G, long long first) {
+    const SweepRun r = runs[blockIdx.x / G];
+    a.params = r.params; a.partials = r.partials; a.frame_idx = r.order + first;
+    gru_gp_train_body<NB, FM, DG, PG, false, HALF>(a, blockIdx.x % G, G);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1479,6 +1503,69 @@ static int launch_gp_train(hipStream_t st, const SeqArgs& a, int P) {
     if constexpr (R == 2)
         if (a.H <= 24) return pg ? launch(gru_gp_train_kernel<R, FM, DG, true, false, true>) : launch(gru_gp_train_kernel<R, FM, DG, false, false, true>);
     return pg ? launch(gru_gp_train_kernel<R, FM, DG, true>) : launch(gru_gp_train_kernel<R, FM, DG, false>);
+}
+// ---- lockstep sweeps: K runs of one model shape, each exactly the solo launch it replaces (same instantiation, same grid per run) ----
+bool gru_sweep_train_ok(const odpd_model_t* m, int B, int T) { return m->bits_w == 0 && gru_train_uses_gp(m, B, T); }
+int gru_sweep_train_rows(const odpd_model_t* m, int B, int T) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P) || !gru_sweep_train_ok(m, B, T)) return ODPD_EUNSUPPORTED;
+    return gp_grid(P, R, DG, B, T);
+}
+template <int R, int FM, bool DG>
+static int launch_gp_sweep(hipStream_t st, const SeqArgs& a, int P, const SweepRun* runs, int K, long long first) {
+    const bool pg = gp_parks_gates(P, R, DG, a.B, a.T);
+    const size_t lds = gp_lds_bytes(P, R, DG, a.T, pg);
+    const int G = gp_grid(P, R, DG, a.B, a.T);
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)G * K), dim3(64), lds, st, a, runs, G, first);
+        return (int)hipGetLastError();
+    };
+    if constexpr (R == 2)
+        if (a.H <= 24) return pg ? launch(gru_gp_train_sweep_kernel<R, FM, DG, true, true>) : launch(gru_gp_train_sweep_kernel<R, FM, DG, false, true>);
+    return pg ? launch(gru_gp_train_sweep_kernel<R, FM, DG, true, false>) : launch(gru_gp_train_sweep_kernel<R, FM, DG, false, false>);
+}
+int gru_sweep_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, const SweepRun* runs, int K, long long first) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P) || !gru_sweep_train_ok(m, a.B, a.T) || K <= 0 || !runs) return ODPD_EUNSUPPORTED;
+    if (R == 1) {
+        if (FM == FEAT_RAW2) return launch_gp_sweep<1, FEAT_RAW2, false>(st, a, P, runs, K, first);
+        if (FM == FEAT_DGRU6) return launch_gp_sweep<1, FEAT_DGRU6, true>(st, a, P, runs, K, first);
+        if (FM == FEAT_Q4) return launch_gp_sweep<1, FEAT_Q4, false>(st, a, P, runs, K, first);
+        return launch_gp_sweep<1, FEAT_A4, false>(st, a, P, runs, K, first);
+    }
+    if (FM == FEAT_RAW2) return launch_gp_sweep<2, FEAT_RAW2, false>(st, a, P, runs, K, first);
+    if (FM == FEAT_DGRU6) return launch_gp_sweep<2, FEAT_DGRU6, true>(st, a, P, runs, K, first);
+    if (FM == FEAT_Q4) return launch_gp_sweep<2, FEAT_Q4, false>(st, a, P, runs, K, first);
+    return launch_gp_sweep<2, FEAT_A4, false>(st, a, P, runs, K, first);
+}
+bool gru_sweep_eval_ok(const odpd_model_t* m, int B, int T) { return m->bits_w == 0 && gru_uses_eval_kernel(m, B, T, false); }
+template <int NB, int FM, bool DG>
+static int launch_eval_sweep(hipStream_t st, const SeqArgs& a, int P, const SweepRun* runs, int K) {
+    const size_t lds = ((size_t)pad4(P) + GruTabs<NB, DG>::kFloats + GruEvalLds<NB>::kFloats) * sizeof(float);
+    const int G = a.B;
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)G * K), dim3(64), lds, st, a, runs, G);
+        return (int)hipGetLastError();
+    };
+    if constexpr (NB == 2)
+        if (a.H <= 24) return launch(gru_eval_sweep_kernel<NB, FM, DG, true>);
+    return launch(gru_eval_sweep_kernel<NB, FM, DG, false>);
+}
+int gru_sweep_eval(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, const SweepRun* runs, int K) {
+    int FM, R, P; bool DG;
+    if (!gru_setup(m, FM, DG, R, P) || !gru_sweep_eval_ok(m, a.B, a.T) || K <= 0 || !runs) return ODPD_EUNSUPPORTED;
+    if (R == 1) {
+        if (FM == FEAT_RAW2) return launch_eval_sweep<1, FEAT_RAW2, false>(st, a, P, runs, K);
+        if (FM == FEAT_DGRU6) return launch_eval_sweep<1, FEAT_DGRU6, true>(st, a, P, runs, K);
+        if (FM == FEAT_Q4) return launch_eval_sweep<1, FEAT_Q4, false>(st, a, P, runs, K);
+        return launch_eval_sweep<1, FEAT_A4, false>(st, a, P, runs, K);
+    }
+    if (FM == FEAT_RAW2) return launch_eval_sweep<2, FEAT_RAW2, false>(st, a, P, runs, K);
+    if (FM == FEAT_DGRU6) return launch_eval_sweep<2, FEAT_DGRU6, true>(st, a, P, runs, K);
+    if (FM == FEAT_Q4) return launch_eval_sweep<2, FEAT_Q4, false>(st, a, P, runs, K);
+    return launch_eval_sweep<2, FEAT_A4, false>(st, a, P, runs, K);
 }
 // the frozen-model variant (forward + loss + dL/dx): taken while every sequence of the batch is resident at once
 static size_t gp_fz_lds_bytes(int P, int R, bool DG, int T) {

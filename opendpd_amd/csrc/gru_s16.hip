@@ -477,8 +477,9 @@ __device__ __forceinline__ void s16_write_row(float* prow, const GruLayout& L, S
 
 // NW: weight-gradient partials (train_pa / the trained model).  !NW && DX: the frozen PA of a cascade in one launch — forward,
 // loss and dL/dx (written to a.dx), one loss partial per workgroup in a.partials[blockIdx.x * kLossCols].
+// (the body takes its workgroup index and count as arguments: the sweep launch below runs it for K models side by side)
 template <int FM, bool DG, int OCC, bool PACK, bool NW = true, bool DX = false>
-__global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs a) {
+__device__ __forceinline__ void gru16_train_body(const SeqArgs& a, const int bid, const int nbl) {
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
     constexpr int kGroups = DX ? kS16GroupsDx : kS16Groups;
     constexpr int kWave = (DX ? 3 : 2) * 2 * 16 * kChunkPad + (NW ? kS16Tiles * kTileFloats : 0);
@@ -505,8 +506,8 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
     S16Grad<DG> G;
     G.zero();
     float loss_acc = 0.0f;
-    const int nwaves = gridDim.x * nwb;
-    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+    const int nwaves = nbl * nwb;
+    for (int grp = bid * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
         const bool valid = b0 + n < a.B;
         float4* ck = reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * 64 + lane;
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
             float v = 0.0f;
             if (threadIdx.x == 0)
                 for (int wv = 0; wv < nwb; ++wv) v += smem[wv];
-            a.partials[(size_t)blockIdx.x * kLossCols + threadIdx.x] = v;
+            a.partials[(size_t)bid * kLossCols + threadIdx.x] = v;
         }
         return;
     }
@@ -612,12 +613,24 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs 
     __syncthreads();
     s16_write_row<FM, DG, s16_packgrad(PACK, NW)>(smem + wave * P4, L, G, n, q, loss_acc);
     __syncthreads();
-    float* prow = a.partials + (size_t)blockIdx.x * P4;
+    float* prow = a.partials + (size_t)bid * P4;
     for (int i = threadIdx.x; i < P4; i += blockDim.x) {
         float v = smem[i];
         for (int wv = 1; wv < nwb; ++wv) v += smem[wv * P4 + i];
         prow[i] = v;
     }
+}
+template <int FM, bool DG, int OCC, bool PACK, bool NW = true, bool DX = false>
+__global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_kernel(SeqArgs a) {
+    gru16_train_body<FM, DG, OCC, PACK, NW, DX>(a, blockIdx.x, gridDim.x);
+}
+// K independent runs of one model shape in lockstep on the 16-sequences-per-wave kernel (odpd_train_epoch_sweep, ODPD_SWEEP_S16): run k owns
+// workgroups [k G, (k + 1) G) and sees the launch it would have alone with this kernel forced (odpd_set_tuning("s16_min_batch", 0))
+template <int FM, bool DG, int OCC, bool PACK>
+__global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_sweep_kernel(SeqArgs a, const SweepRun* __restrict__ runs, int G, long long first) {
+    const SweepRun r = runs[blockIdx.x / G];
+    a.params = r.params; a.partials = r.partials; a.frame_idx = r.order + first; a.ckpt = r.workspace;
+    gru16_train_body<FM, DG, OCC, PACK>(a, blockIdx.x % G, G);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -955,6 +968,39 @@ int gru_s16_lossdx(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
     a.ngroups = gru_s16_groups(a.B);
     const int P = s16_param_count(m->hidden, FM, DG);
     ODPD_S16_DISPATCH(launch_s16_lossdx_occ, st, a, P)
+}
+
+template <int FM, bool DG, int OCC, bool PACK>
+static int launch_s16_sweep(hipStream_t st, const SeqArgs& a, int P, const SweepRun* runs, int K, long long first) {
+    const LaunchShape ls = s16_shape(a.ngroups);
+    const size_t lds = s16_lds_bytes(P, ls.waves);
+    auto k = gru16_train_sweep_kernel<FM, DG, OCC, PACK>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)ls.grid * K), dim3(64 * ls.waves), lds, st, a, runs, ls.grid, first);
+    return (int)hipGetLastError();
+}
+template <int FM, bool DG>
+static int launch_s16_sweep_occ(hipStream_t st, const SeqArgs& a, int P, const SweepRun* runs, int K, long long first) {
+    constexpr bool kCanPack = S16Cfg<FM>::NCH == 2;
+    const bool pack = kCanPack && a.H <= 13;
+    if (s16_occupancy(a.ngroups) == 1) return launch_s16_sweep<FM, DG, 1, false>(st, a, P, runs, K, first);      // (as launch_s16_occ chooses for this batch)
+    if constexpr (kCanPack) { if (pack) return launch_s16_sweep<FM, DG, 2, true>(st, a, P, runs, K, first); }
+    return launch_s16_sweep<FM, DG, 2, false>(st, a, P, runs, K, first);
+}
+bool gru_s16_sweep_ok(const odpd_model_t* m) {
+    int FM; bool DG;
+    return s16_cfg(m, FM, DG) && m->hidden <= 16 && m->bits_w == 0 && !(m->flags & ODPD_FLAG_TWO_LAYERS);
+}
+int gru_s16_sweep_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, const SweepRun* runs, int K, long long first) {
+    int FM; bool DG;
+    if (!s16_cfg(m, FM, DG) || !gru_s16_sweep_ok(m) || K <= 0 || !runs) return ODPD_EUNSUPPORTED;
+    SeqArgs a = a0;
+    a.ngroups = gru_s16_groups(a.B);
+    const int P = s16_param_count(m->hidden, FM, DG);
+    if (FM == FEAT_RAW2) return launch_s16_sweep_occ<FEAT_RAW2, false>(st, a, P, runs, K, first);
+    if (FM == FEAT_DGRU6) return launch_s16_sweep_occ<FEAT_DGRU6, true>(st, a, P, runs, K, first);
+    if (FM == FEAT_Q4) return launch_s16_sweep_occ<FEAT_Q4, false>(st, a, P, runs, K, first);
+    return launch_s16_sweep_occ<FEAT_A4, false>(st, a, P, runs, K, first);
 }
 
 int gru_s16_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {

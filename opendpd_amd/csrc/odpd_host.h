@@ -146,6 +146,22 @@ struct SeqArgs {
     int bits_w, bits_a, eval_out;      // quantised heads (lstm): grid widths; eval_out: ODPD_FLAG_EVAL (fc_out's 16-bit output quantiser)
 };
 
+// one run of a lockstep sweep (K independent runs of one model shape advancing together: odpd_train_epoch_sweep, odpd_backbone_fwd_sweep);
+// the table lives in device memory, a sweep kernel's workgroup picks its entry by blockIdx.x / G
+struct SweepRun {
+    float* params;              // flat parameters of the run
+    float* grad;                // P + kLossCols
+    float* state1;              // AdamW exp_avg
+    float* state2;              // AdamW exp_avg_sq
+    float* partials;            // (rows, P + kLossCols)
+    float* losses;              // per-step mean losses of the epoch
+    float* y;                   // forward output of the evaluation sweep
+    float* workspace;           // BPTT checkpoint workspace of the run (16-sequences-per-wave sweeps)
+    const long long* order;     // the run's epoch order (frame indices)
+    float decay;                // AdamW: 1 - lr * weight_decay at the run's current learning rate
+    float pad;
+};
+
 // comm.hip: communicator of the data-parallel step (one-shot exchange over peer-mapped slots, or RCCL)
 struct XchgDev;                                                          // odpd_xchg.h
 int comm_allreduce(hipStream_t st, void* comm, float* buf, int64_t n);     // in-place sum of n floats over the ranks, on the stream
@@ -163,6 +179,19 @@ int gru_family_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
 int gru_family_lossdx(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);        // frozen PA: forward + loss + dL/dx in one launch
 int gru_family_lossdx_rows(const odpd_model_t* m, int B, int T);
 int gru_family_rows(const odpd_model_t* m, int B, int which /*0 bwd, 1 fused*/, int T);
+// lockstep sweeps on the one-sequence-per-wave kernels (gru_family.hip): a.params / partials / frame_idx / y come from the table
+bool gru_sweep_train_ok(const odpd_model_t* m, int B, int T);
+int gru_sweep_train_rows(const odpd_model_t* m, int B, int T);
+int gru_sweep_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, const SweepRun* runs, int K, long long first);
+bool gru_sweep_eval_ok(const odpd_model_t* m, int B, int T);
+int gru_sweep_eval(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, const SweepRun* runs, int K);
+// ... on the 16-sequences-per-wave train kernel whatever the batch size (gru_s16.hip, hidden <= 16): the throughput mode of a sweep
+bool gru_s16_sweep_ok(const odpd_model_t* m);
+int gru_s16_sweep_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, const SweepRun* runs, int K, long long first);
+// optim.hip: row reduction and clip + AdamW of K runs in one launch each (step_sizes: device, one per run: lr_k / (1 - beta1^step))
+int launch_reduce_sweep(hipStream_t st, const SweepRun* runs, int K, int64_t rows, int64_t P);
+int launch_clip_adamw_sweep(hipStream_t st, const SweepRun* runs, int K, int64_t P, const float* step_sizes, int64_t step, int64_t loss_index, double beta1,
+                            double beta2, double eps, double max_norm, float inv_count);
 // gru_wide.hip: float gru / dgru / qgru / qgru_amp1 of 33 .. 64 hidden units (one sequence per wave, lane = unit; per-step records in `ckpt`)
 bool gru_wide_ok(const odpd_model_t* m);
 int64_t gru_wide_ckpt_floats(const odpd_model_t* m, int B, int T);

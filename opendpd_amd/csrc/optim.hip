@@ -132,18 +132,14 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(int64_t rows, int
 // step, then buf = momentum buf + g, p -= lr buf (torch/optim/sgd.py, dampening 0);  RMSprop: sq = alpha sq + (1 - alpha) g^2,
 // p -= lr g / (sqrt(sq) + eps) (torch/optim/rmsprop.py, no momentum, not centered).  Multiplies and adds are kept apart where torch
 // issues them as separate ATen ops.
-__global__ __launch_bounds__(1024) void clip_optim_kernel(int kind, int64_t P, float* __restrict__ p, float* __restrict__ g,
-                                                          float* __restrict__ m, float* __restrict__ v, float step_size,
-                                                          float bc2_sqrt, float decay, float w1, float b2, float w2,
-                                                          float eps, float max_norm, float* __restrict__ norm_out,
-                                                          float* __restrict__ loss_out, float inv_count,
-                                                          const unsigned char* __restrict__ skip, int first_step, int n_xchg,
-                                                          XchgDev xd) {
+__device__ __forceinline__ void clip_optim_block(int kind, int64_t P, float* __restrict__ p, float* __restrict__ g,
+                                                 float* __restrict__ m, float* __restrict__ v, float step_size,
+                                                 float bc2_sqrt, float decay, float w1, float b2, float w2,
+                                                 float eps, float max_norm, float* __restrict__ norm_out,
+                                                 float* __restrict__ loss_out, float inv_count,
+                                                 const unsigned char* __restrict__ skip, int first_step) {
     __shared__ float sh[16];
     __shared__ float coef_s;
-    // data parallel over a one-shot communicator: the step's collective is this kernel's prologue — g[0 .. P+4) becomes the sum over
-    // the ranks (gradient + loss partial sum), identical bits on every rank
-    if (n_xchg > 0) xchg_allreduce_block(xd, g, n_xchg);
     if (loss_out && threadIdx.x == 0) loss_out[0] = g[P] * inv_count;   // column P of the reduced row = loss partial sum
     float acc = 0.f;
     // skip[i] != 0: a parameter whose .grad is None in the reference — outside the norm, untouched by the update
@@ -179,6 +175,53 @@ __global__ __launch_bounds__(1024) void clip_optim_kernel(int kind, int64_t P, f
             p[i] = pi; m[i] = mi; v[i] = vi;
         }
     }
+}
+__global__ __launch_bounds__(1024) void clip_optim_kernel(int kind, int64_t P, float* __restrict__ p, float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, float step_size,
+                                                          float bc2_sqrt, float decay, float w1, float b2, float w2,
+                                                          float eps, float max_norm, float* __restrict__ norm_out,
+                                                          float* __restrict__ loss_out, float inv_count,
+                                                          const unsigned char* __restrict__ skip, int first_step, int n_xchg,
+                                                          XchgDev xd) {
+    // data parallel over a one-shot communicator: the step's collective is this kernel's prologue — g[0 .. P+4) becomes the sum over
+    // the ranks (gradient + loss partial sum), identical bits on every rank
+    if (n_xchg > 0) xchg_allreduce_block(xd, g, n_xchg);
+    clip_optim_block(kind, P, p, g, m, v, step_size, bc2_sqrt, decay, w1, b2, w2, eps, max_norm, norm_out, loss_out, inv_count, skip, first_step);
+}
+// ---- lockstep sweeps (odpd_train_epoch_sweep): the same two kernels for K runs at once, run k = the workgroup(s) blockIdx.x / per-run count ----
+__global__ __launch_bounds__(1024) void reduce_partials_sweep_kernel(const SweepRun* __restrict__ runs, int cb, int64_t rows, int64_t cols) {
+    __shared__ float sh[16][64];
+    const SweepRun r = runs[blockIdx.x / cb];
+    const float* __restrict__ part = r.partials;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = (int64_t)(blockIdx.x % cb) * 64 + lane;
+    float acc = 0.f;
+    if (c < cols) {      // (the loop of reduce_partials_kernel, instruction for instruction: the sums must not differ by a bit)
+        int64_t rr = wave;
+        for (; rr + 7 * 16 < rows; rr += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(rr + u * 16) * cols + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; rr < rows; rr += 16) acc += part[rr * cols + c];
+    }
+    sh[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        float v = sh[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) v += sh[w][lane];
+        r.grad[c] = v;
+    }
+}
+__global__ __launch_bounds__(1024) void clip_adamw_sweep_kernel(const SweepRun* __restrict__ runs, int64_t P, const float* __restrict__ step_sizes,
+                                                                float bc2_sqrt, float w1, float b2, float w2, float eps, float max_norm,
+                                                                int64_t loss_index, float inv_count) {
+    const SweepRun r = runs[blockIdx.x];
+    clip_optim_block((int)ODPD_OPT_ADAMW, P, r.params, r.grad, r.state1, r.state2, step_sizes[blockIdx.x], bc2_sqrt, r.decay, w1, b2, w2, eps, max_norm,
+                     nullptr, r.losses + loss_index, inv_count, nullptr, 0);
 }
 
 }  // namespace odpd
@@ -224,6 +267,21 @@ int odpd::launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* gra
     hipLaunchKernelGGL(clip_optim_kernel, dim3(1), dim3(1024), 0, st, (int)ODPD_OPT_ADAMW, P, params, grad, exp_avg, exp_avg_sq, step_size,
                        bc2s, decay, w1, (float)beta2, w2, (float)eps, (float)max_norm, norm_out, loss_out, inv_count, skip, 0,
                        xchg ? (int)(P + kLossCols) : 0, xchg ? *xchg : XchgDev{});
+    return (int)hipGetLastError();
+}
+
+int odpd::launch_reduce_sweep(hipStream_t st, const SweepRun* runs, int K, int64_t rows, int64_t P) {
+    const int64_t cols = P + kLossCols;
+    const int cb = (int)((cols + 63) / 64);
+    hipLaunchKernelGGL(reduce_partials_sweep_kernel, dim3((unsigned)(cb * K)), dim3(1024), 0, st, runs, cb, rows, cols);
+    return (int)hipGetLastError();
+}
+// (the per-run step size lr_k / (1 - beta1^step) comes precomputed — in double, rounded once, as launch_clip_adamw forms it)
+int odpd::launch_clip_adamw_sweep(hipStream_t st, const SweepRun* runs, int K, int64_t P, const float* step_sizes, int64_t step, int64_t loss_index,
+                                  double beta1, double beta2, double eps, double max_norm, float inv_count) {
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(clip_adamw_sweep_kernel, dim3((unsigned)K), dim3(1024), 0, st, runs, P, step_sizes, (float)sqrt(bc2), (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), (float)eps, (float)max_norm, loss_index, inv_count);
     return (int)hipGetLastError();
 }
 

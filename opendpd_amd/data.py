@@ -59,9 +59,21 @@ def load_spec(dataset_name=None, dataset_path=None):
     return json.load(open(sp))
 
 
+_share = None      # sweeps (opendpd_amd/sweep.py): {resolved path: arrays} while K runs of one dataset are set up — one parse of the CSVs, not K
+
+
 def load_dataset(dataset_name=None, dataset_path=None):
     """-> (X_train, y_train, X_val, y_val, X_test, y_test), float64 (N,2) arrays."""
     p = resolve_dataset(dataset_name, dataset_path)
+    if _share is not None:
+        key = str(p)
+        if key not in _share:
+            _share[key] = _load_dataset(p)
+        return tuple(a.copy() for a in _share[key])
+    return _load_dataset(p)
+
+
+def _load_dataset(p):
     if p.is_file() and p.suffix.lower() == ".csv":
         return _split_frame(pd.read_csv(p), 0.6, 0.2)
     spec = json.load(open(p / "spec.json")) if (p / "spec.json").exists() else {}

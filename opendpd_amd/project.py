@@ -277,12 +277,16 @@ class Project:
             elif self.eval_test:
                 _, pred, truth = net_eval(self.log_test, net, test_loader, criterion, self.device)
                 self.log_test = calculate_metrics(self.args, self.log_test, pred, truth)
-            self.log_all = self.gen_log_stat((time.time() - start) / 60.0, net, optimizer, epoch)
-            self.logger.write_log(self.log_all)
-            best_net = net.dpd_model if self.step == "train_dpd" else net
-            self.logger.save_best_model(best_net, epoch, self.log_val, best_model_metric)
-            if self.lr_schedule:
-                lr_scheduler.step(self.log_val[best_model_metric])
+            self.finish_epoch(net, optimizer, lr_scheduler, epoch, start, best_model_metric)
+
+    def finish_epoch(self, net, optimizer, lr_scheduler, epoch, start, best_model_metric):
+        """the tail of one epoch of project.py's train loop: log row, best-model checkpoint, plateau scheduler (also opendpd_amd/sweep.py)"""
+        self.log_all = self.gen_log_stat((time.time() - start) / 60.0, net, optimizer, epoch)
+        self.logger.write_log(self.log_all)
+        best_net = net.dpd_model if self.step == "train_dpd" else net
+        self.logger.save_best_model(best_net, epoch, self.log_val, best_model_metric)
+        if self.lr_schedule:
+            lr_scheduler.step(self.log_val[best_model_metric])
 
 
 def run_train_pa(proj):

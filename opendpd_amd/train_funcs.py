@@ -299,8 +299,10 @@ class FusedAdamW:
             return False
         if self.world_size() > 1 or self.native_comm() is not None:
             # sharded epoch from C++ (odpd_train_epoch_dp): needs the library-owned RCCL communicator and fused kernels for this rank's shards
+            if self.native_comm() is None:
+                return False
             sizes = self._shard_sizes(loader)
-            return self.native_comm() is not None and self._one_workspace_meaning(sizes, loader.frame_length) and all(
+            return self._one_workspace_meaning(sizes, loader.frame_length) and all(
                 self.has_fused(b, loader.frame_length) and self.reads_frames(b, loader.frame_length) for b in sizes)
         sizes = self._epoch_batches(loader)
         return self._one_workspace_meaning(sizes, loader.frame_length) and all(
