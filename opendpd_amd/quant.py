@@ -31,6 +31,19 @@ class _QScale(nn.Module):
         self.register_buffer("integer_num", torch.Tensor([bits - 1 - 1.0]))
         self.exercised = False          # has a forward gone through this quantiser (see QuantQGRU.sync_mode)
 
+    def quantise(self, x):
+        """INT_Quantizer.forward through ATen (quantizers.py:73-92; all_positive=False, as recur_rpls_layers builds every layer
+        quantiser, quant_envs.py:57-58): power-of-two scale, clamp, straight-through round.  Used by the backbones whose quantised form has no HIP
+        kernels (the announced ATen route of get_quant_model); the kernel-backed models carry the same arithmetic in csrc/odpd_qat.h."""
+        s = self.scale.abs()
+        l = s.log2().round()
+        pow2 = 2 ** l
+        dec = l.abs().int()
+        if dec != self.decimal_num:
+            self.pow2_scale.copy_(pow2.detach()); self.decimal_num.copy_(dec); self.integer_num.copy_(self.bits - 1 - dec)
+        x = (x / pow2).clamp(-2 ** (self.bits - 1), 2 ** (self.bits - 1) - 1)
+        return ((x.round() - x).detach() + x) * pow2
+
     def refresh(self):
         """What INT_Quantizer.forward does to its buffers when the rounded exponent changes (quantizers.py:67-71)."""
         with torch.no_grad():
@@ -58,6 +71,11 @@ class _QLinear(nn.Module):
         self.out_quantizer = _QScale(16, 2.0 ** (2 - 16))
         self.out_quant = False
 
+    def forward(self, x):
+        """INT_Linear.forward (quant_layers.py:68-80) through ATen"""
+        out = nn.functional.linear(self.act_quantizer.quantise(x), self.weight_quantizer.quantise(self.weight), getattr(self, "bias", None))
+        return self.out_quantizer.quantise(out) if (self.out_quant and not self.training) else out
+
 
 class _QConv2d(nn.Module):
     """INT_Conv2D state (quant_layers.py:10-45): the float layer's weight, a freshly drawn default-init bias (the constructor builds a new
@@ -76,6 +94,13 @@ class _QConv2d(nn.Module):
         self.weight_quantizer = _QScale(bits_w, 1.0)
         self.weight_quantizer.scale = nn.Parameter(conv.weight.detach().abs().mean() * 2 / (2 ** (bits_w - 1) - 1) ** 0.5)
         self.act_quantizer = _QScale(bits_a, 2.0 ** (2 - bits_a))
+        self.geometry = (conv.stride, conv.padding, conv.dilation, conv.groups)
+
+    def forward(self, x):
+        """INT_Conv2D.forward (quant_layers.py:36-45) through ATen"""
+        stride, padding, dilation, groups = self.geometry
+        return nn.functional.conv2d(self.act_quantizer.quantise(x), self.weight_quantizer.quantise(self.weight), getattr(self, "bias", None),
+                                    stride, padding, dilation, groups)
 
 
 class _QOp(nn.Module):
@@ -413,6 +438,58 @@ def _quantise_heads(model, bits_w, bits_a, pre, dev):
     return _wrap(model, bb, dev)
 
 
+def _aten_swap(mod, layer_type, bits_w, bits_a):
+    """recur_rpls_layers (quant_envs.py:40-60) for one layer type: named_children order, depth first; a replaced layer draws its fresh default
+    initialisation exactly where INT_Linear / INT_Conv2D's constructors draw theirs and keeps the float layer's weight"""
+    for name, child in list(mod.named_children()):
+        if type(child) is layer_type:
+            if layer_type is nn.Linear:
+                q = _QLinear(child.in_features, child.out_features, bits_w, bits_a, bias=child.bias is not None)
+                with torch.no_grad():
+                    q.weight.copy_(child.weight)
+            else:
+                q = _QConv2d(child, bits_w, bits_a)
+            setattr(mod, name, q)
+        else:
+            _aten_swap(child, layer_type, bits_w, bits_a)
+
+
+def _quantise_aten(model, bits_w, bits_a, pre, dev):
+    """apnrru / bojanet / dvrjanet / mcldnn (quant_envs.py:285-306 runs on them like on every registry model): their gates, FIR banks and
+    read-outs are nn.Linear (mcldnn: two nn.Conv2d and two nn.Linear next to a float Conv1d and nn.LSTM) — all of them become INT_Linear /
+    INT_Conv2D, the functional sigmoid / tanh calls stay float.  There are no HIP kernels for a quantised mat-vec INSIDE these cells: the
+    quantised model is the ATen restatement of the backbone (backbones/extras.py) with the surgery applied to it — `native` False, said
+    aloud once per configuration, torch optimiser — pinned to fixtures produced by the reference (tests/test_quant_partial_cpu.py)."""
+    import warnings
+    from .backbones import extras as X
+    bt, H = model.backbone_type, model.hidden_size
+    fb = model.backbone
+    sd = {k: v.detach().cpu() for k, v in fb.state_dict().items()}
+    if pre:
+        try:      # load_model strict-loads the float checkpoint before the layers are swapped (quant_envs.py:173-182)
+            pre_sd = torch.load(pre, map_location="cpu")
+            want = {"backbone." + k: tuple(v.shape) for k, v in sd.items()}
+            if not isinstance(pre_sd, dict) or set(pre_sd) != set(want) or any(tuple(pre_sd[k].shape) != s_ for k, s_ in want.items()):
+                raise RuntimeError("Error(s) in loading state_dict for CoreModel")
+            sd = {k: pre_sd["backbone." + k] for k in sd}
+        except Exception as exc:
+            return _warn_float(exc, model)
+    rng = torch.get_rng_state()      # building the holder draws initialisations the reference (a deepcopy) does not: keep the stream where it was
+    ext = {"apnrru": lambda: X.APNRRU(hidden_size=H, bias=True), "bojanet": lambda: X.BOJANET(hidden_size=H, output_size=2, bias=True),
+           "dvrjanet": lambda: X.DVRJANET(hidden_size=H, output_size=2, num_dvr_units=model.num_dvr_units, bias=True),
+           "mcldnn": lambda: X.MCLDNN(hidden_size=H)}[bt]()
+    torch.set_rng_state(rng)
+    ext.load_state_dict(sd)
+    for layer_type in (nn.Conv2d, nn.Linear):       # the order of fq_layers_hash (quant_envs.py:145-148)
+        _aten_swap(ext, layer_type, bits_w, bits_a)
+    for name, mod in ext.named_modules():            # set_last_layer_quant: every module NAMED fc_out (quant_envs.py:276-284)
+        if name.split(".")[-1] == "fc_out" and isinstance(mod, _QLinear):
+            mod.out_quant = True
+    warnings.warn(f"opendpd_amd: --quant on '{bt}' runs the ATen restatement of the quantised model (backbones/extras.py + INT_Linear / INT_Conv2D "
+                  "through torch ops): there are no HIP kernels for quantised mat-vecs inside this cell", stacklevel=3)
+    return _wrap(model, ext, dev)
+
+
 def get_quant_model(proj, model):
     """Reference semantics (quant/__init__.py:20-37): identity unless `proj.quant`; otherwise the quantised model.
     `proj` needs n_bits_w, n_bits_a and optionally pretrained_model.
@@ -422,8 +499,9 @@ def get_quant_model(proj, model):
     swaps (the reference hands back an identical copy: the model itself is returned).  deltagru's layer IS an nn.GRU subclass, the
     reference swaps it for a plain GRU and then fails in forward (TypeError, deltagru.py:74-77): refused here at construction.  In lstm,
     vdlstm, deltajanet and neuraltx the surgery finds only nn.Linear HEADS (float core, INT_Linear heads: `_quantise_heads`; deltajanet
-    and neuraltx up to 64 units / channels); the backbones whose gates or convolutions are themselves nn.Linear / nn.Conv2d modules (`_PARTIAL`) have no
-    quantised kernels yet.
+    and neuraltx up to 64 units / channels); the backbones whose gates or convolutions are themselves nn.Linear / nn.Conv2d modules INSIDE a recurrent
+    cell (`_PARTIAL`: apnrru, bojanet, dvrjanet, mcldnn) have no quantised kernels: their quantised model is the ATen restatement of the backbone
+    with the surgery applied (`_quantise_aten`: `native` False, announced by a warning) — it trains, as it does in the reference.
 
     `pretrained_model` follows Base_GRUQuantEnv.load_model (quant_envs.py:173-182): the checkpoint is strict-loaded into the FLOAT
     holder before quantisation — for the GRU-cell models its keys are `backbone.rnn.rnn_cell_list.0.{x2h,h2h}.{weight,bias}`,
@@ -442,9 +520,9 @@ def get_quant_model(proj, model):
     if bt == "deltagru":
         raise RuntimeError("--quant on 'deltagru': its layer subclasses nn.GRU, the reference's surgery replaces it by a plain GRU and the "
                            "model then fails in forward (TypeError); use 'deltagru_tcnskip'")
-    if bt in _PARTIAL:
-        raise NotImplementedError(f"--quant on '{bt}' (only its nn.Linear layers become INT_Linear in the reference) has no HIP kernels yet")
     bits_w, bits_a = int(getattr(proj, "n_bits_w", 8)), int(getattr(proj, "n_bits_a", 8))
+    if bt in _PARTIAL:
+        return _quantise_aten(model, bits_w, bits_a, getattr(proj, "pretrained_model", ""), next(model.parameters()).device)
     H = model.hidden_size
     max_h = _HEAD_MAX_HIDDEN.get(bt, MAX_HIDDEN)
     # pgjanet, rvtdcnn and neuraltx ignore num_layers (models.py:26-141 never hands it to them; wide.outside_envelope treats them the same way):

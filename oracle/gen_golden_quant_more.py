@@ -63,6 +63,16 @@ CASES = [
     ("quant_pgjanet_h11_w8a8", "pgjanet", 11, 8, 0, 0, False),
     ("quant_pgjanet_h9_w16a16", "pgjanet", 9, 16, 0, 0, False),
     ("quant_pgjanet_h24_w8a8", "pgjanet", 24, 8, 0, 0, False),
+    # the four backbones whose gates / FIR banks / read-outs are nn.Linear (mcldnn: + two nn.Conv2d) INSIDE a recurrent cell: every one of them is
+    # swapped (r05: served by the ATen restatement of the quantised model, opendpd_amd/quant.py::_quantise_aten)
+    ("quant_bojanet_h12_w8a8", "bojanet", 12, 8, 0, 0, False),
+    ("quant_bojanet_h16_w16a16", "bojanet", 16, 16, 0, 0, False),
+    ("quant_apnrru_h8_w8a8", "apnrru", 8, 8, 0, 0, False),
+    ("quant_apnrru_h12_w16a16", "apnrru", 12, 16, 0, 0, False),
+    ("quant_dvrjanet_h12_w8a8", "dvrjanet", 12, 8, 0, 0, False),
+    ("quant_dvrjanet_h10_w16a16", "dvrjanet", 10, 16, 0, 0, False),
+    ("quant_mcldnn_h8_w8a8", "mcldnn", 8, 8, 0, 0, False),
+    ("quant_mcldnn_h6_w16a16", "mcldnn", 6, 16, 0, 0, False),
 ]
 
 
@@ -78,13 +88,13 @@ def main(only):
     for name, bb, H, bits, thx, thh, pre in CASES:
         if only and name not in only:
             continue
-        fnet = gg.build(bb, H, seed=0, thx=thx, thh=thh)
+        fnet = gg.build(bb, H, seed=0, thx=thx, thh=thh, num_dvr_units=3 if bb == "dvrjanet" else None)
         P.n_bits_w = P.n_bits_a = bits
         P.pretrained_model = ""
         extra = {}
         if pre:
             # a float model "trained" elsewhere: another seed's initial weights moved by a few optimiser steps
-            src = gg.build(bb, H, seed=11, thx=thx, thh=thh)
+            src = gg.build(bb, H, seed=11, thx=thx, thh=thh, num_dvr_units=3 if bb == "dvrjanet" else None)
             gg.step_case(src, x, tgt, n_steps=3)
             tmp = tempfile.NamedTemporaryFile(suffix=".pt", delete=False)
             torch.save(src.state_dict(), tmp.name)
@@ -98,7 +108,7 @@ def main(only):
             os.unlink(P.pretrained_model)
         d = {"x": x, "tgt": tgt, "meta": np.array(json.dumps(
             {"backbone": bb, "hidden": H, "bits": bits, "thx": thx, "thh": thh, "lr": gg.LR, "clip": gg.CLIP, "pretrained": pre,
-             "n_param": int(sum(p.numel() for p in qnet.parameters()))}))}
+             "n_param": int(sum(p.numel() for p in qnet.parameters())), "num_dvr_units": 3 if bb == "dvrjanet" else None}))}
         d.update(extra)
         d.update(gg.sd_np(fnet, "fsd"))                      # the float model the surgery started from
         d.update(gg.sd_np(qnet, "sd"))

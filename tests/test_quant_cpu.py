@@ -60,6 +60,22 @@ def test_general_surgery_state_dicts_and_rng_match_the_reference(tmp_path):
             assert np.array_equal(sd["backbone.rnn.x2h.weight"].numpy(), fx["pre/backbone.rnn.x2h.weight"])
 
 
+def warnings_ctx():
+    import warnings
+    ctx = warnings.catch_warnings()
+    ctx.__enter__()
+    warnings.simplefilter("ignore")
+
+    class _C:
+        def __enter__(self_):
+            return self_
+
+        def __exit__(self_, *a):
+            ctx.__exit__(*a)
+            return False
+    return _C()
+
+
 def test_surgery_on_the_other_backbones():
     """gmp / tcnn hold nothing the surgery swaps (the reference returns an identical copy); deltagru's quantised model cannot run in
     the reference either; the partially swapped backbones and configurations beyond the kernels say so."""
@@ -72,8 +88,10 @@ def test_surgery_on_the_other_backbones():
         assert get_quant_model(_Proj, net) is net
     with pytest.raises(RuntimeError):
         get_quant_model(_Proj, CoreModel(2, 8, 1, "deltagru"))
-    with pytest.raises(NotImplementedError):
-        get_quant_model(_Proj, CoreModel(2, 8, 1, "apnrru"))
+    # apnrru / bojanet / dvrjanet / mcldnn: quantised through the announced ATen route since r05 (tests/test_quant_partial_cpu.py)
+    with warnings_ctx():
+        q = get_quant_model(_Proj, CoreModel(2, 8, 1, "apnrru"))
+    assert not q.backbone.native and any("weight_quantizer" in k for k in q.state_dict())
     # num_layers means nothing to pgjanet / rvtdcnn / neuraltx (models.py never hands it to them): `--quant --DPD_num_layers 2` runs in the
     # reference and here; for a recurrent core it is outside the kernels
     import warnings
