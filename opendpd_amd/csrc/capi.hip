@@ -170,7 +170,10 @@ extern "C" int64_t odpd_ckpt_floats(const odpd_model_t* m, int B, int T) {
     if (!R) return ODPD_EUNSUPPORTED;
     switch (family_of(m)) {
     case FAM_GRU:   // [4-sequence group][ckpt][64 lanes], or [16-sequence task][ckpt][64 lanes][4] for the S16 kernels
-        if (gru_uses_s16n(m, B)) return gru_s16n_ckpt_floats(m, B, T);
+        if (gru_uses_s16n(m, B)) {      // (this buffer is also the workspace of odpd_frozen_loss_dx: gru_s16x.hip checkpoints every two steps)
+            const int64_t own = gru_s16n_ckpt_floats(m, B, T), x = gru_s16x_ok(m) ? gru_s16x_ckpt_floats(m, B, T) : 0;
+            return own > x ? own : x;
+        }
         return gru_split_uses_s16(m, B) ? (int64_t)((B + 15) / 16) * num_ckpt(T) * 256 : (int64_t)num_groups(B, R) * num_ckpt(T) * 64;
     case FAM_LSTM: return (int64_t)num_groups(B, R) * num_ckpt(T) * 128;   // h and c
     case FAM_DELTA:

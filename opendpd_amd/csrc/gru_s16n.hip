@@ -595,9 +595,7 @@ int gru_s16n_rows(const odpd_model_t* m, int B) {
     return s16n_shape((B + 15) / 16).grid;
 }
 int64_t gru_s16n_ckpt_floats(const odpd_model_t* m, int B, int T) {
-    const int64_t own = (int64_t)((B + 15) / 16) * num_ckpt(T) * s16n_tiles(m->hidden) * 256;
-    const int64_t x = gru_s16x_ok(m) ? gru_s16x_ckpt_floats(m, B, T) : 0;      // the frozen-PA step of gru_s16x.hip checkpoints more densely
-    return own > x ? own : x;
+    return (int64_t)((B + 15) / 16) * num_ckpt(T) * s16n_tiles(m->hidden) * 256;
 }
 
 template <int FM, bool DG, int NT, int MODE, bool NW, bool DX, int NCK>
