@@ -387,13 +387,26 @@ def test_deltajanet_quantised_train_steps_follow_the_oracle():
             assert rel_err(got, p) < 2e-4, (H, s, names)
 
 
-def test_backbones_without_quantised_head_kernels_are_refused():
-    from opendpd_amd import CoreModel
+def test_backbones_without_quantised_cell_kernels_take_the_announced_aten_route():
+    """apnrru / bojanet / dvrjanet / mcldnn: refused until r04, since r05 the reference's surgery on the ATen restatement — said aloud, `native` False
+    (tests/test_quant_partial_cpu.py pins it to the reference's fixtures); on the GPU the model runs and its descriptor-based entry points still
+    refuse `bits_w > 0` for these backbones (no kernel may answer a quantised descriptor with float arithmetic)"""
+    import ctypes as C
+    import warnings
+    from opendpd_amd import CoreModel, _lib
     from opendpd_amd.quant import get_quant_model
 
     class P:
         quant = True
         n_bits_w = n_bits_a = 8
         pretrained_model = ""
-    with pytest.raises(NotImplementedError):
-        get_quant_model(P, CoreModel(2, 11, 1, "apnrru"))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        q = get_quant_model(P, CoreModel(2, 11, 1, "apnrru").cuda())
+    assert any("ATen restatement of the quantised model" in str(x.message) for x in w) and not q.backbone.native
+    x = (0.3 * torch.randn(3, 24, 2) + 0.1).cuda()
+    y = q(x)
+    y.square().mean().backward()
+    assert y.shape == (3, 24, 2) and bool(torch.isfinite(y).all()) and all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in q.parameters())
+    d = _lib.ModelDesc(_lib.BACKBONE_IDS["apnrru"], 11, 0.0, 0.0, 8, 8, 0)
+    assert int(_lib.load().odpd_param_count(C.byref(d))) < 0
