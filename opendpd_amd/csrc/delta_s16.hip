@@ -246,9 +246,13 @@ __device__ __forceinline__ void d16_stage_out(const float2* lds, float* g, int b
         if (tt < len && b0 + m < B) g2[(size_t)(b0 + m) * T + t0 + tt] = lds[m * (CH + 1) + tt];
     }
 }
-// chunk length of the backward kernel.  (r04 experiment, profiles/r04/headline_experiments.md: with 16 steps per chunk eight waves fit the
-// LDS; under the 256-register cap of two waves per SIMD the kernel then spills 470 B per lane and is still 4 % faster — not shipped.)
-constexpr int kD16BwdCh = kChunk;
+// Chunk length and workgroup size of the backward kernel.  The weight-gradient-only kernel of one unit tile (the trained DPD of train_dpd,
+// BASELINE config 3) runs EIGHT waves per workgroup — two per SIMD — on 16-step chunks (the per-wave LDS region then fits eight times next to
+// the operand table): a lone wave issues one VALU instruction per ~4.7 cycles, two sharing a SIMD one per ~2.3.  r04 measured that shape at
+// -4 % with 472 B of scratch per lane; r05 took the TCN skip's weight gradient out of the kernel (tres_skip_wgrad_kernel: it has no state in
+// it and is time-parallel) — 24 accumulators and their arithmetic less — which leaves 248 B of scratch and 1.65 -> 1.34 ms at 65 536 x 200
+// (profiles/r05/delta16.md; two-step blocks would spill less and are SLOWER: 1.40 ms).  The other variants keep four waves and 32 steps.
+template <int NT, bool DX> constexpr int d16_bwd_ch() { return (NT == 1 && !DX) ? 16 : kChunk; }
 
 template <int NT>
 __device__ __forceinline__ void d16_init_state(TabPtr tl, D16State<NT>& st) {
@@ -397,7 +401,7 @@ template <bool TRES, int NT>
 struct D16Grad {
     f32x4 thh[3][NT][NT], tih[3][NT];
     f32x4 dwout[2][NT], db[4][NT];
-    float dbout[2], dw1[18], dw2[6];
+    float dbout[2];
     __device__ __forceinline__ void zero() {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -413,10 +417,6 @@ struct D16Grad {
             }
         }
         dbout[0] = dbout[1] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 18; ++i) dw1[i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dw2[i] = 0.f;
     }
 };
 template <int NT>
@@ -428,7 +428,7 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                                               float2 x0, int n, int q, int tglob, int tloc, int nstep, int chunk_len, float* dxrow,
                                               D16State<NT> st, D16Carry<NT>& C, const unsigned (&mw)[NT]) {
     using T = D16<NT>;
-    constexpr int S = D16<NT>::S;
+    constexpr int S = D16<NT>::S, CH = d16_bwd_ch<NT, DX>();
     const bool slot_ok[2] = {true, q < 2};
     f32x4 all_units[NT];
 #pragma unroll
@@ -464,33 +464,12 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
     auto tile = [tiles](int qty, int kt) { return tiles + (qty * NT + kt) * kTileFloats; };   // qty: 0 gr 1 gz 2 gn 3 gnh 4 dhm
     float* t_f = tiles + 5 * NT * kTileFloats;
     const f32x4 one = splat4(1.0f);
-    if constexpr (TRES) {
-        // TCN skip gradient (no state in it): quad q takes step q of the block — one evaluation per sequence and step instead of one
-        // exec-masked pass per step on a quarter of the lanes (r01..r03: ~108 of the step's ~450 VALU instructions)
-        if (q < nstep) {
-            const int tt = tloc + q;
-            const float2 dyv = dys[n * (kD16BwdCh + 1) + tt];
-            float s1[3], s2[2];
-            const float2 xm = xr[tt - d16::kHalo], xc = xr[tt], xq = xr[tt + d16::kHalo];
-            d16_tcn<TRES>(sc, xm, xc, xq, s1, s2);
-            const float d2[2] = {dyv.x * d16_hsg(s2[0]), dyv.y * d16_hsg(s2[1])};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float hs = hardswishf_(s1[c]);
-                G.dw2[c] = __builtin_fmaf(d2[0], hs, G.dw2[c]);
-                G.dw2[3 + c] = __builtin_fmaf(d2[1], hs, G.dw2[3 + c]);
-                const float d1 = __builtin_fmaf(d2[0], sc.w2[c], d2[1] * sc.w2[3 + c]) * d16_hsg(s1[c]);
-                G.dw1[c * 6 + 0] = __builtin_fmaf(d1, xm.x, G.dw1[c * 6 + 0]); G.dw1[c * 6 + 1] = __builtin_fmaf(d1, xc.x, G.dw1[c * 6 + 1]);
-                G.dw1[c * 6 + 2] = __builtin_fmaf(d1, xq.x, G.dw1[c * 6 + 2]); G.dw1[c * 6 + 3] = __builtin_fmaf(d1, xm.y, G.dw1[c * 6 + 3]);
-                G.dw1[c * 6 + 4] = __builtin_fmaf(d1, xc.y, G.dw1[c * 6 + 4]); G.dw1[c * 6 + 5] = __builtin_fmaf(d1, xq.y, G.dw1[c * 6 + 5]);
-            }
-        }
-    }
+    // (TRes: the TCN skip's weight gradient has no state in it — tres_skip_wgrad_kernel, time-parallel, writes it into rows of its own)
 #pragma unroll
     for (int si = S - 1; si >= 0; --si) {
         if (FULL || si < nstep) {
             const int tt = tloc + si;
-            const float2 dyv = dys[n * (kD16BwdCh + 1) + tt];
+            const float2 dyv = dys[n * (CH + 1) + tt];
             G.dbout[0] += q == 0 ? dyv.x : 0.0f;
             G.dbout[1] += q == 0 ? dyv.y : 0.0f;
             __builtin_amdgcn_sched_barrier(0);      // keep every step's work together (the block is fully unrolled: measured -1.8 %)
@@ -584,11 +563,11 @@ __device__ __forceinline__ void d16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 }
                 dI = quad_sum(dI); dQ = quad_sum(dQ);
                 if (q == 0) {
-                    dxs[n * (kD16BwdCh + 1) + tt] = make_float2(dI, dQ);
+                    dxs[n * (CH + 1) + tt] = make_float2(dI, dQ);
                     if constexpr (TRES) {
                         const int t1 = tglob + si + 1;
                         if (t1 >= a.T) { C.wrap[0] = nI; C.wrap[1] = nQ; }                 // torch.roll: the last step's "next" is sample 0
-                        else if (tt + 1 < chunk_len) { dxs[n * (kD16BwdCh + 1) + tt + 1].x += nI; dxs[n * (kD16BwdCh + 1) + tt + 1].y += nQ; }
+                        else if (tt + 1 < chunk_len) { dxs[n * (CH + 1) + tt + 1].x += nI; dxs[n * (CH + 1) + tt + 1].y += nQ; }
                         else if (dxrow != nullptr) {   // sample t + 1 lives in the chunk this wave flushed before: add at L2
                             __threadfence();
                             atomicAdd(dxrow + 2 * t1, nI);
@@ -673,16 +652,7 @@ __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L,
             }
         }
     if constexpr (TRES) {
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            const float v = quad_sum(row_sum16(G.dw1[i]));        // (every quad took a quarter of the steps)
-            if (n == 0 && q == 0) prow[L.o_tcn0 + i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const float v = quad_sum(row_sum16(G.dw2[i]));
-            if (n == 0 && q == 0) prow[L.o_tcn2 + i] = v;
-        }
+        if (lane < 24) prow[L.o_tcn0 + lane] = 0.0f;      // tcn.0.weight (18) and tcn.2.weight (6) are contiguous: their gradient arrives in the rows of tres_skip_wgrad_kernel
     } else {
         const float b0 = row_sum16(G.dbout[0]), b1 = row_sum16(G.dbout[1]);
         if (n == 0 && q == 0) { prow[L.o_b_out] = b0; prow[L.o_b_out + 1] = b1; }
@@ -690,9 +660,9 @@ __device__ __forceinline__ void d16_write_row(float* prow, const DeltaLayout& L,
 }
 
 template <bool TRES, int NT, bool DX, bool JAN = false>
-__global__ __launch_bounds__(256, 1) void delta16_bwd_kernel(SeqArgs a) {
+__global__ __launch_bounds__((NT == 1 && !DX) ? 512 : 256, 1) void delta16_bwd_kernel(SeqArgs a) {
     using T = D16<NT>;
-    constexpr int S = D16<NT>::S;
+    constexpr int S = D16<NT>::S, kD16BwdCh = d16_bwd_ch<NT, DX>();
     constexpr int kWave = 2 * 16 * (kD16BwdCh + 2 * d16::kHalo + 1) + (DX ? 2 : 1) * 2 * 16 * (kD16BwdCh + 1) + T::kTiles * kTileFloats;
     constexpr int kGroups = DX ? T::NG_DX : T::NG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -836,6 +806,73 @@ __global__ __launch_bounds__(256) void tres_skip_dx_kernel(const float* __restri
     *o = make_float2(cur.x + gI, cur.y + gQ);
 }
 
+// Weight gradient of the TRes skip path (tcn.0.weight: 3 x 2 x 3, tcn.2.weight: 2 x 3), time-parallel: one (sequence, step) per thread and
+// grid stride, 24 accumulators per thread, a fixed-order workgroup reduction, ONE full-width partial row per workgroup (zero outside the
+// 24 TCN columns) behind the rows of delta16_bwd_kernel — odpd_reduce_partials sums them with the rest.
+constexpr int kTcnRows = 256, kTcnThreads = 1024;      // one workgroup per CU, sixteen waves each: ~50 samples per thread at 65 536 x 200
+__global__ __launch_bounds__(kTcnThreads) void tres_skip_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ params, float* __restrict__ rows, int B, int T, int H) {
+    __shared__ float red[kTcnThreads / 64][24];
+    const DeltaLayout L = delta_layout(H, true);
+    const float* w1 = params + L.o_tcn0;
+    const float* w2 = params + L.o_tcn2;
+    float acc[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) acc[i] = 0.0f;
+    const long total = (long)B * T;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / T), t = (int)(idx % T);
+        const float2* x2 = reinterpret_cast<const float2*>(x) + (size_t)b * T;
+        const float2 dyv = reinterpret_cast<const float2*>(dy)[idx];
+        const float2 z2 = make_float2(0.0f, 0.0f);
+        const float2 xm = t >= 16 ? x2[t - 16] : z2, xc = x2[t], xq = t + 16 < T ? x2[t + 16] : z2;
+        float s1[3], hs[3], s2[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = w1[c * 6] * xm.x;
+            v = __builtin_fmaf(w1[c * 6 + 1], xc.x, v); v = __builtin_fmaf(w1[c * 6 + 2], xq.x, v);
+            v = __builtin_fmaf(w1[c * 6 + 3], xm.y, v); v = __builtin_fmaf(w1[c * 6 + 4], xc.y, v);
+            s1[c] = __builtin_fmaf(w1[c * 6 + 5], xq.y, v);
+            hs[c] = hardswishf_(s1[c]);
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float v = w2[o * 3] * hs[0];
+            v = __builtin_fmaf(w2[o * 3 + 1], hs[1], v);
+            s2[o] = __builtin_fmaf(w2[o * 3 + 2], hs[2], v);
+        }
+        const float d2[2] = {dyv.x * d16_hsg(s2[0]), dyv.y * d16_hsg(s2[1])};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc[18 + c] = __builtin_fmaf(d2[0], hs[c], acc[18 + c]);
+            acc[21 + c] = __builtin_fmaf(d2[1], hs[c], acc[21 + c]);
+            const float d1 = __builtin_fmaf(d2[0], w2[c], d2[1] * w2[3 + c]) * d16_hsg(s1[c]);
+            acc[c * 6 + 0] = __builtin_fmaf(d1, xm.x, acc[c * 6 + 0]); acc[c * 6 + 1] = __builtin_fmaf(d1, xc.x, acc[c * 6 + 1]);
+            acc[c * 6 + 2] = __builtin_fmaf(d1, xq.x, acc[c * 6 + 2]); acc[c * 6 + 3] = __builtin_fmaf(d1, xm.y, acc[c * 6 + 3]);
+            acc[c * 6 + 4] = __builtin_fmaf(d1, xc.y, acc[c * 6 + 4]); acc[c * 6 + 5] = __builtin_fmaf(d1, xq.y, acc[c * 6 + 5]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        float v = acc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);      // fixed tree: bit-repeatable
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    const int P4 = L.P + kLossCols;
+    float* prow = rows + (size_t)blockIdx.x * P4;
+    for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+        float v = 0.0f;
+        const int j = i - L.o_tcn0;      // (tcn.0.weight and tcn.2.weight are adjacent in the parameter buffer)
+        if (j >= 0 && j < 24) {
+#pragma unroll
+            for (int w = 0; w < kTcnThreads / 64; ++w) v += red[w][j];      // fixed order
+        }
+        prow[i] = v;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
@@ -860,8 +897,9 @@ static int d16_tiles(int H) { return (H + 15) / 16; }
 static size_t d16_bwd_lds(int P, int nt, int waves, bool dx) {
     const int groups = nt == 1 ? (dx ? D16<1>::NG_DX : D16<1>::NG) : (dx ? D16<2>::NG_DX : D16<2>::NG);
     const int tiles = nt == 1 ? D16<1>::kTiles : D16<2>::kTiles;
+    const int ch = (nt == 1 && !dx) ? d16_bwd_ch<1, false>() : kChunk;
     size_t lds = ((size_t)pad4(P) + s16_tab_floats(groups) +
-                  (size_t)waves * (2 * 16 * (kD16BwdCh + 2 * d16::kHalo + 1) + (dx ? 2 : 1) * 2 * 16 * (kD16BwdCh + 1) + tiles * kTileFloats)) * sizeof(float);
+                  (size_t)waves * (2 * 16 * (ch + 2 * d16::kHalo + 1) + (dx ? 2 : 1) * 2 * 16 * (ch + 1) + tiles * kTileFloats)) * sizeof(float);
     if (lds < reduce_scratch_bytes(P, waves)) lds = reduce_scratch_bytes(P, waves);
     return lds;
 }
@@ -870,13 +908,16 @@ static LaunchShape d16_bwd_shape(const odpd_model_t* m, int ngroups) {
     LaunchShape ls;
     const int P = delta_layout(m->hidden, m->backbone == ODPD_TRES_DELTAGRU, m->backbone == ODPD_DELTAJANET ? 2 : 3).P, nt = d16_tiles(m->hidden);
     const bool dx = (m->flags & ODPD_FLAG_NEED_DX) != 0;      // the shape (= rows of partials) is fixed by the model, not by the call
-    ls.waves = 4;
+    ls.waves = (nt == 1 && !dx) ? 8 : 4;
     while (ls.waves > 1 && d16_bwd_lds(P, nt, ls.waves, dx) > kMaxLds) --ls.waves;
     const int need = (ngroups + ls.waves - 1) / ls.waves, cus = device_cus();
     ls.grid = need < cus ? need : cus;
     return ls;
 }
-int delta_s16_rows(const odpd_model_t* m, int B) { return d16_bwd_shape(m, (B + 15) / 16).grid; }
+// rows of partials: one per workgroup of the backward kernel; TRes: + the rows of the skip path's weight-gradient kernel
+int delta_s16_rows(const odpd_model_t* m, int B) {
+    return d16_bwd_shape(m, (B + 15) / 16).grid + (m->backbone == ODPD_TRES_DELTAGRU ? kTcnRows : 0);
+}
 int64_t delta_s16_ckpt_floats(const odpd_model_t* m, int B, int T) {
     const int nt = d16_tiles(m->hidden), S = nt == 1 ? D16<1>::S : D16<2>::S;
     return (int64_t)((B + 15) / 16) * ((T + S - 1) / S) * (2 * nt + 1) * 256;
@@ -907,11 +948,14 @@ static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, 
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
         return (int)hipGetLastError();
     };
-    if (a.dx == nullptr) return launch(delta16_bwd_kernel<TRES, NT, false, JAN>);
-    if (int e = launch(delta16_bwd_kernel<TRES, NT, true, JAN>)) return e;
+    if (int e = a.dx == nullptr ? launch(delta16_bwd_kernel<TRES, NT, false, JAN>) : launch(delta16_bwd_kernel<TRES, NT, true, JAN>)) return e;
     if (TRES) {
-        const long n = (long)a.B * a.T;
-        hipLaunchKernelGGL(tres_skip_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.x, a.dy, a.params, a.dx, a.B, a.T, a.H);
+        hipLaunchKernelGGL(tres_skip_wgrad_kernel, dim3(kTcnRows), dim3(kTcnThreads), 0, st, a.x, a.dy, a.params,
+                           a.partials + (size_t)ls.grid * (P + kLossCols), a.B, a.T, a.H);
+        if (a.dx != nullptr) {
+            const long n = (long)a.B * a.T;
+            hipLaunchKernelGGL(tres_skip_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.x, a.dy, a.params, a.dx, a.B, a.T, a.H);
+        }
     }
     return (int)hipGetLastError();
 }
