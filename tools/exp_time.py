@@ -16,14 +16,18 @@ from opendpd_amd import CoreModel
 from opendpd_amd.train_funcs import FusedAdamW, FrameBatch
 B, T, H = int(sys.argv[1]), 200, int(sys.argv[2])
 dev = torch.device("cuda:0")
-xs, ys = bench.synth_frames(B, T, 0, dev, materialize=False)
+import os
+framed = os.environ.get("EXP_FRAMED", "1" if sys.argv[3] in ("gru", "dgru", "qgru", "qgru_amp1") else "0") == "1"
 torch.manual_seed(0)
 net = CoreModel(2, H, 1, sys.argv[3]).to(dev)
 opt = FusedAdamW(net, lr=5e-4)
-fb = FrameBatch(xs, ys, torch.arange(B, device=dev), T, 1)
-import os
+if framed:
+    xs, ys = bench.synth_frames(B, T, 0, dev, materialize=False)
+    x, t = FrameBatch(xs, ys, torch.arange(B, device=dev), T, 1), None
+else:          # kernels that take (B, T, 2) frames
+    x, t = bench.synth_frames(B, T, 0, dev)
 NS = int(os.environ.get("EXP_STEPS", "10"))
-dt, kern_ms, loss = bench.run_steps(opt, fb, None, NS, 3, B * T * 2, None, events=True)
+dt, kern_ms, loss = bench.run_steps(opt, x, t, NS, 3, B * T * 2, None, events=True)
 print(json.dumps({"ms_per_step": dt / NS * 1e3, "kernel_ms_mean": kern_ms, "loss": loss}))
 """ % ROOT
 
