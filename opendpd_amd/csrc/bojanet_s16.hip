@@ -666,8 +666,7 @@ __global__ __launch_bounds__(64) void boj_gp_train_kernel(SeqArgs a) {
                 const float dgp = (gh * (1.0f - f)) * __builtin_fmaf(-g, g, 1.0f);
                 const float d_row = vsel(rm.m[0], dfp, vsel(rm.m[1], dgp, 0.0f));
                 float part = rotdot(0.0f, wT, d_row);
-                part += xor16(part);
-                part += xor32(part);
+                part = sum_rows4(part);
                 carry = __builtin_fmaf(gh, f, part);
                 smem[dk] = d_row;
                 dk -= dk_step;

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) void delta_eval_kernel(SeqArgs a) {
                     gather_rows(sg, g4);                                          // f, g on every row
                     h = __builtin_fmaf(g4[0], h - g4[1], g4[1]);                  // (1 - f) g + f h
                 } else {
-                    const float r = xor32(sg);                                    // row 2 <- r of row 0
+                    const float r = dup32(sg).lo;                                   // row 2 <- r of row 0
                     const float n = tanhf_(__builtin_fmaf(r, res, ax));           // row 2
                     gather_rows(nrow ? n : sg, g4);
                     h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
                         h = __builtin_fmaf(g4[0], h - g4[1], g4[1]);
                         *reinterpret_cast<float4*>(smem + q4) = make_float4(g4[0], g4[1], 0.0f, 0.0f);       // f, g
                     } else {
-                        const float r = xor32(sg);                                    // row 2 <- r of row 0
+                        const float r = dup32(sg).lo;                                   // row 2 <- r of row 0
                         const float n = tanhf_(__builtin_fmaf(r, res, ax));           // row 2
                         gather_rows(nrow ? n : sg, g4);
                         h = __builtin_fmaf(g4[1], h - g4[2], g4[2]);
@@ -839,8 +839,7 @@ __global__ __launch_bounds__(64) void delta_gp_bwd_kernel(SeqArgs a) {
                     acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(vsel(rm.m[2], gn, accg), fsx, acc2, 0, 0, 0);
                 }
                 float ddh = rotdot(0.0f, wT, accg);
-                ddh += xor16(ddh);
-                ddh += xor32(ddh);
+                ddh = sum_rows4(ddh);
                 ghprev = __builtin_fmaf(mk, ddh + ghp, ghprev);
                 ghp = __builtin_fmaf(-mk, ddh, (1.0f - mk) * ghp);
                 gh_c = ghprev;

@@ -635,8 +635,7 @@ __global__ __launch_bounds__(64) void dvr_gp_train_kernel(SeqArgs a, int K, DvrK
                 const float dap = dat * slope;
                 const float dA_row = vsel(rm.m[0], dth, vsel(rm.m[1], dap, vsel(rm.m[2], dfp, 0.0f)));
                 float pat = rotdot(0.0f, wAT, dA_row);
-                pat += xor16(pat);
-                pat += xor32(pat);
+                pat = sum_rows4(pat);
                 dhI = __builtin_fmaf(gI, f, g4[0]) + pat;
                 dhQ = __builtin_fmaf(gQ, f, g4[2]) + pat;
                 const float opnd = vsel(rm.m[0], hIp, vsel(rm.m[1], at * co, vsel(rm.m[2], hQp, at * si)));

@@ -471,12 +471,12 @@ __device__ __forceinline__ void gru_eval_body(const SeqArgs& a, const int bid, c
             for (int ob = 0; ob < NB; ++ob) {
                 arec[ob] = b_rec[ob];
 #pragma unroll
-                for (int kb = 0; kb < NB; ++kb) arec[ob] = (HALF && kb == 1) ? rotdot8(arec[ob], wrec[ob][kb], h[kb]) : rotdot(arec[ob], wrec[ob][kb], h[kb]);
+                for (int kb = 0; kb < NB; ++kb) arec[ob] = (HALF && kb == 1) ? rotdot8_1(arec[ob], wrec[ob][kb], h[kb]) : rotdot1(arec[ob], wrec[ob][kb], h[kb]);
             }
         };
         float2 raw = lane < a.T ? xg[lane] : make_float2(0.5f, 0.5f);
         for (int t0 = 0; t0 < a.T; t0 += EC) {
-            const int len = min(EC, a.T - t0);
+            const int len = __builtin_amdgcn_readfirstlane(min(EC, a.T - t0));     // (a scalar trip count: the step loop's counter off the VALU)
             {
                 float f[F];
                 feat_fwd<FM>(raw.x, raw.y, f);
@@ -508,14 +508,11 @@ __device__ __forceinline__ void gru_eval_body(const SeqArgs& a, const int bid, c
 #pragma unroll
                     for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[ob][i], f[i], ain);
                     const float sg = sigmoidf_(ain + arec[ob]);                 // r (row 0), z (row 3)
-                    const float r1 = xor16(sg);                                 // row 1 <- r
-                    const float n = tanhf_(__builtin_fmaf(r1, arec[ob], ain));  // row 1
-                    const float v = role == 1 ? n : sg;
-                    const float o = xor32(v);                                   // row 1 <- z, row 3 <- n
-                    const float zz = role == 1 ? o : sg, nn = role == 1 ? n : o;
-                    const float h13 = __builtin_fmaf(zz, h[ob] - nn, nn);       // rows 1 and 3: (1 - z) n + z h
-                    const float h02 = xor16(h13);
-                    h[ob] = odd ? h13 : h02;
+                    const RowDup s2 = dup16(sg);                                // .even on row 1: r, .odd on row 3: z
+                    const float n = tanhf_(__builtin_fmaf(s2.even, arec[ob], ain));   // row 1
+                    const HalfDup nz = dup32(role == 1 ? n : s2.odd);           // rows 1 and 3: lo = n, hi = z
+                    const float h13 = __builtin_fmaf(nz.hi, h[ob] - nz.lo, nz.lo);    // rows 1 and 3: (1 - z) n + z h
+                    h[ob] = dup16(h13).odd;                                     // every row: its half's row 1 / 3
                 }
                 // BPTT checkpoints in the layout of the row-rotated backward (4 / NB sequences per wave-task, lane = 16 NB s + 16 ob + col)
                 if constexpr (CK) {
@@ -903,6 +900,12 @@ __device__ __forceinline__ void gru_gp_train_body(const SeqArgs& a, const int bi
     const float bo0 = pl[L.o_b_out], bo1 = pl[L.o_b_out + 1];
     // rotated dot product over input block kb
     auto rd = [](float acc, const float (&w)[16], float v, int kb) { return (HALF && kb == 1) ? rotdot8(acc, w, v) : rotdot(acc, w, v); };
+    // (forward: one accumulator chain, the order of the evaluation kernel and of rotdot3 — where it measured faster: the dgru step 0.1244 -> 0.1208 ms, the
+    //  plain gru step 0.0940 -> 0.0956: that one keeps two chains)
+    auto rd1 = [](float acc, const float (&w)[16], float v, int kb) {
+        if constexpr (!DG) return (HALF && kb == 1) ? rotdot8(acc, w, v) : rotdot(acc, w, v);
+        else return (HALF && kb == 1) ? rotdot8_1(acc, w, v) : rotdot1(acc, w, v);
+    };
     wave_lds_fence();
     // per-time buffers over the tables
     float* ftab = tab;                                  // [Tp][8]   features of step t
@@ -954,7 +957,7 @@ __device__ __forceinline__ void gru_gp_train_body(const SeqArgs& a, const int bi
         for (int ob = 0; ob < NB; ++ob) {
             arec[ob] = b_rec[ob];
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) arec[ob] = rd(arec[ob], wF[ob][kb], hin[kb], kb);
+            for (int kb = 0; kb < NB; ++kb) arec[ob] = rd1(arec[ob], wF[ob][kb], hin[kb], kb);
         }
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) {
@@ -962,11 +965,11 @@ __device__ __forceinline__ void gru_gp_train_body(const SeqArgs& a, const int bi
 #pragma unroll
             for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[ob][i], f[i], ain);
             const float sg = sigmoidf_(ain + arec[ob]);                     // r (row 0), z (row 3)
-            r1[ob] = xor16(sg);                                             // row 1 <- r
+            const RowDup s2 = dup16(sg);                                    // .even on row 1: r, .odd on row 3: z
+            r1[ob] = s2.even;
             const float n = tanhf_(__builtin_fmaf(r1[ob], arec[ob], ain));  // row 1
-            const float v = role == 1 ? n : sg;
-            const float o = xor32(v);                                       // row 1 <- z, row 3 <- n
-            zz[ob] = role == 1 ? o : sg; nn[ob] = role == 1 ? n : o;
+            const HalfDup nz = dup32(role == 1 ? n : s2.odd);               // rows 1 and 3: lo = n, hi = z
+            zz[ob] = nz.hi; nn[ob] = nz.lo;
         }
     };
     auto load_feat = [&](int t, float (&f)[F]) {
@@ -1009,8 +1012,7 @@ __device__ __forceinline__ void gru_gp_train_body(const SeqArgs& a, const int bi
 #pragma unroll
                     for (int ob = 0; ob < NB; ++ob) {
                         const float h13 = __builtin_fmaf(zz[ob], h[ob] - nn[ob], nn[ob]);       // rows 1 and 3: (1 - z) n + z h
-                        const float h02 = xor16(h13);
-                        h[ob] = odd ? h13 : h02;
+                        h[ob] = dup16(h13).odd;                                                 // every row: its half's row 1 / 3
                         // (the head row's first store, act(-1), lands in hist's pad entry)
                         smem[park + 16 * ob] = head_row ? __builtin_fmaxf(arec[ob], 0.0f) : h[ob];
                         if constexpr (PG) *reinterpret_cast<float4*>(smem + gpark + 64 * ob) = make_float4(r1[ob], arec[ob], zz[ob], nn[ob]);
@@ -1024,7 +1026,7 @@ __device__ __forceinline__ void gru_gp_train_body(const SeqArgs& a, const int bi
                 for (int ob = 0; ob < NB; ++ob) {
                     float arec = b_rec[ob];
 #pragma unroll
-                    for (int kb = 0; kb < NB; ++kb) arec = rd(arec, wF[ob][kb], h[kb], kb);
+                    for (int kb = 0; kb < NB; ++kb) arec = rd1(arec, wF[ob][kb], h[kb], kb);
                     if (head_row) actb[(T - 1) * HB + 16 * ob + col] = __builtin_fmaxf(arec, 0.0f);
                 }
             }
@@ -1076,9 +1078,7 @@ __device__ __forceinline__ void gru_gp_train_body(const SeqArgs& a, const int bi
                     float part = 0.0f;
 #pragma unroll
                     for (int kb = 0; kb < NB; ++kb) part = rd(part, wT[ob][kb], head_row ? dhid_cur[kb] : 0.0f, kb);
-                    part += xor16(part);
-                    part += xor32(part);
-                    carry[ob] = part;
+                    carry[ob] = sum_rows4(part);
                 }
             }
             for (int t = T - 1; t >= 0; --t) {
@@ -1117,7 +1117,7 @@ __device__ __forceinline__ void gru_gp_train_body(const SeqArgs& a, const int bi
                     const float dgh = dnp[ob] * r1[ob];
                     const float drp1 = (dnp[ob] * arec[ob]) * (r1[ob] * (1.0f - r1[ob]));
                     const float dzp = dz * (zz[ob] * (1.0f - zz[ob]));
-                    const float drp0 = xor16(drp1);
+                    const float drp0 = dup16(drp1).odd;                              // (row 0 <- row 1)
                     dhid_prev[ob] = 0.0f;
                     if constexpr (DG) {
                         const float atp = actb[tm * HB + 16 * ob + col];
@@ -1139,9 +1139,7 @@ __device__ __forceinline__ void gru_gp_train_body(const SeqArgs& a, const int bi
                     float part = zterm[ob];
 #pragma unroll
                     for (int kb = 0; kb < NB; ++kb) part = rd(part, wT[ob][kb], d_row[kb], kb);
-                    part += xor16(part);
-                    part += xor32(part);
-                    carry[ob] = part;                                                // dL/dh(t-1): W_hh^T d + z dL/dh(t) + fc_hid^T dhid(t-1)
+                    carry[ob] = sum_rows4(part);                                                // dL/dh(t-1): W_hh^T d + z dL/dh(t) + fc_hid^T dhid(t-1)
                 }
                 // weight gradients
 #pragma unroll

@@ -351,17 +351,16 @@ __global__ __launch_bounds__(64) void janet_gp_train_kernel(SeqArgs a) {
                 // round B': rows 0 / 1 sum to dL/du, rows 2 / 3 to h(t-1)'s share through W_gh, W_fh
                 const float dsel = vsel(rm.m[0] | rm.m[3], dfp, dgp);
                 float pb = rotdot(0.0f, wtb, dsel);
-                pb += xor16(pb);                                                   // rows 0, 1: du | rows 2, 3: the h share
-                const float px = xor32(pb);
-                const float du = vsel(rm.m[0] | rm.m[1], pb, px), dhb = vsel(rm.m[0] | rm.m[1], px, pb);
+                const RowDup pb2 = dup16(pb);
+                const HalfDup ps = dup32(pb2.even + pb2.odd);                      // rows 0, 1 sum to du | rows 2, 3 to the h share
+                const float du = ps.lo, dhb = ps.hi;
                 const float Aa = an * (1.0f - an), Ab = p1 * (1.0f - p1), Ac = p2 * (1.0f - p2);
                 const float dap = (du * (1.0f - 2.0f * an) * Ab * Ac) * __builtin_fmaf(-an, an, 1.0f);
                 const float dbp = (du * Aa * (1.0f - 2.0f * p1) * Ac) * __builtin_fmaf(-p1, p1, 1.0f);
                 const float dcp = (du * Aa * Ab * (1.0f - 2.0f * p2)) * __builtin_fmaf(-p2, p2, 1.0f);
                 const float d_a = vsel(rm.m[0], dap, vsel(rm.m[1], dbp, vsel(rm.m[2], dcp, 0.0f)));
                 float pa = rotdot(0.0f, wta, d_a);
-                pa += xor16(pa);
-                pa += xor32(pa);
+                pa = sum_rows4(pa);
                 carry = __builtin_fmaf(dht, f, dhb) + pa;
                 // weight gradients
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(dsel, vsel(rm.m[0] | rm.m[1], u, hp), acc1, 0, 0, 0);

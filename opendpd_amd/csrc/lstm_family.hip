@@ -700,8 +700,7 @@ __global__ __launch_bounds__(64) void lstm_gp_train_kernel(SeqArgs a) {
                 const float up = (role == 3 ? dht : dct) * mul;
                 const float d_row = up * (is_g ? __builtin_fmaf(-own, own, 1.0f) : own * (1.0f - own));
                 float part = rotdot(0.0f, wT, d_row);
-                part += xor16(part);
-                part += xor32(part);
+                part = sum_rows4(part);
                 dh = part;
                 const float xsx = col < F ? ftab[4 * t + xcol] : (col == F ? 1.0f : 0.0f);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(d_row, hp, acc1, 0, 0, 0);

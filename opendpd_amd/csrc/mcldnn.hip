@@ -753,8 +753,7 @@ __global__ __launch_bounds__(kMgpThreads) void mcl_gp_train_kernel(SeqArgs a) {
                 const float up = (role == 3 ? dht : dct) * mul;
                 const float d_row = vo ? up * (is_g ? __builtin_fmaf(-own, own, 1.0f) : own * (1.0f - own)) : 0.0f;
                 float part = rotdot(0.0f, wT, d_row);
-                part += xor16(part);
-                part += xor32(part);
+                part = sum_rows4(part);
                 dh = part;
                 smem[dg] = d_row;
                 dg -= dg_step;

@@ -120,7 +120,7 @@ struct DeltaSeq {
         const float res = rotdot(nrow ? acch : ax, wrec, dhm);            // rows r, z: dm += W_ih dx + W_hh dh; row n: dm_nh += W_hn dh
         accx = nrow ? ax : res; acch = nrow ? res : acch;
         const float sg = sigmoidf_(res);
-        const float r = xor32(sg);                                        // row 2 <- r of row 0
+        const float r = dup32(sg).lo;                                       // row 2 <- r of row 0
         const float n = tanhf_(__builtin_fmaf(r, res, ax));               // row 2
         float g4[4];
         gather_rows(nrow ? n : sg, g4);
@@ -254,8 +254,7 @@ struct DeltaSeq {
             acc1 = __builtin_amdgcn_mfma_f32_16x16x1f32(accg, dhm, acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x1f32(vsel(rm.m[2], gn, accg), fsx, acc2, 0, 0, 0);
             float ddh = rotdot(0.0f, wT, accg);
-            ddh += xor16(ddh);
-            ddh += xor32(ddh);
+            ddh = sum_rows4(ddh);
             ghprev = __builtin_fmaf(mk, ddh + ghp, ghprev);
             ghp = __builtin_fmaf(-mk, ddh, (1.0f - mk) * ghp);
             gh_c = ghprev;

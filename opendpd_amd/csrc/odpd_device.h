@@ -68,6 +68,28 @@ __device__ __forceinline__ float xor16(float v) {       // lane i <-> lane i ^ 1
     const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);      // r[0] = rows (0, 0, 2, 2), r[1] = rows (1, 1, 3, 3)
     return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
 }
+// Both results of swapping a value's rows with themselves, for steps whose consumers sit on known rows (no select needed):
+// dup16(v).even = v of rows (0, 0, 2, 2), .odd = rows (1, 1, 3, 3); dup32(v).lo = rows (0, 1, 0, 1), .hi = rows (2, 3, 2, 3)
+struct RowDup { float even, odd; };
+struct HalfDup { float lo, hi; };
+__device__ __forceinline__ RowDup dup16(float v) {
+    const int iv = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+    const int a = r[0], b = r[1];
+    return RowDup{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+}
+__device__ __forceinline__ HalfDup dup32(float v) {
+    const int iv = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+    const int a = r[0], b = r[1];
+    return HalfDup{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+}
+// sum over the wave's four rows, every lane receives it (the additions of `v += xor16(v); v += xor32(v)`, without the two selects)
+__device__ __forceinline__ float sum_rows4(float v) {
+    const RowDup p = dup16(v);
+    const HalfDup q = dup32(p.even + p.odd);
+    return q.lo + q.hi;
+}
 // Row select without control flow: a ?: on the row index can come out as exec-mask branches inside a step loop, and an inline-asm
 // v_cndmask hides its VGPR write from the compiler's MFMA hazard handling (a following v_mfma read the stale operand).  So: per-lane
 // all-ones / zero masks, made opaque once at kernel start, and a bitwise blend (one v_bfi_b32).
@@ -187,6 +209,43 @@ __device__ __forceinline__ float rotdot8(float acc, const float (&w)[16], float 
 #undef ODPD_R1
 #endif
     return a0 + a1;
+}
+
+// ... as ONE accumulator chain in the order k = 0 .. 15 (the order of rotdot3): a lone wave is issue bound, a dependent v_fmac_dpp issues
+// back to back, and the second chain costs a v_mov and a v_add per dot product (r05: -4 % on the evaluation pass)
+__device__ __forceinline__ float rotdot1(float acc, const float (&w)[16], float h) {
+    float c0 = __builtin_fmaf(w[0], h, acc);
+#if ODPD_DPP_ASM
+    asm("s_nop 1\n\t"
+        ODPD_DPPF(0, 1, 2, 1) ODPD_DPPF(0, 1, 3, 2) ODPD_DPPF(0, 1, 4, 3) ODPD_DPPF(0, 1, 5, 4)
+        ODPD_DPPF(0, 1, 6, 5) ODPD_DPPF(0, 1, 7, 6) ODPD_DPPF(0, 1, 8, 7) ODPD_DPPF(0, 1, 9, 8)
+        ODPD_DPPF(0, 1, 10, 9) ODPD_DPPF(0, 1, 11, 10) ODPD_DPPF(0, 1, 12, 11) ODPD_DPPF(0, 1, 13, 12)
+        ODPD_DPPF(0, 1, 14, 13) ODPD_DPPF(0, 1, 15, 14) ODPD_DPPF(0, 1, 16, 15)
+        : "+&v"(c0)
+        : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]),
+          "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+#else
+#define ODPD_R1(K) c0 = __builtin_fmaf(w[K], dpp_ror<K>(h), c0);
+    ODPD_R1(1) ODPD_R1(2) ODPD_R1(3) ODPD_R1(4) ODPD_R1(5) ODPD_R1(6) ODPD_R1(7) ODPD_R1(8)
+    ODPD_R1(9) ODPD_R1(10) ODPD_R1(11) ODPD_R1(12) ODPD_R1(13) ODPD_R1(14) ODPD_R1(15)
+#undef ODPD_R1
+#endif
+    return c0;
+}
+__device__ __forceinline__ float rotdot8_1(float acc, const float (&w)[16], float h) {
+    float c0 = __builtin_fmaf(w[0], h, acc);
+#if ODPD_DPP_ASM
+    asm("s_nop 1\n\t"
+        ODPD_DPPF(0, 1, 2, 1) ODPD_DPPF(0, 1, 3, 2) ODPD_DPPF(0, 1, 4, 3) ODPD_DPPF(0, 1, 5, 4)
+        ODPD_DPPF(0, 1, 6, 5) ODPD_DPPF(0, 1, 7, 6) ODPD_DPPF(0, 1, 8, 7)
+        : "+&v"(c0)
+        : "v"(h), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+#else
+#define ODPD_R1(K) c0 = __builtin_fmaf(w[K], dpp_ror<K>(h), c0);
+    ODPD_R1(1) ODPD_R1(2) ODPD_R1(3) ODPD_R1(4) ODPD_R1(5) ODPD_R1(6) ODPD_R1(7)
+#undef ODPD_R1
+#endif
+    return c0;
 }
 
 // Rotated dot product with the 16 weights delivered as four quads (e.g. ds_read_b128 from an LDS

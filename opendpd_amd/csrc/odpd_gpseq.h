@@ -50,6 +50,10 @@ struct GpSeq {
     __device__ __forceinline__ static float rd(float acc, const float (&w)[16], float v, int kb) {
         return (HALF && kb == 1) ? rotdot8(acc, w, v) : rotdot(acc, w, v);
     }
+    // forward dot products.  (gru_family.hip's solo kernels add a dgru's products as ONE chain since r05; here the two chains stay: the W16A16
+    // QAT stage of the OpenDPDv2 recipe — thresholds + 2^-14 grids — turns that rounding-level change of its frozen PA into a first-epoch TRAIN_LOSS of
+    // 0.00235 instead of 0.00212 (reference log: 0.00217), and the logged trajectories are the anchors: tests/test_e2e_gpu.py)
+    __device__ __forceinline__ static float rd1(float acc, const float (&w)[16], float v, int kb) { return rd(acc, w, v, kb); }
     // (one workgroup barrier inside: fill_gru_tabs)
     __device__ __forceinline__ void setup(float* base, float* region, const float* params, int Hm, int T_) {
         smem = base;
@@ -135,7 +139,7 @@ struct GpSeq {
         for (int ob = 0; ob < NB; ++ob) {
             arec[ob] = b_rec[ob];
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) arec[ob] = rd(arec[ob], wF[ob][kb], hin[kb], kb);
+            for (int kb = 0; kb < NB; ++kb) arec[ob] = rd1(arec[ob], wF[ob][kb], hin[kb], kb);
         }
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) {
@@ -143,11 +147,11 @@ struct GpSeq {
 #pragma unroll
             for (int i = 0; i < F; ++i) ain = __builtin_fmaf(win[ob][i], f[i], ain);
             const float sg = sigmoidf_(ain + arec[ob]);                     // r (row 0), z (row 3)
-            r1[ob] = xor16(sg);                                             // row 1 <- r
+            const RowDup s2 = dup16(sg);                                    // .even on row 1: r, .odd on row 3: z
+            r1[ob] = s2.even;
             const float n = tanhf_(__builtin_fmaf(r1[ob], arec[ob], ain));  // row 1
-            const float v = role == 1 ? n : sg;
-            const float o = xor32(v);                                       // row 1 <- z, row 3 <- n
-            zz[ob] = role == 1 ? o : sg; nn[ob] = role == 1 ? n : o;
+            const HalfDup nz = dup32(role == 1 ? n : s2.odd);               // rows 1 and 3: lo = n, hi = z
+            zz[ob] = nz.hi; nn[ob] = nz.lo;
         }
     }
     __device__ __forceinline__ void load_feat(int t, float (&f)[F]) const {
@@ -181,8 +185,7 @@ struct GpSeq {
 #pragma unroll
             for (int ob = 0; ob < NB; ++ob) {
                 const float h13 = __builtin_fmaf(zz[ob], h[ob] - nn[ob], nn[ob]);       // rows 1 and 3: (1 - z) n + z h
-                const float h02 = xor16(h13);
-                h[ob] = odd ? h13 : h02;
+                h[ob] = dup16(h13).odd;                                                 // every row: its half's row 1 / 3
                 // (the head row's first store, act(-1), lands in hist's pad entry)
                 smem[park + 16 * ob] = head_row ? __builtin_fmaxf(arec[ob], 0.0f) : h[ob];
             }
@@ -196,7 +199,7 @@ struct GpSeq {
             for (int ob = 0; ob < NB; ++ob) {
                 float arec = b_rec[ob];
 #pragma unroll
-                for (int kb = 0; kb < NB; ++kb) arec = rd(arec, wF[ob][kb], h[kb], kb);
+                for (int kb = 0; kb < NB; ++kb) arec = rd1(arec, wF[ob][kb], h[kb], kb);
                 if (head_row) actb[t * HB + 16 * ob + col] = __builtin_fmaxf(arec, 0.0f);
             }
         }
@@ -241,8 +244,7 @@ struct GpSeq {
                 float part = 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) part = rd(part, wT[ob][kb], head_row ? dhid_cur[kb] : 0.0f, kb);
-                part += xor16(part);
-                part += xor32(part);
+                part = sum_rows4(part);
                 carry[ob] = part;
             }
         }
@@ -279,7 +281,7 @@ struct GpSeq {
                 const float dgh = dnp[ob] * r1[ob];
                 const float drp1 = (dnp[ob] * arec[ob]) * (r1[ob] * (1.0f - r1[ob]));
                 const float dzp = dz * (zz[ob] * (1.0f - zz[ob]));
-                const float drp0 = xor16(drp1);
+                const float drp0 = dup16(drp1).odd;                              // (row 0 <- row 1)
                 dhid_prev[ob] = 0.0f;
                 if constexpr (DG) {
                     const float atp = actb[tm * HB + 16 * ob + col];
@@ -300,8 +302,7 @@ struct GpSeq {
                 float part = zterm[ob];
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) part = rd(part, wT[ob][kb], d_row[kb], kb);
-                part += xor16(part);
-                part += xor32(part);
+                part = sum_rows4(part);
                 carry[ob] = part;                                                // dL/dh(t-1): W_hh^T d + z dL/dh(t) + fc_hid^T dhid(t-1)
             }
 #pragma unroll

@@ -397,8 +397,7 @@ struct QatSeq {
                 float ddh = 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) ddh = rotdot(ddh, wT[ob][kb], d_h[kb]);
-                ddh += xor16(ddh);
-                ddh += xor32(ddh);
+                ddh = sum_rows4(ddh);
                 gh[ob] = dhdir[ob] + ddh * pph[ob];
             }
             // weight gradients on grid-unit operands: (d_r | d_z | d_hn) x q_a(h), (d_r | d_z | d_n) x (q_a(features) | 1 / s_xa)
@@ -782,8 +781,7 @@ struct QatDeltaSeq {
             const float d_h = vsel(rm.m[0], gr, vsel(rm.m[1], gz, vsel(rm.m[2], gnh, 0.0f)));
             const float d_x = vsel(rm.m[0], gr, vsel(rm.m[1], gz, vsel(rm.m[2], gn, 0.0f)));
             float ddh = rotdot(0.0f, wT, d_h);
-            ddh += xor16(ddh);
-            ddh += xor32(ddh);
+            ddh = sum_rows4(ddh);
             const float g2b = ddh * pph;
             gh = ghprev + mh * (g2b + ghp);
             ghp = (1.0f - mh) * ghp - mh * g2b;

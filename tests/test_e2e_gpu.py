@@ -875,6 +875,7 @@ def test_openDPDv2_recipe_on_apa_matches_reference_logs(apa_workdir):
     def compare(hist, rh, n_param):
         assert list(hist.columns) == list(rh.keys())
         assert hist["N_PARAM"][0] == rh["N_PARAM"][0] == n_param
+        print("TRAIN_LOSS here / reference:", hist["TRAIN_LOSS"][0], rh["TRAIN_LOSS"][0], {c: (hist[c][0], rh[c][0]) for c in ("SP_T_DX", "SP_T_DH", "VAL_NMSE", "TEST_NMSE")})
         assert abs(hist["TRAIN_LOSS"][0] - rh["TRAIN_LOSS"][0]) < 0.05 * rh["TRAIN_LOSS"][0], (hist["TRAIN_LOSS"][0], rh["TRAIN_LOSS"][0])
         assert abs(hist["SP_T_DX"][0] - rh["SP_T_DX"][0]) < 0.01 and abs(hist["SP_T_DH"][0] - rh["SP_T_DH"][0]) < 0.03
         for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):

@@ -44,3 +44,13 @@ for K in [int(a) for a in sys.argv[1:]] or [8, 32]:
         tk, res = timed(lambda: od.train_pa_sweep(seeds=tuple(range(100, 100 + K)), exact=exact, **kw))
         assert K == 1 or all(r["lockstep"] for r in res)
         print(f"{K:3d} runs in lockstep ({res[0]['mode']:5s}): {tk:.3f} s = {tk / t1:.2f} x one run ({K * t1 / tk:.1f} x the throughput of K solo runs back to back)", flush=True)
+if os.environ.get("EXP_PROFILE"):            # where the host time of a throughput-mode sweep goes
+    import cProfile
+    import pstats
+    K = int(os.environ["EXP_PROFILE"])
+    pr = cProfile.Profile()
+    pr.enable()
+    od.train_pa_sweep(seeds=tuple(range(100, 100 + K)), exact=False, **kw)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
