@@ -58,7 +58,15 @@ __device__ __forceinline__ void pgq_setup(float* pl, const SeqArgs& a, const Pgq
     wave_lds_fence();
 }
 
-template <bool SAVE>
+// Forward.  HP = padded unit count (16: hidden <= 16, 32: hidden 17 .. 32).  The wave's two halves split a unit's five gate rows, all of them in
+// REGISTERS: lane j < 32 holds the a_n / p1 / p2 rows of unit j, lane 32 + j its f / g rows (h part and u part) and the state h_j.  A step is two
+// rounds of row-times-broadcast-vector dot products — the vectors are read as ds_read_b128 broadcasts, each half from its own layers' slots —
+//   round A: lower half W_a q_0(h), W_p1 q_1(h), W_p2 q_2(h) (+ the scalar input's column) -> a_n, p1, p2 -> u -> q_3(u), q_4(u) to LDS;
+//            upper half, in the same instructions, the h parts W_f[:, :H] q_3(h), W_g[:, :H] q_4(h)
+//   round B: upper half continues its two sums with the u parts -> f, g -> h'
+// with every sum in the order of the reference's mat-vec (k ascending, h part before u part; the padded columns hold zeros and add nothing), so
+// the results are those of the first version of this kernel (r04: both operands of every FMA read from LDS, 1.4 .. 2.6 ms per 256 x 200 step) bit for bit.
+template <int HP, bool SAVE>
 __global__ __launch_bounds__(64) void pgq_fwd_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -70,62 +78,83 @@ __global__ __launch_bounds__(64) void pgq_fwd_kernel(SeqArgs a) {
     float* hist = vq + 8 * 32;                 // [64][33]: h of the chunk's steps
     PgqQ Q;
     pgq_setup(pl, a, L, Q, lane);
-    const bool vo = lane < H;
-    const int j = vo ? lane : 0;
+    const bool up = lane >= 32;
+    const int j0 = lane & 31;
+    const bool vo = j0 < H;
+    const int j = vo ? j0 : 0;
+    float w[3][HP], wu[2][HP], wsc[3], bias[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int lay = up ? 3 + r : r;                       // (upper half, r = 2: no third row — zeros)
+        const bool row = vo && (!up || r < 2);
+#pragma unroll
+        for (int k = 0; k < HP; ++k) w[r][k] = (row && k < H) ? pl[L.ow[row ? lay : 0] + j * (up ? H2 : H1) + k] : 0.0f;
+        wsc[r] = (vo && !up) ? pl[L.ow[r] + j * H1 + H] : 0.0f;
+        bias[r] = row ? pl[L.ob[row ? lay : 0] + j] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < HP; ++k) wu[r][k] = (vo && up && k < H) ? pl[L.ow[3 + r] + j * H2 + H + k] : 0.0f;
+    for (int i = lane; i < 8 * 32; i += 64) vq[i] = 0.0f;
+    const float* va = vq + (up ? 3 * 32 : 0);                  // round A: row r against slot (up ? 3 : 0) + r
+    wave_lds_fence();
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
         float2* yg = reinterpret_cast<float2*>(a.y) + (size_t)b * T;
         float* sv = SAVE ? a.ckpt + (size_t)b * T * kPNS * 64 : nullptr;
-        float h = 0.0f;
+        float h = 0.0f;                                        // upper half: the state of unit j0
         for (int t0 = 0; t0 < T; t0 += kPC) {
             const int len = min(kPC, T - t0);
             wave_lds_fence();
             pgq_stage_inputs(ftab, xg, t0, T, lane);
             wave_lds_fence();
             for (int tt = 0; tt < len; ++tt) {
-                if (lane < 32) {
+                if (up) {
 #pragma unroll
-                    for (int l = 0; l < 5; ++l) vq[l * 32 + lane] = vo ? q16::qapply(h, Q.a[l]) : 0.0f;
+                    for (int l = 0; l < 5; ++l) vq[l * 32 + j0] = vo ? q16::qapply(h, Q.a[l]) : 0.0f;
                 }
                 wave_lds_fence();
                 const float4 in = reinterpret_cast<const float4*>(ftab)[tt];
                 const float sc[3] = {in.x, in.y, in.z};
+                float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int q4 = 0; q4 < HP / 4; ++q4)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float4 v = *reinterpret_cast<const float4*>(va + r * 32 + 4 * q4);
+                        acc[r] = __builtin_fmaf(w[r][4 * q4], v.x, acc[r]); acc[r] = __builtin_fmaf(w[r][4 * q4 + 1], v.y, acc[r]);
+                        acc[r] = __builtin_fmaf(w[r][4 * q4 + 2], v.z, acc[r]); acc[r] = __builtin_fmaf(w[r][4 * q4 + 3], v.w, acc[r]);
+                    }
+                // lower half: the three input gates and u
                 float gate[3];
 #pragma unroll
-                for (int l = 0; l < 3; ++l) {
-                    const float* wr = pl + L.ow[l] + j * H1;
-                    float acc = 0.0f;
-#pragma unroll 8
-                    for (int k = 0; k < H; ++k) acc = __builtin_fmaf(wr[k], vq[l * 32 + k], acc);
-                    acc = __builtin_fmaf(wr[H], q16::qapply(sc[l], Q.a[l]), acc);
-                    gate[l] = tanhf_(acc + pl[L.ob[l] + j]);
-                }
+                for (int l = 0; l < 3; ++l) gate[l] = tanhf_(__builtin_fmaf(wsc[l], q16::qapply(sc[l], Q.a[l]), acc[l]) + bias[l]);
                 const float an = gate[0], p1 = gate[1], p2 = gate[2];
                 const float u = (an * p1 * p2) * ((1.0f - an) * (1.0f - p1) * (1.0f - p2));
-                if (lane < 32) {
-                    vq[5 * 32 + lane] = vo ? q16::qapply(u, Q.a[3]) : 0.0f;
-                    vq[6 * 32 + lane] = vo ? q16::qapply(u, Q.a[4]) : 0.0f;
+                if (!up) {
+                    vq[5 * 32 + j0] = vo ? q16::qapply(u, Q.a[3]) : 0.0f;
+                    vq[6 * 32 + j0] = vo ? q16::qapply(u, Q.a[4]) : 0.0f;
                 }
                 wave_lds_fence();
-                float pre[2];
+                // upper half: the u parts behind the h parts
 #pragma unroll
-                for (int l = 0; l < 2; ++l) {
-                    const float* wr = pl + L.ow[3 + l] + j * H2;
-                    float acc = 0.0f;
-#pragma unroll 8
-                    for (int k = 0; k < H; ++k) acc = __builtin_fmaf(wr[k], vq[(3 + l) * 32 + k], acc);
-#pragma unroll 8
-                    for (int k = 0; k < H; ++k) acc = __builtin_fmaf(wr[H + k], vq[(5 + l) * 32 + k], acc);
-                    pre[l] = acc + pl[L.ob[3 + l] + j];
-                }
-                const float f = sigmoidf_(pre[0]), g = tanhf_(pre[1]);
-                const float hn = vo ? f * h + (1.0f - f) * g : 0.0f;
-                if constexpr (SAVE) {
-                    float* s = sv + (size_t)(t0 + tt) * kPNS * 64 + lane;
-                    s[0] = an; s[64] = p1; s[128] = p2; s[192] = u; s[256] = f; s[320] = g; s[384] = hn;
+                for (int q4 = 0; q4 < HP / 4; ++q4)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const float4 v = *reinterpret_cast<const float4*>(vq + (5 + r) * 32 + 4 * q4);
+                        acc[r] = __builtin_fmaf(wu[r][4 * q4], v.x, acc[r]); acc[r] = __builtin_fmaf(wu[r][4 * q4 + 1], v.y, acc[r]);
+                        acc[r] = __builtin_fmaf(wu[r][4 * q4 + 2], v.z, acc[r]); acc[r] = __builtin_fmaf(wu[r][4 * q4 + 3], v.w, acc[r]);
+                    }
+                const float f = sigmoidf_(acc[0] + bias[0]), g = tanhf_(acc[1] + bias[1]);
+                const float hn = (vo && up) ? f * h + (1.0f - f) * g : 0.0f;
+                if constexpr (SAVE) {      // record of step t: [a_n | p1 | p2 | u | f | g | h'][unit]
+                    float* s = sv + (size_t)(t0 + tt) * kPNS * 64 + j0;
+                    if (!up) { s[0] = an; s[64] = p1; s[128] = p2; s[192] = u; }
+                    else { s[256] = f; s[320] = g; s[384] = hn; }
                 }
                 h = hn;
-                if (lane < 32) hist[tt * kPS + lane] = h;
+                if (up) hist[tt * kPS + j0] = h;
                 wave_lds_fence();
             }
             if (lane < len) {      // the chunk's outputs, lane = time step: W_o on q_5(h)
@@ -143,14 +172,19 @@ __global__ __launch_bounds__(64) void pgq_fwd_kernel(SeqArgs a) {
     }
 }
 
-template <bool NW, bool DX>
+// Backward, the same split.  Lane j < 32: column j of W_a / W_p1 / W_p2 (h part) and the gradient rows of unit j of those layers; lane 32 + j:
+// column j of the h and u parts of W_f / W_g, their gradient rows of unit j, W_o's column, and dL/dh_j — 2 x 4 x HP registers per lane.  Per step:
+// (1) upper half: read-out, d_f, d_g -> LDS; W_f^T d_f, W_g^T d_g (h and u parts: four sums) -> dL/dh(t-1)'s first terms and dL/du; (2) dL/du crosses
+// to the lower half (v_permlane32_swap), which forms d_a, d_p1, d_p2 -> LDS and the three transposed sums, which cross back; (3) the outer products
+// d (x) q_l(input) into the row accumulators, both halves in the same instructions.  Every sum in the order of the first version: same bits.
+template <int HP, bool NW, bool DX>
 __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const PgqLayout L = pgq_layout(a.H);
     const int H = L.H, T = a.T, NC = (T + kPC - 1) / kPC, H1 = H + 1, H2 = 2 * H;
     float* pl = smem;
-    float* gw = smem + pad4(L.P);              // weight-gradient accumulators in the parameter layout (lane j owns the rows of unit j)
+    float* gw = smem + pad4(L.P);              // weight gradients in the parameter layout (deposited at the end)
     float* ftab = gw + pad4(L.P);              // [64][4]  |x|, cos, sin of the chunk's steps
     float* dxb = ftab + kPC * 4;               // [64][2]  dL/dx of the chunk's steps
     float* dyb = dxb + kPC * 2;                // [64][2]  dL/dy of the chunk's steps
@@ -158,26 +192,38 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
     PgqQ Q;
     pgq_setup(pl, a, L, Q, lane);
     for (int i = lane; i < pad4(L.P); i += 64) gw[i] = 0.0f;
-    const bool vo = lane < H;
-    const int j = vo ? lane : 0;
-    const float wo0 = vo ? pl[L.ow[5] + j] : 0.0f, wo1 = vo ? pl[L.ow[5] + H + j] : 0.0f;
-    float db[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, dwo0 = 0.0f, dwo1 = 0.0f, tb0 = 0.0f, tb1 = 0.0f;
-    // the weight-gradient rows of unit j in registers (padded to 32 columns: the broadcast vectors are zero beyond H); written to `gw` at the end
-    float ga[3][33], gfu[2][64];
+    for (int i = lane; i < 16 * 32; i += 64) vb[i] = 0.0f;
+    const bool up = lane >= 32;
+    const int j0 = lane & 31;
+    const bool vo = j0 < H;
+    const int j = vo ? j0 : 0;
+    // transposed columns: lower c = 0..2: W_{a,p1,p2}[r][j] (c = 3: zeros); upper c = 0, 1: W_{f,g}[r][j], c = 2, 3: W_{f,g}[r][H + j]
+    float cT[4][HP];
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
+    for (int c = 0; c < 4; ++c) {
+        const bool col = vo && (up || c < 3);
+        const int lay = up ? 3 + (c & 1) : (c < 3 ? c : 0);
+        const int off = L.ow[lay] + j + ((up && c >= 2) ? H : 0), pitch = up ? H2 : H1;
 #pragma unroll
-        for (int k = 0; k < 33; ++k) ga[l][k] = 0.0f;
+        for (int r = 0; r < HP; ++r) cT[c][r] = (col && r < H) ? pl[off + r * pitch] : 0.0f;
+    }
+    float wsc[3];
 #pragma unroll
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < 3; ++l) wsc[l] = (vo && !up) ? pl[L.ow[l] + j * H1 + H] : 0.0f;
+    const float wo0 = (vo && up) ? pl[L.ow[5] + j] : 0.0f, wo1 = (vo && up) ? pl[L.ow[5] + H + j] : 0.0f;
+    // gradient rows of unit j: lower c = 0..2: W_{a,p1,p2} (h part; gs: the scalar input's column); upper c = 0, 1: W_{f,g} h part, c = 2, 3: u part
+    float gr[4][HP], gs[3] = {0.f, 0.f, 0.f}, dbx[3] = {0.f, 0.f, 0.f}, dwo0 = 0.0f, dwo1 = 0.0f, tb0 = 0.0f, tb1 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 64; ++k) gfu[l][k] = 0.0f;
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < HP; ++k) gr[c][k] = 0.0f;
+    const float* vn = vb + (up ? 3 * 32 : 0);  // outer products: accumulator c against slot (up ? 3 : 0) + c
     wave_lds_fence();
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const float2* xg = reinterpret_cast<const float2*>(a.x) + (size_t)b * T;
         const float2* dyg = reinterpret_cast<const float2*>(a.dy) + (size_t)b * T;
         const float* sv = a.ckpt + (size_t)b * T * kPNS * 64;
-        float dh = 0.0f;
+        float dh = 0.0f;                                       // upper half: dL/dh of unit j0
         for (int c = NC - 1; c >= 0; --c) {
             const int t0 = c * kPC, len = min(kPC, T - t0);
             wave_lds_fence();
@@ -189,96 +235,96 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
             wave_lds_fence();
             for (int tt = len - 1; tt >= 0; --tt) {
                 const int t = t0 + tt;
-                const float* s = sv + (size_t)t * kPNS * 64 + lane;
-                const float an = s[0], p1 = s[64], p2 = s[128], u = s[192], f = s[256], g = s[320], ht = s[384];
-                const float hp = t > 0 ? s[384 - kPNS * 64] : 0.0f;
+                const float* s = sv + (size_t)t * kPNS * 64 + j0;
+                // lower half: a_n, p1, p2; upper half: u, f, g, h(t), h(t-1)
+                const float r0 = s[up ? 192 : 0], r1 = s[up ? 256 : 64], r2 = s[up ? 320 : 128];
+                const float ht = s[384], hp = t > 0 ? s[384 - kPNS * 64] : 0.0f;
+                const float an = r0, p1 = r1, p2 = r2, u = r0, f = r1, g = r2;
                 const float4 in = reinterpret_cast<const float4*>(ftab)[tt];
                 const float sc[3] = {in.x, in.y, in.z};
-                // the step's quantised layer inputs (what the forward pass multiplied with) for the weight gradients
-                if (lane < 32) {
-#pragma unroll
-                    for (int l = 0; l < 5; ++l) vb[l * 32 + lane] = vo ? q16::qapply(hp, Q.a[l]) : 0.0f;
-                    vb[5 * 32 + lane] = vo ? q16::qapply(u, Q.a[3]) : 0.0f;
-                    vb[6 * 32 + lane] = vo ? q16::qapply(u, Q.a[4]) : 0.0f;
-                }
-                // read-out: dL/dh through W_o's activation mask
+                // the step's quantised layer inputs (what the forward pass multiplied with), the read-out, d_f and d_g: upper half
                 const float2 d = reinterpret_cast<const float2*>(dyb)[tt];
                 const float hoq = q16::qapply(ht, Q.a[5]);
                 dh = __builtin_fmaf(q16::qpass(ht, Q.a[5]), d.x * wo0 + d.y * wo1, dh);
                 if constexpr (NW) { dwo0 = __builtin_fmaf(d.x, hoq, dwo0); dwo1 = __builtin_fmaf(d.y, hoq, dwo1); }
-                const float dfp = vo ? (dh * (hp - g)) * (f * (1.0f - f)) : 0.0f;
-                const float dgp = vo ? (dh * (1.0f - f)) * (1.0f - g * g) : 0.0f;
+                const float dfp = (vo && up) ? (dh * (hp - g)) * (f * (1.0f - f)) : 0.0f;
+                const float dgp = (vo && up) ? (dh * (1.0f - f)) * (1.0f - g * g) : 0.0f;
                 float dhp = dh * f;
-                if (lane < 32) { vb[7 * 32 + lane] = dfp; vb[8 * 32 + lane] = dgp; }
+                if (up) {
+#pragma unroll
+                    for (int l = 0; l < 5; ++l) vb[l * 32 + j0] = vo ? q16::qapply(hp, Q.a[l]) : 0.0f;
+                    vb[5 * 32 + j0] = vo ? q16::qapply(u, Q.a[3]) : 0.0f;
+                    vb[6 * 32 + j0] = vo ? q16::qapply(u, Q.a[4]) : 0.0f;
+                    vb[7 * 32 + j0] = dfp; vb[8 * 32 + j0] = dgp;
+                }
                 wave_lds_fence();
-                // W_f^T d_f, W_g^T d_g: the h part (-> dL/dh(t-1)) and the u part (-> dL/du), each through its layer's activation mask
+                // (1) W_f^T d_f, W_g^T d_g: the h parts (-> dL/dh(t-1)) and the u parts (-> dL/du), each through its layer's activation mask
                 float du = 0.0f;
                 {
                     float ah[2] = {0.f, 0.f}, au[2] = {0.f, 0.f};
 #pragma unroll
-                    for (int l = 0; l < 2; ++l) {
-                        const float* wc = pl + L.ow[3 + l] + j;
-#pragma unroll 8
-                        for (int r = 0; r < H; ++r) {
-                            const float dv = vb[(7 + l) * 32 + r];
-                            ah[l] = __builtin_fmaf(wc[r * H2], dv, ah[l]); au[l] = __builtin_fmaf(wc[r * H2 + H], dv, au[l]);
+                    for (int q4 = 0; q4 < HP / 4; ++q4) {
+                        const float4 vf = *reinterpret_cast<const float4*>(vb + 7 * 32 + 4 * q4), vg = *reinterpret_cast<const float4*>(vb + 8 * 32 + 4 * q4);
+                        const float df4[4] = {vf.x, vf.y, vf.z, vf.w}, dg4[4] = {vg.x, vg.y, vg.z, vg.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ah[0] = __builtin_fmaf(cT[0][4 * q4 + e], df4[e], ah[0]); au[0] = __builtin_fmaf(cT[2][4 * q4 + e], df4[e], au[0]);
+                            ah[1] = __builtin_fmaf(cT[1][4 * q4 + e], dg4[e], ah[1]); au[1] = __builtin_fmaf(cT[3][4 * q4 + e], dg4[e], au[1]);
                         }
+                    }
+#pragma unroll
+                    for (int l = 0; l < 2; ++l) {
                         dhp = __builtin_fmaf(q16::qpass(hp, Q.a[3 + l]), ah[l], dhp);
                         du = __builtin_fmaf(q16::qpass(u, Q.a[3 + l]), au[l], du);
                     }
                 }
-                // u = A(a) A(p1) A(p2), A(v) = v (1 - v), A'(v) = 1 - 2 v; through the tanh of the three input gates
+                // (2) dL/du to the lower half; u = A(a) A(p1) A(p2), A(v) = v (1 - v), A'(v) = 1 - 2 v; through the tanh of the three input gates
+                const float dul = dup32(du).hi;
                 const float Aa = an * (1.0f - an), Ab = p1 * (1.0f - p1), Ac = p2 * (1.0f - p2);
                 float dpre[3];
-                dpre[0] = vo ? ((du * (1.0f - 2.0f * an)) * (Ab * Ac)) * (1.0f - an * an) : 0.0f;
-                dpre[1] = vo ? ((du * (1.0f - 2.0f * p1)) * (Aa * Ac)) * (1.0f - p1 * p1) : 0.0f;
-                dpre[2] = vo ? ((du * (1.0f - 2.0f * p2)) * (Aa * Ab)) * (1.0f - p2 * p2) : 0.0f;
-                if (lane < 32) {
+                dpre[0] = (vo && !up) ? ((dul * (1.0f - 2.0f * an)) * (Ab * Ac)) * (1.0f - an * an) : 0.0f;
+                dpre[1] = (vo && !up) ? ((dul * (1.0f - 2.0f * p1)) * (Aa * Ac)) * (1.0f - p1 * p1) : 0.0f;
+                dpre[2] = (vo && !up) ? ((dul * (1.0f - 2.0f * p2)) * (Aa * Ab)) * (1.0f - p2 * p2) : 0.0f;
+                if (!up) {
 #pragma unroll
-                    for (int l = 0; l < 3; ++l) vb[(9 + l) * 32 + lane] = dpre[l];
+                    for (int l = 0; l < 3; ++l) vb[(9 + l) * 32 + j0] = dpre[l];
                 }
                 wave_lds_fence();
                 float dsc[3] = {0.f, 0.f, 0.f};
+                {
+                    float ah[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                for (int l = 0; l < 3; ++l) {
-                    const float* wc = pl + L.ow[l] + j;
-                    float ah = 0.0f;
-#pragma unroll 8
-                    for (int r = 0; r < H; ++r) ah = __builtin_fmaf(wc[r * H1], vb[(9 + l) * 32 + r], ah);
-                    dhp = __builtin_fmaf(q16::qpass(hp, Q.a[l]), ah, dhp);
-                    if constexpr (DX) {      // the scalar input's column: sum over the units
-                        float v = vo ? pl[L.ow[l] + j * H1 + H] * dpre[l] : 0.0f;
-                        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                        dsc[l] = v * q16::qpass(sc[l], Q.a[l]);
-                    }
-                }
-                if constexpr (NW) {      // the rows of unit j: d (x) q_l(input) (dpre / dfp / dgp are 0 on lanes without a unit)
+                    for (int q4 = 0; q4 < HP / 4; ++q4)
+#pragma unroll
+                        for (int l = 0; l < 3; ++l) {
+                            const float4 v = *reinterpret_cast<const float4*>(vb + (9 + l) * 32 + 4 * q4);
+                            ah[l] = __builtin_fmaf(cT[l][4 * q4], v.x, ah[l]); ah[l] = __builtin_fmaf(cT[l][4 * q4 + 1], v.y, ah[l]);
+                            ah[l] = __builtin_fmaf(cT[l][4 * q4 + 2], v.z, ah[l]); ah[l] = __builtin_fmaf(cT[l][4 * q4 + 3], v.w, ah[l]);
+                        }
 #pragma unroll
                     for (int l = 0; l < 3; ++l) {
-                        const float4* v4 = reinterpret_cast<const float4*>(vb + l * 32);
-#pragma unroll
-                        for (int q4 = 0; q4 < 8; ++q4) {
-                            const float4 v = v4[q4];
-                            ga[l][4 * q4] = __builtin_fmaf(dpre[l], v.x, ga[l][4 * q4]); ga[l][4 * q4 + 1] = __builtin_fmaf(dpre[l], v.y, ga[l][4 * q4 + 1]);
-                            ga[l][4 * q4 + 2] = __builtin_fmaf(dpre[l], v.z, ga[l][4 * q4 + 2]); ga[l][4 * q4 + 3] = __builtin_fmaf(dpre[l], v.w, ga[l][4 * q4 + 3]);
+                        dhp = __builtin_fmaf(q16::qpass(hp, Q.a[l]), dup32(ah[l]).lo, dhp);      // (the lower half's sum, on the upper half)
+                        if constexpr (DX) {      // the scalar input's column: sum over the units
+                            float v = wsc[l] * dpre[l];
+                            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                            dsc[l] = v * q16::qpass(sc[l], Q.a[l]);
                         }
-                        ga[l][32] = __builtin_fmaf(dpre[l], q16::qapply(sc[l], Q.a[l]), ga[l][32]);
-                        db[l] += dpre[l];
                     }
+                }
+                if constexpr (NW) {      // (3) the rows of unit j: d (x) q_l(input) (the d's are 0 on lanes without a unit)
+                    const float dsel[4] = {up ? dfp : dpre[0], up ? dgp : dpre[1], up ? dfp : dpre[2], up ? dgp : 0.0f};
 #pragma unroll
-                    for (int l = 0; l < 2; ++l) {
-                        const float dv = l == 0 ? dfp : dgp;
-                        const float4* h4 = reinterpret_cast<const float4*>(vb + (3 + l) * 32);
-                        const float4* u4 = reinterpret_cast<const float4*>(vb + (5 + l) * 32);
+                    for (int q4 = 0; q4 < HP / 4; ++q4)
 #pragma unroll
-                        for (int q4 = 0; q4 < 8; ++q4) {
-                            const float4 v = h4[q4], w = u4[q4];
-                            gfu[l][4 * q4] = __builtin_fmaf(dv, v.x, gfu[l][4 * q4]); gfu[l][4 * q4 + 1] = __builtin_fmaf(dv, v.y, gfu[l][4 * q4 + 1]);
-                            gfu[l][4 * q4 + 2] = __builtin_fmaf(dv, v.z, gfu[l][4 * q4 + 2]); gfu[l][4 * q4 + 3] = __builtin_fmaf(dv, v.w, gfu[l][4 * q4 + 3]);
-                            gfu[l][32 + 4 * q4] = __builtin_fmaf(dv, w.x, gfu[l][32 + 4 * q4]); gfu[l][32 + 4 * q4 + 1] = __builtin_fmaf(dv, w.y, gfu[l][32 + 4 * q4 + 1]);
-                            gfu[l][32 + 4 * q4 + 2] = __builtin_fmaf(dv, w.z, gfu[l][32 + 4 * q4 + 2]); gfu[l][32 + 4 * q4 + 3] = __builtin_fmaf(dv, w.w, gfu[l][32 + 4 * q4 + 3]);
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const float4 v = *reinterpret_cast<const float4*>(vn + c4 * 32 + 4 * q4);
+                            gr[c4][4 * q4] = __builtin_fmaf(dsel[c4], v.x, gr[c4][4 * q4]); gr[c4][4 * q4 + 1] = __builtin_fmaf(dsel[c4], v.y, gr[c4][4 * q4 + 1]);
+                            gr[c4][4 * q4 + 2] = __builtin_fmaf(dsel[c4], v.z, gr[c4][4 * q4 + 2]); gr[c4][4 * q4 + 3] = __builtin_fmaf(dsel[c4], v.w, gr[c4][4 * q4 + 3]);
                         }
-                        db[3 + l] += dv;
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) {
+                        gs[l] = __builtin_fmaf(dpre[l], q16::qapply(sc[l], Q.a[l]), gs[l]);
+                        dbx[l] += dsel[l];
                     }
                 }
                 if constexpr (DX) {
@@ -288,7 +334,7 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
                         reinterpret_cast<float2*>(dxb)[tt] = make_float2(dsc[0] * I / am - dth * Qv / a2, dsc[0] * Qv / am + dth * I / a2);
                     }
                 }
-                dh = vo ? dhp : 0.0f;
+                dh = (vo && up) ? dhp : 0.0f;
                 wave_lds_fence();
             }
             if constexpr (DX) {
@@ -301,19 +347,22 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
     if constexpr (NW) {
         float* prow = a.partials + (size_t)blockIdx.x * (L.P + kLossCols);
         for (int o = 32; o > 0; o >>= 1) { tb0 += __shfl_xor(tb0, o); tb1 += __shfl_xor(tb1, o); }
-        if (vo) {
+        if (vo && !up) {
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
 #pragma unroll
-                for (int k = 0; k < 32; ++k) if (k < H) gw[L.ow[l] + j * H1 + k] = ga[l][k];
-                gw[L.ow[l] + j * H1 + H] = ga[l][32];
+                for (int k = 0; k < HP; ++k) if (k < H) gw[L.ow[l] + j * H1 + k] = gr[l][k];
+                gw[L.ow[l] + j * H1 + H] = gs[l];
+                gw[L.ob[l] + j] = dbx[l];
             }
+        }
+        if (vo && up) {
 #pragma unroll
-            for (int l = 0; l < 2; ++l)
+            for (int l = 0; l < 2; ++l) {
 #pragma unroll
-                for (int k = 0; k < 32; ++k) if (k < H) { gw[L.ow[3 + l] + j * H2 + k] = gfu[l][k]; gw[L.ow[3 + l] + j * H2 + H + k] = gfu[l][32 + k]; }
-#pragma unroll
-            for (int l = 0; l < 5; ++l) gw[L.ob[l] + j] = db[l];
+                for (int k = 0; k < HP; ++k) if (k < H) { gw[L.ow[3 + l] + j * H2 + k] = gr[l][k]; gw[L.ow[3 + l] + j * H2 + H + k] = gr[2 + l][k]; }
+                gw[L.ob[3 + l] + j] = dbx[l];
+            }
             gw[L.ow[5] + j] = dwo0; gw[L.ow[5] + H + j] = dwo1;
         }
         if (lane == 0) { gw[L.ob[5]] = tb0; gw[L.ob[5] + 1] = tb1; }
@@ -352,7 +401,8 @@ int pgjanet_q_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!pgjanet_q_ok(m)) return ODPD_EUNSUPPORTED;
     const size_t lds = (size_t)pgq_fwd_floats(pgq_layout(m->hidden).P) * sizeof(float);
     const int grid = pgjanet_q_rows(m, a.B);
-    return a.ckpt ? pgq_launch(st, pgq_fwd_kernel<true>, grid, lds, a) : pgq_launch(st, pgq_fwd_kernel<false>, grid, lds, a);
+    if (m->hidden <= 16) return a.ckpt ? pgq_launch(st, pgq_fwd_kernel<16, true>, grid, lds, a) : pgq_launch(st, pgq_fwd_kernel<16, false>, grid, lds, a);
+    return a.ckpt ? pgq_launch(st, pgq_fwd_kernel<32, true>, grid, lds, a) : pgq_launch(st, pgq_fwd_kernel<32, false>, grid, lds, a);
 }
 int pgjanet_q_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     if (!pgjanet_q_ok(m)) return ODPD_EUNSUPPORTED;
@@ -360,9 +410,15 @@ int pgjanet_q_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     const size_t lds = (size_t)pgq_bwd_floats(pgq_layout(m->hidden).P) * sizeof(float);
     const int grid = pgjanet_q_rows(m, a.B);
     const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
-    if (nw && dx) return pgq_launch(st, pgq_bwd_kernel<true, true>, grid, lds, a);
-    if (nw) return pgq_launch(st, pgq_bwd_kernel<true, false>, grid, lds, a);
-    return pgq_launch(st, pgq_bwd_kernel<false, true>, grid, lds, a);
+#define ODPD_PGQ_BWD(HP_)                                                                           \
+    {                                                                                              \
+        if (nw && dx) return pgq_launch(st, pgq_bwd_kernel<HP_, true, true>, grid, lds, a);        \
+        if (nw) return pgq_launch(st, pgq_bwd_kernel<HP_, true, false>, grid, lds, a);             \
+        return pgq_launch(st, pgq_bwd_kernel<HP_, false, true>, grid, lds, a);                     \
+    }
+    if (m->hidden <= 16) ODPD_PGQ_BWD(16)
+    ODPD_PGQ_BWD(32)
+#undef ODPD_PGQ_BWD
 }
 
 }  // namespace odpd
