@@ -224,6 +224,13 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
         const float2* dyg = reinterpret_cast<const float2*>(a.dy) + (size_t)b * T;
         const float* sv = a.ckpt + (size_t)b * T * kPNS * 64;
         float dh = 0.0f;                                       // upper half: dL/dh of unit j0
+        // the records of a step are fetched a step ahead (they come from HBM / the Infinity Cache: ~0.5 us that nothing in the step could cover)
+        const int o0 = up ? 192 : 0, o1 = up ? 256 : 64, o2 = up ? 320 : 128;
+        float n0, n1, n2, nht, nhp;
+        {
+            const float* s = sv + (size_t)(T - 1) * kPNS * 64 + j0;
+            n0 = s[o0]; n1 = s[o1]; n2 = s[o2]; nht = s[384]; nhp = T > 1 ? s[384 - kPNS * 64] : 0.0f;
+        }
         for (int c = NC - 1; c >= 0; --c) {
             const int t0 = c * kPC, len = min(kPC, T - t0);
             wave_lds_fence();
@@ -235,10 +242,12 @@ __global__ __launch_bounds__(64) void pgq_bwd_kernel(SeqArgs a) {
             wave_lds_fence();
             for (int tt = len - 1; tt >= 0; --tt) {
                 const int t = t0 + tt;
-                const float* s = sv + (size_t)t * kPNS * 64 + j0;
                 // lower half: a_n, p1, p2; upper half: u, f, g, h(t), h(t-1)
-                const float r0 = s[up ? 192 : 0], r1 = s[up ? 256 : 64], r2 = s[up ? 320 : 128];
-                const float ht = s[384], hp = t > 0 ? s[384 - kPNS * 64] : 0.0f;
+                const float r0 = n0, r1 = n1, r2 = n2, ht = nht, hp = nhp;
+                if (t > 0) {
+                    const float* s = sv + (size_t)(t - 1) * kPNS * 64 + j0;
+                    n0 = s[o0]; n1 = s[o1]; n2 = s[o2]; nht = hp; nhp = t > 1 ? s[384 - kPNS * 64] : 0.0f;
+                }
                 const float an = r0, p1 = r1, p2 = r2, u = r0, f = r1, g = r2;
                 const float4 in = reinterpret_cast<const float4*>(ftab)[tt];
                 const float sc[3] = {in.x, in.y, in.z};
