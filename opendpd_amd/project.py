@@ -41,6 +41,9 @@ def count_net_params(net):
     return sum(p.numel() for p in net.parameters())
 
 
+_stream_share = None      # sweeps: {(dataset, step, device, storage): (x, y) device streams} while the runs of a sweep are set up
+
+
 class DeviceFrameLoader:
     """Iterates (features, targets) batches of frames gathered ON DEVICE from the resident I/Q streams (no
     materialised frame tensor: a frame is a start offset into the stream, data_collector.py:239-247).
@@ -49,14 +52,21 @@ class DeviceFrameLoader:
     DataLoader(train_set, shuffle=True) (project.py:236) — tests/test_api_cpu.py compares it with a real DataLoader; each step is then two index_select launches on an
     overlapping-window view of the stream and no host<->device traffic."""
 
-    def __init__(self, x, y, frame_length, stride, batch_size, device, shuffle=True, storage="fp32"):
+    def __init__(self, x, y, frame_length, stride, batch_size, device, shuffle=True, storage="fp32", share_key=None):
         if storage not in ("fp32", "bf16"):
             raise ValueError(f"frame_storage={storage!r}: expected 'fp32' or 'bf16'")
         # storage="bf16": the resident streams hold bf16 (I, Q) pairs (round-to-nearest-even of the data, 4 bytes per sample); the
         # fused kernels read them in place (odpd_frames_t.sample_format) and batches gathered for the generic path are widened to fp32
         dt = torch.bfloat16 if storage == "bf16" else torch.float32
-        self.x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device).to(dt).contiguous()
-        self.y = torch.as_tensor(np.asarray(y), dtype=torch.float32).to(device).to(dt).contiguous()
+        # the K runs of a sweep train on the SAME resident streams (read-only): one upload, not K (opendpd_amd/sweep.py sets _stream_share)
+        key = None if (_stream_share is None or share_key is None) else (share_key, str(device), storage)
+        if key is not None and key in _stream_share:
+            self.x, self.y = _stream_share[key]
+        else:
+            self.x = torch.as_tensor(np.asarray(x), dtype=torch.float32).to(device).to(dt).contiguous()
+            self.y = torch.as_tensor(np.asarray(y), dtype=torch.float32).to(device).to(dt).contiguous()
+            if key is not None:
+                _stream_share[key] = (self.x, self.y)
         self.n = (len(x) - frame_length) // stride + 1
         self.batch_size, self.device, self.frame_length, self.stride = batch_size, device, frame_length, stride
         win = lambda s: torch.as_strided(s, (self.n, frame_length, 2), (2 * stride, 2, 1))
@@ -212,7 +222,7 @@ class Project:
         if self.step == "train_dpd":
             ytr, yv, yte = self.target_gain * Xtr, self.target_gain * Xv, self.target_gain * Xte
         train = DeviceFrameLoader(Xtr, ytr, self.frame_length, self.frame_stride, self.batch_size, self.device, shuffle=True,
-                                  storage=self.frame_storage)
+                                  storage=self.frame_storage, share_key=(str(D.resolve_dataset(self.dataset_name, self.dataset_path)), self.step))
         val = DataLoader(D.IQSegmentDataset(Xv, yv, nperseg=self.args.nperseg), batch_size=self.batch_size_eval, shuffle=False)
         test = DataLoader(D.IQSegmentDataset(Xte, yte, nperseg=self.args.nperseg), batch_size=self.batch_size_eval, shuffle=False)
         return (train, val, test), Xtr.shape[-1]

@@ -231,7 +231,9 @@ def train_pa_sweep(dataset_name=None, seeds=(0,), hidden_sizes=None, PA_backbone
         raise ValueError("train_pa_sweep requires dataset_name. Create a dataset first with create_dataset().")
     from . import data as D
     runs = []
-    D._share = {}      # one parse of the dataset's CSV files for all runs
+    from . import project as PJ
+    D._share = {}      # one parse of the dataset's CSV files for all runs ...
+    PJ._stream_share = {}      # ... and one upload of its train streams (read-only on the device)
     try:
         for H in (list(hidden_sizes) if hidden_sizes else [PA_hidden_size]):
             for seed in seeds:
@@ -243,6 +245,7 @@ def train_pa_sweep(dataset_name=None, seeds=(0,), hidden_sizes=None, PA_backbone
                 runs.append(run)
     finally:
         D._share = None
+        PJ._stream_share = None
     groups = {}
     for r in runs:
         groups.setdefault(_group_key(r), []).append(r)
