@@ -203,7 +203,7 @@ def test_rvtdcnn_matches_the_oracle_on_ragged_sizes(H, B, T, bits):
 
 
 @pytest.mark.parametrize("H,B,T,bits", [(11, 40, 12, 8), (1, 8, 9, 8), (7, 64, 10, 8), (16, 24, 16, 8), (24, 32, 8, 8), (32, 19, 12, 8), (9, 16, 10, 16), (20, 1300, 6, 8),
-                                         (13, 3, 130, 8)])
+                                         (13, 3, 130, 8), (17, 21, 9, 8), (31, 5, 12, 8)])
 def test_pgjanet_matches_the_oracle_on_ragged_sizes(H, B, T, bits):
     """pgjanet with its six INT_Linear (csrc/pgjanet_q.hip): forward (train = eval: no output quantiser), weight gradients and dL/dx against
     the oracle; weights partly beyond their grids, every layer's activation range narrowed (each layer on a grid of its OWN: the scales are
