@@ -102,6 +102,8 @@ odpd::Tuning& odpd::tuning() {
         v.xchg_fused = e ? atoi(e) : 1;           // 0 = the one-shot exchange as its own launch instead of the optimiser kernel's prologue
         e = getenv("ODPD_S16X");
         v.s16x = e ? atoi(e) : 1;                 // 0 = frozen-PA step of hidden 17 .. 24 on the exact-fp32 kernel (gru_s16n.hip) instead of the bf16x3 one
+        e = getenv("ODPD_LSTM_PACK");
+        v.lstm_pack = e ? atoi(e) : 1;            // 0 = lstm16_train_kernel without K-packed input slots (hidden <= 13)
         return v;
     }();
     return t;
@@ -115,6 +117,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
     if (!strcmp(key, "cascade_one_launch")) { tuning().cascade_one_launch = (int)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "xchg_fused")) { tuning().xchg_fused = (int)value; return 0; }      // (no buffer depends on it)
     if (!strcmp(key, "s16x")) { tuning().s16x = (int)value; ++g_tuning_generation; return 0; }
+    if (!strcmp(key, "lstm_pack")) { tuning().lstm_pack = (int)value; return 0; }      // (same buffers either way)
     return ODPD_EINVAL;
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }

@@ -17,9 +17,14 @@ namespace odpd {
 // registers under the 256-register cap of two waves per SIMD), the others kCkptStride
 // (r04: two steps for the vdlstm at two unit tiles as well — four left lstm16_train_kernel<true, 2> with 336 B of scratch per lane at 512 registers)
 __host__ __device__ constexpr int l16_stride(bool vd, int nt) { return vd ? 2 : kCkptStride; }
-template <bool VD, int NT>
+// PK (one unit tile, hidden <= 13: K positions 13 .. 15 of the h tile are free): three input slots ride there — vdlstm: window amplitudes 1 .. 3,
+// lstm: I, Q and the constant 1 of the bias — so the input weights of those slots are columns 13 .. 15 of the recurrent tiles (forward) and their
+// gradients columns 13 .. 15 of the recurrent gradient tiles (no tih MFMAs); vdlstm's two remaining slots (amplitude 0, the constant 1) keep ONE input
+// chunk per gate and their gradients are 32 FMAs in the transposed domain.  108 -> 84 MFMAs per 16-sequence step (vdlstm), as gru_s16.hip's s16_packgrad.
+template <bool VD, int NT, bool PK = false>
 struct L16 {
-    static constexpr int F = VD ? 4 : 2, NCH = (F + 4) / 4;
+    static_assert(!PK || NT == 1, "K-packing: one unit tile");
+    static constexpr int F = VD ? 4 : 2, NCH = PK ? (VD ? 1 : 0) : (F + 4) / 4;
     static constexpr int HH = 0;                       // (g*NT + mt)*NT + kt, g = i,f,g,o : W_hg[16mt+m][16kt+4q+e]
     static constexpr int IH = HH + 4 * NT * NT;        // g*NT + mt : slot 4e+q of [W_ig | b_ig + b_hg]
     static constexpr int HHT = IH + 4 * NT;            // (g*NT + mt)*NT + kt : W_hg[16kt+4q+e][16mt+m]
@@ -34,9 +39,9 @@ struct L16 {
     static constexpr int kXFloats = 2 * 16 * (VD ? (kChunk + 3 + 2) : kChunkPad);   // one staged stream of float2
 };
 
-template <bool VD, int NT>
+template <bool VD, int NT, bool PK = false>
 __device__ __forceinline__ float4 l16_entry(const float* pl, const LstmLayout& L, int grp, int m, int q) {
-    using T = L16<VD, NT>;
+    using T = L16<VD, NT, PK>;
     const int H = L.H, F = T::F;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -44,10 +49,18 @@ __device__ __forceinline__ float4 l16_entry(const float* pl, const LstmLayout& L
         if (grp < T::IH) {
             const int g = grp / (NT * NT), mt = (grp / NT) % NT, kt = grp % NT, o = 16 * mt + m, k = 16 * kt + 4 * q + e;
             v[e] = (o < H && k < H) ? pl[L.o_w_hh + (g * H + o) * H + k] * (g == 2 ? 1.0f : kNegLog2e) : 0.0f;
+            if (PK && o < H && k >= 13) {      // packed input slots: vdlstm amplitude k - 12; lstm I, Q, bias
+                float w;
+                if (VD) w = pl[L.o_w_ih + (g * H + o) * F + (k - 12)];
+                else w = k < 15 ? pl[L.o_w_ih + (g * H + o) * F + (k - 13)] : pl[L.o_b_ih + g * H + o] + pl[L.o_b_hh + g * H + o];
+                v[e] = w * (g == 2 ? 1.0f : kNegLog2e);
+            }
         } else if (grp < T::HHT) {
             const int g = (grp - T::IH) / NT, o = 16 * ((grp - T::IH) % NT) + m, k = 4 * e + q;
             float w = 0.0f;
-            if (e < T::NCH && o < H) {
+            if (PK) {                          // vdlstm: the one remaining chunk holds amplitude 0 (slot 0) and the bias (slot 1)
+                if (VD && e == 0 && o < H) w = q == 0 ? pl[L.o_w_ih + (g * H + o) * F] : q == 1 ? pl[L.o_b_ih + g * H + o] + pl[L.o_b_hh + g * H + o] : 0.0f;
+            } else if (e < T::NCH && o < H) {
                 if (k < F) w = pl[L.o_w_ih + (g * H + o) * F + k];
                 else if (k == F) w = pl[L.o_b_ih + g * H + o] + pl[L.o_b_hh + g * H + o];
             }
@@ -93,22 +106,40 @@ __device__ __forceinline__ void l16_slots(float2 xv, const L16Win& win, const fl
     }
 }
 
-template <bool VD, int NT>
+// K-packed operand of the recurrent tiles: the state with the three packed input slots on the lanes of quad 3 (whose units 13 .. 15 are padding: 0)
+template <bool VD>
+__device__ __forceinline__ f32x4 l16_pack(const f32x4& h, float2 xv, const L16Win& win, float oh3) {
+    f32x4 b = h;
+    if constexpr (VD) { b[1] = __builtin_fmaf(oh3, win.a[1], h[1]); b[2] = __builtin_fmaf(oh3, win.a[2], h[2]); b[3] = __builtin_fmaf(oh3, win.a[3], h[3]); }
+    else { b[1] = __builtin_fmaf(oh3, xv.x, h[1]); b[2] = __builtin_fmaf(oh3, xv.y, h[2]); b[3] = h[3] + oh3; }
+    return b;
+}
+// PK: fs[0] = vdlstm's remaining chunk (amplitude 0 on quad 0, the constant 1 on quad 1); hB = the packed recurrent operand
+template <bool VD, int NT, bool PK = false>
 __device__ __forceinline__ void l16_cell_fwd(TabPtr tl, const float (&fs)[VD ? 2 : 1], f32x4 (&h)[NT], f32x4 (&c)[NT],
-                                             f32x4 (&gi)[NT], f32x4 (&gf)[NT], f32x4 (&gg)[NT], f32x4 (&go)[NT]) {
-    using T = L16<VD, NT>;
+                                             f32x4 (&gi)[NT], f32x4 (&gf)[NT], f32x4 (&gg)[NT], f32x4 (&go)[NT], const f32x4* hB = nullptr) {
+    using T = L16<VD, NT, PK>;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[4][NT];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
-            const float4 w = tab_ld(tl, (T::IH + g * NT + mt) * 64);
-            acc[g][mt] = mfma4(w.x, fs[0], zero);
-            if constexpr (VD) acc[g][mt] = mfma4(w.y, fs[1], acc[g][mt]);
+            if constexpr (PK && !VD) acc[g][mt] = zero;
+            else {
+                const float4 w = tab_ld(tl, (T::IH + g * NT + mt) * 64);
+                acc[g][mt] = mfma4(w.x, fs[0], zero);
+                if constexpr (VD && !PK) acc[g][mt] = mfma4(w.y, fs[1], acc[g][mt]);
+            }
         }
+    if constexpr (PK) {
+        const f32x4 (&hb)[NT] = *reinterpret_cast<const f32x4(*)[NT]>(hB);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) s16n_matvec<NT>(tl, T::HH + g * NT * NT, h, acc[g]);
+        for (int g = 0; g < 4; ++g) s16n_matvec<NT>(tl, T::HH + g * NT * NT, hb, acc[g]);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s16n_matvec<NT>(tl, T::HH + g * NT * NT, h, acc[g]);
+    }
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
         gi[mt] = sigmoid4_prescaled(acc[0][mt]);
@@ -123,6 +154,7 @@ __device__ __forceinline__ void l16_cell_fwd(TabPtr tl, const float (&fs)[VD ? 2
 template <bool VD, int NT>
 struct L16Grad {
     f32x4 thh[4][NT][NT], tih[4][NT];
+    float gih[4], gbs[4];            // K-packed vdlstm: d W_ig[unit n][amplitude 0] and d bias of gate g, partial sums over the lane's four sequences
     f32x4 dwout[2][NT];              // plain head
     f32x4 tl[NT], dbl, dwo[2];       // VD: d fc_lambda weights (tile rows 0..7), their biases, d fc_out (2x8, on quads 0/1)
     float dbo[2];
@@ -139,17 +171,19 @@ struct L16Grad {
             }
         }
         dbl = z4; dwo[0] = z4; dwo[1] = z4; dbo[0] = dbo[1] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { gih[g] = 0.f; gbs[g] = 0.f; }
     }
 };
 
 // xr: staged x of this lane's sequence; VD: xr[-3..-1] is the halo (circular for the first chunk)
-template <bool VD, int NT, bool FULL>
+template <bool VD, int NT, bool FULL, bool PK = false>
 __device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const float (&oh)[4], L16Grad<VD, NT>& G, const float2* xr,
                                           const float2* tr, float* tiles, int n, int q, int tloc, int nstep, bool valid,
                                           bool last_blk, const f32x4 (&h0)[NT], const f32x4 (&c0)[NT], f32x4 (&dh)[NT],
                                           f32x4 (&dc)[NT], float (&hTn)[NT][4], float& loss_acc) {
-    using T = L16<VD, NT>;
-    constexpr int NCH = T::NCH, S = l16_stride(VD, NT);
+    using T = L16<VD, NT, PK>;
+    constexpr int NCH = VD ? 2 : 1, S = l16_stride(VD, NT);
     f32x4 h[NT], c[NT], hp_s[S][NT], cp_s[S][NT], i_s[S][NT], f_s[S][NT], g_s[S][NT], o_s[S][NT];
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) { h[kt] = h0[kt]; c[kt] = c0[kt]; }
@@ -174,6 +208,11 @@ __device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const fl
                 l16_slots<VD>(xv, win, oh, fs);
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) { hp_s[st][kt] = h[kt]; cp_s[st][kt] = c[kt]; }
+                if constexpr (PK) {      // (hp_s then holds the PACKED operand: it is what the recurrent gradient tiles are formed against)
+                    if constexpr (VD) fs[0] = __builtin_fmaf(oh[0], win.a[0], oh[1]);
+                    hp_s[st][0] = l16_pack<VD>(h[0], xv, win, oh[3]);
+                    l16_cell_fwd<VD, NT, true>(tl, fs, h, c, i_s[st], f_s[st], g_s[st], o_s[st], &hp_s[st][0]);
+                } else
                 l16_cell_fwd<VD, NT>(tl, fs, h, c, i_s[st], f_s[st], g_s[st], o_s[st]);
             }
         }
@@ -299,10 +338,15 @@ __device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const fl
                 tile_put(tile(4, kt), n, q, hp_s[st][kt]);
             }
             if constexpr (VD) tile_put(t_l, n, q, dl);
+            if constexpr (PK) { if constexpr (VD) t_f[n] = win.a[0]; }      // (amplitude 0 of sequence n: the same value from its four lanes)
+            else {
 #pragma unroll
-            for (int cch = 0; cch < NCH; ++cch) t_f[n * kTilePitch + 4 * cch + q] = fs[cch];
+                for (int cch = 0; cch < NCH; ++cch) t_f[n * kTilePitch + 4 * cch + q] = fs[cch];
+            }
             wave_lds_fence();
             float fT[4], hT[NT][4], lT[4];
+            if constexpr (PK) { if constexpr (VD) { ODPD_EACH4 fT[i] = t_f[4 * q + i]; } }      // amplitude 0 of the lane's sequences 4q .. 4q + 3
+            else
             tile_get(t_f, n, q, fT);
             if constexpr (VD) tile_get(t_l, n, q, lT);
 #pragma unroll
@@ -315,7 +359,8 @@ __device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const fl
                     tile_get(tile(g, mt), n, q, dT);
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) {
-                        G.tih[g][mt] = mfma4(dT[cc], fT[cc], G.tih[g][mt]);
+                        if constexpr (!PK) G.tih[g][mt] = mfma4(dT[cc], fT[cc], G.tih[g][mt]);
+                        else if constexpr (VD) { G.gih[g] = __builtin_fmaf(dT[cc], fT[cc], G.gih[g]); G.gbs[g] += dT[cc]; }
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) G.thh[g][mt][nt] = mfma4(dT[cc], hT[nt][cc], G.thh[g][mt][nt]);
                     }
@@ -333,10 +378,17 @@ __device__ __forceinline__ void l16_block(const SeqArgs& a, TabPtr tl0, const fl
     }
 }
 
-template <bool VD, int NT>
+template <bool VD, int NT, bool PK = false>
 __device__ __forceinline__ void l16_write_row(float* prow, const LstmLayout& L, L16Grad<VD, NT>& G, int n, int q, float loss_acc) {
     constexpr int F = L16<VD, NT>::F;
     const int H = L.H;
+    if constexpr (PK && VD) {      // amplitude 0 and the bias of unit n: the quads' partial sums (lane n of every quad holds four sequences' worth)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float wv = quad_sum(G.gih[g]), bv = quad_sum(G.gbs[g]);
+            if (q == 0 && n < H) { prow[L.o_w_ih + (g * H + n) * F] = wv; prow[L.o_b_ih + g * H + n] = bv; prow[L.o_b_hh + g * H + n] = bv; }
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
@@ -345,9 +397,16 @@ __device__ __forceinline__ void l16_write_row(float* prow, const LstmLayout& L, 
             if (i < H) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float v = G.tih[g][mt][rr];
-                    if (n < F) prow[L.o_w_ih + (g * H + i) * F + n] = v;
-                    else if (n == F) { prow[L.o_b_ih + g * H + i] = v; prow[L.o_b_hh + g * H + i] = v; }
+                    if constexpr (!PK) {
+                        const float v = G.tih[g][mt][rr];
+                        if (n < F) prow[L.o_w_ih + (g * H + i) * F + n] = v;
+                        else if (n == F) { prow[L.o_b_ih + g * H + i] = v; prow[L.o_b_hh + g * H + i] = v; }
+                    } else if (n >= 13) {      // the packed slots' gradients: columns 13 .. 15 of the recurrent gradient tile
+                        const float v = G.thh[g][0][0][rr];
+                        if (VD) prow[L.o_w_ih + (g * H + i) * F + (n - 12)] = v;
+                        else if (n < 15) prow[L.o_w_ih + (g * H + i) * F + (n - 13)] = v;
+                        else { prow[L.o_b_ih + g * H + i] = v; prow[L.o_b_hh + g * H + i] = v; }
+                    }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         if (16 * nt + n < H) prow[L.o_w_hh + (g * H + i) * H + 16 * nt + n] = G.thh[g][mt][nt][rr];
@@ -401,10 +460,10 @@ __device__ __forceinline__ void l16_stage_halo(float2* lds, const float* g, int 
 
 // hidden <= 16: two waves per SIMD (eight-wave workgroups sharing one operand table; 256 registers per wave, the VDLSTM variant
 // spills 68 of them to scratch and still gains: 32 768 x 200 lstm H14 1.29 -> 1.08 ms, vdlstm H13 1.54 -> 1.33 ms); hidden 17..32: one
-template <bool VD, int NT>
+template <bool VD, int NT, bool PK = false>
 __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void lstm16_train_kernel(SeqArgs a) {
-    using T = L16<VD, NT>;
-    constexpr int NCH = T::NCH, S = l16_stride(VD, NT);
+    using T = L16<VD, NT, PK>;
+    constexpr int NCH = VD ? 2 : 1, S = l16_stride(VD, NT);
     constexpr int kWave = T::kXFloats + 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
@@ -415,7 +474,7 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void lstm16_t
     stage_params(pl, a.params, L.P);
     {
         float4* t4 = reinterpret_cast<float4*>(tab);
-        for (int grp = wave; grp < T::NG; grp += nwb) t4[grp * 64 + lane] = l16_entry<VD, NT>(pl, L, grp, n, q);
+        for (int grp = wave; grp < T::NG; grp += nwb) t4[grp * 64 + lane] = l16_entry<VD, NT, PK>(pl, L, grp, n, q);
         __syncthreads();
     }
     const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
@@ -466,6 +525,11 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void lstm16_t
                     float fs[NCH];
                     l16_slots<VD>(xv, win, oh, fs);
                     f32x4 gi[NT], gf[NT], gg[NT], go[NT];
+                    if constexpr (PK) {
+                        if constexpr (VD) fs[0] = __builtin_fmaf(oh[0], win.a[0], oh[1]);
+                        const f32x4 hB = l16_pack<VD>(h[0], xv, win, oh[3]);
+                        l16_cell_fwd<VD, NT, true>(opaque(tl), fs, h, c, gi, gf, gg, go, &hB);
+                    } else
                     l16_cell_fwd<VD, NT>(opaque(tl), fs, h, c, gi, gf, gg, go);
                     const int t1 = t0 + tt + 1;
                     if ((t1 % S) == 0 && t1 < a.T) {
@@ -508,14 +572,14 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void lstm16_t
                 cur_chunk = chunk;
             }
             if (nstep == S)
-                l16_block<VD, NT, true>(a, tl, oh, G, xr, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, c0, dh, dc, hTn, loss_acc);
+                l16_block<VD, NT, true, PK>(a, tl, oh, G, xr, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, c0, dh, dc, hTn, loss_acc);
             else
-                l16_block<VD, NT, false>(a, tl, oh, G, xr, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, c0, dh, dc, hTn, loss_acc);
+                l16_block<VD, NT, false, PK>(a, tl, oh, G, xr, ts, tiles, n, q, tb - t0, nstep, valid, blk == a.nck - 1, h0, c0, dh, dc, hTn, loss_acc);
         }
     }
     const int P4 = L.P + kLossCols;
     __syncthreads();
-    l16_write_row<VD, NT>(smem + wave * P4, L, G, n, q, loss_acc);
+    l16_write_row<VD, NT, PK>(smem + wave * P4, L, G, n, q, loss_acc);
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * P4;
     for (int i = threadIdx.x; i < P4; i += blockDim.x) {
@@ -549,9 +613,9 @@ int64_t lstm_s16_workspace_floats(const odpd_model_t* m, int B, int T) {
     const int nt = (m->hidden + 15) / 16, S = l16_stride(m->backbone == ODPD_VDLSTM, nt);
     return (int64_t)((B + 15) / 16) * ((T + S - 1) / S) * 2 * nt * 256;
 }
-template <bool VD, int NT>
+template <bool VD, int NT, bool PK = false>
 static int launch_l16(hipStream_t st, const SeqArgs& a, int P) {
-    using T = L16<VD, NT>;
+    using T = L16<VD, NT, PK>;
     const LaunchShape ls = l16_shape(a.ngroups, NT);
     const int wave_floats = T::kXFloats + 2 * 16 * kChunkPad + T::kTiles * kTileFloats;
     size_t body = (size_t)ls.waves * wave_floats;
@@ -559,7 +623,7 @@ static int launch_l16(hipStream_t st, const SeqArgs& a, int P) {
     size_t lds = ((size_t)s16_tab_floats(T::NG) + body) * sizeof(float);
     if (lds < reduce_scratch_bytes(P, ls.waves)) lds = reduce_scratch_bytes(P, ls.waves);
     if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
-    auto k = lstm16_train_kernel<VD, NT>;
+    auto k = lstm16_train_kernel<VD, NT, PK>;
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
     return (int)hipGetLastError();
@@ -573,6 +637,8 @@ int lstm_s16_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
     const int P = lstm_layout(m->hidden, vd).P, nt = (m->hidden + 15) / 16;
     const int S = l16_stride(vd, nt);
     a.nck = (a.T + S - 1) / S;
+    if (nt == 1 && m->hidden <= 13 && tuning().lstm_pack != 0)      // K-packed input slots (positions 13 .. 15 of the h tile are free)
+        return vd ? launch_l16<true, 1, true>(st, a, P) : launch_l16<false, 1, true>(st, a, P);
     if (nt == 1) return vd ? launch_l16<true, 1>(st, a, P) : launch_l16<false, 1>(st, a, P);
     if (nt == 2) return vd ? launch_l16<true, 2>(st, a, P) : launch_l16<false, 2>(st, a, P);
     return ODPD_EUNSUPPORTED;
