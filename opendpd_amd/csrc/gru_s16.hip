@@ -711,7 +711,7 @@ __global__ __launch_bounds__(1024) void gru16_fwd_kernel(SeqArgs a) {
 }
 
 // backward from dL/dy: weight-gradient partials (NW) and / or dL/dx (DX)
-template <int FM, bool DG, bool NW, bool DX, int WAVES>
+template <int FM, bool DG, bool NW, bool DX, int WAVES, bool PACK = false>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gru16_bwd_kernel(SeqArgs a) {
     constexpr int F = S16Cfg<FM>::F, S = kCkptStride;
     constexpr int kGroups = DX ? kS16GroupsDx : kS16Groups;
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gru16_bwd_kernel(SeqArg
     float* pl = smem;
     stage_params(pl, a.params, L.P);
     float* tab = smem + pad4(L.P);
-    s16_fill_table<FM, DG>(tab, pl, L, lane, wave, nwb, kGroups);
+    s16_fill_table<FM, DG, PACK>(tab, pl, L, lane, wave, nwb, kGroups);
     TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
     float oh[4];
 #pragma unroll
@@ -767,9 +767,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gru16_bwd_kernel(SeqArg
                 cur_chunk = chunk;
             }
             if (nstep == S)
-                s16_block<FM, DG, false, NW, DX, true>(a, tl, oh, G, xs, dys, dxs, tiles, n, q, tb - t0, nstep, true, blk == a.nck - 1, h0, dh, hTn, unused);
+                s16_block<FM, DG, false, NW, DX, true, PACK>(a, tl, oh, G, xs, dys, dxs, tiles, n, q, tb - t0, nstep, true, blk == a.nck - 1, h0, dh, hTn, unused);
             else
-                s16_block<FM, DG, false, NW, DX, false>(a, tl, oh, G, xs, dys, dxs, tiles, n, q, tb - t0, nstep, true, blk == a.nck - 1, h0, dh, hTn, unused);
+                s16_block<FM, DG, false, NW, DX, false, PACK>(a, tl, oh, G, xs, dys, dxs, tiles, n, q, tb - t0, nstep, true, blk == a.nck - 1, h0, dh, hTn, unused);
         }
         if constexpr (DX) {
             if (cur_chunk >= 0) {
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gru16_bwd_kernel(SeqArg
     if constexpr (NW) {
         const int P4 = L.P + kLossCols;
         __syncthreads();
-        s16_write_row<FM, DG>(smem + wave * P4, L, G, n, q, 0.0f);
+        s16_write_row<FM, DG, s16_packgrad(PACK, NW)>(smem + wave * P4, L, G, n, q, 0.0f);
         __syncthreads();
         float* prow = a.partials + (size_t)blockIdx.x * P4;
         for (int i = threadIdx.x; i < P4; i += blockDim.x) {
@@ -924,10 +924,14 @@ static int launch_s16_bwd(hipStream_t st, const SeqArgs& a, int P) {
     const int wave_floats = (DX ? 3 : 2) * 2 * 16 * kChunkPad + (NW ? kS16Tiles * kTileFloats : 0);
     size_t lds = ((size_t)pad4(P) + s16_tab_floats(DX ? kS16GroupsDx : kS16Groups) + (size_t)waves * wave_floats) * sizeof(float);
     if (NW && lds < reduce_scratch_bytes(P, waves)) lds = reduce_scratch_bytes(P, waves);
-    auto k = gru16_bwd_kernel<FM, DG, NW, DX, WAVES>;
-    if (int e = allow_big_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * waves), lds, st, a);
-    return (int)hipGetLastError();
+    auto launch = [&](auto k) {
+        if (int e = allow_big_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * waves), lds, st, a);
+        return (int)hipGetLastError();
+    };
+    // K-packing (as the fused train kernel): the weight-gradient-only backward of a trained DPD with <= 13 units
+    if constexpr (S16Cfg<FM>::NCH == 2 && NW && !DX) { if (a.H <= 13) return launch(gru16_bwd_kernel<FM, DG, NW, DX, WAVES, true>); }
+    return launch(gru16_bwd_kernel<FM, DG, NW, DX, WAVES>);
 }
 template <int FM, bool DG>
 static int launch_s16_bwd_mode(hipStream_t st, const SeqArgs& a, int P) {
