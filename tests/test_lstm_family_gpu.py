@@ -279,3 +279,36 @@ def test_gate_parallel_train_kernel(bb, H, B, T):
             lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
     finally:
         lib.odpd_set_tuning(b"gp_max_batch", C.c_int64(-1))
+
+
+@pytest.mark.parametrize("bb,H,B,T", [("vdlstm", 13, 37, 50), ("lstm", 9, 33, 20), ("vdlstm", 5, 16, 7), ("lstm", 13, 17, 64), ("vdlstm", 1, 3, 5)])
+def test_s16_k_packed_kernel_equals_the_unpacked_one(force_s16, bb, H, B, T):
+    """hidden <= 13: lstm16_train_kernel<.., K-packed> (three input slots in the h tile's free K positions, their gradients out of the recurrent
+    gradient tiles; vdlstm's amplitude-0 / bias gradients on the VALU) against the unpacked instantiation (odpd_set_tuning("lstm_pack", 0)):
+    the same products in another summation order"""
+    from opendpd_amd import CoreModel, _lib
+    from opendpd_amd.train_funcs import FusedAdamW, fused_train_step
+    lib = _lib.load()
+    torch.manual_seed(3)
+    net = CoreModel(2, H, 1, bb).cuda()
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if "bias" in k:
+                p.uniform_(-0.3, 0.3)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = (torch.rand(B, T, 2, device="cuda", generator=g) - 0.5) * 1.6
+    x = x + 0.05 * torch.sign(x)
+    t = torch.randn(B, T, 2, device="cuda", generator=g) * 0.3
+    opt = FusedAdamW(net, lr=0.0, weight_decay=0.0)
+    assert opt.has_fused(B, T)
+    out = {}
+    try:
+        for pack in (1, 0):
+            assert lib.odpd_set_tuning(b"lstm_pack", pack) == 0
+            loss = fused_train_step(opt, x, t, "l2", 0.0)
+            out[pack] = (loss.item(), opt.grad[:-4].cpu().numpy().copy())
+    finally:
+        lib.odpd_set_tuning(b"lstm_pack", 1)
+    assert abs(out[1][0] - out[0][0]) < 1e-6 * max(1.0, out[0][0])
+    assert rel_err(out[1][1], out[0][1]) < 5e-6
+    assert np.abs(out[0][1]).max() > 0
