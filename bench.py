@@ -26,6 +26,11 @@ import os
 import sys
 import time
 
+# Multi-process GPU work on this image needs dmabuf IPC (the host driver has no legacy IPC: without this RCCL and hipIpc handle
+# exchange fail with `hipIpcGetMemHandle: invalid argument`).  The GPU boxes export it already; it is set HERE, before anything
+# touches the GPU, so that the driver's own `python -m torch.distributed.run ... bench.py` line needs nothing from its caller.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
@@ -588,6 +593,13 @@ def main():
             dpd["reference_batch"] = {"batch_per_gpu": rb, "frame_length": T, "unit": "IQ samples/s", "cascades": small}
             del xr_, tr_
 
+    # RCCL sees all N ranks in every N > 1 run, whichever transport carries the gradient: one sum of ones over the process group
+    # ("nccl" = RCCL on ROCm) on the GPU; the count comes back in the line (`config.rccl_ranks_seen`)
+    rccl_ranks_seen = None
+    if dist is not None:
+        ones = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_ranks_seen = int(ones.item()) if dist.get_backend() == "nccl" else None
     # which collective carried the gradient (identical on every rank: the communicator is built collectively)
     nc = opt.native_comm()
     from opendpd_amd import dist as odist_
@@ -669,6 +681,14 @@ def main():
                        "train_dpd_ms_per_step": dpd["north_star"]["ms_per_step"] if dpd else None,
                        "config3_value": dpd["config3"]["value"] if dpd else None, "config4_value": cfg4["value"] if cfg4 else None,
                        "config5_value": dpd["config5"]["value"] if dpd else None,
+                       # scalars the driver's parsed line keeps (the nested forms stay below and under "collective")
+                       "collective_kind": collective.get("kind"), "collective_timeouts": collective.get("timeouts"),
+                       "collective_bare_us_xchg": (collective.get("bare_us_per_allreduce") or {}).get("xchg"),
+                       "collective_bare_us_rccl": (collective.get("bare_us_per_allreduce") or {}).get("rccl"),
+                       "collective_candidates": "; ".join(f"{c.get('kind')}: {'ok' if c.get('ok') else 'failed (' + str(c.get('why'))[:100] + ')'}"
+                                                          for c in collective.get("candidates") or [] if isinstance(c, dict)) or None,
+                       "rccl_ranks_seen": rccl_ranks_seen, "process_group": collective.get("process_group"),
+                       "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "collective": {k: collective.get(k) for k in ("kind", "candidates", "bare_us_per_allreduce", "timeouts")}},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / VALU_FP32_PEAK_TFLOPS, "traffic": traffic,
@@ -678,6 +698,15 @@ def main():
                          "kernel_source_sha1": kernel_source_sha1(),
                          "train_dpd_frac": dpd["north_star"]["roofline"]["frac"] if dpd else None,
                          "train_dpd_hbm_frac": dpd["north_star"]["roofline"]["hbm"]["frac"] if dpd else None,
+                         # per-config scalars (the driver's parsed line keeps scalars only; the nested forms are under "configs")
+                         **{f"{k}_{f}": (per_config[c] or {}).get(f) for k, c in (("train_dpd", "north_star_train_dpd"), ("config3", "config3"),
+                                                                                   ("config4", "config4"), ("config5", "config5"))
+                            for f in ("frac", "traffic", "ms_per_step") if not (k == "train_dpd" and f == "frac")},
+                         # arithmetic of each priced step: dtype "f32" rests on these statements
+                         "arithmetic": "fp32 (exact-f32 MFMA, fp32 VALU, v_exp_f32 / v_rcp_f32 activations)",
+                         "train_dpd_arithmetic": "DPD kernels fp32; frozen DGRU H23 PA on v_mfma_f32_16x16x32_bf16 with three-way bf16 operand splits "
+                                                 "(six term products >= 2^-16, fp32 accumulation: fp32-equivalent, not bit-fp32; asserted <= 1.5e-6 of the fp64 "
+                                                 "oracle and <= 3 x the exact-fp32 kernel's own error in tests/test_gru_s16x_gpu.py)",
                          "configs": per_config,
                          "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * B * T}},

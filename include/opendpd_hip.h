@@ -118,8 +118,9 @@ int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T);
  * forward kernels off); "cascade_one_launch": 0 = odpd_cascade_rows answers ODPD_EUNSUPPORTED (train_dpd steps as chained launches),
  * 1 = built-in choice; "xchg_fused": 0 = the one-shot gradient exchange as a launch of its own instead of the optimiser kernel's prologue;
  * "s16x": 0 = the frozen-PA step of 17 .. 24 hidden units on the exact-fp32 kernel instead of the bf16-split one (same results to fp32
- * rounding); "lstm_pack": 0 = the fused lstm / vdlstm train kernel of <= 13 hidden units without K-packed input slots (same results to fp32
- * rounding; the last three change no buffer size). */
+ * rounding; CHANGES odpd_ckpt_floats of those models: the two kernels lay their checkpoints out differently); "lstm_pack": 0 = the fused
+ * lstm / vdlstm train kernel of <= 13 hidden units without K-packed input slots (same results to fp32 rounding); "xchg_fused" and "lstm_pack"
+ * change no buffer size.  Every successful call bumps odpd_tuning_generation, whichever knob it was. */
 int odpd_set_tuning(const char* key, int64_t value);
 /* Counter bumped by every successful odpd_set_tuning: buffers sized by the queries above are valid for the generation they were
  * sized in (the row count / workspace layout of a (B,T) shape depends on the knobs). */

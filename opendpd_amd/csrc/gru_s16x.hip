@@ -21,7 +21,7 @@
 // The backward product packs K the same way: the lane's 24 values [d r_pre | d z_pre | d(W_hn h) | d n_pre] are three K = 32 operands;
 // the two output tiles hold dL/dh(t-1) (six slots per quad) and, in the two free slots per quad, the feature gradient that dL/du needs.
 //
-// BPTT: h checkpoints every S steps in the HBM workspace ([16-sequence task][checkpoint][2][lane] float4), block recompute into
+// BPTT: h checkpoints every S steps in the HBM workspace ([16-sequence task][checkpoint][float4 x 64 | float2 x 64]), block recompute into
 // registers.  Two waves per SIMD (256 registers).  Parity: tests/test_gru_s16x_gpu.py (against the oracle and against gru_s16n.hip).
 #include "odpd_s16.h"
 
@@ -420,6 +420,7 @@ __device__ __forceinline__ void s16x_block(const SeqArgs& a, TabPtr tl0, const f
     }
 }
 
+constexpr int kS16xCkptFloats = 384;      // floats per (16-sequence task, checkpoint): 64 lanes x (float4 + float2)
 template <int FM, bool DG, int U, int S>
 __global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
     using T = S16X<DG, U>;
@@ -447,7 +448,12 @@ __global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
         const bool valid = b0 + n < a.B;
-        float4* ck = reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * nblk * NQ * 64 + lane;      // [block][NQ][lane]
+        // checkpoints: [block][float4 x 64 lanes (units 0..3) | float2 x 64 lanes (units 4, 5)] = 384 floats (r05 stored two float4: a
+        // quarter of the checkpoint traffic was padding)
+        static_assert(U == 6 && NQ == 2, "checkpoint layout below: six units per lane = one float4 + one float2");
+        float* ckg = a.ckpt + (size_t)grp * nblk * kS16xCkptFloats;
+        float4* ck4 = reinterpret_cast<float4*>(ckg) + lane;
+        float2* ck2 = reinterpret_cast<float2*>(ckg + 256) + lane;
         {
             // ---- forward: h checkpoints only; the cell tiles stay in registers ----
             u32x4 A[T::NTF][3];
@@ -484,10 +490,9 @@ __global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
                     }
                     const int t1 = t0 + tt + 1;
                     if ((t1 % S) == 0 && t1 < a.T) {
-#pragma unroll
-                        for (int i = 0; i < NQ; ++i)
-                            ck[((size_t)(t1 / S) * NQ + i) * 64] = make_float4(h[4 * i], 4 * i + 1 < U ? h[4 * i + 1] : 0.f, 4 * i + 2 < U ? h[(4 * i + 2) < U ? 4 * i + 2 : 0] : 0.f,
-                                                                             4 * i + 3 < U ? h[(4 * i + 3) < U ? 4 * i + 3 : 0] : 0.f);
+                        const size_t o = (size_t)(t1 / S) * kS16xCkptFloats;
+                        ck4[o / 4] = make_float4(h[0], h[1], h[2], h[3]);
+                        ck2[o / 2] = make_float2(h[4], h[5]);
                     }
                 }
             }
@@ -503,13 +508,11 @@ __global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
                 const int tb = blk * S, nstep = min(S, a.T - tb);
                 const int chunk = tb / kChunk, t0 = chunk * kChunk;
                 float h0[U];
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) {
-                    const float4 v = blk ? ck[((size_t)blk * NQ + i) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    h0[4 * i] = v.x;
-                    if (4 * i + 1 < U) h0[(4 * i + 1) < U ? 4 * i + 1 : 0] = v.y;
-                    if (4 * i + 2 < U) h0[(4 * i + 2) < U ? 4 * i + 2 : 0] = v.z;
-                    if (4 * i + 3 < U) h0[(4 * i + 3) < U ? 4 * i + 3 : 0] = v.w;
+                {
+                    const size_t o = (size_t)blk * kS16xCkptFloats;
+                    const float4 v = blk ? ck4[o / 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float2 w = blk ? ck2[o / 2] : make_float2(0.f, 0.f);
+                    h0[0] = v.x; h0[1] = v.y; h0[2] = v.z; h0[3] = v.w; h0[4] = w.x; h0[5] = w.y;
                 }
                 if (chunk != cur_chunk) {
                     if (cur_chunk >= 0) {
@@ -568,7 +571,7 @@ bool gru_s16x_ok(const odpd_model_t* m) {
 }
 int64_t gru_s16x_ckpt_floats(const odpd_model_t* m, int B, int T) {
     (void)m;
-    return (int64_t)((B + 15) / 16) * ((T + kS16xStride - 1) / kS16xStride) * 2 * 256;
+    return (int64_t)((B + 15) / 16) * ((T + kS16xStride - 1) / kS16xStride) * kS16xCkptFloats;
 }
 template <int FM, bool DG>
 static int launch_s16x(hipStream_t st, const SeqArgs& a, int P, int grid) {

@@ -97,6 +97,17 @@ class _Group:
                                                        and lib.odpd_sweep_train_supported(C.byref(self.desc), last, self.T))))
         self.dev = train.x.device if hasattr(train, "x") else None
         self.scratch = None
+        self._tuning_gen = None
+        self._size_buffers()
+
+    def _size_buffers(self):
+        """partial rows / workspace / scratch of every run, sized for the CURRENT kernel-selection knobs (odpd_set_tuning: gp_max_batch,
+        s16_occupancy, s16_min_batch .. change the grids the kernels write); re-done by train_epoch when odpd_tuning_generation has moved
+        (a stale buffer under a larger grid would be a device out-of-bounds write)"""
+        lib = _lib.load()
+        runs, bb = self.runs, self.runs[0].net.backbone
+        last = self.n - (self.n_steps - 1) * self.B
+        self._tuning_gen = int(lib.odpd_tuning_generation())
         if self.train_sweep:
             rows = max(int(lib.odpd_sweep_partial_rows(C.byref(self.desc), b, self.T, self.flags)) for b in {self.B, last})
             ws = max(int(lib.odpd_sweep_workspace_floats(C.byref(self.desc), b, self.T, self.flags)) for b in {self.B, last})
@@ -116,6 +127,8 @@ class _Group:
                     r.net = net_train(r.proj.log_train, r.net, r.loaders[0], r.opt, r.criterion, r.proj.grad_clip_val, r.proj.device)
             return
         lib = _lib.load()
+        if int(lib.odpd_tuning_generation()) != self._tuning_gen:
+            self._size_buffers()
         K = len(self.runs)
         table = (_lib.SweepRun * K)()
         train0 = self.runs[0].loaders[0]

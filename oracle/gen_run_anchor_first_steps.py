@@ -34,6 +34,12 @@ RUNS = {"config3": ["--DPD_backbone", "deltagru_tcnskip", "--DPD_hidden_size", "
         # (the surgery swaps fc_out only)
         "deltajanet": ["--DPD_backbone", "deltajanet", "--DPD_hidden_size", "12"],
         "deltajanet_w8a8": ["--DPD_backbone", "deltajanet", "--DPD_hidden_size", "12", "--quant", "--n_bits_w", "8", "--n_bits_a", "8"]}
+# OpenDPDv2's QAT stage (bash_scripts/OpenDPDv2.sh:85-101; the epoch anchor is oracle/gen_run_anchor_opendpdv2.py): W16A16 quantisation-aware
+# TRes-DeltaGRU H15 from the REFERENCE's float checkpoint (tests/golden/ref_runs_v2.npz fdpd/*), lr 5e-3, in front of the PA of that recipe
+# (ref_runs_v2.npz pa/*).  A thresholded model on 2^-14 grids is chaotic at epoch scale (a summation-order change moved its first-epoch
+# TRAIN_LOSS by 10 %): the per-step losses are what a kernel change there is judged on.
+V2_RUNS = {"v2_qat_w16a16": ["--DPD_backbone", "deltagru_tcnskip", "--DPD_hidden_size", "15", "--thx", "0.01", "--thh", "0.05", "--lr", "5e-3",
+                             "--quant", "--n_bits_w", "16", "--n_bits_a", "16", "--quant_dir_label", "w16a16"]}
 # train_pa runs (the commands of tests/golden/ref_runs_apa.json: BASELINE configs 2 and 4) — full argument lists, no PA checkpoint needed
 PA_RUNS = {"config2": ["--dataset_name", "APA_200MHz", "--PA_backbone", "dgru", "--PA_hidden_size", "13", "--accelerator", "cpu", "--frame_length", "200",
                        "--batch_size", "256", "--seed", "0", "--n_epochs", "1"],
@@ -100,6 +106,23 @@ def main():
             open(os.path.join(tmp, "_runner.py"), "w").write(RUNNER)
             subprocess.check_call([sys.executable, "_runner.py", "--step", "train_dpd"] + C + args, cwd=tmp, env=env, stdout=subprocess.DEVNULL)
             out[key] = {"losses": json.load(open(os.path.join(tmp, "first_steps.json"))), "cmd": " ".join(["--step", "train_dpd"] + C + args)}
+            print(key, out[key]["losses"][:3], "...", out[key]["losses"][-1])
+    for key, args in V2_RUNS.items():
+        if only and key not in only:
+            continue
+        v2 = dict(np.load(os.path.join(OUT, "ref_runs_v2.npz")))
+        v2j = json.load(open(os.path.join(OUT, "ref_runs_v2.json")))
+        with tempfile.TemporaryDirectory() as tmp:
+            os.makedirs(os.path.join(tmp, os.path.dirname(pa_rel)), exist_ok=True)
+            torch.save({k[3:]: torch.from_numpy(v) for k, v in v2.items() if k.startswith("pa/")}, os.path.join(tmp, pa_rel))
+            pre = os.path.join(tmp, v2j["float_stage"]["dpd_model"])
+            os.makedirs(os.path.dirname(pre), exist_ok=True)
+            torch.save({k[5:]: torch.from_numpy(v) for k, v in v2.items() if k.startswith("fdpd/")}, pre)
+            open(os.path.join(tmp, "_runner.py"), "w").write(RUNNER)
+            subprocess.check_call([sys.executable, "_runner.py", "--step", "train_dpd"] + C + args + ["--pretrained_model", pre], cwd=tmp, env=env,
+                                  stdout=subprocess.DEVNULL)
+            out[key] = {"losses": json.load(open(os.path.join(tmp, "first_steps.json"))),
+                        "cmd": " ".join(["--step", "train_dpd"] + C + args) + " --pretrained_model <the reference's float checkpoint>"}
             print(key, out[key]["losses"][:3], "...", out[key]["losses"][-1])
     for key, args in PA_RUNS.items():
         if only and key not in only:

@@ -75,16 +75,35 @@ def test_registry_init_is_bit_identical_to_reference(name, bb):
     from opendpd_amd import CoreModel
     from tests.golden_util import Fixture
     fx = Fixture(name)
-    torch.manual_seed(0)
-    net = CoreModel(2, fx.meta["hidden"], 1, bb, thx=fx.meta.get("thx", 0), thh=fx.meta.get("thh", 0))
-    sd = net.state_dict()
+    # orthogonal_ goes through LAPACK's QR, whose last bit depends on the thread count of the PROCESS (seen on the 256-core GPU host when this
+    # file ran after a test that had set another OpenMP team size).  The fixtures were generated at the build container's default; the
+    # construction below runs single-threaded first and, if an orthogonally initialised tensor then differs, once more at the ambient count —
+    # one of the two reproduces the fixture BIT FOR BIT.  Every tensor that is not orthogonally initialised must be bit-identical outright.
+    def construct():
+        torch.manual_seed(0)
+        return CoreModel(2, fx.meta["hidden"], 1, bb, thx=fx.meta.get("thx", 0), thh=fx.meta.get("thh", 0))
+
+    # the tensors nn.init.orthogonal_ touches: every "weight" of the recurrent core `backbone.rnn.*` (backbones/native.py:49-51, deltagru.py:51-53);
+    # heads, TCN, pgjanet's Linear gates are xavier / kaiming / default — elementwise RNG draws, exact at any thread count
+    ortho = [k for k in construct().state_dict() if k.startswith("backbone.rnn.") and "weight" in k]
+    keep = torch.get_num_threads()
+    tried = {}
+    try:
+        for nt in dict.fromkeys((keep, 1, 8)):
+            torch.set_num_threads(nt)
+            net = construct()
+            sd = net.state_dict()
+            tried[nt] = [k for k in sd if not np.array_equal(sd[k].numpy(), fx["sd/" + k])]
+            if not tried[nt]:
+                break
+    finally:
+        torch.set_num_threads(keep)
     assert list(sd.keys()) == fx.keys("sd")
-    for k in sd:
-        # (orthogonal_ goes through LAPACK's QR, whose last bit depends on the OpenMP thread count of the PROCESS: a test that ran the
-        # oracle with another count earlier in the session moves recurrent weights by one ulp — seen on the 256-core GPU host when this
-        # file runs after tests/test_sweeps_gpu.py; everything else is exact)
-        same = np.array_equal(sd[k].numpy(), fx["sd/" + k]) or (("weight_hh" in k or ".rnn.weight" in k or "W_" in k) and np.abs(sd[k].numpy() - fx["sd/" + k]).max() < 5e-7)
-        assert same, k
+    for nt, bad in tried.items():
+        assert all(k in ortho for k in bad), (nt, bad)      # only QR-initialised tensors may depend on the thread count
+    best = min(tried.values(), key=len)
+    for k in best:       # no thread count of this host reproduced LAPACK's last bit: the tensor must still be the same matrix to one ulp
+        assert np.abs(sd[k].numpy() - fx["sd/" + k]).max() < 5e-7, k
     assert sum(p.numel() for p in net.parameters()) == fx.meta["n_param"]
 
 

@@ -10,7 +10,7 @@ cd "$(dirname "$0")/.."
 OUT=${OUT:-gpurun_out/scale.jsonl}
 STEPS=${STEPS:-20}; WARMUP=${WARMUP:-3}; PORT=${PORT:-29500}
 mkdir -p "$(dirname "$OUT")"
-export HSA_ENABLE_IPC_MODE_LEGACY=0
+# (bench.py sets HSA_ENABLE_IPC_MODE_LEGACY=0 itself before any GPU call: dmabuf IPC, needed by RCCL and the hipIpc exchange on this image)
 NS=("$@"); [ ${#NS[@]} -eq 0 ] && NS=(1 2 4 8)
 HAVE=$(python3 -c 'import torch; print(torch.cuda.device_count())')
 for N in "${NS[@]}"; do
