@@ -102,6 +102,8 @@ odpd::Tuning& odpd::tuning() {
         v.xchg_fused = e ? atoi(e) : 1;           // 0 = the one-shot exchange as its own launch instead of the optimiser kernel's prologue
         e = getenv("ODPD_S16X");
         v.s16x = e ? atoi(e) : 1;                 // 0 = frozen-PA step of hidden 17 .. 24 on the exact-fp32 kernel (gru_s16n.hip) instead of the bf16x3 one
+        e = getenv("ODPD_S16X_TRAIN");
+        v.s16x_train = e ? atoi(e) : 1;           // 0 = fused train step of hidden 17 .. 24 on the exact-fp32 kernel (gru_s16n.hip) instead of the bf16x3 one
         e = getenv("ODPD_LSTM_PACK");
         v.lstm_pack = e ? atoi(e) : 1;            // 0 = lstm16_train_kernel without K-packed input slots (hidden <= 13)
         return v;
@@ -117,6 +119,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
     if (!strcmp(key, "cascade_one_launch")) { tuning().cascade_one_launch = (int)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "xchg_fused")) { tuning().xchg_fused = (int)value; return 0; }      // (no buffer depends on it)
     if (!strcmp(key, "s16x")) { tuning().s16x = (int)value; ++g_tuning_generation; return 0; }
+    if (!strcmp(key, "s16x_train")) { tuning().s16x_train = (int)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "lstm_pack")) { tuning().lstm_pack = (int)value; return 0; }      // (same buffers either way)
     return ODPD_EINVAL;
 }
@@ -253,7 +256,10 @@ extern "C" int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int
         return qat_uses_s16(m, B) ? qat_s16_ckpt_floats(m, B, T) : (int64_t)ODPD_EUNSUPPORTED;
     }
     if (family_of(m) != FAM_GRU) return ODPD_EUNSUPPORTED;
-    if (gru_uses_s16n(m, B)) return gru_s16n_ckpt_floats(m, B, T);
+    if (gru_uses_s16n(m, B)) {      // (the larger of the two layouts: the "s16x_train" knob may change between sizing and launch only with a new generation, but both fit)
+        const int64_t own = gru_s16n_ckpt_floats(m, B, T), x = gru_s16x_ok(m) ? gru_s16x_ckpt_floats(m, B, T) : 0;
+        return own > x ? own : x;
+    }
     return gru_train_uses_s16(m, B, T) ? gru_s16_workspace_floats(m, B, T) : 0;
 }
 
@@ -339,7 +345,8 @@ extern "C" int odpd_train_fwd_bwd(void* stream, const odpd_model_t* m, int loss_
     a.inv_count = (float)(1.0 / (double)count); a.loss_kind = loss_kind; a.ckpt = workspace;
     switch (family_of(m)) {
     case FAM_GRU:
-        if (gru_uses_s16n(m, B)) return gru_s16n_launch((hipStream_t)stream, m, a, 0);
+        if (gru_uses_s16n(m, B))
+            return gru_s16x_train_ok(m) ? gru_s16x_train((hipStream_t)stream, m, a, gru_s16n_rows(m, B)) : gru_s16n_launch((hipStream_t)stream, m, a, 0);
         return gru_train_uses_s16(m, B, T) ? gru_s16_train((hipStream_t)stream, m, a)
                                            : gru_family_train((hipStream_t)stream, m, a);
     case FAM_LSTM:
@@ -457,7 +464,8 @@ inline int framed_train_launch(hipStream_t st, const odpd_model_t* m, const SeqA
     if (family_of(m) == FAM_MCL) return framed_train_ok_shape(m, a.B, a.T) ? mcldnn_gp_train(st, m, a) : (int)ODPD_EUNSUPPORTED;
     const bool s16n = gru_uses_s16n(m, a.B), s16 = !s16n && gru_train_uses_s16(m, a.B, a.T);
     if ((s16 || s16n) && !a.ckpt) return ODPD_EINVAL;
-    return s16n ? gru_s16n_launch(st, m, a, 0) : (s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a));
+    if (s16n) return gru_s16x_train_ok(m) ? gru_s16x_train(st, m, a, gru_s16n_rows(m, a.B)) : gru_s16n_launch(st, m, a, 0);
+    return s16 ? gru_s16_train(st, m, a) : gru_family_train(st, m, a);
 }
 // bf16 sample storage is read by the float GRU family's fused train kernels (stage_in / ld_iq); every other path wants fp32 streams
 inline bool frames_format_ok(const odpd_model_t* m, const odpd_frames_t* fr) {

@@ -421,6 +421,54 @@ __device__ __forceinline__ void s16x_block(const SeqArgs& a, TabPtr tl0, const f
 }
 
 constexpr int kS16xCkptFloats = 384;      // floats per (16-sequence task, checkpoint): 64 lanes x (float4 + float2)
+// ---- forward pass of one 16-sequence task: h checkpoints only; the cell tiles stay in registers ----
+template <int FM, bool DG, int U, int S>
+__device__ __forceinline__ void s16x_forward_pass(const SeqArgs& a, TabPtr tl, const float (&oh)[4], float2* xs, float4* ck4, float2* ck2, int b0, int n,
+                                                  int lane) {
+    using T = S16X<DG, U>;
+    constexpr int NFS = T::NFS;
+    u32x4 A[T::NTF][3];
+    {
+        TabPtr tp = opaque(tl);
+#pragma unroll
+        for (int t = 0; t < T::NTF; ++t)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A[t][k] = tabx_ld(tp, (T::FW + 3 * t + k) * 64);
+    }
+    float h[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) h[j] = 0.0f;
+    for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+        const int len = min(kChunk, a.T - t0);
+        wave_lds_fence();
+        stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+        wave_lds_fence();
+        for (int tt = 0; tt < len; ++tt) {
+            const float2 xv = xs[n * kChunkPad + tt];
+            float fs[NFS];
+            s16x_feats<FM, U>(xv.x, xv.y, oh, fs);
+            const Split3 B = s16x_operand<U>(h, fs);
+            f32x4 acc[T::NTF];
+#pragma unroll
+            for (int t = 0; t < T::NTF; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mm6r<T::NTF>(A, B, acc);
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int sr = j, sz = U + j, sh = 2 * U + j, si = 3 * U + j;
+                const float r = sig_ps(acc[sr / 4][sr % 4]), z = sig_ps(acc[sz / 4][sz % 4]);
+                const float nn = tanh_x<FM>(__builtin_fmaf(r, acc[sh / 4][sh % 4], acc[si / 4][si % 4]));
+                h[j] = __builtin_fmaf(z, h[j] - nn, nn);
+            }
+            const int t1 = t0 + tt + 1;
+            if ((t1 % S) == 0 && t1 < a.T) {
+                const size_t o = (size_t)(t1 / S) * kS16xCkptFloats;
+                ck4[o / 4] = make_float4(h[0], h[1], h[2], h[3]);
+                ck2[o / 2] = make_float2(h[4], h[5]);
+            }
+        }
+    }
+}
+
 template <int FM, bool DG, int U, int S>
 __global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
     using T = S16X<DG, U>;
@@ -454,49 +502,7 @@ __global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
         float* ckg = a.ckpt + (size_t)grp * nblk * kS16xCkptFloats;
         float4* ck4 = reinterpret_cast<float4*>(ckg) + lane;
         float2* ck2 = reinterpret_cast<float2*>(ckg + 256) + lane;
-        {
-            // ---- forward: h checkpoints only; the cell tiles stay in registers ----
-            u32x4 A[T::NTF][3];
-            {
-                TabPtr tp = opaque(tl);
-#pragma unroll
-                for (int t = 0; t < T::NTF; ++t)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) A[t][k] = tabx_ld(tp, (T::FW + 3 * t + k) * 64);
-            }
-            float h[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) h[j] = 0.0f;
-            for (int t0 = 0; t0 < a.T; t0 += kChunk) {
-                const int len = min(kChunk, a.T - t0);
-                wave_lds_fence();
-                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
-                wave_lds_fence();
-                for (int tt = 0; tt < len; ++tt) {
-                    const float2 xv = xs[n * kChunkPad + tt];
-                    float fs[NFS];
-                    s16x_feats<FM, U>(xv.x, xv.y, oh, fs);
-                    const Split3 B = s16x_operand<U>(h, fs);
-                    f32x4 acc[T::NTF];
-#pragma unroll
-                    for (int t = 0; t < T::NTF; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    mm6r<T::NTF>(A, B, acc);
-#pragma unroll
-                    for (int j = 0; j < U; ++j) {
-                        const int sr = j, sz = U + j, sh = 2 * U + j, si = 3 * U + j;
-                        const float r = sig_ps(acc[sr / 4][sr % 4]), z = sig_ps(acc[sz / 4][sz % 4]);
-                        const float nn = tanh_x<FM>(__builtin_fmaf(r, acc[sh / 4][sh % 4], acc[si / 4][si % 4]));
-                        h[j] = __builtin_fmaf(z, h[j] - nn, nn);
-                    }
-                    const int t1 = t0 + tt + 1;
-                    if ((t1 % S) == 0 && t1 < a.T) {
-                        const size_t o = (size_t)(t1 / S) * kS16xCkptFloats;
-                        ck4[o / 4] = make_float4(h[0], h[1], h[2], h[3]);
-                        ck2[o / 2] = make_float2(h[4], h[5]);
-                    }
-                }
-            }
-        }
+        s16x_forward_pass<FM, DG, U, S>(a, tl, oh, xs, ck4, ck2, b0, n, lane);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         {
             // ---- backward ----
@@ -551,6 +557,436 @@ __global__ __launch_bounds__(512, 1) void gru16x_lossdx_kernel(SeqArgs a) {
     }
 }
 
+// =====================================================================================================================================
+// r06: the fused TRAIN step (forward + loss + BPTT with weight gradients: train_pa of the 17 .. 24-unit GRU family, e.g. the DGRU H23 PA
+// every train_dpd run of the reference trains first — bash_scripts/OpenDPDv2.sh:39-52, backbones/dgru.py:59-74) on the same pipe.
+//
+// Forward, recompute, dL/dh chain: exactly the frozen kernel's (the weights are constants within a launch: split once per launch, i.e.
+// once per optimiser step).  New: the WEIGHT GRADIENT.  The forward table [6 cell tiles | 2 fc_hid tiles] x [K = 24 hidden + 8 feature
+// slots] is one matrix, so its gradient is one GEMM over (sequence, time):
+//      d tab[tile T][row 4 q + r][k = 8 kq + i]  =  sum_{n, t}  G_{4T + r}(n, q, t) . V_i(n, kq, t)
+// with G = [d r_pre | d z_pre | d(W_hn h) | d n_pre] (the lane's 24 gate derivatives, the B operand of the dL/dh product) and V = [h(t-1) |
+// feature slots] (the lane's B operand of the cell) — every W_ih / W_hh / bias gradient is an entry of it (bias = the constant-1 slot), and
+// fc_hid's rows ride as two more M tiles on the operand [h(t) | .] one step later, as in the forward.  On the matrix pipe the contraction index
+// must sit on K = (quad, element) while the chain holds it on lane & 15 (the sequence), so both operands are TRANSPOSED first — by the matrix
+// pipe itself: with the data as the A operand (A[m = sequence][k = the lane's eight values]) and a 0 / 1 selection matrix as B, D[sequence]
+// [row] comes back on lane (row, Q) with the four sequences 4 Q .. 4 Q + 3 in its registers: the layout of an A / B operand of the
+// contraction over sequences.  A term of the three-way split is a bf16, 1.0 x it summed with zeros in fp32 is exact, and it converts back
+// to bf16 exactly: the transposition is lossless and costs no LDS traffic (a ds_read_b128 is 16 SIMD cycles nothing overlaps;
+// profiles/r05/frozen_pa.md) and no LDS capacity (the split G of one 16-sequence step alone is 11.5 KB).  K = 32 = 16 sequences x the
+// block's two time steps.  Both operands are run-time values: six term products per tile pair, smallest first, fp32 accumulation.
+// Per 16-sequence step: 33 transposing + 48 contraction MFMAs on top of the chain's 138; accumulators: 16 tiles = 64 registers -> one
+// wave per SIMD (four waves per workgroup, like gru16n_kernel's train flavour).
+// =====================================================================================================================================
+struct S16XSel { u32x4 g[2], v[2]; };
+// g[h]: rows 4 q + r of an M tile <- elements 4 h + r of quad q;   v[j]: columns 8 (kq - 2 j) + i of N tile j <- element i of quad kq
+__device__ __forceinline__ S16XSel s16x_sel(int lane) {
+    const int nn = lane & 15, kq = lane >> 4;
+    S16XSel e;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int pos = 4 * h + (nn & 3);
+        const bool on = kq == (nn >> 2);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) e.g[h][w] = (on && (pos >> 1) == w) ? (0x3F80u << (16 * (pos & 1))) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pos = nn & 7;
+        const bool on = kq == 2 * j + (nn >> 3);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) e.v[j][w] = (on && (pos >> 1) == w) ? (0x3F80u << (16 * (pos & 1))) : 0u;
+    }
+    return e;
+}
+// one transposing product: the lane's eight bf16 (one term of a split) -> two packed words = the selected row's four sequences 4 Q .. 4 Q + 3
+__device__ __forceinline__ void s16x_tr(const u32x4& x, const u32x4& sel, unsigned (&w)[2]) {
+    const f32x4 d = mfma32(x, sel, f32x4{0.f, 0.f, 0.f, 0.f});
+    w[0] = pk_bf16(d[0], d[1]);      // (exact: every d is a bf16 value)
+    w[1] = pk_bf16(d[2], d[3]);
+}
+// the lane's operand [h | features] of one step as the contraction's B operand: [N tile][term][word]
+__device__ __forceinline__ void s16x_tr_v(const Split3& B, const S16XSel& E, unsigned (&out)[2][3][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) s16x_tr(B.t[p], E.v[j], out[j][p]);
+}
+// acc += A . B with both operands split (six term products of weight >= 2^-16, smallest first)
+__device__ __forceinline__ f32x4 mm6w(const u32x4 (&A)[3], const u32x4 (&B)[3], f32x4 c) {
+    c = mfma32(A[0], B[2], c);
+    c = mfma32(A[2], B[0], c);
+    c = mfma32(A[1], B[1], c);
+    c = mfma32(A[0], B[1], c);
+    c = mfma32(A[1], B[0], c);
+    c = mfma32(A[0], B[0], c);
+    return c;
+}
+template <bool DG, int U>
+struct S16XGrad {
+    f32x4 cell[S16X<DG, U>::NTF][2];                  // [M tile][N tile]: lane (nn, Q) register R = d tab[tile][row 4 Q + R][k = 16 j + nn]
+    f32x4 hid[DG ? S16X<DG, U>::NTH : 1][2];
+    float dwo[2][U], dwf[2][8 - U];                   // fc_out: the lane's units / its feature slots (bias = the constant-1 slot)
+    __device__ __forceinline__ void zero() {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < S16X<DG, U>::NTF; ++t) { cell[t][0] = z4; cell[t][1] = z4; }
+#pragma unroll
+        for (int t = 0; t < (DG ? S16X<DG, U>::NTH : 1); ++t) { hid[t][0] = z4; hid[t][1] = z4; }
+#pragma unroll
+        for (int j = 0; j < U; ++j) dwo[0][j] = dwo[1][j] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8 - U; ++e) dwf[0][e] = dwf[1][e] = 0.0f;
+    }
+};
+
+// one block of <= S = 2 steps of the train step's backward pass (s16x_block without dL/du, with the weight gradient)
+template <int FM, bool DG, int U, int S, bool FULL>
+__device__ __forceinline__ void s16x_train_block(const SeqArgs& a, TabPtr tl0, const float (&oh)[4], const S16XSel& E, S16XGrad<DG, U>& G,
+                                                 const float2* xs, const float2* ts, int n, int q, int tloc, int nstep, bool valid,
+                                                 const float (&h0)[U], float (&dh)[U], float& loss_acc) {
+    using T = S16X<DG, U>;
+    constexpr int NFS = T::NFS;
+    static_assert(S == 2, "K = 32 of the weight-gradient contraction = 16 sequences x the block's two steps");
+    float h[U], hp_s[S][U], r_s[S][U], z_s[S][U], n_s[S][U], nh_s[S][U], hid_s[S][U], fs_s[S][NFS];
+    unsigned vc[S][2][3][2], vh[S][2][3][2];          // transposed operands: [step][N tile][term][word] of the cell's / fc_hid's V
+    unsigned gt[S][T::NTF][3][2], ht[S][DG ? T::NTH : 1][3][2];      // transposed gate / hidden-layer derivatives: [step][M tile][term][word]
+    if constexpr (!FULL) {      // steps the ragged tail block does not run contribute 0 x 0 (never 0 x an uninitialised NaN pattern)
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) { vc[st][j][p][w] = 0u; vh[st][j][p][w] = 0u; }
+#pragma unroll
+        for (int st = 0; st < S; ++st)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+#pragma unroll
+                    for (int t = 0; t < T::NTF; ++t) gt[st][t][p][w] = 0u;
+#pragma unroll
+                    for (int t = 0; t < (DG ? T::NTH : 1); ++t) ht[st][t][p][w] = 0u;
+                }
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) h[j] = h0[j];
+    TabPtr tl = opaque(tl0);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+        if (FULL || st < nstep) {
+            const float2 xv = xs[n * kChunkPad + tloc + st];
+            s16x_feats<FM, U>(xv.x, xv.y, oh, fs_s[st]);
+#pragma unroll
+            for (int j = 0; j < U; ++j) hp_s[st][j] = h[j];
+            const Split3 B = s16x_operand<U>(h, fs_s[st]);
+            s16x_tr_v(B, E, vc[st]);
+            if constexpr (DG && FULL) {
+                if (st > 0) s16x_cell<FM, DG, U, true>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[st > 0 ? st - 1 : 0]);
+                else s16x_cell<FM, DG, U, false>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[0]);
+            } else {
+                s16x_cell<FM, DG, U, false>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[st]);
+                if constexpr (DG) {      // (ragged tail block: the hidden layer of every step on an operand of its own)
+                    const Split3 B2 = s16x_operand<U>(h, fs_s[st]);
+                    s16x_hid<DG, U>(tl, B2, hid_s[st]);
+                    s16x_tr_v(B2, E, vh[st]);
+                }
+            }
+        }
+    }
+    if constexpr (DG && FULL) {
+        const Split3 B2 = s16x_operand<U>(h, fs_s[S - 1]);
+        s16x_hid<DG, U>(tl, B2, hid_s[S - 1]);
+        s16x_tr_v(B2, E, vh[S - 1]);
+        // fc_hid of step st rode on the cell operand of step st + 1: [h(st) | features of st + 1] (the constant-1 slot is what its bias needs)
+#pragma unroll
+        for (int st = 0; st + 1 < S; ++st)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) { vh[st][j][p][0] = vc[st + 1][j][p][0]; vh[st][j][p][1] = vc[st + 1][j][p][1]; }
+    }
+    tl = opaque(tl0);
+    const S16Loss lossc = s16_loss_setup(a.loss_kind == ODPD_LOSS_L2, valid ? a.inv_count : 0.0f, valid && q == 0);
+#pragma unroll
+    for (int st = S - 1; st >= 0; --st) {
+        if (FULL || st < nstep) {
+            // ---- head: y, loss, dL/dy, fc_out's gradient ----
+            float w0[U], w1[U];
+            {
+                float wv[4 * (T::NVW - 1)];
+#pragma unroll
+                for (int g = 0; g < T::NVW - 1; ++g) {
+                    const float4 v = tab_ld(tl, (T::VW + g) * 64);
+                    wv[4 * g] = v.x; wv[4 * g + 1] = v.y; wv[4 * g + 2] = v.z; wv[4 * g + 3] = v.w;
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) { w0[j] = wv[j]; w1[j] = wv[U + j]; }
+            }
+            const float4 wf = tab_ld(tl, (T::VW + T::NVW - 1) * 64);
+            float act[U];
+            if constexpr (DG) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) act[j] = relu_(hid_s[st][j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) act[j] = __builtin_fmaf(z_s[st][j], hp_s[st][j] - n_s[st][j], n_s[st][j]);      // h(t)
+            }
+            float p0 = wf.x * fs_s[st][0], p1 = wf.z * fs_s[st][0];
+            if constexpr (NFS > 1) { p0 = __builtin_fmaf(wf.y, fs_s[st][1], p0); p1 = __builtin_fmaf(wf.w, fs_s[st][1], p1); }
+#pragma unroll
+            for (int j = 0; j < U; ++j) { p0 = __builtin_fmaf(w0[j], act[j], p0); p1 = __builtin_fmaf(w1[j], act[j], p1); }
+            const float2 tv = ts[n * kChunkPad + tloc + st];
+            const float y0 = quad_sum(p0), y1 = quad_sum(p1);
+            float dy0, dy1;
+            s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+#pragma unroll
+            for (int j = 0; j < U; ++j) { G.dwo[0][j] = __builtin_fmaf(dy0, act[j], G.dwo[0][j]); G.dwo[1][j] = __builtin_fmaf(dy1, act[j], G.dwo[1][j]); }
+#pragma unroll
+            for (int e = 0; e < NFS; ++e) { G.dwf[0][e] = __builtin_fmaf(dy0, fs_s[st][e], G.dwf[0][e]); G.dwf[1][e] = __builtin_fmaf(dy1, fs_s[st][e], G.dwf[1][e]); }
+            // ---- dL/dh(t) ----
+            float dht[U];
+            if constexpr (DG) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < U; ++j) v[j] = __builtin_fmaf(dy0, w0[j], w1[j] * dy1) * relu_gate(hid_s[st][j]);
+#pragma unroll
+                for (int j = U; j < 8; ++j) v[j] = 0.0f;
+                const Split3 Bd = split8(v);
+                f32x4 acc[T::NTH];
+#pragma unroll
+                for (int t = 0; t < T::NTH; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][e] = 4 * t + e < U ? dh[4 * t + e] : 0.0f;
+                mm6<T::NTH>(tl, T::HT, Bd, acc);
+#pragma unroll
+                for (int j = 0; j < U; ++j) dht[j] = acc[j / 4][j % 4];
+                // d(hid) as rows of the weight-gradient contraction: tile t' <- elements 4 t' .. 4 t' + 3
+#pragma unroll
+                for (int t = 0; t < T::NTH; ++t)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) s16x_tr(Bd.t[p], E.g[t], ht[st][t][p]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) dht[j] = dh[j] + __builtin_fmaf(dy0, w0[j], w1[j] * dy1);
+            }
+            // ---- gate derivatives: v = [d r_pre | d z_pre | d(W_hn h) | d n_pre] ----
+            float v[4 * U];
+            f32x4 acc[T::NTO];
+#pragma unroll
+            for (int t = 0; t < T::NTO; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const float r = r_s[st][j], z = z_s[st][j], nn = n_s[st][j];
+                const float dn = dht[j] * (1.0f - z);
+                const float dnp = dn * __builtin_fmaf(-nn, nn, 1.0f);
+                const float dgh = dnp * r;
+                v[j] = dgh * nh_s[st][j] * (1.0f - r);
+                v[U + j] = (hp_s[st][j] - nn) * z * dn;
+                v[2 * U + j] = dgh;
+                v[3 * U + j] = dnp;
+                acc[j / 4][j % 4] = dht[j] * z;
+            }
+#pragma unroll
+            for (int c = 0; c < T::NM; ++c) {
+                float vcx[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vcx[i] = v[8 * c + i];
+                const Split3 Bg = split8(vcx);
+#pragma unroll
+                for (int t = 0; t < T::NTO; ++t) {
+                    f32x4 one[1] = {acc[t]};
+                    mm6<1>(tl, T::BW + 3 * (t * T::NM + c), Bg, one);
+                    acc[t] = one[0];
+                }
+                // the chunk's eight values = the rows of M tiles 2 c (elements 0 .. 3) and 2 c + 1 (elements 4 .. 7)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) s16x_tr(Bg.t[p], E.g[hh], gt[st][2 * c + hh][p]);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) dh[j] = acc[j / 4][j % 4];
+        }
+    }
+    // ---- weight gradient of the block: K = 32 = (sequence 4 Q + (i & 3), step i >> 2) ----
+#pragma unroll
+    for (int t = 0; t < T::NTF; ++t) {
+        u32x4 A[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) A[p] = u32x4{gt[0][t][p][0], gt[0][t][p][1], gt[1][t][p][0], gt[1][t][p][1]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4 Bw[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) Bw[p] = u32x4{vc[0][j][p][0], vc[0][j][p][1], vc[1][j][p][0], vc[1][j][p][1]};
+            G.cell[t][j] = mm6w(A, Bw, G.cell[t][j]);
+        }
+    }
+    if constexpr (DG) {
+#pragma unroll
+        for (int t = 0; t < T::NTH; ++t) {
+            u32x4 A[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) A[p] = u32x4{ht[0][t][p][0], ht[0][t][p][1], ht[1][t][p][0], ht[1][t][p][1]};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u32x4 Bw[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) Bw[p] = u32x4{vh[0][j][p][0], vh[0][j][p][1], vh[1][j][p][0], vh[1][j][p][1]};
+                G.hid[t][j] = mm6w(A, Bw, G.hid[t][j]);
+            }
+        }
+    }
+}
+
+// the wave's accumulators -> one row of P + kLossCols partial gradients (every parameter has exactly one writer)
+template <int FM, bool DG, int U>
+__device__ __forceinline__ void s16x_write_row(float* prow, const GruLayout& L, S16XGrad<DG, U>& G, int n, int q, float loss_acc) {
+    using T = S16X<DG, U>;
+    constexpr int F = S16Cfg<FM>::F, NFS = T::NFS;
+    const int H = L.H, OW = DG ? H + 6 : H;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kq = 2 * j + (n >> 3), i = n & 7;
+        const int ku = U * kq + i, fsl = NFS * kq + (i - U);      // the column: hidden unit ku (i < U) or feature slot fsl
+#pragma unroll
+        for (int t = 0; t < T::NTF; ++t)
+#pragma unroll
+            for (int R = 0; R < 4; ++R) {
+                constexpr int dummy = 0; (void)dummy;
+                const int s = 4 * t + R, gate = s / U, u = U * q + s % U;
+                const float val = G.cell[t][j][R];
+                if (u < H) {
+                    if (i < U) {
+                        if (gate != 3 && ku < H) prow[L.o_w_hh + (gate * H + u) * H + ku] = val;
+                    } else if (gate == 2) {
+                        if (fsl == F) prow[L.o_b_hh + 2 * H + u] = val;
+                    } else {
+                        const int g = gate == 3 ? 2 : gate;
+                        if (fsl < F) prow[L.o_w_ih + (g * H + u) * F + fsl] = val;
+                        else if (fsl == F) {
+                            prow[L.o_b_ih + g * H + u] = val;
+                            if (gate < 2) prow[L.o_b_hh + g * H + u] = val;
+                        }
+                    }
+                }
+            }
+        if constexpr (DG) {
+#pragma unroll
+            for (int t = 0; t < T::NTH; ++t)
+#pragma unroll
+                for (int R = 0; R < 4; ++R) {
+                    const int jj = 4 * t + R, u = U * q + jj;
+                    const float val = G.hid[t][j][R];
+                    if (jj < U && u < H) {
+                        if (i < U) { if (ku < H) prow[L.o_w_hid + u * H + ku] = val; }
+                        else if (fsl == F) prow[L.o_b_hid + u] = val;
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const float v = row_sum16(G.dwo[cc][j]);
+            if (n == 0 && U * q + j < H) prow[L.o_w_out + cc * OW + U * q + j] = v;
+        }
+#pragma unroll
+        for (int e = 0; e < NFS; ++e) {
+            const float v = row_sum16(G.dwf[cc][e]);
+            const int slot = NFS * q + e;
+            if (n == 0) {
+                if (DG && slot < F) prow[L.o_w_out + cc * OW + H + slot] = v;
+                else if (slot == F) prow[L.o_b_out + cc] = v;
+            }
+        }
+    }
+    const float lp = row_sum16(loss_acc);          // accumulated on the q == 0 lanes
+    if (n == 0 && q == 0) {
+        prow[L.P] = lp;
+        prow[L.P + 1] = 0.f; prow[L.P + 2] = 0.f; prow[L.P + 3] = 0.f;
+    }
+}
+
+template <int FM, bool DG, int U, int S>
+__global__ __launch_bounds__(256, 1) void gru16x_train_kernel(SeqArgs a) {
+    using T = S16X<DG, U>;
+    constexpr int F = S16Cfg<FM>::F;
+    constexpr int kWave = 2 * 2 * 16 * kChunkPad;
+    static_assert(kChunk % S == 0, "a block never straddles two staged chunks");
+    static_assert(U == 6, "checkpoint layout: six units per lane = one float4 + one float2");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const GruLayout L = gru_layout(a.H, F, DG);
+    float* tab = smem;
+    float* pl = tab + s16_tab_floats(T::NG);
+    stage_params(pl, a.params, L.P);
+    s16x_fill_table<FM, DG, U>(tab, pl, L, lane, wave, nwb);
+    const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    const S16XSel E = s16x_sel(lane);
+    float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* ts = xs + 16 * kChunkPad;
+    S16XGrad<DG, U> G;
+    G.zero();
+    float loss_acc = 0.0f;
+    const int nwaves = gridDim.x * nwb, nblk = (a.T + S - 1) / S;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        const bool valid = b0 + n < a.B;
+        float* ckg = a.ckpt + (size_t)grp * nblk * kS16xCkptFloats;
+        float4* ck4 = reinterpret_cast<float4*>(ckg) + lane;
+        float2* ck2 = reinterpret_cast<float2*>(ckg + 256) + lane;
+        s16x_forward_pass<FM, DG, U, S>(a, tl, oh, xs, ck4, ck2, b0, n, lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        float dh[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) dh[j] = 0.0f;
+        int cur_chunk = -1;
+        for (int blk = nblk - 1; blk >= 0; --blk) {
+            const int tb = blk * S, nstep = min(S, a.T - tb);
+            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            float h0[U];
+            {
+                const size_t o = (size_t)blk * kS16xCkptFloats;
+                const float4 v = blk ? ck4[o / 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float2 w = blk ? ck2[o / 2] : make_float2(0.f, 0.f);
+                h0[0] = v.x; h0[1] = v.y; h0[2] = v.z; h0[3] = v.w; h0[4] = w.x; h0[5] = w.y;
+            }
+            if (chunk != cur_chunk) {
+                wave_lds_fence();
+                const int len = min(kChunk, a.T - t0);
+                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+                stage_in<16>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+                wave_lds_fence();
+                cur_chunk = chunk;
+            }
+            if (nstep == S) s16x_train_block<FM, DG, U, S, true>(a, tl, oh, E, G, xs, ts, n, q, tb - t0, nstep, valid, h0, dh, loss_acc);
+            else s16x_train_block<FM, DG, U, S, false>(a, tl, oh, E, G, xs, ts, n, q, tb - t0, nstep, valid, h0, dh, loss_acc);
+        }
+    }
+    // one row per wave in LDS (the tables are dead), summed into the workgroup's row of partials
+    const int P4 = L.P + kLossCols;
+    __syncthreads();
+    s16x_write_row<FM, DG, U>(smem + wave * P4, L, G, n, q, loss_acc);
+    __syncthreads();
+    float* prow = a.partials + (size_t)blockIdx.x * P4;
+    for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+        float v = smem[i];
+        for (int wv = 1; wv < nwb; ++wv) v += smem[wv * P4 + i];
+        prow[i] = v;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
@@ -585,6 +1021,35 @@ static int launch_s16x(hipStream_t st, const SeqArgs& a, int P, int grid) {
     if (int e = allow_big_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
     return (int)hipGetLastError();
+}
+bool gru_s16x_train_ok(const odpd_model_t* m) { return gru_s16x_ok(m) && tuning().s16x_train != 0; }
+template <int FM, bool DG>
+static int launch_s16x_train(hipStream_t st, const SeqArgs& a, int P, int grid) {
+    using T = S16X<DG, 6>;
+    constexpr int kWave = 2 * 2 * 16 * kChunkPad, kWaves = 4;
+    size_t body = (size_t)kWaves * kWave;
+    if (body < (size_t)pad4(P)) body = pad4(P);
+    size_t lds = ((size_t)s16_tab_floats(T::NG) + body) * sizeof(float);
+    if (lds < reduce_scratch_bytes(P, kWaves)) lds = reduce_scratch_bytes(P, kWaves);
+    if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+    auto k = gru16x_train_kernel<FM, DG, 6, kS16xStride>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * kWaves), lds, st, a);
+    return (int)hipGetLastError();
+}
+// fused train step (forward + loss + BPTT with weight gradients); one row of partials per workgroup, grid = gru_s16n_rows(m, B): the same rows
+// (and row layout) as gru16n_kernel's train flavour, so the reduction / optimiser launches behind it are unchanged
+int gru_s16x_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int grid) {
+    int FM; bool DG;
+    if (!s16x_cfg(m, FM, DG) || !gru_s16x_train_ok(m)) return ODPD_EUNSUPPORTED;
+    if (!a0.ckpt || !a0.partials || !a0.target) return ODPD_EINVAL;
+    SeqArgs a = a0;
+    a.ngroups = (a.B + 15) / 16;
+    const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
+    if (FM == FEAT_RAW2) return launch_s16x_train<FEAT_RAW2, false>(st, a, P, grid);
+    if (FM == FEAT_DGRU6) return launch_s16x_train<FEAT_DGRU6, true>(st, a, P, grid);
+    if (FM == FEAT_Q4) return launch_s16x_train<FEAT_Q4, false>(st, a, P, grid);
+    return launch_s16x_train<FEAT_A4, false>(st, a, P, grid);
 }
 // frozen-PA loss step; the grid (= loss rows the host reduces) is gru_s16n_rows(m, B), the same as the exact-fp32 kernel's
 int gru_s16x_lossdx(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int grid) {

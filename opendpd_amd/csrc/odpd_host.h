@@ -54,7 +54,7 @@ inline LaunchShape persistent_shape(int ngroups, int waves_per_cu, int max_waves
 }
 
 // run-time tuning knobs (odpd_set_tuning; initialised from $ODPD_S16_MIN_BATCH / $ODPD_S16_OCCUPANCY)
-struct Tuning { long s16_min_batch; int s16_occupancy; long gp_max_batch; int cascade_one_launch; int xchg_fused; int s16x; int lstm_pack; };
+struct Tuning { long s16_min_batch; int s16_occupancy; long gp_max_batch; int cascade_one_launch; int xchg_fused; int s16x; int lstm_pack; int s16x_train; };
 Tuning& tuning();
 
 // ---- parameter layouts (flattened named_parameters() order of the reference modules) -------------
@@ -286,6 +286,9 @@ int64_t gru_s16n_ckpt_floats(const odpd_model_t* m, int B, int T);
 bool gru_s16x_ok(const odpd_model_t* m);
 int gru_s16x_lossdx(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int grid);
 int64_t gru_s16x_ckpt_floats(const odpd_model_t* m, int B, int T);
+// ... and the fused train step of those models on the same pipe (r06; "s16x_train" knob), rows = gru_s16n_rows, workspace = gru_s16x_ckpt_floats
+bool gru_s16x_train_ok(const odpd_model_t* m);
+int gru_s16x_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int grid);
 // optim.hip: clip + AdamW launch that also records loss = grad[P] * inv_count into loss_out (nullable)
 int launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t step,
                       double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, float* norm_out,

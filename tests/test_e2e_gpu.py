@@ -796,8 +796,12 @@ def test_deltajanet_train_dpd_first_steps_match_the_reference(apa_workdir, steps
     _check_first_steps(key, steps_seen["losses"], n_exact=20, rel_exact=2e-6 if not quant else 5e-5, rel_all=2e-6 if not quant else 5e-5)
 
 
-# bounds of the W16A16 first-steps check (set from the first measured run, see the print of _check_first_steps)
-V2_QAT_EXACT_STEPS, V2_QAT_REL_EXACT, V2_QAT_REL_ALL = 3, 1e-4, 5e-2
+# bounds of the W16A16 first-steps check.  Measured (r06, gpurun_out/r06a): step 1 deviates by 2.4e-4, steps 2 .. 20 by 4e-4 .. 7.3e-3 of the
+# reference's loss — NOT rounding level from the first step on: 32-bit products summed in fp32 land within rounding reach of a 2^-14 grid
+# boundary somewhere among the 64 x 200 x 15 state values of the very first forward pass, the quantised value moves by one grid step and the
+# recurrence carries it (tests/test_quant_gpu.py bounds the same effect per output: <= 2.5 LSB on <= 8 %).  The bounds are ~3 x the measured gaps;
+# a kernel change that breaks the stage moves these by orders of magnitude (the epoch row's 5 % would not see a 1 % regression).
+V2_QAT_EXACT_STEPS, V2_QAT_REL_EXACT, V2_QAT_REL_ALL = 1, 8e-4, 2.2e-2
 
 
 def _check_first_steps(key, losses, n_exact, rel_exact=1e-6, rel_all=2e-3):
