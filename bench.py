@@ -432,6 +432,43 @@ def main():
                                      "frac": ALGO_BYTES_PER_SAMPLE * B4 * T * n4 / float(el4_t.item()) / 1e9 / HBM_PEAK_GBS}}}
         del net4, opt4_, x4, t4
 
+    # side figure (r06): train_pa of the PA every train_dpd run trains first — DGRU H23 (2 751 parameters; bash_scripts/OpenDPDv2.sh:39-52) —
+    # at 32 768 frames per GPU: the fused train step on the bf16 matrix pipe with three-way operand splits (csrc/gru_s16x.hip,
+    # gru16x_train_kernel), and the same step on the exact-fp32 kernel it replaced (knob "s16x_train" = 0) beside it
+    h23 = None
+    if not args.no_cascade and not args.materialized:
+        from opendpd_amd import _lib as _l
+        B23 = min(B, 32768)
+        n23 = max(3, min(args.steps, 10))
+        x23 = FrameBatch(xs_, ys_, torch.arange(B23, device=dev, dtype=torch.int64), T, 1)
+        res23 = {}
+        for knob in (1, 0):
+            _l.load().odpd_set_tuning(b"s16x_train", knob)
+            torch.manual_seed(23)
+            o23 = FusedAdamW(CoreModel(2, 23, 1, "dgru").to(dev), lr=5e-4)
+            el23, k23, loss23 = min((run_steps(o23, x23, None, n23, 2, world * B23 * T * 2, dist, events=True) for _ in range(2)), key=lambda r: r[0])
+            e_t = torch.tensor([el23], device=dev, dtype=torch.float64)
+            if dist is not None:
+                dist.all_reduce(e_t, op=dist.ReduceOp.MAX)
+            res23[knob] = (float(e_t.item()), k23, loss23, o23.backbone.n_flat)
+            del o23
+        _l.load().odpd_set_tuning(b"s16x_train", 1)
+        el23, k23, loss23, np23 = res23[1]
+        tf23 = flops_train_pa_dgru(23) * B23 * T / (k23 * 1e-3) / 1e12
+        h23 = {"workload": f"train_pa DGRU H23 ({np23} params), T={T}, {B23} frames per GPU, fused fwd+MSE+BPTT+clip200+AdamW step", "batch_per_gpu": B23,
+               "value": world * B23 * T * n23 / el23, "unit": "IQ samples/s", "ms_per_step": 1e3 * el23 / n23, "loss": loss23,
+               "arithmetic": "v_mfma_f32_16x16x32_bf16 on three-way bf16 operand splits, six term products per product (>= 2^-16), fp32 accumulation, weight "
+                             "gradient with both operands split: fp32-equivalent (parameter gradients <= 1.5e-6 of the fp64 oracle, tests/test_gru_s16x_train_gpu.py)",
+               "exact_fp32_kernel": {"kernel": "gru16n_kernel<DGRU6, fused train> (v_mfma_f32_16x16x4_f32)", "ms_per_step": 1e3 * res23[0][0] / n23,
+                                     "kernel_ms": res23[0][1], "loss": res23[0][2]},
+               "roofline": {"bound": "mfma", "achieved": tf23, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf23 / VALU_FP32_PEAK_TFLOPS,
+                            "algorithmic_flops_per_sample": flops_train_pa_dgru(23), "kernel": "gru16x_train_kernel<DGRU6> (bf16x3 matrix pipe)", "kernel_ms": k23,
+                            "traffic": measured_traffic(f"dgru_h23_b{B23}_t{T}"),
+                            "note": "priced against the fp32 roof (157.3 TFLOP/s) because the arithmetic is fp32-equivalent; the instructions run on the bf16 pipe",
+                            "hbm": {"achieved": ALGO_BYTES_PER_SAMPLE * B23 * T / (k23 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": ALGO_BYTES_PER_SAMPLE * B23 * T / (k23 * 1e-3) / 1e9 / HBM_PEAK_GBS}}}
+        del x23
+
     # side figure: the reference batch size (launch/latency-bound regime)
     ref = None
     if args.ref_batch and args.ref_batch != B:
@@ -665,6 +702,7 @@ def main():
         per_config = {"north_star_train_dpd": brief(dpd["north_star"], f"train_dpd_dgru13_dgru23_b{B}_t{T}") if dpd else None,
                       "config3": brief(dpd["config3"], f"train_dpd_tres15_dgru23_b{B}_t{T}") if dpd else None,
                       "config4": brief(cfg4, "") if cfg4 else None,
+                      "train_pa_h23": brief(h23, "") if h23 else None,
                       "config5": brief(dpd["config5"], f"train_dpd_qgru10_dgru23_b{B}_t{T}") if dpd else None}
         out = {
             "metric": "iq_samples_per_sec_train", "value": value, "unit": "IQ samples/s", "n_gpus": world,
@@ -681,6 +719,8 @@ def main():
                        "train_dpd_ms_per_step": dpd["north_star"]["ms_per_step"] if dpd else None,
                        "config3_value": dpd["config3"]["value"] if dpd else None, "config4_value": cfg4["value"] if cfg4 else None,
                        "config5_value": dpd["config5"]["value"] if dpd else None,
+                       "train_pa_h23_value": h23["value"] if h23 else None,
+                       "train_pa_h23_value_exact_fp32_kernel": (world * h23["batch_per_gpu"] * T / (h23["exact_fp32_kernel"]["ms_per_step"] * 1e-3)) if h23 else None,
                        # scalars the driver's parsed line keeps (the nested forms stay below and under "collective")
                        "collective_kind": collective.get("kind"), "collective_timeouts": collective.get("timeouts"),
                        "collective_bare_us_xchg": (collective.get("bare_us_per_allreduce") or {}).get("xchg"),
@@ -700,7 +740,7 @@ def main():
                          "train_dpd_hbm_frac": dpd["north_star"]["roofline"]["hbm"]["frac"] if dpd else None,
                          # per-config scalars (the driver's parsed line keeps scalars only; the nested forms are under "configs")
                          **{f"{k}_{f}": (per_config[c] or {}).get(f) for k, c in (("train_dpd", "north_star_train_dpd"), ("config3", "config3"),
-                                                                                   ("config4", "config4"), ("config5", "config5"))
+                                                                                   ("config4", "config4"), ("config5", "config5"), ("train_pa_h23", "train_pa_h23"))
                             for f in ("frac", "traffic", "ms_per_step") if not (k == "train_dpd" and f == "frac")},
                          # arithmetic of each priced step: dtype "f32" rests on these statements
                          "arithmetic": "fp32 (exact-f32 MFMA, fp32 VALU, v_exp_f32 / v_rcp_f32 activations)",
@@ -714,6 +754,7 @@ def main():
             "bf16_frame_storage": bf16_frames,
             "reference_batch": ref,
             "config4": cfg4,
+            "train_pa_h23": h23,
             "reference_shapes": ref_shapes,
             "train_dpd": dpd,
             "collective": collective,

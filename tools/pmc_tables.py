@@ -39,6 +39,8 @@ for k, (calls, us) in sorted(cst.items(), key=lambda kv: -kv[1][1] * kv[1][0]):
     if us < 50:
         continue
     s, f, w = sq.get(k, {}), fe.get(k, {}).get("FETCH_SIZE"), wr.get(k, {}).get("WRITE_SIZE")
+    if not s or f is None or w is None:
+        continue
     rows.append({"kernel": k, "calls": calls, "us": us, "busy": s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (s["GRBM_GUI_ACTIVE"] / 8), "valu": s["SQ_INSTS_VALU"] / 1024,
                  "wait": s["SQ_WAIT_INST_ANY"] / s["SQ_WAVE_CYCLES"], "fetch_kb": f, "write_kb": w, "hbm": (2 * f + w) * 1024, "raw": (f + w) * 1024})
 short = lambda k: k.replace("void ", "").split("(odpd::SeqArgs")[0].split("(float const*")[0]
@@ -75,6 +77,8 @@ e = d["dgru_h13_b65536_t200"]
 e.update({"FETCH_SIZE_KB": round(hfe, 1), "WRITE_SIZE_KB": round(hwr, 1), "hbm_bytes_per_launch_raw": (hfe + hwr) * 1024, "hbm_bytes_per_launch": (2 * hfe + hwr) * 1024,
           "source_files": list(bench.HEADLINE_SOURCES), "source_sha1": bench.kernel_source_sha1(bench.HEADLINE_SOURCES), "avg_us": round(hst[hk][1], 1), "calls": hst[hk][0]})
 d["vdlstm_h13_b32768_t200"] = entry(["lstm16_train_kernel"], ("lstm_s16.hip",) + base, " BPTT checkpoints (h, c) every two steps; algorithmic bytes 16 B x 32768 x 200 = 104.9 MB.")
+if any("gru16x_train_kernel" in r["kernel"] for r in rows):      # (r06: train_pa DGRU H23 at 32 768 x 200 on the bf16 matrix pipe)
+    d["dgru_h23_b32768_t200"] = entry(["gru16x_train_kernel"], ("gru_s16x.hip",) + base, " two-step h checkpoints of 24 units (float4 + float2 per lane); algorithmic bytes 104.9 MB.")
 d["train_dpd_dgru13_dgru23_b65536_t200"] = entry(["gru16_fwd_kernel", "gru16x_lossdx_kernel", "gru16_bwd_kernel"], ("gru_s16.hip", "gru_s16x.hip") + base,
                                                  " The frozen-PA kernel's share = its two-step h checkpoints (839 MB written, read back once) + u, target, dL/du.")
 d["train_dpd_tres15_dgru23_b65536_t200"] = entry(["delta16_fwd_kernel", "gru16x_lossdx_kernel", "delta16_bwd_kernel", "tres_skip_wgrad_kernel"], ("delta_s16.hip", "gru_s16x.hip") + base,
