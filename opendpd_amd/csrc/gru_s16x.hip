@@ -769,6 +769,21 @@ __device__ __forceinline__ void s16x_train_block(const SeqArgs& a, TabPtr tl0, c
                 for (int t = 0; t < T::NTH; ++t)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) s16x_tr(Bd.t[p], E.g[t], ht[st][t][p]);
+                if (st == 0) {      // both steps' rows are there: fc_hid's share of the block's weight gradient (K = 32 = (sequence 4 Q + (i & 3), step i >> 2))
+#pragma unroll
+                    for (int t = 0; t < T::NTH; ++t) {
+                        u32x4 A[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) A[p] = u32x4{ht[0][t][p][0], ht[0][t][p][1], ht[1][t][p][0], ht[1][t][p][1]};
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            u32x4 Bw[3];
+#pragma unroll
+                            for (int p = 0; p < 3; ++p) Bw[p] = u32x4{vh[0][j][p][0], vh[0][j][p][1], vh[1][j][p][0], vh[1][j][p][1]};
+                            G.hid[t][j] = mm6w(A, Bw, G.hid[t][j]);
+                        }
+                    }
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < U; ++j) dht[j] = dh[j] + __builtin_fmaf(dy0, w0[j], w1[j] * dy1);
@@ -807,38 +822,25 @@ __device__ __forceinline__ void s16x_train_block(const SeqArgs& a, TabPtr tl0, c
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) s16x_tr(Bg.t[p], E.g[hh], gt[st][2 * c + hh][p]);
+                if (st == 0) {      // the two tiles' share of the block's weight gradient, issued here so that it runs beside the next chunk's split
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int t = 2 * c + hh;
+                        u32x4 A[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) A[p] = u32x4{gt[0][t][p][0], gt[0][t][p][1], gt[1][t][p][0], gt[1][t][p][1]};
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            u32x4 Bw[3];
+#pragma unroll
+                            for (int p = 0; p < 3; ++p) Bw[p] = u32x4{vc[0][j][p][0], vc[0][j][p][1], vc[1][j][p][0], vc[1][j][p][1]};
+                            G.cell[t][j] = mm6w(A, Bw, G.cell[t][j]);
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) dh[j] = acc[j / 4][j % 4];
-        }
-    }
-    // ---- weight gradient of the block: K = 32 = (sequence 4 Q + (i & 3), step i >> 2) ----
-#pragma unroll
-    for (int t = 0; t < T::NTF; ++t) {
-        u32x4 A[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) A[p] = u32x4{gt[0][t][p][0], gt[0][t][p][1], gt[1][t][p][0], gt[1][t][p][1]};
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            u32x4 Bw[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) Bw[p] = u32x4{vc[0][j][p][0], vc[0][j][p][1], vc[1][j][p][0], vc[1][j][p][1]};
-            G.cell[t][j] = mm6w(A, Bw, G.cell[t][j]);
-        }
-    }
-    if constexpr (DG) {
-#pragma unroll
-        for (int t = 0; t < T::NTH; ++t) {
-            u32x4 A[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) A[p] = u32x4{ht[0][t][p][0], ht[0][t][p][1], ht[1][t][p][0], ht[1][t][p][1]};
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                u32x4 Bw[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) Bw[p] = u32x4{vh[0][j][p][0], vh[0][j][p][1], vh[1][j][p][0], vh[1][j][p][1]};
-                G.hid[t][j] = mm6w(A, Bw, G.hid[t][j]);
-            }
         }
     }
 }
