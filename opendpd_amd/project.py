@@ -120,31 +120,86 @@ class ReduceLROnPlateau:
 
 
 class CsvLogger:
-    """History / best CSV files with the reference's formatting (loggers.py:119-163)."""
+    """History / best CSV files with the reference's formatting (loggers.py:119-163).
+
+    The reference REWRITES the whole history file through pandas after every epoch (loggers.py:131-140).  The bytes of that file are header +
+    one line per epoch and earlier lines never change, so the same file is produced by appending the new line — `csv.writer` with pandas'
+    own dialect (minimal quoting, "\n") on values that are already strings or integers (tests/test_api_cpu.py compares the two writers byte
+    for byte); anything else in a row (a float32 scalar, None, a changed column set) falls back to the pandas rewrite.
+    `defer_checkpoints` (sweeps, opendpd_amd/sweep.py): an improved model is remembered as a device-side copy of its state dict and written
+    once, by `flush()`, instead of one `torch.save` per improving epoch — the file is the one the last improving epoch would have written."""
 
     def __init__(self, path_save_best, path_log_best, path_log_hist, precision=8, writes=True):
         self.path_save_best, self.path_log_best, self.path_log_hist, self.precision = path_save_best, path_log_best, path_log_hist, precision
         self.headers, self.rows, self.best_val_metric = [], [], None
         self.writes = writes          # data-parallel runs: every rank keeps the bookkeeping, rank 0 alone touches the files
+        self.defer_checkpoints = False
+        self._pending = None          # (net, {key: device copy}) of the best model not yet on disk
+        self._hist_ok = False         # the history file on disk = header + self.rows[:-1], written by the fast writer
+
+    @staticmethod
+    def _plain(row):
+        return all(type(v) in (str, int) or (isinstance(v, np.integer) and not isinstance(v, np.bool_)) for v in row)
+
+    @staticmethod
+    def _write_rows(path, mode, lines):
+        import csv
+        with open(path, mode, newline="") as f:
+            csv.writer(f, lineterminator="\n", quoting=csv.QUOTE_MINIMAL).writerows(lines)
 
     def write_log(self, stat):
-        self.headers = list(stat.keys())
+        headers = list(stat.keys())
         fmt = "{:." + str(self.precision) + "f}"
-        self.rows.append([fmt.format(v) if isinstance(v, float) else v for v in stat.values()])
-        if self.writes:
-            pd.DataFrame(self.rows, columns=self.headers).to_csv(self.path_log_hist, index=False)
+        row = [fmt.format(v) if isinstance(v, float) else v for v in stat.values()]
+        same_cols = headers == self.headers
+        self.headers = headers
+        self.rows.append(row)
+        if not self.writes:
+            return
+        if self._plain(row) and self._plain(headers) and all(isinstance(h, str) for h in headers):
+            if self._hist_ok and same_cols and len(self.rows) > 1:
+                self._write_rows(self.path_log_hist, "a", [row])
+                return
+            if len(self.rows) == 1 or all(self._plain(r) and len(r) == len(headers) for r in self.rows):
+                self._write_rows(self.path_log_hist, "w", [headers] + self.rows)
+                self._hist_ok = True
+                return
+        self._hist_ok = False
+        pd.DataFrame(self.rows, columns=self.headers).to_csv(self.path_log_hist, index=False)
 
     def _write_best(self, idx):
         if self.writes:
-            pd.DataFrame([self.rows[idx]], columns=self.headers).to_csv(self.path_log_best, index=False)
+            if self._plain(self.rows[idx]) and all(isinstance(h, str) for h in self.headers):
+                self._write_rows(self.path_log_best, "w", [self.headers, self.rows[idx]])
+            else:
+                pd.DataFrame([self.rows[idx]], columns=self.headers).to_csv(self.path_log_best, index=False)
 
     def save_best_model(self, net, epoch, val_stat, metric_name):
         crit = val_stat[metric_name]
         if epoch == 0 or crit < self.best_val_metric:
             self.best_val_metric = crit
             if self.writes:
-                torch.save(net.state_dict(), self.path_save_best)
+                if self.defer_checkpoints:
+                    self._pending = (net, {k: v.detach().clone() for k, v in net.state_dict().items()})
+                else:
+                    torch.save(net.state_dict(), self.path_save_best)
             self._write_best(epoch)
+
+    def flush(self):
+        """write the remembered best model: its values are copied into the live module for the duration of the `torch.save` call, so that
+        the file has the layout a save at that epoch had (every parameter a view into the one flat storage), then the live values return"""
+        if self._pending is None:
+            return
+        net, best = self._pending
+        self._pending = None
+        with torch.no_grad():
+            sd = net.state_dict()
+            live = {k: v.detach().clone() for k, v in sd.items()}
+            for k, v in sd.items():
+                v.copy_(best[k])
+            torch.save(net.state_dict(), self.path_save_best)
+            for k, v in net.state_dict().items():
+                v.copy_(live[k])
 
 
 class Project:

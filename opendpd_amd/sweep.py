@@ -150,10 +150,12 @@ class _Group:
                                         float(g0["weight_decay"]), float(self.runs[0].proj.grad_clip_val or 0.0), self.flags,
                                         C.c_void_p(self.scratch.data_ptr()))
         _lib.check(rc, "odpd_train_epoch_sweep")
-        for r in self.runs:
+        # the K epoch means: each the reduction its solo run makes (train_funcs.net_train), queued back to back and read with ONE synchronisation
+        means = torch.stack([r.losses.double().mean() for r in self.runs]).cpu() if self.n_steps else None
+        for k, r in enumerate(self.runs):
             r.opt.step_count += self.n_steps
             r.opt.last_epoch_losses = r.losses
-            r.proj.log_train["loss"] = float(r.losses.double().mean().item()) if r.losses.numel() else float("nan")
+            r.proj.log_train["loss"] = float(means[k].item()) if means is not None else float("nan")
 
     # ---- validation + test of every run of the group (train_funcs.net_eval_pair, the K forwards as one launch per batch pair) ----
     def eval_epoch(self):
@@ -220,14 +222,26 @@ class _Group:
                 for k, r in enumerate(self.runs):
                     for (losses, pred, truth), o, t in ((outs[0][k], ys[k][:fa.shape[0]], ta), (outs[1][k], ys[k][fa.shape[0]:], tb)):
                         losses.append(r.criterion(o, t)); pred.append(o); truth.append(t)
-        for k, r in enumerate(self.runs):
-            p = r.proj
-            res = []
-            for log, (losses, pred, truth) in ((p.log_val, outs[0][k]), (p.log_test, outs[1][k])):
-                log["loss"] = float(np.mean(torch.stack([l.float() for l in losses]).cpu().numpy())) if losses else float("nan")
-                res.append((torch.cat(pred, dim=0).cpu().numpy(), torch.cat(truth, dim=0).cpu().numpy()))
-            p.log_val = calculate_metrics(p.args, p.log_val, *res[0])
-            p.log_test = calculate_metrics(p.args, p.log_test, *res[1])
+        # host side of the K x 2 evaluations at sweep level: one device-to-host copy per split for all runs' predictions, one for every loss,
+        # the split's ground truth once (the runs of a group share their dataset), metrics over the (K, segments, nperseg) stack with one
+        # FFT / Welch call per split (metrics.calculate_metrics_many: each run's numbers are those of its own calculate_metrics call)
+        from .metrics import calculate_metrics_many
+        for split, name in ((0, "log_val"), (1, "log_test")):
+            per_run = outs[split]
+            if not per_run[0][0]:
+                for r in self.runs:
+                    getattr(r.proj, name)["loss"] = float("nan")
+                continue
+            loss_m = torch.stack([torch.stack([l.float() for l in per_run[k][0]]) for k in range(K)]).cpu().numpy()      # (K, batches)
+            preds = torch.stack([torch.cat(per_run[k][1], dim=0) for k in range(K)]).cpu().numpy()                       # (K, segments, nperseg, 2)
+            truth = torch.cat(per_run[0][2], dim=0).cpu().numpy()
+            stats = []
+            for k, r in enumerate(self.runs):
+                getattr(r.proj, name)["loss"] = float(np.mean(loss_m[k]))
+                stats.append(getattr(r.proj, name))
+            done = calculate_metrics_many(self.runs[0].proj.args, stats, [preds[k] for k in range(K)], [truth] * K)
+            for r, st in zip(self.runs, done):
+                setattr(r.proj, name, st)
 
 
 def train_pa_sweep(dataset_name=None, seeds=(0,), hidden_sizes=None, PA_backbone="gru", PA_hidden_size=23, n_epochs=100, batch_size=256,
@@ -263,15 +277,23 @@ def train_pa_sweep(dataset_name=None, seeds=(0,), hidden_sizes=None, PA_backbone
     for r in runs:
         groups.setdefault(_group_key(r), []).append(r)
     groups = [_Group(v, exact=exact) for v in groups.values()]
+    # sweep-level bookkeeping: history rows are appended (project.CsvLogger), an improved model is remembered on the device
+    # and its checkpoint written once, when the sweep ends or is interrupted (`flush`), instead of one torch.save per run and improving epoch
+    for r in runs:
+        r.proj.logger.defer_checkpoints = True
     start = time.time()
-    for epoch in range(n_epochs):
-        for g in groups:
-            g.train_epoch()
-        for g in groups:
-            g.eval_epoch()
+    try:
+        for epoch in range(n_epochs):
+            for g in groups:
+                g.train_epoch()
+            for g in groups:
+                g.eval_epoch()
+            for r in runs:
+                with r.rng:
+                    r.proj.finish_epoch(r.net, r.opt, r.sched, epoch, start, "NMSE")
+    finally:
         for r in runs:
-            with r.rng:
-                r.proj.finish_epoch(r.net, r.opt, r.sched, epoch, start, "NMSE")
+            r.proj.logger.flush()
     return [{"status": "completed", "model_path": r.proj.path_save_file_best, "log_path": r.proj.path_log_file_best, "seed": r.proj.seed,
              "PA_hidden_size": r.proj.PA_hidden_size, "lockstep": bool(g_.train_sweep),
              "mode": ("s16" if g_.flags else "exact") if g_.train_sweep else "per-run"}

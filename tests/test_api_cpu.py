@@ -217,3 +217,27 @@ def test_trainer_object_follows_the_reference_flow(monkeypatch, capsys):
     t2 = api.OpenDPDTrainer(dataset_path="/x")
     t2.train_pa()
     assert calls[3] == ("pa", {"dataset_path": "/x"}) and t2.pa_trained and not t2.dpd_trained
+
+
+def test_csv_logger_appends_the_bytes_pandas_would_rewrite(tmp_path):
+    """modules/loggers.py:119-163 rewrites the history CSV through pandas after every epoch; CsvLogger appends the new line instead (and writes
+    the best-row file directly): after every epoch both files equal the pandas rewrite byte for byte — quoting, nan, integer columns, negative
+    zero included; a row holding something the fast writer does not take (a float32 scalar) goes through pandas itself"""
+    import numpy as np
+    import pandas as pd
+    from opendpd_amd.project import CsvLogger
+    lg = CsvLogger(str(tmp_path / "m.pt"), str(tmp_path / "best.csv"), str(tmp_path / "hist.csv"))
+    rows = []
+    for ep in range(6):
+        stat = {"EPOCH": ep, "N_EPOCH": 6, "TIME:": 0.0123 * ep, "LR": 5e-4, "BATCH_SIZE": 64, "N_PARAM": np.int64(1041), "BACKBONE": 'dgru, "x"',
+                "HIDDEN_SIZE": 13, "TRAIN_LOSS": float(np.float64(1e-3 / (ep + 1))), "VAL_NMSE": float("nan") if ep == 2 else -30.123456789 * ep,
+                "VAL_EVM": -1e-12}
+        if ep == 4:
+            stat["VAL_EVM"] = np.float32(0.25)         # not a Python float: the reference's formatter leaves it to pandas
+        lg.write_log(stat)
+        lg._write_best(ep)
+        rows.append(["{:.8f}".format(v) if isinstance(v, float) else v for v in stat.values()])
+        pd.DataFrame(rows, columns=list(stat.keys())).to_csv(tmp_path / "ref.csv", index=False)
+        pd.DataFrame([rows[ep]], columns=list(stat.keys())).to_csv(tmp_path / "refb.csv", index=False)
+        assert (tmp_path / "ref.csv").read_bytes() == (tmp_path / "hist.csv").read_bytes(), ep
+        assert (tmp_path / "refb.csv").read_bytes() == (tmp_path / "best.csv").read_bytes(), ep

@@ -40,7 +40,11 @@ def test_selection_and_workspace(force_s16):
     assert lib.odpd_train_workspace_floats(C.byref(d), 33, 50) == 3 * 13 * 256     # 3 wave-tasks x 13 checkpoints
     assert lib.odpd_partial_rows(C.byref(d), 33, 50, 1) == 1
     big = CoreModel(2, 23, 1, "dgru").backbone.desc                                  # hidden 17..32: two unit tiles per lane
-    assert lib.odpd_train_workspace_floats(C.byref(big), 33, 50) == 3 * 13 * 2 * 256
+    # (r06: hidden 17 .. 24 train on the bf16-split kernel — two-step checkpoints of 64 lanes x (float4 + float2); the query answers the
+    # larger of the two kernels' layouts, so that the "s16x_train" knob can be flipped on a sized buffer)
+    assert lib.odpd_train_workspace_floats(C.byref(big), 33, 50) == max(3 * 13 * 2 * 256, 3 * 25 * 384)
+    big32 = CoreModel(2, 29, 1, "dgru").backbone.desc                                # hidden 25..32: the exact-fp32 kernel only
+    assert lib.odpd_train_workspace_floats(C.byref(big32), 33, 50) == 3 * 13 * 2 * 256
     lib.odpd_set_tuning(b"s16_min_batch", -1)
     assert lib.odpd_train_workspace_floats(C.byref(d), 33, 50) == 0                  # small batch: LDS-resident path
     assert lib.odpd_train_workspace_floats(C.byref(d), 65536, 200) == 4096 * 50 * 256

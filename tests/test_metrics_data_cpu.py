@@ -75,3 +75,25 @@ def test_metrics_are_bit_identical_with_the_reference():
             vals.append(M.EVM(pred, truth, bw_main_ch=c["bw"], n_sub_ch=c["nsub"], nperseg=nperseg))
         assert [float(v).hex() for v in vals] == c["values"], c
         assert [type(v).__name__ for v in vals] == c["types"], c
+
+
+def test_calculate_metrics_many_equals_per_run_calls_bit_for_bit():
+    """sweep-level metrics (opendpd_amd/sweep.py): one FFT / Welch call over the K runs' stacked predictions gives every run the numbers — and
+    the number TYPES (they reach the CSV formatter) — of its own calculate_metrics call (utils/metrics.py:42-187 of the reference)"""
+    from types import SimpleNamespace
+    from opendpd_amd.metrics import calculate_metrics, calculate_metrics_many
+    args = SimpleNamespace(nperseg=2560, n_sub_ch=10, bw_main_ch=200e6, input_signal_fs=800e6)
+    rng = np.random.RandomState(3)
+    K, S, N = 5, 4, 2560
+    truth = (0.3 * rng.randn(S, N, 2)).astype(np.float32)
+    preds = [(truth + 10.0 ** -(1 + k) * rng.randn(S, N, 2)).astype(np.float32) for k in range(K)]
+    for truths in ([truth] * K, [(truth * (1 + 0.01 * k)).astype(np.float32) for k in range(K)]):
+        one = [calculate_metrics(args, {"loss": 0.0}, p, g) for p, g in zip(preds, truths)]
+        many = calculate_metrics_many(args, [{"loss": 0.0} for _ in range(K)], preds, truths)
+        for a, b in zip(one, many):
+            assert list(a.keys()) == list(b.keys())
+            for k in a:
+                assert a[k] == b[k] and type(a[k]) is type(b[k]), (k, a[k], b[k])
+    # ragged shapes fall back to the per-run function
+    many = calculate_metrics_many(args, [{}, {}], [preds[0], preds[1][:2]], [truth, truth[:2]])
+    assert many[1]["NMSE"] == calculate_metrics(args, {}, preds[1][:2], truth[:2])["NMSE"]
