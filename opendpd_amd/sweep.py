@@ -288,9 +288,8 @@ def train_pa_sweep(dataset_name=None, seeds=(0,), hidden_sizes=None, PA_backbone
                 g.train_epoch()
             for g in groups:
                 g.eval_epoch()
-            for r in runs:
-                with r.rng:
-                    r.proj.finish_epoch(r.net, r.opt, r.sched, epoch, start, "NMSE")
+            for r in runs:      # (log row, best-model bookkeeping, plateau scheduler: nothing here draws from an RNG — no state swap)
+                r.proj.finish_epoch(r.net, r.opt, r.sched, epoch, start, "NMSE")
     finally:
         for r in runs:
             r.proj.logger.flush()
