@@ -102,12 +102,30 @@ def build(force=False, verbose=False, extra_flags=(), jobs=None, out=None):
         except (OSError, ValueError, KeyError, IndexError):
             return None
 
+    def file_flags(src):
+        """flags a source asks for itself: a line `// odpd-build-flags: <flags>` among its first 60 lines (e.g. gru_s16x.hip: VGPR-form MFMAs)"""
+        out_ = []
+        with open(src) as f:
+            for _, ln in zip(range(60), f):
+                if ln.startswith("// odpd-build-flags:"):
+                    out_ += ln.split(":", 1)[1].split()
+        return out_
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cached = up_to_date(obj)
+        own = file_flags(src)
+        cached = up_to_date(obj) if not own else None
+        if own and not force and all(os.path.exists(f) for f in (obj, obj + ".d", obj + ".res.json")):
+            try:       # (same rule as up_to_date, with the file's own flags part of the record)
+                rec = json.load(open(obj + ".res.json"))
+                names = open(obj + ".d").read().replace("\\\n", " ").split(":", 1)[1].split()
+                if rec.get("flags") == flags + own and all(os.path.getmtime(n) <= os.path.getmtime(obj) for n in names):
+                    cached = rec["resources"]
+            except (OSError, ValueError, KeyError, IndexError):
+                cached = None
         if cached is not None:
             return obj, cached
-        cmd = [hipcc, *flags, "-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
+        cmd = [hipcc, *flags, *own, "-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -117,7 +135,7 @@ def build(force=False, verbose=False, extra_flags=(), jobs=None, out=None):
         if noise and verbose:
             print("\n".join(noise))
         resources = _parse_resources(p.stderr)
-        json.dump({"flags": flags, "resources": resources}, open(obj + ".res.json", "w"))
+        json.dump({"flags": flags + own, "resources": resources}, open(obj + ".res.json", "w"))
         return obj, resources
 
     jobs = jobs or max(1, min(8, os.cpu_count() or 1))

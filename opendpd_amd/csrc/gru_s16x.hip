@@ -23,6 +23,13 @@
 //
 // BPTT: h checkpoints every S steps in the HBM workspace ([16-sequence task][checkpoint][float4 x 64 | float2 x 64]), block recompute into
 // registers.  Two waves per SIMD (256 registers).  Parity: tests/test_gru_s16x_gpu.py (against the oracle and against gru_s16n.hip).
+//
+// Build: MFMA results in VGPRs wherever the register allocator can afford it.  The train kernel needs more than 256 registers, and the
+// compiler's default for a function that touches AGPRs at all is the AGPR form for EVERY matrix instruction: each of the ~350 results per
+// two-step block that a vector instruction consumes (gates, transposed operands) then costs a v_accvgpr_read — 17 % of the block's vector
+// instructions.  With the VGPR form the accumulators of the weight gradient live in AGPRs through copies the allocator places itself
+// (1 966 -> 1 830 instructions per block, no scratch); the frozen kernel (no AGPRs) compiles to the same code either way.
+// odpd-build-flags: -mllvm -amdgpu-mfma-vgpr-form
 #include "odpd_s16.h"
 
 namespace odpd {
