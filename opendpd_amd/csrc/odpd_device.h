@@ -418,7 +418,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // exact-fp32 MFMA rank-4 update: D[i][j] += sum_k A[i][k] B[k][j], lane l feeds A[l&15][l>>4], B[l>>4][l&15]
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+#ifdef ODPD_X_NOMFMA      // removal experiment (timing only): the rank-4 update as one vector FMA per accumulator element is NOT what replaces it —
+    c[0] = __builtin_fmaf(a, b, c[0]);      // one FMA stands in for the data dependence, the matrix instruction itself is gone
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 }  // namespace odpd

@@ -119,14 +119,21 @@ __device__ __forceinline__ f32x4 sub4(const f32x4& a, const f32x4& b) {
     ODPD_EACH4 r[i] = a[i] - b[i];
     return r;
 }
+#ifdef ODPD_X_NOTRANS      // removal experiment (timing only): transcendentals as one FMA each
+#define ODPD_XEXP2(v) __builtin_fmaf((v), 0.25f, 1.0f)
+#define ODPD_XRCP(v) __builtin_fmaf((v), -0.25f, 1.0f)
+#else
+#define ODPD_XEXP2(v) __builtin_amdgcn_exp2f(v)
+#define ODPD_XRCP(v) fast_rcp(v)
+#endif
 __device__ __forceinline__ f32x4 exp2_4(const f32x4& v) {
     f32x4 r;
-    ODPD_EACH4 r[i] = __builtin_amdgcn_exp2f(v[i]);
+    ODPD_EACH4 r[i] = ODPD_XEXP2(v[i]);
     return r;
 }
 __device__ __forceinline__ f32x4 rcp4(const f32x4& v) {
     f32x4 r;
-    ODPD_EACH4 r[i] = fast_rcp(v[i]);
+    ODPD_EACH4 r[i] = ODPD_XRCP(v[i]);
     return r;
 }
 // sigmoid of a pre-activation that arrives already multiplied by -log2(e)
@@ -153,8 +160,8 @@ __device__ __forceinline__ f32x4 tanh4_rel(const f32x4& v) {
         p = __builtin_fmaf(x2, p, 0.13333333333333333f);
         p = __builtin_fmaf(x2, p, -0.33333333333333333f);
         p = __builtin_fmaf(x2 * x, p, x);
-        const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f;
-        const float t = __builtin_fmaf(fast_rcp(e), -2.0f, 1.0f);
+        const float e = ODPD_XEXP2(x * 2.8853900817779268f) + 1.0f;
+        const float t = __builtin_fmaf(ODPD_XRCP(e), -2.0f, 1.0f);
         const float w = __builtin_amdgcn_fmed3f(__builtin_fmaf(__builtin_fabsf(x), -0x1p100f, 0.3f * 0x1p100f), 0.0f, 1.0f);   // |x| < 0.3
         r[i] = __builtin_fmaf(w, p - t, t);
     }
