@@ -68,8 +68,28 @@ __device__ __forceinline__ f32x4 mfma32(const u32x4& a, const u32x4& b, const f3
 }
 __device__ __forceinline__ u32x4 tabx_ld(TabPtr p, int i) { return __builtin_bit_cast(u32x4, p[i]); }
 // acc[t] += A(group grp0 + 3 t .. + 2: the three terms of tile t) . B, smallest products first
-template <int NT>
+// PF (the lone-wave train kernel): the next tile's three operands are requested before the current tile's six products are issued — a wave
+// that is alone on its SIMD has nobody to cover the LDS latency of a load issued where it is needed
+template <int NT, bool PF = false>
 __device__ __forceinline__ void mm6(TabPtr tl, int grp0, const Split3& B, f32x4 (&acc)[NT]) {
+    if constexpr (PF) {
+        u32x4 a1 = tabx_ld(tl, grp0 * 64), a2 = tabx_ld(tl, (grp0 + 1) * 64), a3 = tabx_ld(tl, (grp0 + 2) * 64);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            u32x4 n1 = a1, n2 = a2, n3 = a3;
+            if (t + 1 < NT) { n1 = tabx_ld(tl, (grp0 + 3 * t + 3) * 64); n2 = tabx_ld(tl, (grp0 + 3 * t + 4) * 64); n3 = tabx_ld(tl, (grp0 + 3 * t + 5) * 64); }
+            f32x4 c = acc[t];
+            c = mfma32(a1, B.t[2], c);
+            c = mfma32(a3, B.t[0], c);
+            c = mfma32(a2, B.t[1], c);
+            c = mfma32(a1, B.t[1], c);
+            c = mfma32(a2, B.t[0], c);
+            c = mfma32(a1, B.t[0], c);
+            acc[t] = c;
+            a1 = n1; a2 = n2; a3 = n3;
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const u32x4 a1 = tabx_ld(tl, (grp0 + 3 * t) * 64), a2 = tabx_ld(tl, (grp0 + 3 * t + 1) * 64), a3 = tabx_ld(tl, (grp0 + 3 * t + 2) * 64);
@@ -251,7 +271,7 @@ __device__ __forceinline__ Split3 s16x_operand(const float (&h)[U], const float 
 }
 // gates of one step from the tile results; h <- h(t).  WITH_HID: the fc_hid tiles ride on the same operand (they are the hidden
 // layer of the operand's h, i.e. of the PREVIOUS step)
-template <int FM, bool DG, int U, bool WITH_HID>
+template <int FM, bool DG, int U, bool WITH_HID, bool PF = false>
 __device__ __forceinline__ void s16x_cell(TabPtr tl, const Split3& B, float (&h)[U], float (&r)[U], float (&z)[U], float (&n)[U], float (&nh)[U],
                                           float (&hid_prev)[U]) {
     using T = S16X<DG, U>;
@@ -259,7 +279,7 @@ __device__ __forceinline__ void s16x_cell(TabPtr tl, const Split3& B, float (&h)
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mm6<NT>(tl, T::FW, B, acc);
+    mm6<NT, PF>(tl, T::FW, B, acc);
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         const int sr = j, sz = U + j, sh = 2 * U + j, si = 3 * U + j;
@@ -271,13 +291,13 @@ __device__ __forceinline__ void s16x_cell(TabPtr tl, const Split3& B, float (&h)
         if constexpr (WITH_HID) hid_prev[j] = acc[T::NTF + j / 4][j % 4];
     }
 }
-template <bool DG, int U>
+template <bool DG, int U, bool PF = false>
 __device__ __forceinline__ void s16x_hid(TabPtr tl, const Split3& B, float (&hid)[U]) {
     using T = S16X<DG, U>;
     f32x4 acc[T::NTH];
 #pragma unroll
     for (int t = 0; t < T::NTH; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mm6<T::NTH>(tl, T::FW + 3 * T::NTF, B, acc);
+    mm6<T::NTH, PF>(tl, T::FW + 3 * T::NTF, B, acc);
 #pragma unroll
     for (int j = 0; j < U; ++j) hid[j] = acc[j / 4][j % 4];
 }
@@ -429,7 +449,7 @@ __device__ __forceinline__ void s16x_block(const SeqArgs& a, TabPtr tl0, const f
 
 constexpr int kS16xCkptFloats = 384;      // floats per (16-sequence task, checkpoint): 64 lanes x (float4 + float2)
 // ---- forward pass of one 16-sequence task: h checkpoints only; the cell tiles stay in registers ----
-template <int FM, bool DG, int U, int S>
+template <int FM, bool DG, int U, int S, bool BATCHED = false>
 __device__ __forceinline__ void s16x_forward_pass(const SeqArgs& a, TabPtr tl, const float (&oh)[4], float2* xs, float4* ck4, float2* ck2, int b0, int n,
                                                   int lane) {
     using T = S16X<DG, U>;
@@ -448,7 +468,7 @@ __device__ __forceinline__ void s16x_forward_pass(const SeqArgs& a, TabPtr tl, c
     for (int t0 = 0; t0 < a.T; t0 += kChunk) {
         const int len = min(kChunk, a.T - t0);
         wave_lds_fence();
-        stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+        stage_in<16, BATCHED>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
         wave_lds_fence();
         for (int tt = 0; tt < len; ++tt) {
             const float2 xv = xs[n * kChunkPad + tt];
@@ -692,13 +712,13 @@ __device__ __forceinline__ void s16x_train_block(const SeqArgs& a, TabPtr tl0, c
             const Split3 B = s16x_operand<U>(h, fs_s[st]);
             s16x_tr_v(B, E, vc[st]);
             if constexpr (DG && FULL) {
-                if (st > 0) s16x_cell<FM, DG, U, true>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[st > 0 ? st - 1 : 0]);
-                else s16x_cell<FM, DG, U, false>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[0]);
+                if (st > 0) s16x_cell<FM, DG, U, true, true>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[st > 0 ? st - 1 : 0]);
+                else s16x_cell<FM, DG, U, false, true>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[0]);
             } else {
-                s16x_cell<FM, DG, U, false>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[st]);
+                s16x_cell<FM, DG, U, false, true>(tl, B, h, r_s[st], z_s[st], n_s[st], nh_s[st], hid_s[st]);
                 if constexpr (DG) {      // (ragged tail block: the hidden layer of every step on an operand of its own)
                     const Split3 B2 = s16x_operand<U>(h, fs_s[st]);
-                    s16x_hid<DG, U>(tl, B2, hid_s[st]);
+                    s16x_hid<DG, U, true>(tl, B2, hid_s[st]);
                     s16x_tr_v(B2, E, vh[st]);
                 }
             }
@@ -706,7 +726,7 @@ __device__ __forceinline__ void s16x_train_block(const SeqArgs& a, TabPtr tl0, c
     }
     if constexpr (DG && FULL) {
         const Split3 B2 = s16x_operand<U>(h, fs_s[S - 1]);
-        s16x_hid<DG, U>(tl, B2, hid_s[S - 1]);
+        s16x_hid<DG, U, true>(tl, B2, hid_s[S - 1]);
         s16x_tr_v(B2, E, vh[S - 1]);
         // fc_hid of step st rode on the cell operand of step st + 1: [h(st) | features of st + 1] (the constant-1 slot is what its bias needs)
 #pragma unroll
@@ -768,7 +788,7 @@ __device__ __forceinline__ void s16x_train_block(const SeqArgs& a, TabPtr tl0, c
                 for (int t = 0; t < T::NTH; ++t)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[t][e] = 4 * t + e < U ? dh[4 * t + e] : 0.0f;
-                mm6<T::NTH>(tl, T::HT, Bd, acc);
+                mm6<T::NTH, true>(tl, T::HT, Bd, acc);
 #pragma unroll
                 for (int j = 0; j < U; ++j) dht[j] = acc[j / 4][j % 4];
                 // d(hid) as rows of the weight-gradient contraction: tile t' <- elements 4 t' .. 4 t' + 3
@@ -955,27 +975,36 @@ __global__ __launch_bounds__(256, 1) void gru16x_train_kernel(SeqArgs a) {
         float* ckg = a.ckpt + (size_t)grp * nblk * kS16xCkptFloats;
         float4* ck4 = reinterpret_cast<float4*>(ckg) + lane;
         float2* ck2 = reinterpret_cast<float2*>(ckg + 256) + lane;
-        s16x_forward_pass<FM, DG, U, S>(a, tl, oh, xs, ck4, ck2, b0, n, lane);
+        s16x_forward_pass<FM, DG, U, S, true>(a, tl, oh, xs, ck4, ck2, b0, n, lane);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         float dh[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) dh[j] = 0.0f;
         int cur_chunk = -1;
+        // the checkpoint of a block is requested ONE BLOCK AHEAD: this wave is alone on its SIMD, a load issued where its value is needed
+        // would expose the whole HBM / Infinity-Cache latency (1 - 2 us of a ~7 us block) — counters before: 14 % of the wave's cycles in s_waitcnt
+        float4 nv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 nw = make_float2(0.f, 0.f);
+        if (nblk > 1) {
+            const size_t o = (size_t)(nblk - 1) * kS16xCkptFloats;
+            nv = ck4[o / 4]; nw = ck2[o / 2];
+        }
         for (int blk = nblk - 1; blk >= 0; --blk) {
             const int tb = blk * S, nstep = min(S, a.T - tb);
             const int chunk = tb / kChunk, t0 = chunk * kChunk;
             float h0[U];
-            {
-                const size_t o = (size_t)blk * kS16xCkptFloats;
-                const float4 v = blk ? ck4[o / 4] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float2 w = blk ? ck2[o / 2] : make_float2(0.f, 0.f);
-                h0[0] = v.x; h0[1] = v.y; h0[2] = v.z; h0[3] = v.w; h0[4] = w.x; h0[5] = w.y;
+            h0[0] = nv.x; h0[1] = nv.y; h0[2] = nv.z; h0[3] = nv.w; h0[4] = nw.x; h0[5] = nw.y;
+            if (blk > 1) {
+                const size_t o = (size_t)(blk - 1) * kS16xCkptFloats;
+                nv = ck4[o / 4]; nw = ck2[o / 2];
+            } else {
+                nv = make_float4(0.f, 0.f, 0.f, 0.f); nw = make_float2(0.f, 0.f);
             }
             if (chunk != cur_chunk) {
                 wave_lds_fence();
                 const int len = min(kChunk, a.T - t0);
-                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
-                stage_in<16>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+                stage_in<16, true>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+                stage_in<16, true>(ts, a.target, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
                 wave_lds_fence();
                 cur_chunk = chunk;
             }

@@ -69,7 +69,9 @@ __device__ __forceinline__ float2 ld_iq(const float* g, size_t i, bool bf16) {
     return reinterpret_cast<const float2*>(g)[i];
 }
 // `fidx` (nullable): frames are windows of a resident stream, row b starts at sample fidx[b] * fstride; `bf16`: its sample format
-template <int SPW>
+// BATCHED: the loads of one call in two passes (see below) — 2 N more live registers at the call site, so the register-capped two-wave kernels
+// keep the element-at-a-time form, whose exposed latency their partner wave covers
+template <int SPW, bool BATCHED = false>
 __device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane,
                                          float2 fill, const long long* fidx = nullptr, int fstride = 0, bool bf16 = false) {
     constexpr int N = SPW * kChunk / 64;   // float2 per lane
@@ -91,15 +93,44 @@ __device__ __forceinline__ void stage_in(float2* lds, const float* g, int b0, in
     }
 #endif
     const float2* g2 = reinterpret_cast<const float2*>(g);
+    if constexpr (!BATCHED) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
+            float2 v = fill;
+            if (tt < len && b0 + m < B) {
+                const size_t row = fidx ? (size_t)fidx[b0 + m] * fstride : (size_t)(b0 + m) * T;
+                v = g2[row + t0 + tt];
+            }
+            lds[m * kChunkPad + tt] = v;
+        }
+        return;
+    }
+    // Two passes (r06): all frame-start indices first, then all samples, then the LDS stores.  Written as one loop, the compiler emits per
+    // element "load the index, s_waitcnt vmcnt(0), load the sample, s_waitcnt vmcnt(0)": 2 N dependent round trips per staged stream where
+    // two suffice — exposed in full on a wave that is alone on its SIMD (gru16x_train_kernel), half hidden with a partner wave.
+    size_t row[N];
+    if (fidx) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int m = (lane + 64 * j) / kChunk;
+            row[j] = (size_t)fidx[min(b0 + m, B - 1)] * fstride;      // (clamped: an unconditional load; rows beyond the batch are not used)
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) row[j] = (size_t)(b0 + (lane + 64 * j) / kChunk) * T;
+    }
+    float2 v[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int e = lane + 64 * j, m = e / kChunk, tt = e % kChunk;
-        float2 v = fill;
-        if (tt < len && b0 + m < B) {
-            const size_t row = fidx ? (size_t)fidx[b0 + m] * fstride : (size_t)(b0 + m) * T;
-            v = g2[row + t0 + tt];
-        }
-        lds[m * kChunkPad + tt] = v;
+        v[j] = fill;
+        if (tt < len && b0 + m < B) v[j] = g2[row[j] + t0 + tt];
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j;
+        lds[(e / kChunk) * kChunkPad + e % kChunk] = v[j];
     }
 }
 template <int SPW>
