@@ -118,7 +118,9 @@ int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T);
  * forward kernels off); "cascade_one_launch": 0 = odpd_cascade_rows answers ODPD_EUNSUPPORTED (train_dpd steps as chained launches),
  * 1 = built-in choice; "xchg_fused": 0 = the one-shot gradient exchange as a launch of its own instead of the optimiser kernel's prologue;
  * "s16x": 0 = the frozen-PA step of 17 .. 24 hidden units on the exact-fp32 kernel instead of the bf16-split one (same results to fp32
- * rounding; CHANGES odpd_ckpt_floats of those models: the two kernels lay their checkpoints out differently); "lstm_pack": 0 = the fused
+ * rounding; CHANGES odpd_ckpt_floats of those models: the two kernels lay their checkpoints out differently); "s16x_train" (r06): 0 = the
+ * fused TRAIN step of those models (odpd_train_fwd_bwd / the framed epoch loops at 16-sequences-per-wave batch sizes) on the exact-fp32 kernel
+ * instead of the bf16-split one (same results to fp32 rounding; odpd_train_workspace_floats answers the larger of the two layouts); "lstm_pack": 0 = the fused
  * lstm / vdlstm train kernel of <= 13 hidden units without K-packed input slots (same results to fp32 rounding); "xchg_fused" and "lstm_pack"
  * change no buffer size.  Every successful call bumps odpd_tuning_generation, whichever knob it was. */
 int odpd_set_tuning(const char* key, int64_t value);

@@ -418,8 +418,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // exact-fp32 MFMA rank-4 update: D[i][j] += sum_k A[i][k] B[k][j], lane l feeds A[l&15][l>>4], B[l>>4][l&15]
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-#ifdef ODPD_X_NOMFMA      // removal experiment (timing only): the rank-4 update as one vector FMA per accumulator element is NOT what replaces it —
-    c[0] = __builtin_fmaf(a, b, c[0]);      // one FMA stands in for the data dependence, the matrix instruction itself is gone
+#ifdef ODPD_X_NOMFMA      // removal experiment (timing only): four vector FMAs keep every accumulator element live and data dependent (with fewer the
+    c[0] = __builtin_fmaf(a, b, c[0]); c[1] = __builtin_fmaf(a, b, c[1]);      // compiler deletes whole gate chains); the matrix instruction itself is gone:
+    c[2] = __builtin_fmaf(a, b, c[2]); c[3] = __builtin_fmaf(a, b, c[3]);      // ~16 issue cycles instead of ~32
     return c;
 #else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
