@@ -213,3 +213,51 @@ def test_isa_scan_finds_the_r02_hazard_in_its_reproduction_build():
     assert n_asm > 100 and war == {"_ZN4odpd13gru16n_kernelILi1ELb1ELi2ELi0ELb0ELb1ELi4EEEvNS_7SeqArgsE"}, war
     findings, n_asm = haz.scan(haz.isa_of(src), 18, 3)
     assert n_asm == 0 and not findings
+
+
+def test_every_tuning_knob_is_documented_in_the_header_and_settable_without_a_gpu():
+    """odpd_set_tuning's keys (csrc/capi.hip) = the keys include/opendpd_hip.h describes; each is accepted, an unknown key answers ODPD_EINVAL, and a
+    key that changes a buffer size bumps odpd_tuning_generation (callers re-size on it: train_funcs.FusedAdamW, sweep._Group)"""
+    import re
+    from opendpd_amd import _lib
+    src = open(os.path.join(ROOT, "opendpd_amd", "csrc", "capi.hip")).read()
+    keys = re.findall(r'!strcmp\(key, "(\w+)"\)', src)
+    assert len(keys) >= 8 and len(set(keys)) == len(keys)
+    header = open(os.path.join(ROOT, "include", "opendpd_hip.h")).read()
+    for k in keys:
+        assert f'"{k}"' in header, f"tuning knob {k} is not described in include/opendpd_hip.h"
+    lib = _lib.load()
+    restore = {"s16_min_batch": -1, "s16_occupancy": 0, "gp_max_batch": -1}      # (knobs whose default is not 1)
+    for k in keys:
+        g0 = lib.odpd_tuning_generation()
+        assert lib.odpd_set_tuning(k.encode(), restore.get(k, 1)) == 0, k
+        sized = k not in ("xchg_fused", "lstm_pack")
+        assert (lib.odpd_tuning_generation() > g0) == sized, k
+    assert lib.odpd_set_tuning(b"no_such_knob", 1) == -1
+
+
+def test_bench_and_package_set_the_ipc_mode_before_any_gpu_call():
+    """the driver's own `torch.distributed.run ... bench.py` line must be self-sufficient — HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC:
+    RCCL and the hipIpc gradient exchange need it on this image) is set by bench.py BEFORE it imports torch, and by the package at import"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    i_env, i_torch = src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")'), src.index("\nimport torch")
+    assert i_env < i_torch
+    assert "export HSA_ENABLE_IPC_MODE_LEGACY" not in open(os.path.join(ROOT, "tools", "scale.sh")).read()
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    out = subprocess.run([sys.executable, "-c", "import os, opendpd_amd; print(os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))"], env=env, cwd=ROOT,
+                         capture_output=True, text=True)
+    assert out.stdout.strip().splitlines()[-1] == "0", out.stderr[-500:]
+
+
+def test_sources_may_carry_their_own_build_flags():
+    """`// odpd-build-flags:` (build.py): gru_s16x.hip asks for VGPR-form MFMAs; the flags are part of the object's cache record"""
+    import json
+    from opendpd_amd import build as hb
+    src = os.path.join(hb.CSRC, "gru_s16x.hip")
+    head = "".join(open(src).readlines()[:60])
+    assert "// odpd-build-flags: -mllvm -amdgpu-mfma-vgpr-form" in head
+    rec = os.path.join(ROOT, "build", "obj", "default", "gru_s16x.o.res.json")
+    if os.path.exists(rec):      # (an in-tree build exists: its record carries the file's own flags)
+        assert "-amdgpu-mfma-vgpr-form" in json.load(open(rec))["flags"]
