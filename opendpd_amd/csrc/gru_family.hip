@@ -1430,7 +1430,7 @@ int gru_family_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
         return launch_eval<2, FEAT_A4, false>(st, a, P);
     }
     if (gru_split_uses_s16(m, a.B)) return gru_s16_fwd(st, m, a);
-    if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 1);
+    if (gru_uses_s16n(m, a.B)) return gru_s16x_train_ok(m) ? gru_s16x_fwd(st, m, a) : gru_s16n_launch(st, m, a, 1);
     ODPD_GRU_DISPATCH_ALL(launch_fwd, st, a, P)
     return ODPD_EUNSUPPORTED;
 }
@@ -1442,7 +1442,7 @@ int gru_family_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a) {
     int FM, R, P; bool DG;
     if (!gru_setup(m, FM, DG, R, P)) return ODPD_EUNSUPPORTED;
     if (gru_split_uses_s16(m, a.B)) return gru_s16_bwd(st, m, a);
-    if (gru_uses_s16n(m, a.B)) return gru_s16n_launch(st, m, a, 2);
+    if (gru_uses_s16n(m, a.B)) return gru_s16x_train_ok(m) ? gru_s16x_bwd(st, m, a, gru_s16n_rows(m, a.B)) : gru_s16n_launch(st, m, a, 2);
     if (gru_bwd_uses_gp(m, a.B, a.T)) {
         // weight gradients only: the fused one-sequence-per-wave kernel with dL/dy given (it runs its own forward; the checkpoints stay unread)
         if (a.partials != nullptr && a.dx == nullptr) { ODPD_GRU_DISPATCH_ALL(launch_gp_train, st, a, P) }

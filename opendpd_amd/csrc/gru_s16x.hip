@@ -270,7 +270,8 @@ __device__ __forceinline__ void s16x_hid(TabPtr tl, const Split3& B, float (&hid
 }
 
 // one block of <= S steps of the backward pass: recompute from the checkpoint h0, then loss, dL/dy and BPTT down to dL/du
-template <int FM, bool DG, int U, int S, bool FULL>
+// FUSED = false (r06, the split backward of a model without parameter gradients): `ts` holds dL/dy instead of the target, no y, no loss
+template <int FM, bool DG, int U, int S, bool FULL, bool FUSED = true>
 __device__ __forceinline__ void s16x_block(const SeqArgs& a, TabPtr tl0, const float (&oh)[4], const float2* xs, const float2* ts, float2* dxs,
                                            int n, int q, int tloc, int nstep, bool valid, const float (&h0)[U], float (&dh)[U], float& loss_acc) {
     using T = S16X<DG, U>;
@@ -329,14 +330,16 @@ __device__ __forceinline__ void s16x_block(const SeqArgs& a, TabPtr tl0, const f
 #pragma unroll
                 for (int j = 0; j < U; ++j) act[j] = __builtin_fmaf(z_s[st][j], hp_s[st][j] - n_s[st][j], n_s[st][j]);      // h(t)
             }
-            float p0 = wf.x * fs_s[st][0], p1 = wf.z * fs_s[st][0];
-            if constexpr (NFS > 1) { p0 = __builtin_fmaf(wf.y, fs_s[st][1], p0); p1 = __builtin_fmaf(wf.w, fs_s[st][1], p1); }
-#pragma unroll
-            for (int j = 0; j < U; ++j) { p0 = __builtin_fmaf(w0[j], act[j], p0); p1 = __builtin_fmaf(w1[j], act[j], p1); }
             const float2 tv = ts[n * kChunkPad + tloc + st];
-            const float y0 = quad_sum(p0), y1 = quad_sum(p1);
-            float dy0, dy1;
-            s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+            float dy0 = tv.x, dy1 = tv.y;
+            if constexpr (FUSED) {
+                float p0 = wf.x * fs_s[st][0], p1 = wf.z * fs_s[st][0];
+                if constexpr (NFS > 1) { p0 = __builtin_fmaf(wf.y, fs_s[st][1], p0); p1 = __builtin_fmaf(wf.w, fs_s[st][1], p1); }
+#pragma unroll
+                for (int j = 0; j < U; ++j) { p0 = __builtin_fmaf(w0[j], act[j], p0); p1 = __builtin_fmaf(w1[j], act[j], p1); }
+                const float y0 = quad_sum(p0), y1 = quad_sum(p1);
+                s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+            }
             // ---- dL/dh(t) ----
             float dht[U];
             if constexpr (DG) {
@@ -635,12 +638,13 @@ struct S16XGrad {
 };
 
 // one block of <= S = 2 steps of the train step's backward pass (s16x_block without dL/du, with the weight gradient)
-template <int FM, bool DG, int U, int S, bool FULL>
+// FUSED = false (the split backward): `ts` holds dL/dy; DX: dL/dx as well (the frozen block's feature-gradient path), written to `dxs`
+template <int FM, bool DG, int U, int S, bool FULL, bool FUSED = true, bool DX = false>
 __device__ __forceinline__ void s16x_train_block(const SeqArgs& a, TabPtr tl0, const float (&oh)[4], const S16XSel& E, S16XGrad<DG, U>& G,
                                                  const float2* xs, const float2* ts, int n, int q, int tloc, int nstep, bool valid,
-                                                 const float (&h0)[U], float (&dh)[U], float& loss_acc) {
+                                                 const float (&h0)[U], float (&dh)[U], float& loss_acc, float2* dxs = nullptr) {
     using T = S16X<DG, U>;
-    constexpr int NFS = T::NFS;
+    constexpr int NFS = T::NFS, F = S16Cfg<FM>::F;
     static_assert(S == 2, "K = 32 of the weight-gradient contraction = 16 sequences x the block's two steps");
     float h[U], hp_s[S][U], r_s[S][U], z_s[S][U], n_s[S][U], nh_s[S][U], hid_s[S][U], fs_s[S][NFS];
     unsigned vc[S][2][3][2], vh[S][2][3][2];          // transposed operands: [step][N tile][term][word] of the cell's / fc_hid's V
@@ -729,14 +733,16 @@ __device__ __forceinline__ void s16x_train_block(const SeqArgs& a, TabPtr tl0, c
 #pragma unroll
                 for (int j = 0; j < U; ++j) act[j] = __builtin_fmaf(z_s[st][j], hp_s[st][j] - n_s[st][j], n_s[st][j]);      // h(t)
             }
-            float p0 = wf.x * fs_s[st][0], p1 = wf.z * fs_s[st][0];
-            if constexpr (NFS > 1) { p0 = __builtin_fmaf(wf.y, fs_s[st][1], p0); p1 = __builtin_fmaf(wf.w, fs_s[st][1], p1); }
-#pragma unroll
-            for (int j = 0; j < U; ++j) { p0 = __builtin_fmaf(w0[j], act[j], p0); p1 = __builtin_fmaf(w1[j], act[j], p1); }
             const float2 tv = ts[n * kChunkPad + tloc + st];
-            const float y0 = quad_sum(p0), y1 = quad_sum(p1);
-            float dy0, dy1;
-            s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+            float dy0 = tv.x, dy1 = tv.y;
+            if constexpr (FUSED) {
+                float p0 = wf.x * fs_s[st][0], p1 = wf.z * fs_s[st][0];
+                if constexpr (NFS > 1) { p0 = __builtin_fmaf(wf.y, fs_s[st][1], p0); p1 = __builtin_fmaf(wf.w, fs_s[st][1], p1); }
+#pragma unroll
+                for (int j = 0; j < U; ++j) { p0 = __builtin_fmaf(w0[j], act[j], p0); p1 = __builtin_fmaf(w1[j], act[j], p1); }
+                const float y0 = quad_sum(p0), y1 = quad_sum(p1);
+                s16_loss(lossc, y0 - tv.x, y1 - tv.y, dy0, dy1, loss_acc);
+            }
 #pragma unroll
             for (int j = 0; j < U; ++j) { G.dwo[0][j] = __builtin_fmaf(dy0, act[j], G.dwo[0][j]); G.dwo[1][j] = __builtin_fmaf(dy1, act[j], G.dwo[1][j]); }
 #pragma unroll
@@ -835,6 +841,26 @@ __device__ __forceinline__ void s16x_train_block(const SeqArgs& a, TabPtr tl0, c
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) dh[j] = acc[j / 4][j % 4];
+            if constexpr (DX) {      // dL/dx: the feature gradient of the lane's slots (two free rows of the second output tile), gathered over the quads
+                float dfs[NFS];
+#pragma unroll
+                for (int e = 0; e < NFS; ++e) {
+                    dfs[e] = acc[(U + e) / 4][(U + e) % 4];
+                    if constexpr (DG) dfs[e] = __builtin_fmaf(dy0, e ? wf.y : wf.x, __builtin_fmaf(dy1, e ? wf.w : wf.z, dfs[e]));
+                }
+                float df[F];
+                {
+                    float g0[4], g1[4];
+                    gather_rows(dfs[0], g0);
+                    if constexpr (F > 1 && NFS > 1) gather_rows(dfs[1], g1);
+#pragma unroll
+                    for (int f = 0; f < F; ++f) df[f] = (f % NFS) ? g1[f / NFS] : g0[f / NFS];
+                }
+                const float2 xv = xs[n * kChunkPad + tloc + st];
+                float dI, dQ;
+                feat_bwd<FM>(xv.x, xv.y, df, dI, dQ);
+                if (q == 0) dxs[n * kChunkPad + tloc + st] = make_float2(dI, dQ);
+            }
         }
     }
 }
@@ -992,6 +1018,210 @@ __global__ __launch_bounds__(256, 1) void gru16x_train_kernel(SeqArgs a) {
     }
 }
 
+// =====================================================================================================================================
+// r06: the SPLIT entry points of these models (odpd_backbone_fwd / odpd_backbone_bwd at 16-sequences-per-wave batch sizes: a trained DPD of
+// 17 .. 24 units inside the chained train_dpd step, the autograd path, inference on large batches) on the same pipe, so that a checkpoint
+// written by one kernel of the family is read by another of the SAME family: forward (y, optional checkpoints in this file's layout),
+// backward from dL/dy with parameter gradients (and optionally dL/dx), backward from dL/dy with dL/dx only.
+// =====================================================================================================================================
+template <int FM, bool DG, int U, int S>
+__global__ __launch_bounds__(512, 1) void gru16x_fwd_kernel(SeqArgs a) {
+    using T = S16X<DG, U>;
+    constexpr int F = S16Cfg<FM>::F, NFS = T::NFS;
+    constexpr int kWave = 2 * 2 * 16 * kChunkPad;
+    static_assert(U == 6, "checkpoint layout: six units per lane = one float4 + one float2");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const GruLayout L = gru_layout(a.H, F, DG);
+    float* tab = smem;
+    float* pl = tab + s16_tab_floats(T::NG);
+    stage_params(pl, a.params, L.P);
+    s16x_fill_table<FM, DG, U>(tab, pl, L, lane, wave, nwb);
+    const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* ys = xs + 16 * kChunkPad;
+    // fc_out of the lane's units and feature slots: constants of the launch
+    float w0[U], w1[U];
+    {
+        float wv[4 * (T::NVW - 1)];
+#pragma unroll
+        for (int g = 0; g < T::NVW - 1; ++g) {
+            const float4 v = tab_ld(tl, (T::VW + g) * 64);
+            wv[4 * g] = v.x; wv[4 * g + 1] = v.y; wv[4 * g + 2] = v.z; wv[4 * g + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) { w0[j] = wv[j]; w1[j] = wv[U + j]; }
+    }
+    const float4 wf = tab_ld(tl, (T::VW + T::NVW - 1) * 64);
+    const int nwaves = gridDim.x * nwb, nblk = (a.T + S - 1) / S;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        float* ckg = a.ckpt ? a.ckpt + (size_t)grp * nblk * kS16xCkptFloats : nullptr;
+        float4* ck4 = reinterpret_cast<float4*>(ckg) + lane;
+        float2* ck2 = reinterpret_cast<float2*>(ckg + 256) + lane;
+        u32x4 A[T::NTF][3];
+        {
+            TabPtr tp = opaque(tl);
+#pragma unroll
+            for (int t = 0; t < T::NTF; ++t)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) A[t][k] = tabx_ld(tp, (T::FW + 3 * t + k) * 64);
+        }
+        float h[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) h[j] = 0.0f;
+        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
+            const int len = min(kChunk, a.T - t0);
+            wave_lds_fence();
+            stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+            wave_lds_fence();
+            for (int tt = 0; tt < len; ++tt) {
+                const float2 xv = xs[n * kChunkPad + tt];
+                float fs[NFS];
+                s16x_feats<FM, U>(xv.x, xv.y, oh, fs);
+                const Split3 B = s16x_operand<U>(h, fs);
+                f32x4 acc[T::NTF];
+#pragma unroll
+                for (int t = 0; t < T::NTF; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mm6r<T::NTF>(A, B, acc);
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int sr = j, sz = U + j, sh = 2 * U + j, si = 3 * U + j;
+                    const float r = sig_ps(acc[sr / 4][sr % 4]), z = sig_ps(acc[sz / 4][sz % 4]);
+                    const float nn = tanh_x<FM>(__builtin_fmaf(r, acc[sh / 4][sh % 4], acc[si / 4][si % 4]));
+                    h[j] = __builtin_fmaf(z, h[j] - nn, nn);
+                }
+                // head of this step: the hidden layer on an operand of its own ([h(t) | the step's feature slots])
+                float act[U];
+                if constexpr (DG) {
+                    const Split3 B2 = s16x_operand<U>(h, fs);
+                    float hid[U];
+                    s16x_hid<DG, U>(opaque(tl), B2, hid);
+#pragma unroll
+                    for (int j = 0; j < U; ++j) act[j] = relu_(hid[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < U; ++j) act[j] = h[j];
+                }
+                float p0 = wf.x * fs[0], p1 = wf.z * fs[0];
+                if constexpr (NFS > 1) { p0 = __builtin_fmaf(wf.y, fs[1], p0); p1 = __builtin_fmaf(wf.w, fs[1], p1); }
+#pragma unroll
+                for (int j = 0; j < U; ++j) { p0 = __builtin_fmaf(w0[j], act[j], p0); p1 = __builtin_fmaf(w1[j], act[j], p1); }
+                const float y0 = quad_sum(p0), y1 = quad_sum(p1);
+                if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
+                const int t1 = t0 + tt + 1;
+                if (ckg != nullptr && (t1 % S) == 0 && t1 < a.T) {
+                    const size_t o = (size_t)(t1 / S) * kS16xCkptFloats;
+                    ck4[o / 4] = make_float4(h[0], h[1], h[2], h[3]);
+                    ck2[o / 2] = make_float2(h[4], h[5]);
+                }
+            }
+            wave_lds_fence();
+            stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+        }
+    }
+}
+
+// backward from dL/dy.  NW: parameter gradients (one wave per SIMD, rows of partials as the train kernel); DX: dL/dx
+template <int FM, bool DG, int U, int S, bool NW, bool DX>
+__global__ __launch_bounds__(NW ? 256 : 512, 1) void gru16x_bwd_kernel(SeqArgs a) {
+    using T = S16X<DG, U>;
+    constexpr int F = S16Cfg<FM>::F;
+    constexpr int kWave = (DX ? 3 : 2) * 2 * 16 * kChunkPad;
+    static_assert(NW || DX, "nothing to compute");
+    static_assert(kChunk % S == 0, "a block never straddles two staged chunks");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const GruLayout L = gru_layout(a.H, F, DG);
+    float* tab = smem;
+    float* pl = tab + s16_tab_floats(T::NG);
+    stage_params(pl, a.params, L.P);
+    s16x_fill_table<FM, DG, U>(tab, pl, L, lane, wave, nwb);
+    const TabPtr tl = to_tab(reinterpret_cast<const float4*>(tab) + lane);
+    float oh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
+    float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
+    float2* xs = reinterpret_cast<float2*>(wbase);
+    float2* ts = xs + 16 * kChunkPad;                     // dL/dy
+    float2* dxs = DX ? ts + 16 * kChunkPad : nullptr;
+    S16XSel E;
+    S16XGrad<DG, U> G;
+    if constexpr (NW) { E = s16x_sel(lane); G.zero(); }
+    float loss_acc = 0.0f;
+    const int nwaves = gridDim.x * nwb, nblk = (a.T + S - 1) / S;
+    for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
+        const int b0 = grp * 16;
+        const bool valid = b0 + n < a.B;
+        const float* ckg = a.ckpt + (size_t)grp * nblk * kS16xCkptFloats;
+        const float4* ck4 = reinterpret_cast<const float4*>(ckg) + lane;
+        const float2* ck2 = reinterpret_cast<const float2*>(ckg + 256) + lane;
+        float dh[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) dh[j] = 0.0f;
+        int cur_chunk = -1;
+        for (int blk = nblk - 1; blk >= 0; --blk) {
+            const int tb = blk * S, nstep = min(S, a.T - tb);
+            const int chunk = tb / kChunk, t0 = chunk * kChunk;
+            float h0[U];
+            {
+                const size_t o = (size_t)blk * kS16xCkptFloats;
+                const float4 v = blk ? ck4[o / 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float2 w = blk ? ck2[o / 2] : make_float2(0.f, 0.f);
+                h0[0] = v.x; h0[1] = v.y; h0[2] = v.z; h0[3] = v.w; h0[4] = w.x; h0[5] = w.y;
+            }
+            if (chunk != cur_chunk) {
+                if constexpr (DX) {
+                    if (cur_chunk >= 0) {
+                        const int pt0 = cur_chunk * kChunk;
+                        wave_lds_fence();
+                        stage_out<16>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                    }
+                }
+                wave_lds_fence();
+                const int len = min(kChunk, a.T - t0);
+                stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f), a.frame_idx, a.frame_stride, a.frames_bf16 != 0);
+                stage_in<16>(ts, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
+                wave_lds_fence();
+                cur_chunk = chunk;
+            }
+            if constexpr (NW) {
+                if (nstep == S) s16x_train_block<FM, DG, U, S, true, false, DX>(a, tl, oh, E, G, xs, ts, n, q, tb - t0, nstep, valid, h0, dh, loss_acc, dxs);
+                else s16x_train_block<FM, DG, U, S, false, false, DX>(a, tl, oh, E, G, xs, ts, n, q, tb - t0, nstep, valid, h0, dh, loss_acc, dxs);
+            } else {
+                if (nstep == S) s16x_block<FM, DG, U, S, true, false>(a, tl, oh, xs, ts, dxs, n, q, tb - t0, nstep, valid, h0, dh, loss_acc);
+                else s16x_block<FM, DG, U, S, false, false>(a, tl, oh, xs, ts, dxs, n, q, tb - t0, nstep, valid, h0, dh, loss_acc);
+            }
+        }
+        if constexpr (DX) {
+            if (cur_chunk >= 0) {
+                const int pt0 = cur_chunk * kChunk;
+                wave_lds_fence();
+                stage_out<16>(dxs, a.dx, b0, a.B, a.T, pt0, min(kChunk, a.T - pt0), lane);
+                wave_lds_fence();
+            }
+        }
+    }
+    if constexpr (NW) {
+        const int P4 = L.P + kLossCols;
+        __syncthreads();
+        s16x_write_row<FM, DG, U>(smem + wave * P4, L, G, n, q, 0.0f);
+        __syncthreads();
+        float* prow = a.partials + (size_t)blockIdx.x * P4;
+        for (int i = threadIdx.x; i < P4; i += blockDim.x) {
+            float v = smem[i];
+            for (int wv = 1; wv < nwb; ++wv) v += smem[wv * P4 + i];
+            prow[i] = v;
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
@@ -1055,6 +1285,70 @@ int gru_s16x_train(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int
     if (FM == FEAT_DGRU6) return launch_s16x_train<FEAT_DGRU6, true>(st, a, P, grid);
     if (FM == FEAT_Q4) return launch_s16x_train<FEAT_Q4, false>(st, a, P, grid);
     return launch_s16x_train<FEAT_A4, false>(st, a, P, grid);
+}
+// ---- split entry points (forward / backward from dL/dy) ----
+template <int FM, bool DG>
+static int launch_s16x_fwd(hipStream_t st, const SeqArgs& a, int P) {
+    using T = S16X<DG, 6>;
+    constexpr int kWave = 2 * 2 * 16 * kChunkPad, kWaves = 8;
+    size_t body = (size_t)kWaves * kWave;
+    if (body < (size_t)pad4(P)) body = pad4(P);
+    const size_t lds = ((size_t)s16_tab_floats(T::NG) + body) * sizeof(float);
+    if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+    const int need = (a.ngroups + kWaves - 1) / kWaves, cap = device_cus();
+    auto k = gru16x_fwd_kernel<FM, DG, 6, kS16xStride>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(need < cap ? need : cap), dim3(64 * kWaves), lds, st, a);
+    return (int)hipGetLastError();
+}
+int gru_s16x_fwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0) {
+    int FM; bool DG;
+    if (!s16x_cfg(m, FM, DG) || !gru_s16x_train_ok(m)) return ODPD_EUNSUPPORTED;
+    if (!a0.y) return ODPD_EINVAL;
+    SeqArgs a = a0;
+    a.ngroups = (a.B + 15) / 16;
+    const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
+    if (FM == FEAT_RAW2) return launch_s16x_fwd<FEAT_RAW2, false>(st, a, P);
+    if (FM == FEAT_DGRU6) return launch_s16x_fwd<FEAT_DGRU6, true>(st, a, P);
+    if (FM == FEAT_Q4) return launch_s16x_fwd<FEAT_Q4, false>(st, a, P);
+    return launch_s16x_fwd<FEAT_A4, false>(st, a, P);
+}
+template <int FM, bool DG, bool NW, bool DX>
+static int launch_s16x_bwd(hipStream_t st, const SeqArgs& a, int P, int rows) {
+    using T = S16X<DG, 6>;
+    constexpr int kWave = (DX ? 3 : 2) * 2 * 16 * kChunkPad, kWaves = NW ? 4 : 8;
+    size_t body = (size_t)kWaves * kWave;
+    if (body < (size_t)pad4(P)) body = pad4(P);
+    size_t lds = ((size_t)s16_tab_floats(T::NG) + body) * sizeof(float);
+    if (NW && lds < reduce_scratch_bytes(P, kWaves)) lds = reduce_scratch_bytes(P, kWaves);
+    if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+    const int need = (a.ngroups + kWaves - 1) / kWaves, cap = device_cus();
+    const int grid = NW ? rows : (need < cap ? need : cap);      // (with parameter gradients: one row per workgroup, the host's row count)
+    auto k = gru16x_bwd_kernel<FM, DG, 6, kS16xStride, NW, DX>;
+    if (int e = allow_big_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * kWaves), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <int FM, bool DG>
+static int launch_s16x_bwd_mode(hipStream_t st, const SeqArgs& a, int P, int rows) {
+    const bool nw = a.partials != nullptr, dx = a.dx != nullptr;
+    if (nw && dx) return launch_s16x_bwd<FM, DG, true, true>(st, a, P, rows);
+    if (nw) return launch_s16x_bwd<FM, DG, true, false>(st, a, P, rows);
+    if (dx) return launch_s16x_bwd<FM, DG, false, true>(st, a, P, rows);
+    return ODPD_EINVAL;
+}
+// rows = gru_s16n_rows(m, B): the partial rows the host reduces (the exact kernels' count)
+int gru_s16x_bwd(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int rows) {
+    int FM; bool DG;
+    if (!s16x_cfg(m, FM, DG) || !gru_s16x_train_ok(m)) return ODPD_EUNSUPPORTED;
+    if (!a0.ckpt || !a0.dy) return ODPD_EINVAL;
+    SeqArgs a = a0;
+    a.ngroups = (a.B + 15) / 16;
+    const int P = gru_layout(m->hidden, FM == FEAT_RAW2 ? 2 : (FM == FEAT_DGRU6 ? 6 : 4), DG).P;
+    if (FM == FEAT_RAW2) return launch_s16x_bwd_mode<FEAT_RAW2, false>(st, a, P, rows);
+    if (FM == FEAT_DGRU6) return launch_s16x_bwd_mode<FEAT_DGRU6, true>(st, a, P, rows);
+    if (FM == FEAT_Q4) return launch_s16x_bwd_mode<FEAT_Q4, false>(st, a, P, rows);
+    return launch_s16x_bwd_mode<FEAT_A4, false>(st, a, P, rows);
 }
 // frozen-PA loss step; the grid (= loss rows the host reduces) is gru_s16n_rows(m, B), the same as the exact-fp32 kernel's
 int gru_s16x_lossdx(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, int grid) {

@@ -289,6 +289,9 @@ int64_t gru_s16x_ckpt_floats(const odpd_model_t* m, int B, int T);
 // ... and the fused train step of those models on the same pipe (r06; "s16x_train" knob), rows = gru_s16n_rows, workspace = gru_s16x_ckpt_floats
 bool gru_s16x_train_ok(const odpd_model_t* m);
 int gru_s16x_train(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int grid);
+// ... and their split forward / backward (from dL/dy) entry points: one checkpoint layout for the whole family (gru_s16x_ckpt_floats)
+int gru_s16x_fwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a);
+int gru_s16x_bwd(hipStream_t s, const odpd_model_t* m, const SeqArgs& a, int rows);
 // optim.hip: clip + AdamW launch that also records loss = grad[P] * inv_count into loss_out (nullable)
 int launch_clip_adamw(hipStream_t st, int64_t P, float* params, float* grad, float* exp_avg, float* exp_avg_sq, int64_t step,
                       double lr, double beta1, double beta2, double eps, double weight_decay, double max_norm, float* norm_out,

@@ -150,3 +150,59 @@ def test_split_train_kernel_on_framed_bf16_and_fp32_streams(s16_lib):
             loss = fused_train_step(opt, x, t, "l2", 200.0, B * T * 2)
             res.append((float(loss.item()), net.backbone.flat_params().detach().clone()))
         assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]), dt
+
+
+def _split(lib, bb, x, dy, knob, want_w, want_dx):
+    """odpd_backbone_fwd (with checkpoints) + odpd_backbone_bwd (from dL/dy) through the raw C ABI -> (y, parameter gradient | None, dL/dx | None)"""
+    from opendpd_amd import _lib
+    assert lib.odpd_set_tuning(b"s16x_train", knob) == 0
+    B, T = x.shape[:2]
+    P = bb.n_flat
+    y = torch.full_like(x, float("nan"))
+    ck = torch.empty(int(lib.odpd_ckpt_floats(C.byref(bb.desc), B, T)), device="cuda")
+    _lib.check(lib.odpd_backbone_fwd(_lib.stream_ptr(), C.byref(bb.desc), B, T, _lib.ptr(bb.flat_params()), _lib.ptr(x), _lib.ptr(y), _lib.ptr(ck), None), "fwd")
+    rows = int(lib.odpd_partial_rows(C.byref(bb.desc), B, T, 0))
+    part = torch.full((rows, P + _lib.LOSS_COLS), float("nan"), device="cuda") if want_w else None
+    dx = torch.full_like(x, float("nan")) if want_dx else None
+    _lib.check(lib.odpd_backbone_bwd(_lib.stream_ptr(), C.byref(bb.desc), B, T, _lib.ptr(bb.flat_params()), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(ck),
+                                     _lib.ptr(part) if want_w else None, _lib.ptr(dx) if want_dx else None), "bwd")
+    torch.cuda.synchronize()
+    return y, (part.double().sum(0)[:P] if want_w else None), dx
+
+
+@pytest.mark.parametrize("bb,H", [("dgru", 23), ("gru", 23), ("dgru", 17), ("qgru", 20), ("qgru_amp1", 24)])
+@pytest.mark.parametrize("B,T", [(37, 70), (16 * 9 + 5, 21), (33, 201), (5, 1)])
+@pytest.mark.parametrize("want_w,want_dx", [(True, False), (True, True), (False, True)])
+def test_split_forward_and_backward_against_fp64_oracle_and_exact_kernels(s16_lib, bb, H, B, T, want_w, want_dx):
+    """the split entry points of hidden 17 .. 24 (r06: gru16x_fwd_kernel, gru16x_bwd_kernel<NW, DX>): forward output, parameter gradients and dL/dx
+    from a given dL/dy against the fp64 oracle at the fused step's bounds, and against the exact-fp32 kernels they replace"""
+    from opendpd_amd import CoreModel
+    from oracle.oracle import Oracle, make_model
+    torch.manual_seed(H * 5 + B)
+    net = CoreModel(2, H, 1, bb).cuda().backbone
+    x, _ = _data(B, T, H + B + 1)
+    rng = np.random.RandomState(B + T)
+    dy = (rng.randn(B, T, 2) / (B * T)).astype(np.float32)
+    xg, dyg = torch.from_numpy(x).cuda(), torch.from_numpy(dy).cuda()
+    yx, gx, dxx = _split(s16_lib, net, xg, dyg, 1, want_w, want_dx)
+    yn, gn, dxn = _split(s16_lib, net, xg, dyg, 0, want_w, want_dx)
+    o = Oracle("f64")
+    m = make_model(bb, H)
+    pp = net.flat_params().detach().cpu().numpy().astype(np.float64)
+    yo, _ = o.forward(m, pp, x.astype(np.float64))
+    go, dxo = o.backward(m, pp, x.astype(np.float64), dy.astype(np.float64), need_dx=want_dx)
+    yo = torch.from_numpy(np.asarray(yo)).cuda()
+    sy = float(yo.abs().max())
+    assert float((yx.double() - yo).abs().max()) / sy < 1.5e-6
+    assert float((yx - yn).abs().max()) / sy < 2e-6
+    if want_w:
+        go = torch.from_numpy(np.asarray(go)).cuda()
+        sc = float(go.abs().max())
+        ex, en = float((gx - go).abs().max()) / sc, float((gn - go).abs().max()) / sc
+        assert ex < 1.5e-6 and ex < 3.0 * en + 1e-7, (ex, en)
+    if want_dx:
+        do = torch.from_numpy(np.asarray(dxo)).cuda()
+        sc = float(do.abs().max())
+        ex, en = float((dxx.double() - do).abs().max()) / sc, float((dxn.double() - do).abs().max()) / sc
+        assert torch.isfinite(dxx).all()
+        assert ex < 1.5e-6 and ex < 3.0 * en + 1e-7, (ex, en)
