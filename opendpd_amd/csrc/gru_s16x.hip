@@ -1,5 +1,13 @@
-// gru_s16x.hip — the frozen-PA step (forward + loss + dL/du, modules/train_funcs.py:33-39 behind models.py:163-176) of the GRU family
-// (backbones/{gru,dgru,qgru,qgru_amp1}.py) for hidden 17 .. 24 — the reference's default PA size is 23 — on the bf16 MATRIX pipe with
+// gru_s16x.hip — the 16-sequences-per-wave kernels of the GRU family (backbones/{gru,dgru,qgru,qgru_amp1}.py) for hidden 17 .. 24 — the
+// reference's default PA size is 23 — on the bf16 MATRIX pipe.  Kernels (all on one checkpoint layout):
+//   gru16x_lossdx_kernel   r05  frozen-PA step: forward + loss + dL/du (modules/train_funcs.py:33-39 behind models.py:163-176)
+//   gru16x_train_kernel    r06  fused train step: forward + loss + BPTT with parameter gradients (train_funcs.py:28-48)
+//   gru16x_fwd_kernel      r06  forward (y, optional checkpoints): odpd_backbone_fwd
+//   gru16x_bwd_kernel      r06  backward from dL/dy: parameter gradients and / or dL/dx: odpd_backbone_bwd
+// The text below describes the arithmetic and the lane mapping on the frozen-PA step, where they were introduced; the weight gradient of the
+// trained kernels has its own header further down ("r06: the fused TRAIN step").
+//
+// Arithmetic: the matrix pipe with
 // three-way operand splits ("bf16x3"): every fp32 operand v is carried as three bf16 terms v = v1 + v2 + v3 (round-to-nearest residuals,
 // exact), and a product a.b is the six term products of weight 2^-16 and above (a1b3, a3b1, a2b2, a1b2, a2b1, a1b1) accumulated in
 // fp32 by v_mfma_f32_16x16x32_bf16: what is dropped is below 2^-23 |a||b| — the size of one fp32 rounding of the product.
