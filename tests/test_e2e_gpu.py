@@ -804,6 +804,46 @@ def test_deltajanet_train_dpd_first_steps_match_the_reference(apa_workdir, steps
 V2_QAT_EXACT_STEPS, V2_QAT_REL_EXACT, V2_QAT_REL_ALL = 1, 8e-4, 2.2e-2
 
 
+def test_train_pa_h23_at_a_large_batch_trains_the_same_on_the_split_and_the_exact_kernels(apa_workdir, steps_seen):
+    """r06: `train_pa --PA_backbone dgru --PA_hidden_size 23` (the PA of every train_dpd run, bash_scripts/OpenDPDv2.sh:39-52) at a batch that takes the
+    16-sequences-per-wave kernels (8 192 frames: 8 steps per epoch on APA_200MHz), three epochs through the API: once on the bf16 x 3 train kernel
+    (csrc/gru_s16x.hip, the default), once on the exact-fp32 kernel it replaced (knob "s16x_train" = 0).  Same seed, same frame order: the per-step
+    losses agree to 2e-5 (two fp32-equivalent summation orders through 24 optimiser steps), the logged metrics to 0.02 dB, and both runs land on the
+    same (still early: 24 optimiser steps) NMSE."""
+    import opendpd_amd as od
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    kw = dict(dataset_name="APA_200MHz", PA_backbone="dgru", PA_hidden_size=23, frame_length=200, batch_size=8192, seed=0, n_epochs=3, accelerator="cuda",
+              lr=2e-3)
+    out = {}
+    try:
+        for knob in (1, 0):
+            assert lib.odpd_set_tuning(b"s16x_train", knob) == 0
+            res = od.train_pa(**kw)
+            hist = pd.read_csv(os.path.join("log", "APA_200MHz", "train_pa", "history", os.path.basename(res["log_path"])))
+            out[knob] = (steps_seen["losses"].cpu().numpy().copy(), hist, torch.load(res["model_path"], map_location="cpu"))
+    finally:
+        lib.odpd_set_tuning(b"s16x_train", 1)
+    # the two runs did take different kernels (their best checkpoints differ in the last bits) and ended in the same place
+    pa, pb = out[1][2], out[0][2]
+    assert list(pa.keys()) == list(pb.keys())
+    assert any(not torch.equal(pa[k], pb[k]) for k in pa)
+    for k in pa:
+        assert (pa[k] - pb[k]).abs().max() <= 2e-5 * max(1.0, float(pb[k].abs().max())), k
+    la, lb = out[1][0], out[0][0]
+    assert la.shape == lb.shape and la.shape[0] >= 7
+    rel = np.abs(la - lb) / lb
+    print("[train_pa H23, batch 8192] last-epoch per-step loss deviation split vs exact:", " ".join(f"{e:.1e}" for e in rel))
+    assert rel.max() < 2e-5, rel
+    ha, hb = out[1][1], out[0][1]
+    assert list(ha.columns) == list(hb.columns) and len(ha) == 3
+    for col in ("TRAIN_LOSS",):
+        assert np.allclose(ha[col], hb[col], rtol=2e-5), (col, ha[col].values, hb[col].values)
+    for col in ("VAL_NMSE", "VAL_EVM", "VAL_ACLR_AVG", "TEST_NMSE", "TEST_ACLR_AVG"):
+        assert np.abs(ha[col] - hb[col]).max() < 0.02, (col, ha[col].values, hb[col].values)
+    assert ha["TRAIN_LOSS"].iloc[-1] < 0.5 * ha["TRAIN_LOSS"].iloc[0] and ha["VAL_NMSE"].iloc[-1] < -5.0      # (24 steps in all: it learns; measured 0.066 -> 0.0195, -6.6 dB)
+
+
 def _check_first_steps(key, losses, n_exact, rel_exact=1e-6, rel_all=2e-3):
     """the reference's per-step losses of the first 20 steps (oracle/gen_run_anchor_first_steps.py): the first `n_exact` to rounding level —
     no threshold decision / quantisation boundary has been crossed differently yet —, all 20 within the epoch's tolerance"""
