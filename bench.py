@@ -596,8 +596,8 @@ def main():
         dpd["config5"] = {"workload": "train_dpd: quantisation-aware QGRU H10 (W8A8, 515 params) DPD -> frozen DGRU H23 PA, target = x",
                           "value": B * T * n3 / el5, "unit": "IQ samples/s", "ms_per_step": 1e3 * el5 / n3, "loss": loss5,
                           "roofline": priced(FLOPS_TRAIN_QGRU10 + flops_frozen_dgru(23), el5, n3, cascade_spans(opt5, xc, tc, world * B * T * 2),
-                                             {"dpd_fwd": "qat16_fwd_kernel<Q4, NT 1, LUT>", "pa_fwd_loss_dx": "gru16x_lossdx_kernel<DGRU6> (bf16x3 matrix pipe; frozen: loss + dL/du)",
-                                              "dpd_bwd": "qat16_bwd_kernel<Q4, NT 1, LUT>", "reduce_clip_optimiser": "reduce_partials_kernel + clip_adamw_kernel"})}
+                                             {"dpd_fwd": "qat16u_fwd_kernel<Q4, LUT, 3 unit slots per lane>", "pa_fwd_loss_dx": "gru16x_lossdx_kernel<DGRU6> (bf16x3 matrix pipe; frozen: loss + dL/du)",
+                                              "dpd_bwd": "qat16u_bwd_kernel<Q4, LUT, 3 unit slots per lane>", "reduce_clip_optimiser": "reduce_partials_kernel + clip_adamw_kernel"})}
         del xc, tc, casc, opt5
         # the same step at the reference's own batch size (latency regime): GRU-family pairs run the one-launch cascade step
         # (csrc/gru_cascade.hip: DPD wave + frozen-PA wave per frame), the others the chained one-sequence-per-wave launches

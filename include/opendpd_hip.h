@@ -121,8 +121,10 @@ int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T);
  * rounding; CHANGES odpd_ckpt_floats of those models: the two kernels lay their checkpoints out differently); "s16x_train" (r06): 0 = the
  * fused TRAIN step of those models (odpd_train_fwd_bwd / the framed epoch loops at 16-sequences-per-wave batch sizes) on the exact-fp32 kernel
  * instead of the bf16-split one (same results to fp32 rounding; odpd_train_workspace_floats answers the larger of the two layouts); "lstm_pack": 0 = the fused
- * lstm / vdlstm train kernel of <= 13 hidden units without K-packed input slots (same results to fp32 rounding); "xchg_fused" and "lstm_pack"
- * change no buffer size.  Every successful call bumps odpd_tuning_generation, whichever knob it was. */
+ * lstm / vdlstm train kernel of <= 13 hidden units without K-packed input slots (same results to fp32 rounding); "qat_u3": 0 = the
+ * quantisation-aware GRUCell models (gru / dgru / qgru / qgru_amp1 with ODPD_FLAG_QUANT) of <= 12 hidden units with four unit slots per lane
+ * instead of three (identical results on 8-bit grids, summation order of the wider ones unchanged); "xchg_fused", "lstm_pack" and "qat_u3"
+ * change no buffer size (and leave odpd_tuning_generation alone); every successful call on one of the others bumps it. */
 int odpd_set_tuning(const char* key, int64_t value);
 /* Counter bumped by every successful odpd_set_tuning: buffers sized by the queries above are valid for the generation they were
  * sized in (the row count / workspace layout of a (B,T) shape depends on the knobs). */

@@ -106,6 +106,8 @@ odpd::Tuning& odpd::tuning() {
         v.s16x_train = e ? atoi(e) : 1;           // 0 = fused train step of hidden 17 .. 24 on the exact-fp32 kernel (gru_s16n.hip) instead of the bf16x3 one
         e = getenv("ODPD_LSTM_PACK");
         v.lstm_pack = e ? atoi(e) : 1;            // 0 = lstm16_train_kernel without K-packed input slots (hidden <= 13)
+        e = getenv("ODPD_QAT_U3");
+        v.qat_u3 = e ? atoi(e) : 1;               // 0 = quantisation-aware GRUCell kinds of hidden <= 12 with four unit slots per lane instead of three (qat_s16.hip)
         return v;
     }();
     return t;
@@ -121,6 +123,7 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
     if (!strcmp(key, "s16x")) { tuning().s16x = (int)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "s16x_train")) { tuning().s16x_train = (int)value; ++g_tuning_generation; return 0; }
     if (!strcmp(key, "lstm_pack")) { tuning().lstm_pack = (int)value; return 0; }      // (same buffers either way)
+    if (!strcmp(key, "qat_u3")) { tuning().qat_u3 = (int)value; return 0; }            // (same buffers either way)
     return ODPD_EINVAL;
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }

@@ -58,12 +58,26 @@ template <int MK, int NT> struct QT {
     static constexpr int kTiles = 5 * NT + 1 + (K::DGRU ? 2 * NT : 0);
 };
 
-template <int MK, int NT>
+// UNIT SLOTS PER LANE.  U = 4: tile index j = 4 q + e of tile kt (row j of an A operand, element e of lane quad q) is unit 16 kt + j.
+// U = 3 (one tile, hidden <= 12) and U = 2 (hidden <= 8): unit U q + e for e < U; elements U .. 3 of every per-unit vector, rows / columns
+// 4 q + U .. 4 q + 3 of every operand tile and those bytes of the packed int8 operands are DEAD (zero weights, never written out), and the
+// kernels do not compute them: a quarter (half) of the per-unit arithmetic of the cell, the head and the backward goes away, and so do the
+// dead K chunks of every mat-vec over units (hidden 10, the reference's QGRU: 12 unit slots per 16 sequences instead of 16).
+// q16_unit answers `H` for "no unit".
+template <int U>
+__host__ __device__ __forceinline__ int q16_unit(int kt, int j, int H) {
+    if (U == 4) return 16 * kt + j;
+    return (j & 3) < U ? U * (j >> 2) + (j & 3) : H;
+}
+#define Q16_EACHU _Pragma("unroll") for (int i = 0; i < U; ++i)
+
+template <int MK, int NT, int U>
 __device__ __forceinline__ float4 q16_entry(const float* pl, const QatLayout& L, const WQ& wq, int grp, int m, int q) {
     using T = QT<MK, NT>;
     using K = Kind<MK>;
     constexpr int F = K::F;
     const int H = L.H;
+    static_assert(U == 4 || NT == 1, "fewer than four units per lane: one unit tile only");
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (NT == 1 && (grp == T::I8W || grp == T::I8W + 1)) {
         // v_mfma_i32_16x16x32_i8 A operands of lane (m, q): byte j <-> K index 8 q + j.  h part: bytes 0..3 = k_w(W_h)[g][m][4q+j];
@@ -71,12 +85,14 @@ __device__ __forceinline__ float4 q16_entry(const float* pl, const QatLayout& L,
         auto byte_of = [](float kf) { return (unsigned)((int)kf) & 0xffu; };
         auto wh = [&](int g) {
             unsigned w = 0;
-            for (int j = 0; j < 4; ++j) { const int u = 4 * q + j; if (m < H && u < H) w |= byte_of(kq(pl[L.o_wh + (g * H + m) * H + u], wq.h)) << (8 * j); }
+            const int o = q16_unit<U>(0, m, H);
+            for (int j = 0; j < 4; ++j) { const int u = q16_unit<U>(0, 4 * q + j, H); if (o < H && u < H) w |= byte_of(kq(pl[L.o_wh + (g * H + o) * H + u], wq.h)) << (8 * j); }
             return w;
         };
         auto wx = [&](int g) {
             unsigned w = 0;
-            for (int c = 0; c < K::NCH; ++c) { const int slot = 4 * c + q; if (m < H && slot < F) w |= byte_of(kq(pl[L.o_wx + (g * H + m) * F + slot], wq.x)) << (8 * c); }
+            const int o = q16_unit<U>(0, m, H);
+            for (int c = 0; c < K::NCH; ++c) { const int slot = 4 * c + q; if (o < H && slot < F) w |= byte_of(kq(pl[L.o_wx + (g * H + o) * F + slot], wq.x)) << (8 * c); }
             return w;
         };
         if (grp == T::I8W) return make_float4(__uint_as_float(wh(0)), __uint_as_float(wx(0)), __uint_as_float(wh(1)), __uint_as_float(wx(1)));
@@ -93,36 +109,36 @@ __device__ __forceinline__ float4 q16_entry(const float* pl, const QatLayout& L,
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (grp < T::HH) {
-            const int g = grp / NT, o = 16 * (grp % NT) + m, slot = 4 * e + q;
+            const int g = grp / NT, o = q16_unit<U>(grp % NT, m, H), slot = 4 * e + q;
             v[e] = (e < K::NCH && slot < F && o < H) ? kq(pl[L.o_wx + (g * H + o) * F + slot], wq.x) : 0.0f;
         } else if (grp < T::BX) {
-            const int r = grp - T::HH, g = r / (NT * NT), o = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::HH, g = r / (NT * NT), o = q16_unit<U>((r / NT) % NT, m, H), k = q16_unit<U>(r % NT, 4 * q + e, H);
             v[e] = (o < H && k < H) ? kq(pl[L.o_wh + (g * H + o) * H + k], wq.h) : 0.0f;
         } else if (grp < T::BH) {
-            const int r = grp - T::BX, u = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::BX, u = q16_unit<U>(r % NT, 4 * q + e, H);
             v[e] = u < H ? pl[L.o_bx + (r / NT) * H + u] : 0.0f;
         } else if (grp < T::WOUT) {
-            const int r = grp - T::BH, u = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::BH, u = q16_unit<U>(r % NT, 4 * q + e, H);
             v[e] = u < H ? pl[L.o_bh + (r / NT) * H + u] : 0.0f;
         } else if (grp < T::HID) {
-            const int r = grp - T::WOUT, u = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::WOUT, u = q16_unit<U>(r % NT, 4 * q + e, H);
             v[e] = u < H ? kq(pl[L.o_wo + (r / NT) * L.OW + u], wq.o) : 0.0f;
         } else if (grp < T::BHID) {
-            const int r = grp - T::HID, o = 16 * (r / NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::HID, o = q16_unit<U>(r / NT, m, H), k = q16_unit<U>(r % NT, 4 * q + e, H);
             v[e] = (o < H && k < H) ? kq(pl[L.o_whid + o * H + k], wq.hid) : 0.0f;
         } else if (grp < T::WOF) {
-            const int u = 16 * (grp - T::BHID) + 4 * q + e;
+            const int u = q16_unit<U>(grp - T::BHID, 4 * q + e, H);
             v[e] = u < H ? pl[L.o_bhid + u] : 0.0f;
         } else if (grp < T::HIDT) {
-            const int r = grp - T::HHT, g = r / (NT * NT), i = 16 * ((r / NT) % NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::HHT, g = r / (NT * NT), i = q16_unit<U>((r / NT) % NT, m, H), k = q16_unit<U>(r % NT, 4 * q + e, H);
             v[e] = (i < H && k < H) ? kq(pl[L.o_wh + (g * H + k) * H + i], wq.h) : 0.0f;
         } else if (grp < T::IHT) {
-            const int r = grp - T::HIDT, i = 16 * (r / NT) + m, k = 16 * (r % NT) + 4 * q + e;
+            const int r = grp - T::HIDT, i = q16_unit<U>(r / NT, m, H), k = q16_unit<U>(r % NT, 4 * q + e, H);
             v[e] = (i < H && k < H) ? kq(pl[L.o_whid + k * H + i], wq.hid) : 0.0f;
         } else {
             // transposed input weights with the output rows permuted so that D row 4 q' + i = slot 4 i + q': the MFMA result of
             // lane (n, q) element c IS the gradient of the lane's own feature slot 4 c + q
-            const int r = grp - T::IHT, g = r / NT, k = 16 * (r % NT) + 4 * q + e, slot = 4 * (m & 3) + (m >> 2);
+            const int r = grp - T::IHT, g = r / NT, k = q16_unit<U>(r % NT, 4 * q + e, H), slot = 4 * (m & 3) + (m >> 2);
             v[e] = (slot < F && k < H) ? kq(pl[L.o_wx + (g * H + k) * F + slot], wq.x) : 0.0f;
         }
     }
@@ -183,17 +199,21 @@ __device__ __forceinline__ void i8_matvecs(TabPtr tl, int base, int bh, int bx, 
 //   pph = p(q_a(h)) s_hw  (the weight scale of the transposed mat-vec rides on the mask)
 template <int NT> struct SaveS { f32x4 hp[NT], hqk[NT], n[NT], z[NT], c2[NT], c3[NT], An[NT], Az[NT], B1[NT], B2A[NT], pph[NT], hnew[NT]; };
 
-template <int MK, int NT, bool LUT, bool SAVE>
+template <int MK, int NT, int U, bool LUT, bool SAVE>
 __device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const QK& k, const float4* lutq, const float (&fqk)[Kind<MK>::NCH],
                                          f32x4 (&h)[NT], SaveS<NT>& sv) {
     using T = QT<MK, NT>;
     constexpr int NCH = Kind<MK>::NCH;
     constexpr bool I8 = LUT && NT == 1;       // 8-bit weights and activations, one unit tile: the integer matrix pipe
     f32x4 hqk[NT];
-    int hb[4];
+    int hb[4] = {0, 0, 0, 0};
+    if constexpr (U < 4) {                    // dead elements: constants (whatever reads a whole vector — tile stores, checkpoints — sees zeros)
+        hqk[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SAVE) sv = SaveS<NT>();
+    }
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
-        ODPD_EACH4 {
+        Q16_EACHU {
             const float v = h[kt][i] * k.inv_ha, m = gm(v, k);
             if constexpr (I8) {
                 hb[i] = i8_bits(m);
@@ -222,7 +242,7 @@ __device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const QK& k, 
             if constexpr (NCH > 1) xs[g][mt] = mfma4(w.y, fqk[1], xs[g][mt]);
             hs[g][mt] = z4;
         }
-        s16n_matvec<NT>(tl, T::HH + g * NT * NT, hqk, hs[g]);
+        s16n_matvec<NT, U>(tl, T::HH + g * NT * NT, hqk, hs[g]);
     }
     }
 #pragma unroll
@@ -230,7 +250,7 @@ __device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const QK& k, 
         const f32x4 Bxr = as_f32x4(tab_ld(tl, (T::BX + 0 * NT + mt) * 64)), Bxz = as_f32x4(tab_ld(tl, (T::BX + 1 * NT + mt) * 64)),
                     Bxn = as_f32x4(tab_ld(tl, (T::BX + 2 * NT + mt) * 64)), Bhr = as_f32x4(tab_ld(tl, (T::BH + 0 * NT + mt) * 64)),
                     Bhz = as_f32x4(tab_ld(tl, (T::BH + 1 * NT + mt) * 64)), Bhn = as_f32x4(tab_ld(tl, (T::BH + 2 * NT + mt) * 64));
-        ODPD_EACH4 {
+        Q16_EACHU {
             const float hv = h[mt][i];
             // x_t = x2h(x), h_t = h2h(h): exact integer sums, scale and fp32 bias in one FMA (== F.linear's result)
             const float xr = __builtin_fmaf(xs[0][mt][i], k.Sx, Bxr[i]), hr = __builtin_fmaf(hs[0][mt][i], k.Sh, Bhr[i]);
@@ -411,29 +431,30 @@ template <int MK, int NT> struct HeadOut {
     float cofk[2], pcof[2];  // dgru: q_a(feature slot) of fc_out, mask * s_ow
 };
 // y (scaled, before bias / output quantiser / skip) of one step; `fs` = the lane's FLOAT feature slots (dgru's cat)
-template <int MK, int NT, bool SAVE>
+template <int MK, int NT, int U, bool SAVE>
 __device__ __forceinline__ void head_fwd(TabPtr tl, const QK& k, const f32x4 (&h)[NT], const float (&fs)[Kind<MK>::NCH], HeadOut<MK, NT>& ho,
                                          float& y0, float& y1) {
     using T = QT<MK, NT>;
     float p0 = 0.0f, p1 = 0.0f;
+    if constexpr (U < 4) ho = HeadOut<MK, NT>();
     if constexpr (Kind<MK>::DGRU) {
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         f32x4 acc[NT];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             acc[kt] = z4;
-            ODPD_EACH4 {
+            Q16_EACHU {
                 const float v = h[kt][i] * k.inv_hida, m = gm(v, k);
                 ho.h2k[kt][i] = rintf(m);
                 if constexpr (SAVE) ho.ph2[kt][i] = m == v ? k.s_hidw : 0.0f;
             }
         }
-        s16n_matvec<NT>(tl, T::HID, ho.h2k, acc);
+        s16n_matvec<NT, U>(tl, T::HID, ho.h2k, acc);
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const f32x4 b = as_f32x4(tab_ld(tl, (T::BHID + mt) * 64));
             const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
-            ODPD_EACH4 {
+            Q16_EACHU {
                 const float pre = __builtin_fmaf(acc[mt][i], k.Shid, b[i]), hid = pre > 0.0f ? pre : 0.0f;      // torch.relu
                 const float v = hid * k.inv_oa, m = gm(v, k);
                 ho.hok[mt][i] = rintf(m);
@@ -454,7 +475,7 @@ __device__ __forceinline__ void head_fwd(TabPtr tl, const QK& k, const f32x4 (&h
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
-            ODPD_EACH4 {
+            Q16_EACHU {
                 const float v = h[mt][i] * k.inv_oa, m = gm(v, k);
                 ho.hok[mt][i] = rintf(m);
                 if constexpr (SAVE) ho.pho[mt][i] = m == v ? k.s_ow : 0.0f;
@@ -496,8 +517,8 @@ __device__ __forceinline__ void init_state(StateD<NT>& st) {
 // -------------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------------
-template <int MK, int NT, bool LUT>
-__global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, int bits_a, int eval_mode) {
+template <int MK, int NT, bool LUT, int U>
+__device__ __forceinline__ void q16_fwd_body(const SeqArgs& a, int bits_w, int bits_a, int eval_mode) {
     using T = QT<MK, NT>;
     using K = Kind<MK>;
     constexpr int S = T::S, NCH = K::NCH;
@@ -516,7 +537,7 @@ __global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
     float* lut = tab + s16_tab_floats(T::NG_FWD);
     {
         float4* t4 = reinterpret_cast<float4*>(tab);
-        for (int grp = wave; grp < T::NG_FWD; grp += nwb) t4[grp * 64 + lane] = q16_entry<MK, NT>(pl, L, wq, grp, n, q);
+        for (int grp = wave; grp < T::NG_FWD; grp += nwb) t4[grp * 64 + lane] = q16_entry<MK, NT, U>(pl, L, wq, grp, n, q);
         if constexpr (LUT) fill_luts(lut, qs, k, bits_a, K::TRES);
         __syncthreads();
     }
@@ -532,7 +553,7 @@ __global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
     const bool slot_ok[2] = {true, q < 2};
     f32x4 unit_ok[NT];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) ODPD_EACH4 unit_ok[kt][i] = (16 * kt + 4 * q + i < a.H) ? 1.0f : 0.0f;
+    for (int kt = 0; kt < NT; ++kt) ODPD_EACH4 unit_ok[kt][i] = (q16_unit<U>(kt, 4 * q + i, a.H) < a.H) ? 1.0f : 0.0f;
     float* wbase = lut + (LUT ? 4 * nlut + kMaxThr : 0) + (size_t)wave * kWaveF;
     float2* xs = reinterpret_cast<float2*>(wbase);
     float2* ys = xs + 16 * K::XSTRIDE;
@@ -567,12 +588,12 @@ __global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) fqk[c] = gk(fs[c] * k.inv_xa, k);
                     SaveS<NT> sv;
-                    std_cell<MK, NT, LUT, false>(tlo, qs, k, lutq, fqk, st.h, sv);
+                    std_cell<MK, NT, U, LUT, false>(tlo, qs, k, lutq, fqk, st.h, sv);
                 }
                 if (a.y != nullptr) {      // (the fused train step's forward launch wants the checkpoints only: no head)
                     HeadOut<MK, NT> ho;
                     float y0, y1;
-                    head_fwd<MK, NT, false>(tlo, k, st.h, fs, ho, y0, y1);
+                    head_fwd<MK, NT, U, false>(tlo, k, st.h, fs, ho, y0, y1);
                     y0 = __builtin_fmaf(y0, k.So, sc.bout[0]); y1 = __builtin_fmaf(y1, k.So, sc.bout[1]);
                     if (eval_mode) { y0 = qapply(y0, qs.out); y1 = qapply(y1, qs.out); }   // fc_out's 16-bit out_quantizer (quant_layers.py:77-80)
                     if constexpr (K::TRES) {
@@ -617,6 +638,15 @@ __global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, i
         }
     }
 }
+template <int MK, int NT, bool LUT>
+__global__ __launch_bounds__(512) void qat16_fwd_kernel(SeqArgs a, int bits_w, int bits_a, int eval_mode) {
+    q16_fwd_body<MK, NT, LUT, 4>(a, bits_w, bits_a, eval_mode);
+}
+// U = 3 / 2 units per lane: one unit tile, hidden <= 12 / <= 8 (see q16_unit)
+template <int MK, bool LUT, int U>
+__global__ __launch_bounds__(512) void qat16u_fwd_kernel(SeqArgs a, int bits_w, int bits_a, int eval_mode) {
+    q16_fwd_body<MK, 1, LUT, U>(a, bits_w, bits_a, eval_mode);
+}
 
 // -------------------------------------------------------------------------------------------------
 // backward
@@ -653,7 +683,7 @@ template <int NT> struct Carry { f32x4 gh[NT], ghp[NT], gr[NT], gz[NT], gn[NT], 
 
 // head backward of one step: accumulates the head's parameter gradients, adds dL/dh' to gh and, for dgru, returns the head's
 // share of dL/d(feature slot)
-template <int MK, int NT>
+template <int MK, int NT, int U>
 __device__ __forceinline__ void head_bwd(TabPtr tl, Grad<MK, NT>& G, const HeadOut<MK, NT>& ho, float2 dyv, int q, f32x4 (&gh)[NT],
                                          float (&dfs)[2], float* tiles) {
     using T = QT<MK, NT>;
@@ -670,8 +700,8 @@ __device__ __forceinline__ void head_bwd(TabPtr tl, Grad<MK, NT>& G, const HeadO
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
-            back[mt] = z4;
-            ODPD_EACH4 {
+            back[mt] = z4; dpre[mt] = z4;
+            Q16_EACHU {
                 G.dwout[0][mt][i] = __builtin_fmaf(dyv.x, ho.hok[mt][i], G.dwout[0][mt][i]);
                 G.dwout[1][mt][i] = __builtin_fmaf(dyv.y, ho.hok[mt][i], G.dwout[1][mt][i]);
                 const float dcat = (dyv.x * w0[i] + dyv.y * w1[i]) * ho.pho[mt][i];
@@ -679,9 +709,9 @@ __device__ __forceinline__ void head_bwd(TabPtr tl, Grad<MK, NT>& G, const HeadO
                 G.dbhid[mt][i] += dpre[mt][i];
             }
         }
-        s16n_matvec<NT>(tl, T::HIDT, dpre, back);
+        s16n_matvec<NT, U>(tl, T::HIDT, dpre, back);
 #pragma unroll
-        for (int mt = 0; mt < NT; ++mt) ODPD_EACH4 gh[mt][i] += back[mt][i] * ho.ph2[mt][i];
+        for (int mt = 0; mt < NT; ++mt) Q16_EACHU gh[mt][i] += back[mt][i] * ho.ph2[mt][i];
         // dW_hid += dpre^T (x) h2 through the transpose tiles (slots 5 NT + 1 ..)
         float* tp = tiles + (5 * NT + 1) * kTileFloats;
         const int n = threadIdx.x & 15;
@@ -706,7 +736,7 @@ __device__ __forceinline__ void head_bwd(TabPtr tl, Grad<MK, NT>& G, const HeadO
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
             const f32x4 w0 = as_f32x4(tab_ld(tl, (T::WOUT + mt) * 64)), w1 = as_f32x4(tab_ld(tl, (T::WOUT + NT + mt) * 64));
-            ODPD_EACH4 {
+            Q16_EACHU {
                 G.dwout[0][mt][i] = __builtin_fmaf(dyv.x, ho.hok[mt][i], G.dwout[0][mt][i]);
                 G.dwout[1][mt][i] = __builtin_fmaf(dyv.y, ho.hok[mt][i], G.dwout[1][mt][i]);
                 gh[mt][i] += (dyv.x * w0[i] + dyv.y * w1[i]) * ho.pho[mt][i];
@@ -804,7 +834,7 @@ __device__ __forceinline__ void slots_bwd(float2 xv, const float (&oh)[4], const
     dI = quad_sum(dI); dQ = quad_sum(dQ);
 }
 
-template <int MK, int NT, bool LUT, bool FULL, bool DX, bool LOSS, bool MERGE>
+template <int MK, int NT, int U, bool LUT, bool FULL, bool DX, bool LOSS, bool MERGE>
 __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, const QSc& qs, const QK& k, const float4* lutq, const float* thr,
                                               int Ksig, const Scalars<MK>& sc, const float (&oh)[4], Grad<MK, NT>& G, const float2* xr,
                                               const float2* dys, float2* dxs, float* tiles, float2 x0, int n, int q, int tglob, int tloc,
@@ -842,7 +872,7 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                         fqk[c] = rintf(m);
                         fq_s[si][c] = fqk[c]; px_s[si][c] = m == v ? k.s_xw : 0.0f;
                     }
-                    std_cell<MK, NT, LUT, true>(tl, qs, k, lutq, fqk, st.h, sv[si]);
+                    std_cell<MK, NT, U, LUT, true>(tl, qs, k, lutq, fqk, st.h, sv[si]);
                 }
             }
         }
@@ -865,7 +895,7 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
             HeadOut<MK, NT> ho;
             {
                 float y0, y1;
-                head_fwd<MK, NT, true>(tl, k, sv[si].hnew, fs, ho, y0, y1);
+                head_fwd<MK, NT, U, true>(tl, k, sv[si].hnew, fs, ho, y0, y1);
                 if constexpr (LOSS) {      // train-mode output of the step, the loss and dL/dy on the fly (no y / dy round trip through HBM)
                     y0 = __builtin_fmaf(y0, k.So, sc.bout[0]); y1 = __builtin_fmaf(y1, k.So, sc.bout[1]);
                     if constexpr (K::TRES) {
@@ -897,7 +927,7 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 }
             }
             float dfs_head[2];
-            head_bwd<MK, NT>(tl, G, ho, dyv, q, C.gh, dfs_head, tiles);
+            head_bwd<MK, NT, U>(tl, G, ho, dyv, q, C.gh, dfs_head, tiles);
             float dfs[2] = {0.0f, 0.0f};
             if constexpr (K::TRES) {
                 const SaveD<NT>& v = sv[si];
@@ -950,8 +980,9 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                 const SaveS<NT>& v = sv[si];
                 f32x4 dar[NT], daz[NT], dan[NT], dhtn[NT], dhdir[NT];
 #pragma unroll
-                for (int mt = 0; mt < NT; ++mt)
-                    ODPD_EACH4 {
+                for (int mt = 0; mt < NT; ++mt) {
+                    if constexpr (U < 4) dar[mt] = daz[mt] = dan[mt] = dhtn[mt] = dhdir[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    Q16_EACHU {
                         const float g2 = C.gh[mt][i] * v.c2[mt][i], g3 = C.gh[mt][i] * v.c3[mt][i];
                         const float dz = g2 * v.hp[mt][i] - g3 * v.n[mt][i];
                         const float da = g3 * (1.0f - v.z[mt][i]) * v.An[mt][i];
@@ -962,14 +993,15 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                         dhdir[mt][i] = g2 * v.z[mt][i];
                         G.dbhn[mt][i] += dhtn[mt][i];
                     }
+                }
                 f32x4 ddh[NT];
 #pragma unroll
                 for (int mt = 0; mt < NT; ++mt) ddh[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s16n_matvec<NT>(tl, T::HHT + 0 * NT * NT, dar, ddh);
-                s16n_matvec<NT>(tl, T::HHT + 1 * NT * NT, daz, ddh);
-                s16n_matvec<NT>(tl, T::HHT + 2 * NT * NT, dhtn, ddh);
+                s16n_matvec<NT, U>(tl, T::HHT + 0 * NT * NT, dar, ddh);
+                s16n_matvec<NT, U>(tl, T::HHT + 1 * NT * NT, daz, ddh);
+                s16n_matvec<NT, U>(tl, T::HHT + 2 * NT * NT, dhtn, ddh);
 #pragma unroll
-                for (int mt = 0; mt < NT; ++mt) ODPD_EACH4 C.gh[mt][i] = dhdir[mt][i] + ddh[mt][i] * v.pph[mt][i];
+                for (int mt = 0; mt < NT; ++mt) Q16_EACHU C.gh[mt][i] = dhdir[mt][i] + ddh[mt][i] * v.pph[mt][i];
                 if constexpr (DX) {
                     f32x4 ds = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -977,7 +1009,7 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
                         const f32x4 wr = as_f32x4(tab_ld(tl, (T::IHT + 0 * NT + kt) * 64)), wz = as_f32x4(tab_ld(tl, (T::IHT + 1 * NT + kt) * 64)),
                                     wn = as_f32x4(tab_ld(tl, (T::IHT + 2 * NT + kt) * 64));
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
+                        for (int c = 0; c < U; ++c) {
                             ds = mfma4(wr[c], dar[kt][c], ds); ds = mfma4(wz[c], daz[kt][c], ds); ds = mfma4(wn[c], dan[kt][c], ds);
                         }
                     }
@@ -1007,10 +1039,11 @@ __device__ __forceinline__ void q16_bwd_block(const SeqArgs& a, TabPtr tl0, cons
     }
 }
 
-template <int MK, int NT, bool MERGE>
+template <int MK, int NT, int U, bool MERGE>
 __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, const QatLayout& L, const WQ& wq, const QK& k, Grad<MK, NT>& G,
                                               int lane, int n, int q) {
     using K = Kind<MK>;
+    static_assert(U == 4 || !MERGE, "merged feature columns: four units per lane only");
     constexpr int F = K::F;
     const int H = L.H;
     constexpr int fcol = MERGE ? 16 - (F + 1) : -1;
@@ -1020,7 +1053,7 @@ __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, cons
     for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int u = 16 * mt + 4 * q + rr;
+            const int u = q16_unit<U>(mt, 4 * q + rr, H);
             if (u < H) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
@@ -1031,12 +1064,12 @@ __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, cons
                     if (!K::TRES && fs == F) { prow[L.o_bx + g * H + u] = tx; if (g < 2) prow[L.o_bh + g * H + u] = tx; }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        if (16 * nt + n < H) { const int j = L.o_wh + (g * H + u) * H + 16 * nt + n; prow[j] = G.thh[g][mt][nt][rr] * k.s_ha * qpass(pl[j], wq.h); }
+                        if (q16_unit<U>(nt, n, H) < H) { const int j = L.o_wh + (g * H + u) * H + q16_unit<U>(nt, n, H); prow[j] = G.thh[g][mt][nt][rr] * k.s_ha * qpass(pl[j], wq.h); }
                 }
                 if constexpr (K::DGRU) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        if (16 * nt + n < H) { const int j = L.o_whid + u * H + 16 * nt + n; prow[j] = G.thid[mt][nt][rr] * k.s_hida * qpass(pl[j], wq.hid); }
+                        if (q16_unit<U>(nt, n, H) < H) { const int j = L.o_whid + u * H + q16_unit<U>(nt, n, H); prow[j] = G.thid[mt][nt][rr] * k.s_hida * qpass(pl[j], wq.hid); }
                 }
             }
             const float w0 = row_sum16(G.dwout[0][mt][rr]) * k.s_oa, w1 = row_sum16(G.dwout[1][mt][rr]) * k.s_oa;
@@ -1080,8 +1113,8 @@ __device__ __forceinline__ void q16_write_row(float* prow, const float* pl, cons
 // (the dgru kind at two waves per SIMD spills 110 .. 170 B per lane and measured 1.46 -> 1.82 ms: it stays at one)
 template <int MK, int NT, bool DX> struct BwdOcc { static constexpr bool W2 = NT == 1 && !Kind<MK>::TRES && !Kind<MK>::DGRU && !DX; };
 // LOSS: `a.target` instead of `a.dy` — the step's output, the loss and dL/dy are formed inside (the fused train step's second launch)
-template <int MK, int NT, bool LUT, bool DX, bool LOSS = false, bool MERGE = false>
-__global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
+template <int MK, int NT, bool LUT, bool DX, bool LOSS, bool MERGE, int U>
+__device__ __forceinline__ void q16_bwd_body(const SeqArgs& a, int bits_w, int bits_a) {
     using T = QT<MK, NT>;
     using K = Kind<MK>;
     constexpr int S = T::S;
@@ -1101,7 +1134,7 @@ __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bw
     float* lut = tab + s16_tab_floats(kGroups);
     {
         float4* t4 = reinterpret_cast<float4*>(tab);
-        for (int grp = wave; grp < kGroups; grp += nwb) t4[grp * 64 + lane] = q16_entry<MK, NT>(pl, L, wq, grp, n, q);
+        for (int grp = wave; grp < kGroups; grp += nwb) t4[grp * 64 + lane] = q16_entry<MK, NT, U>(pl, L, wq, grp, n, q);
         if constexpr (LUT) fill_luts(lut, qs, k, bits_a, K::TRES);
         __syncthreads();
     }
@@ -1163,6 +1196,8 @@ __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bw
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
                     st.h[kt] = as_f32x4(c[kt * 64]);
+#pragma unroll
+                    for (int i = U; i < 4; ++i) st.h[kt][i] = 0.0f;   // (stored as 0: told to the compiler)
                     if constexpr (K::TRES) {
                         st.hp[kt] = as_f32x4(c[(1 * NT + kt) * 64]);
                         st.dmr[kt] = as_f32x4(c[(2 * NT + kt) * 64]); st.dmz[kt] = as_f32x4(c[(3 * NT + kt) * 64]);
@@ -1174,8 +1209,8 @@ __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bw
                     st.xp[0] = xp.x; st.xp[1] = xp.y;
                 }
             }
-            if (nstep == S) q16_bwd_block<MK, NT, LUT, true, DX, LOSS, MERGE>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C, lossc, loss_acc);
-            else q16_bwd_block<MK, NT, LUT, false, DX, LOSS, MERGE>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C, lossc, loss_acc);
+            if (nstep == S) q16_bwd_block<MK, NT, U, LUT, true, DX, LOSS, MERGE>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C, lossc, loss_acc);
+            else q16_bwd_block<MK, NT, U, LUT, false, DX, LOSS, MERGE>(a, tl, qs, k, lutq, thr, Ksig, sc, oh, G, xr, dys, dxs, tiles, x0, n, q, tb, tb - t0, nstep, cur_len, dxrow, st, C, lossc, loss_acc);
         }
         if constexpr (DX) {
             wave_lds_fence();
@@ -1192,7 +1227,7 @@ __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bw
     const int P4 = L.P + kLossCols;
     __syncthreads();
     float* rows = smem + pad4(L.P);
-    q16_write_row<MK, NT, MERGE>(rows + wave * P4, pl, L, wq, k, G, lane, n, q);
+    q16_write_row<MK, NT, U, MERGE>(rows + wave * P4, pl, L, wq, k, G, lane, n, q);
     if constexpr (LOSS) {      // column P of the row: the un-normalised loss sum of the wave's sequences
         float ls = loss_acc;
         for (int o = 32; o > 0; o >>= 1) ls += __shfl_down(ls, o);
@@ -1206,6 +1241,15 @@ __global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bw
         for (int wv = 1; wv < nwb; ++wv) v += rows[wv * P4 + i];
         prow[i] = v;
     }
+}
+template <int MK, int NT, bool LUT, bool DX, bool LOSS = false, bool MERGE = false>
+__global__ __launch_bounds__((BwdOcc<MK, NT, DX>::W2 ? 512 : 256)) void qat16_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
+    q16_bwd_body<MK, NT, LUT, DX, LOSS, MERGE, 4>(a, bits_w, bits_a);
+}
+// U = 3 / 2 units per lane: one unit tile, hidden <= 12 / <= 8 (see q16_unit)
+template <int MK, bool LUT, bool DX, bool LOSS, int U>
+__global__ __launch_bounds__((BwdOcc<MK, 1, DX>::W2 ? 512 : 256)) void qat16u_bwd_kernel(SeqArgs a, int bits_w, int bits_a) {
+    q16_bwd_body<MK, 1, LUT, DX, LOSS, false, U>(a, bits_w, bits_a);
 }
 
 // dL/dx through the TRes skip path  skip = HS(conv2(HS(conv1(x)))), conv1: k3, dilation 16, zero padding (time-parallel)
@@ -1290,9 +1334,25 @@ static LaunchShape shape(const odpd_model_t* m, int ngroups, bool bwd, bool dx, 
 // the backward's grid (= rows of partials) must not depend on whether dL/dx is asked for: it is the grid of the launch WITHOUT dL/dx
 template <int MK, int NT>
 static int bwd_grid(const odpd_model_t* m, int ngroups) { return shape<MK, NT>(m, ngroups, true, false, BwdOcc<MK, NT, false>::W2 ? 8 : 4).grid; }
-template <int MK, int NT, bool LUT>
+// unit slots per lane: 3 at hidden <= 12, 2 at hidden <= 8 (one unit tile, GRUCell kinds; the delta cell's only recipe is hidden 15), else 4
+template <int MK> static int unit_slots(const odpd_model_t* m) {
+    if (Kind<MK>::TRES || m->hidden > 12 || tuning().qat_u3 == 0) return 4;
+    return m->hidden <= 8 ? 2 : 3;
+}
+typedef void (*FwdKernel)(SeqArgs, int, int, int);
+typedef void (*BwdKernel)(SeqArgs, int, int);
+template <int MK, int NT, bool LUT, int U> static FwdKernel fwd_kernel_of() {
+    if constexpr (U < 4) return qat16u_fwd_kernel<MK, LUT, U>;
+    else return qat16_fwd_kernel<MK, NT, LUT>;
+}
+template <int MK, int NT, bool LUT, bool DX, bool LOSS, int U> static BwdKernel bwd_kernel_of() {
+    if constexpr (U < 4) return qat16u_bwd_kernel<MK, LUT, DX, LOSS, U>;
+    else return qat16_bwd_kernel<MK, NT, LUT, DX, LOSS>;
+}
+template <int MK, int NT, bool LUT, int U = 4>
 static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
     using T = QT<MK, NT>;
+    static_assert(U == 4 || (NT == 1 && !Kind<MK>::TRES), "fewer than four unit slots per lane: one tile of a GRUCell kind");
     const int P = qat_layout(MK, m->hidden).P;
     a.nck = (a.T + T::S - 1) / T::S;
     // (MERGE = true instantiations of the backward — input-side weight gradients inside the hq tile's padded columns, hidden <=
@@ -1302,7 +1362,7 @@ static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
         const LaunchShape ls = shape<MK, NT>(m, a.ngroups, false, false, 8);
         const size_t lds = lds_bytes<MK, NT>(P, ls.waves, m->bits_a, LUT, false, false);
         if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
-        auto k = qat16_fwd_kernel<MK, NT, LUT>;
+        auto k = fwd_kernel_of<MK, NT, LUT, U>();
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a, m->bits_w, m->bits_a, (m->flags & ODPD_FLAG_EVAL) ? 1 : 0);
         return (int)hipGetLastError();
@@ -1311,7 +1371,7 @@ static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
         if (!a.partials || !a.target || (!a.ckpt && a.nck > 1)) return ODPD_EINVAL;
         SeqArgs f = a;
         f.y = nullptr; f.stats = nullptr;
-        if (int e = launch<MK, NT, LUT>(st, m, f, 1)) return e;
+        if (int e = launch<MK, NT, LUT, U>(st, m, f, 1)) return e;
         LaunchShape ls = shape<MK, NT>(m, a.ngroups, true, false, BwdOcc<MK, NT, false>::W2 ? 8 : 4);
         ls.grid = bwd_grid<MK, NT>(m, a.ngroups);
         const size_t lds = lds_bytes<MK, NT>(P, ls.waves, m->bits_a, LUT, true, false);
@@ -1323,7 +1383,7 @@ static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
             hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, b, m->bits_w, m->bits_a);
             return (int)hipGetLastError();
         };
-        return go(qat16_bwd_kernel<MK, NT, LUT, false, true, false>);
+        return go(bwd_kernel_of<MK, NT, LUT, false, true, U>());
     }
     if (a.partials == nullptr && a.dx == nullptr) return ODPD_EINVAL;
     if (!a.ckpt && a.nck > 1) return ODPD_EINVAL;
@@ -1337,8 +1397,8 @@ static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a, m->bits_w, m->bits_a);
         return (int)hipGetLastError();
     };
-    if (!dx) return go(qat16_bwd_kernel<MK, NT, LUT, false>);
-    if (int e = go(qat16_bwd_kernel<MK, NT, LUT, true>)) return e;
+    if (!dx) return go(bwd_kernel_of<MK, NT, LUT, false, false, U>());
+    if (int e = go(bwd_kernel_of<MK, NT, LUT, true, false, U>())) return e;
     if (MK == K_TRES) {
         const QatLayout L = qat_layout(MK, m->hidden);
         const long n = (long)a.B * a.T;
@@ -1353,6 +1413,11 @@ static int launch_kind(hipStream_t st, const odpd_model_t* m, const SeqArgs& a, 
     // the table / integer-pipe build needs 8-bit activations AND (for the int8 operands of one unit tile) 8-bit weights; any other
     // combination runs the table-free build (fp32 gates, fp32 MFMAs), which is exact for every grid width
     const bool lut = m->bits_a <= 8 && m->bits_w <= 8;
+    if constexpr (!Kind<MK>::TRES) {
+        const int u = nt == 1 ? unit_slots<MK>(m) : 4;
+        if (u == 3) return lut ? launch<MK, 1, true, 3>(st, m, a, mode) : launch<MK, 1, false, 3>(st, m, a, mode);
+        if (u == 2) return lut ? launch<MK, 1, true, 2>(st, m, a, mode) : launch<MK, 1, false, 2>(st, m, a, mode);
+    }
     if (nt == 1) return lut ? launch<MK, 1, true>(st, m, a, mode) : launch<MK, 1, false>(st, m, a, mode);
     if (nt == 2) return lut ? launch<MK, 2, true>(st, m, a, mode) : launch<MK, 2, false>(st, m, a, mode);
     return ODPD_EUNSUPPORTED;

@@ -121,6 +121,67 @@ RAGGED = [("gru", 11, 3, 5), ("gru", 16, 7, 33), ("gru", 23, 17, 40), ("gru", 32
 def test_w8a8_matches_the_oracle_on_ragged_sizes(bb, H, B, T):
     """Forward bit for bit (train and eval mode), weight gradients and dL/dx — together, and dL/dx alone (frozen model = the PA of a
     cascade) — against the oracle, at hidden sizes on both sides of the 16-unit tile boundary."""
+    _w8a8_against_the_oracle(bb, H, B, T)
+
+
+# hidden <= 12 on the 16-sequences-per-wave kernels: THREE unit slots per lane (csrc/qat_s16.hip q16_unit; hidden 10 = the reference's QGRU,
+# quant_mp_dpd.sh:43; 6 and 9 from quant_qgru_dpd_regr.sh:74; dgru 8 = every script's PA size)
+U3 = [("qgru", 10, 35, 63), ("qgru", 8, 17, 40), ("qgru_amp1", 5, 33, 21), ("qgru", 6, 7, 33), ("qgru", 9, 16, 50), ("qgru", 12, 3, 21), ("qgru_amp1", 12, 19, 40), ("qgru_amp1", 1, 5, 9),
+      ("gru", 11, 21, 37), ("gru", 4, 5, 9), ("dgru", 8, 33, 21), ("dgru", 12, 18, 35), ("dgru", 3, 2, 70)]
+
+
+@pytest.mark.parametrize("bb,H,B,T", U3)
+def test_three_unit_slots_per_lane_match_the_oracle_and_the_four_slot_kernels(bb, H, B, T):
+    """The three-slot kernels (default) and the four-slot ones they replace at hidden <= 12 (knob "qat_u3" = 0), both forced onto the S16 mapping
+    at a ragged batch: each against the oracle (forward bit for bit, gradients and dL/dx at the ragged test's bounds), and the two forwards
+    against each other bit for bit (the gradients differ by the order of the unit sums of the data-gradient mat-vecs)."""
+    import ctypes as C
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    got = []
+    try:
+        _lib.check(lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(0)), "set_tuning")
+        for knob in (1, 0):
+            _lib.check(lib.odpd_set_tuning(b"qat_u3", C.c_int64(knob)), "set_tuning")
+            got.append(_w8a8_against_the_oracle(bb, H, B, T))
+    finally:
+        lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(-1))
+        lib.odpd_set_tuning(b"qat_u3", C.c_int64(1))
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert rel_err(got[0][2], got[1][2]) < 2e-5 and rel_err(got[0][3], got[1][3]) < 2e-5
+
+
+@pytest.mark.parametrize("bb,H", [("qgru", 10), ("dgru", 8), ("gru", 11), ("qgru_amp1", 6)])
+def test_three_unit_slots_on_16_bit_grids_agree_with_four_to_the_summation_order(bb, H):
+    """W16A16 (the table-free build: fp32 MFMAs, fp32 gates): the unit sums of the mat-vecs run in a different order on the three-slot layout,
+    visible at one LSB of the 16-bit grids — the bound the fixtures of the reference itself are held to (2^-12, test_forward_train_eval_...)."""
+    import ctypes as C
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(H)
+    q = _fresh(bb, H, 16).cuda()
+    x, dy = _signal(37, 41, 9)
+    outs = []
+    try:
+        _lib.check(lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(0)), "set_tuning")
+        for knob in (1, 0):
+            _lib.check(lib.odpd_set_tuning(b"qat_u3", C.c_int64(knob)), "set_tuning")
+            for v in q.parameters():
+                v.grad = None
+            q.train()
+            xt = torch.from_numpy(x).cuda().requires_grad_(True)
+            y = q(xt)
+            y.backward(torch.from_numpy(dy).cuda())
+            outs.append((y.detach().cpu().numpy(), np.concatenate([(v.grad if v.grad is not None else torch.zeros_like(v)).cpu().numpy().reshape(-1)
+                                                                   for v in q.parameters()]), xt.grad.cpu().numpy()))
+    finally:
+        lib.odpd_set_tuning(b"s16_min_batch", C.c_int64(-1))
+        lib.odpd_set_tuning(b"qat_u3", C.c_int64(1))
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= 2.0 ** -12
+    assert rel_err(outs[0][1], outs[1][1]) < 1e-3 and rel_err(outs[0][2], outs[1][2]) < 1e-3
+
+
+def _w8a8_against_the_oracle(bb, H, B, T):
     from oracle.oracle import Oracle, make_model
     tres = bb == "deltagru_tcnskip"
     thx, thh = (0.01, 0.05) if tres else (0.0, 0.0)
@@ -171,6 +232,7 @@ def test_w8a8_matches_the_oracle_on_ragged_sizes(bb, H, B, T):
     xt2 = torch.from_numpy(x).cuda().requires_grad_(True)
     q(xt2).backward(torch.from_numpy(dy).cuda())
     assert rel_err(xt2.grad.cpu().numpy(), dxo) < 3e-5
+    return ye, y.detach().cpu().numpy(), g, xt.grad.cpu().numpy()
 
 
 @pytest.mark.parametrize("bb,H", [("qgru", 10), ("qgru_amp1", 16)])

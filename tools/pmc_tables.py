@@ -84,7 +84,7 @@ d["train_dpd_dgru13_dgru23_b65536_t200"] = entry(["gru16_fwd_kernel", "gru16x_lo
 d["train_dpd_tres15_dgru23_b65536_t200"] = entry(["delta16_fwd_kernel", "gru16x_lossdx_kernel", "delta16_bwd_kernel", "tres_skip_wgrad_kernel"], ("delta_s16.hip", "gru_s16x.hip") + base,
                                                  " delta16_bwd_kernel stages x and dL/dy in 16-step chunks (8 B per lane): an access width the guide calls uncalibrated — its UNcorrected "
                                                  "fetch already matches the bytes the kernel addresses (629 MB of checkpoints + 105 MB x + 105 MB dL/dy), so the doubled figure is an upper bound.")
-d["train_dpd_qgru10_dgru23_b65536_t200"] = entry(["qat16_fwd_kernel", "gru16x_lossdx_kernel", "qat16_bwd_kernel"], ("qat_s16.hip", "gru_s16x.hip", "odpd_qat.h") + base)
+d["train_dpd_qgru10_dgru23_b65536_t200"] = entry(["qat16u_fwd_kernel", "gru16x_lossdx_kernel", "qat16u_bwd_kernel"], ("qat_s16.hip", "gru_s16x.hip", "odpd_qat.h") + base)
 json.dump(d, open(p, "w"), indent=1)
 print(open(os.path.join(out, "cascade_kernels_b65536_pmc.md")).read())
 print("headline:", hk[:60], hst[hk], "traffic MB", (2 * hfe + hwr) * 1024 / 1e6)
