@@ -246,6 +246,57 @@ __device__ __forceinline__ void d16_stage_out(const float2* lds, float* g, int b
         if (tt < len && b0 + m < B) g2[(size_t)(b0 + m) * T + t0 + tt] = lds[m * (CH + 1) + tt];
     }
 }
+// r06, the forward kernels of one unit tile: four waves per SIMD.  The staged x carries no halo — CH + 1 samples per sequence, the step's own and
+// the next (torch.roll) — and the chunks are 16 steps, so a wave's LDS share falls 12.5 -> 4.4 KB and TWO eight-wave workgroups fit a CU (the
+// kernels are capped at 128 registers for that).  deltagru_tcnskip (BASELINE config 3's DPD): the TCN skip leaves the step loop.  It has no
+// state, so it is evaluated where the chunk is staged (lane = (sequence, step) there: the 44 instructions once per sample, its taps x[t - 16],
+// x[t], x[t + 16] read from global memory — L2 hits of the stream the kernel stages anyway) and parked in the output tile; the step adds to it.
+template <int CH>
+__device__ __forceinline__ void d16_stage_x1(float2* lds, const float* g, int b0, int B, int T, int t0, int lane) {
+    const float2* g2 = reinterpret_cast<const float2*>(g);
+    constexpr int PER = CH + 1, TOT = 16 * PER, N = (TOT + 63) / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j;
+        if (e < TOT) {
+            const int m = e / PER, pos = e % PER, tg = t0 + pos;
+            lds[m * (CH + 2) + pos] = (tg < T && b0 + m < B) ? g2[(size_t)(b0 + m) * T + tg] : make_float2(0.5f, 0.5f);
+        }
+    }
+}
+// the TCN skip of the chunk's samples, parked where the step loop will add the recurrent output: lane = (sequence, step), taps from global memory,
+// issued with the chunk's staging loads (their latency is waited for once, together)
+template <int CH>
+__device__ __forceinline__ void d16_park_skip(float2* ys, const float* x, const D16Scalars<true>& sc, int b0, int B, int T, int t0, int len, int lane) {
+    const float2* x2 = reinterpret_cast<const float2*>(x);
+    constexpr int N = 16 * CH / 64;
+    const float2 zero = make_float2(0.0f, 0.0f);          // outside the frame: the conv's zero padding
+    float2 xm[N], xc[N], xq[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / CH, tt = e % CH, t = t0 + tt;
+        const bool ok = tt < len && b0 + m < B;
+        const float2* row = x2 + (size_t)(b0 + m) * T;
+        xm[j] = (ok && t >= d16::kHalo) ? row[t - d16::kHalo] : zero;
+        xc[j] = ok ? row[t] : zero;
+        xq[j] = (ok && t + d16::kHalo < T) ? row[t + d16::kHalo] : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / CH, tt = e % CH;
+        float s1[3], s2[2];
+        d16_tcn<true>(sc, xm[j], xc[j], xq[j], s1, s2);
+        ys[m * (CH + 1) + tt] = make_float2(hardswishf_(s2[0]), hardswishf_(s2[1]));
+    }
+}
+// staging geometry of the forward kernel: chunk length, float2 per staged x row, offset of step 0 in it, floats of LDS per wave
+template <bool TRES, int NT> struct D16Fwd {
+    static constexpr bool LEAN = NT == 1, SKIPOUT = TRES && LEAN;
+    static constexpr int CH = LEAN ? 16 : kChunk, XROW = LEAN ? CH + 2 : d16::kStride, XOFF = LEAN ? 0 : d16::kHalo, YROW = CH + 1;
+    static constexpr int kWave = 2 * 16 * XROW + 2 * 16 * YROW;
+    static constexpr int kWavesPerSimd = LEAN ? 4 : 1;
+};
+
 // Chunk length and workgroup size of the backward kernel.  The weight-gradient-only kernel of one unit tile (the trained DPD of train_dpd,
 // BASELINE config 3) runs EIGHT waves per workgroup — two per SIMD — on 16-step chunks (the per-wave LDS region then fits eight times next to
 // the operand table): a lone wave issues one VALU instruction per ~4.7 cycles, two sharing a SIMD one per ~2.3.  r04 measured that shape at
@@ -272,10 +323,11 @@ __device__ __forceinline__ float4 d16_f4(const f32x4& v) { return make_float4(v[
 // forward
 // -------------------------------------------------------------------------------------------------
 template <bool TRES, int NT, bool JAN = false>
-__global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_fwd_kernel(SeqArgs a) {
+__global__ __launch_bounds__(NT == 1 ? 512 : 256, (D16Fwd<TRES, NT>::kWavesPerSimd)) void delta16_fwd_kernel(SeqArgs a) {
     using T = D16<NT>;
+    using G = D16Fwd<TRES, NT>;
     constexpr int S = D16<NT>::S;
-    constexpr int kWave = 2 * 16 * d16::kStride + 2 * 16 * kChunkPad;
+    constexpr int kWave = G::kWave, CH = G::CH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -300,8 +352,8 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
     for (int kt = 0; kt < NT; ++kt) ODPD_EACH4 unit_ok[kt][i] = (16 * kt + 4 * q + i < a.H) ? 1.0f : 0.0f;
     float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
     float2* xs = reinterpret_cast<float2*>(wbase);
-    float2* ys = xs + 16 * d16::kStride;
-    const float2* xr = xs + n * d16::kStride + d16::kHalo;
+    float2* ys = xs + 16 * G::XROW;
+    const float2* xr = xs + n * G::XROW + G::XOFF;
     float zx = 0.0f, zh = 0.0f;
     const int nwaves = gridDim.x * nwb;
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
@@ -316,10 +368,12 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
         float mwf[NT], xps[2] = {st.xp[0], st.xp[1]}, scale = 1.0f, scale_x = 65536.0f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) mwf[kt] = 0.0f;
-        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
-            const int len = min(kChunk, a.T - t0);
+        for (int t0 = 0; t0 < a.T; t0 += CH) {
+            const int len = min(CH, a.T - t0);
             wave_lds_fence();
-            d16_stage_x(xs, a.x, b0, a.B, a.T, t0, lane);
+            if constexpr (G::SKIPOUT) d16_park_skip<CH>(ys, a.x, sc, b0, a.B, a.T, t0, len, lane);
+            if constexpr (G::LEAN) d16_stage_x1<CH>(xs, a.x, b0, a.B, a.T, t0, lane);
+            else d16_stage_x(xs, a.x, b0, a.B, a.T, t0, lane);
             wave_lds_fence();
             for (int tt = 0; tt < len; ++tt) {
                 const float2 xv = xr[tt];
@@ -335,8 +389,10 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
                     ODPD_EACH4 { p0 = __builtin_fmaf(w0[i], st.h[mt][i], p0); p1 = __builtin_fmaf(w1[i], st.h[mt][i], p1); }
                 }
                 const float y0 = quad_sum(p0) + sc.bout[0], y1 = quad_sum(p1) + sc.bout[1];
-                if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
-                if constexpr (TRES) {
+                if constexpr (G::SKIPOUT) {          // (same sum as before: y + HS(s2))
+                    if (q == 0) { const float2 sk = ys[n * G::YROW + tt]; ys[n * G::YROW + tt] = make_float2(y0 + sk.x, y1 + sk.y); }
+                } else if (q == 0) ys[n * G::YROW + tt] = make_float2(y0, y1);
+                if constexpr (TRES && !G::SKIPOUT) {
                     // the TCN skip has no state: instead of all four quads of a sequence evaluating the same 44 instructions every step
                     // (r01..r03), quad q evaluates step q of each block of four steps and adds it to the parked output
                     if ((tt & 3) == 3 || tt == len - 1) {
@@ -376,7 +432,8 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void delta16_
                 }
             }
             wave_lds_fence();
-            stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+            if constexpr (G::LEAN) d16_stage_out<CH>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+            else stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);
         }
         if (valid) { zx += zxs; zh += zhs; }
     }
@@ -663,7 +720,8 @@ template <bool TRES, int NT, bool DX, bool JAN = false>
 __global__ __launch_bounds__((NT == 1 && !DX) ? 512 : 256, 1) void delta16_bwd_kernel(SeqArgs a) {
     using T = D16<NT>;
     constexpr int S = D16<NT>::S, kD16BwdCh = d16_bwd_ch<NT, DX>();
-    constexpr int kWave = 2 * 16 * (kD16BwdCh + 2 * d16::kHalo + 1) + (DX ? 2 : 1) * 2 * 16 * (kD16BwdCh + 1) + T::kTiles * kTileFloats;
+    // (the staged x carries no halo since r06: the TCN skip's gradients are time-parallel kernels of their own — CH + 1 samples per sequence)
+    constexpr int kWave = 2 * 16 * (kD16BwdCh + 2) + (DX ? 2 : 1) * 2 * 16 * (kD16BwdCh + 1) + T::kTiles * kTileFloats;
     constexpr int kGroups = DX ? T::NG_DX : T::NG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
@@ -685,11 +743,11 @@ __global__ __launch_bounds__((NT == 1 && !DX) ? 512 : 256, 1) void delta16_bwd_k
     for (int e = 0; e < 4; ++e) oh[e] = q == e ? 1.0f : 0.0f;
     float* wbase = tab + s16_tab_floats(kGroups) + (size_t)wave * kWave;
     float2* xs = reinterpret_cast<float2*>(wbase);
-    float2* dys = xs + 16 * (kD16BwdCh + 2 * d16::kHalo + 1);
+    float2* dys = xs + 16 * (kD16BwdCh + 2);
     float2* dxs = dys + 16 * (kD16BwdCh + 1);                   // DX only
     float* tiles = reinterpret_cast<float*>(dys + (DX ? 2 : 1) * 16 * (kD16BwdCh + 1));
     for (int i = lane; i < kTileFloats; i += 64) tiles[5 * NT * kTileFloats + i] = 0.0f;
-    const float2* xr = xs + n * (kD16BwdCh + 2 * d16::kHalo + 1) + d16::kHalo;
+    const float2* xr = xs + n * (kD16BwdCh + 2);
     D16Grad<TRES, NT> G;
     G.zero();
     const int nwaves = gridDim.x * nwb;
@@ -718,7 +776,7 @@ __global__ __launch_bounds__((NT == 1 && !DX) ? 512 : 256, 1) void delta16_bwd_k
                 wave_lds_fence();
                 const int len = min(kD16BwdCh, a.T - t0);
                 cur_len = len;
-                d16_stage_x<kD16BwdCh>(xs, a.x, b0, a.B, a.T, t0, lane);
+                d16_stage_x1<kD16BwdCh>(xs, a.x, b0, a.B, a.T, t0, lane);
                 d16_stage_in<kD16BwdCh>(dys, a.dy, b0, a.B, a.T, t0, len, lane, make_float2(0.0f, 0.0f));
                 wave_lds_fence();
                 cur_chunk = chunk;
@@ -885,12 +943,13 @@ bool delta_uses_s16(const odpd_model_t* m, int B) {
     if (min_batch < 0) min_batch = 16L * 4 * device_cus();
     return B >= min_batch;
 }
-static LaunchShape d16_fwd_shape(int ngroups, int nt) {
+// `per_cu`: workgroups of eight waves a CU holds (2 = the four-waves-per-SIMD forward of deltagru_tcnskip)
+static LaunchShape d16_fwd_shape(int ngroups, int nt, int per_cu = 1) {
     LaunchShape ls;
     const int cus = device_cus();
     ls.waves = (nt > 1 || ngroups <= 4 * cus) ? 4 : 8;
-    const int need = (ngroups + ls.waves - 1) / ls.waves;
-    ls.grid = need < cus ? need : cus;
+    const int need = (ngroups + ls.waves - 1) / ls.waves, cap = (ls.waves == 8 ? per_cu : 1) * cus;
+    ls.grid = need < cap ? need : cap;
     return ls;
 }
 static int d16_tiles(int H) { return (H + 15) / 16; }
@@ -899,7 +958,7 @@ static size_t d16_bwd_lds(int P, int nt, int waves, bool dx) {
     const int tiles = nt == 1 ? D16<1>::kTiles : D16<2>::kTiles;
     const int ch = (nt == 1 && !dx) ? d16_bwd_ch<1, false>() : kChunk;
     size_t lds = ((size_t)pad4(P) + s16_tab_floats(groups) +
-                  (size_t)waves * (2 * 16 * (ch + 2 * d16::kHalo + 1) + (dx ? 2 : 1) * 2 * 16 * (ch + 1) + tiles * kTileFloats)) * sizeof(float);
+                  (size_t)waves * (2 * 16 * (ch + 2) + (dx ? 2 : 1) * 2 * 16 * (ch + 1) + tiles * kTileFloats)) * sizeof(float);
     if (lds < reduce_scratch_bytes(P, waves)) lds = reduce_scratch_bytes(P, waves);
     return lds;
 }
@@ -928,8 +987,8 @@ static int d16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, 
     SeqArgs a = a0;
     a.nck = (a.T + T::S - 1) / T::S;                          // checkpoint blocks of this tile count (the generic count is for four steps)
     if (mode == 1) {
-        const LaunchShape ls = d16_fwd_shape(a.ngroups, NT);
-        const size_t lds = ((size_t)pad4(P) + s16_tab_floats(T::NG) + (size_t)ls.waves * (2 * 16 * d16::kStride + 2 * 16 * kChunkPad)) * sizeof(float);
+        const LaunchShape ls = d16_fwd_shape(a.ngroups, NT, D16Fwd<TRES, NT>::LEAN ? 2 : 1);
+        const size_t lds = ((size_t)pad4(P) + s16_tab_floats(T::NG) + (size_t)ls.waves * D16Fwd<TRES, NT>::kWave) * sizeof(float);
         auto k = delta16_fwd_kernel<TRES, NT, JAN>;
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);
