@@ -486,12 +486,19 @@ __device__ __forceinline__ void head_fwd(TabPtr tl, const QK& k, const f32x4 (&h
     y0 = quad_sum(p0); y1 = quad_sum(p1);      // exact integer sums on 8-bit grids: any order
 }
 
-template <int MK>
+// staging geometry of the FORWARD kernels.  GRUCell kinds (r06): 16-step chunks — a wave's LDS share falls 8.4 -> 4.4 KB, so that TWO eight-wave
+// workgroups fit a CU next to the operand table and the gate LUT (90 KB per workgroup before: the kernels compiled for four waves per SIMD ran at
+// two).  The delta cell keeps the 32-step chunks of its TCN halo.
+template <int MK> struct FwdGeo {
+    static constexpr int CH = Kind<MK>::TRES ? kChunk : 16, XROW = CH + 2 * Kind<MK>::HALO + 1, YROW = CH + 1;
+    static constexpr int kWaveF = 2 * 16 * XROW + 2 * 16 * YROW;
+};
+template <int MK, int CH = kChunk>
 __device__ __forceinline__ void q16_stage_x(float2* lds, const float* g, int b0, int B, int T, int t0, int lane, const long long* fidx = nullptr,
                                             int fstride = 0) {
     using K = Kind<MK>;
     const float2* g2 = reinterpret_cast<const float2*>(g);
-    constexpr int PER = kChunk + 2 * K::HALO, TOT = 16 * PER, N = (TOT + 63) / 64;
+    constexpr int PER = CH + 2 * K::HALO, TOT = 16 * PER, N = (TOT + 63) / 64, XROW = CH + 2 * K::HALO + 1;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int e = lane + 64 * j;
@@ -500,8 +507,18 @@ __device__ __forceinline__ void q16_stage_x(float2* lds, const float* g, int b0,
             float2 v = make_float2(0.0f, 0.0f);          // outside the frame: the conv's zero padding
             if (tg >= 0 && tg < T) v = (b0 + m < B) ? g2[(fidx ? (size_t)fidx[b0 + m] * fstride : (size_t)(b0 + m) * T) + tg] : make_float2(0.5f, 0.5f);
             else if (!K::TRES) v = make_float2(0.5f, 0.5f);
-            lds[m * K::XSTRIDE + pos] = v;
+            lds[m * XROW + pos] = v;
         }
+    }
+}
+template <int CH>
+__device__ __forceinline__ void q16_stage_out(const float2* lds, float* g, int b0, int B, int T, int t0, int len, int lane) {
+    float2* g2 = reinterpret_cast<float2*>(g);
+    constexpr int N = 16 * CH / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / CH, tt = e % CH;
+        if (tt < len && b0 + m < B) g2[(size_t)(b0 + m) * T + t0 + tt] = lds[m * (CH + 1) + tt];
     }
 }
 __device__ __forceinline__ float4 q16_f4(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
@@ -522,7 +539,8 @@ __device__ __forceinline__ void q16_fwd_body(const SeqArgs& a, int bits_w, int b
     using T = QT<MK, NT>;
     using K = Kind<MK>;
     constexpr int S = T::S, NCH = K::NCH;
-    constexpr int kWaveF = 2 * 16 * K::XSTRIDE + 2 * 16 * kChunkPad;
+    using Geo = FwdGeo<MK>;
+    constexpr int kWaveF = Geo::kWaveF, CH = Geo::CH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -556,8 +574,8 @@ __device__ __forceinline__ void q16_fwd_body(const SeqArgs& a, int bits_w, int b
     for (int kt = 0; kt < NT; ++kt) ODPD_EACH4 unit_ok[kt][i] = (q16_unit<U>(kt, 4 * q + i, a.H) < a.H) ? 1.0f : 0.0f;
     float* wbase = lut + (LUT ? 4 * nlut + kMaxThr : 0) + (size_t)wave * kWaveF;
     float2* xs = reinterpret_cast<float2*>(wbase);
-    float2* ys = xs + 16 * K::XSTRIDE;
-    const float2* xr = xs + n * K::XSTRIDE + K::HALO;
+    float2* ys = xs + 16 * Geo::XROW;
+    const float2* xr = xs + n * Geo::XROW + K::HALO;
     float zx = 0.0f, zh = 0.0f;
     const int nwaves = gridDim.x * nwb;
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
@@ -568,10 +586,10 @@ __device__ __forceinline__ void q16_fwd_body(const SeqArgs& a, int bits_w, int b
         StateD<NT> st;
         init_state<NT>(st);
         float zxs = 0.0f, zhs = 0.0f;
-        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
-            const int len = min(kChunk, a.T - t0);
+        for (int t0 = 0; t0 < a.T; t0 += CH) {
+            const int len = min(CH, a.T - t0);
             wave_lds_fence();
-            q16_stage_x<MK>(xs, a.x, b0, a.B, a.T, t0, lane, a.frame_idx, a.frame_stride);
+            q16_stage_x<MK, CH>(xs, a.x, b0, a.B, a.T, t0, lane, a.frame_idx, a.frame_stride);
             wave_lds_fence();
             for (int tt = 0; tt < len; ++tt) {
                 const float2 xv = xr[tt];
@@ -601,7 +619,7 @@ __device__ __forceinline__ void q16_fwd_body(const SeqArgs& a, int bits_w, int b
                         q16_tcn<MK>(sc, xr[tt - kHalo], xv, xr[tt + kHalo], s1, s2);
                         y0 += hardswishf_(s2[0]); y1 += hardswishf_(s2[1]);
                     }
-                    if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
+                    if (q == 0) ys[n * Geo::YROW + tt] = make_float2(y0, y1);
                 }
                 const int t1 = t0 + tt + 1;
                 if (ck != nullptr && (t1 % S) == 0 && t1 < a.T) {
@@ -619,7 +637,7 @@ __device__ __forceinline__ void q16_fwd_body(const SeqArgs& a, int bits_w, int b
                 }
             }
             wave_lds_fence();
-            if (a.y != nullptr) stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);      // (the fused train step needs the checkpoints only)
+            if (a.y != nullptr) q16_stage_out<CH>(ys, a.y, b0, a.B, a.T, t0, len, lane);      // (the fused train step needs the checkpoints only)
         }
         if (valid) { zx += zxs; zh += zhs; }
     }
@@ -1310,7 +1328,7 @@ template <int MK, int NT>
 static size_t lds_bytes(int P, int waves, int bits_a, bool lut, bool bwd, bool dx) {
     using K = Kind<MK>;
     const size_t per_wave = bwd ? 2 * 16 * K::XSTRIDE + (dx ? 2 : 1) * 2 * 16 * kChunkPad + QT<MK, NT>::kTiles * kTileFloats
-                                : 2 * 16 * K::XSTRIDE + 2 * 16 * kChunkPad;
+                                : FwdGeo<MK>::kWaveF;
     size_t n = ((size_t)pad4(P) + s16_tab_floats(groups<MK, NT>(bwd, dx)) + (lut ? 4 * (1 << bits_a) + kMaxThr : 0) + (size_t)waves * per_wave) * sizeof(float);
     const size_t need = ((size_t)pad4(P) + (size_t)waves * (P + kLossCols)) * sizeof(float);
     if (bwd && n < need) n = need;
@@ -1359,9 +1377,13 @@ static int launch(hipStream_t st, const odpd_model_t* m, SeqArgs a, int mode) {
     // merge_max_hidden: 16 instead of 24 weight-gradient MFMAs per step — are not launched: at two waves per SIMD they spill ~200 B per
     // lane and measured 1.011 -> 0.995 ms only (profiles/r03/README.md); the code path stays for a register-leaner backward)
     if (mode == 1) {
-        const LaunchShape ls = shape<MK, NT>(m, a.ngroups, false, false, 8);
+        LaunchShape ls = shape<MK, NT>(m, a.ngroups, false, false, 8);
         const size_t lds = lds_bytes<MK, NT>(P, ls.waves, m->bits_a, LUT, false, false);
         if (lds > kMaxLds) return ODPD_EUNSUPPORTED;
+        if (ls.waves == 8 && 2 * lds <= kMaxLds) {      // two workgroups per CU (four waves per SIMD) where the LDS holds both
+            const int need = (a.ngroups + 7) / 8, cap = 2 * device_cus();
+            ls.grid = need < cap ? need : cap;
+        }
         auto k = fwd_kernel_of<MK, NT, LUT, U>();
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a, m->bits_w, m->bits_a, (m->flags & ODPD_FLAG_EVAL) ? 1 : 0);
