@@ -630,6 +630,16 @@ def main():
             dpd["reference_batch"] = {"batch_per_gpu": rb, "frame_length": T, "unit": "IQ samples/s", "cascades": small}
             del xr_, tr_
 
+    # vector-issue speed of this box (ns per wave instruction per SIMD of a pure v_fma loop, ~1.1 on an MI355X at full clocks): the issue-bound
+    # kernels' times scale with it, so a slower line from another box can be told from a slower build (`config.issue_probe_ns`)
+    issue_probe_ns = None
+    if rank == 0:
+        import ctypes as _C
+        from opendpd_amd import _lib as _pl
+        _ns = _C.c_double(0.0)
+        if _pl.load().odpd_probe_issue_ns(_pl.stream_ptr(), 20000, _C.byref(_ns)) == 0:
+            issue_probe_ns = round(_ns.value, 4)
+
     # RCCL sees all N ranks in every N > 1 run, whichever transport carries the gradient: one sum of ones over the process group
     # ("nccl" = RCCL on ROCm) on the GPU; the count comes back in the line (`config.rccl_ranks_seen`)
     rccl_ranks_seen = None
@@ -728,7 +738,7 @@ def main():
                        "collective_candidates": "; ".join(f"{c.get('kind')}: {'ok' if c.get('ok') else 'failed (' + str(c.get('why'))[:100] + ')'}"
                                                           for c in collective.get("candidates") or [] if isinstance(c, dict)) or None,
                        "rccl_ranks_seen": rccl_ranks_seen, "process_group": collective.get("process_group"),
-                       "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                       "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "issue_probe_ns": issue_probe_ns,
                        "collective": {k: collective.get(k) for k in ("kind", "candidates", "bare_us_per_allreduce", "timeouts")}},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / VALU_FP32_PEAK_TFLOPS, "traffic": traffic,

@@ -13,7 +13,7 @@ LOSS_IDS = {"l2": 0, "l1": 1}
 FLAG_EVAL, FLAG_NEED_DX, FLAG_TWO_LAYERS = 1, 2, 4      # odpd_model_t.flags (include/opendpd_hip.h)
 LOSS_COLS = 4        # extra columns of a partials row (column P = loss partial sum)
 LOSS_WS = 1 + 256    # floats behind `loss_out` (result + per-block scratch)
-ABI_VERSION = 12     # odpd_abi_version() of the library these argument lists belong to
+ABI_VERSION = 13     # odpd_abi_version() of the library these argument lists belong to
 
 
 class ModelDesc(C.Structure):
@@ -42,6 +42,7 @@ _EXPORTS = {
     # name: (restype, argtypes)
     "odpd_abi_version": (C.c_int, []),
     "odpd_built_arch": (C.c_char_p, []),
+    "odpd_probe_issue_ns": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "odpd_set_tuning": (C.c_int, [C.c_char_p, C.c_int64]),
     "odpd_tuning_generation": (C.c_int64, []),
     "odpd_param_count": (C.c_int64, [C.POINTER(ModelDesc)]),

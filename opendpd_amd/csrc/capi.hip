@@ -1,5 +1,11 @@
 // capi.hip — the extern "C" surface declared in include/opendpd_hip.h: argument validation and
 // dispatch to the backbone families.
+#include <dlfcn.h>
+
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "odpd_host.h"
 #include "odpd_xchg.h"
 
@@ -112,6 +118,20 @@ odpd::Tuning& odpd::tuning() {
     }();
     return t;
 }
+// ODPD_AUDIT_LDS (odpd_seq.h): one stderr line per distinct (kernel, dynamic LDS bytes)
+void odpd::audit_lds(const void* kernel, size_t lds) {
+    static const bool on = getenv("ODPD_AUDIT_LDS") != nullptr;
+    if (!on) return;
+    static std::mutex mu;
+    static std::set<std::pair<const void*, size_t>> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!seen.insert({kernel, lds}).second) return;
+    Dl_info info;
+    hipFuncAttributes at;
+    const bool named = dladdr(kernel, &info) != 0 && info.dli_sname != nullptr;
+    const int regs = hipFuncGetAttributes(&at, kernel) == hipSuccess ? at.numRegs : -1;
+    fprintf(stderr, "[odpd-lds] %s lds=%zu regs=%d\n", named ? info.dli_sname : "?", lds, regs);
+}
 static int64_t g_tuning_generation = 0;
 extern "C" int odpd_set_tuning(const char* key, int64_t value) {
     if (!key) return ODPD_EINVAL;
@@ -128,7 +148,45 @@ extern "C" int odpd_set_tuning(const char* key, int64_t value) {
 }
 extern "C" int64_t odpd_tuning_generation(void) { return g_tuning_generation; }
 
-extern "C" int odpd_abi_version(void) { return 12; }   // 12: + odpd_sweep_* / odpd_train_epoch_sweep / odpd_backbone_fwd_sweep (K runs of one model shape in lockstep: one launch per step carries them all); 11: + ODPD_FLAG_TWO_LAYERS (gru / qgru / qgru_amp1 with two recurrent layers), hidden 33 .. 64 for the GRU family and lstm, bits_w > 0 on lstm / vdlstm (INT_Linear heads); 10: + odpd_xchg_* (one-shot gradient exchange over peer-mapped slots), odpd_clip_optim_step_dp, odpd_comm_kind / _errors; 9: + odpd_cascade_rows, odpd_cascade_fwd_bwd (train_dpd step body in one launch); 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
+// ---- odpd_probe_issue_ns: vector-issue speed of this GPU ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void probe_issue_kernel(float* out, int iters, float b, float c) {
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (float)(threadIdx.x + j) * 1e-6f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = __builtin_fmaf(a[j], b, c);          // 8 independent chains x 8 = 64 v_fma_f32
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += a[j];
+    if (s == 123.456f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;              // (keeps the chains alive; never true for these operands)
+}
+extern "C" int odpd_probe_issue_ns(void* stream, int iters, double* ns_per_wave_instr) {
+    if (iters < 1 || ns_per_wave_instr == nullptr) return ODPD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float* out = nullptr;
+    const int blocks = device_cus() * 4;             // 4 workgroups of 4 waves per CU = four waves per SIMD
+    if (hipMalloc(&out, (size_t)blocks * 256 * sizeof(float)) != hipSuccess) return ODPD_EINVAL;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0.0f;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipEventRecord(e0, st);
+        hipLaunchKernelGGL(probe_issue_kernel, dim3(blocks), dim3(256), 0, st, out, iters, 0.999f, 1e-3f);
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(out);
+    *ns_per_wave_instr = (double)ms * 1e6 / ((double)iters * 64.0 * 4.0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int odpd_abi_version(void) { return 13; }   // 13: + odpd_probe_issue_ns; 12: + odpd_sweep_* / odpd_train_epoch_sweep / odpd_backbone_fwd_sweep (K runs of one model shape in lockstep: one launch per step carries them all); 11: + ODPD_FLAG_TWO_LAYERS (gru / qgru / qgru_amp1 with two recurrent layers), hidden 33 .. 64 for the GRU family and lstm, bits_w > 0 on lstm / vdlstm (INT_Linear heads); 10: + odpd_xchg_* (one-shot gradient exchange over peer-mapped slots), odpd_clip_optim_step_dp, odpd_comm_kind / _errors; 9: + odpd_cascade_rows, odpd_cascade_fwd_bwd (train_dpd step body in one launch); 8: + odpd_comm_*, odpd_shard_range, odpd_train_epoch_dp (RCCL inside the native step path); 7: quantised gru / dgru / deltagru_tcnskip descriptors (bits_w > 0), QAT hidden <= 32; 3: + odpd_clip_adamw_step_masked, odpd_tuning_generation, backbones 11..13; 4: backbones 14..17; 5: + odpd_framed_train_supported_shape; 6: + odpd_train_epoch_split
 extern "C" const char* odpd_built_arch(void) { return "gfx950"; }
 
 extern "C" int64_t odpd_param_count(const odpd_model_t* m) {

@@ -54,6 +54,7 @@ inline LaunchShape persistent_shape(int ngroups, int waves_per_cu, int max_waves
 }
 
 // run-time tuning knobs (odpd_set_tuning; initialised from $ODPD_S16_MIN_BATCH / $ODPD_S16_OCCUPANCY)
+void audit_lds(const void* kernel, size_t lds);      // $ODPD_AUDIT_LDS: see odpd_seq.h (defined in capi.hip)
 struct Tuning { long s16_min_batch; int s16_occupancy; long gp_max_batch; int cascade_one_launch; int xchg_fused; int s16x; int lstm_pack; int s16x_train; int qat_u3; };
 Tuning& tuning();
 

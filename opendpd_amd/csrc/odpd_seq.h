@@ -163,8 +163,13 @@ __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 
 // ---- host side ---------------------------------------------------------------------------------
 constexpr size_t kMaxLds = 160 * 1024;
+// $ODPD_AUDIT_LDS=1: every launch that goes through allow_big_lds reports its dynamic LDS size on stderr (rocprofv3's kernel trace records only the
+// static part) — tools/occupancy_audit.py joins the lines with the trace to find launches whose LDS allocation, not their registers, caps the
+// waves per SIMD
+void audit_lds(const void* kernel, size_t lds);
 template <typename K>
 static inline int allow_big_lds(K kernel, size_t lds) {
+    audit_lds(reinterpret_cast<const void*>(kernel), lds);
     if (lds <= 64 * 1024) return 0;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)kMaxLds);

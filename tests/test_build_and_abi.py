@@ -21,7 +21,7 @@ def test_library_builds_and_exports_header_symbols():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     assert declared == set(_lib.exported_symbols())
-    assert lib.odpd_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.odpd_abi_version() == _lib.ABI_VERSION == 13
 
 
 def test_no_kernel_spills_beyond_the_recorded_allowance():

@@ -97,6 +97,19 @@ def test_frozen_model_gives_dx_only():
     assert rel_err(xt.grad.cpu().numpy(), dxo) < GRAD_TOL
 
 
+def test_issue_probe_reports_a_plausible_speed_and_rejects_bad_arguments():
+    """odpd_probe_issue_ns (bench.py's `config.issue_probe_ns`): ns per wave instruction per SIMD of a pure v_fma loop at four waves per SIMD —
+    about 1.1 on an MI355X (profiles/r01/ubench_issue_costs.md: 1.06 - 1.29), never below the 4-cycles-per-wave64 floor of a 16-lane SIMD at
+    3 GHz times a half, never tens of ns."""
+    from opendpd_amd import _lib
+    lib = _lib.load()
+    ns = C.c_double(0.0)
+    assert lib.odpd_probe_issue_ns(_lib.stream_ptr(), 4000, C.byref(ns)) == 0
+    assert 0.4 < ns.value < 6.0, ns.value
+    assert lib.odpd_probe_issue_ns(_lib.stream_ptr(), 0, C.byref(ns)) == -1
+    assert lib.odpd_probe_issue_ns(_lib.stream_ptr(), 10, None) == -1
+
+
 def test_c_abi_direct_and_errors():
     """Calls the C ABI without the nn.Module layer; bad arguments return error codes."""
     from opendpd_amd import _lib
