@@ -630,7 +630,7 @@ def main():
             dpd["reference_batch"] = {"batch_per_gpu": rb, "frame_length": T, "unit": "IQ samples/s", "cascades": small}
             del xr_, tr_
 
-    # vector-issue speed of this box (ns per wave instruction per SIMD of a pure v_fma loop, ~1.1 on an MI355X at full clocks): the issue-bound
+    # vector-issue speed of this box (ns per wave instruction per SIMD of a pure v_fmac loop: 1.74 on the r06 boxes = four cycles at 2.3 GHz): the issue-bound
     # kernels' times scale with it, so a slower line from another box can be told from a slower build (`config.issue_probe_ns`)
     issue_probe_ns = None
     if rank == 0:

@@ -153,11 +153,12 @@ __global__ __launch_bounds__(256) void probe_issue_kernel(float* out, int iters,
     float a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = (float)(threadIdx.x + j) * 1e-6f;
+    const float x = (float)threadIdx.x * c;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = __builtin_fmaf(a[j], b, c);          // 8 independent chains x 8 = 64 v_fma_f32
+            for (int j = 0; j < 8; ++j) a[j] = __builtin_fmaf(x, b, a[j]);          // 8 independent accumulate chains x 8 = 64 v_fmac_f32
     }
     float s = 0.0f;
 #pragma unroll

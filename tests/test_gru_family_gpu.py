@@ -98,9 +98,8 @@ def test_frozen_model_gives_dx_only():
 
 
 def test_issue_probe_reports_a_plausible_speed_and_rejects_bad_arguments():
-    """odpd_probe_issue_ns (bench.py's `config.issue_probe_ns`): ns per wave instruction per SIMD of a pure v_fma loop at four waves per SIMD —
-    about 1.1 on an MI355X (profiles/r01/ubench_issue_costs.md: 1.06 - 1.29), never below the 4-cycles-per-wave64 floor of a 16-lane SIMD at
-    3 GHz times a half, never tens of ns."""
+    """odpd_probe_issue_ns (bench.py's `config.issue_probe_ns`): ns per wave instruction per SIMD of a pure v_fmac loop at four waves per SIMD —
+    1.74 on the MI355X boxes of r06 (four cycles of a 16-lane SIMD at 2.3 GHz); never below half of that floor at 3 GHz, never tens of ns."""
     from opendpd_amd import _lib
     lib = _lib.load()
     ns = C.c_double(0.0)
