@@ -135,7 +135,9 @@ const char* odpd_built_arch(void);
 /* Speed of THIS GPU as the recurrent kernels see it (no reference counterpart; bench.py reports it beside its timings so that box-to-box
  * differences of the issue-bound kernels can be told from code changes): runs `iters` x 64 v_fmac_f32 (eight independent accumulate chains) per
  * wave at four waves per SIMD on every CU, twice (the first pass warms the clocks), and returns the second pass's nanoseconds per wave
- * instruction per SIMD (MI355X: 1.74 = four cycles of a 16-lane SIMD at 2.3 GHz).  Synchronises the stream. */
+ * instruction per SIMD (MI355X: 1.74 = four cycles at 2.3 GHz; the accumulate reads a scalar operand, which issues at the four-cycle rate of
+ * DPP / compare / max instructions — the all-VGPR v_fmac_f32 / v_mul_f32 forms issue in ~1.1 - 1.2 ns, transcendentals in 3.45:
+ * profiles/r06/ubench_issue_costs.txt).  Synchronises the stream. */
 int odpd_probe_issue_ns(void* stream, int iters, double* ns_per_wave_instr);
 
 /* ---- backbone forward / backward (replaces backbone.forward + autograd BPTT) ------------- */
