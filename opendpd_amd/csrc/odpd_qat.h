@@ -156,6 +156,31 @@ __device__ __forceinline__ void fill_luts(float* lut, const QSc& qs, const QK& k
         }
     }
 }
+// MAGIC-NUMBER ROUNDING (r06).  (v + 1.5 x 2^23) rounds v to the nearest-even integer k and leaves it in the low mantissa bits:
+// bits = 0x4B400000 + k for |k| < 2^22.  One v_add_f32 (the fast issue class, profiles/r06/ubench_issue_costs.txt) instead of v_rndne_f32 +
+// v_cvt_i32_f32 (two of the four-cycle class), and the table address follows with one v_lshl_add_u32:
+//   &lutq[k] = base + 16 k = (bits << 4) + (base - (0x4B400000 << 4))   (mod 2^32; LDS addresses are 32 bits)
+constexpr float kRneMagic = 12582912.0f;
+typedef float lut_f2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) lut_f2* LutLds;
+__device__ __forceinline__ unsigned lut_bias(const float4* lutq) {
+    return (unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) float4*)lutq + 0x4C000000u;      // 0x4C000000 = -(0x4B400000 << 4) mod 2^32
+}
+// gates of a CLAMPED, not yet rounded value m on the add grid (the rounding happens in the index)
+template <bool LUT>
+__device__ __forceinline__ Gate sig_grid_m(float m, const QSc& qs, const QK& k, const float4* lutq, unsigned bias) {
+    if constexpr (LUT) {
+        const lut_f2 e = *(LutLds)(__SIZE_TYPE__)((__builtin_bit_cast(unsigned, m + kRneMagic) << 4) + bias);
+        Gate g; g.c = e[0]; g.d = e[1]; return g;
+    } else return sig_gate(sigmoid_acc(rintf(m) * k.s_add), qs, k);
+}
+template <bool LUT>
+__device__ __forceinline__ Gate tanh_grid_m(float m, const QSc& qs, const QK& k, const float4* lutq, unsigned bias) {
+    if constexpr (LUT) {
+        const lut_f2 e = *((LutLds)(__SIZE_TYPE__)((__builtin_bit_cast(unsigned, m + kRneMagic) << 4) + bias) + 1);
+        Gate g; g.c = e[0]; g.d = e[1]; return g;
+    } else return tanh_gate(tanh_acc(rintf(m) * k.s_add), qs, k);
+}
 // gates of a value on the add grid, given as its integer ak (lutq = table base shifted by -Qn entries)
 template <bool LUT>
 __device__ __forceinline__ Gate sig_grid(float ak, const QSc& qs, const QK& k, const float4* lutq) {

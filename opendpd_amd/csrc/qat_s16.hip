@@ -171,7 +171,7 @@ __device__ __forceinline__ void q16_slots(float2 xv, float2 xn, const float (&oh
 // (the two sums are needed separately: each gets its own scale and fp32 bias).  6 instructions of 16 cycles on the matrix pipe instead of
 // 15 f32 MFMAs of 32 cycles on the FMA lanes; int32 accumulation is exact.  (tools/probes/mfma_i32_16x16x32_i8_layout.hip: layout, cost.)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-constexpr float kRneMagic = 12582912.0f;          // 1.5 x 2^23: (v + magic) rounds v to the nearest-even integer, which sits in the low mantissa bits
+// (kRneMagic = 1.5 x 2^23, odpd_qat.h: (v + magic) rounds v to the nearest-even integer, which sits in the low mantissa bits)
 __device__ __forceinline__ int i8_bits(float clamped) { return __builtin_bit_cast(int, clamped + kRneMagic); }       // low byte = int8 of rint(v)
 __device__ __forceinline__ int i8_pack4(int b0, int b1, int b2, int b3) {
     const unsigned lo = __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u), hi = __builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x04000c0cu);
@@ -184,6 +184,9 @@ __device__ __forceinline__ void i8_matvecs(TabPtr tl, int base, int bh, int bx, 
     const int wh[3] = {__builtin_bit_cast(int, w0.x), __builtin_bit_cast(int, w0.z), __builtin_bit_cast(int, w1.x)};
     const int wx[3] = {__builtin_bit_cast(int, w0.y), __builtin_bit_cast(int, w0.w), __builtin_bit_cast(int, w1.y)};
     const long b = i8_operand(bh, bx);
+    // (r06, tried: accumulators seeded with the bit pattern of 1.5 x 2^23 so that the result IS a float and a fast-class v_sub_f32 replaces the
+    // v_cvt_f32_i32 — the compiler then allocates a destination that partly overlaps the shared SrcC range, e.g. `v_mfma_i32_16x16x32_i8
+    // v[64:67], v[64:65], v[80:81], v[66:69]`, and every W8A8 result was wrong: zero accumulators, an inline constant, it stays)
     const i32x4 z4 = {0, 0, 0, 0};
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -205,6 +208,7 @@ __device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const QK& k, 
     using T = QT<MK, NT>;
     constexpr int NCH = Kind<MK>::NCH;
     constexpr bool I8 = LUT && NT == 1;       // 8-bit weights and activations, one unit tile: the integer matrix pipe
+    const unsigned lbias = LUT ? lut_bias(lutq) : 0u;
     f32x4 hqk[NT];
     int hb[4] = {0, 0, 0, 0};
     if constexpr (U < 4) {                    // dead elements: constants (whatever reads a whole vector — tile stores, checkpoints — sees zeros)
@@ -258,10 +262,10 @@ __device__ __forceinline__ void std_cell(TabPtr tl, const QSc& qs, const QK& k, 
             const float xn = __builtin_fmaf(xs[2][mt][i], k.Sx, Bxn[i]), hn = __builtin_fmaf(hs[2][mt][i], k.Sh, Bhn[i]);
             const float vr = (xr + hr) * k.inv_add, vz = (xz + hz) * k.inv_add;
             const float mr = gm(vr, k), mz = gm(vz, k);
-            const Gate Gr = sig_grid<LUT>(rintf(mr), qs, k, lutq), Gz = sig_grid<LUT>(rintf(mz), qs, k, lutq);
+            const Gate Gr = sig_grid_m<LUT>(mr, qs, k, lutq, lbias), Gz = sig_grid_m<LUT>(mz, qs, k, lutq, lbias);
             const float pm1 = Gr.c * hn, mm1 = gm(pm1, k);                                     // Qmul(r h_n)
             const float vn = __builtin_fmaf(rintf(mm1), k.s_mul, xn) * k.inv_add, mn = gm(vn, k);      // Qadd(x_n + .)
-            const Gate Gn = tanh_grid<LUT>(rintf(mn), qs, k, lutq);
+            const Gate Gn = tanh_grid_m<LUT>(mn, qs, k, lutq, lbias);
             const float omz = __builtin_fmaf(Gz.c, -k.s_mul, 1.0f);                             // 1 - z, plain
             const float pm2 = Gz.c * hv, pm3 = omz * Gn.c;
             const float mm2 = gm(pm2, k), mm3 = gm(pm3, k);
