@@ -184,9 +184,9 @@ __device__ __forceinline__ void i8_matvecs(TabPtr tl, int base, int bh, int bx, 
     const int wh[3] = {__builtin_bit_cast(int, w0.x), __builtin_bit_cast(int, w0.z), __builtin_bit_cast(int, w1.x)};
     const int wx[3] = {__builtin_bit_cast(int, w0.y), __builtin_bit_cast(int, w0.w), __builtin_bit_cast(int, w1.y)};
     const long b = i8_operand(bh, bx);
-    // (r06, tried: accumulators seeded with the bit pattern of 1.5 x 2^23 so that the result IS a float and a fast-class v_sub_f32 replaces the
-    // v_cvt_f32_i32 — the compiler then allocates a destination that partly overlaps the shared SrcC range, e.g. `v_mfma_i32_16x16x32_i8
-    // v[64:67], v[64:65], v[80:81], v[66:69]`, and every W8A8 result was wrong: zero accumulators, an inline constant, it stays)
+    // (r06, tried: accumulators seeded with the bit pattern of 1.5 x 2^23, so that the result IS a float and a fast-class v_sub_f32 replaces the
+    // v_cvt_f32_i32.  Every W8A8 result came out wrong; cause not established — the ISA looked as intended.  Zero accumulators, an inline
+    // constant, stay.)
     const i32x4 z4 = {0, 0, 0, 0};
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
