@@ -636,7 +636,34 @@ __global__ __launch_bounds__(64 * 4 * OCC, OCC) void gru16_train_sweep_kernel(Se
 // -------------------------------------------------------------------------------------------------
 // split kernels (odpd_backbone_fwd / odpd_backbone_bwd at large batch: autograd path, cascades, inference)
 // -------------------------------------------------------------------------------------------------
-// forward: y for every step, optional checkpoints of h ([task][ckpt][lane] float4)
+// BPTT checkpoints of the split kernels, [task][ckpt] records of 64 float4 (r06: only REAL units travel).  Quads whose four unit slots are all real
+// store their float4 at the usual place; the quad holding the last H % 4 units stores that many dwords, 16 lanes contiguous per element, inside its
+// own float4 region; quads of padding store nothing (their h is 0 for ever: zero weights, zero biases).  Hidden 13: 832 of 1 024 bytes per
+// checkpoint and 16 sequences, written once and read once.  (The fused train kernel keeps whole records: its register allocation is not touched.)
+__device__ __forceinline__ void s16_ckpt_store(float4* rec, int lane, int n, int q, int H, const f32x4& h) {
+    const int nfull = H >> 2, rem = H & 3;
+    if (q < nfull) rec[lane] = make_float4(h[0], h[1], h[2], h[3]);
+    else if (q == nfull) {
+        float* f = reinterpret_cast<float*>(rec + nfull * 16) + n;
+        if (rem > 0) f[0] = h[0];
+        if (rem > 1) f[16] = h[1];
+        if (rem > 2) f[32] = h[2];
+    }
+}
+__device__ __forceinline__ float4 s16_ckpt_load(const float4* rec, int lane, int n, int q, int H) {
+    const int nfull = H >> 2, rem = H & 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < nfull) v = rec[lane];
+    else if (q == nfull) {
+        const float* f = reinterpret_cast<const float*>(rec + nfull * 16) + n;
+        if (rem > 0) v.x = f[0];
+        if (rem > 1) v.y = f[16];
+        if (rem > 2) v.z = f[32];
+    }
+    return v;
+}
+
+// forward: y for every step, optional checkpoints of h ([task][ckpt] records, s16_ckpt_store)
 template <int FM, bool DG, bool PACK>
 __global__ __launch_bounds__(1024) void gru16_fwd_kernel(SeqArgs a) {
     constexpr int F = S16Cfg<FM>::F, NCH = S16Cfg<FM>::NCH, S = kCkptStride;
@@ -661,7 +688,7 @@ __global__ __launch_bounds__(1024) void gru16_fwd_kernel(SeqArgs a) {
     const int nwaves = gridDim.x * nwb;
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
-        float4* ck = a.ckpt ? reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * 64 + lane : nullptr;
+        float4* ck = a.ckpt ? reinterpret_cast<float4*>(a.ckpt) + (size_t)grp * a.nck * 64 : nullptr;
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
         for (int t0 = 0; t0 < a.T; t0 += kChunk) {
             const int len = min(kChunk, a.T - t0);
@@ -702,7 +729,7 @@ __global__ __launch_bounds__(1024) void gru16_fwd_kernel(SeqArgs a) {
                 const float y0 = quad_sum(p0), y1 = quad_sum(p1);
                 if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
                 const int t1 = t0 + tt + 1;
-                if (ck != nullptr && (t1 % S) == 0 && t1 < a.T) ck[(size_t)(t1 / S) * 64] = make_float4(h[0], h[1], h[2], h[3]);
+                if (ck != nullptr && (t1 % S) == 0 && t1 < a.T) s16_ckpt_store(ck + (size_t)(t1 / S) * 64, lane, n, q, a.H, h);
             }
             wave_lds_fence();
             stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);
@@ -741,16 +768,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gru16_bwd_kernel(SeqArg
     const int nwaves = gridDim.x * nwb;
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
-        const float4* ck = reinterpret_cast<const float4*>(a.ckpt) + (size_t)grp * a.nck * 64 + lane;
+        const float4* ck = reinterpret_cast<const float4*>(a.ckpt) + (size_t)grp * a.nck * 64;
         f32x4 dh = {0.f, 0.f, 0.f, 0.f};
         float hTn[4] = {0.f, 0.f, 0.f, 0.f};
         int cur_chunk = -1;
-        float4 h0n = a.nck > 1 ? ck[(size_t)(a.nck - 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 h0n = a.nck > 1 ? s16_ckpt_load(ck + (size_t)(a.nck - 1) * 64, lane, n, q, a.H) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int blk = a.nck - 1; blk >= 0; --blk) {
             const int tb = blk * S, nstep = min(S, a.T - tb);
             const int chunk = tb / kChunk, t0 = chunk * kChunk;
             const f32x4 h0 = {h0n.x, h0n.y, h0n.z, h0n.w};
-            h0n = blk > 1 ? ck[(size_t)(blk - 1) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+            h0n = blk > 1 ? s16_ckpt_load(ck + (size_t)(blk - 1) * 64, lane, n, q, a.H) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (chunk != cur_chunk) {
                 if constexpr (DX) {
                     if (cur_chunk >= 0) {
