@@ -124,7 +124,10 @@ int64_t odpd_train_workspace_floats(const odpd_model_t* m, int B, int T);
  * lstm / vdlstm train kernel of <= 13 hidden units without K-packed input slots (same results to fp32 rounding); "qat_u3": 0 = the
  * quantisation-aware GRUCell models (gru / dgru / qgru / qgru_amp1 with ODPD_FLAG_QUANT) of <= 12 hidden units with four unit slots per lane
  * instead of three (identical results on 8-bit grids, summation order of the wider ones unchanged); "xchg_fused", "lstm_pack" and "qat_u3"
- * change no buffer size (and leave odpd_tuning_generation alone); every successful call on one of the others bumps it. */
+ * change no buffer size (and leave odpd_tuning_generation alone); every successful call on one of the others bumps it.
+ * Each knob's initial value comes from the environment variable of its name in capitals with the prefix ODPD_ (ODPD_S16_MIN_BATCH,
+ * ODPD_QAT_U3, ...).  Two more variables are read: ODPD_XCHG_TIMEOUT_MS (peer wait of the one-shot gradient exchange) and ODPD_AUDIT_LDS
+ * (diagnostic: every launch reports its dynamic LDS size on stderr once, tools/occupancy_audit.py). */
 int odpd_set_tuning(const char* key, int64_t value);
 /* Counter bumped by every successful odpd_set_tuning: buffers sized by the queries above are valid for the generation they were
  * sized in (the row count / workspace layout of a (B,T) shape depends on the knobs). */

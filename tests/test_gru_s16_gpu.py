@@ -161,6 +161,15 @@ def test_s16_split_kernels_against_oracle_ragged(force_s16, bb, H, B, T):
     fam.test_against_oracle_ragged(bb, H, B, T)
 
 
+@pytest.mark.parametrize("H", list(range(1, 17)))
+def test_s16_split_checkpoints_carry_real_units_only_at_every_hidden_size(force_s16, H):
+    """csrc/gru_s16.hip s16_ckpt_store / s16_ckpt_load (r06): full quads keep their float4, the quad with the last H % 4 units stores that many
+    dwords, padding quads nothing — every split of 1 .. 16 units into (full quads, remainder) through forward + backward over several checkpoint
+    blocks, against the oracle (forward, parameter gradients, dL/dx)."""
+    from tests import test_gru_family_gpu as fam
+    fam.test_against_oracle_ragged("dgru" if H % 2 else "gru", H, 19, 37)
+
+
 def test_s16_frozen_model_gives_dx_only(force_s16):
     from tests import test_gru_family_gpu as fam
     fam.test_frozen_model_gives_dx_only()
