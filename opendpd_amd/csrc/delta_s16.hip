@@ -233,7 +233,9 @@ __device__ __forceinline__ void d16_stage_in(float2* lds, const float* g, int b0
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int e = lane + 64 * j, m = e / CH, tt = e % CH;
-        lds[m * (CH + 1) + tt] = (tt < len && b0 + m < B) ? g2[(size_t)(b0 + m) * T + t0 + tt] : fill;
+        float2 v = fill;      // (an `if`, not `?:`: with a run-time `fill` the compiler selects between two ADDRESSES — see stage_in_ch, odpd_seq.h)
+        if (tt < len && b0 + m < B) v = g2[(size_t)(b0 + m) * T + t0 + tt];
+        lds[m * (CH + 1) + tt] = v;
     }
 }
 template <int CH>

@@ -34,7 +34,9 @@ __device__ __forceinline__ void dw_stage_features(float* ftab, const float2* xg,
 // TCN skip of one time step (deltagru_tcnskip.py:32-49): conv(2 -> 3, k 3, dilation 16, zero padded), Hardswish, conv(3 -> 2, k 1), Hardswish
 __device__ __forceinline__ void dw_tcn(const float* pl, const DeltaLayout& L, const float2* xg, int t, int T, float (&s1)[3], float (&s2)[2], float2 (&tap)[3]) {
     const float2 zero = make_float2(0.0f, 0.0f);
-    tap[0] = t - kDHalo >= 0 ? xg[t - kDHalo] : zero; tap[1] = xg[t]; tap[2] = t + kDHalo < T ? xg[t + kDHalo] : zero;
+    tap[0] = zero; tap[1] = xg[t]; tap[2] = zero;      // (`if`, not `?:` on the loads: see stage_in_ch, odpd_seq.h)
+    if (t - kDHalo >= 0) tap[0] = xg[t - kDHalo];
+    if (t + kDHalo < T) tap[2] = xg[t + kDHalo];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float a = 0.0f;

@@ -123,10 +123,12 @@ __device__ __forceinline__ void j16_build_table(float* tab, const float* pl, con
 // -------------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------------
+// (r06: 16-step chunks — the kernel's 96 registers allow four waves per SIMD, its 94 KB workgroup let one onto a CU)
+constexpr int kJ16FwdChunk = 16;
 template <int NT>
-__global__ __launch_bounds__(512, 1) void janet16_fwd_kernel(SeqArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void janet16_fwd_kernel(SeqArgs a) {
     using T = J16<NT>;
-    constexpr int S = kCkptStride, kWave = 2 * 2 * 16 * kChunkPad;
+    constexpr int S = kCkptStride, CH = kJ16FwdChunk, kWave = 2 * 2 * 16 * (CH + 1);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwb = blockDim.x >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(512, 1) void janet16_fwd_kernel(SeqArgs a) {
     const float bo0 = j16_uni(pl[L.o_bo]), bo1 = j16_uni(pl[L.o_bo + 1]);
     float* wbase = tab + s16_tab_floats(T::NG) + (size_t)wave * kWave;
     float2* xs = reinterpret_cast<float2*>(wbase);
-    float2* ys = xs + 16 * kChunkPad;
+    float2* ys = xs + 16 * (CH + 1);
     const int nwaves = gridDim.x * nwb;
     for (int grp = blockIdx.x * nwb + wave; grp < a.ngroups; grp += nwaves) {
         const int b0 = grp * 16;
@@ -147,14 +149,14 @@ __global__ __launch_bounds__(512, 1) void janet16_fwd_kernel(SeqArgs a) {
         f32x4 h[NT];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) h[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int t0 = 0; t0 < a.T; t0 += kChunk) {
-            const int len = min(kChunk, a.T - t0);
+        for (int t0 = 0; t0 < a.T; t0 += CH) {
+            const int len = min(CH, a.T - t0);
             wave_lds_fence();
-            stage_in<16>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
+            stage_in_ch<CH>(xs, a.x, b0, a.B, a.T, t0, len, lane, make_float2(0.5f, 0.5f));
             wave_lds_fence();
             for (int tt = 0; tt < len; ++tt) {
                 float amp, ct, st;
-                j16_inputs(xs[n * kChunkPad + tt], amp, ct, st);
+                j16_inputs(xs[n * (CH + 1) + tt], amp, ct, st);
                 f32x4 an[NT], p1[NT], p2[NT], u[NT], f[NT], g[NT];
                 j16_cell_fwd<NT>(opaque(tl), amp, ct, st, h, an, p1, p2, u, f, g);
                 float s0 = 0.0f, s1 = 0.0f;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(512, 1) void janet16_fwd_kernel(SeqArgs a) {
                     ODPD_EACH4 { s0 = __builtin_fmaf(w0[i], h[mt][i], s0); s1 = __builtin_fmaf(w1[i], h[mt][i], s1); }
                 }
                 const float y0 = quad_sum(s0) + bo0, y1 = quad_sum(s1) + bo1;
-                if (q == 0) ys[n * kChunkPad + tt] = make_float2(y0, y1);
+                if (q == 0) ys[n * (CH + 1) + tt] = make_float2(y0, y1);
                 const int t1 = t0 + tt + 1;
                 if (ck != nullptr && (t1 % S) == 0 && t1 < a.T) {
 #pragma unroll
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(512, 1) void janet16_fwd_kernel(SeqArgs a) {
                 }
             }
             wave_lds_fence();
-            stage_out<16>(ys, a.y, b0, a.B, a.T, t0, len, lane);
+            stage_out_ch<CH>(ys, a.y, b0, a.B, a.T, t0, len, lane);
         }
     }
 }
@@ -485,8 +487,12 @@ int janet_s16_launch(hipStream_t st, const odpd_model_t* m, const SeqArgs& a0, i
     a.ngroups = (a.B + 15) / 16;
     const int P = janet_layout(m->hidden).P;
     if (mode == 1) {
-        const LaunchShape ls = j16_shape(a.ngroups, a.ngroups <= 4 * device_cus() ? 4 : 8);
-        const size_t lds = ((size_t)pad4(P) + s16_tab_floats(T::NG) + (size_t)ls.waves * (2 * 2 * 16 * kChunkPad)) * sizeof(float);
+        LaunchShape ls = j16_shape(a.ngroups, a.ngroups <= 4 * device_cus() ? 4 : 8);
+        const size_t lds = ((size_t)pad4(P) + s16_tab_floats(T::NG) + (size_t)ls.waves * (2 * 2 * 16 * (kJ16FwdChunk + 1))) * sizeof(float);
+        if (ls.waves == 8 && 2 * lds <= kMaxLds) {      // two eight-wave workgroups per CU = four waves per SIMD
+            const int need = (a.ngroups + 7) / 8, cap = 2 * device_cus();
+            ls.grid = need < cap ? need : cap;
+        }
         auto k = janet16_fwd_kernel<1>;
         if (int e = allow_big_lds(k, lds)) return e;
         hipLaunchKernelGGL(k, dim3(ls.grid), dim3(64 * ls.waves), lds, st, a);

@@ -569,9 +569,12 @@ __global__ __launch_bounds__(NT == 1 ? 512 : 256, NT == 1 ? 2 : 1) void lstm16_t
             f32x4 h0[NT], c0[NT];
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                h0[kt] = as_f32x4(blk ? ck[((size_t)ODPD_X_CKBLK(blk) * 2 * NT + kt) * 64] : z);
-                c0[kt] = as_f32x4(blk ? ck[((size_t)ODPD_X_CKBLK(blk) * 2 * NT + NT + kt) * 64] : z);
+                // (an `if`, not `?:` on the loads: the compiler otherwise parks the zeros in a stack slot and selects between the two ADDRESSES —
+                // a scratch store and two flat loads per block, r06)
+                float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), cv = hv;
+                if (blk) { hv = ck[((size_t)ODPD_X_CKBLK(blk) * 2 * NT + kt) * 64]; cv = ck[((size_t)ODPD_X_CKBLK(blk) * 2 * NT + NT + kt) * 64]; }
+                h0[kt] = as_f32x4(hv);
+                c0[kt] = as_f32x4(cv);
             }
             if (chunk != cur_chunk) {
                 wave_lds_fence();

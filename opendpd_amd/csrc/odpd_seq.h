@@ -144,6 +144,32 @@ __device__ __forceinline__ void stage_out(const float2* lds, float* g, int b0, i
     }
 }
 
+// the same two for a kernel-local chunk length CH (LDS layout [16 sequences][CH + 1] float2): forward kernels whose registers allow four waves per
+// SIMD stage 16-step chunks, so that two eight-wave workgroups fit a CU's LDS (r06; tools/occupancy_audit.py)
+template <int CH>
+__device__ __forceinline__ void stage_in_ch(float2* lds, const float* g, int b0, int B, int T, int t0, int len, int lane, float2 fill) {
+    const float2* g2 = reinterpret_cast<const float2*>(g);
+    constexpr int N = 16 * CH / 64;
+    static_assert(N >= 1 && (16 * CH) % 64 == 0, "chunk must tile the wave");
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / CH, tt = e % CH;
+        float2 v = fill;      // (not a `?:` on the load: the compiler then selects between the ADDRESS and a stack slot holding `fill`, a flat load)
+        if (tt < len && b0 + m < B) v = g2[(size_t)(b0 + m) * T + t0 + tt];
+        lds[m * (CH + 1) + tt] = v;
+    }
+}
+template <int CH>
+__device__ __forceinline__ void stage_out_ch(const float2* lds, float* g, int b0, int B, int T, int t0, int len, int lane) {
+    float2* g2 = reinterpret_cast<float2*>(g);
+    constexpr int N = 16 * CH / 64;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int e = lane + 64 * j, m = e / CH, tt = e % CH;
+        if (tt < len && b0 + m < B) g2[(size_t)(b0 + m) * T + t0 + tt] = lds[m * (CH + 1) + tt];
+    }
+}
+
 __device__ __forceinline__ void stage_params(float* pl, const float* params, int P) {
     for (int i = threadIdx.x; i < P; i += blockDim.x) pl[i] = params[i];
     __syncthreads();
